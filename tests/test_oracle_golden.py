@@ -1,0 +1,176 @@
+"""Pins the CPU oracle (oracle/) to the golden vectors captured from the reference
+(tests/golden/*.npz, made by tests/golden/make_golden.py importing /root/reference)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import csr_dict, feats_of, load_golden, rel_err, sub
+from oracle import elimrec_oracle as eo
+from oracle import eval_oracle as ev
+
+
+def make_oracle(g, params_prefix="init"):
+    adj = eo.build_adj(g["train_u"], g["train_i"], int(g["num_users"]), int(g["num_items"]), str(g["adj_type"]))
+    return eo.OracleEliMRec(int(g["num_users"]), int(g["num_items"]), int(g["recdim"]), int(g["layer_num"]), adj,
+                            feats_of(g), sub(g, params_prefix), float(g["alpha"]), dataset_name=str(g["dataset_name"]),
+                            modality=str(g["modality"]), mm_fusion_mode=str(g["mm_fusion_mode"])), adj
+
+
+def test_adjacency_matches_reference(fixture_name):
+    g = load_golden(fixture_name)
+    adj = eo.build_adj(g["train_u"], g["train_i"], int(g["num_users"]), int(g["num_items"]), str(g["adj_type"]))
+    t = eo.adj_to_torch(adj)
+    assert np.array_equal(t.indices().numpy(), g["adj_indices"])
+    assert np.array_equal(t.values().numpy(), g["adj_values"])  # bit-exact: same scipy recipe
+
+
+def test_training_steps_match_reference(fixture_name):
+    g = load_golden(fixture_name)
+    model, _ = make_oracle(g)
+    opt = eo.OracleAdam(model.params, lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    steps = int(g["steps"])
+    for t in range(1, steps + 1):
+        u, p, n = g["step%d/users" % t], g["step%d/pos" % t], g["step%d/neg" % t]
+        loss = model.bpr_loss(u, p, n)
+        model.zero_grad()
+        loss.backward()
+        assert abs(float(loss.detach()) - float(g["step%d/loss" % t])) < 1e-6
+        if t == 1:
+            assert rel_err(model.all_users.detach(), g["fwd1/all_users"]) < 1e-6
+            assert rel_err(model.all_items.detach(), g["fwd1/all_items"]) < 1e-6
+            assert rel_err(model.m_emb["i"].detach(), g["fwd1/i_emb"]) < 1e-6
+            assert rel_err(model.m_emb["v"].detach(), g["fwd1/v_emb"]) < 1e-6
+            ref_grads = sub(g, "grad1")
+            mine = model.grads()
+            assert set(mine.keys()) == set(ref_grads.keys())  # same set of parameters receives a gradient
+            for k, gr in ref_grads.items():
+                assert rel_err(mine[k], gr) < 1e-5, k
+        opt.step()
+        if t in (1, steps):
+            for k, v in sub(g, "after%d" % t).items():
+                # Adam's first steps are ~lr*g/(|g|+eps): entries whose gradient is ~eps amplify 1-ulp
+                # differences in g, so the end-to-end bound is 2e-5 abs (lr=1e-3); the optimiser
+                # itself is pinned tightly in test_adam_matches_reference_given_reference_grads.
+                assert np.abs(model.params[k].detach().numpy() - v).max() < 2e-5, (t, k)
+
+
+def test_adam_matches_reference_given_reference_grads(fixture_name):
+    g = load_golden(fixture_name)
+    model, _ = make_oracle(g)
+    opt = eo.OracleAdam(model.params, lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    for k, gr in sub(g, "grad1").items():
+        model.params[k].grad = torch.from_numpy(gr.copy())
+    opt.step()
+    for k, v in sub(g, "after1").items():
+        assert np.abs(model.params[k].detach().numpy() - v).max() <= 1.2e-7, k
+        if k not in sub(g, "grad1"):
+            assert np.array_equal(model.params[k].detach().numpy(), g["init/" + k])  # no grad -> untouched
+
+
+def test_predict_modes_match_reference(fixture_name):
+    g = load_golden(fixture_name)
+    model, _ = make_oracle(g)
+    c = sub(g, "cache")
+    model.set_cache(c["all_users"], c["all_items"], {k: v for k, v in c.items() if k.startswith("pre_fusion")})
+    users = g["eval_users"]
+    for key, want in sub(g, "predict").items():
+        fmode, ptype = key.split("/")
+        model.fusion_mode, model.predict_type = fmode, ptype
+        got = model.predict(users).numpy()
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() < 2e-6, key
+
+
+def test_cached_tables_come_from_last_forward(fixture_name):
+    """predict() sees tables computed with the parameters BEFORE the last opt.step()."""
+    g = load_golden(fixture_name)
+    model, _ = make_oracle(g)
+    opt = eo.OracleAdam(model.params, lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    for t in range(1, int(g["steps"]) + 1):
+        eo.train_step(model, opt, g["step%d/users" % t], g["step%d/pos" % t], g["step%d/neg" % t])
+    assert rel_err(model.all_users.detach(), g["cache/all_users"]) < 1e-5
+    assert rel_err(model.all_s_embs["pre_fusion_item_v"].detach(), g["cache/pre_fusion_item_v"]) < 1e-5
+
+
+def test_full_evaluate_matches_reference(fixture_name):
+    g = load_golden(fixture_name)
+    model, _ = make_oracle(g)
+    c = sub(g, "cache")
+    model.set_cache(c["all_users"], c["all_items"], {k: v for k, v in c.items() if k.startswith("pre_fusion")})
+    train = csr_dict(g, "train")
+    for ptype in ("TE", "TIE"):
+        model.predict_type = ptype
+        for split in ("valid", "test"):
+            for use_ref in ([False, True] if ev.ref_lib() is not None else [False]):
+                res, buf = ev.uni_evaluate(lambda us: model.predict(us).numpy(), train, csr_dict(g, split),
+                                           use_ref=use_ref)
+                assert np.allclose(res, g["evaluate/%s/%s" % (ptype, split)], atol=1e-7), (ptype, split, use_ref)
+                if split == "valid":
+                    assert buf == str(g["evaluate/%s/valid_str" % ptype])
+
+
+def test_eval_batch_per_user_metrics(fixture_name):
+    g = load_golden(fixture_name)
+    users = g["evalbatch/users"]
+    test = csr_dict(g, "test")
+    tp, ti = ev.truth_to_csr([sorted(set(test[int(u)])) for u in users])
+    res, _ = ev.evaluate_matrix(g["evalbatch/masked_scores"], tp, ti, g["evalbatch/metric_ids"], int(g["evalbatch/top_k"]))
+    assert np.array_equal(res, g["evalbatch/per_user_metrics"])
+
+
+def test_metric_known_answers():
+    g = load_golden("metrics")
+    for c in range(int(g["n_cases"])):
+        s, k = g["case%d/scores" % c], int(g["case%d/top_k" % c])
+        res, topk = ev.evaluate_matrix(s, g["case%d/truth_ptr" % c], g["case%d/truth_items" % c], [1, 2, 3, 4, 5], k)
+        assert np.array_equal(res, g["case%d/result" % c]), c   # bit-exact incl. tie order
+        if ev.ref_lib() is not None:
+            res_r, topk_r = ev.evaluate_matrix(s, g["case%d/truth_ptr" % c], g["case%d/truth_items" % c],
+                                               [1, 2, 3, 4, 5], k, use_ref=True)
+            assert np.array_equal(res_r, g["case%d/result" % c])
+            assert np.array_equal(topk, topk_r), c               # libstdc++ heap tie order reproduced
+
+
+def test_survey_tiny_metric_case():
+    """SURVEY.md §4 probe: ties broken in heap order -> top-3 of row 0 is [4,1,0]."""
+    s = np.array([[.5, .5, .5, .1, .9, .5], [1, 2, 3, 4, 5, 6]], np.float32)
+    tp, ti = ev.truth_to_csr([[1, 4], [0]])
+    res, topk = ev.evaluate_matrix(s, tp, ti, [1, 2, 4], 3)
+    assert topk[0].tolist() == [4, 1, 0]
+    r = res.reshape(2, 3, 3)
+    assert np.allclose(r[0, 0], [1, 1, 2 / 3]) and np.allclose(r[0, 1], [.5, 1, 1]) and np.allclose(r[0, 2], [1, 1, 1])
+    assert np.all(r[1] == 0)
+
+
+def test_sampler_stream_matches_reference():
+    """libc rand() is never seeded by the reference, so a fresh process replays the same stream."""
+    import subprocess, sys, os, json
+    g = load_golden("sampler")
+    code = r'''
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+from oracle import eval_oracle as ev
+g = dict(np.load(%r))
+users, ptr, items = g["train_dict_users"], g["train_dict_ptr"], g["train_dict_items"]
+d = {int(u): items[ptr[k]:ptr[k+1]] for k, u in enumerate(users)}
+np.random.seed(int(g["np_seed"]))
+U, P, N, L = [], [], [], []
+for bu, bp, bn in ev.pairwise_sampler_v2_epoch(d, int(g["num_items"]), 64):
+    U += bu; P += bp; N += bn; L.append(len(bu))
+print(json.dumps([U, P, N, L]))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sampler.npz"))
+    out = subprocess.check_output([sys.executable, "-c", code])
+    U, P, N, L = json.loads(out.decode().strip().splitlines()[-1])
+    assert L == g["batch_lens"].tolist() and len(L) == int(g["len"])
+    assert U == g["users"].tolist()
+    assert P == g["pos"].tolist()
+    assert N == g["neg"].tolist()
+
+
+def test_sampler_contract():
+    g = load_golden("sampler")
+    users, ptr, items = g["train_dict_users"], g["train_dict_ptr"], g["train_dict_items"]
+    d = {int(u): set(items[ptr[k]:ptr[k + 1]].tolist()) for k, u in enumerate(users)}
+    for u, p, n in zip(g["users"], g["pos"], g["neg"]):
+        assert int(p) in d[int(u)] and int(n) not in d[int(u)] and 0 <= n < int(g["num_items"])
+    assert len(g["users"]) == len(items)
