@@ -1,0 +1,79 @@
+"""ctypes binding of libelimrec_hip.so (include/elimrec_hip.h).
+
+This is the stub INTEGRATION.md shows a maintainer of the reference: every entry point of the
+C ABI with its argument types, loaded once, failing LOUDLY when the HIP library is missing --
+there is no CPU fallback anywhere in this package.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libelimrec_hip.so")
+
+c_i32, c_i64, c_f32, c_u32, c_u64 = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint32, ctypes.c_uint64
+c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t
+
+# name -> (restype, argtypes); order and types follow include/elimrec_hip.h exactly.
+SIGNATURES = {
+    "elimrec_abi_version": (c_i32, []),
+    "elimrec_last_error": (ctypes.c_char_p, []),
+    "elimrec_linear_fwd": (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i32, c_i32, c_ptr]),
+    "elimrec_linear_bwd_w_workspace": (c_size, [c_i64, c_i32, c_i32]),
+    "elimrec_linear_bwd_w": (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_i64,
+                                     c_ptr, c_i32, c_ptr, c_size, c_ptr]),
+    "elimrec_assemble_x0": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i32, c_i32, c_ptr]),
+    "elimrec_spmm_hop": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr]),
+    "elimrec_propagate": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "elimrec_bpr_head": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32,
+                                 ctypes.POINTER(c_f32), c_ptr, c_ptr, c_ptr, c_ptr]),
+    "elimrec_sum": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr]),
+    "elimrec_segment_reduce_workspace": (c_size, [c_i64]),
+    "elimrec_segment_reduce_rows": (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "elimrec_head_bwd_input": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i32, c_i32, c_i32,
+                                       ctypes.POINTER(c_i32), c_ptr, c_ptr, ctypes.POINTER(c_ptr), c_f32, c_ptr, c_ptr]),
+    "elimrec_embed_grad": (c_i32, [c_ptr, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_ptr]),
+    "elimrec_adam_step": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_ptr]),
+    "elimrec_score_workspace": (c_size, [c_i32, c_i64, c_i32]),
+    "elimrec_score_topk": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_i32, c_i32, c_i32, c_u32, c_i32, c_i32,
+                                   c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "elimrec_rank_metrics": (c_i32, [c_ptr, c_i32, c_i32, c_ptr, c_ptr, ctypes.POINTER(c_i32), c_i32, c_ptr, c_ptr]),
+    "elimrec_sample_triplets": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_u64, c_u64, c_ptr, c_ptr, c_ptr, c_ptr]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the HIP library and bind every symbol. Raises HipLibraryError if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            "elimrec_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C elimrec_amd/csrc`). There is no CPU fallback for the hot path." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise HipLibraryError("elimrec_amd: cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise HipLibraryError("elimrec_amd: %s does not export %s (stale build?)" % (LIB_PATH, name))
+        fn.restype = res
+        fn.argtypes = args
+    if lib.elimrec_abi_version() != 1:
+        raise HipLibraryError("elimrec_amd: ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().elimrec_last_error()
+        raise RuntimeError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))

@@ -1,0 +1,313 @@
+// Cosine-BPR head, its analytic gradient, the deterministic row scatter-add that replaces
+// IndexBackward, and the row-sparse input gradient of the head Linears.
+// (models/EliMRec.py:129-142,277-297 forward; main.py:99-100 autograd.)
+#include "common.h"
+#include <cstring>
+#include <rocprim/rocprim.hpp>
+
+namespace elimrec {
+
+constexpr int kMaxBlocks = 8;
+struct BlockWeights { float w[kMaxBlocks]; };
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+
+// One wave per triplet. Lane l owns float4 l, l+64, ... of each d-wide block.
+__global__ __launch_bounds__(256) void bpr_head_kernel(const float *__restrict__ Y, int64_t ldy, int64_t U,
+                                                       const int64_t *__restrict__ users,
+                                                       const int64_t *__restrict__ pos,
+                                                       const int64_t *__restrict__ neg, int B, int d, int n_blocks,
+                                                       BlockWeights bw, float inv_b, float *__restrict__ loss_rows,
+                                                       float *__restrict__ grad_rows, int32_t *__restrict__ keys) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int64_t ru = users[b], rp = U + pos[b], rn = U + neg[b];
+    const float *ya = Y + ru * ldy, *yp = Y + rp * ldy, *yn = Y + rn * ldy;
+    const int ldg = n_blocks * d;
+    float *ga = grad_rows ? grad_rows + (int64_t)(3 * b + 0) * ldg : nullptr;
+    float *gp = grad_rows ? grad_rows + (int64_t)(3 * b + 1) * ldg : nullptr;
+    float *gn = grad_rows ? grad_rows + (int64_t)(3 * b + 2) * ldg : nullptr;
+    const float eps = 1e-12f;
+    float loss = 0.f;
+    for (int k = 0; k < n_blocks; ++k) {
+        const float wk = bw.w[k];
+        const int off = k * d;
+        if (wk == 0.f) {
+            if (grad_rows)
+                for (int v = lane * 4; v < d; v += 256) {
+                    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                    st4(ga + off + v, z); st4(gp + off + v, z); st4(gn + off + v, z);
+                }
+            continue;
+        }
+        float saa = 0.f, spp = 0.f, snn = 0.f, sap = 0.f, san = 0.f;
+        for (int v = lane * 4; v < d; v += 256) {
+            const float4 a = ld4(ya + off + v), p = ld4(yp + off + v), n = ld4(yn + off + v);
+            saa += dot4(a, a); spp += dot4(p, p); snn += dot4(n, n); sap += dot4(a, p); san += dot4(a, n);
+        }
+        saa = wave_sum(saa); spp = wave_sum(spp); snn = wave_sum(snn); sap = wave_sum(sap); san = wave_sum(san);
+        const float na = sqrtf(saa), np_ = sqrtf(spp), nn = sqrtf(snn);
+        const float da = fmaxf(na, eps), dp = fmaxf(np_, eps), dn = fmaxf(nn, eps);   // F.normalize denominators
+        const float cp = sap / (da * dp), cn = san / (da * dn);
+        const float x = cn - cp;
+        const float sp = (x > 20.f) ? x : log1pf(expf(x));                           // F.softplus
+        loss += wk * sp * inv_b;
+        if (grad_rows) {
+            const float sig = (x > 20.f) ? 1.f : 1.f / (1.f + expf(-x));
+            const float g = wk * sig * inv_b;
+            // d/da of  <a/da, n/dn - p/dp>: (v - ahat*<ahat,v>)/da when |a| > eps, v/eps otherwise.
+            const bool fa = na > eps, fp = np_ > eps, fn = nn > eps;
+            for (int v = lane * 4; v < d; v += 256) {
+                const float4 a = ld4(ya + off + v), p = ld4(yp + off + v), n = ld4(yn + off + v);
+                float4 ra, rp4, rn4;
+#define ELIMREC_BPR_COMP(c)                                                              \
+    {                                                                                    \
+        const float ah = a.c / da, ph = p.c / dp, nh = n.c / dn;                         \
+        const float vv = nh - ph;                                                        \
+        ra.c = g * (fa ? (vv - ah * x) / da : vv / eps);                                 \
+        rp4.c = -g * (fp ? (ah - ph * cp) / dp : ah / eps);                              \
+        rn4.c = g * (fn ? (ah - nh * cn) / dn : ah / eps);                               \
+    }
+                ELIMREC_BPR_COMP(x) ELIMREC_BPR_COMP(y) ELIMREC_BPR_COMP(z) ELIMREC_BPR_COMP(w)
+#undef ELIMREC_BPR_COMP
+                st4(ga + off + v, ra); st4(gp + off + v, rp4); st4(gn + off + v, rn4);
+            }
+        }
+    }
+    if (lane == 0) {
+        loss_rows[b] = loss;
+        if (keys) { keys[3 * b] = (int32_t)ru; keys[3 * b + 1] = (int32_t)rp; keys[3 * b + 2] = (int32_t)rn; }
+    }
+}
+
+// Fixed-order sum: thread t adds x[t], x[t+1024], ...; then a binary tree over the 1024 partials.
+__global__ __launch_bounds__(1024) void sum_kernel(const float *__restrict__ x, int64_t n, float *__restrict__ out) {
+    __shared__ float s[1024];
+    float acc = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) acc += x[i];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) s[threadIdx.x] += s[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = s[0];
+}
+
+// ------------------------------------------------------------------ segment reduce
+__global__ void iota_kernel(int32_t *v, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (int32_t)i;
+}
+
+__global__ void heads_kernel(const int32_t *__restrict__ ks, int64_t n, int32_t *__restrict__ flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = (i == 0 || ks[i] != ks[i - 1]) ? 1 : 0;
+}
+
+__global__ void finalize_segments_kernel(const int32_t *__restrict__ ks, const int32_t *__restrict__ flag,
+                                         const int32_t *__restrict__ segid, int64_t n, int32_t split_key,
+                                         int32_t *__restrict__ active_rows, int32_t *__restrict__ seg_start,
+                                         int32_t *__restrict__ seg_info) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t s = segid[i] - 1;
+    if (flag[i]) { active_rows[s] = ks[i]; seg_start[s] = (int32_t)i; }
+    if (i == n - 1) { seg_info[0] = s + 1; seg_start[s + 1] = (int32_t)n; }
+    if (i == 0 && ks[0] >= split_key) seg_info[1] = 0;
+    if (ks[i] < split_key && (i == n - 1 || ks[i + 1] >= split_key)) seg_info[1] = s + 1;
+}
+
+// publishes the (begin,end) slot ranges linear_bwd_w consumes (seg_info layout: see the header)
+__global__ void publish_ranges_kernel(int32_t *__restrict__ seg_info) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const int na = seg_info[0], nl = seg_info[1];
+        seg_info[2] = 0; seg_info[3] = nl; seg_info[4] = nl; seg_info[5] = na; seg_info[6] = 0; seg_info[7] = na;
+    }
+}
+
+__global__ __launch_bounds__(256) void segment_sum_kernel(const float *__restrict__ rows,
+                                                          const int32_t *__restrict__ src,
+                                                          const int32_t *__restrict__ seg_start,
+                                                          const int32_t *__restrict__ seg_info, int64_t n, int ld4_,
+                                                          const float *__restrict__ scale, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (s >= n || s >= seg_info[0]) return;
+    const int beg = seg_start[s], end = seg_start[s + 1];
+    const float sc = scale ? scale[0] : 1.f;
+    const float4 *r4 = reinterpret_cast<const float4 *>(rows);
+    float4 *o4 = reinterpret_cast<float4 *>(out);
+    for (int c = lane; c < ld4_; c += 64) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = beg; i < end; ++i) {
+            const float4 v = r4[(int64_t)src[i] * ld4_ + c];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        o4[s * ld4_ + c] = make_float4(acc.x * sc, acc.y * sc, acc.z * sc, acc.w * sc);
+    }
+}
+
+// ------------------------------------------------------------------ head backward wrt input
+constexpr int kMaxHeads = 4;
+struct HeadPtrs { const float *w[kMaxHeads]; int mblock[kMaxHeads]; };
+
+__global__ __launch_bounds__(256) void head_bwd_input_kernel(const float *__restrict__ dY, int64_t lddy,
+                                                             const int32_t *__restrict__ active_rows,
+                                                             const int32_t *__restrict__ seg_info, int64_t n_max,
+                                                             int64_t U, int d, int C, int S, HeadPtrs hp,
+                                                             const float *__restrict__ W_user,
+                                                             const float *__restrict__ W_item, float gscale,
+                                                             float *__restrict__ G0) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (s >= n_max || s >= seg_info[0]) return;
+    const int64_t r = active_rows[s];
+    const float *Wf = (r < U) ? W_user : W_item;
+    const float *dy = dY + s * lddy;
+    for (int c = lane * 4; c < C; c += 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < d; ++k) {
+            const float g = dy[k];
+            const float4 w = ld4(Wf + (int64_t)k * C + c);
+            acc.x = fmaf(g, w.x, acc.x); acc.y = fmaf(g, w.y, acc.y); acc.z = fmaf(g, w.z, acc.z); acc.w = fmaf(g, w.w, acc.w);
+        }
+        const int mb = c / d;            // table block this column belongs to
+        for (int h = 0; h < S; ++h) {
+            if (hp.mblock[h] != mb) continue;
+            const int cc = c - mb * d;
+            const float *dyh = dy + (1 + h) * d;
+            for (int k = 0; k < d; ++k) {
+                const float g = dyh[k];
+                const float4 w = ld4(hp.w[h] + (int64_t)k * d + cc);
+                acc.x = fmaf(g, w.x, acc.x); acc.y = fmaf(g, w.y, acc.y); acc.z = fmaf(g, w.z, acc.z); acc.w = fmaf(g, w.w, acc.w);
+            }
+        }
+        st4(G0 + r * C + c, make_float4(acc.x * gscale, acc.y * gscale, acc.z * gscale, acc.w * gscale));
+    }
+}
+
+struct SegLayout {
+    size_t keys_sorted, vals_in, vals_sorted, flag, segid, seg_start, sort_tmp, scan_tmp, total;
+    size_t sort_bytes, scan_bytes;
+};
+
+static int seg_layout(int64_t n, SegLayout &L) {
+    size_t sort_bytes = 0, scan_bytes = 0;
+    hipError_t e = rocprim::radix_sort_pairs<rocprim::default_config, const int32_t *, int32_t *, const int32_t *, int32_t *>(
+        nullptr, sort_bytes, nullptr, nullptr, nullptr, nullptr, (size_t)n, 0, 32, 0, false);
+    if (e != hipSuccess) return check_hip(e, "radix_sort_pairs(size)");
+    e = rocprim::inclusive_scan<rocprim::default_config, const int32_t *, int32_t *, rocprim::plus<int32_t>>(
+        nullptr, scan_bytes, nullptr, nullptr, (size_t)n, rocprim::plus<int32_t>(), 0, false);
+    if (e != hipSuccess) return check_hip(e, "inclusive_scan(size)");
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t nb = (size_t)n * sizeof(int32_t);
+    L.keys_sorted = take(nb); L.vals_in = take(nb); L.vals_sorted = take(nb); L.flag = take(nb); L.segid = take(nb);
+    L.seg_start = take(nb + sizeof(int32_t));
+    L.sort_tmp = take(sort_bytes ? sort_bytes : 4); L.scan_tmp = take(scan_bytes ? scan_bytes : 4);
+    L.sort_bytes = sort_bytes; L.scan_bytes = scan_bytes; L.total = off;
+    return 0;
+}
+
+}  // namespace elimrec
+
+using namespace elimrec;
+
+extern "C" int elimrec_bpr_head(const float *d_Y, int64_t ldy, int64_t U, int64_t I, const int64_t *d_users,
+                                const int64_t *d_pos, const int64_t *d_neg, int B, int d, int n_blocks,
+                                const float *block_weights, float *d_loss_rows, float *d_grad_rows, int32_t *d_keys,
+                                void *stream) {
+    ELIMREC_REQUIRE(d_Y && d_users && d_pos && d_neg && d_loss_rows && block_weights, "bpr_head: null pointer");
+    ELIMREC_REQUIRE(d > 0 && d % 4 == 0, "bpr_head: recdim must be a positive multiple of 4");
+    ELIMREC_REQUIRE(n_blocks >= 1 && n_blocks <= kMaxBlocks, "bpr_head: 1..%d head blocks supported", kMaxBlocks);
+    ELIMREC_REQUIRE(ldy % 4 == 0 && ldy >= (int64_t)n_blocks * d, "bpr_head: bad ldy");
+    ELIMREC_REQUIRE(U + I < (int64_t)INT32_MAX, "bpr_head: node ids must fit int32");
+    ELIMREC_REQUIRE(!d_grad_rows || d_keys, "bpr_head: keys required with grad_rows");
+    if (B <= 0) return 0;
+    BlockWeights bw;
+    for (int k = 0; k < kMaxBlocks; ++k) bw.w[k] = k < n_blocks ? block_weights[k] : 0.f;
+    hipLaunchKernelGGL(bpr_head_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_Y, ldy, U, d_users,
+                       d_pos, d_neg, B, d, n_blocks, bw, 1.0f / (float)B, d_loss_rows, d_grad_rows, d_keys);
+    ELIMREC_LAUNCH_CHECK("bpr_head");
+    return 0;
+}
+
+extern "C" int elimrec_sum(const float *d_x, int64_t n, float *d_out, void *stream) {
+    ELIMREC_REQUIRE(d_x && d_out && n >= 0, "sum: bad arguments");
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, d_x, n, d_out);
+    ELIMREC_LAUNCH_CHECK("sum");
+    return 0;
+}
+
+extern "C" size_t elimrec_segment_reduce_workspace(int64_t n) {
+    SegLayout L;
+    if (n <= 0 || seg_layout(n, L)) return 0;
+    return L.total;
+}
+
+extern "C" int elimrec_segment_reduce_rows(const float *d_rows, const int32_t *d_keys, int64_t n, int ld,
+                                           int32_t split_key, int32_t *d_active_rows, float *d_reduced,
+                                           const float *d_scale, int32_t *d_seg_info, void *d_workspace,
+                                           size_t workspace_bytes, void *stream) {
+    ELIMREC_REQUIRE(d_rows && d_keys && d_active_rows && d_reduced && d_seg_info && d_workspace,
+                    "segment_reduce_rows: null pointer");
+    ELIMREC_REQUIRE(n > 0 && n < INT32_MAX && ld > 0 && ld % 4 == 0, "segment_reduce_rows: bad n/ld");
+    SegLayout L;
+    int rc = seg_layout(n, L);
+    if (rc) return rc;
+    if (workspace_bytes < L.total) {
+        set_error("segment_reduce_rows: workspace too small (%zu < %zu)", workspace_bytes, L.total);
+        return ELIMREC_E_WORKSPACE;
+    }
+    char *ws = (char *)d_workspace;
+    int32_t *ks = (int32_t *)(ws + L.keys_sorted), *vin = (int32_t *)(ws + L.vals_in);
+    int32_t *vs = (int32_t *)(ws + L.vals_sorted), *flag = (int32_t *)(ws + L.flag);
+    int32_t *segid = (int32_t *)(ws + L.segid), *seg_start = (int32_t *)(ws + L.seg_start);
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(256), 0, s, vin, n);
+    ELIMREC_LAUNCH_CHECK("iota");
+    size_t sb = L.sort_bytes;
+    hipError_t e = rocprim::radix_sort_pairs(ws + L.sort_tmp, sb, d_keys, ks, (const int32_t *)vin, vs, (size_t)n, 0,
+                                             32, s, false);
+    if (e != hipSuccess) return check_hip(e, "radix_sort_pairs");
+    hipLaunchKernelGGL(heads_kernel, dim3(nb), dim3(256), 0, s, ks, n, flag);
+    ELIMREC_LAUNCH_CHECK("heads");
+    size_t cb = L.scan_bytes;
+    e = rocprim::inclusive_scan(ws + L.scan_tmp, cb, (const int32_t *)flag, segid, (size_t)n,
+                                rocprim::plus<int32_t>(), s, false);
+    if (e != hipSuccess) return check_hip(e, "inclusive_scan");
+    hipLaunchKernelGGL(finalize_segments_kernel, dim3(nb), dim3(256), 0, s, ks, flag, segid, n, split_key,
+                       d_active_rows, seg_start, d_seg_info);
+    ELIMREC_LAUNCH_CHECK("finalize_segments");
+    hipLaunchKernelGGL(publish_ranges_kernel, dim3(1), dim3(64), 0, s, d_seg_info);
+    ELIMREC_LAUNCH_CHECK("publish_ranges");
+    hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, d_rows, vs, seg_start,
+                       d_seg_info, n, ld / 4, d_scale, d_reduced);
+    ELIMREC_LAUNCH_CHECK("segment_sum");
+    return 0;
+}
+
+extern "C" int elimrec_head_bwd_input(const float *d_dY, int64_t lddy, const int32_t *d_active_rows,
+                                      const int32_t *d_seg_info, int64_t n_max, int64_t U, int d, int C, int S,
+                                      const int *head_mblock, const float *d_W_user, const float *d_W_item,
+                                      const float *const *d_W_heads, float gscale, float *d_G0, void *stream) {
+    ELIMREC_REQUIRE(d_dY && d_active_rows && d_seg_info && d_W_user && d_W_item && d_G0, "head_bwd_input: null pointer");
+    ELIMREC_REQUIRE(S >= 0 && S <= kMaxHeads, "head_bwd_input: at most %d heads", kMaxHeads);
+    ELIMREC_REQUIRE(d > 0 && d % 4 == 0 && C % d == 0, "head_bwd_input: bad d/C");
+    HeadPtrs hp;
+    for (int h = 0; h < kMaxHeads; ++h) {
+        hp.w[h] = h < S ? d_W_heads[h] : nullptr;
+        hp.mblock[h] = h < S ? head_mblock[h] : -1;
+    }
+    if (n_max <= 0) return 0;
+    hipLaunchKernelGGL(head_bwd_input_kernel, dim3((unsigned)((n_max + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       d_dY, lddy, d_active_rows, d_seg_info, n_max, U, d, C, S, hp, d_W_user, d_W_item, gscale,
+                       d_G0);
+    ELIMREC_LAUNCH_CHECK("head_bwd_input");
+    return 0;
+}

@@ -1,0 +1,315 @@
+// Full-catalogue counterfactual scoring (TE / TIE), train-item masking, top-K and the ranking
+// metrics, all on device (models/EliMRec.py:96-113,155-212; cpp/uni_evaluator.py:131-185;
+// evaluate.h:23-42; metric.h:17-106). Removes the [B_t x I] device->host copy of the reference.
+#include "common.h"
+
+namespace elimrec {
+
+constexpr int SI = 64;    // items per workgroup tile (one per lane)
+constexpr int SU = 32;    // users per workgroup tile (8 per wave)
+constexpr int SK = 128;   // columns staged per step
+constexpr int SLD = SK + 1;
+constexpr int kMaxS = 4;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+struct ScoreArgs {
+    const float *Y; int64_t ldy; int64_t U; int64_t I; const int64_t *users; int B; int d; int S;
+    uint32_t head_mask; int fusion_mode; int predict_type;
+    const float *row_mean;           // [B] mean_i ui (TIE), pass 2 only
+    float *partial;                  // pass 1: [n_item_tiles x B] partial row sums of ui
+    float *scores; int64_t lds;      // pass 2 output
+};
+
+__device__ __forceinline__ float fuse(int mode, float x, const float *z, int S, uint32_t mask) {
+    if (mode == 0) {                 // rubi: EliMRec.py:171-188 (absent modality -> factor 1)
+        float r = x;
+#pragma unroll
+        for (int h = 0; h < kMaxS; ++h) if (h < S && (mask & (1u << h))) r *= sigmoidf_(z[h]);
+        return r;
+    } else if (mode == 1) {          // hm: :190-199 (every head, regardless of the modality mask)
+        float t = sigmoidf_(x);
+#pragma unroll
+        for (int h = 0; h < kMaxS; ++h) if (h < S) t *= sigmoidf_(z[h]);
+        return logf(t + 1e-12f) - log1pf(t);
+    } else {                         // sum: :201-210
+        float t = x;
+#pragma unroll
+        for (int h = 0; h < kMaxS; ++h) if (h < S) t += z[h];
+        return logf(sigmoidf_(t) + 1e-12f);
+    }
+}
+
+// PASS 1: partial row sums of ui = sigmoid(<Yf[u], Yf[item]>) over this item tile.
+// PASS 2: final scores.
+template <int PASS>
+__global__ __launch_bounds__(256) void score_kernel(ScoreArgs a) {
+    __shared__ float it[SI * SLD];
+    __shared__ float us[SU * SLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t i0 = (int64_t)blockIdx.x * SI;
+    const int b0 = blockIdx.y * SU;
+    const int nblk = (PASS == 1) ? 1 : 1 + a.S;
+    float dot[1 + kMaxS][8];
+    float isq[1 + kMaxS];
+    float usq[1 + kMaxS][8];
+    for (int h = 0; h < 1 + kMaxS; ++h) { isq[h] = 0.f; for (int u = 0; u < 8; ++u) { dot[h][u] = 0.f; usq[h][u] = 0.f; } }
+
+#pragma unroll
+    for (int h = 0; h < 1 + kMaxS; ++h) {
+        if (h >= nblk) break;
+        for (int k0 = 0; k0 < a.d; k0 += SK) {
+            const int kc = (a.d - k0) < SK ? (a.d - k0) : SK;
+            __syncthreads();
+            // stage item rows: SI x kc, 4 floats per thread-step
+            for (int e = tid * 4; e < SI * kc; e += 1024) {
+                const int r = e / kc, c = e - r * kc;
+                const int64_t item = i0 + r;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (item < a.I) v = *reinterpret_cast<const float4 *>(a.Y + (a.U + item) * a.ldy + h * a.d + k0 + c);
+                float *dst = it + r * SLD + c;
+                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            }
+            for (int e = tid * 4; e < SU * kc; e += 1024) {
+                const int r = e / kc, c = e - r * kc;
+                const int b = b0 + r;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (b < a.B) v = *reinterpret_cast<const float4 *>(a.Y + a.users[b] * a.ldy + h * a.d + k0 + c);
+                float *dst = us + r * SLD + c;
+                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            }
+            __syncthreads();
+            const float *ip = it + lane * SLD;
+            const float *up = us + (wave * 8) * SLD;
+            for (int k = 0; k < kc; ++k) {
+                const float x = ip[k];
+                isq[h] = fmaf(x, x, isq[h]);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float y = up[u * SLD + k];
+                    dot[h][u] = fmaf(x, y, dot[h][u]);
+                    usq[h][u] = fmaf(y, y, usq[h][u]);
+                }
+            }
+        }
+    }
+    const int64_t item = i0 + lane;
+    const bool item_ok = item < a.I;
+    if (PASS == 1) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            float v = item_ok ? sigmoidf_(dot[0][u]) : 0.f;
+            v = wave_sum(v);
+            const int b = b0 + wave * 8 + u;
+            if (lane == 0 && b < a.B) a.partial[(int64_t)blockIdx.x * a.B + b] = v;
+        }
+        return;
+    }
+    const float eps = 1e-12f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int b = b0 + wave * 8 + u;
+        if (b >= a.B || !item_ok) continue;
+        const float ui = sigmoidf_(dot[0][u]);
+        float out;
+        if (a.predict_type == 0) {
+            out = sigmoidf_(ui);                                    // EliMRec.py:113
+        } else {
+            float z[kMaxS];
+#pragma unroll
+            for (int h = 0; h < kMaxS; ++h)
+                z[h] = (h < a.S) ? dot[1 + h][u] / (fmaxf(sqrtf(usq[1 + h][u]), eps) * fmaxf(sqrtf(isq[1 + h]), eps)) : 0.f;
+            const float te = fuse(a.fusion_mode, ui, z, a.S, a.head_mask);
+            if (a.predict_type == 1) out = sigmoidf_(te);           // :103-105
+            else out = sigmoidf_(te - fuse(a.fusion_mode, a.row_mean[b], z, a.S, a.head_mask));   // :106-111
+        }
+        a.scores[(int64_t)b * a.lds + item] = out;
+    }
+}
+
+__global__ void row_mean_kernel(const float *__restrict__ partial, int n_tiles, int B, int64_t I,
+                                float *__restrict__ row_mean) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int t = 0; t < n_tiles; ++t) s += partial[(int64_t)t * B + b];
+    row_mean[b] = s / (float)I;
+}
+
+__global__ void mask_train_kernel(float *__restrict__ scores, int64_t lds, const int64_t *__restrict__ ptr,
+                                  const int32_t *__restrict__ items, int B) {
+    const int b = blockIdx.x;
+    if (b >= B) return;
+    for (int64_t j = ptr[b] + threadIdx.x; j < ptr[b + 1]; j += blockDim.x)
+        scores[(int64_t)b * lds + items[j]] = -INFINITY;
+}
+
+// Top-K by (score desc, index asc): K rounds; round r takes the best element strictly after the
+// previous pick in that total order. One workgroup per row.
+__global__ __launch_bounds__(1024) void topk_kernel(const float *__restrict__ scores, int64_t lds, int64_t I, int K,
+                                                    int32_t *__restrict__ out_idx, float *__restrict__ out_val) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    __shared__ float last_v;
+    __shared__ int last_i;
+    const int b = blockIdx.x;
+    const float *row = scores + (int64_t)b * lds;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float pv = INFINITY;
+    int pi = -1;
+    for (int r = 0; r < K; ++r) {
+        float bv = -INFINITY;
+        int bi = INT32_MAX;
+        for (int64_t i = threadIdx.x; i < I; i += blockDim.x) {
+            const float v = row[i];
+            const bool after = (r == 0) || (v < pv) || (v == pv && (int)i > pi);
+            if (after && (v > bv || (v == bv && (int)i < bi))) { bv = v; bi = (int)i; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float fv = sv[0];
+            int fi = si[0];
+            for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+                if (sv[w] > fv || (sv[w] == fv && si[w] < fi)) { fv = sv[w]; fi = si[w]; }
+            last_v = fv; last_i = fi;
+            out_idx[(int64_t)b * K + r] = (fi == INT32_MAX) ? -1 : fi;
+            if (out_val) out_val[(int64_t)b * K + r] = fv;
+        }
+        __syncthreads();
+        pv = last_v; pi = last_i;
+        __syncthreads();
+    }
+}
+
+struct MetricIds { int id[8]; };
+
+// metric.h:17-106, one thread per (user, metric). double where the C++ promotes to double.
+__global__ void rank_metrics_kernel(const int32_t *__restrict__ rank, int B, int K, const int64_t *__restrict__ tptr,
+                                    const int32_t *__restrict__ titems, MetricIds mids, int n_metrics,
+                                    float *__restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= B * n_metrics) return;
+    const int b = t / n_metrics, m = t - b * n_metrics;
+    const int32_t *r = rank + (int64_t)b * K;
+    const int32_t *truth = titems + tptr[b];
+    const int nt = (int)(tptr[b + 1] - tptr[b]);
+    float *o = out + ((int64_t)b * n_metrics + m) * K;
+    auto hit = [&](int x) { for (int j = 0; j < nt; ++j) if (truth[j] == x) return true; return false; };
+    const int id = mids.id[m];
+    if (id == 1) {
+        int hits = 0;
+        for (int i = 0; i < K; ++i) { if (hit(r[i])) hits++; o[i] = (float)(1.0 * hits / (i + 1)); }
+    } else if (id == 2) {
+        int hits = 0;
+        for (int i = 0; i < K; ++i) { if (hit(r[i])) hits++; o[i] = (float)(1.0 * hits / (double)nt); }
+    } else if (id == 3) {
+        int hits = 0; float pre = 0.f, sum_pre = 0.f;
+        for (int i = 0; i < K; ++i) {
+            if (hit(r[i])) { hits++; pre = (float)(1.0 * hits / (i + 1)); sum_pre += pre; }
+            o[i] = hits == 0 ? 0.f : sum_pre / hits;
+        }
+    } else if (id == 4) {
+        float idcg = 0.f, dcg = 0.f;
+        for (int i = 0; i < K; ++i) {
+            const double w = 1.0 / log2((double)(i + 2));
+            if (hit(r[i])) dcg = (float)((double)dcg + w);
+            if (i < nt) idcg = (float)((double)idcg + w);
+            o[i] = dcg / idcg;
+        }
+    } else if (id == 5) {
+        int i = 0;
+        for (; i < K; ++i) {
+            if (hit(r[i])) { const float rr = (float)(1.0 / (i + 1)); for (int j = i; j < K; ++j) o[j] = rr; break; }
+            o[i] = 0.f;
+        }
+    }
+}
+
+}  // namespace elimrec
+
+using namespace elimrec;
+
+static inline int n_item_tiles(int64_t I) { return (int)((I + SI - 1) / SI); }
+
+extern "C" size_t elimrec_score_workspace(int B, int64_t I, int K) {
+    (void)K;
+    size_t partial = align_up((size_t)n_item_tiles(I) * (size_t)(B > 0 ? B : 1) * sizeof(float), 256);
+    size_t mean = align_up((size_t)(B > 0 ? B : 1) * sizeof(float), 256);
+    size_t scores = align_up((size_t)(B > 0 ? B : 1) * (size_t)I * sizeof(float), 256);
+    return partial + mean + scores;
+}
+
+extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int64_t I, const int64_t *d_users, int B,
+                                  int d, int S, uint32_t head_mask, int fusion_mode, int predict_type,
+                                  const int64_t *d_train_ptr, const int32_t *d_train_items, float *d_scores,
+                                  int64_t lds, int K, int32_t *d_topk_idx, float *d_topk_val, void *d_workspace,
+                                  size_t workspace_bytes, void *stream) {
+    ELIMREC_REQUIRE(d_Y && d_users && d_workspace, "score_topk: null pointer");
+    ELIMREC_REQUIRE(d > 0 && d % 4 == 0 && ldy % 4 == 0, "score_topk: recdim/ldy must be multiples of 4");
+    ELIMREC_REQUIRE(S >= 0 && S <= kMaxS, "score_topk: at most %d single-modal heads", kMaxS);
+    ELIMREC_REQUIRE(fusion_mode >= 0 && fusion_mode <= 2 && predict_type >= 0 && predict_type <= 2,
+                    "score_topk: bad fusion_mode/predict_type");
+    ELIMREC_REQUIRE(d_scores || d_topk_idx, "score_topk: nothing to output");
+    ELIMREC_REQUIRE(!d_topk_idx || (K > 0 && K <= I), "score_topk: need 0 < K <= I");
+    if (B <= 0) return 0;
+    if (workspace_bytes < elimrec_score_workspace(B, I, K)) {
+        set_error("score_topk: workspace too small (%zu < %zu)", workspace_bytes, elimrec_score_workspace(B, I, K));
+        return ELIMREC_E_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int tiles = n_item_tiles(I);
+    char *ws = (char *)d_workspace;
+    float *partial = (float *)ws;
+    float *mean = (float *)(ws + align_up((size_t)tiles * B * sizeof(float), 256));
+    float *wscores = (float *)((char *)mean + align_up((size_t)B * sizeof(float), 256));
+    ScoreArgs a;
+    a.Y = d_Y; a.ldy = ldy; a.U = U; a.I = I; a.users = d_users; a.B = B; a.d = d; a.S = S; a.head_mask = head_mask;
+    a.fusion_mode = fusion_mode; a.predict_type = predict_type; a.row_mean = mean; a.partial = partial;
+    a.scores = d_scores ? d_scores : wscores; a.lds = d_scores ? lds : I;
+    ELIMREC_REQUIRE(a.lds >= I, "score_topk: lds < I");
+    dim3 grid(tiles, (B + SU - 1) / SU);
+    if (predict_type == 2) {
+        hipLaunchKernelGGL(score_kernel<1>, grid, dim3(256), 0, s, a);
+        ELIMREC_LAUNCH_CHECK("score_pass1");
+        hipLaunchKernelGGL(row_mean_kernel, dim3((B + 127) / 128), dim3(128), 0, s, partial, tiles, B, I, mean);
+        ELIMREC_LAUNCH_CHECK("row_mean");
+    }
+    hipLaunchKernelGGL(score_kernel<2>, grid, dim3(256), 0, s, a);
+    ELIMREC_LAUNCH_CHECK("score_pass2");
+    if (d_train_ptr) {
+        ELIMREC_REQUIRE(d_train_items, "score_topk: train_items missing");
+        hipLaunchKernelGGL(mask_train_kernel, dim3(B), dim3(128), 0, s, a.scores, a.lds, d_train_ptr, d_train_items, B);
+        ELIMREC_LAUNCH_CHECK("mask_train");
+    }
+    if (d_topk_idx) {
+        hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), 0, s, a.scores, a.lds, I, K, d_topk_idx, d_topk_val);
+        ELIMREC_LAUNCH_CHECK("topk");
+    }
+    return 0;
+}
+
+extern "C" int elimrec_rank_metrics(const int32_t *d_topk_idx, int B, int K, const int64_t *d_truth_ptr,
+                                    const int32_t *d_truth_items, const int *metric_ids, int n_metrics, float *d_out,
+                                    void *stream) {
+    ELIMREC_REQUIRE(d_topk_idx && d_truth_ptr && d_truth_items && metric_ids && d_out, "rank_metrics: null pointer");
+    ELIMREC_REQUIRE(n_metrics >= 1 && n_metrics <= 8, "rank_metrics: 1..8 metrics");
+    MetricIds mids;
+    for (int m = 0; m < 8; ++m) {
+        mids.id[m] = m < n_metrics ? metric_ids[m] : 0;
+        ELIMREC_REQUIRE(m >= n_metrics || (metric_ids[m] >= 1 && metric_ids[m] <= 5), "rank_metrics: unknown metric id %d",
+                        metric_ids[m]);
+    }
+    if (B <= 0) return 0;
+    const int total = B * n_metrics;
+    hipLaunchKernelGGL(rank_metrics_kernel, dim3((total + 127) / 128), dim3(128), 0, (hipStream_t)stream, d_topk_idx,
+                       B, K, d_truth_ptr, d_truth_items, mids, n_metrics, d_out);
+    ELIMREC_LAUNCH_CHECK("rank_metrics");
+    return 0;
+}

@@ -1,0 +1,238 @@
+// Dense projections of the EliMRec hot path on the gfx950 matrix cores, fp32 in / fp32 out.
+//
+//   linear_fwd   C = A . W^T + b      (K1 feature projection, K5 fusion Linear, K8 s_dense)
+//   linear_bwd_w out = A^T . B        (their weight gradients), deterministic split over rows
+//
+// v_mfma_f32_32x32x2_f32 is an exact fp32 fma chain (one rounding per product), so results
+// stay within fp32 round-off of the reference's addmm.
+//
+// Operand maps (cdna_hip_programming.md §3): for D[32x32] += A[32x2] . B[2x32]
+//   lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31];
+//   accumulator register r of lane l is D[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][l & 31].
+#include "common.h"
+
+namespace elimrec {
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+// --------------------------------------------------------------------------------- forward
+// Workgroup = 4 waves, tile 128 rows x 64 cols, K staged 32 at a time through LDS
+// (row stride 33 floats: the 32 lanes of a half-wave read 32 different rows at the same k).
+constexpr int FBM = 128, FBN = 64, FBK = 32, FLD = FBK + 1;
+
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict__ A, int64_t lda,
+                                                         const float *__restrict__ W, int64_t ldw,
+                                                         const float *__restrict__ bias,
+                                                         float *__restrict__ C, int64_t ldc,
+                                                         int64_t M, int N, int K) {
+    __shared__ float As[FBM * FLD];
+    __shared__ float Bs[FBN * FLD];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int64_t m0 = (int64_t)blockIdx.x * FBM;
+    const int n0 = blockIdx.y * FBN;
+    const int lr = tid >> 3;        // 0..31 : row inside a 32-row group
+    const int lc = (tid & 7) * 4;   // 0,4,..28 : k offset of this thread's float4
+
+    v16f acc0 = {0}, acc1 = {0};
+    const int ai = lane & 31, ak = lane >> 5;
+
+    for (int k0 = 0; k0 < K; k0 += FBK) {
+        const bool kin = (k0 + lc) < K;  // K % 4 == 0: the whole float4 is in or out
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = lr + 32 * i;
+            const int64_t gr = m0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kin && gr < M) v = *reinterpret_cast<const float4 *>(A + gr * lda + k0 + lc);
+            float *dst = As + r * FLD + lc;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = lr + 32 * i;
+            const int gn = n0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kin && gn < N) v = *reinterpret_cast<const float4 *>(W + (int64_t)gn * ldw + k0 + lc);
+            float *dst = Bs + r * FLD + lc;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+        __syncthreads();
+        const float *ap = As + (wave * 32 + ai) * FLD + ak;
+        const float *bp0 = Bs + ai * FLD + ak;
+        const float *bp1 = Bs + (32 + ai) * FLD + ak;
+#pragma unroll
+        for (int kk = 0; kk < FBK; kk += 2) {
+            const float a = ap[kk];
+            const float b0 = bp0[kk];
+            const float b1 = bp1[kk];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    const int col0 = n0 + (lane & 31);
+    const int col1 = col0 + 32;
+    const float bias0 = (bias && col0 < N) ? bias[col0] : 0.f;
+    const float bias1 = (bias && col1 < N) ? bias[col1] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (row < M) {
+            if (col0 < N) C[row * ldc + col0] = acc0[r] + bias0;
+            if (col1 < N) C[row * ldc + col1] = acc1[r] + bias1;
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------- weight grad
+// out[i, j] = sum_r A[r, i] * B[idx(r), j]. Both MFMA operands are read straight from global
+// memory: lane (i, k) of the A operand is A[r0 + k][i0 + i], i.e. consecutive lanes read
+// consecutive columns of one row -- already coalesced, no LDS transpose needed.
+// A workgroup owns one chunk of TCH rows and one 64 x 128 output tile (4 waves x 2 MFMA tiles);
+// it writes its partial tile to slab[chunk]; slabs are then summed in chunk order.
+constexpr int TCH = 512;   // rows per chunk
+constexpr int TN1 = 64, TN2 = 128;
+
+__global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(
+    const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
+    const int32_t *__restrict__ row_index, const int32_t *__restrict__ range, int64_t R, int n1, int n2,
+    float *__restrict__ slabs, float *__restrict__ colsum_slabs) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int chunk = blockIdx.x;
+    const int n1_tiles = gridDim.y, n2_tiles = gridDim.z;
+    int64_t rb = 0, re = R;
+    if (range) { rb = range[0]; re = range[1]; }
+    int64_t r0 = rb + (int64_t)chunk * TCH;
+    int64_t r1 = r0 + TCH < re ? r0 + TCH : re;
+
+    const int i0 = blockIdx.y * TN1 + (wave & 1) * 32;
+    const int j0 = blockIdx.z * TN2 + (wave >> 1) * 64;
+    const int li = lane & 31, lk = lane >> 5;
+    const bool a_ok = (i0 + li) < n1;
+    const bool b0_ok = (j0 + li) < n2;
+    const bool b1_ok = (j0 + 32 + li) < n2;
+
+    v16f acc0 = {0}, acc1 = {0};
+    float csum = 0.f;   // column sum of A for column i0+li over rows of parity lk
+    for (int64_t r = r0; r < r1; r += 2) {
+        const int64_t rr = r + lk;
+        float a = 0.f, b0 = 0.f, b1 = 0.f;
+        if (rr < r1) {
+            const int64_t br = row_index ? (int64_t)row_index[rr] : rr;
+            if (a_ok) a = A[rr * lda + i0 + li];
+            if (b0_ok) b0 = B[br * ldb + j0 + li];
+            if (b1_ok) b1 = B[br * ldb + j0 + 32 + li];
+        }
+        csum += a;
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+    }
+    // slab layout: [chunk][n1_pad][n2_pad] with n1_pad = n1_tiles*64, n2_pad = n2_tiles*128
+    const int n2_pad = n2_tiles * TN2;
+    float *slab = slabs + (size_t)chunk * (n1_tiles * TN1) * n2_pad;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        slab[(size_t)row * n2_pad + j0 + li] = acc0[r];
+        slab[(size_t)row * n2_pad + j0 + 32 + li] = acc1[r];
+    }
+    if (colsum_slabs && blockIdx.z == 0 && (wave >> 1) == 0) {
+        // rows of parity 0 live in lanes 0..31, parity 1 in lanes 32..63: add the halves.
+        float other = __shfl_xor(csum, 32, 64);
+        if (lk == 0) colsum_slabs[(size_t)chunk * (n1_tiles * TN1) + i0 + li] = csum + other;
+    }
+}
+
+__global__ void reduce_slabs_kernel(const float *__restrict__ slabs, const int32_t *__restrict__ range,
+                                    int64_t R, int n1, int n2, int n1_pad, int n2_pad,
+                                    float *__restrict__ out, int64_t ldo, int accumulate) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n1 * n2) return;
+    const int i = idx / n2, j = idx - i * n2;
+    int64_t rows = range ? (int64_t)range[1] - range[0] : R;
+    if (rows < 0) rows = 0;
+    const int chunks = (int)((rows + TCH - 1) / TCH);
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += slabs[((size_t)c * n1_pad + i) * n2_pad + j];
+    float *o = out + (int64_t)i * ldo + j;
+    *o = accumulate ? (*o + s) : s;
+}
+
+__global__ void reduce_colsum_kernel(const float *__restrict__ cslabs, const int32_t *__restrict__ range,
+                                     int64_t R, int n1, int n1_pad, float *__restrict__ out, int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n1) return;
+    int64_t rows = range ? (int64_t)range[1] - range[0] : R;
+    if (rows < 0) rows = 0;
+    const int chunks = (int)((rows + TCH - 1) / TCH);
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += cslabs[(size_t)c * n1_pad + i];
+    out[i] = accumulate ? (out[i] + s) : s;
+}
+
+}  // namespace elimrec
+
+using namespace elimrec;
+
+extern "C" int elimrec_linear_fwd(const float *d_A, int64_t lda, const float *d_W, int64_t ldw,
+                                  const float *d_bias, float *d_C, int64_t ldc, int64_t M, int N, int K,
+                                  void *stream) {
+    ELIMREC_REQUIRE(d_A && d_W && d_C, "linear_fwd: null pointer");
+    ELIMREC_REQUIRE(M >= 0 && N > 0 && K > 0, "linear_fwd: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
+    ELIMREC_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, "linear_fwd: K, lda, ldw must be multiples of 4");
+    ELIMREC_REQUIRE(((uintptr_t)d_A % 16) == 0 && ((uintptr_t)d_W % 16) == 0, "linear_fwd: A and W must be 16-byte aligned");
+    if (M == 0) return 0;
+    dim3 grid((unsigned)((M + FBM - 1) / FBM), (unsigned)((N + FBN - 1) / FBN));
+    hipLaunchKernelGGL(linear_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_A, lda, d_W, ldw, d_bias, d_C,
+                       ldc, M, N, K);
+    ELIMREC_LAUNCH_CHECK("linear_fwd");
+    return 0;
+}
+
+static inline void bwd_w_dims(int64_t R, int n1, int n2, int &chunks, int &t1, int &t2) {
+    chunks = (int)((R + TCH - 1) / TCH);
+    if (chunks < 1) chunks = 1;
+    t1 = (n1 + TN1 - 1) / TN1;
+    t2 = (n2 + TN2 - 1) / TN2;
+}
+
+extern "C" size_t elimrec_linear_bwd_w_workspace(int64_t R, int n1, int n2) {
+    int chunks, t1, t2;
+    bwd_w_dims(R, n1, n2, chunks, t1, t2);
+    return ((size_t)chunks * t1 * TN1 * t2 * TN2 + (size_t)chunks * t1 * TN1) * sizeof(float);
+}
+
+extern "C" int elimrec_linear_bwd_w(const float *d_A, int64_t lda, const float *d_B, int64_t ldb,
+                                    const int32_t *d_row_index, const int32_t *d_range, int64_t R, int n1, int n2,
+                                    float *d_out, int64_t ldo, float *d_colsum, int accumulate, void *d_workspace,
+                                    size_t workspace_bytes, void *stream) {
+    ELIMREC_REQUIRE(d_A && d_B && d_out && d_workspace, "linear_bwd_w: null pointer");
+    ELIMREC_REQUIRE(R >= 0 && n1 > 0 && n2 > 0, "linear_bwd_w: bad shape");
+    if (workspace_bytes < elimrec_linear_bwd_w_workspace(R, n1, n2)) {
+        set_error("linear_bwd_w: workspace too small (%zu < %zu)", workspace_bytes,
+                  elimrec_linear_bwd_w_workspace(R, n1, n2));
+        return ELIMREC_E_WORKSPACE;
+    }
+    int chunks, t1, t2;
+    bwd_w_dims(R, n1, n2, chunks, t1, t2);
+    float *slabs = (float *)d_workspace;
+    float *cslabs = slabs + (size_t)chunks * t1 * TN1 * t2 * TN2;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(linear_bwd_w_partial_kernel, dim3(chunks, t1, t2), dim3(256), 0, s, d_A, lda, d_B, ldb,
+                       d_row_index, d_range, R, n1, n2, slabs, d_colsum ? cslabs : nullptr);
+    ELIMREC_LAUNCH_CHECK("linear_bwd_w_partial");
+    const int total = n1 * n2;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((total + 255) / 256), dim3(256), 0, s, slabs, d_range, R, n1, n2,
+                       t1 * TN1, t2 * TN2, d_out, ldo, accumulate);
+    ELIMREC_LAUNCH_CHECK("reduce_slabs");
+    if (d_colsum) {
+        hipLaunchKernelGGL(reduce_colsum_kernel, dim3((n1 + 255) / 256), dim3(256), 0, s, cslabs, d_range, R, n1,
+                           t1 * TN1, d_colsum, accumulate);
+        ELIMREC_LAUNCH_CHECK("reduce_colsum");
+    }
+    return 0;
+}

@@ -1,0 +1,147 @@
+// LightGCN propagation for all M tables at once (models/EliMRec.py:238-248, K2-K4 of SURVEY §2a).
+//
+// Layout: one [N x C] fp32 table, C = M*d; at the Tiktok shape a row is 1 KiB = one wave x
+// float4, so a neighbour row is fetched by ONE fully coalesced wave instruction and one pass
+// over the CSR structure serves every table. HBM-bound: per hop read C*4 B per non-zero
+// (+ 8 B of CSR), write C*4 B per row.
+#include "common.h"
+
+namespace elimrec {
+
+// X0[u, m*d + j] = user_emb[u, j]; X0[U+i, j] = item_emb[i, j] (j < d)
+__global__ void assemble_x0_kernel(const float4 *__restrict__ ue, const float4 *__restrict__ ie,
+                                   float4 *__restrict__ X0, int64_t U, int64_t I, int d4, int M) {
+    const int64_t row = blockIdx.x;
+    const int C4 = d4 * M;
+    if (row < U) {
+        for (int c = threadIdx.x; c < C4; c += blockDim.x) X0[row * C4 + c] = ue[row * d4 + (c % d4)];
+    } else {
+        const int64_t i = row - U;
+        for (int c = threadIdx.x; c < d4; c += blockDim.x) X0[row * C4 + c] = ie[i * d4 + c];
+    }
+}
+
+// One wave per output row; lane l owns float4 column l of each 256-column chunk.
+// Neighbour (col, val) pairs are wave-uniform; UNROLL rows are kept in flight per lane.
+template <int UNROLL>
+__global__ __launch_bounds__(256) void spmm_hop_kernel(const int32_t *__restrict__ rowptr,
+                                                       const int32_t *__restrict__ col,
+                                                       const float *__restrict__ val, int64_t n_rows, int C4,
+                                                       const float4 *__restrict__ Xin, float4 *__restrict__ Xout,
+                                                       const float4 *__restrict__ AccIn, float4 *__restrict__ AccOut,
+                                                       float scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    for (int c0 = 0; c0 < C4; c0 += 64) {
+        const int c = c0 + lane;
+        const bool on = c < C4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int j = beg;
+        for (; j + UNROLL <= end; j += UNROLL) {
+            int cj[UNROLL];
+            float vj[UNROLL];
+            float4 x[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) { cj[u] = col[j + u]; vj[u] = val[j + u]; }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                x[u] = on ? Xin[(int64_t)cj[u] * C4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                acc.x = fmaf(vj[u], x[u].x, acc.x); acc.y = fmaf(vj[u], x[u].y, acc.y);
+                acc.z = fmaf(vj[u], x[u].z, acc.z); acc.w = fmaf(vj[u], x[u].w, acc.w);
+            }
+        }
+        for (; j < end; ++j) {
+            const int cj = col[j];
+            const float vj = val[j];
+            if (on) {
+                const float4 x = Xin[(int64_t)cj * C4 + c];
+                acc.x = fmaf(vj, x.x, acc.x); acc.y = fmaf(vj, x.y, acc.y);
+                acc.z = fmaf(vj, x.z, acc.z); acc.w = fmaf(vj, x.w, acc.w);
+            }
+        }
+        if (on) {
+            if (Xout) Xout[row * C4 + c] = acc;
+            if (AccOut) {
+                const float4 a = AccIn[row * C4 + c];
+                AccOut[row * C4 + c] = make_float4((a.x + acc.x) * scale, (a.y + acc.y) * scale,
+                                                   (a.z + acc.z) * scale, (a.w + acc.w) * scale);
+            }
+        }
+    }
+}
+
+__global__ void scale_copy_kernel(const float4 *__restrict__ in, float4 *__restrict__ out, int64_t n4, float s) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 v = in[i];
+        out[i] = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
+    }
+}
+
+}  // namespace elimrec
+
+using namespace elimrec;
+
+extern "C" int elimrec_assemble_x0(const float *d_user_emb, const float *d_item_emb, float *d_X0, int64_t U,
+                                   int64_t I, int d, int M, void *stream) {
+    ELIMREC_REQUIRE(d_user_emb && d_item_emb && d_X0, "assemble_x0: null pointer");
+    ELIMREC_REQUIRE(d > 0 && d % 4 == 0 && M >= 1, "assemble_x0: recdim must be a positive multiple of 4");
+    if (U + I == 0) return 0;
+    hipLaunchKernelGGL(assemble_x0_kernel, dim3((unsigned)(U + I)), dim3(64), 0, (hipStream_t)stream,
+                       (const float4 *)d_user_emb, (const float4 *)d_item_emb, (float4 *)d_X0, U, I, d / 4, M);
+    ELIMREC_LAUNCH_CHECK("assemble_x0");
+    return 0;
+}
+
+extern "C" int elimrec_spmm_hop(const int32_t *d_rowptr, const int32_t *d_col, const float *d_val, int64_t n_rows,
+                                int C, const float *d_Xin, float *d_Xout, const float *d_AccIn, float *d_AccOut,
+                                float scale, void *stream) {
+    ELIMREC_REQUIRE(d_rowptr && d_Xin, "spmm_hop: null pointer");
+    ELIMREC_REQUIRE(C > 0 && C % 4 == 0, "spmm_hop: C must be a positive multiple of 4");
+    ELIMREC_REQUIRE(d_Xout || d_AccOut, "spmm_hop: no output");
+    ELIMREC_REQUIRE(!d_AccOut || d_AccIn, "spmm_hop: AccOut needs AccIn");
+    ELIMREC_REQUIRE(d_Xout != d_Xin, "spmm_hop: Xout must not alias Xin");
+    if (n_rows == 0) return 0;
+    const int waves = 4;
+    hipLaunchKernelGGL(spmm_hop_kernel<4>, dim3((unsigned)((n_rows + waves - 1) / waves)), dim3(64 * waves), 0,
+                       (hipStream_t)stream, d_rowptr, d_col, d_val, n_rows, C / 4, (const float4 *)d_Xin,
+                       (float4 *)d_Xout, (const float4 *)d_AccIn, (float4 *)d_AccOut, scale);
+    ELIMREC_LAUNCH_CHECK("spmm_hop");
+    return 0;
+}
+
+extern "C" int elimrec_propagate(const int32_t *d_rowptr, const int32_t *d_col, const float *d_val, int64_t n_rows,
+                                 int C, int L, const float *d_X0, float *d_tmp0, float *d_tmp1, float *d_Out,
+                                 void *stream) {
+    ELIMREC_REQUIRE(L >= 0, "propagate: layer_num must be >= 0");
+    ELIMREC_REQUIRE(d_X0 && d_Out && d_Out != d_X0, "propagate: bad X0/Out");
+    ELIMREC_REQUIRE(C > 0 && C % 4 == 0, "propagate: C must be a positive multiple of 4");
+    const float inv = 1.0f / (float)(L + 1);
+    if (L == 0) {
+        const int64_t n4 = n_rows * (C / 4);
+        if (n4 == 0) return 0;
+        hipLaunchKernelGGL(scale_copy_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const float4 *)d_X0,
+                           (float4 *)d_Out, n4, 1.0f);
+        ELIMREC_LAUNCH_CHECK("scale_copy");
+        return 0;
+    }
+    ELIMREC_REQUIRE(L < 2 || d_tmp0, "propagate: tmp0 required for L >= 2");
+    ELIMREC_REQUIRE(L < 3 || d_tmp1, "propagate: tmp1 required for L >= 3");
+    // hop k reads X^{k-1}, writes X^k (except the last hop) and folds X^k into the running sum
+    // kept in Out; the last hop applies 1/(L+1).
+    const float *xin = d_X0;
+    float *bufs[2] = {d_tmp0, d_tmp1};
+    for (int k = 1; k <= L; ++k) {
+        const bool last = (k == L);
+        float *xout = last ? nullptr : bufs[(k - 1) & 1];
+        const float *accin = (k == 1) ? d_X0 : d_Out;
+        int rc = elimrec_spmm_hop(d_rowptr, d_col, d_val, n_rows, C, xin, xout, accin, d_Out, last ? inv : 1.0f,
+                                  stream);
+        if (rc) return rc;
+        xin = xout;
+    }
+    return 0;
+}

@@ -1,0 +1,103 @@
+"""Full-catalogue top-K evaluation with the reference's facade (evaluator/proxy_evaluator.py:40-108,
+evaluator/backend/cpp/uni_evaluator.py:37-203): `ProxyEvaluator(...).evaluate(model)` ->
+(float32 ndarray over metrics x top_show, tab-joined "%.8f" string).
+
+What changed underneath: for a model that exposes `predict_device`, scoring, train-item masking,
+top-K and the metric curves all run on the GPU (csrc/eval.hip) and only the per-user metric rows
+([users x metrics*K] floats) come back to the host for the final mean -- the reference instead
+copies a [128 x I] score matrix to the host per batch and ranks it on 8 CPU threads.
+
+Tie rule: the device ranks by (score descending, item id ascending); the reference's
+std::partial_sort_copy breaks ties in heap order. The two agree whenever a row
+has no tied scores at or across the K boundary.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .data_iterator import DataIterator
+
+metric_dict = {"Precision": 1, "Recall": 2, "MAP": 3, "NDCG": 4, "MRR": 5}
+re_metric_dict = {v: k for k, v in metric_dict.items()}
+
+
+class UniEvaluator(object):
+    def __init__(self, dataset, user_train_dict, user_test_dict, user_neg_test=None, metric=None, top_k=50,
+                 batch_size=1024, num_thread=8):
+        if not isinstance(user_train_dict, dict):
+            raise TypeError("user_train_dict must be a dict")
+        if user_test_dict is not None and not isinstance(user_test_dict, dict):
+            raise TypeError("user_test_dict must be a dict or None")
+        if metric is None:
+            metric = ["Precision", "Recall", "MAP", "NDCG", "MRR"]
+        elif isinstance(metric, str):
+            metric = [metric]
+        elif not isinstance(metric, (set, tuple, list)):
+            raise TypeError("The type of 'metric' (%s) is invalid!" % metric.__class__.__name__)
+        for m in metric:
+            if m not in metric_dict:
+                raise ValueError("There is not the metric named '%s'!" % metric)
+        if user_neg_test is not None:
+            raise NotImplementedError("sampled-negative evaluation (rec.evaluate.neg > 0) is not on the EliMRec path")
+        self.dataset = dataset
+        self.user_pos_train = user_train_dict
+        self.user_pos_test = user_test_dict
+        self.user_neg_test = user_neg_test
+        self.metrics_num = len(metric)
+        self.metrics = [metric_dict[m] for m in metric]
+        self.num_thread = num_thread          # kept for interface parity; ranking runs on the GPU
+        self.batch_size = batch_size
+        self.max_top = top_k if isinstance(top_k, int) else max(top_k)
+        self.top_show = np.arange(top_k) + 1 if isinstance(top_k, int) else np.sort(top_k)
+        self._dev_cache = {}
+
+    def metrics_info(self):
+        cols = ["\t".join(("%s@" % re_metric_dict[m] + str(k)).ljust(12) for k in self.top_show) for m in self.metrics]
+        return "metrics:\t%s" % "\t".join(cols)
+
+    def _batch_csr(self, users, table, device, unique):
+        lists = [sorted(set(table.get(u, []))) if unique else table.get(u, []) for u in users]
+        ptr = np.zeros(len(users) + 1, dtype=np.int64)
+        np.cumsum([len(x) for x in lists], out=ptr[1:])
+        flat = np.fromiter((i for x in lists for i in x), dtype=np.int32, count=int(ptr[-1]))
+        return torch.from_numpy(ptr).to(device), torch.from_numpy(flat).to(device)
+
+    def evaluate(self, model, test_users=None):
+        test_users = test_users if test_users is not None else list(self.user_pos_test.keys())
+        if not isinstance(test_users, (list, tuple, set, np.ndarray)):
+            raise TypeError("'test_user' must be a list, tuple, set or numpy array!")
+        if not hasattr(model, "predict_device"):
+            raise TypeError("model must expose predict_device(); host-side ranking is not part of this package")
+        rows = []
+        for batch_users in DataIterator(list(test_users), batch_size=self.batch_size, shuffle=False, drop_last=False):
+            rows.append(self.evaluate_batch(model, batch_users))
+        all_rows = torch.cat(rows, 0).cpu().numpy()                       # [users, metrics*K]
+        final = np.mean(all_rows, axis=0).reshape(self.metrics_num, self.max_top)[:, self.top_show - 1].reshape(-1)
+        buf = "\t".join(("%.8f" % x).ljust(12) for x in final)
+        return final, buf
+
+    def evaluate_batch(self, model, batch_users, return_topk=False):
+        """Per-user metric rows [len(batch_users), metrics*K] (device tensor) for one user block."""
+        device = model._require_gpu()
+        train_ptr, train_items = self._batch_csr(batch_users, self.user_pos_train, device, unique=False)
+        truth_ptr, truth_items = self._batch_csr(batch_users, self.user_pos_test, device, unique=True)
+        idx, val = model.predict_device(batch_users, top_k=self.max_top, train_ptr=train_ptr, train_items=train_items)
+        out = torch.empty(len(batch_users), self.metrics_num * self.max_top, dtype=torch.float32, device=device)
+        ops.rank_metrics(idx, truth_ptr, truth_items, self.metrics, out)
+        return (out, idx, val) if return_topk else out
+
+
+class ProxyEvaluator(object):
+    def __init__(self, dataset, user_train_dict, user_test_dict, user_neg_test=None, metric=None, group_view=None,
+                 top_k=50, batch_size=1024, num_thread=8):
+        if group_view is not None:
+            raise NotImplementedError("group_view evaluation is out of scope (NeuRec.properties:27 sets None; the "
+                                      "reference's GroupedEvaluator cannot be constructed as shipped)")
+        self.evaluator = UniEvaluator(dataset, user_train_dict, user_test_dict, user_neg_test, metric=metric,
+                                      top_k=top_k, batch_size=batch_size, num_thread=num_thread)
+
+    def metrics_info(self):
+        return self.evaluator.metrics_info()
+
+    def evaluate(self, model):
+        return self.evaluator.evaluate(model)

@@ -1,0 +1,416 @@
+"""EliMRec on MI355X: the reference's plugin class (models/EliMRec.py:31-407) with the same
+constructor, parameter names, state_dict keys and methods, whose per-batch work runs entirely
+in libelimrec_hip.so.
+
+Data layout in HBM (fp32, row-major; N = U + I nodes, users first):
+  X0/Out [N x C], C = M*d   every propagated table side by side: column block 0 = id table,
+                            1.. = projected V/A/T features. One 1-KiB row (Tiktok shape) serves
+                            all M LightGCN graphs, so the CSR structure is read once per hop.
+  Y      [N x Cy], Cy=(1+S)d block 0 = fused embedding (all_users / all_items), block 1+h =
+                            single-modal head h (pre_fusion_{user,item}_{v,a,t}). The BPR head
+                            gathers one contiguous row per index; predict() reads only Y.
+What the reference does with 12+12 torch.sparse.mm calls, 8 addmm and autograd per batch is here
+(see DESIGN.md): assemble_x0 + 3 linear_fwd -> propagate -> 5 linear_fwd -> bpr_head, and on the
+way back segment_reduce_rows -> head_bwd_input / linear_bwd_w -> propagate (A^T) -> embed_grad /
+linear_bwd_w. Propagation is linear, so nothing of the forward pass is kept for backward except
+Out and Y.
+"""
+import numpy as np
+import scipy.sparse as sp
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import ops
+from .basic_model import BasicModel
+from .logger import Logger
+
+
+def create_adj_mat(train_users, train_items, num_users, num_items, adj_type):
+    """models/EliMRec.py:309-354. Returns a scipy CSR [N, N] in fp32 (values rounded as scipy does)."""
+    u = np.asarray(train_users, dtype=np.int32)
+    i = np.asarray(train_items, dtype=np.int32)
+    n = num_users + num_items
+    half = sp.csr_matrix((np.ones_like(u, dtype=np.float32), (u, i + num_users)), shape=(n, n))
+    adj = half + half.T
+
+    def row_normalised(a):
+        deg = np.asarray(a.sum(1)).flatten()
+        with np.errstate(divide="ignore"):
+            inv = np.power(deg, -1.0)
+        inv[np.isinf(inv)] = 0.0
+        return sp.diags(inv).dot(a)
+
+    if adj_type == "plain":
+        out = adj
+    elif adj_type == "norm":
+        out = row_normalised(adj + sp.eye(n))
+    elif adj_type == "gcmc":
+        out = row_normalised(adj)
+    elif adj_type == "pre":
+        deg = np.asarray(adj.sum(1))
+        with np.errstate(divide="ignore"):
+            inv = np.power(deg, -0.5).flatten()
+        inv[np.isinf(inv)] = 0.0
+        dm = sp.diags(inv)
+        out = dm.dot(adj).dot(dm)
+    else:
+        out = row_normalised(adj) + sp.eye(n)
+    out = sp.csr_matrix(out).astype(np.float32)
+    out.sort_indices()
+    return out
+
+
+class _BprLossFn(torch.autograd.Function):
+    """Glue between torch's autograd/optimizer API (main.py:98-101) and the HIP path: forward
+    enqueues the forward kernels and returns the 0-dim loss; backward enqueues the backward
+    kernels and hands one gradient per parameter back (None for parameters the loss does not
+    reach, exactly the set the reference leaves without .grad)."""
+
+    @staticmethod
+    def forward(ctx, model, users, pos, neg, *params):
+        ctx.model = model
+        ctx.names = model._param_names
+        loss = model._forward_hip(users, pos, neg, need_grad=True)
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        model = ctx.model
+        grads = model._backward_hip(grad_out.reshape(1).to(torch.float32).contiguous())
+        return (None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
+
+
+class EliMRec(BasicModel):
+    def __init__(self, config, dataset):
+        super(EliMRec, self).__init__(dataset, config)
+        self.__init_weight()
+
+    # ------------------------------------------------------------------ construction
+    def __init_weight(self):
+        cfg = self.config
+        self.num_users = self.dataset.num_users
+        self.num_items = self.dataset.num_items
+        self.latent_dim = cfg["recdim"]
+        self.n_layers = cfg["layer_num"]
+        self.temp = cfg["temp"]
+        self.logits = cfg["logits"]
+        opt = lambda key, default: cfg[key] if key in cfg else default
+        self.predict_type = opt("predict_type", "TIE")
+        Logger.info("predict type: " + self.predict_type)
+        self.mm_fusion_mode = opt("mm_fusion_mode", "concat")
+        Logger.info("mm fusion mode: " + self.mm_fusion_mode)
+        self.is_u_s = opt("is_u_s", False)
+        Logger.info("cf in single modal preference: " + str(self.is_u_s))
+        self.fusion_mode = opt("s_fusion_mode", "rubi")
+        Logger.info("score fusion mode: " + self.fusion_mode)
+        Logger.info("alpha: " + str(cfg["alpha"]))          # KeyError if missing, as in the reference (:66)
+        self.modified_ui_loss = opt("modified_ui_loss", True)
+        Logger.info("modified_ui_loss: " + str(self.modified_ui_loss))
+        self.modality = opt("modality", "vat")
+        Logger.info("Modality Ablation: " + str(self.modality))
+        if self.latent_dim % 4 != 0:
+            raise ValueError("recdim must be a multiple of 4 for the HIP kernels (got %d)" % self.latent_dim)
+        if self.mm_fusion_mode not in ("concat", "mean"):
+            raise ValueError("mm_fusion_mode must be 'concat' or 'mean'")
+        self.dataset_name = cfg["data.input.dataset"]
+        self.is_kwai = self.dataset_name == "kwai"
+        self._mods = ["v"] if self.is_kwai else ["v", "a", "t"]       # tables after the id table
+        self.M = 1 + len(self._mods)
+        self.C = self.M * self.latent_dim
+        self.S = len(self._mods)                                       # single-modal heads
+        self.Cy = (1 + self.S) * self.latent_dim
+
+        self._create_u_embeding_i()
+        self.all_items = self.all_users = None
+        self.all_s_embs = None
+
+        tu, ti = self.dataset.get_train_interactions()
+        adj = create_adj_mat(tu, ti, self.num_users, self.num_items, cfg["adj_type"])
+        self._register_csr("adj", adj)
+        adj_t = adj.T.tocsr()
+        adj_t.sort_indices()
+        self._adj_symmetric = (abs(adj - adj_t)).nnz == 0
+        if not self._adj_symmetric:
+            self._register_csr("adjT", adj_t)
+
+        # same construction order as the reference (:88-93) so a seeded run draws the same init
+        d = self.latent_dim
+        self.s_dense_v = nn.Linear(d, d)
+        self.s_dense_a = nn.Linear(d, d)
+        self.s_dense_t = nn.Linear(d, d)
+        nn.init.xavier_uniform_(self.s_dense_v.weight)
+        nn.init.xavier_uniform_(self.s_dense_a.weight)
+        nn.init.xavier_uniform_(self.s_dense_t.weight)
+        self._param_names = [n for n, _ in self.named_parameters()]
+        self._ws = None
+        self._ws_key = None
+
+    def _register_csr(self, name, m):
+        if m.nnz >= 2 ** 31 or m.shape[0] >= 2 ** 31 - 1:
+            raise ValueError("graph too large for int32 CSR")
+        self.register_buffer(name + "_rowptr", torch.from_numpy(m.indptr.astype(np.int32)), persistent=False)
+        self.register_buffer(name + "_col", torch.from_numpy(m.indices.astype(np.int32)), persistent=False)
+        self.register_buffer(name + "_val", torch.from_numpy(m.data.astype(np.float32)), persistent=False)
+
+    def _csr(self, name):
+        return ops.Csr(getattr(self, name + "_rowptr"), getattr(self, name + "_col"), getattr(self, name + "_val"),
+                       self.num_users + self.num_items)
+
+    def _create_u_embeding_i(self):
+        """models/EliMRec.py:356-407, same RNG draw order."""
+        d = self.latent_dim
+        self.embedding_user = nn.Embedding(self.num_users, d)
+        self.embedding_item = nn.Embedding(self.num_items, d)
+        nn.init.xavier_uniform_(self.embedding_user.weight)
+        nn.init.xavier_uniform_(self.embedding_item.weight)
+        Logger.info("[use Xavier initilizer]")
+        ds = self.dataset
+        self.register_buffer("v_feat", F.normalize(ds.v_feat.float(), dim=1).contiguous(), persistent=False)
+        if not self.is_kwai:
+            self.register_buffer("a_feat", F.normalize(ds.a_feat.float(), dim=1).contiguous(), persistent=False)
+            if self.dataset_name == "tiktok":
+                # :371-378: t_feat is the scatter-mean of word embeddings, built ONCE at init and
+                # never recomputed -> a constant, un-normalised [I x 128] table.
+                words = ds.words_tensor
+                self.word_embedding = nn.Embedding(11574, 128)
+                nn.init.xavier_normal_(self.word_embedding.weight)
+                emb = self.word_embedding.weight.detach()[words[1]]
+                rows = int(words[0].max()) + 1
+                tot = torch.zeros(rows, 128).index_add_(0, words[0], emb)
+                cnt = torch.zeros(rows).index_add_(0, words[0], torch.ones(words.shape[1])).clamp_(min=1)
+                self.register_buffer("t_feat", (tot / cnt[:, None]).contiguous(), persistent=False)
+            else:
+                self.register_buffer("t_feat", F.normalize(ds.t_feat.float(), dim=1).contiguous(), persistent=False)
+        for m in self._mods:
+            feat = getattr(self, m + "_feat")
+            if feat.shape[0] != self.num_items:
+                raise ValueError("%s_feat has %d rows, expected num_items=%d" % (m, feat.shape[0], self.num_items))
+            if feat.shape[1] % 4 != 0:
+                raise ValueError("feature width of '%s' must be a multiple of 4 (got %d)" % (m, feat.shape[1]))
+        self.v_dense = nn.Linear(self.v_feat.shape[1], d)
+        if not self.is_kwai:
+            self.a_dense = nn.Linear(self.a_feat.shape[1], d)
+            self.t_dense = nn.Linear(self.t_feat.shape[1], d)
+        self.item_feat_dim = d * self.M if self.mm_fusion_mode == "concat" else d
+        nn.init.xavier_uniform_(self.v_dense.weight)
+        if not self.is_kwai:
+            nn.init.xavier_uniform_(self.a_dense.weight)
+            nn.init.xavier_uniform_(self.t_dense.weight)
+        self.embedding_user_after_GCN = nn.Linear(self.item_feat_dim, d)
+        nn.init.xavier_uniform_(self.embedding_user_after_GCN.weight)
+        self.embedding_item_after_GCN = nn.Linear(self.item_feat_dim, d)
+        nn.init.xavier_uniform_(self.embedding_item_after_GCN.weight)
+
+    # ------------------------------------------------------------------ device workspace
+    def _device(self):
+        return self.embedding_user.weight.device
+
+    def _require_gpu(self):
+        dev = self._device()
+        if dev.type != "cuda":
+            raise RuntimeError("EliMRec (elimrec_amd): the model is on '%s'. The hot path exists only as HIP kernels "
+                               "for MI355X; move the model to a GPU (`.to('cuda:0')`). There is no CPU fallback." % dev)
+        return dev
+
+    def _workspace(self, B):
+        dev = self._require_gpu()
+        key = (str(dev), int(B))
+        if self._ws is not None and self._ws_key == key:
+            return self._ws
+        N, C, Cy, d = self.num_users + self.num_items, self.C, self.Cy, self.latent_dim
+        f32 = dict(dtype=torch.float32, device=dev)
+        ws = self._ws if (self._ws is not None and self._ws_key[0] == key[0]) else {}
+        if "X0" not in ws:
+            for name in ("X0", "T0", "T1", "Out", "G"):
+                ws[name] = torch.empty(N, C, **f32)
+            ws["Y"] = torch.zeros(N, Cy, **f32)
+            dmax = max(getattr(self, m + "_feat").shape[1] for m in self._mods)
+            nbytes = max(ops.linear_bwd_w_workspace(self.num_items, d, dmax), 1)
+            ws["bwd_w_items"] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            ws["loss"] = torch.zeros(1, **f32)
+            ws["one"] = torch.ones(1, **f32)
+        n3 = 3 * B
+        ws["loss_rows"] = torch.empty(B, **f32)
+        ws["grad_rows"] = torch.empty(n3, Cy, **f32)
+        ws["keys"] = torch.empty(n3, dtype=torch.int32, device=dev)
+        ws["active_rows"] = torch.empty(n3, dtype=torch.int32, device=dev)
+        ws["dY"] = torch.empty(n3, Cy, **f32)
+        ws["seg_info"] = torch.zeros(8, dtype=torch.int32, device=dev)
+        ws["seg_ws"] = torch.empty(max(ops.segment_reduce_workspace(n3), 1), dtype=torch.uint8, device=dev)
+        ws["bwd_w_rows"] = torch.empty(max(ops.linear_bwd_w_workspace(n3, d, C), 1), dtype=torch.uint8, device=dev)
+        self._ws, self._ws_key = ws, key
+        return ws
+
+    def _fusion_weights(self):
+        """[d x C] fusion weights as the kernels consume them. 'mean' fusion (mean over the M
+        tables, then a [d x d] Linear; :224-225) is the same map as a [d x C] Linear whose M
+        column blocks are all W/M."""
+        wu, wi = self.embedding_user_after_GCN.weight, self.embedding_item_after_GCN.weight
+        if self.mm_fusion_mode == "concat":
+            return wu, wi
+        return (wu.detach() / self.M).repeat(1, self.M).contiguous(), (wi.detach() / self.M).repeat(1, self.M).contiguous()
+
+    def _block_weights(self):
+        """Per head block loss weights: fused head 1; single-modal heads alpha if the modality is
+        active (:125-126,133-142)."""
+        w = [1.0]
+        modality = "v" if self.is_kwai else self.modality
+        for m in self._mods:
+            on = (self.predict_type != "normal") and (m in modality)
+            w.append(float(self.config["alpha"]) * modality.count(m) if on else 0.0)
+        return w
+
+    # ------------------------------------------------------------------ forward / backward (HIP)
+    @torch.no_grad()
+    def _compute_tables(self, ws):
+        """compute() + gcn_cf() (:228-272,144-153): fills ws['Out'] and ws['Y']."""
+        U, I, d, M, C = self.num_users, self.num_items, self.latent_dim, self.M, self.C
+        X0, Out, Y = ws["X0"], ws["Out"], ws["Y"]
+        ops.assemble_x0(self.embedding_user.weight, self.embedding_item.weight, X0, M)
+        for k, m in enumerate(self._mods):
+            lin = getattr(self, m + "_dense")
+            ops.linear_fwd(getattr(self, m + "_feat"), lin.weight, lin.bias, X0[U:, (k + 1) * d:(k + 2) * d])
+        ops.propagate(self._csr("adj"), X0, self.n_layers, ws["T0"], ws["T1"], Out)
+        wu, wi = self._fusion_weights()
+        ops.linear_fwd(Out[:U], wu, self.embedding_user_after_GCN.bias, Y[:U, :d])
+        ops.linear_fwd(Out[U:], wi, self.embedding_item_after_GCN.bias, Y[U:, :d])
+        for h, m in enumerate(self._mods):
+            lin = getattr(self, "s_dense_" + m)
+            ops.linear_fwd(Out[:, (h + 1) * d:(h + 2) * d], lin.weight, lin.bias, Y[:, (h + 1) * d:(h + 2) * d])
+        self._publish_cache(Y)
+
+    def _publish_cache(self, Y):
+        U, d = self.num_users, self.latent_dim
+        self.all_users, self.all_items = Y[:U, :d], Y[U:, :d]
+        self.all_s_embs = {}
+        for h, m in enumerate(self._mods):
+            blk = Y[:, (h + 1) * d:(h + 2) * d]
+            self.all_s_embs["pre_fusion_user_" + m] = blk[:U]
+            self.all_s_embs["pre_fusion_item_" + m] = blk[U:]
+
+    @torch.no_grad()
+    def _forward_hip(self, users, pos, neg, need_grad):
+        B = int(users.numel())
+        ws = self._workspace(B)
+        users, pos, neg = (t.to(device=self._device(), dtype=torch.int64).contiguous() for t in (users, pos, neg))
+        self._compute_tables(ws)
+        self._last_block_weights = self._block_weights()
+        ops.bpr_head(ws["Y"], self.num_users, self.num_items, users, pos, neg, self.latent_dim,
+                     self._last_block_weights, ws["loss_rows"], ws["grad_rows"] if need_grad else None,
+                     ws["keys"] if need_grad else None)
+        loss = torch.empty((), dtype=torch.float32, device=self._device())
+        ops.fixed_order_sum(ws["loss_rows"], loss)
+        return loss
+
+    @torch.no_grad()
+    def _backward_hip(self, gscale):
+        """Returns {parameter name: gradient tensor}. gscale: device fp32[1] (d loss_total / d loss)."""
+        ws = self._ws
+        dev = self._device()
+        U, I, d, M, C, S = self.num_users, self.num_items, self.latent_dim, self.M, self.C, self.S
+        dY, seg, act = ws["dY"], ws["seg_info"], ws["active_rows"]
+        ops.segment_reduce_rows(ws["grad_rows"], ws["keys"], U, act, dY, seg, ws["seg_ws"], scale=gscale)
+        bw = self._last_block_weights
+        heads_on = [h for h in range(S) if bw[1 + h] != 0.0]
+        wu, wi = self._fusion_weights()
+        G0 = ws["X0"]
+        G0.zero_()
+        # heads switched off by the modality ablation carry an all-zero gradient block
+        ops.head_bwd_input(dY, act, seg, U, d, C, [h + 1 for h in range(S)], wu, wi,
+                           [getattr(self, "s_dense_" + m).weight for m in self._mods], 1.0, G0)
+        grads = {}
+        f32 = dict(dtype=torch.float32, device=dev)
+        # fusion Linears: dW = dY_f^T . Out[active rows], user slots / item slots separately
+        for name, rng in (("embedding_user_after_GCN", seg[2:4]), ("embedding_item_after_GCN", seg[4:6])):
+            gw = torch.empty(d, C, **f32)
+            gb = torch.empty(d, **f32)
+            ops.linear_bwd_w(dY[:, :d], ws["Out"], gw, ws["bwd_w_rows"], row_index=act, rng=rng, colsum=gb)
+            if self.mm_fusion_mode == "mean":
+                gw = gw.view(d, M, d).sum(1) / M
+            grads[name + ".weight"], grads[name + ".bias"] = gw, gb
+        for h in heads_on:
+            name = "s_dense_" + self._mods[h]
+            gw = torch.empty(d, d, **f32)
+            gb = torch.empty(d, **f32)
+            ops.linear_bwd_w(dY[:, (h + 1) * d:(h + 2) * d], ws["Out"][:, (h + 1) * d:(h + 2) * d], gw, ws["bwd_w_rows"],
+                             row_index=act, rng=seg[6:8], colsum=gb)
+            grads[name + ".weight"], grads[name + ".bias"] = gw, gb
+        # back through the propagation (A^T; A itself when symmetric), then the layer-0 pieces
+        G = ws["G"]
+        ops.propagate(self._csr("adj" if self._adj_symmetric else "adjT"), G0, self.n_layers, ws["T0"], ws["T1"], G)
+        gu = torch.empty(U, d, **f32)
+        gi = torch.empty(I, d, **f32)
+        ops.embed_grad(G, U, I, d, M, gu, gi)
+        grads["embedding_user.weight"], grads["embedding_item.weight"] = gu, gi
+        for k, m in enumerate(self._mods):
+            feat = getattr(self, m + "_feat")
+            gw = torch.empty(d, feat.shape[1], **f32)
+            gb = torch.empty(d, **f32)
+            ops.linear_bwd_w(G[U:, (k + 1) * d:(k + 2) * d], feat, gw, ws["bwd_w_items"], colsum=gb)
+            grads[m + "_dense.weight"], grads[m + "_dense.bias"] = gw, gb
+        return grads
+
+    # ------------------------------------------------------------------ reference API
+    def bpr_loss(self, users, pos_items, neg_items):
+        """models/EliMRec.py:115-142. int64 index tensors of shape [b] -> 0-dim loss supporting
+        .backward(retain_graph=True) and .cpu().item() (main.py:98-102)."""
+        self._require_gpu()
+        if self.is_kwai:
+            self.modality = "v"                        # :133-134
+        params = [p for _, p in self.named_parameters()]
+        return _BprLossFn.apply(self, users.long(), pos_items.long(), neg_items.long(), *params)
+
+    def compute(self):
+        """:228-272. Returns (all_users [U x d], all_items [I x d]) -- views into Y, no autograd."""
+        ws = self._workspace(self._ws_key[1] if self._ws_key else 1)
+        self._compute_tables(ws)
+        return self.all_users, self.all_items
+
+    def gcn_cf(self, detach=False):
+        """:144-153. The single-modal head tables computed by the last compute()."""
+        return self.all_s_embs
+
+    def getEmbedding(self, users, pos_items, neg_items):
+        """:274-289 (forward values only; training goes through bpr_loss)."""
+        all_users, all_items = self.compute()
+        ego_u, ego_i = self.embedding_user.weight.detach(), self.embedding_item.weight.detach()
+        neg = (all_items[neg_items], ego_i[neg_items]) if neg_items is not None else (None, None)
+        return all_users[users], all_items[pos_items], neg[0], ego_u[users], ego_i[pos_items], neg[1]
+
+    def forward(self, users, items):
+        """:299-307."""
+        all_users, all_items = self.compute()
+        return torch.sum(all_users[users] * all_items[items], dim=1).detach()
+
+    def _head_mask(self):
+        modality = "v" if self.is_kwai else self.modality
+        return sum(1 << h for h, m in enumerate(self._mods) if m in modality)
+
+    @torch.no_grad()
+    def predict_device(self, user_ids, scores=None, top_k=0, train_ptr=None, train_items=None):
+        """Device-side predict (+ optional train-item masking and top-K). Uses the tables cached
+        by the LAST training forward, like the reference (:98-99)."""
+        dev = self._require_gpu()
+        if self._ws is None or self.all_users is None:
+            raise RuntimeError("predict() needs the tables cached by a training forward (call bpr_loss or compute first)")
+        users = torch.as_tensor(user_ids, device=dev).long().contiguous()
+        B, I = users.numel(), self.num_items
+        need = ops.score_workspace(B, I, max(top_k, 1))
+        if self._ws.get("score_ws") is None or self._ws["score_ws"].numel() < need:
+            self._ws["score_ws"] = torch.empty(need, dtype=torch.uint8, device=dev)
+        idx = val = None
+        if top_k:
+            idx = torch.empty(B, top_k, dtype=torch.int32, device=dev)
+            val = torch.empty(B, top_k, dtype=torch.float32, device=dev)
+        ops.score_topk(self._ws["Y"], self.num_users, I, users, self.latent_dim, self.S, self._head_mask(),
+                       self.fusion_mode, self.predict_type, self._ws["score_ws"], scores=scores, K=top_k,
+                       topk_idx=idx, topk_val=val, train_ptr=train_ptr, train_items=train_items)
+        return idx, val
+
+    def predict(self, user_ids, candidate_items=None):
+        """:96-113. CPU fp32 tensor [len(user_ids) x I]; `candidate_items` is ignored as in the reference."""
+        dev = self._require_gpu()
+        scores = torch.empty(len(user_ids), self.num_items, dtype=torch.float32, device=dev)
+        self.predict_device(user_ids, scores=scores)
+        return scores.cpu()

@@ -1,0 +1,214 @@
+"""Tensor-level wrappers over the C ABI (include/elimrec_hip.h).
+
+torch is plumbing here: it owns device memory and the current HIP stream; every function below
+hands raw device pointers to libelimrec_hip.so. Inputs must live on a HIP device -- anything
+else raises (no CPU path).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t, name, dtype=torch.float32):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("elimrec_amd.ops: '%s' must be a HIP device tensor (the hot path has no CPU "
+                           "implementation)" % name)
+    if t.dtype != dtype:
+        raise TypeError("elimrec_amd.ops: '%s' must be %s, got %s" % (name, dtype, t.dtype))
+    return t.data_ptr()
+
+
+def _rowmajor(t, name):
+    """(pointer, leading dimension) of a 2-D tensor whose rows are contiguous."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError("elimrec_amd.ops: '%s' must be 2-D with unit column stride" % name)
+    return _dev(t, name), t.stride(0)
+
+
+def linear_fwd(A, W, bias, out):
+    """out[m, n] = sum_k A[m,k] W[n,k] + bias[n]; A/out may be column slices of wider tables."""
+    lib = _lib.load()
+    a, lda = _rowmajor(A, "A")
+    w, ldw = _rowmajor(W, "W")
+    c, ldc = _rowmajor(out, "out")
+    M, K = A.shape
+    N = W.shape[0]
+    assert W.shape[1] == K and out.shape[0] == M and out.shape[1] == N
+    _lib.check(lib.elimrec_linear_fwd(a, lda, w, ldw, _dev(bias, "bias"), c, ldc, M, N, K, _stream()), "linear_fwd")
+    return out
+
+
+def linear_bwd_w_workspace(R, n1, n2):
+    return int(_lib.load().elimrec_linear_bwd_w_workspace(R, n1, n2))
+
+
+def linear_bwd_w(A, B, out, workspace, row_index=None, rng=None, colsum=None, accumulate=False, rows=None):
+    """out[i, j] (+)= sum_r A[r, i] * B[row_index[r] or r, j]; colsum[i] (+)= sum_r A[r, i]."""
+    lib = _lib.load()
+    a, lda = _rowmajor(A, "A")
+    b, ldb = _rowmajor(B, "B")
+    o, ldo = _rowmajor(out, "out")
+    R = A.shape[0] if rows is None else rows
+    n1, n2 = out.shape
+    _lib.check(lib.elimrec_linear_bwd_w(a, lda, b, ldb, _dev(row_index, "row_index", torch.int32),
+                                        _dev(rng, "range", torch.int32), R, n1, n2, o, ldo, _dev(colsum, "colsum"),
+                                        1 if accumulate else 0, _dev(workspace, "workspace", torch.uint8),
+                                        workspace.numel(), _stream()), "linear_bwd_w")
+    return out
+
+
+def assemble_x0(user_emb, item_emb, X0, M):
+    U, d = user_emb.shape
+    I = item_emb.shape[0]
+    assert X0.is_contiguous() and X0.shape == (U + I, M * d)
+    assert user_emb.is_contiguous() and item_emb.is_contiguous()
+    _lib.check(_lib.load().elimrec_assemble_x0(_dev(user_emb, "user_emb"), _dev(item_emb, "item_emb"), _dev(X0, "X0"),
+                                               U, I, d, M, _stream()), "assemble_x0")
+    return X0
+
+
+class Csr:
+    """Device CSR (int32 rowptr/col, fp32 val)."""
+
+    def __init__(self, rowptr, col, val, n_rows):
+        self.rowptr, self.col, self.val, self.n_rows = rowptr, col, val, n_rows
+
+    @staticmethod
+    def from_scipy(m, device):
+        m = m.tocsr()
+        m.sort_indices()
+        if m.nnz >= 2 ** 31:
+            raise ValueError("CSR with >= 2^31 non-zeros is not supported")
+        import numpy as np
+        return Csr(torch.from_numpy(m.indptr.astype(np.int32)).to(device),
+                   torch.from_numpy(m.indices.astype(np.int32)).to(device),
+                   torch.from_numpy(m.data.astype(np.float32)).to(device), m.shape[0])
+
+
+def spmm_hop(csr, Xin, Xout=None, acc_in=None, acc_out=None, scale=1.0):
+    C = Xin.shape[1]
+    assert Xin.is_contiguous()
+    _lib.check(_lib.load().elimrec_spmm_hop(_dev(csr.rowptr, "rowptr", torch.int32), _dev(csr.col, "col", torch.int32),
+                                            _dev(csr.val, "val"), csr.n_rows, C, _dev(Xin, "Xin"), _dev(Xout, "Xout"),
+                                            _dev(acc_in, "acc_in"), _dev(acc_out, "acc_out"), float(scale), _stream()),
+               "spmm_hop")
+
+
+def propagate(csr, X0, L, tmp0, tmp1, out):
+    C = X0.shape[1]
+    assert X0.is_contiguous() and out.is_contiguous() and out.shape == X0.shape
+    _lib.check(_lib.load().elimrec_propagate(_dev(csr.rowptr, "rowptr", torch.int32), _dev(csr.col, "col", torch.int32),
+                                             _dev(csr.val, "val"), csr.n_rows, C, L, _dev(X0, "X0"),
+                                             _dev(tmp0, "tmp0"), _dev(tmp1, "tmp1"), _dev(out, "out"), _stream()),
+               "propagate")
+    return out
+
+
+def bpr_head(Y, U, I, users, pos, neg, d, block_weights, loss_rows, grad_rows=None, keys=None):
+    y, ldy = _rowmajor(Y, "Y")
+    nb = len(block_weights)
+    w = (ctypes.c_float * nb)(*[float(x) for x in block_weights])
+    B = users.numel()
+    _lib.check(_lib.load().elimrec_bpr_head(y, ldy, U, I, _dev(users, "users", torch.int64), _dev(pos, "pos", torch.int64),
+                                            _dev(neg, "neg", torch.int64), B, d, nb, w, _dev(loss_rows, "loss_rows"),
+                                            _dev(grad_rows, "grad_rows"), _dev(keys, "keys", torch.int32), _stream()),
+               "bpr_head")
+
+
+def fixed_order_sum(x, out):
+    _lib.check(_lib.load().elimrec_sum(_dev(x, "x"), x.numel(), _dev(out, "out"), _stream()), "sum")
+    return out
+
+
+def segment_reduce_workspace(n):
+    return int(_lib.load().elimrec_segment_reduce_workspace(n))
+
+
+def segment_reduce_rows(rows, keys, split_key, active_rows, reduced, seg_info, workspace, scale=None):
+    n, ld = rows.shape
+    assert rows.is_contiguous() and reduced.is_contiguous()
+    _lib.check(_lib.load().elimrec_segment_reduce_rows(_dev(rows, "rows"), _dev(keys, "keys", torch.int32), n, ld,
+                                                       int(split_key), _dev(active_rows, "active_rows", torch.int32),
+                                                       _dev(reduced, "reduced"), _dev(scale, "scale"),
+                                                       _dev(seg_info, "seg_info", torch.int32),
+                                                       _dev(workspace, "workspace", torch.uint8), workspace.numel(),
+                                                       _stream()), "segment_reduce_rows")
+
+
+def head_bwd_input(dY, active_rows, seg_info, U, d, C, head_mblock, W_user, W_item, W_heads, gscale, G0):
+    S = len(W_heads)
+    dy, lddy = _rowmajor(dY, "dY")
+    mb = (ctypes.c_int * max(S, 1))(*head_mblock) if S else (ctypes.c_int * 1)(0)
+    wp = (ctypes.c_void_p * max(S, 1))(*[_dev(w, "W_head") for w in W_heads]) if S else (ctypes.c_void_p * 1)(None)
+    for w in list(W_heads) + [W_user, W_item]:
+        assert w.is_contiguous()
+    assert G0.is_contiguous()
+    _lib.check(_lib.load().elimrec_head_bwd_input(dy, lddy, _dev(active_rows, "active_rows", torch.int32),
+                                                  _dev(seg_info, "seg_info", torch.int32), dY.shape[0], U, d, C, S, mb,
+                                                  _dev(W_user, "W_user"), _dev(W_item, "W_item"), wp, float(gscale),
+                                                  _dev(G0, "G0"), _stream()), "head_bwd_input")
+
+
+def embed_grad(G, U, I, d, M, grad_user, grad_item):
+    assert G.is_contiguous() and grad_user.is_contiguous() and grad_item.is_contiguous()
+    _lib.check(_lib.load().elimrec_embed_grad(_dev(G, "G"), U, I, d, M, _dev(grad_user, "grad_user"),
+                                              _dev(grad_item, "grad_item"), _stream()), "embed_grad")
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
+    for t in (p, g, m, v):
+        assert t.is_contiguous()
+    _lib.check(_lib.load().elimrec_adam_step(_dev(p, "p"), _dev(g, "g"), _dev(m, "m"), _dev(v, "v"), p.numel(),
+                                             float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                             int(step), _stream()), "adam_step")
+
+
+def score_workspace(B, I, K):
+    return int(_lib.load().elimrec_score_workspace(B, I, K))
+
+
+FUSION_MODES = {"rubi": 0, "hm": 1, "sum": 2}
+PREDICT_TYPES = {"TE": 1, "TIE": 2}   # anything else -> 0 ("normal", models/EliMRec.py:113)
+
+
+def score_topk(Y, U, I, users, d, S, head_mask, fusion_mode, predict_type, workspace, scores=None, K=0,
+               topk_idx=None, topk_val=None, train_ptr=None, train_items=None):
+    y, ldy = _rowmajor(Y, "Y")
+    B = users.numel()
+    sp, lds = (None, 0)
+    if scores is not None:
+        sp, lds = _rowmajor(scores, "scores")
+    _lib.check(_lib.load().elimrec_score_topk(y, ldy, U, I, _dev(users, "users", torch.int64), B, d, S, int(head_mask),
+                                              FUSION_MODES[fusion_mode], PREDICT_TYPES.get(predict_type, 0),
+                                              _dev(train_ptr, "train_ptr", torch.int64),
+                                              _dev(train_items, "train_items", torch.int32), sp, lds, int(K),
+                                              _dev(topk_idx, "topk_idx", torch.int32), _dev(topk_val, "topk_val"),
+                                              _dev(workspace, "workspace", torch.uint8), workspace.numel(), _stream()),
+               "score_topk")
+
+
+def rank_metrics(topk_idx, truth_ptr, truth_items, metric_ids, out):
+    B, K = topk_idx.shape
+    ids = (ctypes.c_int * len(metric_ids))(*metric_ids)
+    assert topk_idx.is_contiguous() and out.is_contiguous()
+    _lib.check(_lib.load().elimrec_rank_metrics(_dev(topk_idx, "topk_idx", torch.int32), B, K,
+                                                _dev(truth_ptr, "truth_ptr", torch.int64),
+                                                _dev(truth_items, "truth_items", torch.int32), ids, len(metric_ids),
+                                                _dev(out, "out"), _stream()), "rank_metrics")
+    return out
+
+
+def sample_triplets(user_ids, ptr, items, num_items, n, seed, epoch, users, pos, neg):
+    _lib.check(_lib.load().elimrec_sample_triplets(_dev(user_ids, "user_ids", torch.int32), _dev(ptr, "ptr", torch.int64),
+                                                   _dev(items, "items", torch.int32), user_ids.numel(), num_items, n,
+                                                   int(seed), int(epoch), _dev(users, "users", torch.int64),
+                                                   _dev(pos, "pos", torch.int64), _dev(neg, "neg", torch.int64),
+                                                   _stream()), "sample_triplets")

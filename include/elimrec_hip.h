@@ -1,0 +1,190 @@
+/* libelimrec_hip.so -- C ABI of the MI355X (gfx950) EliMRec hot path.
+ *
+ * Plain pointers and sizes only: no torch types, no C++ in the signatures. Every pointer
+ * argument named d_* is a DEVICE pointer (HBM); `stream` is a hipStream_t passed as void*
+ * (NULL = the default stream). All work is enqueued asynchronously on `stream`; nothing here
+ * synchronises the host, allocates device memory or frees it (workspace comes from the caller),
+ * so every entry point may be captured into a hipGraph.
+ *
+ * Return value: 0 on success, non-zero on failure (hipError_t value, or ELIMREC_E_*);
+ * elimrec_last_error() returns a thread-local message for the most recent failure.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the
+ * reference repository root, Xiaohao-Liu/EliMRec). The reference has no FFI of its own for
+ * the model path (it is stock PyTorch); the binding a maintainer adds is the ctypes stub in
+ * INTEGRATION.md (elimrec_amd/_lib.py is that stub, as shipped).
+ *
+ * Layout conventions (all row-major, fp32 unless said otherwise):
+ *   N = U + I graph nodes: users first, then items (models/EliMRec.py:239,316).
+ *   X  [N x C]   propagated tables, C = M*d: column block m holds table m (0 = id, then v,a,t).
+ *   Y  [N x Cy]  head outputs, Cy = (1+S)*d: block 0 = fused embedding (all_users/all_items),
+ *                block 1+s = single-modal head s (pre_fusion_{user,item}_{v,a,t}).
+ */
+#ifndef ELIMREC_HIP_H
+#define ELIMREC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ELIMREC_ABI_VERSION 1
+#define ELIMREC_E_BADARG 10001
+#define ELIMREC_E_UNSUPPORTED 10002
+#define ELIMREC_E_WORKSPACE 10003
+
+int elimrec_abi_version(void);
+const char *elimrec_last_error(void);
+
+/* ---------------------------------------------------------------- dense projections (K1,K5,K8)
+ * C[m, n] = sum_k A[m, k] * W[n, k] + bias[n]      (torch.nn.Linear; bias may be NULL)
+ * Replaces: v_dense/a_dense/t_dense (models/EliMRec.py:233-236), embedding_{user,item}_after_GCN
+ * (:262-270) and s_dense_{v,a,t} (:146-151). fp32-input MFMA (v_mfma_f32_32x32x2_f32).
+ * Leading dimensions in elements. Requires K % 4 == 0, lda % 4 == 0, ldw % 4 == 0 and 16-byte
+ * aligned A, W rows. */
+int elimrec_linear_fwd(const float *d_A, int64_t lda, const float *d_W, int64_t ldw,
+                       const float *d_bias, float *d_C, int64_t ldc,
+                       int64_t M, int N, int K, void *stream);
+
+/* out[i, j] (+)= sum_{r in rows} A[r, i] * B[row_index ? row_index[r] : r, j]
+ * the weight-gradient contraction of a Linear layer (AddmmBackward of the calls above) with a
+ * deterministic two-stage reduction: fixed row chunks -> partial slabs in workspace -> summed in
+ * chunk order. Rows r run over [range[0], range[1]) if d_range != NULL (device int32[2]) else
+ * [0, R). d_colsum (nullable, [n1]) additionally receives sum_r A[r, i] (the bias gradient).
+ * workspace: elimrec_linear_bwd_w_workspace(R, n1, n2) bytes. */
+size_t elimrec_linear_bwd_w_workspace(int64_t R, int n1, int n2);
+int elimrec_linear_bwd_w(const float *d_A, int64_t lda, const float *d_B, int64_t ldb,
+                         const int32_t *d_row_index, const int32_t *d_range, int64_t R,
+                         int n1, int n2, float *d_out, int64_t ldo, float *d_colsum,
+                         int accumulate, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* ---------------------------------------------------------------- layer-0 table assembly (K2)
+ * X0[u, m*d + j] = user_emb[u, j] for every table m;  X0[U+i, j] = item_emb[i, j].
+ * Column blocks 1..M-1 of the item rows are written by elimrec_linear_fwd (ldc = C).
+ * Replaces torch.cat([u_emb, i_emb]) x M (models/EliMRec.py:239,250-256). */
+int elimrec_assemble_x0(const float *d_user_emb, const float *d_item_emb, float *d_X0,
+                        int64_t U, int64_t I, int d, int M, void *stream);
+
+/* ---------------------------------------------------------------- LightGCN propagation (K3,K4)
+ * One hop over a CSR matrix (int32 rowptr[n_rows+1], int32 col, fp32 val) for all C columns:
+ *   r = sum_j val[j] * Xin[col[j], :]
+ *   if Xout   : Xout[row]   = r
+ *   if AccOut : AccOut[row] = (AccIn[row] + r) * scale        (AccIn may alias AccOut)
+ * Replaces torch.sparse.mm (models/EliMRec.py:244) fused with the stack+mean of :246-247.
+ * Requires C % 4 == 0. */
+int elimrec_spmm_hop(const int32_t *d_rowptr, const int32_t *d_col, const float *d_val,
+                     int64_t n_rows, int C, const float *d_Xin, float *d_Xout,
+                     const float *d_AccIn, float *d_AccOut, float scale, void *stream);
+
+/* L hops + mean of the L+1 layer outputs: Out = 1/(L+1) * sum_k A^k X0   (compute_graph,
+ * models/EliMRec.py:238-248, for all M tables at once). d_tmp0/d_tmp1: two [n_rows x C]
+ * scratch tables (unused when L <= 1 / L <= 2). X0 is left intact. Out must not alias X0. */
+int elimrec_propagate(const int32_t *d_rowptr, const int32_t *d_col, const float *d_val,
+                      int64_t n_rows, int C, int L, const float *d_X0, float *d_tmp0,
+                      float *d_tmp1, float *d_Out, void *stream);
+
+/* ---------------------------------------------------------------- cosine-BPR head (K7,K9,K10)
+ * For triplet b and head block k (weight w[k]; w[k] == 0 skips the block):
+ *   a = Y[users[b]], p = Y[U+pos[b]], n = Y[U+neg[b]]  (block k of each row)
+ *   x = cos(a,n) - cos(a,p);  loss_b += w[k] * softplus(x) / B
+ * d_loss_rows[b] = loss_b. If d_grad_rows != NULL it receives d(sum_b loss_b)/dY for the three
+ * gathered rows of every triplet as [3B x Cy] rows (order u,p,n per triplet) and d_keys[3B]
+ * the node ids (u, U+p, U+n) they belong to. Replaces getEmbedding's gathers + original_bpr_loss
+ * x (1+|modality|) + their autograd (models/EliMRec.py:129-142,277-287,291-297).
+ * F.normalize eps 1e-12, softplus threshold 20 as in torch. */
+int elimrec_bpr_head(const float *d_Y, int64_t ldy, int64_t U, int64_t I,
+                     const int64_t *d_users, const int64_t *d_pos, const int64_t *d_neg, int B,
+                     int d, int n_blocks, const float *block_weights /* host, n_blocks */,
+                     float *d_loss_rows, float *d_grad_rows, int32_t *d_keys, void *stream);
+
+/* out[0] = sum_i x[i] in a fixed order (single workgroup, deterministic). */
+int elimrec_sum(const float *d_x, int64_t n, float *d_out, void *stream);
+
+/* ---------------------------------------------------------------- deterministic row scatter-add
+ * IndexBackward/index_put(accumulate) replacement: sorts (key, source row) pairs
+ * (stable radix sort), sums rows with equal keys in ascending source order.
+ * Outputs: d_active_rows[n] sorted unique keys (first n_active valid), d_reduced [n x ld] the
+ * summed rows, d_seg_info int32[8] = {n_active, n_lo = #active keys < split_key,
+ * (0, n_lo), (n_lo, n_active), (0, n_active)}: the three (begin,end) pairs are slot ranges in
+ * the form elimrec_linear_bwd_w's d_range takes (users / items / all, with split_key = U).
+ * workspace: elimrec_segment_reduce_workspace(n) bytes. */
+size_t elimrec_segment_reduce_workspace(int64_t n);
+int elimrec_segment_reduce_rows(const float *d_rows, const int32_t *d_keys, int64_t n, int ld,
+                                int32_t split_key, int32_t *d_active_rows, float *d_reduced,
+                                const float *d_scale /* nullable device fp32[1]: multiplies every sum */,
+                                int32_t *d_seg_info, void *d_workspace, size_t workspace_bytes,
+                                void *stream);
+
+/* ---------------------------------------------------------------- head backward wrt its input
+ * For active row s < n_active (node r = active_rows[s]):
+ *   G0[r, :] = dY[s, 0:d] . Wf(r)  +  sum_h dY[s, (1+h)*d : (2+h)*d] . Ws_h  placed in block mblock[h]
+ * with Wf = W_user [d x C] for r < U else W_item. G0 must be zero-filled by the caller; rows
+ * not in the active list stay zero. `gscale` multiplies everything (upstream d loss).
+ * AddmmBackward (dX) of embedding_*_after_GCN and s_dense_* restricted to the rows whose
+ * gradient is non-zero. head_mblock: host int[S], table index (1..M-1) feeding head h. */
+int elimrec_head_bwd_input(const float *d_dY, int64_t lddy, const int32_t *d_active_rows,
+                           const int32_t *d_seg_info, int64_t n_max, int64_t U, int d, int C,
+                           int S, const int *head_mblock, const float *d_W_user,
+                           const float *d_W_item, const float *const *d_W_heads /* host array of S device ptrs */,
+                           float gscale, float *d_G0, void *stream);
+
+/* ---------------------------------------------------------------- embedding gradients (K2 bwd)
+ * dE_user[u, j] = sum_m G[u, m*d + j];  dE_item[i, j] = G[U+i, j]   (CatBackward of :239). */
+int elimrec_embed_grad(const float *d_G, int64_t U, int64_t I, int d, int M,
+                       float *d_grad_user, float *d_grad_item, void *stream);
+
+/* ---------------------------------------------------------------- optimiser (K11)
+ * torch.optim.Adam single-tensor step with coupled L2 (main.py:49,101):
+ *   g += wd*p; m = m + (1-b1)(g-m); v = b2*v + (1-b2) g*g;
+ *   p -= (lr/(1-b1^t)) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * over n contiguous elements. `step` is the 1-based step count t. */
+int elimrec_adam_step(float *d_p, const float *d_g, float *d_m, float *d_v, int64_t n,
+                      float lr, float beta1, float beta2, float eps, float weight_decay,
+                      int64_t step, void *stream);
+
+/* ---------------------------------------------------------------- counterfactual scoring (K12-K16)
+ * scores[b, i] for users rows `d_users` (node ids < U) against every item:
+ *   ui = sigmoid(<Yf[u], Yf[U+i]>)
+ *   z_h = <Ys_h[u]/|.|, Ys_h[U+i]/|.|>                     (general_cm_fusion, normalize=True)
+ *   fusion_mode 0 (rubi): f(x) = x * prod_{h in mask} sigmoid(z_h)
+ *               1 (hm)  : t = sigmoid(x) * prod_h sigmoid(z_h); f = log(t+1e-12) - log1p(t)
+ *               2 (sum) : f = log(sigmoid(x + sum_h z_h) + 1e-12)
+ *   predict_type 0 (normal): sigmoid(ui) ; 1 (TE): sigmoid(f(ui)) ;
+ *                2 (TIE): sigmoid(f(ui) - f(mean_i ui))
+ * Replaces EliMRec.predict + general_cm_fusion (models/EliMRec.py:96-113,155-212).
+ * d_train_ptr/d_train_items (nullable): CSR over the B rows of items to overwrite with -inf
+ * (cpp/uni_evaluator.py:149-154). d_scores [B x I] may be NULL when only top-K is wanted.
+ * d_topk_idx/d_topk_val [B x K] (nullable): per-row top-K by (score desc, index asc).
+ * workspace: elimrec_score_workspace(B, I, K) bytes. */
+size_t elimrec_score_workspace(int B, int64_t I, int K);
+int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int64_t I, const int64_t *d_users,
+                       int B, int d, int S, uint32_t head_mask, int fusion_mode, int predict_type,
+                       const int64_t *d_train_ptr, const int32_t *d_train_items,
+                       float *d_scores, int64_t lds, int K, int32_t *d_topk_idx, float *d_topk_val,
+                       void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Precision/Recall/MAP/NDCG/MRR prefix curves @1..K from ranked lists (metric.h:17-106).
+ * d_truth_ptr int64[B+1], d_truth_items int32 (unique per row). metric_ids host int[n_metrics]
+ * (1..5 as in cpp/uni_evaluator.py:14). d_out [B x n_metrics x K]. */
+int elimrec_rank_metrics(const int32_t *d_topk_idx, int B, int K, const int64_t *d_truth_ptr,
+                         const int32_t *d_truth_items, const int *metric_ids, int n_metrics,
+                         float *d_out, void *stream);
+
+/* ---------------------------------------------------------------- pairwise sampler (K20)
+ * n triplets: user uniform over the `n_train_users` users with >= 1 training item (with
+ * replacement), positive uniform over that user's training items, negative uniform over [0,I)
+ * rejecting the user's training items (data/sampler.py:93-126; random_choice.pyx:20-62).
+ * Counter-based Philox4x32-10 keyed by (seed, epoch): the stream differs from libc rand() by
+ * construction; the contract is distributional. d_user_ids int32[n_train_users]; d_ptr
+ * int64[n_train_users+1]; d_items int32 sorted ascending within each user. */
+int elimrec_sample_triplets(const int32_t *d_user_ids, const int64_t *d_ptr, const int32_t *d_items,
+                            int64_t n_train_users, int64_t I, int64_t n, uint64_t seed,
+                            uint64_t epoch, int64_t *d_users, int64_t *d_pos, int64_t *d_neg,
+                            void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ELIMREC_HIP_H */

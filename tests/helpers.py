@@ -35,3 +35,68 @@ def rel_err(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+# --------------------------------------------------------------------------- product-side builders
+def make_config(argv_extra=()):
+    """The real Configurator over the repo's NeuRec.properties / conf/EliMRec.properties."""
+    from elimrec_amd import Configurator
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        return Configurator(os.path.join(ROOT, "NeuRec.properties"), default_section="hyperparameters",
+                            argv=["main.py"] + list(argv_extra))
+    finally:
+        os.chdir(cwd)
+
+
+class FixtureDataset(object):
+    """Dataset facade over a golden fixture (same accessors as elimrec_amd.dataset)."""
+
+    def __init__(self, g):
+        import scipy.sparse as sp
+        import torch
+        self.num_users, self.num_items = int(g["num_users"]), int(g["num_items"])
+        self.dataset_name = str(g["dataset_name"])
+        self._dicts = {s: csr_dict(g, s) for s in ("train", "valid", "test")}
+        tu, ti = g["train_u"], g["train_i"]
+        self.train_matrix = sp.csr_matrix((np.ones(len(tu)), (tu, ti)), shape=(self.num_users, self.num_items))
+        for m in ("v", "a", "t"):
+            if (m + "_feat") in g:
+                setattr(self, m + "_feat", torch.from_numpy(g[m + "_feat"].copy()))
+        self._g = g
+
+    def get_train_interactions(self):
+        return self._g["train_u"].tolist(), self._g["train_i"].tolist()
+
+    def get_user_train_dict(self, by_time=False):
+        return self._dicts["train"]
+
+    def get_user_valid_dict(self):
+        return self._dicts["valid"]
+
+    def get_user_test_dict(self):
+        return self._dicts["test"]
+
+
+def fixture_argv(g):
+    argv = ["--recommender=EliMRec", "--data.input.dataset=%s" % str(g["dataset_name"]), "--alpha=%r" % float(g["alpha"]),
+            "--loss=bpr_loss", "--recdim=%d" % int(g["recdim"]), "--layer_num=%d" % int(g["layer_num"]),
+            "--adj_type=%s" % str(g["adj_type"]), "--modality=%s" % str(g["modality"]),
+            "--mm_fusion_mode=%s" % str(g["mm_fusion_mode"]), "--verbose=0"]
+    return argv
+
+
+def build_model_from_fixture(g, device, params_prefix="init"):
+    """elimrec_amd.EliMRec on `device` holding the fixture's graph, features and parameters."""
+    import torch
+    from elimrec_amd import EliMRec
+    cfg = make_config(fixture_argv(g))
+    model = EliMRec(cfg, FixtureDataset(g))
+    with torch.no_grad():
+        for m in ("v", "a", "t"):
+            if (m + "_feat") in g and hasattr(model, m + "_feat"):
+                getattr(model, m + "_feat").copy_(torch.from_numpy(g[m + "_feat"]))   # exact reference bits
+    sd = {k: torch.from_numpy(v.copy()) for k, v in sub(g, params_prefix).items()}
+    model.load_state_dict(sd, strict=True)
+    return model.to(device), cfg

@@ -1,0 +1,354 @@
+"""Parity of the HIP path (through the C ABI) against the golden vectors captured from the
+reference and against the CPU oracle on seeded inputs. Needs a real MI355X: `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_model_from_fixture, csr_dict, load_golden, rel_err, sub
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+# ----------------------------------------------------------------------------- golden fixtures
+def test_training_steps_match_reference(fixture_name):
+    """loss to 1e-5 abs, every parameter gradient to 1e-4 rel (north_star tolerance), the same
+    set of parameters receives a gradient, parameters after Adam steps to 2e-5 abs."""
+    from elimrec_amd import FusedAdam
+    g = load_golden(fixture_name)
+    model, cfg = build_model_from_fixture(g, DEV)
+    opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    steps = int(g["steps"])
+    for t in range(1, steps + 1):
+        u, p, n = (_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg"))
+        loss = model.bpr_loss(u, p, n)
+        opt.zero_grad()
+        loss.backward(retain_graph=True)
+        assert abs(loss.cpu().item() - float(g["step%d/loss" % t])) < 1e-5, t
+        if t == 1:
+            assert rel_err(model.all_users.cpu(), g["fwd1/all_users"]) < 1e-4
+            assert rel_err(model.all_items.cpu(), g["fwd1/all_items"]) < 1e-4
+            ref = sub(g, "grad1")
+            mine = {k: p_.grad for k, p_ in model.named_parameters() if p_.grad is not None}
+            assert set(mine) == set(ref)
+            for k, gr in ref.items():
+                assert rel_err(mine[k].cpu(), gr) < 1e-4, k
+        opt.step()
+        if t in (1, steps):
+            sd = model.state_dict()
+            for k, v in sub(g, "after%d" % t).items():
+                assert np.abs(sd[k].cpu().numpy() - v).max() < 2e-5, (t, k)
+
+
+def test_adam_kernel_given_reference_grads(fixture_name):
+    from elimrec_amd import FusedAdam
+    g = load_golden(fixture_name)
+    model, _ = build_model_from_fixture(g, DEV)
+    opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    ref = sub(g, "grad1")
+    for k, p_ in model.named_parameters():
+        if k in ref:
+            p_.grad = _t(ref[k])
+    opt.step()
+    sd = model.state_dict()
+    for k, v in sub(g, "after1").items():
+        assert np.abs(sd[k].cpu().numpy() - v).max() <= 2.4e-7, k
+        if k not in ref:
+            assert np.array_equal(sd[k].cpu().numpy(), g["init/" + k])
+
+
+def _load_cache(model, g):
+    """Put the reference's cached tables (state after its last training forward) into Y."""
+    ws = model._workspace(8)
+    c = sub(g, "cache")
+    U, d = model.num_users, model.latent_dim
+    Y = ws["Y"]
+    Y[:U, :d] = _t(c["all_users"])
+    Y[U:, :d] = _t(c["all_items"])
+    for h, m in enumerate(model._mods):
+        Y[:U, (h + 1) * d:(h + 2) * d] = _t(c["pre_fusion_user_" + m])
+        Y[U:, (h + 1) * d:(h + 2) * d] = _t(c["pre_fusion_item_" + m])
+    model._publish_cache(Y)
+
+
+def test_predict_modes_match_reference(fixture_name):
+    g = load_golden(fixture_name)
+    model, _ = build_model_from_fixture(g, DEV)
+    _load_cache(model, g)
+    users = g["eval_users"].tolist()
+    for key, want in sub(g, "predict").items():
+        model.fusion_mode, model.predict_type = key.split("/")
+        got = model.predict(users)
+        assert isinstance(got, torch.Tensor) and got.device.type == "cpu" and got.dtype == torch.float32
+        assert got.shape == want.shape
+        assert np.abs(got.numpy() - want).max() < 1e-5, key
+
+
+def test_predict_after_training_uses_stale_tables(fixture_name):
+    """End to end: train `steps` steps on the GPU, then predict() must match the reference's
+    predict() (tables from the last forward, i.e. pre-update parameters)."""
+    from elimrec_amd import FusedAdam
+    g = load_golden(fixture_name)
+    model, _ = build_model_from_fixture(g, DEV)
+    opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    for t in range(1, int(g["steps"]) + 1):
+        loss = model.bpr_loss(*(_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg")))
+        opt.zero_grad()
+        loss.backward(retain_graph=True)
+        opt.step()
+    assert rel_err(model.all_users.cpu(), g["cache/all_users"]) < 1e-4
+    model.fusion_mode, model.predict_type = "rubi", "TIE"
+    got = model.predict(g["eval_users"].tolist()).numpy()
+    assert np.abs(got - g["predict/rubi/TIE"]).max() < 1e-5
+
+
+def _tie_free(scores, k):
+    """rows whose k+1 largest values are pairwise distinct (no tie at or across the K boundary)."""
+    s = -np.sort(-scores, axis=1)[:, :k + 1]
+    return np.all(s[:, :-1] != s[:, 1:], axis=1)
+
+
+def test_device_evaluator_matches_reference(fixture_name):
+    """Masked top-K indices: exact where the reference row has no tie at/across K, otherwise
+    score-equivalent under the reference's own scores; metric rows then equal the oracle's."""
+    from oracle import eval_oracle as ev
+    g = load_golden(fixture_name)
+    model, _ = build_model_from_fixture(g, DEV)
+    _load_cache(model, g)
+    model.fusion_mode, model.predict_type = "rubi", "TIE"
+    users = g["evalbatch/users"].tolist()
+    K = int(g["evalbatch/top_k"])
+    evalr = model.test_evaluator.evaluator
+    rows, idx, val = evalr.evaluate_batch(model, users, return_topk=True)
+    idx = idx.cpu().numpy()
+    ref_scores = g["evalbatch/masked_scores"]
+    test = csr_dict(g, "test")
+    tp, ti = ev.truth_to_csr([sorted(set(test[int(u)])) for u in users])
+    ref_rows, ref_topk = ev.evaluate_matrix(ref_scores, tp, ti, g["evalbatch/metric_ids"], K)
+    clean = _tie_free(ref_scores, K)
+    assert clean.sum() > 0
+    dev_scores = torch.empty(len(users), model.num_items, device=DEV)
+    # the device's own masked scores, to tell real mismatches from 1-ulp score differences
+    train_ptr, train_items = evalr._batch_csr(users, evalr.user_pos_train, DEV, unique=False)
+    model.predict_device(users, scores=dev_scores, train_ptr=train_ptr, train_items=train_items)
+    dev_scores = dev_scores.cpu().numpy()
+    assert np.array_equal(np.isinf(dev_scores), np.isinf(ref_scores))          # same items masked
+    finite = ~np.isinf(ref_scores)
+    assert np.abs(dev_scores[finite] - ref_scores[finite]).max() < 1e-5
+    for r in range(len(users)):
+        same_order = np.array_equal(np.argsort(-dev_scores[r], kind="stable")[:K], np.argsort(-ref_scores[r], kind="stable")[:K])
+        if clean[r] and same_order:
+            assert np.array_equal(idx[r], ref_topk[r]), r
+        # score-equivalence under the DEVICE scores: rank k holds the k-th largest device score
+        assert np.array_equal(dev_scores[r][idx[r]], -np.sort(-dev_scores[r])[:K]), r
+    # metric kernel vs oracle on the device's own ranking
+    want = ev.metrics_from_rank(idx, tp, ti, g["evalbatch/metric_ids"], K)
+    assert np.abs(rows.cpu().numpy() - want).max() < 1e-6
+    # whole evaluate(): same numbers as the reference unless a boundary tie moved an item
+    for ptype in ("TE", "TIE"):
+        model.predict_type = ptype
+        res, buf = model.test()
+        assert res.dtype == np.float32 and res.shape == (3,) and len(buf.split("\t")) == 3
+        assert np.abs(res - g["evaluate/%s/test" % ptype]).max() < 2e-2
+
+
+# ----------------------------------------------------------------------------- op-level vs oracle
+def test_linear_fwd_and_bwd_w_vs_torch():
+    from elimrec_amd import ops
+    gen = torch.Generator().manual_seed(0)
+    for (M, N, K, lda_pad) in [(1000, 64, 128, 0), (777, 32, 40, 24), (130, 96, 2048, 0), (5, 16, 8, 8), (4096, 64, 256, 0)]:
+        A_full = torch.randn(M, K + lda_pad, generator=gen)
+        W = torch.randn(N, K, generator=gen) * 0.1
+        b = torch.randn(N, generator=gen)
+        out_full = torch.zeros(M, N + 16)
+        A_d, W_d, b_d, out_d = A_full.to(DEV), W.to(DEV), b.to(DEV), out_full.to(DEV)
+        ops.linear_fwd(A_d[:, :K], W_d, b_d, out_d[:, 8:8 + N])
+        want = A_full[:, :K].double() @ W.double().T + b.double()
+        got = out_d.cpu()
+        assert rel_err(got[:, 8:8 + N], want) < 2e-6
+        assert got[:, :8].abs().max() == 0 and got[:, 8 + N:].abs().max() == 0   # neighbours untouched
+        # weight gradient: out[i,j] = sum_r A2[r,i] * B2[idx[r], j]
+        G = torch.randn(M, N, generator=gen)
+        idx = torch.randint(0, M, (M,), generator=gen, dtype=torch.int32)
+        ws = torch.empty(ops.linear_bwd_w_workspace(M, N, K), dtype=torch.uint8, device=DEV)
+        gw = torch.empty(N, K, device=DEV)
+        gb = torch.empty(N, device=DEV)
+        ops.linear_bwd_w(G.to(DEV), A_d[:, :K], gw, ws, colsum=gb)
+        assert rel_err(gw.cpu(), G.double().T @ A_full[:, :K].double()) < 5e-6
+        assert rel_err(gb.cpu(), G.double().sum(0)) < 5e-6
+        rng = torch.tensor([M // 5, M - 3], dtype=torch.int32, device=DEV)
+        ops.linear_bwd_w(G.to(DEV), A_d[:, :K], gw, ws, row_index=idx.to(DEV), rng=rng, colsum=gb)
+        lo, hi = M // 5, M - 3
+        want = G[lo:hi].double().T @ A_full[idx[lo:hi].long(), :K].double()
+        assert rel_err(gw.cpu(), want) < 5e-6
+        gw2 = gw.clone()
+        ops.linear_bwd_w(G.to(DEV), A_d[:, :K], gw2, ws, row_index=idx.to(DEV), rng=rng, accumulate=True)
+        assert rel_err(gw2.cpu(), 2 * want) < 5e-6
+        # bitwise reproducible
+        gw3 = torch.empty_like(gw)
+        ops.linear_bwd_w(G.to(DEV), A_d[:, :K], gw3, ws, row_index=idx.to(DEV), rng=rng)
+        assert torch.equal(gw3, gw)
+
+
+def _random_graph(n, nnz, seed):
+    import scipy.sparse as sp
+    rs = np.random.RandomState(seed)
+    r = rs.randint(n, size=nnz)
+    c = (rs.zipf(1.6, size=nnz) - 1) % n          # skewed columns
+    m = sp.csr_matrix((rs.rand(nnz).astype(np.float32), (r, c)), shape=(n, n))
+    m.sum_duplicates()
+    m.sort_indices()
+    return m
+
+
+@pytest.mark.parametrize("C,L", [(256, 3), (128, 2), (64, 1), (512, 3), (48, 4), (256, 0)])
+def test_propagate_vs_oracle(C, L):
+    from elimrec_amd import ops
+    n = 3000
+    m = _random_graph(n, 40000, seed=C + L).tolil()
+    m[17, :] = 0                                   # an empty row
+    m[5, :] = 0.01                                 # a very long row (n non-zeros)
+    m = m.tocsr().astype(np.float32)
+    m.eliminate_zeros()
+    m.sort_indices()
+    X0 = torch.randn(n, C, generator=torch.Generator().manual_seed(1))
+    csr = ops.Csr.from_scipy(m, DEV)
+    X0d = X0.to(DEV)
+    t0, t1, out = torch.empty_like(X0d), torch.empty_like(X0d), torch.empty_like(X0d)
+    ops.propagate(csr, X0d, L, t0, t1, out)
+    coo = m.tocoo()
+    A = torch.sparse_coo_tensor(np.vstack([coo.row, coo.col]), coo.data, (n, n)).double()
+    x = X0.double()
+    acc = x.clone()
+    for _ in range(L):
+        x = torch.sparse.mm(A, x)
+        acc += x
+    want = acc / (L + 1)
+    assert rel_err(out.cpu(), want) < 2e-6
+    assert torch.equal(X0d.cpu(), X0)              # X0 left intact
+    out2 = torch.empty_like(out)
+    ops.propagate(csr, X0d, L, t0, t1, out2)
+    assert torch.equal(out, out2)                  # deterministic
+
+
+def test_propagate_linearity_at_tiktok_shape():
+    """Size-independent property at the full BASELINE shape: P(aX + bZ) == aP(X) + bP(Z), and
+    <P(X), Z> == <X, P^T(Z)> for the symmetric 'pre' adjacency (self-adjointness used by backward)."""
+    from elimrec_amd import SyntheticDataset, ops
+    from elimrec_amd.model import create_adj_mat
+    ds = SyntheticDataset(36656, 76085, 720829, feat_dims=(4, 4, 4), seed=0)
+    tu, ti = ds.get_train_interactions()
+    adj = create_adj_mat(tu, ti, ds.num_users, ds.num_items, "pre")
+    csr = ops.Csr.from_scipy(adj, DEV)
+    n, C = adj.shape[0], 256
+    g = torch.Generator(device=DEV).manual_seed(0)
+    X, Z = torch.randn(n, C, device=DEV, generator=g), torch.randn(n, C, device=DEV, generator=g)
+    t0, t1 = torch.empty_like(X), torch.empty_like(X)
+    PX, PZ, PXZ = torch.empty_like(X), torch.empty_like(X), torch.empty_like(X)
+    ops.propagate(csr, X, 3, t0, t1, PX)
+    ops.propagate(csr, Z, 3, t0, t1, PZ)
+    ops.propagate(csr, 0.5 * X - 2.0 * Z, 3, t0, t1, PXZ)
+    assert rel_err((0.5 * PX - 2.0 * PZ).cpu(), PXZ.cpu()) < 1e-5
+    a = (PX.double() * Z.double()).sum().item()
+    b = (X.double() * PZ.double()).sum().item()
+    assert abs(a - b) < 1e-6 * max(abs(a), 1.0)
+
+
+def test_bpr_head_and_segment_reduce_vs_torch_autograd():
+    from elimrec_amd import ops
+    gen = torch.Generator().manual_seed(3)
+    for (U, I, d, nb, B) in [(200, 300, 64, 4, 257), (50, 60, 32, 2, 64), (40, 40, 256, 4, 33), (64, 64, 16, 3, 100)]:
+        Y = torch.randn(U + I, nb * d, generator=gen)
+        Y[3] = 0.0                                                  # a zero row exercises the eps branch
+        u = torch.randint(0, U, (B,), generator=gen)
+        u[:5] = 3
+        p = torch.randint(0, I, (B,), generator=gen)
+        n = torch.randint(0, I, (B,), generator=gen)
+        w = [1.0, 0.5, 0.0, 0.25][:nb]
+        Yr = Y.clone().double().requires_grad_(True)
+        total = 0
+        F = torch.nn.functional
+        for k in range(nb):
+            blk = Yr[:, k * d:(k + 1) * d]
+            a, pp, nn_ = F.normalize(blk[u], dim=1), F.normalize(blk[U + p], dim=1), F.normalize(blk[U + n], dim=1)
+            total = total + w[k] * torch.mean(F.softplus((a * nn_).sum(1) - (a * pp).sum(1)))
+        total.backward()
+        Yd = Y.to(DEV)
+        loss_rows = torch.empty(B, device=DEV)
+        grad_rows = torch.empty(3 * B, nb * d, device=DEV)
+        keys = torch.empty(3 * B, dtype=torch.int32, device=DEV)
+        ops.bpr_head(Yd, U, I, u.to(DEV), p.to(DEV), n.to(DEV), d, w, loss_rows, grad_rows, keys)
+        loss = torch.empty((), device=DEV)
+        ops.fixed_order_sum(loss_rows, loss)
+        assert abs(loss.item() - total.item()) < 2e-6
+        act = torch.empty(3 * B, dtype=torch.int32, device=DEV)
+        red = torch.zeros(3 * B, nb * d, device=DEV)
+        seg = torch.zeros(8, dtype=torch.int32, device=DEV)
+        ws = torch.empty(ops.segment_reduce_workspace(3 * B), dtype=torch.uint8, device=DEV)
+        ops.segment_reduce_rows(grad_rows, keys, U, act, red, seg, ws)
+        info = seg.cpu().tolist()
+        want_rows = np.unique(np.concatenate([u.numpy(), U + p.numpy(), U + n.numpy()]))
+        assert info[0] == len(want_rows) and info[1] == int((want_rows < U).sum())
+        assert info[2:] == [0, info[1], info[1], info[0], 0, info[0]]
+        assert np.array_equal(act.cpu().numpy()[:info[0]], want_rows)
+        dense = torch.zeros(U + I, nb * d, dtype=torch.float64)
+        dense[act[:info[0]].cpu().long()] = red[:info[0]].cpu().double()
+        gref = Yr.grad.clone()
+        assert torch.isfinite(dense[3]).all()
+        assert rel_err(dense[3], gref[3]) < 1e-5     # zero-norm row: the v/eps branch (values ~1e9)
+        gref[3] = 0
+        dense[3] = 0
+        assert rel_err(dense, gref) < 1e-5
+        red2 = torch.zeros_like(red)
+        ops.segment_reduce_rows(grad_rows, keys, U, act, red2, seg, ws, scale=torch.full((1,), 2.0, device=DEV))
+        assert torch.equal(red2[:info[0]], 2 * red[:info[0]])       # deterministic + scale
+
+
+def test_sampler_contract_on_device():
+    from elimrec_amd import PairwiseSamplerV2, SyntheticDataset
+    ds = SyntheticDataset(400, 300, 6000, feat_dims=(4, 4, 4), seed=9)
+    smp = PairwiseSamplerV2(ds, batch_size=512, device=DEV, seed=7)
+    train = ds.get_user_train_dict()
+    us, ps, ns, nb = [], [], [], 0
+    for bu, bp, bn in smp:
+        assert bu.device.type == "cuda" and bu.dtype == torch.int64 and len(bu) == len(bp) == len(bn) <= 512
+        us.append(bu.cpu()); ps.append(bp.cpu()); ns.append(bn.cpu()); nb += 1
+    assert nb == len(smp)
+    u, p, n = torch.cat(us).numpy(), torch.cat(ps).numpy(), torch.cat(ns).numpy()
+    assert len(u) == smp.num_trainings
+    sets = {k: set(v) for k, v in train.items()}
+    assert all(int(a) in sets for a in u)
+    assert all(int(b) in sets[int(a)] for a, b in zip(u, p))
+    assert all(int(c) not in sets[int(a)] and 0 <= c < ds.num_items for a, c in zip(u, n))
+    # users uniform over users with >= 1 training item (chi-square, 5 sigma)
+    counts = np.bincount(u, minlength=ds.num_users)[sorted(sets)]
+    exp = len(u) / len(sets)
+    chi2 = ((counts - exp) ** 2 / exp).sum()
+    assert abs(chi2 - len(sets)) < 5 * np.sqrt(2 * len(sets))
+    # negatives uniform over the catalogue
+    cn = np.bincount(n, minlength=ds.num_items)
+    assert cn.min() > 0 and cn.max() < 4 * len(n) / ds.num_items
+    # a new epoch draws a new stream; the same (seed, epoch) replays
+    u2, _, _ = smp.sample_epoch()
+    assert not np.array_equal(u2.cpu().numpy(), u)
+    smp2 = PairwiseSamplerV2(ds, batch_size=512, device=DEV, seed=7)
+    assert np.array_equal(smp2.sample_epoch()[0].cpu().numpy(), u)
+
+
+def test_rank_metrics_and_topk_known_answers():
+    """Device top-K + metric kernels against the reference's own outputs (tests/golden/metrics.npz)."""
+    from elimrec_amd import ops
+    from oracle import eval_oracle as ev
+    g = load_golden("metrics")
+    for c in range(int(g["n_cases"])):
+        s, k = g["case%d/scores" % c], int(g["case%d/top_k" % c])
+        tp, ti = g["case%d/truth_ptr" % c], g["case%d/truth_items" % c]
+        _, ref_topk = ev.evaluate_matrix(s, tp, ti, [1, 2, 3, 4, 5], k)
+        out = torch.empty(s.shape[0], 5 * k, device=DEV)
+        ops.rank_metrics(_t(ref_topk), _t(tp), _t(ti), [1, 2, 3, 4, 5], out)
+        assert np.abs(out.cpu().numpy() - g["case%d/result" % c]).max() < 1e-7, c   # same ranking -> same metrics

@@ -1,0 +1,139 @@
+"""CPU-side tests: config surface, iterator/sampler bookkeeping, model construction, C-ABI exports."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROOT, build_model_from_fixture, load_golden, make_config, sub
+
+
+def test_configurator_resolution_rules():
+    cfg = make_config(["--alpha=0.5", "--loss=bpr_loss", "--batch_size=1024", "--recdim=32", "--newkey=[1,2]"])
+    assert cfg["batch_size"] == 1024 and cfg.batch_size == 1024          # CLI overrides a key present in the file
+    assert cfg["recdim"] == 32 and cfg["lr"] == 0.001 and cfg["weight_decay"] == 1e-4
+    assert cfg["alpha"] == 0.5 and cfg["loss"] == "bpr_loss"              # CLI-only keys resolve through cmd_arg
+    assert cfg["newkey"] == [1, 2] and "newkey" in cfg and "nope" not in cfg
+    assert cfg["metric"] == ["Precision", "Recall", "NDCG"] and cfg["group_view"] is None
+    assert cfg["no_cuda"] is False and cfg["save_flag"] is True and cfg["suffix"] == "" and cfg["logits"] == "cosin"
+    with pytest.raises(KeyError):
+        cfg["missing_key"]
+    with pytest.raises(TypeError):
+        cfg[3]
+    with pytest.raises(SyntaxError):
+        make_config(["alpha=0.5"])
+    with pytest.raises(ValueError):
+        make_config(["--a=b=c"])
+    cfg.device = "cuda:0"                                                 # plain attribute (main.py:36)
+    assert cfg.device == "cuda:0"
+    assert "recdim=32" in cfg.params_str()
+
+
+def test_data_iterator_semantics():
+    from elimrec_amd import DataIterator
+    a, b = list(range(10)), list(range(10, 20))
+    batches = list(DataIterator(a, b, batch_size=4, shuffle=False))
+    assert [len(x[0]) for x in batches] == [4, 4, 2] and batches[2] == [[8, 9], [18, 19]]
+    assert len(DataIterator(a, b, batch_size=4)) == 3 and len(DataIterator(a, b, batch_size=4, drop_last=True)) == 2
+    assert list(DataIterator(a, batch_size=5)) == [[0, 1, 2, 3, 4], [5, 6, 7, 8, 9]]     # single column -> flat lists
+    np.random.seed(5)
+    perm = np.random.permutation(10).tolist()
+    np.random.seed(5)
+    got = [x for bu, _ in DataIterator(a, b, batch_size=3, shuffle=True) for x in bu]
+    assert got == perm                                                    # same RNG draw as the reference
+    with pytest.raises(ValueError):
+        DataIterator(a, b[:-1])
+
+
+def test_sampler_bookkeeping_and_errors():
+    from elimrec_amd import PairwiseSamplerV2, SyntheticDataset
+    ds = SyntheticDataset(50, 80, 600, feat_dims=(8, 8, 8), seed=3)
+    s = PairwiseSamplerV2(ds, batch_size=64)
+    assert s.num_trainings == ds.train_matrix.nnz
+    assert len(s) == (s.num_trainings + 63) // 64
+    assert len(PairwiseSamplerV2(ds, batch_size=64, drop_last=True)) == s.num_trainings // 64
+    with pytest.raises(ValueError):
+        PairwiseSamplerV2(ds, neg_num=0)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            next(iter(PairwiseSamplerV2(ds, batch_size=64, device="cpu")))
+
+
+def test_synthetic_dataset_contract():
+    from elimrec_amd import SyntheticDataset
+    ds = SyntheticDataset(300, 500, 5000, feat_dims=(16, 8, 4), seed=0)
+    tot = ds.train_matrix + ds.valid_matrix + ds.test_matrix
+    assert tot.max() == 1.0                                               # splits are disjoint, no duplicates
+    assert (np.asarray(tot.sum(1)).ravel() >= 3).all() and (np.asarray(tot.sum(0)).ravel() >= 1).all()
+    assert abs(ds.train_matrix.nnz / tot.nnz - 0.8) < 0.01
+    assert ds.v_feat.shape == (500, 16) and ds.t_feat.shape == (500, 4)
+    ds2 = SyntheticDataset(300, 500, 5000, feat_dims=(16, 8, 4), seed=0)
+    assert (ds.train_matrix != ds2.train_matrix).nnz == 0 and torch.equal(ds.a_feat, ds2.a_feat)
+
+
+def test_model_construction_matches_reference_surface(fixture_name):
+    """Same state_dict key set as the reference, same adjacency, and (same seed, same draw order)
+    bit-identical initial parameters."""
+    from elimrec_amd import EliMRec, set_seed
+    from helpers import FixtureDataset, fixture_argv
+    g = load_golden(fixture_name)
+    cfg = make_config(fixture_argv(g))
+    set_seed(cfg["seed"])
+    model = EliMRec(cfg, FixtureDataset(g))
+    ref = sub(g, "init")
+    sd = model.state_dict()
+    assert set(sd.keys()) == set(ref.keys())
+    for k, v in ref.items():
+        assert np.array_equal(sd[k].numpy(), v), k
+    n = model.num_users + model.num_items
+    import scipy.sparse as sp
+    mine = sp.csr_matrix((model.adj_val.numpy(), model.adj_col.numpy(), model.adj_rowptr.numpy()), shape=(n, n)).tocoo()
+    ref_adj = sp.coo_matrix((g["adj_values"], (g["adj_indices"][0], g["adj_indices"][1])), shape=(n, n))
+    assert (abs(mine - ref_adj)).max() == 0.0
+    assert model._adj_symmetric == (str(g["adj_type"]) == "pre")
+
+
+def test_hot_path_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    g = load_golden("ml3")
+    model, _ = build_model_from_fixture(g, "cpu")
+    u = torch.from_numpy(g["step1/users"])
+    with pytest.raises(RuntimeError, match="no CPU fallback|HIP"):
+        model.bpr_loss(u, torch.from_numpy(g["step1/pos"]), torch.from_numpy(g["step1/neg"]))
+    with pytest.raises(RuntimeError):
+        model.predict([0, 1])
+    from elimrec_amd import ops
+    with pytest.raises(RuntimeError, match="HIP device"):
+        ops.fixed_order_sum(torch.zeros(4), torch.zeros(1))
+
+
+def test_c_abi_library_exports_every_declared_symbol():
+    """include/elimrec_hip.h is the contract: every function it declares must be exported by the
+    built library and bound (with a signature) by the ctypes stub."""
+    from elimrec_amd import _lib
+    text = open(os.path.join(ROOT, "include", "elimrec_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"\b(elimrec_[a-z0-9_]+)\s*\(", text))
+    assert len(declared) >= 18
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+        assert name in _lib.SIGNATURES, name
+    assert declared == set(_lib.SIGNATURES.keys())
+    assert lib.elimrec_abi_version() == 1
+    # size queries are host-only and must work without a GPU
+    assert lib.elimrec_linear_bwd_w_workspace(76085, 64, 128) > 0
+    assert lib.elimrec_score_workspace(128, 76085, 10) > 0
+
+
+def test_checkpoint_name_and_metrics_info():
+    g = load_golden("ml3")
+    model, cfg = build_model_from_fixture(g, "cpu")
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        cfg.alg_arg["path"] = repr(os.path.join(td, "ck"))
+        name = model.getFileName()
+        assert name.endswith("EliMRec-movielens-bpr_loss-.pth.tar") and os.path.isdir(os.path.join(td, "ck"))
+    assert model.valid_evaluator.metrics_info().startswith("metrics:\tPrecision@10")
