@@ -13,6 +13,15 @@ LIB_PATH = os.path.join(_HERE, "lib", "libelimrec_hip.so")
 c_i32, c_i64, c_f32, c_u32, c_u64 = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_uint32, ctypes.c_uint64
 c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t
 
+class CsrSplit(ctypes.Structure):
+    """struct elimrec_csr_split (include/elimrec_hip.h)."""
+    _fields_ = [("long_threshold", ctypes.c_int32), ("n_long", ctypes.c_int32), ("n_seg", ctypes.c_int32),
+                ("d_long_rows", ctypes.c_void_p), ("d_long_seg_ptr", ctypes.c_void_p),
+                ("d_seg_bounds", ctypes.c_void_p), ("d_partials", ctypes.c_void_p)]
+
+
+c_split = ctypes.POINTER(CsrSplit)
+
 # name -> (restype, argtypes); order and types follow include/elimrec_hip.h exactly.
 SIGNATURES = {
     "elimrec_abi_version": (c_i32, []),
@@ -22,8 +31,8 @@ SIGNATURES = {
     "elimrec_linear_bwd_w": (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_i64,
                                      c_ptr, c_i32, c_ptr, c_size, c_ptr]),
     "elimrec_assemble_x0": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i32, c_i32, c_ptr]),
-    "elimrec_spmm_hop": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr]),
-    "elimrec_propagate": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "elimrec_spmm_hop": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_split, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr]),
+    "elimrec_propagate": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_split, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "elimrec_bpr_head": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32,
                                  ctypes.POINTER(c_f32), c_ptr, c_ptr, c_ptr, c_ptr]),
     "elimrec_sum": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr]),

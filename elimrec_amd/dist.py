@@ -1,0 +1,73 @@
+"""Multi-GPU driver for the training step: one process per GPU, torch.distributed (backend
+"nccl" = RCCL over xGMI), data-parallel over TRIPLETS with replicated tables.
+
+Why replicas and not row shards at this shape: the whole propagated table is 115 MB at the Tiktok
+shape (N=112 741 rows x 1 KiB) against 288 GB of HBM per GPU, and every hop of a row-sharded
+propagation would move most of that table across xGMI (SURVEY.md §7 "xGMI volume") -- six times
+per step. What actually differs between ranks is tiny: the gradient of the loss with respect to the
+3B gathered head rows. So per step each rank
+  1. runs the forward on its own B triplets (tables are bit-identical on every rank),
+  2. all-gathers its [3B x Cy] head-gradient rows + int32 node ids (6.3 MB per rank at B=2048),
+  3. runs the SAME deterministic backward + Adam on the gathered rows scaled by 1/world_size.
+Step 3 is bitwise identical on every rank (deterministic kernels, identical input order), so the
+replicas never drift and no parameter/gradient all-reduce exists. The result equals one
+single-GPU step with batch world_size*B (mean over the global batch).
+
+The `engine` (EliMRec, or a CPU stand-in injected by tests/test_dist_cpu.py) provides
+forward_local / backward_global / named_parameters.
+"""
+import torch
+import torch.distributed as dist
+
+
+class DataParallelTrainer(object):
+    def __init__(self, engine, optimizer, world_size=1, rank=0, group=None):
+        self.engine, self.opt, self.world, self.rank, self.group = engine, optimizer, int(world_size), int(rank), group
+        self.profile_kernels = False
+        self._events = []
+        self._scale = None
+        self._gather = None
+
+    def _buffers(self, grad_rows, keys):
+        shape = (self.world * grad_rows.shape[0], grad_rows.shape[1])
+        if self._gather is None or self._gather[0].shape != shape or self._gather[0].device != grad_rows.device:
+            self._gather = (torch.empty(shape, dtype=grad_rows.dtype, device=grad_rows.device),
+                            torch.empty(self.world * keys.shape[0], dtype=keys.dtype, device=keys.device))
+            self._scale = torch.full((1,), 1.0 / self.world, dtype=torch.float32, device=grad_rows.device)
+        return self._gather
+
+    def step(self, users, pos, neg):
+        """One training step on this rank's triplets; returns the (local) loss as a 0-dim tensor."""
+        eng = self.engine
+        if self.profile_kernels and getattr(eng, "_kernel_events", None) is None:
+            eng._kernel_events = self._events
+        loss, grad_rows, keys = eng.forward_local(users, pos, neg, world_size=self.world)
+        if self.world > 1:
+            all_rows, all_keys = self._buffers(grad_rows, keys)
+            dist.all_gather_into_tensor(all_rows, grad_rows, group=self.group)
+            dist.all_gather_into_tensor(all_keys, keys, group=self.group)
+            grads = eng.backward_global(all_rows, all_keys, self._scale)
+        else:
+            if self._scale is None:
+                self._scale = torch.ones(1, dtype=torch.float32, device=grad_rows.device)
+            grads = eng.backward_global(grad_rows, keys, self._scale)
+        for name, p in eng.named_parameters():
+            p.grad = grads.get(name)          # None => the optimiser skips it (as torch does)
+        self.opt.step()
+        return loss
+
+    def global_loss(self, loss):
+        """Mean of the per-rank losses = loss of the global batch (all ranks hold equal B)."""
+        if self.world > 1:
+            loss = loss.clone()
+            dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.group)
+            loss /= self.world
+        return loss
+
+    def kernel_time_ms(self, name="spmm_hop"):
+        """(total ms, launches) of the event-bracketed propagation kernels since profiling began."""
+        total, launches = 0.0, 0
+        for e0, e1, n in self._events:
+            total += e0.elapsed_time(e1)
+            launches += n
+        return total, launches

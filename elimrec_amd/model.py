@@ -154,8 +154,17 @@ class EliMRec(BasicModel):
         self.register_buffer(name + "_val", torch.from_numpy(m.data.astype(np.float32)), persistent=False)
 
     def _csr(self, name):
-        return ops.Csr(getattr(self, name + "_rowptr"), getattr(self, name + "_col"), getattr(self, name + "_val"),
-                       self.num_users + self.num_items)
+        """Device CSR + its row-split plan (built on first use on the current device)."""
+        rowptr = getattr(self, name + "_rowptr")
+        cache = self.__dict__.setdefault("_csr_cache", {})
+        hit = cache.get(name)
+        if hit is None or hit.rowptr.data_ptr() != rowptr.data_ptr():
+            hit = ops.Csr(rowptr, getattr(self, name + "_col"), getattr(self, name + "_val"),
+                          self.num_users + self.num_items)
+            if rowptr.is_cuda:
+                hit.build_split(self.C)
+            cache[name] = hit
+        return hit
 
     def _create_u_embeding_i(self):
         """models/EliMRec.py:356-407, same RNG draw order."""
@@ -213,9 +222,14 @@ class EliMRec(BasicModel):
                                "for MI355X; move the model to a GPU (`.to('cuda:0')`). There is no CPU fallback." % dev)
         return dev
 
-    def _workspace(self, B):
+    def _workspace(self, B, bwd_rows=None):
+        """Device buffers for batch size B. bwd_rows = number of gradient rows the backward pass
+        will be fed (3*B locally; 3*B*world_size when row gradients are all-gathered)."""
         dev = self._require_gpu()
-        key = (str(dev), int(B))
+        bwd_rows = 3 * int(B) if bwd_rows is None else int(bwd_rows)
+        if self._ws is not None and self._ws_key[:2] == (str(dev), int(B)) and self._ws_key[2] >= bwd_rows:
+            return self._ws
+        key = (str(dev), int(B), bwd_rows)
         if self._ws is not None and self._ws_key == key:
             return self._ws
         N, C, Cy, d = self.num_users + self.num_items, self.C, self.Cy, self.latent_dim
@@ -230,10 +244,10 @@ class EliMRec(BasicModel):
             ws["bwd_w_items"] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             ws["loss"] = torch.zeros(1, **f32)
             ws["one"] = torch.ones(1, **f32)
-        n3 = 3 * B
+        n3 = bwd_rows
         ws["loss_rows"] = torch.empty(B, **f32)
-        ws["grad_rows"] = torch.empty(n3, Cy, **f32)
-        ws["keys"] = torch.empty(n3, dtype=torch.int32, device=dev)
+        ws["grad_rows"] = torch.empty(3 * B, Cy, **f32)
+        ws["keys"] = torch.empty(3 * B, dtype=torch.int32, device=dev)
         ws["active_rows"] = torch.empty(n3, dtype=torch.int32, device=dev)
         ws["dY"] = torch.empty(n3, Cy, **f32)
         ws["seg_info"] = torch.zeros(8, dtype=torch.int32, device=dev)
@@ -271,7 +285,7 @@ class EliMRec(BasicModel):
         for k, m in enumerate(self._mods):
             lin = getattr(self, m + "_dense")
             ops.linear_fwd(getattr(self, m + "_feat"), lin.weight, lin.bias, X0[U:, (k + 1) * d:(k + 2) * d])
-        ops.propagate(self._csr("adj"), X0, self.n_layers, ws["T0"], ws["T1"], Out)
+        self._propagate(self._csr("adj"), X0, ws["T0"], ws["T1"], Out)
         wu, wi = self._fusion_weights()
         ops.linear_fwd(Out[:U], wu, self.embedding_user_after_GCN.bias, Y[:U, :d])
         ops.linear_fwd(Out[U:], wi, self.embedding_item_after_GCN.bias, Y[U:, :d])
@@ -279,6 +293,18 @@ class EliMRec(BasicModel):
             lin = getattr(self, "s_dense_" + m)
             ops.linear_fwd(Out[:, (h + 1) * d:(h + 2) * d], lin.weight, lin.bias, Y[:, (h + 1) * d:(h + 2) * d])
         self._publish_cache(Y)
+
+    def _propagate(self, csr, X0, t0, t1, out):
+        """L fused hops; optionally bracketed by HIP events on the launch stream (bench.py)."""
+        prof = getattr(self, "_kernel_events", None)
+        if prof is None:
+            ops.propagate(csr, X0, self.n_layers, t0, t1, out)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.propagate(csr, X0, self.n_layers, t0, t1, out)
+        e1.record()
+        prof.append((e0, e1, self.n_layers))
 
     def _publish_cache(self, Y):
         U, d = self.num_users, self.latent_dim
@@ -304,13 +330,20 @@ class EliMRec(BasicModel):
         return loss
 
     @torch.no_grad()
-    def _backward_hip(self, gscale):
-        """Returns {parameter name: gradient tensor}. gscale: device fp32[1] (d loss_total / d loss)."""
+    def _backward_hip(self, gscale, grad_rows=None, keys=None):
+        """Returns {parameter name: gradient tensor}. gscale: device fp32[1] (d loss_total / d loss).
+        grad_rows/keys default to the rows the last local forward produced; a data-parallel
+        driver passes the rows gathered from every rank instead."""
         ws = self._ws
         dev = self._device()
         U, I, d, M, C, S = self.num_users, self.num_items, self.latent_dim, self.M, self.C, self.S
-        dY, seg, act = ws["dY"], ws["seg_info"], ws["active_rows"]
-        ops.segment_reduce_rows(ws["grad_rows"], ws["keys"], U, act, dY, seg, ws["seg_ws"], scale=gscale)
+        grad_rows = ws["grad_rows"] if grad_rows is None else grad_rows
+        keys = ws["keys"] if keys is None else keys
+        n_rows = grad_rows.shape[0]
+        if n_rows > ws["dY"].shape[0]:
+            raise RuntimeError("backward workspace holds %d gradient rows, got %d" % (ws["dY"].shape[0], n_rows))
+        dY, seg, act = ws["dY"][:n_rows], ws["seg_info"], ws["active_rows"][:n_rows]
+        ops.segment_reduce_rows(grad_rows, keys, U, act, dY, seg, ws["seg_ws"], scale=gscale)
         bw = self._last_block_weights
         heads_on = [h for h in range(S) if bw[1 + h] != 0.0]
         wu, wi = self._fusion_weights()
@@ -338,7 +371,7 @@ class EliMRec(BasicModel):
             grads[name + ".weight"], grads[name + ".bias"] = gw, gb
         # back through the propagation (A^T; A itself when symmetric), then the layer-0 pieces
         G = ws["G"]
-        ops.propagate(self._csr("adj" if self._adj_symmetric else "adjT"), G0, self.n_layers, ws["T0"], ws["T1"], G)
+        self._propagate(self._csr("adj" if self._adj_symmetric else "adjT"), G0, ws["T0"], ws["T1"], G)
         gu = torch.empty(U, d, **f32)
         gi = torch.empty(I, d, **f32)
         ops.embed_grad(G, U, I, d, M, gu, gi)
@@ -350,6 +383,19 @@ class EliMRec(BasicModel):
             ops.linear_bwd_w(G[U:, (k + 1) * d:(k + 2) * d], feat, gw, ws["bwd_w_items"], colsum=gb)
             grads[m + "_dense.weight"], grads[m + "_dense.bias"] = gw, gb
         return grads
+
+    # ------------------------------------------------------------------ engine API (elimrec_amd/dist.py)
+    def forward_local(self, users, pos, neg, world_size=1):
+        """Forward on this rank's triplets. Returns (loss, grad_rows [3B x Cy], keys [3B]) where
+        grad_rows are d(local mean loss)/dY rows for nodes `keys`."""
+        B = int(users.numel())
+        self._workspace(B, 3 * B * world_size)
+        loss = self._forward_hip(users, pos, neg, need_grad=True)
+        return loss, self._ws["grad_rows"], self._ws["keys"]
+
+    def backward_global(self, grad_rows, keys, scale):
+        """Backward from (possibly gathered) gradient rows; `scale` is a device fp32[1]."""
+        return self._backward_hip(scale, grad_rows=grad_rows, keys=keys)
 
     # ------------------------------------------------------------------ reference API
     def bpr_loss(self, users, pos_items, neg_items):

@@ -75,38 +75,79 @@ def assemble_x0(user_emb, item_emb, X0, M):
     return X0
 
 
+LONG_ROW_THRESHOLD = 128   # rows with more non-zeros are split across waves (csrc/spmm.hip)
+
+
 class Csr:
-    """Device CSR (int32 rowptr/col, fp32 val)."""
+    """Device CSR (int32 rowptr/col, fp32 val) + the optional row-split plan for long rows."""
 
     def __init__(self, rowptr, col, val, n_rows):
         self.rowptr, self.col, self.val, self.n_rows = rowptr, col, val, n_rows
+        self._split = None
+        self._split_tensors = None
 
     @staticmethod
-    def from_scipy(m, device):
+    def from_scipy(m, device, C=None, threshold=LONG_ROW_THRESHOLD):
+        import numpy as np
         m = m.tocsr()
         m.sort_indices()
         if m.nnz >= 2 ** 31:
             raise ValueError("CSR with >= 2^31 non-zeros is not supported")
+        csr = Csr(torch.from_numpy(m.indptr.astype(np.int32)).to(device),
+                  torch.from_numpy(m.indices.astype(np.int32)).to(device),
+                  torch.from_numpy(m.data.astype(np.float32)).to(device), m.shape[0])
+        if C is not None:
+            csr.build_split(C, threshold)
+        return csr
+
+    def build_split(self, C, threshold=LONG_ROW_THRESHOLD):
+        """Cut rows with more than `threshold` non-zeros into segments of <= threshold (host, once)."""
         import numpy as np
-        return Csr(torch.from_numpy(m.indptr.astype(np.int32)).to(device),
-                   torch.from_numpy(m.indices.astype(np.int32)).to(device),
-                   torch.from_numpy(m.data.astype(np.float32)).to(device), m.shape[0])
+        rowptr = self.rowptr.cpu().numpy().astype(np.int64)
+        deg = np.diff(rowptr)
+        long_rows = np.nonzero(deg > threshold)[0]
+        if len(long_rows) == 0:
+            self._split, self._split_tensors = None, None
+            return self
+        nseg = (deg[long_rows] + threshold - 1) // threshold
+        seg_ptr = np.concatenate([[0], np.cumsum(nseg)])
+        total = int(seg_ptr[-1])
+        seg_row = np.repeat(np.arange(len(long_rows)), nseg)
+        k = np.arange(total) - seg_ptr[seg_row]
+        beg = rowptr[long_rows][seg_row] + k * threshold
+        end = np.minimum(beg + threshold, rowptr[long_rows + 1][seg_row])
+        dev = self.rowptr.device
+        t = (torch.from_numpy(long_rows.astype(np.int32)).to(dev), torch.from_numpy(seg_ptr.astype(np.int32)).to(dev),
+             torch.from_numpy(np.stack([beg, end], 1).astype(np.int32).copy()).to(dev),
+             torch.empty(total, C, dtype=torch.float32, device=dev))
+        self._split_tensors = t
+        self._split = _lib.CsrSplit(int(threshold), len(long_rows), total, t[0].data_ptr(), t[1].data_ptr(),
+                                    t[2].data_ptr(), t[3].data_ptr())
+        self._split_C = C
+        return self
+
+    def split_ref(self, C):
+        if self._split is None:
+            return None
+        if self._split_C < C:
+            raise ValueError("row-split plan was built for C=%d, got C=%d" % (self._split_C, C))
+        return ctypes.byref(self._split)
 
 
 def spmm_hop(csr, Xin, Xout=None, acc_in=None, acc_out=None, scale=1.0):
     C = Xin.shape[1]
     assert Xin.is_contiguous()
     _lib.check(_lib.load().elimrec_spmm_hop(_dev(csr.rowptr, "rowptr", torch.int32), _dev(csr.col, "col", torch.int32),
-                                            _dev(csr.val, "val"), csr.n_rows, C, _dev(Xin, "Xin"), _dev(Xout, "Xout"),
-                                            _dev(acc_in, "acc_in"), _dev(acc_out, "acc_out"), float(scale), _stream()),
-               "spmm_hop")
+                                            _dev(csr.val, "val"), csr.n_rows, C, csr.split_ref(C), _dev(Xin, "Xin"),
+                                            _dev(Xout, "Xout"), _dev(acc_in, "acc_in"), _dev(acc_out, "acc_out"),
+                                            float(scale), _stream()), "spmm_hop")
 
 
 def propagate(csr, X0, L, tmp0, tmp1, out):
     C = X0.shape[1]
     assert X0.is_contiguous() and out.is_contiguous() and out.shape == X0.shape
     _lib.check(_lib.load().elimrec_propagate(_dev(csr.rowptr, "rowptr", torch.int32), _dev(csr.col, "col", torch.int32),
-                                             _dev(csr.val, "val"), csr.n_rows, C, L, _dev(X0, "X0"),
+                                             _dev(csr.val, "val"), csr.n_rows, C, csr.split_ref(C), L, _dev(X0, "X0"),
                                              _dev(tmp0, "tmp0"), _dev(tmp1, "tmp1"), _dev(out, "out"), _stream()),
                "propagate")
     return out

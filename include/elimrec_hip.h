@@ -73,17 +73,33 @@ int elimrec_assemble_x0(const float *d_user_emb, const float *d_item_emb, float 
  *   if Xout   : Xout[row]   = r
  *   if AccOut : AccOut[row] = (AccIn[row] + r) * scale        (AccIn may alias AccOut)
  * Replaces torch.sparse.mm (models/EliMRec.py:244) fused with the stack+mean of :246-247.
- * Requires C % 4 == 0. */
+ * Requires C % 4 == 0.
+ *
+ * Load balance for the power-law head (a popular item has ~10^4 neighbours, the median node ~10):
+ * an optional row-split plan, built once per matrix by the caller, cuts every row with more than
+ * `long_threshold` non-zeros into segments of at most that many; segments are summed by separate
+ * waves into d_partials [n_seg x C] and combined per row in segment order (deterministic). */
+typedef struct elimrec_csr_split {
+    int32_t long_threshold;         /* rows with nnz > threshold are split                      */
+    int32_t n_long;                 /* number of split rows (0 => plan unused)                  */
+    int32_t n_seg;                  /* total segments over all split rows                       */
+    const int32_t *d_long_rows;     /* [n_long] row ids                                         */
+    const int32_t *d_long_seg_ptr;  /* [n_long+1] segment range of each split row               */
+    const int32_t *d_seg_bounds;    /* [n_seg][2] (begin,end) positions into col/val            */
+    float *d_partials;              /* [n_seg x C] scratch                                      */
+} elimrec_csr_split;
+
 int elimrec_spmm_hop(const int32_t *d_rowptr, const int32_t *d_col, const float *d_val,
-                     int64_t n_rows, int C, const float *d_Xin, float *d_Xout,
+                     int64_t n_rows, int C, const elimrec_csr_split *split /* nullable */,
+                     const float *d_Xin, float *d_Xout,
                      const float *d_AccIn, float *d_AccOut, float scale, void *stream);
 
 /* L hops + mean of the L+1 layer outputs: Out = 1/(L+1) * sum_k A^k X0   (compute_graph,
  * models/EliMRec.py:238-248, for all M tables at once). d_tmp0/d_tmp1: two [n_rows x C]
  * scratch tables (unused when L <= 1 / L <= 2). X0 is left intact. Out must not alias X0. */
 int elimrec_propagate(const int32_t *d_rowptr, const int32_t *d_col, const float *d_val,
-                      int64_t n_rows, int C, int L, const float *d_X0, float *d_tmp0,
-                      float *d_tmp1, float *d_Out, void *stream);
+                      int64_t n_rows, int C, const elimrec_csr_split *split /* nullable */, int L,
+                      const float *d_X0, float *d_tmp0, float *d_tmp1, float *d_Out, void *stream);
 
 /* ---------------------------------------------------------------- cosine-BPR head (K7,K9,K10)
  * For triplet b and head block k (weight w[k]; w[k] == 0 skips the block):

@@ -217,7 +217,7 @@ def test_propagate_vs_oracle(C, L):
     m.eliminate_zeros()
     m.sort_indices()
     X0 = torch.randn(n, C, generator=torch.Generator().manual_seed(1))
-    csr = ops.Csr.from_scipy(m, DEV)
+    csr = ops.Csr.from_scipy(m, DEV, C=C, threshold=64)
     X0d = X0.to(DEV)
     t0, t1, out = torch.empty_like(X0d), torch.empty_like(X0d), torch.empty_like(X0d)
     ops.propagate(csr, X0d, L, t0, t1, out)
@@ -234,6 +234,10 @@ def test_propagate_vs_oracle(C, L):
     out2 = torch.empty_like(out)
     ops.propagate(csr, X0d, L, t0, t1, out2)
     assert torch.equal(out, out2)                  # deterministic
+    assert csr._split is not None and csr._split.n_long >= 1
+    plain = ops.Csr.from_scipy(m, DEV)             # no row-split plan: one wave per row
+    ops.propagate(plain, X0d, L, t0, t1, out2)
+    assert rel_err(out2.cpu(), want) < 2e-6
 
 
 def test_propagate_linearity_at_tiktok_shape():
@@ -244,7 +248,7 @@ def test_propagate_linearity_at_tiktok_shape():
     ds = SyntheticDataset(36656, 76085, 720829, feat_dims=(4, 4, 4), seed=0)
     tu, ti = ds.get_train_interactions()
     adj = create_adj_mat(tu, ti, ds.num_users, ds.num_items, "pre")
-    csr = ops.Csr.from_scipy(adj, DEV)
+    csr = ops.Csr.from_scipy(adj, DEV, C=256)
     n, C = adj.shape[0], 256
     g = torch.Generator(device=DEV).manual_seed(0)
     X, Z = torch.randn(n, C, device=DEV, generator=g), torch.randn(n, C, device=DEV, generator=g)
