@@ -88,90 +88,139 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
 }
 
 // --------------------------------------------------------------------------------- weight grad
-// out[i, j] = sum_r A[r, i] * B[idx(r), j]. Both MFMA operands are read straight from global
-// memory: lane (i, k) of the A operand is A[r0 + k][i0 + i], i.e. consecutive lanes read
-// consecutive columns of one row -- already coalesced, no LDS transpose needed.
-// A workgroup owns one chunk of TCH rows and one 64 x 128 output tile (4 waves x 2 MFMA tiles);
-// it writes its partial tile to slab[chunk]; slabs are then summed in chunk order.
-constexpr int TCH = 512;   // rows per chunk
-constexpr int TN1 = 64, TN2 = 128;
+// out[i, j] = sum_r A[r, i] * B[idx(r), j]   (A^T . B; the reduction runs over ROWS).
+// A workgroup owns one chunk of rows and one 64 x 128 output tile (4 waves x 2 MFMA tiles).
+// Rows are staged 32 at a time through LDS with 16-byte loads (a row of A or B is contiguous),
+// double-buffered: the global loads of block t+1 are in flight while block t feeds the MFMAs.
+// MFMA operands come straight from the row-major LDS image: lane (i, k) of the A operand is
+// As[k][i0 + i] -- consecutive lanes, consecutive addresses, no transpose anywhere.
+// Each workgroup writes its partial tile to slab[chunk]; slabs are summed in chunk order
+// (reduce_slabs_kernel), so the result is bitwise reproducible.
+constexpr int TN1 = 64, TN2 = 128, TRB = 32;
 
 __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(
     const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
     const int32_t *__restrict__ row_index, const int32_t *__restrict__ range, int64_t R, int n1, int n2,
-    float *__restrict__ slabs, float *__restrict__ colsum_slabs) {
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    int chunk_rows, float *__restrict__ slabs, float *__restrict__ colsum_slabs) {
+    __shared__ float As[2][TRB * TN1];
+    __shared__ float Bs[2][TRB * TN2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int chunk = blockIdx.x;
     const int n1_tiles = gridDim.y, n2_tiles = gridDim.z;
     int64_t rb = 0, re = R;
     if (range) { rb = range[0]; re = range[1]; }
-    int64_t r0 = rb + (int64_t)chunk * TCH;
-    int64_t r1 = r0 + TCH < re ? r0 + TCH : re;
+    const int64_t r0 = rb + (int64_t)chunk * chunk_rows;
+    const int64_t r1 = (r0 + chunk_rows < re) ? r0 + chunk_rows : re;
+    const int i_base = blockIdx.y * TN1, j_base = blockIdx.z * TN2;
 
-    const int i0 = blockIdx.y * TN1 + (wave & 1) * 32;
-    const int j0 = blockIdx.z * TN2 + (wave >> 1) * 64;
-    const int li = lane & 31, lk = lane >> 5;
-    const bool a_ok = (i0 + li) < n1;
-    const bool b0_ok = (j0 + li) < n2;
-    const bool b1_ok = (j0 + 32 + li) < n2;
-
-    v16f acc0 = {0}, acc1 = {0};
-    float csum = 0.f;   // column sum of A for column i0+li over rows of parity lk
-    for (int64_t r = r0; r < r1; r += 2) {
-        const int64_t rr = r + lk;
-        float a = 0.f, b0 = 0.f, b1 = 0.f;
-        if (rr < r1) {
-            const int64_t br = row_index ? (int64_t)row_index[rr] : rr;
-            if (a_ok) a = A[rr * lda + i0 + li];
-            if (b0_ok) b0 = B[br * ldb + j0 + li];
-            if (b1_ok) b1 = B[br * ldb + j0 + 32 + li];
+    // loader geometry: A block = 32 rows x 16 float4 (2 per thread); B block = 32 rows x 32 float4 (4 per thread)
+    const int a_row = tid >> 4, a_c4 = tid & 15;          // + 16 rows on the second pass
+    const int b_row = tid >> 5, b_c4 = tid & 31;          // + 8 rows per pass, 4 passes
+    const bool a_col_ok = (i_base + a_c4 * 4) < n1;       // n1, n2 are multiples of 4
+    const bool b_col_ok = (j_base + b_c4 * 4) < n2;
+    float4 ra[2], rbv[4];
+    auto load_block = [&](int64_t row0) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int64_t r = row0 + a_row + 16 * p;
+            ra[p] = (a_col_ok && r < r1) ? *reinterpret_cast<const float4 *>(A + r * lda + i_base + a_c4 * 4)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        csum += a;
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int64_t r = row0 + b_row + 8 * p;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b_col_ok && r < r1) {
+                const int64_t br = row_index ? (int64_t)row_index[r] : r;
+                v = *reinterpret_cast<const float4 *>(B + br * ldb + j_base + b_c4 * 4);
+            }
+            rbv[p] = v;
+        }
+    };
+    auto store_block = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            *reinterpret_cast<float4 *>(&As[buf][(a_row + 16 * p) * TN1 + a_c4 * 4]) = ra[p];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            *reinterpret_cast<float4 *>(&Bs[buf][(b_row + 8 * p) * TN2 + b_c4 * 4]) = rbv[p];
+    };
+
+    const int wi = (wave & 1) * 32, wj = (wave >> 1) * 64;
+    const int li = lane & 31, lk = lane >> 5;
+    v16f acc0 = {0}, acc1 = {0};
+    float csum = 0.f;                                      // threads 0..63: column sum of A[:, i_base + tid]
+    int buf = 0;
+    if (r0 < r1) {
+        load_block(r0);
+        store_block(0);
     }
-    // slab layout: [chunk][n1_pad][n2_pad] with n1_pad = n1_tiles*64, n2_pad = n2_tiles*128
-    const int n2_pad = n2_tiles * TN2;
-    float *slab = slabs + (size_t)chunk * (n1_tiles * TN1) * n2_pad;
+    __syncthreads();
+    for (int64_t row0 = r0; row0 < r1; row0 += TRB) {
+        const bool more = (row0 + TRB) < r1;
+        if (more) load_block(row0 + TRB);                  // in flight during the MFMAs below
+        const float *as = As[buf], *bs = Bs[buf];
+#pragma unroll
+        for (int kk = 0; kk < TRB; kk += 2) {
+            const float a = as[(kk + lk) * TN1 + wi + li];
+            const float b0 = bs[(kk + lk) * TN2 + wj + li];
+            const float b1 = bs[(kk + lk) * TN2 + wj + 32 + li];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+        }
+        if (colsum_slabs && tid < TN1) {
+#pragma unroll 8
+            for (int k = 0; k < TRB; ++k) csum += as[k * TN1 + tid];
+        }
+        if (more) store_block(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    const int n1_pad = n1_tiles * TN1, n2_pad = n2_tiles * TN2;
+    float *slab = slabs + (size_t)chunk * n1_pad * n2_pad;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int row = i0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        slab[(size_t)row * n2_pad + j0 + li] = acc0[r];
-        slab[(size_t)row * n2_pad + j0 + 32 + li] = acc1[r];
+        const int row = i_base + wi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        slab[(size_t)row * n2_pad + j_base + wj + li] = acc0[r];
+        slab[(size_t)row * n2_pad + j_base + wj + 32 + li] = acc1[r];
     }
-    if (colsum_slabs && blockIdx.z == 0 && (wave >> 1) == 0) {
-        // rows of parity 0 live in lanes 0..31, parity 1 in lanes 32..63: add the halves.
-        float other = __shfl_xor(csum, 32, 64);
-        if (lk == 0) colsum_slabs[(size_t)chunk * (n1_tiles * TN1) + i0 + li] = csum + other;
-    }
+    if (colsum_slabs && blockIdx.z == 0 && tid < TN1) colsum_slabs[(size_t)chunk * n1_pad + i_base + tid] = csum;
 }
 
-__global__ void reduce_slabs_kernel(const float *__restrict__ slabs, const int32_t *__restrict__ range,
-                                    int64_t R, int n1, int n2, int n1_pad, int n2_pad,
-                                    float *__restrict__ out, int64_t ldo, int accumulate) {
+// out[e] (+)= sum over chunks of slab[chunk][e], chunk order fixed; 4 chunks kept in flight.
+__global__ void reduce_slabs_kernel(const float *__restrict__ slabs, const float *__restrict__ cslabs,
+                                    const int32_t *__restrict__ range, int64_t R, int chunk_rows, int n1, int n2,
+                                    int n1_pad, int n2_pad, float *__restrict__ out, int64_t ldo,
+                                    float *__restrict__ colsum, int accumulate) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n1 * n2) return;
-    const int i = idx / n2, j = idx - i * n2;
+    const int total = n1 * n2;
     int64_t rows = range ? (int64_t)range[1] - range[0] : R;
     if (rows < 0) rows = 0;
-    const int chunks = (int)((rows + TCH - 1) / TCH);
+    const int chunks = (int)((rows + chunk_rows - 1) / chunk_rows);
+    const float *src;
+    size_t stride;
+    float *dst;
+    if (idx < total) {
+        const int i = idx / n2, j = idx - i * n2;
+        src = slabs + (size_t)i * n2_pad + j;
+        stride = (size_t)n1_pad * n2_pad;
+        dst = out + (int64_t)i * ldo + j;
+    } else if (colsum && idx < total + n1) {
+        src = cslabs + (idx - total);
+        stride = (size_t)n1_pad;
+        dst = colsum + (idx - total);
+    } else {
+        return;
+    }
     float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += slabs[((size_t)c * n1_pad + i) * n2_pad + j];
-    float *o = out + (int64_t)i * ldo + j;
-    *o = accumulate ? (*o + s) : s;
-}
-
-__global__ void reduce_colsum_kernel(const float *__restrict__ cslabs, const int32_t *__restrict__ range,
-                                     int64_t R, int n1, int n1_pad, float *__restrict__ out, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n1) return;
-    int64_t rows = range ? (int64_t)range[1] - range[0] : R;
-    if (rows < 0) rows = 0;
-    const int chunks = (int)((rows + TCH - 1) / TCH);
-    float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += cslabs[(size_t)c * n1_pad + i];
-    out[i] = accumulate ? (out[i] + s) : s;
+    int c = 0;
+    for (; c + 4 <= chunks; c += 4) {
+        const float v0 = src[(size_t)c * stride], v1 = src[(size_t)(c + 1) * stride];
+        const float v2 = src[(size_t)(c + 2) * stride], v3 = src[(size_t)(c + 3) * stride];
+        s += v0; s += v1; s += v2; s += v3;
+    }
+    for (; c < chunks; ++c) s += src[(size_t)c * stride];
+    *dst = accumulate ? (*dst + s) : s;
 }
 
 }  // namespace elimrec
@@ -193,16 +242,17 @@ extern "C" int elimrec_linear_fwd(const float *d_A, int64_t lda, const float *d_
     return 0;
 }
 
-static inline void bwd_w_dims(int64_t R, int n1, int n2, int &chunks, int &t1, int &t2) {
-    chunks = (int)((R + TCH - 1) / TCH);
+static inline void bwd_w_dims(int64_t R, int n1, int n2, int &chunk_rows, int &chunks, int &t1, int &t2) {
+    chunk_rows = (R >= 32768) ? 512 : 64;      // enough workgroups for the short (row-sparse) reductions
+    chunks = (int)((R + chunk_rows - 1) / chunk_rows);
     if (chunks < 1) chunks = 1;
     t1 = (n1 + TN1 - 1) / TN1;
     t2 = (n2 + TN2 - 1) / TN2;
 }
 
 extern "C" size_t elimrec_linear_bwd_w_workspace(int64_t R, int n1, int n2) {
-    int chunks, t1, t2;
-    bwd_w_dims(R, n1, n2, chunks, t1, t2);
+    int cr, chunks, t1, t2;
+    bwd_w_dims(R, n1, n2, cr, chunks, t1, t2);
     return ((size_t)chunks * t1 * TN1 * t2 * TN2 + (size_t)chunks * t1 * TN1) * sizeof(float);
 }
 
@@ -212,27 +262,25 @@ extern "C" int elimrec_linear_bwd_w(const float *d_A, int64_t lda, const float *
                                     size_t workspace_bytes, void *stream) {
     ELIMREC_REQUIRE(d_A && d_B && d_out && d_workspace, "linear_bwd_w: null pointer");
     ELIMREC_REQUIRE(R >= 0 && n1 > 0 && n2 > 0, "linear_bwd_w: bad shape");
+    ELIMREC_REQUIRE(n1 % 4 == 0 && n2 % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0,
+                    "linear_bwd_w: n1, n2, lda, ldb must be multiples of 4");
+    ELIMREC_REQUIRE(((uintptr_t)d_A % 16) == 0 && ((uintptr_t)d_B % 16) == 0, "linear_bwd_w: A and B must be 16-byte aligned");
     if (workspace_bytes < elimrec_linear_bwd_w_workspace(R, n1, n2)) {
         set_error("linear_bwd_w: workspace too small (%zu < %zu)", workspace_bytes,
                   elimrec_linear_bwd_w_workspace(R, n1, n2));
         return ELIMREC_E_WORKSPACE;
     }
-    int chunks, t1, t2;
-    bwd_w_dims(R, n1, n2, chunks, t1, t2);
+    int cr, chunks, t1, t2;
+    bwd_w_dims(R, n1, n2, cr, chunks, t1, t2);
     float *slabs = (float *)d_workspace;
     float *cslabs = slabs + (size_t)chunks * t1 * TN1 * t2 * TN2;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(linear_bwd_w_partial_kernel, dim3(chunks, t1, t2), dim3(256), 0, s, d_A, lda, d_B, ldb,
-                       d_row_index, d_range, R, n1, n2, slabs, d_colsum ? cslabs : nullptr);
+                       d_row_index, d_range, R, n1, n2, cr, slabs, d_colsum ? cslabs : nullptr);
     ELIMREC_LAUNCH_CHECK("linear_bwd_w_partial");
-    const int total = n1 * n2;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((total + 255) / 256), dim3(256), 0, s, slabs, d_range, R, n1, n2,
-                       t1 * TN1, t2 * TN2, d_out, ldo, accumulate);
+    const int total = n1 * n2 + (d_colsum ? n1 : 0);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((total + 127) / 128), dim3(128), 0, s, slabs, cslabs, d_range, R, cr,
+                       n1, n2, t1 * TN1, t2 * TN2, d_out, ldo, d_colsum, accumulate);
     ELIMREC_LAUNCH_CHECK("reduce_slabs");
-    if (d_colsum) {
-        hipLaunchKernelGGL(reduce_colsum_kernel, dim3((n1 + 255) / 256), dim3(256), 0, s, cslabs, d_range, R, n1,
-                           t1 * TN1, d_colsum, accumulate);
-        ELIMREC_LAUNCH_CHECK("reduce_colsum");
-    }
     return 0;
 }

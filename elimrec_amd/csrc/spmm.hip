@@ -39,29 +39,25 @@ __global__ __launch_bounds__(256) void spmm_hop_kernel(const int32_t *__restrict
         const int c = c0 + lane;
         const bool on = c < C4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        int j = beg;
-        for (; j + UNROLL <= end; j += UNROLL) {
+        // UNROLL neighbour rows in flight; the tail is handled by wave-uniform guards (j, end are
+        // uniform) so a short row still issues all its loads back to back.
+        for (int j = beg; j < end; j += UNROLL) {
             int cj[UNROLL];
             float vj[UNROLL];
             float4 x[UNROLL];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) { cj[u] = col[j + u]; vj[u] = val[j + u]; }
+            for (int u = 0; u < UNROLL; ++u) {
+                const bool in = (j + u) < end;
+                cj[u] = in ? col[j + u] : 0;
+                vj[u] = in ? val[j + u] : 0.f;
+            }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
-                x[u] = on ? Xin[(int64_t)cj[u] * C4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                x[u] = (on && (j + u) < end) ? Xin[(int64_t)cj[u] * C4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 acc.x = fmaf(vj[u], x[u].x, acc.x); acc.y = fmaf(vj[u], x[u].y, acc.y);
                 acc.z = fmaf(vj[u], x[u].z, acc.z); acc.w = fmaf(vj[u], x[u].w, acc.w);
-            }
-        }
-        for (; j < end; ++j) {
-            const int cj = col[j];
-            const float vj = val[j];
-            if (on) {
-                const float4 x = Xin[(int64_t)cj * C4 + c];
-                acc.x = fmaf(vj, x.x, acc.x); acc.y = fmaf(vj, x.y, acc.y);
-                acc.z = fmaf(vj, x.z, acc.z); acc.w = fmaf(vj, x.w, acc.w);
             }
         }
         if (on) {
@@ -92,29 +88,25 @@ __global__ __launch_bounds__(256) void spmm_long_partial_kernel(const int32_t *_
         const int c = c0 + lane;
         const bool on = c < C4;
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        int j = beg;
-        for (; j + UNROLL <= end; j += UNROLL) {
+        // UNROLL neighbour rows in flight; the tail is handled by wave-uniform guards (j, end are
+        // uniform) so a short row still issues all its loads back to back.
+        for (int j = beg; j < end; j += UNROLL) {
             int cj[UNROLL];
             float vj[UNROLL];
             float4 x[UNROLL];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) { cj[u] = col[j + u]; vj[u] = val[j + u]; }
+            for (int u = 0; u < UNROLL; ++u) {
+                const bool in = (j + u) < end;
+                cj[u] = in ? col[j + u] : 0;
+                vj[u] = in ? val[j + u] : 0.f;
+            }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
-                x[u] = on ? Xin[(int64_t)cj[u] * C4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+                x[u] = (on && (j + u) < end) ? Xin[(int64_t)cj[u] * C4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 acc.x = fmaf(vj[u], x[u].x, acc.x); acc.y = fmaf(vj[u], x[u].y, acc.y);
                 acc.z = fmaf(vj[u], x[u].z, acc.z); acc.w = fmaf(vj[u], x[u].w, acc.w);
-            }
-        }
-        for (; j < end; ++j) {
-            const int cj = col[j];
-            const float vj = val[j];
-            if (on) {
-                const float4 x = Xin[(int64_t)cj * C4 + c];
-                acc.x = fmaf(vj, x.x, acc.x); acc.y = fmaf(vj, x.y, acc.y);
-                acc.z = fmaf(vj, x.z, acc.z); acc.w = fmaf(vj, x.w, acc.w);
             }
         }
         if (on) partials[(int64_t)seg * C4 + c] = acc;
@@ -134,7 +126,15 @@ __global__ __launch_bounds__(256) void spmm_long_fixup_kernel(const int32_t *__r
     const int sb = long_seg_ptr[i], se = long_seg_ptr[i + 1];
     for (int c = lane; c < C4; c += 64) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int sgm = sb; sgm < se; ++sgm) {
+        int sgm = sb;
+        for (; sgm + 8 <= se; sgm += 8) {          // 8 partial rows in flight, summed in segment order
+            float4 p[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] = partials[(int64_t)(sgm + u) * C4 + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += p[u].x; acc.y += p[u].y; acc.z += p[u].z; acc.w += p[u].w; }
+        }
+        for (; sgm < se; ++sgm) {
             const float4 p = partials[(int64_t)sgm * C4 + c];
             acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
         }
@@ -186,12 +186,12 @@ static int spmm_hop_impl(const int32_t *d_rowptr, const int32_t *d_col, const fl
                         "spmm_hop: incomplete row-split plan");
     const int thr = has_split ? split->long_threshold : INT32_MAX;
     const int waves = 4;
-    hipLaunchKernelGGL(spmm_hop_kernel<4>, dim3((unsigned)((n_rows + waves - 1) / waves)), dim3(64 * waves), 0, s,
+    hipLaunchKernelGGL(spmm_hop_kernel<8>, dim3((unsigned)((n_rows + waves - 1) / waves)), dim3(64 * waves), 0, s,
                        d_rowptr, d_col, d_val, n_rows, C / 4, (const float4 *)d_Xin, (float4 *)d_Xout,
                        (const float4 *)d_AccIn, (float4 *)d_AccOut, scale, thr);
     ELIMREC_LAUNCH_CHECK("spmm_hop");
     if (has_split) {
-        hipLaunchKernelGGL(spmm_long_partial_kernel<4>, dim3((unsigned)((split->n_seg + waves - 1) / waves)),
+        hipLaunchKernelGGL(spmm_long_partial_kernel<8>, dim3((unsigned)((split->n_seg + waves - 1) / waves)),
                            dim3(64 * waves), 0, s, split->d_seg_bounds, split->n_seg, d_col, d_val, C / 4,
                            (const float4 *)d_Xin, (float4 *)split->d_partials);
         ELIMREC_LAUNCH_CHECK("spmm_long_partial");

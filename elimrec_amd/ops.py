@@ -75,7 +75,7 @@ def assemble_x0(user_emb, item_emb, X0, M):
     return X0
 
 
-LONG_ROW_THRESHOLD = 128   # rows with more non-zeros are split across waves (csrc/spmm.hip)
+LONG_ROW_THRESHOLD = 64   # rows with more non-zeros are split across waves (csrc/spmm.hip)
 
 
 class Csr:
