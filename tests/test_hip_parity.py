@@ -356,3 +356,55 @@ def test_rank_metrics_and_topk_known_answers():
         out = torch.empty(s.shape[0], 5 * k, device=DEV)
         ops.rank_metrics(_t(ref_topk), _t(tp), _t(ti), [1, 2, 3, 4, 5], out)
         assert np.abs(out.cpu().numpy() - g["case%d/result" % c]).max() < 1e-7, c   # same ranking -> same metrics
+
+
+def test_trainer_step_equals_autograd_step():
+    """The fused trainer path (elimrec_amd/dist.py, world 1) and the torch-autograd path
+    (loss.backward + optimizer.step, main.py:98-101 style) are the same kernels: bitwise equal."""
+    from elimrec_amd import FusedAdam
+    from elimrec_amd.dist import DataParallelTrainer
+    g = load_golden("ml3")
+    m1, _ = build_model_from_fixture(g, DEV)
+    m2, _ = build_model_from_fixture(g, DEV)
+    o1 = FusedAdam(m1.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    o2 = FusedAdam(m2.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    tr = DataParallelTrainer(m2, o2)
+    for t in (1, 2, 3):
+        u, p, n = (_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg"))
+        l1 = m1.bpr_loss(u, p, n)
+        o1.zero_grad()
+        l1.backward(retain_graph=True)
+        o1.step()
+        l2 = tr.step(u, p, n)
+        assert torch.equal(l1.detach(), l2)
+    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+def test_driver_runs_epochs_with_eval_and_checkpoint(tmp_path):
+    """main.py's Net.run on a small synthetic data set: trains, validates every test_step epochs,
+    saves the best checkpoint with the reference's state_dict keys, reports TE and TIE test lines."""
+    import sys
+    from helpers import ROOT
+    sys.path.insert(0, ROOT)
+    import importlib
+    main = importlib.import_module("main")
+    from elimrec_amd import Configurator, set_seed
+    import os
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        args = Configurator(os.path.join(ROOT, "NeuRec.properties"), default_section="hyperparameters",
+                            argv=["main.py", "--data.input.dataset=synthetic", "--alpha=0.5", "--loss=bpr_loss",
+                                  "--synthetic_shape=[300,500,6000]", "--synthetic_dims=[16,8,12]", "--recdim=32",
+                                  "--batch_size=512", "--num_epoch=4", "--test_step=2", "--verbose=0",
+                                  "--path=%s" % str(tmp_path / "ck")])
+        set_seed(args["seed"])
+        net = main.Net(args)
+        best, final = net.run()
+    finally:
+        os.chdir(cwd)
+    assert best["TIE"] > 0 and final["TE"].strip().startswith("[TE]") and final["TIE"].strip().startswith("[TIE]")
+    ck = torch.load(net.recommender.getFileName(), map_location="cpu")
+    assert set(ck.keys()) == set(net.recommender.state_dict().keys())
+    assert "embedding_user.weight" in ck and "s_dense_t.bias" in ck
