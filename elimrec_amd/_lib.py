@@ -20,7 +20,14 @@ class CsrSplit(ctypes.Structure):
                 ("d_seg_bounds", ctypes.c_void_p), ("d_partials", ctypes.c_void_p)]
 
 
+class CsrDesc(ctypes.Structure):
+    """struct elimrec_csr (include/elimrec_hip.h)."""
+    _fields_ = [("n_rows", ctypes.c_int64), ("d_rowptr", ctypes.c_void_p), ("d_col", ctypes.c_void_p),
+                ("d_val", ctypes.c_void_p), ("split", CsrSplit)]
+
+
 c_split = ctypes.POINTER(CsrSplit)
+c_csr = ctypes.POINTER(CsrDesc)
 
 # name -> (restype, argtypes); order and types follow include/elimrec_hip.h exactly.
 SIGNATURES = {
@@ -33,6 +40,13 @@ SIGNATURES = {
     "elimrec_assemble_x0": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i32, c_i32, c_ptr]),
     "elimrec_spmm_hop": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_split, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr]),
     "elimrec_propagate": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_split, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "elimrec_bipartite_workspace": (c_size, [c_i64, c_i64, c_i32, c_i32]),
+    "elimrec_propagate_bipartite": (c_i32, [c_csr, c_csr, c_i64, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr,
+                                            c_size, c_ptr]),
+    "elimrec_propagate_bipartite_bwd": (c_i32, [c_csr, c_csr, c_i64, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr,
+                                                c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "elimrec_blocksum_rows": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr]),
+    "elimrec_copy_cols": (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i32, c_ptr]),
     "elimrec_bpr_head": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32,
                                  ctypes.POINTER(c_f32), c_ptr, c_ptr, c_ptr, c_ptr]),
     "elimrec_sum": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr]),

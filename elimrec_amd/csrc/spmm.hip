@@ -242,3 +242,453 @@ extern "C" int elimrec_propagate(const int32_t *d_rowptr, const int32_t *d_col, 
     }
     return 0;
 }
+
+// =====================================================================================================
+// Bipartite propagation.
+//
+// The 'pre' / 'plain' / 'gcmc' adjacencies have no diagonal: A = [[0, P], [Q, 0]] (P: users <- items,
+// Q: items <- users). Layer k of table m is then alive on ONE side only once the layer-0 table is split
+// as [E_u ; item_m] = [E_u ; 0] + [0 ; item_m]:
+//   * the "wide" chain  w_k = A^k [0 ; XI]   (all M tables, C = M*d columns) lives on users for odd k,
+//     on items for even k;
+//   * the "narrow" chain a_k = A^k [E_u ; 0] is the SAME for every table (d columns) and lives on items
+//     for odd k, users for even k.
+// One reference hop (every row gathers C columns over all nnz) becomes two half hops: nnz/2 edges at C
+// columns + nnz/2 edges at d columns = 62.5 % of the gather traffic for M = 4, with identical results
+// (Out = 1/(L+1) sum_k (w_k + bcast(a_k)) on every row). The backward pass is the adjoint in Horner form:
+//   gXI  = inv (G_i + P^T (G_u + Q^T (G_i + P^T G_u)))          L half hops at C columns
+//   gE_u = inv (H_u + Q^T (H_i + P^T (H_u + Q^T H_i)))          L half hops at d columns, H = blocksum(G)
+// and the first half hop of each gathers from the raw head gradient, which is non-zero on <= 3B rows:
+// a row bitmap skips the rest (and the zero-fill of G disappears with it).
+// =====================================================================================================
+namespace elimrec {
+
+struct HalfArgs {
+    const int32_t *rowptr, *col;
+    const float *val;
+    int64_t n_rows;
+    int W4;                       // row width of Xin / Xout / Add* / AccOut in float4
+    const float4 *Xin;
+    const uint32_t *src_mask;     // nullable: bit r set <=> source row r is non-zero
+    float4 *Xout;                 // nullable: raw result
+    const float4 *Add1;           // nullable addends of the epilogue (own row)
+    const uint32_t *add1_mask;    // nullable: Add1 row is read only if its bit is set
+    const float4 *Add2;
+    const float4 *AddN;           // nullable narrow addend [n_rows x N4], broadcast over the W4/N4 blocks
+    int N4;
+    float4 *AccOut;               // nullable: (r + Add1 + Add2 + bcast(AddN)) * scale
+    float scale;
+    int long_threshold;
+    // long-row plan
+    const int32_t *seg_bounds;
+    int n_seg;
+    const int32_t *long_rows;
+    int n_long;
+    const int32_t *long_seg_ptr;
+    float4 *partials;
+};
+
+__device__ __forceinline__ bool mask_bit(const uint32_t *m, int r) { return (m[r >> 5] >> (r & 31)) & 1u; }
+
+__device__ __forceinline__ void half_epilogue(const HalfArgs &a, int64_t row, int c, float4 r) {
+    if (a.Xout) a.Xout[row * a.W4 + c] = r;
+    if (a.AccOut) {
+        float4 s = r;
+        if (a.Add1 && (!a.add1_mask || mask_bit(a.add1_mask, (int)row))) {
+            const float4 t = a.Add1[row * a.W4 + c];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        if (a.Add2) {
+            const float4 t = a.Add2[row * a.W4 + c];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        if (a.AddN) {
+            const float4 t = a.AddN[row * a.N4 + (c % a.N4)];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        a.AccOut[row * a.W4 + c] = make_float4(s.x * a.scale, s.y * a.scale, s.z * a.scale, s.w * a.scale);
+    }
+}
+
+// sum_j val[j] * Xin[col[j], c] over [beg, end), UNROLL rows in flight, optional source-row bitmap.
+template <int UNROLL>
+__device__ __forceinline__ float4 half_gather(const HalfArgs &a, int beg, int end, int c, bool on) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = beg; j < end; j += UNROLL) {
+        int cj[UNROLL];
+        float vj[UNROLL];
+        bool in[UNROLL];
+        float4 x[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            in[u] = (j + u) < end;
+            cj[u] = in[u] ? a.col[j + u] : 0;
+            vj[u] = in[u] ? a.val[j + u] : 0.f;
+        }
+        if (a.src_mask) {
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) in[u] = in[u] && mask_bit(a.src_mask, cj[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+            x[u] = (on && in[u]) ? a.Xin[(int64_t)cj[u] * a.W4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            acc.x = fmaf(vj[u], x[u].x, acc.x); acc.y = fmaf(vj[u], x[u].y, acc.y);
+            acc.z = fmaf(vj[u], x[u].z, acc.z); acc.w = fmaf(vj[u], x[u].w, acc.w);
+        }
+    }
+    return acc;
+}
+
+// LPR lanes per row (power of two <= 64): a wave handles 64/LPR rows, so narrow (d-column) tables use
+// every lane. MODE 0: rows of the CSR (long rows skipped); MODE 1: segments of long rows -> partials.
+template <int LPR, int UNROLL, int MODE>
+__global__ __launch_bounds__(256) void half_hop_kernel(HalfArgs a) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, cl = lane % LPR;
+    const int64_t item = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + sub;
+    const int64_t n_items = (MODE == 0) ? a.n_rows : (int64_t)a.n_seg;
+    bool valid = item < n_items;
+    int beg = 0, end = 0;
+    if (valid) {
+        if (MODE == 0) {
+            beg = a.rowptr[item]; end = a.rowptr[item + 1];
+            if (end - beg > a.long_threshold) valid = false;
+        } else {
+            beg = a.seg_bounds[2 * item]; end = a.seg_bounds[2 * item + 1];
+        }
+    }
+    if (LPR == 64) {
+        beg = __builtin_amdgcn_readfirstlane(beg);
+        end = __builtin_amdgcn_readfirstlane(end);
+    }
+    if (!valid) { beg = 0; end = 0; }
+    for (int c0 = 0; c0 < a.W4; c0 += LPR) {
+        const int c = c0 + cl;
+        const bool on = valid && c < a.W4;
+        const float4 acc = half_gather<UNROLL>(a, beg, end, c, on);
+        if (on) {
+            if (MODE == 0) half_epilogue(a, item, c, acc);
+            else a.partials[item * a.W4 + c] = acc;
+        }
+    }
+}
+
+template <int LPR>
+__global__ __launch_bounds__(256) void half_fixup_kernel(HalfArgs a) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, cl = lane % LPR;
+    const int i = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + sub;
+    if (i >= a.n_long) return;
+    const int64_t row = a.long_rows[i];
+    const int sb = a.long_seg_ptr[i], se = a.long_seg_ptr[i + 1];
+    for (int c = cl; c < a.W4; c += LPR) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int sgm = sb;
+        for (; sgm + 8 <= se; sgm += 8) {
+            float4 p[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) p[u] = a.partials[(int64_t)(sgm + u) * a.W4 + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc.x += p[u].x; acc.y += p[u].y; acc.z += p[u].z; acc.w += p[u].w; }
+        }
+        for (; sgm < se; ++sgm) {
+            const float4 p = a.partials[(int64_t)sgm * a.W4 + c];
+            acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+        }
+        half_epilogue(a, row, c, acc);
+    }
+}
+
+// Out[row] = (Add1[row] + bcast(AddN[row])) * scale   (a side that has no wide step of its own: L <= 1)
+__global__ void combine_kernel(const float4 *__restrict__ Add1, const float4 *__restrict__ AddN, int64_t n_rows,
+                               int W4, int N4, float scale, float4 *__restrict__ out) {
+    const int64_t total = n_rows * W4;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = t / W4;
+        const int c = (int)(t - row * W4);
+        float4 s = Add1 ? Add1[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (AddN) {
+            const float4 n = AddN[row * N4 + (c % N4)];
+            s.x += n.x; s.y += n.y; s.z += n.z; s.w += n.w;
+        }
+        out[t] = make_float4(s.x * scale, s.y * scale, s.z * scale, s.w * scale);
+    }
+}
+
+// bitmaps of the active (non-zero) rows on each side + H = blocksum of the active rows of G
+__global__ void build_masks_kernel(const int32_t *__restrict__ active_rows, const int32_t *__restrict__ seg_info,
+                                   int64_t n_max, int64_t U, uint32_t *__restrict__ mask_u,
+                                   uint32_t *__restrict__ mask_i) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_max || s >= seg_info[0]) return;
+    const int r = active_rows[s];
+    if (r < U) atomicOr(&mask_u[r >> 5], 1u << (r & 31));
+    else atomicOr(&mask_i[(r - U) >> 5], 1u << ((r - U) & 31));
+}
+
+static int launch_half(const elimrec_csr *m, HalfArgs a, int unroll_hint, hipStream_t s) {
+    a.rowptr = m->d_rowptr; a.col = m->d_col; a.val = m->d_val; a.n_rows = m->n_rows;
+    const bool has_split = m->split.n_long > 0;
+    a.long_threshold = has_split ? m->split.long_threshold : INT32_MAX;
+    a.seg_bounds = m->split.d_seg_bounds; a.n_seg = has_split ? m->split.n_seg : 0;
+    a.long_rows = m->split.d_long_rows; a.n_long = has_split ? m->split.n_long : 0;
+    a.long_seg_ptr = m->split.d_long_seg_ptr; a.partials = (float4 *)m->split.d_partials;
+    if (a.n_rows == 0) return 0;
+    int lpr = 64;
+    while (lpr > 1 && lpr / 2 >= a.W4) lpr /= 2;
+    if (lpr < 4) lpr = 4;
+    const int rpw = 64 / lpr;
+    const int waves = 4;
+    auto blocks = [&](int64_t n) { return dim3((unsigned)((n + (int64_t)waves * rpw - 1) / (waves * rpw))); };
+#define ELIMREC_HALF_LAUNCH(LPR)                                                                                     \
+    do {                                                                                                             \
+        hipLaunchKernelGGL((half_hop_kernel<LPR, 8, 0>), blocks(a.n_rows), dim3(64 * waves), 0, s, a);              \
+        ELIMREC_LAUNCH_CHECK("half_hop");                                                                            \
+        if (has_split) {                                                                                             \
+            hipLaunchKernelGGL((half_hop_kernel<LPR, 8, 1>), blocks(a.n_seg), dim3(64 * waves), 0, s, a);           \
+            ELIMREC_LAUNCH_CHECK("half_hop_long");                                                                   \
+            hipLaunchKernelGGL((half_fixup_kernel<LPR>), blocks(a.n_long), dim3(64 * waves), 0, s, a);               \
+            ELIMREC_LAUNCH_CHECK("half_fixup");                                                                      \
+        }                                                                                                            \
+    } while (0)
+    switch (lpr) {
+        case 64: ELIMREC_HALF_LAUNCH(64); break;
+        case 32: ELIMREC_HALF_LAUNCH(32); break;
+        case 16: ELIMREC_HALF_LAUNCH(16); break;
+        case 8: ELIMREC_HALF_LAUNCH(8); break;
+        default: ELIMREC_HALF_LAUNCH(4); break;
+    }
+#undef ELIMREC_HALF_LAUNCH
+    (void)unroll_hint;
+    return 0;
+}
+
+static HalfArgs half_args(int W4, const float *Xin, const uint32_t *src_mask, float *Xout, const float *Add1,
+                          const uint32_t *add1_mask, const float *Add2, const float *AddN, int N4, float *AccOut,
+                          float scale) {
+    HalfArgs a = {};
+    a.W4 = W4; a.Xin = (const float4 *)Xin; a.src_mask = src_mask; a.Xout = (float4 *)Xout;
+    a.Add1 = (const float4 *)Add1; a.add1_mask = add1_mask; a.Add2 = (const float4 *)Add2;
+    a.AddN = (const float4 *)AddN; a.N4 = N4 > 0 ? N4 : 1; a.AccOut = (float4 *)AccOut; a.scale = scale;
+    return a;
+}
+
+}  // namespace elimrec
+
+static size_t bip_ws_layout(int64_t U, int64_t I, int d, int C, size_t off[8]) {
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t r = o; o = align_up(o + bytes, 256); return r; };
+    off[0] = take((size_t)U * C * 4);   // wu
+    off[1] = take((size_t)I * C * 4);   // wi
+    off[2] = take((size_t)U * d * 4);   // au
+    off[3] = take((size_t)I * d * 4);   // ai
+    off[4] = take((size_t)U * d * 4);   // SN_u
+    off[5] = take((size_t)I * d * 4);   // SN_i
+    off[6] = take((size_t)(U + I) * d * 4);   // H (backward)
+    off[7] = take((size_t)(((U + 31) / 32) + ((I + 31) / 32) + 2) * 4);   // masks
+    return o;
+}
+
+extern "C" size_t elimrec_bipartite_workspace(int64_t U, int64_t I, int d, int M) {
+    size_t off[8];
+    return bip_ws_layout(U, I, d, d * M, off);
+}
+
+extern "C" int elimrec_propagate_bipartite(const elimrec_csr *P, const elimrec_csr *Q, int64_t U, int64_t I, int d,
+                                           int M, int L, const float *d_user_emb, const float *d_XI, float *d_Out,
+                                           void *d_workspace, size_t workspace_bytes, void *stream) {
+    ELIMREC_REQUIRE(P && Q && d_user_emb && d_XI && d_Out && d_workspace, "propagate_bipartite: null pointer");
+    ELIMREC_REQUIRE(d > 0 && d % 4 == 0 && M >= 1 && L >= 1, "propagate_bipartite: need d % 4 == 0, M >= 1, L >= 1");
+    ELIMREC_REQUIRE(P->n_rows == U && Q->n_rows == I, "propagate_bipartite: block shapes do not match U, I");
+    const int C = d * M;
+    size_t off[8];
+    if (workspace_bytes < bip_ws_layout(U, I, d, C, off)) {
+        set_error("propagate_bipartite: workspace too small");
+        return ELIMREC_E_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = (char *)d_workspace;
+    float *wu = (float *)(ws + off[0]), *wi = (float *)(ws + off[1]);
+    float *au = (float *)(ws + off[2]), *ai = (float *)(ws + off[3]);
+    float *SNu = (float *)(ws + off[4]), *SNi = (float *)(ws + off[5]);
+    float *Out_u = d_Out, *Out_i = d_Out + (size_t)U * C;
+    const float inv = 1.0f / (float)(L + 1);
+    const int C4 = C / 4, d4 = d / 4;
+    int rc;
+    // ---- narrow chain: a_k = A^k [E_u ; 0]; SN_side = sum of the a_k living on that side (k = 0 included)
+    const float *prev = d_user_emb;
+    for (int k = 1; k <= L; ++k) {
+        const bool to_items = (k & 1);
+        const bool need_next = k < L;
+        if (to_items) {
+            // first items step writes SN_i directly (it doubles as a_1); later ones accumulate in place
+            float *xout = (k == 1) ? SNi : (need_next ? ai : nullptr);
+            HalfArgs a = half_args(d4, prev, nullptr, xout, (k == 1) ? nullptr : SNi, nullptr, nullptr, nullptr, 0,
+                                   (k == 1) ? nullptr : SNi, 1.0f);
+            if ((rc = launch_half(Q, a, 8, s))) return rc;
+            prev = (k == 1) ? SNi : ai;
+        } else {
+            HalfArgs a = half_args(d4, prev, nullptr, need_next ? au : nullptr, (k == 2) ? d_user_emb : SNu, nullptr,
+                                   nullptr, nullptr, 0, SNu, 1.0f);
+            if ((rc = launch_half(P, a, 8, s))) return rc;
+            prev = au;
+        }
+    }
+    const float *SNu_final = (L >= 2) ? SNu : d_user_emb;     // users: a_0 = E_u (+ a_2 + ...)
+    // ---- wide chain: w_k = A^k [0 ; XI]; running sums live in Out, the last step on a side finishes it
+    const float *wprev = d_XI;
+    bool users_done = false, items_done = false;
+    for (int k = 1; k <= L; ++k) {
+        const bool to_users = (k & 1);
+        const bool last_on_side = (k + 2 > L);
+        const bool need_next = k < L;
+        if (to_users) {
+            const bool first = (k == 1);
+            HalfArgs a = half_args(C4, wprev, nullptr, need_next ? wu : nullptr, first ? nullptr : Out_u, nullptr, nullptr,
+                                   last_on_side ? SNu_final : nullptr, d4, Out_u, last_on_side ? inv : 1.0f);
+            if ((rc = launch_half(P, a, 8, s))) return rc;
+            wprev = wu;
+            users_done = last_on_side;
+        } else {
+            const bool first = (k == 2);
+            HalfArgs a = half_args(C4, wprev, nullptr, need_next ? wi : nullptr, first ? d_XI : Out_i, nullptr, nullptr,
+                                   last_on_side ? SNi : nullptr, d4, Out_i, last_on_side ? inv : 1.0f);
+            if ((rc = launch_half(Q, a, 8, s))) return rc;
+            wprev = wi;
+            items_done = last_on_side;
+        }
+    }
+    (void)users_done;
+    if (!items_done) {   // L == 1: Out_i = (XI + bcast(a_1)) / 2
+        hipLaunchKernelGGL(combine_kernel, dim3(2048), dim3(256), 0, s, (const float4 *)d_XI, (const float4 *)SNi, I, C4,
+                           d4, inv, (float4 *)Out_i);
+        ELIMREC_LAUNCH_CHECK("combine");
+    }
+    return 0;
+}
+
+extern "C" int elimrec_propagate_bipartite_bwd(const elimrec_csr *PT, const elimrec_csr *QT, int64_t U, int64_t I,
+                                               int d, int M, int L, const float *d_G, const float *d_H,
+                                               const int32_t *d_active_rows, const int32_t *d_seg_info, int64_t n_max,
+                                               float *d_gXI, float *d_gEu, void *d_workspace, size_t workspace_bytes,
+                                               void *stream) {
+    ELIMREC_REQUIRE(PT && QT && d_G && d_H && d_active_rows && d_seg_info && d_gXI && d_gEu && d_workspace,
+                    "propagate_bipartite_bwd: null pointer");
+    ELIMREC_REQUIRE(d > 0 && d % 4 == 0 && M >= 1 && L >= 1, "propagate_bipartite_bwd: need d % 4 == 0, M >= 1, L >= 1");
+    ELIMREC_REQUIRE(PT->n_rows == I && QT->n_rows == U, "propagate_bipartite_bwd: block shapes do not match U, I");
+    const int C = d * M;
+    size_t off[8];
+    if (workspace_bytes < bip_ws_layout(U, I, d, C, off)) {
+        set_error("propagate_bipartite_bwd: workspace too small");
+        return ELIMREC_E_WORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = (char *)d_workspace;
+    float *wu = (float *)(ws + off[0]), *wi = (float *)(ws + off[1]);
+    float *au = (float *)(ws + off[2]), *ai = (float *)(ws + off[3]);
+    uint32_t *mask_u = (uint32_t *)(ws + off[7]);
+    uint32_t *mask_i = mask_u + (U + 31) / 32 + 1;
+    const size_t mask_bytes = (size_t)(((U + 31) / 32) + ((I + 31) / 32) + 2) * 4;
+    int rc = check_hip(hipMemsetAsync(mask_u, 0, mask_bytes, s), "memset(masks)");
+    if (rc) return rc;
+    if (n_max > 0) {
+        hipLaunchKernelGGL(build_masks_kernel, dim3((unsigned)((n_max + 255) / 256)), dim3(256), 0, s, d_active_rows,
+                           d_seg_info, n_max, U, mask_u, mask_i);
+        ELIMREC_LAUNCH_CHECK("build_masks");
+    }
+    const float inv = 1.0f / (float)(L + 1);
+    const int C4 = C / 4, d4 = d / 4;
+    const float *G_u = d_G, *G_i = d_G + (size_t)U * C;
+    const float *H_u = d_H, *H_i = d_H + (size_t)U * d;
+    // ---- wide adjoint: t_L = G_{s(L)}, t_k = G_{s(k)} + B_k t_{k+1}; s(k) = users for odd k. gXI = inv * t_0.
+    {
+        const float *t = (L & 1) ? G_u : G_i;
+        const uint32_t *tmask = (L & 1) ? mask_u : mask_i;     // the raw gradient is row-sparse
+        for (int k = L - 1; k >= 0; --k) {
+            const bool out_items = !(k & 1);
+            float *dst = (k == 0) ? d_gXI : (out_items ? wi : wu);
+            HalfArgs a = half_args(C4, t, tmask, nullptr, out_items ? G_i : G_u, out_items ? mask_i : mask_u, nullptr,
+                                   nullptr, 0, dst, (k == 0) ? inv : 1.0f);
+            if ((rc = launch_half(out_items ? PT : QT, a, 8, s))) return rc;
+            t = dst;
+            tmask = nullptr;
+        }
+    }
+    // ---- narrow adjoint: s'(k) = users for even k. gE_u = inv * t_0.
+    {
+        const float *t = (L & 1) ? H_i : H_u;
+        const uint32_t *tmask = (L & 1) ? mask_i : mask_u;
+        for (int k = L - 1; k >= 0; --k) {
+            const bool out_users = !(k & 1);
+            float *dst = (k == 0) ? d_gEu : (out_users ? au : ai);
+            HalfArgs a = half_args(d4, t, tmask, nullptr, out_users ? H_u : H_i, out_users ? mask_u : mask_i, nullptr,
+                                   nullptr, 0, dst, (k == 0) ? inv : 1.0f);
+            if ((rc = launch_half(out_users ? QT : PT, a, 8, s))) return rc;
+            t = dst;
+            tmask = nullptr;
+        }
+    }
+    return 0;
+}
+
+namespace elimrec {
+__global__ __launch_bounds__(256) void blocksum_rows_kernel(const float *__restrict__ G,
+                                                            const int32_t *__restrict__ active_rows,
+                                                            const int32_t *__restrict__ seg_info, int64_t n_max, int d,
+                                                            int M, float *__restrict__ H) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (s >= n_max || s >= seg_info[0]) return;
+    const int64_t r = active_rows[s];
+    const float4 *g = reinterpret_cast<const float4 *>(G + r * (int64_t)d * M);
+    float4 *h = reinterpret_cast<float4 *>(H + r * (int64_t)d);
+    const int d4 = d / 4;
+    for (int c = lane; c < d4; c += 64) {
+        float4 acc = g[c];
+        for (int m = 1; m < M; ++m) {
+            const float4 x = g[m * d4 + c];
+            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        }
+        h[c] = acc;
+    }
+}
+
+__global__ void copy_cols_kernel(const float *__restrict__ src, int64_t ld_src, float *__restrict__ dst,
+                                 int64_t ld_dst, int64_t n_rows, int n4) {
+    const int64_t total = n_rows * n4;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = t / n4;
+        const int c = (int)(t - r * n4);
+        *reinterpret_cast<float4 *>(dst + r * ld_dst + 4 * c) = *reinterpret_cast<const float4 *>(src + r * ld_src + 4 * c);
+    }
+}
+}  // namespace elimrec
+
+extern "C" int elimrec_blocksum_rows(const float *d_G, const int32_t *d_active_rows, const int32_t *d_seg_info,
+                                     int64_t n_max, int d, int M, float *d_H, void *stream) {
+    ELIMREC_REQUIRE(d_G && d_active_rows && d_seg_info && d_H, "blocksum_rows: null pointer");
+    ELIMREC_REQUIRE(d > 0 && d % 4 == 0 && M >= 1, "blocksum_rows: bad d/M");
+    if (n_max <= 0) return 0;
+    hipLaunchKernelGGL(blocksum_rows_kernel, dim3((unsigned)((n_max + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_G,
+                       d_active_rows, d_seg_info, n_max, d, M, d_H);
+    ELIMREC_LAUNCH_CHECK("blocksum_rows");
+    return 0;
+}
+
+extern "C" int elimrec_copy_cols(const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst, int64_t n_rows,
+                                 int n_cols, void *stream) {
+    ELIMREC_REQUIRE(d_src && d_dst, "copy_cols: null pointer");
+    ELIMREC_REQUIRE(n_cols > 0 && n_cols % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0, "copy_cols: widths must be multiples of 4");
+    if (n_rows <= 0) return 0;
+    const int64_t total = n_rows * (n_cols / 4);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(copy_cols_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_src, ld_src, d_dst,
+                       ld_dst, n_rows, n_cols / 4);
+    ELIMREC_LAUNCH_CHECK("copy_cols");
+    return 0;
+}

@@ -133,6 +133,17 @@ class EliMRec(BasicModel):
         self._adj_symmetric = (abs(adj - adj_t)).nnz == 0
         if not self._adj_symmetric:
             self._register_csr("adjT", adj_t)
+        # Bipartite fast path (csrc/spmm.hip): no user-user / item-item entries (true for 'pre', 'plain', 'gcmc')
+        U = self.num_users
+        self._bipartite = (self.n_layers >= 1 and adj[:U, :U].nnz == 0 and adj[U:, U:].nnz == 0
+                           and not (opt("propagation", "auto") == "full"))
+        if self._bipartite:
+            P, Q = adj[:U, U:].tocsr(), adj[U:, :U].tocsr()
+            self._register_csr("bipP", P)
+            self._register_csr("bipQ", Q)
+            if not self._adj_symmetric:
+                self._register_csr("bipPT", P.T.tocsr())
+                self._register_csr("bipQT", Q.T.tocsr())
 
         # same construction order as the reference (:88-93) so a seeded run draws the same init
         d = self.latent_dim
@@ -147,6 +158,8 @@ class EliMRec(BasicModel):
         self._ws_key = None
 
     def _register_csr(self, name, m):
+        m = m.tocsr()
+        m.sort_indices()
         if m.nnz >= 2 ** 31 or m.shape[0] >= 2 ** 31 - 1:
             raise ValueError("graph too large for int32 CSR")
         self.register_buffer(name + "_rowptr", torch.from_numpy(m.indptr.astype(np.int32)), persistent=False)
@@ -159,8 +172,7 @@ class EliMRec(BasicModel):
         cache = self.__dict__.setdefault("_csr_cache", {})
         hit = cache.get(name)
         if hit is None or hit.rowptr.data_ptr() != rowptr.data_ptr():
-            hit = ops.Csr(rowptr, getattr(self, name + "_col"), getattr(self, name + "_val"),
-                          self.num_users + self.num_items)
+            hit = ops.Csr(rowptr, getattr(self, name + "_col"), getattr(self, name + "_val"), rowptr.numel() - 1)
             if rowptr.is_cuda:
                 hit.build_split(self.C)
             cache[name] = hit
@@ -236,8 +248,13 @@ class EliMRec(BasicModel):
         f32 = dict(dtype=torch.float32, device=dev)
         ws = self._ws if (self._ws is not None and self._ws_key[0] == key[0]) else {}
         if "X0" not in ws:
-            for name in ("X0", "T0", "T1", "Out", "G"):
+            for name in (("X0", "Out") if self._bipartite else ("X0", "T0", "T1", "Out", "G")):
                 ws[name] = torch.empty(N, C, **f32)
+            if self._bipartite:
+                ws["gXI"] = torch.empty(self.num_items, C, **f32)
+                ws["H"] = torch.empty(N, d, **f32)
+                ws["bip_ws"] = torch.empty(ops.bipartite_workspace(self.num_users, self.num_items, d, self.M),
+                                           dtype=torch.uint8, device=dev)
             ws["Y"] = torch.zeros(N, Cy, **f32)
             dmax = max(getattr(self, m + "_feat").shape[1] for m in self._mods)
             nbytes = max(ops.linear_bwd_w_workspace(self.num_items, d, dmax), 1)
@@ -281,11 +298,18 @@ class EliMRec(BasicModel):
         """compute() + gcn_cf() (:228-272,144-153): fills ws['Out'] and ws['Y']."""
         U, I, d, M, C = self.num_users, self.num_items, self.latent_dim, self.M, self.C
         X0, Out, Y = ws["X0"], ws["Out"], ws["Y"]
-        ops.assemble_x0(self.embedding_user.weight, self.embedding_item.weight, X0, M)
+        if self._bipartite:
+            ops.copy_cols(self.embedding_item.weight, X0[U:, :d])          # XI block 0 = item id table
+        else:
+            ops.assemble_x0(self.embedding_user.weight, self.embedding_item.weight, X0, M)
         for k, m in enumerate(self._mods):
             lin = getattr(self, m + "_dense")
             ops.linear_fwd(getattr(self, m + "_feat"), lin.weight, lin.bias, X0[U:, (k + 1) * d:(k + 2) * d])
-        self._propagate(self._csr("adj"), X0, ws["T0"], ws["T1"], Out)
+        if self._bipartite:
+            self._timed(lambda: ops.propagate_bipartite(self._csr("bipP"), self._csr("bipQ"), U, I, d, M, self.n_layers,
+                                                        self.embedding_user.weight, X0[U:], Out, ws["bip_ws"]))
+        else:
+            self._propagate(self._csr("adj"), X0, ws["T0"], ws["T1"], Out)
         wu, wi = self._fusion_weights()
         ops.linear_fwd(Out[:U], wu, self.embedding_user_after_GCN.bias, Y[:U, :d])
         ops.linear_fwd(Out[U:], wi, self.embedding_item_after_GCN.bias, Y[U:, :d])
@@ -295,14 +319,17 @@ class EliMRec(BasicModel):
         self._publish_cache(Y)
 
     def _propagate(self, csr, X0, t0, t1, out):
-        """L fused hops; optionally bracketed by HIP events on the launch stream (bench.py)."""
+        self._timed(lambda: ops.propagate(csr, X0, self.n_layers, t0, t1, out))
+
+    def _timed(self, fn):
+        """Run one propagation (L hops); optionally bracketed by HIP events on the launch stream (bench.py)."""
         prof = getattr(self, "_kernel_events", None)
         if prof is None:
-            ops.propagate(csr, X0, self.n_layers, t0, t1, out)
+            fn()
             return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        ops.propagate(csr, X0, self.n_layers, t0, t1, out)
+        fn()
         e1.record()
         prof.append((e0, e1, self.n_layers))
 
@@ -348,7 +375,8 @@ class EliMRec(BasicModel):
         heads_on = [h for h in range(S) if bw[1 + h] != 0.0]
         wu, wi = self._fusion_weights()
         G0 = ws["X0"]
-        G0.zero_()
+        if not self._bipartite:
+            G0.zero_()      # the bipartite path masks inactive rows instead of reading zeros
         # heads switched off by the modality ablation carry an all-zero gradient block
         ops.head_bwd_input(dY, act, seg, U, d, C, [h + 1 for h in range(S)], wu, wi,
                            [getattr(self, "s_dense_" + m).weight for m in self._mods], 1.0, G0)
@@ -370,17 +398,28 @@ class EliMRec(BasicModel):
                              row_index=act, rng=seg[6:8], colsum=gb)
             grads[name + ".weight"], grads[name + ".bias"] = gw, gb
         # back through the propagation (A^T; A itself when symmetric), then the layer-0 pieces
-        G = ws["G"]
-        self._propagate(self._csr("adj" if self._adj_symmetric else "adjT"), G0, ws["T0"], ws["T1"], G)
         gu = torch.empty(U, d, **f32)
         gi = torch.empty(I, d, **f32)
-        ops.embed_grad(G, U, I, d, M, gu, gi)
+        if self._bipartite:
+            ops.blocksum_rows(G0, act, seg, d, M, ws["H"])
+            sym = self._adj_symmetric
+            PT, QT = self._csr("bipQ" if sym else "bipPT"), self._csr("bipP" if sym else "bipQT")
+            gXI = ws["gXI"]
+            self._timed(lambda: ops.propagate_bipartite_bwd(PT, QT, U, I, d, M, self.n_layers, G0, ws["H"], act, seg,
+                                                            gXI, gu, ws["bip_ws"]))
+            ops.copy_cols(gXI[:, :d], gi)
+            g_items = gXI
+        else:
+            G = ws["G"]
+            self._propagate(self._csr("adj" if self._adj_symmetric else "adjT"), G0, ws["T0"], ws["T1"], G)
+            ops.embed_grad(G, U, I, d, M, gu, gi)
+            g_items = G[U:]
         grads["embedding_user.weight"], grads["embedding_item.weight"] = gu, gi
         for k, m in enumerate(self._mods):
             feat = getattr(self, m + "_feat")
             gw = torch.empty(d, feat.shape[1], **f32)
             gb = torch.empty(d, **f32)
-            ops.linear_bwd_w(G[U:, (k + 1) * d:(k + 2) * d], feat, gw, ws["bwd_w_items"], colsum=gb)
+            ops.linear_bwd_w(g_items[:, (k + 1) * d:(k + 2) * d], feat, gw, ws["bwd_w_items"], colsum=gb)
             grads[m + "_dense.weight"], grads[m + "_dense.bias"] = gw, gb
         return grads
 

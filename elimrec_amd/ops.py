@@ -126,6 +126,12 @@ class Csr:
         self._split_C = C
         return self
 
+    def desc(self):
+        """struct elimrec_csr for the block-CSR entry points (keeps the tensors alive through self)."""
+        sp = self._split if self._split is not None else _lib.CsrSplit(0, 0, 0, None, None, None, None)
+        self._desc = _lib.CsrDesc(self.n_rows, self.rowptr.data_ptr(), self.col.data_ptr(), self.val.data_ptr(), sp)
+        return ctypes.byref(self._desc)
+
     def split_ref(self, C):
         if self._split is None:
             return None
@@ -151,6 +157,46 @@ def propagate(csr, X0, L, tmp0, tmp1, out):
                                              _dev(tmp0, "tmp0"), _dev(tmp1, "tmp1"), _dev(out, "out"), _stream()),
                "propagate")
     return out
+
+
+def bipartite_workspace(U, I, d, M):
+    return int(_lib.load().elimrec_bipartite_workspace(U, I, d, M))
+
+
+def propagate_bipartite(P, Q, U, I, d, M, L, user_emb, XI, out, workspace):
+    assert user_emb.is_contiguous() and XI.is_contiguous() and out.is_contiguous()
+    assert XI.shape == (I, d * M) and out.shape == (U + I, d * M) and user_emb.shape == (U, d)
+    _lib.check(_lib.load().elimrec_propagate_bipartite(P.desc(), Q.desc(), U, I, d, M, L, _dev(user_emb, "user_emb"),
+                                                       _dev(XI, "XI"), _dev(out, "out"),
+                                                       _dev(workspace, "workspace", torch.uint8), workspace.numel(),
+                                                       _stream()), "propagate_bipartite")
+    return out
+
+
+def propagate_bipartite_bwd(PT, QT, U, I, d, M, L, G, H, active_rows, seg_info, gXI, gEu, workspace):
+    assert G.is_contiguous() and H.is_contiguous() and gXI.is_contiguous() and gEu.is_contiguous()
+    assert G.shape == (U + I, d * M) and H.shape == (U + I, d) and gXI.shape == (I, d * M) and gEu.shape == (U, d)
+    _lib.check(_lib.load().elimrec_propagate_bipartite_bwd(PT.desc(), QT.desc(), U, I, d, M, L, _dev(G, "G"), _dev(H, "H"),
+                                                           _dev(active_rows, "active_rows", torch.int32),
+                                                           _dev(seg_info, "seg_info", torch.int32), active_rows.numel(),
+                                                           _dev(gXI, "gXI"), _dev(gEu, "gEu"),
+                                                           _dev(workspace, "workspace", torch.uint8), workspace.numel(),
+                                                           _stream()), "propagate_bipartite_bwd")
+
+
+def blocksum_rows(G, active_rows, seg_info, d, M, H):
+    assert G.is_contiguous() and H.is_contiguous()
+    _lib.check(_lib.load().elimrec_blocksum_rows(_dev(G, "G"), _dev(active_rows, "active_rows", torch.int32),
+                                                 _dev(seg_info, "seg_info", torch.int32), active_rows.numel(), d, M,
+                                                 _dev(H, "H"), _stream()), "blocksum_rows")
+
+
+def copy_cols(src, dst):
+    s, lds = _rowmajor(src, "src")
+    t, ldt = _rowmajor(dst, "dst")
+    assert src.shape == dst.shape
+    _lib.check(_lib.load().elimrec_copy_cols(s, lds, t, ldt, src.shape[0], src.shape[1], _stream()), "copy_cols")
+    return dst
 
 
 def bpr_head(Y, U, I, users, pos, neg, d, block_weights, loss_rows, grad_rows=None, keys=None):

@@ -94,12 +94,55 @@ int elimrec_spmm_hop(const int32_t *d_rowptr, const int32_t *d_col, const float 
                      const float *d_Xin, float *d_Xout,
                      const float *d_AccIn, float *d_AccOut, float scale, void *stream);
 
+typedef struct elimrec_csr {
+    int64_t n_rows;
+    const int32_t *d_rowptr;        /* [n_rows+1] */
+    const int32_t *d_col;
+    const float *d_val;
+    elimrec_csr_split split;        /* n_long == 0 => no row-split plan */
+} elimrec_csr;
+
 /* L hops + mean of the L+1 layer outputs: Out = 1/(L+1) * sum_k A^k X0   (compute_graph,
  * models/EliMRec.py:238-248, for all M tables at once). d_tmp0/d_tmp1: two [n_rows x C]
  * scratch tables (unused when L <= 1 / L <= 2). X0 is left intact. Out must not alias X0. */
 int elimrec_propagate(const int32_t *d_rowptr, const int32_t *d_col, const float *d_val,
                       int64_t n_rows, int C, const elimrec_csr_split *split /* nullable */, int L,
                       const float *d_X0, float *d_tmp0, float *d_tmp1, float *d_Out, void *stream);
+
+/* Bipartite form of the same propagation, for adjacencies without a diagonal ('pre', 'plain',
+ * 'gcmc': A = [[0, P], [Q, 0]], P = users<-items [U x I], Q = items<-users [I x U], column ids
+ * local to the source side). The layer-0 table is [E_u ; XI] with the user rows shared by all M
+ * tables (models/EliMRec.py:250-256), so layer k splits into a C-column chain alive on one side and
+ * a d-column chain (identical for every table) alive on the other: each hop costs nnz/2 edges at C
+ * columns + nnz/2 at d columns instead of nnz at C. Results are identical to elimrec_propagate:
+ *   Out[N x C] = 1/(L+1) * sum_k A^k [bcast(E_u) ; XI].          Requires L >= 1.
+ * workspace: elimrec_bipartite_workspace(U, I, d, M) bytes (shared by forward and backward). */
+size_t elimrec_bipartite_workspace(int64_t U, int64_t I, int d, int M);
+int elimrec_propagate_bipartite(const elimrec_csr *P, const elimrec_csr *Q, int64_t U, int64_t I,
+                                int d, int M, int L, const float *d_user_emb /* [U x d] */,
+                                const float *d_XI /* [I x C] */, float *d_Out /* [N x C] */,
+                                void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Its adjoint (SparseAddmmBackward x L, StackBackward/MeanBackward, CatBackward of the reference's
+ * autograd): from G = dLoss/dOut [N x C], non-zero only on the rows listed in d_active_rows
+ * (first d_seg_info[0] entries; other rows of G are never read, so G need not be zero-filled) and
+ * H[r, :] = sum_m G[r, m*d:(m+1)*d] on those rows, computes
+ *   gXI [I x C] = dLoss/dXI   and   gE_u [U x d] = dLoss/dE_u.
+ * PT = P^T [I x U], QT = Q^T [U x I] (for a symmetric adjacency PT == Q and QT == P). */
+int elimrec_propagate_bipartite_bwd(const elimrec_csr *PT, const elimrec_csr *QT, int64_t U, int64_t I,
+                                    int d, int M, int L, const float *d_G, const float *d_H,
+                                    const int32_t *d_active_rows, const int32_t *d_seg_info,
+                                    int64_t n_max, float *d_gXI, float *d_gEu, void *d_workspace,
+                                    size_t workspace_bytes, void *stream);
+
+/* H[r, j] = sum_m G[r, m*d + j] for the active rows r (slots < d_seg_info[0]). */
+int elimrec_blocksum_rows(const float *d_G, const int32_t *d_active_rows, const int32_t *d_seg_info,
+                          int64_t n_max, int d, int M, float *d_H, void *stream);
+
+/* dst[r, 0:n_cols] = src[r, 0:n_cols] with independent leading dimensions (column-block copies:
+ * E_item into block 0 of XI; block 0 of gXI into the embedding_item gradient). n_cols % 4 == 0. */
+int elimrec_copy_cols(const float *d_src, int64_t ld_src, float *d_dst, int64_t ld_dst, int64_t n_rows,
+                      int n_cols, void *stream);
 
 /* ---------------------------------------------------------------- cosine-BPR head (K7,K9,K10)
  * For triplet b and head block k (weight w[k]; w[k] == 0 skips the block):
