@@ -155,6 +155,11 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const float *__restric
 constexpr int kMaxHeads = 4;
 struct HeadPtrs { const float *w[kMaxHeads]; int mblock[kMaxHeads]; };
 
+// A workgroup owns HB_ROWS active rows: their dY rows are staged in LDS once, every thread owns one
+// output column (of each 256-column chunk) for all rows, so a weight element is loaded once per
+// workgroup column and reused HB_ROWS times; dY values are LDS broadcasts.
+constexpr int HB_ROWS = 16;
+
 __global__ __launch_bounds__(256) void head_bwd_input_kernel(const float *__restrict__ dY, int64_t lddy,
                                                              const int32_t *__restrict__ active_rows,
                                                              const int32_t *__restrict__ seg_info, int64_t n_max,
@@ -162,31 +167,59 @@ __global__ __launch_bounds__(256) void head_bwd_input_kernel(const float *__rest
                                                              const float *__restrict__ W_user,
                                                              const float *__restrict__ W_item, float gscale,
                                                              float *__restrict__ G0) {
-    const int lane = threadIdx.x & 63;
-    const int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (s >= n_max || s >= seg_info[0]) return;
-    const int64_t r = active_rows[s];
-    const float *Wf = (r < U) ? W_user : W_item;
-    const float *dy = dY + s * lddy;
-    for (int c = lane * 4; c < C; c += 256) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < d; ++k) {
-            const float g = dy[k];
-            const float4 w = ld4(Wf + (int64_t)k * C + c);
-            acc.x = fmaf(g, w.x, acc.x); acc.y = fmaf(g, w.y, acc.y); acc.z = fmaf(g, w.z, acc.z); acc.w = fmaf(g, w.w, acc.w);
-        }
-        const int mb = c / d;            // table block this column belongs to
-        for (int h = 0; h < S; ++h) {
-            if (hp.mblock[h] != mb) continue;
-            const int cc = c - mb * d;
-            const float *dyh = dy + (1 + h) * d;
+    extern __shared__ float dys[];                       // [HB_ROWS][Cy]
+    __shared__ int64_t node[HB_ROWS];
+    const int Cy = (1 + S) * d;
+    const int tid = threadIdx.x;
+    const int64_t s0 = (int64_t)blockIdx.x * HB_ROWS;
+    int64_t n_act = seg_info[0];
+    if (n_act > n_max) n_act = n_max;
+    if (s0 >= n_act) return;
+    const int rows = (int)((n_act - s0) < HB_ROWS ? (n_act - s0) : HB_ROWS);
+    for (int e = tid * 4; e < HB_ROWS * Cy; e += 1024) {
+        const int r = e / Cy, c = e - r * Cy;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < rows) v = ld4(dY + (s0 + r) * lddy + c);
+        st4(dys + r * Cy + c, v);
+    }
+    if (tid < HB_ROWS) node[tid] = (tid < rows) ? (int64_t)active_rows[s0 + tid] : -1;
+    __syncthreads();
+    const bool any_user = node[0] < U;                   // rows are sorted by node id: users first
+    const bool any_item = node[rows - 1] >= U;
+    for (int c = tid; c < C; c += 256) {
+        float acc[HB_ROWS];
+#pragma unroll
+        for (int r = 0; r < HB_ROWS; ++r) acc[r] = 0.f;
+        if (any_user != any_item) {                      // the common case: one weight matrix for the whole tile
+            const float *Wf = any_user ? W_user : W_item;
+#pragma unroll 4
             for (int k = 0; k < d; ++k) {
-                const float g = dyh[k];
-                const float4 w = ld4(hp.w[h] + (int64_t)k * d + cc);
-                acc.x = fmaf(g, w.x, acc.x); acc.y = fmaf(g, w.y, acc.y); acc.z = fmaf(g, w.z, acc.z); acc.w = fmaf(g, w.w, acc.w);
+                const float w = Wf[(int64_t)k * C + c];
+#pragma unroll
+                for (int r = 0; r < HB_ROWS; ++r) acc[r] = fmaf(dys[r * Cy + k], w, acc[r]);
+            }
+        } else {                                         // the one tile that straddles the user/item boundary
+            for (int k = 0; k < d; ++k) {
+                const float wu = W_user[(int64_t)k * C + c], wi = W_item[(int64_t)k * C + c];
+#pragma unroll
+                for (int r = 0; r < HB_ROWS; ++r) acc[r] = fmaf(dys[r * Cy + k], (node[r] < U) ? wu : wi, acc[r]);
             }
         }
-        st4(G0 + r * C + c, make_float4(acc.x * gscale, acc.y * gscale, acc.z * gscale, acc.w * gscale));
+        const int mb = c / d;                            // table block of this column
+        for (int h = 0; h < S; ++h) {
+            if (hp.mblock[h] != mb) continue;
+            const float *Wh = hp.w[h] + (c - mb * d);
+            const float *dyh = dys + (1 + h) * d;
+#pragma unroll 4
+            for (int k = 0; k < d; ++k) {
+                const float w = Wh[(int64_t)k * d];
+#pragma unroll
+                for (int r = 0; r < HB_ROWS; ++r) acc[r] = fmaf(dyh[r * Cy + k], w, acc[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < HB_ROWS; ++r)
+            if (r < rows) G0[node[r] * C + c] = acc[r] * gscale;
     }
 }
 
@@ -305,9 +338,12 @@ extern "C" int elimrec_head_bwd_input(const float *d_dY, int64_t lddy, const int
         hp.mblock[h] = h < S ? head_mblock[h] : -1;
     }
     if (n_max <= 0) return 0;
-    hipLaunchKernelGGL(head_bwd_input_kernel, dim3((unsigned)((n_max + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
-                       d_dY, lddy, d_active_rows, d_seg_info, n_max, U, d, C, S, hp, d_W_user, d_W_item, gscale,
-                       d_G0);
+    const size_t lds = (size_t)HB_ROWS * (1 + S) * d * sizeof(float);
+    ELIMREC_REQUIRE(lds <= 128 * 1024, "head_bwd_input: (1+S)*d too large for the LDS tile");
+    ELIMREC_REQUIRE(lddy % 4 == 0, "head_bwd_input: lddy must be a multiple of 4");
+    hipLaunchKernelGGL(head_bwd_input_kernel, dim3((unsigned)((n_max + HB_ROWS - 1) / HB_ROWS)), dim3(256), lds,
+                       (hipStream_t)stream, d_dY, lddy, d_active_rows, d_seg_info, n_max, U, d, C, S, hp, d_W_user,
+                       d_W_item, gscale, d_G0);
     ELIMREC_LAUNCH_CHECK("head_bwd_input");
     return 0;
 }

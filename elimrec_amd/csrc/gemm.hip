@@ -25,8 +25,10 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
                                                          const float *__restrict__ bias,
                                                          float *__restrict__ C, int64_t ldc,
                                                          int64_t M, int N, int K) {
-    __shared__ float As[FBM * FLD];
-    __shared__ float Bs[FBN * FLD];
+    // two LDS stages: the global loads of K-chunk t+1 are in flight (in registers) while chunk t
+    // feeds the MFMAs; one barrier per chunk.
+    __shared__ float As[2][FBM * FLD];
+    __shared__ float Bs[2][FBN * FLD];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -37,31 +39,44 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
 
     v16f acc0 = {0}, acc1 = {0};
     const int ai = lane & 31, ak = lane >> 5;
-
-    for (int k0 = 0; k0 < K; k0 += FBK) {
+    float4 ra[4], rb[2];
+    auto load_chunk = [&](int k0) {
         const bool kin = (k0 + lc) < K;  // K % 4 == 0: the whole float4 is in or out
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = lr + 32 * i;
-            const int64_t gr = m0 + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kin && gr < M) v = *reinterpret_cast<const float4 *>(A + gr * lda + k0 + lc);
-            float *dst = As + r * FLD + lc;
-            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            const int64_t gr = m0 + lr + 32 * i;
+            ra[i] = (kin && gr < M) ? *reinterpret_cast<const float4 *>(A + gr * lda + k0 + lc)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int r = lr + 32 * i;
-            const int gn = n0 + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kin && gn < N) v = *reinterpret_cast<const float4 *>(W + (int64_t)gn * ldw + k0 + lc);
-            float *dst = Bs + r * FLD + lc;
-            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            const int gn = n0 + lr + 32 * i;
+            rb[i] = (kin && gn < N) ? *reinterpret_cast<const float4 *>(W + (int64_t)gn * ldw + k0 + lc)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        __syncthreads();
-        const float *ap = As + (wave * 32 + ai) * FLD + ak;
-        const float *bp0 = Bs + ai * FLD + ak;
-        const float *bp1 = Bs + (32 + ai) * FLD + ak;
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float *dst = &As[buf][(lr + 32 * i) * FLD + lc];
+            dst[0] = ra[i].x; dst[1] = ra[i].y; dst[2] = ra[i].z; dst[3] = ra[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float *dst = &Bs[buf][(lr + 32 * i) * FLD + lc];
+            dst[0] = rb[i].x; dst[1] = rb[i].y; dst[2] = rb[i].z; dst[3] = rb[i].w;
+        }
+    };
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += FBK) {
+        const bool more = (k0 + FBK) < K;
+        if (more) load_chunk(k0 + FBK);
+        const float *ap = &As[buf][(wave * 32 + ai) * FLD + ak];
+        const float *bp0 = &Bs[buf][ai * FLD + ak];
+        const float *bp1 = &Bs[buf][(32 + ai) * FLD + ak];
 #pragma unroll
         for (int kk = 0; kk < FBK; kk += 2) {
             const float a = ap[kk];
@@ -70,7 +85,9 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
         }
+        if (more) store_chunk(buf ^ 1);
         __syncthreads();
+        buf ^= 1;
     }
 
     const int col0 = n0 + (lane & 31);

@@ -248,6 +248,7 @@ class EliMRec(BasicModel):
         f32 = dict(dtype=torch.float32, device=dev)
         ws = self._ws if (self._ws is not None and self._ws_key[0] == key[0]) else {}
         if "X0" not in ws:
+            self._flatten_parameters(ws)
             for name in (("X0", "Out") if self._bipartite else ("X0", "T0", "T1", "Out", "G")):
                 ws[name] = torch.empty(N, C, **f32)
             if self._bipartite:
@@ -272,6 +273,26 @@ class EliMRec(BasicModel):
         ws["bwd_w_rows"] = torch.empty(max(ops.linear_bwd_w_workspace(n3, d, C), 1), dtype=torch.uint8, device=dev)
         self._ws, self._ws_key = ws, key
         return ws
+
+    def _flatten_parameters(self, ws):
+        """Re-point every parameter into ONE contiguous fp32 buffer (same Parameter objects, so an
+        optimizer created earlier stays valid) and lay the gradients out the same way: the dense Adam
+        update over all 18 tensors then becomes a single launch (optim.FusedAdam merges adjacent
+        tensors)."""
+        params = list(self.named_parameters())
+        dev = self._device()
+        sizes = [(p.numel() + 3) // 4 * 4 for _, p in params]          # keep every tensor 16-B aligned
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+        flat_grad = torch.zeros_like(flat)
+        views, off = {}, 0
+        with torch.no_grad():
+            for (name, p), n in zip(params, sizes):
+                dst = flat[off:off + p.numel()].view_as(p)
+                dst.copy_(p.data)
+                p.data = dst
+                views[name] = flat_grad[off:off + p.numel()].view_as(p)
+                off += n
+        ws["flat_param"], ws["flat_grad"], ws["grad_views"] = flat, flat_grad, views
 
     def _fusion_weights(self):
         """[d x C] fusion weights as the kernels consume them. 'mean' fusion (mean over the M
@@ -383,23 +404,23 @@ class EliMRec(BasicModel):
         grads = {}
         f32 = dict(dtype=torch.float32, device=dev)
         # fusion Linears: dW = dY_f^T . Out[active rows], user slots / item slots separately
+        gv = ws["grad_views"]
         for name, rng in (("embedding_user_after_GCN", seg[2:4]), ("embedding_item_after_GCN", seg[4:6])):
-            gw = torch.empty(d, C, **f32)
-            gb = torch.empty(d, **f32)
+            concat = self.mm_fusion_mode == "concat"
+            gw = gv[name + ".weight"] if concat else torch.empty(d, C, **f32)
+            gb = gv[name + ".bias"]
             ops.linear_bwd_w(dY[:, :d], ws["Out"], gw, ws["bwd_w_rows"], row_index=act, rng=rng, colsum=gb)
-            if self.mm_fusion_mode == "mean":
-                gw = gw.view(d, M, d).sum(1) / M
+            if not concat:
+                gw = gv[name + ".weight"].copy_(gw.view(d, M, d).sum(1) / M)
             grads[name + ".weight"], grads[name + ".bias"] = gw, gb
         for h in heads_on:
             name = "s_dense_" + self._mods[h]
-            gw = torch.empty(d, d, **f32)
-            gb = torch.empty(d, **f32)
+            gw, gb = gv[name + ".weight"], gv[name + ".bias"]
             ops.linear_bwd_w(dY[:, (h + 1) * d:(h + 2) * d], ws["Out"][:, (h + 1) * d:(h + 2) * d], gw, ws["bwd_w_rows"],
                              row_index=act, rng=seg[6:8], colsum=gb)
             grads[name + ".weight"], grads[name + ".bias"] = gw, gb
         # back through the propagation (A^T; A itself when symmetric), then the layer-0 pieces
-        gu = torch.empty(U, d, **f32)
-        gi = torch.empty(I, d, **f32)
+        gu, gi = gv["embedding_user.weight"], gv["embedding_item.weight"]
         if self._bipartite:
             ops.blocksum_rows(G0, act, seg, d, M, ws["H"])
             sym = self._adj_symmetric
@@ -417,8 +438,7 @@ class EliMRec(BasicModel):
         grads["embedding_user.weight"], grads["embedding_item.weight"] = gu, gi
         for k, m in enumerate(self._mods):
             feat = getattr(self, m + "_feat")
-            gw = torch.empty(d, feat.shape[1], **f32)
-            gb = torch.empty(d, **f32)
+            gw, gb = gv[m + "_dense.weight"], gv[m + "_dense.bias"]
             ops.linear_bwd_w(g_items[:, (k + 1) * d:(k + 2) * d], feat, gw, ws["bwd_w_items"], colsum=gb)
             grads[m + "_dense.weight"], grads[m + "_dense.bias"] = gw, gb
         return grads

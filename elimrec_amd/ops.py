@@ -258,6 +258,12 @@ def adam_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
                                              int(step), _stream()), "adam_step")
 
 
+def adam_step_raw(p_ptr, g_ptr, m_ptr, v_ptr, n, lr, beta1, beta2, eps, weight_decay, step):
+    """Same kernel on raw device addresses (a span covering several adjacent tensors)."""
+    _lib.check(_lib.load().elimrec_adam_step(p_ptr, g_ptr, m_ptr, v_ptr, int(n), float(lr), float(beta1), float(beta2),
+                                             float(eps), float(weight_decay), int(step), _stream()), "adam_step")
+
+
 def score_workspace(B, I, K):
     return int(_lib.load().elimrec_score_workspace(B, I, K))
 

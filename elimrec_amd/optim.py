@@ -6,28 +6,69 @@ from . import ops
 
 class FusedAdam(torch.optim.Optimizer):
     """Drop-in for `optim.Adam(params, lr, weight_decay)`; parameters without a gradient are
-    skipped (no decay, no moment update, step count untouched), as torch does."""
+    skipped (no decay, no moment update, step count untouched), as torch does.
+
+    Launch merging: when consecutive parameters (and their gradients) sit back to back in memory --
+    EliMRec lays its parameters and gradients out in one flat buffer each -- and share the same step
+    count, they are updated by ONE kernel launch over the contiguous span; the moments are kept in
+    flat buffers that mirror the parameter storage so they are contiguous too."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._mirror = {}     # storage data_ptr -> (exp_avg_flat, exp_avg_sq_flat)
+
+    def _state_for(self, p):
+        st = self.state[p]
+        if st:
+            return st
+        st["step"] = 0
+        storage = p.untyped_storage()
+        nfloat = storage.nbytes() // 4
+        if p.is_contiguous() and nfloat > p.numel():
+            # p is a view into a larger flat buffer: mirror the whole buffer once
+            key = storage.data_ptr()
+            if key not in self._mirror:
+                self._mirror[key] = (torch.zeros(nfloat, dtype=torch.float32, device=p.device),
+                                     torch.zeros(nfloat, dtype=torch.float32, device=p.device))
+            m, v = self._mirror[key]
+            off = p.storage_offset()
+            st["exp_avg"] = m[off:off + p.numel()].view_as(p)
+            st["exp_avg_sq"] = v[off:off + p.numel()].view_as(p)
+        else:
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+        return st
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         for group in self.param_groups:
             b1, b2 = group["betas"]
+            run = None      # [p_ptr, g_ptr, m_ptr, v_ptr, numel, step, tensors...]
+            def flush(r):
+                if r is not None:
+                    ops.adam_step_raw(r["p"], r["g"], r["m"], r["v"], r["n"], group["lr"], b1, b2, group["eps"],
+                                      group["weight_decay"], r["step"])
             for p in group["params"]:
                 if p.grad is None:
                     continue
                 if not p.is_cuda:
                     raise RuntimeError("FusedAdam: parameters must be on a HIP device (no CPU fallback)")
-                st = self.state[p]
-                if not st:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st = self._state_for(p)
                 st["step"] += 1
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                ops.adam_step(p.data, g, st["exp_avg"], st["exp_avg_sq"], group["lr"], b1, b2, group["eps"],
-                              group["weight_decay"], st["step"])
+                if not p.is_contiguous():
+                    raise RuntimeError("FusedAdam: parameters must be contiguous")
+                ptrs = (p.data_ptr(), g.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr())
+                n = p.numel()
+                if run is not None and run["step"] == st["step"] and all(
+                        0 <= ptrs[i] - (run[k] + 4 * run["n"]) <= 12 and (ptrs[i] - run[k]) % 4 == 0
+                        and ptrs[i] - (run[k] + 4 * run["n"]) == ptrs[0] - (run["p"] + 4 * run["n"])
+                        for i, k in enumerate(("p", "g", "m", "v"))):
+                    run["n"] = (ptrs[0] - run["p"]) // 4 + n      # swallow the (zero) alignment padding
+                    run["keep"].append(g)
+                else:
+                    flush(run)
+                    run = dict(p=ptrs[0], g=ptrs[1], m=ptrs[2], v=ptrs[3], n=n, step=st["step"], keep=[g])
+            flush(run)
         return loss
