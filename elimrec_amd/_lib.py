@@ -26,6 +26,21 @@ class CsrDesc(ctypes.Structure):
                 ("d_val", ctypes.c_void_p), ("split", CsrSplit)]
 
 
+class LinearDesc(ctypes.Structure):
+    """struct elimrec_linear_desc."""
+    _fields_ = [("d_A", ctypes.c_void_p), ("lda", ctypes.c_int64), ("d_W", ctypes.c_void_p), ("ldw", ctypes.c_int64),
+                ("d_bias", ctypes.c_void_p), ("d_C", ctypes.c_void_p), ("ldc", ctypes.c_int64), ("M", ctypes.c_int64),
+                ("N", ctypes.c_int32), ("K", ctypes.c_int32)]
+
+
+class LinearBwdDesc(ctypes.Structure):
+    """struct elimrec_linear_bwd_desc."""
+    _fields_ = [("d_A", ctypes.c_void_p), ("lda", ctypes.c_int64), ("d_B", ctypes.c_void_p), ("ldb", ctypes.c_int64),
+                ("d_row_index", ctypes.c_void_p), ("d_range", ctypes.c_void_p), ("R", ctypes.c_int64),
+                ("n1", ctypes.c_int32), ("n2", ctypes.c_int32), ("d_out", ctypes.c_void_p), ("ldo", ctypes.c_int64),
+                ("d_colsum", ctypes.c_void_p), ("accumulate", ctypes.c_int32)]
+
+
 c_split = ctypes.POINTER(CsrSplit)
 c_csr = ctypes.POINTER(CsrDesc)
 
@@ -34,6 +49,9 @@ SIGNATURES = {
     "elimrec_abi_version": (c_i32, []),
     "elimrec_last_error": (ctypes.c_char_p, []),
     "elimrec_linear_fwd": (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i32, c_i32, c_ptr]),
+    "elimrec_linear_fwd_batched": (c_i32, [ctypes.POINTER(LinearDesc), c_i32, c_ptr]),
+    "elimrec_linear_bwd_w_batched_workspace": (c_size, [ctypes.POINTER(LinearBwdDesc), c_i32]),
+    "elimrec_linear_bwd_w_batched": (c_i32, [ctypes.POINTER(LinearBwdDesc), c_i32, c_ptr, c_size, c_ptr]),
     "elimrec_linear_bwd_w_workspace": (c_size, [c_i64, c_i32, c_i32]),
     "elimrec_linear_bwd_w": (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_i64,
                                      c_ptr, c_i32, c_ptr, c_size, c_ptr]),

@@ -20,11 +20,20 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 // (row stride 33 floats: the 32 lanes of a half-wave read 32 different rows at the same k).
 constexpr int FBM = 128, FBN = 64, FBK = 32, FLD = FBK + 1;
 
-__global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict__ A, int64_t lda,
-                                                         const float *__restrict__ W, int64_t ldw,
-                                                         const float *__restrict__ bias,
-                                                         float *__restrict__ C, int64_t ldc,
-                                                         int64_t M, int N, int K) {
+constexpr int kMaxBatch = 8;
+struct FwdBatch { elimrec_linear_desc p[kMaxBatch]; };
+
+// blockIdx.z selects the problem: independent Linears (the three feature projections; the five head
+// Linears) share one launch so the grid fills the chip.
+__global__ __launch_bounds__(256) void linear_fwd_kernel(FwdBatch batch) {
+    const elimrec_linear_desc &pd = batch.p[blockIdx.z];
+    const float *__restrict__ A = pd.d_A;
+    const float *__restrict__ W = pd.d_W;
+    const float *__restrict__ bias = pd.d_bias;
+    float *__restrict__ C = pd.d_C;
+    const int64_t lda = pd.lda, ldw = pd.ldw, ldc = pd.ldc, M = pd.M;
+    const int N = pd.N, K = pd.K;
+    if ((int64_t)blockIdx.x * FBM >= M || blockIdx.y * FBN >= N) return;
     // two LDS stages: the global loads of K-chunk t+1 are in flight (in registers) while chunk t
     // feeds the MFMAs; one barrier per chunk.
     __shared__ float As[2][FBM * FLD];
@@ -115,20 +124,39 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float *__restrict
 // (reduce_slabs_kernel), so the result is bitwise reproducible.
 constexpr int TN1 = 64, TN2 = 128, TRB = 32;
 
-__global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(
-    const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
-    const int32_t *__restrict__ row_index, const int32_t *__restrict__ range, int64_t R, int n1, int n2,
-    int chunk_rows, float *__restrict__ slabs, float *__restrict__ colsum_slabs) {
+struct BwdProblem {
+    elimrec_linear_bwd_desc d;
+    int chunk_rows, chunks, t1, t2;       // decomposition
+    int first_block;                      // prefix of (chunks * t1 * t2) over the problems before this one
+    float *slabs, *cslabs;
+};
+struct BwdBatch { BwdProblem p[kMaxBatch]; int n; };
+
+__global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(BwdBatch batch) {
     __shared__ float As[2][TRB * TN1];
     __shared__ float Bs[2][TRB * TN2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int chunk = blockIdx.x;
-    const int n1_tiles = gridDim.y, n2_tiles = gridDim.z;
+    int pi = 0;
+    while (pi + 1 < batch.n && (int)blockIdx.x >= batch.p[pi + 1].first_block) ++pi;
+    const BwdProblem &pb = batch.p[pi];
+    const int local = blockIdx.x - pb.first_block;
+    const int n1_tiles = pb.t1, n2_tiles = pb.t2;
+    const int chunk = local / (n1_tiles * n2_tiles);
+    const int tile = local - chunk * (n1_tiles * n2_tiles);
+    const int tile_y = tile / n2_tiles, tile_z = tile - tile_y * n2_tiles;
+    const float *__restrict__ A = pb.d.d_A;
+    const float *__restrict__ B = pb.d.d_B;
+    const int32_t *__restrict__ row_index = pb.d.d_row_index;
+    const int32_t *__restrict__ range = pb.d.d_range;
+    const int64_t lda = pb.d.lda, ldb = pb.d.ldb, R = pb.d.R;
+    const int n1 = pb.d.n1, n2 = pb.d.n2, chunk_rows = pb.chunk_rows;
+    float *__restrict__ slabs = pb.slabs;
+    float *__restrict__ colsum_slabs = pb.d.d_colsum ? pb.cslabs : nullptr;
     int64_t rb = 0, re = R;
     if (range) { rb = range[0]; re = range[1]; }
     const int64_t r0 = rb + (int64_t)chunk * chunk_rows;
     const int64_t r1 = (r0 + chunk_rows < re) ? r0 + chunk_rows : re;
-    const int i_base = blockIdx.y * TN1, j_base = blockIdx.z * TN2;
+    const int i_base = tile_y * TN1, j_base = tile_z * TN2;
 
     // loader geometry: A block = 32 rows x 16 float4 (2 per thread); B block = 32 rows x 32 float4 (4 per thread)
     const int a_row = tid >> 4, a_c4 = tid & 15;          // + 16 rows on the second pass
@@ -201,31 +229,32 @@ __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(
         slab[(size_t)row * n2_pad + j_base + wj + li] = acc0[r];
         slab[(size_t)row * n2_pad + j_base + wj + 32 + li] = acc1[r];
     }
-    if (colsum_slabs && blockIdx.z == 0 && tid < TN1) colsum_slabs[(size_t)chunk * n1_pad + i_base + tid] = csum;
+    if (colsum_slabs && tile_z == 0 && tid < TN1) colsum_slabs[(size_t)chunk * n1_pad + i_base + tid] = csum;
 }
 
 // out[e] (+)= sum over chunks of slab[chunk][e], chunk order fixed; 4 chunks kept in flight.
-__global__ void reduce_slabs_kernel(const float *__restrict__ slabs, const float *__restrict__ cslabs,
-                                    const int32_t *__restrict__ range, int64_t R, int chunk_rows, int n1, int n2,
-                                    int n1_pad, int n2_pad, float *__restrict__ out, int64_t ldo,
-                                    float *__restrict__ colsum, int accumulate) {
+// blockIdx.y selects the problem.
+__global__ void reduce_slabs_kernel(BwdBatch batch) {
+    const BwdProblem &pb = batch.p[blockIdx.y];
+    const int n1 = pb.d.n1, n2 = pb.d.n2;
+    const int n1_pad = pb.t1 * TN1, n2_pad = pb.t2 * TN2;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = n1 * n2;
-    int64_t rows = range ? (int64_t)range[1] - range[0] : R;
+    int64_t rows = pb.d.d_range ? (int64_t)pb.d.d_range[1] - pb.d.d_range[0] : pb.d.R;
     if (rows < 0) rows = 0;
-    const int chunks = (int)((rows + chunk_rows - 1) / chunk_rows);
+    const int chunks = (int)((rows + pb.chunk_rows - 1) / pb.chunk_rows);
     const float *src;
     size_t stride;
     float *dst;
     if (idx < total) {
         const int i = idx / n2, j = idx - i * n2;
-        src = slabs + (size_t)i * n2_pad + j;
+        src = pb.slabs + (size_t)i * n2_pad + j;
         stride = (size_t)n1_pad * n2_pad;
-        dst = out + (int64_t)i * ldo + j;
-    } else if (colsum && idx < total + n1) {
-        src = cslabs + (idx - total);
+        dst = pb.d.d_out + (int64_t)i * pb.d.ldo + j;
+    } else if (pb.d.d_colsum && idx < total + n1) {
+        src = pb.cslabs + (idx - total);
         stride = (size_t)n1_pad;
-        dst = colsum + (idx - total);
+        dst = pb.d.d_colsum + (idx - total);
     } else {
         return;
     }
@@ -237,67 +266,110 @@ __global__ void reduce_slabs_kernel(const float *__restrict__ slabs, const float
         s += v0; s += v1; s += v2; s += v3;
     }
     for (; c < chunks; ++c) s += src[(size_t)c * stride];
-    *dst = accumulate ? (*dst + s) : s;
+    *dst = pb.d.accumulate ? (*dst + s) : s;
 }
 
 }  // namespace elimrec
 
 using namespace elimrec;
 
-extern "C" int elimrec_linear_fwd(const float *d_A, int64_t lda, const float *d_W, int64_t ldw,
-                                  const float *d_bias, float *d_C, int64_t ldc, int64_t M, int N, int K,
-                                  void *stream) {
-    ELIMREC_REQUIRE(d_A && d_W && d_C, "linear_fwd: null pointer");
-    ELIMREC_REQUIRE(M >= 0 && N > 0 && K > 0, "linear_fwd: bad shape M=%lld N=%d K=%d", (long long)M, N, K);
-    ELIMREC_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0, "linear_fwd: K, lda, ldw must be multiples of 4");
-    ELIMREC_REQUIRE(((uintptr_t)d_A % 16) == 0 && ((uintptr_t)d_W % 16) == 0, "linear_fwd: A and W must be 16-byte aligned");
-    if (M == 0) return 0;
-    dim3 grid((unsigned)((M + FBM - 1) / FBM), (unsigned)((N + FBN - 1) / FBN));
-    hipLaunchKernelGGL(linear_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_A, lda, d_W, ldw, d_bias, d_C,
-                       ldc, M, N, K);
+extern "C" int elimrec_linear_fwd_batched(const elimrec_linear_desc *descs, int n, void *stream) {
+    ELIMREC_REQUIRE(descs && n >= 1 && n <= kMaxBatch, "linear_fwd_batched: 1..%d problems", kMaxBatch);
+    FwdBatch batch;
+    int64_t max_tiles_m = 0;
+    int max_tiles_n = 0;
+    for (int i = 0; i < n; ++i) {
+        const elimrec_linear_desc &d = descs[i];
+        ELIMREC_REQUIRE(d.d_A && d.d_W && d.d_C, "linear_fwd: null pointer");
+        ELIMREC_REQUIRE(d.M >= 0 && d.N > 0 && d.K > 0, "linear_fwd: bad shape M=%lld N=%d K=%d", (long long)d.M, d.N, d.K);
+        ELIMREC_REQUIRE(d.K % 4 == 0 && d.lda % 4 == 0 && d.ldw % 4 == 0, "linear_fwd: K, lda, ldw must be multiples of 4");
+        ELIMREC_REQUIRE(((uintptr_t)d.d_A % 16) == 0 && ((uintptr_t)d.d_W % 16) == 0, "linear_fwd: A and W must be 16-byte aligned");
+        batch.p[i] = d;
+        const int64_t tm = (d.M + FBM - 1) / FBM;
+        const int tn = (d.N + FBN - 1) / FBN;
+        if (tm > max_tiles_m) max_tiles_m = tm;
+        if (tn > max_tiles_n) max_tiles_n = tn;
+    }
+    if (max_tiles_m == 0) return 0;
+    dim3 grid((unsigned)max_tiles_m, (unsigned)max_tiles_n, (unsigned)n);
+    hipLaunchKernelGGL(linear_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, batch);
     ELIMREC_LAUNCH_CHECK("linear_fwd");
     return 0;
 }
 
+extern "C" int elimrec_linear_fwd(const float *d_A, int64_t lda, const float *d_W, int64_t ldw,
+                                  const float *d_bias, float *d_C, int64_t ldc, int64_t M, int N, int K,
+                                  void *stream) {
+    elimrec_linear_desc d = {d_A, lda, d_W, ldw, d_bias, d_C, ldc, M, N, K};
+    return elimrec_linear_fwd_batched(&d, 1, stream);
+}
+
 static inline void bwd_w_dims(int64_t R, int n1, int n2, int &chunk_rows, int &chunks, int &t1, int &t2) {
-    chunk_rows = (R >= 32768) ? 512 : 64;      // enough workgroups for the short (row-sparse) reductions
+    chunk_rows = (R >= 32768) ? 256 : 64;      // enough workgroups for the short (row-sparse) reductions
     chunks = (int)((R + chunk_rows - 1) / chunk_rows);
     if (chunks < 1) chunks = 1;
     t1 = (n1 + TN1 - 1) / TN1;
     t2 = (n2 + TN2 - 1) / TN2;
 }
 
-extern "C" size_t elimrec_linear_bwd_w_workspace(int64_t R, int n1, int n2) {
+static inline size_t bwd_w_bytes(int64_t R, int n1, int n2) {
     int cr, chunks, t1, t2;
     bwd_w_dims(R, n1, n2, cr, chunks, t1, t2);
-    return ((size_t)chunks * t1 * TN1 * t2 * TN2 + (size_t)chunks * t1 * TN1) * sizeof(float);
+    return align_up(((size_t)chunks * t1 * TN1 * t2 * TN2 + (size_t)chunks * t1 * TN1) * sizeof(float), 256);
+}
+
+extern "C" size_t elimrec_linear_bwd_w_workspace(int64_t R, int n1, int n2) { return bwd_w_bytes(R, n1, n2); }
+
+extern "C" size_t elimrec_linear_bwd_w_batched_workspace(const elimrec_linear_bwd_desc *descs, int n) {
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += bwd_w_bytes(descs[i].R, descs[i].n1, descs[i].n2);
+    return total;
+}
+
+extern "C" int elimrec_linear_bwd_w_batched(const elimrec_linear_bwd_desc *descs, int n, void *d_workspace,
+                                            size_t workspace_bytes, void *stream) {
+    ELIMREC_REQUIRE(descs && n >= 1 && n <= kMaxBatch, "linear_bwd_w_batched: 1..%d problems", kMaxBatch);
+    ELIMREC_REQUIRE(d_workspace, "linear_bwd_w: null workspace");
+    if (workspace_bytes < elimrec_linear_bwd_w_batched_workspace(descs, n)) {
+        set_error("linear_bwd_w: workspace too small (%zu < %zu)", workspace_bytes,
+                  elimrec_linear_bwd_w_batched_workspace(descs, n));
+        return ELIMREC_E_WORKSPACE;
+    }
+    BwdBatch batch;
+    batch.n = n;
+    char *ws = (char *)d_workspace;
+    int blocks = 0, max_out = 0;
+    for (int i = 0; i < n; ++i) {
+        const elimrec_linear_bwd_desc &d = descs[i];
+        ELIMREC_REQUIRE(d.d_A && d.d_B && d.d_out, "linear_bwd_w: null pointer");
+        ELIMREC_REQUIRE(d.R >= 0 && d.n1 > 0 && d.n2 > 0, "linear_bwd_w: bad shape");
+        ELIMREC_REQUIRE(d.n1 % 4 == 0 && d.n2 % 4 == 0 && d.lda % 4 == 0 && d.ldb % 4 == 0,
+                        "linear_bwd_w: n1, n2, lda, ldb must be multiples of 4");
+        ELIMREC_REQUIRE(((uintptr_t)d.d_A % 16) == 0 && ((uintptr_t)d.d_B % 16) == 0,
+                        "linear_bwd_w: A and B must be 16-byte aligned");
+        BwdProblem &pb = batch.p[i];
+        pb.d = d;
+        bwd_w_dims(d.R, d.n1, d.n2, pb.chunk_rows, pb.chunks, pb.t1, pb.t2);
+        pb.first_block = blocks;
+        blocks += pb.chunks * pb.t1 * pb.t2;
+        pb.slabs = (float *)ws;
+        pb.cslabs = pb.slabs + (size_t)pb.chunks * pb.t1 * TN1 * pb.t2 * TN2;
+        ws += bwd_w_bytes(d.R, d.n1, d.n2);
+        const int out_elems = d.n1 * d.n2 + (d.d_colsum ? d.n1 : 0);
+        if (out_elems > max_out) max_out = out_elems;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(linear_bwd_w_partial_kernel, dim3(blocks), dim3(256), 0, s, batch);
+    ELIMREC_LAUNCH_CHECK("linear_bwd_w_partial");
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((max_out + 127) / 128, n), dim3(128), 0, s, batch);
+    ELIMREC_LAUNCH_CHECK("reduce_slabs");
+    return 0;
 }
 
 extern "C" int elimrec_linear_bwd_w(const float *d_A, int64_t lda, const float *d_B, int64_t ldb,
                                     const int32_t *d_row_index, const int32_t *d_range, int64_t R, int n1, int n2,
                                     float *d_out, int64_t ldo, float *d_colsum, int accumulate, void *d_workspace,
                                     size_t workspace_bytes, void *stream) {
-    ELIMREC_REQUIRE(d_A && d_B && d_out && d_workspace, "linear_bwd_w: null pointer");
-    ELIMREC_REQUIRE(R >= 0 && n1 > 0 && n2 > 0, "linear_bwd_w: bad shape");
-    ELIMREC_REQUIRE(n1 % 4 == 0 && n2 % 4 == 0 && lda % 4 == 0 && ldb % 4 == 0,
-                    "linear_bwd_w: n1, n2, lda, ldb must be multiples of 4");
-    ELIMREC_REQUIRE(((uintptr_t)d_A % 16) == 0 && ((uintptr_t)d_B % 16) == 0, "linear_bwd_w: A and B must be 16-byte aligned");
-    if (workspace_bytes < elimrec_linear_bwd_w_workspace(R, n1, n2)) {
-        set_error("linear_bwd_w: workspace too small (%zu < %zu)", workspace_bytes,
-                  elimrec_linear_bwd_w_workspace(R, n1, n2));
-        return ELIMREC_E_WORKSPACE;
-    }
-    int cr, chunks, t1, t2;
-    bwd_w_dims(R, n1, n2, cr, chunks, t1, t2);
-    float *slabs = (float *)d_workspace;
-    float *cslabs = slabs + (size_t)chunks * t1 * TN1 * t2 * TN2;
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(linear_bwd_w_partial_kernel, dim3(chunks, t1, t2), dim3(256), 0, s, d_A, lda, d_B, ldb,
-                       d_row_index, d_range, R, n1, n2, cr, slabs, d_colsum ? cslabs : nullptr);
-    ELIMREC_LAUNCH_CHECK("linear_bwd_w_partial");
-    const int total = n1 * n2 + (d_colsum ? n1 : 0);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((total + 127) / 128), dim3(128), 0, s, slabs, cslabs, d_range, R, cr,
-                       n1, n2, t1 * TN1, t2 * TN2, d_out, ldo, d_colsum, accumulate);
-    ELIMREC_LAUNCH_CHECK("reduce_slabs");
-    return 0;
+    elimrec_linear_bwd_desc d = {d_A, lda, d_B, ldb, d_row_index, d_range, R, n1, n2, d_out, ldo, d_colsum, accumulate};
+    return elimrec_linear_bwd_w_batched(&d, 1, d_workspace, workspace_bytes, stream);
 }

@@ -257,9 +257,9 @@ class EliMRec(BasicModel):
                 ws["bip_ws"] = torch.empty(ops.bipartite_workspace(self.num_users, self.num_items, d, self.M),
                                            dtype=torch.uint8, device=dev)
             ws["Y"] = torch.zeros(N, Cy, **f32)
-            dmax = max(getattr(self, m + "_feat").shape[1] for m in self._mods)
-            nbytes = max(ops.linear_bwd_w_workspace(self.num_items, d, dmax), 1)
-            ws["bwd_w_items"] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            shapes = [(self.num_items, d, getattr(self, m + "_feat").shape[1]) for m in self._mods]
+            ws["bwd_w_items"] = torch.empty(max(ops.linear_bwd_w_batched_workspace(shapes), 1), dtype=torch.uint8,
+                                            device=dev)
             ws["loss"] = torch.zeros(1, **f32)
             ws["one"] = torch.ones(1, **f32)
         n3 = bwd_rows
@@ -270,7 +270,8 @@ class EliMRec(BasicModel):
         ws["dY"] = torch.empty(n3, Cy, **f32)
         ws["seg_info"] = torch.zeros(8, dtype=torch.int32, device=dev)
         ws["seg_ws"] = torch.empty(max(ops.segment_reduce_workspace(n3), 1), dtype=torch.uint8, device=dev)
-        ws["bwd_w_rows"] = torch.empty(max(ops.linear_bwd_w_workspace(n3, d, C), 1), dtype=torch.uint8, device=dev)
+        shapes = [(n3, d, C), (n3, d, C)] + [(n3, d, d)] * self.S
+        ws["bwd_w_rows"] = torch.empty(max(ops.linear_bwd_w_batched_workspace(shapes), 1), dtype=torch.uint8, device=dev)
         self._ws, self._ws_key = ws, key
         return ws
 
@@ -323,20 +324,21 @@ class EliMRec(BasicModel):
             ops.copy_cols(self.embedding_item.weight, X0[U:, :d])          # XI block 0 = item id table
         else:
             ops.assemble_x0(self.embedding_user.weight, self.embedding_item.weight, X0, M)
-        for k, m in enumerate(self._mods):
-            lin = getattr(self, m + "_dense")
-            ops.linear_fwd(getattr(self, m + "_feat"), lin.weight, lin.bias, X0[U:, (k + 1) * d:(k + 2) * d])
+        ops.linear_fwd_batched([(getattr(self, m + "_feat"), getattr(self, m + "_dense").weight,
+                                 getattr(self, m + "_dense").bias, X0[U:, (k + 1) * d:(k + 2) * d])
+                                for k, m in enumerate(self._mods)])
         if self._bipartite:
             self._timed(lambda: ops.propagate_bipartite(self._csr("bipP"), self._csr("bipQ"), U, I, d, M, self.n_layers,
                                                         self.embedding_user.weight, X0[U:], Out, ws["bip_ws"]))
         else:
             self._propagate(self._csr("adj"), X0, ws["T0"], ws["T1"], Out)
         wu, wi = self._fusion_weights()
-        ops.linear_fwd(Out[:U], wu, self.embedding_user_after_GCN.bias, Y[:U, :d])
-        ops.linear_fwd(Out[U:], wi, self.embedding_item_after_GCN.bias, Y[U:, :d])
+        head = [(Out[:U], wu, self.embedding_user_after_GCN.bias, Y[:U, :d]),
+                (Out[U:], wi, self.embedding_item_after_GCN.bias, Y[U:, :d])]
         for h, m in enumerate(self._mods):
             lin = getattr(self, "s_dense_" + m)
-            ops.linear_fwd(Out[:, (h + 1) * d:(h + 2) * d], lin.weight, lin.bias, Y[:, (h + 1) * d:(h + 2) * d])
+            head.append((Out[:, (h + 1) * d:(h + 2) * d], lin.weight, lin.bias, Y[:, (h + 1) * d:(h + 2) * d]))
+        ops.linear_fwd_batched(head)
         self._publish_cache(Y)
 
     def _propagate(self, csr, X0, t0, t1, out):
@@ -405,20 +407,22 @@ class EliMRec(BasicModel):
         f32 = dict(dtype=torch.float32, device=dev)
         # fusion Linears: dW = dY_f^T . Out[active rows], user slots / item slots separately
         gv = ws["grad_views"]
+        concat = self.mm_fusion_mode == "concat"
+        problems, fused_tmp = [], {}
         for name, rng in (("embedding_user_after_GCN", seg[2:4]), ("embedding_item_after_GCN", seg[4:6])):
-            concat = self.mm_fusion_mode == "concat"
             gw = gv[name + ".weight"] if concat else torch.empty(d, C, **f32)
-            gb = gv[name + ".bias"]
-            ops.linear_bwd_w(dY[:, :d], ws["Out"], gw, ws["bwd_w_rows"], row_index=act, rng=rng, colsum=gb)
-            if not concat:
-                gw = gv[name + ".weight"].copy_(gw.view(d, M, d).sum(1) / M)
-            grads[name + ".weight"], grads[name + ".bias"] = gw, gb
+            fused_tmp[name] = gw
+            problems.append(dict(A=dY[:, :d], B=ws["Out"], out=gw, row_index=act, rng=rng, colsum=gv[name + ".bias"]))
+            grads[name + ".weight"], grads[name + ".bias"] = gv[name + ".weight"], gv[name + ".bias"]
         for h in heads_on:
             name = "s_dense_" + self._mods[h]
-            gw, gb = gv[name + ".weight"], gv[name + ".bias"]
-            ops.linear_bwd_w(dY[:, (h + 1) * d:(h + 2) * d], ws["Out"][:, (h + 1) * d:(h + 2) * d], gw, ws["bwd_w_rows"],
-                             row_index=act, rng=seg[6:8], colsum=gb)
-            grads[name + ".weight"], grads[name + ".bias"] = gw, gb
+            problems.append(dict(A=dY[:, (h + 1) * d:(h + 2) * d], B=ws["Out"][:, (h + 1) * d:(h + 2) * d],
+                                 out=gv[name + ".weight"], row_index=act, rng=seg[6:8], colsum=gv[name + ".bias"]))
+            grads[name + ".weight"], grads[name + ".bias"] = gv[name + ".weight"], gv[name + ".bias"]
+        ops.linear_bwd_w_batched(problems, ws["bwd_w_rows"])
+        if not concat:      # 'mean' fusion: fold the M replicated column blocks back into the [d x d] weight
+            for name, gw in fused_tmp.items():
+                gv[name + ".weight"].copy_(gw.view(d, M, d).sum(1) / M)
         # back through the propagation (A^T; A itself when symmetric), then the layer-0 pieces
         gu, gi = gv["embedding_user.weight"], gv["embedding_item.weight"]
         if self._bipartite:
@@ -436,11 +440,12 @@ class EliMRec(BasicModel):
             ops.embed_grad(G, U, I, d, M, gu, gi)
             g_items = G[U:]
         grads["embedding_user.weight"], grads["embedding_item.weight"] = gu, gi
+        problems = []
         for k, m in enumerate(self._mods):
-            feat = getattr(self, m + "_feat")
-            gw, gb = gv[m + "_dense.weight"], gv[m + "_dense.bias"]
-            ops.linear_bwd_w(g_items[:, (k + 1) * d:(k + 2) * d], feat, gw, ws["bwd_w_items"], colsum=gb)
-            grads[m + "_dense.weight"], grads[m + "_dense.bias"] = gw, gb
+            problems.append(dict(A=g_items[:, (k + 1) * d:(k + 2) * d], B=getattr(self, m + "_feat"),
+                                 out=gv[m + "_dense.weight"], colsum=gv[m + "_dense.bias"]))
+            grads[m + "_dense.weight"], grads[m + "_dense.bias"] = gv[m + "_dense.weight"], gv[m + "_dense.bias"]
+        ops.linear_bwd_w_batched(problems, ws["bwd_w_items"])
         return grads
 
     # ------------------------------------------------------------------ engine API (elimrec_amd/dist.py)

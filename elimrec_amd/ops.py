@@ -46,6 +46,52 @@ def linear_fwd(A, W, bias, out):
     return out
 
 
+def linear_fwd_batched(problems):
+    """problems: list of (A, W, bias, out) -- independent Linears sharing one launch (<= 8)."""
+    n = len(problems)
+    arr = (_lib.LinearDesc * n)()
+    for i, (A, W, bias, out) in enumerate(problems):
+        a, lda = _rowmajor(A, "A")
+        w, ldw = _rowmajor(W, "W")
+        c, ldc = _rowmajor(out, "out")
+        M, K = A.shape
+        N = W.shape[0]
+        assert W.shape[1] == K and out.shape[0] == M and out.shape[1] == N
+        arr[i] = _lib.LinearDesc(a, lda, w, ldw, _dev(bias, "bias"), c, ldc, M, N, K)
+    _lib.check(_lib.load().elimrec_linear_fwd_batched(arr, n, _stream()), "linear_fwd_batched")
+
+
+def _bwd_descs(problems):
+    n = len(problems)
+    arr = (_lib.LinearBwdDesc * n)()
+    for i, pr in enumerate(problems):
+        a, lda = _rowmajor(pr["A"], "A")
+        b, ldb = _rowmajor(pr["B"], "B")
+        o, ldo = _rowmajor(pr["out"], "out")
+        R = pr["A"].shape[0] if pr.get("rows") is None else pr["rows"]
+        n1, n2 = pr["out"].shape
+        arr[i] = _lib.LinearBwdDesc(a, lda, b, ldb, _dev(pr.get("row_index"), "row_index", torch.int32),
+                                    _dev(pr.get("rng"), "range", torch.int32), R, n1, n2, o, ldo,
+                                    _dev(pr.get("colsum"), "colsum"), 1 if pr.get("accumulate") else 0)
+    return arr, n
+
+
+def linear_bwd_w_batched_workspace(shapes):
+    """shapes: list of (R, n1, n2)."""
+    n = len(shapes)
+    arr = (_lib.LinearBwdDesc * n)()
+    for i, (R, n1, n2) in enumerate(shapes):
+        arr[i] = _lib.LinearBwdDesc(None, 0, None, 0, None, None, R, n1, n2, None, 0, None, 0)
+    return int(_lib.load().elimrec_linear_bwd_w_batched_workspace(arr, n))
+
+
+def linear_bwd_w_batched(problems, workspace):
+    """problems: list of dicts(A, B, out[, row_index, rng, colsum, accumulate, rows]) in one launch pair."""
+    arr, n = _bwd_descs(problems)
+    _lib.check(_lib.load().elimrec_linear_bwd_w_batched(arr, n, _dev(workspace, "workspace", torch.uint8),
+                                                        workspace.numel(), _stream()), "linear_bwd_w_batched")
+
+
 def linear_bwd_w_workspace(R, n1, n2):
     return int(_lib.load().elimrec_linear_bwd_w_workspace(R, n1, n2))
 

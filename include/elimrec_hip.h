@@ -48,6 +48,17 @@ int elimrec_linear_fwd(const float *d_A, int64_t lda, const float *d_W, int64_t 
                        const float *d_bias, float *d_C, int64_t ldc,
                        int64_t M, int N, int K, void *stream);
 
+/* Several independent Linears in ONE launch (the three feature projections; the five head Linears):
+ * the grid's z dimension indexes the problem. 1 <= n <= 8. */
+typedef struct elimrec_linear_desc {
+    const float *d_A; int64_t lda;
+    const float *d_W; int64_t ldw;
+    const float *d_bias;            /* nullable */
+    float *d_C; int64_t ldc;
+    int64_t M; int32_t N; int32_t K;
+} elimrec_linear_desc;
+int elimrec_linear_fwd_batched(const elimrec_linear_desc *descs /* host array */, int n, void *stream);
+
 /* out[i, j] (+)= sum_{r in rows} A[r, i] * B[row_index ? row_index[r] : r, j]
  * the weight-gradient contraction of a Linear layer (AddmmBackward of the calls above) with a
  * deterministic two-stage reduction: fixed row chunks -> partial slabs in workspace -> summed in
@@ -59,6 +70,22 @@ int elimrec_linear_bwd_w(const float *d_A, int64_t lda, const float *d_B, int64_
                          const int32_t *d_row_index, const int32_t *d_range, int64_t R,
                          int n1, int n2, float *d_out, int64_t ldo, float *d_colsum,
                          int accumulate, void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Batched form: n independent weight-gradient contractions in one partial launch + one reduce
+ * launch. 1 <= n <= 8. workspace: elimrec_linear_bwd_w_batched_workspace(descs, n) bytes. */
+typedef struct elimrec_linear_bwd_desc {
+    const float *d_A; int64_t lda;
+    const float *d_B; int64_t ldb;
+    const int32_t *d_row_index;     /* nullable */
+    const int32_t *d_range;         /* nullable device int32[2] */
+    int64_t R; int32_t n1; int32_t n2;
+    float *d_out; int64_t ldo;
+    float *d_colsum;                /* nullable */
+    int32_t accumulate;
+} elimrec_linear_bwd_desc;
+size_t elimrec_linear_bwd_w_batched_workspace(const elimrec_linear_bwd_desc *descs, int n);
+int elimrec_linear_bwd_w_batched(const elimrec_linear_bwd_desc *descs /* host array */, int n,
+                                 void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------- layer-0 table assembly (K2)
  * X0[u, m*d + j] = user_emb[u, j] for every table m;  X0[U+i, j] = item_emb[i, j].
