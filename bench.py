@@ -47,6 +47,18 @@ def algorithmic_bytes(model, B):
     return step, hop
 
 
+def pmc_traffic_per_hop():
+    """HBM bytes per propagation hop from the committed PMC passes (profiles/r01_d_pmc_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs of this same command,
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950). None if the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_d_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["propagation_hop_traffic_bytes"]
+    except Exception:
+        return None
+
+
 def build(args, device):
     import torch
     from elimrec_amd import Configurator, EliMRec, FusedAdam, SyntheticDataset, set_seed
@@ -157,7 +169,7 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    hop_ms, hop_launches = trainer.kernel_time_ms("spmm_hop")
+    hop_ms, hop_launches = trainer.kernel_time_ms("propagation_hop")
     final_loss = float(loss.item())
 
     if rank == 0:
@@ -175,8 +187,12 @@ def main():
                        "final_loss": final_loss},
             "step_algorithmic_GB": step_bytes / 1e9,
             "step_achieved_GBps": step_bytes / (dt / args.steps) / 1e9,
-            "roofline": {"bound": "hbm", "kernel": "spmm_hop_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+            "roofline": {"bound": "hbm",
+                         "kernel": "propagation hop = half_hop_kernel<64> (C columns) + half_hop_kernel<16> (d columns) "
+                                   "+ their long-row helpers; 2L hops per step",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                         "traffic": pmc_traffic_per_hop(),
                          "algorithmic_bytes_per_launch": hop_bytes,
                          "avg_launch_us": 1e3 * hop_ms / hop_launches if hop_launches else None,
                          "launches_timed": hop_launches},

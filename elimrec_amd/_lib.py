@@ -63,6 +63,8 @@ SIGNATURES = {
                                             c_size, c_ptr]),
     "elimrec_propagate_bipartite_bwd": (c_i32, [c_csr, c_csr, c_i64, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr,
                                                 c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "elimrec_concurrency": (c_i32, []),
+    "elimrec_set_concurrency": (None, [c_i32]),
     "elimrec_blocksum_rows": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr]),
     "elimrec_copy_cols": (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i32, c_ptr]),
     "elimrec_bpr_head": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32,

@@ -5,6 +5,7 @@
 // over the CSR structure serves every table. HBM-bound: per hop read C*4 B per non-zero
 // (+ 8 B of CSR), write C*4 B per row.
 #include "common.h"
+#include <cstdlib>
 
 namespace elimrec {
 
@@ -430,13 +431,14 @@ __global__ void build_masks_kernel(const int32_t *__restrict__ active_rows, cons
     else atomicOr(&mask_i[(r - U) >> 5], 1u << ((r - U) & 31));
 }
 
-static int launch_half(const elimrec_csr *m, HalfArgs a, int unroll_hint, hipStream_t s) {
+static int launch_half(const elimrec_csr *m, HalfArgs a, size_t partials_offset, hipStream_t s) {
     a.rowptr = m->d_rowptr; a.col = m->d_col; a.val = m->d_val; a.n_rows = m->n_rows;
     const bool has_split = m->split.n_long > 0;
     a.long_threshold = has_split ? m->split.long_threshold : INT32_MAX;
     a.seg_bounds = m->split.d_seg_bounds; a.n_seg = has_split ? m->split.n_seg : 0;
     a.long_rows = m->split.d_long_rows; a.n_long = has_split ? m->split.n_long : 0;
-    a.long_seg_ptr = m->split.d_long_seg_ptr; a.partials = (float4 *)m->split.d_partials;
+    a.long_seg_ptr = m->split.d_long_seg_ptr;
+    a.partials = m->split.d_partials ? (float4 *)(m->split.d_partials + partials_offset) : nullptr;
     if (a.n_rows == 0) return 0;
     int lpr = 64;
     while (lpr > 1 && lpr / 2 >= a.W4) lpr /= 2;
@@ -463,7 +465,6 @@ static int launch_half(const elimrec_csr *m, HalfArgs a, int unroll_hint, hipStr
         default: ELIMREC_HALF_LAUNCH(4); break;
     }
 #undef ELIMREC_HALF_LAUNCH
-    (void)unroll_hint;
     return 0;
 }
 
@@ -478,6 +479,39 @@ static HalfArgs half_args(int W4, const float *Xin, const uint32_t *src_mask, fl
 }
 
 }  // namespace elimrec
+
+// The narrow (d-column) chain is independent of the wide chain for most of a propagation; it runs on a
+// side stream forked from / joined to the caller's stream with events (also valid under stream capture).
+// The partial-sum scratch of a split CSR holds two regions so both chains can use the same block at once:
+// wide partials at offset 0, narrow partials at n_seg * C floats (callers allocate [n_seg x 2C]).
+struct SideStream {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+static SideStream &side_stream() {
+    static thread_local SideStream s;
+    if (!s.stream) {
+        (void)hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+        (void)hipEventCreateWithFlags(&s.fork, hipEventDisableTiming);
+        (void)hipEventCreateWithFlags(&s.join, hipEventDisableTiming);
+    }
+    return s;
+}
+static inline size_t narrow_partials_offset(const elimrec_csr *m, int C) { return (size_t)m->split.n_seg * C; }
+
+static int g_concurrency = -1;
+extern "C" int elimrec_concurrency(void) {
+    if (g_concurrency < 0) {
+        const char *e = getenv("ELIMREC_CONCURRENCY");
+        g_concurrency = (e && e[0] == '1') ? 1 : 0;     // measured: +0.6 % at the Tiktok shape, so off by default
+    }
+    return g_concurrency;
+}
+extern "C" void elimrec_set_concurrency(int on) { g_concurrency = on ? 1 : 0; }
+
+static int bwd_narrow_chain(const elimrec_csr *PT, const elimrec_csr *QT, int L, int C, int d4, const float *H_u,
+                            const float *H_i, const uint32_t *mask_u, const uint32_t *mask_i, float *au, float *ai,
+                            float *d_gEu, float inv, hipStream_t ns);
 
 static size_t bip_ws_layout(int64_t U, int64_t I, int d, int C, size_t off[8]) {
     size_t o = 0;
@@ -519,6 +553,14 @@ extern "C" int elimrec_propagate_bipartite(const elimrec_csr *P, const elimrec_c
     const float inv = 1.0f / (float)(L + 1);
     const int C4 = C / 4, d4 = d / 4;
     int rc;
+    // fork: the narrow chain runs on the side stream while the first wide step runs on the caller's stream
+    SideStream &side = side_stream();
+    const bool use_side = (elimrec_concurrency() != 0);
+    hipStream_t ns = use_side ? side.stream : s;
+    if (use_side) {
+        if ((rc = check_hip(hipEventRecord(side.fork, s), "eventRecord(fork)"))) return rc;
+        if ((rc = check_hip(hipStreamWaitEvent(ns, side.fork, 0), "streamWaitEvent(fork)"))) return rc;
+    }
     // ---- narrow chain: a_k = A^k [E_u ; 0]; SN_side = sum of the a_k living on that side (k = 0 included)
     const float *prev = d_user_emb;
     for (int k = 1; k <= L; ++k) {
@@ -529,15 +571,17 @@ extern "C" int elimrec_propagate_bipartite(const elimrec_csr *P, const elimrec_c
             float *xout = (k == 1) ? SNi : (need_next ? ai : nullptr);
             HalfArgs a = half_args(d4, prev, nullptr, xout, (k == 1) ? nullptr : SNi, nullptr, nullptr, nullptr, 0,
                                    (k == 1) ? nullptr : SNi, 1.0f);
-            if ((rc = launch_half(Q, a, 8, s))) return rc;
+            if ((rc = launch_half(Q, a, narrow_partials_offset(Q, C), ns))) return rc;
             prev = (k == 1) ? SNi : ai;
         } else {
             HalfArgs a = half_args(d4, prev, nullptr, need_next ? au : nullptr, (k == 2) ? d_user_emb : SNu, nullptr,
                                    nullptr, nullptr, 0, SNu, 1.0f);
-            if ((rc = launch_half(P, a, 8, s))) return rc;
+            if ((rc = launch_half(P, a, narrow_partials_offset(P, C), ns))) return rc;
             prev = au;
         }
     }
+    if (use_side && (rc = check_hip(hipEventRecord(side.join, ns), "eventRecord(join)"))) return rc;
+    bool joined = !use_side;
     const float *SNu_final = (L >= 2) ? SNu : d_user_emb;     // users: a_0 = E_u (+ a_2 + ...)
     // ---- wide chain: w_k = A^k [0 ; XI]; running sums live in Out, the last step on a side finishes it
     const float *wprev = d_XI;
@@ -546,23 +590,28 @@ extern "C" int elimrec_propagate_bipartite(const elimrec_csr *P, const elimrec_c
         const bool to_users = (k & 1);
         const bool last_on_side = (k + 2 > L);
         const bool need_next = k < L;
+        if (!joined && (last_on_side || k >= 2)) {      // the narrow sums are consumed from here on
+            if ((rc = check_hip(hipStreamWaitEvent(s, side.join, 0), "streamWaitEvent(join)"))) return rc;
+            joined = true;
+        }
         if (to_users) {
             const bool first = (k == 1);
             HalfArgs a = half_args(C4, wprev, nullptr, need_next ? wu : nullptr, first ? nullptr : Out_u, nullptr, nullptr,
                                    last_on_side ? SNu_final : nullptr, d4, Out_u, last_on_side ? inv : 1.0f);
-            if ((rc = launch_half(P, a, 8, s))) return rc;
+            if ((rc = launch_half(P, a, 0, s))) return rc;
             wprev = wu;
             users_done = last_on_side;
         } else {
             const bool first = (k == 2);
             HalfArgs a = half_args(C4, wprev, nullptr, need_next ? wi : nullptr, first ? d_XI : Out_i, nullptr, nullptr,
                                    last_on_side ? SNi : nullptr, d4, Out_i, last_on_side ? inv : 1.0f);
-            if ((rc = launch_half(Q, a, 8, s))) return rc;
+            if ((rc = launch_half(Q, a, 0, s))) return rc;
             wprev = wi;
             items_done = last_on_side;
         }
     }
     (void)users_done;
+    if (!joined && (rc = check_hip(hipStreamWaitEvent(s, side.join, 0), "streamWaitEvent(join)"))) return rc;
     if (!items_done) {   // L == 1: Out_i = (XI + bcast(a_1)) / 2
         hipLaunchKernelGGL(combine_kernel, dim3(2048), dim3(256), 0, s, (const float4 *)d_XI, (const float4 *)SNi, I, C4,
                            d4, inv, (float4 *)Out_i);
@@ -604,6 +653,15 @@ extern "C" int elimrec_propagate_bipartite_bwd(const elimrec_csr *PT, const elim
     const int C4 = C / 4, d4 = d / 4;
     const float *G_u = d_G, *G_i = d_G + (size_t)U * C;
     const float *H_u = d_H, *H_i = d_H + (size_t)U * d;
+    // fork: narrow adjoint on the side stream, wide adjoint on the caller's stream
+    SideStream &side = side_stream();
+    const bool use_side = (elimrec_concurrency() != 0);
+    hipStream_t ns = use_side ? side.stream : s;
+    if (use_side) {
+        if ((rc = check_hip(hipEventRecord(side.fork, s), "eventRecord(fork)"))) return rc;
+        if ((rc = check_hip(hipStreamWaitEvent(ns, side.fork, 0), "streamWaitEvent(fork)"))) return rc;
+    }
+    if ((rc = bwd_narrow_chain(PT, QT, L, C, d4, H_u, H_i, mask_u, mask_i, au, ai, d_gEu, inv, ns))) return rc;
     // ---- wide adjoint: t_L = G_{s(L)}, t_k = G_{s(k)} + B_k t_{k+1}; s(k) = users for odd k. gXI = inv * t_0.
     {
         const float *t = (L & 1) ? G_u : G_i;
@@ -613,12 +671,23 @@ extern "C" int elimrec_propagate_bipartite_bwd(const elimrec_csr *PT, const elim
             float *dst = (k == 0) ? d_gXI : (out_items ? wi : wu);
             HalfArgs a = half_args(C4, t, tmask, nullptr, out_items ? G_i : G_u, out_items ? mask_i : mask_u, nullptr,
                                    nullptr, 0, dst, (k == 0) ? inv : 1.0f);
-            if ((rc = launch_half(out_items ? PT : QT, a, 8, s))) return rc;
+            if ((rc = launch_half(out_items ? PT : QT, a, 0, s))) return rc;
             t = dst;
             tmask = nullptr;
         }
     }
-    // ---- narrow adjoint: s'(k) = users for even k. gE_u = inv * t_0.
+    // ---- narrow adjoint: s'(k) = users for even k. gE_u = inv * t_0. Independent of the wide chain.
+    if (use_side) {
+        if ((rc = check_hip(hipEventRecord(side.join, ns), "eventRecord(join)"))) return rc;
+        if ((rc = check_hip(hipStreamWaitEvent(s, side.join, 0), "streamWaitEvent(join)"))) return rc;
+    }
+    return 0;
+}
+
+static int bwd_narrow_chain(const elimrec_csr *PT, const elimrec_csr *QT, int L, int C, int d4, const float *H_u,
+                            const float *H_i, const uint32_t *mask_u, const uint32_t *mask_i, float *au, float *ai,
+                            float *d_gEu, float inv, hipStream_t ns) {
+    int rc;
     {
         const float *t = (L & 1) ? H_i : H_u;
         const uint32_t *tmask = (L & 1) ? mask_i : mask_u;
@@ -627,7 +696,8 @@ extern "C" int elimrec_propagate_bipartite_bwd(const elimrec_csr *PT, const elim
             float *dst = (k == 0) ? d_gEu : (out_users ? au : ai);
             HalfArgs a = half_args(d4, t, tmask, nullptr, out_users ? H_u : H_i, out_users ? mask_u : mask_i, nullptr,
                                    nullptr, 0, dst, (k == 0) ? inv : 1.0f);
-            if ((rc = launch_half(out_users ? QT : PT, a, 8, s))) return rc;
+            const elimrec_csr *blk = out_users ? QT : PT;
+            if ((rc = launch_half(blk, a, narrow_partials_offset(blk, C), ns))) return rc;
             t = dst;
             tmask = nullptr;
         }

@@ -165,7 +165,7 @@ class Csr:
         dev = self.rowptr.device
         t = (torch.from_numpy(long_rows.astype(np.int32)).to(dev), torch.from_numpy(seg_ptr.astype(np.int32)).to(dev),
              torch.from_numpy(np.stack([beg, end], 1).astype(np.int32).copy()).to(dev),
-             torch.empty(total, C, dtype=torch.float32, device=dev))
+             torch.empty(total, 2 * C, dtype=torch.float32, device=dev))   # wide + narrow partial regions
         self._split_tensors = t
         self._split = _lib.CsrSplit(int(threshold), len(long_rows), total, t[0].data_ptr(), t[1].data_ptr(),
                                     t[2].data_ptr(), t[3].data_ptr())

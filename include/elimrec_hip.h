@@ -150,6 +150,13 @@ int elimrec_propagate_bipartite(const elimrec_csr *P, const elimrec_csr *Q, int6
                                 const float *d_XI /* [I x C] */, float *d_Out /* [N x C] */,
                                 void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* The C-column and d-column chains of the bipartite propagation are independent for most of a call;
+ * optionally (elimrec_set_concurrency(1) or ELIMREC_CONCURRENCY=1; default off -- the step is bandwidth
+ * bound, measured gain 0.6 %) the d-column chain runs on an internal side stream forked from / joined to
+ * `stream` with events (capturable). The row-split scratch d_partials must hold [n_seg x 2C] floats. */
+int elimrec_concurrency(void);
+void elimrec_set_concurrency(int on);
+
 /* Its adjoint (SparseAddmmBackward x L, StackBackward/MeanBackward, CatBackward of the reference's
  * autograd): from G = dLoss/dOut [N x C], non-zero only on the rows listed in d_active_rows
  * (first d_seg_info[0] entries; other rows of G are never read, so G need not be zero-filled) and

@@ -450,6 +450,15 @@ def test_bipartite_propagation_equals_full_propagation(L, d, M):
     ops.propagate_bipartite(Pd, Qd, U, I, d, M, L, Eu.to(DEV), XI.to(DEV), out_bip, ws)
     assert rel_err(out_full.cpu(), want) < 2e-6
     assert rel_err(out_bip.cpu(), want) < 2e-6
+    from elimrec_amd import _lib
+    _lib.load().elimrec_set_concurrency(1)          # d-column chain on the side stream: same bits
+    try:
+        out_side = torch.empty_like(X0d)
+        ops.propagate_bipartite(Pd, Qd, U, I, d, M, L, Eu.to(DEV), XI.to(DEV), out_side, ws)
+        torch.cuda.synchronize()
+        assert torch.equal(out_side, out_bip)
+    finally:
+        _lib.load().elimrec_set_concurrency(0)
     # ---- adjoint: sparse G (60 active rows), garbage elsewhere (must never be read)
     act = np.sort(rs.choice(U + I, size=60, replace=False)).astype(np.int32)
     G = torch.full((U + I, C), float("nan"))
