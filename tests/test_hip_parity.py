@@ -519,3 +519,62 @@ def test_model_paths_agree_on_gcmc_adjacency():
         assert set(res[mode][1]) == set(om.grads())
         for k, v in om.grads().items():
             assert rel_err(res[mode][1][k], v) < 1e-4, (mode, k)
+
+
+# ----------------------------------------------------------------------------- BASELINE.json shapes
+def _full_shape_step(U, I, E, dims, recdim, B, dataset_name, extra_argv=()):
+    """One full training step at a BASELINE.json shape: HIP path vs the CPU oracle on identical
+    synthetic data, parameters and triplets (loss 1e-5 abs, every gradient 1e-4 rel)."""
+    import os
+    from helpers import make_config
+    from elimrec_amd import EliMRec, SyntheticDataset, set_seed
+    from oracle import elimrec_oracle as eo
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    cfg = make_config(["--data.input.dataset=%s" % dataset_name, "--alpha=0.5", "--loss=bpr_loss", "--recdim=%d" % recdim,
+                       "--verbose=0"] + list(extra_argv))
+    ds = SyntheticDataset(U, I, E, feat_dims=dims, seed=1, name=dataset_name)
+    set_seed(7)
+    model = EliMRec(cfg, ds)
+    init = {k: v.detach().clone().numpy() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    g = torch.Generator().manual_seed(3)
+    train = ds.train_matrix.tocoo()
+    pick = torch.randint(0, train.nnz, (B,), generator=g).numpy()
+    u = torch.from_numpy(train.row[pick].astype(np.int64))
+    p = torch.from_numpy(train.col[pick].astype(np.int64))
+    n = torch.randint(0, I, (B,), generator=g)
+    loss = model.bpr_loss(u.to(DEV), p.to(DEV), n.to(DEV))
+    loss.backward()
+    tu, ti = ds.get_train_interactions()
+    adj = eo.build_adj(tu, ti, U, I, cfg["adj_type"])
+    mods = ["v"] if dataset_name == "kwai" else ["v", "a", "t"]
+    feats = {m: eo.OracleEliMRec.normalize_features(getattr(ds, m + "_feat")) for m in mods}
+    om = eo.OracleEliMRec(U, I, recdim, cfg["layer_num"], adj, feats, init, cfg["alpha"], dataset_name=dataset_name)
+    ol = om.bpr_loss(u, p, n)
+    ol.backward()
+    assert abs(loss.item() - float(ol.detach())) < 1e-5
+    mine = {k: q.grad.cpu() for k, q in model.named_parameters() if q.grad is not None}
+    want = om.grads()
+    assert set(mine) == set(want)
+    for k, v in want.items():
+        assert rel_err(mine[k], v) < 1e-4, k
+    return model, om
+
+
+def test_full_tiktok_shape_step_vs_oracle():
+    """BASELINE.json configs[1]: |U|=36 656, |I|=76 085, 128-d x3, recdim 64, B=2048."""
+    model, om = _full_shape_step(36656, 76085, 720829, (128, 128, 128), 64, 2048, "synthetic")
+    # and the cached tables feed the same counterfactual scores (TIE) for a block of users
+    users = list(range(0, 36656, 300))[:64]
+    model.predict_type = om.predict_type = "TIE"
+    assert np.abs(model.predict(users).numpy() - om.predict(users).numpy()).max() < 1e-5
+
+
+def test_full_kwai_shape_step_vs_oracle():
+    """BASELINE.json configs[2], reference-parity variant: id + V only (dataset name 'kwai'), D_v = 2048."""
+    _full_shape_step(7010, 86483, 298492, (2048,), 64, 2048, "kwai")
+
+
+def test_full_movielens_shape_step_vs_oracle():
+    """BASELINE.json configs[0]: MovieLens shape, D = (2048, 128, 100), recdim 64, batch 1024."""
+    _full_shape_step(55485, 5986, 1239508, (2048, 128, 100), 64, 1024, "movielens")
