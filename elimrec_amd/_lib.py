@@ -17,7 +17,8 @@ class CsrSplit(ctypes.Structure):
     """struct elimrec_csr_split (include/elimrec_hip.h)."""
     _fields_ = [("long_threshold", ctypes.c_int32), ("n_long", ctypes.c_int32), ("n_seg", ctypes.c_int32),
                 ("d_long_rows", ctypes.c_void_p), ("d_long_seg_ptr", ctypes.c_void_p),
-                ("d_seg_bounds", ctypes.c_void_p), ("d_partials", ctypes.c_void_p)]
+                ("d_seg_bounds", ctypes.c_void_p), ("d_partials", ctypes.c_void_p), ("d_seg_row", ctypes.c_void_p),
+                ("d_tickets", ctypes.c_void_p)]
 
 
 class CsrDesc(ctypes.Structure):
@@ -63,6 +64,8 @@ SIGNATURES = {
                                             c_size, c_ptr]),
     "elimrec_propagate_bipartite_bwd": (c_i32, [c_csr, c_csr, c_i64, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr,
                                                 c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "elimrec_ticket_fixup": (c_i32, []),
+    "elimrec_set_ticket_fixup": (None, [c_i32]),
     "elimrec_concurrency": (c_i32, []),
     "elimrec_set_concurrency": (None, [c_i32]),
     "elimrec_blocksum_rows": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr]),

@@ -262,6 +262,8 @@ extern "C" int elimrec_propagate(const int32_t *d_rowptr, const int32_t *d_col, 
 // and the first half hop of each gathers from the raw head gradient, which is non-zero on <= 3B rows:
 // a row bitmap skips the rest (and the zero-fill of G disappears with it).
 // =====================================================================================================
+extern "C" int elimrec_ticket_fixup(void);
+
 namespace elimrec {
 
 struct HalfArgs {
@@ -287,7 +289,11 @@ struct HalfArgs {
     int n_long;
     const int32_t *long_seg_ptr;
     float4 *partials;
+    const int32_t *seg_row;       // [n_seg] index (into long_rows) of the split row a segment belongs to
+    int32_t *tickets;             // [n_long] arrival counters, zero between launches (self-resetting)
 };
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ bool mask_bit(const uint32_t *m, int r) { return (m[r >> 5] >> (r & 31)) & 1u; }
 
@@ -343,18 +349,22 @@ __device__ __forceinline__ float4 half_gather(const HalfArgs &a, int beg, int en
 }
 
 // LPR lanes per row (power of two <= 64): a wave handles 64/LPR rows, so narrow (d-column) tables use
-// every lane. MODE 0: rows of the CSR (long rows skipped); MODE 1: segments of long rows -> partials.
-template <int LPR, int UNROLL, int MODE>
-__global__ __launch_bounds__(256) void half_hop_kernel(HalfArgs a) {
+// every lane. ONE launch covers both kinds of work item: the first `seg_blocks` workgroups take segments
+// of the split (long) rows and write partial sums, the rest take whole rows of the CSR (long rows
+// skipped) and finish them. The heavy segment waves start first and the two kinds overlap.
+template <int LPR, int UNROLL>
+__global__ __launch_bounds__(256) void half_hop_kernel(HalfArgs a, int seg_blocks) {
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR, cl = lane % LPR;
-    const int64_t item = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + sub;
-    const int64_t n_items = (MODE == 0) ? a.n_rows : (int64_t)a.n_seg;
+    const bool seg_mode = (int)blockIdx.x < seg_blocks;            // workgroup-uniform
+    const int64_t blk = seg_mode ? blockIdx.x : (blockIdx.x - seg_blocks);
+    const int64_t item = (blk * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + sub;
+    const int64_t n_items = seg_mode ? (int64_t)a.n_seg : a.n_rows;
     bool valid = item < n_items;
     int beg = 0, end = 0;
     if (valid) {
-        if (MODE == 0) {
+        if (!seg_mode) {
             beg = a.rowptr[item]; end = a.rowptr[item + 1];
             if (end - beg > a.long_threshold) valid = false;
         } else {
@@ -366,14 +376,63 @@ __global__ __launch_bounds__(256) void half_hop_kernel(HalfArgs a) {
         end = __builtin_amdgcn_readfirstlane(end);
     }
     if (!valid) { beg = 0; end = 0; }
+    // partial rows are published write-through (sc1) when another wave will combine them in this launch
+    const bool publish = seg_mode && a.tickets != nullptr;         // workgroup-uniform
+    __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)a.partials, 0, publish ? (int)((size_t)a.n_seg * a.W4 * 16) : 0, 0x00020000);
     for (int c0 = 0; c0 < a.W4; c0 += LPR) {
         const int c = c0 + cl;
         const bool on = valid && c < a.W4;
         const float4 acc = half_gather<UNROLL>(a, beg, end, c, on);
         if (on) {
-            if (MODE == 0) half_epilogue(a, item, c, acc);
-            else a.partials[item * a.W4 + c] = acc;
+            if (!seg_mode) half_epilogue(a, item, c, acc);
+            else if (!publish) a.partials[item * a.W4 + c] = acc;
+            else {
+                u32x4 bits = {__float_as_uint(acc.x), __float_as_uint(acc.y), __float_as_uint(acc.z), __float_as_uint(acc.w)};
+                __builtin_amdgcn_raw_buffer_store_b128(bits, prsrc, (unsigned)((item * a.W4 + c) * 16), 0, 16 /* sc1 */);
+            }
         }
+    }
+    if (!publish) return;                                          // workgroup-uniform
+    // ---- last arriver combines: every segment wave has stored its partial row write-through (sc1: no
+    // release fence, which would write back the whole XCD L2 under the main rows' output stream), drains
+    // its stores, draws a ticket for its split row, and the wave that draws the last one sums that row's
+    // partials in SEGMENT ORDER (same order as half_fixup_kernel => same bits) and runs the epilogue.
+    // cdna_hip_programming.md Guideline 16, recipe R1 in its counter form: sc1 stores -> every storing wave
+    // s_waitcnt vmcnt(0) -> relaxed agent-scope atomic add; consumer: ONE agent acquire (drops this CU's
+    // stale L1 lines) -> s_waitcnt vmcnt(0) -> plain loads.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int li = -1, nseg = 0, ticket = -1;
+    if (valid) {
+        li = a.seg_row[item];
+        nseg = a.long_seg_ptr[li + 1] - a.long_seg_ptr[li];
+        if (cl == 0) ticket = __hip_atomic_fetch_add(&a.tickets[li], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ticket = __shfl(ticket, sub * LPR, 64);
+    const bool last = valid && (ticket == nseg - 1);
+    if (__ballot(last) == 0ull) return;                             // wave-uniform
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (last) {
+        const int64_t row = a.long_rows[li];
+        const int sb = a.long_seg_ptr[li], se = a.long_seg_ptr[li + 1];
+        for (int c = cl; c < a.W4; c += LPR) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int sgm = sb;
+            for (; sgm + 8 <= se; sgm += 8) {
+                float4 p[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p[u] = a.partials[(int64_t)(sgm + u) * a.W4 + c];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc.x += p[u].x; acc.y += p[u].y; acc.z += p[u].z; acc.w += p[u].w; }
+            }
+            for (; sgm < se; ++sgm) {
+                const float4 p = a.partials[(int64_t)sgm * a.W4 + c];
+                acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+            }
+            half_epilogue(a, row, c, acc);
+        }
+        if (cl == 0) __hip_atomic_store(&a.tickets[li], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
 }
 
@@ -439,6 +498,10 @@ static int launch_half(const elimrec_csr *m, HalfArgs a, size_t partials_offset,
     a.long_rows = m->split.d_long_rows; a.n_long = has_split ? m->split.n_long : 0;
     a.long_seg_ptr = m->split.d_long_seg_ptr;
     a.partials = m->split.d_partials ? (float4 *)(m->split.d_partials + partials_offset) : nullptr;
+    a.seg_row = m->split.d_seg_row;
+    // the two chains may touch the same block concurrently: wide launches use tickets[0..n_long), narrow ones the next n_long
+    a.tickets = (m->split.d_tickets && elimrec_ticket_fixup())
+                    ? m->split.d_tickets + (partials_offset ? m->split.n_long : 0) : nullptr;
     if (a.n_rows == 0) return 0;
     int lpr = 64;
     while (lpr > 1 && lpr / 2 >= a.W4) lpr /= 2;
@@ -448,11 +511,11 @@ static int launch_half(const elimrec_csr *m, HalfArgs a, size_t partials_offset,
     auto blocks = [&](int64_t n) { return dim3((unsigned)((n + (int64_t)waves * rpw - 1) / (waves * rpw))); };
 #define ELIMREC_HALF_LAUNCH(LPR)                                                                                     \
     do {                                                                                                             \
-        hipLaunchKernelGGL((half_hop_kernel<LPR, 8, 0>), blocks(a.n_rows), dim3(64 * waves), 0, s, a);              \
+        const unsigned seg_blocks = has_split ? blocks(a.n_seg).x : 0u;                                              \
+        hipLaunchKernelGGL((half_hop_kernel<LPR, 8>), dim3(seg_blocks + blocks(a.n_rows).x), dim3(64 * waves), 0, s, \
+                           a, (int)seg_blocks);                                                                      \
         ELIMREC_LAUNCH_CHECK("half_hop");                                                                            \
-        if (has_split) {                                                                                             \
-            hipLaunchKernelGGL((half_hop_kernel<LPR, 8, 1>), blocks(a.n_seg), dim3(64 * waves), 0, s, a);           \
-            ELIMREC_LAUNCH_CHECK("half_hop_long");                                                                   \
+        if (has_split && !a.tickets) {                                                                               \
             hipLaunchKernelGGL((half_fixup_kernel<LPR>), blocks(a.n_long), dim3(64 * waves), 0, s, a);               \
             ELIMREC_LAUNCH_CHECK("half_fixup");                                                                      \
         }                                                                                                            \
@@ -498,6 +561,16 @@ static SideStream &side_stream() {
     return s;
 }
 static inline size_t narrow_partials_offset(const elimrec_csr *m, int C) { return (size_t)m->split.n_seg * C; }
+
+static int g_ticket_fixup = -1;
+extern "C" int elimrec_ticket_fixup(void) {
+    if (g_ticket_fixup < 0) {
+        const char *e = getenv("ELIMREC_TICKET_FIXUP");
+        g_ticket_fixup = (e && e[0] == '0') ? 0 : 1;
+    }
+    return g_ticket_fixup;
+}
+extern "C" void elimrec_set_ticket_fixup(int on) { g_ticket_fixup = on ? 1 : 0; }
 
 static int g_concurrency = -1;
 extern "C" int elimrec_concurrency(void) {

@@ -165,16 +165,18 @@ class Csr:
         dev = self.rowptr.device
         t = (torch.from_numpy(long_rows.astype(np.int32)).to(dev), torch.from_numpy(seg_ptr.astype(np.int32)).to(dev),
              torch.from_numpy(np.stack([beg, end], 1).astype(np.int32).copy()).to(dev),
-             torch.empty(total, 2 * C, dtype=torch.float32, device=dev))   # wide + narrow partial regions
+             torch.empty(total, 2 * C, dtype=torch.float32, device=dev),   # wide + narrow partial regions
+             torch.from_numpy(seg_row.astype(np.int32)).to(dev),
+             torch.zeros(2 * len(long_rows), dtype=torch.int32, device=dev))
         self._split_tensors = t
         self._split = _lib.CsrSplit(int(threshold), len(long_rows), total, t[0].data_ptr(), t[1].data_ptr(),
-                                    t[2].data_ptr(), t[3].data_ptr())
+                                    t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(), t[5].data_ptr())
         self._split_C = C
         return self
 
     def desc(self):
         """struct elimrec_csr for the block-CSR entry points (keeps the tensors alive through self)."""
-        sp = self._split if self._split is not None else _lib.CsrSplit(0, 0, 0, None, None, None, None)
+        sp = self._split if self._split is not None else _lib.CsrSplit(0, 0, 0, None, None, None, None, None, None)
         self._desc = _lib.CsrDesc(self.n_rows, self.rowptr.data_ptr(), self.col.data_ptr(), self.val.data_ptr(), sp)
         return ctypes.byref(self._desc)
 

@@ -113,7 +113,13 @@ typedef struct elimrec_csr_split {
     const int32_t *d_long_rows;     /* [n_long] row ids                                         */
     const int32_t *d_long_seg_ptr;  /* [n_long+1] segment range of each split row               */
     const int32_t *d_seg_bounds;    /* [n_seg][2] (begin,end) positions into col/val            */
-    float *d_partials;              /* [n_seg x C] scratch                                      */
+    float *d_partials;              /* [n_seg x 2C] scratch (C-column region, then d-column region) */
+    const int32_t *d_seg_row;       /* [n_seg] index into d_long_rows of each segment's row (nullable) */
+    int32_t *d_tickets;             /* [2*n_long] zero-initialised arrival counters (nullable): when
+                                       given, the wave that finishes a split row's LAST segment combines
+                                       the row in segment order inside the same launch (agent-scope
+                                       release/acquire); otherwise a separate fix-up launch does. Counters
+                                       return to zero after every launch.                          */
 } elimrec_csr_split;
 
 int elimrec_spmm_hop(const int32_t *d_rowptr, const int32_t *d_col, const float *d_val,
@@ -154,6 +160,8 @@ int elimrec_propagate_bipartite(const elimrec_csr *P, const elimrec_csr *Q, int6
  * optionally (elimrec_set_concurrency(1) or ELIMREC_CONCURRENCY=1; default off -- the step is bandwidth
  * bound, measured gain 0.6 %) the d-column chain runs on an internal side stream forked from / joined to
  * `stream` with events (capturable). The row-split scratch d_partials must hold [n_seg x 2C] floats. */
+int elimrec_ticket_fixup(void);               /* 1 (default): in-launch combine when d_tickets is given */
+void elimrec_set_ticket_fixup(int on);        /* also ELIMREC_TICKET_FIXUP=0 */
 int elimrec_concurrency(void);
 void elimrec_set_concurrency(int on);
 

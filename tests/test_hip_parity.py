@@ -240,6 +240,39 @@ def test_propagate_vs_oracle(C, L):
     assert rel_err(out2.cpu(), want) < 2e-6
 
 
+def test_in_launch_row_combine_is_bitwise_equal_to_fixup_launch():
+    """The split rows of the power-law head are combined either by a separate fix-up launch or, by
+    default, inside the gather launch by the wave that finishes a row's last segment (agent-scope
+    release/acquire + ticket counter). Same summation order => identical bits, every time, at the
+    full Tiktok shape (hundreds of split rows, thousands of segment waves racing)."""
+    from elimrec_amd import SyntheticDataset, _lib, ops
+    from elimrec_amd.model import create_adj_mat
+    ds = SyntheticDataset(36656, 76085, 720829, feat_dims=(4, 4, 4), seed=0)
+    tu, ti = ds.get_train_interactions()
+    adj = create_adj_mat(tu, ti, ds.num_users, ds.num_items, "pre")
+    U, I, d, M = ds.num_users, ds.num_items, 64, 4
+    P = ops.Csr.from_scipy(adj[:U, U:], DEV, C=d * M)
+    Q = ops.Csr.from_scipy(adj[U:, :U], DEV, C=d * M)
+    assert Q._split is not None and Q._split.n_long > 100
+    g = torch.Generator(device=DEV).manual_seed(0)
+    Eu = torch.randn(U, d, device=DEV, generator=g)
+    XI = torch.randn(I, d * M, device=DEV, generator=g)
+    ws = torch.empty(ops.bipartite_workspace(U, I, d, M), dtype=torch.uint8, device=DEV)
+    lib = _lib.load()
+    ref = torch.empty(U + I, d * M, device=DEV)
+    lib.elimrec_set_ticket_fixup(0)
+    try:
+        ops.propagate_bipartite(P, Q, U, I, d, M, 3, Eu, XI, ref, ws)
+    finally:
+        lib.elimrec_set_ticket_fixup(1)
+    out = torch.empty_like(ref)
+    for it in range(25):
+        out.fill_(float("nan"))
+        ops.propagate_bipartite(P, Q, U, I, d, M, 3, Eu, XI, out, ws)
+        assert torch.equal(out, ref), it
+        assert int(Q._split_tensors[5].abs().sum()) == 0          # ticket counters back to zero
+
+
 def test_propagate_linearity_at_tiktok_shape():
     """Size-independent property at the full BASELINE shape: P(aX + bZ) == aP(X) + bP(Z), and
     <P(X), Z> == <X, P^T(Z)> for the symmetric 'pre' adjacency (self-adjointness used by backward)."""
