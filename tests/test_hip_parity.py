@@ -611,3 +611,26 @@ def test_full_kwai_shape_step_vs_oracle():
 def test_full_movielens_shape_step_vs_oracle():
     """BASELINE.json configs[0]: MovieLens shape, D = (2048, 128, 100), recdim 64, batch 1024."""
     _full_shape_step(55485, 5986, 1239508, (2048, 128, 100), 64, 1024, "movielens")
+
+
+def test_data_parallel_math_on_one_gpu():
+    """What rank r of a 2-rank job computes (elimrec_amd/dist.py) emulated on one GPU: forward on each
+    half batch, concatenate the gradient rows in rank order, one backward scaled by 1/2. Must equal
+    the single-GPU step on the whole batch."""
+    g = load_golden("ml3")
+    u, p, n = (_t(g["step1/%s" % k]) for k in ("users", "pos", "neg"))
+    half = (len(u) // 2)
+    whole, _ = build_model_from_fixture(g, DEV)
+    loss_w, rows_w, keys_w = whole.forward_local(u[:2 * half], p[:2 * half], n[:2 * half])
+    grads_w = {k: v.clone() for k, v in whole.backward_global(rows_w, keys_w, torch.ones(1, device=DEV)).items()}
+    dp, _ = build_model_from_fixture(g, DEV)
+    rows, keys, losses = [], [], []
+    for r in range(2):
+        sl = slice(r * half, (r + 1) * half)
+        loss, gr, gk = dp.forward_local(u[sl], p[sl], n[sl], world_size=2)
+        rows.append(gr.clone()); keys.append(gk.clone()); losses.append(loss.clone())
+    grads_dp = dp.backward_global(torch.cat(rows), torch.cat(keys), torch.full((1,), 0.5, device=DEV))
+    assert abs(float(loss_w) - float((losses[0] + losses[1]) / 2)) < 1e-6
+    assert set(grads_w) == set(grads_dp)
+    for k in grads_w:
+        assert rel_err(grads_dp[k].cpu(), grads_w[k].cpu()) < 1e-5, k
