@@ -197,7 +197,7 @@ def main():
                          "avg_launch_us": 1e3 * hop_ms / hop_launches if hop_launches else None,
                          "launches_timed": hop_launches},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:     # the host baseline is timed on rank 0 at N=1 only
             cpu_batches = [tuple(x.cpu() for x in b) for b in batches[:5]]
             out["cpu_baseline"] = cpu_baseline(ds, {k: v.cpu().numpy() for k, v in init_state.items()}, cfg, cpu_batches)
         print(json.dumps(out))

@@ -192,11 +192,22 @@ __global__ __launch_bounds__(256) void head_bwd_input_kernel(const float *__rest
         for (int r = 0; r < HB_ROWS; ++r) acc[r] = 0.f;
         if (any_user != any_item) {                      // the common case: one weight matrix for the whole tile
             const float *Wf = any_user ? W_user : W_item;
-#pragma unroll 4
-            for (int k = 0; k < d; ++k) {
-                const float w = Wf[(int64_t)k * C + c];
+            // weight rows are prefetched 8 deep (L2-resident, ~0.5 us away); dY comes as 16-B LDS broadcasts
+            for (int k = 0; k < d; k += 8) {
+                float w[8];
 #pragma unroll
-                for (int r = 0; r < HB_ROWS; ++r) acc[r] = fmaf(dys[r * Cy + k], w, acc[r]);
+                for (int q = 0; q < 8; ++q) w[q] = (k + q < d) ? Wf[(int64_t)(k + q) * C + c] : 0.f;
+#pragma unroll
+                for (int r = 0; r < HB_ROWS; ++r) {
+                    const float4 y0 = ld4(dys + r * Cy + k);
+                    acc[r] = fmaf(y0.x, w[0], acc[r]); acc[r] = fmaf(y0.y, w[1], acc[r]);
+                    acc[r] = fmaf(y0.z, w[2], acc[r]); acc[r] = fmaf(y0.w, w[3], acc[r]);
+                    if (k + 4 < d) {
+                        const float4 y1 = ld4(dys + r * Cy + k + 4);
+                        acc[r] = fmaf(y1.x, w[4], acc[r]); acc[r] = fmaf(y1.y, w[5], acc[r]);
+                        acc[r] = fmaf(y1.z, w[6], acc[r]); acc[r] = fmaf(y1.w, w[7], acc[r]);
+                    }
+                }
             }
         } else {                                         // the one tile that straddles the user/item boundary
             for (int k = 0; k < d; ++k) {
@@ -210,16 +221,112 @@ __global__ __launch_bounds__(256) void head_bwd_input_kernel(const float *__rest
             if (hp.mblock[h] != mb) continue;
             const float *Wh = hp.w[h] + (c - mb * d);
             const float *dyh = dys + (1 + h) * d;
-#pragma unroll 4
-            for (int k = 0; k < d; ++k) {
-                const float w = Wh[(int64_t)k * d];
+            for (int k = 0; k < d; k += 8) {
+                float w[8];
 #pragma unroll
-                for (int r = 0; r < HB_ROWS; ++r) acc[r] = fmaf(dyh[r * Cy + k], w, acc[r]);
+                for (int q = 0; q < 8; ++q) w[q] = (k + q < d) ? Wh[(int64_t)(k + q) * d] : 0.f;
+#pragma unroll
+                for (int r = 0; r < HB_ROWS; ++r) {
+                    const float4 y0 = ld4(dyh + r * Cy + k);
+                    acc[r] = fmaf(y0.x, w[0], acc[r]); acc[r] = fmaf(y0.y, w[1], acc[r]);
+                    acc[r] = fmaf(y0.z, w[2], acc[r]); acc[r] = fmaf(y0.w, w[3], acc[r]);
+                    if (k + 4 < d) {
+                        const float4 y1 = ld4(dyh + r * Cy + k + 4);
+                        acc[r] = fmaf(y1.x, w[4], acc[r]); acc[r] = fmaf(y1.y, w[5], acc[r]);
+                        acc[r] = fmaf(y1.z, w[6], acc[r]); acc[r] = fmaf(y1.w, w[7], acc[r]);
+                    }
+                }
             }
         }
 #pragma unroll
         for (int r = 0; r < HB_ROWS; ++r)
             if (r < rows) G0[node[r] * C + c] = acc[r] * gscale;
+    }
+}
+
+// MFMA form of the same contraction (used when d % 32 == 0): a workgroup owns 32 active rows, stages
+// their dY rows in LDS (row stride Cy+1: the 32 lanes of a half-wave read 32 different rows at one k),
+// and each wave produces 32x32 output tiles with v_mfma_f32_32x32x2_f32: K runs over the d fused
+// columns (B operand = rows of W_user / W_item, read from L2 eight k-steps ahead) and then over the d
+// columns of the single-modal head that feeds this table block. A tile that straddles the user/item
+// boundary (rows are sorted by node id) accumulates both weight matrices and selects per row.
+typedef float v16f_ __attribute__((ext_vector_type(16)));
+constexpr int HM_ROWS = 32;
+
+__device__ __forceinline__ v16f_ hm_accumulate(v16f_ acc, const float *__restrict__ a_lds, int a_stride,
+                                               const float *__restrict__ Wp, int64_t ldw, int K, int li, int lk) {
+    // acc[row i][col j] += sum_k a_lds[i*a_stride + k] * Wp[k*ldw + j]
+    // The loop is L2-latency bound, not MFMA bound: 16 B-operand loads (a 32-deep K chunk) are issued
+    // back to back, then their 16 MFMAs; eight waves per workgroup interleave these phases.
+    constexpr int PF = 16;
+    for (int k0 = 0; k0 < K; k0 += 2 * PF) {
+        float b[PF];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int k = k0 + 2 * q + lk;
+            b[q] = (k < K) ? Wp[(int64_t)k * ldw + li] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int k = k0 + 2 * q + lk;
+            const float a = (k < K) ? a_lds[li * a_stride + k] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[q], acc, 0, 0, 0);
+        }
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(512) void head_bwd_input_mfma_kernel(const float *__restrict__ dY, int64_t lddy,
+                                                                  const int32_t *__restrict__ active_rows,
+                                                                  const int32_t *__restrict__ seg_info, int64_t n_max,
+                                                                  int64_t U, int d, int C, int S, HeadPtrs hp,
+                                                                  const float *__restrict__ W_user,
+                                                                  const float *__restrict__ W_item, float gscale,
+                                                                  float *__restrict__ G0) {
+    extern __shared__ float dys[];                       // [HM_ROWS][Cy + 1]
+    __shared__ int64_t node[HM_ROWS];
+    const int Cy = (1 + S) * d, ldy = Cy + 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t s0 = (int64_t)blockIdx.x * HM_ROWS;
+    int64_t n_act = seg_info[0];
+    if (n_act > n_max) n_act = n_max;
+    if (s0 >= n_act) return;
+    const int rows = (int)((n_act - s0) < HM_ROWS ? (n_act - s0) : HM_ROWS);
+    for (int e = tid * 4; e < HM_ROWS * Cy; e += 2048) {
+        const int r = e / Cy, c = e - r * Cy;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < rows) v = ld4(dY + (s0 + r) * lddy + c);
+        float *dst = dys + r * ldy + c;
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+    if (tid < HM_ROWS) node[tid] = (tid < rows) ? (int64_t)active_rows[s0 + tid] : -1;
+    __syncthreads();
+    const bool any_user = node[0] < U;
+    const bool any_item = node[rows - 1] >= U;
+    const bool mixed = any_user && any_item;
+    const int li = lane & 31, lk = lane >> 5;
+    const int n_tiles = C / 32;
+    for (int t = wave; t < n_tiles; t += 8) {
+        const int c0 = t * 32;
+        const int mb = c0 / d;
+        v16f_ acc = {0}, acc2 = {0};
+        acc = hm_accumulate(acc, dys, ldy, (any_user ? W_user : W_item) + c0, C, d, li, lk);
+        if (mixed) acc2 = hm_accumulate(acc2, dys, ldy, W_item + c0, C, d, li, lk);
+        for (int h = 0; h < S; ++h) {
+            if (hp.mblock[h] != mb) continue;
+            const float *Wh = hp.w[h] + (c0 - mb * d);
+            acc = hm_accumulate(acc, dys + (1 + h) * d, ldy, Wh, d, d, li, lk);
+            if (mixed) acc2 = hm_accumulate(acc2, dys + (1 + h) * d, ldy, Wh, d, d, li, lk);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < rows) {
+                const int64_t nd = node[row];
+                const float v = (mixed && nd >= U) ? acc2[r] : acc[r];
+                G0[nd * C + c0 + li] = v * gscale;
+            }
+        }
     }
 }
 
@@ -338,6 +445,15 @@ extern "C" int elimrec_head_bwd_input(const float *d_dY, int64_t lddy, const int
         hp.mblock[h] = h < S ? head_mblock[h] : -1;
     }
     if (n_max <= 0) return 0;
+    if (d % 32 == 0 && (size_t)HM_ROWS * ((1 + S) * d + 1) * sizeof(float) <= 96 * 1024) {
+        const size_t lds_m = (size_t)HM_ROWS * ((1 + S) * d + 1) * sizeof(float);
+        ELIMREC_REQUIRE(lddy % 4 == 0, "head_bwd_input: lddy must be a multiple of 4");
+        hipLaunchKernelGGL(head_bwd_input_mfma_kernel, dim3((unsigned)((n_max + HM_ROWS - 1) / HM_ROWS)), dim3(512),
+                           lds_m, (hipStream_t)stream, d_dY, lddy, d_active_rows, d_seg_info, n_max, U, d, C, S, hp,
+                           d_W_user, d_W_item, gscale, d_G0);
+        ELIMREC_LAUNCH_CHECK("head_bwd_input_mfma");
+        return 0;
+    }
     const size_t lds = (size_t)HB_ROWS * (1 + S) * d * sizeof(float);
     ELIMREC_REQUIRE(lds <= 128 * 1024, "head_bwd_input: (1+S)*d too large for the LDS tile");
     ELIMREC_REQUIRE(lddy % 4 == 0, "head_bwd_input: lddy must be a multiple of 4");
