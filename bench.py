@@ -129,7 +129,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    force_coll = os.environ.get("ELIMREC_FORCE_COLLECTIVES", "0") == "1" and "RANK" in os.environ
+    if world > 1 or force_coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
@@ -140,7 +141,7 @@ def main():
     from elimrec_amd.dist import DataParallelTrainer
     B = WORKLOAD["batch_size"]
     opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
-    trainer = DataParallelTrainer(model, opt, world_size=world, rank=rank)
+    trainer = DataParallelTrainer(model, opt, world_size=world, rank=rank, force_collectives=force_coll)
 
     # triplets for every step, sampled on the device and resident in HBM before the timed region
     total = args.warmup + args.steps
@@ -152,7 +153,7 @@ def main():
     batches = [(U_[i * B:(i + 1) * B], P_[i * B:(i + 1) * B], N_[i * B:(i + 1) * B]) for i in range(total)]
 
     def sync():
-        if world > 1:
+        if world > 1 or force_coll:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -201,7 +202,7 @@ def main():
             cpu_batches = [tuple(x.cpu() for x in b) for b in batches[:5]]
             out["cpu_baseline"] = cpu_baseline(ds, {k: v.cpu().numpy() for k, v in init_state.items()}, cfg, cpu_batches)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_coll:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -21,8 +21,10 @@ import torch.distributed as dist
 
 
 class DataParallelTrainer(object):
-    def __init__(self, engine, optimizer, world_size=1, rank=0, group=None):
+    def __init__(self, engine, optimizer, world_size=1, rank=0, group=None, force_collectives=False):
         self.engine, self.opt, self.world, self.rank, self.group = engine, optimizer, int(world_size), int(rank), group
+        # force_collectives: run the all-gather path even with one rank (exercises RCCL on a 1-GPU box)
+        self.collectives = self.world > 1 or bool(force_collectives)
         self.profile_kernels = False
         self._events = []
         self._scale = None
@@ -42,7 +44,7 @@ class DataParallelTrainer(object):
         if self.profile_kernels and getattr(eng, "_kernel_events", None) is None:
             eng._kernel_events = self._events
         loss, grad_rows, keys = eng.forward_local(users, pos, neg, world_size=self.world)
-        if self.world > 1:
+        if self.collectives:
             all_rows, all_keys = self._buffers(grad_rows, keys)
             dist.all_gather_into_tensor(all_rows, grad_rows, group=self.group)
             dist.all_gather_into_tensor(all_keys, keys, group=self.group)
