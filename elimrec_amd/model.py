@@ -115,7 +115,15 @@ class EliMRec(BasicModel):
             raise ValueError("mm_fusion_mode must be 'concat' or 'mean'")
         self.dataset_name = cfg["data.input.dataset"]
         self.is_kwai = self.dataset_name == "kwai"
-        self._mods = ["v"] if self.is_kwai else ["v", "a", "t"]       # tables after the id table
+        # tables after the id table. The reference keys this on the data set name only (kwai -> V, else V,A,T:
+        # EliMRec.py:148,234,254,261); `--feature_modalities=vt` (CLI-only, not in the reference) selects any
+        # subset whose features the data set provides, e.g. BASELINE.json's Kwai-shape "V+T" configuration.
+        self._mods = ["v"] if self.is_kwai else ["v", "a", "t"]
+        if "feature_modalities" in cfg:
+            self._mods = [m for m in "vat" if m in str(cfg["feature_modalities"])]
+            if not self._mods or any(not hasattr(self.dataset, m + "_feat") for m in self._mods):
+                raise ValueError("feature_modalities=%r needs the matching <m>_feat tensors on the data set"
+                                 % cfg["feature_modalities"])
         self.M = 1 + len(self._mods)
         self.C = self.M * self.latent_dim
         self.S = len(self._mods)                                       # single-modal heads
@@ -187,8 +195,15 @@ class EliMRec(BasicModel):
         nn.init.xavier_uniform_(self.embedding_item.weight)
         Logger.info("[use Xavier initilizer]")
         ds = self.dataset
-        self.register_buffer("v_feat", F.normalize(ds.v_feat.float(), dim=1).contiguous(), persistent=False)
-        if not self.is_kwai:
+        custom = "feature_modalities" in self.config
+        if "v" in self._mods:
+            self.register_buffer("v_feat", F.normalize(ds.v_feat.float(), dim=1).contiguous(), persistent=False)
+        if custom:
+            for m in self._mods:
+                if m != "v":
+                    self.register_buffer(m + "_feat", F.normalize(getattr(ds, m + "_feat").float(), dim=1).contiguous(),
+                                         persistent=False)
+        elif not self.is_kwai:
             self.register_buffer("a_feat", F.normalize(ds.a_feat.float(), dim=1).contiguous(), persistent=False)
             if self.dataset_name == "tiktok":
                 # :371-378: t_feat is the scatter-mean of word embeddings, built ONCE at init and
@@ -209,15 +224,11 @@ class EliMRec(BasicModel):
                 raise ValueError("%s_feat has %d rows, expected num_items=%d" % (m, feat.shape[0], self.num_items))
             if feat.shape[1] % 4 != 0:
                 raise ValueError("feature width of '%s' must be a multiple of 4 (got %d)" % (m, feat.shape[1]))
-        self.v_dense = nn.Linear(self.v_feat.shape[1], d)
-        if not self.is_kwai:
-            self.a_dense = nn.Linear(self.a_feat.shape[1], d)
-            self.t_dense = nn.Linear(self.t_feat.shape[1], d)
+        for m in self._mods:                      # v_dense, a_dense, t_dense in the reference's order (:384-389)
+            setattr(self, m + "_dense", nn.Linear(getattr(self, m + "_feat").shape[1], d))
         self.item_feat_dim = d * self.M if self.mm_fusion_mode == "concat" else d
-        nn.init.xavier_uniform_(self.v_dense.weight)
-        if not self.is_kwai:
-            nn.init.xavier_uniform_(self.a_dense.weight)
-            nn.init.xavier_uniform_(self.t_dense.weight)
+        for m in self._mods:                      # :397-400
+            nn.init.xavier_uniform_(getattr(self, m + "_dense").weight)
         self.embedding_user_after_GCN = nn.Linear(self.item_feat_dim, d)
         nn.init.xavier_uniform_(self.embedding_user_after_GCN.weight)
         self.embedding_item_after_GCN = nn.Linear(self.item_feat_dim, d)

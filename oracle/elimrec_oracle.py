@@ -74,10 +74,13 @@ class OracleEliMRec:
 
     def __init__(self, num_users, num_items, recdim, layer_num, adj, feats, params, alpha,
                  dataset_name="movielens", modality="vat", mm_fusion_mode="concat",
-                 fusion_mode="rubi", predict_type="TIE"):
+                 fusion_mode="rubi", predict_type="TIE", mods=None):
         self.U, self.I, self.d, self.L = int(num_users), int(num_items), int(recdim), int(layer_num)
         self.adj = adj if isinstance(adj, torch.Tensor) else adj_to_torch(adj)
         self.kwai = dataset_name == "kwai"              # EliMRec.py:133,148,158,234,254,261
+        # `mods`: NOT in the reference (it hard-codes V for kwai, V,A,T otherwise). A generalisation used only
+        # for BASELINE.json's "V+T" Kwai-shape case; parity for it is unpinned (no reference run exists).
+        self.mods = list(mods) if mods is not None else (["v"] if self.kwai else ["v", "a", "t"])
         self.feats = {k: torch.as_tensor(v, dtype=torch.float32) for k, v in feats.items()}
         self.params = {k: torch.as_tensor(np.array(v), dtype=torch.float32).clone().requires_grad_(True)
                        for k, v in params.items()}
@@ -117,7 +120,7 @@ class OracleEliMRec:
         p = self.params
         users_emb = p["embedding_user.weight"]
         items_emb = p["embedding_item.weight"]
-        mods = ["v"] if self.kwai else ["v", "a", "t"]
+        mods = self.mods
         dense = {m: self._linear("%s_dense" % m, self.feats[m]) for m in mods}   # :233-236
         self.m_emb = {"i": self._compute_graph(users_emb, items_emb)}           # :250
         for m in mods:                                                           # :252-256
@@ -132,7 +135,7 @@ class OracleEliMRec:
     def gcn_cf(self):
         """models/EliMRec.py:144-153."""
         out = {}
-        for m in (["v"] if self.kwai else ["v", "a", "t"]):
+        for m in self.mods:
             e = self._linear("s_dense_%s" % m, self.m_emb[m])
             out["pre_fusion_user_" + m], out["pre_fusion_item_" + m] = torch.split(e, [self.U, self.I])
         return out
@@ -157,6 +160,8 @@ class OracleEliMRec:
             return fusion
         p_loss = 0
         for m in self.modality:                                                  # :136-140
+            if m not in self.mods:
+                continue
             s = self.all_s_embs
             p_loss = p_loss + self.original_bpr_loss(s["pre_fusion_user_" + m][users],
                                                      s["pre_fusion_item_" + m][pos],
@@ -167,7 +172,7 @@ class OracleEliMRec:
     def general_cm_fusion(self, fusion_logits, users):
         """models/EliMRec.py:155-212 with items=None, normalize=True."""
         s = self.all_s_embs
-        mods = ["v"] if self.kwai else ["v", "a", "t"]
+        mods = self.mods
         z = {}
         for m in mods:
             su = F.normalize(s["pre_fusion_user_" + m][users], dim=1)

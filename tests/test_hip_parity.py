@@ -634,3 +634,45 @@ def test_data_parallel_math_on_one_gpu():
     assert set(grads_w) == set(grads_dp)
     for k in grads_w:
         assert rel_err(grads_dp[k].cpu(), grads_w[k].cpu()) < 1e-5, k
+
+
+def test_kwai_shape_v_plus_t_variant_vs_oracle():
+    """BASELINE.json configs[2] as stated ("V+T only"): id + V + T tables (M = 3, two single-modal heads)
+    via --feature_modalities=vt. The reference itself cannot run this combination, so this checks the HIP
+    path against the oracle's generalisation only (unpinned; see oracle/elimrec_oracle.py)."""
+    import os
+    from helpers import make_config
+    from elimrec_amd import EliMRec, SyntheticDataset, set_seed
+    from oracle import elimrec_oracle as eo
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    U, I, B = 7010, 86483, 2048
+    cfg = make_config(["--data.input.dataset=kwai_vt", "--alpha=0.5", "--loss=bpr_loss", "--verbose=0",
+                       "--feature_modalities=vt", "--modality=vt"])
+    ds = SyntheticDataset(U, I, 298492, feat_dims=(2048, 4, 128), seed=1, name="kwai_vt")
+    set_seed(5)
+    model = EliMRec(cfg, ds)
+    assert model.M == 3 and model.S == 2 and not hasattr(model, "a_dense")
+    init = {k: v.detach().clone().numpy() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    g = torch.Generator().manual_seed(3)
+    train = ds.train_matrix.tocoo()
+    pick = torch.randint(0, train.nnz, (B,), generator=g).numpy()
+    u = torch.from_numpy(train.row[pick].astype(np.int64)); p = torch.from_numpy(train.col[pick].astype(np.int64))
+    n = torch.randint(0, I, (B,), generator=g)
+    loss = model.bpr_loss(u.to(DEV), p.to(DEV), n.to(DEV))
+    loss.backward()
+    tu, ti = ds.get_train_interactions()
+    adj = eo.build_adj(tu, ti, U, I, cfg["adj_type"])
+    feats = {m: eo.OracleEliMRec.normalize_features(getattr(ds, m + "_feat")) for m in "vt"}
+    om = eo.OracleEliMRec(U, I, cfg["recdim"], cfg["layer_num"], adj, feats, init, cfg["alpha"], modality="vt", mods="vt")
+    ol = om.bpr_loss(u, p, n)
+    ol.backward()
+    assert abs(loss.item() - float(ol.detach())) < 1e-5
+    mine = {k: q.grad.cpu() for k, q in model.named_parameters() if q.grad is not None}
+    assert set(mine) == set(om.grads())
+    for k, v in om.grads().items():
+        assert rel_err(mine[k], v) < 1e-4, k
+    users = list(range(0, U, 111))[:48]
+    for ptype in ("TE", "TIE"):
+        model.predict_type = om.predict_type = ptype
+        assert np.abs(model.predict(users).numpy() - om.predict(users).numpy()).max() < 1e-5
