@@ -253,8 +253,6 @@ class EliMRec(BasicModel):
         if self._ws is not None and self._ws_key[:2] == (str(dev), int(B)) and self._ws_key[2] >= bwd_rows:
             return self._ws
         key = (str(dev), int(B), bwd_rows)
-        if self._ws is not None and self._ws_key == key:
-            return self._ws
         N, C, Cy, d = self.num_users + self.num_items, self.C, self.Cy, self.latent_dim
         f32 = dict(dtype=torch.float32, device=dev)
         ws = self._ws if (self._ws is not None and self._ws_key[0] == key[0]) else {}
@@ -271,8 +269,6 @@ class EliMRec(BasicModel):
             shapes = [(self.num_items, d, getattr(self, m + "_feat").shape[1]) for m in self._mods]
             ws["bwd_w_items"] = torch.empty(max(ops.linear_bwd_w_batched_workspace(shapes), 1), dtype=torch.uint8,
                                             device=dev)
-            ws["loss"] = torch.zeros(1, **f32)
-            ws["one"] = torch.ones(1, **f32)
         n3 = bwd_rows
         ws["loss_rows"] = torch.empty(B, **f32)
         ws["grad_rows"] = torch.empty(3 * B, Cy, **f32)
