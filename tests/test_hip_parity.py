@@ -444,7 +444,7 @@ def test_driver_runs_epochs_with_eval_and_checkpoint(tmp_path):
 
 
 @pytest.mark.parametrize("L", [1, 2, 3, 4])
-@pytest.mark.parametrize("d,M", [(64, 4), (32, 2), (16, 3)])
+@pytest.mark.parametrize("d,M", [(64, 4), (32, 2), (16, 3), (128, 4), (256, 2)])
 def test_bipartite_propagation_equals_full_propagation(L, d, M):
     """Forward: Out from the bipartite (wide + narrow chain) kernels == Out from the generic
     full-table kernels == fp64 reference. Backward: the adjoint pair (gXI, gE_u) == the gradients
