@@ -348,11 +348,43 @@ __device__ __forceinline__ float4 half_gather(const HalfArgs &a, int beg, int en
     return acc;
 }
 
+// Same sum when the source table is row-sparse (the raw head gradient: non-zero on <= 3B rows): the LPR
+// lanes of a row test LPR neighbours at once against the row bitmap (one coalesced col load + one bitmap
+// probe per lane + a ballot) and only the few active ones are gathered. Neighbour order is preserved, so
+// the result equals half_gather's on the same data with zeros in the inactive rows.
+template <int LPR>
+__device__ __forceinline__ float4 half_gather_masked(const HalfArgs &a, int beg, int end, int c, bool on, int sub,
+                                                     int cl) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j0 = beg; j0 < end; j0 += LPR) {
+        const int jj = j0 + cl;
+        const bool in = jj < end;
+        const int cj = in ? a.col[jj] : 0;
+        const float vj = in ? a.val[jj] : 0.f;
+        const bool act = in && mask_bit(a.src_mask, cj);
+        unsigned long long bits = __ballot(act);
+        if (LPR < 64) bits = (bits >> (sub * LPR)) & ((1ull << LPR) - 1ull);
+        while (bits) {
+            const int b = __builtin_ctzll(bits);
+            bits &= bits - 1ull;
+            const int src = sub * LPR + b;
+            const int cjb = __shfl(cj, src, 64);
+            const float vjb = __shfl(vj, src, 64);
+            if (on) {
+                const float4 x = a.Xin[(int64_t)cjb * a.W4 + c];
+                acc.x = fmaf(vjb, x.x, acc.x); acc.y = fmaf(vjb, x.y, acc.y);
+                acc.z = fmaf(vjb, x.z, acc.z); acc.w = fmaf(vjb, x.w, acc.w);
+            }
+        }
+    }
+    return acc;
+}
+
 // LPR lanes per row (power of two <= 64): a wave handles 64/LPR rows, so narrow (d-column) tables use
 // every lane. ONE launch covers both kinds of work item: the first `seg_blocks` workgroups take segments
 // of the split (long) rows and write partial sums, the rest take whole rows of the CSR (long rows
 // skipped) and finish them. The heavy segment waves start first and the two kinds overlap.
-template <int LPR, int UNROLL>
+template <int LPR, int UNROLL, bool MASKED>
 __global__ __launch_bounds__(256) void half_hop_kernel(HalfArgs a, int seg_blocks) {
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63;
@@ -383,7 +415,8 @@ __global__ __launch_bounds__(256) void half_hop_kernel(HalfArgs a, int seg_block
     for (int c0 = 0; c0 < a.W4; c0 += LPR) {
         const int c = c0 + cl;
         const bool on = valid && c < a.W4;
-        const float4 acc = half_gather<UNROLL>(a, beg, end, c, on);
+        const float4 acc = MASKED ? half_gather_masked<LPR>(a, beg, end, c, on, sub, cl)
+                                  : half_gather<UNROLL>(a, beg, end, c, on);
         if (on) {
             if (!seg_mode) half_epilogue(a, item, c, acc);
             else if (!publish) a.partials[item * a.W4 + c] = acc;
@@ -512,8 +545,12 @@ static int launch_half(const elimrec_csr *m, HalfArgs a, size_t partials_offset,
 #define ELIMREC_HALF_LAUNCH(LPR)                                                                                     \
     do {                                                                                                             \
         const unsigned seg_blocks = has_split ? blocks(a.n_seg).x : 0u;                                              \
-        hipLaunchKernelGGL((half_hop_kernel<LPR, 8>), dim3(seg_blocks + blocks(a.n_rows).x), dim3(64 * waves), 0, s, \
-                           a, (int)seg_blocks);                                                                      \
+        if (a.src_mask)                                                                                              \
+            hipLaunchKernelGGL((half_hop_kernel<LPR, 8, true>), dim3(seg_blocks + blocks(a.n_rows).x),               \
+                               dim3(64 * waves), 0, s, a, (int)seg_blocks);                                          \
+        else                                                                                                         \
+            hipLaunchKernelGGL((half_hop_kernel<LPR, 8, false>), dim3(seg_blocks + blocks(a.n_rows).x),              \
+                               dim3(64 * waves), 0, s, a, (int)seg_blocks);                                          \
         ELIMREC_LAUNCH_CHECK("half_hop");                                                                            \
         if (has_split && !a.tickets) {                                                                               \
             hipLaunchKernelGGL((half_fixup_kernel<LPR>), blocks(a.n_long), dim3(64 * waves), 0, s, a);               \
