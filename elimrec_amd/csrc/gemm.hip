@@ -10,6 +10,7 @@
 //   lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31];
 //   accumulator register r of lane l is D[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][l & 31].
 #include "common.h"
+#include <cstdlib>
 
 namespace elimrec {
 
@@ -25,6 +26,10 @@ struct FwdBatch { elimrec_linear_desc p[kMaxBatch]; };
 
 // blockIdx.z selects the problem: independent Linears (the three feature projections; the five head
 // Linears) share one launch so the grid fills the chip.
+// BM = 128: wave w owns rows [32w, 32w+32) x all 64 columns (two MFMA tiles share the A operand).
+// BM = 64 : wave w owns rows [32(w&1), +32) x columns [32(w>>1), +32) (one tile); twice the workgroups,
+//           smaller LDS footprint -- better when the grid is only a couple of rounds deep.
+template <int BM>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(FwdBatch batch) {
     const elimrec_linear_desc &pd = batch.p[blockIdx.z];
     const float *__restrict__ A = pd.d_A;
@@ -33,26 +38,29 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(FwdBatch batch) {
     float *__restrict__ C = pd.d_C;
     const int64_t lda = pd.lda, ldw = pd.ldw, ldc = pd.ldc, M = pd.M;
     const int N = pd.N, K = pd.K;
-    if ((int64_t)blockIdx.x * FBM >= M || blockIdx.y * FBN >= N) return;
+    if ((int64_t)blockIdx.x * BM >= M || blockIdx.y * FBN >= N) return;
     // two LDS stages: the global loads of K-chunk t+1 are in flight (in registers) while chunk t
     // feeds the MFMAs; one barrier per chunk.
-    __shared__ float As[2][FBM * FLD];
+    __shared__ float As[2][BM * FLD];
     __shared__ float Bs[2][FBN * FLD];
+    constexpr int AP = BM / 32;      // float4 loads per thread for the A chunk
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int64_t m0 = (int64_t)blockIdx.x * FBM;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
     const int n0 = blockIdx.y * FBN;
     const int lr = tid >> 3;        // 0..31 : row inside a 32-row group
     const int lc = (tid & 7) * 4;   // 0,4,..28 : k offset of this thread's float4
+    const int wrow = (BM == 128) ? wave * 32 : (wave & 1) * 32;
+    const int wcol = (BM == 128) ? 0 : (wave >> 1) * 32;
 
     v16f acc0 = {0}, acc1 = {0};
     const int ai = lane & 31, ak = lane >> 5;
-    float4 ra[4], rb[2];
+    float4 ra[AP], rb[2];
     auto load_chunk = [&](int k0) {
         const bool kin = (k0 + lc) < K;  // K % 4 == 0: the whole float4 is in or out
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < AP; ++i) {
             const int64_t gr = m0 + lr + 32 * i;
             ra[i] = (kin && gr < M) ? *reinterpret_cast<const float4 *>(A + gr * lda + k0 + lc)
                                     : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -66,7 +74,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(FwdBatch batch) {
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < AP; ++i) {
             float *dst = &As[buf][(lr + 32 * i) * FLD + lc];
             dst[0] = ra[i].x; dst[1] = ra[i].y; dst[2] = ra[i].z; dst[3] = ra[i].w;
         }
@@ -83,32 +91,34 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(FwdBatch batch) {
     for (int k0 = 0; k0 < K; k0 += FBK) {
         const bool more = (k0 + FBK) < K;
         if (more) load_chunk(k0 + FBK);
-        const float *ap = &As[buf][(wave * 32 + ai) * FLD + ak];
-        const float *bp0 = &Bs[buf][ai * FLD + ak];
+        const float *ap = &As[buf][(wrow + ai) * FLD + ak];
+        const float *bp0 = &Bs[buf][(wcol + ai) * FLD + ak];
         const float *bp1 = &Bs[buf][(32 + ai) * FLD + ak];
 #pragma unroll
         for (int kk = 0; kk < FBK; kk += 2) {
             const float a = ap[kk];
             const float b0 = bp0[kk];
-            const float b1 = bp1[kk];
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+            if (BM == 128) {
+                const float b1 = bp1[kk];
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+            }
         }
         if (more) store_chunk(buf ^ 1);
         __syncthreads();
         buf ^= 1;
     }
 
-    const int col0 = n0 + (lane & 31);
+    const int col0 = n0 + wcol + (lane & 31);
     const int col1 = col0 + 32;
     const float bias0 = (bias && col0 < N) ? bias[col0] : 0.f;
-    const float bias1 = (bias && col1 < N) ? bias[col1] : 0.f;
+    const float bias1 = (BM == 128 && bias && col1 < N) ? bias[col1] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int64_t row = m0 + wrow + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < M) {
             if (col0 < N) C[row * ldc + col0] = acc0[r] + bias0;
-            if (col1 < N) C[row * ldc + col1] = acc1[r] + bias1;
+            if (BM == 128 && col1 < N) C[row * ldc + col1] = acc1[r] + bias1;
         }
     }
 }
@@ -232,20 +242,22 @@ __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(BwdBatch batc
     if (colsum_slabs && tile_z == 0 && tid < TN1) colsum_slabs[(size_t)chunk * n1_pad + i_base + tid] = csum;
 }
 
-// out[e] (+)= sum over chunks of slab[chunk][e], chunk order fixed; 4 chunks kept in flight.
+// out[e] (+)= sum over chunks of slab[chunk][e] in a FIXED order: four adjacent lanes share one output
+// element, lane q adds chunks q, q+4, q+8, ... (4 loads in flight each), then (q0+q1)+(q2+q3).
 // blockIdx.y selects the problem.
 __global__ void reduce_slabs_kernel(BwdBatch batch) {
     const BwdProblem &pb = batch.p[blockIdx.y];
     const int n1 = pb.d.n1, n2 = pb.d.n2;
     const int n1_pad = pb.t1 * TN1, n2_pad = pb.t2 * TN2;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int idx = gid >> 2, q = gid & 3;
     const int total = n1 * n2;
     int64_t rows = pb.d.d_range ? (int64_t)pb.d.d_range[1] - pb.d.d_range[0] : pb.d.R;
     if (rows < 0) rows = 0;
     const int chunks = (int)((rows + pb.chunk_rows - 1) / pb.chunk_rows);
-    const float *src;
-    size_t stride;
-    float *dst;
+    const float *src = nullptr;
+    size_t stride = 0;
+    float *dst = nullptr;
     if (idx < total) {
         const int i = idx / n2, j = idx - i * n2;
         src = pb.slabs + (size_t)i * n2_pad + j;
@@ -255,18 +267,20 @@ __global__ void reduce_slabs_kernel(BwdBatch batch) {
         src = pb.cslabs + (idx - total);
         stride = (size_t)n1_pad;
         dst = pb.d.d_colsum + (idx - total);
-    } else {
-        return;
     }
     float s = 0.f;
-    int c = 0;
-    for (; c + 4 <= chunks; c += 4) {
-        const float v0 = src[(size_t)c * stride], v1 = src[(size_t)(c + 1) * stride];
-        const float v2 = src[(size_t)(c + 2) * stride], v3 = src[(size_t)(c + 3) * stride];
-        s += v0; s += v1; s += v2; s += v3;
+    if (src) {
+        int c = q;
+        for (; c + 12 < chunks; c += 16) {
+            const float v0 = src[(size_t)c * stride], v1 = src[(size_t)(c + 4) * stride];
+            const float v2 = src[(size_t)(c + 8) * stride], v3 = src[(size_t)(c + 12) * stride];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; c < chunks; c += 4) s += src[(size_t)c * stride];
     }
-    for (; c < chunks; ++c) s += src[(size_t)c * stride];
-    *dst = pb.d.accumulate ? (*dst + s) : s;
+    s += __shfl_xor(s, 1, 64);       // (q0+q1), (q2+q3)
+    s += __shfl_xor(s, 2, 64);       // sum of the two pairs
+    if (src && q == 0) *dst = pb.d.accumulate ? (*dst + s) : s;
 }
 
 }  // namespace elimrec
@@ -285,14 +299,23 @@ extern "C" int elimrec_linear_fwd_batched(const elimrec_linear_desc *descs, int 
         ELIMREC_REQUIRE(d.K % 4 == 0 && d.lda % 4 == 0 && d.ldw % 4 == 0, "linear_fwd: K, lda, ldw must be multiples of 4");
         ELIMREC_REQUIRE(((uintptr_t)d.d_A % 16) == 0 && ((uintptr_t)d.d_W % 16) == 0, "linear_fwd: A and W must be 16-byte aligned");
         batch.p[i] = d;
-        const int64_t tm = (d.M + FBM - 1) / FBM;
+        if (d.M > max_tiles_m) max_tiles_m = d.M;       // rows; converted to tiles below
         const int tn = (d.N + FBN - 1) / FBN;
-        if (tm > max_tiles_m) max_tiles_m = tm;
         if (tn > max_tiles_n) max_tiles_n = tn;
     }
     if (max_tiles_m == 0) return 0;
-    dim3 grid((unsigned)max_tiles_m, (unsigned)max_tiles_n, (unsigned)n);
-    hipLaunchKernelGGL(linear_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, batch);
+    static int tile_rows = 0;
+    if (!tile_rows) {
+        const char *e = getenv("ELIMREC_FWD_TILE");
+        tile_rows = (e && atoi(e) == 128) ? 128 : 64;
+    }
+    if (tile_rows == 128) {
+        dim3 grid((unsigned)((max_tiles_m + 127) / 128), (unsigned)max_tiles_n, (unsigned)n);
+        hipLaunchKernelGGL(linear_fwd_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, batch);
+    } else {
+        dim3 grid((unsigned)((max_tiles_m + 63) / 64), (unsigned)max_tiles_n, (unsigned)n);
+        hipLaunchKernelGGL(linear_fwd_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, batch);
+    }
     ELIMREC_LAUNCH_CHECK("linear_fwd");
     return 0;
 }
@@ -304,8 +327,14 @@ extern "C" int elimrec_linear_fwd(const float *d_A, int64_t lda, const float *d_
     return elimrec_linear_fwd_batched(&d, 1, stream);
 }
 
+// Row-chunk size: the partial kernel holds 48 KB of LDS, i.e. 3 workgroups per CU = 768 resident at once;
+// chunks are sized so that one problem's workgroups fill about a third of that (batches hold ~3 problems
+// of equal weight) in ONE round, between 64 and 512 rows.
 static inline void bwd_w_dims(int64_t R, int n1, int n2, int &chunk_rows, int &chunks, int &t1, int &t2) {
-    chunk_rows = (R >= 32768) ? 256 : 64;      // enough workgroups for the short (row-sparse) reductions
+    const int tiles = ((n1 + TN1 - 1) / TN1) * ((n2 + TN2 - 1) / TN2);
+    int64_t want = (R * tiles + 239) / 240;                 // rows per workgroup for ~240 workgroups
+    want = (want + TRB - 1) / TRB * TRB;
+    chunk_rows = (int)(want < 64 ? 64 : (want > 512 ? 512 : want));
     chunks = (int)((R + chunk_rows - 1) / chunk_rows);
     if (chunks < 1) chunks = 1;
     t1 = (n1 + TN1 - 1) / TN1;
@@ -361,7 +390,7 @@ extern "C" int elimrec_linear_bwd_w_batched(const elimrec_linear_bwd_desc *descs
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(linear_bwd_w_partial_kernel, dim3(blocks), dim3(256), 0, s, batch);
     ELIMREC_LAUNCH_CHECK("linear_bwd_w_partial");
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((max_out + 127) / 128, n), dim3(128), 0, s, batch);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((4 * max_out + 255) / 256, n), dim3(256), 0, s, batch);
     ELIMREC_LAUNCH_CHECK("reduce_slabs");
     return 0;
 }
