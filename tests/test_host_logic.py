@@ -137,3 +137,60 @@ def test_checkpoint_name_and_metrics_info():
         name = model.getFileName()
         assert name.endswith("EliMRec-movielens-bpr_loss-.pth.tar") and os.path.isdir(os.path.join(td, "ck"))
     assert model.valid_evaluator.metrics_info().startswith("metrics:\tPrecision@10")
+
+
+def test_csv_dataset_loader_remaps_ids_like_the_reference(tmp_path):
+    """data/dataset.py:105-185,194-238 semantics: ids remapped by first appearance over
+    concat(train, test, valid); features indexed by ORIGINAL item id; duplicates collapse."""
+    from elimrec_amd import Dataset
+    d = tmp_path / "dataset"
+    d.mkdir()
+    (d / "toy.train").write_text("10,7\n10,3\n20,7\n30,5\n10,7\n")
+    (d / "toy.test").write_text("20,3\n30,9\n")
+    (d / "toy.valid").write_text("10,9\n40,5\n")
+    feats = np.arange(12 * 4, dtype=np.float32).reshape(12, 4)
+    for tag in ("FeatureVideo_normal", "FeatureAudio_avg_normal", "FeatureText_stl_normal"):
+        np.save(d / ("toy_%s.npy" % tag), feats + (0 if "Video" in tag else 100 if "Audio" in tag else 200))
+    conf = {"data.input.dataset": "toy", "data.input.path": str(d), "data.convert.separator": ",",
+            "data.column.format": "UI", "splitter": "given", "with_item_vat": True}
+    ds = Dataset(conf)
+    assert ds.userids == {10: 0, 20: 1, 30: 2, 40: 3}                  # first appearance: train, then test, then valid
+    assert ds.itemids == {7: 0, 3: 1, 5: 2, 9: 3}
+    assert (ds.num_users, ds.num_items) == (4, 4)
+    assert ds.get_user_train_dict() == {0: [0, 1], 1: [0], 2: [2]}     # the duplicate (10,7) collapses
+    assert ds.get_user_test_dict() == {1: [1], 2: [3]} and ds.get_user_valid_dict() == {0: [3], 3: [2]}
+    tu, ti = ds.get_train_interactions()
+    assert sorted(zip(tu, ti)) == [(0, 0), (0, 1), (1, 0), (2, 2)]
+    assert torch.equal(ds.v_feat, torch.from_numpy(feats[[7, 3, 5, 9]]))   # rows of the ORIGINAL ids, in remap order
+    assert float(ds.a_feat[0, 0]) == 100 + 7 * 4 and float(ds.t_feat[3, 1]) == 200 + 9 * 4 + 1
+    with pytest.raises(NotImplementedError):
+        Dataset(dict(conf, splitter="ratio"))
+    with pytest.raises(ValueError):
+        Dataset(dict(conf, **{"data.column.format": "XYZ"}))
+
+
+def test_csv_dataset_loader_matches_reference_on_the_golden_data(tmp_path):
+    """Regenerate the exact files tests/golden/make_golden.py fed to the reference's Dataset (same seeded
+    generator) and load them with elimrec_amd.Dataset: interactions, dicts and (normalised) features must
+    equal what the reference produced (captured in tests/golden/ml3.npz)."""
+    import importlib.util
+    from helpers import GOLDEN, csr_dict
+    from elimrec_amd import Dataset
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    mg.write_dataset(str(tmp_path), "movielens", np.random.RandomState(11), 70, 110, (40, 24, 20))
+    conf = {"data.input.dataset": "movielens", "data.input.path": str(tmp_path / "dataset"),
+            "data.convert.separator": ",", "data.column.format": "UI", "splitter": "given", "with_item_vat": True}
+    ds = Dataset(conf)
+    g = load_golden("ml3")
+    assert (ds.num_users, ds.num_items) == (int(g["num_users"]), int(g["num_items"]))
+    tu, ti = ds.get_train_interactions()
+    assert sorted(zip(tu, ti)) == sorted(zip(g["train_u"].tolist(), g["train_i"].tolist()))
+    for split, got in (("train", ds.get_user_train_dict()), ("valid", ds.get_user_valid_dict()),
+                       ("test", ds.get_user_test_dict())):
+        want = csr_dict(g, split)
+        assert {k: sorted(v) for k, v in got.items()} == {k: sorted(v) for k, v in want.items()}, split
+    for m in "vat":
+        got = torch.nn.functional.normalize(getattr(ds, m + "_feat").float(), dim=1).numpy()
+        assert np.array_equal(got, g[m + "_feat"]), m
