@@ -270,7 +270,8 @@ struct HalfArgs {
     const int32_t *rowptr, *col;
     const float *val;
     int64_t n_rows;
-    int W4;                       // row width of Xin / Xout / Add* / AccOut in float4
+    int W4;                       // columns processed, in float4
+    int ld4;                      // row stride of Xin / Xout / Add1 / Add2 / AccOut in float4 (>= W4)
     const float4 *Xin;
     const uint32_t *src_mask;     // nullable: bit r set <=> source row r is non-zero
     float4 *Xout;                 // nullable: raw result
@@ -298,22 +299,22 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bool mask_bit(const uint32_t *m, int r) { return (m[r >> 5] >> (r & 31)) & 1u; }
 
 __device__ __forceinline__ void half_epilogue(const HalfArgs &a, int64_t row, int c, float4 r) {
-    if (a.Xout) a.Xout[row * a.W4 + c] = r;
+    if (a.Xout) a.Xout[row * a.ld4 + c] = r;
     if (a.AccOut) {
         float4 s = r;
         if (a.Add1 && (!a.add1_mask || mask_bit(a.add1_mask, (int)row))) {
-            const float4 t = a.Add1[row * a.W4 + c];
+            const float4 t = a.Add1[row * a.ld4 + c];
             s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
         }
         if (a.Add2) {
-            const float4 t = a.Add2[row * a.W4 + c];
+            const float4 t = a.Add2[row * a.ld4 + c];
             s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
         }
         if (a.AddN) {
             const float4 t = a.AddN[row * a.N4 + (c % a.N4)];
             s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
         }
-        a.AccOut[row * a.W4 + c] = make_float4(s.x * a.scale, s.y * a.scale, s.z * a.scale, s.w * a.scale);
+        a.AccOut[row * a.ld4 + c] = make_float4(s.x * a.scale, s.y * a.scale, s.z * a.scale, s.w * a.scale);
     }
 }
 
@@ -338,7 +339,7 @@ __device__ __forceinline__ float4 half_gather(const HalfArgs &a, int beg, int en
         }
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u)
-            x[u] = (on && in[u]) ? a.Xin[(int64_t)cj[u] * a.W4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
+            x[u] = (on && in[u]) ? a.Xin[(int64_t)cj[u] * a.ld4 + c] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int u = 0; u < UNROLL; ++u) {
             acc.x = fmaf(vj[u], x[u].x, acc.x); acc.y = fmaf(vj[u], x[u].y, acc.y);
@@ -371,7 +372,7 @@ __device__ __forceinline__ float4 half_gather_masked(const HalfArgs &a, int beg,
             const int cjb = __shfl(cj, src, 64);
             const float vjb = __shfl(vj, src, 64);
             if (on) {
-                const float4 x = a.Xin[(int64_t)cjb * a.W4 + c];
+                const float4 x = a.Xin[(int64_t)cjb * a.ld4 + c];
                 acc.x = fmaf(vjb, x.x, acc.x); acc.y = fmaf(vjb, x.y, acc.y);
                 acc.z = fmaf(vjb, x.z, acc.z); acc.w = fmaf(vjb, x.w, acc.w);
             }
@@ -572,7 +573,7 @@ static HalfArgs half_args(int W4, const float *Xin, const uint32_t *src_mask, fl
                           const uint32_t *add1_mask, const float *Add2, const float *AddN, int N4, float *AccOut,
                           float scale) {
     HalfArgs a = {};
-    a.W4 = W4; a.Xin = (const float4 *)Xin; a.src_mask = src_mask; a.Xout = (float4 *)Xout;
+    a.W4 = W4; a.ld4 = W4; a.Xin = (const float4 *)Xin; a.src_mask = src_mask; a.Xout = (float4 *)Xout;
     a.Add1 = (const float4 *)Add1; a.add1_mask = add1_mask; a.Add2 = (const float4 *)Add2;
     a.AddN = (const float4 *)AddN; a.N4 = N4 > 0 ? N4 : 1; a.AccOut = (float4 *)AccOut; a.scale = scale;
     return a;
@@ -871,4 +872,15 @@ extern "C" int elimrec_copy_cols(const float *d_src, int64_t ld_src, float *d_ds
                        ld_dst, n_rows, n_cols / 4);
     ELIMREC_LAUNCH_CHECK("copy_cols");
     return 0;
+}
+
+// Generic block SpMM with the fused epilogue on a column window of wider tables (leading dimension ld):
+//   r = A . Xin[:, 0:W];  Xout = r;  AccOut = (r + Add1) * scale       (all [rows x W] windows, stride ld)
+extern "C" int elimrec_block_spmm(const elimrec_csr *A, int W, int64_t ld, const float *d_Xin, float *d_Xout,
+                                  const float *d_Add1, float *d_AccOut, float scale, void *stream) {
+    ELIMREC_REQUIRE(A && d_Xin && (d_Xout || d_AccOut), "block_spmm: null pointer");
+    ELIMREC_REQUIRE(W > 0 && W % 4 == 0 && ld % 4 == 0 && ld >= W, "block_spmm: W, ld must be multiples of 4, ld >= W");
+    HalfArgs a = half_args(W / 4, d_Xin, nullptr, d_Xout, d_Add1, nullptr, nullptr, nullptr, 0, d_AccOut, scale);
+    a.ld4 = (int)(ld / 4);
+    return launch_half(A, a, 0, (hipStream_t)stream);
 }

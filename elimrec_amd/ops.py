@@ -233,6 +233,16 @@ def propagate_bipartite_bwd(PT, QT, U, I, d, M, L, G, H, active_rows, seg_info, 
                                                            _stream()), "propagate_bipartite_bwd")
 
 
+def block_spmm(A, Xin, Xout=None, add1=None, acc_out=None, scale=1.0):
+    """r = A . Xin (a column window of a wider table is fine); Xout = r; acc_out = (r + add1) * scale."""
+    x, ld = _rowmajor(Xin, "Xin")
+    W = Xin.shape[1]
+    for t in (Xout, add1, acc_out):
+        assert t is None or (t.stride(0) == ld and t.stride(1) == 1 and t.shape[1] == W)
+    _lib.check(_lib.load().elimrec_block_spmm(A.desc(), W, ld, x, _dev(Xout, "Xout"), _dev(add1, "add1"),
+                                              _dev(acc_out, "acc_out"), float(scale), _stream()), "block_spmm")
+
+
 def blocksum_rows(G, active_rows, seg_info, d, M, H):
     assert G.is_contiguous() and H.is_contiguous()
     _lib.check(_lib.load().elimrec_blocksum_rows(_dev(G, "G"), _dev(active_rows, "active_rows", torch.int32),

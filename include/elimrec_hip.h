@@ -177,6 +177,12 @@ int elimrec_propagate_bipartite_bwd(const elimrec_csr *PT, const elimrec_csr *QT
                                     int64_t n_max, float *d_gXI, float *d_gEu, void *d_workspace,
                                     size_t workspace_bytes, void *stream);
 
+/* One block SpMM with the fused epilogue on a W-column window of wider tables (row stride ld):
+ *   r = A . Xin[:, 0:W];  if Xout: Xout = r;  if AccOut: AccOut = (r + Add1) * scale.
+ * The building block of the bipartite propagation, exposed for callers that tile columns themselves. */
+int elimrec_block_spmm(const elimrec_csr *A, int W, int64_t ld, const float *d_Xin, float *d_Xout,
+                       const float *d_Add1, float *d_AccOut, float scale, void *stream);
+
 /* H[r, j] = sum_m G[r, m*d + j] for the active rows r (slots < d_seg_info[0]). */
 int elimrec_blocksum_rows(const float *d_G, const int32_t *d_active_rows, const int32_t *d_seg_info,
                           int64_t n_max, int d, int M, float *d_H, void *stream);

@@ -676,3 +676,27 @@ def test_kwai_shape_v_plus_t_variant_vs_oracle():
     for ptype in ("TE", "TIE"):
         model.predict_type = om.predict_type = ptype
         assert np.abs(model.predict(users).numpy() - om.predict(users).numpy()).max() < 1e-5
+
+
+def test_block_spmm_on_a_column_window():
+    """elimrec_block_spmm on a strided column window of wider tables == fp64 reference; columns outside
+    the window are untouched."""
+    import scipy.sparse as sp
+    from elimrec_amd import ops
+    rs = np.random.RandomState(4)
+    R, S_, W, ld = 900, 1300, 48, 160
+    m = sp.random(R, S_, density=0.01, random_state=rs, format="csr", dtype=np.float32)
+    m = (m + sp.csr_matrix((np.ones(S_, np.float32), (np.zeros(S_, int), np.arange(S_))), shape=(R, S_))).tocsr()  # one long row
+    A = ops.Csr.from_scipy(m, DEV, C=ld, threshold=64)
+    g = torch.Generator().manual_seed(2)
+    Xin, Add = torch.randn(S_, ld, generator=g), torch.randn(R, ld, generator=g)
+    Xout, Acc = torch.full((R, ld), 7.0), torch.full((R, ld), 9.0)
+    Xin_d, Add_d, Xout_d, Acc_d = (t.to(DEV) for t in (Xin, Add, Xout, Acc))
+    c0 = 32
+    ops.block_spmm(A, Xin_d[:, c0:c0 + W], Xout=Xout_d[:, c0:c0 + W], add1=Add_d[:, c0:c0 + W],
+                   acc_out=Acc_d[:, c0:c0 + W], scale=0.5)
+    want = torch.from_numpy(m.astype(np.float64) @ Xin[:, c0:c0 + W].double().numpy())
+    assert rel_err(Xout_d[:, c0:c0 + W].cpu(), want) < 2e-6
+    assert rel_err(Acc_d[:, c0:c0 + W].cpu(), (want + Add[:, c0:c0 + W].double()) * 0.5) < 2e-6
+    for t, v in ((Xout_d, 7.0), (Acc_d, 9.0)):
+        assert (t[:, :c0] == v).all() and (t[:, c0 + W:] == v).all()
