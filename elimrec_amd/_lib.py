@@ -81,8 +81,10 @@ SIGNATURES = {
     "elimrec_embed_grad": (c_i32, [c_ptr, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_ptr]),
     "elimrec_adam_step": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_ptr]),
     "elimrec_score_workspace": (c_size, [c_i32, c_i64, c_i32]),
+    "elimrec_score_workspace2": (c_size, [c_i32, c_i64, c_i64, c_i32, c_i32]),
+    "elimrec_row_sqnorms": (c_i32, [c_ptr, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr]),
     "elimrec_score_topk": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_i32, c_i32, c_i32, c_u32, c_i32, c_i32,
-                                   c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+                                   c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "elimrec_rank_metrics": (c_i32, [c_ptr, c_i32, c_i32, c_ptr, c_ptr, ctypes.POINTER(c_i32), c_i32, c_ptr, c_ptr]),
     "elimrec_sample_triplets": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_u64, c_u64, c_ptr, c_ptr, c_ptr, c_ptr]),
 }

@@ -2,6 +2,7 @@
 // metrics, all on device (models/EliMRec.py:96-113,155-212; cpp/uni_evaluator.py:131-185;
 // evaluate.h:23-42; metric.h:17-106). Removes the [B_t x I] device->host copy of the reference.
 #include "common.h"
+#include <cstdlib>
 
 namespace elimrec {
 
@@ -19,6 +20,7 @@ struct ScoreArgs {
     const float *row_mean;           // [B] mean_i ui (TIE), pass 2 only
     float *partial;                  // pass 1: [n_item_tiles x B] partial row sums of ui
     float *scores; int64_t lds;      // pass 2 output
+    const float *sqn;                // [N x (1+S)] squared L2 norms of every head block of every row of Y
 };
 
 __device__ __forceinline__ float fuse(int mode, float x, const float *z, int S, uint32_t mask) {
@@ -127,13 +129,124 @@ __global__ __launch_bounds__(256) void score_kernel(ScoreArgs a) {
     }
 }
 
-__global__ void row_mean_kernel(const float *__restrict__ partial, int n_tiles, int B, int64_t I,
-                                float *__restrict__ row_mean) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
+// MFMA form of the same scorer (used when d % 4 == 0 and the head count fits): a workgroup owns 32 items
+// x up to 128 users (the whole evaluation block, so every item row leaves HBM exactly once per block);
+// wave w owns users [32w, 32w+32). Per head block the user and item rows are staged 64 columns at a time
+// (row stride 65: conflict-free operand reads), their squared norms are accumulated from the same LDS
+// image, and v_mfma_f32_32x32x2_f32 accumulates the 32x32 dot products (exact fp32 fma chains).
+typedef float v16f_s __attribute__((ext_vector_type(16)));
+constexpr int MU = 128, MI = 32, MK = 64, MLD = MK + 1;
+
+template <int PASS>
+__global__ __launch_bounds__(256) void score_mfma_kernel(ScoreArgs a) {
+    __shared__ float us[MU * MLD];
+    __shared__ float it[MI * MLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int64_t i0 = (int64_t)blockIdx.x * MI;
+    const int b0 = blockIdx.y * MU;
+    const int nblk = (PASS == 1) ? 1 : 1 + a.S;
+    v16f_s acc[1 + kMaxS];
+#pragma unroll
+    for (int h = 0; h < 1 + kMaxS; ++h) acc[h] = (v16f_s){0};
+#pragma unroll
+    for (int h = 0; h < 1 + kMaxS; ++h) {
+        if (h >= nblk) break;
+        for (int k0 = 0; k0 < a.d; k0 += MK) {
+            const int kc = (a.d - k0) < MK ? (a.d - k0) : MK;
+            __syncthreads();
+            for (int e = tid * 4; e < MU * kc; e += 1024) {
+                const int r = e / kc, c = e - r * kc;
+                const int b = b0 + r;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (b < a.B) v = *reinterpret_cast<const float4 *>(a.Y + a.users[b] * a.ldy + h * a.d + k0 + c);
+                float *dst = us + r * MLD + c;
+                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            }
+            for (int e = tid * 4; e < MI * kc; e += 1024) {
+                const int r = e / kc, c = e - r * kc;
+                const int64_t item = i0 + r;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (item < a.I) v = *reinterpret_cast<const float4 *>(a.Y + (a.U + item) * a.ldy + h * a.d + k0 + c);
+                float *dst = it + r * MLD + c;
+                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            }
+            __syncthreads();
+            const float *ap = us + (wave * 32 + li) * MLD + lk;
+            const float *bp = it + li * MLD + lk;
+            for (int k = 0; k < kc; k += 2)
+                acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[k], bp[k], acc[h], 0, 0, 0);
+        }
+    }
+    const int64_t item = i0 + li;
+    const bool item_ok = item < a.I;
+    const float eps = 1e-12f;
+    const int nb = 1 + a.S;
+    float inorm[kMaxS];                               // max(|item block h|, eps), from the precomputed table
+#pragma unroll
+    for (int h = 0; h < kMaxS; ++h)
+        inorm[h] = (PASS == 2 && h < a.S && item_ok) ? fmaxf(sqrtf(a.sqn[(a.U + item) * nb + 1 + h]), eps) : 1.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int urow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int b = b0 + urow;
+        if (PASS == 1) {
+            float v = (item_ok && b < a.B) ? sigmoidf_(acc[0][r]) : 0.f;
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);      // over the 32 items of the tile
+            if (li == 0 && b < a.B) a.partial[(int64_t)blockIdx.x * a.B + b] = v;
+            continue;
+        }
+        if (b >= a.B || !item_ok) continue;
+        const float ui = sigmoidf_(acc[0][r]);
+        float out;
+        if (a.predict_type == 0) {
+            out = sigmoidf_(ui);
+        } else {
+            float z[kMaxS];
+            const int64_t unode = a.users[b];
+#pragma unroll
+            for (int h = 0; h < kMaxS; ++h)
+                z[h] = (h < a.S) ? acc[1 + h][r] / (fmaxf(sqrtf(a.sqn[unode * nb + 1 + h]), eps) * inorm[h]) : 0.f;
+            const float te = fuse(a.fusion_mode, ui, z, a.S, a.head_mask);
+            if (a.predict_type == 1) out = sigmoidf_(te);
+            else out = sigmoidf_(te - fuse(a.fusion_mode, a.row_mean[b], z, a.S, a.head_mask));
+        }
+        a.scores[(int64_t)b * a.lds + item] = out;
+    }
+}
+
+// sqn[row, h] = sum_k Y[row, h*d + k]^2 : one wave per row, lanes stride the block, fixed-order reduction.
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const float *__restrict__ Y, int64_t ldy, int64_t n_rows, int d,
+                                                         int nb, float *__restrict__ sqn) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= n_rows) return;
+    for (int h = 0; h < nb; ++h) {
+        float s = 0.f;
+        for (int k = lane * 4; k < d; k += 256) {
+            const float4 v = *reinterpret_cast<const float4 *>(Y + row * ldy + h * d + k);
+            s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        s = wave_sum(s);
+        if (lane == 0) sqn[row * nb + h] = s;
+    }
+}
+
+// mean_i ui for one user per workgroup: thread t adds tiles t, t+256, ... then a fixed binary tree.
+__global__ __launch_bounds__(256) void row_mean_kernel(const float *__restrict__ partial, int n_tiles, int B, int64_t I,
+                                                       float *__restrict__ row_mean) {
+    __shared__ float sm[256];
+    const int b = blockIdx.x;
     float s = 0.f;
-    for (int t = 0; t < n_tiles; ++t) s += partial[(int64_t)t * B + b];
-    row_mean[b] = s / (float)I;
+    for (int t = threadIdx.x; t < n_tiles; t += 256) s += partial[(int64_t)t * B + b];
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sm[threadIdx.x] += sm[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) row_mean[b] = sm[0] / (float)I;
 }
 
 __global__ void mask_train_kernel(float *__restrict__ scores, int64_t lds, const int64_t *__restrict__ ptr,
@@ -147,12 +260,14 @@ __global__ void mask_train_kernel(float *__restrict__ scores, int64_t lds, const
 // Top-K by (score desc, index asc): K rounds; round r takes the best element strictly after the
 // previous pick in that total order. One workgroup per row.
 __global__ __launch_bounds__(1024) void topk_kernel(const float *__restrict__ scores, int64_t lds, int64_t I, int K,
-                                                    int32_t *__restrict__ out_idx, float *__restrict__ out_val) {
+                                                    int32_t *__restrict__ out_idx, float *__restrict__ out_val,
+                                                    const int32_t *__restrict__ only_if) {
     __shared__ float sv[16];
     __shared__ int si[16];
     __shared__ float last_v;
     __shared__ int last_i;
     const int b = blockIdx.x;
+    if (only_if && only_if[b] == 0) return;        // this row was finished by topk_select_kernel
     const float *row = scores + (int64_t)b * lds;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float pv = INFINITY;
@@ -185,6 +300,76 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float *__restrict__ sc
         __syncthreads();
         pv = last_v; pi = last_i;
         __syncthreads();
+    }
+}
+
+// Fast path of the same selection (identical result): two sweeps of the row instead of K.
+//   1. every thread keeps the max of its strided elements; G >= 2K group maxima are formed and the K-th
+//      largest of them, tau, is found by rank counting -- at least K elements are >= tau, so the top-K is
+//      among the elements >= tau (about 1.6 K of them for continuous scores);
+//   2. those candidates are compacted into LDS and ranked by (score desc, index asc) by counting, entry
+//      with rank r < K is output r.
+// If more than TK_CAP candidates qualify (massive ties, or fewer than K finite scores) the workgroup falls
+// back to the K-round sweep below, so the result never depends on which path ran.
+constexpr int TK_CAP = 1024;
+__device__ __forceinline__ bool tk_before(float va, int ia, float vb, int ib) {   // a ranks before b
+    return va > vb || (va == vb && ia < ib);
+}
+
+__global__ __launch_bounds__(1024) void topk_select_kernel(const float *__restrict__ scores, int64_t lds, int64_t I,
+                                                           int K, int G, int32_t *__restrict__ out_idx,
+                                                           float *__restrict__ out_val, int32_t *__restrict__ fallback) {
+    __shared__ float tm[1024];
+    __shared__ float gm[1024];
+    __shared__ float cv[TK_CAP];
+    __shared__ int ci[TK_CAP];
+    __shared__ float tau;
+    __shared__ int cnt;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float *row = scores + (int64_t)b * lds;
+    float m = -INFINITY;
+    for (int64_t i = t; i < I; i += 1024) m = fmaxf(m, row[i]);
+    tm[t] = m;
+    if (t == 0) cnt = 0;
+    __syncthreads();
+    const int gs = 1024 / G;                       // threads per group
+    if (t < G) {
+        float g = -INFINITY;
+        for (int j = 0; j < gs; ++j) g = fmaxf(g, tm[t * gs + j]);
+        gm[t] = g;
+    }
+    __syncthreads();
+    if (t < G) {                                   // rank of gm[t] among the G group maxima (ties by index)
+        int rank = 0;
+        const float mine = gm[t];
+        for (int j = 0; j < G; ++j) rank += tk_before(gm[j], j, mine, t) ? 1 : 0;
+        if (rank == K - 1) tau = mine;
+    }
+    __syncthreads();
+    const float th = tau;
+    for (int64_t i = t; i < I; i += 1024) {
+        const float v = row[i];
+        if (v >= th) {
+            const int slot = atomicAdd(&cnt, 1);
+            if (slot < TK_CAP) { cv[slot] = v; ci[slot] = (int)i; }
+        }
+    }
+    __syncthreads();
+    const int n = cnt;
+    if (n > TK_CAP || n < K || th == -INFINITY) {  // workgroup-uniform
+        if (t == 0) fallback[b] = 1;
+        return;
+    }
+    if (t == 0) fallback[b] = 0;
+    if (t < n) {
+        int rank = 0;
+        const float mv = cv[t];
+        const int mi = ci[t];
+        for (int j = 0; j < n; ++j) rank += tk_before(cv[j], ci[j], mv, mi) ? 1 : 0;
+        if (rank < K) {
+            out_idx[(int64_t)b * K + rank] = mi;
+            if (out_val) out_val[(int64_t)b * K + rank] = mv;
+        }
     }
 }
 
@@ -236,21 +421,36 @@ __global__ void rank_metrics_kernel(const int32_t *__restrict__ rank, int B, int
 
 using namespace elimrec;
 
-static inline int n_item_tiles(int64_t I) { return (int)((I + SI - 1) / SI); }
+static inline int n_item_tiles(int64_t I) { return (int)((I + MI - 1) / MI); }   // MFMA tiles (the finer of the two)
 
 extern "C" size_t elimrec_score_workspace(int B, int64_t I, int K) {
     (void)K;
     size_t partial = align_up((size_t)n_item_tiles(I) * (size_t)(B > 0 ? B : 1) * sizeof(float), 256);
     size_t mean = align_up((size_t)(B > 0 ? B : 1) * sizeof(float), 256);
     size_t scores = align_up((size_t)(B > 0 ? B : 1) * (size_t)I * sizeof(float), 256);
-    return partial + mean + scores;
+    size_t flags = align_up((size_t)(B > 0 ? B : 1) * sizeof(int32_t), 256);
+    return partial + mean + scores + flags;      // + the squared-norm table, added by elimrec_score_workspace2
+}
+
+extern "C" size_t elimrec_score_workspace2(int B, int64_t U, int64_t I, int S, int K) {
+    return elimrec_score_workspace(B, I, K) + align_up((size_t)(U + I) * (size_t)(1 + S) * sizeof(float), 256);
+}
+
+extern "C" int elimrec_row_sqnorms(const float *d_Y, int64_t ldy, int64_t n_rows, int d, int n_blocks, float *d_out,
+                                   void *stream) {
+    ELIMREC_REQUIRE(d_Y && d_out && d > 0 && d % 4 == 0 && n_blocks >= 1 && ldy % 4 == 0, "row_sqnorms: bad arguments");
+    if (n_rows <= 0) return 0;
+    hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_Y, ldy,
+                       n_rows, d, n_blocks, d_out);
+    ELIMREC_LAUNCH_CHECK("row_sqnorm");
+    return 0;
 }
 
 extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int64_t I, const int64_t *d_users, int B,
                                   int d, int S, uint32_t head_mask, int fusion_mode, int predict_type,
-                                  const int64_t *d_train_ptr, const int32_t *d_train_items, float *d_scores,
-                                  int64_t lds, int K, int32_t *d_topk_idx, float *d_topk_val, void *d_workspace,
-                                  size_t workspace_bytes, void *stream) {
+                                  const float *d_sqnorm, const int64_t *d_train_ptr, const int32_t *d_train_items,
+                                  float *d_scores, int64_t lds, int K, int32_t *d_topk_idx, float *d_topk_val,
+                                  void *d_workspace, size_t workspace_bytes, void *stream) {
     ELIMREC_REQUIRE(d_Y && d_users && d_workspace, "score_topk: null pointer");
     ELIMREC_REQUIRE(d > 0 && d % 4 == 0 && ldy % 4 == 0, "score_topk: recdim/ldy must be multiples of 4");
     ELIMREC_REQUIRE(S >= 0 && S <= kMaxS, "score_topk: at most %d single-modal heads", kMaxS);
@@ -259,8 +459,8 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
     ELIMREC_REQUIRE(d_scores || d_topk_idx, "score_topk: nothing to output");
     ELIMREC_REQUIRE(!d_topk_idx || (K > 0 && K <= I), "score_topk: need 0 < K <= I");
     if (B <= 0) return 0;
-    if (workspace_bytes < elimrec_score_workspace(B, I, K)) {
-        set_error("score_topk: workspace too small (%zu < %zu)", workspace_bytes, elimrec_score_workspace(B, I, K));
+    if (workspace_bytes < elimrec_score_workspace2(B, U, I, S, K)) {
+        set_error("score_topk: workspace too small (%zu < %zu)", workspace_bytes, elimrec_score_workspace2(B, U, I, S, K));
         return ELIMREC_E_WORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
@@ -269,27 +469,64 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
     float *partial = (float *)ws;
     float *mean = (float *)(ws + align_up((size_t)tiles * B * sizeof(float), 256));
     float *wscores = (float *)((char *)mean + align_up((size_t)B * sizeof(float), 256));
+    int32_t *fallback = (int32_t *)((char *)wscores + align_up((size_t)B * (size_t)I * sizeof(float), 256));
     ScoreArgs a;
     a.Y = d_Y; a.ldy = ldy; a.U = U; a.I = I; a.users = d_users; a.B = B; a.d = d; a.S = S; a.head_mask = head_mask;
     a.fusion_mode = fusion_mode; a.predict_type = predict_type; a.row_mean = mean; a.partial = partial;
     a.scores = d_scores ? d_scores : wscores; a.lds = d_scores ? lds : I;
-    ELIMREC_REQUIRE(a.lds >= I, "score_topk: lds < I");
-    dim3 grid(tiles, (B + SU - 1) / SU);
-    if (predict_type == 2) {
-        hipLaunchKernelGGL(score_kernel<1>, grid, dim3(256), 0, s, a);
-        ELIMREC_LAUNCH_CHECK("score_pass1");
-        hipLaunchKernelGGL(row_mean_kernel, dim3((B + 127) / 128), dim3(128), 0, s, partial, tiles, B, I, mean);
-        ELIMREC_LAUNCH_CHECK("row_mean");
+    float *wsqn = (float *)((char *)fallback + align_up((size_t)B * sizeof(int32_t), 256));
+    if (!d_sqnorm && predict_type != 0) {            // not supplied: compute the whole table for this call
+        const int64_t N = U + I;
+        hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, d_Y, ldy, N, d, 1 + S, wsqn);
+        ELIMREC_LAUNCH_CHECK("row_sqnorm");
     }
-    hipLaunchKernelGGL(score_kernel<2>, grid, dim3(256), 0, s, a);
-    ELIMREC_LAUNCH_CHECK("score_pass2");
+    a.sqn = d_sqnorm ? d_sqnorm : wsqn;
+    ELIMREC_REQUIRE(a.lds >= I, "score_topk: lds < I");
+    static int use_mfma = -1;
+    if (use_mfma < 0) {
+        const char *e = getenv("ELIMREC_SCORE_VALU");
+        use_mfma = (e && e[0] == '1') ? 0 : 1;
+    }
+    if (use_mfma) {
+        dim3 grid(tiles, (B + MU - 1) / MU);
+        if (predict_type == 2) {
+            hipLaunchKernelGGL(score_mfma_kernel<1>, grid, dim3(256), 0, s, a);
+            ELIMREC_LAUNCH_CHECK("score_mfma_pass1");
+            hipLaunchKernelGGL(row_mean_kernel, dim3(B), dim3(256), 0, s, partial, tiles, B, I, mean);
+            ELIMREC_LAUNCH_CHECK("row_mean");
+        }
+        hipLaunchKernelGGL(score_mfma_kernel<2>, grid, dim3(256), 0, s, a);
+        ELIMREC_LAUNCH_CHECK("score_mfma_pass2");
+    } else {
+        const int vtiles = (int)((I + SI - 1) / SI);
+        dim3 grid(vtiles, (B + SU - 1) / SU);
+        if (predict_type == 2) {
+            hipLaunchKernelGGL(score_kernel<1>, grid, dim3(256), 0, s, a);
+            ELIMREC_LAUNCH_CHECK("score_pass1");
+            hipLaunchKernelGGL(row_mean_kernel, dim3(B), dim3(256), 0, s, partial, vtiles, B, I, mean);
+            ELIMREC_LAUNCH_CHECK("row_mean");
+        }
+        hipLaunchKernelGGL(score_kernel<2>, grid, dim3(256), 0, s, a);
+        ELIMREC_LAUNCH_CHECK("score_pass2");
+    }
     if (d_train_ptr) {
         ELIMREC_REQUIRE(d_train_items, "score_topk: train_items missing");
         hipLaunchKernelGGL(mask_train_kernel, dim3(B), dim3(128), 0, s, a.scores, a.lds, d_train_ptr, d_train_items, B);
         ELIMREC_LAUNCH_CHECK("mask_train");
     }
     if (d_topk_idx) {
-        hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), 0, s, a.scores, a.lds, I, K, d_topk_idx, d_topk_val);
+        int G = 32;
+        while (G < 2 * K && G < 1024) G *= 2;
+        if (2 * K <= 1024) {
+            hipLaunchKernelGGL(topk_select_kernel, dim3(B), dim3(1024), 0, s, a.scores, a.lds, I, K, G, d_topk_idx,
+                               d_topk_val, fallback);
+            ELIMREC_LAUNCH_CHECK("topk_select");
+            hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), 0, s, a.scores, a.lds, I, K, d_topk_idx, d_topk_val,
+                               (const int32_t *)fallback);
+        } else {
+            hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), 0, s, a.scores, a.lds, I, K, d_topk_idx, d_topk_val,
+                               (const int32_t *)nullptr);
+        }
         ELIMREC_LAUNCH_CHECK("topk");
     }
     return 0;

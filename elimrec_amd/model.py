@@ -365,6 +365,7 @@ class EliMRec(BasicModel):
 
     def _publish_cache(self, Y):
         U, d = self.num_users, self.latent_dim
+        self._table_version = getattr(self, "_table_version", 0) + 1
         self.all_users, self.all_items = Y[:U, :d], Y[U:, :d]
         self.all_s_embs = {}
         for h, m in enumerate(self._mods):
@@ -513,16 +514,22 @@ class EliMRec(BasicModel):
             raise RuntimeError("predict() needs the tables cached by a training forward (call bpr_loss or compute first)")
         users = torch.as_tensor(user_ids, device=dev).long().contiguous()
         B, I = users.numel(), self.num_items
-        need = ops.score_workspace(B, I, max(top_k, 1))
+        need = ops.score_workspace(B, self.num_users, I, self.S, max(top_k, 1))
         if self._ws.get("score_ws") is None or self._ws["score_ws"].numel() < need:
             self._ws["score_ws"] = torch.empty(need, dtype=torch.uint8, device=dev)
         idx = val = None
         if top_k:
             idx = torch.empty(B, top_k, dtype=torch.int32, device=dev)
             val = torch.empty(B, top_k, dtype=torch.float32, device=dev)
+        # block norms of the cached tables: computed once per table version, reused by every user block
+        if self._ws.get("sqn_version") != self._table_version:
+            if self._ws.get("sqn") is None:
+                self._ws["sqn"] = torch.empty(self.num_users + I, 1 + self.S, dtype=torch.float32, device=dev)
+            ops.row_sqnorms(self._ws["Y"], self.latent_dim, 1 + self.S, self._ws["sqn"])
+            self._ws["sqn_version"] = self._table_version
         ops.score_topk(self._ws["Y"], self.num_users, I, users, self.latent_dim, self.S, self._head_mask(),
                        self.fusion_mode, self.predict_type, self._ws["score_ws"], scores=scores, K=top_k,
-                       topk_idx=idx, topk_val=val, train_ptr=train_ptr, train_items=train_items)
+                       topk_idx=idx, topk_val=val, train_ptr=train_ptr, train_items=train_items, sqnorm=self._ws["sqn"])
         return idx, val
 
     def predict(self, user_ids, candidate_items=None):

@@ -323,8 +323,15 @@ def adam_step_raw(p_ptr, g_ptr, m_ptr, v_ptr, n, lr, beta1, beta2, eps, weight_d
                                              float(eps), float(weight_decay), int(step), _stream()), "adam_step")
 
 
-def score_workspace(B, I, K):
-    return int(_lib.load().elimrec_score_workspace(B, I, K))
+def score_workspace(B, U, I, S, K):
+    return int(_lib.load().elimrec_score_workspace2(B, U, I, S, K))
+
+
+def row_sqnorms(Y, d, n_blocks, out):
+    y, ldy = _rowmajor(Y, "Y")
+    assert out.is_contiguous() and out.shape == (Y.shape[0], n_blocks)
+    _lib.check(_lib.load().elimrec_row_sqnorms(y, ldy, Y.shape[0], d, n_blocks, _dev(out, "out"), _stream()), "row_sqnorms")
+    return out
 
 
 FUSION_MODES = {"rubi": 0, "hm": 1, "sum": 2}
@@ -332,7 +339,7 @@ PREDICT_TYPES = {"TE": 1, "TIE": 2}   # anything else -> 0 ("normal", models/Eli
 
 
 def score_topk(Y, U, I, users, d, S, head_mask, fusion_mode, predict_type, workspace, scores=None, K=0,
-               topk_idx=None, topk_val=None, train_ptr=None, train_items=None):
+               topk_idx=None, topk_val=None, train_ptr=None, train_items=None, sqnorm=None):
     y, ldy = _rowmajor(Y, "Y")
     B = users.numel()
     sp, lds = (None, 0)
@@ -340,7 +347,7 @@ def score_topk(Y, U, I, users, d, S, head_mask, fusion_mode, predict_type, works
         sp, lds = _rowmajor(scores, "scores")
     _lib.check(_lib.load().elimrec_score_topk(y, ldy, U, I, _dev(users, "users", torch.int64), B, d, S, int(head_mask),
                                               FUSION_MODES[fusion_mode], PREDICT_TYPES.get(predict_type, 0),
-                                              _dev(train_ptr, "train_ptr", torch.int64),
+                                              _dev(sqnorm, "sqnorm"), _dev(train_ptr, "train_ptr", torch.int64),
                                               _dev(train_items, "train_items", torch.int32), sp, lds, int(K),
                                               _dev(topk_idx, "topk_idx", torch.int32), _dev(topk_val, "topk_val"),
                                               _dev(workspace, "workspace", torch.uint8), workspace.numel(), _stream()),

@@ -264,11 +264,17 @@ int elimrec_adam_step(float *d_p, const float *d_g, float *d_m, float *d_v, int6
  * d_train_ptr/d_train_items (nullable): CSR over the B rows of items to overwrite with -inf
  * (cpp/uni_evaluator.py:149-154). d_scores [B x I] may be NULL when only top-K is wanted.
  * d_topk_idx/d_topk_val [B x K] (nullable): per-row top-K by (score desc, index asc).
- * workspace: elimrec_score_workspace(B, I, K) bytes. */
-size_t elimrec_score_workspace(int B, int64_t I, int K);
+ * workspace: elimrec_score_workspace2(B, U, I, S, K) bytes. */
+size_t elimrec_score_workspace(int B, int64_t I, int K);              /* without the norm table   */
+size_t elimrec_score_workspace2(int B, int64_t U, int64_t I, int S, int K);   /* what score_topk needs */
+/* d_sqnorm (nullable): [N x (1+S)] squared norms of every head block of every row of Y, from
+ * elimrec_row_sqnorms; pass it when several user blocks are scored against the same tables (an
+ * evaluation pass), otherwise it is recomputed inside every call. */
+int elimrec_row_sqnorms(const float *d_Y, int64_t ldy, int64_t n_rows, int d, int n_blocks, float *d_out,
+                        void *stream);
 int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int64_t I, const int64_t *d_users,
                        int B, int d, int S, uint32_t head_mask, int fusion_mode, int predict_type,
-                       const int64_t *d_train_ptr, const int32_t *d_train_items,
+                       const float *d_sqnorm, const int64_t *d_train_ptr, const int32_t *d_train_items,
                        float *d_scores, int64_t lds, int K, int32_t *d_topk_idx, float *d_topk_val,
                        void *d_workspace, size_t workspace_bytes, void *stream);
 
