@@ -700,3 +700,36 @@ def test_block_spmm_on_a_column_window():
     assert rel_err(Acc_d[:, c0:c0 + W].cpu(), (want + Add[:, c0:c0 + W].double()) * 0.5) < 2e-6
     for t, v in ((Xout_d, 7.0), (Acc_d, 9.0)):
         assert (t[:, :c0] == v).all() and (t[:, c0 + W:] == v).all()
+
+
+def test_topk_paths_agree_with_stable_sort():
+    """Device top-K = first K of a stable sort by (score desc, item id asc), whichever internal path runs:
+    continuous scores (two-sweep select), massive ties and rows with fewer than K unmasked items (K-round
+    fallback), K from 1 to 100."""
+    from elimrec_amd import ops
+    U, I, d, S = 40, 5000, 16, 3
+    Cy = (1 + S) * d
+    g = torch.Generator().manual_seed(11)
+    Yr = torch.randn(U + I, Cy, generator=g)
+    Yt = Yr.clone()
+    Yt[U:] = Yt[U:U + 7].repeat((I + 6) // 7, 1)[:I]            # only 7 distinct item rows -> massive ties
+    users = torch.arange(0, 33)
+    B = len(users)
+    # row 5: everything but 4 items masked; row 6: nothing masked
+    ptr = torch.zeros(B + 1, dtype=torch.int64)
+    masked = torch.tensor([i for i in range(I) if i not in (17, 4000, 3, 999)], dtype=torch.int32)
+    ptr[6:] = len(masked)
+    for Y in (Yr, Yt):
+        for K in (1, 10, 50, 100):
+            Yd = Y.to(DEV)
+            ws = torch.empty(ops.score_workspace(B, U, I, S, K), dtype=torch.uint8, device=DEV)
+            scores = torch.empty(B, I, device=DEV)
+            idx = torch.empty(B, K, dtype=torch.int32, device=DEV)
+            val = torch.empty(B, K, device=DEV)
+            ops.score_topk(Yd, U, I, users.to(DEV), d, S, 0b111, "rubi", "TIE", ws, scores=scores, K=K, topk_idx=idx,
+                           topk_val=val, train_ptr=ptr.to(DEV), train_items=masked.to(DEV))
+            sc = scores.cpu().numpy()
+            assert np.isinf(sc[5]).sum() == I - 4 and not np.isinf(sc[6]).any()
+            order = np.argsort(-sc, axis=1, kind="stable")[:, :K]
+            assert np.array_equal(idx.cpu().numpy(), order), (K, Y is Yt)
+            assert np.array_equal(val.cpu().numpy(), np.take_along_axis(sc, order, 1))
