@@ -50,6 +50,7 @@ class UniEvaluator(object):
         self.max_top = top_k if isinstance(top_k, int) else max(top_k)
         self.top_show = np.arange(top_k) + 1 if isinstance(top_k, int) else np.sort(top_k)
         self._dev_cache = {}
+        self._default_users = None
 
     def metrics_info(self):
         cols = ["\t".join(("%s@" % re_metric_dict[m] + str(k)).ljust(12) for k in self.top_show) for m in self.metrics]
@@ -63,25 +64,40 @@ class UniEvaluator(object):
         return torch.from_numpy(ptr).to(device), torch.from_numpy(flat).to(device)
 
     def evaluate(self, model, test_users=None):
-        test_users = test_users if test_users is not None else list(self.user_pos_test.keys())
+        if test_users is None:
+            if getattr(self, "_default_users", None) is None:
+                self._default_users = list(self.user_pos_test.keys())
+            test_users = self._default_users
         if not isinstance(test_users, (list, tuple, set, np.ndarray)):
             raise TypeError("'test_user' must be a list, tuple, set or numpy array!")
         if not hasattr(model, "predict_device"):
             raise TypeError("model must expose predict_device(); host-side ranking is not part of this package")
         rows = []
-        for batch_users in DataIterator(list(test_users), batch_size=self.batch_size, shuffle=False, drop_last=False):
-            rows.append(self.evaluate_batch(model, batch_users))
+        for k, batch_users in enumerate(DataIterator(list(test_users), batch_size=self.batch_size, shuffle=False,
+                                                     drop_last=False)):
+            rows.append(self.evaluate_batch(model, batch_users,
+                                            cache_key=k if test_users is self._default_users else None))
         all_rows = torch.cat(rows, 0).cpu().numpy()                       # [users, metrics*K]
         final = np.mean(all_rows, axis=0).reshape(self.metrics_num, self.max_top)[:, self.top_show - 1].reshape(-1)
         buf = "\t".join(("%.8f" % x).ljust(12) for x in final)
         return final, buf
 
-    def evaluate_batch(self, model, batch_users, return_topk=False):
-        """Per-user metric rows [len(batch_users), metrics*K] (device tensor) for one user block."""
+    def evaluate_batch(self, model, batch_users, return_topk=False, cache_key=None):
+        """Per-user metric rows [len(batch_users), metrics*K] (device tensor) for one user block.
+        cache_key: the user blocks of the default evaluation order are the same every time, so their
+        index tensors (user ids, train-mask CSR, truth CSR) are built once and stay on the device."""
         device = model._require_gpu()
-        train_ptr, train_items = self._batch_csr(batch_users, self.user_pos_train, device, unique=False)
-        truth_ptr, truth_items = self._batch_csr(batch_users, self.user_pos_test, device, unique=True)
-        idx, val = model.predict_device(batch_users, top_k=self.max_top, train_ptr=train_ptr, train_items=train_items)
+        key = (str(device), cache_key) if cache_key is not None else None
+        hit = self._dev_cache.get(key) if key is not None else None
+        if hit is None:
+            train_ptr, train_items = self._batch_csr(batch_users, self.user_pos_train, device, unique=False)
+            truth_ptr, truth_items = self._batch_csr(batch_users, self.user_pos_test, device, unique=True)
+            users_t = torch.as_tensor(np.asarray(batch_users, dtype=np.int64)).to(device)
+            hit = (users_t, train_ptr, train_items, truth_ptr, truth_items)
+            if key is not None:
+                self._dev_cache[key] = hit
+        users_t, train_ptr, train_items, truth_ptr, truth_items = hit
+        idx, val = model.predict_device(users_t, top_k=self.max_top, train_ptr=train_ptr, train_items=train_items)
         out = torch.empty(len(batch_users), self.metrics_num * self.max_top, dtype=torch.float32, device=device)
         ops.rank_metrics(idx, truth_ptr, truth_items, self.metrics, out)
         return (out, idx, val) if return_topk else out
