@@ -31,7 +31,8 @@ class LinearDesc(ctypes.Structure):
     """struct elimrec_linear_desc."""
     _fields_ = [("d_A", ctypes.c_void_p), ("lda", ctypes.c_int64), ("d_W", ctypes.c_void_p), ("ldw", ctypes.c_int64),
                 ("d_bias", ctypes.c_void_p), ("d_C", ctypes.c_void_p), ("ldc", ctypes.c_int64), ("M", ctypes.c_int64),
-                ("N", ctypes.c_int32), ("K", ctypes.c_int32)]
+                ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("d_rowscale", ctypes.c_void_p), ("d_add", ctypes.c_void_p),
+                ("ldadd", ctypes.c_int64)]
 
 
 class LinearBwdDesc(ctypes.Structure):
@@ -61,7 +62,7 @@ SIGNATURES = {
     "elimrec_propagate": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_split, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "elimrec_bipartite_workspace": (c_size, [c_i64, c_i64, c_i32, c_i32]),
     "elimrec_propagate_bipartite": (c_i32, [c_csr, c_csr, c_i64, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr,
-                                            c_size, c_ptr]),
+                                            c_ptr, c_size, c_ptr]),
     "elimrec_propagate_bipartite_bwd": (c_i32, [c_csr, c_csr, c_i64, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr,
                                                 c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "elimrec_ticket_fixup": (c_i32, []),
@@ -69,7 +70,7 @@ SIGNATURES = {
     "elimrec_concurrency": (c_i32, []),
     "elimrec_set_concurrency": (None, [c_i32]),
     "elimrec_block_spmm": (c_i32, [c_csr, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr]),
-    "elimrec_blocksum_rows": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr]),
+    "elimrec_blocksum_rows": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr]),
     "elimrec_copy_cols": (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i32, c_ptr]),
     "elimrec_bpr_head": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32,
                                  ctypes.POINTER(c_f32), c_ptr, c_ptr, c_ptr, c_ptr]),
@@ -77,7 +78,8 @@ SIGNATURES = {
     "elimrec_segment_reduce_workspace": (c_size, [c_i64]),
     "elimrec_segment_reduce_rows": (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "elimrec_head_bwd_input": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i32, c_i32, c_i32,
-                                       ctypes.POINTER(c_i32), c_ptr, c_ptr, ctypes.POINTER(c_ptr), c_f32, c_ptr, c_ptr]),
+                                       ctypes.POINTER(c_i32), c_ptr, c_ptr, ctypes.POINTER(c_ptr), c_f32, c_ptr, c_i64,
+                                       c_i32, c_ptr, c_ptr]),
     "elimrec_embed_grad": (c_i32, [c_ptr, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_ptr]),
     "elimrec_adam_step": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, c_ptr]),
     "elimrec_score_workspace": (c_size, [c_i32, c_i64, c_i32]),

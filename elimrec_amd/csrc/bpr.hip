@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void head_bwd_input_kernel(const float *__rest
                                                              int64_t U, int d, int C, int S, HeadPtrs hp,
                                                              const float *__restrict__ W_user,
                                                              const float *__restrict__ W_item, float gscale,
-                                                             float *__restrict__ G0) {
+                                                             float *__restrict__ G0, int64_t ldg, int scatter_cols,
+                                                             float *__restrict__ compact) {
     extern __shared__ float dys[];                       // [HB_ROWS][Cy]
     __shared__ int64_t node[HB_ROWS];
     const int Cy = (1 + S) * d;
@@ -240,7 +241,11 @@ __global__ __launch_bounds__(256) void head_bwd_input_kernel(const float *__rest
         }
 #pragma unroll
         for (int r = 0; r < HB_ROWS; ++r)
-            if (r < rows) G0[node[r] * C + c] = acc[r] * gscale;
+            if (r < rows) {
+                const float v = acc[r] * gscale;
+                if (G0 && c < scatter_cols) G0[node[r] * ldg + c] = v;
+                if (compact) compact[(s0 + r) * C + c] = v;
+            }
     }
 }
 
@@ -282,7 +287,8 @@ __global__ __launch_bounds__(512) void head_bwd_input_mfma_kernel(const float *_
                                                                   int64_t U, int d, int C, int S, HeadPtrs hp,
                                                                   const float *__restrict__ W_user,
                                                                   const float *__restrict__ W_item, float gscale,
-                                                                  float *__restrict__ G0) {
+                                                                  float *__restrict__ G0, int64_t ldg, int scatter_cols,
+                                                                  float *__restrict__ compact) {
     extern __shared__ float dys[];                       // [HM_ROWS][Cy + 1]
     __shared__ int64_t node[HM_ROWS];
     const int Cy = (1 + S) * d, ldy = Cy + 1;
@@ -323,8 +329,9 @@ __global__ __launch_bounds__(512) void head_bwd_input_mfma_kernel(const float *_
             const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (row < rows) {
                 const int64_t nd = node[row];
-                const float v = (mixed && nd >= U) ? acc2[r] : acc[r];
-                G0[nd * C + c0 + li] = v * gscale;
+                const float v = ((mixed && nd >= U) ? acc2[r] : acc[r]) * gscale;
+                if (G0 && c0 + li < scatter_cols) G0[nd * ldg + c0 + li] = v;
+                if (compact) compact[(s0 + row) * C + c0 + li] = v;
             }
         }
     }
@@ -435,8 +442,11 @@ extern "C" int elimrec_segment_reduce_rows(const float *d_rows, const int32_t *d
 extern "C" int elimrec_head_bwd_input(const float *d_dY, int64_t lddy, const int32_t *d_active_rows,
                                       const int32_t *d_seg_info, int64_t n_max, int64_t U, int d, int C, int S,
                                       const int *head_mblock, const float *d_W_user, const float *d_W_item,
-                                      const float *const *d_W_heads, float gscale, float *d_G0, void *stream) {
-    ELIMREC_REQUIRE(d_dY && d_active_rows && d_seg_info && d_W_user && d_W_item && d_G0, "head_bwd_input: null pointer");
+                                      const float *const *d_W_heads, float gscale, float *d_G0, int64_t ldg,
+                                      int scatter_cols, float *d_compact, void *stream) {
+    ELIMREC_REQUIRE(d_dY && d_active_rows && d_seg_info && d_W_user && d_W_item && (d_G0 || d_compact),
+                    "head_bwd_input: null pointer");
+    ELIMREC_REQUIRE(!d_G0 || (ldg >= scatter_cols && scatter_cols >= 0 && scatter_cols <= C), "head_bwd_input: bad ldg/scatter_cols");
     ELIMREC_REQUIRE(S >= 0 && S <= kMaxHeads, "head_bwd_input: at most %d heads", kMaxHeads);
     ELIMREC_REQUIRE(d > 0 && d % 4 == 0 && C % d == 0, "head_bwd_input: bad d/C");
     HeadPtrs hp;
@@ -450,7 +460,7 @@ extern "C" int elimrec_head_bwd_input(const float *d_dY, int64_t lddy, const int
         ELIMREC_REQUIRE(lddy % 4 == 0, "head_bwd_input: lddy must be a multiple of 4");
         hipLaunchKernelGGL(head_bwd_input_mfma_kernel, dim3((unsigned)((n_max + HM_ROWS - 1) / HM_ROWS)), dim3(512),
                            lds_m, (hipStream_t)stream, d_dY, lddy, d_active_rows, d_seg_info, n_max, U, d, C, S, hp,
-                           d_W_user, d_W_item, gscale, d_G0);
+                           d_W_user, d_W_item, gscale, d_G0, ldg, scatter_cols, d_compact);
         ELIMREC_LAUNCH_CHECK("head_bwd_input_mfma");
         return 0;
     }
@@ -459,7 +469,7 @@ extern "C" int elimrec_head_bwd_input(const float *d_dY, int64_t lddy, const int
     ELIMREC_REQUIRE(lddy % 4 == 0, "head_bwd_input: lddy must be a multiple of 4");
     hipLaunchKernelGGL(head_bwd_input_kernel, dim3((unsigned)((n_max + HB_ROWS - 1) / HB_ROWS)), dim3(256), lds,
                        (hipStream_t)stream, d_dY, lddy, d_active_rows, d_seg_info, n_max, U, d, C, S, hp, d_W_user,
-                       d_W_item, gscale, d_G0);
+                       d_W_item, gscale, d_G0, ldg, scatter_cols, d_compact);
     ELIMREC_LAUNCH_CHECK("head_bwd_input");
     return 0;
 }

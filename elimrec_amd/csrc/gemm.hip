@@ -36,7 +36,9 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(FwdBatch batch) {
     const float *__restrict__ W = pd.d_W;
     const float *__restrict__ bias = pd.d_bias;
     float *__restrict__ C = pd.d_C;
-    const int64_t lda = pd.lda, ldw = pd.ldw, ldc = pd.ldc, M = pd.M;
+    const float *__restrict__ rowscale = pd.d_rowscale;
+    const float *__restrict__ addm = pd.d_add;
+    const int64_t lda = pd.lda, ldw = pd.ldw, ldc = pd.ldc, ldadd = pd.ldadd, M = pd.M;
     const int N = pd.N, K = pd.K;
     if ((int64_t)blockIdx.x * BM >= M || blockIdx.y * FBN >= N) return;
     // two LDS stages: the global loads of K-chunk t+1 are in flight (in registers) while chunk t
@@ -117,8 +119,9 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(FwdBatch batch) {
     for (int r = 0; r < 16; ++r) {
         const int64_t row = m0 + wrow + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row < M) {
-            if (col0 < N) C[row * ldc + col0] = acc0[r] + bias0;
-            if (BM == 128 && col1 < N) C[row * ldc + col1] = acc1[r] + bias1;
+            const float rs = rowscale ? rowscale[row] : 1.f;         // bias enters as rowscale[row] * bias[n]
+            if (col0 < N) C[row * ldc + col0] = acc0[r] + rs * bias0 + (addm ? addm[row * ldadd + col0] : 0.f);
+            if (BM == 128 && col1 < N) C[row * ldc + col1] = acc1[r] + rs * bias1 + (addm ? addm[row * ldadd + col1] : 0.f);
         }
     }
 }
@@ -323,7 +326,7 @@ extern "C" int elimrec_linear_fwd_batched(const elimrec_linear_desc *descs, int 
 extern "C" int elimrec_linear_fwd(const float *d_A, int64_t lda, const float *d_W, int64_t ldw,
                                   const float *d_bias, float *d_C, int64_t ldc, int64_t M, int N, int K,
                                   void *stream) {
-    elimrec_linear_desc d = {d_A, lda, d_W, ldw, d_bias, d_C, ldc, M, N, K};
+    elimrec_linear_desc d = {d_A, lda, d_W, ldw, d_bias, d_C, ldc, M, N, K, nullptr, nullptr, 0};
     return elimrec_linear_fwd_batched(&d, 1, stream);
 }
 

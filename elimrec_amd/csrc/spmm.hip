@@ -645,7 +645,8 @@ extern "C" size_t elimrec_bipartite_workspace(int64_t U, int64_t I, int d, int M
 
 extern "C" int elimrec_propagate_bipartite(const elimrec_csr *P, const elimrec_csr *Q, int64_t U, int64_t I, int d,
                                            int M, int L, const float *d_user_emb, const float *d_XI, float *d_Out,
-                                           void *d_workspace, size_t workspace_bytes, void *stream) {
+                                           float *d_narrow_out, void *d_workspace, size_t workspace_bytes,
+                                           void *stream) {
     ELIMREC_REQUIRE(P && Q && d_user_emb && d_XI && d_Out && d_workspace, "propagate_bipartite: null pointer");
     ELIMREC_REQUIRE(d > 0 && d % 4 == 0 && M >= 1 && L >= 1, "propagate_bipartite: need d % 4 == 0, M >= 1, L >= 1");
     ELIMREC_REQUIRE(P->n_rows == U && Q->n_rows == I, "propagate_bipartite: block shapes do not match U, I");
@@ -723,6 +724,14 @@ extern "C" int elimrec_propagate_bipartite(const elimrec_csr *P, const elimrec_c
     }
     (void)users_done;
     if (!joined && (rc = check_hip(hipStreamWaitEvent(s, side.join, 0), "streamWaitEvent(join)"))) return rc;
+    if (d_narrow_out) {  // the shared narrow part of Out on both sides, scaled like Out
+        hipLaunchKernelGGL(combine_kernel, dim3(1024), dim3(256), 0, s, (const float4 *)SNu_final, (const float4 *)nullptr,
+                           U, d4, d4, inv, (float4 *)d_narrow_out);
+        ELIMREC_LAUNCH_CHECK("combine(narrow users)");
+        hipLaunchKernelGGL(combine_kernel, dim3(1024), dim3(256), 0, s, (const float4 *)SNi, (const float4 *)nullptr, I,
+                           d4, d4, inv, (float4 *)(d_narrow_out + (size_t)U * d));
+        ELIMREC_LAUNCH_CHECK("combine(narrow items)");
+    }
     if (!items_done) {   // L == 1: Out_i = (XI + bcast(a_1)) / 2
         hipLaunchKernelGGL(combine_kernel, dim3(2048), dim3(256), 0, s, (const float4 *)d_XI, (const float4 *)SNi, I, C4,
                            d4, inv, (float4 *)Out_i);
@@ -820,12 +829,12 @@ namespace elimrec {
 __global__ __launch_bounds__(256) void blocksum_rows_kernel(const float *__restrict__ G,
                                                             const int32_t *__restrict__ active_rows,
                                                             const int32_t *__restrict__ seg_info, int64_t n_max, int d,
-                                                            int M, float *__restrict__ H) {
+                                                            int M, int slot_major, float *__restrict__ H) {
     const int lane = threadIdx.x & 63;
     const int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (s >= n_max || s >= seg_info[0]) return;
     const int64_t r = active_rows[s];
-    const float4 *g = reinterpret_cast<const float4 *>(G + r * (int64_t)d * M);
+    const float4 *g = reinterpret_cast<const float4 *>(G + (slot_major ? s : r) * (int64_t)d * M);
     float4 *h = reinterpret_cast<float4 *>(H + r * (int64_t)d);
     const int d4 = d / 4;
     for (int c = lane; c < d4; c += 64) {
@@ -850,12 +859,12 @@ __global__ void copy_cols_kernel(const float *__restrict__ src, int64_t ld_src, 
 }  // namespace elimrec
 
 extern "C" int elimrec_blocksum_rows(const float *d_G, const int32_t *d_active_rows, const int32_t *d_seg_info,
-                                     int64_t n_max, int d, int M, float *d_H, void *stream) {
+                                     int64_t n_max, int d, int M, int slot_major, float *d_H, void *stream) {
     ELIMREC_REQUIRE(d_G && d_active_rows && d_seg_info && d_H, "blocksum_rows: null pointer");
     ELIMREC_REQUIRE(d > 0 && d % 4 == 0 && M >= 1, "blocksum_rows: bad d/M");
     if (n_max <= 0) return 0;
     hipLaunchKernelGGL(blocksum_rows_kernel, dim3((unsigned)((n_max + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_G,
-                       d_active_rows, d_seg_info, n_max, d, M, d_H);
+                       d_active_rows, d_seg_info, n_max, d, M, slot_major, d_H);
     ELIMREC_LAUNCH_CHECK("blocksum_rows");
     return 0;
 }

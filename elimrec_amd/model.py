@@ -143,8 +143,16 @@ class EliMRec(BasicModel):
             self._register_csr("adjT", adj_t)
         # Bipartite fast path (csrc/spmm.hip): no user-user / item-item entries (true for 'pre', 'plain', 'gcmc')
         U = self.num_users
-        self._bipartite = (self.n_layers >= 1 and adj[:U, :U].nnz == 0 and adj[U:, U:].nnz == 0
-                           and not (opt("propagation", "auto") == "full"))
+        mode = opt("propagation", "auto")        # CLI-only: auto | folded | bipartite | full
+        if mode not in ("auto", "folded", "bipartite", "full"):
+            raise ValueError("propagation must be auto, folded, bipartite or full")
+        self._bipartite = (self.n_layers >= 1 and adj[:U, :U].nnz == 0 and adj[U:, U:].nnz == 0 and mode != "full")
+        # "folded": the propagated FEATURE tables are linear in the projection weights with constant factors,
+        # mean_k A^k [0 ; F_m W_m^T + 1 b_m^T] = (mean_k A^k [0 ; F_m]) W_m^T + (mean_k A^k [0 ; 1]) b_m^T,
+        # so the constant matrices S_m = mean_k A^k [0 ; F_m] ([N x D_m]) and c = mean_k A^k [0 ; 1] are
+        # propagated ONCE at start-up; per step only the id table and the shared user part go through the
+        # graph (d columns instead of M*d) and the feature blocks of Out come from one GEMM each.
+        self._folded = self._bipartite and mode in ("auto", "folded")
         if self._bipartite:
             P, Q = adj[:U, U:].tocsr(), adj[U:, :U].tocsr()
             self._register_csr("bipP", P)
@@ -261,10 +269,16 @@ class EliMRec(BasicModel):
             for name in (("X0", "Out") if self._bipartite else ("X0", "T0", "T1", "Out", "G")):
                 ws[name] = torch.empty(N, C, **f32)
             if self._bipartite:
-                ws["gXI"] = torch.empty(self.num_items, C, **f32)
                 ws["H"] = torch.empty(N, d, **f32)
                 ws["bip_ws"] = torch.empty(ops.bipartite_workspace(self.num_users, self.num_items, d, self.M),
                                            dtype=torch.uint8, device=dev)
+                if self._folded:
+                    ws["Out0"] = torch.empty(N, d, **f32)          # propagated id table
+                    ws["Narrow"] = torch.empty(N, d, **f32)        # the part of Out every table shares
+                    ws["G00"] = torch.empty(N, d, **f32)           # dLoss/dOut, column block 0, scattered by node
+                    self._fold_constants(ws)
+                else:
+                    ws["gXI"] = torch.empty(self.num_items, C, **f32)
             ws["Y"] = torch.zeros(N, Cy, **f32)
             shapes = [(self.num_items, d, getattr(self, m + "_feat").shape[1]) for m in self._mods]
             ws["bwd_w_items"] = torch.empty(max(ops.linear_bwd_w_batched_workspace(shapes), 1), dtype=torch.uint8,
@@ -279,8 +293,40 @@ class EliMRec(BasicModel):
         ws["seg_ws"] = torch.empty(max(ops.segment_reduce_workspace(n3), 1), dtype=torch.uint8, device=dev)
         shapes = [(n3, d, C), (n3, d, C)] + [(n3, d, d)] * self.S
         ws["bwd_w_rows"] = torch.empty(max(ops.linear_bwd_w_batched_workspace(shapes), 1), dtype=torch.uint8, device=dev)
+        if self._folded:
+            ws["dOutR"] = torch.empty(n3, C, **f32)                # dLoss/dOut rows in slot order
+            shapes = [(n3, d, getattr(self, m + "_feat").shape[1]) for m in self._mods] + [(n3, d, 4)] * len(self._mods)
+            ws["bwd_w_fold"] = torch.empty(max(ops.linear_bwd_w_batched_workspace(shapes), 1), dtype=torch.uint8,
+                                           device=dev)
         self._ws, self._ws_key = ws, key
         return ws
+
+    @torch.no_grad()
+    def _fold_constants(self, ws):
+        """S_m = mean_k A^k [0 ; F_m]  ([N x D_m]) and c = mean_k A^k [0 ; 1]  ([N]), computed once per device
+        with the same propagation kernels (narrow part = 0, one table of width D_m)."""
+        U, I, L, dev = self.num_users, self.num_items, self.n_layers, self._device()
+        P, Q = self._csr("bipP"), self._csr("bipQ")
+        fold = {}
+        widths = [getattr(self, m + "_feat").shape[1] for m in self._mods] + [4]
+        wmax = max(widths)
+        for csr in (P, Q):
+            csr.build_split(max(wmax, self.C))              # the row-split scratch must cover the widest table
+        tmp_ws = torch.empty(ops.bipartite_workspace(U, I, wmax, 1), dtype=torch.uint8, device=dev)
+        zeros_u = torch.zeros(U, wmax, dtype=torch.float32, device=dev)
+        for m in self._mods:
+            feat = getattr(self, m + "_feat")
+            D = feat.shape[1]
+            out = torch.empty(U + I, D, dtype=torch.float32, device=dev)
+            ops.propagate_bipartite(P, Q, U, I, D, 1, L, zeros_u[:, :D].contiguous(), feat, out, tmp_ws)
+            fold[m] = out
+        ones = torch.ones(I, 4, dtype=torch.float32, device=dev)
+        cpad = torch.empty(U + I, 4, dtype=torch.float32, device=dev)
+        ops.propagate_bipartite(P, Q, U, I, 4, 1, L, zeros_u[:, :4].contiguous(), ones, cpad, tmp_ws)
+        cpad[:, 1:] = 0.0                                   # column 0 = c; the rest pads the bias-gradient GEMM
+        fold["c_pad"] = cpad
+        fold["c"] = cpad[:, 0].contiguous()
+        ws["fold"] = fold
 
     def _flatten_parameters(self, ws):
         """Re-point every parameter into ONE contiguous fp32 buffer (same Parameter objects, so an
@@ -327,6 +373,18 @@ class EliMRec(BasicModel):
         """compute() + gcn_cf() (:228-272,144-153): fills ws['Out'] and ws['Y']."""
         U, I, d, M, C = self.num_users, self.num_items, self.latent_dim, self.M, self.C
         X0, Out, Y = ws["X0"], ws["Out"], ws["Y"]
+        if self._folded:
+            # id table + shared user part through the graph at d columns; feature blocks from the folded constants
+            self._timed(lambda: ops.propagate_bipartite(self._csr("bipP"), self._csr("bipQ"), U, I, d, 1, self.n_layers,
+                                                        self.embedding_user.weight, self.embedding_item.weight,
+                                                        ws["Out0"], ws["bip_ws"], narrow_out=ws["Narrow"]))
+            ops.copy_cols(ws["Out0"], Out[:, :d])
+            fold = ws["fold"]
+            ops.linear_fwd_batched([(fold[m], getattr(self, m + "_dense").weight, getattr(self, m + "_dense").bias,
+                                     Out[:, (k + 1) * d:(k + 2) * d], fold["c"], ws["Narrow"])
+                                    for k, m in enumerate(self._mods)])
+            self._head_forward(ws)
+            return
         if self._bipartite:
             ops.copy_cols(self.embedding_item.weight, X0[U:, :d])          # XI block 0 = item id table
         else:
@@ -339,6 +397,11 @@ class EliMRec(BasicModel):
                                                         self.embedding_user.weight, X0[U:], Out, ws["bip_ws"]))
         else:
             self._propagate(self._csr("adj"), X0, ws["T0"], ws["T1"], Out)
+        self._head_forward(ws)
+
+    def _head_forward(self, ws):
+        U, d = self.num_users, self.latent_dim
+        Out, Y = ws["Out"], ws["Y"]
         wu, wi = self._fusion_weights()
         head = [(Out[:U], wu, self.embedding_user_after_GCN.bias, Y[:U, :d]),
                 (Out[U:], wi, self.embedding_item_after_GCN.bias, Y[U:, :d])]
@@ -409,8 +472,13 @@ class EliMRec(BasicModel):
         if not self._bipartite:
             G0.zero_()      # the bipartite path masks inactive rows instead of reading zeros
         # heads switched off by the modality ablation carry an all-zero gradient block
-        ops.head_bwd_input(dY, act, seg, U, d, C, [h + 1 for h in range(S)], wu, wi,
-                           [getattr(self, "s_dense_" + m).weight for m in self._mods], 1.0, G0)
+        head_ws = [getattr(self, "s_dense_" + m).weight for m in self._mods]
+        if self._folded:    # block 0 scattered by node for the graph adjoint; every block kept in slot order
+            dOutR = ws["dOutR"][:n_rows]
+            ops.head_bwd_input(dY, act, seg, U, d, C, [h + 1 for h in range(S)], wu, wi, head_ws, 1.0, ws["G00"],
+                               scatter_cols=d, compact=dOutR)
+        else:
+            ops.head_bwd_input(dY, act, seg, U, d, C, [h + 1 for h in range(S)], wu, wi, head_ws, 1.0, G0)
         grads = {}
         f32 = dict(dtype=torch.float32, device=dev)
         # fusion Linears: dW = dY_f^T . Out[active rows], user slots / item slots separately
@@ -433,6 +501,27 @@ class EliMRec(BasicModel):
                 gv[name + ".weight"].copy_(gw.view(d, M, d).sum(1) / M)
         # back through the propagation (A^T; A itself when symmetric), then the layer-0 pieces
         gu, gi = gv["embedding_user.weight"], gv["embedding_item.weight"]
+        if self._folded:
+            ops.blocksum_rows(dOutR, act, seg, d, M, ws["H"], slot_major=True)
+            sym = self._adj_symmetric
+            PT, QT = self._csr("bipQ" if sym else "bipPT"), self._csr("bipP" if sym else "bipQT")
+            self._timed(lambda: ops.propagate_bipartite_bwd(PT, QT, U, I, d, 1, self.n_layers, ws["G00"], ws["H"], act,
+                                                            seg, gi, gu, ws["bip_ws"]))
+            grads["embedding_user.weight"], grads["embedding_item.weight"] = gu, gi
+            # feature projections: Out_m = S_m W_m^T + c b_m^T + (shared part)  =>  dW_m = dOut_m^T S_m over the
+            # active rows only, db_m = dOut_m^T c  (the dense I-row contraction of the unfolded path disappears)
+            fold = ws["fold"]
+            problems, tmp_b = [], {}
+            for k, m in enumerate(self._mods):
+                blk = dOutR[:, (k + 1) * d:(k + 2) * d]
+                problems.append(dict(A=blk, B=fold[m], out=gv[m + "_dense.weight"], row_index=act, rng=seg[6:8]))
+                tmp_b[m] = torch.empty(d, 4, **f32)
+                problems.append(dict(A=blk, B=fold["c_pad"], out=tmp_b[m], row_index=act, rng=seg[6:8]))
+                grads[m + "_dense.weight"], grads[m + "_dense.bias"] = gv[m + "_dense.weight"], gv[m + "_dense.bias"]
+            ops.linear_bwd_w_batched(problems, ws["bwd_w_fold"])
+            for m, t in tmp_b.items():
+                gv[m + "_dense.bias"].copy_(t[:, 0])
+            return grads
         if self._bipartite:
             ops.blocksum_rows(G0, act, seg, d, M, ws["H"])
             sym = self._adj_symmetric

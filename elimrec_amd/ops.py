@@ -47,17 +47,27 @@ def linear_fwd(A, W, bias, out):
 
 
 def linear_fwd_batched(problems):
-    """problems: list of (A, W, bias, out) -- independent Linears sharing one launch (<= 8)."""
+    """problems: list of (A, W, bias, out[, rowscale, add]) -- independent Linears sharing one launch (<= 8).
+    out = A.W^T + rowscale[:, None] * bias + add   (rowscale, add optional)."""
     n = len(problems)
     arr = (_lib.LinearDesc * n)()
-    for i, (A, W, bias, out) in enumerate(problems):
+    for i, pr in enumerate(problems):
+        A, W, bias, out = pr[:4]
+        rowscale = pr[4] if len(pr) > 4 else None
+        add = pr[5] if len(pr) > 5 else None
         a, lda = _rowmajor(A, "A")
         w, ldw = _rowmajor(W, "W")
         c, ldc = _rowmajor(out, "out")
         M, K = A.shape
         N = W.shape[0]
         assert W.shape[1] == K and out.shape[0] == M and out.shape[1] == N
-        arr[i] = _lib.LinearDesc(a, lda, w, ldw, _dev(bias, "bias"), c, ldc, M, N, K)
+        ad, ldadd = (None, 0)
+        if add is not None:
+            assert add.shape == (M, N)
+            ad, ldadd = _rowmajor(add, "add")
+        if rowscale is not None:
+            assert rowscale.is_contiguous() and rowscale.numel() == M
+        arr[i] = _lib.LinearDesc(a, lda, w, ldw, _dev(bias, "bias"), c, ldc, M, N, K, _dev(rowscale, "rowscale"), ad, ldadd)
     _lib.check(_lib.load().elimrec_linear_fwd_batched(arr, n, _stream()), "linear_fwd_batched")
 
 
@@ -212,11 +222,12 @@ def bipartite_workspace(U, I, d, M):
     return int(_lib.load().elimrec_bipartite_workspace(U, I, d, M))
 
 
-def propagate_bipartite(P, Q, U, I, d, M, L, user_emb, XI, out, workspace):
+def propagate_bipartite(P, Q, U, I, d, M, L, user_emb, XI, out, workspace, narrow_out=None):
     assert user_emb.is_contiguous() and XI.is_contiguous() and out.is_contiguous()
     assert XI.shape == (I, d * M) and out.shape == (U + I, d * M) and user_emb.shape == (U, d)
+    assert narrow_out is None or (narrow_out.is_contiguous() and narrow_out.shape == (U + I, d))
     _lib.check(_lib.load().elimrec_propagate_bipartite(P.desc(), Q.desc(), U, I, d, M, L, _dev(user_emb, "user_emb"),
-                                                       _dev(XI, "XI"), _dev(out, "out"),
+                                                       _dev(XI, "XI"), _dev(out, "out"), _dev(narrow_out, "narrow_out"),
                                                        _dev(workspace, "workspace", torch.uint8), workspace.numel(),
                                                        _stream()), "propagate_bipartite")
     return out
@@ -243,11 +254,12 @@ def block_spmm(A, Xin, Xout=None, add1=None, acc_out=None, scale=1.0):
                                               _dev(acc_out, "acc_out"), float(scale), _stream()), "block_spmm")
 
 
-def blocksum_rows(G, active_rows, seg_info, d, M, H):
+def blocksum_rows(G, active_rows, seg_info, d, M, H, slot_major=False):
+    """H[node] = sum over the M column blocks of the node's row of G (rows of G indexed by node, or by slot)."""
     assert G.is_contiguous() and H.is_contiguous()
     _lib.check(_lib.load().elimrec_blocksum_rows(_dev(G, "G"), _dev(active_rows, "active_rows", torch.int32),
                                                  _dev(seg_info, "seg_info", torch.int32), active_rows.numel(), d, M,
-                                                 _dev(H, "H"), _stream()), "blocksum_rows")
+                                                 1 if slot_major else 0, _dev(H, "H"), _stream()), "blocksum_rows")
 
 
 def copy_cols(src, dst):
@@ -289,18 +301,26 @@ def segment_reduce_rows(rows, keys, split_key, active_rows, reduced, seg_info, w
                                                        _stream()), "segment_reduce_rows")
 
 
-def head_bwd_input(dY, active_rows, seg_info, U, d, C, head_mblock, W_user, W_item, W_heads, gscale, G0):
+def head_bwd_input(dY, active_rows, seg_info, U, d, C, head_mblock, W_user, W_item, W_heads, gscale, G0,
+                   scatter_cols=None, compact=None):
+    """G0[node, 0:scatter_cols] (row stride G0.stride(0)) and/or compact[slot, 0:C] receive the input gradient."""
     S = len(W_heads)
     dy, lddy = _rowmajor(dY, "dY")
     mb = (ctypes.c_int * max(S, 1))(*head_mblock) if S else (ctypes.c_int * 1)(0)
     wp = (ctypes.c_void_p * max(S, 1))(*[_dev(w, "W_head") for w in W_heads]) if S else (ctypes.c_void_p * 1)(None)
     for w in list(W_heads) + [W_user, W_item]:
         assert w.is_contiguous()
-    assert G0.is_contiguous()
+    g0, ldg = (None, 0)
+    if G0 is not None:
+        g0, ldg = _rowmajor(G0, "G0")
+    if scatter_cols is None:
+        scatter_cols = C if G0 is not None else 0
+    assert compact is None or (compact.is_contiguous() and compact.shape[1] == C and compact.shape[0] >= dY.shape[0])
     _lib.check(_lib.load().elimrec_head_bwd_input(dy, lddy, _dev(active_rows, "active_rows", torch.int32),
                                                   _dev(seg_info, "seg_info", torch.int32), dY.shape[0], U, d, C, S, mb,
                                                   _dev(W_user, "W_user"), _dev(W_item, "W_item"), wp, float(gscale),
-                                                  _dev(G0, "G0"), _stream()), "head_bwd_input")
+                                                  g0, ldg, int(scatter_cols), _dev(compact, "compact"), _stream()),
+               "head_bwd_input")
 
 
 def embed_grad(G, U, I, d, M, grad_user, grad_item):

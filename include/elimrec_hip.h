@@ -56,6 +56,8 @@ typedef struct elimrec_linear_desc {
     const float *d_bias;            /* nullable */
     float *d_C; int64_t ldc;
     int64_t M; int32_t N; int32_t K;
+    const float *d_rowscale;        /* nullable [M]: the bias term becomes rowscale[m] * bias[n]      */
+    const float *d_add; int64_t ldadd;  /* nullable [M x N]: added to the result (C = A.W^T + .. + add) */
 } elimrec_linear_desc;
 int elimrec_linear_fwd_batched(const elimrec_linear_desc *descs /* host array */, int n, void *stream);
 
@@ -154,6 +156,8 @@ size_t elimrec_bipartite_workspace(int64_t U, int64_t I, int d, int M);
 int elimrec_propagate_bipartite(const elimrec_csr *P, const elimrec_csr *Q, int64_t U, int64_t I,
                                 int d, int M, int L, const float *d_user_emb /* [U x d] */,
                                 const float *d_XI /* [I x C] */, float *d_Out /* [N x C] */,
+                                float *d_narrow_out /* nullable [N x d]: 1/(L+1) * sum_k A^k [E_u ; 0], the part of
+                                                       Out that every table shares */,
                                 void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* The C-column and d-column chains of the bipartite propagation are independent for most of a call;
@@ -185,7 +189,8 @@ int elimrec_block_spmm(const elimrec_csr *A, int W, int64_t ld, const float *d_X
 
 /* H[r, j] = sum_m G[r, m*d + j] for the active rows r (slots < d_seg_info[0]). */
 int elimrec_blocksum_rows(const float *d_G, const int32_t *d_active_rows, const int32_t *d_seg_info,
-                          int64_t n_max, int d, int M, float *d_H, void *stream);
+                          int64_t n_max, int d, int M, int slot_major /* G rows indexed by slot, not node */,
+                          float *d_H, void *stream);
 
 /* dst[r, 0:n_cols] = src[r, 0:n_cols] with independent leading dimensions (column-block copies:
  * E_item into block 0 of XI; block 0 of gXI into the embedding_item gradient). n_cols % 4 == 0. */
@@ -235,7 +240,9 @@ int elimrec_head_bwd_input(const float *d_dY, int64_t lddy, const int32_t *d_act
                            const int32_t *d_seg_info, int64_t n_max, int64_t U, int d, int C,
                            int S, const int *head_mblock, const float *d_W_user,
                            const float *d_W_item, const float *const *d_W_heads /* host array of S device ptrs */,
-                           float gscale, float *d_G0, void *stream);
+                           float gscale, float *d_G0 /* nullable: scattered rows G0[node, 0:scatter_cols], stride ldg */,
+                           int64_t ldg, int scatter_cols,
+                           float *d_compact /* nullable [n_max x C]: the same rows in slot order */, void *stream);
 
 /* ---------------------------------------------------------------- embedding gradients (K2 bwd)
  * dE_user[u, j] = sum_m G[u, m*d + j];  dE_item[i, j] = G[U+i, j]   (CatBackward of :239). */

@@ -532,12 +532,12 @@ def test_model_paths_agree_on_gcmc_adjacency():
     argv = [a for a in fixture_argv(g) if not a.startswith("--adj_type")] + ["--adj_type=gcmc"]
     u, p, n = (_t(g["step1/%s" % k]) for k in ("users", "pos", "neg"))
     res = {}
-    for mode in ("auto", "full"):
+    for mode in ("auto", "bipartite", "full"):
         cfg = make_config(argv + ["--propagation=%s" % mode])
         model = EliMRec(cfg, FixtureDataset(g))
         model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sub(g, "init").items()})
         model = model.to(DEV)
-        assert model._bipartite == (mode == "auto") and not model._adj_symmetric
+        assert model._bipartite == (mode != "full") and model._folded == (mode == "auto") and not model._adj_symmetric
         loss = model.bpr_loss(u, p, n)
         loss.backward()
         res[mode] = (loss.item(), {k: q.grad.cpu() for k, q in model.named_parameters() if q.grad is not None})
@@ -547,7 +547,7 @@ def test_model_paths_agree_on_gcmc_adjacency():
                           sub(g, "init"), float(g["alpha"]))
     ol = om.bpr_loss(g["step1/users"], g["step1/pos"], g["step1/neg"])
     ol.backward()
-    for mode in ("auto", "full"):
+    for mode in ("auto", "bipartite", "full"):
         assert abs(res[mode][0] - float(ol)) < 1e-5
         assert set(res[mode][1]) == set(om.grads())
         for k, v in om.grads().items():
