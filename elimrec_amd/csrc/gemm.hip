@@ -19,7 +19,7 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 // --------------------------------------------------------------------------------- forward
 // Workgroup = 4 waves, tile 128 rows x 64 cols, K staged 32 at a time through LDS
 // (row stride 33 floats: the 32 lanes of a half-wave read 32 different rows at the same k).
-constexpr int FBM = 128, FBN = 64, FBK = 32, FLD = FBK + 1;
+constexpr int FBM = 128, FBN = 64, FBK = 16, FLD = FBK + 1;
 
 constexpr int kMaxBatch = 8;
 struct FwdBatch { elimrec_linear_desc p[kMaxBatch]; };
@@ -40,36 +40,45 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(FwdBatch batch) {
     const float *__restrict__ addm = pd.d_add;
     const int64_t lda = pd.lda, ldw = pd.ldw, ldc = pd.ldc, ldadd = pd.ldadd, M = pd.M;
     const int N = pd.N, K = pd.K;
-    if ((int64_t)blockIdx.x * BM >= M || blockIdx.y * FBN >= N) return;
-    // two LDS stages: the global loads of K-chunk t+1 are in flight (in registers) while chunk t
-    // feeds the MFMAs; one barrier per chunk.
+    const int n0 = blockIdx.y * FBN;
+    const int64_t n_tiles = (M + BM - 1) / BM;
+    if ((int64_t)blockIdx.x >= n_tiles || n0 >= N) return;
+    // PERSISTENT over row tiles: workgroup b takes tiles b, b + gridDim.x, ...; the (tile, K-chunk) pairs form
+    // one software pipeline -- while chunk g feeds the MFMAs, chunk g+1 (possibly the first chunk of the NEXT
+    // tile) is in flight in registers, so the global-load latency is paid once per workgroup, not per tile.
     __shared__ float As[2][BM * FLD];
     __shared__ float Bs[2][FBN * FLD];
-    constexpr int AP = BM / 32;      // float4 loads per thread for the A chunk
+    constexpr int KP4 = FBK / 4;             // float4 per row of a K-chunk
+    constexpr int RPP = 256 / KP4;           // rows covered by one pass of the 256 loader threads
+    constexpr int AP = BM / RPP;             // float4 loads per thread for the A chunk
+    constexpr int BP = FBN / RPP;            // ... for the W chunk
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * FBN;
-    const int lr = tid >> 3;        // 0..31 : row inside a 32-row group
-    const int lc = (tid & 7) * 4;   // 0,4,..28 : k offset of this thread's float4
+    const int lr = tid / KP4;           // row inside a pass
+    const int lc = (tid % KP4) * 4;     // k offset of this thread's float4
     const int wrow = (BM == 128) ? wave * 32 : (wave & 1) * 32;
     const int wcol = (BM == 128) ? 0 : (wave >> 1) * 32;
+    const int chunks = (K + FBK - 1) / FBK;
+    const int64_t my_tiles = (n_tiles - blockIdx.x + gridDim.x - 1) / gridDim.x;
+    const int64_t G = my_tiles * chunks;
 
     v16f acc0 = {0}, acc1 = {0};
     const int ai = lane & 31, ak = lane >> 5;
-    float4 ra[AP], rb[2];
-    auto load_chunk = [&](int k0) {
+    float4 ra[AP], rb[BP];
+    auto load_chunk = [&](int64_t g) {
+        const int64_t m0 = ((int64_t)blockIdx.x + (g / chunks) * gridDim.x) * BM;
+        const int k0 = (int)(g % chunks) * FBK;
         const bool kin = (k0 + lc) < K;  // K % 4 == 0: the whole float4 is in or out
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
-            const int64_t gr = m0 + lr + 32 * i;
+            const int64_t gr = m0 + lr + RPP * i;
             ra[i] = (kin && gr < M) ? *reinterpret_cast<const float4 *>(A + gr * lda + k0 + lc)
                                     : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int gn = n0 + lr + 32 * i;
+        for (int i = 0; i < BP; ++i) {
+            const int gn = n0 + lr + RPP * i;
             rb[i] = (kin && gn < N) ? *reinterpret_cast<const float4 *>(W + (int64_t)gn * ldw + k0 + lc)
                                     : make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -77,22 +86,27 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(FwdBatch batch) {
     auto store_chunk = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
-            float *dst = &As[buf][(lr + 32 * i) * FLD + lc];
+            float *dst = &As[buf][(lr + RPP * i) * FLD + lc];
             dst[0] = ra[i].x; dst[1] = ra[i].y; dst[2] = ra[i].z; dst[3] = ra[i].w;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float *dst = &Bs[buf][(lr + 32 * i) * FLD + lc];
+        for (int i = 0; i < BP; ++i) {
+            float *dst = &Bs[buf][(lr + RPP * i) * FLD + lc];
             dst[0] = rb[i].x; dst[1] = rb[i].y; dst[2] = rb[i].z; dst[3] = rb[i].w;
         }
     };
+    const int col0 = n0 + wcol + (lane & 31);
+    const int col1 = col0 + 32;
+    const float bias0 = (bias && col0 < N) ? bias[col0] : 0.f;
+    const float bias1 = (BM == 128 && bias && col1 < N) ? bias[col1] : 0.f;
+
     load_chunk(0);
     store_chunk(0);
     __syncthreads();
     int buf = 0;
-    for (int k0 = 0; k0 < K; k0 += FBK) {
-        const bool more = (k0 + FBK) < K;
-        if (more) load_chunk(k0 + FBK);
+    for (int64_t g = 0; g < G; ++g) {
+        const bool more = (g + 1) < G;
+        if (more) load_chunk(g + 1);
         const float *ap = &As[buf][(wrow + ai) * FLD + ak];
         const float *bp0 = &Bs[buf][(wcol + ai) * FLD + ak];
         const float *bp1 = &Bs[buf][(32 + ai) * FLD + ak];
@@ -106,23 +120,24 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(FwdBatch batch) {
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
             }
         }
+        if ((int)(g % chunks) == chunks - 1) {           // last K-chunk of this tile: write it out, start the next
+            const int64_t m0 = ((int64_t)blockIdx.x + (g / chunks) * gridDim.x) * BM;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wrow + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < M) {
+                    const float rs = rowscale ? rowscale[row] : 1.f;         // bias enters as rowscale[row] * bias[n]
+                    if (col0 < N) C[row * ldc + col0] = acc0[r] + rs * bias0 + (addm ? addm[row * ldadd + col0] : 0.f);
+                    if (BM == 128 && col1 < N)
+                        C[row * ldc + col1] = acc1[r] + rs * bias1 + (addm ? addm[row * ldadd + col1] : 0.f);
+                }
+            }
+            acc0 = (v16f){0};
+            acc1 = (v16f){0};
+        }
         if (more) store_chunk(buf ^ 1);
         __syncthreads();
         buf ^= 1;
-    }
-
-    const int col0 = n0 + wcol + (lane & 31);
-    const int col1 = col0 + 32;
-    const float bias0 = (bias && col0 < N) ? bias[col0] : 0.f;
-    const float bias1 = (BM == 128 && bias && col1 < N) ? bias[col1] : 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int64_t row = m0 + wrow + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row < M) {
-            const float rs = rowscale ? rowscale[row] : 1.f;         // bias enters as rowscale[row] * bias[n]
-            if (col0 < N) C[row * ldc + col0] = acc0[r] + rs * bias0 + (addm ? addm[row * ldadd + col0] : 0.f);
-            if (BM == 128 && col1 < N) C[row * ldc + col1] = acc1[r] + rs * bias1 + (addm ? addm[row * ldadd + col1] : 0.f);
-        }
     }
 }
 
@@ -312,11 +327,21 @@ extern "C" int elimrec_linear_fwd_batched(const elimrec_linear_desc *descs, int 
         const char *e = getenv("ELIMREC_FWD_TILE");
         tile_rows = (e && atoi(e) == 128) ? 128 : 64;
     }
+    // persistent grid: about 4 (3) resident workgroups per CU in total across the problems of the batch
+    static int wg_budget = 0;
+    if (!wg_budget) {
+        const char *e = getenv("ELIMREC_FWD_WGS");
+        wg_budget = e ? atoi(e) : (1 << 30);      // default: one workgroup per tile (measured best); a smaller budget makes the kernel persistent
+        if (wg_budget < 64) wg_budget = 64;
+    }
+    int64_t per_problem = (wg_budget + (int64_t)n * max_tiles_n - 1) / ((int64_t)n * max_tiles_n);
     if (tile_rows == 128) {
-        dim3 grid((unsigned)((max_tiles_m + 127) / 128), (unsigned)max_tiles_n, (unsigned)n);
+        const int64_t tiles = (max_tiles_m + 127) / 128;
+        dim3 grid((unsigned)(tiles < per_problem ? tiles : per_problem), (unsigned)max_tiles_n, (unsigned)n);
         hipLaunchKernelGGL(linear_fwd_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, batch);
     } else {
-        dim3 grid((unsigned)((max_tiles_m + 63) / 64), (unsigned)max_tiles_n, (unsigned)n);
+        const int64_t tiles = (max_tiles_m + 63) / 64;
+        dim3 grid((unsigned)(tiles < per_problem ? tiles : per_problem), (unsigned)max_tiles_n, (unsigned)n);
         hipLaunchKernelGGL(linear_fwd_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, batch);
     }
     ELIMREC_LAUNCH_CHECK("linear_fwd");
