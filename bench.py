@@ -43,7 +43,10 @@ def algorithmic_bytes(model, B):
     P = sum(p.numel() for p in model.parameters())
     step = 2 * F + 2 * (M - 1) * I * d * s + 2 * (L * (2 * T + Ccsr) + (L + 2) * T) + 2 * (T + G) + 4 * (M - 1) * G \
         + 9 * B * M * d * s + 28 * P
-    hop = (L * (2 * T + Ccsr) + (L + 2) * T) / max(L, 1)      # one spmm_hop launch, layer-mean traffic included
+    # one propagation hop as the kernels run it: all M tables side by side (bipartite / full paths), or -- with
+    # the constant feature tables folded into GEMM operands -- only the id table: d columns
+    Th = G if getattr(model, "_folded", False) else T
+    hop = (L * (2 * Th + Ccsr) + (L + 2) * Th) / max(L, 1)    # layer-mean traffic included
     return step, hop
 
 
@@ -185,12 +188,17 @@ def main():
                        "train_interactions": int(ds.train_matrix.nnz), "feat_dims": list(WORKLOAD["feat_dims"]),
                        "recdim": WORKLOAD["recdim"], "layer_num": WORKLOAD["layer_num"], "batch_per_gpu": B,
                        "global_batch": B * world, "parallelism": "dp%d-replicated-tables" % world,
+                       "propagation": "folded" if getattr(model, "_folded", False) else
+                                      ("bipartite" if getattr(model, "_bipartite", False) else "full"),
                        "final_loss": final_loss},
             "step_algorithmic_GB": step_bytes / 1e9,
             "step_achieved_GBps": step_bytes / (dt / args.steps) / 1e9,
             "roofline": {"bound": "hbm",
-                         "kernel": "propagation hop = half_hop_kernel<64> (C columns) + half_hop_kernel<16> (d columns) "
-                                   "+ their long-row helpers; 2L hops per step",
+                         "kernel": ("propagation hop over the d-column id table = 2 half_hop_kernel<16> launches (users<-items, "
+                                    "items<-users); 2L hops per step; feature tables folded into GEMM operands"
+                                    if getattr(model, "_folded", False) else
+                                    "propagation hop = half_hop_kernel<64> (C columns) + half_hop_kernel<16> (d columns); "
+                                    "2L hops per step"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": pmc_traffic_per_hop(),
