@@ -194,8 +194,8 @@ def main():
             "step_algorithmic_GB": step_bytes / 1e9,
             "step_achieved_GBps": step_bytes / (dt / args.steps) / 1e9,
             "roofline": {"bound": "hbm",
-                         "kernel": ("propagation hop over the d-column id table = 2 half_hop_kernel<16> launches (users<-items, "
-                                    "items<-users); 2L hops per step; feature tables folded into GEMM operands"
+                         "kernel": ("propagation hop of the d-column table [E_u;E_i] = ONE half_hop_kernel<16> launch over the "
+                                    "full adjacency; 2L hops per step; feature tables folded into GEMM operands"
                                     if getattr(model, "_folded", False) else
                                     "propagation hop = half_hop_kernel<64> (C columns) + half_hop_kernel<16> (d columns); "
                                     "2L hops per step"),

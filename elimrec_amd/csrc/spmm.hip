@@ -271,7 +271,15 @@ struct HalfArgs {
     const float *val;
     int64_t n_rows;
     int W4;                       // columns processed, in float4
-    int ld4;                      // row stride of Xin / Xout / Add1 / Add2 / AccOut in float4 (>= W4)
+    int ld4;                      // row stride of Xin / Xout / Add2 in float4 (>= W4)
+    int ld_add1;                  // row stride of Add1 in float4
+    int ld_acc;                   // row stride of AccOut in float4
+    // second accumulator, rows [acc2_lo, acc2_hi) only (contiguous, stride W4):
+    //   Acc2Out[row] = (r + Acc2In[row]) * acc2_scale         (Acc2In nullable)
+    float4 *Acc2Out;
+    const float4 *Acc2In;
+    int64_t acc2_lo, acc2_hi;
+    float acc2_scale;
     const float4 *Xin;
     const uint32_t *src_mask;     // nullable: bit r set <=> source row r is non-zero
     float4 *Xout;                 // nullable: raw result
@@ -303,7 +311,7 @@ __device__ __forceinline__ void half_epilogue(const HalfArgs &a, int64_t row, in
     if (a.AccOut) {
         float4 s = r;
         if (a.Add1 && (!a.add1_mask || mask_bit(a.add1_mask, (int)row))) {
-            const float4 t = a.Add1[row * a.ld4 + c];
+            const float4 t = a.Add1[row * a.ld_add1 + c];
             s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
         }
         if (a.Add2) {
@@ -314,7 +322,15 @@ __device__ __forceinline__ void half_epilogue(const HalfArgs &a, int64_t row, in
             const float4 t = a.AddN[row * a.N4 + (c % a.N4)];
             s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
         }
-        a.AccOut[row * a.ld4 + c] = make_float4(s.x * a.scale, s.y * a.scale, s.z * a.scale, s.w * a.scale);
+        a.AccOut[row * a.ld_acc + c] = make_float4(s.x * a.scale, s.y * a.scale, s.z * a.scale, s.w * a.scale);
+    }
+    if (a.Acc2Out && row >= a.acc2_lo && row < a.acc2_hi) {
+        float4 s = r;
+        if (a.Acc2In) {
+            const float4 t = a.Acc2In[row * a.W4 + c];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        a.Acc2Out[row * a.W4 + c] = make_float4(s.x * a.acc2_scale, s.y * a.acc2_scale, s.z * a.acc2_scale, s.w * a.acc2_scale);
     }
 }
 
@@ -573,7 +589,7 @@ static HalfArgs half_args(int W4, const float *Xin, const uint32_t *src_mask, fl
                           const uint32_t *add1_mask, const float *Add2, const float *AddN, int N4, float *AccOut,
                           float scale) {
     HalfArgs a = {};
-    a.W4 = W4; a.ld4 = W4; a.Xin = (const float4 *)Xin; a.src_mask = src_mask; a.Xout = (float4 *)Xout;
+    a.W4 = W4; a.ld4 = W4; a.ld_add1 = W4; a.ld_acc = W4; a.Xin = (const float4 *)Xin; a.src_mask = src_mask; a.Xout = (float4 *)Xout;
     a.Add1 = (const float4 *)Add1; a.add1_mask = add1_mask; a.Add2 = (const float4 *)Add2;
     a.AddN = (const float4 *)AddN; a.N4 = N4 > 0 ? N4 : 1; a.AccOut = (float4 *)AccOut; a.scale = scale;
     return a;
@@ -890,6 +906,131 @@ extern "C" int elimrec_block_spmm(const elimrec_csr *A, int W, int64_t ld, const
     ELIMREC_REQUIRE(A && d_Xin && (d_Xout || d_AccOut), "block_spmm: null pointer");
     ELIMREC_REQUIRE(W > 0 && W % 4 == 0 && ld % 4 == 0 && ld >= W, "block_spmm: W, ld must be multiples of 4, ld >= W");
     HalfArgs a = half_args(W / 4, d_Xin, nullptr, d_Xout, d_Add1, nullptr, nullptr, nullptr, 0, d_AccOut, scale);
-    a.ld4 = (int)(ld / 4);
+    a.ld4 = a.ld_add1 = a.ld_acc = (int)(ld / 4);
     return launch_half(A, a, 0, (hipStream_t)stream);
+}
+
+// =====================================================================================================
+// Folded propagation: with the constant feature tables folded into GEMM operands only ONE d-column table,
+// X^0 = [E_u ; E_i], goes through the graph, and the two chains of the bipartite form (A^k [0;E_i] and
+// A^k [E_u;0]) live on complementary sides of every layer -- so layer k of both is one ordinary hop
+// X^k = A X^(k-1) over all N rows: ONE launch per hop. The epilogue keeps two sums:
+//   Out0 = 1/(L+1) sum_k X^k                     (written into column block 0 of Out, row stride ldo)
+//   Nar  = 1/(L+1) sum_{k even} X^k on user rows, sum_{k odd} X^k on item rows   (the part every table shares)
+// Backward (adjoint, Horner): T^L = S^L, T^k = S^k + A^T T^(k+1), [gE_u ; gE_i] = 1/(L+1) T^0, where the source
+// table S^k holds H (block sum of dOut) on the rows where the shared part lives at layer k and dOut block 0 on the
+// others: SrcA = [H_u ; G_i] for even k, SrcB = [G_u ; H_i] for odd k (both valid on the active rows only:
+// row bitmap). Requires an adjacency without diagonal blocks and L >= 1.
+// =====================================================================================================
+extern "C" size_t elimrec_folded_workspace(int64_t N, int d) {
+    return 2 * align_up((size_t)N * d * sizeof(float), 256) + align_up((size_t)((N + 31) / 32 + 2) * 4, 256);
+}
+
+extern "C" int elimrec_propagate_folded(const elimrec_csr *A, int64_t U, int64_t I, int d, int L, const float *d_X0,
+                                        float *d_Out0, int64_t ldo, float *d_narrow, void *d_workspace,
+                                        size_t workspace_bytes, void *stream) {
+    ELIMREC_REQUIRE(A && d_X0 && d_Out0 && d_narrow && d_workspace, "propagate_folded: null pointer");
+    ELIMREC_REQUIRE(d > 0 && d % 4 == 0 && L >= 1 && ldo % 4 == 0 && ldo >= d, "propagate_folded: bad d/L/ldo");
+    const int64_t N = U + I;
+    ELIMREC_REQUIRE(A->n_rows == N, "propagate_folded: adjacency has %lld rows, expected %lld", (long long)A->n_rows, (long long)N);
+    if (workspace_bytes < elimrec_folded_workspace(N, d)) { set_error("propagate_folded: workspace too small"); return ELIMREC_E_WORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = (char *)d_workspace;
+    float *xb[2] = {(float *)ws, (float *)(ws + align_up((size_t)N * d * sizeof(float), 256))};
+    const float inv = 1.0f / (float)(L + 1);
+    const int d4 = d / 4;
+    const float *xin = d_X0;
+    int rc;
+    for (int k = 1; k <= L; ++k) {
+        const bool last = (k == L);
+        float *xout = last ? nullptr : xb[(k - 1) & 1];
+        HalfArgs a = half_args(d4, xin, nullptr, xout, (k == 1) ? d_X0 : d_Out0, nullptr, nullptr, nullptr, 0, d_Out0,
+                               last ? inv : 1.0f);
+        a.ld_add1 = (k == 1) ? d4 : (int)(ldo / 4);
+        a.ld_acc = (int)(ldo / 4);
+        // the shared (narrow) part lives on item rows for odd k, on user rows for even k
+        const bool on_items = (k & 1);
+        a.acc2_lo = on_items ? U : 0;
+        a.acc2_hi = on_items ? N : U;
+        a.Acc2Out = (float4 *)d_narrow;
+        // first visit of a side: users start from a_0 = E_u (k = 2), items from nothing (k = 1)
+        a.Acc2In = (k == 1) ? nullptr : ((k == 2) ? (const float4 *)d_X0 : (const float4 *)d_narrow);
+        a.acc2_scale = (k + 2 > L) ? inv : 1.0f;          // last visit of this side
+        if ((rc = launch_half(A, a, 0, s))) return rc;
+        xin = xout;
+    }
+    if (L < 2) {      // the user rows of the shared part were never visited: Nar_u = a_0 / (L+1)
+        hipLaunchKernelGGL(combine_kernel, dim3(1024), dim3(256), 0, s, (const float4 *)d_X0, (const float4 *)nullptr, U, d4,
+                           d4, inv, (float4 *)d_narrow);
+        ELIMREC_LAUNCH_CHECK("combine(narrow users)");
+    }
+    return 0;
+}
+
+namespace elimrec {
+// SrcA[node] = node < U ? H : G ; SrcB[node] = node < U ? G : H, for the active nodes, from the slot-major dOut rows
+// (G = column block 0, H = sum of the M blocks); also sets the row bitmap (pre-zeroed).
+__global__ __launch_bounds__(256) void folded_sources_kernel(const float *__restrict__ dOutR,
+                                                             const int32_t *__restrict__ active_rows,
+                                                             const int32_t *__restrict__ seg_info, int64_t n_max,
+                                                             int64_t U, int d, int M, float *__restrict__ SrcA,
+                                                             float *__restrict__ SrcB, uint32_t *__restrict__ mask) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (s >= n_max || s >= seg_info[0]) return;
+    const int64_t r = active_rows[s];
+    const float4 *g = reinterpret_cast<const float4 *>(dOutR + s * (int64_t)d * M);
+    const int d4 = d / 4;
+    float4 *h_dst = reinterpret_cast<float4 *>((r < U ? SrcA : SrcB) + r * (int64_t)d);
+    float4 *g_dst = reinterpret_cast<float4 *>((r < U ? SrcB : SrcA) + r * (int64_t)d);
+    for (int c = lane; c < d4; c += 64) {
+        const float4 g0 = g[c];
+        float4 acc = g0;
+        for (int m = 1; m < M; ++m) {
+            const float4 x = g[m * d4 + c];
+            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        }
+        h_dst[c] = acc;
+        g_dst[c] = g0;
+    }
+    if (lane == 0) atomicOr(&mask[r >> 5], 1u << (r & 31));
+}
+}  // namespace elimrec
+
+extern "C" int elimrec_propagate_folded_bwd(const elimrec_csr *AT, int64_t U, int64_t I, int d, int M, int L,
+                                            const float *d_dOutR, const int32_t *d_active_rows,
+                                            const int32_t *d_seg_info, int64_t n_max, float *d_SrcA, float *d_SrcB,
+                                            float *d_grad /* [N x d] = [gE_u ; gE_i] */, void *d_workspace,
+                                            size_t workspace_bytes, void *stream) {
+    ELIMREC_REQUIRE(AT && d_dOutR && d_active_rows && d_seg_info && d_SrcA && d_SrcB && d_grad && d_workspace,
+                    "propagate_folded_bwd: null pointer");
+    ELIMREC_REQUIRE(d > 0 && d % 4 == 0 && L >= 1 && M >= 1, "propagate_folded_bwd: bad d/L/M");
+    const int64_t N = U + I;
+    ELIMREC_REQUIRE(AT->n_rows == N, "propagate_folded_bwd: adjacency rows mismatch");
+    if (workspace_bytes < elimrec_folded_workspace(N, d)) { set_error("propagate_folded_bwd: workspace too small"); return ELIMREC_E_WORKSPACE; }
+    hipStream_t s = (hipStream_t)stream;
+    char *ws = (char *)d_workspace;
+    const size_t tb = align_up((size_t)N * d * sizeof(float), 256);
+    float *tbuf[2] = {(float *)ws, (float *)(ws + tb)};
+    uint32_t *mask = (uint32_t *)(ws + 2 * tb);
+    int rc = check_hip(hipMemsetAsync(mask, 0, (size_t)((N + 31) / 32 + 2) * 4, s), "memset(mask)");
+    if (rc) return rc;
+    if (n_max > 0) {
+        hipLaunchKernelGGL(folded_sources_kernel, dim3((unsigned)((n_max + 3) / 4)), dim3(256), 0, s, d_dOutR, d_active_rows,
+                           d_seg_info, n_max, U, d, M, d_SrcA, d_SrcB, mask);
+        ELIMREC_LAUNCH_CHECK("folded_sources");
+    }
+    const float inv = 1.0f / (float)(L + 1);
+    const int d4 = d / 4;
+    const float *t = (L & 1) ? d_SrcB : d_SrcA;       // T^L = S^L (row-sparse)
+    const uint32_t *tmask = mask;
+    for (int k = L - 1; k >= 0; --k) {
+        float *dst = (k == 0) ? d_grad : tbuf[k & 1];
+        HalfArgs a = half_args(d4, t, tmask, nullptr, (k & 1) ? d_SrcB : d_SrcA, mask, nullptr, nullptr, 0, dst,
+                               (k == 0) ? inv : 1.0f);
+        if ((rc = launch_half(AT, a, 0, s))) return rc;
+        t = dst;
+        tmask = nullptr;
+    }
+    return 0;
 }

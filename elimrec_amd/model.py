@@ -266,17 +266,30 @@ class EliMRec(BasicModel):
         ws = self._ws if (self._ws is not None and self._ws_key[0] == key[0]) else {}
         if "X0" not in ws:
             self._flatten_parameters(ws)
-            for name in (("X0", "Out") if self._bipartite else ("X0", "T0", "T1", "Out", "G")):
+            names = ("Out",) if self._folded else (("X0", "Out") if self._bipartite else ("X0", "T0", "T1", "Out", "G"))
+            for name in names:
                 ws[name] = torch.empty(N, C, **f32)
             if self._bipartite:
-                ws["H"] = torch.empty(N, d, **f32)
-                ws["bip_ws"] = torch.empty(ops.bipartite_workspace(self.num_users, self.num_items, d, self.M),
-                                           dtype=torch.uint8, device=dev)
+                if not self._folded:
+                    ws["H"] = torch.empty(N, d, **f32)
+                    ws["bip_ws"] = torch.empty(ops.bipartite_workspace(self.num_users, self.num_items, d, self.M),
+                                               dtype=torch.uint8, device=dev)
                 if self._folded:
-                    ws["Out0"] = torch.empty(N, d, **f32)          # propagated id table
                     ws["Narrow"] = torch.empty(N, d, **f32)        # the part of Out every table shares
-                    ws["G00"] = torch.empty(N, d, **f32)           # dLoss/dOut, column block 0, scattered by node
+                    ws["SrcA"] = torch.empty(N, d, **f32)          # adjoint source tables (active rows only)
+                    ws["SrcB"] = torch.empty(N, d, **f32)
+                    ws["fold_ws"] = torch.empty(ops.folded_workspace(N, d), dtype=torch.uint8, device=dev)
                     self._fold_constants(ws)
+                    # [E_u ; E_i] and its gradient as ONE [N x d] table: the two embeddings are the first two
+                    # tensors of the flat parameter / gradient buffers, back to back
+                    eu, ei = self.embedding_user.weight, self.embedding_item.weight
+                    gv = ws["grad_views"]
+                    adjacent = (ei.data_ptr() == eu.data_ptr() + eu.numel() * 4 and
+                                gv["embedding_item.weight"].data_ptr() == gv["embedding_user.weight"].data_ptr() + eu.numel() * 4)
+                    if not adjacent:
+                        raise RuntimeError("folded propagation expects embedding_user/embedding_item adjacent in the flat buffers")
+                    ws["X0d"] = ws["flat_param"][:N * d].view(N, d)
+                    ws["gX0d"] = ws["flat_grad"][:N * d].view(N, d)
                 else:
                     ws["gXI"] = torch.empty(self.num_items, C, **f32)
             ws["Y"] = torch.zeros(N, Cy, **f32)
@@ -372,13 +385,12 @@ class EliMRec(BasicModel):
     def _compute_tables(self, ws):
         """compute() + gcn_cf() (:228-272,144-153): fills ws['Out'] and ws['Y']."""
         U, I, d, M, C = self.num_users, self.num_items, self.latent_dim, self.M, self.C
-        X0, Out, Y = ws["X0"], ws["Out"], ws["Y"]
+        Out, Y = ws["Out"], ws["Y"]
+        X0 = ws.get("X0")
         if self._folded:
             # id table + shared user part through the graph at d columns; feature blocks from the folded constants
-            self._timed(lambda: ops.propagate_bipartite(self._csr("bipP"), self._csr("bipQ"), U, I, d, 1, self.n_layers,
-                                                        self.embedding_user.weight, self.embedding_item.weight,
-                                                        ws["Out0"], ws["bip_ws"], narrow_out=ws["Narrow"]))
-            ops.copy_cols(ws["Out0"], Out[:, :d])
+            self._timed(lambda: ops.propagate_folded(self._csr("adj"), U, I, d, self.n_layers, ws["X0d"], Out[:, :d],
+                                                     ws["Narrow"], ws["fold_ws"]))
             fold = ws["fold"]
             ops.linear_fwd_batched([(fold[m], getattr(self, m + "_dense").weight, getattr(self, m + "_dense").bias,
                                      Out[:, (k + 1) * d:(k + 2) * d], fold["c"], ws["Narrow"])
@@ -468,15 +480,14 @@ class EliMRec(BasicModel):
         bw = self._last_block_weights
         heads_on = [h for h in range(S) if bw[1 + h] != 0.0]
         wu, wi = self._fusion_weights()
-        G0 = ws["X0"]
+        G0 = ws.get("X0")
         if not self._bipartite:
             G0.zero_()      # the bipartite path masks inactive rows instead of reading zeros
         # heads switched off by the modality ablation carry an all-zero gradient block
         head_ws = [getattr(self, "s_dense_" + m).weight for m in self._mods]
-        if self._folded:    # block 0 scattered by node for the graph adjoint; every block kept in slot order
+        if self._folded:    # dLoss/dOut rows of the active nodes, in slot order
             dOutR = ws["dOutR"][:n_rows]
-            ops.head_bwd_input(dY, act, seg, U, d, C, [h + 1 for h in range(S)], wu, wi, head_ws, 1.0, ws["G00"],
-                               scatter_cols=d, compact=dOutR)
+            ops.head_bwd_input(dY, act, seg, U, d, C, [h + 1 for h in range(S)], wu, wi, head_ws, 1.0, None, compact=dOutR)
         else:
             ops.head_bwd_input(dY, act, seg, U, d, C, [h + 1 for h in range(S)], wu, wi, head_ws, 1.0, G0)
         grads = {}
@@ -502,11 +513,9 @@ class EliMRec(BasicModel):
         # back through the propagation (A^T; A itself when symmetric), then the layer-0 pieces
         gu, gi = gv["embedding_user.weight"], gv["embedding_item.weight"]
         if self._folded:
-            ops.blocksum_rows(dOutR, act, seg, d, M, ws["H"], slot_major=True)
-            sym = self._adj_symmetric
-            PT, QT = self._csr("bipQ" if sym else "bipPT"), self._csr("bipP" if sym else "bipQT")
-            self._timed(lambda: ops.propagate_bipartite_bwd(PT, QT, U, I, d, 1, self.n_layers, ws["G00"], ws["H"], act,
-                                                            seg, gi, gu, ws["bip_ws"]))
+            AT = self._csr("adj" if self._adj_symmetric else "adjT")
+            self._timed(lambda: ops.propagate_folded_bwd(AT, U, I, d, M, self.n_layers, dOutR, act, seg, ws["SrcA"],
+                                                         ws["SrcB"], ws["gX0d"], ws["fold_ws"]))
             grads["embedding_user.weight"], grads["embedding_item.weight"] = gu, gi
             # feature projections: Out_m = S_m W_m^T + c b_m^T + (shared part)  =>  dW_m = dOut_m^T S_m over the
             # active rows only, db_m = dOut_m^T c  (the dense I-row contraction of the unfolded path disappears)

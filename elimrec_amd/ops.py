@@ -244,6 +244,32 @@ def propagate_bipartite_bwd(PT, QT, U, I, d, M, L, G, H, active_rows, seg_info, 
                                                            _stream()), "propagate_bipartite_bwd")
 
 
+def folded_workspace(N, d):
+    return int(_lib.load().elimrec_folded_workspace(N, d))
+
+
+def propagate_folded(A, U, I, d, L, X0, out0, narrow, workspace):
+    """out0: [N x d] window (unit column stride) of a wider table; X0, narrow: contiguous [N x d]."""
+    assert X0.is_contiguous() and narrow.is_contiguous() and X0.shape == (U + I, d) and narrow.shape == (U + I, d)
+    o, ldo = _rowmajor(out0, "out0")
+    assert out0.shape == (U + I, d)
+    _lib.check(_lib.load().elimrec_propagate_folded(A.desc(), U, I, d, L, _dev(X0, "X0"), o, ldo, _dev(narrow, "narrow"),
+                                                    _dev(workspace, "workspace", torch.uint8), workspace.numel(),
+                                                    _stream()), "propagate_folded")
+
+
+def propagate_folded_bwd(AT, U, I, d, M, L, dOutR, active_rows, seg_info, srcA, srcB, grad, workspace):
+    for t in (dOutR, srcA, srcB, grad):
+        assert t.is_contiguous()
+    assert grad.shape == (U + I, d) and dOutR.shape[1] == d * M
+    _lib.check(_lib.load().elimrec_propagate_folded_bwd(AT.desc(), U, I, d, M, L, _dev(dOutR, "dOutR"),
+                                                        _dev(active_rows, "active_rows", torch.int32),
+                                                        _dev(seg_info, "seg_info", torch.int32), active_rows.numel(),
+                                                        _dev(srcA, "srcA"), _dev(srcB, "srcB"), _dev(grad, "grad"),
+                                                        _dev(workspace, "workspace", torch.uint8), workspace.numel(),
+                                                        _stream()), "propagate_folded_bwd")
+
+
 def block_spmm(A, Xin, Xout=None, add1=None, acc_out=None, scale=1.0):
     """r = A . Xin (a column window of a wider table is fine); Xout = r; acc_out = (r + add1) * scale."""
     x, ld = _rowmajor(Xin, "Xin")

@@ -181,6 +181,23 @@ int elimrec_propagate_bipartite_bwd(const elimrec_csr *PT, const elimrec_csr *QT
                                     int64_t n_max, float *d_gXI, float *d_gEu, void *d_workspace,
                                     size_t workspace_bytes, void *stream);
 
+/* Folded propagation (the default path): when the constant feature tables are folded into GEMM operands
+ *  only the d-column table X0 = [E_u ; E_i] goes through the graph, one launch per hop over
+ * the FULL adjacency A [N x N] (no diagonal blocks):
+ *   Out0[row, 0:d] (row stride ldo) = 1/(L+1) sum_k A^k X0
+ *   narrow[N x d] = the part of it that comes from E_u alone (= what every feature table shares)
+ * and its adjoint from the slot-major dOut rows [n x M*d] of the active nodes:
+ *   grad[N x d] = [dLoss/dE_u ; dLoss/dE_i]   (SrcA/SrcB: two [N x d] scratch tables, written on active rows)
+ * AT = A^T (A itself when symmetric). workspace: elimrec_folded_workspace(N, d) bytes for either call. */
+size_t elimrec_folded_workspace(int64_t N, int d);
+int elimrec_propagate_folded(const elimrec_csr *A, int64_t U, int64_t I, int d, int L, const float *d_X0,
+                             float *d_Out0, int64_t ldo, float *d_narrow, void *d_workspace,
+                             size_t workspace_bytes, void *stream);
+int elimrec_propagate_folded_bwd(const elimrec_csr *AT, int64_t U, int64_t I, int d, int M, int L,
+                                 const float *d_dOutR, const int32_t *d_active_rows, const int32_t *d_seg_info,
+                                 int64_t n_max, float *d_SrcA, float *d_SrcB, float *d_grad, void *d_workspace,
+                                 size_t workspace_bytes, void *stream);
+
 /* One block SpMM with the fused epilogue on a W-column window of wider tables (row stride ld):
  *   r = A . Xin[:, 0:W];  if Xout: Xout = r;  if AccOut: AccOut = (r + Add1) * scale.
  * The building block of the bipartite propagation, exposed for callers that tile columns themselves. */
