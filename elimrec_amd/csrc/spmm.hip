@@ -298,6 +298,8 @@ struct HalfArgs {
     int n_long;
     const int32_t *long_seg_ptr;
     float4 *partials;
+    const int32_t *row_order;     // nullable [n_rows]: processing order of the rows (degree-sorted so the rows that
+                                  // share a wave have similar lengths); results do not depend on it
     const int32_t *seg_row;       // [n_seg] index (into long_rows) of the split row a segment belongs to
     int32_t *tickets;             // [n_long] arrival counters, zero between launches (self-resetting)
 };
@@ -408,12 +410,13 @@ __global__ __launch_bounds__(256) void half_hop_kernel(HalfArgs a, int seg_block
     const int sub = lane / LPR, cl = lane % LPR;
     const bool seg_mode = (int)blockIdx.x < seg_blocks;            // workgroup-uniform
     const int64_t blk = seg_mode ? blockIdx.x : (blockIdx.x - seg_blocks);
-    const int64_t item = (blk * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + sub;
+    int64_t item = (blk * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + sub;
     const int64_t n_items = seg_mode ? (int64_t)a.n_seg : a.n_rows;
     bool valid = item < n_items;
     int beg = 0, end = 0;
     if (valid) {
         if (!seg_mode) {
+            if (a.row_order) item = a.row_order[item];
             beg = a.rowptr[item]; end = a.rowptr[item + 1];
             if (end - beg > a.long_threshold) valid = false;
         } else {
@@ -549,6 +552,7 @@ static int launch_half(const elimrec_csr *m, HalfArgs a, size_t partials_offset,
     a.long_seg_ptr = m->split.d_long_seg_ptr;
     a.partials = m->split.d_partials ? (float4 *)(m->split.d_partials + partials_offset) : nullptr;
     a.seg_row = m->split.d_seg_row;
+    a.row_order = m->split.d_row_order;
     // the two chains may touch the same block concurrently: wide launches use tickets[0..n_long), narrow ones the next n_long
     a.tickets = (m->split.d_tickets && elimrec_ticket_fixup())
                     ? m->split.d_tickets + (partials_offset ? m->split.n_long : 0) : nullptr;

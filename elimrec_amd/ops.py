@@ -163,8 +163,15 @@ class Csr:
         rowptr = self.rowptr.cpu().numpy().astype(np.int64)
         deg = np.diff(rowptr)
         long_rows = np.nonzero(deg > threshold)[0]
+        dev = self.rowptr.device
+        # rows in order of decreasing length (split rows count as empty in the main pass): a scheduling hint
+        order = np.argsort(-np.where(deg > threshold, 0, deg), kind="stable").astype(np.int32)
+        self._row_order = torch.from_numpy(order).to(dev) if _os.environ.get("ELIMREC_ROW_ORDER", "1") == "1" else None
+        ro = self._row_order.data_ptr() if self._row_order is not None else None
         if len(long_rows) == 0:
-            self._split, self._split_tensors = None, None
+            self._split_tensors = None
+            self._split = _lib.CsrSplit(0, 0, 0, None, None, None, None, None, ro, None)
+            self._split_C = C
             return self
         nseg = (deg[long_rows] + threshold - 1) // threshold
         seg_ptr = np.concatenate([[0], np.cumsum(nseg)])
@@ -173,7 +180,6 @@ class Csr:
         k = np.arange(total) - seg_ptr[seg_row]
         beg = rowptr[long_rows][seg_row] + k * threshold
         end = np.minimum(beg + threshold, rowptr[long_rows + 1][seg_row])
-        dev = self.rowptr.device
         t = (torch.from_numpy(long_rows.astype(np.int32)).to(dev), torch.from_numpy(seg_ptr.astype(np.int32)).to(dev),
              torch.from_numpy(np.stack([beg, end], 1).astype(np.int32).copy()).to(dev),
              torch.empty(total, 2 * C, dtype=torch.float32, device=dev),   # wide + narrow partial regions
@@ -181,18 +187,18 @@ class Csr:
              torch.zeros(2 * len(long_rows), dtype=torch.int32, device=dev))
         self._split_tensors = t
         self._split = _lib.CsrSplit(int(threshold), len(long_rows), total, t[0].data_ptr(), t[1].data_ptr(),
-                                    t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(), t[5].data_ptr())
+                                    t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(), ro, t[5].data_ptr())
         self._split_C = C
         return self
 
     def desc(self):
         """struct elimrec_csr for the block-CSR entry points (keeps the tensors alive through self)."""
-        sp = self._split if self._split is not None else _lib.CsrSplit(0, 0, 0, None, None, None, None, None, None)
+        sp = self._split if self._split is not None else _lib.CsrSplit(0, 0, 0, None, None, None, None, None, None, None)
         self._desc = _lib.CsrDesc(self.n_rows, self.rowptr.data_ptr(), self.col.data_ptr(), self.val.data_ptr(), sp)
         return ctypes.byref(self._desc)
 
     def split_ref(self, C):
-        if self._split is None:
+        if self._split is None or self._split.n_long == 0:
             return None
         if self._split_C < C:
             raise ValueError("row-split plan was built for C=%d, got C=%d" % (self._split_C, C))

@@ -117,6 +117,9 @@ typedef struct elimrec_csr_split {
     const int32_t *d_seg_bounds;    /* [n_seg][2] (begin,end) positions into col/val            */
     float *d_partials;              /* [n_seg x 2C] scratch (C-column region, then d-column region) */
     const int32_t *d_seg_row;       /* [n_seg] index into d_long_rows of each segment's row (nullable) */
+    const int32_t *d_row_order;     /* [n_rows] (nullable): order in which rows are handed to waves -- sorted
+                                       by length so the 64/LPR rows sharing a wave finish together; a pure
+                                       scheduling hint (used by the narrow-row kernels), results unchanged */
     int32_t *d_tickets;             /* [2*n_long] zero-initialised arrival counters (nullable): when
                                        given, the wave that finishes a split row's LAST segment combines
                                        the row in segment order inside the same launch (agent-scope
