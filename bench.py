@@ -190,6 +190,7 @@ def main():
                        "global_batch": B * world, "parallelism": "dp%d-replicated-tables" % world,
                        "propagation": "folded" if getattr(model, "_folded", False) else
                                       ("bipartite" if getattr(model, "_bipartite", False) else "full"),
+                       "head_rows": "batch" if getattr(model, "_lazy", False) else "all",
                        "final_loss": final_loss},
             "step_algorithmic_GB": step_bytes / 1e9,
             "step_achieved_GBps": step_bytes / (dt / args.steps) / 1e9,

@@ -32,7 +32,7 @@ class LinearDesc(ctypes.Structure):
     _fields_ = [("d_A", ctypes.c_void_p), ("lda", ctypes.c_int64), ("d_W", ctypes.c_void_p), ("ldw", ctypes.c_int64),
                 ("d_bias", ctypes.c_void_p), ("d_C", ctypes.c_void_p), ("ldc", ctypes.c_int64), ("M", ctypes.c_int64),
                 ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("d_rowscale", ctypes.c_void_p), ("d_add", ctypes.c_void_p),
-                ("ldadd", ctypes.c_int64)]
+                ("ldadd", ctypes.c_int64), ("d_row_index", ctypes.c_void_p), ("d_row_count", ctypes.c_void_p)]
 
 
 class LinearBwdDesc(ctypes.Structure):
@@ -75,6 +75,8 @@ SIGNATURES = {
                                              c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "elimrec_block_spmm": (c_i32, [c_csr, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr]),
     "elimrec_blocksum_rows": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr]),
+    "elimrec_triplet_rows": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr]),
+    "elimrec_gather_rows": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr]),
     "elimrec_copy_cols": (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i32, c_ptr]),
     "elimrec_bpr_head": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32,
                                  ctypes.POINTER(c_f32), c_ptr, c_ptr, c_ptr, c_ptr]),

@@ -360,7 +360,61 @@ static int seg_layout(int64_t n, SegLayout &L) {
     return 0;
 }
 
+
+// One 16-lane group per (triplet slot): node id out, and optionally the leading `cols` columns of that row.
+__global__ __launch_bounds__(256) void triplet_rows_kernel(const int64_t *__restrict__ users, const int64_t *__restrict__ pos,
+                                                           const int64_t *__restrict__ neg, int64_t B, int64_t U,
+                                                           int32_t *__restrict__ rows, const float *__restrict__ src,
+                                                           int64_t lds, int c4, float *__restrict__ dst, int64_t ldd) {
+    const int64_t slot = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int sub = threadIdx.x & 15;
+    if (slot >= 3 * B) return;
+    const int64_t b = slot / 3;
+    const int j = (int)(slot - 3 * b);
+    const int64_t node = j == 0 ? users[b] : U + (j == 1 ? pos[b] : neg[b]);
+    if (sub == 0) rows[slot] = (int32_t)node;
+    if (src)
+        for (int c = sub; c < c4; c += 16)
+            *reinterpret_cast<float4 *>(dst + slot * ldd + 4 * c) = *reinterpret_cast<const float4 *>(src + node * lds + 4 * c);
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restrict__ src, int64_t lds,
+                                                          const int32_t *__restrict__ rows, const int32_t *__restrict__ count,
+                                                          int64_t n, int c4, float *__restrict__ dst, int64_t ldd) {
+    const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int sub = threadIdx.x & 15;
+    const int64_t lim = count ? min((int64_t)*count, n) : n;
+    if (r >= lim) return;
+    const int64_t node = rows[r];
+    for (int c = sub; c < c4; c += 16)
+        *reinterpret_cast<float4 *>(dst + r * ldd + 4 * c) = *reinterpret_cast<const float4 *>(src + node * lds + 4 * c);
+}
 }  // namespace elimrec
+
+extern "C" int elimrec_triplet_rows(const int64_t *d_users, const int64_t *d_pos, const int64_t *d_neg, int64_t B, int64_t U,
+                                    int32_t *d_rows, const float *d_src, int64_t lds, int cols, float *d_dst, int64_t ldd,
+                                    void *stream) {
+    ELIMREC_REQUIRE(d_users && d_pos && d_neg && d_rows, "triplet_rows: null pointer");
+    ELIMREC_REQUIRE(!d_src || (d_dst && cols > 0 && cols % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0),
+                    "triplet_rows: cols, lds, ldd must be multiples of 4");
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(elimrec::triplet_rows_kernel, dim3((unsigned)((3 * B + 15) / 16)), dim3(256), 0, (hipStream_t)stream, d_users,
+                       d_pos, d_neg, B, U, d_rows, d_src, lds, cols / 4, d_dst, ldd);
+    ELIMREC_LAUNCH_CHECK("triplet_rows");
+    return 0;
+}
+
+extern "C" int elimrec_gather_rows(const float *d_src, int64_t lds, const int32_t *d_rows, const int32_t *d_count, int64_t n,
+                                   int cols, float *d_dst, int64_t ldd, void *stream) {
+    ELIMREC_REQUIRE(d_src && d_rows && d_dst, "gather_rows: null pointer");
+    ELIMREC_REQUIRE(cols > 0 && cols % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0, "gather_rows: cols, lds, ldd must be multiples of 4");
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(elimrec::gather_rows_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, d_src, lds,
+                       d_rows, d_count, n, cols / 4, d_dst, ldd);
+    ELIMREC_LAUNCH_CHECK("gather_rows");
+    return 0;
+}
+
 
 using namespace elimrec;
 

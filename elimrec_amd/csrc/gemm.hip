@@ -38,7 +38,9 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(FwdBatch batch) {
     float *__restrict__ C = pd.d_C;
     const float *__restrict__ rowscale = pd.d_rowscale;
     const float *__restrict__ addm = pd.d_add;
-    const int64_t lda = pd.lda, ldw = pd.ldw, ldc = pd.ldc, ldadd = pd.ldadd, M = pd.M;
+    const int32_t *__restrict__ row_index = pd.d_row_index;   // A / rowscale / add row of output row m
+    const int64_t lda = pd.lda, ldw = pd.ldw, ldc = pd.ldc, ldadd = pd.ldadd;
+    const int64_t M = pd.d_row_count ? (int64_t)min((int64_t)*pd.d_row_count, pd.M) : pd.M;
     const int N = pd.N, K = pd.K;
     const int n0 = blockIdx.y * FBN;
     const int64_t n_tiles = (M + BM - 1) / BM;
@@ -73,7 +75,8 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(FwdBatch batch) {
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const int64_t gr = m0 + lr + RPP * i;
-            ra[i] = (kin && gr < M) ? *reinterpret_cast<const float4 *>(A + gr * lda + k0 + lc)
+            const int64_t sr = (row_index && gr < M) ? (int64_t)row_index[gr] : gr;
+            ra[i] = (kin && gr < M) ? *reinterpret_cast<const float4 *>(A + sr * lda + k0 + lc)
                                     : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
@@ -126,10 +129,11 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(FwdBatch batch) {
             for (int r = 0; r < 16; ++r) {
                 const int64_t row = m0 + wrow + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row < M) {
-                    const float rs = rowscale ? rowscale[row] : 1.f;         // bias enters as rowscale[row] * bias[n]
-                    if (col0 < N) C[row * ldc + col0] = acc0[r] + rs * bias0 + (addm ? addm[row * ldadd + col0] : 0.f);
+                    const int64_t sr = row_index ? (int64_t)row_index[row] : row;
+                    const float rs = rowscale ? rowscale[sr] : 1.f;          // bias enters as rowscale[row] * bias[n]
+                    if (col0 < N) C[row * ldc + col0] = acc0[r] + rs * bias0 + (addm ? addm[sr * ldadd + col0] : 0.f);
                     if (BM == 128 && col1 < N)
-                        C[row * ldc + col1] = acc1[r] + rs * bias1 + (addm ? addm[row * ldadd + col1] : 0.f);
+                        C[row * ldc + col1] = acc1[r] + rs * bias1 + (addm ? addm[sr * ldadd + col1] : 0.f);
                 }
             }
             acc0 = (v16f){0};
@@ -351,7 +355,7 @@ extern "C" int elimrec_linear_fwd_batched(const elimrec_linear_desc *descs, int 
 extern "C" int elimrec_linear_fwd(const float *d_A, int64_t lda, const float *d_W, int64_t ldw,
                                   const float *d_bias, float *d_C, int64_t ldc, int64_t M, int N, int K,
                                   void *stream) {
-    elimrec_linear_desc d = {d_A, lda, d_W, ldw, d_bias, d_C, ldc, M, N, K, nullptr, nullptr, 0};
+    elimrec_linear_desc d = {d_A, lda, d_W, ldw, d_bias, d_C, ldc, M, N, K, nullptr, nullptr, 0, nullptr, nullptr};
     return elimrec_linear_fwd_batched(&d, 1, stream);
 }
 

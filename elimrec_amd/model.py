@@ -130,8 +130,8 @@ class EliMRec(BasicModel):
         self.Cy = (1 + self.S) * self.latent_dim
 
         self._create_u_embeding_i()
-        self.all_items = self.all_users = None
-        self.all_s_embs = None
+        self._cache = None                     # (all_users, all_items, all_s_embs) views into Y
+        self._tables_dirty = False
 
         tu, ti = self.dataset.get_train_interactions()
         adj = create_adj_mat(tu, ti, self.num_users, self.num_items, cfg["adj_type"])
@@ -153,6 +153,11 @@ class EliMRec(BasicModel):
         # propagated ONCE at start-up; per step only the id table and the shared user part go through the
         # graph (d columns instead of M*d) and the feature blocks of Out come from one GEMM each.
         self._folded = self._bipartite and mode in ("auto", "folded")
+        # "batch" head rows (CLI-only: --head_rows=batch|all): the projections AFTER the graph (feature blocks of
+        # Out, embedding_*_after_GCN, s_dense_*) are row-wise, and the loss reads them at the batch's 3B rows only,
+        # so a training step evaluates them there; the full cached tables predict() reads (:98-99) are filled in on
+        # first use from the graph tables of that same forward and a copy of the (pre-update) projection weights.
+        self._lazy = self._folded and str(opt("head_rows", "batch")) != "all"
         if self._bipartite:
             P, Q = adj[:U, U:].tocsr(), adj[U:, :U].tocsr()
             self._register_csr("bipP", P)
@@ -172,6 +177,17 @@ class EliMRec(BasicModel):
         self._param_names = [n for n, _ in self.named_parameters()]
         self._ws = None
         self._ws_key = None
+
+    # cached tables of the last forward (models/EliMRec.py:121-122); materialised on first use in "batch" mode
+    def _cached(self, k):
+        if self._cache is None:
+            return None
+        self._ensure_tables()
+        return self._cache[k]
+
+    all_users = property(lambda self: self._cached(0))
+    all_items = property(lambda self: self._cached(1))
+    all_s_embs = property(lambda self: self._cached(2))
 
     def _register_csr(self, name, m):
         m = m.tocsr()
@@ -300,6 +316,14 @@ class EliMRec(BasicModel):
         ws["loss_rows"] = torch.empty(B, **f32)
         ws["grad_rows"] = torch.empty(3 * B, Cy, **f32)
         ws["keys"] = torch.empty(3 * B, dtype=torch.int32, device=dev)
+        if self._lazy:
+            ws["rows"] = ws["keys"]                                # node id of every triplet slot = the gradient keys
+            ws["slot_keys"] = torch.empty(3 * B, dtype=torch.int32, device=dev)
+            ws["OutC"] = torch.empty(3 * B, C, **f32)
+            ws["YC"] = torch.empty(3 * B, Cy, **f32)
+            ws["OutAct"] = torch.empty(n3, C, **f32)               # Out rows of the active nodes (backward)
+            slots = torch.arange(B, dtype=torch.int64, device=dev) * 3
+            ws["slot_u"], ws["slot_p"], ws["slot_n"] = slots, slots + 1, slots + 2
         ws["active_rows"] = torch.empty(n3, dtype=torch.int32, device=dev)
         ws["dY"] = torch.empty(n3, Cy, **f32)
         ws["seg_info"] = torch.zeros(8, dtype=torch.int32, device=dev)
@@ -360,12 +384,27 @@ class EliMRec(BasicModel):
                 views[name] = flat_grad[off:off + p.numel()].view_as(p)
                 off += n
         ws["flat_param"], ws["flat_grad"], ws["grad_views"] = flat, flat_grad, views
+        # every non-embedding parameter, live and as the copy a training forward takes (predict() after an
+        # optimizer step must still see the weights its cached tables were computed with)
+        tail = sizes[0] + sizes[1]
+        ws["tail_off"] = tail
+        ws["snap"] = torch.zeros(flat.numel() - tail, dtype=torch.float32, device=dev)
+        live, snap, off = {}, {}, 0
+        for (name, p), n in zip(params, sizes):
+            if off >= tail:
+                live[name] = p.data
+                snap[name] = ws["snap"][off - tail:off - tail + p.numel()].view_as(p)
+            off += n
+        ws["live_views"], ws["snap_views"] = live, snap
 
-    def _fusion_weights(self):
+    def _fusion_weights(self, W=None):
         """[d x C] fusion weights as the kernels consume them. 'mean' fusion (mean over the M
         tables, then a [d x d] Linear; :224-225) is the same map as a [d x C] Linear whose M
         column blocks are all W/M."""
-        wu, wi = self.embedding_user_after_GCN.weight, self.embedding_item_after_GCN.weight
+        if W is None:
+            wu, wi = self.embedding_user_after_GCN.weight, self.embedding_item_after_GCN.weight
+        else:
+            wu, wi = W["embedding_user_after_GCN.weight"], W["embedding_item_after_GCN.weight"]
         if self.mm_fusion_mode == "concat":
             return wu, wi
         return (wu.detach() / self.M).repeat(1, self.M).contiguous(), (wi.detach() / self.M).repeat(1, self.M).contiguous()
@@ -381,9 +420,30 @@ class EliMRec(BasicModel):
         return w
 
     # ------------------------------------------------------------------ forward / backward (HIP)
+    def _fold_problems(self, ws, W, out, rows=None, count=None):
+        """Out_m = S_m W_m^T + c b_m^T + Narrow for every feature table m -- over all rows into `out`, or gathered
+        at `rows` (int32 node ids; first `count` of them) into the compact `out`."""
+        d, fold = self.latent_dim, ws["fold"]
+        extra = () if rows is None else (rows, count)
+        return [(fold[m], W[m + "_dense.weight"], W[m + "_dense.bias"], out[:, (k + 1) * d:(k + 2) * d], fold["c"],
+                 ws["Narrow"]) + extra for k, m in enumerate(self._mods)]
+
     @torch.no_grad()
-    def _compute_tables(self, ws):
-        """compute() + gcn_cf() (:228-272,144-153): fills ws['Out'] and ws['Y']."""
+    def _full_tables(self, ws, W):
+        """Folded mode: everything after the graph, over all N rows, with the projection weights W."""
+        ops.linear_fwd_batched(self._fold_problems(ws, W, ws["Out"]))
+        self._head_forward(ws, W)
+
+    @torch.no_grad()
+    def _ensure_tables(self):
+        if self._tables_dirty:
+            self._tables_dirty = False
+            self._full_tables(self._ws, self._ws["snap_views"])
+
+    @torch.no_grad()
+    def _compute_tables(self, ws, batch=None):
+        """compute() + gcn_cf() (:228-272,144-153): fills ws['Out'] and ws['Y']. With batch = (users, pos, neg) in
+        "batch" mode only those rows are evaluated (ws['OutC'], ws['YC']); the full tables follow on demand."""
         U, I, d, M, C = self.num_users, self.num_items, self.latent_dim, self.M, self.C
         Out, Y = ws["Out"], ws["Y"]
         X0 = ws.get("X0")
@@ -391,11 +451,25 @@ class EliMRec(BasicModel):
             # id table + shared user part through the graph at d columns; feature blocks from the folded constants
             self._timed(lambda: ops.propagate_folded(self._csr("adj"), U, I, d, self.n_layers, ws["X0d"], Out[:, :d],
                                                      ws["Narrow"], ws["fold_ws"]))
-            fold = ws["fold"]
-            ops.linear_fwd_batched([(fold[m], getattr(self, m + "_dense").weight, getattr(self, m + "_dense").bias,
-                                     Out[:, (k + 1) * d:(k + 2) * d], fold["c"], ws["Narrow"])
-                                    for k, m in enumerate(self._mods)])
-            self._head_forward(ws)
+            W = ws["live_views"]
+            if batch is None or not self._lazy:
+                self._tables_dirty = False
+                self._full_tables(ws, W)
+                return
+            users, pos, neg = batch
+            R = 3 * users.numel()
+            rows, OutC, YC = ws["rows"][:R], ws["OutC"][:R], ws["YC"][:R]
+            ws["snap"].copy_(ws["flat_param"][ws["tail_off"]:])
+            ops.triplet_rows(users, pos, neg, U, rows, src=Out[:, :d], dst=OutC[:, :d])
+            ops.linear_fwd_batched(self._fold_problems(ws, W, OutC, rows))
+            wu, wi = self._fusion_weights(W)
+            bu, bi = W["embedding_user_after_GCN.bias"], W["embedding_item_after_GCN.bias"]
+            head = [(OutC[0::3], wu, bu, YC[0::3, :d]), (OutC[1::3], wi, bi, YC[1::3, :d]), (OutC[2::3], wi, bi, YC[2::3, :d])]
+            for h, m in enumerate(self._mods):
+                blk = slice((h + 1) * d, (h + 2) * d)
+                head.append((OutC[:, blk], W["s_dense_%s.weight" % m], W["s_dense_%s.bias" % m], YC[:, blk]))
+            ops.linear_fwd_batched(head)
+            self._publish_cache(Y, dirty=True)
             return
         if self._bipartite:
             ops.copy_cols(self.embedding_item.weight, X0[U:, :d])          # XI block 0 = item id table
@@ -411,17 +485,18 @@ class EliMRec(BasicModel):
             self._propagate(self._csr("adj"), X0, ws["T0"], ws["T1"], Out)
         self._head_forward(ws)
 
-    def _head_forward(self, ws):
+    def _head_forward(self, ws, W=None):
         U, d = self.num_users, self.latent_dim
         Out, Y = ws["Out"], ws["Y"]
-        wu, wi = self._fusion_weights()
-        head = [(Out[:U], wu, self.embedding_user_after_GCN.bias, Y[:U, :d]),
-                (Out[U:], wi, self.embedding_item_after_GCN.bias, Y[U:, :d])]
+        W = ws["live_views"] if W is None else W
+        wu, wi = self._fusion_weights(W)
+        head = [(Out[:U], wu, W["embedding_user_after_GCN.bias"], Y[:U, :d]),
+                (Out[U:], wi, W["embedding_item_after_GCN.bias"], Y[U:, :d])]
         for h, m in enumerate(self._mods):
-            lin = getattr(self, "s_dense_" + m)
-            head.append((Out[:, (h + 1) * d:(h + 2) * d], lin.weight, lin.bias, Y[:, (h + 1) * d:(h + 2) * d]))
+            blk = slice((h + 1) * d, (h + 2) * d)
+            head.append((Out[:, blk], W["s_dense_%s.weight" % m], W["s_dense_%s.bias" % m], Y[:, blk]))
         ops.linear_fwd_batched(head)
-        self._publish_cache(Y)
+        self._publish_cache(Y, dirty=self._tables_dirty)
 
     def _propagate(self, csr, X0, t0, t1, out):
         self._timed(lambda: ops.propagate(csr, X0, self.n_layers, t0, t1, out))
@@ -438,26 +513,32 @@ class EliMRec(BasicModel):
         e1.record()
         prof.append((e0, e1, self.n_layers))
 
-    def _publish_cache(self, Y):
+    def _publish_cache(self, Y, dirty=False):
         U, d = self.num_users, self.latent_dim
         self._table_version = getattr(self, "_table_version", 0) + 1
-        self.all_users, self.all_items = Y[:U, :d], Y[U:, :d]
-        self.all_s_embs = {}
+        s_embs = {}
         for h, m in enumerate(self._mods):
             blk = Y[:, (h + 1) * d:(h + 2) * d]
-            self.all_s_embs["pre_fusion_user_" + m] = blk[:U]
-            self.all_s_embs["pre_fusion_item_" + m] = blk[U:]
+            s_embs["pre_fusion_user_" + m] = blk[:U]
+            s_embs["pre_fusion_item_" + m] = blk[U:]
+        self._cache = (Y[:U, :d], Y[U:, :d], s_embs)
+        self._tables_dirty = dirty
 
     @torch.no_grad()
     def _forward_hip(self, users, pos, neg, need_grad):
         B = int(users.numel())
         ws = self._workspace(B)
         users, pos, neg = (t.to(device=self._device(), dtype=torch.int64).contiguous() for t in (users, pos, neg))
-        self._compute_tables(ws)
+        self._compute_tables(ws, batch=(users, pos, neg))
         self._last_block_weights = self._block_weights()
-        ops.bpr_head(ws["Y"], self.num_users, self.num_items, users, pos, neg, self.latent_dim,
-                     self._last_block_weights, ws["loss_rows"], ws["grad_rows"] if need_grad else None,
-                     ws["keys"] if need_grad else None)
+        if self._lazy:      # the compact tables hold the triplet slots in order: row 3b = user, 3b+1 = pos, 3b+2 = neg
+            ops.bpr_head(ws["YC"], 0, 3 * B, ws["slot_u"], ws["slot_p"], ws["slot_n"], self.latent_dim,
+                         self._last_block_weights, ws["loss_rows"], ws["grad_rows"] if need_grad else None,
+                         ws["slot_keys"] if need_grad else None)
+        else:
+            ops.bpr_head(ws["Y"], self.num_users, self.num_items, users, pos, neg, self.latent_dim,
+                         self._last_block_weights, ws["loss_rows"], ws["grad_rows"] if need_grad else None,
+                         ws["keys"] if need_grad else None)
         loss = torch.empty((), dtype=torch.float32, device=self._device())
         ops.fixed_order_sum(ws["loss_rows"], loss)
         return loss
@@ -492,6 +573,11 @@ class EliMRec(BasicModel):
             ops.head_bwd_input(dY, act, seg, U, d, C, [h + 1 for h in range(S)], wu, wi, head_ws, 1.0, G0)
         grads = {}
         f32 = dict(dtype=torch.float32, device=dev)
+        out_rows, out_index = ws["Out"], act
+        if self._lazy:      # Out at the active nodes (the gathered rows of every rank in a data-parallel step)
+            out_rows, out_index = ws["OutAct"][:n_rows], None
+            ops.gather_rows(ws["Out"][:, :d], act, out_rows[:, :d], count=seg[0:1])
+            ops.linear_fwd_batched(self._fold_problems(ws, ws["live_views"], out_rows, act, seg[0:1]))
         # fusion Linears: dW = dY_f^T . Out[active rows], user slots / item slots separately
         gv = ws["grad_views"]
         concat = self.mm_fusion_mode == "concat"
@@ -499,12 +585,12 @@ class EliMRec(BasicModel):
         for name, rng in (("embedding_user_after_GCN", seg[2:4]), ("embedding_item_after_GCN", seg[4:6])):
             gw = gv[name + ".weight"] if concat else torch.empty(d, C, **f32)
             fused_tmp[name] = gw
-            problems.append(dict(A=dY[:, :d], B=ws["Out"], out=gw, row_index=act, rng=rng, colsum=gv[name + ".bias"]))
+            problems.append(dict(A=dY[:, :d], B=out_rows, out=gw, row_index=out_index, rng=rng, colsum=gv[name + ".bias"]))
             grads[name + ".weight"], grads[name + ".bias"] = gv[name + ".weight"], gv[name + ".bias"]
         for h in heads_on:
             name = "s_dense_" + self._mods[h]
-            problems.append(dict(A=dY[:, (h + 1) * d:(h + 2) * d], B=ws["Out"][:, (h + 1) * d:(h + 2) * d],
-                                 out=gv[name + ".weight"], row_index=act, rng=seg[6:8], colsum=gv[name + ".bias"]))
+            problems.append(dict(A=dY[:, (h + 1) * d:(h + 2) * d], B=out_rows[:, (h + 1) * d:(h + 2) * d],
+                                 out=gv[name + ".weight"], row_index=out_index, rng=seg[6:8], colsum=gv[name + ".bias"]))
             grads[name + ".weight"], grads[name + ".bias"] = gv[name + ".weight"], gv[name + ".bias"]
         ops.linear_bwd_w_batched(problems, ws["bwd_w_rows"])
         if not concat:      # 'mean' fusion: fold the M replicated column blocks back into the [d x d] weight
@@ -608,8 +694,9 @@ class EliMRec(BasicModel):
         """Device-side predict (+ optional train-item masking and top-K). Uses the tables cached
         by the LAST training forward, like the reference (:98-99)."""
         dev = self._require_gpu()
-        if self._ws is None or self.all_users is None:
+        if self._ws is None or self._cache is None:
             raise RuntimeError("predict() needs the tables cached by a training forward (call bpr_loss or compute first)")
+        self._ensure_tables()
         users = torch.as_tensor(user_ids, device=dev).long().contiguous()
         B, I = users.numel(), self.num_items
         need = ops.score_workspace(B, self.num_users, I, self.S, max(top_k, 1))

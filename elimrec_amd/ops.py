@@ -47,27 +47,33 @@ def linear_fwd(A, W, bias, out):
 
 
 def linear_fwd_batched(problems):
-    """problems: list of (A, W, bias, out[, rowscale, add]) -- independent Linears sharing one launch (<= 8).
-    out = A.W^T + rowscale[:, None] * bias + add   (rowscale, add optional)."""
+    """problems: list of (A, W, bias, out[, rowscale, add[, row_index, row_count]]) -- independent Linears sharing
+    one launch (<= 8).  out = A.W^T + rowscale[:, None] * bias + add   (rowscale, add optional).
+    row_index (int32 [M]): output row m reads row row_index[m] of A / rowscale / add; row_count (device int32
+    scalar): only the first min(row_count, M) output rows are produced."""
     n = len(problems)
     arr = (_lib.LinearDesc * n)()
     for i, pr in enumerate(problems):
         A, W, bias, out = pr[:4]
         rowscale = pr[4] if len(pr) > 4 else None
         add = pr[5] if len(pr) > 5 else None
+        row_index = pr[6] if len(pr) > 6 else None
+        row_count = pr[7] if len(pr) > 7 else None
         a, lda = _rowmajor(A, "A")
         w, ldw = _rowmajor(W, "W")
         c, ldc = _rowmajor(out, "out")
-        M, K = A.shape
+        K = A.shape[1]
+        M = A.shape[0] if row_index is None else row_index.numel()
         N = W.shape[0]
         assert W.shape[1] == K and out.shape[0] == M and out.shape[1] == N
         ad, ldadd = (None, 0)
         if add is not None:
-            assert add.shape == (M, N)
+            assert add.shape == (A.shape[0], N)
             ad, ldadd = _rowmajor(add, "add")
         if rowscale is not None:
-            assert rowscale.is_contiguous() and rowscale.numel() == M
-        arr[i] = _lib.LinearDesc(a, lda, w, ldw, _dev(bias, "bias"), c, ldc, M, N, K, _dev(rowscale, "rowscale"), ad, ldadd)
+            assert rowscale.is_contiguous() and rowscale.numel() == A.shape[0]
+        arr[i] = _lib.LinearDesc(a, lda, w, ldw, _dev(bias, "bias"), c, ldc, M, N, K, _dev(rowscale, "rowscale"), ad, ldadd,
+                                 _dev(row_index, "row_index", torch.int32), _dev(row_count, "row_count", torch.int32))
     _lib.check(_lib.load().elimrec_linear_fwd_batched(arr, n, _stream()), "linear_fwd_batched")
 
 
@@ -299,6 +305,31 @@ def copy_cols(src, dst):
     t, ldt = _rowmajor(dst, "dst")
     assert src.shape == dst.shape
     _lib.check(_lib.load().elimrec_copy_cols(s, lds, t, ldt, src.shape[0], src.shape[1], _stream()), "copy_cols")
+    return dst
+
+
+def triplet_rows(users, pos, neg, U, rows, src=None, dst=None):
+    """rows[3b + (0,1,2)] = users[b], U + pos[b], U + neg[b]; dst[slot] = src[rows[slot]] when src is given."""
+    B = users.numel()
+    s, lds, t, ldt, cols = None, 0, None, 0, 0
+    if src is not None:
+        s, lds = _rowmajor(src, "src")
+        t, ldt = _rowmajor(dst, "dst")
+        cols = src.shape[1]
+        assert dst.shape == (3 * B, cols)
+    _lib.check(_lib.load().elimrec_triplet_rows(_dev(users, "users", torch.int64), _dev(pos, "pos", torch.int64),
+                                                _dev(neg, "neg", torch.int64), B, U, _dev(rows, "rows", torch.int32),
+                                                s, lds, cols, t, ldt, _stream()), "triplet_rows")
+    return rows
+
+
+def gather_rows(src, rows, dst, count=None):
+    """dst[r] = src[rows[r]] for r < min(count, len(rows))."""
+    s, lds = _rowmajor(src, "src")
+    t, ldt = _rowmajor(dst, "dst")
+    assert dst.shape == (rows.numel(), src.shape[1])
+    _lib.check(_lib.load().elimrec_gather_rows(s, lds, _dev(rows, "rows", torch.int32), _dev(count, "count", torch.int32),
+                                               rows.numel(), src.shape[1], t, ldt, _stream()), "gather_rows")
     return dst
 
 

@@ -58,8 +58,21 @@ typedef struct elimrec_linear_desc {
     int64_t M; int32_t N; int32_t K;
     const float *d_rowscale;        /* nullable [M]: the bias term becomes rowscale[m] * bias[n]      */
     const float *d_add; int64_t ldadd;  /* nullable [M x N]: added to the result (C = A.W^T + .. + add) */
+    const int32_t *d_row_index;     /* nullable [M]: output row m reads row d_row_index[m] of A, rowscale, add
+                                       (the projections evaluated at the batch's rows only; C stays compact) */
+    const int32_t *d_row_count;     /* nullable device scalar: only the first min(*d_row_count, M) rows exist  */
 } elimrec_linear_desc;
 int elimrec_linear_fwd_batched(const elimrec_linear_desc *descs /* host array */, int n, void *stream);
+
+/* The rows of the node tables one batch touches: rows[3b] = users[b], rows[3b+1] = U + pos[b], rows[3b+2] = U + neg[b]
+ * (the gathers all_users[users], all_items[pos], all_items[neg] of models/EliMRec.py:274-289, as node ids). When d_src
+ * is not NULL the `cols` leading columns of those rows are copied to d_dst in the same order. */
+int elimrec_triplet_rows(const int64_t *d_users, const int64_t *d_pos, const int64_t *d_neg, int64_t B, int64_t U,
+                         int32_t *d_rows, const float *d_src, int64_t lds, int cols, float *d_dst, int64_t ldd,
+                         void *stream);
+/* dst[r, 0:cols] = src[rows[r], 0:cols] for r < min(*d_count, n)  (d_count nullable; cols % 4 == 0). */
+int elimrec_gather_rows(const float *d_src, int64_t lds, const int32_t *d_rows, const int32_t *d_count, int64_t n,
+                        int cols, float *d_dst, int64_t ldd, void *stream);
 
 /* out[i, j] (+)= sum_{r in rows} A[r, i] * B[row_index ? row_index[r] : r, j]
  * the weight-gradient contraction of a Linear layer (AddmmBackward of the calls above) with a

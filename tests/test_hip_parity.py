@@ -107,6 +107,46 @@ def test_predict_after_training_uses_stale_tables(fixture_name):
     assert np.abs(got - g["predict/rubi/TIE"]).max() < 1e-5
 
 
+def test_batch_row_head_equals_full_tables(fixture_name):
+    """--head_rows=batch (default: projections after the graph only at the batch's rows, full cached tables filled
+    in on first use from the pre-update weights) against --head_rows=all (every row, every step): same losses,
+    bit-identical parameters after training, identical stale-table predictions."""
+    from helpers import FixtureDataset, fixture_argv, make_config
+    from elimrec_amd import EliMRec, FusedAdam
+    g = load_golden(fixture_name)
+    out = {}
+    for mode in ("batch", "all"):
+        model = EliMRec(make_config(fixture_argv(g) + ["--head_rows=%s" % mode]), FixtureDataset(g))
+        with torch.no_grad():
+            for m in ("v", "a", "t"):
+                if (m + "_feat") in g and hasattr(model, m + "_feat"):
+                    getattr(model, m + "_feat").copy_(torch.from_numpy(g[m + "_feat"]))
+        model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sub(g, "init").items()})
+        model = model.to(DEV)
+        if not model._folded:
+            pytest.skip("fixture's adjacency is not bipartite: the graph tables are not folded")
+        assert model._lazy == (mode == "batch")
+        opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+        losses = []
+        for t in range(1, int(g["steps"]) + 1):
+            loss = model.bpr_loss(*(_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg")))
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        if mode == "batch":
+            assert model._tables_dirty            # nothing read the full tables during training
+        model.fusion_mode, model.predict_type = "rubi", "TIE"
+        pred = model.predict(g["eval_users"].tolist())
+        out[mode] = (losses, {k: v.cpu().clone() for k, v in model.state_dict().items()}, pred,
+                     model.all_users.cpu().clone(), model.all_s_embs["pre_fusion_item_v"].cpu().clone())
+    assert out["batch"][0] == out["all"][0]
+    for k, v in out["all"][1].items():
+        assert torch.equal(out["batch"][1][k], v), k
+    assert torch.equal(out["batch"][2], out["all"][2])
+    assert torch.equal(out["batch"][3], out["all"][3]) and torch.equal(out["batch"][4], out["all"][4])
+
+
 def _tie_free(scores, k):
     """rows whose k+1 largest values are pairwise distinct (no tie at or across the K boundary)."""
     s = -np.sort(-scores, axis=1)[:, :k + 1]
