@@ -32,7 +32,7 @@ class LinearDesc(ctypes.Structure):
     _fields_ = [("d_A", ctypes.c_void_p), ("lda", ctypes.c_int64), ("d_W", ctypes.c_void_p), ("ldw", ctypes.c_int64),
                 ("d_bias", ctypes.c_void_p), ("d_C", ctypes.c_void_p), ("ldc", ctypes.c_int64), ("M", ctypes.c_int64),
                 ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("d_rowscale", ctypes.c_void_p), ("d_add", ctypes.c_void_p),
-                ("ldadd", ctypes.c_int64), ("d_row_index", ctypes.c_void_p), ("d_row_count", ctypes.c_void_p)]
+                ("ldadd", ctypes.c_int64), ("d_row_index", ctypes.c_void_p), ("d_row_range", ctypes.c_void_p)]
 
 
 class LinearBwdDesc(ctypes.Structure):
@@ -40,7 +40,7 @@ class LinearBwdDesc(ctypes.Structure):
     _fields_ = [("d_A", ctypes.c_void_p), ("lda", ctypes.c_int64), ("d_B", ctypes.c_void_p), ("ldb", ctypes.c_int64),
                 ("d_row_index", ctypes.c_void_p), ("d_range", ctypes.c_void_p), ("R", ctypes.c_int64),
                 ("n1", ctypes.c_int32), ("n2", ctypes.c_int32), ("d_out", ctypes.c_void_p), ("ldo", ctypes.c_int64),
-                ("d_colsum", ctypes.c_void_p), ("accumulate", ctypes.c_int32)]
+                ("d_colsum", ctypes.c_void_p), ("accumulate", ctypes.c_int32), ("d_colsum_weight", ctypes.c_void_p)]
 
 
 c_split = ctypes.POINTER(CsrSplit)
@@ -80,8 +80,12 @@ SIGNATURES = {
     "elimrec_copy_cols": (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i32, c_ptr]),
     "elimrec_bpr_head": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32,
                                  ctypes.POINTER(c_f32), c_ptr, c_ptr, c_ptr, c_ptr]),
+    "elimrec_bpr_head_rows": (c_i32, [c_ptr, c_i64, c_ptr, c_i32, c_i32, c_i32, ctypes.POINTER(c_f32), c_ptr, c_ptr, c_ptr]),
     "elimrec_sum": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr]),
     "elimrec_segment_reduce_workspace": (c_size, [c_i64]),
+    "elimrec_segment_plan_workspace": (c_size, [c_i64]),
+    "elimrec_segment_plan": (c_i32, [c_ptr, c_i64, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "elimrec_segment_apply": (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "elimrec_segment_reduce_rows": (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "elimrec_head_bwd_input": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i32, c_i32, c_i32,
                                        ctypes.POINTER(c_i32), c_ptr, c_ptr, ctypes.POINTER(c_ptr), c_f32, c_ptr, c_i64,

@@ -20,11 +20,15 @@ __global__ __launch_bounds__(256) void bpr_head_kernel(const float *__restrict__
                                                        const int64_t *__restrict__ pos,
                                                        const int64_t *__restrict__ neg, int B, int d, int n_blocks,
                                                        BlockWeights bw, float inv_b, float *__restrict__ loss_rows,
-                                                       float *__restrict__ grad_rows, int32_t *__restrict__ keys) {
+                                                       float *__restrict__ grad_rows, int32_t *__restrict__ keys,
+                                                       const int32_t *__restrict__ slot_rows) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= B) return;
-    const int64_t ru = users[b], rp = U + pos[b], rn = U + neg[b];
+    // rows of Y: node ids, or (compact table) the row of each of the triplet's three slots
+    const int64_t ru = slot_rows ? (int64_t)slot_rows[3 * b] : users[b];
+    const int64_t rp = slot_rows ? (int64_t)slot_rows[3 * b + 1] : U + pos[b];
+    const int64_t rn = slot_rows ? (int64_t)slot_rows[3 * b + 2] : U + neg[b];
     const float *ya = Y + ru * ldy, *yp = Y + rp * ldy, *yn = Y + rn * ldy;
     const int ldg = n_blocks * d;
     float *ga = grad_rows ? grad_rows + (int64_t)(3 * b + 0) * ldg : nullptr;
@@ -127,6 +131,211 @@ __global__ void publish_ranges_kernel(int32_t *__restrict__ seg_info) {
         const int na = seg_info[0], nl = seg_info[1];
         seg_info[2] = 0; seg_info[3] = nl; seg_info[4] = nl; seg_info[5] = na; seg_info[6] = 0; seg_info[7] = na;
     }
+}
+
+// ------------------------------------------------------------------ segment plan in ONE workgroup
+// Keys are node ids below `key_space`, so "sort and unique" is a bitmap: set the bit of every key (LDS atomics,
+// order irrelevant), prefix-sum the word popcounts, and the rank of a key -- its segment -- is
+// prefix[word] + popc(bits below it). Segments come out ascending by node id exactly as the radix-sort path
+// produces them; member lists are filled with atomics and then put in ascending slot order (insertion sort for
+// the usual 1-3 members, a cooperative rank sort for the rare long list), so the plan is a pure function of the
+// key list. One launch of 1024 threads replaces iota + radix sort (6 launches) + heads + scan (2) + finalize +
+// publish.
+constexpr int PLAN_T = 1024;
+constexpr int PLAN_LONG = 32;
+
+__device__ __forceinline__ int32_t ld_l2(const int32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// exclusive prefix of one value per thread over the 1024-thread workgroup; *total = sum of all values
+__device__ __forceinline__ int plan_block_scan(int v, int *wave_sums, int *total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();                                  // wave_sums may still be read from a previous scan
+    if (lane == 63) wave_sums[wave] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < PLAN_T / 64; ++w) {
+        const int t = wave_sums[w];
+        if (w < wave) base += t;
+        tot += t;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+// IN_LDS (n <= PLAN_LDS_N): counts, offsets and member lists live in LDS and the keys in registers, so the ~60
+// dependent round trips of the phases below cost LDS latency; the results are copied out at the end. Otherwise the
+// same phases run on the global arrays (L2 round trips: slower, any n).
+constexpr int PLAN_LDS_N = 8192;
+constexpr int PLAN_KPT = PLAN_LDS_N / PLAN_T;
+
+template <bool IN_LDS>
+__global__ __launch_bounds__(PLAN_T) void segment_plan_kernel(const int32_t *__restrict__ keys, int n, int key_space,
+                                                              int split_key, int32_t *__restrict__ active_rows,
+                                                              int32_t *__restrict__ seg_info,
+                                                              int32_t *__restrict__ slot_seg, int32_t *g_cnt,
+                                                              int32_t *g_seg_start, int32_t *g_members, int32_t *g_tmp) {
+    extern __shared__ uint32_t plan_lds[];
+    const int nw = (key_space + 31) >> 5;
+    uint32_t *bm = plan_lds, *pre = plan_lds + nw;
+    int *wave_sums = (int *)(pre + nw);               // [16]
+    int *long_list = wave_sums + 16;                  // [1 + 255]: count, then segment ids of long member lists
+    int32_t *cnt, *seg_start, *members, *tmp;
+    if constexpr (IN_LDS) {
+        cnt = (int32_t *)(long_list + 256);           // [PLAN_LDS_N]; doubles as the rank-sort scratch at the end
+        seg_start = cnt + PLAN_LDS_N;                 // [PLAN_LDS_N + 1]
+        members = seg_start + PLAN_LDS_N + 1;         // [PLAN_LDS_N]
+        tmp = cnt;
+    } else {
+        cnt = g_cnt; seg_start = g_seg_start; members = g_members; tmp = g_tmp;
+    }
+    auto ld = [&](const int32_t *p) -> int32_t { return IN_LDS ? *p : ld_l2(p); };
+    const int tid = threadIdx.x;
+    int kreg[PLAN_KPT];
+    if constexpr (IN_LDS) {
+#pragma unroll
+        for (int i = 0; i < PLAN_KPT; ++i) {
+            const int j = tid + i * PLAN_T;
+            kreg[i] = j < n ? keys[j] : -1;
+        }
+    }
+    const int iters = IN_LDS ? PLAN_KPT : (n + PLAN_T - 1) / PLAN_T;
+    auto key_of = [&](int i, int j) -> int { return IN_LDS ? kreg[i] : keys[j]; };
+    for (int w = tid; w < nw; w += PLAN_T) bm[w] = 0u;
+    if (tid == 0) long_list[0] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < iters; ++i) {
+        const int j = tid + i * PLAN_T;
+        if (j < n) {
+            const uint32_t k = (uint32_t)key_of(i, j);
+            atomicOr(&bm[k >> 5], 1u << (k & 31));
+        }
+    }
+    __syncthreads();
+    // ranks: exclusive prefix of the word popcounts
+    const int per = (nw + PLAN_T - 1) / PLAN_T;
+    const int w0 = min(tid * per, nw), w1 = min(w0 + per, nw);
+    int local = 0;
+    for (int w = w0; w < w1; ++w) local += __popc(bm[w]);
+    int n_act;
+    int run = plan_block_scan(local, wave_sums, &n_act);
+    for (int w = w0; w < w1; ++w) {
+        pre[w] = (uint32_t)run;
+        uint32_t bits = bm[w];
+        while (bits) {
+            const int b = __ffs(bits) - 1;
+            active_rows[run] = w * 32 + b;
+            cnt[run] = 0;
+            ++run;
+            bits &= bits - 1;
+        }
+    }
+    __syncthreads();
+    int sreg[PLAN_KPT];
+#pragma unroll
+    for (int i = 0; i < iters; ++i) {
+        const int j = tid + i * PLAN_T;
+        if (j < n) {
+            const uint32_t k = (uint32_t)key_of(i, j);
+            const int seg = (int)pre[k >> 5] + __popc(bm[k >> 5] & ((1u << (k & 31)) - 1u));
+            slot_seg[j] = seg;
+            if constexpr (IN_LDS) sreg[i] = seg;
+            atomicAdd(&cnt[seg], 1);
+        }
+    }
+    __syncthreads();
+    // member-list offsets: exclusive prefix of the counts; cnt becomes the fill cursor
+    const int per2 = (n_act + PLAN_T - 1) / PLAN_T;
+    const int s0 = min(tid * per2, n_act), s1 = min(s0 + per2, n_act);
+    local = 0;
+    for (int sgm = s0; sgm < s1; ++sgm) local += ld(cnt + sgm);
+    int total;
+    run = plan_block_scan(local, wave_sums, &total);
+    for (int sgm = s0; sgm < s1; ++sgm) {
+        const int c = ld(cnt + sgm);
+        seg_start[sgm] = run;
+        cnt[sgm] = 0;
+        if (c > PLAN_LONG) {
+            const int q = atomicAdd(&long_list[0], 1);
+            if (q < 255) long_list[1 + q] = sgm;
+        }
+        run += c;
+    }
+    if (tid == 0) seg_start[n_act] = n;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < iters; ++i) {
+        const int j = tid + i * PLAN_T;
+        if (j < n) {
+            int seg;
+            if constexpr (IN_LDS) seg = sreg[i]; else seg = slot_seg[j];
+            const int pos = ld(seg_start + seg) + atomicAdd(&cnt[seg], 1);
+            members[pos] = j;
+        }
+    }
+    __syncthreads();
+    const int n_long = long_list[0];
+    const bool all_serial = n_long > 255;             // more long lists than the table holds: sort them serially too
+    for (int sgm = tid; sgm < n_act; sgm += PLAN_T) {
+        const int b = ld(seg_start + sgm), e = ld(seg_start + sgm + 1);
+        if (e - b > PLAN_LONG && !all_serial) continue;
+        for (int i = b + 1; i < e; ++i) {             // insertion sort, ascending slot
+            const int v = ld(members + i);
+            int q = i - 1;
+            while (q >= b) {
+                const int u = ld(members + q);
+                if (u <= v) break;
+                members[q + 1] = u;
+                --q;
+            }
+            members[q + 1] = v;
+        }
+    }
+    if (!all_serial) {
+        for (int li = 0; li < n_long; ++li) {         // cooperative rank sort of one long list at a time
+            const int sgm = long_list[1 + li];
+            const int b = ld(seg_start + sgm), e = ld(seg_start + sgm + 1);
+            __syncthreads();
+            for (int i = b + tid; i < e; i += PLAN_T) {
+                const int v = ld(members + i);
+                int r = 0;
+                for (int q = b; q < e; ++q) r += ld(members + q) < v;
+                tmp[b + r] = v;                       // slots are distinct: ranks are a permutation
+            }
+            __syncthreads();
+            for (int i = b + tid; i < e; i += PLAN_T) members[i] = ld(tmp + i);
+        }
+    }
+    if constexpr (IN_LDS) {                           // publish the member lists for segment_apply
+        __syncthreads();
+        for (int i = tid; i < n; i += PLAN_T) g_members[i] = members[i];
+        for (int i = tid; i <= n_act; i += PLAN_T) g_seg_start[i] = seg_start[i];
+    }
+    if (tid == 0) {
+        int n_lo = n_act;
+        if (split_key < key_space) {
+            const uint32_t k = (uint32_t)(split_key < 0 ? 0 : split_key);
+            n_lo = (int)pre[k >> 5] + __popc(bm[k >> 5] & ((1u << (k & 31)) - 1u));
+        }
+        seg_info[0] = n_act; seg_info[1] = n_lo;
+        seg_info[2] = 0; seg_info[3] = n_lo; seg_info[4] = n_lo; seg_info[5] = n_act; seg_info[6] = 0; seg_info[7] = n_act;
+    }
+}
+
+// segment of every slot from the sorted path's arrays (slot_seg[src[i]] = segment holding position i)
+__global__ void slot_segments_kernel(const int32_t *__restrict__ src, const int32_t *__restrict__ segid, int64_t n,
+                                     int32_t *__restrict__ slot_seg) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) slot_seg[src[i]] = segid[i] - 1;
 }
 
 __global__ __launch_bounds__(256) void segment_sum_kernel(const float *__restrict__ rows,
@@ -432,8 +641,26 @@ extern "C" int elimrec_bpr_head(const float *d_Y, int64_t ldy, int64_t U, int64_
     BlockWeights bw;
     for (int k = 0; k < kMaxBlocks; ++k) bw.w[k] = k < n_blocks ? block_weights[k] : 0.f;
     hipLaunchKernelGGL(bpr_head_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_Y, ldy, U, d_users,
-                       d_pos, d_neg, B, d, n_blocks, bw, 1.0f / (float)B, d_loss_rows, d_grad_rows, d_keys);
+                       d_pos, d_neg, B, d, n_blocks, bw, 1.0f / (float)B, d_loss_rows, d_grad_rows, d_keys,
+                       (const int32_t *)nullptr);
     ELIMREC_LAUNCH_CHECK("bpr_head");
+    return 0;
+}
+
+extern "C" int elimrec_bpr_head_rows(const float *d_Y, int64_t ldy, const int32_t *d_slot_rows, int B, int d,
+                                     int n_blocks, const float *block_weights, float *d_loss_rows, float *d_grad_rows,
+                                     void *stream) {
+    ELIMREC_REQUIRE(d_Y && d_slot_rows && d_loss_rows && block_weights, "bpr_head_rows: null pointer");
+    ELIMREC_REQUIRE(d > 0 && d % 4 == 0, "bpr_head_rows: recdim must be a positive multiple of 4");
+    ELIMREC_REQUIRE(n_blocks >= 1 && n_blocks <= kMaxBlocks, "bpr_head_rows: 1..%d head blocks supported", kMaxBlocks);
+    ELIMREC_REQUIRE(ldy % 4 == 0 && ldy >= (int64_t)n_blocks * d, "bpr_head_rows: bad ldy");
+    if (B <= 0) return 0;
+    BlockWeights bw;
+    for (int k = 0; k < kMaxBlocks; ++k) bw.w[k] = k < n_blocks ? block_weights[k] : 0.f;
+    hipLaunchKernelGGL(bpr_head_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_Y, ldy, (int64_t)0,
+                       (const int64_t *)nullptr, (const int64_t *)nullptr, (const int64_t *)nullptr, B, d, n_blocks, bw,
+                       1.0f / (float)B, d_loss_rows, d_grad_rows, (int32_t *)nullptr, d_slot_rows);
+    ELIMREC_LAUNCH_CHECK("bpr_head_rows");
     return 0;
 }
 
@@ -444,24 +671,34 @@ extern "C" int elimrec_sum(const float *d_x, int64_t n, float *d_out, void *stre
     return 0;
 }
 
-extern "C" size_t elimrec_segment_reduce_workspace(int64_t n) {
+// plan workspace = the sorted path's layout (it also holds the fast path's arrays: vals_sorted = member lists,
+// seg_start, flag = counts / cursors, segid = rank-sort scratch)
+extern "C" size_t elimrec_segment_plan_workspace(int64_t n) {
     SegLayout L;
     if (n <= 0 || seg_layout(n, L)) return 0;
     return L.total;
 }
+extern "C" size_t elimrec_segment_reduce_workspace(int64_t n) { return elimrec_segment_plan_workspace(n); }
 
-extern "C" int elimrec_segment_reduce_rows(const float *d_rows, const int32_t *d_keys, int64_t n, int ld,
-                                           int32_t split_key, int32_t *d_active_rows, float *d_reduced,
-                                           const float *d_scale, int32_t *d_seg_info, void *d_workspace,
-                                           size_t workspace_bytes, void *stream) {
-    ELIMREC_REQUIRE(d_rows && d_keys && d_active_rows && d_reduced && d_seg_info && d_workspace,
-                    "segment_reduce_rows: null pointer");
-    ELIMREC_REQUIRE(n > 0 && n < INT32_MAX && ld > 0 && ld % 4 == 0, "segment_reduce_rows: bad n/ld");
+static int plan_fast_max_keys() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("ELIMREC_PLAN_FAST");          // 0 disables the one-workgroup planner
+        v = (e && e[0] == '0') ? 0 : (150 * 1024 / 8) * 32;     // bitmap + prefix words within 150 KB of LDS
+    }
+    return v;
+}
+
+extern "C" int elimrec_segment_plan(const int32_t *d_keys, int64_t n, int32_t split_key, int64_t key_space,
+                                    int32_t *d_active_rows, int32_t *d_seg_info, int32_t *d_slot_seg,
+                                    void *d_workspace, size_t workspace_bytes, void *stream) {
+    ELIMREC_REQUIRE(d_keys && d_active_rows && d_seg_info && d_slot_seg && d_workspace, "segment_plan: null pointer");
+    ELIMREC_REQUIRE(n > 0 && n < INT32_MAX, "segment_plan: bad n");
     SegLayout L;
     int rc = seg_layout(n, L);
     if (rc) return rc;
     if (workspace_bytes < L.total) {
-        set_error("segment_reduce_rows: workspace too small (%zu < %zu)", workspace_bytes, L.total);
+        set_error("segment_plan: workspace too small (%zu < %zu)", workspace_bytes, L.total);
         return ELIMREC_E_WORKSPACE;
     }
     char *ws = (char *)d_workspace;
@@ -469,6 +706,29 @@ extern "C" int elimrec_segment_reduce_rows(const float *d_rows, const int32_t *d
     int32_t *vs = (int32_t *)(ws + L.vals_sorted), *flag = (int32_t *)(ws + L.flag);
     int32_t *segid = (int32_t *)(ws + L.segid), *seg_start = (int32_t *)(ws + L.seg_start);
     hipStream_t s = (hipStream_t)stream;
+    if (key_space > 0 && key_space <= plan_fast_max_keys() && n <= (1 << 20)) {
+        const size_t nw = (size_t)((key_space + 31) / 32);
+        const size_t base = (2 * nw + 16 + 256) * sizeof(uint32_t);
+        const size_t lds_arrays = base + (size_t)(3 * PLAN_LDS_N + 1) * sizeof(int32_t);
+        const bool in_lds = n <= PLAN_LDS_N && lds_arrays <= 160 * 1024;
+        const size_t lds = in_lds ? lds_arrays : base;
+        static size_t lds_set[2] = {0, 0};
+        if (lds > 64 * 1024 && lds > lds_set[in_lds]) {
+            hipError_t ea = hipFuncSetAttribute(in_lds ? (const void *)segment_plan_kernel<true>
+                                                       : (const void *)segment_plan_kernel<false>,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (ea != hipSuccess) return check_hip(ea, "segment_plan: LDS size");
+            lds_set[in_lds] = lds;
+        }
+        if (in_lds)
+            hipLaunchKernelGGL(segment_plan_kernel<true>, dim3(1), dim3(PLAN_T), lds, s, d_keys, (int)n, (int)key_space,
+                               (int)split_key, d_active_rows, d_seg_info, d_slot_seg, flag, seg_start, vs, segid);
+        else
+            hipLaunchKernelGGL(segment_plan_kernel<false>, dim3(1), dim3(PLAN_T), lds, s, d_keys, (int)n, (int)key_space,
+                               (int)split_key, d_active_rows, d_seg_info, d_slot_seg, flag, seg_start, vs, segid);
+        ELIMREC_LAUNCH_CHECK("segment_plan");
+        return 0;
+    }
     const unsigned nb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(256), 0, s, vin, n);
     ELIMREC_LAUNCH_CHECK("iota");
@@ -487,10 +747,46 @@ extern "C" int elimrec_segment_reduce_rows(const float *d_rows, const int32_t *d
     ELIMREC_LAUNCH_CHECK("finalize_segments");
     hipLaunchKernelGGL(publish_ranges_kernel, dim3(1), dim3(64), 0, s, d_seg_info);
     ELIMREC_LAUNCH_CHECK("publish_ranges");
-    hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, d_rows, vs, seg_start,
-                       d_seg_info, n, ld / 4, d_scale, d_reduced);
+    hipLaunchKernelGGL(slot_segments_kernel, dim3(nb), dim3(256), 0, s, vs, segid, n, d_slot_seg);
+    ELIMREC_LAUNCH_CHECK("slot_segments");
+    return 0;
+}
+
+extern "C" int elimrec_segment_apply(const float *d_rows, int64_t n, int ld, const int32_t *d_seg_info,
+                                     const float *d_scale, float *d_reduced, const void *d_workspace,
+                                     size_t workspace_bytes, void *stream) {
+    ELIMREC_REQUIRE(d_rows && d_seg_info && d_reduced && d_workspace, "segment_apply: null pointer");
+    ELIMREC_REQUIRE(n > 0 && n < INT32_MAX && ld > 0 && ld % 4 == 0, "segment_apply: bad n/ld");
+    SegLayout L;
+    int rc = seg_layout(n, L);
+    if (rc) return rc;
+    if (workspace_bytes < L.total) {
+        set_error("segment_apply: workspace too small (%zu < %zu)", workspace_bytes, L.total);
+        return ELIMREC_E_WORKSPACE;
+    }
+    const char *ws = (const char *)d_workspace;
+    const int32_t *vs = (const int32_t *)(ws + L.vals_sorted), *seg_start = (const int32_t *)(ws + L.seg_start);
+    hipLaunchKernelGGL(segment_sum_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_rows, vs,
+                       seg_start, d_seg_info, n, ld / 4, d_scale, d_reduced);
     ELIMREC_LAUNCH_CHECK("segment_sum");
     return 0;
+}
+
+extern "C" int elimrec_segment_reduce_rows(const float *d_rows, const int32_t *d_keys, int64_t n, int ld,
+                                           int32_t split_key, int32_t *d_active_rows, float *d_reduced,
+                                           const float *d_scale, int32_t *d_seg_info, void *d_workspace,
+                                           size_t workspace_bytes, void *stream) {
+    ELIMREC_REQUIRE(d_rows && d_keys && d_active_rows && d_reduced && d_seg_info && d_workspace,
+                    "segment_reduce_rows: null pointer");
+    ELIMREC_REQUIRE(n > 0 && n < INT32_MAX && ld > 0 && ld % 4 == 0, "segment_reduce_rows: bad n/ld");
+    SegLayout L;
+    int rc = seg_layout(n, L);
+    if (rc) return rc;
+    // key space unknown here: the sorted plan; its slot->segment map goes to the (then unused) vals_in array
+    rc = elimrec_segment_plan(d_keys, n, split_key, 0, d_active_rows, d_seg_info,
+                              (int32_t *)((char *)d_workspace + L.vals_in), d_workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    return elimrec_segment_apply(d_rows, n, ld, d_seg_info, d_scale, d_reduced, d_workspace, workspace_bytes, stream);
 }
 
 extern "C" int elimrec_head_bwd_input(const float *d_dY, int64_t lddy, const int32_t *d_active_rows,

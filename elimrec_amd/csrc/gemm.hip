@@ -29,7 +29,7 @@ struct FwdBatch { elimrec_linear_desc p[kMaxBatch]; };
 // BM = 128: wave w owns rows [32w, 32w+32) x all 64 columns (two MFMA tiles share the A operand).
 // BM = 64 : wave w owns rows [32(w&1), +32) x columns [32(w>>1), +32) (one tile); twice the workgroups,
 //           smaller LDS footprint -- better when the grid is only a couple of rounds deep.
-template <int BM>
+template <int BM, int PD>
 __global__ __launch_bounds__(256) void linear_fwd_kernel(FwdBatch batch) {
     const elimrec_linear_desc &pd = batch.p[blockIdx.z];
     const float *__restrict__ A = pd.d_A;
@@ -40,10 +40,12 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(FwdBatch batch) {
     const float *__restrict__ addm = pd.d_add;
     const int32_t *__restrict__ row_index = pd.d_row_index;   // A / rowscale / add row of output row m
     const int64_t lda = pd.lda, ldw = pd.ldw, ldc = pd.ldc, ldadd = pd.ldadd;
-    const int64_t M = pd.d_row_count ? (int64_t)min((int64_t)*pd.d_row_count, pd.M) : pd.M;
+    // output rows [row_lo, M): the whole problem, or the device-side range (active rows of this batch)
+    const int64_t row_lo = pd.d_row_range ? (int64_t)max(pd.d_row_range[0], 0) : 0;
+    const int64_t M = pd.d_row_range ? (int64_t)min((int64_t)pd.d_row_range[1], pd.M) : pd.M;
     const int N = pd.N, K = pd.K;
     const int n0 = blockIdx.y * FBN;
-    const int64_t n_tiles = (M + BM - 1) / BM;
+    const int64_t n_tiles = M > row_lo ? (M - row_lo + BM - 1) / BM : 0;
     if ((int64_t)blockIdx.x >= n_tiles || n0 >= N) return;
     // PERSISTENT over row tiles: workgroup b takes tiles b, b + gridDim.x, ...; the (tile, K-chunk) pairs form
     // one software pipeline -- while chunk g feeds the MFMAs, chunk g+1 (possibly the first chunk of the NEXT
@@ -67,35 +69,39 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(FwdBatch batch) {
 
     v16f acc0 = {0}, acc1 = {0};
     const int ai = lane & 31, ak = lane >> 5;
-    float4 ra[AP], rb[BP];
-    auto load_chunk = [&](int64_t g) {
-        const int64_t m0 = ((int64_t)blockIdx.x + (g / chunks) * gridDim.x) * BM;
+    // PD K-chunks are in flight in registers at any time. One chunk is only 0.25 us of MFMA work against a
+    // ~2 us global load: with many resident workgroups (large M) other waves hide that and PD = 1 (least
+    // registers, most waves) is fastest; a launch of a few hundred tiles (the batch-row projections) has one
+    // workgroup per CU and runs at the latency of its own chain, so it wants the deep pipeline.
+    float4 ra[PD][AP], rb[PD][BP];
+    auto load_chunk = [&](int64_t g, float4 (&qa)[AP], float4 (&qb)[BP]) {
+        const int64_t m0 = row_lo + ((int64_t)blockIdx.x + (g / chunks) * gridDim.x) * BM;
         const int k0 = (int)(g % chunks) * FBK;
         const bool kin = (k0 + lc) < K;  // K % 4 == 0: the whole float4 is in or out
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const int64_t gr = m0 + lr + RPP * i;
             const int64_t sr = (row_index && gr < M) ? (int64_t)row_index[gr] : gr;
-            ra[i] = (kin && gr < M) ? *reinterpret_cast<const float4 *>(A + sr * lda + k0 + lc)
+            qa[i] = (kin && gr < M) ? *reinterpret_cast<const float4 *>(A + sr * lda + k0 + lc)
                                     : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
             const int gn = n0 + lr + RPP * i;
-            rb[i] = (kin && gn < N) ? *reinterpret_cast<const float4 *>(W + (int64_t)gn * ldw + k0 + lc)
+            qb[i] = (kin && gn < N) ? *reinterpret_cast<const float4 *>(W + (int64_t)gn * ldw + k0 + lc)
                                     : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, const float4 (&qa)[AP], const float4 (&qb)[BP]) {
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             float *dst = &As[buf][(lr + RPP * i) * FLD + lc];
-            dst[0] = ra[i].x; dst[1] = ra[i].y; dst[2] = ra[i].z; dst[3] = ra[i].w;
+            dst[0] = qa[i].x; dst[1] = qa[i].y; dst[2] = qa[i].z; dst[3] = qa[i].w;
         }
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
             float *dst = &Bs[buf][(lr + RPP * i) * FLD + lc];
-            dst[0] = rb[i].x; dst[1] = rb[i].y; dst[2] = rb[i].z; dst[3] = rb[i].w;
+            dst[0] = qb[i].x; dst[1] = qb[i].y; dst[2] = qb[i].z; dst[3] = qb[i].w;
         }
     };
     const int col0 = n0 + wcol + (lane & 31);
@@ -103,45 +109,51 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(FwdBatch batch) {
     const float bias0 = (bias && col0 < N) ? bias[col0] : 0.f;
     const float bias1 = (BM == 128 && bias && col1 < N) ? bias[col1] : 0.f;
 
-    load_chunk(0);
-    store_chunk(0);
-    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PD; ++j)
+        if (j < G) load_chunk(j, ra[j], rb[j]);
     int buf = 0;
-    for (int64_t g = 0; g < G; ++g) {
-        const bool more = (g + 1) < G;
-        if (more) load_chunk(g + 1);
-        const float *ap = &As[buf][(wrow + ai) * FLD + ak];
-        const float *bp0 = &Bs[buf][(wcol + ai) * FLD + ak];
-        const float *bp1 = &Bs[buf][(32 + ai) * FLD + ak];
+    for (int64_t g0 = 0; g0 < G; g0 += PD) {
 #pragma unroll
-        for (int kk = 0; kk < FBK; kk += 2) {
-            const float a = ap[kk];
-            const float b0 = bp0[kk];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-            if (BM == 128) {
-                const float b1 = bp1[kk];
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
-            }
-        }
-        if ((int)(g % chunks) == chunks - 1) {           // last K-chunk of this tile: write it out, start the next
-            const int64_t m0 = ((int64_t)blockIdx.x + (g / chunks) * gridDim.x) * BM;
+        for (int j = 0; j < PD; ++j) {
+            const int64_t g = g0 + j;
+            if (g >= G) break;
+            // double-buffered LDS, one barrier per chunk: a wave that stores into `buf` here has passed the
+            // barrier of chunk g-1, which every wave reaches only after its MFMAs of chunk g-2 (same buffer)
+            store_chunk(buf, ra[j], rb[j]);
+            __syncthreads();
+            if (g + PD < G) load_chunk(g + PD, ra[j], rb[j]);
+            const float *ap = &As[buf][(wrow + ai) * FLD + ak];
+            const float *bp0 = &Bs[buf][(wcol + ai) * FLD + ak];
+            const float *bp1 = &Bs[buf][(32 + ai) * FLD + ak];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wrow + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < M) {
-                    const int64_t sr = row_index ? (int64_t)row_index[row] : row;
-                    const float rs = rowscale ? rowscale[sr] : 1.f;          // bias enters as rowscale[row] * bias[n]
-                    if (col0 < N) C[row * ldc + col0] = acc0[r] + rs * bias0 + (addm ? addm[sr * ldadd + col0] : 0.f);
-                    if (BM == 128 && col1 < N)
-                        C[row * ldc + col1] = acc1[r] + rs * bias1 + (addm ? addm[sr * ldadd + col1] : 0.f);
+            for (int kk = 0; kk < FBK; kk += 2) {
+                const float a = ap[kk];
+                const float b0 = bp0[kk];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+                if (BM == 128) {
+                    const float b1 = bp1[kk];
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
                 }
             }
-            acc0 = (v16f){0};
-            acc1 = (v16f){0};
+            if ((int)(g % chunks) == chunks - 1) {       // last K-chunk of this tile: write it out, start the next
+                const int64_t m0 = row_lo + ((int64_t)blockIdx.x + (g / chunks) * gridDim.x) * BM;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = m0 + wrow + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < M) {
+                        const int64_t sr = row_index ? (int64_t)row_index[row] : row;
+                        const float rs = rowscale ? rowscale[sr] : 1.f;      // bias enters as rowscale[row] * bias[n]
+                        if (col0 < N) C[row * ldc + col0] = acc0[r] + rs * bias0 + (addm ? addm[sr * ldadd + col0] : 0.f);
+                        if (BM == 128 && col1 < N)
+                            C[row * ldc + col1] = acc1[r] + rs * bias1 + (addm ? addm[sr * ldadd + col1] : 0.f);
+                    }
+                }
+                acc0 = (v16f){0};
+                acc1 = (v16f){0};
+            }
+            buf ^= 1;
         }
-        if (more) store_chunk(buf ^ 1);
-        __syncthreads();
-        buf ^= 1;
     }
 }
 
@@ -167,6 +179,7 @@ struct BwdBatch { BwdProblem p[kMaxBatch]; int n; };
 __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(BwdBatch batch) {
     __shared__ float As[2][TRB * TN1];
     __shared__ float Bs[2][TRB * TN2];
+    __shared__ float Wt[2][TRB];                           // per-row weights of the (weighted) column sum
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int pi = 0;
     while (pi + 1 < batch.n && (int)blockIdx.x >= batch.p[pi + 1].first_block) ++pi;
@@ -184,6 +197,7 @@ __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(BwdBatch batc
     const int n1 = pb.d.n1, n2 = pb.d.n2, chunk_rows = pb.chunk_rows;
     float *__restrict__ slabs = pb.slabs;
     float *__restrict__ colsum_slabs = pb.d.d_colsum ? pb.cslabs : nullptr;
+    const float *__restrict__ cw = pb.d.d_colsum ? pb.d.d_colsum_weight : nullptr;
     int64_t rb = 0, re = R;
     if (range) { rb = range[0]; re = range[1]; }
     const int64_t r0 = rb + (int64_t)chunk * chunk_rows;
@@ -196,7 +210,12 @@ __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(BwdBatch batc
     const bool a_col_ok = (i_base + a_c4 * 4) < n1;       // n1, n2 are multiples of 4
     const bool b_col_ok = (j_base + b_c4 * 4) < n2;
     float4 ra[2], rbv[4];
+    float rw = 1.f;
     auto load_block = [&](int64_t row0) {
+        if (cw && tid < TRB) {
+            const int64_t r = row0 + tid;
+            rw = r < r1 ? cw[row_index ? (int64_t)row_index[r] : r] : 0.f;
+        }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int64_t r = row0 + a_row + 16 * p;
@@ -215,6 +234,7 @@ __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(BwdBatch batc
         }
     };
     auto store_block = [&](int buf) {
+        if (cw && tid < TRB) Wt[buf][tid] = rw;
 #pragma unroll
         for (int p = 0; p < 2; ++p)
             *reinterpret_cast<float4 *>(&As[buf][(a_row + 16 * p) * TN1 + a_c4 * 4]) = ra[p];
@@ -246,8 +266,13 @@ __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(BwdBatch batc
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
         }
         if (colsum_slabs && tid < TN1) {
+            if (cw) {
 #pragma unroll 8
-            for (int k = 0; k < TRB; ++k) csum += as[k * TN1 + tid];
+                for (int k = 0; k < TRB; ++k) csum += as[k * TN1 + tid] * Wt[buf][k];
+            } else {
+#pragma unroll 8
+                for (int k = 0; k < TRB; ++k) csum += as[k * TN1 + tid];
+            }
         }
         if (more) store_block(buf ^ 1);
         __syncthreads();
@@ -342,11 +367,21 @@ extern "C" int elimrec_linear_fwd_batched(const elimrec_linear_desc *descs, int 
     if (tile_rows == 128) {
         const int64_t tiles = (max_tiles_m + 127) / 128;
         dim3 grid((unsigned)(tiles < per_problem ? tiles : per_problem), (unsigned)max_tiles_n, (unsigned)n);
-        hipLaunchKernelGGL(linear_fwd_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, batch);
+        hipLaunchKernelGGL((linear_fwd_kernel<128, 1>), grid, dim3(256), 0, (hipStream_t)stream, batch);
     } else {
         const int64_t tiles = (max_tiles_m + 63) / 64;
         dim3 grid((unsigned)(tiles < per_problem ? tiles : per_problem), (unsigned)max_tiles_n, (unsigned)n);
-        hipLaunchKernelGGL(linear_fwd_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, batch);
+        static int depth = -1;
+        if (depth < 0) {
+            const char *e = getenv("ELIMREC_FWD_DEPTH");
+            depth = e ? atoi(e) : 0;
+        }
+        // small launches (about one workgroup per CU or less) take the deep software pipeline
+        const int64_t wgs = (int64_t)grid.x * grid.y * grid.z;
+        const int pd = depth > 0 ? depth : (wgs <= 768 ? 8 : 1);
+        if (pd >= 8) hipLaunchKernelGGL((linear_fwd_kernel<64, 8>), grid, dim3(256), 0, (hipStream_t)stream, batch);
+        else if (pd >= 4) hipLaunchKernelGGL((linear_fwd_kernel<64, 4>), grid, dim3(256), 0, (hipStream_t)stream, batch);
+        else hipLaunchKernelGGL((linear_fwd_kernel<64, 1>), grid, dim3(256), 0, (hipStream_t)stream, batch);
     }
     ELIMREC_LAUNCH_CHECK("linear_fwd");
     return 0;
@@ -431,6 +466,6 @@ extern "C" int elimrec_linear_bwd_w(const float *d_A, int64_t lda, const float *
                                     const int32_t *d_row_index, const int32_t *d_range, int64_t R, int n1, int n2,
                                     float *d_out, int64_t ldo, float *d_colsum, int accumulate, void *d_workspace,
                                     size_t workspace_bytes, void *stream) {
-    elimrec_linear_bwd_desc d = {d_A, lda, d_B, ldb, d_row_index, d_range, R, n1, n2, d_out, ldo, d_colsum, accumulate};
+    elimrec_linear_bwd_desc d = {d_A, lda, d_B, ldb, d_row_index, d_range, R, n1, n2, d_out, ldo, d_colsum, accumulate, nullptr};
     return elimrec_linear_bwd_w_batched(&d, 1, d_workspace, workspace_bytes, stream);
 }

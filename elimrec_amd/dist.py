@@ -6,15 +6,17 @@ shape (N=112 741 rows x 1 KiB) against 288 GB of HBM per GPU, and every hop of a
 propagation would move most of that table across xGMI (SURVEY.md §7 "xGMI volume") -- six times
 per step. What actually differs between ranks is tiny: the gradient of the loss with respect to the
 3B gathered head rows. So per step each rank
-  1. runs the forward on its own B triplets (tables are bit-identical on every rank),
-  2. all-gathers its [3B x Cy] head-gradient rows + int32 node ids (6.3 MB per rank at B=2048),
-  3. runs the SAME deterministic backward + Adam on the gathered rows scaled by 1/world_size.
-Step 3 is bitwise identical on every rank (deterministic kernels, identical input order), so the
+  1. all-gathers the int32 node ids of its 3B triplet slots (24 KB per rank at B=2048): every rank plans the
+     same set of active nodes and evaluates the head at those rows,
+  2. runs the forward on its own B triplets (tables are bit-identical on every rank),
+  3. all-gathers its [3B x Cy] head-gradient rows (6.3 MB per rank at B=2048),
+  4. runs the SAME deterministic backward + Adam on the gathered rows scaled by 1/world_size.
+Step 4 is bitwise identical on every rank (deterministic kernels, identical input order), so the
 replicas never drift and no parameter/gradient all-reduce exists. The result equals one
 single-GPU step with batch world_size*B (mean over the global batch).
 
 The `engine` (EliMRec, or a CPU stand-in injected by tests/test_dist_cpu.py) provides
-forward_local / backward_global / named_parameters.
+batch_keys / forward_local / backward_global / named_parameters.
 """
 import torch
 import torch.distributed as dist
@@ -43,16 +45,27 @@ class DataParallelTrainer(object):
         eng = self.engine
         if self.profile_kernels and getattr(eng, "_kernel_events", None) is None:
             eng._kernel_events = self._events
-        loss, grad_rows, keys = eng.forward_local(users, pos, neg, world_size=self.world)
         if self.collectives:
-            all_rows, all_keys = self._buffers(grad_rows, keys)
-            dist.all_gather_into_tensor(all_rows, grad_rows, group=self.group)
+            keys = eng.batch_keys(users, pos, neg)
+            if self._gather is None or self._gather[1].numel() != self.world * keys.numel():
+                self._gather = None
+                all_keys = torch.empty(self.world * keys.numel(), dtype=keys.dtype, device=keys.device)
+            else:
+                all_keys = self._gather[1]
             dist.all_gather_into_tensor(all_keys, keys, group=self.group)
-            grads = eng.backward_global(all_rows, all_keys, self._scale)
+            loss, grad_rows = eng.forward_local(users, pos, neg, all_keys=all_keys, rank=self.rank, world_size=self.world)
+            if self._gather is None:
+                self._gather = (torch.empty(self.world * grad_rows.shape[0], grad_rows.shape[1], dtype=grad_rows.dtype,
+                                            device=grad_rows.device), all_keys)
+                self._scale = torch.full((1,), 1.0 / self.world, dtype=torch.float32, device=grad_rows.device)
+            all_rows = self._gather[0]
+            dist.all_gather_into_tensor(all_rows, grad_rows, group=self.group)
+            grads = eng.backward_global(all_rows, self._scale)
         else:
+            loss, grad_rows = eng.forward_local(users, pos, neg)
             if self._scale is None:
                 self._scale = torch.ones(1, dtype=torch.float32, device=grad_rows.device)
-            grads = eng.backward_global(grad_rows, keys, self._scale)
+            grads = eng.backward_global(grad_rows, self._scale)
         for name, p in eng.named_parameters():
             p.grad = grads.get(name)          # None => the optimiser skips it (as torch does)
         self.opt.step()

@@ -49,8 +49,8 @@ def linear_fwd(A, W, bias, out):
 def linear_fwd_batched(problems):
     """problems: list of (A, W, bias, out[, rowscale, add[, row_index, row_count]]) -- independent Linears sharing
     one launch (<= 8).  out = A.W^T + rowscale[:, None] * bias + add   (rowscale, add optional).
-    row_index (int32 [M]): output row m reads row row_index[m] of A / rowscale / add; row_count (device int32
-    scalar): only the first min(row_count, M) output rows are produced."""
+    row_index (int32 [M]): output row m reads row row_index[m] of A / rowscale / add; row_range (device int32[2]):
+    only output rows [begin, min(end, M)) are produced."""
     n = len(problems)
     arr = (_lib.LinearDesc * n)()
     for i, pr in enumerate(problems):
@@ -58,7 +58,7 @@ def linear_fwd_batched(problems):
         rowscale = pr[4] if len(pr) > 4 else None
         add = pr[5] if len(pr) > 5 else None
         row_index = pr[6] if len(pr) > 6 else None
-        row_count = pr[7] if len(pr) > 7 else None
+        row_range = pr[7] if len(pr) > 7 else None
         a, lda = _rowmajor(A, "A")
         w, ldw = _rowmajor(W, "W")
         c, ldc = _rowmajor(out, "out")
@@ -73,7 +73,7 @@ def linear_fwd_batched(problems):
         if rowscale is not None:
             assert rowscale.is_contiguous() and rowscale.numel() == A.shape[0]
         arr[i] = _lib.LinearDesc(a, lda, w, ldw, _dev(bias, "bias"), c, ldc, M, N, K, _dev(rowscale, "rowscale"), ad, ldadd,
-                                 _dev(row_index, "row_index", torch.int32), _dev(row_count, "row_count", torch.int32))
+                                 _dev(row_index, "row_index", torch.int32), _dev(row_range, "row_range", torch.int32))
     _lib.check(_lib.load().elimrec_linear_fwd_batched(arr, n, _stream()), "linear_fwd_batched")
 
 
@@ -88,7 +88,8 @@ def _bwd_descs(problems):
         n1, n2 = pr["out"].shape
         arr[i] = _lib.LinearBwdDesc(a, lda, b, ldb, _dev(pr.get("row_index"), "row_index", torch.int32),
                                     _dev(pr.get("rng"), "range", torch.int32), R, n1, n2, o, ldo,
-                                    _dev(pr.get("colsum"), "colsum"), 1 if pr.get("accumulate") else 0)
+                                    _dev(pr.get("colsum"), "colsum"), 1 if pr.get("accumulate") else 0,
+                                    _dev(pr.get("colsum_weight"), "colsum_weight"))
     return arr, n
 
 
@@ -344,6 +345,17 @@ def bpr_head(Y, U, I, users, pos, neg, d, block_weights, loss_rows, grad_rows=No
                "bpr_head")
 
 
+def bpr_head_rows(Y, slot_rows, d, block_weights, loss_rows, grad_rows=None):
+    """bpr_head over a compact table: slot 3b+j of triplet b reads row slot_rows[3b+j] of Y."""
+    y, ldy = _rowmajor(Y, "Y")
+    nb = len(block_weights)
+    w = (ctypes.c_float * nb)(*[float(x) for x in block_weights])
+    B = slot_rows.numel() // 3
+    _lib.check(_lib.load().elimrec_bpr_head_rows(y, ldy, _dev(slot_rows, "slot_rows", torch.int32), B, d, nb, w,
+                                                 _dev(loss_rows, "loss_rows"), _dev(grad_rows, "grad_rows"), _stream()),
+               "bpr_head_rows")
+
+
 def fixed_order_sum(x, out):
     _lib.check(_lib.load().elimrec_sum(_dev(x, "x"), x.numel(), _dev(out, "out"), _stream()), "sum")
     return out
@@ -351,6 +363,31 @@ def fixed_order_sum(x, out):
 
 def segment_reduce_workspace(n):
     return int(_lib.load().elimrec_segment_reduce_workspace(n))
+
+
+def segment_plan_workspace(n):
+    return int(_lib.load().elimrec_segment_plan_workspace(n))
+
+
+def segment_plan(keys, split_key, key_space, active_rows, seg_info, slot_seg, workspace):
+    """Plan of a key list: active_rows (sorted unique keys), seg_info, slot_seg (segment of every slot); the member
+    lists stay in `workspace` for segment_apply."""
+    n = keys.numel()
+    _lib.check(_lib.load().elimrec_segment_plan(_dev(keys, "keys", torch.int32), n, int(split_key), int(key_space),
+                                                _dev(active_rows, "active_rows", torch.int32),
+                                                _dev(seg_info, "seg_info", torch.int32),
+                                                _dev(slot_seg, "slot_seg", torch.int32),
+                                                _dev(workspace, "workspace", torch.uint8), workspace.numel(), _stream()),
+               "segment_plan")
+
+
+def segment_apply(rows, seg_info, reduced, workspace, scale=None):
+    n, ld = rows.shape
+    assert rows.is_contiguous() and reduced.is_contiguous()
+    _lib.check(_lib.load().elimrec_segment_apply(_dev(rows, "rows"), n, ld, _dev(seg_info, "seg_info", torch.int32),
+                                                 _dev(scale, "scale"), _dev(reduced, "reduced"),
+                                                 _dev(workspace, "workspace", torch.uint8), workspace.numel(), _stream()),
+               "segment_apply")
 
 
 def segment_reduce_rows(rows, keys, split_key, active_rows, reduced, seg_info, workspace, scale=None):

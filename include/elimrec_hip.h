@@ -60,7 +60,8 @@ typedef struct elimrec_linear_desc {
     const float *d_add; int64_t ldadd;  /* nullable [M x N]: added to the result (C = A.W^T + .. + add) */
     const int32_t *d_row_index;     /* nullable [M]: output row m reads row d_row_index[m] of A, rowscale, add
                                        (the projections evaluated at the batch's rows only; C stays compact) */
-    const int32_t *d_row_count;     /* nullable device scalar: only the first min(*d_row_count, M) rows exist  */
+    const int32_t *d_row_range;     /* nullable device int32[2] = (begin, end): only output rows [begin, min(end, M))
+                                       are produced (slot ranges of elimrec_segment_plan's seg_info)            */
 } elimrec_linear_desc;
 int elimrec_linear_fwd_batched(const elimrec_linear_desc *descs /* host array */, int n, void *stream);
 
@@ -97,6 +98,8 @@ typedef struct elimrec_linear_bwd_desc {
     float *d_out; int64_t ldo;
     float *d_colsum;                /* nullable */
     int32_t accumulate;
+    const float *d_colsum_weight;   /* nullable: colsum becomes sum_r w[row(r)] * A[r, i], row(r) as for B (the bias
+                                       gradient of a folded projection, w = c) */
 } elimrec_linear_bwd_desc;
 size_t elimrec_linear_bwd_w_batched_workspace(const elimrec_linear_bwd_desc *descs, int n);
 int elimrec_linear_bwd_w_batched(const elimrec_linear_bwd_desc *descs /* host array */, int n,
@@ -244,6 +247,12 @@ int elimrec_bpr_head(const float *d_Y, int64_t ldy, int64_t U, int64_t I,
                      int d, int n_blocks, const float *block_weights /* host, n_blocks */,
                      float *d_loss_rows, float *d_grad_rows, int32_t *d_keys, void *stream);
 
+/* The same loss over a COMPACT table: slot 3b+j of triplet b reads row d_slot_rows[3b+j] of d_Y (the rows of the
+ * batch's active nodes, elimrec_segment_plan's slot -> segment map). No keys are written. */
+int elimrec_bpr_head_rows(const float *d_Y, int64_t ldy, const int32_t *d_slot_rows, int B, int d, int n_blocks,
+                          const float *block_weights /* host, n_blocks */, float *d_loss_rows, float *d_grad_rows,
+                          void *stream);
+
 /* out[0] = sum_i x[i] in a fixed order (single workgroup, deterministic). */
 int elimrec_sum(const float *d_x, int64_t n, float *d_out, void *stream);
 
@@ -256,6 +265,17 @@ int elimrec_sum(const float *d_x, int64_t n, float *d_out, void *stream);
  * the form elimrec_linear_bwd_w's d_range takes (users / items / all, with split_key = U).
  * workspace: elimrec_segment_reduce_workspace(n) bytes. */
 size_t elimrec_segment_reduce_workspace(int64_t n);
+/* The two halves of elimrec_segment_reduce_rows. The PLAN depends on the keys only (the batch's node ids are known
+ * before the forward pass): sorted unique keys -> d_active_rows, d_seg_info as above, d_slot_seg[n] = the segment
+ * (index into d_active_rows) of every slot, member lists inside the workspace. key_space > 0 promises
+ * 0 <= key < key_space and selects the one-workgroup bitmap planner when the bitmap fits LDS (same output as the
+ * radix-sort path, which is used otherwise). APPLY sums rows per segment in ascending slot order, times *d_scale. */
+size_t elimrec_segment_plan_workspace(int64_t n);
+int elimrec_segment_plan(const int32_t *d_keys, int64_t n, int32_t split_key, int64_t key_space,
+                         int32_t *d_active_rows, int32_t *d_seg_info, int32_t *d_slot_seg, void *d_workspace,
+                         size_t workspace_bytes, void *stream);
+int elimrec_segment_apply(const float *d_rows, int64_t n, int ld, const int32_t *d_seg_info, const float *d_scale,
+                          float *d_reduced, const void *d_workspace, size_t workspace_bytes, void *stream);
 int elimrec_segment_reduce_rows(const float *d_rows, const int32_t *d_keys, int64_t n, int ld,
                                 int32_t split_key, int32_t *d_active_rows, float *d_reduced,
                                 const float *d_scale /* nullable device fp32[1]: multiplies every sum */,

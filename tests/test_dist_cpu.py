@@ -1,5 +1,5 @@
 """The N>1 training path (elimrec_amd/dist.py) on CPU: two gloo ranks, the oracle standing in
-for the HIP kernels behind the same engine interface (forward_local / backward_global). Checks
+for the HIP kernels behind the same engine interface (batch_keys / forward_local / backward_global). Checks
 that a world_size-2 step with per-rank batches B equals ONE single-process step on the
 concatenated batch of 2B triplets, and that the replicas stay bitwise in sync."""
 import os
@@ -36,10 +36,16 @@ class OracleEngine(object):
         blocks = [torch.cat([au, ai])] + [torch.cat([s["pre_fusion_user_" + k], s["pre_fusion_item_" + k]]) for k in mods]
         return torch.cat(blocks, dim=1), mods
 
-    def forward_local(self, users, pos, neg, world_size=1):
+    def batch_keys(self, users, pos, neg):
+        U = self.m.U
+        return torch.stack([users, U + pos, U + neg], dim=1).reshape(-1).to(torch.int32)
+
+    def forward_local(self, users, pos, neg, all_keys=None, rank=0, world_size=1):
         m, U, d = self.m, self.m.U, self.m.d
         self.Y, mods = self._tables()
-        keys = torch.stack([users, U + pos, U + neg], dim=1).reshape(-1).to(torch.int32)
+        keys = self.batch_keys(users, pos, neg)
+        self.all_keys = keys if all_keys is None else all_keys.clone()
+        assert torch.equal(self.all_keys[rank * len(keys):(rank + 1) * len(keys)], keys)
         rows = self.Y.detach()[keys.long()].clone().requires_grad_(True)       # [3B x Cy]
         r3 = rows.view(-1, 3, rows.shape[1])
         w = [1.0] + [m.alpha if k in m.modality else 0.0 for k in mods]
@@ -49,11 +55,11 @@ class OracleEngine(object):
                 blk = r3[:, :, b * d:(b + 1) * d]
                 loss = loss + wk * m.original_bpr_loss(blk[:, 0], blk[:, 1], blk[:, 2])
         loss.backward()
-        return loss.detach(), rows.grad.detach(), keys
+        return loss.detach(), rows.grad.detach()
 
-    def backward_global(self, grad_rows, keys, scale):
+    def backward_global(self, grad_rows, scale):
         dY = torch.zeros_like(self.Y)
-        dY.index_add_(0, keys.long(), grad_rows * scale)
+        dY.index_add_(0, self.all_keys.long(), grad_rows * scale)
         self.m.zero_grad()
         self.Y.backward(dY)
         return self.m.grads()

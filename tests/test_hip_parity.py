@@ -386,6 +386,41 @@ def test_bpr_head_and_segment_reduce_vs_torch_autograd():
         assert torch.equal(red2[:info[0]], 2 * red[:info[0]])       # deterministic + scale
 
 
+@pytest.mark.parametrize("n,key_space,hot", [(6144, 112741, 0), (12288, 112741, 700), (300, 97, 40), (1, 5, 0),
+                                             (49152, 600000, 3000)])
+def test_one_workgroup_segment_plan_equals_sorted_plan(n, key_space, hot):
+    """The bitmap planner (keys < key_space known) against the radix-sort planner: same active rows, seg_info,
+    slot -> segment map and bit-identical segment sums (member lists in ascending slot order), including member
+    lists long enough for the cooperative rank sort (`hot` slots share one key)."""
+    from elimrec_amd import ops
+    gen = torch.Generator().manual_seed(n + key_space)
+    keys = torch.randint(0, key_space, (n,), generator=gen, dtype=torch.int32)
+    if hot:
+        keys[torch.randperm(n, generator=gen)[:hot]] = int(keys[0])
+        keys[torch.randperm(n, generator=gen)[:hot // 2]] = int(keys[1])
+    split = key_space // 3
+    rows = torch.randn(n, 8, generator=gen)
+    keys_d, rows_d = keys.to(DEV), rows.to(DEV)
+    res = []
+    for ks in (key_space, 0):
+        ws = torch.empty(ops.segment_plan_workspace(n), dtype=torch.uint8, device=DEV)
+        act = torch.full((n,), -1, dtype=torch.int32, device=DEV)
+        seg = torch.zeros(8, dtype=torch.int32, device=DEV)
+        slot_seg = torch.full((n,), -1, dtype=torch.int32, device=DEV)
+        red = torch.zeros(n, 8, device=DEV)
+        ops.segment_plan(keys_d, split, ks, act, seg, slot_seg, ws)
+        ops.segment_apply(rows_d, seg, red, ws)
+        na = int(seg[0])
+        res.append((act[:na].cpu(), seg.cpu(), slot_seg.cpu(), red[:na].cpu()))
+    uniq = torch.unique(keys.long())
+    assert torch.equal(res[0][0].long(), uniq) and int(res[0][1][1]) == int((uniq < split).sum())
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    assert torch.equal(uniq[res[0][2].long()], keys.long())
+    want = torch.zeros(len(uniq), 8, dtype=torch.float64).index_add_(0, res[0][2].long(), rows.double())
+    assert (res[0][3].double() - want).abs().max() < 1e-4
+
+
 def test_sampler_contract_on_device():
     from elimrec_amd import PairwiseSamplerV2, SyntheticDataset
     ds = SyntheticDataset(400, 300, 6000, feat_dims=(4, 4, 4), seed=9)
@@ -661,15 +696,18 @@ def test_data_parallel_math_on_one_gpu():
     u, p, n = (_t(g["step1/%s" % k]) for k in ("users", "pos", "neg"))
     half = (len(u) // 2)
     whole, _ = build_model_from_fixture(g, DEV)
-    loss_w, rows_w, keys_w = whole.forward_local(u[:2 * half], p[:2 * half], n[:2 * half])
-    grads_w = {k: v.clone() for k, v in whole.backward_global(rows_w, keys_w, torch.ones(1, device=DEV)).items()}
+    loss_w, rows_w = whole.forward_local(u[:2 * half], p[:2 * half], n[:2 * half])
+    grads_w = {k: v.clone() for k, v in whole.backward_global(rows_w, torch.ones(1, device=DEV)).items()}
     dp, _ = build_model_from_fixture(g, DEV)
-    rows, keys, losses = [], [], []
+    dp._workspace(half, 6 * half)
+    all_keys = torch.cat([dp.batch_keys(u[r * half:(r + 1) * half], p[r * half:(r + 1) * half],
+                                        n[r * half:(r + 1) * half]).clone() for r in range(2)])
+    rows, losses = [], []
     for r in range(2):
         sl = slice(r * half, (r + 1) * half)
-        loss, gr, gk = dp.forward_local(u[sl], p[sl], n[sl], world_size=2)
-        rows.append(gr.clone()); keys.append(gk.clone()); losses.append(loss.clone())
-    grads_dp = dp.backward_global(torch.cat(rows), torch.cat(keys), torch.full((1,), 0.5, device=DEV))
+        loss, gr = dp.forward_local(u[sl], p[sl], n[sl], all_keys=all_keys, rank=r, world_size=2)
+        rows.append(gr.clone()); losses.append(loss.clone())
+    grads_dp = dp.backward_global(torch.cat(rows), torch.full((1,), 0.5, device=DEV))
     assert abs(float(loss_w) - float((losses[0] + losses[1]) / 2)) < 1e-6
     assert set(grads_w) == set(grads_dp)
     for k in grads_w:

@@ -13,12 +13,13 @@ U_, P_, N_ = smp.sample_epoch()
 for W in (1, 2, 4, 8):
     scale = torch.full((1,), 1.0 / W, device="cuda:0")
     def step(i):
-        rows, keys = [], []
-        loss, gr, gk = model.forward_local(U_[i * B:(i + 1) * B], P_[i * B:(i + 1) * B], N_[i * B:(i + 1) * B], world_size=W)
-        # stand-in for the all-gather: W-1 other ranks' rows (different triplets, same values are irrelevant for timing)
-        all_rows = gr.repeat(W, 1) if W > 1 else gr
+        gk = model.batch_keys(U_[i * B:(i + 1) * B], P_[i * B:(i + 1) * B], N_[i * B:(i + 1) * B])
+        # stand-in for the all-gathers: W-1 other ranks' keys / rows (different nodes; values are irrelevant for timing)
         all_keys = torch.cat([gk] + [(gk + 977 * (r + 1)) % (ds.num_users + ds.num_items) for r in range(W - 1)]).to(torch.int32) if W > 1 else gk
-        grads = model.backward_global(all_rows, all_keys, scale)
+        loss, gr = model.forward_local(U_[i * B:(i + 1) * B], P_[i * B:(i + 1) * B], N_[i * B:(i + 1) * B], all_keys=all_keys,
+                                       rank=0, world_size=W)
+        all_rows = gr.repeat(W, 1) if W > 1 else gr
+        grads = model.backward_global(all_rows, scale)
         for name, p in model.named_parameters():
             p.grad = grads.get(name)
         opt.step()
