@@ -971,6 +971,141 @@ extern "C" int elimrec_propagate_folded(const elimrec_csr *A, int64_t U, int64_t
     return 0;
 }
 
+// ---- the same forward with the layer tables KEPT instead of accumulated (training steps that evaluate the
+// head at the batch's rows only): hop k writes X^k = A X^{k-1}; the layer means are formed where they are read
+// -- at the active rows (folded_rows) or, for the cached full tables, over all rows (folded_combine). Only what
+// involves the layer-0 table is summed in the hop epilogues (S01 = X^0 + X^1 on hop 1, N02 = X^0_u + X^2_u on
+// hop 2), because X^0 is the live embedding parameter and the cached tables must not see a later update of it.
+// Per step this drops most of the accumulator traffic of the fused epilogue (read + write of Out_0 and half of
+// Narrow on every hop). Requires L >= 2.
+namespace elimrec {
+constexpr int kMaxLayers = 8;
+struct LayerTables {
+    const float4 *s01;                 // [N x d]  X^0 + X^1
+    const float4 *n02;                 // [U x d]  X^0_u + X^2_u
+    const float4 *x[kMaxLayers + 1];   // x[k] = X^k, 1 <= k <= L
+};
+
+// means over the layers at one row, in the summation order of the fused epilogue:
+//   out0 = inv * (((X^0 + X^1) + X^2) + ... + X^L);  narrow = inv * sum over even k (user rows) / odd k (item rows)
+__device__ __forceinline__ void layer_means(const LayerTables &t, int L, int64_t r, bool user, int d4, int c, float inv,
+                                            float4 &out0, float4 &nar) {
+    float4 s = t.s01[r * d4 + c];
+    float4 n = user ? t.n02[r * d4 + c] : t.x[1][r * d4 + c];
+    for (int k = 2; k <= L; ++k) {
+        const float4 v = t.x[k][r * d4 + c];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        if (k > 2 && ((k & 1) == 0) == user) { n.x = v.x + n.x; n.y = v.y + n.y; n.z = v.z + n.z; n.w = v.w + n.w; }
+    }
+    out0 = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
+    nar = make_float4(n.x * inv, n.y * inv, n.z * inv, n.w * inv);
+}
+
+__global__ __launch_bounds__(256) void folded_rows_kernel(LayerTables t, int L, int64_t U, int d4,
+                                                          const int32_t *__restrict__ rows,
+                                                          const int32_t *__restrict__ count, int64_t n, float inv,
+                                                          float *__restrict__ out_rows, int64_t ldo,
+                                                          float *__restrict__ narrow) {
+    const int64_t s = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int sub = threadIdx.x & 15;
+    const int64_t lim = count ? min((int64_t)*count, n) : n;
+    if (s >= lim) return;
+    const int64_t r = rows[s];
+    for (int c = sub; c < d4; c += 16) {
+        float4 o, nr;
+        layer_means(t, L, r, r < U, d4, c, inv, o, nr);
+        *reinterpret_cast<float4 *>(out_rows + s * ldo + 4 * c) = o;
+        *reinterpret_cast<float4 *>(narrow + r * (int64_t)d4 * 4 + 4 * c) = nr;
+    }
+}
+
+__global__ __launch_bounds__(256) void folded_combine_kernel(LayerTables t, int L, int64_t U, int64_t N, int d4, float inv,
+                                                             float *__restrict__ out0, int64_t ldo,
+                                                             float *__restrict__ narrow) {
+    const int64_t total = N * d4;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / d4;
+        const int c = (int)(e - r * d4);
+        float4 o, nr;
+        layer_means(t, L, r, r < U, d4, c, inv, o, nr);
+        *reinterpret_cast<float4 *>(out0 + r * ldo + 4 * c) = o;
+        *reinterpret_cast<float4 *>(narrow + e * 4) = nr;
+    }
+}
+}  // namespace elimrec
+
+extern "C" size_t elimrec_layer_tables_workspace(int64_t N, int d, int L) {
+    return (size_t)(L + 2) * align_up((size_t)N * d * sizeof(float), 256);
+}
+
+static int layer_tables(int64_t N, int d, int L, const void *d_workspace, size_t workspace_bytes, LayerTables &t,
+                        const char *who) {
+    if (!(d_workspace && d > 0 && d % 4 == 0 && L >= 2 && L <= kMaxLayers)) {
+        set_error("%s: bad arguments (2 <= L <= %d, d %% 4 == 0)", who, kMaxLayers);
+        return ELIMREC_E_BADARG;
+    }
+    if (workspace_bytes < elimrec_layer_tables_workspace(N, d, L)) {
+        set_error("%s: workspace too small", who);
+        return ELIMREC_E_WORKSPACE;
+    }
+    const size_t tb = align_up((size_t)N * d * sizeof(float), 256);
+    const char *ws = (const char *)d_workspace;
+    t.s01 = (const float4 *)ws;
+    t.n02 = (const float4 *)(ws + tb);
+    t.x[0] = nullptr;
+    for (int k = 1; k <= kMaxLayers; ++k) t.x[k] = k <= L ? (const float4 *)(ws + (size_t)(k + 1) * tb) : nullptr;
+    return 0;
+}
+
+extern "C" int elimrec_propagate_layers(const elimrec_csr *A, int64_t U, int d, int L, const float *d_X0,
+                                        void *d_workspace, size_t workspace_bytes, void *stream) {
+    ELIMREC_REQUIRE(A && d_X0, "propagate_layers: null pointer");
+    ELIMREC_REQUIRE(U >= 0 && U <= A->n_rows, "propagate_layers: bad U");
+    LayerTables t;
+    int rc = layer_tables(A->n_rows, d, L, d_workspace, workspace_bytes, t, "propagate_layers");
+    if (rc) return rc;
+    for (int k = 1; k <= L; ++k) {
+        const float *xin = k == 1 ? d_X0 : (const float *)t.x[k - 1];
+        // hop 1 also leaves S01 = X^1 + X^0; hop 2 leaves N02 = X^2_u + X^0_u on the user rows
+        HalfArgs a = half_args(d / 4, xin, nullptr, (float *)t.x[k], k == 1 ? d_X0 : nullptr, nullptr, nullptr, nullptr, 0,
+                               k == 1 ? (float *)t.s01 : nullptr, 1.0f);
+        if (k == 2) {
+            a.acc2_lo = 0; a.acc2_hi = U;
+            a.Acc2Out = (float4 *)t.n02;
+            a.Acc2In = (const float4 *)d_X0;
+            a.acc2_scale = 1.0f;
+        }
+        if ((rc = launch_half(A, a, 0, (hipStream_t)stream))) return rc;
+    }
+    return 0;
+}
+
+extern "C" int elimrec_folded_rows(const void *d_layers, size_t layers_bytes, int64_t U, int64_t I, int d, int L,
+                                   const int32_t *d_rows, const int32_t *d_count, int64_t n, float *d_out_rows,
+                                   int64_t ldo, float *d_narrow, void *stream) {
+    ELIMREC_REQUIRE(d_rows && d_out_rows && d_narrow && ldo % 4 == 0 && ldo >= d, "folded_rows: bad arguments");
+    LayerTables t;
+    int rc = layer_tables(U + I, d, L, d_layers, layers_bytes, t, "folded_rows");
+    if (rc) return rc;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(folded_rows_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, t, L, U, d / 4,
+                       d_rows, d_count, n, 1.0f / (float)(L + 1), d_out_rows, ldo, d_narrow);
+    ELIMREC_LAUNCH_CHECK("folded_rows");
+    return 0;
+}
+
+extern "C" int elimrec_folded_combine(const void *d_layers, size_t layers_bytes, int64_t U, int64_t I, int d, int L,
+                                      float *d_Out0, int64_t ldo, float *d_narrow, void *stream) {
+    ELIMREC_REQUIRE(d_Out0 && d_narrow && ldo % 4 == 0 && ldo >= d, "folded_combine: bad arguments");
+    LayerTables t;
+    int rc = layer_tables(U + I, d, L, d_layers, layers_bytes, t, "folded_combine");
+    if (rc) return rc;
+    hipLaunchKernelGGL(folded_combine_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, t, L, U, U + I, d / 4,
+                       1.0f / (float)(L + 1), d_Out0, ldo, d_narrow);
+    ELIMREC_LAUNCH_CHECK("folded_combine");
+    return 0;
+}
+
 namespace elimrec {
 // SrcA[node] = node < U ? H : G ; SrcB[node] = node < U ? G : H, for the active nodes, from the slot-major dOut rows
 // (G = column block 0, H = sum of the M blocks); also sets the row bitmap (pre-zeroed).

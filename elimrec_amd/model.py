@@ -157,7 +157,7 @@ class EliMRec(BasicModel):
         # Out, embedding_*_after_GCN, s_dense_*) are row-wise, and the loss reads them at the batch's 3B rows only,
         # so a training step evaluates them there; the full cached tables predict() reads (:98-99) are filled in on
         # first use from the graph tables of that same forward and a copy of the (pre-update) projection weights.
-        self._lazy = self._folded and str(opt("head_rows", "batch")) != "all"
+        self._lazy = self._folded and self.n_layers >= 2 and str(opt("head_rows", "batch")) != "all"
         if self._bipartite:
             P, Q = adj[:U, U:].tocsr(), adj[U:, :U].tocsr()
             self._register_csr("bipP", P)
@@ -295,6 +295,9 @@ class EliMRec(BasicModel):
                     ws["SrcA"] = torch.empty(N, d, **f32)          # adjoint source tables (active rows only)
                     ws["SrcB"] = torch.empty(N, d, **f32)
                     ws["fold_ws"] = torch.empty(ops.folded_workspace(N, d), dtype=torch.uint8, device=dev)
+                    if self._lazy:
+                        ws["layers"] = torch.empty(ops.layer_tables_workspace(N, d, self.n_layers), dtype=torch.uint8,
+                                                   device=dev)
                     self._fold_constants(ws)
                     # [E_u ; E_i] and its gradient as ONE [N x d] table: the two embeddings are the first two
                     # tensors of the flat parameter / gradient buffers, back to back
@@ -435,7 +438,9 @@ class EliMRec(BasicModel):
     def _ensure_tables(self):
         if self._tables_dirty:
             self._tables_dirty = False
-            self._full_tables(self._ws, self._ws["snap_views"])
+            ws, d = self._ws, self.latent_dim
+            ops.folded_combine(ws["layers"], self.num_users, self.num_items, d, self.n_layers, ws["Out"][:, :d], ws["Narrow"])
+            self._full_tables(ws, ws["snap_views"])
 
     @torch.no_grad()
     def _compute_tables(self, ws, batch=None):
@@ -446,18 +451,19 @@ class EliMRec(BasicModel):
         X0 = ws.get("X0")
         if self._folded:
             # id table + shared user part through the graph at d columns; feature blocks from the folded constants
-            self._timed(lambda: ops.propagate_folded(self._csr("adj"), U, I, d, self.n_layers, ws["X0d"], Out[:, :d],
-                                                     ws["Narrow"], ws["fold_ws"]))
             W = ws["live_views"]
             if batch is None or not self._lazy:
+                self._timed(lambda: ops.propagate_folded(self._csr("adj"), U, I, d, self.n_layers, ws["X0d"], Out[:, :d],
+                                                         ws["Narrow"], ws["fold_ws"]))
                 self._tables_dirty = False
                 self._full_tables(ws, W)
                 return
+            self._timed(lambda: ops.propagate_layers(self._csr("adj"), U, d, self.n_layers, ws["X0d"], ws["layers"]))
             # the batch's active nodes (ws['active_rows'], planned before the forward): Out and Y at those rows only
             n = self._plan_n
             act, seg, OutAct, YAct = ws["active_rows"][:n], ws["seg_info"], ws["OutAct"][:n], ws["YAct"][:n]
             ws["snap"].copy_(ws["flat_param"][ws["tail_off"]:])
-            ops.gather_rows(Out[:, :d], act, OutAct[:, :d], count=seg[0:1])
+            ops.folded_rows(ws["layers"], U, I, d, self.n_layers, act, seg[0:1], OutAct[:, :d], ws["Narrow"])
             ops.linear_fwd_batched(self._fold_problems(ws, W, OutAct, act, seg[6:8]))
             wu, wi = self._fusion_weights(W)
             bu, bi = W["embedding_user_after_GCN.bias"], W["embedding_item_after_GCN.bias"]

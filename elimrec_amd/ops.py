@@ -271,6 +271,33 @@ def propagate_folded(A, U, I, d, L, X0, out0, narrow, workspace):
                                                     _stream()), "propagate_folded")
 
 
+def layer_tables_workspace(N, d, L):
+    return int(_lib.load().elimrec_layer_tables_workspace(N, d, L))
+
+
+def propagate_layers(A, U, d, L, X0, layers):
+    """X^k = A X^(k-1), k = 1..L, kept in `layers` (uint8 workspace) with the two partial sums that involve X^0."""
+    assert X0.is_contiguous() and X0.shape[1] == d
+    _lib.check(_lib.load().elimrec_propagate_layers(A.desc(), U, d, L, _dev(X0, "X0"), _dev(layers, "layers", torch.uint8),
+                                                    layers.numel(), _stream()), "propagate_layers")
+
+
+def folded_rows(layers, U, I, d, L, rows, count, out_rows, narrow):
+    """Layer means at `rows`: out_rows[s, 0:d] (a window of a wider compact table) and narrow[rows[s]]."""
+    o, ldo = _rowmajor(out_rows, "out_rows")
+    assert narrow.is_contiguous() and narrow.shape == (U + I, d) and out_rows.shape == (rows.numel(), d)
+    _lib.check(_lib.load().elimrec_folded_rows(_dev(layers, "layers", torch.uint8), layers.numel(), U, I, d, L,
+                                               _dev(rows, "rows", torch.int32), _dev(count, "count", torch.int32),
+                                               rows.numel(), o, ldo, _dev(narrow, "narrow"), _stream()), "folded_rows")
+
+
+def folded_combine(layers, U, I, d, L, out0, narrow):
+    o, ldo = _rowmajor(out0, "out0")
+    assert narrow.is_contiguous() and narrow.shape == (U + I, d) and out0.shape == (U + I, d)
+    _lib.check(_lib.load().elimrec_folded_combine(_dev(layers, "layers", torch.uint8), layers.numel(), U, I, d, L, o, ldo,
+                                                  _dev(narrow, "narrow"), _stream()), "folded_combine")
+
+
 def propagate_folded_bwd(AT, U, I, d, M, L, dOutR, active_rows, seg_info, srcA, srcB, grad, workspace):
     for t in (dOutR, srcA, srcB, grad):
         assert t.is_contiguous()

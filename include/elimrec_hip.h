@@ -212,6 +212,20 @@ size_t elimrec_folded_workspace(int64_t N, int d);
 int elimrec_propagate_folded(const elimrec_csr *A, int64_t U, int64_t I, int d, int L, const float *d_X0,
                              float *d_Out0, int64_t ldo, float *d_narrow, void *d_workspace,
                              size_t workspace_bytes, void *stream);
+/* The same forward for training steps that read Out only at the batch's rows: hop k just writes the layer table
+ * X^k = A X^(k-1) into the workspace (plus S01 = X^0 + X^1 on hop 1 and N02 = X^0_u + X^2_u on hop 2, the only sums
+ * that involve the live parameter table X^0), and the layer means of compute_graph (:238-248) are formed where they
+ * are read: elimrec_folded_rows at the active rows (d_out_rows[s, 0:d] = Out0[rows[s]], d_narrow[rows[s]] = narrow
+ * of that node, s < min(*d_count, n)), elimrec_folded_combine over all rows (what elimrec_propagate_folded would
+ * have left in d_Out0 / d_narrow, bit for bit). 2 <= L <= 8. workspace: elimrec_layer_tables_workspace bytes. */
+size_t elimrec_layer_tables_workspace(int64_t N, int d, int L);
+int elimrec_propagate_layers(const elimrec_csr *A, int64_t U, int d, int L, const float *d_X0, void *d_workspace,
+                             size_t workspace_bytes, void *stream);
+int elimrec_folded_rows(const void *d_layers, size_t layers_bytes, int64_t U, int64_t I, int d, int L,
+                        const int32_t *d_rows, const int32_t *d_count, int64_t n, float *d_out_rows, int64_t ldo,
+                        float *d_narrow, void *stream);
+int elimrec_folded_combine(const void *d_layers, size_t layers_bytes, int64_t U, int64_t I, int d, int L, float *d_Out0,
+                           int64_t ldo, float *d_narrow, void *stream);
 int elimrec_propagate_folded_bwd(const elimrec_csr *AT, int64_t U, int64_t I, int d, int M, int L,
                                  const float *d_dOutR, const int32_t *d_active_rows, const int32_t *d_seg_info,
                                  int64_t n_max, float *d_SrcA, float *d_SrcB, float *d_grad, void *d_workspace,
