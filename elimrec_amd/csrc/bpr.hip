@@ -142,7 +142,8 @@ __global__ void publish_ranges_kernel(int32_t *__restrict__ seg_info) {
 // key list. One launch of 1024 threads replaces iota + radix sort (6 launches) + heads + scan (2) + finalize +
 // publish.
 constexpr int PLAN_T = 1024;
-constexpr int PLAN_LONG = 32;
+constexpr int PLAN_LONG = 8;       // member lists longer than this are rank-sorted by a wave (or the workgroup)
+constexpr int PLAN_HUGE = 512;
 
 __device__ __forceinline__ int32_t ld_l2(const int32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -187,10 +188,10 @@ __global__ __launch_bounds__(PLAN_T) void segment_plan_kernel(const int32_t *__r
     const int nw = (key_space + 31) >> 5;
     uint32_t *bm = plan_lds, *pre = plan_lds + nw;
     int *wave_sums = (int *)(pre + nw);               // [16]
-    int *long_list = wave_sums + 16;                  // [1 + 255]: count, then segment ids of long member lists
+    int *long_list = wave_sums + 16;                  // [1 + 1023]: count, then segment ids of long member lists
     int32_t *cnt, *seg_start, *members, *tmp;
     if constexpr (IN_LDS) {
-        cnt = (int32_t *)(long_list + 256);           // [PLAN_LDS_N]; doubles as the rank-sort scratch at the end
+        cnt = (int32_t *)(long_list + 1024);           // [PLAN_LDS_N]; doubles as the rank-sort scratch at the end
         seg_start = cnt + PLAN_LDS_N;                 // [PLAN_LDS_N + 1]
         members = seg_start + PLAN_LDS_N + 1;         // [PLAN_LDS_N]
         tmp = cnt;
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(PLAN_T) void segment_plan_kernel(const int32_t *__r
         cnt[sgm] = 0;
         if (c > PLAN_LONG) {
             const int q = atomicAdd(&long_list[0], 1);
-            if (q < 255) long_list[1 + q] = sgm;
+            if (q < 1023) long_list[1 + q] = sgm;
         }
         run += c;
     }
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(PLAN_T) void segment_plan_kernel(const int32_t *__r
     }
     __syncthreads();
     const int n_long = long_list[0];
-    const bool all_serial = n_long > 255;             // more long lists than the table holds: sort them serially too
+    const bool all_serial = n_long > 1023;             // more long lists than the table holds: sort them serially too
     for (int sgm = tid; sgm < n_act; sgm += PLAN_T) {
         const int b = ld(seg_start + sgm), e = ld(seg_start + sgm + 1);
         if (e - b > PLAN_LONG && !all_serial) continue;
@@ -301,15 +302,39 @@ __global__ __launch_bounds__(PLAN_T) void segment_plan_kernel(const int32_t *__r
         }
     }
     if (!all_serial) {
-        for (int li = 0; li < n_long; ++li) {         // cooperative rank sort of one long list at a time
+        // rank sort (slots are distinct, so the ranks are a permutation): one wave per list, lists of more than
+        // PLAN_HUGE members by the whole workgroup. tmp[b, e) is private to the list.
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int li = wave; li < n_long; li += PLAN_T / 64) {
             const int sgm = long_list[1 + li];
             const int b = ld(seg_start + sgm), e = ld(seg_start + sgm + 1);
+            if (e - b > PLAN_HUGE) continue;
+            for (int i = b + lane; i < e; i += 64) {
+                const int v = ld(members + i);
+                int r = 0;
+                for (int q = b; q < e; ++q) r += ld(members + q) < v;
+                tmp[b + r] = v;
+            }
+            if constexpr (IN_LDS) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            } else {
+                __threadfence();                      // the scratch is in global memory: through L2
+                __builtin_amdgcn_wave_barrier();
+            }
+            for (int i = b + lane; i < e; i += 64) members[i] = ld(tmp + i);
+        }
+        for (int li = 0; li < n_long; ++li) {
+            const int sgm = long_list[1 + li];
+            const int b = ld(seg_start + sgm), e = ld(seg_start + sgm + 1);
+            if (e - b <= PLAN_HUGE) continue;         // uniform over the workgroup
             __syncthreads();
             for (int i = b + tid; i < e; i += PLAN_T) {
                 const int v = ld(members + i);
                 int r = 0;
                 for (int q = b; q < e; ++q) r += ld(members + q) < v;
-                tmp[b + r] = v;                       // slots are distinct: ranks are a permutation
+                tmp[b + r] = v;
             }
             __syncthreads();
             for (int i = b + tid; i < e; i += PLAN_T) members[i] = ld(tmp + i);
@@ -708,7 +733,7 @@ extern "C" int elimrec_segment_plan(const int32_t *d_keys, int64_t n, int32_t sp
     hipStream_t s = (hipStream_t)stream;
     if (key_space > 0 && key_space <= plan_fast_max_keys() && n <= (1 << 20)) {
         const size_t nw = (size_t)((key_space + 31) / 32);
-        const size_t base = (2 * nw + 16 + 256) * sizeof(uint32_t);
+        const size_t base = (2 * nw + 16 + 1024) * sizeof(uint32_t);
         const size_t lds_arrays = base + (size_t)(3 * PLAN_LDS_N + 1) * sizeof(int32_t);
         const bool in_lds = n <= PLAN_LDS_N && lds_arrays <= 160 * 1024;
         const size_t lds = in_lds ? lds_arrays : base;

@@ -329,12 +329,10 @@ class EliMRec(BasicModel):
         ws["seg_info"] = torch.zeros(8, dtype=torch.int32, device=dev)
         ws["plan_ws"] = torch.empty(max(ops.segment_plan_workspace(n3), 1), dtype=torch.uint8, device=dev)
         shapes = [(n3, d, C), (n3, d, C)] + [(n3, d, d)] * self.S
-        ws["bwd_w_rows"] = torch.empty(max(ops.linear_bwd_w_batched_workspace(shapes), 1), dtype=torch.uint8, device=dev)
-        if self._folded:
+        if self._folded:    # the folded feature projections' weight gradients ride in the same launch
             ws["dOutR"] = torch.empty(n3, C, **f32)                # dLoss/dOut rows in slot order
-            shapes = [(n3, d, getattr(self, m + "_feat").shape[1]) for m in self._mods] + [(n3, d, 4)] * len(self._mods)
-            ws["bwd_w_fold"] = torch.empty(max(ops.linear_bwd_w_batched_workspace(shapes), 1), dtype=torch.uint8,
-                                           device=dev)
+            shapes += [(n3, d, getattr(self, m + "_feat").shape[1]) for m in self._mods]
+        ws["bwd_w_rows"] = torch.empty(max(ops.linear_bwd_w_batched_workspace(shapes), 1), dtype=torch.uint8, device=dev)
         self._ws, self._ws_key = ws, key
         return ws
 
@@ -614,6 +612,14 @@ class EliMRec(BasicModel):
             problems.append(dict(A=dY[:, (h + 1) * d:(h + 2) * d], B=out_rows[:, (h + 1) * d:(h + 2) * d],
                                  out=gv[name + ".weight"], row_index=out_index, rng=seg[6:8], colsum=gv[name + ".bias"]))
             grads[name + ".weight"], grads[name + ".bias"] = gv[name + ".weight"], gv[name + ".bias"]
+        if self._folded:
+            # feature projections: Out_m = S_m W_m^T + c b_m^T + (shared part)  =>  dW_m = dOut_m^T S_m over the
+            # active rows only, db_m = dOut_m^T c  (the dense I-row contraction of the unfolded path disappears)
+            fold = ws["fold"]
+            for k, m in enumerate(self._mods):
+                problems.append(dict(A=dOutR[:, (k + 1) * d:(k + 2) * d], B=fold[m], out=gv[m + "_dense.weight"],
+                                     row_index=act, rng=seg[6:8], colsum=gv[m + "_dense.bias"], colsum_weight=fold["c"]))
+                grads[m + "_dense.weight"], grads[m + "_dense.bias"] = gv[m + "_dense.weight"], gv[m + "_dense.bias"]
         ops.linear_bwd_w_batched(problems, ws["bwd_w_rows"])
         if not concat:      # 'mean' fusion: fold the M replicated column blocks back into the [d x d] weight
             for name, gw in fused_tmp.items():
@@ -625,16 +631,6 @@ class EliMRec(BasicModel):
             self._timed(lambda: ops.propagate_folded_bwd(AT, U, I, d, M, self.n_layers, dOutR, act, seg, ws["SrcA"],
                                                          ws["SrcB"], ws["gX0d"], ws["fold_ws"]))
             grads["embedding_user.weight"], grads["embedding_item.weight"] = gu, gi
-            # feature projections: Out_m = S_m W_m^T + c b_m^T + (shared part)  =>  dW_m = dOut_m^T S_m over the
-            # active rows only, db_m = dOut_m^T c  (the dense I-row contraction of the unfolded path disappears)
-            fold = ws["fold"]
-            problems = []
-            for k, m in enumerate(self._mods):
-                blk = dOutR[:, (k + 1) * d:(k + 2) * d]
-                problems.append(dict(A=blk, B=fold[m], out=gv[m + "_dense.weight"], row_index=act, rng=seg[6:8],
-                                     colsum=gv[m + "_dense.bias"], colsum_weight=fold["c"]))
-                grads[m + "_dense.weight"], grads[m + "_dense.bias"] = gv[m + "_dense.weight"], gv[m + "_dense.bias"]
-            ops.linear_bwd_w_batched(problems, ws["bwd_w_fold"])
             return grads
         if self._bipartite:
             ops.blocksum_rows(G0, act, seg, d, M, ws["H"])
