@@ -134,8 +134,42 @@ def load():
         fn.argtypes = args
     if lib.elimrec_abi_version() != 1:
         raise HipLibraryError("elimrec_amd: ABI version mismatch")
-    _lib = lib
-    return lib
+    _lib = _Recording(lib)
+    return _lib
+
+
+class _Recording(object):
+    """The bound library with an optional call recorder: while `record(list)` is active every entry point that
+    returns an error code appends (function, converted arguments) to the list before it runs. A recorded list is a
+    fixed sequence of launches on fixed buffers; `replay` re-issues it without the Python that built the
+    arguments (elimrec_amd.model uses it for the step's regions -- the host side of a 25-launch step otherwise
+    costs as much as the GPU side)."""
+
+    def __init__(self, lib):
+        self._cdll = lib
+        self._rec = None
+        for name, (res, _) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            setattr(self, name, self._wrap(fn) if res is c_i32 and name != "elimrec_abi_version" else fn)
+
+    def _wrap(self, fn):
+        def call(*args):
+            if self._rec is not None:
+                self._rec.append((fn, args))
+            return fn(*args)
+        return call
+
+
+def record(calls):
+    """Start (calls = list) or stop (calls = None) recording the C-ABI calls issued through load()."""
+    load()._rec = calls
+
+
+def replay(calls, what):
+    for fn, args in calls:
+        rc = fn(*args)
+        if rc:
+            check(rc, what)
 
 
 def check(rc, what):

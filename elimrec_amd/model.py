@@ -15,13 +15,15 @@ way back segment_reduce_rows -> head_bwd_input / linear_bwd_w -> propagate (A^T)
 linear_bwd_w. Propagation is linear, so nothing of the forward pass is kept for backward except
 Out and Y.
 """
+import os
+
 import numpy as np
 import scipy.sparse as sp
 import torch
 from torch import nn
 from torch.nn import functional as F
 
-from . import ops
+from . import _lib, ops
 from .basic_model import BasicModel
 from .logger import Logger
 
@@ -175,6 +177,10 @@ class EliMRec(BasicModel):
         nn.init.xavier_uniform_(self.s_dense_a.weight)
         nn.init.xavier_uniform_(self.s_dense_t.weight)
         self._param_names = [n for n, _ in self.named_parameters()]
+        # step regions: recorded C-ABI call lists, or hipGraphs with --hip_graphs=1 (CLI-only; see _region)
+        self._use_graphs = str(opt("hip_graphs", os.environ.get("ELIMREC_GRAPHS", "0"))) == "1"
+        self._use_replay = os.environ.get("ELIMREC_REPLAY", "1") != "0"
+        self._regions = {}
         self._ws = None
         self._ws_key = None
 
@@ -280,7 +286,8 @@ class EliMRec(BasicModel):
         N, C, Cy, d = self.num_users + self.num_items, self.C, self.Cy, self.latent_dim
         f32 = dict(dtype=torch.float32, device=dev)
         ws = self._ws if (self._ws is not None and self._ws_key[0] == key[0]) else {}
-        if "X0" not in ws:
+        self._ws_gen = getattr(self, "_ws_gen", 0) + 1       # recorded regions hold these buffers' addresses
+        if "flat_param" not in ws:                          # everything that does not depend on the batch size
             self._flatten_parameters(ws)
             names = ("Out",) if self._folded else (("X0", "Out") if self._bipartite else ("X0", "T0", "T1", "Out", "G"))
             for name in names:
@@ -441,38 +448,17 @@ class EliMRec(BasicModel):
             self._full_tables(ws, ws["snap_views"])
 
     @torch.no_grad()
-    def _compute_tables(self, ws, batch=None):
-        """compute() + gcn_cf() (:228-272,144-153): fills ws['Out'] and ws['Y']. With batch = (users, pos, neg) in
-        "batch" mode only those rows are evaluated (ws['OutC'], ws['YC']); the full tables follow on demand."""
+    def _compute_tables(self, ws):
+        """compute() + gcn_cf() (:228-272,144-153): fills ws['Out'] and ws['Y'] over all rows."""
         U, I, d, M, C = self.num_users, self.num_items, self.latent_dim, self.M, self.C
         Out, Y = ws["Out"], ws["Y"]
         X0 = ws.get("X0")
         if self._folded:
             # id table + shared user part through the graph at d columns; feature blocks from the folded constants
-            W = ws["live_views"]
-            if batch is None or not self._lazy:
-                self._timed(lambda: ops.propagate_folded(self._csr("adj"), U, I, d, self.n_layers, ws["X0d"], Out[:, :d],
-                                                         ws["Narrow"], ws["fold_ws"]))
-                self._tables_dirty = False
-                self._full_tables(ws, W)
-                return
-            self._timed(lambda: ops.propagate_layers(self._csr("adj"), U, d, self.n_layers, ws["X0d"], ws["layers"]))
-            # the batch's active nodes (ws['active_rows'], planned before the forward): Out and Y at those rows only
-            n = self._plan_n
-            act, seg, OutAct, YAct = ws["active_rows"][:n], ws["seg_info"], ws["OutAct"][:n], ws["YAct"][:n]
-            ws["snap"].copy_(ws["flat_param"][ws["tail_off"]:])
-            ops.folded_rows(ws["layers"], U, I, d, self.n_layers, act, seg[0:1], OutAct[:, :d], ws["Narrow"])
-            ops.linear_fwd_batched(self._fold_problems(ws, W, OutAct, act, seg[6:8]))
-            wu, wi = self._fusion_weights(W)
-            bu, bi = W["embedding_user_after_GCN.bias"], W["embedding_item_after_GCN.bias"]
-            none3 = (None, None, None)
-            head = [(OutAct, wu, bu, YAct[:, :d]) + none3 + (seg[2:4],), (OutAct, wi, bi, YAct[:, :d]) + none3 + (seg[4:6],)]
-            for h, m in enumerate(self._mods):
-                blk = slice((h + 1) * d, (h + 2) * d)
-                head.append((OutAct[:, blk], W["s_dense_%s.weight" % m], W["s_dense_%s.bias" % m], YAct[:, blk]) + none3
-                            + (seg[6:8],))
-            ops.linear_fwd_batched(head)
-            self._publish_cache(Y, dirty=True)
+            self._timed(lambda: ops.propagate_folded(self._csr("adj"), U, I, d, self.n_layers, ws["X0d"], Out[:, :d],
+                                                     ws["Narrow"], ws["fold_ws"]))
+            self._tables_dirty = False
+            self._full_tables(ws, ws["live_views"])
             return
         if self._bipartite:
             ops.copy_cols(self.embedding_item.weight, X0[U:, :d])          # XI block 0 = item id table
@@ -527,6 +513,79 @@ class EliMRec(BasicModel):
         self._cache = (Y[:U, :d], Y[U:, :d], s_embs)
         self._tables_dirty = dirty
 
+    # ------------------------------------------------------------------ hipGraph regions
+    def _region(self, name, key, fn):
+        """Run fn() -- a fixed sequence of launches on workspace buffers. The first run records the C-ABI calls it
+        makes (function + converted arguments); later runs with the same `key` re-issue that list without the
+        Python that built it: the step is some 25 launches of 5-50 us each, and issued one by one through the
+        tensor-level wrappers the host side costs as much as the GPU side. `key` names everything the launches
+        depend on besides buffer contents (sizes, pointers of caller-owned tensors, mode flags, the stream).
+        --hip_graphs=1 captures the region into a hipGraph instead (two eager runs, capture on the third); on this
+        stack graph replay adds ~12 us per graph launch and is slower than the re-issued list."""
+        if self.mm_fusion_mode != "concat" or not self._use_replay:   # 'mean' fusion mixes torch ops into the regions
+            return fn()
+        key = key + (ops._stream(),)
+        ent = self._regions.get(name)
+        if ent is None or ent[0] != key:
+            ent = self._regions[name] = [key, 0, None, None]
+        if ent[2] is not None:
+            if self._use_graphs:
+                ent[2].replay()
+            else:
+                _lib.replay(ent[2], name)
+            return ent[3]
+        if self._use_graphs:
+            ent[1] += 1
+            if ent[1] < 3:
+                return fn()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = fn()
+            ent[2], ent[3] = graph, out
+            graph.replay()                              # capturing does not execute
+            return out
+        calls = []
+        _lib.record(calls)
+        try:
+            out = fn()
+        finally:
+            _lib.record(None)
+        ent[2], ent[3] = calls, out
+        return out
+
+    @torch.no_grad()
+    def _forward_batch_rows(self, ws, all_keys, n, B, rank, grad_rows):
+        """The training forward in "batch" mode: layer tables through the graph, then everything after the graph at
+        the batch's active rows only (ws['OutAct'], ws['YAct']), then the loss rows and their gradient rows."""
+        U, I, d, L = self.num_users, self.num_items, self.latent_dim, self.n_layers
+        adj = self._csr("adj")
+        self._timed(lambda: self._region("fwd_hops", (self._ws_gen,),
+                                         lambda: ops.propagate_layers(adj, U, d, L, ws["X0d"], ws["layers"])))
+        bw = self._last_block_weights
+
+        def head():
+            act, seg, OutAct, YAct = ws["active_rows"][:n], ws["seg_info"], ws["OutAct"][:n], ws["YAct"][:n]
+            W = ws["live_views"]
+            # the plan depends on the indices only; the forward evaluates the head at the active rows it lists and
+            # the backward reduces the (gathered) gradient rows with it
+            ops.segment_plan(all_keys, U, U + I, act, seg, ws["slot_seg"][:n], ws["plan_ws"])
+            ops.copy_cols(ws["flat_param"][ws["tail_off"]:].view(1, -1), ws["snap"].view(1, -1))
+            ops.folded_rows(ws["layers"], U, I, d, L, act, seg[0:1], OutAct[:, :d], ws["Narrow"])
+            ops.linear_fwd_batched(self._fold_problems(ws, W, OutAct, act, seg[6:8]))
+            wu, wi = self._fusion_weights(W)
+            bu, bi = W["embedding_user_after_GCN.bias"], W["embedding_item_after_GCN.bias"]
+            none3 = (None, None, None)
+            problems = [(OutAct, wu, bu, YAct[:, :d]) + none3 + (seg[2:4],), (OutAct, wi, bi, YAct[:, :d]) + none3 + (seg[4:6],)]
+            for h, m in enumerate(self._mods):
+                blk = slice((h + 1) * d, (h + 2) * d)
+                problems.append((OutAct[:, blk], W["s_dense_%s.weight" % m], W["s_dense_%s.bias" % m], YAct[:, blk]) + none3
+                                + (seg[6:8],))
+            ops.linear_fwd_batched(problems)
+            ops.bpr_head_rows(YAct, ws["slot_seg"][3 * B * rank:3 * B * (rank + 1)], d, bw, ws["loss_rows"], grad_rows)
+
+        self._region("fwd_head", (self._ws_gen, all_keys.data_ptr(), n, B, rank, tuple(bw), grad_rows is not None), head)
+        self._publish_cache(ws["Y"], dirty=True)
+
     @torch.no_grad()
     def batch_keys(self, users, pos, neg):
         """int32 [3B] node ids of the triplet slots (3b: user, 3b+1: U + pos, 3b+2: U + neg) -- the rows the loss
@@ -551,20 +610,70 @@ class EliMRec(BasicModel):
         if n > ws["slot_seg"].numel():
             raise RuntimeError("workspace holds %d gradient rows, the gathered batch has %d" % (ws["slot_seg"].numel(), n))
         self._plan_n = n
-        ops.segment_plan(all_keys, self.num_users, self.num_users + self.num_items, ws["active_rows"][:n], ws["seg_info"],
-                         ws["slot_seg"][:n], ws["plan_ws"])
-        self._compute_tables(ws, batch=(users, pos, neg))
         self._last_block_weights = self._block_weights()
         grad_rows = ws["grad_rows"] if need_grad else None
         if self._lazy:
-            ops.bpr_head_rows(ws["YAct"], ws["slot_seg"][3 * B * rank:3 * B * (rank + 1)], self.latent_dim,
-                              self._last_block_weights, ws["loss_rows"], grad_rows)
+            self._forward_batch_rows(ws, all_keys, n, B, rank, grad_rows)
         else:
+            ops.segment_plan(all_keys, self.num_users, self.num_users + self.num_items, ws["active_rows"][:n], ws["seg_info"],
+                             ws["slot_seg"][:n], ws["plan_ws"])
+            self._compute_tables(ws)
             ops.bpr_head(ws["Y"], self.num_users, self.num_items, users, pos, neg, self.latent_dim,
                          self._last_block_weights, ws["loss_rows"], grad_rows, ws["keys_scratch"] if need_grad else None)
         loss = torch.empty((), dtype=torch.float32, device=self._device())
         ops.fixed_order_sum(ws["loss_rows"], loss)
         return loss
+
+    @torch.no_grad()
+    def _backward_batch_rows(self, ws, gscale, grad_rows, n):
+        """Backward of _forward_batch_rows: gradient rows -> active rows (the forward's plan) -> head and projection
+        gradients from the compact Out / dY rows -> adjoint propagation at d columns. Two hipGraph regions."""
+        U, I, d, M, C, S = self.num_users, self.num_items, self.latent_dim, self.M, self.C, self.S
+        dY, seg, act = ws["dY"][:n], ws["seg_info"], ws["active_rows"][:n]
+        dOutR, OutAct, gv, fold = ws["dOutR"][:n], ws["OutAct"][:n], ws["grad_views"], ws["fold"]
+        bw = self._last_block_weights
+        heads_on = [h for h in range(S) if bw[1 + h] != 0.0]     # heads switched off carry an all-zero gradient block
+        concat = self.mm_fusion_mode == "concat"
+        f32 = dict(dtype=torch.float32, device=self._device())
+        grads = {}
+
+        def head():
+            ops.segment_apply(grad_rows, seg, dY, ws["plan_ws"], scale=gscale)
+            wu, wi = self._fusion_weights()
+            head_ws = [getattr(self, "s_dense_" + m).weight for m in self._mods]
+            ops.head_bwd_input(dY, act, seg, U, d, C, [h + 1 for h in range(S)], wu, wi, head_ws, 1.0, None, compact=dOutR)
+            # fusion Linears: dW = dY_f^T . Out[active rows], user slots / item slots separately
+            problems, fused_tmp = [], {}
+            for name, rng in (("embedding_user_after_GCN", seg[2:4]), ("embedding_item_after_GCN", seg[4:6])):
+                gw = gv[name + ".weight"] if concat else torch.empty(d, C, **f32)
+                fused_tmp[name] = gw
+                problems.append(dict(A=dY[:, :d], B=OutAct, out=gw, rng=rng, colsum=gv[name + ".bias"]))
+                grads[name + ".weight"], grads[name + ".bias"] = gv[name + ".weight"], gv[name + ".bias"]
+            for h in heads_on:
+                name, blk = "s_dense_" + self._mods[h], slice((h + 1) * d, (h + 2) * d)
+                problems.append(dict(A=dY[:, blk], B=OutAct[:, blk], out=gv[name + ".weight"], rng=seg[6:8],
+                                     colsum=gv[name + ".bias"]))
+                grads[name + ".weight"], grads[name + ".bias"] = gv[name + ".weight"], gv[name + ".bias"]
+            # feature projections: Out_m = S_m W_m^T + c b_m^T + (shared part)  =>  dW_m = dOut_m^T S_m over the
+            # active rows only, db_m = dOut_m^T c
+            for k, m in enumerate(self._mods):
+                problems.append(dict(A=dOutR[:, (k + 1) * d:(k + 2) * d], B=fold[m], out=gv[m + "_dense.weight"],
+                                     row_index=act, rng=seg[6:8], colsum=gv[m + "_dense.bias"], colsum_weight=fold["c"]))
+                grads[m + "_dense.weight"], grads[m + "_dense.bias"] = gv[m + "_dense.weight"], gv[m + "_dense.bias"]
+            ops.linear_bwd_w_batched(problems, ws["bwd_w_rows"])
+            if not concat:  # 'mean' fusion: fold the M replicated column blocks back into the [d x d] weight
+                for name, gw in fused_tmp.items():
+                    gv[name + ".weight"].copy_(gw.view(d, M, d).sum(1) / M)
+            return dict(grads)
+
+        key = (self._ws_gen, grad_rows.data_ptr(), gscale.data_ptr(), n, tuple(bw))
+        grads = dict(self._region("bwd_head", key, head))
+        AT = self._csr("adj" if self._adj_symmetric else "adjT")
+        self._timed(lambda: self._region("bwd_hops", (self._ws_gen, n),
+                                         lambda: ops.propagate_folded_bwd(AT, U, I, d, M, self.n_layers, dOutR, act, seg,
+                                                                          ws["SrcA"], ws["SrcB"], ws["gX0d"], ws["fold_ws"])))
+        grads["embedding_user.weight"], grads["embedding_item.weight"] = gv["embedding_user.weight"], gv["embedding_item.weight"]
+        return grads
 
     @torch.no_grad()
     def _backward_hip(self, gscale, grad_rows=None):
@@ -578,6 +687,8 @@ class EliMRec(BasicModel):
         n_rows = grad_rows.shape[0]
         if n_rows != self._plan_n:
             raise RuntimeError("backward got %d gradient rows, the forward planned %d" % (n_rows, self._plan_n))
+        if self._lazy:
+            return self._backward_batch_rows(ws, gscale, grad_rows, n_rows)
         dY, seg, act = ws["dY"][:n_rows], ws["seg_info"], ws["active_rows"][:n_rows]
         ops.segment_apply(grad_rows, seg, dY, ws["plan_ws"], scale=gscale)
         bw = self._last_block_weights
@@ -596,8 +707,6 @@ class EliMRec(BasicModel):
         grads = {}
         f32 = dict(dtype=torch.float32, device=dev)
         out_rows, out_index = ws["Out"], act
-        if self._lazy:      # Out at the active nodes: the forward's compact rows
-            out_rows, out_index = ws["OutAct"][:n_rows], None
         # fusion Linears: dW = dY_f^T . Out[active rows], user slots / item slots separately
         gv = ws["grad_views"]
         concat = self.mm_fusion_mode == "concat"
