@@ -76,7 +76,7 @@ SIGNATURES = {
     "elimrec_folded_rows": (c_i32, [c_ptr, c_size, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr]),
     "elimrec_folded_combine": (c_i32, [c_ptr, c_size, c_i64, c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
     "elimrec_propagate_folded_bwd": (c_i32, [c_csr, c_i64, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_ptr,
-                                             c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+                                             c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "elimrec_block_spmm": (c_i32, [c_csr, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr]),
     "elimrec_blocksum_rows": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr]),
     "elimrec_triplet_rows": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr]),
@@ -88,7 +88,10 @@ SIGNATURES = {
     "elimrec_sum": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr]),
     "elimrec_segment_reduce_workspace": (c_size, [c_i64]),
     "elimrec_segment_plan_workspace": (c_size, [c_i64]),
-    "elimrec_segment_plan": (c_i32, [c_ptr, c_i64, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "elimrec_segment_plan": (c_i32, [c_ptr, c_i64, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "elimrec_segment_apply_head_bwd": (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_i64, c_i32,
+                                               c_i32, c_i32, ctypes.POINTER(c_i32), c_ptr, c_ptr, ctypes.POINTER(c_ptr), c_ptr,
+                                               c_ptr]),
     "elimrec_segment_apply": (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "elimrec_segment_reduce_rows": (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "elimrec_head_bwd_input": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i32, c_i32, c_i32,

@@ -183,7 +183,8 @@ __global__ __launch_bounds__(PLAN_T) void segment_plan_kernel(const int32_t *__r
                                                               int split_key, int32_t *__restrict__ active_rows,
                                                               int32_t *__restrict__ seg_info,
                                                               int32_t *__restrict__ slot_seg, int32_t *g_cnt,
-                                                              int32_t *g_seg_start, int32_t *g_members, int32_t *g_tmp) {
+                                                              int32_t *g_seg_start, int32_t *g_members, int32_t *g_tmp,
+                                                              uint32_t *__restrict__ key_bitmap) {
     extern __shared__ uint32_t plan_lds[];
     const int nw = (key_space + 31) >> 5;
     uint32_t *bm = plan_lds, *pre = plan_lds + nw;
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(PLAN_T) void segment_plan_kernel(const int32_t *__r
     for (int w = w0; w < w1; ++w) {
         pre[w] = (uint32_t)run;
         uint32_t bits = bm[w];
+        if (key_bitmap) key_bitmap[w] = bits;
         while (bits) {
             const int b = __ffs(bits) - 1;
             active_rows[run] = w * 32 + b;
@@ -354,6 +356,11 @@ __global__ __launch_bounds__(PLAN_T) void segment_plan_kernel(const int32_t *__r
         seg_info[0] = n_act; seg_info[1] = n_lo;
         seg_info[2] = 0; seg_info[3] = n_lo; seg_info[4] = n_lo; seg_info[5] = n_act; seg_info[6] = 0; seg_info[7] = n_act;
     }
+}
+
+__global__ void key_bitmap_kernel(const int32_t *__restrict__ keys, int64_t n, uint32_t *__restrict__ bitmap) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicOr(&bitmap[keys[i] >> 5], 1u << (keys[i] & 31));
 }
 
 // segment of every slot from the sorted path's arrays (slot_seg[src[i]] = segment holding position i)
@@ -515,6 +522,15 @@ __device__ __forceinline__ v16f_ hm_accumulate(v16f_ acc, const float *__restric
     return acc;
 }
 
+// optional fused segment reduce in front of head_bwd_input_mfma_kernel
+struct SegSrc {
+    const float *rows;            // [n x Cy] gradient rows, or nullptr: dY is read as given
+    const int32_t *members;       // member slots grouped by segment (elimrec_segment_plan)
+    const int32_t *seg_start;
+    const float *scale;           // nullable device fp32[1]
+    float *reduced;               // [n x lddy] receives dY
+};
+
 __global__ __launch_bounds__(512) void head_bwd_input_mfma_kernel(const float *__restrict__ dY, int64_t lddy,
                                                                   const int32_t *__restrict__ active_rows,
                                                                   const int32_t *__restrict__ seg_info, int64_t n_max,
@@ -522,7 +538,7 @@ __global__ __launch_bounds__(512) void head_bwd_input_mfma_kernel(const float *_
                                                                   const float *__restrict__ W_user,
                                                                   const float *__restrict__ W_item, float gscale,
                                                                   float *__restrict__ G0, int64_t ldg, int scatter_cols,
-                                                                  float *__restrict__ compact) {
+                                                                  float *__restrict__ compact, SegSrc seg) {
     extern __shared__ float dys[];                       // [HM_ROWS][Cy + 1]
     __shared__ int64_t node[HM_ROWS];
     const int Cy = (1 + S) * d, ldy = Cy + 1;
@@ -532,10 +548,25 @@ __global__ __launch_bounds__(512) void head_bwd_input_mfma_kernel(const float *_
     if (n_act > n_max) n_act = n_max;
     if (s0 >= n_act) return;
     const int rows = (int)((n_act - s0) < HM_ROWS ? (n_act - s0) : HM_ROWS);
+    const float seg_scale = (seg.rows && seg.scale) ? seg.scale[0] : 1.f;
     for (int e = tid * 4; e < HM_ROWS * Cy; e += 2048) {
         const int r = e / Cy, c = e - r * Cy;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < rows) v = ld4(dY + (s0 + r) * lddy + c);
+        if (r < rows) {
+            if (seg.rows) {
+                // fused segment reduce: dY[s] = scale * sum of the member gradient rows in ascending slot order
+                // (bit for bit what segment_sum_kernel writes); the reduced row is also stored for linear_bwd_w
+                const int beg = seg.seg_start[s0 + r], end = seg.seg_start[s0 + r + 1];
+                for (int i = beg; i < end; ++i) {
+                    const float4 x = ld4(seg.rows + (int64_t)seg.members[i] * Cy + c);
+                    v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+                }
+                v = make_float4(v.x * seg_scale, v.y * seg_scale, v.z * seg_scale, v.w * seg_scale);
+                st4(seg.reduced + (s0 + r) * lddy + c, v);
+            } else {
+                v = ld4(dY + (s0 + r) * lddy + c);
+            }
+        }
         float *dst = dys + r * ldy + c;
         dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
     }
@@ -716,9 +747,10 @@ static int plan_fast_max_keys() {
 
 extern "C" int elimrec_segment_plan(const int32_t *d_keys, int64_t n, int32_t split_key, int64_t key_space,
                                     int32_t *d_active_rows, int32_t *d_seg_info, int32_t *d_slot_seg,
-                                    void *d_workspace, size_t workspace_bytes, void *stream) {
+                                    uint32_t *d_key_bitmap, void *d_workspace, size_t workspace_bytes, void *stream) {
     ELIMREC_REQUIRE(d_keys && d_active_rows && d_seg_info && d_slot_seg && d_workspace, "segment_plan: null pointer");
     ELIMREC_REQUIRE(n > 0 && n < INT32_MAX, "segment_plan: bad n");
+    ELIMREC_REQUIRE(!d_key_bitmap || key_space > 0, "segment_plan: the key bitmap needs key_space");
     SegLayout L;
     int rc = seg_layout(n, L);
     if (rc) return rc;
@@ -747,10 +779,12 @@ extern "C" int elimrec_segment_plan(const int32_t *d_keys, int64_t n, int32_t sp
         }
         if (in_lds)
             hipLaunchKernelGGL(segment_plan_kernel<true>, dim3(1), dim3(PLAN_T), lds, s, d_keys, (int)n, (int)key_space,
-                               (int)split_key, d_active_rows, d_seg_info, d_slot_seg, flag, seg_start, vs, segid);
+                               (int)split_key, d_active_rows, d_seg_info, d_slot_seg, flag, seg_start, vs, segid,
+                               d_key_bitmap);
         else
             hipLaunchKernelGGL(segment_plan_kernel<false>, dim3(1), dim3(PLAN_T), lds, s, d_keys, (int)n, (int)key_space,
-                               (int)split_key, d_active_rows, d_seg_info, d_slot_seg, flag, seg_start, vs, segid);
+                               (int)split_key, d_active_rows, d_seg_info, d_slot_seg, flag, seg_start, vs, segid,
+                               d_key_bitmap);
         ELIMREC_LAUNCH_CHECK("segment_plan");
         return 0;
     }
@@ -774,6 +808,12 @@ extern "C" int elimrec_segment_plan(const int32_t *d_keys, int64_t n, int32_t sp
     ELIMREC_LAUNCH_CHECK("publish_ranges");
     hipLaunchKernelGGL(slot_segments_kernel, dim3(nb), dim3(256), 0, s, vs, segid, n, d_slot_seg);
     ELIMREC_LAUNCH_CHECK("slot_segments");
+    if (d_key_bitmap) {
+        e = hipMemsetAsync(d_key_bitmap, 0, (size_t)((key_space + 31) / 32) * sizeof(uint32_t), s);
+        if (e != hipSuccess) return check_hip(e, "memset(key bitmap)");
+        hipLaunchKernelGGL(key_bitmap_kernel, dim3(nb), dim3(256), 0, s, d_keys, n, d_key_bitmap);
+        ELIMREC_LAUNCH_CHECK("key_bitmap");
+    }
     return 0;
 }
 
@@ -809,7 +849,7 @@ extern "C" int elimrec_segment_reduce_rows(const float *d_rows, const int32_t *d
     if (rc) return rc;
     // key space unknown here: the sorted plan; its slot->segment map goes to the (then unused) vals_in array
     rc = elimrec_segment_plan(d_keys, n, split_key, 0, d_active_rows, d_seg_info,
-                              (int32_t *)((char *)d_workspace + L.vals_in), d_workspace, workspace_bytes, stream);
+                              (int32_t *)((char *)d_workspace + L.vals_in), nullptr, d_workspace, workspace_bytes, stream);
     if (rc) return rc;
     return elimrec_segment_apply(d_rows, n, ld, d_seg_info, d_scale, d_reduced, d_workspace, workspace_bytes, stream);
 }
@@ -835,7 +875,7 @@ extern "C" int elimrec_head_bwd_input(const float *d_dY, int64_t lddy, const int
         ELIMREC_REQUIRE(lddy % 4 == 0, "head_bwd_input: lddy must be a multiple of 4");
         hipLaunchKernelGGL(head_bwd_input_mfma_kernel, dim3((unsigned)((n_max + HM_ROWS - 1) / HM_ROWS)), dim3(512),
                            lds_m, (hipStream_t)stream, d_dY, lddy, d_active_rows, d_seg_info, n_max, U, d, C, S, hp,
-                           d_W_user, d_W_item, gscale, d_G0, ldg, scatter_cols, d_compact);
+                           d_W_user, d_W_item, gscale, d_G0, ldg, scatter_cols, d_compact, SegSrc{});
         ELIMREC_LAUNCH_CHECK("head_bwd_input_mfma");
         return 0;
     }
@@ -846,5 +886,48 @@ extern "C" int elimrec_head_bwd_input(const float *d_dY, int64_t lddy, const int
                        (hipStream_t)stream, d_dY, lddy, d_active_rows, d_seg_info, n_max, U, d, C, S, hp, d_W_user,
                        d_W_item, gscale, d_G0, ldg, scatter_cols, d_compact);
     ELIMREC_LAUNCH_CHECK("head_bwd_input");
+    return 0;
+}
+
+// segment_apply + head_bwd_input in one launch (the MFMA form stages the dY rows in LDS anyway: it sums them
+// from the member gradient rows instead of reading them back). Falls back to the two launches when the MFMA
+// form does not apply.
+extern "C" int elimrec_segment_apply_head_bwd(const float *d_rows, int64_t n, int ld, const int32_t *d_active_rows,
+                                              const int32_t *d_seg_info, const float *d_scale, float *d_reduced,
+                                              const void *d_plan_workspace, size_t plan_workspace_bytes, int64_t U, int d,
+                                              int C, int S, const int *head_mblock, const float *d_W_user,
+                                              const float *d_W_item, const float *const *d_W_heads, float *d_compact,
+                                              void *stream) {
+    ELIMREC_REQUIRE(d_rows && d_active_rows && d_seg_info && d_reduced && d_plan_workspace && d_W_user && d_W_item &&
+                    d_compact, "segment_apply_head_bwd: null pointer");
+    ELIMREC_REQUIRE(n > 0 && n < INT32_MAX && ld > 0 && ld % 4 == 0, "segment_apply_head_bwd: bad n/ld");
+    ELIMREC_REQUIRE(S >= 0 && S <= kMaxHeads && d > 0 && d % 4 == 0 && C % d == 0 && ld == (1 + S) * d,
+                    "segment_apply_head_bwd: bad d/C/S/ld");
+    const size_t lds_m = (size_t)HM_ROWS * ((1 + S) * d + 1) * sizeof(float);
+    if (!(d % 32 == 0 && lds_m <= 96 * 1024)) {
+        int rc = elimrec_segment_apply(d_rows, n, ld, d_seg_info, d_scale, d_reduced, d_plan_workspace,
+                                       plan_workspace_bytes, stream);
+        if (rc) return rc;
+        return elimrec_head_bwd_input(d_reduced, ld, d_active_rows, d_seg_info, n, U, d, C, S, head_mblock, d_W_user,
+                                      d_W_item, d_W_heads, 1.0f, nullptr, 0, 0, d_compact, stream);
+    }
+    SegLayout L;
+    int rc = seg_layout(n, L);
+    if (rc) return rc;
+    if (plan_workspace_bytes < L.total) {
+        set_error("segment_apply_head_bwd: plan workspace too small");
+        return ELIMREC_E_WORKSPACE;
+    }
+    const char *ws = (const char *)d_plan_workspace;
+    SegSrc seg = {d_rows, (const int32_t *)(ws + L.vals_sorted), (const int32_t *)(ws + L.seg_start), d_scale, d_reduced};
+    HeadPtrs hp;
+    for (int h = 0; h < kMaxHeads; ++h) {
+        hp.w[h] = h < S ? d_W_heads[h] : nullptr;
+        hp.mblock[h] = h < S ? head_mblock[h] : -1;
+    }
+    hipLaunchKernelGGL(head_bwd_input_mfma_kernel, dim3((unsigned)((n + HM_ROWS - 1) / HM_ROWS)), dim3(512), lds_m,
+                       (hipStream_t)stream, (const float *)d_reduced, (int64_t)ld, d_active_rows, d_seg_info, n, U, d, C, S, hp,
+                       d_W_user, d_W_item, 1.0f, (float *)nullptr, (int64_t)0, 0, d_compact, seg);
+    ELIMREC_LAUNCH_CHECK("segment_apply_head_bwd");
     return 0;
 }

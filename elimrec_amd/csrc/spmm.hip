@@ -1132,15 +1132,16 @@ __global__ __launch_bounds__(256) void folded_sources_kernel(const float *__rest
         h_dst[c] = acc;
         g_dst[c] = g0;
     }
-    if (lane == 0) atomicOr(&mask[r >> 5], 1u << (r & 31));
+    if (mask && lane == 0) atomicOr(&mask[r >> 5], 1u << (r & 31));
 }
 }  // namespace elimrec
 
 extern "C" int elimrec_propagate_folded_bwd(const elimrec_csr *AT, int64_t U, int64_t I, int d, int M, int L,
                                             const float *d_dOutR, const int32_t *d_active_rows,
                                             const int32_t *d_seg_info, int64_t n_max, float *d_SrcA, float *d_SrcB,
-                                            float *d_grad /* [N x d] = [gE_u ; gE_i] */, void *d_workspace,
-                                            size_t workspace_bytes, void *stream) {
+                                            float *d_grad /* [N x d] = [gE_u ; gE_i] */,
+                                            const uint32_t *d_active_mask, void *d_workspace, size_t workspace_bytes,
+                                            void *stream) {
     ELIMREC_REQUIRE(AT && d_dOutR && d_active_rows && d_seg_info && d_SrcA && d_SrcB && d_grad && d_workspace,
                     "propagate_folded_bwd: null pointer");
     ELIMREC_REQUIRE(d > 0 && d % 4 == 0 && L >= 1 && M >= 1, "propagate_folded_bwd: bad d/L/M");
@@ -1151,12 +1152,14 @@ extern "C" int elimrec_propagate_folded_bwd(const elimrec_csr *AT, int64_t U, in
     char *ws = (char *)d_workspace;
     const size_t tb = align_up((size_t)N * d * sizeof(float), 256);
     float *tbuf[2] = {(float *)ws, (float *)(ws + tb)};
-    uint32_t *mask = (uint32_t *)(ws + 2 * tb);
-    int rc = check_hip(hipMemsetAsync(mask, 0, (size_t)((N + 31) / 32 + 2) * 4, s), "memset(mask)");
-    if (rc) return rc;
+    // bitmap of the active rows: the caller's (elimrec_segment_plan builds it on the way) or built here
+    uint32_t *own_mask = d_active_mask ? nullptr : (uint32_t *)(ws + 2 * tb);
+    const uint32_t *mask = d_active_mask ? d_active_mask : own_mask;
+    int rc = 0;
+    if (own_mask && (rc = check_hip(hipMemsetAsync(own_mask, 0, (size_t)((N + 31) / 32 + 2) * 4, s), "memset(mask)"))) return rc;
     if (n_max > 0) {
         hipLaunchKernelGGL(folded_sources_kernel, dim3((unsigned)((n_max + 3) / 4)), dim3(256), 0, s, d_dOutR, d_active_rows,
-                           d_seg_info, n_max, U, d, M, d_SrcA, d_SrcB, mask);
+                           d_seg_info, n_max, U, d, M, d_SrcA, d_SrcB, own_mask);
         ELIMREC_LAUNCH_CHECK("folded_sources");
     }
     const float inv = 1.0f / (float)(L + 1);

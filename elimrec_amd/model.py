@@ -303,6 +303,7 @@ class EliMRec(BasicModel):
                     ws["SrcB"] = torch.empty(N, d, **f32)
                     ws["fold_ws"] = torch.empty(ops.folded_workspace(N, d), dtype=torch.uint8, device=dev)
                     if self._lazy:
+                        ws["act_mask"] = torch.zeros((N + 31) // 32 + 2, dtype=torch.int32, device=dev)
                         ws["layers"] = torch.empty(ops.layer_tables_workspace(N, d, self.n_layers), dtype=torch.uint8,
                                                    device=dev)
                     self._fold_constants(ws)
@@ -568,7 +569,7 @@ class EliMRec(BasicModel):
             W = ws["live_views"]
             # the plan depends on the indices only; the forward evaluates the head at the active rows it lists and
             # the backward reduces the (gathered) gradient rows with it
-            ops.segment_plan(all_keys, U, U + I, act, seg, ws["slot_seg"][:n], ws["plan_ws"])
+            ops.segment_plan(all_keys, U, U + I, act, seg, ws["slot_seg"][:n], ws["plan_ws"], key_bitmap=ws["act_mask"])
             ops.copy_cols(ws["flat_param"][ws["tail_off"]:].view(1, -1), ws["snap"].view(1, -1))
             ops.folded_rows(ws["layers"], U, I, d, L, act, seg[0:1], OutAct[:, :d], ws["Narrow"])
             ops.linear_fwd_batched(self._fold_problems(ws, W, OutAct, act, seg[6:8]))
@@ -638,10 +639,10 @@ class EliMRec(BasicModel):
         grads = {}
 
         def head():
-            ops.segment_apply(grad_rows, seg, dY, ws["plan_ws"], scale=gscale)
             wu, wi = self._fusion_weights()
             head_ws = [getattr(self, "s_dense_" + m).weight for m in self._mods]
-            ops.head_bwd_input(dY, act, seg, U, d, C, [h + 1 for h in range(S)], wu, wi, head_ws, 1.0, None, compact=dOutR)
+            ops.segment_apply_head_bwd(grad_rows, act, seg, dY, ws["plan_ws"], U, d, C, [h + 1 for h in range(S)], wu, wi,
+                                       head_ws, dOutR, scale=gscale)
             # fusion Linears: dW = dY_f^T . Out[active rows], user slots / item slots separately
             problems, fused_tmp = [], {}
             for name, rng in (("embedding_user_after_GCN", seg[2:4]), ("embedding_item_after_GCN", seg[4:6])):
@@ -671,7 +672,8 @@ class EliMRec(BasicModel):
         AT = self._csr("adj" if self._adj_symmetric else "adjT")
         self._timed(lambda: self._region("bwd_hops", (self._ws_gen, n),
                                          lambda: ops.propagate_folded_bwd(AT, U, I, d, M, self.n_layers, dOutR, act, seg,
-                                                                          ws["SrcA"], ws["SrcB"], ws["gX0d"], ws["fold_ws"])))
+                                                                          ws["SrcA"], ws["SrcB"], ws["gX0d"], ws["fold_ws"],
+                                                                          active_mask=ws["act_mask"])))
         grads["embedding_user.weight"], grads["embedding_item.weight"] = gv["embedding_user.weight"], gv["embedding_item.weight"]
         return grads
 

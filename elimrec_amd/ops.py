@@ -304,7 +304,7 @@ def folded_combine(layers, U, I, d, L, out0, narrow):
                                                   _dev(narrow, "narrow"), _stream()), "folded_combine")
 
 
-def propagate_folded_bwd(AT, U, I, d, M, L, dOutR, active_rows, seg_info, srcA, srcB, grad, workspace):
+def propagate_folded_bwd(AT, U, I, d, M, L, dOutR, active_rows, seg_info, srcA, srcB, grad, workspace, active_mask=None):
     for t in (dOutR, srcA, srcB, grad):
         assert t.is_contiguous()
     assert grad.shape == (U + I, d) and dOutR.shape[1] == d * M
@@ -312,6 +312,7 @@ def propagate_folded_bwd(AT, U, I, d, M, L, dOutR, active_rows, seg_info, srcA, 
                                                         _dev(active_rows, "active_rows", torch.int32),
                                                         _dev(seg_info, "seg_info", torch.int32), active_rows.numel(),
                                                         _dev(srcA, "srcA"), _dev(srcB, "srcB"), _dev(grad, "grad"),
+                                                        _dev(active_mask, "active_mask", torch.int32),
                                                         _dev(workspace, "workspace", torch.uint8), workspace.numel(),
                                                         _stream()), "propagate_folded_bwd")
 
@@ -402,14 +403,16 @@ def segment_plan_workspace(n):
     return int(_lib.load().elimrec_segment_plan_workspace(n))
 
 
-def segment_plan(keys, split_key, key_space, active_rows, seg_info, slot_seg, workspace):
+def segment_plan(keys, split_key, key_space, active_rows, seg_info, slot_seg, workspace, key_bitmap=None):
     """Plan of a key list: active_rows (sorted unique keys), seg_info, slot_seg (segment of every slot); the member
-    lists stay in `workspace` for segment_apply."""
+    lists stay in `workspace` for segment_apply. key_bitmap (int32 words, >= key_space bits): bit k <=> k is active."""
     n = keys.numel()
+    assert key_bitmap is None or key_bitmap.numel() * 32 >= key_space
     _lib.check(_lib.load().elimrec_segment_plan(_dev(keys, "keys", torch.int32), n, int(split_key), int(key_space),
                                                 _dev(active_rows, "active_rows", torch.int32),
                                                 _dev(seg_info, "seg_info", torch.int32),
                                                 _dev(slot_seg, "slot_seg", torch.int32),
+                                                _dev(key_bitmap, "key_bitmap", torch.int32),
                                                 _dev(workspace, "workspace", torch.uint8), workspace.numel(), _stream()),
                "segment_plan")
 
@@ -454,6 +457,24 @@ def head_bwd_input(dY, active_rows, seg_info, U, d, C, head_mblock, W_user, W_it
                                                   _dev(W_user, "W_user"), _dev(W_item, "W_item"), wp, float(gscale),
                                                   g0, ldg, int(scatter_cols), _dev(compact, "compact"), _stream()),
                "head_bwd_input")
+
+
+def segment_apply_head_bwd(rows, active_rows, seg_info, reduced, plan_workspace, U, d, C, head_mblock, W_user, W_item,
+                           W_heads, compact, scale=None):
+    """segment_apply + head_bwd_input(compact=...) in one launch; `reduced` receives dY."""
+    n, ld = rows.shape
+    S = len(W_heads)
+    assert rows.is_contiguous() and reduced.is_contiguous() and reduced.shape[1] == ld and compact.is_contiguous()
+    assert compact.shape[1] == C and compact.shape[0] >= n and reduced.shape[0] >= n
+    mb = (ctypes.c_int * max(S, 1))(*head_mblock) if S else (ctypes.c_int * 1)(0)
+    wp = (ctypes.c_void_p * max(S, 1))(*[_dev(w, "W_head") for w in W_heads]) if S else (ctypes.c_void_p * 1)(None)
+    for w in list(W_heads) + [W_user, W_item]:
+        assert w.is_contiguous()
+    _lib.check(_lib.load().elimrec_segment_apply_head_bwd(
+        _dev(rows, "rows"), n, ld, _dev(active_rows, "active_rows", torch.int32), _dev(seg_info, "seg_info", torch.int32),
+        _dev(scale, "scale"), _dev(reduced, "reduced"), _dev(plan_workspace, "plan_workspace", torch.uint8),
+        plan_workspace.numel(), U, d, C, S, mb, _dev(W_user, "W_user"), _dev(W_item, "W_item"), wp,
+        _dev(compact, "compact"), _stream()), "segment_apply_head_bwd")
 
 
 def embed_grad(G, U, I, d, M, grad_user, grad_item):

@@ -228,8 +228,10 @@ int elimrec_folded_combine(const void *d_layers, size_t layers_bytes, int64_t U,
                            int64_t ldo, float *d_narrow, void *stream);
 int elimrec_propagate_folded_bwd(const elimrec_csr *AT, int64_t U, int64_t I, int d, int M, int L,
                                  const float *d_dOutR, const int32_t *d_active_rows, const int32_t *d_seg_info,
-                                 int64_t n_max, float *d_SrcA, float *d_SrcB, float *d_grad, void *d_workspace,
-                                 size_t workspace_bytes, void *stream);
+                                 int64_t n_max, float *d_SrcA, float *d_SrcB, float *d_grad,
+                                 const uint32_t *d_active_mask /* nullable: bitmap of the active rows (the key bitmap of
+                                 elimrec_segment_plan); built internally when NULL */,
+                                 void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* One block SpMM with the fused epilogue on a W-column window of wider tables (row stride ld):
  *   r = A . Xin[:, 0:W];  if Xout: Xout = r;  if AccOut: AccOut = (r + Add1) * scale.
@@ -286,8 +288,9 @@ size_t elimrec_segment_reduce_workspace(int64_t n);
  * radix-sort path, which is used otherwise). APPLY sums rows per segment in ascending slot order, times *d_scale. */
 size_t elimrec_segment_plan_workspace(int64_t n);
 int elimrec_segment_plan(const int32_t *d_keys, int64_t n, int32_t split_key, int64_t key_space,
-                         int32_t *d_active_rows, int32_t *d_seg_info, int32_t *d_slot_seg, void *d_workspace,
-                         size_t workspace_bytes, void *stream);
+                         int32_t *d_active_rows, int32_t *d_seg_info, int32_t *d_slot_seg,
+                         uint32_t *d_key_bitmap /* nullable [(key_space+31)/32]: bit k set <=> k is an active key */,
+                         void *d_workspace, size_t workspace_bytes, void *stream);
 int elimrec_segment_apply(const float *d_rows, int64_t n, int ld, const int32_t *d_seg_info, const float *d_scale,
                           float *d_reduced, const void *d_workspace, size_t workspace_bytes, void *stream);
 int elimrec_segment_reduce_rows(const float *d_rows, const int32_t *d_keys, int64_t n, int ld,
@@ -310,6 +313,15 @@ int elimrec_head_bwd_input(const float *d_dY, int64_t lddy, const int32_t *d_act
                            float gscale, float *d_G0 /* nullable: scattered rows G0[node, 0:scatter_cols], stride ldg */,
                            int64_t ldg, int scatter_cols,
                            float *d_compact /* nullable [n_max x C]: the same rows in slot order */, void *stream);
+
+/* elimrec_segment_apply followed by elimrec_head_bwd_input (compact output only) as ONE launch: the rows of dY are
+ * summed from their member gradient rows while they are staged for the contraction; d_reduced still receives dY
+ * (elimrec_linear_bwd_w reads it). Same results as the two calls, bit for bit. ld = (1+S)*d. */
+int elimrec_segment_apply_head_bwd(const float *d_rows, int64_t n, int ld, const int32_t *d_active_rows,
+                                   const int32_t *d_seg_info, const float *d_scale, float *d_reduced,
+                                   const void *d_plan_workspace, size_t plan_workspace_bytes, int64_t U, int d, int C,
+                                   int S, const int *head_mblock, const float *d_W_user, const float *d_W_item,
+                                   const float *const *d_W_heads, float *d_compact, void *stream);
 
 /* ---------------------------------------------------------------- embedding gradients (K2 bwd)
  * dE_user[u, j] = sum_m G[u, m*d + j];  dE_item[i, j] = G[U+i, j]   (CatBackward of :239). */

@@ -421,6 +421,38 @@ def test_one_workgroup_segment_plan_equals_sorted_plan(n, key_space, hot):
     assert (res[0][3].double() - want).abs().max() < 1e-4
 
 
+def test_fused_segment_apply_head_bwd_equals_two_launches():
+    """segment_apply + head_bwd_input as one launch: bitwise the same dY and dOut rows; and the planner's key bitmap
+    marks exactly the active rows."""
+    from elimrec_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    U, I, d, S, n = 300, 500, 64, 3, 777
+    C, Cy = (1 + S) * d, (1 + S) * d
+    keys = torch.randint(0, U + I, (n,), generator=gen, dtype=torch.int32).to(DEV)
+    rows = torch.randn(n, Cy, generator=gen).to(DEV)
+    wu, wi = torch.randn(d, C, generator=gen).to(DEV), torch.randn(d, C, generator=gen).to(DEV)
+    heads = [torch.randn(d, d, generator=gen).to(DEV) for _ in range(S)]
+    scale = torch.full((1,), 0.37, device=DEV)
+    ws = torch.empty(ops.segment_plan_workspace(n), dtype=torch.uint8, device=DEV)
+    act = torch.zeros(n, dtype=torch.int32, device=DEV)
+    seg = torch.zeros(8, dtype=torch.int32, device=DEV)
+    slot_seg = torch.zeros(n, dtype=torch.int32, device=DEV)
+    bitmap = torch.full(((U + I + 31) // 32 + 2,), -1, dtype=torch.int32, device=DEV)
+    ops.segment_plan(keys, U, U + I, act, seg, slot_seg, ws, key_bitmap=bitmap)
+    na = int(seg[0])
+    bits = torch.zeros(U + I, dtype=torch.bool)
+    bits[act[:na].long().cpu()] = True
+    words = bitmap[:(U + I + 31) // 32].cpu().numpy().view(np.uint32)
+    got = np.unpackbits(words.view(np.uint8), bitorder="little")[:U + I].astype(bool)
+    assert np.array_equal(got, bits.numpy())
+    dY1, dY2 = torch.zeros(n, Cy, device=DEV), torch.zeros(n, Cy, device=DEV)
+    out1, out2 = torch.zeros(n, C, device=DEV), torch.zeros(n, C, device=DEV)
+    ops.segment_apply(rows, seg, dY1, ws, scale=scale)
+    ops.head_bwd_input(dY1, act, seg, U, d, C, [1, 2, 3], wu, wi, heads, 1.0, None, compact=out1)
+    ops.segment_apply_head_bwd(rows, act, seg, dY2, ws, U, d, C, [1, 2, 3], wu, wi, heads, out2, scale=scale)
+    assert torch.equal(dY1[:na], dY2[:na]) and torch.equal(out1[:na], out2[:na])
+
+
 def test_sampler_contract_on_device():
     from elimrec_amd import PairwiseSamplerV2, SyntheticDataset
     ds = SyntheticDataset(400, 300, 6000, feat_dims=(4, 4, 4), seed=9)
