@@ -14,14 +14,17 @@ __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast
 __device__ __forceinline__ void st4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 
-// One wave per triplet. Lane l owns float4 l, l+64, ... of each d-wide block.
+// One wave per triplet. A d-wide block needs d/4 lanes (float4 each), so the wave splits into 64/LB groups of
+// LB = pow2 >= d/4 lanes and works on that many head blocks at once (d = 64: four blocks side by side instead of
+// one after the other with 48 idle lanes). Reductions are xor butterflies inside a group -- the same additions
+// as a full-wave butterfly whose other lanes hold zeros -- and the loss terms are added in block order.
 __global__ __launch_bounds__(256) void bpr_head_kernel(const float *__restrict__ Y, int64_t ldy, int64_t U,
                                                        const int64_t *__restrict__ users,
                                                        const int64_t *__restrict__ pos,
                                                        const int64_t *__restrict__ neg, int B, int d, int n_blocks,
                                                        BlockWeights bw, float inv_b, float *__restrict__ loss_rows,
                                                        float *__restrict__ grad_rows, int32_t *__restrict__ keys,
-                                                       const int32_t *__restrict__ slot_rows) {
+                                                       const int32_t *__restrict__ slot_rows, int LB) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -35,38 +38,49 @@ __global__ __launch_bounds__(256) void bpr_head_kernel(const float *__restrict__
     float *gp = grad_rows ? grad_rows + (int64_t)(3 * b + 1) * ldg : nullptr;
     float *gn = grad_rows ? grad_rows + (int64_t)(3 * b + 2) * ldg : nullptr;
     const float eps = 1e-12f;
+    const int PB = 64 / LB, grp = lane / LB, sl = lane - grp * LB;
     float loss = 0.f;
-    for (int k = 0; k < n_blocks; ++k) {
-        const float wk = bw.w[k];
+    for (int k0 = 0; k0 < n_blocks; k0 += PB) {
+        const int k = k0 + grp;
+        const bool have = k < n_blocks;
+        float wk = 0.f;
+#pragma unroll
+        for (int q = 0; q < kMaxBlocks; ++q) wk = (q == k) ? bw.w[q] : wk;
         const int off = k * d;
-        if (wk == 0.f) {
+        float term = 0.f;
+        if (have && wk == 0.f) {
             if (grad_rows)
-                for (int v = lane * 4; v < d; v += 256) {
+                for (int v = sl * 4; v < d; v += 4 * LB) {
                     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
                     st4(ga + off + v, z); st4(gp + off + v, z); st4(gn + off + v, z);
                 }
-            continue;
         }
+        const bool on = have && wk != 0.f;
         float saa = 0.f, spp = 0.f, snn = 0.f, sap = 0.f, san = 0.f;
-        for (int v = lane * 4; v < d; v += 256) {
-            const float4 a = ld4(ya + off + v), p = ld4(yp + off + v), n = ld4(yn + off + v);
-            saa += dot4(a, a); spp += dot4(p, p); snn += dot4(n, n); sap += dot4(a, p); san += dot4(a, n);
-        }
-        saa = wave_sum(saa); spp = wave_sum(spp); snn = wave_sum(snn); sap = wave_sum(sap); san = wave_sum(san);
-        const float na = sqrtf(saa), np_ = sqrtf(spp), nn = sqrtf(snn);
-        const float da = fmaxf(na, eps), dp = fmaxf(np_, eps), dn = fmaxf(nn, eps);   // F.normalize denominators
-        const float cp = sap / (da * dp), cn = san / (da * dn);
-        const float x = cn - cp;
-        const float sp = (x > 20.f) ? x : log1pf(expf(x));                           // F.softplus
-        loss += wk * sp * inv_b;
-        if (grad_rows) {
-            const float sig = (x > 20.f) ? 1.f : 1.f / (1.f + expf(-x));
-            const float g = wk * sig * inv_b;
-            // d/da of  <a/da, n/dn - p/dp>: (v - ahat*<ahat,v>)/da when |a| > eps, v/eps otherwise.
-            const bool fa = na > eps, fp = np_ > eps, fn = nn > eps;
-            for (int v = lane * 4; v < d; v += 256) {
+        if (on)
+            for (int v = sl * 4; v < d; v += 4 * LB) {
                 const float4 a = ld4(ya + off + v), p = ld4(yp + off + v), n = ld4(yn + off + v);
-                float4 ra, rp4, rn4;
+                saa += dot4(a, a); spp += dot4(p, p); snn += dot4(n, n); sap += dot4(a, p); san += dot4(a, n);
+            }
+        for (int o = LB >> 1; o > 0; o >>= 1) {
+            saa += __shfl_xor(saa, o, 64); spp += __shfl_xor(spp, o, 64); snn += __shfl_xor(snn, o, 64);
+            sap += __shfl_xor(sap, o, 64); san += __shfl_xor(san, o, 64);
+        }
+        if (on) {
+            const float na = sqrtf(saa), np_ = sqrtf(spp), nn = sqrtf(snn);
+            const float da = fmaxf(na, eps), dp = fmaxf(np_, eps), dn = fmaxf(nn, eps);   // F.normalize denominators
+            const float cp = sap / (da * dp), cn = san / (da * dn);
+            const float x = cn - cp;
+            const float sp = (x > 20.f) ? x : log1pf(expf(x));                           // F.softplus
+            term = wk * sp * inv_b;
+            if (grad_rows) {
+                const float sig = (x > 20.f) ? 1.f : 1.f / (1.f + expf(-x));
+                const float g = wk * sig * inv_b;
+                // d/da of  <a/da, n/dn - p/dp>: (v - ahat*<ahat,v>)/da when |a| > eps, v/eps otherwise.
+                const bool fa = na > eps, fp = np_ > eps, fn = nn > eps;
+                for (int v = sl * 4; v < d; v += 4 * LB) {
+                    const float4 a = ld4(ya + off + v), p = ld4(yp + off + v), n = ld4(yn + off + v);
+                    float4 ra, rp4, rn4;
 #define ELIMREC_BPR_COMP(c)                                                              \
     {                                                                                    \
         const float ah = a.c / da, ph = p.c / dp, nh = n.c / dn;                         \
@@ -75,10 +89,15 @@ __global__ __launch_bounds__(256) void bpr_head_kernel(const float *__restrict__
         rp4.c = -g * (fp ? (ah - ph * cp) / dp : ah / eps);                              \
         rn4.c = g * (fn ? (ah - nh * cn) / dn : ah / eps);                               \
     }
-                ELIMREC_BPR_COMP(x) ELIMREC_BPR_COMP(y) ELIMREC_BPR_COMP(z) ELIMREC_BPR_COMP(w)
+                    ELIMREC_BPR_COMP(x) ELIMREC_BPR_COMP(y) ELIMREC_BPR_COMP(z) ELIMREC_BPR_COMP(w)
 #undef ELIMREC_BPR_COMP
-                st4(ga + off + v, ra); st4(gp + off + v, rp4); st4(gn + off + v, rn4);
+                    st4(ga + off + v, ra); st4(gp + off + v, rp4); st4(gn + off + v, rn4);
+                }
             }
+        }
+        for (int q = 0; q < PB; ++q) {                   // block order: the loss is the same sum as one block at a time
+            const float t = __shfl(term, q * LB, 64);
+            if (k0 + q < n_blocks) loss += t;
         }
     }
     if (lane == 0) {
@@ -683,6 +702,12 @@ extern "C" int elimrec_gather_rows(const float *d_src, int64_t lds, const int32_
 
 using namespace elimrec;
 
+static int bpr_group_lanes(int d) {      // lanes per head block: pow2 >= d/4, at most the wave
+    int lb = 1;
+    while (lb < d / 4 && lb < 64) lb <<= 1;
+    return lb;
+}
+
 extern "C" int elimrec_bpr_head(const float *d_Y, int64_t ldy, int64_t U, int64_t I, const int64_t *d_users,
                                 const int64_t *d_pos, const int64_t *d_neg, int B, int d, int n_blocks,
                                 const float *block_weights, float *d_loss_rows, float *d_grad_rows, int32_t *d_keys,
@@ -698,7 +723,7 @@ extern "C" int elimrec_bpr_head(const float *d_Y, int64_t ldy, int64_t U, int64_
     for (int k = 0; k < kMaxBlocks; ++k) bw.w[k] = k < n_blocks ? block_weights[k] : 0.f;
     hipLaunchKernelGGL(bpr_head_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_Y, ldy, U, d_users,
                        d_pos, d_neg, B, d, n_blocks, bw, 1.0f / (float)B, d_loss_rows, d_grad_rows, d_keys,
-                       (const int32_t *)nullptr);
+                       (const int32_t *)nullptr, bpr_group_lanes(d));
     ELIMREC_LAUNCH_CHECK("bpr_head");
     return 0;
 }
@@ -715,7 +740,7 @@ extern "C" int elimrec_bpr_head_rows(const float *d_Y, int64_t ldy, const int32_
     for (int k = 0; k < kMaxBlocks; ++k) bw.w[k] = k < n_blocks ? block_weights[k] : 0.f;
     hipLaunchKernelGGL(bpr_head_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_Y, ldy, (int64_t)0,
                        (const int64_t *)nullptr, (const int64_t *)nullptr, (const int64_t *)nullptr, B, d, n_blocks, bw,
-                       1.0f / (float)B, d_loss_rows, d_grad_rows, (int32_t *)nullptr, d_slot_rows);
+                       1.0f / (float)B, d_loss_rows, d_grad_rows, (int32_t *)nullptr, d_slot_rows, bpr_group_lanes(d));
     ELIMREC_LAUNCH_CHECK("bpr_head_rows");
     return 0;
 }
