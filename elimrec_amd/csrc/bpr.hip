@@ -164,10 +164,6 @@ constexpr int PLAN_T = 1024;
 constexpr int PLAN_LONG = 8;       // member lists longer than this are rank-sorted by a wave (or the workgroup)
 constexpr int PLAN_HUGE = 512;
 
-__device__ __forceinline__ int32_t ld_l2(const int32_t *p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // exclusive prefix of one value per thread over the 1024-thread workgroup; *total = sum of all values
 __device__ __forceinline__ int plan_block_scan(int v, int *wave_sums, int *total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -191,45 +187,39 @@ __device__ __forceinline__ int plan_block_scan(int v, int *wave_sums, int *total
     return base + inc - v;
 }
 
-// IN_LDS (n <= PLAN_LDS_N): counts, offsets and member lists live in LDS and the keys in registers, so the ~60
-// dependent round trips of the phases below cost LDS latency; the results are copied out at the end. Otherwise the
-// same phases run on the global arrays (L2 round trips: slower, any n).
+// Up to PLAN_LDS_N slots: counts, offsets and member lists live in LDS and the keys in registers, so the ~60
+// dependent round trips of the phases below cost LDS latency; the results are copied out at the end. (The same
+// phases on global arrays cost an L2 round trip each -- measured 4x slower than the radix-sort path at 49 k slots,
+// which therefore keeps the larger key lists.)
 constexpr int PLAN_LDS_N = 8192;
 constexpr int PLAN_KPT = PLAN_LDS_N / PLAN_T;
 
-template <bool IN_LDS>
 __global__ __launch_bounds__(PLAN_T) void segment_plan_kernel(const int32_t *__restrict__ keys, int n, int key_space,
                                                               int split_key, int32_t *__restrict__ active_rows,
                                                               int32_t *__restrict__ seg_info,
-                                                              int32_t *__restrict__ slot_seg, int32_t *g_cnt,
-                                                              int32_t *g_seg_start, int32_t *g_members, int32_t *g_tmp,
+                                                              int32_t *__restrict__ slot_seg,
+                                                              int32_t *__restrict__ g_seg_start,
+                                                              int32_t *__restrict__ g_members,
                                                               uint32_t *__restrict__ key_bitmap) {
     extern __shared__ uint32_t plan_lds[];
     const int nw = (key_space + 31) >> 5;
     uint32_t *bm = plan_lds, *pre = plan_lds + nw;
     int *wave_sums = (int *)(pre + nw);               // [16]
     int *long_list = wave_sums + 16;                  // [1 + 1023]: count, then segment ids of long member lists
-    int32_t *cnt, *seg_start, *members, *tmp;
-    if constexpr (IN_LDS) {
-        cnt = (int32_t *)(long_list + 1024);           // [PLAN_LDS_N]; doubles as the rank-sort scratch at the end
-        seg_start = cnt + PLAN_LDS_N;                 // [PLAN_LDS_N + 1]
-        members = seg_start + PLAN_LDS_N + 1;         // [PLAN_LDS_N]
-        tmp = cnt;
-    } else {
-        cnt = g_cnt; seg_start = g_seg_start; members = g_members; tmp = g_tmp;
-    }
-    auto ld = [&](const int32_t *p) -> int32_t { return IN_LDS ? *p : ld_l2(p); };
+    int32_t *cnt = (int32_t *)(long_list + 1024);      // [PLAN_LDS_N]; doubles as the rank-sort scratch at the end
+    int32_t *seg_start = cnt + PLAN_LDS_N;            // [PLAN_LDS_N + 1]
+    int32_t *members = seg_start + PLAN_LDS_N + 1;    // [PLAN_LDS_N]
+    int32_t *tmp = cnt;
+    auto ld = [&](const int32_t *p) -> int32_t { return *p; };
     const int tid = threadIdx.x;
     int kreg[PLAN_KPT];
-    if constexpr (IN_LDS) {
 #pragma unroll
-        for (int i = 0; i < PLAN_KPT; ++i) {
-            const int j = tid + i * PLAN_T;
-            kreg[i] = j < n ? keys[j] : -1;
-        }
+    for (int i = 0; i < PLAN_KPT; ++i) {
+        const int j = tid + i * PLAN_T;
+        kreg[i] = j < n ? keys[j] : -1;
     }
-    const int iters = IN_LDS ? PLAN_KPT : (n + PLAN_T - 1) / PLAN_T;
-    auto key_of = [&](int i, int j) -> int { return IN_LDS ? kreg[i] : keys[j]; };
+    constexpr int iters = PLAN_KPT;
+    auto key_of = [&](int i, int j) -> int { return kreg[i]; };
     for (int w = tid; w < nw; w += PLAN_T) bm[w] = 0u;
     if (tid == 0) long_list[0] = 0;
     __syncthreads();
@@ -270,7 +260,7 @@ __global__ __launch_bounds__(PLAN_T) void segment_plan_kernel(const int32_t *__r
             const uint32_t k = (uint32_t)key_of(i, j);
             const int seg = (int)pre[k >> 5] + __popc(bm[k >> 5] & ((1u << (k & 31)) - 1u));
             slot_seg[j] = seg;
-            if constexpr (IN_LDS) sreg[i] = seg;
+            sreg[i] = seg;
             atomicAdd(&cnt[seg], 1);
         }
     }
@@ -298,8 +288,7 @@ __global__ __launch_bounds__(PLAN_T) void segment_plan_kernel(const int32_t *__r
     for (int i = 0; i < iters; ++i) {
         const int j = tid + i * PLAN_T;
         if (j < n) {
-            int seg;
-            if constexpr (IN_LDS) seg = sreg[i]; else seg = slot_seg[j];
+            const int seg = sreg[i];
             const int pos = ld(seg_start + seg) + atomicAdd(&cnt[seg], 1);
             members[pos] = j;
         }
@@ -336,14 +325,9 @@ __global__ __launch_bounds__(PLAN_T) void segment_plan_kernel(const int32_t *__r
                 for (int q = b; q < e; ++q) r += ld(members + q) < v;
                 tmp[b + r] = v;
             }
-            if constexpr (IN_LDS) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            } else {
-                __threadfence();                      // the scratch is in global memory: through L2
-                __builtin_amdgcn_wave_barrier();
-            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             for (int i = b + lane; i < e; i += 64) members[i] = ld(tmp + i);
         }
         for (int li = 0; li < n_long; ++li) {
@@ -361,11 +345,9 @@ __global__ __launch_bounds__(PLAN_T) void segment_plan_kernel(const int32_t *__r
             for (int i = b + tid; i < e; i += PLAN_T) members[i] = ld(tmp + i);
         }
     }
-    if constexpr (IN_LDS) {                           // publish the member lists for segment_apply
-        __syncthreads();
-        for (int i = tid; i < n; i += PLAN_T) g_members[i] = members[i];
-        for (int i = tid; i <= n_act; i += PLAN_T) g_seg_start[i] = seg_start[i];
-    }
+    __syncthreads();                                  // publish the member lists for segment_apply
+    for (int i = tid; i < n; i += PLAN_T) g_members[i] = members[i];
+    for (int i = tid; i <= n_act; i += PLAN_T) g_seg_start[i] = seg_start[i];
     if (tid == 0) {
         int n_lo = n_act;
         if (split_key < key_space) {
@@ -765,7 +747,7 @@ static int plan_fast_max_keys() {
     static int v = -1;
     if (v < 0) {
         const char *e = getenv("ELIMREC_PLAN_FAST");          // 0 disables the one-workgroup planner
-        v = (e && e[0] == '0') ? 0 : (150 * 1024 / 8) * 32;     // bitmap + prefix words within 150 KB of LDS
+        v = (e && e[0] == '0') ? 0 : (1 << 30);
     }
     return v;
 }
@@ -788,28 +770,18 @@ extern "C" int elimrec_segment_plan(const int32_t *d_keys, int64_t n, int32_t sp
     int32_t *vs = (int32_t *)(ws + L.vals_sorted), *flag = (int32_t *)(ws + L.flag);
     int32_t *segid = (int32_t *)(ws + L.segid), *seg_start = (int32_t *)(ws + L.seg_start);
     hipStream_t s = (hipStream_t)stream;
-    if (key_space > 0 && key_space <= plan_fast_max_keys() && n <= (1 << 20)) {
-        const size_t nw = (size_t)((key_space + 31) / 32);
-        const size_t base = (2 * nw + 16 + 1024) * sizeof(uint32_t);
-        const size_t lds_arrays = base + (size_t)(3 * PLAN_LDS_N + 1) * sizeof(int32_t);
-        const bool in_lds = n <= PLAN_LDS_N && lds_arrays <= 160 * 1024;
-        const size_t lds = in_lds ? lds_arrays : base;
-        static size_t lds_set[2] = {0, 0};
-        if (lds > 64 * 1024 && lds > lds_set[in_lds]) {
-            hipError_t ea = hipFuncSetAttribute(in_lds ? (const void *)segment_plan_kernel<true>
-                                                       : (const void *)segment_plan_kernel<false>,
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t plan_lds = ((size_t)2 * ((key_space + 31) / 32) + 16 + 1024) * sizeof(uint32_t) +
+                            (size_t)(3 * PLAN_LDS_N + 1) * sizeof(int32_t);
+    if (key_space > 0 && key_space <= plan_fast_max_keys() && n <= PLAN_LDS_N && plan_lds <= 160 * 1024) {
+        static size_t lds_set = 0;
+        if (plan_lds > 64 * 1024 && plan_lds > lds_set) {
+            hipError_t ea = hipFuncSetAttribute((const void *)segment_plan_kernel,
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan_lds);
             if (ea != hipSuccess) return check_hip(ea, "segment_plan: LDS size");
-            lds_set[in_lds] = lds;
+            lds_set = plan_lds;
         }
-        if (in_lds)
-            hipLaunchKernelGGL(segment_plan_kernel<true>, dim3(1), dim3(PLAN_T), lds, s, d_keys, (int)n, (int)key_space,
-                               (int)split_key, d_active_rows, d_seg_info, d_slot_seg, flag, seg_start, vs, segid,
-                               d_key_bitmap);
-        else
-            hipLaunchKernelGGL(segment_plan_kernel<false>, dim3(1), dim3(PLAN_T), lds, s, d_keys, (int)n, (int)key_space,
-                               (int)split_key, d_active_rows, d_seg_info, d_slot_seg, flag, seg_start, vs, segid,
-                               d_key_bitmap);
+        hipLaunchKernelGGL(segment_plan_kernel, dim3(1), dim3(PLAN_T), plan_lds, s, d_keys, (int)n, (int)key_space,
+                           (int)split_key, d_active_rows, d_seg_info, d_slot_seg, seg_start, vs, d_key_bitmap);
         ELIMREC_LAUNCH_CHECK("segment_plan");
         return 0;
     }

@@ -284,8 +284,8 @@ size_t elimrec_segment_reduce_workspace(int64_t n);
 /* The two halves of elimrec_segment_reduce_rows. The PLAN depends on the keys only (the batch's node ids are known
  * before the forward pass): sorted unique keys -> d_active_rows, d_seg_info as above, d_slot_seg[n] = the segment
  * (index into d_active_rows) of every slot, member lists inside the workspace. key_space > 0 promises
- * 0 <= key < key_space and selects the one-workgroup bitmap planner when the bitmap fits LDS (same output as the
- * radix-sort path, which is used otherwise). APPLY sums rows per segment in ascending slot order, times *d_scale. */
+ * 0 <= key < key_space and selects the one-workgroup bitmap planner for n <= 8192 when the bitmap fits LDS (same
+ * output as the radix-sort path, which is used otherwise). APPLY sums rows per segment in ascending slot order, times *d_scale. */
 size_t elimrec_segment_plan_workspace(int64_t n);
 int elimrec_segment_plan(const int32_t *d_keys, int64_t n, int32_t split_key, int64_t key_space,
                          int32_t *d_active_rows, int32_t *d_seg_info, int32_t *d_slot_seg,
