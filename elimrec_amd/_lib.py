@@ -18,7 +18,8 @@ class CsrSplit(ctypes.Structure):
     _fields_ = [("long_threshold", ctypes.c_int32), ("n_long", ctypes.c_int32), ("n_seg", ctypes.c_int32),
                 ("d_long_rows", ctypes.c_void_p), ("d_long_seg_ptr", ctypes.c_void_p),
                 ("d_seg_bounds", ctypes.c_void_p), ("d_partials", ctypes.c_void_p), ("d_seg_row", ctypes.c_void_p),
-                ("d_row_order", ctypes.c_void_p), ("d_tickets", ctypes.c_void_p)]
+                ("d_row_order", ctypes.c_void_p), ("d_tickets", ctypes.c_void_p), ("d_row_items", ctypes.c_void_p),
+                ("n_row_items", ctypes.c_int32)]
 
 
 class CsrDesc(ctypes.Structure):

@@ -302,6 +302,8 @@ struct HalfArgs {
                                   // share a wave have similar lengths); results do not depend on it
     const int32_t *seg_row;       // [n_seg] index (into long_rows) of the split row a segment belongs to
     int32_t *tickets;             // [n_long] arrival counters, zero between launches (self-resetting)
+    const int32_t *row_items;     // nullable [n_row_items][3]: (row, begin, end) of the unsplit rows in processing order
+    int n_row_items;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -399,6 +401,83 @@ __device__ __forceinline__ float4 half_gather_masked(const HalfArgs &a, int beg,
     return acc;
 }
 
+// The unsplit rows as a persistent stream (W4 <= LPR: one float4 column per lane). A row costs four dependent
+// memory round trips when taken cold (order -> rowptr -> col/val -> source rows) and the rows are short (a dozen
+// neighbours), so the kernel is bound by that chain times the rows a CU can keep in flight -- measured: 33 us per
+// hop with the whole source table in L2 against 45 us from HBM. Here every wave walks its items k, k + stride, ...
+// with the index chain software-pipelined: the (row, begin, end) triple of item k+2 and the first UNROLL
+// (col, val) of item k+1 are in flight while item k gathers. Sums are formed in the same order with the same
+// fmaf as half_gather, so the results are bit-identical.
+template <int LPR, int UNROLL>
+__device__ __forceinline__ void half_stream_rows(const HalfArgs &a, int seg_blocks) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, cl = lane % LPR;
+    const int wpb = blockDim.x >> 6;
+    const int64_t wave_g = (int64_t)((int)blockIdx.x - seg_blocks) * wpb + (threadIdx.x >> 6);
+    const int64_t n_slots = (int64_t)((int)gridDim.x - seg_blocks) * wpb;
+    const int64_t n_items = a.n_row_items;
+    const bool con = cl < a.W4;
+    int crow, cbeg, cend, nrow, nbeg, nend;
+    auto load_trip = [&](int64_t k, int &row, int &beg, int &end) {
+        const int64_t it = (wave_g + k * n_slots) * RPW + sub;
+        row = -1; beg = 0; end = 0;
+        if (it < n_items) {
+            const int32_t *p = a.row_items + 3 * it;
+            row = p[0]; beg = p[1]; end = p[2];
+        }
+    };
+    int cj[UNROLL], ncj[UNROLL];
+    float vj[UNROLL], nvj[UNROLL];
+    auto load_idx = [&](int beg, int end, int (&c)[UNROLL], float (&v)[UNROLL]) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) {
+            const bool in = beg + u < end;
+            c[u] = in ? a.col[beg + u] : 0;
+            v[u] = in ? a.val[beg + u] : 0.f;
+        }
+    };
+    load_trip(0, crow, cbeg, cend);
+    load_trip(1, nrow, nbeg, nend);
+    load_idx(cbeg, cend, cj, vj);
+    for (int64_t k = 0; (wave_g + k * n_slots) * RPW < n_items; ++k) {
+        int frow, fbeg, fend;
+        load_trip(k + 2, frow, fbeg, fend);
+        load_idx(nbeg, nend, ncj, nvj);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        {
+            float4 x[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                x[u] = (con && cbeg + u < cend) ? a.Xin[(int64_t)cj[u] * a.ld4 + cl] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                acc.x = fmaf(vj[u], x[u].x, acc.x); acc.y = fmaf(vj[u], x[u].y, acc.y);
+                acc.z = fmaf(vj[u], x[u].z, acc.z); acc.w = fmaf(vj[u], x[u].w, acc.w);
+            }
+        }
+        for (int j = cbeg + UNROLL; j < cend; j += UNROLL) {      // rows longer than one chunk
+            int c2[UNROLL];
+            float v2[UNROLL];
+            float4 x[UNROLL];
+            load_idx(j, cend, c2, v2);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+                x[u] = (con && j + u < cend) ? a.Xin[(int64_t)c2[u] * a.ld4 + cl] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                acc.x = fmaf(v2[u], x[u].x, acc.x); acc.y = fmaf(v2[u], x[u].y, acc.y);
+                acc.z = fmaf(v2[u], x[u].z, acc.z); acc.w = fmaf(v2[u], x[u].w, acc.w);
+            }
+        }
+        if (con && crow >= 0) half_epilogue(a, crow, cl, acc);
+        crow = nrow; cbeg = nbeg; cend = nend;
+        nrow = frow; nbeg = fbeg; nend = fend;
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) { cj[u] = ncj[u]; vj[u] = nvj[u]; }
+    }
+}
+
 // LPR lanes per row (power of two <= 64): a wave handles 64/LPR rows, so narrow (d-column) tables use
 // every lane. ONE launch covers both kinds of work item: the first `seg_blocks` workgroups take segments
 // of the split (long) rows and write partial sums, the rest take whole rows of the CSR (long rows
@@ -409,6 +488,10 @@ __global__ __launch_bounds__(256) void half_hop_kernel(HalfArgs a, int seg_block
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR, cl = lane % LPR;
     const bool seg_mode = (int)blockIdx.x < seg_blocks;            // workgroup-uniform
+    if (!MASKED && !seg_mode && a.row_items && a.W4 <= LPR) {      // workgroup-uniform
+        half_stream_rows<LPR, UNROLL>(a, seg_blocks);
+        return;
+    }
     const int64_t blk = seg_mode ? blockIdx.x : (blockIdx.x - seg_blocks);
     int64_t item = (blk * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + sub;
     const int64_t n_items = seg_mode ? (int64_t)a.n_seg : a.n_rows;
@@ -543,6 +626,16 @@ __global__ void build_masks_kernel(const int32_t *__restrict__ active_rows, cons
     else atomicOr(&mask_i[(r - U) >> 5], 1u << ((r - U) & 31));
 }
 
+static int stream_wgs() {
+    static int v = 0;
+    if (!v) {
+        const char *e = getenv("ELIMREC_STREAM_WGS");
+        v = e ? atoi(e) : 3072;            // 256 CUs x 4 resident workgroups x 3 (measured flat from 1536 up)
+        if (v < 1) v = 1;
+    }
+    return v;
+}
+
 static int launch_half(const elimrec_csr *m, HalfArgs a, size_t partials_offset, hipStream_t s) {
     a.rowptr = m->d_rowptr; a.col = m->d_col; a.val = m->d_val; a.n_rows = m->n_rows;
     const bool has_split = m->split.n_long > 0;
@@ -553,6 +646,8 @@ static int launch_half(const elimrec_csr *m, HalfArgs a, size_t partials_offset,
     a.partials = m->split.d_partials ? (float4 *)(m->split.d_partials + partials_offset) : nullptr;
     a.seg_row = m->split.d_seg_row;
     a.row_order = m->split.d_row_order;
+    a.row_items = m->split.d_row_items;
+    a.n_row_items = m->split.n_row_items;
     // the two chains may touch the same block concurrently: wide launches use tickets[0..n_long), narrow ones the next n_long
     a.tickets = (m->split.d_tickets && elimrec_ticket_fixup())
                     ? m->split.d_tickets + (partials_offset ? m->split.n_long : 0) : nullptr;
@@ -569,9 +664,17 @@ static int launch_half(const elimrec_csr *m, HalfArgs a, size_t partials_offset,
         if (a.src_mask)                                                                                              \
             hipLaunchKernelGGL((half_hop_kernel<LPR, 8, true>), dim3(seg_blocks + blocks(a.n_rows).x),               \
                                dim3(64 * waves), 0, s, a, (int)seg_blocks);                                          \
-        else                                                                                                         \
-            hipLaunchKernelGGL((half_hop_kernel<LPR, 8, false>), dim3(seg_blocks + blocks(a.n_rows).x),              \
+        else {                                                                                                       \
+            /* streaming rows: a persistent grid (stream_wgs workgroups walk all items) */                           \
+            unsigned row_blocks = blocks(a.n_rows).x;                                                                \
+            if (a.row_items && a.W4 <= LPR) {                                                                        \
+                row_blocks = blocks(a.n_row_items).x;                                                                \
+                if (row_blocks > (unsigned)stream_wgs()) row_blocks = (unsigned)stream_wgs();                        \
+                if (row_blocks == 0) row_blocks = 1;                                                                 \
+            }                                                                                                        \
+            hipLaunchKernelGGL((half_hop_kernel<LPR, 8, false>), dim3(seg_blocks + row_blocks),                      \
                                dim3(64 * waves), 0, s, a, (int)seg_blocks);                                          \
+        }                                                                                                            \
         ELIMREC_LAUNCH_CHECK("half_hop");                                                                            \
         if (has_split && !a.tickets) {                                                                               \
             hipLaunchKernelGGL((half_fixup_kernel<LPR>), blocks(a.n_long), dim3(64 * waves), 0, s, a);               \

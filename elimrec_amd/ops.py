@@ -181,9 +181,16 @@ class Csr:
         order = np.argsort(-np.where(deg > threshold, 0, deg), kind="stable").astype(np.int32)
         self._row_order = torch.from_numpy(order).to(dev) if _os.environ.get("ELIMREC_ROW_ORDER", "1") == "1" else None
         ro = self._row_order.data_ptr() if self._row_order is not None else None
+        # (row, begin, end) of the rows that are not split, in that order: the streaming form of the row kernel
+        self._row_items, ri, n_items = None, None, 0
+        if _os.environ.get("ELIMREC_ROW_STREAM", "1") == "1":
+            keep = order[deg[order] <= threshold].astype(np.int64)
+            items = np.stack([keep, rowptr[keep], rowptr[keep + 1]], 1).astype(np.int32)
+            self._row_items = torch.from_numpy(np.ascontiguousarray(items)).to(dev)
+            ri, n_items = self._row_items.data_ptr(), int(len(keep))
         if len(long_rows) == 0:
             self._split_tensors = None
-            self._split = _lib.CsrSplit(0, 0, 0, None, None, None, None, None, ro, None)
+            self._split = _lib.CsrSplit(0, 0, 0, None, None, None, None, None, ro, None, ri, n_items)
             self._split_C = C
             return self
         nseg = (deg[long_rows] + threshold - 1) // threshold
@@ -200,13 +207,13 @@ class Csr:
              torch.zeros(2 * len(long_rows), dtype=torch.int32, device=dev))
         self._split_tensors = t
         self._split = _lib.CsrSplit(int(threshold), len(long_rows), total, t[0].data_ptr(), t[1].data_ptr(),
-                                    t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(), ro, t[5].data_ptr())
+                                    t[2].data_ptr(), t[3].data_ptr(), t[4].data_ptr(), ro, t[5].data_ptr(), ri, n_items)
         self._split_C = C
         return self
 
     def desc(self):
         """struct elimrec_csr for the block-CSR entry points (keeps the tensors alive through self)."""
-        sp = self._split if self._split is not None else _lib.CsrSplit(0, 0, 0, None, None, None, None, None, None, None)
+        sp = self._split if self._split is not None else _lib.CsrSplit(0, 0, 0, None, None, None, None, None, None, None, None, 0)
         self._desc = _lib.CsrDesc(self.n_rows, self.rowptr.data_ptr(), self.col.data_ptr(), self.val.data_ptr(), sp)
         return ctypes.byref(self._desc)
 

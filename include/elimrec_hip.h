@@ -141,6 +141,12 @@ typedef struct elimrec_csr_split {
                                        the row in segment order inside the same launch (agent-scope
                                        release/acquire); otherwise a separate fix-up launch does. Counters
                                        return to zero after every launch.                          */
+    const int32_t *d_row_items;     /* [n_row_items][3] (nullable): (row, begin, end) of every row that is NOT split,
+                                       in processing order (d_row_order's). With it the narrow-row kernel runs as a
+                                       persistent stream: a wave fetches the triple of item k+2 and the first
+                                       neighbour indices of item k+1 while it gathers item k, so a row costs one
+                                       dependent memory round trip instead of four. Results unchanged.             */
+    int32_t n_row_items;
 } elimrec_csr_split;
 
 int elimrec_spmm_hop(const int32_t *d_rowptr, const int32_t *d_col, const float *d_val,
