@@ -401,6 +401,51 @@ __device__ __forceinline__ float4 half_gather_masked(const HalfArgs &a, int beg,
     return acc;
 }
 
+// Sum of one split row's partial rows by a WHOLE wave: the wave's 64/LPR lane groups each add a contiguous
+// quarter of the segments in order (8 loads in flight), the quarter sums are added in group order through
+// shuffles, group 0 runs the epilogue. A fixed order, so the in-launch combine and half_fixup_kernel give the
+// same bits; the longest row (154 segments at the Tiktok shape) needs 5 dependent load rounds instead of 20.
+// Must be called by all lanes of the wave with wave-uniform li.
+template <int LPR>
+__device__ __forceinline__ void combine_split_row(const HalfArgs &a, int li) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int q = lane / LPR, cl = lane % LPR;
+    const int64_t row = a.long_rows[li];
+    const int sb = a.long_seg_ptr[li], se = a.long_seg_ptr[li + 1];
+    const int per = (se - sb + RPW - 1) / RPW;
+    const int qb = min(sb + q * per, se), qe = min(qb + per, se);
+    for (int c0 = 0; c0 < a.W4; c0 += LPR) {
+        const int c = c0 + cl;
+        const bool con = c < a.W4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (con) {
+            int sgm = qb;
+            for (; sgm + 8 <= qe; sgm += 8) {
+                float4 p[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p[u] = a.partials[(int64_t)(sgm + u) * a.W4 + c];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc.x += p[u].x; acc.y += p[u].y; acc.z += p[u].z; acc.w += p[u].w; }
+            }
+            for (; sgm < qe; ++sgm) {
+                const float4 p = a.partials[(int64_t)sgm * a.W4 + c];
+                acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+            }
+        }
+        float4 tot = acc;
+        if (RPW > 1) {
+            tot.x = __shfl(acc.x, cl, 64); tot.y = __shfl(acc.y, cl, 64); tot.z = __shfl(acc.z, cl, 64); tot.w = __shfl(acc.w, cl, 64);
+#pragma unroll
+            for (int t = 1; t < RPW; ++t) {
+                tot.x += __shfl(acc.x, t * LPR + cl, 64); tot.y += __shfl(acc.y, t * LPR + cl, 64);
+                tot.z += __shfl(acc.z, t * LPR + cl, 64); tot.w += __shfl(acc.w, t * LPR + cl, 64);
+            }
+        }
+        if (con && q == 0) half_epilogue(a, row, c, tot);
+    }
+}
+
 // The unsplit rows as a persistent stream (W4 <= LPR: one float4 column per lane). A row costs four dependent
 // memory round trips when taken cold (order -> rowptr -> col/val -> source rows) and the rows are short (a dozen
 // neighbours), so the kernel is bound by that chain times the rows a CU can keep in flight -- measured: 33 us per
@@ -533,7 +578,7 @@ __global__ __launch_bounds__(256) void half_hop_kernel(HalfArgs a, int seg_block
     // ---- last arriver combines: every segment wave has stored its partial row write-through (sc1: no
     // release fence, which would write back the whole XCD L2 under the main rows' output stream), drains
     // its stores, draws a ticket for its split row, and the wave that draws the last one sums that row's
-    // partials in SEGMENT ORDER (same order as half_fixup_kernel => same bits) and runs the epilogue.
+    // partials in the fixed order of combine_split_row (the one half_fixup_kernel uses => same bits) and runs the epilogue.
     // cdna_hip_programming.md Guideline 16, recipe R1 in its counter form: sc1 stores -> every storing wave
     // s_waitcnt vmcnt(0) -> relaxed agent-scope atomic add; consumer: ONE agent acquire (drops this CU's
     // stale L1 lines) -> s_waitcnt vmcnt(0) -> plain loads.
@@ -549,54 +594,20 @@ __global__ __launch_bounds__(256) void half_hop_kernel(HalfArgs a, int seg_block
     if (__ballot(last) == 0ull) return;                             // wave-uniform
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (last) {
-        const int64_t row = a.long_rows[li];
-        const int sb = a.long_seg_ptr[li], se = a.long_seg_ptr[li + 1];
-        for (int c = cl; c < a.W4; c += LPR) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            int sgm = sb;
-            for (; sgm + 8 <= se; sgm += 8) {
-                float4 p[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) p[u] = a.partials[(int64_t)(sgm + u) * a.W4 + c];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { acc.x += p[u].x; acc.y += p[u].y; acc.z += p[u].z; acc.w += p[u].w; }
-            }
-            for (; sgm < se; ++sgm) {
-                const float4 p = a.partials[(int64_t)sgm * a.W4 + c];
-                acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
-            }
-            half_epilogue(a, row, c, acc);
-        }
-        if (cl == 0) __hip_atomic_store(&a.tickets[li], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    for (int g = 0; g < RPW; ++g) {                                 // one finished row at a time, the whole wave on it
+        const int g_last = __shfl(last ? 1 : 0, g * LPR, 64);
+        if (!g_last) continue;                                      // wave-uniform
+        const int g_li = __shfl(li, g * LPR, 64);
+        combine_split_row<LPR>(a, g_li);
+        if (lane == 0) __hip_atomic_store(&a.tickets[g_li], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
     }
 }
 
 template <int LPR>
 __global__ __launch_bounds__(256) void half_fixup_kernel(HalfArgs a) {
-    constexpr int RPW = 64 / LPR;
-    const int lane = threadIdx.x & 63;
-    const int sub = lane / LPR, cl = lane % LPR;
-    const int i = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + sub;
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // one wave per split row
     if (i >= a.n_long) return;
-    const int64_t row = a.long_rows[i];
-    const int sb = a.long_seg_ptr[i], se = a.long_seg_ptr[i + 1];
-    for (int c = cl; c < a.W4; c += LPR) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        int sgm = sb;
-        for (; sgm + 8 <= se; sgm += 8) {
-            float4 p[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) p[u] = a.partials[(int64_t)(sgm + u) * a.W4 + c];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) { acc.x += p[u].x; acc.y += p[u].y; acc.z += p[u].z; acc.w += p[u].w; }
-        }
-        for (; sgm < se; ++sgm) {
-            const float4 p = a.partials[(int64_t)sgm * a.W4 + c];
-            acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
-        }
-        half_epilogue(a, row, c, acc);
-    }
+    combine_split_row<LPR>(a, i);
 }
 
 // Out[row] = (Add1[row] + bcast(AddN[row])) * scale   (a side that has no wide step of its own: L <= 1)
@@ -677,7 +688,7 @@ static int launch_half(const elimrec_csr *m, HalfArgs a, size_t partials_offset,
         }                                                                                                            \
         ELIMREC_LAUNCH_CHECK("half_hop");                                                                            \
         if (has_split && !a.tickets) {                                                                               \
-            hipLaunchKernelGGL((half_fixup_kernel<LPR>), blocks(a.n_long), dim3(64 * waves), 0, s, a);               \
+            hipLaunchKernelGGL((half_fixup_kernel<LPR>), dim3((unsigned)((a.n_long + waves - 1) / waves)), dim3(64 * waves), 0, s, a);               \
             ELIMREC_LAUNCH_CHECK("half_fixup");                                                                      \
         }                                                                                                            \
     } while (0)
