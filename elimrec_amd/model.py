@@ -9,11 +9,16 @@ Data layout in HBM (fp32, row-major; N = U + I nodes, users first):
   Y      [N x Cy], Cy=(1+S)d block 0 = fused embedding (all_users / all_items), block 1+h =
                             single-modal head h (pre_fusion_{user,item}_{v,a,t}). The BPR head
                             gathers one contiguous row per index; predict() reads only Y.
-What the reference does with 12+12 torch.sparse.mm calls, 8 addmm and autograd per batch is here
-(see DESIGN.md): assemble_x0 + 3 linear_fwd -> propagate -> 5 linear_fwd -> bpr_head, and on the
-way back segment_reduce_rows -> head_bwd_input / linear_bwd_w -> propagate (A^T) -> embed_grad /
-linear_bwd_w. Propagation is linear, so nothing of the forward pass is kept for backward except
-Out and Y.
+What the reference does with 12+12 torch.sparse.mm calls, 8 addmm and autograd per batch is here:
+  generic path (any adjacency, --propagation=full):  assemble_x0 + 3 linear_fwd -> propagate -> 5 linear_fwd ->
+      bpr_head, and back: segment plan/apply -> head_bwd_input / linear_bwd_w -> propagate (A^T) -> embed_grad /
+      linear_bwd_w;
+  default path (bipartite adjacency): constant feature tables folded into GEMM operands (only the d-column id table
+      goes through the graph) and, with --head_rows=batch, everything after the graph evaluated at the batch's active
+      rows only: triplet_rows -> propagate_layers -> segment_plan -> folded_rows -> 2 small linear_fwd_batched ->
+      bpr_head_rows, and back: segment_apply_head_bwd -> linear_bwd_w_batched -> propagate_folded_bwd. The full
+      cached tables predict() reads are materialised on first use (_ensure_tables).
+Propagation is linear, so nothing of the forward pass is kept for backward except Out (or its active rows) and Y.
 """
 import os
 
