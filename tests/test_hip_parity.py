@@ -701,6 +701,20 @@ def _full_shape_step(U, I, E, dims, recdim, B, dataset_name, extra_argv=()):
     return model, om
 
 
+@pytest.mark.parametrize("L,recdim,B,dims", [(1, 64, 257, (24, 8, 12)), (2, 32, 1000, (36, 4, 20)), (4, 64, 513, (8, 8, 8)),
+                                             (3, 16, 64, (100, 12, 4)), (2, 128, 300, (16, 16, 16))])
+def test_small_shapes_layers_and_widths_vs_oracle(L, recdim, B, dims):
+    """Layer counts 1..4 (L = 1 runs the eager tables, L = 2 ends on the hop that forms N02, L = 4 adds a second
+    user-side term to the shared part), recdim 16..128 (lane groups of 4..32, VALU and MFMA head kernels), ragged
+    feature widths and batch sizes: one step vs the oracle, then predict() through the lazily materialised tables."""
+    model, om = _full_shape_step(700, 1900, 9000, dims, recdim, B, "synthetic", extra_argv=["--layer_num=%d" % L])
+    assert model._lazy == (L >= 2)
+    users = list(range(0, 700, 13))[:40]
+    for ptype in ("normal", "TIE"):
+        model.predict_type = om.predict_type = ptype
+        assert np.abs(model.predict(users).numpy() - om.predict(users).numpy()).max() < 1e-5
+
+
 def test_full_tiktok_shape_step_vs_oracle():
     """BASELINE.json configs[1]: |U|=36 656, |I|=76 085, 128-d x3, recdim 64, B=2048."""
     model, om = _full_shape_step(36656, 76085, 720829, (128, 128, 128), 64, 2048, "synthetic")
