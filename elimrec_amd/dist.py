@@ -6,12 +6,14 @@ shape (N=112 741 rows x 1 KiB) against 288 GB of HBM per GPU, and every hop of a
 propagation would move most of that table across xGMI (SURVEY.md §7 "xGMI volume") -- six times
 per step. What actually differs between ranks is tiny: the gradient of the loss with respect to the
 3B gathered head rows. So per step each rank
-  1. all-gathers the int32 node ids of its 3B triplet slots (24 KB per rank at B=2048): every rank plans the
-     same set of active nodes and evaluates the head at those rows,
-  2. runs the forward on its own B triplets (tables are bit-identical on every rank),
-  3. all-gathers its [3B x Cy] head-gradient rows (6.3 MB per rank at B=2048),
-  4. runs the SAME deterministic backward + Adam on the gathered rows scaled by 1/world_size.
-Step 4 is bitwise identical on every rank (deterministic kernels, identical input order), so the
+  1. runs the forward and the head's backward on its own B triplets (tables are bit-identical on every rank): loss,
+     dOut rows of its active nodes, its share of the projection-weight gradients, all scaled by 1/world_size,
+  2. all-gathers the [3B x C] dOut rows + int32 node ids (6.3 MB per rank at B=2048) and all-reduces the span of the
+     flat gradient buffer that holds the projection-weight gradients (0.3 MB),
+  3. sums the gathered rows per node (rank order) and runs the SAME deterministic adjoint propagation + Adam.
+(Engines without a sharded head backward -- the unfolded propagation paths -- all-gather node ids before the forward
+and head-gradient rows after it, and run the whole backward on the gathered rows.)
+Step 3 is bitwise identical on every rank (deterministic kernels, identical input order), so the
 replicas never drift and no parameter/gradient all-reduce exists. The result equals one
 single-GPU step with batch world_size*B (mean over the global batch).
 
@@ -32,20 +34,27 @@ class DataParallelTrainer(object):
         self._scale = None
         self._gather = None
 
-    def _buffers(self, grad_rows, keys):
-        shape = (self.world * grad_rows.shape[0], grad_rows.shape[1])
-        if self._gather is None or self._gather[0].shape != shape or self._gather[0].device != grad_rows.device:
-            self._gather = (torch.empty(shape, dtype=grad_rows.dtype, device=grad_rows.device),
-                            torch.empty(self.world * keys.shape[0], dtype=keys.dtype, device=keys.device))
-            self._scale = torch.full((1,), 1.0 / self.world, dtype=torch.float32, device=grad_rows.device)
-        return self._gather
-
     def step(self, users, pos, neg):
         """One training step on this rank's triplets; returns the (local) loss as a 0-dim tensor."""
         eng = self.engine
         if self.profile_kernels and getattr(eng, "_kernel_events", None) is None:
             eng._kernel_events = self._events
-        if self.collectives:
+        if self.collectives and getattr(eng, "dp_shards_head", False):
+            # forward and head backward on this rank's triplets only; the ranks exchange the dOut rows of their active
+            # nodes (+ ids) and sum the projection-weight gradients; the adjoint propagation is replicated
+            loss, _ = eng.forward_local(users, pos, neg, world_size=self.world)
+            if self._scale is None:
+                self._scale = torch.full((1,), 1.0 / self.world, dtype=torch.float32, device=loss.device)
+            rows, keys, wgrads = eng.backward_local(self._scale)
+            if self._gather is None or self._gather[0].shape[0] != self.world * rows.shape[0]:
+                self._gather = (torch.empty(self.world * rows.shape[0], rows.shape[1], dtype=rows.dtype, device=rows.device),
+                                torch.empty(self.world * keys.numel(), dtype=keys.dtype, device=keys.device))
+            all_rows, all_keys = self._gather
+            dist.all_gather_into_tensor(all_rows, rows, group=self.group)
+            dist.all_gather_into_tensor(all_keys, keys, group=self.group)
+            dist.all_reduce(wgrads, op=dist.ReduceOp.SUM, group=self.group)
+            grads = eng.backward_rows_global(all_rows, all_keys)
+        elif self.collectives:
             keys = eng.batch_keys(users, pos, neg)
             if self._gather is None or self._gather[1].numel() != self.world * keys.numel():
                 self._gather = None

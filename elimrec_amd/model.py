@@ -342,6 +342,12 @@ class EliMRec(BasicModel):
         ws["seg_info"] = torch.zeros(8, dtype=torch.int32, device=dev)
         ws["plan_ws"] = torch.empty(max(ops.segment_plan_workspace(n3), 1), dtype=torch.uint8, device=dev)
         shapes = [(n3, d, C), (n3, d, C)] + [(n3, d, d)] * self.S
+        if self._lazy:      # data-parallel steps: the gathered dOut rows of every rank and their merge plan
+            ws["g_act"] = torch.empty(n3, dtype=torch.int32, device=dev)
+            ws["g_slot"] = torch.empty(n3, dtype=torch.int32, device=dev)
+            ws["g_seg"] = torch.zeros(8, dtype=torch.int32, device=dev)
+            ws["g_plan_ws"] = torch.empty(max(ops.segment_plan_workspace(n3), 1), dtype=torch.uint8, device=dev)
+            ws["g_dOut"] = torch.empty(n3, C, **f32)
         if self._folded:    # the folded feature projections' weight gradients ride in the same launch
             ws["dOutR"] = torch.empty(n3, C, **f32)                # dLoss/dOut rows in slot order
             shapes += [(n3, d, getattr(self, m + "_feat").shape[1]) for m in self._mods]
@@ -631,7 +637,7 @@ class EliMRec(BasicModel):
         return loss
 
     @torch.no_grad()
-    def _backward_batch_rows(self, ws, gscale, grad_rows, n):
+    def _backward_batch_rows(self, ws, gscale, grad_rows, n, head_only=False):
         """Backward of _forward_batch_rows: gradient rows -> active rows (the forward's plan) -> head and projection
         gradients from the compact Out / dY rows -> adjoint propagation at d columns. Two hipGraph regions."""
         U, I, d, M, C, S = self.num_users, self.num_items, self.latent_dim, self.M, self.C, self.S
@@ -674,13 +680,20 @@ class EliMRec(BasicModel):
 
         key = (self._ws_gen, grad_rows.data_ptr(), gscale.data_ptr(), n, tuple(bw))
         grads = dict(self._region("bwd_head", key, head))
+        if head_only:
+            return grads
+        self._backward_hops(ws, dOutR, act, seg, n, grads)
+        return grads
+
+    def _backward_hops(self, ws, dOutR, act, seg, n, grads):
+        """Adjoint propagation from the dOut rows of the active nodes (slot order) to [dE_u ; dE_i]."""
+        U, I, d, M, gv = self.num_users, self.num_items, self.latent_dim, self.M, ws["grad_views"]
         AT = self._csr("adj" if self._adj_symmetric else "adjT")
-        self._timed(lambda: self._region("bwd_hops", (self._ws_gen, n),
+        self._timed(lambda: self._region("bwd_hops", (self._ws_gen, n, dOutR.data_ptr(), act.data_ptr(), seg.data_ptr()),
                                          lambda: ops.propagate_folded_bwd(AT, U, I, d, M, self.n_layers, dOutR, act, seg,
                                                                           ws["SrcA"], ws["SrcB"], ws["gX0d"], ws["fold_ws"],
                                                                           active_mask=ws["act_mask"])))
         grads["embedding_user.weight"], grads["embedding_item.weight"] = gv["embedding_user.weight"], gv["embedding_item.weight"]
-        return grads
 
     @torch.no_grad()
     def _backward_hip(self, gscale, grad_rows=None):
@@ -784,6 +797,45 @@ class EliMRec(BasicModel):
     def backward_global(self, grad_rows, scale):
         """Backward from the gradient rows of every rank (rank order); `scale` is a device fp32[1]."""
         return self._backward_hip(scale, grad_rows=grad_rows)
+
+    # Data-parallel steps in "batch" mode shard the head's backward as well: every rank reduces its OWN gradient rows
+    # to dOut rows of its own active nodes and to its share of the projection-weight gradients (backward_local); the
+    # ranks all-gather the dOut rows + node ids and all-reduce the weight-gradient span; every rank then sums the
+    # gathered rows per node and runs the same adjoint propagation (backward_rows_global).
+    @property
+    def dp_shards_head(self):
+        return self._lazy
+
+    @torch.no_grad()
+    def backward_local(self, scale):
+        """-> (dOut rows [3B x C] of this rank's active nodes, zero beyond their count; int32 node ids [3B], the padding
+        slots r carry node id r and a zero row; the span of the flat gradient buffer that holds every
+        projection-weight gradient)."""
+        ws, n = self._ws, self._plan_n
+        self._dp_grads = self._backward_batch_rows(ws, scale, ws["grad_rows"], n, head_only=True)
+        rows, keys = ws["dOutR"][:n], ws["active_rows"][:n]
+        if n > self.num_users + self.num_items:
+            raise RuntimeError("batch of %d slots exceeds the node count: cannot pad the gather buffers" % n)
+        ops.pad_rows(rows, keys, ws["seg_info"][0:1], pad_key=0)
+        return rows, keys, ws["flat_grad"][ws["tail_off"]:]
+
+    @torch.no_grad()
+    def backward_rows_global(self, all_rows, all_keys):
+        """all_rows [W*3B x C] / all_keys [W*3B]: backward_local's rows and ids of every rank in rank order (the
+        weight-gradient span already all-reduced in place)."""
+        ws, n = self._ws, int(all_keys.numel())
+        if n > ws["g_act"].numel():
+            raise RuntimeError("workspace holds %d gathered rows, got %d" % (ws["g_act"].numel(), n))
+        U, I = self.num_users, self.num_items
+        act, seg, dOut = ws["g_act"][:n], ws["g_seg"], ws["g_dOut"][:n]
+
+        def merge():      # rows of the same node (from different ranks) summed in rank order
+            ops.segment_plan(all_keys, U, U + I, act, seg, ws["g_slot"][:n], ws["g_plan_ws"], key_bitmap=ws["act_mask"])
+            ops.segment_apply(all_rows, seg, dOut, ws["g_plan_ws"])
+        self._region("bwd_merge", (self._ws_gen, all_rows.data_ptr(), all_keys.data_ptr(), n), merge)
+        grads = dict(self._dp_grads)
+        self._backward_hops(ws, dOut, act, seg, n, grads)
+        return grads
 
     # ------------------------------------------------------------------ reference API
     def bpr_loss(self, users, pos_items, neg_items):

@@ -365,6 +365,14 @@ def triplet_rows(users, pos, neg, U, rows, src=None, dst=None):
     return rows
 
 
+def pad_rows(rows, keys, count, pad_key=0):
+    """rows[count:] = 0, keys[r] = pad_key + r for r >= count (count: device int32 scalar)."""
+    r, ld = _rowmajor(rows, "rows")
+    assert keys.numel() == rows.shape[0]
+    _lib.check(_lib.load().elimrec_pad_rows(r, ld, _dev(keys, "keys", torch.int32), _dev(count, "count", torch.int32),
+                                            rows.shape[0], rows.shape[1], int(pad_key), _stream()), "pad_rows")
+
+
 def gather_rows(src, rows, dst, count=None):
     """dst[r] = src[rows[r]] for r < min(count, len(rows))."""
     s, lds = _rowmajor(src, "src")

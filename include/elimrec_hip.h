@@ -71,6 +71,11 @@ int elimrec_linear_fwd_batched(const elimrec_linear_desc *descs /* host array */
 int elimrec_triplet_rows(const int64_t *d_users, const int64_t *d_pos, const int64_t *d_neg, int64_t B, int64_t U,
                          int32_t *d_rows, const float *d_src, int64_t lds, int cols, float *d_dst, int64_t ldd,
                          void *stream);
+/* Rows [*d_count, n) of a compact row buffer do not belong to the batch: d_rows[r, 0:cols] = 0, d_keys[r] = pad_key + r
+ * (what a rank hands to the all-gather of a data-parallel step: fixed-size buffers whose tail adds nothing; distinct
+ * keys so that the padding does not pile up in one segment; pad_key + n must stay below the key space). */
+int elimrec_pad_rows(float *d_rows, int64_t ld, int32_t *d_keys, const int32_t *d_count, int64_t n, int cols,
+                     int32_t pad_key, void *stream);
 /* dst[r, 0:cols] = src[rows[r], 0:cols] for r < min(*d_count, n)  (d_count nullable; cols % 4 == 0). */
 int elimrec_gather_rows(const float *d_src, int64_t lds, const int32_t *d_rows, const int32_t *d_count, int64_t n,
                         int cols, float *d_dst, int64_t ldd, void *stream);

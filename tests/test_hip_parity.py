@@ -735,8 +735,9 @@ def test_full_movielens_shape_step_vs_oracle():
 
 
 def test_data_parallel_math_on_one_gpu():
-    """What rank r of a 2-rank job computes (elimrec_amd/dist.py) emulated on one GPU: forward on each
-    half batch, concatenate the gradient rows in rank order, one backward scaled by 1/2. Must equal
+    """What the ranks of a 2-rank job compute (elimrec_amd/dist.py) emulated on one GPU, both flows: (a) the head
+    backward sharded per rank -- dOut rows + node ids concatenated in rank order, weight-gradient spans summed, one
+    replicated adjoint propagation; (b) the whole backward on the concatenated head-gradient rows. Either must equal
     the single-GPU step on the whole batch."""
     g = load_golden("ml3")
     u, p, n = (_t(g["step1/%s" % k]) for k in ("users", "pos", "neg"))
@@ -744,6 +745,23 @@ def test_data_parallel_math_on_one_gpu():
     whole, _ = build_model_from_fixture(g, DEV)
     loss_w, rows_w = whole.forward_local(u[:2 * half], p[:2 * half], n[:2 * half])
     grads_w = {k: v.clone() for k, v in whole.backward_global(rows_w, torch.ones(1, device=DEV)).items()}
+    # (a) sharded head backward
+    dp, _ = build_model_from_fixture(g, DEV)
+    assert dp.dp_shards_head
+    scale = torch.full((1,), 0.5, device=DEV)
+    rows, keys, wg, losses = [], [], [], []
+    for r in range(2):
+        sl = slice(r * half, (r + 1) * half)
+        loss, _ = dp.forward_local(u[sl], p[sl], n[sl], world_size=2)
+        rr, kk, ww = dp.backward_local(scale)
+        rows.append(rr.clone()); keys.append(kk.clone()); wg.append(ww.clone()); losses.append(loss.clone())
+    ww.copy_(wg[0] + wg[1])                              # the all-reduce
+    grads_dp = dp.backward_rows_global(torch.cat(rows), torch.cat(keys))
+    assert abs(float(loss_w) - float((losses[0] + losses[1]) / 2)) < 1e-6
+    assert set(grads_w) == set(grads_dp)
+    for k in grads_w:
+        assert rel_err(grads_dp[k].cpu(), grads_w[k].cpu()) < 1e-5, k
+    # (b) gathered head-gradient rows (engines without a sharded head backward)
     dp, _ = build_model_from_fixture(g, DEV)
     dp._workspace(half, 6 * half)
     all_keys = torch.cat([dp.batch_keys(u[r * half:(r + 1) * half], p[r * half:(r + 1) * half],

@@ -10,19 +10,23 @@ opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay
 B = 2048
 smp = PairwiseSamplerV2(ds, batch_size=B, device="cuda:0", seed=1)
 U_, P_, N_ = smp.sample_epoch()
-for W in (1, 2, 4, 8):
+for W in [int(x) for x in os.environ.get("DP_WORLDS", "1,2,4,8").split(",")]:
     scale = torch.full((1,), 1.0 / W, device="cuda:0")
+    gathered_rows = torch.randn(W * 3 * B, model.C, device="cuda:0") * 1e-4
+    gathered_keys = torch.zeros(W * 3 * B, dtype=torch.int32, device="cuda:0")
     def step(i):
-        gk = model.batch_keys(U_[i * B:(i + 1) * B], P_[i * B:(i + 1) * B], N_[i * B:(i + 1) * B])
-        # stand-in for the all-gathers: W-1 other ranks' keys / rows (different nodes; values are irrelevant for timing)
-        all_keys = torch.cat([gk] + [(gk + 977 * (r + 1)) % (ds.num_users + ds.num_items) for r in range(W - 1)]).to(torch.int32) if W > 1 else gk
-        loss, gr = model.forward_local(U_[i * B:(i + 1) * B], P_[i * B:(i + 1) * B], N_[i * B:(i + 1) * B], all_keys=all_keys,
-                                       rank=0, world_size=W)
-        all_rows = gr.repeat(W, 1) if W > 1 else gr
-        grads = model.backward_global(all_rows, scale)
-        for name, p in model.named_parameters():
-            p.grad = grads.get(name)
-        opt.step()
+        sl = slice(i * B, (i + 1) * B)
+        loss, _ = model.forward_local(U_[sl], P_[sl], N_[sl], world_size=W)
+        if W == 1:
+            grads = model.backward_global(model._ws["grad_rows"], scale)
+        else:
+            rows, keys, wg = model.backward_local(scale)
+            # stand-in for the collectives: W-1 other ranks' rows / ids (different nodes; values irrelevant for timing)
+            all_rows = gathered_rows; all_rows[:rows.shape[0]].copy_(rows)
+            all_keys = gathered_keys
+            for r in range(W):
+                all_keys[r * keys.numel():(r + 1) * keys.numel()].copy_((keys + 977 * r) % (ds.num_users + ds.num_items))
+            grads = model.backward_rows_global(all_rows, all_keys)
     for i in range(3): step(i)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
