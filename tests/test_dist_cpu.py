@@ -122,9 +122,9 @@ class ShardedHeadOracleEngine(OracleEngine):
         m = self.m
         head = {}
         off = 0
-        for k in self.head_names:                      # the all-reduced head-weight gradients
+        for k in self.head_names:                      # views: the trainer's all-reduce may still be in flight
             n = m.params[k].numel()
-            head[k] = self.wbuf[off:off + n].view_as(m.params[k]).clone()
+            head[k] = self.wbuf[off:off + n].view_as(m.params[k])
             off += n
         d_out = torch.zeros_like(self.Out)
         d_out.index_add_(0, all_keys.long(), all_rows)
