@@ -51,10 +51,10 @@ def algorithmic_bytes(model, B):
 
 
 def pmc_traffic_per_hop():
-    """HBM bytes per propagation hop from the committed PMC passes (profiles/r01_g_pmc_traffic.json:
+    """HBM bytes per propagation hop from the committed PMC passes (profiles/r01_h_pmc_traffic.json:
     FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs of this same command,
     FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950). None if the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json")
     try:
         with open(path) as f:
             return json.load(f)["propagation_hop_traffic_bytes"]
