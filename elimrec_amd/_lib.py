@@ -73,7 +73,8 @@ SIGNATURES = {
     "elimrec_folded_workspace": (c_size, [c_i64, c_i32]),
     "elimrec_propagate_folded": (c_i32, [c_csr, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_size, c_ptr]),
     "elimrec_layer_tables_workspace": (c_size, [c_i64, c_i32, c_i32]),
-    "elimrec_propagate_layers": (c_i32, [c_csr, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_size, c_ptr]),
+    "elimrec_propagate_layers": (c_i32, [c_csr, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_size, c_i32, c_i32, c_ptr, c_ptr, c_i64,
+                                         c_ptr]),
     "elimrec_folded_rows": (c_i32, [c_ptr, c_size, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr]),
     "elimrec_folded_combine": (c_i32, [c_ptr, c_size, c_i64, c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
     "elimrec_propagate_folded_bwd": (c_i32, [c_csr, c_i64, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_ptr,

@@ -304,6 +304,11 @@ struct HalfArgs {
     int32_t *tickets;             // [n_long] arrival counters, zero between launches (self-resetting)
     const int32_t *row_items;     // nullable [n_row_items][3]: (row, begin, end) of the unsplit rows in processing order
     int n_row_items;
+    // nullable: only the rows of this device-side list are processed (first min(*row_list_count, row_list_cap)
+    // entries; split rows are still all done by the segment workgroups). The other rows of the outputs are not written.
+    const int32_t *row_list;
+    const int32_t *row_list_count;
+    int64_t row_list_cap;
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -533,18 +538,20 @@ __global__ __launch_bounds__(256) void half_hop_kernel(HalfArgs a, int seg_block
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR, cl = lane % LPR;
     const bool seg_mode = (int)blockIdx.x < seg_blocks;            // workgroup-uniform
-    if (!MASKED && !seg_mode && a.row_items && a.W4 <= LPR) {      // workgroup-uniform
+    if (!MASKED && !seg_mode && a.row_items && !a.row_list && a.W4 <= LPR) {      // workgroup-uniform
         half_stream_rows<LPR, UNROLL>(a, seg_blocks);
         return;
     }
     const int64_t blk = seg_mode ? blockIdx.x : (blockIdx.x - seg_blocks);
     int64_t item = (blk * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + sub;
-    const int64_t n_items = seg_mode ? (int64_t)a.n_seg : a.n_rows;
+    const int64_t n_items = seg_mode ? (int64_t)a.n_seg
+                                     : (a.row_list ? min((int64_t)*a.row_list_count, a.row_list_cap) : a.n_rows);
     bool valid = item < n_items;
     int beg = 0, end = 0;
     if (valid) {
         if (!seg_mode) {
-            if (a.row_order) item = a.row_order[item];
+            if (a.row_list) item = a.row_list[item];
+            else if (a.row_order) item = a.row_order[item];
             beg = a.rowptr[item]; end = a.rowptr[item + 1];
             if (end - beg > a.long_threshold) valid = false;
         } else {
@@ -677,8 +684,8 @@ static int launch_half(const elimrec_csr *m, HalfArgs a, size_t partials_offset,
                                dim3(64 * waves), 0, s, a, (int)seg_blocks);                                          \
         else {                                                                                                       \
             /* streaming rows: a persistent grid (stream_wgs workgroups walk all items) */                           \
-            unsigned row_blocks = blocks(a.n_rows).x;                                                                \
-            if (a.row_items && a.W4 <= LPR) {                                                                        \
+            unsigned row_blocks = blocks(a.row_list ? a.row_list_cap : a.n_rows).x;                                  \
+            if (a.row_items && !a.row_list && a.W4 <= LPR) {                                                         \
                 row_blocks = blocks(a.n_row_items).x;                                                                \
                 if (row_blocks > (unsigned)stream_wgs()) row_blocks = (unsigned)stream_wgs();                        \
                 if (row_blocks == 0) row_blocks = 1;                                                                 \
@@ -1172,13 +1179,19 @@ static int layer_tables(int64_t N, int d, int L, const void *d_workspace, size_t
 }
 
 extern "C" int elimrec_propagate_layers(const elimrec_csr *A, int64_t U, int d, int L, const float *d_X0,
-                                        void *d_workspace, size_t workspace_bytes, void *stream) {
+                                        void *d_workspace, size_t workspace_bytes, int first_hop, int last_hop,
+                                        const int32_t *d_last_rows, const int32_t *d_last_count, int64_t n_last_cap,
+                                        void *stream) {
     ELIMREC_REQUIRE(A && d_X0, "propagate_layers: null pointer");
     ELIMREC_REQUIRE(U >= 0 && U <= A->n_rows, "propagate_layers: bad U");
+    ELIMREC_REQUIRE(first_hop >= 1 && last_hop <= L && first_hop <= last_hop, "propagate_layers: hops %d..%d of %d", first_hop,
+                    last_hop, L);
+    ELIMREC_REQUIRE(!d_last_rows || (d_last_count && n_last_cap >= 0 && L >= 3),
+                    "propagate_layers: a row list for the last hop needs its count and L >= 3");
     LayerTables t;
     int rc = layer_tables(A->n_rows, d, L, d_workspace, workspace_bytes, t, "propagate_layers");
     if (rc) return rc;
-    for (int k = 1; k <= L; ++k) {
+    for (int k = first_hop; k <= last_hop; ++k) {
         const float *xin = k == 1 ? d_X0 : (const float *)t.x[k - 1];
         // hop 1 also leaves S01 = X^1 + X^0; hop 2 leaves N02 = X^2_u + X^0_u on the user rows
         HalfArgs a = half_args(d / 4, xin, nullptr, (float *)t.x[k], k == 1 ? d_X0 : nullptr, nullptr, nullptr, nullptr, 0,
@@ -1188,6 +1201,10 @@ extern "C" int elimrec_propagate_layers(const elimrec_csr *A, int64_t U, int d, 
             a.Acc2Out = (float4 *)t.n02;
             a.Acc2In = (const float4 *)d_X0;
             a.acc2_scale = 1.0f;
+        }
+        if (k == L && d_last_rows) {       // X^L is read at these rows only (elimrec_folded_rows)
+            if (n_last_cap == 0) continue;
+            a.row_list = d_last_rows; a.row_list_count = d_last_count; a.row_list_cap = n_last_cap;
         }
         if ((rc = launch_half(A, a, 0, (hipStream_t)stream))) return rc;
     }

@@ -185,6 +185,8 @@ class EliMRec(BasicModel):
         # step regions: recorded C-ABI call lists, or hipGraphs with --hip_graphs=1 (CLI-only; see _region)
         self._use_graphs = str(opt("hip_graphs", os.environ.get("ELIMREC_GRAPHS", "0"))) == "1"
         self._use_replay = os.environ.get("ELIMREC_REPLAY", "1") != "0"
+        # hop L only feeds the layer mean, which "batch" mode reads at the active rows (hop 2 also forms a sum with X^0)
+        self._last_hop_rows = self._lazy and self.n_layers >= 3 and os.environ.get("ELIMREC_LAST_HOP_ROWS", "1") != "0"
         self._regions = {}
         self._ws = None
         self._ws_key = None
@@ -456,6 +458,9 @@ class EliMRec(BasicModel):
         if self._tables_dirty:
             self._tables_dirty = False
             ws, d = self._ws, self.latent_dim
+            if self._last_hop_rows:     # the training forward left X^L at the active rows only
+                ops.propagate_layers(self._csr("adj"), self.num_users, d, self.n_layers, ws["X0d"], ws["layers"],
+                                     first=self.n_layers)
             ops.folded_combine(ws["layers"], self.num_users, self.num_items, d, self.n_layers, ws["Out"][:, :d], ws["Narrow"])
             self._full_tables(ws, ws["snap_views"])
 
@@ -502,8 +507,9 @@ class EliMRec(BasicModel):
     def _propagate(self, csr, X0, t0, t1, out):
         self._timed(lambda: ops.propagate(csr, X0, self.n_layers, t0, t1, out))
 
-    def _timed(self, fn):
-        """Run one propagation (L hops); optionally bracketed by HIP events on the launch stream (bench.py)."""
+    def _timed(self, fn, hops=None):
+        """Run `hops` (default L) full propagation hops; optionally bracketed by HIP events on the launch stream
+        (bench.py)."""
         prof = getattr(self, "_kernel_events", None)
         if prof is None:
             fn()
@@ -512,7 +518,7 @@ class EliMRec(BasicModel):
         e0.record()
         fn()
         e1.record()
-        prof.append((e0, e1, self.n_layers))
+        prof.append((e0, e1, self.n_layers if hops is None else hops))
 
     def _publish_cache(self, Y, dirty=False):
         U, d = self.num_users, self.latent_dim
@@ -571,16 +577,28 @@ class EliMRec(BasicModel):
         the batch's active rows only (ws['OutAct'], ws['YAct']), then the loss rows and their gradient rows."""
         U, I, d, L = self.num_users, self.num_items, self.latent_dim, self.n_layers
         adj = self._csr("adj")
-        self._timed(lambda: self._region("fwd_hops", (self._ws_gen,),
-                                         lambda: ops.propagate_layers(adj, U, d, L, ws["X0d"], ws["layers"])))
+        act, seg = ws["active_rows"][:n], ws["seg_info"]
+        # the plan depends on the indices only: the last hop and the head are evaluated at the active rows it lists and
+        # the backward reduces the (gathered) gradient rows with it
+        self._region("plan", (self._ws_gen, all_keys.data_ptr(), n),
+                     lambda: ops.segment_plan(all_keys, U, U + I, act, seg, ws["slot_seg"][:n], ws["plan_ws"],
+                                              key_bitmap=ws["act_mask"]))
+        if self._last_hop_rows:
+            # X^L is read at the active rows only: hops 1..L-1 in full, hop L at those rows (and every split row)
+            self._timed(lambda: self._region("fwd_hops", (self._ws_gen,),
+                                             lambda: ops.propagate_layers(adj, U, d, L, ws["X0d"], ws["layers"], last=L - 1)),
+                        hops=L - 1)
+            self._region("fwd_last_hop", (self._ws_gen, n),
+                         lambda: ops.propagate_layers(adj, U, d, L, ws["X0d"], ws["layers"], first=L, last_rows=act,
+                                                      last_count=seg[0:1]))
+        else:
+            self._timed(lambda: self._region("fwd_hops", (self._ws_gen,),
+                                             lambda: ops.propagate_layers(adj, U, d, L, ws["X0d"], ws["layers"])))
         bw = self._last_block_weights
 
         def head():
-            act, seg, OutAct, YAct = ws["active_rows"][:n], ws["seg_info"], ws["OutAct"][:n], ws["YAct"][:n]
+            OutAct, YAct = ws["OutAct"][:n], ws["YAct"][:n]
             W = ws["live_views"]
-            # the plan depends on the indices only; the forward evaluates the head at the active rows it lists and
-            # the backward reduces the (gathered) gradient rows with it
-            ops.segment_plan(all_keys, U, U + I, act, seg, ws["slot_seg"][:n], ws["plan_ws"], key_bitmap=ws["act_mask"])
             ops.copy_cols(ws["flat_param"][ws["tail_off"]:].view(1, -1), ws["snap"].view(1, -1))
             ops.folded_rows(ws["layers"], U, I, d, L, act, seg[0:1], OutAct[:, :d], ws["Narrow"])
             ops.linear_fwd_batched(self._fold_problems(ws, W, OutAct, act, seg[6:8]))

@@ -288,11 +288,16 @@ def layer_tables_workspace(N, d, L):
     return int(_lib.load().elimrec_layer_tables_workspace(N, d, L))
 
 
-def propagate_layers(A, U, d, L, X0, layers):
-    """X^k = A X^(k-1), k = 1..L, kept in `layers` (uint8 workspace) with the two partial sums that involve X^0."""
+def propagate_layers(A, U, d, L, X0, layers, first=1, last=None, last_rows=None, last_count=None):
+    """X^k = A X^(k-1) for k = first..last (default 1..L), kept in `layers` (uint8 workspace) with the two partial
+    sums that involve X^0. last_rows / last_count (int32 list, device count; L >= 3): hop L only at those rows."""
     assert X0.is_contiguous() and X0.shape[1] == d
+    last = L if last is None else last
     _lib.check(_lib.load().elimrec_propagate_layers(A.desc(), U, d, L, _dev(X0, "X0"), _dev(layers, "layers", torch.uint8),
-                                                    layers.numel(), _stream()), "propagate_layers")
+                                                    layers.numel(), first, last, _dev(last_rows, "last_rows", torch.int32),
+                                                    _dev(last_count, "last_count", torch.int32),
+                                                    0 if last_rows is None else last_rows.numel(), _stream()),
+               "propagate_layers")
 
 
 def folded_rows(layers, U, I, d, L, rows, count, out_rows, narrow):

@@ -231,7 +231,12 @@ int elimrec_propagate_folded(const elimrec_csr *A, int64_t U, int64_t I, int d, 
  * have left in d_Out0 / d_narrow, bit for bit). 2 <= L <= 8. workspace: elimrec_layer_tables_workspace bytes. */
 size_t elimrec_layer_tables_workspace(int64_t N, int d, int L);
 int elimrec_propagate_layers(const elimrec_csr *A, int64_t U, int d, int L, const float *d_X0, void *d_workspace,
-                             size_t workspace_bytes, void *stream);
+                             size_t workspace_bytes, int first_hop, int last_hop /* hops first..last of 1..L */,
+                             const int32_t *d_last_rows /* nullable */, const int32_t *d_last_count, int64_t n_last_cap,
+                             void *stream);
+/* d_last_rows (needs L >= 3): hop L, whose table X^L nothing but elimrec_folded_rows reads, is evaluated at the first
+ * min(*d_last_count, n_last_cap) rows of that list only (plus every split row); run hop L again without the list
+ * before elimrec_folded_combine. */
 int elimrec_folded_rows(const void *d_layers, size_t layers_bytes, int64_t U, int64_t I, int d, int L,
                         const int32_t *d_rows, const int32_t *d_count, int64_t n, float *d_out_rows, int64_t ldo,
                         float *d_narrow, void *stream);
