@@ -13,6 +13,8 @@ def read(dirname):
     with open(path) as f:
         for r in csv.DictReader(f):
             name = r["Kernel_Name"].split("(")[0]
+            if "half_hop_kernel" in name:       # full, row-restricted and masked hops share kernels: split by grid
+                name += " grid=%s" % r["Grid_Size"]
             out[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return out
 
@@ -37,7 +39,9 @@ def main():
         if m.get("SQ_VALU_MFMA_BUSY_CYCLES") and sum(m["GRBM_GUI_ACTIVE"]) > 0:
             row["mfma_util"] = round(sum(m["SQ_VALU_MFMA_BUSY_CYCLES"]) / (sum(m["GRBM_GUI_ACTIVE"]) / 8 * 1024), 4)
         kernels.append(row)
-    hop = [k for k in kernels if k["kernel"].startswith("void elimrec::half_hop_kernel<16, 8, false>")]
+    # the full d-column hop = the half_hop_kernel<16, 8, false> group with the largest grid
+    hop = sorted([k for k in kernels if k["kernel"].startswith("void elimrec::half_hop_kernel<16, 8, false>")],
+                 key=lambda k: -int(k["kernel"].split("grid=")[1]))
     doc = {"note": __doc__.split("Usage")[0].strip(), "steps_profiled": a.steps, "kernels": kernels}
     if hop:
         doc["propagation_hop_kernel"] = hop[0]["kernel"]
