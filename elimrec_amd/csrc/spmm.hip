@@ -1267,14 +1267,105 @@ __global__ __launch_bounds__(256) void folded_sources_kernel(const float *__rest
 }
 }  // namespace elimrec
 
+namespace elimrec {
+// Data-parallel merge: every rank contributed the dOut rows of its own active nodes (sorted by node id, padding keys
+// negative). A workgroup owns a range of node ids, finds the slice of every rank's list that falls into it (binary
+// searches, one thread per rank) and walks the ranks IN RANK ORDER with a barrier in between: a node seen before
+// (LDS bitmap) is accumulated, otherwise written -- a fixed order without a sort, float atomics or a second pass.
+// Output = what folded_sources_kernel writes for the summed rows: SrcA / SrcB rows + the row bitmap.
+constexpr int kMaxRanks = 64;
+
+__device__ __forceinline__ int merge_key(const int32_t *keys, int i) {      // padding (negative) sorts last
+    const int k = keys[i];
+    return k < 0 ? INT32_MAX : k;
+}
+
+__global__ __launch_bounds__(256) void merge_rank_rows_kernel(const float *__restrict__ rows, const int32_t *__restrict__ keys,
+                                                              int W, int R, int64_t U, int64_t N, int d, int M, int chunk,
+                                                              float *SrcA, float *SrcB, uint32_t *__restrict__ mask) {
+    __shared__ int s_beg[kMaxRanks], s_end[kMaxRanks];
+    extern __shared__ uint32_t seen[];                   // [chunk / 32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(lo + chunk, N);
+    for (int w = tid; w < chunk / 32; w += 256) seen[w] = 0u;
+    if (tid < W) {                                       // lower_bound(lo), lower_bound(hi), interleaved
+        const int32_t *kr = keys + (int64_t)tid * R;
+        int a0 = 0, a1 = R, b0 = 0, b1 = R;
+        while (a0 < a1 || b0 < b1) {
+            if (a0 < a1) { const int m = (a0 + a1) >> 1; if (merge_key(kr, m) < lo) a0 = m + 1; else a1 = m; }
+            if (b0 < b1) { const int m = (b0 + b1) >> 1; if (merge_key(kr, m) < hi) b0 = m + 1; else b1 = m; }
+        }
+        s_beg[tid] = a0; s_end[tid] = b0;
+    }
+    __syncthreads();
+    const int d4 = d / 4, C = d * M;
+    for (int r = 0; r < W; ++r) {
+        for (int s = s_beg[r] + wave; s < s_end[r]; s += 4) {
+            const int64_t node = keys[(int64_t)r * R + s];
+            const int bit = (int)(node - lo);
+            const bool was = (seen[bit >> 5] >> (bit & 31)) & 1u;
+            const float4 *g = reinterpret_cast<const float4 *>(rows + ((int64_t)r * R + s) * C);
+            float *h_dst = (node < U ? SrcA : SrcB) + node * (int64_t)d;
+            float *g_dst = (node < U ? SrcB : SrcA) + node * (int64_t)d;
+            for (int c = lane; c < d4; c += 64) {
+                const float4 g0 = g[c];
+                float4 h = g0;
+                for (int m = 1; m < M; ++m) {
+                    const float4 x = g[m * d4 + c];
+                    h.x += x.x; h.y += x.y; h.z += x.z; h.w += x.w;
+                }
+                float4 ho = h, go = g0;
+                if (was) {                               // written by an earlier rank of this workgroup: read through L2
+                    float *hp = h_dst + 4 * c, *gp = g_dst + 4 * c;
+                    float4 a, b;
+                    a.x = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a.y = __hip_atomic_load(hp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a.z = __hip_atomic_load(hp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a.w = __hip_atomic_load(hp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    b.x = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    b.y = __hip_atomic_load(gp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    b.z = __hip_atomic_load(gp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    b.w = __hip_atomic_load(gp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ho = make_float4(a.x + h.x, a.y + h.y, a.z + h.z, a.w + h.w);
+                    go = make_float4(b.x + g0.x, b.y + g0.y, b.z + g0.z, b.w + g0.w);
+                }
+                *reinterpret_cast<float4 *>(h_dst + 4 * c) = ho;
+                *reinterpret_cast<float4 *>(g_dst + 4 * c) = go;
+            }
+            if (lane == 0 && !was) atomicOr(&seen[bit >> 5], 1u << (bit & 31));
+        }
+        __syncthreads();                                 // rank r's rows are in memory (and in the bitmap) before rank r+1
+    }
+    for (int w = tid; w < chunk / 32; w += 256)
+        if (lo + 32 * (int64_t)w < ((N + 31) / 32) * 32) mask[lo / 32 + w] = seen[w];
+}
+}  // namespace elimrec
+
+extern "C" int elimrec_merge_rank_rows(const float *d_rows, const int32_t *d_keys, int W, int64_t R, int64_t U, int64_t I,
+                                       int d, int M, float *d_SrcA, float *d_SrcB, uint32_t *d_mask, void *stream) {
+    ELIMREC_REQUIRE(d_rows && d_keys && d_SrcA && d_SrcB && d_mask, "merge_rank_rows: null pointer");
+    ELIMREC_REQUIRE(W >= 1 && W <= kMaxRanks && R >= 1 && R < INT32_MAX, "merge_rank_rows: 1..%d ranks", kMaxRanks);
+    ELIMREC_REQUIRE(d > 0 && d % 4 == 0 && M >= 1, "merge_rank_rows: bad d/M");
+    const int64_t N = U + I;
+    int chunk = (int)((N + 1023) / 1024);                // ~1024 workgroups
+    chunk = (chunk + 31) / 32 * 32;
+    const unsigned grid = (unsigned)((N + chunk - 1) / chunk);
+    hipLaunchKernelGGL(merge_rank_rows_kernel, dim3(grid), dim3(256), (size_t)(chunk / 32) * sizeof(uint32_t),
+                       (hipStream_t)stream, d_rows, d_keys, W, (int)R, U, N, d, M, chunk, d_SrcA, d_SrcB, d_mask);
+    ELIMREC_LAUNCH_CHECK("merge_rank_rows");
+    return 0;
+}
+
 extern "C" int elimrec_propagate_folded_bwd(const elimrec_csr *AT, int64_t U, int64_t I, int d, int M, int L,
                                             const float *d_dOutR, const int32_t *d_active_rows,
                                             const int32_t *d_seg_info, int64_t n_max, float *d_SrcA, float *d_SrcB,
                                             float *d_grad /* [N x d] = [gE_u ; gE_i] */,
                                             const uint32_t *d_active_mask, void *d_workspace, size_t workspace_bytes,
                                             void *stream) {
-    ELIMREC_REQUIRE(AT && d_dOutR && d_active_rows && d_seg_info && d_SrcA && d_SrcB && d_grad && d_workspace,
-                    "propagate_folded_bwd: null pointer");
+    // d_dOutR == NULL: the source tables and the row bitmap are already in place (elimrec_merge_rank_rows)
+    ELIMREC_REQUIRE(AT && d_SrcA && d_SrcB && d_grad && d_workspace, "propagate_folded_bwd: null pointer");
+    ELIMREC_REQUIRE(d_dOutR ? (d_active_rows && d_seg_info) : (d_active_mask != nullptr),
+                    "propagate_folded_bwd: dOut rows need their row list; prefilled sources need their bitmap");
     ELIMREC_REQUIRE(d > 0 && d % 4 == 0 && L >= 1 && M >= 1, "propagate_folded_bwd: bad d/L/M");
     const int64_t N = U + I;
     ELIMREC_REQUIRE(AT->n_rows == N, "propagate_folded_bwd: adjacency rows mismatch");
@@ -1288,7 +1379,7 @@ extern "C" int elimrec_propagate_folded_bwd(const elimrec_csr *AT, int64_t U, in
     const uint32_t *mask = d_active_mask ? d_active_mask : own_mask;
     int rc = 0;
     if (own_mask && (rc = check_hip(hipMemsetAsync(own_mask, 0, (size_t)((N + 31) / 32 + 2) * 4, s), "memset(mask)"))) return rc;
-    if (n_max > 0) {
+    if (d_dOutR && n_max > 0) {
         hipLaunchKernelGGL(folded_sources_kernel, dim3((unsigned)((n_max + 3) / 4)), dim3(256), 0, s, d_dOutR, d_active_rows,
                            d_seg_info, n_max, U, d, M, d_SrcA, d_SrcB, own_mask);
         ELIMREC_LAUNCH_CHECK("folded_sources");

@@ -10,7 +10,8 @@ per step. What actually differs between ranks is tiny: the gradient of the loss 
      dOut rows of its active nodes, its share of the projection-weight gradients, all scaled by 1/world_size,
   2. all-gathers the [3B x C] dOut rows + int32 node ids (6.3 MB per rank at B=2048) and all-reduces the span of the
      flat gradient buffer that holds the projection-weight gradients (0.3 MB),
-  3. sums the gathered rows per node (rank order) and runs the SAME deterministic adjoint propagation + Adam.
+  3. sums the gathered rows per node in rank order (elimrec_merge_rank_rows) and runs the SAME deterministic adjoint
+     propagation + Adam.
 (Engines without a sharded head backward -- the unfolded propagation paths -- all-gather node ids before the forward
 and head-gradient rows after it, and run the whole backward on the gathered rows.)
 Step 3 is bitwise identical on every rank (deterministic kernels, identical input order), so the

@@ -344,12 +344,6 @@ class EliMRec(BasicModel):
         ws["seg_info"] = torch.zeros(8, dtype=torch.int32, device=dev)
         ws["plan_ws"] = torch.empty(max(ops.segment_plan_workspace(n3), 1), dtype=torch.uint8, device=dev)
         shapes = [(n3, d, C), (n3, d, C)] + [(n3, d, d)] * self.S
-        if self._lazy:      # data-parallel steps: the gathered dOut rows of every rank and their merge plan
-            ws["g_act"] = torch.empty(n3, dtype=torch.int32, device=dev)
-            ws["g_slot"] = torch.empty(n3, dtype=torch.int32, device=dev)
-            ws["g_seg"] = torch.zeros(8, dtype=torch.int32, device=dev)
-            ws["g_plan_ws"] = torch.empty(max(ops.segment_plan_workspace(n3), 1), dtype=torch.uint8, device=dev)
-            ws["g_dOut"] = torch.empty(n3, C, **f32)
         if self._folded:    # the folded feature projections' weight gradients ride in the same launch
             ws["dOutR"] = torch.empty(n3, C, **f32)                # dLoss/dOut rows in slot order
             shapes += [(n3, d, getattr(self, m + "_feat").shape[1]) for m in self._mods]
@@ -704,10 +698,12 @@ class EliMRec(BasicModel):
         return grads
 
     def _backward_hops(self, ws, dOutR, act, seg, n, grads):
-        """Adjoint propagation from the dOut rows of the active nodes (slot order) to [dE_u ; dE_i]."""
+        """Adjoint propagation to [dE_u ; dE_i] from the dOut rows of the active nodes (slot order), or -- dOutR None --
+        from source tables and row bitmap already in place (the data-parallel merge)."""
         U, I, d, M, gv = self.num_users, self.num_items, self.latent_dim, self.M, ws["grad_views"]
         AT = self._csr("adj" if self._adj_symmetric else "adjT")
-        self._timed(lambda: self._region("bwd_hops", (self._ws_gen, n, dOutR.data_ptr(), act.data_ptr(), seg.data_ptr()),
+        key = (self._ws_gen, n) + (() if dOutR is None else (dOutR.data_ptr(), act.data_ptr(), seg.data_ptr()))
+        self._timed(lambda: self._region("bwd_hops", key,
                                          lambda: ops.propagate_folded_bwd(AT, U, I, d, M, self.n_layers, dOutR, act, seg,
                                                                           ws["SrcA"], ws["SrcB"], ws["gX0d"], ws["fold_ws"],
                                                                           active_mask=ws["act_mask"])))
@@ -826,33 +822,29 @@ class EliMRec(BasicModel):
 
     @torch.no_grad()
     def backward_local(self, scale):
-        """-> (dOut rows [3B x C] of this rank's active nodes, zero beyond their count; int32 node ids [3B], the padding
-        slots r carry node id r and a zero row; the span of the flat gradient buffer that holds every
+        """-> (dOut rows [3B x C] of this rank's active nodes in ascending node order, zero beyond their count; int32
+        node ids [3B], negative in the unused slots; the span of the flat gradient buffer that holds every
         projection-weight gradient)."""
         ws, n = self._ws, self._plan_n
         self._dp_grads = self._backward_batch_rows(ws, scale, ws["grad_rows"], n, head_only=True)
         rows, keys = ws["dOutR"][:n], ws["active_rows"][:n]
-        if n > self.num_users + self.num_items:
-            raise RuntimeError("batch of %d slots exceeds the node count: cannot pad the gather buffers" % n)
-        ops.pad_rows(rows, keys, ws["seg_info"][0:1], pad_key=0)
+        ops.pad_rows(rows, keys, ws["seg_info"][0:1], pad_key=-(1 << 30))
         return rows, keys, ws["flat_grad"][ws["tail_off"]:]
 
     @torch.no_grad()
     def backward_rows_global(self, all_rows, all_keys):
         """all_rows [W*3B x C] / all_keys [W*3B]: backward_local's rows and ids of every rank in rank order (the
-        weight-gradient span already all-reduced in place)."""
-        ws, n = self._ws, int(all_keys.numel())
-        if n > ws["g_act"].numel():
-            raise RuntimeError("workspace holds %d gathered rows, got %d" % (ws["g_act"].numel(), n))
-        U, I = self.num_users, self.num_items
-        act, seg, dOut = ws["g_act"][:n], ws["g_seg"], ws["g_dOut"][:n]
-
-        def merge():      # rows of the same node (from different ranks) summed in rank order
-            ops.segment_plan(all_keys, U, U + I, act, seg, ws["g_slot"][:n], ws["g_plan_ws"], key_bitmap=ws["act_mask"])
-            ops.segment_apply(all_rows, seg, dOut, ws["g_plan_ws"])
-        self._region("bwd_merge", (self._ws_gen, all_rows.data_ptr(), all_keys.data_ptr(), n), merge)
+        weight-gradient span already all-reduced in place, or being reduced: it is not read here)."""
+        ws, n, n_local = self._ws, int(all_keys.numel()), self._plan_n
+        world = n // n_local
+        if world * n_local != n or all_rows.shape != (n, self.C):
+            raise RuntimeError("gathered rows/keys do not match %d ranks x %d slots" % (world, n_local))
+        U, I, d, M = self.num_users, self.num_items, self.latent_dim, self.M
+        # rows of the same node (from different ranks) summed in rank order, straight into the adjoint's sources
+        self._region("bwd_merge", (self._ws_gen, all_rows.data_ptr(), all_keys.data_ptr(), n),
+                     lambda: ops.merge_rank_rows(all_rows, all_keys, world, U, I, d, M, ws["SrcA"], ws["SrcB"], ws["act_mask"]))
         grads = dict(self._dp_grads)
-        self._backward_hops(ws, dOut, act, seg, n, grads)
+        self._backward_hops(ws, None, None, None, n, grads)
         return grads
 
     # ------------------------------------------------------------------ reference API

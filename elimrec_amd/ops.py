@@ -316,13 +316,25 @@ def folded_combine(layers, U, I, d, L, out0, narrow):
                                                   _dev(narrow, "narrow"), _stream()), "folded_combine")
 
 
+def merge_rank_rows(all_rows, all_keys, world, U, I, d, M, srcA, srcB, mask):
+    """Sum the all-gathered dOut rows per node in rank order into the adjoint's source tables + row bitmap."""
+    R = all_keys.numel() // world
+    assert all_rows.is_contiguous() and all_rows.shape == (world * R, d * M) and all_keys.numel() == world * R
+    assert srcA.is_contiguous() and srcB.is_contiguous() and mask.numel() * 32 >= U + I
+    _lib.check(_lib.load().elimrec_merge_rank_rows(_dev(all_rows, "all_rows"), _dev(all_keys, "all_keys", torch.int32), world,
+                                                   R, U, I, d, M, _dev(srcA, "srcA"), _dev(srcB, "srcB"),
+                                                   _dev(mask, "mask", torch.int32), _stream()), "merge_rank_rows")
+
+
 def propagate_folded_bwd(AT, U, I, d, M, L, dOutR, active_rows, seg_info, srcA, srcB, grad, workspace, active_mask=None):
-    for t in (dOutR, srcA, srcB, grad):
+    """dOutR None: srcA / srcB and active_mask were prefilled (merge_rank_rows)."""
+    for t in (srcA, srcB, grad):
         assert t.is_contiguous()
-    assert grad.shape == (U + I, d) and dOutR.shape[1] == d * M
+    assert grad.shape == (U + I, d) and (dOutR is None or (dOutR.is_contiguous() and dOutR.shape[1] == d * M))
     _lib.check(_lib.load().elimrec_propagate_folded_bwd(AT.desc(), U, I, d, M, L, _dev(dOutR, "dOutR"),
                                                         _dev(active_rows, "active_rows", torch.int32),
-                                                        _dev(seg_info, "seg_info", torch.int32), active_rows.numel(),
+                                                        _dev(seg_info, "seg_info", torch.int32),
+                                                        0 if active_rows is None else active_rows.numel(),
                                                         _dev(srcA, "srcA"), _dev(srcB, "srcB"), _dev(grad, "grad"),
                                                         _dev(active_mask, "active_mask", torch.int32),
                                                         _dev(workspace, "workspace", torch.uint8), workspace.numel(),

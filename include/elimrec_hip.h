@@ -246,8 +246,17 @@ int elimrec_propagate_folded_bwd(const elimrec_csr *AT, int64_t U, int64_t I, in
                                  const float *d_dOutR, const int32_t *d_active_rows, const int32_t *d_seg_info,
                                  int64_t n_max, float *d_SrcA, float *d_SrcB, float *d_grad,
                                  const uint32_t *d_active_mask /* nullable: bitmap of the active rows (the key bitmap of
-                                 elimrec_segment_plan); built internally when NULL */,
+                                 elimrec_segment_plan); built internally when NULL; required when d_dOutR is NULL = sources prefilled by
+                                 elimrec_merge_rank_rows) */,
                                  void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Data-parallel steps: every rank hands in the dOut rows [R x M*d] of its own active nodes with their node ids
+ * (ascending; unused slots carry a NEGATIVE id, see elimrec_pad_rows), all-gathered in rank order: d_rows [W*R x M*d],
+ * d_keys [W*R]. Rows of the same node are summed in rank order and left as the adjoint's source tables d_SrcA / d_SrcB
+ * (what elimrec_propagate_folded_bwd derives from dOut rows) with the row bitmap d_mask [(N+31)/32 words]; then call
+ * elimrec_propagate_folded_bwd with d_dOutR = NULL and d_active_mask = d_mask. W <= 64. */
+int elimrec_merge_rank_rows(const float *d_rows, const int32_t *d_keys, int W, int64_t R, int64_t U, int64_t I, int d,
+                            int M, float *d_SrcA, float *d_SrcB, uint32_t *d_mask, void *stream);
 
 /* One block SpMM with the fused epilogue on a W-column window of wider tables (row stride ld):
  *   r = A . Xin[:, 0:W];  if Xout: Xout = r;  if AccOut: AccOut = (r + Add1) * scale.

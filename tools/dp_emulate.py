@@ -14,6 +14,7 @@ for W in [int(x) for x in os.environ.get("DP_WORLDS", "1,2,4,8").split(",")]:
     scale = torch.full((1,), 1.0 / W, device="cuda:0")
     gathered_rows = torch.randn(W * 3 * B, model.C, device="cuda:0") * 1e-4
     gathered_keys = torch.zeros(W * 3 * B, dtype=torch.int32, device="cuda:0")
+    filled = [False]
     def step(i):
         sl = slice(i * B, (i + 1) * B)
         loss, _ = model.forward_local(U_[sl], P_[sl], N_[sl], world_size=W)
@@ -24,8 +25,15 @@ for W in [int(x) for x in os.environ.get("DP_WORLDS", "1,2,4,8").split(",")]:
             # stand-in for the collectives: W-1 other ranks' rows / ids (different nodes; values irrelevant for timing)
             all_rows = gathered_rows; all_rows[:rows.shape[0]].copy_(rows)
             all_keys = gathered_keys
-            for r in range(W):
-                all_keys[r * keys.numel():(r + 1) * keys.numel()].copy_((keys + 977 * r) % (ds.num_users + ds.num_items))
+            R = keys.numel()
+            all_keys[:R].copy_(keys)
+            if not filled[0]:                         # other ranks: the same node ids shifted, sorted, negative padding
+                valid = keys[keys >= 0]
+                for r in range(1, W):
+                    kr = torch.sort((valid + 977 * r) % (ds.num_users + ds.num_items))[0].to(torch.int32)
+                    all_keys[r * R:r * R + kr.numel()].copy_(kr)
+                    all_keys[r * R + kr.numel():(r + 1) * R].fill_(-1)
+                filled[0] = True
             grads = model.backward_rows_global(all_rows, all_keys)
     for i in range(3): step(i)
     torch.cuda.synchronize()
