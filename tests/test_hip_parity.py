@@ -480,6 +480,40 @@ def test_fused_segment_apply_head_bwd_equals_two_launches():
     assert torch.equal(dY1[:na], dY2[:na]) and torch.equal(out1[:na], out2[:na])
 
 
+@pytest.mark.parametrize("W,R,U,I,d,M", [(5, 300, 700, 1300, 32, 3), (2, 64, 40, 90, 64, 4), (8, 1000, 3000, 5000, 16, 2), (1, 50, 10, 200, 64, 4)])
+def test_merge_rank_rows_vs_torch(W, R, U, I, d, M):
+    """elimrec_merge_rank_rows: rows of the same node from different ranks summed (rank order), H / G source tables
+    and the row bitmap, against an fp64 index_add; padding slots and ranks with few rows included."""
+    from elimrec_amd import ops
+    gen = torch.Generator().manual_seed(W * 1000 + R)
+    N, C = U + I, d * M
+    keys = torch.full((W, R), -(1 << 30), dtype=torch.int32)
+    rows = torch.zeros(W, R, C)
+    for r in range(W):
+        n_r = R if r == 0 else int(torch.randint(1, R + 1, (1,), generator=gen))
+        k = torch.sort(torch.randperm(N, generator=gen)[:n_r])[0]
+        keys[r, :n_r] = k.to(torch.int32)
+        keys[r, n_r:] += torch.arange(n_r, R, dtype=torch.int32)
+        rows[r, :n_r] = torch.randn(n_r, C, generator=gen)
+    srcA = torch.full((N, d), float("nan"), device=DEV)
+    srcB = torch.full((N, d), float("nan"), device=DEV)
+    mask = torch.full(((N + 31) // 32 + 2,), -1, dtype=torch.int32, device=DEV)
+    ops.merge_rank_rows(rows.view(W * R, C).to(DEV), keys.view(-1).to(DEV), W, U, I, d, M, srcA, srcB, mask)
+    valid = keys.view(-1) >= 0
+    tot = torch.zeros(N, C, dtype=torch.float64).index_add_(0, keys.view(-1)[valid].long(), rows.view(-1, C)[valid].double())
+    active = torch.zeros(N, dtype=torch.bool)
+    active[keys.view(-1)[valid].long()] = True
+    words = mask[:(N + 31) // 32].cpu().numpy().view(np.uint32)
+    got = np.unpackbits(words.view(np.uint8), bitorder="little")[:N].astype(bool)
+    assert np.array_equal(got, active.numpy())
+    H = tot.view(N, M, d).sum(1)
+    G = tot[:, :d]
+    wantA = torch.where((torch.arange(N) < U)[:, None], H, G)
+    wantB = torch.where((torch.arange(N) < U)[:, None], G, H)
+    assert (srcA.cpu().double()[active] - wantA[active]).abs().max() < 1e-5
+    assert (srcB.cpu().double()[active] - wantB[active]).abs().max() < 1e-5
+
+
 def test_sampler_contract_on_device():
     from elimrec_amd import PairwiseSamplerV2, SyntheticDataset
     ds = SyntheticDataset(400, 300, 6000, feat_dims=(4, 4, 4), seed=9)
