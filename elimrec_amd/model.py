@@ -69,14 +69,18 @@ def create_adj_mat(train_users, train_items, num_users, num_items, adj_type):
 
 
 class _BprLossFn(torch.autograd.Function):
-    """Glue between torch's autograd/optimizer API (main.py:98-101) and the HIP path: forward
-    enqueues the forward kernels and returns the 0-dim loss; backward enqueues the backward
-    kernels and hands one gradient per parameter back (None for parameters the loss does not
-    reach, exactly the set the reference leaves without .grad)."""
+    """Glue between torch's autograd/optimizer API (main.py:98-101) and the HIP path: forward enqueues the forward
+    kernels and returns the 0-dim loss; backward enqueues the backward kernels and leaves every parameter's gradient in
+    `.grad` (nothing for parameters the loss does not reach, exactly the set the reference leaves without .grad).
+    The gradients live in one flat buffer laid out like the parameters; backward assigns its views to `.grad` itself
+    instead of returning them to autograd, whose AccumulateGrad would copy each of the 18 tensors (the views are not
+    "stealable") -- 18 clones per step, and an optimizer that no longer sees adjacent gradients. A `.grad` that already
+    holds something else is accumulated into, as autograd would."""
 
     @staticmethod
     def forward(ctx, model, users, pos, neg, *params):
         ctx.model = model
+        ctx.params = params
         ctx.names = model._param_names
         loss = model._forward_hip(users, pos, neg, need_grad=True)
         return loss
@@ -84,8 +88,19 @@ class _BprLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         model = ctx.model
-        grads = model._backward_hip(grad_out.reshape(1).to(torch.float32).contiguous())
-        return (None, None, None, None) + tuple(grads.get(n) for n in ctx.names)
+        # upstream gradient into a fixed buffer: the backward regions are recorded against stable addresses
+        gscale = model._ws.setdefault("gscale", torch.ones(1, dtype=torch.float32, device=grad_out.device))
+        gscale.copy_(grad_out.reshape(1))
+        grads = model._backward_hip(gscale)
+        for name, p in zip(ctx.names, ctx.params):
+            g = grads.get(name)
+            if g is None or not p.requires_grad:
+                continue
+            if p.grad is None:
+                p.grad = g
+            elif p.grad.data_ptr() != g.data_ptr():
+                p.grad.add_(g)
+        return (None,) * (4 + len(ctx.params))
 
 
 class EliMRec(BasicModel):
@@ -610,13 +625,19 @@ class EliMRec(BasicModel):
         self._region("fwd_head", (self._ws_gen, all_keys.data_ptr(), n, B, rank, tuple(bw), grad_rows is not None), head)
         self._publish_cache(ws["Y"], dirty=True)
 
+    def _index_tensors(self, *ts):
+        """int64, contiguous, on the model's device (no-ops for tensors that already are)."""
+        dev = self._device()
+        return tuple(t if (t.dtype == torch.int64 and t.device == dev and t.is_contiguous())
+                     else t.to(device=dev, dtype=torch.int64).contiguous() for t in ts)
+
     @torch.no_grad()
     def batch_keys(self, users, pos, neg):
         """int32 [3B] node ids of the triplet slots (3b: user, 3b+1: U + pos, 3b+2: U + neg) -- the rows the loss
         reads (getEmbedding's gathers, :274-289) and the keys of the head-gradient rows."""
         B = int(users.numel())
         ws = self._workspace(B, getattr(self, "_bwd_rows_hint", None))
-        users, pos, neg = (t.to(device=self._device(), dtype=torch.int64).contiguous() for t in (users, pos, neg))
+        users, pos, neg = self._index_tensors(users, pos, neg)
         return ops.triplet_rows(users, pos, neg, self.num_users, ws["keys"][:3 * B])
 
     @torch.no_grad()
@@ -626,7 +647,7 @@ class EliMRec(BasicModel):
         it depends on the indices only, the forward evaluates the head at the active rows, and the backward
         reduces the gathered gradient rows with it."""
         B = int(users.numel())
-        users, pos, neg = (t.to(device=self._device(), dtype=torch.int64).contiguous() for t in (users, pos, neg))
+        users, pos, neg = self._index_tensors(users, pos, neg)
         keys = self.batch_keys(users, pos, neg)
         ws = self._ws
         all_keys = keys if all_keys is None else all_keys
@@ -854,8 +875,10 @@ class EliMRec(BasicModel):
         self._require_gpu()
         if self.is_kwai:
             self.modality = "v"                        # :133-134
-        params = [p for _, p in self.named_parameters()]
-        return _BprLossFn.apply(self, users.long(), pos_items.long(), neg_items.long(), *params)
+        params = self.__dict__.get("_param_list")
+        if params is None:      # the Parameter objects are fixed after construction (they are re-pointed, never replaced)
+            params = self.__dict__["_param_list"] = [p for _, p in self.named_parameters()]
+        return _BprLossFn.apply(self, users, pos_items, neg_items, *params)
 
     def compute(self):
         """:228-272. Returns (all_users [U x d], all_items [I x d]) -- views into Y, no autograd."""
