@@ -19,7 +19,7 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 // --------------------------------------------------------------------------------- forward
 // Workgroup = 4 waves, tile 128 rows x 64 cols, K staged 32 at a time through LDS
 // (row stride 33 floats: the 32 lanes of a half-wave read 32 different rows at the same k).
-constexpr int FBM = 128, FBN = 64, FBK = 16, FLD = FBK + 1;
+constexpr int FBN = 64, FBK = 16, FLD = FBK + 1;
 
 constexpr int kMaxBatch = 8;
 struct FwdBatch { elimrec_linear_desc p[kMaxBatch]; };
