@@ -9,11 +9,13 @@ reference's own `Net` / `EliMRec` / `UniEvaluator` / `PairwiseSamplerV2` are
 driven on tiny synthetic datasets. Inputs and outputs are dumped as data.
 
     python tests/golden/make_golden.py            # writes tests/golden/*.npz
+    python tests/golden/make_golden.py gcmc       # only the named fixture(s)
 
 Fixtures (all fp32, CPU):
   ml3      3-modal generic loader path, concat fusion, adj_type=pre, rubi
   kwai     id+V only (dataset name "kwai"), 2 tables
   ablate   --modality=va, adj_type=norm (non-symmetric), mean fusion
+  gcmc     adj_type=gcmc (bipartite but NOT symmetric), 4 layers, --modality=vt
   metrics  known-answer vectors for the C++ top-K + metric kernels
   sampler  one epoch of PairwiseSamplerV2 on the ml3 data (libc rand stream)
 """
@@ -325,16 +327,27 @@ def main():
     w = prepare_copy()
     sys.path.insert(0, w)
     install_shims()
+    only = set(sys.argv[1:])
+    want = lambda name: not only or name in only
+    sys.argv = sys.argv[:1]
     try:
-        net = run_fixture(w, "ml3", "movielens", U=70, I=110, dims=(40, 24, 20),
-                          argv_extra=["--recdim=32", "--layer_num=3"], B=64, steps=3, seed=11)
-        sampler_epoch(w, net)
-        run_fixture(w, "kwai", "kwai", U=50, I=120, dims=(48,),
-                    argv_extra=["--recdim=64", "--layer_num=2"], B=48, steps=3, seed=22)
-        run_fixture(w, "ablate", "movielens", U=64, I=96, dims=(20, 36, 28),
-                    argv_extra=["--recdim=16", "--layer_num=3", "--adj_type=norm", "--modality=va",
-                                "--mm_fusion_mode=mean"], B=80, steps=3, seed=33)
-        metrics_kat(w)
+        if want("ml3") or want("sampler"):
+            net = run_fixture(w, "ml3", "movielens", U=70, I=110, dims=(40, 24, 20),
+                              argv_extra=["--recdim=32", "--layer_num=3"], B=64, steps=3, seed=11)
+            sampler_epoch(w, net)
+        if want("kwai"):
+            run_fixture(w, "kwai", "kwai", U=50, I=120, dims=(48,),
+                        argv_extra=["--recdim=64", "--layer_num=2"], B=48, steps=3, seed=22)
+        if want("ablate"):
+            run_fixture(w, "ablate", "movielens", U=64, I=96, dims=(20, 36, 28),
+                        argv_extra=["--recdim=16", "--layer_num=3", "--adj_type=norm", "--modality=va",
+                                    "--mm_fusion_mode=mean"], B=80, steps=3, seed=33)
+        if want("gcmc"):
+            run_fixture(w, "gcmc", "movielens", U=60, I=100, dims=(16, 12, 24),
+                        argv_extra=["--recdim=32", "--layer_num=4", "--adj_type=gcmc", "--modality=vt"], B=72, steps=3,
+                        seed=44)
+        if want("metrics"):
+            metrics_kat(w)
     finally:
         os.chdir("/")
         shutil.rmtree(w, ignore_errors=True)
