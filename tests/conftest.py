@@ -18,6 +18,6 @@ def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
 
 
-@pytest.fixture(scope="session", params=["ml3", "kwai", "ablate", "gcmc"])
+@pytest.fixture(scope="session", params=["ml3", "kwai", "ablate", "gcmc", "normal"])
 def fixture_name(request):
     return request.param

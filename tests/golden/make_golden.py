@@ -16,6 +16,7 @@ Fixtures (all fp32, CPU):
   kwai     id+V only (dataset name "kwai"), 2 tables
   ablate   --modality=va, adj_type=norm (non-symmetric), mean fusion
   gcmc     adj_type=gcmc (bipartite but NOT symmetric), 4 layers, --modality=vt
+  normal   --predict_type=normal (fused loss only: the single-modal heads get no gradient), adj_type=plain, 2 layers
   metrics  known-answer vectors for the C++ top-K + metric kernels
   sampler  one epoch of PairwiseSamplerV2 on the ml3 data (libc rand stream)
 """
@@ -175,6 +176,7 @@ def run_fixture(w, name, dataset, U, I, dims, argv_extra, B, steps, seed):
     out["dataset_name"] = np.array(dataset)
     out["modality"] = np.array(rec.modality)
     out["mm_fusion_mode"] = np.array(rec.mm_fusion_mode)
+    out["train_predict_type"] = np.array(str(rec.predict_type))      # what the training loss is built for (:125-126)
     tu, ti = ds.get_train_interactions()
     out["train_u"] = np.asarray(tu, np.int32)
     out["train_i"] = np.asarray(ti, np.int32)
@@ -346,6 +348,10 @@ def main():
             run_fixture(w, "gcmc", "movielens", U=60, I=100, dims=(16, 12, 24),
                         argv_extra=["--recdim=32", "--layer_num=4", "--adj_type=gcmc", "--modality=vt"], B=72, steps=3,
                         seed=44)
+        if want("normal"):
+            run_fixture(w, "normal", "movielens", U=48, I=130, dims=(12, 20, 8),
+                        argv_extra=["--recdim=64", "--layer_num=2", "--adj_type=plain", "--predict_type=normal"], B=56,
+                        steps=3, seed=55)
         if want("metrics"):
             metrics_kat(w)
     finally:

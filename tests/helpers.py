@@ -84,6 +84,8 @@ def fixture_argv(g):
             "--loss=bpr_loss", "--recdim=%d" % int(g["recdim"]), "--layer_num=%d" % int(g["layer_num"]),
             "--adj_type=%s" % str(g["adj_type"]), "--modality=%s" % str(g["modality"]),
             "--mm_fusion_mode=%s" % str(g["mm_fusion_mode"]), "--verbose=0"]
+    if "train_predict_type" in g:          # fixtures made before this field existed trained with the default (TIE)
+        argv.append("--predict_type=%s" % str(g["train_predict_type"]))
     return argv
 
 

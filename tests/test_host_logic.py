@@ -91,7 +91,7 @@ def test_model_construction_matches_reference_surface(fixture_name):
     mine = sp.csr_matrix((model.adj_val.numpy(), model.adj_col.numpy(), model.adj_rowptr.numpy()), shape=(n, n)).tocoo()
     ref_adj = sp.coo_matrix((g["adj_values"], (g["adj_indices"][0], g["adj_indices"][1])), shape=(n, n))
     assert (abs(mine - ref_adj)).max() == 0.0
-    assert model._adj_symmetric == (str(g["adj_type"]) == "pre")
+    assert model._adj_symmetric == (str(g["adj_type"]) in ("pre", "plain"))      # D^-1/2 A D^-1/2 and A itself
 
 
 def test_hot_path_fails_loudly_without_gpu():

@@ -13,7 +13,8 @@ def make_oracle(g, params_prefix="init"):
     adj = eo.build_adj(g["train_u"], g["train_i"], int(g["num_users"]), int(g["num_items"]), str(g["adj_type"]))
     return eo.OracleEliMRec(int(g["num_users"]), int(g["num_items"]), int(g["recdim"]), int(g["layer_num"]), adj,
                             feats_of(g), sub(g, params_prefix), float(g["alpha"]), dataset_name=str(g["dataset_name"]),
-                            modality=str(g["modality"]), mm_fusion_mode=str(g["mm_fusion_mode"])), adj
+                            modality=str(g["modality"]), mm_fusion_mode=str(g["mm_fusion_mode"]),
+                            predict_type=str(g["train_predict_type"]) if "train_predict_type" in g else "TIE"), adj
 
 
 def test_adjacency_matches_reference(fixture_name):
