@@ -461,6 +461,7 @@ __device__ __forceinline__ void combine_split_row(const HalfArgs &a, int li) {
 template <int LPR, int UNROLL>
 __device__ __forceinline__ void half_stream_rows(const HalfArgs &a, int seg_blocks) {
     constexpr int RPW = 64 / LPR;
+    static_assert(LPR >= UNROLL && LPR % UNROLL == 0, "one (col, val) per lane: a lane group holds LPR neighbours");
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR, cl = lane % LPR;
     const int wpb = blockDim.x >> 6;
@@ -477,54 +478,48 @@ __device__ __forceinline__ void half_stream_rows(const HalfArgs &a, int seg_bloc
             row = p[0]; beg = p[1]; end = p[2];
         }
     };
-    int cj[UNROLL], ncj[UNROLL];
-    float vj[UNROLL], nvj[UNROLL];
-    auto load_idx = [&](int beg, int end, int (&c)[UNROLL], float (&v)[UNROLL]) {
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) {
-            const bool in = beg + u < end;
-            c[u] = in ? a.col[beg + u] : 0;
-            v[u] = in ? a.val[beg + u] : 0.f;
-        }
+    // neighbour indices: lane cl of a group holds neighbour (base + cl) of the group's row -- ONE coalesced load per
+    // LPR neighbours instead of UNROLL broadcast loads per UNROLL neighbours; the gather reads them by shuffle
+    int mc, nmc;
+    float mv, nmv;
+    auto load_idx = [&](int j, int end, int &c, float &v) {
+        const bool in = j + cl < end;
+        c = in ? a.col[j + cl] : 0;
+        v = in ? a.val[j + cl] : 0.f;
     };
     load_trip(0, crow, cbeg, cend);
     load_trip(1, nrow, nbeg, nend);
-    load_idx(cbeg, cend, cj, vj);
+    load_idx(cbeg, cend, mc, mv);
     for (int64_t k = 0; (wave_g + k * n_slots) * RPW < n_items; ++k) {
         int frow, fbeg, fend;
         load_trip(k + 2, frow, fbeg, fend);
-        load_idx(nbeg, nend, ncj, nvj);
+        load_idx(nbeg, nend, nmc, nmv);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        {
-            float4 x[UNROLL];
+        // every lane walks the chunks of the LONGEST row of the wave (shuffles need all lanes); shorter rows add zeros
+        int len = cend - cbeg;
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u)
-                x[u] = (con && cbeg + u < cend) ? a.Xin[(int64_t)cj[u] * a.ld4 + cl] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int o = 32; o >= LPR; o >>= 1) len = max(len, __shfl_xor(len, o, 64));
+        for (int base = 0; base < len; base += UNROLL) {
+            if (base > 0 && base % LPR == 0) load_idx(cbeg + base, cend, mc, mv);
+            float4 x[UNROLL];
+            float vj[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int src = sub * LPR + ((base + u) % LPR);
+                const int cj = __shfl(mc, src, 64);
+                vj[u] = __shfl(mv, src, 64);
+                x[u] = (con && cbeg + base + u < cend) ? a.Xin[(int64_t)cj * a.ld4 + cl] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u) {
                 acc.x = fmaf(vj[u], x[u].x, acc.x); acc.y = fmaf(vj[u], x[u].y, acc.y);
                 acc.z = fmaf(vj[u], x[u].z, acc.z); acc.w = fmaf(vj[u], x[u].w, acc.w);
             }
         }
-        for (int j = cbeg + UNROLL; j < cend; j += UNROLL) {      // rows longer than one chunk
-            int c2[UNROLL];
-            float v2[UNROLL];
-            float4 x[UNROLL];
-            load_idx(j, cend, c2, v2);
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u)
-                x[u] = (con && j + u < cend) ? a.Xin[(int64_t)c2[u] * a.ld4 + cl] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                acc.x = fmaf(v2[u], x[u].x, acc.x); acc.y = fmaf(v2[u], x[u].y, acc.y);
-                acc.z = fmaf(v2[u], x[u].z, acc.z); acc.w = fmaf(v2[u], x[u].w, acc.w);
-            }
-        }
         if (con && crow >= 0) half_epilogue(a, crow, cl, acc);
         crow = nrow; cbeg = nbeg; cend = nend;
         nrow = frow; nbeg = fbeg; nend = fend;
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) { cj[u] = ncj[u]; vj[u] = nvj[u]; }
+        mc = nmc; mv = nmv;
     }
 }
 
@@ -538,9 +533,11 @@ __global__ __launch_bounds__(256) void half_hop_kernel(HalfArgs a, int seg_block
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR, cl = lane % LPR;
     const bool seg_mode = (int)blockIdx.x < seg_blocks;            // workgroup-uniform
-    if (!MASKED && !seg_mode && a.row_items && !a.row_list && a.W4 <= LPR) {      // workgroup-uniform
-        half_stream_rows<LPR, UNROLL>(a, seg_blocks);
-        return;
+    if constexpr (LPR >= UNROLL) {
+        if (!MASKED && !seg_mode && a.row_items && !a.row_list && a.W4 <= LPR) {      // workgroup-uniform
+            half_stream_rows<LPR, UNROLL>(a, seg_blocks);
+            return;
+        }
     }
     const int64_t blk = seg_mode ? blockIdx.x : (blockIdx.x - seg_blocks);
     int64_t item = (blk * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RPW + sub;
@@ -685,7 +682,7 @@ static int launch_half(const elimrec_csr *m, HalfArgs a, size_t partials_offset,
         else {                                                                                                       \
             /* streaming rows: a persistent grid (stream_wgs workgroups walk all items) */                           \
             unsigned row_blocks = blocks(a.row_list ? a.row_list_cap : a.n_rows).x;                                  \
-            if (a.row_items && !a.row_list && a.W4 <= LPR) {                                                         \
+            if (LPR >= 8 && a.row_items && !a.row_list && a.W4 <= LPR) {                                             \
                 row_blocks = blocks(a.n_row_items).x;                                                                \
                 if (row_blocks > (unsigned)stream_wgs()) row_blocks = (unsigned)stream_wgs();                        \
                 if (row_blocks == 0) row_blocks = 1;                                                                 \
