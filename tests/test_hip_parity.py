@@ -763,7 +763,8 @@ def _full_shape_step(U, I, E, dims, recdim, B, dataset_name, extra_argv=()):
 
 
 @pytest.mark.parametrize("L,recdim,B,dims", [(1, 64, 257, (24, 8, 12)), (2, 32, 1000, (36, 4, 20)), (4, 64, 513, (8, 8, 8)),
-                                             (3, 16, 64, (100, 12, 4)), (2, 128, 300, (16, 16, 16))])
+                                             (3, 16, 64, (100, 12, 4)), (2, 128, 300, (16, 16, 16)), (3, 64, 1, (8, 8, 8)),
+                                             (3, 32, 3, (8, 12, 4))])
 def test_small_shapes_layers_and_widths_vs_oracle(L, recdim, B, dims):
     """Layer counts 1..4 (L = 1 runs the eager tables, L = 2 ends on the hop that forms N02, L = 4 adds a second
     user-side term to the shared part), recdim 16..128 (lane groups of 4..32, VALU and MFMA head kernels), ragged
