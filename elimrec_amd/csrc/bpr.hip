@@ -550,26 +550,53 @@ __global__ __launch_bounds__(512) void head_bwd_input_mfma_kernel(const float *_
     if (s0 >= n_act) return;
     const int rows = (int)((n_act - s0) < HM_ROWS ? (n_act - s0) : HM_ROWS);
     const float seg_scale = (seg.rows && seg.scale) ? seg.scale[0] : 1.f;
-    for (int e = tid * 4; e < HM_ROWS * Cy; e += 2048) {
-        const int r = e / Cy, c = e - r * Cy;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < rows) {
-            if (seg.rows) {
-                // fused segment reduce: dY[s] = scale * sum of the member gradient rows in ascending slot order
-                // (bit for bit what segment_sum_kernel writes); the reduced row is also stored for linear_bwd_w
-                const int beg = seg.seg_start[s0 + r], end = seg.seg_start[s0 + r + 1];
-                for (int i = beg; i < end; ++i) {
-                    const float4 x = ld4(seg.rows + (int64_t)seg.members[i] * Cy + c);
-                    v.x += x.x; v.y += x.y; v.z += x.z; v.w += x.w;
+    // Staging in batches of HM_STAGE elements per thread so that the dependent loads of the fused segment reduce
+    // (segment bounds -> member slot -> gradient row) are issued for all of a thread's elements at once: three
+    // memory round trips per batch, not three per element. Rows have one member nearly always; further members are
+    // added in ascending slot order by the (rare) loop, so the sums are the ones segment_sum_kernel forms.
+    constexpr int HM_STAGE = 4;
+    for (int e0 = tid * 4; e0 < HM_ROWS * Cy; e0 += 2048 * HM_STAGE) {
+        int r[HM_STAGE], c[HM_STAGE], beg[HM_STAGE], end[HM_STAGE], mem[HM_STAGE];
+        bool in[HM_STAGE];
+        float4 v[HM_STAGE];
+#pragma unroll
+        for (int q = 0; q < HM_STAGE; ++q) {
+            const int e = e0 + 2048 * q;
+            r[q] = e / Cy; c[q] = e - r[q] * Cy;
+            in[q] = e < HM_ROWS * Cy && r[q] < rows;
+            beg[q] = 0; end[q] = 0;
+            if (in[q] && seg.rows) { beg[q] = seg.seg_start[s0 + r[q]]; end[q] = seg.seg_start[s0 + r[q] + 1]; }
+        }
+        if (seg.rows) {
+#pragma unroll
+            for (int q = 0; q < HM_STAGE; ++q) mem[q] = (in[q] && beg[q] < end[q]) ? seg.members[beg[q]] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < HM_STAGE; ++q) {
+            v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (in[q]) {
+                if (!seg.rows) v[q] = ld4(dY + (s0 + r[q]) * lddy + c[q]);
+                else if (beg[q] < end[q]) {
+                    const float4 x = ld4(seg.rows + (int64_t)mem[q] * Cy + c[q]);
+                    v[q].x += x.x; v[q].y += x.y; v[q].z += x.z; v[q].w += x.w;    // 0 + x, as the serial loop does
                 }
-                v = make_float4(v.x * seg_scale, v.y * seg_scale, v.z * seg_scale, v.w * seg_scale);
-                st4(seg.reduced + (s0 + r) * lddy + c, v);
-            } else {
-                v = ld4(dY + (s0 + r) * lddy + c);
             }
         }
-        float *dst = dys + r * ldy + c;
-        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+#pragma unroll
+        for (int q = 0; q < HM_STAGE; ++q) {
+            const int e = e0 + 2048 * q;
+            if (e >= HM_ROWS * Cy) continue;
+            if (in[q] && seg.rows) {
+                for (int i = beg[q] + 1; i < end[q]; ++i) {
+                    const float4 x = ld4(seg.rows + (int64_t)seg.members[i] * Cy + c[q]);
+                    v[q].x += x.x; v[q].y += x.y; v[q].z += x.z; v[q].w += x.w;
+                }
+                v[q] = make_float4(v[q].x * seg_scale, v[q].y * seg_scale, v[q].z * seg_scale, v[q].w * seg_scale);
+                st4(seg.reduced + (s0 + r[q]) * lddy + c[q], v[q]);
+            }
+            float *dst = dys + r[q] * ldy + c[q];
+            dst[0] = v[q].x; dst[1] = v[q].y; dst[2] = v[q].z; dst[3] = v[q].w;
+        }
     }
     if (tid < HM_ROWS) node[tid] = (tid < rows) ? (int64_t)active_rows[s0 + tid] : -1;
     __syncthreads();
