@@ -37,45 +37,51 @@ class Logger(object):
             Logger.logger.log(*msg)
 
 
+HISTORY_FIELDS = ("epoch", "val", "sum", "avg", "time", "count")
+
+
 class Meter(object):
-    """val / running avg / history, printed as `[name val (avg) time:t]`."""
+    """Last value, running mean and the full update history of one scalar (a loss, a metric). Printed as
+    `[name val (avg) time:t]`, t = seconds since the last reset_time() -- the line format of the reference's meters
+    (util/meter.py), which the driver's log lines embed."""
 
     def __init__(self, name, fmt=":f", id=None):
-        self.name, self.fmt, self.id = name, fmt, id
+        self.name, self.id = name, id
+        self._pattern = "[%s {0%s} ({1%s}) time:{2}]" % ("{3}", fmt, fmt)
         self.reset()
 
     def reset(self):
-        self.val = self.avg = self.sum = self.count = 0
-        self.history = []
-        self.epoch = 0
-        self._start_time = 0
+        self.history = []                 # one dict per update(), keys HISTORY_FIELDS
+        self.val = self.sum = self.count = self.epoch = 0
         self.time = 0
+        self._t0 = 0
         return self
 
+    @property
+    def avg(self):
+        return self.sum / self.count if self.count else 0
+
     def reset_time(self):
-        self._start_time = time.time()
+        self._t0 = time.time()
 
     def update(self, val, epoch=0, n=1):
-        self.val = val
-        self.sum += val * n
+        self.val, self.epoch = val, epoch
+        self.sum += n * val
         self.count += n
-        self.avg = self.sum / self.count
-        self.epoch = epoch
-        self.time = time.time() - self._start_time
-        self.history.append(dict(epoch=epoch, val=val, sum=self.sum, avg=self.avg, time=self.time, count=self.count))
+        self.time = time.time() - self._t0
+        self.history.append(dict(zip(HISTORY_FIELDS, (epoch, val, self.sum, self.avg, self.time, self.count))))
 
     def save_history(self, path=""):
+        """CSV of the history, `<path>/<name>_<id>.csv`; False when nothing was recorded."""
         if not self.history:
             print("No %s data updated!" % self.name)
             return False
-        file_path = "%s/%s_%s.csv" % (path, self.name, self.id)
-        keys = list(self.history[0].keys())
-        with open(file_path, "w", encoding="utf-8") as f:
-            f.write(",".join(keys) + "\n")
-            for row in self.history:
-                f.write(",".join(str(row[k]) for k in keys) + "\n")
-        print("[saved %s %d]:to %s" % (self.name, int(time.time()), file_path))
+        target = os.path.join(path, "%s_%s.csv" % (self.name, self.id)) if path else "/%s_%s.csv" % (self.name, self.id)
+        with open(target, "w", encoding="utf-8") as out:
+            out.write(",".join(HISTORY_FIELDS) + "\n")
+            out.writelines(",".join(str(row[f]) for f in HISTORY_FIELDS) + "\n" for row in self.history)
+        print("[saved %s %d]:to %s" % (self.name, int(time.time()), target))
         return True
 
     def __str__(self):
-        return ("[{name} {val" + self.fmt + "} ({avg" + self.fmt + "}) time:{time}]").format(**self.__dict__)
+        return self._pattern.format(self.val, self.avg, self.time, self.name)
