@@ -1278,7 +1278,7 @@ __device__ __forceinline__ int merge_key(const int32_t *keys, int i) {      // p
 }
 
 __global__ __launch_bounds__(256) void merge_rank_rows_kernel(const float *__restrict__ rows, const int32_t *__restrict__ keys,
-                                                              int W, int R, int64_t U, int64_t N, int d, int M, int chunk,
+                                                              int W, int R, int64_t U, int64_t N, int d, int M, int hg, int chunk,
                                                               float *SrcA, float *SrcB, uint32_t *__restrict__ mask) {
     __shared__ int s_beg[kMaxRanks], s_end[kMaxRanks];
     extern __shared__ uint32_t seen[];                   // [chunk / 32]
@@ -1295,7 +1295,7 @@ __global__ __launch_bounds__(256) void merge_rank_rows_kernel(const float *__res
         s_beg[tid] = a0; s_end[tid] = b0;
     }
     __syncthreads();
-    const int d4 = d / 4, C = d * M;
+    const int d4 = d / 4, C = hg ? 2 * d : d * M;        // hg: the rows are [H | G] already (elimrec_source_rows)
     for (int r = 0; r < W; ++r) {
         for (int s = s_beg[r] + wave; s < s_end[r]; s += 4) {
             const int64_t node = keys[(int64_t)r * R + s];
@@ -1305,11 +1305,15 @@ __global__ __launch_bounds__(256) void merge_rank_rows_kernel(const float *__res
             float *h_dst = (node < U ? SrcA : SrcB) + node * (int64_t)d;
             float *g_dst = (node < U ? SrcB : SrcA) + node * (int64_t)d;
             for (int c = lane; c < d4; c += 64) {
-                const float4 g0 = g[c];
-                float4 h = g0;
-                for (int m = 1; m < M; ++m) {
-                    const float4 x = g[m * d4 + c];
-                    h.x += x.x; h.y += x.y; h.z += x.z; h.w += x.w;
+                float4 g0, h;
+                if (hg) { h = g[c]; g0 = g[d4 + c]; }
+                else {
+                    g0 = g[c];
+                    h = g0;
+                    for (int m = 1; m < M; ++m) {
+                        const float4 x = g[m * d4 + c];
+                        h.x += x.x; h.y += x.y; h.z += x.z; h.w += x.w;
+                    }
                 }
                 float4 ho = h, go = g0;
                 if (was) {                               // written by an earlier rank of this workgroup: read through L2
@@ -1338,17 +1342,52 @@ __global__ __launch_bounds__(256) void merge_rank_rows_kernel(const float *__res
 }
 }  // namespace elimrec
 
+namespace elimrec {
+// [H | G] of every active row: H = sum of the M column blocks of its dOut row (block order), G = block 0 -- all the
+// adjoint propagation needs of a dOut row, at half the bytes (what a rank puts on the wire in a data-parallel step)
+__global__ __launch_bounds__(256) void source_rows_kernel(const float *__restrict__ dOutR, const int32_t *__restrict__ count,
+                                                          int64_t n_max, int d4, int M, float *__restrict__ out) {
+    const int64_t s = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int sub = threadIdx.x & 15;
+    if (s >= n_max || s >= *count) return;
+    const float4 *g = reinterpret_cast<const float4 *>(dOutR) + s * (int64_t)d4 * M;
+    float4 *o = reinterpret_cast<float4 *>(out) + s * (int64_t)d4 * 2;
+    for (int c = sub; c < d4; c += 16) {
+        const float4 g0 = g[c];
+        float4 h = g0;
+        for (int m = 1; m < M; ++m) {
+            const float4 x = g[m * d4 + c];
+            h.x += x.x; h.y += x.y; h.z += x.z; h.w += x.w;
+        }
+        o[c] = h;
+        o[d4 + c] = g0;
+    }
+}
+}  // namespace elimrec
+
+extern "C" int elimrec_source_rows(const float *d_dOutR, const int32_t *d_count, int64_t n_max, int d, int M, float *d_out,
+                                   void *stream) {
+    ELIMREC_REQUIRE(d_dOutR && d_count && d_out, "source_rows: null pointer");
+    ELIMREC_REQUIRE(d > 0 && d % 4 == 0 && M >= 1, "source_rows: bad d/M");
+    if (n_max <= 0) return 0;
+    hipLaunchKernelGGL(source_rows_kernel, dim3((unsigned)((n_max + 15) / 16)), dim3(256), 0, (hipStream_t)stream, d_dOutR,
+                       d_count, n_max, d / 4, M, d_out);
+    ELIMREC_LAUNCH_CHECK("source_rows");
+    return 0;
+}
+
 extern "C" int elimrec_merge_rank_rows(const float *d_rows, const int32_t *d_keys, int W, int64_t R, int64_t U, int64_t I,
                                        int d, int M, float *d_SrcA, float *d_SrcB, uint32_t *d_mask, void *stream) {
     ELIMREC_REQUIRE(d_rows && d_keys && d_SrcA && d_SrcB && d_mask, "merge_rank_rows: null pointer");
     ELIMREC_REQUIRE(W >= 1 && W <= kMaxRanks && R >= 1 && R < INT32_MAX, "merge_rank_rows: 1..%d ranks", kMaxRanks);
-    ELIMREC_REQUIRE(d > 0 && d % 4 == 0 && M >= 1, "merge_rank_rows: bad d/M");
+    ELIMREC_REQUIRE(d > 0 && d % 4 == 0 && M >= 0, "merge_rank_rows: bad d/M");
+    const int hg = M == 0;                               // M = 0: the rows are [H | G] (2d columns)
     const int64_t N = U + I;
     int chunk = (int)((N + 1023) / 1024);                // ~1024 workgroups
     chunk = (chunk + 31) / 32 * 32;
     const unsigned grid = (unsigned)((N + chunk - 1) / chunk);
     hipLaunchKernelGGL(merge_rank_rows_kernel, dim3(grid), dim3(256), (size_t)(chunk / 32) * sizeof(uint32_t),
-                       (hipStream_t)stream, d_rows, d_keys, W, (int)R, U, N, d, M, chunk, d_SrcA, d_SrcB, d_mask);
+                       (hipStream_t)stream, d_rows, d_keys, W, (int)R, U, N, d, M, hg, chunk, d_SrcA, d_SrcB, d_mask);
     ELIMREC_LAUNCH_CHECK("merge_rank_rows");
     return 0;
 }

@@ -8,7 +8,8 @@ per step. What actually differs between ranks is tiny: the gradient of the loss 
 3B gathered head rows. So per step each rank
   1. runs the forward and the head's backward on its own B triplets (tables are bit-identical on every rank): loss,
      dOut rows of its active nodes, its share of the projection-weight gradients, all scaled by 1/world_size,
-  2. all-gathers the [3B x C] dOut rows + int32 node ids (6.3 MB per rank at B=2048) and all-reduces the span of the
+  2. all-gathers the [3B x 2d] source rows ([sum of dOut's column blocks | block 0]) + int32 node ids (3.1 MB per
+     rank at B=2048) and all-reduces the span of the
      flat gradient buffer that holds the projection-weight gradients (0.3 MB),
   3. sums the gathered rows per node in rank order (elimrec_merge_rank_rows) and runs the SAME deterministic adjoint
      propagation + Adam.

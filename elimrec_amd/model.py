@@ -359,6 +359,8 @@ class EliMRec(BasicModel):
         ws["seg_info"] = torch.zeros(8, dtype=torch.int32, device=dev)
         ws["plan_ws"] = torch.empty(max(ops.segment_plan_workspace(n3), 1), dtype=torch.uint8, device=dev)
         shapes = [(n3, d, C), (n3, d, C)] + [(n3, d, d)] * self.S
+        if self._lazy:
+            ws["dp_rows"] = torch.empty(3 * B, 2 * d, **f32)       # data-parallel: [H | G] of the local active rows
         if self._folded:    # the folded feature projections' weight gradients ride in the same launch
             ws["dOutR"] = torch.empty(n3, C, **f32)                # dLoss/dOut rows in slot order
             shapes += [(n3, d, getattr(self, m + "_feat").shape[1]) for m in self._mods]
@@ -843,27 +845,30 @@ class EliMRec(BasicModel):
 
     @torch.no_grad()
     def backward_local(self, scale):
-        """-> (dOut rows [3B x C] of this rank's active nodes in ascending node order, zero beyond their count; int32
-        node ids [3B], negative in the unused slots; the span of the flat gradient buffer that holds every
+        """-> ([H | G] source rows [3B x 2d] of this rank's active nodes in ascending node order, zero beyond their
+        count; int32 node ids [3B], negative in the unused slots; the span of the flat gradient buffer that holds every
         projection-weight gradient)."""
         ws, n = self._ws, self._plan_n
         self._dp_grads = self._backward_batch_rows(ws, scale, ws["grad_rows"], n, head_only=True)
-        rows, keys = ws["dOutR"][:n], ws["active_rows"][:n]
+        keys = ws["active_rows"][:n]
+        # all the adjoint propagation needs of a dOut row is [sum of its blocks | block 0]: half the bytes on the wire
+        rows = ws["dp_rows"][:n]
+        ops.source_rows(ws["dOutR"][:n], ws["seg_info"][0:1], self.latent_dim, self.M, rows)
         ops.pad_rows(rows, keys, ws["seg_info"][0:1], pad_key=-(1 << 30))
         return rows, keys, ws["flat_grad"][ws["tail_off"]:]
 
     @torch.no_grad()
     def backward_rows_global(self, all_rows, all_keys):
-        """all_rows [W*3B x C] / all_keys [W*3B]: backward_local's rows and ids of every rank in rank order (the
+        """all_rows [W*3B x 2d] / all_keys [W*3B]: backward_local's rows and ids of every rank in rank order (the
         weight-gradient span already all-reduced in place, or being reduced: it is not read here)."""
         ws, n, n_local = self._ws, int(all_keys.numel()), self._plan_n
         world = n // n_local
-        if world * n_local != n or all_rows.shape != (n, self.C):
+        if world * n_local != n or all_rows.shape != (n, 2 * self.latent_dim):
             raise RuntimeError("gathered rows/keys do not match %d ranks x %d slots" % (world, n_local))
         U, I, d, M = self.num_users, self.num_items, self.latent_dim, self.M
         # rows of the same node (from different ranks) summed in rank order, straight into the adjoint's sources
         self._region("bwd_merge", (self._ws_gen, all_rows.data_ptr(), all_keys.data_ptr(), n),
-                     lambda: ops.merge_rank_rows(all_rows, all_keys, world, U, I, d, M, ws["SrcA"], ws["SrcB"], ws["act_mask"]))
+                     lambda: ops.merge_rank_rows(all_rows, all_keys, world, U, I, d, 0, ws["SrcA"], ws["SrcB"], ws["act_mask"]))
         grads = dict(self._dp_grads)
         self._backward_hops(ws, None, None, None, n, grads)
         return grads

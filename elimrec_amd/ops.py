@@ -316,10 +316,18 @@ def folded_combine(layers, U, I, d, L, out0, narrow):
                                                   _dev(narrow, "narrow"), _stream()), "folded_combine")
 
 
+def source_rows(dOutR, count, d, M, out):
+    """out[s] = [sum of the M column blocks | block 0] of dOutR[s] for s < count (device int32 scalar)."""
+    assert dOutR.is_contiguous() and out.is_contiguous() and dOutR.shape[1] == d * M and out.shape == (dOutR.shape[0], 2 * d)
+    _lib.check(_lib.load().elimrec_source_rows(_dev(dOutR, "dOutR"), _dev(count, "count", torch.int32), dOutR.shape[0], d, M,
+                                               _dev(out, "out"), _stream()), "source_rows")
+
+
 def merge_rank_rows(all_rows, all_keys, world, U, I, d, M, srcA, srcB, mask):
-    """Sum the all-gathered dOut rows per node in rank order into the adjoint's source tables + row bitmap."""
+    """Sum the all-gathered rows per node in rank order into the adjoint's source tables + row bitmap. M >= 1: dOut
+    rows [.. x M*d]; M = 0: [H | G] rows [.. x 2d] from source_rows."""
     R = all_keys.numel() // world
-    assert all_rows.is_contiguous() and all_rows.shape == (world * R, d * M) and all_keys.numel() == world * R
+    assert all_rows.is_contiguous() and all_rows.shape == (world * R, d * M if M else 2 * d) and all_keys.numel() == world * R
     assert srcA.is_contiguous() and srcB.is_contiguous() and mask.numel() * 32 >= U + I
     _lib.check(_lib.load().elimrec_merge_rank_rows(_dev(all_rows, "all_rows"), _dev(all_keys, "all_keys", torch.int32), world,
                                                    R, U, I, d, M, _dev(srcA, "srcA"), _dev(srcB, "srcB"),

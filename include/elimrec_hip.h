@@ -254,7 +254,10 @@ int elimrec_propagate_folded_bwd(const elimrec_csr *AT, int64_t U, int64_t I, in
  * (ascending; unused slots carry a NEGATIVE id, see elimrec_pad_rows), all-gathered in rank order: d_rows [W*R x M*d],
  * d_keys [W*R]. Rows of the same node are summed in rank order and left as the adjoint's source tables d_SrcA / d_SrcB
  * (what elimrec_propagate_folded_bwd derives from dOut rows) with the row bitmap d_mask [(N+31)/32 words]; then call
- * elimrec_propagate_folded_bwd with d_dOutR = NULL and d_active_mask = d_mask. W <= 64. */
+ * elimrec_propagate_folded_bwd with d_dOutR = NULL and d_active_mask = d_mask. W <= 64. M = 0: the rows are the
+ * [H | G] pairs of elimrec_source_rows (2d columns) -- half the bytes on the wire. */
+int elimrec_source_rows(const float *d_dOutR, const int32_t *d_count, int64_t n_max, int d, int M, float *d_out /* [n x 2d] */,
+                        void *stream);
 int elimrec_merge_rank_rows(const float *d_rows, const int32_t *d_keys, int W, int64_t R, int64_t U, int64_t I, int d,
                             int M, float *d_SrcA, float *d_SrcB, uint32_t *d_mask, void *stream);
 

@@ -512,6 +512,17 @@ def test_merge_rank_rows_vs_torch(W, R, U, I, d, M):
     wantB = torch.where((torch.arange(N) < U)[:, None], G, H)
     assert (srcA.cpu().double()[active] - wantA[active]).abs().max() < 1e-5
     assert (srcB.cpu().double()[active] - wantB[active]).abs().max() < 1e-5
+    # the same from [H | G] rows (elimrec_source_rows, what the ranks put on the wire): M = 0
+    hg = torch.zeros(W * R, 2 * d, device=DEV)
+    for r in range(W):
+        cnt = torch.tensor([int((keys[r] >= 0).sum())], dtype=torch.int32, device=DEV)
+        ops.source_rows(rows[r].to(DEV).contiguous(), cnt, d, M, hg[r * R:(r + 1) * R])
+    srcA2, srcB2 = torch.full_like(srcA, float("nan")), torch.full_like(srcB, float("nan"))
+    mask2 = torch.full_like(mask, -1)
+    ops.merge_rank_rows(hg, keys.view(-1).to(DEV), W, U, I, d, 0, srcA2, srcB2, mask2)
+    assert torch.equal(mask2[:(N + 31) // 32], mask[:(N + 31) // 32])
+    assert (srcA2.cpu().double()[active] - wantA[active]).abs().max() < 1e-5
+    assert (srcB2.cpu().double()[active] - wantB[active]).abs().max() < 1e-5
 
 
 def test_sampler_contract_on_device():

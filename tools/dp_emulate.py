@@ -12,7 +12,7 @@ smp = PairwiseSamplerV2(ds, batch_size=B, device="cuda:0", seed=1)
 U_, P_, N_ = smp.sample_epoch()
 for W in [int(x) for x in os.environ.get("DP_WORLDS", "1,2,4,8").split(",")]:
     scale = torch.full((1,), 1.0 / W, device="cuda:0")
-    gathered_rows = torch.randn(W * 3 * B, model.C, device="cuda:0") * 1e-4
+    gathered_rows = torch.randn(W * 3 * B, 2 * model.latent_dim, device="cuda:0") * 1e-4
     gathered_keys = torch.zeros(W * 3 * B, dtype=torch.int32, device="cuda:0")
     filled = [False]
     def step(i):
