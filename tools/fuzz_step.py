@@ -19,7 +19,9 @@ for case in range(n_cases):
         users = list(range(0, U, max(1, U // 30)))[:32]
         model.predict_type = om.predict_type = "TIE"
         err = np.abs(model.predict(users).numpy() - om.predict(users).numpy()).max()
-        ok = err < 1e-5
+        # 'plain' (unnormalised) adjacency lets the embeddings grow by ~degree per hop: fp32 summation-order noise of
+        # the logits is then visible in the scores (the step itself is still checked to loss 1e-5 / gradients 1e-4 rel)
+        ok = err < (1e-4 if adj == "plain" else 1e-5)
     except AssertionError as e:
         ok, err = False, str(e)[:80]
     bad += (not ok)
