@@ -42,6 +42,31 @@ __device__ __forceinline__ float fuse(int mode, float x, const float *z, int S, 
     }
 }
 
+// fuse(x) and fuse(m) for the same z at once: the per-head sigmoids are computed once and applied to both in the
+// order fuse() applies them, so both results have the bits two separate calls give
+__device__ __forceinline__ void fuse2(int mode, float x, float m, const float *z, int S, uint32_t mask, float &fx, float &fm) {
+    if (mode == 0) {
+        fx = x; fm = m;
+#pragma unroll
+        for (int h = 0; h < kMaxS; ++h)
+            if (h < S && (mask & (1u << h))) { const float sg = sigmoidf_(z[h]); fx *= sg; fm *= sg; }
+    } else if (mode == 1) {
+        float tx = sigmoidf_(x), tm = sigmoidf_(m);
+#pragma unroll
+        for (int h = 0; h < kMaxS; ++h)
+            if (h < S) { const float sg = sigmoidf_(z[h]); tx *= sg; tm *= sg; }
+        fx = logf(tx + 1e-12f) - log1pf(tx);
+        fm = logf(tm + 1e-12f) - log1pf(tm);
+    } else {
+        float tx = x, tm = m;
+#pragma unroll
+        for (int h = 0; h < kMaxS; ++h)
+            if (h < S) { tx += z[h]; tm += z[h]; }
+        fx = logf(sigmoidf_(tx) + 1e-12f);
+        fm = logf(sigmoidf_(tm) + 1e-12f);
+    }
+}
+
 // PASS 1: partial row sums of ui = sigmoid(<Yf[u], Yf[item]>) over this item tile.
 // PASS 2: final scores.
 template <int PASS>
@@ -213,6 +238,100 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(ScoreArgs a) {
             else out = sigmoidf_(te - fuse(a.fusion_mode, a.row_mean[b], z, a.S, a.head_mask));
         }
         a.scores[(int64_t)b * a.lds + item] = out;
+    }
+}
+
+// The same scorer with the USERS resident: the kernel above re-stages the 128 user rows (128 KB) for every 32-item
+// tile, 2 378 times per block at the Tiktok shape, and that staging -- not the MFMAs -- is where its time goes
+// (12 % of the fp32 MFMA rate). Here a workgroup keeps its 128 users for the whole launch: every wave holds the MFMA
+// A operands of its 32 users in registers (NB * D / 2 floats per lane), the workgroup walks item tiles
+// blockIdx.x, + gridDim.x, ... and only the 32 item rows of a tile go through LDS. Same k order per output and the
+// same partial-sum layout as score_mfma_kernel, so the scores are bit-identical.
+template <int PASS, int NB, int D>
+__global__ __launch_bounds__(256) void score_resident_kernel(ScoreArgs a, int n_tiles) {
+    constexpr int NH = (PASS == 1) ? 1 : NB;          // head blocks this pass needs
+    constexpr int COLS = NH * D, LD = COLS + 1;
+    __shared__ float it[MI * LD];
+    __shared__ float unorm[MU * (NB > 1 ? NB - 1 : 1)];   // max(|user block 1+h|, eps)
+    __shared__ float umean[MU];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lk = lane >> 5;
+    const int b0 = blockIdx.y * MU;
+    const float eps = 1e-12f;
+    // A operands: user (wave*32 + li), element k = 2*ks + lk of head block h
+    float ua[NH][D / 2];
+    {
+        const int ub = b0 + wave * 32 + li;
+        const float *urow = ub < a.B ? a.Y + a.users[ub] * a.ldy + lk : nullptr;
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int ks = 0; ks < D / 2; ++ks) ua[h][ks] = urow ? urow[h * D + 2 * ks] : 0.f;
+    }
+    if (PASS == 2 && tid < MU) {
+        const int b = b0 + tid;
+        const int64_t un = b < a.B ? a.users[b] : -1;
+        for (int h = 0; h + 1 < NB; ++h)
+            unorm[tid * (NB - 1) + h] = (un >= 0 && a.predict_type != 0) ? fmaxf(sqrtf(a.sqn[un * NB + 1 + h]), eps) : 1.f;
+        umean[tid] = (b < a.B && a.predict_type == 2) ? a.row_mean[b] : 0.f;
+    }
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t i0 = (int64_t)tile * MI;
+        __syncthreads();                                  // the previous tile's operand reads are done
+        for (int e = tid * 4; e < MI * COLS; e += 1024) {
+            const int r = e / COLS, c = e - r * COLS;
+            const int64_t item = i0 + r;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (item < a.I) v = *reinterpret_cast<const float4 *>(a.Y + (a.U + item) * a.ldy + c);
+            float *dst = it + r * LD + c;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+        __syncthreads();
+        v16f_s acc[NH];
+        const float *bp = it + li * LD + lk;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            acc[h] = (v16f_s){0};
+#pragma unroll
+            for (int ks = 0; ks < D / 2; ++ks)
+                acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[h][ks], bp[h * D + 2 * ks], acc[h], 0, 0, 0);
+        }
+        const int64_t item = i0 + li;
+        const bool item_ok = item < a.I;
+        float inorm[NB > 1 ? NB - 1 : 1];
+#pragma unroll
+        for (int h = 0; h + 1 < NB; ++h)
+            inorm[h] = (PASS == 2 && item_ok && a.predict_type != 0) ? fmaxf(sqrtf(a.sqn[(a.U + item) * NB + 1 + h]), eps) : 1.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int urow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int b = b0 + urow;
+            if (PASS == 1) {
+                float v = (item_ok && b < a.B) ? sigmoidf_(acc[0][r]) : 0.f;
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);      // over the 32 items of the tile
+                if (li == 0 && b < a.B) a.partial[(int64_t)tile * a.B + b] = v;
+                continue;
+            }
+            if (b >= a.B || !item_ok) continue;
+            const float ui = sigmoidf_(acc[0][r]);
+            float out;
+            if (a.predict_type == 0) {
+                out = sigmoidf_(ui);
+            } else {
+                float z[kMaxS];
+#pragma unroll
+                for (int h = 0; h < kMaxS; ++h)
+                    z[h] = (h + 1 < NB) ? acc[(h + 1 < NH) ? h + 1 : 0][r] / (unorm[urow * (NB - 1) + (h + 1 < NB ? h : 0)] * inorm[h + 1 < NB ? h : 0]) : 0.f;
+                if (a.predict_type == 1) out = sigmoidf_(fuse(a.fusion_mode, ui, z, NB - 1, a.head_mask));
+                else {
+                    float te, nde;
+                    fuse2(a.fusion_mode, ui, umean[urow], z, NB - 1, a.head_mask, te, nde);
+                    out = sigmoidf_(te - nde);
+                }
+            }
+            a.scores[(int64_t)b * a.lds + item] = out;
+        }
     }
 }
 
@@ -487,7 +606,30 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
         const char *e = getenv("ELIMREC_SCORE_VALU");
         use_mfma = (e && e[0] == '1') ? 0 : 1;
     }
-    if (use_mfma) {
+    static int use_resident = -1;
+    if (use_resident < 0) {
+        const char *e = getenv("ELIMREC_SCORE_RESIDENT");
+        use_resident = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (use_mfma && use_resident && d == 64 && S >= 1 && S <= 3) {
+        // users resident in registers, a persistent grid over the item tiles (two workgroups per CU)
+        dim3 grid((unsigned)(tiles < 512 ? tiles : 512), (B + MU - 1) / MU);
+#define ELIMREC_SCORE_RESIDENT(NB)                                                                          \
+    do {                                                                                                   \
+        if (predict_type == 2) {                                                                           \
+            hipLaunchKernelGGL((score_resident_kernel<1, NB, 64>), grid, dim3(256), 0, s, a, tiles);       \
+            ELIMREC_LAUNCH_CHECK("score_resident_pass1");                                                  \
+            hipLaunchKernelGGL(row_mean_kernel, dim3(B), dim3(256), 0, s, partial, tiles, B, I, mean);     \
+            ELIMREC_LAUNCH_CHECK("row_mean");                                                              \
+        }                                                                                                  \
+        hipLaunchKernelGGL((score_resident_kernel<2, NB, 64>), grid, dim3(256), 0, s, a, tiles);           \
+        ELIMREC_LAUNCH_CHECK("score_resident_pass2");                                                      \
+    } while (0)
+        if (S == 1) ELIMREC_SCORE_RESIDENT(2);
+        else if (S == 2) ELIMREC_SCORE_RESIDENT(3);
+        else ELIMREC_SCORE_RESIDENT(4);
+#undef ELIMREC_SCORE_RESIDENT
+    } else if (use_mfma) {
         dim3 grid(tiles, (B + MU - 1) / MU);
         if (predict_type == 2) {
             hipLaunchKernelGGL(score_mfma_kernel<1>, grid, dim3(256), 0, s, a);
