@@ -251,9 +251,11 @@ template <int PASS, int NB, int D>
 __global__ __launch_bounds__(256) void score_resident_kernel(ScoreArgs a, int n_tiles) {
     constexpr int NH = (PASS == 1) ? 1 : NB;          // head blocks this pass needs
     constexpr int COLS = NH * D, LD = COLS + 1;
-    __shared__ float it[MI * LD];
-    __shared__ float unorm[MU * (NB > 1 ? NB - 1 : 1)];   // max(|user block 1+h|, eps)
-    __shared__ float umean[MU];
+    constexpr int PFN = MI * COLS / 1024;             // float4 per thread per item tile
+    extern __shared__ float smem[];
+    float *it0 = smem, *it1 = smem + MI * LD;         // two item-tile buffers
+    float *unorm = it1 + MI * LD;                     // [MU][NB-1]  max(|user block 1+h|, eps)
+    float *umean = unorm + MU * (NB > 1 ? NB - 1 : 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lk = lane >> 5;
     const int b0 = blockIdx.y * MU;
@@ -275,20 +277,36 @@ __global__ __launch_bounds__(256) void score_resident_kernel(ScoreArgs a, int n_
             unorm[tid * (NB - 1) + h] = (un >= 0 && a.predict_type != 0) ? fmaxf(sqrtf(a.sqn[un * NB + 1 + h]), eps) : 1.f;
         umean[tid] = (b < a.B && a.predict_type == 2) ? a.row_mean[b] : 0.f;
     }
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t i0 = (int64_t)tile * MI;
-        __syncthreads();                                  // the previous tile's operand reads are done
-        for (int e = tid * 4; e < MI * COLS; e += 1024) {
+    // item tiles are double-buffered: the next tile's rows are in flight (registers) during this tile's MFMAs and
+    // epilogue and go to the other LDS buffer afterwards -- one barrier per tile
+    float4 pf[PFN];
+    auto load_tile = [&](int tile) {
+#pragma unroll
+        for (int q = 0; q < PFN; ++q) {
+            const int e = (tid + 256 * q) * 4;
             const int r = e / COLS, c = e - r * COLS;
-            const int64_t item = i0 + r;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (item < a.I) v = *reinterpret_cast<const float4 *>(a.Y + (a.U + item) * a.ldy + c);
-            float *dst = it + r * LD + c;
-            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+            const int64_t item = (int64_t)tile * MI + r;
+            pf[q] = item < a.I ? *reinterpret_cast<const float4 *>(a.Y + (a.U + item) * a.ldy + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        __syncthreads();
+    };
+    auto store_tile = [&](float *buf) {
+#pragma unroll
+        for (int q = 0; q < PFN; ++q) {
+            const int e = (tid + 256 * q) * 4;
+            const int r = e / COLS, c = e - r * COLS;
+            float *dst = buf + r * LD + c;
+            dst[0] = pf[q].x; dst[1] = pf[q].y; dst[2] = pf[q].z; dst[3] = pf[q].w;
+        }
+    };
+    if ((int)blockIdx.x < n_tiles) { load_tile(blockIdx.x); store_tile(it0); }
+    __syncthreads();
+    int cur = 0;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, cur ^= 1) {
+        const int64_t i0 = (int64_t)tile * MI;
+        const int next = tile + gridDim.x;
+        if (next < n_tiles) load_tile(next);
         v16f_s acc[NH];
-        const float *bp = it + li * LD + lk;
+        const float *bp = (cur ? it1 : it0) + li * LD + lk;
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             acc[h] = (v16f_s){0};
@@ -298,40 +316,46 @@ __global__ __launch_bounds__(256) void score_resident_kernel(ScoreArgs a, int n_
         }
         const int64_t item = i0 + li;
         const bool item_ok = item < a.I;
-        float inorm[NB > 1 ? NB - 1 : 1];
+        if (PASS == 1) {
 #pragma unroll
-        for (int h = 0; h + 1 < NB; ++h)
-            inorm[h] = (PASS == 2 && item_ok && a.predict_type != 0) ? fmaxf(sqrtf(a.sqn[(a.U + item) * NB + 1 + h]), eps) : 1.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int urow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int b = b0 + urow;
-            if (PASS == 1) {
+            for (int r = 0; r < 16; ++r) {
+                const int b = b0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 float v = (item_ok && b < a.B) ? sigmoidf_(acc[0][r]) : 0.f;
 #pragma unroll
                 for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);      // over the 32 items of the tile
                 if (li == 0 && b < a.B) a.partial[(int64_t)tile * a.B + b] = v;
-                continue;
             }
-            if (b >= a.B || !item_ok) continue;
-            const float ui = sigmoidf_(acc[0][r]);
-            float out;
-            if (a.predict_type == 0) {
-                out = sigmoidf_(ui);
-            } else {
-                float z[kMaxS];
+        } else {
+            float inorm[NB > 1 ? NB - 1 : 1];
 #pragma unroll
-                for (int h = 0; h < kMaxS; ++h)
-                    z[h] = (h + 1 < NB) ? acc[(h + 1 < NH) ? h + 1 : 0][r] / (unorm[urow * (NB - 1) + (h + 1 < NB ? h : 0)] * inorm[h + 1 < NB ? h : 0]) : 0.f;
-                if (a.predict_type == 1) out = sigmoidf_(fuse(a.fusion_mode, ui, z, NB - 1, a.head_mask));
-                else {
-                    float te, nde;
-                    fuse2(a.fusion_mode, ui, umean[urow], z, NB - 1, a.head_mask, te, nde);
-                    out = sigmoidf_(te - nde);
+            for (int h = 0; h + 1 < NB; ++h)
+                inorm[h] = (item_ok && a.predict_type != 0) ? fmaxf(sqrtf(a.sqn[(a.U + item) * NB + 1 + h]), eps) : 1.f;
+            // all 16 outputs of the lane are computed unconditionally (independent chains the scheduler can
+            // interleave; rows / items past the end hold zeros) and only the store is predicated
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int urow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float ui = sigmoidf_(acc[0][r]);
+                float out;
+                if (a.predict_type == 0) {
+                    out = sigmoidf_(ui);
+                } else {
+                    float z[kMaxS];
+#pragma unroll
+                    for (int h = 0; h < kMaxS; ++h)
+                        z[h] = (h + 1 < NB) ? acc[(h + 1 < NH) ? h + 1 : 0][r] / (unorm[urow * (NB - 1) + (h + 1 < NB ? h : 0)] * inorm[h + 1 < NB ? h : 0]) : 0.f;
+                    if (a.predict_type == 1) out = sigmoidf_(fuse(a.fusion_mode, ui, z, NB - 1, a.head_mask));
+                    else {
+                        float te, nde;
+                        fuse2(a.fusion_mode, ui, umean[urow], z, NB - 1, a.head_mask, te, nde);
+                        out = sigmoidf_(te - nde);
+                    }
                 }
+                if (item_ok && b0 + urow < a.B) a.scores[(int64_t)(b0 + urow) * a.lds + item] = out;
             }
-            a.scores[(int64_t)b * a.lds + item] = out;
         }
+        if (next < n_tiles) store_tile(cur ? it0 : it1);
+        __syncthreads();
     }
 }
 
@@ -565,6 +589,11 @@ extern "C" int elimrec_row_sqnorms(const float *d_Y, int64_t ldy, int64_t n_rows
     return 0;
 }
 
+static size_t resident_lds(int pass, int nb, int d) {
+    const int cols = (pass == 1 ? 1 : nb) * d;
+    return ((size_t)2 * MI * (cols + 1) + (size_t)MU * (nb > 1 ? nb - 1 : 1) + MU) * sizeof(float);
+}
+
 extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int64_t I, const int64_t *d_users, int B,
                                   int d, int S, uint32_t head_mask, int fusion_mode, int predict_type,
                                   const float *d_sqnorm, const int64_t *d_train_ptr, const int32_t *d_train_items,
@@ -617,12 +646,20 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
 #define ELIMREC_SCORE_RESIDENT(NB)                                                                          \
     do {                                                                                                   \
         if (predict_type == 2) {                                                                           \
-            hipLaunchKernelGGL((score_resident_kernel<1, NB, 64>), grid, dim3(256), 0, s, a, tiles);       \
+            hipLaunchKernelGGL((score_resident_kernel<1, NB, 64>), grid, dim3(256), resident_lds(1, NB, 64), s, a, tiles); \
             ELIMREC_LAUNCH_CHECK("score_resident_pass1");                                                  \
             hipLaunchKernelGGL(row_mean_kernel, dim3(B), dim3(256), 0, s, partial, tiles, B, I, mean);     \
             ELIMREC_LAUNCH_CHECK("row_mean");                                                              \
         }                                                                                                  \
-        hipLaunchKernelGGL((score_resident_kernel<2, NB, 64>), grid, dim3(256), 0, s, a, tiles);           \
+        {                                                                                                  \
+            static bool attr = false;                                                                      \
+            if (!attr) {                                                                                   \
+                (void)hipFuncSetAttribute((const void *)score_resident_kernel<2, NB, 64>,                  \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident_lds(2, NB, 64)); \
+                attr = true;                                                                               \
+            }                                                                                              \
+        }                                                                                                  \
+        hipLaunchKernelGGL((score_resident_kernel<2, NB, 64>), grid, dim3(256), resident_lds(2, NB, 64), s, a, tiles); \
         ELIMREC_LAUNCH_CHECK("score_resident_pass2");                                                      \
     } while (0)
         if (S == 1) ELIMREC_SCORE_RESIDENT(2);
