@@ -8,6 +8,7 @@ from .basic_model import BasicModel
 from .model import EliMRec
 from .optim import FusedAdam
 from .sampler import PairwiseSamplerV2
+from .shard import ColumnShardEngine, ColumnShardTrainer
 from .evaluator import ProxyEvaluator, UniEvaluator
 
 

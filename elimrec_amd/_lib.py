@@ -44,6 +44,17 @@ class LinearBwdDesc(ctypes.Structure):
                 ("d_colsum", ctypes.c_void_p), ("accumulate", ctypes.c_int32), ("d_colsum_weight", ctypes.c_void_p)]
 
 
+class SellDesc(ctypes.Structure):
+    """struct elimrec_sell."""
+    _fields_ = [("n_rows", ctypes.c_int64), ("n_src", ctypes.c_int64), ("n_items", ctypes.c_int32),
+                ("n_seg_items", ctypes.c_int32), ("n_seg", ctypes.c_int32), ("n_long", ctypes.c_int32),
+                ("d_item_dst", ctypes.c_void_p), ("d_item_len", ctypes.c_void_p), ("d_blk_off", ctypes.c_void_p),
+                ("d_col", ctypes.c_void_p), ("d_val", ctypes.c_void_p), ("d_long_rows", ctypes.c_void_p),
+                ("d_long_seg_ptr", ctypes.c_void_p), ("d_long_index", ctypes.c_void_p), ("d_rowptr", ctypes.c_void_p),
+                ("d_csr_col", ctypes.c_void_p), ("d_csr_val", ctypes.c_void_p)]
+
+
+c_sell = ctypes.POINTER(SellDesc)
 c_split = ctypes.POINTER(CsrSplit)
 c_csr = ctypes.POINTER(CsrDesc)
 
@@ -110,6 +121,17 @@ SIGNATURES = {
     "elimrec_score_topk": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_i32, c_i32, c_i32, c_u32, c_i32, c_i32,
                                    c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "elimrec_rank_metrics": (c_i32, [c_ptr, c_i32, c_i32, c_ptr, c_ptr, ctypes.POINTER(c_i32), c_i32, c_ptr, c_ptr]),
+    "elimrec_slab_partials_bytes": (c_size, [c_sell, c_i32, c_i32]),
+    "elimrec_slab_set_variant": (None, [c_i32]),
+    "elimrec_slab_hop": (c_i32, [c_sell, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr, c_size, c_i32,
+                                 c_ptr]),
+    "elimrec_slab_rows": (c_i32, [c_sell, c_i32, c_i32, c_i32, c_i64, ctypes.POINTER(c_ptr), c_ptr, c_ptr, c_ptr, c_i64, c_i32,
+                                  c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr]),
+    "elimrec_slab_from_rows": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr]),
+    "elimrec_slab_to_rows": (c_i32, [c_ptr, c_i64, c_i32, c_i32, c_ptr, c_i64, c_i64, c_ptr]),
+    "elimrec_slab_merge_rows": (c_i32, [c_ptr, c_ptr, c_i32, c_i64, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "elimrec_adam_step_out": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64,
+                                      c_ptr]),
     "elimrec_sample_triplets": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_u64, c_u64, c_ptr, c_ptr, c_ptr, c_ptr]),
 }
 

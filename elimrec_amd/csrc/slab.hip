@@ -1,0 +1,574 @@
+// Slab-major (column-sharded) LightGCN propagation: models/EliMRec.py:238-248 for a column slice of the folded
+// d-column table (include/elimrec_hip.h, "slab-major propagation").
+//
+// Layout: a table of dl columns = ns slabs of width w floats, slab s = contiguous [n x w]. A hop is independent per
+// column, so workgroups with equal blockIdx % gs work on the same slab group -- under the round-robin dispatch they
+// share an XCD, whose 4 MiB L2 then has to hold [n x w*spg] floats (3.6 MB at the Tiktok shape for w*spg = 8) instead
+// of the whole [n x d] table (29 MB) that a row-partitioned hop drags through every XCD's L2 (2.5x HBM over-fetch,
+// profiles/r01_h_pmc_traffic.json). Placement changes speed only: every workgroup reads Xin and writes its own
+// outputs, nothing is exchanged inside a launch.
+//
+// Work items (SELL-64, built on the host): rows with <= T non-zeros and <= T-nnz segments of longer rows, sorted by
+// decreasing length; a lane group of LPR = spg*w/4 lanes owns one item, a wave 64/LPR items of similar length, and
+// the (col, val) of step j of the wave's items are consecutive in memory. HBM/L2-bound (9 flop per 4-B gathered).
+#include "common.h"
+#include <cstdlib>
+
+namespace elimrec {
+
+constexpr int kSlabMaxLayers = 8;
+
+struct SellArgs {
+    const int32_t *item_dst, *item_len, *blk_off, *col;
+    const float *val;
+    int64_t n_rows, n_src;
+    int n_seg, n_long;
+    int item_begin, item_end;      // items [begin, end), multiples of 64
+    int seg_limit;                 // items below this index are segments of split rows
+    int w4, w4_shift, gs, spg;
+    const float4 *Xin;
+    const uint32_t *src_mask;
+    float4 *Xout;
+    const float4 *Add;
+    const uint32_t *add_mask;
+    float scale;
+    float4 *partials;
+    const int32_t *long_rows, *long_seg_ptr;
+    int compact_long;              // the fix-up writes Xout compactly: [ns x n_long x w]
+};
+
+__device__ __forceinline__ bool bit_of(const uint32_t *m, int r) { return (m[r >> 5] >> (r & 31)) & 1u; }
+
+__device__ __forceinline__ void slab_epilogue(const SellArgs &a, int slab, int64_t row, int c4, float4 r) {
+    const int64_t idx = ((int64_t)slab * a.n_rows + row) * a.w4 + c4;
+    float4 s = r;
+    if (a.Add && (!a.add_mask || bit_of(a.add_mask, (int)row))) {
+        const float4 t = a.Add[idx];
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+    }
+    a.Xout[idx] = make_float4(s.x * a.scale, s.y * a.scale, s.z * a.scale, s.w * a.scale);
+}
+
+// sum_j val[j] * Xin[col[j]] in neighbour order with fmaf -- the arithmetic of half_gather (spmm.hip), so an unsplit
+// row gets the same bits from either layout.
+template <int LPR, bool MASKED, int U, bool PF>
+__global__ __launch_bounds__(256) void sell_hop_kernel(SellArgs a) {
+    constexpr int IPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int grp = (int)(blockIdx.x % (unsigned)a.gs);
+    const int64_t wblk = (int64_t)(blockIdx.x / (unsigned)a.gs) * 4 + (threadIdx.x >> 6);
+    const int64_t first = (int64_t)a.item_begin + wblk * IPW;
+    if (first >= a.item_end) return;                               // wave-uniform
+    const int64_t item = first + lane / LPR;
+    const int cl = lane % LPR;
+    const int len = a.item_len[item];
+    const int dst = a.item_dst[item];
+    const int slab = grp * a.spg + (cl >> a.w4_shift);
+    const int c4 = cl & (a.w4 - 1);
+    const float4 *X = a.Xin + (int64_t)slab * a.n_src * a.w4 + c4;
+    const int64_t e0 = ((int64_t)a.blk_off[item >> 6] << 6) + (item & 63);
+    const int32_t *colp = a.col + e0;
+    const float *valp = a.val + e0;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int ncj[U];
+    float nvj[U];
+    if (PF) {                      // the (col, val) of step j + U are in flight while step j gathers
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool in = u < len;
+            ncj[u] = in ? colp[(int64_t)u << 6] : 0;
+            nvj[u] = in ? valp[(int64_t)u << 6] : 0.f;
+        }
+    }
+    for (int j = 0; j < len; j += U) {
+        int cj[U];
+        float vj[U];
+        bool in[U];
+        float4 x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            in[u] = (j + u) < len;
+            if (PF) { cj[u] = ncj[u]; vj[u] = nvj[u]; }
+            else {
+                cj[u] = in[u] ? colp[(int64_t)(j + u) << 6] : 0;
+                vj[u] = in[u] ? valp[(int64_t)(j + u) << 6] : 0.f;
+            }
+        }
+        if (PF) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool nin = (j + U + u) < len;
+                ncj[u] = nin ? colp[(int64_t)(j + U + u) << 6] : 0;
+                nvj[u] = nin ? valp[(int64_t)(j + U + u) << 6] : 0.f;
+            }
+        }
+        if (MASKED) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) in[u] = in[u] && bit_of(a.src_mask, cj[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) x[u] = in[u] ? X[(int64_t)cj[u] * a.w4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc.x = fmaf(vj[u], x[u].x, acc.x); acc.y = fmaf(vj[u], x[u].y, acc.y);
+            acc.z = fmaf(vj[u], x[u].z, acc.z); acc.w = fmaf(vj[u], x[u].w, acc.w);
+        }
+    }
+    if (dst < 0) return;                                           // padding item
+    if (item < a.seg_limit) {
+        a.partials[((int64_t)slab * a.n_seg + dst) * a.w4 + c4] = acc;
+        return;
+    }
+    if (a.compact_long) return;                                    // seg_only launches carry no final items
+    slab_epilogue(a, slab, dst, c4, acc);
+}
+
+// One wave per (split row, slab group): the wave's 64/LPR lane groups each add a contiguous share of the row's partial
+// rows in order (8 loads in flight), the shares are added in group order through shuffles, group 0 writes the row.
+template <int LPR>
+__global__ __launch_bounds__(256) void sell_fixup_kernel(SellArgs a) {
+    constexpr int NQ = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int grp = (int)(blockIdx.x % (unsigned)a.gs);
+    const int li = (int)(blockIdx.x / (unsigned)a.gs) * 4 + (int)(threadIdx.x >> 6);
+    if (li >= a.n_long) return;                                    // wave-uniform
+    const int q = lane / LPR, cl = lane % LPR;
+    const int slab = grp * a.spg + (cl >> a.w4_shift);
+    const int c4 = cl & (a.w4 - 1);
+    const int sb = a.long_seg_ptr[li], se = a.long_seg_ptr[li + 1];
+    const int per = (se - sb + NQ - 1) / NQ;
+    const int qb = min(sb + q * per, se), qe = min(qb + per, se);
+    const float4 *P = a.partials + (int64_t)slab * a.n_seg * a.w4 + c4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int sgm = qb;
+    for (; sgm + 8 <= qe; sgm += 8) {
+        float4 p[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) p[u] = P[(int64_t)(sgm + u) * a.w4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc.x += p[u].x; acc.y += p[u].y; acc.z += p[u].z; acc.w += p[u].w; }
+    }
+    for (; sgm < qe; ++sgm) {
+        const float4 p = P[(int64_t)sgm * a.w4];
+        acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
+    }
+    float4 tot = acc;
+    if (NQ > 1) {
+        tot.x = __shfl(acc.x, cl, 64); tot.y = __shfl(acc.y, cl, 64); tot.z = __shfl(acc.z, cl, 64); tot.w = __shfl(acc.w, cl, 64);
+#pragma unroll
+        for (int t = 1; t < NQ; ++t) {
+            tot.x += __shfl(acc.x, t * LPR + cl, 64); tot.y += __shfl(acc.y, t * LPR + cl, 64);
+            tot.z += __shfl(acc.z, t * LPR + cl, 64); tot.w += __shfl(acc.w, t * LPR + cl, 64);
+        }
+    }
+    if (q != 0) return;
+    if (a.compact_long) a.Xout[((int64_t)slab * a.n_long + li) * a.w4 + c4] = tot;
+    else slab_epilogue(a, slab, a.long_rows[li], c4, tot);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct RowsArgs {
+    const float4 *x[kSlabMaxLayers + 1];
+    int L;
+    int64_t U, n_rows;
+    int nc4, w4, w4_shift;
+    const float4 *long_tab;
+    int n_long;
+    const int32_t *long_index, *rowptr, *col;
+    const float *val;
+    const int32_t *rows, *counts;
+    int64_t R;
+    int n_lists;
+    float *out0;
+    int64_t ld_out0;
+    float *narrow;
+    int64_t ld_narrow;
+    int by_node;
+    float inv;
+};
+
+// Layer means at listed rows; hop L inline when its table is absent. LR lanes per listed row, lane cl owns the float4
+// columns cl, cl + LR, ... of the row's nc4 = ns*w/4.
+template <int LR>
+__global__ __launch_bounds__(256) void slab_rows_kernel(RowsArgs a) {
+    constexpr int U8 = 8;
+    const int64_t s = (int64_t)blockIdx.x * (256 / LR) + threadIdx.x / LR;
+    const int cl = threadIdx.x % LR;
+    if (s >= a.R * a.n_lists) return;
+    int64_t r = s;
+    if (a.rows) {
+        const int64_t list = s / a.R;
+        if (s - list * a.R >= a.counts[list]) return;
+        r = a.rows[s];
+    }
+    const bool user = r < a.U;
+    const bool inline_hop = a.x[a.L] == nullptr;
+    int li = -1, beg = 0, end = 0;
+    if (inline_hop) {
+        li = a.long_index[r];
+        if (li < 0) { beg = a.rowptr[r]; end = a.rowptr[r + 1]; }
+    }
+    for (int c = cl; c < a.nc4; c += LR) {
+        const int slab = c >> a.w4_shift, c4 = c & (a.w4 - 1);
+        const int64_t idx = ((int64_t)slab * a.n_rows + r) * a.w4 + c4;
+        float4 xl;
+        if (!inline_hop) xl = a.x[a.L][idx];
+        else if (li >= 0) xl = a.long_tab[((int64_t)slab * a.n_long + li) * a.w4 + c4];
+        else {
+            const float4 *X = a.x[a.L - 1] + (int64_t)slab * a.n_rows * a.w4 + c4;
+            xl = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = beg; j < end; j += U8) {
+                int cj[U8];
+                float vj[U8];
+                float4 x[U8];
+#pragma unroll
+                for (int u = 0; u < U8; ++u) {
+                    const bool in = (j + u) < end;
+                    cj[u] = in ? a.col[j + u] : 0;
+                    vj[u] = in ? a.val[j + u] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < U8; ++u)
+                    x[u] = (j + u) < end ? X[(int64_t)cj[u] * a.w4] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < U8; ++u) {
+                    xl.x = fmaf(vj[u], x[u].x, xl.x); xl.y = fmaf(vj[u], x[u].y, xl.y);
+                    xl.z = fmaf(vj[u], x[u].z, xl.z); xl.w = fmaf(vj[u], x[u].w, xl.w);
+                }
+            }
+        }
+        const float4 x0 = a.x[0][idx];
+        const float4 x1 = (a.L == 1) ? xl : a.x[1][idx];
+        float4 sum = make_float4(x0.x + x1.x, x0.y + x1.y, x0.z + x1.z, x0.w + x1.w);
+        float4 nar = user ? x0 : x1;
+        for (int k = 2; k <= a.L; ++k) {
+            const float4 v = (k == a.L) ? xl : a.x[k][idx];
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            if (((k & 1) == 0) == user) { nar.x += v.x; nar.y += v.y; nar.z += v.z; nar.w += v.w; }
+        }
+        *reinterpret_cast<float4 *>(a.out0 + s * a.ld_out0 + 4 * c) =
+            make_float4(sum.x * a.inv, sum.y * a.inv, sum.z * a.inv, sum.w * a.inv);
+        *reinterpret_cast<float4 *>(a.narrow + (a.by_node ? r : s) * a.ld_narrow + 4 * c) =
+            make_float4(nar.x * a.inv, nar.y * a.inv, nar.z * a.inv, nar.w * a.inv);
+    }
+}
+
+__global__ void slab_from_rows_kernel(const float *__restrict__ src, int64_t ld, int64_t col0, int64_t n, int nc4, int w4,
+                                      int w4_shift, float4 *__restrict__ slab) {
+    const int64_t total = n * nc4;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / nc4;
+        const int c = (int)(e - r * nc4);
+        slab[((int64_t)(c >> w4_shift) * n + r) * w4 + (c & (w4 - 1))] =
+            *reinterpret_cast<const float4 *>(src + r * ld + col0 + 4 * c);
+    }
+}
+
+__global__ void slab_to_rows_kernel(const float4 *__restrict__ slab, int64_t n, int nc4, int w4, int w4_shift,
+                                    float *__restrict__ dst, int64_t ld, int64_t col0) {
+    const int64_t total = n * nc4;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / nc4;
+        const int c = (int)(e - r * nc4);
+        *reinterpret_cast<float4 *>(dst + r * ld + col0 + 4 * c) =
+            slab[((int64_t)(c >> w4_shift) * n + r) * w4 + (c & (w4 - 1))];
+    }
+}
+
+// Rank-ordered merge of [H | G] rows into the slab-major adjoint sources: a workgroup owns a range of node ids, finds
+// the slice of every rank's ascending key list that falls into it (binary searches, one thread per rank) and walks the
+// ranks IN RANK ORDER with a barrier in between; a node seen before (LDS bitmap) is accumulated, otherwise written.
+constexpr int kSlabMaxRanks = 64;
+
+__device__ __forceinline__ int slab_merge_key(const int32_t *keys, int i) {
+    const int k = keys[i];
+    return k < 0 ? INT32_MAX : k;
+}
+
+__global__ __launch_bounds__(256) void slab_merge_rows_kernel(const float *__restrict__ rows, const int32_t *__restrict__ keys,
+                                                              int W, int R, int64_t U, int64_t N, int nc4, int w4,
+                                                              int w4_shift, int chunk, float *SrcA, float *SrcB,
+                                                              uint32_t *__restrict__ mask) {
+    __shared__ int s_beg[kSlabMaxRanks], s_end[kSlabMaxRanks];
+    extern __shared__ uint32_t seen[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(lo + chunk, N);
+    for (int w = tid; w < chunk / 32; w += 256) seen[w] = 0u;
+    if (tid < W) {
+        const int32_t *kr = keys + (int64_t)tid * R;
+        int a0 = 0, a1 = R, b0 = 0, b1 = R;
+        while (a0 < a1 || b0 < b1) {
+            if (a0 < a1) { const int m = (a0 + a1) >> 1; if (slab_merge_key(kr, m) < lo) a0 = m + 1; else a1 = m; }
+            if (b0 < b1) { const int m = (b0 + b1) >> 1; if (slab_merge_key(kr, m) < hi) b0 = m + 1; else b1 = m; }
+        }
+        s_beg[tid] = a0; s_end[tid] = b0;
+    }
+    __syncthreads();
+    for (int r = 0; r < W; ++r) {
+        for (int s = s_beg[r] + wave; s < s_end[r]; s += 4) {
+            const int64_t node = keys[(int64_t)r * R + s];
+            const int bit = (int)(node - lo);
+            const bool was = (seen[bit >> 5] >> (bit & 31)) & 1u;
+            const float4 *g = reinterpret_cast<const float4 *>(rows) + ((int64_t)r * R + s) * 2 * nc4;
+            float *hT = node < U ? SrcA : SrcB;       // H lives in SrcA on user rows, SrcB on item rows
+            float *gT = node < U ? SrcB : SrcA;
+            for (int c = lane; c < nc4; c += 64) {
+                const int64_t idx = (((int64_t)(c >> w4_shift) * N + node) * w4 + (c & (w4 - 1))) * 4;
+                float4 h = g[c], g0 = g[nc4 + c];
+                if (was) {                               // written by an earlier rank of this workgroup: read through L2
+                    float *hp = hT + idx, *gp = gT + idx;
+                    float4 x, y;
+                    x.x = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    x.y = __hip_atomic_load(hp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    x.z = __hip_atomic_load(hp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    x.w = __hip_atomic_load(hp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    y.x = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    y.y = __hip_atomic_load(gp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    y.z = __hip_atomic_load(gp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    y.w = __hip_atomic_load(gp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    h = make_float4(x.x + h.x, x.y + h.y, x.z + h.z, x.w + h.w);
+                    g0 = make_float4(y.x + g0.x, y.y + g0.y, y.z + g0.z, y.w + g0.w);
+                }
+                *reinterpret_cast<float4 *>(hT + idx) = h;
+                *reinterpret_cast<float4 *>(gT + idx) = g0;
+            }
+            if (lane == 0 && !was) atomicOr(&seen[bit >> 5], 1u << (bit & 31));
+        }
+        __syncthreads();
+    }
+    for (int w = tid; w < chunk / 32; w += 256)
+        if (lo + 32 * (int64_t)w < ((N + 31) / 32) * 32) mask[lo / 32 + w] = seen[w];
+}
+
+__global__ void adam_out_kernel(const float *__restrict__ p_in, float *__restrict__ p_out, const float *__restrict__ g,
+                                float *__restrict__ m, float *__restrict__ v, int64_t n, float step_size, float beta1,
+                                float beta2, float inv_sqrt_bc2, float eps, float wd) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float pi = p_in[i];
+        const float gi = fmaf(wd, pi, g[i]);
+        const float mi = m[i] + (1.f - beta1) * (gi - m[i]);
+        const float vi = fmaf(1.f - beta2, gi * gi, beta2 * v[i]);
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        m[i] = mi;
+        v[i] = vi;
+        p_out[i] = pi - step_size * (mi / denom);
+    }
+}
+
+// inner-loop form of the unmasked hop: 0 = 8 neighbours per step; 1 = 4 per step with the next step's indices
+// prefetched; 2 = 8 + prefetch; 3 = 4
+static int g_slab_variant = -1;
+static int slab_variant() {
+    if (g_slab_variant < 0) {
+        const char *e = getenv("ELIMREC_SLAB_VARIANT");
+        g_slab_variant = e ? atoi(e) : 1;      // measured fastest on full tables and on column shards
+    }
+    return g_slab_variant;
+}
+
+static int log2_pow2(int x) {
+    int s = 0;
+    while ((1 << s) < x) ++s;
+    return (1 << s) == x ? s : -1;
+}
+
+}  // namespace elimrec
+
+using namespace elimrec;
+
+extern "C" void elimrec_slab_set_variant(int v) { g_slab_variant = v; }
+
+extern "C" size_t elimrec_slab_partials_bytes(const elimrec_sell *A, int ns, int w) {
+    if (!A || ns <= 0 || w <= 0) return 0;
+    return align_up((size_t)(A->n_seg > 0 ? A->n_seg : 1) * ns * w * sizeof(float), 256);
+}
+
+static int slab_geometry(const char *who, int ns, int w, int gs, int &w4_shift, int &spg, int &lpr) {
+    const int w4 = w / 4;
+    w4_shift = (w > 0 && w % 4 == 0) ? log2_pow2(w4) : -1;
+    if (ns < 1 || w4_shift < 0) { set_error("%s: slab width must be 4 * 2^k (got w=%d, ns=%d)", who, w, ns); return ELIMREC_E_BADARG; }
+    if (gs < 1 || ns % gs != 0) { set_error("%s: %d slab groups do not divide %d slabs", who, gs, ns); return ELIMREC_E_BADARG; }
+    spg = ns / gs;
+    if (log2_pow2(spg) < 0 || spg * w4 > 64) {
+        set_error("%s: slabs per group (%d) must be a power of two with spg*w/4 <= 64", who, spg);
+        return ELIMREC_E_BADARG;
+    }
+    lpr = spg * w4;
+    return 0;
+}
+
+static int slab_simple_geometry(const char *who, int64_t n, int ns, int w, int &w4_shift) {
+    w4_shift = (w > 0 && w % 4 == 0) ? log2_pow2(w / 4) : -1;
+    if (n < 0 || ns < 1 || w4_shift < 0) { set_error("%s: bad slab geometry (n=%lld, ns=%d, w=%d)", who, (long long)n, ns, w); return ELIMREC_E_BADARG; }
+    return 0;
+}
+
+extern "C" int elimrec_slab_hop(const elimrec_sell *A, int ns, int w, int gs, const float *d_Xin,
+                                const uint32_t *d_src_mask, float *d_Xout, const float *d_add,
+                                const uint32_t *d_add_mask, float scale, float *d_partials, size_t partials_bytes,
+                                int seg_only, void *stream) {
+    ELIMREC_REQUIRE(A && d_Xin && d_Xout, "slab_hop: null pointer");
+    ELIMREC_REQUIRE(d_Xin != d_Xout, "slab_hop: Xout must not alias Xin");
+    ELIMREC_REQUIRE(A->n_items % 64 == 0 && A->n_seg_items % 64 == 0 && A->n_seg_items <= A->n_items, "slab_hop: bad plan");
+    int w4_shift, spg, lpr, rc;
+    if ((rc = slab_geometry("slab_hop", ns, w, gs, w4_shift, spg, lpr))) return rc;
+    if (A->n_long > 0 && (!d_partials || partials_bytes < elimrec_slab_partials_bytes(A, ns, w))) {
+        set_error("slab_hop: partial-row scratch too small");
+        return ELIMREC_E_WORKSPACE;
+    }
+    SellArgs a = {};
+    a.item_dst = A->d_item_dst; a.item_len = A->d_item_len; a.blk_off = A->d_blk_off; a.col = A->d_col; a.val = A->d_val;
+    a.n_rows = A->n_rows; a.n_src = A->n_src; a.n_seg = A->n_seg; a.n_long = A->n_long;
+    a.item_begin = 0; a.item_end = seg_only ? A->n_seg_items : A->n_items; a.seg_limit = A->n_seg_items;
+    a.w4 = w / 4; a.w4_shift = w4_shift; a.gs = gs; a.spg = spg;
+    a.Xin = (const float4 *)d_Xin; a.src_mask = d_src_mask; a.Xout = (float4 *)d_Xout;
+    a.Add = seg_only ? nullptr : (const float4 *)d_add; a.add_mask = d_add_mask; a.scale = seg_only ? 1.0f : scale;
+    a.partials = (float4 *)d_partials; a.long_rows = A->d_long_rows; a.long_seg_ptr = A->d_long_seg_ptr;
+    a.compact_long = seg_only ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int variant = slab_variant();
+    const int n_it = a.item_end - a.item_begin;
+    if (n_it > 0) {
+        const int ipw = 64 / lpr;
+        const unsigned blocks = (unsigned)(((int64_t)n_it / ipw + 3) / 4) * (unsigned)gs;
+#define ELIMREC_SELL_LAUNCH(LPR)                                                                          \
+    do {                                                                                                  \
+        if (d_src_mask) hipLaunchKernelGGL((sell_hop_kernel<LPR, true, 8, false>), dim3(blocks), dim3(256), 0, s, a); \
+        else if (variant == 1) hipLaunchKernelGGL((sell_hop_kernel<LPR, false, 4, true>), dim3(blocks), dim3(256), 0, s, a); \
+        else if (variant == 2) hipLaunchKernelGGL((sell_hop_kernel<LPR, false, 8, true>), dim3(blocks), dim3(256), 0, s, a); \
+        else if (variant == 3) hipLaunchKernelGGL((sell_hop_kernel<LPR, false, 4, false>), dim3(blocks), dim3(256), 0, s, a); \
+        else hipLaunchKernelGGL((sell_hop_kernel<LPR, false, 8, false>), dim3(blocks), dim3(256), 0, s, a); \
+    } while (0)
+        switch (lpr) {
+            case 1: ELIMREC_SELL_LAUNCH(1); break;
+            case 2: ELIMREC_SELL_LAUNCH(2); break;
+            case 4: ELIMREC_SELL_LAUNCH(4); break;
+            case 8: ELIMREC_SELL_LAUNCH(8); break;
+            case 16: ELIMREC_SELL_LAUNCH(16); break;
+            case 32: ELIMREC_SELL_LAUNCH(32); break;
+            default: ELIMREC_SELL_LAUNCH(64); break;
+        }
+#undef ELIMREC_SELL_LAUNCH
+        ELIMREC_LAUNCH_CHECK("slab_hop");
+    }
+    if (A->n_long > 0) {
+        const unsigned blocks = (unsigned)((A->n_long + 3) / 4) * (unsigned)gs;
+        switch (lpr) {
+            case 1: hipLaunchKernelGGL((sell_fixup_kernel<1>), dim3(blocks), dim3(256), 0, s, a); break;
+            case 2: hipLaunchKernelGGL((sell_fixup_kernel<2>), dim3(blocks), dim3(256), 0, s, a); break;
+            case 4: hipLaunchKernelGGL((sell_fixup_kernel<4>), dim3(blocks), dim3(256), 0, s, a); break;
+            case 8: hipLaunchKernelGGL((sell_fixup_kernel<8>), dim3(blocks), dim3(256), 0, s, a); break;
+            case 16: hipLaunchKernelGGL((sell_fixup_kernel<16>), dim3(blocks), dim3(256), 0, s, a); break;
+            case 32: hipLaunchKernelGGL((sell_fixup_kernel<32>), dim3(blocks), dim3(256), 0, s, a); break;
+            default: hipLaunchKernelGGL((sell_fixup_kernel<64>), dim3(blocks), dim3(256), 0, s, a); break;
+        }
+        ELIMREC_LAUNCH_CHECK("slab_hop(fixup)");
+    }
+    return 0;
+}
+
+extern "C" int elimrec_slab_rows(const elimrec_sell *A, int ns, int w, int L, int64_t U, const float *const *layers,
+                                 const float *d_long, const int32_t *d_rows, const int32_t *d_counts, int64_t R,
+                                 int n_lists, float *d_out0, int64_t ld_out0, float *d_narrow, int64_t ld_narrow,
+                                 int narrow_by_node, void *stream) {
+    ELIMREC_REQUIRE(A && layers && d_out0 && d_narrow, "slab_rows: null pointer");
+    ELIMREC_REQUIRE(L >= 1 && L <= kSlabMaxLayers, "slab_rows: 1 <= L <= %d", kSlabMaxLayers);
+    ELIMREC_REQUIRE(ld_out0 % 4 == 0 && ld_narrow % 4 == 0, "slab_rows: leading dimensions must be multiples of 4");
+    ELIMREC_REQUIRE(n_lists >= 1 && (d_rows ? d_counts != nullptr : n_lists == 1), "slab_rows: row lists need their counts");
+    int w4_shift, rc;
+    if ((rc = slab_simple_geometry("slab_rows", A->n_rows, ns, w, w4_shift))) return rc;
+    RowsArgs a = {};
+    for (int k = 0; k <= L; ++k) a.x[k] = (const float4 *)layers[k];
+    for (int k = 0; k < L; ++k) ELIMREC_REQUIRE(layers[k], "slab_rows: layer table %d missing", k);
+    ELIMREC_REQUIRE(layers[L] || (A->d_rowptr && A->d_csr_col && A->d_csr_val && A->d_long_index && (A->n_long == 0 || d_long)),
+                    "slab_rows: the inline last hop needs the CSR, the long-row index and the long-row table");
+    a.L = L; a.U = U; a.n_rows = A->n_rows; a.nc4 = ns * (w / 4); a.w4 = w / 4; a.w4_shift = w4_shift;
+    a.long_tab = (const float4 *)d_long; a.n_long = A->n_long; a.long_index = A->d_long_index;
+    a.rowptr = A->d_rowptr; a.col = A->d_csr_col; a.val = A->d_csr_val;
+    a.rows = d_rows; a.counts = d_counts; a.R = R; a.n_lists = n_lists;
+    a.out0 = d_out0; a.ld_out0 = ld_out0; a.narrow = d_narrow; a.ld_narrow = ld_narrow; a.by_node = narrow_by_node;
+    a.inv = 1.0f / (float)(L + 1);
+    const int64_t total = R * n_lists;
+    if (total <= 0) return 0;
+    int lr = 1;
+    while (lr < a.nc4 && lr < 64) lr *= 2;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)((total + (256 / lr) - 1) / (256 / lr));
+    switch (lr) {
+        case 1: hipLaunchKernelGGL((slab_rows_kernel<1>), dim3(blocks), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((slab_rows_kernel<2>), dim3(blocks), dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((slab_rows_kernel<4>), dim3(blocks), dim3(256), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((slab_rows_kernel<8>), dim3(blocks), dim3(256), 0, s, a); break;
+        case 16: hipLaunchKernelGGL((slab_rows_kernel<16>), dim3(blocks), dim3(256), 0, s, a); break;
+        case 32: hipLaunchKernelGGL((slab_rows_kernel<32>), dim3(blocks), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((slab_rows_kernel<64>), dim3(blocks), dim3(256), 0, s, a); break;
+    }
+    ELIMREC_LAUNCH_CHECK("slab_rows");
+    return 0;
+}
+
+extern "C" int elimrec_slab_from_rows(const float *d_src, int64_t ld, int64_t col0, int64_t n, int ns, int w,
+                                      float *d_slab, void *stream) {
+    ELIMREC_REQUIRE(d_src && d_slab && ld % 4 == 0 && col0 % 4 == 0, "slab_from_rows: bad arguments");
+    int sh, rc;
+    if ((rc = slab_simple_geometry("slab_from_rows", n, ns, w, sh))) return rc;
+    if (n == 0) return 0;
+    int64_t blocks = (n * ns * (w / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(slab_from_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_src, ld, col0, n,
+                       ns * (w / 4), w / 4, sh, (float4 *)d_slab);
+    ELIMREC_LAUNCH_CHECK("slab_from_rows");
+    return 0;
+}
+
+extern "C" int elimrec_slab_to_rows(const float *d_slab, int64_t n, int ns, int w, float *d_dst, int64_t ld, int64_t col0,
+                                    void *stream) {
+    ELIMREC_REQUIRE(d_dst && d_slab && ld % 4 == 0 && col0 % 4 == 0, "slab_to_rows: bad arguments");
+    int sh, rc;
+    if ((rc = slab_simple_geometry("slab_to_rows", n, ns, w, sh))) return rc;
+    if (n == 0) return 0;
+    int64_t blocks = (n * ns * (w / 4) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(slab_to_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)d_slab,
+                       n, ns * (w / 4), w / 4, sh, d_dst, ld, col0);
+    ELIMREC_LAUNCH_CHECK("slab_to_rows");
+    return 0;
+}
+
+extern "C" int elimrec_slab_merge_rows(const float *d_rows, const int32_t *d_keys, int world, int64_t R, int64_t U,
+                                       int64_t I, int ns, int w, float *d_SrcA, float *d_SrcB, uint32_t *d_mask,
+                                       void *stream) {
+    ELIMREC_REQUIRE(d_rows && d_keys && d_SrcA && d_SrcB && d_mask, "slab_merge_rows: null pointer");
+    ELIMREC_REQUIRE(world >= 1 && world <= kSlabMaxRanks && R >= 1 && R < INT32_MAX, "slab_merge_rows: 1..%d ranks", kSlabMaxRanks);
+    int sh, rc;
+    const int64_t N = U + I;
+    if ((rc = slab_simple_geometry("slab_merge_rows", N, ns, w, sh))) return rc;
+    int chunk = (int)((N + 1023) / 1024);
+    chunk = (chunk + 31) / 32 * 32;
+    if (chunk < 32) chunk = 32;
+    const unsigned grid = (unsigned)((N + chunk - 1) / chunk);
+    if (grid == 0) return 0;
+    hipLaunchKernelGGL(slab_merge_rows_kernel, dim3(grid), dim3(256), (size_t)(chunk / 32) * sizeof(uint32_t),
+                       (hipStream_t)stream, d_rows, d_keys, world, (int)R, U, N, ns * (w / 4), w / 4, sh, chunk, d_SrcA, d_SrcB,
+                       d_mask);
+    ELIMREC_LAUNCH_CHECK("slab_merge_rows");
+    return 0;
+}
+
+extern "C" int elimrec_adam_step_out(const float *d_p_in, float *d_p_out, const float *d_g, float *d_m, float *d_v,
+                                     int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                     int64_t step, void *stream) {
+    ELIMREC_REQUIRE(d_p_in && d_p_out && d_g && d_m && d_v, "adam_step_out: null pointer");
+    ELIMREC_REQUIRE(step >= 1, "adam_step_out: step is 1-based");
+    if (n <= 0) return 0;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adam_out_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_p_in, d_p_out, d_g, d_m,
+                       d_v, n, step_size, beta1, beta2, inv_sqrt_bc2, eps, weight_decay);
+    ELIMREC_LAUNCH_CHECK("adam_step_out");
+    return 0;
+}

@@ -226,6 +226,12 @@ class EliMRec(BasicModel):
         self.register_buffer(name + "_col", torch.from_numpy(m.indices.astype(np.int32)), persistent=False)
         self.register_buffer(name + "_val", torch.from_numpy(m.data.astype(np.float32)), persistent=False)
 
+    def _scipy_adj(self):
+        """The propagation matrix as scipy CSR (host copy of the registered buffers)."""
+        n = self.num_users + self.num_items
+        return sp.csr_matrix((self.adj_val.cpu().numpy(), self.adj_col.cpu().numpy(), self.adj_rowptr.cpu().numpy()),
+                             shape=(n, n))
+
     def _csr(self, name):
         """Device CSR + its row-split plan (built on first use on the current device)."""
         rowptr = getattr(self, name + "_rowptr")
@@ -469,6 +475,10 @@ class EliMRec(BasicModel):
         if self._tables_dirty:
             self._tables_dirty = False
             ws, d = self._ws, self.latent_dim
+            eng = self.__dict__.get("_slab_engine")
+            if eng is not None and self.__dict__.get("_slab_fwd"):   # the last forward ran on the column-sharded engine
+                eng.materialize_tables(ws)
+                return
             if self._last_hop_rows:     # the training forward left X^L at the active rows only
                 ops.propagate_layers(self._csr("adj"), self.num_users, d, self.n_layers, ws["X0d"], ws["layers"],
                                      first=self.n_layers)
@@ -589,6 +599,7 @@ class EliMRec(BasicModel):
         U, I, d, L = self.num_users, self.num_items, self.latent_dim, self.n_layers
         adj = self._csr("adj")
         act, seg = ws["active_rows"][:n], ws["seg_info"]
+        self._slab_fwd = False
         # the plan depends on the indices only: the last hop and the head are evaluated at the active rows it lists and
         # the backward reduces the (gathered) gradient rows with it
         self._region("plan", (self._ws_gen, all_keys.data_ptr(), n),
@@ -605,13 +616,22 @@ class EliMRec(BasicModel):
         else:
             self._timed(lambda: self._region("fwd_hops", (self._ws_gen,),
                                              lambda: ops.propagate_layers(adj, U, d, L, ws["X0d"], ws["layers"])))
+        self._fwd_head(ws, all_keys, n, B, rank, grad_rows)
+
+    def _fwd_head(self, ws, all_keys, n, B, rank, grad_rows, layer_means=True):
+        """Everything after the graph at the batch's active rows: layer means (unless the caller has already put
+        them into ws['OutAct'][:, :d] / ws['Narrow'] -- the column-sharded engine, shard.py), feature blocks, fused
+        Linear and single-modal heads, loss rows and their gradient rows. One recorded region."""
+        U, I, d, L = self.num_users, self.num_items, self.latent_dim, self.n_layers
+        act, seg = ws["active_rows"][:n], ws["seg_info"]
         bw = self._last_block_weights
 
         def head():
             OutAct, YAct = ws["OutAct"][:n], ws["YAct"][:n]
             W = ws["live_views"]
             ops.copy_cols(ws["flat_param"][ws["tail_off"]:].view(1, -1), ws["snap"].view(1, -1))
-            ops.folded_rows(ws["layers"], U, I, d, L, act, seg[0:1], OutAct[:, :d], ws["Narrow"])
+            if layer_means:
+                ops.folded_rows(ws["layers"], U, I, d, L, act, seg[0:1], OutAct[:, :d], ws["Narrow"])
             ops.linear_fwd_batched(self._fold_problems(ws, W, OutAct, act, seg[6:8]))
             wu, wi = self._fusion_weights(W)
             bu, bi = W["embedding_user_after_GCN.bias"], W["embedding_item_after_GCN.bias"]
@@ -624,7 +644,8 @@ class EliMRec(BasicModel):
             ops.linear_fwd_batched(problems)
             ops.bpr_head_rows(YAct, ws["slot_seg"][3 * B * rank:3 * B * (rank + 1)], d, bw, ws["loss_rows"], grad_rows)
 
-        self._region("fwd_head", (self._ws_gen, all_keys.data_ptr(), n, B, rank, tuple(bw), grad_rows is not None), head)
+        self._region("fwd_head", (self._ws_gen, all_keys.data_ptr(), n, B, rank, tuple(bw), grad_rows is not None,
+                                  layer_means), head)
         self._publish_cache(ws["Y"], dirty=True)
 
     def _index_tensors(self, *ts):

@@ -1,0 +1,362 @@
+"""Column-sharded training of EliMRec: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI),
+every rank owns a COLUMN slice of the graph table and a share of the triplets.
+
+Why columns. With the constant feature tables folded out of the graph (model.py), the only
+table that goes through the LightGCN hops (models/EliMRec.py:238-248) is X^0 = [E_u ; E_i], N x d. A hop
+X^k = A X^(k-1) is independent per column, so rank q can own columns [q*dl, (q+1)*dl), dl = d / world, of
+  * the embedding parameters, their gradient and their Adam moments (master copy, slab-major, csrc/slab.hip),
+  * every layer table of the forward and of the adjoint propagation,
+and run all 2L hops on its slice with NO communication: per-rank propagation work is 1/world of the single-GPU
+work. A row partition (the reference has no counterpart; SURVEY 8(e) lists it as the north star's default) needs
+every hop's full input on every rank: an all-gather of N x d floats per hop, 6 x 29 MB per step at the Tiktok shape.
+What a column partition exchanges per step is only what the batch touches -- per rank, with R = 3B slots:
+  forward   all_gather  R int32 node ids of the rank's active rows               (12 KiB at B = 2048)
+            all_to_all  R x 2*dl floats per peer: the layer means (id block | shared part) of the PEER's active
+                        rows in MY columns                                        (R*2d*4 B = 3.1 MB per rank in total)
+  backward  all_to_all  R x 2*dl floats per peer: [H | G] adjoint sources of MY active rows in the PEER's columns
+            all_reduce  the projection-weight gradients                           (0.3 MB)
+Everything after the graph is row-wise and runs on the rank's own B triplets with replicated projection weights
+(data parallel). Rows of the same node contributed by several ranks are summed in rank order by one kernel
+(elimrec_slab_merge_rows): no float atomics, every rank's update is bitwise reproducible, and the dense weights stay
+in lock-step because every rank applies the same all-reduced gradient.
+
+world = 1 is the same code without the collectives; it is also the fastest single-GPU path (bench.py): the adjoint
+writes the gradient, and Adam updates the master copy, in the layout the hops read.
+
+The trainer talks to an `engine` through the cs_* methods below; ColumnShardEngine implements them on the HIP
+kernels, tests/test_dist_cpu.py injects a CPU stand-in built from the oracle to run the same trainer under gloo.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops, slab
+
+PAD_KEY = -(1 << 30)
+
+
+class ColumnShardTrainer(object):
+    def __init__(self, engine, optimizer, world_size=1, rank=0, group=None):
+        self.engine, self.opt, self.world, self.rank, self.group = engine, optimizer, int(world_size), int(rank), group
+        self.profile_kernels = False
+        self._events = []
+        self._scale = None
+        self._buf = {}
+        engine.cs_setup(self.world, self.rank, optimizer)
+        self.xgmi_bytes = dict(all_gather=0, all_to_all_fwd=0, all_to_all_bwd=0, all_reduce=0)   # sent per rank, last step
+
+    def _like(self, name, t, lead=None):
+        shape = tuple(t.shape) if lead is None else (lead,) + tuple(t.shape)
+        b = self._buf.get(name)
+        if b is None or b.shape != shape or b.dtype != t.dtype or b.device != t.device:
+            b = self._buf[name] = torch.empty(shape, dtype=t.dtype, device=t.device)
+        return b
+
+    def step(self, users, pos, neg):
+        """One training step on this rank's triplets; returns the local loss (0-dim tensor)."""
+        eng, W = self.engine, self.world
+        if self.profile_kernels and getattr(eng, "kernel_events", None) is None:
+            eng.kernel_events = self._events
+        act = eng.cs_plan(users, pos, neg)                       # int32 [R]: sorted unique node ids, negative padding
+        if W > 1:
+            acts = self._like("acts", act, W)
+            dist.all_gather_into_tensor(acts.view(-1), act, group=self.group)
+            self.xgmi_bytes["all_gather"] = act.numel() * 4 * (W - 1)
+        else:
+            acts = act.view(1, -1)
+        send = eng.cs_forward(acts)                              # [W, R, 2*dl]: peers' rows, my columns
+        if W > 1:
+            recv = self._like("recv_f", send)
+            dist.all_to_all_single(recv, send, group=self.group)
+            self.xgmi_bytes["all_to_all_fwd"] = send[0].numel() * 4 * (W - 1)
+        else:
+            recv = send
+        loss = eng.cs_head(recv)                                 # my rows, every rank's columns -> loss, head backward
+        if self._scale is None:
+            self._scale = torch.full((1,), 1.0 / W, dtype=torch.float32, device=loss.device)
+        send2, wgrads = eng.cs_backward_local(self._scale)       # [W, R, 2*dl]: my rows, the peers' columns
+        if W > 1:
+            recv2 = self._like("recv_b", send2)
+            dist.all_to_all_single(recv2, send2, group=self.group)
+            dist.all_reduce(wgrads, op=dist.ReduceOp.SUM, group=self.group)
+            self.xgmi_bytes["all_to_all_bwd"] = send2[0].numel() * 4 * (W - 1)
+            self.xgmi_bytes["all_reduce"] = wgrads.numel() * 4
+        else:
+            recv2 = send2
+        eng.cs_backward_hops(recv2, acts)
+        eng.cs_update()
+        return loss
+
+    def global_loss(self, loss):
+        if self.world > 1:
+            loss = loss.clone()
+            dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.group)
+            loss /= self.world
+        return loss
+
+    def kernel_time_ms(self, name=None):
+        total, launches = 0.0, 0
+        for e0, e1, n in self._events:
+            total += e0.elapsed_time(e1)
+            launches += n
+        return total, launches
+
+
+class ColumnShardEngine(object):
+    """The cs_* interface on the HIP kernels, around an EliMRec model (which keeps the plan, the folded constants, the
+    head kernels' workspace, the projection weights and the cached tables predict() reads)."""
+
+    def __init__(self, model, group=None):
+        if not getattr(model, "_lazy", False):
+            raise ValueError("the column-sharded engine needs the folded propagation with batch head rows "
+                             "(bipartite adjacency: adj_type pre/plain/gcmc; layer_num >= 2; --head_rows=batch)")
+        self.model, self.group = model, group
+        self.kernel_events = None
+        self.world = None
+
+    # ------------------------------------------------------------------ set-up
+    def cs_setup(self, world, rank, optimizer):
+        m = self.model
+        dev = m._require_gpu()
+        d, N = m.latent_dim, m.num_users + m.num_items
+        if d % world != 0 or (d // world) % 4 != 0:
+            raise ValueError("recdim %d cannot be split into %d column slices of a multiple of 4" % (d, world))
+        self.world, self.rank, self.opt = world, rank, optimizer
+        self.dl, self.col0 = d // world, rank * (d // world)
+        self.ns, self.w = slab.choose_slabs(self.dl, N)
+        self.gs = slab.choose_groups(self.ns)
+        adj = m._scipy_adj()
+        self.plan = slab.SellPlan(adj, dev, side_split=m.num_users)
+        self.planT = self.plan if m._adj_symmetric else slab.SellPlan(adj.T.tocsr(), dev, side_split=m.num_users)
+        tab = lambda: slab.SlabTable(N, self.ns, self.w, dev)
+        L = m.n_layers
+        self.master = [tab(), tab()]
+        self.cur = 0
+        self.layers = [None] + [tab() for _ in range(L - 1)]
+        self.long_tab = torch.empty(self.ns * max(self.plan.n_long, 1) * self.w, dtype=torch.float32, device=dev)
+        self.xL = None                                            # full hop-L table, only when predict() needs it
+        self.grad = tab()
+        self.m1 = torch.zeros_like(self.grad.data)
+        self.m2 = torch.zeros_like(self.grad.data)
+        self.srcA, self.srcB, self.tmp = tab(), tab(), [tab(), tab()]
+        self.mask = torch.zeros((N + 31) // 32 + 2, dtype=torch.int32, device=dev)
+        self.step_count = 0
+        self._B = None
+        self._x0_fwd = None
+        ws = m._workspace(1)
+        self.load_from_model()
+        m._slab_engine = self
+        # the embeddings are updated here, not by the caller's optimizer; the projection weights go through it
+        self._tail = [(n, p) for n, p in m.named_parameters() if not n.startswith(("embedding_user.", "embedding_item."))]
+        return ws
+
+    @torch.no_grad()
+    def load_from_model(self):
+        """Master copy <- the model's embedding parameters (start-up, load_state_dict)."""
+        m = self.model
+        ws = m._workspace(m._ws_key[1] if m._ws_key else 1)
+        self.master[self.cur].from_rows(ws["X0d"], col0=self.col0)
+
+    @torch.no_grad()
+    def sync_to_model(self):
+        """The model's embedding parameters <- the master copy (before a checkpoint; all ranks must call it)."""
+        m = self.model
+        x0d = m._ws["X0d"]
+        if self.world == 1:
+            self.master[self.cur].to_rows(x0d, col0=0)
+            return
+        loc = self.master[self.cur].dense()
+        parts = [torch.empty_like(loc) for _ in range(self.world)]
+        dist.all_gather(parts, loc, group=self.group)
+        x0d.copy_(torch.cat(parts, dim=1))
+
+    def _workspace(self, B):
+        m = self.model
+        ws = m._workspace(B, 3 * B)
+        if self._B != (B, m._ws_gen):
+            self._B = (B, m._ws_gen)
+            dev, d, R, W = m._device(), m.latent_dim, 3 * B, self.world
+            N = m.num_users + m.num_items
+            self.hg = torch.zeros(R, 2 * d, dtype=torch.float32, device=dev)
+            self.send_f = torch.empty(W, R, 2 * self.dl, dtype=torch.float32, device=dev) if W > 1 else None
+            self.counts = torch.zeros(W, dtype=torch.int32, device=dev)
+            if getattr(self, "narrow_x", None) is None or ws["Narrow"].data_ptr() != self.narrow_x.data_ptr():
+                self.narrow_x = torch.zeros(N + 1, d, dtype=torch.float32, device=dev)   # spare row: padded slots land there
+                ws["Narrow"] = self.narrow_x[:N]
+                m._ws_gen += 1                                    # recorded regions hold the old buffer's address
+                self._B = (B, m._ws_gen)
+        return ws
+
+    def _timed(self, fn, hops):
+        ev = self.kernel_events
+        if ev is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        ev.append((e0, e1, hops))
+
+    # ------------------------------------------------------------------ the step
+    @torch.no_grad()
+    def cs_plan(self, users, pos, neg):
+        m = self.model
+        B = int(users.numel())
+        ws = self._workspace(B)
+        users, pos, neg = m._index_tensors(users, pos, neg)
+        keys = ops.triplet_rows(users, pos, neg, m.num_users, ws["keys"][:3 * B])
+        R = 3 * B
+        act, seg = ws["active_rows"][:R], ws["seg_info"]
+        m._plan_n = R
+        m._last_block_weights = m._block_weights()
+        self._keys = keys
+
+        def plan():
+            ops.segment_plan(keys, m.num_users, m.num_users + m.num_items, act, seg, ws["slot_seg"][:R], ws["plan_ws"])
+            ops.pad_rows(self.hg, act, seg[0:1], pad_key=PAD_KEY)
+        m._region("cs_plan", (m._ws_gen, keys.data_ptr(), R), plan)
+        return act
+
+    @torch.no_grad()
+    def cs_forward(self, acts):
+        m = self.model
+        ws, L, U = m._ws, m.n_layers, m.num_users
+        W, R = acts.shape
+        x0 = self.master[self.cur]
+        self._x0_fwd = x0
+        self._acts = acts
+        tabs = [x0] + self.layers[1:]
+        if W > 1:
+            torch.sum(acts >= 0, dim=1, dtype=torch.int32, out=self.counts)
+            counts = self.counts
+            out0, narrow, by_node = self.send_f.view(W * R, 2 * self.dl)[:, :self.dl], self.send_f.view(W * R, 2 * self.dl)[:, self.dl:], False
+        else:
+            counts = ws["seg_info"][0:1]
+            out0, narrow, by_node = ws["OutAct"][:R, :m.latent_dim], ws["Narrow"], True
+
+        def hops():
+            for k in range(1, L):
+                slab.hop(self.plan, tabs[k - 1], tabs[k], gs=self.gs)
+        self._timed(lambda: m._region("cs_fwd_hops%d" % self.cur, (m._ws_gen,), hops), L - 1)
+
+        def rows():
+            if self.plan.n_long:
+                slab.hop(self.plan, tabs[L - 1], self.long_tab, gs=self.gs, seg_only=True)
+            slab.rows(self.plan, self.ns, self.w, L, U, [t.data for t in tabs] + [None], self.long_tab, acts, counts, R, W,
+                      out0, narrow, by_node)
+        m._region("cs_fwd_rows%d" % self.cur, (m._ws_gen, acts.data_ptr(), R, W), rows)
+        return self.send_f if W > 1 else None
+
+    @torch.no_grad()
+    def cs_head(self, recv):
+        m = self.model
+        ws, d = m._ws, m.latent_dim
+        R = m._plan_n
+        B = R // 3
+        if recv is not None:                                      # [W, R, (out0 | narrow)] -> my rows, all columns
+            W = recv.shape[0]
+            r = recv.view(W, R, 2, self.dl)
+            ws["OutAct"][:R, :d].unflatten(1, (W, self.dl)).copy_(r[:, :, 0].permute(1, 0, 2))
+            act = ws["active_rows"][:R].long()
+            idx = torch.where(act >= 0, act, torch.full_like(act, self.narrow_x.shape[0] - 1))
+            self.narrow_x.index_copy_(0, idx, r[:, :, 1].permute(1, 0, 2).reshape(R, d))
+        m._fwd_head(ws, self._keys, R, B, 0, ws["grad_rows"], layer_means=False)
+        m._slab_fwd = True
+        loss = torch.empty((), dtype=torch.float32, device=m._device())
+        ops.fixed_order_sum(ws["loss_rows"], loss)
+        return loss
+
+    @torch.no_grad()
+    def cs_backward_local(self, scale):
+        m = self.model
+        ws, d = m._ws, m.latent_dim
+        R = m._plan_n
+        self._grads = m._backward_batch_rows(ws, scale, ws["grad_rows"], R, head_only=True)
+        # [H | G]: all the adjoint needs of a dOut row (rows beyond the active count stay zero, their keys negative)
+        m._region("cs_sources", (m._ws_gen, R), lambda: ops.source_rows(ws["dOutR"][:R], ws["seg_info"][0:1], d, m.M, self.hg))
+        wg = ws["flat_grad"][ws["tail_off"]:]
+        if self.world == 1:
+            return self.hg.view(1, R, 2 * d), wg
+        W = self.world
+        send = self.hg.view(R, 2, W, self.dl).permute(2, 0, 1, 3).contiguous().view(W, R, 2 * self.dl)
+        return send, wg
+
+    @torch.no_grad()
+    def cs_backward_hops(self, recv2, acts):
+        m = self.model
+        U, I, L = m.num_users, m.num_items, m.n_layers
+        W, R = acts.shape
+        inv = 1.0 / (L + 1)
+
+        def hops():
+            slab.merge_rows(recv2.view(W * R, 2 * self.dl), acts.reshape(-1), W, U, I, self.srcA, self.srcB, self.mask)
+            t, tmask = (self.srcB if (L & 1) else self.srcA), self.mask          # T^L = S^L (row-sparse)
+            for k in range(L - 1, -1, -1):
+                dst = self.grad if k == 0 else self.tmp[k & 1]
+                slab.hop(self.planT, t, dst, gs=self.gs, src_mask=tmask, add=self.srcB if (k & 1) else self.srcA,
+                         add_mask=self.mask, scale=inv if k == 0 else 1.0)
+                t, tmask = dst, None
+        self._timed(lambda: m._region("cs_bwd_hops", (m._ws_gen, recv2.data_ptr(), acts.data_ptr(), R, W), hops), L)
+
+    @torch.no_grad()
+    def cs_update(self):
+        m = self.model
+        g = self.opt.param_groups[0]
+        self.step_count += 1
+        nxt = 1 - self.cur
+        slab.adam_step_out(self.master[self.cur].data, self.master[nxt].data, self.grad.data, self.m1, self.m2, g["lr"],
+                           g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.step_count)
+        self.cur = nxt
+        for name, p in m.named_parameters():
+            p.grad = None
+        for name, p in self._tail:
+            p.grad = self._grads.get(name)
+        self.opt.step()
+
+    # ------------------------------------------------------------------ cached tables for predict()
+    @torch.no_grad()
+    def materialize_tables(self, ws):
+        """ws['Out'] / ws['Y'] over all rows from the layer tables of the last forward and the projection weights it
+        used (models/EliMRec.py:98-99: predict() reads what the last TRAINING forward computed)."""
+        m = self.model
+        L, U, d = m.n_layers, m.num_users, m.latent_dim
+        N = U + m.num_items
+        if self._x0_fwd is None:
+            raise RuntimeError("no forward has run on the column-sharded engine yet")
+        if self.xL is None:
+            self.xL = self.grad.like()
+        tabs = [self._x0_fwd] + self.layers[1:]
+        slab.hop(self.plan, tabs[L - 1], self.xL, gs=self.gs)
+        layers = [t.data for t in tabs] + [self.xL.data]
+        if self.world == 1:
+            slab.rows(self.plan, self.ns, self.w, L, U, layers, None, None, None, N, 1, ws["Out"][:, :d], ws["Narrow"], False)
+        else:
+            loc = torch.empty(N, 2 * self.dl, dtype=torch.float32, device=ws["Out"].device)
+            slab.rows(self.plan, self.ns, self.w, L, U, layers, None, None, None, N, 1, loc[:, :self.dl], loc[:, self.dl:], False)
+            parts = [torch.empty_like(loc) for _ in range(self.world)]
+            dist.all_gather(parts, loc, group=self.group)
+            ws["Out"][:, :d].copy_(torch.cat([p[:, :self.dl] for p in parts], dim=1))
+            ws["Narrow"].copy_(torch.cat([p[:, self.dl:] for p in parts], dim=1))
+        m._full_tables(ws, ws["snap_views"])
+
+    # ------------------------------------------------------------------ checkpoint / resume (full, rank-independent tensors)
+    @torch.no_grad()
+    def _gather_cols(self, flat):
+        loc = slab.SlabTable(self.grad.n, self.ns, self.w, flat.device, data=flat).dense()
+        if self.world == 1:
+            return loc
+        parts = [torch.empty_like(loc) for _ in range(self.world)]
+        dist.all_gather(parts, loc, group=self.group)
+        return torch.cat(parts, dim=1)
+
+    @torch.no_grad()
+    def optimizer_state(self):
+        """Adam state of the embeddings as row-major [N x d] tensors + the step count (all ranks must call it)."""
+        return dict(step=self.step_count, exp_avg=self._gather_cols(self.m1).cpu(), exp_avg_sq=self._gather_cols(self.m2).cpu())
+
+    @torch.no_grad()
+    def load_optimizer_state(self, st):
+        dev = self.grad.data.device
+        self.step_count = int(st["step"])
+        for flat, key in ((self.m1, "exp_avg"), (self.m2, "exp_avg_sq")):
+            full = st[key].to(dev).float().contiguous()
+            slab.SlabTable(self.grad.n, self.ns, self.w, dev, data=flat).from_rows(full, col0=self.col0)

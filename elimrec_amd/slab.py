@@ -1,0 +1,226 @@
+"""Slab-major (column-sharded) propagation: host plan + tensor-level wrappers of the elimrec_slab_* entry points.
+
+A table of `dl` columns is kept as `ns` slabs of width `w` floats (include/elimrec_hip.h, "slab-major propagation"):
+`SlabTable.data` is one flat fp32 tensor [ns * n * w]; slab s holds columns [s*w, (s+1)*w) of every row. The
+adjacency (models/EliMRec.py:309-354, as built by model.create_adj_mat) is turned ONCE on the host into the SELL-64
+work-item form the hop kernel consumes (`SellPlan`).
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from .ops import _dev, _stream
+
+# rows with more non-zeros are cut into segments of this length: the longest work item bounds a hop's critical path
+# (32: 21 us per hop on an 8-column shard at the Tiktok shape; 64: 29 us; 16: 40 us -- too many partial rows)
+LONG_ROW_THRESHOLD = int(os.environ.get("ELIMREC_SLAB_LONG_ROW", "32"))
+
+
+def choose_slabs(dl, n_rows=None):
+    """(ns, w) for a table of dl columns: w = the largest power-of-two multiple of 4 dividing dl, capped at 32 floats.
+    Measured at the Tiktok shape (tools/bench_slab_order.py, d = 64, us per hop): w = 64 (row-major) 44, w = 32 in two
+    slab groups 35, w = 16 in four 42, w = 8 in eight 67 -- a gathered piece narrower than one 128-B cache line still
+    moves a whole line from L2 to the CU, so narrower slabs lose more on the L2 -> L1 path than their smaller L2
+    footprint wins; 128-B pieces halve every XCD's footprint at no cost per line."""
+    if dl % 4 != 0:
+        raise ValueError("column count must be a multiple of 4 (got %d)" % dl)
+    cap = int(os.environ.get("ELIMREC_SLAB_W", "0")) or 32
+    w = 4
+    while w * 2 <= cap and dl % (w * 2) == 0:
+        w *= 2
+    return dl // w, w
+
+
+def choose_groups(ns):
+    """Slab groups of a hop launch: as many as divide both the slab count and the 8 XCDs."""
+    gs = int(os.environ.get("ELIMREC_SLAB_GS", "0"))
+    if gs > 0 and ns % gs == 0:
+        return gs
+    for gs in (8, 4, 2, 1):
+        if ns % gs == 0 and _is_pow2(ns // gs):
+            return gs
+    return ns
+
+
+def _is_pow2(x):
+    return x >= 1 and (x & (x - 1)) == 0
+
+
+class SellPlan(object):
+    """SELL-64 work items of a CSR matrix on a device (struct elimrec_sell)."""
+
+    def __init__(self, m, device, threshold=LONG_ROW_THRESHOLD, side_split=None):
+        """side_split = U: the unsplit rows are processed side by side (item rows, then user rows; by decreasing
+        length inside a side) instead of by length alone -- all workgroups then gather from the same side's rows at
+        the same time, which is what an XCD's L2 can hold (users read items by popularity, items read the whole,
+        smaller, user table)."""
+        m = m.tocsr()
+        m.sort_indices()
+        n_rows, n_src = m.shape
+        if m.nnz >= 2 ** 31 - 2 ** 24:
+            raise ValueError("graph too large for int32 SELL offsets")
+        rowptr = m.indptr.astype(np.int64)
+        col = m.indices.astype(np.int32)
+        val = m.data.astype(np.float32)
+        deg = np.diff(rowptr)
+        T = int(threshold)
+        long_rows = np.nonzero(deg > T)[0]
+        short_rows = np.nonzero(deg <= T)[0]
+        # segments of the split rows: slot numbers run row by row, segment by segment
+        nseg = (deg[long_rows] + T - 1) // T
+        seg_ptr = np.concatenate([[0], np.cumsum(nseg)]).astype(np.int64)
+        n_seg = int(seg_ptr[-1])
+        seg_row = np.repeat(np.arange(len(long_rows)), nseg)
+        k = np.arange(n_seg) - seg_ptr[seg_row]
+        seg_beg = rowptr[long_rows][seg_row] + k * T
+        seg_len = np.minimum(T, rowptr[long_rows + 1][seg_row] - seg_beg)
+        # heavy first, inside each kind
+        so = np.argsort(-seg_len, kind="stable")
+        if side_split is None:
+            ro = np.argsort(-deg[short_rows], kind="stable")
+        else:
+            ro = np.lexsort((-deg[short_rows], short_rows < int(side_split)))
+        pad = lambda n: (-n) % 64
+        n_seg_items = n_seg + pad(n_seg)
+        n_fin = len(short_rows)
+        n_items = n_seg_items + n_fin + pad(n_fin)
+        item_dst = np.full(n_items, -1, np.int32)
+        item_len = np.zeros(n_items, np.int32)
+        item_beg = np.zeros(n_items, np.int64)
+        item_dst[:n_seg] = so.astype(np.int32)
+        item_len[:n_seg] = seg_len[so]
+        item_beg[:n_seg] = seg_beg[so]
+        item_dst[n_seg_items:n_seg_items + n_fin] = short_rows[ro].astype(np.int32)
+        item_len[n_seg_items:n_seg_items + n_fin] = deg[short_rows[ro]]
+        item_beg[n_seg_items:n_seg_items + n_fin] = rowptr[short_rows[ro]]
+        nb = n_items // 64
+        blk_len = item_len.reshape(nb, 64).max(1).astype(np.int64) if nb else np.zeros(0, np.int64)
+        blk_off = np.concatenate([[0], np.cumsum(blk_len)]).astype(np.int64)
+        total = int(blk_off[-1]) * 64
+        if total >= 2 ** 31:
+            raise ValueError("graph too large for int32 SELL offsets")
+        sell_col = np.zeros(max(total, 1), np.int32)
+        sell_val = np.zeros(max(total, 1), np.float32)
+        # scatter every non-zero of every item to (blk_off[b] + j) * 64 + i
+        it = np.repeat(np.arange(n_items), item_len)
+        j = np.arange(len(it)) - np.repeat(np.cumsum(item_len) - item_len, item_len)
+        src = item_beg[it] + j
+        dstpos = (blk_off[it // 64] + j) * 64 + (it % 64)
+        sell_col[dstpos] = col[src]
+        sell_val[dstpos] = val[src]
+        long_index = np.full(n_rows, -1, np.int32)
+        long_index[long_rows] = np.arange(len(long_rows), dtype=np.int32)
+
+        dev = torch.device(device)
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a.astype(dt))).to(dev)
+        self.device = dev
+        self.n_rows, self.n_src, self.nnz = int(n_rows), int(n_src), int(m.nnz)
+        self.n_items, self.n_seg_items, self.n_seg, self.n_long = int(n_items), int(n_seg_items), n_seg, int(len(long_rows))
+        self.sell_entries = total
+        self.threshold = T
+        self.t = dict(item_dst=t(item_dst, np.int32), item_len=t(item_len, np.int32), blk_off=t(blk_off, np.int32),
+                      col=t(sell_col, np.int32), val=t(sell_val, np.float32),
+                      long_rows=t(long_rows if len(long_rows) else np.zeros(1), np.int32),
+                      long_seg_ptr=t(seg_ptr, np.int32), long_index=t(long_index, np.int32),
+                      rowptr=t(rowptr, np.int32), csr_col=t(col if len(col) else np.zeros(1), np.int32),
+                      csr_val=t(val if len(val) else np.zeros(1), np.float32))
+        p = lambda k: self.t[k].data_ptr()
+        self.desc = _lib.SellDesc(self.n_rows, self.n_src, self.n_items, self.n_seg_items, self.n_seg, self.n_long,
+                                  p("item_dst"), p("item_len"), p("blk_off"), p("col"), p("val"), p("long_rows"),
+                                  p("long_seg_ptr"), p("long_index"), p("rowptr"), p("csr_col"), p("csr_val"))
+        self._partials = {}
+
+    def ref(self):
+        return ctypes.byref(self.desc)
+
+    def partials(self, ns, w):
+        """Scratch for the split rows' partial sums, one buffer per table geometry."""
+        key = (ns, w)
+        if key not in self._partials:
+            nbytes = int(_lib.load().elimrec_slab_partials_bytes(self.ref(), ns, w))
+            self._partials[key] = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=self.device)
+        return self._partials[key]
+
+    def index_bytes(self):
+        """Bytes of index data one pass of a hop reads (SELL col + val, item records, block offsets)."""
+        return 8 * self.sell_entries + 8 * self.n_items + 4 * (self.n_items // 64 + 1)
+
+
+class SlabTable(object):
+    """[n x (ns*w)] fp32 table stored slab-major in one flat tensor."""
+
+    def __init__(self, n, ns, w, device, data=None):
+        self.n, self.ns, self.w = int(n), int(ns), int(w)
+        self.data = torch.empty(self.ns * self.n * self.w, dtype=torch.float32, device=device) if data is None else data
+        assert self.data.numel() == self.ns * self.n * self.w and self.data.is_contiguous()
+
+    @property
+    def cols(self):
+        return self.ns * self.w
+
+    def like(self):
+        return SlabTable(self.n, self.ns, self.w, self.data.device)
+
+    def from_rows(self, src, col0=0):
+        """Columns [col0, col0 + ns*w) of a row-major 2-D tensor (unit column stride)."""
+        assert src.dim() == 2 and src.stride(1) == 1 and src.shape[0] == self.n and col0 + self.cols <= src.shape[1]
+        _lib.check(_lib.load().elimrec_slab_from_rows(_dev(src, "src"), src.stride(0), int(col0), self.n, self.ns, self.w,
+                                                      _dev(self.data, "slab"), _stream()), "slab_from_rows")
+        return self
+
+    def to_rows(self, dst, col0=0):
+        assert dst.dim() == 2 and dst.stride(1) == 1 and dst.shape[0] == self.n and col0 + self.cols <= dst.shape[1]
+        _lib.check(_lib.load().elimrec_slab_to_rows(_dev(self.data, "slab"), self.n, self.ns, self.w, _dev(dst, "dst"),
+                                                    dst.stride(0), int(col0), _stream()), "slab_to_rows")
+        return dst
+
+    def dense(self):
+        """Row-major copy [n x cols] (tests, checkpoints)."""
+        return self.to_rows(torch.empty(self.n, self.cols, dtype=torch.float32, device=self.data.device))
+
+
+def hop(plan, xin, xout, gs=None, src_mask=None, add=None, add_mask=None, scale=1.0, seg_only=False):
+    """xout = (A . xin + [add_mask] add) * scale on slab tables of equal geometry. seg_only: xout is a flat tensor
+    [ns x n_long x w] receiving the split rows only."""
+    ns, w = xin.ns, xin.w
+    gs = choose_groups(ns) if gs is None else gs
+    part = plan.partials(ns, w)
+    out = xout if isinstance(xout, torch.Tensor) else xout.data
+    _lib.check(_lib.load().elimrec_slab_hop(plan.ref(), ns, w, int(gs), _dev(xin.data, "xin"),
+                                            _dev(src_mask, "src_mask", torch.int32), _dev(out, "xout"),
+                                            _dev(None if add is None else add.data, "add"),
+                                            _dev(add_mask, "add_mask", torch.int32), float(scale), _dev(part, "partials"),
+                                            part.numel() * 4, 1 if seg_only else 0, _stream()), "slab_hop")
+
+
+def rows(plan, ns, w, L, U, layers, long_tab, row_ids, counts, R, n_lists, out0, narrow, narrow_by_node):
+    """Layer means at listed rows (elimrec_slab_rows). layers: list of L+1 flat tensors (last may be None)."""
+    ptrs = (ctypes.c_void_p * (L + 1))(*[None if t is None else _dev(t, "layer") for t in layers])
+    assert out0.stride(1) == 1 and narrow.stride(1) == 1
+    _lib.check(_lib.load().elimrec_slab_rows(plan.ref(), ns, w, L, int(U), ptrs, _dev(long_tab, "long_tab"),
+                                             _dev(row_ids, "rows", torch.int32), _dev(counts, "counts", torch.int32),
+                                             int(R), int(n_lists), _dev(out0, "out0"), out0.stride(0),
+                                             _dev(narrow, "narrow"), narrow.stride(0), 1 if narrow_by_node else 0,
+                                             _stream()), "slab_rows")
+
+
+def merge_rows(all_rows, all_keys, world, U, I, srcA, srcB, mask):
+    """[H | G] rows of `world` ranks -> slab-major adjoint sources + row bitmap (elimrec_slab_merge_rows)."""
+    R = all_keys.numel() // world
+    assert all_rows.is_contiguous() and all_rows.shape == (world * R, 2 * srcA.cols) and mask.numel() * 32 >= U + I
+    _lib.check(_lib.load().elimrec_slab_merge_rows(_dev(all_rows, "rows"), _dev(all_keys, "keys", torch.int32), int(world), R,
+                                                   int(U), int(I), srcA.ns, srcA.w, _dev(srcA.data, "srcA"),
+                                                   _dev(srcB.data, "srcB"), _dev(mask, "mask", torch.int32), _stream()),
+               "slab_merge_rows")
+
+
+def adam_step_out(p_in, p_out, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
+    n = p_in.numel()
+    for t in (p_in, p_out, g, m, v):
+        assert t.is_contiguous() and t.numel() == n
+    _lib.check(_lib.load().elimrec_adam_step_out(_dev(p_in, "p_in"), _dev(p_out, "p_out"), _dev(g, "g"), _dev(m, "m"),
+                                                 _dev(v, "v"), n, float(lr), float(beta1), float(beta2), float(eps),
+                                                 float(weight_decay), int(step), _stream()), "adam_step_out")

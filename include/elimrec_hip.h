@@ -411,6 +411,99 @@ int elimrec_sample_triplets(const int32_t *d_user_ids, const int64_t *d_ptr, con
                             uint64_t epoch, int64_t *d_users, int64_t *d_pos, int64_t *d_neg,
                             void *stream);
 
+/* ================================================================ slab-major propagation (column shards)
+ * The d-column table [E_u ; E_i] and every layer table X^k = A X^(k-1) of the folded propagation
+ * (models/EliMRec.py:238-248 with the constant feature tables folded out) are kept
+ * SLAB-MAJOR: a table of `dl` columns is `ns` slabs of width `w` floats (dl = ns*w, w a power of two >= 4),
+ * slab s = a contiguous [n x w] array holding columns [s*w, (s+1)*w) of every row:
+ *      element (row r, column s*w + c)  at  d_X[(s*n + r)*w + c].
+ * Why: a LightGCN hop is independent per column, so a column slice is a unit of work that needs no
+ * communication -- across GPUs (rank q owns dl = d/world columns of the table, of its gradient and of its
+ * Adam moments; only the rows of the batch's active nodes ever cross xGMI) and across the 8 XCDs of one GPU
+ * (workgroups with equal blockIdx % gs work on the same slab group, whose [n x w*spg] slice fits that
+ * XCD's 4 MiB L2 at the Tiktok shape instead of every XCD dragging the whole table through its L2).
+ *
+ * The adjacency is handed over in SELL-64 work-item form (built once on the host, elimrec_amd/slab.py):
+ * work items = the rows with <= long_threshold non-zeros plus <= long_threshold-nnz SEGMENTS of the longer
+ * rows, sorted by decreasing length; items are grouped in super blocks of 64 whose (col, val) are stored
+ * transposed, entry (block b, neighbour j, item i) at (blk_off[b] + j)*64 + i, so that the lane groups of a
+ * wave read their neighbour indices with one coalesced load per step whatever the number of lanes per item.
+ * Segment items come first (n_seg_items of them, padded to a multiple of 64); they write partial rows which a
+ * second launch adds per long row in a fixed order. Every sum has a fixed order: bitwise reproducible. */
+typedef struct elimrec_sell {
+    int64_t n_rows;                 /* output rows                                                      */
+    int64_t n_src;                  /* rows of the gathered table (= n_rows for the square adjacency)   */
+    int32_t n_items;                /* work items incl. padding, a multiple of 64                       */
+    int32_t n_seg_items;            /* leading segment items incl. padding, a multiple of 64            */
+    int32_t n_seg;                  /* partial slots (= real segment items)                             */
+    int32_t n_long;                 /* split rows                                                       */
+    const int32_t *d_item_dst;      /* [n_items] output row | partial slot (segment items) | -1 padding */
+    const int32_t *d_item_len;      /* [n_items]                                                        */
+    const int32_t *d_blk_off;       /* [n_items/64 + 1] first neighbour row of each super block         */
+    const int32_t *d_col;           /* SELL column indices                                              */
+    const float *d_val;             /* SELL values                                                      */
+    const int32_t *d_long_rows;     /* [n_long] ascending                                               */
+    const int32_t *d_long_seg_ptr;  /* [n_long + 1] partial slots of each split row                     */
+    const int32_t *d_long_index;    /* [n_rows] index into d_long_rows, -1 for unsplit rows             */
+    const int32_t *d_rowptr;        /* plain CSR of the same matrix (row-list evaluation)               */
+    const int32_t *d_csr_col;
+    const float *d_csr_val;
+} elimrec_sell;
+
+/* One hop over a slab-major table:  r = A . Xin ;  Xout[row] = (r + [add_mask bit row] Add[row]) * scale.
+ * gs = slab groups (1, 2, 4 or 8 dividing ns): a workgroup works on the ns/gs slabs of group blockIdx % gs.
+ * d_src_mask (nullable bitmap over the source rows): rows whose bit is clear are zero and are not read (the
+ * first adjoint hop gathers from the row-sparse head gradient). d_add / d_add_mask nullable.
+ * d_partials: scratch [ns x n_seg x w] floats for the split rows. seg_only != 0: only the split rows are
+ * evaluated and written COMPACTLY to d_Xout viewed as [ns x n_long x w] (no add/scale) -- the part of hop L
+ * that elimrec_slab_rows cannot do inline.
+ * Replaces torch.sparse.mm (models/EliMRec.py:244) and its backward for one column slice. */
+size_t elimrec_slab_partials_bytes(const elimrec_sell *A, int ns, int w);
+/* tuning knob (also env ELIMREC_SLAB_VARIANT): inner-loop form of the hop kernel, results identical */
+void elimrec_slab_set_variant(int v);
+int elimrec_slab_hop(const elimrec_sell *A, int ns, int w, int gs, const float *d_Xin,
+                     const uint32_t *d_src_mask, float *d_Xout, const float *d_add,
+                     const uint32_t *d_add_mask, float scale, float *d_partials, size_t partials_bytes,
+                     int seg_only, void *stream);
+
+/* Layer means (models/EliMRec.py:246-247) of the folded propagation at a list of rows, from slab-major layer
+ * tables X^0..X^L (host array of L+1 device pointers):
+ *      out0[s]  = 1/(L+1) * (((X^0 + X^1) + X^2) + ... + X^L)[row_s]
+ *      narrow[] = 1/(L+1) * sum over even k (user rows, row < U) / odd k (item rows) of X^k[row_s]
+ * (the part of Out every feature table shares). layers[L] may be NULL: hop L is then evaluated inline at the
+ * listed rows from X^(L-1) through the plain CSR, split rows taken from d_long [ns x n_long x w]
+ * (elimrec_slab_hop with seg_only). Rows: d_rows int32 [n_lists x R] with d_counts int32[n_lists] valid
+ * entries per list (device), or d_rows NULL = all rows 0..R-1 (n_lists = 1, d_counts ignored).
+ * Output row of slot s (= list*R + index): d_out0 + s*ld_out0 and d_narrow + (narrow_by_node ? row : s)*ld_narrow,
+ * local column c at offset c (row-major within the row). */
+int elimrec_slab_rows(const elimrec_sell *A, int ns, int w, int L, int64_t U,
+                      const float *const *layers, const float *d_long, const int32_t *d_rows,
+                      const int32_t *d_counts, int64_t R, int n_lists, float *d_out0, int64_t ld_out0,
+                      float *d_narrow, int64_t ld_narrow, int narrow_by_node, void *stream);
+
+/* Row-major <-> slab-major: columns [col0, col0 + ns*w) of a row-major [n x ld] table. */
+int elimrec_slab_from_rows(const float *d_src, int64_t ld, int64_t col0, int64_t n, int ns, int w,
+                           float *d_slab, void *stream);
+int elimrec_slab_to_rows(const float *d_slab, int64_t n, int ns, int w, float *d_dst, int64_t ld,
+                         int64_t col0, void *stream);
+
+/* Adjoint sources of the folded propagation from [H | G] rows (elimrec_source_rows restricted to a column
+ * slice: H = block sum of dOut, G = block 0; 2*dl floats per row, dl = ns*w) contributed by `world` ranks:
+ * d_rows [world x R x 2*dl], d_keys int32 [world x R] node ids ascending per rank, negative = padding.
+ * Rows of the same node are added in rank order (no float atomics). Writes, slab-major and on the active rows
+ * only, SrcA = [H_u ; G_i], SrcB = [G_u ; H_i] and the row bitmap d_mask (all ceil(N/32) words written).
+ * Replaces IndexBackward / index_put(accumulate) across ranks ("sparse-grad reduce-scatter"). */
+int elimrec_slab_merge_rows(const float *d_rows, const int32_t *d_keys, int world, int64_t R, int64_t U,
+                            int64_t I, int ns, int w, float *d_SrcA, float *d_SrcB, uint32_t *d_mask,
+                            void *stream);
+
+/* elimrec_adam_step reading the parameters from d_p_in and writing them to d_p_out (may alias): with two
+ * parameter buffers used alternately the tables cached by the last forward keep seeing the parameters they
+ * were computed from (models/EliMRec.py:98-99 reads tables made BEFORE the last optimizer step). */
+int elimrec_adam_step_out(const float *d_p_in, float *d_p_out, const float *d_g, float *d_m, float *d_v,
+                          int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                          int64_t step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

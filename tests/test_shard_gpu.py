@@ -1,0 +1,341 @@
+"""The column-sharded (slab-major) engine on a real MI355X, through the C ABI: op-level checks of the slab kernels
+against torch, the trainer at world 1 against the reference's golden vectors, W ranks emulated on one GPU against
+the single-rank step on the concatenated batch, and one step at the C4 shape (Tiktok x16 items, d = 128) against the
+oracle. Needs a GPU: `-m gpu`."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from helpers import build_model_from_fixture, load_golden, make_config, rel_err, sub
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t if dtype is None else t.to(dtype)
+
+
+def _random_graph(n, seed, hot=6, hot_deg=400):
+    """Ragged rows: empty rows, rows of a few entries and `hot` rows far above the split threshold."""
+    rng = np.random.RandomState(seed)
+    deg = rng.poisson(6, n)
+    deg[rng.rand(n) < 0.05] = 0
+    deg[rng.choice(n, hot, replace=False)] = hot_deg + rng.randint(0, 70, hot)
+    rows = np.repeat(np.arange(n), deg)
+    cols = rng.randint(0, n, len(rows))
+    m = sp.csr_matrix((rng.rand(len(rows)).astype(np.float32) + 0.1, (rows, cols)), shape=(n, n))
+    m.sum_duplicates()
+    m.sort_indices()
+    return m
+
+
+def _bitmap(flags):
+    n = flags.numel()
+    words = torch.zeros((n + 31) // 32 + 2, dtype=torch.int64, device=DEV)
+    bits = torch.zeros(words.numel() * 32, dtype=torch.int64, device=DEV)
+    bits[:n] = flags.long()
+    words.copy_((bits.view(-1, 32) << torch.arange(32, device=DEV)).sum(1))
+    return words.to(torch.int32)                      # bit 31 wraps into the sign bit
+
+
+@pytest.mark.parametrize("d,w,gs", [(64, 32, 2), (64, 8, 8), (64, 64, 1), (16, 16, 1), (8, 8, 1), (4, 4, 1), (128, 32, 4),
+                                    (128, 32, 1), (48, 16, 3), (96, 32, 3)])
+def test_slab_hop_vs_torch(d, w, gs):
+    """elimrec_slab_hop on every lane-group width (1..64 lanes per work item), plain and with the adjoint's options
+    (row-sparse source behind a bitmap, masked addend, scale): 1e-5 against an fp64 product; unsplit rows bitwise equal
+    to the row-major kernel (same fmaf chain)."""
+    from elimrec_amd import ops, slab
+    n = 3000
+    m = _random_graph(n, d + w)
+    ns = d // w
+    if ns % gs or (ns // gs) * (w // 4) > 64:
+        pytest.skip("geometry not representable")
+    plan = slab.SellPlan(m, DEV, threshold=32, side_split=1200)
+    assert plan.n_long > 0
+    torch.manual_seed(d)
+    X = torch.randn(n, d, device=DEV)
+    xs = slab.SlabTable(n, ns, w, DEV).from_rows(X)
+    assert torch.equal(xs.dense(), X)
+    y = xs.like()
+    y.data.fill_(float("nan"))
+    slab.hop(plan, xs, y, gs=gs)
+    A64 = torch.from_numpy(m.astype(np.float64).toarray()).to(DEV)
+    want = A64 @ X.double()
+    got = y.dense()
+    assert (got.double() - want).abs().max().item() < 1e-5
+    if d % 4 == 0 and d <= 256:
+        ref = torch.empty_like(X)
+        ops.block_spmm(ops.Csr.from_scipy(m, DEV, C=d, threshold=32), X, Xout=ref)
+        short = torch.from_numpy(np.diff(m.indptr) <= 32).to(DEV)
+        assert torch.equal(got[short], ref[short])
+    # adjoint form
+    act = torch.rand(n, device=DEV) < 0.07
+    bm = _bitmap(act)
+    S = torch.randn(n, d, device=DEV)
+    ss = slab.SlabTable(n, ns, w, DEV).from_rows(S)          # garbage outside the bitmap on purpose
+    y.data.fill_(float("nan"))
+    slab.hop(plan, ss, y, gs=gs, src_mask=bm, add=ss, add_mask=bm, scale=0.25)
+    Sm = S.double() * act[:, None]
+    assert (y.dense().double() - (A64 @ Sm + Sm) * 0.25).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("d,w,L", [(64, 32, 3), (16, 16, 2), (8, 8, 4), (64, 8, 1), (32, 32, 3)])
+def test_slab_rows_layer_means_and_inline_last_hop(d, w, L):
+    """elimrec_slab_rows: the layer means at listed rows with hop L evaluated inline (split rows from the seg_only
+    launch) are bitwise what the full tables give; several row lists with device counts (the multi-rank form)."""
+    from elimrec_amd import slab
+    n, U = 2500, 900
+    m = _random_graph(n, 5 * d + L)
+    plan = slab.SellPlan(m, DEV, threshold=32, side_split=U)
+    ns = d // w
+    torch.manual_seed(L)
+    tabs = [slab.SlabTable(n, ns, w, DEV).from_rows(torch.randn(n, d, device=DEV))]
+    for k in range(L):
+        tabs.append(tabs[0].like())
+        slab.hop(plan, tabs[k], tabs[k + 1])
+    D = [t.dense() for t in tabs]
+    s = D[0] + D[1]
+    for k in range(2, L + 1):
+        s = s + D[k]
+    inv = 1.0 / (L + 1)
+    nar_u = D[0][:U].clone()
+    nar_i = D[1][U:].clone()
+    for k in range(2, L + 1):
+        if k % 2 == 0:
+            nar_u = nar_u + D[k][:U]
+        else:
+            nar_i = nar_i + D[k][U:]
+    mean, nar = s * inv, torch.cat([nar_u, nar_i]) * inv
+    full0, fulln = torch.empty(n, d, device=DEV), torch.empty(n, d, device=DEV)
+    slab.rows(plan, ns, w, L, U, [t.data for t in tabs], None, None, None, n, 1, full0, fulln, False)
+    assert torch.equal(full0, mean) and torch.equal(fulln, nar)
+    # two row lists, last hop inline
+    R = 640
+    lists, counts = [], []
+    for seed, cnt in ((1, 500), (2, 77)):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        ids = torch.sort(torch.randperm(n, generator=g)[:cnt])[0].int()
+        lists.append(torch.cat([ids, torch.full((R - cnt,), -(1 << 30), dtype=torch.int32)]))
+        counts.append(cnt)
+    rows = torch.stack(lists).to(DEV)
+    cnts = torch.tensor(counts, dtype=torch.int32, device=DEV)
+    long_tab = torch.empty(ns * max(plan.n_long, 1) * w, device=DEV)
+    slab.hop(plan, tabs[L - 1], long_tab, seg_only=True)
+    packed = torch.full((2 * R, 2 * d), float("nan"), device=DEV)
+    slab.rows(plan, ns, w, L, U, [t.data for t in tabs[:L]] + [None], long_tab, rows, cnts, R, 2, packed[:, :d], packed[:, d:], False)
+    for li, cnt in enumerate(counts):
+        r = rows[li, :cnt].long()
+        assert torch.equal(packed[li * R:li * R + cnt, :d], mean[r])
+        assert torch.equal(packed[li * R:li * R + cnt, d:], nar[r])
+        assert torch.isnan(packed[li * R + cnt:(li + 1) * R]).all()          # padded slots are not written
+
+
+@pytest.mark.parametrize("W,R,U,I,d,w", [(5, 300, 700, 1300, 32, 32), (2, 64, 40, 90, 64, 8), (8, 1000, 3000, 5000, 8, 8),
+                                         (1, 50, 10, 200, 64, 32)])
+def test_slab_merge_rows_vs_torch(W, R, U, I, d, w):
+    from elimrec_amd import slab
+    N = U + I
+    torch.manual_seed(W * R)
+    keys, rows = [], torch.randn(W * R, 2 * d, device=DEV)
+    H, G = torch.zeros(N, d, device=DEV, dtype=torch.float64), torch.zeros(N, d, device=DEV, dtype=torch.float64)
+    for r in range(W):
+        cnt = int(torch.randint(R // 2, R, (1,)))
+        ids = torch.sort(torch.randperm(N)[:cnt])[0].int().to(DEV)
+        keys.append(torch.cat([ids, torch.full((R - cnt,), -(1 << 30), dtype=torch.int32, device=DEV)]))
+        H.index_add_(0, ids.long(), rows[r * R:r * R + cnt, :d].double())
+        G.index_add_(0, ids.long(), rows[r * R:r * R + cnt, d:].double())
+    keys = torch.cat(keys)
+    sa, sb = slab.SlabTable(N, d // w, w, DEV), slab.SlabTable(N, d // w, w, DEV)
+    sa.data.zero_(); sb.data.zero_()
+    mask = torch.full(((N + 31) // 32 + 2,), -1, dtype=torch.int32, device=DEV)
+    slab.merge_rows(rows, keys, W, U, I, sa, sb, mask)
+    assert (sa.dense().double() - torch.cat([H[:U], G[U:]])).abs().max().item() < 1e-5
+    assert (sb.dense().double() - torch.cat([G[:U], H[U:]])).abs().max().item() < 1e-5
+    active = torch.zeros(N, dtype=torch.bool, device=DEV)
+    active[keys[keys >= 0].long()] = True
+    assert torch.equal(mask[:(N + 31) // 32], _bitmap(active)[:(N + 31) // 32])
+    again_a = sa.dense().clone()
+    slab.merge_rows(rows, keys, W, U, I, sa, sb, mask)
+    assert torch.equal(sa.dense(), again_a)                                    # fixed summation order
+
+
+def test_adam_step_out_equals_in_place_kernel():
+    from elimrec_amd import ops, slab
+    torch.manual_seed(0)
+    n = 100003
+    p, g, m, v = (torch.randn(n, device=DEV) for _ in range(4))
+    v.abs_()
+    p2, m2, v2, out = p.clone(), m.clone(), v.clone(), torch.empty_like(p)
+    ops.adam_step(p, g, m, v, 1e-3, 0.9, 0.999, 1e-8, 1e-4, 3)
+    slab.adam_step_out(p2, out, g, m2, v2, 1e-3, 0.9, 0.999, 1e-8, 1e-4, 3)
+    assert torch.equal(out, p) and torch.equal(m2, m) and torch.equal(v2, v)
+
+
+# ----------------------------------------------------------------------------- the trainer, world 1, golden fixtures
+@pytest.mark.parametrize("name", ["ml3", "kwai", "gcmc", "normal"])
+def test_column_shard_trainer_matches_reference_fixture(name):
+    """ColumnShardTrainer at world 1 on the reference's golden vectors: losses 1e-5, parameters after Adam 2e-5,
+    predict() after training (tables of the last forward, materialised from the slab-major layer tables) 1e-5."""
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
+    g = load_golden(name)
+    model, _ = build_model_from_fixture(g, DEV)
+    opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    eng = ColumnShardEngine(model)
+    tr = ColumnShardTrainer(eng, opt)
+    steps = int(g["steps"])
+    for t in range(1, steps + 1):
+        loss = tr.step(*(_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg")))
+        assert abs(float(loss) - float(g["step%d/loss" % t])) < 1e-5, t
+        if t in (1, steps):
+            eng.sync_to_model()
+            sd = model.state_dict()
+            for k, v in sub(g, "after%d" % t).items():
+                assert np.abs(sd[k].cpu().numpy() - v).max() < 2e-5, (t, k)
+    assert rel_err(model.all_users.cpu(), g["cache/all_users"]) < 1e-4
+    model.fusion_mode, model.predict_type = "rubi", "TIE"
+    got = model.predict(g["eval_users"].tolist()).numpy()
+    assert np.abs(got - g["predict/rubi/TIE"]).max() < 1e-5
+
+
+def test_column_shard_trainer_equals_row_major_trainer():
+    """Same model, same batches: the slab-major engine and the row-major trainer (dist.py) agree to round-off, and the
+    slab engine is bitwise reproducible."""
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
+    from elimrec_amd.dist import DataParallelTrainer
+    g = load_golden("gcmc")
+    runs = []
+    for kind in ("rows", "slab", "slab"):
+        model, _ = build_model_from_fixture(g, DEV)
+        opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+        if kind == "rows":
+            tr = DataParallelTrainer(model, opt)
+        else:
+            eng = ColumnShardEngine(model)
+            tr = ColumnShardTrainer(eng, opt)
+        losses = [float(tr.step(*(_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg")))) for t in (1, 2, 3)]
+        if kind == "slab":
+            eng.sync_to_model()
+        runs.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}))
+    assert runs[1][0] == runs[2][0]
+    for k in runs[1][1]:
+        assert torch.equal(runs[1][1][k], runs[2][1][k]), k
+        assert (runs[0][1][k] - runs[1][1][k]).abs().max().item() < 1e-6, k
+    assert np.allclose(runs[0][0], runs[1][0], atol=1e-6)
+
+
+# ----------------------------------------------------------------------------- W ranks emulated on one GPU
+def _emulated_step(engines, batches):
+    """What ColumnShardTrainer.step does on W ranks, with the collectives done by hand in one process."""
+    W = len(engines)
+    acts = torch.stack([e.cs_plan(*b).clone() for e, b in zip(engines, batches)])               # all_gather
+    sends = [e.cs_forward(acts) for e in engines]
+    sends = [None if s is None else s.clone() for s in sends]
+    scale = torch.full((1,), 1.0 / W, device=DEV)
+    losses, sends2, wgs = [], [], []
+    for q, e in enumerate(engines):
+        recv = None if W == 1 else torch.stack([sends[p][q] for p in range(W)])                 # all_to_all
+        losses.append(e.cs_head(recv).clone())
+        s2, wg = e.cs_backward_local(scale)
+        sends2.append(s2.clone()); wgs.append(wg)
+    total = torch.stack([w.clone() for w in wgs]).sum(0)                                        # all_reduce
+    for q, e in enumerate(engines):
+        wgs[q].copy_(total)
+        e.cs_backward_hops(torch.stack([sends2[p][q] for p in range(W)]), acts)                 # all_to_all
+        e.cs_update()
+    return torch.stack(losses).mean()
+
+
+@pytest.mark.parametrize("W", [2, 4, 8])
+def test_column_shard_ranks_emulated_on_one_gpu(W):
+    """W column-shard ranks (each owns recdim/W columns and 1/W of the triplets) equal ONE rank on the whole batch:
+    loss, embeddings and projection weights after two steps; every rank holds the same projection weights."""
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
+    g = load_golden("ml3")
+    B = (len(g["step1/users"]) // W) * W
+
+    def make(world, rank):
+        model, _ = build_model_from_fixture(g, DEV)
+        opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+        eng = ColumnShardEngine(model)
+        eng.cs_setup(world, rank, opt)
+        return model, eng
+
+    one_model, one = make(1, 0)
+    ranks = [make(W, q) for q in range(W)]
+    for t in (1, 2):
+        u, p, n = (_t(g["step%d/%s" % (t, k)])[:B] for k in ("users", "pos", "neg"))
+        l1 = _emulated_step([one], [(u, p, n)])
+        h = B // W
+        lw = _emulated_step([e for _, e in ranks], [(u[q * h:(q + 1) * h], p[q * h:(q + 1) * h], n[q * h:(q + 1) * h]) for q in range(W)])
+        assert abs(float(l1) - float(lw)) < 1e-6
+    full = one.master[one.cur].dense()
+    shards = torch.cat([e.master[e.cur].dense() for _, e in ranks], dim=1)
+    assert (full - shards).abs().max().item() < 2e-5        # Adam's lr*g/(|g|+eps) amplifies round-off where |g| ~ eps
+    sd1 = one_model.state_dict()
+    for q, (m, _) in enumerate(ranks):
+        for k, v in m.state_dict().items():
+            if not k.startswith(("embedding_user.", "embedding_item.")):
+                assert (v - sd1[k]).abs().max().item() < 2e-5, (q, k)
+                assert torch.equal(v, ranks[0][0].state_dict()[k]), (q, k)
+
+
+# ----------------------------------------------------------------------------- BASELINE.json configs[3] (C4)
+def _shape_step_vs_oracle(U, I, E, dims, recdim, B, world=1):
+    from elimrec_amd import ColumnShardEngine, EliMRec, FusedAdam, SyntheticDataset, set_seed
+    from oracle import elimrec_oracle as eo
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    cfg = make_config(["--data.input.dataset=synthetic", "--alpha=0.5", "--loss=bpr_loss", "--recdim=%d" % recdim, "--verbose=0"])
+    ds = SyntheticDataset(U, I, E, feat_dims=dims, seed=1)
+    set_seed(7)
+    model = EliMRec(cfg, ds)
+    init = {k: v.detach().clone().numpy() for k, v in model.state_dict().items()}
+    model = model.to(DEV)
+    gen = torch.Generator().manual_seed(3)
+    train = ds.train_matrix.tocoo()
+    pick = torch.randint(0, train.nnz, (B,), generator=gen).numpy()
+    u = torch.from_numpy(train.row[pick].astype(np.int64))
+    p = torch.from_numpy(train.col[pick].astype(np.int64))
+    n = torch.randint(0, I, (B,), generator=gen)
+    opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+    engines = []
+    for q in range(world):
+        eng = ColumnShardEngine(model)
+        eng.cs_setup(world, q, opt)
+        engines.append(eng)
+    # forward + backward of one rank-0 step without the update: gradients against the oracle
+    eng = engines[0]
+    acts = eng.cs_plan(u.to(DEV), p.to(DEV), n.to(DEV)).view(1, -1)
+    assert world == 1
+    eng.cs_forward(acts)
+    loss = eng.cs_head(None)
+    s2, _ = eng.cs_backward_local(torch.ones(1, device=DEV))
+    eng.cs_backward_hops(s2, acts)
+    tu, ti = ds.get_train_interactions()
+    adj = eo.build_adj(tu, ti, U, I, cfg["adj_type"])
+    feats = {m: eo.OracleEliMRec.normalize_features(getattr(ds, m + "_feat")) for m in ("v", "a", "t")}
+    om = eo.OracleEliMRec(U, I, recdim, cfg["layer_num"], adj, feats, init, cfg["alpha"], dataset_name="synthetic")
+    ol = om.bpr_loss(u, p, n)
+    ol.backward()
+    assert abs(float(loss) - float(ol.detach())) < 1e-5
+    want = om.grads()
+    gE = eng.grad.dense().cpu()
+    assert rel_err(gE[:U], want["embedding_user.weight"]) < 1e-4
+    assert rel_err(gE[U:], want["embedding_item.weight"]) < 1e-4
+    for k, v in eng._grads.items():
+        assert rel_err(v.cpu(), want[k]) < 1e-4, k
+    return model, eng
+
+
+def test_small_shape_step_vs_oracle_through_the_slab_engine():
+    _shape_step_vs_oracle(700, 1900, 9000, (24, 8, 12), 64, 257)
+
+
+def test_c4_shape_step_vs_oracle():
+    """BASELINE.json configs[3] on one GPU: Tiktok shape x16 items (|I| = 1 217 360), recdim 128, B = 2048 -- one
+    step of the slab-major engine (the table every rank of an 8-GPU job holds a 16-column slice of) vs the oracle."""
+    _shape_step_vs_oracle(36656, 1217360, 16 * 720829, (128, 128, 128), 128, 2048)
