@@ -9,6 +9,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+import torch.nn.functional as F
 
 from helpers import ROOT, feats_of, load_golden, sub
 
@@ -135,6 +136,139 @@ class ShardedHeadOracleEngine(OracleEngine):
         return grads
 
 
+class ColumnShardOracleEngine(OracleEngine):
+    """CPU stand-in behind the cs_* interface of elimrec_amd/shard.py (ColumnShardTrainer): rank q owns columns
+    [q*dl, (q+1)*dl) of [E_u ; E_i], propagates only those, and exchanges the layer means / adjoint sources of the active
+    rows. The folded algebra (constant feature tables propagated once) is restated here with torch autograd."""
+    PAD = -(1 << 30)
+
+    def cs_setup(self, world, rank, optimizer):
+        m = self.m
+        self.world, self.rank, self.opt = world, rank, optimizer
+        self.dl = m.d // world
+        self.cols = slice(rank * self.dl, (rank + 1) * self.dl)
+        E = torch.cat([m.params["embedding_user.weight"], m.params["embedding_item.weight"]]).detach()
+        self.shard = E[:, self.cols].clone().requires_grad_(True)
+        self.m1, self.m2, self.t = torch.zeros_like(self.shard), torch.zeros_like(self.shard), 0
+        self.mods = ["v"] if m.kwai else ["v", "a", "t"]
+        N = m.U + m.I
+        with torch.no_grad():
+            def mean_prop(x0):
+                xs = [x0]
+                for _ in range(m.L):
+                    xs.append(torch.sparse.mm(m.adj, xs[-1]))
+                return torch.stack(xs).mean(0)
+            self.S = {k: mean_prop(torch.cat([torch.zeros(m.U, m.feats[k].shape[1]), m.feats[k]])) for k in self.mods}
+            self.c = mean_prop(torch.cat([torch.zeros(m.U, 1), torch.ones(m.I, 1)]))
+        self.tail = [k for k in m.params if not k.startswith(("embedding_user.", "embedding_item."))]
+
+    def _tables(self):
+        """out0 = mean_k A^k X0 and the shared part (users: even k, items: odd k) for my columns, with autograd."""
+        m = self.m
+        xs = [self.shard]
+        for _ in range(m.L):
+            xs.append(torch.sparse.mm(m.adj, xs[-1]))
+        inv = 1.0 / (m.L + 1)
+        out0 = sum(xs) * inv
+        nu = sum(x[:m.U] for k, x in enumerate(xs) if k % 2 == 0) * inv
+        ni = sum(x[m.U:] for k, x in enumerate(xs) if k % 2 == 1) * inv if m.L >= 1 else torch.zeros(m.I, self.dl)
+        return out0, torch.cat([nu, ni])
+
+    def cs_plan(self, users, pos, neg):
+        self.keys = self.batch_keys(users, pos, neg).long()
+        act = torch.unique(self.keys)
+        self.n_act = len(act)
+        R = len(self.keys)
+        self.act = torch.cat([act, torch.full((R - len(act),), self.PAD, dtype=torch.long)]).to(torch.int32)
+        return self.act
+
+    def cs_forward(self, acts):
+        W, R = acts.shape
+        self.out0, self.narrow = self._tables()
+        send = torch.zeros(W, R, 2 * self.dl)
+        for p in range(W):
+            ok = acts[p] >= 0
+            r = acts[p][ok].long()
+            send[p, :len(r), :self.dl] = self.out0.detach()[r]
+            send[p, :len(r), self.dl:] = self.narrow.detach()[r]
+        return send if W > 1 else None
+
+    def cs_head(self, recv):
+        m, d, n = self.m, self.m.d, self.n_act
+        act = self.act[:n].long()
+        if recv is None:
+            o, nr = self.out0.detach()[act], self.narrow.detach()[act]
+        else:
+            W = recv.shape[0]
+            o = torch.cat([recv[p, :n, :self.dl] for p in range(W)], dim=1)
+            nr = torch.cat([recv[p, :n, self.dl:] for p in range(W)], dim=1)
+        self.o_leaf, self.n_leaf = o.clone().requires_grad_(True), nr.clone().requires_grad_(True)
+        blocks = [self.o_leaf]
+        for k in self.mods:
+            blocks.append(F.linear(self.S[k][act], m.params[k + "_dense.weight"]) + self.c[act] * m.params[k + "_dense.bias"] + self.n_leaf)
+        out = torch.cat(blocks, dim=1)
+        fused_in = out if m.mm_fusion_mode == "concat" else out.view(n, -1, d).mean(1)
+        is_user = (act < m.U)[:, None]
+        y0 = torch.where(is_user, m._linear("embedding_user_after_GCN", fused_in), m._linear("embedding_item_after_GCN", fused_in))
+        heads = [m._linear("s_dense_%s" % k, out[:, (h + 1) * d:(h + 2) * d]) for h, k in enumerate(self.mods)]
+        Y = torch.cat([y0] + heads, dim=1)
+        slot = torch.searchsorted(act, self.keys)
+        r3 = Y[slot].view(-1, 3, Y.shape[1])
+        w = [1.0] + [m.alpha if k in m.modality else 0.0 for k in self.mods]
+        loss = 0
+        for b, wk in enumerate(w):
+            if wk:
+                blk = r3[:, :, b * d:(b + 1) * d]
+                loss = loss + wk * m.original_bpr_loss(blk[:, 0], blk[:, 1], blk[:, 2])
+        self.loss = loss
+        return loss.detach()
+
+    def cs_backward_local(self, scale):
+        m, d, n, W = self.m, self.m.d, self.n_act, self.world
+        m.zero_grad()
+        (self.loss * scale).backward()
+        G, H = self.o_leaf.grad, self.o_leaf.grad + self.n_leaf.grad
+        R = len(self.keys)
+        send = torch.zeros(W, R, 2 * self.dl)
+        for p in range(W):
+            cs = slice(p * self.dl, (p + 1) * self.dl)
+            send[p, :n, :self.dl], send[p, :n, self.dl:] = H[:, cs], G[:, cs]
+        self.tail_names = [k for k in self.tail if m.params[k].grad is not None]
+        self.wbuf = torch.cat([m.params[k].grad.reshape(-1) for k in self.tail_names])
+        return send, self.wbuf
+
+    def cs_backward_hops(self, recv2, acts):
+        W, R = acts.shape
+        N = self.m.U + self.m.I
+        d_out0, d_nar = torch.zeros(N, self.dl), torch.zeros(N, self.dl)
+        for p in range(W):                                   # rank order
+            ok = acts[p] >= 0
+            r = acts[p][ok].long()
+            Hp, Gp = recv2[p, :len(r), :self.dl], recv2[p, :len(r), self.dl:]
+            d_out0.index_add_(0, r, Gp)
+            d_nar.index_add_(0, r, Hp - Gp)
+        self.shard.grad = None
+        ((self.out0 * d_out0).sum() + (self.narrow * d_nar).sum()).backward()
+
+    @torch.no_grad()
+    def cs_update(self):
+        import math
+        m, o = self.m, self.opt.inner
+        self.t += 1
+        g = self.shard.grad.add(self.shard, alpha=o.wd)
+        self.m1.lerp_(g, 1 - o.b1)
+        self.m2.mul_(o.b2).addcmul_(g, g, value=1 - o.b2)
+        denom = (self.m2.sqrt() / math.sqrt(1 - o.b2 ** self.t)).add_(o.eps)
+        self.shard.addcdiv_(self.m1, denom, value=-o.lr / (1 - o.b1 ** self.t))
+        m.zero_grad()
+        off = 0
+        for k in self.tail_names:
+            nel = m.params[k].numel()
+            m.params[k].grad = self.wbuf[off:off + nel].view_as(m.params[k]).clone()
+            off += nel
+        self.opt.step()
+
+
 class OracleOpt(object):
     def __init__(self, engine, g):
         self.inner = engine.eo.OracleAdam(engine.m.params, lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
@@ -205,3 +339,59 @@ def test_single_rank_trainer_matches_reference_fixture():
         u, p, n = (torch.from_numpy(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg"))
         loss = trainer.step(u, p, n)
         assert abs(float(loss) - float(g["step%d/loss" % t])) < 1e-6
+
+
+def _cs_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from elimrec_amd.shard import ColumnShardTrainer
+    g = load_golden("ml3")
+    eng = ColumnShardOracleEngine(g)
+    trainer = ColumnShardTrainer(eng, OracleOpt(eng, g), world_size=world, rank=rank)
+    losses = []
+    for t in (1, 2):
+        u, p, n = (torch.from_numpy(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg"))
+        h = len(u) // world
+        sl = slice(rank * h, (rank + 1) * h)
+        losses.append(float(trainer.global_loss(trainer.step(u[sl], p[sl], n[sl]))))
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), losses=np.array(losses), shard=eng.shard.detach().numpy(),
+             xgmi=np.array([trainer.xgmi_bytes[k] for k in ("all_gather", "all_to_all_fwd", "all_to_all_bwd", "all_reduce")]),
+             **{k: eng.m.params[k].detach().numpy() for k in eng.tail})
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_column_shard_ranks_equal_single_process_big_batch(tmp_path, world):
+    """elimrec_amd/shard.py under gloo: `world` ranks, each owning recdim/world columns of [E_u ; E_i] and 1/world of
+    the triplets, equal ONE process on the whole batch (oracle): loss, every embedding column, every projection weight;
+    the projection weights are bitwise identical on all ranks; the bytes a rank sends per step are the closed form
+    DESIGN.md quotes."""
+    port = 31500 + (os.getpid() % 2000) + world
+    mp.spawn(_cs_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rs = [dict(np.load(tmp_path / ("rank%d.npz" % r))) for r in range(world)]
+    g = load_golden("ml3")
+    eng = OracleEngine(g)
+    from oracle import elimrec_oracle as eo
+    opt = eo.OracleAdam(eng.m.params, lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    losses = []
+    for t in (1, 2):
+        u, p, n = (g["step%d/%s" % (t, k)] for k in ("users", "pos", "neg"))
+        mlen = (len(u) // world) * world
+        losses.append(eo.train_step(eng.m, opt, u[:mlen], p[:mlen], n[:mlen]))
+    assert np.allclose(rs[0]["losses"], losses, atol=1e-6)
+    E = torch.cat([eng.m.params["embedding_user.weight"], eng.m.params["embedding_item.weight"]]).detach().numpy()
+    assert np.abs(np.concatenate([r["shard"] for r in rs], axis=1) - E).max() < 2e-5
+    for k in rs[0]:
+        if k in ("losses", "shard", "xgmi"):
+            continue
+        assert np.abs(rs[0][k] - eng.m.params[k].detach().numpy()).max() < 2e-5, k
+        for r in rs[1:]:
+            assert np.array_equal(r[k], rs[0][k]), k
+    R, d = 3 * (len(g["step1/users"]) // world), int(g["recdim"])
+    dl = d // world
+    n_tail = sum(rs[0][k].size for k in rs[0] if k not in ("losses", "shard", "xgmi"))
+    assert list(rs[0]["xgmi"]) == [4 * R * (world - 1), 4 * R * 2 * dl * (world - 1), 4 * R * 2 * dl * (world - 1), 4 * n_tail]
