@@ -1,16 +1,17 @@
 #!/usr/bin/env python3
 """BPR triplets/s of the EliMRec training step on MI355X (BASELINE.json metric).
 
-A step = one pass of the hot path over one batch of B triplets already resident in HBM:
-forward (table assembly + feature projections + L-hop propagation + head Linears + cosine-BPR),
-backward (deterministic scatter-add, head/propagation/projection gradients) and the dense Adam
-update -- the tables are re-propagated every step, as the reference does (main.py:98-101).
+A step = one pass of the hot path over one batch of B triplets already resident in HBM: forward (L-hop propagation
+of the folded table + layer means + feature/fusion/head projections at the batch's rows + cosine-BPR), backward
+(deterministic scatter-add, head / projection gradients, adjoint propagation) and the dense Adam update -- the tables
+are re-propagated every step, as the reference does (main.py:98-101).
 
-Workload at N=1: BASELINE.json configs[1], synthetic Tiktok shape (|U|=36 656, |I|=76 085,
-720 829 interactions, 128-d V/A/T features, recdim 64, 3 layers, B=2048), fp32.
-N>1: one process per GPU (torch.distributed / RCCL), data-parallel over triplets with replicated
-tables -- each rank takes its own B triplets, the row-sparse head gradients are all-gathered, and
-every rank applies the identical update (elimrec_amd/dist.py). Weak scaling: per-GPU batch fixed.
+Workload at N=1: BASELINE.json configs[1], synthetic Tiktok shape (|U|=36 656, |I|=76 085, 720 829 interactions,
+128-d V/A/T features, recdim 64, 3 layers, B=2048), fp32.
+N>1: one process per GPU (torch.distributed / RCCL), column-sharded (elimrec_amd/shard.py): rank q owns recdim/N
+columns of [E_u ; E_i], of its gradient and Adam moments and runs every hop on its slice without communication; only
+the layer means / adjoint sources of the batch's active rows cross xGMI (two all-to-alls + one all-gather of ids + the
+projection-weight all-reduce per step). Weak scaling: B triplets per GPU.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
@@ -28,62 +29,64 @@ sys.path.insert(0, ROOT)
 WORKLOAD = dict(name="tiktok-shape-synthetic", num_users=36656, num_items=76085, num_interactions=720829,
                 feat_dims=(128, 128, 128), recdim=64, layer_num=3, batch_size=2048, alpha=0.5)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
+MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector peak
 
 
-def algorithmic_bytes(model, B):
-    """SURVEY.md §8(d) closed form (fp32: s = s_f = 4)."""
+def reference_step_bytes(model, B):
+    """SURVEY.md 8(d) closed form: bytes the REFERENCE algorithm moves per step (fp32: s = s_f = 4)."""
     s = 4
     U, I, d, M, L = model.num_users, model.num_items, model.latent_dim, model.M, model.n_layers
     N = U + I
     nnz = int(model.adj_val.numel())
-    T = N * M * d * s
-    G = N * d * s
+    T, G = N * M * d * s, N * d * s
     Ccsr = 8 * nnz + 4 * (N + 1)
     F = I * sum(getattr(model, m + "_feat").shape[1] for m in model._mods) * s
     P = sum(p.numel() for p in model.parameters())
-    step = 2 * F + 2 * (M - 1) * I * d * s + 2 * (L * (2 * T + Ccsr) + (L + 2) * T) + 2 * (T + G) + 4 * (M - 1) * G \
+    return 2 * F + 2 * (M - 1) * I * d * s + 2 * (L * (2 * T + Ccsr) + (L + 2) * T) + 2 * (T + G) + 4 * (M - 1) * G \
         + 9 * B * M * d * s + 28 * P
-    # one propagation hop as the kernels run it: all M tables side by side (bipartite / full paths), or -- with
-    # the constant feature tables folded into GEMM operands (DESIGN.md §2) -- only the id table: d columns
-    Th = G if getattr(model, "_folded", False) else T
-    hop = (L * (2 * Th + Ccsr) + (L + 2) * Th) / max(L, 1)    # layer-mean traffic included
-    return step, hop
 
 
-def pmc_traffic_per_hop():
-    """HBM bytes per propagation hop from the committed PMC passes (profiles/r01_h_pmc_traffic.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc runs of this same command,
-    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950). None if the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f)["propagation_hop_traffic_bytes"]
-    except Exception:
-        return None
+def step_bytes(model, eng, B, world):
+    """Bytes THIS step has to move per rank: the hops read a table, the index stream once per
+    slab group and write a table; the adjoint's first hop reads only the index stream and writes a table; Adam moves
+    28 B per owned parameter; everything else touches the <= 3B active rows only."""
+    s = 4
+    U, I, d, M, L = model.num_users, model.num_items, model.latent_dim, model.M, model.n_layers
+    N, dl = U + I, eng.dl
+    G = N * dl * s
+    idx = eng.plan.index_bytes()
+    R = 3 * B
+    hop = 2 * G + eng.gs * idx                       # one full hop
+    fwd = (L - 1) * hop + G + eng.gs * 8 * eng.plan.sell_seg_entries      # hop L: the split rows + the active rows only
+    bwd = (G + eng.gs * idx) + (L - 1) * hop         # first adjoint hop: row-sparse source
+    P_tail = sum(p.numel() for n_, p in model.named_parameters() if not n_.startswith(("embedding_user.", "embedding_item.")))
+    adam = 28 * (N * dl + P_tail)
+    D = sum(getattr(model, m + "_feat").shape[1] for m in model._mods)
+    rows = R * s * ((L + 1) * dl + 2 * D + 6 * model.C + 6 * model.Cy + 4 * d)     # layer rows, folded constants, Out/Y rows fwd+bwd, sources
+    return dict(total=fwd + bwd + adam + rows, hop=hop, hop_minimal=2 * G + idx)
 
 
-def build(args, device):
+def build(args, device, extra_argv=()):
     import torch
-    from elimrec_amd import Configurator, EliMRec, FusedAdam, SyntheticDataset, set_seed
+    from elimrec_amd import Configurator, EliMRec, Logger, SyntheticDataset, set_seed
     w = WORKLOAD
     cfg = Configurator(os.path.join(ROOT, "NeuRec.properties"), default_section="hyperparameters",
                        argv=["bench.py", "--data.input.dataset=synthetic", "--alpha=%r" % w["alpha"], "--loss=bpr_loss",
                              "--recdim=%d" % w["recdim"], "--layer_num=%d" % w["layer_num"],
-                             "--batch_size=%d" % w["batch_size"], "--verbose=0"])
+                             "--batch_size=%d" % w["batch_size"], "--verbose=0"] + list(extra_argv))
     os.chdir(ROOT)
     set_seed(cfg["seed"])
     ds = SyntheticDataset(w["num_users"], w["num_items"], w["num_interactions"], feat_dims=w["feat_dims"], seed=0)
-    from elimrec_amd import Logger
     Logger.logger = Logger(show_in_console=False)
     model = EliMRec(cfg, ds)
     return cfg, ds, model
 
 
-def cpu_baseline(ds, model_cpu_state, cfg, batches, thread_counts=(8, 16, 32)):
-    """The oracle (CPU restatement of the reference step, pinned to the reference by
-    tests/test_oracle_golden.py) timed on this box's host cores on a bounded sample: one warm-up
-    step, then one full training step per candidate thread count; the fastest is reported
-    (torch.sparse.mm, 84 % of the reference's step, stops scaling long before 256 threads)."""
+def cpu_baseline(ds, model_cpu_state, cfg, batches, thread_counts=(8, 16, 32), timed_steps=5):
+    """The oracle (CPU restatement of the reference step, pinned to the reference by tests/test_oracle_golden.py and
+    calibrated against the reference's own step time in BASELINE.md) on this box's host cores: one warm-up step, one
+    probe step per candidate thread count, then `timed_steps` steps at the fastest count (torch.sparse.mm, 84 % of the
+    reference's step, stops scaling long before 256 threads)."""
     import torch
     from oracle import elimrec_oracle as eo
     ncpu = os.cpu_count() or 1
@@ -97,19 +100,24 @@ def cpu_baseline(ds, model_cpu_state, cfg, batches, thread_counts=(8, 16, 32)):
     counts = sorted(set(min(c, ncpu) for c in thread_counts))
     torch.set_num_threads(counts[0])
     eo.train_step(om, opt, *batches[0])            # warm-up (allocations, thread pool)
-    best = None
-    timings = {}
+    probe = {}
     for k, c in enumerate(counts):
         torch.set_num_threads(c)
         t0 = time.time()
-        eo.train_step(om, opt, *batches[1 + k % (len(batches) - 1)])
-        dt = time.time() - t0
-        timings[c] = round(dt, 3)
-        if best is None or dt < best[1]:
-            best = (c, dt)
-    return dict(value=B / best[1], unit="triplets/s", cores=best[0], kind="port", host_cpus=ncpu,
-                sample="1 warm-up + 1 full training step (B=%d, same workload) per thread count %s; seconds per step: %s"
-                       % (B, counts, timings), ms_per_step=1e3 * best[1])
+        eo.train_step(om, opt, *batches[(1 + k) % len(batches)])
+        probe[c] = round(time.time() - t0, 3)
+    best = min(probe, key=probe.get)
+    torch.set_num_threads(best)
+    ts = []
+    for k in range(timed_steps):
+        t0 = time.time()
+        eo.train_step(om, opt, *batches[k % len(batches)])
+        ts.append(time.time() - t0)
+    mean = sum(ts) / len(ts)
+    return dict(value=B / mean, unit="triplets/s", cores=best, kind="port", host_cpus=ncpu,
+                sample="1 warm-up + 1 probe step per thread count %s (s/step %s), then %d timed full training steps (B=%d, same "
+                       "workload) at %d threads: %s s" % (counts, probe, timed_steps, B, best, [round(t, 3) for t in ts]),
+                ms_per_step=1e3 * mean)
 
 
 def main():
@@ -119,6 +127,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-eval", action="store_true", help="skip the secondary evaluator timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-work", action="store_true", help="skip the reference-equivalent-work line")
     args = ap.parse_args()
 
     import torch
@@ -133,19 +142,18 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    force_coll = os.environ.get("ELIMREC_FORCE_COLLECTIVES", "0") == "1" and "RANK" in os.environ
-    if world > 1 or force_coll:
+    if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     cfg, ds, model = build(args, device)
     init_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model = model.to(device)
-    from elimrec_amd import FusedAdam, PairwiseSamplerV2
-    from elimrec_amd.dist import DataParallelTrainer
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam, PairwiseSamplerV2, slab
     B = WORKLOAD["batch_size"]
     opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
-    trainer = DataParallelTrainer(model, opt, world_size=world, rank=rank, force_collectives=force_coll)
+    eng = ColumnShardEngine(model)
+    trainer = ColumnShardTrainer(eng, opt, world_size=world, rank=rank)
 
     # triplets for every step, sampled on the device and resident in HBM before the timed region
     total = args.warmup + args.steps
@@ -157,14 +165,13 @@ def main():
     batches = [(U_[i * B:(i + 1) * B], P_[i * B:(i + 1) * B], N_[i * B:(i + 1) * B]) for i in range(total)]
 
     def sync():
-        if world > 1 or force_coll:
+        if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
         trainer.step(*batches[i])
     sync()
-    trainer.profile_kernels = True            # HIP events around the dominant kernel, on the launch stream
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         loss = trainer.step(*batches[i])
@@ -174,62 +181,128 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
-    hop_ms, hop_launches = trainer.kernel_time_ms("propagation_hop")
     final_loss = float(loss.item())
 
+    # roofline sample of the dominant kernel, in its own loop (not in the headline's): ONE full propagation hop of this
+    # rank's column slice = one elimrec_slab_hop call (sell_hop_kernel + the split rows' sell_fixup_kernel), bracketed by
+    # HIP events on the launch stream, alternating between two tables as the forward does
+    tabs = [eng.master[eng.cur], eng.tmp[0], eng.tmp[1]]       # the adjoint's scratch tables are free between steps
+    n_launch = 40
+
+    def hop_chain(n):
+        src, dst = tabs[0], tabs[1]
+        for _ in range(n):
+            slab.hop(eng.plan, src, dst, gs=eng.gs)
+            src, dst = dst, (tabs[2] if dst is tabs[1] else tabs[1])
+    hop_chain(4)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    hop_chain(n_launch)
+    e1.record()
+    torch.cuda.synchronize()
+    hop_us = e0.elapsed_time(e1) * 1e3 / n_launch
+
     if rank == 0:
-        step_bytes, hop_bytes = algorithmic_bytes(model, B)
-        achieved = hop_bytes / (hop_ms * 1e-3 / hop_launches) / 1e9 if hop_launches else None
+        sb = step_bytes(model, eng, B, world)
+        achieved = sb["hop_minimal"] / (hop_us * 1e-6) / 1e9
+        ms = 1e3 * dt / args.steps
         out = {
             "metric": "BPR triplets/sec (Tiktok-shape, d=128x3)", "value": B * world * args.steps / dt,
             "unit": "triplets/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": WORKLOAD["name"], "num_users": ds.num_users, "num_items": ds.num_items,
                        "train_interactions": int(ds.train_matrix.nnz), "feat_dims": list(WORKLOAD["feat_dims"]),
                        "recdim": WORKLOAD["recdim"], "layer_num": WORKLOAD["layer_num"], "batch_per_gpu": B,
-                       "global_batch": B * world, "parallelism": "dp%d-replicated-tables" % world,
-                       "propagation": "folded" if getattr(model, "_folded", False) else
-                                      ("bipartite" if getattr(model, "_bipartite", False) else "full"),
-                       "head_rows": "batch" if getattr(model, "_lazy", False) else "all",
-                       "final_loss": final_loss},
-            "step_algorithmic_GB": step_bytes / 1e9,
-            "step_achieved_GBps": step_bytes / (dt / args.steps) / 1e9,
+                       "global_batch": B * world, "parallelism": "colshard%d" % world,
+                       "columns_per_gpu": eng.dl, "slabs": [eng.ns, eng.w, eng.gs],
+                       "propagation": "folded", "head_rows": "batch", "final_loss": final_loss},
+            # bytes THIS implementation's step has to move per rank (closed form) and the fraction of
+            # the HBM peak the whole step reaches on them; the reference algorithm's bytes are quoted beside it
+            "step_model": {"bytes_per_rank_step": sb["total"], "GBps": sb["total"] / (ms * 1e-3) / 1e9,
+                           "frac_of_hbm_peak": sb["total"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "reference_algorithm_bytes_per_step": reference_step_bytes(model, B)},
             "roofline": {"bound": "hbm",
-                         "kernel": ("propagation hop of the d-column table [E_u;E_i] = ONE half_hop_kernel<16> launch over the "
-                                    "full adjacency; 2L hops per step; feature tables folded into GEMM operands"
-                                    if getattr(model, "_folded", False) else
-                                    "propagation hop = half_hop_kernel<64> (C columns) + half_hop_kernel<16> (d columns); "
-                                    "2L hops per step"),
-                         "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": pmc_traffic_per_hop(),
-                         "algorithmic_bytes_per_launch": hop_bytes,
-                         "avg_launch_us": 1e3 * hop_ms / hop_launches if hop_launches else None,
-                         "launches_timed": hop_launches},
+                         "kernel": "sell_hop_kernel (+ sell_fixup_kernel for the split rows): one full LightGCN hop X' = A X of "
+                                   "this rank's [N x %d] column slice, slab-major %dx%d floats in %d groups" % (eng.dl, eng.ns, eng.w, eng.gs),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(),
+                         "algorithmic_bytes_per_launch": sb["hop_minimal"],
+                         "algorithmic_bytes_formula": "read X + write X' + index stream once: 2*N*dl*4 + (8 B per SELL entry + 8 B per work item)",
+                         "bytes_with_index_per_group": sb["hop"],
+                         "avg_launch_us": hop_us, "launches_timed": n_launch},
         }
+        if world > 1:
+            out["xgmi_bytes_sent_per_rank_step"] = trainer.xgmi_bytes
         if world == 1 and not args.no_eval:
-            # secondary metric of SURVEY 8(d): full-catalogue TIE top-K validation pass on the device evaluator
-            # (after the timed region; the first pass also materialises the full cached tables and the user blocks)
-            model.predict_type = "TIE"
-            secs = []
-            for _ in range(2):
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                model.evaluate()
-                torch.cuda.synchronize()
-                secs.append(time.perf_counter() - t1)
-            n_eval = len(model.valid_evaluator.evaluator.user_pos_test)
-            topks = cfg["topks"]
-            out["eval"] = {"what": "full-catalogue TIE top-%d validation pass" % (max(topks) if isinstance(topks, (list, tuple)) else int(topks)),
-                           "users": n_eval, "seconds_first": secs[0], "seconds": secs[1], "users_per_s": n_eval / secs[1]}
+            out["eval"] = eval_pass(model, cfg, torch)
+        if world == 1 and not args.no_reference_work:
+            out["reference_equivalent_work"] = reference_work_line(args, device, cfg, batches, torch)
         if not args.no_cpu_baseline and world == 1:     # the host baseline is timed on rank 0 at N=1 only
             cpu_batches = [tuple(x.cpu() for x in b) for b in batches[:5]]
             out["cpu_baseline"] = cpu_baseline(ds, {k: v.cpu().numpy() for k, v in init_state.items()}, cfg, cpu_batches)
         print(json.dumps(out))
-    if world > 1 or force_coll:
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic():
+    """HBM bytes per full hop from the committed PMC passes (profiles/r02_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE
+    collected in separate rocprofv3 --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950). None if
+    the file is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            return json.load(f)["propagation_hop_traffic_bytes"]
+    except Exception:
+        return None
+
+
+def eval_pass(model, cfg, torch):
+    """Secondary metric of SURVEY 8(d): full-catalogue TIE top-K validation pass on the device evaluator (after the timed
+    region; the first pass also materialises the cached tables). flops = 2*d per (user, item) for the row means of pass 1
+    + 2*d*(1+S) for the (1+S) dot products of pass 2."""
+    model.predict_type = "TIE"
+    secs = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        model.evaluate()
+        torch.cuda.synchronize()
+        secs.append(time.perf_counter() - t1)
+    n_eval = len(model.valid_evaluator.evaluator.user_pos_test)
+    topks = cfg["topks"]
+    flops = float(n_eval) * model.num_items * 2 * model.latent_dim * (2 + model.S)
+    best = min(secs[1:])
+    return {"what": "full-catalogue TIE top-%d validation pass" % (max(topks) if isinstance(topks, (list, tuple)) else int(topks)),
+            "users": n_eval, "seconds_first": secs[0], "seconds": best, "users_per_s": n_eval / best,
+            "roofline": {"bound": "mfma", "achieved": flops / best / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": flops / best / 1e12 / MFMA_F32_PEAK_TF, "flops": flops}}
+
+
+def reference_work_line(args, device, cfg, batches, torch, steps=20):
+    """The same step with the work the reference's algorithm does: all M tables through the graph (bipartite form) and
+    every projection over all N rows every step (--propagation=bipartite --head_rows=all), row-major trainer."""
+    from elimrec_amd import FusedAdam
+    from elimrec_amd.dist import DataParallelTrainer
+    _, _, model = build(args, device, extra_argv=["--propagation=bipartite", "--head_rows=all"])
+    model = model.to(device)
+    opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+    tr = DataParallelTrainer(model, opt)
+    for i in range(3):
+        tr.step(*batches[i])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        tr.step(*batches[(3 + i) % len(batches)])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    B = batches[0][0].numel()
+    rb = reference_step_bytes(model, B)
+    return {"what": "--propagation=bipartite --head_rows=all: M tables through the graph, projections over all rows",
+            "ms_per_step": 1e3 * dt, "value": B / dt, "unit": "triplets/s", "steps": steps,
+            "reference_algorithm_bytes_per_step": rb, "GBps": rb / dt / 1e9, "frac_of_hbm_peak": rb / dt / 1e9 / HBM_PEAK_GBS}
 
 
 if __name__ == "__main__":

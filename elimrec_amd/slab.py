@@ -120,6 +120,7 @@ class SellPlan(object):
         self.n_rows, self.n_src, self.nnz = int(n_rows), int(n_src), int(m.nnz)
         self.n_items, self.n_seg_items, self.n_seg, self.n_long = int(n_items), int(n_seg_items), n_seg, int(len(long_rows))
         self.sell_entries = total
+        self.sell_seg_entries = int(blk_off[n_seg_items // 64]) * 64
         self.threshold = T
         self.t = dict(item_dst=t(item_dst, np.int32), item_len=t(item_len, np.int32), blk_off=t(blk_off, np.int32),
                       col=t(sell_col, np.int32), val=t(sell_val, np.float32),
