@@ -6,6 +6,7 @@ from .dataset import Dataset, SyntheticDataset, csr_to_user_dict
 from .logger import Logger, Meter
 from .basic_model import BasicModel
 from .model import EliMRec
+from .mlp import MLP
 from .optim import FusedAdam
 from .sampler import PairwiseSamplerV2
 from .shard import ColumnShardEngine, ColumnShardTrainer

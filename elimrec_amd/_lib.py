@@ -33,7 +33,8 @@ class LinearDesc(ctypes.Structure):
     _fields_ = [("d_A", ctypes.c_void_p), ("lda", ctypes.c_int64), ("d_W", ctypes.c_void_p), ("ldw", ctypes.c_int64),
                 ("d_bias", ctypes.c_void_p), ("d_C", ctypes.c_void_p), ("ldc", ctypes.c_int64), ("M", ctypes.c_int64),
                 ("N", ctypes.c_int32), ("K", ctypes.c_int32), ("d_rowscale", ctypes.c_void_p), ("d_add", ctypes.c_void_p),
-                ("ldadd", ctypes.c_int64), ("d_row_index", ctypes.c_void_p), ("d_row_range", ctypes.c_void_p)]
+                ("ldadd", ctypes.c_int64), ("d_row_index", ctypes.c_void_p), ("d_row_range", ctypes.c_void_p),
+                ("act", ctypes.c_int32)]
 
 
 class LinearBwdDesc(ctypes.Structure):

@@ -2,6 +2,8 @@
 valid/test evaluators from the config, names checkpoints, exposes evaluate()/test()."""
 import os
 
+import torch
+import torch.nn.functional as F
 from torch import nn
 
 from .evaluator import ProxyEvaluator
@@ -17,6 +19,7 @@ class BasicModel(nn.Module):
                       batch_size=config["test_batch_size"], num_thread=config["num_thread"])
         self.valid_evaluator = ProxyEvaluator(dataset, train, dataset.get_user_valid_dict(), None, **common)
         self.test_evaluator = ProxyEvaluator(dataset, train, dataset.get_user_test_dict(), None, **common)
+        self.infonce_criterion = nn.CrossEntropyLoss()          # BasicModel.py:32
 
     def getFileName(self):
         """`{path}/{recommender}-{dataset}-{loss}-{suffix}.pth.tar` (BasicModel.py:34-40)."""
@@ -41,12 +44,34 @@ class BasicModel(nn.Module):
     def test(self):
         return self.test_evaluator.evaluate(self)
 
+    # ---- generic losses on top of getEmbedding (BasicModel.py:59-113). EliMRec overrides bpr_loss; these are the
+    # reference's base-class versions, differentiable through EliMRec.compute()'s autograd bridge.
     def bpr_loss(self, users, pos, neg):
-        raise NotImplementedError
+        """BasicModel.py:59-79: softplus(neg - pos) on un-normalised embedding rows."""
+        users_emb, pos_emb, neg_emb, _, _, _ = self.getEmbedding(users.long(), pos.long(), neg.long())
+        pos_scores = torch.sum(torch.mul(users_emb, pos_emb), dim=1)
+        neg_scores = torch.sum(torch.mul(users_emb, neg_emb), dim=1)
+        return torch.mean(F.softplus(neg_scores - pos_scores))
 
-    def infonce(self, users, pos):
-        raise NotImplementedError("infonce (BasicModel.py:81-95) is not on the EliMRec hot path: the reference "
-                                  "driver is run with --loss=bpr_loss; see DESIGN.md, out of scope")
+    def infonce(self, users, pos, neg=None):
+        """BasicModel.py:81-95 (in-batch negatives; `neg` accepted and ignored so the driver's three-argument call works)."""
+        users_emb, pos_emb, _, _, _, _ = self.getEmbedding(users.long(), pos.long(), None)
+        users_emb = F.normalize(users_emb, dim=1)
+        pos_emb = F.normalize(pos_emb, dim=1)
+        logits = torch.mm(users_emb, pos_emb.T) / self.temp
+        labels = torch.arange(users.shape[0], device=logits.device)
+        return self.infonce_criterion(logits, labels)
 
-    def fast_loss(self, users, pos):
-        raise NotImplementedError("fast_loss (BasicModel.py:97-113) is not on the EliMRec hot path; see DESIGN.md")
+    def fast_loss(self, users, pos, neg=None):
+        """BasicModel.py:97-113."""
+        users_emb, pos_emb, _, _, _, _ = self.getEmbedding(users.long(), pos.long(), None)
+        alpha = self.config["alpha"]
+        users_emb = F.normalize(users_emb, dim=1)
+        pos_emb = F.normalize(pos_emb, dim=1)
+        all_users, all_items = self._last_tables          # the tables of THIS forward, with their autograd graph
+        all_users = F.normalize(all_users, dim=1)
+        all_items = F.normalize(all_items, dim=1)
+        pos_scores = torch.sum(torch.mul(users_emb, pos_emb), dim=1)
+        pos_loss = torch.sum((alpha - 1) * torch.pow(pos_scores, 2) - 2 * alpha * pos_scores)
+        all_loss = torch.trace(torch.matmul(torch.matmul(all_users.T, all_users), torch.matmul(all_items.T, all_items)))
+        return pos_loss + all_loss

@@ -44,6 +44,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(FwdBatch batch) {
     const int64_t row_lo = pd.d_row_range ? (int64_t)max(pd.d_row_range[0], 0) : 0;
     const int64_t M = pd.d_row_range ? (int64_t)min((int64_t)pd.d_row_range[1], pd.M) : pd.M;
     const int N = pd.N, K = pd.K;
+    const bool relu = pd.act == 1;
     const int n0 = blockIdx.y * FBN;
     const int64_t n_tiles = M > row_lo ? (M - row_lo + BM - 1) / BM : 0;
     if ((int64_t)blockIdx.x >= n_tiles || n0 >= N) return;
@@ -144,9 +145,14 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(FwdBatch batch) {
                     if (row < M) {
                         const int64_t sr = row_index ? (int64_t)row_index[row] : row;
                         const float rs = rowscale ? rowscale[sr] : 1.f;      // bias enters as rowscale[row] * bias[n]
-                        if (col0 < N) C[row * ldc + col0] = acc0[r] + rs * bias0 + (addm ? addm[sr * ldadd + col0] : 0.f);
-                        if (BM == 128 && col1 < N)
-                            C[row * ldc + col1] = acc1[r] + rs * bias1 + (addm ? addm[sr * ldadd + col1] : 0.f);
+                        if (col0 < N) {
+                            const float v = acc0[r] + rs * bias0 + (addm ? addm[sr * ldadd + col0] : 0.f);
+                            C[row * ldc + col0] = relu ? fmaxf(v, 0.f) : v;
+                        }
+                        if (BM == 128 && col1 < N) {
+                            const float v = acc1[r] + rs * bias1 + (addm ? addm[sr * ldadd + col1] : 0.f);
+                            C[row * ldc + col1] = relu ? fmaxf(v, 0.f) : v;
+                        }
                     }
                 }
                 acc0 = (v16f){0};
@@ -344,6 +350,7 @@ extern "C" int elimrec_linear_fwd_batched(const elimrec_linear_desc *descs, int 
         ELIMREC_REQUIRE(d.d_A && d.d_W && d.d_C, "linear_fwd: null pointer");
         ELIMREC_REQUIRE(d.M >= 0 && d.N > 0 && d.K > 0, "linear_fwd: bad shape M=%lld N=%d K=%d", (long long)d.M, d.N, d.K);
         ELIMREC_REQUIRE(d.K % 4 == 0 && d.lda % 4 == 0 && d.ldw % 4 == 0, "linear_fwd: K, lda, ldw must be multiples of 4");
+        ELIMREC_REQUIRE(d.act == 0 || d.act == 1, "linear_fwd: unknown activation %d", d.act);
         ELIMREC_REQUIRE(((uintptr_t)d.d_A % 16) == 0 && ((uintptr_t)d.d_W % 16) == 0, "linear_fwd: A and W must be 16-byte aligned");
         batch.p[i] = d;
         if (d.M > max_tiles_m) max_tiles_m = d.M;       // rows; converted to tiles below
@@ -390,7 +397,7 @@ extern "C" int elimrec_linear_fwd_batched(const elimrec_linear_desc *descs, int 
 extern "C" int elimrec_linear_fwd(const float *d_A, int64_t lda, const float *d_W, int64_t ldw,
                                   const float *d_bias, float *d_C, int64_t ldc, int64_t M, int N, int K,
                                   void *stream) {
-    elimrec_linear_desc d = {d_A, lda, d_W, ldw, d_bias, d_C, ldc, M, N, K, nullptr, nullptr, 0, nullptr, nullptr};
+    elimrec_linear_desc d = {d_A, lda, d_W, ldw, d_bias, d_C, ldc, M, N, K, nullptr, nullptr, 0, nullptr, nullptr, 0};
     return elimrec_linear_fwd_batched(&d, 1, stream);
 }
 

@@ -103,6 +103,37 @@ class _BprLossFn(torch.autograd.Function):
         return (None,) * (4 + len(ctx.params))
 
 
+class _TablesFn(torch.autograd.Function):
+    """compute() (models/EliMRec.py:228-272) as a differentiable op for losses written against the tables themselves
+    (BasicModel.bpr_loss / infonce / fast_loss on top of getEmbedding, models/BasicModel.py:59-113): forward runs the
+    HIP table build and returns copies of all_users / all_items; backward takes DENSE table gradients, treats every node
+    as an active row of the fused head block and runs the same HIP backward as the training step. Parameter gradients
+    land in `.grad` (the flat gradient views) as with _BprLossFn."""
+
+    @staticmethod
+    def forward(ctx, model, *params):
+        ctx.model, ctx.params, ctx.names = model, params, model._param_names
+        ws = model._workspace(model._ws_key[1] if model._ws_key else 1)
+        model._slab_fwd = False
+        model._compute_tables(ws)
+        U, d = model.num_users, model.latent_dim
+        return ws["Y"][:U, :d].clone(), ws["Y"][U:, :d].clone()
+
+    @staticmethod
+    def backward(ctx, g_users, g_items):
+        model = ctx.model
+        grads = model._backward_tables(g_users, g_items)
+        for name, p in zip(ctx.names, ctx.params):
+            g = grads.get(name)
+            if g is None or not p.requires_grad:
+                continue
+            if p.grad is None:
+                p.grad = g
+            elif p.grad.data_ptr() != g.data_ptr():
+                p.grad.add_(g)
+        return (None,) * (1 + len(ctx.params))
+
+
 class EliMRec(BasicModel):
     def __init__(self, config, dataset):
         super(EliMRec, self).__init__(dataset, config)
@@ -901,23 +932,58 @@ class EliMRec(BasicModel):
         self._require_gpu()
         if self.is_kwai:
             self.modality = "v"                        # :133-134
+        return _BprLossFn.apply(self, users, pos_items, neg_items, *self._all_params())
+
+    def _all_params(self):
         params = self.__dict__.get("_param_list")
         if params is None:      # the Parameter objects are fixed after construction (they are re-pointed, never replaced)
             params = self.__dict__["_param_list"] = [p for _, p in self.named_parameters()]
-        return _BprLossFn.apply(self, users, pos_items, neg_items, *params)
+        return params
 
     def compute(self):
-        """:228-272. Returns (all_users [U x d], all_items [I x d]) -- views into Y, no autograd."""
+        """:228-272. Returns (all_users [U x d], all_items [I x d]). Under torch.no_grad(): views into Y. With autograd
+        enabled: differentiable copies (_TablesFn) -- what getEmbedding / the generic BasicModel losses build on."""
+        self._require_gpu()
+        if torch.is_grad_enabled():
+            self._last_tables = _TablesFn.apply(self, *self._all_params())
+            return self._last_tables
+        self._slab_fwd = False
         ws = self._workspace(self._ws_key[1] if self._ws_key else 1)
         self._compute_tables(ws)
-        return self.all_users, self.all_items
+        self._last_tables = (self.all_users, self.all_items)
+        return self._last_tables
+
+    @torch.no_grad()
+    def _backward_tables(self, g_users, g_items):
+        """HIP backward from dense gradients of all_users / all_items: every node is an active row whose head-gradient
+        row holds its table gradient in the fused block and zeros in the single-modal blocks."""
+        U, I, d, Cy = self.num_users, self.num_items, self.latent_dim, self.Cy
+        N = U + I
+        dev = self._device()
+        ws = self._workspace(self._ws_key[1] if self._ws_key else 1, N)
+        rows = torch.zeros(N, Cy, dtype=torch.float32, device=dev)
+        if g_users is not None:
+            rows[:U, :d] = g_users
+        if g_items is not None:
+            rows[U:, :d] = g_items
+        keys = torch.arange(N, dtype=torch.int32, device=dev)
+        ops.segment_plan(keys, U, N, ws["active_rows"][:N], ws["seg_info"], ws["slot_seg"][:N], ws["plan_ws"])
+        self._plan_n = N
+        self._last_block_weights = [1.0] + [0.0] * self.S
+        lazy, self._lazy = self._lazy, False          # the tables were built over all rows: the full-row backward
+        try:
+            return self._backward_hip(torch.ones(1, dtype=torch.float32, device=dev), grad_rows=rows)
+        finally:
+            self._lazy = lazy
 
     def gcn_cf(self, detach=False):
         """:144-153. The single-modal head tables computed by the last compute()."""
         return self.all_s_embs
 
     def getEmbedding(self, users, pos_items, neg_items):
-        """:274-289 (forward values only; training goes through bpr_loss)."""
+        """:274-289: rows of the fused tables for users / positives / negatives + the raw ("ego") embedding rows. The
+        table rows carry autograd (through compute()); the ego rows are returned detached -- no loss of the reference
+        reads them (BasicModel.py:59-113 only unpacks them)."""
         all_users, all_items = self.compute()
         ego_u, ego_i = self.embedding_user.weight.detach(), self.embedding_item.weight.detach()
         neg = (all_items[neg_items], ego_i[neg_items]) if neg_items is not None else (None, None)

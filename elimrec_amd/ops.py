@@ -39,8 +39,8 @@ def _rowmajor(t, name):
     return _dev(t, name), t.stride(0)
 
 
-def linear_fwd(A, W, bias, out):
-    """out[m, n] = sum_k A[m,k] W[n,k] + bias[n]; A/out may be column slices of wider tables."""
+def linear_fwd(A, W, bias, out, act=None):
+    """out[m, n] = act(sum_k A[m,k] W[n,k] + bias[n]); A/out may be column slices of wider tables. act: None | 'relu'."""
     lib = _lib.load()
     a, lda = _rowmajor(A, "A")
     w, ldw = _rowmajor(W, "W")
@@ -48,7 +48,13 @@ def linear_fwd(A, W, bias, out):
     M, K = A.shape
     N = W.shape[0]
     assert W.shape[1] == K and out.shape[0] == M and out.shape[1] == N
-    _lib.check(lib.elimrec_linear_fwd(a, lda, w, ldw, _dev(bias, "bias"), c, ldc, M, N, K, _stream()), "linear_fwd")
+    if act is None:
+        _lib.check(lib.elimrec_linear_fwd(a, lda, w, ldw, _dev(bias, "bias"), c, ldc, M, N, K, _stream()), "linear_fwd")
+        return out
+    if act != "relu":
+        raise ValueError("linear_fwd: the fused epilogue knows 'relu' only (got %r)" % (act,))
+    arr = (_lib.LinearDesc * 1)(_lib.LinearDesc(a, lda, w, ldw, _dev(bias, "bias"), c, ldc, M, N, K, None, None, 0, None, None, 1))
+    _lib.check(lib.elimrec_linear_fwd_batched(arr, 1, _stream()), "linear_fwd(relu)")
     return out
 
 

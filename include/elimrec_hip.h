@@ -62,6 +62,7 @@ typedef struct elimrec_linear_desc {
                                        (the projections evaluated at the batch's rows only; C stays compact) */
     const int32_t *d_row_range;     /* nullable device int32[2] = (begin, end): only output rows [begin, min(end, M))
                                        are produced (slot ranges of elimrec_segment_plan's seg_info)            */
+    int32_t act;                    /* epilogue activation: 0 none, 1 relu (util/mlp.py:33-35: act between layers) */
 } elimrec_linear_desc;
 int elimrec_linear_fwd_batched(const elimrec_linear_desc *descs /* host array */, int n, void *stream);
 

@@ -1,0 +1,116 @@
+"""The rest of the reference's model API on the GPU: forward() / getEmbedding() against the golden tables, the
+base-class losses (models/BasicModel.py:59-113) differentiated through the HIP table build against the oracle's
+autograd, util/mlp.py's MLP against torch, torch.ops registration. Needs a GPU: `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import build_model_from_fixture, feats_of, load_golden, rel_err, sub
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def test_forward_and_get_embedding_match_reference(fixture_name):
+    """models/EliMRec.py:274-307 against the tables the reference computed in its first forward (fwd1/*)."""
+    g = load_golden(fixture_name)
+    model, _ = build_model_from_fixture(g, DEV)
+    au, ai = g["fwd1/all_users"], g["fwd1/all_items"]
+    u, p, n = (g["step1/%s" % k] for k in ("users", "pos", "neg"))
+    got = model.forward(_t(u), _t(p))
+    assert not got.requires_grad
+    want = (au[u] * ai[p]).sum(1)
+    assert np.abs(got.cpu().numpy() - want).max() < 1e-5 * max(1.0, np.abs(want).max())
+    with torch.no_grad():
+        ue, pe, ne, u0, p0, n0 = model.getEmbedding(_t(u), _t(p), _t(n))
+    for mine, ref in ((ue, au[u]), (pe, ai[p]), (ne, ai[n]), (u0, g["init/embedding_user.weight"][u]),
+                      (p0, g["init/embedding_item.weight"][p]), (n0, g["init/embedding_item.weight"][n])):
+        assert rel_err(mine.cpu(), ref) < 1e-4
+    out = model.getEmbedding(_t(u), _t(p), None)
+    assert out[2] is None and out[5] is None
+
+
+def _oracle(g):
+    from oracle import elimrec_oracle as eo
+    adj = eo.build_adj(g["train_u"], g["train_i"], int(g["num_users"]), int(g["num_items"]), str(g["adj_type"]))
+    return eo.OracleEliMRec(int(g["num_users"]), int(g["num_items"]), int(g["recdim"]), int(g["layer_num"]), adj, feats_of(g),
+                            sub(g, "init"), float(g["alpha"]), dataset_name=str(g["dataset_name"]),
+                            modality=str(g["modality"]), mm_fusion_mode=str(g["mm_fusion_mode"]))
+
+
+@pytest.mark.parametrize("loss_name", ["bpr_loss", "infonce", "fast_loss"])
+@pytest.mark.parametrize("name", ["ml3", "ablate"])
+def test_base_class_losses_through_the_table_autograd_bridge(name, loss_name):
+    """BasicModel's generic losses on EliMRec's tables: value and every parameter gradient against the same formulas
+    differentiated by torch through the oracle's compute() (1e-4 rel)."""
+    from elimrec_amd import BasicModel
+    g = load_golden(name)
+    model, cfg = build_model_from_fixture(g, DEV)
+    om = _oracle(g)
+    u, p, n = (torch.from_numpy(g["step1/%s" % k]).long() for k in ("users", "pos", "neg"))
+    loss = getattr(BasicModel, loss_name)(model, u.to(DEV), p.to(DEV), n.to(DEV))
+    loss.backward()
+    au, ai = om.compute()
+    if loss_name == "bpr_loss":
+        want = torch.mean(F.softplus((au[u] * ai[n]).sum(1) - (au[u] * ai[p]).sum(1)))
+    elif loss_name == "infonce":
+        logits = torch.mm(F.normalize(au[u], dim=1), F.normalize(ai[p], dim=1).T) / cfg["temp"]
+        want = F.cross_entropy(logits, torch.arange(len(u)))
+    else:
+        ue, pe = F.normalize(au[u], dim=1), F.normalize(ai[p], dim=1)
+        nu, ni = F.normalize(au, dim=1), F.normalize(ai, dim=1)
+        ps = (ue * pe).sum(1)
+        a = float(g["alpha"])
+        want = torch.sum((a - 1) * ps ** 2 - 2 * a * ps) + torch.trace((nu.T @ nu) @ (ni.T @ ni))
+    want.backward()
+    assert abs(float(loss.detach()) - float(want.detach())) < 1e-4 * max(1.0, abs(float(want.detach())))
+    ref = om.grads()
+    mine = {k: q.grad for k, q in model.named_parameters() if q.grad is not None}
+    scale = max(float(v.abs().max()) for v in ref.values())
+    for k, v in ref.items():
+        if float(v.abs().max()) < 1e-6 * scale:      # mathematically zero (e.g. the item bias under pos - neg): round-off only
+            assert k not in mine or float(mine[k].abs().max()) < 1e-6 * scale, k
+            continue
+        assert k in mine, k
+        assert rel_err(mine[k].cpu(), v) < 1e-4, k
+
+
+@pytest.mark.parametrize("dims,act", [((128, [64, 64]), "relu"), ((100, [36, 10, 6]), "relu"), ((24, [16]), "relu"),
+                                      ((32, [64, 8]), "tanh")])
+def test_mlp_matches_torch(dims, act):
+    """util/mlp.py:6-38: same parameters, same input -> same output and gradients as the torch module (1e-5 / 1e-4)."""
+    from elimrec_amd import MLP
+    torch.manual_seed(0)
+    mine = MLP(dims[0], dims[1], activation=act).to(DEV)
+    mine.init_weight("xavier")
+    x = torch.randn(37, dims[0], device=DEV, requires_grad=True)
+    y = mine(x)
+    xr = x.detach().clone().requires_grad_(True)
+    h = xr
+    for i, lin in enumerate(mine.linears):
+        h = F.linear(h, lin.weight.detach().clone().requires_grad_(False), lin.bias.detach())
+        if i < len(mine.linears) - 1:
+            h = F.__dict__[act](h)
+    assert (y - h).abs().max().item() < 1e-5
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    # torch reference with its own parameter copies
+    ref = torch.nn.ModuleList([torch.nn.Linear(l.in_features, l.out_features) for l in mine.linears]).to(DEV)
+    for a, b in zip(ref, mine.linears):
+        a.load_state_dict(b.state_dict())
+    h = xr
+    for i, lin in enumerate(ref):
+        h = lin(h)
+        if i < len(ref) - 1:
+            h = F.__dict__[act](h)
+    (h * w).sum().backward()
+    assert rel_err(x.grad.cpu(), xr.grad.cpu()) < 1e-4
+    for a, b in zip(ref, mine.linears):
+        assert rel_err(b.weight.grad.cpu(), a.weight.grad.cpu()) < 1e-4
+        assert rel_err(b.bias.grad.cpu(), a.bias.grad.cpu()) < 1e-4
+    assert len(list(mine.parameters())) == 2 * len(dims[1])
