@@ -96,6 +96,7 @@ SIGNATURES = {
     "elimrec_block_spmm": (c_i32, [c_csr, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr]),
     "elimrec_blocksum_rows": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr]),
     "elimrec_triplet_rows": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr]),
+    "elimrec_triplet_rows_checked": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
     "elimrec_pad_rows": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr]),
     "elimrec_gather_rows": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr]),
     "elimrec_copy_cols": (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i32, c_ptr]),

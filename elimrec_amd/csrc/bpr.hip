@@ -658,13 +658,20 @@ static int seg_layout(int64_t n, SegLayout &L) {
 __global__ __launch_bounds__(256) void triplet_rows_kernel(const int64_t *__restrict__ users, const int64_t *__restrict__ pos,
                                                            const int64_t *__restrict__ neg, int64_t B, int64_t U,
                                                            int32_t *__restrict__ rows, const float *__restrict__ src,
-                                                           int64_t lds, int c4, float *__restrict__ dst, int64_t ldd) {
+                                                           int64_t lds, int c4, float *__restrict__ dst, int64_t ldd,
+                                                           int64_t I, int32_t *__restrict__ err) {
     const int64_t slot = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int sub = threadIdx.x & 15;
     if (slot >= 3 * B) return;
     const int64_t b = slot / 3;
     const int j = (int)(slot - 3 * b);
-    const int64_t node = j == 0 ? users[b] : U + (j == 1 ? pos[b] : neg[b]);
+    int64_t idx = j == 0 ? users[b] : (j == 1 ? pos[b] : neg[b]);
+    const int64_t lim = j == 0 ? U : I;
+    if (I >= 0 && (idx < 0 || idx >= lim)) {     // the reference raises IndexError here; flag it and stay in bounds
+        if (err && sub == 0) atomicOr(err, 1 << j);
+        idx = 0;
+    }
+    const int64_t node = j == 0 ? idx : U + idx;
     if (sub == 0) rows[slot] = (int32_t)node;
     if (src)
         for (int c = sub; c < c4; c += 16)
@@ -707,6 +714,17 @@ extern "C" int elimrec_pad_rows(float *d_rows, int64_t ld, int32_t *d_keys, cons
     return 0;
 }
 
+extern "C" int elimrec_triplet_rows_checked(const int64_t *d_users, const int64_t *d_pos, const int64_t *d_neg, int64_t B,
+                                            int64_t U, int64_t I, int32_t *d_rows, int32_t *d_err, void *stream) {
+    ELIMREC_REQUIRE(d_users && d_pos && d_neg && d_rows && d_err, "triplet_rows_checked: null pointer");
+    ELIMREC_REQUIRE(U >= 0 && I >= 0, "triplet_rows_checked: bad table sizes");
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(elimrec::triplet_rows_kernel, dim3((unsigned)((3 * B + 15) / 16)), dim3(256), 0, (hipStream_t)stream, d_users,
+                       d_pos, d_neg, B, U, d_rows, (const float *)nullptr, (int64_t)0, 0, (float *)nullptr, (int64_t)0, I, d_err);
+    ELIMREC_LAUNCH_CHECK("triplet_rows_checked");
+    return 0;
+}
+
 extern "C" int elimrec_triplet_rows(const int64_t *d_users, const int64_t *d_pos, const int64_t *d_neg, int64_t B, int64_t U,
                                     int32_t *d_rows, const float *d_src, int64_t lds, int cols, float *d_dst, int64_t ldd,
                                     void *stream) {
@@ -715,7 +733,7 @@ extern "C" int elimrec_triplet_rows(const int64_t *d_users, const int64_t *d_pos
                     "triplet_rows: cols, lds, ldd must be multiples of 4");
     if (B <= 0) return 0;
     hipLaunchKernelGGL(elimrec::triplet_rows_kernel, dim3((unsigned)((3 * B + 15) / 16)), dim3(256), 0, (hipStream_t)stream, d_users,
-                       d_pos, d_neg, B, U, d_rows, d_src, lds, cols / 4, d_dst, ldd);
+                       d_pos, d_neg, B, U, d_rows, d_src, lds, cols / 4, d_dst, ldd, (int64_t)-1, (int32_t *)nullptr);
     ELIMREC_LAUNCH_CHECK("triplet_rows");
     return 0;
 }

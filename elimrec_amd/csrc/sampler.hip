@@ -68,7 +68,12 @@ __global__ void sample_triplets_kernel(const int32_t *__restrict__ user_ids, con
             if (!found) cand = a;
         }
     }
-    neg[i] = cand;   // -1 only if the user has interacted with (almost) every item
+    if (cand < 0) {   // a user who interacted with almost every item: the first id missing from the sorted list
+        int64_t k = 0;
+        while (k < cnt && items[beg + k] == (int32_t)k) ++k;
+        cand = k;      // < I: the host rejects users with >= I training items
+    }
+    neg[i] = cand;
 }
 
 }  // namespace elimrec

@@ -341,11 +341,20 @@ class EliMRec(BasicModel):
         bwd_rows = 3 * int(B) if bwd_rows is None else int(bwd_rows)
         if self._ws is not None and self._ws_key[:2] == (str(dev), int(B)) and self._ws_key[2] >= bwd_rows:
             return self._ws
+        # the batch-dependent buffers of every batch size seen so far are kept (an epoch ends with a ragged batch: B ->
+        # tail -> B would otherwise reallocate twice per epoch and invalidate every recorded region)
+        sets = self.__dict__.setdefault("_ws_sets", {})
+        hit = sets.get((str(dev), int(B)))
+        if hit is not None and self._ws is not None and self._ws_key[0] == str(dev) and hit[0] >= bwd_rows:
+            self._ws.update(hit[2])
+            self._ws_key, self._ws_gen = (str(dev), int(B), hit[0]), hit[1]
+            return self._ws
         key = (str(dev), int(B), bwd_rows)
         N, C, Cy, d = self.num_users + self.num_items, self.C, self.Cy, self.latent_dim
         f32 = dict(dtype=torch.float32, device=dev)
         ws = self._ws if (self._ws is not None and self._ws_key[0] == key[0]) else {}
-        self._ws_gen = getattr(self, "_ws_gen", 0) + 1       # recorded regions hold these buffers' addresses
+        self._ws_gen_counter = getattr(self, "_ws_gen_counter", 0) + 1
+        self._ws_gen = self._ws_gen_counter                  # recorded regions hold these buffers' addresses
         if "flat_param" not in ws:                          # everything that does not depend on the batch size
             self._flatten_parameters(ws)
             names = ("Out",) if self._folded else (("X0", "Out") if self._bipartite else ("X0", "T0", "T1", "Out", "G"))
@@ -403,6 +412,9 @@ class EliMRec(BasicModel):
             shapes += [(n3, d, getattr(self, m + "_feat").shape[1]) for m in self._mods]
         ws["bwd_w_rows"] = torch.empty(max(ops.linear_bwd_w_batched_workspace(shapes), 1), dtype=torch.uint8, device=dev)
         self._ws, self._ws_key = ws, key
+        batch_keys_ = ("loss_rows", "grad_rows", "keys", "keys_scratch", "slot_seg", "OutAct", "YAct", "active_rows", "dY",
+                       "seg_info", "plan_ws", "dp_rows", "dOutR", "bwd_w_rows")
+        self.__dict__.setdefault("_ws_sets", {})[(key[0], key[1])] = (bwd_rows, self._ws_gen, {k: ws[k] for k in batch_keys_ if k in ws})
         return ws
 
     @torch.no_grad()
@@ -595,6 +607,7 @@ class EliMRec(BasicModel):
         if self.mm_fusion_mode != "concat" or not self._use_replay:   # 'mean' fusion mixes torch ops into the regions
             return fn()
         key = key + (ops._stream(),)
+        name = "%s@%d" % (name, self._ws_gen)       # one entry per batch-size buffer set
         ent = self._regions.get(name)
         if ent is None or ent[0] != key:
             ent = self._regions[name] = [key, 0, None, None]
@@ -692,7 +705,26 @@ class EliMRec(BasicModel):
         B = int(users.numel())
         ws = self._workspace(B, getattr(self, "_bwd_rows_hint", None))
         users, pos, neg = self._index_tensors(users, pos, neg)
-        return ops.triplet_rows(users, pos, neg, self.num_users, ws["keys"][:3 * B])
+        return ops.triplet_rows(users, pos, neg, self.num_users, ws["keys"][:3 * B], I=self.num_items, err=self._index_err())
+
+    def _index_err(self):
+        e = self.__dict__.get("_index_err_word")
+        if e is None or e.device != self._device():
+            e = self.__dict__["_index_err_word"] = torch.zeros(1, dtype=torch.int32, device=self._device())
+        return e
+
+    def check_indices(self):
+        """Raise IndexError if any batch since the last call held a user / item id outside the tables (the reference
+        fails at the gather, models/EliMRec.py:277-281; here the kernels flag it, keep running in bounds, and the host
+        looks at the flag when it synchronises anyway -- once per epoch in main.py)."""
+        e = self.__dict__.get("_index_err_word")
+        if e is None:
+            return
+        bits = int(e.item())
+        if bits:
+            e.zero_()
+            what = [n for b, n in enumerate(("user", "positive item", "negative item")) if bits >> b & 1]
+            raise IndexError("EliMRec: %s index out of range in a training batch" % " / ".join(what))
 
     @torch.no_grad()
     def _forward_hip(self, users, pos, neg, need_grad, all_keys=None, rank=0):

@@ -381,9 +381,16 @@ def copy_cols(src, dst):
     return dst
 
 
-def triplet_rows(users, pos, neg, U, rows, src=None, dst=None):
-    """rows[3b + (0,1,2)] = users[b], U + pos[b], U + neg[b]; dst[slot] = src[rows[slot]] when src is given."""
+def triplet_rows(users, pos, neg, U, rows, src=None, dst=None, I=None, err=None):
+    """rows[3b + (0,1,2)] = users[b], U + pos[b], U + neg[b]; dst[slot] = src[rows[slot]] when src is given. With I and
+    err (int32[1]): range-checked -- a bad index sets a bit of err and is replaced by 0."""
     B = users.numel()
+    if err is not None:
+        _lib.check(_lib.load().elimrec_triplet_rows_checked(_dev(users, "users", torch.int64), _dev(pos, "pos", torch.int64),
+                                                            _dev(neg, "neg", torch.int64), B, U, int(I),
+                                                            _dev(rows, "rows", torch.int32), _dev(err, "err", torch.int32),
+                                                            _stream()), "triplet_rows_checked")
+        return rows
     s, lds, t, ldt, cols = None, 0, None, 0, 0
     if src is not None:
         s, lds = _rowmajor(src, "src")

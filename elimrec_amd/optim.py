@@ -90,3 +90,27 @@ class FusedAdam(torch.optim.Optimizer):
         # the plan is reusable only if no gradient had to be copied to a temporary
         self._plan = (sig, plan) if all(r["contiguous"] for r, _, _ in plan) else None
         return loss
+
+    # ------------------------------------------------------------------ checkpoint / resume
+    @torch.no_grad()
+    def export_state(self, named_params):
+        """{parameter name: {"step", "exp_avg", "exp_avg_sq"}} on the CPU for the parameters that have state."""
+        out = {}
+        for name, p in named_params:
+            st = self.state.get(p)
+            if st:
+                out[name] = dict(step=int(st["step"]), exp_avg=st["exp_avg"].detach().cpu().clone(),
+                                 exp_avg_sq=st["exp_avg_sq"].detach().cpu().clone())
+        return out
+
+    @torch.no_grad()
+    def import_state(self, named_params, saved):
+        """Inverse of export_state: the moments are copied INTO this optimizer's own (flat, mirrored) buffers, so the
+        merged single-launch update keeps working after a resume."""
+        for name, p in named_params:
+            if name in saved:
+                st = self._state_for(p)
+                st["step"] = int(saved[name]["step"])
+                st["exp_avg"].copy_(saved[name]["exp_avg"].to(p.device))
+                st["exp_avg_sq"].copy_(saved[name]["exp_avg_sq"].to(p.device))
+        self._plan = None

@@ -4,7 +4,7 @@ batches. Sampling itself runs on the GPU (csrc/sampler.hip): the whole epoch of
 `num_trainings` triplets is drawn in one launch and the batches are device-tensor views, so the
 training loop does no per-batch host->device copy.
 
-Contract (tests/test_sampler_gpu.py): users uniform with replacement over users that have >= 1
+Contract (tests/test_hip_parity.py::test_sampler_contract_on_device): users uniform with replacement over users that have >= 1
 training item; positives uniform over that user's training items; negatives uniform over the
 catalogue minus the user's training items. The draws are i.i.d., so the reference's extra
 `shuffle` pass is a distributional no-op and is not repeated. The random stream is Philox keyed
@@ -18,7 +18,10 @@ from . import ops
 
 
 class PairwiseSamplerV2(object):
-    def __init__(self, dataset, neg_num=1, batch_size=1024, shuffle=True, drop_last=False, device=None, seed=2022):
+    def __init__(self, dataset, neg_num=1, batch_size=1024, shuffle=True, drop_last=False, device=None, seed=2022,
+                 shard=None):
+        """shard = (rank, world): this process draws its 1/world share of the epoch's `num_trainings` triplets (rounded
+        up, so every rank runs the same number of batches); give every rank its own seed."""
         if neg_num <= 0:
             raise ValueError("'neg_num' must be a positive integer.")
         if neg_num != 1:
@@ -31,6 +34,11 @@ class PairwiseSamplerV2(object):
         if not user_pos:
             raise ValueError("'user_pos_dict' cannot be empty.")
         self.num_trainings = sum(len(v) for v in user_pos.values())
+        if shard is not None:
+            rank, world = int(shard[0]), int(shard[1])
+            if not (0 <= rank < world):
+                raise ValueError("shard=(rank, world) with 0 <= rank < world")
+            self.num_trainings = (self.num_trainings + world - 1) // world
         users = np.fromiter(user_pos.keys(), dtype=np.int32, count=len(user_pos))
         counts = np.fromiter((len(user_pos[u]) for u in users), dtype=np.int64, count=len(users))
         if int(counts.max()) >= self.item_num:

@@ -46,9 +46,10 @@ class ColumnShardTrainer(object):
 
     def _like(self, name, t, lead=None):
         shape = tuple(t.shape) if lead is None else (lead,) + tuple(t.shape)
-        b = self._buf.get(name)
-        if b is None or b.shape != shape or b.dtype != t.dtype or b.device != t.device:
-            b = self._buf[name] = torch.empty(shape, dtype=t.dtype, device=t.device)
+        key = (name, shape, t.dtype, t.device)                    # one buffer per batch size: stable addresses
+        b = self._buf.get(key)
+        if b is None:
+            b = self._buf[key] = torch.empty(shape, dtype=t.dtype, device=t.device)
         return b
 
     def step(self, users, pos, neg):
@@ -140,7 +141,7 @@ class ColumnShardEngine(object):
         self.srcA, self.srcB, self.tmp = tab(), tab(), [tab(), tab()]
         self.mask = torch.zeros((N + 31) // 32 + 2, dtype=torch.int32, device=dev)
         self.step_count = 0
-        self._B = None
+        self._bufs = {}
         self._x0_fwd = None
         ws = m._workspace(1)
         self.load_from_model()
@@ -172,18 +173,18 @@ class ColumnShardEngine(object):
     def _workspace(self, B):
         m = self.model
         ws = m._workspace(B, 3 * B)
-        if self._B != (B, m._ws_gen):
-            self._B = (B, m._ws_gen)
-            dev, d, R, W = m._device(), m.latent_dim, 3 * B, self.world
-            N = m.num_users + m.num_items
-            self.hg = torch.zeros(R, 2 * d, dtype=torch.float32, device=dev)
-            self.send_f = torch.empty(W, R, 2 * self.dl, dtype=torch.float32, device=dev) if W > 1 else None
-            self.counts = torch.zeros(W, dtype=torch.int32, device=dev)
-            if getattr(self, "narrow_x", None) is None or ws["Narrow"].data_ptr() != self.narrow_x.data_ptr():
-                self.narrow_x = torch.zeros(N + 1, d, dtype=torch.float32, device=dev)   # spare row: padded slots land there
-                ws["Narrow"] = self.narrow_x[:N]
-                m._ws_gen += 1                                    # recorded regions hold the old buffer's address
-                self._B = (B, m._ws_gen)
+        dev, d, R, W = m._device(), m.latent_dim, 3 * B, self.world
+        N = m.num_users + m.num_items
+        if getattr(self, "narrow_x", None) is None or ws["Narrow"].data_ptr() != self.narrow_x.data_ptr():
+            self.narrow_x = torch.zeros(N + 1, d, dtype=torch.float32, device=dev)   # spare row: padded slots land there
+            ws["Narrow"] = self.narrow_x[:N]
+            m._regions = {}                                       # recorded regions hold the old buffer's address
+        bufs = self._bufs.get(B)
+        if bufs is None:                                          # per batch size (an epoch ends with a ragged batch)
+            bufs = self._bufs[B] = dict(hg=torch.zeros(R, 2 * d, dtype=torch.float32, device=dev),
+                                        send_f=torch.empty(W, R, 2 * self.dl, dtype=torch.float32, device=dev) if W > 1 else None,
+                                        counts=torch.zeros(W, dtype=torch.int32, device=dev))
+        self.hg, self.send_f, self.counts = bufs["hg"], bufs["send_f"], bufs["counts"]
         return ws
 
     def _timed(self, fn, hops):
@@ -203,7 +204,7 @@ class ColumnShardEngine(object):
         B = int(users.numel())
         ws = self._workspace(B)
         users, pos, neg = m._index_tensors(users, pos, neg)
-        keys = ops.triplet_rows(users, pos, neg, m.num_users, ws["keys"][:3 * B])
+        keys = ops.triplet_rows(users, pos, neg, m.num_users, ws["keys"][:3 * B], I=m.num_items, err=m._index_err())
         R = 3 * B
         act, seg = ws["active_rows"][:R], ws["seg_info"]
         m._plan_n = R

@@ -72,6 +72,12 @@ int elimrec_linear_fwd_batched(const elimrec_linear_desc *descs /* host array */
 int elimrec_triplet_rows(const int64_t *d_users, const int64_t *d_pos, const int64_t *d_neg, int64_t B, int64_t U,
                          int32_t *d_rows, const float *d_src, int64_t lds, int cols, float *d_dst, int64_t ldd,
                          void *stream);
+/* The same node ids with the range check the reference gets from torch indexing (IndexError / device assert on
+ * all_users[users], all_items[pos], models/EliMRec.py:277-281): an index outside [0, U) / [0, I) sets bit 0 / 1 / 2
+ * (user / positive / negative) of *d_err and is replaced by 0, so nothing downstream reads or writes out of bounds;
+ * the host tests the word when it next synchronises (EliMRec.check_indices()). */
+int elimrec_triplet_rows_checked(const int64_t *d_users, const int64_t *d_pos, const int64_t *d_neg, int64_t B,
+                                 int64_t U, int64_t I, int32_t *d_rows, int32_t *d_err, void *stream);
 /* Rows [*d_count, n) of a compact row buffer do not belong to the batch: d_rows[r, 0:cols] = 0, d_keys[r] = pad_key + r
  * (what a rank hands to the all-gather of a data-parallel step: fixed-size buffers whose tail adds nothing; distinct
  * keys so that the padding does not pile up in one segment; pad_key + n must stay below the key space). */

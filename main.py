@@ -7,8 +7,20 @@ Behaviour kept from the reference's `Net.run`: one pass of the pairwise sampler 
 `test_step` epochs with predict_type TIE, a checkpoint + TE/TIE test pass whenever validation recall improves
 (not on epoch 0), early stop after `stop_cnt` epochs without improvement, the same log lines. The per-batch work,
 the sampler and the evaluator run on the GPU (elimrec_amd). `--data.input.dataset=synthetic` uses the seeded
-Tiktok-shape generator instead of reading files. Multi-GPU: launch with torch.distributed.run, one process per GPU
-(elimrec_amd/dist.py).
+Tiktok-shape generator instead of reading files.
+
+`--loss=<method>` names the model method that computes the loss, as in the reference (main.py:98): `bpr_loss` (EliMRec's
+own loss) runs the fused training step; any other method of the model (`infonce`, `fast_loss`, the base class's
+generic losses) runs loss -> backward -> optimizer step through the differentiable table build.
+`--resume=<checkpoint>` (not in the reference, which only saves): restores the parameters from a reference-format
+checkpoint and, when the side file `<checkpoint>.resume` written next to it exists, the Adam moments, step counts,
+epoch counter and best metrics.
+
+Multi-GPU: launch with torch.distributed.run, one process per GPU. Every rank owns recdim/world columns of the
+embedding tables (elimrec_amd/shard.py); an epoch is split over the ranks -- each draws 1/world of the epoch's
+triplets in batches of batch_size/world, so the global batch, the number of optimizer steps per epoch and the
+learning-rate schedule are those of the single-GPU (and the reference's) configuration; the logged loss is the mean
+over ranks.
 """
 import os
 import time
@@ -17,6 +29,7 @@ import torch
 
 from elimrec_amd import (Configurator, Dataset, EliMRec, FusedAdam, Logger, Meter, PairwiseSamplerV2,
                          SyntheticDataset, set_seed)
+from elimrec_amd import ColumnShardEngine, ColumnShardTrainer
 from elimrec_amd.dist import DataParallelTrainer
 
 EFFECTS = ("TE", "TIE")
@@ -66,18 +79,82 @@ class Net(object):
         self.cf_mode = cfg["cf_mode"] if "cf_mode" in cfg else True
         Logger.info(count_parameters(self.recommender))
         self.opt = FusedAdam(self.recommender.parameters(), lr=cfg.lr, weight_decay=cfg.weight_decay)
-        self.trainer = DataParallelTrainer(self.recommender, self.opt, world_size=self.world, rank=self.rank)
+        self.loss_name = str(cfg.loss)
+        if not callable(getattr(self.recommender, self.loss_name, None)):
+            raise AttributeError("'%s' has no loss method '%s' (--loss)" % (cfg.recommender, self.loss_name))
+        self.engine = None
+        rec = self.recommender
+        if self.loss_name != "bpr_loss":
+            if self.world > 1:
+                raise ValueError("--loss=%s runs through the generic autograd path, which is single-GPU" % self.loss_name)
+            self.trainer = None
+        elif getattr(rec, "_lazy", False) and rec.latent_dim % (4 * self.world) == 0:
+            self.engine = ColumnShardEngine(rec)
+            self.trainer = ColumnShardTrainer(self.engine, self.opt, world_size=self.world, rank=self.rank)
+        else:       # adjacencies with a diagonal (norm / mean+I), layer_num < 2: replicated tables, data parallel
+            self.trainer = DataParallelTrainer(rec, self.opt, world_size=self.world, rank=self.rank)
+        self.start_epoch, self.resume_state = 0, None
+        if "resume" in cfg and cfg["resume"]:
+            self.load_checkpoint(str(cfg["resume"]))
+
+    # ------------------------------------------------------------------ checkpoint / resume
+    def save_checkpoint(self, path, epoch, extra):
+        """The reference's checkpoint (state_dict, main.py:131-133) + a side file with what a resume needs on top."""
+        rec = self.recommender
+        if self.engine is not None:
+            self.engine.sync_to_model()                       # all ranks (collective when world > 1)
+            emb = self.engine.optimizer_state()
+        else:
+            emb = None
+        if self.rank != 0:
+            return
+        torch.save(rec.state_dict(), path)
+        torch.save(dict(epoch=epoch, embedding_adam=emb, adam=self.opt.export_state(rec.named_parameters()), extra=extra),
+                   path + ".resume")
+
+    def load_checkpoint(self, path):
+        rec = self.recommender
+        state = torch.load(path, map_location="cpu")
+        rec.load_state_dict(state, strict=True)
+        if self.engine is not None:
+            self.engine.load_from_model()
+        side = path + ".resume"
+        if os.path.exists(side):
+            extra = torch.load(side, map_location="cpu", weights_only=False)
+            rec._workspace(1)                                  # parameters move into the flat buffers before the moments
+            self.opt.import_state(rec.named_parameters(), extra["adam"])
+            if self.engine is not None and extra.get("embedding_adam") is not None:
+                self.engine.load_optimizer_state(extra["embedding_adam"])
+            self.start_epoch = int(extra["epoch"]) + 1
+            self.resume_state = extra.get("extra")
+            Logger.info("[resumed] %s at epoch %d (optimizer state restored)" % (path, self.start_epoch))
+        else:
+            Logger.info("[resumed] %s (parameters only: no %s)" % (path, side))
 
     # ------------------------------------------------------------------ pieces of an epoch
+    def generic_step(self, users, pos, neg):
+        """main.py:98-101 as written: loss method -> zero_grad -> backward -> optimizer step."""
+        loss = getattr(self.recommender, self.loss_name)(users, pos, neg)
+        self.opt.zero_grad()
+        loss.backward(retain_graph=True)
+        self.opt.step()
+        return loss.detach()
+
     def train_epoch(self, batches):
-        """One pass over the sampler; the mean loss of the epoch (one device->host copy for all batches instead of the
-        reference's per-batch loss.cpu().item())."""
+        """One pass over the sampler; the mean loss of the epoch over all ranks (one device->host copy for all batches
+        instead of the reference's per-batch loss.cpu().item())."""
         self.recommender.train()
         tracker = Meter(name="MultiLoss(bpr)")
         tracker.reset()
-        on_device = [self.trainer.step(users, pos, neg) for users, pos, neg in batches]
-        for value in torch.stack(on_device).cpu().tolist():
+        step = self.generic_step if self.trainer is None else self.trainer.step
+        on_device = torch.stack([step(users, pos, neg) for users, pos, neg in batches])
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(on_device, op=dist.ReduceOp.SUM)
+            on_device /= self.world
+        for value in on_device.cpu().tolist():
             tracker.update(val=value)
+        self.recommender.check_indices()
         return tracker.avg
 
     def validate(self, epoch, meters):
@@ -114,13 +191,20 @@ class Net(object):
         stamp = int(time.time())
         loss_meter = Meter("loss", id=stamp)
         meters = {"recall": Meter("R@" + k, id=stamp), "precision": Meter("P@" + k, id=stamp), "ndcg": Meter("N@" + k, id=stamp)}
-        batches = PairwiseSamplerV2(self.dataset, neg_num=1, batch_size=cfg.batch_size, shuffle=True, device=cfg.device,
-                                    seed=cfg.seed + self.rank)
+        if cfg.batch_size % self.world != 0:
+            raise ValueError("batch_size %d is not a multiple of the %d ranks" % (cfg.batch_size, self.world))
+        batches = PairwiseSamplerV2(self.dataset, neg_num=1, batch_size=cfg.batch_size // self.world, shuffle=True,
+                                    device=cfg.device, seed=cfg.seed + self.rank,
+                                    shard=(self.rank, self.world) if self.world > 1 else None)
+        batches.epoch = self.start_epoch
         best_recall = dict.fromkeys(EFFECTS, 0)
         best_epoch = dict.fromkeys(EFFECTS, 0)
         best_valid_line, test_lines = "", dict.fromkeys(EFFECTS, "")
         checkpoint = rec.getFileName()
-        for epoch in range(cfg.num_epoch):
+        if self.resume_state:
+            best_recall, best_epoch = dict(self.resume_state["best_recall"]), dict(self.resume_state["best_epoch"])
+            best_valid_line, test_lines = self.resume_state["best_valid_line"], dict(self.resume_state["test_lines"])
+        for epoch in range(self.start_epoch, cfg.num_epoch):
             Logger.info("======================")
             Logger.info("EPOCH[%d/%d]" % (epoch, cfg.num_epoch))
             loss_meter.reset_time()
@@ -128,15 +212,16 @@ class Net(object):
             if (epoch + 1) % cfg["test_step"] == 0:
                 result = self.validate(epoch, meters)
                 if meters["recall"].val > best_recall["TIE"] and epoch != 0:
-                    if cfg["save_flag"] and self.rank == 0:
-                        Logger.info("[saved][EPOCH %d]" % epoch)
-                        torch.save(rec.state_dict(), checkpoint)
                     best_valid_line = "[EPOCH {}]\n{}\t{}\t{}".format(epoch, meters["recall"], meters["ndcg"], meters["precision"])
                     Logger.info("[Better Result]")
                     Logger.info("[TEST]")
                     for effect in EFFECTS:
-                        best_recall[effect], best_epoch[effect] = result[1], epoch
+                        best_recall[effect], best_epoch[effect] = float(result[1]), epoch
                     test_lines = self.test_all_effects()
+                    if cfg["save_flag"]:
+                        Logger.info("[saved][EPOCH %d]" % epoch)
+                        self.save_checkpoint(checkpoint, epoch, dict(best_recall=best_recall, best_epoch=best_epoch,
+                                                                     best_valid_line=best_valid_line, test_lines=test_lines))
                 if epoch - best_epoch["TIE"] > cfg.stop_cnt:
                     break
             loss_meter.update(val=epoch_loss, epoch=epoch)
