@@ -180,9 +180,26 @@ def _tie_free(scores, k):
     return np.all(s[:, :-1] != s[:, 1:], axis=1)
 
 
+def _my_rule_topk(scores, K):
+    """Top-K under the device's stated tie rule: score descending, item id ascending."""
+    return np.argsort(-scores, axis=1, kind="stable")[:, :K].astype(np.int32)
+
+
+def _ulps(a, b):
+    a = np.asarray(a, np.float32).view(np.int32).astype(np.int64)
+    b = np.asarray(b, np.float32).view(np.int32).astype(np.int64)
+    return np.abs(a - b)
+
+
 def test_device_evaluator_matches_reference(fixture_name):
-    """Masked top-K indices: exact where the reference row has no tie at/across K, otherwise
-    score-equivalent under the reference's own scores; metric rows then equal the oracle's."""
+    """SURVEY section 7 (ii), judged on the REFERENCE's scores (the fixture's masked score matrix of the whole test split):
+      * rank by rank, the item the device puts at rank k has the same reference score as the item the reference puts
+        there -- asserted for every row whose device scores equal the reference's bit for bit at those items;
+      * rows without a tie at or across K: the device indices ARE the reference indices. Where they are not, the cause
+        must be a device/reference score difference of a few ulp between two near-equal (not equal) scores: each such
+        row is checked for exactly that and their number is bounded;
+      * evaluate(): equal (1e-7) to the metrics recomputed from the reference scores under the device's tie rule (score
+        desc, item id asc), up to the rows whose order an ulp moved -- none on most fixtures."""
     from oracle import eval_oracle as ev
     g = load_golden(fixture_name)
     model, _ = build_model_from_fixture(g, DEV)
@@ -190,38 +207,110 @@ def test_device_evaluator_matches_reference(fixture_name):
     model.fusion_mode, model.predict_type = "rubi", "TIE"
     users = g["evalbatch/users"].tolist()
     K = int(g["evalbatch/top_k"])
+    mids = g["evalbatch/metric_ids"]
     evalr = model.test_evaluator.evaluator
     rows, idx, val = evalr.evaluate_batch(model, users, return_topk=True)
     idx = idx.cpu().numpy()
     ref_scores = g["evalbatch/masked_scores"]
     test = csr_dict(g, "test")
     tp, ti = ev.truth_to_csr([sorted(set(test[int(u)])) for u in users])
-    ref_rows, ref_topk = ev.evaluate_matrix(ref_scores, tp, ti, g["evalbatch/metric_ids"], K)
-    clean = _tie_free(ref_scores, K)
-    assert clean.sum() > 0
+    _, ref_topk = ev.evaluate_matrix(ref_scores, tp, ti, mids, K)          # the reference's heap-order ranking
+    mine_topk = _my_rule_topk(ref_scores, K)                              # reference scores, device tie rule
     dev_scores = torch.empty(len(users), model.num_items, device=DEV)
-    # the device's own masked scores, to tell real mismatches from 1-ulp score differences
     train_ptr, train_items = evalr._batch_csr(users, evalr.user_pos_train, DEV, unique=False)
     model.predict_device(users, scores=dev_scores, train_ptr=train_ptr, train_items=train_items)
     dev_scores = dev_scores.cpu().numpy()
     assert np.array_equal(np.isinf(dev_scores), np.isinf(ref_scores))          # same items masked
     finite = ~np.isinf(ref_scores)
     assert np.abs(dev_scores[finite] - ref_scores[finite]).max() < 1e-5
+    clean = _tie_free(ref_scores, K)
+    assert clean.sum() > 0
+    n_bitwise = n_moved = 0
     for r in range(len(users)):
-        same_order = np.array_equal(np.argsort(-dev_scores[r], kind="stable")[:K], np.argsort(-ref_scores[r], kind="stable")[:K])
-        if clean[r] and same_order:
-            assert np.array_equal(idx[r], ref_topk[r]), r
-        # score-equivalence under the DEVICE scores: rank k holds the k-th largest device score
-        assert np.array_equal(dev_scores[r][idx[r]], -np.sort(-dev_scores[r])[:K]), r
-    # metric kernel vs oracle on the device's own ranking
-    want = ev.metrics_from_rank(idx, tp, ti, g["evalbatch/metric_ids"], K)
+        touched = np.union1d(idx[r], ref_topk[r])
+        if np.array_equal(dev_scores[r][touched], ref_scores[r][touched]):
+            n_bitwise += 1
+            assert np.array_equal(ref_scores[r][idx[r]], ref_scores[r][ref_topk[r]]), r     # score-equivalent, rank by rank
+            if clean[r]:
+                assert np.array_equal(idx[r], ref_topk[r]), r                                 # tie-free: the same items
+        elif clean[r] and not np.array_equal(idx[r], ref_topk[r]):
+            # an ulp-level score difference reordered two near-equal reference scores: the swapped ranks hold reference
+            # scores within 4 ulp of each other, and the device ranked by ITS scores correctly
+            n_moved += 1
+            assert _ulps(ref_scores[r][idx[r]], ref_scores[r][ref_topk[r]]).max() <= 4, r
+        assert np.array_equal(dev_scores[r][idx[r]], -np.sort(-dev_scores[r])[:K]), r         # the device's own ranking is exact
+    assert n_bitwise > 0
+    assert n_moved <= max(1, len(users) // 20), n_moved
+    # metric kernel on the device's ranking == the metric port on the same ranking
+    want = ev.metrics_from_rank(idx, tp, ti, mids, K)
     assert np.abs(rows.cpu().numpy() - want).max() < 1e-6
-    # whole evaluate(): same numbers as the reference unless a boundary tie moved an item
-    for ptype in ("TE", "TIE"):
-        model.predict_type = ptype
-        res, buf = model.test()
-        assert res.dtype == np.float32 and res.shape == (3,) and len(buf.split("\t")) == 3
-        assert np.abs(res - g["evaluate/%s/test" % ptype]).max() < 2e-2
+    # evaluate() against the metrics recomputed from the reference scores under the device's tie rule
+    moved = int((idx != mine_topk).any(1).sum())
+    for r in np.nonzero((idx != mine_topk).any(1))[0]:
+        assert _ulps(ref_scores[r][idx[r]], ref_scores[r][mine_topk[r]]).max() <= 4, r
+    per_user = ev.metrics_from_rank(mine_topk, tp, ti, mids, K)
+    n_metrics = len(mids)
+    expect = per_user.mean(0).reshape(n_metrics, K)[:, evalr.top_show - 1].reshape(-1)
+    res, buf = model.test()
+    assert res.dtype == np.float32 and res.shape == (3,) and len(buf.split("\t")) == 3
+    assert np.abs(res - expect).max() <= 1e-7 + moved / len(users), (res, expect, moved)
+    if moved == 0:
+        assert np.abs(res - expect).max() <= 1e-7
+    # TE: scores from the oracle (pinned to the reference's predict() to 2e-6), same recomputation
+    from oracle import elimrec_oracle as eo
+    from helpers import feats_of
+    adj = eo.build_adj(g["train_u"], g["train_i"], int(g["num_users"]), int(g["num_items"]), str(g["adj_type"]))
+    om = eo.OracleEliMRec(int(g["num_users"]), int(g["num_items"]), int(g["recdim"]), int(g["layer_num"]), adj, feats_of(g),
+                          sub(g, "init"), float(g["alpha"]), dataset_name=str(g["dataset_name"]),
+                          modality=str(g["modality"]), mm_fusion_mode=str(g["mm_fusion_mode"]), predict_type="TE")
+    om.set_cache(g["cache/all_users"], g["cache/all_items"], {k: v for k, v in sub(g, "cache").items() if k.startswith("pre_fusion")})
+    te = om.predict(users).numpy().astype(np.float32)
+    train = csr_dict(g, "train")
+    for r, u in enumerate(users):
+        te[r, train.get(int(u), [])] = -np.inf
+    te_topk = _my_rule_topk(te, K)
+    model.predict_type = "TE"
+    _, te_idx, _ = evalr.evaluate_batch(model, users, return_topk=True)
+    te_idx = te_idx.cpu().numpy()
+    te_moved = int((te_idx != te_topk).any(1).sum())
+    for r in np.nonzero((te_idx != te_topk).any(1))[0]:
+        assert np.abs(te[r][te_idx[r]] - te[r][te_topk[r]]).max() < 4e-6, r       # oracle scores are 2e-6 from the reference's
+    expect = ev.metrics_from_rank(te_topk, tp, ti, mids, K).mean(0).reshape(n_metrics, K)[:, evalr.top_show - 1].reshape(-1)
+    res, _ = model.test()
+    assert np.abs(res - expect).max() <= 1e-7 + te_moved / len(users)
+    # and the reference's own reported numbers differ from ours only through its heap tie order
+    ref_per_user = ev.metrics_from_rank(ref_topk, tp, ti, mids, K).mean(0).reshape(n_metrics, K)[:, evalr.top_show - 1].reshape(-1)
+    assert np.abs(ref_per_user - g["evaluate/TIE/test"]).max() < 1e-7
+
+
+def test_tie_straddling_k_is_score_equivalent_to_the_reference_order():
+    """Identical scores on both sides of the K boundary: the device keeps the lowest item ids (its stated rule), the
+    reference's partial_sort_copy keeps whatever its heap order leaves -- different items, but rank by rank the same
+    score, on the same score matrix."""
+    from elimrec_amd import ops
+    from oracle import eval_oracle as ev
+    U, I, d, S, K = 8, 600, 16, 3, 10
+    Cy = (1 + S) * d
+    gen = torch.Generator().manual_seed(4)
+    Y = torch.randn(U + I, Cy, generator=gen)
+    Y[U + 40:U + 520] = Y[U + 40:U + 52].repeat(40, 1)        # 12 distinct rows x 40 copies: every score value 40 times
+    users = torch.arange(U)
+    ws = torch.empty(ops.score_workspace(U, U, I, S, K), dtype=torch.uint8, device=DEV)
+    scores = torch.empty(U, I, device=DEV)
+    idx = torch.empty(U, K, dtype=torch.int32, device=DEV)
+    val = torch.empty(U, K, device=DEV)
+    ptr = torch.zeros(U + 1, dtype=torch.int64, device=DEV)
+    ops.score_topk(Y.to(DEV), U, I, users.to(DEV), d, S, 0b111, "rubi", "TIE", ws, scores=scores, K=K, topk_idx=idx,
+                   topk_val=val, train_ptr=ptr, train_items=torch.zeros(1, dtype=torch.int32, device=DEV))
+    sc, idx = scores.cpu().numpy(), idx.cpu().numpy()
+    kth = -np.sort(-sc, axis=1)[:, K - 1:K + 1]
+    assert (kth[:, 0] == kth[:, 1]).any()                     # a tie does straddle K on some rows
+    tp, ti = ev.truth_to_csr([[1]] * U)
+    _, ref_topk = ev.evaluate_matrix(sc, tp, ti, [1, 2, 4], K)
+    assert (idx != ref_topk).any()                            # the two tie rules do pick different items here
+    for r in range(U):
+        assert np.array_equal(sc[r][idx[r]], sc[r][ref_topk[r]]), r
+        assert np.array_equal(idx[r], _my_rule_topk(sc[r:r + 1], K)[0]), r
 
 
 # ----------------------------------------------------------------------------- op-level vs oracle
