@@ -1,0 +1,184 @@
+// torch.ops.elimrec.* : a thin TORCH_LIBRARY registration over the C ABI of libelimrec_hip.so (include/elimrec_hip.h),
+// the form SURVEY.md 8(b) names for a PyTorch host. Nothing is computed here: every op checks its tensors, unpacks
+// pointers / strides, takes torch's current HIP stream, allocates its outputs and scratch with torch and calls ONE
+// entry point of the C ABI; failures become c10::Error (RuntimeError in Python) carrying elimrec_last_error().
+// The ctypes binding (elimrec_amd/_lib.py) stays for hosts without torch; both call the same library.
+//
+//   propagate(rowptr i32[N+1], col i32[nnz], val f32[nnz], X f32[N x C], L) -> mean over the L+1 layer tables
+//   linear_fwd(A, W, bias?) -> A W^T + bias                linear_bwd_w(A, B) -> (A^T B, column sums of A)
+//   bpr_head_fwd(Y, U, I, users, pos, neg, d, block_weights) -> (loss_rows, grad_rows, keys)
+//   adam_step_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step) -> p
+//   score_topk(Y, U, I, users, d, S, head_mask, fusion_mode, predict_type, train_ptr?, train_items?, K) -> (idx, val)
+//   rank_metrics(topk_idx, truth_ptr, truth_items, metric_ids) -> f32[B x n_metrics x K]
+//   sample_triplets(user_ids, ptr, items, num_items, n, seed, epoch) -> (users, pos, neg)
+#include <ATen/ATen.h>
+#include <ATen/hip/HIPContext.h>
+#include <torch/library.h>
+
+#include <vector>
+
+#include "../../include/elimrec_hip.h"
+
+namespace {
+
+void *cur_stream() { return (void *)at::hip::getCurrentHIPStream().stream(); }
+
+void check(int rc, const char *what) {
+    if (rc != 0) {
+        const char *msg = elimrec_last_error();
+        TORCH_CHECK(false, "elimrec::", what, " failed (rc=", rc, "): ", msg ? msg : "?");
+    }
+}
+
+void need(const at::Tensor &t, const char *name, at::ScalarType dt, int64_t dim = -1) {
+    TORCH_CHECK(t.is_cuda(), "elimrec: '", name, "' must be a HIP device tensor (the hot path has no CPU implementation)");
+    TORCH_CHECK(t.scalar_type() == dt, "elimrec: '", name, "' has dtype ", t.scalar_type(), ", expected ", dt);
+    TORCH_CHECK(dim < 0 || t.dim() == dim, "elimrec: '", name, "' must be ", dim, "-D");
+}
+
+const at::Tensor rowmajor(const at::Tensor &t, const char *name) {
+    need(t, name, at::kFloat, 2);
+    return t.stride(1) == 1 ? t : t.contiguous();
+}
+
+at::Tensor propagate(const at::Tensor &rowptr, const at::Tensor &col, const at::Tensor &val, const at::Tensor &X, int64_t L) {
+    need(rowptr, "rowptr", at::kInt, 1); need(col, "col", at::kInt, 1); need(val, "val", at::kFloat, 1);
+    need(X, "X", at::kFloat, 2);
+    const at::Tensor x = X.contiguous(), rp = rowptr.contiguous(), c = col.contiguous(), v = val.contiguous();
+    const int64_t n = x.size(0), C = x.size(1);
+    TORCH_CHECK(rp.numel() == n + 1, "elimrec::propagate: rowptr has ", rp.numel(), " entries for ", n, " rows");
+    at::Tensor out = at::empty_like(x), t0 = at::empty_like(x), t1 = at::empty_like(x);
+    check(elimrec_propagate(rp.data_ptr<int32_t>(), c.data_ptr<int32_t>(), v.data_ptr<float>(), n, (int)C, nullptr, (int)L,
+                            x.data_ptr<float>(), t0.data_ptr<float>(), t1.data_ptr<float>(), out.data_ptr<float>(), cur_stream()),
+          "propagate");
+    return out;
+}
+
+at::Tensor linear_fwd(const at::Tensor &A, const at::Tensor &W, const c10::optional<at::Tensor> &bias) {
+    const at::Tensor a = rowmajor(A, "A"), w = rowmajor(W, "W");
+    TORCH_CHECK(a.size(1) == w.size(1), "elimrec::linear_fwd: A is [", a.size(0), " x ", a.size(1), "], W is [", w.size(0), " x ", w.size(1), "]");
+    at::Tensor b;
+    if (bias.has_value() && bias->defined()) { need(*bias, "bias", at::kFloat, 1); b = bias->contiguous(); }
+    at::Tensor out = at::empty({a.size(0), w.size(0)}, a.options());
+    check(elimrec_linear_fwd(a.data_ptr<float>(), a.stride(0), w.data_ptr<float>(), w.stride(0), b.defined() ? b.data_ptr<float>() : nullptr,
+                             out.data_ptr<float>(), out.stride(0), a.size(0), (int)w.size(0), (int)a.size(1), cur_stream()),
+          "linear_fwd");
+    return out;
+}
+
+std::tuple<at::Tensor, at::Tensor> linear_bwd_w(const at::Tensor &A, const at::Tensor &B) {
+    const at::Tensor a = rowmajor(A, "A"), b = rowmajor(B, "B");
+    TORCH_CHECK(a.size(0) == b.size(0), "elimrec::linear_bwd_w: row counts differ");
+    at::Tensor out = at::empty({a.size(1), b.size(1)}, a.options()), colsum = at::empty({a.size(1)}, a.options());
+    const size_t need_ws = elimrec_linear_bwd_w_workspace(a.size(0), (int)a.size(1), (int)b.size(1));
+    at::Tensor ws = at::empty({(int64_t)(need_ws ? need_ws : 1)}, a.options().dtype(at::kByte));
+    check(elimrec_linear_bwd_w(a.data_ptr<float>(), a.stride(0), b.data_ptr<float>(), b.stride(0), nullptr, nullptr, a.size(0),
+                               (int)a.size(1), (int)b.size(1), out.data_ptr<float>(), out.stride(0), colsum.data_ptr<float>(), 0,
+                               ws.data_ptr(), (size_t)ws.numel(), cur_stream()),
+          "linear_bwd_w");
+    return {out, colsum};
+}
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor> bpr_head_fwd(const at::Tensor &Y, int64_t U, int64_t I, const at::Tensor &users,
+                                                            const at::Tensor &pos, const at::Tensor &neg, int64_t d,
+                                                            std::vector<double> block_weights) {
+    const at::Tensor y = rowmajor(Y, "Y");
+    need(users, "users", at::kLong, 1); need(pos, "pos", at::kLong, 1); need(neg, "neg", at::kLong, 1);
+    const int64_t B = users.numel();
+    TORCH_CHECK(pos.numel() == B && neg.numel() == B, "elimrec::bpr_head_fwd: users / pos / neg differ in length");
+    TORCH_CHECK(y.size(0) == U + I && y.size(1) == d * (int64_t)block_weights.size(), "elimrec::bpr_head_fwd: Y must be [(U+I) x d*blocks]");
+    std::vector<float> w(block_weights.begin(), block_weights.end());
+    at::Tensor loss = at::empty({B}, y.options()), grad = at::empty({3 * B, y.size(1)}, y.options());
+    at::Tensor keys = at::empty({3 * B}, y.options().dtype(at::kInt));
+    const at::Tensor u = users.contiguous(), p = pos.contiguous(), n = neg.contiguous();
+    check(elimrec_bpr_head(y.data_ptr<float>(), y.stride(0), U, I, u.data_ptr<int64_t>(), p.data_ptr<int64_t>(), n.data_ptr<int64_t>(),
+                           (int)B, (int)d, (int)w.size(), w.data(), loss.data_ptr<float>(), grad.data_ptr<float>(),
+                           keys.data_ptr<int32_t>(), cur_stream()),
+          "bpr_head_fwd");
+    return {loss, grad, keys};
+}
+
+at::Tensor adam_step_(at::Tensor p, const at::Tensor &g, at::Tensor m, at::Tensor v, double lr, double beta1, double beta2,
+                      double eps, double weight_decay, int64_t step) {
+    need(p, "p", at::kFloat); need(g, "g", at::kFloat); need(m, "m", at::kFloat); need(v, "v", at::kFloat);
+    TORCH_CHECK(p.is_contiguous() && g.is_contiguous() && m.is_contiguous() && v.is_contiguous(), "elimrec::adam_step_: contiguous tensors");
+    TORCH_CHECK(g.numel() == p.numel() && m.numel() == p.numel() && v.numel() == p.numel(), "elimrec::adam_step_: sizes differ");
+    check(elimrec_adam_step(p.data_ptr<float>(), g.data_ptr<float>(), m.data_ptr<float>(), v.data_ptr<float>(), p.numel(), (float)lr,
+                            (float)beta1, (float)beta2, (float)eps, (float)weight_decay, step, cur_stream()),
+          "adam_step_");
+    return p;
+}
+
+std::tuple<at::Tensor, at::Tensor> score_topk(const at::Tensor &Y, int64_t U, int64_t I, const at::Tensor &users, int64_t d, int64_t S,
+                                              int64_t head_mask, int64_t fusion_mode, int64_t predict_type,
+                                              const c10::optional<at::Tensor> &train_ptr,
+                                              const c10::optional<at::Tensor> &train_items, int64_t K) {
+    const at::Tensor y = rowmajor(Y, "Y");
+    need(users, "users", at::kLong, 1);
+    const at::Tensor u = users.contiguous();
+    const int64_t B = u.numel();
+    TORCH_CHECK(K >= 1, "elimrec::score_topk: K >= 1");
+    at::Tensor tp, ti;
+    if (train_ptr.has_value() && train_ptr->defined()) {
+        TORCH_CHECK(train_items.has_value() && train_items->defined(), "elimrec::score_topk: train_ptr needs train_items");
+        need(*train_ptr, "train_ptr", at::kLong, 1); need(*train_items, "train_items", at::kInt, 1);
+        tp = train_ptr->contiguous(); ti = train_items->contiguous();
+    }
+    at::Tensor idx = at::empty({B, K}, y.options().dtype(at::kInt)), val = at::empty({B, K}, y.options());
+    const size_t need_ws = elimrec_score_workspace2((int)B, U, I, (int)S, (int)K);
+    at::Tensor ws = at::empty({(int64_t)(need_ws ? need_ws : 1)}, y.options().dtype(at::kByte));
+    check(elimrec_score_topk(y.data_ptr<float>(), y.stride(0), U, I, u.data_ptr<int64_t>(), (int)B, (int)d, (int)S, (uint32_t)head_mask,
+                             (int)fusion_mode, (int)predict_type, nullptr, tp.defined() ? tp.data_ptr<int64_t>() : nullptr,
+                             ti.defined() ? ti.data_ptr<int32_t>() : nullptr, nullptr, 0, (int)K, idx.data_ptr<int32_t>(),
+                             val.data_ptr<float>(), ws.data_ptr(), (size_t)ws.numel(), cur_stream()),
+          "score_topk");
+    return {idx, val};
+}
+
+at::Tensor rank_metrics(const at::Tensor &topk_idx, const at::Tensor &truth_ptr, const at::Tensor &truth_items,
+                        std::vector<int64_t> metric_ids) {
+    need(topk_idx, "topk_idx", at::kInt, 2); need(truth_ptr, "truth_ptr", at::kLong, 1); need(truth_items, "truth_items", at::kInt, 1);
+    const at::Tensor t = topk_idx.contiguous(), tp = truth_ptr.contiguous(), ti = truth_items.contiguous();
+    std::vector<int> ids(metric_ids.begin(), metric_ids.end());
+    at::Tensor out = at::empty({t.size(0), (int64_t)ids.size() * t.size(1)}, t.options().dtype(at::kFloat));
+    check(elimrec_rank_metrics(t.data_ptr<int32_t>(), (int)t.size(0), (int)t.size(1), tp.data_ptr<int64_t>(), ti.data_ptr<int32_t>(),
+                               ids.data(), (int)ids.size(), out.data_ptr<float>(), cur_stream()),
+          "rank_metrics");
+    return out;
+}
+
+std::tuple<at::Tensor, at::Tensor, at::Tensor> sample_triplets(const at::Tensor &user_ids, const at::Tensor &ptr, const at::Tensor &items,
+                                                               int64_t num_items, int64_t n, int64_t seed, int64_t epoch) {
+    need(user_ids, "user_ids", at::kInt, 1); need(ptr, "ptr", at::kLong, 1); need(items, "items", at::kInt, 1);
+    const at::Tensor uid = user_ids.contiguous(), p = ptr.contiguous(), it = items.contiguous();
+    at::Tensor u = at::empty({n}, p.options()), po = at::empty({n}, p.options()), ne = at::empty({n}, p.options());
+    check(elimrec_sample_triplets(uid.data_ptr<int32_t>(), p.data_ptr<int64_t>(), it.data_ptr<int32_t>(), uid.numel(), num_items, n,
+                                  (uint64_t)seed, (uint64_t)epoch, u.data_ptr<int64_t>(), po.data_ptr<int64_t>(), ne.data_ptr<int64_t>(),
+                                  cur_stream()),
+          "sample_triplets");
+    return {u, po, ne};
+}
+
+}  // namespace
+
+TORCH_LIBRARY(elimrec, m) {
+    m.def("propagate(Tensor rowptr, Tensor col, Tensor val, Tensor X, int L) -> Tensor");
+    m.def("linear_fwd(Tensor A, Tensor W, Tensor? bias) -> Tensor");
+    m.def("linear_bwd_w(Tensor A, Tensor B) -> (Tensor, Tensor)");
+    m.def("bpr_head_fwd(Tensor Y, int U, int I, Tensor users, Tensor pos, Tensor neg, int d, float[] block_weights) -> (Tensor, Tensor, Tensor)");
+    m.def("adam_step_(Tensor(a!) p, Tensor g, Tensor(b!) m, Tensor(c!) v, float lr, float beta1, float beta2, float eps, float weight_decay, int step) -> Tensor(a!)");
+    m.def("score_topk(Tensor Y, int U, int I, Tensor users, int d, int S, int head_mask, int fusion_mode, int predict_type, Tensor? train_ptr, Tensor? train_items, int K) -> (Tensor, Tensor)");
+    m.def("rank_metrics(Tensor topk_idx, Tensor truth_ptr, Tensor truth_items, int[] metric_ids) -> Tensor");
+    m.def("sample_triplets(Tensor user_ids, Tensor ptr, Tensor items, int num_items, int n, int seed, int epoch) -> (Tensor, Tensor, Tensor)");
+}
+
+TORCH_LIBRARY_IMPL(elimrec, CUDA, m) {
+    m.impl("propagate", &propagate);
+    m.impl("linear_fwd", &linear_fwd);
+    m.impl("linear_bwd_w", &linear_bwd_w);
+    m.impl("bpr_head_fwd", &bpr_head_fwd);
+    m.impl("adam_step_", &adam_step_);
+    m.impl("score_topk", &score_topk);
+    m.impl("rank_metrics", &rank_metrics);
+    m.impl("sample_triplets", &sample_triplets);
+}

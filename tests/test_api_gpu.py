@@ -204,3 +204,57 @@ def test_out_of_range_index_is_flagged_not_dereferenced():
     with pytest.raises(IndexError):
         model.check_indices()
     model.check_indices()          # the flag is cleared
+
+
+def test_torch_ops_match_the_ctypes_binding():
+    """torch.ops.elimrec.* (TORCH_LIBRARY over the C ABI) against the same entry points through ctypes / torch."""
+    from elimrec_amd import ops, torch_ops
+    import scipy.sparse as sp
+    t = torch_ops.load()
+    rng = np.random.RandomState(0)
+    n, C, L = 800, 64, 3
+    m = sp.random(n, n, density=0.01, random_state=rng, format="csr", dtype=np.float32)
+    m.sort_indices()
+    X = torch.randn(n, C, device=DEV)
+    rp, col, val = (_t(m.indptr.astype(np.int32)), _t(m.indices.astype(np.int32)), _t(m.data.astype(np.float32)))
+    got = t.propagate(rp, col, val, X, L)
+    A = torch.from_numpy(m.toarray()).to(DEV).double()
+    xs = [X.double()]
+    for _ in range(L):
+        xs.append(A @ xs[-1])
+    assert (got.double() - torch.stack(xs).mean(0)).abs().max().item() < 1e-5
+    # Linear forward / weight gradient
+    a, w, b = torch.randn(300, 128, device=DEV), torch.randn(64, 128, device=DEV), torch.randn(64, device=DEV)
+    assert (t.linear_fwd(a, w, b) - F.linear(a, w, b)).abs().max().item() < 1e-4
+    gw, gb = t.linear_bwd_w(a, torch.randn(300, 32, device=DEV).mul_(0).add_(1.0))
+    assert (gb - a.sum(0)).abs().max().item() < 1e-3 and gw.shape == (128, 32)
+    # Adam in place == the ctypes call
+    p, g, mm, vv = (torch.randn(1000, device=DEV) for _ in range(4))
+    vv.abs_()
+    p2, m2, v2 = p.clone(), mm.clone(), vv.clone()
+    out = t.adam_step_(p, g, mm, vv, 1e-3, 0.9, 0.999, 1e-8, 1e-4, 2)
+    ops.adam_step(p2, g, m2, v2, 1e-3, 0.9, 0.999, 1e-8, 1e-4, 2)
+    assert out.data_ptr() == p.data_ptr() and torch.equal(p, p2) and torch.equal(mm, m2) and torch.equal(vv, v2)
+    # scoring + top-K + metrics on a fixture
+    g_ = load_golden("ml3")
+    model, _ = build_model_from_fixture(g_, DEV)
+    model.compute()
+    users = torch.arange(20, device=DEV)
+    model.predict_type = "TIE"
+    idx_ref, val_ref = model.predict_device(users, top_k=10)
+    idx, vals = t.score_topk(model._ws["Y"], model.num_users, model.num_items, users, model.latent_dim, model.S, model._head_mask(),
+                             0, 2, None, None, 10)
+    assert torch.equal(idx, idx_ref) and torch.equal(vals, val_ref)
+    tp = torch.arange(0, 21, device=DEV, dtype=torch.int64)
+    ti = torch.arange(20, device=DEV, dtype=torch.int32)
+    want = torch.empty(20, 30, device=DEV)
+    ops.rank_metrics(idx_ref, tp, ti, [1, 2, 4], want)
+    assert torch.equal(t.rank_metrics(idx, tp, ti, [1, 2, 4]), want)
+    # loss rows of the BPR head
+    u, pp, nn_ = (_t(g_["step1/%s" % k]) for k in ("users", "pos", "neg"))
+    bw = model._block_weights()
+    loss_rows, grad_rows, keys = t.bpr_head_fwd(model._ws["Y"], model.num_users, model.num_items, u, pp, nn_, model.latent_dim, bw)
+    assert keys.numel() == 3 * u.numel() and grad_rows.shape == (3 * u.numel(), model.Cy)
+    assert abs(float(loss_rows.sum()) - float(g_["step1/loss"])) < 1e-5
+    with pytest.raises(RuntimeError):
+        t.propagate(rp[:-3], col, val, X, L)

@@ -194,3 +194,16 @@ def test_csv_dataset_loader_matches_reference_on_the_golden_data(tmp_path):
     for m in "vat":
         got = torch.nn.functional.normalize(getattr(ds, m + "_feat").float(), dim=1).numpy()
         assert np.array_equal(got, g[m + "_feat"]), m
+
+
+def test_torch_ops_library_registers_every_op():
+    """libelimrec_torch.so loads without a GPU and registers the TORCH_LIBRARY(elimrec) schema; a CPU tensor
+    has no kernel behind it -- the dispatcher says so instead of anything falling back."""
+    import pytest
+    import torch
+    from elimrec_amd import torch_ops
+    ns = torch_ops.load()
+    for name in torch_ops.OPS:
+        assert hasattr(ns, name), name
+    with pytest.raises(NotImplementedError):
+        ns.linear_fwd(torch.zeros(4, 4), torch.zeros(4, 4), None)
