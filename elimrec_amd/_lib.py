@@ -129,6 +129,13 @@ SIGNATURES = {
                                  c_ptr]),
     "elimrec_slab_rows": (c_i32, [c_sell, c_i32, c_i32, c_i32, c_i64, ctypes.POINTER(c_ptr), c_ptr, c_ptr, c_ptr, c_i64, c_i32,
                                   c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr]),
+    "elimrec_slab_hop16": (c_i32, [c_sell, c_i32, c_i32, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_f32, c_ptr, c_size,
+                                   c_i32, c_ptr]),
+    "elimrec_slab_rows16": (c_i32, [c_sell, c_i32, c_i32, c_i32, c_i64, c_ptr, ctypes.POINTER(c_ptr), c_ptr, c_ptr, c_ptr, c_i64,
+                                    c_i32, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr]),
+    "elimrec_slab_to_bf16": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr]),
+    "elimrec_adam_step_out16": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32,
+                                        c_i64, c_ptr]),
     "elimrec_slab_from_rows": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr]),
     "elimrec_slab_to_rows": (c_i32, [c_ptr, c_i64, c_i32, c_i32, c_ptr, c_i64, c_i64, c_ptr]),
     "elimrec_slab_merge_rows": (c_i32, [c_ptr, c_ptr, c_i32, c_i64, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr]),

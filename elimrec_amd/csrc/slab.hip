@@ -12,6 +12,7 @@
 // decreasing length; a lane group of LPR = spg*w/4 lanes owns one item, a wave 64/LPR items of similar length, and
 // the (col, val) of step j of the wave's items are consecutive in memory. HBM/L2-bound (9 flop per 4-B gathered).
 #include "common.h"
+#include <hip/hip_bf16.h>
 #include <cstdlib>
 
 namespace elimrec {
@@ -366,6 +367,344 @@ static int slab_variant() {
     return g_slab_variant;
 }
 
+// =====================================================================================================================
+// bf16 table storage (--table_dtype=bf16): the layer tables X^1..X^(L-1), the gather copy of X^0 and the adjoint's
+// intermediate tables are stored as bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32); every sum is accumulated in fp32 and
+// the master parameters, the gradient, the Adam moments, the adjoint sources and the layer means stay fp32. A lane owns 8
+// columns (one 16-B load of a bf16 row piece, or two of an fp32 one), so a 64-column row is 128 B = one cache line.
+struct Sell16Args {
+    const int32_t *item_dst, *item_len, *blk_off, *col;
+    const float *val;
+    int64_t n_rows, n_src;
+    int n_seg, n_long;
+    int item_begin, item_end, seg_limit;
+    int w8, w8_shift, gs, spg;
+    const void *Xin;               // bf16 table, or fp32 table (IN_F32: row-sparse source behind src_mask, may be null mask)
+    const uint32_t *src_mask;
+    void *Xout;                    // bf16 or fp32 (OUT_F32)
+    const float4 *Add;             // fp32 table
+    const uint32_t *add_mask;
+    float scale;
+    float4 *partials;
+    const int32_t *long_rows, *long_seg_ptr;
+    int compact_long;
+};
+
+__device__ __forceinline__ void unpack_bf16x8(const uint4 q, float (&x)[8]) {
+    x[0] = __uint_as_float(q.x << 16); x[1] = __uint_as_float(q.x & 0xFFFF0000u);
+    x[2] = __uint_as_float(q.y << 16); x[3] = __uint_as_float(q.y & 0xFFFF0000u);
+    x[4] = __uint_as_float(q.z << 16); x[5] = __uint_as_float(q.z & 0xFFFF0000u);
+    x[6] = __uint_as_float(q.w << 16); x[7] = __uint_as_float(q.w & 0xFFFF0000u);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    const __hip_bfloat16 a = __float2bfloat16(lo), b = __float2bfloat16(hi);
+    return (uint32_t)__bfloat16_as_ushort(a) | ((uint32_t)__bfloat16_as_ushort(b) << 16);
+}
+
+__device__ __forceinline__ uint4 pack_bf16x8(const float (&x)[8]) {
+    return make_uint4(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7]));
+}
+
+template <bool OUT_F32>
+__device__ __forceinline__ void slab16_epilogue(const Sell16Args &a, int slab, int64_t row, int c8, float (&r)[8]) {
+    const int64_t idx = ((int64_t)slab * a.n_rows + row) * a.w8 + c8;      // in units of 8 columns
+    if (a.Add && (!a.add_mask || bit_of(a.add_mask, (int)row))) {
+        const float4 t0 = a.Add[2 * idx], t1 = a.Add[2 * idx + 1];
+        r[0] += t0.x; r[1] += t0.y; r[2] += t0.z; r[3] += t0.w; r[4] += t1.x; r[5] += t1.y; r[6] += t1.z; r[7] += t1.w;
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) r[t] *= a.scale;
+    if (OUT_F32) {
+        float4 *o = (float4 *)a.Xout + 2 * idx;
+        o[0] = make_float4(r[0], r[1], r[2], r[3]);
+        o[1] = make_float4(r[4], r[5], r[6], r[7]);
+    } else {
+        ((uint4 *)a.Xout)[idx] = pack_bf16x8(r);
+    }
+}
+
+template <int LPR, bool IN_F32, bool OUT_F32>
+__global__ __launch_bounds__(256) void sell_hop16_kernel(Sell16Args a) {
+    constexpr int IPW = 64 / LPR, U = 4;
+    const int lane = threadIdx.x & 63;
+    const int grp = (int)(blockIdx.x % (unsigned)a.gs);
+    const int64_t wblk = (int64_t)(blockIdx.x / (unsigned)a.gs) * 4 + (threadIdx.x >> 6);
+    const int64_t first = (int64_t)a.item_begin + wblk * IPW;
+    if (first >= a.item_end) return;
+    const int64_t item = first + lane / LPR;
+    const int cl = lane % LPR;
+    const int len = a.item_len[item];
+    const int dst = a.item_dst[item];
+    const int slab = grp * a.spg + (cl >> a.w8_shift);
+    const int c8 = cl & (a.w8 - 1);
+    const int64_t base = (int64_t)slab * a.n_src * a.w8 + c8;
+    const uint4 *X16 = (const uint4 *)a.Xin + base;
+    const float4 *X32 = (const float4 *)a.Xin + 2 * base;
+    const int64_t e0 = ((int64_t)a.blk_off[item >> 6] << 6) + (item & 63);
+    const int32_t *colp = a.col + e0;
+    const float *valp = a.val + e0;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int ncj[U];
+    float nvj[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const bool in = u < len;
+        ncj[u] = in ? colp[(int64_t)u << 6] : 0;
+        nvj[u] = in ? valp[(int64_t)u << 6] : 0.f;
+    }
+    for (int j = 0; j < len; j += U) {
+        int cj[U];
+        float vj[U];
+        bool in[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { in[u] = (j + u) < len; cj[u] = ncj[u]; vj[u] = nvj[u]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool nin = (j + U + u) < len;
+            ncj[u] = nin ? colp[(int64_t)(j + U + u) << 6] : 0;
+            nvj[u] = nin ? valp[(int64_t)(j + U + u) << 6] : 0.f;
+        }
+        if (IN_F32 && a.src_mask) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) in[u] = in[u] && bit_of(a.src_mask, cj[u]);
+        }
+        if (IN_F32) {
+            float4 x0[U], x1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                x0[u] = in[u] ? X32[(int64_t)cj[u] * a.w8 * 2] : z;
+                x1[u] = in[u] ? X32[(int64_t)cj[u] * a.w8 * 2 + 1] : z;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc[0] = fmaf(vj[u], x0[u].x, acc[0]); acc[1] = fmaf(vj[u], x0[u].y, acc[1]);
+                acc[2] = fmaf(vj[u], x0[u].z, acc[2]); acc[3] = fmaf(vj[u], x0[u].w, acc[3]);
+                acc[4] = fmaf(vj[u], x1[u].x, acc[4]); acc[5] = fmaf(vj[u], x1[u].y, acc[5]);
+                acc[6] = fmaf(vj[u], x1[u].z, acc[6]); acc[7] = fmaf(vj[u], x1[u].w, acc[7]);
+            }
+        } else {
+            uint4 q[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) q[u] = in[u] ? X16[(int64_t)cj[u] * a.w8] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                float x[8];
+                unpack_bf16x8(q[u], x);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc[t] = fmaf(vj[u], x[t], acc[t]);
+            }
+        }
+    }
+    if (dst < 0) return;
+    if (item < a.seg_limit) {
+        float4 *P = a.partials + 2 * (((int64_t)slab * a.n_seg + dst) * a.w8 + c8);
+        P[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        P[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        return;
+    }
+    if (a.compact_long) return;
+    slab16_epilogue<OUT_F32>(a, slab, dst, c8, acc);
+}
+
+template <int LPR, bool OUT_F32>
+__global__ __launch_bounds__(256) void sell_fixup16_kernel(Sell16Args a) {
+    constexpr int NQ = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int grp = (int)(blockIdx.x % (unsigned)a.gs);
+    const int li = (int)(blockIdx.x / (unsigned)a.gs) * 4 + (int)(threadIdx.x >> 6);
+    if (li >= a.n_long) return;
+    const int q = lane / LPR, cl = lane % LPR;
+    const int slab = grp * a.spg + (cl >> a.w8_shift);
+    const int c8 = cl & (a.w8 - 1);
+    const int sb = a.long_seg_ptr[li], se = a.long_seg_ptr[li + 1];
+    const int per = (se - sb + NQ - 1) / NQ;
+    const int qb = min(sb + q * per, se), qe = min(qb + per, se);
+    const float4 *P = a.partials + 2 * ((int64_t)slab * a.n_seg * a.w8 + c8);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int sgm = qb;
+    for (; sgm + 4 <= qe; sgm += 4) {
+        float4 p0[4], p1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { p0[u] = P[(int64_t)(sgm + u) * a.w8 * 2]; p1[u] = P[(int64_t)(sgm + u) * a.w8 * 2 + 1]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc[0] += p0[u].x; acc[1] += p0[u].y; acc[2] += p0[u].z; acc[3] += p0[u].w;
+            acc[4] += p1[u].x; acc[5] += p1[u].y; acc[6] += p1[u].z; acc[7] += p1[u].w;
+        }
+    }
+    for (; sgm < qe; ++sgm) {
+        const float4 p0 = P[(int64_t)sgm * a.w8 * 2], p1 = P[(int64_t)sgm * a.w8 * 2 + 1];
+        acc[0] += p0.x; acc[1] += p0.y; acc[2] += p0.z; acc[3] += p0.w; acc[4] += p1.x; acc[5] += p1.y; acc[6] += p1.z; acc[7] += p1.w;
+    }
+    float tot[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        tot[t] = acc[t];
+        if (NQ > 1) {
+            tot[t] = __shfl(acc[t], cl, 64);
+#pragma unroll
+            for (int g = 1; g < NQ; ++g) tot[t] += __shfl(acc[t], g * LPR + cl, 64);
+        }
+    }
+    if (q != 0) return;
+    if (a.compact_long) {
+        float4 *o = (float4 *)a.Xout + 2 * (((int64_t)slab * a.n_long + li) * a.w8 + c8);
+        o[0] = make_float4(tot[0], tot[1], tot[2], tot[3]);
+        o[1] = make_float4(tot[4], tot[5], tot[6], tot[7]);
+    } else slab16_epilogue<OUT_F32>(a, slab, a.long_rows[li], c8, tot);
+}
+
+struct Rows16Args {
+    const float4 *x0;                              // fp32 master table
+    const uint4 *x[kSlabMaxLayers + 1];            // bf16 layer tables 1..L (x[L] may be null)
+    int L;
+    int64_t U, n_rows;
+    int nc8, w8, w8_shift;
+    const float4 *long_tab;
+    int n_long;
+    const int32_t *long_index, *rowptr, *col;
+    const float *val;
+    const int32_t *rows, *counts;
+    int64_t R;
+    int n_lists;
+    float *out0;
+    int64_t ld_out0;
+    float *narrow;
+    int64_t ld_narrow;
+    int by_node;
+    float inv;
+};
+
+template <int LR>
+__global__ __launch_bounds__(256) void slab_rows16_kernel(Rows16Args a) {
+    const int64_t s = (int64_t)blockIdx.x * (256 / LR) + threadIdx.x / LR;
+    const int cl = threadIdx.x % LR;
+    if (s >= a.R * a.n_lists) return;
+    int64_t r = s;
+    if (a.rows) {
+        const int64_t list = s / a.R;
+        if (s - list * a.R >= a.counts[list]) return;
+        r = a.rows[s];
+    }
+    const bool user = r < a.U;
+    const bool inline_hop = a.x[a.L] == nullptr;
+    int li = -1, beg = 0, end = 0;
+    if (inline_hop) {
+        li = a.long_index[r];
+        if (li < 0) { beg = a.rowptr[r]; end = a.rowptr[r + 1]; }
+    }
+    for (int c = cl; c < a.nc8; c += LR) {
+        const int slab = c >> a.w8_shift, c8 = c & (a.w8 - 1);
+        const int64_t idx = ((int64_t)slab * a.n_rows + r) * a.w8 + c8;
+        float xl[8];
+        if (!inline_hop) unpack_bf16x8(a.x[a.L][idx], xl);
+        else if (li >= 0) {
+            const float4 *p = a.long_tab + 2 * (((int64_t)slab * a.n_long + li) * a.w8 + c8);
+            const float4 p0 = p[0], p1 = p[1];
+            xl[0] = p0.x; xl[1] = p0.y; xl[2] = p0.z; xl[3] = p0.w; xl[4] = p1.x; xl[5] = p1.y; xl[6] = p1.z; xl[7] = p1.w;
+        } else {
+            const void *src = (a.L == 1) ? (const void *)a.x0 : (const void *)a.x[a.L - 1];
+            const int64_t base = (int64_t)slab * a.n_rows * a.w8 + c8;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) xl[t] = 0.f;
+            for (int j = beg; j < end; j += 4) {
+                int cj[4];
+                float vj[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool in = (j + u) < end;
+                    cj[u] = in ? a.col[j + u] : 0;
+                    vj[u] = in ? a.val[j + u] : 0.f;
+                }
+                if (a.L == 1) {            // the gather source is the fp32 master itself
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if ((j + u) < end) {
+                            const float4 *p = (const float4 *)src + 2 * (base + (int64_t)cj[u] * a.w8);
+                            const float4 p0 = p[0], p1 = p[1];
+                            xl[0] = fmaf(vj[u], p0.x, xl[0]); xl[1] = fmaf(vj[u], p0.y, xl[1]); xl[2] = fmaf(vj[u], p0.z, xl[2]);
+                            xl[3] = fmaf(vj[u], p0.w, xl[3]); xl[4] = fmaf(vj[u], p1.x, xl[4]); xl[5] = fmaf(vj[u], p1.y, xl[5]);
+                            xl[6] = fmaf(vj[u], p1.z, xl[6]); xl[7] = fmaf(vj[u], p1.w, xl[7]);
+                        }
+                    }
+                } else {
+                    uint4 q[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        q[u] = (j + u) < end ? ((const uint4 *)src)[base + (int64_t)cj[u] * a.w8] : make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        float x[8];
+                        unpack_bf16x8(q[u], x);
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) xl[t] = fmaf(vj[u], x[t], xl[t]);
+                    }
+                }
+            }
+        }
+        float x0[8], x1[8], sum[8], nar[8];
+        {
+            const float4 p0 = a.x0[2 * idx], p1 = a.x0[2 * idx + 1];
+            x0[0] = p0.x; x0[1] = p0.y; x0[2] = p0.z; x0[3] = p0.w; x0[4] = p1.x; x0[5] = p1.y; x0[6] = p1.z; x0[7] = p1.w;
+        }
+        if (a.L == 1) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) x1[t] = xl[t];
+        } else unpack_bf16x8(a.x[1][idx], x1);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { sum[t] = x0[t] + x1[t]; nar[t] = user ? x0[t] : x1[t]; }
+        for (int k = 2; k <= a.L; ++k) {
+            float v[8];
+            if (k == a.L) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] = xl[t];
+            } else unpack_bf16x8(a.x[k][idx], v);
+            const bool mine = ((k & 1) == 0) == user;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) { sum[t] += v[t]; if (mine) nar[t] += v[t]; }
+        }
+        float4 *o = reinterpret_cast<float4 *>(a.out0 + s * a.ld_out0 + 8 * c);
+        o[0] = make_float4(sum[0] * a.inv, sum[1] * a.inv, sum[2] * a.inv, sum[3] * a.inv);
+        o[1] = make_float4(sum[4] * a.inv, sum[5] * a.inv, sum[6] * a.inv, sum[7] * a.inv);
+        float4 *q2 = reinterpret_cast<float4 *>(a.narrow + (a.by_node ? r : s) * a.ld_narrow + 8 * c);
+        q2[0] = make_float4(nar[0] * a.inv, nar[1] * a.inv, nar[2] * a.inv, nar[3] * a.inv);
+        q2[1] = make_float4(nar[4] * a.inv, nar[5] * a.inv, nar[6] * a.inv, nar[7] * a.inv);
+    }
+}
+
+__global__ void slab_to_bf16_kernel(const float4 *__restrict__ src, int64_t n8, uint4 *__restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = src[2 * i], b = src[2 * i + 1];
+        const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        dst[i] = pack_bf16x8(x);
+    }
+}
+
+// Adam with the parameters read from p_in and written to p_out AND, rounded, to the bf16 gather copy
+__global__ void adam_out16_kernel(const float4 *__restrict__ p_in, float4 *__restrict__ p_out, uint2 *__restrict__ p16,
+                                  const float4 *__restrict__ g, float4 *__restrict__ m, float4 *__restrict__ v, int64_t n4,
+                                  float step_size, float beta1, float beta2, float inv_sqrt_bc2, float eps, float wd) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 P = p_in[i], G = g[i], M = m[i], V = v[i];
+        float pi[4] = {P.x, P.y, P.z, P.w}, gi[4] = {G.x, G.y, G.z, G.w}, mi[4] = {M.x, M.y, M.z, M.w}, vi[4] = {V.x, V.y, V.z, V.w};
+        float po[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float gg = fmaf(wd, pi[t], gi[t]);
+            mi[t] = mi[t] + (1.f - beta1) * (gg - mi[t]);
+            vi[t] = fmaf(1.f - beta2, gg * gg, beta2 * vi[t]);
+            const float denom = sqrtf(vi[t]) * inv_sqrt_bc2 + eps;
+            po[t] = pi[t] - step_size * (mi[t] / denom);
+        }
+        m[i] = make_float4(mi[0], mi[1], mi[2], mi[3]);
+        v[i] = make_float4(vi[0], vi[1], vi[2], vi[3]);
+        p_out[i] = make_float4(po[0], po[1], po[2], po[3]);
+        p16[i] = make_uint2(pack_bf16x2(po[0], po[1]), pack_bf16x2(po[2], po[3]));
+    }
+}
+
 static int log2_pow2(int x) {
     int s = 0;
     while ((1 << s) < x) ++s;
@@ -570,5 +909,142 @@ extern "C" int elimrec_adam_step_out(const float *d_p_in, float *d_p_out, const 
     hipLaunchKernelGGL(adam_out_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_p_in, d_p_out, d_g, d_m,
                        d_v, n, step_size, beta1, beta2, inv_sqrt_bc2, eps, weight_decay);
     ELIMREC_LAUNCH_CHECK("adam_step_out");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------- bf16 storage
+static int slab16_geometry(const char *who, int ns, int w, int gs, int &w8_shift, int &spg, int &lpr) {
+    w8_shift = (w > 0 && w % 8 == 0) ? log2_pow2(w / 8) : -1;
+    if (ns < 1 || w8_shift < 0) { set_error("%s: bf16 slab width must be 8 * 2^k (got w=%d, ns=%d)", who, w, ns); return ELIMREC_E_BADARG; }
+    if (gs < 1 || ns % gs != 0) { set_error("%s: %d slab groups do not divide %d slabs", who, gs, ns); return ELIMREC_E_BADARG; }
+    spg = ns / gs;
+    if (log2_pow2(spg) < 0 || spg * (w / 8) > 64) { set_error("%s: bad slabs per group %d", who, spg); return ELIMREC_E_BADARG; }
+    lpr = spg * (w / 8);
+    return 0;
+}
+
+extern "C" int elimrec_slab_hop16(const elimrec_sell *A, int ns, int w, int gs, const void *d_Xin, int in_f32,
+                                  const uint32_t *d_src_mask, void *d_Xout, int out_f32, const float *d_add,
+                                  const uint32_t *d_add_mask, float scale, float *d_partials, size_t partials_bytes,
+                                  int seg_only, void *stream) {
+    ELIMREC_REQUIRE(A && d_Xin && d_Xout && d_Xin != d_Xout, "slab_hop16: bad pointers");
+    ELIMREC_REQUIRE(in_f32 || !d_src_mask, "slab_hop16: a source bitmap goes with an fp32 (row-sparse) source");
+    ELIMREC_REQUIRE(A->n_items % 64 == 0 && A->n_seg_items % 64 == 0 && A->n_seg_items <= A->n_items, "slab_hop16: bad plan");
+    int w8_shift, spg, lpr, rc;
+    if ((rc = slab16_geometry("slab_hop16", ns, w, gs, w8_shift, spg, lpr))) return rc;
+    if (A->n_long > 0 && (!d_partials || partials_bytes < elimrec_slab_partials_bytes(A, ns, w))) {
+        set_error("slab_hop16: partial-row scratch too small");
+        return ELIMREC_E_WORKSPACE;
+    }
+    Sell16Args a = {};
+    a.item_dst = A->d_item_dst; a.item_len = A->d_item_len; a.blk_off = A->d_blk_off; a.col = A->d_col; a.val = A->d_val;
+    a.n_rows = A->n_rows; a.n_src = A->n_src; a.n_seg = A->n_seg; a.n_long = A->n_long;
+    a.item_begin = 0; a.item_end = seg_only ? A->n_seg_items : A->n_items; a.seg_limit = A->n_seg_items;
+    a.w8 = w / 8; a.w8_shift = w8_shift; a.gs = gs; a.spg = spg;
+    a.Xin = d_Xin; a.src_mask = d_src_mask; a.Xout = d_Xout;
+    a.Add = seg_only ? nullptr : (const float4 *)d_add; a.add_mask = d_add_mask; a.scale = seg_only ? 1.0f : scale;
+    a.partials = (float4 *)d_partials; a.long_rows = A->d_long_rows; a.long_seg_ptr = A->d_long_seg_ptr;
+    a.compact_long = seg_only ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int n_it = a.item_end - a.item_begin;
+    const bool of = out_f32 != 0 || seg_only;
+#define ELIMREC_SELL16(LPR)                                                                                         \
+    do {                                                                                                            \
+        if (n_it > 0) {                                                                                             \
+            const unsigned blocks = (unsigned)(((int64_t)n_it / (64 / LPR) + 3) / 4) * (unsigned)gs;                \
+            if (in_f32 && of) hipLaunchKernelGGL((sell_hop16_kernel<LPR, true, true>), dim3(blocks), dim3(256), 0, s, a);   \
+            else if (in_f32) hipLaunchKernelGGL((sell_hop16_kernel<LPR, true, false>), dim3(blocks), dim3(256), 0, s, a);   \
+            else if (of) hipLaunchKernelGGL((sell_hop16_kernel<LPR, false, true>), dim3(blocks), dim3(256), 0, s, a);       \
+            else hipLaunchKernelGGL((sell_hop16_kernel<LPR, false, false>), dim3(blocks), dim3(256), 0, s, a);              \
+        }                                                                                                           \
+        if (A->n_long > 0) {                                                                                        \
+            const unsigned blocks = (unsigned)((A->n_long + 3) / 4) * (unsigned)gs;                                 \
+            if (of) hipLaunchKernelGGL((sell_fixup16_kernel<LPR, true>), dim3(blocks), dim3(256), 0, s, a);         \
+            else hipLaunchKernelGGL((sell_fixup16_kernel<LPR, false>), dim3(blocks), dim3(256), 0, s, a);           \
+        }                                                                                                           \
+    } while (0)
+    switch (lpr) {
+        case 1: ELIMREC_SELL16(1); break;
+        case 2: ELIMREC_SELL16(2); break;
+        case 4: ELIMREC_SELL16(4); break;
+        case 8: ELIMREC_SELL16(8); break;
+        case 16: ELIMREC_SELL16(16); break;
+        case 32: ELIMREC_SELL16(32); break;
+        default: ELIMREC_SELL16(64); break;
+    }
+#undef ELIMREC_SELL16
+    ELIMREC_LAUNCH_CHECK("slab_hop16");
+    return 0;
+}
+
+extern "C" int elimrec_slab_rows16(const elimrec_sell *A, int ns, int w, int L, int64_t U, const float *d_x0,
+                                   const void *const *layers16, const float *d_long, const int32_t *d_rows,
+                                   const int32_t *d_counts, int64_t R, int n_lists, float *d_out0, int64_t ld_out0,
+                                   float *d_narrow, int64_t ld_narrow, int narrow_by_node, void *stream) {
+    ELIMREC_REQUIRE(A && d_x0 && layers16 && d_out0 && d_narrow, "slab_rows16: null pointer");
+    ELIMREC_REQUIRE(L >= 1 && L <= kSlabMaxLayers, "slab_rows16: 1 <= L <= %d", kSlabMaxLayers);
+    ELIMREC_REQUIRE(ld_out0 % 4 == 0 && ld_narrow % 4 == 0, "slab_rows16: leading dimensions must be multiples of 4");
+    ELIMREC_REQUIRE(n_lists >= 1 && (d_rows ? d_counts != nullptr : n_lists == 1), "slab_rows16: row lists need their counts");
+    int w8_shift, spg, lpr, rc;
+    if ((rc = slab16_geometry("slab_rows16", ns, w, ns, w8_shift, spg, lpr))) return rc;
+    Rows16Args a = {};
+    a.x0 = (const float4 *)d_x0;
+    a.x[0] = nullptr;
+    for (int k = 1; k <= L; ++k) a.x[k] = (const uint4 *)layers16[k - 1];
+    for (int k = 1; k < L; ++k) ELIMREC_REQUIRE(a.x[k], "slab_rows16: layer table %d missing", k);
+    ELIMREC_REQUIRE(a.x[L] || (A->d_rowptr && A->d_csr_col && A->d_csr_val && A->d_long_index && (A->n_long == 0 || d_long)),
+                    "slab_rows16: the inline last hop needs the CSR, the long-row index and the long-row table");
+    a.L = L; a.U = U; a.n_rows = A->n_rows; a.nc8 = ns * (w / 8); a.w8 = w / 8; a.w8_shift = w8_shift;
+    a.long_tab = (const float4 *)d_long; a.n_long = A->n_long; a.long_index = A->d_long_index;
+    a.rowptr = A->d_rowptr; a.col = A->d_csr_col; a.val = A->d_csr_val;
+    a.rows = d_rows; a.counts = d_counts; a.R = R; a.n_lists = n_lists;
+    a.out0 = d_out0; a.ld_out0 = ld_out0; a.narrow = d_narrow; a.ld_narrow = ld_narrow; a.by_node = narrow_by_node;
+    a.inv = 1.0f / (float)(L + 1);
+    const int64_t total = R * n_lists;
+    if (total <= 0) return 0;
+    int lr = 1;
+    while (lr < a.nc8 && lr < 64) lr *= 2;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned blocks = (unsigned)((total + (256 / lr) - 1) / (256 / lr));
+    switch (lr) {
+        case 1: hipLaunchKernelGGL((slab_rows16_kernel<1>), dim3(blocks), dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((slab_rows16_kernel<2>), dim3(blocks), dim3(256), 0, s, a); break;
+        case 4: hipLaunchKernelGGL((slab_rows16_kernel<4>), dim3(blocks), dim3(256), 0, s, a); break;
+        case 8: hipLaunchKernelGGL((slab_rows16_kernel<8>), dim3(blocks), dim3(256), 0, s, a); break;
+        case 16: hipLaunchKernelGGL((slab_rows16_kernel<16>), dim3(blocks), dim3(256), 0, s, a); break;
+        case 32: hipLaunchKernelGGL((slab_rows16_kernel<32>), dim3(blocks), dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((slab_rows16_kernel<64>), dim3(blocks), dim3(256), 0, s, a); break;
+    }
+    ELIMREC_LAUNCH_CHECK("slab_rows16");
+    return 0;
+}
+
+extern "C" int elimrec_slab_to_bf16(const float *d_src, int64_t n_elems, void *d_dst, void *stream) {
+    ELIMREC_REQUIRE(d_src && d_dst && n_elems % 8 == 0, "slab_to_bf16: element count must be a multiple of 8");
+    if (n_elems <= 0) return 0;
+    int64_t blocks = (n_elems / 8 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(slab_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)d_src,
+                       n_elems / 8, (uint4 *)d_dst);
+    ELIMREC_LAUNCH_CHECK("slab_to_bf16");
+    return 0;
+}
+
+extern "C" int elimrec_adam_step_out16(const float *d_p_in, float *d_p_out, void *d_p_bf16, const float *d_g, float *d_m,
+                                       float *d_v, int64_t n, float lr, float beta1, float beta2, float eps,
+                                       float weight_decay, int64_t step, void *stream) {
+    ELIMREC_REQUIRE(d_p_in && d_p_out && d_p_bf16 && d_g && d_m && d_v, "adam_step_out16: null pointer");
+    ELIMREC_REQUIRE(step >= 1 && n % 4 == 0, "adam_step_out16: step is 1-based, n a multiple of 4");
+    if (n <= 0) return 0;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(adam_out16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)d_p_in,
+                       (float4 *)d_p_out, (uint2 *)d_p_bf16, (const float4 *)d_g, (float4 *)d_m, (float4 *)d_v, n / 4, step_size,
+                       beta1, beta2, inv_sqrt_bc2, eps, weight_decay);
+    ELIMREC_LAUNCH_CHECK("adam_step_out16");
     return 0;
 }

@@ -58,13 +58,18 @@ class ColumnShardTrainer(object):
         if self.profile_kernels and getattr(eng, "kernel_events", None) is None:
             eng.kernel_events = self._events
         act = eng.cs_plan(users, pos, neg)                       # int32 [R]: sorted unique node ids, negative padding
+        h_ids = None
         if W > 1:
+            # the id exchange runs on RCCL's stream under the forward hops, which do not need it
             acts = self._like("acts", act, W)
-            dist.all_gather_into_tensor(acts.view(-1), act, group=self.group)
+            h_ids = dist.all_gather_into_tensor(acts.view(-1), act, group=self.group, async_op=True)
             self.xgmi_bytes["all_gather"] = act.numel() * 4 * (W - 1)
         else:
             acts = act.view(1, -1)
-        send = eng.cs_forward(acts)                              # [W, R, 2*dl]: peers' rows, my columns
+        eng.cs_forward_hops()                                    # hops 1..L-1 of my column slice: no communication
+        if h_ids is not None:
+            h_ids.wait()
+        send = eng.cs_forward_rows(acts)                         # [W, R, 2*dl]: layer means of the peers' rows, my columns
         if W > 1:
             recv = self._like("recv_f", send)
             dist.all_to_all_single(recv, send, group=self.group)
@@ -75,15 +80,19 @@ class ColumnShardTrainer(object):
         if self._scale is None:
             self._scale = torch.full((1,), 1.0 / W, dtype=torch.float32, device=loss.device)
         send2, wgrads = eng.cs_backward_local(self._scale)       # [W, R, 2*dl]: my rows, the peers' columns
+        h_w = None
         if W > 1:
             recv2 = self._like("recv_b", send2)
             dist.all_to_all_single(recv2, send2, group=self.group)
-            dist.all_reduce(wgrads, op=dist.ReduceOp.SUM, group=self.group)
+            # the projection-weight gradients are needed by the optimizer step only: reduced under the adjoint hops
+            h_w = dist.all_reduce(wgrads, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self.xgmi_bytes["all_to_all_bwd"] = send2[0].numel() * 4 * (W - 1)
             self.xgmi_bytes["all_reduce"] = wgrads.numel() * 4
         else:
             recv2 = send2
         eng.cs_backward_hops(recv2, acts)
+        if h_w is not None:
+            h_w.wait()
         eng.cs_update()
         return loss
 
@@ -106,7 +115,16 @@ class ColumnShardEngine(object):
     """The cs_* interface on the HIP kernels, around an EliMRec model (which keeps the plan, the folded constants, the
     head kernels' workspace, the projection weights and the cached tables predict() reads)."""
 
-    def __init__(self, model, group=None):
+    def __init__(self, model, group=None, table_dtype=None):
+        """table_dtype: "f32" (default) or "bf16" -- bf16 STORAGE of the layer tables, of the gather copy of X^0 and of the
+        adjoint's intermediate tables with fp32 accumulation and fp32 master parameters / moments (also the config key
+        --table_dtype). A separately toleranced mode, never the parity path."""
+        cfg = model.config
+        if table_dtype is None:
+            table_dtype = str(cfg["table_dtype"]) if "table_dtype" in cfg else "f32"
+        if table_dtype not in ("f32", "bf16"):
+            raise ValueError("table_dtype must be 'f32' or 'bf16' (got %r)" % (table_dtype,))
+        self.bf16 = table_dtype == "bf16"
         if not getattr(model, "_lazy", False):
             raise ValueError("the column-sharded engine needs the folded propagation with batch head rows "
                              "(bipartite adjacency: adj_type pre/plain/gcmc; layer_num >= 2; --head_rows=batch)")
@@ -123,22 +141,25 @@ class ColumnShardEngine(object):
             raise ValueError("recdim %d cannot be split into %d column slices of a multiple of 4" % (d, world))
         self.world, self.rank, self.opt = world, rank, optimizer
         self.dl, self.col0 = d // world, rank * (d // world)
-        self.ns, self.w = slab.choose_slabs(self.dl, N)
+        self.ns, self.w = slab.choose_slabs16(self.dl) if self.bf16 else slab.choose_slabs(self.dl, N)
         self.gs = slab.choose_groups(self.ns)
         adj = m._scipy_adj()
         self.plan = slab.SellPlan(adj, dev, side_split=m.num_users)
         self.planT = self.plan if m._adj_symmetric else slab.SellPlan(adj.T.tocsr(), dev, side_split=m.num_users)
         tab = lambda: slab.SlabTable(N, self.ns, self.w, dev)
+        tdt = torch.bfloat16 if self.bf16 else torch.float32
+        ttab = lambda: slab.SlabTable(N, self.ns, self.w, dev, dtype=tdt)      # a propagated (stored) table
         L = m.n_layers
         self.master = [tab(), tab()]
+        self.mirror = [ttab(), ttab()] if self.bf16 else None       # bf16 gather copies of the two master buffers
         self.cur = 0
-        self.layers = [None] + [tab() for _ in range(L - 1)]
+        self.layers = [None] + [ttab() for _ in range(L - 1)]
         self.long_tab = torch.empty(self.ns * max(self.plan.n_long, 1) * self.w, dtype=torch.float32, device=dev)
         self.xL = None                                            # full hop-L table, only when predict() needs it
         self.grad = tab()
         self.m1 = torch.zeros_like(self.grad.data)
         self.m2 = torch.zeros_like(self.grad.data)
-        self.srcA, self.srcB, self.tmp = tab(), tab(), [tab(), tab()]
+        self.srcA, self.srcB, self.tmp = tab(), tab(), [ttab(), ttab()]
         self.mask = torch.zeros((N + 31) // 32 + 2, dtype=torch.int32, device=dev)
         self.step_count = 0
         self._bufs = {}
@@ -156,6 +177,8 @@ class ColumnShardEngine(object):
         m = self.model
         ws = m._workspace(m._ws_key[1] if m._ws_key else 1)
         self.master[self.cur].from_rows(ws["X0d"], col0=self.col0)
+        if self.bf16:
+            self.master[self.cur].to_bf16(self.mirror[self.cur])
 
     @torch.no_grad()
     def sync_to_model(self):
@@ -218,14 +241,27 @@ class ColumnShardEngine(object):
         return act
 
     @torch.no_grad()
-    def cs_forward(self, acts):
+    def cs_forward_hops(self):
+        m = self.model
+        L = m.n_layers
+        x0 = self.master[self.cur]
+        self._x0_fwd = x0
+        tabs = self._tabs = [x0] + self.layers[1:]
+        # what the hops GATHER from: the bf16 copy of the master in bf16-storage mode, the tables themselves otherwise
+        srcs = self._srcs = ([self.mirror[self.cur]] if self.bf16 else [x0]) + self.layers[1:]
+
+        def hops():
+            for k in range(1, L):
+                slab.hop(self.plan, srcs[k - 1], tabs[k], gs=self.gs)
+        self._timed(lambda: m._region("cs_fwd_hops%d" % self.cur, (m._ws_gen,), hops), L - 1)
+
+    @torch.no_grad()
+    def cs_forward_rows(self, acts):
         m = self.model
         ws, L, U = m._ws, m.n_layers, m.num_users
         W, R = acts.shape
-        x0 = self.master[self.cur]
-        self._x0_fwd = x0
+        tabs = self._tabs
         self._acts = acts
-        tabs = [x0] + self.layers[1:]
         if W > 1:
             torch.sum(acts >= 0, dim=1, dtype=torch.int32, out=self.counts)
             counts = self.counts
@@ -234,18 +270,21 @@ class ColumnShardEngine(object):
             counts = ws["seg_info"][0:1]
             out0, narrow, by_node = ws["OutAct"][:R, :m.latent_dim], ws["Narrow"], True
 
-        def hops():
-            for k in range(1, L):
-                slab.hop(self.plan, tabs[k - 1], tabs[k], gs=self.gs)
-        self._timed(lambda: m._region("cs_fwd_hops%d" % self.cur, (m._ws_gen,), hops), L - 1)
-
         def rows():
             if self.plan.n_long:
-                slab.hop(self.plan, tabs[L - 1], self.long_tab, gs=self.gs, seg_only=True)
-            slab.rows(self.plan, self.ns, self.w, L, U, [t.data for t in tabs] + [None], self.long_tab, acts, counts, R, W,
-                      out0, narrow, by_node)
+                slab.hop(self.plan, self._srcs[L - 1], self.long_tab, gs=self.gs, seg_only=True)
+            if self.bf16:
+                slab.rows16(self.plan, self.ns, self.w, L, U, tabs[0].data, [t.data for t in tabs[1:]] + [None], self.long_tab,
+                            acts, counts, R, W, out0, narrow, by_node)
+            else:
+                slab.rows(self.plan, self.ns, self.w, L, U, [t.data for t in tabs] + [None], self.long_tab, acts, counts, R, W,
+                          out0, narrow, by_node)
         m._region("cs_fwd_rows%d" % self.cur, (m._ws_gen, acts.data_ptr(), R, W), rows)
         return self.send_f if W > 1 else None
+
+    def cs_forward(self, acts):
+        self.cs_forward_hops()
+        return self.cs_forward_rows(acts)
 
     @torch.no_grad()
     def cs_head(self, recv):
@@ -304,8 +343,13 @@ class ColumnShardEngine(object):
         g = self.opt.param_groups[0]
         self.step_count += 1
         nxt = 1 - self.cur
-        slab.adam_step_out(self.master[self.cur].data, self.master[nxt].data, self.grad.data, self.m1, self.m2, g["lr"],
-                           g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.step_count)
+        if self.bf16:
+            slab.adam_step_out16(self.master[self.cur].data, self.master[nxt].data, self.mirror[nxt].data, self.grad.data,
+                                 self.m1, self.m2, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
+                                 self.step_count)
+        else:
+            slab.adam_step_out(self.master[self.cur].data, self.master[nxt].data, self.grad.data, self.m1, self.m2, g["lr"],
+                               g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.step_count)
         self.cur = nxt
         for name, p in m.named_parameters():
             p.grad = None
@@ -324,15 +368,22 @@ class ColumnShardEngine(object):
         if self._x0_fwd is None:
             raise RuntimeError("no forward has run on the column-sharded engine yet")
         if self.xL is None:
-            self.xL = self.grad.like()
+            self.xL = self.layers[1].like() if L >= 2 else self.grad.like()
         tabs = [self._x0_fwd] + self.layers[1:]
-        slab.hop(self.plan, tabs[L - 1], self.xL, gs=self.gs)
-        layers = [t.data for t in tabs] + [self.xL.data]
+        slab.hop(self.plan, self._srcs[L - 1], self.xL, gs=self.gs)     # (bf16 storage: X^L is rounded here, not in training)
+
+        def all_rows(out0, narrow):
+            if self.bf16:
+                slab.rows16(self.plan, self.ns, self.w, L, U, tabs[0].data, [t.data for t in tabs[1:]] + [self.xL.data], None,
+                            None, None, N, 1, out0, narrow, False)
+            else:
+                slab.rows(self.plan, self.ns, self.w, L, U, [t.data for t in tabs] + [self.xL.data], None, None, None, N, 1,
+                          out0, narrow, False)
         if self.world == 1:
-            slab.rows(self.plan, self.ns, self.w, L, U, layers, None, None, None, N, 1, ws["Out"][:, :d], ws["Narrow"], False)
+            all_rows(ws["Out"][:, :d], ws["Narrow"])
         else:
             loc = torch.empty(N, 2 * self.dl, dtype=torch.float32, device=ws["Out"].device)
-            slab.rows(self.plan, self.ns, self.w, L, U, layers, None, None, None, N, 1, loc[:, :self.dl], loc[:, self.dl:], False)
+            all_rows(loc[:, :self.dl], loc[:, self.dl:])
             parts = [torch.empty_like(loc) for _ in range(self.world)]
             dist.all_gather(parts, loc, group=self.group)
             ws["Out"][:, :d].copy_(torch.cat([p[:, :self.dl] for p in parts], dim=1))

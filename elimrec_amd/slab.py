@@ -19,6 +19,16 @@ from .ops import _dev, _stream
 LONG_ROW_THRESHOLD = int(os.environ.get("ELIMREC_SLAB_LONG_ROW", "32"))
 
 
+def choose_slabs16(dl):
+    """(ns, w) for a bf16 table of dl columns: a lane owns 8 columns; up to 64 columns (one 128-B line) per slab row."""
+    if dl % 8 != 0:
+        raise ValueError("bf16 table storage needs a column count that is a multiple of 8 (got %d)" % dl)
+    w = 8
+    while w * 2 <= 64 and dl % (w * 2) == 0:
+        w *= 2
+    return dl // w, w
+
+
 def choose_slabs(dl, n_rows=None):
     """(ns, w) for a table of dl columns: w = the largest power-of-two multiple of 4 dividing dl, capped at 32 floats.
     Measured at the Tiktok shape (tools/bench_slab_order.py, d = 64, us per hop): w = 64 (row-major) 44, w = 32 in two
@@ -151,50 +161,95 @@ class SellPlan(object):
 
 
 class SlabTable(object):
-    """[n x (ns*w)] fp32 table stored slab-major in one flat tensor."""
+    """[n x (ns*w)] table stored slab-major in one flat tensor; fp32, or bf16 for the bf16-storage mode."""
 
-    def __init__(self, n, ns, w, device, data=None):
+    def __init__(self, n, ns, w, device, data=None, dtype=torch.float32):
         self.n, self.ns, self.w = int(n), int(ns), int(w)
-        self.data = torch.empty(self.ns * self.n * self.w, dtype=torch.float32, device=device) if data is None else data
+        self.data = torch.empty(self.ns * self.n * self.w, dtype=dtype, device=device) if data is None else data
         assert self.data.numel() == self.ns * self.n * self.w and self.data.is_contiguous()
 
     @property
     def cols(self):
         return self.ns * self.w
 
-    def like(self):
-        return SlabTable(self.n, self.ns, self.w, self.data.device)
+    @property
+    def bf16(self):
+        return self.data.dtype == torch.bfloat16
+
+    def like(self, dtype=None):
+        return SlabTable(self.n, self.ns, self.w, self.data.device, dtype=self.data.dtype if dtype is None else dtype)
 
     def from_rows(self, src, col0=0):
-        """Columns [col0, col0 + ns*w) of a row-major 2-D tensor (unit column stride)."""
+        """Columns [col0, col0 + ns*w) of a row-major 2-D fp32 tensor (unit column stride)."""
+        assert not self.bf16
         assert src.dim() == 2 and src.stride(1) == 1 and src.shape[0] == self.n and col0 + self.cols <= src.shape[1]
         _lib.check(_lib.load().elimrec_slab_from_rows(_dev(src, "src"), src.stride(0), int(col0), self.n, self.ns, self.w,
                                                       _dev(self.data, "slab"), _stream()), "slab_from_rows")
         return self
 
     def to_rows(self, dst, col0=0):
+        assert not self.bf16
         assert dst.dim() == 2 and dst.stride(1) == 1 and dst.shape[0] == self.n and col0 + self.cols <= dst.shape[1]
         _lib.check(_lib.load().elimrec_slab_to_rows(_dev(self.data, "slab"), self.n, self.ns, self.w, _dev(dst, "dst"),
                                                     dst.stride(0), int(col0), _stream()), "slab_to_rows")
         return dst
 
     def dense(self):
-        """Row-major copy [n x cols] (tests, checkpoints)."""
+        """Row-major fp32 copy [n x cols] (tests, checkpoints)."""
+        if self.bf16:
+            return self.data.view(self.ns, self.n, self.w).permute(1, 0, 2).reshape(self.n, self.cols).float()
         return self.to_rows(torch.empty(self.n, self.cols, dtype=torch.float32, device=self.data.device))
+
+    def to_bf16(self, dst):
+        """dst (a bf16 table of the same geometry) <- this fp32 table, rounded to nearest even."""
+        assert not self.bf16 and dst.bf16 and (dst.n, dst.ns, dst.w) == (self.n, self.ns, self.w)
+        _lib.check(_lib.load().elimrec_slab_to_bf16(_dev(self.data, "src"), self.data.numel(), _dev(dst.data, "dst", torch.bfloat16),
+                                                    _stream()), "slab_to_bf16")
+        return dst
 
 
 def hop(plan, xin, xout, gs=None, src_mask=None, add=None, add_mask=None, scale=1.0, seg_only=False):
-    """xout = (A . xin + [add_mask] add) * scale on slab tables of equal geometry. seg_only: xout is a flat tensor
-    [ns x n_long x w] receiving the split rows only."""
+    """xout = (A . xin + [add_mask] add) * scale on slab tables of equal geometry. seg_only: xout is a flat fp32 tensor
+    [ns x n_long x w] receiving the split rows only. bf16 tables on either side select the bf16-storage kernels (the
+    source may be fp32 there too: the row-sparse adjoint source behind src_mask)."""
     ns, w = xin.ns, xin.w
     gs = choose_groups(ns) if gs is None else gs
     part = plan.partials(ns, w)
     out = xout if isinstance(xout, torch.Tensor) else xout.data
-    _lib.check(_lib.load().elimrec_slab_hop(plan.ref(), ns, w, int(gs), _dev(xin.data, "xin"),
-                                            _dev(src_mask, "src_mask", torch.int32), _dev(out, "xout"),
-                                            _dev(None if add is None else add.data, "add"),
-                                            _dev(add_mask, "add_mask", torch.int32), float(scale), _dev(part, "partials"),
-                                            part.numel() * 4, 1 if seg_only else 0, _stream()), "slab_hop")
+    lib = _lib.load()
+    if xin.bf16 or out.dtype == torch.bfloat16:
+        _lib.check(lib.elimrec_slab_hop16(plan.ref(), ns, w, int(gs), _dev(xin.data, "xin", xin.data.dtype), 0 if xin.bf16 else 1,
+                                          _dev(src_mask, "src_mask", torch.int32), _dev(out, "xout", out.dtype),
+                                          0 if out.dtype == torch.bfloat16 else 1, _dev(None if add is None else add.data, "add"),
+                                          _dev(add_mask, "add_mask", torch.int32), float(scale), _dev(part, "partials"),
+                                          part.numel() * 4, 1 if seg_only else 0, _stream()), "slab_hop16")
+        return
+    _lib.check(lib.elimrec_slab_hop(plan.ref(), ns, w, int(gs), _dev(xin.data, "xin"),
+                                    _dev(src_mask, "src_mask", torch.int32), _dev(out, "xout"),
+                                    _dev(None if add is None else add.data, "add"),
+                                    _dev(add_mask, "add_mask", torch.int32), float(scale), _dev(part, "partials"),
+                                    part.numel() * 4, 1 if seg_only else 0, _stream()), "slab_hop")
+
+
+def rows16(plan, ns, w, L, U, x0, layers16, long_tab, row_ids, counts, R, n_lists, out0, narrow, narrow_by_node):
+    """elimrec_slab_rows16: x0 fp32 master (flat), layers16 = [X^1 .. X^L] flat bf16 tensors (the last may be None)."""
+    ptrs = (ctypes.c_void_p * L)(*[None if t is None else _dev(t, "layer", torch.bfloat16) for t in layers16])
+    assert len(layers16) == L and out0.stride(1) == 1 and narrow.stride(1) == 1
+    _lib.check(_lib.load().elimrec_slab_rows16(plan.ref(), ns, w, L, int(U), _dev(x0, "x0"), ptrs, _dev(long_tab, "long_tab"),
+                                               _dev(row_ids, "rows", torch.int32), _dev(counts, "counts", torch.int32),
+                                               int(R), int(n_lists), _dev(out0, "out0"), out0.stride(0),
+                                               _dev(narrow, "narrow"), narrow.stride(0), 1 if narrow_by_node else 0,
+                                               _stream()), "slab_rows16")
+
+
+def adam_step_out16(p_in, p_out, p16, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
+    n = p_in.numel()
+    for t in (p_in, p_out, p16, g, m, v):
+        assert t.is_contiguous() and t.numel() == n
+    _lib.check(_lib.load().elimrec_adam_step_out16(_dev(p_in, "p_in"), _dev(p_out, "p_out"), _dev(p16, "p16", torch.bfloat16),
+                                                   _dev(g, "g"), _dev(m, "m"), _dev(v, "v"), n, float(lr), float(beta1),
+                                                   float(beta2), float(eps), float(weight_decay), int(step), _stream()),
+               "adam_step_out16")
 
 
 def rows(plan, ns, w, L, U, layers, long_tab, row_ids, counts, R, n_lists, out0, narrow, narrow_by_node):

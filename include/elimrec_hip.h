@@ -504,6 +504,30 @@ int elimrec_slab_merge_rows(const float *d_rows, const int32_t *d_keys, int worl
                             int64_t I, int ns, int w, float *d_SrcA, float *d_SrcB, uint32_t *d_mask,
                             void *stream);
 
+/* ---- bf16 table storage (configs[1] "bf16" / configs[4] "fp16" of BASELINE.json; --table_dtype=bf16). The layer
+ * tables X^1..X^(L-1), the gather copy of X^0 and the adjoint's intermediate tables are bf16 (round-to-nearest-even);
+ * all sums are fp32; master parameters, gradient, Adam moments, adjoint sources and layer means stay fp32. Geometry as
+ * above with w a multiple of 8 (a lane owns 8 columns: 16 B of a bf16 row piece). Tolerance against an oracle that
+ * rounds at the same points of the forward: loss 2e-3, gradients 2e-2 rel.
+ * elimrec_slab_hop16: d_Xin bf16, or fp32 when in_f32 (the row-sparse first adjoint source, with its bitmap);
+ * d_Xout bf16, or fp32 when out_f32 (the gradient; always fp32 and compact [ns x n_long x w] with seg_only);
+ * d_add fp32. elimrec_slab_rows16: d_x0 = fp32 master table, layers16 = host array of L device pointers X^1..X^L
+ * (bf16; the last may be NULL = hop L inline), d_long fp32. */
+int elimrec_slab_hop16(const elimrec_sell *A, int ns, int w, int gs, const void *d_Xin, int in_f32,
+                       const uint32_t *d_src_mask, void *d_Xout, int out_f32, const float *d_add,
+                       const uint32_t *d_add_mask, float scale, float *d_partials, size_t partials_bytes,
+                       int seg_only, void *stream);
+int elimrec_slab_rows16(const elimrec_sell *A, int ns, int w, int L, int64_t U, const float *d_x0,
+                        const void *const *layers16, const float *d_long, const int32_t *d_rows,
+                        const int32_t *d_counts, int64_t R, int n_lists, float *d_out0, int64_t ld_out0,
+                        float *d_narrow, int64_t ld_narrow, int narrow_by_node, void *stream);
+/* fp32 -> bf16, element for element (a slab-major table keeps its layout); n_elems % 8 == 0. */
+int elimrec_slab_to_bf16(const float *d_src, int64_t n_elems, void *d_dst, void *stream);
+/* elimrec_adam_step_out that also writes the updated parameters, rounded, to the bf16 gather copy. */
+int elimrec_adam_step_out16(const float *d_p_in, float *d_p_out, void *d_p_bf16, const float *d_g, float *d_m,
+                            float *d_v, int64_t n, float lr, float beta1, float beta2, float eps,
+                            float weight_decay, int64_t step, void *stream);
+
 /* elimrec_adam_step reading the parameters from d_p_in and writing them to d_p_out (may alias): with two
  * parameter buffers used alternately the tables cached by the last forward keep seeing the parameters they
  * were computed from (models/EliMRec.py:98-99 reads tables made BEFORE the last optimizer step). */

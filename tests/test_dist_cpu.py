@@ -141,6 +141,7 @@ class ColumnShardOracleEngine(OracleEngine):
     [q*dl, (q+1)*dl) of [E_u ; E_i], propagates only those, and exchanges the layer means / adjoint sources of the active
     rows. The folded algebra (constant feature tables propagated once) is restated here with torch autograd."""
     PAD = -(1 << 30)
+    round_fn = None          # bf16-storage variant: straight-through rounding of the stored / gathered layer tables
 
     def cs_setup(self, world, rank, optimizer):
         m = self.m
@@ -166,8 +167,13 @@ class ColumnShardOracleEngine(OracleEngine):
         """out0 = mean_k A^k X0 and the shared part (users: even k, items: odd k) for my columns, with autograd."""
         m = self.m
         xs = [self.shard]
-        for _ in range(m.L):
-            xs.append(torch.sparse.mm(m.adj, xs[-1]))
+        r = self.round_fn
+        for k in range(1, m.L + 1):
+            src = xs[-1] if r is None else (r(xs[-1]) if k == 1 else xs[-1])    # X^(k-1) for k >= 2 is already the stored (rounded) table
+            x = torch.sparse.mm(m.adj, src)
+            if r is not None and k < m.L:
+                x = r(x)                                                       # stored as bf16; hop L stays fp32
+            xs.append(x)
         inv = 1.0 / (m.L + 1)
         out0 = sum(xs) * inv
         nu = sum(x[:m.U] for k, x in enumerate(xs) if k % 2 == 0) * inv
@@ -182,9 +188,11 @@ class ColumnShardOracleEngine(OracleEngine):
         self.act = torch.cat([act, torch.full((R - len(act),), self.PAD, dtype=torch.long)]).to(torch.int32)
         return self.act
 
-    def cs_forward(self, acts):
-        W, R = acts.shape
+    def cs_forward_hops(self):
         self.out0, self.narrow = self._tables()
+
+    def cs_forward_rows(self, acts):
+        W, R = acts.shape
         send = torch.zeros(W, R, 2 * self.dl)
         for p in range(W):
             ok = acts[p] >= 0

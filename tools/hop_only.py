@@ -1,0 +1,24 @@
+"""N full hops of a slab-major table at the Tiktok shape, for rocprofv3 (--pmc / --kernel-trace). Dev tool.
+usage: hop_only.py [d] [hops]   env: ELIMREC_SLAB_W / ELIMREC_SLAB_GS choose the geometry"""
+import os, sys, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from elimrec_amd import SyntheticDataset, slab
+from elimrec_amd.model import create_adj_mat
+dev = "cuda:0"
+d = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+hops = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+U, I = 36656, 76085
+ds = SyntheticDataset(U, I, 720829, feat_dims=(4, 4, 4), seed=0)
+adj = create_adj_mat(*ds.get_train_interactions(), U, I, "pre").tocsr()
+N = adj.shape[0]
+plan = slab.SellPlan(adj, dev, side_split=U)
+ns, w = slab.choose_slabs(d, N)
+gs = slab.choose_groups(ns)
+torch.manual_seed(0)
+tabs = [slab.SlabTable(N, ns, w, dev).from_rows(torch.randn(N, d, device=dev)) for _ in range(3)]
+src, dst = tabs[0], tabs[1]
+for _ in range(hops):
+    slab.hop(plan, src, dst, gs=gs)
+    src, dst = dst, (tabs[2] if dst is tabs[1] else tabs[1])
+torch.cuda.synchronize()
+print("geometry ns=%d w=%d gs=%d, %d hops, index bytes %d" % (ns, w, gs, hops, plan.index_bytes()))
