@@ -52,7 +52,7 @@ class SellDesc(ctypes.Structure):
                 ("d_item_dst", ctypes.c_void_p), ("d_item_len", ctypes.c_void_p), ("d_blk_off", ctypes.c_void_p),
                 ("d_col", ctypes.c_void_p), ("d_val", ctypes.c_void_p), ("d_long_rows", ctypes.c_void_p),
                 ("d_long_seg_ptr", ctypes.c_void_p), ("d_long_index", ctypes.c_void_p), ("d_rowptr", ctypes.c_void_p),
-                ("d_csr_col", ctypes.c_void_p), ("d_csr_val", ctypes.c_void_p)]
+                ("d_csr_col", ctypes.c_void_p), ("d_csr_val", ctypes.c_void_p), ("d_item_long", ctypes.c_void_p)]
 
 
 c_sell = ctypes.POINTER(SellDesc)
@@ -125,6 +125,7 @@ SIGNATURES = {
     "elimrec_rank_metrics": (c_i32, [c_ptr, c_i32, c_i32, c_ptr, c_ptr, ctypes.POINTER(c_i32), c_i32, c_ptr, c_ptr]),
     "elimrec_slab_partials_bytes": (c_size, [c_sell, c_i32, c_i32]),
     "elimrec_slab_set_variant": (None, [c_i32]),
+    "elimrec_slab_set_stream": (None, [c_i32]),
     "elimrec_slab_hop": (c_i32, [c_sell, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr, c_size, c_i32,
                                  c_ptr]),
     "elimrec_slab_rows": (c_i32, [c_sell, c_i32, c_i32, c_i32, c_i64, ctypes.POINTER(c_ptr), c_ptr, c_ptr, c_ptr, c_i64, c_i32,

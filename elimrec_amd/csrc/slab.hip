@@ -38,6 +38,8 @@ struct SellArgs {
     int compact_long;              // the fix-up writes Xout compactly: [ns x n_long x w]
 };
 
+typedef unsigned int u32x4s __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ bool bit_of(const uint32_t *m, int r) { return (m[r >> 5] >> (r & 31)) & 1u; }
 
 __device__ __forceinline__ void slab_epilogue(const SellArgs &a, int slab, int64_t row, int c4, float4 r) {
@@ -156,8 +158,9 @@ __global__ __launch_bounds__(256) void sell_fixup_kernel(SellArgs a) {
     float4 tot = acc;
     if (NQ > 1) {
         tot.x = __shfl(acc.x, cl, 64); tot.y = __shfl(acc.y, cl, 64); tot.z = __shfl(acc.z, cl, 64); tot.w = __shfl(acc.w, cl, 64);
-#pragma unroll
-        for (int t = 1; t < NQ; ++t) {
+        const int nq = NQ + (a.n_long < 0 ? 1 : 0);      // = NQ; a run-time bound keeps the loop from being fully unrolled
+#pragma unroll 2
+        for (int t = 1; t < nq; ++t) {
             tot.x += __shfl(acc.x, t * LPR + cl, 64); tot.y += __shfl(acc.y, t * LPR + cl, 64);
             tot.z += __shfl(acc.z, t * LPR + cl, 64); tot.w += __shfl(acc.w, t * LPR + cl, 64);
         }
@@ -540,13 +543,12 @@ __global__ __launch_bounds__(256) void sell_fixup16_kernel(Sell16Args a) {
     }
     float tot[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        tot[t] = acc[t];
-        if (NQ > 1) {
-            tot[t] = __shfl(acc[t], cl, 64);
+    for (int t = 0; t < 8; ++t) tot[t] = NQ > 1 ? __shfl(acc[t], cl, 64) : acc[t];
+    const int nq = NQ + (a.n_long < 0 ? 1 : 0);
+#pragma unroll 2
+    for (int g = 1; g < nq; ++g) {
 #pragma unroll
-            for (int g = 1; g < NQ; ++g) tot[t] += __shfl(acc[t], g * LPR + cl, 64);
-        }
+        for (int t = 0; t < 8; ++t) tot[t] += __shfl(acc[t], g * LPR + cl, 64);
     }
     if (q != 0) return;
     if (a.compact_long) {
@@ -705,6 +707,273 @@ __global__ void adam_out16_kernel(const float4 *__restrict__ p_in, float4 *__res
     }
 }
 
+// =====================================================================================================================
+// The hop as ONE persistent launch (ELIMREC_SLAB_STREAM=1/2; measured slower than hop + fix-up kernels, kept as the
+// experiment it was -- see slab_stream()): every wave walks its wave blocks b, b + stride, ... with the index chain
+// software-pipelined across blocks -- the (len, dst, offset) records of block b+2 and the first (col, val) of block b+1
+// are in flight while block b gathers -- so the three dependent round trips a block costs when taken cold (record ->
+// indices -> rows) are paid once per wave instead of once per block: what bounds a hop whose table is small (a column
+// shard, bf16 storage) is that chain times the number of rounds, not bytes. The split rows are finished inside the same
+// launch: a segment wave publishes its partial row write-through (sc1), drains its stores, draws a ticket for the row,
+// and the wave that draws a row's last ticket does one agent-scope acquire and adds the row's partials in the order of
+// sell_fixup_kernel (so both forms give the same bits) -- cdna_hip_programming.md Guideline 16, recipe R1 in its
+// counter form; no second launch. One template covers fp32 tables (a lane owns 4 columns) and the bf16-storage family
+// (8 columns: 16 B of a bf16 row piece, or two float4 of an fp32 one).
+struct StreamArgs {
+    const int32_t *item_dst, *item_len, *blk_off, *col, *item_long;
+    const float *val;
+    int64_t n_rows, n_src;
+    int n_seg, n_long;
+    int64_t n_blocks;              // wave blocks (64/LPR items each) to walk
+    int seg_limit;
+    int wl, wl_shift, gs, spg;     // wl = lanes per slab row
+    const void *Xin;
+    const uint32_t *src_mask;
+    void *Xout;
+    const float4 *Add;
+    const uint32_t *add_mask;
+    float scale;
+    float *partials;
+    const int32_t *long_rows, *long_seg_ptr;
+    int32_t *tickets;              // [gs x n_long], zero between launches (self-resetting)
+    int compact_long;
+};
+
+template <int VPL, bool BF16>
+__device__ __forceinline__ void lane_load(const void *base, int64_t idx, float (&x)[VPL]) {
+    if constexpr (VPL == 4) {
+        const float4 t = ((const float4 *)base)[idx];
+        x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
+    } else if constexpr (BF16) {
+        unpack_bf16x8(((const uint4 *)base)[idx], x);
+    } else {
+        const float4 t0 = ((const float4 *)base)[2 * idx], t1 = ((const float4 *)base)[2 * idx + 1];
+        x[0] = t0.x; x[1] = t0.y; x[2] = t0.z; x[3] = t0.w; x[4] = t1.x; x[5] = t1.y; x[6] = t1.z; x[7] = t1.w;
+    }
+}
+
+template <int VPL, bool BF16>
+__device__ __forceinline__ void lane_store(void *base, int64_t idx, const float (&x)[VPL]) {
+    if constexpr (VPL == 4) {
+        ((float4 *)base)[idx] = make_float4(x[0], x[1], x[2], x[3]);
+    } else if constexpr (BF16) {
+        ((uint4 *)base)[idx] = pack_bf16x8(x);
+    } else {
+        ((float4 *)base)[2 * idx] = make_float4(x[0], x[1], x[2], x[3]);
+        ((float4 *)base)[2 * idx + 1] = make_float4(x[4], x[5], x[6], x[7]);
+    }
+}
+
+template <int VPL, bool OUT_BF16>
+__device__ __forceinline__ void stream_epilogue(const StreamArgs &a, int slab, int64_t row, int c, float (&r)[VPL]) {
+    const int64_t idx = ((int64_t)slab * a.n_rows + row) * a.wl + c;
+    if (a.Add && (!a.add_mask || bit_of(a.add_mask, (int)row))) {
+        float t[VPL];
+        lane_load<VPL, false>(a.Add, idx, t);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) r[i] += t[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) r[i] *= a.scale;
+    lane_store<VPL, OUT_BF16>(a.Xout, idx, r);
+}
+
+// the whole wave on one split row (li wave-uniform): same order as sell_fixup_kernel / sell_fixup16_kernel
+template <int LPR, int VPL, bool OUT_BF16>
+__device__ __forceinline__ void stream_combine(const StreamArgs &a, int grp, int li) {
+    constexpr int NQ = 64 / LPR, UNR = VPL == 4 ? 8 : 4;
+    const int lane = threadIdx.x & 63;
+    const int q = lane / LPR, cl = lane % LPR;
+    const int slab = grp * a.spg + (cl >> a.wl_shift);
+    const int c = cl & (a.wl - 1);
+    const int sb = a.long_seg_ptr[li], se = a.long_seg_ptr[li + 1];
+    const int per = (se - sb + NQ - 1) / NQ;
+    const int qb = min(sb + q * per, se), qe = min(qb + per, se);
+    const int64_t pbase = (int64_t)slab * a.n_seg * a.wl + c;
+    float acc[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) acc[i] = 0.f;
+    int sgm = qb;
+    for (; sgm + UNR <= qe; sgm += UNR) {
+        float p[UNR][VPL];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) lane_load<VPL, false>(a.partials, pbase + (int64_t)(sgm + u) * a.wl, p[u]);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) acc[i] += p[u][i];
+    }
+    for (; sgm < qe; ++sgm) {
+        float p[VPL];
+        lane_load<VPL, false>(a.partials, pbase + (int64_t)sgm * a.wl, p);
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) acc[i] += p[i];
+    }
+    float tot[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) tot[i] = NQ > 1 ? __shfl(acc[i], cl, 64) : acc[i];
+    const int nq = NQ + (a.n_long < 0 ? 1 : 0);  // = NQ, but not a compile-time bound: an unrolled loop keeps every
+#pragma unroll 2                                  // shuffle result (a register each) in flight -- 256 VGPRs at 32 groups
+    for (int g = 1; g < nq; ++g) {              // group order
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) tot[i] += __shfl(acc[i], g * LPR + cl, 64);
+    }
+    if (q != 0) return;
+    if (a.compact_long) lane_store<VPL, false>(a.Xout, ((int64_t)slab * a.n_long + li) * a.wl + c, tot);
+    else stream_epilogue<VPL, OUT_BF16>(a, slab, a.long_rows[li], c, tot);
+}
+
+// sum_j val[j] * Xin[col[j]] of one work item per lane group, neighbour order, fmaf; the (col, val) of step j + U are in
+// flight while step j gathers; ccj / cvj hold the first step on entry
+template <int VPL, bool IN_BF16, bool MASKED, int U>
+__device__ __forceinline__ void stream_gather(const StreamArgs &a, int64_t in_base, int64_t e0, int len, int (&ccj)[U], float (&cvj)[U],
+                                              float (&acc)[VPL]) {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) acc[i] = 0.f;
+    for (int j = 0; j < len; j += U) {
+        int cj[U];
+        float vj[U];
+        bool in[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { in[u] = (j + u) < len; cj[u] = ccj[u]; vj[u] = cvj[u]; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool nin = (j + U + u) < len;
+            ccj[u] = nin ? a.col[e0 + ((int64_t)(j + U + u) << 6)] : 0;
+            cvj[u] = nin ? a.val[e0 + ((int64_t)(j + U + u) << 6)] : 0.f;
+        }
+        if (MASKED) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) in[u] = in[u] && bit_of(a.src_mask, cj[u]);
+        }
+        float x[U][VPL];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (in[u]) lane_load<VPL, IN_BF16>(a.Xin, in_base + (int64_t)cj[u] * a.wl, x[u]);
+            else {
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) x[u][i] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) acc[i] = fmaf(vj[u], x[u][i], acc[i]);
+    }
+}
+
+template <int LPR, int VPL, bool IN_BF16, bool OUT_BF16, bool MASKED>
+__global__ __launch_bounds__(256) void sell_stream_kernel(StreamArgs a) {
+    constexpr int IPW = 64 / LPR, U = 4;
+    const int lane = threadIdx.x & 63;
+    const int grp = (int)(blockIdx.x % (unsigned)a.gs);
+    const int64_t wave_g = (int64_t)(blockIdx.x / (unsigned)a.gs) * 4 + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)(gridDim.x / (unsigned)a.gs) * 4;
+    const int sub = lane / LPR, cl = lane % LPR;
+    const int slab = grp * a.spg + (cl >> a.wl_shift);
+    const int c = cl & (a.wl - 1);
+    const int64_t in_base = (int64_t)slab * a.n_src * a.wl + c;
+    auto load_desc = [&](int64_t wb, int &len, int &dst, int64_t &e0) {
+        len = 0; dst = -1; e0 = 0;
+        if (wb < a.n_blocks) {
+            const int64_t item = wb * IPW + sub;
+            len = a.item_len[item];
+            dst = a.item_dst[item];
+            e0 = ((int64_t)a.blk_off[item >> 6] << 6) + (item & 63);
+        }
+    };
+    auto load_idx = [&](int64_t e0, int len, int (&cj)[U], float (&vj)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const bool in = u < len;
+            cj[u] = in ? a.col[e0 + ((int64_t)u << 6)] : 0;
+            vj[u] = in ? a.val[e0 + ((int64_t)u << 6)] : 0.f;
+        }
+    };
+    const int64_t seg_blocks = (int64_t)a.seg_limit / IPW;           // segment items fill whole blocks of 64
+    int64_t wb = wave_g;
+    // ---- phase A: the segments of the split rows (the heaviest items, first in the order); partial rows, tickets
+    if (wb < seg_blocks && wb < a.n_blocks) {
+        __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(
+            (void *)a.partials, 0, a.tickets ? (int)min((size_t)0x7FFFFFF0, (size_t)a.n_seg * a.gs * a.spg * a.wl * VPL * 4) : 0, 0x00020000);
+        for (; wb < seg_blocks && wb < a.n_blocks; wb += stride) {
+            int len, dst;
+            int64_t e0;
+            load_desc(wb, len, dst, e0);
+            int cj0[U];
+            float vj0[U];
+            load_idx(e0, len, cj0, vj0);
+            float acc[VPL];
+            stream_gather<VPL, IN_BF16, MASKED, U>(a, in_base, e0, len, cj0, vj0, acc);
+            if (dst >= 0) {
+                const int64_t pidx = ((int64_t)slab * a.n_seg + dst) * a.wl + c;
+                if (!a.tickets) lane_store<VPL, false>(a.partials, pidx, acc);
+                else {
+#pragma unroll
+                    for (int h = 0; h < VPL / 4; ++h) {
+                        u32x4s bits = {__float_as_uint(acc[4 * h]), __float_as_uint(acc[4 * h + 1]), __float_as_uint(acc[4 * h + 2]),
+                                       __float_as_uint(acc[4 * h + 3])};
+                        __builtin_amdgcn_raw_buffer_store_b128(bits, prsrc, (unsigned)((pidx * (VPL / 4) + h) * 16), 0, 16 /* sc1 */);
+                    }
+                }
+            }
+            if (!a.tickets) continue;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int li = -1, ticket = -1, nseg = 0;
+            if (dst >= 0) {
+                li = a.item_long[wb * IPW + sub];
+                nseg = a.long_seg_ptr[li + 1] - a.long_seg_ptr[li];
+                if (cl == 0) ticket = __hip_atomic_fetch_add(&a.tickets[(int64_t)grp * a.n_long + li], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ticket = __shfl(ticket, sub * LPR, 64);
+            const bool last = dst >= 0 && ticket == nseg - 1;
+            if (__ballot(last) == 0ull) continue;                   // wave-uniform
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll 1
+            for (int g = 0; g < IPW; ++g) {
+                if (!__shfl(last ? 1 : 0, g * LPR, 64)) continue;
+                const int g_li = __shfl(li, g * LPR, 64);
+                stream_combine<LPR, VPL, OUT_BF16>(a, grp, g_li);
+                if (lane == 0) __hip_atomic_store(&a.tickets[(int64_t)grp * a.n_long + g_li], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    if (a.compact_long || wb >= a.n_blocks) return;
+    // ---- phase B: the unsplit rows, index chain pipelined across blocks
+    int clen, cdst, nlen, ndst;
+    int64_t ce0, ne0;
+    load_desc(wb, clen, cdst, ce0);
+    load_desc(wb + stride, nlen, ndst, ne0);
+    int ccj[U];
+    float cvj[U];
+    load_idx(ce0, clen, ccj, cvj);
+    for (; wb < a.n_blocks; wb += stride) {
+        int flen, fdst;
+        int64_t fe0;
+        load_desc(wb + 2 * stride, flen, fdst, fe0);
+        int ncj0[U];
+        float nvj0[U];
+        load_idx(ne0, nlen, ncj0, nvj0);
+        float acc[VPL];
+        stream_gather<VPL, IN_BF16, MASKED, U>(a, in_base, ce0, clen, ccj, cvj, acc);
+        if (cdst >= 0) stream_epilogue<VPL, OUT_BF16>(a, slab, cdst, c, acc);
+        clen = nlen; cdst = ndst; ce0 = ne0;
+        nlen = flen; ndst = fdst; ne0 = fe0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) { ccj[u] = ncj0[u]; cvj[u] = nvj0[u]; }
+    }
+}
+
+// the split rows by a second launch (ELIMREC_SLAB_STREAM=2: persistent hop without the in-launch combine)
+template <int LPR, int VPL, bool OUT_BF16>
+__global__ __launch_bounds__(256) void stream_fixup_kernel(StreamArgs a) {
+    const int grp = (int)(blockIdx.x % (unsigned)a.gs);
+    const int li = (int)(blockIdx.x / (unsigned)a.gs) * 4 + (int)(threadIdx.x >> 6);
+    if (li >= a.n_long) return;
+    stream_combine<LPR, VPL, OUT_BF16>(a, grp, li);
+}
+
 static int log2_pow2(int x) {
     int s = 0;
     while ((1 << s) < x) ++s;
@@ -717,9 +986,111 @@ using namespace elimrec;
 
 extern "C" void elimrec_slab_set_variant(int v) { g_slab_variant = v; }
 
+static size_t slab_partial_floats_bytes(const elimrec_sell *A, int ns, int w) {
+    return align_up((size_t)(A->n_seg > 0 ? A->n_seg : 1) * ns * w * sizeof(float), 256);
+}
+
+// partial rows + the arrival counters of the in-launch combine (8 slab groups at most); the caller zeroes the buffer ONCE
 extern "C" size_t elimrec_slab_partials_bytes(const elimrec_sell *A, int ns, int w) {
     if (!A || ns <= 0 || w <= 0) return 0;
-    return align_up((size_t)(A->n_seg > 0 ? A->n_seg : 1) * ns * w * sizeof(float), 256);
+    return slab_partial_floats_bytes(A, ns, w) + align_up((size_t)8 * (A->n_long > 0 ? A->n_long : 1) * sizeof(int32_t), 256);
+}
+
+static int g_slab_stream = -1;
+static int slab_stream() {
+    if (g_slab_stream < 0) {
+        const char *e = getenv("ELIMREC_SLAB_STREAM");
+        // 0 (default): hop + fix-up kernels; 1: persistent, in-launch combine; 2: persistent + fix-up launch. Measured at
+        // the Tiktok shape (tools/bench_slab_modes.py, us per hop, T = 32): fp32 w32x2  37.0 / 45.5 / 40.9; bf16 w64
+        // 25.7 / 42.5 / 32.8; an 8-column shard  21.0 / 76.8 / 19.9 (bf16: 25 / 256 / 28) -- the acquire fence of the
+        // in-launch combine drops the CU's L1 under every wave that is gathering from an L1/L2-resident table
+        g_slab_stream = e ? atoi(e) : 0;
+    }
+    return g_slab_stream;
+}
+extern "C" void elimrec_slab_set_stream(int mode) { g_slab_stream = mode; }
+
+static int slab_wg_budget() {
+    static int v = 0;
+    if (!v) {
+        const char *e = getenv("ELIMREC_SLAB_WGS");
+        v = e ? atoi(e) : 256 * 6;
+        if (v < 8) v = 8;
+    }
+    return v;
+}
+
+// family: 0 = fp32 tables (4 columns per lane); 1 = bf16-storage family (8 columns per lane)
+static int launch_stream(const elimrec_sell *A, int family, int ns, int wl, int wl_shift, int gs, int spg, int lpr, const void *Xin,
+                         bool in_bf16, const uint32_t *src_mask, void *Xout, bool out_bf16, const float *add,
+                         const uint32_t *add_mask, float scale, float *partials, int seg_only, hipStream_t s) {
+    StreamArgs a = {};
+    a.item_dst = A->d_item_dst; a.item_len = A->d_item_len; a.blk_off = A->d_blk_off; a.col = A->d_col; a.val = A->d_val;
+    a.item_long = A->d_item_long;
+    a.n_rows = A->n_rows; a.n_src = A->n_src; a.n_seg = A->n_seg; a.n_long = A->n_long;
+    const int ipw = 64 / lpr;
+    a.n_blocks = (int64_t)(seg_only ? A->n_seg_items : A->n_items) / ipw;
+    a.seg_limit = A->n_seg_items;
+    a.wl = wl; a.wl_shift = wl_shift; a.gs = gs; a.spg = spg;
+    a.Xin = Xin; a.src_mask = src_mask; a.Xout = Xout;
+    a.Add = seg_only ? nullptr : (const float4 *)add; a.add_mask = add_mask; a.scale = seg_only ? 1.0f : scale;
+    a.partials = partials; a.long_rows = A->d_long_rows; a.long_seg_ptr = A->d_long_seg_ptr;
+    const int vpl = family ? 8 : 4;
+    const bool in_launch = slab_stream() == 1;
+    a.tickets = (A->n_long > 0 && in_launch) ? (int32_t *)((char *)partials + slab_partial_floats_bytes(A, ns, wl * vpl)) : nullptr;
+    a.compact_long = seg_only ? 1 : 0;
+    if (a.n_blocks <= 0) return 0;
+    int64_t per_group = (a.n_blocks + 3) / 4;
+    const int64_t cap = slab_wg_budget() / gs > 0 ? slab_wg_budget() / gs : 1;
+    if (per_group > cap) per_group = cap;
+    const dim3 grid((unsigned)(per_group * gs));
+    const bool masked = src_mask != nullptr;
+#define ELIMREC_STREAM(LPR)                                                                                                     \
+    do {                                                                                                                        \
+        if (!family) {                                                                                                          \
+            if (masked) hipLaunchKernelGGL((sell_stream_kernel<LPR, 4, false, false, true>), grid, dim3(256), 0, s, a);         \
+            else hipLaunchKernelGGL((sell_stream_kernel<LPR, 4, false, false, false>), grid, dim3(256), 0, s, a);               \
+        } else if (in_bf16) {                                                                                                   \
+            if (out_bf16) hipLaunchKernelGGL((sell_stream_kernel<LPR, 8, true, true, false>), grid, dim3(256), 0, s, a);        \
+            else hipLaunchKernelGGL((sell_stream_kernel<LPR, 8, true, false, false>), grid, dim3(256), 0, s, a);                \
+        } else if (masked) {                                                                                                    \
+            if (out_bf16) hipLaunchKernelGGL((sell_stream_kernel<LPR, 8, false, true, true>), grid, dim3(256), 0, s, a);        \
+            else hipLaunchKernelGGL((sell_stream_kernel<LPR, 8, false, false, true>), grid, dim3(256), 0, s, a);                \
+        } else {                                                                                                                \
+            if (out_bf16) hipLaunchKernelGGL((sell_stream_kernel<LPR, 8, false, true, false>), grid, dim3(256), 0, s, a);       \
+            else hipLaunchKernelGGL((sell_stream_kernel<LPR, 8, false, false, false>), grid, dim3(256), 0, s, a);               \
+        }                                                                                                                       \
+    } while (0)
+    switch (lpr) {
+        case 1: ELIMREC_STREAM(1); break;
+        case 2: ELIMREC_STREAM(2); break;
+        case 4: ELIMREC_STREAM(4); break;
+        case 8: ELIMREC_STREAM(8); break;
+        case 16: ELIMREC_STREAM(16); break;
+        case 32: ELIMREC_STREAM(32); break;
+        default: ELIMREC_STREAM(64); break;
+    }
+#undef ELIMREC_STREAM
+    int rc = check_hip(hipGetLastError(), "slab_hop(stream)");
+    if (rc || in_launch || A->n_long <= 0) return rc;
+    const dim3 fgrid((unsigned)((A->n_long + 3) / 4) * (unsigned)gs);
+#define ELIMREC_SFIX(LPR)                                                                                              \
+    do {                                                                                                               \
+        if (!family) hipLaunchKernelGGL((stream_fixup_kernel<LPR, 4, false>), fgrid, dim3(256), 0, s, a);              \
+        else if (out_bf16) hipLaunchKernelGGL((stream_fixup_kernel<LPR, 8, true>), fgrid, dim3(256), 0, s, a);         \
+        else hipLaunchKernelGGL((stream_fixup_kernel<LPR, 8, false>), fgrid, dim3(256), 0, s, a);                      \
+    } while (0)
+    switch (lpr) {
+        case 1: ELIMREC_SFIX(1); break;
+        case 2: ELIMREC_SFIX(2); break;
+        case 4: ELIMREC_SFIX(4); break;
+        case 8: ELIMREC_SFIX(8); break;
+        case 16: ELIMREC_SFIX(16); break;
+        case 32: ELIMREC_SFIX(32); break;
+        default: ELIMREC_SFIX(64); break;
+    }
+#undef ELIMREC_SFIX
+    return check_hip(hipGetLastError(), "slab_hop(stream fix-up)");
 }
 
 static int slab_geometry(const char *who, int ns, int w, int gs, int &w4_shift, int &spg, int &lpr) {
@@ -765,6 +1136,9 @@ extern "C" int elimrec_slab_hop(const elimrec_sell *A, int ns, int w, int gs, co
     a.partials = (float4 *)d_partials; a.long_rows = A->d_long_rows; a.long_seg_ptr = A->d_long_seg_ptr;
     a.compact_long = seg_only ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
+    if (slab_stream() && A->d_item_long)
+        return launch_stream(A, 0, ns, w / 4, w4_shift, gs, spg, lpr, d_Xin, false, d_src_mask, d_Xout, false, d_add, d_add_mask, scale,
+                             d_partials, seg_only, s);
     const int variant = slab_variant();
     const int n_it = a.item_end - a.item_begin;
     if (n_it > 0) {
@@ -948,6 +1322,9 @@ extern "C" int elimrec_slab_hop16(const elimrec_sell *A, int ns, int w, int gs, 
     hipStream_t s = (hipStream_t)stream;
     const int n_it = a.item_end - a.item_begin;
     const bool of = out_f32 != 0 || seg_only;
+    if (slab_stream() && A->d_item_long)
+        return launch_stream(A, 1, ns, w / 8, w8_shift, gs, spg, lpr, d_Xin, !in_f32, d_src_mask, d_Xout, !of, d_add, d_add_mask, scale,
+                             d_partials, seg_only, s);
 #define ELIMREC_SELL16(LPR)                                                                                         \
     do {                                                                                                            \
         if (n_it > 0) {                                                                                             \

@@ -121,6 +121,8 @@ class SellPlan(object):
         dstpos = (blk_off[it // 64] + j) * 64 + (it % 64)
         sell_col[dstpos] = col[src]
         sell_val[dstpos] = val[src]
+        item_long = np.zeros(max(n_seg_items, 1), np.int32)
+        item_long[:n_seg] = seg_row[so]
         long_index = np.full(n_rows, -1, np.int32)
         long_index[long_rows] = np.arange(len(long_rows), dtype=np.int32)
 
@@ -137,11 +139,11 @@ class SellPlan(object):
                       long_rows=t(long_rows if len(long_rows) else np.zeros(1), np.int32),
                       long_seg_ptr=t(seg_ptr, np.int32), long_index=t(long_index, np.int32),
                       rowptr=t(rowptr, np.int32), csr_col=t(col if len(col) else np.zeros(1), np.int32),
-                      csr_val=t(val if len(val) else np.zeros(1), np.float32))
+                      csr_val=t(val if len(val) else np.zeros(1), np.float32), item_long=t(item_long, np.int32))
         p = lambda k: self.t[k].data_ptr()
         self.desc = _lib.SellDesc(self.n_rows, self.n_src, self.n_items, self.n_seg_items, self.n_seg, self.n_long,
                                   p("item_dst"), p("item_len"), p("blk_off"), p("col"), p("val"), p("long_rows"),
-                                  p("long_seg_ptr"), p("long_index"), p("rowptr"), p("csr_col"), p("csr_val"))
+                                  p("long_seg_ptr"), p("long_index"), p("rowptr"), p("csr_col"), p("csr_val"), p("item_long"))
         self._partials = {}
 
     def ref(self):
@@ -152,7 +154,7 @@ class SellPlan(object):
         key = (ns, w)
         if key not in self._partials:
             nbytes = int(_lib.load().elimrec_slab_partials_bytes(self.ref(), ns, w))
-            self._partials[key] = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=self.device)
+            self._partials[key] = torch.zeros(max(nbytes // 4, 1), dtype=torch.float32, device=self.device)   # + arrival counters
         return self._partials[key]
 
     def index_bytes(self):

@@ -455,6 +455,8 @@ typedef struct elimrec_sell {
     const int32_t *d_rowptr;        /* plain CSR of the same matrix (row-list evaluation)               */
     const int32_t *d_csr_col;
     const float *d_csr_val;
+    const int32_t *d_item_long;     /* [n_seg_items] split row (index into d_long_rows) of a segment item; NULL
+                                       selects the two-launch form (hop + fix-up) instead of the in-launch combine */
 } elimrec_sell;
 
 /* One hop over a slab-major table:  r = A . Xin ;  Xout[row] = (r + [add_mask bit row] Add[row]) * scale.
@@ -466,8 +468,12 @@ typedef struct elimrec_sell {
  * that elimrec_slab_rows cannot do inline.
  * Replaces torch.sparse.mm (models/EliMRec.py:244) and its backward for one column slice. */
 size_t elimrec_slab_partials_bytes(const elimrec_sell *A, int ns, int w);
-/* tuning knob (also env ELIMREC_SLAB_VARIANT): inner-loop form of the hop kernel, results identical */
+/* tuning knobs, results identical: inner-loop form of the hop kernel (env ELIMREC_SLAB_VARIANT); launch form (env
+ * ELIMREC_SLAB_STREAM): 0 = hop kernel + fix-up kernel for the split rows (default, measured fastest), 1 = ONE
+ * persistent launch with the split rows combined in-launch by the last-arriving segment wave, 2 = persistent + fix-up.
+ * d_partials must be zero-filled once after allocation (form 1 keeps its arrival counters there). */
 void elimrec_slab_set_variant(int v);
+void elimrec_slab_set_stream(int on);
 int elimrec_slab_hop(const elimrec_sell *A, int ns, int w, int gs, const float *d_Xin,
                      const uint32_t *d_src_mask, float *d_Xout, const float *d_add,
                      const uint32_t *d_add_mask, float scale, float *d_partials, size_t partials_bytes,

@@ -417,3 +417,43 @@ def test_bf16_storage_trainer_vs_rounding_oracle(name):
             model.predict_type = "TIE"
             assert np.isfinite(model.predict(g["eval_users"].tolist()).numpy()).all()
     print("max |loss - oracle|, max |E - oracle|:", res)
+
+
+@pytest.mark.parametrize("d,w,gs,bf16", [(64, 32, 2, False), (8, 8, 1, False), (128, 32, 4, False), (64, 64, 1, True), (16, 16, 1, True)])
+def test_persistent_hop_with_in_launch_combine_equals_two_launch_form(d, w, gs, bf16):
+    """The persistent forms of the hop (1: split rows combined in-launch by the last-arriving segment wave; they are not
+    the default: measured slower) give the same bits as the default hop kernel + fix-up launch, run after run, plain / masked+addend / seg_only, under uneven load (the 6 hot
+    rows have ~400 neighbours against a median of 6)."""
+    from elimrec_amd import _lib, slab
+    lib = _lib.load()
+    n = 4000
+    m = _random_graph(n, 3 * d + w, hot=9, hot_deg=900)
+    plan = slab.SellPlan(m, DEV, threshold=32, side_split=1500)
+    ns = d // w
+    torch.manual_seed(1)
+    X = torch.randn(n, d, device=DEV)
+    x = slab.SlabTable(n, ns, w, DEV).from_rows(X)
+    if bf16:
+        x = x.to_bf16(x.like(torch.bfloat16))
+    act = torch.rand(n, device=DEV) < 0.1
+    bm = _bitmap(act)
+    src = slab.SlabTable(n, ns, w, DEV).from_rows(torch.randn(n, d, device=DEV))
+    outs = {}
+    try:
+        for mode in (0, 1, 1, 1):
+            lib.elimrec_slab_set_stream(mode)
+            y, z = x.like(), x.like()
+            long_tab = torch.full((ns * plan.n_long * w,), float("nan"), device=DEV)
+            y.data.fill_(float("nan")); z.data.fill_(float("nan"))
+            slab.hop(plan, x, y, gs=gs)
+            slab.hop(plan, src, z, gs=gs, src_mask=bm, add=src, add_mask=bm, scale=0.5)
+            slab.hop(plan, x, long_tab, gs=gs, seg_only=True)
+            got = (y.data.clone(), z.data.clone(), long_tab.clone())
+            if mode in outs:
+                for a, b in zip(outs[mode], got):
+                    assert torch.equal(a, b)
+            outs[mode] = got
+    finally:
+        lib.elimrec_slab_set_stream(0)
+    for a, b in zip(outs[0], outs[1]):
+        assert not torch.isnan(a.float()).any() and torch.equal(a, b)
