@@ -55,6 +55,13 @@ class SellDesc(ctypes.Structure):
                 ("d_csr_col", ctypes.c_void_p), ("d_csr_val", ctypes.c_void_p), ("d_item_long", ctypes.c_void_p)]
 
 
+class AdamJob(ctypes.Structure):
+    """struct elimrec_adam_job."""
+    _fields_ = [("d_p_in", ctypes.c_void_p), ("d_p_out", ctypes.c_void_p), ("d_p_bf16", ctypes.c_void_p), ("d_g", ctypes.c_void_p),
+                ("d_m", ctypes.c_void_p), ("d_v", ctypes.c_void_p), ("d_copy_dst", ctypes.c_void_p), ("n", ctypes.c_int64),
+                ("step", ctypes.c_int64)]
+
+
 c_sell = ctypes.POINTER(SellDesc)
 c_split = ctypes.POINTER(CsrSplit)
 c_csr = ctypes.POINTER(CsrDesc)
@@ -97,6 +104,8 @@ SIGNATURES = {
     "elimrec_blocksum_rows": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr]),
     "elimrec_triplet_rows": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr]),
     "elimrec_triplet_rows_checked": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
+    "elimrec_batch_plan": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr,
+                                   c_size, c_ptr]),
     "elimrec_pad_rows": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr]),
     "elimrec_gather_rows": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr]),
     "elimrec_copy_cols": (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i32, c_ptr]),
@@ -139,9 +148,15 @@ SIGNATURES = {
                                         c_i64, c_ptr]),
     "elimrec_slab_from_rows": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr]),
     "elimrec_slab_to_rows": (c_i32, [c_ptr, c_i64, c_i32, c_i32, c_ptr, c_i64, c_i64, c_ptr]),
-    "elimrec_slab_merge_rows": (c_i32, [c_ptr, c_ptr, c_i32, c_i64, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "elimrec_slab_merge_rows": (c_i32, [c_ptr, c_ptr, c_i32, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "elimrec_adam_step_out": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64,
                                       c_ptr]),
+    "elimrec_head_pack_floats": (c_size, [c_i32, ctypes.POINTER(c_i32)]),
+    "elimrec_head_fwd_fused": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i32, ctypes.POINTER(c_ptr),
+                                       ctypes.POINTER(c_i64), ctypes.POINTER(c_i32), ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr),
+                                       c_ptr, c_ptr, c_ptr, c_ptr, ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr), c_ptr, c_size,
+                                       c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr]),
+    "elimrec_adam_multi": (c_i32, [ctypes.POINTER(AdamJob), c_i32, c_f32, c_f32, c_f32, c_f32, c_f32, c_ptr]),
     "elimrec_sample_triplets": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_u64, c_u64, c_ptr, c_ptr, c_ptr, c_ptr]),
 }
 

@@ -191,6 +191,15 @@ __device__ __forceinline__ int plan_block_scan(int v, int *wave_sums, int *total
 // dependent round trips of the phases below cost LDS latency; the results are copied out at the end. (The same
 // phases on global arrays cost an L2 round trip each -- measured 4x slower than the radix-sort path at 49 k slots,
 // which therefore keeps the larger key lists.)
+// optional batch front end of the planner: the keys are the node ids of B triplets, computed (and range-checked) here
+struct PlanBatch {
+    const int64_t *users, *pos, *neg;
+    int64_t U, I;
+    int32_t *keys_out, *err;
+    int32_t pad_key;
+    int pad;
+};
+
 constexpr int PLAN_LDS_N = 8192;
 constexpr int PLAN_KPT = PLAN_LDS_N / PLAN_T;
 
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(PLAN_T) void segment_plan_kernel(const int32_t *__r
                                                               int32_t *__restrict__ slot_seg,
                                                               int32_t *__restrict__ g_seg_start,
                                                               int32_t *__restrict__ g_members,
-                                                              uint32_t *__restrict__ key_bitmap) {
+                                                              uint32_t *__restrict__ key_bitmap, PlanBatch pb) {
     extern __shared__ uint32_t plan_lds[];
     const int nw = (key_space + 31) >> 5;
     uint32_t *bm = plan_lds, *pre = plan_lds + nw;
@@ -216,7 +225,18 @@ __global__ __launch_bounds__(PLAN_T) void segment_plan_kernel(const int32_t *__r
 #pragma unroll
     for (int i = 0; i < PLAN_KPT; ++i) {
         const int j = tid + i * PLAN_T;
-        kreg[i] = j < n ? keys[j] : -1;
+        if (j >= n) { kreg[i] = -1; continue; }
+        if (!pb.users) { kreg[i] = keys[j]; continue; }
+        // the node id of triplet slot j, range-checked as elimrec_triplet_rows_checked does (slot 3b + {0,1,2})
+        const int b = j / 3, which = j - 3 * b;
+        int64_t idx = which == 0 ? pb.users[b] : (which == 1 ? pb.pos[b] : pb.neg[b]);
+        const int64_t lim = which == 0 ? pb.U : pb.I;
+        if (idx < 0 || idx >= lim) {
+            if (pb.err) atomicOr(pb.err, 1 << which);
+            idx = 0;
+        }
+        kreg[i] = (int)(which == 0 ? idx : pb.U + idx);
+        if (pb.keys_out) pb.keys_out[j] = kreg[i];
     }
     constexpr int iters = PLAN_KPT;
     auto key_of = [&](int i, int j) -> int { return kreg[i]; };
@@ -357,6 +377,13 @@ __global__ __launch_bounds__(PLAN_T) void segment_plan_kernel(const int32_t *__r
         seg_info[0] = n_act; seg_info[1] = n_lo;
         seg_info[2] = 0; seg_info[3] = n_lo; seg_info[4] = n_lo; seg_info[5] = n_act; seg_info[6] = 0; seg_info[7] = n_act;
     }
+    if (pb.pad)                                       // unused tail of the active-row list: distinct negative keys
+        for (int r = n_act + tid; r < n; r += PLAN_T) active_rows[r] = pb.pad_key + r;
+}
+
+__global__ void pad_keys_kernel(int32_t *__restrict__ keys, const int32_t *__restrict__ count, int64_t n, int32_t pad_key) {
+    const int64_t r = (int64_t)*count + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) keys[r] = pad_key + (int32_t)r;
 }
 
 __global__ void key_bitmap_kernel(const int32_t *__restrict__ keys, int64_t n, uint32_t *__restrict__ bitmap) {
@@ -820,9 +847,34 @@ static int plan_fast_max_keys() {
     return v;
 }
 
+static int segment_plan_impl(const int32_t *d_keys, int64_t n, int32_t split_key, int64_t key_space,
+                             int32_t *d_active_rows, int32_t *d_seg_info, int32_t *d_slot_seg,
+                             uint32_t *d_key_bitmap, void *d_workspace, size_t workspace_bytes, void *stream,
+                             const PlanBatch &pb);
+
 extern "C" int elimrec_segment_plan(const int32_t *d_keys, int64_t n, int32_t split_key, int64_t key_space,
                                     int32_t *d_active_rows, int32_t *d_seg_info, int32_t *d_slot_seg,
                                     uint32_t *d_key_bitmap, void *d_workspace, size_t workspace_bytes, void *stream) {
+    PlanBatch pb = {};
+    return segment_plan_impl(d_keys, n, split_key, key_space, d_active_rows, d_seg_info, d_slot_seg, d_key_bitmap, d_workspace,
+                             workspace_bytes, stream, pb);
+}
+
+extern "C" int elimrec_batch_plan(const int64_t *d_users, const int64_t *d_pos, const int64_t *d_neg, int64_t B, int64_t U,
+                                  int64_t I, int32_t *d_keys, int32_t *d_active_rows, int32_t *d_seg_info,
+                                  int32_t *d_slot_seg, uint32_t *d_key_bitmap, int32_t pad_key, int32_t *d_err,
+                                  void *d_workspace, size_t workspace_bytes, void *stream) {
+    ELIMREC_REQUIRE(d_users && d_pos && d_neg && d_keys && d_err, "batch_plan: null pointer");
+    ELIMREC_REQUIRE(B > 0 && U >= 0 && I >= 0 && U + I < INT32_MAX, "batch_plan: bad sizes");
+    PlanBatch pb = {d_users, d_pos, d_neg, U, I, d_keys, d_err, pad_key, 1};
+    return segment_plan_impl(d_keys, 3 * B, (int32_t)U, U + I, d_active_rows, d_seg_info, d_slot_seg, d_key_bitmap, d_workspace,
+                             workspace_bytes, stream, pb);
+}
+
+static int segment_plan_impl(const int32_t *d_keys, int64_t n, int32_t split_key, int64_t key_space,
+                             int32_t *d_active_rows, int32_t *d_seg_info, int32_t *d_slot_seg,
+                             uint32_t *d_key_bitmap, void *d_workspace, size_t workspace_bytes, void *stream,
+                             const PlanBatch &pb) {
     ELIMREC_REQUIRE(d_keys && d_active_rows && d_seg_info && d_slot_seg && d_workspace, "segment_plan: null pointer");
     ELIMREC_REQUIRE(n > 0 && n < INT32_MAX, "segment_plan: bad n");
     ELIMREC_REQUIRE(!d_key_bitmap || key_space > 0, "segment_plan: the key bitmap needs key_space");
@@ -849,9 +901,13 @@ extern "C" int elimrec_segment_plan(const int32_t *d_keys, int64_t n, int32_t sp
             lds_set = plan_lds;
         }
         hipLaunchKernelGGL(segment_plan_kernel, dim3(1), dim3(PLAN_T), plan_lds, s, d_keys, (int)n, (int)key_space,
-                           (int)split_key, d_active_rows, d_seg_info, d_slot_seg, seg_start, vs, d_key_bitmap);
+                           (int)split_key, d_active_rows, d_seg_info, d_slot_seg, seg_start, vs, d_key_bitmap, pb);
         ELIMREC_LAUNCH_CHECK("segment_plan");
         return 0;
+    }
+    if (pb.users) {      // key lists beyond the one-workgroup planner: the keys by their own (range-checked) launch first
+        int rc2 = elimrec_triplet_rows_checked(pb.users, pb.pos, pb.neg, n / 3, pb.U, pb.I, pb.keys_out, pb.err, stream);
+        if (rc2) return rc2;
     }
     const unsigned nb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(iota_kernel, dim3(nb), dim3(256), 0, s, vin, n);
@@ -878,6 +934,10 @@ extern "C" int elimrec_segment_plan(const int32_t *d_keys, int64_t n, int32_t sp
         if (e != hipSuccess) return check_hip(e, "memset(key bitmap)");
         hipLaunchKernelGGL(key_bitmap_kernel, dim3(nb), dim3(256), 0, s, d_keys, n, d_key_bitmap);
         ELIMREC_LAUNCH_CHECK("key_bitmap");
+    }
+    if (pb.pad) {
+        hipLaunchKernelGGL(pad_keys_kernel, dim3(nb), dim3(256), 0, s, d_active_rows, (const int32_t *)d_seg_info, n, pb.pad_key);
+        ELIMREC_LAUNCH_CHECK("pad_keys");
     }
     return 0;
 }

@@ -1,0 +1,295 @@
+// Everything the training step evaluates AFTER the graph, at the batch's active rows, in ONE launch
+// (models/EliMRec.py:233-236 folded, :262-270, :146-151): for a tile of 32 active rows
+//     Out_m = S_m[rows] W_m^T + c[rows] b_m^T + narrow[rows]         (feature blocks, folded form)
+//     Y_0   = Out W_side^T + b_side                                   (embedding_{user,item}_after_GCN)
+//     Y_m   = Out_m Ws_m^T + bs_m                                     (s_dense_m)
+// with the row tile, the Out tile and the K-half partial sums in LDS and the weights read in MFMA-fragment order from a
+// packed copy (one coalesced 256-B load per v_mfma_f32_32x32x2_f32, 16 steps in flight), so the two batched GEMM launches
+// of the unfused path (each a latency chain of global -> LDS -> MFMA rounds at ~6 % MFMA utilisation) and the Out
+// round trip through HBM between them disappear. fp32-input MFMA: an exact fp32 fma chain, K split in two halves that
+// are added once -- within fp32 round-off of the unfused path (tests/test_shard_gpu.py).
+// Specialised for recdim = 64 (two 32-column MFMA tiles) and feature widths that fit LDS; other shapes keep the
+// batched-GEMM path.
+#include "common.h"
+
+namespace elimrec {
+
+typedef float v16h __attribute__((ext_vector_type(16)));
+constexpr int HD = 64;            // recdim
+constexpr int HROWS = 32;         // rows per tile
+constexpr int HMAXM = 3;
+
+struct PackJob { const float *W; int64_t ld; int K; int64_t dst; };
+struct PackJobs { PackJob j[8]; int n; int first_block[9]; };
+
+// fragment-major copy of a [64 x K] weight matrix: element (n, k) at ((n / 32) * (K / 2) + k / 2) * 64 + (k & 1) * 32 + n % 32,
+// i.e. the B operand of MFMA step s of column tile nt is the 64 consecutive floats at ((nt * K/2) + s) * 64
+__global__ __launch_bounds__(256) void pack_head_weights_kernel(PackJobs jobs, float *__restrict__ pk) {
+    int q = 0;
+    while (q + 1 < jobs.n && (int)blockIdx.x >= jobs.first_block[q + 1]) ++q;
+    const PackJob &jb = jobs.j[q];
+    const int64_t total = (int64_t)HD * jb.K;
+    const int nb = jobs.first_block[q + 1] - jobs.first_block[q];
+    for (int64_t e = (int64_t)((int)blockIdx.x - jobs.first_block[q]) * 256 + threadIdx.x; e < total; e += (int64_t)nb * 256) {
+        const int lane = (int)(e & 63);
+        const int64_t blk = e >> 6;                 // nt * (K/2) + s
+        const int nt = (int)(blk / (jb.K / 2)), s = (int)(blk - (int64_t)nt * (jb.K / 2));
+        pk[jb.dst + e] = jb.W[(int64_t)(nt * 32 + (lane & 31)) * jb.ld + 2 * s + (lane >> 5)];
+    }
+}
+
+struct HeadFwdArgs {
+    const int32_t *act, *seg_info;
+    const float *out0; int64_t ld_out0;             // [R x 64] block 0 of Out (layer means), compact
+    const float *narrow; int64_t ld_nar;            // [R x 64] shared part, compact
+    const float *c;                                 // [N]
+    const float *S[HMAXM]; int64_t ldS[HMAXM]; int D[HMAXM];
+    const float *bias_m[HMAXM];
+    int n_mod;
+    const float *pk;
+    int64_t off_Wm[HMAXM], off_Wf[2], off_Ws[HMAXM];
+    const float *bias_f[2], *bias_s[HMAXM];
+    float *OutAct; int64_t ld_out;
+    float *YAct; int64_t ld_y;
+    int a_off[HMAXM];                               // LDS offsets (floats) of the S_m row tiles
+    int out_off, part_off;
+};
+
+// acc += A[32 x (2*nsteps)] . B for MFMA steps [s0, s0 + nsteps): A from LDS (row stride folded into ap together with this
+// lane's row / k-parity), B = packed weights (bp = start of the column tile + lane). 16 B operands in flight.
+__device__ __forceinline__ v16h head_mfma_run(v16h acc, const float *ap, const float *__restrict__ bp, int s0, int nsteps) {
+    constexpr int PF = 16;
+    s0 = __builtin_amdgcn_readfirstlane(s0);           // wave-uniform: plain scalar loop control, no exec masking
+    nsteps = __builtin_amdgcn_readfirstlane(nsteps);
+    const float *a0 = ap + 2 * s0;
+    const float *b0 = bp + (int64_t)s0 * 64;
+    float bq[PF];
+    if (nsteps >= PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) bq[u] = b0[u * 64];
+    }
+    int s = 0;
+    for (; s + PF <= nsteps; s += PF) {
+        float bc[PF], av[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) bc[u] = bq[u];
+        if (s + 2 * PF <= nsteps) {                    // the next block's B operands, in flight under this block's MFMAs
+#pragma unroll
+            for (int u = 0; u < PF; ++u) bq[u] = b0[(int64_t)(s + PF + u) * 64];
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) av[u] = a0[2 * (s + u)];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bc[u], acc, 0, 0, 0);
+    }
+    for (; s < nsteps; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[2 * s], b0[(int64_t)s * 64], acc, 0, 0, 0);
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void head_fwd_fused_kernel(HeadFwdArgs a) {
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nt = wave & 1, kh = wave >> 1;
+    const int n_act = a.seg_info[0], n_lo = a.seg_info[1];
+    const int tu = (n_lo + HROWS - 1) / HROWS;
+    const int ti = (n_act - n_lo + HROWS - 1) / HROWS;
+    const int t = blockIdx.x;
+    if (t >= tu + ti) return;
+    const bool user = t < tu;
+    const int r0 = user ? t * HROWS : n_lo + (t - tu) * HROWS;
+    const int r1 = min(r0 + HROWS, user ? n_lo : n_act);
+    const int nrows = r1 - r0;
+    const int side = user ? 0 : 1;
+    constexpr int LDA = HD + 1;
+    float *A0 = lds;                                   // out0 rows   [32][65]
+    float *AN = lds + HROWS * LDA;                     // narrow rows [32][65]
+    float *OutT = lds + a.out_off;                     // Out tile    [32][C + 1]
+    float *Part = lds + a.part_off;                    // K-half partial sums [<= 4][32][64]
+    __shared__ float s_c[HROWS];
+    const int C = (1 + a.n_mod) * HD, LDO = C + 1;
+    if (tid < HROWS) s_c[tid] = tid < nrows ? a.c[a.act[r0 + tid]] : 0.f;
+    // ---- load the row tiles: out0, narrow (compact rows) and the folded feature rows S_m[node] (gathered)
+    for (int e = tid; e < HROWS * (HD / 4); e += 256) {
+        const int r = e / (HD / 4), c4 = e % (HD / 4);
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
+        if (r < nrows) {
+            x = *reinterpret_cast<const float4 *>(a.out0 + (int64_t)(r0 + r) * a.ld_out0 + 4 * c4);
+            y = *reinterpret_cast<const float4 *>(a.narrow + (int64_t)(r0 + r) * a.ld_nar + 4 * c4);
+        }
+        float *p = A0 + r * LDA + 4 * c4, *q = AN + r * LDA + 4 * c4;
+        p[0] = x.x; p[1] = x.y; p[2] = x.z; p[3] = x.w;
+        q[0] = y.x; q[1] = y.y; q[2] = y.z; q[3] = y.w;
+        float *o = OutT + r * LDO + 4 * c4;            // block 0 of the Out tile
+        o[0] = x.x; o[1] = x.y; o[2] = x.z; o[3] = x.w;
+    }
+    for (int m = 0; m < a.n_mod; ++m) {
+        const int D4 = a.D[m] / 4, lda = a.D[m] + 1;
+        float *Am = lds + a.a_off[m];
+        for (int e = tid; e < HROWS * D4; e += 256) {
+            const int r = e / D4, c4 = e % D4;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < nrows) x = *reinterpret_cast<const float4 *>(a.S[m] + (int64_t)a.act[r0 + r] * a.ldS[m] + 4 * c4);
+            float *p = Am + r * lda + 4 * c4;
+            p[0] = x.x; p[1] = x.y; p[2] = x.z; p[3] = x.w;
+        }
+    }
+    __syncthreads();
+    const int ai = lane & 31, ak = lane >> 5;
+    // ---- stage 1: feature blocks, K = D_m split in halves over the wave pairs
+    v16h accm[HMAXM];
+#pragma unroll
+    for (int m = 0; m < HMAXM; ++m) {
+        accm[m] = (v16h){0};
+        if (m < a.n_mod) {
+            const int K = a.D[m], steps = K / 2, hs = (steps + 1) / 2;
+            const int s0 = kh * hs, ns = min(hs, steps - s0);
+            const float *ap = lds + a.a_off[m] + ai * (K + 1) + ak;
+            const float *bp = a.pk + a.off_Wm[m] + (int64_t)nt * steps * 64 + lane;
+            if (ns > 0) accm[m] = head_mfma_run(accm[m], ap, bp, s0, ns);
+        }
+    }
+    if (kh == 1) {
+#pragma unroll
+        for (int m = 0; m < HMAXM; ++m)
+            if (m < a.n_mod)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * ak;
+                    Part[(m * HROWS + row) * HD + nt * 32 + ai] = accm[m][r];
+                }
+    }
+    __syncthreads();
+    if (kh == 0) {
+#pragma unroll
+        for (int m = 0; m < HMAXM; ++m)
+            if (m < a.n_mod) {
+                const int col = nt * 32 + ai;
+                const float bm = a.bias_m[m] ? a.bias_m[m][col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * ak;
+                    const float v = (accm[m][r] + Part[(m * HROWS + row) * HD + col]) + s_c[row] * bm + AN[row * LDA + col];
+                    OutT[row * LDO + (m + 1) * HD + col] = v;
+                    if (row < nrows) a.OutAct[(int64_t)(r0 + row) * a.ld_out + (m + 1) * HD + col] = v;
+                }
+            }
+    }
+    __syncthreads();
+    // ---- stage 2: fused Linear over the whole Out tile (K = C) and the single-modal heads (K = 64)
+    v16h accy[1 + HMAXM];
+    {
+        const int steps = C / 2, hs = steps / 2;
+        const float *ap = OutT + ai * LDO + ak;
+        const float *bp = a.pk + a.off_Wf[side] + (int64_t)nt * steps * 64 + lane;
+        accy[0] = head_mfma_run((v16h){0}, ap, bp, kh * hs, hs);
+    }
+#pragma unroll
+    for (int m = 0; m < HMAXM; ++m) {
+        accy[1 + m] = (v16h){0};
+        if (m < a.n_mod) {
+            const int steps = HD / 2, hs = steps / 2;
+            const float *ap = OutT + ai * LDO + (m + 1) * HD + ak;
+            const float *bp = a.pk + a.off_Ws[m] + (int64_t)nt * steps * 64 + lane;
+            accy[1 + m] = head_mfma_run(accy[1 + m], ap, bp, kh * hs, hs);
+        }
+    }
+    if (kh == 1) {
+#pragma unroll
+        for (int b = 0; b < 1 + HMAXM; ++b)
+            if (b <= a.n_mod)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * ak;
+                    Part[(b * HROWS + row) * HD + nt * 32 + ai] = accy[b][r];
+                }
+    }
+    __syncthreads();
+    if (kh == 0) {
+        const int col = nt * 32 + ai;
+#pragma unroll
+        for (int b = 0; b < 1 + HMAXM; ++b)
+            if (b <= a.n_mod) {
+                const float *bias = b == 0 ? a.bias_f[side] : a.bias_s[b - 1];
+                const float bb = bias ? bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * ak;
+                    if (row < nrows) a.YAct[(int64_t)(r0 + row) * a.ld_y + b * HD + col] = (accy[b][r] + Part[(b * HROWS + row) * HD + col]) + bb;
+                }
+            }
+    }
+}
+
+}  // namespace elimrec
+
+using namespace elimrec;
+
+extern "C" size_t elimrec_head_pack_floats(int n_mod, const int *D) {
+    if (n_mod < 0 || n_mod > HMAXM) return 0;
+    size_t f = 0;
+    for (int m = 0; m < n_mod; ++m) f += (size_t)HD * D[m];
+    f += (size_t)2 * HD * (1 + n_mod) * HD + (size_t)n_mod * HD * HD;
+    return f;
+}
+
+extern "C" int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg_info, int64_t R, const float *d_out0,
+                                      int64_t ld_out0, const float *d_narrow, int64_t ld_nar, const float *d_c, int n_mod,
+                                      const float *const *d_S, const int64_t *ldS, const int *D, const float *const *d_Wm,
+                                      const float *const *d_bm, const float *d_Wf_user, const float *d_bf_user,
+                                      const float *d_Wf_item, const float *d_bf_item, const float *const *d_Ws,
+                                      const float *const *d_bs, float *d_pack, size_t pack_floats, float *d_OutAct,
+                                      int64_t ld_out, float *d_YAct, int64_t ld_y, int recdim, void *stream) {
+    ELIMREC_REQUIRE(d_act && d_seg_info && d_out0 && d_narrow && d_c && d_S && d_Wm && d_Wf_user && d_Wf_item && d_Ws && d_pack &&
+                        d_OutAct && d_YAct, "head_fwd_fused: null pointer");
+    if (recdim != HD || n_mod < 1 || n_mod > HMAXM) { set_error("head_fwd_fused: recdim must be %d and 1..%d feature tables", HD, HMAXM); return ELIMREC_E_UNSUPPORTED; }
+    const int C = (1 + n_mod) * HD;
+    ELIMREC_REQUIRE(ld_out0 % 4 == 0 && ld_nar % 4 == 0 && ld_out >= C && ld_y >= C, "head_fwd_fused: bad leading dimensions");
+    ELIMREC_REQUIRE(pack_floats >= elimrec_head_pack_floats(n_mod, D), "head_fwd_fused: packed-weight buffer too small");
+    if (R <= 0) return 0;
+    HeadFwdArgs a = {};
+    PackJobs pj = {};
+    int64_t off = 0;
+    int lds_f = 2 * HROWS * (HD + 1);
+    int blocks = 0;
+    auto add_job = [&](const float *W, int K) {
+        PackJob &j = pj.j[pj.n];
+        j.W = W; j.ld = K; j.K = K; j.dst = off;
+        pj.first_block[pj.n] = blocks;
+        blocks += (HD * K + 255) / 256 > 64 ? 64 : (HD * K + 255) / 256;
+        ++pj.n;
+        const int64_t at = off;
+        off += (int64_t)HD * K;
+        return at;
+    };
+    for (int m = 0; m < n_mod; ++m) {
+        ELIMREC_REQUIRE(d_S[m] && d_Wm[m] && d_Ws[m] && D[m] > 0 && D[m] % 4 == 0 && ldS[m] % 4 == 0, "head_fwd_fused: bad feature table %d", m);
+        a.S[m] = d_S[m]; a.ldS[m] = ldS[m]; a.D[m] = D[m]; a.bias_m[m] = d_bm ? d_bm[m] : nullptr;
+        a.a_off[m] = lds_f;
+        lds_f += HROWS * (D[m] + 1);
+        a.off_Wm[m] = add_job(d_Wm[m], D[m]);
+    }
+    a.off_Wf[0] = add_job(d_Wf_user, C);
+    a.off_Wf[1] = add_job(d_Wf_item, C);
+    for (int m = 0; m < n_mod; ++m) { a.off_Ws[m] = add_job(d_Ws[m], HD); a.bias_s[m] = d_bs ? d_bs[m] : nullptr; }
+    pj.first_block[pj.n] = blocks;
+    a.out_off = lds_f; lds_f += HROWS * (C + 1);
+    a.part_off = lds_f; lds_f += (1 + n_mod) * HROWS * HD;
+    const size_t lds_bytes = (size_t)lds_f * sizeof(float);
+    if (lds_bytes > 158 * 1024) { set_error("head_fwd_fused: feature widths need %zu B of LDS", lds_bytes); return ELIMREC_E_UNSUPPORTED; }
+    a.act = d_act; a.seg_info = d_seg_info; a.out0 = d_out0; a.ld_out0 = ld_out0; a.narrow = d_narrow; a.ld_nar = ld_nar; a.c = d_c;
+    a.n_mod = n_mod; a.pk = d_pack; a.bias_f[0] = d_bf_user; a.bias_f[1] = d_bf_item;
+    a.OutAct = d_OutAct; a.ld_out = ld_out; a.YAct = d_YAct; a.ld_y = ld_y;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(pack_head_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pj, d_pack);
+    ELIMREC_LAUNCH_CHECK("pack_head_weights");
+    static size_t lds_set = 0;
+    if (lds_bytes > 64 * 1024 && lds_bytes > lds_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)head_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return check_hip(e, "head_fwd_fused: LDS size");
+        lds_set = lds_bytes;
+    }
+    const unsigned tiles = (unsigned)((R + HROWS - 1) / HROWS + 1);      // user tiles + item tiles <= R/32 + 2
+    hipLaunchKernelGGL(head_fwd_fused_kernel, dim3(tiles + 1), dim3(256), lds_bytes, s, a);
+    ELIMREC_LAUNCH_CHECK("head_fwd_fused");
+    return 0;
+}

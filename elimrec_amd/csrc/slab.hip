@@ -291,7 +291,7 @@ __device__ __forceinline__ int slab_merge_key(const int32_t *keys, int i) {
 
 __global__ __launch_bounds__(256) void slab_merge_rows_kernel(const float *__restrict__ rows, const int32_t *__restrict__ keys,
                                                               int W, int R, int64_t U, int64_t N, int nc4, int w4,
-                                                              int w4_shift, int chunk, float *SrcA, float *SrcB,
+                                                              int w4_shift, int chunk, int M, float *SrcA, float *SrcB,
                                                               uint32_t *__restrict__ mask) {
     __shared__ int s_beg[kSlabMaxRanks], s_end[kSlabMaxRanks];
     extern __shared__ uint32_t seen[];
@@ -313,12 +313,20 @@ __global__ __launch_bounds__(256) void slab_merge_rows_kernel(const float *__res
             const int64_t node = keys[(int64_t)r * R + s];
             const int bit = (int)(node - lo);
             const bool was = (seen[bit >> 5] >> (bit & 31)) & 1u;
-            const float4 *g = reinterpret_cast<const float4 *>(rows) + ((int64_t)r * R + s) * 2 * nc4;
+            const float4 *g = reinterpret_cast<const float4 *>(rows) + ((int64_t)r * R + s) * (M ? M : 2) * nc4;
             float *hT = node < U ? SrcA : SrcB;       // H lives in SrcA on user rows, SrcB on item rows
             float *gT = node < U ? SrcB : SrcA;
             for (int c = lane; c < nc4; c += 64) {
                 const int64_t idx = (((int64_t)(c >> w4_shift) * N + node) * w4 + (c & (w4 - 1))) * 4;
-                float4 h = g[c], g0 = g[nc4 + c];
+                float4 h, g0;
+                if (M) {                                 // dOut rows: G = block 0, H = sum of the M blocks (block order)
+                    g0 = g[c];
+                    h = g0;
+                    for (int mb = 1; mb < M; ++mb) {
+                        const float4 x = g[mb * nc4 + c];
+                        h.x += x.x; h.y += x.y; h.z += x.z; h.w += x.w;
+                    }
+                } else { h = g[c]; g0 = g[nc4 + c]; }
                 if (was) {                               // written by an earlier rank of this workgroup: read through L2
                     float *hp = hT + idx, *gp = gT + idx;
                     float4 x, y;
@@ -974,6 +982,44 @@ __global__ __launch_bounds__(256) void stream_fixup_kernel(StreamArgs a) {
     stream_combine<LPR, VPL, OUT_BF16>(a, grp, li);
 }
 
+// The whole optimizer step in ONE launch: up to 8 jobs (the column shard of the embeddings, read from one buffer and
+// written to the other and -- bf16 storage -- to the gather copy; the spans of the projection weights that have a
+// gradient, in place; copy-only spans). A job may also copy its PRE-update parameters to copy_dst: the snapshot of the
+// projection weights the cached tables were computed with (models/EliMRec.py:98-99). Arithmetic of adam_kernel.
+struct AdamJob {
+    const float *p_in;
+    float *p_out;
+    uint16_t *p16;          // nullable
+    const float *g;         // nullable: copy-only job
+    float *m, *v;
+    float *copy_dst;        // nullable
+    int64_t n;
+    float step_size, inv_sqrt_bc2;
+    int first_block;
+};
+struct AdamJobs { AdamJob j[8]; int n; };
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamJobs jobs, float beta1, float beta2, float eps, float wd) {
+    int k = 0;
+    while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.j[k + 1].first_block) ++k;
+    const AdamJob &jb = jobs.j[k];
+    const int nb = (k + 1 < jobs.n ? jobs.j[k + 1].first_block : (int)gridDim.x) - jb.first_block;
+    for (int64_t i = (int64_t)((int)blockIdx.x - jb.first_block) * 256 + threadIdx.x; i < jb.n; i += (int64_t)nb * 256) {
+        const float pi = jb.p_in[i];
+        if (jb.copy_dst) jb.copy_dst[i] = pi;
+        if (!jb.g) continue;
+        const float gi = fmaf(wd, pi, jb.g[i]);
+        const float mi = jb.m[i] + (1.f - beta1) * (gi - jb.m[i]);
+        const float vi = fmaf(1.f - beta2, gi * gi, beta2 * jb.v[i]);
+        const float denom = sqrtf(vi) * jb.inv_sqrt_bc2 + eps;
+        jb.m[i] = mi;
+        jb.v[i] = vi;
+        const float po = pi - jb.step_size * (mi / denom);
+        jb.p_out[i] = po;
+        if (jb.p16) jb.p16[i] = __bfloat16_as_ushort(__float2bfloat16(po));
+    }
+}
+
 static int log2_pow2(int x) {
     int s = 0;
     while ((1 << s) < x) ++s;
@@ -1249,8 +1295,9 @@ extern "C" int elimrec_slab_to_rows(const float *d_slab, int64_t n, int ns, int 
 }
 
 extern "C" int elimrec_slab_merge_rows(const float *d_rows, const int32_t *d_keys, int world, int64_t R, int64_t U,
-                                       int64_t I, int ns, int w, float *d_SrcA, float *d_SrcB, uint32_t *d_mask,
+                                       int64_t I, int ns, int w, int M, float *d_SrcA, float *d_SrcB, uint32_t *d_mask,
                                        void *stream) {
+    ELIMREC_REQUIRE(M >= 0, "slab_merge_rows: M >= 0");
     ELIMREC_REQUIRE(d_rows && d_keys && d_SrcA && d_SrcB && d_mask, "slab_merge_rows: null pointer");
     ELIMREC_REQUIRE(world >= 1 && world <= kSlabMaxRanks && R >= 1 && R < INT32_MAX, "slab_merge_rows: 1..%d ranks", kSlabMaxRanks);
     int sh, rc;
@@ -1262,7 +1309,7 @@ extern "C" int elimrec_slab_merge_rows(const float *d_rows, const int32_t *d_key
     const unsigned grid = (unsigned)((N + chunk - 1) / chunk);
     if (grid == 0) return 0;
     hipLaunchKernelGGL(slab_merge_rows_kernel, dim3(grid), dim3(256), (size_t)(chunk / 32) * sizeof(uint32_t),
-                       (hipStream_t)stream, d_rows, d_keys, world, (int)R, U, N, ns * (w / 4), w / 4, sh, chunk, d_SrcA, d_SrcB,
+                       (hipStream_t)stream, d_rows, d_keys, world, (int)R, U, N, ns * (w / 4), w / 4, sh, chunk, M, d_SrcA, d_SrcB,
                        d_mask);
     ELIMREC_LAUNCH_CHECK("slab_merge_rows");
     return 0;
@@ -1423,5 +1470,37 @@ extern "C" int elimrec_adam_step_out16(const float *d_p_in, float *d_p_out, void
                        (float4 *)d_p_out, (uint2 *)d_p_bf16, (const float4 *)d_g, (float4 *)d_m, (float4 *)d_v, n / 4, step_size,
                        beta1, beta2, inv_sqrt_bc2, eps, weight_decay);
     ELIMREC_LAUNCH_CHECK("adam_step_out16");
+    return 0;
+}
+
+extern "C" int elimrec_adam_multi(const elimrec_adam_job *jobs, int n_jobs, float lr, float beta1, float beta2, float eps,
+                                  float weight_decay, void *stream) {
+    ELIMREC_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= 8, "adam_multi: 1..8 jobs");
+    AdamJobs a = {};
+    a.n = 0;
+    int blocks = 0;
+    for (int k = 0; k < n_jobs; ++k) {
+        const elimrec_adam_job &j = jobs[k];
+        if (j.n <= 0) continue;
+        ELIMREC_REQUIRE(j.d_p_in, "adam_multi: job %d has no parameters", k);
+        ELIMREC_REQUIRE(!j.d_g || (j.d_p_out && j.d_m && j.d_v && j.step >= 1), "adam_multi: job %d: an update needs p_out, m, v and a 1-based step", k);
+        ELIMREC_REQUIRE(j.d_g || j.d_copy_dst, "adam_multi: job %d does nothing", k);
+        AdamJob &o = a.j[a.n++];
+        o.p_in = j.d_p_in; o.p_out = j.d_p_out; o.p16 = (uint16_t *)j.d_p_bf16; o.g = j.d_g; o.m = j.d_m; o.v = j.d_v;
+        o.copy_dst = j.d_copy_dst; o.n = j.n;
+        if (j.d_g) {
+            const double bc1 = 1.0 - pow((double)beta1, (double)j.step);
+            const double bc2 = 1.0 - pow((double)beta2, (double)j.step);
+            o.step_size = (float)((double)lr / bc1);
+            o.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+        }
+        o.first_block = blocks;
+        int64_t nb = (j.n + 255) / 256;
+        if (nb > 4096) nb = 4096;
+        blocks += (int)nb;
+    }
+    if (a.n == 0) return 0;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, beta1, beta2, eps, weight_decay);
+    ELIMREC_LAUNCH_CHECK("adam_multi");
     return 0;
 }

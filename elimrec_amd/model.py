@@ -463,6 +463,11 @@ class EliMRec(BasicModel):
                 views[name] = flat_grad[off:off + p.numel()].view_as(p)
                 off += n
         ws["flat_param"], ws["flat_grad"], ws["grad_views"] = flat, flat_grad, views
+        offs, o = {}, 0
+        for (name, p), n in zip(params, sizes):
+            offs[name] = (o, p.numel())
+            o += n
+        ws["param_off"] = offs                   # name -> (offset in the flat buffers, numel)
         # every non-embedding parameter, live and as the copy a training forward takes (predict() after an
         # optimizer step must still see the weights its cached tables were computed with)
         tail = sizes[0] + sizes[1]
@@ -662,7 +667,7 @@ class EliMRec(BasicModel):
                                              lambda: ops.propagate_layers(adj, U, d, L, ws["X0d"], ws["layers"])))
         self._fwd_head(ws, all_keys, n, B, rank, grad_rows)
 
-    def _fwd_head(self, ws, all_keys, n, B, rank, grad_rows, layer_means=True):
+    def _fwd_head(self, ws, all_keys, n, B, rank, grad_rows, layer_means=True, snapshot=True):
         """Everything after the graph at the batch's active rows: layer means (unless the caller has already put
         them into ws['OutAct'][:, :d] / ws['Narrow'] -- the column-sharded engine, shard.py), feature blocks, fused
         Linear and single-modal heads, loss rows and their gradient rows. One recorded region."""
@@ -673,7 +678,8 @@ class EliMRec(BasicModel):
         def head():
             OutAct, YAct = ws["OutAct"][:n], ws["YAct"][:n]
             W = ws["live_views"]
-            ops.copy_cols(ws["flat_param"][ws["tail_off"]:].view(1, -1), ws["snap"].view(1, -1))
+            if snapshot:        # the projection weights this forward uses, for the lazily materialised cached tables
+                ops.copy_cols(ws["flat_param"][ws["tail_off"]:].view(1, -1), ws["snap"].view(1, -1))
             if layer_means:
                 ops.folded_rows(ws["layers"], U, I, d, L, act, seg[0:1], OutAct[:, :d], ws["Narrow"])
             ops.linear_fwd_batched(self._fold_problems(ws, W, OutAct, act, seg[6:8]))
@@ -689,7 +695,7 @@ class EliMRec(BasicModel):
             ops.bpr_head_rows(YAct, ws["slot_seg"][3 * B * rank:3 * B * (rank + 1)], d, bw, ws["loss_rows"], grad_rows)
 
         self._region("fwd_head", (self._ws_gen, all_keys.data_ptr(), n, B, rank, tuple(bw), grad_rows is not None,
-                                  layer_means), head)
+                                  layer_means, snapshot), head)
         self._publish_cache(ws["Y"], dirty=True)
 
     def _index_tensors(self, *ts):

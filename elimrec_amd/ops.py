@@ -403,6 +403,19 @@ def triplet_rows(users, pos, neg, U, rows, src=None, dst=None, I=None, err=None)
     return rows
 
 
+def batch_plan(users, pos, neg, U, I, keys, active_rows, seg_info, slot_seg, workspace, err, pad_key, key_bitmap=None):
+    """triplet_rows (range-checked) + segment_plan + padding of the active-row list in one launch (elimrec_batch_plan)."""
+    B = users.numel()
+    _lib.check(_lib.load().elimrec_batch_plan(_dev(users, "users", torch.int64), _dev(pos, "pos", torch.int64),
+                                              _dev(neg, "neg", torch.int64), B, int(U), int(I), _dev(keys, "keys", torch.int32),
+                                              _dev(active_rows, "active_rows", torch.int32),
+                                              _dev(seg_info, "seg_info", torch.int32), _dev(slot_seg, "slot_seg", torch.int32),
+                                              _dev(key_bitmap, "key_bitmap", torch.int32), int(pad_key),
+                                              _dev(err, "err", torch.int32), _dev(workspace, "workspace", torch.uint8),
+                                              workspace.numel(), _stream()), "batch_plan")
+    return keys
+
+
 def pad_rows(rows, keys, count, pad_key=0):
     """rows[count:] = 0, keys[r] = pad_key + r for r >= count (count: device int32 scalar)."""
     r, ld = _rowmajor(rows, "rows")
@@ -598,3 +611,29 @@ def sample_triplets(user_ids, ptr, items, num_items, n, seed, epoch, users, pos,
                                                    int(seed), int(epoch), _dev(users, "users", torch.int64),
                                                    _dev(pos, "pos", torch.int64), _dev(neg, "neg", torch.int64),
                                                    _stream()), "sample_triplets")
+
+
+def head_pack_floats(dims):
+    arr = (ctypes.c_int * max(len(dims), 1))(*dims)
+    return int(_lib.load().elimrec_head_pack_floats(len(dims), arr))
+
+
+def head_fwd_fused(act, seg_info, out0, narrow, c, S, Wm, bm, Wf_user, bf_user, Wf_item, bf_item, Ws, bs, pack, OutAct, YAct, d):
+    """elimrec_head_fwd_fused: S / Wm / bm / Ws / bs are lists over the feature tables. Returns False when the shape is
+    outside the fused kernel's range (the caller keeps the batched GEMMs)."""
+    n = len(S)
+    R = act.numel()
+    ptr = lambda ts: (ctypes.c_void_p * max(n, 1))(*[_dev(t, "table") for t in ts])
+    ldS = (ctypes.c_int64 * max(n, 1))(*[t.stride(0) for t in S])
+    D = (ctypes.c_int * max(n, 1))(*[t.shape[1] for t in S])
+    for w in list(Wm) + list(Ws) + [Wf_user, Wf_item]:
+        assert w.is_contiguous()
+    rc = _lib.load().elimrec_head_fwd_fused(
+        _dev(act, "act", torch.int32), _dev(seg_info, "seg_info", torch.int32), R, _dev(out0, "out0"), out0.stride(0),
+        _dev(narrow, "narrow"), narrow.stride(0), _dev(c, "c"), n, ptr(S), ldS, D, ptr(Wm), ptr(bm), _dev(Wf_user, "Wf_user"),
+        _dev(bf_user, "bf_user"), _dev(Wf_item, "Wf_item"), _dev(bf_item, "bf_item"), ptr(Ws), ptr(bs), _dev(pack, "pack"),
+        pack.numel(), _dev(OutAct, "OutAct"), OutAct.stride(0), _dev(YAct, "YAct"), YAct.stride(0), int(d), _stream())
+    if rc == 10002:           # ELIMREC_E_UNSUPPORTED
+        return False
+    _lib.check(rc, "head_fwd_fused")
+    return True

@@ -29,7 +29,7 @@ kernels, tests/test_dist_cpu.py injects a CPU stand-in built from the oracle to 
 import torch
 import torch.distributed as dist
 
-from . import ops, slab
+from . import _lib, ops, slab
 
 PAD_KEY = -(1 << 30)
 
@@ -162,6 +162,8 @@ class ColumnShardEngine(object):
         self.srcA, self.srcB, self.tmp = tab(), tab(), [ttab(), ttab()]
         self.mask = torch.zeros((N + 31) // 32 + 2, dtype=torch.int32, device=dev)
         self.step_count = 0
+        self._fused = None
+        self._tail_plan = None
         self._bufs = {}
         self._x0_fwd = None
         ws = m._workspace(1)
@@ -179,6 +181,7 @@ class ColumnShardEngine(object):
         self.master[self.cur].from_rows(ws["X0d"], col0=self.col0)
         if self.bf16:
             self.master[self.cur].to_bf16(self.mirror[self.cur])
+        ws["snap"].copy_(ws["flat_param"][ws["tail_off"]:])        # from here on the snapshot is refreshed by cs_update
 
     @torch.no_grad()
     def sync_to_model(self):
@@ -208,7 +211,23 @@ class ColumnShardEngine(object):
                                         send_f=torch.empty(W, R, 2 * self.dl, dtype=torch.float32, device=dev) if W > 1 else None,
                                         counts=torch.zeros(W, dtype=torch.int32, device=dev))
         self.hg, self.send_f, self.counts = bufs["hg"], bufs["send_f"], bufs["counts"]
+        if "nar_act" not in bufs:
+            bufs["nar_act"] = torch.zeros(R, d, dtype=torch.float32, device=dev)       # shared part of Out, compact rows
+        self.nar_act = bufs["nar_act"]
         return ws
+
+    def _fused_head_ok(self):
+        """The one-launch head forward (csrc/head.hip) covers recdim 64, concat fusion and row tiles that fit LDS."""
+        m = self.model
+        if self._fused is None:
+            import os
+            dims = [getattr(m, k + "_feat").shape[1] for k in m._mods]
+            lds = 4 * (2 * 32 * 65 + sum(32 * (D + 1) for D in dims) + 32 * (m.C + 1) + (1 + m.S) * 32 * 64)
+            self._fused = (os.environ.get("ELIMREC_FUSED_HEAD", "1") != "0" and m.latent_dim == 64 and 1 <= m.S <= 3
+                           and m.mm_fusion_mode == "concat" and lds <= 158 * 1024)
+            if self._fused:
+                self._pack = torch.empty(ops.head_pack_floats(dims), dtype=torch.float32, device=m._device())
+        return self._fused
 
     def _timed(self, fn, hops):
         ev = self.kernel_events
@@ -227,17 +246,17 @@ class ColumnShardEngine(object):
         B = int(users.numel())
         ws = self._workspace(B)
         users, pos, neg = m._index_tensors(users, pos, neg)
-        keys = ops.triplet_rows(users, pos, neg, m.num_users, ws["keys"][:3 * B], I=m.num_items, err=m._index_err())
         R = 3 * B
+        keys = ws["keys"][:R]
         act, seg = ws["active_rows"][:R], ws["seg_info"]
         m._plan_n = R
         m._last_block_weights = m._block_weights()
         self._keys = keys
+        err = m._index_err()
 
-        def plan():
-            ops.segment_plan(keys, m.num_users, m.num_users + m.num_items, act, seg, ws["slot_seg"][:R], ws["plan_ws"])
-            ops.pad_rows(self.hg, act, seg[0:1], pad_key=PAD_KEY)
-        m._region("cs_plan", (m._ws_gen, keys.data_ptr(), R), plan)
+        def plan():       # node ids of the slots, unique active rows + slot map, padded tail: one launch
+            ops.batch_plan(users, pos, neg, m.num_users, m.num_items, keys, act, seg, ws["slot_seg"][:R], ws["plan_ws"], err, PAD_KEY)
+        m._region("cs_plan", (m._ws_gen, users.data_ptr(), pos.data_ptr(), neg.data_ptr(), R), plan)
         return act
 
     @torch.no_grad()
@@ -268,7 +287,10 @@ class ColumnShardEngine(object):
             out0, narrow, by_node = self.send_f.view(W * R, 2 * self.dl)[:, :self.dl], self.send_f.view(W * R, 2 * self.dl)[:, self.dl:], False
         else:
             counts = ws["seg_info"][0:1]
-            out0, narrow, by_node = ws["OutAct"][:R, :m.latent_dim], ws["Narrow"], True
+            if self._fused_head_ok():
+                out0, narrow, by_node = ws["OutAct"][:R, :m.latent_dim], self.nar_act, False
+            else:
+                out0, narrow, by_node = ws["OutAct"][:R, :m.latent_dim], ws["Narrow"], True
 
         def rows():
             if self.plan.n_long:
@@ -279,7 +301,7 @@ class ColumnShardEngine(object):
             else:
                 slab.rows(self.plan, self.ns, self.w, L, U, [t.data for t in tabs] + [None], self.long_tab, acts, counts, R, W,
                           out0, narrow, by_node)
-        m._region("cs_fwd_rows%d" % self.cur, (m._ws_gen, acts.data_ptr(), R, W), rows)
+        m._region("cs_fwd_rows%d" % self.cur, (m._ws_gen, acts.data_ptr(), R, W, narrow.data_ptr()), rows)
         return self.send_f if W > 1 else None
 
     def cs_forward(self, acts):
@@ -292,18 +314,46 @@ class ColumnShardEngine(object):
         ws, d = m._ws, m.latent_dim
         R = m._plan_n
         B = R // 3
+        fused = self._fused_head_ok()
         if recv is not None:                                      # [W, R, (out0 | narrow)] -> my rows, all columns
             W = recv.shape[0]
             r = recv.view(W, R, 2, self.dl)
             ws["OutAct"][:R, :d].unflatten(1, (W, self.dl)).copy_(r[:, :, 0].permute(1, 0, 2))
-            act = ws["active_rows"][:R].long()
-            idx = torch.where(act >= 0, act, torch.full_like(act, self.narrow_x.shape[0] - 1))
-            self.narrow_x.index_copy_(0, idx, r[:, :, 1].permute(1, 0, 2).reshape(R, d))
-        m._fwd_head(ws, self._keys, R, B, 0, ws["grad_rows"], layer_means=False)
+            if fused:
+                self.nar_act.unflatten(1, (W, self.dl)).copy_(r[:, :, 1].permute(1, 0, 2))
+            else:
+                act = ws["active_rows"][:R].long()
+                idx = torch.where(act >= 0, act, torch.full_like(act, self.narrow_x.shape[0] - 1))
+                self.narrow_x.index_copy_(0, idx, r[:, :, 1].permute(1, 0, 2).reshape(R, d))
+        if fused:
+            self._head_forward_fused(ws, R, B)
+        else:
+            m._fwd_head(ws, self._keys, R, B, 0, ws["grad_rows"], layer_means=False, snapshot=False)
         m._slab_fwd = True
         loss = torch.empty((), dtype=torch.float32, device=m._device())
         ops.fixed_order_sum(ws["loss_rows"], loss)
         return loss
+
+    def _head_forward_fused(self, ws, R, B):
+        """Feature blocks, fused Linear, single-modal heads at the active rows in one launch, then the cosine-BPR rows."""
+        m = self.model
+        d, fold, W = m.latent_dim, ws["fold"], ws["live_views"]
+        act, seg = ws["active_rows"][:R], ws["seg_info"]
+        OutAct, YAct = ws["OutAct"][:R], ws["YAct"][:R]
+        bw = m._last_block_weights
+
+        def head():
+            wu, wi = m._fusion_weights(W)
+            ok = ops.head_fwd_fused(act, seg, OutAct[:, :d], self.nar_act, fold["c"], [fold[k] for k in m._mods],
+                                    [W[k + "_dense.weight"] for k in m._mods], [W[k + "_dense.bias"] for k in m._mods], wu,
+                                    W["embedding_user_after_GCN.bias"], wi, W["embedding_item_after_GCN.bias"],
+                                    [W["s_dense_%s.weight" % k] for k in m._mods], [W["s_dense_%s.bias" % k] for k in m._mods],
+                                    self._pack, OutAct, YAct, d)
+            if not ok:
+                raise RuntimeError("fused head forward refused a shape _fused_head_ok accepted")
+            ops.bpr_head_rows(YAct, ws["slot_seg"][:3 * B], d, bw, ws["loss_rows"], ws["grad_rows"])
+        m._region("cs_head_fused", (m._ws_gen, R, B, tuple(bw), self.nar_act.data_ptr()), head)
+        m._publish_cache(ws["Y"], dirty=True)
 
     @torch.no_grad()
     def cs_backward_local(self, scale):
@@ -311,11 +361,12 @@ class ColumnShardEngine(object):
         ws, d = m._ws, m.latent_dim
         R = m._plan_n
         self._grads = m._backward_batch_rows(ws, scale, ws["grad_rows"], R, head_only=True)
-        # [H | G]: all the adjoint needs of a dOut row (rows beyond the active count stay zero, their keys negative)
-        m._region("cs_sources", (m._ws_gen, R), lambda: ops.source_rows(ws["dOutR"][:R], ws["seg_info"][0:1], d, m.M, self.hg))
         wg = ws["flat_grad"][ws["tail_off"]:]
-        if self.world == 1:
-            return self.hg.view(1, R, 2 * d), wg
+        if self.world == 1:       # one rank owns every column: the merge reads the dOut rows themselves
+            return ws["dOutR"][:R].view(1, R, m.C), wg
+        # [H | G]: all the adjoint needs of a dOut row, split into the peers' column slices (rows beyond the active
+        # count are never read: their keys are negative)
+        m._region("cs_sources", (m._ws_gen, R), lambda: ops.source_rows(ws["dOutR"][:R], ws["seg_info"][0:1], d, m.M, self.hg))
         W = self.world
         send = self.hg.view(R, 2, W, self.dl).permute(2, 0, 1, 3).contiguous().view(W, R, 2 * self.dl)
         return send, wg
@@ -328,7 +379,10 @@ class ColumnShardEngine(object):
         inv = 1.0 / (L + 1)
 
         def hops():
-            slab.merge_rows(recv2.view(W * R, 2 * self.dl), acts.reshape(-1), W, U, I, self.srcA, self.srcB, self.mask)
+            if W == 1:
+                slab.merge_rows(recv2.view(R, m.C), acts.reshape(-1), 1, U, I, self.srcA, self.srcB, self.mask, M=m.M)
+            else:
+                slab.merge_rows(recv2.view(W * R, 2 * self.dl), acts.reshape(-1), W, U, I, self.srcA, self.srcB, self.mask)
             t, tmask = (self.srcB if (L & 1) else self.srcA), self.mask          # T^L = S^L (row-sparse)
             for k in range(L - 1, -1, -1):
                 dst = self.grad if k == 0 else self.tmp[k & 1]
@@ -339,23 +393,60 @@ class ColumnShardEngine(object):
 
     @torch.no_grad()
     def cs_update(self):
+        """Adam (coupled L2) on the column shard of the embeddings (buffer `cur` -> the other one, + the bf16 gather copy)
+        and on the projection weights that received a gradient, in ONE launch; the same launch copies the projection
+        weights as they were BEFORE the update into the snapshot predict()'s lazily built tables use."""
         m = self.model
         g = self.opt.param_groups[0]
         self.step_count += 1
         nxt = 1 - self.cur
-        if self.bf16:
-            slab.adam_step_out16(self.master[self.cur].data, self.master[nxt].data, self.mirror[nxt].data, self.grad.data,
-                                 self.m1, self.m2, g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
-                                 self.step_count)
-        else:
-            slab.adam_step_out(self.master[self.cur].data, self.master[nxt].data, self.grad.data, self.m1, self.m2, g["lr"],
-                               g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self.step_count)
+        jobs = [_lib.AdamJob(self.master[self.cur].data.data_ptr(), self.master[nxt].data.data_ptr(),
+                             self.mirror[nxt].data.data_ptr() if self.bf16 else None, self.grad.data.data_ptr(),
+                             self.m1.data_ptr(), self.m2.data_ptr(), None, self.grad.data.numel(), self.step_count)]
+        jobs += self._tail_jobs()
+        if len(jobs) > 8:
+            raise RuntimeError("more than 8 optimizer spans")
+        arr = (_lib.AdamJob * len(jobs))(*jobs)
+        _lib.check(_lib.load().elimrec_adam_multi(arr, len(jobs), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                                                  g["weight_decay"], ops._stream()), "adam_multi")
         self.cur = nxt
-        for name, p in m.named_parameters():
-            p.grad = None
-        for name, p in self._tail:
-            p.grad = self._grads.get(name)
-        self.opt.step()
+
+    def _tail_jobs(self):
+        """Spans of the flat parameter buffer behind the embeddings: runs of adjacent projection weights that have a
+        gradient (Adam in place, moments = the caller's FusedAdam state, whose step counts advance) and the runs that
+        have none (copied to the snapshot only). The span list is fixed for a given set of gradients."""
+        m, ws = self.model, self.model._ws
+        have = tuple(name for name, _ in self._tail if self._grads.get(name) is not None)
+        if self._tail_plan is None or self._tail_plan[0] != have:
+            base_p, base_g, snap = ws["flat_param"].data_ptr(), ws["flat_grad"].data_ptr(), ws["snap"].data_ptr()
+            tail_off = ws["tail_off"]
+            spans, states = [], []
+            for name, p in self._tail:
+                off, numel = ws["param_off"][name]
+                upd = name in have
+                st = self.opt._state_for(p) if upd else None
+                if upd:
+                    states.append(st)
+                if spans and spans[-1]["upd"] == upd and spans[-1]["end"] + 3 >= off and (not upd or (
+                        st["step"] == spans[-1]["step"] and st["exp_avg"].data_ptr() == spans[-1]["m"] + 4 * (off - spans[-1]["off"]))):
+                    spans[-1]["end"] = off + numel
+                else:
+                    spans.append(dict(off=off, end=off + numel, upd=upd, step=st["step"] if upd else 0,
+                                      m=st["exp_avg"].data_ptr() if upd else 0, v=st["exp_avg_sq"].data_ptr() if upd else 0))
+            self._tail_plan = (have, spans, states, base_p, base_g, snap, tail_off)
+        _, spans, states, base_p, base_g, snap, tail_off = self._tail_plan
+        for st in states:
+            st["step"] += 1
+        jobs = []
+        for sp in spans:
+            n, o = sp["end"] - sp["off"], sp["off"]
+            if sp["upd"]:
+                sp["step"] += 1
+                jobs.append(_lib.AdamJob(base_p + 4 * o, base_p + 4 * o, None, base_g + 4 * o, sp["m"], sp["v"],
+                                         snap + 4 * (o - tail_off), n, sp["step"]))
+            else:
+                jobs.append(_lib.AdamJob(base_p + 4 * o, None, None, None, None, None, snap + 4 * (o - tail_off), n, 0))
+        return jobs
 
     # ------------------------------------------------------------------ cached tables for predict()
     @torch.no_grad()

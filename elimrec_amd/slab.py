@@ -265,12 +265,13 @@ def rows(plan, ns, w, L, U, layers, long_tab, row_ids, counts, R, n_lists, out0,
                                              _stream()), "slab_rows")
 
 
-def merge_rows(all_rows, all_keys, world, U, I, srcA, srcB, mask):
-    """[H | G] rows of `world` ranks -> slab-major adjoint sources + row bitmap (elimrec_slab_merge_rows)."""
+def merge_rows(all_rows, all_keys, world, U, I, srcA, srcB, mask, M=0):
+    """[H | G] rows (M = 0) or dOut rows of M column blocks (M >= 1) of `world` ranks -> slab-major adjoint sources + row
+    bitmap (elimrec_slab_merge_rows)."""
     R = all_keys.numel() // world
-    assert all_rows.is_contiguous() and all_rows.shape == (world * R, 2 * srcA.cols) and mask.numel() * 32 >= U + I
+    assert all_rows.is_contiguous() and all_rows.shape == (world * R, (M if M else 2) * srcA.cols) and mask.numel() * 32 >= U + I
     _lib.check(_lib.load().elimrec_slab_merge_rows(_dev(all_rows, "rows"), _dev(all_keys, "keys", torch.int32), int(world), R,
-                                                   int(U), int(I), srcA.ns, srcA.w, _dev(srcA.data, "srcA"),
+                                                   int(U), int(I), srcA.ns, srcA.w, int(M), _dev(srcA.data, "srcA"),
                                                    _dev(srcB.data, "srcB"), _dev(mask, "mask", torch.int32), _stream()),
                "slab_merge_rows")
 

@@ -78,6 +78,14 @@ int elimrec_triplet_rows(const int64_t *d_users, const int64_t *d_pos, const int
  * the host tests the word when it next synchronises (EliMRec.check_indices()). */
 int elimrec_triplet_rows_checked(const int64_t *d_users, const int64_t *d_pos, const int64_t *d_neg, int64_t B,
                                  int64_t U, int64_t I, int32_t *d_rows, int32_t *d_err, void *stream);
+/* The whole index front end of a training step in ONE launch (for 3B <= 8192 slots; more fall back to separate
+ * launches): node ids of the triplet slots (range-checked as above) -> d_keys, then elimrec_segment_plan of those
+ * keys (split_key = U, key_space = U + I), then the unused tail of d_active_rows set to pad_key + slot (distinct
+ * negative keys: what the ranks of a column-sharded job exchange and merge). */
+int elimrec_batch_plan(const int64_t *d_users, const int64_t *d_pos, const int64_t *d_neg, int64_t B, int64_t U,
+                       int64_t I, int32_t *d_keys, int32_t *d_active_rows, int32_t *d_seg_info,
+                       int32_t *d_slot_seg, uint32_t *d_key_bitmap, int32_t pad_key, int32_t *d_err,
+                       void *d_workspace, size_t workspace_bytes, void *stream);
 /* Rows [*d_count, n) of a compact row buffer do not belong to the batch: d_rows[r, 0:cols] = 0, d_keys[r] = pad_key + r
  * (what a rank hands to the all-gather of a data-parallel step: fixed-size buffers whose tail adds nothing; distinct
  * keys so that the padding does not pile up in one segment; pad_key + n must stay below the key space). */
@@ -505,9 +513,11 @@ int elimrec_slab_to_rows(const float *d_slab, int64_t n, int ns, int w, float *d
  * d_rows [world x R x 2*dl], d_keys int32 [world x R] node ids ascending per rank, negative = padding.
  * Rows of the same node are added in rank order (no float atomics). Writes, slab-major and on the active rows
  * only, SrcA = [H_u ; G_i], SrcB = [G_u ; H_i] and the row bitmap d_mask (all ceil(N/32) words written).
+ * M = 0: [H | G] rows as above. M >= 1 (one rank owning every column): d_rows are the dOut rows themselves,
+ * [world x R x M*dl], and H (sum of the M column blocks) / G (block 0) are formed on the fly.
  * Replaces IndexBackward / index_put(accumulate) across ranks ("sparse-grad reduce-scatter"). */
 int elimrec_slab_merge_rows(const float *d_rows, const int32_t *d_keys, int world, int64_t R, int64_t U,
-                            int64_t I, int ns, int w, float *d_SrcA, float *d_SrcB, uint32_t *d_mask,
+                            int64_t I, int ns, int w, int M, float *d_SrcA, float *d_SrcB, uint32_t *d_mask,
                             void *stream);
 
 /* ---- bf16 table storage (configs[1] "bf16" / configs[4] "fp16" of BASELINE.json; --table_dtype=bf16). The layer
@@ -540,6 +550,39 @@ int elimrec_adam_step_out16(const float *d_p_in, float *d_p_out, void *d_p_bf16,
 int elimrec_adam_step_out(const float *d_p_in, float *d_p_out, const float *d_g, float *d_m, float *d_v,
                           int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                           int64_t step, void *stream);
+
+/* ---------------------------------------------------------------- fused head forward at the batch's rows
+ * Everything after the graph for the <= R active rows of a batch in ONE launch (+ a weight-packing launch): the
+ * folded feature blocks Out_m = S_m[node] W_m^T + c[node] b_m^T + narrow (models/EliMRec.py:233-236, DESIGN.md
+ * section 2), the fused Linear Y_0 = Out W_side^T + b_side (:262-270; user rows are the first seg_info[1] active rows)
+ * and the single-modal heads Y_m = Out_m Ws_m^T + bs_m (:146-151). d_act / d_seg_info: elimrec_segment_plan's active
+ * rows and counts; d_out0 / d_narrow: compact [R x 64] rows (layer means of the id table, shared part);
+ * d_S[m] [N x D[m]], d_c [N]: the folded constants; weights row-major as torch.nn.Linear holds them.
+ * d_OutAct [R x ld_out] receives blocks 1..n_mod (block 0 = d_out0 is expected there already when they alias),
+ * d_YAct [R x ld_y] all 1 + n_mod blocks. d_pack: scratch of elimrec_head_pack_floats floats.
+ * recdim must be 64 and the row tiles must fit LDS, else ELIMREC_E_UNSUPPORTED (callers keep the batched GEMMs). */
+size_t elimrec_head_pack_floats(int n_mod, const int *D);
+int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg_info, int64_t R, const float *d_out0,
+                           int64_t ld_out0, const float *d_narrow, int64_t ld_nar, const float *d_c, int n_mod,
+                           const float *const *d_S, const int64_t *ldS, const int *D, const float *const *d_Wm,
+                           const float *const *d_bm, const float *d_Wf_user, const float *d_bf_user,
+                           const float *d_Wf_item, const float *d_bf_item, const float *const *d_Ws,
+                           const float *const *d_bs, float *d_pack, size_t pack_floats, float *d_OutAct,
+                           int64_t ld_out, float *d_YAct, int64_t ld_y, int recdim, void *stream);
+
+/* The optimizer step of a training step in ONE launch (torch.optim.Adam with coupled L2, main.py:49,101): up to 8 jobs.
+ * A job with d_g updates n parameters read from d_p_in and written to d_p_out (may alias) and, when d_p_bf16 is given,
+ * rounded to that bf16 copy; a job without d_g only copies. d_copy_dst (nullable) receives the parameters as they were
+ * BEFORE the update (the snapshot of the projection weights the cached tables were computed with,
+ * models/EliMRec.py:98-99). `step` is the 1-based step count of the job's parameters. */
+typedef struct elimrec_adam_job {
+    const float *d_p_in; float *d_p_out; void *d_p_bf16;
+    const float *d_g; float *d_m; float *d_v;
+    float *d_copy_dst;
+    int64_t n; int64_t step;
+} elimrec_adam_job;
+int elimrec_adam_multi(const elimrec_adam_job *jobs /* host array */, int n_jobs, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, void *stream);
 
 #ifdef __cplusplus
 }

@@ -457,3 +457,35 @@ def test_persistent_hop_with_in_launch_combine_equals_two_launch_form(d, w, gs, 
         lib.elimrec_slab_set_stream(0)
     for a, b in zip(outs[0], outs[1]):
         assert not torch.isnan(a.float()).any() and torch.equal(a, b)
+
+
+def test_fused_head_forward_equals_batched_gemms(monkeypatch):
+    """csrc/head.hip (feature blocks + fused Linear + single-modal heads of the active rows in one launch) against the
+    two batched-GEMM launches it replaces, on a recdim-64 model: OutAct, YAct, loss and the gradient rows to fp32
+    round-off; the whole step then matches the oracle like the unfused one."""
+    from elimrec_amd import ColumnShardEngine, EliMRec, FusedAdam, SyntheticDataset, set_seed
+    cfg = make_config(["--data.input.dataset=synthetic", "--alpha=0.5", "--loss=bpr_loss", "--recdim=64", "--verbose=0"])
+    ds = SyntheticDataset(700, 1900, 9000, feat_dims=(128, 24, 64), seed=1)
+    got = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("ELIMREC_FUSED_HEAD", fused)
+        set_seed(7)
+        model = EliMRec(cfg, ds).to(DEV)
+        eng = ColumnShardEngine(model)
+        eng.cs_setup(1, 0, FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"]))
+        assert eng._fused_head_ok() == (fused == "1")
+        gen = torch.Generator().manual_seed(3)
+        B = 300
+        u = torch.randint(0, 700, (B,), generator=gen).to(DEV)
+        p = torch.randint(0, 1900, (B,), generator=gen).to(DEV)
+        n = torch.randint(0, 1900, (B,), generator=gen).to(DEV)
+        acts = eng.cs_plan(u, p, n).view(1, -1)
+        eng.cs_forward(acts)
+        loss = eng.cs_head(None)
+        ws = model._ws
+        na = int(ws["seg_info"][0])
+        got[fused] = (float(loss), ws["OutAct"][:na].clone(), ws["YAct"][:na].clone(), ws["grad_rows"].clone())
+    a, b = got["0"], got["1"]
+    assert abs(a[0] - b[0]) < 1e-6
+    for x, y in zip(a[1:], b[1:]):
+        assert rel_err(y.cpu(), x.cpu()) < 2e-6
