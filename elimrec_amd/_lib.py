@@ -156,6 +156,9 @@ SIGNATURES = {
                                        ctypes.POINTER(c_i64), ctypes.POINTER(c_i32), ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr),
                                        c_ptr, c_ptr, c_ptr, c_ptr, ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr), c_ptr, c_size,
                                        c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr]),
+    "elimrec_build_adj_workspace": (c_size, [c_i64, c_i64, c_i32]),
+    "elimrec_build_adj": (c_i32, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size,
+                                  c_ptr]),
     "elimrec_adam_multi": (c_i32, [ctypes.POINTER(AdamJob), c_i32, c_f32, c_f32, c_f32, c_f32, c_f32, c_ptr]),
     "elimrec_sample_triplets": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_u64, c_u64, c_ptr, c_ptr, c_ptr, c_ptr]),
 }

@@ -187,7 +187,13 @@ class EliMRec(BasicModel):
         self._tables_dirty = False
 
         tu, ti = self.dataset.get_train_interactions()
-        adj = create_adj_mat(tu, ti, self.num_users, self.num_items, cfg["adj_type"])
+        if str(opt("adj_build", "host")) == "device":     # CLI-only: degree count, normalisation and sort on the GPU (adjacency.py)
+            from .adjacency import build_adj_device
+            rp, cl, vl = build_adj_device(tu, ti, self.num_users, self.num_items, cfg["adj_type"], torch.device("cuda", torch.cuda.current_device()))
+            n_nodes = self.num_users + self.num_items
+            adj = sp.csr_matrix((vl.cpu().numpy(), cl.cpu().numpy(), rp.cpu().numpy()), shape=(n_nodes, n_nodes))
+        else:
+            adj = create_adj_mat(tu, ti, self.num_users, self.num_items, cfg["adj_type"])
         self._register_csr("adj", adj)
         adj_t = adj.T.tocsr()
         adj_t.sort_indices()

@@ -570,6 +570,18 @@ int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg_info, int6
                            const float *const *d_bs, float *d_pack, size_t pack_floats, float *d_OutAct,
                            int64_t ld_out, float *d_YAct, int64_t ld_y, int recdim, void *stream);
 
+/* ---------------------------------------------------------------- propagation matrix on the device (N3)
+ * create_adj_mat (models/EliMRec.py:309-354) from the UNIQUE training interactions d_users / d_items [E] (int64):
+ * CSR of plain A (adj_type 0), D^-1/2 A D^-1/2 (1, 'pre'), D^-1 A (2, 'gcmc'), (D+I)^-1 (A+I) (3, 'norm'),
+ * D^-1 A + I (4, the reference's fall-through branch); N = U + I rows, columns sorted inside a row, values
+ * bit-identical to scipy's: d_pow_table[k] (host-computed with numpy: float32(k^-1/2), float32(k^-1), ...; 0 for
+ * k = 0) supplies the only inexact step. d_rowptr [N+1], d_col / d_val [2E (+ N with a diagonal)].
+ * *d_err: bit 0 = duplicate interaction, bit 1 = degree beyond the table. */
+size_t elimrec_build_adj_workspace(int64_t E, int64_t N, int with_diag);
+int elimrec_build_adj(const int64_t *d_users, const int64_t *d_items, int64_t E, int64_t U, int64_t I, int adj_type,
+                      const float *d_pow_table, int table_len, int32_t *d_rowptr, int32_t *d_col, float *d_val,
+                      int32_t *d_err, void *d_workspace, size_t workspace_bytes, void *stream);
+
 /* The optimizer step of a training step in ONE launch (torch.optim.Adam with coupled L2, main.py:49,101): up to 8 jobs.
  * A job with d_g updates n parameters read from d_p_in and written to d_p_out (may alias) and, when d_p_bf16 is given,
  * rounded to that bf16 copy; a job without d_g only copies. d_copy_dst (nullable) receives the parameters as they were

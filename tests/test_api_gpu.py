@@ -258,3 +258,45 @@ def test_torch_ops_match_the_ctypes_binding():
     assert abs(float(loss_rows.sum()) - float(g_["step1/loss"])) < 1e-5
     with pytest.raises(RuntimeError):
         t.propagate(rp[:-3], col, val, X, L)
+
+
+@pytest.mark.parametrize("adj_type", ["pre", "plain", "gcmc", "norm", "mean"])
+def test_device_adjacency_is_bit_identical_to_scipy(adj_type):
+    """N3: csrc/adj.hip against model.create_adj_mat (itself bit-identical to the reference's matrix, test_host_logic):
+    same row pointers, same sorted columns, same fp32 values bit for bit -- fixtures and a skewed random graph with
+    isolated nodes."""
+    from elimrec_amd.adjacency import build_adj_device
+    from elimrec_amd.model import create_adj_mat
+    cases = []
+    g = load_golden("ml3")
+    cases.append((g["train_u"], g["train_i"], int(g["num_users"]), int(g["num_items"])))
+    rng = np.random.RandomState(3)
+    U, I = 3000, 5000
+    pop = 1.0 / np.arange(1, I + 1) ** 0.9
+    pairs = np.unique(np.stack([rng.randint(0, U - 50, 60000), rng.choice(I - 80, 60000, p=pop[:I - 80] / pop[:I - 80].sum())], 1), axis=0)
+    cases.append((pairs[:, 0], pairs[:, 1], U, I))             # the last 50 users / 80 items are isolated
+    for tu, ti, nu, ni in cases:
+        want = create_adj_mat(tu, ti, nu, ni, adj_type)
+        rp, cl, vl = build_adj_device(tu, ti, nu, ni, adj_type, DEV)
+        assert np.array_equal(rp.cpu().numpy(), want.indptr)
+        assert np.array_equal(cl.cpu().numpy(), want.indices)
+        assert np.array_equal(vl.cpu().numpy().view(np.uint32), want.data.astype(np.float32).view(np.uint32))
+    with pytest.raises(ValueError):
+        build_adj_device([1, 1], [2, 2], 5, 5, "pre", DEV)
+
+
+def test_model_built_on_the_device_adjacency_trains_like_the_host_one():
+    g = load_golden("ml3")
+    from helpers import FixtureDataset, fixture_argv, make_config
+    from elimrec_amd import EliMRec
+    runs = []
+    for how in ("host", "device"):
+        cfg = make_config(fixture_argv(g) + ["--adj_build=%s" % how])
+        model = EliMRec(cfg, FixtureDataset(g))
+        model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sub(g, "init").items()})
+        for m in ("v", "a", "t"):
+            getattr(model, m + "_feat").copy_(torch.from_numpy(g[m + "_feat"]))
+        model = model.to(DEV)
+        loss = model.bpr_loss(*(_t(g["step1/%s" % k]) for k in ("users", "pos", "neg")))
+        runs.append(float(loss))
+    assert runs[0] == runs[1] and abs(runs[0] - float(g["step1/loss"])) < 1e-5
