@@ -973,6 +973,180 @@ __global__ __launch_bounds__(256) void sell_stream_kernel(StreamArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Form 3 (default): ONE launch, no partial rows for all but a handful of rows. Work is tiered by row length:
+//   * rows of <= T non-zeros: a lane group each, SELL order (as above);
+//   * T < length <= T1: one WAVE per row -- its 64/LPR lane groups take contiguous chunks of the neighbour list, the chunk
+//     sums are added in group order through shuffles;
+//   * T1 < length <= T2: one WORKGROUP per row -- the same per wave, the four wave sums added in wave order through LDS;
+//   * longer (a dozen rows at the Tiktok shape): T-long segments + the last-arriver combine of form 1. The acquire
+//     fence that made form 1 slow is executed a dozen times per launch instead of once per split row.
+// Every sum has a fixed order, so the result is bitwise reproducible (it differs in round-off from forms 0-2, whose
+// split rows are summed in segment order).
+struct TierArgs {
+    StreamArgs s;
+    const int32_t *w1_rows, *w4_rows, *rowptr, *ccol, *long_index;
+    const float *cval;
+    int n_w1, n_w4;
+    int b_w1, b_seg, b_fin;        // first block (per slab group) of the wave rows, the segment items, the unsplit rows
+};
+
+// sum over neighbours [jb, je) of one CSR row for this lane's columns
+template <int VPL, bool IN_BF16, bool MASKED>
+__device__ __forceinline__ void tier_chunk(const TierArgs &t, int64_t in_base, int jb, int je, float (&acc)[VPL]) {
+    constexpr int U = 4;
+    const StreamArgs &a = t.s;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) acc[i] = 0.f;
+    for (int j = jb; j < je; j += U) {
+        int cj[U];
+        float vj[U];
+        bool in[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            in[u] = (j + u) < je;
+            cj[u] = in[u] ? t.ccol[j + u] : 0;
+            vj[u] = in[u] ? t.cval[j + u] : 0.f;
+        }
+        if (MASKED) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) in[u] = in[u] && bit_of(a.src_mask, cj[u]);
+        }
+        float x[U][VPL];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (in[u]) lane_load<VPL, IN_BF16>(a.Xin, in_base + (int64_t)cj[u] * a.wl, x[u]);
+            else {
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) x[u][i] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) acc[i] = fmaf(vj[u], x[u][i], acc[i]);
+    }
+}
+
+// the lane groups' sums of one wave added in group order; valid in the lanes of group 0
+template <int LPR, int VPL>
+__device__ __forceinline__ void tier_wave_sum(const float (&acc)[VPL], int cl, int n_long_guard, float (&tot)[VPL]) {
+    constexpr int NQ = 64 / LPR;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) tot[i] = NQ > 1 ? __shfl(acc[i], cl, 64) : acc[i];
+    const int nq = NQ + (n_long_guard < 0 ? 1 : 0);          // run-time bound: see stream_combine
+#pragma unroll 2
+    for (int g = 1; g < nq; ++g) {
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) tot[i] += __shfl(acc[i], g * LPR + cl, 64);
+    }
+}
+
+template <int LPR, int VPL, bool IN_BF16, bool OUT_BF16, bool MASKED>
+__global__ __launch_bounds__(256) void sell_tier_kernel(TierArgs t) {
+    constexpr int IPW = 64 / LPR, U = 4;
+    const StreamArgs &a = t.s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int grp = (int)(blockIdx.x % (unsigned)a.gs);
+    const int bidx = (int)(blockIdx.x / (unsigned)a.gs);
+    const int sub = lane / LPR, cl = lane % LPR;
+    const int slab = grp * a.spg + (cl >> a.wl_shift);
+    const int c = cl & (a.wl - 1);
+    const int64_t in_base = (int64_t)slab * a.n_src * a.wl + c;
+    __shared__ float s_part[4 * 64 * 8];
+    if (bidx < t.b_w1) {
+        // ---- a workgroup per row
+        const int row = t.w4_rows[bidx];
+        const int beg = t.rowptr[row], end = t.rowptr[row + 1];
+        const int per = (end - beg + 4 * IPW - 1) / (4 * IPW);
+        const int jb = min(beg + (wave * IPW + sub) * per, end), je = min(jb + per, end);
+        float acc[VPL], tot[VPL];
+        tier_chunk<VPL, IN_BF16, MASKED>(t, in_base, jb, je, acc);
+        tier_wave_sum<LPR, VPL>(acc, cl, a.n_long, tot);
+        if (sub == 0) {
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) s_part[(wave * LPR + cl) * VPL + i] = tot[i];
+        }
+        __syncthreads();
+        if (wave == 0 && sub == 0) {
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) tot[i] = ((s_part[cl * VPL + i] + s_part[(LPR + cl) * VPL + i]) + s_part[(2 * LPR + cl) * VPL + i]) +
+                                                   s_part[(3 * LPR + cl) * VPL + i];
+            if (a.compact_long) lane_store<VPL, false>(a.Xout, ((int64_t)slab * a.n_long + t.long_index[row]) * a.wl + c, tot);
+            else stream_epilogue<VPL, OUT_BF16>(a, slab, row, c, tot);
+        }
+        return;
+    }
+    if (bidx < t.b_seg) {
+        // ---- a wave per row
+        const int i1 = (bidx - t.b_w1) * 4 + wave;
+        if (i1 >= t.n_w1) return;
+        const int row = t.w1_rows[i1];
+        const int beg = t.rowptr[row], end = t.rowptr[row + 1];
+        const int per = (end - beg + IPW - 1) / IPW;
+        const int jb = min(beg + sub * per, end), je = min(jb + per, end);
+        float acc[VPL], tot[VPL];
+        tier_chunk<VPL, IN_BF16, MASKED>(t, in_base, jb, je, acc);
+        tier_wave_sum<LPR, VPL>(acc, cl, a.n_long, tot);
+        if (sub == 0) {
+            if (a.compact_long) lane_store<VPL, false>(a.Xout, ((int64_t)slab * a.n_long + t.long_index[row]) * a.wl + c, tot);
+            else stream_epilogue<VPL, OUT_BF16>(a, slab, row, c, tot);
+        }
+        return;
+    }
+    // ---- SELL items: segments of the longest rows (tickets), then the unsplit rows
+    const int64_t wb = (int64_t)(bidx - t.b_seg) * 4 + wave;
+    if (wb >= a.n_blocks) return;
+    const int64_t item = wb * IPW + sub;
+    const int len = a.item_len[item], dst = a.item_dst[item];
+    const int64_t e0 = ((int64_t)a.blk_off[item >> 6] << 6) + (item & 63);
+    int cj0[U];
+    float vj0[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const bool in = u < len;
+        cj0[u] = in ? a.col[e0 + ((int64_t)u << 6)] : 0;
+        vj0[u] = in ? a.val[e0 + ((int64_t)u << 6)] : 0.f;
+    }
+    float acc[VPL];
+    stream_gather<VPL, IN_BF16, MASKED, U>(a, in_base, e0, len, cj0, vj0, acc);
+    const bool seg_block = wb * IPW < a.seg_limit;                   // wave-uniform
+    if (!seg_block) {
+        if (dst >= 0 && !a.compact_long) stream_epilogue<VPL, OUT_BF16>(a, slab, dst, c, acc);
+        return;
+    }
+    __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)a.partials, 0, (int)min((size_t)0x7FFFFFF0, (size_t)a.n_seg * a.gs * a.spg * a.wl * VPL * 4), 0x00020000);
+    if (dst >= 0) {
+        const int64_t pidx = ((int64_t)slab * a.n_seg + dst) * a.wl + c;
+#pragma unroll
+        for (int h = 0; h < VPL / 4; ++h) {
+            u32x4s bits = {__float_as_uint(acc[4 * h]), __float_as_uint(acc[4 * h + 1]), __float_as_uint(acc[4 * h + 2]),
+                           __float_as_uint(acc[4 * h + 3])};
+            __builtin_amdgcn_raw_buffer_store_b128(bits, prsrc, (unsigned)((pidx * (VPL / 4) + h) * 16), 0, 16 /* sc1 */);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int li = -1, ticket = -1, nseg = 0;
+    if (dst >= 0) {
+        li = a.item_long[item];
+        nseg = a.long_seg_ptr[li + 1] - a.long_seg_ptr[li];
+        if (cl == 0) ticket = __hip_atomic_fetch_add(&a.tickets[(int64_t)grp * a.n_long + li], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    ticket = __shfl(ticket, sub * LPR, 64);
+    const bool last = dst >= 0 && ticket == nseg - 1;
+    if (__ballot(last) == 0ull) return;                               // wave-uniform
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll 1
+    for (int g = 0; g < IPW; ++g) {
+        if (!__shfl(last ? 1 : 0, g * LPR, 64)) continue;
+        const int g_li = __shfl(li, g * LPR, 64);
+        stream_combine<LPR, VPL, OUT_BF16>(a, grp, g_li);
+        if (lane == 0) __hip_atomic_store(&a.tickets[(int64_t)grp * a.n_long + g_li], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // the split rows by a second launch (ELIMREC_SLAB_STREAM=2: persistent hop without the in-launch combine)
 template <int LPR, int VPL, bool OUT_BF16>
 __global__ __launch_bounds__(256) void stream_fixup_kernel(StreamArgs a) {
@@ -1055,6 +1229,61 @@ static int slab_stream() {
     return g_slab_stream;
 }
 extern "C" void elimrec_slab_set_stream(int mode) { g_slab_stream = mode; }
+
+static int launch_tier(const elimrec_sell *A, int family, int ns, int wl, int wl_shift, int gs, int spg, int lpr, const void *Xin,
+                       bool in_bf16, const uint32_t *src_mask, void *Xout, bool out_bf16, const float *add,
+                       const uint32_t *add_mask, float scale, float *partials, int seg_only, hipStream_t s) {
+    TierArgs t = {};
+    StreamArgs &a = t.s;
+    a.item_dst = A->d_item_dst; a.item_len = A->d_item_len; a.blk_off = A->d_blk_off; a.col = A->d_col; a.val = A->d_val;
+    a.item_long = A->d_item_long;
+    a.n_rows = A->n_rows; a.n_src = A->n_src; a.n_seg = A->n_seg; a.n_long = A->n_long;
+    const int ipw = 64 / lpr;
+    a.n_blocks = (int64_t)(seg_only ? A->n_seg_items : A->n_items) / ipw;
+    a.seg_limit = A->n_seg_items;
+    a.wl = wl; a.wl_shift = wl_shift; a.gs = gs; a.spg = spg;
+    a.Xin = Xin; a.src_mask = src_mask; a.Xout = Xout;
+    a.Add = seg_only ? nullptr : (const float4 *)add; a.add_mask = add_mask; a.scale = seg_only ? 1.0f : scale;
+    a.partials = partials; a.long_rows = A->d_long_rows; a.long_seg_ptr = A->d_long_seg_ptr;
+    const int vpl = family ? 8 : 4;
+    a.tickets = (int32_t *)((char *)partials + slab_partial_floats_bytes(A, ns, wl * vpl));
+    a.compact_long = seg_only ? 1 : 0;
+    t.w1_rows = A->d_w1_rows; t.w4_rows = A->d_w4_rows; t.n_w1 = A->n_w1; t.n_w4 = A->n_w4;
+    t.rowptr = A->d_rowptr; t.ccol = A->d_csr_col; t.cval = A->d_csr_val; t.long_index = A->d_long_index;
+    t.b_w1 = A->n_w4;
+    t.b_seg = t.b_w1 + (A->n_w1 + 3) / 4;
+    const int64_t per_group = t.b_seg + (a.n_blocks + 3) / 4;
+    if (per_group <= 0) return 0;
+    const dim3 grid((unsigned)(per_group * gs));
+    const bool masked = src_mask != nullptr;
+#define ELIMREC_TIER(LPR)                                                                                                     \
+    do {                                                                                                                      \
+        if (!family) {                                                                                                        \
+            if (masked) hipLaunchKernelGGL((sell_tier_kernel<LPR, 4, false, false, true>), grid, dim3(256), 0, s, t);         \
+            else hipLaunchKernelGGL((sell_tier_kernel<LPR, 4, false, false, false>), grid, dim3(256), 0, s, t);               \
+        } else if (in_bf16) {                                                                                                 \
+            if (out_bf16) hipLaunchKernelGGL((sell_tier_kernel<LPR, 8, true, true, false>), grid, dim3(256), 0, s, t);        \
+            else hipLaunchKernelGGL((sell_tier_kernel<LPR, 8, true, false, false>), grid, dim3(256), 0, s, t);                \
+        } else if (masked) {                                                                                                  \
+            if (out_bf16) hipLaunchKernelGGL((sell_tier_kernel<LPR, 8, false, true, true>), grid, dim3(256), 0, s, t);        \
+            else hipLaunchKernelGGL((sell_tier_kernel<LPR, 8, false, false, true>), grid, dim3(256), 0, s, t);                \
+        } else {                                                                                                              \
+            if (out_bf16) hipLaunchKernelGGL((sell_tier_kernel<LPR, 8, false, true, false>), grid, dim3(256), 0, s, t);       \
+            else hipLaunchKernelGGL((sell_tier_kernel<LPR, 8, false, false, false>), grid, dim3(256), 0, s, t);               \
+        }                                                                                                                     \
+    } while (0)
+    switch (lpr) {
+        case 1: ELIMREC_TIER(1); break;
+        case 2: ELIMREC_TIER(2); break;
+        case 4: ELIMREC_TIER(4); break;
+        case 8: ELIMREC_TIER(8); break;
+        case 16: ELIMREC_TIER(16); break;
+        case 32: ELIMREC_TIER(32); break;
+        default: ELIMREC_TIER(64); break;
+    }
+#undef ELIMREC_TIER
+    return check_hip(hipGetLastError(), "slab_hop(tiered)");
+}
 
 static int slab_wg_budget() {
     static int v = 0;
@@ -1168,7 +1397,7 @@ extern "C" int elimrec_slab_hop(const elimrec_sell *A, int ns, int w, int gs, co
     ELIMREC_REQUIRE(A->n_items % 64 == 0 && A->n_seg_items % 64 == 0 && A->n_seg_items <= A->n_items, "slab_hop: bad plan");
     int w4_shift, spg, lpr, rc;
     if ((rc = slab_geometry("slab_hop", ns, w, gs, w4_shift, spg, lpr))) return rc;
-    if (A->n_long > 0 && (!d_partials || partials_bytes < elimrec_slab_partials_bytes(A, ns, w))) {
+    if ((A->n_long > 0 || A->tiered) && (!d_partials || partials_bytes < elimrec_slab_partials_bytes(A, ns, w))) {
         set_error("slab_hop: partial-row scratch too small");
         return ELIMREC_E_WORKSPACE;
     }
@@ -1182,6 +1411,9 @@ extern "C" int elimrec_slab_hop(const elimrec_sell *A, int ns, int w, int gs, co
     a.partials = (float4 *)d_partials; a.long_rows = A->d_long_rows; a.long_seg_ptr = A->d_long_seg_ptr;
     a.compact_long = seg_only ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
+    if (A->tiered)
+        return launch_tier(A, 0, ns, w / 4, w4_shift, gs, spg, lpr, d_Xin, false, d_src_mask, d_Xout, false, d_add, d_add_mask, scale,
+                           d_partials, seg_only, s);
     if (slab_stream() && A->d_item_long)
         return launch_stream(A, 0, ns, w / 4, w4_shift, gs, spg, lpr, d_Xin, false, d_src_mask, d_Xout, false, d_add, d_add_mask, scale,
                              d_partials, seg_only, s);
@@ -1353,7 +1585,7 @@ extern "C" int elimrec_slab_hop16(const elimrec_sell *A, int ns, int w, int gs, 
     ELIMREC_REQUIRE(A->n_items % 64 == 0 && A->n_seg_items % 64 == 0 && A->n_seg_items <= A->n_items, "slab_hop16: bad plan");
     int w8_shift, spg, lpr, rc;
     if ((rc = slab16_geometry("slab_hop16", ns, w, gs, w8_shift, spg, lpr))) return rc;
-    if (A->n_long > 0 && (!d_partials || partials_bytes < elimrec_slab_partials_bytes(A, ns, w))) {
+    if ((A->n_long > 0 || A->tiered) && (!d_partials || partials_bytes < elimrec_slab_partials_bytes(A, ns, w))) {
         set_error("slab_hop16: partial-row scratch too small");
         return ELIMREC_E_WORKSPACE;
     }
@@ -1369,6 +1601,9 @@ extern "C" int elimrec_slab_hop16(const elimrec_sell *A, int ns, int w, int gs, 
     hipStream_t s = (hipStream_t)stream;
     const int n_it = a.item_end - a.item_begin;
     const bool of = out_f32 != 0 || seg_only;
+    if (A->tiered)
+        return launch_tier(A, 1, ns, w / 8, w8_shift, gs, spg, lpr, d_Xin, !in_f32, d_src_mask, d_Xout, !of, d_add, d_add_mask, scale,
+                           d_partials, seg_only, s);
     if (slab_stream() && A->d_item_long)
         return launch_stream(A, 1, ns, w / 8, w8_shift, gs, spg, lpr, d_Xin, !in_f32, d_src_mask, d_Xout, !of, d_add, d_add_mask, scale,
                              d_partials, seg_only, s);

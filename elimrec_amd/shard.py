@@ -144,8 +144,15 @@ class ColumnShardEngine(object):
         self.ns, self.w = slab.choose_slabs16(self.dl) if self.bf16 else slab.choose_slabs(self.dl, N)
         self.gs = slab.choose_groups(self.ns)
         adj = m._scipy_adj()
-        self.plan = slab.SellPlan(adj, dev, side_split=m.num_users)
-        self.planT = self.plan if m._adj_symmetric else slab.SellPlan(adj.T.tocsr(), dev, side_split=m.num_users)
+        ipw = 64 // max(1, (self.ns // self.gs) * (self.w // (8 if self.bf16 else 4)))     # lane groups per wave of this geometry
+        # launch form of a hop (tools/bench_slab_modes.py, Tiktok shape, us per hop): whole fp32 table -- tiered one-launch
+        # form with 64-neighbour work items 33 vs 37 for hop + fix-up kernels; column shards and bf16 tables -- hop +
+        # fix-up with 32-neighbour items (21 vs 25; 26 vs 31)
+        import os
+        tiered = world == 1 and not self.bf16 and os.environ.get("ELIMREC_SLAB_TIERED", "1") != "0"
+        kw = dict(side_split=m.num_users, ipw=ipw, tiered=tiered, threshold=64 if tiered else slab.LONG_ROW_THRESHOLD)
+        self.plan = slab.SellPlan(adj, dev, **kw)
+        self.planT = self.plan if m._adj_symmetric else slab.SellPlan(adj.T.tocsr(), dev, **kw)
         tab = lambda: slab.SlabTable(N, self.ns, self.w, dev)
         tdt = torch.bfloat16 if self.bf16 else torch.float32
         ttab = lambda: slab.SlabTable(N, self.ns, self.w, dev, dtype=tdt)      # a propagated (stored) table

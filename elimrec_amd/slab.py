@@ -62,11 +62,17 @@ def _is_pow2(x):
 class SellPlan(object):
     """SELL-64 work items of a CSR matrix on a device (struct elimrec_sell)."""
 
-    def __init__(self, m, device, threshold=LONG_ROW_THRESHOLD, side_split=None):
+    def __init__(self, m, device, threshold=LONG_ROW_THRESHOLD, side_split=None, tiered=None, ipw=8):
         """side_split = U: the unsplit rows are processed side by side (item rows, then user rows; by decreasing
         length inside a side) instead of by length alone -- all workgroups then gather from the same side's rows at
         the same time, which is what an XCD's L2 can hold (users read items by popularity, items read the whole,
-        smaller, user table)."""
+        smaller, user table).
+        tiered (the engine turns it on for whole fp32 tables, where it measured faster): rows above `threshold` are not cut into segments
+        but given to one wave (up to 32 neighbours per lane group: 32*ipw) or one workgroup (up to 64 per lane group:
+        256*ipw) each, and only the rows longer still are segmented -- one launch per hop, no fix-up launch. ipw = lane
+        groups per wave of the geometry the plan will mostly run with (64 / lanes per work item)."""
+        if tiered is None:
+            tiered = False
         m = m.tocsr()
         m.sort_indices()
         n_rows, n_src = m.shape
@@ -77,10 +83,16 @@ class SellPlan(object):
         val = m.data.astype(np.float32)
         deg = np.diff(rowptr)
         T = int(threshold)
+        T1 = int(os.environ.get("ELIMREC_SLAB_T1", 32 * ipw)) if tiered else T
+        T2 = int(os.environ.get("ELIMREC_SLAB_T2", 256 * ipw)) if tiered else T
         long_rows = np.nonzero(deg > T)[0]
         short_rows = np.nonzero(deg <= T)[0]
-        # segments of the split rows: slot numbers run row by row, segment by segment
-        nseg = (deg[long_rows] + T - 1) // T
+        w1 = long_rows[deg[long_rows] <= T1]
+        w4 = long_rows[(deg[long_rows] > T1) & (deg[long_rows] <= T2)]
+        w1 = w1[np.argsort(-deg[w1], kind="stable")]
+        w4 = w4[np.argsort(-deg[w4], kind="stable")]
+        # segments of the split rows (tiered: of the rows above T2 only): slot numbers run row by row, segment by segment
+        nseg = np.where(deg[long_rows] > T2, (deg[long_rows] + T - 1) // T, 0) if tiered else (deg[long_rows] + T - 1) // T
         seg_ptr = np.concatenate([[0], np.cumsum(nseg)]).astype(np.int64)
         n_seg = int(seg_ptr[-1])
         seg_row = np.repeat(np.arange(len(long_rows)), nseg)
@@ -139,11 +151,14 @@ class SellPlan(object):
                       long_rows=t(long_rows if len(long_rows) else np.zeros(1), np.int32),
                       long_seg_ptr=t(seg_ptr, np.int32), long_index=t(long_index, np.int32),
                       rowptr=t(rowptr, np.int32), csr_col=t(col if len(col) else np.zeros(1), np.int32),
-                      csr_val=t(val if len(val) else np.zeros(1), np.float32), item_long=t(item_long, np.int32))
+                      csr_val=t(val if len(val) else np.zeros(1), np.float32), item_long=t(item_long, np.int32),
+                      w1_rows=t(w1 if len(w1) else np.zeros(1), np.int32), w4_rows=t(w4 if len(w4) else np.zeros(1), np.int32))
+        self.tiered, self.n_w1, self.n_w4 = bool(tiered), int(len(w1)), int(len(w4))
         p = lambda k: self.t[k].data_ptr()
         self.desc = _lib.SellDesc(self.n_rows, self.n_src, self.n_items, self.n_seg_items, self.n_seg, self.n_long,
                                   p("item_dst"), p("item_len"), p("blk_off"), p("col"), p("val"), p("long_rows"),
-                                  p("long_seg_ptr"), p("long_index"), p("rowptr"), p("csr_col"), p("csr_val"), p("item_long"))
+                                  p("long_seg_ptr"), p("long_index"), p("rowptr"), p("csr_col"), p("csr_val"), p("item_long"),
+                                  1 if tiered else 0, self.n_w1, self.n_w4, p("w1_rows"), p("w4_rows"))
         self._partials = {}
 
     def ref(self):

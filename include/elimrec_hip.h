@@ -465,6 +465,12 @@ typedef struct elimrec_sell {
     const float *d_csr_val;
     const int32_t *d_item_long;     /* [n_seg_items] split row (index into d_long_rows) of a segment item; NULL
                                        selects the two-launch form (hop + fix-up) instead of the in-launch combine */
+    /* tiered plan (tiered != 0; ONE launch per hop): rows of more than long_threshold non-zeros are NOT work items;
+     * d_w1_rows [n_w1] get one wave each, d_w4_rows [n_w4] one workgroup each, and only the rows longer still are cut
+     * into segment items (their partial rows are combined in-launch by the last-arriving segment wave).
+     * d_long_rows / d_long_index / n_long still cover every row above long_threshold (compact seg_only output). */
+    int32_t tiered, n_w1, n_w4;
+    const int32_t *d_w1_rows, *d_w4_rows;
 } elimrec_sell;
 
 /* One hop over a slab-major table:  r = A . Xin ;  Xout[row] = (r + [add_mask bit row] Add[row]) * scale.

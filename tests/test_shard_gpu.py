@@ -428,7 +428,7 @@ def test_persistent_hop_with_in_launch_combine_equals_two_launch_form(d, w, gs, 
     lib = _lib.load()
     n = 4000
     m = _random_graph(n, 3 * d + w, hot=9, hot_deg=900)
-    plan = slab.SellPlan(m, DEV, threshold=32, side_split=1500)
+    plan = slab.SellPlan(m, DEV, threshold=32, side_split=1500, tiered=False)
     ns = d // w
     torch.manual_seed(1)
     X = torch.randn(n, d, device=DEV)
@@ -489,3 +489,55 @@ def test_fused_head_forward_equals_batched_gemms(monkeypatch):
     assert abs(a[0] - b[0]) < 1e-6
     for x, y in zip(a[1:], b[1:]):
         assert rel_err(y.cpu(), x.cpu()) < 2e-6
+
+
+@pytest.mark.parametrize("d,w,gs,bf16,ipw", [(64, 32, 2, False, 8), (8, 8, 1, False, 32), (64, 64, 1, False, 4), (64, 64, 1, True, 8),
+                                             (128, 32, 4, False, 8), (16, 16, 1, True, 32)])
+def test_tiered_one_launch_hop(d, w, gs, bf16, ipw):
+    """The default hop: rows above the lane-group threshold go to one wave or one workgroup each, only the longest are
+    segmented and combined in-launch. Against an fp64 product (1e-5; bf16 output <= 1 bf16 ulp), plain / masked +
+    addend / seg_only (every row above the threshold, compact), and bitwise reproducible."""
+    from elimrec_amd import slab
+    n = 4000
+    m = _random_graph(n, 7 * d + w, hot=9, hot_deg=900)
+    rng = np.random.RandomState(5)
+    extra = sp.csr_matrix((np.ones(3000, np.float32) * 0.01, (np.zeros(3000, int) + 17, rng.choice(n, 3000, replace=False))), shape=(n, n))
+    mid_rows = np.repeat(np.arange(40, 70), 120)                                  # 30 rows of ~120 neighbours: a wave each
+    mid = sp.csr_matrix((np.full(len(mid_rows), 0.02, np.float32), (mid_rows, rng.randint(0, n, len(mid_rows)))), shape=(n, n))
+    m = (m + extra + mid).tocsr()                # row 17: ~3000 neighbours -> segments + tickets at every ipw
+    m.sum_duplicates()
+    m.sort_indices()
+    plan = slab.SellPlan(m, DEV, threshold=32, side_split=1500, tiered=True, ipw=ipw)
+    assert plan.tiered and plan.n_w1 + plan.n_w4 > 0 and (plan.n_seg > 0 or ipw >= 32)
+    ns = d // w
+    torch.manual_seed(1)
+    X = torch.randn(n, d, device=DEV)
+    x = slab.SlabTable(n, ns, w, DEV).from_rows(X)
+    if bf16:
+        x = x.to_bf16(x.like(torch.bfloat16))
+    Xr = x.dense().double()
+    A64 = torch.from_numpy(m.astype(np.float64).toarray()).to(DEV)
+    want = A64 @ Xr
+    # fp32 sums of up to 3000 terms: the error bound scales with sum |a||x| of the row (4 ulp-ish of it), not with 1
+    scale = A64.abs() @ Xr.abs()
+    tol = lambda ref, sc=scale: (ref.abs() * 2.0 ** -7 + 1e-6 if bf16 else 0) + 4e-6 * sc + 1e-6
+    y = x.like()
+    y.data.fill_(float("nan"))
+    slab.hop(plan, x, y, gs=gs)
+    assert ((y.dense().double() - want).abs() <= tol(want)).all()
+    y2 = x.like()
+    slab.hop(plan, x, y2, gs=gs)
+    assert torch.equal(y.data, y2.data)
+    act = torch.rand(n, device=DEV) < 0.1
+    bm = _bitmap(act)
+    S = torch.randn(n, d, device=DEV)
+    src = slab.SlabTable(n, ns, w, DEV).from_rows(S)
+    slab.hop(plan, src, y, gs=gs, src_mask=bm, add=src, add_mask=bm, scale=0.5)
+    Sm = S.double() * act[:, None]
+    want2 = (A64 @ Sm + Sm) * 0.5
+    assert ((y.dense().double() - want2).abs() <= tol(want2, A64.abs() @ Sm.abs() + Sm.abs())).all()
+    long_tab = torch.full((ns * plan.n_long * w,), float("nan"), device=DEV)
+    slab.hop(plan, x, long_tab, gs=gs, seg_only=True)
+    lt = long_tab.view(ns, plan.n_long, w).permute(1, 0, 2).reshape(plan.n_long, d).double()
+    rows = plan.t["long_rows"][:plan.n_long].long()
+    assert ((lt - want[rows]).abs() <= 4e-6 * scale[rows] + 1e-6).all()

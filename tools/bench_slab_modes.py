@@ -24,8 +24,10 @@ lib = _lib.load()
 geoms = [("f32 w32 gs2", 32, 2, 2, 0, False), ("f32 w64 gs1", 64, 1, 1, 0, False), ("bf16 w64 gs1", 64, 1, 1, 0, True),
          ("f32 shard8", 8, 1, 1, 8, False), ("f32 shard16", 16, 1, 1, 16, False), ("bf16 shard8", 8, 1, 1, 8, True)]
 for T in (64, 32):
-    plan = slab.SellPlan(adj, dev, threshold=T, side_split=U)
     for name, w, ns, gs, shard, bf in geoms:
+        plan = slab.SellPlan(adj, dev, threshold=T, side_split=U, tiered=False)
+        ipw = 64 // max(1, (ns // gs) * (w // (8 if bf else 4)))
+        tplan = slab.SellPlan(adj, dev, threshold=T, side_split=U, tiered=True, ipw=ipw)
         xs = slab.SlabTable(N, ns, w, dev).from_rows(X, col0=shard)
         if bf: xs = xs.to_bf16(xs.like(torch.bfloat16))
         y1, y2 = xs.like(), xs.like()
@@ -35,5 +37,8 @@ for T in (64, 32):
             def chain():
                 slab.hop(plan, xs, y1, gs=gs); slab.hop(plan, y1, y2, gs=gs); slab.hop(plan, y2, y1, gs=gs)
             res.append(timeit(chain) / 3)
-        print("T=%2d %-12s us/hop by form [2 kernels, in-launch, persistent+fixup] = %s  (segs %d, long rows %d)"
-              % (T, name, " ".join("%.1f" % t for t in res), plan.n_seg, plan.n_long))
+        def tchain():
+            slab.hop(tplan, xs, y1, gs=gs); slab.hop(tplan, y1, y2, gs=gs); slab.hop(tplan, y2, y1, gs=gs)
+        res.append(timeit(tchain) / 3)
+        print("T=%2d %-12s us/hop by form [2 kernels, in-launch, persistent+fixup, TIERED one launch] = %s  (segs %d -> %d, wave rows %d, wg rows %d)"
+              % (T, name, " ".join("%.1f" % t for t in res), plan.n_seg, tplan.n_seg, tplan.n_w1, tplan.n_w4))
