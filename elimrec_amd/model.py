@@ -768,7 +768,7 @@ class EliMRec(BasicModel):
         return loss
 
     @torch.no_grad()
-    def _backward_batch_rows(self, ws, gscale, grad_rows, n, head_only=False):
+    def _backward_batch_rows(self, ws, gscale, grad_rows, n, head_only=False, w_stream=None):
         """Backward of _forward_batch_rows: gradient rows -> active rows (the forward's plan) -> head and projection
         gradients from the compact Out / dY rows -> adjoint propagation at d columns. Two hipGraph regions."""
         U, I, d, M, C, S = self.num_users, self.num_items, self.latent_dim, self.M, self.C, self.S
@@ -780,11 +780,13 @@ class EliMRec(BasicModel):
         f32 = dict(dtype=torch.float32, device=self._device())
         grads = {}
 
-        def head():
+        def head_input():
             wu, wi = self._fusion_weights()
             head_ws = [getattr(self, "s_dense_" + m).weight for m in self._mods]
             ops.segment_apply_head_bwd(grad_rows, act, seg, dY, ws["plan_ws"], U, d, C, [h + 1 for h in range(S)], wu, wi,
                                        head_ws, dOutR, scale=gscale)
+
+        def head_weights():
             # fusion Linears: dW = dY_f^T . Out[active rows], user slots / item slots separately
             problems, fused_tmp = [], {}
             for name, rng in (("embedding_user_after_GCN", seg[2:4]), ("embedding_item_after_GCN", seg[4:6])):
@@ -810,7 +812,16 @@ class EliMRec(BasicModel):
             return dict(grads)
 
         key = (self._ws_gen, grad_rows.data_ptr(), gscale.data_ptr(), n, tuple(bw))
-        grads = dict(self._region("bwd_head", key, head))
+        self._region("bwd_head_in", key, head_input)
+        if w_stream is None:
+            grads = dict(self._region("bwd_head_w", key, head_weights))
+        else:
+            # the weight gradients are needed by the optimizer step only: they run beside whatever the caller enqueues next
+            # (the adjoint hops) on a second stream; the caller joins it before the update (w_stream is its handle)
+            main = torch.cuda.current_stream()
+            w_stream.wait_stream(main)
+            with torch.cuda.stream(w_stream):
+                grads = dict(self._region("bwd_head_w", key, head_weights))
         if head_only:
             return grads
         self._backward_hops(ws, dOutR, act, seg, n, grads)

@@ -169,6 +169,7 @@ class ColumnShardEngine(object):
         self.srcA, self.srcB, self.tmp = tab(), tab(), [ttab(), ttab()]
         self.mask = torch.zeros((N + 31) // 32 + 2, dtype=torch.int32, device=dev)
         self.step_count = 0
+        self._side = None
         self._fused = None
         self._tail_plan = None
         self._bufs = {}
@@ -235,6 +236,15 @@ class ColumnShardEngine(object):
             if self._fused:
                 self._pack = torch.empty(ops.head_pack_floats(dims), dtype=torch.float32, device=m._device())
         return self._fused
+
+    def _side_stream(self):
+        """Second HIP stream for work off the step's critical path (ELIMREC_SIDE_STREAM=1: the weight-gradient GEMMs run
+        beside the adjoint hops). Off by default: measured 0.395 ms per step either way at the Tiktok shape -- the hops keep
+        every CU busy, so the side kernels' workgroups only interleave with theirs, and the fork/join costs host time."""
+        if self._side is None:
+            import os
+            self._side = torch.cuda.Stream() if os.environ.get("ELIMREC_SIDE_STREAM", "0") == "1" else False
+        return self._side or None
 
     def _timed(self, fn, hops):
         ev = self.kernel_events
@@ -367,7 +377,8 @@ class ColumnShardEngine(object):
         m = self.model
         ws, d = m._ws, m.latent_dim
         R = m._plan_n
-        self._grads = m._backward_batch_rows(ws, scale, ws["grad_rows"], R, head_only=True)
+        self._grads = m._backward_batch_rows(ws, scale, ws["grad_rows"], R, head_only=True,
+                                             w_stream=self._side_stream() if self.world == 1 else None)
         wg = ws["flat_grad"][ws["tail_off"]:]
         if self.world == 1:       # one rank owns every column: the merge reads the dOut rows themselves
             return ws["dOutR"][:R].view(1, R, m.C), wg
@@ -397,6 +408,8 @@ class ColumnShardEngine(object):
                          add_mask=self.mask, scale=inv if k == 0 else 1.0)
                 t, tmask = dst, None
         self._timed(lambda: m._region("cs_bwd_hops", (m._ws_gen, recv2.data_ptr(), acts.data_ptr(), R, W), hops), L)
+        if self._side and self.world == 1:
+            torch.cuda.current_stream().wait_stream(self._side)      # the weight gradients, computed beside the hops
 
     @torch.no_grad()
     def cs_update(self):

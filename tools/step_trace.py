@@ -1,0 +1,22 @@
+"""Steps of the real trainer for rocprofv3 --kernel-trace (bench.py's training loop without the extras). usage: step_trace.py [steps] [table_dtype]"""
+import os, sys, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, Configurator, EliMRec, FusedAdam, Logger, PairwiseSamplerV2, SyntheticDataset, set_seed
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.chdir(ROOT)
+dev = "cuda:0"
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+cfg = Configurator(os.path.join(ROOT, "NeuRec.properties"), default_section="hyperparameters",
+                   argv=["x", "--data.input.dataset=synthetic", "--alpha=0.5", "--loss=bpr_loss", "--recdim=64", "--verbose=0"])
+Logger.logger = Logger(show_in_console=False)
+ds = SyntheticDataset(36656, 76085, 720829, feat_dims=(128, 128, 128), seed=0)
+B = 2048
+u, p, n = PairwiseSamplerV2(ds, batch_size=B, device=dev).sample_epoch()
+set_seed(1)
+model = EliMRec(cfg, ds).to(dev)
+opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+tr = ColumnShardTrainer(ColumnShardEngine(model, table_dtype=sys.argv[2] if len(sys.argv) > 2 else "f32"), opt)
+for i in range(K):
+    tr.step(u[i * B:(i + 1) * B], p[i * B:(i + 1) * B], n[i * B:(i + 1) * B])
+torch.cuda.synchronize()
+print("done")
