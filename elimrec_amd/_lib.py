@@ -53,8 +53,11 @@ class SellDesc(ctypes.Structure):
                 ("d_col", ctypes.c_void_p), ("d_val", ctypes.c_void_p), ("d_long_rows", ctypes.c_void_p),
                 ("d_long_seg_ptr", ctypes.c_void_p), ("d_long_index", ctypes.c_void_p), ("d_rowptr", ctypes.c_void_p),
                 ("d_csr_col", ctypes.c_void_p), ("d_csr_val", ctypes.c_void_p), ("d_item_long", ctypes.c_void_p),
-                ("tiered", ctypes.c_int32), ("n_w1", ctypes.c_int32), ("n_w4", ctypes.c_int32), ("d_w1_rows", ctypes.c_void_p),
-                ("d_w4_rows", ctypes.c_void_p)]
+                ("tiered", ctypes.c_int32), ("n_w1", ctypes.c_int32), ("n_w4", ctypes.c_int32),
+                ("tile_groups", ctypes.c_int32), ("n_t4", ctypes.c_int32), ("n_t1", ctypes.c_int32), ("n_tseg", ctypes.c_int32),
+                ("n_tfin", ctypes.c_int32), ("tile_kmax", ctypes.c_int32), ("d_tile_off", ctypes.c_void_p), ("d_tile_len", ctypes.c_void_p),
+                ("d_tile_dst", ctypes.c_void_p), ("d_tile_long", ctypes.c_void_p), ("d_tile_col", ctypes.c_void_p),
+                ("d_tile_val", ctypes.c_void_p)]
 
 
 class AdamJob(ctypes.Structure):

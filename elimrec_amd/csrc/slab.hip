@@ -834,8 +834,8 @@ __device__ __forceinline__ void stream_combine(const StreamArgs &a, int grp, int
 // sum_j val[j] * Xin[col[j]] of one work item per lane group, neighbour order, fmaf; the (col, val) of step j + U are in
 // flight while step j gathers; ccj / cvj hold the first step on entry
 template <int VPL, bool IN_BF16, bool MASKED, int U>
-__device__ __forceinline__ void stream_gather(const StreamArgs &a, int64_t in_base, int64_t e0, int len, int (&ccj)[U], float (&cvj)[U],
-                                              float (&acc)[VPL]) {
+__device__ __forceinline__ void stream_gather(const StreamArgs &a, const uint32_t *mask, int64_t in_base, int64_t e0, int len,
+                                              int (&ccj)[U], float (&cvj)[U], float (&acc)[VPL]) {
 #pragma unroll
     for (int i = 0; i < VPL; ++i) acc[i] = 0.f;
     for (int j = 0; j < len; j += U) {
@@ -852,7 +852,7 @@ __device__ __forceinline__ void stream_gather(const StreamArgs &a, int64_t in_ba
         }
         if (MASKED) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) in[u] = in[u] && bit_of(a.src_mask, cj[u]);
+            for (int u = 0; u < U; ++u) in[u] = in[u] && bit_of(mask, cj[u]);
         }
         float x[U][VPL];
 #pragma unroll
@@ -912,7 +912,7 @@ __global__ __launch_bounds__(256) void sell_stream_kernel(StreamArgs a) {
             float vj0[U];
             load_idx(e0, len, cj0, vj0);
             float acc[VPL];
-            stream_gather<VPL, IN_BF16, MASKED, U>(a, in_base, e0, len, cj0, vj0, acc);
+            stream_gather<VPL, IN_BF16, MASKED, U>(a, a.src_mask, in_base, e0, len, cj0, vj0, acc);
             if (dst >= 0) {
                 const int64_t pidx = ((int64_t)slab * a.n_seg + dst) * a.wl + c;
                 if (!a.tickets) lane_store<VPL, false>(a.partials, pidx, acc);
@@ -964,7 +964,7 @@ __global__ __launch_bounds__(256) void sell_stream_kernel(StreamArgs a) {
         float nvj0[U];
         load_idx(ne0, nlen, ncj0, nvj0);
         float acc[VPL];
-        stream_gather<VPL, IN_BF16, MASKED, U>(a, in_base, ce0, clen, ccj, cvj, acc);
+        stream_gather<VPL, IN_BF16, MASKED, U>(a, a.src_mask, in_base, ce0, clen, ccj, cvj, acc);
         if (cdst >= 0) stream_epilogue<VPL, OUT_BF16>(a, slab, cdst, c, acc);
         clen = nlen; cdst = ndst; ce0 = ne0;
         nlen = flen; ndst = fdst; ne0 = fe0;
@@ -974,57 +974,109 @@ __global__ __launch_bounds__(256) void sell_stream_kernel(StreamArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Form 3 (default): ONE launch, no partial rows for all but a handful of rows. Work is tiered by row length:
-//   * rows of <= T non-zeros: a lane group each, SELL order (as above);
-//   * T < length <= T1: one WAVE per row -- its 64/LPR lane groups take contiguous chunks of the neighbour list, the chunk
-//     sums are added in group order through shuffles;
-//   * T1 < length <= T2: one WORKGROUP per row -- the same per wave, the four wave sums added in wave order through LDS;
-//   * longer (a dozen rows at the Tiktok shape): T-long segments + the last-arriver combine of form 1. The acquire
-//     fence that made form 1 slow is executed a dozen times per launch instead of once per split row.
-// Every sum has a fixed order, so the result is bitwise reproducible (it differs in round-off from forms 0-2, whose
-// split rows are summed in segment order).
+// Form 3 (whole fp32 tables; the engine's default there): ONE launch per hop over WAVE TILES. What bounds the older
+// forms at the Tiktok shape is not HBM but the CU's memory pipeline walking the index: every (col, val) pair costs two
+// wave-wide load instructions that return 32 useful bytes each, a step of 4 neighbours depends on the index loads of
+// the step before, and a hop that gathers nothing still takes 28 of the 34 us (tools/bench_tier.py). Here a tile is
+// the work of one wave -- G = 64/LPR lane groups -- with its index stored [step][group]: the wave reads it with
+// full-width coalesced loads (lane l takes entry l, l+64, ...; two loads ahead), and a lane group picks its neighbour
+// of step j out of the loaded registers with a cross-lane read (ds_bpermute), so the index costs one load instruction
+// per 64 neighbours instead of one per G, and the chain is index -> gathers with 8 gathers per lane in flight.
+// Tiles by row length (T = long_threshold, G groups):
+//   * rows of <= T non-zeros: G rows per tile, a lane group each, SELL order (sum in neighbour order, = CSR order);
+//   * T < length <= T1: one wave per row, the row's neighbours dealt round-robin to the G groups, the group sums added
+//     in group order through shuffles;
+//   * T1 < length <= T2: one workgroup per row -- four such tiles over contiguous quarters, the four wave sums added in
+//     wave order through LDS;
+//   * longer (a dozen rows at the Tiktok shape): T-long segments, G per tile; a segment wave publishes its partial rows
+//     write-through, draws a ticket per row, and the wave that draws a row's last ticket adds the partials in segment
+//     order after ONE agent-scope acquire (cdna_hip_programming.md Guideline 16, recipe R1 in its counter form).
+// Every sum has a fixed order, so results are bitwise reproducible; rows above T differ in round-off from forms 0-2.
 struct TierArgs {
     StreamArgs s;
-    const int32_t *w1_rows, *w4_rows, *rowptr, *ccol, *long_index;
-    const float *cval;
-    int n_w1, n_w4;
-    int b_w1, b_seg, b_fin;        // first block (per slab group) of the wave rows, the segment items, the unsplit rows
+    const int32_t *tile_off, *tile_len, *tile_dst, *tile_long, *tcol, *long_index;
+    const float *tval;
+    int n_w4;                      // workgroup rows (4 tiles each)
+    int t1_base, tseg_base, tfin_base, n_tiles;     // first tile of the wave rows, segment tiles, unsplit-row tiles
+    int n_tiles_run;               // tiles this launch walks (seg_only: up to tfin_base)
+    const uint64_t *ballots;       // masked hop: [n_tiles x kmax] source-mask bits of each 64-entry index line
+    int kmax;
 };
 
-// sum over neighbours [jb, je) of one CSR row for this lane's columns
-template <int VPL, bool IN_BF16, bool MASKED>
-__device__ __forceinline__ void tier_chunk(const TierArgs &t, int64_t in_base, int jb, int je, float (&acc)[VPL]) {
-    constexpr int U = 4;
+// The first adjoint hop gathers from a row-sparse table (<= 3B active rows). Testing the row bitmap per neighbour would
+// cost a scattered load instruction per 64/LPR neighbours -- as many memory instructions as the gathers of a full hop,
+// on the pipeline that bounds it -- so the bitmap is looked up ONCE per index entry by this pass (coalesced index read,
+// L1-resident bitmap) and the hop kernel reads one 64-bit word per index line through the scalar cache.
+__global__ __launch_bounds__(256) void tile_ballot_kernel(const int32_t *__restrict__ tile_off, const int32_t *__restrict__ tcol,
+                                                          const uint32_t *__restrict__ mask, int G, int n_tiles, int kmax,
+                                                          uint64_t *__restrict__ ballots) {
+    const int lane = threadIdx.x & 63;
+    const int ti = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+    if (ti >= n_tiles) return;
+    const int off = tile_off[ti];
+    const int nk = (tile_off[ti + 1] - off + 63) >> 6;
+    for (int k = 0; k < nk; ++k) {
+        const int cidx = tcol[off + (k << 6) + lane];
+        const uint64_t b = __ballot(bit_of(mask, cidx));
+        if (lane == 0) ballots[(int64_t)ti * kmax + k] = b;
+    }
+}
+
+// sum over the tile's steps of val * Xin[col] for this lane group; neighbour order, fmaf
+template <int LPR, int VPL, bool IN_BF16, bool MASKED>
+__device__ __forceinline__ void tile_gather(const TierArgs &t, int ti, int64_t in_base, int off, int steps, int glen, int lane, int sub,
+                                            float (&acc)[VPL]) {
+    constexpr int G = 64 / LPR;
+    constexpr int UB = LPR < 8 ? LPR : 8;                  // neighbours per lane group in flight
     const StreamArgs &a = t.s;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) acc[i] = 0.f;
-    for (int j = jb; j < je; j += U) {
-        int cj[U];
-        float vj[U];
-        bool in[U];
+    const int nk = (steps * G + 63) >> 6;                  // index loads of 64 entries (= LPR steps) each
+    const int32_t *colp = t.tcol + off + lane;
+    const float *valp = t.tval + off + lane;
+    int c0 = 0, c1 = 0;
+    float v0 = 0.f, v1 = 0.f;
+    if (nk > 0) { c0 = colp[0]; v0 = valp[0]; }
+    if (nk > 1) { c1 = colp[64]; v1 = valp[64]; }
+    for (int k = 0; k < nk; ++k) {
+        int c2 = 0;
+        float v2 = 0.f;
+        if (k + 2 < nk) { c2 = colp[(k + 2) << 6]; v2 = valp[(k + 2) << 6]; }
+        const int jbase = k * LPR;
+        uint64_t bal = 0;
+        if (MASKED) bal = t.ballots[(int64_t)ti * t.kmax + k];          // wave-uniform address: scalar load
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            in[u] = (j + u) < je;
-            cj[u] = in[u] ? t.ccol[j + u] : 0;
-            vj[u] = in[u] ? t.cval[j + u] : 0.f;
-        }
-        if (MASKED) {
+        for (int u0 = 0; u0 < LPR; u0 += UB) {
+            if (jbase + u0 >= steps) continue;             // wave-uniform
+            int cj[UB];
+            float vj[UB];
+            bool in[UB];
 #pragma unroll
-            for (int u = 0; u < U; ++u) in[u] = in[u] && bit_of(a.src_mask, cj[u]);
-        }
-        float x[U][VPL];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (in[u]) lane_load<VPL, IN_BF16>(a.Xin, in_base + (int64_t)cj[u] * a.wl, x[u]);
-            else {
-#pragma unroll
-                for (int i = 0; i < VPL; ++i) x[u][i] = 0.f;
+            for (int u = 0; u < UB; ++u) {
+                const int srcl = (u0 + u) * G + sub;
+                cj[u] = G == 64 ? c0 : __shfl(c0, srcl, 64);
+                vj[u] = G == 64 ? v0 : __shfl(v0, srcl, 64);
+                in[u] = (jbase + u0 + u) < glen;
             }
+            if (MASKED) {
+#pragma unroll
+                for (int u = 0; u < UB; ++u) in[u] = in[u] && ((bal >> ((u0 + u) * G + sub)) & 1ull);
+            }
+            float x[UB][VPL];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                if (in[u]) lane_load<VPL, IN_BF16>(a.Xin, in_base + (int64_t)cj[u] * a.wl, x[u]);
+                else {
+#pragma unroll
+                    for (int i = 0; i < VPL; ++i) x[u][i] = 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+#pragma unroll
+                for (int i = 0; i < VPL; ++i) acc[i] = fmaf(vj[u], x[u][i], acc[i]);
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int i = 0; i < VPL; ++i) acc[i] = fmaf(vj[u], x[u][i], acc[i]);
+        c0 = c1; v0 = v1; c1 = c2; v1 = v2;
     }
 }
 
@@ -1044,7 +1096,7 @@ __device__ __forceinline__ void tier_wave_sum(const float (&acc)[VPL], int cl, i
 
 template <int LPR, int VPL, bool IN_BF16, bool OUT_BF16, bool MASKED>
 __global__ __launch_bounds__(256) void sell_tier_kernel(TierArgs t) {
-    constexpr int IPW = 64 / LPR, U = 4;
+    constexpr int G = 64 / LPR;
     const StreamArgs &a = t.s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int grp = (int)(blockIdx.x % (unsigned)a.gs);
@@ -1054,14 +1106,20 @@ __global__ __launch_bounds__(256) void sell_tier_kernel(TierArgs t) {
     const int c = cl & (a.wl - 1);
     const int64_t in_base = (int64_t)slab * a.n_src * a.wl + c;
     __shared__ float s_part[4 * 64 * 8];
-    if (bidx < t.b_w1) {
-        // ---- a workgroup per row
-        const int row = t.w4_rows[bidx];
-        const int beg = t.rowptr[row], end = t.rowptr[row + 1];
-        const int per = (end - beg + 4 * IPW - 1) / (4 * IPW);
-        const int jb = min(beg + (wave * IPW + sub) * per, end), je = min(jb + per, end);
-        float acc[VPL], tot[VPL];
-        tier_chunk<VPL, IN_BF16, MASKED>(t, in_base, jb, je, acc);
+    const int ti = __builtin_amdgcn_readfirstlane(bidx * 4 + wave);       // tiles are laid out workgroup by workgroup
+    const bool wg_row = bidx < t.n_w4;
+    int off = 0, steps = 0, glen = 0, dst = -1;
+    if (ti < t.n_tiles_run) {
+        off = t.tile_off[ti];
+        steps = (t.tile_off[ti + 1] - off) / G;
+        glen = t.tile_len[(int64_t)ti * G + sub];
+        dst = t.tile_dst[(int64_t)ti * G + sub];
+    }
+    float acc[VPL];
+    tile_gather<LPR, VPL, IN_BF16, MASKED>(t, ti, in_base, off, steps, glen, lane, sub, acc);
+    if (wg_row) {
+        // ---- a workgroup per row: wave sums through LDS, wave order
+        float tot[VPL];
         tier_wave_sum<LPR, VPL>(acc, cl, a.n_long, tot);
         if (sub == 0) {
 #pragma unroll
@@ -1072,21 +1130,17 @@ __global__ __launch_bounds__(256) void sell_tier_kernel(TierArgs t) {
 #pragma unroll
             for (int i = 0; i < VPL; ++i) tot[i] = ((s_part[cl * VPL + i] + s_part[(LPR + cl) * VPL + i]) + s_part[(2 * LPR + cl) * VPL + i]) +
                                                    s_part[(3 * LPR + cl) * VPL + i];
-            if (a.compact_long) lane_store<VPL, false>(a.Xout, ((int64_t)slab * a.n_long + t.long_index[row]) * a.wl + c, tot);
-            else stream_epilogue<VPL, OUT_BF16>(a, slab, row, c, tot);
+            if (a.compact_long) lane_store<VPL, false>(a.Xout, ((int64_t)slab * a.n_long + t.long_index[dst]) * a.wl + c, tot);
+            else stream_epilogue<VPL, OUT_BF16>(a, slab, dst, c, tot);
         }
         return;
     }
-    if (bidx < t.b_seg) {
+    if (ti >= t.n_tiles_run) return;
+    if (ti < t.tseg_base) {
         // ---- a wave per row
-        const int i1 = (bidx - t.b_w1) * 4 + wave;
-        if (i1 >= t.n_w1) return;
-        const int row = t.w1_rows[i1];
-        const int beg = t.rowptr[row], end = t.rowptr[row + 1];
-        const int per = (end - beg + IPW - 1) / IPW;
-        const int jb = min(beg + sub * per, end), je = min(jb + per, end);
-        float acc[VPL], tot[VPL];
-        tier_chunk<VPL, IN_BF16, MASKED>(t, in_base, jb, je, acc);
+        const int row = __shfl(dst, 0, 64);
+        if (row < 0) return;                               // padding tile
+        float tot[VPL];
         tier_wave_sum<LPR, VPL>(acc, cl, a.n_long, tot);
         if (sub == 0) {
             if (a.compact_long) lane_store<VPL, false>(a.Xout, ((int64_t)slab * a.n_long + t.long_index[row]) * a.wl + c, tot);
@@ -1094,27 +1148,12 @@ __global__ __launch_bounds__(256) void sell_tier_kernel(TierArgs t) {
         }
         return;
     }
-    // ---- SELL items: segments of the longest rows (tickets), then the unsplit rows
-    const int64_t wb = (int64_t)(bidx - t.b_seg) * 4 + wave;
-    if (wb >= a.n_blocks) return;
-    const int64_t item = wb * IPW + sub;
-    const int len = a.item_len[item], dst = a.item_dst[item];
-    const int64_t e0 = ((int64_t)a.blk_off[item >> 6] << 6) + (item & 63);
-    int cj0[U];
-    float vj0[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const bool in = u < len;
-        cj0[u] = in ? a.col[e0 + ((int64_t)u << 6)] : 0;
-        vj0[u] = in ? a.val[e0 + ((int64_t)u << 6)] : 0.f;
-    }
-    float acc[VPL];
-    stream_gather<VPL, IN_BF16, MASKED, U>(a, in_base, e0, len, cj0, vj0, acc);
-    const bool seg_block = wb * IPW < a.seg_limit;                   // wave-uniform
-    if (!seg_block) {
-        if (dst >= 0 && !a.compact_long) stream_epilogue<VPL, OUT_BF16>(a, slab, dst, c, acc);
+    if (ti >= t.tfin_base) {
+        // ---- unsplit rows, a lane group each
+        if (dst >= 0) stream_epilogue<VPL, OUT_BF16>(a, slab, dst, c, acc);
         return;
     }
+    // ---- segments of the longest rows: partial rows, tickets, last arriver combines
     __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void *)a.partials, 0, (int)min((size_t)0x7FFFFFF0, (size_t)a.n_seg * a.gs * a.spg * a.wl * VPL * 4), 0x00020000);
     if (dst >= 0) {
@@ -1129,7 +1168,7 @@ __global__ __launch_bounds__(256) void sell_tier_kernel(TierArgs t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     int li = -1, ticket = -1, nseg = 0;
     if (dst >= 0) {
-        li = a.item_long[item];
+        li = t.tile_long[(int64_t)(ti - t.tseg_base) * G + sub];
         nseg = a.long_seg_ptr[li + 1] - a.long_seg_ptr[li];
         if (cl == 0) ticket = __hip_atomic_fetch_add(&a.tickets[(int64_t)grp * a.n_long + li], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -1139,7 +1178,7 @@ __global__ __launch_bounds__(256) void sell_tier_kernel(TierArgs t) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll 1
-    for (int g = 0; g < IPW; ++g) {
+    for (int g = 0; g < G; ++g) {
         if (!__shfl(last ? 1 : 0, g * LPR, 64)) continue;
         const int g_li = __shfl(li, g * LPR, 64);
         stream_combine<LPR, VPL, OUT_BF16>(a, grp, g_li);
@@ -1209,11 +1248,17 @@ extern "C" void elimrec_slab_set_variant(int v) { g_slab_variant = v; }
 static size_t slab_partial_floats_bytes(const elimrec_sell *A, int ns, int w) {
     return align_up((size_t)(A->n_seg > 0 ? A->n_seg : 1) * ns * w * sizeof(float), 256);
 }
+static size_t slab_ticket_bytes(const elimrec_sell *A) { return align_up((size_t)8 * (A->n_long > 0 ? A->n_long : 1) * sizeof(int32_t), 256); }
+static size_t slab_ballot_bytes(const elimrec_sell *A) {
+    if (!A->tiered) return 0;
+    const size_t tiles = (size_t)A->n_t4 + A->n_t1 + A->n_tseg + A->n_tfin;
+    return align_up(tiles * (size_t)(A->tile_kmax > 0 ? A->tile_kmax : 1) * sizeof(uint64_t), 256);
+}
 
 // partial rows + the arrival counters of the in-launch combine (8 slab groups at most); the caller zeroes the buffer ONCE
 extern "C" size_t elimrec_slab_partials_bytes(const elimrec_sell *A, int ns, int w) {
     if (!A || ns <= 0 || w <= 0) return 0;
-    return slab_partial_floats_bytes(A, ns, w) + align_up((size_t)8 * (A->n_long > 0 ? A->n_long : 1) * sizeof(int32_t), 256);
+    return slab_partial_floats_bytes(A, ns, w) + slab_ticket_bytes(A) + slab_ballot_bytes(A);
 }
 
 static int g_slab_stream = -1;
@@ -1233,14 +1278,17 @@ extern "C" void elimrec_slab_set_stream(int mode) { g_slab_stream = mode; }
 static int launch_tier(const elimrec_sell *A, int family, int ns, int wl, int wl_shift, int gs, int spg, int lpr, const void *Xin,
                        bool in_bf16, const uint32_t *src_mask, void *Xout, bool out_bf16, const float *add,
                        const uint32_t *add_mask, float scale, float *partials, int seg_only, hipStream_t s) {
+    if (A->tile_groups != 64 / lpr) {
+        set_error("slab_hop: the plan's wave tiles were laid out for %d lane groups per wave, this table geometry has %d",
+                  A->tile_groups, 64 / lpr);
+        return ELIMREC_E_BADARG;
+    }
+    ELIMREC_REQUIRE(A->d_tile_off && A->d_tile_len && A->d_tile_dst && A->d_tile_col && A->d_tile_val && A->n_t4 == 4 * A->n_w4 &&
+                        A->n_t1 % 4 == 0 && A->n_tseg % 4 == 0 && A->n_tfin % 4 == 0 && (A->n_tseg == 0 || A->d_tile_long),
+                    "slab_hop: bad tile plan");
     TierArgs t = {};
     StreamArgs &a = t.s;
-    a.item_dst = A->d_item_dst; a.item_len = A->d_item_len; a.blk_off = A->d_blk_off; a.col = A->d_col; a.val = A->d_val;
-    a.item_long = A->d_item_long;
     a.n_rows = A->n_rows; a.n_src = A->n_src; a.n_seg = A->n_seg; a.n_long = A->n_long;
-    const int ipw = 64 / lpr;
-    a.n_blocks = (int64_t)(seg_only ? A->n_seg_items : A->n_items) / ipw;
-    a.seg_limit = A->n_seg_items;
     a.wl = wl; a.wl_shift = wl_shift; a.gs = gs; a.spg = spg;
     a.Xin = Xin; a.src_mask = src_mask; a.Xout = Xout;
     a.Add = seg_only ? nullptr : (const float4 *)add; a.add_mask = add_mask; a.scale = seg_only ? 1.0f : scale;
@@ -1248,14 +1296,24 @@ static int launch_tier(const elimrec_sell *A, int family, int ns, int wl, int wl
     const int vpl = family ? 8 : 4;
     a.tickets = (int32_t *)((char *)partials + slab_partial_floats_bytes(A, ns, wl * vpl));
     a.compact_long = seg_only ? 1 : 0;
-    t.w1_rows = A->d_w1_rows; t.w4_rows = A->d_w4_rows; t.n_w1 = A->n_w1; t.n_w4 = A->n_w4;
-    t.rowptr = A->d_rowptr; t.ccol = A->d_csr_col; t.cval = A->d_csr_val; t.long_index = A->d_long_index;
-    t.b_w1 = A->n_w4;
-    t.b_seg = t.b_w1 + (A->n_w1 + 3) / 4;
-    const int64_t per_group = t.b_seg + (a.n_blocks + 3) / 4;
+    t.tile_off = A->d_tile_off; t.tile_len = A->d_tile_len; t.tile_dst = A->d_tile_dst; t.tile_long = A->d_tile_long;
+    t.tcol = A->d_tile_col; t.tval = A->d_tile_val; t.long_index = A->d_long_index;
+    t.n_w4 = A->n_w4;
+    t.t1_base = A->n_t4; t.tseg_base = t.t1_base + A->n_t1; t.tfin_base = t.tseg_base + A->n_tseg;
+    t.n_tiles = t.tfin_base + A->n_tfin;
+    t.n_tiles_run = seg_only ? t.tfin_base : t.n_tiles;
+    const int64_t per_group = t.n_tiles_run / 4;
     if (per_group <= 0) return 0;
     const dim3 grid((unsigned)(per_group * gs));
     const bool masked = src_mask != nullptr;
+    if (masked) {
+        ELIMREC_REQUIRE(A->tile_kmax > 0, "slab_hop: bad tile plan (tile_kmax)");
+        t.kmax = A->tile_kmax;
+        uint64_t *ballots = (uint64_t *)((char *)a.tickets + slab_ticket_bytes(A));
+        t.ballots = ballots;
+        hipLaunchKernelGGL(tile_ballot_kernel, dim3((unsigned)per_group), dim3(256), 0, s, t.tile_off, t.tcol, src_mask, 64 / lpr,
+                           t.n_tiles_run, t.kmax, ballots);
+    }
 #define ELIMREC_TIER(LPR)                                                                                                     \
     do {                                                                                                                      \
         if (!family) {                                                                                                        \

@@ -105,19 +105,60 @@ class SellPlan(object):
             ro = np.argsort(-deg[short_rows], kind="stable")
         else:
             ro = np.lexsort((-deg[short_rows], short_rows < int(side_split)))
+        long_index = np.full(n_rows, -1, np.int32)
+        long_index[long_rows] = np.arange(len(long_rows), dtype=np.int32)
+        dev = torch.device(device)
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(np.asarray(a).astype(dt))).to(dev)
+        self.device = dev
+        self.n_rows, self.n_src, self.nnz = int(n_rows), int(n_src), int(m.nnz)
+        self.n_seg, self.n_long = n_seg, int(len(long_rows))
+        self.threshold = T
+        self.tiered, self.n_w1, self.n_w4 = bool(tiered), int(len(w1)), int(len(w4))
+        self.t = dict(long_rows=t(long_rows if len(long_rows) else np.zeros(1), np.int32),
+                      long_seg_ptr=t(seg_ptr, np.int32), long_index=t(long_index, np.int32),
+                      rowptr=t(rowptr, np.int32), csr_col=t(col if len(col) else np.zeros(1), np.int32),
+                      csr_val=t(val if len(val) else np.zeros(1), np.float32))
+        p = lambda k: self.t[k].data_ptr() if k in self.t else None
+        if tiered:
+            tiles = self._wave_tiles(int(ipw), rowptr, col, val, deg, w4, w1, seg_beg[so], seg_len[so], so, seg_row[so], short_rows[ro])
+            self.t.update({k: t(v, np.float32 if k == "tile_val" else np.int32) for k, v in tiles.items() if k.startswith("tile_")})
+            self.n_items = self.n_seg_items = 0
+            self.sell_entries, self.sell_seg_entries = tiles["entries"], tiles["seg_entries"]
+            self.n_tiles = tiles["n_t4"] + tiles["n_t1"] + tiles["n_tseg"] + tiles["n_tfin"]
+            self.tile_groups = int(ipw)
+            tile_counts = (int(ipw), tiles["n_t4"], tiles["n_t1"], tiles["n_tseg"], tiles["n_tfin"], tiles["kmax"])
+        else:
+            sell = self._sell64(rowptr, col, val, deg, seg_beg[so], seg_len[so], so, seg_row[so], short_rows[ro])
+            self.t.update({k: t(v, np.float32 if k == "val" else np.int32) for k, v in sell.items() if not k.startswith("_")})
+            self.n_items, self.n_seg_items = sell["_n_items"], sell["_n_seg_items"]
+            self.sell_entries, self.sell_seg_entries = sell["_entries"], sell["_seg_entries"]
+            self.n_tiles, self.tile_groups = 0, 0
+            tile_counts = (0, 0, 0, 0, 0, 0)
+        self.desc = _lib.SellDesc(self.n_rows, self.n_src, self.n_items, self.n_seg_items, self.n_seg, self.n_long,
+                                  p("item_dst"), p("item_len"), p("blk_off"), p("col"), p("val"), p("long_rows"),
+                                  p("long_seg_ptr"), p("long_index"), p("rowptr"), p("csr_col"), p("csr_val"), p("item_long"),
+                                  1 if tiered else 0, self.n_w1, self.n_w4, *tile_counts,
+                                  p("tile_off"), p("tile_len"), p("tile_dst"), p("tile_long"), p("tile_col"), p("tile_val"))
+        self._partials = {}
+
+    @staticmethod
+    def _sell64(rowptr, col, val, deg, seg_beg, seg_len, seg_slot, seg_long, fin_rows):
+        """SELL-64 work items (two-launch form): segment items, then the unsplit rows, super blocks of 64, (col, val)
+        transposed inside a super block."""
+        n_seg = len(seg_beg)
         pad = lambda n: (-n) % 64
         n_seg_items = n_seg + pad(n_seg)
-        n_fin = len(short_rows)
+        n_fin = len(fin_rows)
         n_items = n_seg_items + n_fin + pad(n_fin)
         item_dst = np.full(n_items, -1, np.int32)
         item_len = np.zeros(n_items, np.int32)
         item_beg = np.zeros(n_items, np.int64)
-        item_dst[:n_seg] = so.astype(np.int32)
-        item_len[:n_seg] = seg_len[so]
-        item_beg[:n_seg] = seg_beg[so]
-        item_dst[n_seg_items:n_seg_items + n_fin] = short_rows[ro].astype(np.int32)
-        item_len[n_seg_items:n_seg_items + n_fin] = deg[short_rows[ro]]
-        item_beg[n_seg_items:n_seg_items + n_fin] = rowptr[short_rows[ro]]
+        item_dst[:n_seg] = seg_slot.astype(np.int32)
+        item_len[:n_seg] = seg_len
+        item_beg[:n_seg] = seg_beg
+        item_dst[n_seg_items:n_seg_items + n_fin] = fin_rows.astype(np.int32)
+        item_len[n_seg_items:n_seg_items + n_fin] = deg[fin_rows]
+        item_beg[n_seg_items:n_seg_items + n_fin] = rowptr[fin_rows]
         nb = n_items // 64
         blk_len = item_len.reshape(nb, 64).max(1).astype(np.int64) if nb else np.zeros(0, np.int64)
         blk_off = np.concatenate([[0], np.cumsum(blk_len)]).astype(np.int64)
@@ -134,32 +175,63 @@ class SellPlan(object):
         sell_col[dstpos] = col[src]
         sell_val[dstpos] = val[src]
         item_long = np.zeros(max(n_seg_items, 1), np.int32)
-        item_long[:n_seg] = seg_row[so]
-        long_index = np.full(n_rows, -1, np.int32)
-        long_index[long_rows] = np.arange(len(long_rows), dtype=np.int32)
+        item_long[:n_seg] = seg_long
+        return dict(item_dst=item_dst, item_len=item_len, blk_off=blk_off, col=sell_col, val=sell_val, item_long=item_long,
+                    _n_items=int(n_items), _n_seg_items=int(n_seg_items), _entries=total,
+                    _seg_entries=int(blk_off[n_seg_items // 64]) * 64)
 
-        dev = torch.device(device)
-        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a.astype(dt))).to(dev)
-        self.device = dev
-        self.n_rows, self.n_src, self.nnz = int(n_rows), int(n_src), int(m.nnz)
-        self.n_items, self.n_seg_items, self.n_seg, self.n_long = int(n_items), int(n_seg_items), n_seg, int(len(long_rows))
-        self.sell_entries = total
-        self.sell_seg_entries = int(blk_off[n_seg_items // 64]) * 64
-        self.threshold = T
-        self.t = dict(item_dst=t(item_dst, np.int32), item_len=t(item_len, np.int32), blk_off=t(blk_off, np.int32),
-                      col=t(sell_col, np.int32), val=t(sell_val, np.float32),
-                      long_rows=t(long_rows if len(long_rows) else np.zeros(1), np.int32),
-                      long_seg_ptr=t(seg_ptr, np.int32), long_index=t(long_index, np.int32),
-                      rowptr=t(rowptr, np.int32), csr_col=t(col if len(col) else np.zeros(1), np.int32),
-                      csr_val=t(val if len(val) else np.zeros(1), np.float32), item_long=t(item_long, np.int32),
-                      w1_rows=t(w1 if len(w1) else np.zeros(1), np.int32), w4_rows=t(w4 if len(w4) else np.zeros(1), np.int32))
-        self.tiered, self.n_w1, self.n_w4 = bool(tiered), int(len(w1)), int(len(w4))
-        p = lambda k: self.t[k].data_ptr()
-        self.desc = _lib.SellDesc(self.n_rows, self.n_src, self.n_items, self.n_seg_items, self.n_seg, self.n_long,
-                                  p("item_dst"), p("item_len"), p("blk_off"), p("col"), p("val"), p("long_rows"),
-                                  p("long_seg_ptr"), p("long_index"), p("rowptr"), p("csr_col"), p("csr_val"), p("item_long"),
-                                  1 if tiered else 0, self.n_w1, self.n_w4, p("w1_rows"), p("w4_rows"))
-        self._partials = {}
+    @staticmethod
+    def _wave_tiles(G, rowptr, col, val, deg, w4, w1, seg_beg, seg_len, seg_slot, seg_long, fin_rows):
+        """Wave tiles of the one-launch form (struct elimrec_sell, tiered plan): per tile and lane group the first CSR
+        position, the count and the stride of its neighbours, then one scatter of every non-zero to
+        tile_off[tile] + step * G + group."""
+        i64 = np.int64
+        g = np.arange(G, dtype=i64)[None, :]
+        def row_tiles(beg, n, dst):          # a contiguous run of a row per tile, dealt round-robin to the groups
+            beg, n = np.asarray(beg, i64)[:, None], np.asarray(n, i64)[:, None]
+            return beg + g, np.maximum(0, (n - g + G - 1) // G), np.full((len(beg), G), G, i64), np.repeat(np.asarray(dst, i64)[:, None], G, 1)
+        def item_tiles(beg, n, dst):         # G items per tile, a group each
+            k = len(beg)
+            k_pad = (-k) % (4 * G)
+            z = lambda a, fill: np.concatenate([np.asarray(a, i64), np.full(k_pad, fill, i64)]).reshape(-1, G)
+            return z(beg, 0), z(n, 0), np.ones(((k + k_pad) // G, G), i64), z(dst, -1)
+        def pad4(parts):                     # empty tiles up to a multiple of 4
+            k = (-len(parts[0])) % 4
+            if k == 0:
+                return parts
+            e = (np.zeros((k, G), i64), np.zeros((k, G), i64), np.ones((k, G), i64), np.full((k, G), -1, i64))
+            return tuple(np.concatenate([a, b]) for a, b in zip(parts, e))
+        n4 = deg[w4].astype(i64)
+        q = (((n4 + 3) // 4 + G - 1) // G) * G                          # quarter length, a multiple of G
+        cidx = np.arange(4, dtype=i64)[None, :]
+        cb = (rowptr[w4].astype(i64)[:, None] + cidx * q[:, None]).reshape(-1)
+        cn = np.clip(n4[:, None] - cidx * q[:, None], 0, q[:, None]).reshape(-1)
+        A = row_tiles(cb, cn, np.repeat(w4, 4))
+        B = pad4(row_tiles(rowptr[w1], deg[w1], w1))
+        C = item_tiles(seg_beg, seg_len, seg_slot)
+        D = item_tiles(rowptr[fin_rows], deg[fin_rows], fin_rows)
+        GB, GL, GS, GD = (np.concatenate([a, b, c, d]) for a, b, c, d in zip(A, B, C, D))
+        steps = GL.max(1) if len(GL) else np.zeros(0, i64)
+        tile_off = np.concatenate([[0], np.cumsum(steps * G)]).astype(i64)
+        total = int(tile_off[-1])
+        if total + 128 >= 2 ** 31:
+            raise ValueError("graph too large for int32 tile offsets")
+        tcol = np.zeros(total + 128, np.int32)                         # a wave reads whole 64-entry lines past its tile
+        tval = np.zeros(total + 128, np.float32)
+        glf, gbf, gsf = GL.reshape(-1), GB.reshape(-1), GS.reshape(-1)
+        it = np.repeat(np.arange(len(glf), dtype=i64), glf)
+        j = np.arange(len(it), dtype=i64) - np.repeat(np.cumsum(glf) - glf, glf)
+        src = gbf[it] + j * gsf[it]
+        pos = tile_off[it // G] + j * G + (it % G)
+        tcol[pos] = col[src]
+        tval[pos] = val[src]
+        n_tseg = len(C[0])
+        tile_long = np.zeros(max(n_tseg * G, 1), np.int32)
+        tile_long[:len(seg_long)] = seg_long
+        seg_end = len(A[0]) + len(B[0]) + n_tseg
+        return dict(tile_off=tile_off, tile_len=GL.reshape(-1), tile_dst=GD.reshape(-1), tile_long=tile_long, tile_col=tcol,
+                    tile_val=tval, n_t4=len(A[0]), n_t1=len(B[0]), n_tseg=n_tseg, n_tfin=len(D[0]), entries=total,
+                    seg_entries=int(tile_off[seg_end]), kmax=int(((steps * G + 63) // 64).max()) if len(steps) else 1)
 
     def ref(self):
         return ctypes.byref(self.desc)
@@ -174,6 +246,8 @@ class SellPlan(object):
 
     def index_bytes(self):
         """Bytes of index data one pass of a hop reads (SELL col + val, item records, block offsets)."""
+        if self.tiered:
+            return 8 * self.sell_entries + (8 * self.tile_groups + 4) * self.n_tiles
         return 8 * self.sell_entries + 8 * self.n_items + 4 * (self.n_items // 64 + 1)
 
 

@@ -465,19 +465,30 @@ typedef struct elimrec_sell {
     const float *d_csr_val;
     const int32_t *d_item_long;     /* [n_seg_items] split row (index into d_long_rows) of a segment item; NULL
                                        selects the two-launch form (hop + fix-up) instead of the in-launch combine */
-    /* tiered plan (tiered != 0; ONE launch per hop): rows of more than long_threshold non-zeros are NOT work items;
-     * d_w1_rows [n_w1] get one wave each, d_w4_rows [n_w4] one workgroup each, and only the rows longer still are cut
-     * into segment items (their partial rows are combined in-launch by the last-arriving segment wave).
-     * d_long_rows / d_long_index / n_long still cover every row above long_threshold (compact seg_only output). */
+    /* tiered plan (tiered != 0; ONE launch per hop over WAVE TILES, csrc/slab.hip form 3): a tile is the work of one
+     * wave of tile_groups lane groups, its index stored [step][group] in d_tile_col / d_tile_val from entry
+     * d_tile_off[tile] (int32 [n_tiles + 1], multiples of tile_groups; both arrays padded by 64 entries), with
+     * d_tile_len / d_tile_dst [n_tiles x tile_groups] = neighbours of each lane group and its output row (partial
+     * slot for segment tiles, -1 padding). Tile order: n_t4 = 4*n_w4 tiles of the n_w4 rows that get a workgroup
+     * (contiguous quarters, d_tile_dst = the row), n_t1 tiles of the rows that get a wave (neighbours dealt round-robin
+     * to the groups), n_tseg tiles of long_threshold-long segments of the rows longer still (d_tile_long
+     * [n_tseg x tile_groups] = index into d_long_rows; partial rows combined in-launch by the last-arriving wave),
+     * n_tfin tiles of tile_groups unsplit rows each. n_t1, n_tseg, n_tfin are multiples of 4 (empty padding tiles).
+     * d_long_rows / d_long_index / n_long cover every row above long_threshold (compact seg_only output);
+     * d_long_seg_ptr / n_seg only the segmented rows' slots. The SELL-64 arrays above may be NULL for a tiered plan. */
     int32_t tiered, n_w1, n_w4;
-    const int32_t *d_w1_rows, *d_w4_rows;
+    int32_t tile_groups, n_t4, n_t1, n_tseg, n_tfin;
+    int32_t tile_kmax;              /* most 64-entry index lines of any tile (row stride of the masked hop's bit words) */
+    const int32_t *d_tile_off, *d_tile_len, *d_tile_dst, *d_tile_long, *d_tile_col;
+    const float *d_tile_val;
 } elimrec_sell;
 
 /* One hop over a slab-major table:  r = A . Xin ;  Xout[row] = (r + [add_mask bit row] Add[row]) * scale.
  * gs = slab groups (1, 2, 4 or 8 dividing ns): a workgroup works on the ns/gs slabs of group blockIdx % gs.
  * d_src_mask (nullable bitmap over the source rows): rows whose bit is clear are zero and are not read (the
  * first adjoint hop gathers from the row-sparse head gradient). d_add / d_add_mask nullable.
- * d_partials: scratch [ns x n_seg x w] floats for the split rows. seg_only != 0: only the split rows are
+ * d_partials: scratch of elimrec_slab_partials_bytes: [ns x n_seg x w] floats for the split rows, the in-launch
+ * combine's arrival counters and (tiered plans) the masked hop's per-index-line source bits; zero-filled once. seg_only != 0: only the split rows are
  * evaluated and written COMPACTLY to d_Xout viewed as [ns x n_long x w] (no add/scale) -- the part of hop L
  * that elimrec_slab_rows cannot do inline.
  * Replaces torch.sparse.mm (models/EliMRec.py:244) and its backward for one column slice. */

@@ -11,9 +11,10 @@ U, I = 36656, 76085
 ds = SyntheticDataset(U, I, 720829, feat_dims=(4, 4, 4), seed=0)
 adj = create_adj_mat(*ds.get_train_interactions(), U, I, "pre").tocsr()
 N = adj.shape[0]
-plan = slab.SellPlan(adj, dev, side_split=U)
 ns, w = slab.choose_slabs(d, N)
 gs = slab.choose_groups(ns)
+tiered = os.environ.get("TIERED", "1") == "1"
+plan = slab.SellPlan(adj, dev, side_split=U, tiered=tiered, threshold=64 if tiered else 32, ipw=64 // ((ns // gs) * (w // 4)))
 torch.manual_seed(0)
 tabs = [slab.SlabTable(N, ns, w, dev).from_rows(torch.randn(N, d, device=dev)) for _ in range(3)]
 src, dst = tabs[0], tabs[1]
