@@ -160,7 +160,9 @@ SIGNATURES = {
     "elimrec_head_fwd_fused": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i32, ctypes.POINTER(c_ptr),
                                        ctypes.POINTER(c_i64), ctypes.POINTER(c_i32), ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr),
                                        c_ptr, c_ptr, c_ptr, c_ptr, ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr), c_ptr, c_size,
-                                       c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr]),
+                                       c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32, c_ptr]),
+    "elimrec_score_set_math": (None, [c_i32]),
+    "elimrec_score_get_math": (c_i32, []),
     "elimrec_build_adj_workspace": (c_size, [c_i64, c_i64, c_i32]),
     "elimrec_build_adj": (c_i32, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size,
                                   c_ptr]),

@@ -14,6 +14,86 @@ constexpr int kMaxS = 4;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
+// reductions over the 16 lanes of a DPP row (the 16 items of a tile) on the VALU: quad swaps, half-row mirror, row mirror;
+// every lane of the row ends with the result (HIP's __shfl_xor is an LDS-pipe ds_bpermute per step)
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    return fmaxf(v, dpp_f<0x140>(v));
+}
+__device__ __forceinline__ float row16_sum(float v) {      // fixed order: ((a+b)+(c+d)) quads, then the mirrored halves
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);
+    return v + dpp_f<0x140>(v);
+}
+
+// Evaluation math (elimrec_score_set_math): EXACT = the expressions above with IEEE division and libm expf/logf -- scores
+// equal to the reference's to a few ulp, about 196 VALU instructions per (user, item) pair, which is what bounds the
+// scorer (51 % VALU-issue busy against 29 % MFMA busy). FAST = v_exp_f32 / v_log_f32 / v_rcp_f32 (1 ulp each) and
+// reciprocal norms: about a quarter of the instructions, scores within 2e-6 of EXACT (tests/test_hip_parity.py), top-K
+// indices equal except where two scores differ by less than that.
+template <bool FAST> __device__ __forceinline__ float sig_(float x) {
+    if (FAST) return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+    return sigmoidf_(x);
+}
+template <bool FAST> __device__ __forceinline__ float log_(float x) {
+    if (FAST) return __builtin_amdgcn_logf(x) * 0.693147180559945309f;
+    return logf(x);
+}
+template <bool FAST> __device__ __forceinline__ float log1p_(float x) {
+    if (FAST) return __builtin_amdgcn_logf(1.f + x) * 0.693147180559945309f;
+    return log1pf(x);
+}
+
+template <bool FAST>
+__device__ __forceinline__ float fuse_t(int mode, float x, const float *z, int S, uint32_t mask) {
+    if (mode == 0) {
+        float r = x;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) if (h < S && (mask & (1u << h))) r *= sig_<FAST>(z[h]);
+        return r;
+    } else if (mode == 1) {
+        float t = sig_<FAST>(x);
+#pragma unroll
+        for (int h = 0; h < 4; ++h) if (h < S) t *= sig_<FAST>(z[h]);
+        return log_<FAST>(t + 1e-12f) - log1p_<FAST>(t);
+    } else {
+        float t = x;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) if (h < S) t += z[h];
+        return log_<FAST>(sig_<FAST>(t) + 1e-12f);
+    }
+}
+
+template <bool FAST>
+__device__ __forceinline__ void fuse2_t(int mode, float x, float m, const float *z, int S, uint32_t mask, float &fx, float &fm) {
+    if (mode == 0) {
+        fx = x; fm = m;
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+            if (h < S && (mask & (1u << h))) { const float sg = sig_<FAST>(z[h]); fx *= sg; fm *= sg; }
+    } else if (mode == 1) {
+        float tx = sig_<FAST>(x), tm = sig_<FAST>(m);
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+            if (h < S) { const float sg = sig_<FAST>(z[h]); tx *= sg; tm *= sg; }
+        fx = log_<FAST>(tx + 1e-12f) - log1p_<FAST>(tx);
+        fm = log_<FAST>(tm + 1e-12f) - log1p_<FAST>(tm);
+    } else {
+        float tx = x, tm = m;
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+            if (h < S) { tx += z[h]; tm += z[h]; }
+        fx = log_<FAST>(sig_<FAST>(tx) + 1e-12f);
+        fm = log_<FAST>(sig_<FAST>(tm) + 1e-12f);
+    }
+}
+
 struct ScoreArgs {
     const float *Y; int64_t ldy; int64_t U; int64_t I; const int64_t *users; int B; int d; int S;
     uint32_t head_mask; int fusion_mode; int predict_type;
@@ -21,6 +101,8 @@ struct ScoreArgs {
     float *partial;                  // pass 1: [n_item_tiles x B] partial row sums of ui
     float *scores; int64_t lds;      // pass 2 output
     const float *sqn;                // [N x (1+S)] squared L2 norms of every head block of every row of Y
+    float *tile_max;                 // pass 2, optional: [B x tmax_ld] max score of every 16-item tile (BEFORE masking)
+    int64_t tmax_ld;
 };
 
 __device__ __forceinline__ float fuse(int mode, float x, const float *z, int S, uint32_t mask) {
@@ -247,8 +329,11 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(ScoreArgs a) {
 // A operands of its 32 users in registers (NB * D / 2 floats per lane), the workgroup walks item tiles
 // blockIdx.x, + gridDim.x, ... and only the 32 item rows of a tile go through LDS. Same k order per output and the
 // same partial-sum layout as score_mfma_kernel, so the scores are bit-identical.
-template <int PASS, int NB, int D>
-__global__ __launch_bounds__(256) void score_resident_kernel(ScoreArgs a, int n_tiles) {
+// PT / FM: predict type and fusion mode as compile-time constants (PASS 2; -1 = read them from the arguments) -- one
+// epilogue instead of seven in the instruction stream and in the register budget.
+template <int PASS, int NB, int D, int PT, int FM>
+__global__ __launch_bounds__(256, 2) void score_resident_kernel(ScoreArgs a, int n_tiles) {
+    const int ptype = PT >= 0 ? PT : ptype, fmode = FM >= 0 ? FM : fmode;
     constexpr int NH = (PASS == 1) ? 1 : NB;          // head blocks this pass needs
     constexpr int COLS = NH * D, LD = COLS + 1;
     constexpr int PFN = MI * COLS / 1024;             // float4 per thread per item tile
@@ -274,8 +359,8 @@ __global__ __launch_bounds__(256) void score_resident_kernel(ScoreArgs a, int n_
         const int b = b0 + tid;
         const int64_t un = b < a.B ? a.users[b] : -1;
         for (int h = 0; h + 1 < NB; ++h)
-            unorm[tid * (NB - 1) + h] = (un >= 0 && a.predict_type != 0) ? fmaxf(sqrtf(a.sqn[un * NB + 1 + h]), eps) : 1.f;
-        umean[tid] = (b < a.B && a.predict_type == 2) ? a.row_mean[b] : 0.f;
+            unorm[tid * (NB - 1) + h] = (un >= 0 && ptype != 0) ? fmaxf(sqrtf(a.sqn[un * NB + 1 + h]), eps) : 1.f;
+        umean[tid] = (b < a.B && ptype == 2) ? a.row_mean[b] : 0.f;
     }
     // item tiles are double-buffered: the next tile's rows are in flight (registers) during this tile's MFMAs and
     // epilogue and go to the other LDS buffer afterwards -- one barrier per tile
@@ -329,7 +414,7 @@ __global__ __launch_bounds__(256) void score_resident_kernel(ScoreArgs a, int n_
             float inorm[NB > 1 ? NB - 1 : 1];
 #pragma unroll
             for (int h = 0; h + 1 < NB; ++h)
-                inorm[h] = (item_ok && a.predict_type != 0) ? fmaxf(sqrtf(a.sqn[(a.U + item) * NB + 1 + h]), eps) : 1.f;
+                inorm[h] = (item_ok && ptype != 0) ? fmaxf(sqrtf(a.sqn[(a.U + item) * NB + 1 + h]), eps) : 1.f;
             // all 16 outputs of the lane are computed unconditionally (independent chains the scheduler can
             // interleave; rows / items past the end hold zeros) and only the store is predicated
 #pragma unroll
@@ -337,25 +422,193 @@ __global__ __launch_bounds__(256) void score_resident_kernel(ScoreArgs a, int n_
                 const int urow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const float ui = sigmoidf_(acc[0][r]);
                 float out;
-                if (a.predict_type == 0) {
+                if (ptype == 0) {
                     out = sigmoidf_(ui);
                 } else {
                     float z[kMaxS];
 #pragma unroll
                     for (int h = 0; h < kMaxS; ++h)
                         z[h] = (h + 1 < NB) ? acc[(h + 1 < NH) ? h + 1 : 0][r] / (unorm[urow * (NB - 1) + (h + 1 < NB ? h : 0)] * inorm[h + 1 < NB ? h : 0]) : 0.f;
-                    if (a.predict_type == 1) out = sigmoidf_(fuse(a.fusion_mode, ui, z, NB - 1, a.head_mask));
+                    if (ptype == 1) out = sigmoidf_(fuse(fmode, ui, z, NB - 1, a.head_mask));
                     else {
                         float te, nde;
-                        fuse2(a.fusion_mode, ui, umean[urow], z, NB - 1, a.head_mask, te, nde);
+                        fuse2(fmode, ui, umean[urow], z, NB - 1, a.head_mask, te, nde);
                         out = sigmoidf_(te - nde);
                     }
                 }
                 if (item_ok && b0 + urow < a.B) a.scores[(int64_t)(b0 + urow) * a.lds + item] = out;
+                // four independent chains at a time are enough to hide the VALU latencies; all 16 interleaved cost
+                // 370 registers and the second wave per SIMD
+                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (next < n_tiles) store_tile(cur ? it0 : it1);
         __syncthreads();
+    }
+}
+
+// The scorer the evaluator runs (recdim 64, 1-3 single-modal heads): the resident form above needs 128 registers for a
+// wave's 32 users' A operands, 64 accumulators and a 16-output epilogue -- 370 registers, ONE wave per SIMD, nothing to
+// hide the epilogue's transcendental chains or the item loads behind (15 % of the fp32 MFMA rate, 18 % MFMA-busy,
+// 30 % VALU-busy by the PMC counters). Here a wave owns 16 users (v_mfma_f32_16x16x4_f32: 64 A registers for four
+// head blocks, 16 accumulators, 4 outputs per lane), eight waves = the 128 users of an evaluation block share every
+// 16-item tile through LDS, and two workgroups fit a CU: four waves per SIMD. The item tile is double-buffered as
+// before; its row stride (cols + 4 floats) keeps the b128 stores aligned and the B-operand reads two-way at worst.
+constexpr int TU = 16, TI = 16, TW = 8;           // users per wave, items per tile, waves per workgroup
+typedef float v4f_s __attribute__((ext_vector_type(4)));
+
+constexpr int t16_sub(int pass) { return pass == 1 ? 1 : 1; }     // 16-item tiles per barrier interval (measured: 4 / 2 are slower -- fewer, fatter workgroups)
+
+template <int PASS, int NB, int PT, int FM, bool FAST>
+__global__ __launch_bounds__(512, 4) void score_t16_kernel(ScoreArgs a, int n_tiles) {
+    constexpr int D = 64;
+    constexpr int NH = (PASS == 1) ? 1 : NB;
+    constexpr int COLS = NH * D, LD = COLS + 4;
+    constexpr int SUB = t16_sub(PASS), CI = SUB * TI;  // items per chunk
+    extern __shared__ float smem[];
+    float *it0 = smem, *it1 = smem + CI * LD;
+    float *unorm = it1 + CI * LD;                     // [128][NB-1]
+    float *umean = unorm + TW * TU * (NB > 1 ? NB - 1 : 1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int b0 = blockIdx.y * (TW * TU);
+    const float eps = 1e-12f;
+    const int ptype = PT >= 0 ? PT : a.predict_type, fmode = FM >= 0 ? FM : a.fusion_mode;
+    const int n_chunks = (n_tiles + SUB - 1) / SUB;
+    // A operands: user (wave*16 + li), element k = 4*ks + kq of head block h
+    float ua[NH][D / 4];
+    {
+        const int ub = b0 + wave * TU + li;
+        const float *urow = ub < a.B ? a.Y + a.users[ub] * a.ldy + kq : nullptr;
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int ks = 0; ks < D / 4; ++ks) ua[h][ks] = urow ? urow[h * D + 4 * ks] : 0.f;
+    }
+    if (PASS == 2 && tid < TW * TU) {
+        const int b = b0 + tid;
+        const int64_t un = b < a.B ? a.users[b] : -1;
+        for (int h = 0; h + 1 < NB; ++h) {
+            const float nrm = (un >= 0 && ptype != 0) ? fmaxf(sqrtf(a.sqn[un * NB + 1 + h]), eps) : 1.f;
+            unorm[tid * (NB - 1) + h] = FAST ? __builtin_amdgcn_rcpf(nrm) : nrm;       // FAST: reciprocal norms
+        }
+        umean[tid] = (b < a.B && ptype == 2) ? a.row_mean[b] : 0.f;
+    }
+    // the chunk's rows as float4 over the 512 threads
+    constexpr int PFN = (CI * COLS / 4 + 511) / 512;
+    float4 pf[PFN];
+    auto load_chunk = [&](int chunk) {
+#pragma unroll
+        for (int q = 0; q < PFN; ++q) {
+            const int e = (tid + 512 * q) * 4;
+            if (e < CI * COLS) {
+                const int r = e / COLS, c = e - r * COLS;
+                const int64_t item = (int64_t)chunk * CI + r;
+                pf[q] = item < a.I ? *reinterpret_cast<const float4 *>(a.Y + (a.U + item) * a.ldy + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto store_chunk = [&](float *buf) {
+#pragma unroll
+        for (int q = 0; q < PFN; ++q) {
+            const int e = (tid + 512 * q) * 4;
+            if (e < CI * COLS) {
+                const int r = e / COLS, c = e - r * COLS;
+                *reinterpret_cast<float4 *>(buf + r * LD + c) = pf[q];
+            }
+        }
+    };
+    float psum[4] = {0.f, 0.f, 0.f, 0.f};             // PASS 1: this wave's users' running sums of ui, tiles in ascending order
+    if ((int)blockIdx.x < n_chunks) { load_chunk(blockIdx.x); store_chunk(it0); }
+    __syncthreads();
+    int cur = 0;
+    for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x, cur ^= 1) {
+        const int next = chunk + gridDim.x;
+        if (next < n_chunks) load_chunk(next);
+#pragma unroll
+        for (int sub = 0; sub < SUB; ++sub) {
+            const int tile = chunk * SUB + sub;
+            if (tile >= n_tiles) break;               // workgroup-uniform
+            const int64_t i0 = (int64_t)tile * TI;
+            v4f_s acc[NH];
+            const float *bp = (cur ? it1 : it0) + (sub * TI + li) * LD + kq;
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                acc[h] = (v4f_s){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < D / 4; ++ks)
+                    acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(ua[h][ks], bp[h * D + 4 * ks], acc[h], 0, 0, 0);
+            }
+            // lane: item i0 + li, users wave*16 + 4*kq + r
+            const int64_t item = i0 + li;
+            const bool item_ok = item < a.I;
+            if (PASS == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int b = b0 + wave * TU + 4 * kq + r;
+                    const float v = (item_ok && b < a.B) ? sig_<FAST>(acc[0][r]) : 0.f;
+                    psum[r] += row16_sum(v);          // over the 16 items of the tile
+                }
+            } else {
+                float inorm[NB > 1 ? NB - 1 : 1];
+#pragma unroll
+                for (int h = 0; h + 1 < NB; ++h) {
+                    inorm[h] = (item_ok && ptype != 0) ? fmaxf(sqrtf(a.sqn[(a.U + item) * NB + 1 + h]), eps) : 1.f;
+                    if (FAST) inorm[h] = __builtin_amdgcn_rcpf(inorm[h]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int urow = wave * TU + 4 * kq + r;
+                    const float ui = sig_<FAST>(acc[0][r]);
+                    float out;
+                    if (ptype == 0) {
+                        out = sig_<FAST>(ui);
+                    } else {
+                        float z[kMaxS];
+#pragma unroll
+                        for (int h = 0; h < kMaxS; ++h) {
+                            const float nn = unorm[urow * (NB - 1) + (h + 1 < NB ? h : 0)] * inorm[h + 1 < NB ? h : 0];
+                            const float dp = acc[(h + 1 < NH) ? h + 1 : 0][r];
+                            z[h] = (h + 1 < NB) ? (FAST ? dp * nn : dp / nn) : 0.f;
+                        }
+                        if (ptype == 1) out = sig_<FAST>(fuse_t<FAST>(fmode, ui, z, NB - 1, a.head_mask));
+                        else {
+                            float te, nde;
+                            fuse2_t<FAST>(fmode, ui, umean[urow], z, NB - 1, a.head_mask, te, nde);
+                            out = sig_<FAST>(te - nde);
+                        }
+                    }
+                    const bool row_ok = b0 + urow < a.B;
+                    if (item_ok && row_ok) a.scores[(int64_t)(b0 + urow) * a.lds + item] = out;
+                    if (a.tile_max) {                               // max over the tile's 16 items (lanes li) of this user
+                        const float mx = row16_max(item_ok ? out : -INFINITY);
+                        if (li == 0 && row_ok) a.tile_max[(int64_t)(b0 + urow) * a.tmax_ld + tile] = mx;
+                    }
+                }
+            }
+        }
+        if (next < n_chunks) store_chunk(cur ? it0 : it1);
+        __syncthreads();
+    }
+    if (PASS == 1 && li == 0) {                       // one partial per (workgroup, user): row_mean_kernel adds them in order
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = b0 + wave * TU + 4 * kq + r;
+            if (b < a.B) a.partial[(int64_t)blockIdx.x * a.B + b] = psum[r];
+        }
+    }
+}
+
+// bitmap of the items to mask, one workgroup per user row: clear, then set (rows are disjoint, the atomics stay in one row)
+__global__ __launch_bounds__(256) void train_bits_kernel(const int64_t *__restrict__ ptr, const int32_t *__restrict__ items, int64_t I,
+                                                         uint32_t *__restrict__ bits, int64_t bits_ld) {
+    const int b = blockIdx.x;
+    uint32_t *row = bits + (int64_t)b * bits_ld;
+    for (int64_t w = threadIdx.x; w < bits_ld; w += 256) row[w] = 0u;
+    __syncthreads();
+    for (int64_t j = ptr[b] + threadIdx.x; j < ptr[b + 1]; j += 256) {
+        const int it = items[j];
+        if (it >= 0 && it < I) atomicOr(&row[it >> 5], 1u << (it & 31));
     }
 }
 
@@ -404,7 +657,8 @@ __global__ void mask_train_kernel(float *__restrict__ scores, int64_t lds, const
 // previous pick in that total order. One workgroup per row.
 __global__ __launch_bounds__(1024) void topk_kernel(const float *__restrict__ scores, int64_t lds, int64_t I, int K,
                                                     int32_t *__restrict__ out_idx, float *__restrict__ out_val,
-                                                    const int32_t *__restrict__ only_if) {
+                                                    const int32_t *__restrict__ only_if,
+                                                    const uint32_t *__restrict__ mask_bits = nullptr, int64_t bits_ld = 0) {
     __shared__ float sv[16];
     __shared__ int si[16];
     __shared__ float last_v;
@@ -419,7 +673,8 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float *__restrict__ sc
         float bv = -INFINITY;
         int bi = INT32_MAX;
         for (int64_t i = threadIdx.x; i < I; i += blockDim.x) {
-            const float v = row[i];
+            float v = row[i];
+            if (mask_bits && ((mask_bits[(int64_t)b * bits_ld + (i >> 5)] >> (i & 31)) & 1u)) v = -INFINITY;   // a masked item
             const bool after = (r == 0) || (v < pv) || (v == pv && (int)i > pi);
             if (after && (v > bv || (v == bv && (int)i < bi))) { bv = v; bi = (int)i; }
         }
@@ -516,46 +771,157 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float *__restri
     }
 }
 
+// The same selection guided by the scorer's tile maxima: the row is never swept. Thread t folds the maxima of tiles t,
+// t+256, ... into a group maximum; tau = the (K + n_masked)-th largest of the 256 group maxima. The maxima are taken
+// BEFORE the train items are masked (a mask test per score in the scorer's epilogue costs more than the whole selection):
+// at most n_masked groups owe their maximum to a masked item, so at least K groups -- K unmasked scores -- are >= tau,
+// and all of them sit in tiles whose maximum is >= tau, a few dozen of the 4 756 at the Tiktok shape. Only those tiles'
+// scores are read, the masked ones dropped (bitmap), the rest compacted and ranked as above. Same fall-back protocol
+// (K + n_masked > 256 groups, massive ties, fewer than K unmasked scores).
+__global__ __launch_bounds__(256) void topk_tiles_kernel(const float *__restrict__ scores, int64_t lds, int64_t I,
+                                                         const float *__restrict__ tile_max, int64_t tmax_ld, int n_tiles, int K,
+                                                         const int64_t *__restrict__ mask_ptr, const uint32_t *__restrict__ mask_bits,
+                                                         int64_t bits_ld, int32_t *__restrict__ out_idx,
+                                                         float *__restrict__ out_val, int32_t *__restrict__ fallback) {
+    __shared__ float gm[256];
+    __shared__ float cv[TK_CAP];
+    __shared__ int ci[TK_CAP];
+    __shared__ int ct[TK_CAP];
+    __shared__ float tau;
+    __shared__ int cnt, n_ct;
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float *row = scores + (int64_t)b * lds;
+    const float *tmx = tile_max + (int64_t)b * tmax_ld;
+    const uint32_t *bits = mask_bits ? mask_bits + (int64_t)b * bits_ld : nullptr;
+    const int64_t n_masked = mask_ptr ? mask_ptr[b + 1] - mask_ptr[b] : 0;
+    float m = -INFINITY;
+    for (int i = t; i < n_tiles; i += 256) m = fmaxf(m, tmx[i]);
+    gm[t] = m;
+    if (t == 0) { cnt = 0; n_ct = 0; tau = -INFINITY; }
+    __syncthreads();
+    {
+        int rank = 0;
+        for (int j = 0; j < 256; ++j) rank += tk_before(gm[j], j, m, t) ? 1 : 0;
+        if ((int64_t)rank == K - 1 + n_masked) tau = m;
+    }
+    __syncthreads();
+    const float th = tau;
+    if (th != -INFINITY) {
+        // candidate tiles first (their numbers into ci[], which the ranking below reuses), then one score per thread
+        for (int i = t; i < n_tiles; i += 256) {
+            if (tmx[i] >= th) {
+                const int slot = atomicAdd(&n_ct, 1);
+                if (slot < TK_CAP) ct[slot] = i;
+            }
+        }
+        __syncthreads();
+        const int nct = n_ct < TK_CAP ? n_ct : TK_CAP;
+        if (n_ct > TK_CAP && t == 0) cnt = TK_CAP + 1;                 // too many tiles: fall back
+        for (int w = t; w < nct * TI; w += 256) {
+            const int64_t i = (int64_t)ct[w / TI] * TI + (w % TI);
+            if (i >= I) continue;
+            const float v = row[i];
+            if (v >= th && !(bits && ((bits[i >> 5] >> (i & 31)) & 1u))) {
+                const int slot = atomicAdd(&cnt, 1);
+                if (slot < TK_CAP) { cv[slot] = v; ci[slot] = (int)i; }
+            }
+        }
+    }
+    __syncthreads();
+    const int n = cnt;
+    if (n > TK_CAP || n < K || th == -INFINITY) {  // workgroup-uniform
+        if (t == 0) fallback[b] = 1;
+        return;
+    }
+    if (t == 0) fallback[b] = 0;
+    for (int c = t; c < n; c += 256) {
+        int rank = 0;
+        const float mv = cv[c];
+        const int mi = ci[c];
+        for (int j = 0; j < n; ++j) rank += tk_before(cv[j], ci[j], mv, mi) ? 1 : 0;
+        if (rank < K) {
+            out_idx[(int64_t)b * K + rank] = mi;
+            if (out_val) out_val[(int64_t)b * K + rank] = mv;
+        }
+    }
+}
+
 struct MetricIds { int id[8]; };
 
-// metric.h:17-106, one thread per (user, metric). double where the C++ promotes to double.
-__global__ void rank_metrics_kernel(const int32_t *__restrict__ rank, int B, int K, const int64_t *__restrict__ tptr,
-                                    const int32_t *__restrict__ titems, MetricIds mids, int n_metrics,
-                                    float *__restrict__ out) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= B * n_metrics) return;
-    const int b = t / n_metrics, m = t - b * n_metrics;
-    const int32_t *r = rank + (int64_t)b * K;
-    const int32_t *truth = titems + tptr[b];
-    const int nt = (int)(tptr[b + 1] - tptr[b]);
-    float *o = out + ((int64_t)b * n_metrics + m) * K;
-    auto hit = [&](int x) { for (int j = 0; j < nt; ++j) if (truth[j] == x) return true; return false; };
-    const int id = mids.id[m];
-    if (id == 1) {
-        int hits = 0;
-        for (int i = 0; i < K; ++i) { if (hit(r[i])) hits++; o[i] = (float)(1.0 * hits / (i + 1)); }
-    } else if (id == 2) {
-        int hits = 0;
-        for (int i = 0; i < K; ++i) { if (hit(r[i])) hits++; o[i] = (float)(1.0 * hits / (double)nt); }
-    } else if (id == 3) {
-        int hits = 0; float pre = 0.f, sum_pre = 0.f;
-        for (int i = 0; i < K; ++i) {
-            if (hit(r[i])) { hits++; pre = (float)(1.0 * hits / (i + 1)); sum_pre += pre; }
-            o[i] = hits == 0 ? 0.f : sum_pre / hits;
+// metric.h:17-106. One wave per user, a lane per rank: the hit flags of the K ranks are found in parallel (ballots), the
+// discount table 1/log2(i+2) once per workgroup, and every lane then evaluates its own prefix of the reference's
+// sequential recurrences IN THE REFERENCE'S ORDER (float / double exactly where the C++ rounds), so the curves have the
+// bits of a one-thread-per-metric loop at a fraction of its latency. K <= 256.
+constexpr int RM_KMAX = 256;
+__global__ __launch_bounds__(256) void rank_metrics_kernel(const int32_t *__restrict__ rank, int B, int K, const int64_t *__restrict__ tptr,
+                                                           const int32_t *__restrict__ titems, MetricIds mids, int n_metrics,
+                                                           float *__restrict__ out) {
+    __shared__ double s_w[RM_KMAX];
+    __shared__ unsigned long long s_hit[4][RM_KMAX / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wv;
+    for (int i = threadIdx.x; i < K; i += 256) s_w[i] = 1.0 / log2((double)(i + 2));
+    const int KW = (K + 63) >> 6;
+    int nt = 0;
+    if (b < B) {
+        const int32_t *r = rank + (int64_t)b * K;
+        const int32_t *truth = titems + tptr[b];
+        nt = (int)(tptr[b + 1] - tptr[b]);
+        for (int c = 0; c < KW; ++c) {
+            const int i = lane + 64 * c;
+            const int x = i < K ? r[i] : -1;
+            bool h = false;
+            for (int j = 0; j < nt; ++j) h = h || (truth[j] == x);
+            const unsigned long long bal = __ballot(h && i < K);
+            if (lane == 0) s_hit[wv][c] = bal;
         }
-    } else if (id == 4) {
-        float idcg = 0.f, dcg = 0.f;
-        for (int i = 0; i < K; ++i) {
-            const double w = 1.0 / log2((double)(i + 2));
-            if (hit(r[i])) dcg = (float)((double)dcg + w);
-            if (i < nt) idcg = (float)((double)idcg + w);
-            o[i] = dcg / idcg;
+    }
+    __syncthreads();
+    if (b >= B) return;
+    // visit the hit ranks j <= i in ascending order
+    auto for_hits_upto = [&](int i, auto &&fn) {
+        for (int c = 0; c <= (i >> 6); ++c) {
+            unsigned long long bits = s_hit[wv][c];
+            if (c == (i >> 6)) bits &= (~0ull) >> (63 - (i & 63));
+            while (bits) {
+                const int j = __builtin_ctzll(bits) + 64 * c;
+                bits &= bits - 1;
+                fn(j);
+            }
         }
-    } else if (id == 5) {
-        int i = 0;
-        for (; i < K; ++i) {
-            if (hit(r[i])) { const float rr = (float)(1.0 / (i + 1)); for (int j = i; j < K; ++j) o[j] = rr; break; }
-            o[i] = 0.f;
+    };
+    for (int m = 0; m < n_metrics; ++m) {
+        const int id = mids.id[m];
+        float *o = out + ((int64_t)b * n_metrics + m) * K;
+        for (int c = 0; c < KW; ++c) {
+            const int i = lane + 64 * c;
+            if (i >= K) continue;
+            float v = 0.f;
+            if (id == 1 || id == 2) {
+                int hits = 0;
+                for_hits_upto(i, [&](int) { ++hits; });
+                v = id == 1 ? (float)(1.0 * hits / (i + 1)) : (float)(1.0 * hits / (double)nt);
+            } else if (id == 3) {
+                int hits = 0;
+                float sum_pre = 0.f;
+                for_hits_upto(i, [&](int j) { ++hits; sum_pre += (float)(1.0 * hits / (j + 1)); });
+                v = hits == 0 ? 0.f : sum_pre / hits;
+            } else if (id == 4) {
+                float dcg = 0.f, idcg = 0.f;
+                for_hits_upto(i, [&](int j) { dcg = (float)((double)dcg + s_w[j]); });
+                const int lim = i < nt ? i + 1 : nt;
+                for (int j = 0; j < lim; ++j) idcg = (float)((double)idcg + s_w[j]);
+                v = dcg / idcg;
+            } else if (id == 5) {
+                int first = -1;
+                for (int c2 = 0; c2 <= (i >> 6) && first < 0; ++c2) {
+                    unsigned long long bits = s_hit[wv][c2];
+                    if (c2 == (i >> 6)) bits &= (~0ull) >> (63 - (i & 63));
+                    if (bits) first = __builtin_ctzll(bits) + 64 * c2;
+                }
+                v = first < 0 ? 0.f : (float)(1.0 / (first + 1));
+            }
+            o[i] = v;
         }
     }
 }
@@ -564,7 +930,18 @@ __global__ void rank_metrics_kernel(const int32_t *__restrict__ rank, int B, int
 
 using namespace elimrec;
 
-static inline int n_item_tiles(int64_t I) { return (int)((I + MI - 1) / MI); }   // MFMA tiles (the finer of the two)
+static int g_score_math = -1;
+static int score_math() {
+    if (g_score_math < 0) {
+        const char *e = getenv("ELIMREC_EVAL_MATH");
+        g_score_math = (e && (e[0] == 'f' || e[0] == '1')) ? 1 : 0;
+    }
+    return g_score_math;
+}
+extern "C" void elimrec_score_set_math(int mode) { g_score_math = mode ? 1 : 0; }
+extern "C" int elimrec_score_get_math(void) { return score_math(); }
+
+static inline int n_item_tiles(int64_t I) { return (int)((I + TI - 1) / TI); }   // 16-item tiles (the finest of the forms)
 
 extern "C" size_t elimrec_score_workspace(int B, int64_t I, int K) {
     (void)K;
@@ -575,8 +952,12 @@ extern "C" size_t elimrec_score_workspace(int B, int64_t I, int K) {
     return partial + mean + scores + flags;      // + the squared-norm table, added by elimrec_score_workspace2
 }
 
+static size_t score_sqn_bytes(int64_t U, int64_t I, int S) { return align_up((size_t)(U + I) * (size_t)(1 + S) * sizeof(float), 256); }
+static size_t score_bits_bytes(int B, int64_t I) { return align_up((size_t)(B > 0 ? B : 1) * (size_t)((I + 31) / 32) * sizeof(uint32_t), 256); }
+static size_t score_tmax_bytes(int B, int64_t I) { return align_up((size_t)(B > 0 ? B : 1) * (size_t)n_item_tiles(I) * sizeof(float), 256); }
+
 extern "C" size_t elimrec_score_workspace2(int B, int64_t U, int64_t I, int S, int K) {
-    return elimrec_score_workspace(B, I, K) + align_up((size_t)(U + I) * (size_t)(1 + S) * sizeof(float), 256);
+    return elimrec_score_workspace(B, I, K) + score_sqn_bytes(U, I, S) + score_bits_bytes(B, I) + score_tmax_bytes(B, I);
 }
 
 extern "C" int elimrec_row_sqnorms(const float *d_Y, int64_t ldy, int64_t n_rows, int d, int n_blocks, float *d_out,
@@ -629,6 +1010,11 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
         ELIMREC_LAUNCH_CHECK("row_sqnorm");
     }
     a.sqn = d_sqnorm ? d_sqnorm : wsqn;
+    uint32_t *wbits = (uint32_t *)((char *)wsqn + score_sqn_bytes(U, I, S));
+    float *wtmax = (float *)((char *)wbits + score_bits_bytes(B, I));
+    const int64_t bits_ld = (I + 31) / 32;
+    a.tile_max = nullptr; a.tmax_ld = n_item_tiles(I);
+    bool tiles_ready = false;
     ELIMREC_REQUIRE(a.lds >= I, "score_topk: lds < I");
     static int use_mfma = -1;
     if (use_mfma < 0) {
@@ -640,31 +1026,107 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
         const char *e = getenv("ELIMREC_SCORE_RESIDENT");
         use_resident = (e && e[0] == '0') ? 0 : 1;
     }
-    if (use_mfma && use_resident && d == 64 && S >= 1 && S <= 3) {
+    static int use_t16 = -1;
+    if (use_t16 < 0) {
+        const char *e = getenv("ELIMREC_SCORE_T16");
+        use_t16 = (e && e[0] == '0') ? 0 : 1;
+    }
+    if (use_mfma && use_t16 && d == 64 && S >= 1 && S <= 3) {
+        // 16 users per wave, 128 per workgroup, a persistent grid over 16-item tiles (two workgroups per CU)
+        const int t16 = (int)((I + TI - 1) / TI);
+        const bool fast = score_math() == 1;
+        if (d_topk_idx && K <= 256) {    // the selection reads the scorer's tile maxima and a bitmap of the masked items
+            a.tile_max = wtmax;
+            tiles_ready = true;
+            if (d_train_ptr) {
+                ELIMREC_REQUIRE(d_train_items, "score_topk: train_items missing");
+                hipLaunchKernelGGL(train_bits_kernel, dim3(B), dim3(256), 0, s, d_train_ptr, d_train_items, I, wbits, bits_ld);
+                ELIMREC_LAUNCH_CHECK("train_bits");
+            }
+        }
+        auto t16_grid = [&](int pass) {      // chunks dealt evenly to at most 512 workgroups
+            const int chunks = (t16 + t16_sub(pass) - 1) / t16_sub(pass);
+            const int per = (chunks + 511) / 512;
+            return dim3((unsigned)((chunks + per - 1) / per), (B + TW * TU - 1) / (TW * TU));
+        };
+        const dim3 grid1 = t16_grid(1), grid = t16_grid(2);
+        auto t16_lds = [](int pass, int nb) {
+            const int cols = (pass == 1 ? 1 : nb) * 64;
+            return ((size_t)2 * t16_sub(pass) * TI * (cols + 4) + (size_t)TW * TU * (nb > 1 ? nb - 1 : 1) + TW * TU) * sizeof(float);
+        };
+#define ELIMREC_T16_LAUNCH(PASS, NB, PT, FM, FAST, GRID)                                                     \
+    do {                                                                                                   \
+        static bool attr = false;                                                                          \
+        if (!attr && t16_lds(PASS, NB) > 64 * 1024) {                                                      \
+            (void)hipFuncSetAttribute((const void *)score_t16_kernel<PASS, NB, PT, FM, FAST>,              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)t16_lds(PASS, NB)); \
+            attr = true;                                                                                   \
+        }                                                                                                  \
+        hipLaunchKernelGGL((score_t16_kernel<PASS, NB, PT, FM, FAST>), GRID, dim3(512), t16_lds(PASS, NB), s, a, t16); \
+    } while (0)
+#define ELIMREC_T16_P2(NB, PT, FM)                                                                           \
+    do {                                                                                                   \
+        if (fast) ELIMREC_T16_LAUNCH(2, NB, PT, FM, true, grid);                                           \
+        else ELIMREC_T16_LAUNCH(2, NB, PT, FM, false, grid);                                               \
+    } while (0)
+#define ELIMREC_T16(NB)                                                                                     \
+    do {                                                                                                   \
+        if (predict_type == 2) {                                                                           \
+            if (fast) ELIMREC_T16_LAUNCH(1, NB, -1, -1, true, grid1);                                      \
+            else ELIMREC_T16_LAUNCH(1, NB, -1, -1, false, grid1);                                          \
+            ELIMREC_LAUNCH_CHECK("score_t16_pass1");                                                       \
+            hipLaunchKernelGGL(row_mean_kernel, dim3(B), dim3(256), 0, s, partial, (int)grid1.x, B, I, mean); \
+            ELIMREC_LAUNCH_CHECK("row_mean");                                                              \
+        }                                                                                                  \
+        if (predict_type == 0) ELIMREC_T16_P2(NB, 0, 0);                                                   \
+        else if (predict_type == 1 && fusion_mode == 0) ELIMREC_T16_P2(NB, 1, 0);                          \
+        else if (predict_type == 1 && fusion_mode == 1) ELIMREC_T16_P2(NB, 1, 1);                          \
+        else if (predict_type == 1) ELIMREC_T16_P2(NB, 1, 2);                                              \
+        else if (fusion_mode == 0) ELIMREC_T16_P2(NB, 2, 0);                                               \
+        else if (fusion_mode == 1) ELIMREC_T16_P2(NB, 2, 1);                                               \
+        else ELIMREC_T16_P2(NB, 2, 2);                                                                     \
+        ELIMREC_LAUNCH_CHECK("score_t16_pass2");                                                           \
+    } while (0)
+        if (S == 1) ELIMREC_T16(2);
+        else if (S == 2) ELIMREC_T16(3);
+        else ELIMREC_T16(4);
+#undef ELIMREC_T16
+#undef ELIMREC_T16_P2
+#undef ELIMREC_T16_LAUNCH
+    } else if (use_mfma && use_resident && d == 64 && S >= 1 && S <= 3) {
         // users resident in registers, a persistent grid over the item tiles (two workgroups per CU)
         dim3 grid((unsigned)(tiles < 512 ? tiles : 512), (B + MU - 1) / MU);
+#define ELIMREC_SCORE_RESIDENT2(NB, PT, FM)                                                                  \
+    do {                                                                                                   \
+        static bool attr = false;                                                                          \
+        if (!attr) {                                                                                       \
+            (void)hipFuncSetAttribute((const void *)score_resident_kernel<2, NB, 64, PT, FM>,              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident_lds(2, NB, 64)); \
+            attr = true;                                                                                   \
+        }                                                                                                  \
+        hipLaunchKernelGGL((score_resident_kernel<2, NB, 64, PT, FM>), grid, dim3(256), resident_lds(2, NB, 64), s, a, tiles); \
+    } while (0)
 #define ELIMREC_SCORE_RESIDENT(NB)                                                                          \
     do {                                                                                                   \
         if (predict_type == 2) {                                                                           \
-            hipLaunchKernelGGL((score_resident_kernel<1, NB, 64>), grid, dim3(256), resident_lds(1, NB, 64), s, a, tiles); \
+            hipLaunchKernelGGL((score_resident_kernel<1, NB, 64, -1, -1>), grid, dim3(256), resident_lds(1, NB, 64), s, a, tiles); \
             ELIMREC_LAUNCH_CHECK("score_resident_pass1");                                                  \
             hipLaunchKernelGGL(row_mean_kernel, dim3(B), dim3(256), 0, s, partial, tiles, B, I, mean);     \
             ELIMREC_LAUNCH_CHECK("row_mean");                                                              \
         }                                                                                                  \
-        {                                                                                                  \
-            static bool attr = false;                                                                      \
-            if (!attr) {                                                                                   \
-                (void)hipFuncSetAttribute((const void *)score_resident_kernel<2, NB, 64>,                  \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident_lds(2, NB, 64)); \
-                attr = true;                                                                               \
-            }                                                                                              \
-        }                                                                                                  \
-        hipLaunchKernelGGL((score_resident_kernel<2, NB, 64>), grid, dim3(256), resident_lds(2, NB, 64), s, a, tiles); \
+        if (predict_type == 0) ELIMREC_SCORE_RESIDENT2(NB, 0, 0);                                          \
+        else if (predict_type == 1 && fusion_mode == 0) ELIMREC_SCORE_RESIDENT2(NB, 1, 0);                 \
+        else if (predict_type == 1 && fusion_mode == 1) ELIMREC_SCORE_RESIDENT2(NB, 1, 1);                 \
+        else if (predict_type == 1) ELIMREC_SCORE_RESIDENT2(NB, 1, 2);                                     \
+        else if (fusion_mode == 0) ELIMREC_SCORE_RESIDENT2(NB, 2, 0);                                      \
+        else if (fusion_mode == 1) ELIMREC_SCORE_RESIDENT2(NB, 2, 1);                                      \
+        else ELIMREC_SCORE_RESIDENT2(NB, 2, 2);                                                            \
         ELIMREC_LAUNCH_CHECK("score_resident_pass2");                                                      \
     } while (0)
         if (S == 1) ELIMREC_SCORE_RESIDENT(2);
         else if (S == 2) ELIMREC_SCORE_RESIDENT(3);
         else ELIMREC_SCORE_RESIDENT(4);
+#undef ELIMREC_SCORE_RESIDENT2
 #undef ELIMREC_SCORE_RESIDENT
     } else if (use_mfma) {
         dim3 grid(tiles, (B + MU - 1) / MU);
@@ -688,7 +1150,7 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
         hipLaunchKernelGGL(score_kernel<2>, grid, dim3(256), 0, s, a);
         ELIMREC_LAUNCH_CHECK("score_pass2");
     }
-    if (d_train_ptr) {
+    if (d_train_ptr && (d_scores || !tiles_ready)) {       // the caller's score matrix is masked; a private one only if a sweep reads it
         ELIMREC_REQUIRE(d_train_items, "score_topk: train_items missing");
         hipLaunchKernelGGL(mask_train_kernel, dim3(B), dim3(128), 0, s, a.scores, a.lds, d_train_ptr, d_train_items, B);
         ELIMREC_LAUNCH_CHECK("mask_train");
@@ -696,7 +1158,14 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
     if (d_topk_idx) {
         int G = 32;
         while (G < 2 * K && G < 1024) G *= 2;
-        if (2 * K <= 1024) {
+        if (tiles_ready) {
+            hipLaunchKernelGGL(topk_tiles_kernel, dim3(B), dim3(256), 0, s, a.scores, a.lds, I, (const float *)wtmax, a.tmax_ld,
+                               (int)a.tmax_ld, K, d_train_ptr, d_train_ptr ? (const uint32_t *)wbits : (const uint32_t *)nullptr,
+                               bits_ld, d_topk_idx, d_topk_val, fallback);
+            ELIMREC_LAUNCH_CHECK("topk_tiles");
+            hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), 0, s, a.scores, a.lds, I, K, d_topk_idx, d_topk_val,
+                               (const int32_t *)fallback, d_train_ptr ? (const uint32_t *)wbits : (const uint32_t *)nullptr, bits_ld);
+        } else if (2 * K <= 1024) {
             hipLaunchKernelGGL(topk_select_kernel, dim3(B), dim3(1024), 0, s, a.scores, a.lds, I, K, G, d_topk_idx,
                                d_topk_val, fallback);
             ELIMREC_LAUNCH_CHECK("topk_select");
@@ -722,9 +1191,9 @@ extern "C" int elimrec_rank_metrics(const int32_t *d_topk_idx, int B, int K, con
         ELIMREC_REQUIRE(m >= n_metrics || (metric_ids[m] >= 1 && metric_ids[m] <= 5), "rank_metrics: unknown metric id %d",
                         metric_ids[m]);
     }
+    ELIMREC_REQUIRE(K >= 1 && K <= RM_KMAX, "rank_metrics: 1 <= K <= %d", RM_KMAX);
     if (B <= 0) return 0;
-    const int total = B * n_metrics;
-    hipLaunchKernelGGL(rank_metrics_kernel, dim3((total + 127) / 128), dim3(128), 0, (hipStream_t)stream, d_topk_idx,
+    hipLaunchKernelGGL(rank_metrics_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_topk_idx,
                        B, K, d_truth_ptr, d_truth_items, mids, n_metrics, d_out);
     ELIMREC_LAUNCH_CHECK("rank_metrics");
     return 0;

@@ -11,7 +11,6 @@
 // Specialised for recdim = 64 (two 32-column MFMA tiles) and feature widths that fit LDS; other shapes keep the
 // batched-GEMM path.
 #include "common.h"
-#include <cstdlib>
 
 namespace elimrec {
 
@@ -54,8 +53,7 @@ struct HeadFwdArgs {
     float *YAct; int64_t ld_y;
     int a_off[HMAXM];                               // LDS offsets (floats) of the S_m row tiles
     int out_off, part_off;
-    int dbg;                                        // timing experiments only (ELIMREC_HEAD_DBG): 1 no S gather, 2 no stage 1,
-};                                                  // 4 no stage 2, 8 no global stores
+};
 
 // acc += A[32 x (2*nsteps)] . B for MFMA steps [s0, s0 + nsteps): A from LDS (row stride folded into ap together with this
 // lane's row / k-parity), B = packed weights (bp = start of the column tile + lane). 16 B operands in flight.
@@ -130,7 +128,7 @@ __global__ __launch_bounds__(256) void head_fwd_fused_kernel(HeadFwdArgs a) {
         for (int e = tid; e < HROWS * D4; e += 256) {
             const int r = e / D4, c4 = e % D4;
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < nrows && !(a.dbg & 1)) x = *reinterpret_cast<const float4 *>(a.S[m] + (int64_t)a.act[r0 + r] * a.ldS[m] + 4 * c4);
+            if (r < nrows) x = *reinterpret_cast<const float4 *>(a.S[m] + (int64_t)a.act[r0 + r] * a.ldS[m] + 4 * c4);
             float *p = Am + r * lda + 4 * c4;
             p[0] = x.x; p[1] = x.y; p[2] = x.z; p[3] = x.w;
         }
@@ -147,7 +145,7 @@ __global__ __launch_bounds__(256) void head_fwd_fused_kernel(HeadFwdArgs a) {
             const int s0 = kh * hs, ns = min(hs, steps - s0);
             const float *ap = lds + a.a_off[m] + ai * (K + 1) + ak;
             const float *bp = a.pk + a.off_Wm[m] + (int64_t)nt * steps * 64 + lane;
-            if (ns > 0 && !(a.dbg & 2)) accm[m] = head_mfma_run(accm[m], ap, bp, s0, ns);
+            if (ns > 0) accm[m] = head_mfma_run(accm[m], ap, bp, s0, ns);
         }
     }
     if (kh == 1) {
@@ -172,7 +170,7 @@ __global__ __launch_bounds__(256) void head_fwd_fused_kernel(HeadFwdArgs a) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * ak;
                     const float v = (accm[m][r] + Part[(m * HROWS + row) * HD + col]) + s_c[row] * bm + AN[row * LDA + col];
                     OutT[row * LDO + (m + 1) * HD + col] = v;
-                    if (row < nrows && !(a.dbg & 8)) a.OutAct[(int64_t)(r0 + row) * a.ld_out + (m + 1) * HD + col] = v;
+                    if (row < nrows) a.OutAct[(int64_t)(r0 + row) * a.ld_out + (m + 1) * HD + col] = v;
                 }
             }
     }
@@ -183,7 +181,7 @@ __global__ __launch_bounds__(256) void head_fwd_fused_kernel(HeadFwdArgs a) {
         const int steps = C / 2, hs = steps / 2;
         const float *ap = OutT + ai * LDO + ak;
         const float *bp = a.pk + a.off_Wf[side] + (int64_t)nt * steps * 64 + lane;
-        accy[0] = (a.dbg & 4) ? (v16h){0} : head_mfma_run((v16h){0}, ap, bp, kh * hs, hs);
+        accy[0] = head_mfma_run((v16h){0}, ap, bp, kh * hs, hs);
     }
 #pragma unroll
     for (int m = 0; m < HMAXM; ++m) {
@@ -192,7 +190,7 @@ __global__ __launch_bounds__(256) void head_fwd_fused_kernel(HeadFwdArgs a) {
             const int steps = HD / 2, hs = steps / 2;
             const float *ap = OutT + ai * LDO + (m + 1) * HD + ak;
             const float *bp = a.pk + a.off_Ws[m] + (int64_t)nt * steps * 64 + lane;
-            if (!(a.dbg & 4)) accy[1 + m] = head_mfma_run(accy[1 + m], ap, bp, kh * hs, hs);
+            accy[1 + m] = head_mfma_run(accy[1 + m], ap, bp, kh * hs, hs);
         }
     }
     if (kh == 1) {
@@ -216,7 +214,7 @@ __global__ __launch_bounds__(256) void head_fwd_fused_kernel(HeadFwdArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * ak;
-                    if (row < nrows && !(a.dbg & 8)) a.YAct[(int64_t)(r0 + row) * a.ld_y + b * HD + col] = (accy[b][r] + Part[(b * HROWS + row) * HD + col]) + bb;
+                    if (row < nrows) a.YAct[(int64_t)(r0 + row) * a.ld_y + b * HD + col] = (accy[b][r] + Part[(b * HROWS + row) * HD + col]) + bb;
                 }
             }
     }
@@ -240,13 +238,14 @@ extern "C" int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg
                                       const float *const *d_bm, const float *d_Wf_user, const float *d_bf_user,
                                       const float *d_Wf_item, const float *d_bf_item, const float *const *d_Ws,
                                       const float *const *d_bs, float *d_pack, size_t pack_floats, float *d_OutAct,
-                                      int64_t ld_out, float *d_YAct, int64_t ld_y, int recdim, void *stream) {
+                                      int64_t ld_out, float *d_YAct, int64_t ld_y, int recdim, int phase, void *stream) {
     ELIMREC_REQUIRE(d_act && d_seg_info && d_out0 && d_narrow && d_c && d_S && d_Wm && d_Wf_user && d_Wf_item && d_Ws && d_pack &&
                         d_OutAct && d_YAct, "head_fwd_fused: null pointer");
     if (recdim != HD || n_mod < 1 || n_mod > HMAXM) { set_error("head_fwd_fused: recdim must be %d and 1..%d feature tables", HD, HMAXM); return ELIMREC_E_UNSUPPORTED; }
     const int C = (1 + n_mod) * HD;
     ELIMREC_REQUIRE(ld_out0 % 4 == 0 && ld_nar % 4 == 0 && ld_out >= C && ld_y >= C, "head_fwd_fused: bad leading dimensions");
     ELIMREC_REQUIRE(pack_floats >= elimrec_head_pack_floats(n_mod, D), "head_fwd_fused: packed-weight buffer too small");
+    ELIMREC_REQUIRE(phase >= 0 && phase <= 2, "head_fwd_fused: phase 0 (pack + head), 1 (pack only) or 2 (head only)");
     if (R <= 0) return 0;
     HeadFwdArgs a = {};
     PackJobs pj = {};
@@ -281,11 +280,12 @@ extern "C" int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg
     a.act = d_act; a.seg_info = d_seg_info; a.out0 = d_out0; a.ld_out0 = ld_out0; a.narrow = d_narrow; a.ld_nar = ld_nar; a.c = d_c;
     a.n_mod = n_mod; a.pk = d_pack; a.bias_f[0] = d_bf_user; a.bias_f[1] = d_bf_item;
     a.OutAct = d_OutAct; a.ld_out = ld_out; a.YAct = d_YAct; a.ld_y = ld_y;
-    { const char *e = getenv("ELIMREC_HEAD_DBG"); a.dbg = e ? atoi(e) : 0; }
     hipStream_t s = (hipStream_t)stream;
-    if (!(a.dbg & 16))
-    hipLaunchKernelGGL(pack_head_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pj, d_pack);
-    ELIMREC_LAUNCH_CHECK("pack_head_weights");
+    if (phase != 2) {
+        hipLaunchKernelGGL(pack_head_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pj, d_pack);
+        ELIMREC_LAUNCH_CHECK("pack_head_weights");
+    }
+    if (phase == 1) return 0;
     static size_t lds_set = 0;
     if (lds_bytes > 64 * 1024 && lds_bytes > lds_set) {
         hipError_t e = hipFuncSetAttribute((const void *)head_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);

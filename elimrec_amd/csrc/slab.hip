@@ -1022,61 +1022,104 @@ __global__ __launch_bounds__(256) void tile_ballot_kernel(const int32_t *__restr
     }
 }
 
-// sum over the tile's steps of val * Xin[col] for this lane group; neighbour order, fmaf
+// one batch of UB neighbours per lane group: predicate, gather, fused multiply-adds in neighbour order
+template <int VPL, bool IN_BF16, int UB>
+__device__ __forceinline__ void tile_batch(const StreamArgs &a, int64_t in_base, const int (&cj)[UB], const float (&vj)[UB],
+                                           const bool (&in)[UB], float (&acc)[VPL]) {
+    float x[UB][VPL];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+        if (in[u]) lane_load<VPL, IN_BF16>(a.Xin, in_base + (int64_t)cj[u] * a.wl, x[u]);
+        else {
+#pragma unroll
+            for (int i = 0; i < VPL; ++i) x[u][i] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u)
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) acc[i] = fmaf(vj[u], x[u][i], acc[i]);
+}
+
+// sum over the tile's steps of val * Xin[col] for this lane group; neighbour order, fmaf. An index line (64 entries)
+// holds LPR steps of the G groups; a batch is UB steps: a part of a line (LPR >= UB) or UB/LPR whole lines (narrow
+// row pieces: column shards).
 template <int LPR, int VPL, bool IN_BF16, bool MASKED>
 __device__ __forceinline__ void tile_gather(const TierArgs &t, int ti, int64_t in_base, int off, int steps, int glen, int lane, int sub,
                                             float (&acc)[VPL]) {
     constexpr int G = 64 / LPR;
-    constexpr int UB = LPR < 8 ? LPR : 8;                  // neighbours per lane group in flight
+    constexpr int UB = 8;                                  // neighbours per lane group in flight
     const StreamArgs &a = t.s;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) acc[i] = 0.f;
-    const int nk = (steps * G + 63) >> 6;                  // index loads of 64 entries (= LPR steps) each
+    const int nk = (steps * G + 63) >> 6;                  // index lines
     const int32_t *colp = t.tcol + off + lane;
     const float *valp = t.tval + off + lane;
-    int c0 = 0, c1 = 0;
-    float v0 = 0.f, v1 = 0.f;
-    if (nk > 0) { c0 = colp[0]; v0 = valp[0]; }
-    if (nk > 1) { c1 = colp[64]; v1 = valp[64]; }
-    for (int k = 0; k < nk; ++k) {
-        int c2 = 0;
-        float v2 = 0.f;
-        if (k + 2 < nk) { c2 = colp[(k + 2) << 6]; v2 = valp[(k + 2) << 6]; }
-        const int jbase = k * LPR;
-        uint64_t bal = 0;
-        if (MASKED) bal = t.ballots[(int64_t)ti * t.kmax + k];          // wave-uniform address: scalar load
+    if constexpr (LPR >= UB) {
+        int c0 = 0, c1 = 0;
+        float v0 = 0.f, v1 = 0.f;
+        if (nk > 0) { c0 = colp[0]; v0 = valp[0]; }
+        if (nk > 1) { c1 = colp[64]; v1 = valp[64]; }
+        for (int k = 0; k < nk; ++k) {
+            int c2 = 0;
+            float v2 = 0.f;
+            if (k + 2 < nk) { c2 = colp[(k + 2) << 6]; v2 = valp[(k + 2) << 6]; }
+            const int jbase = k * LPR;
+            uint64_t bal = 0;
+            if (MASKED) bal = t.ballots[(int64_t)ti * t.kmax + k];      // wave-uniform address: scalar load
 #pragma unroll
-        for (int u0 = 0; u0 < LPR; u0 += UB) {
-            if (jbase + u0 >= steps) continue;             // wave-uniform
+            for (int u0 = 0; u0 < LPR; u0 += UB) {
+                if (jbase + u0 >= steps) continue;         // wave-uniform
+                int cj[UB];
+                float vj[UB];
+                bool in[UB];
+#pragma unroll
+                for (int u = 0; u < UB; ++u) {
+                    const int srcl = (u0 + u) * G + sub;
+                    cj[u] = __shfl(c0, srcl, 64);
+                    vj[u] = __shfl(v0, srcl, 64);
+                    in[u] = (jbase + u0 + u) < glen;
+                    if (MASKED) in[u] = in[u] && ((bal >> srcl) & 1ull);
+                }
+                tile_batch<VPL, IN_BF16, UB>(a, in_base, cj, vj, in, acc);
+            }
+            c0 = c1; v0 = v1; c1 = c2; v1 = v2;
+        }
+    } else {
+        constexpr int KL = UB / LPR;                       // lines per batch
+        int cc[KL], cn[KL];
+        float vc[KL], vn[KL];
+#pragma unroll
+        for (int q = 0; q < KL; ++q) {
+            cc[q] = q < nk ? colp[q << 6] : 0;
+            vc[q] = q < nk ? valp[q << 6] : 0.f;
+        }
+        for (int k = 0; k < nk; k += KL) {
+#pragma unroll
+            for (int q = 0; q < KL; ++q) {
+                const bool more = k + KL + q < nk;
+                cn[q] = more ? colp[(k + KL + q) << 6] : 0;
+                vn[q] = more ? valp[(k + KL + q) << 6] : 0.f;
+            }
+            const int jbase = k * LPR;
+            uint64_t bal[KL];
+#pragma unroll
+            for (int q = 0; q < KL; ++q) bal[q] = (MASKED && k + q < nk) ? t.ballots[(int64_t)ti * t.kmax + k + q] : 0ull;
             int cj[UB];
             float vj[UB];
             bool in[UB];
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
-                const int srcl = (u0 + u) * G + sub;
-                cj[u] = G == 64 ? c0 : __shfl(c0, srcl, 64);
-                vj[u] = G == 64 ? v0 : __shfl(v0, srcl, 64);
-                in[u] = (jbase + u0 + u) < glen;
+                const int q = u / LPR, srcl = (u % LPR) * G + sub;
+                cj[u] = G == 64 ? cc[q] : __shfl(cc[q], srcl, 64);
+                vj[u] = G == 64 ? vc[q] : __shfl(vc[q], srcl, 64);
+                in[u] = (jbase + u) < glen;
+                if (MASKED) in[u] = in[u] && ((bal[q] >> srcl) & 1ull);
             }
-            if (MASKED) {
+            tile_batch<VPL, IN_BF16, UB>(a, in_base, cj, vj, in, acc);
 #pragma unroll
-                for (int u = 0; u < UB; ++u) in[u] = in[u] && ((bal >> ((u0 + u) * G + sub)) & 1ull);
-            }
-            float x[UB][VPL];
-#pragma unroll
-            for (int u = 0; u < UB; ++u) {
-                if (in[u]) lane_load<VPL, IN_BF16>(a.Xin, in_base + (int64_t)cj[u] * a.wl, x[u]);
-                else {
-#pragma unroll
-                    for (int i = 0; i < VPL; ++i) x[u][i] = 0.f;
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < UB; ++u)
-#pragma unroll
-                for (int i = 0; i < VPL; ++i) acc[i] = fmaf(vj[u], x[u][i], acc[i]);
+            for (int q = 0; q < KL; ++q) { cc[q] = cn[q]; vc[q] = vn[q]; }
         }
-        c0 = c1; v0 = v1; c1 = c2; v1 = v2;
     }
 }
 

@@ -68,21 +68,23 @@ class UniEvaluator(object):
             if getattr(self, "_default_users", None) is None:
                 self._default_users = list(self.user_pos_test.keys())
             test_users = self._default_users
+        cached = test_users is self._default_users
         if not isinstance(test_users, (list, tuple, set, np.ndarray)):
             raise TypeError("'test_user' must be a list, tuple, set or numpy array!")
         if not hasattr(model, "predict_device"):
             raise TypeError("model must expose predict_device(); host-side ranking is not part of this package")
-        rows = []
-        for k, batch_users in enumerate(DataIterator(list(test_users), batch_size=self.batch_size, shuffle=False,
-                                                     drop_last=False)):
-            rows.append(self.evaluate_batch(model, batch_users,
-                                            cache_key=k if test_users is self._default_users else None))
-        all_rows = torch.cat(rows, 0).cpu().numpy()                       # [users, metrics*K]
+        test_users = list(test_users)
+        all_dev = torch.empty(len(test_users), self.metrics_num * self.max_top, dtype=torch.float32, device=model._require_gpu())
+        at = 0
+        for k, batch_users in enumerate(DataIterator(test_users, batch_size=self.batch_size, shuffle=False, drop_last=False)):
+            self.evaluate_batch(model, batch_users, cache_key=k if cached else None, out=all_dev[at:at + len(batch_users)])
+            at += len(batch_users)
+        all_rows = all_dev.cpu().numpy()                                  # [users, metrics*K]
         final = np.mean(all_rows, axis=0).reshape(self.metrics_num, self.max_top)[:, self.top_show - 1].reshape(-1)
         buf = "\t".join(("%.8f" % x).ljust(12) for x in final)
         return final, buf
 
-    def evaluate_batch(self, model, batch_users, return_topk=False, cache_key=None):
+    def evaluate_batch(self, model, batch_users, return_topk=False, cache_key=None, out=None):
         """Per-user metric rows [len(batch_users), metrics*K] (device tensor) for one user block.
         cache_key: the user blocks of the default evaluation order are the same every time, so their
         index tensors (user ids, train-mask CSR, truth CSR) are built once and stay on the device."""
@@ -98,7 +100,8 @@ class UniEvaluator(object):
                 self._dev_cache[key] = hit
         users_t, train_ptr, train_items, truth_ptr, truth_items = hit
         idx, val = model.predict_device(users_t, top_k=self.max_top, train_ptr=train_ptr, train_items=train_items)
-        out = torch.empty(len(batch_users), self.metrics_num * self.max_top, dtype=torch.float32, device=device)
+        if out is None:
+            out = torch.empty(len(batch_users), self.metrics_num * self.max_top, dtype=torch.float32, device=device)
         ops.rank_metrics(idx, truth_ptr, truth_items, self.metrics, out)
         return (out, idx, val) if return_topk else out
 

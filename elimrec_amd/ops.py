@@ -618,9 +618,10 @@ def head_pack_floats(dims):
     return int(_lib.load().elimrec_head_pack_floats(len(dims), arr))
 
 
-def head_fwd_fused(act, seg_info, out0, narrow, c, S, Wm, bm, Wf_user, bf_user, Wf_item, bf_item, Ws, bs, pack, OutAct, YAct, d):
-    """elimrec_head_fwd_fused: S / Wm / bm / Ws / bs are lists over the feature tables. Returns False when the shape is
-    outside the fused kernel's range (the caller keeps the batched GEMMs)."""
+def head_fwd_fused(act, seg_info, out0, narrow, c, S, Wm, bm, Wf_user, bf_user, Wf_item, bf_item, Ws, bs, pack, OutAct, YAct, d, phase=0):
+    """elimrec_head_fwd_fused: S / Wm / bm / Ws / bs are lists over the feature tables. phase 0: pack the weights and
+    run the head; 1: pack only; 2: head only (pack holds the packed weights). Returns False when the shape is outside the
+    fused kernel's range (the caller keeps the batched GEMMs)."""
     n = len(S)
     R = act.numel()
     ptr = lambda ts: (ctypes.c_void_p * max(n, 1))(*[_dev(t, "table") for t in ts])
@@ -632,7 +633,7 @@ def head_fwd_fused(act, seg_info, out0, narrow, c, S, Wm, bm, Wf_user, bf_user, 
         _dev(act, "act", torch.int32), _dev(seg_info, "seg_info", torch.int32), R, _dev(out0, "out0"), out0.stride(0),
         _dev(narrow, "narrow"), narrow.stride(0), _dev(c, "c"), n, ptr(S), ldS, D, ptr(Wm), ptr(bm), _dev(Wf_user, "Wf_user"),
         _dev(bf_user, "bf_user"), _dev(Wf_item, "Wf_item"), _dev(bf_item, "bf_item"), ptr(Ws), ptr(bs), _dev(pack, "pack"),
-        pack.numel(), _dev(OutAct, "OutAct"), OutAct.stride(0), _dev(YAct, "YAct"), YAct.stride(0), int(d), _stream())
+        pack.numel(), _dev(OutAct, "OutAct"), OutAct.stride(0), _dev(YAct, "YAct"), YAct.stride(0), int(d), int(phase), _stream())
     if rc == 10002:           # ELIMREC_E_UNSUPPORTED
         return False
     _lib.check(rc, "head_fwd_fused")

@@ -170,6 +170,8 @@ class ColumnShardEngine(object):
         self.mask = torch.zeros((N + 31) // 32 + 2, dtype=torch.int32, device=dev)
         self.step_count = 0
         self._side = None
+        self._aux = None
+        self._aux_pending = False
         self._fused = None
         self._tail_plan = None
         self._bufs = {}
@@ -246,6 +248,17 @@ class ColumnShardEngine(object):
             self._side = torch.cuda.Stream() if os.environ.get("ELIMREC_SIDE_STREAM", "0") == "1" else False
         return self._side or None
 
+    def _aux_stream(self):
+        """Second HIP stream for the two launches of a step that do not depend on the forward hops and are latency-bound
+        (one workgroup, or a few): the batch plan and the packing of the head's weights. Issued there, they run UNDER the
+        hops instead of in front of / behind them (ELIMREC_AUX_STREAM=0: everything on one stream). One rank only: with
+        peers the plan feeds the id exchange at once."""
+        if self._aux is None:
+            import os
+            on = self.world == 1 and os.environ.get("ELIMREC_AUX_STREAM", "1") != "0"
+            self._aux = torch.cuda.Stream() if on else False
+        return self._aux or None
+
     def _timed(self, fn, hops):
         ev = self.kernel_events
         if ev is None:
@@ -273,7 +286,19 @@ class ColumnShardEngine(object):
 
         def plan():       # node ids of the slots, unique active rows + slot map, padded tail: one launch
             ops.batch_plan(users, pos, neg, m.num_users, m.num_items, keys, act, seg, ws["slot_seg"][:R], ws["plan_ws"], err, PAD_KEY)
-        m._region("cs_plan", (m._ws_gen, users.data_ptr(), pos.data_ptr(), neg.data_ptr(), R), plan)
+
+        def pack():       # the head's weights in MFMA fragment order (they changed in the last optimizer step)
+            self._head_fused_call(ws, R, phase=1)
+        aux = self._aux_stream()
+        if aux is None:
+            m._region("cs_plan", (m._ws_gen, users.data_ptr(), pos.data_ptr(), neg.data_ptr(), R), plan)
+            return act
+        aux.wait_stream(torch.cuda.current_stream())              # the triplets, and last step's readers of the plan buffers
+        with torch.cuda.stream(aux):
+            m._region("cs_plan", (m._ws_gen, users.data_ptr(), pos.data_ptr(), neg.data_ptr(), R), plan)
+            if self._fused_head_ok():
+                m._region("cs_pack", (m._ws_gen, R), pack)
+        self._aux_pending = True
         return act
 
     @torch.no_grad()
@@ -298,6 +323,9 @@ class ColumnShardEngine(object):
         W, R = acts.shape
         tabs = self._tabs
         self._acts = acts
+        if self._aux_pending:                                     # the plan (and the packed weights) from the second stream
+            torch.cuda.current_stream().wait_stream(self._aux)
+            self._aux_pending = False
         if W > 1:
             torch.sum(acts >= 0, dim=1, dtype=torch.int32, out=self.counts)
             counts = self.counts
@@ -359,18 +387,26 @@ class ColumnShardEngine(object):
         OutAct, YAct = ws["OutAct"][:R], ws["YAct"][:R]
         bw = m._last_block_weights
 
+        packed = self._aux is not None and self._aux is not False      # cs_plan packed the weights on the second stream
+
         def head():
-            wu, wi = m._fusion_weights(W)
-            ok = ops.head_fwd_fused(act, seg, OutAct[:, :d], self.nar_act, fold["c"], [fold[k] for k in m._mods],
-                                    [W[k + "_dense.weight"] for k in m._mods], [W[k + "_dense.bias"] for k in m._mods], wu,
-                                    W["embedding_user_after_GCN.bias"], wi, W["embedding_item_after_GCN.bias"],
-                                    [W["s_dense_%s.weight" % k] for k in m._mods], [W["s_dense_%s.bias" % k] for k in m._mods],
-                                    self._pack, OutAct, YAct, d)
-            if not ok:
-                raise RuntimeError("fused head forward refused a shape _fused_head_ok accepted")
+            self._head_fused_call(ws, R, phase=2 if packed else 0)
             ops.bpr_head_rows(YAct, ws["slot_seg"][:3 * B], d, bw, ws["loss_rows"], ws["grad_rows"])
-        m._region("cs_head_fused", (m._ws_gen, R, B, tuple(bw), self.nar_act.data_ptr()), head)
+        m._region("cs_head_fused", (m._ws_gen, R, B, tuple(bw), self.nar_act.data_ptr(), packed), head)
         m._publish_cache(ws["Y"], dirty=True)
+
+    def _head_fused_call(self, ws, R, phase):
+        m = self.model
+        d, fold, W = m.latent_dim, ws["fold"], ws["live_views"]
+        OutAct, YAct = ws["OutAct"][:R], ws["YAct"][:R]
+        wu, wi = m._fusion_weights(W)
+        ok = ops.head_fwd_fused(ws["active_rows"][:R], ws["seg_info"], OutAct[:, :d], self.nar_act, fold["c"],
+                                [fold[k] for k in m._mods], [W[k + "_dense.weight"] for k in m._mods],
+                                [W[k + "_dense.bias"] for k in m._mods], wu, W["embedding_user_after_GCN.bias"], wi,
+                                W["embedding_item_after_GCN.bias"], [W["s_dense_%s.weight" % k] for k in m._mods],
+                                [W["s_dense_%s.bias" % k] for k in m._mods], self._pack, OutAct, YAct, d, phase=phase)
+        if not ok:
+            raise RuntimeError("fused head forward refused a shape _fused_head_ok accepted")
 
     @torch.no_grad()
     def cs_backward_local(self, scale):

@@ -396,6 +396,12 @@ int elimrec_adam_step(float *d_p, const float *d_g, float *d_m, float *d_v, int6
  * workspace: elimrec_score_workspace2(B, U, I, S, K) bytes. */
 size_t elimrec_score_workspace(int B, int64_t I, int K);              /* without the norm table   */
 size_t elimrec_score_workspace2(int B, int64_t U, int64_t I, int S, int K);   /* what score_topk needs */
+/* Evaluation math of the scorer: 0 = EXACT (default; IEEE division, libm expf/logf: scores within a few ulp of the
+ * reference's), 1 = FAST (v_exp_f32 / v_log_f32 / v_rcp_f32 and reciprocal norms: scores within 2e-6 of EXACT, the
+ * scorer about twice as fast). Also env ELIMREC_EVAL_MATH=fast, read once. */
+void elimrec_score_set_math(int mode);
+int elimrec_score_get_math(void);
+
 /* d_sqnorm (nullable): [N x (1+S)] squared norms of every head block of every row of Y, from
  * elimrec_row_sqnorms; pass it when several user blocks are scored against the same tables (an
  * evaluation pass), otherwise it is recomputed inside every call. */
@@ -577,6 +583,8 @@ int elimrec_adam_step_out(const float *d_p_in, float *d_p_out, const float *d_g,
  * d_S[m] [N x D[m]], d_c [N]: the folded constants; weights row-major as torch.nn.Linear holds them.
  * d_OutAct [R x ld_out] receives blocks 1..n_mod (block 0 = d_out0 is expected there already when they alias),
  * d_YAct [R x ld_y] all 1 + n_mod blocks. d_pack: scratch of elimrec_head_pack_floats floats.
+ * phase: 0 = pack the weights, then the head; 1 = pack only (the weights change once per optimizer step: a caller can
+ * issue this on a second stream under the forward hops); 2 = head only, d_pack holds the packed weights.
  * recdim must be 64 and the row tiles must fit LDS, else ELIMREC_E_UNSUPPORTED (callers keep the batched GEMMs). */
 size_t elimrec_head_pack_floats(int n_mod, const int *D);
 int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg_info, int64_t R, const float *d_out0,
@@ -585,7 +593,7 @@ int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg_info, int6
                            const float *const *d_bm, const float *d_Wf_user, const float *d_bf_user,
                            const float *d_Wf_item, const float *d_bf_item, const float *const *d_Ws,
                            const float *const *d_bs, float *d_pack, size_t pack_floats, float *d_OutAct,
-                           int64_t ld_out, float *d_YAct, int64_t ld_y, int recdim, void *stream);
+                           int64_t ld_out, float *d_YAct, int64_t ld_y, int recdim, int phase, void *stream);
 
 /* ---------------------------------------------------------------- propagation matrix on the device (N3)
  * create_adj_mat (models/EliMRec.py:309-354) from the UNIQUE training interactions d_users / d_items [E] (int64):
