@@ -519,12 +519,26 @@ __global__ __launch_bounds__(512, 4) void score_t16_kernel(ScoreArgs a, int n_ti
         }
     };
     float psum[4] = {0.f, 0.f, 0.f, 0.f};             // PASS 1: this wave's users' running sums of ui, tiles in ascending order
-    if ((int)blockIdx.x < n_chunks) { load_chunk(blockIdx.x); store_chunk(it0); }
+    // PASS 2: the squared block norms of this lane's item, fetched one chunk ahead like the rows (a dependent load at the
+    // head of every epilogue otherwise)
+    constexpr int NQ = (PASS == 2 && NB > 1) ? SUB * (NB - 1) : 1;
+    float sq_cur[NQ], sq_nxt[NQ];
+    auto load_sqn = [&](int chunk, float (&dst)[NQ]) {
+        if (PASS != 2 || NB <= 1) return;
+#pragma unroll
+        for (int sub = 0; sub < SUB; ++sub) {
+            const int64_t item = ((int64_t)chunk * SUB + sub) * TI + li;
+#pragma unroll
+            for (int h = 0; h + 1 < NB; ++h)
+                dst[sub * (NB - 1) + h] = (item < a.I && ptype != 0) ? a.sqn[(a.U + item) * NB + 1 + h] : 1.f;
+        }
+    };
+    if ((int)blockIdx.x < n_chunks) { load_chunk(blockIdx.x); load_sqn(blockIdx.x, sq_cur); store_chunk(it0); }
     __syncthreads();
     int cur = 0;
     for (int chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x, cur ^= 1) {
         const int next = chunk + gridDim.x;
-        if (next < n_chunks) load_chunk(next);
+        if (next < n_chunks) { load_chunk(next); load_sqn(next, sq_nxt); }
 #pragma unroll
         for (int sub = 0; sub < SUB; ++sub) {
             const int tile = chunk * SUB + sub;
@@ -553,7 +567,7 @@ __global__ __launch_bounds__(512, 4) void score_t16_kernel(ScoreArgs a, int n_ti
                 float inorm[NB > 1 ? NB - 1 : 1];
 #pragma unroll
                 for (int h = 0; h + 1 < NB; ++h) {
-                    inorm[h] = (item_ok && ptype != 0) ? fmaxf(sqrtf(a.sqn[(a.U + item) * NB + 1 + h]), eps) : 1.f;
+                    inorm[h] = (item_ok && ptype != 0) ? fmaxf(sqrtf(sq_cur[sub * (NB - 1) + h]), eps) : 1.f;
                     if (FAST) inorm[h] = __builtin_amdgcn_rcpf(inorm[h]);
                 }
 #pragma unroll
@@ -588,6 +602,8 @@ __global__ __launch_bounds__(512, 4) void score_t16_kernel(ScoreArgs a, int n_ti
             }
         }
         if (next < n_chunks) store_chunk(cur ? it0 : it1);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) sq_cur[q] = sq_nxt[q];
         __syncthreads();
     }
     if (PASS == 1 && li == 0) {                       // one partial per (workgroup, user): row_mean_kernel adds them in order

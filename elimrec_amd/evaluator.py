@@ -47,6 +47,11 @@ class UniEvaluator(object):
         self.metrics = [metric_dict[m] for m in metric]
         self.num_thread = num_thread          # kept for interface parity; ranking runs on the GPU
         self.batch_size = batch_size
+        # users scored per launch. The reference's test_batch_size (128) bounds the [batch x I] host matrix it ranks on the
+        # CPU; on the device the per-user results do not depend on the grouping, and a larger block lets eight workgroups
+        # share every item tile through L2 and amortises the launches (0.048 -> 0.035 s per validation pass at the Tiktok shape)
+        import os
+        self.block_users = max(int(batch_size), int(os.environ.get("ELIMREC_EVAL_BLOCK", 1024)))
         self.max_top = top_k if isinstance(top_k, int) else max(top_k)
         self.top_show = np.arange(top_k) + 1 if isinstance(top_k, int) else np.sort(top_k)
         self._dev_cache = {}
@@ -76,7 +81,7 @@ class UniEvaluator(object):
         test_users = list(test_users)
         all_dev = torch.empty(len(test_users), self.metrics_num * self.max_top, dtype=torch.float32, device=model._require_gpu())
         at = 0
-        for k, batch_users in enumerate(DataIterator(test_users, batch_size=self.batch_size, shuffle=False, drop_last=False)):
+        for k, batch_users in enumerate(DataIterator(test_users, batch_size=self.block_users, shuffle=False, drop_last=False)):
             self.evaluate_batch(model, batch_users, cache_key=k if cached else None, out=all_dev[at:at + len(batch_users)])
             at += len(batch_users)
         all_rows = all_dev.cpu().numpy()                                  # [users, metrics*K]
