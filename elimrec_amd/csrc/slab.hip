@@ -745,6 +745,12 @@ struct StreamArgs {
     const int32_t *long_rows, *long_seg_ptr;
     int32_t *tickets;              // [gs x n_long], zero between launches (self-resetting)
     int compact_long;
+    // optional Adam epilogue (the adjoint's last hop, fp32 tables): the hop's output IS the gradient of the column shard, and
+    // the optimizer update of a row piece is applied where it is produced instead of by a later pass that reads it back
+    const float *ad_p_in;          // null: plain hop
+    float *ad_p_out, *ad_m, *ad_v;
+    float ad_step_size, ad_inv_sqrt_bc2, ad_beta1, ad_beta2, ad_eps, ad_wd;
+    int ad_keep_grad;              // also write the gradient to Xout
 };
 
 template <int VPL, bool BF16>
@@ -783,6 +789,23 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, int slab, i
     }
 #pragma unroll
     for (int i = 0; i < VPL; ++i) r[i] *= a.scale;
+    if (VPL == 4 && !OUT_BF16 && a.ad_p_in) {          // arithmetic of adam_multi_kernel, element for element
+        const float4 p4 = ((const float4 *)a.ad_p_in)[idx], m4 = ((const float4 *)a.ad_m)[idx], v4 = ((const float4 *)a.ad_v)[idx];
+        const float pi[4] = {p4.x, p4.y, p4.z, p4.w}, mo[4] = {m4.x, m4.y, m4.z, m4.w}, vo[4] = {v4.x, v4.y, v4.z, v4.w};
+        float po[4], mi[4], vi[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float gi = fmaf(a.ad_wd, pi[i], r[i]);
+            mi[i] = mo[i] + (1.f - a.ad_beta1) * (gi - mo[i]);
+            vi[i] = fmaf(1.f - a.ad_beta2, gi * gi, a.ad_beta2 * vo[i]);
+            const float denom = sqrtf(vi[i]) * a.ad_inv_sqrt_bc2 + a.ad_eps;
+            po[i] = pi[i] - a.ad_step_size * (mi[i] / denom);
+        }
+        ((float4 *)a.ad_m)[idx] = make_float4(mi[0], mi[1], mi[2], mi[3]);
+        ((float4 *)a.ad_v)[idx] = make_float4(vi[0], vi[1], vi[2], vi[3]);
+        ((float4 *)a.ad_p_out)[idx] = make_float4(po[0], po[1], po[2], po[3]);
+        if (!a.ad_keep_grad) return;
+    }
     lane_store<VPL, OUT_BF16>(a.Xout, idx, r);
 }
 
@@ -1318,9 +1341,16 @@ static int slab_stream() {
 }
 extern "C" void elimrec_slab_set_stream(int mode) { g_slab_stream = mode; }
 
+struct AdamEpilogue {
+    const float *p_in; float *p_out, *m, *v;
+    float step_size, inv_sqrt_bc2, beta1, beta2, eps, wd;
+    int keep_grad;
+};
+
 static int launch_tier(const elimrec_sell *A, int family, int ns, int wl, int wl_shift, int gs, int spg, int lpr, const void *Xin,
                        bool in_bf16, const uint32_t *src_mask, void *Xout, bool out_bf16, const float *add,
-                       const uint32_t *add_mask, float scale, float *partials, int seg_only, hipStream_t s) {
+                       const uint32_t *add_mask, float scale, float *partials, int seg_only, hipStream_t s,
+                       const AdamEpilogue *adam = nullptr) {
     if (A->tile_groups != 64 / lpr) {
         set_error("slab_hop: the plan's wave tiles were laid out for %d lane groups per wave, this table geometry has %d",
                   A->tile_groups, 64 / lpr);
@@ -1339,6 +1369,11 @@ static int launch_tier(const elimrec_sell *A, int family, int ns, int wl, int wl
     const int vpl = family ? 8 : 4;
     a.tickets = (int32_t *)((char *)partials + slab_partial_floats_bytes(A, ns, wl * vpl));
     a.compact_long = seg_only ? 1 : 0;
+    if (adam) {
+        a.ad_p_in = adam->p_in; a.ad_p_out = adam->p_out; a.ad_m = adam->m; a.ad_v = adam->v;
+        a.ad_step_size = adam->step_size; a.ad_inv_sqrt_bc2 = adam->inv_sqrt_bc2; a.ad_beta1 = adam->beta1; a.ad_beta2 = adam->beta2;
+        a.ad_eps = adam->eps; a.ad_wd = adam->wd; a.ad_keep_grad = adam->keep_grad;
+    }
     t.tile_off = A->d_tile_off; t.tile_len = A->d_tile_len; t.tile_dst = A->d_tile_dst; t.tile_long = A->d_tile_long;
     t.tcol = A->d_tile_col; t.tval = A->d_tile_val; t.long_index = A->d_long_index;
     t.n_w4 = A->n_w4;
@@ -1557,6 +1592,31 @@ extern "C" int elimrec_slab_hop(const elimrec_sell *A, int ns, int w, int gs, co
         ELIMREC_LAUNCH_CHECK("slab_hop(fixup)");
     }
     return 0;
+}
+
+extern "C" int elimrec_slab_hop_adam(const elimrec_sell *A, int ns, int w, int gs, const float *d_Xin, float *d_grad_out,
+                                     const float *d_add, const uint32_t *d_add_mask, float scale, float *d_partials,
+                                     size_t partials_bytes, const float *d_p_in, float *d_p_out, float *d_m, float *d_v, float lr,
+                                     float beta1, float beta2, float eps, float weight_decay, int64_t step, void *stream) {
+    ELIMREC_REQUIRE(A && d_Xin && d_p_in && d_p_out && d_m && d_v, "slab_hop_adam: null pointer");
+    ELIMREC_REQUIRE(A->tiered, "slab_hop_adam: needs a tiered (wave-tile) plan");
+    ELIMREC_REQUIRE(step >= 1, "slab_hop_adam: 1-based step");
+    ELIMREC_REQUIRE((const void *)d_Xin != (const void *)d_p_out && (const void *)d_Xin != (const void *)d_m &&
+                        (const void *)d_Xin != (const void *)d_v, "slab_hop_adam: the gathered table must not be written");
+    int w4_shift, spg, lpr, rc;
+    if ((rc = slab_geometry("slab_hop_adam", ns, w, gs, w4_shift, spg, lpr))) return rc;
+    if (!d_partials || partials_bytes < elimrec_slab_partials_bytes(A, ns, w)) {
+        set_error("slab_hop_adam: partial-row scratch too small");
+        return ELIMREC_E_WORKSPACE;
+    }
+    AdamEpilogue ad;
+    ad.p_in = d_p_in; ad.p_out = d_p_out; ad.m = d_m; ad.v = d_v;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    ad.step_size = (float)((double)lr / bc1);
+    ad.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    ad.beta1 = beta1; ad.beta2 = beta2; ad.eps = eps; ad.wd = weight_decay; ad.keep_grad = d_grad_out ? 1 : 0;
+    return launch_tier(A, 0, ns, w / 4, w4_shift, gs, spg, lpr, d_Xin, false, nullptr, d_grad_out, false, d_add, d_add_mask, scale,
+                       d_partials, 0, (hipStream_t)stream, &ad);
 }
 
 extern "C" int elimrec_slab_rows(const elimrec_sell *A, int ns, int w, int L, int64_t U, const float *const *layers,

@@ -172,6 +172,8 @@ class ColumnShardEngine(object):
         self._side = None
         self._aux = None
         self._aux_pending = False
+        self._adam_in_hop = False
+        self.keep_grad = False
         self._fused = None
         self._tail_plan = None
         self._bufs = {}
@@ -258,6 +260,14 @@ class ColumnShardEngine(object):
             on = self.world == 1 and os.environ.get("ELIMREC_AUX_STREAM", "1") != "0"
             self._aux = torch.cuda.Stream() if on else False
         return self._aux or None
+
+    def _fuse_adam(self):
+        """Adam of the embeddings as the epilogue of the adjoint's last hop: one rank owning every column, fp32 tables, the
+        tiered plan, at least two layers (ELIMREC_FUSE_ADAM=0 keeps the separate optimizer launch; `keep_grad` = True also
+        stores the gradient table, for tests that read it)."""
+        import os
+        return (self.world == 1 and not self.bf16 and self.planT.tiered and self.model.n_layers >= 2
+                and os.environ.get("ELIMREC_FUSE_ADAM", "1") != "0")
 
     def _timed(self, fn, hops):
         ev = self.kernel_events
@@ -432,18 +442,32 @@ class ColumnShardEngine(object):
         W, R = acts.shape
         inv = 1.0 / (L + 1)
 
+        fuse = self._fuse_adam()
+        last = 1 if fuse else 0                                    # the hops the recorded region covers: L-1 .. last
+
         def hops():
             if W == 1:
                 slab.merge_rows(recv2.view(R, m.C), acts.reshape(-1), 1, U, I, self.srcA, self.srcB, self.mask, M=m.M)
             else:
                 slab.merge_rows(recv2.view(W * R, 2 * self.dl), acts.reshape(-1), W, U, I, self.srcA, self.srcB, self.mask)
             t, tmask = (self.srcB if (L & 1) else self.srcA), self.mask          # T^L = S^L (row-sparse)
-            for k in range(L - 1, -1, -1):
+            for k in range(L - 1, last - 1, -1):
                 dst = self.grad if k == 0 else self.tmp[k & 1]
                 slab.hop(self.planT, t, dst, gs=self.gs, src_mask=tmask, add=self.srcB if (k & 1) else self.srcA,
                          add_mask=self.mask, scale=inv if k == 0 else 1.0)
                 t, tmask = dst, None
-        self._timed(lambda: m._region("cs_bwd_hops", (m._ws_gen, recv2.data_ptr(), acts.data_ptr(), R, W), hops), L)
+        self._timed(lambda: m._region("cs_bwd_hops", (m._ws_gen, recv2.data_ptr(), acts.data_ptr(), R, W, fuse), hops), L - last)
+        self._adam_in_hop = fuse
+        if fuse:
+            # the last hop's output is the gradient: the embeddings' Adam step is its epilogue (no gradient table written and
+            # read back; cs_update then only has the projection weights left). Issued outside the recorded region: its
+            # bias-correction constants change every step.
+            g = self.opt.param_groups[0]
+            nxt = 1 - self.cur
+            self._timed(lambda: slab.hop_adam(self.planT, self.tmp[1], self.grad if self.keep_grad else None, self.gs, self.srcA,
+                                              self.mask, inv, self.master[self.cur].data, self.master[nxt].data, self.m1, self.m2,
+                                              g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
+                                              self.step_count + 1), 1)
         if self._side and self.world == 1:
             torch.cuda.current_stream().wait_stream(self._side)      # the weight gradients, computed beside the hops
 
@@ -456,15 +480,18 @@ class ColumnShardEngine(object):
         g = self.opt.param_groups[0]
         self.step_count += 1
         nxt = 1 - self.cur
-        jobs = [_lib.AdamJob(self.master[self.cur].data.data_ptr(), self.master[nxt].data.data_ptr(),
-                             self.mirror[nxt].data.data_ptr() if self.bf16 else None, self.grad.data.data_ptr(),
-                             self.m1.data_ptr(), self.m2.data_ptr(), None, self.grad.data.numel(), self.step_count)]
+        jobs = []
+        if not getattr(self, "_adam_in_hop", False):              # else the last adjoint hop has already applied it
+            jobs.append(_lib.AdamJob(self.master[self.cur].data.data_ptr(), self.master[nxt].data.data_ptr(),
+                                     self.mirror[nxt].data.data_ptr() if self.bf16 else None, self.grad.data.data_ptr(),
+                                     self.m1.data_ptr(), self.m2.data_ptr(), None, self.grad.data.numel(), self.step_count))
         jobs += self._tail_jobs()
         if len(jobs) > 8:
             raise RuntimeError("more than 8 optimizer spans")
-        arr = (_lib.AdamJob * len(jobs))(*jobs)
-        _lib.check(_lib.load().elimrec_adam_multi(arr, len(jobs), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
-                                                  g["weight_decay"], ops._stream()), "adam_multi")
+        if jobs:
+            arr = (_lib.AdamJob * len(jobs))(*jobs)
+            _lib.check(_lib.load().elimrec_adam_multi(arr, len(jobs), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+                                                      g["weight_decay"], ops._stream()), "adam_multi")
         self.cur = nxt
 
     def _tail_jobs(self):

@@ -322,6 +322,18 @@ def hop(plan, xin, xout, gs=None, src_mask=None, add=None, add_mask=None, scale=
                                     part.numel() * 4, 1 if seg_only else 0, _stream()), "slab_hop")
 
 
+def hop_adam(plan, xin, grad_out, gs, add, add_mask, scale, p_in, p_out, m, v, lr, beta1, beta2, eps, weight_decay, step):
+    """elimrec_slab_hop_adam: the hop whose output is the gradient of the fp32 slab table p_in, consumed in place by an
+    Adam step (p_out / m / v flat fp32 of the table's geometry). grad_out: a table to also receive the gradient, or None."""
+    ns, w = xin.ns, xin.w
+    part = plan.partials(ns, w)
+    _lib.check(_lib.load().elimrec_slab_hop_adam(
+        plan.ref(), ns, w, int(gs), _dev(xin.data, "xin"), _dev(None if grad_out is None else grad_out.data, "grad"),
+        _dev(None if add is None else add.data, "add"), _dev(add_mask, "add_mask", torch.int32), float(scale), _dev(part, "partials"),
+        part.numel() * 4, _dev(p_in, "p_in"), _dev(p_out, "p_out"), _dev(m, "m"), _dev(v, "v"), float(lr), float(beta1), float(beta2),
+        float(eps), float(weight_decay), int(step), _stream()), "slab_hop_adam")
+
+
 def rows16(plan, ns, w, L, U, x0, layers16, long_tab, row_ids, counts, R, n_lists, out0, narrow, narrow_by_node):
     """elimrec_slab_rows16: x0 fp32 master (flat), layers16 = [X^1 .. X^L] flat bf16 tensors (the last may be None)."""
     ptrs = (ctypes.c_void_p * L)(*[None if t is None else _dev(t, "layer", torch.bfloat16) for t in layers16])

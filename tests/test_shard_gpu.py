@@ -309,6 +309,7 @@ def _shape_step_vs_oracle(U, I, E, dims, recdim, B, world=1):
         engines.append(eng)
     # forward + backward of one rank-0 step without the update: gradients against the oracle
     eng = engines[0]
+    eng.keep_grad = True          # the fused last-hop + Adam epilogue also stores the gradient table this test reads
     acts = eng.cs_plan(u.to(DEV), p.to(DEV), n.to(DEV)).view(1, -1)
     assert world == 1
     eng.cs_forward(acts)
