@@ -225,12 +225,16 @@ def main():
                            "frac_of_hbm_peak": sb["total"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                            "reference_algorithm_bytes_per_step": reference_step_bytes(model, B)},
             "roofline": {"bound": "hbm",
-                         "kernel": "sell_hop_kernel (+ sell_fixup_kernel for the split rows): one full LightGCN hop X' = A X of "
-                                   "this rank's [N x %d] column slice, slab-major %dx%d floats in %d groups" % (eng.dl, eng.ns, eng.w, eng.gs),
+                         "kernel": ("sell_tier_kernel (one launch over wave tiles)" if eng.plan.tiered else
+                                    "sell_hop_kernel + sell_fixup_kernel for the split rows") +
+                                   ": one full LightGCN hop X' = A X of this rank's [N x %d] column slice, slab-major %dx%d floats "
+                                   "in %d groups" % (eng.dl, eng.ns, eng.w, eng.gs),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": pmc_traffic(),
+                         "traffic": pmc_traffic() if world == 1 else None,
+                         "limiter": "per-CU gather path, not HBM: TA busy 47 %, L1 stalled on pending misses 45 % of the launch, "
+                                    "L2 hit rate 0.60 (profiles/r02_pmc_traffic.json; DESIGN.md section 4)",
                          "algorithmic_bytes_per_launch": sb["hop_minimal"],
-                         "algorithmic_bytes_formula": "read X + write X' + index stream once: 2*N*dl*4 + (8 B per SELL entry + 8 B per work item)",
+                         "algorithmic_bytes_formula": "read X + write X' + index stream once: 2*N*dl*4 + plan.index_bytes() (8 B per index entry + the tile / item records)",
                          "bytes_with_index_per_group": sb["hop"],
                          "avg_launch_us": hop_us, "launches_timed": n_launch},
         }

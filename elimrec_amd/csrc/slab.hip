@@ -778,7 +778,7 @@ __device__ __forceinline__ void lane_store(void *base, int64_t idx, const float 
     }
 }
 
-template <int VPL, bool OUT_BF16>
+template <int VPL, bool OUT_BF16, bool ADAM = false>
 __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, int slab, int64_t row, int c, float (&r)[VPL]) {
     const int64_t idx = ((int64_t)slab * a.n_rows + row) * a.wl + c;
     if (a.Add && (!a.add_mask || bit_of(a.add_mask, (int)row))) {
@@ -789,7 +789,7 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, int slab, i
     }
 #pragma unroll
     for (int i = 0; i < VPL; ++i) r[i] *= a.scale;
-    if (VPL == 4 && !OUT_BF16 && a.ad_p_in) {          // arithmetic of adam_multi_kernel, element for element
+    if (ADAM && VPL == 4 && !OUT_BF16) {               // arithmetic of adam_multi_kernel, element for element
         const float4 p4 = ((const float4 *)a.ad_p_in)[idx], m4 = ((const float4 *)a.ad_m)[idx], v4 = ((const float4 *)a.ad_v)[idx];
         const float pi[4] = {p4.x, p4.y, p4.z, p4.w}, mo[4] = {m4.x, m4.y, m4.z, m4.w}, vo[4] = {v4.x, v4.y, v4.z, v4.w};
         float po[4], mi[4], vi[4];
@@ -810,7 +810,7 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, int slab, i
 }
 
 // the whole wave on one split row (li wave-uniform): same order as sell_fixup_kernel / sell_fixup16_kernel
-template <int LPR, int VPL, bool OUT_BF16>
+template <int LPR, int VPL, bool OUT_BF16, bool ADAM = false>
 __device__ __forceinline__ void stream_combine(const StreamArgs &a, int grp, int li) {
     constexpr int NQ = 64 / LPR, UNR = VPL == 4 ? 8 : 4;
     const int lane = threadIdx.x & 63;
@@ -851,7 +851,7 @@ __device__ __forceinline__ void stream_combine(const StreamArgs &a, int grp, int
     }
     if (q != 0) return;
     if (a.compact_long) lane_store<VPL, false>(a.Xout, ((int64_t)slab * a.n_long + li) * a.wl + c, tot);
-    else stream_epilogue<VPL, OUT_BF16>(a, slab, a.long_rows[li], c, tot);
+    else stream_epilogue<VPL, OUT_BF16, ADAM>(a, slab, a.long_rows[li], c, tot);
 }
 
 // sum_j val[j] * Xin[col[j]] of one work item per lane group, neighbour order, fmaf; the (col, val) of step j + U are in
@@ -1160,7 +1160,7 @@ __device__ __forceinline__ void tier_wave_sum(const float (&acc)[VPL], int cl, i
     }
 }
 
-template <int LPR, int VPL, bool IN_BF16, bool OUT_BF16, bool MASKED>
+template <int LPR, int VPL, bool IN_BF16, bool OUT_BF16, bool MASKED, bool ADAM = false>
 __global__ __launch_bounds__(256) void sell_tier_kernel(TierArgs t) {
     constexpr int G = 64 / LPR;
     const StreamArgs &a = t.s;
@@ -1197,7 +1197,7 @@ __global__ __launch_bounds__(256) void sell_tier_kernel(TierArgs t) {
             for (int i = 0; i < VPL; ++i) tot[i] = ((s_part[cl * VPL + i] + s_part[(LPR + cl) * VPL + i]) + s_part[(2 * LPR + cl) * VPL + i]) +
                                                    s_part[(3 * LPR + cl) * VPL + i];
             if (a.compact_long) lane_store<VPL, false>(a.Xout, ((int64_t)slab * a.n_long + t.long_index[dst]) * a.wl + c, tot);
-            else stream_epilogue<VPL, OUT_BF16>(a, slab, dst, c, tot);
+            else stream_epilogue<VPL, OUT_BF16, ADAM>(a, slab, dst, c, tot);
         }
         return;
     }
@@ -1210,13 +1210,13 @@ __global__ __launch_bounds__(256) void sell_tier_kernel(TierArgs t) {
         tier_wave_sum<LPR, VPL>(acc, cl, a.n_long, tot);
         if (sub == 0) {
             if (a.compact_long) lane_store<VPL, false>(a.Xout, ((int64_t)slab * a.n_long + t.long_index[row]) * a.wl + c, tot);
-            else stream_epilogue<VPL, OUT_BF16>(a, slab, row, c, tot);
+            else stream_epilogue<VPL, OUT_BF16, ADAM>(a, slab, row, c, tot);
         }
         return;
     }
     if (ti >= t.tfin_base) {
         // ---- unsplit rows, a lane group each
-        if (dst >= 0) stream_epilogue<VPL, OUT_BF16>(a, slab, dst, c, acc);
+        if (dst >= 0) stream_epilogue<VPL, OUT_BF16, ADAM>(a, slab, dst, c, acc);
         return;
     }
     // ---- segments of the longest rows: partial rows, tickets, last arriver combines
@@ -1247,7 +1247,7 @@ __global__ __launch_bounds__(256) void sell_tier_kernel(TierArgs t) {
     for (int g = 0; g < G; ++g) {
         if (!__shfl(last ? 1 : 0, g * LPR, 64)) continue;
         const int g_li = __shfl(li, g * LPR, 64);
-        stream_combine<LPR, VPL, OUT_BF16>(a, grp, g_li);
+        stream_combine<LPR, VPL, OUT_BF16, ADAM>(a, grp, g_li);
         if (lane == 0) __hip_atomic_store(&a.tickets[(int64_t)grp * a.n_long + g_li], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -1395,7 +1395,8 @@ static int launch_tier(const elimrec_sell *A, int family, int ns, int wl, int wl
 #define ELIMREC_TIER(LPR)                                                                                                     \
     do {                                                                                                                      \
         if (!family) {                                                                                                        \
-            if (masked) hipLaunchKernelGGL((sell_tier_kernel<LPR, 4, false, false, true>), grid, dim3(256), 0, s, t);         \
+            if (adam) hipLaunchKernelGGL((sell_tier_kernel<LPR, 4, false, false, false, true>), grid, dim3(256), 0, s, t);    \
+            else if (masked) hipLaunchKernelGGL((sell_tier_kernel<LPR, 4, false, false, true>), grid, dim3(256), 0, s, t);    \
             else hipLaunchKernelGGL((sell_tier_kernel<LPR, 4, false, false, false>), grid, dim3(256), 0, s, t);               \
         } else if (in_bf16) {                                                                                                 \
             if (out_bf16) hipLaunchKernelGGL((sell_tier_kernel<LPR, 8, true, true, false>), grid, dim3(256), 0, s, t);        \

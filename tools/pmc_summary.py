@@ -1,8 +1,8 @@
 """Summarise rocprofv3 --pmc passes of `bench.py --steps K --warmup W --no-cpu-baseline` into the JSON bench.py reads
 (profiles/<round>_pmc_traffic.json). Usage:
     python tools/pmc_summary.py --fetch DIR --write DIR --mfma DIR --steps 10 --out profiles/r01_g_pmc_traffic.json
-FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (calibrated on
-adam_kernel: reads p,g,m,v = 4 x 29.1 MB, writes p,m,v). MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES /
+FETCH_SIZE / WRITE_SIZE are KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (its calibration:
+wide coalesced streaming reads; the hop's 128-B row-piece gathers are the same 16 B/lane loads). MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES /
 (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)."""
 import argparse, collections, csv, glob, json, os
 
@@ -13,7 +13,7 @@ def read(dirname):
     with open(path) as f:
         for r in csv.DictReader(f):
             name = r["Kernel_Name"].split("(")[0]
-            if "half_hop_kernel" in name:       # full, row-restricted and masked hops share kernels: split by grid
+            if "half_hop_kernel" in name or "sell_tier_kernel" in name or "sell_hop" in name:   # full / long-rows-only hops share kernels: split by grid
                 name += " grid=%s" % r["Grid_Size"]
             out[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     return out
@@ -39,8 +39,9 @@ def main():
         if m.get("SQ_VALU_MFMA_BUSY_CYCLES") and sum(m["GRBM_GUI_ACTIVE"]) > 0:
             row["mfma_util"] = round(sum(m["SQ_VALU_MFMA_BUSY_CYCLES"]) / (sum(m["GRBM_GUI_ACTIVE"]) / 8 * 1024), 4)
         kernels.append(row)
-    # the full d-column hop = the half_hop_kernel<16, 8, false> group with the largest grid
-    hop = sorted([k for k in kernels if k["kernel"].startswith("void elimrec::half_hop_kernel<16, 8, false>")],
+    # the full hop of the training step = the unmasked, Adam-less sell_tier_kernel group with the largest grid
+    hop = sorted([k for k in kernels if k["kernel"].startswith("void elimrec::sell_tier_kernel<") and
+                  k["kernel"].split(">")[0].replace(" ", "").endswith("false,false,false")],
                  key=lambda k: -int(k["kernel"].split("grid=")[1]))
     doc = {"note": __doc__.split("Usage")[0].strip(), "steps_profiled": a.steps, "kernels": kernels}
     if hop:
