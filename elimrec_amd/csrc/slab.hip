@@ -1033,16 +1033,17 @@ struct TierArgs {
 __global__ __launch_bounds__(256) void tile_ballot_kernel(const int32_t *__restrict__ tile_off, const int32_t *__restrict__ tcol,
                                                           const uint32_t *__restrict__ mask, int G, int n_tiles, int kmax,
                                                           uint64_t *__restrict__ ballots) {
+    // a wave per (tile, index line): blockIdx.y = line, so every wave is one short independent chain
     const int lane = threadIdx.x & 63;
     const int ti = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
+    const int k = (int)blockIdx.y;
     if (ti >= n_tiles) return;
     const int off = tile_off[ti];
     const int nk = (tile_off[ti + 1] - off + 63) >> 6;
-    for (int k = 0; k < nk; ++k) {
-        const int cidx = tcol[off + (k << 6) + lane];
-        const uint64_t b = __ballot(bit_of(mask, cidx));
-        if (lane == 0) ballots[(int64_t)ti * kmax + k] = b;
-    }
+    if (k >= nk) return;
+    const int cidx = tcol[off + (k << 6) + lane];
+    const uint64_t b = __ballot(bit_of(mask, cidx));
+    if (lane == 0) ballots[(int64_t)ti * kmax + k] = b;
 }
 
 // one batch of UB neighbours per lane group: predicate, gather, fused multiply-adds in neighbour order
@@ -1389,7 +1390,7 @@ static int launch_tier(const elimrec_sell *A, int family, int ns, int wl, int wl
         t.kmax = A->tile_kmax;
         uint64_t *ballots = (uint64_t *)((char *)a.tickets + slab_ticket_bytes(A));
         t.ballots = ballots;
-        hipLaunchKernelGGL(tile_ballot_kernel, dim3((unsigned)per_group), dim3(256), 0, s, t.tile_off, t.tcol, src_mask, 64 / lpr,
+        hipLaunchKernelGGL(tile_ballot_kernel, dim3((unsigned)per_group, (unsigned)t.kmax), dim3(256), 0, s, t.tile_off, t.tcol, src_mask, 64 / lpr,
                            t.n_tiles_run, t.kmax, ballots);
     }
 #define ELIMREC_TIER(LPR)                                                                                                     \

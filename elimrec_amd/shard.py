@@ -145,12 +145,14 @@ class ColumnShardEngine(object):
         self.gs = slab.choose_groups(self.ns)
         adj = m._scipy_adj()
         ipw = 64 // max(1, (self.ns // self.gs) * (self.w // (8 if self.bf16 else 4)))     # lane groups per wave of this geometry
-        # launch form of a hop (tools/bench_slab_modes.py, Tiktok shape, us per hop): whole fp32 table -- tiered one-launch
-        # form with 64-neighbour work items 33 vs 37 for hop + fix-up kernels; column shards and bf16 tables -- hop +
-        # fix-up with 32-neighbour items (21 vs 25; 26 vs 31)
+        # launch form of a hop (tools/bench_slab_modes.py, Tiktok shape, us per hop): fp32 tables -- the one-launch form over
+        # wave tiles (whole table, 64-neighbour tiles: 31 against 36 for hop + fix-up kernels; an 8-column shard, 32-neighbour
+        # tiles: 20.3 against 21.6; 16 columns: 19.5 against 21.7), which also lets the last adjoint hop carry the Adam
+        # step; bf16 tables -- hop + fix-up kernels with 32-neighbour items (25 against 30)
         import os
-        tiered = world == 1 and not self.bf16 and os.environ.get("ELIMREC_SLAB_TIERED", "1") != "0"
-        kw = dict(side_split=m.num_users, ipw=ipw, tiered=tiered, threshold=64 if tiered else slab.LONG_ROW_THRESHOLD)
+        tiered = not self.bf16 and os.environ.get("ELIMREC_SLAB_TIERED", "1") != "0"
+        kw = dict(side_split=m.num_users, ipw=ipw, tiered=tiered,
+                  threshold=(64 if world == 1 else 32) if tiered else slab.LONG_ROW_THRESHOLD)
         self.plan = slab.SellPlan(adj, dev, **kw)
         self.planT = self.plan if m._adj_symmetric else slab.SellPlan(adj.T.tocsr(), dev, **kw)
         tab = lambda: slab.SlabTable(N, self.ns, self.w, dev)
@@ -262,11 +264,11 @@ class ColumnShardEngine(object):
         return self._aux or None
 
     def _fuse_adam(self):
-        """Adam of the embeddings as the epilogue of the adjoint's last hop: one rank owning every column, fp32 tables, the
+        """Adam of the embeddings (this rank's column shard) as the epilogue of the adjoint's last hop: fp32 tables, the
         tiered plan, at least two layers (ELIMREC_FUSE_ADAM=0 keeps the separate optimizer launch; `keep_grad` = True also
         stores the gradient table, for tests that read it)."""
         import os
-        return (self.world == 1 and not self.bf16 and self.planT.tiered and self.model.n_layers >= 2
+        return (not self.bf16 and self.planT.tiered and self.model.n_layers >= 2
                 and os.environ.get("ELIMREC_FUSE_ADAM", "1") != "0")
 
     def _timed(self, fn, hops):
