@@ -71,11 +71,18 @@ def create_adj_mat(train_users, train_items, num_users, num_items, adj_type):
 class _BprLossFn(torch.autograd.Function):
     """Glue between torch's autograd/optimizer API (main.py:98-101) and the HIP path: forward enqueues the forward
     kernels and returns the 0-dim loss; backward enqueues the backward kernels and leaves every parameter's gradient in
-    `.grad` (nothing for parameters the loss does not reach, exactly the set the reference leaves without .grad).
+    `.grad` (nothing for parameters the loss does not reach: the set the reference leaves without .grad -- with ONE
+    stated exception, `word_embedding.weight` on the tiktok data set: the reference builds t_feat once from it and keeps
+    that graph alive with retain_graph=True (main.py:99), so the dead parameter keeps receiving a gradient and an Adam /
+    weight-decay update every step; here t_feat is a constant and word_embedding a checkpoint key that stays at its
+    initial value -- losses and scores are unaffected, the saved tensor differs from a reference run's).
     The gradients live in one flat buffer laid out like the parameters; backward assigns its views to `.grad` itself
     instead of returning them to autograd, whose AccumulateGrad would copy each of the 18 tensors (the views are not
     "stealable") -- 18 clones per step, and an optimizer that no longer sees adjacent gradients. A `.grad` that already
-    holds something else is accumulated into, as autograd would."""
+    holds something else is accumulated into, as autograd would; a `.grad` that already IS the flat view is overwritten
+    (two backward passes without zero_grad do not accumulate -- the reference's loop zeroes every step, main.py:98).
+    The forward's state lives in the model's workspace, not in the autograd context: backward must follow ITS forward.
+    Each forward takes a generation number; backward raises if another forward (or compute()) ran in between."""
 
     @staticmethod
     def forward(ctx, model, users, pos, neg, *params):
@@ -83,11 +90,15 @@ class _BprLossFn(torch.autograd.Function):
         ctx.params = params
         ctx.names = model._param_names
         loss = model._forward_hip(users, pos, neg, need_grad=True)
+        ctx.gen = model._fwd_gen
         return loss
 
     @staticmethod
     def backward(ctx, grad_out):
         model = ctx.model
+        if ctx.gen != model._fwd_gen:
+            raise RuntimeError("backward of a stale loss: another forward ran on this model since (the forward's state "
+                               "lives in the model's workspace; call backward before the next bpr_loss / compute)")
         # upstream gradient into a fixed buffer: the backward regions are recorded against stable addresses
         gscale = model._ws.setdefault("gscale", torch.ones(1, dtype=torch.float32, device=grad_out.device))
         gscale.copy_(grad_out.reshape(1))
@@ -115,6 +126,8 @@ class _TablesFn(torch.autograd.Function):
         ctx.model, ctx.params, ctx.names = model, params, model._param_names
         ws = model._workspace(model._ws_key[1] if model._ws_key else 1)
         model._slab_fwd = False
+        model._fwd_gen = getattr(model, "_fwd_gen", 0) + 1
+        ctx.gen = model._fwd_gen
         model._compute_tables(ws)
         U, d = model.num_users, model.latent_dim
         return ws["Y"][:U, :d].clone(), ws["Y"][U:, :d].clone()
@@ -122,6 +135,8 @@ class _TablesFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_users, g_items):
         model = ctx.model
+        if ctx.gen != model._fwd_gen:
+            raise RuntimeError("backward of stale tables: another forward ran on this model since compute()")
         grads = model._backward_tables(g_users, g_items)
         for name, p in zip(ctx.names, ctx.params):
             g = grads.get(name)
@@ -745,6 +760,7 @@ class EliMRec(BasicModel):
         it depends on the indices only, the forward evaluates the head at the active rows, and the backward
         reduces the gathered gradient rows with it."""
         B = int(users.numel())
+        self._fwd_gen = getattr(self, "_fwd_gen", 0) + 1
         users, pos, neg = self._index_tensors(users, pos, neg)
         keys = self.batch_keys(users, pos, neg)
         ws = self._ws
