@@ -136,6 +136,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("ELIMREC_SAME_GPU") == "1":          # tools/two_ranks_one_gpu.py: every rank on device 0 (smoke test)
+        local_rank = 0
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks (WORLD_SIZE=%d)"
                          % (args.gpus, args.gpus, world))
