@@ -61,6 +61,8 @@ def step_bytes(model, eng, B, world):
     bwd = (G + eng.gs * idx) + (L - 1) * hop         # first adjoint hop: row-sparse source
     P_tail = sum(p.numel() for n_, p in model.named_parameters() if not n_.startswith(("embedding_user.", "embedding_item.")))
     adam = 28 * (N * dl + P_tail)
+    if eng._fuse_adam():                              # Adam is the last adjoint hop's epilogue: the gradient table is neither
+        adam -= 2 * G                                 # written by the hop nor read back by the optimizer
     D = sum(getattr(model, m + "_feat").shape[1] for m in model._mods)
     rows = R * s * ((L + 1) * dl + 2 * D + 6 * model.C + 6 * model.Cy + 4 * d)     # layer rows, folded constants, Out/Y rows fwd+bwd, sources
     return dict(total=fwd + bwd + adam + rows, hop=hop, hop_minimal=2 * G + idx)
