@@ -1350,8 +1350,10 @@ struct AdamEpilogue {
 
 static int launch_tier(const elimrec_sell *A, int family, int ns, int wl, int wl_shift, int gs, int spg, int lpr, const void *Xin,
                        bool in_bf16, const uint32_t *src_mask, void *Xout, bool out_bf16, const float *add,
-                       const uint32_t *add_mask, float scale, float *partials, int seg_only, hipStream_t s,
+                       const uint32_t *add_mask, float scale, float *partials, int flags, hipStream_t s,
                        const AdamEpilogue *adam = nullptr) {
+    const int seg_only = flags & 1;
+    const bool bits_ready = (flags & 2) != 0;          // elimrec_slab_source_bits has run for this source bitmap
     if (A->tile_groups != 64 / lpr) {
         set_error("slab_hop: the plan's wave tiles were laid out for %d lane groups per wave, this table geometry has %d",
                   A->tile_groups, 64 / lpr);
@@ -1390,6 +1392,7 @@ static int launch_tier(const elimrec_sell *A, int family, int ns, int wl, int wl
         t.kmax = A->tile_kmax;
         uint64_t *ballots = (uint64_t *)((char *)a.tickets + slab_ticket_bytes(A));
         t.ballots = ballots;
+        if (!bits_ready)
         hipLaunchKernelGGL(tile_ballot_kernel, dim3((unsigned)per_group, (unsigned)t.kmax), dim3(256), 0, s, t.tile_off, t.tcol, src_mask, 64 / lpr,
                            t.n_tiles_run, t.kmax, ballots);
     }
@@ -1529,7 +1532,8 @@ static int slab_simple_geometry(const char *who, int64_t n, int ns, int w, int &
 extern "C" int elimrec_slab_hop(const elimrec_sell *A, int ns, int w, int gs, const float *d_Xin,
                                 const uint32_t *d_src_mask, float *d_Xout, const float *d_add,
                                 const uint32_t *d_add_mask, float scale, float *d_partials, size_t partials_bytes,
-                                int seg_only, void *stream) {
+                                int flags, void *stream) {
+    const int seg_only = flags & 1;
     ELIMREC_REQUIRE(A && d_Xin && d_Xout, "slab_hop: null pointer");
     ELIMREC_REQUIRE(d_Xin != d_Xout, "slab_hop: Xout must not alias Xin");
     ELIMREC_REQUIRE(A->n_items % 64 == 0 && A->n_seg_items % 64 == 0 && A->n_seg_items <= A->n_items, "slab_hop: bad plan");
@@ -1551,7 +1555,7 @@ extern "C" int elimrec_slab_hop(const elimrec_sell *A, int ns, int w, int gs, co
     hipStream_t s = (hipStream_t)stream;
     if (A->tiered)
         return launch_tier(A, 0, ns, w / 4, w4_shift, gs, spg, lpr, d_Xin, false, d_src_mask, d_Xout, false, d_add, d_add_mask, scale,
-                           d_partials, seg_only, s);
+                           d_partials, flags, s);
     if (slab_stream() && A->d_item_long)
         return launch_stream(A, 0, ns, w / 4, w4_shift, gs, spg, lpr, d_Xin, false, d_src_mask, d_Xout, false, d_add, d_add_mask, scale,
                              d_partials, seg_only, s);
@@ -1593,6 +1597,23 @@ extern "C" int elimrec_slab_hop(const elimrec_sell *A, int ns, int w, int gs, co
         }
         ELIMREC_LAUNCH_CHECK("slab_hop(fixup)");
     }
+    return 0;
+}
+
+extern "C" int elimrec_slab_source_bits(const elimrec_sell *A, int ns, int w, int gs, const uint32_t *d_src_mask,
+                                        float *d_partials, size_t partials_bytes, void *stream) {
+    ELIMREC_REQUIRE(A && d_src_mask && d_partials, "slab_source_bits: null pointer");
+    ELIMREC_REQUIRE(A->tiered && A->tile_kmax > 0, "slab_source_bits: needs a tiered (wave-tile) plan");
+    int w4_shift, spg, lpr, rc;
+    if ((rc = slab_geometry("slab_source_bits", ns, w, gs, w4_shift, spg, lpr))) return rc;
+    ELIMREC_REQUIRE(A->tile_groups == 64 / lpr, "slab_source_bits: the plan's tiles were laid out for another geometry");
+    if (partials_bytes < elimrec_slab_partials_bytes(A, ns, w)) { set_error("slab_source_bits: scratch too small"); return ELIMREC_E_WORKSPACE; }
+    const int n_tiles = A->n_t4 + A->n_t1 + A->n_tseg + A->n_tfin;
+    if (n_tiles <= 0) return 0;
+    uint64_t *ballots = (uint64_t *)((char *)d_partials + slab_partial_floats_bytes(A, ns, w) + slab_ticket_bytes(A));
+    hipLaunchKernelGGL(tile_ballot_kernel, dim3((unsigned)(n_tiles / 4), (unsigned)A->tile_kmax), dim3(256), 0, (hipStream_t)stream,
+                       A->d_tile_off, A->d_tile_col, d_src_mask, 64 / lpr, n_tiles, A->tile_kmax, ballots);
+    ELIMREC_LAUNCH_CHECK("slab_source_bits");
     return 0;
 }
 

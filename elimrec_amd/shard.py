@@ -175,6 +175,7 @@ class ColumnShardEngine(object):
         self._aux = None
         self._aux_pending = False
         self._adam_in_hop = False
+        self._bits_ready = False
         self.keep_grad = False
         self._fused = None
         self._tail_plan = None
@@ -296,12 +297,18 @@ class ColumnShardEngine(object):
         self._keys = keys
         err = m._index_err()
 
+        aux = self._aux_stream()
+        early_bits = aux is not None and self.planT.tiered and not self.bf16
+
         def plan():       # node ids of the slots, unique active rows + slot map, padded tail: one launch
-            ops.batch_plan(users, pos, neg, m.num_users, m.num_items, keys, act, seg, ws["slot_seg"][:R], ws["plan_ws"], err, PAD_KEY)
+            ops.batch_plan(users, pos, neg, m.num_users, m.num_items, keys, act, seg, ws["slot_seg"][:R], ws["plan_ws"], err, PAD_KEY,
+                           key_bitmap=self.mask if early_bits else None)
+            if early_bits:    # the planner's bitmap of the active rows IS the first adjoint hop's source bitmap (one rank):
+                slab.source_bits(self.planT, self.ns, self.w, self.gs, self.mask)      # its per-line bits, off the critical path
 
         def pack():       # the head's weights in MFMA fragment order (they changed in the last optimizer step)
             self._head_fused_call(ws, R, phase=1)
-        aux = self._aux_stream()
+        self._bits_ready = early_bits
         if aux is None:
             m._region("cs_plan", (m._ws_gen, users.data_ptr(), pos.data_ptr(), neg.data_ptr(), R), plan)
             return act
@@ -456,9 +463,9 @@ class ColumnShardEngine(object):
             for k in range(L - 1, last - 1, -1):
                 dst = self.grad if k == 0 else self.tmp[k & 1]
                 slab.hop(self.planT, t, dst, gs=self.gs, src_mask=tmask, add=self.srcB if (k & 1) else self.srcA,
-                         add_mask=self.mask, scale=inv if k == 0 else 1.0)
+                         add_mask=self.mask, scale=inv if k == 0 else 1.0, bits_ready=tmask is not None and self._bits_ready)
                 t, tmask = dst, None
-        self._timed(lambda: m._region("cs_bwd_hops", (m._ws_gen, recv2.data_ptr(), acts.data_ptr(), R, W, fuse), hops), L - last)
+        self._timed(lambda: m._region("cs_bwd_hops", (m._ws_gen, recv2.data_ptr(), acts.data_ptr(), R, W, fuse, self._bits_ready), hops), L - last)
         self._adam_in_hop = fuse
         if fuse:
             # the last hop's output is the gradient: the embeddings' Adam step is its epilogue (no gradient table written and

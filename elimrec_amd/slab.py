@@ -299,7 +299,14 @@ class SlabTable(object):
         return dst
 
 
-def hop(plan, xin, xout, gs=None, src_mask=None, add=None, add_mask=None, scale=1.0, seg_only=False):
+def source_bits(plan, ns, w, gs, src_mask):
+    """elimrec_slab_source_bits: the masked hop's per-index-line source bits for this bitmap, ahead of the hop."""
+    part = plan.partials(ns, w)
+    _lib.check(_lib.load().elimrec_slab_source_bits(plan.ref(), ns, w, int(gs), _dev(src_mask, "src_mask", torch.int32),
+                                                    _dev(part, "partials"), part.numel() * 4, _stream()), "slab_source_bits")
+
+
+def hop(plan, xin, xout, gs=None, src_mask=None, add=None, add_mask=None, scale=1.0, seg_only=False, bits_ready=False):
     """xout = (A . xin + [add_mask] add) * scale on slab tables of equal geometry. seg_only: xout is a flat fp32 tensor
     [ns x n_long x w] receiving the split rows only. bf16 tables on either side select the bf16-storage kernels (the
     source may be fp32 there too: the row-sparse adjoint source behind src_mask)."""
@@ -319,7 +326,7 @@ def hop(plan, xin, xout, gs=None, src_mask=None, add=None, add_mask=None, scale=
                                     _dev(src_mask, "src_mask", torch.int32), _dev(out, "xout"),
                                     _dev(None if add is None else add.data, "add"),
                                     _dev(add_mask, "add_mask", torch.int32), float(scale), _dev(part, "partials"),
-                                    part.numel() * 4, 1 if seg_only else 0, _stream()), "slab_hop")
+                                    part.numel() * 4, (1 if seg_only else 0) | (2 if bits_ready else 0), _stream()), "slab_hop")
 
 
 def hop_adam(plan, xin, grad_out, gs, add, add_mask, scale, p_in, p_out, m, v, lr, beta1, beta2, eps, weight_decay, step):

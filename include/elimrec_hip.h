@@ -509,6 +509,12 @@ int elimrec_slab_hop(const elimrec_sell *A, int ns, int w, int gs, const float *
                      const uint32_t *d_src_mask, float *d_Xout, const float *d_add,
                      const uint32_t *d_add_mask, float scale, float *d_partials, size_t partials_bytes,
                      int seg_only, void *stream);
+/* Tiered plans look the source bitmap up once per index entry before a masked hop (one 64-bit word per index line, kept
+ * in d_partials). This entry runs that pass alone -- e.g. on a second stream as soon as the batch's active rows are
+ * known -- and elimrec_slab_hop with bit 1 of `seg_only` set (seg_only = 2) then skips it. The bitmap passed to both
+ * must hold the same bits. */
+int elimrec_slab_source_bits(const elimrec_sell *A, int ns, int w, int gs, const uint32_t *d_src_mask,
+                             float *d_partials, size_t partials_bytes, void *stream);
 
 /* elimrec_slab_hop (tiered plan, no source bitmap) whose output row pieces are not stored but consumed as the GRADIENT
  * of the same slab-major parameter table by an Adam step with coupled L2 (torch.optim.Adam semantics, arithmetic of
