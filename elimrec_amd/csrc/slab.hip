@@ -996,6 +996,49 @@ __global__ __launch_bounds__(256) void sell_stream_kernel(StreamArgs a) {
     }
 }
 
+// The whole optimizer step in ONE launch: up to 8 jobs (the column shard of the embeddings, read from one buffer and
+// written to the other and -- bf16 storage -- to the gather copy; the spans of the projection weights that have a
+// gradient, in place; copy-only spans). A job may also copy its PRE-update parameters to copy_dst: the snapshot of the
+// projection weights the cached tables were computed with (models/EliMRec.py:98-99). Arithmetic of adam_kernel.
+// The same body also runs as extra workgroups at the end of the hop + Adam launch (sell_tier_kernel<..., ADAM>).
+struct AdamJob {
+    const float *p_in;
+    float *p_out;
+    uint16_t *p16;          // nullable
+    const float *g;         // nullable: copy-only job
+    float *m, *v;
+    float *copy_dst;        // nullable
+    int64_t n;
+    float step_size, inv_sqrt_bc2;
+    int first_block;
+};
+struct AdamJobs { AdamJob j[8]; int n; int blocks; };
+
+__device__ __forceinline__ void adam_jobs_body(const AdamJobs &jobs, int block, float beta1, float beta2, float eps, float wd) {
+    int k = 0;
+    while (k + 1 < jobs.n && block >= jobs.j[k + 1].first_block) ++k;
+    const AdamJob &jb = jobs.j[k];
+    const int nb = (k + 1 < jobs.n ? jobs.j[k + 1].first_block : jobs.blocks) - jb.first_block;
+    for (int64_t i = (int64_t)(block - jb.first_block) * 256 + threadIdx.x; i < jb.n; i += (int64_t)nb * 256) {
+        const float pi = jb.p_in[i];
+        if (jb.copy_dst) jb.copy_dst[i] = pi;
+        if (!jb.g) continue;
+        const float gi = fmaf(wd, pi, jb.g[i]);
+        const float mi = jb.m[i] + (1.f - beta1) * (gi - jb.m[i]);
+        const float vi = fmaf(1.f - beta2, gi * gi, beta2 * jb.v[i]);
+        const float denom = sqrtf(vi) * jb.inv_sqrt_bc2 + eps;
+        jb.m[i] = mi;
+        jb.v[i] = vi;
+        const float po = pi - jb.step_size * (mi / denom);
+        jb.p_out[i] = po;
+        if (jb.p16) jb.p16[i] = __bfloat16_as_ushort(__float2bfloat16(po));
+    }
+}
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(AdamJobs jobs, float beta1, float beta2, float eps, float wd) {
+    adam_jobs_body(jobs, (int)blockIdx.x, beta1, beta2, eps, wd);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Form 3 (whole fp32 tables; the engine's default there): ONE launch per hop over WAVE TILES. What bounds the older
 // forms at the Tiktok shape is not HBM but the CU's memory pipeline walking the index: every (col, val) pair costs two
@@ -1161,8 +1204,8 @@ __device__ __forceinline__ void tier_wave_sum(const float (&acc)[VPL], int cl, i
     }
 }
 
-template <int LPR, int VPL, bool IN_BF16, bool OUT_BF16, bool MASKED, bool ADAM = false>
-__global__ __launch_bounds__(256) void sell_tier_kernel(TierArgs t) {
+template <int LPR, int VPL, bool IN_BF16, bool OUT_BF16, bool MASKED, bool ADAM>
+__device__ __forceinline__ void tier_body(const TierArgs &t) {
     constexpr int G = 64 / LPR;
     const StreamArgs &a = t.s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1253,6 +1296,22 @@ __global__ __launch_bounds__(256) void sell_tier_kernel(TierArgs t) {
     }
 }
 
+template <int LPR, int VPL, bool IN_BF16, bool OUT_BF16, bool MASKED>
+__global__ __launch_bounds__(256) void sell_tier_kernel(TierArgs t) {
+    tier_body<LPR, VPL, IN_BF16, OUT_BF16, MASKED, false>(t);
+}
+
+// the adjoint's last hop: Adam of the shard as the epilogue, and the projection weights' optimizer spans (which need
+// nothing of this hop) as extra workgroups behind the tiles -- its own kernel, so that the other hops' argument block stays small
+template <int LPR>
+__global__ __launch_bounds__(256) void sell_tier_adam_kernel(TierArgs t, AdamJobs tail, int tail_block0) {
+    if ((int)blockIdx.x >= tail_block0) {
+        adam_jobs_body(tail, (int)blockIdx.x - tail_block0, t.s.ad_beta1, t.s.ad_beta2, t.s.ad_eps, t.s.ad_wd);
+        return;
+    }
+    tier_body<LPR, 4, false, false, false, true>(t);
+}
+
 // the split rows by a second launch (ELIMREC_SLAB_STREAM=2: persistent hop without the in-launch combine)
 template <int LPR, int VPL, bool OUT_BF16>
 __global__ __launch_bounds__(256) void stream_fixup_kernel(StreamArgs a) {
@@ -1260,44 +1319,6 @@ __global__ __launch_bounds__(256) void stream_fixup_kernel(StreamArgs a) {
     const int li = (int)(blockIdx.x / (unsigned)a.gs) * 4 + (int)(threadIdx.x >> 6);
     if (li >= a.n_long) return;
     stream_combine<LPR, VPL, OUT_BF16>(a, grp, li);
-}
-
-// The whole optimizer step in ONE launch: up to 8 jobs (the column shard of the embeddings, read from one buffer and
-// written to the other and -- bf16 storage -- to the gather copy; the spans of the projection weights that have a
-// gradient, in place; copy-only spans). A job may also copy its PRE-update parameters to copy_dst: the snapshot of the
-// projection weights the cached tables were computed with (models/EliMRec.py:98-99). Arithmetic of adam_kernel.
-struct AdamJob {
-    const float *p_in;
-    float *p_out;
-    uint16_t *p16;          // nullable
-    const float *g;         // nullable: copy-only job
-    float *m, *v;
-    float *copy_dst;        // nullable
-    int64_t n;
-    float step_size, inv_sqrt_bc2;
-    int first_block;
-};
-struct AdamJobs { AdamJob j[8]; int n; };
-
-__global__ __launch_bounds__(256) void adam_multi_kernel(AdamJobs jobs, float beta1, float beta2, float eps, float wd) {
-    int k = 0;
-    while (k + 1 < jobs.n && (int)blockIdx.x >= jobs.j[k + 1].first_block) ++k;
-    const AdamJob &jb = jobs.j[k];
-    const int nb = (k + 1 < jobs.n ? jobs.j[k + 1].first_block : (int)gridDim.x) - jb.first_block;
-    for (int64_t i = (int64_t)((int)blockIdx.x - jb.first_block) * 256 + threadIdx.x; i < jb.n; i += (int64_t)nb * 256) {
-        const float pi = jb.p_in[i];
-        if (jb.copy_dst) jb.copy_dst[i] = pi;
-        if (!jb.g) continue;
-        const float gi = fmaf(wd, pi, jb.g[i]);
-        const float mi = jb.m[i] + (1.f - beta1) * (gi - jb.m[i]);
-        const float vi = fmaf(1.f - beta2, gi * gi, beta2 * jb.v[i]);
-        const float denom = sqrtf(vi) * jb.inv_sqrt_bc2 + eps;
-        jb.m[i] = mi;
-        jb.v[i] = vi;
-        const float po = pi - jb.step_size * (mi / denom);
-        jb.p_out[i] = po;
-        if (jb.p16) jb.p16[i] = __bfloat16_as_ushort(__float2bfloat16(po));
-    }
 }
 
 static int log2_pow2(int x) {
@@ -1346,6 +1367,7 @@ struct AdamEpilogue {
     const float *p_in; float *p_out, *m, *v;
     float step_size, inv_sqrt_bc2, beta1, beta2, eps, wd;
     int keep_grad;
+    const AdamJobs *tail;          // nullable
 };
 
 static int launch_tier(const elimrec_sell *A, int family, int ns, int wl, int wl_shift, int gs, int spg, int lpr, const void *Xin,
@@ -1385,7 +1407,10 @@ static int launch_tier(const elimrec_sell *A, int family, int ns, int wl, int wl
     t.n_tiles_run = seg_only ? t.tfin_base : t.n_tiles;
     const int64_t per_group = t.n_tiles_run / 4;
     if (per_group <= 0) return 0;
-    const dim3 grid((unsigned)(per_group * gs));
+    const int tail_block0 = (int)(per_group * gs);
+    AdamJobs tail = {};
+    if (adam && adam->tail && adam->tail->n > 0) tail = *adam->tail;
+    const dim3 grid((unsigned)(per_group * gs)), grid_adam((unsigned)(per_group * gs) + (unsigned)(tail.n > 0 ? tail.blocks : 0));
     const bool masked = src_mask != nullptr;
     if (masked) {
         ELIMREC_REQUIRE(A->tile_kmax > 0, "slab_hop: bad tile plan (tile_kmax)");
@@ -1399,7 +1424,7 @@ static int launch_tier(const elimrec_sell *A, int family, int ns, int wl, int wl
 #define ELIMREC_TIER(LPR)                                                                                                     \
     do {                                                                                                                      \
         if (!family) {                                                                                                        \
-            if (adam) hipLaunchKernelGGL((sell_tier_kernel<LPR, 4, false, false, false, true>), grid, dim3(256), 0, s, t);    \
+            if (adam) hipLaunchKernelGGL((sell_tier_adam_kernel<LPR>), grid_adam, dim3(256), 0, s, t, tail, tail_block0);     \
             else if (masked) hipLaunchKernelGGL((sell_tier_kernel<LPR, 4, false, false, true>), grid, dim3(256), 0, s, t);    \
             else hipLaunchKernelGGL((sell_tier_kernel<LPR, 4, false, false, false>), grid, dim3(256), 0, s, t);               \
         } else if (in_bf16) {                                                                                                 \
@@ -1600,6 +1625,33 @@ extern "C" int elimrec_slab_hop(const elimrec_sell *A, int ns, int w, int gs, co
     return 0;
 }
 
+static int build_adam_jobs(const char *who, const elimrec_adam_job *jobs, int n_jobs, float lr, float beta1, float beta2, AdamJobs &a) {
+    a.n = 0;
+    int blocks = 0;
+    for (int k = 0; k < n_jobs; ++k) {
+        const elimrec_adam_job &j = jobs[k];
+        if (j.n <= 0) continue;
+        ELIMREC_REQUIRE(j.d_p_in, "%s: job %d has no parameters", who, k);
+        ELIMREC_REQUIRE(!j.d_g || (j.d_p_out && j.d_m && j.d_v && j.step >= 1), "%s: job %d: an update needs p_out, m, v and a 1-based step", who, k);
+        ELIMREC_REQUIRE(j.d_g || j.d_copy_dst, "%s: job %d does nothing", who, k);
+        AdamJob &o = a.j[a.n++];
+        o.p_in = j.d_p_in; o.p_out = j.d_p_out; o.p16 = (uint16_t *)j.d_p_bf16; o.g = j.d_g; o.m = j.d_m; o.v = j.d_v;
+        o.copy_dst = j.d_copy_dst; o.n = j.n;
+        if (j.d_g) {
+            const double bc1 = 1.0 - pow((double)beta1, (double)j.step);
+            const double bc2 = 1.0 - pow((double)beta2, (double)j.step);
+            o.step_size = (float)((double)lr / bc1);
+            o.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+        }
+        o.first_block = blocks;
+        int64_t nb = (j.n + 255) / 256;
+        if (nb > 4096) nb = 4096;
+        blocks += (int)nb;
+    }
+    a.blocks = blocks;
+    return 0;
+}
+
 extern "C" int elimrec_slab_source_bits(const elimrec_sell *A, int ns, int w, int gs, const uint32_t *d_src_mask,
                                         float *d_partials, size_t partials_bytes, void *stream) {
     ELIMREC_REQUIRE(A && d_src_mask && d_partials, "slab_source_bits: null pointer");
@@ -1620,7 +1672,8 @@ extern "C" int elimrec_slab_source_bits(const elimrec_sell *A, int ns, int w, in
 extern "C" int elimrec_slab_hop_adam(const elimrec_sell *A, int ns, int w, int gs, const float *d_Xin, float *d_grad_out,
                                      const float *d_add, const uint32_t *d_add_mask, float scale, float *d_partials,
                                      size_t partials_bytes, const float *d_p_in, float *d_p_out, float *d_m, float *d_v, float lr,
-                                     float beta1, float beta2, float eps, float weight_decay, int64_t step, void *stream) {
+                                     float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                                     const elimrec_adam_job *tail_jobs, int n_tail_jobs, void *stream) {
     ELIMREC_REQUIRE(A && d_Xin && d_p_in && d_p_out && d_m && d_v, "slab_hop_adam: null pointer");
     ELIMREC_REQUIRE(A->tiered, "slab_hop_adam: needs a tiered (wave-tile) plan");
     ELIMREC_REQUIRE(step >= 1, "slab_hop_adam: 1-based step");
@@ -1638,6 +1691,13 @@ extern "C" int elimrec_slab_hop_adam(const elimrec_sell *A, int ns, int w, int g
     ad.step_size = (float)((double)lr / bc1);
     ad.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     ad.beta1 = beta1; ad.beta2 = beta2; ad.eps = eps; ad.wd = weight_decay; ad.keep_grad = d_grad_out ? 1 : 0;
+    AdamJobs tail = {};
+    ad.tail = nullptr;
+    if (tail_jobs && n_tail_jobs > 0) {
+        ELIMREC_REQUIRE(n_tail_jobs <= 8, "slab_hop_adam: at most 8 tail jobs");
+        if ((rc = build_adam_jobs("slab_hop_adam", tail_jobs, n_tail_jobs, lr, beta1, beta2, tail))) return rc;
+        ad.tail = &tail;
+    }
     return launch_tier(A, 0, ns, w / 4, w4_shift, gs, spg, lpr, d_Xin, false, nullptr, d_grad_out, false, d_add, d_add_mask, scale,
                        d_partials, 0, (hipStream_t)stream, &ad);
 }
@@ -1896,30 +1956,10 @@ extern "C" int elimrec_adam_multi(const elimrec_adam_job *jobs, int n_jobs, floa
                                   float weight_decay, void *stream) {
     ELIMREC_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= 8, "adam_multi: 1..8 jobs");
     AdamJobs a = {};
-    a.n = 0;
-    int blocks = 0;
-    for (int k = 0; k < n_jobs; ++k) {
-        const elimrec_adam_job &j = jobs[k];
-        if (j.n <= 0) continue;
-        ELIMREC_REQUIRE(j.d_p_in, "adam_multi: job %d has no parameters", k);
-        ELIMREC_REQUIRE(!j.d_g || (j.d_p_out && j.d_m && j.d_v && j.step >= 1), "adam_multi: job %d: an update needs p_out, m, v and a 1-based step", k);
-        ELIMREC_REQUIRE(j.d_g || j.d_copy_dst, "adam_multi: job %d does nothing", k);
-        AdamJob &o = a.j[a.n++];
-        o.p_in = j.d_p_in; o.p_out = j.d_p_out; o.p16 = (uint16_t *)j.d_p_bf16; o.g = j.d_g; o.m = j.d_m; o.v = j.d_v;
-        o.copy_dst = j.d_copy_dst; o.n = j.n;
-        if (j.d_g) {
-            const double bc1 = 1.0 - pow((double)beta1, (double)j.step);
-            const double bc2 = 1.0 - pow((double)beta2, (double)j.step);
-            o.step_size = (float)((double)lr / bc1);
-            o.inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-        }
-        o.first_block = blocks;
-        int64_t nb = (j.n + 255) / 256;
-        if (nb > 4096) nb = 4096;
-        blocks += (int)nb;
-    }
+    int rc = build_adam_jobs("adam_multi", jobs, n_jobs, lr, beta1, beta2, a);
+    if (rc) return rc;
     if (a.n == 0) return 0;
-    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, beta1, beta2, eps, weight_decay);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)a.blocks), dim3(256), 0, (hipStream_t)stream, a, beta1, beta2, eps, weight_decay);
     ELIMREC_LAUNCH_CHECK("adam_multi");
     return 0;
 }

@@ -467,16 +467,22 @@ class ColumnShardEngine(object):
                 t, tmask = dst, None
         self._timed(lambda: m._region("cs_bwd_hops", (m._ws_gen, recv2.data_ptr(), acts.data_ptr(), R, W, fuse, self._bits_ready), hops), L - last)
         self._adam_in_hop = fuse
+        self._tail_in_hop = False
         if fuse:
             # the last hop's output is the gradient: the embeddings' Adam step is its epilogue (no gradient table written and
-            # read back; cs_update then only has the projection weights left). Issued outside the recorded region: its
-            # bias-correction constants change every step.
+            # read back). One rank: the projection weights' spans ride along as extra workgroups of the same launch (their
+            # gradients are complete since the head's backward; with peers they still wait for the all-reduce -> cs_update).
+            # Issued outside the recorded region: the bias-correction constants change every step.
             g = self.opt.param_groups[0]
             nxt = 1 - self.cur
+            tail = self._tail_jobs() if W == 1 else []        # (advances the weights' step counts: called once per step)
+            if len(tail) > 8:
+                raise RuntimeError("more than 8 optimizer spans")
+            self._tail_in_hop = W == 1
             self._timed(lambda: slab.hop_adam(self.planT, self.tmp[1], self.grad if self.keep_grad else None, self.gs, self.srcA,
                                               self.mask, inv, self.master[self.cur].data, self.master[nxt].data, self.m1, self.m2,
                                               g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
-                                              self.step_count + 1), 1)
+                                              self.step_count + 1, tail_jobs=tail), 1)
         if self._side and self.world == 1:
             torch.cuda.current_stream().wait_stream(self._side)      # the weight gradients, computed beside the hops
 
@@ -494,7 +500,8 @@ class ColumnShardEngine(object):
             jobs.append(_lib.AdamJob(self.master[self.cur].data.data_ptr(), self.master[nxt].data.data_ptr(),
                                      self.mirror[nxt].data.data_ptr() if self.bf16 else None, self.grad.data.data_ptr(),
                                      self.m1.data_ptr(), self.m2.data_ptr(), None, self.grad.data.numel(), self.step_count))
-        jobs += self._tail_jobs()
+        if not getattr(self, "_tail_in_hop", False):              # else they ran as extra workgroups of the last hop
+            jobs += self._tail_jobs()
         if len(jobs) > 8:
             raise RuntimeError("more than 8 optimizer spans")
         if jobs:

@@ -329,16 +329,18 @@ def hop(plan, xin, xout, gs=None, src_mask=None, add=None, add_mask=None, scale=
                                     part.numel() * 4, (1 if seg_only else 0) | (2 if bits_ready else 0), _stream()), "slab_hop")
 
 
-def hop_adam(plan, xin, grad_out, gs, add, add_mask, scale, p_in, p_out, m, v, lr, beta1, beta2, eps, weight_decay, step):
+def hop_adam(plan, xin, grad_out, gs, add, add_mask, scale, p_in, p_out, m, v, lr, beta1, beta2, eps, weight_decay, step, tail_jobs=()):
     """elimrec_slab_hop_adam: the hop whose output is the gradient of the fp32 slab table p_in, consumed in place by an
-    Adam step (p_out / m / v flat fp32 of the table's geometry). grad_out: a table to also receive the gradient, or None."""
+    Adam step (p_out / m / v flat fp32 of the table's geometry). grad_out: a table to also receive the gradient, or None.
+    tail_jobs: _lib.AdamJob spans (the projection weights) updated by extra workgroups of the same launch."""
+    arr = (_lib.AdamJob * len(tail_jobs))(*tail_jobs) if tail_jobs else None
     ns, w = xin.ns, xin.w
     part = plan.partials(ns, w)
     _lib.check(_lib.load().elimrec_slab_hop_adam(
         plan.ref(), ns, w, int(gs), _dev(xin.data, "xin"), _dev(None if grad_out is None else grad_out.data, "grad"),
         _dev(None if add is None else add.data, "add"), _dev(add_mask, "add_mask", torch.int32), float(scale), _dev(part, "partials"),
         part.numel() * 4, _dev(p_in, "p_in"), _dev(p_out, "p_out"), _dev(m, "m"), _dev(v, "v"), float(lr), float(beta1), float(beta2),
-        float(eps), float(weight_decay), int(step), _stream()), "slab_hop_adam")
+        float(eps), float(weight_decay), int(step), arr, len(tail_jobs), _stream()), "slab_hop_adam")
 
 
 def rows16(plan, ns, w, L, U, x0, layers16, long_tab, row_ids, counts, R, n_lists, out0, narrow, narrow_by_node):

@@ -520,11 +520,15 @@ int elimrec_slab_source_bits(const elimrec_sell *A, int ns, int w, int gs, const
  * of the same slab-major parameter table by an Adam step with coupled L2 (torch.optim.Adam semantics, arithmetic of
  * elimrec_adam_multi element for element): p_out = adam(p_in, g, m, v) with m, v updated in place; d_p_in / d_p_out
  * may alias or be the two buffers of a ping-pong pair. d_grad_out nullable: also store the gradient there.
- * The adjoint's last hop and the optimizer step of models/EliMRec.py's embeddings in one pass over the shard. */
+ * tail_jobs (nullable, <= 8): further optimizer spans as elimrec_adam_multi takes them -- the projection weights, whose
+ * gradients do not depend on this hop -- run by extra workgroups of the same launch.
+ * The adjoint's last hop and the optimizer step (main.py:101) in one launch. */
+struct elimrec_adam_job;          /* defined with elimrec_adam_multi below */
 int elimrec_slab_hop_adam(const elimrec_sell *A, int ns, int w, int gs, const float *d_Xin, float *d_grad_out,
                           const float *d_add, const uint32_t *d_add_mask, float scale, float *d_partials,
                           size_t partials_bytes, const float *d_p_in, float *d_p_out, float *d_m, float *d_v, float lr,
-                          float beta1, float beta2, float eps, float weight_decay, int64_t step, void *stream);
+                          float beta1, float beta2, float eps, float weight_decay, int64_t step,
+                          const struct elimrec_adam_job *tail_jobs, int n_tail_jobs, void *stream);
 
 /* Layer means (models/EliMRec.py:246-247) of the folded propagation at a list of rows, from slab-major layer
  * tables X^0..X^L (host array of L+1 device pointers):
