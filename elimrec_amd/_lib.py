@@ -117,6 +117,8 @@ SIGNATURES = {
     "elimrec_bpr_head": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32,
                                  ctypes.POINTER(c_f32), c_ptr, c_ptr, c_ptr, c_ptr]),
     "elimrec_bpr_head_rows": (c_i32, [c_ptr, c_i64, c_ptr, c_i32, c_i32, c_i32, ctypes.POINTER(c_f32), c_ptr, c_ptr, c_ptr]),
+    "elimrec_bpr_head_rows_sum": (c_i32, [c_ptr, c_i64, c_ptr, c_i32, c_i32, c_i32, ctypes.POINTER(c_f32), c_ptr, c_ptr, c_ptr, c_ptr,
+                                          c_ptr]),
     "elimrec_sum": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr]),
     "elimrec_segment_reduce_workspace": (c_size, [c_i64]),
     "elimrec_segment_plan_workspace": (c_size, [c_i64]),

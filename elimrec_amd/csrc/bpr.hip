@@ -18,13 +18,14 @@ __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a
 // LB = pow2 >= d/4 lanes and works on that many head blocks at once (d = 64: four blocks side by side instead of
 // one after the other with 48 idle lanes). Reductions are xor butterflies inside a group -- the same additions
 // as a full-wave butterfly whose other lanes hold zeros -- and the loss terms are added in block order.
-__global__ __launch_bounds__(256) void bpr_head_kernel(const float *__restrict__ Y, int64_t ldy, int64_t U,
-                                                       const int64_t *__restrict__ users,
-                                                       const int64_t *__restrict__ pos,
-                                                       const int64_t *__restrict__ neg, int B, int d, int n_blocks,
-                                                       BlockWeights bw, float inv_b, float *__restrict__ loss_rows,
-                                                       float *__restrict__ grad_rows, int32_t *__restrict__ keys,
-                                                       const int32_t *__restrict__ slot_rows, int LB) {
+template <bool PUBLISH>
+__device__ __forceinline__ void bpr_head_body(const float *__restrict__ Y, int64_t ldy, int64_t U,
+                                              const int64_t *__restrict__ users,
+                                              const int64_t *__restrict__ pos,
+                                              const int64_t *__restrict__ neg, int B, int d, int n_blocks,
+                                              const BlockWeights &bw, float inv_b, float *__restrict__ loss_rows,
+                                              float *__restrict__ grad_rows, int32_t *__restrict__ keys,
+                                              const int32_t *__restrict__ slot_rows, int LB) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -101,8 +102,60 @@ __global__ __launch_bounds__(256) void bpr_head_kernel(const float *__restrict__
         }
     }
     if (lane == 0) {
-        loss_rows[b] = loss;
+        if (PUBLISH) {      // write-through: another workgroup of this launch adds the rows up (bpr_head_sum_kernel)
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)loss_rows, 0, B * 4, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(loss), rs, (unsigned)b * 4u, 0, 16 /* sc1 */);
+        } else {
+            loss_rows[b] = loss;
+        }
         if (keys) { keys[3 * b] = (int32_t)ru; keys[3 * b + 1] = (int32_t)rp; keys[3 * b + 2] = (int32_t)rn; }
+    }
+}
+
+__global__ __launch_bounds__(256) void bpr_head_kernel(const float *__restrict__ Y, int64_t ldy, int64_t U,
+                                                       const int64_t *__restrict__ users,
+                                                       const int64_t *__restrict__ pos,
+                                                       const int64_t *__restrict__ neg, int B, int d, int n_blocks,
+                                                       BlockWeights bw, float inv_b, float *__restrict__ loss_rows,
+                                                       float *__restrict__ grad_rows, int32_t *__restrict__ keys,
+                                                       const int32_t *__restrict__ slot_rows, int LB) {
+    bpr_head_body<false>(Y, ldy, U, users, pos, neg, B, d, n_blocks, bw, inv_b, loss_rows, grad_rows, keys, slot_rows, LB);
+}
+
+// bpr_head over the compact rows + the batch loss in the same launch: every workgroup publishes its loss rows
+// write-through, drains them and draws a ticket; the one that draws the last ticket does one agent-scope acquire and
+// adds all B rows in sum_kernel's order -- thread t of 1024 virtual threads adds x[t], x[t+1024], ..., then the binary
+// tree -- so the loss has the bits of elimrec_sum over the same rows (cdna_hip_programming.md G16, counter form).
+__global__ __launch_bounds__(256) void bpr_head_sum_kernel(const float *__restrict__ Y, int64_t ldy, int B, int d, int n_blocks,
+                                                           BlockWeights bw, float inv_b, float *__restrict__ loss_rows,
+                                                           float *__restrict__ grad_rows, const int32_t *__restrict__ slot_rows,
+                                                           int LB, float *__restrict__ loss_out, int32_t *__restrict__ ticket) {
+    __shared__ float s[1024];
+    __shared__ int is_last;
+    bpr_head_body<true>(Y, ldy, 0, nullptr, nullptr, nullptr, B, d, n_blocks, bw, inv_b, loss_rows, grad_rows, nullptr, slot_rows, LB);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int tk = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = tk == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int vt = threadIdx.x; vt < 1024; vt += 256) {
+        float acc = 0.f;
+        for (int i = vt; i < B; i += 1024) acc += loss_rows[i];
+        s[vt] = acc;
+    }
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        for (int idx = threadIdx.x; idx < w; idx += 256) s[idx] += s[idx + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        loss_out[0] = s[0];
+        __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -819,6 +872,22 @@ extern "C" int elimrec_bpr_head_rows(const float *d_Y, int64_t ldy, const int32_
                        (const int64_t *)nullptr, (const int64_t *)nullptr, (const int64_t *)nullptr, B, d, n_blocks, bw,
                        1.0f / (float)B, d_loss_rows, d_grad_rows, (int32_t *)nullptr, d_slot_rows, bpr_group_lanes(d));
     ELIMREC_LAUNCH_CHECK("bpr_head_rows");
+    return 0;
+}
+
+extern "C" int elimrec_bpr_head_rows_sum(const float *d_Y, int64_t ldy, const int32_t *d_slot_rows, int B, int d,
+                                         int n_blocks, const float *block_weights, float *d_loss_rows, float *d_grad_rows,
+                                         float *d_loss, int32_t *d_ticket, void *stream) {
+    ELIMREC_REQUIRE(d_Y && d_slot_rows && d_loss_rows && block_weights && d_loss && d_ticket, "bpr_head_rows_sum: null pointer");
+    ELIMREC_REQUIRE(d > 0 && d % 4 == 0, "bpr_head_rows_sum: recdim must be a positive multiple of 4");
+    ELIMREC_REQUIRE(n_blocks >= 1 && n_blocks <= kMaxBlocks, "bpr_head_rows_sum: 1..%d head blocks supported", kMaxBlocks);
+    ELIMREC_REQUIRE(ldy % 4 == 0 && ldy >= (int64_t)n_blocks * d, "bpr_head_rows_sum: bad ldy");
+    if (B <= 0) return check_hip(hipMemsetAsync(d_loss, 0, sizeof(float), (hipStream_t)stream), "memset(loss)");
+    BlockWeights bw;
+    for (int k = 0; k < kMaxBlocks; ++k) bw.w[k] = k < n_blocks ? block_weights[k] : 0.f;
+    hipLaunchKernelGGL(bpr_head_sum_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_Y, ldy, B, d, n_blocks, bw,
+                       1.0f / (float)B, d_loss_rows, d_grad_rows, d_slot_rows, bpr_group_lanes(d), d_loss, d_ticket);
+    ELIMREC_LAUNCH_CHECK("bpr_head_rows_sum");
     return 0;
 }
 

@@ -456,6 +456,19 @@ def bpr_head_rows(Y, slot_rows, d, block_weights, loss_rows, grad_rows=None):
                "bpr_head_rows")
 
 
+def bpr_head_rows_sum(Y, slot_rows, d, block_weights, loss_rows, grad_rows, loss_out, ticket):
+    """bpr_head_rows + the fixed-order sum of its loss rows into loss_out (0-dim / 1-element fp32) in one launch; ticket: a
+    zero-initialised int32 the kernel leaves at zero."""
+    y, ldy = _rowmajor(Y, "Y")
+    nb = len(block_weights)
+    w = (ctypes.c_float * nb)(*[float(x) for x in block_weights])
+    B = slot_rows.numel() // 3
+    _lib.check(_lib.load().elimrec_bpr_head_rows_sum(y, ldy, _dev(slot_rows, "slot_rows", torch.int32), B, d, nb, w,
+                                                     _dev(loss_rows, "loss_rows"), _dev(grad_rows, "grad_rows"),
+                                                     _dev(loss_out, "loss_out"), _dev(ticket, "ticket", torch.int32), _stream()),
+               "bpr_head_rows_sum")
+
+
 def fixed_order_sum(x, out):
     _lib.check(_lib.load().elimrec_sum(_dev(x, "x"), x.numel(), _dev(out, "out"), _stream()), "sum")
     return out

@@ -175,6 +175,7 @@ class ColumnShardEngine(object):
         self._aux = None
         self._aux_pending = False
         self._adam_in_hop = False
+        self._loss_ring, self._loss_at = None, 0
         self._bits_ready = False
         self.keep_grad = False
         self._fused = None
@@ -389,11 +390,10 @@ class ColumnShardEngine(object):
                 act = ws["active_rows"][:R].long()
                 idx = torch.where(act >= 0, act, torch.full_like(act, self.narrow_x.shape[0] - 1))
                 self.narrow_x.index_copy_(0, idx, r[:, :, 1].permute(1, 0, 2).reshape(R, d))
-        if fused:
-            self._head_forward_fused(ws, R, B)
-        else:
-            m._fwd_head(ws, self._keys, R, B, 0, ws["grad_rows"], layer_means=False, snapshot=False)
         m._slab_fwd = True
+        if fused:
+            return self._head_forward_fused(ws, R, B)
+        m._fwd_head(ws, self._keys, R, B, 0, ws["grad_rows"], layer_means=False, snapshot=False)
         loss = torch.empty((), dtype=torch.float32, device=m._device())
         ops.fixed_order_sum(ws["loss_rows"], loss)
         return loss
@@ -410,9 +410,18 @@ class ColumnShardEngine(object):
 
         def head():
             self._head_fused_call(ws, R, phase=2 if packed else 0)
-            ops.bpr_head_rows(YAct, ws["slot_seg"][:3 * B], d, bw, ws["loss_rows"], ws["grad_rows"])
-        m._region("cs_head_fused", (m._ws_gen, R, B, tuple(bw), self.nar_act.data_ptr(), packed), head)
+        m._region("cs_head_fused", (m._ws_gen, R, B, packed, self.nar_act.data_ptr()), head)
+        # the cosine-BPR rows and the batch loss in one launch (the workgroup that finishes last adds the loss rows in
+        # elimrec_sum's order). Issued directly: the loss goes to the next slot of a ring, so that a caller holding the
+        # tensors of earlier steps (up to 64) does not see them change.
+        if self._loss_ring is None:
+            self._loss_ring = torch.zeros(64, dtype=torch.float32, device=m._device())
+            self._loss_ticket = torch.zeros(1, dtype=torch.int32, device=m._device())
+        loss = self._loss_ring[self._loss_at]
+        self._loss_at = (self._loss_at + 1) % 64
+        ops.bpr_head_rows_sum(YAct, ws["slot_seg"][:3 * B], d, bw, ws["loss_rows"], ws["grad_rows"], loss, self._loss_ticket)
         m._publish_cache(ws["Y"], dirty=True)
+        return loss
 
     def _head_fused_call(self, ws, R, phase):
         m = self.model

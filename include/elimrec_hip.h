@@ -311,6 +311,12 @@ int elimrec_bpr_head(const float *d_Y, int64_t ldy, int64_t U, int64_t I,
 int elimrec_bpr_head_rows(const float *d_Y, int64_t ldy, const int32_t *d_slot_rows, int B, int d, int n_blocks,
                           const float *block_weights /* host, n_blocks */, float *d_loss_rows, float *d_grad_rows,
                           void *stream);
+/* elimrec_bpr_head_rows + elimrec_sum of its loss rows in ONE launch: the workgroup that finishes last adds the B loss
+ * rows in elimrec_sum's order (same bits) into *d_loss. d_ticket: one int32, zero before the first call (the kernel
+ * leaves it zero). */
+int elimrec_bpr_head_rows_sum(const float *d_Y, int64_t ldy, const int32_t *d_slot_rows, int B, int d,
+                              int n_blocks, const float *block_weights, float *d_loss_rows, float *d_grad_rows,
+                              float *d_loss, int32_t *d_ticket, void *stream);
 
 /* out[0] = sum_i x[i] in a fixed order (single workgroup, deterministic). */
 int elimrec_sum(const float *d_x, int64_t n, float *d_out, void *stream);
