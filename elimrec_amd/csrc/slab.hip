@@ -206,7 +206,16 @@ __global__ __launch_bounds__(256) void slab_rows_kernel(RowsArgs a) {
         r = a.rows[s];
     }
     const bool user = r < a.U;
-    const bool inline_hop = a.x[a.L] == nullptr;
+    // layer pointers by compare-select over constant indices: indexing the by-value argument array with a run-time k
+    // makes the compiler spill it to scratch (32 B of private segment, and the scratch set-up with it)
+    auto layer = [&](int k) -> const float4 * {
+        const float4 *p = a.x[0];
+#pragma unroll
+        for (int q = 1; q <= kSlabMaxLayers; ++q) p = (k == q) ? a.x[q] : p;
+        return p;
+    };
+    const float4 *xL = layer(a.L), *xLm1 = layer(a.L - 1);
+    const bool inline_hop = xL == nullptr;
     int li = -1, beg = 0, end = 0;
     if (inline_hop) {
         li = a.long_index[r];
@@ -216,10 +225,10 @@ __global__ __launch_bounds__(256) void slab_rows_kernel(RowsArgs a) {
         const int slab = c >> a.w4_shift, c4 = c & (a.w4 - 1);
         const int64_t idx = ((int64_t)slab * a.n_rows + r) * a.w4 + c4;
         float4 xl;
-        if (!inline_hop) xl = a.x[a.L][idx];
+        if (!inline_hop) xl = xL[idx];
         else if (li >= 0) xl = a.long_tab[((int64_t)slab * a.n_long + li) * a.w4 + c4];
         else {
-            const float4 *X = a.x[a.L - 1] + (int64_t)slab * a.n_rows * a.w4 + c4;
+            const float4 *X = xLm1 + (int64_t)slab * a.n_rows * a.w4 + c4;
             xl = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int j = beg; j < end; j += U8) {
                 int cj[U8];
@@ -246,7 +255,7 @@ __global__ __launch_bounds__(256) void slab_rows_kernel(RowsArgs a) {
         float4 sum = make_float4(x0.x + x1.x, x0.y + x1.y, x0.z + x1.z, x0.w + x1.w);
         float4 nar = user ? x0 : x1;
         for (int k = 2; k <= a.L; ++k) {
-            const float4 v = (k == a.L) ? xl : a.x[k][idx];
+            const float4 v = (k == a.L) ? xl : layer(k)[idx];
             sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
             if (((k & 1) == 0) == user) { nar.x += v.x; nar.y += v.y; nar.z += v.z; nar.w += v.w; }
         }
