@@ -1037,3 +1037,102 @@ def test_topk_paths_agree_with_stable_sort():
             order = np.argsort(-sc, axis=1, kind="stable")[:, :K]
             assert np.array_equal(idx.cpu().numpy(), order), (K, Y is Yt)
             assert np.array_equal(val.cpu().numpy(), np.take_along_axis(sc, order, 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_scores", [True, False])
+def test_tile_guided_topk_at_recdim_64(with_scores):
+    """The evaluator's own configuration (recdim 64: 16-user-per-wave scorer, selection from tile maxima, bitmap masking)
+    against a stable sort of the full masked score matrix: continuous scores and massive ties; rows with nothing, a few,
+    hundreds (K + masked > 256 group maxima -> fall-back) and all-but-4 items masked; 200 users (two user groups per
+    launch); with the caller's score matrix and with the private one (top-K only)."""
+    from elimrec_amd import ops
+    U, I, d, S = 260, 3000, 64, 3
+    Cy = (1 + S) * d
+    g = torch.Generator().manual_seed(5)
+    Yr = torch.randn(U + I, Cy, generator=g) * 0.3
+    Yt = Yr.clone()
+    Yt[U:] = Yt[U:U + 9].repeat((I + 8) // 9, 1)[:I]            # 9 distinct item rows -> massive ties
+    users = torch.arange(0, 200)
+    B = len(users)
+    lists = [[] for _ in range(B)]
+    lists[3] = [5, 17, 2999, 1024]
+    lists[5] = [i for i in range(I) if i not in (17, 2000, 3, 999)]
+    lists[7] = list(range(0, 900, 3))                            # 300 masked items
+    lists[8] = [11, 11, 12]                                      # a duplicate
+    rng = np.random.default_rng(0)
+    for b in range(20, 200):
+        lists[b] = rng.choice(I, size=int(rng.integers(0, 40)), replace=False).tolist()
+    ptr = torch.zeros(B + 1, dtype=torch.int64)
+    ptr[1:] = torch.tensor(np.cumsum([len(x) for x in lists]))
+    items = torch.tensor([i for x in lists for i in x], dtype=torch.int32)
+    for Y in (Yr, Yt):
+        Yd = Y.to(DEV)
+        ref = torch.empty(B, I, device=DEV)
+        ws = torch.empty(ops.score_workspace(B, U, I, S, 1), dtype=torch.uint8, device=DEV)
+        ops.score_topk(Yd, U, I, users.to(DEV), d, S, 0b111, "rubi", "TIE", ws, scores=ref, train_ptr=ptr.to(DEV),
+                       train_items=items.to(DEV))
+        sc = ref.cpu().numpy()
+        for b in (3, 5, 7, 8):
+            assert np.isinf(sc[b]).sum() == len(set(lists[b]))
+        for K in (1, 10, 50, 100):
+            ws = torch.empty(ops.score_workspace(B, U, I, S, K), dtype=torch.uint8, device=DEV)
+            scores = torch.empty(B, I, device=DEV) if with_scores else None
+            idx = torch.empty(B, K, dtype=torch.int32, device=DEV)
+            val = torch.empty(B, K, device=DEV)
+            ops.score_topk(Yd, U, I, users.to(DEV), d, S, 0b111, "rubi", "TIE", ws, scores=scores, K=K, topk_idx=idx,
+                           topk_val=val, train_ptr=ptr.to(DEV), train_items=items.to(DEV))
+            if with_scores:
+                assert np.array_equal(scores.cpu().numpy(), sc)
+            order = np.argsort(-sc, axis=1, kind="stable")[:, :K]
+            got = idx.cpu().numpy()
+            full = np.isfinite(np.take_along_axis(sc, order, 1)).all(1)      # rows with at least K unmasked items
+            assert np.array_equal(got[full], order[full]), (K, Y is Yt)
+            assert np.array_equal(val.cpu().numpy()[full], np.take_along_axis(sc, order, 1)[full])
+            assert not full[5] or K <= 4
+
+
+@pytest.mark.gpu
+def test_fast_evaluation_math_is_close_and_ranks_alike():
+    """elimrec_score_set_math(1): v_exp / v_rcp sigmoids and reciprocal norms. Scores within 2e-6 of the EXACT mode in
+    all three fusion modes; top-K lists differ only where two EXACT scores are closer than that."""
+    from elimrec_amd import _lib, ops
+    lib = _lib.load()
+    U, I, d, S, K = 130, 4000, 64, 3, 20
+    g = torch.Generator().manual_seed(9)
+    Y = (torch.randn(U + I, (1 + S) * d, generator=g) * 0.4).to(DEV)
+    users = torch.arange(0, 128).to(DEV)
+    ws = torch.empty(ops.score_workspace(128, U, I, S, K), dtype=torch.uint8, device=DEV)
+    try:
+        for mode in ("rubi", "hm", "sum"):
+            for ptype in ("normal", "TE", "TIE"):
+                out = {}
+                for fast in (0, 1):
+                    lib.elimrec_score_set_math(fast)
+                    sc = torch.empty(128, I, device=DEV)
+                    idx = torch.empty(128, K, dtype=torch.int32, device=DEV)
+                    ops.score_topk(Y, U, I, users, d, S, 0b111, mode, ptype, ws, scores=sc, K=K, topk_idx=idx)
+                    out[fast] = (sc.cpu().numpy(), idx.cpu().numpy())
+                e, f = out[0][0], out[1][0]
+                assert np.abs(e - f).max() < 2e-6, (mode, ptype, np.abs(e - f).max())
+                for r in np.nonzero((out[0][1] != out[1][1]).any(1))[0]:
+                    a, b = out[0][1][r], out[1][1][r]
+                    assert np.abs(e[r][a] - e[r][b]).max() < 4e-6, (mode, ptype, r)
+    finally:
+        lib.elimrec_score_set_math(0)
+
+
+@pytest.mark.gpu
+def test_evaluator_results_do_not_depend_on_the_users_per_launch(monkeypatch):
+    """The device evaluator scores 1024 users per launch where the reference's test_batch_size is 128: same metric rows."""
+    g = load_golden("ml3")
+    model, _ = build_model_from_fixture(g, DEV)
+    _load_cache(model, g)
+    model.fusion_mode, model.predict_type = "rubi", "TIE"
+    evalr = model.test_evaluator.evaluator
+    users = list(evalr.user_pos_test.keys())
+    res = {}
+    for blk in (7, 128, 4096):
+        evalr.block_users = blk
+        res[blk], _ = evalr.evaluate(model, users[:])
+    assert np.array_equal(res[7], res[128]) and np.array_equal(res[128], res[4096])

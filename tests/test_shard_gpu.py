@@ -542,3 +542,41 @@ def test_tiered_one_launch_hop(d, w, gs, bf16, ipw):
     lt = long_tab.view(ns, plan.n_long, w).permute(1, 0, 2).reshape(plan.n_long, d).double()
     rows = plan.t["long_rows"][:plan.n_long].long()
     assert ((lt - want[rows]).abs() <= 4e-6 * scale[rows] + 1e-6).all()
+
+
+def test_step_variants_are_bitwise_equal(monkeypatch):
+    """The launch-saving forms of the step change WHERE work runs, not what is computed: Adam as the last hop's epilogue
+    (+ the projection weights' spans as extra workgroups), the planner / source-bit pass / weight packing on a second
+    stream, the loss summed inside the BPR-head launch -- each switched off gives bitwise the same losses, parameters and
+    Adam moments after three steps. The two-launch SELL-64 hop sums long rows in another order: equal to round-off."""
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
+    g = load_golden("ml3")
+
+    def run(env):
+        for k in ("ELIMREC_FUSE_ADAM", "ELIMREC_AUX_STREAM", "ELIMREC_SLAB_TIERED", "ELIMREC_FUSED_HEAD"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        model, _ = build_model_from_fixture(g, DEV)
+        opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+        eng = ColumnShardEngine(model)
+        tr = ColumnShardTrainer(eng, opt)
+        losses = [tr.step(*(_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg"))).clone() for t in (1, 2, 3)]
+        eng.sync_to_model()
+        st = eng.optimizer_state()
+        return (torch.stack(losses).cpu(), {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
+                st["exp_avg"], st["exp_avg_sq"])
+
+    base = run({})
+    for env in ({"ELIMREC_FUSE_ADAM": "0"}, {"ELIMREC_AUX_STREAM": "0"}, {"ELIMREC_FUSE_ADAM": "0", "ELIMREC_AUX_STREAM": "0"}):
+        other = run(env)
+        assert torch.equal(base[0], other[0]), env
+        for k in base[1]:
+            assert torch.equal(base[1][k], other[1][k]), (env, k)
+        assert torch.equal(base[2], other[2]) and torch.equal(base[3], other[3]), env
+    other = run({"ELIMREC_FUSED_HEAD": "0"})           # two batched GEMM launches + separate loss sum: same arithmetic?
+    assert (base[0] - other[0]).abs().max() < 1e-6
+    other = run({"ELIMREC_SLAB_TIERED": "0"})
+    assert (base[0] - other[0]).abs().max() < 1e-6
+    for k in base[1]:
+        assert (base[1][k] - other[1][k]).abs().max() < 2e-5, k
