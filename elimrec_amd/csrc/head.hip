@@ -11,6 +11,7 @@
 // Specialised for recdim = 64 (two 32-column MFMA tiles) and feature widths that fit LDS; other shapes keep the
 // batched-GEMM path.
 #include "common.h"
+#include <cstdlib>
 
 namespace elimrec {
 
@@ -220,6 +221,153 @@ __global__ __launch_bounds__(256) void head_fwd_fused_kernel(HeadFwdArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same head on 16-row tiles (default): twice the workgroups, a third of the LDS (three workgroups per CU instead of
+// one), v_mfma_f32_16x16x4_f32, and wave w owns output columns [16w, 16w + 16) of EVERY block over the whole K -- no
+// K-split, no partial-sum exchange, two barriers fewer, every wave takes part in both epilogues. The 32-row form above
+// is a chain of exposed latencies at one wave per SIMD (launch + LDS skeleton 12 us, MFMAs 9, gathers + stores 10).
+// Packed weights: element (n, k) of a [64 x K] matrix at ((n / 16) * (K / 4) + k / 4) * 64 + (k & 3) * 16 + n % 16,
+// i.e. the B operand of MFMA step s of column tile ct is the 64 consecutive floats at ((ct * K/4) + s) * 64.
+typedef float v4h __attribute__((ext_vector_type(4)));
+constexpr int H16 = 16;
+
+__global__ __launch_bounds__(256) void pack_head_weights16_kernel(PackJobs jobs, float *__restrict__ pk) {
+    int q = 0;
+    while (q + 1 < jobs.n && (int)blockIdx.x >= jobs.first_block[q + 1]) ++q;
+    const PackJob &jb = jobs.j[q];
+    const int64_t total = (int64_t)HD * jb.K;
+    const int nb = jobs.first_block[q + 1] - jobs.first_block[q];
+    for (int64_t e = (int64_t)((int)blockIdx.x - jobs.first_block[q]) * 256 + threadIdx.x; e < total; e += (int64_t)nb * 256) {
+        const int lane = (int)(e & 63);
+        const int64_t blk = e >> 6;                 // ct * (K/4) + s
+        const int ct = (int)(blk / (jb.K / 4)), s = (int)(blk - (int64_t)ct * (jb.K / 4));
+        pk[jb.dst + e] = jb.W[(int64_t)(ct * 16 + (lane & 15)) * jb.ld + 4 * s + (lane >> 4)];
+    }
+}
+
+// acc += A[16 x 4*nsteps] . B : A from LDS (ap = this lane's row and k-quarter), B = packed weights (bp = column tile + lane)
+__device__ __forceinline__ v4h head16_run(v4h acc, const float *ap, const float *__restrict__ bp, int nsteps) {
+    constexpr int PF = 16;
+    nsteps = __builtin_amdgcn_readfirstlane(nsteps);
+    float bq[PF];
+    if (nsteps >= PF) {
+#pragma unroll
+        for (int u = 0; u < PF; ++u) bq[u] = bp[u * 64];
+    }
+    int s = 0;
+    for (; s + PF <= nsteps; s += PF) {
+        float bc[PF], av[PF];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) bc[u] = bq[u];
+        if (s + 2 * PF <= nsteps) {
+#pragma unroll
+            for (int u = 0; u < PF; ++u) bq[u] = bp[(int64_t)(s + PF + u) * 64];
+        }
+#pragma unroll
+        for (int u = 0; u < PF; ++u) av[u] = ap[4 * (s + u)];
+#pragma unroll
+        for (int u = 0; u < PF; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bc[u], acc, 0, 0, 0);
+    }
+    for (; s < nsteps; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[4 * s], bp[(int64_t)s * 64], acc, 0, 0, 0);
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void head_fwd16_kernel(HeadFwdArgs a) {
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_act = a.seg_info[0], n_lo = a.seg_info[1];
+    const int tu = (n_lo + H16 - 1) / H16;
+    const int ti = (n_act - n_lo + H16 - 1) / H16;
+    const int t = blockIdx.x;
+    if (t >= tu + ti) return;
+    const bool user = t < tu;
+    const int r0 = user ? t * H16 : n_lo + (t - tu) * H16;
+    const int r1 = min(r0 + H16, user ? n_lo : n_act);
+    const int nrows = r1 - r0;
+    const int side = user ? 0 : 1;
+    const int C = (1 + a.n_mod) * HD, LDO = C + 4;
+    constexpr int LDN = HD + 4;
+    float *AN = lds;                                   // narrow rows [16][68]
+    float *OutT = lds + a.out_off;                     // Out tile    [16][C + 4]
+    __shared__ float s_c[H16];
+    __shared__ int s_act[H16];
+    if (tid < H16) {
+        const int node = tid < nrows ? a.act[r0 + tid] : 0;
+        s_act[tid] = node;
+        s_c[tid] = tid < nrows ? a.c[node] : 0.f;
+    }
+    // out0 -> block 0 of the Out tile, narrow -> AN (compact rows: no index needed)
+    for (int e = tid; e < H16 * (HD / 4); e += 256) {
+        const int r = e / (HD / 4), c4 = e % (HD / 4);
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
+        if (r < nrows) {
+            x = *reinterpret_cast<const float4 *>(a.out0 + (int64_t)(r0 + r) * a.ld_out0 + 4 * c4);
+            y = *reinterpret_cast<const float4 *>(a.narrow + (int64_t)(r0 + r) * a.ld_nar + 4 * c4);
+        }
+        *reinterpret_cast<float4 *>(OutT + r * LDO + 4 * c4) = x;
+        *reinterpret_cast<float4 *>(AN + r * LDN + 4 * c4) = y;
+    }
+    __syncthreads();                                   // s_act
+    for (int m = 0; m < a.n_mod; ++m) {
+        const int D4 = a.D[m] / 4, lda = a.D[m] + 4;
+        float *Am = lds + a.a_off[m];
+        for (int e = tid; e < H16 * D4; e += 256) {
+            const int r = e / D4, c4 = e % D4;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < nrows) x = *reinterpret_cast<const float4 *>(a.S[m] + (int64_t)s_act[r] * a.ldS[m] + 4 * c4);
+            *reinterpret_cast<float4 *>(Am + r * lda + 4 * c4) = x;
+        }
+    }
+    __syncthreads();
+    const int ai = lane & 15, kq = lane >> 4;
+    const int col = wave * 16 + ai;                    // this lane's output column inside a 64-column block
+    // ---- stage 1: feature blocks
+#pragma unroll
+    for (int m = 0; m < HMAXM; ++m) {
+        if (m < a.n_mod) {
+            const int K = a.D[m];
+            const float *ap = lds + a.a_off[m] + ai * (K + 4) + kq;
+            const float *bp = a.pk + a.off_Wm[m] + (int64_t)wave * (K / 4) * 64 + lane;
+            const v4h acc = head16_run((v4h){0.f, 0.f, 0.f, 0.f}, ap, bp, K / 4);
+            const float bm = a.bias_m[m] ? a.bias_m[m][col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * kq + r;
+                const float v = acc[r] + s_c[row] * bm + AN[row * LDN + col];
+                OutT[row * LDO + (m + 1) * HD + col] = v;
+                if (row < nrows) a.OutAct[(int64_t)(r0 + row) * a.ld_out + (m + 1) * HD + col] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- stage 2: fused Linear over the whole Out tile (K = C) and the single-modal heads (K = 64)
+    {
+        const float *ap = OutT + ai * LDO + kq;
+        const float *bp = a.pk + a.off_Wf[side] + (int64_t)wave * (C / 4) * 64 + lane;
+        const v4h acc = head16_run((v4h){0.f, 0.f, 0.f, 0.f}, ap, bp, C / 4);
+        const float bb = a.bias_f[side] ? a.bias_f[side][col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * kq + r;
+            if (row < nrows) a.YAct[(int64_t)(r0 + row) * a.ld_y + col] = acc[r] + bb;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < HMAXM; ++m) {
+        if (m < a.n_mod) {
+            const float *ap = OutT + ai * LDO + (m + 1) * HD + kq;
+            const float *bp = a.pk + a.off_Ws[m] + (int64_t)wave * (HD / 4) * 64 + lane;
+            const v4h acc = head16_run((v4h){0.f, 0.f, 0.f, 0.f}, ap, bp, HD / 4);
+            const float bb = a.bias_s[m] ? a.bias_s[m][col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * kq + r;
+                if (row < nrows) a.YAct[(int64_t)(r0 + row) * a.ld_y + (m + 1) * HD + col] = acc[r] + bb;
+            }
+        }
+    }
+}
+
 }  // namespace elimrec
 
 using namespace elimrec;
@@ -262,19 +410,23 @@ extern "C" int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg
         off += (int64_t)HD * K;
         return at;
     };
+    static int form16 = -1;
+    if (form16 < 0) { const char *e = getenv("ELIMREC_HEAD_ROWS"); form16 = (e && atoi(e) == 32) ? 0 : 1; }
+    const int rows_t = form16 ? H16 : HROWS;
+    if (form16) lds_f = H16 * (HD + 4);              // narrow tile first
     for (int m = 0; m < n_mod; ++m) {
         ELIMREC_REQUIRE(d_S[m] && d_Wm[m] && d_Ws[m] && D[m] > 0 && D[m] % 4 == 0 && ldS[m] % 4 == 0, "head_fwd_fused: bad feature table %d", m);
         a.S[m] = d_S[m]; a.ldS[m] = ldS[m]; a.D[m] = D[m]; a.bias_m[m] = d_bm ? d_bm[m] : nullptr;
         a.a_off[m] = lds_f;
-        lds_f += HROWS * (D[m] + 1);
+        lds_f += rows_t * (D[m] + (form16 ? 4 : 1));
         a.off_Wm[m] = add_job(d_Wm[m], D[m]);
     }
     a.off_Wf[0] = add_job(d_Wf_user, C);
     a.off_Wf[1] = add_job(d_Wf_item, C);
     for (int m = 0; m < n_mod; ++m) { a.off_Ws[m] = add_job(d_Ws[m], HD); a.bias_s[m] = d_bs ? d_bs[m] : nullptr; }
     pj.first_block[pj.n] = blocks;
-    a.out_off = lds_f; lds_f += HROWS * (C + 1);
-    a.part_off = lds_f; lds_f += (1 + n_mod) * HROWS * HD;
+    a.out_off = lds_f; lds_f += rows_t * (C + (form16 ? 4 : 1));
+    a.part_off = lds_f; if (!form16) lds_f += (1 + n_mod) * HROWS * HD;
     const size_t lds_bytes = (size_t)lds_f * sizeof(float);
     if (lds_bytes > 158 * 1024) { set_error("head_fwd_fused: feature widths need %zu B of LDS", lds_bytes); return ELIMREC_E_UNSUPPORTED; }
     a.act = d_act; a.seg_info = d_seg_info; a.out0 = d_out0; a.ld_out0 = ld_out0; a.narrow = d_narrow; a.ld_nar = ld_nar; a.c = d_c;
@@ -282,10 +434,23 @@ extern "C" int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg
     a.OutAct = d_OutAct; a.ld_out = ld_out; a.YAct = d_YAct; a.ld_y = ld_y;
     hipStream_t s = (hipStream_t)stream;
     if (phase != 2) {
-        hipLaunchKernelGGL(pack_head_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pj, d_pack);
+        if (form16) hipLaunchKernelGGL(pack_head_weights16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pj, d_pack);
+        else hipLaunchKernelGGL(pack_head_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pj, d_pack);
         ELIMREC_LAUNCH_CHECK("pack_head_weights");
     }
     if (phase == 1) return 0;
+    if (form16) {
+        static size_t lds_set16 = 0;
+        if (lds_bytes > 64 * 1024 && lds_bytes > lds_set16) {
+            hipError_t e = hipFuncSetAttribute((const void *)head_fwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return check_hip(e, "head_fwd_fused: LDS size");
+            lds_set16 = lds_bytes;
+        }
+        const unsigned tiles = (unsigned)((R + H16 - 1) / H16 + 2);     // user tiles + item tiles <= R/16 + 2
+        hipLaunchKernelGGL(head_fwd16_kernel, dim3(tiles), dim3(256), lds_bytes, s, a);
+        ELIMREC_LAUNCH_CHECK("head_fwd16");
+        return 0;
+    }
     static size_t lds_set = 0;
     if (lds_bytes > 64 * 1024 && lds_bytes > lds_set) {
         hipError_t e = hipFuncSetAttribute((const void *)head_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
