@@ -2,6 +2,7 @@
 // IndexBackward, and the row-sparse input gradient of the head Linears.
 // (models/EliMRec.py:129-142,277-297 forward; main.py:99-100 autograd.)
 #include "common.h"
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
 
@@ -710,6 +711,127 @@ __global__ __launch_bounds__(512) void head_bwd_input_mfma_kernel(const float *_
     }
 }
 
+// The same kernel on 16-row tiles (ELIMREC_HEAD_BWD_ROWS=16; not the default, see the launch site): twice the workgroups
+// at half the threads, a quarter of the LDS, v_mfma_f32_16x16x4_f32, four 16-column output tiles per wave.
+typedef float v4f_ __attribute__((ext_vector_type(4)));
+constexpr int HM16 = 16;
+
+__device__ __forceinline__ v4f_ hm16_accumulate(v4f_ acc, const float *__restrict__ a_row, const float *__restrict__ Wp,
+                                                int64_t ldw, int K, int kq) {
+    // acc[row i][col j] += sum_k a_row[k] * Wp[k*ldw]   (a_row = this lane's LDS row, Wp = this lane's column)
+    constexpr int PF = 16;
+    for (int k0 = 0; k0 < K; k0 += 4 * PF) {
+        float b[PF];
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int k = k0 + 4 * q + kq;
+            b[q] = (k < K) ? Wp[(int64_t)k * ldw] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < PF; ++q) {
+            const int k = k0 + 4 * q + kq;
+            const float a = (k < K) ? a_row[k] : 0.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[q], acc, 0, 0, 0);
+        }
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__restrict__ dY, int64_t lddy,
+                                                               const int32_t *__restrict__ active_rows,
+                                                               const int32_t *__restrict__ seg_info, int64_t n_max,
+                                                               int64_t U, int d, int C, int S, HeadPtrs hp,
+                                                               const float *__restrict__ W_user,
+                                                               const float *__restrict__ W_item, float gscale,
+                                                               float *__restrict__ G0, int64_t ldg, int scatter_cols,
+                                                               float *__restrict__ compact, SegSrc seg) {
+    extern __shared__ float dys[];                       // [16][Cy + 4]
+    __shared__ int64_t node[HM16];
+    const int Cy = (1 + S) * d, ldy = Cy + 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t s0 = (int64_t)blockIdx.x * HM16;
+    int64_t n_act = seg_info[0];
+    if (n_act > n_max) n_act = n_max;
+    if (s0 >= n_act) return;
+    const int rows = (int)((n_act - s0) < HM16 ? (n_act - s0) : HM16);
+    const float seg_scale = (seg.rows && seg.scale) ? seg.scale[0] : 1.f;
+    // staging as in the 32-row kernel: the dependent loads of the fused segment reduce in batches of 4 per thread
+    constexpr int ST = 4;
+    for (int e0 = tid * 4; e0 < HM16 * Cy; e0 += 1024 * ST) {
+        int r[ST], c[ST], beg[ST], end[ST], mem[ST];
+        bool in[ST];
+        float4 v[ST];
+#pragma unroll
+        for (int q = 0; q < ST; ++q) {
+            const int e = e0 + 1024 * q;
+            r[q] = e / Cy; c[q] = e - r[q] * Cy;
+            in[q] = e < HM16 * Cy && r[q] < rows;
+            beg[q] = 0; end[q] = 0;
+            if (in[q] && seg.rows) { beg[q] = seg.seg_start[s0 + r[q]]; end[q] = seg.seg_start[s0 + r[q] + 1]; }
+        }
+        if (seg.rows) {
+#pragma unroll
+            for (int q = 0; q < ST; ++q) mem[q] = (in[q] && beg[q] < end[q]) ? seg.members[beg[q]] : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < ST; ++q) {
+            v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (in[q]) {
+                if (!seg.rows) v[q] = ld4(dY + (s0 + r[q]) * lddy + c[q]);
+                else if (beg[q] < end[q]) {
+                    const float4 x = ld4(seg.rows + (int64_t)mem[q] * Cy + c[q]);
+                    v[q].x += x.x; v[q].y += x.y; v[q].z += x.z; v[q].w += x.w;    // 0 + x, as the serial loop does
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < ST; ++q) {
+            const int e = e0 + 1024 * q;
+            if (e >= HM16 * Cy) continue;
+            if (in[q] && seg.rows) {
+                for (int i = beg[q] + 1; i < end[q]; ++i) {
+                    const float4 x = ld4(seg.rows + (int64_t)seg.members[i] * Cy + c[q]);
+                    v[q].x += x.x; v[q].y += x.y; v[q].z += x.z; v[q].w += x.w;
+                }
+                v[q] = make_float4(v[q].x * seg_scale, v[q].y * seg_scale, v[q].z * seg_scale, v[q].w * seg_scale);
+                st4(seg.reduced + (s0 + r[q]) * lddy + c[q], v[q]);
+            }
+            st4(dys + r[q] * ldy + c[q], v[q]);
+        }
+    }
+    if (tid < HM16) node[tid] = (tid < rows) ? (int64_t)active_rows[s0 + tid] : -1;
+    __syncthreads();
+    const bool any_user = node[0] < U;
+    const bool any_item = node[rows - 1] >= U;
+    const bool mixed = any_user && any_item;
+    const int li = lane & 15, kq = lane >> 4;
+    const int n_tiles = C / 16;
+    const float *a_row = dys + li * ldy;
+    for (int t = wave; t < n_tiles; t += 4) {
+        const int c0 = t * 16;
+        const int mb = c0 / d;
+        v4f_ acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+        acc = hm16_accumulate(acc, a_row, (any_user ? W_user : W_item) + c0 + li, C, d, kq);
+        if (mixed) acc2 = hm16_accumulate(acc2, a_row, W_item + c0 + li, C, d, kq);
+        for (int h = 0; h < S; ++h) {
+            if (hp.mblock[h] != mb) continue;
+            const float *Wh = hp.w[h] + (c0 - mb * d) + li;
+            acc = hm16_accumulate(acc, a_row + (1 + h) * d, Wh, d, d, kq);
+            if (mixed) acc2 = hm16_accumulate(acc2, a_row + (1 + h) * d, Wh, d, d, kq);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * kq + r;
+            if (row < rows) {
+                const int64_t nd = node[row];
+                const float v = ((mixed && nd >= U) ? acc2[r] : acc[r]) * gscale;
+                if (G0 && c0 + li < scatter_cols) G0[nd * ldg + c0 + li] = v;
+                if (compact) compact[(s0 + row) * C + c0 + li] = v;
+            }
+        }
+    }
+}
+
 struct SegLayout {
     size_t keys_sorted, vals_in, vals_sorted, flag, segid, seg_start, sort_tmp, scan_tmp, total;
     size_t sort_bytes, scan_bytes;
@@ -1118,6 +1240,18 @@ extern "C" int elimrec_segment_apply_head_bwd(const float *d_rows, int64_t n, in
     for (int h = 0; h < kMaxHeads; ++h) {
         hp.w[h] = h < S ? d_W_heads[h] : nullptr;
         hp.mblock[h] = h < S ? head_mblock[h] : -1;
+    }
+    // measured at the Tiktok shape: 32.4 us against 28.5 for the 32-row kernel -- the B operands here are read unpacked from
+    // L2 and the smaller MFMA doubles those loads; off unless ELIMREC_HEAD_BWD_ROWS=16
+    static int rows16 = -1;
+    if (rows16 < 0) { const char *e = getenv("ELIMREC_HEAD_BWD_ROWS"); rows16 = (e && atoi(e) == 16) ? 1 : 0; }
+    if (rows16 && C % 16 == 0 && (1 + S) * d % 4 == 0) {
+        const size_t lds16 = (size_t)HM16 * ((1 + S) * d + 4) * sizeof(float);
+        hipLaunchKernelGGL(head_bwd_input16_kernel, dim3((unsigned)((n + HM16 - 1) / HM16)), dim3(256), lds16,
+                           (hipStream_t)stream, (const float *)d_reduced, (int64_t)ld, d_active_rows, d_seg_info, n, U, d, C, S, hp,
+                           d_W_user, d_W_item, 1.0f, (float *)nullptr, (int64_t)0, 0, d_compact, seg);
+        ELIMREC_LAUNCH_CHECK("segment_apply_head_bwd16");
+        return 0;
     }
     hipLaunchKernelGGL(head_bwd_input_mfma_kernel, dim3((unsigned)((n + HM_ROWS - 1) / HM_ROWS)), dim3(512), lds_m,
                        (hipStream_t)stream, (const float *)d_reduced, (int64_t)ld, d_active_rows, d_seg_info, n, U, d, C, S, hp,
