@@ -406,7 +406,9 @@ extern "C" int elimrec_linear_fwd(const float *d_A, int64_t lda, const float *d_
 // of equal weight) in ONE round, between 64 and 512 rows.
 static inline void bwd_w_dims(int64_t R, int n1, int n2, int &chunk_rows, int &chunks, int &t1, int &t2) {
     const int tiles = ((n1 + TN1 - 1) / TN1) * ((n2 + TN2 - 1) / TN2);
-    int64_t want = (R * tiles + 239) / 240;                 // rows per workgroup for ~240 workgroups
+    static int target = 0;
+    if (!target) { const char *e = getenv("ELIMREC_BWDW_WGS"); target = e ? atoi(e) : 240; if (target < 8) target = 8; }
+    int64_t want = (R * tiles + target - 1) / target;       // rows per workgroup for ~`target` workgroups per problem
     want = (want + TRB - 1) / TRB * TRB;
     chunk_rows = (int)(want < 64 ? 64 : (want > 512 ? 512 : want));
     chunks = (int)((R + chunk_rows - 1) / chunk_rows);
