@@ -126,6 +126,9 @@ SIGNATURES = {
     "elimrec_segment_apply_head_bwd": (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_i64, c_i32,
                                                c_i32, c_i32, ctypes.POINTER(c_i32), c_ptr, c_ptr, ctypes.POINTER(c_ptr), c_ptr,
                                                c_ptr]),
+    "elimrec_segment_apply_head_bwd_packed": (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_i64, c_i32,
+                                               c_i32, c_i32, ctypes.POINTER(c_i32), c_ptr, c_ptr, ctypes.POINTER(c_ptr), c_ptr,
+                                               c_ptr, c_ptr]),
     "elimrec_segment_apply": (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "elimrec_segment_reduce_rows": (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "elimrec_head_bwd_input": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i32, c_i32, c_i32,
@@ -162,6 +165,7 @@ SIGNATURES = {
     "elimrec_adam_step_out": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64,
                                       c_ptr]),
     "elimrec_head_pack_floats": (c_size, [c_i32, ctypes.POINTER(c_i32)]),
+    "elimrec_head_pack_bwd_offset": (c_size, [c_i32, ctypes.POINTER(c_i32)]),
     "elimrec_head_fwd_fused": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i32, ctypes.POINTER(c_ptr),
                                        ctypes.POINTER(c_i64), ctypes.POINTER(c_i32), ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr),
                                        c_ptr, c_ptr, c_ptr, c_ptr, ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr), c_ptr, c_size,

@@ -737,6 +737,19 @@ __device__ __forceinline__ v4f_ hm16_accumulate(v4f_ acc, const float *__restric
     return acc;
 }
 
+// the same with the B operand from the packed copy (head.hip, common.h head_pack_layout): bp = start of the column tile +
+// lane, one coalesced 256-B load per MFMA; K = 64
+__device__ __forceinline__ v4f_ hm16_accumulate_packed(v4f_ acc, const float *__restrict__ a_row, const float *__restrict__ bp, int kq) {
+    float b[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) b[q] = bp[q * 64];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_row[4 * q + kq], b[q], acc, 0, 0, 0);
+    return acc;
+}
+
+struct HeadPackPtrs { const float *f[2]; const float *s[kMaxHeads]; };      // null f[0]: weights read unpacked
+
 __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__restrict__ dY, int64_t lddy,
                                                                const int32_t *__restrict__ active_rows,
                                                                const int32_t *__restrict__ seg_info, int64_t n_max,
@@ -744,7 +757,7 @@ __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__re
                                                                const float *__restrict__ W_user,
                                                                const float *__restrict__ W_item, float gscale,
                                                                float *__restrict__ G0, int64_t ldg, int scatter_cols,
-                                                               float *__restrict__ compact, SegSrc seg) {
+                                                               float *__restrict__ compact, SegSrc seg, HeadPackPtrs pk) {
     extern __shared__ float dys[];                       // [16][Cy + 4]
     __shared__ int64_t node[HM16];
     const int Cy = (1 + S) * d, ldy = Cy + 4;
@@ -811,13 +824,25 @@ __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__re
         const int c0 = t * 16;
         const int mb = c0 / d;
         v4f_ acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-        acc = hm16_accumulate(acc, a_row, (any_user ? W_user : W_item) + c0 + li, C, d, kq);
-        if (mixed) acc2 = hm16_accumulate(acc2, a_row, W_item + c0 + li, C, d, kq);
-        for (int h = 0; h < S; ++h) {
-            if (hp.mblock[h] != mb) continue;
-            const float *Wh = hp.w[h] + (c0 - mb * d) + li;
-            acc = hm16_accumulate(acc, a_row + (1 + h) * d, Wh, d, d, kq);
-            if (mixed) acc2 = hm16_accumulate(acc2, a_row + (1 + h) * d, Wh, d, d, kq);
+        if (pk.f[0] && d == 64) {
+            const int64_t ft = (int64_t)t * 16 * 64 + lane;                       // column tile t of the [C x 64] fusion operand
+            acc = hm16_accumulate_packed(acc, a_row, pk.f[any_user ? 0 : 1] + ft, kq);
+            if (mixed) acc2 = hm16_accumulate_packed(acc2, a_row, pk.f[1] + ft, kq);
+            for (int h = 0; h < S; ++h) {
+                if (hp.mblock[h] != mb) continue;
+                const float *bp = pk.s[h] + (int64_t)((c0 - mb * d) / 16) * 16 * 64 + lane;
+                acc = hm16_accumulate_packed(acc, a_row + (1 + h) * d, bp, kq);
+                if (mixed) acc2 = hm16_accumulate_packed(acc2, a_row + (1 + h) * d, bp, kq);
+            }
+        } else {
+            acc = hm16_accumulate(acc, a_row, (any_user ? W_user : W_item) + c0 + li, C, d, kq);
+            if (mixed) acc2 = hm16_accumulate(acc2, a_row, W_item + c0 + li, C, d, kq);
+            for (int h = 0; h < S; ++h) {
+                if (hp.mblock[h] != mb) continue;
+                const float *Wh = hp.w[h] + (c0 - mb * d) + li;
+                acc = hm16_accumulate(acc, a_row + (1 + h) * d, Wh, d, d, kq);
+                if (mixed) acc2 = hm16_accumulate(acc2, a_row + (1 + h) * d, Wh, d, d, kq);
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1208,12 +1233,42 @@ extern "C" int elimrec_head_bwd_input(const float *d_dY, int64_t lddy, const int
 // segment_apply + head_bwd_input in one launch (the MFMA form stages the dY rows in LDS anyway: it sums them
 // from the member gradient rows instead of reading them back). Falls back to the two launches when the MFMA
 // form does not apply.
+static int segment_apply_head_bwd_impl(const float *d_rows, int64_t n, int ld, const int32_t *d_active_rows,
+                                       const int32_t *d_seg_info, const float *d_scale, float *d_reduced,
+                                       const void *d_plan_workspace, size_t plan_workspace_bytes, int64_t U, int d,
+                                       int C, int S, const int *head_mblock, const float *d_W_user,
+                                       const float *d_W_item, const float *const *d_W_heads, float *d_compact,
+                                       const float *d_pack_bwd, void *stream);
+
 extern "C" int elimrec_segment_apply_head_bwd(const float *d_rows, int64_t n, int ld, const int32_t *d_active_rows,
                                               const int32_t *d_seg_info, const float *d_scale, float *d_reduced,
                                               const void *d_plan_workspace, size_t plan_workspace_bytes, int64_t U, int d,
                                               int C, int S, const int *head_mblock, const float *d_W_user,
                                               const float *d_W_item, const float *const *d_W_heads, float *d_compact,
                                               void *stream) {
+    return segment_apply_head_bwd_impl(d_rows, n, ld, d_active_rows, d_seg_info, d_scale, d_reduced, d_plan_workspace,
+                                       plan_workspace_bytes, U, d, C, S, head_mblock, d_W_user, d_W_item, d_W_heads, d_compact,
+                                       nullptr, stream);
+}
+
+extern "C" int elimrec_segment_apply_head_bwd_packed(const float *d_rows, int64_t n, int ld, const int32_t *d_active_rows,
+                                                     const int32_t *d_seg_info, const float *d_scale, float *d_reduced,
+                                                     const void *d_plan_workspace, size_t plan_workspace_bytes, int64_t U,
+                                                     int d, int C, int S, const int *head_mblock, const float *d_W_user,
+                                                     const float *d_W_item, const float *const *d_W_heads,
+                                                     float *d_compact, const float *d_pack_bwd, void *stream) {
+    ELIMREC_REQUIRE(d_pack_bwd, "segment_apply_head_bwd_packed: null pack pointer");
+    return segment_apply_head_bwd_impl(d_rows, n, ld, d_active_rows, d_seg_info, d_scale, d_reduced, d_plan_workspace,
+                                       plan_workspace_bytes, U, d, C, S, head_mblock, d_W_user, d_W_item, d_W_heads, d_compact,
+                                       d_pack_bwd, stream);
+}
+
+static int segment_apply_head_bwd_impl(const float *d_rows, int64_t n, int ld, const int32_t *d_active_rows,
+                                       const int32_t *d_seg_info, const float *d_scale, float *d_reduced,
+                                       const void *d_plan_workspace, size_t plan_workspace_bytes, int64_t U, int d,
+                                       int C, int S, const int *head_mblock, const float *d_W_user,
+                                       const float *d_W_item, const float *const *d_W_heads, float *d_compact,
+                                       const float *d_pack_bwd, void *stream) {
     ELIMREC_REQUIRE(d_rows && d_active_rows && d_seg_info && d_reduced && d_plan_workspace && d_W_user && d_W_item &&
                     d_compact, "segment_apply_head_bwd: null pointer");
     ELIMREC_REQUIRE(n > 0 && n < INT32_MAX && ld > 0 && ld % 4 == 0, "segment_apply_head_bwd: bad n/ld");
@@ -1241,15 +1296,22 @@ extern "C" int elimrec_segment_apply_head_bwd(const float *d_rows, int64_t n, in
         hp.w[h] = h < S ? d_W_heads[h] : nullptr;
         hp.mblock[h] = h < S ? head_mblock[h] : -1;
     }
-    // measured at the Tiktok shape: 32.4 us against 28.5 for the 32-row kernel -- the B operands here are read unpacked from
-    // L2 and the smaller MFMA doubles those loads; off unless ELIMREC_HEAD_BWD_ROWS=16
+    // 16-row tiles: with the weights read unpacked from L2 the smaller MFMA doubles the operand loads (32.4 us against
+    // 28.5 for the 32-row kernel at the Tiktok shape) -- used when the caller hands over the packed operands
+    // (recdim 64), or with ELIMREC_HEAD_BWD_ROWS=16
     static int rows16 = -1;
-    if (rows16 < 0) { const char *e = getenv("ELIMREC_HEAD_BWD_ROWS"); rows16 = (e && atoi(e) == 16) ? 1 : 0; }
-    if (rows16 && C % 16 == 0 && (1 + S) * d % 4 == 0) {
+    if (rows16 < 0) { const char *e = getenv("ELIMREC_HEAD_BWD_ROWS"); rows16 = e ? atoi(e) : 0; }
+    const bool packed = d_pack_bwd && d == 64 && rows16 != 32;
+    if ((packed || rows16 == 16) && C % 16 == 0 && (1 + S) * d % 4 == 0) {
         const size_t lds16 = (size_t)HM16 * ((1 + S) * d + 4) * sizeof(float);
+        HeadPackPtrs pk = {};
+        if (packed) {
+            pk.f[0] = d_pack_bwd; pk.f[1] = d_pack_bwd + (int64_t)C * 64;
+            for (int h = 0; h < S && h < kMaxHeads; ++h) pk.s[h] = d_pack_bwd + (int64_t)2 * C * 64 + (int64_t)h * 64 * 64;
+        }
         hipLaunchKernelGGL(head_bwd_input16_kernel, dim3((unsigned)((n + HM16 - 1) / HM16)), dim3(256), lds16,
                            (hipStream_t)stream, (const float *)d_reduced, (int64_t)ld, d_active_rows, d_seg_info, n, U, d, C, S, hp,
-                           d_W_user, d_W_item, 1.0f, (float *)nullptr, (int64_t)0, 0, d_compact, seg);
+                           d_W_user, d_W_item, 1.0f, (float *)nullptr, (int64_t)0, 0, d_compact, seg, pk);
         ELIMREC_LAUNCH_CHECK("segment_apply_head_bwd16");
         return 0;
     }

@@ -20,8 +20,8 @@ constexpr int HD = 64;            // recdim
 constexpr int HROWS = 32;         // rows per tile
 constexpr int HMAXM = 3;
 
-struct PackJob { const float *W; int64_t ld; int K; int64_t dst; };
-struct PackJobs { PackJob j[8]; int n; int first_block[9]; };
+struct PackJob { const float *W; int64_t ld; int K; int64_t dst; int N; int64_t sn, sk; };   // 16-row form: element (n, k) = W[n*sn + k*sk], N columns
+struct PackJobs { PackJob j[16]; int n; int first_block[17]; };
 
 // fragment-major copy of a [64 x K] weight matrix: element (n, k) at ((n / 32) * (K / 2) + k / 2) * 64 + (k & 1) * 32 + n % 32,
 // i.e. the B operand of MFMA step s of column tile nt is the 64 consecutive floats at ((nt * K/2) + s) * 64
@@ -235,13 +235,13 @@ __global__ __launch_bounds__(256) void pack_head_weights16_kernel(PackJobs jobs,
     int q = 0;
     while (q + 1 < jobs.n && (int)blockIdx.x >= jobs.first_block[q + 1]) ++q;
     const PackJob &jb = jobs.j[q];
-    const int64_t total = (int64_t)HD * jb.K;
+    const int64_t total = (int64_t)jb.N * jb.K;
     const int nb = jobs.first_block[q + 1] - jobs.first_block[q];
     for (int64_t e = (int64_t)((int)blockIdx.x - jobs.first_block[q]) * 256 + threadIdx.x; e < total; e += (int64_t)nb * 256) {
         const int lane = (int)(e & 63);
         const int64_t blk = e >> 6;                 // ct * (K/4) + s
         const int ct = (int)(blk / (jb.K / 4)), s = (int)(blk - (int64_t)ct * (jb.K / 4));
-        pk[jb.dst + e] = jb.W[(int64_t)(ct * 16 + (lane & 15)) * jb.ld + 4 * s + (lane >> 4)];
+        pk[jb.dst + e] = jb.W[(int64_t)(ct * 16 + (lane & 15)) * jb.sn + (int64_t)(4 * s + (lane >> 4)) * jb.sk];
     }
 }
 
@@ -374,10 +374,12 @@ using namespace elimrec;
 
 extern "C" size_t elimrec_head_pack_floats(int n_mod, const int *D) {
     if (n_mod < 0 || n_mod > HMAXM) return 0;
-    size_t f = 0;
-    for (int m = 0; m < n_mod; ++m) f += (size_t)HD * D[m];
-    f += (size_t)2 * HD * (1 + n_mod) * HD + (size_t)n_mod * HD * HD;
-    return f;
+    return (size_t)head_pack_layout(n_mod, D).total;
+}
+
+extern "C" size_t elimrec_head_pack_bwd_offset(int n_mod, const int *D) {
+    if (n_mod < 0 || n_mod > HMAXM) return 0;
+    return (size_t)head_pack_layout(n_mod, D).fwd_total;
 }
 
 extern "C" int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg_info, int64_t R, const float *d_out0,
@@ -400,16 +402,17 @@ extern "C" int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg
     int64_t off = 0;
     int lds_f = 2 * HROWS * (HD + 1);
     int blocks = 0;
-    auto add_job = [&](const float *W, int K) {
+    auto add_job_g = [&](const float *W, int N, int K, int64_t sn, int64_t sk) {
         PackJob &j = pj.j[pj.n];
-        j.W = W; j.ld = K; j.K = K; j.dst = off;
+        j.W = W; j.ld = K; j.K = K; j.dst = off; j.N = N; j.sn = sn; j.sk = sk;
         pj.first_block[pj.n] = blocks;
-        blocks += (HD * K + 255) / 256 > 64 ? 64 : (HD * K + 255) / 256;
+        blocks += (N * K + 255) / 256 > 64 ? 64 : (N * K + 255) / 256;
         ++pj.n;
         const int64_t at = off;
-        off += (int64_t)HD * K;
+        off += (int64_t)N * K;
         return at;
     };
+    auto add_job = [&](const float *W, int K) { return add_job_g(W, HD, K, K, 1); };
     static int form16 = -1;
     if (form16 < 0) { const char *e = getenv("ELIMREC_HEAD_ROWS"); form16 = (e && atoi(e) == 32) ? 0 : 1; }
     const int rows_t = form16 ? H16 : HROWS;
@@ -424,6 +427,12 @@ extern "C" int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg
     a.off_Wf[0] = add_job(d_Wf_user, C);
     a.off_Wf[1] = add_job(d_Wf_item, C);
     for (int m = 0; m < n_mod; ++m) { a.off_Ws[m] = add_job(d_Ws[m], HD); a.bias_s[m] = d_bs ? d_bs[m] : nullptr; }
+    if (form16) {        // the head backward's operands B[k][c] = W[k][c] (common.h: head_pack_layout)
+        add_job_g(d_Wf_user, C, HD, 1, C);
+        add_job_g(d_Wf_item, C, HD, 1, C);
+        for (int m = 0; m < n_mod; ++m) add_job_g(d_Ws[m], HD, HD, 1, HD);
+        ELIMREC_REQUIRE(off == head_pack_layout(n_mod, D).total, "head_fwd_fused: pack layout mismatch");
+    }
     pj.first_block[pj.n] = blocks;
     a.out_off = lds_f; lds_f += rows_t * (C + (form16 ? 4 : 1));
     a.part_off = lds_f; if (!form16) lds_f += (1 + n_mod) * HROWS * HD;

@@ -539,8 +539,9 @@ def head_bwd_input(dY, active_rows, seg_info, U, d, C, head_mblock, W_user, W_it
 
 
 def segment_apply_head_bwd(rows, active_rows, seg_info, reduced, plan_workspace, U, d, C, head_mblock, W_user, W_item,
-                           W_heads, compact, scale=None):
-    """segment_apply + head_bwd_input(compact=...) in one launch; `reduced` receives dY."""
+                           W_heads, compact, scale=None, pack_bwd=None):
+    """segment_apply + head_bwd_input(compact=...) in one launch; `reduced` receives dY. pack_bwd: the backward region of
+    the fused head's packed weights (a view starting at head_pack_bwd_offset floats), if the forward left it behind."""
     n, ld = rows.shape
     S = len(W_heads)
     assert rows.is_contiguous() and reduced.is_contiguous() and reduced.shape[1] == ld and compact.is_contiguous()
@@ -549,6 +550,13 @@ def segment_apply_head_bwd(rows, active_rows, seg_info, reduced, plan_workspace,
     wp = (ctypes.c_void_p * max(S, 1))(*[_dev(w, "W_head") for w in W_heads]) if S else (ctypes.c_void_p * 1)(None)
     for w in list(W_heads) + [W_user, W_item]:
         assert w.is_contiguous()
+    if pack_bwd is not None:
+        _lib.check(_lib.load().elimrec_segment_apply_head_bwd_packed(
+            _dev(rows, "rows"), n, ld, _dev(active_rows, "active_rows", torch.int32), _dev(seg_info, "seg_info", torch.int32),
+            _dev(scale, "scale"), _dev(reduced, "reduced"), _dev(plan_workspace, "plan_workspace", torch.uint8),
+            plan_workspace.numel(), U, d, C, S, mb, _dev(W_user, "W_user"), _dev(W_item, "W_item"), wp,
+            _dev(compact, "compact"), _dev(pack_bwd, "pack_bwd"), _stream()), "segment_apply_head_bwd_packed")
+        return
     _lib.check(_lib.load().elimrec_segment_apply_head_bwd(
         _dev(rows, "rows"), n, ld, _dev(active_rows, "active_rows", torch.int32), _dev(seg_info, "seg_info", torch.int32),
         _dev(scale, "scale"), _dev(reduced, "reduced"), _dev(plan_workspace, "plan_workspace", torch.uint8),
@@ -629,6 +637,11 @@ def sample_triplets(user_ids, ptr, items, num_items, n, seed, epoch, users, pos,
 def head_pack_floats(dims):
     arr = (ctypes.c_int * max(len(dims), 1))(*dims)
     return int(_lib.load().elimrec_head_pack_floats(len(dims), arr))
+
+
+def head_pack_bwd_offset(dims):
+    arr = (ctypes.c_int * max(len(dims), 1))(*dims)
+    return int(_lib.load().elimrec_head_pack_bwd_offset(len(dims), arr))
 
 
 def head_fwd_fused(act, seg_info, out0, narrow, c, S, Wm, bm, Wf_user, bf_user, Wf_item, bf_item, Ws, bs, pack, OutAct, YAct, d, phase=0):

@@ -241,8 +241,11 @@ class ColumnShardEngine(object):
             lds = 4 * (2 * 32 * 65 + sum(32 * (D + 1) for D in dims) + 32 * (m.C + 1) + (1 + m.S) * 32 * 64)
             self._fused = (os.environ.get("ELIMREC_FUSED_HEAD", "1") != "0" and m.latent_dim == 64 and 1 <= m.S <= 3
                            and m.mm_fusion_mode == "concat" and lds <= 158 * 1024)
+            self._pack_bwd_off = 0
             if self._fused:
                 self._pack = torch.empty(ops.head_pack_floats(dims), dtype=torch.float32, device=m._device())
+                if os.environ.get("ELIMREC_HEAD_ROWS", "16") != "32" and os.environ.get("ELIMREC_HEAD_BWD_ROWS", "16") != "32":
+                    self._pack_bwd_off = ops.head_pack_bwd_offset(dims)
         return self._fused
 
     def _side_stream(self):
@@ -441,8 +444,10 @@ class ColumnShardEngine(object):
         m = self.model
         ws, d = m._ws, m.latent_dim
         R = m._plan_n
+        # the head backward reads its weight operands from the packed copy the fused forward left behind (16-row forms)
+        pack_bwd = self._pack[self._pack_bwd_off:] if (self._fused_head_ok() and self._pack_bwd_off) else None
         self._grads = m._backward_batch_rows(ws, scale, ws["grad_rows"], R, head_only=True,
-                                             w_stream=self._side_stream() if self.world == 1 else None)
+                                             w_stream=self._side_stream() if self.world == 1 else None, pack_bwd=pack_bwd)
         wg = ws["flat_grad"][ws["tail_off"]:]
         if self.world == 1:       # one rank owns every column: the merge reads the dOut rows themselves
             return ws["dOutR"][:R].view(1, R, m.C), wg

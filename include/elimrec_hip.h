@@ -371,6 +371,14 @@ int elimrec_segment_apply_head_bwd(const float *d_rows, int64_t n, int ld, const
                                    const void *d_plan_workspace, size_t plan_workspace_bytes, int64_t U, int d, int C,
                                    int S, const int *head_mblock, const float *d_W_user, const float *d_W_item,
                                    const float *const *d_W_heads, float *d_compact, void *stream);
+/* The same with the weight operands taken from the packed copy elimrec_head_fwd_fused (phase 0/1, 16-row form) leaves
+ * behind: d_pack_bwd = d_pack + elimrec_head_pack_bwd_offset(n_mod, D) floats; recdim 64, head h = feature table h. */
+int elimrec_segment_apply_head_bwd_packed(const float *d_rows, int64_t n, int ld, const int32_t *d_active_rows,
+                                          const int32_t *d_seg_info, const float *d_scale, float *d_reduced,
+                                          const void *d_plan_workspace, size_t plan_workspace_bytes, int64_t U,
+                                          int d, int C, int S, const int *head_mblock, const float *d_W_user,
+                                          const float *d_W_item, const float *const *d_W_heads,
+                                          float *d_compact, const float *d_pack_bwd, void *stream);
 
 /* ---------------------------------------------------------------- embedding gradients (K2 bwd)
  * dE_user[u, j] = sum_m G[u, m*d + j];  dE_item[i, j] = G[U+i, j]   (CatBackward of :239). */
@@ -613,6 +621,7 @@ int elimrec_adam_step_out(const float *d_p_in, float *d_p_out, const float *d_g,
  * issue this on a second stream under the forward hops); 2 = head only, d_pack holds the packed weights.
  * recdim must be 64 and the row tiles must fit LDS, else ELIMREC_E_UNSUPPORTED (callers keep the batched GEMMs). */
 size_t elimrec_head_pack_floats(int n_mod, const int *D);
+size_t elimrec_head_pack_bwd_offset(int n_mod, const int *D);   /* first float of the head BACKWARD's operands */
 int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg_info, int64_t R, const float *d_out0,
                            int64_t ld_out0, const float *d_narrow, int64_t ld_nar, const float *d_c, int n_mod,
                            const float *const *d_S, const int64_t *ldS, const int *D, const float *const *d_Wm,
