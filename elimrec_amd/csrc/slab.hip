@@ -195,7 +195,7 @@ struct RowsArgs {
 // columns cl, cl + LR, ... of the row's nc4 = ns*w/4.
 template <int LR>
 __global__ __launch_bounds__(256) void slab_rows_kernel(RowsArgs a) {
-    constexpr int U8 = 8;
+    constexpr int U8 = 16;
     const int64_t s = (int64_t)blockIdx.x * (256 / LR) + threadIdx.x / LR;
     const int cl = threadIdx.x % LR;
     if (s >= a.R * a.n_lists) return;
