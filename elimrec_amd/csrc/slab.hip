@@ -1137,7 +1137,11 @@ template <int LPR, int VPL, bool IN_BF16, bool MASKED>
 __device__ __forceinline__ void tile_gather(const TierArgs &t, int ti, int64_t in_base, int off, int steps, int glen, int lane, int sub,
                                             float (&acc)[VPL]) {
     constexpr int G = 64 / LPR;
+#ifdef ELIMREC_TILE_UB
+    constexpr int UB = ELIMREC_TILE_UB;
+#else
     constexpr int UB = 8;                                  // neighbours per lane group in flight
+#endif
     const StreamArgs &a = t.s;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) acc[i] = 0.f;
@@ -1318,8 +1322,11 @@ __device__ __forceinline__ void tier_body(const TierArgs &t) {
     }
 }
 
+#ifndef ELIMREC_TILE_WAVES
+#define ELIMREC_TILE_WAVES 1
+#endif
 template <int LPR, int VPL, bool IN_BF16, bool OUT_BF16, bool MASKED>
-__global__ __launch_bounds__(256) void sell_tier_kernel(TierArgs t) {
+__global__ __launch_bounds__(256, ELIMREC_TILE_WAVES) void sell_tier_kernel(TierArgs t) {
     tier_body<LPR, VPL, IN_BF16, OUT_BF16, MASKED, false>(t);
 }
 
