@@ -1,9 +1,8 @@
 """Fused head forward alone, with phases switched off (ELIMREC_HEAD_DBG bits) -- where do its microseconds go. Dev tool."""
 import os, subprocess, sys
-if len(sys.argv) == 1:
-    for dbg in (0, 16, 1, 2, 4, 8, 1 | 2 | 4 | 8 | 16, 2 | 4, 1 | 8):
-        env = dict(os.environ, ELIMREC_HEAD_DBG=str(dbg))
-        subprocess.run([sys.executable, __file__, str(dbg)], env=env)
+if len(sys.argv) == 1:       # the ELIMREC_HEAD_DBG phase switches this tool used were removed from the kernel after the ablation
+    for rows in ("16", "32"):
+        subprocess.run([sys.executable, __file__, rows], env=dict(os.environ, ELIMREC_HEAD_ROWS=rows))
     sys.exit(0)
 import torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -32,4 +31,4 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 for _ in range(50): run()
 e1.record(); torch.cuda.synchronize()
-print("dbg %2d: %.1f us per (pack +) head_fwd_fused + bpr_head_rows" % (int(sys.argv[1]), e0.elapsed_time(e1) * 1e3 / 50))
+print("%s-row tiles: %.1f us per head forward + BPR head (+ loss sum)" % (sys.argv[1], e0.elapsed_time(e1) * 1e3 / 50))
