@@ -459,9 +459,8 @@ typedef float v4f_s __attribute__((ext_vector_type(4)));
 
 constexpr int t16_sub(int pass) { return pass == 1 ? 1 : 1; }     // 16-item tiles per barrier interval (measured: 4 / 2 are slower -- fewer, fatter workgroups)
 
-template <int PASS, int NB, int PT, int FM, bool FAST>
-__global__ __launch_bounds__(512, 4) void score_t16_kernel(ScoreArgs a, int n_tiles) {
-    constexpr int D = 64;
+template <int PASS, int NB, int PT, int FM, bool FAST, int D>
+__global__ __launch_bounds__(512, (D > 64 ? 2 : 4)) void score_t16_kernel(ScoreArgs a, int n_tiles) {
     constexpr int NH = (PASS == 1) ? 1 : NB;
     constexpr int COLS = NH * D, LD = COLS + 4;
     constexpr int SUB = t16_sub(PASS), CI = SUB * TI;  // items per chunk
@@ -1047,7 +1046,7 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
         const char *e = getenv("ELIMREC_SCORE_T16");
         use_t16 = (e && e[0] == '0') ? 0 : 1;
     }
-    if (use_mfma && use_t16 && d == 64 && S >= 1 && S <= 3) {
+    if (use_mfma && use_t16 && (d == 32 || d == 64 || d == 128) && S >= 1 && S <= 3) {
         // 16 users per wave, 128 per workgroup, a persistent grid over 16-item tiles (two workgroups per CU)
         const int t16 = (int)((I + TI - 1) / TI);
         const bool fast = score_math() == 1;
@@ -1066,19 +1065,25 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
             return dim3((unsigned)((chunks + per - 1) / per), (B + TW * TU - 1) / (TW * TU));
         };
         const dim3 grid1 = t16_grid(1), grid = t16_grid(2);
-        auto t16_lds = [](int pass, int nb) {
-            const int cols = (pass == 1 ? 1 : nb) * 64;
+        auto t16_lds = [d](int pass, int nb) {
+            const int cols = (pass == 1 ? 1 : nb) * d;
             return ((size_t)2 * t16_sub(pass) * TI * (cols + 4) + (size_t)TW * TU * (nb > 1 ? nb - 1 : 1) + TW * TU) * sizeof(float);
         };
-#define ELIMREC_T16_LAUNCH(PASS, NB, PT, FM, FAST, GRID)                                                     \
+#define ELIMREC_T16_LAUNCH_D(PASS, NB, PT, FM, FAST, GRID, DD)                                               \
     do {                                                                                                   \
         static bool attr = false;                                                                          \
         if (!attr && t16_lds(PASS, NB) > 64 * 1024) {                                                      \
-            (void)hipFuncSetAttribute((const void *)score_t16_kernel<PASS, NB, PT, FM, FAST>,              \
+            (void)hipFuncSetAttribute((const void *)score_t16_kernel<PASS, NB, PT, FM, FAST, DD>,          \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)t16_lds(PASS, NB)); \
             attr = true;                                                                                   \
         }                                                                                                  \
-        hipLaunchKernelGGL((score_t16_kernel<PASS, NB, PT, FM, FAST>), GRID, dim3(512), t16_lds(PASS, NB), s, a, t16); \
+        hipLaunchKernelGGL((score_t16_kernel<PASS, NB, PT, FM, FAST, DD>), GRID, dim3(512), t16_lds(PASS, NB), s, a, t16); \
+    } while (0)
+#define ELIMREC_T16_LAUNCH(PASS, NB, PT, FM, FAST, GRID)                                                     \
+    do {                                                                                                   \
+        if (d == 64) ELIMREC_T16_LAUNCH_D(PASS, NB, PT, FM, FAST, GRID, 64);                               \
+        else if (d == 128) ELIMREC_T16_LAUNCH_D(PASS, NB, PT, FM, FAST, GRID, 128);                        \
+        else ELIMREC_T16_LAUNCH_D(PASS, NB, PT, FM, FAST, GRID, 32);                                       \
     } while (0)
 #define ELIMREC_T16_P2(NB, PT, FM)                                                                           \
     do {                                                                                                   \
@@ -1109,6 +1114,7 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
 #undef ELIMREC_T16
 #undef ELIMREC_T16_P2
 #undef ELIMREC_T16_LAUNCH
+#undef ELIMREC_T16_LAUNCH_D
     } else if (use_mfma && use_resident && d == 64 && S >= 1 && S <= 3) {
         // users resident in registers, a persistent grid over the item tiles (two workgroups per CU)
         dim3 grid((unsigned)(tiles < 512 ? tiles : 512), (B + MU - 1) / MU);

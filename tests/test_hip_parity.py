@@ -1040,14 +1040,14 @@ def test_topk_paths_agree_with_stable_sort():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("with_scores", [True, False])
-def test_tile_guided_topk_at_recdim_64(with_scores):
-    """The evaluator's own configuration (recdim 64: 16-user-per-wave scorer, selection from tile maxima, bitmap masking)
+@pytest.mark.parametrize("with_scores,d", [(True, 64), (False, 64), (False, 128), (True, 32)])
+def test_tile_guided_topk_at_recdim_64(with_scores, d):
+    """The evaluator's own configuration (recdim 32 / 64 / 128: 16-user-per-wave scorer, selection from tile maxima, bitmap masking)
     against a stable sort of the full masked score matrix: continuous scores and massive ties; rows with nothing, a few,
     hundreds (K + masked > 256 group maxima -> fall-back) and all-but-4 items masked; 200 users (two user groups per
     launch); with the caller's score matrix and with the private one (top-K only)."""
     from elimrec_amd import ops
-    U, I, d, S = 260, 3000, 64, 3
+    U, I, S = 260, 3000, 3
     Cy = (1 + S) * d
     g = torch.Generator().manual_seed(5)
     Yr = torch.randn(U + I, Cy, generator=g) * 0.3
