@@ -68,7 +68,11 @@ class UniEvaluator(object):
         flat = np.fromiter((i for x in lists for i in x), dtype=np.int32, count=int(ptr[-1]))
         return torch.from_numpy(ptr).to(device), torch.from_numpy(flat).to(device)
 
-    def evaluate(self, model, test_users=None):
+    def evaluate(self, model, test_users=None, shard=None):
+        """shard = (rank, world): this process scores a contiguous 1/world slice of the users and the per-user metric rows
+        are summed across the ranks (all_reduce of the zero-filled [users x metrics*K] matrix), so every rank ends with
+        the same rows -- and, the final mean being taken over the same matrix, the same bits -- as a single process.
+        Default: the ranks of an initialised torch.distributed job (the cached tables are replicated on every rank)."""
         if test_users is None:
             if getattr(self, "_default_users", None) is None:
                 self._default_users = list(self.user_pos_test.keys())
@@ -79,15 +83,32 @@ class UniEvaluator(object):
         if not hasattr(model, "predict_device"):
             raise TypeError("model must expose predict_device(); host-side ranking is not part of this package")
         test_users = list(test_users)
-        all_dev = torch.empty(len(test_users), self.metrics_num * self.max_top, dtype=torch.float32, device=model._require_gpu())
-        at = 0
-        for k, batch_users in enumerate(DataIterator(test_users, batch_size=self.block_users, shuffle=False, drop_last=False)):
-            self.evaluate_batch(model, batch_users, cache_key=k if cached else None, out=all_dev[at:at + len(batch_users)])
-            at += len(batch_users)
+        all_dev = self.metric_rows(model, test_users, shard=shard, cached=cached)
         all_rows = all_dev.cpu().numpy()                                  # [users, metrics*K]
         final = np.mean(all_rows, axis=0).reshape(self.metrics_num, self.max_top)[:, self.top_show - 1].reshape(-1)
         buf = "\t".join(("%.8f" % x).ljust(12) for x in final)
         return final, buf
+
+    def metric_rows(self, model, test_users, shard=None, cached=False, reduce=True):
+        """Per-user metric rows of `test_users` on the device, [len(test_users), metrics*K]; with shard = (rank, world)
+        only this rank's slice is computed (the rest zero) and `reduce` sums the matrix over the ranks."""
+        import torch.distributed as dist
+        if shard is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            shard = (dist.get_rank(), dist.get_world_size())
+        n = len(test_users)
+        sharded = shard is not None and shard[1] > 1
+        lo, hi = (n * shard[0] // shard[1], n * (shard[0] + 1) // shard[1]) if sharded else (0, n)
+        alloc = torch.zeros if sharded else torch.empty
+        all_dev = alloc(n, self.metrics_num * self.max_top, dtype=torch.float32, device=model._require_gpu())
+        at = lo
+        mine = test_users[lo:hi]
+        for k, batch_users in enumerate(DataIterator(mine, batch_size=self.block_users, shuffle=False, drop_last=False)):
+            key = (k, lo, hi) if cached else None
+            self.evaluate_batch(model, batch_users, cache_key=key, out=all_dev[at:at + len(batch_users)])
+            at += len(batch_users)
+        if sharded and reduce:
+            dist.all_reduce(all_dev, op=dist.ReduceOp.SUM)
+        return all_dev
 
     def evaluate_batch(self, model, batch_users, return_topk=False, cache_key=None, out=None):
         """Per-user metric rows [len(batch_users), metrics*K] (device tensor) for one user block.

@@ -1136,3 +1136,21 @@ def test_evaluator_results_do_not_depend_on_the_users_per_launch(monkeypatch):
         evalr.block_users = blk
         res[blk], _ = evalr.evaluate(model, users[:])
     assert np.array_equal(res[7], res[128]) and np.array_equal(res[128], res[4096])
+
+
+@pytest.mark.gpu
+def test_rank_sharded_evaluation_equals_one_process():
+    """Multi-GPU validation: every rank scores a contiguous slice of the users and the zero-filled metric-row matrices
+    are summed (all_reduce) -- simulated here by adding the W matrices on one GPU: bitwise the single-process rows."""
+    g = load_golden("ml3")
+    model, _ = build_model_from_fixture(g, DEV)
+    _load_cache(model, g)
+    model.fusion_mode, model.predict_type = "rubi", "TIE"
+    evalr = model.test_evaluator.evaluator
+    users = list(evalr.user_pos_test.keys())
+    whole = evalr.metric_rows(model, users)
+    for W in (2, 3, 8):
+        parts = [evalr.metric_rows(model, users, shard=(r, W), reduce=False) for r in range(W)]
+        assert torch.equal(sum(parts[1:], parts[0]), whole), W
+    res, buf = evalr.evaluate(model)
+    assert np.array_equal(res, np.mean(whole.cpu().numpy(), axis=0).reshape(evalr.metrics_num, evalr.max_top)[:, evalr.top_show - 1].reshape(-1))
