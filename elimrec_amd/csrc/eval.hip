@@ -103,6 +103,8 @@ struct ScoreArgs {
     const float *sqn;                // [N x (1+S)] squared L2 norms of every head block of every row of Y
     float *tile_max;                 // pass 2, optional: [B x tmax_ld] max score of every 16-item tile (BEFORE masking)
     int64_t tmax_ld;
+    int64_t item0, item_end;         // score_t16_kernel: the launch covers items [item0, item_end); scores / tile_max are
+                                     // indexed relative to item0 (a chunk of the catalogue when only top-K is wanted)
 };
 
 __device__ __forceinline__ float fuse(int mode, float x, const float *z, int S, uint32_t mask) {
@@ -502,8 +504,8 @@ __global__ __launch_bounds__(512, (D > 64 ? 2 : 4)) void score_t16_kernel(ScoreA
             const int e = (tid + 512 * q) * 4;
             if (e < CI * COLS) {
                 const int r = e / COLS, c = e - r * COLS;
-                const int64_t item = (int64_t)chunk * CI + r;
-                pf[q] = item < a.I ? *reinterpret_cast<const float4 *>(a.Y + (a.U + item) * a.ldy + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int64_t item = a.item0 + (int64_t)chunk * CI + r;
+                pf[q] = item < a.item_end ? *reinterpret_cast<const float4 *>(a.Y + (a.U + item) * a.ldy + c) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
     };
@@ -526,10 +528,10 @@ __global__ __launch_bounds__(512, (D > 64 ? 2 : 4)) void score_t16_kernel(ScoreA
         if (PASS != 2 || NB <= 1) return;
 #pragma unroll
         for (int sub = 0; sub < SUB; ++sub) {
-            const int64_t item = ((int64_t)chunk * SUB + sub) * TI + li;
+            const int64_t item = a.item0 + ((int64_t)chunk * SUB + sub) * TI + li;
 #pragma unroll
             for (int h = 0; h + 1 < NB; ++h)
-                dst[sub * (NB - 1) + h] = (item < a.I && ptype != 0) ? a.sqn[(a.U + item) * NB + 1 + h] : 1.f;
+                dst[sub * (NB - 1) + h] = (item < a.item_end && ptype != 0) ? a.sqn[(a.U + item) * NB + 1 + h] : 1.f;
         }
     };
     if ((int)blockIdx.x < n_chunks) { load_chunk(blockIdx.x); load_sqn(blockIdx.x, sq_cur); store_chunk(it0); }
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(512, (D > 64 ? 2 : 4)) void score_t16_kernel(ScoreA
         for (int sub = 0; sub < SUB; ++sub) {
             const int tile = chunk * SUB + sub;
             if (tile >= n_tiles) break;               // workgroup-uniform
-            const int64_t i0 = (int64_t)tile * TI;
+            const int64_t i0 = a.item0 + (int64_t)tile * TI;
             v4f_s acc[NH];
             const float *bp = (cur ? it1 : it0) + (sub * TI + li) * LD + kq;
 #pragma unroll
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(512, (D > 64 ? 2 : 4)) void score_t16_kernel(ScoreA
             }
             // lane: item i0 + li, users wave*16 + 4*kq + r
             const int64_t item = i0 + li;
-            const bool item_ok = item < a.I;
+            const bool item_ok = item < a.item_end;
             if (PASS == 1) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(512, (D > 64 ? 2 : 4)) void score_t16_kernel(ScoreA
                         }
                     }
                     const bool row_ok = b0 + urow < a.B;
-                    if (item_ok && row_ok) a.scores[(int64_t)(b0 + urow) * a.lds + item] = out;
+                    if (item_ok && row_ok) a.scores[(int64_t)(b0 + urow) * a.lds + (item - a.item0)] = out;
                     if (a.tile_max) {                               // max over the tile's 16 items (lanes li) of this user
                         const float mx = row16_max(item_ok ? out : -INFINITY);
                         if (li == 0 && row_ok) a.tile_max[(int64_t)(b0 + urow) * a.tmax_ld + tile] = mx;
@@ -670,17 +672,16 @@ __global__ void mask_train_kernel(float *__restrict__ scores, int64_t lds, const
 
 // Top-K by (score desc, index asc): K rounds; round r takes the best element strictly after the
 // previous pick in that total order. One workgroup per row.
-__global__ __launch_bounds__(1024) void topk_kernel(const float *__restrict__ scores, int64_t lds, int64_t I, int K,
-                                                    int32_t *__restrict__ out_idx, float *__restrict__ out_val,
-                                                    const int32_t *__restrict__ only_if,
-                                                    const uint32_t *__restrict__ mask_bits = nullptr, int64_t bits_ld = 0) {
+// K rounds over one row by the whole workgroup (any multiple of 64 threads <= 1024): round r takes the best element strictly
+// after the previous pick in the order (score desc, index asc). item0 / ldo / oo: the row holds items [item0, item0 + I) of
+// the catalogue (a chunk when only top-K is wanted); results go to out[b * ldo + oo + rank] with catalogue item ids.
+__device__ void topk_rounds(const float *__restrict__ row, int64_t I, int K, int b, int32_t *__restrict__ out_idx,
+                            float *__restrict__ out_val, const uint32_t *__restrict__ mask_bits, int64_t bits_ld, int64_t item0,
+                            int64_t ldo, int64_t oo) {
     __shared__ float sv[16];
     __shared__ int si[16];
     __shared__ float last_v;
     __shared__ int last_i;
-    const int b = blockIdx.x;
-    if (only_if && only_if[b] == 0) return;        // this row was finished by topk_select_kernel
-    const float *row = scores + (int64_t)b * lds;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float pv = INFINITY;
     int pi = -1;
@@ -689,7 +690,7 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float *__restrict__ sc
         int bi = INT32_MAX;
         for (int64_t i = threadIdx.x; i < I; i += blockDim.x) {
             float v = row[i];
-            if (mask_bits && ((mask_bits[(int64_t)b * bits_ld + (i >> 5)] >> (i & 31)) & 1u)) v = -INFINITY;   // a masked item
+            if (mask_bits && ((mask_bits[(int64_t)b * bits_ld + ((item0 + i) >> 5)] >> ((item0 + i) & 31)) & 1u)) v = -INFINITY;   // a masked item
             const bool after = (r == 0) || (v < pv) || (v == pv && (int)i > pi);
             if (after && (v > bv || (v == bv && (int)i < bi))) { bv = v; bi = (int)i; }
         }
@@ -707,13 +708,23 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float *__restrict__ sc
             for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
                 if (sv[w] > fv || (sv[w] == fv && si[w] < fi)) { fv = sv[w]; fi = si[w]; }
             last_v = fv; last_i = fi;
-            out_idx[(int64_t)b * K + r] = (fi == INT32_MAX) ? -1 : fi;
-            if (out_val) out_val[(int64_t)b * K + r] = fv;
+            out_idx[(int64_t)b * ldo + oo + r] = (fi == INT32_MAX) ? -1 : (int32_t)(item0 + fi);
+            if (out_val) out_val[(int64_t)b * ldo + oo + r] = fv;
         }
         __syncthreads();
         pv = last_v; pi = last_i;
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(1024) void topk_kernel(const float *__restrict__ scores, int64_t lds, int64_t I, int K,
+                                                    int32_t *__restrict__ out_idx, float *__restrict__ out_val,
+                                                    const int32_t *__restrict__ only_if,
+                                                    const uint32_t *__restrict__ mask_bits, int64_t bits_ld,
+                                                    int64_t item0, int64_t ldo, int64_t oo) {
+    const int b = blockIdx.x;
+    if (only_if && only_if[b] == 0) return;        // this row was finished by topk_select_kernel
+    topk_rounds(scores + (int64_t)b * lds, I, K, b, out_idx, out_val, mask_bits, bits_ld, item0, ldo, oo);
 }
 
 // Fast path of the same selection (identical result): two sweeps of the row instead of K.
@@ -797,7 +808,8 @@ __global__ __launch_bounds__(256) void topk_tiles_kernel(const float *__restrict
                                                          const float *__restrict__ tile_max, int64_t tmax_ld, int n_tiles, int K,
                                                          const int64_t *__restrict__ mask_ptr, const uint32_t *__restrict__ mask_bits,
                                                          int64_t bits_ld, int32_t *__restrict__ out_idx,
-                                                         float *__restrict__ out_val, int32_t *__restrict__ fallback) {
+                                                         float *__restrict__ out_val, int32_t *__restrict__ fallback,
+                                                         int64_t item0, int64_t ldo, int64_t oo) {
     __shared__ float gm[256];
     __shared__ float cv[TK_CAP];
     __shared__ int ci[TK_CAP];
@@ -807,13 +819,24 @@ __global__ __launch_bounds__(256) void topk_tiles_kernel(const float *__restrict
     const int b = blockIdx.x, t = threadIdx.x;
     const float *row = scores + (int64_t)b * lds;
     const float *tmx = tile_max + (int64_t)b * tmax_ld;
-    const uint32_t *bits = mask_bits ? mask_bits + (int64_t)b * bits_ld : nullptr;
-    const int64_t n_masked = mask_ptr ? mask_ptr[b + 1] - mask_ptr[b] : 0;
+    // the bitmap words of this row's item range (item0 is a multiple of 32)
+    const uint32_t *bits = mask_bits ? mask_bits + (int64_t)b * bits_ld + (item0 >> 5) : nullptr;
+    __shared__ int n_msk;
     float m = -INFINITY;
     for (int i = t; i < n_tiles; i += 256) m = fmaxf(m, tmx[i]);
     gm[t] = m;
-    if (t == 0) { cnt = 0; n_ct = 0; tau = -INFINITY; }
+    if (t == 0) { cnt = 0; n_ct = 0; tau = -INFINITY; n_msk = 0; }
     __syncthreads();
+    if (bits && mask_ptr) {          // masked items inside the range: the whole list when the range is the catalogue
+        if (item0 == 0 && I + 31 >= bits_ld * 32) { if (t == 0) n_msk = (int)(mask_ptr[b + 1] - mask_ptr[b]); }
+        else {
+            int c = 0;
+            for (int64_t w = t; w < (I + 31) / 32; w += 256) c += __popc(bits[w]);
+            if (c) atomicAdd(&n_msk, c);
+        }
+    }
+    __syncthreads();
+    const int64_t n_masked = n_msk;
     {
         int rank = 0;
         for (int j = 0; j < 256; ++j) rank += tk_before(gm[j], j, m, t) ? 1 : 0;
@@ -844,16 +867,42 @@ __global__ __launch_bounds__(256) void topk_tiles_kernel(const float *__restrict
     }
     __syncthreads();
     const int n = cnt;
-    if (n > TK_CAP || n < K || th == -INFINITY) {  // workgroup-uniform
-        if (t == 0) fallback[b] = 1;
+    if (n > TK_CAP || n < K || th == -INFINITY) {  // workgroup-uniform: the K-round sweep, by this workgroup (rare)
+        if (t == 0 && fallback) fallback[b] = 1;
+        topk_rounds(row, I, K, b, out_idx, out_val, mask_bits, bits_ld, item0, ldo, oo);
         return;
     }
-    if (t == 0) fallback[b] = 0;
+    if (t == 0 && fallback) fallback[b] = 0;
     for (int c = t; c < n; c += 256) {
         int rank = 0;
         const float mv = cv[c];
         const int mi = ci[c];
         for (int j = 0; j < n; ++j) rank += tk_before(cv[j], ci[j], mv, mi) ? 1 : 0;
+        if (rank < K) {
+            out_idx[(int64_t)b * ldo + oo + rank] = (int32_t)(item0 + mi);
+            if (out_val) out_val[(int64_t)b * ldo + oo + rank] = mv;
+        }
+    }
+}
+
+// Top-K of the per-chunk top-K lists (catalogue scored chunk by chunk: no [B x I] score matrix when only top-K is wanted):
+// cand_* [B x n] hold n = chunks * K (score, item id) pairs per user, -1 ids for the slots a chunk could not fill. Ranked by
+// (score desc, id asc) by counting -- the order of the whole-catalogue selection, so both give the same list.
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict__ cand_val, const int32_t *__restrict__ cand_idx,
+                                                         int n, int K, int32_t *__restrict__ out_idx, float *__restrict__ out_val) {
+    extern __shared__ float mrg[];                   // [n] values, [n] ids
+    float *cv = mrg;
+    int *ci = (int *)(mrg + n);
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < n; i += 256) { cv[i] = cand_val[(int64_t)b * n + i]; ci[i] = cand_idx[(int64_t)b * n + i]; }
+    for (int r = threadIdx.x; r < K; r += 256) { out_idx[(int64_t)b * K + r] = -1; if (out_val) out_val[(int64_t)b * K + r] = -INFINITY; }
+    __syncthreads();
+    for (int c = threadIdx.x; c < n; c += 256) {
+        const float mv = cv[c];
+        const int mi = ci[c];
+        if (mi < 0) continue;
+        int rank = 0;
+        for (int j = 0; j < n; ++j) rank += (ci[j] >= 0 && tk_before(cv[j], ci[j], mv, mi)) ? 1 : 0;
         if (rank < K) {
             out_idx[(int64_t)b * K + rank] = mi;
             if (out_val) out_val[(int64_t)b * K + rank] = mv;
@@ -958,21 +1007,41 @@ extern "C" int elimrec_score_get_math(void) { return score_math(); }
 
 static inline int n_item_tiles(int64_t I) { return (int)((I + TI - 1) / TI); }   // 16-item tiles (the finest of the forms)
 
-extern "C" size_t elimrec_score_workspace(int B, int64_t I, int K) {
-    (void)K;
-    size_t partial = align_up((size_t)n_item_tiles(I) * (size_t)(B > 0 ? B : 1) * sizeof(float), 256);
-    size_t mean = align_up((size_t)(B > 0 ? B : 1) * sizeof(float), 256);
-    size_t scores = align_up((size_t)(B > 0 ? B : 1) * (size_t)I * sizeof(float), 256);
-    size_t flags = align_up((size_t)(B > 0 ? B : 1) * sizeof(int32_t), 256);
-    return partial + mean + scores + flags;      // + the squared-norm table, added by elimrec_score_workspace2
+constexpr int64_t SCORE_CHUNK = 16384;    // items per scorer launch when only top-K is wanted (a multiple of 512)
+
+// Workspace layout of elimrec_score_topk. full: a [B x I] score block (the caller wants the scores, or a scorer without tile
+// maxima runs); top-K only: a [B x SCORE_CHUNK] block, the tile maxima of one chunk and the per-chunk candidate lists.
+struct ScoreLayout { size_t partial, mean, scores, flags, sqn, bits, tmax, cand_val, cand_idx, total; };
+static ScoreLayout score_layout(int B, int64_t U, int64_t I, int S, int K, bool topk_only) {
+    const size_t b = (size_t)(B > 0 ? B : 1);
+    const int64_t cols = topk_only && I > SCORE_CHUNK ? SCORE_CHUNK : I;
+    const int64_t nch = topk_only ? (I + SCORE_CHUNK - 1) / SCORE_CHUNK : 0;
+    ScoreLayout L;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t at = off; off += align_up(bytes, 256); return at; };
+    L.partial = take((size_t)n_item_tiles(I) * b * sizeof(float));
+    L.mean = take(b * sizeof(float));
+    L.scores = take(b * (size_t)cols * sizeof(float));
+    L.flags = take(b * sizeof(int32_t));
+    L.sqn = take((size_t)(U + I) * (size_t)(1 + S) * sizeof(float));
+    L.bits = take(b * (size_t)((I + 31) / 32) * sizeof(uint32_t));
+    L.tmax = take(b * (size_t)n_item_tiles(cols) * sizeof(float));
+    L.cand_val = take(b * (size_t)nch * (size_t)(K > 0 ? K : 1) * sizeof(float));
+    L.cand_idx = take(b * (size_t)nch * (size_t)(K > 0 ? K : 1) * sizeof(int32_t));
+    L.total = off;
+    return L;
 }
 
-static size_t score_sqn_bytes(int64_t U, int64_t I, int S) { return align_up((size_t)(U + I) * (size_t)(1 + S) * sizeof(float), 256); }
-static size_t score_bits_bytes(int B, int64_t I) { return align_up((size_t)(B > 0 ? B : 1) * (size_t)((I + 31) / 32) * sizeof(uint32_t), 256); }
-static size_t score_tmax_bytes(int B, int64_t I) { return align_up((size_t)(B > 0 ? B : 1) * (size_t)n_item_tiles(I) * sizeof(float), 256); }
+extern "C" size_t elimrec_score_workspace(int B, int64_t I, int K) {      // (without the squared-norm table: legacy entry)
+    return score_layout(B, 0, I, 0, K, false).total;
+}
 
 extern "C" size_t elimrec_score_workspace2(int B, int64_t U, int64_t I, int S, int K) {
-    return elimrec_score_workspace(B, I, K) + score_sqn_bytes(U, I, S) + score_bits_bytes(B, I) + score_tmax_bytes(B, I);
+    return score_layout(B, U, I, S, K, false).total;
+}
+
+extern "C" size_t elimrec_score_workspace_topk(int B, int64_t U, int64_t I, int S, int K) {
+    return score_layout(B, U, I, S, K, true).total;
 }
 
 extern "C" int elimrec_row_sqnorms(const float *d_Y, int64_t ldy, int64_t n_rows, int d, int n_blocks, float *d_out,
@@ -1003,50 +1072,48 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
     ELIMREC_REQUIRE(d_scores || d_topk_idx, "score_topk: nothing to output");
     ELIMREC_REQUIRE(!d_topk_idx || (K > 0 && K <= I), "score_topk: need 0 < K <= I");
     if (B <= 0) return 0;
-    if (workspace_bytes < elimrec_score_workspace2(B, U, I, S, K)) {
-        set_error("score_topk: workspace too small (%zu < %zu)", workspace_bytes, elimrec_score_workspace2(B, U, I, S, K));
+    static int use_mfma = -1, use_resident = -1, use_t16 = -1, use_chunks = -1;
+    if (use_mfma < 0) { const char *e = getenv("ELIMREC_SCORE_VALU"); use_mfma = (e && e[0] == '1') ? 0 : 1; }
+    if (use_resident < 0) { const char *e = getenv("ELIMREC_SCORE_RESIDENT"); use_resident = (e && e[0] == '0') ? 0 : 1; }
+    if (use_t16 < 0) { const char *e = getenv("ELIMREC_SCORE_T16"); use_t16 = (e && e[0] == '0') ? 0 : 1; }
+    if (use_chunks < 0) { const char *e = getenv("ELIMREC_SCORE_CHUNKED"); use_chunks = (e && e[0] == '0') ? 0 : 1; }
+    const bool t16_path = use_mfma && use_t16 && (d == 32 || d == 64 || d == 128) && S >= 1 && S <= 3;
+    // only top-K wanted: no [B x I] score block -- the catalogue goes through the scorer in chunks (a workspace sized by
+    // elimrec_score_workspace_topk is enough; a larger one is accepted)
+    const bool chunked = t16_path && use_chunks && !d_scores && d_topk_idx && K <= 256 && I > SCORE_CHUNK;
+    const ScoreLayout L = score_layout(B, U, I, S, K, chunked);
+    if (workspace_bytes < L.total) {
+        set_error("score_topk: workspace too small (%zu < %zu)", workspace_bytes, L.total);
         return ELIMREC_E_WORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
     const int tiles = n_item_tiles(I);
     char *ws = (char *)d_workspace;
-    float *partial = (float *)ws;
-    float *mean = (float *)(ws + align_up((size_t)tiles * B * sizeof(float), 256));
-    float *wscores = (float *)((char *)mean + align_up((size_t)B * sizeof(float), 256));
-    int32_t *fallback = (int32_t *)((char *)wscores + align_up((size_t)B * (size_t)I * sizeof(float), 256));
+    float *partial = (float *)(ws + L.partial);
+    float *mean = (float *)(ws + L.mean);
+    float *wscores = (float *)(ws + L.scores);
+    int32_t *fallback = (int32_t *)(ws + L.flags);
+    float *cand_val = (float *)(ws + L.cand_val);
+    int32_t *cand_idx = (int32_t *)(ws + L.cand_idx);
     ScoreArgs a;
     a.Y = d_Y; a.ldy = ldy; a.U = U; a.I = I; a.users = d_users; a.B = B; a.d = d; a.S = S; a.head_mask = head_mask;
     a.fusion_mode = fusion_mode; a.predict_type = predict_type; a.row_mean = mean; a.partial = partial;
-    a.scores = d_scores ? d_scores : wscores; a.lds = d_scores ? lds : I;
-    float *wsqn = (float *)((char *)fallback + align_up((size_t)B * sizeof(int32_t), 256));
+    a.scores = d_scores ? d_scores : wscores; a.lds = d_scores ? lds : (chunked ? SCORE_CHUNK : I);
+    a.item0 = 0; a.item_end = I;
+    float *wsqn = (float *)(ws + L.sqn);
     if (!d_sqnorm && predict_type != 0) {            // not supplied: compute the whole table for this call
         const int64_t N = U + I;
         hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, d_Y, ldy, N, d, 1 + S, wsqn);
         ELIMREC_LAUNCH_CHECK("row_sqnorm");
     }
     a.sqn = d_sqnorm ? d_sqnorm : wsqn;
-    uint32_t *wbits = (uint32_t *)((char *)wsqn + score_sqn_bytes(U, I, S));
-    float *wtmax = (float *)((char *)wbits + score_bits_bytes(B, I));
+    uint32_t *wbits = (uint32_t *)(ws + L.bits);
+    float *wtmax = (float *)(ws + L.tmax);
     const int64_t bits_ld = (I + 31) / 32;
-    a.tile_max = nullptr; a.tmax_ld = n_item_tiles(I);
+    a.tile_max = nullptr; a.tmax_ld = n_item_tiles(chunked ? SCORE_CHUNK : I);
     bool tiles_ready = false;
-    ELIMREC_REQUIRE(a.lds >= I, "score_topk: lds < I");
-    static int use_mfma = -1;
-    if (use_mfma < 0) {
-        const char *e = getenv("ELIMREC_SCORE_VALU");
-        use_mfma = (e && e[0] == '1') ? 0 : 1;
-    }
-    static int use_resident = -1;
-    if (use_resident < 0) {
-        const char *e = getenv("ELIMREC_SCORE_RESIDENT");
-        use_resident = (e && e[0] == '0') ? 0 : 1;
-    }
-    static int use_t16 = -1;
-    if (use_t16 < 0) {
-        const char *e = getenv("ELIMREC_SCORE_T16");
-        use_t16 = (e && e[0] == '0') ? 0 : 1;
-    }
-    if (use_mfma && use_t16 && (d == 32 || d == 64 || d == 128) && S >= 1 && S <= 3) {
+    ELIMREC_REQUIRE(chunked || a.lds >= I, "score_topk: lds < I");
+    if (t16_path) {
         // 16 users per wave, 128 per workgroup, a persistent grid over 16-item tiles (two workgroups per CU)
         const int t16 = (int)((I + TI - 1) / TI);
         const bool fast = score_math() == 1;
@@ -1090,15 +1157,13 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
         if (fast) ELIMREC_T16_LAUNCH(2, NB, PT, FM, true, grid);                                           \
         else ELIMREC_T16_LAUNCH(2, NB, PT, FM, false, grid);                                               \
     } while (0)
-#define ELIMREC_T16(NB)                                                                                     \
+#define ELIMREC_T16_PASS1(NB)                                                                               \
     do {                                                                                                   \
-        if (predict_type == 2) {                                                                           \
-            if (fast) ELIMREC_T16_LAUNCH(1, NB, -1, -1, true, grid1);                                      \
-            else ELIMREC_T16_LAUNCH(1, NB, -1, -1, false, grid1);                                          \
-            ELIMREC_LAUNCH_CHECK("score_t16_pass1");                                                       \
-            hipLaunchKernelGGL(row_mean_kernel, dim3(B), dim3(256), 0, s, partial, (int)grid1.x, B, I, mean); \
-            ELIMREC_LAUNCH_CHECK("row_mean");                                                              \
-        }                                                                                                  \
+        if (fast) ELIMREC_T16_LAUNCH(1, NB, -1, -1, true, grid1);                                          \
+        else ELIMREC_T16_LAUNCH(1, NB, -1, -1, false, grid1);                                              \
+    } while (0)
+#define ELIMREC_T16_PASS2(NB)                                                                               \
+    do {                                                                                                   \
         if (predict_type == 0) ELIMREC_T16_P2(NB, 0, 0);                                                   \
         else if (predict_type == 1 && fusion_mode == 0) ELIMREC_T16_P2(NB, 1, 0);                          \
         else if (predict_type == 1 && fusion_mode == 1) ELIMREC_T16_P2(NB, 1, 1);                          \
@@ -1106,11 +1171,53 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
         else if (fusion_mode == 0) ELIMREC_T16_P2(NB, 2, 0);                                               \
         else if (fusion_mode == 1) ELIMREC_T16_P2(NB, 2, 1);                                               \
         else ELIMREC_T16_P2(NB, 2, 2);                                                                     \
-        ELIMREC_LAUNCH_CHECK("score_t16_pass2");                                                           \
     } while (0)
-        if (S == 1) ELIMREC_T16(2);
-        else if (S == 2) ELIMREC_T16(3);
-        else ELIMREC_T16(4);
+        // pass 1 (TIE): row means of sigmoid(u.i) over the WHOLE catalogue
+        a.item0 = 0; a.item_end = I;
+        if (predict_type == 2) {
+            if (S == 1) ELIMREC_T16_PASS1(2);
+            else if (S == 2) ELIMREC_T16_PASS1(3);
+            else ELIMREC_T16_PASS1(4);
+            ELIMREC_LAUNCH_CHECK("score_t16_pass1");
+            hipLaunchKernelGGL(row_mean_kernel, dim3(B), dim3(256), 0, s, partial, (int)grid1.x, B, I, mean);
+            ELIMREC_LAUNCH_CHECK("row_mean");
+        }
+        // pass 2 over items [a.item0, a.item_end): the arguments, tile count and grid are the lambda's (they shadow the outer ones)
+        auto pass2 = [&](const ScoreArgs &a, int t16, dim3 grid) -> int {
+            if (S == 1) ELIMREC_T16_PASS2(2);
+            else if (S == 2) ELIMREC_T16_PASS2(3);
+            else ELIMREC_T16_PASS2(4);
+            ELIMREC_LAUNCH_CHECK("score_t16_pass2");
+            return 0;
+        };
+        if (chunked) {
+            // only top-K is wanted: the catalogue goes through the scorer SCORE_CHUNK items at a time, a [B x SCORE_CHUNK]
+            // block instead of [B x I]; every chunk leaves its K best (id, score) pairs per user, merged at the end
+            const int nch = (int)((I + SCORE_CHUNK - 1) / SCORE_CHUNK);
+            for (int c = 0; c < nch; ++c) {
+                ScoreArgs ac = a;
+                ac.item0 = (int64_t)c * SCORE_CHUNK;
+                ac.item_end = ac.item0 + SCORE_CHUNK < I ? ac.item0 + SCORE_CHUNK : I;
+                const int64_t cnt = ac.item_end - ac.item0;
+                const int tc = (int)((cnt + TI - 1) / TI);
+                // ~512 workgroups per launch in all: a workgroup walks several tiles with its users' operands resident
+                const int ug = (B + TW * TU - 1) / (TW * TU);
+                int gx = 512 / ug > 0 ? 512 / ug : 1;
+                if (gx > tc) gx = tc;
+                const int per = (tc + gx - 1) / gx;
+                int rc = pass2(ac, tc, dim3((unsigned)((tc + per - 1) / per), ug));
+                if (rc) return rc;
+                hipLaunchKernelGGL(topk_tiles_kernel, dim3(B), dim3(256), 0, s, ac.scores, ac.lds, cnt, (const float *)wtmax, ac.tmax_ld,
+                                   tc, K, d_train_ptr, d_train_ptr ? (const uint32_t *)wbits : (const uint32_t *)nullptr, bits_ld,
+                                   cand_idx, cand_val, fallback, ac.item0, (int64_t)nch * K, (int64_t)c * K);
+                ELIMREC_LAUNCH_CHECK("topk_tiles(chunk)");
+            }
+            hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(256), (size_t)nch * K * 8, s, (const float *)cand_val,
+                               (const int32_t *)cand_idx, nch * K, K, d_topk_idx, d_topk_val);
+            ELIMREC_LAUNCH_CHECK("topk_merge");
+            return 0;
+        }
+        { int rc = pass2(a, t16, grid); if (rc) return rc; }
 #undef ELIMREC_T16
 #undef ELIMREC_T16_P2
 #undef ELIMREC_T16_LAUNCH
@@ -1183,19 +1290,17 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
         if (tiles_ready) {
             hipLaunchKernelGGL(topk_tiles_kernel, dim3(B), dim3(256), 0, s, a.scores, a.lds, I, (const float *)wtmax, a.tmax_ld,
                                (int)a.tmax_ld, K, d_train_ptr, d_train_ptr ? (const uint32_t *)wbits : (const uint32_t *)nullptr,
-                               bits_ld, d_topk_idx, d_topk_val, fallback);
+                               bits_ld, d_topk_idx, d_topk_val, fallback, (int64_t)0, (int64_t)K, (int64_t)0);
             ELIMREC_LAUNCH_CHECK("topk_tiles");
-            hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), 0, s, a.scores, a.lds, I, K, d_topk_idx, d_topk_val,
-                               (const int32_t *)fallback, d_train_ptr ? (const uint32_t *)wbits : (const uint32_t *)nullptr, bits_ld);
         } else if (2 * K <= 1024) {
             hipLaunchKernelGGL(topk_select_kernel, dim3(B), dim3(1024), 0, s, a.scores, a.lds, I, K, G, d_topk_idx,
                                d_topk_val, fallback);
             ELIMREC_LAUNCH_CHECK("topk_select");
             hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), 0, s, a.scores, a.lds, I, K, d_topk_idx, d_topk_val,
-                               (const int32_t *)fallback);
+                               (const int32_t *)fallback, (const uint32_t *)nullptr, (int64_t)0, (int64_t)0, (int64_t)K, (int64_t)0);
         } else {
             hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(1024), 0, s, a.scores, a.lds, I, K, d_topk_idx, d_topk_val,
-                               (const int32_t *)nullptr);
+                               (const int32_t *)nullptr, (const uint32_t *)nullptr, (int64_t)0, (int64_t)0, (int64_t)K, (int64_t)0);
         }
         ELIMREC_LAUNCH_CHECK("topk");
     }

@@ -1079,7 +1079,10 @@ class EliMRec(BasicModel):
         self._ensure_tables()
         users = torch.as_tensor(user_ids, device=dev).long().contiguous()
         B, I = users.numel(), self.num_items
-        need = ops.score_workspace(B, self.num_users, I, self.S, max(top_k, 1))
+        # top-K only (the evaluator): no [B x I] score block in the workspace, the catalogue is scored in chunks
+        import os
+        chunked = scores is None and top_k > 0 and os.environ.get("ELIMREC_SCORE_CHUNKED", "1") != "0"
+        need = ops.score_workspace(B, self.num_users, I, self.S, max(top_k, 1), topk_only=chunked)
         if self._ws.get("score_ws") is None or self._ws["score_ws"].numel() < need:
             self._ws["score_ws"] = torch.empty(need, dtype=torch.uint8, device=dev)
         idx = val = None

@@ -584,7 +584,11 @@ def adam_step_raw(p_ptr, g_ptr, m_ptr, v_ptr, n, lr, beta1, beta2, eps, weight_d
                                              float(eps), float(weight_decay), int(step), _stream()), "adam_step")
 
 
-def score_workspace(B, U, I, S, K):
+def score_workspace(B, U, I, S, K, topk_only=False):
+    """Bytes of score_topk's workspace. topk_only: the call will ask for top-K lists only (no score matrix) -- no
+    [B x I] block, the catalogue is scored in chunks."""
+    if topk_only:
+        return int(_lib.load().elimrec_score_workspace_topk(B, U, I, S, K))
     return int(_lib.load().elimrec_score_workspace2(B, U, I, S, K))
 
 

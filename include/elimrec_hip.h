@@ -409,7 +409,11 @@ int elimrec_adam_step(float *d_p, const float *d_g, float *d_m, float *d_v, int6
  * d_topk_idx/d_topk_val [B x K] (nullable): per-row top-K by (score desc, index asc).
  * workspace: elimrec_score_workspace2(B, U, I, S, K) bytes. */
 size_t elimrec_score_workspace(int B, int64_t I, int K);              /* without the norm table   */
-size_t elimrec_score_workspace2(int B, int64_t U, int64_t I, int S, int K);   /* what score_topk needs */
+size_t elimrec_score_workspace2(int B, int64_t U, int64_t I, int S, int K);
+/* Workspace when ONLY top-K is requested (d_scores == NULL, K <= 256, recdim 32 / 64 / 128): no [B x I] score block -- the
+ * catalogue goes through the scorer 16384 items at a time, every chunk leaves its K best (id, score) pairs per user and a
+ * last launch merges them (same list as the whole-catalogue selection). */
+size_t elimrec_score_workspace_topk(int B, int64_t U, int64_t I, int S, int K);   /* what score_topk needs */
 /* Evaluation math of the scorer: 0 = EXACT (default; IEEE division, libm expf/logf: scores within a few ulp of the
  * reference's), 1 = FAST (v_exp_f32 / v_log_f32 / v_rcp_f32 and reciprocal norms: scores within 2e-6 of EXACT, the
  * scorer about twice as fast). Also env ELIMREC_EVAL_MATH=fast, read once. */

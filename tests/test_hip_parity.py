@@ -1040,14 +1040,16 @@ def test_topk_paths_agree_with_stable_sort():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("with_scores,d", [(True, 64), (False, 64), (False, 128), (True, 32)])
-def test_tile_guided_topk_at_recdim_64(with_scores, d):
+@pytest.mark.parametrize("with_scores,d,I", [(True, 64, 3000), (False, 64, 3000), (False, 128, 3000), (True, 32, 3000),
+                                             (False, 64, 40000), (False, 32, 33000)])
+def test_tile_guided_topk_at_recdim_64(with_scores, d, I):
     """The evaluator's own configuration (recdim 32 / 64 / 128: 16-user-per-wave scorer, selection from tile maxima, bitmap masking)
     against a stable sort of the full masked score matrix: continuous scores and massive ties; rows with nothing, a few,
     hundreds (K + masked > 256 group maxima -> fall-back) and all-but-4 items masked; 200 users (two user groups per
-    launch); with the caller's score matrix and with the private one (top-K only)."""
+    launch); with the caller's score matrix and with the private one (top-K only). I > 16384 without a score matrix: the
+    catalogue is scored in chunks (no [B x I] block in the workspace), per-chunk top-K lists merged -- the same lists."""
     from elimrec_amd import ops
-    U, I, S = 260, 3000, 3
+    U, S = 260, 3
     Cy = (1 + S) * d
     g = torch.Generator().manual_seed(5)
     Yr = torch.randn(U + I, Cy, generator=g) * 0.3
@@ -1056,7 +1058,7 @@ def test_tile_guided_topk_at_recdim_64(with_scores, d):
     users = torch.arange(0, 200)
     B = len(users)
     lists = [[] for _ in range(B)]
-    lists[3] = [5, 17, 2999, 1024]
+    lists[3] = [5, 17, I - 1, 1024]
     lists[5] = [i for i in range(I) if i not in (17, 2000, 3, 999)]
     lists[7] = list(range(0, 900, 3))                            # 300 masked items
     lists[8] = [11, 11, 12]                                      # a duplicate
@@ -1076,7 +1078,9 @@ def test_tile_guided_topk_at_recdim_64(with_scores, d):
         for b in (3, 5, 7, 8):
             assert np.isinf(sc[b]).sum() == len(set(lists[b]))
         for K in (1, 10, 50, 100):
-            ws = torch.empty(ops.score_workspace(B, U, I, S, K), dtype=torch.uint8, device=DEV)
+            ws = torch.empty(ops.score_workspace(B, U, I, S, K, topk_only=not with_scores), dtype=torch.uint8, device=DEV)
+            if not with_scores and I > 16384:
+                assert ws.numel() < B * I * 4            # no [B x I] score block
             scores = torch.empty(B, I, device=DEV) if with_scores else None
             idx = torch.empty(B, K, dtype=torch.int32, device=DEV)
             val = torch.empty(B, K, device=DEV)
