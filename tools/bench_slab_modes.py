@@ -21,9 +21,9 @@ def timeit(fn, n=30):
 torch.manual_seed(0)
 X = torch.randn(N, d, device=dev)
 lib = _lib.load()
-geoms = [("f32 w32 gs2", 32, 2, 2, 0, False), ("f32 w64 gs1", 64, 1, 1, 0, False), ("bf16 w64 gs1", 64, 1, 1, 0, True),
+geoms = [("bf16 w32 gs2", 32, 2, 2, 0, True), ("bf16 w16 gs4", 16, 4, 4, 0, True), ("f32 w32 gs2", 32, 2, 2, 0, False), ("f32 w64 gs1", 64, 1, 1, 0, False), ("bf16 w64 gs1", 64, 1, 1, 0, True),
          ("f32 shard8", 8, 1, 1, 8, False), ("f32 shard16", 16, 1, 1, 16, False), ("bf16 shard8", 8, 1, 1, 8, True)]
-for T in (64, 32, 48):
+for T in (64, 32):
     for name, w, ns, gs, shard, bf in geoms:
         plan = slab.SellPlan(adj, dev, threshold=T, side_split=U, tiered=False)
         ipw = 64 // max(1, (ns // gs) * (w // (8 if bf else 4)))
