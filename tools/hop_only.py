@@ -11,12 +11,16 @@ U, I = 36656, 76085
 ds = SyntheticDataset(U, I, 720829, feat_dims=(4, 4, 4), seed=0)
 adj = create_adj_mat(*ds.get_train_interactions(), U, I, "pre").tocsr()
 N = adj.shape[0]
-ns, w = slab.choose_slabs(d, N)
+bf16 = os.environ.get("BF16") == "1"
+ns, w = slab.choose_slabs16(d) if bf16 else slab.choose_slabs(d, N)
 gs = slab.choose_groups(ns)
 tiered = os.environ.get("TIERED", "1") == "1"
-plan = slab.SellPlan(adj, dev, side_split=U, tiered=tiered, threshold=64 if tiered else 32, ipw=64 // ((ns // gs) * (w // 4)))
+T = int(os.environ.get("T", 64 if tiered else 32))
+plan = slab.SellPlan(adj, dev, side_split=U, tiered=tiered, threshold=T, ipw=64 // ((ns // gs) * (w // (8 if bf16 else 4))))
 torch.manual_seed(0)
 tabs = [slab.SlabTable(N, ns, w, dev).from_rows(torch.randn(N, d, device=dev)) for _ in range(3)]
+if bf16:
+    tabs = [t.to_bf16(t.like(torch.bfloat16)) for t in tabs]
 src, dst = tabs[0], tabs[1]
 for _ in range(hops):
     slab.hop(plan, src, dst, gs=gs)
