@@ -580,3 +580,54 @@ def test_step_variants_are_bitwise_equal(monkeypatch):
     assert (base[0] - other[0]).abs().max() < 1e-6
     for k in base[1]:
         assert (base[1][k] - other[1][k]).abs().max() < 2e-5, k
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_random_shapes_column_shard_vs_row_major_trainer(seed):
+    """Random small graphs, batch sizes that are not multiples of any tile height, 2-4 layers, the three bipartite
+    adjacencies, recdim 64 (fused 16-row head, wave-tile hops, Adam epilogue, second stream) and 32 (batched-GEMM head):
+    two steps of the column-shard trainer against the row-major trainer (dist.py: other hop, head and optimizer kernels)
+    -- losses 1e-5, parameters 2e-5."""
+    import os
+    from helpers import ROOT
+    from elimrec_amd import (ColumnShardEngine, ColumnShardTrainer, Configurator, EliMRec, FusedAdam, Logger,
+                             PairwiseSamplerV2, SyntheticDataset, set_seed)
+    from elimrec_amd.dist import DataParallelTrainer
+    rs = np.random.RandomState(100 + seed)
+    U, I = int(rs.randint(40, 900)), int(rs.randint(60, 2500))
+    E = int(rs.randint(max(U, I) * 3, max(U, I) * 10))
+    dims = tuple(int(4 * rs.randint(2, 36)) for _ in range(3))
+    recdim = 64 if seed % 3 else 32
+    L = int(rs.randint(2, 5))
+    B = int(rs.randint(5, 700))
+    adj = str(rs.choice(["pre", "gcmc", "plain"]))
+    Logger.logger = Logger(show_in_console=False)
+    cwd = os.getcwd()
+    os.chdir(ROOT)
+    try:
+        cfg = Configurator(os.path.join(ROOT, "NeuRec.properties"), default_section="hyperparameters",
+                           argv=["x", "--data.input.dataset=synthetic", "--alpha=0.5", "--loss=bpr_loss", "--recdim=%d" % recdim,
+                                 "--layer_num=%d" % L, "--adj_type=%s" % adj, "--verbose=0"])
+        ds = SyntheticDataset(U, I, E, feat_dims=dims, seed=seed)
+        u, p, n = PairwiseSamplerV2(ds, batch_size=B, device=DEV, seed=seed).sample_epoch()
+        out = []
+        for kind in ("rows", "slab"):
+            set_seed(7)
+            model = EliMRec(cfg, ds).to(DEV)
+            opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+            if kind == "rows":
+                tr, eng = DataParallelTrainer(model, opt), None
+            else:
+                eng = ColumnShardEngine(model)
+                tr = ColumnShardTrainer(eng, opt)
+            losses = [float(tr.step(u[i * B:(i + 1) * B], p[i * B:(i + 1) * B], n[i * B:(i + 1) * B])) for i in range(2)]
+            if eng is not None:
+                eng.sync_to_model()
+            out.append((losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}))
+    finally:
+        os.chdir(cwd)
+    (l0, p0), (l1, p1) = out
+    tol = 1e-4 if adj == "plain" else 1e-5            # un-normalised adjacency: the embeddings grow by ~degree per hop
+    assert max(abs(a - b) for a, b in zip(l0, l1)) < tol, (l0, l1, U, I, B, L, adj, recdim)
+    for k in p0:
+        assert (p0[k] - p1[k]).abs().max() < 2e-5 * (10 if adj == "plain" else 1), (k, U, I, B, L, adj, recdim)
