@@ -97,6 +97,7 @@ SIGNATURES = {
     "elimrec_folded_workspace": (c_size, [c_i64, c_i32]),
     "elimrec_propagate_folded": (c_i32, [c_csr, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_size, c_ptr]),
     "elimrec_source_rows": (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr]),
+    "elimrec_source_rows_split": (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr]),
     "elimrec_merge_rank_rows": (c_i32, [c_ptr, c_ptr, c_i32, c_i64, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "elimrec_layer_tables_workspace": (c_size, [c_i64, c_i32, c_i32]),
     "elimrec_propagate_layers": (c_i32, [c_csr, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_size, c_i32, c_i32, c_ptr, c_ptr, c_i64,

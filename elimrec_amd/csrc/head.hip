@@ -306,6 +306,8 @@ __global__ __launch_bounds__(256) void head_fwd16_kernel(HeadFwdArgs a) {
         }
         *reinterpret_cast<float4 *>(OutT + r * LDO + 4 * c4) = x;
         *reinterpret_cast<float4 *>(AN + r * LDN + 4 * c4) = y;
+        if (r < nrows && a.out0 != a.OutAct)             // out0 handed over separately: block 0 of OutAct is written here
+            *reinterpret_cast<float4 *>(a.OutAct + (int64_t)(r0 + r) * a.ld_out + 4 * c4) = x;
     }
     __syncthreads();                                   // s_act
     for (int m = 0; m < a.n_mod; ++m) {

@@ -202,8 +202,9 @@ __global__ __launch_bounds__(256) void slab_rows_kernel(RowsArgs a) {
     int64_t r = s;
     if (a.rows) {
         const int64_t list = s / a.R;
-        if (s - list * a.R >= a.counts[list]) return;
+        if (a.counts && s - list * a.R >= a.counts[list]) return;
         r = a.rows[s];
+        if (r < 0) return;                              // padding of a gathered list (negative keys); counts may be null
     }
     const bool user = r < a.U;
     // layer pointers by compare-select over constant indices: indexing the by-value argument array with a run-time k
@@ -604,8 +605,9 @@ __global__ __launch_bounds__(256) void slab_rows16_kernel(Rows16Args a) {
     int64_t r = s;
     if (a.rows) {
         const int64_t list = s / a.R;
-        if (s - list * a.R >= a.counts[list]) return;
+        if (a.counts && s - list * a.R >= a.counts[list]) return;
         r = a.rows[s];
+        if (r < 0) return;                              // padding of a gathered list (negative keys); counts may be null
     }
     const bool user = r < a.U;
     const bool inline_hop = a.x[a.L] == nullptr;
@@ -1738,7 +1740,7 @@ extern "C" int elimrec_slab_rows(const elimrec_sell *A, int ns, int w, int L, in
     ELIMREC_REQUIRE(A && layers && d_out0 && d_narrow, "slab_rows: null pointer");
     ELIMREC_REQUIRE(L >= 1 && L <= kSlabMaxLayers, "slab_rows: 1 <= L <= %d", kSlabMaxLayers);
     ELIMREC_REQUIRE(ld_out0 % 4 == 0 && ld_narrow % 4 == 0, "slab_rows: leading dimensions must be multiples of 4");
-    ELIMREC_REQUIRE(n_lists >= 1 && (d_rows ? d_counts != nullptr : n_lists == 1), "slab_rows: row lists need their counts");
+    ELIMREC_REQUIRE(n_lists >= 1 && (d_rows || n_lists == 1), "slab_rows: several lists need row ids");
     int w4_shift, rc;
     if ((rc = slab_simple_geometry("slab_rows", A->n_rows, ns, w, w4_shift))) return rc;
     RowsArgs a = {};
@@ -1916,7 +1918,7 @@ extern "C" int elimrec_slab_rows16(const elimrec_sell *A, int ns, int w, int L, 
     ELIMREC_REQUIRE(A && d_x0 && layers16 && d_out0 && d_narrow, "slab_rows16: null pointer");
     ELIMREC_REQUIRE(L >= 1 && L <= kSlabMaxLayers, "slab_rows16: 1 <= L <= %d", kSlabMaxLayers);
     ELIMREC_REQUIRE(ld_out0 % 4 == 0 && ld_narrow % 4 == 0, "slab_rows16: leading dimensions must be multiples of 4");
-    ELIMREC_REQUIRE(n_lists >= 1 && (d_rows ? d_counts != nullptr : n_lists == 1), "slab_rows16: row lists need their counts");
+    ELIMREC_REQUIRE(n_lists >= 1 && (d_rows || n_lists == 1), "slab_rows16: several lists need row ids");
     int w8_shift, spg, lpr, rc;
     if ((rc = slab16_geometry("slab_rows16", ns, w, ns, w8_shift, spg, lpr))) return rc;
     Rows16Args a = {};

@@ -1363,7 +1363,40 @@ __global__ __launch_bounds__(256) void source_rows_kernel(const float *__restric
         o[d4 + c] = g0;
     }
 }
+// the same rows already cut into the `world` column slices a column-sharded job sends to its peers:
+// out[w][s] = [H[s][w*dl : (w+1)*dl] | G[s][w*dl : (w+1)*dl]], dl = d / world  (layout [world x n_max x 2*dl])
+__global__ __launch_bounds__(256) void source_rows_split_kernel(const float *__restrict__ dOutR, const int32_t *__restrict__ count,
+                                                                int64_t n_max, int d4, int M, int dl4, float *__restrict__ out) {
+    const int64_t s = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const int sub = threadIdx.x & 15;
+    if (s >= n_max || s >= *count) return;
+    const float4 *g = reinterpret_cast<const float4 *>(dOutR) + s * (int64_t)d4 * M;
+    float4 *o = reinterpret_cast<float4 *>(out);
+    for (int c = sub; c < d4; c += 16) {
+        const float4 g0 = g[c];
+        float4 h = g0;
+        for (int m = 1; m < M; ++m) {
+            const float4 x = g[m * d4 + c];
+            h.x += x.x; h.y += x.y; h.z += x.z; h.w += x.w;
+        }
+        const int w = c / dl4, j = c - w * dl4;
+        float4 *row = o + ((int64_t)w * n_max + s) * 2 * dl4;
+        row[j] = h;
+        row[dl4 + j] = g0;
+    }
+}
 }  // namespace elimrec
+
+extern "C" int elimrec_source_rows_split(const float *d_dOutR, const int32_t *d_count, int64_t n_max, int d, int M, int world,
+                                         float *d_out, void *stream) {
+    ELIMREC_REQUIRE(d_dOutR && d_count && d_out, "source_rows_split: null pointer");
+    ELIMREC_REQUIRE(d > 0 && M >= 1 && world >= 1 && d % world == 0 && (d / world) % 4 == 0, "source_rows_split: bad d/M/world");
+    if (n_max <= 0) return 0;
+    hipLaunchKernelGGL(source_rows_split_kernel, dim3((unsigned)((n_max + 15) / 16)), dim3(256), 0, (hipStream_t)stream, d_dOutR,
+                       d_count, n_max, d / 4, M, d / world / 4, d_out);
+    ELIMREC_LAUNCH_CHECK("source_rows_split");
+    return 0;
+}
 
 extern "C" int elimrec_source_rows(const float *d_dOutR, const int32_t *d_count, int64_t n_max, int d, int M, float *d_out,
                                    void *stream) {

@@ -329,6 +329,14 @@ def source_rows(dOutR, count, d, M, out):
                                                _dev(out, "out"), _stream()), "source_rows")
 
 
+def source_rows_split(dOutR, count, d, M, world, out):
+    """source_rows cut into the peers' column slices: out [world x n x 2*d/world]."""
+    n = dOutR.shape[0]
+    assert dOutR.is_contiguous() and out.is_contiguous() and dOutR.shape[1] == d * M and out.shape == (world, n, 2 * d // world)
+    _lib.check(_lib.load().elimrec_source_rows_split(_dev(dOutR, "dOutR"), _dev(count, "count", torch.int32), n, d, M, world,
+                                                     _dev(out, "out"), _stream()), "source_rows_split")
+
+
 def merge_rank_rows(all_rows, all_keys, world, U, I, d, M, srcA, srcB, mask):
     """Sum the all-gathered rows per node in rank order into the adjoint's source tables + row bitmap. M >= 1: dOut
     rows [.. x M*d]; M = 0: [H | G] rows [.. x 2d] from source_rows."""

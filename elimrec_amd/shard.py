@@ -175,6 +175,10 @@ class ColumnShardEngine(object):
         self._aux = None
         self._aux_pending = False
         self._adam_in_hop = False
+        self._out0_src = self._nar_src = None
+        self._pairs = {}
+        self._head16 = os.environ.get("ELIMREC_HEAD_ROWS", "16") != "32"
+        self.send_b = None
         self._loss_ring, self._loss_at = None, 0
         self._bits_ready = False
         self.keep_grad = False
@@ -225,8 +229,9 @@ class ColumnShardEngine(object):
         if bufs is None:                                          # per batch size (an epoch ends with a ragged batch)
             bufs = self._bufs[B] = dict(hg=torch.zeros(R, 2 * d, dtype=torch.float32, device=dev),
                                         send_f=torch.empty(W, R, 2 * self.dl, dtype=torch.float32, device=dev) if W > 1 else None,
+                                        send_b=torch.zeros(W, R, 2 * self.dl, dtype=torch.float32, device=dev) if W > 1 else None,
                                         counts=torch.zeros(W, dtype=torch.int32, device=dev))
-        self.hg, self.send_f, self.counts = bufs["hg"], bufs["send_f"], bufs["counts"]
+        self.hg, self.send_f, self.send_b, self.counts = bufs["hg"], bufs["send_f"], bufs["send_b"], bufs["counts"]
         if "nar_act" not in bufs:
             bufs["nar_act"] = torch.zeros(R, d, dtype=torch.float32, device=dev)       # shared part of Out, compact rows
         self.nar_act = bufs["nar_act"]
@@ -350,8 +355,7 @@ class ColumnShardEngine(object):
             torch.cuda.current_stream().wait_stream(self._aux)
             self._aux_pending = False
         if W > 1:
-            torch.sum(acts >= 0, dim=1, dtype=torch.int32, out=self.counts)
-            counts = self.counts
+            counts = None                                        # the gathered lists are padded with negative keys
             out0, narrow, by_node = self.send_f.view(W * R, 2 * self.dl)[:, :self.dl], self.send_f.view(W * R, 2 * self.dl)[:, self.dl:], False
         else:
             counts = ws["seg_info"][0:1]
@@ -386,13 +390,23 @@ class ColumnShardEngine(object):
         if recv is not None:                                      # [W, R, (out0 | narrow)] -> my rows, all columns
             W = recv.shape[0]
             r = recv.view(W, R, 2, self.dl)
-            ws["OutAct"][:R, :d].unflatten(1, (W, self.dl)).copy_(r[:, :, 0].permute(1, 0, 2))
-            if fused:
-                self.nar_act.unflatten(1, (W, self.dl)).copy_(r[:, :, 1].permute(1, 0, 2))
+            if fused and self._head16:
+                # one copy: [R, (out0 | narrow), d]; the fused head reads both halves with a 2d row stride and writes
+                # block 0 of OutAct itself
+                pair = self._pair(R, d)
+                pair.view(R, 2, W, self.dl).copy_(r.permute(1, 2, 0, 3))
+                self._out0_src, self._nar_src = pair[:, 0, :], pair[:, 1, :]
             else:
-                act = ws["active_rows"][:R].long()
-                idx = torch.where(act >= 0, act, torch.full_like(act, self.narrow_x.shape[0] - 1))
-                self.narrow_x.index_copy_(0, idx, r[:, :, 1].permute(1, 0, 2).reshape(R, d))
+                ws["OutAct"][:R, :d].unflatten(1, (W, self.dl)).copy_(r[:, :, 0].permute(1, 0, 2))
+                if fused:
+                    self.nar_act.unflatten(1, (W, self.dl)).copy_(r[:, :, 1].permute(1, 0, 2))
+                else:
+                    act = ws["active_rows"][:R].long()
+                    idx = torch.where(act >= 0, act, torch.full_like(act, self.narrow_x.shape[0] - 1))
+                    self.narrow_x.index_copy_(0, idx, r[:, :, 1].permute(1, 0, 2).reshape(R, d))
+                self._out0_src = self._nar_src = None
+        else:
+            self._out0_src = self._nar_src = None
         m._slab_fwd = True
         if fused:
             return self._head_forward_fused(ws, R, B)
@@ -413,7 +427,8 @@ class ColumnShardEngine(object):
 
         def head():
             self._head_fused_call(ws, R, phase=2 if packed else 0)
-        m._region("cs_head_fused", (m._ws_gen, R, B, packed, self.nar_act.data_ptr()), head)
+        m._region("cs_head_fused", (m._ws_gen, R, B, packed, self.nar_act.data_ptr(),
+                                    0 if self._out0_src is None else self._out0_src.data_ptr()), head)
         # the cosine-BPR rows and the batch loss in one launch (the workgroup that finishes last adds the loss rows in
         # elimrec_sum's order). Issued directly: the loss goes to the next slot of a ring, so that a caller holding the
         # tensors of earlier steps (up to 64) does not see them change.
@@ -426,12 +441,20 @@ class ColumnShardEngine(object):
         m._publish_cache(ws["Y"], dirty=True)
         return loss
 
+    def _pair(self, R, d):
+        b = self._pairs.get(R)
+        if b is None:
+            b = self._pairs[R] = torch.zeros(R, 2, d, dtype=torch.float32, device=self.model._device())
+        return b
+
     def _head_fused_call(self, ws, R, phase):
         m = self.model
         d, fold, W = m.latent_dim, ws["fold"], ws["live_views"]
         OutAct, YAct = ws["OutAct"][:R], ws["YAct"][:R]
         wu, wi = m._fusion_weights(W)
-        ok = ops.head_fwd_fused(ws["active_rows"][:R], ws["seg_info"], OutAct[:, :d], self.nar_act, fold["c"],
+        out0 = self._out0_src if self._out0_src is not None else OutAct[:, :d]
+        nar = self._nar_src if self._nar_src is not None else self.nar_act
+        ok = ops.head_fwd_fused(ws["active_rows"][:R], ws["seg_info"], out0, nar, fold["c"],
                                 [fold[k] for k in m._mods], [W[k + "_dense.weight"] for k in m._mods],
                                 [W[k + "_dense.bias"] for k in m._mods], wu, W["embedding_user_after_GCN.bias"], wi,
                                 W["embedding_item_after_GCN.bias"], [W["s_dense_%s.weight" % k] for k in m._mods],
@@ -451,11 +474,12 @@ class ColumnShardEngine(object):
         wg = ws["flat_grad"][ws["tail_off"]:]
         if self.world == 1:       # one rank owns every column: the merge reads the dOut rows themselves
             return ws["dOutR"][:R].view(1, R, m.C), wg
-        # [H | G]: all the adjoint needs of a dOut row, split into the peers' column slices (rows beyond the active
-        # count are never read: their keys are negative)
-        m._region("cs_sources", (m._ws_gen, R), lambda: ops.source_rows(ws["dOutR"][:R], ws["seg_info"][0:1], d, m.M, self.hg))
+        # [H | G]: all the adjoint needs of a dOut row, written straight into the peers' column slices [W, R, 2*dl] (rows
+        # beyond the active count are never read: their keys are negative)
         W = self.world
-        send = self.hg.view(R, 2, W, self.dl).permute(2, 0, 1, 3).contiguous().view(W, R, 2 * self.dl)
+        send = self.send_b
+        m._region("cs_sources", (m._ws_gen, R, send.data_ptr()),
+                  lambda: ops.source_rows_split(ws["dOutR"][:R], ws["seg_info"][0:1], d, m.M, W, send))
         return send, wg
 
     @torch.no_grad()

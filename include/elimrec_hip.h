@@ -273,6 +273,10 @@ int elimrec_propagate_folded_bwd(const elimrec_csr *AT, int64_t U, int64_t I, in
  * [H | G] pairs of elimrec_source_rows (2d columns) -- half the bytes on the wire. */
 int elimrec_source_rows(const float *d_dOutR, const int32_t *d_count, int64_t n_max, int d, int M, float *d_out /* [n x 2d] */,
                         void *stream);
+/* elimrec_source_rows with the rows already cut into the column slices a column-sharded job sends to its `world` peers:
+ * d_out [world x n_max x 2*dl], dl = d / world: slice w of row s = [H[s][w*dl:(w+1)*dl] | G[s][w*dl:(w+1)*dl]]. */
+int elimrec_source_rows_split(const float *d_dOutR, const int32_t *d_count, int64_t n_max, int d, int M, int world,
+                              float *d_out, void *stream);
 int elimrec_merge_rank_rows(const float *d_rows, const int32_t *d_keys, int W, int64_t R, int64_t U, int64_t I, int d,
                             int M, float *d_SrcA, float *d_SrcB, uint32_t *d_mask, void *stream);
 
@@ -555,7 +559,8 @@ int elimrec_slab_hop_adam(const elimrec_sell *A, int ns, int w, int gs, const fl
  * (the part of Out every feature table shares). layers[L] may be NULL: hop L is then evaluated inline at the
  * listed rows from X^(L-1) through the plain CSR, split rows taken from d_long [ns x n_long x w]
  * (elimrec_slab_hop with seg_only). Rows: d_rows int32 [n_lists x R] with d_counts int32[n_lists] valid
- * entries per list (device), or d_rows NULL = all rows 0..R-1 (n_lists = 1, d_counts ignored).
+ * entries per list (device; NULL: every entry with a non-negative id is valid -- gathered lists are padded with
+ * negative keys), or d_rows NULL = all rows 0..R-1 (n_lists = 1, d_counts ignored).
  * Output row of slot s (= list*R + index): d_out0 + s*ld_out0 and d_narrow + (narrow_by_node ? row : s)*ld_narrow,
  * local column c at offset c (row-major within the row). */
 int elimrec_slab_rows(const elimrec_sell *A, int ns, int w, int L, int64_t U,
@@ -619,7 +624,8 @@ int elimrec_adam_step_out(const float *d_p_in, float *d_p_out, const float *d_g,
  * and the single-modal heads Y_m = Out_m Ws_m^T + bs_m (:146-151). d_act / d_seg_info: elimrec_segment_plan's active
  * rows and counts; d_out0 / d_narrow: compact [R x 64] rows (layer means of the id table, shared part);
  * d_S[m] [N x D[m]], d_c [N]: the folded constants; weights row-major as torch.nn.Linear holds them.
- * d_OutAct [R x ld_out] receives blocks 1..n_mod (block 0 = d_out0 is expected there already when they alias),
+ * d_OutAct [R x ld_out] receives blocks 1..n_mod, and block 0 too when d_out0 is a separate buffer (16-row form; when
+ * d_out0 IS block 0 of d_OutAct it is left as it is),
  * d_YAct [R x ld_y] all 1 + n_mod blocks. d_pack: scratch of elimrec_head_pack_floats floats.
  * phase: 0 = pack the weights, then the head; 1 = pack only (the weights change once per optimizer step: a caller can
  * issue this on a second stream under the forward hops); 2 = head only, d_pack holds the packed weights.
