@@ -318,15 +318,20 @@ __global__ __launch_bounds__(256) void slab_merge_rows_kernel(const float *__res
         s_beg[tid] = a0; s_end[tid] = b0;
     }
     __syncthreads();
+    // lanes per row = the power of two >= the row's float4 count: a wave takes 64 / lg rows of a rank at a time (a column
+    // shard's rows are 2-4 float4 wide; one row per wave would leave 60 lanes idle and cost a round trip per row)
+    int lg = 1;
+    while (lg < nc4 && lg < 64) lg <<= 1;
+    const int rpw = 64 / lg, sub = lane / lg, cl = lane % lg;
     for (int r = 0; r < W; ++r) {
-        for (int s = s_beg[r] + wave; s < s_end[r]; s += 4) {
+        for (int s = s_beg[r] + wave * rpw + sub; s < s_end[r]; s += 4 * rpw) {
             const int64_t node = keys[(int64_t)r * R + s];
             const int bit = (int)(node - lo);
             const bool was = (seen[bit >> 5] >> (bit & 31)) & 1u;
             const float4 *g = reinterpret_cast<const float4 *>(rows) + ((int64_t)r * R + s) * (M ? M : 2) * nc4;
             float *hT = node < U ? SrcA : SrcB;       // H lives in SrcA on user rows, SrcB on item rows
             float *gT = node < U ? SrcB : SrcA;
-            for (int c = lane; c < nc4; c += 64) {
+            for (int c = cl; c < nc4; c += lg) {
                 const int64_t idx = (((int64_t)(c >> w4_shift) * N + node) * w4 + (c & (w4 - 1))) * 4;
                 float4 h, g0;
                 if (M) {                                 // dOut rows: G = block 0, H = sum of the M blocks (block order)
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(256) void slab_merge_rows_kernel(const float *__res
                 *reinterpret_cast<float4 *>(hT + idx) = h;
                 *reinterpret_cast<float4 *>(gT + idx) = g0;
             }
-            if (lane == 0 && !was) atomicOr(&seen[bit >> 5], 1u << (bit & 31));
+            if (cl == 0 && !was) atomicOr(&seen[bit >> 5], 1u << (bit & 31));
         }
         __syncthreads();
     }
