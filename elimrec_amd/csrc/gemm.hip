@@ -251,6 +251,10 @@ __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(BwdBatch batc
 
     const int wi = (wave & 1) * 32, wj = (wave >> 1) * 64;
     const int li = lane & 31, lk = lane >> 5;
+    // 64-column problems (the single-modal heads) fill half of the 128-column tile: the waves of the empty half do not
+    // multiply zeros or write them (the reduce never reads the padding columns)
+    const bool wave_on = (j_base + wj) < n2;
+    const bool half1_on = (j_base + wj + 32) < n2;
     v16f acc0 = {0}, acc1 = {0};
     float csum = 0.f;                                      // threads 0..63: column sum of A[:, i_base + tid]
     int buf = 0;
@@ -263,13 +267,15 @@ __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(BwdBatch batc
         const bool more = (row0 + TRB) < r1;
         if (more) load_block(row0 + TRB);                  // in flight during the MFMAs below
         const float *as = As[buf], *bs = Bs[buf];
+        if (wave_on) {
 #pragma unroll
-        for (int kk = 0; kk < TRB; kk += 2) {
-            const float a = as[(kk + lk) * TN1 + wi + li];
-            const float b0 = bs[(kk + lk) * TN2 + wj + li];
-            const float b1 = bs[(kk + lk) * TN2 + wj + 32 + li];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+            for (int kk = 0; kk < TRB; kk += 2) {
+                const float a = as[(kk + lk) * TN1 + wi + li];
+                const float b0 = bs[(kk + lk) * TN2 + wj + li];
+                const float b1 = bs[(kk + lk) * TN2 + wj + 32 + li];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+            }
         }
         if (colsum_slabs && tid < TN1) {
             if (cw) {
@@ -286,11 +292,13 @@ __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(BwdBatch batc
     }
     const int n1_pad = n1_tiles * TN1, n2_pad = n2_tiles * TN2;
     float *slab = slabs + (size_t)chunk * n1_pad * n2_pad;
+    if (wave_on) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = i_base + wi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        slab[(size_t)row * n2_pad + j_base + wj + li] = acc0[r];
-        slab[(size_t)row * n2_pad + j_base + wj + 32 + li] = acc1[r];
+        for (int r = 0; r < 16; ++r) {
+            const int row = i_base + wi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            slab[(size_t)row * n2_pad + j_base + wj + li] = acc0[r];
+            if (half1_on) slab[(size_t)row * n2_pad + j_base + wj + 32 + li] = acc1[r];
+        }
     }
     if (colsum_slabs && tile_z == 0 && tid < TN1) colsum_slabs[(size_t)chunk * n1_pad + i_base + tid] = csum;
 }
