@@ -165,14 +165,19 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(FwdBatch batch) {
 
 // --------------------------------------------------------------------------------- weight grad
 // out[i, j] = sum_r A[r, i] * B[idx(r), j]   (A^T . B; the reduction runs over ROWS).
-// A workgroup owns one chunk of rows and one 64 x 128 output tile (4 waves x 2 MFMA tiles).
+// A workgroup owns one chunk of rows and one 64 x TN2 output tile (4 waves x TN2/64 MFMA tiles).
 // Rows are staged 32 at a time through LDS with 16-byte loads (a row of A or B is contiguous),
 // double-buffered: the global loads of block t+1 are in flight while block t feeds the MFMAs.
 // MFMA operands come straight from the row-major LDS image: lane (i, k) of the A operand is
 // As[k][i0 + i] -- consecutive lanes, consecutive addresses, no transpose anywhere.
 // Each workgroup writes its partial tile to slab[chunk]; slabs are summed in chunk order
 // (reduce_slabs_kernel), so the result is bitwise reproducible.
-constexpr int TN1 = 64, TN2 = 128, TRB = 32;
+#ifndef ELIMREC_BWDW_TN2
+#define ELIMREC_BWDW_TN2 64
+#endif
+constexpr int TN1 = 64, TN2 = ELIMREC_BWDW_TN2, TRB = 32;      // TN2 = 64 (one MFMA tile per wave; measured 3 us faster
+                                                                  // per step than 128 = two tiles per wave: more, smaller workgroups)
+constexpr int BNJ = TN2 / 64, BC4 = TN2 / 4, BRP = 256 / BC4, BPS = TRB / BRP;   // tiles per wave; B loader geometry
 
 struct BwdProblem {
     elimrec_linear_bwd_desc d;
@@ -212,10 +217,10 @@ __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(BwdBatch batc
 
     // loader geometry: A block = 32 rows x 16 float4 (2 per thread); B block = 32 rows x 32 float4 (4 per thread)
     const int a_row = tid >> 4, a_c4 = tid & 15;          // + 16 rows on the second pass
-    const int b_row = tid >> 5, b_c4 = tid & 31;          // + 8 rows per pass, 4 passes
+    const int b_row = tid / BC4, b_c4 = tid % BC4;        // + BRP rows per pass, BPS passes
     const bool a_col_ok = (i_base + a_c4 * 4) < n1;       // n1, n2 are multiples of 4
     const bool b_col_ok = (j_base + b_c4 * 4) < n2;
-    float4 ra[2], rbv[4];
+    float4 ra[2], rbv[BPS];
     float rw = 1.f;
     auto load_block = [&](int64_t row0) {
         if (cw && tid < TRB) {
@@ -229,8 +234,8 @@ __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(BwdBatch batc
                                          : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int64_t r = row0 + b_row + 8 * p;
+        for (int p = 0; p < BPS; ++p) {
+            const int64_t r = row0 + b_row + BRP * p;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (b_col_ok && r < r1) {
                 const int64_t br = row_index ? (int64_t)row_index[r] : r;
@@ -245,16 +250,16 @@ __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(BwdBatch batc
         for (int p = 0; p < 2; ++p)
             *reinterpret_cast<float4 *>(&As[buf][(a_row + 16 * p) * TN1 + a_c4 * 4]) = ra[p];
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-            *reinterpret_cast<float4 *>(&Bs[buf][(b_row + 8 * p) * TN2 + b_c4 * 4]) = rbv[p];
+        for (int p = 0; p < BPS; ++p)
+            *reinterpret_cast<float4 *>(&Bs[buf][(b_row + BRP * p) * TN2 + b_c4 * 4]) = rbv[p];
     };
 
-    const int wi = (wave & 1) * 32, wj = (wave >> 1) * 64;
+    const int wi = (wave & 1) * 32, wj = (wave >> 1) * (TN2 / 2);
     const int li = lane & 31, lk = lane >> 5;
     // 64-column problems (the single-modal heads) fill half of the 128-column tile: the waves of the empty half do not
     // multiply zeros or write them (the reduce never reads the padding columns)
     const bool wave_on = (j_base + wj) < n2;
-    const bool half1_on = (j_base + wj + 32) < n2;
+    const bool half1_on = BNJ > 1 && (j_base + wj + 32) < n2;
     v16f acc0 = {0}, acc1 = {0};
     float csum = 0.f;                                      // threads 0..63: column sum of A[:, i_base + tid]
     int buf = 0;
@@ -272,9 +277,11 @@ __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(BwdBatch batc
             for (int kk = 0; kk < TRB; kk += 2) {
                 const float a = as[(kk + lk) * TN1 + wi + li];
                 const float b0 = bs[(kk + lk) * TN2 + wj + li];
-                const float b1 = bs[(kk + lk) * TN2 + wj + 32 + li];
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+                if (BNJ > 1) {
+                    const float b1 = bs[(kk + lk) * TN2 + wj + (BNJ > 1 ? 32 : 0) + li];
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+                }
             }
         }
         if (colsum_slabs && tid < TN1) {
@@ -415,7 +422,7 @@ extern "C" int elimrec_linear_fwd(const float *d_A, int64_t lda, const float *d_
 static inline void bwd_w_dims(int64_t R, int n1, int n2, int &chunk_rows, int &chunks, int &t1, int &t2) {
     const int tiles = ((n1 + TN1 - 1) / TN1) * ((n2 + TN2 - 1) / TN2);
     static int target = 0;
-    if (!target) { const char *e = getenv("ELIMREC_BWDW_WGS"); target = e ? atoi(e) : 240; if (target < 8) target = 8; }
+    if (!target) { const char *e = getenv("ELIMREC_BWDW_WGS"); target = e ? atoi(e) : 480; if (target < 8) target = 8; }
     int64_t want = (R * tiles + target - 1) / target;       // rows per workgroup for ~`target` workgroups per problem
     want = (want + TRB - 1) / TRB * TRB;
     chunk_rows = (int)(want < 64 ? 64 : (want > 512 ? 512 : want));
