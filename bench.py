@@ -236,7 +236,7 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic() if world == 1 else None,
                          "limiter": "per-CU gather path, not HBM: TA busy 47 %, L1 stalled on pending misses 45 % of the launch, "
-                                    "L2 hit rate 0.60 (profiles/r02_pmc_traffic.json; DESIGN.md section 4)",
+                                    "L2 hit rate 0.60 (profiles/r02_pmc_traffic.json; DESIGN.md section 3)",
                          "algorithmic_bytes_per_launch": sb["hop_minimal"],
                          "algorithmic_bytes_formula": "read X + write X' + index stream once: 2*N*dl*4 + plan.index_bytes() (8 B per index entry + the tile / item records)",
                          "bytes_with_index_per_group": sb["hop"],
