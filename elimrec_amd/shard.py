@@ -227,11 +227,9 @@ class ColumnShardEngine(object):
             m._regions = {}                                       # recorded regions hold the old buffer's address
         bufs = self._bufs.get(B)
         if bufs is None:                                          # per batch size (an epoch ends with a ragged batch)
-            bufs = self._bufs[B] = dict(hg=torch.zeros(R, 2 * d, dtype=torch.float32, device=dev),
-                                        send_f=torch.empty(W, R, 2 * self.dl, dtype=torch.float32, device=dev) if W > 1 else None,
-                                        send_b=torch.zeros(W, R, 2 * self.dl, dtype=torch.float32, device=dev) if W > 1 else None,
-                                        counts=torch.zeros(W, dtype=torch.int32, device=dev))
-        self.hg, self.send_f, self.send_b, self.counts = bufs["hg"], bufs["send_f"], bufs["send_b"], bufs["counts"]
+            bufs = self._bufs[B] = dict(send_f=torch.empty(W, R, 2 * self.dl, dtype=torch.float32, device=dev) if W > 1 else None,
+                                        send_b=torch.zeros(W, R, 2 * self.dl, dtype=torch.float32, device=dev) if W > 1 else None)
+        self.send_f, self.send_b = bufs["send_f"], bufs["send_b"]
         if "nar_act" not in bufs:
             bufs["nar_act"] = torch.zeros(R, d, dtype=torch.float32, device=dev)       # shared part of Out, compact rows
         self.nar_act = bufs["nar_act"]
