@@ -34,6 +34,18 @@ from . import _lib, ops, slab
 PAD_KEY = -(1 << 30)
 
 
+def _all_gather_parts(loc, world, group):
+    """[world] tensors like `loc`, one per rank (host-staged when the group is gloo and `loc` lives on a device)."""
+    if loc.is_cuda and dist.get_backend(group) == "gloo":
+        host = loc.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host, group=group)
+        return [p.to(loc.device) for p in parts]
+    parts = [torch.empty_like(loc) for _ in range(world)]
+    dist.all_gather(parts, loc, group=group)
+    return parts
+
+
 class ColumnShardTrainer(object):
     def __init__(self, engine, optimizer, world_size=1, rank=0, group=None):
         self.engine, self.opt, self.world, self.rank, self.group = engine, optimizer, int(world_size), int(rank), group
@@ -52,6 +64,39 @@ class ColumnShardTrainer(object):
             b = self._buf[key] = torch.empty(shape, dtype=t.dtype, device=t.device)
         return b
 
+    # ---- collectives. RCCL ("nccl") takes the device buffers as they are. A gloo group with device tensors -- the
+    # multi-process tests that run several ranks on ONE GPU, where RCCL refuses duplicate devices -- stages through the
+    # host: same trainer, same engine, same kernels, only the transport differs.
+    class _Done(object):
+        def wait(self):
+            return True
+
+    def _staged(self, t):
+        return t.is_cuda and dist.get_backend(self.group) == "gloo"
+
+    def _all_gather(self, out, inp):
+        if not self._staged(inp):
+            return dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(host, inp.cpu(), group=self.group)
+        out.copy_(host)
+        return self._Done()
+
+    def _all_to_all(self, out, inp):
+        if not self._staged(inp):
+            return dist.all_to_all_single(out, inp, group=self.group)
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(host, inp.cpu(), group=self.group)
+        out.copy_(host)
+
+    def _all_reduce_async(self, t):
+        if not self._staged(t):
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+        t.copy_(host)
+        return self._Done()
+
     def step(self, users, pos, neg):
         """One training step on this rank's triplets; returns the local loss (0-dim tensor)."""
         eng, W = self.engine, self.world
@@ -62,7 +107,7 @@ class ColumnShardTrainer(object):
         if W > 1:
             # the id exchange runs on RCCL's stream under the forward hops, which do not need it
             acts = self._like("acts", act, W)
-            h_ids = dist.all_gather_into_tensor(acts.view(-1), act, group=self.group, async_op=True)
+            h_ids = self._all_gather(acts.view(-1), act)
             self.xgmi_bytes["all_gather"] = act.numel() * 4 * (W - 1)
         else:
             acts = act.view(1, -1)
@@ -72,7 +117,7 @@ class ColumnShardTrainer(object):
         send = eng.cs_forward_rows(acts)                         # [W, R, 2*dl]: layer means of the peers' rows, my columns
         if W > 1:
             recv = self._like("recv_f", send)
-            dist.all_to_all_single(recv, send, group=self.group)
+            self._all_to_all(recv, send)
             self.xgmi_bytes["all_to_all_fwd"] = send[0].numel() * 4 * (W - 1)
         else:
             recv = send
@@ -83,9 +128,9 @@ class ColumnShardTrainer(object):
         h_w = None
         if W > 1:
             recv2 = self._like("recv_b", send2)
-            dist.all_to_all_single(recv2, send2, group=self.group)
+            self._all_to_all(recv2, send2)
             # the projection-weight gradients are needed by the optimizer step only: reduced under the adjoint hops
-            h_w = dist.all_reduce(wgrads, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            h_w = self._all_reduce_async(wgrads)
             self.xgmi_bytes["all_to_all_bwd"] = send2[0].numel() * 4 * (W - 1)
             self.xgmi_bytes["all_reduce"] = wgrads.numel() * 4
         else:
@@ -99,7 +144,12 @@ class ColumnShardTrainer(object):
     def global_loss(self, loss):
         if self.world > 1:
             loss = loss.clone()
-            dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.group)
+            if self._staged(loss):
+                host = loss.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                loss.copy_(host)
+            else:
+                dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=self.group)
             loss /= self.world
         return loss
 
@@ -212,9 +262,7 @@ class ColumnShardEngine(object):
             self.master[self.cur].to_rows(x0d, col0=0)
             return
         loc = self.master[self.cur].dense()
-        parts = [torch.empty_like(loc) for _ in range(self.world)]
-        dist.all_gather(parts, loc, group=self.group)
-        x0d.copy_(torch.cat(parts, dim=1))
+        x0d.copy_(torch.cat(_all_gather_parts(loc, self.world, self.group), dim=1))
 
     def _workspace(self, B):
         m = self.model
@@ -610,8 +658,7 @@ class ColumnShardEngine(object):
         else:
             loc = torch.empty(N, 2 * self.dl, dtype=torch.float32, device=ws["Out"].device)
             all_rows(loc[:, :self.dl], loc[:, self.dl:])
-            parts = [torch.empty_like(loc) for _ in range(self.world)]
-            dist.all_gather(parts, loc, group=self.group)
+            parts = _all_gather_parts(loc, self.world, self.group)
             ws["Out"][:, :d].copy_(torch.cat([p[:, :self.dl] for p in parts], dim=1))
             ws["Narrow"].copy_(torch.cat([p[:, self.dl:] for p in parts], dim=1))
         m._full_tables(ws, ws["snap_views"])
@@ -622,9 +669,7 @@ class ColumnShardEngine(object):
         loc = slab.SlabTable(self.grad.n, self.ns, self.w, flat.device, data=flat).dense()
         if self.world == 1:
             return loc
-        parts = [torch.empty_like(loc) for _ in range(self.world)]
-        dist.all_gather(parts, loc, group=self.group)
-        return torch.cat(parts, dim=1)
+        return torch.cat(_all_gather_parts(loc, self.world, self.group), dim=1)
 
     @torch.no_grad()
     def optimizer_state(self):

@@ -631,3 +631,57 @@ def test_random_shapes_column_shard_vs_row_major_trainer(seed):
     assert max(abs(a - b) for a, b in zip(l0, l1)) < tol, (l0, l1, U, I, B, L, adj, recdim)
     for k in p0:
         assert (p0[k] - p1[k]).abs().max() < 2e-5 * (10 if adj == "plain" else 1), (k, U, I, B, L, adj, recdim)
+
+
+# ----------------------------------------------------------------------------- two PROCESSES, one GPU
+def _two_proc_worker(rank, world, port, out_dir):
+    import os, sys
+    import torch.distributed as dist
+    from helpers import ROOT
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)        # RCCL refuses two ranks on one device
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
+    g = load_golden("ml3")
+    model, _ = build_model_from_fixture(g, DEV)
+    opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    eng = ColumnShardEngine(model)
+    tr = ColumnShardTrainer(eng, opt, world_size=world, rank=rank)
+    losses = []
+    for t in (1, 2):
+        u, p, n = (_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg"))
+        h = len(u) // world
+        sl = slice(rank * h, (rank + 1) * h)
+        losses.append(float(tr.global_loss(tr.step(u[sl], p[sl], n[sl]))))
+    eng.sync_to_model()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), losses=np.array(losses),
+             **{k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
+    dist.destroy_process_group()
+
+
+def test_two_processes_on_one_gpu_equal_one_process(tmp_path):
+    """The real engine and the real trainer in two PROCESSES (both on cuda:0; gloo group, collectives staged through the host
+    because RCCL refuses duplicate devices): every collective of a column-sharded step executes between processes. Both ranks
+    end with the same full model, equal to one process on the concatenated batch."""
+    import torch.multiprocessing as mp
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
+    world = 2
+    port = 33500 + (os.getpid() % 2000)
+    mp.spawn(_two_proc_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rs = [dict(np.load(tmp_path / ("rank%d.npz" % r))) for r in range(world)]
+    for k in rs[0]:
+        assert np.array_equal(rs[0][k], rs[1][k]), k
+    g = load_golden("ml3")
+    model, _ = build_model_from_fixture(g, DEV)
+    opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    eng = ColumnShardEngine(model)
+    tr = ColumnShardTrainer(eng, opt)
+    losses = []
+    for t in (1, 2):
+        u, p, n = (_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg"))
+        mlen = (len(u) // world) * world
+        losses.append(float(tr.step(u[:mlen], p[:mlen], n[:mlen])))
+    eng.sync_to_model()
+    assert np.allclose(rs[0]["losses"], losses, atol=1e-5)
+    for k, v in model.state_dict().items():
+        assert np.abs(rs[0][k] - v.detach().cpu().numpy()).max() < 2e-5, k
