@@ -244,15 +244,20 @@ def main():
         }
         if world > 1:
             out["xgmi_bytes_sent_per_rank_step"] = trainer.xgmi_bytes
+        def extra(key, fn):          # the secondary lines never cost the headline: a failure is reported in place
+            try:
+                out[key] = fn()
+            except Exception as e:   # noqa: BLE001
+                out[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         if world == 1 and not args.no_eval:
-            out["eval"] = eval_pass(model, cfg, torch)
+            extra("eval", lambda: eval_pass(model, cfg, torch))
         if world == 1 and not args.no_reference_work:
-            out["reference_equivalent_work"] = reference_work_line(args, device, cfg, batches, torch)
+            extra("reference_equivalent_work", lambda: reference_work_line(args, device, cfg, batches, torch))
         if world == 1 and not args.no_bf16:
-            out["bf16_storage"] = bf16_line(args, device, cfg, batches, torch)
+            extra("bf16_storage", lambda: bf16_line(args, device, cfg, batches, torch))
         if not args.no_cpu_baseline and world == 1:     # the host baseline is timed on rank 0 at N=1 only
             cpu_batches = [tuple(x.cpu() for x in b) for b in batches[:5]]
-            out["cpu_baseline"] = cpu_baseline(ds, {k: v.cpu().numpy() for k, v in init_state.items()}, cfg, cpu_batches)
+            extra("cpu_baseline", lambda: cpu_baseline(ds, {k: v.cpu().numpy() for k, v in init_state.items()}, cfg, cpu_batches))
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
