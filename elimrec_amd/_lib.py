@@ -79,6 +79,8 @@ SIGNATURES = {
     "elimrec_linear_fwd_batched": (c_i32, [ctypes.POINTER(LinearDesc), c_i32, c_ptr]),
     "elimrec_linear_bwd_w_batched_workspace": (c_size, [ctypes.POINTER(LinearBwdDesc), c_i32]),
     "elimrec_linear_bwd_w_batched": (c_i32, [ctypes.POINTER(LinearBwdDesc), c_i32, c_ptr, c_size, c_ptr]),
+    "elimrec_linear_bwd_w_batched_merge": (c_i32, [ctypes.POINTER(LinearBwdDesc), c_i32, c_ptr, c_size, c_ptr, c_ptr, c_i32, c_i64,
+                                                   c_i64, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr]),
     "elimrec_linear_bwd_w_workspace": (c_size, [c_i64, c_i32, c_i32]),
     "elimrec_linear_bwd_w": (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_i64,
                                      c_ptr, c_i32, c_ptr, c_size, c_ptr]),

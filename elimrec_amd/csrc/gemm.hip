@@ -10,6 +10,7 @@
 //   lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31];
 //   accumulator register r of lane l is D[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][l & 31].
 #include "common.h"
+#include "merge_rows.h"
 #include <cstdlib>
 
 namespace elimrec {
@@ -187,15 +188,13 @@ struct BwdProblem {
 };
 struct BwdBatch { BwdProblem p[kMaxBatch]; int n; };
 
-__global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(BwdBatch batch) {
-    __shared__ float As[2][TRB * TN1];
-    __shared__ float Bs[2][TRB * TN2];
-    __shared__ float Wt[2][TRB];                           // per-row weights of the (weighted) column sum
+__device__ __forceinline__ void bwd_w_partial_body(const BwdBatch &batch, int block, float (*As)[TRB * TN1], float (*Bs)[TRB * TN2],
+                                                   float (*Wt)[TRB]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int pi = 0;
-    while (pi + 1 < batch.n && (int)blockIdx.x >= batch.p[pi + 1].first_block) ++pi;
+    while (pi + 1 < batch.n && block >= batch.p[pi + 1].first_block) ++pi;
     const BwdProblem &pb = batch.p[pi];
-    const int local = blockIdx.x - pb.first_block;
+    const int local = block - pb.first_block;
     const int n1_tiles = pb.t1, n2_tiles = pb.t2;
     const int chunk = local / (n1_tiles * n2_tiles);
     const int tile = local - chunk * (n1_tiles * n2_tiles);
@@ -308,6 +307,34 @@ __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(BwdBatch batc
         }
     }
     if (colsum_slabs && tile_z == 0 && tid < TN1) colsum_slabs[(size_t)chunk * n1_pad + i_base + tid] = csum;
+}
+
+__global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(BwdBatch batch) {
+    __shared__ float As[2][TRB * TN1];
+    __shared__ float Bs[2][TRB * TN2];
+    __shared__ float Wt[2][TRB];                           // per-row weights of the (weighted) column sum
+    bwd_w_partial_body(batch, (int)blockIdx.x, As, Bs, Wt);
+}
+
+// The same launch with the adjoint-source merge (merge_rows.h) as `merge_blocks` extra workgroups, in front of
+// (merge_first) or behind the weight-gradient workgroups: both read the head backward's dOut rows and nothing of each
+// other, and the merge alone is a latency-bound launch of its own on the step's critical path.
+__global__ __launch_bounds__(256) void linear_bwd_w_merge_kernel(BwdBatch batch, MergeArgs mg, int bw_blocks, int merge_blocks,
+                                                                 int merge_first) {
+    __shared__ float As[2][TRB * TN1];
+    __shared__ float Bs[2][TRB * TN2];
+    __shared__ float Wt[2][TRB];
+    int b = (int)blockIdx.x;
+    bool merge;
+    if (merge_first) { merge = b < merge_blocks; if (!merge) b -= merge_blocks; }
+    else { merge = b >= bw_blocks; if (merge) b -= bw_blocks; }
+    if (merge) {
+        // LDS of the GEMM stages, reused: two rank tables + the chunk's row bits
+        int *s_beg = reinterpret_cast<int *>(&Bs[0][0]);
+        slab_merge_rows_body(mg, b, s_beg, s_beg + kSlabMaxRanks, reinterpret_cast<uint32_t *>(&As[0][0]));
+        return;
+    }
+    bwd_w_partial_body(batch, b, As, Bs, Wt);
 }
 
 // out[e] (+)= sum over chunks of slab[chunk][e] in a FIXED order: four adjacent lanes share one output
@@ -446,8 +473,8 @@ extern "C" size_t elimrec_linear_bwd_w_batched_workspace(const elimrec_linear_bw
     return total;
 }
 
-extern "C" int elimrec_linear_bwd_w_batched(const elimrec_linear_bwd_desc *descs, int n, void *d_workspace,
-                                            size_t workspace_bytes, void *stream) {
+static int linear_bwd_w_batched_impl(const elimrec_linear_bwd_desc *descs, int n, void *d_workspace, size_t workspace_bytes,
+                                     const MergeArgs *mg, void *stream) {
     ELIMREC_REQUIRE(descs && n >= 1 && n <= kMaxBatch, "linear_bwd_w_batched: 1..%d problems", kMaxBatch);
     ELIMREC_REQUIRE(d_workspace, "linear_bwd_w: null workspace");
     if (workspace_bytes < elimrec_linear_bwd_w_batched_workspace(descs, n)) {
@@ -479,11 +506,41 @@ extern "C" int elimrec_linear_bwd_w_batched(const elimrec_linear_bwd_desc *descs
         if (out_elems > max_out) max_out = out_elems;
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(linear_bwd_w_partial_kernel, dim3(blocks), dim3(256), 0, s, batch);
+    if (mg) {
+        const int merge_blocks = (int)((mg->N + mg->chunk - 1) / mg->chunk);
+        static int merge_first = -1;
+        if (merge_first < 0) { const char *e = getenv("ELIMREC_MERGE_FIRST"); merge_first = e ? atoi(e) : 1; }
+        hipLaunchKernelGGL(linear_bwd_w_merge_kernel, dim3(blocks + merge_blocks), dim3(256), 0, s, batch, *mg, blocks, merge_blocks,
+                           merge_first);
+    } else {
+        hipLaunchKernelGGL(linear_bwd_w_partial_kernel, dim3(blocks), dim3(256), 0, s, batch);
+    }
     ELIMREC_LAUNCH_CHECK("linear_bwd_w_partial");
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((4 * max_out + 255) / 256, n), dim3(256), 0, s, batch);
     ELIMREC_LAUNCH_CHECK("reduce_slabs");
     return 0;
+}
+
+extern "C" int elimrec_linear_bwd_w_batched(const elimrec_linear_bwd_desc *descs, int n, void *d_workspace,
+                                            size_t workspace_bytes, void *stream) {
+    return linear_bwd_w_batched_impl(descs, n, d_workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int elimrec_linear_bwd_w_batched_merge(const elimrec_linear_bwd_desc *descs, int n, void *d_workspace,
+                                                  size_t workspace_bytes, const float *d_rows, const int32_t *d_keys, int world,
+                                                  int64_t R, int64_t U, int64_t I, int ns, int w, int M, float *d_SrcA,
+                                                  float *d_SrcB, uint32_t *d_mask, void *stream) {
+    ELIMREC_REQUIRE(M >= 0, "linear_bwd_w_batched_merge: M >= 0");
+    ELIMREC_REQUIRE(d_rows && d_keys && d_SrcA && d_SrcB && d_mask, "linear_bwd_w_batched_merge: null pointer");
+    ELIMREC_REQUIRE(world >= 1 && world <= kSlabMaxRanks && R >= 1 && R < INT32_MAX, "linear_bwd_w_batched_merge: 1..%d ranks", kSlabMaxRanks);
+    ELIMREC_REQUIRE(ns >= 1 && w >= 4 && (w & (w - 1)) == 0, "linear_bwd_w_batched_merge: bad slab geometry (ns=%d, w=%d)", ns, w);
+    const int64_t N = U + I;
+    int sh = 0;
+    while ((4 << sh) < w) ++sh;
+    MergeArgs mg = {d_rows, d_keys, world, (int)R, U, N, ns * (w / 4), w / 4, sh, merge_rows_chunk(N), M, d_SrcA, d_SrcB, d_mask};
+    ELIMREC_REQUIRE(mg.chunk / 32 <= kMergeSeenWords, "linear_bwd_w_batched_merge: %lld rows are more than the fused launch takes "
+                    "(call elimrec_slab_merge_rows)", (long long)N);
+    return linear_bwd_w_batched_impl(descs, n, d_workspace, workspace_bytes, N > 0 ? &mg : nullptr, stream);
 }
 
 extern "C" int elimrec_linear_bwd_w(const float *d_A, int64_t lda, const float *d_B, int64_t ldb,

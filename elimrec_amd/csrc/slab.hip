@@ -12,6 +12,7 @@
 // decreasing length; a lane group of LPR = spg*w/4 lanes owns one item, a wave 64/LPR items of similar length, and
 // the (col, val) of step j of the wave's items are consecutive in memory. HBM/L2-bound (9 flop per 4-B gathered).
 #include "common.h"
+#include "merge_rows.h"
 #include <hip/hip_bf16.h>
 #include <cstdlib>
 
@@ -292,79 +293,10 @@ __global__ void slab_to_rows_kernel(const float4 *__restrict__ slab, int64_t n, 
 // Rank-ordered merge of [H | G] rows into the slab-major adjoint sources: a workgroup owns a range of node ids, finds
 // the slice of every rank's ascending key list that falls into it (binary searches, one thread per rank) and walks the
 // ranks IN RANK ORDER with a barrier in between; a node seen before (LDS bitmap) is accumulated, otherwise written.
-constexpr int kSlabMaxRanks = 64;
-
-__device__ __forceinline__ int slab_merge_key(const int32_t *keys, int i) {
-    const int k = keys[i];
-    return k < 0 ? INT32_MAX : k;
-}
-
-__global__ __launch_bounds__(256) void slab_merge_rows_kernel(const float *__restrict__ rows, const int32_t *__restrict__ keys,
-                                                              int W, int R, int64_t U, int64_t N, int nc4, int w4,
-                                                              int w4_shift, int chunk, int M, float *SrcA, float *SrcB,
-                                                              uint32_t *__restrict__ mask) {
+__global__ __launch_bounds__(256) void slab_merge_rows_kernel(MergeArgs a) {
     __shared__ int s_beg[kSlabMaxRanks], s_end[kSlabMaxRanks];
     extern __shared__ uint32_t seen[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(lo + chunk, N);
-    for (int w = tid; w < chunk / 32; w += 256) seen[w] = 0u;
-    if (tid < W) {
-        const int32_t *kr = keys + (int64_t)tid * R;
-        int a0 = 0, a1 = R, b0 = 0, b1 = R;
-        while (a0 < a1 || b0 < b1) {
-            if (a0 < a1) { const int m = (a0 + a1) >> 1; if (slab_merge_key(kr, m) < lo) a0 = m + 1; else a1 = m; }
-            if (b0 < b1) { const int m = (b0 + b1) >> 1; if (slab_merge_key(kr, m) < hi) b0 = m + 1; else b1 = m; }
-        }
-        s_beg[tid] = a0; s_end[tid] = b0;
-    }
-    __syncthreads();
-    // lanes per row = the power of two >= the row's float4 count: a wave takes 64 / lg rows of a rank at a time (a column
-    // shard's rows are 2-4 float4 wide; one row per wave would leave 60 lanes idle and cost a round trip per row)
-    int lg = 1;
-    while (lg < nc4 && lg < 64) lg <<= 1;
-    const int rpw = 64 / lg, sub = lane / lg, cl = lane % lg;
-    for (int r = 0; r < W; ++r) {
-        for (int s = s_beg[r] + wave * rpw + sub; s < s_end[r]; s += 4 * rpw) {
-            const int64_t node = keys[(int64_t)r * R + s];
-            const int bit = (int)(node - lo);
-            const bool was = (seen[bit >> 5] >> (bit & 31)) & 1u;
-            const float4 *g = reinterpret_cast<const float4 *>(rows) + ((int64_t)r * R + s) * (M ? M : 2) * nc4;
-            float *hT = node < U ? SrcA : SrcB;       // H lives in SrcA on user rows, SrcB on item rows
-            float *gT = node < U ? SrcB : SrcA;
-            for (int c = cl; c < nc4; c += lg) {
-                const int64_t idx = (((int64_t)(c >> w4_shift) * N + node) * w4 + (c & (w4 - 1))) * 4;
-                float4 h, g0;
-                if (M) {                                 // dOut rows: G = block 0, H = sum of the M blocks (block order)
-                    g0 = g[c];
-                    h = g0;
-                    for (int mb = 1; mb < M; ++mb) {
-                        const float4 x = g[mb * nc4 + c];
-                        h.x += x.x; h.y += x.y; h.z += x.z; h.w += x.w;
-                    }
-                } else { h = g[c]; g0 = g[nc4 + c]; }
-                if (was) {                               // written by an earlier rank of this workgroup: read through L2
-                    float *hp = hT + idx, *gp = gT + idx;
-                    float4 x, y;
-                    x.x = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    x.y = __hip_atomic_load(hp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    x.z = __hip_atomic_load(hp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    x.w = __hip_atomic_load(hp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    y.x = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    y.y = __hip_atomic_load(gp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    y.z = __hip_atomic_load(gp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    y.w = __hip_atomic_load(gp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    h = make_float4(x.x + h.x, x.y + h.y, x.z + h.z, x.w + h.w);
-                    g0 = make_float4(y.x + g0.x, y.y + g0.y, y.z + g0.z, y.w + g0.w);
-                }
-                *reinterpret_cast<float4 *>(hT + idx) = h;
-                *reinterpret_cast<float4 *>(gT + idx) = g0;
-            }
-            if (cl == 0 && !was) atomicOr(&seen[bit >> 5], 1u << (bit & 31));
-        }
-        __syncthreads();
-    }
-    for (int w = tid; w < chunk / 32; w += 256)
-        if (lo + 32 * (int64_t)w < ((N + 31) / 32) * 32) mask[lo / 32 + w] = seen[w];
+    slab_merge_rows_body(a, (int)blockIdx.x, s_beg, s_end, seen);
 }
 
 __global__ void adam_out_kernel(const float *__restrict__ p_in, float *__restrict__ p_out, const float *__restrict__ g,
@@ -1815,14 +1747,10 @@ extern "C" int elimrec_slab_merge_rows(const float *d_rows, const int32_t *d_key
     int sh, rc;
     const int64_t N = U + I;
     if ((rc = slab_simple_geometry("slab_merge_rows", N, ns, w, sh))) return rc;
-    int chunk = (int)((N + 1023) / 1024);
-    chunk = (chunk + 31) / 32 * 32;
-    if (chunk < 32) chunk = 32;
-    const unsigned grid = (unsigned)((N + chunk - 1) / chunk);
+    MergeArgs a = {d_rows, d_keys, world, (int)R, U, N, ns * (w / 4), w / 4, sh, merge_rows_chunk(N), M, d_SrcA, d_SrcB, d_mask};
+    const unsigned grid = (unsigned)((N + a.chunk - 1) / a.chunk);
     if (grid == 0) return 0;
-    hipLaunchKernelGGL(slab_merge_rows_kernel, dim3(grid), dim3(256), (size_t)(chunk / 32) * sizeof(uint32_t),
-                       (hipStream_t)stream, d_rows, d_keys, world, (int)R, U, N, ns * (w / 4), w / 4, sh, chunk, M, d_SrcA, d_SrcB,
-                       d_mask);
+    hipLaunchKernelGGL(slab_merge_rows_kernel, dim3(grid), dim3(256), (size_t)(a.chunk / 32) * sizeof(uint32_t), (hipStream_t)stream, a);
     ELIMREC_LAUNCH_CHECK("slab_merge_rows");
     return 0;
 }

@@ -114,9 +114,22 @@ def linear_bwd_w_batched_workspace(shapes):
     return int(_lib.load().elimrec_linear_bwd_w_batched_workspace(arr, n))
 
 
-def linear_bwd_w_batched(problems, workspace):
-    """problems: list of dicts(A, B, out[, row_index, rng, colsum, accumulate, rows]) in one launch pair."""
+def linear_bwd_w_batched(problems, workspace, merge=None):
+    """problems: list of dicts(A, B, out[, row_index, rng, colsum, accumulate, rows]) in one launch pair.
+    merge: dict(rows, keys, world, U, I, srcA, srcB, mask, M) -- the arguments of slab.merge_rows, run as extra workgroups
+    of the partial launch (elimrec_linear_bwd_w_batched_merge)."""
     arr, n = _bwd_descs(problems)
+    if merge is not None:
+        rows, keys, srcA, srcB, M, world = merge["rows"], merge["keys"], merge["srcA"], merge["srcB"], merge["M"], merge["world"]
+        R = keys.numel() // world
+        assert rows.is_contiguous() and rows.shape == (world * R, (M if M else 2) * srcA.cols)
+        assert merge["mask"].numel() * 32 >= merge["U"] + merge["I"]
+        _lib.check(_lib.load().elimrec_linear_bwd_w_batched_merge(
+            arr, n, _dev(workspace, "workspace", torch.uint8), workspace.numel(), _dev(rows, "rows"),
+            _dev(keys, "keys", torch.int32), int(world), R, int(merge["U"]), int(merge["I"]), srcA.ns, srcA.w, int(M),
+            _dev(srcA.data, "srcA"), _dev(srcB.data, "srcB"), _dev(merge["mask"], "mask", torch.int32), _stream()),
+            "linear_bwd_w_batched_merge")
+        return
     _lib.check(_lib.load().elimrec_linear_bwd_w_batched(arr, n, _dev(workspace, "workspace", torch.uint8),
                                                         workspace.numel(), _stream()), "linear_bwd_w_batched")
 

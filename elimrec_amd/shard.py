@@ -327,6 +327,10 @@ class ColumnShardEngine(object):
         return (not self.bf16 and self.planT.tiered and self.model.n_layers >= 2
                 and os.environ.get("ELIMREC_FUSE_ADAM", "1") != "0")
 
+    def _fuse_merge(self):
+        import os
+        return os.environ.get("ELIMREC_FUSE_MERGE", "1") != "0" and (self.model.num_users + self.model.num_items) <= (1 << 27)
+
     def _timed(self, fn, hops):
         ev = self.kernel_events
         if ev is None:
@@ -515,8 +519,16 @@ class ColumnShardEngine(object):
         R = m._plan_n
         # the head backward reads its weight operands from the packed copy the fused forward left behind (16-row forms)
         pack_bwd = self._pack[self._pack_bwd_off:] if (self._fused_head_ok() and self._pack_bwd_off) else None
-        self._grads = m._backward_batch_rows(ws, scale, ws["grad_rows"], R, head_only=True,
-                                             w_stream=self._side_stream() if self.world == 1 else None, pack_bwd=pack_bwd)
+        side = self._side_stream() if self.world == 1 else None
+        # one rank: the merge of the dOut rows into the adjoint sources rides in the weight-gradient launch (both read the
+        # head backward's rows and nothing of each other; ELIMREC_FUSE_MERGE=0: a launch of its own before the hops)
+        merge = None
+        if self.world == 1 and side is None and self._fuse_merge():
+            merge = dict(rows=ws["dOutR"][:R].view(R, m.C), keys=self._acts.reshape(-1), world=1, U=m.num_users, I=m.num_items,
+                         srcA=self.srcA, srcB=self.srcB, mask=self.mask, M=m.M)
+        self._merged = merge is not None
+        self._grads = m._backward_batch_rows(ws, scale, ws["grad_rows"], R, head_only=True, w_stream=side, pack_bwd=pack_bwd,
+                                             merge=merge)
         wg = ws["flat_grad"][ws["tail_off"]:]
         if self.world == 1:       # one rank owns every column: the merge reads the dOut rows themselves
             return ws["dOutR"][:R].view(1, R, m.C), wg
@@ -538,8 +550,12 @@ class ColumnShardEngine(object):
         fuse = self._fuse_adam()
         last = 1 if fuse else 0                                    # the hops the recorded region covers: L-1 .. last
 
+        merged = W == 1 and getattr(self, "_merged", False)
+
         def hops():
-            if W == 1:
+            if merged:
+                pass                                               # done beside the weight gradients (cs_backward_local)
+            elif W == 1:
                 slab.merge_rows(recv2.view(R, m.C), acts.reshape(-1), 1, U, I, self.srcA, self.srcB, self.mask, M=m.M)
             else:
                 slab.merge_rows(recv2.view(W * R, 2 * self.dl), acts.reshape(-1), W, U, I, self.srcA, self.srcB, self.mask)
@@ -549,7 +565,7 @@ class ColumnShardEngine(object):
                 slab.hop(self.planT, t, dst, gs=self.gs, src_mask=tmask, add=self.srcB if (k & 1) else self.srcA,
                          add_mask=self.mask, scale=inv if k == 0 else 1.0, bits_ready=tmask is not None and self._bits_ready)
                 t, tmask = dst, None
-        self._timed(lambda: m._region("cs_bwd_hops", (m._ws_gen, recv2.data_ptr(), acts.data_ptr(), R, W, fuse, self._bits_ready), hops), L - last)
+        self._timed(lambda: m._region("cs_bwd_hops", (m._ws_gen, recv2.data_ptr(), acts.data_ptr(), R, W, fuse, self._bits_ready, merged), hops), L - last)
         self._adam_in_hop = fuse
         self._tail_in_hop = False
         if fuse:

@@ -124,6 +124,14 @@ typedef struct elimrec_linear_bwd_desc {
 size_t elimrec_linear_bwd_w_batched_workspace(const elimrec_linear_bwd_desc *descs, int n);
 int elimrec_linear_bwd_w_batched(const elimrec_linear_bwd_desc *descs /* host array */, int n,
                                  void *d_workspace, size_t workspace_bytes, void *stream);
+/* The same, with elimrec_slab_merge_rows (arguments as there, declared below) as extra workgroups of the partial
+ * launch: both consume the head backward's dOut rows and nothing of each other (IndexBackward into the adjoint sources
+ * next to AddmmBackward's dW -- /root/reference/models/EliMRec.py:262-270 under autograd), so the latency-bound merge
+ * costs no launch of its own. Same bits as the two calls. (U + I) / 1024 <= 131072 rows per workgroup. */
+int elimrec_linear_bwd_w_batched_merge(const elimrec_linear_bwd_desc *descs /* host array */, int n, void *d_workspace,
+                                       size_t workspace_bytes, const float *d_rows, const int32_t *d_keys, int world,
+                                       int64_t R, int64_t U, int64_t I, int ns, int w, int M, float *d_SrcA,
+                                       float *d_SrcB, uint32_t *d_mask, void *stream);
 
 /* ---------------------------------------------------------------- layer-0 table assembly (K2)
  * X0[u, m*d + j] = user_emb[u, j] for every table m;  X0[U+i, j] = item_emb[i, j].
