@@ -1,0 +1,126 @@
+// Weight-gradient contraction (gemm.hip): problem table, decomposition and the fixed-order slab reduce, shared with the
+// hop launch that can carry the reduce as extra workgroups (slab.hip, elimrec_slab_hop_reduce).
+#pragma once
+#include "common.h"
+#include <cstdlib>
+
+namespace elimrec {
+
+constexpr int kMaxBatch = 8;
+#ifndef ELIMREC_BWDW_TN2
+#define ELIMREC_BWDW_TN2 64
+#endif
+constexpr int TN1 = 64, TN2 = ELIMREC_BWDW_TN2, TRB = 32;      // TN2 = 64 (one MFMA tile per wave; measured 3 us faster
+                                                                  // per step than 128 = two tiles per wave: more, smaller workgroups)
+constexpr int BNJ = TN2 / 64, BC4 = TN2 / 4, BRP = 256 / BC4, BPS = TRB / BRP;   // tiles per wave; B loader geometry
+
+struct BwdProblem {
+    elimrec_linear_bwd_desc d;
+    int chunk_rows, chunks, t1, t2;       // decomposition
+    int first_block;                      // prefix of (chunks * t1 * t2) over the problems before this one
+    float *slabs, *cslabs;
+};
+struct BwdBatch { BwdProblem p[kMaxBatch]; int n; };
+
+// out[e] (+)= sum over chunks of slab[chunk][e] in a FIXED order: four adjacent lanes share one output
+// element, lane q adds chunks q, q+4, q+8, ... (4 loads in flight each), then (q0+q1)+(q2+q3).
+// by selects the problem; 256 threads per workgroup.
+__device__ __forceinline__ void reduce_slabs_body(const BwdBatch &batch, int bx, int by) {
+    const BwdProblem &pb = batch.p[by];
+    const int n1 = pb.d.n1, n2 = pb.d.n2;
+    const int n1_pad = pb.t1 * TN1, n2_pad = pb.t2 * TN2;
+    const int gid = bx * 256 + (int)threadIdx.x;
+    const int idx = gid >> 2, q = gid & 3;
+    const int total = n1 * n2;
+    int64_t rows = pb.d.d_range ? (int64_t)pb.d.d_range[1] - pb.d.d_range[0] : pb.d.R;
+    if (rows < 0) rows = 0;
+    const int chunks = (int)((rows + pb.chunk_rows - 1) / pb.chunk_rows);
+    const float *src = nullptr;
+    size_t stride = 0;
+    float *dst = nullptr;
+    if (idx < total) {
+        const int i = idx / n2, j = idx - i * n2;
+        src = pb.slabs + (size_t)i * n2_pad + j;
+        stride = (size_t)n1_pad * n2_pad;
+        dst = pb.d.d_out + (int64_t)i * pb.d.ldo + j;
+    } else if (pb.d.d_colsum && idx < total + n1) {
+        src = pb.cslabs + (idx - total);
+        stride = (size_t)n1_pad;
+        dst = pb.d.d_colsum + (idx - total);
+    }
+    float s = 0.f;
+    if (src) {
+        int c = q;
+        for (; c + 12 < chunks; c += 16) {
+            const float v0 = src[(size_t)c * stride], v1 = src[(size_t)(c + 4) * stride];
+            const float v2 = src[(size_t)(c + 8) * stride], v3 = src[(size_t)(c + 12) * stride];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; c < chunks; c += 4) s += src[(size_t)c * stride];
+    }
+    s += __shfl_xor(s, 1, 64);       // (q0+q1), (q2+q3)
+    s += __shfl_xor(s, 2, 64);       // sum of the two pairs
+    if (src && q == 0) *dst = pb.d.accumulate ? (*dst + s) : s;
+}
+
+
+// ---- host side
+// Row-chunk size: the partial kernel holds 48 KB of LDS, i.e. 3 workgroups per CU = 768 resident at once;
+// chunks are sized so that one problem's workgroups fill about a third of that (batches hold ~3 problems
+// of equal weight) in ONE round, between 64 and 512 rows.
+static inline void bwd_w_dims(int64_t R, int n1, int n2, int &chunk_rows, int &chunks, int &t1, int &t2) {
+    const int tiles = ((n1 + TN1 - 1) / TN1) * ((n2 + TN2 - 1) / TN2);
+    static int target = 0;
+    if (!target) { const char *e = getenv("ELIMREC_BWDW_WGS"); target = e ? atoi(e) : 480; if (target < 8) target = 8; }
+    int64_t want = (R * tiles + target - 1) / target;       // rows per workgroup for ~`target` workgroups per problem
+    want = (want + TRB - 1) / TRB * TRB;
+    chunk_rows = (int)(want < 64 ? 64 : (want > 512 ? 512 : want));
+    chunks = (int)((R + chunk_rows - 1) / chunk_rows);
+    if (chunks < 1) chunks = 1;
+    t1 = (n1 + TN1 - 1) / TN1;
+    t2 = (n2 + TN2 - 1) / TN2;
+}
+
+static inline size_t bwd_w_bytes(int64_t R, int n1, int n2) {
+    int cr, chunks, t1, t2;
+    bwd_w_dims(R, n1, n2, cr, chunks, t1, t2);
+    return align_up(((size_t)chunks * t1 * TN1 * t2 * TN2 + (size_t)chunks * t1 * TN1) * sizeof(float), 256);
+}
+
+
+// fills the problem table of `n` contractions whose slabs live in d_workspace; blocks = workgroups of the partial launch,
+// max_out = the largest problem's output elements (the reduce runs a (4 * max_out / 256) x n grid)
+static inline int bwd_w_build_batch(const elimrec_linear_bwd_desc *descs, int n, void *d_workspace, BwdBatch &batch, int &blocks,
+                                    int &max_out) {
+    batch.n = n;
+    char *ws = (char *)d_workspace;
+    blocks = 0; max_out = 0;
+    for (int i = 0; i < n; ++i) {
+        const elimrec_linear_bwd_desc &d = descs[i];
+        ELIMREC_REQUIRE(d.d_A && d.d_B && d.d_out, "linear_bwd_w: null pointer");
+        ELIMREC_REQUIRE(d.R >= 0 && d.n1 > 0 && d.n2 > 0, "linear_bwd_w: bad shape");
+        ELIMREC_REQUIRE(d.n1 % 4 == 0 && d.n2 % 4 == 0 && d.lda % 4 == 0 && d.ldb % 4 == 0,
+                        "linear_bwd_w: n1, n2, lda, ldb must be multiples of 4");
+        ELIMREC_REQUIRE(((uintptr_t)d.d_A % 16) == 0 && ((uintptr_t)d.d_B % 16) == 0,
+                        "linear_bwd_w: A and B must be 16-byte aligned");
+        BwdProblem &pb = batch.p[i];
+        pb.d = d;
+        bwd_w_dims(d.R, d.n1, d.n2, pb.chunk_rows, pb.chunks, pb.t1, pb.t2);
+        pb.first_block = blocks;
+        blocks += pb.chunks * pb.t1 * pb.t2;
+        pb.slabs = (float *)ws;
+        pb.cslabs = pb.slabs + (size_t)pb.chunks * pb.t1 * TN1 * pb.t2 * TN2;
+        ws += bwd_w_bytes(d.R, d.n1, d.n2);
+        const int out_elems = d.n1 * d.n2 + (d.d_colsum ? d.n1 : 0);
+        if (out_elems > max_out) max_out = out_elems;
+    }
+    return 0;
+}
+
+static inline size_t bwd_w_batched_bytes(const elimrec_linear_bwd_desc *descs, int n) {
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += bwd_w_bytes(descs[i].R, descs[i].n1, descs[i].n2);
+    return total;
+}
+
+}  // namespace elimrec

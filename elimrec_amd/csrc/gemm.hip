@@ -11,6 +11,7 @@
 //   accumulator register r of lane l is D[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][l & 31].
 #include "common.h"
 #include "merge_rows.h"
+#include "bwd_w.h"
 #include <cstdlib>
 
 namespace elimrec {
@@ -22,7 +23,6 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 // (row stride 33 floats: the 32 lanes of a half-wave read 32 different rows at the same k).
 constexpr int FBN = 64, FBK = 16, FLD = FBK + 1;
 
-constexpr int kMaxBatch = 8;
 struct FwdBatch { elimrec_linear_desc p[kMaxBatch]; };
 
 // blockIdx.z selects the problem: independent Linears (the three feature projections; the five head
@@ -173,21 +173,6 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(FwdBatch batch) {
 // As[k][i0 + i] -- consecutive lanes, consecutive addresses, no transpose anywhere.
 // Each workgroup writes its partial tile to slab[chunk]; slabs are summed in chunk order
 // (reduce_slabs_kernel), so the result is bitwise reproducible.
-#ifndef ELIMREC_BWDW_TN2
-#define ELIMREC_BWDW_TN2 64
-#endif
-constexpr int TN1 = 64, TN2 = ELIMREC_BWDW_TN2, TRB = 32;      // TN2 = 64 (one MFMA tile per wave; measured 3 us faster
-                                                                  // per step than 128 = two tiles per wave: more, smaller workgroups)
-constexpr int BNJ = TN2 / 64, BC4 = TN2 / 4, BRP = 256 / BC4, BPS = TRB / BRP;   // tiles per wave; B loader geometry
-
-struct BwdProblem {
-    elimrec_linear_bwd_desc d;
-    int chunk_rows, chunks, t1, t2;       // decomposition
-    int first_block;                      // prefix of (chunks * t1 * t2) over the problems before this one
-    float *slabs, *cslabs;
-};
-struct BwdBatch { BwdProblem p[kMaxBatch]; int n; };
-
 __device__ __forceinline__ void bwd_w_partial_body(const BwdBatch &batch, int block, float (*As)[TRB * TN1], float (*Bs)[TRB * TN2],
                                                    float (*Wt)[TRB]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -337,46 +322,7 @@ __global__ __launch_bounds__(256) void linear_bwd_w_merge_kernel(BwdBatch batch,
     bwd_w_partial_body(batch, b, As, Bs, Wt);
 }
 
-// out[e] (+)= sum over chunks of slab[chunk][e] in a FIXED order: four adjacent lanes share one output
-// element, lane q adds chunks q, q+4, q+8, ... (4 loads in flight each), then (q0+q1)+(q2+q3).
-// blockIdx.y selects the problem.
-__global__ void reduce_slabs_kernel(BwdBatch batch) {
-    const BwdProblem &pb = batch.p[blockIdx.y];
-    const int n1 = pb.d.n1, n2 = pb.d.n2;
-    const int n1_pad = pb.t1 * TN1, n2_pad = pb.t2 * TN2;
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int idx = gid >> 2, q = gid & 3;
-    const int total = n1 * n2;
-    int64_t rows = pb.d.d_range ? (int64_t)pb.d.d_range[1] - pb.d.d_range[0] : pb.d.R;
-    if (rows < 0) rows = 0;
-    const int chunks = (int)((rows + pb.chunk_rows - 1) / pb.chunk_rows);
-    const float *src = nullptr;
-    size_t stride = 0;
-    float *dst = nullptr;
-    if (idx < total) {
-        const int i = idx / n2, j = idx - i * n2;
-        src = pb.slabs + (size_t)i * n2_pad + j;
-        stride = (size_t)n1_pad * n2_pad;
-        dst = pb.d.d_out + (int64_t)i * pb.d.ldo + j;
-    } else if (pb.d.d_colsum && idx < total + n1) {
-        src = pb.cslabs + (idx - total);
-        stride = (size_t)n1_pad;
-        dst = pb.d.d_colsum + (idx - total);
-    }
-    float s = 0.f;
-    if (src) {
-        int c = q;
-        for (; c + 12 < chunks; c += 16) {
-            const float v0 = src[(size_t)c * stride], v1 = src[(size_t)(c + 4) * stride];
-            const float v2 = src[(size_t)(c + 8) * stride], v3 = src[(size_t)(c + 12) * stride];
-            s += v0; s += v1; s += v2; s += v3;
-        }
-        for (; c < chunks; c += 4) s += src[(size_t)c * stride];
-    }
-    s += __shfl_xor(s, 1, 64);       // (q0+q1), (q2+q3)
-    s += __shfl_xor(s, 2, 64);       // sum of the two pairs
-    if (src && q == 0) *dst = pb.d.accumulate ? (*dst + s) : s;
-}
+__global__ void reduce_slabs_kernel(BwdBatch batch) { reduce_slabs_body(batch, (int)blockIdx.x, (int)blockIdx.y); }
 
 }  // namespace elimrec
 
@@ -443,28 +389,6 @@ extern "C" int elimrec_linear_fwd(const float *d_A, int64_t lda, const float *d_
     return elimrec_linear_fwd_batched(&d, 1, stream);
 }
 
-// Row-chunk size: the partial kernel holds 48 KB of LDS, i.e. 3 workgroups per CU = 768 resident at once;
-// chunks are sized so that one problem's workgroups fill about a third of that (batches hold ~3 problems
-// of equal weight) in ONE round, between 64 and 512 rows.
-static inline void bwd_w_dims(int64_t R, int n1, int n2, int &chunk_rows, int &chunks, int &t1, int &t2) {
-    const int tiles = ((n1 + TN1 - 1) / TN1) * ((n2 + TN2 - 1) / TN2);
-    static int target = 0;
-    if (!target) { const char *e = getenv("ELIMREC_BWDW_WGS"); target = e ? atoi(e) : 480; if (target < 8) target = 8; }
-    int64_t want = (R * tiles + target - 1) / target;       // rows per workgroup for ~`target` workgroups per problem
-    want = (want + TRB - 1) / TRB * TRB;
-    chunk_rows = (int)(want < 64 ? 64 : (want > 512 ? 512 : want));
-    chunks = (int)((R + chunk_rows - 1) / chunk_rows);
-    if (chunks < 1) chunks = 1;
-    t1 = (n1 + TN1 - 1) / TN1;
-    t2 = (n2 + TN2 - 1) / TN2;
-}
-
-static inline size_t bwd_w_bytes(int64_t R, int n1, int n2) {
-    int cr, chunks, t1, t2;
-    bwd_w_dims(R, n1, n2, cr, chunks, t1, t2);
-    return align_up(((size_t)chunks * t1 * TN1 * t2 * TN2 + (size_t)chunks * t1 * TN1) * sizeof(float), 256);
-}
-
 extern "C" size_t elimrec_linear_bwd_w_workspace(int64_t R, int n1, int n2) { return bwd_w_bytes(R, n1, n2); }
 
 extern "C" size_t elimrec_linear_bwd_w_batched_workspace(const elimrec_linear_bwd_desc *descs, int n) {
@@ -474,7 +398,7 @@ extern "C" size_t elimrec_linear_bwd_w_batched_workspace(const elimrec_linear_bw
 }
 
 static int linear_bwd_w_batched_impl(const elimrec_linear_bwd_desc *descs, int n, void *d_workspace, size_t workspace_bytes,
-                                     const MergeArgs *mg, void *stream) {
+                                     const MergeArgs *mg, int defer_reduce, void *stream) {
     ELIMREC_REQUIRE(descs && n >= 1 && n <= kMaxBatch, "linear_bwd_w_batched: 1..%d problems", kMaxBatch);
     ELIMREC_REQUIRE(d_workspace, "linear_bwd_w: null workspace");
     if (workspace_bytes < elimrec_linear_bwd_w_batched_workspace(descs, n)) {
@@ -483,28 +407,8 @@ static int linear_bwd_w_batched_impl(const elimrec_linear_bwd_desc *descs, int n
         return ELIMREC_E_WORKSPACE;
     }
     BwdBatch batch;
-    batch.n = n;
-    char *ws = (char *)d_workspace;
-    int blocks = 0, max_out = 0;
-    for (int i = 0; i < n; ++i) {
-        const elimrec_linear_bwd_desc &d = descs[i];
-        ELIMREC_REQUIRE(d.d_A && d.d_B && d.d_out, "linear_bwd_w: null pointer");
-        ELIMREC_REQUIRE(d.R >= 0 && d.n1 > 0 && d.n2 > 0, "linear_bwd_w: bad shape");
-        ELIMREC_REQUIRE(d.n1 % 4 == 0 && d.n2 % 4 == 0 && d.lda % 4 == 0 && d.ldb % 4 == 0,
-                        "linear_bwd_w: n1, n2, lda, ldb must be multiples of 4");
-        ELIMREC_REQUIRE(((uintptr_t)d.d_A % 16) == 0 && ((uintptr_t)d.d_B % 16) == 0,
-                        "linear_bwd_w: A and B must be 16-byte aligned");
-        BwdProblem &pb = batch.p[i];
-        pb.d = d;
-        bwd_w_dims(d.R, d.n1, d.n2, pb.chunk_rows, pb.chunks, pb.t1, pb.t2);
-        pb.first_block = blocks;
-        blocks += pb.chunks * pb.t1 * pb.t2;
-        pb.slabs = (float *)ws;
-        pb.cslabs = pb.slabs + (size_t)pb.chunks * pb.t1 * TN1 * pb.t2 * TN2;
-        ws += bwd_w_bytes(d.R, d.n1, d.n2);
-        const int out_elems = d.n1 * d.n2 + (d.d_colsum ? d.n1 : 0);
-        if (out_elems > max_out) max_out = out_elems;
-    }
+    int blocks = 0, max_out = 0, rc;
+    if ((rc = bwd_w_build_batch(descs, n, d_workspace, batch, blocks, max_out))) return rc;
     hipStream_t s = (hipStream_t)stream;
     if (mg) {
         const int merge_blocks = (int)((mg->N + mg->chunk - 1) / mg->chunk);
@@ -516,22 +420,36 @@ static int linear_bwd_w_batched_impl(const elimrec_linear_bwd_desc *descs, int n
         hipLaunchKernelGGL(linear_bwd_w_partial_kernel, dim3(blocks), dim3(256), 0, s, batch);
     }
     ELIMREC_LAUNCH_CHECK("linear_bwd_w_partial");
+    if (defer_reduce) return 0;
     hipLaunchKernelGGL(reduce_slabs_kernel, dim3((4 * max_out + 255) / 256, n), dim3(256), 0, s, batch);
+    ELIMREC_LAUNCH_CHECK("reduce_slabs");
+    return 0;
+}
+
+extern "C" int elimrec_linear_bwd_w_reduce(const elimrec_linear_bwd_desc *descs, int n, void *d_workspace, size_t workspace_bytes,
+                                           void *stream) {
+    ELIMREC_REQUIRE(descs && n >= 1 && n <= kMaxBatch, "linear_bwd_w_reduce: 1..%d problems", kMaxBatch);
+    ELIMREC_REQUIRE(d_workspace && workspace_bytes >= bwd_w_batched_bytes(descs, n), "linear_bwd_w_reduce: workspace");
+    BwdBatch batch;
+    int blocks = 0, max_out = 0, rc;
+    if ((rc = bwd_w_build_batch(descs, n, d_workspace, batch, blocks, max_out))) return rc;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3((4 * max_out + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, batch);
     ELIMREC_LAUNCH_CHECK("reduce_slabs");
     return 0;
 }
 
 extern "C" int elimrec_linear_bwd_w_batched(const elimrec_linear_bwd_desc *descs, int n, void *d_workspace,
                                             size_t workspace_bytes, void *stream) {
-    return linear_bwd_w_batched_impl(descs, n, d_workspace, workspace_bytes, nullptr, stream);
+    return linear_bwd_w_batched_impl(descs, n, d_workspace, workspace_bytes, nullptr, 0, stream);
 }
 
 extern "C" int elimrec_linear_bwd_w_batched_merge(const elimrec_linear_bwd_desc *descs, int n, void *d_workspace,
                                                   size_t workspace_bytes, const float *d_rows, const int32_t *d_keys, int world,
                                                   int64_t R, int64_t U, int64_t I, int ns, int w, int M, float *d_SrcA,
-                                                  float *d_SrcB, uint32_t *d_mask, void *stream) {
+                                                  float *d_SrcB, uint32_t *d_mask, int defer_reduce, void *stream) {
+    if (!d_rows) return linear_bwd_w_batched_impl(descs, n, d_workspace, workspace_bytes, nullptr, defer_reduce, stream);
     ELIMREC_REQUIRE(M >= 0, "linear_bwd_w_batched_merge: M >= 0");
-    ELIMREC_REQUIRE(d_rows && d_keys && d_SrcA && d_SrcB && d_mask, "linear_bwd_w_batched_merge: null pointer");
+    ELIMREC_REQUIRE(d_keys && d_SrcA && d_SrcB && d_mask, "linear_bwd_w_batched_merge: null pointer");
     ELIMREC_REQUIRE(world >= 1 && world <= kSlabMaxRanks && R >= 1 && R < INT32_MAX, "linear_bwd_w_batched_merge: 1..%d ranks", kSlabMaxRanks);
     ELIMREC_REQUIRE(ns >= 1 && w >= 4 && (w & (w - 1)) == 0, "linear_bwd_w_batched_merge: bad slab geometry (ns=%d, w=%d)", ns, w);
     const int64_t N = U + I;
@@ -540,7 +458,7 @@ extern "C" int elimrec_linear_bwd_w_batched_merge(const elimrec_linear_bwd_desc 
     MergeArgs mg = {d_rows, d_keys, world, (int)R, U, N, ns * (w / 4), w / 4, sh, merge_rows_chunk(N), M, d_SrcA, d_SrcB, d_mask};
     ELIMREC_REQUIRE(mg.chunk / 32 <= kMergeSeenWords, "linear_bwd_w_batched_merge: %lld rows are more than the fused launch takes "
                     "(call elimrec_slab_merge_rows)", (long long)N);
-    return linear_bwd_w_batched_impl(descs, n, d_workspace, workspace_bytes, N > 0 ? &mg : nullptr, stream);
+    return linear_bwd_w_batched_impl(descs, n, d_workspace, workspace_bytes, N > 0 ? &mg : nullptr, defer_reduce, stream);
 }
 
 extern "C" int elimrec_linear_bwd_w(const float *d_A, int64_t lda, const float *d_B, int64_t ldb,

@@ -13,6 +13,7 @@
 // the (col, val) of step j of the wave's items are consecutive in memory. HBM/L2-bound (9 flop per 4-B gathered).
 #include "common.h"
 #include "merge_rows.h"
+#include "bwd_w.h"
 #include <hip/hip_bf16.h>
 #include <cstdlib>
 
@@ -1280,6 +1281,18 @@ __global__ __launch_bounds__(256) void sell_tier_adam_kernel(TierArgs t, AdamJob
     tier_body<LPR, 4, false, false, false, true>(t);
 }
 
+// the adjoint's first (masked) hop with the weight gradients' slab reduce (bwd_w.h) as extra workgroups behind the tiles:
+// the reduce needs the partial launch before it and is needed by the optimizer only -- its own kernel for the same reason
+template <int LPR>
+__global__ __launch_bounds__(256) void sell_tier_reduce_kernel(TierArgs t, BwdBatch batch, int tail_block0, int gx) {
+    if ((int)blockIdx.x >= tail_block0) {
+        const int b = (int)blockIdx.x - tail_block0;
+        reduce_slabs_body(batch, b % gx, b / gx);
+        return;
+    }
+    tier_body<LPR, 4, false, false, true, false>(t);
+}
+
 // the split rows by a second launch (ELIMREC_SLAB_STREAM=2: persistent hop without the in-launch combine)
 template <int LPR, int VPL, bool OUT_BF16>
 __global__ __launch_bounds__(256) void stream_fixup_kernel(StreamArgs a) {
@@ -1341,7 +1354,7 @@ struct AdamEpilogue {
 static int launch_tier(const elimrec_sell *A, int family, int ns, int wl, int wl_shift, int gs, int spg, int lpr, const void *Xin,
                        bool in_bf16, const uint32_t *src_mask, void *Xout, bool out_bf16, const float *add,
                        const uint32_t *add_mask, float scale, float *partials, int flags, hipStream_t s,
-                       const AdamEpilogue *adam = nullptr) {
+                       const AdamEpilogue *adam = nullptr, const BwdBatch *reduce = nullptr, int reduce_gx = 0) {
     const int seg_only = flags & 1;
     const bool bits_ready = (flags & 2) != 0;          // elimrec_slab_source_bits has run for this source bitmap
     if (A->tile_groups != 64 / lpr) {
@@ -1393,6 +1406,9 @@ static int launch_tier(const elimrec_sell *A, int family, int ns, int wl, int wl
     do {                                                                                                                      \
         if (!family) {                                                                                                        \
             if (adam) hipLaunchKernelGGL((sell_tier_adam_kernel<LPR>), grid_adam, dim3(256), 0, s, t, tail, tail_block0);     \
+            else if (masked && reduce)                                                                                        \
+                hipLaunchKernelGGL((sell_tier_reduce_kernel<LPR>), dim3(grid.x + (unsigned)(reduce_gx * reduce->n)), dim3(256), 0, s, t, \
+                                   *reduce, tail_block0, reduce_gx);                                                          \
             else if (masked) hipLaunchKernelGGL((sell_tier_kernel<LPR, 4, false, false, true>), grid, dim3(256), 0, s, t);    \
             else hipLaunchKernelGGL((sell_tier_kernel<LPR, 4, false, false, false>), grid, dim3(256), 0, s, t);               \
         } else if (in_bf16) {                                                                                                 \
@@ -1635,6 +1651,27 @@ extern "C" int elimrec_slab_source_bits(const elimrec_sell *A, int ns, int w, in
                        A->d_tile_off, A->d_tile_col, d_src_mask, 64 / lpr, n_tiles, A->tile_kmax, ballots);
     ELIMREC_LAUNCH_CHECK("slab_source_bits");
     return 0;
+}
+
+extern "C" int elimrec_slab_hop_reduce(const elimrec_sell *A, int ns, int w, int gs, const float *d_Xin, const uint32_t *d_src_mask,
+                                       float *d_Xout, const float *d_add, const uint32_t *d_add_mask, float scale, float *d_partials,
+                                       size_t partials_bytes, int flags, const elimrec_linear_bwd_desc *descs, int n,
+                                       void *d_workspace, size_t workspace_bytes, void *stream) {
+    ELIMREC_REQUIRE(A && d_Xin && d_Xout && d_src_mask && d_Xin != d_Xout, "slab_hop_reduce: null pointer / alias");
+    ELIMREC_REQUIRE(A->tiered && !(flags & 1), "slab_hop_reduce: needs a tiered (wave-tile) plan and a full hop");
+    ELIMREC_REQUIRE(descs && n >= 1 && n <= kMaxBatch, "slab_hop_reduce: 1..%d problems", kMaxBatch);
+    ELIMREC_REQUIRE(d_workspace && workspace_bytes >= bwd_w_batched_bytes(descs, n), "slab_hop_reduce: weight-gradient workspace");
+    int w4_shift, spg, lpr, rc;
+    if ((rc = slab_geometry("slab_hop_reduce", ns, w, gs, w4_shift, spg, lpr))) return rc;
+    if (!d_partials || partials_bytes < elimrec_slab_partials_bytes(A, ns, w)) {
+        set_error("slab_hop_reduce: partial-row scratch too small");
+        return ELIMREC_E_WORKSPACE;
+    }
+    BwdBatch batch;
+    int blocks = 0, max_out = 0;
+    if ((rc = bwd_w_build_batch(descs, n, d_workspace, batch, blocks, max_out))) return rc;
+    return launch_tier(A, 0, ns, w / 4, w4_shift, gs, spg, lpr, d_Xin, false, d_src_mask, d_Xout, false, d_add, d_add_mask, scale,
+                       d_partials, flags, (hipStream_t)stream, nullptr, &batch, (4 * max_out + 255) / 256);
 }
 
 extern "C" int elimrec_slab_hop_adam(const elimrec_sell *A, int ns, int w, int gs, const float *d_Xin, float *d_grad_out,

@@ -784,7 +784,8 @@ class EliMRec(BasicModel):
         return loss
 
     @torch.no_grad()
-    def _backward_batch_rows(self, ws, gscale, grad_rows, n, head_only=False, w_stream=None, pack_bwd=None, merge=None):
+    def _backward_batch_rows(self, ws, gscale, grad_rows, n, head_only=False, w_stream=None, pack_bwd=None, merge=None,
+                             defer_reduce=False):
         """Backward of _forward_batch_rows: gradient rows -> active rows (the forward's plan) -> head and projection
         gradients from the compact Out / dY rows -> adjoint propagation at d columns. Two hipGraph regions."""
         U, I, d, M, C, S = self.num_users, self.num_items, self.latent_dim, self.M, self.C, self.S
@@ -821,24 +822,26 @@ class EliMRec(BasicModel):
                 problems.append(dict(A=dOutR[:, (k + 1) * d:(k + 2) * d], B=fold[m], out=gv[m + "_dense.weight"],
                                      row_index=act, rng=seg[6:8], colsum=gv[m + "_dense.bias"], colsum_weight=fold["c"]))
                 grads[m + "_dense.weight"], grads[m + "_dense.bias"] = gv[m + "_dense.weight"], gv[m + "_dense.bias"]
-            ops.linear_bwd_w_batched(problems, ws["bwd_w_rows"], merge=merge)
+            handle = ops.linear_bwd_w_batched(problems, ws["bwd_w_rows"], merge=merge, defer_reduce=defer_reduce and concat)
             if not concat:  # 'mean' fusion: fold the M replicated column blocks back into the [d x d] weight
                 for name, gw in fused_tmp.items():
                     gv[name + ".weight"].copy_(gw.view(d, M, d).sum(1) / M)
-            return dict(grads)
+            return dict(grads), handle
 
         key = (self._ws_gen, grad_rows.data_ptr(), gscale.data_ptr(), n, tuple(bw))
         self._region("bwd_head_in", key + (0 if pack_bwd is None else pack_bwd.data_ptr(),), head_input)
         if w_stream is None:
-            mkey = () if merge is None else (merge["rows"].data_ptr(), merge["keys"].data_ptr(), merge["mask"].data_ptr())
-            grads = dict(self._region("bwd_head_w", key + mkey, head_weights))
+            mkey = (bool(defer_reduce),) + (() if merge is None else (merge["rows"].data_ptr(), merge["keys"].data_ptr(),
+                                                                     merge["mask"].data_ptr()))
+            grads, self._bwd_w_reduce = self._region("bwd_head_w", key + mkey, head_weights)
+            grads = dict(grads)
         else:
             # the weight gradients are needed by the optimizer step only: they run beside whatever the caller enqueues next
             # (the adjoint hops) on a second stream; the caller joins it before the update (w_stream is its handle)
             main = torch.cuda.current_stream()
             w_stream.wait_stream(main)
             with torch.cuda.stream(w_stream):
-                grads = dict(self._region("bwd_head_w", key, head_weights))
+                grads = dict(self._region("bwd_head_w", key, head_weights)[0])
         if head_only:
             return grads
         self._backward_hops(ws, dOutR, act, seg, n, grads)

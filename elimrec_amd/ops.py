@@ -114,24 +114,36 @@ def linear_bwd_w_batched_workspace(shapes):
     return int(_lib.load().elimrec_linear_bwd_w_batched_workspace(arr, n))
 
 
-def linear_bwd_w_batched(problems, workspace, merge=None):
+def linear_bwd_w_batched(problems, workspace, merge=None, defer_reduce=False):
     """problems: list of dicts(A, B, out[, row_index, rng, colsum, accumulate, rows]) in one launch pair.
     merge: dict(rows, keys, world, U, I, srcA, srcB, mask, M) -- the arguments of slab.merge_rows, run as extra workgroups
-    of the partial launch (elimrec_linear_bwd_w_batched_merge)."""
+    of the partial launch (elimrec_linear_bwd_w_batched_merge).
+    defer_reduce: stop after the partial launch and return the handle `linear_bwd_w_reduce` / `slab.hop(reduce=)` finish
+    the gradients with (the outputs hold nothing until then)."""
     arr, n = _bwd_descs(problems)
+    wsp, wsn = _dev(workspace, "workspace", torch.uint8), workspace.numel()
+    if merge is None and not defer_reduce:
+        _lib.check(_lib.load().elimrec_linear_bwd_w_batched(arr, n, wsp, wsn, _stream()), "linear_bwd_w_batched")
+        return None
     if merge is not None:
         rows, keys, srcA, srcB, M, world = merge["rows"], merge["keys"], merge["srcA"], merge["srcB"], merge["M"], merge["world"]
         R = keys.numel() // world
         assert rows.is_contiguous() and rows.shape == (world * R, (M if M else 2) * srcA.cols)
         assert merge["mask"].numel() * 32 >= merge["U"] + merge["I"]
-        _lib.check(_lib.load().elimrec_linear_bwd_w_batched_merge(
-            arr, n, _dev(workspace, "workspace", torch.uint8), workspace.numel(), _dev(rows, "rows"),
-            _dev(keys, "keys", torch.int32), int(world), R, int(merge["U"]), int(merge["I"]), srcA.ns, srcA.w, int(M),
-            _dev(srcA.data, "srcA"), _dev(srcB.data, "srcB"), _dev(merge["mask"], "mask", torch.int32), _stream()),
-            "linear_bwd_w_batched_merge")
-        return
-    _lib.check(_lib.load().elimrec_linear_bwd_w_batched(arr, n, _dev(workspace, "workspace", torch.uint8),
-                                                        workspace.numel(), _stream()), "linear_bwd_w_batched")
+        margs = (_dev(rows, "rows"), _dev(keys, "keys", torch.int32), int(world), R, int(merge["U"]), int(merge["I"]), srcA.ns, srcA.w,
+                 int(M), _dev(srcA.data, "srcA"), _dev(srcB.data, "srcB"), _dev(merge["mask"], "mask", torch.int32))
+    else:
+        margs = (None, None, 1, 1, 0, 0, 1, 4, 0, None, None, None)
+    _lib.check(_lib.load().elimrec_linear_bwd_w_batched_merge(arr, n, wsp, wsn, *margs, 1 if defer_reduce else 0, _stream()),
+               "linear_bwd_w_batched_merge")
+    return (arr, n, workspace) if defer_reduce else None
+
+
+def linear_bwd_w_reduce(handle):
+    """The fixed-order slab reduce of a `linear_bwd_w_batched(..., defer_reduce=True)` launch, as a launch of its own."""
+    arr, n, workspace = handle
+    _lib.check(_lib.load().elimrec_linear_bwd_w_reduce(arr, n, _dev(workspace, "workspace", torch.uint8), workspace.numel(), _stream()),
+               "linear_bwd_w_reduce")
 
 
 def linear_bwd_w_workspace(R, n1, n2):

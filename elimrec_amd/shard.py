@@ -26,6 +26,8 @@ writes the gradient, and Adam updates the master copy, in the layout the hops re
 The trainer talks to an `engine` through the cs_* methods below; ColumnShardEngine implements them on the HIP
 kernels, tests/test_dist_cpu.py injects a CPU stand-in built from the oracle to run the same trainer under gloo.
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
 
@@ -327,6 +329,15 @@ class ColumnShardEngine(object):
         return (not self.bf16 and self.planT.tiered and self.model.n_layers >= 2
                 and os.environ.get("ELIMREC_FUSE_ADAM", "1") != "0")
 
+    def _fuse_reduce(self):
+        """The weight gradients' slab reduce as extra workgroups of the adjoint's first hop: one rank, fp32 tables, the
+        tiered plan, 'concat' fusion, and a plain masked hop to carry it (ELIMREC_FUSE_REDUCE=0: its own launch)."""
+        import os
+        m = self.model
+        hops_in_region = m.n_layers - (1 if self._fuse_adam() else 0)
+        return (os.environ.get("ELIMREC_FUSE_REDUCE", "1") != "0" and not self.bf16 and self.planT.tiered and hops_in_region >= 1
+                and m.mm_fusion_mode == "concat")
+
     def _fuse_merge(self):
         import os
         return os.environ.get("ELIMREC_FUSE_MERGE", "1") != "0" and (self.model.num_users + self.model.num_items) <= (1 << 27)
@@ -527,8 +538,11 @@ class ColumnShardEngine(object):
             merge = dict(rows=ws["dOutR"][:R].view(R, m.C), keys=self._acts.reshape(-1), world=1, U=m.num_users, I=m.num_items,
                          srcA=self.srcA, srcB=self.srcB, mask=self.mask, M=m.M)
         self._merged = merge is not None
+        # ... and the weight gradients' slab reduce, needed by the optimizer only, in the adjoint's first hop launch
+        defer = (self.world == 1 and side is None and self._fuse_reduce())
         self._grads = m._backward_batch_rows(ws, scale, ws["grad_rows"], R, head_only=True, w_stream=side, pack_bwd=pack_bwd,
-                                             merge=merge)
+                                             merge=merge, defer_reduce=defer)
+        self._reduce = m._bwd_w_reduce if defer else None
         wg = ws["flat_grad"][ws["tail_off"]:]
         if self.world == 1:       # one rank owns every column: the merge reads the dOut rows themselves
             return ws["dOutR"][:R].view(1, R, m.C), wg
@@ -551,6 +565,8 @@ class ColumnShardEngine(object):
         last = 1 if fuse else 0                                    # the hops the recorded region covers: L-1 .. last
 
         merged = W == 1 and getattr(self, "_merged", False)
+        reduce = getattr(self, "_reduce", None) if W == 1 else None
+        self._reduce = None
 
         def hops():
             if merged:
@@ -563,9 +579,11 @@ class ColumnShardEngine(object):
             for k in range(L - 1, last - 1, -1):
                 dst = self.grad if k == 0 else self.tmp[k & 1]
                 slab.hop(self.planT, t, dst, gs=self.gs, src_mask=tmask, add=self.srcB if (k & 1) else self.srcA,
-                         add_mask=self.mask, scale=inv if k == 0 else 1.0, bits_ready=tmask is not None and self._bits_ready)
+                         add_mask=self.mask, scale=inv if k == 0 else 1.0, bits_ready=tmask is not None and self._bits_ready,
+                         reduce=reduce if tmask is not None else None)
                 t, tmask = dst, None
-        self._timed(lambda: m._region("cs_bwd_hops", (m._ws_gen, recv2.data_ptr(), acts.data_ptr(), R, W, fuse, self._bits_ready, merged), hops), L - last)
+        self._timed(lambda: m._region("cs_bwd_hops", (m._ws_gen, recv2.data_ptr(), acts.data_ptr(), R, W, fuse, self._bits_ready, merged,
+                                                               0 if reduce is None else ctypes.addressof(reduce[0])), hops), L - last)
         self._adam_in_hop = fuse
         self._tail_in_hop = False
         if fuse:
