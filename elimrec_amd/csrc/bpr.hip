@@ -748,6 +748,10 @@ __device__ __forceinline__ v4f_ hm16_accumulate_packed(v4f_ acc, const float *__
     return acc;
 }
 
+// slab-major adjoint source tables (slab.hip layout: [d / w][N][w]) the 16-row head backward can fill directly when one
+// rank owns every column and every active row is listed once: what elimrec_slab_merge_rows(M >= 1) would write
+struct SlabSources { float *A, *B; int64_t N; int w, w_shift; };
+
 struct HeadPackPtrs { const float *f[2]; const float *s[kMaxHeads]; };      // null f[0]: weights read unpacked
 
 __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__restrict__ dY, int64_t lddy,
@@ -757,7 +761,8 @@ __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__re
                                                                const float *__restrict__ W_user,
                                                                const float *__restrict__ W_item, float gscale,
                                                                float *__restrict__ G0, int64_t ldg, int scatter_cols,
-                                                               float *__restrict__ compact, SegSrc seg, HeadPackPtrs pk) {
+                                                               float *__restrict__ compact, SegSrc seg, HeadPackPtrs pk,
+                                                               SlabSources src) {
     extern __shared__ float dys[];                       // [16][Cy + 4]
     __shared__ int64_t node[HM16];
     const int Cy = (1 + S) * d, ldy = Cy + 4;
@@ -820,6 +825,10 @@ __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__re
     const int li = lane & 15, kq = lane >> 4;
     const int n_tiles = C / 16;
     const float *a_row = dys + li * ldy;
+    // adjoint sources (one rank, d = 64): H = the sum of a row's M column blocks in block order, G = block 0. A wave's
+    // tiles t = wave, wave + 4, ... are then the same 16 columns of consecutive blocks: H accumulates in registers
+    float hs[4] = {0.f, 0.f, 0.f, 0.f};
+    const int last_block = C / d - 1;
     for (int t = wave; t < n_tiles; t += 4) {
         const int c0 = t * 16;
         const int mb = c0 / d;
@@ -852,6 +861,14 @@ __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__re
                 const float v = ((mixed && nd >= U) ? acc2[r] : acc[r]) * gscale;
                 if (G0 && c0 + li < scatter_cols) G0[nd * ldg + c0 + li] = v;
                 if (compact) compact[(s0 + row) * C + c0 + li] = v;
+                if (src.A) {
+                    const int cb = c0 - mb * d + li;                 // column within the block
+                    const float h = mb == 0 ? v : hs[r] + v;
+                    hs[r] = h;
+                    const int64_t at = ((int64_t)(cb >> src.w_shift) * src.N + nd) * src.w + (cb & (src.w - 1));
+                    if (mb == 0) (nd < U ? src.B : src.A)[at] = v;
+                    if (mb == last_block) (nd < U ? src.A : src.B)[at] = h;
+                }
             }
         }
     }
@@ -1238,7 +1255,7 @@ static int segment_apply_head_bwd_impl(const float *d_rows, int64_t n, int ld, c
                                        const void *d_plan_workspace, size_t plan_workspace_bytes, int64_t U, int d,
                                        int C, int S, const int *head_mblock, const float *d_W_user,
                                        const float *d_W_item, const float *const *d_W_heads, float *d_compact,
-                                       const float *d_pack_bwd, void *stream);
+                                       const float *d_pack_bwd, const SlabSources *src, void *stream);
 
 extern "C" int elimrec_segment_apply_head_bwd(const float *d_rows, int64_t n, int ld, const int32_t *d_active_rows,
                                               const int32_t *d_seg_info, const float *d_scale, float *d_reduced,
@@ -1248,7 +1265,7 @@ extern "C" int elimrec_segment_apply_head_bwd(const float *d_rows, int64_t n, in
                                               void *stream) {
     return segment_apply_head_bwd_impl(d_rows, n, ld, d_active_rows, d_seg_info, d_scale, d_reduced, d_plan_workspace,
                                        plan_workspace_bytes, U, d, C, S, head_mblock, d_W_user, d_W_item, d_W_heads, d_compact,
-                                       nullptr, stream);
+                                       nullptr, nullptr, stream);
 }
 
 extern "C" int elimrec_segment_apply_head_bwd_packed(const float *d_rows, int64_t n, int ld, const int32_t *d_active_rows,
@@ -1260,7 +1277,24 @@ extern "C" int elimrec_segment_apply_head_bwd_packed(const float *d_rows, int64_
     ELIMREC_REQUIRE(d_pack_bwd, "segment_apply_head_bwd_packed: null pack pointer");
     return segment_apply_head_bwd_impl(d_rows, n, ld, d_active_rows, d_seg_info, d_scale, d_reduced, d_plan_workspace,
                                        plan_workspace_bytes, U, d, C, S, head_mblock, d_W_user, d_W_item, d_W_heads, d_compact,
-                                       d_pack_bwd, stream);
+                                       d_pack_bwd, nullptr, stream);
+}
+
+extern "C" int elimrec_segment_apply_head_bwd_sources(const float *d_rows, int64_t n, int ld, const int32_t *d_active_rows,
+                                                      const int32_t *d_seg_info, const float *d_scale, float *d_reduced,
+                                                      const void *d_plan_workspace, size_t plan_workspace_bytes, int64_t U,
+                                                      int d, int C, int S, const int *head_mblock, const float *d_W_user,
+                                                      const float *d_W_item, const float *const *d_W_heads,
+                                                      float *d_compact, const float *d_pack_bwd, int64_t N, int ns, int w,
+                                                      float *d_SrcA, float *d_SrcB, void *stream) {
+    ELIMREC_REQUIRE(d_pack_bwd && d_SrcA && d_SrcB, "segment_apply_head_bwd_sources: null pointer");
+    ELIMREC_REQUIRE(d == 64 && w >= 4 && (w & (w - 1)) == 0 && ns * w == d && N >= U,
+                    "segment_apply_head_bwd_sources: recdim 64 in [ns x N x w] slabs (d=%d, ns=%d, w=%d)", d, ns, w);
+    SlabSources src = {d_SrcA, d_SrcB, N, w, 0};
+    while ((1 << src.w_shift) < w) ++src.w_shift;
+    return segment_apply_head_bwd_impl(d_rows, n, ld, d_active_rows, d_seg_info, d_scale, d_reduced, d_plan_workspace,
+                                       plan_workspace_bytes, U, d, C, S, head_mblock, d_W_user, d_W_item, d_W_heads, d_compact,
+                                       d_pack_bwd, &src, stream);
 }
 
 static int segment_apply_head_bwd_impl(const float *d_rows, int64_t n, int ld, const int32_t *d_active_rows,
@@ -1268,7 +1302,7 @@ static int segment_apply_head_bwd_impl(const float *d_rows, int64_t n, int ld, c
                                        const void *d_plan_workspace, size_t plan_workspace_bytes, int64_t U, int d,
                                        int C, int S, const int *head_mblock, const float *d_W_user,
                                        const float *d_W_item, const float *const *d_W_heads, float *d_compact,
-                                       const float *d_pack_bwd, void *stream) {
+                                       const float *d_pack_bwd, const SlabSources *src, void *stream) {
     ELIMREC_REQUIRE(d_rows && d_active_rows && d_seg_info && d_reduced && d_plan_workspace && d_W_user && d_W_item &&
                     d_compact, "segment_apply_head_bwd: null pointer");
     ELIMREC_REQUIRE(n > 0 && n < INT32_MAX && ld > 0 && ld % 4 == 0, "segment_apply_head_bwd: bad n/ld");
@@ -1311,10 +1345,11 @@ static int segment_apply_head_bwd_impl(const float *d_rows, int64_t n, int ld, c
         }
         hipLaunchKernelGGL(head_bwd_input16_kernel, dim3((unsigned)((n + HM16 - 1) / HM16)), dim3(256), lds16,
                            (hipStream_t)stream, (const float *)d_reduced, (int64_t)ld, d_active_rows, d_seg_info, n, U, d, C, S, hp,
-                           d_W_user, d_W_item, 1.0f, (float *)nullptr, (int64_t)0, 0, d_compact, seg, pk);
+                           d_W_user, d_W_item, 1.0f, (float *)nullptr, (int64_t)0, 0, d_compact, seg, pk, src ? *src : SlabSources{});
         ELIMREC_LAUNCH_CHECK("segment_apply_head_bwd16");
         return 0;
     }
+    ELIMREC_REQUIRE(!src, "segment_apply_head_bwd_sources: the 16-row kernel is switched off (ELIMREC_HEAD_BWD_ROWS)");
     hipLaunchKernelGGL(head_bwd_input_mfma_kernel, dim3((unsigned)((n + HM_ROWS - 1) / HM_ROWS)), dim3(512), lds_m,
                        (hipStream_t)stream, (const float *)d_reduced, (int64_t)ld, d_active_rows, d_seg_info, n, U, d, C, S, hp,
                        d_W_user, d_W_item, 1.0f, (float *)nullptr, (int64_t)0, 0, d_compact, seg);

@@ -338,6 +338,14 @@ class ColumnShardEngine(object):
         return (os.environ.get("ELIMREC_FUSE_REDUCE", "1") != "0" and not self.bf16 and self.planT.tiered and hops_in_region >= 1
                 and m.mm_fusion_mode == "concat")
 
+    def _sources_in_head(self):
+        """One rank, recdim 64, packed head weights: the head backward's kernel writes the adjoint sources at the active rows
+        (each listed once) and the planner's key bitmap is their row bitmap -- no merge at all (ELIMREC_HEAD_SOURCES=0: the
+        merge rides in the weight-gradient launch)."""
+        import os
+        return (self.world == 1 and self._fused_head_ok() and bool(self._pack_bwd_off) and self.model.latent_dim == 64
+                and os.environ.get("ELIMREC_HEAD_SOURCES", "1") != "0" and os.environ.get("ELIMREC_HEAD_BWD_ROWS", "16") != "32")
+
     def _fuse_merge(self):
         import os
         return os.environ.get("ELIMREC_FUSE_MERGE", "1") != "0" and (self.model.num_users + self.model.num_items) <= (1 << 27)
@@ -372,7 +380,7 @@ class ColumnShardEngine(object):
 
         def plan():       # node ids of the slots, unique active rows + slot map, padded tail: one launch
             ops.batch_plan(users, pos, neg, m.num_users, m.num_items, keys, act, seg, ws["slot_seg"][:R], ws["plan_ws"], err, PAD_KEY,
-                           key_bitmap=self.mask if early_bits else None)
+                           key_bitmap=self.mask if (early_bits or self._sources_in_head()) else None)
             if early_bits:    # the planner's bitmap of the active rows IS the first adjoint hop's source bitmap (one rank):
                 slab.source_bits(self.planT, self.ns, self.w, self.gs, self.mask)      # its per-line bits, off the critical path
 
@@ -534,14 +542,17 @@ class ColumnShardEngine(object):
         # one rank: the merge of the dOut rows into the adjoint sources rides in the weight-gradient launch (both read the
         # head backward's rows and nothing of each other; ELIMREC_FUSE_MERGE=0: a launch of its own before the hops)
         merge = None
-        if self.world == 1 and side is None and self._fuse_merge():
+        sources = (self.srcA, self.srcB) if (pack_bwd is not None and self._sources_in_head()) else None
+        if sources is not None:
+            pass                       # the head backward writes the sources itself; their row bitmap is the planner's
+        elif self.world == 1 and side is None and self._fuse_merge():
             merge = dict(rows=ws["dOutR"][:R].view(R, m.C), keys=self._acts.reshape(-1), world=1, U=m.num_users, I=m.num_items,
                          srcA=self.srcA, srcB=self.srcB, mask=self.mask, M=m.M)
-        self._merged = merge is not None
+        self._merged = merge is not None or sources is not None
         # ... and the weight gradients' slab reduce, needed by the optimizer only, in the adjoint's first hop launch
         defer = (self.world == 1 and side is None and self._fuse_reduce())
         self._grads = m._backward_batch_rows(ws, scale, ws["grad_rows"], R, head_only=True, w_stream=side, pack_bwd=pack_bwd,
-                                             merge=merge, defer_reduce=defer)
+                                             merge=merge, defer_reduce=defer, sources=sources)
         self._reduce = m._bwd_w_reduce if defer else None
         wg = ws["flat_grad"][ws["tail_off"]:]
         if self.world == 1:       # one rank owns every column: the merge reads the dOut rows themselves

@@ -396,6 +396,19 @@ int elimrec_segment_apply_head_bwd_packed(const float *d_rows, int64_t n, int ld
                                           int d, int C, int S, const int *head_mblock, const float *d_W_user,
                                           const float *d_W_item, const float *const *d_W_heads,
                                           float *d_compact, const float *d_pack_bwd, void *stream);
+/* The packed form for ONE rank that owns every table column (recdim 64): the kernel also writes what
+ * elimrec_slab_merge_rows(world = 1, M = C / d) would make of d_compact -- the slab-major adjoint sources [ns x N x w]
+ * (H = sum of a row's column blocks in block order, G = block 0; users: H -> SrcA, G -> SrcB, items the other way round)
+ * at the active rows. Every active row is listed once, so there is nothing to accumulate; the row bitmap of the
+ * sources is the planner's key bitmap (elimrec_batch_plan). IndexBackward's index_put into the adjoint sources
+ * (/root/reference/models/EliMRec.py:239-256 under autograd) without a launch of its own. */
+int elimrec_segment_apply_head_bwd_sources(const float *d_rows, int64_t n, int ld, const int32_t *d_active_rows,
+                                           const int32_t *d_seg_info, const float *d_scale, float *d_reduced,
+                                           const void *d_plan_workspace, size_t plan_workspace_bytes, int64_t U,
+                                           int d, int C, int S, const int *head_mblock, const float *d_W_user,
+                                           const float *d_W_item, const float *const *d_W_heads,
+                                           float *d_compact, const float *d_pack_bwd, int64_t N, int ns, int w,
+                                           float *d_SrcA, float *d_SrcB, void *stream);
 
 /* ---------------------------------------------------------------- embedding gradients (K2 bwd)
  * dE_user[u, j] = sum_m G[u, m*d + j];  dE_item[i, j] = G[U+i, j]   (CatBackward of :239). */
