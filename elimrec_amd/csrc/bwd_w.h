@@ -7,6 +7,7 @@
 namespace elimrec {
 
 constexpr int kMaxBatch = 8;
+typedef float v16f __attribute__((ext_vector_type(16)));
 #ifndef ELIMREC_BWDW_TN2
 #define ELIMREC_BWDW_TN2 64
 #endif
@@ -21,6 +22,129 @@ struct BwdProblem {
     float *slabs, *cslabs;
 };
 struct BwdBatch { BwdProblem p[kMaxBatch]; int n; };
+
+// One workgroup of the partial launch: a chunk of rows x one 64 x TN2 output tile (see gemm.hip, "weight grad").
+// As / Bs / Wt: the caller's LDS stages ([2][TRB * TN1], [2][TRB * TN2], [2][TRB] floats).
+__device__ __forceinline__ void bwd_w_partial_body(const BwdBatch &batch, int block, float (*As)[TRB * TN1], float (*Bs)[TRB * TN2],
+                                                   float (*Wt)[TRB]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int pi = 0;
+    while (pi + 1 < batch.n && block >= batch.p[pi + 1].first_block) ++pi;
+    const BwdProblem &pb = batch.p[pi];
+    const int local = block - pb.first_block;
+    const int n1_tiles = pb.t1, n2_tiles = pb.t2;
+    const int chunk = local / (n1_tiles * n2_tiles);
+    const int tile = local - chunk * (n1_tiles * n2_tiles);
+    const int tile_y = tile / n2_tiles, tile_z = tile - tile_y * n2_tiles;
+    const float *__restrict__ A = pb.d.d_A;
+    const float *__restrict__ B = pb.d.d_B;
+    const int32_t *__restrict__ row_index = pb.d.d_row_index;
+    const int32_t *__restrict__ range = pb.d.d_range;
+    const int64_t lda = pb.d.lda, ldb = pb.d.ldb, R = pb.d.R;
+    const int n1 = pb.d.n1, n2 = pb.d.n2, chunk_rows = pb.chunk_rows;
+    float *__restrict__ slabs = pb.slabs;
+    float *__restrict__ colsum_slabs = pb.d.d_colsum ? pb.cslabs : nullptr;
+    const float *__restrict__ cw = pb.d.d_colsum ? pb.d.d_colsum_weight : nullptr;
+    int64_t rb = 0, re = R;
+    if (range) { rb = range[0]; re = range[1]; }
+    const int64_t r0 = rb + (int64_t)chunk * chunk_rows;
+    const int64_t r1 = (r0 + chunk_rows < re) ? r0 + chunk_rows : re;
+    const int i_base = tile_y * TN1, j_base = tile_z * TN2;
+
+    // loader geometry: A block = 32 rows x 16 float4 (2 per thread); B block = 32 rows x 32 float4 (4 per thread)
+    const int a_row = tid >> 4, a_c4 = tid & 15;          // + 16 rows on the second pass
+    const int b_row = tid / BC4, b_c4 = tid % BC4;        // + BRP rows per pass, BPS passes
+    const bool a_col_ok = (i_base + a_c4 * 4) < n1;       // n1, n2 are multiples of 4
+    const bool b_col_ok = (j_base + b_c4 * 4) < n2;
+    float4 ra[2], rbv[BPS];
+    float rw = 1.f;
+    auto load_block = [&](int64_t row0) {
+        if (cw && tid < TRB) {
+            const int64_t r = row0 + tid;
+            rw = r < r1 ? cw[row_index ? (int64_t)row_index[r] : r] : 0.f;
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int64_t r = row0 + a_row + 16 * p;
+            ra[p] = (a_col_ok && r < r1) ? *reinterpret_cast<const float4 *>(A + r * lda + i_base + a_c4 * 4)
+                                         : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int p = 0; p < BPS; ++p) {
+            const int64_t r = row0 + b_row + BRP * p;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b_col_ok && r < r1) {
+                const int64_t br = row_index ? (int64_t)row_index[r] : r;
+                v = *reinterpret_cast<const float4 *>(B + br * ldb + j_base + b_c4 * 4);
+            }
+            rbv[p] = v;
+        }
+    };
+    auto store_block = [&](int buf) {
+        if (cw && tid < TRB) Wt[buf][tid] = rw;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            *reinterpret_cast<float4 *>(&As[buf][(a_row + 16 * p) * TN1 + a_c4 * 4]) = ra[p];
+#pragma unroll
+        for (int p = 0; p < BPS; ++p)
+            *reinterpret_cast<float4 *>(&Bs[buf][(b_row + BRP * p) * TN2 + b_c4 * 4]) = rbv[p];
+    };
+
+    const int wi = (wave & 1) * 32, wj = (wave >> 1) * (TN2 / 2);
+    const int li = lane & 31, lk = lane >> 5;
+    // 64-column problems (the single-modal heads) fill half of the 128-column tile: the waves of the empty half do not
+    // multiply zeros or write them (the reduce never reads the padding columns)
+    const bool wave_on = (j_base + wj) < n2;
+    const bool half1_on = BNJ > 1 && (j_base + wj + 32) < n2;
+    v16f acc0 = {0}, acc1 = {0};
+    float csum = 0.f;                                      // threads 0..63: column sum of A[:, i_base + tid]
+    int buf = 0;
+    if (r0 < r1) {
+        load_block(r0);
+        store_block(0);
+    }
+    __syncthreads();
+    for (int64_t row0 = r0; row0 < r1; row0 += TRB) {
+        const bool more = (row0 + TRB) < r1;
+        if (more) load_block(row0 + TRB);                  // in flight during the MFMAs below
+        const float *as = As[buf], *bs = Bs[buf];
+        if (wave_on) {
+#pragma unroll
+            for (int kk = 0; kk < TRB; kk += 2) {
+                const float a = as[(kk + lk) * TN1 + wi + li];
+                const float b0 = bs[(kk + lk) * TN2 + wj + li];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+                if (BNJ > 1) {
+                    const float b1 = bs[(kk + lk) * TN2 + wj + (BNJ > 1 ? 32 : 0) + li];
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+                }
+            }
+        }
+        if (colsum_slabs && tid < TN1) {
+            if (cw) {
+#pragma unroll 8
+                for (int k = 0; k < TRB; ++k) csum += as[k * TN1 + tid] * Wt[buf][k];
+            } else {
+#pragma unroll 8
+                for (int k = 0; k < TRB; ++k) csum += as[k * TN1 + tid];
+            }
+        }
+        if (more) store_block(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    const int n1_pad = n1_tiles * TN1, n2_pad = n2_tiles * TN2;
+    float *slab = slabs + (size_t)chunk * n1_pad * n2_pad;
+    if (wave_on) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = i_base + wi + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            slab[(size_t)row * n2_pad + j_base + wj + li] = acc0[r];
+            if (half1_on) slab[(size_t)row * n2_pad + j_base + wj + 32 + li] = acc1[r];
+        }
+    }
+    if (colsum_slabs && tile_z == 0 && tid < TN1) colsum_slabs[(size_t)chunk * n1_pad + i_base + tid] = csum;
+}
 
 // out[e] (+)= sum over chunks of slab[chunk][e] in a FIXED order: four adjacent lanes share one output
 // element, lane q adds chunks q, q+4, q+8, ... (4 loads in flight each), then (q0+q1)+(q2+q3).

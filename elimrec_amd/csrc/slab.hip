@@ -1170,8 +1170,8 @@ __device__ __forceinline__ void tier_wave_sum(const float (&acc)[VPL], int cl, i
     }
 }
 
-template <int LPR, int VPL, bool IN_BF16, bool OUT_BF16, bool MASKED, bool ADAM>
-__device__ __forceinline__ void tier_body(const TierArgs &t) {
+template <int LPR, int VPL, bool IN_BF16, bool OUT_BF16, bool MASKED, bool ADAM, bool EXT_LDS = false>
+__device__ __forceinline__ void tier_body(const TierArgs &t, float *lds = nullptr) {
     constexpr int G = 64 / LPR;
     const StreamArgs &a = t.s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1181,7 +1181,8 @@ __device__ __forceinline__ void tier_body(const TierArgs &t) {
     const int slab = grp * a.spg + (cl >> a.wl_shift);
     const int c = cl & (a.wl - 1);
     const int64_t in_base = (int64_t)slab * a.n_src * a.wl + c;
-    __shared__ float s_part[4 * 64 * 8];
+    __shared__ float s_own[EXT_LDS ? 1 : 4 * 64 * 8];
+    float *s_part = EXT_LDS ? lds : s_own;                  // 4 * 64 * 8 floats
     const int ti = __builtin_amdgcn_readfirstlane(bidx * 4 + wave);       // tiles are laid out workgroup by workgroup
     const bool wg_row = bidx < t.n_w4;
     int off = 0, steps = 0, glen = 0, dst = -1;
@@ -1281,16 +1282,23 @@ __global__ __launch_bounds__(256) void sell_tier_adam_kernel(TierArgs t, AdamJob
     tier_body<LPR, 4, false, false, false, true>(t);
 }
 
-// the adjoint's first (masked) hop with the weight gradients' slab reduce (bwd_w.h) as extra workgroups behind the tiles:
-// the reduce needs the partial launch before it and is needed by the optimizer only -- its own kernel for the same reason
-template <int LPR>
-__global__ __launch_bounds__(256) void sell_tier_reduce_kernel(TierArgs t, BwdBatch batch, int tail_block0, int gx) {
+// An adjoint hop with a phase of the projections' weight gradients (bwd_w.h) as extra workgroups behind the tiles: the
+// partial launch (tail_mode 2; it needs the head backward's rows, as the adjoint's first hop does) or the fixed-order slab
+// reduce (tail_mode 1; needs the partial launch, is needed by the optimizer only). Neither reads what the hop writes.
+// Kernels of their own for the reason above: the plain hops keep their small argument block.
+template <int LPR, bool MASKED>
+__global__ __launch_bounds__(256) void sell_tier_bwdw_kernel(TierArgs t, BwdBatch batch, int tail_block0, int tail_mode, int gx) {
+    __shared__ float As[2][TRB * TN1];                      // the GEMM stages; the hop's wave sums (8 KB) share them
+    __shared__ float Bs[2][TRB * TN2];
+    __shared__ float Wt[2][TRB];
+    static_assert(2 * TRB * TN1 >= 4 * 64 * 8, "the hop's LDS scratch must fit the A stages");
     if ((int)blockIdx.x >= tail_block0) {
         const int b = (int)blockIdx.x - tail_block0;
-        reduce_slabs_body(batch, b % gx, b / gx);
+        if (tail_mode == 1) { reduce_slabs_body(batch, b % gx, b / gx); return; }
+        bwd_w_partial_body(batch, b, As, Bs, Wt);
         return;
     }
-    tier_body<LPR, 4, false, false, true, false>(t);
+    tier_body<LPR, 4, false, false, MASKED, false, true>(t, &As[0][0]);
 }
 
 // the split rows by a second launch (ELIMREC_SLAB_STREAM=2: persistent hop without the in-launch combine)
@@ -1354,7 +1362,8 @@ struct AdamEpilogue {
 static int launch_tier(const elimrec_sell *A, int family, int ns, int wl, int wl_shift, int gs, int spg, int lpr, const void *Xin,
                        bool in_bf16, const uint32_t *src_mask, void *Xout, bool out_bf16, const float *add,
                        const uint32_t *add_mask, float scale, float *partials, int flags, hipStream_t s,
-                       const AdamEpilogue *adam = nullptr, const BwdBatch *reduce = nullptr, int reduce_gx = 0) {
+                       const AdamEpilogue *adam = nullptr, const BwdBatch *bwdw = nullptr, int tail_mode = 0, int tail_blocks = 0,
+                       int reduce_gx = 1) {
     const int seg_only = flags & 1;
     const bool bits_ready = (flags & 2) != 0;          // elimrec_slab_source_bits has run for this source bitmap
     if (A->tile_groups != 64 / lpr) {
@@ -1406,9 +1415,12 @@ static int launch_tier(const elimrec_sell *A, int family, int ns, int wl, int wl
     do {                                                                                                                      \
         if (!family) {                                                                                                        \
             if (adam) hipLaunchKernelGGL((sell_tier_adam_kernel<LPR>), grid_adam, dim3(256), 0, s, t, tail, tail_block0);     \
-            else if (masked && reduce)                                                                                        \
-                hipLaunchKernelGGL((sell_tier_reduce_kernel<LPR>), dim3(grid.x + (unsigned)(reduce_gx * reduce->n)), dim3(256), 0, s, t, \
-                                   *reduce, tail_block0, reduce_gx);                                                          \
+            else if (bwdw && masked)                                                                                          \
+                hipLaunchKernelGGL((sell_tier_bwdw_kernel<LPR, true>), dim3(grid.x + (unsigned)tail_blocks), dim3(256), 0, s, t,       \
+                                   *bwdw, tail_block0, tail_mode, reduce_gx);                                                 \
+            else if (bwdw)                                                                                                    \
+                hipLaunchKernelGGL((sell_tier_bwdw_kernel<LPR, false>), dim3(grid.x + (unsigned)tail_blocks), dim3(256), 0, s, t,      \
+                                   *bwdw, tail_block0, tail_mode, reduce_gx);                                                 \
             else if (masked) hipLaunchKernelGGL((sell_tier_kernel<LPR, 4, false, false, true>), grid, dim3(256), 0, s, t);    \
             else hipLaunchKernelGGL((sell_tier_kernel<LPR, 4, false, false, false>), grid, dim3(256), 0, s, t);               \
         } else if (in_bf16) {                                                                                                 \
@@ -1653,25 +1665,27 @@ extern "C" int elimrec_slab_source_bits(const elimrec_sell *A, int ns, int w, in
     return 0;
 }
 
-extern "C" int elimrec_slab_hop_reduce(const elimrec_sell *A, int ns, int w, int gs, const float *d_Xin, const uint32_t *d_src_mask,
-                                       float *d_Xout, const float *d_add, const uint32_t *d_add_mask, float scale, float *d_partials,
-                                       size_t partials_bytes, int flags, const elimrec_linear_bwd_desc *descs, int n,
-                                       void *d_workspace, size_t workspace_bytes, void *stream) {
-    ELIMREC_REQUIRE(A && d_Xin && d_Xout && d_src_mask && d_Xin != d_Xout, "slab_hop_reduce: null pointer / alias");
-    ELIMREC_REQUIRE(A->tiered && !(flags & 1), "slab_hop_reduce: needs a tiered (wave-tile) plan and a full hop");
-    ELIMREC_REQUIRE(descs && n >= 1 && n <= kMaxBatch, "slab_hop_reduce: 1..%d problems", kMaxBatch);
-    ELIMREC_REQUIRE(d_workspace && workspace_bytes >= bwd_w_batched_bytes(descs, n), "slab_hop_reduce: weight-gradient workspace");
+extern "C" int elimrec_slab_hop_bwd_w(const elimrec_sell *A, int ns, int w, int gs, const float *d_Xin, const uint32_t *d_src_mask,
+                                      float *d_Xout, const float *d_add, const uint32_t *d_add_mask, float scale, float *d_partials,
+                                      size_t partials_bytes, int flags, const elimrec_linear_bwd_desc *descs, int n,
+                                      void *d_workspace, size_t workspace_bytes, int phase, void *stream) {
+    ELIMREC_REQUIRE(A && d_Xin && d_Xout && d_Xin != d_Xout, "slab_hop_bwd_w: null pointer / alias");
+    ELIMREC_REQUIRE(A->tiered && !(flags & 1), "slab_hop_bwd_w: needs a tiered (wave-tile) plan and a full hop");
+    ELIMREC_REQUIRE(phase == 0 || phase == 1, "slab_hop_bwd_w: phase 0 (partial launch) or 1 (slab reduce)");
+    ELIMREC_REQUIRE(descs && n >= 1 && n <= kMaxBatch, "slab_hop_bwd_w: 1..%d problems", kMaxBatch);
+    ELIMREC_REQUIRE(d_workspace && workspace_bytes >= bwd_w_batched_bytes(descs, n), "slab_hop_bwd_w: weight-gradient workspace");
     int w4_shift, spg, lpr, rc;
-    if ((rc = slab_geometry("slab_hop_reduce", ns, w, gs, w4_shift, spg, lpr))) return rc;
+    if ((rc = slab_geometry("slab_hop_bwd_w", ns, w, gs, w4_shift, spg, lpr))) return rc;
     if (!d_partials || partials_bytes < elimrec_slab_partials_bytes(A, ns, w)) {
-        set_error("slab_hop_reduce: partial-row scratch too small");
+        set_error("slab_hop_bwd_w: partial-row scratch too small");
         return ELIMREC_E_WORKSPACE;
     }
     BwdBatch batch;
     int blocks = 0, max_out = 0;
     if ((rc = bwd_w_build_batch(descs, n, d_workspace, batch, blocks, max_out))) return rc;
+    const int gx = (4 * max_out + 255) / 256;
     return launch_tier(A, 0, ns, w / 4, w4_shift, gs, spg, lpr, d_Xin, false, d_src_mask, d_Xout, false, d_add, d_add_mask, scale,
-                       d_partials, flags, (hipStream_t)stream, nullptr, &batch, (4 * max_out + 255) / 256);
+                       d_partials, flags, (hipStream_t)stream, nullptr, &batch, phase == 0 ? 2 : 1, phase == 0 ? blocks : gx * n, gx);
 }
 
 extern "C" int elimrec_slab_hop_adam(const elimrec_sell *A, int ns, int w, int gs, const float *d_Xin, float *d_grad_out,

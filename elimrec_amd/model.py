@@ -822,7 +822,8 @@ class EliMRec(BasicModel):
                 problems.append(dict(A=dOutR[:, (k + 1) * d:(k + 2) * d], B=fold[m], out=gv[m + "_dense.weight"],
                                      row_index=act, rng=seg[6:8], colsum=gv[m + "_dense.bias"], colsum_weight=fold["c"]))
                 grads[m + "_dense.weight"], grads[m + "_dense.bias"] = gv[m + "_dense.weight"], gv[m + "_dense.bias"]
-            handle = ops.linear_bwd_w_batched(problems, ws["bwd_w_rows"], merge=merge, defer_reduce=defer_reduce and concat)
+            handle = ops.linear_bwd_w_batched(problems, ws["bwd_w_rows"], merge=merge, defer_reduce=bool(defer_reduce) and concat,
+                                              defer_all=defer_reduce == "all" and concat)
             if not concat:  # 'mean' fusion: fold the M replicated column blocks back into the [d x d] weight
                 for name, gw in fused_tmp.items():
                     gv[name + ".weight"].copy_(gw.view(d, M, d).sum(1) / M)
@@ -832,7 +833,7 @@ class EliMRec(BasicModel):
         self._region("bwd_head_in", key + (0 if pack_bwd is None else pack_bwd.data_ptr(),
                                            0 if sources is None else sources[0].data.data_ptr()), head_input)
         if w_stream is None:
-            mkey = (bool(defer_reduce),) + (() if merge is None else (merge["rows"].data_ptr(), merge["keys"].data_ptr(),
+            mkey = (str(defer_reduce),) + (() if merge is None else (merge["rows"].data_ptr(), merge["keys"].data_ptr(),
                                                                      merge["mask"].data_ptr()))
             grads, self._bwd_w_reduce = self._region("bwd_head_w", key + mkey, head_weights)
             grads = dict(grads)

@@ -114,13 +114,19 @@ def linear_bwd_w_batched_workspace(shapes):
     return int(_lib.load().elimrec_linear_bwd_w_batched_workspace(arr, n))
 
 
-def linear_bwd_w_batched(problems, workspace, merge=None, defer_reduce=False):
+def linear_bwd_w_batched(problems, workspace, merge=None, defer_reduce=False, defer_all=False):
     """problems: list of dicts(A, B, out[, row_index, rng, colsum, accumulate, rows]) in one launch pair.
     merge: dict(rows, keys, world, U, I, srcA, srcB, mask, M) -- the arguments of slab.merge_rows, run as extra workgroups
     of the partial launch (elimrec_linear_bwd_w_batched_merge).
-    defer_reduce: stop after the partial launch and return the handle `linear_bwd_w_reduce` / `slab.hop(reduce=)` finish
-    the gradients with (the outputs hold nothing until then)."""
+    defer_reduce: stop after the partial launch and return the handle `linear_bwd_w_reduce` / `slab.hop(bwd_w=)` finish
+    the gradients with (the outputs hold nothing until then). defer_all: launch nothing, return the handle: both phases
+    ride in hop launches (slab.hop(bwd_w=handle, bwd_w_phase=0), then bwd_w_phase=1)."""
     arr, n = _bwd_descs(problems)
+    if defer_all:
+        assert merge is None
+        need = int(_lib.load().elimrec_linear_bwd_w_batched_workspace(arr, n))
+        assert workspace.numel() >= need, "linear_bwd_w: workspace too small"
+        return (arr, n, workspace)
     wsp, wsn = _dev(workspace, "workspace", torch.uint8), workspace.numel()
     if merge is None and not defer_reduce:
         _lib.check(_lib.load().elimrec_linear_bwd_w_batched(arr, n, wsp, wsn, _stream()), "linear_bwd_w_batched")

@@ -338,6 +338,12 @@ class ColumnShardEngine(object):
         return (os.environ.get("ELIMREC_FUSE_REDUCE", "1") != "0" and not self.bf16 and self.planT.tiered and hops_in_region >= 1
                 and m.mm_fusion_mode == "concat")
 
+    def _fuse_bwd_w(self):
+        """Both phases of the weight gradients behind adjoint hops' tiles: needs two plain hops before the Adam hop."""
+        import os
+        hops_in_region = self.model.n_layers - (1 if self._fuse_adam() else 0)
+        return os.environ.get("ELIMREC_FUSE_BWDW", "1") != "0" and hops_in_region >= 2
+
     def _sources_in_head(self):
         """One rank, recdim 64, packed head weights: the head backward's kernel writes the adjoint sources at the active rows
         (each listed once) and the planner's key bitmap is their row bitmap -- no merge at all (ELIMREC_HEAD_SOURCES=0: the
@@ -551,9 +557,11 @@ class ColumnShardEngine(object):
         self._merged = merge is not None or sources is not None
         # ... and the weight gradients' slab reduce, needed by the optimizer only, in the adjoint's first hop launch
         defer = (self.world == 1 and side is None and self._fuse_reduce())
+        if defer and merge is None and self._fuse_bwd_w():
+            defer = "all"              # ... and the partial launch too: behind the first hop's tiles, the reduce behind the second's
         self._grads = m._backward_batch_rows(ws, scale, ws["grad_rows"], R, head_only=True, w_stream=side, pack_bwd=pack_bwd,
                                              merge=merge, defer_reduce=defer, sources=sources)
-        self._reduce = m._bwd_w_reduce if defer else None
+        self._reduce = (m._bwd_w_reduce, 0 if defer == "all" else 1) if defer else None
         wg = ws["flat_grad"][ws["tail_off"]:]
         if self.world == 1:       # one rank owns every column: the merge reads the dOut rows themselves
             return ws["dOutR"][:R].view(1, R, m.C), wg
@@ -580,6 +588,7 @@ class ColumnShardEngine(object):
         self._reduce = None
 
         def hops():
+            phase = None if reduce is None else reduce[1]
             if merged:
                 pass                                               # done beside the weight gradients (cs_backward_local)
             elif W == 1:
@@ -591,10 +600,11 @@ class ColumnShardEngine(object):
                 dst = self.grad if k == 0 else self.tmp[k & 1]
                 slab.hop(self.planT, t, dst, gs=self.gs, src_mask=tmask, add=self.srcB if (k & 1) else self.srcA,
                          add_mask=self.mask, scale=inv if k == 0 else 1.0, bits_ready=tmask is not None and self._bits_ready,
-                         reduce=reduce if tmask is not None else None)
+                         bwd_w=reduce[0] if phase is not None and phase <= 1 else None, bwd_w_phase=phase)
+                phase = None if phase is None else phase + 1
                 t, tmask = dst, None
         self._timed(lambda: m._region("cs_bwd_hops", (m._ws_gen, recv2.data_ptr(), acts.data_ptr(), R, W, fuse, self._bits_ready, merged,
-                                                               0 if reduce is None else ctypes.addressof(reduce[0])), hops), L - last)
+                                                               0 if reduce is None else ctypes.addressof(reduce[0][0]), 0 if reduce is None else reduce[1]), hops), L - last)
         self._adam_in_hop = fuse
         self._tail_in_hop = False
         if fuse:

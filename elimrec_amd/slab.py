@@ -306,12 +306,12 @@ def source_bits(plan, ns, w, gs, src_mask):
                                                     _dev(part, "partials"), part.numel() * 4, _stream()), "slab_source_bits")
 
 
-def hop(plan, xin, xout, gs=None, src_mask=None, add=None, add_mask=None, scale=1.0, seg_only=False, bits_ready=False, reduce=None):
+def hop(plan, xin, xout, gs=None, src_mask=None, add=None, add_mask=None, scale=1.0, seg_only=False, bits_ready=False, bwd_w=None, bwd_w_phase=1):
     """xout = (A . xin + [add_mask] add) * scale on slab tables of equal geometry. seg_only: xout is a flat fp32 tensor
     [ns x n_long x w] receiving the split rows only. bf16 tables on either side select the bf16-storage kernels (the
     source may be fp32 there too: the row-sparse adjoint source behind src_mask).
-    reduce: the handle of ops.linear_bwd_w_batched(..., defer_reduce=True) -- its slab reduce runs as extra workgroups of
-    this launch (fp32 tables, tiered plan, src_mask given: elimrec_slab_hop_reduce)."""
+    bwd_w: the handle of ops.linear_bwd_w_batched(..., defer_reduce=True / defer_all=True) -- bwd_w_phase 1: its slab reduce,
+    0: its partial launch, run as extra workgroups of this launch (fp32 tables, tiered plan: elimrec_slab_hop_bwd_w)."""
     ns, w = xin.ns, xin.w
     gs = choose_groups(ns) if gs is None else gs
     part = plan.partials(ns, w)
@@ -323,15 +323,15 @@ def hop(plan, xin, xout, gs=None, src_mask=None, add=None, add_mask=None, scale=
                                           0 if out.dtype == torch.bfloat16 else 1, _dev(None if add is None else add.data, "add"),
                                           _dev(add_mask, "add_mask", torch.int32), float(scale), _dev(part, "partials"),
                                           part.numel() * 4, 1 if seg_only else 0, _stream()), "slab_hop16")
-        assert reduce is None
+        assert bwd_w is None
         return
-    if reduce is not None:
-        arr, n, wsp = reduce
-        _lib.check(lib.elimrec_slab_hop_reduce(plan.ref(), ns, w, int(gs), _dev(xin.data, "xin"), _dev(src_mask, "src_mask", torch.int32),
+    if bwd_w is not None:
+        arr, n, wsp = bwd_w
+        _lib.check(lib.elimrec_slab_hop_bwd_w(plan.ref(), ns, w, int(gs), _dev(xin.data, "xin"), _dev(src_mask, "src_mask", torch.int32),
                                                _dev(out, "xout"), _dev(None if add is None else add.data, "add"),
                                                _dev(add_mask, "add_mask", torch.int32), float(scale), _dev(part, "partials"),
                                                part.numel() * 4, 2 if bits_ready else 0, arr, n, _dev(wsp, "workspace", torch.uint8),
-                                               wsp.numel(), _stream()), "slab_hop_reduce")
+                                               wsp.numel(), int(bwd_w_phase), _stream()), "slab_hop_bwd_w")
         return
     _lib.check(lib.elimrec_slab_hop(plan.ref(), ns, w, int(gs), _dev(xin.data, "xin"),
                                     _dev(src_mask, "src_mask", torch.int32), _dev(out, "xout"),

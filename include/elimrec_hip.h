@@ -134,7 +134,7 @@ int elimrec_linear_bwd_w_batched_merge(const elimrec_linear_bwd_desc *descs /* h
                                        float *d_SrcB, uint32_t *d_mask, int defer_reduce, void *stream);
 /* defer_reduce != 0: the launch above ends with the partial slabs in the workspace; the caller runs the fixed-order
  * reduce later, before the gradients are read -- by this call, or as extra workgroups of the adjoint's first hop
- * (elimrec_slab_hop_reduce below). d_rows == NULL: no merge. Same descs / workspace as the partial launch. */
+ * (elimrec_slab_hop_bwd_w below). d_rows == NULL: no merge. Same descs / workspace as the partial launch. */
 int elimrec_linear_bwd_w_reduce(const elimrec_linear_bwd_desc *descs /* host array */, int n, void *d_workspace,
                                 size_t workspace_bytes, void *stream);
 
@@ -564,13 +564,15 @@ int elimrec_slab_hop(const elimrec_sell *A, int ns, int w, int gs, const float *
 int elimrec_slab_source_bits(const elimrec_sell *A, int ns, int w, int gs, const uint32_t *d_src_mask,
                              float *d_partials, size_t partials_bytes, void *stream);
 
-/* elimrec_slab_hop (tiered plan, source bitmap given: the adjoint's first hop) with elimrec_linear_bwd_w_reduce of a
- * deferred weight-gradient launch as extra workgroups behind the hop's tiles: SparseAddmmBackward's first product and the
- * tail of AddmmBackward's dW in one launch -- neither reads what the other writes. Same bits as the two calls. */
-int elimrec_slab_hop_reduce(const elimrec_sell *A, int ns, int w, int gs, const float *d_Xin, const uint32_t *d_src_mask,
-                            float *d_Xout, const float *d_add, const uint32_t *d_add_mask, float scale, float *d_partials,
-                            size_t partials_bytes, int flags, const elimrec_linear_bwd_desc *descs /* host array */, int n,
-                            void *d_workspace, size_t workspace_bytes, void *stream);
+/* elimrec_slab_hop (tiered plan, fp32 tables) with one phase of a weight-gradient batch as extra workgroups behind the
+ * hop's tiles: phase 0 = the partial launch (what elimrec_linear_bwd_w_batched_merge(defer_reduce) runs first), phase 1 =
+ * elimrec_linear_bwd_w_reduce. SparseAddmmBackward's products and AddmmBackward's dW share launches -- neither reads
+ * what the other writes; the weight gradients are off the step's critical path. Same bits as the separate calls.
+ * descs / workspace as for elimrec_linear_bwd_w_batched; phase 1 must follow phase 0 on the stream. */
+int elimrec_slab_hop_bwd_w(const elimrec_sell *A, int ns, int w, int gs, const float *d_Xin, const uint32_t *d_src_mask,
+                           float *d_Xout, const float *d_add, const uint32_t *d_add_mask, float scale, float *d_partials,
+                           size_t partials_bytes, int flags, const elimrec_linear_bwd_desc *descs /* host array */, int n,
+                           void *d_workspace, size_t workspace_bytes, int phase, void *stream);
 
 /* elimrec_slab_hop (tiered plan, no source bitmap) whose output row pieces are not stored but consumed as the GRADIENT
  * of the same slab-major parameter table by an Adam step with coupled L2 (torch.optim.Adam semantics, arithmetic of

@@ -555,7 +555,7 @@ def test_step_variants_are_bitwise_equal(monkeypatch):
 
     def run(env):
         for k in ("ELIMREC_FUSE_ADAM", "ELIMREC_AUX_STREAM", "ELIMREC_SLAB_TIERED", "ELIMREC_FUSED_HEAD", "ELIMREC_FUSE_MERGE", "ELIMREC_MERGE_FIRST",
-                  "ELIMREC_FUSE_REDUCE", "ELIMREC_HEAD_SOURCES"):
+                  "ELIMREC_FUSE_REDUCE", "ELIMREC_HEAD_SOURCES", "ELIMREC_FUSE_BWDW"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -571,7 +571,7 @@ def test_step_variants_are_bitwise_equal(monkeypatch):
 
     base = run({})
     for env in ({"ELIMREC_FUSE_ADAM": "0"}, {"ELIMREC_AUX_STREAM": "0"}, {"ELIMREC_FUSE_ADAM": "0", "ELIMREC_AUX_STREAM": "0"},
-                {"ELIMREC_HEAD_SOURCES": "0"}, {"ELIMREC_HEAD_SOURCES": "0", "ELIMREC_FUSE_MERGE": "0"}, {"ELIMREC_FUSE_REDUCE": "0"},
+                {"ELIMREC_HEAD_SOURCES": "0"}, {"ELIMREC_HEAD_SOURCES": "0", "ELIMREC_FUSE_MERGE": "0"}, {"ELIMREC_FUSE_REDUCE": "0"}, {"ELIMREC_FUSE_BWDW": "0"},
                 {"ELIMREC_HEAD_SOURCES": "0", "ELIMREC_FUSE_MERGE": "0", "ELIMREC_FUSE_REDUCE": "0", "ELIMREC_AUX_STREAM": "0"}):
         other = run(env)
         assert torch.equal(base[0], other[0]), env
