@@ -68,7 +68,7 @@ class SellPlan(object):
         the same time, which is what an XCD's L2 can hold (users read items by popularity, items read the whole,
         smaller, user table).
         tiered (the engine turns it on for whole fp32 tables, where it measured faster): rows above `threshold` are not cut into segments
-        but given to one wave (up to 32 neighbours per lane group: 32*ipw) or one workgroup (up to 64 per lane group:
+        but given to one wave (up to 64 neighbours per lane group at ipw <= 8, else 32) or one workgroup (up to 64 per lane group:
         256*ipw) each, and only the rows longer still are segmented -- one launch per hop, no fix-up launch. ipw = lane
         groups per wave of the geometry the plan will mostly run with (64 / lanes per work item)."""
         if tiered is None:
@@ -83,7 +83,9 @@ class SellPlan(object):
         val = m.data.astype(np.float32)
         deg = np.diff(rowptr)
         T = int(threshold)
-        T1 = int(os.environ.get("ELIMREC_SLAB_T1", 32 * ipw)) if tiered else T
+        # a wave per row up to 64 neighbours per lane group at 8 groups (measured: 0.319 against 0.322 ms per step with 32),
+        # 32 with more, narrower groups (column shards; not re-measured)
+        T1 = int(os.environ.get("ELIMREC_SLAB_T1", (64 if ipw <= 8 else 32) * ipw)) if tiered else T
         T2 = int(os.environ.get("ELIMREC_SLAB_T2", 256 * ipw)) if tiered else T
         long_rows = np.nonzero(deg > T)[0]
         short_rows = np.nonzero(deg <= T)[0]
