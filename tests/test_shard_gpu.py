@@ -544,6 +544,76 @@ def test_tiered_one_launch_hop(d, w, gs, bf16, ipw):
     assert ((lt - want[rows]).abs() <= 4e-6 * scale[rows] + 1e-6).all()
 
 
+@pytest.mark.parametrize("masked", [True, False])
+def test_weight_gradients_behind_a_hops_tiles(masked):
+    """elimrec_slab_hop_bwd_w: the partial launch (phase 0) and the slab reduce (phase 1) of a weight-gradient batch as
+    extra workgroups of two hop launches, and the merge / deferred-reduce forms of the batched call -- bitwise the
+    gradients of elimrec_linear_bwd_w_batched, bitwise the tables of elimrec_slab_hop; gradients 1e-4 rel vs fp64."""
+    from elimrec_amd import ops, slab
+    n, d, w, gs = 3000, 64, 32, 2
+    m = _random_graph(n, 11, hot=5, hot_deg=700)
+    plan = slab.SellPlan(m, DEV, threshold=64, side_split=1000, tiered=True, ipw=8)
+    torch.manual_seed(3)
+    x = slab.SlabTable(n, d // w, w, DEV).from_rows(torch.randn(n, d, device=DEV))
+    bm = _bitmap(torch.rand(n, device=DEV) < 0.2) if masked else None
+    R = 1500
+    A1, B1 = torch.randn(R, 64, device=DEV), torch.randn(R, 256, device=DEV)
+    A2, B2 = torch.randn(R, 64, device=DEV), torch.randn(n, 128, device=DEV)
+    idx = torch.randint(0, n, (R,), device=DEV, dtype=torch.int32)
+    rng = torch.tensor([100, 1400], dtype=torch.int32, device=DEV)
+
+    def problems(tag):
+        o = {k: torch.full(s, float("nan"), device=DEV) for k, s in (("w1", (64, 256)), ("b1", (64,)), ("w2", (64, 128)), ("b2", (64,)))}
+        return o, [dict(A=A1, B=B1, out=o["w1"], colsum=o["b1"]), dict(A=A2, B=B2, out=o["w2"], row_index=idx, rng=rng, colsum=o["b2"])]
+
+    wsp = torch.empty(ops.linear_bwd_w_batched_workspace([(R, 64, 256), (R, 64, 128)]), dtype=torch.uint8, device=DEV)
+    ref, pr = problems("ref")
+    ops.linear_bwd_w_batched(pr, wsp)
+    assert rel_err(ref["w1"], (A1.double().T @ B1.double()).float()) < 1e-4
+    sel = slice(100, 1400)
+    assert rel_err(ref["w2"], (A2[sel].double().T @ B2[idx[sel].long()].double()).float()) < 1e-4
+    y0, y1 = x.like(), x.like()
+    slab.hop(plan, x, y0, gs=gs, src_mask=bm)
+    slab.hop(plan, y0, y1, gs=gs)
+    # both phases behind hops
+    got, pr = problems("tail")
+    wsp2 = torch.empty_like(wsp)
+    h = ops.linear_bwd_w_batched(pr, wsp2, defer_all=True)
+    z0, z1 = x.like(), x.like()
+    slab.hop(plan, x, z0, gs=gs, src_mask=bm, bwd_w=h, bwd_w_phase=0)
+    slab.hop(plan, z0, z1, gs=gs, bwd_w=h, bwd_w_phase=1)
+    assert torch.equal(z0.data, y0.data) and torch.equal(z1.data, y1.data)
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), k
+    # partial launch of its own, reduce behind a hop / as a launch
+    for tail in (True, False):
+        got, pr = problems("defer")
+        h = ops.linear_bwd_w_batched(pr, wsp2, defer_reduce=True)
+        if tail:
+            slab.hop(plan, x, z0, gs=gs, src_mask=bm, bwd_w=h, bwd_w_phase=1)
+            assert torch.equal(z0.data, y0.data)
+        else:
+            ops.linear_bwd_w_reduce(h)
+        for k in ref:
+            assert torch.equal(ref[k], got[k]), (k, tail)
+    # the adjoint-source merge as extra workgroups of the partial launch
+    U, I, M = 1000, 2000, 2
+    keys = torch.sort(torch.randperm(n)[:700])[0].int().to(DEV)
+    keys = torch.cat([keys, torch.full((68,), -(1 << 30), dtype=torch.int32, device=DEV)])
+    rows = torch.randn(768, M * d, device=DEV)
+    sa, sb, ta, tb = (slab.SlabTable(n, d // w, w, DEV) for _ in range(4))
+    for t in (sa, sb, ta, tb):
+        t.data.zero_()
+    mk1 = torch.full(((n + 31) // 32 + 2,), -1, dtype=torch.int32, device=DEV)
+    mk2 = mk1.clone()
+    slab.merge_rows(rows, keys, 1, U, I, sa, sb, mk1, M=M)
+    got, pr = problems("merge")
+    ops.linear_bwd_w_batched(pr, wsp2, merge=dict(rows=rows, keys=keys, world=1, U=U, I=I, srcA=ta, srcB=tb, mask=mk2, M=M))
+    assert torch.equal(sa.data, ta.data) and torch.equal(sb.data, tb.data) and torch.equal(mk1, mk2)
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), k
+
+
 def test_step_variants_are_bitwise_equal(monkeypatch):
     """The launch-saving forms of the step change WHERE work runs, not what is computed: Adam as the last hop's epilogue
     (+ the projection weights' spans as extra workgroups), the planner / source-bit pass / weight packing on a second

@@ -1,0 +1,68 @@
+"""gpurun_out/r02/* (tools/profile_round.sh) -> profiles/r02_*: kernel-stat CSVs copied, PMC passes summarised.
+Usage: python tools/profile_collect.py"""
+import collections
+import csv
+import glob
+import json
+import shutil
+import subprocess
+import sys
+
+O = "gpurun_out/r02"
+
+
+def read(d):
+    out = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(glob.glob(d + "/*counter_collection.csv")[0])):
+        name = r["Kernel_Name"].split("(")[0]
+        if "sell_tier_kernel" in name or "half_hop" in name:
+            name += " grid=%s" % r["Grid_Size"]
+        out[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return out
+
+
+subprocess.check_call([sys.executable, "tools/pmc_summary.py", "--fetch", O + "/fetch", "--write", O + "/write", "--mfma", O + "/mfma",
+                       "--steps", "10", "--out", "/tmp/r02_pmc.json"], stdout=subprocess.DEVNULL)
+doc = json.load(open("/tmp/r02_pmc.json"))
+l2, ta = read(O + "/l2"), read(O + "/ta")
+hop = doc["propagation_hop_kernel"]
+h, t = l2[hop], ta[hop]
+avg = lambda v: sum(v) / len(v)
+gui = avg(t["GRBM_GUI_ACTIVE"])
+doc["propagation_hop_L2_hit_rate"] = round(sum(h["TCC_HIT_sum"]) / (sum(h["TCC_HIT_sum"]) + sum(h["TCC_MISS_sum"])), 4)
+doc["propagation_hop_counters_per_launch"] = {"TA_BUSY_avr_cycles": round(avg(t["TA_BUSY_avr"])),
+                                              "TCP_PENDING_STALL_CYCLES_sum": round(avg(t["TCP_PENDING_STALL_CYCLES_sum"])),
+                                              "GRBM_GUI_ACTIVE": round(gui)}
+doc["propagation_hop_TA_busy_frac"] = round(avg(t["TA_BUSY_avr"]) / (gui / 8.0), 3)
+doc["propagation_hop_TCP_pending_stall_frac"] = round(avg(t["TCP_PENDING_STALL_CYCLES_sum"]) / 256.0 / (gui / 8.0), 3)
+doc["note"] += (" TCC_HIT/TCC_MISS, TA_BUSY_avr, TCP_PENDING_STALL_CYCLES_sum from two more passes of the same command. Busy fractions: "
+                "counter / (GRBM_GUI_ACTIVE / 8 XCDs); TCP stall cycles are summed over the 256 CUs.")
+json.dump(doc, open("profiles/r02_pmc_traffic.json", "w"), indent=1)
+shutil.copy(O + "/stats/b_kernel_stats.csv", "profiles/r02_bench_kernel_stats.csv")
+shutil.copy(O + "/eval_stats/e_kernel_stats.csv", "profiles/r02_eval_kernel_stats.csv")
+ev, ef, ew = read(O + "/eval_pmc"), read(O + "/eval_fetch"), read(O + "/eval_write")
+out = {}
+for name in ev:
+    if "score_t16" in name or "topk" in name or "rank_metrics" in name:
+        c = ev[name]
+        n = len(c["SQ_BUSY_CYCLES"])
+        row = {"launches": n}
+        for k, v in c.items():
+            row[k + "_per_launch"] = round(sum(v) / n)
+        if name in ef:
+            row["fetch_MB_per_launch_x2"] = round(2 * sum(ef[name]["FETCH_SIZE"]) * 1024 / 1e6 / len(ef[name]["FETCH_SIZE"]), 2)
+        if name in ew:
+            row["write_MB_per_launch"] = round(sum(ew[name]["WRITE_SIZE"]) * 1024 / 1e6 / len(ew[name]["WRITE_SIZE"]), 2)
+        dur = row["SQ_BUSY_CYCLES_per_launch"] / 32.0
+        row["mfma_busy_frac"] = round(row["SQ_VALU_MFMA_BUSY_CYCLES_per_launch"] / 1024.0 / dur, 3)
+        row["valu_issue_busy_frac"] = round(4 * row["SQ_ACTIVE_INST_VALU_per_launch"] / 1024.0 / dur, 3)
+        out[name] = row
+json.dump({"note": "rocprofv3 --pmc passes over tools/eval_prof.py (3 TIE validation passes, 2048 users per launch, catalogue in "
+                   "16384-item chunks, EXACT math). mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 SEs); "
+                   "valu_issue_busy_frac = 4 x SQ_ACTIVE_INST_VALU (quad-cycles) / 1024 / the same duration. FETCH_SIZE doubled (gfx950).",
+           "kernels": out}, open("profiles/r02_eval_pmc.json", "w"), indent=1)
+for k in ("propagation_hop_kernel", "propagation_hop_traffic_bytes", "propagation_hop_L2_hit_rate", "propagation_hop_TA_busy_frac",
+          "propagation_hop_TCP_pending_stall_frac"):
+    print(k, doc.get(k))
+for k, v in out.items():
+    print(k[:60], {a: b for a, b in v.items() if "frac" in a})
