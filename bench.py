@@ -147,8 +147,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    multi_path = os.environ.get("ELIMREC_SHARD_MULTI") == "1"     # one rank through the multi-rank step over a one-rank RCCL group
+    if world > 1 or multi_path:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     cfg, ds, model = build(args, device)
@@ -220,7 +222,7 @@ def main():
             "config": {"workload": WORKLOAD["name"], "num_users": ds.num_users, "num_items": ds.num_items,
                        "train_interactions": int(ds.train_matrix.nnz), "feat_dims": list(WORKLOAD["feat_dims"]),
                        "recdim": WORKLOAD["recdim"], "layer_num": WORKLOAD["layer_num"], "batch_per_gpu": B,
-                       "global_batch": B * world, "parallelism": "colshard%d" % world,
+                       "global_batch": B * world, "parallelism": "colshard%d" % world + ("-multi-rank-path" if multi_path else ""),
                        "columns_per_gpu": eng.dl, "slabs": [eng.ns, eng.w, eng.gs],
                        "propagation": "folded", "head_rows": "batch", "final_loss": final_loss},
             # bytes THIS implementation's step has to move per rank (closed form) and the fraction of

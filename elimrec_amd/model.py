@@ -258,11 +258,26 @@ class EliMRec(BasicModel):
         self._ws = None
         self._ws_key = None
 
+    def __setattr__(self, name, value):
+        # per-step bookkeeping (plan sizes, cache markers, ...) skips nn.Module's parameter / buffer / submodule checks
+        if name[0] == "_" and not isinstance(value, (torch.Tensor, torch.nn.Module)) and name not in self.__dict__.get("_buffers", ()):
+            object.__setattr__(self, name, value)
+        else:
+            super().__setattr__(name, value)
+
     # cached tables of the last forward (models/EliMRec.py:121-122); materialised on first use in "batch" mode
     def _cached(self, k):
         if self._cache is None:
             return None
         self._ensure_tables()
+        if self._cache is True:                 # published by a training step: the views are built on first use
+            Y, U, d = self._cache_src, self.num_users, self.latent_dim
+            s_embs = {}
+            for h, m in enumerate(self._mods):
+                blk = Y[:, (h + 1) * d:(h + 2) * d]
+                s_embs["pre_fusion_user_" + m] = blk[:U]
+                s_embs["pre_fusion_item_" + m] = blk[U:]
+            self._cache = (Y[:U, :d], Y[U:, :d], s_embs)
         return self._cache[k]
 
     all_users = property(lambda self: self._cached(0))
@@ -517,11 +532,17 @@ class EliMRec(BasicModel):
     def _block_weights(self):
         """Per head block loss weights: fused head 1; single-modal heads alpha if the modality is
         active (:125-126,133-142)."""
-        w = [1.0]
         modality = "v" if self.is_kwai else self.modality
+        key = (self.predict_type, modality)
+        hit = self.__dict__.get("_bw_cache")
+        if hit is not None and hit[0] == key:
+            return list(hit[1])
+        alpha = float(self.config["alpha"])
+        w = [1.0]
         for m in self._mods:
             on = (self.predict_type != "normal") and (m in modality)
-            w.append(float(self.config["alpha"]) * modality.count(m) if on else 0.0)
+            w.append(alpha * modality.count(m) if on else 0.0)
+        self._bw_cache = (key, tuple(w))
         return w
 
     # ------------------------------------------------------------------ forward / backward (HIP)
@@ -611,14 +632,11 @@ class EliMRec(BasicModel):
         prof.append((e0, e1, self.n_layers if hops is None else hops))
 
     def _publish_cache(self, Y, dirty=False):
-        U, d = self.num_users, self.latent_dim
+        """The tables of this forward are the ones predict() / all_users / all_items / all_s_embs read (views into Y, built
+        on first use: a training step only notes where they are)."""
         self._table_version = getattr(self, "_table_version", 0) + 1
-        s_embs = {}
-        for h, m in enumerate(self._mods):
-            blk = Y[:, (h + 1) * d:(h + 2) * d]
-            s_embs["pre_fusion_user_" + m] = blk[:U]
-            s_embs["pre_fusion_item_" + m] = blk[U:]
-        self._cache = (Y[:U, :d], Y[U:, :d], s_embs)
+        self._cache_src = Y
+        self._cache = True
         self._tables_dirty = dirty
 
     # ------------------------------------------------------------------ hipGraph regions

@@ -48,6 +48,19 @@ def _all_gather_parts(loc, world, group):
     return parts
 
 
+def _once(fn):
+    """Memoise a no-argument predicate per engine: the launch-form switches read the environment once, not every step."""
+    key = "_once_" + fn.__name__
+
+    def wrapper(self):
+        v = self.__dict__.get(key)
+        if v is None:
+            v = self.__dict__[key] = bool(fn(self))
+        return v
+    wrapper.__name__, wrapper.__doc__ = fn.__name__, fn.__doc__
+    return wrapper
+
+
 class ColumnShardTrainer(object):
     def __init__(self, engine, optimizer, world_size=1, rank=0, group=None):
         self.engine, self.opt, self.world, self.rank, self.group = engine, optimizer, int(world_size), int(rank), group
@@ -56,6 +69,18 @@ class ColumnShardTrainer(object):
         self._scale = None
         self._buf = {}
         engine.cs_setup(self.world, self.rank, optimizer)
+        # several ranks, or ELIMREC_SHARD_MULTI=1: one rank runs the multi-rank code path, collectives included (a one-rank
+        # RCCL group exercises every collective call of the step on a single GPU -- tests)
+        self.multi = getattr(engine, "multi", self.world > 1)
+        self._gloo = None
+        # the HIP engine's phases without their torch.no_grad() wrappers: step() enters no_grad once (host time)
+        self._hip_engine = isinstance(engine, ColumnShardEngine)
+
+        def phase(name):
+            f = getattr(type(engine), name)
+            return getattr(f, "__wrapped__", f).__get__(engine) if self._hip_engine else getattr(engine, name)
+        self._ph = {n: phase(n) for n in ("cs_plan", "cs_forward_hops", "cs_forward_rows", "cs_head", "cs_backward_local",
+                                          "cs_backward_hops", "cs_update")}
         self.xgmi_bytes = dict(all_gather=0, all_to_all_fwd=0, all_to_all_bwd=0, all_reduce=0)   # sent per rank, last step
 
     def _like(self, name, t, lead=None):
@@ -74,7 +99,9 @@ class ColumnShardTrainer(object):
             return True
 
     def _staged(self, t):
-        return t.is_cuda and dist.get_backend(self.group) == "gloo"
+        if self._gloo is None:
+            self._gloo = dist.get_backend(self.group) == "gloo"
+        return self._gloo and t.is_cuda
 
     def _all_gather(self, out, inp):
         if not self._staged(inp):
@@ -101,34 +128,40 @@ class ColumnShardTrainer(object):
 
     def step(self, users, pos, neg):
         """One training step on this rank's triplets; returns the local loss (0-dim tensor)."""
-        eng, W = self.engine, self.world
+        if self._hip_engine and torch.is_grad_enabled():
+            with torch.no_grad():
+                return self._step(users, pos, neg)
+        return self._step(users, pos, neg)
+
+    def _step(self, users, pos, neg):
+        eng, W, ph = self.engine, self.world, self._ph
         if self.profile_kernels and getattr(eng, "kernel_events", None) is None:
             eng.kernel_events = self._events
-        act = eng.cs_plan(users, pos, neg)                       # int32 [R]: sorted unique node ids, negative padding
+        act = ph["cs_plan"](users, pos, neg)                       # int32 [R]: sorted unique node ids, negative padding
         h_ids = None
-        if W > 1:
+        if self.multi:
             # the id exchange runs on RCCL's stream under the forward hops, which do not need it
             acts = self._like("acts", act, W)
             h_ids = self._all_gather(acts.view(-1), act)
             self.xgmi_bytes["all_gather"] = act.numel() * 4 * (W - 1)
         else:
             acts = act.view(1, -1)
-        eng.cs_forward_hops()                                    # hops 1..L-1 of my column slice: no communication
+        ph["cs_forward_hops"]()                                    # hops 1..L-1 of my column slice: no communication
         if h_ids is not None:
             h_ids.wait()
-        send = eng.cs_forward_rows(acts)                         # [W, R, 2*dl]: layer means of the peers' rows, my columns
-        if W > 1:
+        send = ph["cs_forward_rows"](acts)                         # [W, R, 2*dl]: layer means of the peers' rows, my columns
+        if self.multi:
             recv = self._like("recv_f", send)
             self._all_to_all(recv, send)
             self.xgmi_bytes["all_to_all_fwd"] = send[0].numel() * 4 * (W - 1)
         else:
             recv = send
-        loss = eng.cs_head(recv)                                 # my rows, every rank's columns -> loss, head backward
+        loss = ph["cs_head"](recv)                                 # my rows, every rank's columns -> loss, head backward
         if self._scale is None:
             self._scale = torch.full((1,), 1.0 / W, dtype=torch.float32, device=loss.device)
-        send2, wgrads = eng.cs_backward_local(self._scale)       # [W, R, 2*dl]: my rows, the peers' columns
+        send2, wgrads = ph["cs_backward_local"](self._scale)       # [W, R, 2*dl]: my rows, the peers' columns
         h_w = None
-        if W > 1:
+        if self.multi:
             recv2 = self._like("recv_b", send2)
             self._all_to_all(recv2, send2)
             # the projection-weight gradients are needed by the optimizer step only: reduced under the adjoint hops
@@ -137,10 +170,10 @@ class ColumnShardTrainer(object):
             self.xgmi_bytes["all_reduce"] = wgrads.numel() * 4
         else:
             recv2 = send2
-        eng.cs_backward_hops(recv2, acts)
+        ph["cs_backward_hops"](recv2, acts)
         if h_w is not None:
             h_w.wait()
-        eng.cs_update()
+        ph["cs_update"]()
         return loss
 
     def global_loss(self, loss):
@@ -192,6 +225,8 @@ class ColumnShardEngine(object):
         if d % world != 0 or (d // world) % 4 != 0:
             raise ValueError("recdim %d cannot be split into %d column slices of a multiple of 4" % (d, world))
         self.world, self.rank, self.opt = world, rank, optimizer
+        import os
+        self.multi = world > 1 or os.environ.get("ELIMREC_SHARD_MULTI", "0") == "1"
         self.dl, self.col0 = d // world, rank * (d // world)
         self.ns, self.w = slab.choose_slabs16(self.dl) if self.bf16 else slab.choose_slabs(self.dl, N)
         self.gs = slab.choose_groups(self.ns)
@@ -277,8 +312,8 @@ class ColumnShardEngine(object):
             m._regions = {}                                       # recorded regions hold the old buffer's address
         bufs = self._bufs.get(B)
         if bufs is None:                                          # per batch size (an epoch ends with a ragged batch)
-            bufs = self._bufs[B] = dict(send_f=torch.empty(W, R, 2 * self.dl, dtype=torch.float32, device=dev) if W > 1 else None,
-                                        send_b=torch.zeros(W, R, 2 * self.dl, dtype=torch.float32, device=dev) if W > 1 else None)
+            bufs = self._bufs[B] = dict(send_f=torch.empty(W, R, 2 * self.dl, dtype=torch.float32, device=dev) if self.multi else None,
+                                        send_b=torch.zeros(W, R, 2 * self.dl, dtype=torch.float32, device=dev) if self.multi else None)
         self.send_f, self.send_b = bufs["send_f"], bufs["send_b"]
         if "nar_act" not in bufs:
             bufs["nar_act"] = torch.zeros(R, d, dtype=torch.float32, device=dev)       # shared part of Out, compact rows
@@ -317,10 +352,11 @@ class ColumnShardEngine(object):
         peers the plan feeds the id exchange at once."""
         if self._aux is None:
             import os
-            on = self.world == 1 and os.environ.get("ELIMREC_AUX_STREAM", "1") != "0"
+            on = not self.multi and os.environ.get("ELIMREC_AUX_STREAM", "1") != "0"
             self._aux = torch.cuda.Stream() if on else False
         return self._aux or None
 
+    @_once
     def _fuse_adam(self):
         """Adam of the embeddings (this rank's column shard) as the epilogue of the adjoint's last hop: fp32 tables, the
         tiered plan, at least two layers (ELIMREC_FUSE_ADAM=0 keeps the separate optimizer launch; `keep_grad` = True also
@@ -329,6 +365,7 @@ class ColumnShardEngine(object):
         return (not self.bf16 and self.planT.tiered and self.model.n_layers >= 2
                 and os.environ.get("ELIMREC_FUSE_ADAM", "1") != "0")
 
+    @_once
     def _fuse_reduce(self):
         """The weight gradients' slab reduce as extra workgroups of the adjoint's first hop: one rank, fp32 tables, the
         tiered plan, 'concat' fusion, and a plain masked hop to carry it (ELIMREC_FUSE_REDUCE=0: its own launch)."""
@@ -338,20 +375,23 @@ class ColumnShardEngine(object):
         return (os.environ.get("ELIMREC_FUSE_REDUCE", "1") != "0" and not self.bf16 and self.planT.tiered and hops_in_region >= 1
                 and m.mm_fusion_mode == "concat")
 
+    @_once
     def _fuse_bwd_w(self):
         """Both phases of the weight gradients behind adjoint hops' tiles: needs two plain hops before the Adam hop."""
         import os
         hops_in_region = self.model.n_layers - (1 if self._fuse_adam() else 0)
         return os.environ.get("ELIMREC_FUSE_BWDW", "1") != "0" and hops_in_region >= 2
 
+    @_once
     def _sources_in_head(self):
         """One rank, recdim 64, packed head weights: the head backward's kernel writes the adjoint sources at the active rows
         (each listed once) and the planner's key bitmap is their row bitmap -- no merge at all (ELIMREC_HEAD_SOURCES=0: the
         merge rides in the weight-gradient launch)."""
         import os
-        return (self.world == 1 and self._fused_head_ok() and bool(self._pack_bwd_off) and self.model.latent_dim == 64
+        return (not self.multi and self._fused_head_ok() and bool(self._pack_bwd_off) and self.model.latent_dim == 64
                 and os.environ.get("ELIMREC_HEAD_SOURCES", "1") != "0" and os.environ.get("ELIMREC_HEAD_BWD_ROWS", "16") != "32")
 
+    @_once
     def _fuse_merge(self):
         import os
         return os.environ.get("ELIMREC_FUSE_MERGE", "1") != "0" and (self.model.num_users + self.model.num_items) <= (1 << 27)
@@ -429,7 +469,7 @@ class ColumnShardEngine(object):
         if self._aux_pending:                                     # the plan (and the packed weights) from the second stream
             torch.cuda.current_stream().wait_stream(self._aux)
             self._aux_pending = False
-        if W > 1:
+        if self.multi:
             counts = None                                        # the gathered lists are padded with negative keys
             out0, narrow, by_node = self.send_f.view(W * R, 2 * self.dl)[:, :self.dl], self.send_f.view(W * R, 2 * self.dl)[:, self.dl:], False
         else:
@@ -449,7 +489,7 @@ class ColumnShardEngine(object):
                 slab.rows(self.plan, self.ns, self.w, L, U, [t.data for t in tabs] + [None], self.long_tab, acts, counts, R, W,
                           out0, narrow, by_node)
         m._region("cs_fwd_rows%d" % self.cur, (m._ws_gen, acts.data_ptr(), R, W, narrow.data_ptr()), rows)
-        return self.send_f if W > 1 else None
+        return self.send_f if self.multi else None
 
     def cs_forward(self, acts):
         self.cs_forward_hops()
@@ -544,26 +584,26 @@ class ColumnShardEngine(object):
         R = m._plan_n
         # the head backward reads its weight operands from the packed copy the fused forward left behind (16-row forms)
         pack_bwd = self._pack[self._pack_bwd_off:] if (self._fused_head_ok() and self._pack_bwd_off) else None
-        side = self._side_stream() if self.world == 1 else None
+        side = self._side_stream() if not self.multi else None
         # one rank: the merge of the dOut rows into the adjoint sources rides in the weight-gradient launch (both read the
         # head backward's rows and nothing of each other; ELIMREC_FUSE_MERGE=0: a launch of its own before the hops)
         merge = None
         sources = (self.srcA, self.srcB) if (pack_bwd is not None and self._sources_in_head()) else None
         if sources is not None:
             pass                       # the head backward writes the sources itself; their row bitmap is the planner's
-        elif self.world == 1 and side is None and self._fuse_merge():
+        elif not self.multi and side is None and self._fuse_merge():
             merge = dict(rows=ws["dOutR"][:R].view(R, m.C), keys=self._acts.reshape(-1), world=1, U=m.num_users, I=m.num_items,
                          srcA=self.srcA, srcB=self.srcB, mask=self.mask, M=m.M)
         self._merged = merge is not None or sources is not None
         # ... and the weight gradients' slab reduce, needed by the optimizer only, in the adjoint's first hop launch
-        defer = (self.world == 1 and side is None and self._fuse_reduce())
+        defer = (not self.multi and side is None and self._fuse_reduce())
         if defer and merge is None and self._fuse_bwd_w():
             defer = "all"              # ... and the partial launch too: behind the first hop's tiles, the reduce behind the second's
         self._grads = m._backward_batch_rows(ws, scale, ws["grad_rows"], R, head_only=True, w_stream=side, pack_bwd=pack_bwd,
                                              merge=merge, defer_reduce=defer, sources=sources)
         self._reduce = (m._bwd_w_reduce, 0 if defer == "all" else 1) if defer else None
         wg = ws["flat_grad"][ws["tail_off"]:]
-        if self.world == 1:       # one rank owns every column: the merge reads the dOut rows themselves
+        if not self.multi:        # one rank owns every column: the merge reads the dOut rows themselves
             return ws["dOutR"][:R].view(1, R, m.C), wg
         # [H | G]: all the adjoint needs of a dOut row, written straight into the peers' column slices [W, R, 2*dl] (rows
         # beyond the active count are never read: their keys are negative)
@@ -583,15 +623,16 @@ class ColumnShardEngine(object):
         fuse = self._fuse_adam()
         last = 1 if fuse else 0                                    # the hops the recorded region covers: L-1 .. last
 
-        merged = W == 1 and getattr(self, "_merged", False)
-        reduce = getattr(self, "_reduce", None) if W == 1 else None
+        single = not self.multi
+        merged = single and getattr(self, "_merged", False)
+        reduce = getattr(self, "_reduce", None) if single else None
         self._reduce = None
 
         def hops():
             phase = None if reduce is None else reduce[1]
             if merged:
                 pass                                               # done beside the weight gradients (cs_backward_local)
-            elif W == 1:
+            elif single:
                 slab.merge_rows(recv2.view(R, m.C), acts.reshape(-1), 1, U, I, self.srcA, self.srcB, self.mask, M=m.M)
             else:
                 slab.merge_rows(recv2.view(W * R, 2 * self.dl), acts.reshape(-1), W, U, I, self.srcA, self.srcB, self.mask)
@@ -614,15 +655,15 @@ class ColumnShardEngine(object):
             # Issued outside the recorded region: the bias-correction constants change every step.
             g = self.opt.param_groups[0]
             nxt = 1 - self.cur
-            tail = self._tail_jobs() if W == 1 else []        # (advances the weights' step counts: called once per step)
+            tail = self._tail_jobs() if single else []        # (advances the weights' step counts: called once per step)
             if len(tail) > 8:
                 raise RuntimeError("more than 8 optimizer spans")
-            self._tail_in_hop = W == 1
+            self._tail_in_hop = single
             self._timed(lambda: slab.hop_adam(self.planT, self.tmp[1], self.grad if self.keep_grad else None, self.gs, self.srcA,
                                               self.mask, inv, self.master[self.cur].data, self.master[nxt].data, self.m1, self.m2,
                                               g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
                                               self.step_count + 1, tail_jobs=tail), 1)
-        if self._side and self.world == 1:
+        if self._side and not self.multi:
             torch.cuda.current_stream().wait_stream(self._side)      # the weight gradients, computed beside the hops
 
     @torch.no_grad()

@@ -761,3 +761,53 @@ def test_two_processes_on_one_gpu_equal_one_process(tmp_path):
     assert np.allclose(rs[0]["losses"], losses, atol=1e-5)
     for k, v in model.state_dict().items():
         assert np.abs(rs[0][k] - v.detach().cpu().numpy()).max() < 2e-5, k
+
+
+# ----------------------------------------------------------------------------- one-rank RCCL group, multi-rank code path
+def _rccl_one_rank_worker(rank, port, out_dir):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["ELIMREC_SHARD_MULTI"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
+    g = load_golden("ml3")
+    model, _ = build_model_from_fixture(g, DEV)
+    opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    eng = ColumnShardEngine(model)
+    tr = ColumnShardTrainer(eng, opt, world_size=1, rank=0)
+    assert tr.multi and eng.multi
+    losses = []
+    for t in (1, 2, 3):
+        u, p, n = (_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg"))
+        losses.append(float(tr.global_loss(tr.step(u, p, n))))
+    eng.sync_to_model()
+    np.savez(os.path.join(out_dir, "rccl.npz"), losses=np.array(losses), xgmi=np.array(sorted(tr.xgmi_bytes)),
+             **{k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
+    dist.destroy_process_group()
+
+
+def test_multi_rank_step_over_a_one_rank_rccl_group(tmp_path):
+    """ELIMREC_SHARD_MULTI=1: ONE rank runs the multi-rank step -- all_gather of the active ids, both all_to_alls, the
+    asynchronous all_reduce of the weight gradients, the rank-ordered merge, the separate optimizer launch -- over a real
+    RCCL (backend "nccl") process group on the GPU: every collective call of the step as the 8-GPU job issues it (tensor
+    shapes, dtypes, contiguity, stream hand-over, async handles). Three steps equal the one-rank fast path to round-off."""
+    import torch.multiprocessing as mp
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
+    port = 35500 + (os.getpid() % 2000)
+    mp.spawn(_rccl_one_rank_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
+    got = dict(np.load(tmp_path / "rccl.npz"))
+    assert set(got.pop("xgmi").tolist()) == {"all_gather", "all_to_all_fwd", "all_to_all_bwd", "all_reduce"}
+    g = load_golden("ml3")
+    model, _ = build_model_from_fixture(g, DEV)
+    opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    eng = ColumnShardEngine(model)
+    tr = ColumnShardTrainer(eng, opt)
+    assert not tr.multi
+    losses = [float(tr.step(*(_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg")))) for t in (1, 2, 3)]
+    eng.sync_to_model()
+    assert np.abs(got.pop("losses") - np.array(losses)).max() < 1e-5
+    for k, v in model.state_dict().items():
+        assert np.abs(got[k] - v.detach().cpu().numpy()).max() < 2e-5, k

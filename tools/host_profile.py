@@ -1,23 +1,21 @@
-"""cProfile of the host side of the training step (dev tool)."""
+"""cProfile of the host side of the training step (which Python / ctypes / torch.distributed calls the issue time goes to).
+usage: [ELIMREC_SHARD_MULTI=1] host_profile.py [steps]"""
 import cProfile, os, pstats, sys, torch
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-import bench
-from elimrec_amd import FusedAdam
-from elimrec_amd.dist import DataParallelTrainer
-cfg, ds, model = bench.build(None, "cuda:0")
-model = model.to("cuda:0")
-opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
-tr = DataParallelTrainer(model, opt)
-g = torch.Generator(device="cuda:0").manual_seed(0)
-u = torch.randint(0, ds.num_users, (2048,), device="cuda:0", generator=g)
-p = torch.randint(0, ds.num_items, (2048,), device="cuda:0", generator=g)
-n = torch.randint(0, ds.num_items, (2048,), device="cuda:0", generator=g)
-for _ in range(5): tr.step(u, p, n)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.argv = [sys.argv[0]] + sys.argv[1:]
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+sys.argv = [sys.argv[0], "40"]
+import runpy
+g = runpy.run_path(os.path.join(os.path.dirname(os.path.abspath(__file__)), "step_trace.py"))
+tr, u, p, n, B = g["tr"], g["u"], g["p"], g["n"], g["B"]
+nb = u.numel() // B
 torch.cuda.synchronize()
 pr = cProfile.Profile()
 pr.enable()
-for _ in range(100): tr.step(u, p, n)
-pr.disable()
+for i in range(K):
+    j = i % nb
+    tr.step(u[j * B:(j + 1) * B], p[j * B:(j + 1) * B], n[j * B:(j + 1) * B])
 torch.cuda.synchronize()
+pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("cumulative").print_stats(45)
+st.sort_stats("tottime").print_stats(int(os.environ.get("ROWS", "22")))

@@ -12,6 +12,11 @@ Logger.logger = Logger(show_in_console=False)
 ds = SyntheticDataset(36656, 76085, 720829, feat_dims=(128, 128, 128), seed=0)
 B = 2048
 u, p, n = PairwiseSamplerV2(ds, batch_size=B, device=dev).sample_epoch()
+if os.environ.get("ELIMREC_SHARD_MULTI") == "1":       # the multi-rank step over a one-rank RCCL group
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(dev))
 set_seed(1)
 model = EliMRec(cfg, ds).to(dev)
 opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
