@@ -136,6 +136,9 @@ SIGNATURES = {
     "elimrec_segment_apply_head_bwd_sources": (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_i64, c_i32,
                                                 c_i32, c_i32, ctypes.POINTER(c_i32), c_ptr, c_ptr, ctypes.POINTER(c_ptr), c_ptr,
                                                 c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_ptr]),
+    "elimrec_segment_apply_head_bwd_split": (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_i64, c_i32,
+                                              c_i32, c_i32, ctypes.POINTER(c_i32), c_ptr, c_ptr, ctypes.POINTER(c_ptr), c_ptr,
+                                              c_ptr, c_i64, c_i32, c_ptr, c_ptr]),
     "elimrec_segment_apply": (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "elimrec_segment_reduce_rows": (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "elimrec_head_bwd_input": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i64, c_i32, c_i32, c_i32,

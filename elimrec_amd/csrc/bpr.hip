@@ -750,7 +750,10 @@ __device__ __forceinline__ v4f_ hm16_accumulate_packed(v4f_ acc, const float *__
 
 // slab-major adjoint source tables (slab.hip layout: [d / w][N][w]) the 16-row head backward can fill directly when one
 // rank owns every column and every active row is listed once: what elimrec_slab_merge_rows(M >= 1) would write
-struct SlabSources { float *A, *B; int64_t N; int w, w_shift; };
+// ... or, with peers (split != NULL): the [H | G] rows cut into the `world` column slices a column-sharded job sends them,
+// split[q][slot] = [H[slot][q*dl : (q+1)*dl] | G[slot][q*dl : (q+1)*dl]] (layout [world x n_max x 2*dl]: what
+// elimrec_source_rows_split makes of the compact rows)
+struct SlabSources { float *A, *B; int64_t N; int w, w_shift; float *split; int64_t n_max; int dl; };
 
 struct HeadPackPtrs { const float *f[2]; const float *s[kMaxHeads]; };      // null f[0]: weights read unpacked
 
@@ -861,13 +864,20 @@ __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__re
                 const float v = ((mixed && nd >= U) ? acc2[r] : acc[r]) * gscale;
                 if (G0 && c0 + li < scatter_cols) G0[nd * ldg + c0 + li] = v;
                 if (compact) compact[(s0 + row) * C + c0 + li] = v;
-                if (src.A) {
+                if (src.A || src.split) {
                     const int cb = c0 - mb * d + li;                 // column within the block
                     const float h = mb == 0 ? v : hs[r] + v;
                     hs[r] = h;
-                    const int64_t at = ((int64_t)(cb >> src.w_shift) * src.N + nd) * src.w + (cb & (src.w - 1));
-                    if (mb == 0) (nd < U ? src.B : src.A)[at] = v;
-                    if (mb == last_block) (nd < U ? src.A : src.B)[at] = h;
+                    if (src.split) {
+                        const int q = cb / src.dl, j = cb - q * src.dl;
+                        float *rp = src.split + ((int64_t)q * src.n_max + (s0 + row)) * 2 * src.dl;
+                        if (mb == last_block) rp[j] = h;
+                        if (mb == 0) rp[src.dl + j] = v;
+                    } else {
+                        const int64_t at = ((int64_t)(cb >> src.w_shift) * src.N + nd) * src.w + (cb & (src.w - 1));
+                        if (mb == 0) (nd < U ? src.B : src.A)[at] = v;
+                        if (mb == last_block) (nd < U ? src.A : src.B)[at] = h;
+                    }
                 }
             }
         }
@@ -1290,8 +1300,24 @@ extern "C" int elimrec_segment_apply_head_bwd_sources(const float *d_rows, int64
     ELIMREC_REQUIRE(d_pack_bwd && d_SrcA && d_SrcB, "segment_apply_head_bwd_sources: null pointer");
     ELIMREC_REQUIRE(d == 64 && w >= 4 && (w & (w - 1)) == 0 && ns * w == d && N >= U,
                     "segment_apply_head_bwd_sources: recdim 64 in [ns x N x w] slabs (d=%d, ns=%d, w=%d)", d, ns, w);
-    SlabSources src = {d_SrcA, d_SrcB, N, w, 0};
+    SlabSources src = {d_SrcA, d_SrcB, N, w, 0, nullptr, 0, 0};
     while ((1 << src.w_shift) < w) ++src.w_shift;
+    return segment_apply_head_bwd_impl(d_rows, n, ld, d_active_rows, d_seg_info, d_scale, d_reduced, d_plan_workspace,
+                                       plan_workspace_bytes, U, d, C, S, head_mblock, d_W_user, d_W_item, d_W_heads, d_compact,
+                                       d_pack_bwd, &src, stream);
+}
+
+extern "C" int elimrec_segment_apply_head_bwd_split(const float *d_rows, int64_t n, int ld, const int32_t *d_active_rows,
+                                                    const int32_t *d_seg_info, const float *d_scale, float *d_reduced,
+                                                    const void *d_plan_workspace, size_t plan_workspace_bytes, int64_t U,
+                                                    int d, int C, int S, const int *head_mblock, const float *d_W_user,
+                                                    const float *d_W_item, const float *const *d_W_heads,
+                                                    float *d_compact, const float *d_pack_bwd, int64_t n_max, int world,
+                                                    float *d_out, void *stream) {
+    ELIMREC_REQUIRE(d_pack_bwd && d_out, "segment_apply_head_bwd_split: null pointer");
+    ELIMREC_REQUIRE(d == 64 && world >= 1 && d % world == 0 && (d / world) % 4 == 0 && n_max >= n,
+                    "segment_apply_head_bwd_split: recdim 64 in %d column slices, n_max >= n", world);
+    SlabSources src = {nullptr, nullptr, 0, 0, 0, d_out, n_max, d / world};
     return segment_apply_head_bwd_impl(d_rows, n, ld, d_active_rows, d_seg_info, d_scale, d_reduced, d_plan_workspace,
                                        plan_workspace_bytes, U, d, C, S, head_mblock, d_W_user, d_W_item, d_W_heads, d_compact,
                                        d_pack_bwd, &src, stream);

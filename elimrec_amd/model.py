@@ -849,7 +849,8 @@ class EliMRec(BasicModel):
 
         key = (self._ws_gen, grad_rows.data_ptr(), gscale.data_ptr(), n, tuple(bw))
         self._region("bwd_head_in", key + (0 if pack_bwd is None else pack_bwd.data_ptr(),
-                                           0 if sources is None else sources[0].data.data_ptr()), head_input)
+                                           0 if sources is None else (sources[1] if sources[0] == "split" else sources[0].data).data_ptr()),
+                     head_input)
         if w_stream is None:
             mkey = (str(defer_reduce),) + (() if merge is None else (merge["rows"].data_ptr(), merge["keys"].data_ptr(),
                                                                      merge["mask"].data_ptr()))

@@ -582,7 +582,7 @@ def segment_apply_head_bwd(rows, active_rows, seg_info, reduced, plan_workspace,
     """segment_apply + head_bwd_input(compact=...) in one launch; `reduced` receives dY. pack_bwd: the backward region of
     the fused head's packed weights (a view starting at head_pack_bwd_offset floats), if the forward left it behind.
     sources = (srcA, srcB) slab tables: the kernel also fills the adjoint sources at the active rows (one rank, recdim 64,
-    packed weights: elimrec_segment_apply_head_bwd_sources)."""
+    packed weights: elimrec_segment_apply_head_bwd_sources); ("split", send, world): the peers' [H | G] column slices."""
     n, ld = rows.shape
     S = len(W_heads)
     assert rows.is_contiguous() and reduced.is_contiguous() and reduced.shape[1] == ld and compact.is_contiguous()
@@ -591,6 +591,16 @@ def segment_apply_head_bwd(rows, active_rows, seg_info, reduced, plan_workspace,
     wp = (ctypes.c_void_p * max(S, 1))(*[_dev(w, "W_head") for w in W_heads]) if S else (ctypes.c_void_p * 1)(None)
     for w in list(W_heads) + [W_user, W_item]:
         assert w.is_contiguous()
+    if sources is not None and sources[0] == "split":          # ("split", send [W x n_max x 2*dl], W)
+        _, send, world = sources
+        assert pack_bwd is not None and send.is_contiguous() and send.shape == (world, send.shape[1], 2 * (d // world)) and send.shape[1] >= n
+        _lib.check(_lib.load().elimrec_segment_apply_head_bwd_split(
+            _dev(rows, "rows"), n, ld, _dev(active_rows, "active_rows", torch.int32), _dev(seg_info, "seg_info", torch.int32),
+            _dev(scale, "scale"), _dev(reduced, "reduced"), _dev(plan_workspace, "plan_workspace", torch.uint8),
+            plan_workspace.numel(), U, d, C, S, mb, _dev(W_user, "W_user"), _dev(W_item, "W_item"), wp,
+            _dev(compact, "compact"), _dev(pack_bwd, "pack_bwd"), send.shape[1], int(world), _dev(send, "send"), _stream()),
+            "segment_apply_head_bwd_split")
+        return
     if sources is not None:
         srcA, srcB = sources
         assert pack_bwd is not None and srcA.ns == srcB.ns and srcA.w == srcB.w and srcA.n == srcB.n

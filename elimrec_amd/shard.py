@@ -397,6 +397,12 @@ class ColumnShardEngine(object):
                 and os.environ.get("ELIMREC_HEAD_SOURCES", "1") != "0" and os.environ.get("ELIMREC_HEAD_BWD_ROWS", "16") != "32")
 
     @_once
+    def _split_in_head(self):
+        import os
+        return (self._fused_head_ok() and bool(self._pack_bwd_off) and self.model.latent_dim == 64
+                and os.environ.get("ELIMREC_HEAD_SOURCES", "1") != "0" and os.environ.get("ELIMREC_HEAD_BWD_ROWS", "16") != "32")
+
+    @_once
     def _fuse_merge(self):
         import os
         return os.environ.get("ELIMREC_FUSE_MERGE", "1") != "0" and (self.model.num_users + self.model.num_items) <= (1 << 27)
@@ -594,6 +600,8 @@ class ColumnShardEngine(object):
         # head backward's rows and nothing of each other; ELIMREC_FUSE_MERGE=0: a launch of its own before the hops)
         merge = None
         sources = (self.srcA, self.srcB) if (pack_bwd is not None and self._sources_in_head()) else None
+        if self.multi and pack_bwd is not None and self._split_in_head():
+            sources = ("split", self.send_b, self.world)      # the head backward fills the peers' [H | G] slices itself
         if sources is not None:
             pass                       # the head backward writes the sources itself; their row bitmap is the planner's
         elif not self.multi and side is None and self._fuse_merge():
@@ -614,6 +622,8 @@ class ColumnShardEngine(object):
         # beyond the active count are never read: their keys are negative)
         W = self.world
         send = self.send_b
+        if sources is not None:
+            return send, wg
         m._region("cs_sources", (m._ws_gen, R, send.data_ptr()),
                   lambda: ops.source_rows_split(ws["dOutR"][:R], ws["seg_info"][0:1], d, m.M, W, send))
         return send, wg

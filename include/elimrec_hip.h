@@ -409,6 +409,15 @@ int elimrec_segment_apply_head_bwd_sources(const float *d_rows, int64_t n, int l
                                            const float *d_W_item, const float *const *d_W_heads,
                                            float *d_compact, const float *d_pack_bwd, int64_t N, int ns, int w,
                                            float *d_SrcA, float *d_SrcB, void *stream);
+/* ... and with peers: the kernel also writes what elimrec_source_rows_split(d_compact) would -- the [H | G] rows cut into
+ * the `world` column slices of a column-sharded job, d_out [world x n_max x 2*(d/world)] -- ready for the all-to-all. */
+int elimrec_segment_apply_head_bwd_split(const float *d_rows, int64_t n, int ld, const int32_t *d_active_rows,
+                                         const int32_t *d_seg_info, const float *d_scale, float *d_reduced,
+                                         const void *d_plan_workspace, size_t plan_workspace_bytes, int64_t U,
+                                         int d, int C, int S, const int *head_mblock, const float *d_W_user,
+                                         const float *d_W_item, const float *const *d_W_heads,
+                                         float *d_compact, const float *d_pack_bwd, int64_t n_max, int world,
+                                         float *d_out, void *stream);
 
 /* ---------------------------------------------------------------- embedding gradients (K2 bwd)
  * dE_user[u, j] = sum_m G[u, m*d + j];  dE_item[i, j] = G[U+i, j]   (CatBackward of :239). */
