@@ -11,12 +11,20 @@ U, I = 36656, 76085
 ds = SyntheticDataset(U, I, 720829, feat_dims=(4, 4, 4), seed=0)
 adj = create_adj_mat(*ds.get_train_interactions(), U, I, "pre").tocsr()
 N = adj.shape[0]
+if os.environ.get("RELABEL") == "1":        # node ids = the plan's processing order: item rows then user rows, by decreasing degree
+    import numpy as np
+    deg = np.diff(adj.indptr)
+    order = np.lexsort((-deg, np.arange(N) < U))          # same key as SellPlan's side_split order
+    inv = np.empty(N, np.int64); inv[order] = np.arange(N)
+    adj = adj[order][:, order].tocsr()
+    adj.sort_indices()
+    U = 0 if False else U    # (side_split below then no longer separates sides: pass None)
 bf16 = os.environ.get("BF16") == "1"
 ns, w = slab.choose_slabs16(d) if bf16 else slab.choose_slabs(d, N)
 gs = slab.choose_groups(ns)
 tiered = os.environ.get("TIERED", "1") == "1"
 T = int(os.environ.get("T", 64 if tiered else 32))
-plan = slab.SellPlan(adj, dev, side_split=U, tiered=tiered, threshold=T, ipw=64 // ((ns // gs) * (w // (8 if bf16 else 4))))
+plan = slab.SellPlan(adj, dev, side_split=None if os.environ.get("RELABEL") == "1" else U, tiered=tiered, threshold=T, ipw=64 // ((ns // gs) * (w // (8 if bf16 else 4))))
 torch.manual_seed(0)
 tabs = [slab.SlabTable(N, ns, w, dev).from_rows(torch.randn(N, d, device=dev)) for _ in range(3)]
 if bf16:
@@ -26,4 +34,12 @@ for _ in range(hops):
     slab.hop(plan, src, dst, gs=gs)
     src, dst = dst, (tabs[2] if dst is tabs[1] else tabs[1])
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(40):
+    slab.hop(plan, src, dst, gs=gs)
+    src, dst = dst, (tabs[2] if dst is tabs[1] else tabs[1])
+e1.record()
+torch.cuda.synchronize()
+print("%.2f us per hop" % (e0.elapsed_time(e1) * 1e3 / 40))
 print("geometry ns=%d w=%d gs=%d, %d hops, index bytes %d" % (ns, w, gs, hops, plan.index_bytes()))
