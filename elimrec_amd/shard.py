@@ -232,6 +232,7 @@ class ColumnShardEngine(object):
         self.world, self.rank, self.opt = world, rank, optimizer
         import os
         self.multi = world > 1 or os.environ.get("ELIMREC_SHARD_MULTI", "0") == "1"
+        self._late_wait = os.environ.get("ELIMREC_LATE_WAIT", "1") != "0"
         self.dl, self.col0 = d // world, rank * (d // world)
         self.ns, self.w = slab.choose_slabs16(self.dl) if self.bf16 else slab.choose_slabs(self.dl, N)
         self.gs = slab.choose_groups(self.ns)
@@ -477,9 +478,10 @@ class ColumnShardEngine(object):
         W, R = acts.shape
         tabs = self._tabs
         self._acts = acts
-        if self._aux_pending:                                     # the plan (and the packed weights) from the second stream
+        late_wait = self._aux_pending and self._late_wait       # the long-rows hop needs nothing of the plan: join after it
+        if self._aux_pending and not late_wait:                  # the plan (and the packed weights) from the second stream
             torch.cuda.current_stream().wait_stream(self._aux)
-            self._aux_pending = False
+        self._aux_pending = False
         if self.multi:
             counts = None                                        # the gathered lists are padded with negative keys
             out0, narrow, by_node = self.send_f.view(W * R, 2 * self.dl)[:, :self.dl], self.send_f.view(W * R, 2 * self.dl)[:, self.dl:], False
@@ -490,16 +492,23 @@ class ColumnShardEngine(object):
             else:
                 out0, narrow, by_node = ws["OutAct"][:R, :m.latent_dim], ws["Narrow"], True
 
-        def rows():
+        def long_rows():
             if self.plan.n_long:
                 slab.hop(self.plan, self._srcs[L - 1], self.long_tab, gs=self.gs, seg_only=True)
+
+        def rows():
+            if not late_wait:
+                long_rows()
             if self.bf16:
                 slab.rows16(self.plan, self.ns, self.w, L, U, tabs[0].data, [t.data for t in tabs[1:]] + [None], self.long_tab,
                             acts, counts, R, W, out0, narrow, by_node)
             else:
                 slab.rows(self.plan, self.ns, self.w, L, U, [t.data for t in tabs] + [None], self.long_tab, acts, counts, R, W,
                           out0, narrow, by_node)
-        m._region("cs_fwd_rows%d" % self.cur, (m._ws_gen, acts.data_ptr(), R, W, narrow.data_ptr()), rows)
+        if late_wait:
+            m._region("cs_fwd_long%d" % self.cur, (m._ws_gen,), long_rows)
+            torch.cuda.current_stream().wait_stream(self._aux)
+        m._region("cs_fwd_rows%d" % self.cur, (m._ws_gen, acts.data_ptr(), R, W, narrow.data_ptr(), late_wait), rows)
         return self.send_f if self.multi else None
 
     def cs_forward(self, acts):
