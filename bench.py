@@ -239,6 +239,14 @@ def main():
                          "traffic": pmc_traffic() if world == 1 else None,
                          "limiter": "per-CU gather path, not HBM: TA busy 47 %, L1 stalled on pending misses 45 % of the launch, "
                                     "L2 hit rate 0.60 (profiles/r02_pmc_traffic.json; DESIGN.md section 3)",
+                         # what the launch's gather instructions move: every non-zero pulls one row piece of each slab through the
+                         # CUs' L1 (a source row is gathered deg times; the algorithmic bytes count it once). The chip's measured
+                         # rate for uniformly random rows: MI355X_MICROARCH.md, "Indexed rows: gather into LDS"
+                         "gather": {"gathered_bytes_per_launch": int(eng.plan.nnz) * eng.dl * 4,
+                                    "achieved_GBps": int(eng.plan.nnz) * eng.dl * 4 / (hop_us * 1e-6) / 1e9,
+                                    "chip_random_row_gather_GBps": {"table in Infinity Cache (38 MB, 1152-B rows)": 8600,
+                                                                    "151 MB table": 7650, "rows shared through L2": 17800},
+                                    "frac_of_random_gather_rate": int(eng.plan.nnz) * eng.dl * 4 / (hop_us * 1e-6) / 1e9 / 8600.0},
                          "algorithmic_bytes_per_launch": sb["hop_minimal"],
                          "algorithmic_bytes_formula": "read X + write X' + index stream once: 2*N*dl*4 + plan.index_bytes() (8 B per index entry + the tile / item records)",
                          "bytes_with_index_per_group": sb["hop"],
