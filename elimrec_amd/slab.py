@@ -62,7 +62,7 @@ def _is_pow2(x):
 class SellPlan(object):
     """SELL-64 work items of a CSR matrix on a device (struct elimrec_sell)."""
 
-    def __init__(self, m, device, threshold=LONG_ROW_THRESHOLD, side_split=None, tiered=None, ipw=8):
+    def __init__(self, m, device, threshold=LONG_ROW_THRESHOLD, side_split=None, tiered=None, ipw=8, phase=None):
         """side_split = U: the unsplit rows are processed side by side (item rows, then user rows; by decreasing
         length inside a side) instead of by length alone -- all workgroups then gather from the same side's rows at
         the same time, which is what an XCD's L2 can hold (users read items by popularity, items read the whole,
@@ -103,7 +103,9 @@ class SellPlan(object):
         seg_len = np.minimum(T, rowptr[long_rows + 1][seg_row] - seg_beg)
         # heavy first, inside each kind
         so = np.argsort(-seg_len, kind="stable")
-        if side_split is None:
+        if phase is not None:        # explicit processing phases of the unsplit rows (int per row), by decreasing length inside
+            ro = np.lexsort((-deg[short_rows], np.asarray(phase)[short_rows]))
+        elif side_split is None:
             ro = np.argsort(-deg[short_rows], kind="stable")
         else:
             ro = np.lexsort((-deg[short_rows], short_rows < int(side_split)))

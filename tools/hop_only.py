@@ -19,26 +19,47 @@ if os.environ.get("RELABEL") == "1":        # node ids = the plan's processing o
     adj = adj[order][:, order].tocsr()
     adj.sort_indices()
     U = 0 if False else U    # (side_split below then no longer separates sides: pass None)
+phase, n_out = None, N
+if os.environ.get("SPLIT"):                 # user rows cut into K virtual rows by item range: what an L2-sized source window would cost
+    import numpy as np, scipy.sparse as sp
+    K = int(os.environ["SPLIT"])
+    coo = adj.tocoo()
+    is_user_row = coo.row < U
+    part = np.where(is_user_row, np.minimum(K - 1, (coo.col - U) * K // I), 0)
+    new_row = np.where(part == 0, coo.row, N + (part - 1) * U + coo.row)
+    n_out = N + (K - 1) * U
+    adj = sp.csr_matrix((coo.data, (new_row, coo.col)), shape=(n_out, N))
+    adj.sort_indices()
+    phase = np.zeros(n_out, np.int64)
+    phase[:U] = 1                                              # items (phase 0), then user parts 1..K
+    for k in range(1, K):
+        phase[N + (k - 1) * U:N + k * U] = 1 + k
 bf16 = os.environ.get("BF16") == "1"
 ns, w = slab.choose_slabs16(d) if bf16 else slab.choose_slabs(d, N)
 gs = slab.choose_groups(ns)
 tiered = os.environ.get("TIERED", "1") == "1"
 T = int(os.environ.get("T", 64 if tiered else 32))
-plan = slab.SellPlan(adj, dev, side_split=None if os.environ.get("RELABEL") == "1" else U, tiered=tiered, threshold=T, ipw=64 // ((ns // gs) * (w // (8 if bf16 else 4))))
+plan = slab.SellPlan(adj, dev, phase=phase, side_split=None if os.environ.get("RELABEL") == "1" else U, tiered=tiered, threshold=T, ipw=64 // ((ns // gs) * (w // (8 if bf16 else 4))))
 torch.manual_seed(0)
 tabs = [slab.SlabTable(N, ns, w, dev).from_rows(torch.randn(N, d, device=dev)) for _ in range(3)]
+if n_out != N:                              # rectangular: every hop reads table 0 and writes an [n_out x d] table
+    outs = [slab.SlabTable(n_out, ns, w, dev) for _ in range(2)]
 if bf16:
     tabs = [t.to_bf16(t.like(torch.bfloat16)) for t in tabs]
 src, dst = tabs[0], tabs[1]
-for _ in range(hops):
-    slab.hop(plan, src, dst, gs=gs)
-    src, dst = dst, (tabs[2] if dst is tabs[1] else tabs[1])
+def run(n):
+    global src, dst
+    for i in range(n):
+        if n_out != N:
+            slab.hop(plan, tabs[i % 3], outs[i % 2], gs=gs)
+            continue
+        slab.hop(plan, src, dst, gs=gs)
+        src, dst = dst, (tabs[2] if dst is tabs[1] else tabs[1])
+run(hops)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(40):
-    slab.hop(plan, src, dst, gs=gs)
-    src, dst = dst, (tabs[2] if dst is tabs[1] else tabs[1])
+run(40)
 e1.record()
 torch.cuda.synchronize()
 print("%.2f us per hop" % (e0.elapsed_time(e1) * 1e3 / 40))
