@@ -1,5 +1,5 @@
 // Weight-gradient contraction (gemm.hip): problem table, decomposition and the fixed-order slab reduce, shared with the
-// hop launch that can carry the reduce as extra workgroups (slab.hip, elimrec_slab_hop_reduce).
+// hop launches that can carry either phase as extra workgroups (slab.hip, elimrec_slab_hop_bwd_w).
 #pragma once
 #include "common.h"
 #include <cstdlib>
