@@ -94,13 +94,14 @@ class SellPlan(object):
         w1 = w1[np.argsort(-deg[w1], kind="stable")]
         w4 = w4[np.argsort(-deg[w4], kind="stable")]
         # segments of the split rows (tiered: of the rows above T2 only): slot numbers run row by row, segment by segment
-        nseg = np.where(deg[long_rows] > T2, (deg[long_rows] + T - 1) // T, 0) if tiered else (deg[long_rows] + T - 1) // T
+        TS = int(os.environ.get("ELIMREC_SLAB_SEGT", T)) if tiered else T      # segment length of the rows above T2
+        nseg = np.where(deg[long_rows] > T2, (deg[long_rows] + TS - 1) // TS, 0) if tiered else (deg[long_rows] + T - 1) // T
         seg_ptr = np.concatenate([[0], np.cumsum(nseg)]).astype(np.int64)
         n_seg = int(seg_ptr[-1])
         seg_row = np.repeat(np.arange(len(long_rows)), nseg)
         k = np.arange(n_seg) - seg_ptr[seg_row]
-        seg_beg = rowptr[long_rows][seg_row] + k * T
-        seg_len = np.minimum(T, rowptr[long_rows + 1][seg_row] - seg_beg)
+        seg_beg = rowptr[long_rows][seg_row] + k * TS
+        seg_len = np.minimum(TS, rowptr[long_rows + 1][seg_row] - seg_beg)
         # heavy first, inside each kind
         so = np.argsort(-seg_len, kind="stable")
         if phase is not None:        # explicit processing phases of the unsplit rows (int per row), by decreasing length inside
