@@ -32,23 +32,36 @@ __device__ __forceinline__ float row16_sum(float v) {      // fixed order: ((a+b
     return v + dpp_f<0x140>(v);
 }
 
-// Evaluation math (elimrec_score_set_math): EXACT = the expressions above with IEEE division and libm expf/logf -- scores
-// equal to the reference's to a few ulp, about 196 VALU instructions per (user, item) pair, which is what bounds the
-// scorer (51 % VALU-issue busy against 29 % MFMA busy). FAST = v_exp_f32 / v_log_f32 / v_rcp_f32 (1 ulp each) and
-// reciprocal norms: about a quarter of the instructions, scores within 2e-6 of EXACT (tests/test_hip_parity.py), top-K
-// indices equal except where two scores differ by less than that.
+// Evaluation math (elimrec_score_set_math). EXACT (0) = the expressions above with IEEE division and libm expf -- about 196
+// VALU instructions per (user, item) pair, which is what bounds the scorer (58 % VALU-issue busy against 31 % MFMA busy).
+// FAST (1, the default) = sigmoids through v_exp_f32 with a two-float argument product and v_rcp_f32 + one Newton step, and
+// reciprocal norms refined the same way: every factor within ~2 ulp of the EXACT form, scores within 1.2e-7 absolute
+// (tools/eval_math_accuracy.py, tests/test_hip_parity.py), a validation pass 0.027 s against 0.033. libm's expf is itself
+// a <= 1 ulp approximation and not the one the reference's torch build uses, so neither mode is "the" reference bit
+// pattern; both sit inside the 1e-5 the predict parity tests allow by two orders of magnitude.
+// 1 / d to <= 1 ulp: v_rcp_f32 + one Newton step
+__device__ __forceinline__ float rcp_nr(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(fmaf(-d, r, 1.f), r, r);
+}
+// exp(-x) through v_exp_f32 with the product x * log2(e) carried in two floats: the rounding of the product would
+// otherwise cost |x| * 2^-24 relative (the 2e-6 of the first FAST form at |x| ~ 16); with the residual applied as
+// 2^err = 1 + err * ln 2 the result is within ~2 ulp of libm's for |x| < 80
+__device__ __forceinline__ float exp_neg_(float x) {
+    const float c_hi = 1.44269502162933349609375f, c_lo = 1.92596299112661746e-8f;   // log2(e) = c_hi + c_lo
+    const float xc = fminf(fmaxf(x, -88.f), 100.f);        // exp stays finite: sigmoid saturates to 2.7e-39 / 1 beyond
+    const float t = -xc * c_hi;
+    const float err = fmaf(-xc, c_lo, fmaf(-xc, c_hi, -t));
+    const float e = __builtin_amdgcn_exp2f(t);
+    return fmaf(e * err, 0.693147180559945309f, e);
+}
 template <bool FAST> __device__ __forceinline__ float sig_(float x) {
-    if (FAST) return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
+    if (FAST) return rcp_nr(1.f + exp_neg_(x));
     return sigmoidf_(x);
 }
-template <bool FAST> __device__ __forceinline__ float log_(float x) {
-    if (FAST) return __builtin_amdgcn_logf(x) * 0.693147180559945309f;
-    return logf(x);
-}
-template <bool FAST> __device__ __forceinline__ float log1p_(float x) {
-    if (FAST) return __builtin_amdgcn_logf(1.f + x) * 0.693147180559945309f;
-    return log1pf(x);
-}
+// (the logarithms of the 'hm' / 'sum' fusions are libm's in both modes: v_log_f32 costs 7e-7 relative there)
+template <bool FAST> __device__ __forceinline__ float log_(float x) { return logf(x); }
+template <bool FAST> __device__ __forceinline__ float log1p_(float x) { return log1pf(x); }
 
 template <bool FAST>
 __device__ __forceinline__ float fuse_t(int mode, float x, const float *z, int S, uint32_t mask) {
@@ -491,7 +504,7 @@ __global__ __launch_bounds__(512, (D > 64 ? 2 : 4)) void score_t16_kernel(ScoreA
         const int64_t un = b < a.B ? a.users[b] : -1;
         for (int h = 0; h + 1 < NB; ++h) {
             const float nrm = (un >= 0 && ptype != 0) ? fmaxf(sqrtf(a.sqn[un * NB + 1 + h]), eps) : 1.f;
-            unorm[tid * (NB - 1) + h] = FAST ? __builtin_amdgcn_rcpf(nrm) : nrm;       // FAST: reciprocal norms
+            unorm[tid * (NB - 1) + h] = FAST ? rcp_nr(nrm) : nrm;                      // FAST: reciprocal norms
         }
         umean[tid] = (b < a.B && ptype == 2) ? a.row_mean[b] : 0.f;
     }
@@ -569,7 +582,7 @@ __global__ __launch_bounds__(512, (D > 64 ? 2 : 4)) void score_t16_kernel(ScoreA
 #pragma unroll
                 for (int h = 0; h + 1 < NB; ++h) {
                     inorm[h] = (item_ok && ptype != 0) ? fmaxf(sqrtf(sq_cur[sub * (NB - 1) + h]), eps) : 1.f;
-                    if (FAST) inorm[h] = __builtin_amdgcn_rcpf(inorm[h]);
+                    if (FAST) inorm[h] = rcp_nr(inorm[h]);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -998,7 +1011,7 @@ static int g_score_math = -1;
 static int score_math() {
     if (g_score_math < 0) {
         const char *e = getenv("ELIMREC_EVAL_MATH");
-        g_score_math = (e && (e[0] == 'f' || e[0] == '1')) ? 1 : 0;
+        g_score_math = (e && (e[0] == 'e' || e[0] == '0')) ? 0 : 1;      // "exact" / "0": IEEE division + libm expf
     }
     return g_score_math;
 }

@@ -1,5 +1,6 @@
 """Parity of the HIP path (through the C ABI) against the golden vectors captured from the
 reference and against the CPU oracle on seeded inputs. Needs a real MI355X: `-m gpu`."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -1098,15 +1099,19 @@ def test_tile_guided_topk_at_recdim_64(with_scores, d, I):
 
 @pytest.mark.gpu
 def test_fast_evaluation_math_is_close_and_ranks_alike():
-    """elimrec_score_set_math(1): v_exp / v_rcp sigmoids and reciprocal norms. Scores within 2e-6 of the EXACT mode in
-    all three fusion modes; top-K lists differ only where two EXACT scores are closer than that."""
+    """elimrec_score_set_math(1), the default: sigmoids through v_exp_f32 (two-float argument product) and v_rcp_f32 + one
+    Newton step, reciprocal norms. Scores within 4e-7 of the EXACT mode (IEEE division, libm expf) in all three fusion
+    modes; top-K lists differ only where two EXACT scores are closer than that."""
     from elimrec_amd import _lib, ops
     lib = _lib.load()
     U, I, d, S, K = 130, 4000, 64, 3, 20
     g = torch.Generator().manual_seed(9)
     Y = (torch.randn(U + I, (1 + S) * d, generator=g) * 0.4).to(DEV)
+    Y[U:U + 40] *= 6.0                              # dot products beyond +-88: the saturated ends of the sigmoid
     users = torch.arange(0, 128).to(DEV)
     ws = torch.empty(ops.score_workspace(128, U, I, S, K), dtype=torch.uint8, device=DEV)
+    before = int(lib.elimrec_score_get_math())
+    assert before == 1 or os.environ.get("ELIMREC_EVAL_MATH", "")[:1] in ("e", "0")
     try:
         for mode in ("rubi", "hm", "sum"):
             for ptype in ("normal", "TE", "TIE"):
@@ -1118,12 +1123,12 @@ def test_fast_evaluation_math_is_close_and_ranks_alike():
                     ops.score_topk(Y, U, I, users, d, S, 0b111, mode, ptype, ws, scores=sc, K=K, topk_idx=idx)
                     out[fast] = (sc.cpu().numpy(), idx.cpu().numpy())
                 e, f = out[0][0], out[1][0]
-                assert np.abs(e - f).max() < 2e-6, (mode, ptype, np.abs(e - f).max())
+                assert np.isfinite(f).all() and np.abs(e - f).max() < 4e-7, (mode, ptype, np.abs(e - f).max())
                 for r in np.nonzero((out[0][1] != out[1][1]).any(1))[0]:
                     a, b = out[0][1][r], out[1][1][r]
-                    assert np.abs(e[r][a] - e[r][b]).max() < 4e-6, (mode, ptype, r)
+                    assert np.abs(e[r][a] - e[r][b]).max() < 8e-7, (mode, ptype, r)
     finally:
-        lib.elimrec_score_set_math(0)
+        lib.elimrec_score_set_math(before)
 
 
 @pytest.mark.gpu
