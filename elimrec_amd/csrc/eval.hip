@@ -33,7 +33,8 @@ __device__ __forceinline__ float row16_sum(float v) {      // fixed order: ((a+b
 }
 
 // Evaluation math (elimrec_score_set_math). EXACT (0) = the expressions above with IEEE division and libm expf -- about 196
-// VALU instructions per (user, item) pair, which is what bounds the scorer (58 % VALU-issue busy against 31 % MFMA busy).
+// VALU instructions per (user, item) pair, which is what bounds the scorer then (58 % VALU-issue busy against 31 % MFMA busy;
+// FAST: 47 % against 40 %).
 // FAST (1, the default) = sigmoids through v_exp_f32 with a two-float argument product and v_rcp_f32 + one Newton step, and
 // reciprocal norms refined the same way: every factor within ~2 ulp of the EXACT form, scores within 1.2e-7 absolute
 // (tools/eval_math_accuracy.py, tests/test_hip_parity.py), a validation pass 0.027 s against 0.033. libm's expf is itself
