@@ -139,6 +139,10 @@ class ColumnShardTrainer(object):
         eng, W, ph = self.engine, self.world, self._ph
         if self.profile_kernels and getattr(eng, "kernel_events", None) is None:
             eng.kernel_events = self._events
+        # one rank: the hops go to the GPU before the plan's host work (they do not need it; the plan runs on a second stream)
+        early = self._hip_engine and not self.multi and eng.cs_fork()
+        if early:
+            ph["cs_forward_hops"]()
         act = ph["cs_plan"](users, pos, neg)                       # int32 [R]: sorted unique node ids, negative padding
         h_ids = None
         if self.multi:
@@ -148,7 +152,8 @@ class ColumnShardTrainer(object):
             self.xgmi_bytes["all_gather"] = act.numel() * 4 * (W - 1)
         else:
             acts = act.view(1, -1)
-        ph["cs_forward_hops"]()                                    # hops 1..L-1 of my column slice: no communication
+        if not early:
+            ph["cs_forward_hops"]()                                # hops 1..L-1 of my column slice: no communication
         if h_ids is not None:
             h_ids.wait()
         send = ph["cs_forward_rows"](acts)                         # [W, R, 2*dl]: layer means of the peers' rows, my columns
@@ -232,6 +237,8 @@ class ColumnShardEngine(object):
         self.world, self.rank, self.opt = world, rank, optimizer
         import os
         self.multi = world > 1 or os.environ.get("ELIMREC_SHARD_MULTI", "0") == "1"
+        self._forked = False
+        self._early_hops = os.environ.get("ELIMREC_EARLY_HOPS", "1") != "0"
         self._late_wait = os.environ.get("ELIMREC_LATE_WAIT", "1") != "0"
         self.dl, self.col0 = d // world, rank * (d // world)
         self.ns, self.w = slab.choose_slabs16(self.dl) if self.bf16 else slab.choose_slabs(self.dl, N)
@@ -448,13 +455,26 @@ class ColumnShardEngine(object):
         if aux is None:
             m._region("cs_plan", (m._ws_gen, users.data_ptr(), pos.data_ptr(), neg.data_ptr(), R), plan)
             return act
-        aux.wait_stream(torch.cuda.current_stream())              # the triplets, and last step's readers of the plan buffers
+        if not self._forked:
+            aux.wait_stream(torch.cuda.current_stream())          # the triplets, and last step's readers of the plan buffers
+        self._forked = False
         with torch.cuda.stream(aux):
             m._region("cs_plan", (m._ws_gen, users.data_ptr(), pos.data_ptr(), neg.data_ptr(), R), plan)
             if self._fused_head_ok():
                 m._region("cs_pack", (m._ws_gen, R), pack)
         self._aux_pending = True
         return act
+
+    def cs_fork(self):
+        """One rank with the second stream: order it behind what the main stream holds NOW, so that the caller can enqueue the
+        forward hops (which need nothing of the plan) before cs_plan's host work -- the GPU starts on the step at once.
+        Returns whether it did (then cs_plan does not fork again)."""
+        aux = self._aux_stream()
+        if aux is None or self.model._ws is None or not self._early_hops:
+            return False
+        aux.wait_stream(torch.cuda.current_stream())
+        self._forked = True
+        return True
 
     @torch.no_grad()
     def cs_forward_hops(self):
