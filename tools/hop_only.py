@@ -18,7 +18,6 @@ if os.environ.get("RELABEL") == "1":        # node ids = the plan's processing o
     inv = np.empty(N, np.int64); inv[order] = np.arange(N)
     adj = adj[order][:, order].tocsr()
     adj.sort_indices()
-    U = 0 if False else U    # (side_split below then no longer separates sides: pass None)
 phase, n_out = None, N
 if os.environ.get("SPLIT"):                 # user rows cut into K virtual rows by item range: what an L2-sized source window would cost
     import numpy as np, scipy.sparse as sp
