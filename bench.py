@@ -194,7 +194,7 @@ def main():
     # rank's column slice = one elimrec_slab_hop call (sell_hop_kernel + the split rows' sell_fixup_kernel), bracketed by
     # HIP events on the launch stream, alternating between two tables as the forward does
     tabs = [eng.master[eng.cur], eng.tmp[0], eng.tmp[1]]       # the adjoint's scratch tables are free between steps
-    n_launch = 40
+    n_launch = 100
 
     def hop_chain(n):
         src, dst = tabs[0], tabs[1]
@@ -342,7 +342,7 @@ def bf16_line(args, device, cfg, batches, torch, steps=30):
     dt = (time.perf_counter() - t0) / steps
     tabs = [eng.mirror[eng.cur], eng.tmp[0], eng.tmp[1]]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n_launch = 40
+    n_launch = 100
 
     def chain(n):
         src, dst = tabs[0], tabs[1]
