@@ -57,8 +57,8 @@ for name in ev:
         row["mfma_busy_frac"] = round(row["SQ_VALU_MFMA_BUSY_CYCLES_per_launch"] / 1024.0 / dur, 3)
         row["valu_issue_busy_frac"] = round(4 * row["SQ_ACTIVE_INST_VALU_per_launch"] / 1024.0 / dur, 3)
         out[name] = row
-json.dump({"note": "rocprofv3 --pmc passes over tools/eval_prof.py (3 TIE validation passes, 2048 users per launch, catalogue in "
-                   "16384-item chunks, EXACT math). mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 SEs); "
+json.dump({"note": "rocprofv3 --pmc passes over tools/eval_prof.py (3 TIE validation passes, 8192 users per launch, default math, catalogue in "
+                   "16384-item chunks). mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 SEs); "
                    "valu_issue_busy_frac = 4 x SQ_ACTIVE_INST_VALU (quad-cycles) / 1024 / the same duration. FETCH_SIZE doubled (gfx950).",
            "kernels": out}, open("profiles/r02_eval_pmc.json", "w"), indent=1)
 for k in ("propagation_hop_kernel", "propagation_hop_traffic_bytes", "propagation_hop_L2_hit_rate", "propagation_hop_TA_busy_frac",
