@@ -48,6 +48,9 @@ def _all_gather_parts(loc, world, group):
     return parts
 
 
+LOSS_RING = 1 << 16       # steps whose loss tensors stay valid (256 KB of device memory)
+
+
 def _once(fn):
     """Memoise a no-argument predicate per engine: the launch-form switches read the environment once, not every step."""
     key = "_once_" + fn.__name__
@@ -226,6 +229,8 @@ class ColumnShardEngine(object):
         self.model, self.group = model, group
         self.kernel_events = None
         self.world = None
+
+    loss_ring_len = LOSS_RING      # the loss tensor a step returns is overwritten that many steps later
 
     # ------------------------------------------------------------------ set-up
     def cs_setup(self, world, rank, optimizer):
@@ -586,12 +591,13 @@ class ColumnShardEngine(object):
                                     0 if self._out0_src is None else self._out0_src.data_ptr()), head)
         # the cosine-BPR rows and the batch loss in one launch (the workgroup that finishes last adds the loss rows in
         # elimrec_sum's order). Issued directly: the loss goes to the next slot of a ring, so that a caller holding the
-        # tensors of earlier steps (up to 64) does not see them change.
+        # tensors of earlier steps -- main.py stacks an epoch's losses before it copies them to the host -- does not see them
+        # change (LOSS_RING steps back; `loss_ring_len` lets a caller that keeps more clone them).
         if self._loss_ring is None:
-            self._loss_ring = torch.zeros(64, dtype=torch.float32, device=m._device())
+            self._loss_ring = torch.zeros(LOSS_RING, dtype=torch.float32, device=m._device())
             self._loss_ticket = torch.zeros(1, dtype=torch.int32, device=m._device())
         loss = self._loss_ring[self._loss_at]
-        self._loss_at = (self._loss_at + 1) % 64
+        self._loss_at = (self._loss_at + 1) % LOSS_RING
         ops.bpr_head_rows_sum(YAct, ws["slot_seg"][:3 * B], d, bw, ws["loss_rows"], ws["grad_rows"], loss, self._loss_ticket)
         m._publish_cache(ws["Y"], dirty=True)
         return loss

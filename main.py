@@ -147,7 +147,10 @@ class Net(object):
         tracker = Meter(name="MultiLoss(bpr)")
         tracker.reset()
         step = self.generic_step if self.trainer is None else self.trainer.step
-        on_device = torch.stack([step(users, pos, neg) for users, pos, neg in batches])
+        # the column-shard engine returns views into a ring of loss slots: an epoch longer than the ring keeps copies
+        ring = getattr(self.engine, "loss_ring_len", 0) if self.engine is not None else 0
+        keep = (lambda t: t.clone()) if ring and len(batches) >= ring else (lambda t: t)
+        on_device = torch.stack([keep(step(users, pos, neg)) for users, pos, neg in batches])
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(on_device, op=dist.ReduceOp.SUM)

@@ -544,6 +544,23 @@ def test_tiered_one_launch_hop(d, w, gs, bf16, ipw):
     assert ((lt - want[rows]).abs() <= 4e-6 * scale[rows] + 1e-6).all()
 
 
+def test_loss_tensors_of_an_epoch_stay_valid():
+    """main.py stacks the loss tensors of a whole epoch before one device->host copy: the tensors the trainer returned
+    hundreds of steps ago must still hold their step's loss (they are slots of a ring, shard.LOSS_RING long)."""
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
+    g = load_golden("ml3")
+    batches = [tuple(_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg")) for t in (1, 2, 3)]
+    runs = []
+    for keep in (True, False):
+        model, _ = build_model_from_fixture(g, DEV)
+        opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+        tr = ColumnShardTrainer(ColumnShardEngine(model), opt)
+        assert tr.engine.loss_ring_len >= 4096
+        out = [tr.step(*batches[i % 3]) for i in range(300)] if keep else [float(tr.step(*batches[i % 3])) for i in range(300)]
+        runs.append(torch.stack(out).cpu().tolist() if keep else out)
+    assert runs[0] == runs[1]
+
+
 @pytest.mark.parametrize("masked", [True, False])
 def test_weight_gradients_behind_a_hops_tiles(masked):
     """elimrec_slab_hop_bwd_w: the partial launch (phase 0) and the slab reduce (phase 1) of a weight-gradient batch as
