@@ -105,7 +105,7 @@ class UniEvaluator(object):
         at = lo
         mine = test_users[lo:hi]
         for k, batch_users in enumerate(DataIterator(mine, batch_size=self.block_users, shuffle=False, drop_last=False)):
-            key = (k, lo, hi) if cached else None
+            key = (k, lo, hi, self.block_users) if cached else None
             self.evaluate_batch(model, batch_users, cache_key=key, out=all_dev[at:at + len(batch_users)])
             at += len(batch_users)
         if sharded and reduce:
