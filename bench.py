@@ -122,6 +122,20 @@ def cpu_baseline(ds, model_cpu_state, cfg, batches, thread_counts=(8, 16, 32), t
                 ms_per_step=1e3 * mean)
 
 
+def spawn_ranks(n):
+    """python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same arguments>, as a child process."""
+    import socket
+    import subprocess
+    with socket.socket() as s:          # a free rendezvous port on the loop-back interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,16 +147,21 @@ def main():
     ap.add_argument("--no-bf16", action="store_true", help="skip the bf16-storage line")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # bare `python bench.py --gpus N`: start the N ranks ourselves, as CHILD processes of a parent that has not touched
+        # the GPU (nothing above imports torch), and leave with their exit code -- the same launch line the driver uses
+        raise SystemExit(spawn_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("ELIMREC_SAME_GPU") == "1":          # tools/two_ranks_one_gpu.py: every rank on device 0 (smoke test)
-        local_rank = 0
+    same_gpu = os.environ.get("ELIMREC_SAME_GPU") == "1"   # every rank on device 0 (one-GPU staging of the multi-rank job:
+    if same_gpu:                                           # RCCL refuses duplicate devices, so the group is gloo and the
+        local_rank = 0                                     # collectives are staged through the host, shard.py)
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs a torch.distributed.run launch with %d ranks (WORLD_SIZE=%d)"
-                         % (args.gpus, args.gpus, world))
+        raise SystemExit("--gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     torch.cuda.set_device(local_rank)
@@ -151,7 +170,10 @@ def main():
     if world > 1 or multi_path:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if same_gpu and world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     cfg, ds, model = build(args, device)
     init_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
@@ -172,9 +194,10 @@ def main():
     batches = [(U_[i * B:(i + 1) * B], P_[i * B:(i + 1) * B], N_[i * B:(i + 1) * B]) for i in range(total)]
 
     def sync():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     for i in range(args.warmup):
         trainer.step(*batches[i])
@@ -184,7 +207,7 @@ def main():
         loss = trainer.step(*batches[i])
     sync()
     dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    t = torch.tensor([dt], dtype=torch.float64, device="cpu" if (same_gpu and world > 1) else device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())

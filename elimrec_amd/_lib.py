@@ -149,6 +149,7 @@ SIGNATURES = {
     "elimrec_score_workspace": (c_size, [c_i32, c_i64, c_i32]),
     "elimrec_score_workspace2": (c_size, [c_i32, c_i64, c_i64, c_i32, c_i32]),
     "elimrec_score_workspace_topk": (c_size, [c_i32, c_i64, c_i64, c_i32, c_i32]),
+    "elimrec_score_workspace_for": (c_size, [c_i32, c_i64, c_i64, c_i32, c_i32, c_i32, c_i32]),
     "elimrec_row_sqnorms": (c_i32, [c_ptr, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr]),
     "elimrec_score_topk": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_i32, c_i32, c_i32, c_u32, c_i32, c_i32,
                                    c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),

@@ -1058,6 +1058,33 @@ extern "C" size_t elimrec_score_workspace_topk(int B, int64_t U, int64_t I, int 
     return score_layout(B, U, I, S, K, true).total;
 }
 
+// The ONE predicate for the chunked (top-K only, no [B x I] score block) form, shared by the sizing function below and by
+// elimrec_score_topk: the 16-user-per-wave scorer (recdim 32 / 64 / 128, 1..3 heads, MFMA + T16 forms enabled), K <= 256
+// (the tile-guided selection), more than one chunk, and per-chunk candidate lists that fit the merge kernel's LDS.
+constexpr size_t TOPK_MERGE_LDS_MAX = 160 * 1024;
+static bool score_env_flag(const char *name, char off, int *cache) {
+    if (*cache < 0) { const char *e = getenv(name); *cache = (e && e[0] == off) ? 0 : 1; }
+    return *cache != 0;
+}
+static bool score_uses_mfma() { static int c = -1; return score_env_flag("ELIMREC_SCORE_VALU", '1', &c); }
+static bool score_uses_t16() { static int c = -1; return score_env_flag("ELIMREC_SCORE_T16", '0', &c); }
+static bool score_uses_chunks() { static int c = -1; return score_env_flag("ELIMREC_SCORE_CHUNKED", '0', &c); }
+static bool score_t16_path(int d, int S) {
+    return score_uses_mfma() && score_uses_t16() && (d == 32 || d == 64 || d == 128) && S >= 1 && S <= 3;
+}
+static bool score_chunked_form(int d, int S, int K, int64_t I, bool want_scores, bool want_topk) {
+    const int64_t nch = (I + SCORE_CHUNK - 1) / SCORE_CHUNK;
+    return score_t16_path(d, S) && score_uses_chunks() && !want_scores && want_topk && K <= 256 && I > SCORE_CHUNK &&
+           (size_t)nch * (size_t)K * 8 <= TOPK_MERGE_LDS_MAX;
+}
+
+// Bytes elimrec_score_topk needs for THIS call shape: recdim d, K, and whether the caller passes a score matrix
+// (want_scores) -- the chunked layout exactly when the call will take the chunked form, the full [B x I] layout otherwise
+// (any recdim, any K: the reference accepts both, models/EliMRec.py:96-113, evaluator/backend/cpp/uni_evaluator.py:131).
+extern "C" size_t elimrec_score_workspace_for(int B, int64_t U, int64_t I, int S, int K, int d, int want_scores) {
+    return score_layout(B, U, I, S, K, score_chunked_form(d, S, K, I, want_scores != 0, K > 0)).total;
+}
+
 extern "C" int elimrec_row_sqnorms(const float *d_Y, int64_t ldy, int64_t n_rows, int d, int n_blocks, float *d_out,
                                    void *stream) {
     ELIMREC_REQUIRE(d_Y && d_out && d > 0 && d % 4 == 0 && n_blocks >= 1 && ldy % 4 == 0, "row_sqnorms: bad arguments");
@@ -1086,15 +1113,13 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
     ELIMREC_REQUIRE(d_scores || d_topk_idx, "score_topk: nothing to output");
     ELIMREC_REQUIRE(!d_topk_idx || (K > 0 && K <= I), "score_topk: need 0 < K <= I");
     if (B <= 0) return 0;
-    static int use_mfma = -1, use_resident = -1, use_t16 = -1, use_chunks = -1;
-    if (use_mfma < 0) { const char *e = getenv("ELIMREC_SCORE_VALU"); use_mfma = (e && e[0] == '1') ? 0 : 1; }
+    static int use_resident = -1;
     if (use_resident < 0) { const char *e = getenv("ELIMREC_SCORE_RESIDENT"); use_resident = (e && e[0] == '0') ? 0 : 1; }
-    if (use_t16 < 0) { const char *e = getenv("ELIMREC_SCORE_T16"); use_t16 = (e && e[0] == '0') ? 0 : 1; }
-    if (use_chunks < 0) { const char *e = getenv("ELIMREC_SCORE_CHUNKED"); use_chunks = (e && e[0] == '0') ? 0 : 1; }
-    const bool t16_path = use_mfma && use_t16 && (d == 32 || d == 64 || d == 128) && S >= 1 && S <= 3;
+    const bool use_mfma = score_uses_mfma();
+    const bool t16_path = score_t16_path(d, S);
     // only top-K wanted: no [B x I] score block -- the catalogue goes through the scorer in chunks (a workspace sized by
-    // elimrec_score_workspace_topk is enough; a larger one is accepted)
-    const bool chunked = t16_path && use_chunks && !d_scores && d_topk_idx && K <= 256 && I > SCORE_CHUNK;
+    // elimrec_score_workspace_for is enough; a larger one is accepted)
+    const bool chunked = score_chunked_form(d, S, K, I, d_scores != nullptr, d_topk_idx != nullptr);
     const ScoreLayout L = score_layout(B, U, I, S, K, chunked);
     if (workspace_bytes < L.total) {
         set_error("score_topk: workspace too small (%zu < %zu)", workspace_bytes, L.total);
@@ -1225,6 +1250,14 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
                                    tc, K, d_train_ptr, d_train_ptr ? (const uint32_t *)wbits : (const uint32_t *)nullptr, bits_ld,
                                    cand_idx, cand_val, fallback, ac.item0, (int64_t)nch * K, (int64_t)c * K);
                 ELIMREC_LAUNCH_CHECK("topk_tiles(chunk)");
+            }
+            if ((size_t)nch * K * 8 > 64 * 1024) {       // beyond the default dynamic-LDS limit (score_chunked_form bounds it)
+                static bool attr = false;
+                if (!attr) {
+                    (void)hipFuncSetAttribute((const void *)topk_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)TOPK_MERGE_LDS_MAX);
+                    attr = true;
+                }
             }
             hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(256), (size_t)nch * K * 8, s, (const float *)cand_val,
                                (const int32_t *)cand_idx, nch * K, K, d_topk_idx, d_topk_val);

@@ -99,6 +99,10 @@ class UniEvaluator(object):
             shard = (dist.get_rank(), dist.get_world_size())
         n = len(test_users)
         sharded = shard is not None and shard[1] > 1
+        if sharded and hasattr(model, "_ensure_tables"):
+            # every rank, before any rank can run out of users: materialising the cached tables of a multi-rank job is a
+            # collective (ColumnShardEngine.materialize_tables), and a rank with an empty slice would otherwise skip it
+            model._ensure_tables()
         lo, hi = (n * shard[0] // shard[1], n * (shard[0] + 1) // shard[1]) if sharded else (0, n)
         alloc = torch.zeros if sharded else torch.empty
         all_dev = alloc(n, self.metrics_num * self.max_top, dtype=torch.float32, device=model._require_gpu())

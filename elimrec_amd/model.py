@@ -333,14 +333,9 @@ class EliMRec(BasicModel):
             if self.dataset_name == "tiktok":
                 # :371-378: t_feat is the scatter-mean of word embeddings, built ONCE at init and
                 # never recomputed -> a constant, un-normalised [I x 128] table.
-                words = ds.words_tensor
                 self.word_embedding = nn.Embedding(11574, 128)
                 nn.init.xavier_normal_(self.word_embedding.weight)
-                emb = self.word_embedding.weight.detach()[words[1]]
-                rows = int(words[0].max()) + 1
-                tot = torch.zeros(rows, 128).index_add_(0, words[0], emb)
-                cnt = torch.zeros(rows).index_add_(0, words[0], torch.ones(words.shape[1])).clamp_(min=1)
-                self.register_buffer("t_feat", (tot / cnt[:, None]).contiguous(), persistent=False)
+                self.register_buffer("t_feat", self._word_bag_t_feat(), persistent=False)
             else:
                 self.register_buffer("t_feat", F.normalize(ds.t_feat.float(), dim=1).contiguous(), persistent=False)
         for m in self._mods:
@@ -358,6 +353,33 @@ class EliMRec(BasicModel):
         nn.init.xavier_uniform_(self.embedding_user_after_GCN.weight)
         self.embedding_item_after_GCN = nn.Linear(self.item_feat_dim, d)
         nn.init.xavier_uniform_(self.embedding_item_after_GCN.weight)
+
+    @torch.no_grad()
+    def _word_bag_t_feat(self):
+        """:371-378: scatter-mean of the word embeddings of every item's words -- [I x 128], not normalised."""
+        words = self.dataset.words_tensor
+        w = self.word_embedding.weight.detach()
+        idx0, idx1 = words[0].to(w.device), words[1].to(w.device)
+        rows = int(words[0].max()) + 1
+        tot = torch.zeros(rows, 128, device=w.device).index_add_(0, idx0, w[idx1])
+        cnt = torch.zeros(rows, device=w.device).index_add_(0, idx0, torch.ones(words.shape[1], device=w.device)).clamp_(min=1)
+        return (tot / cnt[:, None]).contiguous()
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        """nn.Module.load_state_dict + what depends on the loaded tensors without being a checkpoint key: on the tiktok
+        data set t_feat is built from word_embedding (:371-378) and the folded constant S_t from t_feat, so both are
+        rebuilt from the LOADED word_embedding -- a resume under another seed scores with the features its weights were
+        trained with."""
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        if self.dataset_name == "tiktok" and hasattr(self, "word_embedding") and "feature_modalities" not in self.config:
+            self.t_feat.copy_(self._word_bag_t_feat().to(self.t_feat.device))
+            if self._ws is not None and "fold" in self._ws:
+                self._fold_constants(self._ws)
+                self._regions = {}            # recorded launches hold the old constants' addresses
+                eng = self.__dict__.get("_slab_engine")
+                if eng is not None and getattr(eng, "_on_constants_changed", None):
+                    eng._on_constants_changed()
+        return out
 
     # ------------------------------------------------------------------ device workspace
     def _device(self):
@@ -1107,7 +1129,7 @@ class EliMRec(BasicModel):
         # top-K only (the evaluator): no [B x I] score block in the workspace, the catalogue is scored in chunks
         import os
         chunked = scores is None and top_k > 0 and os.environ.get("ELIMREC_SCORE_CHUNKED", "1") != "0"
-        need = ops.score_workspace(B, self.num_users, I, self.S, max(top_k, 1), topk_only=chunked)
+        need = ops.score_workspace(B, self.num_users, I, self.S, max(top_k, 1), topk_only=chunked, d=self.latent_dim)
         if self._ws.get("score_ws") is None or self._ws["score_ws"].numel() < need:
             self._ws["score_ws"] = torch.empty(need, dtype=torch.uint8, device=dev)
         idx = val = None

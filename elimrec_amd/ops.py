@@ -645,9 +645,12 @@ def adam_step_raw(p_ptr, g_ptr, m_ptr, v_ptr, n, lr, beta1, beta2, eps, weight_d
                                              float(eps), float(weight_decay), int(step), _stream()), "adam_step")
 
 
-def score_workspace(B, U, I, S, K, topk_only=False):
-    """Bytes of score_topk's workspace. topk_only: the call will ask for top-K lists only (no score matrix) -- no
-    [B x I] block, the catalogue is scored in chunks."""
+def score_workspace(B, U, I, S, K, topk_only=False, d=None):
+    """Bytes of score_topk's workspace. topk_only: the call will ask for top-K lists only (no score matrix); with the
+    recdim `d` given the library itself decides whether that call takes the chunked form (no [B x I] block) and returns
+    the layout it will use -- the full one for a recdim / K / scorer switch outside the chunked form's range."""
+    if topk_only and d is not None:
+        return int(_lib.load().elimrec_score_workspace_for(B, U, I, S, K, int(d), 0))
     if topk_only:
         return int(_lib.load().elimrec_score_workspace_topk(B, U, I, S, K))
     return int(_lib.load().elimrec_score_workspace2(B, U, I, S, K))

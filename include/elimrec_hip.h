@@ -452,7 +452,11 @@ size_t elimrec_score_workspace2(int B, int64_t U, int64_t I, int S, int K);
 /* Workspace when ONLY top-K is requested (d_scores == NULL, K <= 256, recdim 32 / 64 / 128): no [B x I] score block -- the
  * catalogue goes through the scorer 16384 items at a time, every chunk leaves its K best (id, score) pairs per user and a
  * last launch merges them (same list as the whole-catalogue selection). */
-size_t elimrec_score_workspace_topk(int B, int64_t U, int64_t I, int S, int K);   /* what score_topk needs */
+size_t elimrec_score_workspace_topk(int B, int64_t U, int64_t I, int S, int K);   /* the chunked layout itself */
+/* What elimrec_score_topk needs for THIS call shape (recdim d, K, score matrix asked for or not): the chunked layout exactly
+ * when the call takes the chunked form, else the full [B x I] layout -- one predicate inside the library decides both, so
+ * any recdim and any K the reference accepts (models/EliMRec.py:96-113) get a workspace that fits. */
+size_t elimrec_score_workspace_for(int B, int64_t U, int64_t I, int S, int K, int d, int want_scores);
 /* Evaluation math of the scorer: 0 = EXACT (IEEE division, libm expf), 1 = FAST (default: sigmoids through v_exp_f32 with
  * a two-float argument product and v_rcp_f32 + one Newton step, reciprocal norms refined the same way -- every factor
  * within ~2 ulp of the EXACT form, scores within 1.2e-7 absolute, a validation pass 19 % shorter). Both are within 1e-6 of

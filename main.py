@@ -16,7 +16,7 @@ generic losses) runs loss -> backward -> optimizer step through the differentiab
 checkpoint and, when the side file `<checkpoint>.resume` written next to it exists, the Adam moments, step counts,
 epoch counter and best metrics.
 
-Multi-GPU: launch with torch.distributed.run, one process per GPU. Every rank owns recdim/world columns of the
+Multi-GPU: `--gpus=N` (starts N ranks itself) or a torch.distributed.run launch, one process per GPU. Every rank owns recdim/world columns of the
 embedding tables (elimrec_amd/shard.py); an epoch is split over the ranks -- each draws 1/world of the epoch's
 triplets in batches of batch_size/world, so the global batch, the number of optimizer steps per epoch and the
 learning-rate schedule are those of the single-GPU (and the reference's) configuration; the logged loss is the mean
@@ -120,7 +120,7 @@ class Net(object):
             self.engine.load_from_model()
         side = path + ".resume"
         if os.path.exists(side):
-            extra = torch.load(side, map_location="cpu", weights_only=False)
+            extra = torch.load(side, map_location="cpu", weights_only=True)     # tensors, numbers, strings, dicts only
             rec._workspace(1)                                  # parameters move into the flat buffers before the moments
             self.opt.import_state(rec.named_parameters(), extra["adam"])
             if self.engine is not None and extra.get("embedding_adam") is not None:
@@ -157,6 +157,9 @@ class Net(object):
             on_device /= self.world
         for value in on_device.cpu().tolist():
             tracker.update(val=value)
+        if self.world > 1:       # every rank sees a bad index of any rank: all raise together, none is left in a collective
+            import torch.distributed as dist
+            dist.all_reduce(self.recommender._index_err(), op=dist.ReduceOp.MAX)
         self.recommender.check_indices()
         return tracker.avg
 
@@ -239,5 +242,18 @@ if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))
     os.chdir(here)
     config = Configurator(os.path.join(here, "NeuRec.properties"), default_section="hyperparameters")
+    if "gpus" in config and int(config["gpus"]) > 1 and "WORLD_SIZE" not in os.environ:
+        # --gpus=N from a bare shell: start one rank per GPU as child processes (this parent has not touched the GPU)
+        import socket
+        import subprocess
+        import sys
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        raise SystemExit(subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node",
+                                          str(int(config["gpus"])), "--master-addr", "127.0.0.1", "--master-port", str(port),
+                                          os.path.abspath(__file__)] + sys.argv[1:], env=env))
     set_seed(config["seed"])
     Net(config).run()

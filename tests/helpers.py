@@ -37,6 +37,29 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
+def row_err(a, b, rel=1e-4, floor=1e-7):
+    """Row-wise criterion for gradient tables: max over rows r of
+    ||a_r - b_r||_2 / (rel * ||b_r||_2 + floor * max_r ||b_r||_2). A value <= 1 means every row -- the hot items' and the
+    rows a batch touched once alike -- is within `rel` of the reference's row (plus a floor of `floor` x the largest row
+    norm for rows that are zero or pure round-off in the reference). 1-D tensors count as one row."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    if a.ndim < 2:
+        a, b = a.reshape(1, -1), b.reshape(1, -1)
+    a, b = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    nb = np.sqrt((b * b).sum(1))
+    nd = np.sqrt(((a - b) ** 2).sum(1))
+    return float((nd / (rel * nb + floor * nb.max() + 1e-300)).max())
+
+
+def assert_grad_close(mine, want, what, rel=1e-4):
+    """North-star tolerance on a gradient tensor, max-norm AND row by row."""
+    e = rel_err(mine, want)
+    assert e < rel, (what, "max-norm rel err", e)
+    r = row_err(mine, want, rel=rel)
+    assert r <= 1.0, (what, "row-wise err / tolerance", r)
+
+
 # --------------------------------------------------------------------------- product-side builders
 def make_config(argv_extra=()):
     """The real Configurator over the repo's NeuRec.properties / conf/EliMRec.properties."""

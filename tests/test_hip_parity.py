@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import build_model_from_fixture, csr_dict, load_golden, rel_err, sub
+from helpers import assert_grad_close, build_model_from_fixture, csr_dict, load_golden, rel_err, sub
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -17,6 +17,18 @@ def _t(a, dtype=None):
 
 
 # ----------------------------------------------------------------------------- golden fixtures
+@pytest.fixture(params=["exact", "fast"])
+def eval_math(request):
+    """Both evaluator math modes explicitly (elimrec_score_set_math): EXACT = IEEE division + libm expf; FAST (the default)
+    = v_exp_f32 / v_rcp_f32 + Newton step, every score within 1.2e-7 of EXACT."""
+    from elimrec_amd import _lib
+    lib = _lib.load()
+    before = int(lib.elimrec_score_get_math())
+    lib.elimrec_score_set_math(0 if request.param == "exact" else 1)
+    yield request.param
+    lib.elimrec_score_set_math(before)
+
+
 def test_training_steps_match_reference(fixture_name):
     """loss to 1e-5 abs, every parameter gradient to 1e-4 rel (north_star tolerance), the same
     set of parameters receives a gradient, parameters after Adam steps to 2e-5 abs."""
@@ -38,7 +50,7 @@ def test_training_steps_match_reference(fixture_name):
             mine = {k: p_.grad for k, p_ in model.named_parameters() if p_.grad is not None}
             assert set(mine) == set(ref)
             for k, gr in ref.items():
-                assert rel_err(mine[k].cpu(), gr) < 1e-4, k
+                assert_grad_close(mine[k].cpu(), gr, k)
         opt.step()
         if t in (1, steps):
             sd = model.state_dict()
@@ -77,7 +89,7 @@ def _load_cache(model, g):
     model._publish_cache(Y)
 
 
-def test_predict_modes_match_reference(fixture_name):
+def test_predict_modes_match_reference(fixture_name, eval_math):
     g = load_golden(fixture_name)
     model, _ = build_model_from_fixture(g, DEV)
     _load_cache(model, g)
@@ -192,15 +204,16 @@ def _ulps(a, b):
     return np.abs(a - b)
 
 
-def test_device_evaluator_matches_reference(fixture_name):
+def test_device_evaluator_matches_reference(fixture_name, eval_math):
     """SURVEY section 7 (ii), judged on the REFERENCE's scores (the fixture's masked score matrix of the whole test split):
       * rank by rank, the item the device puts at rank k has the same reference score as the item the reference puts
         there -- asserted for every row whose device scores equal the reference's bit for bit at those items;
       * rows without a tie at or across K: the device indices ARE the reference indices. Where they are not, the cause
         must be a device/reference score difference of a few ulp between two near-equal (not equal) scores: each such
         row is checked for exactly that and their number is bounded;
-      * evaluate(): equal (1e-7) to the metrics recomputed from the reference scores under the device's tie rule (score
-        desc, item id asc), up to the rows whose order an ulp moved -- none on most fixtures."""
+      * evaluate(): equal to 1e-7, no slack, to the metrics the oracle's metric port computes from the device's ranking --
+        the ranking verified row by row above; and that ranking IS the reference scores' ranking under the device's tie
+        rule (score desc, item id asc) except on the counted rows where a <= 4-ulp score difference moved two items."""
     from oracle import eval_oracle as ev
     g = load_golden(fixture_name)
     model, _ = build_model_from_fixture(g, DEV)
@@ -249,14 +262,14 @@ def test_device_evaluator_matches_reference(fixture_name):
     moved = int((idx != mine_topk).any(1).sum())
     for r in np.nonzero((idx != mine_topk).any(1))[0]:
         assert _ulps(ref_scores[r][idx[r]], ref_scores[r][mine_topk[r]]).max() <= 4, r
-    per_user = ev.metrics_from_rank(mine_topk, tp, ti, mids, K)
+    assert moved <= max(1, len(users) // 20), moved
     n_metrics = len(mids)
-    expect = per_user.mean(0).reshape(n_metrics, K)[:, evalr.top_show - 1].reshape(-1)
+    mean_of = lambda topk: ev.metrics_from_rank(topk, tp, ti, mids, K).mean(0).reshape(n_metrics, K)[:, evalr.top_show - 1].reshape(-1)
     res, buf = model.test()
     assert res.dtype == np.float32 and res.shape == (3,) and len(buf.split("\t")) == 3
-    assert np.abs(res - expect).max() <= 1e-7 + moved / len(users), (res, expect, moved)
+    assert np.abs(res - mean_of(idx)).max() <= 1e-7, (res, mean_of(idx))
     if moved == 0:
-        assert np.abs(res - expect).max() <= 1e-7
+        assert np.abs(res - mean_of(mine_topk)).max() <= 1e-7
     # TE: scores from the oracle (pinned to the reference's predict() to 2e-6), same recomputation
     from oracle import elimrec_oracle as eo
     from helpers import feats_of
@@ -276,9 +289,11 @@ def test_device_evaluator_matches_reference(fixture_name):
     te_moved = int((te_idx != te_topk).any(1).sum())
     for r in np.nonzero((te_idx != te_topk).any(1))[0]:
         assert np.abs(te[r][te_idx[r]] - te[r][te_topk[r]]).max() < 4e-6, r       # oracle scores are 2e-6 from the reference's
-    expect = ev.metrics_from_rank(te_topk, tp, ti, mids, K).mean(0).reshape(n_metrics, K)[:, evalr.top_show - 1].reshape(-1)
+    assert te_moved <= max(1, len(users) // 20), te_moved
     res, _ = model.test()
-    assert np.abs(res - expect).max() <= 1e-7 + te_moved / len(users)
+    assert np.abs(res - mean_of(te_idx)).max() <= 1e-7
+    if te_moved == 0:
+        assert np.abs(res - mean_of(te_topk)).max() <= 1e-7
     # and the reference's own reported numbers differ from ours only through its heap tie order
     ref_per_user = ev.metrics_from_rank(ref_topk, tp, ti, mids, K).mean(0).reshape(n_metrics, K)[:, evalr.top_show - 1].reshape(-1)
     assert np.abs(ref_per_user - g["evaluate/TIE/test"]).max() < 1e-7
@@ -820,7 +835,7 @@ def test_model_paths_agree_on_gcmc_adjacency():
         assert abs(res[mode][0] - float(ol)) < 1e-5
         assert set(res[mode][1]) == set(om.grads())
         for k, v in om.grads().items():
-            assert rel_err(res[mode][1][k], v) < 1e-4, (mode, k)
+            assert_grad_close(res[mode][1][k], v, (mode, k))
 
 
 # ----------------------------------------------------------------------------- BASELINE.json shapes
@@ -859,7 +874,7 @@ def _full_shape_step(U, I, E, dims, recdim, B, dataset_name, extra_argv=()):
     want = om.grads()
     assert set(mine) == set(want)
     for k, v in want.items():
-        assert rel_err(mine[k], v) < 1e-4, k
+        assert_grad_close(mine[k], v, k)
     return model, om
 
 
@@ -976,7 +991,7 @@ def test_kwai_shape_v_plus_t_variant_vs_oracle():
     mine = {k: q.grad.cpu() for k, q in model.named_parameters() if q.grad is not None}
     assert set(mine) == set(om.grads())
     for k, v in om.grads().items():
-        assert rel_err(mine[k], v) < 1e-4, k
+        assert_grad_close(mine[k], v, k)
     users = list(range(0, U, 111))[:48]
     for ptype in ("TE", "TIE"):
         model.predict_type = om.predict_type = ptype
@@ -1163,3 +1178,36 @@ def test_rank_sharded_evaluation_equals_one_process():
         assert torch.equal(sum(parts[1:], parts[0]), whole), W
     res, buf = evalr.evaluate(model)
     assert np.array_equal(res, np.mean(whole.cpu().numpy(), axis=0).reshape(evalr.metrics_num, evalr.max_top)[:, evalr.top_show - 1].reshape(-1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,K", [(48, 10), (64, 300), (256, 10), (64, 10)])
+def test_topk_only_workspace_fits_any_recdim_and_k(d, K):
+    """top-K only at I > 16384 with a recdim outside the 16-user-per-wave scorer's set (48, 256) or
+    K > 256 takes the whole-catalogue form; ops.score_workspace(..., topk_only=True, d=d) asks the library's own predicate
+    and returns a workspace that fits (the reference accepts any recdim and any K, models/EliMRec.py:96-113). The lists
+    equal a stable sort of the full masked score matrix."""
+    from elimrec_amd import ops
+    U, I, S = 40, 20000, 3
+    g = torch.Generator().manual_seed(d + K)
+    Y = (torch.randn(U + I, (1 + S) * d, generator=g) * 0.3).to(DEV)
+    users = torch.arange(0, 33).to(DEV)
+    B = 33
+    ptr = torch.zeros(B + 1, dtype=torch.int64)
+    masked = torch.tensor([5, 17, 19999, 1024], dtype=torch.int32)
+    ptr[4:] = len(masked)
+    ref = torch.empty(B, I, device=DEV)
+    ws = torch.empty(ops.score_workspace(B, U, I, S, K), dtype=torch.uint8, device=DEV)
+    ops.score_topk(Y, U, I, users, d, S, 0b111, "rubi", "TIE", ws, scores=ref, train_ptr=ptr.to(DEV), train_items=masked.to(DEV))
+    sc = ref.cpu().numpy()
+    need = ops.score_workspace(B, U, I, S, K, topk_only=True, d=d)
+    chunked_bytes = ops.score_workspace(B, U, I, S, K, topk_only=True)
+    assert (need == chunked_bytes) == (d in (32, 64, 128) and K <= 256)
+    ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+    idx = torch.empty(B, K, dtype=torch.int32, device=DEV)
+    val = torch.empty(B, K, device=DEV)
+    ops.score_topk(Y, U, I, users, d, S, 0b111, "rubi", "TIE", ws, K=K, topk_idx=idx, topk_val=val, train_ptr=ptr.to(DEV),
+                   train_items=masked.to(DEV))
+    order = np.argsort(-sc, axis=1, kind="stable")[:, :K]
+    assert np.array_equal(idx.cpu().numpy(), order)
+    assert np.array_equal(val.cpu().numpy(), np.take_along_axis(sc, order, 1))
