@@ -74,15 +74,20 @@ class OracleEliMRec:
 
     def __init__(self, num_users, num_items, recdim, layer_num, adj, feats, params, alpha,
                  dataset_name="movielens", modality="vat", mm_fusion_mode="concat",
-                 fusion_mode="rubi", predict_type="TIE", mods=None):
+                 fusion_mode="rubi", predict_type="TIE", mods=None, dtype=torch.float32):
+        """dtype: torch.float32 is the reference's arithmetic (and what every fixture pins). torch.float64 evaluates the
+        SAME formulas on the same fp32 inputs in double precision: the tests use it to tell a row where the fp32 reference
+        itself is off by more than the tolerance (cancellation) from a row where the HIP path is."""
         self.U, self.I, self.d, self.L = int(num_users), int(num_items), int(recdim), int(layer_num)
         self.adj = adj if isinstance(adj, torch.Tensor) else adj_to_torch(adj)
+        if dtype != torch.float32:
+            self.adj = self.adj.to(dtype)
         self.kwai = dataset_name == "kwai"              # EliMRec.py:133,148,158,234,254,261
         # `mods`: NOT in the reference (it hard-codes V for kwai, V,A,T otherwise). A generalisation used only
         # for BASELINE.json's "V+T" Kwai-shape case; parity for it is unpinned (no reference run exists).
         self.mods = list(mods) if mods is not None else (["v"] if self.kwai else ["v", "a", "t"])
-        self.feats = {k: torch.as_tensor(v, dtype=torch.float32) for k, v in feats.items()}
-        self.params = {k: torch.as_tensor(np.array(v), dtype=torch.float32).clone().requires_grad_(True)
+        self.feats = {k: torch.as_tensor(v, dtype=torch.float32).to(dtype) for k, v in feats.items()}
+        self.params = {k: torch.as_tensor(np.array(v), dtype=torch.float32).to(dtype).clone().requires_grad_(True)
                        for k, v in params.items()}
         self.alpha = float(alpha)
         self.modality = "v" if self.kwai else modality  # EliMRec.py:133-134

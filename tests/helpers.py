@@ -52,11 +52,18 @@ def row_err(a, b, rel=1e-4, floor=1e-7):
     return float((nd / (rel * nb + floor * nb.max() + 1e-300)).max())
 
 
-def assert_grad_close(mine, want, what, rel=1e-4):
-    """North-star tolerance on a gradient tensor, max-norm AND row by row."""
+def assert_grad_close(mine, want, what, rel=1e-4, truth=None):
+    """North-star tolerance on a gradient tensor, max-norm AND row by row against the reference arithmetic (fp32 oracle /
+    fixture). `truth` (optional): the same gradient from the oracle evaluated in fp64. A row that misses the row-wise
+    tolerance against `want` passes only if the fp32 reference ITSELF is that far from the exact value there (a sum
+    that cancels) and the HIP result is no further from the exact value than twice the reference is."""
     e = rel_err(mine, want)
     assert e < rel, (what, "max-norm rel err", e)
     r = row_err(mine, want, rel=rel)
+    if r > 1.0 and truth is not None:
+        r_ref, r_mine = row_err(want, truth, rel=rel), row_err(mine, truth, rel=rel)
+        assert r_mine <= max(1.0, 2.0 * r_ref), (what, "row-wise err / tolerance vs fp64", r_mine, "reference's own", r_ref)
+        return
     assert r <= 1.0, (what, "row-wise err / tolerance", r)
 
 

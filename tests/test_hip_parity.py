@@ -873,8 +873,14 @@ def _full_shape_step(U, I, E, dims, recdim, B, dataset_name, extra_argv=()):
     mine = {k: q.grad.cpu() for k, q in model.named_parameters() if q.grad is not None}
     want = om.grads()
     assert set(mine) == set(want)
+    truth = None
+    if U * recdim <= 1 << 20:       # small shapes: the same step in fp64, the arbiter of rows where fp32 sums cancel
+        om64 = eo.OracleEliMRec(U, I, recdim, cfg["layer_num"], adj, feats, init, cfg["alpha"], dataset_name=dataset_name,
+                                dtype=torch.float64)
+        om64.bpr_loss(u, p, n).backward()
+        truth = om64.grads()
     for k, v in want.items():
-        assert_grad_close(mine[k], v, k)
+        assert_grad_close(mine[k], v, k, truth=None if truth is None else truth[k])
     return model, om
 
 
