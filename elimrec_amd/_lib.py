@@ -190,6 +190,11 @@ SIGNATURES = {
     "elimrec_build_adj": (c_i32, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size,
                                   c_ptr]),
     "elimrec_adam_multi": (c_i32, [ctypes.POINTER(AdamJob), c_i32, c_f32, c_f32, c_f32, c_f32, c_f32, c_ptr]),
+    "elimrec_lookup_counts": (c_i32, [c_ptr, c_i32, c_i64, c_i64, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_ptr, c_ptr]),
+    "elimrec_lookup_pack": (c_i32, [c_ptr, c_i32, c_i64, c_i64, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_i32, c_ptr, c_i64,
+                                    c_ptr, c_ptr, c_ptr]),
+    "elimrec_lookup_unpack": (c_i32, [c_ptr, c_i32, c_i64, c_i64, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_i32, c_ptr, c_i64,
+                                      c_i32, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
     "elimrec_sample_triplets": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_u64, c_u64, c_ptr, c_ptr, c_ptr, c_ptr]),
 }
 

@@ -572,6 +572,13 @@ class EliMRec(BasicModel):
         """Out_m = S_m W_m^T + c b_m^T + Narrow for every feature table m -- over all rows into `out`, or gathered
         at `rows` (int32 node ids; slots `rng` = device (begin, end)) into the compact `out`."""
         d, fold = self.latent_dim, ws["fold"]
+        fr = self.__dict__.get("_fold_rows") if self.__dict__.get("_slab_fwd") else None
+        if rows is not None and fr is not None:
+            # the column-sharded engine looked the constants' rows up for this batch (row-sharded / 16-bit storage,
+            # lookup.py): compact [R x D_m] rows in active-row order, c and the shared part compact too -- row r, not rows[r]
+            n = out.shape[0]
+            return [(fr["S"][m][:n], W[m + "_dense.weight"], W[m + "_dense.bias"], out[:, (k + 1) * d:(k + 2) * d], fr["c"][:n],
+                     fr["narrow"][:n], None, rng) for k, m in enumerate(self._mods)]
         extra = () if rows is None else (rows, rng)
         return [(fold[m], W[m + "_dense.weight"], W[m + "_dense.bias"], out[:, (k + 1) * d:(k + 2) * d], fold["c"],
                  ws["Narrow"]) + extra for k, m in enumerate(self._mods)]
@@ -858,9 +865,14 @@ class EliMRec(BasicModel):
                 grads[name + ".weight"], grads[name + ".bias"] = gv[name + ".weight"], gv[name + ".bias"]
             # feature projections: Out_m = S_m W_m^T + c b_m^T + (shared part)  =>  dW_m = dOut_m^T S_m over the
             # active rows only, db_m = dOut_m^T c
+            fr = self.__dict__.get("_fold_rows") if self.__dict__.get("_slab_fwd") else None
             for k, m in enumerate(self._mods):
-                problems.append(dict(A=dOutR[:, (k + 1) * d:(k + 2) * d], B=fold[m], out=gv[m + "_dense.weight"],
-                                     row_index=act, rng=seg[6:8], colsum=gv[m + "_dense.bias"], colsum_weight=fold["c"]))
+                if fr is not None:      # the constants' rows of this batch, compact (looked up by the engine): row r itself
+                    problems.append(dict(A=dOutR[:, (k + 1) * d:(k + 2) * d], B=fr["S"][m][:n], out=gv[m + "_dense.weight"],
+                                         rng=seg[6:8], colsum=gv[m + "_dense.bias"], colsum_weight=fr["c"]))
+                else:
+                    problems.append(dict(A=dOutR[:, (k + 1) * d:(k + 2) * d], B=fold[m], out=gv[m + "_dense.weight"],
+                                         row_index=act, rng=seg[6:8], colsum=gv[m + "_dense.bias"], colsum_weight=fold["c"]))
                 grads[m + "_dense.weight"], grads[m + "_dense.bias"] = gv[m + "_dense.weight"], gv[m + "_dense.bias"]
             handle = ops.linear_bwd_w_batched(problems, ws["bwd_w_rows"], merge=merge, defer_reduce=bool(defer_reduce) and concat,
                                               defer_all=defer_reduce == "all" and concat)

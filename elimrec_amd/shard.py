@@ -32,6 +32,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib, ops, slab
+from .lookup import FeatureShard, RowOwnerMap
 
 PAD_KEY = -(1 << 30)
 
@@ -85,6 +86,12 @@ class ColumnShardTrainer(object):
         self._ph = {n: phase(n) for n in ("cs_plan", "cs_forward_hops", "cs_forward_rows", "cs_head", "cs_backward_local",
                                           "cs_backward_hops", "cs_update")}
         self.xgmi_bytes = dict(all_gather=0, all_to_all_fwd=0, all_to_all_bwd=0, all_reduce=0)   # sent per rank, last step
+        # row-sharded constant tables (engine.lookup): the all_to_all split sizes of every planned batch, as host integers
+        self.lookup = bool(getattr(engine, "lookup", False))
+        self._lookup_plan = {}
+        self.lookup_syncs = 0          # steps that had to read their split sizes back from the device (no plan entry)
+        if self.lookup:
+            self.xgmi_bytes["all_to_all_lookup"] = 0
 
     def _like(self, name, t, lead=None):
         shape = tuple(t.shape) if lead is None else (lead,) + tuple(t.shape)
@@ -122,6 +129,61 @@ class ColumnShardTrainer(object):
         host = torch.empty(out.shape, dtype=out.dtype)
         dist.all_to_all_single(host, inp.cpu(), group=self.group)
         out.copy_(host)
+
+    def _all_to_all_v(self, out, inp, out_splits, in_splits):
+        """Variable-size exchange of flat uint8 buffers (the looked-up rows): split sizes in bytes, per peer."""
+        if not self._staged(inp):
+            return dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
+        host = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(host, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
+        out.copy_(host)
+
+    def plan_lookup(self, batches):
+        """Row-sharded constant tables: the split sizes of every batch's row exchange, computed ahead for a whole epoch (one
+        device pass + one device->host copy + one all_gather of a [batches x world] int table) so that no step has to stop
+        and read its own sizes back. `batches`: the (users, pos, neg) the following step() calls will get, in order; the
+        plan replaces the previous one (an epoch's tensors may reuse the addresses of the last epoch's). A step whose batch
+        is not in the plan reads its sizes from the device (one synchronisation per step)."""
+        self._lookup_plan = {}
+        if not self.lookup or not batches:
+            return
+        eng, W = self.engine, self.world
+        mine = eng.cs_lookup_plan_counts(batches)                 # int64 [n_batches, W] (host): my active rows per owner
+        if W > 1:
+            loc = torch.from_numpy(mine)
+            parts = [torch.empty_like(loc) for _ in range(W)]
+            if dist.get_backend(self.group) == "gloo":
+                dist.all_gather(parts, loc, group=self.group)
+            else:
+                dev = batches[0][0].device
+                parts_d = [p.to(dev) for p in parts]
+                dist.all_gather(parts_d, loc.to(dev), group=self.group)
+                parts = [p.cpu() for p in parts_d]
+            allc = torch.stack(parts).numpy()                     # [requester, batch, owner]
+        else:
+            allc = mine[None]
+        for k, (u, p, n) in enumerate(batches):
+            self._lookup_plan[(u.data_ptr(), int(u.numel()))] = allc[:, k, :]
+
+    def _lookup_counts(self, users, acts):
+        c = self._lookup_plan.get((users.data_ptr(), int(users.numel())))
+        if c is None:
+            self.lookup_syncs += 1
+            c = self.engine.cs_lookup_counts(acts).cpu().numpy()  # device -> host: the step waits for its plan
+        return c
+
+    def _lookup_exchange(self, users, acts):
+        """Looked-up rows of the row-sharded constant tables: owners pack, all_to_all, requesters unpack."""
+        eng, q = self.engine, self.rank
+        counts = self._lookup_counts(users, acts)                 # [requester][owner] rows
+        rb = eng.lookup_row_bytes
+        send = eng.cs_lookup_pack(acts)
+        in_splits = [int(counts[r][q]) * rb for r in range(self.world)]      # what I send to requester r
+        out_splits = [int(counts[q][o]) * rb for o in range(self.world)]     # what owner o sends me
+        recv = eng.cs_lookup_recv(sum(out_splits))
+        self._all_to_all_v(recv, send[:sum(in_splits)], out_splits, in_splits)
+        self.xgmi_bytes["all_to_all_lookup"] = sum(in_splits) - in_splits[q]
+        eng.cs_lookup_unpack(recv)
 
     def _all_reduce_async(self, t):
         if not self._staged(t):
@@ -161,6 +223,8 @@ class ColumnShardTrainer(object):
             h_ids.wait()
         send = ph["cs_forward_rows"](acts)                         # [W, R, 2*dl]: layer means of the peers' rows, my columns
         if self.multi:
+            if self.lookup:
+                self._lookup_exchange(users, acts)                 # S_m / c rows of MY active rows from their owners
             recv = self._like("recv_f", send)
             self._all_to_all(recv, send)
             self.xgmi_bytes["all_to_all_fwd"] = send[0].numel() * 4 * (W - 1)
@@ -213,11 +277,28 @@ class ColumnShardEngine(object):
     """The cs_* interface on the HIP kernels, around an EliMRec model (which keeps the plan, the folded constants, the
     head kernels' workspace, the projection weights and the cached tables predict() reads)."""
 
-    def __init__(self, model, group=None, table_dtype=None):
+    def __init__(self, model, group=None, table_dtype=None, feature_shard=None, feature_dtype=None):
         """table_dtype: "f32" (default) or "bf16" -- bf16 STORAGE of the layer tables, of the gather copy of X^0 and of the
         adjoint's intermediate tables with fp32 accumulation and fp32 master parameters / moments (also the config key
-        --table_dtype). A separately toleranced mode, never the parity path."""
+        --table_dtype). A separately toleranced mode, never the parity path.
+        feature_shard: "replicated" (default: every rank holds the folded constants S_m / c of all N rows) or "row" (config
+        key --feature_shard): rank o holds the rows of its 1/world of the users and of the items only, and a step fetches
+        the rows of its active nodes from their owners with an all_to_all (elimrec_amd/lookup.py) -- the north star's row
+        shards + all-to-all index lookup, for the tables that are N x sum(D_m) and only read. Bitwise the replicated
+        result in fp32. feature_dtype: "f32" | "f16" | "bf16" storage of those constants (--feature_dtype; BASELINE.json
+        configs[4] says fp16): rows are widened to fp32 when they are looked up, all arithmetic stays fp32."""
         cfg = model.config
+        if feature_shard is None:
+            feature_shard = str(cfg["feature_shard"]) if "feature_shard" in cfg else "replicated"
+        if feature_dtype is None:
+            feature_dtype = str(cfg["feature_dtype"]) if "feature_dtype" in cfg else "f32"
+        if feature_shard not in ("replicated", "row"):
+            raise ValueError("feature_shard must be 'replicated' or 'row' (got %r)" % (feature_shard,))
+        if feature_dtype not in ("f32", "f16", "bf16"):
+            raise ValueError("feature_dtype must be 'f32', 'f16' or 'bf16' (got %r)" % (feature_dtype,))
+        self.feature_shard, self.feature_dtype = feature_shard, feature_dtype
+        # the lookup path (compact rows of the constants per step) serves the row shards and the 16-bit storage alike
+        self.lookup = feature_shard == "row" or feature_dtype != "f32"
         if table_dtype is None:
             table_dtype = str(cfg["table_dtype"]) if "table_dtype" in cfg else "f32"
         if table_dtype not in ("f32", "bf16"):
@@ -292,6 +373,14 @@ class ColumnShardEngine(object):
         self._bufs = {}
         self._x0_fwd = None
         ws = m._workspace(1)
+        self.fshard = None
+        if self.lookup:
+            fold = ws["fold"]
+            owners = RowOwnerMap(m.num_users, m.num_items, world if self.feature_shard == "row" else 1)
+            self.fshard = FeatureShard(owners, rank if self.feature_shard == "row" else 0, [fold[k] for k in m._mods], fold["c"],
+                                       dtype=self.feature_dtype, device=dev)
+            self.lookup_row_bytes = self.fshard.row_bytes
+            self._lookup_bufs = {}
         self.load_from_model()
         m._slab_engine = self
         # the embeddings are updated here, not by the caller's optimizer; the projection weights go through it
@@ -336,6 +425,18 @@ class ColumnShardEngine(object):
         if "nar_act" not in bufs:
             bufs["nar_act"] = torch.zeros(R, d, dtype=torch.float32, device=dev)       # shared part of Out, compact rows
         self.nar_act = bufs["nar_act"]
+        if self.lookup:
+            if "s_rows" not in bufs:       # the constants' rows of this batch's active nodes, fp32, in active-row order
+                sd = self.fshard.sum_d
+                bufs["s_rows"] = torch.zeros(R, sd, dtype=torch.float32, device=dev)
+                bufs["c_rows"] = torch.zeros(R, dtype=torch.float32, device=dev)
+                bufs["iota"] = torch.arange(R, dtype=torch.int32, device=dev)
+            self.s_rows, self.c_rows, self.iota = bufs["s_rows"], bufs["c_rows"], bufs["iota"]
+            views, off = {}, 0
+            for k, D in zip(m._mods, self.fshard.dims):
+                views[k] = self.s_rows[:, off:off + D]
+                off += D
+            m._fold_rows = dict(S=views, c=self.c_rows, narrow=self.nar_act, R=R)
         return ws
 
     def _fused_head_ok(self):
@@ -512,7 +613,7 @@ class ColumnShardEngine(object):
             out0, narrow, by_node = self.send_f.view(W * R, 2 * self.dl)[:, :self.dl], self.send_f.view(W * R, 2 * self.dl)[:, self.dl:], False
         else:
             counts = ws["seg_info"][0:1]
-            if self._fused_head_ok():
+            if self._fused_head_ok() or self.lookup:
                 out0, narrow, by_node = ws["OutAct"][:R, :m.latent_dim], self.nar_act, False
             else:
                 out0, narrow, by_node = ws["OutAct"][:R, :m.latent_dim], ws["Narrow"], True
@@ -530,6 +631,8 @@ class ColumnShardEngine(object):
             else:
                 slab.rows(self.plan, self.ns, self.w, L, U, [t.data for t in tabs] + [None], self.long_tab, acts, counts, R, W,
                           out0, narrow, by_node)
+            if self.lookup and not self.multi:       # one rank: this rank owns every row -- no exchange, widen in place
+                self.fshard.unpack(ws["active_rows"][:R], None, self.s_rows, self.c_rows, direct=True)
         if late_wait:
             m._region("cs_fwd_long%d" % self.cur, (m._ws_gen,), long_rows)
             torch.cuda.current_stream().wait_stream(self._aux)
@@ -558,7 +661,7 @@ class ColumnShardEngine(object):
                 self._out0_src, self._nar_src = pair[:, 0, :], pair[:, 1, :]
             else:
                 ws["OutAct"][:R, :d].unflatten(1, (W, self.dl)).copy_(r[:, :, 0].permute(1, 0, 2))
-                if fused:
+                if fused or self.lookup:
                     self.nar_act.unflatten(1, (W, self.dl)).copy_(r[:, :, 1].permute(1, 0, 2))
                 else:
                     act = ws["active_rows"][:R].long()
@@ -615,8 +718,12 @@ class ColumnShardEngine(object):
         wu, wi = m._fusion_weights(W)
         out0 = self._out0_src if self._out0_src is not None else OutAct[:, :d]
         nar = self._nar_src if self._nar_src is not None else self.nar_act
-        ok = ops.head_fwd_fused(ws["active_rows"][:R], ws["seg_info"], out0, nar, fold["c"],
-                                [fold[k] for k in m._mods], [W[k + "_dense.weight"] for k in m._mods],
+        if self.lookup:      # compact rows of the constants (looked up / widened for this batch): row r, not row act[r]
+            rows, c_tab, s_tabs = self.iota[:R], self.c_rows, [m._fold_rows["S"][k] for k in m._mods]
+        else:
+            rows, c_tab, s_tabs = ws["active_rows"][:R], fold["c"], [fold[k] for k in m._mods]
+        ok = ops.head_fwd_fused(rows, ws["seg_info"], out0, nar, c_tab,
+                                s_tabs, [W[k + "_dense.weight"] for k in m._mods],
                                 [W[k + "_dense.bias"] for k in m._mods], wu, W["embedding_user_after_GCN.bias"], wi,
                                 W["embedding_item_after_GCN.bias"], [W["s_dense_%s.weight" % k] for k in m._mods],
                                 [W["s_dense_%s.bias" % k] for k in m._mods], self._pack, OutAct, YAct, d, phase=phase)
@@ -781,6 +888,58 @@ class ColumnShardEngine(object):
             else:
                 jobs.append(_lib.AdamJob(base_p + 4 * o, None, None, None, None, None, snap + 4 * (o - tail_off), n, 0))
         return jobs
+
+    # ------------------------------------------------------------------ row-sharded constants: the lookup's device steps
+    def cs_lookup_counts(self, acts):
+        """int32 [W x W] on the device: rows of requester r's list that owner o holds."""
+        return self.fshard.counts(acts.contiguous())
+
+    @torch.no_grad()
+    def cs_lookup_plan_counts(self, batches):
+        """int64 [n_batches x W] on the host: per batch, how many of ITS active rows (unique users, positives, negatives) each
+        rank owns -- the epoch-ahead form of cs_lookup_counts for this rank's own lists."""
+        m, own = self.model, self.fshard.owners
+        U, W = m.num_users, own.world
+        dev = batches[0][0].device
+        ub = torch.from_numpy(own.ub[1:].copy()).to(dev)
+        ib = torch.from_numpy(own.ib[1:].copy()).to(dev)
+        out = torch.zeros(len(batches), W, dtype=torch.int64, device=dev)
+        by_size = {}
+        for k, (u, p, n) in enumerate(batches):
+            by_size.setdefault(int(u.numel()), []).append(k)
+        for B, ks in by_size.items():
+            u = torch.stack([batches[k][0] for k in ks]).long()
+            it = torch.cat([torch.stack([batches[k][1] for k in ks]), torch.stack([batches[k][2] for k in ks])], dim=1).long()
+            for ids, bounds in ((u, ub), (it, ib)):
+                srt, _ = torch.sort(ids, dim=1)
+                first = torch.ones_like(srt, dtype=torch.bool)
+                first[:, 1:] = srt[:, 1:] != srt[:, :-1]
+                owner = torch.bucketize(srt, bounds, right=True).clamp_(max=W - 1)
+                flat = (torch.arange(len(ks), device=dev)[:, None] * W + owner)[first]
+                cnt = torch.zeros(len(ks) * W, dtype=torch.int64, device=dev).scatter_add_(0, flat, torch.ones_like(flat))
+                out[torch.tensor(ks, device=dev)] += cnt.view(len(ks), W)
+        return out.cpu().numpy()
+
+    def cs_lookup_pack(self, acts):
+        """Owner side: my rows of every rank's list -> a flat uint8 send buffer (chunks in requester order)."""
+        W, R = acts.shape
+        buf = self._lookup_bufs.get(("send", W, R))
+        if buf is None:
+            buf = self._lookup_bufs[("send", W, R)] = torch.empty(W * R * self.lookup_row_bytes, dtype=torch.uint8, device=acts.device)
+        self.fshard.pack(acts.contiguous(), buf)
+        return buf
+
+    def cs_lookup_recv(self, nbytes):
+        R = self.model._plan_n
+        buf = self._lookup_bufs.get(("recv", R))
+        if buf is None:
+            buf = self._lookup_bufs[("recv", R)] = torch.empty(R * self.lookup_row_bytes, dtype=torch.uint8, device=self.model._device())
+        return buf[:nbytes]
+
+    def cs_lookup_unpack(self, recv):
+        """Requester side: the received chunks -> compact fp32 rows of the constants in active-row order."""
+        R = self.model._plan_n
+        self.fshard.unpack(self.model._ws["active_rows"][:R], recv, self.s_rows, self.c_rows)
 
     # ------------------------------------------------------------------ cached tables for predict()
     @torch.no_grad()

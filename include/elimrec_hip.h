@@ -716,6 +716,31 @@ typedef struct elimrec_adam_job {
 int elimrec_adam_multi(const elimrec_adam_job *jobs /* host array */, int n_jobs, float lr, float beta1, float beta2,
                        float eps, float weight_decay, void *stream);
 
+/* ---------------------------------------------------------------- row-sharded constant tables: id lookup (csrc/lookup.hip)
+ * The row partition of SURVEY.md 8(e) for the tables that are only READ at the batch's active rows: the propagated form
+ * S_m = mean_k A^k [0 ; F_m] of the V/A/T feature tables (/root/reference/models/EliMRec.py:233-236,366-381) and
+ * c = mean_k A^k [0 ; 1]. Rank o owns users [ub[o], ub[o+1]) and items [ib[o], ib[o+1]) (host arrays of world+1 entries,
+ * ub[0] = ib[0] = 0, ub[world] = U, ib[world] = I), stored as one local table [own users ; own items] x row_bytes:
+ * sum_d elements (dtype 0 = fp32, 1 = fp16, 2 = bf16) of the S_m side by side, then c (fp32: one element; 16-bit: hi + lo in
+ * two elements), zero padding to a multiple of 16 bytes.
+ * d_acts [world x R] int32: every rank's active-row list (ascending node ids, negative padding behind the valid prefix --
+ * what elimrec_batch_plan writes, all-gathered).
+ *   lookup_counts  d_counts[r * world + o] = rows of rank r's list that rank o owns (the all_to_all split sizes).
+ *   lookup_pack    owner `me`: d_send = my rows of list 0, list 1, ... (per list: users ascending, then items ascending);
+ *                  d_send_off [world + 1] (nullable) receives the row offsets of the per-requester chunks.
+ *   lookup_unpack  requester `me`: d_rows = the chunks received from owner 0, 1, ... -> d_S [R x sum_d] (leading dimension
+ *                  ldS) fp32 rows in the order of d_act (= d_acts + me * R) and d_c [R]. direct = 1 (world 1): d_rows is the
+ *                  local table itself, nothing was exchanged. Rows behind the valid prefix of d_act are not written. */
+#define ELIMREC_MAX_RANKS 16
+int elimrec_lookup_counts(const int32_t *d_acts, int world, int64_t R, int64_t U, int64_t I, const int64_t *ub,
+                          const int64_t *ib, int32_t *d_counts, void *stream);
+int elimrec_lookup_pack(const int32_t *d_acts, int world, int64_t R, int64_t U, int64_t I, const int64_t *ub,
+                        const int64_t *ib, int me, const void *d_shard, int64_t row_bytes, void *d_send,
+                        int32_t *d_send_off, void *stream);
+int elimrec_lookup_unpack(const int32_t *d_act, int world, int64_t R, int64_t U, int64_t I, const int64_t *ub,
+                          const int64_t *ib, int me, const void *d_rows, int64_t row_bytes, int dtype, int sum_d,
+                          int direct, float *d_S, int64_t ldS, float *d_c, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -142,6 +142,58 @@ class ColumnShardOracleEngine(OracleEngine):
     rows. The folded algebra (constant feature tables propagated once) is restated here with torch autograd."""
     PAD = -(1 << 30)
     round_fn = None          # bf16-storage variant: straight-through rounding of the stored / gathered layer tables
+    lookup = False           # True: the constants S_m / c are ROW-sharded; a step fetches its active rows from the owners
+
+    # ---- row-sharded constants (elimrec_amd/lookup.py restated with torch indexing; rows travel as raw fp32 bytes)
+    def _lookup_setup(self):
+        from elimrec_amd.lookup import RowOwnerMap
+        m = self.m
+        self.owners = RowOwnerMap(m.U, m.I, self.world)
+        mine = torch.from_numpy(self.owners.nodes(self.rank))
+        self.first_node = {int(n): k for k, n in enumerate(mine.tolist())}
+        self.loc = torch.cat([self.S[k][mine] for k in self.mods] + [self.c[mine]], dim=1).contiguous()    # [own rows x (sumD + 1)]
+        self.lookup_row_bytes = 4 * self.loc.shape[1]
+        self.S = self.c = None                         # from here on the full tables do not exist on this rank
+        self.owner_of = np.zeros(m.U + m.I, np.int64)
+        for o in range(self.world):
+            self.owner_of[self.owners.nodes(o)] = o
+
+    def _owned(self, ids, o):
+        ids = ids[ids >= 0].long()
+        return ids[torch.from_numpy(self.owner_of[ids.numpy()] == o)]
+
+    def cs_lookup_counts(self, acts):
+        W = acts.shape[0]
+        return torch.tensor([[len(self._owned(acts[r], o)) for o in range(W)] for r in range(W)], dtype=torch.int32)
+
+    def cs_lookup_plan_counts(self, batches):
+        out = np.zeros((len(batches), self.world), np.int64)
+        for k, (u, p, n) in enumerate(batches):
+            act = torch.unique(self.batch_keys(u, p, n).long())
+            out[k] = np.bincount(self.owner_of[act.numpy()], minlength=self.world)
+        return out
+
+    def cs_lookup_pack(self, acts):
+        rows = [self.loc[[self.first_node[int(n)] for n in self._owned(acts[r], self.rank)]] for r in range(acts.shape[0])]
+        return torch.cat(rows).contiguous().view(torch.uint8).reshape(-1)
+
+    def cs_lookup_recv(self, nbytes):
+        return torch.empty(nbytes, dtype=torch.uint8)
+
+    def cs_lookup_unpack(self, recv):
+        rows = recv.view(torch.float32).view(-1, self.loc.shape[1])          # owner by owner, ascending inside an owner
+        act = self.act[:self.n_act].long()
+        order = torch.cat([self._owned(act, o) for o in range(self.world)])
+        assert len(order) == len(rows) == self.n_act
+        pos = torch.searchsorted(act, order)
+        full = torch.empty_like(rows)
+        full[pos] = rows
+        self.rows_S, off = {}, 0
+        for k in self.mods:
+            D = self.m.feats[k].shape[1]
+            self.rows_S[k] = full[:, off:off + D]
+            off += D
+        self.rows_c = full[:, off:off + 1]
 
     def cs_setup(self, world, rank, optimizer):
         m = self.m
@@ -162,6 +214,8 @@ class ColumnShardOracleEngine(OracleEngine):
             self.S = {k: mean_prop(torch.cat([torch.zeros(m.U, m.feats[k].shape[1]), m.feats[k]])) for k in self.mods}
             self.c = mean_prop(torch.cat([torch.zeros(m.U, 1), torch.ones(m.I, 1)]))
         self.tail = [k for k in m.params if not k.startswith(("embedding_user.", "embedding_item."))]
+        if self.lookup:
+            self._lookup_setup()
 
     def _tables(self):
         """out0 = mean_k A^k X0 and the shared part (users: even k, items: odd k) for my columns, with autograd."""
@@ -212,8 +266,11 @@ class ColumnShardOracleEngine(OracleEngine):
             nr = torch.cat([recv[p, :n, self.dl:] for p in range(W)], dim=1)
         self.o_leaf, self.n_leaf = o.clone().requires_grad_(True), nr.clone().requires_grad_(True)
         blocks = [self.o_leaf]
+        if self.lookup and self.world == 1 and recv is None:       # one rank without a trainer-side exchange: its own rows
+            self.cs_lookup_unpack(self.cs_lookup_pack(self.act.view(1, -1)))
         for k in self.mods:
-            blocks.append(F.linear(self.S[k][act], m.params[k + "_dense.weight"]) + self.c[act] * m.params[k + "_dense.bias"] + self.n_leaf)
+            Sk, ck = (self.rows_S[k], self.rows_c) if self.lookup else (self.S[k][act], self.c[act])
+            blocks.append(F.linear(Sk, m.params[k + "_dense.weight"]) + ck * m.params[k + "_dense.bias"] + self.n_leaf)
         out = torch.cat(blocks, dim=1)
         fused_in = out if m.mm_fusion_mode == "concat" else out.view(n, -1, d).mean(1)
         is_user = (act < m.U)[:, None]
@@ -349,7 +406,7 @@ def test_single_rank_trainer_matches_reference_fixture():
         assert abs(float(loss) - float(g["step%d/loss" % t])) < 1e-6
 
 
-def _cs_worker(rank, world, port, out_dir):
+def _cs_worker(rank, world, port, out_dir, lookup="off"):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -359,17 +416,62 @@ def _cs_worker(rank, world, port, out_dir):
     from elimrec_amd.shard import ColumnShardTrainer
     g = load_golden("ml3")
     eng = ColumnShardOracleEngine(g)
+    eng.lookup = lookup != "off"
     trainer = ColumnShardTrainer(eng, OracleOpt(eng, g), world_size=world, rank=rank)
-    losses = []
+    batches = []
     for t in (1, 2):
         u, p, n = (torch.from_numpy(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg"))
         h = len(u) // world
         sl = slice(rank * h, (rank + 1) * h)
-        losses.append(float(trainer.global_loss(trainer.step(u[sl], p[sl], n[sl]))))
+        batches.append((u[sl].clone(), p[sl].clone(), n[sl].clone()))
+    if lookup == "planned":
+        trainer.plan_lookup(batches)              # the epoch's split sizes ahead of time: no step reads its own back
+    losses = [float(trainer.global_loss(trainer.step(*b))) for b in batches]
+    extra = {}
+    if eng.lookup:
+        assert eng.S is None and eng.loc.shape[0] < eng.m.U + eng.m.I        # this rank never held the full constants
+        assert trainer.lookup_syncs == (0 if lookup == "planned" else len(batches))
+        extra["lookup_bytes"] = np.array([trainer.xgmi_bytes["all_to_all_lookup"], eng.lookup_row_bytes, eng.n_act, eng.loc.shape[0]])
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), losses=np.array(losses), shard=eng.shard.detach().numpy(),
              xgmi=np.array([trainer.xgmi_bytes[k] for k in ("all_gather", "all_to_all_fwd", "all_to_all_bwd", "all_reduce")]),
-             **{k: eng.m.params[k].detach().numpy() for k in eng.tail})
+             **extra, **{k: eng.m.params[k].detach().numpy() for k in eng.tail})
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("lookup", ["planned", "synced"])
+@pytest.mark.parametrize("world", [2, 4])
+def test_row_sharded_constants_with_all_to_all_lookup_equal_single_process(tmp_path, world, lookup):
+    """north_star's row shards + all-to-all index lookup for the V/A/T (folded-constant) tables, under gloo: every rank
+    holds 1/world of the rows of S_m / c and NOTHING else of them; a step all-gathers the active ids (as before), every
+    owner packs the rows the others asked for, one variable-size all_to_all moves them, the requester puts them in
+    active-row order. `world` ranks equal ONE process on the whole batch (oracle); the bytes on the wire are the rows a
+    rank does not own itself; with plan_lookup() no step synchronises to learn its split sizes."""
+    port = 33500 + (os.getpid() % 2000) + world + (10 if lookup == "planned" else 0)
+    mp.spawn(_cs_worker, args=(world, port, str(tmp_path), lookup), nprocs=world, join=True)
+    rs = [dict(np.load(tmp_path / ("rank%d.npz" % r))) for r in range(world)]
+    g = load_golden("ml3")
+    eng = OracleEngine(g)
+    from oracle import elimrec_oracle as eo
+    opt = eo.OracleAdam(eng.m.params, lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    losses = []
+    for t in (1, 2):
+        u, p, n = (g["step%d/%s" % (t, k)] for k in ("users", "pos", "neg"))
+        mlen = (len(u) // world) * world
+        losses.append(eo.train_step(eng.m, opt, u[:mlen], p[:mlen], n[:mlen]))
+    assert np.allclose(rs[0]["losses"], losses, atol=1e-6)
+    E = torch.cat([eng.m.params["embedding_user.weight"], eng.m.params["embedding_item.weight"]]).detach().numpy()
+    assert np.abs(np.concatenate([r["shard"] for r in rs], axis=1) - E).max() < 2e-5
+    skip = ("losses", "shard", "xgmi", "lookup_bytes")
+    for k in rs[0]:
+        if k in skip:
+            continue
+        assert np.abs(rs[0][k] - eng.m.params[k].detach().numpy()).max() < 2e-5, k
+        for r in rs[1:]:
+            assert np.array_equal(r[k], rs[0][k]), k
+    assert sum(int(r["lookup_bytes"][3]) for r in rs) == eng.m.U + eng.m.I              # the shards partition the rows
+    for r in rs:
+        sent, row_bytes, n_act, _ = (int(x) for x in r["lookup_bytes"])
+        assert 0 < sent <= (world - 1) * 3 * (len(g["step2/users"]) // world) * row_bytes and sent % row_bytes == 0
 
 
 @pytest.mark.parametrize("world", [2, 4])

@@ -239,6 +239,16 @@ def _emulated_step(engines, batches):
     acts = torch.stack([e.cs_plan(*b).clone() for e, b in zip(engines, batches)])               # all_gather
     sends = [e.cs_forward(acts) for e in engines]
     sends = [None if s is None else s.clone() for s in sends]
+    if W > 1 and engines[0].lookup:      # row-sharded constants: owners pack, the all_to_all by hand, requesters unpack
+        rb = engines[0].lookup_row_bytes
+        counts = engines[0].cs_lookup_counts(acts).cpu().numpy()            # [requester][owner]
+        packed = [e.cs_lookup_pack(acts).clone() for e in engines]
+        for q, e in enumerate(engines):
+            chunks = []
+            for o in range(W):
+                off = int(counts[:q, o].sum()) * rb
+                chunks.append(packed[o][off:off + int(counts[q, o]) * rb])
+            e.cs_lookup_unpack(torch.cat(chunks))
     scale = torch.full((1,), 1.0 / W, device=DEV)
     losses, sends2, wgs = [], [], []
     for q, e in enumerate(engines):
@@ -731,7 +741,7 @@ def test_random_shapes_column_shard_vs_row_major_trainer(seed):
 
 
 # ----------------------------------------------------------------------------- two PROCESSES, one GPU
-def _two_proc_worker(rank, world, port, out_dir):
+def _two_proc_worker(rank, world, port, out_dir, feature_shard="replicated"):
     import os, sys
     import torch.distributed as dist
     from helpers import ROOT
@@ -742,29 +752,37 @@ def _two_proc_worker(rank, world, port, out_dir):
     g = load_golden("ml3")
     model, _ = build_model_from_fixture(g, DEV)
     opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
-    eng = ColumnShardEngine(model)
+    eng = ColumnShardEngine(model, feature_shard=feature_shard)
     tr = ColumnShardTrainer(eng, opt, world_size=world, rank=rank)
-    losses = []
+    losses, batches = [], []
     for t in (1, 2):
         u, p, n = (_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg"))
         h = len(u) // world
         sl = slice(rank * h, (rank + 1) * h)
-        losses.append(float(tr.global_loss(tr.step(u[sl], p[sl], n[sl]))))
+        batches.append((u[sl].clone(), p[sl].clone(), n[sl].clone()))
+    tr.plan_lookup(batches[:1])                     # step 1 planned ahead, step 2 reads its split sizes from the device
+    for b in batches:
+        losses.append(float(tr.global_loss(tr.step(*b))))
+    if feature_shard == "row":
+        assert tr.lookup and tr.lookup_syncs == 1 and tr.xgmi_bytes["all_to_all_lookup"] > 0
+        assert eng.fshard.table.shape[0] < model.num_users + model.num_items
     eng.sync_to_model()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), losses=np.array(losses),
              **{k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
     dist.destroy_process_group()
 
 
-def test_two_processes_on_one_gpu_equal_one_process(tmp_path):
+@pytest.mark.parametrize("feature_shard", ["replicated", "row"])
+def test_two_processes_on_one_gpu_equal_one_process(tmp_path, feature_shard):
     """The real engine and the real trainer in two PROCESSES (both on cuda:0; gloo group, collectives staged through the host
     because RCCL refuses duplicate devices): every collective of a column-sharded step executes between processes. Both ranks
-    end with the same full model, equal to one process on the concatenated batch."""
+    end with the same full model, equal to one process on the concatenated batch. feature_shard = row: each process holds
+    half the rows of the folded constants and the step's variable-size all_to_all brings the other half's active rows."""
     import torch.multiprocessing as mp
     from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
     world = 2
-    port = 33500 + (os.getpid() % 2000)
-    mp.spawn(_two_proc_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    port = 33500 + (os.getpid() % 2000) + (3 if feature_shard == "row" else 0)
+    mp.spawn(_two_proc_worker, args=(world, port, str(tmp_path), feature_shard), nprocs=world, join=True)
     rs = [dict(np.load(tmp_path / ("rank%d.npz" % r))) for r in range(world)]
     for k in rs[0]:
         assert np.array_equal(rs[0][k], rs[1][k]), k
@@ -785,7 +803,7 @@ def test_two_processes_on_one_gpu_equal_one_process(tmp_path):
 
 
 # ----------------------------------------------------------------------------- one-rank RCCL group, multi-rank code path
-def _rccl_one_rank_worker(rank, port, out_dir):
+def _rccl_one_rank_worker(rank, port, out_dir, feature_shard="replicated"):
     import os
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -797,9 +815,9 @@ def _rccl_one_rank_worker(rank, port, out_dir):
     g = load_golden("ml3")
     model, _ = build_model_from_fixture(g, DEV)
     opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
-    eng = ColumnShardEngine(model)
+    eng = ColumnShardEngine(model, feature_shard=feature_shard)
     tr = ColumnShardTrainer(eng, opt, world_size=1, rank=0)
-    assert tr.multi and eng.multi
+    assert tr.multi and eng.multi and tr.lookup == (feature_shard == "row")
     losses = []
     for t in (1, 2, 3):
         u, p, n = (_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg"))
@@ -810,17 +828,19 @@ def _rccl_one_rank_worker(rank, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_multi_rank_step_over_a_one_rank_rccl_group(tmp_path):
+@pytest.mark.parametrize("feature_shard", ["replicated", "row"])
+def test_multi_rank_step_over_a_one_rank_rccl_group(tmp_path, feature_shard):
     """ELIMREC_SHARD_MULTI=1: ONE rank runs the multi-rank step -- all_gather of the active ids, both all_to_alls, the
     asynchronous all_reduce of the weight gradients, the rank-ordered merge, the separate optimizer launch -- over a real
     RCCL (backend "nccl") process group on the GPU: every collective call of the step as the 8-GPU job issues it (tensor
     shapes, dtypes, contiguity, stream hand-over, async handles). Three steps equal the one-rank fast path to round-off."""
     import torch.multiprocessing as mp
     from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
-    port = 35500 + (os.getpid() % 2000)
-    mp.spawn(_rccl_one_rank_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
+    port = 35500 + (os.getpid() % 2000) + (3 if feature_shard == "row" else 0)
+    mp.spawn(_rccl_one_rank_worker, args=(port, str(tmp_path), feature_shard), nprocs=1, join=True)
     got = dict(np.load(tmp_path / "rccl.npz"))
-    assert set(got.pop("xgmi").tolist()) == {"all_gather", "all_to_all_fwd", "all_to_all_bwd", "all_reduce"}
+    assert set(got.pop("xgmi").tolist()) == {"all_gather", "all_to_all_fwd", "all_to_all_bwd", "all_reduce"} | (
+        {"all_to_all_lookup"} if feature_shard == "row" else set())        # ... + the uint8 all_to_all with split sizes
     g = load_golden("ml3")
     model, _ = build_model_from_fixture(g, DEV)
     opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
@@ -832,3 +852,127 @@ def test_multi_rank_step_over_a_one_rank_rccl_group(tmp_path):
     assert np.abs(got.pop("losses") - np.array(losses)).max() < 1e-5
     for k, v in model.state_dict().items():
         assert np.abs(got[k] - v.detach().cpu().numpy()).max() < 2e-5, k
+
+
+# ----------------------------------------------------------------------------- row-sharded constant tables (lookup)
+@pytest.mark.parametrize("W,dtype", [(1, "f32"), (2, "f32"), (5, "f16"), (8, "bf16"), (8, "f32"), (3, "f16")])
+def test_lookup_counts_pack_unpack_vs_torch(W, dtype):
+    """csrc/lookup.hip on W emulated ranks: counts == a torch count of every list's ids per owner; pack -> (all_to_all by
+    hand) -> unpack gives, for every requester, exactly the owner tables' rows (rounded to the storage dtype) of ITS
+    active nodes in ITS order, and c to fp32 (16-bit storage: hi + lo, 2^-16 relative at worst for bf16)."""
+    from elimrec_amd.lookup import DTYPES, FeatureShard, RowOwnerMap
+    U, I, R = 700, 1900, 300
+    dims = (24, 8, 12)
+    g = torch.Generator().manual_seed(W)
+    tabs = [torch.randn(U + I, D, generator=g).to(DEV) for D in dims]
+    c = torch.rand(U + I, generator=g).to(DEV)
+    ub = None if W != 5 else [0, 10, 10, 300, 650, 700]          # an empty user block, uneven blocks
+    owners = RowOwnerMap(U, I, W, ub=ub)
+    shards = [FeatureShard(owners, o, tabs, c, dtype=dtype) for o in range(W)]
+    lists = []
+    for r in range(W):
+        n_act = int(torch.randint(1, R + 1, (1,), generator=g)) if r else R       # list 0 is full, the others ragged
+        ids = torch.randperm(U + I, generator=g)[:n_act].sort().values
+        lists.append(torch.cat([ids, torch.full((R - n_act,), -(1 << 30), dtype=torch.int64)]).to(torch.int32))
+    acts = torch.stack(lists).to(DEV)
+    counts = shards[0].counts(acts).cpu().numpy()
+    owner_of = np.zeros(U + I, np.int64)
+    for o in range(W):
+        owner_of[owners.nodes(o)] = o
+    for r in range(W):
+        valid = lists[r][lists[r] >= 0].numpy()
+        assert np.array_equal(counts[r], np.bincount(owner_of[valid], minlength=W)), r
+    rb = shards[0].row_bytes
+    packed = []
+    for o in range(W):
+        buf = torch.zeros(W * R * rb, dtype=torch.uint8, device=DEV)
+        off = torch.zeros(W + 1, dtype=torch.int32, device=DEV)
+        shards[o].pack(acts, buf, off)
+        assert np.array_equal(off.cpu().numpy(), np.concatenate([[0], np.cumsum(counts[:, o])]))
+        packed.append(buf)
+    tdt = DTYPES[dtype][1]
+    full = torch.cat(tabs, dim=1)
+    for q in range(W):
+        recv = torch.cat([packed[o][int(counts[:q, o].sum()) * rb:(int(counts[:q, o].sum()) + int(counts[q, o])) * rb] for o in range(W)])
+        S = torch.full((R, sum(dims)), 7.0, device=DEV)
+        cr = torch.full((R,), 7.0, device=DEV)
+        shards[q].unpack(acts[q], recv, S, cr)
+        valid = lists[q][lists[q] >= 0].long().to(DEV)
+        n = len(valid)
+        assert torch.equal(S[:n], full[valid].to(tdt).float())
+        assert (S[n:] == 7.0).all() and (cr[n:] == 7.0).all()            # rows behind the valid prefix untouched
+        tol = 0.0 if dtype == "f32" else (2.0 ** -20 if dtype == "f16" else 2.0 ** -15)
+        assert (cr[:n] - c[valid]).abs().max().item() <= tol
+    if W == 1:       # one rank: straight from the local table
+        S2, c2 = torch.empty_like(S), torch.empty_like(cr)
+        shards[0].unpack(acts[0], None, S2, c2, direct=True)
+        assert torch.equal(S2[:n], S[:n]) and torch.equal(c2[:n], cr[:n])
+
+
+@pytest.mark.parametrize("W", [1, 2, 4])
+@pytest.mark.parametrize("name", ["ml3", "kwai"])
+def test_row_sharded_constants_equal_replicated_bitwise(W, name):
+    """--feature_shard=row on W emulated ranks (each holds 1/W of the rows of S_m / c; every step fetches the rows of its
+    active nodes: counts -> pack -> exchange -> unpack) against the replicated tables on the same W ranks: the looked-up
+    rows are the same fp32 values consumed in the same order, so losses, embeddings and weights agree BITWISE; and both
+    match the reference fixture's losses (kwai: recdim 64, the fused head; ml3: recdim 32, the batched GEMMs)."""
+    from elimrec_amd import ColumnShardEngine, FusedAdam
+    g = load_golden(name)
+    B = (len(g["step1/users"]) // W) * W
+
+    def make(rank, mode):
+        model, _ = build_model_from_fixture(g, DEV)
+        opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+        eng = ColumnShardEngine(model, feature_shard=mode)
+        eng.cs_setup(W, rank, opt)
+        return model, eng
+
+    out = {}
+    for mode in ("replicated", "row"):
+        ranks = [make(q, mode) for q in range(W)]
+        assert all(e.lookup == (mode == "row") for _, e in ranks)
+        if mode == "row" and W > 1:
+            rows = sum(e.fshard.table.shape[0] for _, e in ranks)
+            assert rows == int(g["num_users"]) + int(g["num_items"])          # a partition of the rows
+        losses = []
+        for t in (1, 2, 3):
+            u, p, n = (_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg"))
+            h = min(B, len(u)) // W          # (the fixture's third batch is the epoch's ragged tail)
+            losses.append(float(_emulated_step([e for _, e in ranks], [(u[q * h:(q + 1) * h], p[q * h:(q + 1) * h], n[q * h:(q + 1) * h])
+                                                                        for q in range(W)])))
+        out[mode] = (losses, torch.cat([e.master[e.cur].dense() for _, e in ranks], dim=1),
+                     {k: v.clone() for k, v in ranks[0][0].state_dict().items() if not k.startswith("embedding_")})
+    assert out["row"][0] == out["replicated"][0]
+    assert torch.equal(out["row"][1], out["replicated"][1])
+    for k, v in out["replicated"][2].items():
+        assert torch.equal(out["row"][2][k], v), k
+    if W == 1:
+        for t in (1, 2, 3):
+            assert abs(out["row"][0][t - 1] - float(g["step%d/loss" % t])) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_16bit_feature_storage_equals_fp32_engine_on_rounded_constants(dtype):
+    """--feature_dtype=f16|bf16 (BASELINE.json configs[4]: "fp16" features): the constants are STORED in 16 bits and widened
+    when a step looks its rows up; everything else is the fp32 path. So the run equals, to the last bits of c's hi + lo
+    split (tolerance 2e-6), the fp32 engine on a model whose S_m were rounded to that dtype -- the rounding oracle of
+    this mode -- and differs from the unrounded fp32 run by the storage error (stated tolerance: loss 2e-3)."""
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
+    g = load_golden("kwai")
+    tdt = torch.float16 if dtype == "f16" else torch.bfloat16
+    res = {}
+    for mode in ("stored", "rounded", "plain"):
+        model, _ = build_model_from_fixture(g, DEV)
+        opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+        eng = ColumnShardEngine(model, feature_dtype=dtype if mode == "stored" else "f32")
+        tr = ColumnShardTrainer(eng, opt)
+        if mode == "rounded":
+            fold = model._ws["fold"]
+            for k in model._mods:
+                fold[k].copy_(fold[k].to(tdt).float())
+        losses = [float(tr.step(*(_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg")))) for t in (1, 2, 3)]
+        res[mode] = (losses, eng.master[eng.cur].dense().clone())
+    assert np.abs(np.array(res["stored"][0]) - np.array(res["rounded"][0])).max() < 2e-6
+    assert (res["stored"][1] - res["rounded"][1]).abs().max().item() < 2e-5
+    assert res["stored"][0] != res["plain"][0]                                   # the storage really is 16-bit
+    assert np.abs(np.array(res["stored"][0]) - np.array(res["plain"][0])).max() < 2e-3
