@@ -153,6 +153,10 @@ SIGNATURES = {
     "elimrec_row_sqnorms": (c_i32, [c_ptr, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr]),
     "elimrec_score_topk": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_i32, c_i32, c_i32, c_u32, c_i32, c_i32,
                                    c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "elimrec_score_topk_shard": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_i32, c_i32, c_i32, c_u32, c_i32, c_i32,
+                                         c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_size, c_i32, c_ptr, c_i64,
+                                         c_i64, c_ptr]),
+    "elimrec_topk_merge": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr]),
     "elimrec_rank_metrics": (c_i32, [c_ptr, c_i32, c_i32, c_ptr, c_ptr, ctypes.POINTER(c_i32), c_i32, c_ptr, c_ptr]),
     "elimrec_slab_partials_bytes": (c_size, [c_sell, c_i32, c_i32]),
     "elimrec_slab_set_variant": (None, [c_i32]),

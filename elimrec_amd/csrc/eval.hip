@@ -676,6 +676,18 @@ __global__ __launch_bounds__(256) void row_mean_kernel(const float *__restrict__
     if (threadIdx.x == 0) row_mean[b] = sm[0] / (float)I;
 }
 
+// item-sharded evaluation: the row sums of sigmoid(u.i) were added over the shards by the caller (all_reduce)
+__global__ void mean_from_sum_kernel(const float *__restrict__ row_sum, int B, int64_t I_total, float *__restrict__ row_mean) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) row_mean[b] = row_sum[b] / (float)I_total;
+}
+
+// ... and this shard's item ids become catalogue ids
+__global__ void add_id_offset_kernel(int32_t *__restrict__ idx, int64_t n, int32_t off) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && idx[i] >= 0) idx[i] += off;
+}
+
 __global__ void mask_train_kernel(float *__restrict__ scores, int64_t lds, const int64_t *__restrict__ ptr,
                                   const int32_t *__restrict__ items, int B) {
     const int b = blockIdx.x;
@@ -1100,17 +1112,23 @@ static size_t resident_lds(int pass, int nb, int d) {
     return ((size_t)2 * MI * (cols + 1) + (size_t)MU * (nb > 1 ? nb - 1 : 1) + MU) * sizeof(float);
 }
 
-extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int64_t I, const int64_t *d_users, int B,
-                                  int d, int S, uint32_t head_mask, int fusion_mode, int predict_type,
-                                  const float *d_sqnorm, const int64_t *d_train_ptr, const int32_t *d_train_items,
-                                  float *d_scores, int64_t lds, int K, int32_t *d_topk_idx, float *d_topk_val,
-                                  void *d_workspace, size_t workspace_bytes, void *stream) {
+// phase 0: the whole call. Item-sharded evaluation (this rank holds items [id_offset, id_offset + I) of I_total):
+// phase 1 = pass 1 only, d_row_sum[b] = sum over MY items of sigmoid(u.i) (TIE; a no-op otherwise); the caller adds the
+// shards' sums (all_reduce); phase 2 = the rest with row mean = d_row_sum[b] / I_total, top-K ids + id_offset.
+static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, const int64_t *d_users, int B,
+                           int d, int S, uint32_t head_mask, int fusion_mode, int predict_type,
+                           const float *d_sqnorm, const int64_t *d_train_ptr, const int32_t *d_train_items,
+                           float *d_scores, int64_t lds, int K, int32_t *d_topk_idx, float *d_topk_val,
+                           void *d_workspace, size_t workspace_bytes, void *stream, int phase, float *d_row_sum,
+                           int64_t I_total, int64_t id_offset) {
     ELIMREC_REQUIRE(d_Y && d_users && d_workspace, "score_topk: null pointer");
+    ELIMREC_REQUIRE(phase == 0 || (d_row_sum && I_total >= I), "score_topk: sharded phases need d_row_sum and I_total >= I");
+    if (phase == 1 && predict_type != 2) return 0;             // only TIE has a catalogue-wide mean
     ELIMREC_REQUIRE(d > 0 && d % 4 == 0 && ldy % 4 == 0, "score_topk: recdim/ldy must be multiples of 4");
     ELIMREC_REQUIRE(S >= 0 && S <= kMaxS, "score_topk: at most %d single-modal heads", kMaxS);
     ELIMREC_REQUIRE(fusion_mode >= 0 && fusion_mode <= 2 && predict_type >= 0 && predict_type <= 2,
                     "score_topk: bad fusion_mode/predict_type");
-    ELIMREC_REQUIRE(d_scores || d_topk_idx, "score_topk: nothing to output");
+    ELIMREC_REQUIRE(d_scores || d_topk_idx || phase == 1, "score_topk: nothing to output");
     ELIMREC_REQUIRE(!d_topk_idx || (K > 0 && K <= I), "score_topk: need 0 < K <= I");
     if (B <= 0) return 0;
     static int use_resident = -1;
@@ -1120,7 +1138,11 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
     // only top-K wanted: no [B x I] score block -- the catalogue goes through the scorer in chunks (a workspace sized by
     // elimrec_score_workspace_for is enough; a larger one is accepted)
     const bool chunked = score_chunked_form(d, S, K, I, d_scores != nullptr, d_topk_idx != nullptr);
-    const ScoreLayout L = score_layout(B, U, I, S, K, chunked);
+    ScoreLayout L = score_layout(B, U, I, S, K, chunked);
+    if (phase == 1) {        // row sums only: no score block is touched -- the chunked layout (no [B x I] block) will do as well
+        const ScoreLayout Lc = score_layout(B, U, I, S, K, true);
+        if (Lc.total < L.total) L = Lc;
+    }
     if (workspace_bytes < L.total) {
         set_error("score_topk: workspace too small (%zu < %zu)", workspace_bytes, L.total);
         return ELIMREC_E_WORKSPACE;
@@ -1146,6 +1168,13 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
         ELIMREC_LAUNCH_CHECK("row_sqnorm");
     }
     a.sqn = d_sqnorm ? d_sqnorm : wsqn;
+    const bool own_pass1 = predict_type == 2 && phase != 2;      // phase 2: the mean comes from the all-reduced sums
+    float *mean_dst = phase == 1 ? d_row_sum : mean;            // phase 1: sums (divisor 1), straight to the caller
+    const int64_t mean_div = phase == 1 ? 1 : I;
+    if (phase == 2 && predict_type == 2) {
+        hipLaunchKernelGGL(mean_from_sum_kernel, dim3((B + 255) / 256), dim3(256), 0, s, (const float *)d_row_sum, B, I_total, mean);
+        ELIMREC_LAUNCH_CHECK("mean_from_sum");
+    }
     uint32_t *wbits = (uint32_t *)(ws + L.bits);
     float *wtmax = (float *)(ws + L.tmax);
     const int64_t bits_ld = (I + 31) / 32;
@@ -1213,14 +1242,15 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
     } while (0)
         // pass 1 (TIE): row means of sigmoid(u.i) over the WHOLE catalogue
         a.item0 = 0; a.item_end = I;
-        if (predict_type == 2) {
+        if (own_pass1) {
             if (S == 1) ELIMREC_T16_PASS1(2);
             else if (S == 2) ELIMREC_T16_PASS1(3);
             else ELIMREC_T16_PASS1(4);
             ELIMREC_LAUNCH_CHECK("score_t16_pass1");
-            hipLaunchKernelGGL(row_mean_kernel, dim3(B), dim3(256), 0, s, partial, (int)grid1.x, B, I, mean);
+            hipLaunchKernelGGL(row_mean_kernel, dim3(B), dim3(256), 0, s, partial, (int)grid1.x, B, mean_div, mean_dst);
             ELIMREC_LAUNCH_CHECK("row_mean");
         }
+        if (phase == 1) return 0;
         // pass 2 over items [a.item0, a.item_end): the arguments, tile count and grid are the lambda's (they shadow the outer ones)
         auto pass2 = [&](const ScoreArgs &a, int t16, dim3 grid) -> int {
             if (S == 1) ELIMREC_T16_PASS2(2);
@@ -1262,6 +1292,11 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
             hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(256), (size_t)nch * K * 8, s, (const float *)cand_val,
                                (const int32_t *)cand_idx, nch * K, K, d_topk_idx, d_topk_val);
             ELIMREC_LAUNCH_CHECK("topk_merge");
+            if (id_offset) {
+                hipLaunchKernelGGL(add_id_offset_kernel, dim3((unsigned)(((int64_t)B * K + 255) / 256)), dim3(256), 0, s, d_topk_idx,
+                                   (int64_t)B * K, (int32_t)id_offset);
+                ELIMREC_LAUNCH_CHECK("add_id_offset");
+            }
             return 0;
         }
         { int rc = pass2(a, t16, grid); if (rc) return rc; }
@@ -1284,12 +1319,13 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
     } while (0)
 #define ELIMREC_SCORE_RESIDENT(NB)                                                                          \
     do {                                                                                                   \
-        if (predict_type == 2) {                                                                           \
+        if (own_pass1) {                                                                                   \
             hipLaunchKernelGGL((score_resident_kernel<1, NB, 64, -1, -1>), grid, dim3(256), resident_lds(1, NB, 64), s, a, tiles); \
             ELIMREC_LAUNCH_CHECK("score_resident_pass1");                                                  \
-            hipLaunchKernelGGL(row_mean_kernel, dim3(B), dim3(256), 0, s, partial, tiles, B, I, mean);     \
+            hipLaunchKernelGGL(row_mean_kernel, dim3(B), dim3(256), 0, s, partial, tiles, B, mean_div, mean_dst); \
             ELIMREC_LAUNCH_CHECK("row_mean");                                                              \
         }                                                                                                  \
+        if (phase == 1) return 0;                                                                          \
         if (predict_type == 0) ELIMREC_SCORE_RESIDENT2(NB, 0, 0);                                          \
         else if (predict_type == 1 && fusion_mode == 0) ELIMREC_SCORE_RESIDENT2(NB, 1, 0);                 \
         else if (predict_type == 1 && fusion_mode == 1) ELIMREC_SCORE_RESIDENT2(NB, 1, 1);                 \
@@ -1306,23 +1342,25 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
 #undef ELIMREC_SCORE_RESIDENT
     } else if (use_mfma) {
         dim3 grid(tiles, (B + MU - 1) / MU);
-        if (predict_type == 2) {
+        if (own_pass1) {
             hipLaunchKernelGGL(score_mfma_kernel<1>, grid, dim3(256), 0, s, a);
             ELIMREC_LAUNCH_CHECK("score_mfma_pass1");
-            hipLaunchKernelGGL(row_mean_kernel, dim3(B), dim3(256), 0, s, partial, tiles, B, I, mean);
+            hipLaunchKernelGGL(row_mean_kernel, dim3(B), dim3(256), 0, s, partial, tiles, B, mean_div, mean_dst);
             ELIMREC_LAUNCH_CHECK("row_mean");
         }
+        if (phase == 1) return 0;
         hipLaunchKernelGGL(score_mfma_kernel<2>, grid, dim3(256), 0, s, a);
         ELIMREC_LAUNCH_CHECK("score_mfma_pass2");
     } else {
         const int vtiles = (int)((I + SI - 1) / SI);
         dim3 grid(vtiles, (B + SU - 1) / SU);
-        if (predict_type == 2) {
+        if (own_pass1) {
             hipLaunchKernelGGL(score_kernel<1>, grid, dim3(256), 0, s, a);
             ELIMREC_LAUNCH_CHECK("score_pass1");
-            hipLaunchKernelGGL(row_mean_kernel, dim3(B), dim3(256), 0, s, partial, vtiles, B, I, mean);
+            hipLaunchKernelGGL(row_mean_kernel, dim3(B), dim3(256), 0, s, partial, vtiles, B, mean_div, mean_dst);
             ELIMREC_LAUNCH_CHECK("row_mean");
         }
+        if (phase == 1) return 0;
         hipLaunchKernelGGL(score_kernel<2>, grid, dim3(256), 0, s, a);
         ELIMREC_LAUNCH_CHECK("score_pass2");
     }
@@ -1350,7 +1388,50 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
                                (const int32_t *)nullptr, (const uint32_t *)nullptr, (int64_t)0, (int64_t)0, (int64_t)K, (int64_t)0);
         }
         ELIMREC_LAUNCH_CHECK("topk");
+        if (id_offset) {
+            hipLaunchKernelGGL(add_id_offset_kernel, dim3((unsigned)(((int64_t)B * K + 255) / 256)), dim3(256), 0, s, d_topk_idx,
+                               (int64_t)B * K, (int32_t)id_offset);
+            ELIMREC_LAUNCH_CHECK("add_id_offset");
+        }
     }
+    return 0;
+}
+
+extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int64_t I, const int64_t *d_users, int B,
+                                  int d, int S, uint32_t head_mask, int fusion_mode, int predict_type,
+                                  const float *d_sqnorm, const int64_t *d_train_ptr, const int32_t *d_train_items,
+                                  float *d_scores, int64_t lds, int K, int32_t *d_topk_idx, float *d_topk_val,
+                                  void *d_workspace, size_t workspace_bytes, void *stream) {
+    return score_topk_impl(d_Y, ldy, U, I, d_users, B, d, S, head_mask, fusion_mode, predict_type, d_sqnorm, d_train_ptr,
+                           d_train_items, d_scores, lds, K, d_topk_idx, d_topk_val, d_workspace, workspace_bytes, stream, 0,
+                           nullptr, I, 0);
+}
+
+extern "C" int elimrec_score_topk_shard(const float *d_Y, int64_t ldy, int64_t U, int64_t I, const int64_t *d_users, int B,
+                                        int d, int S, uint32_t head_mask, int fusion_mode, int predict_type,
+                                        const float *d_sqnorm, const int64_t *d_train_ptr, const int32_t *d_train_items,
+                                        float *d_scores, int64_t lds, int K, int32_t *d_topk_idx, float *d_topk_val,
+                                        void *d_workspace, size_t workspace_bytes, int phase, float *d_row_sum,
+                                        int64_t I_total, int64_t id_offset, void *stream) {
+    ELIMREC_REQUIRE(phase == 1 || phase == 2, "score_topk_shard: phase 1 (row sums) or 2 (scores / top-K)");
+    ELIMREC_REQUIRE(id_offset >= 0 && id_offset + I <= I_total && I_total < (int64_t)INT32_MAX, "score_topk_shard: bad item range");
+    return score_topk_impl(d_Y, ldy, U, I, d_users, B, d, S, head_mask, fusion_mode, predict_type, d_sqnorm, d_train_ptr,
+                           d_train_items, d_scores, lds, K, d_topk_idx, d_topk_val, d_workspace, workspace_bytes, stream, phase,
+                           d_row_sum, I_total, id_offset);
+}
+
+// Merge per-shard (or per-chunk) candidate lists: d_cand_val / d_cand_idx [B x n_cand] (idx < 0 = no candidate) -> the K
+// best per row by (score descending, item id ascending), the rule of every selection in this file.
+extern "C" int elimrec_topk_merge(const float *d_cand_val, const int32_t *d_cand_idx, int B, int n_cand, int K,
+                                  int32_t *d_topk_idx, float *d_topk_val, void *stream) {
+    ELIMREC_REQUIRE(d_cand_val && d_cand_idx && d_topk_idx && K >= 1 && n_cand >= 1, "topk_merge: bad arguments");
+    ELIMREC_REQUIRE((size_t)n_cand * 8 <= TOPK_MERGE_LDS_MAX, "topk_merge: %d candidates per row exceed the LDS budget", n_cand);
+    if (B <= 0) return 0;
+    if ((size_t)n_cand * 8 > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)topk_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)TOPK_MERGE_LDS_MAX);
+    hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(256), (size_t)n_cand * 8, (hipStream_t)stream, d_cand_val, d_cand_idx, n_cand, K,
+                       d_topk_idx, d_topk_val);
+    ELIMREC_LAUNCH_CHECK("topk_merge");
     return 0;
 }
 

@@ -103,6 +103,10 @@ class UniEvaluator(object):
             # every rank, before any rank can run out of users: materialising the cached tables of a multi-rank job is a
             # collective (ColumnShardEngine.materialize_tables), and a rank with an empty slice would otherwise skip it
             model._ensure_tables()
+        if getattr(model, "_eval_shard", None) is not None:
+            # the cached tables are ITEM-sharded (row-sharded constants, shard_eval.py): every rank scores every user
+            # against its items and the merged lists -- hence the metric rows -- are identical on all ranks
+            sharded = False
         lo, hi = (n * shard[0] // shard[1], n * (shard[0] + 1) // shard[1]) if sharded else (0, n)
         alloc = torch.zeros if sharded else torch.empty
         all_dev = alloc(n, self.metrics_num * self.max_top, dtype=torch.float32, device=model._require_gpu())

@@ -270,6 +270,9 @@ class EliMRec(BasicModel):
         if self._cache is None:
             return None
         self._ensure_tables()
+        if self.__dict__.get("_eval_shard") is not None and k != 0:
+            raise RuntimeError("the cached item tables are sharded over the ranks (--feature_shard=row): all_items / all_s_embs "
+                               "exist per item block only; use predict() / evaluate(), which gather what they need")
         if self._cache is True:                 # published by a training step: the views are built on first use
             Y, U, d = self._cache_src, self.num_users, self.latent_dim
             s_embs = {}
@@ -667,6 +670,8 @@ class EliMRec(BasicModel):
         self._cache_src = Y
         self._cache = True
         self._tables_dirty = dirty
+        if dirty:
+            self._eval_shard = None          # an item-sharded scorer of an older forward (shard.py) is stale now
 
     # ------------------------------------------------------------------ hipGraph regions
     def _region(self, name, key, fn):
@@ -1138,6 +1143,13 @@ class EliMRec(BasicModel):
         self._ensure_tables()
         users = torch.as_tensor(user_ids, device=dev).long().contiguous()
         B, I = users.numel(), self.num_items
+        sh = self.__dict__.get("_eval_shard")
+        if sh is not None:       # several ranks with row-sharded tables: this rank scores its block of the items (shard_eval.py)
+            if scores is not None:
+                scores.copy_(sh.scores(users, train_ptr, train_items))
+            if top_k:
+                return sh.topk(users, top_k, train_ptr, train_items)
+            return None, None
         # top-K only (the evaluator): no [B x I] score block in the workspace, the catalogue is scored in chunks
         import os
         chunked = scores is None and top_k > 0 and os.environ.get("ELIMREC_SCORE_CHUNKED", "1") != "0"

@@ -683,6 +683,33 @@ def score_topk(Y, U, I, users, d, S, head_mask, fusion_mode, predict_type, works
                "score_topk")
 
 
+def score_topk_shard(Y, U, I, users, d, S, head_mask, fusion_mode, predict_type, workspace, phase, row_sum, I_total, id_offset,
+                     scores=None, K=0, topk_idx=None, topk_val=None, train_ptr=None, train_items=None, sqnorm=None):
+    """elimrec_score_topk_shard: Y = [all user rows ; this shard's I item rows]. phase 1 -> row_sum [B] (TIE), phase 2 ->
+    scores [B x I] and / or top-K (catalogue ids) given the all-reduced row_sum."""
+    y, ldy = _rowmajor(Y, "Y")
+    B = users.numel()
+    sp, lds = (None, 0)
+    if scores is not None:
+        sp, lds = _rowmajor(scores, "scores")
+    _lib.check(_lib.load().elimrec_score_topk_shard(y, ldy, U, I, _dev(users, "users", torch.int64), B, d, S, int(head_mask),
+                                                    FUSION_MODES[fusion_mode], PREDICT_TYPES.get(predict_type, 0),
+                                                    _dev(sqnorm, "sqnorm"), _dev(train_ptr, "train_ptr", torch.int64),
+                                                    _dev(train_items, "train_items", torch.int32), sp, lds, int(K),
+                                                    _dev(topk_idx, "topk_idx", torch.int32), _dev(topk_val, "topk_val"),
+                                                    _dev(workspace, "workspace", torch.uint8), workspace.numel(), int(phase),
+                                                    _dev(row_sum, "row_sum"), int(I_total), int(id_offset), _stream()),
+               "score_topk_shard")
+
+
+def topk_merge(cand_val, cand_idx, K, out_idx, out_val=None):
+    """[B x n] candidate (value, id) lists -> the K best per row by (score desc, id asc)."""
+    B, n = cand_val.shape
+    assert cand_val.is_contiguous() and cand_idx.is_contiguous() and cand_idx.shape == (B, n) and out_idx.shape == (B, K)
+    _lib.check(_lib.load().elimrec_topk_merge(_dev(cand_val, "cand_val"), _dev(cand_idx, "cand_idx", torch.int32), B, n, int(K),
+                                              _dev(out_idx, "out_idx", torch.int32), _dev(out_val, "out_val"), _stream()), "topk_merge")
+
+
 def rank_metrics(topk_idx, truth_ptr, truth_items, metric_ids, out):
     B, K = topk_idx.shape
     ids = (ctypes.c_int * len(metric_ids))(*metric_ids)

@@ -965,6 +965,10 @@ class ColumnShardEngine(object):
                           out0, narrow, False)
         if self.world == 1:
             all_rows(ws["Out"][:, :d], ws["Narrow"])
+        elif self.feature_shard == "row":
+            loc = torch.empty(N, 2 * self.dl, dtype=torch.float32, device=ws["Out"].device)
+            all_rows(loc[:, :self.dl], loc[:, self.dl:])
+            return self._materialize_item_shard(ws, loc)
         else:
             loc = torch.empty(N, 2 * self.dl, dtype=torch.float32, device=ws["Out"].device)
             all_rows(loc[:, :self.dl], loc[:, self.dl:])
@@ -972,6 +976,55 @@ class ColumnShardEngine(object):
             ws["Out"][:, :d].copy_(torch.cat([p[:, :self.dl] for p in parts], dim=1))
             ws["Narrow"].copy_(torch.cat([p[:, self.dl:] for p in parts], dim=1))
         m._full_tables(ws, ws["snap_views"])
+
+    @torch.no_grad()
+    def _materialize_item_shard(self, ws, loc):
+        """Row-sharded constants, several ranks: the cached tables are built ROW-sharded too -- every rank computes Out / Y
+        for the nodes it owns (its users, its items), from its own rows of S_m / c, and evaluation runs item-sharded
+        (shard_eval.py). loc [N x 2*dl]: (layer mean | shared part) of all rows in MY columns; one all_to_all hands every
+        owner its rows of every rank's columns (the column shards' transpose), one all_gather replicates the users' Y rows
+        (every rank scores all users against its items)."""
+        from .shard_eval import Collectives, HipShardBackend, ItemShardScorer
+        m, W, q, own = self.model, self.world, self.rank, self.fshard.owners
+        d, dl, C, Cy, U = m.latent_dim, self.dl, m.C, m.Cy, m.num_users
+        dev = loc.device
+        coll = Collectives(self.group)
+        if getattr(self, "_own_nodes", None) is None:
+            self._own_nodes = [torch.from_numpy(own.nodes(o)).to(dev) for o in range(W)]
+        rows = [len(n) for n in self._own_nodes]
+        mine = rows[q]
+        recv = coll.all_to_all_rows(torch.cat([loc[n] for n in self._own_nodes]), rows, [mine] * W).view(W, mine, 2, dl)
+        Out = torch.empty(mine, C, dtype=torch.float32, device=dev)
+        Out[:, :d].unflatten(1, (W, dl)).copy_(recv[:, :, 0].permute(1, 0, 2))
+        Nar = recv[:, :, 1].permute(1, 0, 2).reshape(mine, d).contiguous()
+        # my rows of the constants, widened to fp32 (direct read of the local table, in its own order)
+        S = torch.empty(mine, self.fshard.sum_d, dtype=torch.float32, device=dev)
+        c = torch.empty(mine, dtype=torch.float32, device=dev)
+        self.fshard.unpack(self._own_nodes[q].to(torch.int32), None, S, c, direct=True)
+        Wt = ws["snap_views"]                                       # the weights the last forward used (predict() is stale)
+        problems, off = [], 0
+        for k, (name, D) in enumerate(zip(m._mods, self.fshard.dims)):
+            problems.append((S[:, off:off + D], Wt[name + "_dense.weight"], Wt[name + "_dense.bias"], Out[:, (k + 1) * d:(k + 2) * d], c, Nar))
+            off += D
+        ops.linear_fwd_batched(problems)
+        nu = own.rows(q)[0]
+        Y = torch.empty(mine, Cy, dtype=torch.float32, device=dev)
+        wu, wi = m._fusion_weights(Wt)
+        head = []
+        if nu:
+            head.append((Out[:nu], wu, Wt["embedding_user_after_GCN.bias"], Y[:nu, :d]))
+        if mine > nu:
+            head.append((Out[nu:], wi, Wt["embedding_item_after_GCN.bias"], Y[nu:, :d]))
+        for h, name in enumerate(m._mods):
+            blk = slice((h + 1) * d, (h + 2) * d)
+            head.append((Out[:, blk], Wt["s_dense_%s.weight" % name], Wt["s_dense_%s.bias" % name], Y[:, blk]))
+        ops.linear_fwd_batched(head)
+        Yu = coll.all_gather_rows(Y[:nu].contiguous(), [own.rows(o)[0] for o in range(W)])          # [U x Cy]
+        Yshard = torch.cat([Yu, Y[nu:]]).contiguous()
+        i0, i1 = int(own.ib[q]), int(own.ib[q + 1])
+        m._eval_shard = ItemShardScorer(HipShardBackend(m, Yshard, i0, i1), coll, own.ib)
+        m._eval_shard_Y = Yshard
+        m._publish_cache(Yshard, dirty=False)
 
     # ------------------------------------------------------------------ checkpoint / resume (full, rank-independent tensors)
     @torch.no_grad()

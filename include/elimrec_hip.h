@@ -457,6 +457,21 @@ size_t elimrec_score_workspace_topk(int B, int64_t U, int64_t I, int S, int K); 
  * when the call takes the chunked form, else the full [B x I] layout -- one predicate inside the library decides both, so
  * any recdim and any K the reference accepts (models/EliMRec.py:96-113) get a workspace that fits. */
 size_t elimrec_score_workspace_for(int B, int64_t U, int64_t I, int S, int K, int d, int want_scores);
+/* Item-sharded evaluation (last row; reference: models/EliMRec.py:96-113 scores the whole catalogue, the
+ * mean of :107 runs over all items; evaluator/backend/cpp/uni_evaluator.py:131-185 ranks it): this rank holds the cached rows
+ * of items [id_offset, id_offset + I) of I_total -- d_Y = [all U user rows ; MY I item rows], train_items already restricted
+ * to my range and shifted to local ids. phase 1 (TIE only, otherwise a no-op): d_row_sum[b] = sum over MY items of
+ * sigmoid(u.i), summed in fixed order; the caller adds the shards' sums (all_reduce over xGMI). phase 2: scores / top-K of
+ * my items with the row mean d_row_sum[b] / I_total; top-K ids are catalogue ids (local id + id_offset). The K best of the
+ * whole catalogue are elimrec_topk_merge of the shards' lists. Workspace as for elimrec_score_topk with I = my item count. */
+int elimrec_score_topk_shard(const float *d_Y, int64_t ldy, int64_t U, int64_t I, const int64_t *d_users, int B, int recdim,
+                             int S, uint32_t head_mask, int fusion_mode, int predict_type, const float *d_sqnorm,
+                             const int64_t *d_train_ptr, const int32_t *d_train_items, float *d_scores, int64_t lds, int K,
+                             int32_t *d_topk_idx, float *d_topk_val, void *d_workspace, size_t workspace_bytes, int phase,
+                             float *d_row_sum, int64_t I_total, int64_t id_offset, void *stream);
+/* d_cand_val / d_cand_idx [B x n_cand] (idx < 0: no candidate) -> per row the K best by (score desc, item id asc). */
+int elimrec_topk_merge(const float *d_cand_val, const int32_t *d_cand_idx, int B, int n_cand, int K, int32_t *d_topk_idx,
+                       float *d_topk_val, void *stream);
 /* Evaluation math of the scorer: 0 = EXACT (IEEE division, libm expf), 1 = FAST (default: sigmoids through v_exp_f32 with
  * a two-float argument product and v_rcp_f32 + one Newton step, reciprocal norms refined the same way -- every factor
  * within ~2 ulp of the EXACT form, scores within 1.2e-7 absolute, a validation pass 19 % shorter). Both are within 1e-6 of

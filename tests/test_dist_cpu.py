@@ -505,3 +505,114 @@ def test_column_shard_ranks_equal_single_process_big_batch(tmp_path, world):
     dl = d // world
     n_tail = sum(rs[0][k].size for k in rs[0] if k not in ("losses", "shard", "xgmi"))
     assert list(rs[0]["xgmi"]) == [4 * R * (world - 1), 4 * R * 2 * dl * (world - 1), 4 * R * 2 * dl * (world - 1), 4 * n_tail]
+
+
+# ----------------------------------------------------------------------------- item-sharded evaluation (shard_eval.py)
+class TorchShardBackend(object):
+    """ItemShardScorer's backend restated with the oracle's predict() formulas on one item block (tests only): the
+    oracle object holds ALL users' cached rows and the rows of items [i0, i1)."""
+
+    def __init__(self, om, i0, i1):
+        self.om, self.i0, self.i1 = om, i0, i1
+
+    def _ui(self, users):
+        return torch.sigmoid(self.om.all_users[users] @ self.om.all_items.t())
+
+    def row_sums(self, users):
+        return self._ui(users).sum(1) if self.om.predict_type == "TIE" else None
+
+    def score(self, users, row_sum, K, ptr, items, want_scores):
+        om, ui = self.om, self._ui(users)
+        if om.predict_type == "TIE":
+            mean = (row_sum / float(self.n_total)).view(-1, 1)
+            sc = torch.sigmoid(om.general_cm_fusion(ui, users) - om.general_cm_fusion(mean, users))
+        elif om.predict_type == "TE":
+            sc = torch.sigmoid(om.general_cm_fusion(ui, users))
+        else:
+            sc = torch.sigmoid(ui)
+        sc = sc.clone()
+        if ptr is not None:
+            for b in range(len(users)):
+                sc[b, items[ptr[b]:ptr[b + 1]].long()] = -float("inf")
+        if not K:
+            return sc, None, None
+        order = torch.from_numpy(np.argsort(-sc.numpy(), axis=1, kind="stable")[:, :K].copy())
+        return (sc if want_scores else None), (order + self.i0).to(torch.int32), torch.gather(sc, 1, order)
+
+    def merge(self, cand_val, cand_idx, K):
+        key = np.lexsort((cand_idx.numpy(), -cand_val.numpy()), axis=1)[:, :K]        # score desc, then id asc
+        key = torch.from_numpy(key.copy())
+        return torch.gather(cand_idx, 1, key), torch.gather(cand_val, 1, key)
+
+
+def _eval_worker(rank, world, port, out_dir, ptype):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from elimrec_amd.lookup import RowOwnerMap
+    from elimrec_amd.shard_eval import Collectives, ItemShardScorer
+    from helpers import csr_dict
+    g = load_golden("ml3")
+    om = OracleEngine(g).m
+    om.predict_type = ptype
+    cache = sub(g, "cache")
+    own = RowOwnerMap(om.U, om.I, world)
+    i0, i1 = int(own.ib[rank]), int(own.ib[rank + 1])
+    om.set_cache(cache["all_users"], cache["all_items"][i0:i1],
+                 {k: (v[i0:i1] if "_item_" in k else v) for k, v in cache.items() if k.startswith("pre_fusion")})
+    backend = TorchShardBackend(om, i0, i1)
+    backend.n_total = om.I
+    scorer = ItemShardScorer(backend, Collectives(), own.ib)
+    users = torch.from_numpy(g["evalbatch/users"]).long()
+    train = csr_dict(g, "train")
+    lists = [train.get(int(u), []) for u in users.tolist()]
+    ptr = torch.zeros(len(users) + 1, dtype=torch.int64)
+    ptr[1:] = torch.tensor(np.cumsum([len(x) for x in lists]))
+    items = torch.tensor([i for x in lists for i in x], dtype=torch.int32)
+    K = int(g["evalbatch/top_k"])
+    idx, val = scorer.topk(users, K, ptr, items)
+    full = scorer.scores(users, ptr, items)
+    np.savez(os.path.join(out_dir, "eval%d.npz" % rank), idx=idx.numpy(), val=val.numpy(), scores=full.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ptype", ["TIE", "TE"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_item_sharded_evaluation_equals_whole_catalogue(tmp_path, world, ptype):
+    """shard_eval.ItemShardScorer under gloo (a torch backend built from the oracle's predict() formulas): every rank holds
+    1/world of the item rows, phase-1 row sums are all-reduced into the catalogue-wide NDE mean, per-shard top-K lists are
+    all-gathered and merged by (score desc, id asc). All ranks end with the same lists; they are the reference fixture's
+    masked score matrix ranked under that rule, and the gathered score matrix is that matrix (1e-6)."""
+    from helpers import csr_dict
+    port = 36500 + (os.getpid() % 2000) + world + (10 if ptype == "TE" else 0)
+    mp.spawn(_eval_worker, args=(world, port, str(tmp_path), ptype), nprocs=world, join=True)
+    rs = [dict(np.load(tmp_path / ("eval%d.npz" % r))) for r in range(world)]
+    for r in rs[1:]:
+        assert np.array_equal(r["idx"], rs[0]["idx"]) and np.array_equal(r["val"], rs[0]["val"])
+    g = load_golden("ml3")
+    K = int(g["evalbatch/top_k"])
+    if ptype == "TIE":
+        ref = g["evalbatch/masked_scores"]                       # the reference's own predict() + train mask
+    else:
+        om = OracleEngine(g).m
+        om.predict_type = "TE"
+        c = sub(g, "cache")
+        om.set_cache(c["all_users"], c["all_items"], {k: v for k, v in c.items() if k.startswith("pre_fusion")})
+        ref = om.predict(g["evalbatch/users"]).numpy().copy()
+        train = csr_dict(g, "train")
+        for b, u in enumerate(g["evalbatch/users"].tolist()):
+            ref[b, train.get(int(u), [])] = -np.inf
+    got = rs[0]["scores"]
+    assert np.array_equal(np.isinf(got), np.isinf(ref))
+    fin = ~np.isinf(ref)
+    assert np.abs(got[fin] - ref[fin]).max() < 1e-6
+    order = np.argsort(-got, axis=1, kind="stable")[:, :K]
+    assert np.array_equal(rs[0]["idx"], order)                    # the merged lists rank the gathered matrix exactly
+    ref_order = np.argsort(-ref, axis=1, kind="stable")[:, :K]
+    moved = (order != ref_order).any(1)
+    for r in np.nonzero(moved)[0]:                                # ... and the reference's, up to sub-1e-6 near-ties
+        assert np.abs(ref[r][order[r]] - ref[r][ref_order[r]]).max() < 1e-6
+    assert moved.sum() <= max(1, len(order) // 20)

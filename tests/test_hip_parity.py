@@ -1217,3 +1217,59 @@ def test_topk_only_workspace_fits_any_recdim_and_k(d, K):
     order = np.argsort(-sc, axis=1, kind="stable")[:, :K]
     assert np.array_equal(idx.cpu().numpy(), order)
     assert np.array_equal(val.cpu().numpy(), np.take_along_axis(sc, order, 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,ptype,W", [(64, "TIE", 3), (64, "TE", 2), (48, "TIE", 4), (128, "TIE", 2), (32, "normal", 5)])
+def test_item_sharded_scoring_equals_whole_catalogue(d, ptype, W, eval_math):
+    """elimrec_score_topk_shard on W emulated item shards (uneven blocks): phase 1 row sums added in rank order (the
+    all_reduce), phase 2 scores / top-K per shard, elimrec_topk_merge of the W lists. The concatenated shard scores equal
+    the whole-catalogue call's to 2e-7 (the NDE mean is the same sum split into W fixed-order partial sums), masks land on
+    the same items, and the merged top-K IS the stable (score desc, id asc) ranking of those scores."""
+    from elimrec_amd import ops
+    U, I, S, K, B = 90, 7000, 3, 20, 70
+    g = torch.Generator().manual_seed(d + W)
+    Y = (torch.randn(U + I, (1 + S) * d, generator=g) * 0.3).to(DEV)
+    users = torch.randperm(U, generator=g)[:B].to(DEV)
+    rng = np.random.default_rng(1)
+    lists = [sorted(rng.choice(I, size=int(rng.integers(0, 60)), replace=False).tolist()) for _ in range(B)]
+    ptr = np.zeros(B + 1, np.int64); ptr[1:] = np.cumsum([len(x) for x in lists])
+    items = np.array([i for x in lists for i in x], np.int32)
+    whole = torch.empty(B, I, device=DEV)
+    ws = torch.empty(ops.score_workspace(B, U, I, S, K), dtype=torch.uint8, device=DEV)
+    ops.score_topk(Y, U, I, users, d, S, 0b111, "rubi", ptype, ws, scores=whole, train_ptr=_t(ptr), train_items=_t(items))
+    bounds = [0] + sorted(rng.choice(np.arange(200, I - 200), size=W - 1, replace=False).tolist()) + [I]
+    shards = []
+    for o in range(W):
+        i0, i1 = bounds[o], bounds[o + 1]
+        Ysh = torch.cat([Y[:U], Y[U + i0:U + i1]]).contiguous()
+        lp = np.zeros(B + 1, np.int64)
+        loc = [[i - i0 for i in x if i0 <= i < i1] for x in lists]
+        lp[1:] = np.cumsum([len(x) for x in loc])
+        li = np.array([i for x in loc for i in x] + [0], np.int32)
+        wsp = torch.empty(ops.score_workspace(B, U, i1 - i0, S, K), dtype=torch.uint8, device=DEV)
+        shards.append((i0, i1, Ysh, _t(lp), _t(li), wsp))
+    total = torch.zeros(B, device=DEV)
+    for i0, i1, Ysh, lp, li, wsp in shards:                                   # phase 1 + the all_reduce, in rank order
+        part = torch.zeros(B, device=DEV)
+        ops.score_topk_shard(Ysh, U, i1 - i0, users, d, S, 0b111, "rubi", ptype, wsp, 1, part, I, i0)
+        total += part
+    cols, cand_i, cand_v = [], [], []
+    for i0, i1, Ysh, lp, li, wsp in shards:
+        sc = torch.empty(B, i1 - i0, device=DEV)
+        idx = torch.empty(B, K, dtype=torch.int32, device=DEV)
+        val = torch.empty(B, K, device=DEV)
+        ops.score_topk_shard(Ysh, U, i1 - i0, users, d, S, 0b111, "rubi", ptype, wsp, 2, total, I, i0, scores=sc, K=K,
+                             topk_idx=idx, topk_val=val, train_ptr=lp, train_items=li)
+        cols.append(sc); cand_i.append(idx); cand_v.append(val)
+    sharded = torch.cat(cols, dim=1).cpu().numpy()
+    w = whole.cpu().numpy()
+    assert np.array_equal(np.isinf(sharded), np.isinf(w))
+    fin = ~np.isinf(w)
+    assert np.abs(sharded[fin] - w[fin]).max() < 2e-7
+    out_i = torch.empty(B, K, dtype=torch.int32, device=DEV)
+    out_v = torch.empty(B, K, device=DEV)
+    ops.topk_merge(torch.stack(cand_v, 1).reshape(B, W * K).contiguous(), torch.stack(cand_i, 1).reshape(B, W * K).contiguous(), K, out_i, out_v)
+    order = np.argsort(-sharded, axis=1, kind="stable")[:, :K]
+    assert np.array_equal(out_i.cpu().numpy(), order)
+    assert np.array_equal(out_v.cpu().numpy(), np.take_along_axis(sharded, order, 1))

@@ -766,8 +766,17 @@ def _two_proc_worker(rank, world, port, out_dir, feature_shard="replicated"):
     if feature_shard == "row":
         assert tr.lookup and tr.lookup_syncs == 1 and tr.xgmi_bytes["all_to_all_lookup"] > 0
         assert eng.fshard.table.shape[0] < model.num_users + model.num_items
+    # validation on the tables of the last forward: user-sharded with replicated tables, ITEM-sharded with row shards
+    model.fusion_mode, model.predict_type = "rubi", "TIE"
+    res, _ = model.test()
+    users = g["eval_users"].tolist()
+    pred = model.predict(users).numpy()
+    if feature_shard == "row":
+        assert model._eval_shard is not None and model._eval_shard_Y.shape[0] < model.num_users + model.num_items
+        with pytest.raises(RuntimeError):
+            model.all_items
     eng.sync_to_model()
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), losses=np.array(losses),
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), losses=np.array(losses), eval_result=res, predict=pred,
              **{k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
     dist.destroy_process_group()
 
@@ -796,10 +805,16 @@ def test_two_processes_on_one_gpu_equal_one_process(tmp_path, feature_shard):
         u, p, n = (_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg"))
         mlen = (len(u) // world) * world
         losses.append(float(tr.step(u[:mlen], p[:mlen], n[:mlen])))
+    model.fusion_mode, model.predict_type = "rubi", "TIE"
+    res, _ = model.test()
+    pred = model.predict(g["eval_users"].tolist()).numpy()
     eng.sync_to_model()
     assert np.allclose(rs[0]["losses"], losses, atol=1e-5)
     for k, v in model.state_dict().items():
         assert np.abs(rs[0][k] - v.detach().cpu().numpy()).max() < 2e-5, k
+    # evaluation of the two-process job (item-sharded when the constants are row-sharded) == one process
+    assert np.abs(rs[0]["predict"] - pred).max() < 2e-6
+    assert np.abs(rs[0]["eval_result"] - res).max() < 1e-7, (rs[0]["eval_result"], res)
 
 
 # ----------------------------------------------------------------------------- one-rank RCCL group, multi-rank code path
