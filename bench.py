@@ -84,11 +84,11 @@ def build(args, device, extra_argv=()):
     return cfg, ds, model
 
 
-def cpu_baseline(ds, model_cpu_state, cfg, batches, thread_counts=(8, 16, 32), timed_steps=5):
+def cpu_baseline(ds, model_cpu_state, cfg, batches, thread_counts=(8, 16, 32, 64, 128, 1 << 20), timed_steps=5):
     """The oracle (CPU restatement of the reference step, pinned to the reference by tests/test_oracle_golden.py and
     calibrated against the reference's own step time in BASELINE.md) on this box's host cores: one warm-up step, one
-    probe step per candidate thread count, then `timed_steps` steps at the fastest count (torch.sparse.mm, 84 % of the
-    reference's step, stops scaling long before 256 threads)."""
+    probe step per candidate thread count -- 8, 16, 32, 64, 128 and ALL host cores -- then `timed_steps` steps at the fastest
+    count (torch.sparse.mm, 84 % of the reference's step, stops scaling long before 256 threads: the probe shows it)."""
     import torch
     from oracle import elimrec_oracle as eo
     ncpu = os.cpu_count() or 1
@@ -108,6 +108,8 @@ def cpu_baseline(ds, model_cpu_state, cfg, batches, thread_counts=(8, 16, 32), t
         t0 = time.time()
         eo.train_step(om, opt, *batches[(1 + k) % len(batches)])
         probe[c] = round(time.time() - t0, 3)
+        if probe[c] > 1.5 * min(probe.values()):      # past the knee (a step at ALL 256 cores measured 63 s against 1.2 s at 32):
+            break                                     # larger counts are not probed, the sample text says where it stopped
     best = min(probe, key=probe.get)
     torch.set_num_threads(best)
     ts = []
@@ -117,8 +119,9 @@ def cpu_baseline(ds, model_cpu_state, cfg, batches, thread_counts=(8, 16, 32), t
         ts.append(time.time() - t0)
     mean = sum(ts) / len(ts)
     return dict(value=B / mean, unit="triplets/s", cores=best, kind="port", host_cpus=ncpu,
-                sample="1 warm-up + 1 probe step per thread count %s (s/step %s), then %d timed full training steps (B=%d, same "
-                       "workload) at %d threads: %s s" % (counts, probe, timed_steps, B, best, [round(t, 3) for t in ts]),
+                sample="1 warm-up + 1 probe step per thread count of %s up to the first that is 1.5x slower than the best (s/step %s; "
+                       "all %d cores in one step measured 62.7 s, profiles/README.md), then %d timed full training steps (B=%d, same "
+                       "workload) at %d threads: %s s" % (counts, probe, ncpu, timed_steps, B, best, [round(t, 3) for t in ts]),
                 ms_per_step=1e3 * mean)
 
 
@@ -145,6 +148,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-work", action="store_true", help="skip the reference-equivalent-work line")
     ap.add_argument("--no-bf16", action="store_true", help="skip the bf16-storage line")
+    ap.add_argument("--feature-shard", choices=["auto", "row", "replicated"], default="auto",
+                    help="folded constants S_m / c: row-sharded with an all_to_all lookup (default for N > 1, the north star's "
+                         "partition) or replicated on every rank (default for N = 1, where both are the same tables)")
+    ap.add_argument("--feature-dtype", choices=["f32", "f16", "bf16"], default="f32", help="storage of the folded constants")
+    ap.add_argument("--no-b-sweep", action="store_true", help="skip the batch-size sweep line")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -181,7 +189,8 @@ def main():
     from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam, PairwiseSamplerV2, slab
     B = WORKLOAD["batch_size"]
     opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
-    eng = ColumnShardEngine(model)
+    fshard = args.feature_shard if args.feature_shard != "auto" else ("row" if world > 1 else "replicated")
+    eng = ColumnShardEngine(model, feature_shard=fshard, feature_dtype=args.feature_dtype)
     trainer = ColumnShardTrainer(eng, opt, world_size=world, rank=rank)
 
     # triplets for every step, sampled on the device and resident in HBM before the timed region
@@ -198,6 +207,16 @@ def main():
         if world > 1:
             dist.barrier()
             torch.cuda.synchronize()
+
+    # row-sharded constants: the split sizes of every batch's row exchange are planned ahead, as main.py does once per epoch
+    # (one device pass over the epoch's triplets + one all_gather; timed here, outside the step loop like the sampler)
+    plan_ms = None
+    if trainer.lookup and trainer.multi:
+        sync()
+        t_plan = time.perf_counter()
+        trainer.plan_lookup(batches)
+        torch.cuda.synchronize()
+        plan_ms = 1e3 * (time.perf_counter() - t_plan) / len(batches)
 
     for i in range(args.warmup):
         trainer.step(*batches[i])
@@ -245,7 +264,12 @@ def main():
             "config": {"workload": WORKLOAD["name"], "num_users": ds.num_users, "num_items": ds.num_items,
                        "train_interactions": int(ds.train_matrix.nnz), "feat_dims": list(WORKLOAD["feat_dims"]),
                        "recdim": WORKLOAD["recdim"], "layer_num": WORKLOAD["layer_num"], "batch_per_gpu": B,
-                       "global_batch": B * world, "parallelism": "colshard%d" % world + ("-multi-rank-path" if multi_path else ""),
+                       "global_batch": B * world, "parallelism": "colshard%d" % world + ("-multi-rank-path" if multi_path else "") +
+                                                                ("+rowshard-features" if fshard == "row" and world > 1 else ""),
+                       "graph_table": "column-sharded (%d of %d columns per rank): hops need no communication" % (eng.dl, WORKLOAD["recdim"]),
+                       "feature_tables": ("row-sharded S_m / c (1/%d of the users' and items' rows per rank), all_to_all id lookup of the "
+                                          "active rows per step" % world) if fshard == "row" and world > 1 else "replicated S_m / c",
+                       "feature_dtype": args.feature_dtype,
                        "columns_per_gpu": eng.dl, "slabs": [eng.ns, eng.w, eng.gs],
                        "propagation": "folded", "head_rows": "batch", "final_loss": final_loss},
             # bytes THIS implementation's step has to move per rank (closed form) and the fraction of
@@ -277,6 +301,9 @@ def main():
         }
         if world > 1:
             out["xgmi_bytes_sent_per_rank_step"] = trainer.xgmi_bytes
+            if plan_ms is not None:
+                out["lookup"] = {"plan_ms_per_batch": plan_ms, "steps_that_synchronised_for_split_sizes": trainer.lookup_syncs,
+                                 "row_bytes": eng.lookup_row_bytes, "shard_bytes_per_rank": eng.fshard.nbytes()}
         def extra(key, fn):          # the secondary lines never cost the headline: a failure is reported in place
             try:
                 out[key] = fn()
@@ -288,6 +315,11 @@ def main():
             extra("reference_equivalent_work", lambda: reference_work_line(args, device, cfg, batches, torch))
         if world == 1 and not args.no_bf16:
             extra("bf16_storage", lambda: bf16_line(args, device, cfg, batches, torch))
+        if world == 1 and not args.no_b_sweep:
+            extra("batch_sweep", lambda: batch_sweep(trainer, sampler, pools, B, torch))
+        mu = pmc_field("mfma_utilisation")
+        if mu is not None:
+            out["mfma_utilisation"] = mu
         if not args.no_cpu_baseline and world == 1:     # the host baseline is timed on rank 0 at N=1 only
             cpu_batches = [tuple(x.cpu() for x in b) for b in batches[:5]]
             extra("cpu_baseline", lambda: cpu_baseline(ds, {k: v.cpu().numpy() for k, v in init_state.items()}, cfg, cpu_batches))
@@ -295,6 +327,39 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def batch_sweep(trainer, sampler, pools, B0, torch, sizes=(2048, 4096, 8192, 16384, 32768), steps=20, warmup=3):
+    """One GPU, the same engine: the step at growing batch sizes. A step is O(graph) + O(B): the hops, the adjoint and Adam do
+    not depend on B, everything at the active rows does -- so triplets/s rises with B on ONE GPU, and a multi-GPU "weak
+    scaling" number (B triplets per GPU) has to be read against this curve, not against the B = 2048 point alone."""
+    import time as _t
+    out = []
+    for B in sizes:
+        need = (steps + warmup) * B
+        while sum(p[0].numel() for p in pools) < need:
+            pools.append(sampler.sample_epoch())
+        U_, P_, N_ = (torch.cat([p[i] for p in pools]) for i in range(3))
+        bs = [(U_[i * B:(i + 1) * B], P_[i * B:(i + 1) * B], N_[i * B:(i + 1) * B]) for i in range(steps + warmup)]
+        for b in bs[:warmup]:
+            trainer.step(*b)
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        for b in bs[warmup:]:
+            trainer.step(*b)
+        torch.cuda.synchronize()
+        dt = (_t.perf_counter() - t0) / steps
+        out.append({"batch": B, "ms_per_step": 1e3 * dt, "triplets_per_s": B / dt})
+    return {"what": "same engine, one GPU, %d timed steps per size" % steps, "sizes": out}
+
+
+def pmc_field(key, name="r03_pmc_traffic.json"):
+    """A field of the committed PMC summary (profiles/), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f).get(key)
+    except Exception:
+        return None
 
 
 def pmc_traffic():

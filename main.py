@@ -150,6 +150,9 @@ class Net(object):
         # the column-shard engine returns views into a ring of loss slots: an epoch longer than the ring keeps copies
         ring = getattr(self.engine, "loss_ring_len", 0) if self.engine is not None else 0
         keep = (lambda t: t.clone()) if ring and len(batches) >= ring else (lambda t: t)
+        if self.trainer is not None and getattr(self.trainer, "lookup", False) and getattr(self.trainer, "multi", False):
+            batches = list(batches)                   # row-sharded constants: this epoch's lookup split sizes, planned ahead
+            self.trainer.plan_lookup(batches)
         on_device = torch.stack([keep(step(users, pos, neg)) for users, pos, neg in batches])
         if self.world > 1:
             import torch.distributed as dist
