@@ -180,7 +180,8 @@ struct RowsArgs {
     int nc4, w4, w4_shift;
     const float4 *long_tab;
     int n_long;
-    const int32_t *long_index, *rowptr, *col;
+    const int32_t *long_index, *col;
+    const int64_t *rowptr;          // plain CSR row pointers: 64-bit (a 2e9-non-zero graph, BASELINE.json configs[4])
     const float *val;
     const int32_t *rows, *counts;
     int64_t R;
@@ -219,7 +220,8 @@ __global__ __launch_bounds__(256) void slab_rows_kernel(RowsArgs a) {
     };
     const float4 *xL = layer(a.L), *xLm1 = layer(a.L - 1);
     const bool inline_hop = xL == nullptr;
-    int li = -1, beg = 0, end = 0;
+    int li = -1;
+    int64_t beg = 0, end = 0;
     if (inline_hop) {
         li = a.long_index[r];
         if (li < 0) { beg = a.rowptr[r]; end = a.rowptr[r + 1]; }
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256) void slab_rows_kernel(RowsArgs a) {
         else {
             const float4 *X = xLm1 + (int64_t)slab * a.n_rows * a.w4 + c4;
             xl = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int j = beg; j < end; j += U8) {
+            for (int64_t j = beg; j < end; j += U8) {
                 int cj[U8];
                 float vj[U8];
                 float4 x[U8];
@@ -522,7 +524,8 @@ struct Rows16Args {
     int nc8, w8, w8_shift;
     const float4 *long_tab;
     int n_long;
-    const int32_t *long_index, *rowptr, *col;
+    const int32_t *long_index, *col;
+    const int64_t *rowptr;          // plain CSR row pointers: 64-bit (a 2e9-non-zero graph, BASELINE.json configs[4])
     const float *val;
     const int32_t *rows, *counts;
     int64_t R;
@@ -549,7 +552,8 @@ __global__ __launch_bounds__(256) void slab_rows16_kernel(Rows16Args a) {
     }
     const bool user = r < a.U;
     const bool inline_hop = a.x[a.L] == nullptr;
-    int li = -1, beg = 0, end = 0;
+    int li = -1;
+    int64_t beg = 0, end = 0;
     if (inline_hop) {
         li = a.long_index[r];
         if (li < 0) { beg = a.rowptr[r]; end = a.rowptr[r + 1]; }
@@ -568,7 +572,7 @@ __global__ __launch_bounds__(256) void slab_rows16_kernel(Rows16Args a) {
             const int64_t base = (int64_t)slab * a.n_rows * a.w8 + c8;
 #pragma unroll
             for (int t = 0; t < 8; ++t) xl[t] = 0.f;
-            for (int j = beg; j < end; j += 4) {
+            for (int64_t j = beg; j < end; j += 4) {
                 int cj[4];
                 float vj[4];
 #pragma unroll
@@ -1015,7 +1019,8 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(AdamJobs jobs, float be
 // Every sum has a fixed order, so results are bitwise reproducible; rows above T differ in round-off from forms 0-2.
 struct TierArgs {
     StreamArgs s;
-    const int32_t *tile_off, *tile_len, *tile_dst, *tile_long, *tcol, *long_index;
+    const int64_t *tile_off;       // first index entry of a tile: 64-bit (>= 2^31 entries at configs[4])
+    const int32_t *tile_len, *tile_dst, *tile_long, *tcol, *long_index;
     const float *tval;
     int n_w4;                      // workgroup rows (4 tiles each)
     int t1_base, tseg_base, tfin_base, n_tiles;     // first tile of the wave rows, segment tiles, unsplit-row tiles
@@ -1031,7 +1036,7 @@ struct TierArgs {
 // cost a scattered load instruction per 64/LPR neighbours -- as many memory instructions as the gathers of a full hop,
 // on the pipeline that bounds it -- so the bitmap is looked up ONCE per index entry by this pass (coalesced index read,
 // L1-resident bitmap) and the hop kernel reads one 64-bit word per index line through the scalar cache.
-__global__ __launch_bounds__(256) void tile_ballot_kernel(const int32_t *__restrict__ tile_off, const int32_t *__restrict__ tcol,
+__global__ __launch_bounds__(256) void tile_ballot_kernel(const int64_t *__restrict__ tile_off, const int32_t *__restrict__ tcol,
                                                           const uint32_t *__restrict__ mask, int G, int n_tiles, int kmax,
                                                           uint64_t *__restrict__ ballots) {
     // a wave per (tile, index line): blockIdx.y = line, so every wave is one short independent chain
@@ -1039,8 +1044,8 @@ __global__ __launch_bounds__(256) void tile_ballot_kernel(const int32_t *__restr
     const int ti = __builtin_amdgcn_readfirstlane((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6));
     const int k = (int)blockIdx.y;
     if (ti >= n_tiles) return;
-    const int off = tile_off[ti];
-    const int nk = (tile_off[ti + 1] - off + 63) >> 6;
+    const int64_t off = tile_off[ti];
+    const int nk = (int)((tile_off[ti + 1] - off + 63) >> 6);
     if (k >= nk) return;
     const int cidx = tcol[off + (k << 6) + lane];
     const uint64_t b = __ballot(bit_of(mask, cidx));
@@ -1077,7 +1082,7 @@ __device__ __forceinline__ void tile_batch(const StreamArgs &a, int64_t in_base,
 // holds LPR steps of the G groups; a batch is UB steps: a part of a line (LPR >= UB) or UB/LPR whole lines (narrow
 // row pieces: column shards).
 template <int LPR, int VPL, bool IN_BF16, bool MASKED>
-__device__ __forceinline__ void tile_gather(const TierArgs &t, int ti, int64_t in_base, int off, int steps, int glen, int lane, int sub,
+__device__ __forceinline__ void tile_gather(const TierArgs &t, int ti, int64_t in_base, int64_t off, int steps, int glen, int lane, int sub,
                                             float (&acc)[VPL]) {
     constexpr int G = 64 / LPR;
 #ifdef ELIMREC_TILE_UB
@@ -1188,10 +1193,11 @@ __device__ __forceinline__ void tier_body(const TierArgs &t, float *lds = nullpt
     float *s_part = EXT_LDS ? lds : s_own;                  // 4 * 64 * 8 floats
     const int ti = __builtin_amdgcn_readfirstlane(bidx * 4 + wave);       // tiles are laid out workgroup by workgroup
     const bool wg_row = bidx < t.n_w4;
-    int off = 0, steps = 0, glen = 0, dst = -1;
+    int64_t off = 0;
+    int steps = 0, glen = 0, dst = -1;
     if (ti < t.n_tiles_run) {
         off = t.tile_off[ti];
-        steps = (t.tile_off[ti + 1] - off) / G;
+        steps = (int)((t.tile_off[ti + 1] - off) / G);
         glen = t.tile_len[(int64_t)ti * G + sub];
         dst = t.tile_dst[(int64_t)ti * G + sub];
     }

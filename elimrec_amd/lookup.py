@@ -80,6 +80,40 @@ class FeatureShard(object):
         self.table = loc
         self.device = loc.device
 
+    @classmethod
+    def from_local(cls, owners, rank, local_tables, local_c, dtype="f32"):
+        """The same shard from rows this rank already holds: local_tables [own rows x D_m] fp32 in local-table order (own
+        users, then own items), local_c [own rows] -- what the distributed fold (shard.py) produces; no rank ever held the
+        full tables."""
+        self = cls.__new__(cls)
+        if dtype not in DTYPES:
+            raise ValueError("feature storage dtype must be one of %s (got %r)" % (sorted(DTYPES), dtype))
+        self.owners, self.rank, self.dtype = owners, int(rank), dtype
+        self.code, tdt = DTYPES[dtype]
+        self.dims = [int(t.shape[1]) for t in local_tables]
+        self.sum_d = sum(self.dims)
+        es = 4 if self.code == 0 else 2
+        n_c = 1 if self.code == 0 else 2
+        self.row_elems = ((self.sum_d + n_c) * es + 15) // 16 * 16 // es
+        self.row_bytes = self.row_elems * es
+        n = sum(owners.rows(self.rank))
+        dev = local_tables[0].device
+        loc = torch.zeros(n, self.row_elems, dtype=tdt, device=dev)
+        off = 0
+        for t in local_tables:
+            assert t.shape[0] == n
+            loc[:, off:off + t.shape[1]] = t.to(tdt)
+            off += t.shape[1]
+        cr = local_c.to(torch.float32)
+        if self.code == 0:
+            loc[:, off] = cr
+        else:
+            hi = cr.to(tdt)
+            loc[:, off] = hi
+            loc[:, off + 1] = (cr - hi.float()).to(tdt)
+        self.table, self.device = loc, dev
+        return self
+
     def nbytes(self):
         return self.table.numel() * self.table.element_size()
 

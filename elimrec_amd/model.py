@@ -376,7 +376,7 @@ class EliMRec(BasicModel):
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         if self.dataset_name == "tiktok" and hasattr(self, "word_embedding") and "feature_modalities" not in self.config:
             self.t_feat.copy_(self._word_bag_t_feat().to(self.t_feat.device))
-            if self._ws is not None and "fold" in self._ws:
+            if self._ws is not None and self._ws.get("fold") is not None:
                 self._fold_constants(self._ws)
                 self._regions = {}            # recorded launches hold the old constants' addresses
                 eng = self.__dict__.get("_slab_engine")
@@ -435,7 +435,10 @@ class EliMRec(BasicModel):
                         ws["act_mask"] = torch.zeros((N + 31) // 32 + 2, dtype=torch.int32, device=dev)
                         ws["layers"] = torch.empty(ops.layer_tables_workspace(N, d, self.n_layers), dtype=torch.uint8,
                                                    device=dev)
-                    self._fold_constants(ws)
+                    if self.__dict__.get("_skip_fold"):    # the column-sharded engine folds the constants itself, row-sharded
+                        ws["fold"] = None
+                    else:
+                        self._fold_constants(ws)
                     # [E_u ; E_i] and its gradient as ONE [N x d] table: the two embeddings are the first two
                     # tensors of the flat parameter / gradient buffers, back to back
                     eu, ei = self.embedding_user.weight, self.embedding_item.weight

@@ -372,13 +372,28 @@ class ColumnShardEngine(object):
         self._tail_plan = None
         self._bufs = {}
         self._x0_fwd = None
+        # where the folded constants come from: "model" = EliMRec._fold_constants (every rank computes all N rows, then keeps
+        # its own); "sharded" = the distributed fold below (no rank ever holds more than a column slice or its own rows --
+        # what BASELINE.json configs[4] needs). Default: sharded for row shards over several ranks of a real process group.
+        fold_mode = os.environ.get("ELIMREC_FOLD", "")
+        if fold_mode not in ("model", "sharded"):
+            fold_mode = "sharded" if (self.feature_shard == "row" and world > 1 and dist.is_available() and dist.is_initialized()
+                                      and dist.get_world_size(self.group) == world) else "model"
+        self.fold_mode = fold_mode
+        m._skip_fold = fold_mode == "sharded"
         ws = m._workspace(1)
         self.fshard = None
         if self.lookup:
-            fold = ws["fold"]
             owners = RowOwnerMap(m.num_users, m.num_items, world if self.feature_shard == "row" else 1)
-            self.fshard = FeatureShard(owners, rank if self.feature_shard == "row" else 0, [fold[k] for k in m._mods], fold["c"],
-                                       dtype=self.feature_dtype, device=dev)
+            frank = rank if self.feature_shard == "row" else 0
+            if fold_mode == "sharded":
+                tabs, c_loc = self._fold_sharded(owners, frank)
+                self.fshard = FeatureShard.from_local(owners, frank, tabs, c_loc, dtype=self.feature_dtype)
+            else:
+                fold = ws["fold"]
+                self.fshard = FeatureShard(owners, frank, [fold[k] for k in m._mods], fold["c"], dtype=self.feature_dtype, device=dev)
+                if self.feature_shard == "row" and world > 1 and os.environ.get("ELIMREC_KEEP_FOLD", "0") != "1":
+                    ws["fold"] = None                # the full tables are gone: every consumer goes through the shards
             self.lookup_row_bytes = self.fshard.row_bytes
             self._lookup_bufs = {}
         self.load_from_model()
@@ -888,6 +903,65 @@ class ColumnShardEngine(object):
             else:
                 jobs.append(_lib.AdamJob(base_p + 4 * o, None, None, None, None, None, snap + 4 * (o - tail_off), n, 0))
         return jobs
+
+    # ------------------------------------------------------------------ row-sharded constants: the distributed fold
+    @torch.no_grad()
+    def _horner_mean(self, x0_rows):
+        """mean_k A^k X0 of a row-major [N x cols] table with the engine's own hop kernels: t <- X0 + A t, L times, the last with
+        the 1/(L+1) scale. cols is padded to the column count per slab group of the engine's plan (the wave-tile plan is laid
+        out for that many lanes per row piece)."""
+        m, N, L = self.model, x0_rows.shape[0], self.model.n_layers
+        per_group = (self.ns // self.gs) * self.w                    # columns one lane group covers
+        cols = x0_rows.shape[1]
+        padded = (cols + per_group - 1) // per_group * per_group
+        if padded != cols:
+            x0_rows = torch.cat([x0_rows, torch.zeros(N, padded - cols, dtype=torch.float32, device=x0_rows.device)], dim=1)
+        ns, gs = padded // self.w, padded // per_group
+        mk = lambda: slab.SlabTable(N, ns, self.w, x0_rows.device)
+        x0, a, b = mk().from_rows(x0_rows.contiguous()), mk(), mk()
+        t = x0
+        for k in range(L):
+            dst = a if t is not a else b
+            slab.hop(self.plan, t, dst, gs=gs, add=x0, scale=1.0 / (L + 1) if k == L - 1 else 1.0)
+            t = dst
+        return t.dense()[:, :cols]
+
+    @torch.no_grad()
+    def _fold_sharded(self, owners, frank):
+        """S_m = mean_k A^k [0 ; F_m] and c = mean_k A^k [0 ; 1] WITHOUT any rank holding a full [N x D_m] table: the rank takes
+        its item block of the raw features (models/EliMRec.py:366-381; here a slice of the replicated buffer, with a sharded
+        loader the block it read), one all_to_all turns row blocks into COLUMN slices [I x D_m/W], every rank propagates its
+        slice through the (replicated) graph with the hop kernels -- no communication, like the training hops -- and a second
+        all_to_all hands every owner its rows of every slice. c is one column: every rank computes it, keeps its rows."""
+        from .shard_eval import Collectives
+        m, W = self.model, owners.world
+        U, I, dev = m.num_users, m.num_items, m._device()
+        q = frank
+        coll = Collectives(self.group) if W > 1 else None
+        nodes = [torch.from_numpy(owners.nodes(o)).to(dev) for o in range(W)]
+        rows = [len(n) for n in nodes]
+        i_rows = [owners.rows(o)[1] for o in range(W)]
+        i0, i1 = int(owners.ib[q]), int(owners.ib[q + 1])
+        tabs = []
+        for k in m._mods:
+            feat = getattr(m, k + "_feat")
+            D = feat.shape[1]
+            if W > 1 and D % W == 0 and (D // W) % 4 == 0:
+                Dq = D // W
+                mine = feat[i0:i1]                                                  # my item block, all columns
+                cols = coll.all_to_all_rows(torch.cat([mine[:, p * Dq:(p + 1) * Dq] for p in range(W)]).contiguous(),
+                                            [i1 - i0] * W, i_rows)                  # all items, my columns
+                x0 = torch.cat([torch.zeros(U, Dq, dtype=torch.float32, device=dev), cols])
+                S = self._horner_mean(x0)                                           # [N x Dq]
+                recv = coll.all_to_all_rows(torch.cat([S[n] for n in nodes]), rows, [rows[q]] * W).view(W, rows[q], Dq)
+                tabs.append(recv.permute(1, 0, 2).reshape(rows[q], D).contiguous())
+            else:       # a width that does not split: the whole table on every rank (small shapes), own rows kept
+                x0 = torch.cat([torch.zeros(U, D, dtype=torch.float32, device=dev), feat])
+                tabs.append(self._horner_mean(x0)[nodes[q]].contiguous())
+        ones = torch.zeros(U + I, 4, dtype=torch.float32, device=dev)
+        ones[U:, 0] = 1.0
+        c_loc = self._horner_mean(ones)[nodes[q], 0].contiguous()
+        return tabs, c_loc
 
     # ------------------------------------------------------------------ row-sharded constants: the lookup's device steps
     def cs_lookup_counts(self, acts):

@@ -76,8 +76,9 @@ class SellPlan(object):
         m = m.tocsr()
         m.sort_indices()
         n_rows, n_src = m.shape
-        if m.nnz >= 2 ** 31 - 2 ** 24:
-            raise ValueError("graph too large for int32 SELL offsets")
+        if max(n_rows, n_src) >= 2 ** 31 - 1:
+            raise ValueError("node ids must fit int32 (%d x %d matrix)" % (n_rows, n_src))
+        # offsets into the index arrays (tile_off, rowptr) are int64: >= 2^31 non-zeros build (BASELINE.json configs[4]: 2e9)
         rowptr = m.indptr.astype(np.int64)
         col = m.indices.astype(np.int32)
         val = m.data.astype(np.float32)
@@ -121,12 +122,13 @@ class SellPlan(object):
         self.tiered, self.n_w1, self.n_w4 = bool(tiered), int(len(w1)), int(len(w4))
         self.t = dict(long_rows=t(long_rows if len(long_rows) else np.zeros(1), np.int32),
                       long_seg_ptr=t(seg_ptr, np.int32), long_index=t(long_index, np.int32),
-                      rowptr=t(rowptr, np.int32), csr_col=t(col if len(col) else np.zeros(1), np.int32),
+                      rowptr=t(rowptr, np.int64), csr_col=t(col if len(col) else np.zeros(1), np.int32),
                       csr_val=t(val if len(val) else np.zeros(1), np.float32))
         p = lambda k: self.t[k].data_ptr() if k in self.t else None
         if tiered:
             tiles = self._wave_tiles(int(ipw), rowptr, col, val, deg, w4, w1, seg_beg[so], seg_len[so], so, seg_row[so], short_rows[ro])
-            self.t.update({k: t(v, np.float32 if k == "tile_val" else np.int32) for k, v in tiles.items() if k.startswith("tile_")})
+            self.t.update({k: t(v, np.float32 if k == "tile_val" else (np.int64 if k == "tile_off" else np.int32))
+                           for k, v in tiles.items() if k.startswith("tile_")})
             self.n_items = self.n_seg_items = 0
             self.sell_entries, self.sell_seg_entries = tiles["entries"], tiles["seg_entries"]
             self.n_tiles = tiles["n_t4"] + tiles["n_t1"] + tiles["n_tseg"] + tiles["n_tfin"]
@@ -218,9 +220,7 @@ class SellPlan(object):
         GB, GL, GS, GD = (np.concatenate([a, b, c, d]) for a, b, c, d in zip(A, B, C, D))
         steps = GL.max(1) if len(GL) else np.zeros(0, i64)
         tile_off = np.concatenate([[0], np.cumsum(steps * G)]).astype(i64)
-        total = int(tile_off[-1])
-        if total + 128 >= 2 ** 31:
-            raise ValueError("graph too large for int32 tile offsets")
+        total = int(tile_off[-1])          # may exceed 2^31: tile_off is int64 on the device too
         tcol = np.zeros(total + 128, np.int32)                         # a wave reads whole 64-entry lines past its tile
         tval = np.zeros(total + 128, np.float32)
         glf, gbf, gsf = GL.reshape(-1), GB.reshape(-1), GS.reshape(-1)
@@ -252,7 +252,7 @@ class SellPlan(object):
     def index_bytes(self):
         """Bytes of index data one pass of a hop reads (SELL col + val, item records, block offsets)."""
         if self.tiered:
-            return 8 * self.sell_entries + (8 * self.tile_groups + 4) * self.n_tiles
+            return 8 * self.sell_entries + (8 * self.tile_groups + 8) * self.n_tiles
         return 8 * self.sell_entries + 8 * self.n_items + 4 * (self.n_items // 64 + 1)
 
 

@@ -543,14 +543,15 @@ typedef struct elimrec_sell {
     const int32_t *d_long_rows;     /* [n_long] ascending                                               */
     const int32_t *d_long_seg_ptr;  /* [n_long + 1] partial slots of each split row                     */
     const int32_t *d_long_index;    /* [n_rows] index into d_long_rows, -1 for unsplit rows             */
-    const int32_t *d_rowptr;        /* plain CSR of the same matrix (row-list evaluation)               */
+    const int64_t *d_rowptr;        /* plain CSR of the same matrix (row-list evaluation); 64-bit: a graph of >= 2^31
+                                     * non-zeros (BASELINE.json configs[4]: 2e9) keeps int32 NODE ids but not int32 offsets */
     const int32_t *d_csr_col;
     const float *d_csr_val;
     const int32_t *d_item_long;     /* [n_seg_items] split row (index into d_long_rows) of a segment item; NULL
                                        selects the two-launch form (hop + fix-up) instead of the in-launch combine */
     /* tiered plan (tiered != 0; ONE launch per hop over WAVE TILES, csrc/slab.hip form 3): a tile is the work of one
      * wave of tile_groups lane groups, its index stored [step][group] in d_tile_col / d_tile_val from entry
-     * d_tile_off[tile] (int32 [n_tiles + 1], multiples of tile_groups; both arrays padded by 64 entries), with
+     * d_tile_off[tile] (int64 [n_tiles + 1], multiples of tile_groups; both arrays padded by 64 entries), with
      * d_tile_len / d_tile_dst [n_tiles x tile_groups] = neighbours of each lane group and its output row (partial
      * slot for segment tiles, -1 padding). Tile order: n_t4 = 4*n_w4 tiles of the n_w4 rows that get a workgroup
      * (contiguous quarters, d_tile_dst = the row), n_t1 tiles of the rows that get a wave (neighbours dealt round-robin
@@ -562,7 +563,8 @@ typedef struct elimrec_sell {
     int32_t tiered, n_w1, n_w4;
     int32_t tile_groups, n_t4, n_t1, n_tseg, n_tfin;
     int32_t tile_kmax;              /* most 64-entry index lines of any tile (row stride of the masked hop's bit words) */
-    const int32_t *d_tile_off, *d_tile_len, *d_tile_dst, *d_tile_long, *d_tile_col;
+    const int64_t *d_tile_off;      /* int64 [n_tiles + 1] */
+    const int32_t *d_tile_len, *d_tile_dst, *d_tile_long, *d_tile_col;
     const float *d_tile_val;
 } elimrec_sell;
 

@@ -766,6 +766,7 @@ def _two_proc_worker(rank, world, port, out_dir, feature_shard="replicated"):
     if feature_shard == "row":
         assert tr.lookup and tr.lookup_syncs == 1 and tr.xgmi_bytes["all_to_all_lookup"] > 0
         assert eng.fshard.table.shape[0] < model.num_users + model.num_items
+        assert eng.fold_mode == "sharded" and model._ws["fold"] is None      # no rank ever computed or held a full S_m
     # validation on the tables of the last forward: user-sharded with replicated tables, ITEM-sharded with row shards
     model.fusion_mode, model.predict_type = "rubi", "TIE"
     res, _ = model.test()
@@ -991,3 +992,31 @@ def test_16bit_feature_storage_equals_fp32_engine_on_rounded_constants(dtype):
     assert (res["stored"][1] - res["rounded"][1]).abs().max().item() < 2e-5
     assert res["stored"][0] != res["plain"][0]                                   # the storage really is 16-bit
     assert np.abs(np.array(res["stored"][0]) - np.array(res["plain"][0])).max() < 2e-3
+
+
+@pytest.mark.parametrize("name", ["ml3", "kwai", "gcmc"])
+def test_hop_kernel_fold_of_the_constants_equals_the_model_fold(name, monkeypatch):
+    """The distributed fold's arithmetic (ColumnShardEngine._horner_mean: t <- X0 + A t with the slab hop kernels, widths
+    padded to the plan's lane-group geometry) on one rank against EliMRec._fold_constants (the bipartite propagation
+    kernels): S_m and c agree to 1e-6 -- two summation orders of the same mean_k A^k [0 ; F_m]."""
+    from elimrec_amd import ColumnShardEngine, FusedAdam
+    g = load_golden(name)
+    model, _ = build_model_from_fixture(g, DEV)
+    opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    ref = ColumnShardEngine(model, feature_shard="row")
+    ref.cs_setup(1, 0, opt)
+    assert ref.fold_mode == "model"
+    want = ref.fshard.table.clone()
+    monkeypatch.setenv("ELIMREC_FOLD", "sharded")
+    model2, _ = build_model_from_fixture(g, DEV)
+    eng = ColumnShardEngine(model2, feature_shard="row")
+    eng.cs_setup(1, 0, FusedAdam(model2.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"])))
+    assert eng.fold_mode == "sharded" and model2._ws["fold"] is None
+    got = eng.fshard.table
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() < 1e-6 * max(1.0, want.abs().max().item())
+    # and a step on the hop-folded constants still matches the reference fixture
+    u, p, n = (_t(g["step1/%s" % k]) for k in ("users", "pos", "neg"))
+    acts = eng.cs_plan(u, p, n).view(1, -1)
+    eng.cs_forward(acts)
+    assert abs(float(eng.cs_head(None)) - float(g["step1/loss"])) < 1e-5
