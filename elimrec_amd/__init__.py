@@ -11,6 +11,7 @@ from .optim import FusedAdam
 from .sampler import PairwiseSamplerV2
 from .shard import ColumnShardEngine, ColumnShardTrainer
 from .evaluator import ProxyEvaluator, UniEvaluator
+from . import capacity
 
 
 def set_seed(seed):

@@ -67,6 +67,19 @@ class AdamJob(ctypes.Structure):
                 ("step", ctypes.c_int64)]
 
 
+PROGRAM_MAX_ARGS = 32
+
+
+class ProgramOp(ctypes.Structure):
+    """struct elimrec_op."""
+    _fields_ = [("kind", ctypes.c_int32), ("fn", ctypes.c_int32), ("args", ctypes.c_uint64 * PROGRAM_MAX_ARGS)]
+
+
+class ProgramPatch(ctypes.Structure):
+    """struct elimrec_patch."""
+    _fields_ = [("op", ctypes.c_int32), ("arg", ctypes.c_int32), ("value", ctypes.c_uint64)]
+
+
 c_sell = ctypes.POINTER(SellDesc)
 c_split = ctypes.POINTER(CsrSplit)
 c_csr = ctypes.POINTER(CsrDesc)
@@ -199,6 +212,15 @@ SIGNATURES = {
                                     c_ptr, c_ptr, c_ptr]),
     "elimrec_lookup_unpack": (c_i32, [c_ptr, c_i32, c_i64, c_i64, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_i32, c_ptr, c_i64,
                                       c_i32, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
+    "elimrec_program_fn_count": (c_i32, []),
+    "elimrec_program_fn_name": (ctypes.c_char_p, [c_i32]),
+    "elimrec_program_fn_args": (c_i32, [c_i32]),
+    "elimrec_program_create": (c_i32, [ctypes.POINTER(ProgramOp), c_i32, ctypes.POINTER(c_ptr)]),
+    "elimrec_program_run": (c_i32, [c_ptr, ctypes.POINTER(ProgramPatch), c_i32]),
+    "elimrec_program_destroy": (c_i32, [c_ptr]),
+    "elimrec_comm_unique_id": (c_i32, [c_ptr]),
+    "elimrec_comm_create": (c_i32, [c_ptr, c_i32, c_i32, ctypes.POINTER(c_ptr)]),
+    "elimrec_comm_destroy": (c_i32, [c_ptr]),
     "elimrec_sample_triplets": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_u64, c_u64, c_ptr, c_ptr, c_ptr, c_ptr]),
 }
 
@@ -245,14 +267,19 @@ class _Recording(object):
     def __init__(self, lib):
         self._cdll = lib
         self._rec = None
+        self._trace = None          # program.py: every call of a traced step, in issue order, with stream hand-overs in between
         for name, (res, _) in SIGNATURES.items():
             fn = getattr(lib, name)
-            setattr(self, name, self._wrap(fn) if res is c_i32 and name != "elimrec_abi_version" else fn)
+            plain = name in ("elimrec_abi_version", "elimrec_program_fn_count", "elimrec_program_fn_args") or name.startswith(
+                ("elimrec_program_", "elimrec_comm_"))
+            setattr(self, name, self._wrap(fn, name) if res is c_i32 and not plain else fn)
 
-    def _wrap(self, fn):
+    def _wrap(self, fn, name):
         def call(*args):
             if self._rec is not None:
                 self._rec.append((fn, args))
+            if self._trace is not None:
+                self._trace.append(("call", name, fn, args))
             return fn(*args)
         return call
 

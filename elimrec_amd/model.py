@@ -177,6 +177,11 @@ class EliMRec(BasicModel):
         Logger.info("modified_ui_loss: " + str(self.modified_ui_loss))
         self.modality = opt("modality", "vat")
         Logger.info("Modality Ablation: " + str(self.modality))
+        # --lean_tables=1 (CLI-only; BASELINE.json configs[4]): nothing of size N lives on the device outside the
+        # column-sharded engine -- the embedding PARAMETERS and the raw feature tables stay on the host (the engine uploads
+        # its column slice / its item block), no device CSR copies of the graph, no [N x C] tables in the workspace. Training
+        # and evaluation run through ColumnShardTrainer / the item-sharded evaluator only.
+        self._lean = str(opt("lean_tables", "0")) in ("1", "True", "true")
         if self.latent_dim % 4 != 0:
             raise ValueError("recdim must be a multiple of 4 for the HIP kernels (got %d)" % self.latent_dim)
         if self.mm_fusion_mode not in ("concat", "mean"):
@@ -209,11 +214,13 @@ class EliMRec(BasicModel):
             adj = sp.csr_matrix((vl.cpu().numpy(), cl.cpu().numpy(), rp.cpu().numpy()), shape=(n_nodes, n_nodes))
         else:
             adj = create_adj_mat(tu, ti, self.num_users, self.num_items, cfg["adj_type"])
-        self._register_csr("adj", adj)
+        self._adj_host = adj                      # the engine's plan is built from this (host) matrix
+        if not self._lean:
+            self._register_csr("adj", adj)
         adj_t = adj.T.tocsr()
         adj_t.sort_indices()
         self._adj_symmetric = (abs(adj - adj_t)).nnz == 0
-        if not self._adj_symmetric:
+        if not self._adj_symmetric and not self._lean:
             self._register_csr("adjT", adj_t)
         # Bipartite fast path (csrc/spmm.hip): no user-user / item-item entries (true for 'pre', 'plain', 'gcmc')
         U = self.num_users
@@ -232,7 +239,9 @@ class EliMRec(BasicModel):
         # so a training step evaluates them there; the full cached tables predict() reads (:98-99) are filled in on
         # first use from the graph tables of that same forward and a copy of the (pre-update) projection weights.
         self._lazy = self._folded and self.n_layers >= 2 and str(opt("head_rows", "batch")) != "all"
-        if self._bipartite:
+        if self._lean and not self._lazy:
+            raise ValueError("--lean_tables=1 needs the folded propagation with batch head rows (bipartite adjacency, layer_num >= 2)")
+        if self._bipartite and not self._lean:
             P, Q = adj[:U, U:].tocsr(), adj[U:, :U].tocsr()
             self._register_csr("bipP", P)
             self._register_csr("bipQ", Q)
@@ -297,7 +306,9 @@ class EliMRec(BasicModel):
         self.register_buffer(name + "_val", torch.from_numpy(m.data.astype(np.float32)), persistent=False)
 
     def _scipy_adj(self):
-        """The propagation matrix as scipy CSR (host copy of the registered buffers)."""
+        """The propagation matrix as scipy CSR (the host matrix it was built as)."""
+        if self.__dict__.get("_adj_host") is not None:
+            return self._adj_host
         n = self.num_users + self.num_items
         return sp.csr_matrix((self.adj_val.cpu().numpy(), self.adj_col.cpu().numpy(), self.adj_rowptr.cpu().numpy()),
                              shape=(n, n))
@@ -324,9 +335,18 @@ class EliMRec(BasicModel):
         Logger.info("[use Xavier initilizer]")
         ds = self.dataset
         custom = "feature_modalities" in self.config
-        if "v" in self._mods:
+        if self._lean:
+            # host tensors (not buffers: .to(device) leaves them where they are); the engine's distributed fold uploads the
+            # rank's item block of each (shard.py)
+            if self.dataset_name == "tiktok" and not custom:
+                raise ValueError("--lean_tables=1 does not cover the tiktok word-bag text features")
+            for m in self._mods:
+                object.__setattr__(self, m + "_feat", F.normalize(getattr(ds, m + "_feat").float(), dim=1).contiguous())
+        elif "v" in self._mods:
             self.register_buffer("v_feat", F.normalize(ds.v_feat.float(), dim=1).contiguous(), persistent=False)
-        if custom:
+        if self._lean:
+            pass
+        elif custom:
             for m in self._mods:
                 if m != "v":
                     self.register_buffer(m + "_feat", F.normalize(getattr(ds, m + "_feat").float(), dim=1).contiguous(),
@@ -386,7 +406,25 @@ class EliMRec(BasicModel):
 
     # ------------------------------------------------------------------ device workspace
     def _device(self):
-        return self.embedding_user.weight.device
+        return self.embedding_user_after_GCN.weight.device
+
+    def _apply(self, fn, *args, **kwargs):
+        """Lean tables: .to(device) / .cuda() move everything EXCEPT the two embedding tables, which stay host parameters
+        (state_dict keys as ever); the engine uploads the column slice its rank owns."""
+        if not self.__dict__.get("_lean"):
+            return super()._apply(fn, *args, **kwargs)
+        keep = {k: self._modules[k] for k in ("embedding_user", "embedding_item")}
+        order = list(self._modules.keys())
+        for k in keep:
+            del self._modules[k]
+        try:
+            return super()._apply(fn, *args, **kwargs)
+        finally:
+            mods = dict(self._modules)
+            mods.update(keep)
+            self._modules.clear()
+            for k in order:
+                self._modules[k] = mods[k]
 
     def _require_gpu(self):
         dev = self._device()
@@ -416,7 +454,13 @@ class EliMRec(BasicModel):
         ws = self._ws if (self._ws is not None and self._ws_key[0] == key[0]) else {}
         self._ws_gen_counter = getattr(self, "_ws_gen_counter", 0) + 1
         self._ws_gen = self._ws_gen_counter                  # recorded regions hold these buffers' addresses
-        if "flat_param" not in ws:                          # everything that does not depend on the batch size
+        if "flat_param" not in ws and self._lean:
+            # lean tables: the projection weights only (the embeddings are host parameters; the engine holds its column slice
+            # of them, of their gradient and of their moments), no table of N rows at all
+            self._flatten_parameters(ws)
+            ws["fold"] = None
+            ws["Y"] = None
+        elif "flat_param" not in ws:                        # everything that does not depend on the batch size
             self._flatten_parameters(ws)
             names = ("Out",) if self._folded else (("X0", "Out") if self._bipartite else ("X0", "T0", "T1", "Out", "G"))
             for name in names:
@@ -514,6 +558,8 @@ class EliMRec(BasicModel):
         update over all 18 tensors then becomes a single launch (optim.FusedAdam merges adjacent
         tensors)."""
         params = list(self.named_parameters())
+        if self._lean:
+            params = [(n_, p) for n_, p in params if not n_.startswith(("embedding_user.", "embedding_item."))]
         dev = self._device()
         sizes = [(p.numel() + 3) // 4 * 4 for _, p in params]          # keep every tensor 16-B aligned
         flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
@@ -534,7 +580,7 @@ class EliMRec(BasicModel):
         ws["param_off"] = offs                   # name -> (offset in the flat buffers, numel)
         # every non-embedding parameter, live and as the copy a training forward takes (predict() after an
         # optimizer step must still see the weights its cached tables were computed with)
-        tail = sizes[0] + sizes[1]
+        tail = 0 if self._lean else sizes[0] + sizes[1]
         ws["tail_off"] = tail
         ws["snap"] = torch.zeros(flat.numel() - tail, dtype=torch.float32, device=dev)
         live, snap, off = {}, {}, 0
@@ -1016,6 +1062,7 @@ class EliMRec(BasicModel):
         """Forward on this rank's triplets; all_keys = batch_keys() of every rank, concatenated in rank order.
         Returns (loss, grad_rows [3B x Cy]): d(local mean loss)/dY rows of this rank's slots."""
         B = int(users.numel())
+        self._no_lean("the row-major data-parallel trainer")
         self._bwd_rows_hint = 3 * B * world_size
         self._workspace(B, 3 * B * world_size)
         loss = self._forward_hip(users, pos, neg, need_grad=True, all_keys=all_keys, rank=rank)
@@ -1068,6 +1115,7 @@ class EliMRec(BasicModel):
         """models/EliMRec.py:115-142. int64 index tensors of shape [b] -> 0-dim loss supporting
         .backward(retain_graph=True) and .cpu().item() (main.py:98-102)."""
         self._require_gpu()
+        self._no_lean("bpr_loss() through autograd")
         if self.is_kwai:
             self.modality = "v"                        # :133-134
         return _BprLossFn.apply(self, users, pos_items, neg_items, *self._all_params())
@@ -1078,10 +1126,16 @@ class EliMRec(BasicModel):
             params = self.__dict__["_param_list"] = [p for _, p in self.named_parameters()]
         return params
 
+    def _no_lean(self, what):
+        if self.__dict__.get("_lean"):
+            raise RuntimeError("--lean_tables=1: %s is not available (no table of N rows lives outside the column-sharded "
+                               "engine); train with ColumnShardTrainer, evaluate with evaluate() / predict()" % what)
+
     def compute(self):
         """:228-272. Returns (all_users [U x d], all_items [I x d]). Under torch.no_grad(): views into Y. With autograd
         enabled: differentiable copies (_TablesFn) -- what getEmbedding / the generic BasicModel losses build on."""
         self._require_gpu()
+        self._no_lean("compute()")
         if torch.is_grad_enabled():
             self._last_tables = _TablesFn.apply(self, *self._all_params())
             return self._last_tables

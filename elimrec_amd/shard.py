@@ -296,6 +296,9 @@ class ColumnShardEngine(object):
             raise ValueError("feature_shard must be 'replicated' or 'row' (got %r)" % (feature_shard,))
         if feature_dtype not in ("f32", "f16", "bf16"):
             raise ValueError("feature_dtype must be 'f32', 'f16' or 'bf16' (got %r)" % (feature_dtype,))
+        self.lean = bool(getattr(model, "_lean", False))
+        if self.lean:
+            feature_shard = "row"        # lean tables: the constants exist as this rank's rows only, built by the distributed fold
         self.feature_shard, self.feature_dtype = feature_shard, feature_dtype
         # the lookup path (compact rows of the constants per step) serves the row shards and the 16-bit storage alike
         self.lookup = feature_shard == "row" or feature_dtype != "f32"
@@ -376,6 +379,8 @@ class ColumnShardEngine(object):
         # its own); "sharded" = the distributed fold below (no rank ever holds more than a column slice or its own rows --
         # what BASELINE.json configs[4] needs). Default: sharded for row shards over several ranks of a real process group.
         fold_mode = os.environ.get("ELIMREC_FOLD", "")
+        if self.lean:
+            fold_mode = "sharded"
         if fold_mode not in ("model", "sharded"):
             fold_mode = "sharded" if (self.feature_shard == "row" and world > 1 and dist.is_available() and dist.is_initialized()
                                       and dist.get_world_size(self.group) == world) else "model"
@@ -398,6 +403,7 @@ class ColumnShardEngine(object):
             self._lookup_bufs = {}
         self.load_from_model()
         m._slab_engine = self
+        m._regions = {}                  # recorded launches of an engine attached earlier hold ITS tables' addresses
         # the embeddings are updated here, not by the caller's optimizer; the projection weights go through it
         self._tail = [(n, p) for n, p in m.named_parameters() if not n.startswith(("embedding_user.", "embedding_item."))]
         return ws
@@ -407,7 +413,15 @@ class ColumnShardEngine(object):
         """Master copy <- the model's embedding parameters (start-up, load_state_dict)."""
         m = self.model
         ws = m._workspace(m._ws_key[1] if m._ws_key else 1)
-        self.master[self.cur].from_rows(ws["X0d"], col0=self.col0)
+        if self.lean:       # host parameters: upload my column slice (users, then items) and lay it out slab-major
+            dev, U = m._device(), m.num_users
+            x0 = torch.empty(U + m.num_items, self.dl, dtype=torch.float32, device=dev)
+            x0[:U].copy_(m.embedding_user.weight.detach()[:, self.col0:self.col0 + self.dl])
+            x0[U:].copy_(m.embedding_item.weight.detach()[:, self.col0:self.col0 + self.dl])
+            self.master[self.cur].from_rows(x0, col0=0)
+            del x0
+        else:
+            self.master[self.cur].from_rows(ws["X0d"], col0=self.col0)
         if self.bf16:
             self.master[self.cur].to_bf16(self.mirror[self.cur])
         ws["snap"].copy_(ws["flat_param"][ws["tail_off"]:])        # from here on the snapshot is refreshed by cs_update
@@ -416,6 +430,15 @@ class ColumnShardEngine(object):
     def sync_to_model(self):
         """The model's embedding parameters <- the master copy (before a checkpoint; all ranks must call it)."""
         m = self.model
+        if self.lean:       # every rank's column slice into every rank's host parameters (checkpoint time only)
+            U = m.num_users
+            loc = self.master[self.cur].dense()
+            parts = [loc] if self.world == 1 else _all_gather_parts(loc, self.world, self.group)
+            for q, part in enumerate(parts):
+                host = part.cpu()
+                m.embedding_user.weight.data[:, q * self.dl:(q + 1) * self.dl] = host[:U]
+                m.embedding_item.weight.data[:, q * self.dl:(q + 1) * self.dl] = host[U:]
+            return
         x0d = m._ws["X0d"]
         if self.world == 1:
             self.master[self.cur].to_rows(x0d, col0=0)
@@ -428,7 +451,8 @@ class ColumnShardEngine(object):
         ws = m._workspace(B, 3 * B)
         dev, d, R, W = m._device(), m.latent_dim, 3 * B, self.world
         N = m.num_users + m.num_items
-        if getattr(self, "narrow_x", None) is None or ws["Narrow"].data_ptr() != self.narrow_x.data_ptr():
+        if not self.lookup and (getattr(self, "narrow_x", None) is None or ws["Narrow"].data_ptr() != self.narrow_x.data_ptr()):
+            # (by-node copy of the shared part: only the path without compact rows reads it)
             self.narrow_x = torch.zeros(N + 1, d, dtype=torch.float32, device=dev)   # spare row: padded slots land there
             ws["Narrow"] = self.narrow_x[:N]
             m._regions = {}                                       # recorded regions hold the old buffer's address
@@ -933,11 +957,11 @@ class ColumnShardEngine(object):
         loader the block it read), one all_to_all turns row blocks into COLUMN slices [I x D_m/W], every rank propagates its
         slice through the (replicated) graph with the hop kernels -- no communication, like the training hops -- and a second
         all_to_all hands every owner its rows of every slice. c is one column: every rank computes it, keeps its rows."""
-        from .shard_eval import Collectives
+        from .shard_eval import collectives_for
         m, W = self.model, owners.world
         U, I, dev = m.num_users, m.num_items, m._device()
         q = frank
-        coll = Collectives(self.group) if W > 1 else None
+        coll = collectives_for(self.group, W)
         nodes = [torch.from_numpy(owners.nodes(o)).to(dev) for o in range(W)]
         rows = [len(n) for n in nodes]
         i_rows = [owners.rows(o)[1] for o in range(W)]
@@ -948,7 +972,7 @@ class ColumnShardEngine(object):
             D = feat.shape[1]
             if W > 1 and D % W == 0 and (D // W) % 4 == 0:
                 Dq = D // W
-                mine = feat[i0:i1]                                                  # my item block, all columns
+                mine = feat[i0:i1].to(dev)                                          # my item block, all columns
                 cols = coll.all_to_all_rows(torch.cat([mine[:, p * Dq:(p + 1) * Dq] for p in range(W)]).contiguous(),
                                             [i1 - i0] * W, i_rows)                  # all items, my columns
                 x0 = torch.cat([torch.zeros(U, Dq, dtype=torch.float32, device=dev), cols])
@@ -956,7 +980,7 @@ class ColumnShardEngine(object):
                 recv = coll.all_to_all_rows(torch.cat([S[n] for n in nodes]), rows, [rows[q]] * W).view(W, rows[q], Dq)
                 tabs.append(recv.permute(1, 0, 2).reshape(rows[q], D).contiguous())
             else:       # a width that does not split: the whole table on every rank (small shapes), own rows kept
-                x0 = torch.cat([torch.zeros(U, D, dtype=torch.float32, device=dev), feat])
+                x0 = torch.cat([torch.zeros(U, D, dtype=torch.float32, device=dev), feat.to(dev)])
                 tabs.append(self._horner_mean(x0)[nodes[q]].contiguous())
         ones = torch.zeros(U + I, 4, dtype=torch.float32, device=dev)
         ones[U:, 0] = 1.0
@@ -1037,12 +1061,12 @@ class ColumnShardEngine(object):
             else:
                 slab.rows(self.plan, self.ns, self.w, L, U, [t.data for t in tabs] + [self.xL.data], None, None, None, N, 1,
                           out0, narrow, False)
-        if self.world == 1:
-            all_rows(ws["Out"][:, :d], ws["Narrow"])
-        elif self.feature_shard == "row":
-            loc = torch.empty(N, 2 * self.dl, dtype=torch.float32, device=ws["Out"].device)
+        if self.feature_shard == "row" and (self.world > 1 or self.lean or ws.get("fold") is None):
+            loc = torch.empty(N, 2 * self.dl, dtype=torch.float32, device=m._device())
             all_rows(loc[:, :self.dl], loc[:, self.dl:])
             return self._materialize_item_shard(ws, loc)
+        if self.world == 1:
+            all_rows(ws["Out"][:, :d], ws["Narrow"])
         else:
             loc = torch.empty(N, 2 * self.dl, dtype=torch.float32, device=ws["Out"].device)
             all_rows(loc[:, :self.dl], loc[:, self.dl:])
@@ -1058,11 +1082,11 @@ class ColumnShardEngine(object):
         (shard_eval.py). loc [N x 2*dl]: (layer mean | shared part) of all rows in MY columns; one all_to_all hands every
         owner its rows of every rank's columns (the column shards' transpose), one all_gather replicates the users' Y rows
         (every rank scores all users against its items)."""
-        from .shard_eval import Collectives, HipShardBackend, ItemShardScorer
+        from .shard_eval import HipShardBackend, ItemShardScorer, collectives_for
         m, W, q, own = self.model, self.world, self.rank, self.fshard.owners
         d, dl, C, Cy, U = m.latent_dim, self.dl, m.C, m.Cy, m.num_users
         dev = loc.device
-        coll = Collectives(self.group)
+        coll = collectives_for(self.group, W)
         if getattr(self, "_own_nodes", None) is None:
             self._own_nodes = [torch.from_numpy(own.nodes(o)).to(dev) for o in range(W)]
         rows = [len(n) for n in self._own_nodes]

@@ -60,6 +60,27 @@ class Collectives(object):
         return out.to(send.device)
 
 
+class LocalCollectives(object):
+    """One rank without a process group (lean tables on a single GPU): every collective is the identity."""
+    world, rank = 1, 0
+
+    def all_reduce_sum(self, t):
+        return t
+
+    def all_gather(self, t):
+        return t.unsqueeze(0)
+
+    def all_gather_rows(self, t, counts):
+        return t
+
+    def all_to_all_rows(self, send, in_rows, out_rows):
+        return send
+
+
+def collectives_for(group, world):
+    return Collectives(group) if world > 1 else LocalCollectives()
+
+
 class ItemShardScorer(object):
     """Top-K / scores of user blocks over an item-sharded catalogue. backend: row_sums(users) -> [B] fp32 partial sums
     (None when the predict type has no catalogue-wide mean); score(users, row_sum, K, train_ptr, train_items, want_scores)

@@ -758,6 +758,36 @@ int elimrec_lookup_unpack(const int32_t *d_act, int world, int64_t R, int64_t U,
                           const int64_t *ib, int me, const void *d_rows, int64_t row_bytes, int dtype, int sum_d,
                           int direct, float *d_S, int64_t ldS, float *d_c, void *stream);
 
+/* ---------------------------------------------------------------- a training step as one host call (csrc/program.hip)
+ * The reference's loop body (main.py:98-101) is, on this path, ~13 launches on two HIP streams plus -- with several ranks --
+ * four collectives. A program is that sequence written down once: calls of THIS library's entry points with their arguments
+ * packed as 64-bit words (pointers, integers, fp32 bit patterns in the low half), event record / wait pairs that hand work
+ * between streams, and RCCL collectives on a communicator owned by this library, enqueued on the caller's stream.
+ * elimrec_program_run applies `patches` (argument words that change every step: the batch's index tensors, the loss slot,
+ * Adam's step count) and issues the list. Nothing here allocates device memory or synchronises the host. */
+#define ELIMREC_PROGRAM_MAX_ARGS 32
+enum { ELIMREC_OP_CALL = 0,          /* fn = index into the function table (elimrec_program_fn_name), args = its arguments      */
+       ELIMREC_OP_RECORD = 1,        /* args: stream, event slot                                                                */
+       ELIMREC_OP_WAIT = 2,          /* args: stream, event slot                                                                */
+       ELIMREC_OP_ALL_GATHER = 3,    /* args: comm, send, recv [world x bytes], bytes per rank, stream                          */
+       ELIMREC_OP_ALL_REDUCE_F32 = 4,/* args: comm, buffer (in place, sum), floats, stream                                      */
+       ELIMREC_OP_ALL_TO_ALL = 5,    /* args: comm, send [world x bytes], recv [world x bytes], bytes per peer, stream          */
+       ELIMREC_OP_ALL_TO_ALL_V = 6 };/* args: comm, send, recv, host int64[2 x world] (send bytes | recv bytes per peer), stream */
+typedef struct elimrec_op { int32_t kind; int32_t fn; uint64_t args[ELIMREC_PROGRAM_MAX_ARGS]; } elimrec_op;
+typedef struct elimrec_patch { int32_t op; int32_t arg; uint64_t value; } elimrec_patch;
+int elimrec_program_fn_count(void);
+const char *elimrec_program_fn_name(int i);
+int elimrec_program_fn_args(int i);
+int elimrec_program_create(const elimrec_op *ops, int n_ops, void **prog_out);
+int elimrec_program_run(void *prog, const elimrec_patch *patches, int n_patches);
+int elimrec_program_destroy(void *prog);
+/* RCCL communicator of the ranks of a job (one per process / GPU): rank 0 draws the 128-byte id, the host side hands it to the
+ * others (torch.distributed broadcast), every rank calls elimrec_comm_create. The RCCL library is the one the process has
+ * already loaded (PyTorch-ROCm's), resolved at run time. */
+int elimrec_comm_unique_id(void *id128);
+int elimrec_comm_create(const void *id128, int world, int rank, void **comm_out);
+int elimrec_comm_destroy(void *comm);
+
 #ifdef __cplusplus
 }
 #endif

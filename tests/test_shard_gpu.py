@@ -343,7 +343,26 @@ def _shape_step_vs_oracle(U, I, E, dims, recdim, B, world=1):
     assert_grad_close(gE[U:], want["embedding_item.weight"], "embedding_item.weight")
     for k, v in eng._grads.items():
         assert_grad_close(v.cpu(), want[k], k)
+    eng._test_batch, eng._test_oracle, eng._test_init = (u, p, n), om, init
     return model, eng
+
+
+def _predict_and_topk_vs_oracle(model, om, users, K=10):
+    """predict() of a block of users on the tables the last forward cached, and the device top-K, against the oracle's
+    predict(): scores 1e-5; the top-K lists ARE the stable (score desc, id asc) ranking of the device scores and differ
+    from the oracle's ranking only where two oracle scores are closer than 2e-6."""
+    for ptype in ("TIE", "TE"):
+        model.predict_type = om.predict_type = ptype
+        got = model.predict(users).numpy()
+        want = om.predict(users).numpy()
+        assert np.abs(got - want).max() < 1e-5, ptype
+        idx, val = model.predict_device(users, top_k=K)
+        idx = idx.cpu().numpy()
+        order = np.argsort(-got, axis=1, kind="stable")[:, :K]
+        assert np.array_equal(idx, order), ptype
+        ref_order = np.argsort(-want, axis=1, kind="stable")[:, :K]
+        for r in np.nonzero((order != ref_order).any(1))[0]:
+            assert np.abs(want[r][order[r]] - want[r][ref_order[r]]).max() < 2e-6, (ptype, r)
 
 
 def test_small_shape_step_vs_oracle_through_the_slab_engine():
@@ -353,7 +372,48 @@ def test_small_shape_step_vs_oracle_through_the_slab_engine():
 def test_c4_shape_step_vs_oracle():
     """BASELINE.json configs[3] on one GPU: Tiktok shape x16 items (|I| = 1 217 360), recdim 128, B = 2048 -- one
     step of the slab-major engine (the table every rank of an 8-GPU job holds a 16-column slice of) vs the oracle."""
-    _shape_step_vs_oracle(36656, 1217360, 16 * 720829, (128, 128, 128), 128, 2048)
+    model, eng = _shape_step_vs_oracle(36656, 1217360, 16 * 720829, (128, 128, 128), 128, 2048)
+    # ... and predict() / top-10 of 64 users over the 1.2 M-item catalogue at recdim 128 (the 16-user-per-wave scorer, chunked
+    # selection) from the tables that forward cached, against the oracle
+    _predict_and_topk_vs_oracle(model, eng._test_oracle, list(range(0, 36656, 570))[:64])
+
+
+def test_c5_shape_scaled_step_and_eval_vs_oracle():
+    """BASELINE.json configs[4] scaled to one GPU and an oracle that finishes: |I| = 2 000 000, |U| = 20 000, 16 M
+    interactions (users of degree ~800, items of degree ~8: the C5 ratio), recdim 256, three 256-d feature tables.
+      * fp32: one step of the slab engine vs the oracle (loss 1e-5, every gradient 1e-4 max-norm and row by row);
+        predict() / top-10 for 64 users over the 2 M-item catalogue vs the oracle;
+      * --feature_dtype=f16 (the storage configs[4] names): the same step with the folded constants stored in fp16 and
+        widened at the lookup -- stated tolerance of the mode against the fp32 run: loss 2e-3 abs, gradients 2e-2 max-norm
+        (the exact statement of what it computes is test_16bit_feature_storage_equals_fp32_engine_on_rounded_constants);
+    (Memory: tests/test_capacity_gpu.py checks capacity.plan() against the device allocator on the lean form of this shape.)"""
+    from elimrec_amd import ColumnShardEngine, FusedAdam
+    U, I, E, dims, d, B = 20000, 2000000, 16000000, (256, 256, 256), 256, 2048
+    model, eng = _shape_step_vs_oracle(U, I, E, dims, d, B)
+    om = eng._test_oracle
+    print("device memory held after set-up + one step: %.2f GiB" % (torch.cuda.memory_allocated() / 2 ** 30))
+    _predict_and_topk_vs_oracle(model, om, list(range(0, U, 311))[:64])
+    # fp16 storage of the constants on the same model and batch
+    u, p, n = eng._test_batch
+    g32 = {k: v.clone() for k, v in eng._grads.items()}
+    gE32 = eng.grad.dense().clone()
+    # (the first engine's last adjoint hop carried the projection weights' Adam spans: back to the initial parameters)
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in eng._test_init.items()})
+    opt = FusedAdam(model.parameters(), lr=1e-3, weight_decay=1e-4)
+    e16 = ColumnShardEngine(model, feature_dtype="f16")
+    e16.cs_setup(1, 0, opt)
+    e16.keep_grad = True
+    acts = e16.cs_plan(u.to(DEV), p.to(DEV), n.to(DEV)).view(1, -1)
+    e16.cs_forward(acts)
+    loss16 = float(e16.cs_head(None))
+    s2, _ = e16.cs_backward_local(torch.ones(1, device=DEV))
+    e16.cs_backward_hops(s2, acts)
+    loss32 = float(om.bpr_loss(u, p, n).detach())
+    assert 0 < abs(loss16 - loss32) < 2e-3, (loss16, loss32)
+    assert rel_err(e16.grad.dense().cpu(), gE32.cpu()) < 2e-2
+    for k, v in e16._grads.items():
+        assert rel_err(v.cpu(), g32[k].cpu()) < 2e-2, k
+    assert e16.fshard.table.dtype == torch.float16 and e16.fshard.nbytes() < 0.51 * (U + I) * (sum(dims) + 4) * 4
 
 
 # ----------------------------------------------------------------------------- bf16 table storage (J1)
@@ -967,14 +1027,15 @@ def test_row_sharded_constants_equal_replicated_bitwise(W, name):
             assert abs(out["row"][0][t - 1] - float(g["step%d/loss" % t])) < 1e-5
 
 
+@pytest.mark.parametrize("name", ["kwai", "ml3"])
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
-def test_16bit_feature_storage_equals_fp32_engine_on_rounded_constants(dtype):
+def test_16bit_feature_storage_equals_fp32_engine_on_rounded_constants(dtype, name):
     """--feature_dtype=f16|bf16 (BASELINE.json configs[4]: "fp16" features): the constants are STORED in 16 bits and widened
     when a step looks its rows up; everything else is the fp32 path. So the run equals, to the last bits of c's hi + lo
     split (tolerance 2e-6), the fp32 engine on a model whose S_m were rounded to that dtype -- the rounding oracle of
     this mode -- and differs from the unrounded fp32 run by the storage error (stated tolerance: loss 2e-3)."""
     from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
-    g = load_golden("kwai")
+    g = load_golden(name)            # kwai: recdim 64, the fused head; ml3: recdim 32, the batched GEMMs
     tdt = torch.float16 if dtype == "f16" else torch.bfloat16
     res = {}
     for mode in ("stored", "rounded", "plain"):
