@@ -31,7 +31,7 @@ import ctypes
 import torch
 import torch.distributed as dist
 
-from . import _lib, ops, slab
+from . import _lib, ops, program, slab
 from .lookup import FeatureShard, RowOwnerMap
 
 PAD_KEY = -(1 << 30)
@@ -200,7 +200,80 @@ class ColumnShardTrainer(object):
                 return self._step(users, pos, neg)
         return self._step(users, pos, neg)
 
+    # ---- the step as one host call (program.py / csrc/program.hip): one rank, after a few ordinary steps
+    NATIVE_WARM = 1          # ordinary steps before tracing starts (buffers of this batch size allocated, the loss ring in place):
+                             # steps 2-5 are traced, the sixth step of a run is the first one issued from C
+
+    def _native_state(self):
+        st = self.__dict__.get("_native")
+        if st is None:
+            import os
+            st = self._native = dict(on=os.environ.get("ELIMREC_NATIVE_STEP", "1") != "0", traces={}, programs={}, failed=None,
+                                     steps=0, native_steps=0)
+        return st
+
+    def _native_eligible(self, users, pos, neg):
+        eng = self.engine
+        return (self._hip_engine and not self.multi and not self.profile_kernels and eng.kernel_events is None and not eng.keep_grad
+                and eng.model.mm_fusion_mode == "concat" and eng.model._use_replay and not eng.model._use_graphs
+                and all(t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() for t in (users, pos, neg))
+                and users.numel() == pos.numel() == neg.numel() and eng._side_stream() is None)
+
     def _step(self, users, pos, neg):
+        st = self._native_state()
+        if not st["on"] or st["failed"] or not self._native_eligible(users, pos, neg):
+            return self._step_python(users, pos, neg)
+        eng = self.engine
+        B = int(users.numel())
+        key = (B, tuple(eng.model._block_weights()))
+        progs = st["programs"].get(key)
+        if progs is not None and progs[eng.cur] is not None:
+            return self._step_native(progs[eng.cur], users, pos, neg, B)
+        st["steps"] += 1
+        if st["steps"] <= self.NATIVE_WARM or eng._loss_ring is None:
+            return self._step_python(users, pos, neg)
+        # trace this step (launched from Python, every call recorded) -- two traces per buffer parity make a program
+        known = dict(users=users.data_ptr(), pos=pos.data_ptr(), neg=neg.data_ptr(),
+                     loss=eng._loss_ring.data_ptr() + 4 * eng._loss_at, step=eng.step_count + 1)
+        parity = eng.cur
+        m = eng.model
+        m._use_replay = False
+        try:
+            with program.StepTracer() as tr:
+                loss = self._step_python(users, pos, neg)
+        finally:
+            m._use_replay = True
+        got = st["traces"].setdefault(key, {0: [], 1: []})[parity]
+        got.append((tr.items, known))
+        if len(got) >= 2 and progs is None:
+            progs = st["programs"][key] = [None, None]
+        if len(got) >= 2:
+            try:
+                (ta, ka), (tb, kb) = got[-2], got[-1]
+                if any(ka[k] == kb[k] for k in ka):
+                    raise ValueError("a per-step value did not change between the two traced steps")
+                items, varying = program.diff_traces(ta, tb, ka, kb)
+                missing = set(ka) - set(varying.values())
+                if missing:
+                    raise ValueError("per-step values %s appear in no call" % sorted(missing))
+                st["programs"][key][parity] = program.StepProgram(items, varying, keep=(ta, tb))
+            except (ValueError, KeyError, TypeError) as e:
+                st["failed"] = str(e)                         # the ordinary path stays; the reason is kept for inspection
+        return loss
+
+    def _step_native(self, prog, users, pos, neg, B):
+        eng = self.engine
+        m = eng.model
+        if m._ws_key is None or m._ws_key[1] != B:
+            eng._workspace(B)                                 # (an epoch's ragged last batch switched the buffer set)
+        loss = eng._next_loss_slot()
+        eng.native_prologue()
+        prog.run(dict(users=users.data_ptr(), pos=pos.data_ptr(), neg=neg.data_ptr(), loss=loss.data_ptr(), step=eng.step_count + 1))
+        eng.native_epilogue(3 * B)
+        self._native["native_steps"] += 1
+        return loss
+
+    def _step_python(self, users, pos, neg):
         eng, W, ph = self.engine, self.world, self._ph
         if self.profile_kernels and getattr(eng, "kernel_events", None) is None:
             eng.kernel_events = self._events
@@ -601,7 +674,7 @@ class ColumnShardEngine(object):
             m._region("cs_plan", (m._ws_gen, users.data_ptr(), pos.data_ptr(), neg.data_ptr(), R), plan)
             return act
         if not self._forked:
-            aux.wait_stream(torch.cuda.current_stream())          # the triplets, and last step's readers of the plan buffers
+            program.sync(aux, torch.cuda.current_stream())       # the triplets, and last step's readers of the plan buffers
         self._forked = False
         with torch.cuda.stream(aux):
             m._region("cs_plan", (m._ws_gen, users.data_ptr(), pos.data_ptr(), neg.data_ptr(), R), plan)
@@ -617,7 +690,7 @@ class ColumnShardEngine(object):
         aux = self._aux_stream()
         if aux is None or self.model._ws is None or not self._early_hops:
             return False
-        aux.wait_stream(torch.cuda.current_stream())
+        program.sync(aux, torch.cuda.current_stream())
         self._forked = True
         return True
 
@@ -645,7 +718,7 @@ class ColumnShardEngine(object):
         self._acts = acts
         late_wait = self._aux_pending and self._late_wait       # the long-rows hop needs nothing of the plan: join after it
         if self._aux_pending and not late_wait:                  # the plan (and the packed weights) from the second stream
-            torch.cuda.current_stream().wait_stream(self._aux)
+            program.sync(torch.cuda.current_stream(), self._aux)
         self._aux_pending = False
         if self.multi:
             counts = None                                        # the gathered lists are padded with negative keys
@@ -674,7 +747,7 @@ class ColumnShardEngine(object):
                 self.fshard.unpack(ws["active_rows"][:R], None, self.s_rows, self.c_rows, direct=True)
         if late_wait:
             m._region("cs_fwd_long%d" % self.cur, (m._ws_gen,), long_rows)
-            torch.cuda.current_stream().wait_stream(self._aux)
+            program.sync(torch.cuda.current_stream(), self._aux)
         m._region("cs_fwd_rows%d" % self.cur, (m._ws_gen, acts.data_ptr(), R, W, narrow.data_ptr(), late_wait), rows)
         return self.send_f if self.multi else None
 
@@ -713,8 +786,18 @@ class ColumnShardEngine(object):
         if fused:
             return self._head_forward_fused(ws, R, B)
         m._fwd_head(ws, self._keys, R, B, 0, ws["grad_rows"], layer_means=False, snapshot=False)
-        loss = torch.empty((), dtype=torch.float32, device=m._device())
+        loss = self._next_loss_slot()
         ops.fixed_order_sum(ws["loss_rows"], loss)
+        return loss
+
+    def _next_loss_slot(self):
+        """The next slot of the loss ring (a caller holding the tensors of earlier steps -- main.py stacks an epoch's losses
+        before it copies them to the host -- does not see them change for LOSS_RING steps)."""
+        if self._loss_ring is None:
+            self._loss_ring = torch.zeros(LOSS_RING, dtype=torch.float32, device=self.model._device())
+            self._loss_ticket = torch.zeros(1, dtype=torch.int32, device=self.model._device())
+        loss = self._loss_ring[self._loss_at]
+        self._loss_at = (self._loss_at + 1) % LOSS_RING
         return loss
 
     def _head_forward_fused(self, ws, R, B):
@@ -735,11 +818,7 @@ class ColumnShardEngine(object):
         # elimrec_sum's order). Issued directly: the loss goes to the next slot of a ring, so that a caller holding the
         # tensors of earlier steps -- main.py stacks an epoch's losses before it copies them to the host -- does not see them
         # change (LOSS_RING steps back; `loss_ring_len` lets a caller that keeps more clone them).
-        if self._loss_ring is None:
-            self._loss_ring = torch.zeros(LOSS_RING, dtype=torch.float32, device=m._device())
-            self._loss_ticket = torch.zeros(1, dtype=torch.int32, device=m._device())
-        loss = self._loss_ring[self._loss_at]
-        self._loss_at = (self._loss_at + 1) % LOSS_RING
+        loss = self._next_loss_slot()
         ops.bpr_head_rows_sum(YAct, ws["slot_seg"][:3 * B], d, bw, ws["loss_rows"], ws["grad_rows"], loss, self._loss_ticket)
         m._publish_cache(ws["Y"], dirty=True)
         return loss
@@ -859,6 +938,12 @@ class ColumnShardEngine(object):
             tail = self._tail_jobs() if in_hop else []        # (advances the weights' step counts: called once per step)
             if len(tail) > 8:
                 raise RuntimeError("more than 8 optimizer spans")
+            if getattr(self, "_tail_arr", None) is None:
+                self._tail_arr = (_lib.AdamJob * 8)()         # one array for every step: its address is part of the step's
+            for i, job in enumerate(tail):                    # recorded arguments (program.py), its step counts change in place
+                self._tail_arr[i] = job
+            self._tail_n = len(tail)
+            tail = (self._tail_arr, len(tail))
             self._tail_in_hop = in_hop
             self._timed(lambda: slab.hop_adam(self.planT, self.tmp[1], self.grad if self.keep_grad else None, self.gs, self.srcA,
                                               self.mask, inv, self.master[self.cur].data, self.master[nxt].data, self.m1, self.m2,
@@ -890,6 +975,33 @@ class ColumnShardEngine(object):
             _lib.check(_lib.load().elimrec_adam_multi(arr, len(jobs), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                                                       g["weight_decay"], ops._stream()), "adam_multi")
         self.cur = nxt
+
+    def native_prologue(self):
+        """What the ordinary step's Python does besides launching, ahead of the launches of a native step: the projection
+        weights' step counts (optimizer state and the persistent job array the last hop's launch reads)."""
+        if self._tail_plan is not None and getattr(self, "_tail_n", 0):
+            _, spans, states = self._tail_plan[:3]
+            for st in states:
+                st["step"] += 1
+            i = 0
+            for sp in spans:
+                if sp["upd"]:
+                    sp["step"] += 1
+                    self._tail_arr[i].step = sp["step"]
+                i += 1
+
+    def native_epilogue(self, R):
+        """... and behind them: the buffer flip, the step count, the markers predict() / evaluate() go by."""
+        m = self.model
+        x0 = self.master[self.cur]
+        self._x0_fwd = x0
+        self._tabs = [x0] + self.layers[1:]
+        self._srcs = ([self.mirror[self.cur]] if self.bf16 else [x0]) + self.layers[1:]
+        m._plan_n = R
+        m._slab_fwd = True
+        m._publish_cache(m._ws["Y"], dirty=True)
+        self.step_count += 1
+        self.cur = 1 - self.cur
 
     def _tail_jobs(self):
         """Spans of the flat parameter buffer behind the embeddings: runs of adjacent projection weights that have a

@@ -349,14 +349,17 @@ def hop_adam(plan, xin, grad_out, gs, add, add_mask, scale, p_in, p_out, m, v, l
     """elimrec_slab_hop_adam: the hop whose output is the gradient of the fp32 slab table p_in, consumed in place by an
     Adam step (p_out / m / v flat fp32 of the table's geometry). grad_out: a table to also receive the gradient, or None.
     tail_jobs: _lib.AdamJob spans (the projection weights) updated by extra workgroups of the same launch."""
-    arr = (_lib.AdamJob * len(tail_jobs))(*tail_jobs) if tail_jobs else None
+    if isinstance(tail_jobs, tuple) and len(tail_jobs) == 2 and not isinstance(tail_jobs[0], _lib.AdamJob):
+        arr, n_tail = tail_jobs                      # (persistent AdamJob array, count): the caller keeps it alive and in place
+    else:
+        arr, n_tail = ((_lib.AdamJob * len(tail_jobs))(*tail_jobs) if tail_jobs else None), len(tail_jobs)
     ns, w = xin.ns, xin.w
     part = plan.partials(ns, w)
     _lib.check(_lib.load().elimrec_slab_hop_adam(
         plan.ref(), ns, w, int(gs), _dev(xin.data, "xin"), _dev(None if grad_out is None else grad_out.data, "grad"),
         _dev(None if add is None else add.data, "add"), _dev(add_mask, "add_mask", torch.int32), float(scale), _dev(part, "partials"),
         part.numel() * 4, _dev(p_in, "p_in"), _dev(p_out, "p_out"), _dev(m, "m"), _dev(v, "v"), float(lr), float(beta1), float(beta2),
-        float(eps), float(weight_decay), int(step), arr, len(tail_jobs), _stream()), "slab_hop_adam")
+        float(eps), float(weight_decay), int(step), arr, n_tail, _stream()), "slab_hop_adam")
 
 
 def rows16(plan, ns, w, L, U, x0, layers16, long_tab, row_ids, counts, R, n_lists, out0, narrow, narrow_by_node):

@@ -1081,3 +1081,47 @@ def test_hop_kernel_fold_of_the_constants_equals_the_model_fold(name, monkeypatc
     acts = eng.cs_plan(u, p, n).view(1, -1)
     eng.cs_forward(acts)
     assert abs(float(eng.cs_head(None)) - float(g["step1/loss"])) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["kwai", "ml3", "gcmc"])
+def test_native_step_program_equals_python_issued_steps(name, monkeypatch):
+    """The step as ONE host call (csrc/program.hip: the traced launches, stream hand-overs and patched per-step arguments,
+    issued from C) against the same steps issued launch by launch from Python: 40 steps on changing batches (every step a
+    different set of index tensors), losses and every parameter bit for bit; predict() on the tables of the last native step;
+    a batch of another size in between takes the ordinary path and the programs keep working after it."""
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
+    g = load_golden(name)
+    base = [tuple(_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg")) for t in (1, 2)]
+    n0 = min(len(b[0]) for b in base)
+    gen = torch.Generator().manual_seed(0)
+    batches = []
+    for s in range(40):
+        b = base[s % 2]
+        perm = torch.randperm(n0, generator=gen).to(DEV)
+        size = n0 - 5 if s == 25 else n0
+        batches.append(tuple(x[:n0][perm][:size].clone() for x in b))
+    out = {}
+    for native in ("0", "1"):
+        monkeypatch.setenv("ELIMREC_NATIVE_STEP", native)
+        model, _ = build_model_from_fixture(g, DEV)
+        opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+        eng = ColumnShardEngine(model)
+        tr = ColumnShardTrainer(eng, opt)
+        losses = torch.stack([tr.step(*b) for b in batches]).cpu().numpy()
+        st = tr._native_state()
+        if native == "1":
+            assert st["failed"] is None, st["failed"]
+            assert st["native_steps"] >= 20, st
+        else:
+            assert st["native_steps"] == 0
+        model.fusion_mode, model.predict_type = "rubi", "TIE"
+        pred = model.predict(g["eval_users"].tolist())
+        eng.sync_to_model()
+        out[native] = (losses, pred, {k: v.detach().clone() for k, v in model.state_dict().items()},
+                       opt.export_state(model.named_parameters()))
+    assert np.array_equal(out["0"][0], out["1"][0])
+    assert torch.equal(out["0"][1], out["1"][1])
+    for k, v in out["0"][2].items():
+        assert torch.equal(out["1"][2][k], v), k
+    for k, st0 in out["0"][3].items():
+        assert out["1"][3][k]["step"] == st0["step"] and torch.equal(out["1"][3][k]["exp_avg"], st0["exp_avg"]), k
