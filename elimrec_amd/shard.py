@@ -660,6 +660,11 @@ class ColumnShardEngine(object):
 
         aux = self._aux_stream()
         early_bits = aux is not None and self.planT.tiered and not self.bf16
+        if aux is not None and self._forked and getattr(self, "_ws_gen_planned", None) != m._ws_gen:
+            # another batch size's buffer set (possibly allocated -- and zero-filled ON THE MAIN STREAM -- a moment ago, after
+            # cs_fork ordered the second stream): order it again behind the main stream before the planner writes into it
+            program.sync(aux, torch.cuda.current_stream())
+        self._ws_gen_planned = m._ws_gen
 
         def plan():       # node ids of the slots, unique active rows + slot map, padded tail: one launch
             ops.batch_plan(users, pos, neg, m.num_users, m.num_items, keys, act, seg, ws["slot_seg"][:R], ws["plan_ws"], err, PAD_KEY,
