@@ -212,6 +212,7 @@ SIGNATURES = {
                                     c_ptr, c_ptr, c_ptr]),
     "elimrec_lookup_unpack": (c_i32, [c_ptr, c_i32, c_i64, c_i64, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_i32, c_ptr, c_i64,
                                       c_i32, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
+    "elimrec_peer_cols_to_rows": (c_i32, [c_ptr, c_i32, c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     "elimrec_program_fn_count": (c_i32, []),
     "elimrec_program_fn_name": (ctypes.c_char_p, [c_i32]),
     "elimrec_program_fn_args": (c_i32, [c_i32]),
@@ -221,6 +222,10 @@ SIGNATURES = {
     "elimrec_comm_unique_id": (c_i32, [c_ptr]),
     "elimrec_comm_create": (c_i32, [c_ptr, c_i32, c_i32, ctypes.POINTER(c_ptr)]),
     "elimrec_comm_destroy": (c_i32, [c_ptr]),
+    "elimrec_comm_all_gather": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
+    "elimrec_comm_all_reduce_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr]),
+    "elimrec_comm_all_to_all": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
+    "elimrec_comm_all_to_all_v": (c_i32, [c_ptr, c_ptr, c_ptr, ctypes.POINTER(c_i64), c_ptr]),
     "elimrec_sample_triplets": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_u64, c_u64, c_ptr, c_ptr, c_ptr, c_ptr]),
 }
 
@@ -270,8 +275,8 @@ class _Recording(object):
         self._trace = None          # program.py: every call of a traced step, in issue order, with stream hand-overs in between
         for name, (res, _) in SIGNATURES.items():
             fn = getattr(lib, name)
-            plain = name in ("elimrec_abi_version", "elimrec_program_fn_count", "elimrec_program_fn_args") or name.startswith(
-                ("elimrec_program_", "elimrec_comm_"))
+            plain = name in ("elimrec_abi_version", "elimrec_program_fn_count", "elimrec_program_fn_args", "elimrec_comm_unique_id",
+                             "elimrec_comm_create", "elimrec_comm_destroy") or name.startswith("elimrec_program_")
             setattr(self, name, self._wrap(fn, name) if res is c_i32 and not plain else fn)
 
     def _wrap(self, fn, name):

@@ -161,6 +161,21 @@ __global__ __launch_bounds__(256) void lookup_unpack_kernel(const int32_t *__res
     }
 }
 
+// The column shards' forward exchange leaves, per peer q, the (layer mean | shared part) of MY active rows in q's columns:
+// recv [W x R x 2 x dl]. The head wants rows: out0[r, q*dl + c] = recv[q, r, 0, c], out1[r, q*dl + c] = recv[q, r, 1, c].
+__global__ __launch_bounds__(256) void peer_cols_to_rows_kernel(const float4 *__restrict__ recv, int W, int64_t R, int dl4,
+                                                                float *__restrict__ out0, int64_t ld0, float *__restrict__ out1, int64_t ld1) {
+    const int64_t per_row = (int64_t)W * 2 * dl4;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= R * per_row) return;
+    const int64_t r = t / per_row;
+    const int k = (int)(t % per_row);
+    const int q = k / (2 * dl4), h = (k / dl4) & 1, c4 = k % dl4;
+    const float4 v = recv[(((int64_t)q * R + r) * 2 + h) * dl4 + c4];
+    float *dst = (h ? out1 + r * ld1 : out0 + r * ld0) + ((int64_t)q * dl4 + c4) * 4;
+    *reinterpret_cast<float4 *>(dst) = v;
+}
+
 static int fill_owner_map(OwnerMap &m, int world, int64_t U, int64_t I, const int64_t *ub, const int64_t *ib) {
     ELIMREC_REQUIRE(world >= 1 && world <= ELIMREC_MAX_RANKS, "lookup: 1..%d ranks", ELIMREC_MAX_RANKS);
     ELIMREC_REQUIRE(ub && ib, "lookup: owner bounds missing");
@@ -236,5 +251,17 @@ extern "C" int elimrec_lookup_unpack(const int32_t *d_act, int world, int64_t R,
         hipLaunchKernelGGL(lookup_unpack_kernel<2>, grid, blk, 0, s, d_act, (int)R, m, me, (const char *)d_rows, row_bytes, sum_d, direct,
                            d_S, ldS, d_c);
     ELIMREC_LAUNCH_CHECK("lookup_unpack");
+    return 0;
+}
+
+extern "C" int elimrec_peer_cols_to_rows(const float *d_recv, int world, int64_t R, int dl, float *d_out0, int64_t ld0,
+                                         float *d_out1, int64_t ld1, void *stream) {
+    ELIMREC_REQUIRE(d_recv && d_out0 && d_out1 && world >= 1 && dl > 0 && dl % 4 == 0 && ld0 % 4 == 0 && ld1 % 4 == 0,
+                    "peer_cols_to_rows: bad arguments");
+    if (R <= 0) return 0;
+    const int64_t total = R * world * 2 * (dl / 4);
+    hipLaunchKernelGGL(peer_cols_to_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4 *)d_recv, world, R, dl / 4, d_out0, ld0, d_out1, ld1);
+    ELIMREC_LAUNCH_CHECK("peer_cols_to_rows");
     return 0;
 }

@@ -5,9 +5,9 @@
 // torch.distributed collectives on top, is host-bound. A `program` is what such a step does, written down once:
 //   CALL        one entry point of this library with its arguments packed as 64-bit words (pointers, integers, fp32 bits)
 //   RECORD/WAIT hipEventRecord on one stream / hipStreamWaitEvent on another: the fork and join of the second stream
-//   collectives ncclAllGather / ncclAllReduce / grouped ncclSend+ncclRecv (all_to_all, fixed or per-peer sizes) on a
-//               communicator this library owns (RCCL over xGMI), enqueued on the step's stream between the kernels --
-//               no host round trip, no stream hand-over to another library's internal stream
+// The step's collectives are entry points of this library too (elimrec_comm_*: ncclAllGather / ncclAllReduce / grouped
+// ncclSend + ncclRecv on a communicator the library owns -- RCCL over xGMI, enqueued on the caller's stream, no host round
+// trip, no hand-over to another library's internal stream), so a program lists them like any kernel launch.
 // elimrec_program_run walks the list; `patches` overwrite argument words that change from step to step (the batch's index
 // tensors, the loss slot, Adam's step count) before the walk. The Python side (elimrec_amd/program.py) builds a program by
 // tracing steps of the ordinary path and diffing their calls, so a program issues exactly what that path issues.
@@ -47,6 +47,8 @@ static const FnEntry kFns[] = {
     ELIMREC_FN(elimrec_linear_bwd_w_batched_merge), ELIMREC_FN(elimrec_linear_bwd_w_reduce), ELIMREC_FN(elimrec_adam_multi),
     ELIMREC_FN(elimrec_source_rows_split), ELIMREC_FN(elimrec_copy_cols), ELIMREC_FN(elimrec_lookup_pack), ELIMREC_FN(elimrec_lookup_unpack),
     ELIMREC_FN(elimrec_lookup_counts), ELIMREC_FN(elimrec_adam_step_out), ELIMREC_FN(elimrec_adam_step_out16),
+    ELIMREC_FN(elimrec_peer_cols_to_rows), ELIMREC_FN(elimrec_comm_all_gather), ELIMREC_FN(elimrec_comm_all_reduce_f32),
+    ELIMREC_FN(elimrec_comm_all_to_all), ELIMREC_FN(elimrec_comm_all_to_all_v),
 };
 constexpr int kNumFns = (int)(sizeof(kFns) / sizeof(kFns[0]));
 
@@ -89,7 +91,7 @@ static int rccl_check(int rc, const char *what) {
     set_error("%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error");
     return 20000 + rc;
 }
-constexpr int kNcclInt32 = 2, kNcclFloat32 = 7, kNcclUint8 = 1, kNcclSum = 0;     // ncclDataType_t / ncclRedOp_t values (nccl.h)
+constexpr int kNcclFloat32 = 7, kNcclUint8 = 1, kNcclSum = 0;     // ncclDataType_t / ncclRedOp_t values (nccl.h)
 
 struct Comm { ncclComm_t comm; int world, rank; };
 
@@ -133,6 +135,53 @@ extern "C" int elimrec_comm_destroy(void *comm) {
     return rc;
 }
 
+// Collectives on the library's communicator, enqueued on `stream` (no host synchronisation, no internal stream): what the
+// step's exchanges are made of. They are ordinary entry points, so a program lists them like any kernel launch.
+extern "C" int elimrec_comm_all_gather(void *comm, const void *d_send, void *d_recv, int64_t bytes_per_rank, void *stream) {
+    ELIMREC_REQUIRE(comm && d_send && d_recv && bytes_per_rank >= 0, "comm_all_gather: bad arguments");
+    Comm *c = (Comm *)comm;
+    return rccl_check(g_rccl.AllGather(d_send, d_recv, (size_t)bytes_per_rank, kNcclUint8, c->comm, (hipStream_t)stream), "ncclAllGather");
+}
+
+extern "C" int elimrec_comm_all_reduce_f32(void *comm, float *d_buf, int64_t n, void *stream) {
+    ELIMREC_REQUIRE(comm && d_buf && n >= 0, "comm_all_reduce: bad arguments");
+    Comm *c = (Comm *)comm;
+    return rccl_check(g_rccl.AllReduce(d_buf, d_buf, (size_t)n, kNcclFloat32, kNcclSum, c->comm, (hipStream_t)stream), "ncclAllReduce");
+}
+
+extern "C" int elimrec_comm_all_to_all(void *comm, const void *d_send, void *d_recv, int64_t bytes_per_peer, void *stream) {
+    ELIMREC_REQUIRE(comm && d_send && d_recv && bytes_per_peer >= 0, "comm_all_to_all: bad arguments");
+    Comm *c = (Comm *)comm;
+    const char *s = (const char *)d_send;
+    char *r = (char *)d_recv;
+    const size_t nb = (size_t)bytes_per_peer;
+    int rc = rccl_check(g_rccl.GroupStart(), "ncclGroupStart");
+    for (int q = 0; q < c->world && !rc; ++q) {
+        rc = rccl_check(g_rccl.Send(s + (size_t)q * nb, nb, kNcclUint8, q, c->comm, (hipStream_t)stream), "ncclSend");
+        if (!rc) rc = rccl_check(g_rccl.Recv(r + (size_t)q * nb, nb, kNcclUint8, q, c->comm, (hipStream_t)stream), "ncclRecv");
+    }
+    const int rc2 = rccl_check(g_rccl.GroupEnd(), "ncclGroupEnd");
+    return rc ? rc : rc2;
+}
+
+// sizes: HOST int64 [2 x world] = bytes to send to peer 0.., then bytes to receive from peer 0.. (chunks back to back)
+extern "C" int elimrec_comm_all_to_all_v(void *comm, const void *d_send, void *d_recv, const int64_t *sizes, void *stream) {
+    ELIMREC_REQUIRE(comm && d_send && d_recv && sizes, "comm_all_to_all_v: bad arguments");
+    Comm *c = (Comm *)comm;
+    const char *s = (const char *)d_send;
+    char *r = (char *)d_recv;
+    int rc = rccl_check(g_rccl.GroupStart(), "ncclGroupStart");
+    size_t so = 0, ro = 0;
+    for (int q = 0; q < c->world && !rc; ++q) {
+        const size_t sb = (size_t)sizes[q], rb = (size_t)sizes[c->world + q];
+        if (sb) rc = rccl_check(g_rccl.Send(s + so, sb, kNcclUint8, q, c->comm, (hipStream_t)stream), "ncclSend");
+        if (!rc && rb) rc = rccl_check(g_rccl.Recv(r + ro, rb, kNcclUint8, q, c->comm, (hipStream_t)stream), "ncclRecv");
+        so += sb; ro += rb;
+    }
+    const int rc2 = rccl_check(g_rccl.GroupEnd(), "ncclGroupEnd");
+    return rc ? rc : rc2;
+}
+
 extern "C" int elimrec_program_create(const elimrec_op *ops, int n_ops, void **prog_out) {
     ELIMREC_REQUIRE(ops && n_ops > 0 && prog_out, "program_create: bad arguments");
     Program *p = new Program();
@@ -143,7 +192,7 @@ extern "C" int elimrec_program_create(const elimrec_op *ops, int n_ops, void **p
             if (o.fn < 0 || o.fn >= kNumFns) { delete p; set_error("program_create: unknown function index %d", o.fn); return ELIMREC_E_BADARG; }
         } else if (o.kind == ELIMREC_OP_RECORD || o.kind == ELIMREC_OP_WAIT) {
             if ((int)o.args[1] + 1 > n_events) n_events = (int)o.args[1] + 1;
-        } else if (o.kind < 0 || o.kind > ELIMREC_OP_ALL_TO_ALL_V) {
+        } else {
             delete p; set_error("program_create: unknown op kind %d", o.kind); return ELIMREC_E_BADARG;
         }
     }
@@ -181,45 +230,6 @@ extern "C" int elimrec_program_run(void *prog, const elimrec_patch *patches, int
             case ELIMREC_OP_CALL: rc = kFns[o.fn].thunk(a); break;
             case ELIMREC_OP_RECORD: rc = check_hip(hipEventRecord(p->events[a[1]], (hipStream_t)a[0]), "hipEventRecord"); break;
             case ELIMREC_OP_WAIT: rc = check_hip(hipStreamWaitEvent((hipStream_t)a[0], p->events[a[1]], 0), "hipStreamWaitEvent"); break;
-            case ELIMREC_OP_ALL_GATHER: {        // comm, send, recv, bytes per rank, stream
-                Comm *c = (Comm *)a[0];
-                rc = rccl_check(g_rccl.AllGather((const void *)a[1], (void *)a[2], (size_t)a[3], kNcclUint8, c->comm, (hipStream_t)a[4]), "ncclAllGather");
-                break;
-            }
-            case ELIMREC_OP_ALL_REDUCE_F32: {    // comm, buffer (in place), floats, stream
-                Comm *c = (Comm *)a[0];
-                rc = rccl_check(g_rccl.AllReduce((const void *)a[1], (void *)a[1], (size_t)a[2], kNcclFloat32, kNcclSum, c->comm, (hipStream_t)a[3]), "ncclAllReduce");
-                break;
-            }
-            case ELIMREC_OP_ALL_TO_ALL: {        // comm, send, recv, bytes per peer, stream
-                Comm *c = (Comm *)a[0];
-                const char *s = (const char *)a[1];
-                char *r = (char *)a[2];
-                const size_t nb = (size_t)a[3];
-                rc = rccl_check(g_rccl.GroupStart(), "ncclGroupStart");
-                for (int q = 0; q < c->world && !rc; ++q) {
-                    rc = rccl_check(g_rccl.Send(s + (size_t)q * nb, nb, kNcclUint8, q, c->comm, (hipStream_t)a[4]), "ncclSend");
-                    if (!rc) rc = rccl_check(g_rccl.Recv(r + (size_t)q * nb, nb, kNcclUint8, q, c->comm, (hipStream_t)a[4]), "ncclRecv");
-                }
-                if (!rc) rc = rccl_check(g_rccl.GroupEnd(), "ncclGroupEnd");
-                break;
-            }
-            case ELIMREC_OP_ALL_TO_ALL_V: {      // comm, send, recv, host int64 [2 x world] = send bytes | recv bytes per peer, stream
-                Comm *c = (Comm *)a[0];
-                const char *s = (const char *)a[1];
-                char *r = (char *)a[2];
-                const int64_t *sz = (const int64_t *)a[3];
-                rc = rccl_check(g_rccl.GroupStart(), "ncclGroupStart");
-                size_t so = 0, ro = 0;
-                for (int q = 0; q < c->world && !rc; ++q) {
-                    const size_t sb = (size_t)sz[q], rb = (size_t)sz[c->world + q];
-                    if (sb) rc = rccl_check(g_rccl.Send(s + so, sb, kNcclUint8, q, c->comm, (hipStream_t)a[4]), "ncclSend");
-                    if (!rc && rb) rc = rccl_check(g_rccl.Recv(r + ro, rb, kNcclUint8, q, c->comm, (hipStream_t)a[4]), "ncclRecv");
-                    so += sb; ro += rb;
-                }
-                if (!rc) rc = rccl_check(g_rccl.GroupEnd(), "ncclGroupEnd");
-                break;
-            }
             default: break;
         }
         if (rc) return rc;

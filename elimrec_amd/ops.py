@@ -759,3 +759,12 @@ def head_fwd_fused(act, seg_info, out0, narrow, c, S, Wm, bm, Wf_user, bf_user, 
         return False
     _lib.check(rc, "head_fwd_fused")
     return True
+
+
+def peer_cols_to_rows(recv, out0, out1):
+    """recv [W x R x 2*dl] (per peer: layer mean | shared part of my rows in its columns) -> out0 / out1 [R x W*dl] row views."""
+    W, R, two_dl = recv.shape
+    dl = two_dl // 2
+    assert recv.is_contiguous() and out0.stride(1) == 1 and out1.stride(1) == 1 and out0.shape == (R, W * dl) and out1.shape == (R, W * dl)
+    _lib.check(_lib.load().elimrec_peer_cols_to_rows(_dev(recv, "recv"), W, R, dl, _dev(out0, "out0"), out0.stride(0), _dev(out1, "out1"),
+                                                    out1.stride(0), _stream()), "peer_cols_to_rows")

@@ -108,12 +108,61 @@ class ColumnShardTrainer(object):
         def wait(self):
             return True
 
+    class _OnStream(object):
+        """Handle of a collective enqueued on the exchange stream: wait() orders the CURRENT stream behind it."""
+
+        def __init__(self, stream):
+            self.stream = stream
+
+        def wait(self):
+            program.sync(torch.cuda.current_stream(), self.stream)
+            return True
+
+    def _native_comm(self):
+        """The library's own RCCL communicator (csrc/program.hip) for the step's exchanges: collectives become C-ABI calls
+        enqueued on our streams -- no torch.distributed host path (~30 us per collective), and a native step program can list
+        them. Backend "nccl" only (ELIMREC_NATIVE_COMM=0: torch.distributed's collectives, as the gloo-staged tests use)."""
+        if self.__dict__.get("_comm") is None:
+            import os
+            self._comm = False
+            if (self.multi and self._hip_engine and os.environ.get("ELIMREC_NATIVE_COMM", "1") != "0" and dist.is_available()
+                    and dist.is_initialized() and dist.get_backend(self.group) == "nccl"):
+                lib = _lib.load()
+                dev = self.engine.model._device()
+                ident = (ctypes.c_char * 128)()
+                ok = 1
+                if self.rank == 0:
+                    ok = 0 if lib.elimrec_comm_unique_id(ident) else 1
+                t = torch.frombuffer(bytearray(bytes(ident)), dtype=torch.uint8).to(dev)
+                if self.world > 1:
+                    dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+                raw = bytes(t.cpu().numpy().tobytes())
+                ident = (ctypes.c_char * 128).from_buffer_copy(raw)
+                handle = ctypes.c_void_p()
+                if ok and lib.elimrec_comm_create(ident, self.world, self.rank, ctypes.byref(handle)) != 0:
+                    ok = 0
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                if self.world > 1:
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)      # all ranks or none
+                if int(flag.item()) == 1:
+                    self._comm, self._comm_stream = handle, torch.cuda.Stream()
+                elif handle:
+                    lib.elimrec_comm_destroy(handle)
+        return self._comm or None
+
     def _staged(self, t):
         if self._gloo is None:
             self._gloo = dist.get_backend(self.group) == "gloo"
         return self._gloo and t.is_cuda
 
     def _all_gather(self, out, inp):
+        comm = self._native_comm()
+        if comm is not None:            # on the exchange stream, under whatever the caller enqueues next on its own
+            program.sync(self._comm_stream, torch.cuda.current_stream())
+            with torch.cuda.stream(self._comm_stream):
+                _lib.check(_lib.load().elimrec_comm_all_gather(comm, inp.data_ptr(), out.data_ptr(), inp.numel() * inp.element_size(),
+                                                               ops._stream()), "comm_all_gather")
+            return self._OnStream(self._comm_stream)
         if not self._staged(inp):
             return dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
         host = torch.empty(out.shape, dtype=out.dtype)
@@ -122,6 +171,11 @@ class ColumnShardTrainer(object):
         return self._Done()
 
     def _all_to_all(self, out, inp):
+        comm = self._native_comm()
+        if comm is not None:            # on the compute stream, between the kernels that produce and consume the rows
+            _lib.check(_lib.load().elimrec_comm_all_to_all(comm, inp.data_ptr(), out.data_ptr(), inp[0].numel() * inp.element_size(),
+                                                           ops._stream()), "comm_all_to_all")
+            return
         if not self._staged(inp):
             # (synchronous form = on the compute stream; async_op + wait costs 24 us less host time per step and 23 us
             # more of stream hand-over: 0.461 against 0.438 ms per step over a one-rank RCCL group)
@@ -130,8 +184,15 @@ class ColumnShardTrainer(object):
         dist.all_to_all_single(host, inp.cpu(), group=self.group)
         out.copy_(host)
 
-    def _all_to_all_v(self, out, inp, out_splits, in_splits):
-        """Variable-size exchange of flat uint8 buffers (the looked-up rows): split sizes in bytes, per peer."""
+    def _all_to_all_v(self, out, inp, out_splits, in_splits, sizes=None):
+        """Variable-size exchange of flat uint8 buffers (the looked-up rows): split sizes in bytes, per peer. sizes: the same
+        numbers as a host int64 array [in_splits | out_splits] for the library's communicator."""
+        comm = self._native_comm()
+        if comm is not None:
+            if sizes is None:
+                sizes = (ctypes.c_int64 * (2 * self.world))(*(list(in_splits) + list(out_splits)))
+            _lib.check(_lib.load().elimrec_comm_all_to_all_v(comm, inp.data_ptr(), out.data_ptr(), sizes, ops._stream()), "comm_all_to_all_v")
+            return
         if not self._staged(inp):
             return dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=self.group)
         host = torch.empty(out.shape, dtype=out.dtype)
@@ -145,6 +206,7 @@ class ColumnShardTrainer(object):
         plan replaces the previous one (an epoch's tensors may reuse the addresses of the last epoch's). A step whose batch
         is not in the plan reads its sizes from the device (one synchronisation per step)."""
         self._lookup_plan = {}
+        self._lookup_size_arrays = {}
         if not self.lookup or not batches:
             return
         eng, W = self.engine, self.world
@@ -175,17 +237,36 @@ class ColumnShardTrainer(object):
     def _lookup_exchange(self, users, acts):
         """Looked-up rows of the row-sharded constant tables: owners pack, all_to_all, requesters unpack."""
         eng, q = self.engine, self.rank
-        counts = self._lookup_counts(users, acts)                 # [requester][owner] rows
-        rb = eng.lookup_row_bytes
+        sizes = self._lookup_sizes(users, acts)                   # host int64 [2W]: bytes to requester r | bytes from owner o
+        W = self.world
+        in_splits, out_splits = list(sizes[:W]), list(sizes[W:2 * W])
         send = eng.cs_lookup_pack(acts)
-        in_splits = [int(counts[r][q]) * rb for r in range(self.world)]      # what I send to requester r
-        out_splits = [int(counts[q][o]) * rb for o in range(self.world)]     # what owner o sends me
         recv = eng.cs_lookup_recv(sum(out_splits))
-        self._all_to_all_v(recv, send[:sum(in_splits)], out_splits, in_splits)
+        self._all_to_all_v(recv, send[:sum(in_splits)], out_splits, in_splits, sizes=sizes)
         self.xgmi_bytes["all_to_all_lookup"] = sum(in_splits) - in_splits[q]
         eng.cs_lookup_unpack(recv)
 
+    def _lookup_sizes(self, users, acts, peek=False):
+        """The exchange's split sizes in bytes as a host int64 array (kept per planned batch: its address is an argument of
+        the step's program)."""
+        key = (users.data_ptr(), int(users.numel()))
+        hit = self.__dict__.setdefault("_lookup_size_arrays", {}).get(key)
+        if hit is not None or peek:
+            return hit
+        counts = self._lookup_counts(users, acts)                 # [requester][owner] rows
+        rb, q, W = self.engine.lookup_row_bytes, self.rank, self.world
+        arr = (ctypes.c_int64 * (2 * W))(*([int(counts[r][q]) * rb for r in range(W)] + [int(counts[q][o]) * rb for o in range(W)]))
+        if key in self._lookup_plan:
+            self._lookup_size_arrays[key] = arr
+        return arr
+
     def _all_reduce_async(self, t):
+        comm = self._native_comm()
+        if comm is not None:
+            program.sync(self._comm_stream, torch.cuda.current_stream())
+            with torch.cuda.stream(self._comm_stream):
+                _lib.check(_lib.load().elimrec_comm_all_reduce_f32(comm, t.data_ptr(), t.numel(), ops._stream()), "comm_all_reduce")
+            return self._OnStream(self._comm_stream)
         if not self._staged(t):
             return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         host = t.cpu()
@@ -214,10 +295,18 @@ class ColumnShardTrainer(object):
 
     def _native_eligible(self, users, pos, neg):
         eng = self.engine
-        return (self._hip_engine and not self.multi and not self.profile_kernels and eng.kernel_events is None and not eng.keep_grad
+        if not (self._hip_engine and not self.profile_kernels and eng.kernel_events is None and not eng.keep_grad
                 and eng.model.mm_fusion_mode == "concat" and eng.model._use_replay and not eng.model._use_graphs
                 and all(t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() for t in (users, pos, neg))
-                and users.numel() == pos.numel() == neg.numel() and eng._side_stream() is None)
+                and users.numel() == pos.numel() == neg.numel()):
+            return False
+        if not self.multi:
+            return eng._side_stream() is None
+        # several ranks (or the multi-rank path on one): the exchanges must be the library's own RCCL calls, the received
+        # columns turned into rows by a kernel (fused head or compact constants), the lookup's split sizes planned ahead
+        if self._native_comm() is None or not (eng._fused_head_ok() or eng.lookup):
+            return False
+        return not self.lookup or (users.data_ptr(), int(users.numel())) in self._lookup_plan
 
     def _step(self, users, pos, neg):
         st = self._native_state()
@@ -235,6 +324,8 @@ class ColumnShardTrainer(object):
         # trace this step (launched from Python, every call recorded) -- two traces per buffer parity make a program
         known = dict(users=users.data_ptr(), pos=pos.data_ptr(), neg=neg.data_ptr(),
                      loss=eng._loss_ring.data_ptr() + 4 * eng._loss_at, step=eng.step_count + 1)
+        if self.multi and self.lookup:
+            known["sizes"] = ctypes.addressof(self._lookup_sizes(users, None))
         parity = eng.cur
         m = eng.model
         m._use_replay = False
@@ -268,7 +359,12 @@ class ColumnShardTrainer(object):
             eng._workspace(B)                                 # (an epoch's ragged last batch switched the buffer set)
         loss = eng._next_loss_slot()
         eng.native_prologue()
-        prog.run(dict(users=users.data_ptr(), pos=pos.data_ptr(), neg=neg.data_ptr(), loss=loss.data_ptr(), step=eng.step_count + 1))
+        values = dict(users=users.data_ptr(), pos=pos.data_ptr(), neg=neg.data_ptr(), loss=loss.data_ptr(), step=eng.step_count + 1)
+        if self.multi and self.lookup:
+            sizes = self._lookup_sizes(users, None)
+            values["sizes"] = ctypes.addressof(sizes)
+            self.xgmi_bytes["all_to_all_lookup"] = sum(sizes[:self.world]) - sizes[self.rank]
+        prog.run(values)
         eng.native_epilogue(3 * B)
         self._native["native_steps"] += 1
         return loss
@@ -771,11 +867,14 @@ class ColumnShardEngine(object):
             W = recv.shape[0]
             r = recv.view(W, R, 2, self.dl)
             if fused and self._head16:
-                # one copy: [R, (out0 | narrow), d]; the fused head reads both halves with a 2d row stride and writes
+                # one pass: [R, (out0 | narrow), d]; the fused head reads both halves with a 2d row stride and writes
                 # block 0 of OutAct itself
                 pair = self._pair(R, d)
-                pair.view(R, 2, W, self.dl).copy_(r.permute(1, 2, 0, 3))
+                ops.peer_cols_to_rows(recv.view(W, R, 2 * self.dl), pair[:, 0, :], pair[:, 1, :])
                 self._out0_src, self._nar_src = pair[:, 0, :], pair[:, 1, :]
+            elif fused or self.lookup:
+                ops.peer_cols_to_rows(recv.view(W, R, 2 * self.dl), ws["OutAct"][:R, :d], self.nar_act[:R])
+                self._out0_src = self._nar_src = None
             else:
                 ws["OutAct"][:R, :d].unflatten(1, (W, self.dl)).copy_(r[:, :, 0].permute(1, 0, 2))
                 if fused or self.lookup:

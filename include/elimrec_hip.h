@@ -758,6 +758,11 @@ int elimrec_lookup_unpack(const int32_t *d_act, int world, int64_t R, int64_t U,
                           const int64_t *ib, int me, const void *d_rows, int64_t row_bytes, int dtype, int sum_d,
                           int direct, float *d_S, int64_t ldS, float *d_c, void *stream);
 
+/* Column shards, forward exchange: d_recv [world x R x 2 x dl] = per peer q the (layer mean | shared part) of MY R active rows
+ * in q's dl columns -> rows: d_out0[r, q*dl + c] (leading dimension ld0) and d_out1[r, q*dl + c] (ld1). */
+int elimrec_peer_cols_to_rows(const float *d_recv, int world, int64_t R, int dl, float *d_out0, int64_t ld0, float *d_out1,
+                              int64_t ld1, void *stream);
+
 /* ---------------------------------------------------------------- a training step as one host call (csrc/program.hip)
  * The reference's loop body (main.py:98-101) is, on this path, ~13 launches on two HIP streams plus -- with several ranks --
  * four collectives. A program is that sequence written down once: calls of THIS library's entry points with their arguments
@@ -768,11 +773,7 @@ int elimrec_lookup_unpack(const int32_t *d_act, int world, int64_t R, int64_t U,
 #define ELIMREC_PROGRAM_MAX_ARGS 32
 enum { ELIMREC_OP_CALL = 0,          /* fn = index into the function table (elimrec_program_fn_name), args = its arguments      */
        ELIMREC_OP_RECORD = 1,        /* args: stream, event slot                                                                */
-       ELIMREC_OP_WAIT = 2,          /* args: stream, event slot                                                                */
-       ELIMREC_OP_ALL_GATHER = 3,    /* args: comm, send, recv [world x bytes], bytes per rank, stream                          */
-       ELIMREC_OP_ALL_REDUCE_F32 = 4,/* args: comm, buffer (in place, sum), floats, stream                                      */
-       ELIMREC_OP_ALL_TO_ALL = 5,    /* args: comm, send [world x bytes], recv [world x bytes], bytes per peer, stream          */
-       ELIMREC_OP_ALL_TO_ALL_V = 6 };/* args: comm, send, recv, host int64[2 x world] (send bytes | recv bytes per peer), stream */
+       ELIMREC_OP_WAIT = 2 };        /* args: stream, event slot                                                                */
 typedef struct elimrec_op { int32_t kind; int32_t fn; uint64_t args[ELIMREC_PROGRAM_MAX_ARGS]; } elimrec_op;
 typedef struct elimrec_patch { int32_t op; int32_t arg; uint64_t value; } elimrec_patch;
 int elimrec_program_fn_count(void);
@@ -787,6 +788,13 @@ int elimrec_program_destroy(void *prog);
 int elimrec_comm_unique_id(void *id128);
 int elimrec_comm_create(const void *id128, int world, int rank, void **comm_out);
 int elimrec_comm_destroy(void *comm);
+/* The step's exchanges on that communicator, enqueued on `stream` (sizes in BYTES; all_reduce: fp32 sum in place;
+ * all_to_all_v: `sizes` = HOST int64 [2 x world], bytes to send to peer 0.. then bytes to receive from peer 0.., chunks back
+ * to back in d_send / d_recv). Callable directly or from a program (they are in its function table). */
+int elimrec_comm_all_gather(void *comm, const void *d_send, void *d_recv, int64_t bytes_per_rank, void *stream);
+int elimrec_comm_all_reduce_f32(void *comm, float *d_buf, int64_t n, void *stream);
+int elimrec_comm_all_to_all(void *comm, const void *d_send, void *d_recv, int64_t bytes_per_peer, void *stream);
+int elimrec_comm_all_to_all_v(void *comm, const void *d_send, void *d_recv, const int64_t *sizes, void *stream);
 
 #ifdef __cplusplus
 }

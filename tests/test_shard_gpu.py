@@ -1125,3 +1125,56 @@ def test_native_step_program_equals_python_issued_steps(name, monkeypatch):
         assert torch.equal(out["1"][2][k], v), k
     for k, st0 in out["0"][3].items():
         assert out["1"][3][k]["step"] == st0["step"] and torch.equal(out["1"][3][k]["exp_avg"], st0["exp_avg"]), k
+
+
+def _native_multi_worker(rank, port, out_dir, feature_shard, native):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["ELIMREC_SHARD_MULTI"] = "1"
+    os.environ["ELIMREC_NATIVE_STEP"] = os.environ["ELIMREC_NATIVE_COMM"] = native
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
+    g = load_golden("kwai")
+    model, _ = build_model_from_fixture(g, DEV)
+    opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    eng = ColumnShardEngine(model, feature_shard=feature_shard)
+    tr = ColumnShardTrainer(eng, opt, world_size=1, rank=0)
+    base = [tuple(_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg")) for t in (1, 2)]
+    n0 = min(len(b[0]) for b in base)
+    gen = torch.Generator().manual_seed(0)
+    batches = []
+    for s in range(30):
+        perm = torch.randperm(n0, generator=gen).to(DEV)
+        batches.append(tuple(x[:n0][perm].clone() for x in base[s % 2]))
+    tr.plan_lookup(batches)
+    losses = torch.stack([tr.step(*b) for b in batches]).cpu().numpy()
+    st = tr._native_state()
+    assert (tr._native_comm() is not None) == (native == "1")
+    if native == "1":
+        assert st["failed"] is None, st["failed"]
+        assert st["native_steps"] >= 20, st
+        names = [tr._native["programs"][k][0]._keep for k in tr._native["programs"]]
+        assert names
+    eng.sync_to_model()
+    np.savez(os.path.join(out_dir, "native%s.npz" % native), losses=losses, lookup_syncs=np.array(tr.lookup_syncs),
+             **{k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("feature_shard", ["replicated", "row"])
+def test_native_multi_rank_program_with_rccl_calls(tmp_path, feature_shard):
+    """The MULTI-rank step as one host call: the exchanges are the library's own RCCL calls (elimrec_comm_all_gather /
+    all_to_all / all_to_all_v / all_reduce_f32 on a communicator created from a broadcast unique id), enqueued on our
+    streams and listed in the step's program beside the kernels. One rank over a real RCCL communicator: 30 steps from the
+    program equal, bit for bit, the same steps issued from Python with torch.distributed's collectives."""
+    import torch.multiprocessing as mp
+    port = 37500 + (os.getpid() % 2000) + (3 if feature_shard == "row" else 0)
+    for native in ("0", "1"):
+        mp.spawn(_native_multi_worker, args=(port + int(native), str(tmp_path), feature_shard, native), nprocs=1, join=True)
+    a, b = dict(np.load(tmp_path / "native0.npz")), dict(np.load(tmp_path / "native1.npz"))
+    assert int(a["lookup_syncs"]) == 0 and int(b["lookup_syncs"]) == 0
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
