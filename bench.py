@@ -323,7 +323,12 @@ def main():
         if not args.no_cpu_baseline and world == 1:     # the host baseline is timed on rank 0 at N=1 only
             cpu_batches = [tuple(x.cpu() for x in b) for b in batches[:5]]
             extra("cpu_baseline", lambda: cpu_baseline(ds, {k: v.cpu().numpy() for k, v in init_state.items()}, cfg, cpu_batches))
-        print(json.dumps(out))
+        try:        # C-side stdio first (RCCL prints its version banner there), so that the JSON line is the LAST line on stdout
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -212,6 +212,7 @@ SIGNATURES = {
                                     c_ptr, c_ptr, c_ptr]),
     "elimrec_lookup_unpack": (c_i32, [c_ptr, c_i32, c_i64, c_i64, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_i32, c_ptr, c_i64,
                                       c_i32, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
+    "elimrec_rows_bitmap": (c_i32, [c_ptr, c_i32, c_i64, c_i64, c_ptr, c_ptr]),
     "elimrec_peer_cols_to_rows": (c_i32, [c_ptr, c_i32, c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     "elimrec_program_fn_count": (c_i32, []),
     "elimrec_program_fn_name": (ctypes.c_char_p, [c_i32]),

@@ -47,7 +47,7 @@ static const FnEntry kFns[] = {
     ELIMREC_FN(elimrec_linear_bwd_w_batched_merge), ELIMREC_FN(elimrec_linear_bwd_w_reduce), ELIMREC_FN(elimrec_adam_multi),
     ELIMREC_FN(elimrec_source_rows_split), ELIMREC_FN(elimrec_copy_cols), ELIMREC_FN(elimrec_lookup_pack), ELIMREC_FN(elimrec_lookup_unpack),
     ELIMREC_FN(elimrec_lookup_counts), ELIMREC_FN(elimrec_adam_step_out), ELIMREC_FN(elimrec_adam_step_out16),
-    ELIMREC_FN(elimrec_peer_cols_to_rows), ELIMREC_FN(elimrec_comm_all_gather), ELIMREC_FN(elimrec_comm_all_reduce_f32),
+    ELIMREC_FN(elimrec_peer_cols_to_rows), ELIMREC_FN(elimrec_rows_bitmap), ELIMREC_FN(elimrec_comm_all_gather), ELIMREC_FN(elimrec_comm_all_reduce_f32),
     ELIMREC_FN(elimrec_comm_all_to_all), ELIMREC_FN(elimrec_comm_all_to_all_v),
 };
 constexpr int kNumFns = (int)(sizeof(kFns) / sizeof(kFns[0]));

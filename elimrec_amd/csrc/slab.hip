@@ -1822,6 +1822,47 @@ extern "C" int elimrec_slab_merge_rows(const float *d_rows, const int32_t *d_key
     return 0;
 }
 
+// Row bitmap of `world` sorted key lists (negative padding behind the valid prefix): bit n <=> node n is in some list. The
+// words elimrec_slab_merge_rows writes for the same lists -- available as soon as the ids are gathered, i.e. a whole forward
+// pass before the rows themselves arrive, so the masked hop's source bits can be prepared off the critical path.
+namespace elimrec {
+__global__ __launch_bounds__(256) void rows_bitmap_kernel(const int32_t *__restrict__ keys, int W, int R, int64_t N, int chunk,
+                                                          uint32_t *__restrict__ mask) {
+    extern __shared__ uint32_t seen[];
+    __shared__ int s_beg[kSlabMaxRanks], s_end[kSlabMaxRanks];
+    const int tid = threadIdx.x;
+    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(lo + chunk, N);
+    for (int w = tid; w < chunk / 32; w += 256) seen[w] = 0u;
+    if (tid < W) {
+        const int32_t *kr = keys + (int64_t)tid * R;
+        int a0 = 0, a1 = R, b0 = 0, b1 = R;
+        while (a0 < a1 || b0 < b1) {
+            if (a0 < a1) { const int m = (a0 + a1) >> 1; if (slab_merge_key(kr, m) < lo) a0 = m + 1; else a1 = m; }
+            if (b0 < b1) { const int m = (b0 + b1) >> 1; if (slab_merge_key(kr, m) < hi) b0 = m + 1; else b1 = m; }
+        }
+        s_beg[tid] = a0; s_end[tid] = b0;
+    }
+    __syncthreads();
+    for (int r = 0; r < W; ++r)
+        for (int s = s_beg[r] + tid; s < s_end[r]; s += 256) {
+            const int bit = (int)((int64_t)keys[(int64_t)r * R + s] - lo);
+            atomicOr(&seen[bit >> 5], 1u << (bit & 31));
+        }
+    __syncthreads();
+    for (int w = tid; w < chunk / 32; w += 256)
+        if (lo + 32 * (int64_t)w < ((N + 31) / 32) * 32) mask[lo / 32 + w] = seen[w];
+}
+}  // namespace elimrec
+
+extern "C" int elimrec_rows_bitmap(const int32_t *d_keys, int world, int64_t R, int64_t N, uint32_t *d_mask, void *stream) {
+    ELIMREC_REQUIRE(d_keys && d_mask && world >= 1 && world <= kSlabMaxRanks && R >= 1 && R < INT32_MAX && N >= 1, "rows_bitmap: bad arguments");
+    const int chunk = merge_rows_chunk(N);
+    hipLaunchKernelGGL(rows_bitmap_kernel, dim3((unsigned)((N + chunk - 1) / chunk)), dim3(256), (size_t)(chunk / 32) * sizeof(uint32_t),
+                       (hipStream_t)stream, d_keys, world, (int)R, N, chunk, d_mask);
+    ELIMREC_LAUNCH_CHECK("rows_bitmap");
+    return 0;
+}
+
 extern "C" int elimrec_adam_step_out(const float *d_p_in, float *d_p_out, const float *d_g, float *d_m, float *d_v,
                                      int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                                      int64_t step, void *stream) {

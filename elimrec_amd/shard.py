@@ -77,6 +77,11 @@ class ColumnShardTrainer(object):
         # RCCL group exercises every collective call of the step on a single GPU -- tests)
         self.multi = getattr(engine, "multi", self.world > 1)
         self._gloo = None
+        if isinstance(engine, ColumnShardEngine) and self.multi:
+            import os
+            on = os.environ.get("ELIMREC_MULTI_ASYNC", "1") != "0"
+            engine.multi_aux = on           # plan / weight packing / source bits on the second stream, as with one rank
+            engine.defer_wgrads = on        # weight gradients behind the adjoint hops' tiles, their all-reduce under the last hop
         # the HIP engine's phases without their torch.no_grad() wrappers: step() enters no_grad once (host time)
         self._hip_engine = isinstance(engine, ColumnShardEngine)
 
@@ -155,20 +160,23 @@ class ColumnShardTrainer(object):
             self._gloo = dist.get_backend(self.group) == "gloo"
         return self._gloo and t.is_cuda
 
-    def _all_gather(self, out, inp):
+    def _all_gather(self, out, inp, after=None):
+        """after: the stream that produced `inp` when it is not the current one (the planner's second stream)."""
         comm = self._native_comm()
         if comm is not None:            # on the exchange stream, under whatever the caller enqueues next on its own
-            program.sync(self._comm_stream, torch.cuda.current_stream())
+            program.sync(self._comm_stream, after if after is not None else torch.cuda.current_stream())
             with torch.cuda.stream(self._comm_stream):
                 _lib.check(_lib.load().elimrec_comm_all_gather(comm, inp.data_ptr(), out.data_ptr(), inp.numel() * inp.element_size(),
                                                                ops._stream()), "comm_all_gather")
             return self._OnStream(self._comm_stream)
+        if after is not None:
+            program.sync(torch.cuda.current_stream(), after)
         if not self._staged(inp):
             return dist.all_gather_into_tensor(out, inp, group=self.group, async_op=True)
         host = torch.empty(out.shape, dtype=out.dtype)
         dist.all_gather_into_tensor(host, inp.cpu(), group=self.group)
         out.copy_(host)
-        return self._Done()
+        return self._OnStream(torch.cuda.current_stream()) if out.is_cuda else self._Done()
 
     def _all_to_all(self, out, inp):
         comm = self._native_comm()
@@ -374,16 +382,18 @@ class ColumnShardTrainer(object):
         if self.profile_kernels and getattr(eng, "kernel_events", None) is None:
             eng.kernel_events = self._events
         # one rank: the hops go to the GPU before the plan's host work (they do not need it; the plan runs on a second stream)
-        early = self._hip_engine and not self.multi and eng.cs_fork()
+        early = self._hip_engine and eng.cs_fork()
         if early:
             ph["cs_forward_hops"]()
         act = ph["cs_plan"](users, pos, neg)                       # int32 [R]: sorted unique node ids, negative padding
         h_ids = None
         if self.multi:
-            # the id exchange runs on RCCL's stream under the forward hops, which do not need it
+            # the id exchange runs on the exchange stream under the forward hops, which do not need it
             acts = self._like("acts", act, W)
-            h_ids = self._all_gather(acts.view(-1), act)
+            h_ids = self._all_gather(acts.view(-1), act, after=eng.plan_stream() if self._hip_engine else None)
             self.xgmi_bytes["all_gather"] = act.numel() * 4 * (W - 1)
+            if self._hip_engine:
+                eng.cs_gathered_ids(acts, h_ids)                   # second stream: the adjoint's source bits, a forward pass early
         else:
             acts = act.view(1, -1)
         if not early:
@@ -404,16 +414,23 @@ class ColumnShardTrainer(object):
             self._scale = torch.full((1,), 1.0 / W, dtype=torch.float32, device=loss.device)
         send2, wgrads = ph["cs_backward_local"](self._scale)       # [W, R, 2*dl]: my rows, the peers' columns
         h_w = None
+        late = self.multi and self._hip_engine and eng.wgrads_deferred()
         if self.multi:
             recv2 = self._like("recv_b", send2)
             self._all_to_all(recv2, send2)
-            # the projection-weight gradients are needed by the optimizer step only: reduced under the adjoint hops
-            h_w = self._all_reduce_async(wgrads)
             self.xgmi_bytes["all_to_all_bwd"] = send2[0].numel() * 4 * (W - 1)
             self.xgmi_bytes["all_reduce"] = wgrads.numel() * 4
+            if not late:
+                # the projection-weight gradients are needed by the optimizer step only: reduced under the adjoint hops
+                h_w = self._all_reduce_async(wgrads)
         else:
             recv2 = send2
-        if h_w is not None and self._hip_engine:
+        if late:
+            # the weight gradients are FINISHED by the adjoint's first two hop launches (behind their tiles); they are reduced
+            # under the last hop, and the projection weights' optimizer spans follow in a launch of their own (cs_update)
+            ph["cs_backward_hops"](recv2, acts, None, lambda: self._all_reduce_async(wgrads))
+            h_w = eng.wgrads_handle
+        elif h_w is not None and self._hip_engine:
             ph["cs_backward_hops"](recv2, acts, h_w)
         else:
             ph["cs_backward_hops"](recv2, acts)
@@ -679,7 +696,7 @@ class ColumnShardEngine(object):
         peers the plan feeds the id exchange at once."""
         if self._aux is None:
             import os
-            on = not self.multi and os.environ.get("ELIMREC_AUX_STREAM", "1") != "0"
+            on = (not self.multi or getattr(self, "multi_aux", False)) and os.environ.get("ELIMREC_AUX_STREAM", "1") != "0"
             self._aux = torch.cuda.Stream() if on else False
         return self._aux or None
 
@@ -755,7 +772,7 @@ class ColumnShardEngine(object):
         err = m._index_err()
 
         aux = self._aux_stream()
-        early_bits = aux is not None and self.planT.tiered and not self.bf16
+        early_bits = aux is not None and self.planT.tiered and not self.bf16 and not self.multi      # (several ranks: cs_gathered_ids)
         if aux is not None and self._forked and getattr(self, "_ws_gen_planned", None) != m._ws_gen:
             # another batch size's buffer set (possibly allocated -- and zero-filled ON THE MAIN STREAM -- a moment ago, after
             # cs_fork ordered the second stream): order it again behind the main stream before the planner writes into it
@@ -783,6 +800,36 @@ class ColumnShardEngine(object):
                 m._region("cs_pack", (m._ws_gen, R), pack)
         self._aux_pending = True
         return act
+
+    def plan_stream(self):
+        """The stream cs_plan's launches went to when it is not the caller's (the second stream), else None."""
+        return self._aux_stream()
+
+    def wgrads_deferred(self):
+        """Several ranks: the weight gradients ride behind the adjoint hops' tiles (both phases) and are all-reduced late."""
+        return bool(getattr(self, "defer_wgrads", False)) and self.multi and self._side_stream_multi_ok() and self._fuse_reduce() \
+            and self._fuse_bwd_w()
+
+    def _side_stream_multi_ok(self):
+        return True
+
+    @torch.no_grad()
+    def cs_gathered_ids(self, acts, handle):
+        """Several ranks, second stream: as soon as every rank's active ids are here, the row bitmap of the adjoint's sources
+        (all ranks' rows) and the masked hop's per-line source bits -- a whole forward pass before the rows arrive."""
+        aux = self._aux_stream()
+        m = self.model
+        if aux is None or not self.planT.tiered or self.bf16:
+            return
+        with torch.cuda.stream(aux):
+            handle.wait()                                   # the second stream behind the id exchange
+
+            def bits():
+                slab.rows_bitmap(acts, m.num_users + m.num_items, self.mask)
+                slab.source_bits(self.planT, self.ns, self.w, self.gs, self.mask)
+            m._region("cs_bits", (m._ws_gen, acts.data_ptr(), acts.shape[0], acts.shape[1]), bits)
+        self._bits_ready = True
+        self._aux_pending = True
 
     def cs_fork(self):
         """One rank with the second stream: order it behind what the main stream holds NOW, so that the caller can enqueue the
@@ -976,6 +1023,8 @@ class ColumnShardEngine(object):
         defer = (not self.multi and side is None and self._fuse_reduce())
         if defer and merge is None and self._fuse_bwd_w():
             defer = "all"              # ... and the partial launch too: behind the first hop's tiles, the reduce behind the second's
+        if self.multi and self.wgrads_deferred():
+            defer = "all"              # several ranks: the same, and the all-reduce waits for the second hop (cs_backward_hops)
         self._grads = m._backward_batch_rows(ws, scale, ws["grad_rows"], R, head_only=True, w_stream=side, pack_bwd=pack_bwd,
                                              merge=merge, defer_reduce=defer, sources=sources)
         self._reduce = (m._bwd_w_reduce, 0 if defer == "all" else 1) if defer else None
@@ -993,9 +1042,11 @@ class ColumnShardEngine(object):
         return send, wg
 
     @torch.no_grad()
-    def cs_backward_hops(self, recv2, acts, grads_ready=None):
+    def cs_backward_hops(self, recv2, acts, grads_ready=None, reduce_wgrads=None):
         """grads_ready (several ranks): the handle of the weight gradients' all-reduce. Waited for before the LAST hop, whose
-        launch then carries the projection weights' optimizer spans as one rank's does; without it they run in cs_update."""
+        launch then carries the projection weights' optimizer spans as one rank's does; without it they run in cs_update.
+        reduce_wgrads (several ranks, deferred weight gradients): called once the hops that finish the weight gradients are
+        enqueued; returns the all-reduce's handle (kept in self.wgrads_handle), which then runs under the last hop."""
         m = self.model
         U, I, L = m.num_users, m.num_items, m.n_layers
         W, R = acts.shape
@@ -1006,8 +1057,9 @@ class ColumnShardEngine(object):
 
         single = not self.multi
         merged = single and getattr(self, "_merged", False)
-        reduce = getattr(self, "_reduce", None) if single else None
+        reduce = getattr(self, "_reduce", None) if (single or reduce_wgrads is not None) else None
         self._reduce = None
+        self.wgrads_handle = None
 
         def hops():
             phase = None if reduce is None else reduce[1]
@@ -1037,6 +1089,9 @@ class ColumnShardEngine(object):
             g = self.opt.param_groups[0]
             nxt = 1 - self.cur
             in_hop = single or grads_ready is not None
+            if reduce_wgrads is not None:                     # finished by the hops above: reduce them under this last hop
+                self.wgrads_handle = reduce_wgrads()
+                in_hop = False
             if grads_ready is not None:
                 grads_ready.wait()                            # reduced under the hops issued so far
             tail = self._tail_jobs() if in_hop else []        # (advances the weights' step counts: called once per step)
@@ -1075,8 +1130,12 @@ class ColumnShardEngine(object):
         if len(jobs) > 8:
             raise RuntimeError("more than 8 optimizer spans")
         if jobs:
-            arr = (_lib.AdamJob * len(jobs))(*jobs)
-            _lib.check(_lib.load().elimrec_adam_multi(arr, len(jobs), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
+            if getattr(self, "_tail_arr", None) is None:
+                self._tail_arr = (_lib.AdamJob * 8)()         # one array for every step (its address is a recorded argument)
+            for i, job in enumerate(jobs):
+                self._tail_arr[i] = job
+            self._tail_n = len(jobs) if getattr(self, "_adam_in_hop", False) else 0     # (native_prologue: spans from slot 0 only)
+            _lib.check(_lib.load().elimrec_adam_multi(self._tail_arr, len(jobs), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                                                       g["weight_decay"], ops._stream()), "adam_multi")
         self.cur = nxt
 

@@ -412,3 +412,11 @@ def adam_step_out(p_in, p_out, g, m, v, lr, beta1, beta2, eps, weight_decay, ste
     _lib.check(_lib.load().elimrec_adam_step_out(_dev(p_in, "p_in"), _dev(p_out, "p_out"), _dev(g, "g"), _dev(m, "m"),
                                                  _dev(v, "v"), n, float(lr), float(beta1), float(beta2), float(eps),
                                                  float(weight_decay), int(step), _stream()), "adam_step_out")
+
+
+def rows_bitmap(keys, N, mask):
+    """mask <- row bitmap of the key lists keys [W x R] (elimrec_rows_bitmap): the words merge_rows writes for the same lists."""
+    W, R = keys.shape
+    assert keys.is_contiguous() and mask.numel() * 32 >= N
+    _lib.check(_lib.load().elimrec_rows_bitmap(_dev(keys, "keys", torch.int32), int(W), int(R), int(N), _dev(mask, "mask", torch.int32),
+                                               _stream()), "rows_bitmap")

@@ -758,6 +758,9 @@ int elimrec_lookup_unpack(const int32_t *d_act, int world, int64_t R, int64_t U,
                           const int64_t *ib, int me, const void *d_rows, int64_t row_bytes, int dtype, int sum_d,
                           int direct, float *d_S, int64_t ldS, float *d_c, void *stream);
 
+/* Row bitmap of `world` active-row lists d_keys [world x R] (ascending, negative padding last): bit n of d_mask
+ * ((N + 31) / 32 words) <=> node n is in some list -- the words elimrec_slab_merge_rows writes for the same lists. */
+int elimrec_rows_bitmap(const int32_t *d_keys, int world, int64_t R, int64_t N, uint32_t *d_mask, void *stream);
 /* Column shards, forward exchange: d_recv [world x R x 2 x dl] = per peer q the (layer mean | shared part) of MY R active rows
  * in q's dl columns -> rows: d_out0[r, q*dl + c] (leading dimension ld0) and d_out1[r, q*dl + c] (ld1). */
 int elimrec_peer_cols_to_rows(const float *d_recv, int world, int64_t R, int dl, float *d_out0, int64_t ld0, float *d_out1,
