@@ -147,7 +147,7 @@ def main():
     ap.add_argument("--no-eval", action="store_true", help="skip the secondary evaluator timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-work", action="store_true", help="skip the reference-equivalent-work line")
-    ap.add_argument("--no-bf16", action="store_true", help="skip the bf16-storage line")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the bf16-storage (capacity mode) line")
     ap.add_argument("--feature-shard", choices=["auto", "row", "replicated"], default="auto",
                     help="folded constants S_m / c: row-sharded with an all_to_all lookup (default for N > 1, the north star's "
                          "partition) or replicated on every rank (default for N = 1, where both are the same tables)")
@@ -271,7 +271,10 @@ def main():
                                           "active rows per step" % world) if fshard == "row" and world > 1 else "replicated S_m / c",
                        "feature_dtype": args.feature_dtype,
                        "columns_per_gpu": eng.dl, "slabs": [eng.ns, eng.w, eng.gs],
-                       "propagation": "folded", "head_rows": "batch", "final_loss": final_loss},
+                       "propagation": "folded", "head_rows": "batch", "final_loss": final_loss,
+                       "step_issue": ("one host call per step (csrc/program.hip): %d of the %d timed steps" % (
+                           min(trainer._native_state()["native_steps"], args.steps), args.steps)) if trainer._native_state()["native_steps"] else
+                                     "launch by launch from Python" + (" (%s)" % trainer._native_state()["failed"] if trainer._native_state()["failed"] else "")},
             # bytes THIS implementation's step has to move per rank (closed form) and the fraction of
             # the HBM peak the whole step reaches on them; the reference algorithm's bytes are quoted beside it
             "step_model": {"bytes_per_rank_step": sb["total"], "GBps": sb["total"] / (ms * 1e-3) / 1e9,
@@ -285,7 +288,7 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic() if world == 1 else None,
                          "limiter": "per-CU gather path, not HBM: TA busy 47 %, L1 stalled on pending misses 45 % of the launch, "
-                                    "L2 hit rate 0.60 (profiles/r02_pmc_traffic.json; DESIGN.md section 3)",
+                                    "L2 hit rate 0.60 (profiles/r03_pmc_traffic.json; DESIGN.md section 3)",
                          # what the launch's gather instructions move: every non-zero pulls one row piece of each slab through the
                          # CUs' L1 (a source row is gathered deg times; the algorithmic bytes count it once). The chip's measured
                          # rate for uniformly random rows: MI355X_MICROARCH.md, "Indexed rows: gather into LDS"
@@ -368,12 +371,16 @@ def pmc_field(key, name="r03_pmc_traffic.json"):
 
 
 def pmc_traffic():
-    """HBM bytes per full hop from the committed PMC passes (profiles/r02_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE
+    """HBM bytes per full hop from the committed PMC passes (profiles/r03_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE
     collected in separate rocprofv3 --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950). None if
     the file is absent."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-            return json.load(f)["propagation_hop_traffic_bytes"]
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+            path = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(path):
+                with open(path) as f:
+                    return json.load(f)["propagation_hop_traffic_bytes"]
+        return None
     except Exception:
         return None
 
@@ -450,7 +457,11 @@ def bf16_line(args, device, cfg, batches, torch, steps=30):
     B = batches[0][0].numel()
     N = model.num_users + model.num_items
     hop_bytes = 2 * N * eng.dl * 2 + eng.plan.index_bytes()
-    return {"dtype": "bf16-storage/f32-acc", "ms_per_step": 1e3 * dt, "value": B / dt, "unit": "triplets/s", "steps": steps,
+    return {"dtype": "bf16-storage/f32-acc", "purpose": "CAPACITY mode, not a throughput result: half the bytes of the layer / adjoint tables "
+                                                         "for shapes that would not fit (configs[4]); at this shape the fp32 step is the faster one "
+                                                         "(the hop is gather-latency bound, not byte bound; the one-launch tile hop, the Adam epilogue "
+                                                         "and the tail-workgroup fusions exist for fp32 only)",
+            "ms_per_step": 1e3 * dt, "steps": steps,
             "final_loss": float(loss), "slabs": [eng.ns, eng.w, eng.gs],
             "roofline": {"bound": "hbm", "kernel": "sell_hop16_kernel (+ sell_fixup16_kernel)", "achieved": hop_bytes / (hop_us * 1e-6) / 1e9,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hop_bytes / (hop_us * 1e-6) / 1e9 / HBM_PEAK_GBS,

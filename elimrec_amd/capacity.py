@@ -23,7 +23,7 @@ def stats_of(plan):
 
 
 def plan(U, I, interactions, d, dims, world=1, layers=3, batch=2048, mods=None, symmetric=True, feature_dtype="f32",
-         eval_users=8192, topk=10, plan_stats=None, fused_head=None):
+         eval_users=8192, topk=10, plan_stats=None, fused_head=None, materialize_rows=1 << 18):
     """Bytes per GPU, by component. interactions = unique (user, item) training pairs (the adjacency has twice as many
     non-zeros); dims = widths of the feature tables; batch = triplets per GPU and step."""
     N, W, L = U + I, int(world), int(layers)
@@ -69,7 +69,9 @@ def plan(U, I, interactions, d, dims, world=1, layers=3, batch=2048, mods=None, 
     ev = {}
     i_loc = -(-I // W)
     ev["cached rows [all users ; my items] x Cy fp32 + squared block norms"] = (U + i_loc) * (Cy + M) * 4
-    ev["transient while materialising (my rows of Out, Y, S in fp32, the column transpose)"] = rows_loc * (C + Cy + sumD + 2 * d) * 4 + N * 2 * dl * 4
+    chunk = min(rows_loc, materialize_rows)
+    ev["transient while materialising (chunks of %d of every owner's rows: Out, S in fp32, the column transpose; the users' Y gather)" % chunk] = (
+        chunk * (C + sumD + 1 + d) * 4 + 2 * W * chunk * 2 * dl * 4 + (-(-U // W) * (W + 1) + U) * Cy * 4)
     ev["score workspace (%d users per launch, chunked top-%d)" % (eval_users, topk)] = ops.score_workspace(eval_users, U, i_loc, M - 1, topk, topk_only=True, d=d)
     return dict(components=out, training_bytes=int(train), eval_components=ev, eval_bytes=int(sum(ev.values())),
                 total_bytes=int(train + sum(ev.values())), per_gpu_GiB=round((train + sum(ev.values())) / 2 ** 30, 2))

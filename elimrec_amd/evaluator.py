@@ -99,6 +99,8 @@ class UniEvaluator(object):
             shard = (dist.get_rank(), dist.get_world_size())
         n = len(test_users)
         sharded = shard is not None and shard[1] > 1
+        if hasattr(model, "_ensure_tables") and getattr(model, "_cache", None) is not None and not sharded:
+            model._ensure_tables()       # (lean tables on one rank: the item-shard scorer exists once the tables are built)
         if sharded and hasattr(model, "_ensure_tables"):
             # every rank, before any rank can run out of users: materialising the cached tables of a multi-rank job is a
             # collective (ColumnShardEngine.materialize_tables), and a rank with an empty slice would otherwise skip it
@@ -112,13 +114,28 @@ class UniEvaluator(object):
         all_dev = alloc(n, self.metrics_num * self.max_top, dtype=torch.float32, device=model._require_gpu())
         at = lo
         mine = test_users[lo:hi]
-        for k, batch_users in enumerate(DataIterator(mine, batch_size=self.block_users, shuffle=False, drop_last=False)):
-            key = (k, lo, hi, self.block_users) if cached else None
+        block = self._users_per_launch(model)
+        for k, batch_users in enumerate(DataIterator(mine, batch_size=block, shuffle=False, drop_last=False)):
+            key = (k, lo, hi, block) if cached else None
             self.evaluate_batch(model, batch_users, cache_key=key, out=all_dev[at:at + len(batch_users)])
             at += len(batch_users)
         if sharded and reduce:
             dist.all_reduce(all_dev, op=dist.ReduceOp.SUM)
         return all_dev
+
+    def _users_per_launch(self, model):
+        """block_users, halved until the scorer's workspace for this catalogue (or this rank's item shard) fits the budget
+        (ELIMREC_EVAL_WS_GB, default 8): a recdim outside the chunked scorer's set needs a [users x items] score block, which
+        at 12.5 M items per rank is 50 MB per user."""
+        import os
+        block = self.block_users
+        sh = getattr(model, "_eval_shard", None)
+        n_items = (sh.i1 - sh.i0) if sh is not None else model.num_items
+        budget = float(os.environ.get("ELIMREC_EVAL_WS_GB", 8)) * 2 ** 30
+        while block > 16 and ops.score_workspace(block, model.num_users, n_items, model.S, self.max_top, topk_only=True,
+                                                 d=model.latent_dim) > budget:
+            block //= 2
+        return block
 
     def evaluate_batch(self, model, batch_users, return_topk=False, cache_key=None, out=None):
         """Per-user metric rows [len(batch_users), metrics*K] (device tensor) for one user block.

@@ -1337,9 +1337,15 @@ class ColumnShardEngine(object):
                 slab.rows(self.plan, self.ns, self.w, L, U, [t.data for t in tabs] + [self.xL.data], None, None, None, N, 1,
                           out0, narrow, False)
         if self.feature_shard == "row" and (self.world > 1 or self.lean or ws.get("fold") is None):
-            loc = torch.empty(N, 2 * self.dl, dtype=torch.float32, device=m._device())
-            all_rows(loc[:, :self.dl], loc[:, self.dl:])
-            return self._materialize_item_shard(ws, loc)
+            def rows_of(node_ids, out0, narrow):               # (layer mean | shared part) of the listed rows, my columns
+                n = int(node_ids.numel())
+                if self.bf16:
+                    slab.rows16(self.plan, self.ns, self.w, L, U, tabs[0].data, [t.data for t in tabs[1:]] + [self.xL.data], None,
+                                node_ids.view(1, n), None, n, 1, out0, narrow, False)
+                else:
+                    slab.rows(self.plan, self.ns, self.w, L, U, [t.data for t in tabs] + [self.xL.data], None, node_ids.view(1, n), None, n, 1,
+                              out0, narrow, False)
+            return self._materialize_item_shard(ws, rows_of)
         if self.world == 1:
             all_rows(ws["Out"][:, :d], ws["Narrow"])
         else:
@@ -1351,49 +1357,66 @@ class ColumnShardEngine(object):
         m._full_tables(ws, ws["snap_views"])
 
     @torch.no_grad()
-    def _materialize_item_shard(self, ws, loc):
-        """Row-sharded constants, several ranks: the cached tables are built ROW-sharded too -- every rank computes Out / Y
-        for the nodes it owns (its users, its items), from its own rows of S_m / c, and evaluation runs item-sharded
-        (shard_eval.py). loc [N x 2*dl]: (layer mean | shared part) of all rows in MY columns; one all_to_all hands every
-        owner its rows of every rank's columns (the column shards' transpose), one all_gather replicates the users' Y rows
-        (every rank scores all users against its items)."""
+    def _materialize_item_shard(self, ws, rows_of):
+        """Row-sharded constants: the cached tables are built ROW-sharded too -- every rank computes Out / Y for the nodes it
+        owns (its users, its items) from its own rows of S_m / c, and evaluation runs item-sharded (shard_eval.py).
+        rows_of(node ids, out0, narrow): (layer mean | shared part) of listed rows in MY columns. In chunks of
+        ELIMREC_MATERIALIZE_ROWS of every owner's rows (the transient stays a few GiB whatever N is): one all_to_all hands
+        every owner its chunk's rows of every rank's columns (the column shards' transpose), the projections run on the
+        chunk, and one all_gather at the end replicates the users' Y rows (every rank scores all users against its items)."""
+        import os
         from .shard_eval import HipShardBackend, ItemShardScorer, collectives_for
         m, W, q, own = self.model, self.world, self.rank, self.fshard.owners
-        d, dl, C, Cy, U = m.latent_dim, self.dl, m.C, m.Cy, m.num_users
-        dev = loc.device
+        d, dl, C, Cy = m.latent_dim, self.dl, m.C, m.Cy
+        dev = m._device()
         coll = collectives_for(self.group, W)
         if getattr(self, "_own_nodes", None) is None:
-            self._own_nodes = [torch.from_numpy(own.nodes(o)).to(dev) for o in range(W)]
-        rows = [len(n) for n in self._own_nodes]
+            self._own_nodes = [torch.from_numpy(own.nodes(o)).to(device=dev, dtype=torch.int32) for o in range(W)]
+        rows = [int(n.numel()) for n in self._own_nodes]
         mine = rows[q]
-        recv = coll.all_to_all_rows(torch.cat([loc[n] for n in self._own_nodes]), rows, [mine] * W).view(W, mine, 2, dl)
-        Out = torch.empty(mine, C, dtype=torch.float32, device=dev)
-        Out[:, :d].unflatten(1, (W, dl)).copy_(recv[:, :, 0].permute(1, 0, 2))
-        Nar = recv[:, :, 1].permute(1, 0, 2).reshape(mine, d).contiguous()
-        # my rows of the constants, widened to fp32 (direct read of the local table, in its own order)
-        S = torch.empty(mine, self.fshard.sum_d, dtype=torch.float32, device=dev)
-        c = torch.empty(mine, dtype=torch.float32, device=dev)
-        self.fshard.unpack(self._own_nodes[q].to(torch.int32), None, S, c, direct=True)
-        Wt = ws["snap_views"]                                       # the weights the last forward used (predict() is stale)
-        problems, off = [], 0
-        for k, (name, D) in enumerate(zip(m._mods, self.fshard.dims)):
-            problems.append((S[:, off:off + D], Wt[name + "_dense.weight"], Wt[name + "_dense.bias"], Out[:, (k + 1) * d:(k + 2) * d], c, Nar))
-            off += D
-        ops.linear_fwd_batched(problems)
         nu = own.rows(q)[0]
-        Y = torch.empty(mine, Cy, dtype=torch.float32, device=dev)
+        U, i_loc = m.num_users, mine - nu
+        Yshard = torch.empty(U + i_loc, Cy, dtype=torch.float32, device=dev)     # [all users ; my items]: what the scorer reads
+        Yu_loc, Yi = torch.empty(nu, Cy, dtype=torch.float32, device=dev), Yshard[U:]
+        Wt = ws["snap_views"]                                       # the weights the last forward used (predict() is stale)
         wu, wi = m._fusion_weights(Wt)
-        head = []
-        if nu:
-            head.append((Out[:nu], wu, Wt["embedding_user_after_GCN.bias"], Y[:nu, :d]))
-        if mine > nu:
-            head.append((Out[nu:], wi, Wt["embedding_item_after_GCN.bias"], Y[nu:, :d]))
-        for h, name in enumerate(m._mods):
-            blk = slice((h + 1) * d, (h + 2) * d)
-            head.append((Out[:, blk], Wt["s_dense_%s.weight" % name], Wt["s_dense_%s.bias" % name], Y[:, blk]))
-        ops.linear_fwd_batched(head)
-        Yu = coll.all_gather_rows(Y[:nu].contiguous(), [own.rows(o)[0] for o in range(W)])          # [U x Cy]
-        Yshard = torch.cat([Yu, Y[nu:]]).contiguous()
+        step = max(1024, int(os.environ.get("ELIMREC_MATERIALIZE_ROWS", 1 << 18)))
+        for r0 in range(0, max(rows), step):
+            span = [(min(r0, n), min(r0 + step, n)) for n in rows]          # this chunk of every owner's local rows
+            cnt = [b - a for a, b in span]
+            ids = torch.cat([self._own_nodes[o][a:b] for o, (a, b) in enumerate(span)])
+            loc = torch.empty(int(ids.numel()), 2 * dl, dtype=torch.float32, device=dev)
+            if ids.numel():
+                rows_of(ids, loc[:, :dl], loc[:, dl:])
+            k = cnt[q]
+            recv = coll.all_to_all_rows(loc, cnt, [k] * W).view(W, k, 2, dl)
+            if k == 0:
+                continue
+            a, b = span[q]
+            Out = torch.empty(k, C, dtype=torch.float32, device=dev)
+            Nar = torch.empty(k, d, dtype=torch.float32, device=dev)
+            ops.peer_cols_to_rows(recv.view(W, k, 2 * dl), Out[:, :d], Nar)
+            # my rows of the constants, widened to fp32 (direct read of the local table, in its own order)
+            S = torch.empty(k, self.fshard.sum_d, dtype=torch.float32, device=dev)
+            c = torch.empty(k, dtype=torch.float32, device=dev)
+            self.fshard.unpack(self._own_nodes[q][a:b].contiguous(), None, S, c, direct=True)
+            problems, off = [], 0
+            for j, (name, D) in enumerate(zip(m._mods, self.fshard.dims)):
+                problems.append((S[:, off:off + D], Wt[name + "_dense.weight"], Wt[name + "_dense.bias"], Out[:, (j + 1) * d:(j + 2) * d], c, Nar))
+                off += D
+            ops.linear_fwd_batched(problems)
+            ku = max(0, min(b, nu) - a)                             # user rows of this chunk come first
+            for lo, hi, dst, wf, bf in ((0, ku, Yu_loc[a:a + ku], wu, "embedding_user_after_GCN.bias"),
+                                        (ku, k, Yi[max(a, nu) - nu:b - nu], wi, "embedding_item_after_GCN.bias")):
+                if hi <= lo:
+                    continue
+                head = [(Out[lo:hi], wf, Wt[bf], dst[:, :d])]
+                for h, name in enumerate(m._mods):
+                    blk = slice((h + 1) * d, (h + 2) * d)
+                    head.append((Out[lo:hi, blk], Wt["s_dense_%s.weight" % name], Wt["s_dense_%s.bias" % name], dst[:, blk]))
+                ops.linear_fwd_batched(head)
+        Yshard[:U].copy_(coll.all_gather_rows(Yu_loc, [own.rows(o)[0] for o in range(W)]))           # every rank: all users' rows
+        del Yu_loc
         i0, i1 = int(own.ib[q]), int(own.ib[q + 1])
         m._eval_shard = ItemShardScorer(HipShardBackend(m, Yshard, i0, i1), coll, own.ib)
         m._eval_shard_Y = Yshard

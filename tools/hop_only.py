@@ -1,4 +1,4 @@
-"""N full hops of a slab-major table at the Tiktok shape, for rocprofv3 (--pmc / --kernel-trace). Dev tool.
+"""N full hops of a slab-major table at the Tiktok shape (SHAPE=c4: Tiktok x16 items), for rocprofv3 (--pmc / --kernel-trace). Dev tool.
 usage: hop_only.py [d] [hops]   env: ELIMREC_SLAB_W / ELIMREC_SLAB_GS choose the geometry"""
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -7,8 +7,8 @@ from elimrec_amd.model import create_adj_mat
 dev = "cuda:0"
 d = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 hops = int(sys.argv[2]) if len(sys.argv) > 2 else 12
-U, I = 36656, 76085
-ds = SyntheticDataset(U, I, 720829, feat_dims=(4, 4, 4), seed=0)
+U, I, E = (36656, 1217360, 16 * 720829) if os.environ.get("SHAPE") == "c4" else (36656, 76085, 720829)   # SHAPE=c4: BASELINE configs[3]
+ds = SyntheticDataset(U, I, E, feat_dims=(4, 4, 4), seed=0)
 adj = create_adj_mat(*ds.get_train_interactions(), U, I, "pre").tocsr()
 N = adj.shape[0]
 if os.environ.get("RELABEL") == "1":        # node ids = the plan's processing order: item rows then user rows, by decreasing degree

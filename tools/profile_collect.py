@@ -1,4 +1,4 @@
-"""gpurun_out/r02/* (tools/profile_round.sh) -> profiles/r02_*: kernel-stat CSVs copied, PMC passes summarised.
+"""gpurun_out/r03/* (tools/profile_round.sh) -> profiles/r03_*: kernel-stat CSVs copied, PMC passes summarised.
 Usage: python tools/profile_collect.py"""
 import collections
 import csv
@@ -8,7 +8,7 @@ import shutil
 import subprocess
 import sys
 
-O = "gpurun_out/r02"
+O = "gpurun_out/r03"
 
 
 def read(d):
@@ -22,8 +22,8 @@ def read(d):
 
 
 subprocess.check_call([sys.executable, "tools/pmc_summary.py", "--fetch", O + "/fetch", "--write", O + "/write", "--mfma", O + "/mfma",
-                       "--steps", "10", "--out", "/tmp/r02_pmc.json"], stdout=subprocess.DEVNULL)
-doc = json.load(open("/tmp/r02_pmc.json"))
+                       "--steps", "10", "--out", "/tmp/r03_pmc.json"], stdout=subprocess.DEVNULL)
+doc = json.load(open("/tmp/r03_pmc.json"))
 l2, ta = read(O + "/l2"), read(O + "/ta")
 hop = doc["propagation_hop_kernel"]
 h, t = l2[hop], ta[hop]
@@ -37,9 +37,46 @@ doc["propagation_hop_TA_busy_frac"] = round(avg(t["TA_BUSY_avr"]) / (gui / 8.0),
 doc["propagation_hop_TCP_pending_stall_frac"] = round(avg(t["TCP_PENDING_STALL_CYCLES_sum"]) / 256.0 / (gui / 8.0), 3)
 doc["note"] += (" TCC_HIT/TCC_MISS, TA_BUSY_avr, TCP_PENDING_STALL_CYCLES_sum from two more passes of the same command. Busy fractions: "
                 "counter / (GRBM_GUI_ACTIVE / 8 XCDs); TCP stall cycles are summed over the 256 CUs.")
-json.dump(doc, open("profiles/r02_pmc_traffic.json", "w"), indent=1)
-shutil.copy(O + "/stats/b_kernel_stats.csv", "profiles/r02_bench_kernel_stats.csv")
-shutil.copy(O + "/eval_stats/e_kernel_stats.csv", "profiles/r02_eval_kernel_stats.csv")
+# MFMA utilisation of the kernels that hold the reference's dense contractions (K1 feature projections, K5 fusion
+# Linears, K8 single-modal heads -- fused in head_fwd16 / head_bwd_input16; their weight gradients ride in the adjoint hops' tails)
+mf = read(O + "/mfma")
+util = {}
+for name, c in mf.items():
+    if c.get("SQ_VALU_MFMA_BUSY_CYCLES") and sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) > 0:
+        util[name.replace("void ", "").replace("elimrec::", "")] = round(sum(c["SQ_VALU_MFMA_BUSY_CYCLES"]) / (sum(c["GRBM_GUI_ACTIVE"]) / 8 * 1024), 4)
+doc["mfma_utilisation"] = {"what": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) per kernel, over its launches; K1 + K5 + K8 forward = "
+                                   "head_fwd16_kernel, their input gradients = head_bwd_input16_kernel, their weight gradients = the tail workgroups of "
+                                   "sell_tier_bwdw_kernel<8, true> (partial products) -- all latency-bound at <= 3B active rows, not MFMA-bound",
+                           "kernels": util}
+json.dump(doc, open("profiles/r03_pmc_traffic.json", "w"), indent=1)
+# C4 shape: one full hop of the [N x 128] table, slab groups side by side (default) and one after the other
+import os
+c4 = {}
+for tag, label in (("c4", "groups side by side (blockIdx % gs)"), ("c4o", "groups one after the other (ELIMREC_SLAB_ORDER=1)")):
+    if not os.path.isdir(O + "/%s_fetch" % tag):
+        continue
+    f, w = read(O + "/%s_fetch" % tag), read(O + "/%s_write" % tag)
+    hopk = [k for k in f if "sell_tier_kernel" in k][0]
+    rows = list(csv.DictReader(open(O + "/%s_stats/h_kernel_stats.csv" % tag)))
+    avg_ns = float([r for r in rows if "sell_tier_kernel" in r["Name"]][0]["AverageNs"])
+    fetch = 2 * sum(f[hopk]["FETCH_SIZE"]) * 1024 / len(f[hopk]["FETCH_SIZE"])
+    write = sum(w[hopk]["WRITE_SIZE"]) * 1024 / len(w[hopk]["WRITE_SIZE"])
+    c4[label] = {"avg_launch_us": round(avg_ns / 1e3, 1), "fetch_MB_x2": round(fetch / 1e6, 1), "write_MB": round(write / 1e6, 1),
+                 "traffic_MB": round((fetch + write) / 1e6, 1)}
+    if os.path.isdir(O + "/%s_l2" % tag):
+        l = read(O + "/%s_l2" % tag)[hopk]
+        c4[label]["L2_hit_rate"] = round(sum(l["TCC_HIT_sum"]) / (sum(l["TCC_HIT_sum"]) + sum(l["TCC_MISS_sum"])), 3)
+if c4:
+    N, dcol = 36656 + 1217360, 128
+    json.dump({"note": "tools/hop_only.py 128 12 with SHAPE=c4 (BASELINE configs[3]: |U| = 36 656, |I| = 1 217 360, recdim 128) under rocprofv3: kernel "
+                       "stats, FETCH_SIZE (x2, gfx950) and WRITE_SIZE in separate passes. Algorithmic bytes of a hop = read X + write X' = 2 x N x 128 x 4 "
+                       "+ the index stream.", "table_MB": round(N * dcol * 4 / 1e6, 1), "algorithmic_MB_without_index": round(2 * N * dcol * 4 / 1e6, 1),
+               "variants": c4}, open("profiles/r03_c4_hop_traffic.json", "w"), indent=1)
+    print(json.dumps(c4, indent=1))
+if os.path.exists(O + "/multi_stats/m_kernel_stats.csv"):
+    shutil.copy(O + "/multi_stats/m_kernel_stats.csv", "profiles/r03_multi_rank_path_kernel_stats.csv")
+shutil.copy(O + "/stats/b_kernel_stats.csv", "profiles/r03_bench_kernel_stats.csv")
+shutil.copy(O + "/eval_stats/e_kernel_stats.csv", "profiles/r03_eval_kernel_stats.csv")
 ev, ef, ew = read(O + "/eval_pmc"), read(O + "/eval_fetch"), read(O + "/eval_write")
 out = {}
 for name in ev:
@@ -60,7 +97,7 @@ for name in ev:
 json.dump({"note": "rocprofv3 --pmc passes over tools/eval_prof.py (3 TIE validation passes, 8192 users per launch, default math, catalogue in "
                    "16384-item chunks). mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 SEs); "
                    "valu_issue_busy_frac = 4 x SQ_ACTIVE_INST_VALU (quad-cycles) / 1024 / the same duration. FETCH_SIZE doubled (gfx950).",
-           "kernels": out}, open("profiles/r02_eval_pmc.json", "w"), indent=1)
+           "kernels": out}, open("profiles/r03_eval_pmc.json", "w"), indent=1)
 for k in ("propagation_hop_kernel", "propagation_hop_traffic_bytes", "propagation_hop_L2_hit_rate", "propagation_hop_TA_busy_frac",
           "propagation_hop_TCP_pending_stall_frac"):
     print(k, doc.get(k))

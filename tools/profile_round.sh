@@ -1,10 +1,10 @@
-# Round profiles (run on the GPU box through gpurun; outputs under gpurun_out/r02, summaries are then copied to profiles/).
+# Round profiles (run on the GPU box through gpurun; outputs under gpurun_out/r03, summaries are then copied to profiles/).
 # Kernel stats and PMC counters in SEPARATE rocprofv3 runs (no --pmc together with trace domains).
 cd /tmp; export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; mkdir -p $O
-B="python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-reference-work --no-bf16"
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03; mkdir -p $O
+B="python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-reference-work --no-bf16 --no-b-sweep"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- $B > $O/bench_stats.log 2>&1 < /dev/null
-P="python3 $R/bench.py --steps 9 --warmup 1 --no-cpu-baseline --no-reference-work --no-bf16 --no-eval"
+P="python3 $R/bench.py --steps 9 --warmup 1 --no-cpu-baseline --no-reference-work --no-bf16 --no-eval --no-b-sweep"
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o p -- $P > /dev/null 2>&1 < /dev/null
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o p -- $P > /dev/null 2>&1 < /dev/null
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -o p -- $P > /dev/null 2>&1 < /dev/null
@@ -16,5 +16,21 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/eval_stat
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $O/eval_pmc -o p -- $E > /dev/null 2>&1 < /dev/null
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/eval_fetch -o p -- $E > /dev/null 2>&1 < /dev/null
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/eval_write -o p -- $E > /dev/null 2>&1 < /dev/null
+# C4 shape (BASELINE configs[3]: |I| = 1.2 M, recdim 128): HBM traffic of a full hop, slab groups side by side and one after the other
+export SHAPE=c4
+H="python3 $R/tools/hop_only.py 128 12"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4_stats -o h -- $H > $O/c4_hop.log 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c4_fetch -o p -- $H > /dev/null 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c4_write -o p -- $H > /dev/null 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/c4_l2 -o p -- $H > /dev/null 2>&1 < /dev/null
+export ELIMREC_SLAB_ORDER=1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4o_stats -o h -- $H > $O/c4o_hop.log 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c4o_fetch -o p -- $H > /dev/null 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c4o_write -o p -- $H > /dev/null 2>&1 < /dev/null
+unset ELIMREC_SLAB_ORDER SHAPE
+# the multi-rank step over a one-rank RCCL communicator (the library's own RCCL calls, issued from the step's program)
+export ELIMREC_SHARD_MULTI=1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/multi_stats -o m -- python3 $R/tools/step_trace.py 60 > $O/multi.log 2>&1 < /dev/null
+unset ELIMREC_SHARD_MULTI
 find $O -name "*kernel_trace.csv" -delete      # large; the stats csv is what gets committed
 ls -R $O | head -50

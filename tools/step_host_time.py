@@ -5,15 +5,21 @@ import os, sys, time, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench
 from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam, PairwiseSamplerV2
+if os.environ.get("ELIMREC_SHARD_MULTI") == "1":       # the multi-rank step over a one-rank RCCL group
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29534")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
 cfg, ds, model = bench.build(None, "cuda:0")
 model = model.to("cuda:0")
 opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
-eng = ColumnShardEngine(model)
+eng = ColumnShardEngine(model, feature_shard=os.environ.get("FSHARD", "replicated"))
 tr = ColumnShardTrainer(eng, opt)
 B = 2048
 s = PairwiseSamplerV2(ds, batch_size=B, device="cuda:0", seed=1)
 U, P, N = s.sample_epoch()
 bs = [(U[i * B:(i + 1) * B], P[i * B:(i + 1) * B], N[i * B:(i + 1) * B]) for i in range(200)]
+tr.plan_lookup(bs)
 for b in bs[:20]:
     tr.step(*b)
 torch.cuda.synchronize()
