@@ -4,7 +4,10 @@
 // entry point of the C ABI; failures become c10::Error (RuntimeError in Python) carrying elimrec_last_error().
 // The ctypes binding (elimrec_amd/_lib.py) stays for hosts without torch; both call the same library.
 //
-//   propagate(rowptr i32[N+1], col i32[nnz], val f32[nnz], X f32[N x C], L) -> mean over the L+1 layer tables
+//   propagate(rowptr i32[N+1], col i32[nnz], val f32[nnz], X f32[N x C], L, transpose=False) -> mean over the L+1 layer tables
+//       (transpose: with A^T -- the adjoint of a propagation matrix that is not self-adjoint)
+//   segment_reduce(rows f32[n x ld], keys i32[n], split_key) -> (active keys, summed rows, seg_info): the deterministic
+//       index_put(accumulate) of the backward pass; bpr_head_fwd's grad_rows + keys are its inputs (= "bpr_head_bwd")
 //   linear_fwd(A, W, bias?) -> A W^T + bias                linear_bwd_w(A, B) -> (A^T B, column sums of A)
 //   bpr_head_fwd(Y, U, I, users, pos, neg, d, block_weights) -> (loss_rows, grad_rows, keys)
 //   adam_step_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step) -> p
@@ -41,12 +44,25 @@ const at::Tensor rowmajor(const at::Tensor &t, const char *name) {
     return t.stride(1) == 1 ? t : t.contiguous();
 }
 
-at::Tensor propagate(const at::Tensor &rowptr, const at::Tensor &col, const at::Tensor &val, const at::Tensor &X, int64_t L) {
+at::Tensor propagate(const at::Tensor &rowptr, const at::Tensor &col, const at::Tensor &val, const at::Tensor &X, int64_t L,
+                     bool transpose) {
     need(rowptr, "rowptr", at::kInt, 1); need(col, "col", at::kInt, 1); need(val, "val", at::kFloat, 1);
     need(X, "X", at::kFloat, 2);
-    const at::Tensor x = X.contiguous(), rp = rowptr.contiguous(), c = col.contiguous(), v = val.contiguous();
+    const at::Tensor x = X.contiguous();
+    at::Tensor rp = rowptr.contiguous(), c = col.contiguous(), v = val.contiguous();
     const int64_t n = x.size(0), C = x.size(1);
     TORCH_CHECK(rp.numel() == n + 1, "elimrec::propagate: rowptr has ", rp.numel(), " entries for ", n, " rows");
+    if (transpose) {
+        // the adjoint's matrix (SparseAddmmBackward multiplies by A^T; 'pre' is self-adjoint, 'gcmc' / 'norm' are not): CSR of
+        // A^T from CSR of A -- index bookkeeping only (a stable sort by column), the propagation itself is the same kernel
+        const at::Tensor counts = (rp.slice(0, 1) - rp.slice(0, 0, n)).to(at::kLong);
+        const at::Tensor rows = at::repeat_interleave(at::arange(n, counts.options()), counts);
+        const at::Tensor cl = c.to(at::kLong);
+        const at::Tensor order = at::argsort(cl * n + rows, /*stable=*/true, 0, false);
+        rp = at::cat({at::zeros({1}, counts.options()), at::cumsum(at::bincount(cl, {}, n), 0)}).to(at::kInt);
+        c = rows.index_select(0, order).to(at::kInt);
+        v = v.index_select(0, order);
+    }
     at::Tensor out = at::empty_like(x), t0 = at::empty_like(x), t1 = at::empty_like(x);
     check(elimrec_propagate(rp.data_ptr<int32_t>(), c.data_ptr<int32_t>(), v.data_ptr<float>(), n, (int)C, nullptr, (int)L,
                             x.data_ptr<float>(), t0.data_ptr<float>(), t1.data_ptr<float>(), out.data_ptr<float>(), cur_stream()),
@@ -147,6 +163,24 @@ at::Tensor rank_metrics(const at::Tensor &topk_idx, const at::Tensor &truth_ptr,
     return out;
 }
 
+// IndexBackward / index_put(accumulate): rows with equal keys summed in ascending row order, deterministic.
+// -> (active keys int32[n] (first n_active valid), reduced f32[n x ld], seg_info int32[8] = {n_active, #keys < split_key, ...})
+std::tuple<at::Tensor, at::Tensor, at::Tensor> segment_reduce(const at::Tensor &rows, const at::Tensor &keys, int64_t split_key) {
+    need(keys, "keys", at::kInt, 1);
+    const at::Tensor r = rowmajor(rows, "rows").contiguous(), k = keys.contiguous();
+    const int64_t n = r.size(0), ld = r.size(1);
+    TORCH_CHECK(k.numel() == n, "elimrec::segment_reduce: one key per row");
+    at::Tensor active = at::empty({n}, k.options()), reduced = at::empty({n, ld}, r.options());
+    at::Tensor seg = at::zeros({8}, k.options());
+    const size_t need_ws = elimrec_segment_reduce_workspace(n);
+    at::Tensor ws = at::empty({(int64_t)(need_ws ? need_ws : 1)}, r.options().dtype(at::kByte));
+    check(elimrec_segment_reduce_rows(r.data_ptr<float>(), k.data_ptr<int32_t>(), n, (int)ld, (int32_t)split_key, active.data_ptr<int32_t>(),
+                                      reduced.data_ptr<float>(), nullptr, seg.data_ptr<int32_t>(), ws.data_ptr(), (size_t)ws.numel(),
+                                      cur_stream()),
+          "segment_reduce");
+    return {active, reduced, seg};
+}
+
 std::tuple<at::Tensor, at::Tensor, at::Tensor> sample_triplets(const at::Tensor &user_ids, const at::Tensor &ptr, const at::Tensor &items,
                                                                int64_t num_items, int64_t n, int64_t seed, int64_t epoch) {
     need(user_ids, "user_ids", at::kInt, 1); need(ptr, "ptr", at::kLong, 1); need(items, "items", at::kInt, 1);
@@ -162,7 +196,8 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> sample_triplets(const at::Tensor 
 }  // namespace
 
 TORCH_LIBRARY(elimrec, m) {
-    m.def("propagate(Tensor rowptr, Tensor col, Tensor val, Tensor X, int L) -> Tensor");
+    m.def("propagate(Tensor rowptr, Tensor col, Tensor val, Tensor X, int L, bool transpose=False) -> Tensor");
+    m.def("segment_reduce(Tensor rows, Tensor keys, int split_key) -> (Tensor, Tensor, Tensor)");
     m.def("linear_fwd(Tensor A, Tensor W, Tensor? bias) -> Tensor");
     m.def("linear_bwd_w(Tensor A, Tensor B) -> (Tensor, Tensor)");
     m.def("bpr_head_fwd(Tensor Y, int U, int I, Tensor users, Tensor pos, Tensor neg, int d, float[] block_weights) -> (Tensor, Tensor, Tensor)");
@@ -174,6 +209,7 @@ TORCH_LIBRARY(elimrec, m) {
 
 TORCH_LIBRARY_IMPL(elimrec, CUDA, m) {
     m.impl("propagate", &propagate);
+    m.impl("segment_reduce", &segment_reduce);
     m.impl("linear_fwd", &linear_fwd);
     m.impl("linear_bwd_w", &linear_bwd_w);
     m.impl("bpr_head_fwd", &bpr_head_fwd);

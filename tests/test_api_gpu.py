@@ -258,6 +258,19 @@ def test_torch_ops_match_the_ctypes_binding():
     assert abs(float(loss_rows.sum()) - float(g_["step1/loss"])) < 1e-5
     with pytest.raises(RuntimeError):
         t.propagate(rp[:-3], col, val, X, L)
+    # transpose flag: the adjoint of a matrix that is not self-adjoint (SparseAddmmBackward multiplies by A^T)
+    got_t = t.propagate(rp, col, val, X, L, True)
+    xs = [X.double()]
+    for _ in range(L):
+        xs.append(A.t() @ xs[-1])
+    assert (got_t.double() - torch.stack(xs).mean(0)).abs().max().item() < 1e-5
+    # segment_reduce (= the row-gradient reduction behind bpr_head_fwd: "bpr_head_bwd") == index_add in key order
+    active, reduced, seg = t.segment_reduce(grad_rows, keys, model.num_users)
+    n_act = int(seg[0])
+    uniq = torch.unique(keys.long())
+    assert n_act == len(uniq) and torch.equal(active[:n_act].long(), uniq) and int(seg[1]) == int((uniq < model.num_users).sum())
+    want = torch.zeros(model.num_users + model.num_items, model.Cy, device=DEV, dtype=torch.float64).index_add_(0, keys.long(), grad_rows.double())
+    assert (reduced[:n_act].double() - want[uniq]).abs().max().item() < 1e-6
 
 
 @pytest.mark.parametrize("adj_type", ["pre", "plain", "gcmc", "norm", "mean"])

@@ -1178,3 +1178,41 @@ def test_native_multi_rank_program_with_rccl_calls(tmp_path, feature_shard):
     assert int(a["lookup_syncs"]) == 0 and int(b["lookup_syncs"]) == 0
     for k in a:
         assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("W,R,dl", [(1, 50, 64), (2, 300, 32), (8, 1000, 8), (5, 7, 4)])
+def test_peer_cols_to_rows_and_rows_bitmap_vs_torch(W, R, dl):
+    """The two exchange helpers of the multi-rank step: received column slices [W x R x 2 x dl] -> two row views (what the
+    torch permuted copies did), and the row bitmap of W sorted id lists == the words elimrec_slab_merge_rows writes for the
+    same lists (an all-padding list and duplicates across lists included)."""
+    from elimrec_amd import ops, slab
+    g = torch.Generator().manual_seed(W * 1000 + R)
+    recv = torch.randn(W, R, 2 * dl, generator=g).to(DEV)
+    pair = torch.full((R, 2, W * dl + 4), 7.0, device=DEV)                     # strided destinations, padding untouched
+    ops.peer_cols_to_rows(recv, pair[:, 0, :W * dl], pair[:, 1, :W * dl])
+    r = recv.view(W, R, 2, dl)
+    assert torch.equal(pair[:, 0, :W * dl], r[:, :, 0].permute(1, 0, 2).reshape(R, W * dl))
+    assert torch.equal(pair[:, 1, :W * dl], r[:, :, 1].permute(1, 0, 2).reshape(R, W * dl))
+    assert (pair[:, :, W * dl:] == 7.0).all()
+    U, I = 700, 1900
+    N = U + I
+    lists = []
+    for q in range(W):
+        n_act = 0 if (q == 1 and W > 2) else int(torch.randint(1, min(R, N) + 1, (1,), generator=g))
+        ids = torch.randperm(N, generator=g)[:n_act].sort().values
+        lists.append(torch.cat([ids, torch.full((R - n_act,), -(1 << 30), dtype=torch.int64)]).to(torch.int32))
+    acts = torch.stack(lists).to(DEV)
+    mask = torch.full(((N + 31) // 32 + 2,), -1, dtype=torch.int32, device=DEV)
+    slab.rows_bitmap(acts, N, mask)
+    want = np.zeros(N, bool)
+    for l in lists:
+        want[l[l >= 0].numpy()] = True
+    words = mask.cpu().numpy().view(np.uint32)[:(N + 31) // 32]
+    got = ((words[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).astype(bool).reshape(-1)[:N]
+    assert np.array_equal(got, want)
+    # ... and the same words as the merge kernel leaves for these lists
+    ns, w = slab.choose_slabs(dl)
+    srcA, srcB = slab.SlabTable(N, ns, w, DEV), slab.SlabTable(N, ns, w, DEV)
+    mask2 = torch.zeros_like(mask)
+    slab.merge_rows(torch.randn(W * R, 2 * dl, generator=g).to(DEV), acts.reshape(-1), W, U, I, srcA, srcB, mask2)
+    assert torch.equal(mask2[:(N + 31) // 32], mask[:(N + 31) // 32])
