@@ -1216,3 +1216,56 @@ def test_peer_cols_to_rows_and_rows_bitmap_vs_torch(W, R, dl):
     mask2 = torch.zeros_like(mask)
     slab.merge_rows(torch.randn(W * R, 2 * dl, generator=g).to(DEV), acts.reshape(-1), W, U, I, srcA, srcB, mask2)
     assert torch.equal(mask2[:(N + 31) // 32], mask[:(N + 31) // 32])
+
+
+def test_bf16_storage_vs_rounding_oracle_at_the_tiktok_shape():
+    """--table_dtype=bf16 at the size BASELINE.json configs[1] names it for (|U| = 36 656, |I| = 76 085, 128-d x 3, recdim 64,
+    B = 2048): two steps against the folded oracle with straight-through bf16 rounding at the same points of the forward
+    (gather copy of X^0, stored X^1..X^(L-1)) -- loss 2e-3 abs, embeddings after Adam 2e-3 abs, the mode's stated tolerance --
+    with the fp32 engine against the same oracle WITHOUT rounding beside it (1e-5 / 2e-5)."""
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, EliMRec, FusedAdam, SyntheticDataset, set_seed
+    from elimrec_amd.shard import ColumnShardTrainer as T
+    from test_dist_cpu import ColumnShardOracleEngine, OracleOpt
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    U, I, B = 36656, 76085, 2048
+    cfg = make_config(["--data.input.dataset=synthetic", "--alpha=0.5", "--loss=bpr_loss", "--recdim=64", "--verbose=0"])
+    ds = SyntheticDataset(U, I, 720829, feat_dims=(128, 128, 128), seed=0)
+    set_seed(3)
+    model0 = EliMRec(cfg, ds)
+    init = {k: v.detach().clone() for k, v in model0.state_dict().items()}
+    tu, ti = ds.get_train_interactions()
+    g = {"train_u": np.asarray(tu), "train_i": np.asarray(ti), "num_users": U, "num_items": I, "adj_type": "pre", "recdim": 64,
+         "layer_num": int(cfg["layer_num"]), "alpha": 0.5, "dataset_name": "synthetic", "modality": "vat", "mm_fusion_mode": "concat",
+         "lr": float(cfg["lr"]), "weight_decay": float(cfg["weight_decay"])}
+    for m in "vat":
+        g[m + "_feat"] = getattr(model0, m + "_feat").numpy()
+    for k, v in init.items():
+        g["init/" + k] = v.numpy()
+    gen = torch.Generator().manual_seed(5)
+    train = ds.train_matrix.tocoo()
+    batches = []
+    for _ in range(2):
+        pick = torch.randint(0, train.nnz, (B,), generator=gen).numpy()
+        batches.append((torch.from_numpy(train.row[pick].astype(np.int64)), torch.from_numpy(train.col[pick].astype(np.int64)),
+                        torch.randint(0, I, (B,), generator=gen)))
+    res = {}
+    for mode in ("f32", "bf16"):
+        model = EliMRec(cfg, ds)
+        model.load_state_dict(init)
+        model = model.to(DEV)
+        opt = FusedAdam(model.parameters(), lr=g["lr"], weight_decay=g["weight_decay"])
+        eng = ColumnShardEngine(model, table_dtype=mode)
+        tr = ColumnShardTrainer(eng, opt)
+        ora = ColumnShardOracleEngine(g)
+        ora.round_fn = _ste_bf16 if mode == "bf16" else None
+        otr = T(ora, OracleOpt(ora, g))
+        worst = 0.0
+        for u, p, n in batches:
+            lo = float(otr.step(u, p, n))
+            lg = float(tr.step(u.to(DEV), p.to(DEV), n.to(DEV)))
+            worst = max(worst, abs(lo - lg))
+        emb = (eng.master[eng.cur].dense().cpu() - ora.shard.detach()).abs().max().item()
+        res[mode] = (worst, emb)
+        assert worst < (2e-3 if mode == "bf16" else 1e-5), (mode, worst)
+        assert emb < (2e-3 if mode == "bf16" else 2e-5), (mode, emb)
+    print("Tiktok shape, max |loss - oracle|, max |E - oracle|:", res)
