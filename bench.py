@@ -413,10 +413,13 @@ def eval_pass(model, cfg, torch):
     best = min(secs[1:])
     return {"what": "full-catalogue TIE top-%d validation pass" % (max(topks) if isinstance(topks, (list, tuple)) else int(topks)),
             "users": n_eval,
-            "math": "v_exp/v_rcp + Newton step, scores within 1.2e-7 of the IEEE/libm form (default)" if default_math else "exact",
+            "math": "v_exp/v_rcp + Newton step, dot products as six bf16 piece products with fp32 accumulation: scores within 2.4e-7 of the "
+                    "IEEE/libm fp32-MFMA form (default)" if default_math else "exact",
             "users_per_launch": model.valid_evaluator.evaluator.block_users,
             "seconds_first": secs[0], "seconds": best, "users_per_s": n_eval / best,
-            "roofline": {"bound": "mfma", "kernel": "score_t16_kernel (pass 1 + pass 2) over the whole pass", "achieved": flops / best / 1e12,
+            "roofline": {"bound": "mfma", "kernel": "score_t16b_kernel (pass 1 + pass 2 on the bf16 matrix cores from exact three-piece splits of the "
+                                                    "fp32 operands) over the whole pass; achieved = the pass's fp32-equivalent dot-product flops / time, "
+                                                    "against the fp32 MFMA peak", "achieved": flops / best / 1e12,
                          "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": flops / best / 1e12 / MFMA_F32_PEAK_TF, "flops": flops},
             "exact_math": {"seconds": min(exact), "users_per_s": n_eval / min(exact),
                            "frac_of_mfma_peak": flops / min(exact) / 1e12 / MFMA_F32_PEAK_TF}}

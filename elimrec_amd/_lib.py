@@ -203,6 +203,8 @@ SIGNATURES = {
                                        c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32, c_ptr]),
     "elimrec_score_set_math": (None, [c_i32]),
     "elimrec_score_get_math": (c_i32, []),
+    "elimrec_score_set_bf16x3": (None, [c_i32]),
+    "elimrec_score_get_bf16x3": (c_i32, []),
     "elimrec_build_adj_workspace": (c_size, [c_i64, c_i64, c_i32]),
     "elimrec_build_adj": (c_i32, [c_ptr, c_ptr, c_i64, c_i64, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size,
                                   c_ptr]),
@@ -277,6 +279,7 @@ class _Recording(object):
         for name, (res, _) in SIGNATURES.items():
             fn = getattr(lib, name)
             plain = name in ("elimrec_abi_version", "elimrec_program_fn_count", "elimrec_program_fn_args", "elimrec_comm_unique_id",
+                             "elimrec_score_get_math", "elimrec_score_get_bf16x3",
                              "elimrec_comm_create", "elimrec_comm_destroy") or name.startswith("elimrec_program_")
             setattr(self, name, self._wrap(fn, name) if res is c_i32 and not plain else fn)
 

@@ -119,6 +119,7 @@ struct ScoreArgs {
     int64_t tmax_ld;
     int64_t item0, item_end;         // score_t16_kernel: the launch covers items [item0, item_end); scores / tile_max are
                                      // indexed relative to item0 (a chunk of the catalogue when only top-K is wanted)
+    const uint4 *planes;             // score_t16b_kernel: the chunk's item rows as three bf16 planes, [item - item0][3][COLS]
 };
 
 __device__ __forceinline__ float fuse(int mode, float x, const float *z, int S, uint32_t mask) {
@@ -630,6 +631,208 @@ __global__ __launch_bounds__(512, (D > 64 ? 2 : 4)) void score_t16_kernel(ScoreA
     }
 }
 
+// ---- pass 2 on the bf16 matrix cores with fp32 results (the FAST math's scorer for recdim 32 / 64)
+// An fp32 value splits EXACTLY into three bf16 pieces x = x1 + x2 + x3 (8 + 8 + 8 significand bits, by truncation), a product
+// of two pieces is exact in fp32, and of the nine piece products of a.b the six with i + j <= 4 carry everything above
+// 2^-24 relative: a.b = a1b1 + (a1b2 + a2b1) + (a1b3 + a2b2 + a3b1) to fp32 round-off, accumulated in the MFMA's fp32
+// accumulator. v_mfma_f32_16x16x32_bf16 retires 8192 MACs in 16 cycles against 1024 in 32 for v_mfma_f32_16x16x4_f32: six
+// of the former replace sixteen of the latter per 16 x 16 x 64 block -- 2.7x less matrix-core time for the same scores.
+// The items' pieces are made once per catalogue chunk (split3_items_kernel, 16 MB read + 25 MB written against a 0.9 ms
+// scorer launch), the users' pieces once per workgroup, in registers.
+typedef __bf16 bf16x8_s __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3(float x, uint32_t &p1, uint32_t &p2, uint32_t &p3) {      // bf16 bit patterns in the HIGH half
+    p1 = __float_as_uint(x) & 0xffff0000u;
+    const float r1 = x - __uint_as_float(p1);
+    p2 = __float_as_uint(r1) & 0xffff0000u;
+    const float r2 = r1 - __uint_as_float(p2);
+    p3 = __float_as_uint(r2) & 0xffff0000u;
+}
+
+// 8 consecutive floats -> three uint4 of 8 bf16 each (element t in bits [16 (t & 1), +16) of word t >> 1)
+__device__ __forceinline__ void split3x8(const float4 &lo, const float4 &hi, uint4 &q1, uint4 &q2, uint4 &q3) {
+    const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    uint32_t w1[4], w2[4], w3[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        uint32_t a1, a2, a3, b1, b2, b3;
+        split3(x[2 * t], a1, a2, a3);
+        split3(x[2 * t + 1], b1, b2, b3);
+        w1[t] = (a1 >> 16) | b1; w2[t] = (a2 >> 16) | b2; w3[t] = (a3 >> 16) | b3;
+    }
+    q1 = make_uint4(w1[0], w1[1], w1[2], w1[3]); q2 = make_uint4(w2[0], w2[1], w2[2], w2[3]); q3 = make_uint4(w3[0], w3[1], w3[2], w3[3]);
+}
+
+// planes[(item - item0)][p][c] (bf16) <- piece p of Y[U + item][c], c < cols (a multiple of 8): a thread per 8 columns
+__global__ __launch_bounds__(256) void split3_items_kernel(const float *__restrict__ Y, int64_t ldy, int64_t U, int64_t item0,
+                                                           int64_t n_items, int cols, uint4 *__restrict__ planes) {
+    const int c8 = cols / 8;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_items * c8) return;
+    const int64_t it = t / c8;
+    const int c = (int)(t % c8);
+    const float4 *src = reinterpret_cast<const float4 *>(Y + (U + item0 + it) * ldy + 8 * c);
+    uint4 q1, q2, q3;
+    split3x8(src[0], src[1], q1, q2, q3);
+    uint4 *dst = planes + it * 3 * c8 + c;
+    dst[0] = q1; dst[c8] = q2; dst[2 * c8] = q3;
+}
+
+template <int PASS, int NB, int PT, int FM, int D>
+__global__ __launch_bounds__(512, 2) void score_t16b_kernel(ScoreArgs a, int n_tiles) {
+    constexpr bool FAST = true;
+    constexpr int NH = (PASS == 1) ? 1 : NB, COLS = NH * D;
+    constexpr int ROW4 = 3 * COLS / 8 + 1;            // LDS row of an item in uint4 units: three planes + 16 B of padding
+    constexpr int KB = D / 32;                         // 32-deep MFMA steps per head block
+    extern __shared__ float smem[];
+    uint4 *it0 = reinterpret_cast<uint4 *>(smem), *it1 = it0 + TI * ROW4;
+    float *unorm = reinterpret_cast<float *>(it1 + TI * ROW4);     // [128][NB-1]
+    float *umean = unorm + TW * TU * (NB > 1 ? NB - 1 : 1);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int b0 = blockIdx.y * (TW * TU);
+    const float eps = 1e-12f;
+    const int ptype = PT >= 0 ? PT : a.predict_type, fmode = FM >= 0 ? FM : a.fusion_mode;
+    // A operands: user (wave*16 + li), pieces of elements k = 32 j + 8 kq .. + 8 of head block h
+    uint4 ua[3][NH][KB];
+    {
+        const int ub = b0 + wave * TU + li;
+        const float *urow = ub < a.B ? a.Y + a.users[ub] * a.ldy : nullptr;
+#pragma unroll
+        for (int h = 0; h < NH; ++h)
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+                float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+                if (urow) {
+                    const float4 *s4 = reinterpret_cast<const float4 *>(urow + h * D + 32 * j + 8 * kq);
+                    lo = s4[0]; hi = s4[1];
+                }
+                split3x8(lo, hi, ua[0][h][j], ua[1][h][j], ua[2][h][j]);
+            }
+    }
+    if (PASS == 2 && tid < TW * TU) {
+        const int b = b0 + tid;
+        const int64_t un = b < a.B ? a.users[b] : -1;
+        for (int h = 0; h + 1 < NB; ++h) {
+            const float nrm = (un >= 0 && ptype != 0) ? fmaxf(sqrtf(a.sqn[un * NB + 1 + h]), eps) : 1.f;
+            unorm[tid * (NB - 1) + h] = rcp_nr(nrm);
+        }
+        umean[tid] = (b < a.B && ptype == 2) ? a.row_mean[b] : 0.f;
+    }
+    float psum[4] = {0.f, 0.f, 0.f, 0.f};             // PASS 1: this wave's users' running sums of ui, tiles in ascending order
+    // a tile's rows (16 items x three planes) as uint4 over the 512 threads
+    constexpr int TILE4 = TI * 3 * COLS / 8;
+    constexpr int PFN = (TILE4 + 511) / 512;
+    uint4 pf[PFN];
+    auto load_tile = [&](int tile) {
+#pragma unroll
+        for (int q = 0; q < PFN; ++q) {
+            const int e = tid + 512 * q;
+            if (e < TILE4) {
+                const int64_t it = (int64_t)tile * TI + e / (3 * COLS / 8);
+                pf[q] = (a.item0 + it < a.item_end) ? a.planes[it * (3 * COLS / 8) + e % (3 * COLS / 8)] : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+    };
+    auto store_tile = [&](uint4 *buf) {
+#pragma unroll
+        for (int q = 0; q < PFN; ++q) {
+            const int e = tid + 512 * q;
+            if (e < TILE4) buf[(e / (3 * COLS / 8)) * ROW4 + e % (3 * COLS / 8)] = pf[q];
+        }
+    };
+    constexpr int NQ = (PASS == 2 && NB > 1) ? NB - 1 : 1;
+    float sq_cur[NQ], sq_nxt[NQ];
+    auto load_sqn = [&](int tile, float (&dst)[NQ]) {
+        if (PASS != 2 || NB <= 1) return;
+        const int64_t item = a.item0 + (int64_t)tile * TI + li;
+#pragma unroll
+        for (int h = 0; h + 1 < NB; ++h) dst[h] = (item < a.item_end && ptype != 0) ? a.sqn[(a.U + item) * NB + 1 + h] : 1.f;
+    };
+    if ((int)blockIdx.x < n_tiles) { load_tile(blockIdx.x); load_sqn(blockIdx.x, sq_cur); store_tile(it0); }
+    __syncthreads();
+    int cur = 0;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, cur ^= 1) {
+        const int next = tile + gridDim.x;
+        if (next < n_tiles) { load_tile(next); load_sqn(next, sq_nxt); }
+        const int64_t i0 = a.item0 + (int64_t)tile * TI;
+        v4f_s acc[NH];
+        const uint4 *brow = (cur ? it1 : it0) + li * ROW4 + kq;          // this lane's item row, its k-block of 8
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            acc[h] = (v4f_s){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < KB; ++j) {
+                const int c8 = (h * D + 32 * j) / 8;
+                const bf16x8_s b1 = __builtin_bit_cast(bf16x8_s, brow[c8]);
+                const bf16x8_s b2 = __builtin_bit_cast(bf16x8_s, brow[COLS / 8 + c8]);
+                const bf16x8_s b3 = __builtin_bit_cast(bf16x8_s, brow[2 * (COLS / 8) + c8]);
+                const bf16x8_s a1 = __builtin_bit_cast(bf16x8_s, ua[0][h][j]), a2 = __builtin_bit_cast(bf16x8_s, ua[1][h][j]),
+                               a3 = __builtin_bit_cast(bf16x8_s, ua[2][h][j]);
+                // smallest terms first
+                acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3, b1, acc[h], 0, 0, 0);
+                acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b2, acc[h], 0, 0, 0);
+                acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b3, acc[h], 0, 0, 0);
+                acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2, b1, acc[h], 0, 0, 0);
+                acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b2, acc[h], 0, 0, 0);
+                acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[h], 0, 0, 0);
+            }
+        }
+        // lane: item i0 + li, users wave*16 + 4*kq + r  (the 16x16 output layout of the fp32 form)
+        const int64_t item = i0 + li;
+        const bool item_ok = item < a.item_end;
+        float inorm[NQ];
+        if (PASS == 2) {
+#pragma unroll
+            for (int h = 0; h + 1 < NB; ++h) inorm[h] = rcp_nr((item_ok && ptype != 0) ? fmaxf(sqrtf(sq_cur[h]), eps) : 1.f);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int urow = wave * TU + 4 * kq + r;
+            const float ui = sig_<FAST>(acc[0][r]);
+            if (PASS == 1) {
+                psum[r] += row16_sum((item_ok && b0 + urow < a.B) ? ui : 0.f);     // over the 16 items of the tile
+                continue;
+            }
+            float out;
+            if (ptype == 0) {
+                out = sig_<FAST>(ui);
+            } else {
+                float z[kMaxS];
+#pragma unroll
+                for (int h = 0; h < kMaxS; ++h) {
+                    const float nn = unorm[urow * (NB - 1) + (h + 1 < NB ? h : 0)] * inorm[h + 1 < NB ? h : 0];
+                    const float dp = acc[(h + 1 < NH) ? h + 1 : 0][r];
+                    z[h] = (h + 1 < NB) ? dp * nn : 0.f;
+                }
+                if (ptype == 1) out = sig_<FAST>(fuse_t<FAST>(fmode, ui, z, NB - 1, a.head_mask));
+                else {
+                    float te, nde;
+                    fuse2_t<FAST>(fmode, ui, umean[urow], z, NB - 1, a.head_mask, te, nde);
+                    out = sig_<FAST>(te - nde);
+                }
+            }
+            const bool row_ok = b0 + urow < a.B;
+            if (item_ok && row_ok) a.scores[(int64_t)(b0 + urow) * a.lds + (item - a.item0)] = out;
+            if (a.tile_max) {
+                const float mx = row16_max(item_ok ? out : -INFINITY);
+                if (li == 0 && row_ok) a.tile_max[(int64_t)(b0 + urow) * a.tmax_ld + tile] = mx;
+            }
+        }
+        if (next < n_tiles) store_tile(cur ? it0 : it1);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) sq_cur[q] = sq_nxt[q];
+        __syncthreads();
+    }
+    if (PASS == 1 && li == 0) {                       // one partial per (workgroup, user): row_mean_kernel adds them in order
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = b0 + wave * TU + 4 * kq + r;
+            if (b < a.B) a.partial[(int64_t)blockIdx.x * a.B + b] = psum[r];
+        }
+    }
+}
+
 // bitmap of the items to mask, one workgroup per user row: clear, then set (rows are disjoint, the atomics stay in one row)
 __global__ __launch_bounds__(256) void train_bits_kernel(const int64_t *__restrict__ ptr, const int32_t *__restrict__ items, int64_t I,
                                                          uint32_t *__restrict__ bits, int64_t bits_ld) {
@@ -1028,6 +1231,13 @@ static int score_math() {
     }
     return g_score_math;
 }
+static int g_score_b3 = -1;
+static int score_bf16x3() {
+    if (g_score_b3 < 0) { const char *e = getenv("ELIMREC_SCORE_BF16X3"); g_score_b3 = (e && e[0] == '0') ? 0 : 1; }
+    return g_score_b3;
+}
+extern "C" void elimrec_score_set_bf16x3(int on) { g_score_b3 = on ? 1 : 0; }
+extern "C" int elimrec_score_get_bf16x3(void) { return score_bf16x3(); }
 extern "C" void elimrec_score_set_math(int mode) { g_score_math = mode ? 1 : 0; }
 extern "C" int elimrec_score_get_math(void) { return score_math(); }
 
@@ -1037,8 +1247,9 @@ constexpr int64_t SCORE_CHUNK = 16384;    // items per scorer launch when only t
 
 // Workspace layout of elimrec_score_topk. full: a [B x I] score block (the caller wants the scores, or a scorer without tile
 // maxima runs); top-K only: a [B x SCORE_CHUNK] block, the tile maxima of one chunk and the per-chunk candidate lists.
-struct ScoreLayout { size_t partial, mean, scores, flags, sqn, bits, tmax, cand_val, cand_idx, total; };
-static ScoreLayout score_layout(int B, int64_t U, int64_t I, int S, int K, bool topk_only) {
+struct ScoreLayout { size_t partial, mean, scores, flags, sqn, bits, tmax, cand_val, cand_idx, planes, total; };
+// d > 0 with the chunked layout: room for one chunk's item rows as three bf16 planes (score_t16b_kernel, recdim 32 / 64)
+static ScoreLayout score_layout(int B, int64_t U, int64_t I, int S, int K, bool topk_only, int d = 0) {
     const size_t b = (size_t)(B > 0 ? B : 1);
     const int64_t cols = topk_only && I > SCORE_CHUNK ? SCORE_CHUNK : I;
     const int64_t nch = topk_only ? (I + SCORE_CHUNK - 1) / SCORE_CHUNK : 0;
@@ -1054,6 +1265,8 @@ static ScoreLayout score_layout(int B, int64_t U, int64_t I, int S, int K, bool 
     L.tmax = take(b * (size_t)n_item_tiles(cols) * sizeof(float));
     L.cand_val = take(b * (size_t)nch * (size_t)(K > 0 ? K : 1) * sizeof(float));
     L.cand_idx = take(b * (size_t)nch * (size_t)(K > 0 ? K : 1) * sizeof(int32_t));
+    L.planes = off;
+    if (topk_only && (d == 32 || d == 64)) take((size_t)cols * 3 * (size_t)(1 + S) * (size_t)d * 2);
     L.total = off;
     return L;
 }
@@ -1094,7 +1307,7 @@ static bool score_chunked_form(int d, int S, int K, int64_t I, bool want_scores,
 // (want_scores) -- the chunked layout exactly when the call will take the chunked form, the full [B x I] layout otherwise
 // (any recdim, any K: the reference accepts both, models/EliMRec.py:96-113, evaluator/backend/cpp/uni_evaluator.py:131).
 extern "C" size_t elimrec_score_workspace_for(int B, int64_t U, int64_t I, int S, int K, int d, int want_scores) {
-    return score_layout(B, U, I, S, K, score_chunked_form(d, S, K, I, want_scores != 0, K > 0)).total;
+    return score_layout(B, U, I, S, K, score_chunked_form(d, S, K, I, want_scores != 0, K > 0), d).total;
 }
 
 extern "C" int elimrec_row_sqnorms(const float *d_Y, int64_t ldy, int64_t n_rows, int d, int n_blocks, float *d_out,
@@ -1147,6 +1360,11 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
         set_error("score_topk: workspace too small (%zu < %zu)", workspace_bytes, L.total);
         return ELIMREC_E_WORKSPACE;
     }
+    // FAST math, chunked top-K, recdim 32 / 64: pass 2 on the bf16 matrix cores from exact three-piece splits (needs room for one
+    // chunk's pieces behind the chunked layout: a workspace sized by elimrec_score_workspace_for has it)
+    const int use_b3 = score_bf16x3();
+    const ScoreLayout Lp = score_layout(B, U, I, S, K, chunked, d);
+    const bool bf16x3 = chunked && use_b3 && score_math() == 1 && (d == 32 || d == 64) && phase != 1 && workspace_bytes >= Lp.total;
     hipStream_t s = (hipStream_t)stream;
     const int tiles = n_item_tiles(I);
     char *ws = (char *)d_workspace;
@@ -1160,7 +1378,7 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
     a.Y = d_Y; a.ldy = ldy; a.U = U; a.I = I; a.users = d_users; a.B = B; a.d = d; a.S = S; a.head_mask = head_mask;
     a.fusion_mode = fusion_mode; a.predict_type = predict_type; a.row_mean = mean; a.partial = partial;
     a.scores = d_scores ? d_scores : wscores; a.lds = d_scores ? lds : (chunked ? SCORE_CHUNK : I);
-    a.item0 = 0; a.item_end = I;
+    a.item0 = 0; a.item_end = I; a.planes = nullptr;
     float *wsqn = (float *)(ws + L.sqn);
     if (!d_sqnorm && predict_type != 0) {            // not supplied: compute the whole table for this call
         const int64_t N = U + I;
@@ -1242,7 +1460,7 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
     } while (0)
         // pass 1 (TIE): row means of sigmoid(u.i) over the WHOLE catalogue
         a.item0 = 0; a.item_end = I;
-        if (own_pass1) {
+        if (own_pass1 && !(bf16x3 && phase == 0)) {
             if (S == 1) ELIMREC_T16_PASS1(2);
             else if (S == 2) ELIMREC_T16_PASS1(3);
             else ELIMREC_T16_PASS1(4);
@@ -1259,10 +1477,79 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
             ELIMREC_LAUNCH_CHECK("score_t16_pass2");
             return 0;
         };
+        auto b3_lds = [d](int pass, int nb) {
+            const int nh = pass == 1 ? 1 : nb;
+            return ((size_t)2 * TI * (3 * nh * d / 8 + 1) * 16 + ((size_t)TW * TU * (nb > 1 ? nb - 1 : 1) + TW * TU) * sizeof(float));
+        };
+#define ELIMREC_T16B_LAUNCH1(NB, GRID, DD)                                                                   \
+    hipLaunchKernelGGL((score_t16b_kernel<1, NB, -1, -1, DD>), GRID, dim3(512), b3_lds(1, NB), s, a, t16)
+#define ELIMREC_T16B_LAUNCH(NB, PT, FM, GRID, DD)                                                            \
+    do {                                                                                                   \
+        static bool attr = false;                                                                          \
+        if (!attr && b3_lds(2, NB) > 64 * 1024) {                                                          \
+            (void)hipFuncSetAttribute((const void *)score_t16b_kernel<2, NB, PT, FM, DD>,                  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)b3_lds(2, NB));     \
+            attr = true;                                                                                   \
+        }                                                                                                  \
+        hipLaunchKernelGGL((score_t16b_kernel<2, NB, PT, FM, DD>), GRID, dim3(512), b3_lds(2, NB), s, a, t16); \
+    } while (0)
+#define ELIMREC_T16B_D(NB, PT, FM, GRID)                                                                     \
+    do {                                                                                                   \
+        if (d == 64) ELIMREC_T16B_LAUNCH(NB, PT, FM, GRID, 64);                                            \
+        else ELIMREC_T16B_LAUNCH(NB, PT, FM, GRID, 32);                                                    \
+    } while (0)
+#define ELIMREC_T16B_PASS2(NB)                                                                              \
+    do {                                                                                                   \
+        if (predict_type == 0) ELIMREC_T16B_D(NB, 0, 0, grid);                                             \
+        else if (predict_type == 1 && fusion_mode == 0) ELIMREC_T16B_D(NB, 1, 0, grid);                    \
+        else if (predict_type == 1 && fusion_mode == 1) ELIMREC_T16B_D(NB, 1, 1, grid);                    \
+        else if (predict_type == 1) ELIMREC_T16B_D(NB, 1, 2, grid);                                        \
+        else if (fusion_mode == 0) ELIMREC_T16B_D(NB, 2, 0, grid);                                         \
+        else if (fusion_mode == 1) ELIMREC_T16B_D(NB, 2, 1, grid);                                         \
+        else ELIMREC_T16B_D(NB, 2, 2, grid);                                                               \
+    } while (0)
+        auto pass1_b3 = [&](const ScoreArgs &a, int t16, dim3 grid) -> int {
+            if (d == 64) { if (S == 1) ELIMREC_T16B_LAUNCH1(2, grid, 64); else if (S == 2) ELIMREC_T16B_LAUNCH1(3, grid, 64); else ELIMREC_T16B_LAUNCH1(4, grid, 64); }
+            else { if (S == 1) ELIMREC_T16B_LAUNCH1(2, grid, 32); else if (S == 2) ELIMREC_T16B_LAUNCH1(3, grid, 32); else ELIMREC_T16B_LAUNCH1(4, grid, 32); }
+            ELIMREC_LAUNCH_CHECK("score_t16b_pass1");
+            return 0;
+        };
+        auto pass2_b3 = [&](const ScoreArgs &a, int t16, dim3 grid) -> int {
+            if (S == 1) ELIMREC_T16B_PASS2(2);
+            else if (S == 2) ELIMREC_T16B_PASS2(3);
+            else ELIMREC_T16B_PASS2(4);
+            ELIMREC_LAUNCH_CHECK("score_t16b_pass2");
+            return 0;
+        };
         if (chunked) {
             // only top-K is wanted: the catalogue goes through the scorer SCORE_CHUNK items at a time, a [B x SCORE_CHUNK]
             // block instead of [B x I]; every chunk leaves its K best (id, score) pairs per user, merged at the end
             const int nch = (int)((I + SCORE_CHUNK - 1) / SCORE_CHUNK);
+            if (own_pass1 && bf16x3 && phase == 0) {
+                // pass 1 (row means of sigmoid(u.i)) on the bf16 matrix cores too: chunk by chunk (the fused block's pieces only),
+                // <= 64 workgroups per user group and chunk, partials in (chunk, workgroup) order
+                uint4 *planes = (uint4 *)(ws + Lp.planes);
+                const int ug = (B + TW * TU - 1) / (TW * TU);
+                int n_part = 0;
+                for (int c = 0; c < nch; ++c) {
+                    ScoreArgs ac = a;
+                    ac.item0 = (int64_t)c * SCORE_CHUNK;
+                    ac.item_end = ac.item0 + SCORE_CHUNK < I ? ac.item0 + SCORE_CHUNK : I;
+                    const int64_t cnt = ac.item_end - ac.item0;
+                    const int tc = (int)((cnt + TI - 1) / TI);
+                    hipLaunchKernelGGL(split3_items_kernel, dim3((unsigned)((cnt * (d / 8) + 255) / 256)), dim3(256), 0, s, d_Y, ldy, U,
+                                       ac.item0, cnt, d, planes);
+                    ELIMREC_LAUNCH_CHECK("split3_items(pass 1)");
+                    int gx = tc < 64 ? tc : 64;
+                    ac.planes = planes;
+                    ac.partial = partial + (int64_t)n_part * B;
+                    int rc = pass1_b3(ac, tc, dim3((unsigned)gx, ug));
+                    if (rc) return rc;
+                    n_part += gx;
+                }
+                hipLaunchKernelGGL(row_mean_kernel, dim3(B), dim3(256), 0, s, partial, n_part, B, mean_div, mean_dst);
+                ELIMREC_LAUNCH_CHECK("row_mean");
+            }
             for (int c = 0; c < nch; ++c) {
                 ScoreArgs ac = a;
                 ac.item0 = (int64_t)c * SCORE_CHUNK;
@@ -1274,7 +1561,18 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
                 int gx = 512 / ug > 0 ? 512 / ug : 1;
                 if (gx > tc) gx = tc;
                 const int per = (tc + gx - 1) / gx;
-                int rc = pass2(ac, tc, dim3((unsigned)((tc + per - 1) / per), ug));
+                int rc = 0;
+                if (bf16x3) {
+                    const int cols = (1 + S) * d;
+                    uint4 *planes = (uint4 *)(ws + Lp.planes);
+                    hipLaunchKernelGGL(split3_items_kernel, dim3((unsigned)((cnt * (cols / 8) + 255) / 256)), dim3(256), 0, s, d_Y, ldy, U,
+                                       ac.item0, cnt, cols, planes);
+                    ELIMREC_LAUNCH_CHECK("split3_items");
+                    ac.planes = planes;
+                    rc = pass2_b3(ac, tc, dim3((unsigned)((tc + per - 1) / per), ug));
+                } else {
+                    rc = pass2(ac, tc, dim3((unsigned)((tc + per - 1) / per), ug));
+                }
                 if (rc) return rc;
                 hipLaunchKernelGGL(topk_tiles_kernel, dim3(B), dim3(256), 0, s, ac.scores, ac.lds, cnt, (const float *)wtmax, ac.tmax_ld,
                                    tc, K, d_train_ptr, d_train_ptr ? (const uint32_t *)wbits : (const uint32_t *)nullptr, bits_ld,

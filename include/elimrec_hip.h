@@ -478,6 +478,13 @@ int elimrec_topk_merge(const float *d_cand_val, const int32_t *d_cand_idx, int B
  * the reference's scores (/root/reference/models/EliMRec.py:155-212). Also env ELIMREC_EVAL_MATH=exact, read once. */
 void elimrec_score_set_math(int mode);
 int elimrec_score_get_math(void);
+/* FAST math, chunked top-K (no score matrix), recdim 32 / 64: both scorer passes run on the bf16 matrix cores from EXACT
+ * three-piece splits of the fp32 operands (x = x1 + x2 + x3, bf16 each; the six piece products above 2^-24 relative,
+ * accumulated in fp32): the same scores to fp32 round-off (within 2.4e-7 of the EXACT mode, tests) at 2.7x less matrix-core
+ * time. On by default (env ELIMREC_SCORE_BF16X3=0 or this switch turn it off); needs the workspace of
+ * elimrec_score_workspace_for (room for one chunk's pieces), otherwise the fp32 MFMA form runs. */
+void elimrec_score_set_bf16x3(int on);
+int elimrec_score_get_bf16x3(void);
 
 /* d_sqnorm (nullable): [N x (1+S)] squared norms of every head block of every row of Y, from
  * elimrec_row_sqnorms; pass it when several user blocks are scored against the same tables (an
