@@ -1336,3 +1336,36 @@ def test_item_sharded_scoring_equals_whole_catalogue(d, ptype, W, eval_math):
     order = np.argsort(-sharded, axis=1, kind="stable")[:, :K]
     assert np.array_equal(out_i.cpu().numpy(), order)
     assert np.array_equal(out_v.cpu().numpy(), np.take_along_axis(sharded, order, 1))
+
+
+@pytest.mark.gpu
+def test_device_evaluator_against_the_references_own_compiled_code(fixture_name):
+    """oracle/_ref/libref_eval.so -- the reference's evaluate.h / metric.h / arg_topk.h compiled where they lie (never copied) --
+    travels to the GPU box for this: the reference's C++ ranks and scores the DEVICE's own masked score matrix, and on every row
+    where its heap-order top-K is the device's (score desc, id asc) top-K -- all rows without a tie at the K boundary -- the
+    per-user metric rows agree bit for bit; the other rows hold the same scores rank by rank."""
+    from oracle import eval_oracle as ev
+    if ev.ref_lib() is None:
+        pytest.skip("oracle/_ref/libref_eval.so was not built (needs /root/reference at build time)")
+    g = load_golden(fixture_name)
+    model, _ = build_model_from_fixture(g, DEV)
+    _load_cache(model, g)
+    model.fusion_mode, model.predict_type = "rubi", "TIE"
+    users = g["evalbatch/users"].tolist()
+    K = int(g["evalbatch/top_k"])
+    mids = g["evalbatch/metric_ids"]
+    evalr = model.test_evaluator.evaluator
+    rows, idx, _ = evalr.evaluate_batch(model, users, return_topk=True)
+    dev_scores = torch.empty(len(users), model.num_items, device=DEV)
+    train_ptr, train_items = evalr._batch_csr(users, evalr.user_pos_train, DEV, unique=False)
+    model.predict_device(users, scores=dev_scores, train_ptr=train_ptr, train_items=train_items)
+    sc = np.ascontiguousarray(dev_scores.cpu().numpy())
+    test = csr_dict(g, "test")
+    tp, ti = ev.truth_to_csr([sorted(set(test[int(u)])) for u in users])
+    ref_rows, ref_topk = ev.evaluate_matrix(sc.copy(), tp, ti, mids, K, use_ref=True)
+    idx, rows = idx.cpu().numpy(), rows.cpu().numpy()
+    same = (idx == ref_topk).all(1) & _tie_free(sc, K)
+    assert same.sum() >= len(users) // 2
+    assert np.array_equal(rows[same], np.asarray(ref_rows, np.float32).reshape(len(users), -1)[same])
+    for r in np.nonzero(~same)[0]:
+        assert np.array_equal(sc[r][idx[r]], sc[r][ref_topk[r]]), r
