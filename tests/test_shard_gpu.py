@@ -233,9 +233,16 @@ def test_column_shard_trainer_equals_row_major_trainer():
 
 
 # ----------------------------------------------------------------------------- W ranks emulated on one GPU
-def _emulated_step(engines, batches):
-    """What ColumnShardTrainer.step does on W ranks, with the collectives done by hand in one process."""
+def _emulated_step(engines, batches, deferred=False):
+    """What ColumnShardTrainer.step does on W ranks, with the collectives done by hand in one process. deferred: the trainer's
+    default multi-rank order -- the weight gradients are finished behind the adjoint hops' tiles, all-reduced after them, and
+    the projection weights' optimizer spans run in cs_update."""
     W = len(engines)
+    class _NoWait(object):
+        def wait(self):
+            return True
+    for e in engines:
+        e.defer_wgrads = bool(deferred)
     acts = torch.stack([e.cs_plan(*b).clone() for e, b in zip(engines, batches)])               # all_gather
     sends = [e.cs_forward(acts) for e in engines]
     sends = [None if s is None else s.clone() for s in sends]
@@ -256,6 +263,15 @@ def _emulated_step(engines, batches):
         losses.append(e.cs_head(recv).clone())
         s2, wg = e.cs_backward_local(scale)
         sends2.append(s2.clone()); wgs.append(wg)
+    if deferred and W > 1:
+        assert all(e.wgrads_deferred() for e in engines)
+        for q, e in enumerate(engines):
+            e.cs_backward_hops(torch.stack([sends2[p][q] for p in range(W)]), acts, None, lambda: _NoWait())      # all_to_all; hops finish wg
+        total = torch.stack([w.clone() for w in wgs]).sum(0)                                    # the late all_reduce
+        for q, e in enumerate(engines):
+            wgs[q].copy_(total)
+            e.cs_update()
+        return torch.stack(losses).mean()
     total = torch.stack([w.clone() for w in wgs]).sum(0)                                        # all_reduce
     for q, e in enumerate(engines):
         wgs[q].copy_(total)
@@ -264,10 +280,13 @@ def _emulated_step(engines, batches):
     return torch.stack(losses).mean()
 
 
+@pytest.mark.parametrize("deferred", [False, True], ids=["early-allreduce", "deferred-weight-gradients"])
 @pytest.mark.parametrize("W", [2, 4, 8])
-def test_column_shard_ranks_emulated_on_one_gpu(W):
+def test_column_shard_ranks_emulated_on_one_gpu(W, deferred):
     """W column-shard ranks (each owns recdim/W columns and 1/W of the triplets) equal ONE rank on the whole batch:
-    loss, embeddings and projection weights after two steps; every rank holds the same projection weights."""
+    loss, embeddings and projection weights after two steps; every rank holds the same projection weights. Both orders of
+    the multi-rank backward: weight gradients in a launch of their own, all-reduced under the adjoint hops; and the trainer's
+    default -- both phases behind the adjoint hops' tiles (4- and 2-lane row pieces at W = 4 / 8), the all-reduce after them."""
     from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
     g = load_golden("ml3")
     B = (len(g["step1/users"]) // W) * W
@@ -285,7 +304,8 @@ def test_column_shard_ranks_emulated_on_one_gpu(W):
         u, p, n = (_t(g["step%d/%s" % (t, k)])[:B] for k in ("users", "pos", "neg"))
         l1 = _emulated_step([one], [(u, p, n)])
         h = B // W
-        lw = _emulated_step([e for _, e in ranks], [(u[q * h:(q + 1) * h], p[q * h:(q + 1) * h], n[q * h:(q + 1) * h]) for q in range(W)])
+        lw = _emulated_step([e for _, e in ranks], [(u[q * h:(q + 1) * h], p[q * h:(q + 1) * h], n[q * h:(q + 1) * h]) for q in range(W)],
+                            deferred=deferred)
         assert abs(float(l1) - float(lw)) < 1e-6
     full = one.master[one.cur].dense()
     shards = torch.cat([e.master[e.cur].dense() for _, e in ranks], dim=1)
