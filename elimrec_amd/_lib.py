@@ -214,6 +214,9 @@ SIGNATURES = {
                                     c_ptr, c_ptr, c_ptr]),
     "elimrec_lookup_unpack": (c_i32, [c_ptr, c_i32, c_i64, c_i64, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64), c_i32, c_ptr, c_i64,
                                       c_i32, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
+    "elimrec_wide_from_master": (c_i32, [c_ptr, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr]),
+    "elimrec_wide_rows": (c_i32, [ctypes.POINTER(c_ptr), c_i32, c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
+    "elimrec_wide_grad": (c_i32, [c_ptr, c_i64, c_i64, c_i32, c_i32, c_f32, c_ptr, c_ptr]),
     "elimrec_rows_bitmap": (c_i32, [c_ptr, c_i32, c_i64, c_i64, c_ptr, c_ptr]),
     "elimrec_peer_cols_to_rows": (c_i32, [c_ptr, c_i32, c_i64, c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     "elimrec_program_fn_count": (c_i32, []),

@@ -23,9 +23,10 @@ def stats_of(plan):
 
 
 def plan(U, I, interactions, d, dims, world=1, layers=3, batch=2048, mods=None, symmetric=True, feature_dtype="f32",
-         eval_users=8192, topk=10, plan_stats=None, fused_head=None, materialize_rows=1 << 18):
+         eval_users=8192, topk=10, plan_stats=None, fused_head=None, materialize_rows=1 << 18, wide=False):
     """Bytes per GPU, by component. interactions = unique (user, item) training pairs (the adjacency has twice as many
-    non-zeros); dims = widths of the feature tables; batch = triplets per GPU and step."""
+    non-zeros); dims = widths of the feature tables; batch = triplets per GPU and step. wide: an adjacency with a diagonal
+    (adj_type norm / mean + I; N more non-zeros) -- the propagated tables are 2 dl columns wide and all L of them are kept."""
     N, W, L = U + I, int(world), int(layers)
     M = 1 + (len(dims) if mods is None else int(mods))
     C, Cy, dl = M * d, M * d, d // W
@@ -37,7 +38,11 @@ def plan(U, I, interactions, d, dims, world=1, layers=3, batch=2048, mods=None, 
     rows_loc = -(-U // W) + -(-I // W)
     out = {}
     # ---- ColumnShardEngine.cs_setup: slab-major tables of this rank's dl columns
-    n_tables = 2 + (L - 1) + 1 + 2 + 2 + 2           # master x2, X^1..X^(L-1), gradient, Adam m / v, srcA / srcB, tmp x2
+    if wide:        # master x2, gradient, Adam m / v narrow; layer 0, X^1..X^L, the adjoint source [H | G], scratch x2 wide
+        n_tables = 5 + 2 * (L + 4)
+        nnz += N
+    else:
+        n_tables = 2 + (L - 1) + 1 + 2 + 2 + 2       # master x2, X^1..X^(L-1), gradient, Adam m / v, srcA / srcB, tmp x2
     out["graph tables (%d x [N x %d] fp32: master x2, layers, gradient, Adam m/v, adjoint sources, scratch)" % (n_tables, dl)] = n_tables * N * dl * 4
     out["hop-L table for evaluation (lazily, [N x %d])" % dl] = N * dl * 4
     out["row bitmap of the adjoint sources"] = ((N + 31) // 32 + 2) * 4

@@ -334,7 +334,7 @@ extern "C" int elimrec_linear_bwd_w_batched_merge(const elimrec_linear_bwd_desc 
     const int64_t N = U + I;
     int sh = 0;
     while ((4 << sh) < w) ++sh;
-    MergeArgs mg = {d_rows, d_keys, world, (int)R, U, N, ns * (w / 4), w / 4, sh, merge_rows_chunk(N), M, d_SrcA, d_SrcB, d_mask};
+    MergeArgs mg = {d_rows, d_keys, world, (int)R, U, N, ns * (w / 4), w / 4, sh, merge_rows_chunk(N), M, d_SrcA, d_SrcB, d_mask, 0};
     ELIMREC_REQUIRE(mg.chunk / 32 <= kMergeSeenWords, "linear_bwd_w_batched_merge: %lld rows are more than the fused launch takes "
                     "(call elimrec_slab_merge_rows)", (long long)N);
     return linear_bwd_w_batched_impl(descs, n, d_workspace, workspace_bytes, N > 0 ? &mg : nullptr, defer_reduce, stream);

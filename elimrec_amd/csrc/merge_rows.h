@@ -17,6 +17,7 @@ struct MergeArgs {
     int nc4, w4, w4_shift, chunk, M;
     float *SrcA, *SrcB;
     uint32_t *mask;
+    int plain;                             // 1: H always to SrcA, G always to SrcB (the wide form's [H | G] source, wide.hip); 0: by side
 };
 
 // rows per workgroup: about 1024 workgroups over the N rows, whole bitmap words
@@ -63,8 +64,8 @@ __device__ __forceinline__ void slab_merge_rows_body(const MergeArgs &a, int blo
             const int bit = (int)(node - lo);
             const bool was = (seen[bit >> 5] >> (bit & 31)) & 1u;
             const float4 *g = reinterpret_cast<const float4 *>(rows) + ((int64_t)r * R + s) * (M ? M : 2) * nc4;
-            float *hT = node < U ? SrcA : SrcB;       // H lives in SrcA on user rows, SrcB on item rows
-            float *gT = node < U ? SrcB : SrcA;
+            float *hT = (a.plain || node < U) ? SrcA : SrcB;       // H lives in SrcA on user rows, SrcB on item rows
+            float *gT = (a.plain || node < U) ? SrcB : SrcA;
             for (int c = cl; c < nc4; c += lg) {
                 const int64_t idx = (((int64_t)(c >> w4_shift) * N + node) * w4 + (c & (w4 - 1))) * 4;
                 float4 h, g0;

@@ -1808,13 +1808,15 @@ extern "C" int elimrec_slab_to_rows(const float *d_slab, int64_t n, int ns, int 
 extern "C" int elimrec_slab_merge_rows(const float *d_rows, const int32_t *d_keys, int world, int64_t R, int64_t U,
                                        int64_t I, int ns, int w, int M, float *d_SrcA, float *d_SrcB, uint32_t *d_mask,
                                        void *stream) {
-    ELIMREC_REQUIRE(M >= 0, "slab_merge_rows: M >= 0");
+    ELIMREC_REQUIRE(M >= -1, "slab_merge_rows: M >= 0, or -1 for [H | G] rows without the user / item side swap");
+    const int plain = M < 0 ? 1 : 0;
+    if (M < 0) M = 0;
     ELIMREC_REQUIRE(d_rows && d_keys && d_SrcA && d_SrcB && d_mask, "slab_merge_rows: null pointer");
     ELIMREC_REQUIRE(world >= 1 && world <= kSlabMaxRanks && R >= 1 && R < INT32_MAX, "slab_merge_rows: 1..%d ranks", kSlabMaxRanks);
     int sh, rc;
     const int64_t N = U + I;
     if ((rc = slab_simple_geometry("slab_merge_rows", N, ns, w, sh))) return rc;
-    MergeArgs a = {d_rows, d_keys, world, (int)R, U, N, ns * (w / 4), w / 4, sh, merge_rows_chunk(N), M, d_SrcA, d_SrcB, d_mask};
+    MergeArgs a = {d_rows, d_keys, world, (int)R, U, N, ns * (w / 4), w / 4, sh, merge_rows_chunk(N), M, d_SrcA, d_SrcB, d_mask, plain};
     const unsigned grid = (unsigned)((N + a.chunk - 1) / a.chunk);
     if (grid == 0) return 0;
     hipLaunchKernelGGL(slab_merge_rows_kernel, dim3(grid), dim3(256), (size_t)(a.chunk / 32) * sizeof(uint32_t), (hipStream_t)stream, a);

@@ -234,6 +234,14 @@ class EliMRec(BasicModel):
         # propagated ONCE at start-up; per step only the id table and the shared user part go through the
         # graph (d columns instead of M*d) and the feature blocks of Out come from one GEMM each.
         self._folded = self._bipartite and mode in ("auto", "folded")
+        # an adjacency WITH a diagonal (adj_type norm / mean + I) and --propagation=folded asked for explicitly: the folded
+        # algebra holds for any A-hat, only the one-table parity trick does not -- the column-sharded engine then carries the
+        # E_u-borne and the E_i-borne part side by side ("wide" tables, csrc/wide.hip, shard.py). The model's own training path
+        # (bpr_loss through autograd) has no such form: train with ColumnShardTrainer (main.py does), evaluate as ever.
+        no_cross = adj[:U, :U].nnz == 0 and adj[U:, U:].nnz == 0
+        self._wide = (not no_cross) and mode == "folded" and self.n_layers >= 2
+        if self._wide:
+            self._folded = True
         # "batch" head rows (CLI-only: --head_rows=batch|all): the projections AFTER the graph (feature blocks of
         # Out, embedding_*_after_GCN, s_dense_*) are row-wise, and the loss reads them at the batch's 3B rows only,
         # so a training step evaluates them there; the full cached tables predict() reads (:98-99) are filled in on
@@ -465,6 +473,11 @@ class EliMRec(BasicModel):
             names = ("Out",) if self._folded else (("X0", "Out") if self._bipartite else ("X0", "T0", "T1", "Out", "G"))
             for name in names:
                 ws[name] = torch.empty(N, C, **f32)
+            if self._wide:
+                # the engine's wide form: its own fold (hop kernels), its own tables; here only the parameter views it loads from
+                ws["fold"] = None
+                ws["X0d"] = ws["flat_param"][:N * d].view(N, d)
+                ws["gX0d"] = ws["flat_grad"][:N * d].view(N, d)
             if self._bipartite:
                 if not self._folded:
                     ws["H"] = torch.empty(N, d, **f32)
@@ -1127,6 +1140,9 @@ class EliMRec(BasicModel):
         return params
 
     def _no_lean(self, what):
+        if self.__dict__.get("_wide"):
+            raise RuntimeError("--propagation=folded on an adjacency with a diagonal: %s is not available (the folded form of such "
+                               "an adjacency exists on the column-sharded engine only); train with ColumnShardTrainer" % what)
         if self.__dict__.get("_lean"):
             raise RuntimeError("--lean_tables=1: %s is not available (no table of N rows lives outside the column-sharded "
                                "engine); train with ColumnShardTrainer, evaluate with evaluate() / predict()" % what)

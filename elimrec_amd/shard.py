@@ -92,7 +92,7 @@ class ColumnShardTrainer(object):
                                           "cs_backward_hops", "cs_update")}
         self.xgmi_bytes = dict(all_gather=0, all_to_all_fwd=0, all_to_all_bwd=0, all_reduce=0)   # sent per rank, last step
         # row-sharded constant tables (engine.lookup): the all_to_all split sizes of every planned batch, as host integers
-        self.lookup = bool(getattr(engine, "lookup", False))
+        self.lookup = bool(getattr(engine, "lookup", False)) and bool(getattr(engine, "lookup_exchange", True))
         self._lookup_plan = {}
         self.lookup_syncs = 0          # steps that had to read their split sizes back from the device (no plan entry)
         if self.lookup:
@@ -353,6 +353,8 @@ class ColumnShardTrainer(object):
                     raise ValueError("a per-step value did not change between the two traced steps")
                 items, varying = program.diff_traces(ta, tb, ka, kb)
                 missing = set(ka) - set(varying.values())
+                if getattr(eng, "_tail_base", 0):
+                    missing.discard("step")          # the step count travels in the job array native_prologue refreshes
                 if missing:
                     raise ValueError("per-step values %s appear in no call" % sorted(missing))
                 st["programs"][key][parity] = program.StepProgram(items, varying, keep=(ta, tb))
@@ -487,7 +489,9 @@ class ColumnShardEngine(object):
             feature_shard = "row"        # lean tables: the constants exist as this rank's rows only, built by the distributed fold
         self.feature_shard, self.feature_dtype = feature_shard, feature_dtype
         # the lookup path (compact rows of the constants per step) serves the row shards and the 16-bit storage alike
-        self.lookup = feature_shard == "row" or feature_dtype != "f32"
+        self.lookup = feature_shard == "row" or feature_dtype != "f32" or bool(getattr(model, "_wide", False))
+        # ... and only row shards exchange rows between ranks; otherwise every rank widens / gathers from its own full copy
+        self.lookup_exchange = feature_shard == "row"
         if table_dtype is None:
             table_dtype = str(cfg["table_dtype"]) if "table_dtype" in cfg else "f32"
         if table_dtype not in ("f32", "bf16"):
@@ -518,8 +522,17 @@ class ColumnShardEngine(object):
         self.dl, self.col0 = d // world, rank * (d // world)
         self.ns, self.w = slab.choose_slabs16(self.dl) if self.bf16 else slab.choose_slabs(self.dl, N)
         self.gs = slab.choose_groups(self.ns)
+        # an adjacency with a diagonal (adj_type norm / mean + I): the graph carries the E_u-borne and the E_i-borne part side by
+        # side in WIDE tables of 2 dl columns (csrc/wide.hip); `hns` / `hgs` = slabs / slab groups of the tables the hops run on
+        self.wide = bool(getattr(m, "_wide", False))
+        if self.wide and self.bf16:
+            raise ValueError("bf16 table storage is not available for adjacencies with a diagonal (adj_type norm / mean)")
+        if self.wide and world > 1 and self.feature_shard != "row":
+            raise ValueError("an adjacency with a diagonal on several ranks needs --feature_shard=row")
+        self.hns = 2 * self.ns if self.wide else self.ns
+        self.hgs = slab.choose_groups(self.hns) if self.wide else self.gs
         adj = m._scipy_adj()
-        ipw = 64 // max(1, (self.ns // self.gs) * (self.w // (8 if self.bf16 else 4)))     # lane groups per wave of this geometry
+        ipw = 64 // max(1, (self.hns // self.hgs) * (self.w // (8 if self.bf16 else 4)))   # lane groups per wave of this geometry
         # launch form of a hop (tools/bench_slab_modes.py, Tiktok shape, us per hop): fp32 tables -- the one-launch form over
         # wave tiles (whole table, 64-neighbour tiles: 31 against 36 for hop + fix-up kernels; an 8-column shard, 32-neighbour
         # tiles: 20.3 against 21.6; 16 columns: 19.5 against 21.7), which also lets the last adjoint hop carry the Adam
@@ -537,13 +550,22 @@ class ColumnShardEngine(object):
         self.master = [tab(), tab()]
         self.mirror = [ttab(), ttab()] if self.bf16 else None       # bf16 gather copies of the two master buffers
         self.cur = 0
-        self.layers = [None] + [ttab() for _ in range(L - 1)]
         self.long_tab = torch.empty(self.ns * max(self.plan.n_long, 1) * self.w, dtype=torch.float32, device=dev)
         self.xL = None                                            # full hop-L table, only when predict() needs it
         self.grad = tab()
         self.m1 = torch.zeros_like(self.grad.data)
         self.m2 = torch.zeros_like(self.grad.data)
-        self.srcA, self.srcB, self.tmp = tab(), tab(), [ttab(), ttab()]
+        if self.wide:
+            wtab = lambda: slab.SlabTable(N, self.hns, self.w, dev)
+            self.x0w = wtab()                                     # layer 0: [E_u | 0] on user rows, [0 | E_i] on item rows
+            self.layers = [None] + [wtab() for _ in range(L)]     # X^1 .. X^L, all of them whole (no row-list last hop)
+            self.srcW, self.tmp = wtab(), [wtab(), wtab()]
+            half = self.ns * N * self.w                           # the adjoint source [H | G]: left / right halves as narrow tables
+            self.srcA = slab.SlabTable(N, self.ns, self.w, dev, data=self.srcW.data[:half])
+            self.srcB = slab.SlabTable(N, self.ns, self.w, dev, data=self.srcW.data[half:])
+        else:
+            self.layers = [None] + [ttab() for _ in range(L - 1)]
+            self.srcA, self.srcB, self.tmp = tab(), tab(), [ttab(), ttab()]
         self.mask = torch.zeros((N + 31) // 32 + 2, dtype=torch.int32, device=dev)
         self.step_count = 0
         self._side = None
@@ -565,8 +587,8 @@ class ColumnShardEngine(object):
         # its own); "sharded" = the distributed fold below (no rank ever holds more than a column slice or its own rows --
         # what BASELINE.json configs[4] needs). Default: sharded for row shards over several ranks of a real process group.
         fold_mode = os.environ.get("ELIMREC_FOLD", "")
-        if self.lean:
-            fold_mode = "sharded"
+        if self.lean or self.wide:
+            fold_mode = "sharded"            # (wide: the model's fold kernels are the bipartite ones)
         if fold_mode not in ("model", "sharded"):
             fold_mode = "sharded" if (self.feature_shard == "row" and world > 1 and dist.is_available() and dist.is_initialized()
                                       and dist.get_world_size(self.group) == world) else "model"
@@ -645,7 +667,7 @@ class ColumnShardEngine(object):
         bufs = self._bufs.get(B)
         if bufs is None:                                          # per batch size (an epoch ends with a ragged batch)
             bufs = self._bufs[B] = dict(send_f=torch.empty(W, R, 2 * self.dl, dtype=torch.float32, device=dev) if self.multi else None,
-                                        send_b=torch.zeros(W, R, 2 * self.dl, dtype=torch.float32, device=dev) if self.multi else None)
+                                        send_b=torch.zeros(W, R, 2 * self.dl, dtype=torch.float32, device=dev) if (self.multi or self.wide) else None)
         self.send_f, self.send_b = bufs["send_f"], bufs["send_b"]
         if "nar_act" not in bufs:
             bufs["nar_act"] = torch.zeros(R, d, dtype=torch.float32, device=dev)       # shared part of Out, compact rows
@@ -706,7 +728,7 @@ class ColumnShardEngine(object):
         tiered plan, at least two layers (ELIMREC_FUSE_ADAM=0 keeps the separate optimizer launch; `keep_grad` = True also
         stores the gradient table, for tests that read it)."""
         import os
-        return (not self.bf16 and self.planT.tiered and self.model.n_layers >= 2
+        return (not self.bf16 and not self.wide and self.planT.tiered and self.model.n_layers >= 2
                 and os.environ.get("ELIMREC_FUSE_ADAM", "1") != "0")
 
     @_once
@@ -716,8 +738,8 @@ class ColumnShardEngine(object):
         import os
         m = self.model
         hops_in_region = m.n_layers - (1 if self._fuse_adam() else 0)
-        return (os.environ.get("ELIMREC_FUSE_REDUCE", "1") != "0" and not self.bf16 and self.planT.tiered and hops_in_region >= 1
-                and m.mm_fusion_mode == "concat")
+        return (os.environ.get("ELIMREC_FUSE_REDUCE", "1") != "0" and not self.bf16 and not self.wide and self.planT.tiered
+                and hops_in_region >= 1 and m.mm_fusion_mode == "concat")
 
     @_once
     def _fuse_bwd_w(self):
@@ -732,19 +754,20 @@ class ColumnShardEngine(object):
         (each listed once) and the planner's key bitmap is their row bitmap -- no merge at all (ELIMREC_HEAD_SOURCES=0: the
         merge rides in the weight-gradient launch)."""
         import os
-        return (not self.multi and self._fused_head_ok() and bool(self._pack_bwd_off) and self.model.latent_dim == 64
+        return (not self.multi and not self.wide and self._fused_head_ok() and bool(self._pack_bwd_off) and self.model.latent_dim == 64
                 and os.environ.get("ELIMREC_HEAD_SOURCES", "1") != "0" and os.environ.get("ELIMREC_HEAD_BWD_ROWS", "16") != "32")
 
     @_once
     def _split_in_head(self):
         import os
-        return (self._fused_head_ok() and bool(self._pack_bwd_off) and self.model.latent_dim == 64
+        return (not self.wide and self._fused_head_ok() and bool(self._pack_bwd_off) and self.model.latent_dim == 64
                 and os.environ.get("ELIMREC_HEAD_SOURCES", "1") != "0" and os.environ.get("ELIMREC_HEAD_BWD_ROWS", "16") != "32")
 
     @_once
     def _fuse_merge(self):
         import os
-        return os.environ.get("ELIMREC_FUSE_MERGE", "1") != "0" and (self.model.num_users + self.model.num_items) <= (1 << 27)
+        return (os.environ.get("ELIMREC_FUSE_MERGE", "1") != "0" and not self.wide
+                and (self.model.num_users + self.model.num_items) <= (1 << 27))
 
     def _timed(self, fn, hops):
         ev = self.kernel_events
@@ -783,7 +806,7 @@ class ColumnShardEngine(object):
             ops.batch_plan(users, pos, neg, m.num_users, m.num_items, keys, act, seg, ws["slot_seg"][:R], ws["plan_ws"], err, PAD_KEY,
                            key_bitmap=self.mask if (early_bits or self._sources_in_head()) else None)
             if early_bits:    # the planner's bitmap of the active rows IS the first adjoint hop's source bitmap (one rank):
-                slab.source_bits(self.planT, self.ns, self.w, self.gs, self.mask)      # its per-line bits, off the critical path
+                slab.source_bits(self.planT, self.hns, self.w, self.hgs, self.mask)    # its per-line bits, off the critical path
 
         def pack():       # the head's weights in MFMA fragment order (they changed in the last optimizer step)
             self._head_fused_call(ws, R, phase=1)
@@ -826,7 +849,7 @@ class ColumnShardEngine(object):
 
             def bits():
                 slab.rows_bitmap(acts, m.num_users + m.num_items, self.mask)
-                slab.source_bits(self.planT, self.ns, self.w, self.gs, self.mask)
+                slab.source_bits(self.planT, self.hns, self.w, self.hgs, self.mask)
             m._region("cs_bits", (m._ws_gen, acts.data_ptr(), acts.shape[0], acts.shape[1]), bits)
         self._bits_ready = True
         self._aux_pending = True
@@ -852,6 +875,16 @@ class ColumnShardEngine(object):
         # what the hops GATHER from: the bf16 copy of the master in bf16-storage mode, the tables themselves otherwise
         srcs = self._srcs = ([self.mirror[self.cur]] if self.bf16 else [x0]) + self.layers[1:]
 
+        if self.wide:
+            tabs = self._tabs = self._srcs = [self.x0w] + self.layers[1:]
+
+            def wide_hops():
+                slab.wide_from_master(x0, m.num_users, self.x0w)
+                for k in range(1, L + 1):
+                    slab.hop(self.plan, tabs[k - 1], tabs[k], gs=self.hgs)
+            self._timed(lambda: m._region("cs_fwd_hops%d" % self.cur, (m._ws_gen,), wide_hops), L)
+            return
+
         def hops():
             for k in range(1, L):
                 slab.hop(self.plan, srcs[k - 1], tabs[k], gs=self.gs)
@@ -873,25 +906,28 @@ class ColumnShardEngine(object):
             out0, narrow, by_node = self.send_f.view(W * R, 2 * self.dl)[:, :self.dl], self.send_f.view(W * R, 2 * self.dl)[:, self.dl:], False
         else:
             counts = ws["seg_info"][0:1]
-            if self._fused_head_ok() or self.lookup:
+            if self._fused_head_ok() or self.lookup or self.wide:
                 out0, narrow, by_node = ws["OutAct"][:R, :m.latent_dim], self.nar_act, False
             else:
                 out0, narrow, by_node = ws["OutAct"][:R, :m.latent_dim], ws["Narrow"], True
 
         def long_rows():
-            if self.plan.n_long:
+            if self.plan.n_long and not self.wide:
                 slab.hop(self.plan, self._srcs[L - 1], self.long_tab, gs=self.gs, seg_only=True)
 
         def rows():
             if not late_wait:
                 long_rows()
-            if self.bf16:
+            if self.wide:         # all L + 1 wide tables are whole: layer means at the listed rows (padding ids are negative)
+                assert not by_node
+                slab.wide_rows([t.data for t in tabs], tabs[0].n, self.ns, self.w, acts.reshape(-1), W * R, out0, narrow)
+            elif self.bf16:
                 slab.rows16(self.plan, self.ns, self.w, L, U, tabs[0].data, [t.data for t in tabs[1:]] + [None], self.long_tab,
                             acts, counts, R, W, out0, narrow, by_node)
             else:
                 slab.rows(self.plan, self.ns, self.w, L, U, [t.data for t in tabs] + [None], self.long_tab, acts, counts, R, W,
                           out0, narrow, by_node)
-            if self.lookup and not self.multi:       # one rank: this rank owns every row -- no exchange, widen in place
+            if self.lookup and not (self.multi and self.lookup_exchange):     # this rank holds every row: no exchange, widen in place
                 self.fshard.unpack(ws["active_rows"][:R], None, self.s_rows, self.c_rows, direct=True)
         if late_wait:
             m._region("cs_fwd_long%d" % self.cur, (m._ws_gen,), long_rows)
@@ -1029,7 +1065,7 @@ class ColumnShardEngine(object):
                                              merge=merge, defer_reduce=defer, sources=sources)
         self._reduce = (m._bwd_w_reduce, 0 if defer == "all" else 1) if defer else None
         wg = ws["flat_grad"][ws["tail_off"]:]
-        if not self.multi:        # one rank owns every column: the merge reads the dOut rows themselves
+        if not self.multi and not self.wide:        # one rank owns every column: the merge reads the dOut rows themselves
             return ws["dOutR"][:R].view(1, R, m.C), wg
         # [H | G]: all the adjoint needs of a dOut row, written straight into the peers' column slices [W, R, 2*dl] (rows
         # beyond the active count are never read: their keys are negative)
@@ -1060,6 +1096,24 @@ class ColumnShardEngine(object):
         reduce = getattr(self, "_reduce", None) if (single or reduce_wgrads is not None) else None
         self._reduce = None
         self.wgrads_handle = None
+
+        if self.wide:
+            # the wide form: ONE source [H | G] for every layer (left <- H, right <- G, no user / item side swap), L whole hops
+            # T <- Src + A^T T, then the parameters' gradient = left half on user rows / right half on item rows
+            def wide_hops():
+                slab.merge_rows(recv2.view(W * R, 2 * self.dl), acts.reshape(-1), W, U, I, self.srcA, self.srcB, self.mask, M=-1)
+                t, tmask = self.srcW, self.mask
+                for k in range(L - 1, -1, -1):
+                    dst = self.tmp[k & 1]
+                    slab.hop(self.planT, t, dst, gs=self.hgs, src_mask=tmask, add=self.srcW, add_mask=self.mask, scale=1.0,
+                             bits_ready=tmask is not None and self._bits_ready)
+                    t, tmask = dst, None
+                slab.wide_grad(t, U, inv, self.grad)
+            self._timed(lambda: m._region("cs_bwd_hops", (m._ws_gen, recv2.data_ptr(), acts.data_ptr(), R, W, self._bits_ready), wide_hops), L)
+            self._adam_in_hop = self._tail_in_hop = False
+            if reduce_wgrads is not None:
+                self.wgrads_handle = reduce_wgrads()
+            return
 
         def hops():
             phase = None if reduce is None else reduce[1]
@@ -1101,7 +1155,7 @@ class ColumnShardEngine(object):
                 self._tail_arr = (_lib.AdamJob * 8)()         # one array for every step: its address is part of the step's
             for i, job in enumerate(tail):                    # recorded arguments (program.py), its step counts change in place
                 self._tail_arr[i] = job
-            self._tail_n = len(tail)
+            self._tail_n, self._tail_base = len(tail), 0
             tail = (self._tail_arr, len(tail))
             self._tail_in_hop = in_hop
             self._timed(lambda: slab.hop_adam(self.planT, self.tmp[1], self.grad if self.keep_grad else None, self.gs, self.srcA,
@@ -1134,7 +1188,8 @@ class ColumnShardEngine(object):
                 self._tail_arr = (_lib.AdamJob * 8)()         # one array for every step (its address is a recorded argument)
             for i, job in enumerate(jobs):
                 self._tail_arr[i] = job
-            self._tail_n = len(jobs) if getattr(self, "_adam_in_hop", False) else 0     # (native_prologue: spans from slot 0 only)
+            self._tail_base = 0 if getattr(self, "_adam_in_hop", False) else 1           # slot 0: the embeddings' span
+            self._tail_n = len(jobs) - self._tail_base
             _lib.check(_lib.load().elimrec_adam_multi(self._tail_arr, len(jobs), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                                                       g["weight_decay"], ops._stream()), "adam_multi")
         self.cur = nxt
@@ -1142,11 +1197,17 @@ class ColumnShardEngine(object):
     def native_prologue(self):
         """What the ordinary step's Python does besides launching, ahead of the launches of a native step: the projection
         weights' step counts (optimizer state and the persistent job array the last hop's launch reads)."""
+        base = getattr(self, "_tail_base", 0)
+        if base:            # the embeddings' Adam is a span of the optimizer launch (wide form), not part of the last hop:
+            nxt = 1 - self.cur          # this step's buffers and step count into the persistent job array the launch reads
+            self._tail_arr[0] = _lib.AdamJob(self.master[self.cur].data.data_ptr(), self.master[nxt].data.data_ptr(),
+                                             self.mirror[nxt].data.data_ptr() if self.bf16 else None, self.grad.data.data_ptr(),
+                                             self.m1.data_ptr(), self.m2.data_ptr(), None, self.grad.data.numel(), self.step_count + 1)
         if self._tail_plan is not None and getattr(self, "_tail_n", 0):
             _, spans, states = self._tail_plan[:3]
             for st in states:
                 st["step"] += 1
-            i = 0
+            i = base
             for sp in spans:
                 if sp["upd"]:
                     sp["step"] += 1
@@ -1210,7 +1271,7 @@ class ColumnShardEngine(object):
         the 1/(L+1) scale. cols is padded to the column count per slab group of the engine's plan (the wave-tile plan is laid
         out for that many lanes per row piece)."""
         m, N, L = self.model, x0_rows.shape[0], self.model.n_layers
-        per_group = (self.ns // self.gs) * self.w                    # columns one lane group covers
+        per_group = (self.hns // self.hgs) * self.w                  # columns one lane group covers
         cols = x0_rows.shape[1]
         padded = (cols + per_group - 1) // per_group * per_group
         if padded != cols:
@@ -1236,7 +1297,8 @@ class ColumnShardEngine(object):
         m, W = self.model, owners.world
         U, I, dev = m.num_users, m.num_items, m._device()
         q = frank
-        coll = collectives_for(self.group, W)
+        real = W > 1 and dist.is_available() and dist.is_initialized()      # (ranks emulated in one process: whole tables, own rows)
+        coll = collectives_for(self.group, W) if real else None
         nodes = [torch.from_numpy(owners.nodes(o)).to(dev) for o in range(W)]
         rows = [len(n) for n in nodes]
         i_rows = [owners.rows(o)[1] for o in range(W)]
@@ -1245,7 +1307,7 @@ class ColumnShardEngine(object):
         for k in m._mods:
             feat = getattr(m, k + "_feat")
             D = feat.shape[1]
-            if W > 1 and D % W == 0 and (D // W) % 4 == 0:
+            if real and D % W == 0 and (D // W) % 4 == 0:
                 Dq = D // W
                 mine = feat[i0:i1].to(dev)                                          # my item block, all columns
                 cols = coll.all_to_all_rows(torch.cat([mine[:, p * Dq:(p + 1) * Dq] for p in range(W)]).contiguous(),
@@ -1324,10 +1386,13 @@ class ColumnShardEngine(object):
         N = U + m.num_items
         if self._x0_fwd is None:
             raise RuntimeError("no forward has run on the column-sharded engine yet")
-        if self.xL is None:
-            self.xL = self.layers[1].like() if L >= 2 else self.grad.like()
-        tabs = [self._x0_fwd] + self.layers[1:]
-        slab.hop(self.plan, self._srcs[L - 1], self.xL, gs=self.gs)     # (bf16 storage: X^L is rounded here, not in training)
+        if self.wide:
+            tabs = [self.x0w] + self.layers[1:]                  # every layer of the last forward, whole (x0w was built from its master)
+        else:
+            if self.xL is None:
+                self.xL = self.layers[1].like() if L >= 2 else self.grad.like()
+            tabs = [self._x0_fwd] + self.layers[1:]
+            slab.hop(self.plan, self._srcs[L - 1], self.xL, gs=self.gs)     # (bf16 storage: X^L is rounded here, not in training)
 
         def all_rows(out0, narrow):
             if self.bf16:
@@ -1336,10 +1401,12 @@ class ColumnShardEngine(object):
             else:
                 slab.rows(self.plan, self.ns, self.w, L, U, [t.data for t in tabs] + [self.xL.data], None, None, None, N, 1,
                           out0, narrow, False)
-        if self.feature_shard == "row" and (self.world > 1 or self.lean or ws.get("fold") is None):
+        if self.lookup and ((self.feature_shard == "row" and (self.world > 1 or self.lean)) or ws.get("fold") is None):
             def rows_of(node_ids, out0, narrow):               # (layer mean | shared part) of the listed rows, my columns
                 n = int(node_ids.numel())
-                if self.bf16:
+                if self.wide:
+                    slab.wide_rows([t.data for t in tabs], N, self.ns, self.w, node_ids, n, out0, narrow)
+                elif self.bf16:
                     slab.rows16(self.plan, self.ns, self.w, L, U, tabs[0].data, [t.data for t in tabs[1:]] + [self.xL.data], None,
                                 node_ids.view(1, n), None, n, 1, out0, narrow, False)
                 else:

@@ -396,9 +396,9 @@ def rows(plan, ns, w, L, U, layers, long_tab, row_ids, counts, R, n_lists, out0,
 
 def merge_rows(all_rows, all_keys, world, U, I, srcA, srcB, mask, M=0):
     """[H | G] rows (M = 0) or dOut rows of M column blocks (M >= 1) of `world` ranks -> slab-major adjoint sources + row
-    bitmap (elimrec_slab_merge_rows)."""
+    bitmap (elimrec_slab_merge_rows). M = -1: [H | G] rows, H always into srcA and G always into srcB (the wide form)."""
     R = all_keys.numel() // world
-    assert all_rows.is_contiguous() and all_rows.shape == (world * R, (M if M else 2) * srcA.cols) and mask.numel() * 32 >= U + I
+    assert all_rows.is_contiguous() and all_rows.shape == (world * R, (M if M > 0 else 2) * srcA.cols) and mask.numel() * 32 >= U + I
     _lib.check(_lib.load().elimrec_slab_merge_rows(_dev(all_rows, "rows"), _dev(all_keys, "keys", torch.int32), int(world), R,
                                                    int(U), int(I), srcA.ns, srcA.w, int(M), _dev(srcA.data, "srcA"),
                                                    _dev(srcB.data, "srcB"), _dev(mask, "mask", torch.int32), _stream()),
@@ -420,3 +420,27 @@ def rows_bitmap(keys, N, mask):
     assert keys.is_contiguous() and mask.numel() * 32 >= N
     _lib.check(_lib.load().elimrec_rows_bitmap(_dev(keys, "keys", torch.int32), int(W), int(R), int(N), _dev(mask, "mask", torch.int32),
                                                _stream()), "rows_bitmap")
+
+
+def wide_from_master(master, U, wide):
+    """Layer 0 of the wide form (csrc/wide.hip): wide [N x 2 dl] <- [E_u | 0] on user rows, [0 | E_i] on item rows."""
+    assert wide.ns == 2 * master.ns and wide.w == master.w and wide.n == master.n
+    _lib.check(_lib.load().elimrec_wide_from_master(_dev(master.data, "master"), int(U), master.n, master.ns, master.w, _dev(wide.data, "wide"),
+                                                    _stream()), "wide_from_master")
+
+
+def wide_rows(layers, n, ns, w, rows, total, out0, narrow):
+    """(layer mean, shared part) of listed rows from the L+1 wide layer tables (flat tensors): out0 = mean_k (left + right),
+    narrow = mean_k left. rows: int32 ids (negative = padding) or None for rows 0 .. total-1."""
+    L = len(layers) - 1
+    ptrs = (ctypes.c_void_p * (L + 1))(*[_dev(t, "layer") for t in layers])
+    assert out0.stride(1) == 1 and narrow.stride(1) == 1
+    _lib.check(_lib.load().elimrec_wide_rows(ptrs, L, int(n), int(ns), int(w), _dev(rows, "rows", torch.int32), int(total), _dev(out0, "out0"),
+                                             out0.stride(0), _dev(narrow, "narrow"), narrow.stride(0), _stream()), "wide_rows")
+
+
+def wide_grad(wide, U, scale, grad):
+    """grad [N x dl] <- scale * (left half of the wide adjoint table on user rows, right half on item rows)."""
+    assert wide.ns == 2 * grad.ns and wide.w == grad.w and wide.n == grad.n
+    _lib.check(_lib.load().elimrec_wide_grad(_dev(wide.data, "wide"), int(U), grad.n, grad.ns, grad.w, float(scale), _dev(grad.data, "grad"),
+                                             _stream()), "wide_grad")

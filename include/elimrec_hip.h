@@ -655,6 +655,8 @@ int elimrec_slab_to_rows(const float *d_slab, int64_t n, int ns, int w, float *d
  * only, SrcA = [H_u ; G_i], SrcB = [G_u ; H_i] and the row bitmap d_mask (all ceil(N/32) words written).
  * M = 0: [H | G] rows as above. M >= 1 (one rank owning every column): d_rows are the dOut rows themselves,
  * [world x R x M*dl], and H (sum of the M column blocks) / G (block 0) are formed on the fly.
+ * M = -1 (the wide form, csrc/wide.hip): [H | G] rows as for M = 0, but H goes to SrcA and G to SrcB on EVERY row --
+ * SrcA / SrcB are the left / right half of one wide adjoint source.
  * Replaces IndexBackward / index_put(accumulate) across ranks ("sparse-grad reduce-scatter"). */
 int elimrec_slab_merge_rows(const float *d_rows, const int32_t *d_keys, int world, int64_t R, int64_t U,
                             int64_t I, int ns, int w, int M, float *d_SrcA, float *d_SrcB, uint32_t *d_mask,
@@ -765,6 +767,16 @@ int elimrec_lookup_unpack(const int32_t *d_act, int world, int64_t R, int64_t U,
                           const int64_t *ib, int me, const void *d_rows, int64_t row_bytes, int dtype, int sum_d,
                           int direct, float *d_S, int64_t ldS, float *d_c, void *stream);
 
+/* ---------------------------------------------------------------- folded propagation for adjacencies with a diagonal (csrc/wide.hip)
+ * adj_type = norm / mean + I (/root/reference/models/EliMRec.py:332-335,349-352): the E_u-borne and the E_i-borne part of the
+ * tables no longer alternate by layer, so the graph carries both side by side in a WIDE slab table [N x 2 dl] (2 ns slabs of w
+ * floats; slabs [0, ns) = left = the E_u-borne part). Layer 0 from the [N x dl] parameters; (layer mean, shared part) of listed
+ * rows (d_rows NULL: rows 0 .. total-1; negative ids are padding): out0 = mean_k (left + right), narrow = mean_k left; the
+ * parameters' gradient from the wide adjoint table: left half on user rows, right half on item rows, times scale. */
+int elimrec_wide_from_master(const float *d_master, int64_t U, int64_t N, int ns, int w, float *d_wide, void *stream);
+int elimrec_wide_rows(const float *const *layers /* L+1 wide tables */, int L, int64_t N, int ns, int w, const int32_t *d_rows,
+                      int64_t total, float *d_out0, int64_t ld_out0, float *d_narrow, int64_t ld_narrow, void *stream);
+int elimrec_wide_grad(const float *d_wide_grad, int64_t U, int64_t N, int ns, int w, float scale, float *d_grad, void *stream);
 /* Row bitmap of `world` active-row lists d_keys [world x R] (ascending, negative padding last): bit n of d_mask
  * ((N + 31) / 32 words) <=> node n is in some list -- the words elimrec_slab_merge_rows writes for the same lists. */
 int elimrec_rows_bitmap(const int32_t *d_keys, int world, int64_t R, int64_t N, uint32_t *d_mask, void *stream);

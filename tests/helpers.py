@@ -119,11 +119,11 @@ def fixture_argv(g):
     return argv
 
 
-def build_model_from_fixture(g, device, params_prefix="init"):
+def build_model_from_fixture(g, device, params_prefix="init", extra_argv=()):
     """elimrec_amd.EliMRec on `device` holding the fixture's graph, features and parameters."""
     import torch
     from elimrec_amd import EliMRec
-    cfg = make_config(fixture_argv(g))
+    cfg = make_config(fixture_argv(g) + list(extra_argv))
     model = EliMRec(cfg, FixtureDataset(g))
     with torch.no_grad():
         for m in ("v", "a", "t"):

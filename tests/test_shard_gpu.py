@@ -821,7 +821,7 @@ def test_random_shapes_column_shard_vs_row_major_trainer(seed):
 
 
 # ----------------------------------------------------------------------------- two PROCESSES, one GPU
-def _two_proc_worker(rank, world, port, out_dir, feature_shard="replicated"):
+def _two_proc_worker(rank, world, port, out_dir, feature_shard="replicated", name="ml3", extra=()):
     import os, sys
     import torch.distributed as dist
     from helpers import ROOT
@@ -829,8 +829,8 @@ def _two_proc_worker(rank, world, port, out_dir, feature_shard="replicated"):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)        # RCCL refuses two ranks on one device
     from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
-    g = load_golden("ml3")
-    model, _ = build_model_from_fixture(g, DEV)
+    g = load_golden(name)
+    model, _ = build_model_from_fixture(g, DEV, extra_argv=extra)
     opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
     eng = ColumnShardEngine(model, feature_shard=feature_shard)
     tr = ColumnShardTrainer(eng, opt, world_size=world, rank=rank)
@@ -862,22 +862,26 @@ def _two_proc_worker(rank, world, port, out_dir, feature_shard="replicated"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("feature_shard", ["replicated", "row"])
-def test_two_processes_on_one_gpu_equal_one_process(tmp_path, feature_shard):
+@pytest.mark.parametrize("feature_shard,name,extra", [("replicated", "ml3", ()), ("row", "ml3", ()),
+                                                      ("row", "ablate", ("--propagation=folded",))],
+                         ids=["replicated", "row", "row-wide-form"])
+def test_two_processes_on_one_gpu_equal_one_process(tmp_path, feature_shard, name, extra):
     """The real engine and the real trainer in two PROCESSES (both on cuda:0; gloo group, collectives staged through the host
     because RCCL refuses duplicate devices): every collective of a column-sharded step executes between processes. Both ranks
     end with the same full model, equal to one process on the concatenated batch. feature_shard = row: each process holds
-    half the rows of the folded constants and the step's variable-size all_to_all brings the other half's active rows."""
+    half the rows of the folded constants and the step's variable-size all_to_all brings the other half's active rows.
+    row-wide-form: the `ablate` fixture (adjacency with a diagonal, mean fusion) in the wide form, two column slices of both
+    halves of the wide tables."""
     import torch.multiprocessing as mp
     from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
     world = 2
     port = 33500 + (os.getpid() % 2000) + (3 if feature_shard == "row" else 0)
-    mp.spawn(_two_proc_worker, args=(world, port, str(tmp_path), feature_shard), nprocs=world, join=True)
+    mp.spawn(_two_proc_worker, args=(world, port + (7 if extra else 0), str(tmp_path), feature_shard, name, extra), nprocs=world, join=True)
     rs = [dict(np.load(tmp_path / ("rank%d.npz" % r))) for r in range(world)]
     for k in rs[0]:
         assert np.array_equal(rs[0][k], rs[1][k]), k
-    g = load_golden("ml3")
-    model, _ = build_model_from_fixture(g, DEV)
+    g = load_golden(name)
+    model, _ = build_model_from_fixture(g, DEV, extra_argv=extra)
     opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
     eng = ColumnShardEngine(model)
     tr = ColumnShardTrainer(eng, opt)
@@ -1289,3 +1293,137 @@ def test_bf16_storage_vs_rounding_oracle_at_the_tiktok_shape():
         assert worst < (2e-3 if mode == "bf16" else 1e-5), (mode, worst)
         assert emb < (2e-3 if mode == "bf16" else 2e-5), (mode, emb)
     print("Tiktok shape, max |loss - oracle|, max |E - oracle|:", res)
+
+
+# ----------------------------------------------------------------------------- adjacencies with a diagonal: the wide form
+def test_wide_form_trains_the_norm_adjacency_fixture_on_the_column_shard_engine():
+    """The fifth fixture (`ablate`: adj_type = norm, D^-1 (A + I); mean fusion; modality ablation 'va') on ColumnShardTrainer
+    with --propagation=folded: the graph carries the E_u-borne and the E_i-borne part side by side in wide tables
+    (csrc/wide.hip) -- losses 1e-5, parameters after Adam 2e-5, predict() after training 1e-5 against the reference's golden
+    vectors, as the other four fixtures on this engine."""
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
+    g = load_golden("ablate")
+    model, _ = build_model_from_fixture(g, DEV, extra_argv=["--propagation=folded"])
+    assert model._wide and model._lazy and not model._bipartite
+    with pytest.raises(RuntimeError):
+        model.bpr_loss(*(_t(g["step1/%s" % k]) for k in ("users", "pos", "neg")))
+    opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    eng = ColumnShardEngine(model)
+    tr = ColumnShardTrainer(eng, opt)
+    assert eng.wide and eng.lookup
+    steps = int(g["steps"])
+    for t in range(1, steps + 1):
+        loss = tr.step(*(_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg")))
+        assert abs(float(loss) - float(g["step%d/loss" % t])) < 1e-5, t
+        if t in (1, steps):
+            eng.sync_to_model()
+            sd = model.state_dict()
+            for k, v in sub(g, "after%d" % t).items():
+                assert np.abs(sd[k].cpu().numpy() - v).max() < 2e-5, (t, k)
+    model.fusion_mode, model.predict_type = "rubi", "TIE"
+    got = model.predict(g["eval_users"].tolist()).numpy()
+    assert np.abs(got - g["predict/rubi/TIE"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("adj_type,L,recdim,W", [("norm", 3, 64, 1), ("mean", 2, 32, 1), ("norm", 4, 64, 2), ("mean", 3, 32, 4)])
+def test_wide_form_step_vs_oracle(adj_type, L, recdim, W):
+    """One step of the wide form against the oracle on a seeded shape, adj_type norm and mean + I, layer counts 2-4, the fused
+    (recdim 64) and the generic head, one rank and W emulated ranks with row-sharded constants: loss 1e-5, the embedding
+    gradient and every weight gradient 1e-4 max-norm and row by row."""
+    from elimrec_amd import ColumnShardEngine, EliMRec, FusedAdam, SyntheticDataset, set_seed
+    from oracle import elimrec_oracle as eo
+    U, I, E, dims, B = 700, 1900, 9000, (24, 8, 12), 256
+    argv = ["--data.input.dataset=synthetic", "--alpha=0.5", "--loss=bpr_loss", "--recdim=%d" % recdim, "--verbose=0",
+            "--adj_type=%s" % adj_type, "--layer_num=%d" % L, "--propagation=folded"]
+    ds = SyntheticDataset(U, I, E, feat_dims=dims, seed=1)
+    gen = torch.Generator().manual_seed(3)
+    train = ds.train_matrix.tocoo()
+    pick = torch.randint(0, train.nnz, (B,), generator=gen).numpy()
+    u = torch.from_numpy(train.row[pick].astype(np.int64)); p = torch.from_numpy(train.col[pick].astype(np.int64))
+    n = torch.randint(0, I, (B,), generator=gen)
+    engines, init = [], None
+    for q in range(W):
+        cfg = make_config(argv + (["--feature_shard=row"] if W > 1 else []))
+        set_seed(7)
+        model = EliMRec(cfg, ds)
+        init = {k: v.detach().clone().numpy() for k, v in model.state_dict().items()}
+        model = model.to(DEV)
+        eng = ColumnShardEngine(model)
+        eng.cs_setup(W, q, FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"]))
+        eng.keep_grad = True
+        assert eng.wide
+        engines.append(eng)
+    h = B // W
+    batches = [(u[q * h:(q + 1) * h].to(DEV), p[q * h:(q + 1) * h].to(DEV), n[q * h:(q + 1) * h].to(DEV)) for q in range(W)]
+    # the emulated step without the update: forward, head, backward -- gradients against the oracle on the whole batch
+    acts = torch.stack([e.cs_plan(*b).clone() for e, b in zip(engines, batches)])
+    sends = [e.cs_forward(acts) for e in engines]
+    sends = [None if s is None else s.clone() for s in sends]
+    if W > 1:
+        rb = engines[0].lookup_row_bytes
+        counts = engines[0].cs_lookup_counts(acts).cpu().numpy()
+        packed = [e.cs_lookup_pack(acts).clone() for e in engines]
+        for q, e in enumerate(engines):
+            e.cs_lookup_unpack(torch.cat([packed[o][int(counts[:q, o].sum()) * rb:(int(counts[:q, o].sum()) + int(counts[q, o])) * rb] for o in range(W)]))
+    scale = torch.full((1,), 1.0 / W, device=DEV)
+    losses, sends2, wgs = [], [], []
+    for q, e in enumerate(engines):
+        recv = None if W == 1 else torch.stack([sends[o][q] for o in range(W)])
+        losses.append(e.cs_head(recv).clone())
+        s2, wg = e.cs_backward_local(scale)
+        sends2.append(s2.clone()); wgs.append(wg.clone())
+    for q, e in enumerate(engines):
+        e.cs_backward_hops(torch.stack([sends2[o][q] for o in range(W)]) if W > 1 else sends2[0], acts)
+    tu, ti = ds.get_train_interactions()
+    cfg = make_config(argv)
+    adj = eo.build_adj(tu, ti, U, I, adj_type)
+    feats = {m: eo.OracleEliMRec.normalize_features(getattr(ds, m + "_feat")) for m in ("v", "a", "t")}
+    om = eo.OracleEliMRec(U, I, recdim, L, adj, feats, init, cfg["alpha"], dataset_name="synthetic")
+    hB = h * W
+    ol = om.bpr_loss(u[:hB], p[:hB], n[:hB])
+    ol.backward()
+    assert abs(float(torch.stack(losses).mean()) - float(ol.detach())) < 1e-5
+    want = om.grads()
+    gE = torch.cat([e.grad.dense() for e in engines], dim=1).cpu()
+    assert_grad_close(gE[:U], want["embedding_user.weight"], "embedding_user.weight")
+    assert_grad_close(gE[U:], want["embedding_item.weight"], "embedding_item.weight")
+    wg = torch.stack(wgs).sum(0)                      # the all_reduce of the projection-weight gradients
+    ws0 = engines[0].model._ws
+    for k, (off, numel) in ws0["param_off"].items():
+        if k.startswith(("embedding_user.", "embedding_item.")) or k not in want:
+            continue
+        mine = wg[off - ws0["tail_off"]:off - ws0["tail_off"] + numel].view_as(want[k]).cpu()
+        assert_grad_close(mine, want[k], k)
+
+
+def test_wide_form_native_step_program_equals_python_issued_steps(monkeypatch):
+    """The wide form's step (wide_rows, the plain merge, L adjoint hops, wide_grad) as a native program: 30 steps on changing
+    batches, bit for bit the steps issued from Python (concat fusion; the `ablate` fixture's mean fusion keeps the ordinary
+    path, its head runs torch ops)."""
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, EliMRec, FusedAdam, SyntheticDataset, set_seed
+    U, I, E, dims, B = 700, 1900, 9000, (24, 8, 12), 256
+    argv = ["--data.input.dataset=synthetic", "--alpha=0.5", "--loss=bpr_loss", "--recdim=64", "--verbose=0",
+            "--adj_type=norm", "--layer_num=3", "--propagation=folded"]
+    ds = SyntheticDataset(U, I, E, feat_dims=dims, seed=1)
+    gen = torch.Generator().manual_seed(5)
+    batches = [(torch.randint(0, U, (B,), generator=gen).to(DEV), torch.randint(0, I, (B,), generator=gen).to(DEV),
+                torch.randint(0, I, (B,), generator=gen).to(DEV)) for _ in range(30)]
+    out = {}
+    for native in ("0", "1"):
+        monkeypatch.setenv("ELIMREC_NATIVE_STEP", native)
+        cfg = make_config(argv)
+        set_seed(7)
+        model = EliMRec(cfg, ds).to(DEV)
+        opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+        eng = ColumnShardEngine(model)
+        tr = ColumnShardTrainer(eng, opt)
+        assert eng.wide
+        losses = torch.stack([tr.step(*b) for b in batches]).cpu().numpy()
+        st = tr._native_state()
+        assert st["failed"] is None, st["failed"]
+        assert (st["native_steps"] >= 20) == (native == "1"), st
+        eng.sync_to_model()
+        out[native] = (losses, {k: v.detach().clone() for k, v in model.state_dict().items()})
+    assert np.array_equal(out["0"][0], out["1"][0])
+    for k, v in out["0"][1].items():
+        assert torch.equal(out["1"][1][k], v), k
