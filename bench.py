@@ -413,8 +413,8 @@ def eval_pass(model, cfg, torch):
     best = min(secs[1:])
     return {"what": "full-catalogue TIE top-%d validation pass" % (max(topks) if isinstance(topks, (list, tuple)) else int(topks)),
             "users": n_eval,
-            "math": "v_exp/v_rcp + Newton step, dot products as six bf16 piece products with fp32 accumulation: scores within 2.4e-7 of the "
-                    "IEEE/libm fp32-MFMA form (default)" if default_math else "exact",
+            "math": "v_exp/v_rcp + Newton step, the heads' sigmoid product through one reciprocal, dot products as six bf16 piece products "
+                    "with fp32 accumulation: scores within 2.4e-7 of the IEEE/libm fp32-MFMA form (default)" if default_math else "exact",
             "users_per_launch": model.valid_evaluator.evaluator.block_users,
             "seconds_first": secs[0], "seconds": best, "users_per_s": n_eval / best,
             "roofline": {"bound": "mfma", "kernel": "score_t16b_kernel (pass 1 + pass 2 on the bf16 matrix cores from exact three-piece splits of the "

@@ -60,21 +60,52 @@ template <bool FAST> __device__ __forceinline__ float sig_(float x) {
     if (FAST) return rcp_nr(1.f + exp_neg_(x));
     return sigmoidf_(x);
 }
+// FAST forms for BOUNDED arguments -- the heads' z_h are cosines of normalised rows (|z| <= 1), ui / the row mean / the rubi
+// fusion are sigmoids or products of sigmoids (in (0, 1)), a difference of two rubi fusions is in (-1, 1): the rounding of
+// x * log2(e) costs |x| 2^-24 relative there, below the final rounding, so the two-float product and the clamp of exp_neg_
+// are not needed (one multiply + v_exp_f32 instead of six operations + v_exp_f32) ...
+__device__ __forceinline__ float exp_neg_small_(float x) { return __builtin_amdgcn_exp2f(x * -1.44269502162933349609375f); }
+template <bool FAST> __device__ __forceinline__ float sig_small_(float x) {
+    if (FAST) return rcp_nr(1.f + exp_neg_small_(x));
+    return sigmoidf_(x);
+}
+// Where only the ABSOLUTE accuracy of a sigmoid matters -- ui = sigmoid(u . i) (used as a factor, a summand or averaged: never
+// under a logarithm) and the last sigmoid of a score -- the product's rounding is harmless for any argument: the error of
+// sigmoid is s (1 - s) |x| 2^-24 <= 1.4e-8. One clamp (v_exp_f32 must not overflow: 1 + inf -> NaN in the Newton step).
+template <bool FAST> __device__ __forceinline__ float sig_abs_(float x) {
+    if (FAST) return rcp_nr(1.f + __builtin_amdgcn_exp2f(fmaxf(x, -88.f) * -1.44269502162933349609375f));
+    return sigmoidf_(x);
+}
+// ... and a PRODUCT of sigmoids goes through one reciprocal: prod_h 1 / (1 + e^-z_h) = 1 / prod_h (1 + e^-z_h), the
+// denominator <= (1 + e)^4 (two v_rcp_f32 + Newton steps fewer per (user, item) pair with three heads)
+template <bool MASKED> __device__ __forceinline__ float sig_den_(const float *z, int S, uint32_t mask) {
+    float den = 1.f;
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+        if (h < S && (!MASKED || (mask & (1u << h)))) den *= 1.f + exp_neg_small_(z[h]);
+    return den;
+}
 // (the logarithms of the 'hm' / 'sum' fusions are libm's in both modes: v_log_f32 costs 7e-7 relative there)
 template <bool FAST> __device__ __forceinline__ float log_(float x) { return logf(x); }
 template <bool FAST> __device__ __forceinline__ float log1p_(float x) { return log1pf(x); }
 
+// x: ui = sigmoid(u . i) (or the row mean of it), in (0, 1); z: the heads' cosines
 template <bool FAST>
 __device__ __forceinline__ float fuse_t(int mode, float x, const float *z, int S, uint32_t mask) {
     if (mode == 0) {
+        if (FAST) return x * rcp_nr(sig_den_<true>(z, S, mask));
         float r = x;
 #pragma unroll
         for (int h = 0; h < 4; ++h) if (h < S && (mask & (1u << h))) r *= sig_<FAST>(z[h]);
         return r;
     } else if (mode == 1) {
-        float t = sig_<FAST>(x);
+        float t;
+        if (FAST) t = rcp_nr((1.f + exp_neg_small_(x)) * sig_den_<false>(z, S, mask));
+        else {
+            t = sig_<FAST>(x);
 #pragma unroll
-        for (int h = 0; h < 4; ++h) if (h < S) t *= sig_<FAST>(z[h]);
+            for (int h = 0; h < 4; ++h) if (h < S) t *= sig_<FAST>(z[h]);
+        }
         return log_<FAST>(t + 1e-12f) - log1p_<FAST>(t);
     } else {
         float t = x;
@@ -87,15 +118,27 @@ __device__ __forceinline__ float fuse_t(int mode, float x, const float *z, int S
 template <bool FAST>
 __device__ __forceinline__ void fuse2_t(int mode, float x, float m, const float *z, int S, uint32_t mask, float &fx, float &fm) {
     if (mode == 0) {
+        if (FAST) {
+            const float p = rcp_nr(sig_den_<true>(z, S, mask));
+            fx = x * p; fm = m * p;
+            return;
+        }
         fx = x; fm = m;
 #pragma unroll
         for (int h = 0; h < 4; ++h)
             if (h < S && (mask & (1u << h))) { const float sg = sig_<FAST>(z[h]); fx *= sg; fm *= sg; }
     } else if (mode == 1) {
-        float tx = sig_<FAST>(x), tm = sig_<FAST>(m);
+        float tx, tm;
+        if (FAST) {
+            const float den = sig_den_<false>(z, S, mask);
+            tx = rcp_nr((1.f + exp_neg_small_(x)) * den);
+            tm = rcp_nr((1.f + exp_neg_small_(m)) * den);
+        } else {
+            tx = sig_<FAST>(x); tm = sig_<FAST>(m);
 #pragma unroll
-        for (int h = 0; h < 4; ++h)
-            if (h < S) { const float sg = sig_<FAST>(z[h]); tx *= sg; tm *= sg; }
+            for (int h = 0; h < 4; ++h)
+                if (h < S) { const float sg = sig_<FAST>(z[h]); tx *= sg; tm *= sg; }
+        }
         fx = log_<FAST>(tx + 1e-12f) - log1p_<FAST>(tx);
         fm = log_<FAST>(tm + 1e-12f) - log1p_<FAST>(tm);
     } else {
@@ -107,6 +150,23 @@ __device__ __forceinline__ void fuse2_t(int mode, float x, float m, const float 
         fm = log_<FAST>(sig_<FAST>(tm) + 1e-12f);
     }
 }
+// FAST, rubi fusion, predict type TE / TIE as ONE expression with ONE reciprocal per (user, item) pair: with Q = 1 + e^-a
+// (ui = 1 / Q) and D = prod_h (1 + e^-z_h) over the heads of the modality mask,
+//   TE  argument  ui / D       = 1 / (Q D)
+//   TIE argument  (ui - m) / D = (1 - m Q) / (Q D)            (m = the user's mean of ui over the catalogue)
+// a clamped at -80 (Q D stays finite; sigmoid(-80) = 2e-35); zs[h] = z_h * -log2(e), the factor folded into the item norms.
+__device__ __forceinline__ float rubi_fast_(float a, const float *zs, int S, uint32_t mask, bool tie, float m) {
+    const float q = 1.f + __builtin_amdgcn_exp2f(fmaxf(a, -80.f) * -1.44269502162933349609375f);
+    float den = q;
+#pragma unroll
+    for (int h = 0; h < 4; ++h)
+        if (h < S && (mask & (1u << h))) den *= 1.f + __builtin_amdgcn_exp2f(zs[h]);
+    const float p = rcp_nr(den);
+    return sig_small_<true>(tie ? fmaf(-m, q, 1.f) * p : p);
+}
+// the last sigmoid of a score: its argument is bounded for the rubi fusion (a product of sigmoids or a difference of two) and
+// for predict type normal (ui itself); the logarithms of hm / sum are not
+template <bool FAST> __device__ __forceinline__ float sig_out_(int mode, float x) { return mode == 0 ? sig_small_<FAST>(x) : sig_abs_<FAST>(x); }
 
 struct ScoreArgs {
     const float *Y; int64_t ldy; int64_t U; int64_t I; const int64_t *users; int B; int d; int S;
@@ -576,7 +636,7 @@ __global__ __launch_bounds__(512, (D > 64 ? 2 : 4)) void score_t16_kernel(ScoreA
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int b = b0 + wave * TU + 4 * kq + r;
-                    const float v = (item_ok && b < a.B) ? sig_<FAST>(acc[0][r]) : 0.f;
+                    const float v = (item_ok && b < a.B) ? sig_abs_<FAST>(acc[0][r]) : 0.f;
                     psum[r] += row16_sum(v);          // over the 16 items of the tile
                 }
             } else {
@@ -586,13 +646,21 @@ __global__ __launch_bounds__(512, (D > 64 ? 2 : 4)) void score_t16_kernel(ScoreA
                     inorm[h] = (item_ok && ptype != 0) ? fmaxf(sqrtf(sq_cur[sub * (NB - 1) + h]), eps) : 1.f;
                     if (FAST) inorm[h] = rcp_nr(inorm[h]);
                 }
+                const bool rubi_fast = FAST && fmode == 0 && ptype != 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int urow = wave * TU + 4 * kq + r;
-                    const float ui = sig_<FAST>(acc[0][r]);
+                    const float ui = sig_abs_<FAST>(acc[0][r]);
                     float out;
                     if (ptype == 0) {
-                        out = sig_<FAST>(ui);
+                        out = sig_small_<FAST>(ui);
+                    } else if (rubi_fast) {
+                        float zs[kMaxS];
+#pragma unroll
+                        for (int h = 0; h < kMaxS; ++h)
+                            zs[h] = (h + 1 < NB) ? acc[(h + 1 < NH) ? h + 1 : 0][r] * (unorm[urow * (NB - 1) + (h + 1 < NB ? h : 0)] *
+                                                                                   (inorm[h + 1 < NB ? h : 0] * -1.44269502162933349609375f)) : 0.f;
+                        out = rubi_fast_(acc[0][r], zs, NB - 1, a.head_mask, ptype == 2, umean[urow]);
                     } else {
                         float z[kMaxS];
 #pragma unroll
@@ -601,11 +669,11 @@ __global__ __launch_bounds__(512, (D > 64 ? 2 : 4)) void score_t16_kernel(ScoreA
                             const float dp = acc[(h + 1 < NH) ? h + 1 : 0][r];
                             z[h] = (h + 1 < NB) ? (FAST ? dp * nn : dp / nn) : 0.f;
                         }
-                        if (ptype == 1) out = sig_<FAST>(fuse_t<FAST>(fmode, ui, z, NB - 1, a.head_mask));
+                        if (ptype == 1) out = sig_out_<FAST>(fmode, fuse_t<FAST>(fmode, ui, z, NB - 1, a.head_mask));
                         else {
                             float te, nde;
                             fuse2_t<FAST>(fmode, ui, umean[urow], z, NB - 1, a.head_mask, te, nde);
-                            out = sig_<FAST>(te - nde);
+                            out = sig_out_<FAST>(fmode, te - nde);
                         }
                     }
                     const bool row_ok = b0 + urow < a.B;
@@ -782,22 +850,33 @@ __global__ __launch_bounds__(512, 2) void score_t16b_kernel(ScoreArgs a, int n_t
         const int64_t item = i0 + li;
         const bool item_ok = item < a.item_end;
         float inorm[NQ];
+        const bool rubi_fast = PASS == 2 && fmode == 0 && ptype != 0;
         if (PASS == 2) {
 #pragma unroll
-            for (int h = 0; h + 1 < NB; ++h) inorm[h] = rcp_nr((item_ok && ptype != 0) ? fmaxf(sqrtf(sq_cur[h]), eps) : 1.f);
+            for (int h = 0; h + 1 < NB; ++h) {
+                inorm[h] = rcp_nr((item_ok && ptype != 0) ? fmaxf(sqrtf(sq_cur[h]), eps) : 1.f);
+                if (rubi_fast) inorm[h] *= -1.44269502162933349609375f;      // rubi_fast_ takes z_h * -log2(e)
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int urow = wave * TU + 4 * kq + r;
-            const float ui = sig_<FAST>(acc[0][r]);
             if (PASS == 1) {
+                const float ui = sig_abs_<FAST>(acc[0][r]);
                 psum[r] += row16_sum((item_ok && b0 + urow < a.B) ? ui : 0.f);     // over the 16 items of the tile
                 continue;
             }
             float out;
             if (ptype == 0) {
-                out = sig_<FAST>(ui);
+                out = sig_small_<FAST>(sig_abs_<FAST>(acc[0][r]));
+            } else if (rubi_fast) {
+                float zs[kMaxS];
+#pragma unroll
+                for (int h = 0; h < kMaxS; ++h)
+                    zs[h] = (h + 1 < NB) ? acc[(h + 1 < NH) ? h + 1 : 0][r] * (unorm[urow * (NB - 1) + (h + 1 < NB ? h : 0)] * inorm[h + 1 < NB ? h : 0]) : 0.f;
+                out = rubi_fast_(acc[0][r], zs, NB - 1, a.head_mask, ptype == 2, umean[urow]);
             } else {
+                const float ui = sig_abs_<FAST>(acc[0][r]);
                 float z[kMaxS];
 #pragma unroll
                 for (int h = 0; h < kMaxS; ++h) {
@@ -805,11 +884,11 @@ __global__ __launch_bounds__(512, 2) void score_t16b_kernel(ScoreArgs a, int n_t
                     const float dp = acc[(h + 1 < NH) ? h + 1 : 0][r];
                     z[h] = (h + 1 < NB) ? dp * nn : 0.f;
                 }
-                if (ptype == 1) out = sig_<FAST>(fuse_t<FAST>(fmode, ui, z, NB - 1, a.head_mask));
+                if (ptype == 1) out = sig_out_<FAST>(fmode, fuse_t<FAST>(fmode, ui, z, NB - 1, a.head_mask));
                 else {
                     float te, nde;
                     fuse2_t<FAST>(fmode, ui, umean[urow], z, NB - 1, a.head_mask, te, nde);
-                    out = sig_<FAST>(te - nde);
+                    out = sig_out_<FAST>(fmode, te - nde);
                 }
             }
             const bool row_ok = b0 + urow < a.B;
