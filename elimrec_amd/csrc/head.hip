@@ -54,6 +54,9 @@ struct HeadFwdArgs {
     float *YAct; int64_t ld_y;
     int a_off[HMAXM];                               // LDS offsets (floats) of the S_m row tiles
     int out_off, part_off;
+    int stage;                                      // head_fwd16_kernel: 0 = whole head; 1 = the feature blocks only, WITHOUT the
+                                                    // shared part (needs nothing of the graph: can run beside the forward hops);
+                                                    // 2 = the rest (shared part added to what stage 1 left in OutAct, fusion, heads)
 };
 
 // acc += A[32 x (2*nsteps)] . B for MFMA steps [s0, s0 + nsteps): A from LDS (row stride folded into ap together with this
@@ -297,6 +300,7 @@ __global__ __launch_bounds__(256) void head_fwd16_kernel(HeadFwdArgs a) {
         s_c[tid] = tid < nrows ? a.c[node] : 0.f;
     }
     // out0 -> block 0 of the Out tile, narrow -> AN (compact rows: no index needed)
+    if (a.stage != 1)
     for (int e = tid; e < H16 * (HD / 4); e += 256) {
         const int r = e / (HD / 4), c4 = e % (HD / 4);
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
@@ -310,6 +314,21 @@ __global__ __launch_bounds__(256) void head_fwd16_kernel(HeadFwdArgs a) {
             *reinterpret_cast<float4 *>(a.OutAct + (int64_t)(r0 + r) * a.ld_out + 4 * c4) = x;
     }
     __syncthreads();                                   // s_act
+    if (a.stage == 2) {
+        // the feature blocks stage 1 left in OutAct (acc + c * b_m), + the shared part: the sum stage 0 forms in one expression
+        const int per_row = a.n_mod * (HD / 4);
+        for (int e = tid; e < H16 * per_row; e += 256) {
+            const int r = e / per_row, q = e % per_row, m = q / (HD / 4), c4 = q % (HD / 4);
+            float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+            float *dst = a.OutAct + (int64_t)(r0 + r) * a.ld_out + (m + 1) * HD + 4 * c4;
+            if (r < nrows) pv = *reinterpret_cast<const float4 *>(dst);
+            const float4 an = *reinterpret_cast<const float4 *>(AN + r * LDN + 4 * c4);
+            const float4 v = make_float4(pv.x + an.x, pv.y + an.y, pv.z + an.z, pv.w + an.w);
+            *reinterpret_cast<float4 *>(OutT + r * LDO + (m + 1) * HD + 4 * c4) = v;
+            if (r < nrows) *reinterpret_cast<float4 *>(dst) = v;
+        }
+    }
+    if (a.stage != 2)
     for (int m = 0; m < a.n_mod; ++m) {
         const int D4 = a.D[m] / 4, lda = a.D[m] + 4;
         float *Am = lds + a.a_off[m];
@@ -324,6 +343,7 @@ __global__ __launch_bounds__(256) void head_fwd16_kernel(HeadFwdArgs a) {
     const int ai = lane & 15, kq = lane >> 4;
     const int col = wave * 16 + ai;                    // this lane's output column inside a 64-column block
     // ---- stage 1: feature blocks
+    if (a.stage != 2) {
 #pragma unroll
     for (int m = 0; m < HMAXM; ++m) {
         if (m < a.n_mod) {
@@ -335,12 +355,19 @@ __global__ __launch_bounds__(256) void head_fwd16_kernel(HeadFwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 4 * kq + r;
-                const float v = acc[r] + s_c[row] * bm + AN[row * LDN + col];
+                const float part = acc[r] + s_c[row] * bm;
+                if (a.stage == 1) {
+                    if (row < nrows) a.OutAct[(int64_t)(r0 + row) * a.ld_out + (m + 1) * HD + col] = part;
+                    continue;
+                }
+                const float v = part + AN[row * LDN + col];
                 OutT[row * LDO + (m + 1) * HD + col] = v;
                 if (row < nrows) a.OutAct[(int64_t)(r0 + row) * a.ld_out + (m + 1) * HD + col] = v;
             }
         }
     }
+    }
+    if (a.stage == 1) return;
     __syncthreads();
     // ---- stage 2: fused Linear over the whole Out tile (K = C) and the single-modal heads (K = 64)
     {
@@ -397,7 +424,7 @@ extern "C" int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg
     const int C = (1 + n_mod) * HD;
     ELIMREC_REQUIRE(ld_out0 % 4 == 0 && ld_nar % 4 == 0 && ld_out >= C && ld_y >= C, "head_fwd_fused: bad leading dimensions");
     ELIMREC_REQUIRE(pack_floats >= elimrec_head_pack_floats(n_mod, D), "head_fwd_fused: packed-weight buffer too small");
-    ELIMREC_REQUIRE(phase >= 0 && phase <= 2, "head_fwd_fused: phase 0 (pack + head), 1 (pack only) or 2 (head only)");
+    ELIMREC_REQUIRE(phase >= 0 && phase <= 4, "head_fwd_fused: phase 0 (pack + head), 1 (pack only), 2 (head only), 3 / 4 (head in two launches)");
     if (R <= 0) return 0;
     HeadFwdArgs a = {};
     PackJobs pj = {};
@@ -444,7 +471,9 @@ extern "C" int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg
     a.n_mod = n_mod; a.pk = d_pack; a.bias_f[0] = d_bf_user; a.bias_f[1] = d_bf_item;
     a.OutAct = d_OutAct; a.ld_out = ld_out; a.YAct = d_YAct; a.ld_y = ld_y;
     hipStream_t s = (hipStream_t)stream;
-    if (phase != 2) {
+    if (phase >= 3 && !form16) { set_error("head_fwd_fused: phases 3 / 4 need the 16-row form"); return ELIMREC_E_UNSUPPORTED; }
+    a.stage = phase == 3 ? 1 : (phase == 4 ? 2 : 0);
+    if (phase < 2) {
         if (form16) hipLaunchKernelGGL(pack_head_weights16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pj, d_pack);
         else hipLaunchKernelGGL(pack_head_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pj, d_pack);
         ELIMREC_LAUNCH_CHECK("pack_head_weights");

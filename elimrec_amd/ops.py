@@ -741,7 +741,8 @@ def head_pack_bwd_offset(dims):
 
 def head_fwd_fused(act, seg_info, out0, narrow, c, S, Wm, bm, Wf_user, bf_user, Wf_item, bf_item, Ws, bs, pack, OutAct, YAct, d, phase=0):
     """elimrec_head_fwd_fused: S / Wm / bm / Ws / bs are lists over the feature tables. phase 0: pack the weights and
-    run the head; 1: pack only; 2: head only (pack holds the packed weights). Returns False when the shape is outside the
+    run the head; 1: pack only; 2: head only (pack holds the packed weights); 3 / 4: the head in two launches (the feature
+    blocks without the shared part -- no out0 / narrow needed --, then the rest). Returns False when the shape is outside the
     fused kernel's range (the caller keeps the batched GEMMs)."""
     n = len(S)
     R = act.numel()

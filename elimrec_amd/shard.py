@@ -575,6 +575,8 @@ class ColumnShardEngine(object):
         self._out0_src = self._nar_src = None
         self._pairs = {}
         self._head16 = os.environ.get("ELIMREC_HEAD_ROWS", "16") != "32"
+        self._split_head = os.environ.get("ELIMREC_HEAD_SPLIT", "1") != "0"     # feature blocks of the head beside the forward hops
+        self._head_split = False
         self.send_b = None
         self._loss_ring, self._loss_at = None, 0
         self._bits_ready = False
@@ -795,6 +797,7 @@ class ColumnShardEngine(object):
         err = m._index_err()
 
         aux = self._aux_stream()
+        self._head_split = False
         early_bits = aux is not None and self.planT.tiered and not self.bf16 and not self.multi      # (several ranks: cs_gathered_ids)
         if aux is not None and self._forked and getattr(self, "_ws_gen_planned", None) != m._ws_gen:
             # another batch size's buffer set (possibly allocated -- and zero-filled ON THE MAIN STREAM -- a moment ago, after
@@ -810,6 +813,9 @@ class ColumnShardEngine(object):
 
         def pack():       # the head's weights in MFMA fragment order (they changed in the last optimizer step)
             self._head_fused_call(ws, R, phase=1)
+
+        def features():   # ... and the head's feature blocks (constants' rows x projections: nothing of the graph) beside the hops
+            self._head_fused_call(ws, R, phase=3)
         self._bits_ready = early_bits
         if aux is None:
             m._region("cs_plan", (m._ws_gen, users.data_ptr(), pos.data_ptr(), neg.data_ptr(), R), plan)
@@ -821,6 +827,9 @@ class ColumnShardEngine(object):
             m._region("cs_plan", (m._ws_gen, users.data_ptr(), pos.data_ptr(), neg.data_ptr(), R), plan)
             if self._fused_head_ok():
                 m._region("cs_pack", (m._ws_gen, R), pack)
+                self._head_split = self._head16 and not self.lookup and self._split_head
+                if self._head_split:
+                    m._region("cs_head_features", (m._ws_gen, R), features)
         self._aux_pending = True
         return act
 
@@ -997,9 +1006,11 @@ class ColumnShardEngine(object):
 
         packed = self._aux is not None and self._aux is not False      # cs_plan packed the weights on the second stream
 
+        split = packed and getattr(self, "_head_split", False)     # cs_plan ran the feature blocks on the second stream
+
         def head():
-            self._head_fused_call(ws, R, phase=2 if packed else 0)
-        m._region("cs_head_fused", (m._ws_gen, R, B, packed, self.nar_act.data_ptr(),
+            self._head_fused_call(ws, R, phase=4 if split else (2 if packed else 0))
+        m._region("cs_head_fused", (m._ws_gen, R, B, packed, split, self.nar_act.data_ptr(),
                                     0 if self._out0_src is None else self._out0_src.data_ptr()), head)
         # the cosine-BPR rows and the batch loss in one launch (the workgroup that finishes last adds the loss rows in
         # elimrec_sum's order). Issued directly: the loss goes to the next slot of a ring, so that a caller holding the

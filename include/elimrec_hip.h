@@ -705,6 +705,10 @@ int elimrec_adam_step_out(const float *d_p_in, float *d_p_out, const float *d_g,
  * d_YAct [R x ld_y] all 1 + n_mod blocks. d_pack: scratch of elimrec_head_pack_floats floats.
  * phase: 0 = pack the weights, then the head; 1 = pack only (the weights change once per optimizer step: a caller can
  * issue this on a second stream under the forward hops); 2 = head only, d_pack holds the packed weights.
+ * The head in two launches (16-row form, packed weights in place): 3 = the feature blocks without the shared part,
+ * acc + c * b_m into blocks 1.. of d_OutAct -- needs the active rows and the constants only, not d_out0 / d_narrow, so it
+ * can run beside the forward hops; 4 = the rest (the shared part added to what phase 3 left, block 0, the fusion and the
+ * single-modal heads). 3 then 4 leave the bits of phase 2.
  * recdim must be 64 and the row tiles must fit LDS, else ELIMREC_E_UNSUPPORTED (callers keep the batched GEMMs). */
 size_t elimrec_head_pack_floats(int n_mod, const int *D);
 size_t elimrec_head_pack_bwd_offset(int n_mod, const int *D);   /* first float of the head BACKWARD's operands */
