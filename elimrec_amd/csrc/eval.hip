@@ -637,7 +637,7 @@ __global__ __launch_bounds__(512, (D > 64 ? 2 : 4)) void score_t16_kernel(ScoreA
                 for (int r = 0; r < 4; ++r) {
                     const int b = b0 + wave * TU + 4 * kq + r;
                     const float v = (item_ok && b < a.B) ? sig_abs_<FAST>(acc[0][r]) : 0.f;
-                    psum[r] += row16_sum(v);          // over the 16 items of the tile
+                    psum[r] += v;                     // this lane's item of every tile; the 16 lanes are added once, at the end
                 }
             } else {
                 float inorm[NB > 1 ? NB - 1 : 1];
@@ -690,11 +690,12 @@ __global__ __launch_bounds__(512, (D > 64 ? 2 : 4)) void score_t16_kernel(ScoreA
         for (int q = 0; q < NQ; ++q) sq_cur[q] = sq_nxt[q];
         __syncthreads();
     }
-    if (PASS == 1 && li == 0) {                       // one partial per (workgroup, user): row_mean_kernel adds them in order
+    if (PASS == 1) {                                  // one partial per (workgroup, user): row_mean_kernel adds them in order
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int b = b0 + wave * TU + 4 * kq + r;
-            if (b < a.B) a.partial[(int64_t)blockIdx.x * a.B + b] = psum[r];
+            const float tot = row16_sum(psum[r]);     // the 16 item lanes of this user, fixed order
+            if (li == 0 && b < a.B) a.partial[(int64_t)blockIdx.x * a.B + b] = tot;
         }
     }
 }
@@ -863,7 +864,7 @@ __global__ __launch_bounds__(512, 2) void score_t16b_kernel(ScoreArgs a, int n_t
             const int urow = wave * TU + 4 * kq + r;
             if (PASS == 1) {
                 const float ui = sig_abs_<FAST>(acc[0][r]);
-                psum[r] += row16_sum((item_ok && b0 + urow < a.B) ? ui : 0.f);     // over the 16 items of the tile
+                psum[r] += (item_ok && b0 + urow < a.B) ? ui : 0.f;      // this lane's item of every tile; the 16 lanes are added at the end
                 continue;
             }
             float out;
@@ -903,11 +904,12 @@ __global__ __launch_bounds__(512, 2) void score_t16b_kernel(ScoreArgs a, int n_t
         for (int q = 0; q < NQ; ++q) sq_cur[q] = sq_nxt[q];
         __syncthreads();
     }
-    if (PASS == 1 && li == 0) {                       // one partial per (workgroup, user): row_mean_kernel adds them in order
+    if (PASS == 1) {                                  // one partial per (workgroup, user): row_mean_kernel adds them in order
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int b = b0 + wave * TU + 4 * kq + r;
-            if (b < a.B) a.partial[(int64_t)blockIdx.x * a.B + b] = psum[r];
+            const float tot = row16_sum(psum[r]);     // the 16 item lanes of this user, fixed order
+            if (li == 0 && b < a.B) a.partial[(int64_t)blockIdx.x * a.B + b] = tot;
         }
     }
 }
