@@ -160,7 +160,7 @@ __device__ __forceinline__ float rubi_fast_(float a, const float *zs, int S, uin
     float den = q;
 #pragma unroll
     for (int h = 0; h < 4; ++h)
-        if (h < S && (mask & (1u << h))) den *= 1.f + __builtin_amdgcn_exp2f(zs[h]);
+        if (h < S) den *= (mask & (1u << h)) ? 1.f + __builtin_amdgcn_exp2f(zs[h]) : 1.f;      // (a select, not a branch)
     const float p = rcp_nr(den);
     return sig_small_<true>(tie ? fmaf(-m, q, 1.f) * p : p);
 }
@@ -180,6 +180,7 @@ struct ScoreArgs {
     int64_t item0, item_end;         // score_t16_kernel: the launch covers items [item0, item_end); scores / tile_max are
                                      // indexed relative to item0 (a chunk of the catalogue when only top-K is wanted)
     const uint4 *planes;             // score_t16b_kernel: the chunk's item rows as three bf16 planes, [item - item0][3][COLS]
+    const float *inrm;               // score_t16b_kernel pass 2: 1 / max(|row's head block|, eps) of the chunk's items, [item - item0][S]
 };
 
 __device__ __forceinline__ float fuse(int mode, float x, const float *z, int S, uint32_t mask) {
@@ -733,13 +734,17 @@ __device__ __forceinline__ void split3x8(const float4 &lo, const float4 &hi, uin
 }
 
 // planes[(item - item0)][p][c] (bf16) <- piece p of Y[U + item][c], c < cols (a multiple of 8): a thread per 8 columns
+// inrm (pass 2, nullable): the items' inverse head-block norms, once per chunk instead of once per (user group, tile) -- the
+// expression the scorers evaluate: rcp_nr(max(sqrtf(sqn), eps)); nb = 1 + heads, sqn [N x nb]
 __global__ __launch_bounds__(256) void split3_items_kernel(const float *__restrict__ Y, int64_t ldy, int64_t U, int64_t item0,
-                                                           int64_t n_items, int cols, uint4 *__restrict__ planes) {
+                                                           int64_t n_items, int cols, uint4 *__restrict__ planes,
+                                                           const float *__restrict__ sqn, int nb, float *__restrict__ inrm) {
     const int c8 = cols / 8;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= n_items * c8) return;
     const int64_t it = t / c8;
     const int c = (int)(t % c8);
+    if (inrm && c + 1 < nb) inrm[it * (nb - 1) + c] = rcp_nr(fmaxf(sqrtf(sqn[(U + item0 + it) * nb + 1 + c]), 1e-12f));
     const float4 *src = reinterpret_cast<const float4 *>(Y + (U + item0 + it) * ldy + 8 * c);
     uint4 q1, q2, q3;
     split3x8(src[0], src[1], q1, q2, q3);
@@ -747,8 +752,12 @@ __global__ __launch_bounds__(256) void split3_items_kernel(const float *__restri
     dst[0] = q1; dst[c8] = q2; dst[2 * c8] = q3;
 }
 
+// (Measured: four waves / 64 users per workgroup and two workgroups per CU -- so that the per-tile barrier ties four waves
+// together and the CU's two workgroups drift apart -- 0.0169 s per validation pass against 0.0157 s: the item tile is then
+// staged twice per CU.)
+constexpr int TWB = 8, NTB = 64 * TWB;
 template <int PASS, int NB, int PT, int FM, int D>
-__global__ __launch_bounds__(512, 2) void score_t16b_kernel(ScoreArgs a, int n_tiles) {
+__global__ __launch_bounds__(NTB, 2) void score_t16b_kernel(ScoreArgs a, int n_tiles) {
     constexpr bool FAST = true;
     constexpr int NH = (PASS == 1) ? 1 : NB, COLS = NH * D;
     constexpr int ROW4 = 3 * COLS / 8 + 1;            // LDS row of an item in uint4 units: three planes + 16 B of padding
@@ -756,10 +765,10 @@ __global__ __launch_bounds__(512, 2) void score_t16b_kernel(ScoreArgs a, int n_t
     extern __shared__ float smem[];
     uint4 *it0 = reinterpret_cast<uint4 *>(smem), *it1 = it0 + TI * ROW4;
     float *unorm = reinterpret_cast<float *>(it1 + TI * ROW4);     // [128][NB-1]
-    float *umean = unorm + TW * TU * (NB > 1 ? NB - 1 : 1);
+    float *umean = unorm + TWB * TU * (NB > 1 ? NB - 1 : 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
-    const int b0 = blockIdx.y * (TW * TU);
+    const int b0 = blockIdx.y * (TWB * TU);
     const float eps = 1e-12f;
     const int ptype = PT >= 0 ? PT : a.predict_type, fmode = FM >= 0 ? FM : a.fusion_mode;
     // A operands: user (wave*16 + li), pieces of elements k = 32 j + 8 kq .. + 8 of head block h
@@ -779,7 +788,7 @@ __global__ __launch_bounds__(512, 2) void score_t16b_kernel(ScoreArgs a, int n_t
                 split3x8(lo, hi, ua[0][h][j], ua[1][h][j], ua[2][h][j]);
             }
     }
-    if (PASS == 2 && tid < TW * TU) {
+    if (PASS == 2 && tid < TWB * TU) {
         const int b = b0 + tid;
         const int64_t un = b < a.B ? a.users[b] : -1;
         for (int h = 0; h + 1 < NB; ++h) {
@@ -789,14 +798,14 @@ __global__ __launch_bounds__(512, 2) void score_t16b_kernel(ScoreArgs a, int n_t
         umean[tid] = (b < a.B && ptype == 2) ? a.row_mean[b] : 0.f;
     }
     float psum[4] = {0.f, 0.f, 0.f, 0.f};             // PASS 1: this wave's users' running sums of ui, tiles in ascending order
-    // a tile's rows (16 items x three planes) as uint4 over the 512 threads
+    // a tile's rows (16 items x three planes) as uint4 over the workgroup's threads
     constexpr int TILE4 = TI * 3 * COLS / 8;
-    constexpr int PFN = (TILE4 + 511) / 512;
+    constexpr int PFN = (TILE4 + NTB - 1) / NTB;
     uint4 pf[PFN];
     auto load_tile = [&](int tile) {
 #pragma unroll
         for (int q = 0; q < PFN; ++q) {
-            const int e = tid + 512 * q;
+            const int e = tid + NTB * q;
             if (e < TILE4) {
                 const int64_t it = (int64_t)tile * TI + e / (3 * COLS / 8);
                 pf[q] = (a.item0 + it < a.item_end) ? a.planes[it * (3 * COLS / 8) + e % (3 * COLS / 8)] : make_uint4(0u, 0u, 0u, 0u);
@@ -806,17 +815,17 @@ __global__ __launch_bounds__(512, 2) void score_t16b_kernel(ScoreArgs a, int n_t
     auto store_tile = [&](uint4 *buf) {
 #pragma unroll
         for (int q = 0; q < PFN; ++q) {
-            const int e = tid + 512 * q;
+            const int e = tid + NTB * q;
             if (e < TILE4) buf[(e / (3 * COLS / 8)) * ROW4 + e % (3 * COLS / 8)] = pf[q];
         }
     };
     constexpr int NQ = (PASS == 2 && NB > 1) ? NB - 1 : 1;
     float sq_cur[NQ], sq_nxt[NQ];
-    auto load_sqn = [&](int tile, float (&dst)[NQ]) {
+    auto load_sqn = [&](int tile, float (&dst)[NQ]) {       // (the INVERSE norms of the tile's items: split3_items_kernel made them)
         if (PASS != 2 || NB <= 1) return;
-        const int64_t item = a.item0 + (int64_t)tile * TI + li;
+        const int64_t it = (int64_t)tile * TI + li;
 #pragma unroll
-        for (int h = 0; h + 1 < NB; ++h) dst[h] = (item < a.item_end && ptype != 0) ? a.sqn[(a.U + item) * NB + 1 + h] : 1.f;
+        for (int h = 0; h + 1 < NB; ++h) dst[h] = (a.item0 + it < a.item_end && ptype != 0) ? a.inrm[it * (NB - 1) + h] : 1.f;
     };
     if ((int)blockIdx.x < n_tiles) { load_tile(blockIdx.x); load_sqn(blockIdx.x, sq_cur); store_tile(it0); }
     __syncthreads();
@@ -855,10 +864,13 @@ __global__ __launch_bounds__(512, 2) void score_t16b_kernel(ScoreArgs a, int n_t
         if (PASS == 2) {
 #pragma unroll
             for (int h = 0; h + 1 < NB; ++h) {
-                inorm[h] = rcp_nr((item_ok && ptype != 0) ? fmaxf(sqrtf(sq_cur[h]), eps) : 1.f);
+                inorm[h] = sq_cur[h];                          // rcp_nr(max(sqrtf(sqn), eps)), or 1 beyond the chunk / for type normal
                 if (rubi_fast) inorm[h] *= -1.44269502162933349609375f;      // rubi_fast_ takes z_h * -log2(e)
             }
         }
+        // all four users' scores first -- four independent chains of transcendentals in ONE basic block, so that the scheduler can
+        // interleave them (a predicated store after each would end the block) -- then the stores and the tile maxima
+        float outs[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int urow = wave * TU + 4 * kq + r;
@@ -892,11 +904,23 @@ __global__ __launch_bounds__(512, 2) void score_t16b_kernel(ScoreArgs a, int n_t
                     out = sig_out_<FAST>(fmode, te - nde);
                 }
             }
-            const bool row_ok = b0 + urow < a.B;
-            if (item_ok && row_ok) a.scores[(int64_t)(b0 + urow) * a.lds + (item - a.item0)] = out;
-            if (a.tile_max) {
-                const float mx = row16_max(item_ok ? out : -INFINITY);
-                if (li == 0 && row_ok) a.tile_max[(int64_t)(b0 + urow) * a.tmax_ld + tile] = mx;
+            outs[r] = out;
+        }
+        if (PASS == 2) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int urow = wave * TU + 4 * kq + r;
+                const float out = outs[r];
+                const bool row_ok = b0 + urow < a.B;
+                // unpredicated stores (lanes beyond the chunk / the user block write a.partial[0], which nothing reads in pass 2):
+                // a predicated store is a branch, and a branch per user ends the basic block the four chains are scheduled in
+                float *dst = (item_ok && row_ok) ? a.scores + (int64_t)(b0 + urow) * a.lds + (item - a.item0) : a.partial;
+                *dst = out;
+                if (a.tile_max) {
+                    const float mx = row16_max(item_ok ? out : -INFINITY);
+                    float *dmx = (li == 0 && row_ok) ? a.tile_max + (int64_t)(b0 + urow) * a.tmax_ld + tile : a.partial;
+                    *dmx = mx;
+                }
             }
         }
         if (next < n_tiles) store_tile(cur ? it0 : it1);
@@ -1347,7 +1371,7 @@ static ScoreLayout score_layout(int B, int64_t U, int64_t I, int S, int K, bool 
     L.cand_val = take(b * (size_t)nch * (size_t)(K > 0 ? K : 1) * sizeof(float));
     L.cand_idx = take(b * (size_t)nch * (size_t)(K > 0 ? K : 1) * sizeof(int32_t));
     L.planes = off;
-    if (topk_only && (d == 32 || d == 64)) take((size_t)cols * 3 * (size_t)(1 + S) * (size_t)d * 2);
+    if (topk_only && (d == 32 || d == 64)) take((size_t)cols * 3 * (size_t)(1 + S) * (size_t)d * 2 + (size_t)cols * (size_t)(S > 0 ? S : 1) * 4);
     L.total = off;
     return L;
 }
@@ -1459,7 +1483,7 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
     a.Y = d_Y; a.ldy = ldy; a.U = U; a.I = I; a.users = d_users; a.B = B; a.d = d; a.S = S; a.head_mask = head_mask;
     a.fusion_mode = fusion_mode; a.predict_type = predict_type; a.row_mean = mean; a.partial = partial;
     a.scores = d_scores ? d_scores : wscores; a.lds = d_scores ? lds : (chunked ? SCORE_CHUNK : I);
-    a.item0 = 0; a.item_end = I; a.planes = nullptr;
+    a.item0 = 0; a.item_end = I; a.planes = nullptr; a.inrm = nullptr;
     float *wsqn = (float *)(ws + L.sqn);
     if (!d_sqnorm && predict_type != 0) {            // not supplied: compute the whole table for this call
         const int64_t N = U + I;
@@ -1560,10 +1584,10 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
         };
         auto b3_lds = [d](int pass, int nb) {
             const int nh = pass == 1 ? 1 : nb;
-            return ((size_t)2 * TI * (3 * nh * d / 8 + 1) * 16 + ((size_t)TW * TU * (nb > 1 ? nb - 1 : 1) + TW * TU) * sizeof(float));
+            return ((size_t)2 * TI * (3 * nh * d / 8 + 1) * 16 + ((size_t)TWB * TU * (nb > 1 ? nb - 1 : 1) + TWB * TU) * sizeof(float));
         };
 #define ELIMREC_T16B_LAUNCH1(NB, GRID, DD)                                                                   \
-    hipLaunchKernelGGL((score_t16b_kernel<1, NB, -1, -1, DD>), GRID, dim3(512), b3_lds(1, NB), s, a, t16)
+    hipLaunchKernelGGL((score_t16b_kernel<1, NB, -1, -1, DD>), GRID, dim3(NTB), b3_lds(1, NB), s, a, t16)
 #define ELIMREC_T16B_LAUNCH(NB, PT, FM, GRID, DD)                                                            \
     do {                                                                                                   \
         static bool attr = false;                                                                          \
@@ -1572,7 +1596,7 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)b3_lds(2, NB));     \
             attr = true;                                                                                   \
         }                                                                                                  \
-        hipLaunchKernelGGL((score_t16b_kernel<2, NB, PT, FM, DD>), GRID, dim3(512), b3_lds(2, NB), s, a, t16); \
+        hipLaunchKernelGGL((score_t16b_kernel<2, NB, PT, FM, DD>), GRID, dim3(NTB), b3_lds(2, NB), s, a, t16); \
     } while (0)
 #define ELIMREC_T16B_D(NB, PT, FM, GRID)                                                                     \
     do {                                                                                                   \
@@ -1610,7 +1634,7 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
                 // pass 1 (row means of sigmoid(u.i)) on the bf16 matrix cores too: chunk by chunk (the fused block's pieces only),
                 // <= 64 workgroups per user group and chunk, partials in (chunk, workgroup) order
                 uint4 *planes = (uint4 *)(ws + Lp.planes);
-                const int ug = (B + TW * TU - 1) / (TW * TU);
+                const int ug = (B + TWB * TU - 1) / (TWB * TU);
                 int n_part = 0;
                 for (int c = 0; c < nch; ++c) {
                     ScoreArgs ac = a;
@@ -1619,7 +1643,7 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
                     const int64_t cnt = ac.item_end - ac.item0;
                     const int tc = (int)((cnt + TI - 1) / TI);
                     hipLaunchKernelGGL(split3_items_kernel, dim3((unsigned)((cnt * (d / 8) + 255) / 256)), dim3(256), 0, s, d_Y, ldy, U,
-                                       ac.item0, cnt, d, planes);
+                                       ac.item0, cnt, d, planes, (const float *)nullptr, 0, (float *)nullptr);
                     ELIMREC_LAUNCH_CHECK("split3_items(pass 1)");
                     int gx = tc < 64 ? tc : 64;
                     ac.planes = planes;
@@ -1638,7 +1662,8 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
                 const int64_t cnt = ac.item_end - ac.item0;
                 const int tc = (int)((cnt + TI - 1) / TI);
                 // ~512 workgroups per launch in all: a workgroup walks several tiles with its users' operands resident
-                const int ug = (B + TW * TU - 1) / (TW * TU);
+                const int wu = (bf16x3 ? TWB : TW) * TU;               // users per workgroup
+                const int ug = (B + wu - 1) / wu;
                 int gx = 512 / ug > 0 ? 512 / ug : 1;
                 if (gx > tc) gx = tc;
                 const int per = (tc + gx - 1) / gx;
@@ -1646,10 +1671,14 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
                 if (bf16x3) {
                     const int cols = (1 + S) * d;
                     uint4 *planes = (uint4 *)(ws + Lp.planes);
+                    // (the chunk's inverse item norms behind its planes; predict type normal has no heads to normalise)
+                    float *inrm = (float *)(ws + Lp.planes + (size_t)(chunked && I > SCORE_CHUNK ? SCORE_CHUNK : I) * 3 * (size_t)cols * 2);
                     hipLaunchKernelGGL(split3_items_kernel, dim3((unsigned)((cnt * (cols / 8) + 255) / 256)), dim3(256), 0, s, d_Y, ldy, U,
-                                       ac.item0, cnt, cols, planes);
+                                       ac.item0, cnt, cols, planes, predict_type != 0 ? a.sqn : (const float *)nullptr, 1 + S,
+                                       predict_type != 0 ? inrm : (float *)nullptr);
                     ELIMREC_LAUNCH_CHECK("split3_items");
                     ac.planes = planes;
+                    ac.inrm = inrm;
                     rc = pass2_b3(ac, tc, dim3((unsigned)((tc + per - 1) / per), ug));
                 } else {
                     rc = pass2(ac, tc, dim3((unsigned)((tc + per - 1) / per), ug));

@@ -1209,7 +1209,7 @@ def test_topk_only_workspace_fits_any_recdim_and_k(d, K):
     need = ops.score_workspace(B, U, I, S, K, topk_only=True, d=d)
     chunked_bytes = ops.score_workspace(B, U, I, S, K, topk_only=True)
     if d in (32, 64, 128) and K <= 256:      # the chunked layout (+ one chunk's bf16 pieces for the recdim 32 / 64 scorer)
-        assert chunked_bytes <= need <= chunked_bytes + 16384 * 3 * (1 + S) * d * 2 + 512
+        assert chunked_bytes <= need <= chunked_bytes + 16384 * 3 * (1 + S) * d * 2 + 16384 * S * 4 + 512     # (+ its inverse item norms)
     else:                                    # the whole-catalogue layout
         assert need == ops.score_workspace(B, U, I, S, K)
     ws = torch.empty(need, dtype=torch.uint8, device=DEV)
