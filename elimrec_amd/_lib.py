@@ -70,6 +70,13 @@ class AdamJob(ctypes.Structure):
 PROGRAM_MAX_ARGS = 32
 
 
+class HeadRows(ctypes.Structure):
+    """struct elimrec_head_rows."""
+    _fields_ = [("A", ctypes.POINTER(SellDesc)), ("ns", ctypes.c_int32), ("w", ctypes.c_int32), ("L", ctypes.c_int32),
+                ("U", ctypes.c_int64), ("layers", ctypes.c_void_p * 9), ("d_long", ctypes.c_void_p),
+                ("d_narrow_out", ctypes.c_void_p), ("ld_narrow_out", ctypes.c_int64)]
+
+
 class ProgramOp(ctypes.Structure):
     """struct elimrec_op."""
     _fields_ = [("kind", ctypes.c_int32), ("fn", ctypes.c_int32), ("args", ctypes.c_uint64 * PROGRAM_MAX_ARGS)]
@@ -201,6 +208,10 @@ SIGNATURES = {
                                        ctypes.POINTER(c_i64), ctypes.POINTER(c_i32), ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr),
                                        c_ptr, c_ptr, c_ptr, c_ptr, ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr), c_ptr, c_size,
                                        c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32, c_ptr]),
+    "elimrec_head_fwd_fused_rows": (c_i32, [ctypes.POINTER(HeadRows), c_ptr, c_ptr, c_i64, c_ptr, c_i32, ctypes.POINTER(c_ptr),
+                                            ctypes.POINTER(c_i64), ctypes.POINTER(c_i32), ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr),
+                                            c_ptr, c_ptr, c_ptr, c_ptr, ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr), c_ptr, c_size,
+                                            c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr]),
     "elimrec_score_set_math": (None, [c_i32]),
     "elimrec_score_get_math": (c_i32, []),
     "elimrec_score_set_bf16x3": (None, [c_i32]),

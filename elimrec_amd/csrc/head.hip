@@ -11,6 +11,7 @@
 // Specialised for recdim = 64 (two 32-column MFMA tiles) and feature widths that fit LDS; other shapes keep the
 // batched-GEMM path.
 #include "common.h"
+#include "rows_args.h"
 #include <cstdlib>
 
 namespace elimrec {
@@ -275,7 +276,10 @@ __device__ __forceinline__ v4h head16_run(v4h acc, const float *ap, const float 
     return acc;
 }
 
-__global__ __launch_bounds__(256) void head_fwd16_kernel(HeadFwdArgs a) {
+// ROWS: stage 2 with out0 / narrow EVALUATED here (rows_piece: the layer means of the tile's 16 rows, hop L inline) instead of
+// read back from a rows launch -- thread (row tid / 16, float4 column tid % 16), the mapping of slab_rows_kernel<16>; recdim 64.
+template <bool ROWS>
+__device__ __forceinline__ void head_fwd16_body(const HeadFwdArgs &a, const RowsArgs *ra) {
     extern __shared__ float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n_act = a.seg_info[0], n_lo = a.seg_info[1];
@@ -304,13 +308,18 @@ __global__ __launch_bounds__(256) void head_fwd16_kernel(HeadFwdArgs a) {
     for (int e = tid; e < H16 * (HD / 4); e += 256) {
         const int r = e / (HD / 4), c4 = e % (HD / 4);
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
-        if (r < nrows) {
+        if (ROWS) {
+            if (r < nrows) {
+                rows_piece(*ra, (int64_t)a.act[r0 + r], c4, x, y);
+                *reinterpret_cast<float4 *>(ra->narrow + (int64_t)(r0 + r) * ra->ld_narrow + 4 * c4) = y;      // (kept, as the rows launch does)
+            }
+        } else if (r < nrows) {
             x = *reinterpret_cast<const float4 *>(a.out0 + (int64_t)(r0 + r) * a.ld_out0 + 4 * c4);
             y = *reinterpret_cast<const float4 *>(a.narrow + (int64_t)(r0 + r) * a.ld_nar + 4 * c4);
         }
         *reinterpret_cast<float4 *>(OutT + r * LDO + 4 * c4) = x;
         *reinterpret_cast<float4 *>(AN + r * LDN + 4 * c4) = y;
-        if (r < nrows && a.out0 != a.OutAct)             // out0 handed over separately: block 0 of OutAct is written here
+        if (r < nrows && (ROWS || a.out0 != a.OutAct))   // out0 handed over separately (or made here): block 0 of OutAct is written here
             *reinterpret_cast<float4 *>(a.OutAct + (int64_t)(r0 + r) * a.ld_out + 4 * c4) = x;
     }
     __syncthreads();                                   // s_act
@@ -397,6 +406,9 @@ __global__ __launch_bounds__(256) void head_fwd16_kernel(HeadFwdArgs a) {
     }
 }
 
+__global__ __launch_bounds__(256) void head_fwd16_kernel(HeadFwdArgs a) { head_fwd16_body<false>(a, nullptr); }
+__global__ __launch_bounds__(256) void head_rows_fwd16_kernel(HeadFwdArgs a, RowsArgs ra) { head_fwd16_body<true>(a, &ra); }
+
 }  // namespace elimrec
 
 using namespace elimrec;
@@ -411,7 +423,7 @@ extern "C" size_t elimrec_head_pack_bwd_offset(int n_mod, const int *D) {
     return (size_t)head_pack_layout(n_mod, D).fwd_total;
 }
 
-extern "C" int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg_info, int64_t R, const float *d_out0,
+static int head_fwd_fused_impl(const elimrec_head_rows *rows, const int32_t *d_act, const int32_t *d_seg_info, int64_t R, const float *d_out0,
                                       int64_t ld_out0, const float *d_narrow, int64_t ld_nar, const float *d_c, int n_mod,
                                       const float *const *d_S, const int64_t *ldS, const int *D, const float *const *d_Wm,
                                       const float *const *d_bm, const float *d_Wf_user, const float *d_bf_user,
@@ -487,10 +499,28 @@ extern "C" int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg
             lds_set16 = lds_bytes;
         }
         const unsigned tiles = (unsigned)((R + H16 - 1) / H16 + 2);     // user tiles + item tiles <= R/16 + 2
+        if (rows) {
+            RowsArgs ra = {};
+            int rc = rows_args_fill("head_fwd_fused_rows", rows->A, rows->ns, rows->w, rows->L, rows->U, rows->layers, rows->d_long, ra);
+            if (rc) return rc;
+            ELIMREC_REQUIRE(ra.nc4 == HD / 4 && rows->d_narrow_out && rows->ld_narrow_out % 4 == 0 && phase == 4,
+                            "head_fwd_fused_rows: %d table columns per row, a narrow buffer, phase 4", HD);
+            ra.narrow = rows->d_narrow_out; ra.ld_narrow = rows->ld_narrow_out;
+            static size_t lds_set16r = 0;
+            if (lds_bytes > 64 * 1024 && lds_bytes > lds_set16r) {
+                hipError_t e = hipFuncSetAttribute((const void *)head_rows_fwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                if (e != hipSuccess) return check_hip(e, "head_fwd_fused_rows: LDS size");
+                lds_set16r = lds_bytes;
+            }
+            hipLaunchKernelGGL(head_rows_fwd16_kernel, dim3(tiles), dim3(256), lds_bytes, s, a, ra);
+            ELIMREC_LAUNCH_CHECK("head_rows_fwd16");
+            return 0;
+        }
         hipLaunchKernelGGL(head_fwd16_kernel, dim3(tiles), dim3(256), lds_bytes, s, a);
         ELIMREC_LAUNCH_CHECK("head_fwd16");
         return 0;
     }
+    if (rows) { set_error("head_fwd_fused_rows: needs the 16-row form"); return ELIMREC_E_UNSUPPORTED; }
     static size_t lds_set = 0;
     if (lds_bytes > 64 * 1024 && lds_bytes > lds_set) {
         hipError_t e = hipFuncSetAttribute((const void *)head_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -501,4 +531,29 @@ extern "C" int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg
     hipLaunchKernelGGL(head_fwd_fused_kernel, dim3(tiles + 1), dim3(256), lds_bytes, s, a);
     ELIMREC_LAUNCH_CHECK("head_fwd_fused");
     return 0;
+}
+
+extern "C" int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg_info, int64_t R, const float *d_out0,
+                                      int64_t ld_out0, const float *d_narrow, int64_t ld_nar, const float *d_c, int n_mod,
+                                      const float *const *d_S, const int64_t *ldS, const int *D, const float *const *d_Wm,
+                                      const float *const *d_bm, const float *d_Wf_user, const float *d_bf_user,
+                                      const float *d_Wf_item, const float *d_bf_item, const float *const *d_Ws,
+                                      const float *const *d_bs, float *d_pack, size_t pack_floats, float *d_OutAct,
+                                      int64_t ld_out, float *d_YAct, int64_t ld_y, int recdim, int phase, void *stream) {
+    return head_fwd_fused_impl(nullptr, d_act, d_seg_info, R, d_out0, ld_out0, d_narrow, ld_nar, d_c, n_mod, d_S, ldS, D, d_Wm, d_bm,
+                               d_Wf_user, d_bf_user, d_Wf_item, d_bf_item, d_Ws, d_bs, d_pack, pack_floats, d_OutAct, ld_out, d_YAct,
+                               ld_y, recdim, phase, stream);
+}
+
+extern "C" int elimrec_head_fwd_fused_rows(const elimrec_head_rows *rows, const int32_t *d_act, const int32_t *d_seg_info, int64_t R,
+                                           const float *d_c, int n_mod, const float *const *d_S, const int64_t *ldS, const int *D,
+                                           const float *const *d_Wm, const float *const *d_bm, const float *d_Wf_user,
+                                           const float *d_bf_user, const float *d_Wf_item, const float *d_bf_item,
+                                           const float *const *d_Ws, const float *const *d_bs, float *d_pack, size_t pack_floats,
+                                           float *d_OutAct, int64_t ld_out, float *d_YAct, int64_t ld_y, int recdim, void *stream) {
+    ELIMREC_REQUIRE(rows && d_OutAct, "head_fwd_fused_rows: null pointer");
+    // (out0 / narrow of the plain entry are the buffers this launch fills itself: block 0 of OutAct and rows->d_narrow_out)
+    return head_fwd_fused_impl(rows, d_act, d_seg_info, R, d_OutAct, ld_out, rows->d_narrow_out, rows->ld_narrow_out, d_c, n_mod, d_S, ldS, D,
+                               d_Wm, d_bm, d_Wf_user, d_bf_user, d_Wf_item, d_bf_item, d_Ws, d_bs, d_pack, pack_floats, d_OutAct, ld_out,
+                               d_YAct, ld_y, recdim, 4, stream);
 }

@@ -13,13 +13,13 @@
 // the (col, val) of step j of the wave's items are consecutive in memory. HBM/L2-bound (9 flop per 4-B gathered).
 #include "common.h"
 #include "merge_rows.h"
+#include "rows_args.h"
 #include "bwd_w.h"
 #include <hip/hip_bf16.h>
 #include <cstdlib>
 
 namespace elimrec {
 
-constexpr int kSlabMaxLayers = 8;
 
 struct SellArgs {
     const int32_t *item_dst, *item_len, *blk_off, *col;
@@ -173,32 +173,10 @@ __global__ __launch_bounds__(256) void sell_fixup_kernel(SellArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-struct RowsArgs {
-    const float4 *x[kSlabMaxLayers + 1];
-    int L;
-    int64_t U, n_rows;
-    int nc4, w4, w4_shift;
-    const float4 *long_tab;
-    int n_long;
-    const int32_t *long_index, *col;
-    const int64_t *rowptr;          // plain CSR row pointers: 64-bit (a 2e9-non-zero graph, BASELINE.json configs[4])
-    const float *val;
-    const int32_t *rows, *counts;
-    int64_t R;
-    int n_lists;
-    float *out0;
-    int64_t ld_out0;
-    float *narrow;
-    int64_t ld_narrow;
-    int by_node;
-    float inv;
-};
-
-// Layer means at listed rows; hop L inline when its table is absent. LR lanes per listed row, lane cl owns the float4
-// columns cl, cl + LR, ... of the row's nc4 = ns*w/4.
+// Layer means at listed rows; hop L inline when its table is absent (rows_args.h: rows_piece). LR lanes per listed row, lane
+// cl owns the float4 columns cl, cl + LR, ... of the row's nc4 = ns*w/4.
 template <int LR>
 __global__ __launch_bounds__(256) void slab_rows_kernel(RowsArgs a) {
-    constexpr int U8 = 16;
     const int64_t s = (int64_t)blockIdx.x * (256 / LR) + threadIdx.x / LR;
     const int cl = threadIdx.x % LR;
     if (s >= a.R * a.n_lists) return;
@@ -209,65 +187,11 @@ __global__ __launch_bounds__(256) void slab_rows_kernel(RowsArgs a) {
         r = a.rows[s];
         if (r < 0) return;                              // padding of a gathered list (negative keys); counts may be null
     }
-    const bool user = r < a.U;
-    // layer pointers by compare-select over constant indices: indexing the by-value argument array with a run-time k
-    // makes the compiler spill it to scratch (32 B of private segment, and the scratch set-up with it)
-    auto layer = [&](int k) -> const float4 * {
-        const float4 *p = a.x[0];
-#pragma unroll
-        for (int q = 1; q <= kSlabMaxLayers; ++q) p = (k == q) ? a.x[q] : p;
-        return p;
-    };
-    const float4 *xL = layer(a.L), *xLm1 = layer(a.L - 1);
-    const bool inline_hop = xL == nullptr;
-    int li = -1;
-    int64_t beg = 0, end = 0;
-    if (inline_hop) {
-        li = a.long_index[r];
-        if (li < 0) { beg = a.rowptr[r]; end = a.rowptr[r + 1]; }
-    }
     for (int c = cl; c < a.nc4; c += LR) {
-        const int slab = c >> a.w4_shift, c4 = c & (a.w4 - 1);
-        const int64_t idx = ((int64_t)slab * a.n_rows + r) * a.w4 + c4;
-        float4 xl;
-        if (!inline_hop) xl = xL[idx];
-        else if (li >= 0) xl = a.long_tab[((int64_t)slab * a.n_long + li) * a.w4 + c4];
-        else {
-            const float4 *X = xLm1 + (int64_t)slab * a.n_rows * a.w4 + c4;
-            xl = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int64_t j = beg; j < end; j += U8) {
-                int cj[U8];
-                float vj[U8];
-                float4 x[U8];
-#pragma unroll
-                for (int u = 0; u < U8; ++u) {
-                    const bool in = (j + u) < end;
-                    cj[u] = in ? a.col[j + u] : 0;
-                    vj[u] = in ? a.val[j + u] : 0.f;
-                }
-#pragma unroll
-                for (int u = 0; u < U8; ++u)
-                    x[u] = (j + u) < end ? X[(int64_t)cj[u] * a.w4] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int u = 0; u < U8; ++u) {
-                    xl.x = fmaf(vj[u], x[u].x, xl.x); xl.y = fmaf(vj[u], x[u].y, xl.y);
-                    xl.z = fmaf(vj[u], x[u].z, xl.z); xl.w = fmaf(vj[u], x[u].w, xl.w);
-                }
-            }
-        }
-        const float4 x0 = a.x[0][idx];
-        const float4 x1 = (a.L == 1) ? xl : a.x[1][idx];
-        float4 sum = make_float4(x0.x + x1.x, x0.y + x1.y, x0.z + x1.z, x0.w + x1.w);
-        float4 nar = user ? x0 : x1;
-        for (int k = 2; k <= a.L; ++k) {
-            const float4 v = (k == a.L) ? xl : layer(k)[idx];
-            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-            if (((k & 1) == 0) == user) { nar.x += v.x; nar.y += v.y; nar.z += v.z; nar.w += v.w; }
-        }
-        *reinterpret_cast<float4 *>(a.out0 + s * a.ld_out0 + 4 * c) =
-            make_float4(sum.x * a.inv, sum.y * a.inv, sum.z * a.inv, sum.w * a.inv);
-        *reinterpret_cast<float4 *>(a.narrow + (a.by_node ? r : s) * a.ld_narrow + 4 * c) =
-            make_float4(nar.x * a.inv, nar.y * a.inv, nar.z * a.inv, nar.w * a.inv);
+        float4 out, nar;
+        rows_piece(a, r, c, out, nar);
+        *reinterpret_cast<float4 *>(a.out0 + s * a.ld_out0 + 4 * c) = out;
+        *reinterpret_cast<float4 *>(a.narrow + (a.by_node ? r : s) * a.ld_narrow + 4 * c) = nar;
     }
 }
 
@@ -1742,22 +1666,13 @@ extern "C" int elimrec_slab_rows(const elimrec_sell *A, int ns, int w, int L, in
                                  int n_lists, float *d_out0, int64_t ld_out0, float *d_narrow, int64_t ld_narrow,
                                  int narrow_by_node, void *stream) {
     ELIMREC_REQUIRE(A && layers && d_out0 && d_narrow, "slab_rows: null pointer");
-    ELIMREC_REQUIRE(L >= 1 && L <= kSlabMaxLayers, "slab_rows: 1 <= L <= %d", kSlabMaxLayers);
     ELIMREC_REQUIRE(ld_out0 % 4 == 0 && ld_narrow % 4 == 0, "slab_rows: leading dimensions must be multiples of 4");
     ELIMREC_REQUIRE(n_lists >= 1 && (d_rows || n_lists == 1), "slab_rows: several lists need row ids");
-    int w4_shift, rc;
-    if ((rc = slab_simple_geometry("slab_rows", A->n_rows, ns, w, w4_shift))) return rc;
     RowsArgs a = {};
-    for (int k = 0; k <= L; ++k) a.x[k] = (const float4 *)layers[k];
-    for (int k = 0; k < L; ++k) ELIMREC_REQUIRE(layers[k], "slab_rows: layer table %d missing", k);
-    ELIMREC_REQUIRE(layers[L] || (A->d_rowptr && A->d_csr_col && A->d_csr_val && A->d_long_index && (A->n_long == 0 || d_long)),
-                    "slab_rows: the inline last hop needs the CSR, the long-row index and the long-row table");
-    a.L = L; a.U = U; a.n_rows = A->n_rows; a.nc4 = ns * (w / 4); a.w4 = w / 4; a.w4_shift = w4_shift;
-    a.long_tab = (const float4 *)d_long; a.n_long = A->n_long; a.long_index = A->d_long_index;
-    a.rowptr = A->d_rowptr; a.col = A->d_csr_col; a.val = A->d_csr_val;
+    int rc;
+    if ((rc = rows_args_fill("slab_rows", A, ns, w, L, U, layers, d_long, a))) return rc;
     a.rows = d_rows; a.counts = d_counts; a.R = R; a.n_lists = n_lists;
     a.out0 = d_out0; a.ld_out0 = ld_out0; a.narrow = d_narrow; a.ld_narrow = ld_narrow; a.by_node = narrow_by_node;
-    a.inv = 1.0f / (float)(L + 1);
     const int64_t total = R * n_lists;
     if (total <= 0) return 0;
     int lr = 1;

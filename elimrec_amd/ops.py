@@ -739,6 +739,35 @@ def head_pack_bwd_offset(dims):
     return int(_lib.load().elimrec_head_pack_bwd_offset(len(dims), arr))
 
 
+def head_fwd_fused_rows(rows, act, seg_info, c, S, Wm, bm, Wf_user, bf_user, Wf_item, bf_item, Ws, bs, pack, OutAct, YAct, d):
+    """elimrec_head_fwd_fused_rows: phase 4 of head_fwd_fused with the rows launch folded in. rows: dict(plan, ns, w, L, U,
+    layers (L + 1 flat tensors, the last may be None), long_tab, narrow). Returns (ok, the host struct the call read -- kept by
+    the caller for as long as a recorded program refers to it)."""
+    n = len(S)
+    R = act.numel()
+    hr = _lib.HeadRows()
+    hr.A = ctypes.pointer(rows["plan"].desc)
+    hr.ns, hr.w, hr.L, hr.U = int(rows["ns"]), int(rows["w"]), int(rows["L"]), int(rows["U"])
+    for k, t in enumerate(rows["layers"]):
+        hr.layers[k] = None if t is None else _dev(t, "layer")
+    hr.d_long = _dev(rows["long_tab"], "long_tab")
+    nar = rows["narrow"]
+    assert nar.stride(1) == 1
+    hr.d_narrow_out, hr.ld_narrow_out = _dev(nar, "narrow"), nar.stride(0)
+    ptr = lambda ts: (ctypes.c_void_p * max(n, 1))(*[_dev(t, "table") for t in ts])
+    ldS = (ctypes.c_int64 * max(n, 1))(*[t.stride(0) for t in S])
+    D = (ctypes.c_int * max(n, 1))(*[t.shape[1] for t in S])
+    rc = _lib.load().elimrec_head_fwd_fused_rows(
+        ctypes.byref(hr), _dev(act, "act", torch.int32), _dev(seg_info, "seg_info", torch.int32), R, _dev(c, "c"), n, ptr(S), ldS, D,
+        ptr(Wm), ptr(bm), _dev(Wf_user, "Wf_user"), _dev(bf_user, "bf_user"), _dev(Wf_item, "Wf_item"), _dev(bf_item, "bf_item"),
+        ptr(Ws), ptr(bs), _dev(pack, "pack"), pack.numel(), _dev(OutAct, "OutAct"), OutAct.stride(0), _dev(YAct, "YAct"),
+        YAct.stride(0), int(d), _stream())
+    if rc == 10002:           # ELIMREC_E_UNSUPPORTED
+        return False
+    _lib.check(rc, "head_fwd_fused_rows")
+    return True
+
+
 def head_fwd_fused(act, seg_info, out0, narrow, c, S, Wm, bm, Wf_user, bf_user, Wf_item, bf_item, Ws, bs, pack, OutAct, YAct, d, phase=0):
     """elimrec_head_fwd_fused: S / Wm / bm / Ws / bs are lists over the feature tables. phase 0: pack the weights and
     run the head; 1: pack only; 2: head only (pack holds the packed weights); 3 / 4: the head in two launches (the feature

@@ -577,6 +577,11 @@ class ColumnShardEngine(object):
         self._head16 = os.environ.get("ELIMREC_HEAD_ROWS", "16") != "32"
         self._split_head = os.environ.get("ELIMREC_HEAD_SPLIT", "1") != "0"     # feature blocks of the head beside the forward hops
         self._head_split = False
+        # ... and the layer means of the active rows evaluated by the head's main-stream launch itself (no rows launch): one rank
+        # that owns all 64 columns, fp32 tables, the two-launch head
+        self._rows_in_head_on = os.environ.get("ELIMREC_ROWS_IN_HEAD", "1") != "0"
+        self._rows_in_head = False
+        self._head_rows_keep = None
         self.send_b = None
         self._loss_ring, self._loss_at = None, 0
         self._bits_ready = False
@@ -797,7 +802,7 @@ class ColumnShardEngine(object):
         err = m._index_err()
 
         aux = self._aux_stream()
-        self._head_split = False
+        self._head_split = self._rows_in_head = False
         early_bits = aux is not None and self.planT.tiered and not self.bf16 and not self.multi      # (several ranks: cs_gathered_ids)
         if aux is not None and self._forked and getattr(self, "_ws_gen_planned", None) != m._ws_gen:
             # another batch size's buffer set (possibly allocated -- and zero-filled ON THE MAIN STREAM -- a moment ago, after
@@ -830,6 +835,8 @@ class ColumnShardEngine(object):
                 self._head_split = self._head16 and not self.lookup and self._split_head
                 if self._head_split:
                     m._region("cs_head_features", (m._ws_gen, R), features)
+                self._rows_in_head = (self._head_split and self._rows_in_head_on and not self.multi and not self.bf16 and not self.wide
+                                      and self.dl == 64 and self.ns * self.w == 64)
         self._aux_pending = True
         return act
 
@@ -933,6 +940,8 @@ class ColumnShardEngine(object):
             elif self.bf16:
                 slab.rows16(self.plan, self.ns, self.w, L, U, tabs[0].data, [t.data for t in tabs[1:]] + [None], self.long_tab,
                             acts, counts, R, W, out0, narrow, by_node)
+            elif self._rows_in_head:
+                pass                  # the head's launch evaluates the rows itself (cs_head: elimrec_head_fwd_fused_rows)
             else:
                 slab.rows(self.plan, self.ns, self.w, L, U, [t.data for t in tabs] + [None], self.long_tab, acts, counts, R, W,
                           out0, narrow, by_node)
@@ -941,7 +950,7 @@ class ColumnShardEngine(object):
         if late_wait:
             m._region("cs_fwd_long%d" % self.cur, (m._ws_gen,), long_rows)
             program.sync(torch.cuda.current_stream(), self._aux)
-        m._region("cs_fwd_rows%d" % self.cur, (m._ws_gen, acts.data_ptr(), R, W, narrow.data_ptr(), late_wait), rows)
+        m._region("cs_fwd_rows%d" % self.cur, (m._ws_gen, acts.data_ptr(), R, W, narrow.data_ptr(), late_wait, self._rows_in_head), rows)
         return self.send_f if self.multi else None
 
     def cs_forward(self, acts):
@@ -1008,9 +1017,14 @@ class ColumnShardEngine(object):
 
         split = packed and getattr(self, "_head_split", False)     # cs_plan ran the feature blocks on the second stream
 
+        with_rows = split and self._rows_in_head
+
         def head():
-            self._head_fused_call(ws, R, phase=4 if split else (2 if packed else 0))
-        m._region("cs_head_fused", (m._ws_gen, R, B, packed, split, self.nar_act.data_ptr(),
+            if with_rows:
+                self._head_fused_rows_call(ws, R)
+            else:
+                self._head_fused_call(ws, R, phase=4 if split else (2 if packed else 0))
+        m._region("cs_head_fused%d" % (self.cur if with_rows else 2), (m._ws_gen, R, B, packed, split, with_rows, self.nar_act.data_ptr(),
                                     0 if self._out0_src is None else self._out0_src.data_ptr()), head)
         # the cosine-BPR rows and the batch loss in one launch (the workgroup that finishes last adds the loss rows in
         # elimrec_sum's order). Issued directly: the loss goes to the next slot of a ring, so that a caller holding the
@@ -1026,6 +1040,23 @@ class ColumnShardEngine(object):
         if b is None:
             b = self._pairs[R] = torch.zeros(R, 2, d, dtype=torch.float32, device=self.model._device())
         return b
+
+    def _head_fused_rows_call(self, ws, R):
+        """Phase 4 of the fused head with the rows launch folded in: the layer tables of THIS step's buffers."""
+        m = self.model
+        d, fold, W = m.latent_dim, ws["fold"], ws["live_views"]
+        OutAct, YAct = ws["OutAct"][:R], ws["YAct"][:R]
+        wu, wi = m._fusion_weights(W)
+        tabs = self._tabs
+        rows = dict(plan=self.plan, ns=self.ns, w=self.w, L=m.n_layers, U=m.num_users, layers=[t.data for t in tabs] + [None],
+                    long_tab=self.long_tab, narrow=self.nar_act)
+        ok = ops.head_fwd_fused_rows(rows, ws["active_rows"][:R], ws["seg_info"], fold["c"], [fold[k] for k in m._mods],
+                                     [W[k + "_dense.weight"] for k in m._mods], [W[k + "_dense.bias"] for k in m._mods], wu,
+                                     W["embedding_user_after_GCN.bias"], wi, W["embedding_item_after_GCN.bias"],
+                                     [W["s_dense_%s.weight" % k] for k in m._mods], [W["s_dense_%s.bias" % k] for k in m._mods],
+                                     self._pack, OutAct, YAct, d)
+        if not ok:
+            raise RuntimeError("fused head forward (with rows) refused a shape _fused_head_ok accepted")
 
     def _head_fused_call(self, ws, R, phase):
         m = self.model

@@ -720,6 +720,27 @@ int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg_info, int6
                            const float *const *d_bs, float *d_pack, size_t pack_floats, float *d_OutAct,
                            int64_t ld_out, float *d_YAct, int64_t ld_y, int recdim, int phase, void *stream);
 
+/* Phase 4 of elimrec_head_fwd_fused with the layer means of the active rows EVALUATED by the same launch instead of read back
+ * from elimrec_slab_rows (one rank owning every table column, recdim 64 = ns * w): the arguments of that call in a host
+ * struct -- plan, slab geometry, layer tables X^0 .. X^L (layers[L] NULL: hop L inline through the plain CSR, split rows
+ * from d_long), and where the shared part of the rows is kept (d_narrow_out [R x ld_narrow_out], as elimrec_slab_rows
+ * leaves it). Block 0 of d_OutAct is written here. Same bits as elimrec_slab_rows followed by phase 4. */
+typedef struct elimrec_head_rows {
+    const elimrec_sell *A;
+    int32_t ns, w, L;
+    int64_t U;
+    const float *layers[9];         /* L + 1 device pointers */
+    const float *d_long;
+    float *d_narrow_out;
+    int64_t ld_narrow_out;
+} elimrec_head_rows;
+int elimrec_head_fwd_fused_rows(const elimrec_head_rows *rows, const int32_t *d_act, const int32_t *d_seg_info, int64_t R,
+                                const float *d_c, int n_mod, const float *const *d_S, const int64_t *ldS, const int *D,
+                                const float *const *d_Wm, const float *const *d_bm, const float *d_Wf_user,
+                                const float *d_bf_user, const float *d_Wf_item, const float *d_bf_item,
+                                const float *const *d_Ws, const float *const *d_bs, float *d_pack, size_t pack_floats,
+                                float *d_OutAct, int64_t ld_out, float *d_YAct, int64_t ld_y, int recdim, void *stream);
+
 /* ---------------------------------------------------------------- propagation matrix on the device (N3)
  * create_adj_mat (models/EliMRec.py:309-354) from the UNIQUE training interactions d_users / d_items [E] (int64):
  * CSR of plain A (adj_type 0), D^-1/2 A D^-1/2 (1, 'pre'), D^-1 A (2, 'gcmc'), (D+I)^-1 (A+I) (3, 'norm'),
