@@ -31,7 +31,7 @@ def choose_slabs16(dl):
 
 def choose_slabs(dl, n_rows=None):
     """(ns, w) for a table of dl columns: w = the largest power-of-two multiple of 4 dividing dl, capped at 32 floats.
-    Measured at the Tiktok shape (tools/bench_slab_order.py, d = 64, us per hop): w = 64 (row-major) 44, w = 32 in two
+    Measured at the Tiktok shape (round 2; tools/bench_slab_modes.py repeats the geometries; d = 64, us per hop): w = 64 (row-major) 44, w = 32 in two
     slab groups 35, w = 16 in four 42, w = 8 in eight 67 -- a gathered piece narrower than one 128-B cache line still
     moves a whole line from L2 to the CU, so narrower slabs lose more on the L2 -> L1 path than their smaller L2
     footprint wins; 128-B pieces halve every XCD's footprint at no cost per line."""
