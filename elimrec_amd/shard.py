@@ -379,6 +379,11 @@ class ColumnShardTrainer(object):
         self._native["native_steps"] += 1
         return loss
 
+    @property
+    def _lookup_early(self):
+        import os
+        return os.environ.get("ELIMREC_LOOKUP_EARLY", "1") != "0"
+
     def _step_python(self, users, pos, neg):
         eng, W, ph = self.engine, self.world, self._ph
         if self.profile_kernels and getattr(eng, "kernel_events", None) is None:
@@ -400,11 +405,19 @@ class ColumnShardTrainer(object):
             acts = act.view(1, -1)
         if not early:
             ph["cs_forward_hops"]()                                # hops 1..L-1 of my column slice: no communication
+        lookup_early = False
+        if (self.multi and self.lookup and h_ids is not None and isinstance(h_ids, self._OnStream) and self._native_comm() is not None
+                and self._lookup_early):
+            # the row exchange of the constants needs the gathered ids and nothing of the graph: on the exchange stream, right
+            # behind the id exchange and UNDER the forward hops (pack, all_to_all_v, unpack); the head joins it
+            with torch.cuda.stream(self._comm_stream):
+                self._lookup_exchange(users, acts)
+            lookup_early = True
         if h_ids is not None:
             h_ids.wait()
         send = ph["cs_forward_rows"](acts)                         # [W, R, 2*dl]: layer means of the peers' rows, my columns
         if self.multi:
-            if self.lookup:
+            if self.lookup and not lookup_early:
                 self._lookup_exchange(users, acts)                 # S_m / c rows of MY active rows from their owners
             recv = self._like("recv_f", send)
             self._all_to_all(recv, send)
