@@ -287,8 +287,13 @@ def main():
                                    "in %d groups" % (eng.dl, eng.ns, eng.w, eng.gs),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic() if world == 1 else None,
-                         "limiter": "per-CU gather path, not HBM: TA busy 47 %, L1 stalled on pending misses 45 % of the launch, "
-                                    "L2 hit rate 0.60 (profiles/r03_pmc_traffic.json; DESIGN.md section 3)",
+                         # the L2-miss traffic the launch really moves (the PMC figure above) against the same peak: what the
+                         # memory side sees, over-fetch included
+                         "traffic_GBps": (pmc_traffic() / (hop_us * 1e-6) / 1e9) if (world == 1 and pmc_traffic()) else None,
+                         "traffic_frac_of_peak": (pmc_traffic() / (hop_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (world == 1 and pmc_traffic()) else None,
+                         "limiter": "the launch moves 2.5x its algorithmic bytes (every XCD pulls its half of the table through a 4 MB L2 on "
+                                    "a random graph) at two thirds of the HBM peak; on the CU side TA busy 46 %, L1 stalled on pending "
+                                    "misses 44 % of the launch, L2 hit rate 0.60 (profiles/r03_pmc_traffic.json; DESIGN.md section 3)",
                          # what the launch's gather instructions move: every non-zero pulls one row piece of each slab through the
                          # CUs' L1 (a source row is gathered deg times; the algorithmic bytes count it once). The chip's measured
                          # rate for uniformly random rows: MI355X_MICROARCH.md, "Indexed rows: gather into LDS"
