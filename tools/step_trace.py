@@ -21,7 +21,9 @@ set_seed(1)
 model = EliMRec(cfg, ds).to(dev)
 opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
 tr = ColumnShardTrainer(ColumnShardEngine(model, table_dtype=sys.argv[2] if len(sys.argv) > 2 else "f32"), opt)
+nb = int(u.numel()) // B                                 # whole batches of the sampled epoch; more steps go round again
 for i in range(K):
-    tr.step(u[i * B:(i + 1) * B], p[i * B:(i + 1) * B], n[i * B:(i + 1) * B])
+    j = i % nb
+    tr.step(u[j * B:(j + 1) * B], p[j * B:(j + 1) * B], n[j * B:(j + 1) * B])
 torch.cuda.synchronize()
 print("done")
