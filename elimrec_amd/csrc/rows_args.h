@@ -1,5 +1,6 @@
-// Layer means of the folded propagation at listed rows (elimrec_slab_rows): the argument block and the per-(row, column)
-// body, shared by slab_rows_kernel (slab.hip) and the head forward that evaluates its own rows (head.hip).
+// Layer means of the folded propagation at listed rows (elimrec_slab_rows; the reference's torch.stack(embs).mean over the
+// L + 1 propagated tables, models/EliMRec.py:244-247, evaluated at the batch's rows only): the argument block and the
+// per-(row, column) body, shared by slab_rows_kernel (slab.hip) and the head forward that evaluates its own rows (head.hip).
 #pragma once
 #include "common.h"
 
