@@ -47,13 +47,19 @@ def open_device(cfg):
     if cfg.no_cuda or not torch.cuda.is_available():
         print("use cpu")
         raise SystemExit("elimrec_amd has no CPU path for training: an MI355X is required (no_cuda must be FALSE)")
+    same_gpu = os.environ.get("ELIMREC_SAME_GPU") == "1"   # every rank on device 0 (one-GPU staging of the multi-rank job, as in
+    if same_gpu:                                           # bench.py: RCCL refuses duplicate devices, so the group is gloo and
+        local_rank = 0                                     # the collectives are staged through the host)
     print("use", "cuda:%d" % local_rank)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if same_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     return device, rank, world
 
 
