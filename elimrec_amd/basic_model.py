@@ -24,8 +24,7 @@ class BasicModel(nn.Module):
     def getFileName(self):
         """`{path}/{recommender}-{dataset}-{loss}-{suffix}.pth.tar` (BasicModel.py:34-40)."""
         cfg = self.config
-        if not os.path.exists(cfg["path"]):
-            os.mkdir(cfg["path"])
+        os.makedirs(cfg["path"], exist_ok=True)          # (several ranks of one job arrive here together)
         name = "%s-%s-%s-%s.pth.tar" % (cfg["recommender"], cfg["data.input.dataset"], cfg["loss"], cfg["suffix"])
         return os.path.join(cfg["path"], name)
 
