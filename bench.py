@@ -142,8 +142,8 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=300)      # the first ~15 steps after an idle GPU run 1-3 % slower
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-eval", action="store_true", help="skip the secondary evaluator timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-work", action="store_true", help="skip the reference-equivalent-work line")
