@@ -1171,7 +1171,21 @@ __global__ __launch_bounds__(256) void topk_tiles_kernel(const float *__restrict
     }
     __syncthreads();
     const int64_t n_masked = n_msk;
-    {
+    // tau = the (K + n_masked)-th largest of a set of GROUP maxima: that many different scores are >= tau, so at least K unmasked
+    // ones are. 64 coarse groups ranked by one wave when K + n_masked fits (the usual case: 4 096 comparisons instead of 65 536
+    // -- this ranking was 85 % of the kernel's instructions; the coarser threshold admits one or two candidates more), the 256
+    // fine groups otherwise.
+    if (K - 1 + n_masked < 64) {
+        __shared__ float g64[64];
+        if (t < 64) g64[t] = fmaxf(fmaxf(gm[4 * t], gm[4 * t + 1]), fmaxf(gm[4 * t + 2], gm[4 * t + 3]));
+        __syncthreads();
+        if (t < 64) {
+            const float mine = g64[t];
+            int rank = 0;
+            for (int j = 0; j < 64; ++j) rank += tk_before(g64[j], j, mine, t) ? 1 : 0;
+            if ((int64_t)rank == K - 1 + n_masked) tau = mine;
+        }
+    } else {
         int rank = 0;
         for (int j = 0; j < 256; ++j) rank += tk_before(gm[j], j, m, t) ? 1 : 0;
         if ((int64_t)rank == K - 1 + n_masked) tau = m;
