@@ -594,7 +594,6 @@ class ColumnShardEngine(object):
         # that owns all 64 columns, fp32 tables, the two-launch head
         self._rows_in_head_on = os.environ.get("ELIMREC_ROWS_IN_HEAD", "1") != "0"
         self._rows_in_head = False
-        self._head_rows_keep = None
         self.send_b = None
         self._loss_ring, self._loss_at = None, 0
         self._bits_ready = False
