@@ -309,6 +309,15 @@ def main():
         }
         if world > 1:
             out["xgmi_bytes_sent_per_rank_step"] = trainer.xgmi_bytes
+            # what ONE GPU does at the same global batch (a step is O(graph) + O(B), so one GPU's triplets/s rises with B):
+            # a weak-scaling value is a speed-up only against this figure. Measured here, on rank 0's GPU, after the timed
+            # region, while the other ranks wait at the closing barrier.
+            out["one_gpu_same_global_batch_triplets_per_s"] = None
+            if not args.no_b_sweep:
+                try:
+                    out["one_gpu_same_global_batch_triplets_per_s"] = one_gpu_at_batch(args, device, cfg, ds, B * world, torch)
+                except Exception as e:   # noqa: BLE001
+                    out["one_gpu_same_global_batch_error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
             if plan_ms is not None:
                 out["lookup"] = {"plan_ms_per_batch": plan_ms, "steps_that_synchronised_for_split_sizes": trainer.lookup_syncs,
                                  "row_bytes": eng.lookup_row_bytes, "shard_bytes_per_rank": eng.fshard.nbytes()}
@@ -341,6 +350,29 @@ def main():
         dist.barrier()
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
+
+
+def one_gpu_at_batch(args, device, cfg, ds, Bg, torch, steps=20, warmup=5):
+    """The one-rank engine (all columns, replicated constants, the one-GPU fast path) at batch Bg on this rank's GPU."""
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam, PairwiseSamplerV2
+    _, _, model = build(args, device)
+    model = model.to(device)
+    opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+    tr = ColumnShardTrainer(ColumnShardEngine(model), opt, world_size=1, rank=0)
+    sampler = PairwiseSamplerV2(ds, batch_size=Bg, device=device, seed=cfg["seed"])
+    pools = []
+    while sum(p[0].numel() for p in pools) < (steps + warmup) * Bg:
+        pools.append(sampler.sample_epoch())
+    U_, P_, N_ = (torch.cat([p[i] for p in pools]) for i in range(3))
+    bs = [(U_[i * Bg:(i + 1) * Bg], P_[i * Bg:(i + 1) * Bg], N_[i * Bg:(i + 1) * Bg]) for i in range(steps + warmup)]
+    for b in bs[:warmup]:
+        tr.step(*b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in bs[warmup:]:
+        tr.step(*b)
+    torch.cuda.synchronize()
+    return Bg * steps / (time.perf_counter() - t0)
 
 
 def batch_sweep(trainer, sampler, pools, B0, torch, sizes=(2048, 4096, 8192, 16384, 32768), steps=20, warmup=3):

@@ -1,7 +1,19 @@
 """Console/file logger and running-average meter with the reference's line formats
 (util/logger.py:4-39, util/meter.py:5-59)."""
 import os
+import sys
 import time
+
+
+def _emit(text):
+    """One console line as ONE write + flush: the ranks of a multi-rank job share a pipe, and `print` issues the text and the
+    newline as separate writes that another rank's line can land between. In a job of several ranks (WORLD_SIZE > 1) every
+    line carries `[rank k]`; a one-rank run prints the reference's lines unchanged (util/logger.py:24-30)."""
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        tag = "[rank %s]\t" % os.environ.get("RANK", "0")
+        text = "\n".join(tag + l for l in text.split("\n"))
+    sys.stdout.write(text + "\n")
+    sys.stdout.flush()
 
 
 class Logger(object):
@@ -19,12 +31,12 @@ class Logger(object):
                 f.write("============Start Logging============\n")
                 f.write("[Created At]:" + time.asctime(time.localtime(time.time())) + "\n")
                 f.write("=====================================\n")
-            print("log to file: ", self.log_file_name)
+            _emit("log to file:  " + self.log_file_name)
 
     def log(self, *msg):
         line = "\t".join(str(m) for m in msg)
         if self.show_in_console:
-            print(line)
+            _emit(line)
         if self.in_file is True:
             with open(self.log_file_name, "a") as f:
                 f.write(line + "\n")
@@ -32,7 +44,7 @@ class Logger(object):
     @staticmethod
     def info(*msg):
         if Logger.logger is None:
-            print(*msg)
+            _emit(" ".join(str(m) for m in msg))
         else:
             Logger.logger.log(*msg)
 

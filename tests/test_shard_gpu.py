@@ -1430,41 +1430,3 @@ def test_wide_form_native_step_program_equals_python_issued_steps(monkeypatch):
     assert np.array_equal(out["0"][0], out["1"][0])
     for k, v in out["0"][1].items():
         assert torch.equal(out["1"][1][k], v), k
-
-
-def test_driver_with_four_ranks_staged_on_one_gpu(tmp_path):
-    """`main.py --gpus=4` end to end as the user runs it (it starts its own ranks), staged on ONE GPU (ELIMREC_SAME_GPU=1: gloo
-    group, collectives through the host): column-sharded training with row-sharded constants, item-sharded validation and test,
-    the best checkpoint written by rank 0 -- and every rank reports the same results. (The first run of this kind found a
-    check-then-mkdir race in getFileName.)"""
-    import subprocess, sys
-    from helpers import ROOT
-    env = dict(os.environ, ELIMREC_SAME_GPU="1")
-    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "main.py"), "--gpus=4", "--data.input.dataset=synthetic", "--alpha=0.5",
-                          "--loss=bpr_loss", "--feature_shard=row", "--synthetic_shape=[600,1400,12000]", "--synthetic_dims=[16,8,12]",
-                          "--batch_size=512", "--num_epoch=4", "--test_step=2", "--verbose=1", "--path=%s" % str(tmp_path / "ck")],
-                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    tie = [l.strip() for l in out.stdout.splitlines() if l.strip().startswith("[TIE]\t") and "R@" not in l]     # "[TIE] R P NDCG" of a test pass
-    assert len(tie) >= 4 and len(set(tie[-4:])) == 1, tie        # the four ranks' final test lines agree
-    assert any(f.endswith(".pth.tar") for f in os.listdir(tmp_path / "ck"))
-
-
-def test_bench_starts_its_own_ranks_staged_on_one_gpu():
-    """`python bench.py --gpus 2` from a bare shell (no WORLD_SIZE): it starts its two ranks as child processes before touching
-    the GPU, and rank 0 prints ONE JSON line last with n_gpus = 2, the hybrid partition and the per-rank xGMI bytes -- staged on
-    one GPU (ELIMREC_SAME_GPU=1: gloo group)."""
-    import json, subprocess, sys
-    from helpers import ROOT
-    env = dict(os.environ, ELIMREC_SAME_GPU="1")
-    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
-        env.pop(k, None)
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline",
-                          "--no-b-sweep"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["steps"] == 6 and line["warmup"] == 2 and line["unit"] == "triplets/s" and line["scaling"] == "weak"
-    assert line["config"]["parallelism"] == "colshard2+rowshard-features" and line["config"]["global_batch"] == 2 * line["config"]["batch_per_gpu"]
-    assert line["value"] > 0 and abs(line["value"] - line["config"]["global_batch"] * 1e3 / line["ms_per_step"]) < 1e-6 * line["value"]
-    assert set(line["xgmi_bytes_sent_per_rank_step"]) >= {"all_gather", "all_to_all_fwd", "all_to_all_bwd", "all_reduce", "all_to_all_lookup"}
