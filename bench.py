@@ -30,6 +30,7 @@ WORKLOAD = dict(name="tiktok-shape-synthetic", num_users=36656, num_items=76085,
                 feat_dims=(128, 128, 128), recdim=64, layer_num=3, batch_size=2048, alpha=0.5)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TF = 157.3       # MI355X_MICROARCH.md: fp32-input MFMA = the fp32 vector peak
+MFMA_BF16_PEAK_TF = 2500.0     # MI355X_MICROARCH.md: dense bf16 MFMA peak (the 5 PF headline includes 2:1 sparsity)
 
 
 def reference_step_bytes(model, B):
@@ -287,13 +288,14 @@ def main():
                                    "in %d groups" % (eng.dl, eng.ns, eng.w, eng.gs),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic() if world == 1 else None,
+                         "traffic_source": ("profiles/%s: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE passes of a committed profile "
+                                            "run of this workload (tools/profile_round.sh), per launch -- NOT collected in this run"
+                                            % pmc_file()[0]) if (world == 1 and pmc_file()[0]) else None,
                          # the L2-miss traffic the launch really moves (the PMC figure above) against the same peak: what the
                          # memory side sees, over-fetch included
                          "traffic_GBps": (pmc_traffic() / (hop_us * 1e-6) / 1e9) if (world == 1 and pmc_traffic()) else None,
                          "traffic_frac_of_peak": (pmc_traffic() / (hop_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if (world == 1 and pmc_traffic()) else None,
-                         "limiter": "the launch moves 2.5x its algorithmic bytes (every XCD pulls its half of the table through a 4 MB L2 on "
-                                    "a random graph) at two thirds of the HBM peak; on the CU side TA busy 46 %, L1 stalled on pending "
-                                    "misses 44 % of the launch, L2 hit rate 0.60 (profiles/r03_pmc_traffic.json; DESIGN.md section 3)",
+                         "limiter": pmc_limiter(sb["hop_minimal"]),
                          # what the launch's gather instructions move: every non-zero pulls one row piece of each slab through the
                          # CUs' L1 (a source row is gathered deg times; the algorithmic bytes count it once). The chip's measured
                          # rate for uniformly random rows: MI355X_MICROARCH.md, "Indexed rows: gather into LDS"
@@ -336,7 +338,7 @@ def main():
             extra("batch_sweep", lambda: batch_sweep(trainer, sampler, pools, B, torch))
         mu = pmc_field("mfma_utilisation")
         if mu is not None:
-            out["mfma_utilisation"] = mu
+            out["mfma_utilisation"] = dict(mu, source="profiles/%s (committed profile run, not this run)" % pmc_file()[0])
         if not args.no_cpu_baseline and world == 1:     # the host baseline is timed on rank 0 at N=1 only
             cpu_batches = [tuple(x.cpu() for x in b) for b in batches[:5]]
             extra("cpu_baseline", lambda: cpu_baseline(ds, {k: v.cpu().numpy() for k, v in init_state.items()}, cfg, cpu_batches))
@@ -399,28 +401,42 @@ def batch_sweep(trainer, sampler, pools, B0, torch, sizes=(2048, 4096, 8192, 163
     return {"what": "same engine, one GPU, %d timed steps per size" % steps, "sizes": out}
 
 
-def pmc_field(key, name="r03_pmc_traffic.json"):
-    """A field of the committed PMC summary (profiles/), or None."""
+def pmc_file():
+    """The newest committed PMC summary of the training step (profiles/rNN_pmc_traffic.json, written by tools/pmc_summary.py from
+    the rocprofv3 --pmc passes of tools/profile_round.sh), as (name, contents) -- or (None, {})."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+    if not paths:
+        return None, {}
     try:
-        with open(os.path.join(ROOT, "profiles", name)) as f:
-            return json.load(f).get(key)
+        with open(paths[-1]) as f:
+            return os.path.basename(paths[-1]), json.load(f)
     except Exception:
-        return None
+        return None, {}
+
+
+def pmc_field(key):
+    return pmc_file()[1].get(key)
 
 
 def pmc_traffic():
-    """HBM bytes per full hop from the committed PMC passes (profiles/r03_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE
-    collected in separate rocprofv3 --pmc runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950). None if
-    the file is absent."""
-    try:
-        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
-            path = os.path.join(ROOT, "profiles", name)
-            if os.path.exists(path):
-                with open(path) as f:
-                    return json.load(f)["propagation_hop_traffic_bytes"]
+    """HBM-side bytes per full hop from the committed PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate rocprofv3 --pmc
+    runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950). A number of the COMMITTED profile, not of this run:
+    the line says which file it came from (`traffic_source`). None if there is no such file."""
+    return pmc_file()[1].get("propagation_hop_traffic_bytes")
+
+
+def pmc_limiter(algorithmic_bytes):
+    """What the committed counters say bounds the hop, in words, with every number read from the file."""
+    name, d = pmc_file()
+    t = d.get("propagation_hop_traffic_bytes")
+    if not t:
         return None
-    except Exception:
-        return None
+    return ("the launch moves %.2fx its algorithmic bytes past L2 (every XCD pulls its share of the table through a 4 MB L2 on a random "
+            "graph), L2 hit rate %.2f; on the CU side TA busy %.0f %% and L1 stalled on pending misses %.0f %% of the launch "
+            "(profiles/%s; DESIGN.md section 3)" % (t / algorithmic_bytes, d.get("propagation_hop_L2_hit_rate", float("nan")),
+                                                    100 * d.get("propagation_hop_TA_busy_frac", float("nan")),
+                                                    100 * d.get("propagation_hop_TCP_pending_stall_frac", float("nan")), name))
 
 
 def eval_pass(model, cfg, torch):
@@ -455,10 +471,15 @@ def eval_pass(model, cfg, torch):
                     "with fp32 accumulation: scores within 2.4e-7 of the IEEE/libm fp32-MFMA form (default)" if default_math else "exact",
             "users_per_launch": model.valid_evaluator.evaluator.block_users,
             "seconds_first": secs[0], "seconds": best, "users_per_s": n_eval / best,
-            "roofline": {"bound": "mfma", "kernel": "score_t16b_kernel (pass 1 + pass 2 on the bf16 matrix cores from exact three-piece splits of the "
-                                                    "fp32 operands) over the whole pass; achieved = the pass's fp32-equivalent dot-product flops / time, "
-                                                    "against the fp32 MFMA peak", "achieved": flops / best / 1e12,
-                         "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": flops / best / 1e12 / MFMA_F32_PEAK_TF, "flops": flops},
+            # the scorer's dot products run on the bf16 matrix cores: SIX bf16 piece products per fp32 product (exact three-piece
+            # splits), so the matrix cores retire 6x the fp32-equivalent flops and the pipe to price them against is the dense
+            # bf16 MFMA peak; the fp32-equivalent figure (against the fp32 MFMA peak) stays beside it
+            "roofline": {"bound": "mfma", "kernel": "score_t16b_kernel (pass 1 + pass 2 on the bf16 matrix cores, six piece products per fp32 "
+                                                    "product) over the whole validation pass",
+                         "achieved": 6 * flops / best / 1e12, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                         "frac": 6 * flops / best / 1e12 / MFMA_BF16_PEAK_TF, "bf16_flops": 6 * flops,
+                         "fp32_equivalent": {"flops": flops, "achieved": flops / best / 1e12, "peak": MFMA_F32_PEAK_TF,
+                                             "frac": flops / best / 1e12 / MFMA_F32_PEAK_TF}},
             "exact_math": {"seconds": min(exact), "users_per_s": n_eval / min(exact),
                            "frac_of_mfma_peak": flops / min(exact) / 1e12 / MFMA_F32_PEAK_TF}}
 

@@ -130,7 +130,10 @@ class UniEvaluator(object):
         import os
         block = self.block_users
         sh = getattr(model, "_eval_shard", None)
-        n_items = (sh.i1 - sh.i0) if sh is not None else model.num_items
+        # (item shards differ by one item between ranks when I % W != 0, and the sharded scorer's collectives run once per user
+        # block: the block size must come out the same on every rank, so it is sized from the LARGEST shard)
+        bounds = getattr(sh, "bounds", None)
+        n_items = (max(b - a for a, b in zip(bounds[:-1], bounds[1:])) if bounds else sh.i1 - sh.i0) if sh is not None else model.num_items
         budget = float(os.environ.get("ELIMREC_EVAL_WS_GB", 8)) * 2 ** 30
         while block > 16 and ops.score_workspace(block, model.num_users, n_items, model.S, self.max_top, topk_only=True,
                                                  d=model.latent_dim) > budget:

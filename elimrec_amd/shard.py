@@ -94,6 +94,7 @@ class ColumnShardTrainer(object):
         # row-sharded constant tables (engine.lookup): the all_to_all split sizes of every planned batch, as host integers
         self.lookup = bool(getattr(engine, "lookup", False)) and bool(getattr(engine, "lookup_exchange", True))
         self._lookup_plan = {}
+        self._lookup_owner = {}
         self.lookup_syncs = 0          # steps that had to read their split sizes back from the device (no plan entry)
         if self.lookup:
             self.xgmi_bytes["all_to_all_lookup"] = 0
@@ -215,9 +216,24 @@ class ColumnShardTrainer(object):
         is not in the plan reads its sizes from the device (one synchronisation per step)."""
         self._lookup_plan = {}
         self._lookup_size_arrays = {}
-        if not self.lookup or not batches:
+        self._lookup_owner = {}
+        if not self.lookup:
             return
         eng, W = self.engine, self.world
+        if W > 1:
+            # the [batches x W] table below is all_gathered: every rank must bring the same number of batches
+            nb = torch.tensor([len(batches), -len(batches)], dtype=torch.int64)
+            if dist.get_backend(self.group) == "gloo":
+                dist.all_reduce(nb, op=dist.ReduceOp.MAX, group=self.group)
+            else:
+                nb_d = nb.to(eng.model._device())
+                dist.all_reduce(nb_d, op=dist.ReduceOp.MAX, group=self.group)
+                nb = nb_d.cpu()
+            if int(nb[0]) != -int(nb[1]):
+                raise ValueError("plan_lookup: the ranks bring different numbers of batches (%d here, between %d and %d over the job)"
+                                 % (len(batches), -int(nb[1]), int(nb[0])))
+        if not batches:
+            return
         mine = eng.cs_lookup_plan_counts(batches)                 # int64 [n_batches, W] (host): my active rows per owner
         if W > 1:
             loc = torch.from_numpy(mine)
@@ -233,10 +249,28 @@ class ColumnShardTrainer(object):
         else:
             allc = mine[None]
         for k, (u, p, n) in enumerate(batches):
-            self._lookup_plan[(u.data_ptr(), int(u.numel()))] = allc[:, k, :]
+            key = (u.data_ptr(), int(u.numel()))
+            self._lookup_plan[key] = allc[:, k, :]
+            # a plan entry belongs to the three tensor OBJECTS it was computed from (kept alive here, so their addresses cannot
+            # be recycled while the plan stands) at their current versions: another tensor at the same address, or the same
+            # tensors rewritten in place, take the synchronising path instead of stale split sizes
+            self._lookup_owner[key] = ((u, p, n), (u._version, p._version, n._version))
+
+    def _planned(self, users, pos=None, neg=None):
+        """The plan key of this batch if the plan holds an entry made from these very tensors, else None."""
+        key = (users.data_ptr(), int(users.numel()))
+        own = self._lookup_owner.get(key)
+        if own is None:
+            return None
+        (u, p, n), vers = own
+        if u is not users or u._version != vers[0] or (pos is not None and (p is not pos or p._version != vers[1])) \
+                or (neg is not None and (n is not neg or n._version != vers[2])):
+            return None
+        return key
 
     def _lookup_counts(self, users, acts):
-        c = self._lookup_plan.get((users.data_ptr(), int(users.numel())))
+        key = self._planned(users)
+        c = self._lookup_plan.get(key) if key is not None else None
         if c is None:
             self.lookup_syncs += 1
             c = self.engine.cs_lookup_counts(acts).cpu().numpy()  # device -> host: the step waits for its plan
@@ -257,14 +291,14 @@ class ColumnShardTrainer(object):
     def _lookup_sizes(self, users, acts, peek=False):
         """The exchange's split sizes in bytes as a host int64 array (kept per planned batch: its address is an argument of
         the step's program)."""
-        key = (users.data_ptr(), int(users.numel()))
-        hit = self.__dict__.setdefault("_lookup_size_arrays", {}).get(key)
+        key = self._planned(users)
+        hit = self.__dict__.setdefault("_lookup_size_arrays", {}).get(key) if key is not None else None
         if hit is not None or peek:
             return hit
         counts = self._lookup_counts(users, acts)                 # [requester][owner] rows
         rb, q, W = self.engine.lookup_row_bytes, self.rank, self.world
         arr = (ctypes.c_int64 * (2 * W))(*([int(counts[r][q]) * rb for r in range(W)] + [int(counts[q][o]) * rb for o in range(W)]))
-        if key in self._lookup_plan:
+        if key is not None and key in self._lookup_plan:
             self._lookup_size_arrays[key] = arr
         return arr
 
@@ -314,7 +348,7 @@ class ColumnShardTrainer(object):
         # columns turned into rows by a kernel (fused head or compact constants), the lookup's split sizes planned ahead
         if self._native_comm() is None or not (eng._fused_head_ok() or eng.lookup):
             return False
-        return not self.lookup or (users.data_ptr(), int(users.numel())) in self._lookup_plan
+        return not self.lookup or self._planned(users, pos, neg) is not None
 
     def _step(self, users, pos, neg):
         st = self._native_state()
@@ -532,6 +566,7 @@ class ColumnShardEngine(object):
         self._forked = False
         self._early_hops = os.environ.get("ELIMREC_EARLY_HOPS", "1") != "0"
         self._late_wait = os.environ.get("ELIMREC_LATE_WAIT", "1") != "0"
+        self._bits_late_on = os.environ.get("ELIMREC_BITS_LATE", "1") != "0"
         self.dl, self.col0 = d // world, rank * (d // world)
         self.ns, self.w = slab.choose_slabs16(self.dl) if self.bf16 else slab.choose_slabs(self.dl, N)
         self.gs = slab.choose_groups(self.ns)
@@ -822,11 +857,16 @@ class ColumnShardEngine(object):
             program.sync(aux, torch.cuda.current_stream())
         self._ws_gen_planned = m._ws_gen
 
+        # the per-line source bits are needed by the first ADJOINT hop only: issued on the second stream BEHIND the forward's join
+        # (cs_forward_rows), they run under the head kernels instead of lengthening what the forward waits for
+        # (ELIMREC_BITS_LATE=0: right behind the planner, in the forward's shadow)
+        self._bits_late = early_bits and self._bits_late_on and self._sources_in_head()
+
         def plan():       # node ids of the slots, unique active rows + slot map, padded tail: one launch
             ops.batch_plan(users, pos, neg, m.num_users, m.num_items, keys, act, seg, ws["slot_seg"][:R], ws["plan_ws"], err, PAD_KEY,
                            key_bitmap=self.mask if (early_bits or self._sources_in_head()) else None)
-            if early_bits:    # the planner's bitmap of the active rows IS the first adjoint hop's source bitmap (one rank):
-                slab.source_bits(self.planT, self.hns, self.w, self.hgs, self.mask)    # its per-line bits, off the critical path
+            if early_bits and not self._bits_late:    # the planner's bitmap of the active rows IS the first adjoint hop's source
+                slab.source_bits(self.planT, self.hns, self.w, self.hgs, self.mask)    # bitmap (one rank): its per-line bits
 
         def pack():       # the head's weights in MFMA fragment order (they changed in the last optimizer step)
             self._head_fused_call(ws, R, phase=1)
@@ -962,6 +1002,12 @@ class ColumnShardEngine(object):
         if late_wait:
             m._region("cs_fwd_long%d" % self.cur, (m._ws_gen,), long_rows)
             program.sync(torch.cuda.current_stream(), self._aux)
+        if getattr(self, "_bits_late", False):
+            # (the join above was recorded before this is enqueued: the forward does not wait for it; the adjoint's first hop does)
+            with torch.cuda.stream(self._aux):
+                m._region("cs_bits_late", (m._ws_gen,), lambda: slab.source_bits(self.planT, self.hns, self.w, self.hgs, self.mask))
+            self._bits_late = False
+            self._bits_join = True
         m._region("cs_fwd_rows%d" % self.cur, (m._ws_gen, acts.data_ptr(), R, W, narrow.data_ptr(), late_wait, self._rows_in_head), rows)
         return self.send_f if self.multi else None
 
@@ -1147,6 +1193,9 @@ class ColumnShardEngine(object):
 
         single = not self.multi
         merged = single and getattr(self, "_merged", False)
+        if getattr(self, "_bits_join", False):                      # the source bits from the second stream (cs_forward_rows)
+            program.sync(torch.cuda.current_stream(), self._aux)
+            self._bits_join = False
         reduce = getattr(self, "_reduce", None) if (single or reduce_wgrads is not None) else None
         self._reduce = None
         self.wgrads_handle = None

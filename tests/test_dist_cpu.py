@@ -426,7 +426,22 @@ def _cs_worker(rank, world, port, out_dir, lookup="off"):
         batches.append((u[sl].clone(), p[sl].clone(), n[sl].clone()))
     if lookup == "planned":
         trainer.plan_lookup(batches)              # the epoch's split sizes ahead of time: no step reads its own back
+    if lookup == "stale":
+        # a plan made while the tensors held OTHER triplets (the two batches swapped), then rewritten in place: the entries
+        # belong to tensor versions that are gone, and every step must learn its split sizes from the device instead
+        right = [tuple(t.clone() for t in b) for b in batches]
+        for b, other in zip(batches, right[::-1]):
+            for t, o in zip(b, other):
+                t.copy_(o)
+        trainer.plan_lookup(batches)
+        for b, mine in zip(batches, right):
+            for t, o in zip(b, mine):
+                t.copy_(o)
     losses = [float(trainer.global_loss(trainer.step(*b))) for b in batches]
+    if lookup == "planned":
+        # the same numbers in OTHER tensor objects (an epoch whose tensors are new): not the planned ones either
+        again = [tuple(t.clone() for t in b) for b in batches]
+        assert all(trainer._planned(*b) is not None for b in batches) and all(trainer._planned(*b) is None for b in again)
     extra = {}
     if eng.lookup:
         assert eng.S is None and eng.loc.shape[0] < eng.m.U + eng.m.I        # this rank never held the full constants
@@ -438,15 +453,16 @@ def _cs_worker(rank, world, port, out_dir, lookup="off"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("lookup", ["planned", "synced"])
+@pytest.mark.parametrize("lookup", ["planned", "synced", "stale"])
 @pytest.mark.parametrize("world", [2, 4])
 def test_row_sharded_constants_with_all_to_all_lookup_equal_single_process(tmp_path, world, lookup):
     """north_star's row shards + all-to-all index lookup for the V/A/T (folded-constant) tables, under gloo: every rank
     holds 1/world of the rows of S_m / c and NOTHING else of them; a step all-gathers the active ids (as before), every
     owner packs the rows the others asked for, one variable-size all_to_all moves them, the requester puts them in
     active-row order. `world` ranks equal ONE process on the whole batch (oracle); the bytes on the wire are the rows a
-    rank does not own itself; with plan_lookup() no step synchronises to learn its split sizes."""
-    port = 33500 + (os.getpid() % 2000) + world + (10 if lookup == "planned" else 0)
+    rank does not own itself; with plan_lookup() no step synchronises to learn its split sizes; a plan whose tensors were
+    rewritten in place since ("stale") is not used."""
+    port = 33500 + (os.getpid() % 2000) + world + {"planned": 10, "synced": 0, "stale": 20}[lookup]
     mp.spawn(_cs_worker, args=(world, port, str(tmp_path), lookup), nprocs=world, join=True)
     rs = [dict(np.load(tmp_path / ("rank%d.npz" % r))) for r in range(world)]
     g = load_golden("ml3")

@@ -1409,8 +1409,15 @@ def test_device_evaluator_against_the_references_own_compiled_code(fixture_name)
     tp, ti = ev.truth_to_csr([sorted(set(test[int(u)])) for u in users])
     ref_rows, ref_topk = ev.evaluate_matrix(sc.copy(), tp, ti, mids, K, use_ref=True)
     idx, rows = idx.cpu().numpy(), rows.cpu().numpy()
+    # EVERY row whose K + 1 best scores are further apart than the two device scorers can differ (the evaluator's chunked bf16x3
+    # form against the score-matrix form ranked here: 2.4e-7 each way) must carry the reference's list and metric row bit for bit;
+    # only rows with a (near-)tie at or across the K boundary may differ, and then hold the same scores rank by rank
+    top = -np.sort(-sc, axis=1)[:, :K + 1]
+    clear = np.all(top[:, :-1] - top[:, 1:] > 1e-6, axis=1)
+    assert clear.sum() >= len(users) // 2, clear.sum()              # (the criterion below is not vacuous)
+    assert np.array_equal(idx[clear], ref_topk[clear]), np.nonzero(clear & ~(idx == ref_topk).all(1))[0]
+    assert np.array_equal(rows[clear], np.asarray(ref_rows, np.float32).reshape(len(users), -1)[clear])
     same = (idx == ref_topk).all(1) & _tie_free(sc, K)
-    assert same.sum() >= len(users) // 2
     assert np.array_equal(rows[same], np.asarray(ref_rows, np.float32).reshape(len(users), -1)[same])
     for r in np.nonzero(~same)[0]:
-        assert np.array_equal(sc[r][idx[r]], sc[r][ref_topk[r]]), r
+        assert np.abs(sc[r][idx[r]] - sc[r][ref_topk[r]]).max() <= 1e-6, r

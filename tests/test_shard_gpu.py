@@ -430,9 +430,10 @@ def test_c5_shape_scaled_step_and_eval_vs_oracle():
     e16.cs_backward_hops(s2, acts)
     loss32 = float(om.bpr_loss(u, p, n).detach())
     assert 0 < abs(loss16 - loss32) < 2e-3, (loss16, loss32)
-    assert rel_err(e16.grad.dense().cpu(), gE32.cpu()) < 2e-2
+    # the mode's stated tolerance (2e-2) in max-norm AND row by row, as the fp32 path is held to 1e-4 (helpers.assert_grad_close)
+    assert_grad_close(e16.grad.dense().cpu(), gE32.cpu(), "embedding gradient, fp16 constants", rel=2e-2)
     for k, v in e16._grads.items():
-        assert rel_err(v.cpu(), g32[k].cpu()) < 2e-2, k
+        assert_grad_close(v.cpu(), g32[k].cpu(), k, rel=2e-2)
     assert e16.fshard.table.dtype == torch.float16 and e16.fshard.nbytes() < 0.51 * (U + I) * (sum(dims) + 4) * 4
 
 
