@@ -13,13 +13,17 @@ from . import ops, slab
 
 PLAN_BYTES_PER_NNZ = 17.6      # tile_col + tile_val (padded, 8 B / entry) + csr_col + csr_val (8 B / non-zero); measured 17.2-17.6
 PLAN_BYTES_PER_ROW = 13.0      # rowptr (8) + long_index (4) + tile records amortised
+SWEEP_BYTES_PER_NNZ = 23.0     # column slices beyond the Infinity Cache (slab.sweep_wanted): 80-B step records of the user rows' half
+                               # of the non-zeros (~11-12.5 B each at 0.8-0.9 fill) + a tile plan of the item rows' half (short rows:
+                               # padded tiles, ~30 B each); measured 23.0 per non-zero of the whole graph at the scaled configs[4] shape
 
 
 def stats_of(plan):
     """The data-dependent numbers of a live slab.SellPlan."""
     t = sum(v.numel() * v.element_size() for v in plan.t.values())
     parts = sum(v.numel() * v.element_size() for v in plan._partials.values())
-    return dict(index_bytes=int(t), partial_bytes=int(parts), nnz=int(plan.nnz))
+    sweep = plan.sweep.device_bytes() if getattr(plan, "sweep", None) is not None else 0
+    return dict(index_bytes=int(t), partial_bytes=int(parts), nnz=int(plan.nnz), sweep_bytes=int(sweep))
 
 
 def plan(U, I, interactions, d, dims, world=1, layers=3, batch=2048, mods=None, symmetric=True, feature_dtype="f32",
@@ -53,6 +57,12 @@ def plan(U, I, interactions, d, dims, world=1, layers=3, batch=2048, mods=None, 
         idx, part = plan_stats["index_bytes"], plan_stats["partial_bytes"]
     out["adjacency plan (wave tiles + CSR; replicated: every hop of a column slice needs the whole graph)"] = idx * (1 if symmetric else 2)
     out["split rows' partial sums"] = part
+    if plan_stats is not None:
+        sweep = plan_stats.get("sweep_bytes", 0)
+    else:
+        sweep = int(SWEEP_BYTES_PER_NNZ * nnz) if (not wide and slab.sweep_wanted(N, dl)) else 0
+    if sweep:
+        out["window-sweep plan of the user rows + tile plan of the item rows (whole hops of a slice beyond the caches)"] = sweep * (1 if symmetric else 2)
     # ---- lookup.py: this rank's rows of [S_1 | .. | S_n | c]
     out["folded constants, my rows (%d x %d B, %s)" % (rows_loc, row_bytes, feature_dtype)] = rows_loc * row_bytes
     out["looked-up rows of a batch (fp32 [R x %d] + c + iota)" % sumD] = R * sumD * 4 + R * 8

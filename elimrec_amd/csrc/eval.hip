@@ -188,6 +188,9 @@ struct ScoreArgs {
     float *scores; int64_t lds;      // pass 2 output
     const float *sqn;                // [N x (1+S)] squared L2 norms of every head block of every row of Y
     float *tile_max;                 // pass 2, optional: [B x tmax_ld] max score of every 16-item tile (BEFORE masking)
+    const float *thr;                // pass 2, chunked top-K (nullable): [B] a lower bound of the user's final K-th best score (from
+                                     // the chunks scored so far). A tile's 16 scores of a user are STORED only if their maximum
+                                     // reaches it; the tile maxima always are, and the selection never reads an unstored tile
     int64_t tmax_ld;
     int64_t item0, item_end;         // score_t16_kernel: the launch covers items [item0, item_end); scores / tile_max are
                                      // indexed relative to item0 (a chunk of the catalogue when only top-K is wanted)
@@ -608,6 +611,12 @@ __global__ __launch_bounds__(512, (D > 64 ? 2 : 4)) void score_t16_kernel(ScoreA
         }
     };
     float psum[4] = {0.f, 0.f, 0.f, 0.f};             // PASS 1: this wave's users' running sums of ui, tiles in ascending order
+    float thr_r[4];                                   // PASS 2: the store thresholds of this lane's four users
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = b0 + wave * TU + 4 * kq + r;
+        thr_r[r] = (PASS == 2 && a.thr && b < a.B) ? a.thr[b] : -INFINITY;
+    }
     // PASS 2: the squared block norms of this lane's item, fetched one chunk ahead like the rows (a dependent load at the
     // head of every epilogue otherwise)
     constexpr int NQ = (PASS == 2 && NB > 1) ? SUB * (NB - 1) : 1;
@@ -690,11 +699,13 @@ __global__ __launch_bounds__(512, (D > 64 ? 2 : 4)) void score_t16_kernel(ScoreA
                         }
                     }
                     const bool row_ok = b0 + urow < a.B;
-                    if (item_ok && row_ok) a.scores[(int64_t)(b0 + urow) * a.lds + (item - a.item0)] = out;
+                    bool keep = true;
                     if (a.tile_max) {                               // max over the tile's 16 items (lanes li) of this user
                         const float mx = row16_max_nonneg(item_ok ? out : -INFINITY);
                         if (li == 0 && row_ok) a.tile_max[(int64_t)(b0 + urow) * a.tmax_ld + tile] = mx;
+                        keep = !(mx < thr_r[r]);                    // below the user's running K-th best: never read again
                     }
+                    if (item_ok && row_ok && keep) a.scores[(int64_t)(b0 + urow) * a.lds + (item - a.item0)] = out;
                 }
             }
         }
@@ -826,6 +837,12 @@ __global__ __launch_bounds__(NTB, 2) void score_t16b_kernel(ScoreArgs a, int n_t
         umean[tid] = (b < a.B && ptype == 2) ? a.row_mean[b] : 0.f;
     }
     float psum[4] = {0.f, 0.f, 0.f, 0.f};             // PASS 1: this wave's users' running sums of ui, tiles in ascending order
+    float thr_r[4];                                   // PASS 2: the store thresholds of this lane's four users
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int b = b0 + wave * TU + 4 * kq + r;
+        thr_r[r] = (PASS == 2 && a.thr && b < a.B) ? a.thr[b] : -INFINITY;
+    }
     // a tile's rows (16 items x three planes) as uint4 over the workgroup's threads
     constexpr int TILE4 = TI * 3 * COLS / 8;
     constexpr int PFN = (TILE4 + NTB - 1) / NTB;
@@ -976,19 +993,32 @@ __global__ __launch_bounds__(NTB, 2) void score_t16b_kernel(ScoreArgs a, int n_t
         }
 #endif
         if (PASS == 2) {
+            // the tile maxima first (always stored), then the scores -- of the users whose maximum reaches their threshold only:
+            // a wave none of whose 16 users keeps the tile (the usual case once a chunk or two have been scored) skips the stores
+            bool keep[4];
+            bool any = !a.tile_max;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int urow = wave * TU + 4 * kq + r;
-                const float out = outs[r];
                 const bool row_ok = b0 + urow < a.B;
-                // unpredicated stores (lanes beyond the chunk / the user block write a.partial[0], which nothing reads in pass 2):
-                // a predicated store is a branch, and a branch per user ends the basic block the four chains are scheduled in
-                float *dst = (item_ok && row_ok) ? a.scores + (int64_t)(b0 + urow) * a.lds + (item - a.item0) : a.partial;
-                *dst = out;
+                keep[r] = true;
                 if (a.tile_max) {
-                    const float mx = row16_max_nonneg(item_ok ? out : -INFINITY);
+                    const float mx = row16_max_nonneg(item_ok ? outs[r] : -INFINITY);
+                    // unpredicated stores (the other lanes write a.partial[0], which nothing reads in pass 2): a predicated store
+                    // is a branch, and a branch per user ends the basic block the four chains are scheduled in
                     float *dmx = (li == 0 && row_ok) ? a.tile_max + (int64_t)(b0 + urow) * a.tmax_ld + tile : a.partial;
                     *dmx = mx;
+                    keep[r] = !(mx < thr_r[r]);
+                    any = any || keep[r];
+                }
+            }
+            if (__builtin_amdgcn_ballot_w64(any) != 0ull) {       // wave-uniform
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int urow = wave * TU + 4 * kq + r;
+                    const bool row_ok = b0 + urow < a.B;
+                    float *dst = (item_ok && row_ok && keep[r]) ? a.scores + (int64_t)(b0 + urow) * a.lds + (item - a.item0) : a.partial;
+                    *dst = outs[r];
                 }
             }
         }
@@ -1078,11 +1108,13 @@ __global__ void mask_train_kernel(float *__restrict__ scores, int64_t lds, const
 // Top-K by (score desc, index asc): K rounds; round r takes the best element strictly after the
 // previous pick in that total order. One workgroup per row.
 // K rounds over one row by the whole workgroup (any multiple of 64 threads <= 1024): round r takes the best element strictly
-// after the previous pick in the order (score desc, index asc). item0 / ldo / oo: the row holds items [item0, item0 + I) of
-// the catalogue (a chunk when only top-K is wanted); results go to out[b * ldo + oo + rank] with catalogue item ids.
-__device__ void topk_rounds(const float *__restrict__ row, int64_t I, int K, int b, int32_t *__restrict__ out_idx,
-                            float *__restrict__ out_val, const uint32_t *__restrict__ mask_bits, int64_t bits_ld, int64_t item0,
-                            int64_t ldo, int64_t oo) {
+// after the previous pick in the order (score desc, index asc). item0: the row holds items [item0, item0 + I) of the catalogue
+// (a chunk when only top-K is wanted); results go to oi[rank] / ov[rank] (global or LDS) with catalogue item ids, -1 / -inf
+// where the row runs out. tmx / floor_v (nullable): only elements of 16-item tiles whose maximum tmx[i / 16] reaches floor_v
+// were stored by the scorer -- the others are not read (they cannot reach the final top-K).
+__device__ void topk_rounds(const float *__restrict__ row, int64_t I, int K, int b, int32_t *oi, float *ov,
+                            const uint32_t *__restrict__ mask_bits, int64_t bits_ld, int64_t item0,
+                            const float *__restrict__ tmx = nullptr, float floor_v = -INFINITY) {
     __shared__ float sv[16];
     __shared__ int si[16];
     __shared__ float last_v;
@@ -1094,6 +1126,7 @@ __device__ void topk_rounds(const float *__restrict__ row, int64_t I, int K, int
         float bv = -INFINITY;
         int bi = INT32_MAX;
         for (int64_t i = threadIdx.x; i < I; i += blockDim.x) {
+            if (tmx && tmx[i / TI] < floor_v) continue;                       // an unstored tile
             float v = row[i];
             if (mask_bits && ((mask_bits[(int64_t)b * bits_ld + ((item0 + i) >> 5)] >> ((item0 + i) & 31)) & 1u)) v = -INFINITY;   // a masked item
             const bool after = (r == 0) || (v < pv) || (v == pv && (int)i > pi);
@@ -1101,9 +1134,9 @@ __device__ void topk_rounds(const float *__restrict__ row, int64_t I, int K, int
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
-            const float ov = __shfl_xor(bv, off, 64);
-            const int oi = __shfl_xor(bi, off, 64);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+            const float ov2 = __shfl_xor(bv, off, 64);
+            const int oi2 = __shfl_xor(bi, off, 64);
+            if (ov2 > bv || (ov2 == bv && oi2 < bi)) { bv = ov2; bi = oi2; }
         }
         if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
         __syncthreads();
@@ -1113,8 +1146,8 @@ __device__ void topk_rounds(const float *__restrict__ row, int64_t I, int K, int
             for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
                 if (sv[w] > fv || (sv[w] == fv && si[w] < fi)) { fv = sv[w]; fi = si[w]; }
             last_v = fv; last_i = fi;
-            out_idx[(int64_t)b * ldo + oo + r] = (fi == INT32_MAX) ? -1 : (int32_t)(item0 + fi);
-            if (out_val) out_val[(int64_t)b * ldo + oo + r] = fv;
+            oi[r] = (fi == INT32_MAX) ? -1 : (int32_t)(item0 + fi);
+            if (ov) ov[r] = fv;
         }
         __syncthreads();
         pv = last_v; pi = last_i;
@@ -1129,7 +1162,8 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float *__restrict__ sc
                                                     int64_t item0, int64_t ldo, int64_t oo) {
     const int b = blockIdx.x;
     if (only_if && only_if[b] == 0) return;        // this row was finished by topk_select_kernel
-    topk_rounds(scores + (int64_t)b * lds, I, K, b, out_idx, out_val, mask_bits, bits_ld, item0, ldo, oo);
+    topk_rounds(scores + (int64_t)b * lds, I, K, b, out_idx + (int64_t)b * ldo + oo, out_val ? out_val + (int64_t)b * ldo + oo : nullptr,
+                mask_bits, bits_ld, item0);
 }
 
 // Fast path of the same selection (identical result): two sweeps of the row instead of K.
@@ -1141,6 +1175,7 @@ __global__ __launch_bounds__(1024) void topk_kernel(const float *__restrict__ sc
 // If more than TK_CAP candidates qualify (massive ties, or fewer than K finite scores) the workgroup falls
 // back to the K-round sweep below, so the result never depends on which path ran.
 constexpr int TK_CAP = 1024;
+constexpr int RM_KMAX = 256;          // largest K of the tile-guided selection and of the metric kernel
 __device__ __forceinline__ bool tk_before(float va, int ia, float vb, int ib) {   // a ranks before b
     return va > vb || (va == vb && ia < ib);
 }
@@ -1212,25 +1247,36 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float *__restri
 __global__ __launch_bounds__(256) void topk_tiles_kernel(const float *__restrict__ scores, int64_t lds, int64_t I,
                                                          const float *__restrict__ tile_max, int64_t tmax_ld, int n_tiles, int K,
                                                          const int64_t *__restrict__ mask_ptr, const uint32_t *__restrict__ mask_bits,
-                                                         int64_t bits_ld, int32_t *__restrict__ out_idx,
-                                                         float *__restrict__ out_val, int32_t *__restrict__ fallback,
-                                                         int64_t item0, int64_t ldo, int64_t oo) {
+                                                         int64_t bits_ld, int32_t *out_idx, float *out_val,
+                                                         int32_t *__restrict__ fallback, int64_t item0, int64_t ldo, int64_t oo,
+                                                         float *thr, int first_chunk) {
+    // thr (nullable) = the RUNNING form of a catalogue scored chunk by chunk: out_idx / out_val [b][K] hold the user's best K of the
+    // chunks selected so far (-1 ids where there are fewer) and thr[b] their K-th score (-inf below K entries). The scorer stored
+    // this chunk's scores only in tiles whose maximum reaches thr[b]; the selection takes the chunk's candidates >= max(tau, thr[b])
+    // -- possibly fewer than K, possibly none --, ranks them TOGETHER with the running list by the same (score desc, id asc)
+    // counting and leaves the new list and threshold: after the last chunk the list is the catalogue's top-K, the list the
+    // whole-catalogue selection gives (top-K of a union = top-K of the parts' top-Ks under one total order).
+    constexpr int POOL = TK_CAP + RM_KMAX;
     __shared__ float gm[256];
-    __shared__ float cv[TK_CAP];
-    __shared__ int ci[TK_CAP];
+    __shared__ float cv[POOL];
+    __shared__ int ci[POOL];
     __shared__ int ct[TK_CAP];
     __shared__ float tau;
-    __shared__ int cnt, n_ct;
+    __shared__ int cnt, n_ct, n_run;
     const int b = blockIdx.x, t = threadIdx.x;
     const float *row = scores + (int64_t)b * lds;
     const float *tmx = tile_max + (int64_t)b * tmax_ld;
+    const bool running = thr != nullptr;
+    const float floor_v = (running && !first_chunk) ? thr[b] : -INFINITY;       // (first chunk: no list yet, whatever the buffers hold)
+    int32_t *oi = out_idx + (int64_t)b * ldo + oo;
+    float *ov = out_val ? out_val + (int64_t)b * ldo + oo : nullptr;
     // the bitmap words of this row's item range (item0 is a multiple of 32)
     const uint32_t *bits = mask_bits ? mask_bits + (int64_t)b * bits_ld + (item0 >> 5) : nullptr;
     __shared__ int n_msk;
     float m = -INFINITY;
     for (int i = t; i < n_tiles; i += 256) m = fmaxf(m, tmx[i]);
     gm[t] = m;
-    if (t == 0) { cnt = 0; n_ct = 0; tau = -INFINITY; n_msk = 0; }
+    if (t == 0) { cnt = 0; n_ct = 0; tau = -INFINITY; n_msk = 0; n_run = 0; }
     __syncthreads();
     if (bits && mask_ptr) {          // masked items inside the range: the whole list when the range is the catalogue
         if (item0 == 0 && I + 31 >= bits_ld * 32) { if (t == 0) n_msk = (int)(mask_ptr[b + 1] - mask_ptr[b]); }
@@ -1262,9 +1308,10 @@ __global__ __launch_bounds__(256) void topk_tiles_kernel(const float *__restrict
         if ((int64_t)rank == K - 1 + n_masked) tau = m;
     }
     __syncthreads();
-    const float th = tau;
+    const float tau_c = tau;
+    const float th = fmaxf(tau_c, floor_v);
     if (th != -INFINITY) {
-        // candidate tiles first (their numbers into ci[], which the ranking below reuses), then one score per thread
+        // candidate tiles first (their numbers into ct[]), then one score per thread
         for (int i = t; i < n_tiles; i += 256) {
             if (tmx[i] >= th) {
                 const int slot = atomicAdd(&n_ct, 1);
@@ -1280,26 +1327,56 @@ __global__ __launch_bounds__(256) void topk_tiles_kernel(const float *__restrict
             const float v = row[i];
             if (v >= th && !(bits && ((bits[i >> 5] >> (i & 31)) & 1u))) {
                 const int slot = atomicAdd(&cnt, 1);
-                if (slot < TK_CAP) { cv[slot] = v; ci[slot] = (int)i; }
+                if (slot < TK_CAP) { cv[slot] = v; ci[slot] = (int)(item0 + i); }
             }
         }
     }
     __syncthreads();
-    const int n = cnt;
-    if (n > TK_CAP || n < K || th == -INFINITY) {  // workgroup-uniform: the K-round sweep, by this workgroup (rare)
+    int n = cnt;
+    // the chunk must bring K candidates unless the running threshold (not the chunk's own tau) is what cut them
+    const bool short_ok = running && floor_v > tau_c;
+    if (n > TK_CAP || (n < K && !short_ok) || th == -INFINITY) {   // workgroup-uniform: the K-round sweep, by this workgroup (rare)
         if (t == 0 && fallback) fallback[b] = 1;
-        topk_rounds(row, I, K, b, out_idx, out_val, mask_bits, bits_ld, item0, ldo, oo);
-        return;
+        if (!running) {
+            topk_rounds(row, I, K, b, oi, ov, mask_bits, bits_ld, item0);
+            return;
+        }
+        // (over the stored tiles only; its picks become the chunk's candidates)
+        topk_rounds(row, I, K, b, ci, cv, mask_bits, bits_ld, item0, tmx, floor_v);
+        __syncthreads();
+        if (t == 0) {                                                  // compact: the sweep leaves -1 ids where the row ran out
+            int k = 0;
+            for (int j = 0; j < K; ++j)
+                if (ci[j] >= 0 && cv[j] != -INFINITY) { ci[k] = ci[j]; cv[k] = cv[j]; ++k; }
+            cnt = k;
+        }
+        __syncthreads();
+        n = cnt;
+    } else if (t == 0 && fallback) fallback[b] = 0;
+    if (running) {                       // the running list joins the pool (read before anything is written back)
+        for (int r = t; r < K; r += 256) {
+            const int id = first_chunk ? -1 : oi[r];
+            if (id >= 0) {
+                const int slot = n + atomicAdd(&n_run, 1);
+                cv[slot] = ov[r]; ci[slot] = id;
+            }
+        }
+        __syncthreads();
+        n += n_run;
+        __syncthreads();
+        for (int r = t; r < K; r += 256)
+            if (r >= n) { oi[r] = -1; ov[r] = -INFINITY; }
+        if (t == 0 && n < K) thr[b] = -INFINITY;
     }
-    if (t == 0 && fallback) fallback[b] = 0;
     for (int c = t; c < n; c += 256) {
         int rank = 0;
         const float mv = cv[c];
         const int mi = ci[c];
         for (int j = 0; j < n; ++j) rank += tk_before(cv[j], ci[j], mv, mi) ? 1 : 0;
         if (rank < K) {
-            out_idx[(int64_t)b * ldo + oo + rank] = (int32_t)(item0 + mi);
-            if (out_val) out_val[(int64_t)b * ldo + oo + rank] = mv;
+            oi[rank] = (int32_t)mi;
+            if (ov) ov[rank] = mv;
+            if (running && rank == K - 1) thr[b] = mv;
         }
     }
 }
@@ -1335,7 +1412,6 @@ struct MetricIds { int id[8]; };
 // discount table 1/log2(i+2) once per workgroup, and every lane then evaluates its own prefix of the reference's
 // sequential recurrences IN THE REFERENCE'S ORDER (float / double exactly where the C++ rounds), so the curves have the
 // bits of a one-thread-per-metric loop at a fraction of its latency. K <= 256.
-constexpr int RM_KMAX = 256;
 __global__ __launch_bounds__(256) void rank_metrics_kernel(const int32_t *__restrict__ rank, int B, int K, const int64_t *__restrict__ tptr,
                                                            const int32_t *__restrict__ titems, MetricIds mids, int n_metrics,
                                                            float *__restrict__ out) {
@@ -1433,6 +1509,7 @@ extern "C" int elimrec_score_get_math(void) { return score_math(); }
 
 static inline int n_item_tiles(int64_t I) { return (int)((I + TI - 1) / TI); }   // 16-item tiles (the finest of the forms)
 
+constexpr int64_t SCORE_PILOT = 2048;     // ... the first chunk of a chunked pass: its top-K gives every later launch a store threshold
 constexpr int64_t SCORE_CHUNK = 16384;    // items per scorer launch when only top-K is wanted (a multiple of 512)
 
 // Workspace layout of elimrec_score_topk. full: a [B x I] score block (the caller wants the scores, or a scorer without tile
@@ -1442,7 +1519,6 @@ struct ScoreLayout { size_t partial, mean, scores, flags, sqn, bits, tmax, cand_
 static ScoreLayout score_layout(int B, int64_t U, int64_t I, int S, int K, bool topk_only, int d = 0) {
     const size_t b = (size_t)(B > 0 ? B : 1);
     const int64_t cols = topk_only && I > SCORE_CHUNK ? SCORE_CHUNK : I;
-    const int64_t nch = topk_only ? (I + SCORE_CHUNK - 1) / SCORE_CHUNK : 0;
     ScoreLayout L;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t at = off; off += align_up(bytes, 256); return at; };
@@ -1453,8 +1529,8 @@ static ScoreLayout score_layout(int B, int64_t U, int64_t I, int S, int K, bool 
     L.sqn = take((size_t)(U + I) * (size_t)(1 + S) * sizeof(float));
     L.bits = take(b * (size_t)((I + 31) / 32) * sizeof(uint32_t));
     L.tmax = take(b * (size_t)n_item_tiles(cols) * sizeof(float));
-    L.cand_val = take(b * (size_t)nch * (size_t)(K > 0 ? K : 1) * sizeof(float));
-    L.cand_idx = take(b * (size_t)nch * (size_t)(K > 0 ? K : 1) * sizeof(int32_t));
+    L.cand_val = take(topk_only ? b * (size_t)(K > 0 ? K : 1) * sizeof(float) : 0);      // the running list's scores when the caller keeps none
+    L.cand_idx = take(topk_only ? b * sizeof(float) : 0);                                // the running K-th best score per user
     L.planes = off;
     if (topk_only && (d == 32 || d == 64)) take((size_t)cols * 3 * (size_t)(1 + S) * (size_t)d * 2 + (size_t)cols * (size_t)(S > 0 ? S : 1) * 4);
     L.total = off;
@@ -1475,7 +1551,7 @@ extern "C" size_t elimrec_score_workspace_topk(int B, int64_t U, int64_t I, int 
 
 // The ONE predicate for the chunked (top-K only, no [B x I] score block) form, shared by the sizing function below and by
 // elimrec_score_topk: the 16-user-per-wave scorer (recdim 32 / 64 / 128, 1..3 heads, MFMA + T16 forms enabled), K <= 256
-// (the tile-guided selection), more than one chunk, and per-chunk candidate lists that fit the merge kernel's LDS.
+// (the tile-guided selection with its running list) and more than one chunk -- any catalogue size.
 constexpr size_t TOPK_MERGE_LDS_MAX = 160 * 1024;
 static bool score_env_flag(const char *name, char off, int *cache) {
     if (*cache < 0) { const char *e = getenv(name); *cache = (e && e[0] == off) ? 0 : 1; }
@@ -1488,9 +1564,7 @@ static bool score_t16_path(int d, int S) {
     return score_uses_mfma() && score_uses_t16() && (d == 32 || d == 64 || d == 128) && S >= 1 && S <= 3;
 }
 static bool score_chunked_form(int d, int S, int K, int64_t I, bool want_scores, bool want_topk) {
-    const int64_t nch = (I + SCORE_CHUNK - 1) / SCORE_CHUNK;
-    return score_t16_path(d, S) && score_uses_chunks() && !want_scores && want_topk && K <= 256 && I > SCORE_CHUNK &&
-           (size_t)nch * (size_t)K * 8 <= TOPK_MERGE_LDS_MAX;
+    return score_t16_path(d, S) && score_uses_chunks() && !want_scores && want_topk && K <= RM_KMAX && I > SCORE_CHUNK;
 }
 
 // Bytes elimrec_score_topk needs for THIS call shape: recdim d, K, and whether the caller passes a score matrix
@@ -1568,7 +1642,7 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
     a.Y = d_Y; a.ldy = ldy; a.U = U; a.I = I; a.users = d_users; a.B = B; a.d = d; a.S = S; a.head_mask = head_mask;
     a.fusion_mode = fusion_mode; a.predict_type = predict_type; a.row_mean = mean; a.partial = partial;
     a.scores = d_scores ? d_scores : wscores; a.lds = d_scores ? lds : (chunked ? SCORE_CHUNK : I);
-    a.item0 = 0; a.item_end = I; a.planes = nullptr; a.inrm = nullptr;
+    a.item0 = 0; a.item_end = I; a.planes = nullptr; a.inrm = nullptr; a.thr = nullptr;
     float *wsqn = (float *)(ws + L.sqn);
     if (!d_sqnorm && predict_type != 0) {            // not supplied: compute the whole table for this call
         const int64_t N = U + I;
@@ -1740,10 +1814,21 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
                 hipLaunchKernelGGL(row_mean_kernel, dim3(B), dim3(256), 0, s, partial, n_part, B, mean_div, mean_dst);
                 ELIMREC_LAUNCH_CHECK("row_mean");
             }
-            for (int c = 0; c < nch; ++c) {
+            // pass 2 + selection, chunk by chunk, with a RUNNING top-K per user (topk_tiles_kernel): every chunk's selection leaves
+            // the best K so far and their K-th score; the next chunk's scorer stores a tile's scores of a user only where the tile's
+            // maximum reaches that score -- about one tile in seven after the 2 048-item pilot chunk, one in a hundred after the
+            // first full chunk -- so the [B x 16 384] block is hardly written at all (it was 537 MB per launch at 8 192 users). The
+            // lists after the last chunk are the result: no merge launch.
+            float *thrbuf = (float *)cand_idx;                           // [B]
+            float *run_val = d_topk_val ? d_topk_val : cand_val;         // [B x K] (the caller's list is the running list)
+            int64_t at = 0;
+            for (int c = 0; at < I; ++c) {
                 ScoreArgs ac = a;
-                ac.item0 = (int64_t)c * SCORE_CHUNK;
-                ac.item_end = ac.item0 + SCORE_CHUNK < I ? ac.item0 + SCORE_CHUNK : I;
+                ac.item0 = at;
+                const int64_t len = (c == 0 && I > SCORE_PILOT) ? SCORE_PILOT : SCORE_CHUNK;
+                ac.item_end = ac.item0 + len < I ? ac.item0 + len : I;
+                at = ac.item_end;
+                ac.thr = c == 0 ? nullptr : thrbuf;
                 const int64_t cnt = ac.item_end - ac.item0;
                 const int tc = (int)((cnt + TI - 1) / TI);
                 // ~512 workgroups per launch in all: a workgroup walks several tiles with its users' operands resident
@@ -1771,20 +1856,9 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
                 if (rc) return rc;
                 hipLaunchKernelGGL(topk_tiles_kernel, dim3(B), dim3(256), 0, s, ac.scores, ac.lds, cnt, (const float *)wtmax, ac.tmax_ld,
                                    tc, K, d_train_ptr, d_train_ptr ? (const uint32_t *)wbits : (const uint32_t *)nullptr, bits_ld,
-                                   cand_idx, cand_val, fallback, ac.item0, (int64_t)nch * K, (int64_t)c * K);
+                                   d_topk_idx, run_val, fallback, ac.item0, (int64_t)K, (int64_t)0, thrbuf, c == 0 ? 1 : 0);
                 ELIMREC_LAUNCH_CHECK("topk_tiles(chunk)");
             }
-            if ((size_t)nch * K * 8 > 64 * 1024) {       // beyond the default dynamic-LDS limit (score_chunked_form bounds it)
-                static bool attr = false;
-                if (!attr) {
-                    (void)hipFuncSetAttribute((const void *)topk_merge_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                              (int)TOPK_MERGE_LDS_MAX);
-                    attr = true;
-                }
-            }
-            hipLaunchKernelGGL(topk_merge_kernel, dim3(B), dim3(256), (size_t)nch * K * 8, s, (const float *)cand_val,
-                               (const int32_t *)cand_idx, nch * K, K, d_topk_idx, d_topk_val);
-            ELIMREC_LAUNCH_CHECK("topk_merge");
             if (id_offset) {
                 hipLaunchKernelGGL(add_id_offset_kernel, dim3((unsigned)(((int64_t)B * K + 255) / 256)), dim3(256), 0, s, d_topk_idx,
                                    (int64_t)B * K, (int32_t)id_offset);
@@ -1868,7 +1942,7 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
         if (tiles_ready) {
             hipLaunchKernelGGL(topk_tiles_kernel, dim3(B), dim3(256), 0, s, a.scores, a.lds, I, (const float *)wtmax, a.tmax_ld,
                                (int)a.tmax_ld, K, d_train_ptr, d_train_ptr ? (const uint32_t *)wbits : (const uint32_t *)nullptr,
-                               bits_ld, d_topk_idx, d_topk_val, fallback, (int64_t)0, (int64_t)K, (int64_t)0);
+                               bits_ld, d_topk_idx, d_topk_val, fallback, (int64_t)0, (int64_t)K, (int64_t)0, (float *)nullptr, 0);
             ELIMREC_LAUNCH_CHECK("topk_tiles");
         } else if (2 * K <= 1024) {
             hipLaunchKernelGGL(topk_select_kernel, dim3(B), dim3(1024), 0, s, a.scores, a.lds, I, K, G, d_topk_idx,

@@ -591,6 +591,15 @@ class ColumnShardEngine(object):
                   threshold=(64 if world == 1 else 32) if tiered else slab.LONG_ROW_THRESHOLD)
         self.plan = slab.SellPlan(adj, dev, **kw)
         self.planT = self.plan if m._adj_symmetric else slab.SellPlan(adj.T.tocsr(), dev, **kw)
+        # a column slice beyond the Infinity Cache (configs[3] on one GPU, configs[4] on eight): the user rows of every WHOLE hop
+        # by the window sweep (csrc/sweep.hip), the item rows by a tile plan of their own; the masked hop, the split-rows hop of
+        # the last forward layer and the batch-row kernels keep the whole plan. The hops then carry no tails (Adam, weight
+        # gradients): those run as launches of their own, a few tens of microseconds beside hops of a millisecond.
+        self.sweep = bool(tiered and not self.wide and self.w in (16, 32) and slab.sweep_wanted(N, self.dl))
+        if self.sweep:
+            self.plan.sweep = slab.SweepPlan(self.plan, adj, m.num_users, dev, kw["threshold"], ipw)
+            if self.planT is not self.plan:
+                self.planT.sweep = slab.SweepPlan(self.planT, adj.T.tocsr(), m.num_users, dev, kw["threshold"], ipw)
         tab = lambda: slab.SlabTable(N, self.ns, self.w, dev)
         tdt = torch.bfloat16 if self.bf16 else torch.float32
         ttab = lambda: slab.SlabTable(N, self.ns, self.w, dev, dtype=tdt)      # a propagated (stored) table
@@ -782,7 +791,7 @@ class ColumnShardEngine(object):
         tiered plan, at least two layers (ELIMREC_FUSE_ADAM=0 keeps the separate optimizer launch; `keep_grad` = True also
         stores the gradient table, for tests that read it)."""
         import os
-        return (not self.bf16 and not self.wide and self.planT.tiered and self.model.n_layers >= 2
+        return (not self.bf16 and not self.wide and not self.sweep and self.planT.tiered and self.model.n_layers >= 2
                 and os.environ.get("ELIMREC_FUSE_ADAM", "1") != "0")
 
     @_once
@@ -792,7 +801,7 @@ class ColumnShardEngine(object):
         import os
         m = self.model
         hops_in_region = m.n_layers - (1 if self._fuse_adam() else 0)
-        return (os.environ.get("ELIMREC_FUSE_REDUCE", "1") != "0" and not self.bf16 and not self.wide and self.planT.tiered
+        return (os.environ.get("ELIMREC_FUSE_REDUCE", "1") != "0" and not self.bf16 and not self.wide and not self.sweep and self.planT.tiered
                 and hops_in_region >= 1 and m.mm_fusion_mode == "concat")
 
     @_once

@@ -62,7 +62,7 @@ def _is_pow2(x):
 class SellPlan(object):
     """SELL-64 work items of a CSR matrix on a device (struct elimrec_sell)."""
 
-    def __init__(self, m, device, threshold=LONG_ROW_THRESHOLD, side_split=None, tiered=None, ipw=8, phase=None):
+    def __init__(self, m, device, threshold=LONG_ROW_THRESHOLD, side_split=None, tiered=None, ipw=8, phase=None, rows_from=0, share=None):
         """side_split = U: the unsplit rows are processed side by side (item rows, then user rows; by decreasing
         length inside a side) instead of by length alone -- all workgroups then gather from the same side's rows at
         the same time, which is what an XCD's L2 can hold (users read items by popularity, items read the whole,
@@ -90,6 +90,9 @@ class SellPlan(object):
         T2 = int(os.environ.get("ELIMREC_SLAB_T2", 256 * ipw)) if tiered else T
         long_rows = np.nonzero(deg > T)[0]
         short_rows = np.nonzero(deg <= T)[0]
+        if rows_from:                # a plan of rows [rows_from, n) only: the rows below belong to another launch (SweepPlan)
+            long_rows, short_rows = long_rows[long_rows >= rows_from], short_rows[short_rows >= rows_from]
+        self.sweep = None
         w1 = long_rows[deg[long_rows] <= T1]
         w4 = long_rows[(deg[long_rows] > T1) & (deg[long_rows] <= T2)]
         w1 = w1[np.argsort(-deg[w1], kind="stable")]
@@ -121,9 +124,14 @@ class SellPlan(object):
         self.threshold = T
         self.tiered, self.n_w1, self.n_w4 = bool(tiered), int(len(w1)), int(len(w4))
         self.t = dict(long_rows=t(long_rows if len(long_rows) else np.zeros(1), np.int32),
-                      long_seg_ptr=t(seg_ptr, np.int32), long_index=t(long_index, np.int32),
-                      rowptr=t(rowptr, np.int64), csr_col=t(col if len(col) else np.zeros(1), np.int32),
-                      csr_val=t(val if len(val) else np.zeros(1), np.float32))
+                      long_seg_ptr=t(seg_ptr, np.int32), long_index=t(long_index, np.int32))
+        if share is not None:        # a plan of some rows of the SAME matrix as `share` (SweepPlan.items): one CSR copy on the device
+            self.t.update({k: share.t[k] for k in ("rowptr", "csr_col", "csr_val")})
+            self.shared = ("rowptr", "csr_col", "csr_val")
+        else:
+            self.t.update(rowptr=t(rowptr, np.int64), csr_col=t(col if len(col) else np.zeros(1), np.int32),
+                          csr_val=t(val if len(val) else np.zeros(1), np.float32))
+            self.shared = ()
         p = lambda k: self.t[k].data_ptr() if k in self.t else None
         if tiered:
             tiles = self._wave_tiles(int(ipw), rowptr, col, val, deg, w4, w1, seg_beg[so], seg_len[so], so, seg_row[so], short_rows[ro])
@@ -256,6 +264,133 @@ class SellPlan(object):
         return 8 * self.sell_entries + 8 * self.n_items + 4 * (self.n_items // 64 + 1)
 
 
+class SweepPlan(object):
+    """The rows [0, n_sweep) of a bipartite adjacency -- one side, whose sources [n_sweep, n) are a table far beyond the caches --
+    as the window-sweep hop takes them (csrc/sweep.hip, elimrec_slab_sweep_hop), beside a tile plan of the OTHER side's rows:
+    a full hop of `plan` is then the tile hop over `items` (rows >= n_sweep, which gather from the small side) + the sweep over
+    the rows below (models/EliMRec.py:243-247; BASELINE.json configs[3] / [4]: 36 k / 1 M user rows gathering from 1.2 M / 100 M
+    item rows). Row blocks and entry streams depend on the table geometry (LDS rows per workgroup, XCD roles per slab) and are
+    made per (ns, w)."""
+
+    BPX = int(os.environ.get("ELIMREC_SWEEP_BPX", "32"))            # workgroups per XCD role (32 CUs per XCD)
+
+    def __init__(self, plan, m, n_sweep, device, threshold, ipw):
+        m = m.tocsr()
+        m.sort_indices()
+        self.n_sweep, self.n = int(n_sweep), int(m.shape[0])
+        nnz = int(m.indptr[self.n_sweep])
+        assert m.shape[0] == m.shape[1] and (nnz == 0 or int(m.indices[:nnz].min()) >= self.n_sweep), \
+            "the swept rows must gather from rows >= n_sweep only"
+        self.items = SellPlan(m, device, threshold=threshold, side_split=None, tiered=True, ipw=ipw, rows_from=self.n_sweep, share=plan)
+        self.row_nnz = np.diff(m.indptr[:self.n_sweep + 1]).astype(np.int64)
+        self._col, self._val = m.indices[:nnz].astype(np.int32), m.data[:nnz].astype(np.float32)
+        self.device = torch.device(device)
+        self._geo = {}
+
+    def window(self, w):
+        """Source rows per window: 3 MB of row pieces of an XCD's 4 MB L2 (measured at the configs[3] shape, 128-B pieces: 12 288
+        rows 892 us per hop, 16 384 879, 24 576 875, 32 768 875)."""
+        return int(os.environ.get("ELIMREC_SWEEP_WINDOW", (3 << 20) // (4 * w)))
+
+    def geometry(self, ns, w):
+        """For tables of ns slabs x w floats: the swept rows cut into parts x passes x bpx contiguous blocks of about equal
+        non-zero counts (none above the LDS capacity), their entries ordered by (block, source window, row, column) -- a stable
+        sort of the CSR order -- and every (block, window) cut at row boundaries into 64 chunks of about equal length."""
+        key = (ns, w)
+        if key not in self._geo:
+            cap = int(_lib.load().elimrec_slab_sweep_lds_rows(int(w)))
+            parts, bpx, n = 8 // min(ns, 8), self.BPX, self.n_sweep
+            passes = max(1, -(-n // (parts * bpx * cap)))
+            nb = parts * passes * bpx
+            cum = np.concatenate([[0], np.cumsum(self.row_nnz)])
+            want = np.searchsorted(cum, np.arange(1, nb) * (cum[-1] / nb))          # equal non-zeros ...
+            ptr = np.zeros(nb + 1, np.int64)
+            ptr[-1] = n
+            for k in range(1, nb):                                                   # ... under the row cap, leaving room for the rest
+                ptr[k] = min(max(int(want[k - 1]), ptr[k - 1], n - (nb - k) * cap), ptr[k - 1] + cap, n)
+            assert np.all(np.diff(ptr) >= 0) and np.diff(ptr).max() <= cap, "sweep blocks do not fit"
+            rows = np.repeat(np.arange(n, dtype=np.int64), self.row_nnz)
+            blk = np.searchsorted(ptr, rows, side="right") - 1
+            rloc = rows - ptr[blk]
+            win = (self._col.astype(np.int64) - n) // self.window(w)
+            n_win = int(win.max()) + 1 if len(win) else 1
+            # rows to the waves of their block's workgroup: by decreasing length, dealt forth and back -- equal non-zero counts
+            lpr = w // 4
+            G, NW = 64 // lpr, lpr
+            blk_of_row = np.searchsorted(ptr, np.arange(n), side="right") - 1
+            by_len = np.lexsort((-self.row_nnz, blk_of_row))
+            pos = np.arange(n) - ptr[blk_of_row[by_len]]
+            snake = np.where((pos // NW) % 2 == 0, pos % NW, NW - 1 - pos % NW)
+            wave_of_row = np.empty(n, np.int64)
+            wave_of_row[by_len] = snake
+            # entries by (block, wave, window), rows ascending inside (stable: the CSR order is kept), then every such cell cut at
+            # row boundaries into G chunks of about equal length
+            cell = (blk * NW + wave_of_row[rows]) * n_win + win
+            order = np.argsort(cell, kind="stable")
+            n_cells = nb * NW * n_win
+            cell_ptr = np.concatenate([[0], np.cumsum(np.bincount(cell, minlength=n_cells))]).astype(np.int64)
+            srow, scell = rows[order], cell[order]
+            first = np.concatenate([[True], (srow[1:] != srow[:-1]) | (scell[1:] != scell[:-1])]) if len(srow) else np.zeros(0, bool)
+            starts = np.nonzero(first)[0]                                            # cut points allowed: an entry that opens a row of a cell
+            k = np.arange(G + 1, dtype=np.int64)[None, :]
+            ideal = (cell_ptr[:-1, None] + ((cell_ptr[1:] - cell_ptr[:-1])[:, None] * k) // G).reshape(-1)
+            cut = starts[np.minimum(np.searchsorted(starts, ideal), len(starts) - 1)] if len(starts) else ideal
+            cut = np.minimum(np.maximum(cut.reshape(-1, G + 1), cell_ptr[:-1, None]), cell_ptr[1:, None])
+            cut[:, 0], cut[:, -1] = cell_ptr[:-1], cell_ptr[1:]
+            cut = np.maximum.accumulate(cut, axis=1)
+            # every chunk as 80-byte step records (8 source rows | 8 values | 8 block-relative rows, 16 bit, 0xffff = none); all G
+            # chunks of a (block, wave, window) cell get the cell's longest chunk's record count, and the records go [step][group]
+            csz = cut[:, 1:] - cut[:, :-1]                                         # [cells, G] entries per chunk
+            cell_steps = ((csz + 7) // 8).max(axis=1)                              # steps of a cell
+            step_ptr = np.concatenate([[0], np.cumsum(cell_steps)]).astype(np.int64)
+            n_steps = int(step_ptr[-1])
+            dummy = int(np.diff(ptr).max())                                        # the row behind every block's rows
+            rec = np.zeros(((n_steps + 8) * G, 20), np.int32)                      # (+ the kernel's read-ahead past the last step)
+            rows16 = np.full(((n_steps + 8) * G, 8), dummy, np.uint16)
+            chunk_of = np.repeat(np.arange(csz.size, dtype=np.int64), csz.reshape(-1))   # chunk of every (sorted) entry
+            p_in = np.arange(len(chunk_of), dtype=np.int64) - np.repeat(cut[:, :-1].reshape(-1), csz.reshape(-1))
+            ri = (step_ptr[chunk_of // G] + p_in // 8) * G + chunk_of % G
+            si = p_in % 8
+            rec[ri, si] = (self._col[order].astype(np.int64) * lpr).astype(np.uint32).view(np.int32)
+            rec[ri, 8 + si] = self._val[order].view(np.int32)
+            rows16[ri, si] = rloc[order].astype(np.uint16)
+            rec[:, 16:20] = rows16.view(np.int32)
+            slot_ptr = step_ptr[::n_win]                                           # per (block, wave): its cells are consecutive
+            t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a.astype(dt))).to(self.device)
+            self._geo[key] = dict(block_ptr=t(ptr, np.int32), slot_ptr=t(slot_ptr, np.int64), rec=t(rec.reshape(-1), np.int32),
+                                  parts=parts, passes=passes, bpx=bpx, rows=int(np.diff(ptr).max()), n_win=n_win, n_rec=n_steps * G,
+                                  fill=float(len(order)) / max(8 * n_steps * G, 1))
+        return self._geo[key]
+
+    def index_bytes(self, ns, w):
+        """Index bytes one hop reads: the records of the swept side + the tile plan of the other."""
+        return 80 * int(self.geometry(ns, w)["n_rec"]) + self.items.index_bytes()
+
+    def device_bytes(self):
+        """Device memory of this plan beyond the whole-graph plan it sits beside."""
+        own = sum(v.numel() * v.element_size() for k, v in self.items.t.items() if k not in self.items.shared)
+        own += sum(v.numel() * v.element_size() for v in self.items._partials.values())
+        return own + sum(v.numel() * v.element_size() for g in self._geo.values() for v in g.values() if hasattr(v, "numel"))
+
+    def hop(self, xin, xout, add=None, add_mask=None, scale=1.0):
+        ns, w = xin.ns, xin.w
+        g = self.geometry(ns, w)
+        _lib.check(_lib.load().elimrec_slab_sweep_hop(_dev(g["slot_ptr"], "slot_ptr", torch.int64), _dev(g["rec"], "records", torch.int32), self.n, self.n,
+                                                      _dev(g["block_ptr"], "block_ptr", torch.int32), g["parts"], g["passes"], g["bpx"],
+                                                      g["rows"], ns, w, _dev(xin.data, "xin"), _dev(xout.data, "xout"),
+                                                      _dev(None if add is None else add.data, "add"),
+                                                      _dev(add_mask, "add_mask", torch.int32), float(scale), _stream()), "slab_sweep_hop")
+
+
+def sweep_wanted(n_rows, dl):
+    """Tables whose column slice is beyond the Infinity Cache (256 MB) take the window-sweep form for the side that gathers from
+    the large side (ELIMREC_SWEEP=1 / 0 forces it on / off)."""
+    env = os.environ.get("ELIMREC_SWEEP", "")
+    if env in ("0", "1"):
+        return env == "1"
+    return n_rows * dl * 4 > (256 << 20)
+
+
 class SlabTable(object):
     """[n x (ns*w)] table stored slab-major in one flat tensor; fp32, or bf16 for the bf16-storage mode."""
 
@@ -319,6 +454,12 @@ def hop(plan, xin, xout, gs=None, src_mask=None, add=None, add_mask=None, scale=
     0: its partial launch, run as extra workgroups of this launch (fp32 tables, tiered plan: elimrec_slab_hop_bwd_w)."""
     ns, w = xin.ns, xin.w
     gs = choose_groups(ns) if gs is None else gs
+    if (plan.sweep is not None and src_mask is None and not seg_only and bwd_w is None and not xin.bf16 and isinstance(xout, SlabTable)
+            and not xout.bf16 and w in (16, 32)):
+        # a whole fp32 hop of a graph with a swept side: the tile hop over the other side's rows, the window sweep over this side's
+        hop(plan.sweep.items, xin, xout, gs=gs, add=add, add_mask=add_mask, scale=scale)
+        plan.sweep.hop(xin, xout, add=add, add_mask=add_mask, scale=scale)
+        return
     part = plan.partials(ns, w)
     out = xout if isinstance(xout, torch.Tensor) else xout.data
     lib = _lib.load()

@@ -595,6 +595,27 @@ int elimrec_slab_hop(const elimrec_sell *A, int ns, int w, int gs, const float *
                      const uint32_t *d_src_mask, float *d_Xout, const float *d_add,
                      const uint32_t *d_add_mask, float scale, float *d_partials, size_t partials_bytes,
                      int seg_only, void *stream);
+/* The same hop for the rows [0, n_sweep) of ONE side of a bipartite graph whose SOURCE side is a table far beyond the caches
+ * (the user rows of BASELINE.json configs[3] / configs[4]; models/EliMRec.py:243-247 for one column slice), csrc/sweep.hip:
+ * the rows are cut into contiguous blocks (d_block_ptr int32 [parts * passes * bpx + 1], each <= max_block_rows <=
+ * elimrec_slab_sweep_lds_rows(w) rows: a block's output pieces stay in one workgroup's LDS), parts = 8 / min(ns, 8) row parts
+ * per slab, bpx workgroups per XCD role, every workgroup takes `passes` blocks one after the other. A block's rows are dealt
+ * to the workgroup's waves (w / 4 of them); a wave's non-zeros are laid out window by window (windows of the source range that
+ * fit L2), row by row inside a window, columns ascending inside a row, every (wave, window) cut at row boundaries into one
+ * chunk per lane group (G = 256 / w per wave) and every chunk into 80-byte step records -- uint32 (source row * w / 4) x 8 |
+ * fp32 value x 8 | uint16 (row - the block's first row) x 8; a slot without an entry holds source 0, value 0 and row
+ * max_block_rows (a dummy row) -- the same number of records for all lane groups of a (wave, window). d_records holds them as
+ * [step][lane group], followed by 8 all-empty steps (the kernel's read-ahead); d_slot_ptr int64 [n_blocks * waves + 1] are
+ * the waves' stretches in steps. All waves
+ * then gather from two or three windows of the source range at a time, and a source piece leaves L2 once per XCD instead of
+ * once per neighbour. A row is summed over its neighbours in column order with fmaf (a fixed order). Rows >= n_sweep are not
+ * touched: they are elimrec_slab_hop's on a plan of those rows. w = 32 or 16. */
+size_t elimrec_slab_sweep_lds_rows(int w);
+int elimrec_slab_sweep_hop(const int64_t *d_slot_ptr, const void *d_records,
+                           int64_t n_rows, int64_t n_src, const int32_t *d_block_ptr, int parts, int passes, int bpx,
+                           int max_block_rows, int ns, int w, const float *d_Xin, float *d_Xout,
+                           const float *d_add, const uint32_t *d_add_mask, float scale, void *stream);
+
 /* Tiered plans look the source bitmap up once per index entry before a masked hop (one 64-bit word per index line, kept
  * in d_partials). This entry runs that pass alone -- e.g. on a second stream as soon as the batch's active rows are
  * known -- and elimrec_slab_hop with bit 1 of `seg_only` set (seg_only = 2) then skips it. The bitmap passed to both

@@ -104,3 +104,6 @@ def test_capacity_plan_matches_the_device_allocator_at_the_scaled_c5_shape():
     st = capacity.stats_of(eng.plan)
     est = capacity.PLAN_BYTES_PER_NNZ * st["nnz"] + capacity.PLAN_BYTES_PER_ROW * (U + I)
     assert abs(est - st["index_bytes"]) < 0.10 * st["index_bytes"], (est, st["index_bytes"])
+    # ... and of the window-sweep plan this shape's whole hops run on (a [N x 256] slice is 2 GB: beyond the Infinity Cache)
+    assert eng.sweep and abs(capacity.SWEEP_BYTES_PER_NNZ * st["nnz"] - st["sweep_bytes"]) < 0.25 * st["sweep_bytes"], (
+        capacity.SWEEP_BYTES_PER_NNZ * st["nnz"], st["sweep_bytes"])

@@ -84,6 +84,100 @@ def test_slab_hop_vs_torch(d, w, gs):
     assert (y.dense().double() - (A64 @ Sm + Sm) * 0.25).abs().max().item() < 1e-5
 
 
+def _bipartite(U, I, seed, hot=5):
+    """A symmetric bipartite graph [[0, R], [R^T, 0]]: ragged user rows (some empty, a few hot), Zipf-ish items, fp32 weights."""
+    rng = np.random.RandomState(seed)
+    deg = rng.poisson(40, U)
+    deg[rng.rand(U) < 0.03] = 0
+    deg[rng.choice(U, hot, replace=False)] = 900 + rng.randint(0, 90, hot)
+    r = np.repeat(np.arange(U), deg)
+    c = np.minimum((I * rng.rand(len(r)) ** 1.7).astype(np.int64), I - 1)
+    R = sp.csr_matrix((rng.rand(len(r)).astype(np.float32) + 0.1, (r, c)), shape=(U, I))
+    R.sum_duplicates()
+    m = sp.bmat([[None, R], [R.T, None]], format="csr").astype(np.float32)
+    m.sort_indices()
+    return m
+
+
+@pytest.mark.parametrize("d,w,U,I,window", [(128, 32, 3000, 20000, 1024), (64, 32, 700, 9000, 512), (256, 32, 2100, 6000, 4096),
+                                             (512, 32, 300, 5000, 700), (32, 16, 900, 7000, 333), (16, 16, 40000, 3000, 256)])
+def test_window_sweep_hop_equals_the_tile_hop(d, w, U, I, window, monkeypatch):
+    """elimrec_slab_sweep_hop (csrc/sweep.hip) + the tile hop over the item rows = the tile hop over all rows: the item rows bit
+    for bit (same kernel, same tiles), the user rows to fp32 round-off of another fixed summation order (a row's neighbours in
+    column order, one fmaf chain) -- which is checked exactly against that order evaluated in fp64-free torch arithmetic on a few
+    rows --, with the adjoint's add / add_mask / scale epilogue, at 1 / 2 / 4 / 8 / 16 slabs (8, 4, 2, 1 row parts per slab, several
+    slabs per XCD role), row blocks beyond one pass (U = 40 000 at 16-float pieces), windows that do not divide the range, and
+    bitwise equal from launch to launch."""
+    from elimrec_amd import slab
+    monkeypatch.setenv("ELIMREC_SWEEP_WINDOW", str(window))
+    n = U + I
+    m = _bipartite(U, I, d + w)
+    ns = d // w
+    gs = slab.choose_groups(ns)
+    ipw = 64 // ((ns // gs) * (w // 4))
+    plan = slab.SellPlan(m, DEV, threshold=64, side_split=U, tiered=True, ipw=ipw)
+    torch.manual_seed(U)
+    X = torch.randn(n, d, device=DEV)
+    xs = slab.SlabTable(n, ns, w, DEV).from_rows(X)
+    ref = xs.like()
+    slab.hop(plan, xs, ref, gs=gs)
+    plan.sweep = slab.SweepPlan(plan, m, U, DEV, threshold=64, ipw=ipw)
+    got = xs.like()
+    got.data.fill_(float("nan"))
+    slab.hop(plan, xs, got, gs=gs)
+    a, b = ref.dense(), got.dense()
+    assert torch.equal(a[U:], b[U:])
+    assert (a[:U] - b[:U]).abs().max().item() < 2e-5 * max(1.0, a.abs().max().item())
+    g = plan.sweep.geometry(ns, w)
+    assert g["parts"] == 8 // min(ns, 8) and g["rows"] <= 1247 * (32 // w) + 1 and (U <= 1247 * 32 * g["parts"] or g["passes"] > 1)
+    # the stated order, exactly: fmaf over the neighbours in column order
+    rows = [0, U // 3, U - 1] + np.argsort(-np.diff(m.indptr[:U + 1]))[:2].tolist()
+    for r in rows:
+        cols, vals = m.indices[m.indptr[r]:m.indptr[r + 1]], m.data[m.indptr[r]:m.indptr[r + 1]]
+        acc = np.zeros(d, np.float32)
+        Xh = X[torch.from_numpy(cols.astype(np.int64)).to(DEV)].cpu().numpy() if len(cols) else np.zeros((0, d), np.float32)
+        for v, x in zip(vals, Xh):
+            acc = (np.float64(v) * x.astype(np.float64) + acc.astype(np.float64)).astype(np.float32)      # fmaf: one rounding
+        assert np.array_equal(b[r].cpu().numpy(), acc), r
+    # the adjoint's epilogue, and a second launch of the same call
+    act = torch.rand(n, device=DEV) < 0.3
+    bm = _bitmap(act)
+    S = torch.randn(n, d, device=DEV)
+    ss = slab.SlabTable(n, ns, w, DEV).from_rows(S)
+    want = (torch.from_numpy(m.astype(np.float64).toarray()).to(DEV) @ X.double() + S.double() * act[:, None]) * 0.25 if n <= 30000 else None
+    y1, y2 = xs.like(), xs.like()
+    slab.hop(plan, xs, y1, gs=gs, add=ss, add_mask=bm, scale=0.25)
+    slab.hop(plan, xs, y2, gs=gs, add=ss, add_mask=bm, scale=0.25)
+    assert torch.equal(y1.data, y2.data)
+    if want is not None:
+        assert (y1.dense().double() - want).abs().max().item() < 1e-4
+    assert torch.equal(y1.dense()[:U], ((b[:U] + S[:U] * act[:U, None]) * 0.25))
+
+
+def test_trainer_with_the_window_sweep_matches_the_reference_fixtures(monkeypatch):
+    """ELIMREC_SWEEP=1 forces the large-table form of the hops on the small fixtures: whole hops = tile hop over the item rows +
+    window sweep over the user rows, no tails on the hops (Adam and the weight gradients in launches of their own). Three trainer
+    steps reproduce the reference's golden losses and parameters, as the default form does."""
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
+    monkeypatch.setenv("ELIMREC_SWEEP", "1")
+    monkeypatch.setenv("ELIMREC_SWEEP_WINDOW", "64")
+    for name in ("ml3", "kwai", "gcmc"):
+        g = load_golden(name)
+        model, cfg = build_model_from_fixture(g, DEV)
+        opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+        eng = ColumnShardEngine(model)
+        tr = ColumnShardTrainer(eng, opt)
+        assert eng.sweep and eng.plan.sweep is not None and not eng._fuse_adam()
+        steps = int(g["steps"])
+        for t in range(1, steps + 1):
+            loss = tr.step(*(_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg")))
+            assert abs(float(loss) - float(g["step%d/loss" % t])) < 1e-5, (name, t)
+        eng.sync_to_model()
+        sd = model.state_dict()
+        for k, v in sub(g, "after%d" % steps).items():
+            assert np.abs(sd[k].cpu().numpy() - v).max() < 2e-5, (name, k)
+
+
 @pytest.mark.parametrize("d,w,L", [(64, 32, 3), (16, 16, 2), (8, 8, 4), (64, 8, 1), (32, 32, 3)])
 def test_slab_rows_layer_means_and_inline_last_hop(d, w, L):
     """elimrec_slab_rows: the layer means at listed rows with hop L evaluated inline (split rows from the seg_only

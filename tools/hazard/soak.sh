@@ -5,7 +5,7 @@
 cd "$(dirname "$0")/build" || exit 0
 mkdir -p ../../../gpurun_out/hazard
 {
-  echo "== $(date -u +%FT%TZ) gpu unique_id: $(cat /sys/class/drm/card*/device/unique_id 2>/dev/null | tr '\n' ' ') host $(hostname)"
+  echo "== $(date -u +%FT%TZ) gpu unique_id: $(cat /sys/class/drm/card*/device/unique_id 2>/dev/null | tr '\n' ' ') visible ${ROCR_VISIBLE_DEVICES:-?}/${HIP_VISIBLE_DEVICES:-?} host $(hostname)"
   for lib in lib_old_slp.so lib_slp.so; do
     [ -f $lib ] || continue
     timeout 200 ./scorer_repro ./$lib ${REPS:-1500} 1 2 64 1 2>&1 | tail -8

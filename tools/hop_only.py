@@ -41,6 +41,16 @@ T = int(os.environ.get("T", 64 if tiered else 32))
 plan = slab.SellPlan(adj, dev, phase=phase, side_split=None if os.environ.get("RELABEL") == "1" else U, tiered=tiered, threshold=T, ipw=64 // ((ns // gs) * (w // (8 if bf16 else 4))))
 torch.manual_seed(0)
 tabs = [slab.SlabTable(N, ns, w, dev).from_rows(torch.randn(N, d, device=dev)) for _ in range(3)]
+if os.environ.get("SWEEP") == "1":           # the user rows by the window sweep (csrc/sweep.hip), the item rows by a tile plan of their own
+    ref = slab.SlabTable(N, ns, w, dev)
+    slab.hop(plan, tabs[0], ref, gs=gs)
+    plan.sweep = slab.SweepPlan(plan, adj, U, dev, threshold=T, ipw=64 // ((ns // gs) * (w // 4)))
+    got = slab.SlabTable(N, ns, w, dev)
+    slab.hop(plan, tabs[0], got, gs=gs)
+    a, b = ref.dense(), got.dense()
+    print("sweep vs tile hop: max |diff| users %.3e items %.3e (max |value| %.3e); blocks %s window %d" % (
+        (a[:U] - b[:U]).abs().max().item(), (a[U:] - b[U:]).abs().max().item(), a.abs().max().item(),
+        {k: (round(v, 3) if isinstance(v, float) else v) for k, v in plan.sweep.geometry(ns, w).items() if not hasattr(v, "shape")}, plan.sweep.window(w)))
 if n_out != N:                              # rectangular: every hop reads table 0 and writes an [n_out x d] table
     outs = [slab.SlabTable(n_out, ns, w, dev) for _ in range(2)]
 if bf16:
@@ -62,4 +72,14 @@ run(40)
 e1.record()
 torch.cuda.synchronize()
 print("%.2f us per hop" % (e0.elapsed_time(e1) * 1e3 / 40))
+if getattr(plan, "sweep", None) is not None:
+    for name, fn in (("tile hop over the item rows", lambda: slab.hop(plan.sweep.items, tabs[0], tabs[1], gs=gs)),
+                     ("window sweep over the user rows", lambda: plan.sweep.hop(tabs[0], tabs[1]))):
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(20): fn()
+        e1.record()
+        torch.cuda.synchronize()
+        print("  %s: %.2f us" % (name, e0.elapsed_time(e1) * 1e3 / 20))
 print("geometry ns=%d w=%d gs=%d, %d hops, index bytes %d" % (ns, w, gs, hops, plan.index_bytes()))
