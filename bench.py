@@ -25,6 +25,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")      # before the HIP runtime initialises (elimrec_amd/__init__.py has the measurements)
 
 WORKLOAD = dict(name="tiktok-shape-synthetic", num_users=36656, num_items=76085, num_interactions=720829,
                 feat_dims=(128, 128, 128), recdim=64, layer_num=3, batch_size=2048, alpha=0.5)

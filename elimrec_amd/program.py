@@ -70,12 +70,45 @@ def sync(waiter, signaller):
         tr.append(("sync", int(waiter.cuda_stream), int(signaller.cuda_stream)))
 
 
+class Recorded(object):
+    """An event recorded on a stream at one point of the step (record()), for a wait() issued LATER from another stream: unlike
+    sync(), work enqueued on the signalling stream between the two is not waited for."""
+
+    def __init__(self, event, stream, token):
+        self.event, self.stream, self.token = event, stream, token
+
+
+def record(stream):
+    """Record an event on `stream` now; reported to an active tracer as ("record", stream, n-th record of this trace)."""
+    import torch
+    ev = torch.cuda.Event()
+    ev.record(stream)
+    tr = _lib.load()._trace
+    token = None
+    if tr is not None:
+        token = sum(1 for it in tr if it[0] == "record")
+        tr.append(("record", int(stream.cuda_stream), token))
+    return Recorded(ev, stream, token)
+
+
+def wait(waiter, recorded):
+    """waiter waits for the event of record(); reported to an active tracer."""
+    waiter.wait_event(recorded.event)
+    tr = _lib.load()._trace
+    if tr is not None:
+        if recorded.token is None:
+            raise RuntimeError("program.wait: the event was recorded outside this trace")
+        tr.append(("wait", int(waiter.cuda_stream), recorded.token))
+
+
 def words_of(trace):
     """[(kind, name, [words])] of a trace: calls with packed arguments, syncs as (waiter, signaller)."""
     out = []
     for it in trace:
         if it[0] == "sync":
             out.append(("sync", None, [it[1], it[2]]))
+        elif it[0] in ("record", "wait"):
+            out.append((it[0], None, [it[1], it[2]]))
         else:
             _, name, fn, args = it
             types = fn.argtypes
@@ -91,8 +124,14 @@ class StepProgram(object):
         lib = _lib.load()
         table = _fn_table()
         ops, index_of = [], {}
-        n_events = 0
+        n_events = sum(1 for kind, _, _ in items if kind == "record")      # events 0 .. of record() / wait(), then one per sync()
         for k, (kind, name, words) in enumerate(items):
+            if kind in ("record", "wait"):
+                op = _lib.ProgramOp()
+                op.kind, op.fn = (OP_RECORD if kind == "record" else OP_WAIT), 0
+                op.args[0], op.args[1] = words[0], words[1]
+                ops.append(op)
+                continue
             if kind == "sync":
                 waiter, signaller = words
                 rec, wait = _lib.ProgramOp(), _lib.ProgramOp()
@@ -180,8 +219,8 @@ def diff_traces(a, b, known_a, known_b):
         for j, (u, v) in enumerate(zip(xa, xb)):
             if u == v:
                 continue
-            if ka == "sync":
-                raise ValueError("stream handles differ between the traces")
+            if ka in ("sync", "record", "wait"):
+                raise ValueError("stream handles or event numbers differ between the traces")
             label = next((lab for lab in known_a if known_a[lab] == u and known_b[lab] == v), None)
             if label is not None:
                 varying[(k, j)] = label

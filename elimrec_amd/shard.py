@@ -117,11 +117,14 @@ class ColumnShardTrainer(object):
     class _OnStream(object):
         """Handle of a collective enqueued on the exchange stream: wait() orders the CURRENT stream behind it."""
 
-        def __init__(self, stream):
-            self.stream = stream
+        def __init__(self, stream, recorded=None):
+            self.stream, self.recorded = stream, recorded
 
         def wait(self):
-            program.sync(torch.cuda.current_stream(), self.stream)
+            if self.recorded is not None:       # the collective alone: not what was enqueued behind it on that stream since
+                program.wait(torch.cuda.current_stream(), self.recorded)
+            else:
+                program.sync(torch.cuda.current_stream(), self.stream)
             return True
 
     def _native_comm(self):
@@ -151,7 +154,11 @@ class ColumnShardTrainer(object):
                 if self.world > 1:
                     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)      # all ranks or none
                 if int(flag.item()) == 1:
-                    self._comm, self._comm_stream = handle, torch.cuda.Stream()
+                    # the exchanges that run beside the main stream (ids, constants' rows, weight gradients) share the engine's
+                    # second stream with the plan they follow: one hand-over fewer on the way plan -> ids -> rows (each costs
+                    # 10-20 us of command-processor latency), and the stream's order is the order they are needed in
+                    aux = self.engine._aux_stream() if hasattr(self.engine, "_aux_stream") else None
+                    self._comm, self._comm_stream = handle, (aux if aux is not None else torch.cuda.Stream())
                 elif handle:
                     lib.elimrec_comm_destroy(handle)
         return self._comm or None
@@ -165,11 +172,15 @@ class ColumnShardTrainer(object):
         """after: the stream that produced `inp` when it is not the current one (the planner's second stream)."""
         comm = self._native_comm()
         if comm is not None:            # on the exchange stream, under whatever the caller enqueues next on its own
-            program.sync(self._comm_stream, after if after is not None else torch.cuda.current_stream())
+            src = after if after is not None else torch.cuda.current_stream()
+            if src is not self._comm_stream and src.cuda_stream != self._comm_stream.cuda_stream:
+                program.sync(self._comm_stream, src)
             with torch.cuda.stream(self._comm_stream):
                 _lib.check(_lib.load().elimrec_comm_all_gather(comm, inp.data_ptr(), out.data_ptr(), inp.numel() * inp.element_size(),
                                                                ops._stream()), "comm_all_gather")
-            return self._OnStream(self._comm_stream)
+            # (an event of its own: the constants' row exchange is enqueued on this stream right behind, and whoever needs the
+            # ids only -- the rows launch, the source bits -- must not wait for that)
+            return self._OnStream(self._comm_stream, program.record(self._comm_stream))
         if after is not None:
             program.sync(torch.cuda.current_stream(), after)
         if not self._staged(inp):
@@ -408,7 +419,19 @@ class ColumnShardTrainer(object):
             sizes = self._lookup_sizes(users, None)
             values["sizes"] = ctypes.addressof(sizes)
             self.xgmi_bytes["all_to_all_lookup"] = sum(sizes[:self.world]) - sizes[self.rank]
+        depth = self._native.get("throttle")
+        if depth is None:
+            import os
+            depth = self._native["throttle"] = int(os.environ.get("ELIMREC_NATIVE_THROTTLE", "0"))
+        if depth:                                            # (experiment: the host at most `depth` steps ahead of the GPU)
+            ring = self._native.setdefault("ring", [])
+            if len(ring) >= depth:
+                ring.pop(0).synchronize()
         prog.run(values)
+        if depth:
+            ev = torch.cuda.Event()
+            ev.record()
+            self._native["ring"].append(ev)
         eng.native_epilogue(3 * B)
         self._native["native_steps"] += 1
         return loss
@@ -433,8 +456,6 @@ class ColumnShardTrainer(object):
             acts = self._like("acts", act, W)
             h_ids = self._all_gather(acts.view(-1), act, after=eng.plan_stream() if self._hip_engine else None)
             self.xgmi_bytes["all_gather"] = act.numel() * 4 * (W - 1)
-            if self._hip_engine:
-                eng.cs_gathered_ids(acts, h_ids)                   # second stream: the adjoint's source bits, a forward pass early
         else:
             acts = act.view(1, -1)
         if not early:
@@ -446,7 +467,12 @@ class ColumnShardTrainer(object):
             # behind the id exchange and UNDER the forward hops (pack, all_to_all_v, unpack); the head joins it
             with torch.cuda.stream(self._comm_stream):
                 self._lookup_exchange(users, acts)
+                lookup_rec = program.record(self._comm_stream)
             lookup_early = True
+        if self.multi and self._hip_engine:
+            eng.cs_gathered_ids(acts, h_ids)                       # second stream, behind the exchanges: the adjoint's source bits
+        if self.multi and self._hip_engine:
+            eng.cs_forward_long()                                  # the split rows of hop L need neither ids nor plan: ahead of the waits
         if h_ids is not None:
             h_ids.wait()
         send = ph["cs_forward_rows"](acts)                         # [W, R, 2*dl]: layer means of the peers' rows, my columns
@@ -456,6 +482,8 @@ class ColumnShardTrainer(object):
             recv = self._like("recv_f", send)
             self._all_to_all(recv, send)
             self.xgmi_bytes["all_to_all_fwd"] = send[0].numel() * 4 * (W - 1)
+            if lookup_early:
+                program.wait(torch.cuda.current_stream(), lookup_rec)             # the looked-up rows: the head reads them
         else:
             recv = send
         loss = ph["cs_head"](recv)                                 # my rows, every rank's columns -> loss, head backward
@@ -899,6 +927,9 @@ class ColumnShardEngine(object):
                 self._rows_in_head = (self._head_split and self._rows_in_head_on and not self.multi and not self.bf16 and not self.wide
                                       and self.dl == 64 and self.ns * self.w == 64)
         self._aux_pending = True
+        # several ranks: the second stream goes on to the adjoint's source bits once the ids are gathered (cs_gathered_ids); what
+        # the forward joins is the plan and the packed weights, recorded here
+        self._plan_rec = program.record(aux) if self.multi else None
         return act
 
     def plan_stream(self):
@@ -929,7 +960,7 @@ class ColumnShardEngine(object):
                 slab.source_bits(self.planT, self.hns, self.w, self.hgs, self.mask)
             m._region("cs_bits", (m._ws_gen, acts.data_ptr(), acts.shape[0], acts.shape[1]), bits)
         self._bits_ready = True
-        self._aux_pending = True
+        self._bits_join = True                              # the adjoint's first hop joins the second stream for them
 
     def cs_fork(self):
         """One rank with the second stream: order it behind what the main stream holds NOW, so that the caller can enqueue the
@@ -975,8 +1006,16 @@ class ColumnShardEngine(object):
         tabs = self._tabs
         self._acts = acts
         late_wait = self._aux_pending and self._late_wait       # the long-rows hop needs nothing of the plan: join after it
+
+        def join_plan():
+            rec = getattr(self, "_plan_rec", None)
+            if rec is not None:                                  # (several ranks: the plan's event, not the stream's tail)
+                program.wait(torch.cuda.current_stream(), rec)
+                self._plan_rec = None
+            else:
+                program.sync(torch.cuda.current_stream(), self._aux)
         if self._aux_pending and not late_wait:                  # the plan (and the packed weights) from the second stream
-            program.sync(torch.cuda.current_stream(), self._aux)
+            join_plan()
         self._aux_pending = False
         if self.multi:
             counts = None                                        # the gathered lists are padded with negative keys
@@ -988,8 +1027,11 @@ class ColumnShardEngine(object):
             else:
                 out0, narrow, by_node = ws["OutAct"][:R, :m.latent_dim], ws["Narrow"], True
 
+        long_done = getattr(self, "_long_done", False)          # cs_forward_long issued it already (several ranks)
+        self._long_done = False
+
         def long_rows():
-            if self.plan.n_long and not self.wide:
+            if self.plan.n_long and not self.wide and not long_done:
                 slab.hop(self.plan, self._srcs[L - 1], self.long_tab, gs=self.gs, seg_only=True)
 
         def rows():
@@ -1010,7 +1052,7 @@ class ColumnShardEngine(object):
                 self.fshard.unpack(ws["active_rows"][:R], None, self.s_rows, self.c_rows, direct=True)
         if late_wait:
             m._region("cs_fwd_long%d" % self.cur, (m._ws_gen,), long_rows)
-            program.sync(torch.cuda.current_stream(), self._aux)
+            join_plan()
         if getattr(self, "_bits_late", False):
             # (the join above was recorded before this is enqueued: the forward does not wait for it; the adjoint's first hop does)
             with torch.cuda.stream(self._aux):
@@ -1019,6 +1061,18 @@ class ColumnShardEngine(object):
             self._bits_join = True
         m._region("cs_fwd_rows%d" % self.cur, (m._ws_gen, acts.data_ptr(), R, W, narrow.data_ptr(), late_wait, self._rows_in_head), rows)
         return self.send_f if self.multi else None
+
+    @torch.no_grad()
+    def cs_forward_long(self):
+        """Hop L at the split rows (the part the rows launch cannot evaluate inline) right behind the forward hops: it needs
+        nothing of the batch, so with several ranks it runs before the main stream waits for the gathered ids."""
+        m = self.model
+        if not self.plan.n_long or self.wide or self.bf16:
+            return
+        L = m.n_layers
+        m._region("cs_fwd_long_early%d" % self.cur, (m._ws_gen,),
+                  lambda: slab.hop(self.plan, self._srcs[L - 1], self.long_tab, gs=self.gs, seg_only=True))
+        self._long_done = True
 
     def cs_forward(self, acts):
         self.cs_forward_hops()

@@ -156,6 +156,78 @@ class SellPlan(object):
                                   p("tile_off"), p("tile_len"), p("tile_dst"), p("tile_long"), p("tile_col"), p("tile_val"))
         self._partials = {}
 
+    @classmethod
+    def on_device(cls, rowptr, col, val, n_src, threshold=64, side_split=None, ipw=8, rows_from=0, share=None):
+        """The tiered plan of a CSR that is ALREADY on the device (rowptr int64 [n + 1], col int32, val fp32: csrc/adj.hip's output, or
+        a rank's part of an edge list too large to plan on a host), built there by csrc/plan.hip: the arrays of SellPlan(m,
+        tiered=True, ...) bit for bit (tests/test_shard_gpu.py::test_device_plan_build_equals_the_host_plan), with two read-backs of a
+        handful of counts. T1 / T2 / segment length follow the same rules and environment switches as the host form."""
+        lib = _lib.load()
+        dev = rowptr.device
+        n_rows = int(rowptr.numel()) - 1
+        T = int(threshold)
+        T1 = int(os.environ.get("ELIMREC_SLAB_T1", (64 if ipw <= 8 else 32) * ipw))
+        T2 = int(os.environ.get("ELIMREC_SLAB_T2", 256 * ipw))
+        TS = int(os.environ.get("ELIMREC_SLAB_SEGT", T))
+        G = int(ipw)
+        split = -1 if side_split is None else int(side_split)
+        i32 = lambda n: torch.empty(max(int(n), 1), dtype=torch.int32, device=dev)
+        i64 = lambda n: torch.empty(max(int(n), 1), dtype=torch.int64, device=dev)
+        order, long_rows, long_index, seg_ptr, counts = i32(n_rows), i32(n_rows + 1), i32(n_rows), i32(n_rows + 1), i64(8)
+        ws = torch.empty(int(lib.elimrec_plan_workspace(n_rows, 1, 1)), dtype=torch.uint8, device=dev)
+        _lib.check(lib.elimrec_plan_rows(_dev(rowptr, "rowptr", torch.int64), n_rows, T, T1, T2, TS, G, split, int(rows_from),
+                                         _dev(order, "order", torch.int32), _dev(long_rows, "long_rows", torch.int32),
+                                         _dev(long_index, "long_index", torch.int32), _dev(seg_ptr, "long_seg_ptr", torch.int32),
+                                         _dev(counts, "counts", torch.int64), _dev(ws, "workspace", torch.uint8), ws.numel(), _stream()), "plan_rows")
+        n_w4, n_w1, n_split, n_short, _, n_long, n_seg = (int(x) for x in counts[:7].tolist())       # read-back 1
+        n_tiles = int(lib.elimrec_plan_tile_count(n_w4, n_w1, n_seg, n_short, G))
+        n_tseg = -(-n_seg // (4 * G)) * 4
+        need = int(lib.elimrec_plan_workspace(n_rows, n_seg, n_tiles))
+        if ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        tile_off, tile_len, tile_dst = i64(n_tiles + 1), i32(n_tiles * G), i32(n_tiles * G)
+        tile_long, gb, gs, totals = i32(n_tseg * G), i64(n_tiles * G), i32(n_tiles * G), i64(4)
+        _lib.check(lib.elimrec_plan_tiles(_dev(rowptr, "rowptr", torch.int64), n_rows, T, T1, T2, TS, G, split, int(rows_from),
+                                          _dev(order, "order", torch.int32), _dev(long_rows, "long_rows", torch.int32),
+                                          _dev(seg_ptr, "long_seg_ptr", torch.int32), n_w4, n_w1, n_split, n_short, n_long, n_seg,
+                                          _dev(tile_off, "tile_off", torch.int64), _dev(tile_len, "tile_len", torch.int32),
+                                          _dev(tile_dst, "tile_dst", torch.int32), _dev(tile_long, "tile_long", torch.int32),
+                                          _dev(gb, "gb", torch.int64), _dev(gs, "gs", torch.int32), _dev(totals, "totals", torch.int64),
+                                          _dev(ws, "workspace", torch.uint8), ws.numel(), _stream()), "plan_tiles")
+        total, seg_entries, kmax = (int(x) for x in totals[:3].tolist())                             # read-back 2
+        tile_col = torch.zeros(total + 128, dtype=torch.int32, device=dev)
+        tile_val = torch.zeros(total + 128, dtype=torch.float32, device=dev)
+        _lib.check(lib.elimrec_plan_scatter(n_tiles, G, _dev(tile_off, "tile_off", torch.int64), _dev(gb, "gb", torch.int64),
+                                            _dev(tile_len, "tile_len", torch.int32), _dev(gs, "gs", torch.int32), _dev(col, "col", torch.int32),
+                                            _dev(val, "val"), _dev(tile_col, "tile_col", torch.int32), _dev(tile_val, "tile_val"), _stream()),
+                   "plan_scatter")
+        self = object.__new__(cls)
+        self.device, self.sweep = dev, None
+        self.n_rows, self.n_src, self.nnz = n_rows, int(n_src), int(rowptr[-1])
+        self.n_seg, self.n_long, self.threshold = n_seg, n_long, T
+        self.tiered, self.n_w1, self.n_w4 = True, n_w1, n_w4
+        self.t = dict(long_rows=long_rows[:max(n_long, 1)].clone() if n_long else torch.zeros(1, dtype=torch.int32, device=dev),
+                      long_seg_ptr=seg_ptr[:n_long + 1].clone(), long_index=long_index,
+                      tile_off=tile_off, tile_len=tile_len, tile_dst=tile_dst, tile_long=tile_long, tile_col=tile_col, tile_val=tile_val)
+        if share is not None:
+            self.t.update({k: share.t[k] for k in ("rowptr", "csr_col", "csr_val")})
+            self.shared = ("rowptr", "csr_col", "csr_val")
+        else:
+            self.t.update(rowptr=rowptr, csr_col=col, csr_val=val)
+            self.shared = ()
+        self.n_items = self.n_seg_items = 0
+        self.sell_entries, self.sell_seg_entries = total, seg_entries
+        self.n_tiles, self.tile_groups = n_tiles, G
+        n_t1 = -(-n_w1 // 4) * 4
+        n_tfin = n_tiles - 4 * n_w4 - n_t1 - n_tseg
+        p = lambda k: self.t[k].data_ptr() if k in self.t else None
+        self.desc = _lib.SellDesc(self.n_rows, self.n_src, 0, 0, self.n_seg, self.n_long, None, None, None, None, None, p("long_rows"),
+                                  p("long_seg_ptr"), p("long_index"), p("rowptr"), p("csr_col"), p("csr_val"), None,
+                                  1, self.n_w1, self.n_w4, G, 4 * n_w4, n_t1, n_tseg, n_tfin, max(kmax, 1),
+                                  p("tile_off"), p("tile_len"), p("tile_dst"), p("tile_long"), p("tile_col"), p("tile_val"))
+        self._partials = {}
+        return self
+
     @staticmethod
     def _sell64(rowptr, col, val, deg, seg_beg, seg_len, seg_slot, seg_long, fin_rows):
         """SELL-64 work items (two-launch form): segment items, then the unsplit rows, super blocks of 64, (col, val)

@@ -575,6 +575,35 @@ typedef struct elimrec_sell {
     const float *d_tile_val;
 } elimrec_sell;
 
+/* The wave-tile plan above built ON THE DEVICE from a device CSR (csrc/plan.hip): the arrays slab.SellPlan builds on the host
+ * with numpy sorts over all non-zeros, bit for bit, in three stages with two host read-backs of a few counts in between (the
+ * caller sizes the next stage's arrays from them). Tiered plans only. T: rows up to T neighbours are short (G of them per tile);
+ * up to T1 a wave per row; up to T2 a workgroup per row (four tiles); longer rows are cut into segments of TS. side_split: rows
+ * below are the user side (inside the short rows' tiles the item side goes first; < 0: none); rows_from: rows below take no
+ * part (SweepPlan's tile plan of the item rows). Replaces the host-side plan build for graphs a host cannot plan in reasonable
+ * time or memory (models/EliMRec.py:309-354 at BASELINE.json configs[3] / configs[4] scale).
+ *   elimrec_plan_rows    d_order int32 [n_rows] (rows by class, side, descending length), d_long_rows / d_long_seg_ptr int32
+ *                        [n_rows + 1] (n_long / n_long + 1 used), d_long_index int32 [n_rows], d_counts int64 [8] on the device:
+ *                        rows per class (workgroup, wave, split, short, none), long rows, segments
+ *   elimrec_plan_tiles   d_tile_off int64 [n_tiles + 1], d_tile_len / d_tile_dst int32 [n_tiles x G], d_tile_long int32
+ *                        [max(n_tseg x G, 1)], the scatter's d_gb int64 / d_gs int32 [n_tiles x G], d_totals int64 [4] on the
+ *                        device: entries, entries before the short rows' tiles, most 64-entry lines of a tile
+ *   elimrec_plan_scatter d_tile_col / d_tile_val [entries + 128], zero-filled by the caller
+ * Workspace: elimrec_plan_workspace(n_rows, n_seg, n_tiles) bytes (stage 1: n_seg = n_tiles = 1). */
+size_t elimrec_plan_workspace(int64_t n_rows, int64_t n_seg, int64_t n_tiles);
+int64_t elimrec_plan_tile_count(int64_t n_w4, int64_t n_w1, int64_t n_seg, int64_t n_short, int G);
+int elimrec_plan_rows(const int64_t *d_rowptr, int64_t n_rows, int T, int T1, int T2, int TS, int G, int64_t side_split,
+                      int64_t rows_from, int32_t *d_order, int32_t *d_long_rows, int32_t *d_long_index, int32_t *d_long_seg_ptr,
+                      int64_t *d_counts, void *d_workspace, size_t workspace_bytes, void *stream);
+int elimrec_plan_tiles(const int64_t *d_rowptr, int64_t n_rows, int T, int T1, int T2, int TS, int G, int64_t side_split,
+                       int64_t rows_from, const int32_t *d_order, const int32_t *d_long_rows, const int32_t *d_long_seg_ptr,
+                       int64_t n_w4, int64_t n_w1, int64_t n_split, int64_t n_short, int64_t n_long, int64_t n_seg,
+                       int64_t *d_tile_off, int32_t *d_tile_len, int32_t *d_tile_dst, int32_t *d_tile_long, int64_t *d_gb,
+                       int32_t *d_gs, int64_t *d_totals, void *d_workspace, size_t workspace_bytes, void *stream);
+int elimrec_plan_scatter(int64_t n_tiles, int G, const int64_t *d_tile_off, const int64_t *d_gb, const int32_t *d_tile_len,
+                         const int32_t *d_gs, const int32_t *d_col, const float *d_val, int32_t *d_tile_col, float *d_tile_val,
+                         void *stream);
+
 /* One hop over a slab-major table:  r = A . Xin ;  Xout[row] = (r + [add_mask bit row] Add[row]) * scale.
  * gs = slab groups (1, 2, 4 or 8 dividing ns): a workgroup works on the ns/gs slabs of group blockIdx % gs.
  * d_src_mask (nullable bitmap over the source rows): rows whose bit is clear are zero and are not read (the

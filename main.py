@@ -25,6 +25,8 @@ over ranks.
 import os
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")      # before the HIP runtime initialises (elimrec_amd/__init__.py has the measurements)
+
 import torch
 
 from elimrec_amd import (Configurator, Dataset, EliMRec, FusedAdam, Logger, Meter, PairwiseSamplerV2,

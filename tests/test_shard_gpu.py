@@ -154,6 +154,78 @@ def test_window_sweep_hop_equals_the_tile_hop(d, w, U, I, window, monkeypatch):
     assert torch.equal(y1.dense()[:U], ((b[:U] + S[:U] * act[:U, None]) * 0.25))
 
 
+def _plans_equal(host, devp):
+    assert (host.n_rows, host.n_src, host.nnz, host.n_seg, host.n_long, host.n_w1, host.n_w4, host.n_tiles, host.tile_groups,
+            host.sell_entries, host.sell_seg_entries) == (devp.n_rows, devp.n_src, devp.nnz, devp.n_seg, devp.n_long, devp.n_w1, devp.n_w4,
+                                                          devp.n_tiles, devp.tile_groups, devp.sell_entries, devp.sell_seg_entries)
+    for k in ("long_rows", "long_seg_ptr", "long_index", "tile_off", "tile_len", "tile_dst", "tile_long", "tile_col", "tile_val", "rowptr",
+              "csr_col", "csr_val"):
+        a, b = host.t[k], devp.t[k]
+        assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b), k
+    for f, _ in host.desc._fields_:
+        if not f.startswith("d_"):
+            assert getattr(host.desc, f) == getattr(devp.desc, f), f
+
+
+@pytest.mark.parametrize("kind,n,U,ipw,T,split,rows_from", [("random", 2500, 900, 8, 64, 900, 0), ("random", 2500, 900, 8, 32, None, 0),
+                                                            ("random", 3000, 1, 16, 32, 1, 0), ("random", 700, 300, 32, 32, 300, 0),
+                                                            ("bipartite", 9700, 700, 8, 64, 700, 0), ("bipartite", 9700, 700, 8, 64, None, 700),
+                                                            ("bipartite", 23000, 3000, 4, 64, 3000, 0), ("hot", 4000, 2000, 8, 64, 2000, 0)])
+def test_device_plan_build_equals_the_host_plan(kind, n, U, ipw, T, split, rows_from):
+    """elimrec_plan_rows / _tiles / _scatter (csrc/plan.hip: rocPRIM sorts and scans + one thread per row / segment / tile group) on a
+    device CSR give the arrays, counts and descriptor of slab.SellPlan(tiered=True) -- the host's numpy build -- bit for bit: ragged
+    rows in every tier (short, a wave, a workgroup, segments), empty rows, several lane-group counts, with and without the side
+    order, a plan of the rows from rows_from on (the window sweep's item-row plan); and a hop on the device-built plan equals a hop
+    on the host-built one bitwise."""
+    from elimrec_amd import slab
+    if kind == "random":
+        m = _random_graph(n, n + ipw, hot=9, hot_deg=300 * ipw)
+    elif kind == "hot":
+        m = _random_graph(n, 7, hot=4, hot_deg=20000)
+    else:
+        m = _bipartite(U, n - U, n)
+    host = slab.SellPlan(m, DEV, threshold=T, side_split=split, tiered=True, ipw=ipw, rows_from=rows_from)
+    rp, col, val = _t(m.indptr.astype(np.int64)), _t(m.indices.astype(np.int32)), _t(m.data.astype(np.float32))
+    devp = slab.SellPlan.on_device(rp, col, val, m.shape[1], threshold=T, side_split=split, ipw=ipw, rows_from=rows_from)
+    _plans_equal(host, devp)
+    if rows_from == 0:
+        d = 256 // ipw if 256 // ipw <= 64 else 64
+        ns, w = slab.choose_slabs(d)
+        if 64 // ((ns // slab.choose_groups(ns)) * (w // 4)) == ipw:
+            X = slab.SlabTable(n, ns, w, DEV).from_rows(torch.randn(n, d, device=DEV))
+            ya, yb = X.like(), X.like()
+            slab.hop(host, X, ya)
+            slab.hop(devp, X, yb)
+            assert torch.equal(ya.data, yb.data)
+
+
+def test_device_plan_build_at_the_tiktok_and_c4_shapes():
+    """The same equality on the graphs of BASELINE.json configs[1] and configs[3] (18 M non-zeros, |I| = 1.2 M), the device CSR
+    coming from csrc/adj.hip (elimrec_build_adj) as it would for a graph that never exists on the host; the configs[3] plan is
+    built in well under half a second (< 0.5 s), the host form takes seconds."""
+    import time
+    from elimrec_amd import SyntheticDataset, slab
+    from elimrec_amd.model import create_adj_mat
+    for (U, I, E, ipw) in ((36656, 76085, 720829, 8), (36656, 1217360, 16 * 720829, 8)):
+        ds = SyntheticDataset(U, I, E, feat_dims=(4, 4, 4), seed=0)
+        adj = create_adj_mat(*ds.get_train_interactions(), U, I, "pre").tocsr()
+        adj.sort_indices()
+        t0 = time.perf_counter()
+        host = slab.SellPlan(adj, DEV, threshold=64, side_split=U, tiered=True, ipw=ipw)
+        torch.cuda.synchronize()
+        t_host = time.perf_counter() - t0
+        rp, col, val = _t(adj.indptr.astype(np.int64)), _t(adj.indices.astype(np.int32)), _t(adj.data.astype(np.float32))
+        slab.SellPlan.on_device(rp, col, val, adj.shape[1], threshold=64, side_split=U, ipw=ipw)      # (code objects, allocator)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        devp = slab.SellPlan.on_device(rp, col, val, adj.shape[1], threshold=64, side_split=U, ipw=ipw)
+        torch.cuda.synchronize()
+        t_dev = time.perf_counter() - t0
+        _plans_equal(host, devp)
+        print("plan of %d non-zeros: host %.2f s, device %.3f s" % (adj.nnz, t_host, t_dev))
+        assert t_dev < 0.5
+
+
 def test_trainer_with_the_window_sweep_matches_the_reference_fixtures(monkeypatch):
     """ELIMREC_SWEEP=1 forces the large-table form of the hops on the small fixtures: whole hops = tile hop over the item rows +
     window sweep over the user rows, no tails on the hops (Adam and the weight gradients in launches of their own). Three trainer

@@ -1,5 +1,5 @@
-"""gpurun_out/r03/* (tools/profile_round.sh) -> profiles/r03_*: kernel-stat CSVs copied, PMC passes summarised.
-Usage: python tools/profile_collect.py"""
+"""gpurun_out/$ROUND/* (tools/profile_round.sh; ROUND defaults to r04) -> profiles/$ROUND_*: kernel-stat CSVs copied, PMC passes
+summarised. Usage: python tools/profile_collect.py"""
 import collections
 import csv
 import glob
@@ -8,7 +8,9 @@ import shutil
 import subprocess
 import sys
 
-O = "gpurun_out/r03"
+import os
+RND = os.environ.get("ROUND", "r04")
+O = "gpurun_out/" + RND
 
 
 def read(d):
@@ -22,8 +24,8 @@ def read(d):
 
 
 subprocess.check_call([sys.executable, "tools/pmc_summary.py", "--fetch", O + "/fetch", "--write", O + "/write", "--mfma", O + "/mfma",
-                       "--steps", "10", "--out", "/tmp/r03_pmc.json"], stdout=subprocess.DEVNULL)
-doc = json.load(open("/tmp/r03_pmc.json"))
+                       "--steps", "10", "--out", "/tmp/%s_pmc.json" % RND], stdout=subprocess.DEVNULL)
+doc = json.load(open("/tmp/%s_pmc.json" % RND))
 l2, ta = read(O + "/l2"), read(O + "/ta")
 hop = doc["propagation_hop_kernel"]
 h, t = l2[hop], ta[hop]
@@ -48,16 +50,39 @@ doc["mfma_utilisation"] = {"what": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE 
                                    "head_fwd16_kernel, their input gradients = head_bwd_input16_kernel, their weight gradients = the tail workgroups of "
                                    "sell_tier_bwdw_kernel<8, true> (partial products) -- all latency-bound at <= 3B active rows, not MFMA-bound",
                            "kernels": util}
-json.dump(doc, open("profiles/r03_pmc_traffic.json", "w"), indent=1)
+json.dump(doc, open("profiles/%s_pmc_traffic.json" % RND, "w"), indent=1)
 # C4 shape: one full hop of the [N x 128] table, slab groups side by side (default) and one after the other
 import os
 c4 = {}
-for tag, label in (("c4", "groups side by side (blockIdx % gs)"), ("c4o", "groups one after the other (ELIMREC_SLAB_ORDER=1)")):
+for tag, label in (("c4", "tile hop over all rows, slab groups side by side (blockIdx % gs)"),
+                   ("c4o", "tile hop, slab groups one after the other (ELIMREC_SLAB_ORDER=1)"),
+                   ("c4s", "window sweep over the user rows (sweep_rows_kernel) + tile hop over the item rows: both launches of a hop")):
     if not os.path.isdir(O + "/%s_fetch" % tag):
         continue
     f, w = read(O + "/%s_fetch" % tag), read(O + "/%s_write" % tag)
-    hopk = [k for k in f if "sell_tier_kernel" in k][0]
     rows = list(csv.DictReader(open(O + "/%s_stats/h_kernel_stats.csv" % tag)))
+    per = lambda c, key: sum(c[key]) * 1024 / len(c[key])
+    if tag == "c4s":
+        # the hop's two launches; the item-rows launch is the sell_tier_kernel grid that is not the reference run's whole-plan hop
+        sweep = [k for k in f if "sweep_rows_kernel" in k][0]
+        grids = sorted((k for k in f if "sell_tier_kernel" in k), key=lambda k: len(f[k]["FETCH_SIZE"]))
+        items = grids[-1]                                   # launched with every hop (the whole-plan hop runs once, as the reference)
+        parts = {"window sweep over the user rows": sweep, "tile hop over the item rows": items}
+        fetch = sum(2 * per(f[k], "FETCH_SIZE") for k in parts.values())
+        write = sum(per(w[k], "WRITE_SIZE") for k in parts.values())
+        tr = list(csv.DictReader(open(glob.glob(O + "/c4s_stats/*kernel_stats.csv")[0])))
+        avg_ns = float([r for r in tr if "sweep_rows_kernel" in r["Name"]][0]["AverageNs"])
+        log = open(O + "/c4s_hop.log").read()
+        c4[label] = {"us_per_hop_both_launches": float([l for l in log.splitlines() if "us per hop" in l][-1].split()[0]),
+                     "sweep_launch_us": round(avg_ns / 1e3, 1), "fetch_MB_x2": round(fetch / 1e6, 1), "write_MB": round(write / 1e6, 1),
+                     "traffic_MB": round((fetch + write) / 1e6, 1),
+                     "per_launch": {n: {"fetch_MB_x2": round(2 * per(f[k], "FETCH_SIZE") / 1e6, 1), "write_MB": round(per(w[k], "WRITE_SIZE") / 1e6, 1)}
+                                    for n, k in parts.items()}}
+        if os.path.isdir(O + "/c4s_l2"):
+            l = read(O + "/c4s_l2")
+            c4[label]["L2_hit_rate"] = {n: round(sum(l[k]["TCC_HIT_sum"]) / (sum(l[k]["TCC_HIT_sum"]) + sum(l[k]["TCC_MISS_sum"])), 3) for n, k in parts.items()}
+        continue
+    hopk = sorted((k for k in f if "sell_tier_kernel" in k), key=lambda k: -len(f[k]["FETCH_SIZE"]))[0]
     avg_ns = float([r for r in rows if "sell_tier_kernel" in r["Name"]][0]["AverageNs"])
     fetch = 2 * sum(f[hopk]["FETCH_SIZE"]) * 1024 / len(f[hopk]["FETCH_SIZE"])
     write = sum(w[hopk]["WRITE_SIZE"]) * 1024 / len(w[hopk]["WRITE_SIZE"])
@@ -71,12 +96,14 @@ if c4:
     json.dump({"note": "tools/hop_only.py 128 12 with SHAPE=c4 (BASELINE configs[3]: |U| = 36 656, |I| = 1 217 360, recdim 128) under rocprofv3: kernel "
                        "stats, FETCH_SIZE (x2, gfx950) and WRITE_SIZE in separate passes. Algorithmic bytes of a hop = read X + write X' = 2 x N x 128 x 4 "
                        "+ the index stream.", "table_MB": round(N * dcol * 4 / 1e6, 1), "algorithmic_MB_without_index": round(2 * N * dcol * 4 / 1e6, 1),
-               "variants": c4}, open("profiles/r03_c4_hop_traffic.json", "w"), indent=1)
+               "variants": c4}, open("profiles/%s_c4_hop_traffic.json" % RND, "w"), indent=1)
     print(json.dumps(c4, indent=1))
 if os.path.exists(O + "/multi_stats/m_kernel_stats.csv"):
-    shutil.copy(O + "/multi_stats/m_kernel_stats.csv", "profiles/r03_multi_rank_path_kernel_stats.csv")
-shutil.copy(O + "/stats/b_kernel_stats.csv", "profiles/r03_bench_kernel_stats.csv")
-shutil.copy(O + "/eval_stats/e_kernel_stats.csv", "profiles/r03_eval_kernel_stats.csv")
+    shutil.copy(O + "/multi_stats/m_kernel_stats.csv", "profiles/%s_multi_rank_path_kernel_stats.csv" % RND)
+if os.path.exists(O + "/multi_timeline.txt"):
+    shutil.copy(O + "/multi_timeline.txt", "profiles/%s_multi_rank_path_timeline.txt" % RND)
+shutil.copy(O + "/stats/b_kernel_stats.csv", "profiles/%s_bench_kernel_stats.csv" % RND)
+shutil.copy(O + "/eval_stats/e_kernel_stats.csv", "profiles/%s_eval_kernel_stats.csv" % RND)
 ev, ef, ew = read(O + "/eval_pmc"), read(O + "/eval_fetch"), read(O + "/eval_write")
 out = {}
 for name in ev:
@@ -95,9 +122,9 @@ for name in ev:
         row["valu_issue_busy_frac"] = round(4 * row["SQ_ACTIVE_INST_VALU_per_launch"] / 1024.0 / dur, 3)
         out[name] = row
 json.dump({"note": "rocprofv3 --pmc passes over tools/eval_prof.py (3 TIE validation passes, 8192 users per launch, default math, catalogue in "
-                   "16384-item chunks). mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 SEs); "
+                   "a 2048-item pilot chunk + 16384-item chunks, scores stored only in tiles that reach the running K-th best). mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (SQ_BUSY_CYCLES / 32 SEs); "
                    "valu_issue_busy_frac = 4 x SQ_ACTIVE_INST_VALU (quad-cycles) / 1024 / the same duration. FETCH_SIZE doubled (gfx950).",
-           "kernels": out}, open("profiles/r03_eval_pmc.json", "w"), indent=1)
+           "kernels": out}, open("profiles/%s_eval_pmc.json" % RND, "w"), indent=1)
 for k in ("propagation_hop_kernel", "propagation_hop_traffic_bytes", "propagation_hop_L2_hit_rate", "propagation_hop_TA_busy_frac",
           "propagation_hop_TCP_pending_stall_frac"):
     print(k, doc.get(k))

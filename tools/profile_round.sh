@@ -1,7 +1,8 @@
-# Round profiles (run on the GPU box through gpurun; outputs under gpurun_out/r03, summaries are then copied to profiles/).
+# Round profiles (run on the GPU box through gpurun; outputs under gpurun_out/$ROUND (default r04), summaries are then copied to
+# profiles/ by tools/profile_collect.py).
 # Kernel stats and PMC counters in SEPARATE rocprofv3 runs (no --pmc together with trace domains).
 cd /tmp; export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND:-r04}; rm -rf $O; mkdir -p $O
 B="python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-reference-work --no-bf16 --no-b-sweep"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- $B > $O/bench_stats.log 2>&1 < /dev/null
 P="python3 $R/bench.py --steps 9 --warmup 1 --no-cpu-baseline --no-reference-work --no-bf16 --no-eval --no-b-sweep"
@@ -27,10 +28,18 @@ export ELIMREC_SLAB_ORDER=1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4o_stats -o h -- $H > $O/c4o_hop.log 2>&1 < /dev/null
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c4o_fetch -o p -- $H > /dev/null 2>&1 < /dev/null
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c4o_write -o p -- $H > /dev/null 2>&1 < /dev/null
-unset ELIMREC_SLAB_ORDER SHAPE
+unset ELIMREC_SLAB_ORDER
+# ... and the same hop with the user rows by the window sweep (csrc/sweep.hip) + the item rows by a tile plan of their own
+export SWEEP=1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4s_stats -o h -- $H > $O/c4s_hop.log 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c4s_fetch -o p -- $H > /dev/null 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c4s_write -o p -- $H > /dev/null 2>&1 < /dev/null
+timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/c4s_l2 -o p -- $H > /dev/null 2>&1 < /dev/null
+unset SWEEP SHAPE
 # the multi-rank step over a one-rank RCCL communicator (the library's own RCCL calls, issued from the step's program)
-export ELIMREC_SHARD_MULTI=1
+export ELIMREC_SHARD_MULTI=1 FEATURE_SHARD=row
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/multi_stats -o m -- python3 $R/tools/step_trace.py 60 > $O/multi.log 2>&1 < /dev/null
-unset ELIMREC_SHARD_MULTI
+python3 $R/tools/timeline.py $(find $O/multi_stats -name "*kernel_trace.csv" | head -1) 3 > $O/multi_timeline.txt 2>&1
+unset ELIMREC_SHARD_MULTI FEATURE_SHARD
 find $O -name "*kernel_trace.csv" -delete      # large; the stats csv is what gets committed
 ls -R $O | head -50

@@ -20,10 +20,19 @@ if os.environ.get("ELIMREC_SHARD_MULTI") == "1":       # the multi-rank step ove
 set_seed(1)
 model = EliMRec(cfg, ds).to(dev)
 opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
-tr = ColumnShardTrainer(ColumnShardEngine(model, table_dtype=sys.argv[2] if len(sys.argv) > 2 else "f32"), opt)
+eng = ColumnShardEngine(model, table_dtype=sys.argv[2] if len(sys.argv) > 2 else "f32", feature_shard=os.environ.get("FEATURE_SHARD") or None)
+tr = ColumnShardTrainer(eng, opt)
+if tr.lookup and tr.multi:                               # row-sharded constants: the split sizes planned ahead, as main.py does per epoch
+    pass
 nb = int(u.numel()) // B                                 # whole batches of the sampled epoch; more steps go round again
+batches = [(u[j * B:(j + 1) * B], p[j * B:(j + 1) * B], n[j * B:(j + 1) * B]) for j in range(nb)]
+if tr.lookup and tr.multi:                               # row-sharded constants: the split sizes planned ahead, as main.py does per epoch
+    tr.plan_lookup(batches)
+import time
+torch.cuda.synchronize(); t0 = time.perf_counter()
 for i in range(K):
     j = i % nb
-    tr.step(u[j * B:(j + 1) * B], p[j * B:(j + 1) * B], n[j * B:(j + 1) * B])
+    tr.step(*batches[j])
 torch.cuda.synchronize()
-print("done")
+print("done: %.4f ms per step over %d steps (the first ones traced / warm-up included); native steps %d, failed: %s" % (
+    1e3 * (time.perf_counter() - t0) / K, K, tr._native_state()["native_steps"], tr._native_state()["failed"]))
