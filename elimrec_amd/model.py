@@ -214,7 +214,10 @@ class EliMRec(BasicModel):
             adj = sp.csr_matrix((vl.cpu().numpy(), cl.cpu().numpy(), rp.cpu().numpy()), shape=(n_nodes, n_nodes))
         else:
             adj = create_adj_mat(tu, ti, self.num_users, self.num_items, cfg["adj_type"])
-        self._adj_host = adj                      # the engine's plan is built from this (host) matrix
+        self._adj_host = adj                      # the engine's plan is built from this (host) matrix ...
+        self._plan_build = str(opt("plan_build", "host"))      # ... or, --plan_build=device (CLI-only), from the device CSR by csrc/plan.hip
+        if self._plan_build not in ("host", "device"):
+            raise ValueError("plan_build must be host or device")
         if not self._lean:
             self._register_csr("adj", adj)
         adj_t = adj.T.tocsr()

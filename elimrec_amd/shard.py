@@ -28,6 +28,7 @@ kernels, tests/test_dist_cpu.py injects a CPU stand-in built from the oracle to 
 """
 import ctypes
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -617,8 +618,23 @@ class ColumnShardEngine(object):
         tiered = not self.bf16 and os.environ.get("ELIMREC_SLAB_TIERED", "1") != "0"
         kw = dict(side_split=m.num_users, ipw=ipw, tiered=tiered,
                   threshold=(64 if world == 1 else 32) if tiered else slab.LONG_ROW_THRESHOLD)
-        self.plan = slab.SellPlan(adj, dev, **kw)
-        self.planT = self.plan if m._adj_symmetric else slab.SellPlan(adj.T.tocsr(), dev, **kw)
+        if tiered and getattr(m, "_plan_build", "host") == "device":
+            # the wave-tile plan from a device CSR (csrc/plan.hip: the host build's arrays bit for bit, without its sorts over all
+            # non-zeros on the host): the model's device copy of the adjacency, or an upload of the host matrix (lean tables)
+            def device_plan(name, mat):
+                if hasattr(m, name + "_rowptr"):
+                    rp, cl, vl = getattr(m, name + "_rowptr").to(dev).long(), getattr(m, name + "_col").to(dev), getattr(m, name + "_val").to(dev)
+                else:
+                    mat = mat.tocsr()
+                    mat.sort_indices()
+                    up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a.astype(dt))).to(dev)
+                    rp, cl, vl = up(mat.indptr, np.int64), up(mat.indices, np.int32), up(mat.data, np.float32)
+                return slab.SellPlan.on_device(rp, cl, vl, N, threshold=kw["threshold"], side_split=kw["side_split"], ipw=ipw)
+            self.plan = device_plan("adj", adj)
+            self.planT = self.plan if m._adj_symmetric else device_plan("adjT", adj.T)
+        else:
+            self.plan = slab.SellPlan(adj, dev, **kw)
+            self.planT = self.plan if m._adj_symmetric else slab.SellPlan(adj.T.tocsr(), dev, **kw)
         # a column slice beyond the Infinity Cache (configs[3] on one GPU, configs[4] on eight): the user rows of every WHOLE hop
         # by the window sweep (csrc/sweep.hip), the item rows by a tile plan of their own; the masked hop, the split-rows hop of
         # the last forward layer and the batch-row kernels keep the whole plan. The hops then carry no tails (Adam, weight

@@ -186,7 +186,7 @@ class SellPlan(object):
         if ws.numel() < need:
             ws = torch.empty(need, dtype=torch.uint8, device=dev)
         tile_off, tile_len, tile_dst = i64(n_tiles + 1), i32(n_tiles * G), i32(n_tiles * G)
-        tile_long, gb, gs, totals = i32(n_tseg * G), i64(n_tiles * G), i32(n_tiles * G), i64(4)
+        tile_long, gb, gs, totals = torch.zeros(max(n_tseg * G, 1), dtype=torch.int32, device=dev), i64(n_tiles * G), i32(n_tiles * G), i64(4)
         _lib.check(lib.elimrec_plan_tiles(_dev(rowptr, "rowptr", torch.int64), n_rows, T, T1, T2, TS, G, split, int(rows_from),
                                           _dev(order, "order", torch.int32), _dev(long_rows, "long_rows", torch.int32),
                                           _dev(seg_ptr, "long_seg_ptr", torch.int32), n_w4, n_w1, n_split, n_short, n_long, n_seg,

@@ -226,6 +226,30 @@ def test_device_plan_build_at_the_tiktok_and_c4_shapes():
         assert t_dev < 0.5
 
 
+@pytest.mark.parametrize("name", ["ml3", "gcmc"])
+def test_trainer_on_a_device_built_plan_matches_the_reference_fixture(name):
+    """--plan_build=device: the engine's wave-tile plans (the transposed one too for the gcmc adjacency, which is not symmetric) come
+    from the device CSR through csrc/plan.hip; the trainer reproduces the reference's golden losses and parameters, and the plan is
+    the host-built one bit for bit."""
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam, slab
+    g = load_golden(name)
+    model, _ = build_model_from_fixture(g, DEV, extra_argv=["--plan_build=device"])
+    opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    eng = ColumnShardEngine(model)
+    tr = ColumnShardTrainer(eng, opt)
+    host = slab.SellPlan(model._scipy_adj(), DEV, threshold=eng.plan.threshold, side_split=model.num_users, tiered=True, ipw=eng.plan.tile_groups)
+    _plans_equal(host, eng.plan)
+    assert (eng.planT is eng.plan) == bool(model._adj_symmetric)
+    steps = int(g["steps"])
+    for t in range(1, steps + 1):
+        loss = tr.step(*(_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg")))
+        assert abs(float(loss) - float(g["step%d/loss" % t])) < 1e-5, t
+    eng.sync_to_model()
+    sd = model.state_dict()
+    for k, v in sub(g, "after%d" % steps).items():
+        assert np.abs(sd[k].cpu().numpy() - v).max() < 2e-5, k
+
+
 def test_trainer_with_the_window_sweep_matches_the_reference_fixtures(monkeypatch):
     """ELIMREC_SWEEP=1 forces the large-table form of the hops on the small fixtures: whole hops = tile hop over the item rows +
     window sweep over the user rows, no tails on the hops (Adam and the weight gradients in launches of their own). Three trainer
