@@ -1004,10 +1004,10 @@ __global__ __launch_bounds__(NTB, 2) void score_t16b_kernel(ScoreArgs a, int n_t
                 keep[r] = true;
                 if (a.tile_max) {
                     const float mx = row16_max_nonneg(item_ok ? outs[r] : -INFINITY);
-                    // unpredicated stores (the other lanes write a.partial[0], which nothing reads in pass 2): a predicated store
-                    // is a branch, and a branch per user ends the basic block the four chains are scheduled in
-                    float *dmx = (li == 0 && row_ok) ? a.tile_max + (int64_t)(b0 + urow) * a.tmax_ld + tile : a.partial;
-                    *dmx = mx;
+                    // (the four chains above are complete: predicated stores no longer cut the block they are scheduled in, and a
+                    // lane that has nothing to store stores nothing -- a dump word written by 60 lanes of every store instruction
+                    // counted 64 B of write traffic each)
+                    if (li == 0 && row_ok) a.tile_max[(int64_t)(b0 + urow) * a.tmax_ld + tile] = mx;
                     keep[r] = !(mx < thr_r[r]);
                     any = any || keep[r];
                 }
@@ -1017,8 +1017,7 @@ __global__ __launch_bounds__(NTB, 2) void score_t16b_kernel(ScoreArgs a, int n_t
                 for (int r = 0; r < 4; ++r) {
                     const int urow = wave * TU + 4 * kq + r;
                     const bool row_ok = b0 + urow < a.B;
-                    float *dst = (item_ok && row_ok && keep[r]) ? a.scores + (int64_t)(b0 + urow) * a.lds + (item - a.item0) : a.partial;
-                    *dst = outs[r];
+                    if (item_ok && row_ok && keep[r]) a.scores[(int64_t)(b0 + urow) * a.lds + (item - a.item0)] = outs[r];
                 }
             }
         }

@@ -360,9 +360,10 @@ class SweepPlan(object):
         self._geo = {}
 
     def window(self, w):
-        """Source rows per window: 3 MB of row pieces of an XCD's 4 MB L2 (measured at the configs[3] shape, 128-B pieces: 12 288
-        rows 892 us per hop, 16 384 879, 24 576 875, 32 768 875)."""
-        return int(os.environ.get("ELIMREC_SWEEP_WINDOW", (3 << 20) // (4 * w)))
+        """Source rows per window: 2 MB of row pieces, half an XCD's L2 (measured at the configs[3] shape, 128-B pieces, us per hop /
+        GB past L2 of the sweep launch: 8 192 rows 927 / 1.64, 12 288 892, 16 384 879, 24 576 875 / 2.26, 32 768 875 -- the time is flat
+        from 16 384 on, the traffic is not)."""
+        return int(os.environ.get("ELIMREC_SWEEP_WINDOW", (2 << 20) // (4 * w)))
 
     def geometry(self, ns, w):
         """For tables of ns slabs x w floats: the swept rows cut into parts x passes x bpx contiguous blocks of about equal

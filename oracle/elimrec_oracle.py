@@ -74,7 +74,7 @@ class OracleEliMRec:
 
     def __init__(self, num_users, num_items, recdim, layer_num, adj, feats, params, alpha,
                  dataset_name="movielens", modality="vat", mm_fusion_mode="concat",
-                 fusion_mode="rubi", predict_type="TIE", mods=None, dtype=torch.float32):
+                 fusion_mode="rubi", predict_type="TIE", mods=None, dtype=torch.float32, words=None):
         """dtype: torch.float32 is the reference's arithmetic (and what every fixture pins). torch.float64 evaluates the
         SAME formulas on the same fp32 inputs in double precision: the tests use it to tell a row where the fp32 reference
         itself is off by more than the tolerance (cancellation) from a row where the HIP path is."""
@@ -89,6 +89,19 @@ class OracleEliMRec:
         self.feats = {k: torch.as_tensor(v, dtype=torch.float32).to(dtype) for k, v in feats.items()}
         self.params = {k: torch.as_tensor(np.array(v), dtype=torch.float32).to(dtype).clone().requires_grad_(True)
                        for k, v in params.items()}
+        # models/EliMRec.py:371-378 (data set "tiktok"): t_feat = scatter-mean of the word embeddings of every item's words (`words`
+        # = dataset.words_tensor, [2 x n]: item id, word id), built ONCE from the initial word_embedding.weight, not normalised --
+        # and left attached to it: with main.py:100's backward(retain_graph=True) the parameter receives the gradient that
+        # arrives at t_feat every step (and coupled weight decay), although its new values never reach a forward pass again.
+        self.retain_graph = False
+        if words is not None:
+            w = self.params["word_embedding.weight"]
+            idx0, idx1 = (torch.as_tensor(np.asarray(x), dtype=torch.int64) for x in words)
+            n = int(idx0.max()) + 1
+            tot = torch.zeros(n, w.shape[1], dtype=w.dtype).index_add(0, idx0, w[idx1])
+            cnt = torch.zeros(n, dtype=w.dtype).index_add(0, idx0, torch.ones(idx0.numel(), dtype=w.dtype)).clamp(min=1)
+            self.feats["t"] = tot / cnt[:, None]
+            self.retain_graph = True
         self.alpha = float(alpha)
         self.modality = "v" if self.kwai else modality  # EliMRec.py:133-134
         self.mm_fusion_mode = mm_fusion_mode
@@ -261,6 +274,6 @@ def train_step(model, opt, users, pos, neg):
     """main.py:98-102 loop body."""
     loss = model.bpr_loss(users, pos, neg)
     model.zero_grad()
-    loss.backward()
+    loss.backward(retain_graph=bool(getattr(model, "retain_graph", False)))      # main.py:100
     opt.step()
     return float(loss.item())

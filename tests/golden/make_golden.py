@@ -66,7 +66,19 @@ def install_shims():
         m = types.ModuleType(n)
         m.__spec__ = importlib.machinery.ModuleSpec(n, None)
         sys.modules[n] = m
-    sys.modules["torch_scatter"].scatter = None  # never called (no "tiktok" fixture)
+    sys.modules["torch_scatter"].scatter = scatter_mean_stub      # called on the "tiktok" path only (models/EliMRec.py:377)
+
+
+def scatter_mean_stub(src, index, reduce="mean", dim=0):
+    """torch_scatter.scatter(src, index, reduce='mean', dim=0) for the one call site of the reference (word embeddings of an item's
+    words -> their mean): out[i] = sum of the rows of src with index i / their number (torch_scatter clamps the count at 1); rows
+    0 .. max(index). torch_scatter itself is not installed in the build container -- this stub IS what the fixture pins."""
+    import torch
+    assert reduce == "mean" and dim == 0 and src.dim() == 2
+    n = int(index.max()) + 1
+    tot = torch.zeros(n, src.shape[1], dtype=src.dtype).index_add_(0, index, src)
+    cnt = torch.zeros(n, dtype=src.dtype).index_add_(0, index, torch.ones(index.numel(), dtype=src.dtype)).clamp_(min=1)
+    return tot / cnt[:, None]
 
 
 def synth_interactions(rs, U, I, per_user=(4, 9)):
@@ -119,6 +131,16 @@ def write_dataset(w, name, rs, U, I, dims):
         v = rs.randn(I, dims[0]).astype(np.float32)
         torch.save(torch.from_numpy(v), os.path.join(d, "kwai_feat_v.pt"))
         feats["v"] = v
+    elif name == "tiktok":
+        # data/dataset.py:165-176: visual / audio tensors indexed by ORIGINAL item id, and the text as a [2 x n] tensor of
+        # (original item id, word id) pairs -- every item gets 1..6 words out of the reference's 11 574-word vocabulary
+        for key, fn, dm in (("v", "visual", dims[0]), ("a", "audio", dims[1])):
+            x = rs.randn(I, dm).astype(np.float32)
+            torch.save(torch.from_numpy(x), os.path.join(d, "tiktok_%s_feat.pt" % fn))
+            feats[key] = x
+        pairs = [(i, int(wd)) for i in range(I) for wd in rs.randint(0, 11574, size=rs.randint(1, 7))]
+        rs.shuffle(pairs)
+        torch.save(torch.tensor(pairs, dtype=torch.int64).T.contiguous(), os.path.join(d, "tiktok_textual_feat.pt"))
     else:
         for key, fn, dm in (("v", "FeatureVideo_normal", dims[0]),
                             ("a", "FeatureAudio_avg_normal", dims[1]),
@@ -193,6 +215,8 @@ def run_fixture(w, name, dataset, U, I, dims, argv_extra, B, steps, seed):
     if dataset != "kwai":
         out["a_feat"] = rec.a_feat.numpy()
         out["t_feat"] = rec.t_feat.detach().numpy()
+    if dataset == "tiktok":
+        out["words_tensor"] = rec.words_tensor.numpy().astype(np.int64)      # [2 x n]: (item id after the remap, word id)
     for k, v in rec.state_dict().items():
         out["init/" + k] = v.detach().numpy().copy()
 
@@ -258,6 +282,20 @@ def run_fixture(w, name, dataset, U, I, dims, argv_extra, B, steps, seed):
     out["evalbatch/per_user_metrics"] = np.asarray(res, np.float32)
     out["evalbatch/metric_ids"] = np.asarray(ev.metrics, np.int32)
     out["evalbatch/top_k"] = np.int64(ev.max_top)
+    if dataset == "tiktok":
+        # word_embedding.weight is [11 574 x 128] and appears four times: keep the rows of the words that occur (the others feed
+        # nothing) and, of the rest, how far coupled weight decay moved them -- helpers.load_golden puts the tables back
+        rows = np.unique(out["words_tensor"][1])
+        out["word_rows"], out["word_vocab"] = rows.astype(np.int64), np.int64(out["init/word_embedding.weight"].shape[0])
+        rest = np.setdiff1d(np.arange(int(out["word_vocab"])), rows)
+        for k in [k for k in out if k.endswith("word_embedding.weight")]:
+            if k.startswith("after"):
+                out[k + "@unused_max_move"] = np.float32(np.abs(out[k][rest] - out["init/word_embedding.weight"][rest]).max())
+            if not k.startswith("init/"):
+                out[k + "@rows"] = out[k][rows].copy()
+        out["init/word_embedding.weight@rows"] = out["init/word_embedding.weight"][rows].copy()
+        for k in [k for k in out if k.endswith("word_embedding.weight")]:
+            del out[k]
     np.savez_compressed(os.path.join(OUT, "%s.npz" % name), **out)
     print("wrote %s.npz  (%d arrays)  loss=%s" % (name, len(out), [float(out["step%d/loss" % t]) for t in range(1, steps + 1)]))
     return net
@@ -352,6 +390,11 @@ def main():
             run_fixture(w, "normal", "movielens", U=48, I=130, dims=(12, 20, 8),
                         argv_extra=["--recdim=64", "--layer_num=2", "--adj_type=plain", "--predict_type=normal"], B=56,
                         steps=3, seed=55)
+        if want("tiktok"):
+            # the word-bag text path (models/EliMRec.py:371-378): t_feat = scatter-mean of word embeddings, NOT normalised, and
+            # word_embedding.weight a parameter that keeps receiving gradients through the retained graph (main.py:100)
+            run_fixture(w, "tiktok", "tiktok", U=56, I=90, dims=(24, 16, 128),
+                        argv_extra=["--recdim=32", "--layer_num=3"], B=60, steps=3, seed=66)
         if want("metrics"):
             metrics_kat(w)
     finally:

@@ -11,7 +11,14 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 def load_golden(name):
-    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+    g = dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+    if "word_rows" in g:      # the tiktok fixture keeps the occurring words' rows of word_embedding.weight: zero rows for the others
+        rows, vocab = g["word_rows"], int(g["word_vocab"])
+        for k in [k for k in g if k.endswith("@rows")]:
+            full = np.zeros((vocab, g[k].shape[1]), g[k].dtype)
+            full[rows] = g[k]
+            g[k[:-5]] = full
+    return g
 
 
 def sub(g, prefix):
@@ -94,6 +101,8 @@ class FixtureDataset(object):
         for m in ("v", "a", "t"):
             if (m + "_feat") in g:
                 setattr(self, m + "_feat", torch.from_numpy(g[m + "_feat"].copy()))
+        if "words_tensor" in g:                      # data set "tiktok": (item id, word id) pairs (data/dataset.py:169-176)
+            self.words_tensor = torch.from_numpy(g["words_tensor"].astype(np.int64))
         self._g = g
 
     def get_train_interactions(self):

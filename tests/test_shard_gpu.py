@@ -250,6 +250,44 @@ def test_trainer_on_a_device_built_plan_matches_the_reference_fixture(name):
         assert np.abs(sd[k].cpu().numpy() - v).max() < 2e-5, k
 
 
+def test_tiktok_word_bag_fixture_on_the_engine():
+    """The data set "tiktok" (models/EliMRec.py:371-378; fixture `tiktok`, captured from the reference with a scatter-mean stub): the
+    model builds t_feat from the loaded word_embedding.weight and the items' word lists exactly as the reference does (1e-7, not
+    normalised), the trainer reproduces the reference's three losses and every parameter after Adam -- except word_embedding.weight,
+    which the reference keeps updating through its retained graph although nothing reads it again, and which stays a frozen
+    checkpoint key here (stated deviation 3; the reference moves it by <= lr per step, pinned in tests/test_oracle_golden.py)."""
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, EliMRec, FusedAdam
+    from helpers import FixtureDataset, fixture_argv
+    g = load_golden("tiktok")
+    model = EliMRec(make_config(fixture_argv(g)), FixtureDataset(g))
+    model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sub(g, "init").items() if "@" not in k}, strict=True)
+    assert (model.t_feat.numpy() - g["t_feat"]).__abs__().max() < 1e-7            # built from the LOADED word embeddings
+    with torch.no_grad():
+        for m in ("v", "a"):
+            getattr(model, m + "_feat").copy_(torch.from_numpy(g[m + "_feat"]))
+    model = model.to(DEV)
+    opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    tr = ColumnShardTrainer(ColumnShardEngine(model), opt)
+    steps = int(g["steps"])
+    for t in range(1, steps + 1):
+        loss = tr.step(*(_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg")))
+        assert abs(float(loss) - float(g["step%d/loss" % t])) < 1e-5, t
+    tr.engine.sync_to_model()
+    sd = model.state_dict()
+    for k, v in sub(g, "after%d" % steps).items():
+        if "@" in k:
+            continue
+        if k == "word_embedding.weight":
+            assert np.array_equal(sd[k].cpu().numpy(), g["init/" + k])               # frozen here
+            assert np.abs(v[g["word_rows"]] - g["init/" + k][g["word_rows"]]).max() < 1.05 * steps * float(g["lr"])   # the deviation's size
+            continue
+        assert np.abs(sd[k].cpu().numpy() - v).max() < 2e-5, k
+    # predict() on the tables of the last forward, as for the other fixtures
+    model.predict_type, model.fusion_mode = "TIE", "rubi"
+    users = g["eval_users"].tolist()
+    assert np.abs(model.predict(users).numpy() - g["predict/rubi/TIE"]).max() < 1e-5
+
+
 def test_trainer_with_the_window_sweep_matches_the_reference_fixtures(monkeypatch):
     """ELIMREC_SWEEP=1 forces the large-table form of the hops on the small fixtures: whole hops = tile hop over the item rows +
     window sweep over the user rows, no tails on the hops (Adam and the weight gradients in launches of their own). Three trainer
