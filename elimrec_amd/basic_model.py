@@ -19,6 +19,11 @@ class BasicModel(nn.Module):
                       batch_size=config["test_batch_size"], num_thread=config["num_thread"])
         self.valid_evaluator = ProxyEvaluator(dataset, train, dataset.get_user_valid_dict(), None, **common)
         self.test_evaluator = ProxyEvaluator(dataset, train, dataset.get_user_test_dict(), None, **common)
+        if "tie_order" in config:        # --tie_order=reference (CLI-only): the reference's lists among equal scores too (evaluator.py)
+            if str(config["tie_order"]) not in ("id", "reference"):
+                raise ValueError("tie_order must be id or reference")
+            for ev in (self.valid_evaluator, self.test_evaluator):
+                ev.evaluator.tie_order = str(config["tie_order"])
         self.infonce_criterion = nn.CrossEntropyLoss()          # BasicModel.py:32
 
     def getFileName(self):

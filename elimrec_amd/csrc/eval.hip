@@ -2019,3 +2019,25 @@ extern "C" int elimrec_rank_metrics(const int32_t *d_topk_idx, int B, int K, con
     ELIMREC_LAUNCH_CHECK("rank_metrics");
     return 0;
 }
+
+
+// The reference's OWN order among equal scores, for the rows that have any: evaluate.h:26-33 ranks a user's scores with
+// std::partial_sort_copy over the item ids under comp(x1, x2) = ratings[x1] > ratings[x2], whose result among ties is the heap order
+// of the C++ library's algorithm -- not an order of the ids. The device ranks by (score descending, id ascending); a caller that
+// wants the reference's list bit for bit (--tie_order=reference) hands the few rows whose K + 1 best scores contain a tie to this
+// HOST function, which runs that very algorithm of the C++ library this package is built with on the row's masked scores.
+// h_scores [n_rows x ld] (host), h_topk [n_rows x K] (host, out).
+#include <algorithm>
+#include <numeric>
+#include <vector>
+extern "C" int elimrec_topk_reference_order(const float *h_scores, int64_t n_rows, int64_t I, int64_t ld, int K, int32_t *h_topk) {
+    ELIMREC_REQUIRE(h_scores && h_topk && I > 0 && K > 0 && K <= I && ld >= I && I < INT32_MAX, "topk_reference_order: bad arguments");
+    std::vector<int> index((size_t)I);
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const float *ratings = h_scores + r * ld;
+        std::iota(index.begin(), index.end(), 0);
+        int32_t *out = h_topk + r * K;
+        std::partial_sort_copy(index.begin(), index.end(), out, out + K, [ratings](int x1, int x2) -> bool { return ratings[x1] > ratings[x2]; });
+    }
+    return 0;
+}

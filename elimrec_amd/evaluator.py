@@ -58,6 +58,12 @@ class UniEvaluator(object):
         self.top_show = np.arange(top_k) + 1 if isinstance(top_k, int) else np.sort(top_k)
         self._dev_cache = {}
         self._default_users = None
+        # ties among equal scores: "id" = the device's rule (score descending, item id ascending); "reference" = the reference's
+        # lists bit for bit, rows with a tie at or across K re-ranked on the host by its own algorithm (ProxyEvaluator sets it from
+        # --tie_order / ELIMREC_TIE_ORDER)
+        import os as _os
+        self.tie_order = _os.environ.get("ELIMREC_TIE_ORDER", "id")
+        self.tie_rows_replayed = 0
 
     def metrics_info(self):
         cols = ["\t".join(("%s@" % re_metric_dict[m] + str(k)).ljust(12) for k in self.top_show) for m in self.metrics]
@@ -140,6 +146,37 @@ class UniEvaluator(object):
             block //= 2
         return block
 
+    def _topk_in_reference_order(self, model, users_t, train_ptr, train_items):
+        """--tie_order=reference: the device's top-(K + 1); a row whose K + 1 best scores are pairwise different has ONE ranking
+        under any tie rule -- the device's is the reference's. The other rows (equal scores inside the list or straddling K: rare
+        on trained tables) get their masked score rows from the device and are ranked on the host by the reference's own
+        algorithm, std::partial_sort_copy (evaluate.h:26-33, elimrec_topk_reference_order)."""
+        import ctypes
+        from . import _lib
+        K = self.max_top
+        idx1, val1 = model.predict_device(users_t, top_k=K + 1, train_ptr=train_ptr, train_items=train_items)
+        idx, val = idx1[:, :K].contiguous(), val1[:, :K].contiguous()
+        tied = torch.nonzero((val1[:, 1:] == val1[:, :-1]).any(1)).flatten()
+        self.tie_rows_replayed += int(tied.numel())
+        if tied.numel():
+            ptr = train_ptr.cpu().numpy()
+            sub_ptr = np.zeros(tied.numel() + 1, np.int64)
+            rows = tied.cpu().numpy()
+            np.cumsum(ptr[rows + 1] - ptr[rows], out=sub_ptr[1:])
+            items_h = train_items.cpu().numpy()
+            sub_items = np.concatenate([items_h[ptr[r]:ptr[r + 1]] for r in rows] + [np.zeros(0, np.int32)]).astype(np.int32)
+            dev = users_t.device
+            sc = torch.empty(tied.numel(), model.num_items, dtype=torch.float32, device=dev)
+            model.predict_device(users_t[tied], scores=sc, train_ptr=torch.from_numpy(sub_ptr).to(dev),
+                                 train_items=torch.from_numpy(sub_items if len(sub_items) else np.zeros(1, np.int32)).to(dev))
+            host = np.ascontiguousarray(sc.cpu().numpy())
+            out = np.empty((tied.numel(), K), np.int32)
+            _lib.check(_lib.load().elimrec_topk_reference_order(host.ctypes.data_as(ctypes.c_void_p), host.shape[0], host.shape[1], host.shape[1], K,
+                                                                out.ctypes.data_as(ctypes.c_void_p)), "topk_reference_order")
+            idx[tied] = torch.from_numpy(out).to(dev)
+            val[tied] = torch.gather(sc, 1, idx[tied].long())
+        return idx, val
+
     def evaluate_batch(self, model, batch_users, return_topk=False, cache_key=None, out=None):
         """Per-user metric rows [len(batch_users), metrics*K] (device tensor) for one user block.
         cache_key: the user blocks of the default evaluation order are the same every time, so their
@@ -155,7 +192,10 @@ class UniEvaluator(object):
             if key is not None:
                 self._dev_cache[key] = hit
         users_t, train_ptr, train_items, truth_ptr, truth_items = hit
-        idx, val = model.predict_device(users_t, top_k=self.max_top, train_ptr=train_ptr, train_items=train_items)
+        if self.tie_order == "reference" and self.max_top < min(256, model.num_items):
+            idx, val = self._topk_in_reference_order(model, users_t, train_ptr, train_items)
+        else:
+            idx, val = model.predict_device(users_t, top_k=self.max_top, train_ptr=train_ptr, train_items=train_items)
         if out is None:
             out = torch.empty(len(batch_users), self.metrics_num * self.max_top, dtype=torch.float32, device=device)
         ops.rank_metrics(idx, truth_ptr, truth_items, self.metrics, out)

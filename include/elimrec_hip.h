@@ -497,6 +497,12 @@ int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int64_t I, cons
                        float *d_scores, int64_t lds, int K, int32_t *d_topk_idx, float *d_topk_val,
                        void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* The reference's order among EQUAL scores (evaluate.h:26-33: std::partial_sort_copy of the item ids by score, whose order of
+ * ties is the C++ library's heap order, not an order of the ids), for callers that want its lists bit for bit on rows that tie at
+ * or across K: a HOST function over host rows of masked scores [n_rows x ld] -> h_topk [n_rows x K], running that algorithm of
+ * the C++ library this package is built with. The device ranking stays (score descending, id ascending). */
+int elimrec_topk_reference_order(const float *h_scores, int64_t n_rows, int64_t I, int64_t ld, int K, int32_t *h_topk);
+
 /* Precision/Recall/MAP/NDCG/MRR prefix curves @1..K from ranked lists (metric.h:17-106).
  * d_truth_ptr int64[B+1], d_truth_items int32 (unique per row). metric_ids host int[n_metrics]
  * (1..5 as in cpp/uni_evaluator.py:14). d_out [B x n_metrics x K]. */

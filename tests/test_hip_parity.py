@@ -1421,3 +1421,58 @@ def test_device_evaluator_against_the_references_own_compiled_code(fixture_name)
     assert np.array_equal(rows[same], np.asarray(ref_rows, np.float32).reshape(len(users), -1)[same])
     for r in np.nonzero(~same)[0]:
         assert np.abs(sc[r][idx[r]] - sc[r][ref_topk[r]]).max() <= 1e-6, r
+
+
+@pytest.mark.gpu
+def test_reference_tie_order_is_reproduced_on_request(fixture_name):
+    """--tie_order=reference. The fixture's cached tables with groups of DUPLICATED item rows (equal rows score equally under every
+    user, so ties sit inside the top-K and across its boundary for most users): with the device's own rule the lists differ from
+    those of the reference's compiled evaluate.h on rows with ties; on request every row -- tied or not -- carries the reference's
+    list and metric row bit for bit (rows without a tie have one ranking under any rule; the others are re-ranked on the host by
+    std::partial_sort_copy, the reference's algorithm). EXACT evaluation math, so that the score matrix the reference's code ranks
+    and the evaluator's chunk-wise scores are the same bits."""
+    from elimrec_amd import _lib
+    from oracle import eval_oracle as ev
+    if ev.ref_lib() is None:
+        pytest.skip("oracle/_ref/libref_eval.so was not built (needs /root/reference at build time)")
+    lib = _lib.load()
+    g = load_golden(fixture_name)
+    model, _ = build_model_from_fixture(g, DEV)
+    _load_cache(model, g)
+    U = model.num_users
+    Y = model._ws["Y"]
+    rng = np.random.default_rng(5)
+    for base in rng.choice(model.num_items, size=12, replace=False):          # every picked item gets three exact copies
+        for dup in rng.choice(model.num_items, size=3, replace=False):
+            Y[U + int(dup)] = Y[U + int(base)]
+    model._publish_cache(Y)
+    model.fusion_mode, model.predict_type = "rubi", "TIE"
+    users = g["evalbatch/users"].tolist()
+    K = int(g["evalbatch/top_k"])
+    mids = g["evalbatch/metric_ids"]
+    evalr = model.test_evaluator.evaluator
+    math0 = int(lib.elimrec_score_get_math())
+    try:
+        lib.elimrec_score_set_math(0)
+        dev_scores = torch.empty(len(users), model.num_items, device=DEV)
+        train_ptr, train_items = evalr._batch_csr(users, evalr.user_pos_train, DEV, unique=False)
+        model.predict_device(users, scores=dev_scores, train_ptr=train_ptr, train_items=train_items)
+        sc = np.ascontiguousarray(dev_scores.cpu().numpy())
+        test = csr_dict(g, "test")
+        tp, ti = ev.truth_to_csr([sorted(set(test[int(u)])) for u in users])
+        ref_rows, ref_topk = ev.evaluate_matrix(sc.copy(), tp, ti, mids, K, use_ref=True)
+        ref_rows = np.asarray(ref_rows, np.float32).reshape(len(users), -1)
+        evalr.tie_order = "id"
+        rows_id, idx_id, _ = evalr.evaluate_batch(model, users, return_topk=True)
+        evalr.tie_order, evalr.tie_rows_replayed = "reference", 0
+        rows_ref, idx_ref, val_ref = evalr.evaluate_batch(model, users, return_topk=True)
+    finally:
+        lib.elimrec_score_set_math(math0)
+        evalr.tie_order = "id"
+    tied = ~_tie_free(sc, K)
+    assert tied.sum() >= 3 and evalr.tie_rows_replayed == int(tied.sum())
+    assert not np.array_equal(idx_id.cpu().numpy(), ref_topk)                     # the device's rule IS another order on these rows
+    assert np.array_equal(idx_id.cpu().numpy()[~tied], ref_topk[~tied])
+    assert np.array_equal(idx_ref.cpu().numpy(), ref_topk)                        # ... and on request the reference's, everywhere
+    assert np.array_equal(rows_ref.cpu().numpy(), ref_rows)
+    assert np.array_equal(val_ref.cpu().numpy(), np.take_along_axis(sc, ref_topk.astype(np.int64), 1))
