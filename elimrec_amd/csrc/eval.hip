@@ -779,16 +779,6 @@ __global__ __launch_bounds__(256) void split3_items_kernel(const float *__restri
 // together and the CU's two workgroups drift apart -- 0.0169 s per validation pass against 0.0157 s: the item tile is then
 // staged twice per CU.)
 constexpr int TWB = 8, NTB = 64 * TWB;
-#if defined(HAZ_DETECT)
-__device__ unsigned g_haz_count;
-__device__ float g_haz_rec[4096 * 16];
-extern "C" int elimrec_haz_read(unsigned *count, float *rec, int reset) {
-    (void)hipMemcpyFromSymbol(count, HIP_SYMBOL(g_haz_count), sizeof(unsigned));
-    (void)hipMemcpyFromSymbol(rec, HIP_SYMBOL(g_haz_rec), sizeof(float) * 4096 * 16);
-    if (reset) { unsigned z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_haz_count), &z, sizeof(z)); }
-    return 0;
-}
-#endif
 template <int PASS, int NB, int PT, int FM, int D>
 __global__ __launch_bounds__(NTB, 2) void score_t16b_kernel(ScoreArgs a, int n_tiles) {
     constexpr bool FAST = true;
@@ -804,12 +794,6 @@ __global__ __launch_bounds__(NTB, 2) void score_t16b_kernel(ScoreArgs a, int n_t
     const int b0 = blockIdx.y * (TWB * TU);
     const float eps = 1e-12f;
     const int ptype = PT >= 0 ? PT : a.predict_type, fmode = FM >= 0 ? FM : a.fusion_mode;
-#if defined(HAZ_POISON)
-    if (PASS == 2) {                                   // probe: whatever reads these words before they are written sees 7.0
-        for (int q = tid; q < TWB * TU * (NB > 1 ? NB - 1 : 1) + TWB * TU; q += NTB) unorm[q] = 7.0f;
-        __syncthreads();
-    }
-#endif
     // A operands: user (wave*16 + li), pieces of elements k = 32 j + 8 kq .. + 8 of head block h
     uint4 ua[3][NH][KB];
     {
@@ -874,24 +858,6 @@ __global__ __launch_bounds__(NTB, 2) void score_t16b_kernel(ScoreArgs a, int n_t
     };
     if ((int)blockIdx.x < n_tiles) { load_tile(blockIdx.x); load_sqn(blockIdx.x, sq_cur); store_tile(it0); }
     __syncthreads();
-#if defined(HAZ_HOIST)
-    // probe: the users' norms / means once, in registers
-    float h_un[4][NB > 1 ? NB - 1 : 1], h_um[4];
-    if (PASS == 2) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int urow = wave * TU + 4 * kq + r;
-            h_um[r] = umean[urow];
-#pragma unroll
-            for (int h = 0; h + 1 < NB; ++h) h_un[r][h] = unorm[urow * (NB - 1) + h];
-        }
-    }
-#define UNORM_(urow, r, h) h_un[r][h]
-#define UMEAN_(urow, r) h_um[r]
-#else
-#define UNORM_(urow, r, h) unorm[(urow) * (NB - 1) + (h)]
-#define UMEAN_(urow, r) umean[urow]
-#endif
     int cur = 0;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, cur ^= 1) {
         const int next = tile + gridDim.x;
@@ -919,11 +885,6 @@ __global__ __launch_bounds__(NTB, 2) void score_t16b_kernel(ScoreArgs a, int n_t
                 acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, b1, acc[h], 0, 0, 0);
             }
         }
-#if defined(HAZ_NOPS)
-        __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#endif
         // lane: item i0 + li, users wave*16 + 4*kq + r  (the 16x16 output layout of the fp32 form)
         const int64_t item = i0 + li;
         const bool item_ok = item < a.item_end;
@@ -954,44 +915,26 @@ __global__ __launch_bounds__(NTB, 2) void score_t16b_kernel(ScoreArgs a, int n_t
                 float zs[kMaxS];
 #pragma unroll
                 for (int h = 0; h < kMaxS; ++h)
-                    zs[h] = (h + 1 < NB) ? acc[(h + 1 < NH) ? h + 1 : 0][r] * (UNORM_(urow, r, (h + 1 < NB ? h : 0)) * inorm[h + 1 < NB ? h : 0]) : 0.f;
-                out = rubi_fast_(acc[0][r], zs, NB - 1, a.head_mask, ptype == 2, UMEAN_(urow, r));
+                    zs[h] = (h + 1 < NB) ? acc[(h + 1 < NH) ? h + 1 : 0][r] * (unorm[urow * (NB - 1) + (h + 1 < NB ? h : 0)] * inorm[h + 1 < NB ? h : 0]) : 0.f;
+                out = rubi_fast_(acc[0][r], zs, NB - 1, a.head_mask, ptype == 2, umean[urow]);
             } else {
                 const float ui = sig_abs_<FAST>(acc[0][r]);
                 float z[kMaxS];
 #pragma unroll
                 for (int h = 0; h < kMaxS; ++h) {
-                    const float nn = UNORM_(urow, r, (h + 1 < NB ? h : 0)) * inorm[h + 1 < NB ? h : 0];
+                    const float nn = unorm[urow * (NB - 1) + (h + 1 < NB ? h : 0)] * inorm[h + 1 < NB ? h : 0];
                     const float dp = acc[(h + 1 < NH) ? h + 1 : 0][r];
                     z[h] = (h + 1 < NB) ? dp * nn : 0.f;
                 }
                 if (ptype == 1) out = sig_out_<FAST>(fmode, fuse_t<FAST>(fmode, ui, z, NB - 1, a.head_mask));
                 else {
                     float te, nde;
-                    fuse2_t<FAST>(fmode, ui, UMEAN_(urow, r), z, NB - 1, a.head_mask, te, nde);
+                    fuse2_t<FAST>(fmode, ui, umean[urow], z, NB - 1, a.head_mask, te, nde);
                     out = sig_out_<FAST>(fmode, te - nde);
                 }
             }
             outs[r] = out;
         }
-#if defined(HAZ_DETECT)
-        if (PASS == 2 && ptype == 2) {                    // probe: a score of exactly 1.0 leaves a record of what the lane holds NOW
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int urow = wave * TU + 4 * kq + r;
-                if (outs[r] == 1.0f && b0 + urow < a.B && item_ok) {
-                    const unsigned slot = atomicAdd(&g_haz_count, 1u);
-                    if (slot < 4096) {
-                        float *rec = g_haz_rec + slot * 16;
-                        rec[0] = (float)blockIdx.x; rec[1] = (float)blockIdx.y; rec[2] = (float)tid; rec[3] = (float)r;
-                        rec[4] = (float)tile; rec[5] = (float)(tile == (int)blockIdx.x); rec[6] = umean[urow]; rec[7] = a.row_mean[b0 + urow];
-                        rec[8] = acc[0][r]; rec[9] = acc[NH > 1 ? 1 : 0][r]; rec[10] = acc[NH > 2 ? 2 : 0][r]; rec[11] = acc[NH > 3 ? 3 : 0][r];
-                        rec[12] = unorm[urow * (NB - 1)]; rec[13] = unorm[urow * (NB - 1) + (NB > 2 ? 1 : 0)]; rec[14] = inorm[0]; rec[15] = (float)cur;
-                    }
-                }
-            }
-        }
-#endif
         if (PASS == 2) {
             // the tile maxima first (always stored), then the scores -- of the users whose maximum reaches their threshold only:
             // a wave none of whose 16 users keeps the tile (the usual case once a chunk or two have been scored) skips the stores
@@ -1034,8 +977,6 @@ __global__ __launch_bounds__(NTB, 2) void score_t16b_kernel(ScoreArgs a, int n_t
             if (li == 0 && b < a.B) a.partial[(int64_t)blockIdx.x * a.B + b] = tot;
         }
     }
-#undef UNORM_
-#undef UMEAN_
 }
 
 // bitmap of the items to mask, one workgroup per user row: clear, then set (rows are disjoint, the atomics stay in one row)
