@@ -856,12 +856,17 @@ __global__ __launch_bounds__(NTB, 2) void score_t16b_kernel(ScoreArgs a, int n_t
 #pragma unroll
         for (int h = 0; h + 1 < NB; ++h) dst[h] = (a.item0 + it < a.item_end && ptype != 0) ? a.inrm[it * (NB - 1) + h] : 1.f;
     };
-    if ((int)blockIdx.x < n_tiles) { load_tile(blockIdx.x); load_sqn(blockIdx.x, sq_cur); store_tile(it0); }
+    // a workgroup takes a CONTIGUOUS stretch of the launch's tiles: the maxima of 16 consecutive tiles of a user then leave as one
+    // 64-B store (below) instead of sixteen 4-B ones, each of which cost a 32-B write at the memory side
+    const int per = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int t_begin = (int)blockIdx.x * per, t_end = t_begin + per < n_tiles ? t_begin + per : n_tiles;
+    if (t_begin < t_end) { load_tile(t_begin); load_sqn(t_begin, sq_cur); store_tile(it0); }
     __syncthreads();
     int cur = 0;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, cur ^= 1) {
-        const int next = tile + gridDim.x;
-        if (next < n_tiles) { load_tile(next); load_sqn(next, sq_nxt); }
+    float mxb[4] = {0.f, 0.f, 0.f, 0.f};              // PASS 2: lane li holds the maximum of tile (base + li) of its four users
+    for (int tile = t_begin; tile < t_end; ++tile, cur ^= 1) {
+        const int next = tile + 1;
+        if (next < t_end) { load_tile(next); load_sqn(next, sq_nxt); }
         const int64_t i0 = a.item0 + (int64_t)tile * TI;
         v4f_s acc[NH];
         const uint4 *brow = (cur ? it1 : it0) + li * ROW4 + kq;          // this lane's item row, its k-block of 8
@@ -947,10 +952,12 @@ __global__ __launch_bounds__(NTB, 2) void score_t16b_kernel(ScoreArgs a, int n_t
                 keep[r] = true;
                 if (a.tile_max) {
                     const float mx = row16_max_nonneg(item_ok ? outs[r] : -INFINITY);
-                    // (the four chains above are complete: predicated stores no longer cut the block they are scheduled in, and a
-                    // lane that has nothing to store stores nothing -- a dump word written by 60 lanes of every store instruction
-                    // counted 64 B of write traffic each)
-                    if (li == 0 && row_ok) a.tile_max[(int64_t)(b0 + urow) * a.tmax_ld + tile] = mx;
+                    // (the four chains above are complete: predicated stores no longer cut the block they are scheduled in)
+                    const int slot = (tile - t_begin) & 15;
+                    if (li == slot) mxb[r] = mx;
+                    if (slot == 15 || tile == t_end - 1) {           // 16 maxima of this user (fewer at the stretch's end): one 64-B store
+                        if (row_ok && li <= slot) a.tile_max[(int64_t)(b0 + urow) * a.tmax_ld + (tile - slot) + li] = mxb[r];
+                    }
                     keep[r] = !(mx < thr_r[r]);
                     any = any || keep[r];
                 }
@@ -964,7 +971,7 @@ __global__ __launch_bounds__(NTB, 2) void score_t16b_kernel(ScoreArgs a, int n_t
                 }
             }
         }
-        if (next < n_tiles) store_tile(cur ? it0 : it1);
+        if (next < t_end) store_tile(cur ? it0 : it1);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) sq_cur[q] = sq_nxt[q];
         __syncthreads();
