@@ -1081,14 +1081,7 @@ extern "C" size_t elimrec_segment_plan_workspace(int64_t n) {
 }
 extern "C" size_t elimrec_segment_reduce_workspace(int64_t n) { return elimrec_segment_plan_workspace(n); }
 
-static int plan_fast_max_keys() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("ELIMREC_PLAN_FAST");          // 0 disables the one-workgroup planner
-        v = (e && e[0] == '0') ? 0 : (1 << 30);
-    }
-    return v;
-}
+static int plan_fast_max_keys() { return 1 << 30; }          // (the one-workgroup planner for every batch size)
 
 static int segment_plan_impl(const int32_t *d_keys, int64_t n, int32_t split_key, int64_t key_space,
                              int32_t *d_active_rows, int32_t *d_seg_info, int32_t *d_slot_seg,

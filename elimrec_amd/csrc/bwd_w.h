@@ -195,7 +195,7 @@ __device__ __forceinline__ void reduce_slabs_body(const BwdBatch &batch, int bx,
 static inline void bwd_w_dims(int64_t R, int n1, int n2, int &chunk_rows, int &chunks, int &t1, int &t2) {
     const int tiles = ((n1 + TN1 - 1) / TN1) * ((n2 + TN2 - 1) / TN2);
     static int target = 0;
-    if (!target) { const char *e = getenv("ELIMREC_BWDW_WGS"); target = e ? atoi(e) : 480; if (target < 8) target = 8; }
+    if (!target) target = 480;
     int64_t want = (R * tiles + target - 1) / target;       // rows per workgroup for ~`target` workgroups per problem
     want = (want + TRB - 1) / TRB * TRB;
     chunk_rows = (int)(want < 64 ? 64 : (want > 512 ? 512 : want));

@@ -225,18 +225,8 @@ extern "C" int elimrec_linear_fwd_batched(const elimrec_linear_desc *descs, int 
         if (tn > max_tiles_n) max_tiles_n = tn;
     }
     if (max_tiles_m == 0) return 0;
-    static int tile_rows = 0;
-    if (!tile_rows) {
-        const char *e = getenv("ELIMREC_FWD_TILE");
-        tile_rows = (e && atoi(e) == 128) ? 128 : 64;
-    }
-    // persistent grid: about 4 (3) resident workgroups per CU in total across the problems of the batch
-    static int wg_budget = 0;
-    if (!wg_budget) {
-        const char *e = getenv("ELIMREC_FWD_WGS");
-        wg_budget = e ? atoi(e) : (1 << 30);      // default: one workgroup per tile (measured best); a smaller budget makes the kernel persistent
-        if (wg_budget < 64) wg_budget = 64;
-    }
+    const int tile_rows = 64;                     // (128-row tiles measured slower at these shapes)
+    const int wg_budget = 1 << 30;                // one workgroup per tile (measured best; a smaller budget makes the kernel persistent)
     int64_t per_problem = (wg_budget + (int64_t)n * max_tiles_n - 1) / ((int64_t)n * max_tiles_n);
     if (tile_rows == 128) {
         const int64_t tiles = (max_tiles_m + 127) / 128;
@@ -245,11 +235,7 @@ extern "C" int elimrec_linear_fwd_batched(const elimrec_linear_desc *descs, int 
     } else {
         const int64_t tiles = (max_tiles_m + 63) / 64;
         dim3 grid((unsigned)(tiles < per_problem ? tiles : per_problem), (unsigned)max_tiles_n, (unsigned)n);
-        static int depth = -1;
-        if (depth < 0) {
-            const char *e = getenv("ELIMREC_FWD_DEPTH");
-            depth = e ? atoi(e) : 0;
-        }
+        const int depth = 0;
         // small launches (about one workgroup per CU or less) take the deep software pipeline
         const int64_t wgs = (int64_t)grid.x * grid.y * grid.z;
         const int pd = depth > 0 ? depth : (wgs <= 768 ? 8 : 1);

@@ -1389,15 +1389,7 @@ static int launch_tier(const elimrec_sell *A, int family, int ns, int wl, int wl
     return check_hip(hipGetLastError(), "slab_hop(tiered)");
 }
 
-static int slab_wg_budget() {
-    static int v = 0;
-    if (!v) {
-        const char *e = getenv("ELIMREC_SLAB_WGS");
-        v = e ? atoi(e) : 256 * 6;
-        if (v < 8) v = 8;
-    }
-    return v;
-}
+static int slab_wg_budget() { return 256 * 6; }
 
 // family: 0 = fp32 tables (4 columns per lane); 1 = bf16-storage family (8 columns per lane)
 static int launch_stream(const elimrec_sell *A, int family, int ns, int wl, int wl_shift, int gs, int spg, int lpr, const void *Xin,

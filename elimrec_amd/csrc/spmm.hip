@@ -644,9 +644,7 @@ __global__ void build_masks_kernel(const int32_t *__restrict__ active_rows, cons
 static int stream_wgs() {
     static int v = 0;
     if (!v) {
-        const char *e = getenv("ELIMREC_STREAM_WGS");
-        v = e ? atoi(e) : 3072;            // 256 CUs x 4 resident workgroups x 3 (measured flat from 1536 up)
-        if (v < 1) v = 1;
+        v = 3072;                          // 256 CUs x 4 resident workgroups x 3 (measured flat from 1536 up)
     }
     return v;
 }

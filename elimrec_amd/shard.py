@@ -420,19 +420,7 @@ class ColumnShardTrainer(object):
             sizes = self._lookup_sizes(users, None)
             values["sizes"] = ctypes.addressof(sizes)
             self.xgmi_bytes["all_to_all_lookup"] = sum(sizes[:self.world]) - sizes[self.rank]
-        depth = self._native.get("throttle")
-        if depth is None:
-            import os
-            depth = self._native["throttle"] = int(os.environ.get("ELIMREC_NATIVE_THROTTLE", "0"))
-        if depth:                                            # (experiment: the host at most `depth` steps ahead of the GPU)
-            ring = self._native.setdefault("ring", [])
-            if len(ring) >= depth:
-                ring.pop(0).synchronize()
         prog.run(values)
-        if depth:
-            ev = torch.cuda.Event()
-            ev.record()
-            self._native["ring"].append(ev)
         eng.native_epilogue(3 * B)
         self._native["native_steps"] += 1
         return loss
@@ -595,7 +583,6 @@ class ColumnShardEngine(object):
         self._forked = False
         self._early_hops = os.environ.get("ELIMREC_EARLY_HOPS", "1") != "0"
         self._late_wait = os.environ.get("ELIMREC_LATE_WAIT", "1") != "0"
-        self._bits_late_on = os.environ.get("ELIMREC_BITS_LATE", "1") != "0"
         self.dl, self.col0 = d // world, rank * (d // world)
         self.ns, self.w = slab.choose_slabs16(self.dl) if self.bf16 else slab.choose_slabs(self.dl, N)
         self.gs = slab.choose_groups(self.ns)
@@ -635,11 +622,11 @@ class ColumnShardEngine(object):
         else:
             self.plan = slab.SellPlan(adj, dev, **kw)
             self.planT = self.plan if m._adj_symmetric else slab.SellPlan(adj.T.tocsr(), dev, **kw)
-        # a column slice beyond the Infinity Cache (configs[3] on one GPU, configs[4] on eight): the user rows of every WHOLE hop
+        # a column slice beyond the Infinity Cache (configs[3] on one GPU; up to 2^27 non-zeros unless forced): the user rows of every WHOLE hop
         # by the window sweep (csrc/sweep.hip), the item rows by a tile plan of their own; the masked hop, the split-rows hop of
         # the last forward layer and the batch-row kernels keep the whole plan. The hops then carry no tails (Adam, weight
         # gradients): those run as launches of their own, a few tens of microseconds beside hops of a millisecond.
-        self.sweep = bool(tiered and not self.wide and self.w in (16, 32) and slab.sweep_wanted(N, self.dl))
+        self.sweep = bool(tiered and not self.wide and self.w in (16, 32) and slab.sweep_wanted(N, self.dl, adj.nnz))
         if self.sweep:
             self.plan.sweep = slab.SweepPlan(self.plan, adj, m.num_users, dev, kw["threshold"], ipw)
             if self.planT is not self.plan:
@@ -912,8 +899,8 @@ class ColumnShardEngine(object):
 
         # the per-line source bits are needed by the first ADJOINT hop only: issued on the second stream BEHIND the forward's join
         # (cs_forward_rows), they run under the head kernels instead of lengthening what the forward waits for
-        # (ELIMREC_BITS_LATE=0: right behind the planner, in the forward's shadow)
-        self._bits_late = early_bits and self._bits_late_on and self._sources_in_head()
+        # (measured +-0 at today's hop times; it takes the bits out of the forward's shadow for faster hops)
+        self._bits_late = early_bits and self._sources_in_head()
 
         def plan():       # node ids of the slots, unique active rows + slot map, padded tail: one launch
             ops.batch_plan(users, pos, neg, m.num_users, m.num_items, keys, act, seg, ws["slot_seg"][:R], ws["plan_ws"], err, PAD_KEY,

@@ -455,13 +455,18 @@ class SweepPlan(object):
                                                       _dev(add_mask, "add_mask", torch.int32), float(scale), _stream()), "slab_sweep_hop")
 
 
-def sweep_wanted(n_rows, dl):
+SWEEP_AUTO_MAX_NNZ = 1 << 27
+
+
+def sweep_wanted(n_rows, dl, nnz=None):
     """Tables whose column slice is beyond the Infinity Cache (256 MB) take the window-sweep form for the side that gathers from
-    the large side (ELIMREC_SWEEP=1 / 0 forces it on / off)."""
+    the large side (ELIMREC_SWEEP=1 / 0 forces it on / off). Automatically only up to 2^27 non-zeros: the sweep plan costs 23 B
+    per non-zero on top of the tile plan and its geometry is built by numpy on the host -- at BASELINE.json configs[4]'s 2e9
+    non-zeros that is 43 GiB per GPU and hours, so that shape keeps the tile hop unless asked (capacity.plan counts either)."""
     env = os.environ.get("ELIMREC_SWEEP", "")
     if env in ("0", "1"):
         return env == "1"
-    return n_rows * dl * 4 > (256 << 20)
+    return n_rows * dl * 4 > (256 << 20) and (nnz is None or nnz <= SWEEP_AUTO_MAX_NNZ)
 
 
 class SlabTable(object):

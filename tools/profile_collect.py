@@ -100,8 +100,9 @@ if c4:
     print(json.dumps(c4, indent=1))
 if os.path.exists(O + "/multi_stats/m_kernel_stats.csv"):
     shutil.copy(O + "/multi_stats/m_kernel_stats.csv", "profiles/%s_multi_rank_path_kernel_stats.csv" % RND)
-if os.path.exists(O + "/multi_timeline.txt"):
-    shutil.copy(O + "/multi_timeline.txt", "profiles/%s_multi_rank_path_timeline.txt" % RND)
+for src, dst in (("multi_timeline.txt", "multi_rank_path_timeline.txt"), ("step_timeline.txt", "step_timeline.txt")):
+    if os.path.exists(O + "/" + src) and "step span" in open(O + "/" + src).read():
+        shutil.copy(O + "/" + src, "profiles/%s_%s" % (RND, dst))
 shutil.copy(O + "/stats/b_kernel_stats.csv", "profiles/%s_bench_kernel_stats.csv" % RND)
 shutil.copy(O + "/eval_stats/e_kernel_stats.csv", "profiles/%s_eval_kernel_stats.csv" % RND)
 ev, ef, ew = read(O + "/eval_pmc"), read(O + "/eval_fetch"), read(O + "/eval_write")

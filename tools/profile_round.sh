@@ -39,7 +39,12 @@ unset SWEEP SHAPE
 # the multi-rank step over a one-rank RCCL communicator (the library's own RCCL calls, issued from the step's program)
 export ELIMREC_SHARD_MULTI=1 FEATURE_SHARD=row
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/multi_stats -o m -- python3 $R/tools/step_trace.py 60 > $O/multi.log 2>&1 < /dev/null
-python3 $R/tools/timeline.py $(find $O/multi_stats -name "*kernel_trace.csv" | head -1) 3 > $O/multi_timeline.txt 2>&1
+T=$(find $O/multi_stats -name "*kernel_trace.csv" | head -1)
+[ -n "$T" ] && python3 $R/tools/timeline.py $T 3 > $O/multi_timeline.txt 2>&1       # (no trace file: the run died; keep the old timeline)
 unset ELIMREC_SHARD_MULTI FEATURE_SHARD
+# the one-rank step's timeline (the headline path)
+timeout 400 rocprofv3 --kernel-trace --output-format csv -d $O/step_trace -o s -- python3 $R/tools/step_trace.py 80 > $O/step_trace.log 2>&1 < /dev/null
+T=$(find $O/step_trace -name "*kernel_trace.csv" | head -1)
+[ -n "$T" ] && python3 $R/tools/timeline.py $T 3 > $O/step_timeline.txt 2>&1
 find $O -name "*kernel_trace.csv" -delete      # large; the stats csv is what gets committed
 ls -R $O | head -50
