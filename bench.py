@@ -149,7 +149,6 @@ def main():
     ap.add_argument("--no-eval", action="store_true", help="skip the secondary evaluator timing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-work", action="store_true", help="skip the reference-equivalent-work line")
-    ap.add_argument("--no-bf16", action="store_true", help="skip the bf16-storage (capacity mode) line")
     ap.add_argument("--feature-shard", choices=["auto", "row", "replicated"], default="auto",
                     help="folded constants S_m / c: row-sharded with an all_to_all lookup (default for N > 1, the north star's "
                          "partition) or replicated on every rank (default for N = 1, where both are the same tables)")
@@ -333,8 +332,6 @@ def main():
             extra("eval", lambda: eval_pass(model, cfg, torch))
         if world == 1 and not args.no_reference_work:
             extra("reference_equivalent_work", lambda: reference_work_line(args, device, cfg, batches, torch))
-        if world == 1 and not args.no_bf16:
-            extra("bf16_storage", lambda: bf16_line(args, device, cfg, batches, torch))
         if world == 1 and not args.no_b_sweep:
             extra("batch_sweep", lambda: batch_sweep(trainer, sampler, pools, B, torch))
         mu = pmc_field("mfma_utilisation")
@@ -483,52 +480,6 @@ def eval_pass(model, cfg, torch):
                                              "frac": flops / best / 1e12 / MFMA_F32_PEAK_TF}},
             "exact_math": {"seconds": min(exact), "users_per_s": n_eval / min(exact),
                            "frac_of_mfma_peak": flops / min(exact) / 1e12 / MFMA_F32_PEAK_TF}}
-
-
-def bf16_line(args, device, cfg, batches, torch, steps=30):
-    """The same step with bf16 table STORAGE (BASELINE.json configs[1] says "bf16"): bf16 layer tables, gather copy of X^0
-    and adjoint tables; fp32 accumulation, fp32 master parameters and Adam moments. A separately toleranced mode (loss
-    2e-3, tests/test_shard_gpu.py::test_bf16_storage_trainer_vs_rounding_oracle) printed BESIDE the fp32 headline."""
-    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam, slab
-    _, _, model = build(args, device)
-    model = model.to(device)
-    opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
-    eng = ColumnShardEngine(model, table_dtype="bf16")
-    tr = ColumnShardTrainer(eng, opt)
-    for i in range(5):
-        tr.step(*batches[i])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        loss = tr.step(*batches[(5 + i) % len(batches)])
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    tabs = [eng.mirror[eng.cur], eng.tmp[0], eng.tmp[1]]
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n_launch = 100
-
-    def chain(n):
-        src, dst = tabs[0], tabs[1]
-        for _ in range(n):
-            slab.hop(eng.plan, src, dst, gs=eng.gs)
-            src, dst = dst, (tabs[2] if dst is tabs[1] else tabs[1])
-    chain(4)
-    torch.cuda.synchronize()
-    e0.record(); chain(n_launch); e1.record()
-    torch.cuda.synchronize()
-    hop_us = e0.elapsed_time(e1) * 1e3 / n_launch
-    B = batches[0][0].numel()
-    N = model.num_users + model.num_items
-    hop_bytes = 2 * N * eng.dl * 2 + eng.plan.index_bytes()
-    return {"dtype": "bf16-storage/f32-acc", "purpose": "CAPACITY mode, not a throughput result: half the bytes of the layer / adjoint tables "
-                                                         "for shapes that would not fit (configs[4]); at this shape the fp32 step is the faster one "
-                                                         "(the hop is gather-latency bound, not byte bound; the one-launch tile hop, the Adam epilogue "
-                                                         "and the tail-workgroup fusions exist for fp32 only)",
-            "ms_per_step": 1e3 * dt, "steps": steps,
-            "final_loss": float(loss), "slabs": [eng.ns, eng.w, eng.gs],
-            "roofline": {"bound": "hbm", "kernel": "sell_hop16_kernel (+ sell_fixup16_kernel)", "achieved": hop_bytes / (hop_us * 1e-6) / 1e9,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hop_bytes / (hop_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_launch": hop_bytes, "avg_launch_us": hop_us, "launches_timed": n_launch}}
 
 
 def reference_work_line(args, device, cfg, batches, torch, steps=20):

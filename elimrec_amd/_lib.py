@@ -62,7 +62,7 @@ class SellDesc(ctypes.Structure):
 
 class AdamJob(ctypes.Structure):
     """struct elimrec_adam_job."""
-    _fields_ = [("d_p_in", ctypes.c_void_p), ("d_p_out", ctypes.c_void_p), ("d_p_bf16", ctypes.c_void_p), ("d_g", ctypes.c_void_p),
+    _fields_ = [("d_p_in", ctypes.c_void_p), ("d_p_out", ctypes.c_void_p), ("d_g", ctypes.c_void_p),
                 ("d_m", ctypes.c_void_p), ("d_v", ctypes.c_void_p), ("d_copy_dst", ctypes.c_void_p), ("n", ctypes.c_int64),
                 ("step", ctypes.c_int64)]
 
@@ -179,8 +179,6 @@ SIGNATURES = {
     "elimrec_topk_merge": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr]),
     "elimrec_rank_metrics": (c_i32, [c_ptr, c_i32, c_i32, c_ptr, c_ptr, ctypes.POINTER(c_i32), c_i32, c_ptr, c_ptr]),
     "elimrec_slab_partials_bytes": (c_size, [c_sell, c_i32, c_i32]),
-    "elimrec_slab_set_variant": (None, [c_i32]),
-    "elimrec_slab_set_stream": (None, [c_i32]),
     "elimrec_slab_hop": (c_i32, [c_sell, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr, c_size, c_i32,
                                  c_ptr]),
     "elimrec_topk_reference_order": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_i32, c_ptr]),
@@ -200,13 +198,6 @@ SIGNATURES = {
                                       c_ptr, c_ptr, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, ctypes.POINTER(AdamJob), c_i32, c_ptr]),
     "elimrec_slab_rows": (c_i32, [c_sell, c_i32, c_i32, c_i32, c_i64, ctypes.POINTER(c_ptr), c_ptr, c_ptr, c_ptr, c_i64, c_i32,
                                   c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr]),
-    "elimrec_slab_hop16": (c_i32, [c_sell, c_i32, c_i32, c_i32, c_ptr, c_i32, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_f32, c_ptr, c_size,
-                                   c_i32, c_ptr]),
-    "elimrec_slab_rows16": (c_i32, [c_sell, c_i32, c_i32, c_i32, c_i64, c_ptr, ctypes.POINTER(c_ptr), c_ptr, c_ptr, c_ptr, c_i64,
-                                    c_i32, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr]),
-    "elimrec_slab_to_bf16": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr]),
-    "elimrec_adam_step_out16": (c_i32, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32,
-                                        c_i64, c_ptr]),
     "elimrec_slab_from_rows": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr]),
     "elimrec_slab_to_rows": (c_i32, [c_ptr, c_i64, c_i32, c_i32, c_ptr, c_i64, c_i64, c_ptr]),
     "elimrec_slab_merge_rows": (c_i32, [c_ptr, c_ptr, c_i32, c_i64, c_i64, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr]),

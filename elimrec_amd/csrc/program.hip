@@ -39,14 +39,14 @@ struct FnEntry { const char *name; int (*thunk)(const uint64_t *); int n_args; }
 #define ELIMREC_FN(fn) {#fn, [](const uint64_t *a) -> int { return call_packed(fn, a); }, arg_count(fn)}
 static const FnEntry kFns[] = {
     ELIMREC_FN(elimrec_batch_plan), ELIMREC_FN(elimrec_slab_hop), ELIMREC_FN(elimrec_slab_sweep_hop), ELIMREC_FN(elimrec_slab_source_bits), ELIMREC_FN(elimrec_slab_hop_bwd_w),
-    ELIMREC_FN(elimrec_slab_hop_adam), ELIMREC_FN(elimrec_slab_rows), ELIMREC_FN(elimrec_slab_merge_rows), ELIMREC_FN(elimrec_slab_hop16),
-    ELIMREC_FN(elimrec_slab_rows16), ELIMREC_FN(elimrec_slab_to_bf16), ELIMREC_FN(elimrec_head_fwd_fused), ELIMREC_FN(elimrec_bpr_head_rows),
+    ELIMREC_FN(elimrec_slab_hop_adam), ELIMREC_FN(elimrec_slab_rows), ELIMREC_FN(elimrec_slab_merge_rows),
+    ELIMREC_FN(elimrec_head_fwd_fused), ELIMREC_FN(elimrec_bpr_head_rows),
     ELIMREC_FN(elimrec_bpr_head_rows_sum), ELIMREC_FN(elimrec_sum), ELIMREC_FN(elimrec_segment_apply_head_bwd),
     ELIMREC_FN(elimrec_segment_apply_head_bwd_packed), ELIMREC_FN(elimrec_segment_apply_head_bwd_sources),
     ELIMREC_FN(elimrec_segment_apply_head_bwd_split), ELIMREC_FN(elimrec_linear_fwd_batched), ELIMREC_FN(elimrec_linear_bwd_w_batched),
     ELIMREC_FN(elimrec_linear_bwd_w_batched_merge), ELIMREC_FN(elimrec_linear_bwd_w_reduce), ELIMREC_FN(elimrec_adam_multi),
     ELIMREC_FN(elimrec_source_rows_split), ELIMREC_FN(elimrec_copy_cols), ELIMREC_FN(elimrec_lookup_pack), ELIMREC_FN(elimrec_lookup_unpack),
-    ELIMREC_FN(elimrec_lookup_counts), ELIMREC_FN(elimrec_adam_step_out), ELIMREC_FN(elimrec_adam_step_out16),
+    ELIMREC_FN(elimrec_lookup_counts), ELIMREC_FN(elimrec_adam_step_out),
     ELIMREC_FN(elimrec_peer_cols_to_rows), ELIMREC_FN(elimrec_rows_bitmap), ELIMREC_FN(elimrec_comm_all_gather), ELIMREC_FN(elimrec_comm_all_reduce_f32),
     ELIMREC_FN(elimrec_comm_all_to_all), ELIMREC_FN(elimrec_comm_all_to_all_v), ELIMREC_FN(elimrec_wide_from_master),
     ELIMREC_FN(elimrec_wide_rows), ELIMREC_FN(elimrec_wide_grad), ELIMREC_FN(elimrec_head_fwd_fused_rows),

@@ -241,369 +241,11 @@ __global__ void adam_out_kernel(const float *__restrict__ p_in, float *__restric
     }
 }
 
-// inner-loop form of the unmasked hop: 0 = 8 neighbours per step; 1 = 4 per step with the next step's indices
-// prefetched; 2 = 8 + prefetch; 3 = 4
-static int g_slab_variant = -1;
-static int slab_variant() {
-    if (g_slab_variant < 0) {
-        const char *e = getenv("ELIMREC_SLAB_VARIANT");
-        g_slab_variant = e ? atoi(e) : 1;      // measured fastest on full tables and on column shards
-    }
-    return g_slab_variant;
-}
-
 // =====================================================================================================================
-// bf16 table storage (--table_dtype=bf16): the layer tables X^1..X^(L-1), the gather copy of X^0 and the adjoint's
-// intermediate tables are stored as bf16 (round-to-nearest-even, v_cvt_pk_bf16_f32); every sum is accumulated in fp32 and
-// the master parameters, the gradient, the Adam moments, the adjoint sources and the layer means stay fp32. A lane owns 8
-// columns (one 16-B load of a bf16 row piece, or two of an fp32 one), so a 64-column row is 128 B = one cache line.
-struct Sell16Args {
-    const int32_t *item_dst, *item_len, *blk_off, *col;
-    const float *val;
-    int64_t n_rows, n_src;
-    int n_seg, n_long;
-    int item_begin, item_end, seg_limit;
-    int w8, w8_shift, gs, spg;
-    const void *Xin;               // bf16 table, or fp32 table (IN_F32: row-sparse source behind src_mask, may be null mask)
-    const uint32_t *src_mask;
-    void *Xout;                    // bf16 or fp32 (OUT_F32)
-    const float4 *Add;             // fp32 table
-    const uint32_t *add_mask;
-    float scale;
-    float4 *partials;
-    const int32_t *long_rows, *long_seg_ptr;
-    int compact_long;
-};
-
-__device__ __forceinline__ void unpack_bf16x8(const uint4 q, float (&x)[8]) {
-    x[0] = __uint_as_float(q.x << 16); x[1] = __uint_as_float(q.x & 0xFFFF0000u);
-    x[2] = __uint_as_float(q.y << 16); x[3] = __uint_as_float(q.y & 0xFFFF0000u);
-    x[4] = __uint_as_float(q.z << 16); x[5] = __uint_as_float(q.z & 0xFFFF0000u);
-    x[6] = __uint_as_float(q.w << 16); x[7] = __uint_as_float(q.w & 0xFFFF0000u);
-}
-
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    const __hip_bfloat16 a = __float2bfloat16(lo), b = __float2bfloat16(hi);
-    return (uint32_t)__bfloat16_as_ushort(a) | ((uint32_t)__bfloat16_as_ushort(b) << 16);
-}
-
-__device__ __forceinline__ uint4 pack_bf16x8(const float (&x)[8]) {
-    return make_uint4(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7]));
-}
-
-template <bool OUT_F32>
-__device__ __forceinline__ void slab16_epilogue(const Sell16Args &a, int slab, int64_t row, int c8, float (&r)[8]) {
-    const int64_t idx = ((int64_t)slab * a.n_rows + row) * a.w8 + c8;      // in units of 8 columns
-    if (a.Add && (!a.add_mask || bit_of(a.add_mask, (int)row))) {
-        const float4 t0 = a.Add[2 * idx], t1 = a.Add[2 * idx + 1];
-        r[0] += t0.x; r[1] += t0.y; r[2] += t0.z; r[3] += t0.w; r[4] += t1.x; r[5] += t1.y; r[6] += t1.z; r[7] += t1.w;
-    }
-#pragma unroll
-    for (int t = 0; t < 8; ++t) r[t] *= a.scale;
-    if (OUT_F32) {
-        float4 *o = (float4 *)a.Xout + 2 * idx;
-        o[0] = make_float4(r[0], r[1], r[2], r[3]);
-        o[1] = make_float4(r[4], r[5], r[6], r[7]);
-    } else {
-        ((uint4 *)a.Xout)[idx] = pack_bf16x8(r);
-    }
-}
-
-template <int LPR, bool IN_F32, bool OUT_F32>
-__global__ __launch_bounds__(256) void sell_hop16_kernel(Sell16Args a) {
-    constexpr int IPW = 64 / LPR, U = 4;
-    const int lane = threadIdx.x & 63;
-    const int grp = (int)(blockIdx.x % (unsigned)a.gs);
-    const int64_t wblk = (int64_t)(blockIdx.x / (unsigned)a.gs) * 4 + (threadIdx.x >> 6);
-    const int64_t first = (int64_t)a.item_begin + wblk * IPW;
-    if (first >= a.item_end) return;
-    const int64_t item = first + lane / LPR;
-    const int cl = lane % LPR;
-    const int len = a.item_len[item];
-    const int dst = a.item_dst[item];
-    const int slab = grp * a.spg + (cl >> a.w8_shift);
-    const int c8 = cl & (a.w8 - 1);
-    const int64_t base = (int64_t)slab * a.n_src * a.w8 + c8;
-    const uint4 *X16 = (const uint4 *)a.Xin + base;
-    const float4 *X32 = (const float4 *)a.Xin + 2 * base;
-    const int64_t e0 = ((int64_t)a.blk_off[item >> 6] << 6) + (item & 63);
-    const int32_t *colp = a.col + e0;
-    const float *valp = a.val + e0;
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int ncj[U];
-    float nvj[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const bool in = u < len;
-        ncj[u] = in ? colp[(int64_t)u << 6] : 0;
-        nvj[u] = in ? valp[(int64_t)u << 6] : 0.f;
-    }
-    for (int j = 0; j < len; j += U) {
-        int cj[U];
-        float vj[U];
-        bool in[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) { in[u] = (j + u) < len; cj[u] = ncj[u]; vj[u] = nvj[u]; }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool nin = (j + U + u) < len;
-            ncj[u] = nin ? colp[(int64_t)(j + U + u) << 6] : 0;
-            nvj[u] = nin ? valp[(int64_t)(j + U + u) << 6] : 0.f;
-        }
-        if (IN_F32 && a.src_mask) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) in[u] = in[u] && bit_of(a.src_mask, cj[u]);
-        }
-        if (IN_F32) {
-            float4 x0[U], x1[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-                x0[u] = in[u] ? X32[(int64_t)cj[u] * a.w8 * 2] : z;
-                x1[u] = in[u] ? X32[(int64_t)cj[u] * a.w8 * 2 + 1] : z;
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                acc[0] = fmaf(vj[u], x0[u].x, acc[0]); acc[1] = fmaf(vj[u], x0[u].y, acc[1]);
-                acc[2] = fmaf(vj[u], x0[u].z, acc[2]); acc[3] = fmaf(vj[u], x0[u].w, acc[3]);
-                acc[4] = fmaf(vj[u], x1[u].x, acc[4]); acc[5] = fmaf(vj[u], x1[u].y, acc[5]);
-                acc[6] = fmaf(vj[u], x1[u].z, acc[6]); acc[7] = fmaf(vj[u], x1[u].w, acc[7]);
-            }
-        } else {
-            uint4 q[U];
-#pragma unroll
-            for (int u = 0; u < U; ++u) q[u] = in[u] ? X16[(int64_t)cj[u] * a.w8] : make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                float x[8];
-                unpack_bf16x8(q[u], x);
-#pragma unroll
-                for (int t = 0; t < 8; ++t) acc[t] = fmaf(vj[u], x[t], acc[t]);
-            }
-        }
-    }
-    if (dst < 0) return;
-    if (item < a.seg_limit) {
-        float4 *P = a.partials + 2 * (((int64_t)slab * a.n_seg + dst) * a.w8 + c8);
-        P[0] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-        P[1] = make_float4(acc[4], acc[5], acc[6], acc[7]);
-        return;
-    }
-    if (a.compact_long) return;
-    slab16_epilogue<OUT_F32>(a, slab, dst, c8, acc);
-}
-
-template <int LPR, bool OUT_F32>
-__global__ __launch_bounds__(256) void sell_fixup16_kernel(Sell16Args a) {
-    constexpr int NQ = 64 / LPR;
-    const int lane = threadIdx.x & 63;
-    const int grp = (int)(blockIdx.x % (unsigned)a.gs);
-    const int li = (int)(blockIdx.x / (unsigned)a.gs) * 4 + (int)(threadIdx.x >> 6);
-    if (li >= a.n_long) return;
-    const int q = lane / LPR, cl = lane % LPR;
-    const int slab = grp * a.spg + (cl >> a.w8_shift);
-    const int c8 = cl & (a.w8 - 1);
-    const int sb = a.long_seg_ptr[li], se = a.long_seg_ptr[li + 1];
-    const int per = (se - sb + NQ - 1) / NQ;
-    const int qb = min(sb + q * per, se), qe = min(qb + per, se);
-    const float4 *P = a.partials + 2 * ((int64_t)slab * a.n_seg * a.w8 + c8);
-    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int sgm = qb;
-    for (; sgm + 4 <= qe; sgm += 4) {
-        float4 p0[4], p1[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { p0[u] = P[(int64_t)(sgm + u) * a.w8 * 2]; p1[u] = P[(int64_t)(sgm + u) * a.w8 * 2 + 1]; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            acc[0] += p0[u].x; acc[1] += p0[u].y; acc[2] += p0[u].z; acc[3] += p0[u].w;
-            acc[4] += p1[u].x; acc[5] += p1[u].y; acc[6] += p1[u].z; acc[7] += p1[u].w;
-        }
-    }
-    for (; sgm < qe; ++sgm) {
-        const float4 p0 = P[(int64_t)sgm * a.w8 * 2], p1 = P[(int64_t)sgm * a.w8 * 2 + 1];
-        acc[0] += p0.x; acc[1] += p0.y; acc[2] += p0.z; acc[3] += p0.w; acc[4] += p1.x; acc[5] += p1.y; acc[6] += p1.z; acc[7] += p1.w;
-    }
-    float tot[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) tot[t] = NQ > 1 ? __shfl(acc[t], cl, 64) : acc[t];
-    const int nq = NQ + (a.n_long < 0 ? 1 : 0);
-#pragma unroll 2
-    for (int g = 1; g < nq; ++g) {
-#pragma unroll
-        for (int t = 0; t < 8; ++t) tot[t] += __shfl(acc[t], g * LPR + cl, 64);
-    }
-    if (q != 0) return;
-    if (a.compact_long) {
-        float4 *o = (float4 *)a.Xout + 2 * (((int64_t)slab * a.n_long + li) * a.w8 + c8);
-        o[0] = make_float4(tot[0], tot[1], tot[2], tot[3]);
-        o[1] = make_float4(tot[4], tot[5], tot[6], tot[7]);
-    } else slab16_epilogue<OUT_F32>(a, slab, a.long_rows[li], c8, tot);
-}
-
-struct Rows16Args {
-    const float4 *x0;                              // fp32 master table
-    const uint4 *x[kSlabMaxLayers + 1];            // bf16 layer tables 1..L (x[L] may be null)
-    int L;
-    int64_t U, n_rows;
-    int nc8, w8, w8_shift;
-    const float4 *long_tab;
-    int n_long;
-    const int32_t *long_index, *col;
-    const int64_t *rowptr;          // plain CSR row pointers: 64-bit (a 2e9-non-zero graph, BASELINE.json configs[4])
-    const float *val;
-    const int32_t *rows, *counts;
-    int64_t R;
-    int n_lists;
-    float *out0;
-    int64_t ld_out0;
-    float *narrow;
-    int64_t ld_narrow;
-    int by_node;
-    float inv;
-};
-
-template <int LR>
-__global__ __launch_bounds__(256) void slab_rows16_kernel(Rows16Args a) {
-    const int64_t s = (int64_t)blockIdx.x * (256 / LR) + threadIdx.x / LR;
-    const int cl = threadIdx.x % LR;
-    if (s >= a.R * a.n_lists) return;
-    int64_t r = s;
-    if (a.rows) {
-        const int64_t list = s / a.R;
-        if (a.counts && s - list * a.R >= a.counts[list]) return;
-        r = a.rows[s];
-        if (r < 0) return;                              // padding of a gathered list (negative keys); counts may be null
-    }
-    const bool user = r < a.U;
-    const bool inline_hop = a.x[a.L] == nullptr;
-    int li = -1;
-    int64_t beg = 0, end = 0;
-    if (inline_hop) {
-        li = a.long_index[r];
-        if (li < 0) { beg = a.rowptr[r]; end = a.rowptr[r + 1]; }
-    }
-    for (int c = cl; c < a.nc8; c += LR) {
-        const int slab = c >> a.w8_shift, c8 = c & (a.w8 - 1);
-        const int64_t idx = ((int64_t)slab * a.n_rows + r) * a.w8 + c8;
-        float xl[8];
-        if (!inline_hop) unpack_bf16x8(a.x[a.L][idx], xl);
-        else if (li >= 0) {
-            const float4 *p = a.long_tab + 2 * (((int64_t)slab * a.n_long + li) * a.w8 + c8);
-            const float4 p0 = p[0], p1 = p[1];
-            xl[0] = p0.x; xl[1] = p0.y; xl[2] = p0.z; xl[3] = p0.w; xl[4] = p1.x; xl[5] = p1.y; xl[6] = p1.z; xl[7] = p1.w;
-        } else {
-            const void *src = (a.L == 1) ? (const void *)a.x0 : (const void *)a.x[a.L - 1];
-            const int64_t base = (int64_t)slab * a.n_rows * a.w8 + c8;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) xl[t] = 0.f;
-            for (int64_t j = beg; j < end; j += 4) {
-                int cj[4];
-                float vj[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const bool in = (j + u) < end;
-                    cj[u] = in ? a.col[j + u] : 0;
-                    vj[u] = in ? a.val[j + u] : 0.f;
-                }
-                if (a.L == 1) {            // the gather source is the fp32 master itself
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        if ((j + u) < end) {
-                            const float4 *p = (const float4 *)src + 2 * (base + (int64_t)cj[u] * a.w8);
-                            const float4 p0 = p[0], p1 = p[1];
-                            xl[0] = fmaf(vj[u], p0.x, xl[0]); xl[1] = fmaf(vj[u], p0.y, xl[1]); xl[2] = fmaf(vj[u], p0.z, xl[2]);
-                            xl[3] = fmaf(vj[u], p0.w, xl[3]); xl[4] = fmaf(vj[u], p1.x, xl[4]); xl[5] = fmaf(vj[u], p1.y, xl[5]);
-                            xl[6] = fmaf(vj[u], p1.z, xl[6]); xl[7] = fmaf(vj[u], p1.w, xl[7]);
-                        }
-                    }
-                } else {
-                    uint4 q[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        q[u] = (j + u) < end ? ((const uint4 *)src)[base + (int64_t)cj[u] * a.w8] : make_uint4(0u, 0u, 0u, 0u);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        float x[8];
-                        unpack_bf16x8(q[u], x);
-#pragma unroll
-                        for (int t = 0; t < 8; ++t) xl[t] = fmaf(vj[u], x[t], xl[t]);
-                    }
-                }
-            }
-        }
-        float x0[8], x1[8], sum[8], nar[8];
-        {
-            const float4 p0 = a.x0[2 * idx], p1 = a.x0[2 * idx + 1];
-            x0[0] = p0.x; x0[1] = p0.y; x0[2] = p0.z; x0[3] = p0.w; x0[4] = p1.x; x0[5] = p1.y; x0[6] = p1.z; x0[7] = p1.w;
-        }
-        if (a.L == 1) {
-#pragma unroll
-            for (int t = 0; t < 8; ++t) x1[t] = xl[t];
-        } else unpack_bf16x8(a.x[1][idx], x1);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) { sum[t] = x0[t] + x1[t]; nar[t] = user ? x0[t] : x1[t]; }
-        for (int k = 2; k <= a.L; ++k) {
-            float v[8];
-            if (k == a.L) {
-#pragma unroll
-                for (int t = 0; t < 8; ++t) v[t] = xl[t];
-            } else unpack_bf16x8(a.x[k][idx], v);
-            const bool mine = ((k & 1) == 0) == user;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) { sum[t] += v[t]; if (mine) nar[t] += v[t]; }
-        }
-        float4 *o = reinterpret_cast<float4 *>(a.out0 + s * a.ld_out0 + 8 * c);
-        o[0] = make_float4(sum[0] * a.inv, sum[1] * a.inv, sum[2] * a.inv, sum[3] * a.inv);
-        o[1] = make_float4(sum[4] * a.inv, sum[5] * a.inv, sum[6] * a.inv, sum[7] * a.inv);
-        float4 *q2 = reinterpret_cast<float4 *>(a.narrow + (a.by_node ? r : s) * a.ld_narrow + 8 * c);
-        q2[0] = make_float4(nar[0] * a.inv, nar[1] * a.inv, nar[2] * a.inv, nar[3] * a.inv);
-        q2[1] = make_float4(nar[4] * a.inv, nar[5] * a.inv, nar[6] * a.inv, nar[7] * a.inv);
-    }
-}
-
-__global__ void slab_to_bf16_kernel(const float4 *__restrict__ src, int64_t n8, uint4 *__restrict__ dst) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
-        const float4 a = src[2 * i], b = src[2 * i + 1];
-        const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-        dst[i] = pack_bf16x8(x);
-    }
-}
-
-// Adam with the parameters read from p_in and written to p_out AND, rounded, to the bf16 gather copy
-__global__ void adam_out16_kernel(const float4 *__restrict__ p_in, float4 *__restrict__ p_out, uint2 *__restrict__ p16,
-                                  const float4 *__restrict__ g, float4 *__restrict__ m, float4 *__restrict__ v, int64_t n4,
-                                  float step_size, float beta1, float beta2, float inv_sqrt_bc2, float eps, float wd) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const float4 P = p_in[i], G = g[i], M = m[i], V = v[i];
-        float pi[4] = {P.x, P.y, P.z, P.w}, gi[4] = {G.x, G.y, G.z, G.w}, mi[4] = {M.x, M.y, M.z, M.w}, vi[4] = {V.x, V.y, V.z, V.w};
-        float po[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float gg = fmaf(wd, pi[t], gi[t]);
-            mi[t] = mi[t] + (1.f - beta1) * (gg - mi[t]);
-            vi[t] = fmaf(1.f - beta2, gg * gg, beta2 * vi[t]);
-            const float denom = sqrtf(vi[t]) * inv_sqrt_bc2 + eps;
-            po[t] = pi[t] - step_size * (mi[t] / denom);
-        }
-        m[i] = make_float4(mi[0], mi[1], mi[2], mi[3]);
-        v[i] = make_float4(vi[0], vi[1], vi[2], vi[3]);
-        p_out[i] = make_float4(po[0], po[1], po[2], po[3]);
-        p16[i] = make_uint2(pack_bf16x2(po[0], po[1]), pack_bf16x2(po[2], po[3]));
-    }
-}
-
-// =====================================================================================================================
-// The hop as ONE persistent launch (ELIMREC_SLAB_STREAM=1/2; measured slower than hop + fix-up kernels, kept as the
-// experiment it was -- see slab_stream()): every wave walks its wave blocks b, b + stride, ... with the index chain
-// software-pipelined across blocks -- the (len, dst, offset) records of block b+2 and the first (col, val) of block b+1
-// are in flight while block b gathers -- so the three dependent round trips a block costs when taken cold (record ->
-// indices -> rows) are paid once per wave instead of once per block: what bounds a hop whose table is small (a column
-// shard, bf16 storage) is that chain times the number of rounds, not bytes. The split rows are finished inside the same
-// launch: a segment wave publishes its partial row write-through (sc1), drains its stores, draws a ticket for the row,
-// and the wave that draws a row's last ticket does one agent-scope acquire and adds the row's partials in the order of
-// sell_fixup_kernel (so both forms give the same bits) -- cdna_hip_programming.md Guideline 16, recipe R1 in its
-// counter form; no second launch. One template covers fp32 tables (a lane owns 4 columns) and the bf16-storage family
-// (8 columns: 16 B of a bf16 row piece, or two float4 of an fp32 one).
+// Argument block and lane helpers shared by the hop forms below. A lane owns VPL = 4 columns of a row piece (one 16-B load);
+// split rows publish partial rows write-through (sc1), draw a ticket per row, and the wave that draws a row's last ticket adds
+// the partials in segment order after ONE agent-scope acquire (cdna_hip_programming.md Guideline 16, recipe R1 in its counter
+// form).
 struct StreamArgs {
     const int32_t *item_dst, *item_len, *blk_off, *col, *item_long;
     const float *val;
@@ -632,33 +274,21 @@ struct StreamArgs {
 
 template <int VPL, bool BF16>
 __device__ __forceinline__ void lane_load(const void *base, int64_t idx, float (&x)[VPL]) {
-    if constexpr (VPL == 4) {
-        const float4 t = ((const float4 *)base)[idx];
-        x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
-    } else if constexpr (BF16) {
-        unpack_bf16x8(((const uint4 *)base)[idx], x);
-    } else {
-        const float4 t0 = ((const float4 *)base)[2 * idx], t1 = ((const float4 *)base)[2 * idx + 1];
-        x[0] = t0.x; x[1] = t0.y; x[2] = t0.z; x[3] = t0.w; x[4] = t1.x; x[5] = t1.y; x[6] = t1.z; x[7] = t1.w;
-    }
+    static_assert(VPL == 4 && !BF16, "fp32 tables: a lane owns four columns");
+    const float4 t = ((const float4 *)base)[idx];
+    x[0] = t.x; x[1] = t.y; x[2] = t.z; x[3] = t.w;
 }
 
 template <int VPL, bool BF16>
 __device__ __forceinline__ void lane_store(void *base, int64_t idx, const float (&x)[VPL]) {
-    if constexpr (VPL == 4) {
+    static_assert(VPL == 4 && !BF16, "fp32 tables: a lane owns four columns");
 #ifdef ELIMREC_NT_OUT
-        typedef float f4v __attribute__((ext_vector_type(4)));
-        f4v v = {x[0], x[1], x[2], x[3]};
-        __builtin_nontemporal_store(v, ((f4v *)base) + idx);
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    f4v v = {x[0], x[1], x[2], x[3]};
+    __builtin_nontemporal_store(v, ((f4v *)base) + idx);
 #else
-        ((float4 *)base)[idx] = make_float4(x[0], x[1], x[2], x[3]);
+    ((float4 *)base)[idx] = make_float4(x[0], x[1], x[2], x[3]);
 #endif
-    } else if constexpr (BF16) {
-        ((uint4 *)base)[idx] = pack_bf16x8(x);
-    } else {
-        ((float4 *)base)[2 * idx] = make_float4(x[0], x[1], x[2], x[3]);
-        ((float4 *)base)[2 * idx + 1] = make_float4(x[4], x[5], x[6], x[7]);
-    }
 }
 
 template <int VPL, bool OUT_BF16, bool ADAM = false>
@@ -692,7 +322,7 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, int slab, i
     lane_store<VPL, OUT_BF16>(a.Xout, idx, r);
 }
 
-// the whole wave on one split row (li wave-uniform): same order as sell_fixup_kernel / sell_fixup16_kernel
+// the whole wave on one split row (li wave-uniform): same order as sell_fixup_kernel
 template <int LPR, int VPL, bool OUT_BF16, bool ADAM = false>
 __device__ __forceinline__ void stream_combine(const StreamArgs &a, int grp, int li) {
     constexpr int NQ = 64 / LPR, UNR = VPL == 4 ? 8 : 4;
@@ -737,157 +367,14 @@ __device__ __forceinline__ void stream_combine(const StreamArgs &a, int grp, int
     else stream_epilogue<VPL, OUT_BF16, ADAM>(a, slab, a.long_rows[li], c, tot);
 }
 
-// sum_j val[j] * Xin[col[j]] of one work item per lane group, neighbour order, fmaf; the (col, val) of step j + U are in
-// flight while step j gathers; ccj / cvj hold the first step on entry
-template <int VPL, bool IN_BF16, bool MASKED, int U>
-__device__ __forceinline__ void stream_gather(const StreamArgs &a, const uint32_t *mask, int64_t in_base, int64_t e0, int len,
-                                              int (&ccj)[U], float (&cvj)[U], float (&acc)[VPL]) {
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) acc[i] = 0.f;
-    for (int j = 0; j < len; j += U) {
-        int cj[U];
-        float vj[U];
-        bool in[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) { in[u] = (j + u) < len; cj[u] = ccj[u]; vj[u] = cvj[u]; }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool nin = (j + U + u) < len;
-            ccj[u] = nin ? a.col[e0 + ((int64_t)(j + U + u) << 6)] : 0;
-            cvj[u] = nin ? a.val[e0 + ((int64_t)(j + U + u) << 6)] : 0.f;
-        }
-        if (MASKED) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) in[u] = in[u] && bit_of(mask, cj[u]);
-        }
-        float x[U][VPL];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (in[u]) lane_load<VPL, IN_BF16>(a.Xin, in_base + (int64_t)cj[u] * a.wl, x[u]);
-            else {
-#pragma unroll
-                for (int i = 0; i < VPL; ++i) x[u][i] = 0.f;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int i = 0; i < VPL; ++i) acc[i] = fmaf(vj[u], x[u][i], acc[i]);
-    }
-}
-
-template <int LPR, int VPL, bool IN_BF16, bool OUT_BF16, bool MASKED>
-__global__ __launch_bounds__(256) void sell_stream_kernel(StreamArgs a) {
-    constexpr int IPW = 64 / LPR, U = 4;
-    const int lane = threadIdx.x & 63;
-    const int grp = (int)(blockIdx.x % (unsigned)a.gs);
-    const int64_t wave_g = (int64_t)(blockIdx.x / (unsigned)a.gs) * 4 + (threadIdx.x >> 6);
-    const int64_t stride = (int64_t)(gridDim.x / (unsigned)a.gs) * 4;
-    const int sub = lane / LPR, cl = lane % LPR;
-    const int slab = grp * a.spg + (cl >> a.wl_shift);
-    const int c = cl & (a.wl - 1);
-    const int64_t in_base = (int64_t)slab * a.n_src * a.wl + c;
-    auto load_desc = [&](int64_t wb, int &len, int &dst, int64_t &e0) {
-        len = 0; dst = -1; e0 = 0;
-        if (wb < a.n_blocks) {
-            const int64_t item = wb * IPW + sub;
-            len = a.item_len[item];
-            dst = a.item_dst[item];
-            e0 = ((int64_t)a.blk_off[item >> 6] << 6) + (item & 63);
-        }
-    };
-    auto load_idx = [&](int64_t e0, int len, int (&cj)[U], float (&vj)[U]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool in = u < len;
-            cj[u] = in ? a.col[e0 + ((int64_t)u << 6)] : 0;
-            vj[u] = in ? a.val[e0 + ((int64_t)u << 6)] : 0.f;
-        }
-    };
-    const int64_t seg_blocks = (int64_t)a.seg_limit / IPW;           // segment items fill whole blocks of 64
-    int64_t wb = wave_g;
-    // ---- phase A: the segments of the split rows (the heaviest items, first in the order); partial rows, tickets
-    if (wb < seg_blocks && wb < a.n_blocks) {
-        __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(
-            (void *)a.partials, 0, a.tickets ? (int)min((size_t)0x7FFFFFF0, (size_t)a.n_seg * a.gs * a.spg * a.wl * VPL * 4) : 0, 0x00020000);
-        for (; wb < seg_blocks && wb < a.n_blocks; wb += stride) {
-            int len, dst;
-            int64_t e0;
-            load_desc(wb, len, dst, e0);
-            int cj0[U];
-            float vj0[U];
-            load_idx(e0, len, cj0, vj0);
-            float acc[VPL];
-            stream_gather<VPL, IN_BF16, MASKED, U>(a, a.src_mask, in_base, e0, len, cj0, vj0, acc);
-            if (dst >= 0) {
-                const int64_t pidx = ((int64_t)slab * a.n_seg + dst) * a.wl + c;
-                if (!a.tickets) lane_store<VPL, false>(a.partials, pidx, acc);
-                else {
-#pragma unroll
-                    for (int h = 0; h < VPL / 4; ++h) {
-                        u32x4s bits = {__float_as_uint(acc[4 * h]), __float_as_uint(acc[4 * h + 1]), __float_as_uint(acc[4 * h + 2]),
-                                       __float_as_uint(acc[4 * h + 3])};
-                        __builtin_amdgcn_raw_buffer_store_b128(bits, prsrc, (unsigned)((pidx * (VPL / 4) + h) * 16), 0, 16 /* sc1 */);
-                    }
-                }
-            }
-            if (!a.tickets) continue;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            int li = -1, ticket = -1, nseg = 0;
-            if (dst >= 0) {
-                li = a.item_long[wb * IPW + sub];
-                nseg = a.long_seg_ptr[li + 1] - a.long_seg_ptr[li];
-                if (cl == 0) ticket = __hip_atomic_fetch_add(&a.tickets[(int64_t)grp * a.n_long + li], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            ticket = __shfl(ticket, sub * LPR, 64);
-            const bool last = dst >= 0 && ticket == nseg - 1;
-            if (__ballot(last) == 0ull) continue;                   // wave-uniform
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll 1
-            for (int g = 0; g < IPW; ++g) {
-                if (!__shfl(last ? 1 : 0, g * LPR, 64)) continue;
-                const int g_li = __shfl(li, g * LPR, 64);
-                stream_combine<LPR, VPL, OUT_BF16>(a, grp, g_li);
-                if (lane == 0) __hip_atomic_store(&a.tickets[(int64_t)grp * a.n_long + g_li], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-    if (a.compact_long || wb >= a.n_blocks) return;
-    // ---- phase B: the unsplit rows, index chain pipelined across blocks
-    int clen, cdst, nlen, ndst;
-    int64_t ce0, ne0;
-    load_desc(wb, clen, cdst, ce0);
-    load_desc(wb + stride, nlen, ndst, ne0);
-    int ccj[U];
-    float cvj[U];
-    load_idx(ce0, clen, ccj, cvj);
-    for (; wb < a.n_blocks; wb += stride) {
-        int flen, fdst;
-        int64_t fe0;
-        load_desc(wb + 2 * stride, flen, fdst, fe0);
-        int ncj0[U];
-        float nvj0[U];
-        load_idx(ne0, nlen, ncj0, nvj0);
-        float acc[VPL];
-        stream_gather<VPL, IN_BF16, MASKED, U>(a, a.src_mask, in_base, ce0, clen, ccj, cvj, acc);
-        if (cdst >= 0) stream_epilogue<VPL, OUT_BF16>(a, slab, cdst, c, acc);
-        clen = nlen; cdst = ndst; ce0 = ne0;
-        nlen = flen; ndst = fdst; ne0 = fe0;
-#pragma unroll
-        for (int u = 0; u < U; ++u) { ccj[u] = ncj0[u]; cvj[u] = nvj0[u]; }
-    }
-}
-
 // The whole optimizer step in ONE launch: up to 8 jobs (the column shard of the embeddings, read from one buffer and
-// written to the other and -- bf16 storage -- to the gather copy; the spans of the projection weights that have a
+// written to the other; the spans of the projection weights that have a
 // gradient, in place; copy-only spans). A job may also copy its PRE-update parameters to copy_dst: the snapshot of the
 // projection weights the cached tables were computed with (models/EliMRec.py:98-99). Arithmetic of adam_kernel.
 // The same body also runs as extra workgroups at the end of the hop + Adam launch (sell_tier_kernel<..., ADAM>).
 struct AdamJob {
     const float *p_in;
     float *p_out;
-    uint16_t *p16;          // nullable
     const float *g;         // nullable: copy-only job
     float *m, *v;
     float *copy_dst;        // nullable
@@ -914,7 +401,6 @@ __device__ __forceinline__ void adam_jobs_body(const AdamJobs &jobs, int block, 
         jb.v[i] = vi;
         const float po = pi - jb.step_size * (mi / denom);
         jb.p_out[i] = po;
-        if (jb.p16) jb.p16[i] = __bfloat16_as_ushort(__float2bfloat16(po));
     }
 }
 
@@ -1236,15 +722,6 @@ __global__ __launch_bounds__(256) void sell_tier_bwdw_kernel(TierArgs t, BwdBatc
     tier_body<LPR, 4, false, false, MASKED, false, true>(t, &As[0][0]);
 }
 
-// the split rows by a second launch (ELIMREC_SLAB_STREAM=2: persistent hop without the in-launch combine)
-template <int LPR, int VPL, bool OUT_BF16>
-__global__ __launch_bounds__(256) void stream_fixup_kernel(StreamArgs a) {
-    const int grp = (int)(blockIdx.x % (unsigned)a.gs);
-    const int li = (int)(blockIdx.x / (unsigned)a.gs) * 4 + (int)(threadIdx.x >> 6);
-    if (li >= a.n_long) return;
-    stream_combine<LPR, VPL, OUT_BF16>(a, grp, li);
-}
-
 static int log2_pow2(int x) {
     int s = 0;
     while ((1 << s) < x) ++s;
@@ -1254,8 +731,6 @@ static int log2_pow2(int x) {
 }  // namespace elimrec
 
 using namespace elimrec;
-
-extern "C" void elimrec_slab_set_variant(int v) { g_slab_variant = v; }
 
 static size_t slab_partial_floats_bytes(const elimrec_sell *A, int ns, int w) {
     return align_up((size_t)(A->n_seg > 0 ? A->n_seg : 1) * ns * w * sizeof(float), 256);
@@ -1273,20 +748,6 @@ extern "C" size_t elimrec_slab_partials_bytes(const elimrec_sell *A, int ns, int
     return slab_partial_floats_bytes(A, ns, w) + slab_ticket_bytes(A) + slab_ballot_bytes(A);
 }
 
-static int g_slab_stream = -1;
-static int slab_stream() {
-    if (g_slab_stream < 0) {
-        const char *e = getenv("ELIMREC_SLAB_STREAM");
-        // 0 (default): hop + fix-up kernels; 1: persistent, in-launch combine; 2: persistent + fix-up launch. Measured at
-        // the Tiktok shape (tools/bench_slab_modes.py, us per hop, T = 32): fp32 w32x2  37.0 / 45.5 / 40.9; bf16 w64
-        // 25.7 / 42.5 / 32.8; an 8-column shard  21.0 / 76.8 / 19.9 (bf16: 25 / 256 / 28) -- the acquire fence of the
-        // in-launch combine drops the CU's L1 under every wave that is gathering from an L1/L2-resident table
-        g_slab_stream = e ? atoi(e) : 0;
-    }
-    return g_slab_stream;
-}
-extern "C" void elimrec_slab_set_stream(int mode) { g_slab_stream = mode; }
-
 struct AdamEpilogue {
     const float *p_in; float *p_out, *m, *v;
     float step_size, inv_sqrt_bc2, beta1, beta2, eps, wd;
@@ -1294,8 +755,8 @@ struct AdamEpilogue {
     const AdamJobs *tail;          // nullable
 };
 
-static int launch_tier(const elimrec_sell *A, int family, int ns, int wl, int wl_shift, int gs, int spg, int lpr, const void *Xin,
-                       bool in_bf16, const uint32_t *src_mask, void *Xout, bool out_bf16, const float *add,
+static int launch_tier(const elimrec_sell *A, int ns, int wl, int wl_shift, int gs, int spg, int lpr, const void *Xin,
+                       const uint32_t *src_mask, void *Xout, const float *add,
                        const uint32_t *add_mask, float scale, float *partials, int flags, hipStream_t s,
                        const AdamEpilogue *adam = nullptr, const BwdBatch *bwdw = nullptr, int tail_mode = 0, int tail_blocks = 0,
                        int reduce_gx = 1) {
@@ -1316,8 +777,7 @@ static int launch_tier(const elimrec_sell *A, int family, int ns, int wl, int wl
     a.Xin = Xin; a.src_mask = src_mask; a.Xout = Xout;
     a.Add = seg_only ? nullptr : (const float4 *)add; a.add_mask = add_mask; a.scale = seg_only ? 1.0f : scale;
     a.partials = partials; a.long_rows = A->d_long_rows; a.long_seg_ptr = A->d_long_seg_ptr;
-    const int vpl = family ? 8 : 4;
-    a.tickets = (int32_t *)((char *)partials + slab_partial_floats_bytes(A, ns, wl * vpl));
+    a.tickets = (int32_t *)((char *)partials + slab_partial_floats_bytes(A, ns, wl * 4));
     a.compact_long = seg_only ? 1 : 0;
     if (adam) {
         a.ad_p_in = adam->p_in; a.ad_p_out = adam->p_out; a.ad_m = adam->m; a.ad_v = adam->v;
@@ -1355,26 +815,15 @@ static int launch_tier(const elimrec_sell *A, int family, int ns, int wl, int wl
     }
 #define ELIMREC_TIER(LPR)                                                                                                     \
     do {                                                                                                                      \
-        if (!family) {                                                                                                        \
-            if (adam) hipLaunchKernelGGL((sell_tier_adam_kernel<LPR>), grid_adam, dim3(256), 0, s, t, tail, tail_block0);     \
-            else if (bwdw && masked)                                                                                          \
-                hipLaunchKernelGGL((sell_tier_bwdw_kernel<LPR, true>), dim3(grid.x + (unsigned)tail_blocks), dim3(256), 0, s, t,       \
-                                   *bwdw, tail_block0, tail_mode, reduce_gx);                                                 \
-            else if (bwdw)                                                                                                    \
-                hipLaunchKernelGGL((sell_tier_bwdw_kernel<LPR, false>), dim3(grid.x + (unsigned)tail_blocks), dim3(256), 0, s, t,      \
-                                   *bwdw, tail_block0, tail_mode, reduce_gx);                                                 \
-            else if (masked) hipLaunchKernelGGL((sell_tier_kernel<LPR, 4, false, false, true>), grid, dim3(256), 0, s, t);    \
-            else hipLaunchKernelGGL((sell_tier_kernel<LPR, 4, false, false, false>), grid, dim3(256), 0, s, t);               \
-        } else if (in_bf16) {                                                                                                 \
-            if (out_bf16) hipLaunchKernelGGL((sell_tier_kernel<LPR, 8, true, true, false>), grid, dim3(256), 0, s, t);        \
-            else hipLaunchKernelGGL((sell_tier_kernel<LPR, 8, true, false, false>), grid, dim3(256), 0, s, t);                \
-        } else if (masked) {                                                                                                  \
-            if (out_bf16) hipLaunchKernelGGL((sell_tier_kernel<LPR, 8, false, true, true>), grid, dim3(256), 0, s, t);        \
-            else hipLaunchKernelGGL((sell_tier_kernel<LPR, 8, false, false, true>), grid, dim3(256), 0, s, t);                \
-        } else {                                                                                                              \
-            if (out_bf16) hipLaunchKernelGGL((sell_tier_kernel<LPR, 8, false, true, false>), grid, dim3(256), 0, s, t);       \
-            else hipLaunchKernelGGL((sell_tier_kernel<LPR, 8, false, false, false>), grid, dim3(256), 0, s, t);               \
-        }                                                                                                                     \
+        if (adam) hipLaunchKernelGGL((sell_tier_adam_kernel<LPR>), grid_adam, dim3(256), 0, s, t, tail, tail_block0);         \
+        else if (bwdw && masked)                                                                                              \
+            hipLaunchKernelGGL((sell_tier_bwdw_kernel<LPR, true>), dim3(grid.x + (unsigned)tail_blocks), dim3(256), 0, s, t,  \
+                               *bwdw, tail_block0, tail_mode, reduce_gx);                                                     \
+        else if (bwdw)                                                                                                        \
+            hipLaunchKernelGGL((sell_tier_bwdw_kernel<LPR, false>), dim3(grid.x + (unsigned)tail_blocks), dim3(256), 0, s, t, \
+                               *bwdw, tail_block0, tail_mode, reduce_gx);                                                     \
+        else if (masked) hipLaunchKernelGGL((sell_tier_kernel<LPR, 4, false, false, true>), grid, dim3(256), 0, s, t);        \
+        else hipLaunchKernelGGL((sell_tier_kernel<LPR, 4, false, false, false>), grid, dim3(256), 0, s, t);                   \
     } while (0)
     switch (lpr) {
         case 1: ELIMREC_TIER(1); break;
@@ -1387,81 +836,6 @@ static int launch_tier(const elimrec_sell *A, int family, int ns, int wl, int wl
     }
 #undef ELIMREC_TIER
     return check_hip(hipGetLastError(), "slab_hop(tiered)");
-}
-
-static int slab_wg_budget() { return 256 * 6; }
-
-// family: 0 = fp32 tables (4 columns per lane); 1 = bf16-storage family (8 columns per lane)
-static int launch_stream(const elimrec_sell *A, int family, int ns, int wl, int wl_shift, int gs, int spg, int lpr, const void *Xin,
-                         bool in_bf16, const uint32_t *src_mask, void *Xout, bool out_bf16, const float *add,
-                         const uint32_t *add_mask, float scale, float *partials, int seg_only, hipStream_t s) {
-    StreamArgs a = {};
-    a.item_dst = A->d_item_dst; a.item_len = A->d_item_len; a.blk_off = A->d_blk_off; a.col = A->d_col; a.val = A->d_val;
-    a.item_long = A->d_item_long;
-    a.n_rows = A->n_rows; a.n_src = A->n_src; a.n_seg = A->n_seg; a.n_long = A->n_long;
-    const int ipw = 64 / lpr;
-    a.n_blocks = (int64_t)(seg_only ? A->n_seg_items : A->n_items) / ipw;
-    a.seg_limit = A->n_seg_items;
-    a.wl = wl; a.wl_shift = wl_shift; a.gs = gs; a.spg = spg;
-    a.Xin = Xin; a.src_mask = src_mask; a.Xout = Xout;
-    a.Add = seg_only ? nullptr : (const float4 *)add; a.add_mask = add_mask; a.scale = seg_only ? 1.0f : scale;
-    a.partials = partials; a.long_rows = A->d_long_rows; a.long_seg_ptr = A->d_long_seg_ptr;
-    const int vpl = family ? 8 : 4;
-    const bool in_launch = slab_stream() == 1;
-    a.tickets = (A->n_long > 0 && in_launch) ? (int32_t *)((char *)partials + slab_partial_floats_bytes(A, ns, wl * vpl)) : nullptr;
-    a.compact_long = seg_only ? 1 : 0;
-    if (a.n_blocks <= 0) return 0;
-    int64_t per_group = (a.n_blocks + 3) / 4;
-    const int64_t cap = slab_wg_budget() / gs > 0 ? slab_wg_budget() / gs : 1;
-    if (per_group > cap) per_group = cap;
-    const dim3 grid((unsigned)(per_group * gs));
-    const bool masked = src_mask != nullptr;
-#define ELIMREC_STREAM(LPR)                                                                                                     \
-    do {                                                                                                                        \
-        if (!family) {                                                                                                          \
-            if (masked) hipLaunchKernelGGL((sell_stream_kernel<LPR, 4, false, false, true>), grid, dim3(256), 0, s, a);         \
-            else hipLaunchKernelGGL((sell_stream_kernel<LPR, 4, false, false, false>), grid, dim3(256), 0, s, a);               \
-        } else if (in_bf16) {                                                                                                   \
-            if (out_bf16) hipLaunchKernelGGL((sell_stream_kernel<LPR, 8, true, true, false>), grid, dim3(256), 0, s, a);        \
-            else hipLaunchKernelGGL((sell_stream_kernel<LPR, 8, true, false, false>), grid, dim3(256), 0, s, a);                \
-        } else if (masked) {                                                                                                    \
-            if (out_bf16) hipLaunchKernelGGL((sell_stream_kernel<LPR, 8, false, true, true>), grid, dim3(256), 0, s, a);        \
-            else hipLaunchKernelGGL((sell_stream_kernel<LPR, 8, false, false, true>), grid, dim3(256), 0, s, a);                \
-        } else {                                                                                                                \
-            if (out_bf16) hipLaunchKernelGGL((sell_stream_kernel<LPR, 8, false, true, false>), grid, dim3(256), 0, s, a);       \
-            else hipLaunchKernelGGL((sell_stream_kernel<LPR, 8, false, false, false>), grid, dim3(256), 0, s, a);               \
-        }                                                                                                                       \
-    } while (0)
-    switch (lpr) {
-        case 1: ELIMREC_STREAM(1); break;
-        case 2: ELIMREC_STREAM(2); break;
-        case 4: ELIMREC_STREAM(4); break;
-        case 8: ELIMREC_STREAM(8); break;
-        case 16: ELIMREC_STREAM(16); break;
-        case 32: ELIMREC_STREAM(32); break;
-        default: ELIMREC_STREAM(64); break;
-    }
-#undef ELIMREC_STREAM
-    int rc = check_hip(hipGetLastError(), "slab_hop(stream)");
-    if (rc || in_launch || A->n_long <= 0) return rc;
-    const dim3 fgrid((unsigned)((A->n_long + 3) / 4) * (unsigned)gs);
-#define ELIMREC_SFIX(LPR)                                                                                              \
-    do {                                                                                                               \
-        if (!family) hipLaunchKernelGGL((stream_fixup_kernel<LPR, 4, false>), fgrid, dim3(256), 0, s, a);              \
-        else if (out_bf16) hipLaunchKernelGGL((stream_fixup_kernel<LPR, 8, true>), fgrid, dim3(256), 0, s, a);         \
-        else hipLaunchKernelGGL((stream_fixup_kernel<LPR, 8, false>), fgrid, dim3(256), 0, s, a);                      \
-    } while (0)
-    switch (lpr) {
-        case 1: ELIMREC_SFIX(1); break;
-        case 2: ELIMREC_SFIX(2); break;
-        case 4: ELIMREC_SFIX(4); break;
-        case 8: ELIMREC_SFIX(8); break;
-        case 16: ELIMREC_SFIX(16); break;
-        case 32: ELIMREC_SFIX(32); break;
-        default: ELIMREC_SFIX(64); break;
-    }
-#undef ELIMREC_SFIX
-    return check_hip(hipGetLastError(), "slab_hop(stream fix-up)");
 }
 
 static int slab_geometry(const char *who, int ns, int w, int gs, int &w4_shift, int &spg, int &lpr) {
@@ -1509,12 +883,8 @@ extern "C" int elimrec_slab_hop(const elimrec_sell *A, int ns, int w, int gs, co
     a.compact_long = seg_only ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
     if (A->tiered)
-        return launch_tier(A, 0, ns, w / 4, w4_shift, gs, spg, lpr, d_Xin, false, d_src_mask, d_Xout, false, d_add, d_add_mask, scale,
+        return launch_tier(A, ns, w / 4, w4_shift, gs, spg, lpr, d_Xin, d_src_mask, d_Xout, d_add, d_add_mask, scale,
                            d_partials, flags, s);
-    if (slab_stream() && A->d_item_long)
-        return launch_stream(A, 0, ns, w / 4, w4_shift, gs, spg, lpr, d_Xin, false, d_src_mask, d_Xout, false, d_add, d_add_mask, scale,
-                             d_partials, seg_only, s);
-    const int variant = slab_variant();
     const int n_it = a.item_end - a.item_begin;
     if (n_it > 0) {
         const int ipw = 64 / lpr;
@@ -1522,10 +892,7 @@ extern "C" int elimrec_slab_hop(const elimrec_sell *A, int ns, int w, int gs, co
 #define ELIMREC_SELL_LAUNCH(LPR)                                                                          \
     do {                                                                                                  \
         if (d_src_mask) hipLaunchKernelGGL((sell_hop_kernel<LPR, true, 8, false>), dim3(blocks), dim3(256), 0, s, a); \
-        else if (variant == 1) hipLaunchKernelGGL((sell_hop_kernel<LPR, false, 4, true>), dim3(blocks), dim3(256), 0, s, a); \
-        else if (variant == 2) hipLaunchKernelGGL((sell_hop_kernel<LPR, false, 8, true>), dim3(blocks), dim3(256), 0, s, a); \
-        else if (variant == 3) hipLaunchKernelGGL((sell_hop_kernel<LPR, false, 4, false>), dim3(blocks), dim3(256), 0, s, a); \
-        else hipLaunchKernelGGL((sell_hop_kernel<LPR, false, 8, false>), dim3(blocks), dim3(256), 0, s, a); \
+        else hipLaunchKernelGGL((sell_hop_kernel<LPR, false, 4, true>), dim3(blocks), dim3(256), 0, s, a);            \
     } while (0)
         switch (lpr) {
             case 1: ELIMREC_SELL_LAUNCH(1); break;
@@ -1565,7 +932,7 @@ static int build_adam_jobs(const char *who, const elimrec_adam_job *jobs, int n_
         ELIMREC_REQUIRE(!j.d_g || (j.d_p_out && j.d_m && j.d_v && j.step >= 1), "%s: job %d: an update needs p_out, m, v and a 1-based step", who, k);
         ELIMREC_REQUIRE(j.d_g || j.d_copy_dst, "%s: job %d does nothing", who, k);
         AdamJob &o = a.j[a.n++];
-        o.p_in = j.d_p_in; o.p_out = j.d_p_out; o.p16 = (uint16_t *)j.d_p_bf16; o.g = j.d_g; o.m = j.d_m; o.v = j.d_v;
+        o.p_in = j.d_p_in; o.p_out = j.d_p_out; o.g = j.d_g; o.m = j.d_m; o.v = j.d_v;
         o.copy_dst = j.d_copy_dst; o.n = j.n;
         if (j.d_g) {
             const double bc1 = 1.0 - pow((double)beta1, (double)j.step);
@@ -1618,7 +985,7 @@ extern "C" int elimrec_slab_hop_bwd_w(const elimrec_sell *A, int ns, int w, int 
     int blocks = 0, max_out = 0;
     if ((rc = bwd_w_build_batch(descs, n, d_workspace, batch, blocks, max_out))) return rc;
     const int gx = (4 * max_out + 255) / 256;
-    return launch_tier(A, 0, ns, w / 4, w4_shift, gs, spg, lpr, d_Xin, false, d_src_mask, d_Xout, false, d_add, d_add_mask, scale,
+    return launch_tier(A, ns, w / 4, w4_shift, gs, spg, lpr, d_Xin, d_src_mask, d_Xout, d_add, d_add_mask, scale,
                        d_partials, flags, (hipStream_t)stream, nullptr, &batch, phase == 0 ? 2 : 1, phase == 0 ? blocks : gx * n, gx);
 }
 
@@ -1651,7 +1018,7 @@ extern "C" int elimrec_slab_hop_adam(const elimrec_sell *A, int ns, int w, int g
         if ((rc = build_adam_jobs("slab_hop_adam", tail_jobs, n_tail_jobs, lr, beta1, beta2, tail))) return rc;
         ad.tail = &tail;
     }
-    return launch_tier(A, 0, ns, w / 4, w4_shift, gs, spg, lpr, d_Xin, false, nullptr, d_grad_out, false, d_add, d_add_mask, scale,
+    return launch_tier(A, ns, w / 4, w4_shift, gs, spg, lpr, d_Xin, nullptr, d_grad_out, d_add, d_add_mask, scale,
                        d_partials, 0, (hipStream_t)stream, &ad);
 }
 
@@ -1789,149 +1156,6 @@ extern "C" int elimrec_adam_step_out(const float *d_p_in, float *d_p_out, const 
     hipLaunchKernelGGL(adam_out_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_p_in, d_p_out, d_g, d_m,
                        d_v, n, step_size, beta1, beta2, inv_sqrt_bc2, eps, weight_decay);
     ELIMREC_LAUNCH_CHECK("adam_step_out");
-    return 0;
-}
-
-// ---------------------------------------------------------------------------------------------------- bf16 storage
-static int slab16_geometry(const char *who, int ns, int w, int gs, int &w8_shift, int &spg, int &lpr) {
-    w8_shift = (w > 0 && w % 8 == 0) ? log2_pow2(w / 8) : -1;
-    if (ns < 1 || w8_shift < 0) { set_error("%s: bf16 slab width must be 8 * 2^k (got w=%d, ns=%d)", who, w, ns); return ELIMREC_E_BADARG; }
-    if (gs < 1 || ns % gs != 0) { set_error("%s: %d slab groups do not divide %d slabs", who, gs, ns); return ELIMREC_E_BADARG; }
-    spg = ns / gs;
-    if (log2_pow2(spg) < 0 || spg * (w / 8) > 64) { set_error("%s: bad slabs per group %d", who, spg); return ELIMREC_E_BADARG; }
-    lpr = spg * (w / 8);
-    return 0;
-}
-
-extern "C" int elimrec_slab_hop16(const elimrec_sell *A, int ns, int w, int gs, const void *d_Xin, int in_f32,
-                                  const uint32_t *d_src_mask, void *d_Xout, int out_f32, const float *d_add,
-                                  const uint32_t *d_add_mask, float scale, float *d_partials, size_t partials_bytes,
-                                  int seg_only, void *stream) {
-    ELIMREC_REQUIRE(A && d_Xin && d_Xout && d_Xin != d_Xout, "slab_hop16: bad pointers");
-    ELIMREC_REQUIRE(in_f32 || !d_src_mask, "slab_hop16: a source bitmap goes with an fp32 (row-sparse) source");
-    ELIMREC_REQUIRE(A->n_items % 64 == 0 && A->n_seg_items % 64 == 0 && A->n_seg_items <= A->n_items, "slab_hop16: bad plan");
-    int w8_shift, spg, lpr, rc;
-    if ((rc = slab16_geometry("slab_hop16", ns, w, gs, w8_shift, spg, lpr))) return rc;
-    if ((A->n_long > 0 || A->tiered) && (!d_partials || partials_bytes < elimrec_slab_partials_bytes(A, ns, w))) {
-        set_error("slab_hop16: partial-row scratch too small");
-        return ELIMREC_E_WORKSPACE;
-    }
-    Sell16Args a = {};
-    a.item_dst = A->d_item_dst; a.item_len = A->d_item_len; a.blk_off = A->d_blk_off; a.col = A->d_col; a.val = A->d_val;
-    a.n_rows = A->n_rows; a.n_src = A->n_src; a.n_seg = A->n_seg; a.n_long = A->n_long;
-    a.item_begin = 0; a.item_end = seg_only ? A->n_seg_items : A->n_items; a.seg_limit = A->n_seg_items;
-    a.w8 = w / 8; a.w8_shift = w8_shift; a.gs = gs; a.spg = spg;
-    a.Xin = d_Xin; a.src_mask = d_src_mask; a.Xout = d_Xout;
-    a.Add = seg_only ? nullptr : (const float4 *)d_add; a.add_mask = d_add_mask; a.scale = seg_only ? 1.0f : scale;
-    a.partials = (float4 *)d_partials; a.long_rows = A->d_long_rows; a.long_seg_ptr = A->d_long_seg_ptr;
-    a.compact_long = seg_only ? 1 : 0;
-    hipStream_t s = (hipStream_t)stream;
-    const int n_it = a.item_end - a.item_begin;
-    const bool of = out_f32 != 0 || seg_only;
-    if (A->tiered)
-        return launch_tier(A, 1, ns, w / 8, w8_shift, gs, spg, lpr, d_Xin, !in_f32, d_src_mask, d_Xout, !of, d_add, d_add_mask, scale,
-                           d_partials, seg_only, s);
-    if (slab_stream() && A->d_item_long)
-        return launch_stream(A, 1, ns, w / 8, w8_shift, gs, spg, lpr, d_Xin, !in_f32, d_src_mask, d_Xout, !of, d_add, d_add_mask, scale,
-                             d_partials, seg_only, s);
-#define ELIMREC_SELL16(LPR)                                                                                         \
-    do {                                                                                                            \
-        if (n_it > 0) {                                                                                             \
-            const unsigned blocks = (unsigned)(((int64_t)n_it / (64 / LPR) + 3) / 4) * (unsigned)gs;                \
-            if (in_f32 && of) hipLaunchKernelGGL((sell_hop16_kernel<LPR, true, true>), dim3(blocks), dim3(256), 0, s, a);   \
-            else if (in_f32) hipLaunchKernelGGL((sell_hop16_kernel<LPR, true, false>), dim3(blocks), dim3(256), 0, s, a);   \
-            else if (of) hipLaunchKernelGGL((sell_hop16_kernel<LPR, false, true>), dim3(blocks), dim3(256), 0, s, a);       \
-            else hipLaunchKernelGGL((sell_hop16_kernel<LPR, false, false>), dim3(blocks), dim3(256), 0, s, a);              \
-        }                                                                                                           \
-        if (A->n_long > 0) {                                                                                        \
-            const unsigned blocks = (unsigned)((A->n_long + 3) / 4) * (unsigned)gs;                                 \
-            if (of) hipLaunchKernelGGL((sell_fixup16_kernel<LPR, true>), dim3(blocks), dim3(256), 0, s, a);         \
-            else hipLaunchKernelGGL((sell_fixup16_kernel<LPR, false>), dim3(blocks), dim3(256), 0, s, a);           \
-        }                                                                                                           \
-    } while (0)
-    switch (lpr) {
-        case 1: ELIMREC_SELL16(1); break;
-        case 2: ELIMREC_SELL16(2); break;
-        case 4: ELIMREC_SELL16(4); break;
-        case 8: ELIMREC_SELL16(8); break;
-        case 16: ELIMREC_SELL16(16); break;
-        case 32: ELIMREC_SELL16(32); break;
-        default: ELIMREC_SELL16(64); break;
-    }
-#undef ELIMREC_SELL16
-    ELIMREC_LAUNCH_CHECK("slab_hop16");
-    return 0;
-}
-
-extern "C" int elimrec_slab_rows16(const elimrec_sell *A, int ns, int w, int L, int64_t U, const float *d_x0,
-                                   const void *const *layers16, const float *d_long, const int32_t *d_rows,
-                                   const int32_t *d_counts, int64_t R, int n_lists, float *d_out0, int64_t ld_out0,
-                                   float *d_narrow, int64_t ld_narrow, int narrow_by_node, void *stream) {
-    ELIMREC_REQUIRE(A && d_x0 && layers16 && d_out0 && d_narrow, "slab_rows16: null pointer");
-    ELIMREC_REQUIRE(L >= 1 && L <= kSlabMaxLayers, "slab_rows16: 1 <= L <= %d", kSlabMaxLayers);
-    ELIMREC_REQUIRE(ld_out0 % 4 == 0 && ld_narrow % 4 == 0, "slab_rows16: leading dimensions must be multiples of 4");
-    ELIMREC_REQUIRE(n_lists >= 1 && (d_rows || n_lists == 1), "slab_rows16: several lists need row ids");
-    int w8_shift, spg, lpr, rc;
-    if ((rc = slab16_geometry("slab_rows16", ns, w, ns, w8_shift, spg, lpr))) return rc;
-    Rows16Args a = {};
-    a.x0 = (const float4 *)d_x0;
-    a.x[0] = nullptr;
-    for (int k = 1; k <= L; ++k) a.x[k] = (const uint4 *)layers16[k - 1];
-    for (int k = 1; k < L; ++k) ELIMREC_REQUIRE(a.x[k], "slab_rows16: layer table %d missing", k);
-    ELIMREC_REQUIRE(a.x[L] || (A->d_rowptr && A->d_csr_col && A->d_csr_val && A->d_long_index && (A->n_long == 0 || d_long)),
-                    "slab_rows16: the inline last hop needs the CSR, the long-row index and the long-row table");
-    a.L = L; a.U = U; a.n_rows = A->n_rows; a.nc8 = ns * (w / 8); a.w8 = w / 8; a.w8_shift = w8_shift;
-    a.long_tab = (const float4 *)d_long; a.n_long = A->n_long; a.long_index = A->d_long_index;
-    a.rowptr = A->d_rowptr; a.col = A->d_csr_col; a.val = A->d_csr_val;
-    a.rows = d_rows; a.counts = d_counts; a.R = R; a.n_lists = n_lists;
-    a.out0 = d_out0; a.ld_out0 = ld_out0; a.narrow = d_narrow; a.ld_narrow = ld_narrow; a.by_node = narrow_by_node;
-    a.inv = 1.0f / (float)(L + 1);
-    const int64_t total = R * n_lists;
-    if (total <= 0) return 0;
-    int lr = 1;
-    while (lr < a.nc8 && lr < 64) lr *= 2;
-    hipStream_t s = (hipStream_t)stream;
-    const unsigned blocks = (unsigned)((total + (256 / lr) - 1) / (256 / lr));
-    switch (lr) {
-        case 1: hipLaunchKernelGGL((slab_rows16_kernel<1>), dim3(blocks), dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL((slab_rows16_kernel<2>), dim3(blocks), dim3(256), 0, s, a); break;
-        case 4: hipLaunchKernelGGL((slab_rows16_kernel<4>), dim3(blocks), dim3(256), 0, s, a); break;
-        case 8: hipLaunchKernelGGL((slab_rows16_kernel<8>), dim3(blocks), dim3(256), 0, s, a); break;
-        case 16: hipLaunchKernelGGL((slab_rows16_kernel<16>), dim3(blocks), dim3(256), 0, s, a); break;
-        case 32: hipLaunchKernelGGL((slab_rows16_kernel<32>), dim3(blocks), dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL((slab_rows16_kernel<64>), dim3(blocks), dim3(256), 0, s, a); break;
-    }
-    ELIMREC_LAUNCH_CHECK("slab_rows16");
-    return 0;
-}
-
-extern "C" int elimrec_slab_to_bf16(const float *d_src, int64_t n_elems, void *d_dst, void *stream) {
-    ELIMREC_REQUIRE(d_src && d_dst && n_elems % 8 == 0, "slab_to_bf16: element count must be a multiple of 8");
-    if (n_elems <= 0) return 0;
-    int64_t blocks = (n_elems / 8 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(slab_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)d_src,
-                       n_elems / 8, (uint4 *)d_dst);
-    ELIMREC_LAUNCH_CHECK("slab_to_bf16");
-    return 0;
-}
-
-extern "C" int elimrec_adam_step_out16(const float *d_p_in, float *d_p_out, void *d_p_bf16, const float *d_g, float *d_m,
-                                       float *d_v, int64_t n, float lr, float beta1, float beta2, float eps,
-                                       float weight_decay, int64_t step, void *stream) {
-    ELIMREC_REQUIRE(d_p_in && d_p_out && d_p_bf16 && d_g && d_m && d_v, "adam_step_out16: null pointer");
-    ELIMREC_REQUIRE(step >= 1 && n % 4 == 0, "adam_step_out16: step is 1-based, n a multiple of 4");
-    if (n <= 0) return 0;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    const float step_size = (float)((double)lr / bc1);
-    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    int64_t blocks = (n / 4 + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(adam_out16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)d_p_in,
-                       (float4 *)d_p_out, (uint2 *)d_p_bf16, (const float4 *)d_g, (float4 *)d_m, (float4 *)d_v, n / 4, step_size,
-                       beta1, beta2, inv_sqrt_bc2, eps, weight_decay);
-    ELIMREC_LAUNCH_CHECK("adam_step_out16");
     return 0;
 }
 

@@ -529,11 +529,8 @@ class ColumnShardEngine(object):
     """The cs_* interface on the HIP kernels, around an EliMRec model (which keeps the plan, the folded constants, the
     head kernels' workspace, the projection weights and the cached tables predict() reads)."""
 
-    def __init__(self, model, group=None, table_dtype=None, feature_shard=None, feature_dtype=None):
-        """table_dtype: "f32" (default) or "bf16" -- bf16 STORAGE of the layer tables, of the gather copy of X^0 and of the
-        adjoint's intermediate tables with fp32 accumulation and fp32 master parameters / moments (also the config key
-        --table_dtype). A separately toleranced mode, never the parity path.
-        feature_shard: "replicated" (default: every rank holds the folded constants S_m / c of all N rows) or "row" (config
+    def __init__(self, model, group=None, feature_shard=None, feature_dtype=None):
+        """feature_shard: "replicated" (default: every rank holds the folded constants S_m / c of all N rows) or "row" (config
         key --feature_shard): rank o holds the rows of its 1/world of the users and of the items only, and a step fetches
         the rows of its active nodes from their owners with an all_to_all (elimrec_amd/lookup.py) -- the north star's row
         shards + all-to-all index lookup, for the tables that are N x sum(D_m) and only read. Bitwise the replicated
@@ -556,11 +553,10 @@ class ColumnShardEngine(object):
         self.lookup = feature_shard == "row" or feature_dtype != "f32" or bool(getattr(model, "_wide", False))
         # ... and only row shards exchange rows between ranks; otherwise every rank widens / gathers from its own full copy
         self.lookup_exchange = feature_shard == "row"
-        if table_dtype is None:
-            table_dtype = str(cfg["table_dtype"]) if "table_dtype" in cfg else "f32"
-        if table_dtype not in ("f32", "bf16"):
-            raise ValueError("table_dtype must be 'f32' or 'bf16' (got %r)" % (table_dtype,))
-        self.bf16 = table_dtype == "bf16"
+        if "table_dtype" in cfg and str(cfg["table_dtype"]) != "f32":
+            raise ValueError("--table_dtype=%s: the graph tables are fp32 (bf16 storage of the layer tables was removed in round 4: "
+                             "it saved 9 %% of the table bytes and was slower, DESIGN.md section 7); 16-bit storage exists for the "
+                             "feature constants: --feature_dtype=f16|bf16" % cfg["table_dtype"])
         if not getattr(model, "_lazy", False):
             raise ValueError("the column-sharded engine needs the folded propagation with batch head rows "
                              "(bipartite adjacency: adj_type pre/plain/gcmc; layer_num >= 2; --head_rows=batch)")
@@ -581,28 +577,23 @@ class ColumnShardEngine(object):
         import os
         self.multi = world > 1 or os.environ.get("ELIMREC_SHARD_MULTI", "0") == "1"
         self._forked = False
-        self._early_hops = os.environ.get("ELIMREC_EARLY_HOPS", "1") != "0"
-        self._late_wait = os.environ.get("ELIMREC_LATE_WAIT", "1") != "0"
         self.dl, self.col0 = d // world, rank * (d // world)
-        self.ns, self.w = slab.choose_slabs16(self.dl) if self.bf16 else slab.choose_slabs(self.dl, N)
+        self.ns, self.w = slab.choose_slabs(self.dl, N)
         self.gs = slab.choose_groups(self.ns)
         # an adjacency with a diagonal (adj_type norm / mean + I): the graph carries the E_u-borne and the E_i-borne part side by
         # side in WIDE tables of 2 dl columns (csrc/wide.hip); `hns` / `hgs` = slabs / slab groups of the tables the hops run on
         self.wide = bool(getattr(m, "_wide", False))
-        if self.wide and self.bf16:
-            raise ValueError("bf16 table storage is not available for adjacencies with a diagonal (adj_type norm / mean)")
         if self.wide and world > 1 and self.feature_shard != "row":
             raise ValueError("an adjacency with a diagonal on several ranks needs --feature_shard=row")
         self.hns = 2 * self.ns if self.wide else self.ns
         self.hgs = slab.choose_groups(self.hns) if self.wide else self.gs
         adj = m._scipy_adj()
-        ipw = 64 // max(1, (self.hns // self.hgs) * (self.w // (8 if self.bf16 else 4)))   # lane groups per wave of this geometry
-        # launch form of a hop (tools/bench_slab_modes.py, Tiktok shape, us per hop): fp32 tables -- the one-launch form over
-        # wave tiles (whole table, 64-neighbour tiles: 31 against 36 for hop + fix-up kernels; an 8-column shard, 32-neighbour
-        # tiles: 20.3 against 21.6; 16 columns: 19.5 against 21.7), which also lets the last adjoint hop carry the Adam
-        # step; bf16 tables -- hop + fix-up kernels with 32-neighbour items (25 against 30)
+        ipw = 64 // max(1, (self.hns // self.hgs) * (self.w // 4))   # lane groups per wave of this geometry
+        # launch form of a hop (Tiktok shape, us per hop): the one-launch form over wave tiles (whole table, 64-neighbour tiles:
+        # 31 against 36 for hop + fix-up kernels; an 8-column shard, 32-neighbour tiles: 20.3 against 21.6; 16 columns: 19.5
+        # against 21.7), which also lets the last adjoint hop carry the Adam step
         import os
-        tiered = not self.bf16 and os.environ.get("ELIMREC_SLAB_TIERED", "1") != "0"
+        tiered = os.environ.get("ELIMREC_SLAB_TIERED", "1") != "0"
         kw = dict(side_split=m.num_users, ipw=ipw, tiered=tiered,
                   threshold=(64 if world == 1 else 32) if tiered else slab.LONG_ROW_THRESHOLD)
         if tiered and getattr(m, "_plan_build", "host") == "device":
@@ -632,11 +623,8 @@ class ColumnShardEngine(object):
             if self.planT is not self.plan:
                 self.planT.sweep = slab.SweepPlan(self.planT, adj.T.tocsr(), m.num_users, dev, kw["threshold"], ipw)
         tab = lambda: slab.SlabTable(N, self.ns, self.w, dev)
-        tdt = torch.bfloat16 if self.bf16 else torch.float32
-        ttab = lambda: slab.SlabTable(N, self.ns, self.w, dev, dtype=tdt)      # a propagated (stored) table
         L = m.n_layers
         self.master = [tab(), tab()]
-        self.mirror = [ttab(), ttab()] if self.bf16 else None       # bf16 gather copies of the two master buffers
         self.cur = 0
         self.long_tab = torch.empty(self.ns * max(self.plan.n_long, 1) * self.w, dtype=torch.float32, device=dev)
         self.xL = None                                            # full hop-L table, only when predict() needs it
@@ -652,8 +640,8 @@ class ColumnShardEngine(object):
             self.srcA = slab.SlabTable(N, self.ns, self.w, dev, data=self.srcW.data[:half])
             self.srcB = slab.SlabTable(N, self.ns, self.w, dev, data=self.srcW.data[half:])
         else:
-            self.layers = [None] + [ttab() for _ in range(L - 1)]
-            self.srcA, self.srcB, self.tmp = tab(), tab(), [ttab(), ttab()]
+            self.layers = [None] + [tab() for _ in range(L - 1)]
+            self.srcA, self.srcB, self.tmp = tab(), tab(), [tab(), tab()]
         self.mask = torch.zeros((N + 31) // 32 + 2, dtype=torch.int32, device=dev)
         self.step_count = 0
         self._side = None
@@ -724,8 +712,6 @@ class ColumnShardEngine(object):
             del x0
         else:
             self.master[self.cur].from_rows(ws["X0d"], col0=self.col0)
-        if self.bf16:
-            self.master[self.cur].to_bf16(self.mirror[self.cur])
         ws["snap"].copy_(ws["flat_param"][ws["tail_off"]:])        # from here on the snapshot is refreshed by cs_update
 
     @torch.no_grad()
@@ -822,7 +808,7 @@ class ColumnShardEngine(object):
         tiered plan, at least two layers (ELIMREC_FUSE_ADAM=0 keeps the separate optimizer launch; `keep_grad` = True also
         stores the gradient table, for tests that read it)."""
         import os
-        return (not self.bf16 and not self.wide and not self.sweep and self.planT.tiered and self.model.n_layers >= 2
+        return (not self.wide and not self.sweep and self.planT.tiered and self.model.n_layers >= 2
                 and os.environ.get("ELIMREC_FUSE_ADAM", "1") != "0")
 
     @_once
@@ -832,7 +818,7 @@ class ColumnShardEngine(object):
         import os
         m = self.model
         hops_in_region = m.n_layers - (1 if self._fuse_adam() else 0)
-        return (os.environ.get("ELIMREC_FUSE_REDUCE", "1") != "0" and not self.bf16 and not self.wide and not self.sweep and self.planT.tiered
+        return (os.environ.get("ELIMREC_FUSE_REDUCE", "1") != "0" and not self.wide and not self.sweep and self.planT.tiered
                 and hops_in_region >= 1 and m.mm_fusion_mode == "concat")
 
     @_once
@@ -890,7 +876,7 @@ class ColumnShardEngine(object):
 
         aux = self._aux_stream()
         self._head_split = self._rows_in_head = False
-        early_bits = aux is not None and self.planT.tiered and not self.bf16 and not self.multi      # (several ranks: cs_gathered_ids)
+        early_bits = aux is not None and self.planT.tiered and not self.multi      # (several ranks: cs_gathered_ids)
         if aux is not None and self._forked and getattr(self, "_ws_gen_planned", None) != m._ws_gen:
             # another batch size's buffer set (possibly allocated -- and zero-filled ON THE MAIN STREAM -- a moment ago, after
             # cs_fork ordered the second stream): order it again behind the main stream before the planner writes into it
@@ -927,7 +913,7 @@ class ColumnShardEngine(object):
                 self._head_split = self._head16 and not self.lookup and self._split_head
                 if self._head_split:
                     m._region("cs_head_features", (m._ws_gen, R), features)
-                self._rows_in_head = (self._head_split and self._rows_in_head_on and not self.multi and not self.bf16 and not self.wide
+                self._rows_in_head = (self._head_split and self._rows_in_head_on and not self.multi and not self.wide
                                       and self.dl == 64 and self.ns * self.w == 64)
         self._aux_pending = True
         # several ranks: the second stream goes on to the adjoint's source bits once the ids are gathered (cs_gathered_ids); what
@@ -953,7 +939,7 @@ class ColumnShardEngine(object):
         (all ranks' rows) and the masked hop's per-line source bits -- a whole forward pass before the rows arrive."""
         aux = self._aux_stream()
         m = self.model
-        if aux is None or not self.planT.tiered or self.bf16:
+        if aux is None or not self.planT.tiered:
             return
         with torch.cuda.stream(aux):
             handle.wait()                                   # the second stream behind the id exchange
@@ -970,7 +956,7 @@ class ColumnShardEngine(object):
         forward hops (which need nothing of the plan) before cs_plan's host work -- the GPU starts on the step at once.
         Returns whether it did (then cs_plan does not fork again)."""
         aux = self._aux_stream()
-        if aux is None or self.model._ws is None or not self._early_hops:
+        if aux is None or self.model._ws is None:
             return False
         program.sync(aux, torch.cuda.current_stream())
         self._forked = True
@@ -983,8 +969,7 @@ class ColumnShardEngine(object):
         x0 = self.master[self.cur]
         self._x0_fwd = x0
         tabs = self._tabs = [x0] + self.layers[1:]
-        # what the hops GATHER from: the bf16 copy of the master in bf16-storage mode, the tables themselves otherwise
-        srcs = self._srcs = ([self.mirror[self.cur]] if self.bf16 else [x0]) + self.layers[1:]
+        srcs = self._srcs = [x0] + self.layers[1:]                 # what the hops gather from
 
         if self.wide:
             tabs = self._tabs = self._srcs = [self.x0w] + self.layers[1:]
@@ -1008,7 +993,7 @@ class ColumnShardEngine(object):
         W, R = acts.shape
         tabs = self._tabs
         self._acts = acts
-        late_wait = self._aux_pending and self._late_wait       # the long-rows hop needs nothing of the plan: join after it
+        late_wait = self._aux_pending                           # the long-rows hop needs nothing of the plan: join after it
 
         def join_plan():
             rec = getattr(self, "_plan_rec", None)
@@ -1043,9 +1028,6 @@ class ColumnShardEngine(object):
             if self.wide:         # all L + 1 wide tables are whole: layer means at the listed rows (padding ids are negative)
                 assert not by_node
                 slab.wide_rows([t.data for t in tabs], tabs[0].n, self.ns, self.w, acts.reshape(-1), W * R, out0, narrow)
-            elif self.bf16:
-                slab.rows16(self.plan, self.ns, self.w, L, U, tabs[0].data, [t.data for t in tabs[1:]] + [None], self.long_tab,
-                            acts, counts, R, W, out0, narrow, by_node)
             elif self._rows_in_head:
                 pass                  # the head's launch evaluates the rows itself (cs_head: elimrec_head_fwd_fused_rows)
             else:
@@ -1070,7 +1052,7 @@ class ColumnShardEngine(object):
         """Hop L at the split rows (the part the rows launch cannot evaluate inline) right behind the forward hops: it needs
         nothing of the batch, so with several ranks it runs before the main stream waits for the gathered ids."""
         m = self.model
-        if not self.plan.n_long or self.wide or self.bf16:
+        if not self.plan.n_long or self.wide:
             return
         L = m.n_layers
         m._region("cs_fwd_long_early%d" % self.cur, (m._ws_gen,),
@@ -1336,7 +1318,7 @@ class ColumnShardEngine(object):
 
     @torch.no_grad()
     def cs_update(self):
-        """Adam (coupled L2) on the column shard of the embeddings (buffer `cur` -> the other one, + the bf16 gather copy)
+        """Adam (coupled L2) on the column shard of the embeddings (buffer `cur` -> the other one)
         and on the projection weights that received a gradient, in ONE launch; the same launch copies the projection
         weights as they were BEFORE the update into the snapshot predict()'s lazily built tables use."""
         m = self.model
@@ -1346,7 +1328,7 @@ class ColumnShardEngine(object):
         jobs = []
         if not getattr(self, "_adam_in_hop", False):              # else the last adjoint hop has already applied it
             jobs.append(_lib.AdamJob(self.master[self.cur].data.data_ptr(), self.master[nxt].data.data_ptr(),
-                                     self.mirror[nxt].data.data_ptr() if self.bf16 else None, self.grad.data.data_ptr(),
+                                     self.grad.data.data_ptr(),
                                      self.m1.data_ptr(), self.m2.data_ptr(), None, self.grad.data.numel(), self.step_count))
         if not getattr(self, "_tail_in_hop", False):              # else they ran as extra workgroups of the last hop
             jobs += self._tail_jobs()
@@ -1370,7 +1352,7 @@ class ColumnShardEngine(object):
         if base:            # the embeddings' Adam is a span of the optimizer launch (wide form), not part of the last hop:
             nxt = 1 - self.cur          # this step's buffers and step count into the persistent job array the launch reads
             self._tail_arr[0] = _lib.AdamJob(self.master[self.cur].data.data_ptr(), self.master[nxt].data.data_ptr(),
-                                             self.mirror[nxt].data.data_ptr() if self.bf16 else None, self.grad.data.data_ptr(),
+                                             self.grad.data.data_ptr(),
                                              self.m1.data_ptr(), self.m2.data_ptr(), None, self.grad.data.numel(), self.step_count + 1)
         if self._tail_plan is not None and getattr(self, "_tail_n", 0):
             _, spans, states = self._tail_plan[:3]
@@ -1389,7 +1371,7 @@ class ColumnShardEngine(object):
         x0 = self.master[self.cur]
         self._x0_fwd = x0
         self._tabs = [x0] + self.layers[1:]
-        self._srcs = ([self.mirror[self.cur]] if self.bf16 else [x0]) + self.layers[1:]
+        self._srcs = [x0] + self.layers[1:]
         m._plan_n = R
         m._slab_fwd = True
         m._publish_cache(m._ws["Y"], dirty=True)
@@ -1427,10 +1409,10 @@ class ColumnShardEngine(object):
             n, o = sp["end"] - sp["off"], sp["off"]
             if sp["upd"]:
                 sp["step"] += 1
-                jobs.append(_lib.AdamJob(base_p + 4 * o, base_p + 4 * o, None, base_g + 4 * o, sp["m"], sp["v"],
+                jobs.append(_lib.AdamJob(base_p + 4 * o, base_p + 4 * o, base_g + 4 * o, sp["m"], sp["v"],
                                          snap + 4 * (o - tail_off), n, sp["step"]))
             else:
-                jobs.append(_lib.AdamJob(base_p + 4 * o, None, None, None, None, None, snap + 4 * (o - tail_off), n, 0))
+                jobs.append(_lib.AdamJob(base_p + 4 * o, None, None, None, None, snap + 4 * (o - tail_off), n, 0))
         return jobs
 
     # ------------------------------------------------------------------ row-sharded constants: the distributed fold
@@ -1561,23 +1543,16 @@ class ColumnShardEngine(object):
             if self.xL is None:
                 self.xL = self.layers[1].like() if L >= 2 else self.grad.like()
             tabs = [self._x0_fwd] + self.layers[1:]
-            slab.hop(self.plan, self._srcs[L - 1], self.xL, gs=self.gs)     # (bf16 storage: X^L is rounded here, not in training)
+            slab.hop(self.plan, self._srcs[L - 1], self.xL, gs=self.gs)
 
         def all_rows(out0, narrow):
-            if self.bf16:
-                slab.rows16(self.plan, self.ns, self.w, L, U, tabs[0].data, [t.data for t in tabs[1:]] + [self.xL.data], None,
-                            None, None, N, 1, out0, narrow, False)
-            else:
-                slab.rows(self.plan, self.ns, self.w, L, U, [t.data for t in tabs] + [self.xL.data], None, None, None, N, 1,
-                          out0, narrow, False)
+            slab.rows(self.plan, self.ns, self.w, L, U, [t.data for t in tabs] + [self.xL.data], None, None, None, N, 1,
+                      out0, narrow, False)
         if self.lookup and ((self.feature_shard == "row" and (self.world > 1 or self.lean)) or ws.get("fold") is None):
             def rows_of(node_ids, out0, narrow):               # (layer mean | shared part) of the listed rows, my columns
                 n = int(node_ids.numel())
                 if self.wide:
                     slab.wide_rows([t.data for t in tabs], N, self.ns, self.w, node_ids, n, out0, narrow)
-                elif self.bf16:
-                    slab.rows16(self.plan, self.ns, self.w, L, U, tabs[0].data, [t.data for t in tabs[1:]] + [self.xL.data], None,
-                                node_ids.view(1, n), None, n, 1, out0, narrow, False)
                 else:
                     slab.rows(self.plan, self.ns, self.w, L, U, [t.data for t in tabs] + [self.xL.data], None, node_ids.view(1, n), None, n, 1,
                               out0, narrow, False)

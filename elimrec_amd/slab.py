@@ -19,19 +19,9 @@ from .ops import _dev, _stream
 LONG_ROW_THRESHOLD = int(os.environ.get("ELIMREC_SLAB_LONG_ROW", "32"))
 
 
-def choose_slabs16(dl):
-    """(ns, w) for a bf16 table of dl columns: a lane owns 8 columns; up to 64 columns (one 128-B line) per slab row."""
-    if dl % 8 != 0:
-        raise ValueError("bf16 table storage needs a column count that is a multiple of 8 (got %d)" % dl)
-    w = 8
-    while w * 2 <= 64 and dl % (w * 2) == 0:
-        w *= 2
-    return dl // w, w
-
-
 def choose_slabs(dl, n_rows=None):
     """(ns, w) for a table of dl columns: w = the largest power-of-two multiple of 4 dividing dl, capped at 32 floats.
-    Measured at the Tiktok shape (round 2; tools/bench_slab_modes.py repeats the geometries; d = 64, us per hop): w = 64 (row-major) 44, w = 32 in two
+    Measured at the Tiktok shape (round 2; d = 64, us per hop): w = 64 (row-major) 44, w = 32 in two
     slab groups 35, w = 16 in four 42, w = 8 in eight 67 -- a gathered piece narrower than one 128-B cache line still
     moves a whole line from L2 to the CU, so narrower slabs lose more on the L2 -> L1 path than their smaller L2
     footprint wins; 128-B pieces halve every XCD's footprint at no cost per line."""
@@ -470,34 +460,28 @@ def sweep_wanted(n_rows, dl, nnz=None):
 
 
 class SlabTable(object):
-    """[n x (ns*w)] table stored slab-major in one flat tensor; fp32, or bf16 for the bf16-storage mode."""
+    """[n x (ns*w)] fp32 table stored slab-major in one flat tensor."""
 
-    def __init__(self, n, ns, w, device, data=None, dtype=torch.float32):
+    def __init__(self, n, ns, w, device, data=None):
         self.n, self.ns, self.w = int(n), int(ns), int(w)
-        self.data = torch.empty(self.ns * self.n * self.w, dtype=dtype, device=device) if data is None else data
-        assert self.data.numel() == self.ns * self.n * self.w and self.data.is_contiguous()
+        self.data = torch.empty(self.ns * self.n * self.w, dtype=torch.float32, device=device) if data is None else data
+        assert self.data.numel() == self.ns * self.n * self.w and self.data.is_contiguous() and self.data.dtype == torch.float32
 
     @property
     def cols(self):
         return self.ns * self.w
 
-    @property
-    def bf16(self):
-        return self.data.dtype == torch.bfloat16
-
-    def like(self, dtype=None):
-        return SlabTable(self.n, self.ns, self.w, self.data.device, dtype=self.data.dtype if dtype is None else dtype)
+    def like(self):
+        return SlabTable(self.n, self.ns, self.w, self.data.device)
 
     def from_rows(self, src, col0=0):
         """Columns [col0, col0 + ns*w) of a row-major 2-D fp32 tensor (unit column stride)."""
-        assert not self.bf16
         assert src.dim() == 2 and src.stride(1) == 1 and src.shape[0] == self.n and col0 + self.cols <= src.shape[1]
         _lib.check(_lib.load().elimrec_slab_from_rows(_dev(src, "src"), src.stride(0), int(col0), self.n, self.ns, self.w,
                                                       _dev(self.data, "slab"), _stream()), "slab_from_rows")
         return self
 
     def to_rows(self, dst, col0=0):
-        assert not self.bf16
         assert dst.dim() == 2 and dst.stride(1) == 1 and dst.shape[0] == self.n and col0 + self.cols <= dst.shape[1]
         _lib.check(_lib.load().elimrec_slab_to_rows(_dev(self.data, "slab"), self.n, self.ns, self.w, _dev(dst, "dst"),
                                                     dst.stride(0), int(col0), _stream()), "slab_to_rows")
@@ -505,16 +489,7 @@ class SlabTable(object):
 
     def dense(self):
         """Row-major fp32 copy [n x cols] (tests, checkpoints)."""
-        if self.bf16:
-            return self.data.view(self.ns, self.n, self.w).permute(1, 0, 2).reshape(self.n, self.cols).float()
         return self.to_rows(torch.empty(self.n, self.cols, dtype=torch.float32, device=self.data.device))
-
-    def to_bf16(self, dst):
-        """dst (a bf16 table of the same geometry) <- this fp32 table, rounded to nearest even."""
-        assert not self.bf16 and dst.bf16 and (dst.n, dst.ns, dst.w) == (self.n, self.ns, self.w)
-        _lib.check(_lib.load().elimrec_slab_to_bf16(_dev(self.data, "src"), self.data.numel(), _dev(dst.data, "dst", torch.bfloat16),
-                                                    _stream()), "slab_to_bf16")
-        return dst
 
 
 def source_bits(plan, ns, w, gs, src_mask):
@@ -526,29 +501,19 @@ def source_bits(plan, ns, w, gs, src_mask):
 
 def hop(plan, xin, xout, gs=None, src_mask=None, add=None, add_mask=None, scale=1.0, seg_only=False, bits_ready=False, bwd_w=None, bwd_w_phase=1):
     """xout = (A . xin + [add_mask] add) * scale on slab tables of equal geometry. seg_only: xout is a flat fp32 tensor
-    [ns x n_long x w] receiving the split rows only. bf16 tables on either side select the bf16-storage kernels (the
-    source may be fp32 there too: the row-sparse adjoint source behind src_mask).
+    [ns x n_long x w] receiving the split rows only.
     bwd_w: the handle of ops.linear_bwd_w_batched(..., defer_reduce=True / defer_all=True) -- bwd_w_phase 1: its slab reduce,
     0: its partial launch, run as extra workgroups of this launch (fp32 tables, tiered plan: elimrec_slab_hop_bwd_w)."""
     ns, w = xin.ns, xin.w
     gs = choose_groups(ns) if gs is None else gs
-    if (plan.sweep is not None and src_mask is None and not seg_only and bwd_w is None and not xin.bf16 and isinstance(xout, SlabTable)
-            and not xout.bf16 and w in (16, 32)):
-        # a whole fp32 hop of a graph with a swept side: the tile hop over the other side's rows, the window sweep over this side's
+    if plan.sweep is not None and src_mask is None and not seg_only and bwd_w is None and isinstance(xout, SlabTable) and w in (16, 32):
+        # a whole hop of a graph with a swept side: the tile hop over the other side's rows, the window sweep over this side's
         hop(plan.sweep.items, xin, xout, gs=gs, add=add, add_mask=add_mask, scale=scale)
         plan.sweep.hop(xin, xout, add=add, add_mask=add_mask, scale=scale)
         return
     part = plan.partials(ns, w)
     out = xout if isinstance(xout, torch.Tensor) else xout.data
     lib = _lib.load()
-    if xin.bf16 or out.dtype == torch.bfloat16:
-        _lib.check(lib.elimrec_slab_hop16(plan.ref(), ns, w, int(gs), _dev(xin.data, "xin", xin.data.dtype), 0 if xin.bf16 else 1,
-                                          _dev(src_mask, "src_mask", torch.int32), _dev(out, "xout", out.dtype),
-                                          0 if out.dtype == torch.bfloat16 else 1, _dev(None if add is None else add.data, "add"),
-                                          _dev(add_mask, "add_mask", torch.int32), float(scale), _dev(part, "partials"),
-                                          part.numel() * 4, 1 if seg_only else 0, _stream()), "slab_hop16")
-        assert bwd_w is None
-        return
     if bwd_w is not None:
         arr, n, wsp = bwd_w
         _lib.check(lib.elimrec_slab_hop_bwd_w(plan.ref(), ns, w, int(gs), _dev(xin.data, "xin"), _dev(src_mask, "src_mask", torch.int32),
@@ -580,26 +545,6 @@ def hop_adam(plan, xin, grad_out, gs, add, add_mask, scale, p_in, p_out, m, v, l
         part.numel() * 4, _dev(p_in, "p_in"), _dev(p_out, "p_out"), _dev(m, "m"), _dev(v, "v"), float(lr), float(beta1), float(beta2),
         float(eps), float(weight_decay), int(step), arr, n_tail, _stream()), "slab_hop_adam")
 
-
-def rows16(plan, ns, w, L, U, x0, layers16, long_tab, row_ids, counts, R, n_lists, out0, narrow, narrow_by_node):
-    """elimrec_slab_rows16: x0 fp32 master (flat), layers16 = [X^1 .. X^L] flat bf16 tensors (the last may be None)."""
-    ptrs = (ctypes.c_void_p * L)(*[None if t is None else _dev(t, "layer", torch.bfloat16) for t in layers16])
-    assert len(layers16) == L and out0.stride(1) == 1 and narrow.stride(1) == 1
-    _lib.check(_lib.load().elimrec_slab_rows16(plan.ref(), ns, w, L, int(U), _dev(x0, "x0"), ptrs, _dev(long_tab, "long_tab"),
-                                               _dev(row_ids, "rows", torch.int32), _dev(counts, "counts", torch.int32),
-                                               int(R), int(n_lists), _dev(out0, "out0"), out0.stride(0),
-                                               _dev(narrow, "narrow"), narrow.stride(0), 1 if narrow_by_node else 0,
-                                               _stream()), "slab_rows16")
-
-
-def adam_step_out16(p_in, p_out, p16, g, m, v, lr, beta1, beta2, eps, weight_decay, step):
-    n = p_in.numel()
-    for t in (p_in, p_out, p16, g, m, v):
-        assert t.is_contiguous() and t.numel() == n
-    _lib.check(_lib.load().elimrec_adam_step_out16(_dev(p_in, "p_in"), _dev(p_out, "p_out"), _dev(p16, "p16", torch.bfloat16),
-                                                   _dev(g, "g"), _dev(m, "m"), _dev(v, "v"), n, float(lr), float(beta1),
-                                                   float(beta2), float(eps), float(weight_decay), int(step), _stream()),
-               "adam_step_out16")
 
 
 def rows(plan, ns, w, L, U, layers, long_tab, row_ids, counts, R, n_lists, out0, narrow, narrow_by_node):

@@ -620,12 +620,7 @@ int elimrec_plan_scatter(int64_t n_tiles, int G, const int64_t *d_tile_off, cons
  * that elimrec_slab_rows cannot do inline.
  * Replaces torch.sparse.mm (models/EliMRec.py:244) and its backward for one column slice. */
 size_t elimrec_slab_partials_bytes(const elimrec_sell *A, int ns, int w);
-/* tuning knobs, results identical: inner-loop form of the hop kernel (env ELIMREC_SLAB_VARIANT); launch form (env
- * ELIMREC_SLAB_STREAM): 0 = hop kernel + fix-up kernel for the split rows (default, measured fastest), 1 = ONE
- * persistent launch with the split rows combined in-launch by the last-arriving segment wave, 2 = persistent + fix-up.
- * d_partials must be zero-filled once after allocation (form 1 keeps its arrival counters there). */
-void elimrec_slab_set_variant(int v);
-void elimrec_slab_set_stream(int on);
+/* d_partials must be zero-filled once after allocation (the one-launch tile form keeps its arrival counters there). */
 int elimrec_slab_hop(const elimrec_sell *A, int ns, int w, int gs, const float *d_Xin,
                      const uint32_t *d_src_mask, float *d_Xout, const float *d_add,
                      const uint32_t *d_add_mask, float scale, float *d_partials, size_t partials_bytes,
@@ -718,30 +713,6 @@ int elimrec_slab_merge_rows(const float *d_rows, const int32_t *d_keys, int worl
                             int64_t I, int ns, int w, int M, float *d_SrcA, float *d_SrcB, uint32_t *d_mask,
                             void *stream);
 
-/* ---- bf16 table storage (configs[1] "bf16" / configs[4] "fp16" of BASELINE.json; --table_dtype=bf16). The layer
- * tables X^1..X^(L-1), the gather copy of X^0 and the adjoint's intermediate tables are bf16 (round-to-nearest-even);
- * all sums are fp32; master parameters, gradient, Adam moments, adjoint sources and layer means stay fp32. Geometry as
- * above with w a multiple of 8 (a lane owns 8 columns: 16 B of a bf16 row piece). Tolerance against an oracle that
- * rounds at the same points of the forward: loss 2e-3, gradients 2e-2 rel.
- * elimrec_slab_hop16: d_Xin bf16, or fp32 when in_f32 (the row-sparse first adjoint source, with its bitmap);
- * d_Xout bf16, or fp32 when out_f32 (the gradient; always fp32 and compact [ns x n_long x w] with seg_only);
- * d_add fp32. elimrec_slab_rows16: d_x0 = fp32 master table, layers16 = host array of L device pointers X^1..X^L
- * (bf16; the last may be NULL = hop L inline), d_long fp32. */
-int elimrec_slab_hop16(const elimrec_sell *A, int ns, int w, int gs, const void *d_Xin, int in_f32,
-                       const uint32_t *d_src_mask, void *d_Xout, int out_f32, const float *d_add,
-                       const uint32_t *d_add_mask, float scale, float *d_partials, size_t partials_bytes,
-                       int seg_only, void *stream);
-int elimrec_slab_rows16(const elimrec_sell *A, int ns, int w, int L, int64_t U, const float *d_x0,
-                        const void *const *layers16, const float *d_long, const int32_t *d_rows,
-                        const int32_t *d_counts, int64_t R, int n_lists, float *d_out0, int64_t ld_out0,
-                        float *d_narrow, int64_t ld_narrow, int narrow_by_node, void *stream);
-/* fp32 -> bf16, element for element (a slab-major table keeps its layout); n_elems % 8 == 0. */
-int elimrec_slab_to_bf16(const float *d_src, int64_t n_elems, void *d_dst, void *stream);
-/* elimrec_adam_step_out that also writes the updated parameters, rounded, to the bf16 gather copy. */
-int elimrec_adam_step_out16(const float *d_p_in, float *d_p_out, void *d_p_bf16, const float *d_g, float *d_m,
-                            float *d_v, int64_t n, float lr, float beta1, float beta2, float eps,
-                            float weight_decay, int64_t step, void *stream);
-
 /* elimrec_adam_step reading the parameters from d_p_in and writing them to d_p_out (may alias): with two
  * parameter buffers used alternately the tables cached by the last forward keep seeing the parameters they
  * were computed from (models/EliMRec.py:98-99 reads tables made BEFORE the last optimizer step). */
@@ -810,12 +781,11 @@ int elimrec_build_adj(const int64_t *d_users, const int64_t *d_items, int64_t E,
                       int32_t *d_err, void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* The optimizer step of a training step in ONE launch (torch.optim.Adam with coupled L2, main.py:49,101): up to 8 jobs.
- * A job with d_g updates n parameters read from d_p_in and written to d_p_out (may alias) and, when d_p_bf16 is given,
- * rounded to that bf16 copy; a job without d_g only copies. d_copy_dst (nullable) receives the parameters as they were
+ * A job with d_g updates n parameters read from d_p_in and written to d_p_out (may alias); a job without d_g only copies. d_copy_dst (nullable) receives the parameters as they were
  * BEFORE the update (the snapshot of the projection weights the cached tables were computed with,
  * models/EliMRec.py:98-99). `step` is the 1-based step count of the job's parameters. */
 typedef struct elimrec_adam_job {
-    const float *d_p_in; float *d_p_out; void *d_p_bf16;
+    const float *d_p_in; float *d_p_out;
     const float *d_g; float *d_m; float *d_v;
     float *d_copy_dst;
     int64_t n; int64_t step;

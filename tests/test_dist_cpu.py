@@ -141,7 +141,6 @@ class ColumnShardOracleEngine(OracleEngine):
     [q*dl, (q+1)*dl) of [E_u ; E_i], propagates only those, and exchanges the layer means / adjoint sources of the active
     rows. The folded algebra (constant feature tables propagated once) is restated here with torch autograd."""
     PAD = -(1 << 30)
-    round_fn = None          # bf16-storage variant: straight-through rounding of the stored / gathered layer tables
     lookup = False           # True: the constants S_m / c are ROW-sharded; a step fetches its active rows from the owners
 
     # ---- row-sharded constants (elimrec_amd/lookup.py restated with torch indexing; rows travel as raw fp32 bytes)
@@ -221,13 +220,8 @@ class ColumnShardOracleEngine(OracleEngine):
         """out0 = mean_k A^k X0 and the shared part (users: even k, items: odd k) for my columns, with autograd."""
         m = self.m
         xs = [self.shard]
-        r = self.round_fn
         for k in range(1, m.L + 1):
-            src = xs[-1] if r is None else (r(xs[-1]) if k == 1 else xs[-1])    # X^(k-1) for k >= 2 is already the stored (rounded) table
-            x = torch.sparse.mm(m.adj, src)
-            if r is not None and k < m.L:
-                x = r(x)                                                       # stored as bf16; hop L stays fp32
-            xs.append(x)
+            xs.append(torch.sparse.mm(m.adj, xs[-1]))
         inv = 1.0 / (m.L + 1)
         out0 = sum(xs) * inv
         nu = sum(x[:m.U] for k, x in enumerate(xs) if k % 2 == 0) * inv

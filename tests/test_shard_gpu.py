@@ -665,124 +665,6 @@ def test_c5_shape_scaled_step_and_eval_vs_oracle():
     assert e16.fshard.table.dtype == torch.float16 and e16.fshard.nbytes() < 0.51 * (U + I) * (sum(dims) + 4) * 4
 
 
-# ----------------------------------------------------------------------------- bf16 table storage (J1)
-def _ste_bf16(x):
-    return x + (x.bfloat16().float() - x).detach()
-
-
-@pytest.mark.parametrize("d,w,gs", [(64, 64, 1), (128, 64, 2), (32, 32, 1), (8, 8, 1), (16, 16, 1), (128, 64, 1)])
-def test_slab_hop16_vs_torch(d, w, gs):
-    """bf16-storage hop: bf16 source -> fp32 accumulate -> bf16 result equals the fp64 product of the SAME rounded inputs
-    rounded once (<= 1 bf16 ulp: the fp32 sum may sit on a rounding boundary); fp32 masked source + addend + scale (the
-    adjoint's first hop) and the fp32 output form (its last hop) to 1e-5."""
-    from elimrec_amd import slab
-    n = 3000
-    m = _random_graph(n, d + w + 1)
-    ns = d // w
-    plan = slab.SellPlan(m, DEV, threshold=32, side_split=1200)
-    torch.manual_seed(d)
-    X = torch.randn(n, d, device=DEV)
-    x32 = slab.SlabTable(n, ns, w, DEV).from_rows(X)
-    x16 = x32.to_bf16(x32.like(torch.bfloat16))
-    Xr = X.bfloat16().float()
-    assert torch.equal(x16.dense(), Xr)
-    A64 = torch.from_numpy(m.astype(np.float64).toarray()).to(DEV)
-    want = A64 @ Xr.double()
-    y16 = x16.like()
-    slab.hop(plan, x16, y16, gs=gs)
-    got = y16.dense().double()
-    ulp = torch.maximum(want.abs(), torch.tensor(1e-30, device=DEV, dtype=torch.float64)) * 2.0 ** -7
-    assert ((got - want).abs() <= ulp).all()
-    y32 = x32.like()
-    slab.hop(plan, x16, y32, gs=gs)                               # bf16 in, fp32 out
-    assert (y32.dense().double() - want).abs().max().item() < 1e-5
-    act = torch.rand(n, device=DEV) < 0.07
-    bm = _bitmap(act)
-    S = torch.randn(n, d, device=DEV)
-    ss = slab.SlabTable(n, ns, w, DEV).from_rows(S)
-    slab.hop(plan, ss, y16, gs=gs, src_mask=bm, add=ss, add_mask=bm, scale=0.25)      # fp32 masked in, bf16 out
-    Sm = S.double() * act[:, None]
-    want2 = (A64 @ Sm + Sm) * 0.25
-    ulp2 = torch.maximum(want2.abs(), torch.tensor(1e-30, device=DEV, dtype=torch.float64)) * 2.0 ** -7
-    assert ((y16.dense().double() - want2).abs() <= ulp2 + 1e-6).all()
-
-
-@pytest.mark.parametrize("name", ["ml3", "kwai", "gcmc"])
-def test_bf16_storage_trainer_vs_rounding_oracle(name):
-    """--table_dtype=bf16: three steps against the oracle restated in folded form with straight-through bf16 rounding at
-    the same points of the forward (gather copy of X^0, stored X^1..X^(L-1)). Stated tolerance of the mode (DESIGN.md
-    section 7): loss 2e-3 abs, embeddings and weights after Adam 2e-3 abs (lr = 1e-3 steps), and the fp32 path stays
-    within its own tolerance of the same oracle WITHOUT rounding -- the two are printed side by side."""
-    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
-    from test_dist_cpu import ColumnShardOracleEngine, OracleOpt
-    g = load_golden(name)
-    res = {}
-    for mode in ("f32", "bf16"):
-        model, _ = build_model_from_fixture(g, DEV)
-        opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
-        eng = ColumnShardEngine(model, table_dtype=mode)
-        tr = ColumnShardTrainer(eng, opt)
-        ora = ColumnShardOracleEngine(g)
-        ora.round_fn = _ste_bf16 if mode == "bf16" else None
-        from elimrec_amd.shard import ColumnShardTrainer as T
-        otr = T(ora, OracleOpt(ora, g))
-        worst = 0.0
-        for t in (1, 2, 3):
-            u, p, n = (g["step%d/%s" % (t, k)] for k in ("users", "pos", "neg"))
-            lo = float(otr.step(torch.from_numpy(u), torch.from_numpy(p), torch.from_numpy(n)))
-            lg = float(tr.step(_t(u), _t(p), _t(n)))
-            worst = max(worst, abs(lo - lg))
-        emb = (eng.master[eng.cur].dense().cpu() - ora.shard.detach()).abs().max().item()
-        res[mode] = (worst, emb)
-        assert worst < (2e-3 if mode == "bf16" else 1e-5), (mode, worst)
-        assert emb < (2e-3 if mode == "bf16" else 2e-5), (mode, emb)
-        if mode == "bf16":
-            # the mode really stores bf16: its losses differ from the fp32 run's, and predict() still works
-            model.predict_type = "TIE"
-            assert np.isfinite(model.predict(g["eval_users"].tolist()).numpy()).all()
-    print("max |loss - oracle|, max |E - oracle|:", res)
-
-
-@pytest.mark.parametrize("d,w,gs,bf16", [(64, 32, 2, False), (8, 8, 1, False), (128, 32, 4, False), (64, 64, 1, True), (16, 16, 1, True)])
-def test_persistent_hop_with_in_launch_combine_equals_two_launch_form(d, w, gs, bf16):
-    """The persistent forms of the hop (1: split rows combined in-launch by the last-arriving segment wave; they are not
-    the default: measured slower) give the same bits as the default hop kernel + fix-up launch, run after run, plain / masked+addend / seg_only, under uneven load (the 6 hot
-    rows have ~400 neighbours against a median of 6)."""
-    from elimrec_amd import _lib, slab
-    lib = _lib.load()
-    n = 4000
-    m = _random_graph(n, 3 * d + w, hot=9, hot_deg=900)
-    plan = slab.SellPlan(m, DEV, threshold=32, side_split=1500, tiered=False)
-    ns = d // w
-    torch.manual_seed(1)
-    X = torch.randn(n, d, device=DEV)
-    x = slab.SlabTable(n, ns, w, DEV).from_rows(X)
-    if bf16:
-        x = x.to_bf16(x.like(torch.bfloat16))
-    act = torch.rand(n, device=DEV) < 0.1
-    bm = _bitmap(act)
-    src = slab.SlabTable(n, ns, w, DEV).from_rows(torch.randn(n, d, device=DEV))
-    outs = {}
-    try:
-        for mode in (0, 1, 1, 1):
-            lib.elimrec_slab_set_stream(mode)
-            y, z = x.like(), x.like()
-            long_tab = torch.full((ns * plan.n_long * w,), float("nan"), device=DEV)
-            y.data.fill_(float("nan")); z.data.fill_(float("nan"))
-            slab.hop(plan, x, y, gs=gs)
-            slab.hop(plan, src, z, gs=gs, src_mask=bm, add=src, add_mask=bm, scale=0.5)
-            slab.hop(plan, x, long_tab, gs=gs, seg_only=True)
-            got = (y.data.clone(), z.data.clone(), long_tab.clone())
-            if mode in outs:
-                for a, b in zip(outs[mode], got):
-                    assert torch.equal(a, b)
-            outs[mode] = got
-    finally:
-        lib.elimrec_slab_set_stream(0)
-    for a, b in zip(outs[0], outs[1]):
-        assert not torch.isnan(a.float()).any() and torch.equal(a, b)
-
-
 def test_fused_head_forward_equals_batched_gemms(monkeypatch):
     """csrc/head.hip (feature blocks + fused Linear + single-modal heads of the active rows in one launch) against the
     two batched-GEMM launches it replaces, on a recdim-64 model: OutAct, YAct, loss and the gradient rows to fp32
@@ -815,11 +697,11 @@ def test_fused_head_forward_equals_batched_gemms(monkeypatch):
         assert rel_err(y.cpu(), x.cpu()) < 2e-6
 
 
-@pytest.mark.parametrize("d,w,gs,bf16,ipw", [(64, 32, 2, False, 8), (8, 8, 1, False, 32), (64, 64, 1, False, 4), (64, 64, 1, True, 8),
-                                             (128, 32, 4, False, 8), (16, 16, 1, True, 32)])
-def test_tiered_one_launch_hop(d, w, gs, bf16, ipw):
+@pytest.mark.parametrize("d,w,gs,ipw", [(64, 32, 2, 8), (8, 8, 1, 32), (64, 64, 1, 4),
+                                        (128, 32, 4, 8), (16, 16, 1, 16)])
+def test_tiered_one_launch_hop(d, w, gs, ipw):
     """The default hop: rows above the lane-group threshold go to one wave or one workgroup each, only the longest are
-    segmented and combined in-launch. Against an fp64 product (1e-5; bf16 output <= 1 bf16 ulp), plain / masked +
+    segmented and combined in-launch. Against an fp64 product (1e-5), plain / masked +
     addend / seg_only (every row above the threshold, compact), and bitwise reproducible."""
     from elimrec_amd import slab
     n = 4000
@@ -837,14 +719,12 @@ def test_tiered_one_launch_hop(d, w, gs, bf16, ipw):
     torch.manual_seed(1)
     X = torch.randn(n, d, device=DEV)
     x = slab.SlabTable(n, ns, w, DEV).from_rows(X)
-    if bf16:
-        x = x.to_bf16(x.like(torch.bfloat16))
     Xr = x.dense().double()
     A64 = torch.from_numpy(m.astype(np.float64).toarray()).to(DEV)
     want = A64 @ Xr
     # fp32 sums of up to 3000 terms: the error bound scales with sum |a||x| of the row (4 ulp-ish of it), not with 1
     scale = A64.abs() @ Xr.abs()
-    tol = lambda ref, sc=scale: (ref.abs() * 2.0 ** -7 + 1e-6 if bf16 else 0) + 4e-6 * sc + 1e-6
+    tol = lambda ref, sc=scale: 4e-6 * sc + 1e-6
     y = x.like()
     y.data.fill_(float("nan"))
     slab.hop(plan, x, y, gs=gs)
@@ -1472,59 +1352,6 @@ def test_peer_cols_to_rows_and_rows_bitmap_vs_torch(W, R, dl):
     mask2 = torch.zeros_like(mask)
     slab.merge_rows(torch.randn(W * R, 2 * dl, generator=g).to(DEV), acts.reshape(-1), W, U, I, srcA, srcB, mask2)
     assert torch.equal(mask2[:(N + 31) // 32], mask[:(N + 31) // 32])
-
-
-def test_bf16_storage_vs_rounding_oracle_at_the_tiktok_shape():
-    """--table_dtype=bf16 at the size BASELINE.json configs[1] names it for (|U| = 36 656, |I| = 76 085, 128-d x 3, recdim 64,
-    B = 2048): two steps against the folded oracle with straight-through bf16 rounding at the same points of the forward
-    (gather copy of X^0, stored X^1..X^(L-1)) -- loss 2e-3 abs, embeddings after Adam 2e-3 abs, the mode's stated tolerance --
-    with the fp32 engine against the same oracle WITHOUT rounding beside it (1e-5 / 2e-5)."""
-    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, EliMRec, FusedAdam, SyntheticDataset, set_seed
-    from elimrec_amd.shard import ColumnShardTrainer as T
-    from test_dist_cpu import ColumnShardOracleEngine, OracleOpt
-    torch.set_num_threads(min(32, os.cpu_count() or 1))
-    U, I, B = 36656, 76085, 2048
-    cfg = make_config(["--data.input.dataset=synthetic", "--alpha=0.5", "--loss=bpr_loss", "--recdim=64", "--verbose=0"])
-    ds = SyntheticDataset(U, I, 720829, feat_dims=(128, 128, 128), seed=0)
-    set_seed(3)
-    model0 = EliMRec(cfg, ds)
-    init = {k: v.detach().clone() for k, v in model0.state_dict().items()}
-    tu, ti = ds.get_train_interactions()
-    g = {"train_u": np.asarray(tu), "train_i": np.asarray(ti), "num_users": U, "num_items": I, "adj_type": "pre", "recdim": 64,
-         "layer_num": int(cfg["layer_num"]), "alpha": 0.5, "dataset_name": "synthetic", "modality": "vat", "mm_fusion_mode": "concat",
-         "lr": float(cfg["lr"]), "weight_decay": float(cfg["weight_decay"])}
-    for m in "vat":
-        g[m + "_feat"] = getattr(model0, m + "_feat").numpy()
-    for k, v in init.items():
-        g["init/" + k] = v.numpy()
-    gen = torch.Generator().manual_seed(5)
-    train = ds.train_matrix.tocoo()
-    batches = []
-    for _ in range(2):
-        pick = torch.randint(0, train.nnz, (B,), generator=gen).numpy()
-        batches.append((torch.from_numpy(train.row[pick].astype(np.int64)), torch.from_numpy(train.col[pick].astype(np.int64)),
-                        torch.randint(0, I, (B,), generator=gen)))
-    res = {}
-    for mode in ("f32", "bf16"):
-        model = EliMRec(cfg, ds)
-        model.load_state_dict(init)
-        model = model.to(DEV)
-        opt = FusedAdam(model.parameters(), lr=g["lr"], weight_decay=g["weight_decay"])
-        eng = ColumnShardEngine(model, table_dtype=mode)
-        tr = ColumnShardTrainer(eng, opt)
-        ora = ColumnShardOracleEngine(g)
-        ora.round_fn = _ste_bf16 if mode == "bf16" else None
-        otr = T(ora, OracleOpt(ora, g))
-        worst = 0.0
-        for u, p, n in batches:
-            lo = float(otr.step(u, p, n))
-            lg = float(tr.step(u.to(DEV), p.to(DEV), n.to(DEV)))
-            worst = max(worst, abs(lo - lg))
-        emb = (eng.master[eng.cur].dense().cpu() - ora.shard.detach()).abs().max().item()
-        res[mode] = (worst, emb)
-        assert worst < (2e-3 if mode == "bf16" else 1e-5), (mode, worst)
-        assert emb < (2e-3 if mode == "bf16" else 2e-5), (mode, emb)
-    print("Tiktok shape, max |loss - oracle|, max |E - oracle|:", res)
 
 
 # ----------------------------------------------------------------------------- adjacencies with a diagonal: the wide form

@@ -33,12 +33,11 @@ if os.environ.get("SPLIT"):                 # user rows cut into K virtual rows 
     phase[:U] = 1                                              # items (phase 0), then user parts 1..K
     for k in range(1, K):
         phase[N + (k - 1) * U:N + k * U] = 1 + k
-bf16 = os.environ.get("BF16") == "1"
-ns, w = slab.choose_slabs16(d) if bf16 else slab.choose_slabs(d, N)
+ns, w = slab.choose_slabs(d, N)
 gs = slab.choose_groups(ns)
 tiered = os.environ.get("TIERED", "1") == "1"
 T = int(os.environ.get("T", 64 if tiered else 32))
-plan = slab.SellPlan(adj, dev, phase=phase, side_split=None if os.environ.get("RELABEL") == "1" else U, tiered=tiered, threshold=T, ipw=64 // ((ns // gs) * (w // (8 if bf16 else 4))))
+plan = slab.SellPlan(adj, dev, phase=phase, side_split=None if os.environ.get("RELABEL") == "1" else U, tiered=tiered, threshold=T, ipw=64 // ((ns // gs) * (w // 4)))
 torch.manual_seed(0)
 tabs = [slab.SlabTable(N, ns, w, dev).from_rows(torch.randn(N, d, device=dev)) for _ in range(3)]
 if os.environ.get("SWEEP") == "1":           # the user rows by the window sweep (csrc/sweep.hip), the item rows by a tile plan of their own
@@ -53,8 +52,6 @@ if os.environ.get("SWEEP") == "1":           # the user rows by the window sweep
         {k: (round(v, 3) if isinstance(v, float) else v) for k, v in plan.sweep.geometry(ns, w).items() if not hasattr(v, "shape")}, plan.sweep.window(w)))
 if n_out != N:                              # rectangular: every hop reads table 0 and writes an [n_out x d] table
     outs = [slab.SlabTable(n_out, ns, w, dev) for _ in range(2)]
-if bf16:
-    tabs = [t.to_bf16(t.like(torch.bfloat16)) for t in tabs]
 src, dst = tabs[0], tabs[1]
 def run(n):
     global src, dst

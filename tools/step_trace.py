@@ -1,4 +1,4 @@
-"""Steps of the real trainer for rocprofv3 --kernel-trace (bench.py's training loop without the extras). usage: step_trace.py [steps] [table_dtype]"""
+"""Steps of the real trainer for rocprofv3 --kernel-trace (bench.py's training loop without the extras). usage: step_trace.py [steps]"""
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, Configurator, EliMRec, FusedAdam, Logger, PairwiseSamplerV2, SyntheticDataset, set_seed
@@ -20,7 +20,7 @@ if os.environ.get("ELIMREC_SHARD_MULTI") == "1":       # the multi-rank step ove
 set_seed(1)
 model = EliMRec(cfg, ds).to(dev)
 opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
-eng = ColumnShardEngine(model, table_dtype=sys.argv[2] if len(sys.argv) > 2 else "f32", feature_shard=os.environ.get("FEATURE_SHARD") or None)
+eng = ColumnShardEngine(model, feature_shard=os.environ.get("FEATURE_SHARD") or None)
 tr = ColumnShardTrainer(eng, opt)
 if tr.lookup and tr.multi:                               # row-sharded constants: the split sizes planned ahead, as main.py does per epoch
     pass
