@@ -193,6 +193,140 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> sample_triplets(const at::Tensor 
     return {u, po, ne};
 }
 
+// "bpr_head_bwd" of SURVEY.md 8(b): the row gradients bpr_head_fwd saved, scaled by the upstream gradient of the mean loss and
+// reduced per node in ascending slot order (IndexBackward, deterministic) into a dense dY [n_rows x Cy].
+at::Tensor bpr_head_bwd(const at::Tensor &grad_rows, const at::Tensor &keys, const at::Tensor &grad_out, int64_t n_rows) {
+    need(keys, "keys", at::kInt, 1); need(grad_out, "grad_out", at::kFloat);
+    TORCH_CHECK(grad_out.numel() == 1, "elimrec::bpr_head_bwd: grad_out is the gradient of the scalar loss");
+    const at::Tensor r = rowmajor(grad_rows, "grad_rows").contiguous(), k = keys.contiguous();
+    const int64_t n = r.size(0), ld = r.size(1);
+    TORCH_CHECK(k.numel() == n && n_rows >= 1, "elimrec::bpr_head_bwd: one key per row");
+    at::Tensor active = at::empty({n}, k.options()), reduced = at::empty({n, ld}, r.options()), seg = at::zeros({8}, k.options());
+    const size_t need_ws = elimrec_segment_reduce_workspace(n);
+    at::Tensor ws = at::empty({(int64_t)(need_ws ? need_ws : 1)}, r.options().dtype(at::kByte));
+    check(elimrec_segment_reduce_rows(r.data_ptr<float>(), k.data_ptr<int32_t>(), n, (int)ld, 0, active.data_ptr<int32_t>(),
+                                      reduced.data_ptr<float>(), nullptr, seg.data_ptr<int32_t>(), ws.data_ptr(), (size_t)ws.numel(),
+                                      cur_stream()),
+          "bpr_head_bwd");
+    // rows behind the valid prefix go to a dump row (no host read-back of the count)
+    const at::Tensor slot = at::arange(n, k.options());
+    const at::Tensor dst = at::where(slot < seg[0], active, at::full({}, n_rows, k.options())).to(at::kLong);
+    at::Tensor dY = at::zeros({n_rows + 1, ld}, r.options());
+    dY.index_copy_(0, dst, reduced * grad_out.reshape({}));
+    return dY.narrow(0, 0, n_rows);
+}
+
+// ---- item-sharded evaluation (elimrec_score_topk_shard phases 1 / 2, elimrec_topk_merge)
+static void train_csr(const c10::optional<at::Tensor> &train_ptr, const c10::optional<at::Tensor> &train_items, at::Tensor &tp, at::Tensor &ti) {
+    if (train_ptr.has_value() && train_ptr->defined()) {
+        TORCH_CHECK(train_items.has_value() && train_items->defined(), "elimrec: train_ptr needs train_items");
+        need(*train_ptr, "train_ptr", at::kLong, 1); need(*train_items, "train_items", at::kInt, 1);
+        tp = train_ptr->contiguous(); ti = train_items->contiguous();
+    }
+}
+
+at::Tensor score_shard_row_sums(const at::Tensor &Y, int64_t U, int64_t I, const at::Tensor &users, int64_t d, int64_t S, int64_t head_mask,
+                                int64_t fusion_mode, int64_t I_total) {
+    const at::Tensor y = rowmajor(Y, "Y");
+    need(users, "users", at::kLong, 1);
+    const at::Tensor u = users.contiguous();
+    const int64_t B = u.numel();
+    at::Tensor row_sum = at::zeros({B}, y.options());
+    const size_t need_ws = elimrec_score_workspace_for((int)B, U, I, (int)S, 1, (int)d, 0);
+    at::Tensor ws = at::empty({(int64_t)(need_ws ? need_ws : 1)}, y.options().dtype(at::kByte));
+    check(elimrec_score_topk_shard(y.data_ptr<float>(), y.stride(0), U, I, u.data_ptr<int64_t>(), (int)B, (int)d, (int)S, (uint32_t)head_mask,
+                                   (int)fusion_mode, 2, nullptr, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, ws.data_ptr(),
+                                   (size_t)ws.numel(), 1, row_sum.data_ptr<float>(), I_total, 0, cur_stream()),
+          "score_shard_row_sums");
+    return row_sum;
+}
+
+std::tuple<at::Tensor, at::Tensor> score_topk_shard(const at::Tensor &Y, int64_t U, int64_t I, const at::Tensor &users, int64_t d, int64_t S,
+                                                    int64_t head_mask, int64_t fusion_mode, int64_t predict_type,
+                                                    const c10::optional<at::Tensor> &train_ptr, const c10::optional<at::Tensor> &train_items,
+                                                    int64_t K, const at::Tensor &row_sum, int64_t I_total, int64_t id_offset) {
+    const at::Tensor y = rowmajor(Y, "Y");
+    need(users, "users", at::kLong, 1); need(row_sum, "row_sum", at::kFloat, 1);
+    const at::Tensor u = users.contiguous(), rs = row_sum.contiguous();
+    const int64_t B = u.numel();
+    TORCH_CHECK(K >= 1 && rs.numel() == B, "elimrec::score_topk_shard: K >= 1, one row sum per user");
+    at::Tensor tp, ti;
+    train_csr(train_ptr, train_items, tp, ti);
+    at::Tensor idx = at::empty({B, K}, y.options().dtype(at::kInt)), val = at::empty({B, K}, y.options());
+    const size_t need_ws = elimrec_score_workspace_for((int)B, U, I, (int)S, (int)K, (int)d, 0);
+    at::Tensor ws = at::empty({(int64_t)(need_ws ? need_ws : 1)}, y.options().dtype(at::kByte));
+    check(elimrec_score_topk_shard(y.data_ptr<float>(), y.stride(0), U, I, u.data_ptr<int64_t>(), (int)B, (int)d, (int)S, (uint32_t)head_mask,
+                                   (int)fusion_mode, (int)predict_type, nullptr, tp.defined() ? tp.data_ptr<int64_t>() : nullptr,
+                                   ti.defined() ? ti.data_ptr<int32_t>() : nullptr, nullptr, 0, (int)K, idx.data_ptr<int32_t>(),
+                                   val.data_ptr<float>(), ws.data_ptr(), (size_t)ws.numel(), 2, rs.data_ptr<float>(), I_total, id_offset,
+                                   cur_stream()),
+          "score_topk_shard");
+    return {idx, val};
+}
+
+std::tuple<at::Tensor, at::Tensor> topk_merge(const at::Tensor &cand_val, const at::Tensor &cand_idx, int64_t K) {
+    need(cand_val, "cand_val", at::kFloat, 2); need(cand_idx, "cand_idx", at::kInt, 2);
+    const at::Tensor v = cand_val.contiguous(), i = cand_idx.contiguous();
+    TORCH_CHECK(v.sizes() == i.sizes() && K >= 1 && K <= v.size(1), "elimrec::topk_merge: [B x n] values and ids, 1 <= K <= n");
+    at::Tensor idx = at::empty({v.size(0), K}, i.options()), val = at::empty({v.size(0), K}, v.options());
+    check(elimrec_topk_merge(v.data_ptr<float>(), i.data_ptr<int32_t>(), (int)v.size(0), (int)v.size(1), (int)K, idx.data_ptr<int32_t>(),
+                             val.data_ptr<float>(), cur_stream()),
+          "topk_merge");
+    return {idx, val};
+}
+
+// ---- row-sharded feature constants: the all-to-all id lookup (elimrec_lookup_counts / _pack / _unpack). user_bounds / item_bounds:
+// world + 1 ascending row bounds of the owners' blocks.
+static void bounds(const std::vector<int64_t> &ub, const std::vector<int64_t> &ib, int64_t &world) {
+    world = (int64_t)ub.size() - 1;
+    TORCH_CHECK(world >= 1 && world <= ELIMREC_MAX_RANKS && ib.size() == ub.size(), "elimrec::lookup: user_bounds / item_bounds hold world + 1 entries");
+}
+
+at::Tensor lookup_counts(const at::Tensor &acts, int64_t U, int64_t I, std::vector<int64_t> user_bounds, std::vector<int64_t> item_bounds) {
+    int64_t world;
+    bounds(user_bounds, item_bounds, world);
+    need(acts, "acts", at::kInt, 2);
+    const at::Tensor a = acts.contiguous();
+    TORCH_CHECK(a.size(0) == world, "elimrec::lookup_counts: one active-row list per rank");
+    at::Tensor counts = at::empty({world, world}, a.options());
+    check(elimrec_lookup_counts(a.data_ptr<int32_t>(), (int)world, a.size(1), U, I, user_bounds.data(), item_bounds.data(),
+                                counts.data_ptr<int32_t>(), cur_stream()),
+          "lookup_counts");
+    return counts;
+}
+
+std::tuple<at::Tensor, at::Tensor> lookup_pack(const at::Tensor &acts, int64_t U, int64_t I, std::vector<int64_t> user_bounds,
+                                               std::vector<int64_t> item_bounds, int64_t me, const at::Tensor &shard, int64_t row_bytes) {
+    int64_t world;
+    bounds(user_bounds, item_bounds, world);
+    need(acts, "acts", at::kInt, 2);
+    const at::Tensor a = acts.contiguous();
+    TORCH_CHECK(shard.is_cuda() && shard.is_contiguous() && row_bytes % 16 == 0 && me >= 0 && me < world && a.size(0) == world,
+                "elimrec::lookup_pack: contiguous device shard, rows padded to 16 bytes, 0 <= me < world");
+    at::Tensor send = at::empty({world * a.size(1), row_bytes}, a.options().dtype(at::kByte));     // worst case: every listed row is mine
+    at::Tensor off = at::empty({world + 1}, a.options());
+    check(elimrec_lookup_pack(a.data_ptr<int32_t>(), (int)world, a.size(1), U, I, user_bounds.data(), item_bounds.data(), (int)me,
+                              shard.data_ptr(), row_bytes, send.data_ptr(), off.data_ptr<int32_t>(), cur_stream()),
+          "lookup_pack");
+    return {send, off};
+}
+
+std::tuple<at::Tensor, at::Tensor> lookup_unpack(const at::Tensor &act, int64_t U, int64_t I, std::vector<int64_t> user_bounds,
+                                                 std::vector<int64_t> item_bounds, int64_t me, const at::Tensor &rows, int64_t row_bytes,
+                                                 int64_t dtype, int64_t sum_d, bool direct) {
+    int64_t world;
+    bounds(user_bounds, item_bounds, world);
+    need(act, "act", at::kInt, 1);
+    const at::Tensor a = act.contiguous();
+    TORCH_CHECK(rows.is_cuda() && rows.is_contiguous() && sum_d >= 1 && dtype >= 0 && dtype <= 2, "elimrec::lookup_unpack: bad arguments");
+    at::Tensor S = at::zeros({a.numel(), sum_d}, a.options().dtype(at::kFloat)), c = at::zeros({a.numel()}, a.options().dtype(at::kFloat));
+    check(elimrec_lookup_unpack(a.data_ptr<int32_t>(), (int)world, a.numel(), U, I, user_bounds.data(), item_bounds.data(), (int)me,
+                                rows.data_ptr(), row_bytes, (int)dtype, (int)sum_d, direct ? 1 : 0, S.data_ptr<float>(), S.stride(0),
+                                c.data_ptr<float>(), cur_stream()),
+          "lookup_unpack");
+    return {S, c};
+}
+
 }  // namespace
 
 TORCH_LIBRARY(elimrec, m) {
@@ -205,6 +339,13 @@ TORCH_LIBRARY(elimrec, m) {
     m.def("score_topk(Tensor Y, int U, int I, Tensor users, int d, int S, int head_mask, int fusion_mode, int predict_type, Tensor? train_ptr, Tensor? train_items, int K) -> (Tensor, Tensor)");
     m.def("rank_metrics(Tensor topk_idx, Tensor truth_ptr, Tensor truth_items, int[] metric_ids) -> Tensor");
     m.def("sample_triplets(Tensor user_ids, Tensor ptr, Tensor items, int num_items, int n, int seed, int epoch) -> (Tensor, Tensor, Tensor)");
+    m.def("bpr_head_bwd(Tensor grad_rows, Tensor keys, Tensor grad_out, int n_rows) -> Tensor");
+    m.def("score_shard_row_sums(Tensor Y, int U, int I, Tensor users, int d, int S, int head_mask, int fusion_mode, int I_total) -> Tensor");
+    m.def("score_topk_shard(Tensor Y, int U, int I, Tensor users, int d, int S, int head_mask, int fusion_mode, int predict_type, Tensor? train_ptr, Tensor? train_items, int K, Tensor row_sum, int I_total, int id_offset) -> (Tensor, Tensor)");
+    m.def("topk_merge(Tensor cand_val, Tensor cand_idx, int K) -> (Tensor, Tensor)");
+    m.def("lookup_counts(Tensor acts, int U, int I, int[] user_bounds, int[] item_bounds) -> Tensor");
+    m.def("lookup_pack(Tensor acts, int U, int I, int[] user_bounds, int[] item_bounds, int me, Tensor shard, int row_bytes) -> (Tensor, Tensor)");
+    m.def("lookup_unpack(Tensor act, int U, int I, int[] user_bounds, int[] item_bounds, int me, Tensor rows, int row_bytes, int dtype, int sum_d, bool direct) -> (Tensor, Tensor)");
 }
 
 TORCH_LIBRARY_IMPL(elimrec, CUDA, m) {
@@ -217,4 +358,11 @@ TORCH_LIBRARY_IMPL(elimrec, CUDA, m) {
     m.impl("score_topk", &score_topk);
     m.impl("rank_metrics", &rank_metrics);
     m.impl("sample_triplets", &sample_triplets);
+    m.impl("bpr_head_bwd", &bpr_head_bwd);
+    m.impl("score_shard_row_sums", &score_shard_row_sums);
+    m.impl("score_topk_shard", &score_topk_shard);
+    m.impl("topk_merge", &topk_merge);
+    m.impl("lookup_counts", &lookup_counts);
+    m.impl("lookup_pack", &lookup_pack);
+    m.impl("lookup_unpack", &lookup_unpack);
 }

@@ -273,6 +273,61 @@ def test_torch_ops_match_the_ctypes_binding():
     assert (reduced[:n_act].double() - want[uniq]).abs().max().item() < 1e-6
 
 
+def test_torch_ops_of_the_sharded_paths_and_the_head_backward():
+    """torch.ops.elimrec for the entry points SURVEY.md 8(b) lists beyond the first nine (missing 5): `bpr_head_bwd`
+    (the saved row gradients reduced per node into a dense dY == index_add), the item-sharded scorer (`score_shard_row_sums` +
+    `score_topk_shard` per shard + `topk_merge` == `score_topk` over the whole catalogue) and the row-sharded constants' lookup
+    (`lookup_counts` / `lookup_pack` / `lookup_unpack` over two owners == indexing the full tables)."""
+    from elimrec_amd import torch_ops
+    from elimrec_amd.lookup import FeatureShard, RowOwnerMap
+    t = torch_ops.load()
+    g_ = load_golden("ml3")
+    model, _ = build_model_from_fixture(g_, DEV)
+    model.compute()
+    U, I, d, Y = model.num_users, model.num_items, model.latent_dim, model._ws["Y"]
+    u, pp, nn_ = (_t(g_["step1/%s" % k]) for k in ("users", "pos", "neg"))
+    loss_rows, grad_rows, keys = t.bpr_head_fwd(Y, U, I, u, pp, nn_, d, model._block_weights())
+    gout = torch.full((), 0.5, device=DEV)
+    dY = t.bpr_head_bwd(grad_rows, keys, gout, U + I)
+    want = torch.zeros(U + I, model.Cy, device=DEV, dtype=torch.float64).index_add_(0, keys.long(), grad_rows.double() * 0.5)
+    assert dY.shape == (U + I, model.Cy) and (dY.double() - want).abs().max().item() < 1e-6
+    # item shards: W = 2
+    users = torch.arange(24, device=DEV)
+    idx_ref, val_ref = t.score_topk(Y, U, I, users, d, model.S, model._head_mask(), 0, 2, None, None, 10)
+    cut = [0, I // 3, I]
+    shards = [torch.cat([Y[:U], Y[U + cut[r]:U + cut[r + 1]]]).contiguous() for r in range(2)]
+    total = sum(t.score_shard_row_sums(shards[r], U, cut[r + 1] - cut[r], users, d, model.S, model._head_mask(), 0, I) for r in range(2))
+    parts = [t.score_topk_shard(shards[r], U, cut[r + 1] - cut[r], users, d, model.S, model._head_mask(), 0, 2, None, None, 10, total, I, cut[r])
+             for r in range(2)]
+    idx, val = t.topk_merge(torch.cat([p[1] for p in parts], 1), torch.cat([p[0] for p in parts], 1), 10)
+    assert torch.equal(idx, idx_ref) and (val - val_ref).abs().max().item() < 1e-6
+    # row-sharded constants: two owners, requester 0
+    torch.manual_seed(0)
+    N = U + I
+    tabs = [torch.randn(N, 12, device=DEV), torch.randn(N, 20, device=DEV)]
+    c = torch.rand(N, device=DEV)
+    own = RowOwnerMap(U, I, 2)
+    fs = [FeatureShard(own, r, tabs, c) for r in range(2)]
+    R = 64
+    acts = torch.full((2, R), -(1 << 30), dtype=torch.int32, device=DEV)
+    for r in range(2):
+        ids = torch.unique(torch.randint(0, N, (R - 9,), generator=torch.Generator().manual_seed(r))).to(DEV).int()
+        acts[r, :ids.numel()] = ids
+    ub, ib = own.ub.tolist(), own.ib.tolist()
+    counts = t.lookup_counts(acts, U, I, ub, ib)
+    assert int(counts[0].sum()) == int((acts[0] >= 0).sum())
+    chunks = []
+    for o in range(2):
+        send, off = t.lookup_pack(acts, U, I, ub, ib, o, fs[o].table, fs[o].row_bytes)
+        lo, hi = int(off[0]), int(off[1])
+        assert hi - lo == int(counts[0, o])
+        chunks.append(send[lo:hi])
+    S, cc = t.lookup_unpack(acts[0], U, I, ub, ib, 0, torch.cat(chunks).contiguous(), fs[0].row_bytes, 0, 32, False)
+    n0 = int((acts[0] >= 0).sum())
+    a0 = acts[0, :n0].long()
+    assert torch.equal(S[:n0], torch.cat([tabs[0][a0], tabs[1][a0]], 1)) and torch.equal(cc[:n0], c[a0])
+
+
 @pytest.mark.parametrize("adj_type", ["pre", "plain", "gcmc", "norm", "mean"])
 def test_device_adjacency_is_bit_identical_to_scipy(adj_type):
     """N3: csrc/adj.hip against model.create_adj_mat (itself bit-identical to the reference's matrix, test_host_logic):

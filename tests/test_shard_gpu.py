@@ -714,7 +714,7 @@ def test_tiered_one_launch_hop(d, w, gs, ipw):
     m.sum_duplicates()
     m.sort_indices()
     plan = slab.SellPlan(m, DEV, threshold=32, side_split=1500, tiered=True, ipw=ipw)
-    assert plan.tiered and plan.n_w1 + plan.n_w4 > 0 and (plan.n_seg > 0 or ipw >= 32)
+    assert plan.tiered and plan.n_w1 + plan.n_w4 > 0 and (plan.n_seg > 0 or ipw >= 16)
     ns = d // w
     torch.manual_seed(1)
     X = torch.randn(n, d, device=DEV)
