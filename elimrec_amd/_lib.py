@@ -156,10 +156,6 @@ SIGNATURES = {
     "elimrec_segment_apply_head_bwd_sources": (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_i64, c_i32,
                                                 c_i32, c_i32, ctypes.POINTER(c_i32), c_ptr, c_ptr, ctypes.POINTER(c_ptr), c_ptr,
                                                 c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_ptr]),
-    "elimrec_bpr_head_bwd_sources": (c_i32, [c_ptr, c_i64, c_ptr, c_i32, ctypes.POINTER(ctypes.c_float), c_ptr, c_ptr, c_ptr,
-                                      c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_i64, c_i32, c_i32, c_i32,
-                                      ctypes.POINTER(c_i32), c_ptr, c_ptr, ctypes.POINTER(c_ptr), c_ptr, c_ptr, c_i64, c_i32,
-                                      c_ptr, c_ptr, c_ptr]),
     "elimrec_segment_apply_head_bwd_split": (c_i32, [c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_i64, c_i32,
                                               c_i32, c_i32, ctypes.POINTER(c_i32), c_ptr, c_ptr, ctypes.POINTER(c_ptr), c_ptr,
                                               c_ptr, c_i64, c_i32, c_ptr, c_ptr]),

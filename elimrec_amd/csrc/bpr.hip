@@ -757,63 +757,6 @@ struct SlabSources { float *A, *B; int64_t N; int w, w_shift; float *split; int6
 
 struct HeadPackPtrs { const float *f[2]; const float *s[kMaxHeads]; };      // null f[0]: weights read unpacked
 
-// The cosine-BPR rows inside the head backward (one rank, recdim 64): instead of reading the gradient row a bpr_head launch left
-// for a slot, the wave that reduces an active row evaluates the slot's triplet itself -- the three compact Y rows, the five dot
-// products per head block (16 lanes a block, the butterflies of bpr_head_body), the role's gradient components with that
-// kernel's expressions -- so every value has the bits of the two-launch path; the user slot's visit also publishes the triplet's
-// loss row, and the workgroup that finishes last adds the B rows in elimrec_sum's order (bpr_head_sum_kernel).
-struct BprIn {
-    const float *Y; int64_t ldy; const int32_t *slot_rows; BlockWeights bw; float inv_b;
-    float *loss_rows, *loss_out; int32_t *ticket; int B, n_blocks;
-};
-
-__device__ __forceinline__ float4 bpr_slot_grad(const BprIn &bp, int slot, int lane, float wk, bool on, const float4 a, const float4 p,
-                                                const float4 n) {
-    const int b = slot / 3, j = slot - 3 * b;                      // (wave-uniform)
-    const float eps = 1e-12f;
-    float saa = 0.f, spp = 0.f, snn = 0.f, sap = 0.f, san = 0.f, term = 0.f;
-    if (on) { saa += dot4(a, a); spp += dot4(p, p); snn += dot4(n, n); sap += dot4(a, p); san += dot4(a, n); }
-    for (int o = 8; o > 0; o >>= 1) {
-        saa += __shfl_xor(saa, o, 64); spp += __shfl_xor(spp, o, 64); snn += __shfl_xor(snn, o, 64);
-        sap += __shfl_xor(sap, o, 64); san += __shfl_xor(san, o, 64);
-    }
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (on) {
-        const float na = sqrtf(saa), np_ = sqrtf(spp), nn = sqrtf(snn);
-        const float da = fmaxf(na, eps), dp = fmaxf(np_, eps), dn = fmaxf(nn, eps);
-        const float cp = sap / (da * dp), cn = san / (da * dn);
-        const float x = cn - cp;
-        const float sp = (x > 20.f) ? x : log1pf(expf(x));
-        term = wk * sp * bp.inv_b;
-        const float sig = (x > 20.f) ? 1.f : 1.f / (1.f + expf(-x));
-        const float g = wk * sig * bp.inv_b;
-        const bool fa = na > eps, fp = np_ > eps, fn = nn > eps;
-#define ELIMREC_BPR_ROLE(c)                                                              \
-    {                                                                                    \
-        const float ah = a.c / da, ph = p.c / dp, nh = n.c / dn;                         \
-        const float vv = nh - ph;                                                        \
-        if (j == 0) r.c = g * (fa ? (vv - ah * x) / da : vv / eps);                      \
-        else if (j == 1) r.c = -g * (fp ? (ah - ph * cp) / dp : ah / eps);               \
-        else r.c = g * (fn ? (ah - nh * cn) / dn : ah / eps);                            \
-    }
-        ELIMREC_BPR_ROLE(x) ELIMREC_BPR_ROLE(y) ELIMREC_BPR_ROLE(z) ELIMREC_BPR_ROLE(w)
-#undef ELIMREC_BPR_ROLE
-    }
-    if (j == 0) {                                                   // the triplet's loss row: block order, as bpr_head_body
-        float loss = 0.f;
-        for (int q = 0; q < 4; ++q) {
-            const float t = __shfl(term, q * 16, 64);
-            if (q < bp.n_blocks) loss += t;
-        }
-        if (lane == 0) {
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)bp.loss_rows, 0, bp.B * 4, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(loss), rs, (unsigned)b * 4u, 0, 16 /* sc1 */);
-        }
-    }
-    return r;
-}
-
-template <bool BPR>
 __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__restrict__ dY, int64_t lddy,
                                                                const int32_t *__restrict__ active_rows,
                                                                const int32_t *__restrict__ seg_info, int64_t n_max,
@@ -822,7 +765,7 @@ __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__re
                                                                const float *__restrict__ W_item, float gscale,
                                                                float *__restrict__ G0, int64_t ldg, int scatter_cols,
                                                                float *__restrict__ compact, SegSrc seg, HeadPackPtrs pk,
-                                                               SlabSources src, BprIn bp) {
+                                                               SlabSources src) {
     extern __shared__ float dys[];                       // [16][Cy + 4]
     __shared__ int64_t node[HM16];
     const int Cy = (1 + S) * d, ldy = Cy + 4;
@@ -832,66 +775,7 @@ __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__re
     if (n_act > n_max) n_act = n_max;
     if (s0 >= n_act) return;
     const int rows = (int)((n_act - s0) < HM16 ? (n_act - s0) : HM16);
-    const float seg_scale = ((BPR || seg.rows) && seg.scale) ? seg.scale[0] : 1.f;
-    if constexpr (BPR) {
-        // a wave per row (rows wave, wave + 4, ...): lane l holds columns 4l .. 4l + 3 of the row's Cy <= 256 = block l / 16
-        const int c = lane * 4, k = lane >> 4;
-        const bool have = k < bp.n_blocks;
-        float wk = 0.f;
-#pragma unroll
-        for (int q = 0; q < kMaxBlocks; ++q) wk = (q == k) ? bp.bw.w[q] : wk;
-        const bool on = have && wk != 0.f;
-        int beg[4], end[4], mem[4], tr[4][3];
-        float4 v[4], ya[4], yp[4], yn[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = wave + 4 * q;
-            beg[q] = 0; end[q] = 0;
-            if (r < rows) { beg[q] = seg.seg_start[s0 + r]; end[q] = seg.seg_start[s0 + r + 1]; }
-            v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) mem[q] = beg[q] < end[q] ? seg.members[beg[q]] : -1;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int b3 = mem[q] >= 0 ? 3 * (mem[q] / 3) : 0;
-#pragma unroll
-            for (int t = 0; t < 3; ++t) tr[q][t] = mem[q] >= 0 ? bp.slot_rows[b3 + t] : 0;
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            ya[q] = yp[q] = yn[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (mem[q] >= 0 && on) {
-                ya[q] = ld4(bp.Y + (int64_t)tr[q][0] * bp.ldy + c); yp[q] = ld4(bp.Y + (int64_t)tr[q][1] * bp.ldy + c);
-                yn[q] = ld4(bp.Y + (int64_t)tr[q][2] * bp.ldy + c);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int r = wave + 4 * q;
-            if (mem[q] >= 0) {
-                const float4 x = bpr_slot_grad(bp, mem[q], lane, wk, on, ya[q], yp[q], yn[q]);
-                v[q].x += x.x; v[q].y += x.y; v[q].z += x.z; v[q].w += x.w;           // 0 + x, as the serial loop does
-                for (int i = beg[q] + 1; i < end[q]; ++i) {
-                    const int m2 = seg.members[i], b3 = 3 * (m2 / 3);
-                    float4 a2 = make_float4(0.f, 0.f, 0.f, 0.f), p2 = a2, n2 = a2;
-                    if (on) {
-                        a2 = ld4(bp.Y + (int64_t)bp.slot_rows[b3] * bp.ldy + c); p2 = ld4(bp.Y + (int64_t)bp.slot_rows[b3 + 1] * bp.ldy + c);
-                        n2 = ld4(bp.Y + (int64_t)bp.slot_rows[b3 + 2] * bp.ldy + c);
-                    }
-                    const float4 x2 = bpr_slot_grad(bp, m2, lane, wk, on, a2, p2, n2);
-                    v[q].x += x2.x; v[q].y += x2.y; v[q].z += x2.z; v[q].w += x2.w;
-                }
-            }
-            if (have) {
-                if (r < rows) {
-                    v[q] = make_float4(v[q].x * seg_scale, v[q].y * seg_scale, v[q].z * seg_scale, v[q].w * seg_scale);
-                    st4(seg.reduced + (s0 + r) * lddy + c, v[q]);
-                }
-                st4(dys + r * ldy + c, v[q]);
-            }
-        }
-    } else {
+    const float seg_scale = (seg.rows && seg.scale) ? seg.scale[0] : 1.f;
     // staging as in the 32-row kernel: the dependent loads of the fused segment reduce in batches of 4 per thread
     constexpr int ST = 4;
     for (int e0 = tid * 4; e0 < HM16 * Cy; e0 += 1024 * ST) {
@@ -935,7 +819,6 @@ __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__re
             }
             st4(dys + r[q] * ldy + c[q], v[q]);
         }
-    }
     }
     if (tid < HM16) node[tid] = (tid < rows) ? (int64_t)active_rows[s0 + tid] : -1;
     __syncthreads();
@@ -997,34 +880,6 @@ __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__re
                     }
                 }
             }
-        }
-    }
-    if constexpr (BPR) {                                 // the batch loss, by the workgroup that finishes last (bpr_head_sum_kernel)
-        __shared__ float s[1024];
-        __shared__ int is_last;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-            const int tk = __hip_atomic_fetch_add(bp.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            is_last = tk == (int)((n_act + HM16 - 1) / HM16) - 1;
-        }
-        __syncthreads();
-        if (!is_last) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        for (int vt = tid; vt < 1024; vt += 256) {
-            float acc = 0.f;
-            for (int i = vt; i < bp.B; i += 1024) acc += bp.loss_rows[i];
-            s[vt] = acc;
-        }
-        __syncthreads();
-        for (int w = 512; w > 0; w >>= 1) {
-            for (int idx = tid; idx < w; idx += 256) s[idx] += s[idx + w];
-            __syncthreads();
-        }
-        if (tid == 0) {
-            bp.loss_out[0] = s[0];
-            __hip_atomic_store(bp.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -1403,7 +1258,7 @@ static int segment_apply_head_bwd_impl(const float *d_rows, int64_t n, int ld, c
                                        const void *d_plan_workspace, size_t plan_workspace_bytes, int64_t U, int d,
                                        int C, int S, const int *head_mblock, const float *d_W_user,
                                        const float *d_W_item, const float *const *d_W_heads, float *d_compact,
-                                       const float *d_pack_bwd, const SlabSources *src, void *stream, const BprIn *bpr = nullptr);
+                                       const float *d_pack_bwd, const SlabSources *src, void *stream);
 
 extern "C" int elimrec_segment_apply_head_bwd(const float *d_rows, int64_t n, int ld, const int32_t *d_active_rows,
                                               const int32_t *d_seg_info, const float *d_scale, float *d_reduced,
@@ -1461,47 +1316,19 @@ extern "C" int elimrec_segment_apply_head_bwd_split(const float *d_rows, int64_t
                                        d_pack_bwd, &src, stream);
 }
 
-extern "C" int elimrec_bpr_head_bwd_sources(const float *d_Y, int64_t ldy, const int32_t *d_slot_rows, int B,
-                                            const float *block_weights, float *d_loss_rows, float *d_loss, int32_t *d_ticket,
-                                            const int32_t *d_active_rows, const int32_t *d_seg_info,
-                                            const float *d_scale, float *d_reduced, const void *d_plan_workspace,
-                                            size_t plan_workspace_bytes, int64_t U, int d, int C, int S, const int *head_mblock,
-                                            const float *d_W_user, const float *d_W_item, const float *const *d_W_heads,
-                                            float *d_compact, const float *d_pack_bwd, int64_t N, int w, float *d_SrcA,
-                                            float *d_SrcB, void *stream) {
-    ELIMREC_REQUIRE(d_Y && d_slot_rows && block_weights && d_loss_rows && d_loss && d_ticket && d_pack_bwd && d_SrcA && d_SrcB,
-                    "bpr_head_bwd_sources: null pointer");
-    const int n_blocks = 1 + S, ld = n_blocks * d;                    // the head's blocks: fused + S single-modal
-    const int64_t n = (int64_t)3 * B;                                 // slots
-    ELIMREC_REQUIRE(d == 64 && n_blocks >= 1 && n_blocks <= 4 && n_blocks <= kMaxBlocks,
-                    "bpr_head_bwd_sources: recdim 64, 1..4 head blocks (d=%d, S=%d)", d, S);
-    ELIMREC_REQUIRE(ldy % 4 == 0 && ldy >= (int64_t)n_blocks * d && B > 0, "bpr_head_bwd_sources: bad ldy / B");
-    ELIMREC_REQUIRE(w >= 4 && (w & (w - 1)) == 0 && d % w == 0 && N >= U, "bpr_head_bwd_sources: [d / w x N x w] slabs (w=%d)", w);
-    ELIMREC_REQUIRE(C % 16 == 0, "bpr_head_bwd_sources: C must be a multiple of 16");
-    SlabSources src = {d_SrcA, d_SrcB, N, w, 0, nullptr, 0, 0};
-    while ((1 << src.w_shift) < w) ++src.w_shift;
-    BprIn bp = {};
-    bp.Y = d_Y; bp.ldy = ldy; bp.slot_rows = d_slot_rows; bp.inv_b = 1.0f / (float)B;
-    for (int k = 0; k < kMaxBlocks; ++k) bp.bw.w[k] = k < n_blocks ? block_weights[k] : 0.f;
-    bp.loss_rows = d_loss_rows; bp.loss_out = d_loss; bp.ticket = d_ticket; bp.B = B; bp.n_blocks = n_blocks;
-    return segment_apply_head_bwd_impl(nullptr, n, ld, d_active_rows, d_seg_info, d_scale, d_reduced, d_plan_workspace,
-                                       plan_workspace_bytes, U, d, C, S, head_mblock, d_W_user, d_W_item, d_W_heads, d_compact,
-                                       d_pack_bwd, &src, stream, &bp);
-}
-
 static int segment_apply_head_bwd_impl(const float *d_rows, int64_t n, int ld, const int32_t *d_active_rows,
                                        const int32_t *d_seg_info, const float *d_scale, float *d_reduced,
                                        const void *d_plan_workspace, size_t plan_workspace_bytes, int64_t U, int d,
                                        int C, int S, const int *head_mblock, const float *d_W_user,
                                        const float *d_W_item, const float *const *d_W_heads, float *d_compact,
-                                       const float *d_pack_bwd, const SlabSources *src, void *stream, const BprIn *bpr) {
-    ELIMREC_REQUIRE((d_rows || bpr) && d_active_rows && d_seg_info && d_reduced && d_plan_workspace && d_W_user && d_W_item &&
+                                       const float *d_pack_bwd, const SlabSources *src, void *stream) {
+    ELIMREC_REQUIRE(d_rows && d_active_rows && d_seg_info && d_reduced && d_plan_workspace && d_W_user && d_W_item &&
                     d_compact, "segment_apply_head_bwd: null pointer");
     ELIMREC_REQUIRE(n > 0 && n < INT32_MAX && ld > 0 && ld % 4 == 0, "segment_apply_head_bwd: bad n/ld");
     ELIMREC_REQUIRE(S >= 0 && S <= kMaxHeads && d > 0 && d % 4 == 0 && C % d == 0 && ld == (1 + S) * d,
                     "segment_apply_head_bwd: bad d/C/S/ld");
     const size_t lds_m = (size_t)HM_ROWS * ((1 + S) * d + 1) * sizeof(float);
-    if (!bpr && !(d % 32 == 0 && lds_m <= 96 * 1024)) {
+    if (!(d % 32 == 0 && lds_m <= 96 * 1024)) {
         int rc = elimrec_segment_apply(d_rows, n, ld, d_seg_info, d_scale, d_reduced, d_plan_workspace,
                                        plan_workspace_bytes, stream);
         if (rc) return rc;
@@ -1535,18 +1362,12 @@ static int segment_apply_head_bwd_impl(const float *d_rows, int64_t n, int ld, c
             pk.f[0] = d_pack_bwd; pk.f[1] = d_pack_bwd + (int64_t)C * 64;
             for (int h = 0; h < S && h < kMaxHeads; ++h) pk.s[h] = d_pack_bwd + (int64_t)2 * C * 64 + (int64_t)h * 64 * 64;
         }
-        if (bpr)
-            hipLaunchKernelGGL(head_bwd_input16_kernel<true>, dim3((unsigned)((n + HM16 - 1) / HM16)), dim3(256), lds16,
-                               (hipStream_t)stream, (const float *)d_reduced, (int64_t)ld, d_active_rows, d_seg_info, n, U, d, C, S, hp,
-                               d_W_user, d_W_item, 1.0f, (float *)nullptr, (int64_t)0, 0, d_compact, seg, pk, src ? *src : SlabSources{}, *bpr);
-        else
-            hipLaunchKernelGGL(head_bwd_input16_kernel<false>, dim3((unsigned)((n + HM16 - 1) / HM16)), dim3(256), lds16,
-                               (hipStream_t)stream, (const float *)d_reduced, (int64_t)ld, d_active_rows, d_seg_info, n, U, d, C, S, hp,
-                               d_W_user, d_W_item, 1.0f, (float *)nullptr, (int64_t)0, 0, d_compact, seg, pk, src ? *src : SlabSources{}, BprIn{});
+        hipLaunchKernelGGL(head_bwd_input16_kernel, dim3((unsigned)((n + HM16 - 1) / HM16)), dim3(256), lds16,
+                           (hipStream_t)stream, (const float *)d_reduced, (int64_t)ld, d_active_rows, d_seg_info, n, U, d, C, S, hp,
+                           d_W_user, d_W_item, 1.0f, (float *)nullptr, (int64_t)0, 0, d_compact, seg, pk, src ? *src : SlabSources{});
         ELIMREC_LAUNCH_CHECK("segment_apply_head_bwd16");
         return 0;
     }
-    ELIMREC_REQUIRE(!bpr, "bpr_head_bwd_sources: the 16-row kernel is switched off (ELIMREC_HEAD_BWD_ROWS)");
     ELIMREC_REQUIRE(!src, "segment_apply_head_bwd_sources: the 16-row kernel is switched off (ELIMREC_HEAD_BWD_ROWS)");
     hipLaunchKernelGGL(head_bwd_input_mfma_kernel, dim3((unsigned)((n + HM_ROWS - 1) / HM_ROWS)), dim3(512), lds_m,
                        (hipStream_t)stream, (const float *)d_reduced, (int64_t)ld, d_active_rows, d_seg_info, n, U, d, C, S, hp,

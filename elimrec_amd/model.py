@@ -902,7 +902,7 @@ class EliMRec(BasicModel):
 
     @torch.no_grad()
     def _backward_batch_rows(self, ws, gscale, grad_rows, n, head_only=False, w_stream=None, pack_bwd=None, merge=None,
-                             defer_reduce=False, sources=None, bpr=None):
+                             defer_reduce=False, sources=None):
         """Backward of _forward_batch_rows: gradient rows -> active rows (the forward's plan) -> head and projection
         gradients from the compact Out / dY rows -> adjoint propagation at d columns. Two hipGraph regions."""
         U, I, d, M, C, S = self.num_users, self.num_items, self.latent_dim, self.M, self.C, self.S
@@ -918,7 +918,7 @@ class EliMRec(BasicModel):
             wu, wi = self._fusion_weights()
             head_ws = [getattr(self, "s_dense_" + m).weight for m in self._mods]
             ops.segment_apply_head_bwd(grad_rows, act, seg, dY, ws["plan_ws"], U, d, C, [h + 1 for h in range(S)], wu, wi,
-                                       head_ws, dOutR, scale=gscale, pack_bwd=pack_bwd, sources=sources, bpr=bpr)
+                                       head_ws, dOutR, scale=gscale, pack_bwd=pack_bwd, sources=sources)
 
         def head_weights():
             # fusion Linears: dW = dY_f^T . Out[active rows], user slots / item slots separately
@@ -952,12 +952,9 @@ class EliMRec(BasicModel):
             return dict(grads), handle
 
         key = (self._ws_gen, grad_rows.data_ptr(), gscale.data_ptr(), n, tuple(bw))
-        if bpr is not None:
-            head_input()               # issued directly: the loss slot it writes is another one every step (shard.LOSS_RING)
-        else:
-            self._region("bwd_head_in", key + (0 if pack_bwd is None else pack_bwd.data_ptr(),
-                                               0 if sources is None else (sources[1] if sources[0] == "split" else sources[0].data).data_ptr()),
-                         head_input)
+        self._region("bwd_head_in", key + (0 if pack_bwd is None else pack_bwd.data_ptr(),
+                                           0 if sources is None else (sources[1] if sources[0] == "split" else sources[0].data).data_ptr()),
+                     head_input)
         if w_stream is None:
             mkey = (str(defer_reduce),) + (() if merge is None else (merge["rows"].data_ptr(), merge["keys"].data_ptr(),
                                                                      merge["mask"].data_ptr()))

@@ -578,13 +578,11 @@ def head_bwd_input(dY, active_rows, seg_info, U, d, C, head_mblock, W_user, W_it
 
 
 def segment_apply_head_bwd(rows, active_rows, seg_info, reduced, plan_workspace, U, d, C, head_mblock, W_user, W_item,
-                           W_heads, compact, scale=None, pack_bwd=None, sources=None, bpr=None):
+                           W_heads, compact, scale=None, pack_bwd=None, sources=None):
     """segment_apply + head_bwd_input(compact=...) in one launch; `reduced` receives dY. pack_bwd: the backward region of
     the fused head's packed weights (a view starting at head_pack_bwd_offset floats), if the forward left it behind.
     sources = (srcA, srcB) slab tables: the kernel also fills the adjoint sources at the active rows (one rank, recdim 64,
-    packed weights: elimrec_segment_apply_head_bwd_sources); ("split", send, world): the peers' [H | G] column slices.
-    bpr (with sources = tables): dict(Y, slot_rows, block_weights, loss_rows, loss_out, ticket) -- the cosine-BPR rows of the
-    slots are evaluated by this launch itself (elimrec_bpr_head_bwd_sources); `rows` only gives the shape [3B x Cy]."""
+    packed weights: elimrec_segment_apply_head_bwd_sources); ("split", send, world): the peers' [H | G] column slices."""
     n, ld = rows.shape
     S = len(W_heads)
     assert rows.is_contiguous() and reduced.is_contiguous() and reduced.shape[1] == ld and compact.is_contiguous()
@@ -602,22 +600,6 @@ def segment_apply_head_bwd(rows, active_rows, seg_info, reduced, plan_workspace,
             plan_workspace.numel(), U, d, C, S, mb, _dev(W_user, "W_user"), _dev(W_item, "W_item"), wp,
             _dev(compact, "compact"), _dev(pack_bwd, "pack_bwd"), send.shape[1], int(world), _dev(send, "send"), _stream()),
             "segment_apply_head_bwd_split")
-        return
-    if bpr is not None:
-        srcA, srcB = sources
-        assert pack_bwd is not None and srcA.ns == srcB.ns and srcA.w == srcB.w and srcA.n == srcB.n
-        y, ldy = _rowmajor(bpr["Y"], "Y")
-        nb = len(bpr["block_weights"])
-        bwts = (ctypes.c_float * nb)(*[float(x) for x in bpr["block_weights"]])
-        B = bpr["slot_rows"].numel() // 3
-        assert n == 3 * B and nb == 1 + S and ld == nb * d and srcA.ns * srcA.w == d
-        _lib.check(_lib.load().elimrec_bpr_head_bwd_sources(
-            y, ldy, _dev(bpr["slot_rows"], "slot_rows", torch.int32), B, bwts, _dev(bpr["loss_rows"], "loss_rows"),
-            _dev(bpr["loss_out"], "loss_out"), _dev(bpr["ticket"], "ticket", torch.int32),
-            _dev(active_rows, "active_rows", torch.int32), _dev(seg_info, "seg_info", torch.int32), _dev(scale, "scale"),
-            _dev(reduced, "reduced"), _dev(plan_workspace, "plan_workspace", torch.uint8), plan_workspace.numel(), U, d, C, S, mb,
-            _dev(W_user, "W_user"), _dev(W_item, "W_item"), wp, _dev(compact, "compact"), _dev(pack_bwd, "pack_bwd"), srcA.n,
-            srcA.w, _dev(srcA.data, "srcA"), _dev(srcB.data, "srcB"), _stream()), "bpr_head_bwd_sources")
         return
     if sources is not None:
         srcA, srcB = sources

@@ -475,14 +475,10 @@ class ColumnShardTrainer(object):
                 program.wait(torch.cuda.current_stream(), lookup_rec)             # the looked-up rows: the head reads them
         else:
             recv = send
-        if self._hip_engine:
-            eng._step_defers_bpr = True                             # a whole step: the BPR rows may ride in the head backward's launch
         loss = ph["cs_head"](recv)                                 # my rows, every rank's columns -> loss, head backward
         if self._scale is None:
             self._scale = torch.full((1,), 1.0 / W, dtype=torch.float32, device=loss.device)
         send2, wgrads = ph["cs_backward_local"](self._scale)       # [W, R, 2*dl]: my rows, the peers' columns
-        if self._hip_engine:
-            eng._step_defers_bpr = False
         h_w = None
         late = self.multi and self._hip_engine and eng.wgrads_deferred()
         if self.multi:
@@ -842,13 +838,6 @@ class ColumnShardEngine(object):
                 and os.environ.get("ELIMREC_HEAD_SOURCES", "1") != "0" and os.environ.get("ELIMREC_HEAD_BWD_ROWS", "16") != "32")
 
     @_once
-    def _bpr_in_bwd(self):
-        """The cosine-BPR rows inside the head backward's launch (elimrec_bpr_head_bwd_sources: one rank, the sources written by
-        the head backward, at most four head blocks of 64 columns; ELIMREC_FUSE_BPR=0: a launch of their own after the head)."""
-        import os
-        return self._sources_in_head() and 1 + self.model.S <= 4 and os.environ.get("ELIMREC_FUSE_BPR", "1") != "0"
-
-    @_once
     def _split_in_head(self):
         import os
         return (not self.wide and self._fused_head_ok() and bool(self._pack_bwd_off) and self.model.latent_dim == 64
@@ -1148,13 +1137,7 @@ class ColumnShardEngine(object):
         # tensors of earlier steps -- main.py stacks an epoch's losses before it copies them to the host -- does not see them
         # change (LOSS_RING steps back; `loss_ring_len` lets a caller that keeps more clone them).
         loss = self._next_loss_slot()
-        self._bpr_deferred = None
-        if getattr(self, "_step_defers_bpr", False) and self._bpr_in_bwd():
-            # ... or not at all: the head backward's launch evaluates the triplets itself (cs_backward_local) and writes this slot
-            self._bpr_deferred = dict(Y=YAct, slot_rows=ws["slot_seg"][:3 * B], block_weights=bw, loss_rows=ws["loss_rows"],
-                                      loss_out=loss, ticket=self._loss_ticket)
-        else:
-            ops.bpr_head_rows_sum(YAct, ws["slot_seg"][:3 * B], d, bw, ws["loss_rows"], ws["grad_rows"], loss, self._loss_ticket)
+        ops.bpr_head_rows_sum(YAct, ws["slot_seg"][:3 * B], d, bw, ws["loss_rows"], ws["grad_rows"], loss, self._loss_ticket)
         m._publish_cache(ws["Y"], dirty=True)
         return loss
 
@@ -1226,12 +1209,8 @@ class ColumnShardEngine(object):
             defer = "all"              # ... and the partial launch too: behind the first hop's tiles, the reduce behind the second's
         if self.multi and self.wgrads_deferred():
             defer = "all"              # several ranks: the same, and the all-reduce waits for the second hop (cs_backward_hops)
-        bpr = getattr(self, "_bpr_deferred", None)
-        self._bpr_deferred = None
-        if bpr is not None and not (isinstance(sources, tuple) and sources[0] is self.srcA):
-            raise RuntimeError("the BPR rows were left to a head backward that does not write the sources")
         self._grads = m._backward_batch_rows(ws, scale, ws["grad_rows"], R, head_only=True, w_stream=side, pack_bwd=pack_bwd,
-                                             merge=merge, defer_reduce=defer, sources=sources, bpr=bpr)
+                                             merge=merge, defer_reduce=defer, sources=sources)
         self._reduce = (m._bwd_w_reduce, 0 if defer == "all" else 1) if defer else None
         wg = ws["flat_grad"][ws["tail_off"]:]
         if not self.multi and not self.wide:        # one rank owns every column: the merge reads the dOut rows themselves

@@ -419,21 +419,6 @@ int elimrec_segment_apply_head_bwd_split(const float *d_rows, int64_t n, int ld,
                                          float *d_compact, const float *d_pack_bwd, int64_t n_max, int world,
                                          float *d_out, void *stream);
 
-/* elimrec_bpr_head_rows_sum + elimrec_segment_apply_head_bwd_sources in ONE launch (one rank, recdim 64, 1..4 head blocks):
- * the wave that reduces an active row's slots evaluates each slot's triplet itself from the compact Y rows (d_Y, d_slot_rows as
- * for elimrec_bpr_head_rows) instead of reading a gradient row a BPR launch wrote -- the same expressions in the same order, so
- * d_reduced, d_compact, the sources and *d_loss have the bits of the two launches; no [3B x Cy] gradient rows exist. The head
- * has 1 + S blocks (block_weights: host, 1 + S floats), 3 B slots, sources in [d / w x N x w] slabs.
- * Replaces the gathers + original_bpr_loss x (1 + |modality|) and their autograd together with IndexBackward / AddmmBackward of
- * the head (models/EliMRec.py:129-142,291-297,262-270). */
-int elimrec_bpr_head_bwd_sources(const float *d_Y, int64_t ldy, const int32_t *d_slot_rows, int B,
-                                 const float *block_weights, float *d_loss_rows, float *d_loss, int32_t *d_ticket,
-                                 const int32_t *d_active_rows, const int32_t *d_seg_info, const float *d_scale,
-                                 float *d_reduced, const void *d_plan_workspace, size_t plan_workspace_bytes, int64_t U,
-                                 int d, int C, int S, const int *head_mblock, const float *d_W_user, const float *d_W_item,
-                                 const float *const *d_W_heads, float *d_compact, const float *d_pack_bwd, int64_t N, int w,
-                                 float *d_SrcA, float *d_SrcB, void *stream);
-
 /* ---------------------------------------------------------------- embedding gradients (K2 bwd)
  * dE_user[u, j] = sum_m G[u, m*d + j];  dE_item[i, j] = G[U+i, j]   (CatBackward of :239). */
 int elimrec_embed_grad(const float *d_G, int64_t U, int64_t I, int d, int M,

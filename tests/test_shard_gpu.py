@@ -836,16 +836,19 @@ def test_weight_gradients_behind_a_hops_tiles(masked):
         assert torch.equal(ref[k], got[k]), k
 
 
-def test_step_variants_are_bitwise_equal(monkeypatch):
+@pytest.mark.parametrize("name", ["ml3", "normal", "kwai"])
+def test_step_variants_are_bitwise_equal(monkeypatch, name):
     """The launch-saving forms of the step change WHERE work runs, not what is computed: Adam as the last hop's epilogue
     (+ the projection weights' spans as extra workgroups), the planner / source-bit pass / weight packing on a second
     stream, the adjoint sources written by the head backward (or merged inside the weight-gradient launch), the weight
     gradients' slab reduce inside the adjoint's first hop launch, the loss summed inside the BPR-head launch, the head's feature
     blocks in a launch of their own on the second stream beside the forward hops, the active rows' layer means evaluated by the
     head's main-stream launch instead of a rows launch -- each switched off gives bitwise the same losses, parameters and
-    Adam moments after three steps. The two-launch SELL-64 hop sums long rows in another order: equal to round-off."""
+    Adam moments after three steps. The two-launch SELL-64 hop sums long rows in another order: equal to round-off.
+    Fixtures: ml3 (recdim 32: the generic head kernels), normal (recdim 64, three modalities: the fused 16-row head, the sources
+    written by the head backward) and kwai (recdim 64, one modality)."""
     from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
-    g = load_golden("ml3")
+    g = load_golden(name)
 
     def run(env):
         for k in ("ELIMREC_FUSE_ADAM", "ELIMREC_AUX_STREAM", "ELIMREC_SLAB_TIERED", "ELIMREC_FUSED_HEAD", "ELIMREC_FUSE_MERGE", "ELIMREC_MERGE_FIRST",
@@ -858,6 +861,8 @@ def test_step_variants_are_bitwise_equal(monkeypatch):
         eng = ColumnShardEngine(model)
         tr = ColumnShardTrainer(eng, opt)
         losses = [tr.step(*(_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg"))).clone() for t in (1, 2, 3)]
+        if not env:
+            assert eng._sources_in_head() == (int(g["recdim"]) == 64)      # recdim 64: the fused forms are what the default step runs
         eng.sync_to_model()
         st = eng.optimizer_state()
         return (torch.stack(losses).cpu(), {k: v.detach().cpu().clone() for k, v in model.state_dict().items()},
