@@ -810,7 +810,20 @@ __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__re
             const int e = e0 + 1024 * q;
             if (e >= HM16 * Cy) continue;
             if (in[q] && seg.rows) {
-                for (int i = beg[q] + 1; i < end[q]; ++i) {
+                // a popular item is listed by dozens of slots, and this loop is the launch's longest chain: eight members' rows in
+                // flight at a time (added in member order, as before)
+                int i = beg[q] + 1;
+                for (; i + 8 <= end[q]; i += 8) {
+                    int mm[8];
+                    float4 x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) mm[u] = seg.members[i + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x[u] = ld4(seg.rows + (int64_t)mm[u] * Cy + c[q]);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { v[q].x += x[u].x; v[q].y += x[u].y; v[q].z += x[u].z; v[q].w += x[u].w; }
+                }
+                for (; i < end[q]; ++i) {
                     const float4 x = ld4(seg.rows + (int64_t)seg.members[i] * Cy + c[q]);
                     v[q].x += x.x; v[q].y += x.y; v[q].z += x.z; v[q].w += x.w;
                 }
