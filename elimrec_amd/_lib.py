@@ -195,7 +195,8 @@ SIGNATURES = {
                                        ctypes.POINTER(LinearBwdDesc), c_i32, c_ptr, c_size, c_i32, c_ptr]),
     "elimrec_slab_source_bits": (c_i32, [c_sell, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_size, c_ptr]),
     "elimrec_slab_hop_adam": (c_i32, [c_sell, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr, c_size, c_ptr, c_ptr,
-                                      c_ptr, c_ptr, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, ctypes.POINTER(AdamJob), c_i32, c_ptr]),
+                                      c_ptr, c_ptr, c_f32, c_f32, c_f32, c_f32, c_f32, c_i64, ctypes.POINTER(AdamJob), c_i32, c_ptr, c_i64,
+                                      c_ptr, c_ptr]),
     "elimrec_slab_rows": (c_i32, [c_sell, c_i32, c_i32, c_i32, c_i64, ctypes.POINTER(c_ptr), c_ptr, c_ptr, c_ptr, c_i64, c_i32,
                                   c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr]),
     "elimrec_slab_from_rows": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr]),

@@ -382,7 +382,26 @@ struct AdamJob {
     float step_size, inv_sqrt_bc2;
     int first_block;
 };
-struct AdamJobs { AdamJob j[8]; int n; int blocks; };
+struct AdamJobs {
+    AdamJob j[8]; int n; int blocks;
+    const float *sum_src; float *sum_dst; int sum_n;      // one more workgroup: sum_dst[0] = sum of sum_src[0 .. sum_n) in elimrec_sum's order
+};
+
+// elimrec_sum (bpr.hip sum_kernel) by one workgroup of 256 threads: 1024 virtual threads add x[t], x[t + 1024], ..., then the
+// binary tree over the 1024 partials -- the same additions, so the same bits
+__device__ __forceinline__ void fixed_order_sum_body(const float *__restrict__ x, int n, float *__restrict__ out, float *s) {
+    for (int vt = threadIdx.x; vt < 1024; vt += 256) {
+        float acc = 0.f;
+        for (int i = vt; i < n; i += 1024) acc += x[i];
+        s[vt] = acc;
+    }
+    __syncthreads();
+    for (int w = 512; w > 0; w >>= 1) {
+        for (int idx = threadIdx.x; idx < w; idx += 256) s[idx] += s[idx + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = s[0];
+}
 
 __device__ __forceinline__ void adam_jobs_body(const AdamJobs &jobs, int block, float beta1, float beta2, float eps, float wd) {
     int k = 0;
@@ -696,11 +715,14 @@ __global__ __launch_bounds__(256, ELIMREC_TILE_WAVES) void sell_tier_kernel(Tier
 // nothing of this hop) as extra workgroups behind the tiles -- its own kernel, so that the other hops' argument block stays small
 template <int LPR>
 __global__ __launch_bounds__(256) void sell_tier_adam_kernel(TierArgs t, AdamJobs tail, int tail_block0) {
+    __shared__ float scratch[4 * 64 * 8];                   // the hop's wave sums; the loss sum's 1024 partials
     if ((int)blockIdx.x >= tail_block0) {
-        adam_jobs_body(tail, (int)blockIdx.x - tail_block0, t.s.ad_beta1, t.s.ad_beta2, t.s.ad_eps, t.s.ad_wd);
+        const int b = (int)blockIdx.x - tail_block0;
+        if (b < tail.blocks) adam_jobs_body(tail, b, t.s.ad_beta1, t.s.ad_beta2, t.s.ad_eps, t.s.ad_wd);
+        else fixed_order_sum_body(tail.sum_src, tail.sum_n, tail.sum_dst, scratch);     // the step's loss (needed by the host only)
         return;
     }
-    tier_body<LPR, 4, false, false, false, true>(t);
+    tier_body<LPR, 4, false, false, false, true, true>(t, scratch);
 }
 
 // An adjoint hop with a phase of the projections' weight gradients (bwd_w.h) as extra workgroups behind the tiles: the
@@ -801,8 +823,9 @@ static int launch_tier(const elimrec_sell *A, int ns, int wl, int wl_shift, int 
     }
     const int tail_block0 = (int)(per_group * gs);
     AdamJobs tail = {};
-    if (adam && adam->tail && adam->tail->n > 0) tail = *adam->tail;
-    const dim3 grid((unsigned)(per_group * gs)), grid_adam((unsigned)(per_group * gs) + (unsigned)(tail.n > 0 ? tail.blocks : 0));
+    if (adam && adam->tail && (adam->tail->n > 0 || adam->tail->sum_src)) tail = *adam->tail;
+    if (tail.n <= 0) tail.blocks = 0;
+    const dim3 grid((unsigned)(per_group * gs)), grid_adam((unsigned)(per_group * gs) + (unsigned)tail.blocks + (tail.sum_src ? 1u : 0u));
     const bool masked = src_mask != nullptr;
     if (masked) {
         ELIMREC_REQUIRE(A->tile_kmax > 0, "slab_hop: bad tile plan (tile_kmax)");
@@ -993,8 +1016,10 @@ extern "C" int elimrec_slab_hop_adam(const elimrec_sell *A, int ns, int w, int g
                                      const float *d_add, const uint32_t *d_add_mask, float scale, float *d_partials,
                                      size_t partials_bytes, const float *d_p_in, float *d_p_out, float *d_m, float *d_v, float lr,
                                      float beta1, float beta2, float eps, float weight_decay, int64_t step,
-                                     const elimrec_adam_job *tail_jobs, int n_tail_jobs, void *stream) {
+                                     const elimrec_adam_job *tail_jobs, int n_tail_jobs, const float *d_sum_src, int64_t sum_n,
+                                     float *d_sum_dst, void *stream) {
     ELIMREC_REQUIRE(A && d_Xin && d_p_in && d_p_out && d_m && d_v, "slab_hop_adam: null pointer");
+    ELIMREC_REQUIRE(!d_sum_src || (d_sum_dst && sum_n >= 0 && sum_n < INT32_MAX), "slab_hop_adam: the sum needs a destination");
     ELIMREC_REQUIRE(A->tiered, "slab_hop_adam: needs a tiered (wave-tile) plan");
     ELIMREC_REQUIRE(step >= 1, "slab_hop_adam: 1-based step");
     ELIMREC_REQUIRE((const void *)d_Xin != (const void *)d_p_out && (const void *)d_Xin != (const void *)d_m &&
@@ -1018,6 +1043,7 @@ extern "C" int elimrec_slab_hop_adam(const elimrec_sell *A, int ns, int w, int g
         if ((rc = build_adam_jobs("slab_hop_adam", tail_jobs, n_tail_jobs, lr, beta1, beta2, tail))) return rc;
         ad.tail = &tail;
     }
+    if (d_sum_src) { tail.sum_src = d_sum_src; tail.sum_dst = d_sum_dst; tail.sum_n = (int)sum_n; ad.tail = &tail; }
     return launch_tier(A, ns, w / 4, w4_shift, gs, spg, lpr, d_Xin, nullptr, d_grad_out, d_add, d_add_mask, scale,
                        d_partials, 0, (hipStream_t)stream, &ad);
 }

@@ -475,7 +475,11 @@ class ColumnShardTrainer(object):
                 program.wait(torch.cuda.current_stream(), lookup_rec)             # the looked-up rows: the head reads them
         else:
             recv = send
+        if self._hip_engine:
+            eng._step_in_flight = True                              # cs_head may leave work to the later launches of this step
         loss = ph["cs_head"](recv)                                 # my rows, every rank's columns -> loss, head backward
+        if self._hip_engine:
+            eng._step_in_flight = False
         if self._scale is None:
             self._scale = torch.full((1,), 1.0 / W, dtype=torch.float32, device=loss.device)
         send2, wgrads = ph["cs_backward_local"](self._scale)       # [W, R, 2*dl]: my rows, the peers' columns
@@ -838,6 +842,12 @@ class ColumnShardEngine(object):
                 and os.environ.get("ELIMREC_HEAD_SOURCES", "1") != "0" and os.environ.get("ELIMREC_HEAD_BWD_ROWS", "16") != "32")
 
     @_once
+    def _loss_sum_late(self):
+        """The loss rows are summed by an extra workgroup of the Adam hop (ELIMREC_LOSS_LATE=0: by the BPR launch's last workgroup)."""
+        import os
+        return not self.multi and self._fuse_adam() and os.environ.get("ELIMREC_LOSS_LATE", "1") != "0"
+
+    @_once
     def _split_in_head(self):
         import os
         return (not self.wide and self._fused_head_ok() and bool(self._pack_bwd_off) and self.model.latent_dim == 64
@@ -1137,7 +1147,13 @@ class ColumnShardEngine(object):
         # tensors of earlier steps -- main.py stacks an epoch's losses before it copies them to the host -- does not see them
         # change (LOSS_RING steps back; `loss_ring_len` lets a caller that keeps more clone them).
         loss = self._next_loss_slot()
-        ops.bpr_head_rows_sum(YAct, ws["slot_seg"][:3 * B], d, bw, ws["loss_rows"], ws["grad_rows"], loss, self._loss_ticket)
+        if getattr(self, "_step_in_flight", False) and self._loss_sum_late():
+            # a whole step on one rank: only the host reads the loss, so its fixed-order sum rides in the LAST launch of the step
+            # (an extra workgroup of the Adam hop) instead of ending this one behind a ticket and an acquire
+            ops.bpr_head_rows(YAct, ws["slot_seg"][:3 * B], d, bw, ws["loss_rows"], ws["grad_rows"])
+            self._loss_late = (ws["loss_rows"][:B], loss)
+        else:
+            ops.bpr_head_rows_sum(YAct, ws["slot_seg"][:3 * B], d, bw, ws["loss_rows"], ws["grad_rows"], loss, self._loss_ticket)
         m._publish_cache(ws["Y"], dirty=True)
         return loss
 
@@ -1309,10 +1325,12 @@ class ColumnShardEngine(object):
             self._tail_n, self._tail_base = len(tail), 0
             tail = (self._tail_arr, len(tail))
             self._tail_in_hop = in_hop
+            late = getattr(self, "_loss_late", None)          # cs_head left the loss rows' sum to this launch
+            self._loss_late = None
             self._timed(lambda: slab.hop_adam(self.planT, self.tmp[1], self.grad if self.keep_grad else None, self.gs, self.srcA,
                                               self.mask, inv, self.master[self.cur].data, self.master[nxt].data, self.m1, self.m2,
                                               g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
-                                              self.step_count + 1, tail_jobs=tail), 1)
+                                              self.step_count + 1, tail_jobs=tail, loss_sum=late), 1)
         if self._side and not self.multi:
             torch.cuda.current_stream().wait_stream(self._side)      # the weight gradients, computed beside the hops
 

@@ -529,10 +529,12 @@ def hop(plan, xin, xout, gs=None, src_mask=None, add=None, add_mask=None, scale=
                                     part.numel() * 4, (1 if seg_only else 0) | (2 if bits_ready else 0), _stream()), "slab_hop")
 
 
-def hop_adam(plan, xin, grad_out, gs, add, add_mask, scale, p_in, p_out, m, v, lr, beta1, beta2, eps, weight_decay, step, tail_jobs=()):
+def hop_adam(plan, xin, grad_out, gs, add, add_mask, scale, p_in, p_out, m, v, lr, beta1, beta2, eps, weight_decay, step, tail_jobs=(),
+             loss_sum=None):
     """elimrec_slab_hop_adam: the hop whose output is the gradient of the fp32 slab table p_in, consumed in place by an
     Adam step (p_out / m / v flat fp32 of the table's geometry). grad_out: a table to also receive the gradient, or None.
-    tail_jobs: _lib.AdamJob spans (the projection weights) updated by extra workgroups of the same launch."""
+    tail_jobs: _lib.AdamJob spans (the projection weights) updated by extra workgroups of the same launch.
+    loss_sum = (loss_rows, loss_out): one more workgroup adds the loss rows in elimrec_sum's order into loss_out."""
     if isinstance(tail_jobs, tuple) and len(tail_jobs) == 2 and not isinstance(tail_jobs[0], _lib.AdamJob):
         arr, n_tail = tail_jobs                      # (persistent AdamJob array, count): the caller keeps it alive and in place
     else:
@@ -543,7 +545,9 @@ def hop_adam(plan, xin, grad_out, gs, add, add_mask, scale, p_in, p_out, m, v, l
         plan.ref(), ns, w, int(gs), _dev(xin.data, "xin"), _dev(None if grad_out is None else grad_out.data, "grad"),
         _dev(None if add is None else add.data, "add"), _dev(add_mask, "add_mask", torch.int32), float(scale), _dev(part, "partials"),
         part.numel() * 4, _dev(p_in, "p_in"), _dev(p_out, "p_out"), _dev(m, "m"), _dev(v, "v"), float(lr), float(beta1), float(beta2),
-        float(eps), float(weight_decay), int(step), arr, n_tail, _stream()), "slab_hop_adam")
+        float(eps), float(weight_decay), int(step), arr, n_tail, _dev(None if loss_sum is None else loss_sum[0], "loss_rows"),
+        0 if loss_sum is None else loss_sum[0].numel(), _dev(None if loss_sum is None else loss_sum[1], "loss_out"), _stream()),
+        "slab_hop_adam")
 
 
 

@@ -669,13 +669,17 @@ int elimrec_slab_hop_bwd_w(const elimrec_sell *A, int ns, int w, int gs, const f
  * may alias or be the two buffers of a ping-pong pair. d_grad_out nullable: also store the gradient there.
  * tail_jobs (nullable, <= 8): further optimizer spans as elimrec_adam_multi takes them -- the projection weights, whose
  * gradients do not depend on this hop -- run by extra workgroups of the same launch.
+ * d_sum_src (nullable): one more workgroup leaves sum(d_sum_src[0 .. sum_n)) in d_sum_dst[0], added in elimrec_sum's order
+ * (same bits) -- the step's loss from the BPR head's loss rows: it is needed by the host only, so it rides here instead of
+ * ending the BPR launch.
  * The adjoint's last hop and the optimizer step (main.py:101) in one launch. */
 struct elimrec_adam_job;          /* defined with elimrec_adam_multi below */
 int elimrec_slab_hop_adam(const elimrec_sell *A, int ns, int w, int gs, const float *d_Xin, float *d_grad_out,
                           const float *d_add, const uint32_t *d_add_mask, float scale, float *d_partials,
                           size_t partials_bytes, const float *d_p_in, float *d_p_out, float *d_m, float *d_v, float lr,
                           float beta1, float beta2, float eps, float weight_decay, int64_t step,
-                          const struct elimrec_adam_job *tail_jobs, int n_tail_jobs, void *stream);
+                          const struct elimrec_adam_job *tail_jobs, int n_tail_jobs, const float *d_sum_src, int64_t sum_n,
+                          float *d_sum_dst, void *stream);
 
 /* Layer means (models/EliMRec.py:246-247) of the folded propagation at a list of rows, from slab-major layer
  * tables X^0..X^L (host array of L+1 device pointers):

@@ -841,7 +841,8 @@ def test_step_variants_are_bitwise_equal(monkeypatch, name):
     """The launch-saving forms of the step change WHERE work runs, not what is computed: Adam as the last hop's epilogue
     (+ the projection weights' spans as extra workgroups), the planner / source-bit pass / weight packing on a second
     stream, the adjoint sources written by the head backward (or merged inside the weight-gradient launch), the weight
-    gradients' slab reduce inside the adjoint's first hop launch, the loss summed inside the BPR-head launch, the head's feature
+    gradients' slab reduce inside the adjoint's first hop launch, the loss summed by an extra workgroup of the Adam hop (or inside
+    the BPR-head launch), the head's feature
     blocks in a launch of their own on the second stream beside the forward hops, the active rows' layer means evaluated by the
     head's main-stream launch instead of a rows launch -- each switched off gives bitwise the same losses, parameters and
     Adam moments after three steps. The two-launch SELL-64 hop sums long rows in another order: equal to round-off.
@@ -852,7 +853,7 @@ def test_step_variants_are_bitwise_equal(monkeypatch, name):
 
     def run(env):
         for k in ("ELIMREC_FUSE_ADAM", "ELIMREC_AUX_STREAM", "ELIMREC_SLAB_TIERED", "ELIMREC_FUSED_HEAD", "ELIMREC_FUSE_MERGE", "ELIMREC_MERGE_FIRST",
-                  "ELIMREC_FUSE_REDUCE", "ELIMREC_HEAD_SOURCES", "ELIMREC_FUSE_BWDW", "ELIMREC_HEAD_SPLIT", "ELIMREC_ROWS_IN_HEAD"):
+                  "ELIMREC_FUSE_REDUCE", "ELIMREC_HEAD_SOURCES", "ELIMREC_FUSE_BWDW", "ELIMREC_HEAD_SPLIT", "ELIMREC_ROWS_IN_HEAD", "ELIMREC_LOSS_LATE"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -869,7 +870,7 @@ def test_step_variants_are_bitwise_equal(monkeypatch, name):
                 st["exp_avg"], st["exp_avg_sq"])
 
     base = run({})
-    for env in ({"ELIMREC_FUSE_ADAM": "0"}, {"ELIMREC_AUX_STREAM": "0"}, {"ELIMREC_FUSE_ADAM": "0", "ELIMREC_AUX_STREAM": "0"},
+    for env in ({"ELIMREC_LOSS_LATE": "0"}, {"ELIMREC_FUSE_ADAM": "0"}, {"ELIMREC_AUX_STREAM": "0"}, {"ELIMREC_FUSE_ADAM": "0", "ELIMREC_AUX_STREAM": "0"},
                 {"ELIMREC_HEAD_SOURCES": "0"}, {"ELIMREC_HEAD_SOURCES": "0", "ELIMREC_FUSE_MERGE": "0"}, {"ELIMREC_FUSE_REDUCE": "0"}, {"ELIMREC_FUSE_BWDW": "0"},
                 {"ELIMREC_HEAD_SPLIT": "0"}, {"ELIMREC_ROWS_IN_HEAD": "0"},
                 {"ELIMREC_HEAD_SOURCES": "0", "ELIMREC_FUSE_MERGE": "0", "ELIMREC_FUSE_REDUCE": "0", "ELIMREC_AUX_STREAM": "0"}):
