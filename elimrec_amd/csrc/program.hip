@@ -35,6 +35,15 @@ template <typename R, typename... A> static R call_packed(R (*f)(A...), const ui
 }
 template <typename R, typename... A> constexpr int arg_count(R (*)(A...)) { return (int)sizeof...(A); }
 
+// The program's events order streams of ONE device: no system-scope fence (cache write-back + invalidate for the host and other
+// devices) when one is recorded -- the kernels' own agent-scope release / acquire is what the streams need of each other
+// (ELIMREC_EVENT_FENCE=1 keeps the default events).
+static unsigned event_flags() {
+    static int fence = -1;
+    if (fence < 0) { const char *e = getenv("ELIMREC_EVENT_FENCE"); fence = (e && e[0] == '1') ? 1 : 0; }
+    return fence ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
+}
+
 struct FnEntry { const char *name; int (*thunk)(const uint64_t *); int n_args; };
 #define ELIMREC_FN(fn) {#fn, [](const uint64_t *a) -> int { return call_packed(fn, a); }, arg_count(fn)}
 static const FnEntry kFns[] = {
@@ -199,7 +208,7 @@ extern "C" int elimrec_program_create(const elimrec_op *ops, int n_ops, void **p
     }
     p->events.resize(n_events);
     for (int e = 0; e < n_events; ++e) {
-        int rc = check_hip(hipEventCreateWithFlags(&p->events[e], hipEventDisableTiming), "hipEventCreate");
+        int rc = check_hip(hipEventCreateWithFlags(&p->events[e], event_flags()), "hipEventCreate");
         if (rc) { delete p; return rc; }
     }
     *prog_out = p;
