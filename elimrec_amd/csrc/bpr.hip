@@ -810,18 +810,29 @@ __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__re
             const int e = e0 + 1024 * q;
             if (e >= HM16 * Cy) continue;
             if (in[q] && seg.rows) {
-                // a popular item is listed by dozens of slots, and this loop is the launch's longest chain: eight members' rows in
-                // flight at a time (added in member order, as before)
+                // a popular item is listed by dozens of slots (48 of 6144 at the Tiktok shape), and walking them one dependent load
+                // pair at a time was the launch's longest chain (26 us; 19.5 with sixteen, then four, members' rows in flight --
+                // added in member order, as before)
                 int i = beg[q] + 1;
-                for (; i + 8 <= end[q]; i += 8) {
-                    int mm[8];
-                    float4 x[8];
+                for (; i + 16 <= end[q]; i += 16) {
+                    int mm[16];
+                    float4 x[16];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) mm[u] = seg.members[i + u];
+                    for (int u = 0; u < 16; ++u) mm[u] = seg.members[i + u];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) x[u] = ld4(seg.rows + (int64_t)mm[u] * Cy + c[q]);
+                    for (int u = 0; u < 16; ++u) x[u] = ld4(seg.rows + (int64_t)mm[u] * Cy + c[q]);
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) { v[q].x += x[u].x; v[q].y += x[u].y; v[q].z += x[u].z; v[q].w += x[u].w; }
+                    for (int u = 0; u < 16; ++u) { v[q].x += x[u].x; v[q].y += x[u].y; v[q].z += x[u].z; v[q].w += x[u].w; }
+                }
+                for (; i + 4 <= end[q]; i += 4) {
+                    int mm[4];
+                    float4 x[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) mm[u] = seg.members[i + u];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) x[u] = ld4(seg.rows + (int64_t)mm[u] * Cy + c[q]);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { v[q].x += x[u].x; v[q].y += x[u].y; v[q].z += x[u].z; v[q].w += x[u].w; }
                 }
                 for (; i < end[q]; ++i) {
                     const float4 x = ld4(seg.rows + (int64_t)seg.members[i] * Cy + c[q]);
