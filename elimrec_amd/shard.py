@@ -845,7 +845,7 @@ class ColumnShardEngine(object):
     def _loss_sum_late(self):
         """The loss rows are summed by an extra workgroup of the Adam hop (ELIMREC_LOSS_LATE=0: by the BPR launch's last workgroup)."""
         import os
-        return not self.multi and self._fuse_adam() and os.environ.get("ELIMREC_LOSS_LATE", "1") != "0"
+        return self._fuse_adam() and os.environ.get("ELIMREC_LOSS_LATE", "1") != "0"
 
     @_once
     def _split_in_head(self):
@@ -1148,7 +1148,7 @@ class ColumnShardEngine(object):
         # change (LOSS_RING steps back; `loss_ring_len` lets a caller that keeps more clone them).
         loss = self._next_loss_slot()
         if getattr(self, "_step_in_flight", False) and self._loss_sum_late():
-            # a whole step on one rank: only the host reads the loss, so its fixed-order sum rides in the LAST launch of the step
+            # a whole step: only the host reads the loss, so its fixed-order sum rides in the LAST launch of the step
             # (an extra workgroup of the Adam hop) instead of ending this one behind a ticket and an acquire
             ops.bpr_head_rows(YAct, ws["slot_seg"][:3 * B], d, bw, ws["loss_rows"], ws["grad_rows"])
             self._loss_late = (ws["loss_rows"][:B], loss)
