@@ -79,4 +79,31 @@ if getattr(plan, "sweep", None) is not None:
         e1.record()
         torch.cuda.synchronize()
         print("  %s: %.2f us" % (name, e0.elapsed_time(e1) * 1e3 / 20))
+if getattr(plan, "sweep", None) is not None and os.environ.get("EXPT") == "1":
+    # where the in-situ item hop loses 100 us against its isolated timing: rotating tables, the other order, two streams
+    def chain(fn, n):
+        s_, d_ = tabs[0], tabs[1]
+        for _ in range(n):
+            fn(s_, d_)
+            s_, d_ = d_, (tabs[2] if d_ is tabs[1] else tabs[1])
+    side = torch.cuda.Stream()
+    def both_streams(a, b):
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            plan.sweep.hop(a, b)
+        slab.hop(plan.sweep.items, a, b, gs=gs)
+        main.wait_stream(side)
+    for name, fn in (("item rows only, rotating tables", lambda a, b: slab.hop(plan.sweep.items, a, b, gs=gs)),
+                     ("user rows only, rotating tables", lambda a, b: plan.sweep.hop(a, b)),
+                     ("items then users", lambda a, b: (slab.hop(plan.sweep.items, a, b, gs=gs), plan.sweep.hop(a, b))),
+                     ("users then items", lambda a, b: (plan.sweep.hop(a, b), slab.hop(plan.sweep.items, a, b, gs=gs))),
+                     ("both on two streams", both_streams)):
+        chain(fn, 4)
+        torch.cuda.synchronize()
+        e0.record()
+        chain(fn, 30)
+        e1.record()
+        torch.cuda.synchronize()
+        print("  EXPT %s: %.2f us per hop" % (name, e0.elapsed_time(e1) * 1e3 / 30))
 print("geometry ns=%d w=%d gs=%d, %d hops, index bytes %d" % (ns, w, gs, hops, plan.index_bytes()))
