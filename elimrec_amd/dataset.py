@@ -64,6 +64,35 @@ def _ones_csr(u, i, shape):
     return m
 
 
+class FeatureBlocks(object):
+    """A raw item-feature table read BLOCK BY BLOCK (--feature_load=block; the raw features of BASELINE.json configs[4] are 100 M
+    rows x 256 x 3: no host holds them whole per rank): `shape`, and `table[i0:i1]` = rows i0 .. i1 - 1 in model item order, row-
+    normalised as the model's buffers are (models/EliMRec.py:366-381), fp32. `reader(i0, i1)` returns the raw rows; `rows_read`
+    counts what was asked for (tests: a rank reads its own item block and nothing else)."""
+
+    def __init__(self, n_rows, dim, reader, normalize=True):
+        self.shape = (int(n_rows), int(dim))
+        self._reader, self._normalize = reader, normalize
+        self.rows_read = 0
+        self.blocks = []
+
+    def __getitem__(self, key):
+        if not isinstance(key, slice) or key.step not in (None, 1):
+            raise TypeError("a block-loaded feature table is read by contiguous row ranges only (table[i0:i1])")
+        i0, i1, _ = key.indices(self.shape[0])
+        raw = torch.as_tensor(self._reader(i0, i1)).float()
+        if raw.shape != (i1 - i0, self.shape[1]):
+            raise ValueError("feature block [%d, %d) came back as %s" % (i0, i1, tuple(raw.shape)))
+        self.rows_read += i1 - i0
+        self.blocks.append((i0, i1))
+        return torch.nn.functional.normalize(raw, dim=1).contiguous() if self._normalize else raw.contiguous()
+
+    def to(self, *a, **k):
+        raise RuntimeError("a block-loaded feature table has no whole-table form: this path needs --feature_load=full")
+
+    float = contiguous = to
+
+
 class SyntheticDataset(_DatasetBase):
     """Seeded synthetic interactions + features: every user >= 3 items, the rest
     user-uniform x item-Zipf(0.8), de-duplicated, every item >= 1 edge, random 80/10/10 split."""
@@ -92,6 +121,11 @@ class SyntheticDataset(_DatasetBase):
         g = torch.Generator().manual_seed(seed + 1)
         for name_, dm in zip(names, feat_dims):
             setattr(self, name_, torch.randn(I, int(dm), generator=g, dtype=torch.float32))
+
+    def feature_blocks(self, m):
+        """The same table as `<m>_feat`, served block by block (a stand-in for a file: the rows are sliced out of the seeded tensor)."""
+        t = getattr(self, m + "_feat")
+        return FeatureBlocks(t.shape[0], t.shape[1], lambda i0, i1: t[i0:i1])
 
 
 class Dataset(_DatasetBase):
@@ -129,8 +163,27 @@ class Dataset(_DatasetBase):
         if conf["with_item_vat"] if "with_item_vat" in conf else True:
             self._load_features(path, list(self.itemids.keys()))
 
+    def feature_blocks(self, m):
+        """`<m>_feat` block by block, without reading the file whole: the .npy files of the generic loader are memory-mapped and
+        a block gathers its rows by ORIGINAL item id (data/dataset.py:181-185); the .pt files of tiktok / kwai are torch.load-ed
+        with mmap=True."""
+        ids = np.asarray(self._feature_ids)
+        name, path = self.dataset_name, self._feature_path
+        if name in ("tiktok", "kwai"):
+            fn = {"v": "%s/%s_visual_feat.pt" if name == "tiktok" else "%s/%s_feat_v.pt", "a": "%s/%s_audio_feat.pt"}.get(m)
+            if fn is None:
+                raise ValueError("no block loader for the '%s' features of the %s data set" % (m, name))
+            table = torch.load(fn % (path, name), mmap=True)
+            return FeatureBlocks(len(ids), table.shape[1], lambda i0, i1: table[torch.as_tensor(ids[i0:i1])])
+        tag = {"v": "FeatureVideo_normal", "a": "FeatureAudio_avg_normal", "t": "FeatureText_stl_normal"}[m]
+        table = np.load("%s/%s_%s.npy" % (path, name, tag), mmap_mode="r")
+        return FeatureBlocks(len(ids), table.shape[1], lambda i0, i1: np.ascontiguousarray(table[ids[i0:i1]]))
+
     def _load_features(self, path, original_item_ids):
         name = self.dataset_name
+        self._feature_path, self._feature_ids = path, original_item_ids
+        if "feature_load" in self.conf and str(self.conf["feature_load"]) == "block":
+            return                                              # nothing is read here: feature_blocks(m) serves the rows
         if name == "tiktok":                                    # data/dataset.py:164-177
             self.v_feat = torch.load("%s/%s_visual_feat.pt" % (path, name))[original_item_ids]
             self.a_feat = torch.load("%s/%s_audio_feat.pt" % (path, name))[original_item_ids]

@@ -351,8 +351,14 @@ class EliMRec(BasicModel):
             # rank's item block of each (shard.py)
             if self.dataset_name == "tiktok" and not custom:
                 raise ValueError("--lean_tables=1 does not cover the tiktok word-bag text features")
+            # --feature_load=block: not even that -- a reader that serves normalised row blocks (dataset.FeatureBlocks); the
+            # distributed fold asks it for the rank's item block and for nothing else
+            block = str(self.config["feature_load"]) == "block" if "feature_load" in self.config else False
             for m in self._mods:
-                object.__setattr__(self, m + "_feat", F.normalize(getattr(ds, m + "_feat").float(), dim=1).contiguous())
+                object.__setattr__(self, m + "_feat", ds.feature_blocks(m) if block else
+                                   F.normalize(getattr(ds, m + "_feat").float(), dim=1).contiguous())
+        elif "feature_load" in self.config and str(self.config["feature_load"]) == "block":
+            raise ValueError("--feature_load=block needs --lean_tables=1 (and --feature_shard=row): the other forms keep whole feature tables")
         elif "v" in self._mods:
             self.register_buffer("v_feat", F.normalize(ds.v_feat.float(), dim=1).contiguous(), persistent=False)
         if self._lean:

@@ -1458,8 +1458,8 @@ class ColumnShardEngine(object):
     @torch.no_grad()
     def _fold_sharded(self, owners, frank):
         """S_m = mean_k A^k [0 ; F_m] and c = mean_k A^k [0 ; 1] WITHOUT any rank holding a full [N x D_m] table: the rank takes
-        its item block of the raw features (models/EliMRec.py:366-381; here a slice of the replicated buffer, with a sharded
-        loader the block it read), one all_to_all turns row blocks into COLUMN slices [I x D_m/W], every rank propagates its
+        its item block of the raw features (models/EliMRec.py:366-381: a slice of the host tensor, or -- --feature_load=block --
+        the one block the rank reads from the file, dataset.FeatureBlocks), one all_to_all turns row blocks into COLUMN slices [I x D_m/W], every rank propagates its
         slice through the (replicated) graph with the hop kernels -- no communication, like the training hops -- and a second
         all_to_all hands every owner its rows of every slice. c is one column: every rank computes it, keeps its rows."""
         from .shard_eval import collectives_for
@@ -1486,7 +1486,8 @@ class ColumnShardEngine(object):
                 recv = coll.all_to_all_rows(torch.cat([S[n] for n in nodes]), rows, [rows[q]] * W).view(W, rows[q], Dq)
                 tabs.append(recv.permute(1, 0, 2).reshape(rows[q], D).contiguous())
             else:       # a width that does not split: the whole table on every rank (small shapes), own rows kept
-                x0 = torch.cat([torch.zeros(U, D, dtype=torch.float32, device=dev), feat.to(dev)])
+                whole = feat[0:I] if hasattr(feat, "rows_read") else feat       # (a block-loaded table: the one block there is)
+                x0 = torch.cat([torch.zeros(U, D, dtype=torch.float32, device=dev), whole.to(dev)])
                 tabs.append(self._horner_mean(x0)[nodes[q]].contiguous())
         ones = torch.zeros(U + I, 4, dtype=torch.float32, device=dev)
         ones[U:, 0] = 1.0

@@ -108,6 +108,12 @@ class FixtureDataset(object):
     def get_train_interactions(self):
         return self._g["train_u"].tolist(), self._g["train_i"].tolist()
 
+    def feature_blocks(self, m):
+        """--feature_load=block on a fixture: the reference's (already normalised) rows, served block by block."""
+        from elimrec_amd.dataset import FeatureBlocks
+        t = getattr(self, m + "_feat")
+        return FeatureBlocks(t.shape[0], t.shape[1], lambda i0, i1: t[i0:i1], normalize=False)
+
     def get_user_train_dict(self, by_time=False):
         return self._dicts["train"]
 
@@ -136,7 +142,7 @@ def build_model_from_fixture(g, device, params_prefix="init", extra_argv=()):
     model = EliMRec(cfg, FixtureDataset(g))
     with torch.no_grad():
         for m in ("v", "a", "t"):
-            if (m + "_feat") in g and hasattr(model, m + "_feat"):
+            if (m + "_feat") in g and hasattr(model, m + "_feat") and torch.is_tensor(getattr(model, m + "_feat")):
                 getattr(model, m + "_feat").copy_(torch.from_numpy(g[m + "_feat"]))   # exact reference bits
     sd = {k: torch.from_numpy(v.copy()) for k, v in sub(g, params_prefix).items()}
     model.load_state_dict(sd, strict=True)

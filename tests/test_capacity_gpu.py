@@ -13,7 +13,7 @@ DEV = "cuda:0"
 def _build(U, I, E, dims, recdim, lean, seed=7):
     from elimrec_amd import EliMRec, SyntheticDataset, set_seed
     argv = ["--data.input.dataset=synthetic", "--alpha=0.5", "--loss=bpr_loss", "--recdim=%d" % recdim, "--verbose=0",
-            "--feature_shard=row"] + (["--lean_tables=1"] if lean else [])
+            "--feature_shard=row"] + (["--lean_tables=1"] if lean else []) + (["--feature_load=block"] if lean == "block" else [])
     cfg = make_config(argv)
     ds = SyntheticDataset(U, I, E, feat_dims=dims, seed=1)
     set_seed(seed)
@@ -41,11 +41,14 @@ def test_lean_tables_train_and_evaluate_like_regular_tables(recdim, monkeypatch)
     monkeypatch.setenv("ELIMREC_FOLD", "sharded")
     U, I, E, dims, B = 700, 1900, 9000, (24, 8, 12), 257
     res = {}
-    for lean in (False, True):
+    for lean in (False, True, "block"):       # "block": lean tables + the raw features read block by block (--feature_load=block)
         cfg, ds, model = _build(U, I, E, dims, recdim, lean)
-        assert model._lean == lean
-        if lean:
+        assert model._lean == bool(lean)
+        if lean == "block":
+            assert not torch.is_tensor(model.v_feat) and model.v_feat.shape == (I, dims[0]) and model.v_feat.rows_read == 0
+        elif lean:
             assert model.embedding_user.weight.device.type == "cpu" and model.v_feat.device.type == "cpu"
+        if lean:
             assert model.s_dense_v.weight.is_cuda and not hasattr(model, "adj_rowptr")
         opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
         eng = ColumnShardEngine(model)
@@ -58,16 +61,20 @@ def test_lean_tables_train_and_evaluate_like_regular_tables(recdim, monkeypatch)
         ev, _ = model.evaluate()
         eng.sync_to_model()
         res[lean] = (losses, pred, ev, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
+        if lean == "block":                   # one rank: its item block is the whole range, read once per modality
+            for m_ in "vat":
+                assert getattr(model, m_ + "_feat").blocks == [(0, I)]
         if lean:
             ws = model._ws
             assert ws["fold"] is None and ws["Y"] is None and "Out" not in ws and "X0d" not in ws and "layers" not in ws
             with pytest.raises(RuntimeError):
                 model.bpr_loss(*_batches(ds, 8, 1)[0])
-    assert res[True][0] == res[False][0]
-    for k, v in res[False][3].items():
-        assert torch.equal(res[True][3][k], v), k
-    assert np.abs(res[True][1] - res[False][1]).max() < 2e-7
-    assert np.abs(res[True][2] - res[False][2]).max() < 1e-7
+    for lean in (True, "block"):
+        assert res[lean][0] == res[False][0]
+        for k, v in res[False][3].items():
+            assert torch.equal(res[lean][3][k], v), k
+        assert np.abs(res[lean][1] - res[False][1]).max() < 2e-7
+        assert np.abs(res[lean][2] - res[False][2]).max() < 1e-7
 
 
 def test_capacity_plan_matches_the_device_allocator_at_the_scaled_c5_shape():

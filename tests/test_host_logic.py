@@ -167,6 +167,19 @@ def test_csv_dataset_loader_remaps_ids_like_the_reference(tmp_path):
         Dataset(dict(conf, splitter="ratio"))
     with pytest.raises(ValueError):
         Dataset(dict(conf, **{"data.column.format": "XYZ"}))
+    # --feature_load=block: nothing is read at construction; a block is the rows of its ORIGINAL ids out of the memory-mapped
+    # file, row-normalised as the model's buffers are, and only the rows asked for are counted
+    lazy = Dataset(dict(conf, feature_load="block"))
+    assert not hasattr(lazy, "v_feat")
+    fb = lazy.feature_blocks("a")
+    assert fb.shape == (4, 4) and fb.rows_read == 0
+    want = torch.nn.functional.normalize(ds.a_feat.float(), dim=1)
+    assert torch.equal(fb[1:3], want[1:3]) and torch.equal(fb[3:4], want[3:4]) and fb.rows_read == 3 and fb.blocks == [(1, 3), (3, 4)]
+    with pytest.raises(TypeError):
+        fb[[0, 2]]
+    with pytest.raises(RuntimeError):
+        fb.to("cpu")
+    assert torch.equal(ds.feature_blocks("v")[0:4], torch.nn.functional.normalize(ds.v_feat.float(), dim=1))
 
 
 def test_csv_dataset_loader_matches_reference_on_the_golden_data(tmp_path):

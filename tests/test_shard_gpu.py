@@ -965,6 +965,15 @@ def _two_proc_worker(rank, world, port, out_dir, feature_shard="replicated", nam
         assert tr.lookup and tr.lookup_syncs == 1 and tr.xgmi_bytes["all_to_all_lookup"] > 0
         assert eng.fshard.table.shape[0] < model.num_users + model.num_items
         assert eng.fold_mode == "sharded" and model._ws["fold"] is None      # no rank ever computed or held a full S_m
+    if "--feature_load=block" in extra:
+        # the raw features were READ block by block: this rank asked for its own item block of every table whose width splits
+        # over the ranks (the distributed fold's column slices must be multiples of 4 floats) -- and for nothing else
+        I = model.num_items
+        mine = (I * rank // world, I * (rank + 1) // world)
+        for m_ in model._mods:
+            fb = getattr(model, m_ + "_feat")
+            splits = fb.shape[1] % world == 0 and (fb.shape[1] // world) % 4 == 0
+            assert fb.blocks == [mine if splits else (0, I)], (m_, fb.blocks)
     # validation on the tables of the last forward: user-sharded with replicated tables, ITEM-sharded with row shards
     model.fusion_mode, model.predict_type = "rubi", "TIE"
     res, _ = model.test()
@@ -981,15 +990,17 @@ def _two_proc_worker(rank, world, port, out_dir, feature_shard="replicated", nam
 
 
 @pytest.mark.parametrize("feature_shard,name,extra", [("replicated", "ml3", ()), ("row", "ml3", ()),
-                                                      ("row", "ablate", ("--propagation=folded",))],
-                         ids=["replicated", "row", "row-wide-form"])
+                                                      ("row", "ablate", ("--propagation=folded",)),
+                                                      ("row", "ml3", ("--lean_tables=1", "--feature_load=block"))],
+                         ids=["replicated", "row", "row-wide-form", "row-lean-block-loader"])
 def test_two_processes_on_one_gpu_equal_one_process(tmp_path, feature_shard, name, extra):
     """The real engine and the real trainer in two PROCESSES (both on cuda:0; gloo group, collectives staged through the host
     because RCCL refuses duplicate devices): every collective of a column-sharded step executes between processes. Both ranks
     end with the same full model, equal to one process on the concatenated batch. feature_shard = row: each process holds
     half the rows of the folded constants and the step's variable-size all_to_all brings the other half's active rows.
     row-wide-form: the `ablate` fixture (adjacency with a diagonal, mean fusion) in the wide form, two column slices of both
-    halves of the wide tables."""
+    halves of the wide tables. row-lean-block-loader: lean tables with the raw features read block by block (--feature_load=block):
+    every process reads its own item block of a feature table and nothing else of it."""
     import torch.multiprocessing as mp
     from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
     world = 2
