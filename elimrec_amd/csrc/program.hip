@@ -35,13 +35,15 @@ template <typename R, typename... A> static R call_packed(R (*f)(A...), const ui
 }
 template <typename R, typename... A> constexpr int arg_count(R (*)(A...)) { return (int)sizeof...(A); }
 
-// The program's events order streams of ONE device: no system-scope fence (cache write-back + invalidate for the host and other
-// devices) when one is recorded -- the kernels' own agent-scope release / acquire is what the streams need of each other
-// (ELIMREC_EVENT_FENCE=1 keeps the default events).
-static unsigned event_flags() {
+// The events of a program WITHOUT collectives order streams of ONE device whose buffers no other device writes: no system-scope
+// fence (cache write-back + invalidate for the host and other devices) when one is recorded -- the kernels' own agent-scope
+// release / acquire is what the streams need of each other. A program that lists the library's RCCL calls keeps the default
+// events: peers write into this device's buffers over xGMI, and a stream that consumes them behind an event must see them at
+// system scope. ELIMREC_EVENT_FENCE=1 keeps the default events everywhere.
+static unsigned event_flags(bool has_collectives) {
     static int fence = -1;
     if (fence < 0) { const char *e = getenv("ELIMREC_EVENT_FENCE"); fence = (e && e[0] == '1') ? 1 : 0; }
-    return fence ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
+    return (fence || has_collectives) ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
 }
 
 struct FnEntry { const char *name; int (*thunk)(const uint64_t *); int n_args; };
@@ -197,9 +199,11 @@ extern "C" int elimrec_program_create(const elimrec_op *ops, int n_ops, void **p
     Program *p = new Program();
     p->ops.assign(ops, ops + n_ops);
     int n_events = 0;
+    bool has_collectives = false;
     for (const elimrec_op &o : p->ops) {
         if (o.kind == ELIMREC_OP_CALL) {
             if (o.fn < 0 || o.fn >= kNumFns) { delete p; set_error("program_create: unknown function index %d", o.fn); return ELIMREC_E_BADARG; }
+            has_collectives = has_collectives || strncmp(kFns[o.fn].name, "elimrec_comm_", 13) == 0;
         } else if (o.kind == ELIMREC_OP_RECORD || o.kind == ELIMREC_OP_WAIT) {
             if ((int)o.args[1] + 1 > n_events) n_events = (int)o.args[1] + 1;
         } else {
@@ -208,7 +212,7 @@ extern "C" int elimrec_program_create(const elimrec_op *ops, int n_ops, void **p
     }
     p->events.resize(n_events);
     for (int e = 0; e < n_events; ++e) {
-        int rc = check_hip(hipEventCreateWithFlags(&p->events[e], event_flags()), "hipEventCreate");
+        int rc = check_hip(hipEventCreateWithFlags(&p->events[e], event_flags(has_collectives)), "hipEventCreate");
         if (rc) { delete p; return rc; }
     }
     *prog_out = p;
