@@ -893,10 +893,12 @@ class ColumnShardEngine(object):
             program.sync(aux, torch.cuda.current_stream())
         self._ws_gen_planned = m._ws_gen
 
-        # the per-line source bits are needed by the first ADJOINT hop only: issued on the second stream BEHIND the forward's join
-        # (cs_forward_rows), they run under the head kernels instead of lengthening what the forward waits for
-        # (measured +-0 at today's hop times; it takes the bits out of the forward's shadow for faster hops)
-        self._bits_late = early_bits and self._sources_in_head()
+        # the per-line source bits are needed by the first ADJOINT hop only. They can be issued on the second stream BEHIND the
+        # forward's join (cs_forward_rows: `_bits_late`; they then run under the head kernels and the adjoint joins the second
+        # stream a second time) or right behind the planner, before the weight packing and the feature blocks (one join per step;
+        # the second stream's forward work is then 72 us against the main stream's 74). Measured at the end of round 4, three
+        # pairs of 300 steps: 0.2834 ms late, 0.2821 early -- early it is
+        self._bits_late = False
 
         def plan():       # node ids of the slots, unique active rows + slot map, padded tail: one launch
             ops.batch_plan(users, pos, neg, m.num_users, m.num_items, keys, act, seg, ws["slot_seg"][:R], ws["plan_ws"], err, PAD_KEY,
