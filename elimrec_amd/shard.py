@@ -893,17 +893,15 @@ class ColumnShardEngine(object):
             program.sync(aux, torch.cuda.current_stream())
         self._ws_gen_planned = m._ws_gen
 
-        # the per-line source bits are needed by the first ADJOINT hop only. They can be issued on the second stream BEHIND the
-        # forward's join (cs_forward_rows: `_bits_late`; they then run under the head kernels and the adjoint joins the second
-        # stream a second time) or right behind the planner, before the weight packing and the feature blocks (one join per step;
-        # the second stream's forward work is then 72 us against the main stream's 74). Measured at the end of round 4, three
-        # pairs of 300 steps: 0.2834 ms late, 0.2821 early -- early it is
-        self._bits_late = False
+        # the per-line source bits are needed by the first ADJOINT hop only. Issued on the second stream right behind the planner,
+        # before the weight packing and the feature blocks: one join per step (the second stream's forward work is then 72 us
+        # against the main stream's 74). Behind the forward's join instead -- under the head kernels, with a second join before the
+        # adjoint -- measured 0.2834 against 0.2821 ms at the end of round 4 (three pairs of 300 steps) and was removed
 
         def plan():       # node ids of the slots, unique active rows + slot map, padded tail: one launch
             ops.batch_plan(users, pos, neg, m.num_users, m.num_items, keys, act, seg, ws["slot_seg"][:R], ws["plan_ws"], err, PAD_KEY,
                            key_bitmap=self.mask if (early_bits or self._sources_in_head()) else None)
-            if early_bits and not self._bits_late:    # the planner's bitmap of the active rows IS the first adjoint hop's source
+            if early_bits:                             # the planner's bitmap of the active rows IS the first adjoint hop's source
                 slab.source_bits(self.planT, self.hns, self.w, self.hgs, self.mask)    # bitmap (one rank): its per-line bits
 
         def pack():       # the head's weights in MFMA fragment order (they changed in the last optimizer step)
@@ -1050,12 +1048,6 @@ class ColumnShardEngine(object):
         if late_wait:
             m._region("cs_fwd_long%d" % self.cur, (m._ws_gen,), long_rows)
             join_plan()
-        if getattr(self, "_bits_late", False):
-            # (the join above was recorded before this is enqueued: the forward does not wait for it; the adjoint's first hop does)
-            with torch.cuda.stream(self._aux):
-                m._region("cs_bits_late", (m._ws_gen,), lambda: slab.source_bits(self.planT, self.hns, self.w, self.hgs, self.mask))
-            self._bits_late = False
-            self._bits_join = True
         m._region("cs_fwd_rows%d" % self.cur, (m._ws_gen, acts.data_ptr(), R, W, narrow.data_ptr(), late_wait, self._rows_in_head), rows)
         return self.send_f if self.multi else None
 
@@ -1259,7 +1251,7 @@ class ColumnShardEngine(object):
 
         single = not self.multi
         merged = single and getattr(self, "_merged", False)
-        if getattr(self, "_bits_join", False):                      # the source bits from the second stream (cs_forward_rows)
+        if getattr(self, "_bits_join", False):                      # the source bits from the second stream (several ranks: cs_gathered_ids)
             program.sync(torch.cuda.current_stream(), self._aux)
             self._bits_join = False
         reduce = getattr(self, "_reduce", None) if (single or reduce_wgrads is not None) else None
