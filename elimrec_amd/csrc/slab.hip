@@ -15,7 +15,6 @@
 #include "merge_rows.h"
 #include "rows_args.h"
 #include "bwd_w.h"
-#include <hip/hip_bf16.h>
 #include <cstdlib>
 
 namespace elimrec {
