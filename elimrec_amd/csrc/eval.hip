@@ -88,6 +88,13 @@ template <bool FAST> __device__ __forceinline__ float sig_abs_(float x) {
     if (FAST) return rcp_nr(1.f + __builtin_amdgcn_exp2f(fmaxf(x, -88.f) * -1.44269502162933349609375f));
     return sigmoidf_(x);
 }
+// ... and a sigmoid that is only ever AVERAGED over a catalogue (pass 1: the mean of sigmoid(u.i) behind the NDE term,
+// models/EliMRec.py:107) needs neither the Newton step -- v_rcp_f32 is within 1 ulp, 3e-8 absolute on a value near 0.5, and the
+// mean of 76 k such terms moves a TIE score by less than 1e-8 -- nor the clamp (1 + inf -> 0 without the Newton step)
+template <bool FAST> __device__ __forceinline__ float sig_mean_(float x) {
+    if (FAST) return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * -1.44269502162933349609375f));
+    return sigmoidf_(x);
+}
 // ... and a PRODUCT of sigmoids goes through one reciprocal: prod_h 1 / (1 + e^-z_h) = 1 / prod_h (1 + e^-z_h), the
 // denominator <= (1 + e)^4 (two v_rcp_f32 + Newton steps fewer per (user, item) pair with three heads)
 template <bool MASKED> __device__ __forceinline__ float sig_den_(const float *z, int S, uint32_t mask) {
@@ -909,7 +916,7 @@ __global__ __launch_bounds__(NTB, 2) void score_t16b_kernel(ScoreArgs a, int n_t
         for (int r = 0; r < 4; ++r) {
             const int urow = wave * TU + 4 * kq + r;
             if (PASS == 1) {
-                const float ui = sig_abs_<FAST>(acc[0][r]);
+                const float ui = sig_mean_<FAST>(acc[0][r]);
                 psum[r] += (item_ok && b0 + urow < a.B) ? ui : 0.f;      // this lane's item of every tile; the 16 lanes are added at the end
                 continue;
             }
