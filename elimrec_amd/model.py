@@ -269,8 +269,7 @@ class EliMRec(BasicModel):
         nn.init.xavier_uniform_(self.s_dense_a.weight)
         nn.init.xavier_uniform_(self.s_dense_t.weight)
         self._param_names = [n for n, _ in self.named_parameters()]
-        # step regions: recorded C-ABI call lists, or hipGraphs with --hip_graphs=1 (CLI-only; see _region)
-        self._use_graphs = str(opt("hip_graphs", os.environ.get("ELIMREC_GRAPHS", "0"))) == "1"
+        # step regions: recorded C-ABI call lists (see _region)
         self._use_replay = os.environ.get("ELIMREC_REPLAY", "1") != "0"
         # hop L only feeds the layer mean, which "batch" mode reads at the active rows (hop 2 also forms a sum with X^0)
         self._last_hop_rows = self._lazy and self.n_layers >= 3 and os.environ.get("ELIMREC_LAST_HOP_ROWS", "1") != "0"
@@ -744,15 +743,15 @@ class EliMRec(BasicModel):
         if dirty:
             self._eval_shard = None          # an item-sharded scorer of an older forward (shard.py) is stale now
 
-    # ------------------------------------------------------------------ hipGraph regions
+    # ------------------------------------------------------------------ recorded regions
     def _region(self, name, key, fn):
         """Run fn() -- a fixed sequence of launches on workspace buffers. The first run records the C-ABI calls it
         makes (function + converted arguments); later runs with the same `key` re-issue that list without the
         Python that built it: the step is some 25 launches of 5-50 us each, and issued one by one through the
         tensor-level wrappers the host side costs as much as the GPU side. `key` names everything the launches
         depend on besides buffer contents (sizes, pointers of caller-owned tensors, mode flags, the stream).
-        --hip_graphs=1 captures the region into a hipGraph instead (two eager runs, capture on the third); on this
-        stack graph replay adds ~12 us per graph launch and is slower than the re-issued list."""
+        (Capturing the regions as hipGraphs instead was measured in round 2 -- + 12 us per graph launch on this stack -- and
+        removed in round 4; a whole step is one host call through csrc/program.hip, elimrec_amd/program.py.)"""
         if self.mm_fusion_mode != "concat" or not self._use_replay:   # 'mean' fusion mixes torch ops into the regions
             return fn()
         key = key + (ops._stream(),)
@@ -761,21 +760,8 @@ class EliMRec(BasicModel):
         if ent is None or ent[0] != key:
             ent = self._regions[name] = [key, 0, None, None]
         if ent[2] is not None:
-            if self._use_graphs:
-                ent[2].replay()
-            else:
-                _lib.replay(ent[2], name)
+            _lib.replay(ent[2], name)
             return ent[3]
-        if self._use_graphs:
-            ent[1] += 1
-            if ent[1] < 3:
-                return fn()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = fn()
-            ent[2], ent[3] = graph, out
-            graph.replay()                              # capturing does not execute
-            return out
         calls = []
         _lib.record(calls)
         try:
@@ -907,7 +893,7 @@ class EliMRec(BasicModel):
         return loss
 
     @torch.no_grad()
-    def _backward_batch_rows(self, ws, gscale, grad_rows, n, head_only=False, w_stream=None, pack_bwd=None, merge=None,
+    def _backward_batch_rows(self, ws, gscale, grad_rows, n, head_only=False, pack_bwd=None, merge=None,
                              defer_reduce=False, sources=None):
         """Backward of _forward_batch_rows: gradient rows -> active rows (the forward's plan) -> head and projection
         gradients from the compact Out / dY rows -> adjoint propagation at d columns. Two hipGraph regions."""
@@ -961,18 +947,10 @@ class EliMRec(BasicModel):
         self._region("bwd_head_in", key + (0 if pack_bwd is None else pack_bwd.data_ptr(),
                                            0 if sources is None else (sources[1] if sources[0] == "split" else sources[0].data).data_ptr()),
                      head_input)
-        if w_stream is None:
-            mkey = (str(defer_reduce),) + (() if merge is None else (merge["rows"].data_ptr(), merge["keys"].data_ptr(),
-                                                                     merge["mask"].data_ptr()))
-            grads, self._bwd_w_reduce = self._region("bwd_head_w", key + mkey, head_weights)
-            grads = dict(grads)
-        else:
-            # the weight gradients are needed by the optimizer step only: they run beside whatever the caller enqueues next
-            # (the adjoint hops) on a second stream; the caller joins it before the update (w_stream is its handle)
-            main = torch.cuda.current_stream()
-            w_stream.wait_stream(main)
-            with torch.cuda.stream(w_stream):
-                grads = dict(self._region("bwd_head_w", key, head_weights)[0])
+        mkey = (str(defer_reduce),) + (() if merge is None else (merge["rows"].data_ptr(), merge["keys"].data_ptr(),
+                                                                 merge["mask"].data_ptr()))
+        grads, self._bwd_w_reduce = self._region("bwd_head_w", key + mkey, head_weights)
+        grads = dict(grads)
         if head_only:
             return grads
         self._backward_hops(ws, dOutR, act, seg, n, grads)

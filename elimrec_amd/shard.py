@@ -350,12 +350,12 @@ class ColumnShardTrainer(object):
     def _native_eligible(self, users, pos, neg):
         eng = self.engine
         if not (self._hip_engine and not self.profile_kernels and eng.kernel_events is None and not eng.keep_grad
-                and eng.model.mm_fusion_mode == "concat" and eng.model._use_replay and not eng.model._use_graphs
+                and eng.model.mm_fusion_mode == "concat" and eng.model._use_replay
                 and all(t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() for t in (users, pos, neg))
                 and users.numel() == pos.numel() == neg.numel()):
             return False
         if not self.multi:
-            return eng._side_stream() is None
+            return True
         # several ranks (or the multi-rank path on one): the exchanges must be the library's own RCCL calls, the received
         # columns turned into rows by a kernel (fused head or compact constants), the lookup's split sizes planned ahead
         if self._native_comm() is None or not (eng._fused_head_ok() or eng.lookup):
@@ -648,7 +648,6 @@ class ColumnShardEngine(object):
             self.srcA, self.srcB, self.tmp = tab(), tab(), [tab(), tab()]
         self.mask = torch.zeros((N + 31) // 32 + 2, dtype=torch.int32, device=dev)
         self.step_count = 0
-        self._side = None
         self._aux = None
         self._aux_pending = False
         self._adam_in_hop = False
@@ -785,15 +784,6 @@ class ColumnShardEngine(object):
                 if os.environ.get("ELIMREC_HEAD_ROWS", "16") != "32" and os.environ.get("ELIMREC_HEAD_BWD_ROWS", "16") != "32":
                     self._pack_bwd_off = ops.head_pack_bwd_offset(dims)
         return self._fused
-
-    def _side_stream(self):
-        """Second HIP stream for work off the step's critical path (ELIMREC_SIDE_STREAM=1: the weight-gradient GEMMs run
-        beside the adjoint hops). Off by default: measured 0.395 ms per step either way at the Tiktok shape -- the hops keep
-        every CU busy, so the side kernels' workgroups only interleave with theirs, and the fork/join costs host time."""
-        if self._side is None:
-            import os
-            self._side = torch.cuda.Stream() if os.environ.get("ELIMREC_SIDE_STREAM", "0") == "1" else False
-        return self._side or None
 
     def _aux_stream(self):
         """Second HIP stream for the two launches of a step that do not depend on the forward hops and are latency-bound
@@ -937,11 +927,7 @@ class ColumnShardEngine(object):
 
     def wgrads_deferred(self):
         """Several ranks: the weight gradients ride behind the adjoint hops' tiles (both phases) and are all-reduced late."""
-        return bool(getattr(self, "defer_wgrads", False)) and self.multi and self._side_stream_multi_ok() and self._fuse_reduce() \
-            and self._fuse_bwd_w()
-
-    def _side_stream_multi_ok(self):
-        return True
+        return bool(getattr(self, "defer_wgrads", False)) and self.multi and self._fuse_reduce() and self._fuse_bwd_w()
 
     @torch.no_grad()
     def cs_gathered_ids(self, acts, handle):
@@ -1200,7 +1186,6 @@ class ColumnShardEngine(object):
         R = m._plan_n
         # the head backward reads its weight operands from the packed copy the fused forward left behind (16-row forms)
         pack_bwd = self._pack[self._pack_bwd_off:] if (self._fused_head_ok() and self._pack_bwd_off) else None
-        side = self._side_stream() if not self.multi else None
         # one rank: the merge of the dOut rows into the adjoint sources rides in the weight-gradient launch (both read the
         # head backward's rows and nothing of each other; ELIMREC_FUSE_MERGE=0: a launch of its own before the hops)
         merge = None
@@ -1209,17 +1194,17 @@ class ColumnShardEngine(object):
             sources = ("split", self.send_b, self.world)      # the head backward fills the peers' [H | G] slices itself
         if sources is not None:
             pass                       # the head backward writes the sources itself; their row bitmap is the planner's
-        elif not self.multi and side is None and self._fuse_merge():
+        elif not self.multi and self._fuse_merge():
             merge = dict(rows=ws["dOutR"][:R].view(R, m.C), keys=self._acts.reshape(-1), world=1, U=m.num_users, I=m.num_items,
                          srcA=self.srcA, srcB=self.srcB, mask=self.mask, M=m.M)
         self._merged = merge is not None or sources is not None
         # ... and the weight gradients' slab reduce, needed by the optimizer only, in the adjoint's first hop launch
-        defer = (not self.multi and side is None and self._fuse_reduce())
+        defer = (not self.multi and self._fuse_reduce())
         if defer and merge is None and self._fuse_bwd_w():
             defer = "all"              # ... and the partial launch too: behind the first hop's tiles, the reduce behind the second's
         if self.multi and self.wgrads_deferred():
             defer = "all"              # several ranks: the same, and the all-reduce waits for the second hop (cs_backward_hops)
-        self._grads = m._backward_batch_rows(ws, scale, ws["grad_rows"], R, head_only=True, w_stream=side, pack_bwd=pack_bwd,
+        self._grads = m._backward_batch_rows(ws, scale, ws["grad_rows"], R, head_only=True, pack_bwd=pack_bwd,
                                              merge=merge, defer_reduce=defer, sources=sources)
         self._reduce = (m._bwd_w_reduce, 0 if defer == "all" else 1) if defer else None
         wg = ws["flat_grad"][ws["tail_off"]:]
@@ -1325,8 +1310,6 @@ class ColumnShardEngine(object):
                                               self.mask, inv, self.master[self.cur].data, self.master[nxt].data, self.m1, self.m2,
                                               g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
                                               self.step_count + 1, tail_jobs=tail, loss_sum=late), 1)
-        if self._side and not self.multi:
-            torch.cuda.current_stream().wait_stream(self._side)      # the weight gradients, computed beside the hops
 
     @torch.no_grad()
     def cs_update(self):

@@ -160,10 +160,10 @@ def test_batch_row_head_equals_full_tables(fixture_name):
     assert torch.equal(out["batch"][3], out["all"][3]) and torch.equal(out["batch"][4], out["all"][4])
 
 
-def test_step_regions_replay_and_graph_capture_equal_eager(monkeypatch):
-    """The step's regions three ways -- launched from Python every time, re-issued from the recorded C-ABI call
-    lists (default), captured as hipGraphs (--hip_graphs=1) -- give bit-identical parameters after several steps,
-    including a change of batch size in between (regions are re-recorded against the new workspace buffers)."""
+def test_step_regions_replayed_equal_eager(monkeypatch):
+    """The step's regions two ways -- launched from Python every time, re-issued from the recorded C-ABI call
+    lists (default) -- give bit-identical parameters after several steps, including a change of batch size in
+    between (regions are re-recorded against the new workspace buffers)."""
     from helpers import FixtureDataset, fixture_argv, make_config
     from elimrec_amd import EliMRec, FusedAdam
     from elimrec_amd.dist import DataParallelTrainer
@@ -171,17 +171,16 @@ def test_step_regions_replay_and_graph_capture_equal_eager(monkeypatch):
     u, p, n = (_t(g["step1/%s" % k]) for k in ("users", "pos", "neg"))
     sizes = [len(u)] * 5 + [len(u) - 7] * 2 + [len(u)] * 4
     out = {}
-    for mode in ("eager", "replay", "graphs"):
+    for mode in ("eager", "replay"):
         monkeypatch.setenv("ELIMREC_REPLAY", "0" if mode == "eager" else "1")
-        argv = fixture_argv(g) + (["--hip_graphs=1"] if mode == "graphs" else [])
-        model = EliMRec(make_config(argv), FixtureDataset(g))
+        model = EliMRec(make_config(fixture_argv(g)), FixtureDataset(g))
         model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sub(g, "init").items()})
         model = model.to(DEV)
-        assert model._lazy and model._use_graphs == (mode == "graphs") and model._use_replay == (mode != "eager")
+        assert model._lazy and model._use_replay == (mode != "eager")
         trainer = DataParallelTrainer(model, FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"])))
         losses = [float(trainer.step(u[:b], p[:b], n[:b])) for b in sizes]
         out[mode] = (losses, {k: v.cpu().clone() for k, v in model.state_dict().items()})
-    for mode in ("replay", "graphs"):
+    for mode in ("replay",):
         assert out[mode][0] == out["eager"][0], mode
         for k, v in out["eager"][1].items():
             assert torch.equal(out[mode][1][k], v), (mode, k)
