@@ -22,7 +22,6 @@ single-GPU step with batch world_size*B (mean over the global batch).
 The `engine` (EliMRec, or a CPU stand-in injected by tests/test_dist_cpu.py) provides
 batch_keys / forward_local / backward_global / named_parameters.
 """
-import os
 
 import torch
 import torch.distributed as dist
@@ -54,19 +53,12 @@ class DataParallelTrainer(object):
                 self._gather = (torch.empty(self.world * rows.shape[0], rows.shape[1], dtype=rows.dtype, device=rows.device),
                                 torch.empty(self.world * keys.numel(), dtype=keys.dtype, device=keys.device))
             all_rows, all_keys = self._gather
-            # ELIMREC_DP_ASYNC=1 issues the collectives asynchronously so that the weight-gradient all-reduce (needed
-            # only by the optimizer step) runs under the merge and the adjoint propagation; measured on one GPU the
-            # extra stream hand-offs cost 35 us per step, so the default is in-order
-            sync = os.environ.get("ELIMREC_DP_ASYNC", "0") != "1"
-            h_rows = dist.all_gather_into_tensor(all_rows, rows, group=self.group, async_op=not sync)
-            h_keys = dist.all_gather_into_tensor(all_keys, keys, group=self.group, async_op=not sync)
-            h_w = dist.all_reduce(wgrads, op=dist.ReduceOp.SUM, group=self.group, async_op=not sync)
-            if not sync:
-                h_rows.wait()
-                h_keys.wait()
+            # in order (issued asynchronously, with the weight-gradient all-reduce under the merge and the adjoint propagation,
+            # the extra stream hand-offs measured + 35 us per step on one GPU)
+            dist.all_gather_into_tensor(all_rows, rows, group=self.group)
+            dist.all_gather_into_tensor(all_keys, keys, group=self.group)
+            dist.all_reduce(wgrads, op=dist.ReduceOp.SUM, group=self.group)
             grads = eng.backward_rows_global(all_rows, all_keys)
-            if not sync:
-                h_w.wait()
         elif self.collectives:
             keys = eng.batch_keys(users, pos, neg)
             if self._gather is None or self._gather[1].numel() != self.world * keys.numel():

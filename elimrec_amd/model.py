@@ -272,7 +272,7 @@ class EliMRec(BasicModel):
         # step regions: recorded C-ABI call lists (see _region)
         self._use_replay = os.environ.get("ELIMREC_REPLAY", "1") != "0"
         # hop L only feeds the layer mean, which "batch" mode reads at the active rows (hop 2 also forms a sum with X^0)
-        self._last_hop_rows = self._lazy and self.n_layers >= 3 and os.environ.get("ELIMREC_LAST_HOP_ROWS", "1") != "0"
+        self._last_hop_rows = self._lazy and self.n_layers >= 3
         self._regions = {}
         self._ws = None
         self._ws_key = None

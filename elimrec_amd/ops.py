@@ -216,15 +216,13 @@ class Csr:
         dev = self.rowptr.device
         # rows in order of decreasing length (split rows count as empty in the main pass): a scheduling hint
         order = np.argsort(-np.where(deg > threshold, 0, deg), kind="stable").astype(np.int32)
-        self._row_order = torch.from_numpy(order).to(dev) if _os.environ.get("ELIMREC_ROW_ORDER", "1") == "1" else None
-        ro = self._row_order.data_ptr() if self._row_order is not None else None
+        self._row_order = torch.from_numpy(order).to(dev)
+        ro = self._row_order.data_ptr()
         # (row, begin, end) of the rows that are not split, in that order: the streaming form of the row kernel
-        self._row_items, ri, n_items = None, None, 0
-        if _os.environ.get("ELIMREC_ROW_STREAM", "1") == "1":
-            keep = order[deg[order] <= threshold].astype(np.int64)
-            items = np.stack([keep, rowptr[keep], rowptr[keep + 1]], 1).astype(np.int32)
-            self._row_items = torch.from_numpy(np.ascontiguousarray(items)).to(dev)
-            ri, n_items = self._row_items.data_ptr(), int(len(keep))
+        keep = order[deg[order] <= threshold].astype(np.int64)
+        items = np.stack([keep, rowptr[keep], rowptr[keep + 1]], 1).astype(np.int32)
+        self._row_items = torch.from_numpy(np.ascontiguousarray(items)).to(dev)
+        ri, n_items = self._row_items.data_ptr(), int(len(keep))
         if len(long_rows) == 0:
             self._split_tensors = None
             self._split = _lib.CsrSplit(0, 0, 0, None, None, None, None, None, ro, None, ri, n_items)

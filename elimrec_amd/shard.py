@@ -79,10 +79,8 @@ class ColumnShardTrainer(object):
         self.multi = getattr(engine, "multi", self.world > 1)
         self._gloo = None
         if isinstance(engine, ColumnShardEngine) and self.multi:
-            import os
-            on = os.environ.get("ELIMREC_MULTI_ASYNC", "1") != "0"
-            engine.multi_aux = on           # plan / weight packing / source bits on the second stream, as with one rank
-            engine.defer_wgrads = on        # weight gradients behind the adjoint hops' tiles, their all-reduce under the last hop
+            engine.multi_aux = True         # plan / weight packing / source bits on the second stream, as with one rank
+            engine.defer_wgrads = True      # weight gradients behind the adjoint hops' tiles, their all-reduce under the last hop
         # the HIP engine's phases without their torch.no_grad() wrappers: step() enters no_grad once (host time)
         self._hip_engine = isinstance(engine, ColumnShardEngine)
 
@@ -690,7 +688,7 @@ class ColumnShardEngine(object):
             else:
                 fold = ws["fold"]
                 self.fshard = FeatureShard(owners, frank, [fold[k] for k in m._mods], fold["c"], dtype=self.feature_dtype, device=dev)
-                if self.feature_shard == "row" and world > 1 and os.environ.get("ELIMREC_KEEP_FOLD", "0") != "1":
+                if self.feature_shard == "row" and world > 1:
                     ws["fold"] = None                # the full tables are gone: every consumer goes through the shards
             self.lookup_row_bytes = self.fshard.row_bytes
             self._lookup_bufs = {}
