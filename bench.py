@@ -233,6 +233,14 @@ def main():
     dt = float(t.item())
     final_loss = float(loss.item())
 
+    # the same workload, model, optimizer and engine through the REFERENCE'S loop body (main.py:98-101), right behind the headline
+    plugin = None
+    if world == 1:
+        try:
+            plugin = plugin_api_loop(model, opt, batches, torch, steps=args.steps, warmup=args.warmup, headline_ms=1e3 * dt / args.steps)
+        except Exception as e:   # noqa: BLE001
+            plugin = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
     # roofline sample of the dominant kernel, in its own loop (not in the headline's): ONE full propagation hop of this
     # rank's column slice = one elimrec_slab_hop call (sell_hop_kernel + the split rows' sell_fixup_kernel), bracketed by
     # HIP events on the launch stream, alternating between two tables as the forward does
@@ -309,6 +317,8 @@ def main():
                          "bytes_with_index_per_group": sb["hop"],
                          "avg_launch_us": hop_us, "launches_timed": n_launch},
         }
+        if plugin is not None:
+            out["plugin_api_loop"] = plugin
         if world > 1:
             out["xgmi_bytes_sent_per_rank_step"] = trainer.xgmi_bytes
             # what ONE GPU does at the same global batch (a step is O(graph) + O(B), so one GPU's triplets/s rises with B):
@@ -350,6 +360,47 @@ def main():
         dist.barrier()
     if dist.is_available() and dist.is_initialized():
         dist.destroy_process_group()
+
+
+def plugin_api_loop(model, opt, batches, torch, steps, warmup, headline_ms):
+    """The reference's loop body verbatim -- `loss = model.bpr_loss(u, p, n); opt.zero_grad(); loss.backward(retain_graph=True);
+    opt.step()` (main.py:98-101) -- on the headline's model, optimizer and engine (elimrec_amd/plugin.py: the four calls
+    complete a request, FusedAdam.step() enqueues the engine's whole step). Then the same with line 102's per-step
+    `loss.cpu().item()`, which makes the host wait for every step."""
+    ctl = model.plugin
+    fast0, slow0 = ctl.fast_steps, ctl.slow_steps
+    n = len(batches)
+
+    def body(k):
+        u, p, neg = batches[k % n]
+        loss = model.bpr_loss(u, p, neg)
+        opt.zero_grad()
+        loss.backward(retain_graph=True)
+        opt.step()
+        return loss
+    for k in range(warmup):
+        body(k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        loss = body(warmup + k)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    B = batches[0][0].numel()
+    out = {"what": "main.py:98-101 of the reference verbatim (model.bpr_loss -> opt.zero_grad -> loss.backward(retain_graph=True) -> "
+                   "opt.step), same model / optimizer / engine / batches as the headline, %d timed steps after %d" % (steps, warmup),
+           "ms_per_step": 1e3 * dt, "triplets_per_s": B / dt, "vs_headline_ms_per_step": 1e3 * dt / headline_ms,
+           "final_loss": float(loss.item())}
+    k_sync = min(steps, 100)
+    t0 = time.perf_counter()
+    for k in range(k_sync):
+        body(k).cpu().item()
+    torch.cuda.synchronize()
+    dts = (time.perf_counter() - t0) / k_sync
+    out["with_line_102_loss_item_every_step"] = {"ms_per_step": 1e3 * dts, "triplets_per_s": B / dts, "steps": k_sync}
+    out["steps_through_the_one_enqueue_path"] = ctl.fast_steps - fast0
+    out["steps_launch_by_launch"] = ctl.slow_steps - slow0
+    return out
 
 
 def one_gpu_at_batch(args, device, cfg, ds, Bg, torch, steps=20, warmup=5):

@@ -31,6 +31,7 @@ from torch.nn import functional as F
 from . import _lib, ops
 from .basic_model import BasicModel
 from .logger import Logger
+from .plugin import EmbeddingParameter, LazyGradParameter, StepController
 
 
 def create_adj_mat(train_users, train_items, num_users, num_items, adj_type):
@@ -268,6 +269,15 @@ class EliMRec(BasicModel):
         nn.init.xavier_uniform_(self.s_dense_v.weight)
         nn.init.xavier_uniform_(self.s_dense_a.weight)
         nn.init.xavier_uniform_(self.s_dense_t.weight)
+        # the same tensors as parameter classes that know about the deferred training step (plugin.py): `.grad` of every
+        # parameter and the VALUE of the two embedding tables become real on first read
+        self._plugin = StepController(self)
+        for mod in self.modules():
+            for pname, prm in list(mod._parameters.items()):
+                if prm is not None:
+                    cls = EmbeddingParameter if mod in (self.embedding_user, self.embedding_item) else LazyGradParameter
+                    mod._parameters[pname] = cls(prm.data, prm.requires_grad)
+        self._plugin.adopt(self.parameters())
         self._param_names = [n for n, _ in self.named_parameters()]
         # step regions: recorded C-ABI call lists (see _region)
         self._use_replay = os.environ.get("ELIMREC_REPLAY", "1") != "0"
@@ -286,6 +296,7 @@ class EliMRec(BasicModel):
 
     # cached tables of the last forward (models/EliMRec.py:121-122); materialised on first use in "batch" mode
     def _cached(self, k):
+        self._plugin.realise_forward()         # a bpr_loss whose step has not run yet IS the last training forward
         if self._cache is None:
             return None
         self._ensure_tables()
@@ -410,6 +421,7 @@ class EliMRec(BasicModel):
         rebuilt from the LOADED word_embedding -- a resume under another seed scores with the features its weights were
         trained with."""
         out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._plugin.params_changed()
         if self.dataset_name == "tiktok" and hasattr(self, "word_embedding") and "feature_modalities" not in self.config:
             self.t_feat.copy_(self._word_bag_t_feat().to(self.t_feat.device))
             if self._ws is not None and self._ws.get("fold") is not None:
@@ -1115,10 +1127,23 @@ class EliMRec(BasicModel):
         """models/EliMRec.py:115-142. int64 index tensors of shape [b] -> 0-dim loss supporting
         .backward(retain_graph=True) and .cpu().item() (main.py:98-102)."""
         self._require_gpu()
-        self._no_lean("bpr_loss() through autograd")
         if self.is_kwai:
             self.modality = "v"                        # :133-134
+        if self._lazy:
+            # the column-shard engine's step, run when the caller's optimizer steps (plugin.py): loss.backward() and
+            # FusedAdam.step() complete the request; whatever is read in between is made real first
+            return self._plugin.begin(users, pos_items, neg_items)
         return _BprLossFn.apply(self, users, pos_items, neg_items, *self._all_params())
+
+    @property
+    def plugin(self):
+        """The controller behind bpr_loss -> backward -> optimizer.step (plugin.py): `.engine`, `.trainer` once a step ran."""
+        return self._plugin
+
+    def state_dict(self, *args, **kwargs):
+        """nn.Module.state_dict with the embedding tables written back from the engine's master copy first."""
+        self._plugin.sync_params()
+        return super().state_dict(*args, **kwargs)
 
     def _all_params(self):
         params = self.__dict__.get("_param_list")
@@ -1139,6 +1164,8 @@ class EliMRec(BasicModel):
         enabled: differentiable copies (_TablesFn) -- what getEmbedding / the generic BasicModel losses build on."""
         self._require_gpu()
         self._no_lean("compute()")
+        self._plugin.settle()
+        self._plugin.sync_params()               # the table build below reads the parameters themselves
         if torch.is_grad_enabled():
             self._last_tables = _TablesFn.apply(self, *self._all_params())
             return self._last_tables
@@ -1198,6 +1225,7 @@ class EliMRec(BasicModel):
         """Device-side predict (+ optional train-item masking and top-K). Uses the tables cached
         by the LAST training forward, like the reference (:98-99)."""
         dev = self._require_gpu()
+        self._plugin.realise_forward()
         if self._ws is None or self._cache is None:
             raise RuntimeError("predict() needs the tables cached by a training forward (call bpr_loss or compute first)")
         self._ensure_tables()

@@ -17,6 +17,20 @@ class FusedAdam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._mirror = {}     # storage data_ptr -> (exp_avg_flat, exp_avg_sq_flat)
         self._plan = None     # (signature, merged runs) of the last step: same gradient tensors -> same launches
+        # parameters of an EliMRec model whose training step is deferred to this call (plugin.py): step() runs the engine's
+        # whole step when a backward() was requested for the pending loss
+        self._ctl = next((p.__dict__["_elimrec_ctl"] for g in self.param_groups for p in g["params"]
+                          if p.__dict__.get("_elimrec_ctl") is not None), None)
+        if self._ctl is not None:
+            self._ctl.register_optimizer(self)
+
+    def zero_grad(self, set_to_none=True):
+        ctl = self._ctl
+        if ctl is not None and set_to_none and not ctl.grads_set and not ctl.grads_deferred():
+            return              # no .grad was ever assigned (the deferred step keeps its gradients inside the engine)
+        super().zero_grad(set_to_none=set_to_none)
+        if ctl is not None and set_to_none:
+            ctl.grads_set = False
 
     def _state_for(self, p):
         st = self.state[p]
@@ -43,6 +57,13 @@ class FusedAdam(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
+        ctl = self._ctl
+        if ctl is not None:
+            if ctl.step(self):
+                return loss
+            if ctl.engine is not None:
+                ctl.sync_params()           # the update below reads and writes the embedding parameters themselves: current
+                ctl.params_changed()        # values first, and the master copy reloads from them before the next step
         # fast path: the same gradient buffers as last step (a trainer that keeps its gradients in fixed memory)
         # => the same merged launches, one step further
         sig = tuple(0 if p.grad is None else p.grad.data_ptr() for group in self.param_groups for p in group["params"])

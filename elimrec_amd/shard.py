@@ -89,6 +89,9 @@ class ColumnShardTrainer(object):
             return getattr(f, "__wrapped__", f).__get__(engine) if self._hip_engine else getattr(engine, name)
         self._ph = {n: phase(n) for n in ("cs_plan", "cs_forward_hops", "cs_forward_rows", "cs_head", "cs_backward_local",
                                           "cs_backward_hops", "cs_update")}
+        ctl = getattr(getattr(engine, "model", None), "_plugin", None) if self._hip_engine else None
+        if ctl is not None:
+            ctl.attach(engine, self)        # model.bpr_loss -> backward -> optimizer.step runs on THIS engine (plugin.py)
         self.xgmi_bytes = dict(all_gather=0, all_to_all_fwd=0, all_to_all_bwd=0, all_reduce=0)   # sent per rank, last step
         # row-sharded constant tables (engine.lookup): the all_to_all split sizes of every planned batch, as host integers
         self.lookup = bool(getattr(engine, "lookup", False)) and bool(getattr(engine, "lookup_exchange", True))
@@ -97,6 +100,13 @@ class ColumnShardTrainer(object):
         self.lookup_syncs = 0          # steps that had to read their split sizes back from the device (no plan entry)
         if self.lookup:
             self.xgmi_bytes["all_to_all_lookup"] = 0
+
+    def set_optimizer(self, optimizer):
+        """The optimizer whose hyper-parameters and projection-weight state the engine's Adam launches use (a trainer made
+        before the caller's optimizer existed: plugin.py)."""
+        self.opt = self.engine.opt = optimizer
+        if self._hip_engine:
+            self.engine._tail_plan = None
 
     def _like(self, name, t, lead=None):
         shape = tuple(t.shape) if lead is None else (lead,) + tuple(t.shape)
@@ -326,12 +336,20 @@ class ColumnShardTrainer(object):
         t.copy_(host)
         return self._Done()
 
-    def step(self, users, pos, neg):
-        """One training step on this rank's triplets; returns the local loss (0-dim tensor)."""
-        if self._hip_engine and torch.is_grad_enabled():
-            with torch.no_grad():
-                return self._step(users, pos, neg)
-        return self._step(users, pos, neg)
+    def step(self, users, pos, neg, loss=None):
+        """One training step on this rank's triplets; returns the local loss (0-dim tensor). loss: the device tensor the
+        step's loss goes to (default: the next slot of the engine's loss ring) -- plugin.py hands the slot out when the
+        caller asks for the loss and runs the step when the caller's optimizer steps."""
+        if loss is not None:
+            self.engine._loss_given = loss
+        try:
+            if self._hip_engine and torch.is_grad_enabled():
+                with torch.no_grad():
+                    return self._step(users, pos, neg)
+            return self._step(users, pos, neg)
+        finally:
+            if loss is not None:
+                self.engine._loss_given = None
 
     # ---- the step as one host call (program.py / csrc/program.hip): one rank, after a few ordinary steps
     NATIVE_WARM = 1          # ordinary steps before tracing starts (buffers of this batch size allocated, the loss ring in place):
@@ -375,7 +393,7 @@ class ColumnShardTrainer(object):
             return self._step_python(users, pos, neg)
         # trace this step (launched from Python, every call recorded) -- two traces per buffer parity make a program
         known = dict(users=users.data_ptr(), pos=pos.data_ptr(), neg=neg.data_ptr(),
-                     loss=eng._loss_ring.data_ptr() + 4 * eng._loss_at, step=eng.step_count + 1)
+                     loss=eng._peek_loss_slot(), step=eng.step_count + 1)
         if self.multi and self.lookup:
             known["sizes"] = ctypes.addressof(self._lookup_sizes(users, None))
         parity = eng.cur
@@ -403,7 +421,12 @@ class ColumnShardTrainer(object):
                     raise ValueError("per-step values %s appear in no call" % sorted(missing))
                 st["programs"][key][parity] = program.StepProgram(items, varying, keep=(ta, tb))
             except (ValueError, KeyError, TypeError) as e:
-                st["failed"] = str(e)                         # the ordinary path stays; the reason is kept for inspection
+                # two traces of different STRUCTURE (one of them followed a step of another batch size and carries the extra
+                # stream hand-over of a buffer-set switch): the newer one is kept and paired with the next; anything else, or
+                # eight such pairs in a row, and the ordinary path stays -- the reason is kept for inspection
+                st["mismatch"] = st.get("mismatch", 0) + 1
+                if "traces differ in" not in str(e) or st["mismatch"] >= 8:
+                    st["failed"] = str(e)
         return loss
 
     def _step_native(self, prog, users, pos, neg, B):
@@ -429,6 +452,28 @@ class ColumnShardTrainer(object):
         return os.environ.get("ELIMREC_LOOKUP_EARLY", "1") != "0"
 
     def _step_python(self, users, pos, neg):
+        return self._backward_python(self._forward_python(users, pos, neg, whole=True))
+
+    def forward_only(self, users, pos, neg, loss=None):
+        """The forward half of a step, launch by launch: tables propagated, head and cosine-BPR rows at the batch's rows, the
+        loss summed at once. Returns the context backward_only() continues from (plugin.py: a caller that reads the loss, the
+        cached tables or a gradient between bpr_loss() and optimizer.step())."""
+        if loss is not None:
+            self.engine._loss_given = loss
+        try:
+            with torch.no_grad():
+                return self._forward_python(users, pos, neg, whole=False)
+        finally:
+            self.engine._loss_given = None
+
+    def backward_only(self, ctx, grads_only=False, scale=None):
+        """The backward half behind forward_only(). grads_only: stop before the optimizer -- the last adjoint hop writes the
+        gradient table instead of carrying the Adam step, nothing is updated (engine.grad, engine._grads hold the gradients).
+        scale: device fp32[1], d(total) / d(this loss) (default 1 / world)."""
+        with torch.no_grad():
+            return self._backward_python(ctx, grads_only=grads_only, scale=scale)
+
+    def _forward_python(self, users, pos, neg, whole):
         eng, W, ph = self.engine, self.world, self._ph
         if self.profile_kernels and getattr(eng, "kernel_events", None) is None:
             eng.kernel_events = self._events
@@ -474,37 +519,52 @@ class ColumnShardTrainer(object):
         else:
             recv = send
         if self._hip_engine:
-            eng._step_in_flight = True                              # cs_head may leave work to the later launches of this step
-        loss = ph["cs_head"](recv)                                 # my rows, every rank's columns -> loss, head backward
-        if self._hip_engine:
-            eng._step_in_flight = False
+            assert getattr(eng, "_loss_late", None) is None, "a step was abandoned between its head and its last hop"
+            eng._step_in_flight = bool(whole)                       # a whole step: cs_head may leave work to its later launches
+        try:
+            loss = ph["cs_head"](recv)                             # my rows, every rank's columns -> loss, head backward
+        finally:
+            if self._hip_engine:
+                eng._step_in_flight = False
+        return dict(loss=loss, acts=acts)
+
+    def _backward_python(self, ctx, grads_only=False, scale=None):
+        eng, W, ph = self.engine, self.world, self._ph
+        loss, acts = ctx["loss"], ctx["acts"]
         if self._scale is None:
             self._scale = torch.full((1,), 1.0 / W, dtype=torch.float32, device=loss.device)
-        send2, wgrads = ph["cs_backward_local"](self._scale)       # [W, R, 2*dl]: my rows, the peers' columns
-        h_w = None
-        late = self.multi and self._hip_engine and eng.wgrads_deferred()
-        if self.multi:
-            recv2 = self._like("recv_b", send2)
-            self._all_to_all(recv2, send2)
-            self.xgmi_bytes["all_to_all_bwd"] = send2[0].numel() * 4 * (W - 1)
-            self.xgmi_bytes["all_reduce"] = wgrads.numel() * 4
-            if not late:
-                # the projection-weight gradients are needed by the optimizer step only: reduced under the adjoint hops
-                h_w = self._all_reduce_async(wgrads)
-        else:
-            recv2 = send2
-        if late:
-            # the weight gradients are FINISHED by the adjoint's first two hop launches (behind their tiles); they are reduced
-            # under the last hop, and the projection weights' optimizer spans follow in a launch of their own (cs_update)
-            ph["cs_backward_hops"](recv2, acts, None, lambda: self._all_reduce_async(wgrads))
-            h_w = eng.wgrads_handle
-        elif h_w is not None and self._hip_engine:
-            ph["cs_backward_hops"](recv2, acts, h_w)
-        else:
-            ph["cs_backward_hops"](recv2, acts)
-        if h_w is not None:
-            h_w.wait()
-        ph["cs_update"]()
+        if self._hip_engine:
+            eng.grads_only = bool(grads_only)
+        try:
+            send2, wgrads = ph["cs_backward_local"](self._scale if scale is None else scale)   # [W, R, 2*dl]: my rows, the peers' columns
+            h_w = None
+            late = self.multi and self._hip_engine and eng.wgrads_deferred()
+            if self.multi:
+                recv2 = self._like("recv_b", send2)
+                self._all_to_all(recv2, send2)
+                self.xgmi_bytes["all_to_all_bwd"] = send2[0].numel() * 4 * (W - 1)
+                self.xgmi_bytes["all_reduce"] = wgrads.numel() * 4
+                if not late:
+                    # the projection-weight gradients are needed by the optimizer step only: reduced under the adjoint hops
+                    h_w = self._all_reduce_async(wgrads)
+            else:
+                recv2 = send2
+            if late:
+                # the weight gradients are FINISHED by the adjoint's first two hop launches (behind their tiles); they are reduced
+                # under the last hop, and the projection weights' optimizer spans follow in a launch of their own (cs_update)
+                ph["cs_backward_hops"](recv2, acts, None, lambda: self._all_reduce_async(wgrads))
+                h_w = eng.wgrads_handle
+            elif h_w is not None and self._hip_engine:
+                ph["cs_backward_hops"](recv2, acts, h_w)
+            else:
+                ph["cs_backward_hops"](recv2, acts)
+            if h_w is not None:
+                h_w.wait()
+            if not grads_only:
+                ph["cs_update"]()
+        finally:
+            if self._hip_engine:
+                eng.grads_only = False
         return loss
 
     def global_loss(self, loss):
@@ -718,15 +778,25 @@ class ColumnShardEngine(object):
     @torch.no_grad()
     def sync_to_model(self):
         """The model's embedding parameters <- the master copy (before a checkpoint; all ranks must call it)."""
+        ctl = getattr(self.model, "_plugin", None)
+        if ctl is not None and ctl.engine is self:
+            ctl.master_newer = False          # (first: the write-back below touches the parameters it is about to refresh)
+        self._sync_to_model()
+        if ctl is not None and ctl.engine is self:
+            ctl.synced()
+
+    @torch.no_grad()
+    def _sync_to_model(self):
         m = self.model
         if self.lean:       # every rank's column slice into every rank's host parameters (checkpoint time only)
             U = m.num_users
             loc = self.master[self.cur].dense()
             parts = [loc] if self.world == 1 else _all_gather_parts(loc, self.world, self.group)
+            eu, ei = m.embedding_user.weight.data, m.embedding_item.weight.data
             for q, part in enumerate(parts):
                 host = part.cpu()
-                m.embedding_user.weight.data[:, q * self.dl:(q + 1) * self.dl] = host[:U]
-                m.embedding_item.weight.data[:, q * self.dl:(q + 1) * self.dl] = host[U:]
+                eu[:, q * self.dl:(q + 1) * self.dl] = host[:U]
+                ei[:, q * self.dl:(q + 1) * self.dl] = host[U:]
             return
         x0d = m._ws["X0d"]
         if self.world == 1:
@@ -1092,12 +1162,26 @@ class ColumnShardEngine(object):
     def _next_loss_slot(self):
         """The next slot of the loss ring (a caller holding the tensors of earlier steps -- main.py stacks an epoch's losses
         before it copies them to the host -- does not see them change for LOSS_RING steps)."""
+        given = getattr(self, "_loss_given", None)
+        if given is not None:                 # handed out earlier (trainer.step(..., loss=...)): this step fills it
+            self._loss_given = None
+            return given
+        return self.new_loss_slot()
+
+    def new_loss_slot(self):
         if self._loss_ring is None:
             self._loss_ring = torch.zeros(LOSS_RING, dtype=torch.float32, device=self.model._device())
             self._loss_ticket = torch.zeros(1, dtype=torch.int32, device=self.model._device())
         loss = self._loss_ring[self._loss_at]
         self._loss_at = (self._loss_at + 1) % LOSS_RING
         return loss
+
+    def _peek_loss_slot(self):
+        """Address of the tensor the next _next_loss_slot() returns."""
+        given = getattr(self, "_loss_given", None)
+        if given is not None:
+            return given.data_ptr()
+        return self._loss_ring.data_ptr() + 4 * self._loss_at
 
     def _head_forward_fused(self, ws, R, B):
         """Feature blocks, fused Linear, single-modal heads at the active rows in one launch, then the cosine-BPR rows."""
@@ -1229,7 +1313,7 @@ class ColumnShardEngine(object):
         W, R = acts.shape
         inv = 1.0 / (L + 1)
 
-        fuse = self._fuse_adam()
+        fuse = self._fuse_adam() and not getattr(self, "grads_only", False)
         last = 1 if fuse else 0                                    # the hops the recorded region covers: L-1 .. last
 
         single = not self.multi
@@ -1337,6 +1421,14 @@ class ColumnShardEngine(object):
             _lib.check(_lib.load().elimrec_adam_multi(self._tail_arr, len(jobs), g["lr"], g["betas"][0], g["betas"][1], g["eps"],
                                                       g["weight_decay"], ops._stream()), "adam_multi")
         self.cur = nxt
+        self._updated()
+
+    def _updated(self):
+        """The master copy now holds newer embeddings than the model's parameters: whoever reads those next writes it back
+        first (plugin.py: EmbeddingParameter, state_dict)."""
+        ctl = getattr(self.model, "_plugin", None)
+        if ctl is not None and ctl.engine is self:
+            ctl.master_newer = True
 
     def native_prologue(self):
         """What the ordinary step's Python does besides launching, ahead of the launches of a native step: the projection
@@ -1370,6 +1462,7 @@ class ColumnShardEngine(object):
         m._publish_cache(m._ws["Y"], dirty=True)
         self.step_count += 1
         self.cur = 1 - self.cur
+        self._updated()
 
     def _tail_jobs(self):
         """Spans of the flat parameter buffer behind the embeddings: runs of adjacent projection weights that have a

@@ -9,9 +9,10 @@ Behaviour kept from the reference's `Net.run`: one pass of the pairwise sampler 
 the sampler and the evaluator run on the GPU (elimrec_amd). `--data.input.dataset=synthetic` uses the seeded
 Tiktok-shape generator instead of reading files.
 
-`--loss=<method>` names the model method that computes the loss, as in the reference (main.py:98): `bpr_loss` (EliMRec's
-own loss) runs the fused training step; any other method of the model (`infonce`, `fast_loss`, the base class's
-generic losses) runs loss -> backward -> optimizer step through the differentiable table build.
+`--loss=<method>` names the model method that computes the loss, as in the reference (main.py:98), and the epoch loop is the
+reference's: loss method -> zero_grad -> backward(retain_graph=True) -> optimizer step. With `bpr_loss` (EliMRec's own loss)
+those four lines run the column-shard engine's fused step (elimrec_amd/plugin.py); any other method of the model (`infonce`,
+`fast_loss`, the base class's generic losses) goes through the differentiable table build.
 `--resume=<checkpoint>` (not in the reference, which only saves): restores the parameters from a reference-format
 checkpoint and, when the side file `<checkpoint>.resume` written next to it exists, the Adam moments, step counts,
 epoch counter and best metrics.
@@ -90,16 +91,17 @@ class Net(object):
         self.loss_name = str(cfg.loss)
         if not callable(getattr(self.recommender, self.loss_name, None)):
             raise AttributeError("'%s' has no loss method '%s' (--loss)" % (cfg.recommender, self.loss_name))
-        self.engine = None
+        self.engine = self.trainer = None
         rec = self.recommender
         if self.loss_name != "bpr_loss":
             if self.world > 1:
                 raise ValueError("--loss=%s runs through the generic autograd path, which is single-GPU" % self.loss_name)
-            self.trainer = None
         elif getattr(rec, "_lazy", False) and rec.latent_dim % (4 * self.world) == 0:
+            # the column-shard engine with this job's world / rank. It attaches itself to the model (elimrec_amd/plugin.py): the
+            # epoch loop below is the reference's own four lines (main.py:98-101) and runs on it
             self.engine = ColumnShardEngine(rec)
             self.trainer = ColumnShardTrainer(self.engine, self.opt, world_size=self.world, rank=self.rank)
-        else:       # adjacencies with a diagonal (norm / mean+I), layer_num < 2: replicated tables, data parallel
+        else:       # adjacencies with a diagonal (norm / mean+I) without --propagation=folded, layer_num < 2: replicated tables
             self.trainer = DataParallelTrainer(rec, self.opt, world_size=self.world, rank=self.rank)
         self.start_epoch, self.resume_state = 0, None
         if "resume" in cfg and cfg["resume"]:
@@ -154,13 +156,15 @@ class Net(object):
         self.recommender.train()
         tracker = Meter(name="MultiLoss(bpr)")
         tracker.reset()
-        step = self.generic_step if self.trainer is None else self.trainer.step
+        # the reference's loop body; only the replicated-table fallback (no engine) has a step call of its own
+        step = self.generic_step if (self.trainer is None or self.engine is not None) else self.trainer.step
         # the column-shard engine returns views into a ring of loss slots: an epoch longer than the ring keeps copies
         ring = getattr(self.engine, "loss_ring_len", 0) if self.engine is not None else 0
         keep = (lambda t: t.clone()) if ring and len(batches) >= ring else (lambda t: t)
-        if self.trainer is not None and getattr(self.trainer, "lookup", False) and getattr(self.trainer, "multi", False):
+        shard_trainer = self.trainer if self.engine is not None else None
+        if shard_trainer is not None and getattr(shard_trainer, "lookup", False) and getattr(shard_trainer, "multi", False):
             batches = list(batches)                   # row-sharded constants: this epoch's lookup split sizes, planned ahead
-            self.trainer.plan_lookup(batches)
+            shard_trainer.plan_lookup(batches)
         on_device = torch.stack([keep(step(users, pos, neg)) for users, pos, neg in batches])
         if self.world > 1:
             import torch.distributed as dist

@@ -1,0 +1,233 @@
+"""The reference's own loop body (main.py:98-101: bpr_loss -> zero_grad -> backward(retain_graph=True) -> opt.step) on the
+column-shard engine (elimrec_amd/plugin.py): bitwise the engine's own step, whatever the caller reads in between. `-m gpu`."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import assert_grad_close, build_model_from_fixture, load_golden, sub
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def _batches(g, n):
+    """n batches of the fixture: its equal-sized ones in turn, its short last one once in the middle (an epoch's tail)."""
+    steps = int(g["steps"])
+    order = [1 + k % (steps - 1) for k in range(n)]
+    if n >= steps:
+        order[n // 2] = steps
+    return [tuple(_t(g["step%d/%s" % (t, key)]) for key in ("users", "pos", "neg")) for t in order]
+
+
+def _opt(model, g, cls=None):
+    from elimrec_amd import FusedAdam
+    return (cls or FusedAdam)(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+
+
+def _state(model, eng):
+    out = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    st = eng.optimizer_state()
+    out["@m1"], out["@m2"] = st["exp_avg"], st["exp_avg_sq"]
+    return out
+
+
+def _trainer_run(g, n, extra=()):
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer
+    model, _ = build_model_from_fixture(g, DEV, extra_argv=extra)
+    eng = ColumnShardEngine(model)
+    tr = ColumnShardTrainer(eng, _opt(model, g))
+    losses = [tr.step(*b) for b in _batches(g, n)]
+    losses = [float(x) for x in torch.stack(losses).cpu()]
+    return losses, _state(model, eng), tr
+
+
+def _same(a, b):
+    assert set(a) == set(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("name", ["ml3", "kwai", "gcmc", "normal"])
+def test_plugin_loop_equals_trainer_step_bitwise(name):
+    """main.py:98-101 as written, 12 steps (the native one-call program takes over at the sixth): every loss, every parameter,
+    both Adam moments bit for bit those of ColumnShardTrainer.step -- and every step went down the one-enqueue path."""
+    g = load_golden(name)
+    n = 17
+    want_losses, want, tr = _trainer_run(g, n)
+    assert tr._native_state()["native_steps"] > 0, tr._native_state()["failed"]
+    model, _ = build_model_from_fixture(g, DEV)
+    opt = _opt(model, g)
+    losses = []
+    for u, p, neg in _batches(g, n):
+        loss = model.bpr_loss(u, p, neg)
+        opt.zero_grad()
+        loss.backward(retain_graph=True)
+        opt.step()
+        losses.append(loss)
+    ctl = model.plugin
+    assert ctl.fast_steps == n and ctl.slow_steps == 0
+    assert ctl.trainer._native_state()["native_steps"] > 0, ctl.trainer._native_state()["failed"]
+    assert [loss.cpu().item() for loss in losses] == want_losses
+    _same(_state(model, ctl.engine), want)
+
+
+def test_plugin_loop_with_per_step_loss_item_and_reads_in_between():
+    """The reference's line 102 (`loss.cpu().item()` every step) and every other look at an intermediate result -- the loss
+    before backward, .grad after it, the cached tables, predict() -- leave the bits alone: the halves run launch by launch."""
+    g = load_golden("ml3")
+    n = 9
+    want_losses, want, _ = _trainer_run(g, n)
+    model, _ = build_model_from_fixture(g, DEV)
+    opt = _opt(model, g)
+    got = []
+    ref = sub(g, "grad1")
+    for k, (u, p, neg) in enumerate(_batches(g, n)):
+        loss = model.bpr_loss(u, p, neg)
+        if k % 3 == 1:
+            assert loss.item() == want_losses[k]          # read BEFORE backward: forward half runs
+        opt.zero_grad()
+        loss.backward(retain_graph=True)
+        if k == 0:
+            mine = {name: prm.grad for name, prm in model.named_parameters() if prm.grad is not None}
+            assert set(mine) == set(ref)
+            for name, gr in ref.items():
+                assert_grad_close(mine[name].cpu(), gr, name)
+        if k == 4:
+            assert model.all_users.shape == (model.num_users, model.latent_dim)
+            model.predict(g["eval_users"].tolist()[:4])
+        opt.step()
+        got.append(loss.cpu().item())                                 # main.py:102
+    assert got == want_losses
+    ctl = model.plugin
+    assert ctl.slow_steps >= 4 and ctl.fast_steps >= 4
+    _same(_state(model, ctl.engine), want)
+
+
+def test_plugin_loop_reference_fixture_and_stale_predict():
+    """The golden run through the loop body: losses, parameters after the steps, predict() on the stale tables."""
+    g = load_golden("ml3")
+    model, _ = build_model_from_fixture(g, DEV)
+    opt = _opt(model, g)
+    steps = int(g["steps"])
+    for t in range(1, steps + 1):
+        loss = model.bpr_loss(*(_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg")))
+        opt.zero_grad()
+        loss.backward(retain_graph=True)
+        opt.step()
+        assert abs(loss.cpu().item() - float(g["step%d/loss" % t])) < 1e-5
+    sd = model.state_dict()
+    for k, v in sub(g, "after%d" % steps).items():
+        assert np.abs(sd[k].cpu().numpy() - v).max() < 2e-5, k
+    model.fusion_mode, model.predict_type = "rubi", "TIE"
+    got = model.predict(g["eval_users"].tolist()).numpy()
+    assert np.abs(got - g["predict/rubi/TIE"]).max() < 1e-5
+
+
+def test_plugin_loop_with_torch_adam():
+    """optim.Adam(model.parameters()) as the reference constructs it (main.py:49): gradients are materialised for it, the
+    embedding tables it updates are re-loaded into the engine -- the golden parameters after three steps."""
+    g = load_golden("ml3")
+    model, _ = build_model_from_fixture(g, DEV)
+    opt = _opt(model, g, torch.optim.Adam)
+    steps = int(g["steps"])
+    for t in range(1, steps + 1):
+        loss = model.bpr_loss(*(_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg")))
+        opt.zero_grad()
+        loss.backward(retain_graph=True)
+        opt.step()
+        assert abs(loss.cpu().item() - float(g["step%d/loss" % t])) < 1e-5, t
+    sd = model.state_dict()
+    for k, v in sub(g, "after%d" % steps).items():
+        assert np.abs(sd[k].cpu().numpy() - v).max() < 2e-5, k
+
+
+def test_plugin_backward_with_gradient_and_edited_grads():
+    """backward(gradient=2) goes through autograd and doubles every gradient; gradients edited before the step are the ones
+    the update uses (here: zeroed -> only weight decay moves the parameters, as with torch)."""
+    g = load_golden("ml3")
+    model, _ = build_model_from_fixture(g, DEV)
+    opt = _opt(model, g)
+    u, p, neg = _batches(g, 1)[0]
+    loss = model.bpr_loss(u, p, neg)
+    opt.zero_grad()
+    loss.backward(gradient=torch.tensor(2.0, device=DEV))
+    ref = sub(g, "grad1")
+    for name, prm in model.named_parameters():
+        if name in ref:
+            assert_grad_close(prm.grad.cpu(), 2.0 * ref[name], name)
+    opt.zero_grad()
+    model2, _ = build_model_from_fixture(g, DEV)
+    opt2 = _opt(model2, g)
+    loss = model2.bpr_loss(u, p, neg)
+    loss.backward()
+    for prm in model2.parameters():
+        if prm.grad is not None:
+            prm.grad.zero_()
+    before = {k: v.cpu().clone() for k, v in model2.state_dict().items()}
+    opt2.step()
+    after = model2.state_dict()
+    for k in ref:
+        twin = before[k].clone().requires_grad_(True)
+        twin.grad = torch.zeros_like(twin)
+        torch.optim.Adam([twin], lr=float(g["lr"]), weight_decay=float(g["weight_decay"])).step()
+        assert (after[k].cpu() - twin.detach()).abs().max().item() < 2e-7, k
+
+
+def test_plugin_stale_backward_raises_and_second_loss_settles_the_first():
+    g = load_golden("ml3")
+    model, _ = build_model_from_fixture(g, DEV)
+    opt = _opt(model, g)
+    b = _batches(g, 2)
+    first = model.bpr_loss(*b[0])
+    second = model.bpr_loss(*b[1])                  # the first loss becomes real here (its tensor is still held)
+    assert abs(first.item() - float(g["step1/loss"])) < 1e-5
+    with pytest.raises(RuntimeError, match="stale"):
+        first.backward()
+    second.backward()
+    opt.step()
+    assert np.isfinite(second.item())
+
+
+@pytest.mark.parametrize("extra", [["--lean_tables=1"], ["--feature_dtype=bf16"]])
+def test_plugin_loop_under_lean_tables_and_16bit_features(extra):
+    g = load_golden("ml3")
+    want_losses, want, _ = _trainer_run(g, 4, extra=extra)
+    model, _ = build_model_from_fixture(g, DEV, extra_argv=extra)
+    opt = _opt(model, g)
+    got = []
+    for u, p, neg in _batches(g, 4):
+        loss = model.bpr_loss(u, p, neg)
+        opt.zero_grad()
+        loss.backward(retain_graph=True)
+        opt.step()
+        got.append(loss)
+    assert [x.item() for x in got] == want_losses
+    _same(_state(model, model.plugin.engine), want)
+
+
+def test_plugin_loop_on_an_adjacency_with_a_diagonal():
+    """--propagation=folded on adj_type=norm (the wide form): no raise, the golden losses."""
+    g = load_golden("ablate")
+    extra = ["--propagation=folded"]
+    model, _ = build_model_from_fixture(g, DEV, extra_argv=extra)
+    opt = _opt(model, g)
+    got = []
+    batches = [tuple(_t(g["step%d/%s" % (t, key)]) for key in ("users", "pos", "neg")) for t in (1, 2, 3)]
+    for u, p, neg in batches:
+        loss = model.bpr_loss(u, p, neg)
+        opt.zero_grad()
+        loss.backward(retain_graph=True)
+        opt.step()
+        got.append(loss.cpu().item())
+    for t in range(3):
+        assert abs(got[t] - float(g["step%d/loss" % (t + 1)])) < 1e-5
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer
+    twin, _ = build_model_from_fixture(g, DEV, extra_argv=extra)
+    eng = ColumnShardEngine(twin)
+    tr = ColumnShardTrainer(eng, _opt(twin, g))
+    assert [tr.step(*b).item() for b in batches] == got
+    _same(_state(model, model.plugin.engine), _state(twin, eng))

@@ -1381,8 +1381,6 @@ def test_wide_form_trains_the_norm_adjacency_fixture_on_the_column_shard_engine(
     g = load_golden("ablate")
     model, _ = build_model_from_fixture(g, DEV, extra_argv=["--propagation=folded"])
     assert model._wide and model._lazy and not model._bipartite
-    with pytest.raises(RuntimeError):
-        model.bpr_loss(*(_t(g["step1/%s" % k]) for k in ("users", "pos", "neg")))
     opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
     eng = ColumnShardEngine(model)
     tr = ColumnShardTrainer(eng, opt)
