@@ -119,14 +119,7 @@ SIGNATURES = {
     "elimrec_set_concurrency": (None, [c_i32]),
     "elimrec_folded_workspace": (c_size, [c_i64, c_i32]),
     "elimrec_propagate_folded": (c_i32, [c_csr, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_size, c_ptr]),
-    "elimrec_source_rows": (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr]),
     "elimrec_source_rows_split": (c_i32, [c_ptr, c_ptr, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr]),
-    "elimrec_merge_rank_rows": (c_i32, [c_ptr, c_ptr, c_i32, c_i64, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr]),
-    "elimrec_layer_tables_workspace": (c_size, [c_i64, c_i32, c_i32]),
-    "elimrec_propagate_layers": (c_i32, [c_csr, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_size, c_i32, c_i32, c_ptr, c_ptr, c_i64,
-                                         c_ptr]),
-    "elimrec_folded_rows": (c_i32, [c_ptr, c_size, c_i64, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr]),
-    "elimrec_folded_combine": (c_i32, [c_ptr, c_size, c_i64, c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
     "elimrec_propagate_folded_bwd": (c_i32, [c_csr, c_i64, c_i64, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_i64, c_ptr,
                                              c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "elimrec_block_spmm": (c_i32, [c_csr, c_i32, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr]),
@@ -135,7 +128,6 @@ SIGNATURES = {
     "elimrec_triplet_rows_checked": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr]),
     "elimrec_batch_plan": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr,
                                    c_size, c_ptr]),
-    "elimrec_pad_rows": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr]),
     "elimrec_gather_rows": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_ptr]),
     "elimrec_copy_cols": (c_i32, [c_ptr, c_i64, c_ptr, c_i64, c_i64, c_i32, c_ptr]),
     "elimrec_bpr_head": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i32,

@@ -968,29 +968,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float *__restric
         *reinterpret_cast<float4 *>(dst + r * ldd + 4 * c) = *reinterpret_cast<const float4 *>(src + node * lds + 4 * c);
 }
 
-// rows [count, n) of a compact row buffer are not part of the batch: zero them and give each a harmless key of its
-// own (pad_key + r: a shared key would make one huge segment of zero rows for the merge to walk through)
-__global__ __launch_bounds__(256) void pad_rows_kernel(float *__restrict__ rows, int64_t ld, int32_t *__restrict__ keys,
-                                                       const int32_t *__restrict__ count, int64_t n, int c4,
-                                                       int32_t pad_key) {
-    const int64_t r = (int64_t)*count + (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const int sub = threadIdx.x & 15;
-    if (r >= n) return;
-    if (sub == 0) keys[r] = pad_key + (int32_t)r;
-    for (int c = sub; c < c4; c += 16) *reinterpret_cast<float4 *>(rows + r * ld + 4 * c) = make_float4(0.f, 0.f, 0.f, 0.f);
-}
 }  // namespace elimrec
-
-extern "C" int elimrec_pad_rows(float *d_rows, int64_t ld, int32_t *d_keys, const int32_t *d_count, int64_t n, int cols,
-                                int32_t pad_key, void *stream) {
-    ELIMREC_REQUIRE(d_rows && d_keys && d_count, "pad_rows: null pointer");
-    ELIMREC_REQUIRE(cols > 0 && cols % 4 == 0 && ld % 4 == 0 && ld >= cols, "pad_rows: cols, ld must be multiples of 4");
-    if (n <= 0) return 0;
-    hipLaunchKernelGGL(elimrec::pad_rows_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, d_rows, ld,
-                       d_keys, d_count, n, cols / 4, pad_key);
-    ELIMREC_LAUNCH_CHECK("pad_rows");
-    return 0;
-}
 
 extern "C" int elimrec_triplet_rows_checked(const int64_t *d_users, const int64_t *d_pos, const int64_t *d_neg, int64_t B,
                                             int64_t U, int64_t I, int32_t *d_rows, int32_t *d_err, void *stream) {

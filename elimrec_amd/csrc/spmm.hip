@@ -1087,151 +1087,6 @@ extern "C" int elimrec_propagate_folded(const elimrec_csr *A, int64_t U, int64_t
     return 0;
 }
 
-// ---- the same forward with the layer tables KEPT instead of accumulated (training steps that evaluate the
-// head at the batch's rows only): hop k writes X^k = A X^{k-1}; the layer means are formed where they are read
-// -- at the active rows (folded_rows) or, for the cached full tables, over all rows (folded_combine). Only what
-// involves the layer-0 table is summed in the hop epilogues (S01 = X^0 + X^1 on hop 1, N02 = X^0_u + X^2_u on
-// hop 2), because X^0 is the live embedding parameter and the cached tables must not see a later update of it.
-// Per step this drops most of the accumulator traffic of the fused epilogue (read + write of Out_0 and half of
-// Narrow on every hop). Requires L >= 2.
-namespace elimrec {
-constexpr int kMaxLayers = 8;
-struct LayerTables {
-    const float4 *s01;                 // [N x d]  X^0 + X^1
-    const float4 *n02;                 // [U x d]  X^0_u + X^2_u
-    const float4 *x[kMaxLayers + 1];   // x[k] = X^k, 1 <= k <= L
-};
-
-// means over the layers at one row, in the summation order of the fused epilogue:
-//   out0 = inv * (((X^0 + X^1) + X^2) + ... + X^L);  narrow = inv * sum over even k (user rows) / odd k (item rows)
-__device__ __forceinline__ void layer_means(const LayerTables &t, int L, int64_t r, bool user, int d4, int c, float inv,
-                                            float4 &out0, float4 &nar) {
-    float4 s = t.s01[r * d4 + c];
-    float4 n = user ? t.n02[r * d4 + c] : t.x[1][r * d4 + c];
-    for (int k = 2; k <= L; ++k) {
-        const float4 v = t.x[k][r * d4 + c];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        if (k > 2 && ((k & 1) == 0) == user) { n.x = v.x + n.x; n.y = v.y + n.y; n.z = v.z + n.z; n.w = v.w + n.w; }
-    }
-    out0 = make_float4(s.x * inv, s.y * inv, s.z * inv, s.w * inv);
-    nar = make_float4(n.x * inv, n.y * inv, n.z * inv, n.w * inv);
-}
-
-__global__ __launch_bounds__(256) void folded_rows_kernel(LayerTables t, int L, int64_t U, int d4,
-                                                          const int32_t *__restrict__ rows,
-                                                          const int32_t *__restrict__ count, int64_t n, float inv,
-                                                          float *__restrict__ out_rows, int64_t ldo,
-                                                          float *__restrict__ narrow) {
-    const int64_t s = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const int sub = threadIdx.x & 15;
-    const int64_t lim = count ? min((int64_t)*count, n) : n;
-    if (s >= lim) return;
-    const int64_t r = rows[s];
-    for (int c = sub; c < d4; c += 16) {
-        float4 o, nr;
-        layer_means(t, L, r, r < U, d4, c, inv, o, nr);
-        *reinterpret_cast<float4 *>(out_rows + s * ldo + 4 * c) = o;
-        *reinterpret_cast<float4 *>(narrow + r * (int64_t)d4 * 4 + 4 * c) = nr;
-    }
-}
-
-__global__ __launch_bounds__(256) void folded_combine_kernel(LayerTables t, int L, int64_t U, int64_t N, int d4, float inv,
-                                                             float *__restrict__ out0, int64_t ldo,
-                                                             float *__restrict__ narrow) {
-    const int64_t total = N * d4;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = e / d4;
-        const int c = (int)(e - r * d4);
-        float4 o, nr;
-        layer_means(t, L, r, r < U, d4, c, inv, o, nr);
-        *reinterpret_cast<float4 *>(out0 + r * ldo + 4 * c) = o;
-        *reinterpret_cast<float4 *>(narrow + e * 4) = nr;
-    }
-}
-}  // namespace elimrec
-
-extern "C" size_t elimrec_layer_tables_workspace(int64_t N, int d, int L) {
-    return (size_t)(L + 2) * align_up((size_t)N * d * sizeof(float), 256);
-}
-
-static int layer_tables(int64_t N, int d, int L, const void *d_workspace, size_t workspace_bytes, LayerTables &t,
-                        const char *who) {
-    if (!(d_workspace && d > 0 && d % 4 == 0 && L >= 2 && L <= kMaxLayers)) {
-        set_error("%s: bad arguments (2 <= L <= %d, d %% 4 == 0)", who, kMaxLayers);
-        return ELIMREC_E_BADARG;
-    }
-    if (workspace_bytes < elimrec_layer_tables_workspace(N, d, L)) {
-        set_error("%s: workspace too small", who);
-        return ELIMREC_E_WORKSPACE;
-    }
-    const size_t tb = align_up((size_t)N * d * sizeof(float), 256);
-    const char *ws = (const char *)d_workspace;
-    t.s01 = (const float4 *)ws;
-    t.n02 = (const float4 *)(ws + tb);
-    t.x[0] = nullptr;
-    for (int k = 1; k <= kMaxLayers; ++k) t.x[k] = k <= L ? (const float4 *)(ws + (size_t)(k + 1) * tb) : nullptr;
-    return 0;
-}
-
-extern "C" int elimrec_propagate_layers(const elimrec_csr *A, int64_t U, int d, int L, const float *d_X0,
-                                        void *d_workspace, size_t workspace_bytes, int first_hop, int last_hop,
-                                        const int32_t *d_last_rows, const int32_t *d_last_count, int64_t n_last_cap,
-                                        void *stream) {
-    ELIMREC_REQUIRE(A && d_X0, "propagate_layers: null pointer");
-    ELIMREC_REQUIRE(U >= 0 && U <= A->n_rows, "propagate_layers: bad U");
-    ELIMREC_REQUIRE(first_hop >= 1 && last_hop <= L && first_hop <= last_hop, "propagate_layers: hops %d..%d of %d", first_hop,
-                    last_hop, L);
-    ELIMREC_REQUIRE(!d_last_rows || (d_last_count && n_last_cap >= 0 && L >= 3),
-                    "propagate_layers: a row list for the last hop needs its count and L >= 3");
-    LayerTables t;
-    int rc = layer_tables(A->n_rows, d, L, d_workspace, workspace_bytes, t, "propagate_layers");
-    if (rc) return rc;
-    for (int k = first_hop; k <= last_hop; ++k) {
-        const float *xin = k == 1 ? d_X0 : (const float *)t.x[k - 1];
-        // hop 1 also leaves S01 = X^1 + X^0; hop 2 leaves N02 = X^2_u + X^0_u on the user rows
-        HalfArgs a = half_args(d / 4, xin, nullptr, (float *)t.x[k], k == 1 ? d_X0 : nullptr, nullptr, nullptr, nullptr, 0,
-                               k == 1 ? (float *)t.s01 : nullptr, 1.0f);
-        if (k == 2) {
-            a.acc2_lo = 0; a.acc2_hi = U;
-            a.Acc2Out = (float4 *)t.n02;
-            a.Acc2In = (const float4 *)d_X0;
-            a.acc2_scale = 1.0f;
-        }
-        if (k == L && d_last_rows) {       // X^L is read at these rows only (elimrec_folded_rows)
-            if (n_last_cap == 0) continue;
-            a.row_list = d_last_rows; a.row_list_count = d_last_count; a.row_list_cap = n_last_cap;
-        }
-        if ((rc = launch_half(A, a, 0, (hipStream_t)stream))) return rc;
-    }
-    return 0;
-}
-
-extern "C" int elimrec_folded_rows(const void *d_layers, size_t layers_bytes, int64_t U, int64_t I, int d, int L,
-                                   const int32_t *d_rows, const int32_t *d_count, int64_t n, float *d_out_rows,
-                                   int64_t ldo, float *d_narrow, void *stream) {
-    ELIMREC_REQUIRE(d_rows && d_out_rows && d_narrow && ldo % 4 == 0 && ldo >= d, "folded_rows: bad arguments");
-    LayerTables t;
-    int rc = layer_tables(U + I, d, L, d_layers, layers_bytes, t, "folded_rows");
-    if (rc) return rc;
-    if (n <= 0) return 0;
-    hipLaunchKernelGGL(folded_rows_kernel, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, t, L, U, d / 4,
-                       d_rows, d_count, n, 1.0f / (float)(L + 1), d_out_rows, ldo, d_narrow);
-    ELIMREC_LAUNCH_CHECK("folded_rows");
-    return 0;
-}
-
-extern "C" int elimrec_folded_combine(const void *d_layers, size_t layers_bytes, int64_t U, int64_t I, int d, int L,
-                                      float *d_Out0, int64_t ldo, float *d_narrow, void *stream) {
-    ELIMREC_REQUIRE(d_Out0 && d_narrow && ldo % 4 == 0 && ldo >= d, "folded_combine: bad arguments");
-    LayerTables t;
-    int rc = layer_tables(U + I, d, L, d_layers, layers_bytes, t, "folded_combine");
-    if (rc) return rc;
-    hipLaunchKernelGGL(folded_combine_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, t, L, U, U + I, d / 4,
-                       1.0f / (float)(L + 1), d_Out0, ldo, d_narrow);
-    ELIMREC_LAUNCH_CHECK("folded_combine");
-    return 0;
-}
-
 namespace elimrec {
 // SrcA[node] = node < U ? H : G ; SrcB[node] = node < U ? G : H, for the active nodes, from the slot-major dOut rows
 // (G = column block 0, H = sum of the M blocks); also sets the row bitmap (pre-zeroed).
@@ -1263,105 +1118,8 @@ __global__ __launch_bounds__(256) void folded_sources_kernel(const float *__rest
 }  // namespace elimrec
 
 namespace elimrec {
-// Data-parallel merge: every rank contributed the dOut rows of its own active nodes (sorted by node id, padding keys
-// negative). A workgroup owns a range of node ids, finds the slice of every rank's list that falls into it (binary
-// searches, one thread per rank) and walks the ranks IN RANK ORDER with a barrier in between: a node seen before
-// (LDS bitmap) is accumulated, otherwise written -- a fixed order without a sort, float atomics or a second pass.
-// Output = what folded_sources_kernel writes for the summed rows: SrcA / SrcB rows + the row bitmap.
-constexpr int kMaxRanks = 64;
-
-__device__ __forceinline__ int merge_key(const int32_t *keys, int i) {      // padding (negative) sorts last
-    const int k = keys[i];
-    return k < 0 ? INT32_MAX : k;
-}
-
-__global__ __launch_bounds__(256) void merge_rank_rows_kernel(const float *__restrict__ rows, const int32_t *__restrict__ keys,
-                                                              int W, int R, int64_t U, int64_t N, int d, int M, int hg, int chunk,
-                                                              float *SrcA, float *SrcB, uint32_t *__restrict__ mask) {
-    __shared__ int s_beg[kMaxRanks], s_end[kMaxRanks];
-    extern __shared__ uint32_t seen[];                   // [chunk / 32]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t lo = (int64_t)blockIdx.x * chunk, hi = min(lo + chunk, N);
-    for (int w = tid; w < chunk / 32; w += 256) seen[w] = 0u;
-    if (tid < W) {                                       // lower_bound(lo), lower_bound(hi), interleaved
-        const int32_t *kr = keys + (int64_t)tid * R;
-        int a0 = 0, a1 = R, b0 = 0, b1 = R;
-        while (a0 < a1 || b0 < b1) {
-            if (a0 < a1) { const int m = (a0 + a1) >> 1; if (merge_key(kr, m) < lo) a0 = m + 1; else a1 = m; }
-            if (b0 < b1) { const int m = (b0 + b1) >> 1; if (merge_key(kr, m) < hi) b0 = m + 1; else b1 = m; }
-        }
-        s_beg[tid] = a0; s_end[tid] = b0;
-    }
-    __syncthreads();
-    const int d4 = d / 4, C = hg ? 2 * d : d * M;        // hg: the rows are [H | G] already (elimrec_source_rows)
-    for (int r = 0; r < W; ++r) {
-        for (int s = s_beg[r] + wave; s < s_end[r]; s += 4) {
-            const int64_t node = keys[(int64_t)r * R + s];
-            const int bit = (int)(node - lo);
-            const bool was = (seen[bit >> 5] >> (bit & 31)) & 1u;
-            const float4 *g = reinterpret_cast<const float4 *>(rows + ((int64_t)r * R + s) * C);
-            float *h_dst = (node < U ? SrcA : SrcB) + node * (int64_t)d;
-            float *g_dst = (node < U ? SrcB : SrcA) + node * (int64_t)d;
-            for (int c = lane; c < d4; c += 64) {
-                float4 g0, h;
-                if (hg) { h = g[c]; g0 = g[d4 + c]; }
-                else {
-                    g0 = g[c];
-                    h = g0;
-                    for (int m = 1; m < M; ++m) {
-                        const float4 x = g[m * d4 + c];
-                        h.x += x.x; h.y += x.y; h.z += x.z; h.w += x.w;
-                    }
-                }
-                float4 ho = h, go = g0;
-                if (was) {                               // written by an earlier rank of this workgroup: read through L2
-                    float *hp = h_dst + 4 * c, *gp = g_dst + 4 * c;
-                    float4 a, b;
-                    a.x = __hip_atomic_load(hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    a.y = __hip_atomic_load(hp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    a.z = __hip_atomic_load(hp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    a.w = __hip_atomic_load(hp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    b.x = __hip_atomic_load(gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    b.y = __hip_atomic_load(gp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    b.z = __hip_atomic_load(gp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    b.w = __hip_atomic_load(gp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ho = make_float4(a.x + h.x, a.y + h.y, a.z + h.z, a.w + h.w);
-                    go = make_float4(b.x + g0.x, b.y + g0.y, b.z + g0.z, b.w + g0.w);
-                }
-                *reinterpret_cast<float4 *>(h_dst + 4 * c) = ho;
-                *reinterpret_cast<float4 *>(g_dst + 4 * c) = go;
-            }
-            if (lane == 0 && !was) atomicOr(&seen[bit >> 5], 1u << (bit & 31));
-        }
-        __syncthreads();                                 // rank r's rows are in memory (and in the bitmap) before rank r+1
-    }
-    for (int w = tid; w < chunk / 32; w += 256)
-        if (lo + 32 * (int64_t)w < ((N + 31) / 32) * 32) mask[lo / 32 + w] = seen[w];
-}
-}  // namespace elimrec
-
-namespace elimrec {
-// [H | G] of every active row: H = sum of the M column blocks of its dOut row (block order), G = block 0 -- all the
-// adjoint propagation needs of a dOut row, at half the bytes (what a rank puts on the wire in a data-parallel step)
-__global__ __launch_bounds__(256) void source_rows_kernel(const float *__restrict__ dOutR, const int32_t *__restrict__ count,
-                                                          int64_t n_max, int d4, int M, float *__restrict__ out) {
-    const int64_t s = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-    const int sub = threadIdx.x & 15;
-    if (s >= n_max || s >= *count) return;
-    const float4 *g = reinterpret_cast<const float4 *>(dOutR) + s * (int64_t)d4 * M;
-    float4 *o = reinterpret_cast<float4 *>(out) + s * (int64_t)d4 * 2;
-    for (int c = sub; c < d4; c += 16) {
-        const float4 g0 = g[c];
-        float4 h = g0;
-        for (int m = 1; m < M; ++m) {
-            const float4 x = g[m * d4 + c];
-            h.x += x.x; h.y += x.y; h.z += x.z; h.w += x.w;
-        }
-        o[c] = h;
-        o[d4 + c] = g0;
-    }
-}
-// the same rows already cut into the `world` column slices a column-sharded job sends to its peers:
+// [H | G] of every active row -- H = sum of the M column blocks of its dOut row (block order), G = block 0: all the adjoint
+// propagation needs of a dOut row -- cut into the `world` column slices a column-sharded job sends to its peers:
 // out[w][s] = [H[s][w*dl : (w+1)*dl] | G[s][w*dl : (w+1)*dl]], dl = d / world  (layout [world x n_max x 2*dl])
 __global__ __launch_bounds__(256) void source_rows_split_kernel(const float *__restrict__ dOutR, const int32_t *__restrict__ count,
                                                                 int64_t n_max, int d4, int M, int dl4, float *__restrict__ out) {
@@ -1396,40 +1154,13 @@ extern "C" int elimrec_source_rows_split(const float *d_dOutR, const int32_t *d_
     return 0;
 }
 
-extern "C" int elimrec_source_rows(const float *d_dOutR, const int32_t *d_count, int64_t n_max, int d, int M, float *d_out,
-                                   void *stream) {
-    ELIMREC_REQUIRE(d_dOutR && d_count && d_out, "source_rows: null pointer");
-    ELIMREC_REQUIRE(d > 0 && d % 4 == 0 && M >= 1, "source_rows: bad d/M");
-    if (n_max <= 0) return 0;
-    hipLaunchKernelGGL(source_rows_kernel, dim3((unsigned)((n_max + 15) / 16)), dim3(256), 0, (hipStream_t)stream, d_dOutR,
-                       d_count, n_max, d / 4, M, d_out);
-    ELIMREC_LAUNCH_CHECK("source_rows");
-    return 0;
-}
-
-extern "C" int elimrec_merge_rank_rows(const float *d_rows, const int32_t *d_keys, int W, int64_t R, int64_t U, int64_t I,
-                                       int d, int M, float *d_SrcA, float *d_SrcB, uint32_t *d_mask, void *stream) {
-    ELIMREC_REQUIRE(d_rows && d_keys && d_SrcA && d_SrcB && d_mask, "merge_rank_rows: null pointer");
-    ELIMREC_REQUIRE(W >= 1 && W <= kMaxRanks && R >= 1 && R < INT32_MAX, "merge_rank_rows: 1..%d ranks", kMaxRanks);
-    ELIMREC_REQUIRE(d > 0 && d % 4 == 0 && M >= 0, "merge_rank_rows: bad d/M");
-    const int hg = M == 0;                               // M = 0: the rows are [H | G] (2d columns)
-    const int64_t N = U + I;
-    int chunk = (int)((N + 1023) / 1024);                // ~1024 workgroups
-    chunk = (chunk + 31) / 32 * 32;
-    const unsigned grid = (unsigned)((N + chunk - 1) / chunk);
-    hipLaunchKernelGGL(merge_rank_rows_kernel, dim3(grid), dim3(256), (size_t)(chunk / 32) * sizeof(uint32_t),
-                       (hipStream_t)stream, d_rows, d_keys, W, (int)R, U, N, d, M, hg, chunk, d_SrcA, d_SrcB, d_mask);
-    ELIMREC_LAUNCH_CHECK("merge_rank_rows");
-    return 0;
-}
-
 extern "C" int elimrec_propagate_folded_bwd(const elimrec_csr *AT, int64_t U, int64_t I, int d, int M, int L,
                                             const float *d_dOutR, const int32_t *d_active_rows,
                                             const int32_t *d_seg_info, int64_t n_max, float *d_SrcA, float *d_SrcB,
                                             float *d_grad /* [N x d] = [gE_u ; gE_i] */,
                                             const uint32_t *d_active_mask, void *d_workspace, size_t workspace_bytes,
                                             void *stream) {
-    // d_dOutR == NULL: the source tables and the row bitmap are already in place (elimrec_merge_rank_rows)
+    // d_dOutR == NULL: the source tables and the row bitmap are already in place
     ELIMREC_REQUIRE(AT && d_SrcA && d_SrcB && d_grad && d_workspace, "propagate_folded_bwd: null pointer");
     ELIMREC_REQUIRE(d_dOutR ? (d_active_rows && d_seg_info) : (d_active_mask != nullptr),
                     "propagate_folded_bwd: dOut rows need their row list; prefilled sources need their bitmap");

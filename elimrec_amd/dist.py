@@ -1,23 +1,17 @@
-"""Multi-GPU driver for the training step: one process per GPU, torch.distributed (backend
-"nccl" = RCCL over xGMI), data-parallel over TRIPLETS with replicated tables.
+"""Data-parallel driver for the UNFOLDED row-major forms of the step (--propagation=full | bipartite, --head_rows=all,
+layer_num < 2, an adjacency with a diagonal without --propagation=folded): one process per GPU, torch.distributed (backend
+"nccl" = RCCL over xGMI), data-parallel over TRIPLETS with replicated tables. The default form of the step runs on the
+column-shard engine instead (shard.py, plugin.py); this driver is what main.py falls back to for the shapes the engine does
+not take, and what bench.py's "reference-equivalent work" line times.
 
-Why replicas and not row shards at this shape: the whole propagated table is 115 MB at the Tiktok
-shape (N=112 741 rows x 1 KiB) against 288 GB of HBM per GPU, and every hop of a row-sharded
-propagation would move most of that table across xGMI (SURVEY.md §7 "xGMI volume") -- six times
-per step. What actually differs between ranks is tiny: the gradient of the loss with respect to the
-3B gathered head rows. So per step each rank
-  1. runs the forward and the head's backward on its own B triplets (tables are bit-identical on every rank): loss,
-     dOut rows of its active nodes, its share of the projection-weight gradients, all scaled by 1/world_size,
-  2. all-gathers the [3B x 2d] source rows ([sum of dOut's column blocks | block 0]) + int32 node ids (3.1 MB per
-     rank at B=2048) and all-reduces the span of the
-     flat gradient buffer that holds the projection-weight gradients (0.3 MB),
-  3. sums the gathered rows per node in rank order (elimrec_merge_rank_rows) and runs the SAME deterministic adjoint
-     propagation + Adam.
-(Engines without a sharded head backward -- the unfolded propagation paths -- all-gather node ids before the forward
-and head-gradient rows after it, and run the whole backward on the gathered rows.)
-Step 3 is bitwise identical on every rank (deterministic kernels, identical input order), so the
-replicas never drift and no parameter/gradient all-reduce exists. The result equals one
-single-GPU step with batch world_size*B (mean over the global batch).
+What differs between ranks is tiny: the gradient of the loss with respect to the 3B gathered head rows. Per step each rank
+  1. all-gathers the int32 node ids of its triplet slots and runs the forward on its own B triplets (tables are
+     bit-identical on every rank): loss and the [3B x Cy] head-gradient rows,
+  2. all-gathers those rows,
+  3. runs the whole backward on the gathered rows (scaled by 1/world_size) and the SAME deterministic Adam.
+Step 3 is bitwise identical on every rank (deterministic kernels, identical input order), so the replicas never drift and
+no parameter/gradient all-reduce exists. The result equals one single-GPU step with batch world_size*B (mean over the
+global batch).
 
 The `engine` (EliMRec, or a CPU stand-in injected by tests/test_dist_cpu.py) provides
 batch_keys / forward_local / backward_global / named_parameters.
@@ -42,24 +36,7 @@ class DataParallelTrainer(object):
         eng = self.engine
         if self.profile_kernels and getattr(eng, "_kernel_events", None) is None:
             eng._kernel_events = self._events
-        if self.collectives and getattr(eng, "dp_shards_head", False):
-            # forward and head backward on this rank's triplets only; the ranks exchange the dOut rows of their active
-            # nodes (+ ids) and sum the projection-weight gradients; the adjoint propagation is replicated
-            loss, _ = eng.forward_local(users, pos, neg, world_size=self.world)
-            if self._scale is None:
-                self._scale = torch.full((1,), 1.0 / self.world, dtype=torch.float32, device=loss.device)
-            rows, keys, wgrads = eng.backward_local(self._scale)
-            if self._gather is None or self._gather[0].shape[0] != self.world * rows.shape[0]:
-                self._gather = (torch.empty(self.world * rows.shape[0], rows.shape[1], dtype=rows.dtype, device=rows.device),
-                                torch.empty(self.world * keys.numel(), dtype=keys.dtype, device=keys.device))
-            all_rows, all_keys = self._gather
-            # in order (issued asynchronously, with the weight-gradient all-reduce under the merge and the adjoint propagation,
-            # the extra stream hand-offs measured + 35 us per step on one GPU)
-            dist.all_gather_into_tensor(all_rows, rows, group=self.group)
-            dist.all_gather_into_tensor(all_keys, keys, group=self.group)
-            dist.all_reduce(wgrads, op=dist.ReduceOp.SUM, group=self.group)
-            grads = eng.backward_rows_global(all_rows, all_keys)
-        elif self.collectives:
+        if self.collectives:
             keys = eng.batch_keys(users, pos, neg)
             if self._gather is None or self._gather[1].numel() != self.world * keys.numel():
                 self._gather = None

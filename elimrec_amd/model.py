@@ -9,15 +9,16 @@ Data layout in HBM (fp32, row-major; N = U + I nodes, users first):
   Y      [N x Cy], Cy=(1+S)d block 0 = fused embedding (all_users / all_items), block 1+h =
                             single-modal head h (pre_fusion_{user,item}_{v,a,t}). The BPR head
                             gathers one contiguous row per index; predict() reads only Y.
-What the reference does with 12+12 torch.sparse.mm calls, 8 addmm and autograd per batch is here (DESIGN.md §2):
-  generic path (any adjacency, --propagation=full):  assemble_x0 + 3 linear_fwd -> propagate -> 5 linear_fwd ->
-      bpr_head, and back: segment plan/apply -> head_bwd_input / linear_bwd_w -> propagate (A^T) -> embed_grad /
-      linear_bwd_w;
-  default path (bipartite adjacency): constant feature tables folded into GEMM operands (only the d-column id table
-      goes through the graph) and, with --head_rows=batch, everything after the graph evaluated at the batch's active
-      rows only: triplet_rows -> propagate_layers -> segment_plan -> folded_rows -> 2 small linear_fwd_batched ->
-      bpr_head_rows, and back: segment_apply_head_bwd -> linear_bwd_w_batched -> propagate_folded_bwd. The full
-      cached tables predict() reads are materialised on first use (_ensure_tables).
+What the reference does with 12+12 torch.sparse.mm calls, 8 addmm and autograd per batch is here (DESIGN.md section 2):
+  default (bipartite adjacency, or --propagation=folded on one with a diagonal; layer_num >= 2): the constant feature tables
+      folded into GEMM operands, only the d-column id table through the graph, everything after the graph at the batch's
+      active rows -- the column-shard engine (shard.py: slab-major tables, wave-tile hops, fused head, Adam as the last
+      adjoint hop's epilogue). bpr_loss -> backward -> optimizer.step completes a request the engine runs as ONE enqueue
+      (plugin.py). The full cached tables predict() reads are materialised on first use (_ensure_tables).
+  the unfolded forms (any adjacency: --propagation=full | bipartite, --head_rows=all, layer_num < 2), row-major, every row
+      every step: assemble_x0 + 3 linear_fwd -> propagate -> 5 linear_fwd -> bpr_head, and back: segment plan/apply ->
+      head_bwd_input / linear_bwd_w -> propagate (A^T) -> embed_grad / linear_bwd_w. Also what compute() and the generic
+      BasicModel losses differentiate through, and bench.py's "reference-equivalent work" line.
 Propagation is linear, so nothing of the forward pass is kept for backward except Out (or its active rows) and Y.
 """
 import os
@@ -281,8 +282,6 @@ class EliMRec(BasicModel):
         self._param_names = [n for n, _ in self.named_parameters()]
         # step regions: recorded C-ABI call lists (see _region)
         self._use_replay = os.environ.get("ELIMREC_REPLAY", "1") != "0"
-        # hop L only feeds the layer mean, which "batch" mode reads at the active rows (hop 2 also forms a sum with X^0)
-        self._last_hop_rows = self._lazy and self.n_layers >= 3
         self._regions = {}
         self._ws = None
         self._ws_key = None
@@ -508,10 +507,6 @@ class EliMRec(BasicModel):
                     ws["SrcA"] = torch.empty(N, d, **f32)          # adjoint source tables (active rows only)
                     ws["SrcB"] = torch.empty(N, d, **f32)
                     ws["fold_ws"] = torch.empty(ops.folded_workspace(N, d), dtype=torch.uint8, device=dev)
-                    if self._lazy:
-                        ws["act_mask"] = torch.zeros((N + 31) // 32 + 2, dtype=torch.int32, device=dev)
-                        ws["layers"] = torch.empty(ops.layer_tables_workspace(N, d, self.n_layers), dtype=torch.uint8,
-                                                   device=dev)
                     if self.__dict__.get("_skip_fold"):    # the column-sharded engine folds the constants itself, row-sharded
                         ws["fold"] = None
                     else:
@@ -546,15 +541,13 @@ class EliMRec(BasicModel):
         ws["seg_info"] = torch.zeros(8, dtype=torch.int32, device=dev)
         ws["plan_ws"] = torch.empty(max(ops.segment_plan_workspace(n3), 1), dtype=torch.uint8, device=dev)
         shapes = [(n3, d, C), (n3, d, C)] + [(n3, d, d)] * self.S
-        if self._lazy:
-            ws["dp_rows"] = torch.empty(3 * B, 2 * d, **f32)       # data-parallel: [H | G] of the local active rows
         if self._folded:    # the folded feature projections' weight gradients ride in the same launch
             ws["dOutR"] = torch.empty(n3, C, **f32)                # dLoss/dOut rows in slot order
             shapes += [(n3, d, getattr(self, m + "_feat").shape[1]) for m in self._mods]
         ws["bwd_w_rows"] = torch.empty(max(ops.linear_bwd_w_batched_workspace(shapes), 1), dtype=torch.uint8, device=dev)
         self._ws, self._ws_key = ws, key
         batch_keys_ = ("loss_rows", "grad_rows", "keys", "keys_scratch", "slot_seg", "OutAct", "YAct", "active_rows", "dY",
-                       "seg_info", "plan_ws", "dp_rows", "dOutR", "bwd_w_rows")
+                       "seg_info", "plan_ws", "dOutR", "bwd_w_rows")
         self.__dict__.setdefault("_ws_sets", {})[(key[0], key[1])] = (bwd_rows, self._ws_gen, {k: ws[k] for k in batch_keys_ if k in ws})
         return ws
 
@@ -676,18 +669,10 @@ class EliMRec(BasicModel):
 
     @torch.no_grad()
     def _ensure_tables(self):
+        """Batch-row mode: the full cached tables of the last training forward, built when somebody reads them."""
         if self._tables_dirty:
             self._tables_dirty = False
-            ws, d = self._ws, self.latent_dim
-            eng = self.__dict__.get("_slab_engine")
-            if eng is not None and self.__dict__.get("_slab_fwd"):   # the last forward ran on the column-sharded engine
-                eng.materialize_tables(ws)
-                return
-            if self._last_hop_rows:     # the training forward left X^L at the active rows only
-                ops.propagate_layers(self._csr("adj"), self.num_users, d, self.n_layers, ws["X0d"], ws["layers"],
-                                     first=self.n_layers)
-            ops.folded_combine(ws["layers"], self.num_users, self.num_items, d, self.n_layers, ws["Out"][:, :d], ws["Narrow"])
-            self._full_tables(ws, ws["snap_views"])
+            self.__dict__["_slab_engine"].materialize_tables(self._ws)
 
     @torch.no_grad()
     def _compute_tables(self, ws):
@@ -783,36 +768,10 @@ class EliMRec(BasicModel):
         ent[2], ent[3] = calls, out
         return out
 
-    @torch.no_grad()
-    def _forward_batch_rows(self, ws, all_keys, n, B, rank, grad_rows):
-        """The training forward in "batch" mode: layer tables through the graph, then everything after the graph at
-        the batch's active rows only (ws['OutAct'], ws['YAct']), then the loss rows and their gradient rows."""
-        U, I, d, L = self.num_users, self.num_items, self.latent_dim, self.n_layers
-        adj = self._csr("adj")
-        act, seg = ws["active_rows"][:n], ws["seg_info"]
-        self._slab_fwd = False
-        # the plan depends on the indices only: the last hop and the head are evaluated at the active rows it lists and
-        # the backward reduces the (gathered) gradient rows with it
-        self._region("plan", (self._ws_gen, all_keys.data_ptr(), n),
-                     lambda: ops.segment_plan(all_keys, U, U + I, act, seg, ws["slot_seg"][:n], ws["plan_ws"],
-                                              key_bitmap=ws["act_mask"]))
-        if self._last_hop_rows:
-            # X^L is read at the active rows only: hops 1..L-1 in full, hop L at those rows (and every split row)
-            self._timed(lambda: self._region("fwd_hops", (self._ws_gen,),
-                                             lambda: ops.propagate_layers(adj, U, d, L, ws["X0d"], ws["layers"], last=L - 1)),
-                        hops=L - 1)
-            self._region("fwd_last_hop", (self._ws_gen, n),
-                         lambda: ops.propagate_layers(adj, U, d, L, ws["X0d"], ws["layers"], first=L, last_rows=act,
-                                                      last_count=seg[0:1]))
-        else:
-            self._timed(lambda: self._region("fwd_hops", (self._ws_gen,),
-                                             lambda: ops.propagate_layers(adj, U, d, L, ws["X0d"], ws["layers"])))
-        self._fwd_head(ws, all_keys, n, B, rank, grad_rows)
-
-    def _fwd_head(self, ws, all_keys, n, B, rank, grad_rows, layer_means=True, snapshot=True):
-        """Everything after the graph at the batch's active rows: layer means (unless the caller has already put
-        them into ws['OutAct'][:, :d] / ws['Narrow'] -- the column-sharded engine, shard.py), feature blocks, fused
-        Linear and single-modal heads, loss rows and their gradient rows. One recorded region."""
+    def _fwd_head(self, ws, all_keys, n, B, rank, grad_rows):
+        """Everything after the graph at the batch's active rows, generic shapes (the column-shard engine's head when its
+        fused 16-row kernels do not cover the shape; the layer means are in ws['OutAct'][:, :d] / the compact shared part
+        already): feature blocks, fused Linear and single-modal heads, loss rows and their gradient rows. One recorded region."""
         U, I, d, L = self.num_users, self.num_items, self.latent_dim, self.n_layers
         act, seg = ws["active_rows"][:n], ws["seg_info"]
         bw = self._last_block_weights
@@ -820,10 +779,6 @@ class EliMRec(BasicModel):
         def head():
             OutAct, YAct = ws["OutAct"][:n], ws["YAct"][:n]
             W = ws["live_views"]
-            if snapshot:        # the projection weights this forward uses, for the lazily materialised cached tables
-                ops.copy_cols(ws["flat_param"][ws["tail_off"]:].view(1, -1), ws["snap"].view(1, -1))
-            if layer_means:
-                ops.folded_rows(ws["layers"], U, I, d, L, act, seg[0:1], OutAct[:, :d], ws["Narrow"])
             ops.linear_fwd_batched(self._fold_problems(ws, W, OutAct, act, seg[6:8]))
             wu, wi = self._fusion_weights(W)
             bu, bi = W["embedding_user_after_GCN.bias"], W["embedding_item_after_GCN.bias"]
@@ -836,8 +791,7 @@ class EliMRec(BasicModel):
             ops.linear_fwd_batched(problems)
             ops.bpr_head_rows(YAct, ws["slot_seg"][3 * B * rank:3 * B * (rank + 1)], d, bw, ws["loss_rows"], grad_rows)
 
-        self._region("fwd_head", (self._ws_gen, all_keys.data_ptr(), n, B, rank, tuple(bw), grad_rows is not None,
-                                  layer_means, snapshot), head)
+        self._region("fwd_head", (self._ws_gen, all_keys.data_ptr(), n, B, rank, tuple(bw), grad_rows is not None), head)
         self._publish_cache(ws["Y"], dirty=True)
 
     def _index_tensors(self, *ts):
@@ -892,23 +846,21 @@ class EliMRec(BasicModel):
         self._plan_n = n
         self._last_block_weights = self._block_weights()
         grad_rows = ws["grad_rows"] if need_grad else None
-        if self._lazy:
-            self._forward_batch_rows(ws, all_keys, n, B, rank, grad_rows)
-        else:
-            ops.segment_plan(all_keys, self.num_users, self.num_users + self.num_items, ws["active_rows"][:n], ws["seg_info"],
-                             ws["slot_seg"][:n], ws["plan_ws"])
-            self._compute_tables(ws)
-            ops.bpr_head(ws["Y"], self.num_users, self.num_items, users, pos, neg, self.latent_dim,
-                         self._last_block_weights, ws["loss_rows"], grad_rows, ws["keys_scratch"] if need_grad else None)
+        ops.segment_plan(all_keys, self.num_users, self.num_users + self.num_items, ws["active_rows"][:n], ws["seg_info"],
+                         ws["slot_seg"][:n], ws["plan_ws"])
+        self._compute_tables(ws)
+        ops.bpr_head(ws["Y"], self.num_users, self.num_items, users, pos, neg, self.latent_dim,
+                     self._last_block_weights, ws["loss_rows"], grad_rows, ws["keys_scratch"] if need_grad else None)
         loss = torch.empty((), dtype=torch.float32, device=self._device())
         ops.fixed_order_sum(ws["loss_rows"], loss)
         return loss
 
     @torch.no_grad()
-    def _backward_batch_rows(self, ws, gscale, grad_rows, n, head_only=False, pack_bwd=None, merge=None,
+    def _backward_batch_rows(self, ws, gscale, grad_rows, n, head_only=True, pack_bwd=None, merge=None,
                              defer_reduce=False, sources=None):
-        """Backward of _forward_batch_rows: gradient rows -> active rows (the forward's plan) -> head and projection
-        gradients from the compact Out / dY rows -> adjoint propagation at d columns. Two hipGraph regions."""
+        """The head's backward at the batch's active rows (the column-shard engine's cs_backward_local): gradient rows ->
+        active rows (the forward's plan) -> dOut rows, head and projection weight gradients from the compact Out / dY rows.
+        Two recorded regions; the adjoint propagation is the engine's."""
         U, I, d, M, C, S = self.num_users, self.num_items, self.latent_dim, self.M, self.C, self.S
         dY, seg, act = ws["dY"][:n], ws["seg_info"], ws["active_rows"][:n]
         dOutR, OutAct, gv, fold = ws["dOutR"][:n], ws["OutAct"][:n], ws["grad_views"], ws["fold"]
@@ -962,23 +914,7 @@ class EliMRec(BasicModel):
         mkey = (str(defer_reduce),) + (() if merge is None else (merge["rows"].data_ptr(), merge["keys"].data_ptr(),
                                                                  merge["mask"].data_ptr()))
         grads, self._bwd_w_reduce = self._region("bwd_head_w", key + mkey, head_weights)
-        grads = dict(grads)
-        if head_only:
-            return grads
-        self._backward_hops(ws, dOutR, act, seg, n, grads)
-        return grads
-
-    def _backward_hops(self, ws, dOutR, act, seg, n, grads):
-        """Adjoint propagation to [dE_u ; dE_i] from the dOut rows of the active nodes (slot order), or -- dOutR None --
-        from source tables and row bitmap already in place (the data-parallel merge)."""
-        U, I, d, M, gv = self.num_users, self.num_items, self.latent_dim, self.M, ws["grad_views"]
-        AT = self._csr("adj" if self._adj_symmetric else "adjT")
-        key = (self._ws_gen, n) + (() if dOutR is None else (dOutR.data_ptr(), act.data_ptr(), seg.data_ptr()))
-        self._timed(lambda: self._region("bwd_hops", key,
-                                         lambda: ops.propagate_folded_bwd(AT, U, I, d, M, self.n_layers, dOutR, act, seg,
-                                                                          ws["SrcA"], ws["SrcB"], ws["gX0d"], ws["fold_ws"],
-                                                                          active_mask=ws["act_mask"])))
-        grads["embedding_user.weight"], grads["embedding_item.weight"] = gv["embedding_user.weight"], gv["embedding_item.weight"]
+        return dict(grads)
 
     @torch.no_grad()
     def _backward_hip(self, gscale, grad_rows=None):
@@ -992,8 +928,6 @@ class EliMRec(BasicModel):
         n_rows = grad_rows.shape[0]
         if n_rows != self._plan_n:
             raise RuntimeError("backward got %d gradient rows, the forward planned %d" % (n_rows, self._plan_n))
-        if self._lazy:
-            return self._backward_batch_rows(ws, gscale, grad_rows, n_rows)
         dY, seg, act = ws["dY"][:n_rows], ws["seg_info"], ws["active_rows"][:n_rows]
         ops.segment_apply(grad_rows, seg, dY, ws["plan_ws"], scale=gscale)
         bw = self._last_block_weights
@@ -1074,7 +1008,10 @@ class EliMRec(BasicModel):
         """Forward on this rank's triplets; all_keys = batch_keys() of every rank, concatenated in rank order.
         Returns (loss, grad_rows [3B x Cy]): d(local mean loss)/dY rows of this rank's slots."""
         B = int(users.numel())
-        self._no_lean("the row-major data-parallel trainer")
+        if self._lazy:
+            raise RuntimeError("forward_local / backward_global (elimrec_amd.dist.DataParallelTrainer) drive the unfolded row-major "
+                               "forms only (--propagation=full|bipartite, --head_rows=all, layer_num < 2); this model trains on the "
+                               "column-shard engine: model.bpr_loss -> backward -> FusedAdam.step, or ColumnShardTrainer.step")
         self._bwd_rows_hint = 3 * B * world_size
         self._workspace(B, 3 * B * world_size)
         loss = self._forward_hip(users, pos, neg, need_grad=True, all_keys=all_keys, rank=rank)
@@ -1083,44 +1020,6 @@ class EliMRec(BasicModel):
     def backward_global(self, grad_rows, scale):
         """Backward from the gradient rows of every rank (rank order); `scale` is a device fp32[1]."""
         return self._backward_hip(scale, grad_rows=grad_rows)
-
-    # Data-parallel steps in "batch" mode shard the head's backward as well: every rank reduces its OWN gradient rows
-    # to dOut rows of its own active nodes and to its share of the projection-weight gradients (backward_local); the
-    # ranks all-gather the dOut rows + node ids and all-reduce the weight-gradient span; every rank then sums the
-    # gathered rows per node and runs the same adjoint propagation (backward_rows_global).
-    @property
-    def dp_shards_head(self):
-        return self._lazy
-
-    @torch.no_grad()
-    def backward_local(self, scale):
-        """-> ([H | G] source rows [3B x 2d] of this rank's active nodes in ascending node order, zero beyond their
-        count; int32 node ids [3B], negative in the unused slots; the span of the flat gradient buffer that holds every
-        projection-weight gradient)."""
-        ws, n = self._ws, self._plan_n
-        self._dp_grads = self._backward_batch_rows(ws, scale, ws["grad_rows"], n, head_only=True)
-        keys = ws["active_rows"][:n]
-        # all the adjoint propagation needs of a dOut row is [sum of its blocks | block 0]: half the bytes on the wire
-        rows = ws["dp_rows"][:n]
-        ops.source_rows(ws["dOutR"][:n], ws["seg_info"][0:1], self.latent_dim, self.M, rows)
-        ops.pad_rows(rows, keys, ws["seg_info"][0:1], pad_key=-(1 << 30))
-        return rows, keys, ws["flat_grad"][ws["tail_off"]:]
-
-    @torch.no_grad()
-    def backward_rows_global(self, all_rows, all_keys):
-        """all_rows [W*3B x 2d] / all_keys [W*3B]: backward_local's rows and ids of every rank in rank order (the
-        weight-gradient span already all-reduced in place, or being reduced: it is not read here)."""
-        ws, n, n_local = self._ws, int(all_keys.numel()), self._plan_n
-        world = n // n_local
-        if world * n_local != n or all_rows.shape != (n, 2 * self.latent_dim):
-            raise RuntimeError("gathered rows/keys do not match %d ranks x %d slots" % (world, n_local))
-        U, I, d, M = self.num_users, self.num_items, self.latent_dim, self.M
-        # rows of the same node (from different ranks) summed in rank order, straight into the adjoint's sources
-        self._region("bwd_merge", (self._ws_gen, all_rows.data_ptr(), all_keys.data_ptr(), n),
-                     lambda: ops.merge_rank_rows(all_rows, all_keys, world, U, I, d, 0, ws["SrcA"], ws["SrcB"], ws["act_mask"]))
-        grads = dict(self._dp_grads)
-        self._backward_hops(ws, None, None, None, n, grads)
-        return grads
 
     # ------------------------------------------------------------------ reference API
     def bpr_loss(self, users, pos_items, neg_items):

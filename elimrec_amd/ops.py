@@ -319,66 +319,17 @@ def propagate_folded(A, U, I, d, L, X0, out0, narrow, workspace):
                                                     _stream()), "propagate_folded")
 
 
-def layer_tables_workspace(N, d, L):
-    return int(_lib.load().elimrec_layer_tables_workspace(N, d, L))
-
-
-def propagate_layers(A, U, d, L, X0, layers, first=1, last=None, last_rows=None, last_count=None):
-    """X^k = A X^(k-1) for k = first..last (default 1..L), kept in `layers` (uint8 workspace) with the two partial
-    sums that involve X^0. last_rows / last_count (int32 list, device count; L >= 3): hop L only at those rows."""
-    assert X0.is_contiguous() and X0.shape[1] == d
-    last = L if last is None else last
-    _lib.check(_lib.load().elimrec_propagate_layers(A.desc(), U, d, L, _dev(X0, "X0"), _dev(layers, "layers", torch.uint8),
-                                                    layers.numel(), first, last, _dev(last_rows, "last_rows", torch.int32),
-                                                    _dev(last_count, "last_count", torch.int32),
-                                                    0 if last_rows is None else last_rows.numel(), _stream()),
-               "propagate_layers")
-
-
-def folded_rows(layers, U, I, d, L, rows, count, out_rows, narrow):
-    """Layer means at `rows`: out_rows[s, 0:d] (a window of a wider compact table) and narrow[rows[s]]."""
-    o, ldo = _rowmajor(out_rows, "out_rows")
-    assert narrow.is_contiguous() and narrow.shape == (U + I, d) and out_rows.shape == (rows.numel(), d)
-    _lib.check(_lib.load().elimrec_folded_rows(_dev(layers, "layers", torch.uint8), layers.numel(), U, I, d, L,
-                                               _dev(rows, "rows", torch.int32), _dev(count, "count", torch.int32),
-                                               rows.numel(), o, ldo, _dev(narrow, "narrow"), _stream()), "folded_rows")
-
-
-def folded_combine(layers, U, I, d, L, out0, narrow):
-    o, ldo = _rowmajor(out0, "out0")
-    assert narrow.is_contiguous() and narrow.shape == (U + I, d) and out0.shape == (U + I, d)
-    _lib.check(_lib.load().elimrec_folded_combine(_dev(layers, "layers", torch.uint8), layers.numel(), U, I, d, L, o, ldo,
-                                                  _dev(narrow, "narrow"), _stream()), "folded_combine")
-
-
-def source_rows(dOutR, count, d, M, out):
-    """out[s] = [sum of the M column blocks | block 0] of dOutR[s] for s < count (device int32 scalar)."""
-    assert dOutR.is_contiguous() and out.is_contiguous() and dOutR.shape[1] == d * M and out.shape == (dOutR.shape[0], 2 * d)
-    _lib.check(_lib.load().elimrec_source_rows(_dev(dOutR, "dOutR"), _dev(count, "count", torch.int32), dOutR.shape[0], d, M,
-                                               _dev(out, "out"), _stream()), "source_rows")
-
-
 def source_rows_split(dOutR, count, d, M, world, out):
-    """source_rows cut into the peers' column slices: out [world x n x 2*d/world]."""
+    """out[w][s] = [H | G] of dOutR[s] (H = sum of its M column blocks, G = block 0) in peer w's column slice, s < count:
+    out [world x n x 2*d/world]."""
     n = dOutR.shape[0]
     assert dOutR.is_contiguous() and out.is_contiguous() and dOutR.shape[1] == d * M and out.shape == (world, n, 2 * d // world)
     _lib.check(_lib.load().elimrec_source_rows_split(_dev(dOutR, "dOutR"), _dev(count, "count", torch.int32), n, d, M, world,
                                                      _dev(out, "out"), _stream()), "source_rows_split")
 
 
-def merge_rank_rows(all_rows, all_keys, world, U, I, d, M, srcA, srcB, mask):
-    """Sum the all-gathered rows per node in rank order into the adjoint's source tables + row bitmap. M >= 1: dOut
-    rows [.. x M*d]; M = 0: [H | G] rows [.. x 2d] from source_rows."""
-    R = all_keys.numel() // world
-    assert all_rows.is_contiguous() and all_rows.shape == (world * R, d * M if M else 2 * d) and all_keys.numel() == world * R
-    assert srcA.is_contiguous() and srcB.is_contiguous() and mask.numel() * 32 >= U + I
-    _lib.check(_lib.load().elimrec_merge_rank_rows(_dev(all_rows, "all_rows"), _dev(all_keys, "all_keys", torch.int32), world,
-                                                   R, U, I, d, M, _dev(srcA, "srcA"), _dev(srcB, "srcB"),
-                                                   _dev(mask, "mask", torch.int32), _stream()), "merge_rank_rows")
-
-
 def propagate_folded_bwd(AT, U, I, d, M, L, dOutR, active_rows, seg_info, srcA, srcB, grad, workspace, active_mask=None):
-    """dOutR None: srcA / srcB and active_mask were prefilled (merge_rank_rows)."""
+    """dOutR None: srcA / srcB and active_mask were prefilled by the caller."""
     for t in (srcA, srcB, grad):
         assert t.is_contiguous()
     assert grad.shape == (U + I, d) and (dOutR is None or (dOutR.is_contiguous() and dOutR.shape[1] == d * M))
@@ -451,14 +402,6 @@ def batch_plan(users, pos, neg, U, I, keys, active_rows, seg_info, slot_seg, wor
                                               _dev(err, "err", torch.int32), _dev(workspace, "workspace", torch.uint8),
                                               workspace.numel(), _stream()), "batch_plan")
     return keys
-
-
-def pad_rows(rows, keys, count, pad_key=0):
-    """rows[count:] = 0, keys[r] = pad_key + r for r >= count (count: device int32 scalar)."""
-    r, ld = _rowmajor(rows, "rows")
-    assert keys.numel() == rows.shape[0]
-    _lib.check(_lib.load().elimrec_pad_rows(r, ld, _dev(keys, "keys", torch.int32), _dev(count, "count", torch.int32),
-                                            rows.shape[0], rows.shape[1], int(pad_key), _stream()), "pad_rows")
 
 
 def gather_rows(src, rows, dst, count=None):

@@ -1154,7 +1154,7 @@ class ColumnShardEngine(object):
         m._slab_fwd = True
         if fused:
             return self._head_forward_fused(ws, R, B)
-        m._fwd_head(ws, self._keys, R, B, 0, ws["grad_rows"], layer_means=False, snapshot=False)
+        m._fwd_head(ws, self._keys, R, B, 0, ws["grad_rows"])
         loss = self._next_loss_slot()
         ops.fixed_order_sum(ws["loss_rows"], loss)
         return loss

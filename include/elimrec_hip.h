@@ -86,11 +86,6 @@ int elimrec_batch_plan(const int64_t *d_users, const int64_t *d_pos, const int64
                        int64_t I, int32_t *d_keys, int32_t *d_active_rows, int32_t *d_seg_info,
                        int32_t *d_slot_seg, uint32_t *d_key_bitmap, int32_t pad_key, int32_t *d_err,
                        void *d_workspace, size_t workspace_bytes, void *stream);
-/* Rows [*d_count, n) of a compact row buffer do not belong to the batch: d_rows[r, 0:cols] = 0, d_keys[r] = pad_key + r
- * (what a rank hands to the all-gather of a data-parallel step: fixed-size buffers whose tail adds nothing; distinct
- * keys so that the padding does not pile up in one segment; pad_key + n must stay below the key space). */
-int elimrec_pad_rows(float *d_rows, int64_t ld, int32_t *d_keys, const int32_t *d_count, int64_t n, int cols,
-                     int32_t pad_key, void *stream);
 /* dst[r, 0:cols] = src[rows[r], 0:cols] for r < min(*d_count, n)  (d_count nullable; cols % 4 == 0). */
 int elimrec_gather_rows(const float *d_src, int64_t lds, const int32_t *d_rows, const int32_t *d_count, int64_t n,
                         int cols, float *d_dst, int64_t ldd, void *stream);
@@ -251,48 +246,21 @@ size_t elimrec_folded_workspace(int64_t N, int d);
 int elimrec_propagate_folded(const elimrec_csr *A, int64_t U, int64_t I, int d, int L, const float *d_X0,
                              float *d_Out0, int64_t ldo, float *d_narrow, void *d_workspace,
                              size_t workspace_bytes, void *stream);
-/* The same forward for training steps that read Out only at the batch's rows: hop k just writes the layer table
- * X^k = A X^(k-1) into the workspace (plus S01 = X^0 + X^1 on hop 1 and N02 = X^0_u + X^2_u on hop 2, the only sums
- * that involve the live parameter table X^0), and the layer means of compute_graph (:238-248) are formed where they
- * are read: elimrec_folded_rows at the active rows (d_out_rows[s, 0:d] = Out0[rows[s]], d_narrow[rows[s]] = narrow
- * of that node, s < min(*d_count, n)), elimrec_folded_combine over all rows (what elimrec_propagate_folded would
- * have left in d_Out0 / d_narrow, bit for bit). 2 <= L <= 8. workspace: elimrec_layer_tables_workspace bytes. */
-size_t elimrec_layer_tables_workspace(int64_t N, int d, int L);
-int elimrec_propagate_layers(const elimrec_csr *A, int64_t U, int d, int L, const float *d_X0, void *d_workspace,
-                             size_t workspace_bytes, int first_hop, int last_hop /* hops first..last of 1..L */,
-                             const int32_t *d_last_rows /* nullable */, const int32_t *d_last_count, int64_t n_last_cap,
-                             void *stream);
-/* d_last_rows (needs L >= 3): hop L, whose table X^L nothing but elimrec_folded_rows reads, is evaluated at the first
- * min(*d_last_count, n_last_cap) rows of that list only (plus every split row); run hop L again without the list
- * before elimrec_folded_combine. */
-int elimrec_folded_rows(const void *d_layers, size_t layers_bytes, int64_t U, int64_t I, int d, int L,
-                        const int32_t *d_rows, const int32_t *d_count, int64_t n, float *d_out_rows, int64_t ldo,
-                        float *d_narrow, void *stream);
-int elimrec_folded_combine(const void *d_layers, size_t layers_bytes, int64_t U, int64_t I, int d, int L, float *d_Out0,
-                           int64_t ldo, float *d_narrow, void *stream);
 int elimrec_propagate_folded_bwd(const elimrec_csr *AT, int64_t U, int64_t I, int d, int M, int L,
                                  const float *d_dOutR, const int32_t *d_active_rows, const int32_t *d_seg_info,
                                  int64_t n_max, float *d_SrcA, float *d_SrcB, float *d_grad,
                                  const uint32_t *d_active_mask /* nullable: bitmap of the active rows (the key bitmap of
-                                 elimrec_segment_plan); built internally when NULL; required when d_dOutR is NULL = sources prefilled by
-                                 elimrec_merge_rank_rows) */,
+                                 elimrec_segment_plan); built internally when NULL; required when d_dOutR is NULL = sources
+                                 prefilled by the caller) */,
                                  void *d_workspace, size_t workspace_bytes, void *stream);
 
-/* Data-parallel steps: every rank hands in the dOut rows [R x M*d] of its own active nodes with their node ids
- * (ascending; unused slots carry a NEGATIVE id, see elimrec_pad_rows), all-gathered in rank order: d_rows [W*R x M*d],
- * d_keys [W*R]. Rows of the same node are summed in rank order and left as the adjoint's source tables d_SrcA / d_SrcB
- * (what elimrec_propagate_folded_bwd derives from dOut rows) with the row bitmap d_mask [(N+31)/32 words]; then call
- * elimrec_propagate_folded_bwd with d_dOutR = NULL and d_active_mask = d_mask. W <= 64. M = 0: the rows are the
- * [H | G] pairs of elimrec_source_rows (2d columns) -- half the bytes on the wire. */
-int elimrec_source_rows(const float *d_dOutR, const int32_t *d_count, int64_t n_max, int d, int M, float *d_out /* [n x 2d] */,
-                        void *stream);
-/* elimrec_source_rows with the rows already cut into the column slices a column-sharded job sends to its `world` peers:
- * d_out [world x n_max x 2*dl], dl = d / world: slice w of row s = [H[s][w*dl:(w+1)*dl] | G[s][w*dl:(w+1)*dl]]. */
+/* [H | G] of every active row -- H = sum of the M column blocks of its dOut row (block order), G = block 0: all the adjoint
+ * propagation needs of a dOut row -- cut into the column slices a column-sharded job sends to its `world` peers (the
+ * "sparse-grad" exchange, elimrec_amd/shard.py; the receiving side sums rows of one node in rank order with
+ * elimrec_slab_merge_rows): d_out [world x n_max x 2*dl], dl = d / world: slice w of row s =
+ * [H[s][w*dl:(w+1)*dl] | G[s][w*dl:(w+1)*dl]]. */
 int elimrec_source_rows_split(const float *d_dOutR, const int32_t *d_count, int64_t n_max, int d, int M, int world,
                               float *d_out, void *stream);
-int elimrec_merge_rank_rows(const float *d_rows, const int32_t *d_keys, int W, int64_t R, int64_t U, int64_t I, int d,
-                            int M, float *d_SrcA, float *d_SrcB, uint32_t *d_mask, void *stream);
-
 /* One block SpMM with the fused epilogue on a W-column window of wider tables (row stride ld):
  *   r = A . Xin[:, 0:W];  if Xout: Xout = r;  if AccOut: AccOut = (r + Add1) * scale.
  * The building block of the bipartite propagation, exposed for callers that tile columns themselves. */

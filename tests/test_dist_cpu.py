@@ -66,76 +66,6 @@ class OracleEngine(object):
         return self.m.grads()
 
 
-class ShardedHeadOracleEngine(OracleEngine):
-    """The same stand-in behind the engine interface of a sharded head backward (EliMRec in "batch" mode): local
-    forward + head backward -> dOut rows of the local active nodes and the head-weight gradients; the trainer
-    all-gathers the rows and all-reduces the weight-gradient buffer; the propagation backward is replicated."""
-    dp_shards_head = True
-    HEAD = ("embedding_user_after_GCN", "embedding_item_after_GCN", "s_dense_")
-
-    def _out_tables(self):
-        """Out [N x C] (graph + feature projections), with an autograd graph back to the parameters."""
-        m = self.m
-        m.compute()
-        mods = ["v"] if m.kwai else ["v", "a", "t"]
-        return torch.cat([m.m_emb[k] for k in ["i"] + mods], dim=1), mods
-
-    def _head(self, out):
-        """Y [N x Cy] from Out with the live head parameters."""
-        m, d = self.m, self.m.d
-        mods = ["v"] if m.kwai else ["v", "a", "t"]
-        fused_in = out if m.mm_fusion_mode == "concat" else out.view(out.shape[0], -1, d).mean(1)
-        y0 = torch.cat([m._linear("embedding_user_after_GCN", fused_in[:m.U]), m._linear("embedding_item_after_GCN", fused_in[m.U:])])
-        heads = [m._linear("s_dense_%s" % k, out[:, (h + 1) * d:(h + 2) * d]) for h, k in enumerate(mods)]
-        return torch.cat([y0] + heads, dim=1), mods
-
-    def forward_local(self, users, pos, neg, all_keys=None, rank=0, world_size=1):
-        m, d = self.m, self.m.d
-        self.Out, _ = self._out_tables()
-        self.out_leaf = self.Out.detach().clone().requires_grad_(True)
-        Y, mods = self._head(self.out_leaf)
-        self.keys = self.batch_keys(users, pos, neg)
-        r3 = Y[self.keys.long()].view(-1, 3, Y.shape[1])
-        w = [1.0] + [m.alpha if k in m.modality else 0.0 for k in mods]
-        loss = 0
-        for b, wk in enumerate(w):
-            if wk:
-                blk = r3[:, :, b * d:(b + 1) * d]
-                loss = loss + wk * m.original_bpr_loss(blk[:, 0], blk[:, 1], blk[:, 2])
-        self.loss = loss
-        return loss.detach(), None
-
-    def backward_local(self, scale):
-        m = self.m
-        m.zero_grad()
-        (self.loss * scale).backward()
-        n = len(self.keys)
-        act = torch.unique(self.keys.long())
-        rows = torch.zeros(n, self.Out.shape[1])
-        rows[:len(act)] = self.out_leaf.grad[act]
-        keys = torch.arange(n, dtype=torch.int32)         # padding slot r: node r with a zero row
-        keys[:len(act)] = act.to(torch.int32)
-        self.head_names = [k for k, v in m.params.items() if k.startswith(self.HEAD) and v.grad is not None]
-        self.wbuf = torch.cat([m.params[k].grad.reshape(-1) for k in self.head_names])
-        return rows, keys, self.wbuf
-
-    def backward_rows_global(self, all_rows, all_keys):
-        m = self.m
-        head = {}
-        off = 0
-        for k in self.head_names:                      # views: the trainer's all-reduce may still be in flight
-            n = m.params[k].numel()
-            head[k] = self.wbuf[off:off + n].view_as(m.params[k])
-            off += n
-        d_out = torch.zeros_like(self.Out)
-        d_out.index_add_(0, all_keys.long(), all_rows)
-        m.zero_grad()
-        self.Out.backward(d_out)
-        grads = m.grads()
-        grads.update(head)
-        return grads
-
-
 class ColumnShardOracleEngine(OracleEngine):
     """CPU stand-in behind the cs_* interface of elimrec_amd/shard.py (ColumnShardTrainer): rank q owns columns
     [q*dl, (q+1)*dl) of [E_u ; E_i], propagates only those, and exchanges the layer means / adjoint sources of the active
@@ -336,7 +266,7 @@ class OracleOpt(object):
         self.inner.step()
 
 
-def _worker(rank, world, port, out_dir, sharded):
+def _worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -345,7 +275,7 @@ def _worker(rank, world, port, out_dir, sharded):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from elimrec_amd.dist import DataParallelTrainer
     g = load_golden("ml3")
-    eng = (ShardedHeadOracleEngine if sharded else OracleEngine)(g)
+    eng = OracleEngine(g)
     trainer = DataParallelTrainer(eng, OracleOpt(eng, g), world_size=world, rank=rank)
     losses = []
     for t in (1, 2):
@@ -362,13 +292,12 @@ def _worker(rank, world, port, out_dir, sharded):
 import pytest
 
 
-@pytest.mark.parametrize("sharded", [False, True], ids=["gathered-grad-rows", "sharded-head-backward"])
-def test_two_rank_step_equals_single_process_big_batch(tmp_path, sharded):
-    """Both data-parallel flows of elimrec_amd/dist.py: the whole backward on all-gathered head-gradient rows, and the
-    head backward sharded per rank (all-gather of dOut rows + all-reduce of the head-weight gradients)."""
+def test_two_rank_step_equals_single_process_big_batch(tmp_path):
+    """The data-parallel flow of elimrec_amd/dist.py (the unfolded row-major forms): the whole backward on all-gathered
+    head-gradient rows."""
     world = 2
-    port = 29500 + (os.getpid() % 2000) + (7 if sharded else 0)
-    mp.spawn(_worker, args=(world, port, str(tmp_path), sharded), nprocs=world, join=True)
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     r0 = dict(np.load(tmp_path / "rank0.npz"))
     r1 = dict(np.load(tmp_path / "rank1.npz"))
     for k in r0:

@@ -162,14 +162,15 @@ def test_batch_row_head_equals_full_tables(fixture_name):
 
 def test_step_regions_replayed_equal_eager(monkeypatch):
     """The step's regions two ways -- launched from Python every time, re-issued from the recorded C-ABI call
-    lists (default) -- give bit-identical parameters after several steps, including a change of batch size in
-    between (regions are re-recorded against the new workspace buffers)."""
+    lists (default; the native one-call program switched off so that the regions carry every step) -- give bit-identical
+    parameters after several steps, including a change of batch size in between (regions are re-recorded against the new
+    workspace buffers)."""
     from helpers import FixtureDataset, fixture_argv, make_config
-    from elimrec_amd import EliMRec, FusedAdam
-    from elimrec_amd.dist import DataParallelTrainer
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, EliMRec, FusedAdam
     g = load_golden("ml3")
     u, p, n = (_t(g["step1/%s" % k]) for k in ("users", "pos", "neg"))
     sizes = [len(u)] * 5 + [len(u) - 7] * 2 + [len(u)] * 4
+    monkeypatch.setenv("ELIMREC_NATIVE_STEP", "0")
     out = {}
     for mode in ("eager", "replay"):
         monkeypatch.setenv("ELIMREC_REPLAY", "0" if mode == "eager" else "1")
@@ -177,8 +178,9 @@ def test_step_regions_replayed_equal_eager(monkeypatch):
         model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sub(g, "init").items()})
         model = model.to(DEV)
         assert model._lazy and model._use_replay == (mode != "eager")
-        trainer = DataParallelTrainer(model, FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"])))
+        trainer = ColumnShardTrainer(ColumnShardEngine(model), FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"])))
         losses = [float(trainer.step(u[:b], p[:b], n[:b])) for b in sizes]
+        assert trainer._native_state()["native_steps"] == 0
         out[mode] = (losses, {k: v.cpu().clone() for k, v in model.state_dict().items()})
     for mode in ("replay",):
         assert out[mode][0] == out["eager"][0], mode
@@ -584,51 +586,6 @@ def test_fused_segment_apply_head_bwd_equals_two_launches():
     assert torch.equal(dY1[:na], dY2[:na]) and torch.equal(out1[:na], out2[:na])
 
 
-@pytest.mark.parametrize("W,R,U,I,d,M", [(5, 300, 700, 1300, 32, 3), (2, 64, 40, 90, 64, 4), (8, 1000, 3000, 5000, 16, 2), (1, 50, 10, 200, 64, 4)])
-def test_merge_rank_rows_vs_torch(W, R, U, I, d, M):
-    """elimrec_merge_rank_rows: rows of the same node from different ranks summed (rank order), H / G source tables
-    and the row bitmap, against an fp64 index_add; padding slots and ranks with few rows included."""
-    from elimrec_amd import ops
-    gen = torch.Generator().manual_seed(W * 1000 + R)
-    N, C = U + I, d * M
-    keys = torch.full((W, R), -(1 << 30), dtype=torch.int32)
-    rows = torch.zeros(W, R, C)
-    for r in range(W):
-        n_r = R if r == 0 else int(torch.randint(1, R + 1, (1,), generator=gen))
-        k = torch.sort(torch.randperm(N, generator=gen)[:n_r])[0]
-        keys[r, :n_r] = k.to(torch.int32)
-        keys[r, n_r:] += torch.arange(n_r, R, dtype=torch.int32)
-        rows[r, :n_r] = torch.randn(n_r, C, generator=gen)
-    srcA = torch.full((N, d), float("nan"), device=DEV)
-    srcB = torch.full((N, d), float("nan"), device=DEV)
-    mask = torch.full(((N + 31) // 32 + 2,), -1, dtype=torch.int32, device=DEV)
-    ops.merge_rank_rows(rows.view(W * R, C).to(DEV), keys.view(-1).to(DEV), W, U, I, d, M, srcA, srcB, mask)
-    valid = keys.view(-1) >= 0
-    tot = torch.zeros(N, C, dtype=torch.float64).index_add_(0, keys.view(-1)[valid].long(), rows.view(-1, C)[valid].double())
-    active = torch.zeros(N, dtype=torch.bool)
-    active[keys.view(-1)[valid].long()] = True
-    words = mask[:(N + 31) // 32].cpu().numpy().view(np.uint32)
-    got = np.unpackbits(words.view(np.uint8), bitorder="little")[:N].astype(bool)
-    assert np.array_equal(got, active.numpy())
-    H = tot.view(N, M, d).sum(1)
-    G = tot[:, :d]
-    wantA = torch.where((torch.arange(N) < U)[:, None], H, G)
-    wantB = torch.where((torch.arange(N) < U)[:, None], G, H)
-    assert (srcA.cpu().double()[active] - wantA[active]).abs().max() < 1e-5
-    assert (srcB.cpu().double()[active] - wantB[active]).abs().max() < 1e-5
-    # the same from [H | G] rows (elimrec_source_rows, what the ranks put on the wire): M = 0
-    hg = torch.zeros(W * R, 2 * d, device=DEV)
-    for r in range(W):
-        cnt = torch.tensor([int((keys[r] >= 0).sum())], dtype=torch.int32, device=DEV)
-        ops.source_rows(rows[r].to(DEV).contiguous(), cnt, d, M, hg[r * R:(r + 1) * R])
-    srcA2, srcB2 = torch.full_like(srcA, float("nan")), torch.full_like(srcB, float("nan"))
-    mask2 = torch.full_like(mask, -1)
-    ops.merge_rank_rows(hg, keys.view(-1).to(DEV), W, U, I, d, 0, srcA2, srcB2, mask2)
-    assert torch.equal(mask2[:(N + 31) // 32], mask[:(N + 31) // 32])
-    assert (srcA2.cpu().double()[active] - wantA[active]).abs().max() < 1e-5
-    assert (srcB2.cpu().double()[active] - wantB[active]).abs().max() < 1e-5
-
-
 def test_sampler_contract_on_device():
     from elimrec_amd import PairwiseSamplerV2, SyntheticDataset
     ds = SyntheticDataset(400, 300, 6000, feat_dims=(4, 4, 4), seed=9)
@@ -672,29 +629,6 @@ def test_rank_metrics_and_topk_known_answers():
         out = torch.empty(s.shape[0], 5 * k, device=DEV)
         ops.rank_metrics(_t(ref_topk), _t(tp), _t(ti), [1, 2, 3, 4, 5], out)
         assert np.abs(out.cpu().numpy() - g["case%d/result" % c]).max() < 1e-7, c   # same ranking -> same metrics
-
-
-def test_trainer_step_equals_autograd_step():
-    """The fused trainer path (elimrec_amd/dist.py, world 1) and the torch-autograd path
-    (loss.backward + optimizer.step, main.py:98-101 style) are the same kernels: bitwise equal."""
-    from elimrec_amd import FusedAdam
-    from elimrec_amd.dist import DataParallelTrainer
-    g = load_golden("ml3")
-    m1, _ = build_model_from_fixture(g, DEV)
-    m2, _ = build_model_from_fixture(g, DEV)
-    o1 = FusedAdam(m1.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
-    o2 = FusedAdam(m2.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
-    tr = DataParallelTrainer(m2, o2)
-    for t in (1, 2, 3):
-        u, p, n = (_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg"))
-        l1 = m1.bpr_loss(u, p, n)
-        o1.zero_grad()
-        l1.backward(retain_graph=True)
-        o1.step()
-        l2 = tr.step(u, p, n)
-        assert torch.equal(l1.detach(), l2)
-    for (k, a), (_, b) in zip(m1.state_dict().items(), m2.state_dict().items()):
-        assert torch.equal(a, b), k
 
 
 def test_driver_runs_epochs_with_eval_and_checkpoint(tmp_path):
@@ -918,34 +852,17 @@ def test_full_movielens_shape_step_vs_oracle():
 
 
 def test_data_parallel_math_on_one_gpu():
-    """What the ranks of a 2-rank job compute (elimrec_amd/dist.py) emulated on one GPU, both flows: (a) the head
-    backward sharded per rank -- dOut rows + node ids concatenated in rank order, weight-gradient spans summed, one
-    replicated adjoint propagation; (b) the whole backward on the concatenated head-gradient rows. Either must equal
-    the single-GPU step on the whole batch."""
+    """What the ranks of a 2-rank job compute (elimrec_amd/dist.py: the unfolded row-major forms) emulated on one GPU: the
+    whole backward on the concatenated head-gradient rows of both ranks equals the single-GPU step on the whole batch."""
     g = load_golden("ml3")
+    extra = ["--head_rows=all"]
     u, p, n = (_t(g["step1/%s" % k]) for k in ("users", "pos", "neg"))
     half = (len(u) // 2)
-    whole, _ = build_model_from_fixture(g, DEV)
+    whole, _ = build_model_from_fixture(g, DEV, extra_argv=extra)
+    assert not whole._lazy
     loss_w, rows_w = whole.forward_local(u[:2 * half], p[:2 * half], n[:2 * half])
     grads_w = {k: v.clone() for k, v in whole.backward_global(rows_w, torch.ones(1, device=DEV)).items()}
-    # (a) sharded head backward
-    dp, _ = build_model_from_fixture(g, DEV)
-    assert dp.dp_shards_head
-    scale = torch.full((1,), 0.5, device=DEV)
-    rows, keys, wg, losses = [], [], [], []
-    for r in range(2):
-        sl = slice(r * half, (r + 1) * half)
-        loss, _ = dp.forward_local(u[sl], p[sl], n[sl], world_size=2)
-        rr, kk, ww = dp.backward_local(scale)
-        rows.append(rr.clone()); keys.append(kk.clone()); wg.append(ww.clone()); losses.append(loss.clone())
-    ww.copy_(wg[0] + wg[1])                              # the all-reduce
-    grads_dp = dp.backward_rows_global(torch.cat(rows), torch.cat(keys))
-    assert abs(float(loss_w) - float((losses[0] + losses[1]) / 2)) < 1e-6
-    assert set(grads_w) == set(grads_dp)
-    for k in grads_w:
-        assert rel_err(grads_dp[k].cpu(), grads_w[k].cpu()) < 1e-5, k
-    # (b) gathered head-gradient rows (engines without a sharded head backward)
-    dp, _ = build_model_from_fixture(g, DEV)
+    dp, _ = build_model_from_fixture(g, DEV, extra_argv=extra)
     dp._workspace(half, 6 * half)
     all_keys = torch.cat([dp.batch_keys(u[r * half:(r + 1) * half], p[r * half:(r + 1) * half],
                                         n[r * half:(r + 1) * half]).clone() for r in range(2)])
@@ -959,6 +876,9 @@ def test_data_parallel_math_on_one_gpu():
     assert set(grads_w) == set(grads_dp)
     for k in grads_w:
         assert rel_err(grads_dp[k].cpu(), grads_w[k].cpu()) < 1e-5, k
+    lazy, _ = build_model_from_fixture(g, DEV)
+    with pytest.raises(RuntimeError, match="column-shard engine"):
+        lazy.forward_local(u, p, n)
 
 
 def test_kwai_shape_v_plus_t_variant_vs_oracle():

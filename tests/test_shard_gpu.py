@@ -435,29 +435,29 @@ def test_column_shard_trainer_matches_reference_fixture(name):
 
 
 def test_column_shard_trainer_equals_row_major_trainer():
-    """Same model, same batches: the slab-major engine and the row-major trainer (dist.py) agree to round-off, and the
-    slab engine is bitwise reproducible."""
+    """Same model, same batches: the slab-major engine (folded tables, batch rows) and the row-major trainer on the UNFOLDED
+    form (dist.py; --propagation=bipartite --head_rows=all: every table through the graph, every projection over all rows --
+    the reference's own amount of work) agree to the suite's tolerances, and the slab engine is bitwise reproducible."""
     from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
     from elimrec_amd.dist import DataParallelTrainer
     g = load_golden("gcmc")
     runs = []
     for kind in ("rows", "slab", "slab"):
-        model, _ = build_model_from_fixture(g, DEV)
+        model, _ = build_model_from_fixture(g, DEV, extra_argv=["--propagation=bipartite", "--head_rows=all"] if kind == "rows" else [])
         opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
         if kind == "rows":
+            assert not model._lazy and not model._folded
             tr = DataParallelTrainer(model, opt)
         else:
             eng = ColumnShardEngine(model)
             tr = ColumnShardTrainer(eng, opt)
         losses = [float(tr.step(*(_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg")))) for t in (1, 2, 3)]
-        if kind == "slab":
-            eng.sync_to_model()
         runs.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}))
     assert runs[1][0] == runs[2][0]
     for k in runs[1][1]:
         assert torch.equal(runs[1][1][k], runs[2][1][k]), k
-        assert (runs[0][1][k] - runs[1][1][k]).abs().max().item() < 1e-6, k
-    assert np.allclose(runs[0][0], runs[1][0], atol=1e-6)
+        assert (runs[0][1][k] - runs[1][1][k]).abs().max().item() < 2e-5, k
+    assert np.allclose(runs[0][0], runs[1][0], atol=1e-5)
 
 
 # ----------------------------------------------------------------------------- W ranks emulated on one GPU
@@ -891,7 +891,8 @@ def test_step_variants_are_bitwise_equal(monkeypatch, name):
 def test_random_shapes_column_shard_vs_row_major_trainer(seed):
     """Random small graphs, batch sizes that are not multiples of any tile height, 2-4 layers, the three bipartite
     adjacencies, recdim 64 (fused 16-row head, wave-tile hops, Adam epilogue, second stream) and 32 (batched-GEMM head):
-    two steps of the column-shard trainer against the row-major trainer (dist.py: other hop, head and optimizer kernels)
+    two steps of the column-shard trainer against the row-major trainer on the unfolded form (dist.py,
+    --propagation=bipartite --head_rows=all: other hop, head and optimizer kernels, all tables through the graph)
     -- losses 1e-5, parameters 2e-5."""
     import os
     from helpers import ROOT
@@ -910,15 +911,18 @@ def test_random_shapes_column_shard_vs_row_major_trainer(seed):
     cwd = os.getcwd()
     os.chdir(ROOT)
     try:
-        cfg = Configurator(os.path.join(ROOT, "NeuRec.properties"), default_section="hyperparameters",
-                           argv=["x", "--data.input.dataset=synthetic", "--alpha=0.5", "--loss=bpr_loss", "--recdim=%d" % recdim,
-                                 "--layer_num=%d" % L, "--adj_type=%s" % adj, "--verbose=0"])
+        argv = ["x", "--data.input.dataset=synthetic", "--alpha=0.5", "--loss=bpr_loss", "--recdim=%d" % recdim,
+                "--layer_num=%d" % L, "--adj_type=%s" % adj, "--verbose=0"]
+        cfgs = {kind: Configurator(os.path.join(ROOT, "NeuRec.properties"), default_section="hyperparameters",
+                                   argv=argv + (["--propagation=bipartite", "--head_rows=all"] if kind == "rows" else []))
+                for kind in ("rows", "slab")}
+        cfg = cfgs["slab"]
         ds = SyntheticDataset(U, I, E, feat_dims=dims, seed=seed)
         u, p, n = PairwiseSamplerV2(ds, batch_size=B, device=DEV, seed=seed).sample_epoch()
         out = []
         for kind in ("rows", "slab"):
             set_seed(7)
-            model = EliMRec(cfg, ds).to(DEV)
+            model = EliMRec(cfgs[kind], ds).to(DEV)
             opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
             if kind == "rows":
                 tr, eng = DataParallelTrainer(model, opt), None
@@ -926,8 +930,6 @@ def test_random_shapes_column_shard_vs_row_major_trainer(seed):
                 eng = ColumnShardEngine(model)
                 tr = ColumnShardTrainer(eng, opt)
             losses = [float(tr.step(u[i * B:(i + 1) * B], p[i * B:(i + 1) * B], n[i * B:(i + 1) * B])) for i in range(2)]
-            if eng is not None:
-                eng.sync_to_model()
             out.append((losses, {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}))
     finally:
         os.chdir(cwd)
