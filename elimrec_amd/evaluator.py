@@ -9,7 +9,9 @@ copies a [128 x I] score matrix to the host per batch and ranks it on 8 CPU thre
 
 Tie rule: the device ranks by (score descending, item id ascending); the reference's
 std::partial_sort_copy breaks ties in heap order (SURVEY quirk 6). The two agree whenever a row
-has no tied scores at or across the K boundary.
+has no tied scores at or across the K boundary; the rows that have are re-ranked by the reference's
+own algorithm (tie_order = "reference", the default; "id" keeps the device's rule and never leaves
+the device).
 """
 import numpy as np
 import torch
@@ -58,11 +60,13 @@ class UniEvaluator(object):
         self.top_show = np.arange(top_k) + 1 if isinstance(top_k, int) else np.sort(top_k)
         self._dev_cache = {}
         self._default_users = None
-        # ties among equal scores: "id" = the device's rule (score descending, item id ascending); "reference" = the reference's
-        # lists bit for bit, rows with a tie at or across K re-ranked on the host by its own algorithm (ProxyEvaluator sets it from
-        # --tie_order / ELIMREC_TIE_ORDER)
+        # ties among equal scores: "reference" (default) = the reference's lists, rows with a tie at or across K re-ranked on the
+        # host by its own algorithm (evaluate.h:26-33); "id" = the device's rule (score descending, item id ascending), nothing
+        # leaves the device (--tie_order / ELIMREC_TIE_ORDER)
         import os as _os
-        self.tie_order = _os.environ.get("ELIMREC_TIE_ORDER", "id")
+        self.tie_order = _os.environ.get("ELIMREC_TIE_ORDER", "reference")
+        if self.tie_order not in ("id", "reference"):
+            raise ValueError("ELIMREC_TIE_ORDER must be id or reference")
         self.tie_rows_replayed = 0
 
     def metrics_info(self):
@@ -146,17 +150,28 @@ class UniEvaluator(object):
             block //= 2
         return block
 
+    # the chunked top-K scorer's default math (six bf16 piece products per fp32 product, v_exp / v_rcp) returns scores within
+    # 2.4e-7 of the score-matrix form the replayed rows are ranked on: two scores further apart than twice
+    # that have the same order in both forms
+    NEAR_TIE = 4.8e-7
+
     def _topk_in_reference_order(self, model, users_t, train_ptr, train_items):
-        """--tie_order=reference: the device's top-(K + 1); a row whose K + 1 best scores are pairwise different has ONE ranking
-        under any tie rule -- the device's is the reference's. The other rows (equal scores inside the list or straddling K: rare
-        on trained tables) get their masked score rows from the device and are ranked on the host by the reference's own
-        algorithm, std::partial_sort_copy (evaluate.h:26-33, elimrec_topk_reference_order)."""
+        """tie_order = "reference": the device's top-(K + 1); a row whose K + 1 best scores are clearly apart has ONE ranking
+        under any tie rule and in either score form -- the device's list is the reference's. The other rows (equal or
+        near-equal scores inside the list or straddling K: rare on trained tables) get their masked score ROWS from the device
+        -- one score form for the whole row, the one predict() returns -- and are ranked on the host by the reference's own
+        algorithm, std::partial_sort_copy (evaluate.h:26-33, elimrec_topk_reference_order): selection and order of those rows
+        are the reference's code on that row. With EXACT evaluation math both score forms are the same bits and only exact
+        ties are replayed."""
         import ctypes
         from . import _lib
         K = self.max_top
+        lib = _lib.load()
+        tol = 0.0 if int(lib.elimrec_score_get_math()) == 0 else self.NEAR_TIE
         idx1, val1 = model.predict_device(users_t, top_k=K + 1, train_ptr=train_ptr, train_items=train_items)
         idx, val = idx1[:, :K].contiguous(), val1[:, :K].contiguous()
-        tied = torch.nonzero((val1[:, 1:] == val1[:, :-1]).any(1)).flatten()
+        hi, lo = val1[:, :-1], val1[:, 1:]
+        tied = torch.nonzero(((hi == lo) | ((hi - lo) <= tol)).any(1)).flatten()
         self.tie_rows_replayed += int(tied.numel())
         if tied.numel():
             ptr = train_ptr.cpu().numpy()
@@ -166,15 +181,20 @@ class UniEvaluator(object):
             items_h = train_items.cpu().numpy()
             sub_items = np.concatenate([items_h[ptr[r]:ptr[r + 1]] for r in rows] + [np.zeros(0, np.int32)]).astype(np.int32)
             dev = users_t.device
-            sc = torch.empty(tied.numel(), model.num_items, dtype=torch.float32, device=dev)
-            model.predict_device(users_t[tied], scores=sc, train_ptr=torch.from_numpy(sub_ptr).to(dev),
-                                 train_items=torch.from_numpy(sub_items if len(sub_items) else np.zeros(1, np.int32)).to(dev))
-            host = np.ascontiguousarray(sc.cpu().numpy())
-            out = np.empty((tied.numel(), K), np.int32)
-            _lib.check(_lib.load().elimrec_topk_reference_order(host.ctypes.data_as(ctypes.c_void_p), host.shape[0], host.shape[1], host.shape[1], K,
-                                                                out.ctypes.data_as(ctypes.c_void_p)), "topk_reference_order")
-            idx[tied] = torch.from_numpy(out).to(dev)
-            val[tied] = torch.gather(sc, 1, idx[tied].long())
+            step = max(1, (1 << 28) // max(1, model.num_items))          # <= 1 GiB of score rows at a time
+            for a in range(0, tied.numel(), step):
+                part = tied[a:a + step]
+                sc = torch.empty(part.numel(), model.num_items, dtype=torch.float32, device=dev)
+                p0 = sub_ptr[a:a + part.numel() + 1] - sub_ptr[a]
+                it = sub_items[sub_ptr[a]:sub_ptr[a + part.numel()]]
+                model.predict_device(users_t[part], scores=sc, train_ptr=torch.from_numpy(p0).to(dev),
+                                     train_items=torch.from_numpy(it if len(it) else np.zeros(1, np.int32)).to(dev))
+                host = np.ascontiguousarray(sc.cpu().numpy())
+                out = np.empty((part.numel(), K), np.int32)
+                _lib.check(lib.elimrec_topk_reference_order(host.ctypes.data_as(ctypes.c_void_p), host.shape[0], host.shape[1], host.shape[1], K,
+                                                            out.ctypes.data_as(ctypes.c_void_p)), "topk_reference_order")
+                idx[part] = torch.from_numpy(out).to(dev)
+                val[part] = torch.gather(sc, 1, idx[part].long())
         return idx, val
 
     def evaluate_batch(self, model, batch_users, return_topk=False, cache_key=None, out=None):
@@ -192,7 +212,11 @@ class UniEvaluator(object):
             if key is not None:
                 self._dev_cache[key] = hit
         users_t, train_ptr, train_items, truth_ptr, truth_items = hit
-        if self.tie_order == "reference" and self.max_top < min(256, model.num_items):
+        if self.tie_order == "reference":
+            if self.max_top + 1 > min(256, model.num_items):
+                raise ValueError("tie_order=reference needs the device's top-(K + 1) list: K + 1 = %d exceeds min(256, num_items = %d); "
+                                 "evaluate with --tie_order=id (the device's rule: lowest item id first among equal scores)"
+                                 % (self.max_top + 1, model.num_items))
             idx, val = self._topk_in_reference_order(model, users_t, train_ptr, train_items)
         else:
             idx, val = model.predict_device(users_t, top_k=self.max_top, train_ptr=train_ptr, train_items=train_items)

@@ -814,6 +814,7 @@ def _full_shape_step(U, I, E, dims, recdim, B, dataset_name, extra_argv=()):
         truth = om64.grads()
     for k, v in want.items():
         assert_grad_close(mine[k], v, k, truth=None if truth is None else truth[k])
+    model._test_case = dict(cfg=cfg, ds=ds, init=init, batch=(u, p, n), loss=loss.item(), grads=mine)
     return model, om
 
 
@@ -839,6 +840,44 @@ def test_full_tiktok_shape_step_vs_oracle():
     users = list(range(0, 36656, 300))[:64]
     model.predict_type = om.predict_type = "TIE"
     assert np.abs(model.predict(users).numpy() - om.predict(users).numpy()).max() < 1e-5
+
+
+def test_full_tiktok_shape_with_bf16_feature_storage():
+    """BASELINE.json configs[1] as labelled ("bf16"): the V / A / T feature constants STORED in bf16 (--feature_dtype=bf16),
+    all arithmetic fp32, at the full Tiktok shape. Two statements: (1) what the mode computes -- the fp32 engine on constants
+    rounded to bf16, to the last bits of c's hi + lo split (loss 2e-6, gradients 1e-4 row-wise); (2) the mode's stated
+    tolerance against the unrounded reference arithmetic (the oracle): loss 2e-3 abs, every gradient 2e-2 max-norm and row
+    by row."""
+    from helpers import make_config
+    from elimrec_amd import EliMRec, set_seed
+    model32, om = _full_shape_step(36656, 76085, 720829, (128, 128, 128), 64, 2048, "synthetic")
+    case = model32._test_case
+    u, p, n = (t.to(DEV) for t in case["batch"])
+    want = om.grads()
+    res = {}
+    for mode in ("stored", "rounded"):
+        argv = ["--data.input.dataset=synthetic", "--alpha=0.5", "--loss=bpr_loss", "--recdim=64", "--verbose=0"]
+        set_seed(7)
+        model = EliMRec(make_config(argv + (["--feature_dtype=bf16"] if mode == "stored" else [])), case["ds"])
+        model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in case["init"].items()})
+        model = model.to(DEV)
+        eng = model.plugin.ensure_engine()
+        assert eng.feature_dtype == ("bf16" if mode == "stored" else "f32")
+        if mode == "rounded":
+            fold = model._ws["fold"]
+            for k in model._mods:
+                fold[k].copy_(fold[k].to(torch.bfloat16).float())
+        loss = model.bpr_loss(u, p, n)
+        loss.backward()
+        res[mode] = (loss.item(), {k: q.grad.cpu().clone() for k, q in model.named_parameters() if q.grad is not None})
+    assert abs(res["stored"][0] - res["rounded"][0]) < 2e-6
+    assert set(res["stored"][1]) == set(res["rounded"][1]) == set(want)
+    for k, v in res["rounded"][1].items():
+        assert_grad_close(res["stored"][1][k], v, ("bf16 storage vs fp32 engine on rounded constants", k))
+    assert res["stored"][0] != case["loss"]                                  # the storage really is 16-bit
+    assert abs(res["stored"][0] - float(om.bpr_loss(*case["batch"]).detach())) < 2e-3
+    for k, v in want.items():
+        assert_grad_close(res["stored"][1][k], v, ("bf16 storage vs the oracle", k), rel=2e-2)
 
 
 def test_full_kwai_shape_step_vs_oracle():
@@ -1387,11 +1426,27 @@ def test_reference_tie_order_is_reproduced_on_request(fixture_name):
         rows_ref, idx_ref, val_ref = evalr.evaluate_batch(model, users, return_topk=True)
     finally:
         lib.elimrec_score_set_math(math0)
-        evalr.tie_order = "id"
+        evalr.tie_order = "reference"
     tied = ~_tie_free(sc, K)
-    assert tied.sum() >= 3 and evalr.tie_rows_replayed == int(tied.sum())
+    assert tied.sum() >= 3 and evalr.tie_rows_replayed == int(tied.sum())             # (EXACT math: exact ties only)
     assert not np.array_equal(idx_id.cpu().numpy(), ref_topk)                     # the device's rule IS another order on these rows
     assert np.array_equal(idx_id.cpu().numpy()[~tied], ref_topk[~tied])
     assert np.array_equal(idx_ref.cpu().numpy(), ref_topk)                        # ... and on request the reference's, everywhere
     assert np.array_equal(rows_ref.cpu().numpy(), ref_rows)
     assert np.array_equal(val_ref.cpu().numpy(), np.take_along_axis(sc, ref_topk.astype(np.int64), 1))
+    # the DEFAULT evaluation math: the chunked top-K scorer and the score-matrix form differ by <= 2.4e-7, so a tie in one need not
+    # be a tie in the other -- rows whose K + 1 best scores are closer than twice that are replayed on the score rows predict()
+    # returns, and every row carries what the reference's code makes of THOSE rows
+    lib.elimrec_score_set_math(1)
+    try:
+        model.predict_device(users, scores=dev_scores, train_ptr=train_ptr, train_items=train_items)
+        sc_fast = np.ascontiguousarray(dev_scores.cpu().numpy())
+        _, fast_topk = ev.evaluate_matrix(sc_fast.copy(), tp, ti, mids, K, use_ref=True)
+        evalr.tie_rows_replayed = 0
+        _, idx_fast, val_fast = evalr.evaluate_batch(model, users, return_topk=True)
+    finally:
+        lib.elimrec_score_set_math(math0)
+    assert evalr.tie_rows_replayed >= int(tied.sum())
+    assert np.array_equal(idx_fast.cpu().numpy(), fast_topk)
+    replayed = ~_tie_free(sc_fast, K)
+    assert np.array_equal(val_fast.cpu().numpy()[replayed], np.take_along_axis(sc_fast, fast_topk.astype(np.int64), 1)[replayed])
