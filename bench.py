@@ -127,18 +127,118 @@ def cpu_baseline(ds, model_cpu_state, cfg, batches, thread_counts=(8, 16, 32, 64
                 ms_per_step=1e3 * mean)
 
 
-def spawn_ranks(n):
-    """python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same arguments>, as a child process."""
+def _free_port():
     import socket
-    import subprocess
-    with socket.socket() as s:          # a free rendezvous port on the loop-back interface
+    with socket.socket() as s:          # a free port on the loop-back interface
         s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+        return s.getsockname()[1]
+
+
+def _tail(path, n=25):
+    try:
+        with open(path, "rb") as f:
+            return b"\n".join(f.read().splitlines()[-n:]).decode("utf-8", "replace")
+    except OSError:
+        return "(no log)"
+
+
+def spawn_ranks(n):
+    """python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same arguments>, as a child process of a
+    parent that has not touched the GPU -- the launch line the driver uses. Every rank it starts is a SUPERVISOR (supervise()
+    below) that enforces the wall-clock limit per attempt; this parent only adds an outer guard around the whole launch."""
+    import signal
+    import subprocess
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    limit = float(os.environ.get("ELIMREC_BENCH_LIMIT", 600))
+    child = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return child.wait(timeout=2 * limit + 120)           # two attempts of `limit` seconds each + start-up
+    except subprocess.TimeoutExpired:
+        sys.stderr.write("bench.py: the %d-rank launch did not end within %.0f s: killing it\n" % (n, 2 * limit + 120))
+        os.killpg(child.pid, signal.SIGKILL)
+        return 124
+
+
+def supervise(args):
+    """One torch.distributed.run rank of a multi-GPU bench = one SUPERVISOR: a process that never touches the GPU, starts the
+    real rank (`bench.py --worker`, a fresh child each attempt -- nothing is ever exec'ed over a process that initialised HIP),
+    and ends it after a wall-clock limit. The supervisors keep a gloo group among themselves (CPU only) and poll once a second
+    in lock-step: all children done -> rank 0 forwards its child's JSON line; any child dead, or the limit reached -> every
+    child is killed (SIGUSR1 first: the workers dump their Python stacks), each rank prints its child's last log lines, and
+    ONE more attempt runs with torch.distributed's collectives instead of the library-owned RCCL communicator
+    (ELIMREC_NATIVE_COMM=0) on a fresh rendezvous port. The JSON line says which attempt produced it.
+    ELIMREC_BENCH_LIMIT (seconds per attempt, default 600); ELIMREC_TEST_HANG=1 / first (tests): the workers of every / of the
+    first attempt hang before their first step."""
+    import datetime
+    import signal
+    import subprocess
+    import tempfile
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    limit = float(os.environ.get("ELIMREC_BENCH_LIMIT", 600))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=max(120.0, limit)))
+    logdir = os.environ.get("ELIMREC_BENCH_LOGDIR") or tempfile.mkdtemp(prefix="elimrec_bench_")
+    attempts = [("the library's own RCCL communicator", {}), ("torch.distributed collectives (fallback)", {"ELIMREC_NATIVE_COMM": "0"})]
+    RUNNING, OK, FAILED = 0, 1, 2
+    why = ""
+    for k, (name, extra) in enumerate(attempts):
+        port = [_free_port() if rank == 0 else None]
+        dist.broadcast_object_list(port, src=0)
+        env = dict(os.environ)
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)        # the workers' rank 0 hosts its own store on the fresh port
+        env.update(MASTER_PORT=str(port[0]), ELIMREC_BENCH_ATTEMPT=str(k), ELIMREC_BENCH_COLLECTIVES=name, **extra)
+        env.setdefault("NCCL_DEBUG", "WARN")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if k > 0:
+            env["ELIMREC_BENCH_FALLBACK_REASON"] = why[:300]
+        out_path = os.path.join(logdir, "rank%d_attempt%d.out" % (rank, k))
+        err_path = os.path.join(logdir, "rank%d_attempt%d.err" % (rank, k))
+        with open(out_path, "wb") as fo, open(err_path, "wb") as fe:
+            child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker"] + sys.argv[1:], env=env, stdout=fo, stderr=fe,
+                                     start_new_session=True)
+            t0 = time.time()
+            verdict = None
+            while verdict is None:
+                time.sleep(1.0)
+                rc = child.poll()
+                mine = RUNNING if rc is None else (OK if rc == 0 else FAILED)
+                st = torch.zeros(world + 1, dtype=torch.int64)
+                st[rank] = mine
+                st[world] = int(time.time() - t0 > limit)     # any supervisor's clock past the limit ends the attempt for all
+                dist.all_reduce(st)
+                states = st[:world].tolist()
+                if all(x == OK for x in states):
+                    verdict = "ok"
+                elif any(x == FAILED for x in states):
+                    verdict = "rank(s) %s exited with an error" % [r for r, x in enumerate(states) if x == FAILED]
+                elif int(st[world]) > 0:
+                    verdict = "no result within %.0f s (ranks still running: %s)" % (limit, [r for r, x in enumerate(states) if x == RUNNING])
+            if verdict != "ok" and child.poll() is None:
+                try:
+                    os.killpg(child.pid, signal.SIGUSR1)     # faulthandler in the worker: Python stacks into its log
+                    time.sleep(1.0)
+                    os.killpg(child.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                child.wait()
+        if verdict == "ok":
+            if rank == 0:
+                with open(out_path, "rb") as f:
+                    sys.stdout.write(f.read().decode("utf-8", "replace"))
+                sys.stdout.flush()
+            dist.barrier()
+            dist.destroy_process_group()
+            return 0
+        why = "attempt %d (%s): %s" % (k, name, verdict)
+        sys.stderr.write("[rank %d] bench.py %s\n[rank %d] last lines of %s:\n%s\n" % (rank, why, rank, err_path, _tail(err_path)))
+        sys.stderr.flush()
+    dist.destroy_process_group()
+    return 1
 
 
 def main():
@@ -155,12 +255,21 @@ def main():
     ap.add_argument("--feature-dtype", choices=["f32", "f16", "bf16"], default="f32", help="storage of the folded constants")
     ap.add_argument("--no-b-sweep", action="store_true", help="skip the batch-size sweep line")
     ap.add_argument("--no-reduced-precision", action="store_true", help="skip the bf16-feature-storage line (configs[1]'s label)")
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)      # a rank started by supervise()
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: start the N ranks ourselves, as CHILD processes of a parent that has not touched
         # the GPU (nothing above imports torch), and leave with their exit code -- the same launch line the driver uses
         raise SystemExit(spawn_ranks(args.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not args.worker:
+        # a rank of a multi-GPU launch (the driver's torch.distributed.run line, or spawn_ranks above): supervise the real rank
+        raise SystemExit(supervise(args))
+    if args.worker:
+        import faulthandler
+        import signal
+        faulthandler.register(signal.SIGUSR1, all_threads=True)          # the supervisor asks for the stacks before it kills
+        sys.argv = [a for a in sys.argv if a != "--worker"]
 
     import torch
     import torch.distributed as dist
@@ -220,6 +329,12 @@ def main():
         torch.cuda.synchronize()
         plan_ms = 1e3 * (time.perf_counter() - t_plan) / len(batches)
 
+    hang = os.environ.get("ELIMREC_TEST_HANG", "")
+    if args.worker and (hang == "1" or (hang == "first" and os.environ.get("ELIMREC_BENCH_ATTEMPT", "0") == "0")):
+        sys.stderr.write("[rank %d] ELIMREC_TEST_HANG: sleeping in front of the first step\n" % rank)
+        sys.stderr.flush()
+        while True:
+            time.sleep(3600)
     first_losses = []            # the losses of the first steps (ring slots, read after the timed region): the reduced-precision
     for i in range(args.warmup):  # line runs the same batches from the same initial parameters and reports the difference
         first_losses.append(trainer.step(*batches[i]))
@@ -323,6 +438,20 @@ def main():
         }
         if plugin is not None:
             out["plugin_api_loop"] = plugin
+        if world > 1 or multi_path:
+            comm = trainer._native_comm()
+            nranks = None
+            if comm is not None:
+                import ctypes
+                from elimrec_amd import _lib
+                n_c = ctypes.c_int32(0)
+                if _lib.load().elimrec_comm_nranks(comm, ctypes.byref(n_c)) == 0:
+                    nranks = int(n_c.value)
+            out["collectives"] = {"path": ("library-owned RCCL communicator (csrc/program.hip: ncclAllGather / grouped ncclSend+ncclRecv / "
+                                           "ncclAllReduce on the step's own streams)") if comm is not None else
+                                          ("torch.distributed, backend %s" % dist.get_backend()),
+                                  "rccl_nranks": nranks, "attempt": int(os.environ.get("ELIMREC_BENCH_ATTEMPT", "0")),
+                                  "fallback_reason": os.environ.get("ELIMREC_BENCH_FALLBACK_REASON")}
         if world > 1:
             out["xgmi_bytes_sent_per_rank_step"] = trainer.xgmi_bytes
             # what ONE GPU does at the same global batch (a step is O(graph) + O(B), so one GPU's triplets/s rises with B):

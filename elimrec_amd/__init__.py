@@ -1,15 +1,11 @@
 """elimrec_amd -- the EliMRec per-batch hot path (models/EliMRec.py of Xiaohao-Liu/EliMRec)
 as hand-written gfx950 HIP kernels behind the reference's own plugin surface."""
-import os as _os
 
-# The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4), and a dependency between two
-# streams costs far more when it crosses queues than the kernels around it: a training step has three streams in flight at most
-# (compute, the plan / exchange stream, the library's RCCL calls), and measured on MI355X (ms per step, one host call per step):
-#   one rank                 1 queue 0.361   2 0.307   3 0.303   4 0.303
-#   multi-rank path (1 rank) 1 queue 0.496   2 0.391   3 0.392   4 0.493   8 0.772
-# Read by the runtime when it initialises (the first HIP call of the process); an explicit setting of the caller's wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
-
+# (GPU_MAX_HW_QUEUES -- the HIP runtime's cap on hardware queues per process, which decides what a dependency between two of the
+# step's streams costs -- is a process-wide knob of the HOST application: main.py and bench.py set it for their own process
+# before the runtime initialises (3: compute stream, plan / exchange stream, one spare for copies and RCCL's own work; measured
+# ms per step with 1 / 2 / 3 / 4 / 8 queues: one rank 0.361 / 0.307 / 0.303 / 0.303 / -, the multi-rank path on one rank
+# 0.496 / 0.391 / 0.392 / 0.493 / 0.772). Importing this package does not touch it.)
 from .configurator import Configurator
 from .data_iterator import DataIterator
 from .dataset import Dataset, SyntheticDataset, csr_to_user_dict

@@ -228,10 +228,12 @@ SIGNATURES = {
     "elimrec_program_fn_name": (ctypes.c_char_p, [c_i32]),
     "elimrec_program_fn_args": (c_i32, [c_i32]),
     "elimrec_program_create": (c_i32, [ctypes.POINTER(ProgramOp), c_i32, ctypes.POINTER(c_ptr)]),
+    "elimrec_program_create_scoped": (c_i32, [ctypes.POINTER(ProgramOp), c_i32, c_i32, ctypes.POINTER(c_ptr)]),
     "elimrec_program_run": (c_i32, [c_ptr, ctypes.POINTER(ProgramPatch), c_i32]),
     "elimrec_program_destroy": (c_i32, [c_ptr]),
     "elimrec_comm_unique_id": (c_i32, [c_ptr]),
     "elimrec_comm_create": (c_i32, [c_ptr, c_i32, c_i32, ctypes.POINTER(c_ptr)]),
+    "elimrec_comm_nranks": (c_i32, [c_ptr, ctypes.POINTER(c_i32)]),
     "elimrec_comm_destroy": (c_i32, [c_ptr]),
     "elimrec_comm_all_gather": (c_i32, [c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
     "elimrec_comm_all_reduce_f32": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr]),
@@ -288,7 +290,7 @@ class _Recording(object):
             fn = getattr(lib, name)
             plain = name in ("elimrec_abi_version", "elimrec_program_fn_count", "elimrec_program_fn_args", "elimrec_comm_unique_id",
                              "elimrec_score_get_math", "elimrec_score_get_bf16x3",
-                             "elimrec_comm_create", "elimrec_comm_destroy") or name.startswith("elimrec_program_")
+                             "elimrec_comm_create", "elimrec_comm_destroy", "elimrec_comm_nranks") or name.startswith("elimrec_program_")
             setattr(self, name, self._wrap(fn, name) if res is c_i32 and not plain else fn)
 
     def _wrap(self, fn, name):

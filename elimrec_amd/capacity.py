@@ -60,7 +60,9 @@ def plan(U, I, interactions, d, dims, world=1, layers=3, batch=2048, mods=None, 
     if plan_stats is not None:
         sweep = plan_stats.get("sweep_bytes", 0)
     else:
-        sweep = int(SWEEP_BYTES_PER_NNZ * nnz) if (not wide and slab.sweep_wanted(N, dl, nnz)) else 0
+        ns_, w_ = slab.choose_slabs(dl)
+        sweep = int(SWEEP_BYTES_PER_NNZ * nnz) if (not wide and w_ in (16, 32) and slab.sweep_tiles_xcds(ns_)
+                                                   and slab.sweep_wanted(N, dl, nnz)) else 0
     if sweep:
         out["window-sweep plan of the user rows + tile plan of the item rows (whole hops of a slice beyond the caches)"] = sweep * (1 if symmetric else 2)
     # ---- lookup.py: this rank's rows of [S_1 | .. | S_n | c]

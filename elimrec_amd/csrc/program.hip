@@ -72,6 +72,7 @@ struct Rccl {
     int (*GetUniqueId)(NcclId *) = nullptr;
     int (*CommInitRank)(ncclComm_t *, int, NcclId, int) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*CommCount)(ncclComm_t, int *) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
@@ -92,6 +93,7 @@ static int rccl_load() {
     *(void **)(&g_rccl.field) = dlsym(h, name);                                          \
     if (!g_rccl.field) { set_error("program: %s missing in librccl", name); return ELIMREC_E_UNSUPPORTED; }
     ELIMREC_SYM(GetUniqueId, "ncclGetUniqueId") ELIMREC_SYM(CommInitRank, "ncclCommInitRank") ELIMREC_SYM(CommDestroy, "ncclCommDestroy")
+    ELIMREC_SYM(CommCount, "ncclCommCount")
     ELIMREC_SYM(AllGather, "ncclAllGather") ELIMREC_SYM(AllReduce, "ncclAllReduce") ELIMREC_SYM(Send, "ncclSend") ELIMREC_SYM(Recv, "ncclRecv")
     ELIMREC_SYM(GroupStart, "ncclGroupStart") ELIMREC_SYM(GroupEnd, "ncclGroupEnd") ELIMREC_SYM(GetErrorString, "ncclGetErrorString")
 #undef ELIMREC_SYM
@@ -137,6 +139,11 @@ extern "C" int elimrec_comm_create(const void *id128, int world, int rank, void 
     if (rc) { delete c; return rc; }
     *comm_out = c;
     return 0;
+}
+
+extern "C" int elimrec_comm_nranks(void *comm, int *n_out) {
+    ELIMREC_REQUIRE(comm && n_out, "comm_nranks: bad arguments");
+    return rccl_check(g_rccl.CommCount(((Comm *)comm)->comm, n_out), "ncclCommCount");
 }
 
 extern "C" int elimrec_comm_destroy(void *comm) {
@@ -194,12 +201,14 @@ extern "C" int elimrec_comm_all_to_all_v(void *comm, const void *d_send, void *d
     return rc ? rc : rc2;
 }
 
-extern "C" int elimrec_program_create(const elimrec_op *ops, int n_ops, void **prog_out) {
+extern "C" int elimrec_program_create_scoped(const elimrec_op *ops, int n_ops, int system_scope_events, void **prog_out) {
     ELIMREC_REQUIRE(ops && n_ops > 0 && prog_out, "program_create: bad arguments");
     Program *p = new Program();
     p->ops.assign(ops, ops + n_ops);
     int n_events = 0;
-    bool has_collectives = false;
+    // system-scope events: what the caller says (peers or the host write buffers the program's kernels read behind an event), or --
+    // a caller that says nothing -- whenever the list holds one of this library's RCCL calls
+    bool has_collectives = system_scope_events != 0;
     for (const elimrec_op &o : p->ops) {
         if (o.kind == ELIMREC_OP_CALL) {
             if (o.fn < 0 || o.fn >= kNumFns) { delete p; set_error("program_create: unknown function index %d", o.fn); return ELIMREC_E_BADARG; }
@@ -217,6 +226,10 @@ extern "C" int elimrec_program_create(const elimrec_op *ops, int n_ops, void **p
     }
     *prog_out = p;
     return 0;
+}
+
+extern "C" int elimrec_program_create(const elimrec_op *ops, int n_ops, void **prog_out) {
+    return elimrec_program_create_scoped(ops, n_ops, 0, prog_out);
 }
 
 extern "C" int elimrec_program_destroy(void *prog) {

@@ -74,8 +74,8 @@ class Recorded(object):
     """An event recorded on a stream at one point of the step (record()), for a wait() issued LATER from another stream: unlike
     sync(), work enqueued on the signalling stream between the two is not waited for."""
 
-    def __init__(self, event, stream, token):
-        self.event, self.stream, self.token = event, stream, token
+    def __init__(self, event, stream, token, trace=None):
+        self.event, self.stream, self.token, self.trace = event, stream, token, trace
 
 
 def record(stream):
@@ -88,7 +88,7 @@ def record(stream):
     if tr is not None:
         token = sum(1 for it in tr if it[0] == "record")
         tr.append(("record", int(stream.cuda_stream), token))
-    return Recorded(ev, stream, token)
+    return Recorded(ev, stream, token, tr)
 
 
 def wait(waiter, recorded):
@@ -96,7 +96,7 @@ def wait(waiter, recorded):
     waiter.wait_event(recorded.event)
     tr = _lib.load()._trace
     if tr is not None:
-        if recorded.token is None:
+        if recorded.token is None or recorded.trace is not tr:
             raise RuntimeError("program.wait: the event was recorded outside this trace")
         tr.append(("wait", int(waiter.cuda_stream), recorded.token))
 
@@ -119,8 +119,10 @@ def words_of(trace):
 class StepProgram(object):
     """A built program + the patch slots of its per-step values. keep: Python objects the packed pointers refer to."""
 
-    def __init__(self, items, varying, keep):
-        """items: words_of(trace); varying: {(op index, arg index): label}."""
+    def __init__(self, items, varying, keep, system_scope_events=False):
+        """items: words_of(trace); varying: {(op index, arg index): label}. system_scope_events: the step's kernels read, behind
+        one of the program's events, memory that peers or the host write (a multi-rank step): events keep their system-scope
+        fence; otherwise the hand-overs between this device's streams are fence-free."""
         lib = _lib.load()
         table = _fn_table()
         ops, index_of = [], {}
@@ -172,7 +174,8 @@ class StepProgram(object):
                 at += 1
         self._n_patch = n_patch
         handle = ctypes.c_void_p()
-        _lib.check(lib.elimrec_program_create(self._ops, len(ops), ctypes.byref(handle)), "program_create")
+        _lib.check(lib.elimrec_program_create_scoped(self._ops, len(ops), 1 if system_scope_events else 0, ctypes.byref(handle)),
+                   "program_create")
         self._handle = handle
         self._run = lib.elimrec_program_run
 

@@ -419,7 +419,7 @@ class ColumnShardTrainer(object):
                     missing.discard("step")          # the step count travels in the job array native_prologue refreshes
                 if missing:
                     raise ValueError("per-step values %s appear in no call" % sorted(missing))
-                st["programs"][key][parity] = program.StepProgram(items, varying, keep=(ta, tb))
+                st["programs"][key][parity] = program.StepProgram(items, varying, keep=(ta, tb), system_scope_events=self.multi)
             except (ValueError, KeyError, TypeError) as e:
                 # two traces of different STRUCTURE (one of them followed a step of another batch size and carries the extra
                 # stream hand-over of a buffer-set switch): the newer one is kept and paired with the next; anything else, or
@@ -679,7 +679,8 @@ class ColumnShardEngine(object):
         # by the window sweep (csrc/sweep.hip), the item rows by a tile plan of their own; the masked hop, the split-rows hop of
         # the last forward layer and the batch-row kernels keep the whole plan. The hops then carry no tails (Adam, weight
         # gradients): those run as launches of their own, a few tens of microseconds beside hops of a millisecond.
-        self.sweep = bool(tiered and not self.wide and self.w in (16, 32) and slab.sweep_wanted(N, self.dl, adj.nnz))
+        self.sweep = bool(tiered and not self.wide and self.w in (16, 32) and slab.sweep_tiles_xcds(self.ns)
+                          and slab.sweep_wanted(N, self.dl, adj.nnz))
         if self.sweep:
             self.plan.sweep = slab.SweepPlan(self.plan, adj, m.num_users, dev, kw["threshold"], ipw)
             if self.planT is not self.plan:

@@ -459,6 +459,12 @@ def sweep_wanted(n_rows, dl, nnz=None):
     return n_rows * dl * 4 > (256 << 20) and (nnz is None or nnz <= SWEEP_AUTO_MAX_NNZ)
 
 
+def sweep_tiles_xcds(ns):
+    """The window sweep gives every XCD one slab role (elimrec_slab_sweep_hop): the slab count must divide, or be a multiple of,
+    the 8 XCDs. A slice of 96, 48 or 192 columns (3 or 6 slabs) keeps the tile hop."""
+    return (8 % ns == 0) if ns <= 8 else (ns % 8 == 0)
+
+
 class SlabTable(object):
     """[n x (ns*w)] fp32 table stored slab-major in one flat tensor."""
 
@@ -506,7 +512,8 @@ def hop(plan, xin, xout, gs=None, src_mask=None, add=None, add_mask=None, scale=
     0: its partial launch, run as extra workgroups of this launch (fp32 tables, tiered plan: elimrec_slab_hop_bwd_w)."""
     ns, w = xin.ns, xin.w
     gs = choose_groups(ns) if gs is None else gs
-    if plan.sweep is not None and src_mask is None and not seg_only and bwd_w is None and isinstance(xout, SlabTable) and w in (16, 32):
+    if (plan.sweep is not None and src_mask is None and not seg_only and bwd_w is None and isinstance(xout, SlabTable) and w in (16, 32)
+            and sweep_tiles_xcds(xin.ns)):
         # a whole hop of a graph with a swept side: the tile hop over the other side's rows, the window sweep over this side's
         hop(plan.sweep.items, xin, xout, gs=gs, add=add, add_mask=add_mask, scale=scale)
         plan.sweep.hop(xin, xout, add=add, add_mask=add_mask, scale=scale)

@@ -825,6 +825,10 @@ int elimrec_program_fn_count(void);
 const char *elimrec_program_fn_name(int i);
 int elimrec_program_fn_args(int i);
 int elimrec_program_create(const elimrec_op *ops, int n_ops, void **prog_out);
+/* ... with the scope of the RECORD / WAIT events stated by the caller: system_scope_events != 0 keeps the default (system-scope
+ * fence at every record: needed when peers' or the host's writes must be visible behind an event); 0 = fence-free events between
+ * the streams of one device, unless the list holds one of this library's RCCL calls (then system scope regardless). */
+int elimrec_program_create_scoped(const elimrec_op *ops, int n_ops, int system_scope_events, void **prog_out);
 int elimrec_program_run(void *prog, const elimrec_patch *patches, int n_patches);
 int elimrec_program_destroy(void *prog);
 /* RCCL communicator of the ranks of a job (one per process / GPU): rank 0 draws the 128-byte id, the host side hands it to the
@@ -832,6 +836,7 @@ int elimrec_program_destroy(void *prog);
  * already loaded (PyTorch-ROCm's), resolved at run time. */
 int elimrec_comm_unique_id(void *id128);
 int elimrec_comm_create(const void *id128, int world, int rank, void **comm_out);
+int elimrec_comm_nranks(void *comm, int *n_out);      /* ncclCommCount of the communicator: what a benchmark line reports */
 int elimrec_comm_destroy(void *comm);
 /* The step's exchanges on that communicator, enqueued on `stream` (sizes in BYTES; all_reduce: fp32 sum in place;
  * all_to_all_v: `sizes` = HOST int64 [2 x world], bytes to send to peer 0.. then bytes to receive from peer 0.., chunks back

@@ -626,6 +626,20 @@ def test_c4_shape_step_vs_oracle():
     _predict_and_topk_vs_oracle(model, eng._test_oracle, list(range(0, 36656, 570))[:64])
 
 
+def test_sweep_gate_keeps_the_tile_hop_when_the_slabs_do_not_tile_the_xcds(monkeypatch):
+    """recdim 96 = 3 slabs of 32 floats: the window sweep hands every XCD one slab role and refuses 3 (or 6) slabs, so the
+    engine must not take it even when it is forced on (ELIMREC_SWEEP=1) or the slice outgrows the caches -- one step vs the
+    oracle on the tile hop; capacity.plan counts no sweep plan for such a slice either."""
+    from elimrec_amd import capacity, slab
+    monkeypatch.setenv("ELIMREC_SWEEP", "1")
+    model, eng = _shape_step_vs_oracle(500, 1300, 9000, (16, 8, 12), 96, 300)
+    assert (eng.ns, eng.w) == (3, 32) and not eng.sweep and eng.plan.sweep is None
+    assert not slab.sweep_tiles_xcds(3) and not slab.sweep_tiles_xcds(6) and slab.sweep_tiles_xcds(4) and slab.sweep_tiles_xcds(16)
+    with_sweep = capacity.plan(500, 1300, 9000, 64, (16, 8, 12), world=1, batch=300)
+    without = capacity.plan(500, 1300, 9000, 96, (16, 8, 12), world=1, batch=300)
+    assert any("window-sweep" in k for k in with_sweep["components"]) and not any("window-sweep" in k for k in without["components"])
+
+
 def test_c5_shape_scaled_step_and_eval_vs_oracle():
     """BASELINE.json configs[4] scaled to one GPU and an oracle that finishes: |I| = 2 000 000, |U| = 20 000, 16 M
     interactions (users of degree ~800, items of degree ~8: the C5 ratio), recdim 256, three 256-d feature tables.

@@ -37,6 +37,28 @@ def test_bench_starts_its_own_ranks_staged_on_one_gpu():
     assert line["one_gpu_same_global_batch_triplets_per_s"] is None or line["one_gpu_same_global_batch_triplets_per_s"] > 0
 
 
+def test_bench_launch_survives_a_hang():
+    """The first multi-GPU run of a path that has only ever run on one GPU must fail loudly and cheaply (or recover), never sit
+    out the driver's limit. Every rank of a launch is a supervisor that ends its worker after ELIMREC_BENCH_LIMIT seconds:
+    ELIMREC_TEST_HANG=first -- the first attempt's workers hang in front of their first step -- the supervisors kill them,
+    print the ranks' last log lines and run ONE more attempt with torch.distributed's collectives: exit 0 and a JSON line that
+    says so. ELIMREC_TEST_HANG=1 -- every attempt hangs: non-zero exit inside twice the limit (+ start-up), diagnostics on stderr."""
+    import time
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-b-sweep"]
+    env = dict(_bare_env(), ELIMREC_BENCH_LIMIT="45", ELIMREC_TEST_HANG="first")
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["collectives"]["attempt"] == 1 and "no result within" in line["collectives"]["fallback_reason"]
+    assert "ELIMREC_TEST_HANG" in out.stderr and "attempt 0" in out.stderr
+    env["ELIMREC_TEST_HANG"] = "1"
+    env["ELIMREC_BENCH_LIMIT"] = "25"
+    t0 = time.time()
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and time.time() - t0 < 2 * 25 + 120
+    assert "attempt 1" in out.stderr and not any(l.startswith("{") for l in out.stdout.splitlines())
+
+
 # a "[TIE]\tR\tP\tNDCG" line of a TEST pass (main.py:141-143's format), whatever else shares the pipe's line with it
 _TIE = re.compile(r"\[TIE\]\t(\d\S*)\t(\d\S*)\t(\d\S*)")
 
