@@ -673,6 +673,9 @@ def eval_pass(model, cfg, torch):
                          "frac": 6 * flops / best / 1e12 / MFMA_BF16_PEAK_TF, "bf16_flops": 6 * flops,
                          "fp32_equivalent": {"flops": flops, "achieved": flops / best / 1e12, "peak": MFMA_F32_PEAK_TF,
                                              "frac": flops / best / 1e12 / MFMA_F32_PEAK_TF}},
+            "scorer_cross_check": {"what": "every evaluation re-scores its first users with the fp32-MFMA scorer and compares the K returned "
+                                           "scores with the default bf16x3 scorer's (> 1e-6 = mismatch; included in the pass times)",
+                                   "users_checked": evalr.scorer_checked_rows, "scorer_mismatch_rows": evalr.scorer_mismatch_rows},
             "tie_order": {"id (device rule: lowest item id among equal scores; what `seconds` above is)": {"seconds": best},
                           "reference (default: tied rows replayed through the reference's partial_sort_copy)":
                               {"seconds": min(ref_secs), "users_per_s": n_eval / min(ref_secs), "tie_rows_replayed": replayed}},

@@ -158,6 +158,7 @@ class StepProgram(object):
         self.n_ops = len(ops)
         self._ops = (_lib.ProgramOp * len(ops))(*ops)
         self._keep = keep
+        self._items, self._varying = items, dict(varying)
         self.slots = {}                                  # label -> [(op, arg)]
         for (k, j), label in varying.items():
             self.slots.setdefault(label, []).append((index_of[k], j))
@@ -189,6 +190,33 @@ class StepProgram(object):
         rc = self._run(self._handle, p, self._n_patch)
         if rc:
             _lib.check(rc, "program_run")
+
+    def verify(self, trace, known):
+        """A freshly traced ordinary step against this program: the same calls in the same order, every argument word either
+        the one the program holds or -- at a patch slot -- this step's value of that label (known: {label: word}); host-side
+        argument blocks may live elsewhere but must hold the same bytes. Returns None, or what differs (the program freezes
+        every argument that did not change between its two traced steps: anything a step starts to vary later shows here)."""
+        mine, now = self._items, words_of(trace)
+        if len(mine) != len(now):
+            return "the step now issues %d items, the program holds %d" % (len(now), len(mine))
+        ref = self._keep[0] if self._keep else None
+        for k, ((ka, na, xa), (kb, nb, xb)) in enumerate(zip(mine, now)):
+            if ka != kb or na != nb or len(xa) != len(xb):
+                return "item %d is %s %s now, %s %s in the program" % (k, kb, nb, ka, na)
+            for j, (u, v) in enumerate(zip(xa, xb)):
+                label = self._varying.get((k, j))
+                if label is not None:
+                    if known.get(label) != v:
+                        return "argument %d of %s (patched as '%s') is %#x, the step's value of that label is %#x" % (j, na, label, v, known.get(label, 0))
+                    continue
+                if u == v:
+                    continue
+                if ka == "call" and ref is not None:
+                    ha, hb = _host_bytes(ref[k][3][j]), _host_bytes(trace[k][3][j])
+                    if ha is not None and ha == hb:
+                        continue
+                return "argument %d of %s is %#x now, frozen as %#x in the program" % (j, na if na else ka, v, u)
+        return None
 
     def __del__(self):
         try:

@@ -360,7 +360,9 @@ class ColumnShardTrainer(object):
         if st is None:
             import os
             st = self._native = dict(on=os.environ.get("ELIMREC_NATIVE_STEP", "1") != "0", traces={}, programs={}, failed=None,
-                                     steps=0, native_steps=0)
+                                     steps=0, native_steps=0, checks=0,
+                                     # every N-th step of a program is issued the ordinary way under a tracer and compared with it
+                                     check_every=int(os.environ.get("ELIMREC_PROGRAM_CHECK", "0") or 0))
         return st
 
     def _native_eligible(self, users, pos, neg):
@@ -384,9 +386,13 @@ class ColumnShardTrainer(object):
             return self._step_python(users, pos, neg)
         eng = self.engine
         B = int(users.numel())
-        key = (B, tuple(eng.model._block_weights()))
+        g = self.opt.param_groups[0]
+        # everything a step's launches take by VALUE besides the per-step patches: a program is frozen on them
+        key = (B, tuple(eng.model._block_weights()), g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"])
         progs = st["programs"].get(key)
         if progs is not None and progs[eng.cur] is not None:
+            if st["check_every"] and (st["native_steps"] + st["checks"] + 1) % st["check_every"] == 0:
+                return self._step_checked(progs[eng.cur], st, key, users, pos, neg)
             return self._step_native(progs[eng.cur], users, pos, neg, B)
         st["steps"] += 1
         if st["steps"] <= self.NATIVE_WARM or eng._loss_ring is None:
@@ -427,6 +433,30 @@ class ColumnShardTrainer(object):
                 st["mismatch"] = st.get("mismatch", 0) + 1
                 if "traces differ in" not in str(e) or st["mismatch"] >= 8:
                     st["failed"] = str(e)
+        return loss
+
+    def _step_checked(self, prog, st, key, users, pos, neg):
+        """ELIMREC_PROGRAM_CHECK=N: this step launch by launch under a tracer, compared call by call with the program that would
+        have issued it. A difference drops the programs of this batch size (the ordinary path carries on) and keeps the reason."""
+        eng = self.engine
+        m = eng.model
+        B = int(users.numel())
+        if m._ws_key is None or m._ws_key[1] != B or getattr(eng, "_ws_gen_planned", None) != m._ws_gen:
+            return self._step_native(prog, users, pos, neg, B)       # a buffer-set switch adds a stream hand-over: not a step to compare
+        known = dict(users=users.data_ptr(), pos=pos.data_ptr(), neg=neg.data_ptr(), loss=eng._peek_loss_slot(), step=eng.step_count + 1)
+        if self.multi and self.lookup:
+            known["sizes"] = ctypes.addressof(self._lookup_sizes(users, None))
+        m._use_replay = False
+        try:
+            with program.StepTracer() as tr:
+                loss = self._step_python(users, pos, neg)
+        finally:
+            m._use_replay = True
+        st["checks"] += 1
+        what = prog.verify(tr.items, known)
+        if what is not None:
+            st["failed"] = "program check: " + what
+            st["programs"].pop(key, None)
         return loss
 
     def _step_native(self, prog, users, pos, neg, B):

@@ -1450,3 +1450,38 @@ def test_reference_tie_order_is_reproduced_on_request(fixture_name):
     assert np.array_equal(idx_fast.cpu().numpy(), fast_topk)
     replayed = ~_tie_free(sc_fast, K)
     assert np.array_equal(val_fast.cpu().numpy()[replayed], np.take_along_axis(sc_fast, fast_topk.astype(np.int64), 1)[replayed])
+
+
+@pytest.mark.gpu
+def test_evaluator_cross_checks_the_default_scorer_against_the_fp32_scorer(monkeypatch):
+    """Every evaluation re-scores its first users with the fp32-MFMA scorer: on healthy hardware no row differs; a scorer that
+    returns a wrong score (injected here: the first launch's best score overwritten, the signature of round 3's fault) is counted,
+    and the process falls back to the fp32 scorer."""
+    from elimrec_amd import _lib
+    lib = _lib.load()
+    g = load_golden("kwai")                      # recdim 64: the bf16 x 3 scorer's shape
+    model, _ = build_model_from_fixture(g, DEV)
+    _load_cache(model, g)
+    model.fusion_mode, model.predict_type = "rubi", "TIE"
+    evalr = model.test_evaluator.evaluator
+    math0, b0 = int(lib.elimrec_score_get_math()), int(lib.elimrec_score_get_bf16x3())
+    try:
+        lib.elimrec_score_set_math(1)
+        lib.elimrec_score_set_bf16x3(1)
+        model.test()
+        assert evalr.scorer_checked_rows > 0 and evalr.scorer_mismatch_rows == 0
+        real = model.predict_device
+        state = {"n": 0}
+
+        def faulty(*a, **kw):
+            idx, val = real(*a, **kw)
+            state["n"] += 1
+            if state["n"] == 1 and val is not None:
+                val[0, 0] = 1.0
+            return idx, val
+        monkeypatch.setattr(model, "predict_device", faulty)
+        model.test()
+        assert evalr.scorer_mismatch_rows == 1 and int(lib.elimrec_score_get_bf16x3()) == 0
+    finally:
+        lib.elimrec_score_set_math(math0)
+        lib.elimrec_score_set_bf16x3(b0)

@@ -1517,3 +1517,37 @@ def test_wide_form_native_step_program_equals_python_issued_steps(monkeypatch):
     assert np.array_equal(out["0"][0], out["1"][0])
     for k, v in out["0"][1].items():
         assert torch.equal(out["1"][1][k], v), k
+
+
+def test_native_program_periodic_self_check_and_hyper_parameter_changes(monkeypatch):
+    """ELIMREC_PROGRAM_CHECK=N: every N-th step of a native program is issued the ordinary way under a tracer and compared with
+    the program call by call -- same bits as an unchecked run, checks counted, nothing flagged. A learning rate changed
+    mid-run (a scheduler) is NOT frozen into the program: the program is keyed by the optimizer's hyper-parameters, and the
+    run equals one that issues every step from Python."""
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
+    g = load_golden("ml3")
+    # (three copies of one batch in turn: a program is built from two steps whose index tensors are different objects)
+    batches = [tuple(_t(g["step1/%s" % k]) for k in ("users", "pos", "neg")) for _ in range(3)]
+    res = {}
+    for mode in ("native", "checked", "python"):
+        monkeypatch.setenv("ELIMREC_PROGRAM_CHECK", "3" if mode == "checked" else "0")
+        monkeypatch.setenv("ELIMREC_NATIVE_STEP", "0" if mode == "python" else "1")
+        model, _ = build_model_from_fixture(g, DEV)
+        opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+        tr = ColumnShardTrainer(ColumnShardEngine(model), opt)
+        losses = []
+        for k in range(24):
+            if k == 14:
+                opt.param_groups[0]["lr"] = 0.5 * float(g["lr"])
+            losses.append(tr.step(*batches[k % 3]))
+        st = tr._native_state()
+        res[mode] = ([float(x) for x in losses], {k: v.cpu().clone() for k, v in model.state_dict().items()})
+        if mode == "python":
+            assert st["native_steps"] == 0
+        else:
+            assert st["native_steps"] > 8 and st["failed"] is None, st["failed"]
+            assert (st["checks"] >= 2) == (mode == "checked")
+    for mode in ("checked", "python"):
+        assert res[mode][0] == res["native"][0], mode
+        for k, v in res["native"][1].items():
+            assert torch.equal(res[mode][1][k], v), (mode, k)

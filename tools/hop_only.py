@@ -11,6 +11,12 @@ U, I, E = (36656, 1217360, 16 * 720829) if os.environ.get("SHAPE") == "c4" else 
 ds = SyntheticDataset(U, I, E, feat_dims=(4, 4, 4), seed=0)
 adj = create_adj_mat(*ds.get_train_interactions(), U, I, "pre").tocsr()
 N = adj.shape[0]
+if os.environ.get("MIRROR") == "1":         # the two sides swapped (items first): SWEEP=1 then sweeps the ITEM rows over windows of USER rows
+    import numpy as np
+    perm = np.concatenate([np.arange(U, N), np.arange(U)])
+    adj = adj[perm][:, perm].tocsr()
+    adj.sort_indices()
+    U, I = I, U
 if os.environ.get("RELABEL") == "1":        # node ids = the plan's processing order: item rows then user rows, by decreasing degree
     import numpy as np
     deg = np.diff(adj.indptr)

@@ -10,7 +10,7 @@ cfg = Configurator(os.path.join(ROOT, "NeuRec.properties"), default_section="hyp
                    argv=["x", "--data.input.dataset=synthetic", "--alpha=0.5", "--loss=bpr_loss", "--recdim=64", "--verbose=0"])
 Logger.logger = Logger(show_in_console=False)
 ds = SyntheticDataset(36656, 76085, 720829, feat_dims=(128, 128, 128), seed=0)
-B = 2048
+B = int(os.environ.get("B", 2048))
 u, p, n = PairwiseSamplerV2(ds, batch_size=B, device=dev).sample_epoch()
 if os.environ.get("ELIMREC_SHARD_MULTI") == "1":       # the multi-rank step over a one-rank RCCL group
     import torch.distributed as dist
