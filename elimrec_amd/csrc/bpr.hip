@@ -2,6 +2,7 @@
 // IndexBackward, and the row-sparse input gradient of the head Linears.
 // (models/EliMRec.py:129-142,277-297 forward; main.py:99-100 autograd.)
 #include "common.h"
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <rocprim/rocprim.hpp>
@@ -433,6 +434,178 @@ __global__ __launch_bounds__(PLAN_T) void segment_plan_kernel(const int32_t *__r
     }
     if (pb.pad)                                       // unused tail of the active-row list: distinct negative keys
         for (int r = n_act + tid; r < n; r += PLAN_T) active_rows[r] = pb.pad_key + r;
+}
+
+
+// ------------------------------------------------------------------ the same bitmap plan on the whole device
+// Key lists beyond the one-workgroup planner's LDS (more than PLAN_LDS_N slots: batches above 2730 triplets) took the
+// radix-sort path: iota + 6 sort launches + heads + 2 scan launches + finalize + publish + slot map + bitmap + padding, some 22
+// launches of ~5 us each on the step's second stream -- 160 us, twice what the main stream has to do before it needs the plan
+// (a cliff of +0.1 ms per step between B = 2048 and B = 4096). The bitmap algorithm needs no sort: the same phases as
+// segment_plan_kernel, each as one launch over the slots (or one workgroup for the two prefix sums), global atomics instead
+// of LDS atomics, and the member lists put in ascending slot order afterwards (a thread per short list, a wave per long one):
+// 7 launches, the same plan bit for bit.
+__global__ __launch_bounds__(256) void plan_bits_kernel(const int32_t *__restrict__ keys, int64_t n, uint32_t *__restrict__ bm,
+                                                         int32_t *__restrict__ cnt, int32_t *__restrict__ cursor, PlanBatch pb) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j > n) return;
+    cnt[j] = 0;                                                   // counters [0, n] (one past the last possible segment) ...
+    if (j == n) return;
+    cursor[j] = 0;                                                // ... and the fill cursors
+    int k;
+    if (!pb.users) k = keys[j];
+    else {
+        const int64_t b = j / 3;
+        const int which = (int)(j - 3 * b);
+        int64_t idx = which == 0 ? pb.users[b] : (which == 1 ? pb.pos[b] : pb.neg[b]);
+        const int64_t lim = which == 0 ? pb.U : pb.I;
+        if (idx < 0 || idx >= lim) {
+            if (pb.err) atomicOr(pb.err, 1 << which);
+            idx = 0;
+        }
+        k = (int)(which == 0 ? idx : pb.U + idx);
+        if (pb.keys_out) pb.keys_out[j] = k;
+    }
+    atomicOr(&bm[(uint32_t)k >> 5], 1u << (k & 31));
+}
+
+// ranks: pre[] = exclusive prefix of the bitmap words' popcounts, a device-wide scan (rocPRIM over a popcount iterator: a
+// one-workgroup walk over the words and their rows took 51 us at the Tiktok shape). Then, one launch: a thread per bitmap word
+// writes the word's rows into the ascending list of active rows (and the two threads that know them, seg_info), a thread per
+// slot looks its segment up and counts it, the unused tail of the row list gets its padding keys.
+struct PopcOp { __device__ int32_t operator()(uint32_t w) const { return (int32_t)__popc(w); } };
+
+__global__ __launch_bounds__(256) void plan_slots_kernel(const int32_t *__restrict__ keys, int64_t n, const uint32_t *__restrict__ bm,
+                                                          int nw, const int32_t *__restrict__ pre, int split_key, int key_space,
+                                                          int32_t *__restrict__ active_rows, int32_t *__restrict__ seg_info,
+                                                          int32_t *__restrict__ long_list, int32_t *__restrict__ slot_seg,
+                                                          int32_t *__restrict__ cnt, int pad, int32_t pad_key) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int n_act = pre[nw - 1] + __popc(bm[nw - 1]);
+    if (j < nw) {
+        int run = pre[j];
+        uint32_t bits = bm[j];
+        while (bits) {
+            const int b = __ffs(bits) - 1;
+            active_rows[run++] = (int)j * 32 + b;
+            bits &= bits - 1;
+        }
+        if (j == 0) {
+            int n_lo = n_act;
+            if (split_key < key_space) {                            // rank of the first key >= split_key
+                const uint32_t k = (uint32_t)(split_key < 0 ? 0 : split_key);
+                n_lo = pre[k >> 5] + __popc(bm[k >> 5] & ((1u << (k & 31)) - 1u));
+            }
+            seg_info[0] = n_act; seg_info[1] = n_lo;
+            seg_info[2] = 0; seg_info[3] = n_lo; seg_info[4] = n_lo; seg_info[5] = n_act; seg_info[6] = 0; seg_info[7] = n_act;
+            long_list[0] = 0;
+        }
+    }
+    if (j >= n) return;
+    if (pad && j >= n_act) active_rows[j] = pad_key + (int32_t)j;
+    const uint32_t k = (uint32_t)keys[j];
+    const int seg = pre[k >> 5] + __popc(bm[k >> 5] & ((1u << (k & 31)) - 1u));
+    slot_seg[j] = seg;
+    atomicAdd(&cnt[seg], 1);
+}
+
+// (member-list offsets: a device-wide exclusive scan of the counters [0, n], rocPRIM -- a one-workgroup scan walks 60 000
+// counters in global memory one L2 round trip at a time)
+__global__ __launch_bounds__(256) void plan_fill_kernel(const int32_t *__restrict__ slot_seg, int64_t n, const int32_t *__restrict__ seg_start,
+                                                         int32_t *__restrict__ cursor, int32_t *__restrict__ members) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int seg = slot_seg[j];
+    members[seg_start[seg] + atomicAdd(&cursor[seg], 1)] = (int32_t)j;
+}
+
+// ascending slot order inside every member list (the atomics above filled them in arrival order): a thread per short list
+// (insertion sort), then a wave per long list (rank sort through tmp: slots are distinct, the ranks are a permutation)
+__global__ __launch_bounds__(256) void plan_sort_short_kernel(const int32_t *__restrict__ seg_info, const int32_t *__restrict__ seg_start,
+                                                               int32_t *__restrict__ members, int32_t *__restrict__ long_list) {
+    const int sgm = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (sgm >= seg_info[0]) return;
+    const int b = seg_start[sgm], e = seg_start[sgm + 1];
+    if (e - b > PLAN_LONG) {                                      // a long list: into the table plan_sort_long_kernel walks
+        long_list[1 + atomicAdd(&long_list[0], 1)] = sgm;
+        return;
+    }
+    int v[PLAN_LONG];
+#pragma unroll
+    for (int i = 0; i < PLAN_LONG; ++i) v[i] = b + i < e ? members[b + i] : INT32_MAX;
+#pragma unroll
+    for (int i = 1; i < PLAN_LONG; ++i) {                     // a fixed 8-element insertion network on registers
+#pragma unroll
+        for (int q = i; q > 0; --q) {
+            const int lo = min(v[q - 1], v[q]), hi = max(v[q - 1], v[q]);
+            v[q - 1] = lo; v[q] = hi;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PLAN_LONG; ++i)
+        if (b + i < e) members[b + i] = v[i];
+}
+
+// a workgroup per long list: up to 64 members by the first wave (every lane ranks its member against the others with
+// cross-lane reads), up to PLAN_SORT_LDS by a bitonic sort in LDS, longer ones (batches beyond ~150 k triplets) by a rank sort
+// through global scratch
+constexpr int PLAN_SORT_LDS = 8192;
+__global__ __launch_bounds__(256) void plan_sort_long_kernel(const int32_t *__restrict__ long_list, const int32_t *__restrict__ seg_start,
+                                                              int32_t *__restrict__ members, int32_t *__restrict__ tmp) {
+    __shared__ int32_t buf[PLAN_SORT_LDS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int n_long = long_list[0];
+    for (int li = (int)blockIdx.x; li < n_long; li += (int)gridDim.x) {
+        const int sgm = long_list[1 + li];
+        const int b = seg_start[sgm], e = seg_start[sgm + 1], m = e - b;
+        if (m <= 64) {
+            if (tid < 64) {
+                const int v = lane < m ? members[b + lane] : INT32_MAX;
+                int r = 0;
+                for (int q = 0; q < m; ++q) r += __shfl(v, q, 64) < v;
+                if (lane < m) members[b + r] = v;
+            }
+            continue;
+        }
+        if (m <= PLAN_SORT_LDS) {
+            int p2 = 128;
+            while (p2 < m) p2 <<= 1;
+            __syncthreads();                                      // buf of the previous list
+            for (int i = tid; i < p2; i += 256) buf[i] = i < m ? members[b + i] : INT32_MAX;
+            __syncthreads();
+            for (int k = 2; k <= p2; k <<= 1) {
+                for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                    for (int i = tid; i < p2; i += 256) {
+                        const int x = i ^ jj;
+                        if (x > i) {
+                            const int a0 = buf[i], a1 = buf[x];
+                            const bool up = (i & k) == 0;
+                            if ((a0 > a1) == up) { buf[i] = a1; buf[x] = a0; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            for (int i = tid; i < m; i += 256) members[b + i] = buf[i];
+            continue;
+        }
+        for (int i = b + tid; i < e; i += 256) {                 // (rare) rank sort through tmp[b, e), copied back by the next launch
+            const int v = members[i];
+            int r = 0;
+            for (int q = b; q < e; ++q) r += members[q] < v;
+            tmp[b + r] = v;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void plan_copy_long_kernel(const int32_t *__restrict__ long_list, const int32_t *__restrict__ seg_start,
+                                                              int32_t *__restrict__ members, const int32_t *__restrict__ tmp) {
+    const int n_long = long_list[0];
+    for (int li = (int)blockIdx.x; li < n_long; li += (int)gridDim.x) {
+        const int sgm = long_list[1 + li];
+        const int b = seg_start[sgm], e = seg_start[sgm + 1];
+        if (e - b <= PLAN_SORT_LDS) continue;
+        for (int i = b + (int)threadIdx.x; i < e; i += 256) members[i] = tmp[i];
+    }
 }
 
 __global__ void pad_keys_kernel(int32_t *__restrict__ keys, const int32_t *__restrict__ count, int64_t n, int32_t pad_key) {
@@ -909,7 +1082,7 @@ __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__re
 }
 
 struct SegLayout {
-    size_t keys_sorted, vals_in, vals_sorted, flag, segid, seg_start, sort_tmp, scan_tmp, total;
+    size_t keys_sorted, vals_in, vals_sorted, flag, segid, seg_start, long_list, sort_tmp, scan_tmp, total;
     size_t sort_bytes, scan_bytes;
 };
 
@@ -921,11 +1094,17 @@ static int seg_layout(int64_t n, SegLayout &L) {
     e = rocprim::inclusive_scan<rocprim::default_config, const int32_t *, int32_t *, rocprim::plus<int32_t>>(
         nullptr, scan_bytes, nullptr, nullptr, (size_t)n, rocprim::plus<int32_t>(), 0, false);
     if (e != hipSuccess) return check_hip(e, "inclusive_scan(size)");
+    size_t scan2 = 0;
+    e = rocprim::exclusive_scan<rocprim::default_config, const int32_t *, int32_t *, int32_t, rocprim::plus<int32_t>>(
+        nullptr, scan2, nullptr, nullptr, (int32_t)0, (size_t)n + 1, rocprim::plus<int32_t>(), 0, false);
+    if (e != hipSuccess) return check_hip(e, "exclusive_scan(size)");
+    if (scan2 > scan_bytes) scan_bytes = scan2;          // (also covers the scan of <= n bitmap-word popcounts)
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t nb = (size_t)n * sizeof(int32_t);
-    L.keys_sorted = take(nb); L.vals_in = take(nb); L.vals_sorted = take(nb); L.flag = take(nb); L.segid = take(nb);
+    L.keys_sorted = take(nb); L.vals_in = take(nb); L.vals_sorted = take(nb); L.flag = take(nb + sizeof(int32_t)); L.segid = take(nb);
     L.seg_start = take(nb + sizeof(int32_t));
+    L.long_list = take(nb + sizeof(int32_t));
     L.sort_tmp = take(sort_bytes ? sort_bytes : 4); L.scan_tmp = take(scan_bytes ? scan_bytes : 4);
     L.sort_bytes = sort_bytes; L.scan_bytes = scan_bytes; L.total = off;
     return 0;
@@ -1141,6 +1320,45 @@ static int segment_plan_impl(const int32_t *d_keys, int64_t n, int32_t split_key
         hipLaunchKernelGGL(segment_plan_kernel, dim3(1), dim3(PLAN_T), plan_lds, s, d_keys, (int)n, (int)key_space,
                            (int)split_key, d_active_rows, d_seg_info, d_slot_seg, seg_start, vs, d_key_bitmap, pb);
         ELIMREC_LAUNCH_CHECK("segment_plan");
+        return 0;
+    }
+    const int64_t nw_words = (key_space + 31) / 32;
+    static int sorted_only = -1;
+    if (sorted_only < 0) { const char *e = getenv("ELIMREC_PLAN_SORTED"); sorted_only = (e && e[0] == '1') ? 1 : 0; }
+    if (key_space > 0 && nw_words <= n && !sorted_only) {
+        // the bitmap plan, device-wide (see plan_bits_kernel): bm = the caller's key bitmap or the (unused) vals_in array, pre in
+        // keys_sorted, counters in flag, the rank sort's scratch in segid, member lists in vals_sorted -- where segment_apply and
+        // the head backward look for them
+        uint32_t *bm = d_key_bitmap ? d_key_bitmap : (uint32_t *)vin;
+        int32_t *long_list = (int32_t *)(ws + L.long_list);
+        const unsigned nb = (unsigned)((n + 255) / 256);
+        hipError_t e = hipMemsetAsync(bm, 0, (size_t)nw_words * sizeof(uint32_t), s);
+        if (e != hipSuccess) return check_hip(e, "memset(plan bitmap)");
+        hipLaunchKernelGGL(plan_bits_kernel, dim3((unsigned)((n + 256) / 256)), dim3(256), 0, s, d_keys, n, bm, flag, segid, pb);
+        ELIMREC_LAUNCH_CHECK("plan_bits");
+        size_t cb1 = L.scan_bytes;
+        e = rocprim::exclusive_scan(ws + L.scan_tmp, cb1, rocprim::make_transform_iterator((const uint32_t *)bm, PopcOp()), ks, (int32_t)0,
+                                    (size_t)nw_words, rocprim::plus<int32_t>(), s, false);
+        if (e != hipSuccess) return check_hip(e, "exclusive_scan(plan ranks)");
+        hipLaunchKernelGGL(plan_slots_kernel, dim3((unsigned)((std::max<int64_t>(n, nw_words) + 255) / 256)), dim3(256), 0, s,
+                           pb.users ? (const int32_t *)pb.keys_out : d_keys, n, (const uint32_t *)bm, (int)nw_words, (const int32_t *)ks,
+                           (int)split_key, (int)key_space, d_active_rows, d_seg_info, long_list, d_slot_seg, flag, pb.pad, pb.pad_key);
+        ELIMREC_LAUNCH_CHECK("plan_slots");
+        size_t cb2 = L.scan_bytes;
+        e = rocprim::exclusive_scan(ws + L.scan_tmp, cb2, (const int32_t *)flag, seg_start, (int32_t)0, (size_t)n + 1,
+                                    rocprim::plus<int32_t>(), s, false);          // seg_start[n_act .. n] = n
+        if (e != hipSuccess) return check_hip(e, "exclusive_scan(plan)");
+        hipLaunchKernelGGL(plan_fill_kernel, dim3(nb), dim3(256), 0, s, (const int32_t *)d_slot_seg, n, (const int32_t *)seg_start, segid, vs);
+        ELIMREC_LAUNCH_CHECK("plan_fill");
+        hipLaunchKernelGGL(plan_sort_short_kernel, dim3(nb), dim3(256), 0, s, (const int32_t *)d_seg_info, (const int32_t *)seg_start, vs, long_list);
+        ELIMREC_LAUNCH_CHECK("plan_sort_short");
+        hipLaunchKernelGGL(plan_sort_long_kernel, dim3(2048), dim3(256), 0, s, (const int32_t *)long_list, (const int32_t *)seg_start, vs, ks);
+        ELIMREC_LAUNCH_CHECK("plan_sort_long");
+        if (n > PLAN_SORT_LDS) {
+            hipLaunchKernelGGL(plan_copy_long_kernel, dim3(256), dim3(256), 0, s, (const int32_t *)long_list, (const int32_t *)seg_start, vs,
+                               (const int32_t *)ks);
+            ELIMREC_LAUNCH_CHECK("plan_copy_long");
+        }
         return 0;
     }
     if (pb.users) {      // key lists beyond the one-workgroup planner: the keys by their own (range-checked) launch first

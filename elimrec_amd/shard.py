@@ -987,10 +987,16 @@ class ColumnShardEngine(object):
         # against the main stream's 74). Behind the forward's join instead -- under the head kernels, with a second join before the
         # adjoint -- measured 0.2834 against 0.2821 ms at the end of round 4 (three pairs of 300 steps) and was removed
 
+        # a large batch (more than 8192 slots: the device-wide planner, feature blocks of tens of microseconds) makes the second
+        # stream the forward's critical path: the source bits then follow the forward's join instead (cs_forward_rows) and the
+        # adjoint joins them -- a second join for 13 us less in front of the head
+        late_bits = early_bits and R > 8192
+        self._late_bits = late_bits
+
         def plan():       # node ids of the slots, unique active rows + slot map, padded tail: one launch
             ops.batch_plan(users, pos, neg, m.num_users, m.num_items, keys, act, seg, ws["slot_seg"][:R], ws["plan_ws"], err, PAD_KEY,
                            key_bitmap=self.mask if (early_bits or self._sources_in_head()) else None)
-            if early_bits:                             # the planner's bitmap of the active rows IS the first adjoint hop's source
+            if early_bits and not late_bits:           # the planner's bitmap of the active rows IS the first adjoint hop's source
                 slab.source_bits(self.planT, self.hns, self.w, self.hgs, self.mask)    # bitmap (one rank): its per-line bits
 
         def pack():       # the head's weights in MFMA fragment order (they changed in the last optimizer step)
@@ -1133,6 +1139,11 @@ class ColumnShardEngine(object):
         if late_wait:
             m._region("cs_fwd_long%d" % self.cur, (m._ws_gen,), long_rows)
             join_plan()
+            if getattr(self, "_late_bits", False):             # (large batches) the adjoint's source bits: behind the forward's join
+                self._late_bits = False
+                with torch.cuda.stream(self._aux):
+                    m._region("cs_late_bits", (m._ws_gen, R), lambda: slab.source_bits(self.planT, self.hns, self.w, self.hgs, self.mask))
+                self._bits_join = True
         m._region("cs_fwd_rows%d" % self.cur, (m._ws_gen, acts.data_ptr(), R, W, narrow.data_ptr(), late_wait, self._rows_in_head), rows)
         return self.send_f if self.multi else None
 

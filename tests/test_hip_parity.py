@@ -520,11 +520,12 @@ def test_bpr_head_and_segment_reduce_vs_torch_autograd():
 
 
 @pytest.mark.parametrize("n,key_space,hot", [(6144, 112741, 0), (12288, 112741, 700), (300, 97, 40), (1, 5, 0),
-                                             (49152, 600000, 3000)])
+                                             (49152, 600000, 3000), (98304, 112741, 2500), (8193, 8200, 9)])
 def test_one_workgroup_segment_plan_equals_sorted_plan(n, key_space, hot):
-    """The bitmap planner (keys < key_space known) against the radix-sort planner: same active rows, seg_info,
-    slot -> segment map and bit-identical segment sums (member lists in ascending slot order), including member
-    lists long enough for the cooperative rank sort (`hot` slots share one key)."""
+    """The bitmap planner (keys < key_space known; one workgroup up to 8192 slots, the device-wide form of the same phases
+    above that) against the radix-sort planner: same active rows, seg_info, slot -> segment map and bit-identical segment
+    sums (member lists in ascending slot order), including member lists long enough for the cooperative rank sort (`hot`
+    slots share one key)."""
     from elimrec_amd import ops
     gen = torch.Generator().manual_seed(n + key_space)
     keys = torch.randint(0, key_space, (n,), generator=gen, dtype=torch.int32)

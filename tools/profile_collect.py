@@ -1,4 +1,4 @@
-"""gpurun_out/$ROUND/* (tools/profile_round.sh; ROUND defaults to r04) -> profiles/$ROUND_*: kernel-stat CSVs copied, PMC passes
+"""gpurun_out/$ROUND/* (tools/profile_round.sh; ROUND defaults to r05) -> profiles/$ROUND_*: kernel-stat CSVs copied, PMC passes
 summarised. Usage: python tools/profile_collect.py"""
 import collections
 import csv
@@ -9,7 +9,7 @@ import subprocess
 import sys
 
 import os
-RND = os.environ.get("ROUND", "r04")
+RND = os.environ.get("ROUND", "r05")
 O = "gpurun_out/" + RND
 
 
@@ -104,6 +104,28 @@ for src, dst in (("multi_timeline.txt", "multi_rank_path_timeline.txt"), ("step_
     if os.path.exists(O + "/" + src) and "step span" in open(O + "/" + src).read():
         shutil.copy(O + "/" + src, "profiles/%s_%s" % (RND, dst))
 shutil.copy(O + "/stats/b_kernel_stats.csv", "profiles/%s_bench_kernel_stats.csv" % RND)
+if os.path.exists(O + "/bench_kernels_by_grid.csv"):       # the same run with kernels that cover several launch shapes split by grid size
+    shutil.copy(O + "/bench_kernels_by_grid.csv", "profiles/%s_bench_kernels_by_grid.csv" % RND)
+if os.path.exists(O + "/step_table.json"):
+    # the step's table (tools/step_table.py over the step_trace run) + per-launch counter bytes of the PMC passes (kernel + grid match)
+    # + the algorithmic bytes of the hop launches
+    tab = json.load(open(O + "/step_table.json"))
+    fetch, write = read(O + "/fetch"), read(O + "/write")
+    strip = lambda k: k.replace("void ", "").replace("elimrec::", "")
+    byname = {}
+    for k in fetch:
+        base, _, grid = k.partition(" grid=")
+        byname.setdefault(strip(base), []).append((grid, k))
+    for row in tab["kernels"]:
+        cands = byname.get(row["kernel"], [])
+        hit = [k for g, k in cands if g == row["grid"]] or ([k for g, k in cands] if len(cands) == 1 else [])
+        if hit:
+            f, w = fetch[hit[0]].get("FETCH_SIZE", []), write.get(hit[0], {}).get("WRITE_SIZE", [])
+            if f:
+                row["counter_MB_per_launch"] = round((2 * sum(f) / len(f) + (sum(w) / len(w) if w else 0)) * 1024 / 1e6, 2)
+    tab["note"] = ("counter_MB_per_launch = FETCH_SIZE x 2 + WRITE_SIZE of the same kernel and grid in the PMC passes of bench.py (separate "
+                   "rocprofv3 --pmc runs); the trace itself stretches a step by ~3 % against the untraced bench figure")
+    json.dump(tab, open("profiles/%s_step_table.json" % RND, "w"), indent=1)
 shutil.copy(O + "/eval_stats/e_kernel_stats.csv", "profiles/%s_eval_kernel_stats.csv" % RND)
 ev, ef, ew = read(O + "/eval_pmc"), read(O + "/eval_fetch"), read(O + "/eval_write")
 out = {}

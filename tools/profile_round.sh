@@ -1,11 +1,11 @@
-# Round profiles (run on the GPU box through gpurun; outputs under gpurun_out/$ROUND (default r04), summaries are then copied to
+# Round profiles (run on the GPU box through gpurun; outputs under gpurun_out/$ROUND (default r05), summaries are then copied to
 # profiles/ by tools/profile_collect.py).
 # Kernel stats and PMC counters in SEPARATE rocprofv3 runs (no --pmc together with trace domains).
 cd /tmp; export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND:-r04}; rm -rf $O; mkdir -p $O
-B="python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-reference-work --no-b-sweep"
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND:-r05}; rm -rf $O; mkdir -p $O
+B="python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-reference-work --no-b-sweep --no-reduced-precision"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- $B > $O/bench_stats.log 2>&1 < /dev/null
-P="python3 $R/bench.py --steps 9 --warmup 1 --no-cpu-baseline --no-reference-work --no-eval --no-b-sweep"
+P="python3 $R/bench.py --steps 9 --warmup 1 --no-cpu-baseline --no-reference-work --no-eval --no-b-sweep --no-reduced-precision"
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o p -- $P > /dev/null 2>&1 < /dev/null
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o p -- $P > /dev/null 2>&1 < /dev/null
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -o p -- $P > /dev/null 2>&1 < /dev/null
@@ -46,5 +46,21 @@ unset ELIMREC_SHARD_MULTI FEATURE_SHARD
 timeout 400 rocprofv3 --kernel-trace --output-format csv -d $O/step_trace -o s -- python3 $R/tools/step_trace.py 80 > $O/step_trace.log 2>&1 < /dev/null
 T=$(find $O/step_trace -name "*kernel_trace.csv" | head -1)
 [ -n "$T" ] && python3 $R/tools/timeline.py $T 3 > $O/step_timeline.txt 2>&1
+[ -n "$T" ] && python3 $R/tools/step_table.py $T $O/step_table.json 20 > $O/step_table.log 2>&1
+# the bench run's kernels with the names that cover several launch shapes split by grid size (full hops / long-rows hop / the roofline loop)
+T=$(find $O/stats -name "*kernel_trace.csv" | head -1)
+[ -n "$T" ] && python3 - "$T" "$O/bench_kernels_by_grid.csv" <<'PY'
+import collections, csv, sys
+acc = collections.OrderedDict()
+for r in csv.DictReader(open(sys.argv[1])):
+    k = (r["Kernel_Name"].split("(")[0], r.get("Grid_Size", "?"), r.get("Queue_Id", "?"))
+    e = acc.setdefault(k, [0, 0])
+    e[0] += 1; e[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+with open(sys.argv[2], "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Grid_Size", "Queue_Id", "Calls", "TotalDurationNs", "AverageNs"])
+    for (n, g, q), (c, t) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+        w.writerow([n, g, q, c, t, round(t / c)])
+PY
 find $O -name "*kernel_trace.csv" -delete      # large; the stats csv is what gets committed
 ls -R $O | head -50

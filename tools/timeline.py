@@ -4,7 +4,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # a step starts at each segment_plan / batch plan kernel
-starts = [i for i, r in enumerate(rows) if "segment_plan" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if any(k in r["Kernel_Name"] for k in ("segment_plan", "triplet_rows_kernel", "plan_bits_kernel"))]   # (large batches: the multi-launch plan)
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 a, b = starts[-k - 1], starts[-k]
 t0 = int(rows[a]["Start_Timestamp"])
