@@ -926,7 +926,8 @@ __device__ __forceinline__ v4f_ hm16_accumulate_packed(v4f_ acc, const float *__
 // ... or, with peers (split != NULL): the [H | G] rows cut into the `world` column slices a column-sharded job sends them,
 // split[q][slot] = [H[slot][q*dl : (q+1)*dl] | G[slot][q*dl : (q+1)*dl]] (layout [world x n_max x 2*dl]: what
 // elimrec_source_rows_split makes of the compact rows)
-struct SlabSources { float *A, *B; int64_t N; int w, w_shift; float *split; int64_t n_max; int dl; };
+struct SlabSources { float *A, *B; int64_t N; int w, w_shift; float *split; int64_t n_max; int dl;
+                     int pipelined; };     // (pipelined: operand loads of the next MFMA round ahead of this one's; ELIMREC_BWD_PIPE=0 = serial, A/B runs)
 
 struct HeadPackPtrs { const float *f[2]; const float *s[kMaxHeads]; };      // null f[0]: weights read unpacked
 
@@ -1029,30 +1030,8 @@ __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__re
     // tiles t = wave, wave + 4, ... are then the same 16 columns of consecutive blocks: H accumulates in registers
     float hs[4] = {0.f, 0.f, 0.f, 0.f};
     const int last_block = C / d - 1;
-    for (int t = wave; t < n_tiles; t += 4) {
-        const int c0 = t * 16;
-        const int mb = c0 / d;
-        v4f_ acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-        if (pk.f[0] && d == 64) {
-            const int64_t ft = (int64_t)t * 16 * 64 + lane;                       // column tile t of the [C x 64] fusion operand
-            acc = hm16_accumulate_packed(acc, a_row, pk.f[any_user ? 0 : 1] + ft, kq);
-            if (mixed) acc2 = hm16_accumulate_packed(acc2, a_row, pk.f[1] + ft, kq);
-            for (int h = 0; h < S; ++h) {
-                if (hp.mblock[h] != mb) continue;
-                const float *bp = pk.s[h] + (int64_t)((c0 - mb * d) / 16) * 16 * 64 + lane;
-                acc = hm16_accumulate_packed(acc, a_row + (1 + h) * d, bp, kq);
-                if (mixed) acc2 = hm16_accumulate_packed(acc2, a_row + (1 + h) * d, bp, kq);
-            }
-        } else {
-            acc = hm16_accumulate(acc, a_row, (any_user ? W_user : W_item) + c0 + li, C, d, kq);
-            if (mixed) acc2 = hm16_accumulate(acc2, a_row, W_item + c0 + li, C, d, kq);
-            for (int h = 0; h < S; ++h) {
-                if (hp.mblock[h] != mb) continue;
-                const float *Wh = hp.w[h] + (c0 - mb * d) + li;
-                acc = hm16_accumulate(acc, a_row + (1 + h) * d, Wh, d, d, kq);
-                if (mixed) acc2 = hm16_accumulate(acc2, a_row + (1 + h) * d, Wh, d, d, kq);
-            }
-        }
+    // the store part of a finished output tile (c0 = its first column, mb = its table block)
+    auto emit = [&](int c0, int mb, const v4f_ &acc, const v4f_ &acc2) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 4 * kq + r;
@@ -1078,6 +1057,84 @@ __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__re
                 }
             }
         }
+    };
+    if (pk.f[0] && d == 64 && !mixed && C <= 256 && src.pipelined) {
+        // Packed operands, one weight matrix for the whole tile (every tile but the one that straddles the user / item boundary):
+        // wave w owns column tile w of every table block k (t = w + 4k), i.e. up to 8 rounds of 16 MFMAs -- the fusion operand of
+        // block k, then the single-modal head that feeds block k -- each behind one 16-register operand load from L2. The loads of
+        // round r + 1 are issued before the MFMAs of round r (the serial form exposed a round trip per round: the launch's chain
+        // at 2 workgroups per CU). Same MFMAs in the same order on the same accumulators: the same bits.
+        const int M = C / 64;
+        const float *pf = pk.f[any_user ? 0 : 1] + (int64_t)wave * 16 * 64 + lane;      // + 4 kb tiles per block
+        const float *ph[4];
+        const float *ah[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            ph[kb] = nullptr; ah[kb] = a_row;
+            for (int h = 0; h < S; ++h)
+                if (hp.mblock[h] == kb) { ph[kb] = pk.s[h] + (int64_t)wave * 16 * 64 + lane; ah[kb] = a_row + (1 + h) * d; }
+        }
+        float bc[16], bn[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) bc[q] = pf[q * 64];
+        const v4f_ zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            if (kb < M) {
+                // round 1: the fusion operand of block kb (bc holds it); meanwhile this block's head operand, or the next block's
+                const float *nxt = ph[kb] ? ph[kb] : (kb + 1 < M ? pf + (int64_t)4 * (kb + 1) * 16 * 64 : nullptr);
+                if (nxt) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) bn[q] = nxt[q * 64];
+                }
+                v4f_ acc = zero;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a_row[4 * q + kq], bc[q], acc, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 16; ++q) bc[q] = bn[q];
+                if (ph[kb]) {
+                    // round 2: the single-modal head that feeds block kb; meanwhile the next block's fusion operand
+                    if (kb + 1 < M) {
+                        const float *n2 = pf + (int64_t)4 * (kb + 1) * 16 * 64;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) bn[q] = n2[q * 64];
+                    }
+                    const float *ar = ah[kb];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ar[4 * q + kq], bc[q], acc, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) bc[q] = bn[q];
+                }
+                emit((wave + 4 * kb) * 16, kb, acc, zero);
+            }
+        }
+        return;
+    }
+    for (int t = wave; t < n_tiles; t += 4) {
+        const int c0 = t * 16;
+        const int mb = c0 / d;
+        v4f_ acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
+        if (pk.f[0] && d == 64) {
+            const int64_t ft = (int64_t)t * 16 * 64 + lane;                       // column tile t of the [C x 64] fusion operand
+            acc = hm16_accumulate_packed(acc, a_row, pk.f[any_user ? 0 : 1] + ft, kq);
+            if (mixed) acc2 = hm16_accumulate_packed(acc2, a_row, pk.f[1] + ft, kq);
+            for (int h = 0; h < S; ++h) {
+                if (hp.mblock[h] != mb) continue;
+                const float *bp = pk.s[h] + (int64_t)((c0 - mb * d) / 16) * 16 * 64 + lane;
+                acc = hm16_accumulate_packed(acc, a_row + (1 + h) * d, bp, kq);
+                if (mixed) acc2 = hm16_accumulate_packed(acc2, a_row + (1 + h) * d, bp, kq);
+            }
+        } else {
+            acc = hm16_accumulate(acc, a_row, (any_user ? W_user : W_item) + c0 + li, C, d, kq);
+            if (mixed) acc2 = hm16_accumulate(acc2, a_row, W_item + c0 + li, C, d, kq);
+            for (int h = 0; h < S; ++h) {
+                if (hp.mblock[h] != mb) continue;
+                const float *Wh = hp.w[h] + (c0 - mb * d) + li;
+                acc = hm16_accumulate(acc, a_row + (1 + h) * d, Wh, d, d, kq);
+                if (mixed) acc2 = hm16_accumulate(acc2, a_row + (1 + h) * d, Wh, d, d, kq);
+            }
+        }
+        emit(c0, mb, acc, acc2);
     }
 }
 
@@ -1582,9 +1639,13 @@ static int segment_apply_head_bwd_impl(const float *d_rows, int64_t n, int ld, c
             pk.f[0] = d_pack_bwd; pk.f[1] = d_pack_bwd + (int64_t)C * 64;
             for (int h = 0; h < S && h < kMaxHeads; ++h) pk.s[h] = d_pack_bwd + (int64_t)2 * C * 64 + (int64_t)h * 64 * 64;
         }
+        static int pipe = -1;
+        if (pipe < 0) { const char *e = getenv("ELIMREC_BWD_PIPE"); pipe = (e && e[0] == '0') ? 0 : 1; }
+        SlabSources ss = src ? *src : SlabSources{};
+        ss.pipelined = pipe;
         hipLaunchKernelGGL(head_bwd_input16_kernel, dim3((unsigned)((n + HM16 - 1) / HM16)), dim3(256), lds16,
                            (hipStream_t)stream, (const float *)d_reduced, (int64_t)ld, d_active_rows, d_seg_info, n, U, d, C, S, hp,
-                           d_W_user, d_W_item, 1.0f, (float *)nullptr, (int64_t)0, 0, d_compact, seg, pk, src ? *src : SlabSources{});
+                           d_W_user, d_W_item, 1.0f, (float *)nullptr, (int64_t)0, 0, d_compact, seg, pk, ss);
         ELIMREC_LAUNCH_CHECK("segment_apply_head_bwd16");
         return 0;
     }

@@ -66,6 +66,17 @@ class LazyGradParameter(nn.Parameter):
         return _GRAD.__get__(self)
 
 
+def _instances(args, cls, kwargs=None):
+    """The `cls` instances among a torch function's arguments, one level of lists / tuples included (torch.cat([p, q]))."""
+    for a in list(args) + (list(kwargs.values()) if kwargs else []):
+        if isinstance(a, cls):
+            yield a
+        elif isinstance(a, (list, tuple)):
+            for b in a:
+                if isinstance(b, cls):
+                    yield b
+
+
 def _reads_values(func):
     """Does this torch function / Tensor method / attribute getter look at the tensor's elements?"""
     name = getattr(func, "__name__", "")
@@ -81,12 +92,10 @@ class EmbeddingParameter(LazyGradParameter):
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         if _reads_values(func):
-            for a in args:
-                if isinstance(a, EmbeddingParameter):
-                    ctl = a.__dict__.get("_elimrec_ctl")
-                    if ctl is not None and ctl.master_newer:
-                        ctl.sync_params(implicit=True)
-                    break
+            for a in _instances(args, EmbeddingParameter, kwargs):
+                ctl = a.__dict__.get("_elimrec_ctl")
+                if ctl is not None and ctl.master_newer:
+                    ctl.sync_params(implicit=True)
         with torch._C.DisableTorchFunctionSubclass():
             return func(*args, **(kwargs or {}))
 
@@ -98,13 +107,15 @@ class PendingLoss(torch.Tensor):
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
-        me = next((a for a in args if isinstance(a, PendingLoss)), None)
-        ctl = None if me is None else me.__dict__.get("_elimrec_ctl")
-        if ctl is not None:
-            if func is torch.Tensor.backward and args[0] is me and len(args) == 1 and kwargs.get("gradient") is None \
+        reads = _reads_values(func) or func is torch.Tensor.backward
+        for me in _instances(args, PendingLoss, kwargs):
+            ctl = me.__dict__.get("_elimrec_ctl")
+            if ctl is None:
+                continue
+            if func is torch.Tensor.backward and args and args[0] is me and len(args) == 1 and kwargs.get("gradient") is None \
                     and kwargs.get("inputs") is None and ctl.request_backward(me):
                 return None
-            if _reads_values(func) or func is torch.Tensor.backward:
+            if reads:
                 ctl.realise_forward(me)
         with torch._C.DisableTorchFunctionSubclass():
             return func(*args, **kwargs)

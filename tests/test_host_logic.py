@@ -220,3 +220,81 @@ def test_torch_ops_library_registers_every_op():
         assert hasattr(ns, name), name
     with pytest.raises(NotImplementedError):
         ns.linear_fwd(torch.zeros(4, 4), torch.zeros(4, 4), None)
+
+
+def test_plugin_tensor_classes_route_reads_through_the_controller():
+    """elimrec_amd/plugin.py without a GPU: the parameter and loss classes behind `bpr_loss -> backward -> optimizer.step`.
+    Reading a VALUE of an embedding parameter (directly, nested in a list, through .data) asks the controller to write the
+    engine's master copy back first; metadata does not. `.grad` materialises a deferred backward on first read; assigning
+    None (zero_grad) cancels it. A pending loss takes `backward()` without arguments as a request and makes itself real for
+    every other use."""
+    import torch
+    from torch import nn
+    from elimrec_amd.plugin import EmbeddingParameter, LazyGradParameter, PendingLoss
+
+    class Ctl(object):
+        def __init__(self):
+            self.master_newer, self.synced, self.deferred, self.materialised, self.cancelled = True, 0, False, 0, 0
+            self.requested, self.realised, self.grads_set = 0, 0, False
+
+        def sync_params(self, implicit=False):
+            self.synced += 1
+            self.master_newer = False
+
+        def grads_deferred(self):
+            return self.deferred
+
+        def materialise_grads(self):
+            self.materialised += 1
+            self.deferred = False
+
+        def cancel_backward(self):
+            self.cancelled += 1
+
+        def request_backward(self, handle):
+            self.requested += 1
+            return True
+
+        def realise_forward(self, handle=None):
+            self.realised += 1
+
+    ctl = Ctl()
+    emb = nn.Embedding(5, 4)
+    p = EmbeddingParameter(emb.weight.data)
+    emb.weight = p
+    p.__dict__["_elimrec_ctl"] = ctl
+    assert isinstance(emb.weight, nn.Parameter) and [n for n, _ in emb.named_parameters()] == ["weight"]
+    assert p.shape == (5, 4) and p.data_ptr() and p.numel() == 20 and p.device.type == "cpu" and ctl.synced == 0     # metadata
+    _ = p.sum()
+    assert ctl.synced == 1 and not ctl.master_newer
+    _ = p.sum()
+    assert ctl.synced == 1                                  # nothing newer: no second write-back
+    ctl.master_newer = True
+    _ = torch.cat([p, p])                                   # nested in a list
+    assert ctl.synced == 2
+    ctl.master_newer = True
+    _ = p.data
+    assert ctl.synced == 3
+    ctl.master_newer = True
+    _ = emb.state_dict()["weight"]                          # state_dict detaches the parameter: a read
+    assert ctl.synced == 4
+    w = LazyGradParameter(torch.ones(3))
+    w.__dict__["_elimrec_ctl"] = ctl
+    assert w.grad is None and ctl.materialised == 0
+    ctl.deferred = True
+    assert w.grad is None and ctl.materialised == 1         # a deferred backward becomes real on first read
+    w.grad = torch.zeros(3)
+    assert ctl.grads_set and w.grad is not None and ctl.cancelled == 0
+    w.grad = None                                           # what zero_grad() does
+    assert ctl.cancelled == 1 and w.grad is None
+    opt = torch.optim.SGD([w, p], lr=0.1)                   # a torch optimizer sees ordinary parameters
+    w.grad = torch.ones(3)
+    opt.step()
+    assert torch.allclose(w.detach(), torch.full((3,), 0.9))
+    loss = torch.zeros((), requires_grad=True).clone().as_subclass(PendingLoss)
+    loss.__dict__["_elimrec_ctl"] = ctl
+    assert loss.shape == () and loss.requires_grad and ctl.realised == 0        # metadata
+    assert loss.backward(retain_graph=True) is None and ctl.requested == 1      # a request, not an autograd pass
+    assert loss.item() == 0.0 and ctl.realised == 1
+    assert float(torch.stack([loss, loss]).sum()) == 0.0 and ctl.realised >= 2  # nested too
+    assert type(loss.detach()) is torch.Tensor
