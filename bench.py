@@ -616,11 +616,30 @@ def pmc_limiter(algorithmic_bytes):
     t = d.get("propagation_hop_traffic_bytes")
     if not t:
         return None
-    return ("the launch moves %.2fx its algorithmic bytes past L2 (every XCD pulls its share of the table through a 4 MB L2 on a random "
+    text = ("the launch moves %.2fx its algorithmic bytes past L2 (every XCD pulls its share of the table through a 4 MB L2 on a random "
             "graph), L2 hit rate %.2f; on the CU side TA busy %.0f %% and L1 stalled on pending misses %.0f %% of the launch "
             "(profiles/%s; DESIGN.md section 3)" % (t / algorithmic_bytes, d.get("propagation_hop_L2_hit_rate", float("nan")),
                                                     100 * d.get("propagation_hop_TA_busy_frac", float("nan")),
                                                     100 * d.get("propagation_hop_TCP_pending_stall_frac", float("nan")), name))
+    return text + hop_forms_note()
+
+
+def hop_forms_note():
+    """The other launch form of the hop tried at this shape (the window sweep, csrc/sweep.hip: one side's rows accumulated in LDS
+    over L2-sized windows of the other side), from the committed profile of that experiment."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_hop_forms.json")))
+    if not paths:
+        return ""
+    try:
+        with open(paths[-1]) as f:
+            forms = json.load(f)["forms"]
+        us = lambda form: float([l for l in forms[form]["timing"] if l.endswith("us per hop")][0].split()[0])
+        return ("; the window-sweep form of the hop at this shape (user rows in LDS over windows of item rows, item rows by their own tile "
+                "hop): %.1f us against %.1f us for the tile hop and no fewer bytes past L2 -- not taken (profiles/%s)"
+                % (us("sweep"), us("tile"), os.path.basename(paths[-1])))
+    except Exception:
+        return ""
 
 
 def eval_pass(model, cfg, torch):

@@ -51,9 +51,16 @@ T=$(find $O/step_trace -name "*kernel_trace.csv" | head -1)
 T=$(find $O/stats -name "*kernel_trace.csv" | head -1)
 [ -n "$T" ] && python3 - "$T" "$O/bench_kernels_by_grid.csv" <<'PY'
 import collections, csv, sys
+def _grid(r):
+    if r.get("Grid_Size"):
+        return str(r["Grid_Size"])
+    try:
+        return str(int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]))
+    except (KeyError, ValueError):
+        return "?"
 acc = collections.OrderedDict()
 for r in csv.DictReader(open(sys.argv[1])):
-    k = (r["Kernel_Name"].split("(")[0], r.get("Grid_Size", "?"), r.get("Queue_Id", "?"))
+    k = (r["Kernel_Name"].split("(")[0], _grid(r), r.get("Queue_Id", "?"))
     e = acc.setdefault(k, [0, 0])
     e[0] += 1; e[1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
 with open(sys.argv[2], "w") as f:

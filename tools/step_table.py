@@ -3,6 +3,18 @@ last `n` of the trace), every (kernel, grid, queue) with its launches per step a
 the gaps between its launches, and the step span they add up to. Kernels that share a name (full hops / the long-rows hop) are split
 by grid size. usage: step_table.py <kernel_trace.csv> <out.json> [n_steps]"""
 import collections, csv, json, sys
+
+
+def _grid(r):
+    """Work-items of the launch as the counter csv names them (Grid_Size = X * Y * Z of the kernel-trace csv)."""
+    if r.get("Grid_Size"):
+        return str(r["Grid_Size"])
+    try:
+        return str(int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]))
+    except (KeyError, ValueError):
+        return "?"
+
+
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 20
@@ -13,7 +25,7 @@ span = (int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"])) / 1e3
 per = collections.OrderedDict()
 main_q = collections.Counter(r.get("Queue_Id", "?") for r in rows[a:b] if "sell_tier" in r["Kernel_Name"]).most_common(1)[0][0]
 for r in rows[a:b]:
-    key = (r["Kernel_Name"].split("(")[0].replace("void ", "").replace("elimrec::", ""), r.get("Grid_Size", "?"), r.get("Queue_Id", "?"))
+    key = (r["Kernel_Name"].split("(")[0].replace("void ", "").replace("elimrec::", ""), _grid(r), r.get("Queue_Id", "?"))
     e = per.setdefault(key, [0, 0.0])
     e[0] += 1
     e[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
