@@ -368,6 +368,7 @@ class ColumnShardTrainer(object):
     def _native_eligible(self, users, pos, neg):
         eng = self.engine
         if not (self._hip_engine and not self.profile_kernels and eng.kernel_events is None and not eng.keep_grad
+                and not getattr(eng, "word_train", False)        # (its gradient path mixes torch ops into the step)
                 and eng.model.mm_fusion_mode == "concat" and eng.model._use_replay
                 and all(t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() for t in (users, pos, neg))
                 and users.numel() == pos.numel() == neg.numel()):
@@ -783,6 +784,20 @@ class ColumnShardEngine(object):
                     ws["fold"] = None                # the full tables are gone: every consumer goes through the shards
             self.lookup_row_bytes = self.fshard.row_bytes
             self._lookup_bufs = {}
+        # data set "tiktok": word_embedding keeps receiving the gradient the reference's retained graph gives it (default), or stays
+        # frozen (--word_embedding=frozen)
+        self.word_train = False
+        if hasattr(m, "word_embedding") and m.dataset_name == "tiktok" and "feature_modalities" not in m.config:
+            mode = str(m.config["word_embedding"]) if "word_embedding" in m.config else "train"
+            if mode not in ("train", "frozen"):
+                raise ValueError("word_embedding must be train or frozen (got %r)" % mode)
+            if mode == "train" and (world > 1 or self.lean or self.wide or self.multi):
+                from .logger import Logger
+                Logger.info("word_embedding stays frozen: its gradient (the reference's retained graph) is computed on one rank with "
+                            "regular tables only")
+            elif mode == "train":
+                self._word_setup()
+                self.word_train = True
         self.load_from_model()
         m._slab_engine = self
         m._regions = {}                  # recorded launches of an engine attached earlier hold ITS tables' addresses
@@ -1331,6 +1346,8 @@ class ColumnShardEngine(object):
         self._grads = m._backward_batch_rows(ws, scale, ws["grad_rows"], R, head_only=True, pack_bwd=pack_bwd,
                                              merge=merge, defer_reduce=defer, sources=sources)
         self._reduce = (m._bwd_w_reduce, 0 if defer == "all" else 1) if defer else None
+        if self.word_train:
+            self._word_grad(ws, R)
         wg = ws["flat_grad"][ws["tail_off"]:]
         if not self.multi and not self.wide:        # one rank owns every column: the merge reads the dOut rows themselves
             return ws["dOutR"][:R].view(1, R, m.C), wg
@@ -1545,10 +1562,11 @@ class ColumnShardEngine(object):
 
     # ------------------------------------------------------------------ row-sharded constants: the distributed fold
     @torch.no_grad()
-    def _horner_mean(self, x0_rows):
+    def _horner_mean(self, x0_rows, plan=None):
         """mean_k A^k X0 of a row-major [N x cols] table with the engine's own hop kernels: t <- X0 + A t, L times, the last with
-        the 1/(L+1) scale. cols is padded to the column count per slab group of the engine's plan (the wave-tile plan is laid
-        out for that many lanes per row piece)."""
+        the 1/(L+1) scale (plan: the matrix's wave-tile plan, default the adjacency's; its transpose's gives the adjoint).
+        cols is padded to the column count per slab group of the engine's plan (the wave-tile plan is laid out for that many
+        lanes per row piece)."""
         m, N, L = self.model, x0_rows.shape[0], self.model.n_layers
         per_group = (self.hns // self.hgs) * self.w                  # columns one lane group covers
         cols = x0_rows.shape[1]
@@ -1561,9 +1579,51 @@ class ColumnShardEngine(object):
         t = x0
         for k in range(L):
             dst = a if t is not a else b
-            slab.hop(self.plan, t, dst, gs=gs, add=x0, scale=1.0 / (L + 1) if k == L - 1 else 1.0)
+            slab.hop(self.plan if plan is None else plan, t, dst, gs=gs, add=x0, scale=1.0 / (L + 1) if k == L - 1 else 1.0)
             t = dst
         return t.dense()[:, :cols]
+
+    # ------------------------------------------------------------------ the tiktok data set's word embeddings
+    def _word_setup(self):
+        """models/EliMRec.py:371-378 + main.py:100 (`retain_graph=True`): on the data set "tiktok" t_feat is built ONCE from
+        word_embedding (scatter-mean of the items' words) and never again, but its graph is retained -- so every step's backward
+        still reaches word_embedding, and Adam (with its weight decay) keeps moving a parameter nothing reads. To train the
+        checkpoint the reference trains, the engine does the same: per step, dL/dt_feat = (mean_k (A^T)^k dOut_t)[items] W_t
+        (one more adjoint propagation of a d-column table, with the hop kernels) and dL/dword_embedding = the scatter-mean's
+        adjoint, a fixed sparse matrix [words x items] of 1 / (words of the item) applied by the deterministic row kernel
+        (elimrec_block_spmm). `--word_embedding=frozen` skips all of it (losses and scores are the same either way: nothing reads
+        the parameter after start-up). One rank, regular tables."""
+        import scipy.sparse as sp
+        m = self.model
+        words = m.dataset.words_tensor
+        it, wd = words[0].numpy().astype(np.int64), words[1].numpy().astype(np.int64)
+        cnt = np.bincount(it, minlength=m.num_items).astype(np.float64)
+        vals = (1.0 / cnt[it]).astype(np.float32)
+        V = m.word_embedding.weight.shape[0]
+        mat = sp.csr_matrix((vals, (wd, it)), shape=(V, m.num_items))       # duplicate (word, item) pairs add up, as the mean's adjoint does
+        dev = m._device()
+        self._word_csr = ops.Csr.from_scipy(mat, dev, C=m.word_embedding.weight.shape[1])
+        N, d = m.num_users + m.num_items, m.latent_dim
+        self._word_full = torch.zeros(N + 1, d, dtype=torch.float32, device=dev)          # + one row that collects the unused slots
+        self._word_dF = torch.empty(m.num_items, m.word_embedding.weight.shape[1], dtype=torch.float32, device=dev)
+
+    @torch.no_grad()
+    def _word_grad(self, ws, R):
+        m = self.model
+        d, U = m.latent_dim, m.num_users
+        N = U + m.num_items
+        k = m._mods.index("t")
+        blk = ws["dOutR"][:R, (k + 1) * d:(k + 2) * d]
+        act = ws["active_rows"][:R].long()
+        full = self._word_full
+        full.zero_()
+        full.index_copy_(0, torch.where(act >= 0, act, torch.full_like(act, N)), blk)       # active rows are listed once
+        g_items = self._horner_mean(full[:N], plan=self.planT)[U:].contiguous()            # [I x d]: dL / d(F_t W_t^T + b_t)
+        wt = ws["live_views"]["t_dense.weight"]                                            # [d x D_t]
+        ops.linear_fwd_batched([(g_items, wt.t().contiguous(), None, self._word_dF)])      # dL/dt_feat = g_items . W_t
+        gview = ws["grad_views"]["word_embedding.weight"]
+        ops.block_spmm(self._word_csr, self._word_dF, Xout=gview)
+        self._grads["word_embedding.weight"] = gview
 
     @torch.no_grad()
     def _fold_sharded(self, owners, frank):

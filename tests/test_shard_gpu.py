@@ -250,16 +250,19 @@ def test_trainer_on_a_device_built_plan_matches_the_reference_fixture(name):
         assert np.abs(sd[k].cpu().numpy() - v).max() < 2e-5, k
 
 
-def test_tiktok_word_bag_fixture_on_the_engine():
+@pytest.mark.parametrize("mode", ["train", "frozen"])
+def test_tiktok_word_bag_fixture_on_the_engine(mode):
     """The data set "tiktok" (models/EliMRec.py:371-378; fixture `tiktok`, captured from the reference with a scatter-mean stub): the
     model builds t_feat from the loaded word_embedding.weight and the items' word lists exactly as the reference does (1e-7, not
-    normalised), the trainer reproduces the reference's three losses and every parameter after Adam -- except word_embedding.weight,
-    which the reference keeps updating through its retained graph although nothing reads it again, and which stays a frozen
-    checkpoint key here (stated deviation 3; the reference moves it by <= lr per step, pinned in tests/test_oracle_golden.py)."""
+    normalised), the trainer reproduces the reference's three losses and every parameter after Adam -- INCLUDING
+    word_embedding.weight, which the reference keeps updating through its retained graph (main.py:100) although nothing reads it
+    again: the engine computes that gradient too (default; first-step gradient 1e-4 row-wise, the rows of the words in use after
+    three Adam steps 2e-5). `--word_embedding=frozen` leaves it a frozen
+    checkpoint key -- the same losses, parameters and scores otherwise."""
     from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, EliMRec, FusedAdam
     from helpers import FixtureDataset, fixture_argv
     g = load_golden("tiktok")
-    model = EliMRec(make_config(fixture_argv(g)), FixtureDataset(g))
+    model = EliMRec(make_config(fixture_argv(g) + ["--word_embedding=%s" % mode]), FixtureDataset(g))
     model.load_state_dict({k: torch.from_numpy(v.copy()) for k, v in sub(g, "init").items() if "@" not in k}, strict=True)
     assert (model.t_feat.numpy() - g["t_feat"]).__abs__().max() < 1e-7            # built from the LOADED word embeddings
     with torch.no_grad():
@@ -267,19 +270,31 @@ def test_tiktok_word_bag_fixture_on_the_engine():
             getattr(model, m + "_feat").copy_(torch.from_numpy(g[m + "_feat"]))
     model = model.to(DEV)
     opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
-    tr = ColumnShardTrainer(ColumnShardEngine(model), opt)
+    eng = ColumnShardEngine(model)
+    tr = ColumnShardTrainer(eng, opt)
+    assert eng.word_train == (mode == "train")
     steps = int(g["steps"])
+    rows = g["word_rows"]
     for t in range(1, steps + 1):
         loss = tr.step(*(_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg")))
         assert abs(float(loss) - float(g["step%d/loss" % t])) < 1e-5, t
-    tr.engine.sync_to_model()
+        if t == 1 and mode == "train":
+            assert_grad_close(eng._grads["word_embedding.weight"].cpu().numpy()[rows], g["grad1/word_embedding.weight@rows"], "word_embedding.weight")
     sd = model.state_dict()
     for k, v in sub(g, "after%d" % steps).items():
         if "@" in k:
             continue
         if k == "word_embedding.weight":
-            assert np.array_equal(sd[k].cpu().numpy(), g["init/" + k])               # frozen here
-            assert np.abs(v[g["word_rows"]] - g["init/" + k][g["word_rows"]]).max() < 1.05 * steps * float(g["lr"])   # the deviation's size
+            mine = sd[k].cpu().numpy()
+            if mode == "frozen":
+                assert np.array_equal(mine, g["init/" + k])
+                assert np.abs(v[rows] - g["init/" + k][rows]).max() < 1.05 * steps * float(g["lr"])   # the deviation's size
+            else:
+                assert np.abs(mine[rows] - v[rows]).max() < 2e-5
+                # (the fixture keeps the rows of the words in use; the others are loaded as zeros here and stay zero -- weight
+                # decay of zero -- where the reference's own rows decay by <= lr per step: `@unused_max_move`)
+                unused = np.setdiff1d(np.arange(mine.shape[0]), rows)
+                assert np.abs(mine[unused]).max() == 0.0
             continue
         assert np.abs(sd[k].cpu().numpy() - v).max() < 2e-5, k
     # predict() on the tables of the last forward, as for the other fixtures
