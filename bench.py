@@ -329,6 +329,8 @@ def main():
         torch.cuda.synchronize()
         plan_ms = 1e3 * (time.perf_counter() - t_plan) / len(batches)
 
+    trainer.prestage(batches)          # every step's triplets are resident (sampled above): planners may run ahead of the step before
+
     hang = os.environ.get("ELIMREC_TEST_HANG", "")
     if args.worker and (hang == "1" or (hang == "first" and os.environ.get("ELIMREC_BENCH_ATTEMPT", "0") == "0")):
         sys.stderr.write("[rank %d] ELIMREC_TEST_HANG: sleeping in front of the first step\n" % rank)
@@ -551,6 +553,7 @@ def one_gpu_at_batch(args, device, cfg, ds, Bg, torch, steps=20, warmup=5):
         pools.append(sampler.sample_epoch())
     U_, P_, N_ = (torch.cat([p[i] for p in pools]) for i in range(3))
     bs = [(U_[i * Bg:(i + 1) * Bg], P_[i * Bg:(i + 1) * Bg], N_[i * Bg:(i + 1) * Bg]) for i in range(steps + warmup)]
+    tr.prestage(bs)
     for b in bs[:warmup]:
         tr.step(*b)
     torch.cuda.synchronize()
@@ -573,6 +576,7 @@ def batch_sweep(trainer, sampler, pools, B0, torch, sizes=(2048, 4096, 8192, 163
             pools.append(sampler.sample_epoch())
         U_, P_, N_ = (torch.cat([p[i] for p in pools]) for i in range(3))
         bs = [(U_[i * B:(i + 1) * B], P_[i * B:(i + 1) * B], N_[i * B:(i + 1) * B]) for i in range(steps + warmup)]
+        trainer.prestage(bs)
         for b in bs[:warmup]:
             trainer.step(*b)
         torch.cuda.synchronize()
@@ -712,6 +716,7 @@ def reduced_precision_line(args, device, cfg, batches, first_losses, torch, step
     opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
     eng = ColumnShardEngine(model, feature_dtype="bf16")
     tr = ColumnShardTrainer(eng, opt)
+    tr.prestage(batches)
     n_cmp = len(first_losses)
     mine = [tr.step(*batches[i]) for i in range(n_cmp)]
     a = torch.stack([x.detach() for x in mine]).cpu()

@@ -126,7 +126,7 @@ class _TablesFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, *params):
         ctx.model, ctx.params, ctx.names = model, params, model._param_names
-        ws = model._workspace(model._ws_key[1] if model._ws_key else 1)
+        ws = model._workspace(model._ws_key[1] if model._ws_key else 1, parity=model._ws_key[3] if model._ws_key else 0)
         model._slab_fwd = False
         model._fwd_gen = getattr(model, "_fwd_gen", 0) + 1
         ctx.gen = model._fwd_gen
@@ -460,22 +460,27 @@ class EliMRec(BasicModel):
                                "for MI355X; move the model to a GPU (`.to('cuda:0')`). There is no CPU fallback." % dev)
         return dev
 
-    def _workspace(self, B, bwd_rows=None):
+    def _workspace(self, B, bwd_rows=None, parity=0):
         """Device buffers for batch size B. bwd_rows = number of gradient rows the backward pass
-        will be fed (3*B locally; 3*B*world_size when row gradients are all-gathered)."""
+        will be fed (3*B locally; 3*B*world_size when row gradients are all-gathered). parity: the column-shard engine keeps TWO
+        sets of the batch-dependent buffers per batch size and alternates them step by step, so that the planner of step
+        t + 1 never writes what a kernel of step t still reads (shard.py: cs_plan)."""
         dev = self._require_gpu()
         bwd_rows = 3 * int(B) if bwd_rows is None else int(bwd_rows)
-        if self._ws is not None and self._ws_key[:2] == (str(dev), int(B)) and self._ws_key[2] >= bwd_rows:
+        parity = int(parity)
+        if (self._ws is not None and self._ws_key[:2] == (str(dev), int(B)) and self._ws_key[2] >= bwd_rows
+                and self._ws_key[3] == parity):
             return self._ws
         # the batch-dependent buffers of every batch size seen so far are kept (an epoch ends with a ragged batch: B ->
         # tail -> B would otherwise reallocate twice per epoch and invalidate every recorded region)
         sets = self.__dict__.setdefault("_ws_sets", {})
-        hit = sets.get((str(dev), int(B)))
+        hit = sets.get((str(dev), int(B), parity))
         if hit is not None and self._ws is not None and self._ws_key[0] == str(dev) and hit[0] >= bwd_rows:
             self._ws.update(hit[2])
-            self._ws_key, self._ws_gen = (str(dev), int(B), hit[0]), hit[1]
+            self._ws_key, self._ws_gen = (str(dev), int(B), hit[0], parity), hit[1]
             return self._ws
-        key = (str(dev), int(B), bwd_rows)
+        key = (str(dev), int(B), bwd_rows, parity)
+        self._ws_new = getattr(self, "_ws_new", 0) + 1           # a set allocated (and zero-filled on the CURRENT stream) just now
         N, C, Cy, d = self.num_users + self.num_items, self.C, self.Cy, self.latent_dim
         f32 = dict(dtype=torch.float32, device=dev)
         ws = self._ws if (self._ws is not None and self._ws_key[0] == key[0]) else {}
@@ -548,7 +553,7 @@ class EliMRec(BasicModel):
         self._ws, self._ws_key = ws, key
         batch_keys_ = ("loss_rows", "grad_rows", "keys", "keys_scratch", "slot_seg", "OutAct", "YAct", "active_rows", "dY",
                        "seg_info", "plan_ws", "dOutR", "bwd_w_rows")
-        self.__dict__.setdefault("_ws_sets", {})[(key[0], key[1])] = (bwd_rows, self._ws_gen, {k: ws[k] for k in batch_keys_ if k in ws})
+        self.__dict__.setdefault("_ws_sets", {})[(key[0], key[1], parity)] = (bwd_rows, self._ws_gen, {k: ws[k] for k in batch_keys_ if k in ws})
         return ws
 
     @torch.no_grad()
@@ -1069,7 +1074,7 @@ class EliMRec(BasicModel):
             self._last_tables = _TablesFn.apply(self, *self._all_params())
             return self._last_tables
         self._slab_fwd = False
-        ws = self._workspace(self._ws_key[1] if self._ws_key else 1)
+        ws = self._workspace(self._ws_key[1] if self._ws_key else 1, parity=self._ws_key[3] if self._ws_key else 0)
         self._compute_tables(ws)
         self._last_tables = (self.all_users, self.all_items)
         return self._last_tables
@@ -1081,7 +1086,7 @@ class EliMRec(BasicModel):
         U, I, d, Cy = self.num_users, self.num_items, self.latent_dim, self.Cy
         N = U + I
         dev = self._device()
-        ws = self._workspace(self._ws_key[1] if self._ws_key else 1, N)
+        ws = self._workspace(self._ws_key[1] if self._ws_key else 1, N, parity=self._ws_key[3] if self._ws_key else 0)
         rows = torch.zeros(N, Cy, dtype=torch.float32, device=dev)
         if g_users is not None:
             rows[:U, :d] = g_users

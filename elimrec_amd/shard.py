@@ -101,6 +101,11 @@ class ColumnShardTrainer(object):
         if self.lookup:
             self.xgmi_bytes["all_to_all_lookup"] = 0
 
+    def prestage(self, batches):
+        """The (users, pos, neg) tensors of the coming steps, complete on the device now (ColumnShardEngine.prestage)."""
+        if self._hip_engine:
+            self.engine.prestage(list(batches))
+
     def set_optimizer(self, optimizer):
         """The optimizer whose hyper-parameters and projection-weight state the engine's Adam launches use (a trainer made
         before the caller's optimizer existed: plugin.py)."""
@@ -389,7 +394,8 @@ class ColumnShardTrainer(object):
         B = int(users.numel())
         g = self.opt.param_groups[0]
         # everything a step's launches take by VALUE besides the per-step patches: a program is frozen on them
-        key = (B, tuple(eng.model._block_weights()), g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"])
+        key = (B, tuple(eng.model._block_weights()), g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"],
+               eng.prestaged_ok(users, pos, neg))          # (... and the planner's place in the second stream's order)
         progs = st["programs"].get(key)
         if progs is not None and progs[eng.cur] is not None:
             if st["check_every"] and (st["native_steps"] + st["checks"] + 1) % st["check_every"] == 0:
@@ -442,8 +448,8 @@ class ColumnShardTrainer(object):
         eng = self.engine
         m = eng.model
         B = int(users.numel())
-        if m._ws_key is None or m._ws_key[1] != B or getattr(eng, "_ws_gen_planned", None) != m._ws_gen:
-            return self._step_native(prog, users, pos, neg, B)       # a buffer-set switch adds a stream hand-over: not a step to compare
+        if B not in eng._bufs or getattr(eng, "_ws_new_seen", None) != getattr(m, "_ws_new", 0):
+            return self._step_native(prog, users, pos, neg, B)       # fresh buffers add a stream hand-over: not a step to compare
         known = dict(users=users.data_ptr(), pos=pos.data_ptr(), neg=neg.data_ptr(), loss=eng._peek_loss_slot(), step=eng.step_count + 1)
         if self.multi and self.lookup:
             known["sizes"] = ctypes.addressof(self._lookup_sizes(users, None))
@@ -463,8 +469,8 @@ class ColumnShardTrainer(object):
     def _step_native(self, prog, users, pos, neg, B):
         eng = self.engine
         m = eng.model
-        if m._ws_key is None or m._ws_key[1] != B:
-            eng._workspace(B)                                 # (an epoch's ragged last batch switched the buffer set)
+        eng._workspace(B)                                     # this step's set of batch buffers (they alternate; an epoch's ragged
+                                                              # last batch switches the size too)
         loss = eng._next_loss_slot()
         eng.native_prologue()
         values = dict(users=users.data_ptr(), pos=pos.data_ptr(), neg=neg.data_ptr(), loss=loss.data_ptr(), step=eng.step_count + 1)
@@ -658,6 +664,7 @@ class ColumnShardEngine(object):
         self.world = None
 
     loss_ring_len = LOSS_RING      # the loss tensor a step returns is overwritten that many steps later
+    mask = property(lambda self: self._masks[self.cur])
 
     # ------------------------------------------------------------------ set-up
     def cs_setup(self, world, rank, optimizer):
@@ -736,7 +743,9 @@ class ColumnShardEngine(object):
         else:
             self.layers = [None] + [tab() for _ in range(L - 1)]
             self.srcA, self.srcB, self.tmp = tab(), tab(), [tab(), tab()]
-        self.mask = torch.zeros((N + 31) // 32 + 2, dtype=torch.int32, device=dev)
+        # row bitmap of the adjoint's sources (= the planner's key bitmap on one rank): one per step parity, like the batch
+        # buffers -- the planner of step t + 1 may run while step t's adjoint hops still read theirs (cs_plan)
+        self._masks = [torch.zeros((N + 31) // 32 + 2, dtype=torch.int32, device=dev) for _ in range(2)]
         self.step_count = 0
         self._aux = None
         self._aux_pending = False
@@ -809,7 +818,7 @@ class ColumnShardEngine(object):
     def load_from_model(self):
         """Master copy <- the model's embedding parameters (start-up, load_state_dict)."""
         m = self.model
-        ws = m._workspace(m._ws_key[1] if m._ws_key else 1)
+        ws = m._workspace(m._ws_key[1] if m._ws_key else 1, parity=m._ws_key[3] if m._ws_key else 0)
         if self.lean:       # host parameters: upload my column slice (users, then items) and lay it out slab-major
             dev, U = m._device(), m.num_users
             x0 = torch.empty(U + m.num_items, self.dl, dtype=torch.float32, device=dev)
@@ -853,7 +862,9 @@ class ColumnShardEngine(object):
 
     def _workspace(self, B):
         m = self.model
-        ws = m._workspace(B, 3 * B)
+        if B not in self._bufs:                   # first use of this batch size: BOTH sets of its batch buffers now (cs_plan)
+            m._workspace(B, 3 * B, parity=1 - self.cur)
+        ws = m._workspace(B, 3 * B, parity=self.cur)
         dev, d, R, W = m._device(), m.latent_dim, 3 * B, self.world
         N = m.num_users + m.num_items
         if not self.lookup and (getattr(self, "narrow_x", None) is None or ws["Narrow"].data_ptr() != self.narrow_x.data_ptr()):
@@ -991,11 +1002,14 @@ class ColumnShardEngine(object):
         aux = self._aux_stream()
         self._head_split = self._rows_in_head = False
         early_bits = aux is not None and self.planT.tiered and not self.multi      # (several ranks: cs_gathered_ids)
-        if aux is not None and self._forked and getattr(self, "_ws_gen_planned", None) != m._ws_gen:
-            # another batch size's buffer set (possibly allocated -- and zero-filled ON THE MAIN STREAM -- a moment ago, after
-            # cs_fork ordered the second stream): order it again behind the main stream before the planner writes into it
+        fresh = aux is not None and getattr(self, "_ws_new_seen", None) != getattr(m, "_ws_new", 0)
+        if fresh:
+            # a buffer set allocated -- and zero-filled ON THE MAIN STREAM -- a moment ago (first step of this batch size): the
+            # second stream behind the main one before the planner writes into it
             program.sync(aux, torch.cuda.current_stream())
-        self._ws_gen_planned = m._ws_gen
+            self._ws_new_seen = getattr(m, "_ws_new", 0)
+        # the planner ahead of the previous step's end (prestage): one rank, the triplets announced as complete
+        ahead = (aux is not None and self._forked and not fresh and not self.multi and self.prestaged_ok(users, pos, neg))
 
         # the per-line source bits are needed by the first ADJOINT hop only. Issued on the second stream right behind the planner,
         # before the weight packing and the feature blocks: one join per step (the second stream's forward work is then 72 us
@@ -1008,11 +1022,17 @@ class ColumnShardEngine(object):
         late_bits = early_bits and R > 8192
         self._late_bits = late_bits
 
-        def plan():       # node ids of the slots, unique active rows + slot map, padded tail: one launch
+        def plan_only():  # node ids of the slots, unique active rows + slot map, padded tail: one launch
             ops.batch_plan(users, pos, neg, m.num_users, m.num_items, keys, act, seg, ws["slot_seg"][:R], ws["plan_ws"], err, PAD_KEY,
                            key_bitmap=self.mask if (early_bits or self._sources_in_head()) else None)
-            if early_bits and not late_bits:           # the planner's bitmap of the active rows IS the first adjoint hop's source
-                slab.source_bits(self.planT, self.hns, self.w, self.hgs, self.mask)    # bitmap (one rank): its per-line bits
+
+        def bits_only():  # the planner's bitmap of the active rows IS the first adjoint hop's source bitmap (one rank): its per-line
+            if early_bits and not late_bits:           # bits (they live in the plan's one scratch area: never ahead of the step before)
+                slab.source_bits(self.planT, self.hns, self.w, self.hgs, self.mask)
+
+        def plan():
+            plan_only()
+            bits_only()
 
         def pack():       # the head's weights in MFMA fragment order (they changed in the last optimizer step)
             self._head_fused_call(ws, R, phase=1)
@@ -1025,9 +1045,17 @@ class ColumnShardEngine(object):
             return act
         if not self._forked:
             program.sync(aux, torch.cuda.current_stream())       # the triplets, and last step's readers of the plan buffers
-        self._forked = False
+        fork_rec = getattr(self, "_fork_rec", None) if self._forked else None
+        self._forked, self._fork_rec = False, None
         with torch.cuda.stream(aux):
-            m._region("cs_plan", (m._ws_gen, users.data_ptr(), pos.data_ptr(), neg.data_ptr(), R), plan)
+            if ahead:
+                m._region("cs_plan_a", (m._ws_gen, users.data_ptr(), pos.data_ptr(), neg.data_ptr(), R), plan_only)
+                program.wait(aux, fork_rec)                      # everything else of this stream: behind the previous step
+                m._region("cs_bits_a", (m._ws_gen, R, early_bits, late_bits), bits_only)
+            else:
+                if fork_rec is not None:
+                    program.wait(aux, fork_rec)
+                m._region("cs_plan", (m._ws_gen, users.data_ptr(), pos.data_ptr(), neg.data_ptr(), R), plan)
             if self._fused_head_ok():
                 m._region("cs_pack", (m._ws_gen, R), pack)
                 self._head_split = self._head16 and not self.lookup and self._split_head
@@ -1074,9 +1102,27 @@ class ColumnShardEngine(object):
         aux = self._aux_stream()
         if aux is None or self.model._ws is None:
             return False
-        program.sync(aux, torch.cuda.current_stream())
+        self._fork_rec = program.record(torch.cuda.current_stream())     # waited for by the second stream in cs_plan
         self._forked = True
         return True
+
+    def prestage(self, batches):
+        """The caller states that these (users, pos, neg) tensors are complete on the device NOW (an epoch's triplets sampled
+        ahead: main.py, bench.py). For such a batch the planner of a step does not wait for the step before it: it reads only the
+        triplets and writes this step's own set of batch buffers (two sets, alternating), so on the second stream it runs UNDER the
+        previous step's backward -- at large batches (device-wide planner: 60-110 us) that takes it off the forward's critical
+        path. Batches not announced here keep the conservative order (their triplets may be the product of work still queued on
+        the caller's stream)."""
+        aux = self._aux_stream()
+        self._prestaged = {}
+        if aux is None or self.multi:
+            return
+        program.sync(aux, torch.cuda.current_stream())       # once: whatever produced them is done before any of their planners runs
+        self._prestaged = {id(u): (u, p, n) for u, p, n in batches}
+
+    def prestaged_ok(self, users, pos, neg):
+        e = getattr(self, "_prestaged", {}).get(id(users))
+        return e is not None and e[0] is users and e[1] is pos and e[2] is neg
 
     @torch.no_grad()
     def cs_forward_hops(self):

@@ -162,9 +162,11 @@ class Net(object):
         ring = getattr(self.engine, "loss_ring_len", 0) if self.engine is not None else 0
         keep = (lambda t: t.clone()) if ring and len(batches) >= ring else (lambda t: t)
         shard_trainer = self.trainer if self.engine is not None else None
-        if shard_trainer is not None and getattr(shard_trainer, "lookup", False) and getattr(shard_trainer, "multi", False):
-            batches = list(batches)                   # row-sharded constants: this epoch's lookup split sizes, planned ahead
-            shard_trainer.plan_lookup(batches)
+        if shard_trainer is not None:
+            batches = list(batches)                   # the epoch's triplets, sampled on the device in one launch (data/sampler.py)
+            shard_trainer.prestage(batches)           # ... complete before the first step: every step's planner may run ahead
+            if getattr(shard_trainer, "lookup", False) and getattr(shard_trainer, "multi", False):
+                shard_trainer.plan_lookup(batches)    # row-sharded constants: this epoch's lookup split sizes, planned ahead
         on_device = torch.stack([keep(step(users, pos, neg)) for users, pos, neg in batches])
         if self.world > 1:
             import torch.distributed as dist

@@ -28,6 +28,8 @@ nb = int(u.numel()) // B                                 # whole batches of the 
 batches = [(u[j * B:(j + 1) * B], p[j * B:(j + 1) * B], n[j * B:(j + 1) * B]) for j in range(nb)]
 if tr.lookup and tr.multi:                               # row-sharded constants: the split sizes planned ahead, as main.py does per epoch
     tr.plan_lookup(batches)
+if os.environ.get("PRESTAGE", "1") == "1":               # the epoch's triplets are resident: planners may run ahead (as main.py / bench.py say)
+    tr.prestage(batches)
 import time
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for i in range(K):
