@@ -931,6 +931,12 @@ struct SlabSources { float *A, *B; int64_t N; int w, w_shift; float *split; int6
 
 struct HeadPackPtrs { const float *f[2]; const float *s[kMaxHeads]; };      // null f[0]: weights read unpacked
 
+// SEG: the segment reduce of the slot rows fused in front (the dY rows are formed here); !SEG: dY rows given (a reduce launch of its
+// own ran before: large batches, where the launch is paced by how many tiles a CU holds and the staging registers cost a third
+// of them)
+// PACKED: the operands from the packed copy, recdim 64 (the caller checked): the instantiation carries no code for weights read
+// unpacked
+template <bool SEG, bool PACKED>
 __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__restrict__ dY, int64_t lddy,
                                                                const int32_t *__restrict__ active_rows,
                                                                const int32_t *__restrict__ seg_info, int64_t n_max,
@@ -949,7 +955,8 @@ __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__re
     if (n_act > n_max) n_act = n_max;
     if (s0 >= n_act) return;
     const int rows = (int)((n_act - s0) < HM16 ? (n_act - s0) : HM16);
-    const float seg_scale = (seg.rows && seg.scale) ? seg.scale[0] : 1.f;
+    const bool segd = SEG && seg.rows != nullptr;
+    const float seg_scale = (segd && seg.scale) ? seg.scale[0] : 1.f;
     // staging as in the 32-row kernel: the dependent loads of the fused segment reduce in batches of 4 per thread
     constexpr int ST = 4;
     for (int e0 = tid * 4; e0 < HM16 * Cy; e0 += 1024 * ST) {
@@ -962,9 +969,9 @@ __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__re
             r[q] = e / Cy; c[q] = e - r[q] * Cy;
             in[q] = e < HM16 * Cy && r[q] < rows;
             beg[q] = 0; end[q] = 0;
-            if (in[q] && seg.rows) { beg[q] = seg.seg_start[s0 + r[q]]; end[q] = seg.seg_start[s0 + r[q] + 1]; }
+            if (in[q] && segd) { beg[q] = seg.seg_start[s0 + r[q]]; end[q] = seg.seg_start[s0 + r[q] + 1]; }
         }
-        if (seg.rows) {
+        if (segd) {
 #pragma unroll
             for (int q = 0; q < ST; ++q) mem[q] = (in[q] && beg[q] < end[q]) ? seg.members[beg[q]] : 0;
         }
@@ -972,7 +979,7 @@ __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__re
         for (int q = 0; q < ST; ++q) {
             v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (in[q]) {
-                if (!seg.rows) v[q] = ld4(dY + (s0 + r[q]) * lddy + c[q]);
+                if (!segd) v[q] = ld4(dY + (s0 + r[q]) * lddy + c[q]);
                 else if (beg[q] < end[q]) {
                     const float4 x = ld4(seg.rows + (int64_t)mem[q] * Cy + c[q]);
                     v[q].x += x.x; v[q].y += x.y; v[q].z += x.z; v[q].w += x.w;    // 0 + x, as the serial loop does
@@ -983,7 +990,7 @@ __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__re
         for (int q = 0; q < ST; ++q) {
             const int e = e0 + 1024 * q;
             if (e >= HM16 * Cy) continue;
-            if (in[q] && seg.rows) {
+            if (in[q] && segd) {
                 // a popular item is listed by dozens of slots (48 of 6144 at the Tiktok shape), and walking them one dependent load
                 // pair at a time was the launch's longest chain (26 us; 19.5 with sixteen, then four, members' rows in flight --
                 // added in member order, as before)
@@ -1058,7 +1065,7 @@ __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__re
             }
         }
     };
-    if (pk.f[0] && d == 64 && !mixed && C <= 256 && src.pipelined) {
+    if (PACKED && !mixed && C <= 256 && src.pipelined) {
         // Packed operands, one weight matrix for the whole tile (every tile but the one that straddles the user / item boundary):
         // wave w owns column tile w of every table block k (t = w + 4k), i.e. up to 8 rounds of 16 MFMAs -- the fusion operand of
         // block k, then the single-modal head that feeds block k -- each behind one 16-register operand load from L2. The loads of
@@ -1114,7 +1121,7 @@ __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__re
         const int c0 = t * 16;
         const int mb = c0 / d;
         v4f_ acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
-        if (pk.f[0] && d == 64) {
+        if (PACKED) {
             const int64_t ft = (int64_t)t * 16 * 64 + lane;                       // column tile t of the [C x 64] fusion operand
             acc = hm16_accumulate_packed(acc, a_row, pk.f[any_user ? 0 : 1] + ft, kq);
             if (mixed) acc2 = hm16_accumulate_packed(acc2, a_row, pk.f[1] + ft, kq);
@@ -1124,7 +1131,7 @@ __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__re
                 acc = hm16_accumulate_packed(acc, a_row + (1 + h) * d, bp, kq);
                 if (mixed) acc2 = hm16_accumulate_packed(acc2, a_row + (1 + h) * d, bp, kq);
             }
-        } else {
+        } else if (!PACKED) {
             acc = hm16_accumulate(acc, a_row, (any_user ? W_user : W_item) + c0 + li, C, d, kq);
             if (mixed) acc2 = hm16_accumulate(acc2, a_row, W_item + c0 + li, C, d, kq);
             for (int h = 0; h < S; ++h) {
@@ -1643,9 +1650,14 @@ static int segment_apply_head_bwd_impl(const float *d_rows, int64_t n, int ld, c
         if (pipe < 0) { const char *e = getenv("ELIMREC_BWD_PIPE"); pipe = (e && e[0] == '0') ? 0 : 1; }
         SlabSources ss = src ? *src : SlabSources{};
         ss.pipelined = pipe;
-        hipLaunchKernelGGL(head_bwd_input16_kernel, dim3((unsigned)((n + HM16 - 1) / HM16)), dim3(256), lds16,
-                           (hipStream_t)stream, (const float *)d_reduced, (int64_t)ld, d_active_rows, d_seg_info, n, U, d, C, S, hp,
-                           d_W_user, d_W_item, 1.0f, (float *)nullptr, (int64_t)0, 0, d_compact, seg, pk, ss);
+        if (packed)
+            hipLaunchKernelGGL((head_bwd_input16_kernel<true, true>), dim3((unsigned)((n + HM16 - 1) / HM16)), dim3(256), lds16,
+                               (hipStream_t)stream, (const float *)d_reduced, (int64_t)ld, d_active_rows, d_seg_info, n, U, d, C, S, hp,
+                               d_W_user, d_W_item, 1.0f, (float *)nullptr, (int64_t)0, 0, d_compact, seg, pk, ss);
+        else
+            hipLaunchKernelGGL((head_bwd_input16_kernel<true, false>), dim3((unsigned)((n + HM16 - 1) / HM16)), dim3(256), lds16,
+                               (hipStream_t)stream, (const float *)d_reduced, (int64_t)ld, d_active_rows, d_seg_info, n, U, d, C, S, hp,
+                               d_W_user, d_W_item, 1.0f, (float *)nullptr, (int64_t)0, 0, d_compact, seg, pk, ss);
         ELIMREC_LAUNCH_CHECK("segment_apply_head_bwd16");
         return 0;
     }
@@ -1656,3 +1668,5 @@ static int segment_apply_head_bwd_impl(const float *d_rows, int64_t n, int ld, c
     ELIMREC_LAUNCH_CHECK("segment_apply_head_bwd");
     return 0;
 }
+
+namespace elimrec { template __global__ void head_bwd_input16_kernel<false, true>(const float *, int64_t, const int32_t *, const int32_t *, int64_t, int64_t, int, int, int, HeadPtrs, const float *, const float *, float, float *, int64_t, int, float *, SegSrc, HeadPackPtrs, SlabSources); }

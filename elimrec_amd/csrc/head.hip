@@ -477,6 +477,18 @@ static int head_fwd_fused_impl(const elimrec_head_rows *rows, const int32_t *d_a
     pj.first_block[pj.n] = blocks;
     a.out_off = lds_f; lds_f += rows_t * (C + (form16 ? 4 : 1));
     a.part_off = lds_f; if (!form16) lds_f += (1 + n_mod) * HROWS * HD;
+    if (form16 && phase == 4) {
+        // the second launch of the two-launch head stages no feature rows: narrow tile + Out tile only (21 KB instead of 51 KB at
+        // three 128-d tables: as many workgroups per CU as the registers allow -- a launch of thousands of tiles (large batches) is
+        // paced by how many tiles a CU holds; at B = 2048 every tile is resident either way)
+        a.out_off = H16 * (HD + 4);
+        lds_f = a.out_off + rows_t * (C + 4);
+    } else if (form16 && phase == 3) {
+        // ... and the first launch stages nothing else: the feature tiles from offset 0
+        int at = 0;
+        for (int m = 0; m < n_mod; ++m) { a.a_off[m] = at; at += rows_t * (D[m] + 4); }
+        lds_f = at;
+    }
     const size_t lds_bytes = (size_t)lds_f * sizeof(float);
     if (lds_bytes > 158 * 1024) { set_error("head_fwd_fused: feature widths need %zu B of LDS", lds_bytes); return ELIMREC_E_UNSUPPORTED; }
     a.act = d_act; a.seg_info = d_seg_info; a.out0 = d_out0; a.ld_out0 = ld_out0; a.narrow = d_narrow; a.ld_nar = ld_nar; a.c = d_c;
