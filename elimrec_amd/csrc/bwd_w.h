@@ -24,9 +24,9 @@ struct BwdProblem {
 struct BwdBatch { BwdProblem p[kMaxBatch]; int n; };
 
 // One workgroup of the partial launch: a chunk of rows x one 64 x TN2 output tile (see gemm.hip, "weight grad").
-// As / Bs / Wt: the caller's LDS stages ([2][TRB * TN1], [2][TRB * TN2], [2][TRB] floats).
-__device__ __forceinline__ void bwd_w_partial_body(const BwdBatch &batch, int block, float (*As)[TRB * TN1], float (*Bs)[TRB * TN2],
-                                                   float (*Wt)[TRB]) {
+// As / Bs: the caller's LDS stages ([2][TRB * TN1], [2][TRB * TN2] floats = 32 KB: five workgroups per CU). The per-row
+// weights of the weighted column sum stay in registers: lane k of wave 0 holds row k's, the sum reads it with v_readlane.
+__device__ __forceinline__ void bwd_w_partial_body(const BwdBatch &batch, int block, float (*As)[TRB * TN1], float (*Bs)[TRB * TN2]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int pi = 0;
     while (pi + 1 < batch.n && block >= batch.p[pi + 1].first_block) ++pi;
@@ -57,7 +57,7 @@ __device__ __forceinline__ void bwd_w_partial_body(const BwdBatch &batch, int bl
     const bool a_col_ok = (i_base + a_c4 * 4) < n1;       // n1, n2 are multiples of 4
     const bool b_col_ok = (j_base + b_c4 * 4) < n2;
     float4 ra[2], rbv[BPS];
-    float rw = 1.f;
+    float rw = 1.f, rw_cur = 1.f;                          // the block in flight / the block in LDS
     auto load_block = [&](int64_t row0) {
         if (cw && tid < TRB) {
             const int64_t r = row0 + tid;
@@ -81,7 +81,7 @@ __device__ __forceinline__ void bwd_w_partial_body(const BwdBatch &batch, int bl
         }
     };
     auto store_block = [&](int buf) {
-        if (cw && tid < TRB) Wt[buf][tid] = rw;
+        rw_cur = rw;
 #pragma unroll
         for (int p = 0; p < 2; ++p)
             *reinterpret_cast<float4 *>(&As[buf][(a_row + 16 * p) * TN1 + a_c4 * 4]) = ra[p];
@@ -122,8 +122,9 @@ __device__ __forceinline__ void bwd_w_partial_body(const BwdBatch &batch, int bl
         }
         if (colsum_slabs && tid < TN1) {
             if (cw) {
-#pragma unroll 8
-                for (int k = 0; k < TRB; ++k) csum += as[k * TN1 + tid] * Wt[buf][k];
+#pragma unroll
+                for (int k = 0; k < TRB; ++k)
+                    csum += as[k * TN1 + tid] * __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rw_cur), k));
             } else {
 #pragma unroll 8
                 for (int k = 0; k < TRB; ++k) csum += as[k * TN1 + tid];

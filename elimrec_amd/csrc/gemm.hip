@@ -176,8 +176,7 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(FwdBatch batch) {
 __global__ __launch_bounds__(256) void linear_bwd_w_partial_kernel(BwdBatch batch) {
     __shared__ float As[2][TRB * TN1];
     __shared__ float Bs[2][TRB * TN2];
-    __shared__ float Wt[2][TRB];                           // per-row weights of the (weighted) column sum
-    bwd_w_partial_body(batch, (int)blockIdx.x, As, Bs, Wt);
+    bwd_w_partial_body(batch, (int)blockIdx.x, As, Bs);
 }
 
 // The same launch with the adjoint-source merge (merge_rows.h) as `merge_blocks` extra workgroups, in front of
@@ -187,7 +186,6 @@ __global__ __launch_bounds__(256) void linear_bwd_w_merge_kernel(BwdBatch batch,
                                                                  int merge_first) {
     __shared__ float As[2][TRB * TN1];
     __shared__ float Bs[2][TRB * TN2];
-    __shared__ float Wt[2][TRB];
     int b = (int)blockIdx.x;
     bool merge;
     if (merge_first) { merge = b < merge_blocks; if (!merge) b -= merge_blocks; }
@@ -198,7 +196,7 @@ __global__ __launch_bounds__(256) void linear_bwd_w_merge_kernel(BwdBatch batch,
         slab_merge_rows_body(mg, b, s_beg, s_beg + kSlabMaxRanks, reinterpret_cast<uint32_t *>(&As[0][0]));
         return;
     }
-    bwd_w_partial_body(batch, b, As, Bs, Wt);
+    bwd_w_partial_body(batch, b, As, Bs);
 }
 
 __global__ void reduce_slabs_kernel(BwdBatch batch) { reduce_slabs_body(batch, (int)blockIdx.x, (int)blockIdx.y); }

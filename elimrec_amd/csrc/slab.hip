@@ -729,15 +729,14 @@ __global__ __launch_bounds__(256) void sell_tier_adam_kernel(TierArgs t, AdamJob
 // reduce (tail_mode 1; needs the partial launch, is needed by the optimizer only). Neither reads what the hop writes.
 // Kernels of their own for the reason above: the plain hops keep their small argument block.
 template <int LPR, bool MASKED>
-__global__ __launch_bounds__(256) void sell_tier_bwdw_kernel(TierArgs t, BwdBatch batch, int tail_block0, int tail_mode, int gx) {
+__global__ __launch_bounds__(256, (LPR <= 8 ? 5 : 1)) void sell_tier_bwdw_kernel(TierArgs t, BwdBatch batch, int tail_block0, int tail_mode, int gx) {
     __shared__ float As[2][TRB * TN1];                      // the GEMM stages; the hop's wave sums (8 KB) share them
     __shared__ float Bs[2][TRB * TN2];
-    __shared__ float Wt[2][TRB];
     static_assert(2 * TRB * TN1 >= 4 * 64 * 8, "the hop's LDS scratch must fit the A stages");
     if ((int)blockIdx.x >= tail_block0) {
         const int b = (int)blockIdx.x - tail_block0;
         if (tail_mode == 1) { reduce_slabs_body(batch, b % gx, b / gx); return; }
-        bwd_w_partial_body(batch, b, As, Bs, Wt);
+        bwd_w_partial_body(batch, b, As, Bs);
         return;
     }
     tier_body<LPR, 4, false, false, MASKED, false, true>(t, &As[0][0]);
