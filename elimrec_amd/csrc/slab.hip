@@ -607,12 +607,13 @@ __device__ __forceinline__ void tier_wave_sum(const float (&acc)[VPL], int cl, i
 }
 
 template <int LPR, int VPL, bool IN_BF16, bool OUT_BF16, bool MASKED, bool ADAM, bool EXT_LDS = false>
-__device__ __forceinline__ void tier_body(const TierArgs &t, float *lds = nullptr) {
+__device__ __forceinline__ void tier_body(const TierArgs &t, float *lds = nullptr, unsigned front = 0) {
     constexpr int G = 64 / LPR;
     const StreamArgs &a = t.s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int grp = t.per_group ? (int)(blockIdx.x / (unsigned)t.per_group) : (int)(blockIdx.x % (unsigned)a.gs);
-    const int bidx = t.per_group ? (int)(blockIdx.x % (unsigned)t.per_group) : (int)(blockIdx.x / (unsigned)a.gs);
+    const unsigned bx = blockIdx.x - front;                 // (front: a multiple of 8 -- the workgroup's XCD and slab group keep their relation)
+    const int grp = t.per_group ? (int)(bx / (unsigned)t.per_group) : (int)(bx % (unsigned)a.gs);
+    const int bidx = t.per_group ? (int)(bx % (unsigned)t.per_group) : (int)(bx / (unsigned)a.gs);
     const int sub = lane / LPR, cl = lane % LPR;
     const int slab = grp * a.spg + (cl >> a.wl_shift);
     const int c = cl & (a.wl - 1);
@@ -733,13 +734,16 @@ __global__ __launch_bounds__(256, (LPR <= 8 ? 5 : 1)) void sell_tier_bwdw_kernel
     __shared__ float As[2][TRB * TN1];                      // the GEMM stages; the hop's wave sums (8 KB) share them
     __shared__ float Bs[2][TRB * TN2];
     static_assert(2 * TRB * TN1 >= 4 * 64 * 8, "the hop's LDS scratch must fit the A stages");
-    if ((int)blockIdx.x >= tail_block0) {
-        const int b = (int)blockIdx.x - tail_block0;
+    // tail_block0 < 0: the tail's -tail_block0 workgroups (rounded up to a multiple of 8) come FIRST
+    const int front = tail_block0 < 0 ? (-tail_block0 + 7) & ~7 : 0;
+    if (tail_block0 < 0 ? (int)blockIdx.x < front : (int)blockIdx.x >= tail_block0) {
+        const int b = tail_block0 < 0 ? (int)blockIdx.x : (int)blockIdx.x - tail_block0;
+        if (tail_block0 < 0 && b >= -tail_block0) return;
         if (tail_mode == 1) { reduce_slabs_body(batch, b % gx, b / gx); return; }
         bwd_w_partial_body(batch, b, As, Bs);
         return;
     }
-    tier_body<LPR, 4, false, false, MASKED, false, true>(t, &As[0][0]);
+    tier_body<LPR, 4, false, false, MASKED, false, true>(t, &As[0][0], (unsigned)front);
 }
 
 static int log2_pow2(int x) {
@@ -819,7 +823,18 @@ static int launch_tier(const elimrec_sell *A, int ns, int wl, int wl_shift, int 
         if (order < 0) { const char *e = getenv("ELIMREC_SLAB_ORDER"); order = e ? atoi(e) : 0; }
         t.per_group = order == 1 ? (int)per_group : 0;
     }
-    const int tail_block0 = (int)(per_group * gs);
+    int tail_block0 = (int)(per_group * gs);
+    {
+        // the weight gradients' partial launch (bit 0) / slab reduce (bit 1) AHEAD of the hop's tiles instead of behind them. The
+        // partial launch is a serial chain per workgroup (18.9 us as a launch of its own): begun at once it ends under the tiles --
+        // measured -1 us per step at B = 2048, -5 at 4096, -15 at 32768; the reduce first: +-0. Same bits either way.
+        static int first = -1;
+        if (first < 0) { const char *e = getenv("ELIMREC_TAIL_FIRST"); first = e ? atoi(e) : 1; }
+        if (bwdw && tail_blocks > 0 && !adam && ((first & 1 && tail_mode == 2) || (first & 2 && tail_mode == 1))) {
+            tail_block0 = -tail_blocks;
+            tail_blocks = (tail_blocks + 7) & ~7;
+        }
+    }
     AdamJobs tail = {};
     if (adam && adam->tail && (adam->tail->n > 0 || adam->tail->sum_src)) tail = *adam->tail;
     if (tail.n <= 0) tail.blocks = 0;
