@@ -936,6 +936,11 @@ struct HeadPackPtrs { const float *f[2]; const float *s[kMaxHeads]; };      // n
 // of them)
 // PACKED: the operands from the packed copy, recdim 64 (the caller checked): the instantiation carries no code for weights read
 // unpacked
+// (Measured in round 5, B = 32768 = 65 k active rows, the same bits each time: 32- and 64-row tiles of this kernel -- every operand
+// load feeding 2 / 4 MFMAs on independent accumulators -- are SLOWER at every batch size (B = 2048 0.289 -> 0.302 / 0.326 ms per
+// step, B = 32768 0.758 -> 0.765 / 0.779); the segment sums as a launch of their own (a wave per segment, sixteen members in
+// flight) + this kernel with SEG = false: 73.6 + 73.0 us against 133 fused, step 0.743 -> 0.764 ms -- the sums' launch is the
+// chain of the batch's most popular item (604 members), which the fused form hides under the other tiles.)
 template <bool SEG, bool PACKED>
 __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__restrict__ dY, int64_t lddy,
                                                                const int32_t *__restrict__ active_rows,
@@ -1669,4 +1674,3 @@ static int segment_apply_head_bwd_impl(const float *d_rows, int64_t n, int ld, c
     return 0;
 }
 
-namespace elimrec { template __global__ void head_bwd_input16_kernel<false, true>(const float *, int64_t, const int32_t *, const int32_t *, int64_t, int64_t, int, int, int, HeadPtrs, const float *, const float *, float, float *, int64_t, int, float *, SegSrc, HeadPackPtrs, SlabSources); }
