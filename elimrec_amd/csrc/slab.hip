@@ -302,7 +302,13 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, int slab, i
 #pragma unroll
     for (int i = 0; i < VPL; ++i) r[i] *= a.scale;
     if (ADAM && VPL == 4 && !OUT_BF16) {               // arithmetic of adam_multi_kernel, element for element
+#ifdef ELIMREC_NT_ADAM
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v p4 = __builtin_nontemporal_load((const f4v *)a.ad_p_in + idx), m4 = __builtin_nontemporal_load((const f4v *)a.ad_m + idx),
+                  v4 = __builtin_nontemporal_load((const f4v *)a.ad_v + idx);
+#else
         const float4 p4 = ((const float4 *)a.ad_p_in)[idx], m4 = ((const float4 *)a.ad_m)[idx], v4 = ((const float4 *)a.ad_v)[idx];
+#endif
         const float pi[4] = {p4.x, p4.y, p4.z, p4.w}, mo[4] = {m4.x, m4.y, m4.z, m4.w}, vo[4] = {v4.x, v4.y, v4.z, v4.w};
         float po[4], mi[4], vi[4];
 #pragma unroll
@@ -313,8 +319,13 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, int slab, i
             const float denom = sqrtf(vi[i]) * a.ad_inv_sqrt_bc2 + a.ad_eps;
             po[i] = pi[i] - a.ad_step_size * (mi[i] / denom);
         }
+#ifdef ELIMREC_NT_ADAM
+        __builtin_nontemporal_store((f4v){mi[0], mi[1], mi[2], mi[3]}, (f4v *)a.ad_m + idx);
+        __builtin_nontemporal_store((f4v){vi[0], vi[1], vi[2], vi[3]}, (f4v *)a.ad_v + idx);
+#else
         ((float4 *)a.ad_m)[idx] = make_float4(mi[0], mi[1], mi[2], mi[3]);
         ((float4 *)a.ad_v)[idx] = make_float4(vi[0], vi[1], vi[2], vi[3]);
+#endif
         ((float4 *)a.ad_p_out)[idx] = make_float4(po[0], po[1], po[2], po[3]);
         if (!a.ad_keep_grad) return;
     }
@@ -481,7 +492,8 @@ __global__ __launch_bounds__(256) void tile_ballot_kernel(const int64_t *__restr
 }
 
 // -DELIMREC_NT_INDEX / -DELIMREC_NT_OUT: non-temporal index loads / output stores (measured at the Tiktok shape: index
-// 32.4 -> 35.5 us per hop, output 32.4 -> 31.6 with the masked hop 0.8 us slower -- neither is on)
+// 32.4 -> 35.5 us per hop, output 32.4 -> 31.6 with the masked hop 0.8 us slower; the build sets ELIMREC_NT_OUT and, for the Adam
+// epilogue's once-per-step streams, ELIMREC_NT_ADAM: see the Makefile)
 #ifdef ELIMREC_NT_INDEX
 #define ELIMREC_IDX_LD(p) __builtin_nontemporal_load(p)
 #else
