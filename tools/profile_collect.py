@@ -100,8 +100,9 @@ if c4:
     print(json.dumps(c4, indent=1))
 if os.path.exists(O + "/multi_stats/m_kernel_stats.csv"):
     shutil.copy(O + "/multi_stats/m_kernel_stats.csv", "profiles/%s_multi_rank_path_kernel_stats.csv" % RND)
-for src, dst in (("multi_timeline.txt", "multi_rank_path_timeline.txt"), ("step_timeline.txt", "step_timeline.txt")):
-    if os.path.exists(O + "/" + src) and "step span" in open(O + "/" + src).read():
+for src, dst in (("multi_timeline.txt", "multi_rank_path_timeline.txt"), ("step_timeline.txt", "step_timeline.txt"),
+                 ("step_timeline_B32768.txt", "step_timeline_B32768.txt"), ("bigb_counters.txt", "bigb_counters.txt")):
+    if os.path.exists(O + "/" + src) and any(k in open(O + "/" + src).read() for k in ("step span", "mfma_busy")):
         shutil.copy(O + "/" + src, "profiles/%s_%s" % (RND, dst))
 shutil.copy(O + "/stats/b_kernel_stats.csv", "profiles/%s_bench_kernel_stats.csv" % RND)
 if os.path.exists(O + "/bench_kernels_by_grid.csv"):       # the same run with kernels that cover several launch shapes split by grid size

@@ -69,5 +69,10 @@ with open(sys.argv[2], "w") as f:
     for (n, g, q), (c, t) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
         w.writerow([n, g, q, c, t, round(t / c)])
 PY
+# the step at B = 32768 (65 k active rows): timeline of one step, counters of its O(B) kernels
+B=32768 bash $R/tools/bigb_trace.sh > /dev/null 2>&1
+cp $R/gpurun_out/bigb_timeline_32768.txt $O/step_timeline_B32768.txt
+B=32768 bash $R/tools/bigb_pmc.sh > $O/bigb_counters.txt 2>&1
+rm -rf $R/gpurun_out/bigb_trace_32768 $R/gpurun_out/r05_bigb
 find $O -name "*kernel_trace.csv" -delete      # large; the stats csv is what gets committed
 ls -R $O | head -50
