@@ -539,15 +539,27 @@ __device__ __forceinline__ void tile_gather(const TierArgs &t, int ti, int64_t i
     if constexpr (LPR >= UB) {
         int c0 = 0, c1 = 0;
         float v0 = 0.f, v1 = 0.f;
-        if (nk > 0) { c0 = ELIMREC_IDX_LD(colp); v0 = ELIMREC_IDX_LD(valp); }
-        if (nk > 1) { c1 = ELIMREC_IDX_LD(colp + 64); v1 = ELIMREC_IDX_LD(valp + 64); }
+        // MASKED (the first adjoint hop: <= 3B active source rows, a few per cent of the index entries): the source bits of an
+        // index line are ONE 64-bit word read through the scalar cache, three lines ahead of its use -- a line none of whose entries
+        // is active (most of them) costs neither its two index loads nor the cross-lane picks and predicated gathers of its steps
+        const uint64_t *balp = MASKED ? t.ballots + (int64_t)ti * t.kmax : nullptr;
+        uint64_t b0 = ~0ull, b1 = ~0ull, b2 = ~0ull;
+        if (MASKED) {
+            b0 = nk > 0 ? balp[0] : 0ull; b1 = nk > 1 ? balp[1] : 0ull; b2 = nk > 2 ? balp[2] : 0ull;
+        }
+        if (nk > 0 && b0) { c0 = ELIMREC_IDX_LD(colp); v0 = ELIMREC_IDX_LD(valp); }
+        if (nk > 1 && b1) { c1 = ELIMREC_IDX_LD(colp + 64); v1 = ELIMREC_IDX_LD(valp + 64); }
         for (int k = 0; k < nk; ++k) {
             int c2 = 0;
             float v2 = 0.f;
-            if (k + 2 < nk) { c2 = ELIMREC_IDX_LD(colp + ((k + 2) << 6)); v2 = ELIMREC_IDX_LD(valp + ((k + 2) << 6)); }
+            if (k + 2 < nk && b2) { c2 = ELIMREC_IDX_LD(colp + ((k + 2) << 6)); v2 = ELIMREC_IDX_LD(valp + ((k + 2) << 6)); }
+            const uint64_t b3 = (MASKED && k + 3 < nk) ? balp[k + 3] : (MASKED ? 0ull : ~0ull);
             const int jbase = k * LPR;
-            uint64_t bal = 0;
-            if (MASKED) bal = t.ballots[(int64_t)ti * t.kmax + k];      // wave-uniform address: scalar load
+            const uint64_t bal = b0;
+            if (MASKED && bal == 0ull) {                   // wave-uniform
+                c0 = c1; v0 = v1; c1 = c2; v1 = v2; b0 = b1; b1 = b2; b2 = b3;
+                continue;
+            }
 #pragma unroll
             for (int u0 = 0; u0 < LPR; u0 += UB) {
                 if (jbase + u0 >= steps) continue;         // wave-uniform
@@ -564,7 +576,7 @@ __device__ __forceinline__ void tile_gather(const TierArgs &t, int ti, int64_t i
                 }
                 tile_batch<VPL, IN_BF16, UB>(a, in_base, cj, vj, in, acc);
             }
-            c0 = c1; v0 = v1; c1 = c2; v1 = v2;
+            c0 = c1; v0 = v1; c1 = c2; v1 = v2; b0 = b1; b1 = b2; b2 = b3;
         }
     } else {
         constexpr int KL = UB / LPR;                       // lines per batch

@@ -112,4 +112,19 @@ if getattr(plan, "sweep", None) is not None and os.environ.get("EXPT") == "1":
         e1.record()
         torch.cuda.synchronize()
         print("  EXPT %s: %.2f us per hop" % (name, e0.elapsed_time(e1) * 1e3 / 30))
+if os.environ.get("MASKED"):                 # the first adjoint hop alone: a source table of which MASKED random rows are active
+    import numpy as np
+    R = int(os.environ["MASKED"])
+    keys = torch.from_numpy(np.random.default_rng(0).choice(N, R, replace=False).astype(np.int32)).to(dev).view(1, -1).contiguous()
+    mask = torch.zeros((N + 31) // 32, dtype=torch.int32, device=dev)
+    slab.rows_bitmap(keys, N, mask)
+    slab.source_bits(plan, ns, w, gs, mask)
+    for name, kw in (("masked hop, source bits ready", dict(src_mask=mask, bits_ready=True)), ("full hop", {})):
+        for _ in range(3): slab.hop(plan, tabs[0], tabs[1], gs=gs, **kw)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(40): slab.hop(plan, tabs[0], tabs[1], gs=gs, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        print("  %s (%d active rows of %d): %.2f us" % (name, R, N, e0.elapsed_time(e1) * 1e3 / 40))
 print("geometry ns=%d w=%d gs=%d, %d hops, index bytes %d" % (ns, w, gs, hops, plan.index_bytes()))
