@@ -926,8 +926,7 @@ __device__ __forceinline__ v4f_ hm16_accumulate_packed(v4f_ acc, const float *__
 // ... or, with peers (split != NULL): the [H | G] rows cut into the `world` column slices a column-sharded job sends them,
 // split[q][slot] = [H[slot][q*dl : (q+1)*dl] | G[slot][q*dl : (q+1)*dl]] (layout [world x n_max x 2*dl]: what
 // elimrec_source_rows_split makes of the compact rows)
-struct SlabSources { float *A, *B; int64_t N; int w, w_shift; float *split; int64_t n_max; int dl;
-                     int pipelined; };     // (pipelined: operand loads of the next MFMA round ahead of this one's; ELIMREC_BWD_PIPE=0 = serial, A/B runs)
+struct SlabSources { float *A, *B; int64_t N; int w, w_shift; float *split; int64_t n_max; int dl; };
 
 struct HeadPackPtrs { const float *f[2]; const float *s[kMaxHeads]; };      // null f[0]: weights read unpacked
 
@@ -1070,7 +1069,7 @@ __global__ __launch_bounds__(256) void head_bwd_input16_kernel(const float *__re
             }
         }
     };
-    if (PACKED && !mixed && C <= 256 && src.pipelined) {
+    if (PACKED && !mixed && C <= 256) {
         // Packed operands, one weight matrix for the whole tile (every tile but the one that straddles the user / item boundary):
         // wave w owns column tile w of every table block k (t = w + 4k), i.e. up to 8 rounds of 16 MFMAs -- the fusion operand of
         // block k, then the single-modal head that feeds block k -- each behind one 16-register operand load from L2. The loads of
@@ -1651,10 +1650,7 @@ static int segment_apply_head_bwd_impl(const float *d_rows, int64_t n, int ld, c
             pk.f[0] = d_pack_bwd; pk.f[1] = d_pack_bwd + (int64_t)C * 64;
             for (int h = 0; h < S && h < kMaxHeads; ++h) pk.s[h] = d_pack_bwd + (int64_t)2 * C * 64 + (int64_t)h * 64 * 64;
         }
-        static int pipe = -1;
-        if (pipe < 0) { const char *e = getenv("ELIMREC_BWD_PIPE"); pipe = (e && e[0] == '0') ? 0 : 1; }
         SlabSources ss = src ? *src : SlabSources{};
-        ss.pipelined = pipe;
         if (packed)
             hipLaunchKernelGGL((head_bwd_input16_kernel<true, true>), dim3((unsigned)((n + HM16 - 1) / HM16)), dim3(256), lds16,
                                (hipStream_t)stream, (const float *)d_reduced, (int64_t)ld, d_active_rows, d_seg_info, n, U, d, C, S, hp,

@@ -466,9 +466,6 @@ struct TierArgs {
     int n_tiles_run;               // tiles this launch walks (seg_only: up to tfin_base)
     const uint64_t *ballots;       // masked hop: [n_tiles x kmax] source-mask bits of each 64-entry index line
     int kmax;
-    int per_group;                 // 0: workgroup b works on slab group b % gs (an XCD keeps to one group: tables that fit
-                                   // the caches); > 0: on group b / per_group -- the groups one after the other, so that
-                                   // what the chip gathers from at any time is ONE group's slice (ELIMREC_SLAB_ORDER=1)
 };
 
 // The first adjoint hop gathers from a row-sparse table (<= 3B active rows). Testing the row bitmap per neighbour would
@@ -636,8 +633,8 @@ __device__ __forceinline__ void tier_body(const TierArgs &t, float *lds = nullpt
     const StreamArgs &a = t.s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned bx = blockIdx.x - front;                 // (front: a multiple of 8 -- the workgroup's XCD and slab group keep their relation)
-    const int grp = t.per_group ? (int)(bx / (unsigned)t.per_group) : (int)(bx % (unsigned)a.gs);
-    const int bidx = t.per_group ? (int)(bx % (unsigned)t.per_group) : (int)(bx / (unsigned)a.gs);
+    const int grp = (int)(bx % (unsigned)a.gs);            // workgroup b works on slab group b % gs: an XCD keeps to one group
+    const int bidx = (int)(bx / (unsigned)a.gs);
     const int sub = lane / LPR, cl = lane % LPR;
     const int slab = grp * a.spg + (cl >> a.wl_shift);
     const int c = cl & (a.wl - 1);
@@ -840,21 +837,15 @@ static int launch_tier(const elimrec_sell *A, int ns, int wl, int wl_shift, int 
     t.n_tiles_run = seg_only ? t.tfin_base : t.n_tiles;
     const int64_t per_group = t.n_tiles_run / 4;
     if (per_group <= 0) return 0;
-    {
-        // ELIMREC_SLAB_ORDER=1: the slab groups one after the other. Measured at the C4 shape (642 MB table, 160 MB per group):
-        // 6.60 against 6.51 ms per step -- the hop is bound by the CUs' gather rate, not by where the lines come from
-        static int order = -1;
-        if (order < 0) { const char *e = getenv("ELIMREC_SLAB_ORDER"); order = e ? atoi(e) : 0; }
-        t.per_group = order == 1 ? (int)per_group : 0;
-    }
+    // (the slab groups one after the other instead of side by side -- what the chip gathers from at any time being ONE group's
+    // slice -- measured at the configs[3] shape: 6.60 against 6.51 ms per step; the hop is bound by the CUs' gather rate, not by where
+    // the lines come from. Removed.)
     int tail_block0 = (int)(per_group * gs);
     {
-        // the weight gradients' partial launch (bit 0) / slab reduce (bit 1) AHEAD of the hop's tiles instead of behind them. The
-        // partial launch is a serial chain per workgroup (18.9 us as a launch of its own): begun at once it ends under the tiles --
-        // measured -1 us per step at B = 2048, -5 at 4096, -15 at 32768; the reduce first: +-0. Same bits either way.
-        static int first = -1;
-        if (first < 0) { const char *e = getenv("ELIMREC_TAIL_FIRST"); first = e ? atoi(e) : 1; }
-        if (bwdw && tail_blocks > 0 && !adam && ((first & 1 && tail_mode == 2) || (first & 2 && tail_mode == 1))) {
+        // the weight gradients' partial launch AHEAD of the hop's tiles instead of behind them: it is a serial chain per workgroup
+        // (18.9 us as a launch of its own), and begun at once it ends under the tiles -- measured -1 us per step at B = 2048, -5 at
+        // 4096, -15 at 32768; the slab reduce first: +-0 (it stays behind). Same bits either way.
+        if (bwdw && tail_blocks > 0 && !adam && tail_mode == 2) {
             tail_block0 = -tail_blocks;
             tail_blocks = (tail_blocks + 7) & ~7;
         }

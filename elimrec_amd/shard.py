@@ -483,11 +483,6 @@ class ColumnShardTrainer(object):
         self._native["native_steps"] += 1
         return loss
 
-    @property
-    def _lookup_early(self):
-        import os
-        return os.environ.get("ELIMREC_LOOKUP_EARLY", "1") != "0"
-
     def _step_python(self, users, pos, neg):
         return self._backward_python(self._forward_python(users, pos, neg, whole=True))
 
@@ -530,8 +525,7 @@ class ColumnShardTrainer(object):
         if not early:
             ph["cs_forward_hops"]()                                # hops 1..L-1 of my column slice: no communication
         lookup_early = False
-        if (self.multi and self.lookup and h_ids is not None and isinstance(h_ids, self._OnStream) and self._native_comm() is not None
-                and self._lookup_early):
+        if (self.multi and self.lookup and h_ids is not None and isinstance(h_ids, self._OnStream) and self._native_comm() is not None):
             # the row exchange of the constants needs the gathered ids and nothing of the graph: on the exchange stream, right
             # behind the id exchange and UNDER the forward hops (pack, all_to_all_v, unpack); the head joins it
             with torch.cuda.stream(self._comm_stream):

@@ -51,11 +51,10 @@ doc["mfma_utilisation"] = {"what": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE 
                                    "sell_tier_bwdw_kernel<8, true> (partial products) -- all latency-bound at <= 3B active rows, not MFMA-bound",
                            "kernels": util}
 json.dump(doc, open("profiles/%s_pmc_traffic.json" % RND, "w"), indent=1)
-# C4 shape: one full hop of the [N x 128] table, slab groups side by side (default) and one after the other
+# C4 shape: one full hop of the [N x 128] table
 import os
 c4 = {}
 for tag, label in (("c4", "tile hop over all rows, slab groups side by side (blockIdx % gs)"),
-                   ("c4o", "tile hop, slab groups one after the other (ELIMREC_SLAB_ORDER=1)"),
                    ("c4s", "window sweep over the user rows (sweep_rows_kernel) + tile hop over the item rows: both launches of a hop")):
     if not os.path.isdir(O + "/%s_fetch" % tag):
         continue

@@ -17,18 +17,13 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/eval_stat
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_INSTS_VALU --output-format csv -d $O/eval_pmc -o p -- $E > /dev/null 2>&1 < /dev/null
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/eval_fetch -o p -- $E > /dev/null 2>&1 < /dev/null
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/eval_write -o p -- $E > /dev/null 2>&1 < /dev/null
-# C4 shape (BASELINE configs[3]: |I| = 1.2 M, recdim 128): HBM traffic of a full hop, slab groups side by side and one after the other
+# C4 shape (BASELINE configs[3]: |I| = 1.2 M, recdim 128): HBM traffic of a full hop
 export SHAPE=c4
 H="python3 $R/tools/hop_only.py 128 12"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4_stats -o h -- $H > $O/c4_hop.log 2>&1 < /dev/null
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c4_fetch -o p -- $H > /dev/null 2>&1 < /dev/null
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c4_write -o p -- $H > /dev/null 2>&1 < /dev/null
 timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $O/c4_l2 -o p -- $H > /dev/null 2>&1 < /dev/null
-export ELIMREC_SLAB_ORDER=1
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4o_stats -o h -- $H > $O/c4o_hop.log 2>&1 < /dev/null
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c4o_fetch -o p -- $H > /dev/null 2>&1 < /dev/null
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c4o_write -o p -- $H > /dev/null 2>&1 < /dev/null
-unset ELIMREC_SLAB_ORDER
 # ... and the same hop with the user rows by the window sweep (csrc/sweep.hip) + the item rows by a tile plan of their own
 export SWEEP=1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4s_stats -o h -- $H > $O/c4s_hop.log 2>&1 < /dev/null
