@@ -183,6 +183,9 @@ SIGNATURES = {
     "elimrec_slab_sweep_lds_rows": (c_size, [c_i32]),
     "elimrec_slab_sweep_hop": (c_i32, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                        c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr]),
+    "elimrec_slab_sweep_hop_adam": (c_i32, [c_ptr, c_ptr, c_i64, c_i64, c_ptr, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                            c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_f32, c_f32, c_f32, c_f32,
+                                            c_i64, c_ptr]),
     "elimrec_slab_hop_bwd_w": (c_i32, [c_sell, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr, c_size, c_i32,
                                        ctypes.POINTER(LinearBwdDesc), c_i32, c_ptr, c_size, c_i32, c_ptr]),
     "elimrec_slab_source_bits": (c_i32, [c_sell, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_size, c_ptr]),

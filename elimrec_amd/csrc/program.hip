@@ -49,7 +49,7 @@ static unsigned event_flags(bool has_collectives) {
 struct FnEntry { const char *name; int (*thunk)(const uint64_t *); int n_args; };
 #define ELIMREC_FN(fn) {#fn, [](const uint64_t *a) -> int { return call_packed(fn, a); }, arg_count(fn)}
 static const FnEntry kFns[] = {
-    ELIMREC_FN(elimrec_batch_plan), ELIMREC_FN(elimrec_slab_hop), ELIMREC_FN(elimrec_slab_sweep_hop), ELIMREC_FN(elimrec_slab_source_bits), ELIMREC_FN(elimrec_slab_hop_bwd_w),
+    ELIMREC_FN(elimrec_batch_plan), ELIMREC_FN(elimrec_slab_hop), ELIMREC_FN(elimrec_slab_sweep_hop), ELIMREC_FN(elimrec_slab_sweep_hop_adam), ELIMREC_FN(elimrec_slab_source_bits), ELIMREC_FN(elimrec_slab_hop_bwd_w),
     ELIMREC_FN(elimrec_slab_hop_adam), ELIMREC_FN(elimrec_slab_rows), ELIMREC_FN(elimrec_slab_merge_rows),
     ELIMREC_FN(elimrec_head_fwd_fused), ELIMREC_FN(elimrec_bpr_head_rows),
     ELIMREC_FN(elimrec_bpr_head_rows_sum), ELIMREC_FN(elimrec_sum), ELIMREC_FN(elimrec_segment_apply_head_bwd),

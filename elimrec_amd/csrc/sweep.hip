@@ -28,6 +28,7 @@
 // Placement: workgroup b takes the role of XCD b % 8 (workgroups b and b + 8 share an XCD on this chip; another placement
 // costs speed only).
 #include "common.h"
+#include <cmath>
 
 namespace elimrec {
 
@@ -46,9 +47,14 @@ struct SweepArgs {
     const float4 *Add;
     const uint32_t *add_mask;
     float scale;
+    // ADAM: the swept rows' sums are the gradient of the table p_in, consumed here (the epilogue of the tile hop's Adam launch,
+    // slab.hip stream_epilogue, element for element); Xout then is nullable (the gradient is written only when asked for)
+    const float4 *ad_p_in;
+    float4 *ad_p_out, *ad_m, *ad_v;
+    float ad_step_size, ad_inv_sqrt_bc2, ad_beta1, ad_beta2, ad_eps, ad_wd;
 };
 
-template <int LPR>
+template <int LPR, bool ADAM>
 __global__ __launch_bounds__(64 * LPR) void sweep_rows_kernel(SweepArgs a) {
     constexpr int G = 64 / LPR;                         // lane groups of a wave
     constexpr int NT = 64 * LPR;                        // 64 lane groups per workgroup
@@ -136,7 +142,27 @@ __global__ __launch_bounds__(64 * LPR) void sweep_rows_kernel(SweepArgs a) {
                     const float4 t = a.Add[idx];
                     v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
                 }
-                a.Xout[idx] = make_float4(v.x * a.scale, v.y * a.scale, v.z * a.scale, v.w * a.scale);
+                const float4 g = make_float4(v.x * a.scale, v.y * a.scale, v.z * a.scale, v.w * a.scale);
+                if (ADAM) {
+                    typedef float f4v __attribute__((ext_vector_type(4)));       // (each touched once per step: streamed past L2, as the tile form does)
+                    const f4v p4 = __builtin_nontemporal_load((const f4v *)a.ad_p_in + idx), m4 = __builtin_nontemporal_load((const f4v *)a.ad_m + idx),
+                              v4 = __builtin_nontemporal_load((const f4v *)a.ad_v + idx);
+                    const float gr[4] = {g.x, g.y, g.z, g.w};
+                    float po[4], mi[4], vi[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float gi = fmaf(a.ad_wd, p4[i], gr[i]);
+                        mi[i] = m4[i] + (1.f - a.ad_beta1) * (gi - m4[i]);
+                        vi[i] = fmaf(1.f - a.ad_beta2, gi * gi, a.ad_beta2 * v4[i]);
+                        const float denom = sqrtf(vi[i]) * a.ad_inv_sqrt_bc2 + a.ad_eps;
+                        po[i] = p4[i] - a.ad_step_size * (mi[i] / denom);
+                    }
+                    __builtin_nontemporal_store((f4v){mi[0], mi[1], mi[2], mi[3]}, (f4v *)a.ad_m + idx);
+                    __builtin_nontemporal_store((f4v){vi[0], vi[1], vi[2], vi[3]}, (f4v *)a.ad_v + idx);
+                    a.ad_p_out[idx] = make_float4(po[0], po[1], po[2], po[3]);
+                    if (!a.Xout) continue;
+                }
+                a.Xout[idx] = g;
             }
             __syncthreads();
         }
@@ -154,35 +180,66 @@ extern "C" size_t elimrec_slab_sweep_lds_rows(int w) {
     return rows < 65534 ? rows : 65534;
 }
 
-extern "C" int elimrec_slab_sweep_hop(const int64_t *d_slot_ptr, const void *d_records,
-                                      int64_t n_rows, int64_t n_src, const int32_t *d_block_ptr, int parts, int passes, int bpx,
-                                      int max_block_rows, int ns, int w, const float *d_Xin, float *d_Xout,
-                                      const float *d_add, const uint32_t *d_add_mask, float scale, void *stream) {
-    ELIMREC_REQUIRE(d_slot_ptr && d_records && d_block_ptr && d_Xin && d_Xout, "slab_sweep_hop: null pointer");
-    ELIMREC_REQUIRE(d_Xin != d_Xout, "slab_sweep_hop: Xout must not alias Xin");
-    ELIMREC_REQUIRE(w == 32 || w == 16, "slab_sweep_hop: slab width %d (32 or 16 floats)", w);
-    ELIMREC_REQUIRE(ns >= 1 && (ns <= 8 ? 8 % ns == 0 : ns % 8 == 0), "slab_sweep_hop: %d slabs do not tile the 8 XCD roles", ns);
+static int sweep_launch(const char *who, const int64_t *d_slot_ptr, const void *d_records, int64_t n_rows, int64_t n_src,
+                        const int32_t *d_block_ptr, int parts, int passes, int bpx, int max_block_rows, int ns, int w, const float *d_Xin,
+                        float *d_Xout, const float *d_add, const uint32_t *d_add_mask, float scale, const SweepArgs *adam, void *stream) {
+    ELIMREC_REQUIRE(d_slot_ptr && d_records && d_block_ptr && d_Xin && (d_Xout || adam), "%s: null pointer", who);
+    ELIMREC_REQUIRE(d_Xin != d_Xout, "%s: Xout must not alias Xin", who);
+    ELIMREC_REQUIRE(w == 32 || w == 16, "%s: slab width %d (32 or 16 floats)", who, w);
+    ELIMREC_REQUIRE(ns >= 1 && (ns <= 8 ? 8 % ns == 0 : ns % 8 == 0), "%s: %d slabs do not tile the 8 XCD roles", who, ns);
     const int nsx = ns < 8 ? ns : 8;
-    ELIMREC_REQUIRE(parts == 8 / nsx && passes >= 1 && bpx >= 1, "slab_sweep_hop: bad partition (parts %d passes %d bpx %d)", parts, passes, bpx);
-    ELIMREC_REQUIRE(max_block_rows >= 1 && (size_t)max_block_rows <= elimrec_slab_sweep_lds_rows(w), "slab_sweep_hop: a block of %d rows does not fit LDS",
-                    max_block_rows);
-    ELIMREC_REQUIRE(n_src * (w / 4) < ((int64_t)1 << 32), "slab_sweep_hop: source piece numbers must fit 32 bits");
-    SweepArgs a;
+    ELIMREC_REQUIRE(parts == 8 / nsx && passes >= 1 && bpx >= 1, "%s: bad partition (parts %d passes %d bpx %d)", who, parts, passes, bpx);
+    ELIMREC_REQUIRE(max_block_rows >= 1 && (size_t)max_block_rows <= elimrec_slab_sweep_lds_rows(w), "%s: a block of %d rows does not fit LDS",
+                    who, max_block_rows);
+    ELIMREC_REQUIRE(n_src * (w / 4) < ((int64_t)1 << 32), "%s: source piece numbers must fit 32 bits", who);
+    SweepArgs a = adam ? *adam : SweepArgs{};
     a.slot_ptr = d_slot_ptr; a.rec = (const uint4 *)d_records; a.dummy = max_block_rows; a.n_rows = n_rows; a.n_src = n_src;
     a.block_ptr = d_block_ptr; a.parts = parts; a.passes = passes; a.bpx = bpx; a.ns = ns; a.nsx = nsx;
     a.Xin = (const float4 *)d_Xin; a.Xout = (float4 *)d_Xout; a.Add = (const float4 *)d_add; a.add_mask = d_add_mask; a.scale = scale;
     const size_t lds = (size_t)(max_block_rows + 1) * (size_t)w * 4;
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(8 * bpx));
-    if (w == 32) {
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void *)sweep_rows_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-        hipLaunchKernelGGL((sweep_rows_kernel<8>), grid, dim3(512), lds, s, a);
-    } else {
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void *)sweep_rows_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
-        hipLaunchKernelGGL((sweep_rows_kernel<4>), grid, dim3(256), lds, s, a);
-    }
-    ELIMREC_LAUNCH_CHECK("slab_sweep_hop");
-    return 0;
+#define ELIMREC_SWEEP(LPR_, ADAM_)                                                                                                       \
+    do {                                                                                                                                 \
+        static bool attr = false;                                                                                                        \
+        if (!attr) {                                                                                                                     \
+            (void)hipFuncSetAttribute((const void *)sweep_rows_kernel<LPR_, ADAM_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+            attr = true;                                                                                                                 \
+        }                                                                                                                                \
+        hipLaunchKernelGGL((sweep_rows_kernel<LPR_, ADAM_>), grid, dim3(64 * LPR_), lds, s, a);                                          \
+    } while (0)
+    if (w == 32) { if (adam) ELIMREC_SWEEP(8, true); else ELIMREC_SWEEP(8, false); }
+    else { if (adam) ELIMREC_SWEEP(4, true); else ELIMREC_SWEEP(4, false); }
+#undef ELIMREC_SWEEP
+    return check_hip(hipGetLastError(), who);
+}
+
+extern "C" int elimrec_slab_sweep_hop(const int64_t *d_slot_ptr, const void *d_records,
+                                      int64_t n_rows, int64_t n_src, const int32_t *d_block_ptr, int parts, int passes, int bpx,
+                                      int max_block_rows, int ns, int w, const float *d_Xin, float *d_Xout,
+                                      const float *d_add, const uint32_t *d_add_mask, float scale, void *stream) {
+    return sweep_launch("slab_sweep_hop", d_slot_ptr, d_records, n_rows, n_src, d_block_ptr, parts, passes, bpx, max_block_rows, ns, w,
+                        d_Xin, d_Xout, d_add, d_add_mask, scale, nullptr, stream);
+}
+
+// The same sweep as the adjoint's LAST hop: the swept rows' sums are the gradient of the fp32 table d_p_in, consumed by the Adam
+// step in the launch's epilogue (the arithmetic of elimrec_slab_hop_adam / elimrec_adam_multi, element for element; coupled L2,
+// 1-based step); d_grad_out nullable.
+extern "C" int elimrec_slab_sweep_hop_adam(const int64_t *d_slot_ptr, const void *d_records, int64_t n_rows, int64_t n_src,
+                                           const int32_t *d_block_ptr, int parts, int passes, int bpx, int max_block_rows, int ns, int w,
+                                           const float *d_Xin, float *d_grad_out, const float *d_add, const uint32_t *d_add_mask,
+                                           float scale, const float *d_p_in, float *d_p_out, float *d_m, float *d_v, float lr,
+                                           float beta1, float beta2, float eps, float weight_decay, int64_t step, void *stream) {
+    ELIMREC_REQUIRE(d_p_in && d_p_out && d_m && d_v, "slab_sweep_hop_adam: null pointer");
+    ELIMREC_REQUIRE(step >= 1, "slab_sweep_hop_adam: 1-based step");
+    ELIMREC_REQUIRE((const void *)d_Xin != (const void *)d_p_out && (const void *)d_Xin != (const void *)d_m &&
+                        (const void *)d_Xin != (const void *)d_v, "slab_sweep_hop_adam: the gathered table must not be written");
+    SweepArgs ad = {};
+    ad.ad_p_in = (const float4 *)d_p_in; ad.ad_p_out = (float4 *)d_p_out; ad.ad_m = (float4 *)d_m; ad.ad_v = (float4 *)d_v;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    ad.ad_step_size = (float)((double)lr / bc1);
+    ad.ad_inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    ad.ad_beta1 = beta1; ad.ad_beta2 = beta2; ad.ad_eps = eps; ad.ad_wd = weight_decay;
+    return sweep_launch("slab_sweep_hop_adam", d_slot_ptr, d_records, n_rows, n_src, d_block_ptr, parts, passes, bpx, max_block_rows, ns, w,
+                        d_Xin, d_grad_out, d_add, d_add_mask, scale, &ad, stream);
 }

@@ -921,7 +921,7 @@ class ColumnShardEngine(object):
         tiered plan, at least two layers (ELIMREC_FUSE_ADAM=0 keeps the separate optimizer launch; `keep_grad` = True also
         stores the gradient table, for tests that read it)."""
         import os
-        return (not self.wide and not self.sweep and self.planT.tiered and self.model.n_layers >= 2
+        return (not self.wide and self.planT.tiered and self.model.n_layers >= 2
                 and os.environ.get("ELIMREC_FUSE_ADAM", "1") != "0")
 
     @_once
@@ -931,7 +931,7 @@ class ColumnShardEngine(object):
         import os
         m = self.model
         hops_in_region = m.n_layers - (1 if self._fuse_adam() else 0)
-        return (os.environ.get("ELIMREC_FUSE_REDUCE", "1") != "0" and not self.wide and not self.sweep and self.planT.tiered
+        return (os.environ.get("ELIMREC_FUSE_REDUCE", "1") != "0" and not self.wide and self.planT.tiered
                 and hops_in_region >= 1 and m.mm_fusion_mode == "concat")
 
     @_once

@@ -444,6 +444,17 @@ class SweepPlan(object):
                                                       _dev(None if add is None else add.data, "add"),
                                                       _dev(add_mask, "add_mask", torch.int32), float(scale), _stream()), "slab_sweep_hop")
 
+    def hop_adam(self, xin, grad_out, add, add_mask, scale, p_in, p_out, m, v, lr, beta1, beta2, eps, weight_decay, step):
+        """elimrec_slab_sweep_hop_adam: the swept rows of the adjoint's last hop, their Adam step as the launch's epilogue."""
+        ns, w = xin.ns, xin.w
+        g = self.geometry(ns, w)
+        _lib.check(_lib.load().elimrec_slab_sweep_hop_adam(
+            _dev(g["slot_ptr"], "slot_ptr", torch.int64), _dev(g["rec"], "records", torch.int32), self.n, self.n,
+            _dev(g["block_ptr"], "block_ptr", torch.int32), g["parts"], g["passes"], g["bpx"], g["rows"], ns, w, _dev(xin.data, "xin"),
+            _dev(None if grad_out is None else grad_out.data, "grad"), _dev(None if add is None else add.data, "add"),
+            _dev(add_mask, "add_mask", torch.int32), float(scale), _dev(p_in, "p_in"), _dev(p_out, "p_out"), _dev(m, "m"), _dev(v, "v"),
+            float(lr), float(beta1), float(beta2), float(eps), float(weight_decay), int(step), _stream()), "slab_sweep_hop_adam")
+
 
 SWEEP_AUTO_MAX_NNZ = 1 << 27
 
@@ -505,6 +516,11 @@ def source_bits(plan, ns, w, gs, src_mask):
                                                     _dev(part, "partials"), part.numel() * 4, _stream()), "slab_source_bits")
 
 
+def _swept(plan, xin):
+    """Whether whole hops of this plan on tables of xin's geometry take the two-launch form with a swept side."""
+    return plan.sweep is not None and xin.w in (16, 32) and sweep_tiles_xcds(xin.ns)
+
+
 def hop(plan, xin, xout, gs=None, src_mask=None, add=None, add_mask=None, scale=1.0, seg_only=False, bits_ready=False, bwd_w=None, bwd_w_phase=1):
     """xout = (A . xin + [add_mask] add) * scale on slab tables of equal geometry. seg_only: xout is a flat fp32 tensor
     [ns x n_long x w] receiving the split rows only.
@@ -512,10 +528,10 @@ def hop(plan, xin, xout, gs=None, src_mask=None, add=None, add_mask=None, scale=
     0: its partial launch, run as extra workgroups of this launch (fp32 tables, tiered plan: elimrec_slab_hop_bwd_w)."""
     ns, w = xin.ns, xin.w
     gs = choose_groups(ns) if gs is None else gs
-    if (plan.sweep is not None and src_mask is None and not seg_only and bwd_w is None and isinstance(xout, SlabTable) and w in (16, 32)
-            and sweep_tiles_xcds(xin.ns)):
-        # a whole hop of a graph with a swept side: the tile hop over the other side's rows, the window sweep over this side's
-        hop(plan.sweep.items, xin, xout, gs=gs, add=add, add_mask=add_mask, scale=scale)
+    if _swept(plan, xin) and src_mask is None and not seg_only and isinstance(xout, SlabTable):
+        # a whole hop of a graph with a swept side: the tile hop over the other side's rows (it carries the weight gradients' extra
+        # workgroups, if any), the window sweep over this side's
+        hop(plan.sweep.items, xin, xout, gs=gs, add=add, add_mask=add_mask, scale=scale, bwd_w=bwd_w, bwd_w_phase=bwd_w_phase)
         plan.sweep.hop(xin, xout, add=add, add_mask=add_mask, scale=scale)
         return
     part = plan.partials(ns, w)
@@ -547,6 +563,13 @@ def hop_adam(plan, xin, grad_out, gs, add, add_mask, scale, p_in, p_out, m, v, l
     else:
         arr, n_tail = ((_lib.AdamJob * len(tail_jobs))(*tail_jobs) if tail_jobs else None), len(tail_jobs)
     ns, w = xin.ns, xin.w
+    if _swept(plan, xin):
+        # the other side's rows by the tile hop (with the optimizer spans and the loss sum as its extra workgroups), the swept side's
+        # by the window sweep: both with the Adam step as their epilogue, on disjoint rows of the same buffers
+        hop_adam(plan.sweep.items, xin, grad_out, gs, add, add_mask, scale, p_in, p_out, m, v, lr, beta1, beta2, eps, weight_decay, step,
+                 tail_jobs=(arr, n_tail), loss_sum=loss_sum)
+        plan.sweep.hop_adam(xin, grad_out, add, add_mask, scale, p_in, p_out, m, v, lr, beta1, beta2, eps, weight_decay, step)
+        return
     part = plan.partials(ns, w)
     _lib.check(_lib.load().elimrec_slab_hop_adam(
         plan.ref(), ns, w, int(gs), _dev(xin.data, "xin"), _dev(None if grad_out is None else grad_out.data, "grad"),

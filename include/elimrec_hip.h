@@ -613,6 +613,15 @@ int elimrec_slab_sweep_hop(const int64_t *d_slot_ptr, const void *d_records,
                            int64_t n_rows, int64_t n_src, const int32_t *d_block_ptr, int parts, int passes, int bpx,
                            int max_block_rows, int ns, int w, const float *d_Xin, float *d_Xout,
                            const float *d_add, const uint32_t *d_add_mask, float scale, void *stream);
+/* ... as the adjoint's LAST hop over the swept rows: their sums are the gradient of the fp32 table d_p_in and are consumed by the
+ * Adam step (torch.optim.Adam with coupled L2, main.py:101; the arithmetic of elimrec_slab_hop_adam, element for element) in the
+ * launch's epilogue -- no gradient table written and read back; d_grad_out nullable (also store the gradient). The rows of the
+ * other side are elimrec_slab_hop_adam's on a plan of those rows (the two launches update disjoint rows of the same buffers). */
+int elimrec_slab_sweep_hop_adam(const int64_t *d_slot_ptr, const void *d_records, int64_t n_rows, int64_t n_src,
+                                const int32_t *d_block_ptr, int parts, int passes, int bpx, int max_block_rows, int ns, int w,
+                                const float *d_Xin, float *d_grad_out, const float *d_add, const uint32_t *d_add_mask, float scale,
+                                const float *d_p_in, float *d_p_out, float *d_m, float *d_v, float lr, float beta1, float beta2,
+                                float eps, float weight_decay, int64_t step /* 1-based */, void *stream);
 
 /* Tiered plans look the source bitmap up once per index entry before a masked hop (one 64-bit word per index line, kept
  * in d_partials). This entry runs that pass alone -- e.g. on a second stream as soon as the batch's active rows are

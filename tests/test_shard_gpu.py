@@ -303,20 +303,26 @@ def test_tiktok_word_bag_fixture_on_the_engine(mode):
     assert np.abs(model.predict(users).numpy() - g["predict/rubi/TIE"]).max() < 1e-5
 
 
-def test_trainer_with_the_window_sweep_matches_the_reference_fixtures(monkeypatch):
+@pytest.mark.parametrize("fused", ["1", "0"])
+def test_trainer_with_the_window_sweep_matches_the_reference_fixtures(monkeypatch, fused):
     """ELIMREC_SWEEP=1 forces the large-table form of the hops on the small fixtures: whole hops = tile hop over the item rows +
-    window sweep over the user rows, no tails on the hops (Adam and the weight gradients in launches of their own). Three trainer
-    steps reproduce the reference's golden losses and parameters, as the default form does."""
+    window sweep over the user rows. fused = 1 (the default): the adjoint's second hop carries the weight gradients' slab reduce
+    behind the item rows' tiles, and the last hop's two launches have the Adam step as their epilogue (elimrec_slab_sweep_hop_adam
+    for the user rows; the optimizer spans of the projections ride with the item rows); fused = 0: Adam and the weight gradients in
+    launches of their own. Three trainer steps reproduce the reference's golden losses and parameters, as the default form does."""
     from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
     monkeypatch.setenv("ELIMREC_SWEEP", "1")
     monkeypatch.setenv("ELIMREC_SWEEP_WINDOW", "64")
+    if fused == "0":
+        monkeypatch.setenv("ELIMREC_FUSE_ADAM", "0")
+        monkeypatch.setenv("ELIMREC_FUSE_REDUCE", "0")
     for name in ("ml3", "kwai", "gcmc"):
         g = load_golden(name)
         model, cfg = build_model_from_fixture(g, DEV)
         opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
         eng = ColumnShardEngine(model)
         tr = ColumnShardTrainer(eng, opt)
-        assert eng.sweep and eng.plan.sweep is not None and not eng._fuse_adam()
+        assert eng.sweep and eng.plan.sweep is not None and eng._fuse_adam() == (fused == "1") and eng._fuse_reduce() == (fused == "1")
         steps = int(g["steps"])
         for t in range(1, steps + 1):
             loss = tr.step(*(_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg")))
