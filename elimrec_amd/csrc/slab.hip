@@ -651,6 +651,19 @@ __device__ __forceinline__ void tier_body(const TierArgs &t, float *lds = nullpt
         glen = t.tile_len[(int64_t)ti * G + sub];
         dst = t.tile_dst[(int64_t)ti * G + sub];
     }
+    if (a.compact_long && a.add_mask && ti < t.n_tiles_run) {
+        // the split rows only (seg_only), and of those only the WANTED ones (a.add_mask: bit r = row r's sum is read -- the rows of the
+        // batch): a row nobody reads costs no gathers. A workgroup's / a wave's row is the same for all its lanes; a segment tile's
+        // lane groups belong to different rows -- one that is not wanted publishes nothing and draws no ticket (all segments of a
+        // row decide alike, so its tickets stay at rest)
+        if (wg_row || ti < t.tseg_base) {
+            const int row = __shfl(dst, 0, 64);
+            if (row >= 0 && !bit_of(a.add_mask, row)) return;          // (workgroup rows: the four waves share the row -- all return)
+        } else if (dst >= 0) {
+            const int li0 = t.tile_long[(int64_t)(ti - t.tseg_base) * G + sub];
+            if (!bit_of(a.add_mask, a.long_rows[li0])) { dst = -1; glen = 0; }
+        }
+    }
     float acc[VPL];
     tile_gather<LPR, VPL, IN_BF16, MASKED>(t, ti, in_base, off, steps, glen, lane, sub, acc);
     if (wg_row) {

@@ -931,8 +931,18 @@ class ColumnShardEngine(object):
         import os
         m = self.model
         hops_in_region = m.n_layers - (1 if self._fuse_adam() else 0)
-        return (os.environ.get("ELIMREC_FUSE_REDUCE", "1") != "0" and not self.wide and self.planT.tiered
+        # (not with the swept form: at the configs[3] shape the masked hop that carries the reduce takes 898 us against 700 + 14 apart)
+        return (os.environ.get("ELIMREC_FUSE_REDUCE", "1") != "0" and not self.wide and not self.sweep and self.planT.tiered
                 and hops_in_region >= 1 and m.mm_fusion_mode == "concat")
+
+    @_once
+    def _long_wanted_only(self):
+        """Hop L at the split rows of the batch only (elimrec_slab_hop, seg_only with the wanted-rows bitmap): one rank, the swept
+        form (ELIMREC_LONG_WANTED=1 / 0 forces it on / off)."""
+        import os
+        e = os.environ.get("ELIMREC_LONG_WANTED")
+        return (not self.multi and not self.wide and self.planT.tiered and self.plan.tiered
+                and (self.sweep if e is None else e == "1"))
 
     @_once
     def _fuse_bwd_w(self):
@@ -1158,8 +1168,6 @@ class ColumnShardEngine(object):
                 self._plan_rec = None
             else:
                 program.sync(torch.cuda.current_stream(), self._aux)
-        if self._aux_pending and not late_wait:                  # the plan (and the packed weights) from the second stream
-            join_plan()
         self._aux_pending = False
         if self.multi:
             counts = None                                        # the gathered lists are padded with negative keys
@@ -1174,9 +1182,18 @@ class ColumnShardEngine(object):
         long_done = getattr(self, "_long_done", False)          # cs_forward_long issued it already (several ranks)
         self._long_done = False
 
+        # the swept form (tables beyond the caches: every user row of configs[3] is a split row): layer L only at the split rows
+        # of the BATCH -- the planner's bitmap of the active rows says which -- so the join comes first (651 -> 60 us there; at the
+        # Tiktok shape the split rows are the popular items, nearly all of them in every batch, and the join ahead of the hop costs more)
+        wanted = self.mask if (self._long_wanted_only() and self._bits_ready and not long_done) else None
+        joined = False
+        if wanted is not None and late_wait:
+            join_plan()
+            late_wait, joined = False, True
+
         def long_rows():
             if self.plan.n_long and not self.wide and not long_done:
-                slab.hop(self.plan, self._srcs[L - 1], self.long_tab, gs=self.gs, seg_only=True)
+                slab.hop(self.plan, self._srcs[L - 1], self.long_tab, gs=self.gs, seg_only=True, add_mask=wanted)
 
         def rows():
             if not late_wait:
@@ -1193,13 +1210,14 @@ class ColumnShardEngine(object):
                 self.fshard.unpack(ws["active_rows"][:R], None, self.s_rows, self.c_rows, direct=True)
         if late_wait:
             m._region("cs_fwd_long%d" % self.cur, (m._ws_gen,), long_rows)
-            join_plan()
-            if getattr(self, "_late_bits", False):             # (large batches) the adjoint's source bits: behind the forward's join
-                self._late_bits = False
-                with torch.cuda.stream(self._aux):
-                    m._region("cs_late_bits", (m._ws_gen, R), lambda: slab.source_bits(self.planT, self.hns, self.w, self.hgs, self.mask))
-                self._bits_join = True
-        m._region("cs_fwd_rows%d" % self.cur, (m._ws_gen, acts.data_ptr(), R, W, narrow.data_ptr(), late_wait, self._rows_in_head), rows)
+            join_plan()                                        # the plan (and the packed weights) from the second stream
+            joined = True
+        if joined and getattr(self, "_late_bits", False):      # (large batches) the adjoint's source bits: behind the forward's join
+            self._late_bits = False
+            with torch.cuda.stream(self._aux):
+                m._region("cs_late_bits", (m._ws_gen, R), lambda: slab.source_bits(self.planT, self.hns, self.w, self.hgs, self.mask))
+            self._bits_join = True
+        m._region("cs_fwd_rows%d" % self.cur, (m._ws_gen, acts.data_ptr(), R, W, narrow.data_ptr(), late_wait, self._rows_in_head, wanted is not None), rows)
         return self.send_f if self.multi else None
 
     @torch.no_grad()

@@ -585,7 +585,9 @@ int elimrec_plan_scatter(int64_t n_tiles, int G, const int64_t *d_tile_off, cons
  * d_partials: scratch of elimrec_slab_partials_bytes: [ns x n_seg x w] floats for the split rows, the in-launch
  * combine's arrival counters and (tiered plans) the masked hop's per-index-line source bits; zero-filled once. seg_only != 0: only the split rows are
  * evaluated and written COMPACTLY to d_Xout viewed as [ns x n_long x w] (no add/scale) -- the part of hop L
- * that elimrec_slab_rows cannot do inline.
+ * that elimrec_slab_rows cannot do inline; d_add_mask (nullable) then is the bitmap of the rows whose sums are WANTED (the
+ * batch's rows: models/EliMRec.py:274-281 reads layer L at the batch rows only) -- the others are not evaluated and their
+ * compact rows keep what they held (tiered plans; the two-launch form evaluates every split row).
  * Replaces torch.sparse.mm (models/EliMRec.py:244) and its backward for one column slice. */
 size_t elimrec_slab_partials_bytes(const elimrec_sell *A, int ns, int w);
 /* d_partials must be zero-filled once after allocation (the one-launch tile form keeps its arrival counters there). */

@@ -306,23 +306,21 @@ def test_tiktok_word_bag_fixture_on_the_engine(mode):
 @pytest.mark.parametrize("fused", ["1", "0"])
 def test_trainer_with_the_window_sweep_matches_the_reference_fixtures(monkeypatch, fused):
     """ELIMREC_SWEEP=1 forces the large-table form of the hops on the small fixtures: whole hops = tile hop over the item rows +
-    window sweep over the user rows. fused = 1 (the default): the adjoint's second hop carries the weight gradients' slab reduce
-    behind the item rows' tiles, and the last hop's two launches have the Adam step as their epilogue (elimrec_slab_sweep_hop_adam
-    for the user rows; the optimizer spans of the projections ride with the item rows); fused = 0: Adam and the weight gradients in
-    launches of their own. Three trainer steps reproduce the reference's golden losses and parameters, as the default form does."""
+    window sweep over the user rows. fused = 1 (the default): the last hop's two launches have the Adam step as their epilogue
+    (elimrec_slab_sweep_hop_adam for the user rows; the optimizer spans of the projections ride with the item rows); fused = 0: Adam
+    in a launch of its own. (The weight gradients' reduce is a launch of its own in this form either way.) Three trainer steps reproduce the reference's golden losses and parameters, as the default form does."""
     from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
     monkeypatch.setenv("ELIMREC_SWEEP", "1")
     monkeypatch.setenv("ELIMREC_SWEEP_WINDOW", "64")
     if fused == "0":
         monkeypatch.setenv("ELIMREC_FUSE_ADAM", "0")
-        monkeypatch.setenv("ELIMREC_FUSE_REDUCE", "0")
     for name in ("ml3", "kwai", "gcmc"):
         g = load_golden(name)
         model, cfg = build_model_from_fixture(g, DEV)
         opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
         eng = ColumnShardEngine(model)
         tr = ColumnShardTrainer(eng, opt)
-        assert eng.sweep and eng.plan.sweep is not None and eng._fuse_adam() == (fused == "1") and eng._fuse_reduce() == (fused == "1")
+        assert eng.sweep and eng.plan.sweep is not None and eng._fuse_adam() == (fused == "1") and not eng._fuse_reduce()
         steps = int(g["steps"])
         for t in range(1, steps + 1):
             loss = tr.step(*(_t(g["step%d/%s" % (t, k)]) for k in ("users", "pos", "neg")))
@@ -331,6 +329,36 @@ def test_trainer_with_the_window_sweep_matches_the_reference_fixtures(monkeypatc
         sd = model.state_dict()
         for k, v in sub(g, "after%d" % steps).items():
             assert np.abs(sd[k].cpu().numpy() - v).max() < 2e-5, (name, k)
+
+
+def test_split_rows_of_the_batch_only_changes_no_bit(monkeypatch):
+    """ELIMREC_LONG_WANTED=1 forces what the swept form does by default -- hop L's split rows evaluated for the batch's rows only,
+    behind the join with the planner -- on a synthetic graph with rows of hundreds of neighbours: losses, parameters and Adam
+    moments after ten steps (the native program engaged) are bitwise those of the default order (every split row, ahead of the join)."""
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, EliMRec, FusedAdam, SyntheticDataset, set_seed
+    cfg = make_config(["--data.input.dataset=synthetic", "--alpha=0.5", "--loss=bpr_loss", "--recdim=64", "--verbose=0"])
+    ds = SyntheticDataset(300, 2500, 40000, feat_dims=(16, 8, 12), seed=3)
+    gen = torch.Generator().manual_seed(5)
+    B = 256
+    batches = [(torch.randint(0, 300, (B,), generator=gen).to(DEV), torch.randint(0, 2500, (B,), generator=gen).to(DEV),
+                torch.randint(0, 2500, (B,), generator=gen).to(DEV)) for _ in range(10)]
+    got = {}
+    for wanted in ("0", "1"):
+        monkeypatch.setenv("ELIMREC_LONG_WANTED", wanted)
+        set_seed(11)
+        model = EliMRec(cfg, ds).to(DEV)
+        opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+        eng = ColumnShardEngine(model)
+        tr = ColumnShardTrainer(eng, opt)
+        assert eng._long_wanted_only() == (wanted == "1") and eng.plan.n_long > 100       # (every user row: ~130 neighbours each)
+        losses = [float(tr.step(*b)) for b in batches]
+        assert tr._native_state()["native_steps"] > 0 and tr._native_state()["failed"] is None
+        eng.sync_to_model()
+        st = eng.optimizer_state()
+        got[wanted] = (losses, {k: v.clone() for k, v in model.state_dict().items()}, st["exp_avg"].clone(), st["exp_avg_sq"].clone())
+    a, b = got["0"], got["1"]
+    assert a[0] == b[0]
+    assert all(torch.equal(a[1][k], b[1][k]) for k in a[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
 
 
 @pytest.mark.parametrize("d,w,L", [(64, 32, 3), (16, 16, 2), (8, 8, 4), (64, 8, 1), (32, 32, 3)])
@@ -382,6 +410,24 @@ def test_slab_rows_layer_means_and_inline_last_hop(d, w, L):
         assert torch.equal(packed[li * R:li * R + cnt, :d], mean[r])
         assert torch.equal(packed[li * R:li * R + cnt, d:], nar[r])
         assert torch.isnan(packed[li * R + cnt:(li + 1) * R]).all()          # padded slots are not written
+    # the split rows of the WANTED rows only (seg_only with a row bitmap: the batch's rows): the listed rows read the same bits,
+    # the split rows nobody listed keep what the buffer held
+    wanted = torch.zeros((n + 31) // 32, dtype=torch.int32, device=DEV)
+    slab.rows_bitmap(rows, n, wanted)
+    long2 = torch.full_like(long_tab, 7.0)
+    slab.hop(plan, tabs[L - 1], long2, seg_only=True, add_mask=wanted)
+    packed2 = torch.full((2 * R, 2 * d), float("nan"), device=DEV)
+    slab.rows(plan, ns, w, L, U, [t.data for t in tabs[:L]] + [None], long2, rows, cnts, R, 2, packed2[:, :d], packed2[:, d:], False)
+    for li, cnt in enumerate(counts):
+        assert torch.equal(packed2[li * R:li * R + cnt], packed[li * R:li * R + cnt])
+    if plan.n_long:
+        listed = torch.zeros(n, dtype=torch.bool, device=DEV)
+        for li, cnt in enumerate(counts):
+            listed[rows[li, :cnt].long()] = True
+        lt, l2 = long_tab.view(ns, plan.n_long, w), long2.view(ns, plan.n_long, w)
+        is_listed = listed[plan.t["long_rows"].long()[:plan.n_long]]
+        assert torch.equal(l2[:, is_listed], lt[:, is_listed])
+        assert (l2[:, ~is_listed] == 7.0).all() and bool((~is_listed).any())
 
 
 @pytest.mark.parametrize("W,R,U,I,d,w", [(5, 300, 700, 1300, 32, 32), (2, 64, 40, 90, 64, 8), (8, 1000, 3000, 5000, 8, 8),

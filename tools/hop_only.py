@@ -114,16 +114,27 @@ if getattr(plan, "sweep", None) is not None and os.environ.get("EXPT") == "1":
         print("  EXPT %s: %.2f us per hop" % (name, e0.elapsed_time(e1) * 1e3 / 30))
 if os.environ.get("MASKED"):                 # the first adjoint hop alone: a source table of which MASKED random rows are active
     import numpy as np
-    R = int(os.environ["MASKED"])
-    keys = torch.from_numpy(np.random.default_rng(0).choice(N, R, replace=False).astype(np.int32)).to(dev).view(1, -1).contiguous()
+    if os.environ["MASKED"] == "batch":      # the rows of a sampled training batch of 2048 triplets (positives drawn by interaction)
+        from elimrec_amd import PairwiseSamplerV2
+        bu, bp, bn = PairwiseSamplerV2(ds, batch_size=2048, device=dev).sample_epoch()
+        k = torch.cat([bu[:2048], U + bp[:2048], U + bn[:2048]]).unique().to(torch.int32)
+        R = int(k.numel())
+        keys = k.view(1, -1).contiguous()
+    else:
+        R = int(os.environ["MASKED"])
+        keys = torch.from_numpy(np.random.default_rng(0).choice(N, R, replace=False).astype(np.int32)).to(dev).view(1, -1).contiguous()
     mask = torch.zeros((N + 31) // 32, dtype=torch.int32, device=dev)
     slab.rows_bitmap(keys, N, mask)
     slab.source_bits(plan, ns, w, gs, mask)
-    for name, kw in (("masked hop, source bits ready", dict(src_mask=mask, bits_ready=True)), ("full hop", {})):
-        for _ in range(3): slab.hop(plan, tabs[0], tabs[1], gs=gs, **kw)
+    forms = [("masked hop, source bits ready", plan, dict(src_mask=mask, bits_ready=True)), ("full hop", plan, {})]
+    if getattr(plan, "sweep", None) is not None:
+        slab.source_bits(plan.sweep.items, ns, w, gs, mask)
+        forms.append(("masked tile hop over the ITEM rows only", plan.sweep.items, dict(src_mask=mask, bits_ready=True)))
+    for name, pl, kw in forms:
+        for _ in range(3): slab.hop(pl, tabs[0], tabs[1], gs=gs, **kw)
         torch.cuda.synchronize()
         e0.record()
-        for _ in range(40): slab.hop(plan, tabs[0], tabs[1], gs=gs, **kw)
+        for _ in range(40): slab.hop(pl, tabs[0], tabs[1], gs=gs, **kw)
         e1.record()
         torch.cuda.synchronize()
         print("  %s (%d active rows of %d): %.2f us" % (name, R, N, e0.elapsed_time(e1) * 1e3 / 40))
