@@ -410,24 +410,27 @@ def test_slab_rows_layer_means_and_inline_last_hop(d, w, L):
         assert torch.equal(packed[li * R:li * R + cnt, :d], mean[r])
         assert torch.equal(packed[li * R:li * R + cnt, d:], nar[r])
         assert torch.isnan(packed[li * R + cnt:(li + 1) * R]).all()          # padded slots are not written
-    # the split rows of the WANTED rows only (seg_only with a row bitmap: the batch's rows): the listed rows read the same bits,
-    # the split rows nobody listed keep what the buffer held
-    wanted = torch.zeros((n + 31) // 32, dtype=torch.int32, device=DEV)
-    slab.rows_bitmap(rows, n, wanted)
-    long2 = torch.full_like(long_tab, 7.0)
-    slab.hop(plan, tabs[L - 1], long2, seg_only=True, add_mask=wanted)
-    packed2 = torch.full((2 * R, 2 * d), float("nan"), device=DEV)
-    slab.rows(plan, ns, w, L, U, [t.data for t in tabs[:L]] + [None], long2, rows, cnts, R, 2, packed2[:, :d], packed2[:, d:], False)
-    for li, cnt in enumerate(counts):
-        assert torch.equal(packed2[li * R:li * R + cnt], packed[li * R:li * R + cnt])
-    if plan.n_long:
+    # the split rows of the WANTED rows only (seg_only with a row bitmap -- the batch's rows -- on the wave-tile plan the engine uses):
+    # the listed rows' compact rows hold the bits of the launch over every split row, those nobody listed keep what the buffer held
+    gs = slab.choose_groups(ns)
+    plan_t = slab.SellPlan(m, DEV, threshold=32, side_split=U, tiered=True, ipw=64 // ((ns // gs) * (w // 4)))
+    if plan_t.n_long:
+        lr = plan_t.t["long_rows"][:plan_t.n_long]
         listed = torch.zeros(n, dtype=torch.bool, device=DEV)
         for li, cnt in enumerate(counts):
             listed[rows[li, :cnt].long()] = True
-        lt, l2 = long_tab.view(ns, plan.n_long, w), long2.view(ns, plan.n_long, w)
-        is_listed = listed[plan.t["long_rows"].long()[:plan.n_long]]
-        assert torch.equal(l2[:, is_listed], lt[:, is_listed])
-        assert (l2[:, ~is_listed] == 7.0).all() and bool((~is_listed).any())
+        listed[lr[::2].long()] = True                                            # (... and every second split row, listed or not)
+        wanted = torch.zeros((n + 31) // 32, dtype=torch.int32, device=DEV)
+        slab.rows_bitmap(torch.nonzero(listed).flatten().int().view(1, -1).contiguous(), n, wanted)
+        long_all = torch.full((ns * plan_t.n_long * w,), 7.0, device=DEV)
+        long_w = torch.full_like(long_all, 7.0)
+        slab.hop(plan_t, tabs[L - 1], long_all, gs=gs, seg_only=True)
+        slab.hop(plan_t, tabs[L - 1], long_w, gs=gs, seg_only=True, add_mask=wanted)
+        la, lw = long_all.view(ns, plan_t.n_long, w), long_w.view(ns, plan_t.n_long, w)
+        is_listed = listed[plan_t.t["long_rows"].long()[:plan_t.n_long]]
+        assert bool(is_listed.any()) and (plan_t.n_long < 2 or bool((~is_listed).any())) and not bool((la == 7.0).all(-1).all(0).any())
+        assert torch.equal(lw[:, is_listed], la[:, is_listed])
+        assert (lw[:, ~is_listed] == 7.0).all()
 
 
 @pytest.mark.parametrize("W,R,U,I,d,w", [(5, 300, 700, 1300, 32, 32), (2, 64, 40, 90, 64, 8), (8, 1000, 3000, 5000, 8, 8),
