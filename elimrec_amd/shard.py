@@ -534,7 +534,7 @@ class ColumnShardTrainer(object):
             lookup_early = True
         if self.multi and self._hip_engine:
             eng.cs_gathered_ids(acts, h_ids)                       # second stream, behind the exchanges: the adjoint's source bits
-        if self.multi and self._hip_engine:
+        if self.multi and self._hip_engine and not eng._long_wanted_only():
             eng.cs_forward_long()                                  # the split rows of hop L need neither ids nor plan: ahead of the waits
         if h_ids is not None:
             h_ids.wait()
@@ -711,6 +711,8 @@ class ColumnShardEngine(object):
         # by the window sweep (csrc/sweep.hip), the item rows by a tile plan of their own; the masked hop, the split-rows hop of
         # the last forward layer and the batch-row kernels keep the whole plan. The hops then carry no tails (Adam, weight
         # gradients): those run as launches of their own, a few tens of microseconds beside hops of a millisecond.
+        deg = np.diff(adj.tocsr().indptr)
+        self._split_share = float(deg[deg > kw["threshold"]].sum()) / max(float(deg.sum()), 1.0)      # non-zeros in split rows
         self.sweep = bool(tiered and not self.wide and self.w in (16, 32) and slab.sweep_tiles_xcds(self.ns)
                           and slab.sweep_wanted(N, self.dl, adj.nnz))
         if self.sweep:
@@ -937,12 +939,14 @@ class ColumnShardEngine(object):
 
     @_once
     def _long_wanted_only(self):
-        """Hop L at the split rows of the batch only (elimrec_slab_hop, seg_only with the wanted-rows bitmap): one rank, the swept
-        form (ELIMREC_LONG_WANTED=1 / 0 forces it on / off)."""
+        """Hop L at the split rows of the batch only (elimrec_slab_hop, seg_only with the wanted-rows bitmap -- several ranks: of every
+        rank's batch): graphs whose split rows hold 30 % of the non-zeros or more (every user row of configs[3]; 15 % at the Tiktok
+        shape, where the popular items that are split rows are in nearly every batch) and the swept form (ELIMREC_LONG_WANTED=1 / 0
+        forces it on / off)."""
         import os
         e = os.environ.get("ELIMREC_LONG_WANTED")
-        return (not self.multi and not self.wide and self.planT.tiered and self.plan.tiered
-                and (self.sweep if e is None else e == "1"))
+        return (not self.wide and self.planT.tiered and self.plan.tiered
+                and ((self.sweep or self._split_share >= 0.3) if e is None else e == "1"))
 
     @_once
     def _fuse_bwd_w(self):
@@ -1092,10 +1096,11 @@ class ColumnShardEngine(object):
         with torch.cuda.stream(aux):
             handle.wait()                                   # the second stream behind the id exchange
 
-            def bits():
-                slab.rows_bitmap(acts, m.num_users + m.num_items, self.mask)
-                slab.source_bits(self.planT, self.hns, self.w, self.hgs, self.mask)
-            m._region("cs_bits", (m._ws_gen, acts.data_ptr(), acts.shape[0], acts.shape[1]), bits)
+            key = (m._ws_gen, acts.data_ptr(), acts.shape[0], acts.shape[1])
+            m._region("cs_row_bits", key, lambda: slab.rows_bitmap(acts, m.num_users + m.num_items, self.mask))
+            # (the bitmap of every rank's active rows is also the wanted-rows bitmap of hop L's split rows: cs_forward_rows)
+            self._rows_rec = program.record(aux) if self._long_wanted_only() else None
+            m._region("cs_bits", key, lambda: slab.source_bits(self.planT, self.hns, self.w, self.hgs, self.mask))
         self._bits_ready = True
         self._bits_join = True                              # the adjoint's first hop joins the second stream for them
 
@@ -1187,7 +1192,16 @@ class ColumnShardEngine(object):
         # Tiktok shape the split rows are the popular items, nearly all of them in every batch, and the join ahead of the hop costs more)
         wanted = self.mask if (self._long_wanted_only() and self._bits_ready and not long_done) else None
         joined = False
-        if wanted is not None and late_wait:
+        if wanted is not None and self.multi:
+            rec = getattr(self, "_rows_rec", None)
+            if rec is None:
+                wanted = None                                    # (no second stream / no bitmap of the gathered ids: every split row)
+            else:
+                program.wait(torch.cuda.current_stream(), rec)   # the gathered ids' row bitmap (behind the plan on the second stream)
+                self._rows_rec = self._plan_rec = None
+                if late_wait:
+                    late_wait, joined = False, True
+        elif wanted is not None and late_wait:
             join_plan()
             late_wait, joined = False, True
 

@@ -1419,6 +1419,51 @@ def test_native_multi_rank_program_with_rccl_calls(tmp_path, feature_shard):
         assert np.array_equal(a[k], b[k]), k
 
 
+def _long_wanted_multi_worker(rank, port, out_dir, wanted):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["ELIMREC_SHARD_MULTI"] = "1"
+    os.environ["ELIMREC_LONG_WANTED"] = wanted
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, EliMRec, FusedAdam, SyntheticDataset, set_seed
+    cfg = make_config(["--data.input.dataset=synthetic", "--alpha=0.5", "--loss=bpr_loss", "--recdim=64", "--verbose=0"])
+    ds = SyntheticDataset(300, 2500, 40000, feat_dims=(16, 8, 12), seed=3)
+    gen = torch.Generator().manual_seed(5)
+    B = 256
+    batches = [(torch.randint(0, 300, (B,), generator=gen).to(DEV), torch.randint(0, 2500, (B,), generator=gen).to(DEV),
+                torch.randint(0, 2500, (B,), generator=gen).to(DEV)) for _ in range(14)]
+    set_seed(11)
+    model = EliMRec(cfg, ds).to(DEV)
+    opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+    eng = ColumnShardEngine(model)
+    tr = ColumnShardTrainer(eng, opt, world_size=1, rank=0)
+    assert tr.multi and eng._long_wanted_only() == (wanted == "1") and eng.plan.n_long > 100 and eng._split_share > 0.3
+    losses = torch.stack([tr.step(*b) for b in batches]).cpu().numpy()
+    st = tr._native_state()
+    assert st["failed"] is None and st["native_steps"] > 0, st
+    eng.sync_to_model()
+    np.savez(os.path.join(out_dir, "wanted%s.npz" % wanted), losses=losses,
+             **{k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
+    dist.destroy_process_group()
+
+
+def test_multi_rank_step_with_the_split_rows_of_the_batches_only(tmp_path):
+    """Several ranks (here: one rank's multi-rank step over a real RCCL communicator, the step's program engaged): hop L's split
+    rows for the rows of every rank's batch only -- the bitmap of the gathered ids, made on the second stream, is the wanted-rows
+    bitmap, and the main stream waits for it instead of running the split rows ahead of the id exchange. Bitwise the steps of the
+    default order on a graph whose split rows hold most of the non-zeros (where the engine chooses this form by itself)."""
+    import torch.multiprocessing as mp
+    port = 38300 + (os.getpid() % 1000)
+    for wanted in ("0", "1"):
+        mp.spawn(_long_wanted_multi_worker, args=(port + int(wanted), str(tmp_path), wanted), nprocs=1, join=True)
+    a, b = dict(np.load(tmp_path / "wanted0.npz")), dict(np.load(tmp_path / "wanted1.npz"))
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+
+
 @pytest.mark.parametrize("W,R,dl", [(1, 50, 64), (2, 300, 32), (8, 1000, 8), (5, 7, 4)])
 def test_peer_cols_to_rows_and_rows_bitmap_vs_torch(W, R, dl):
     """The two exchange helpers of the multi-rank step: received column slices [W x R x 2 x dl] -> two row views (what the

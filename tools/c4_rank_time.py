@@ -19,6 +19,13 @@ B = 2048
 u, p, n = PairwiseSamplerV2(ds, batch_size=B, device=dev).sample_epoch()
 print("data set %.0f s: U=%d I=%d train nnz=%d, recdim %d" % (time.time() - t0, U, I, ds.train_matrix.nnz, d), flush=True)
 K = 30
+
+
+class _Done:
+    def wait(self):
+        pass
+
+
 for W in [int(x) for x in sys.argv[1:]] or [1, 8]:
     set_seed(1)
     t0 = time.time()
@@ -30,12 +37,17 @@ for W in [int(x) for x in sys.argv[1:]] or [1, 8]:
         step = lambda i: tr.step(u[i * B:(i + 1) * B], p[i * B:(i + 1) * B], n[i * B:(i + 1) * B])
     else:
         eng.cs_setup(W, 0, opt)
+        eng.multi_aux = True                              # the trainer's second stream (planner, row bitmap, source bits under the hops)
         scale = torch.full((1,), 1.0 / W, device=dev)
 
         def step(i):
             act = eng.cs_plan(u[i * B:(i + 1) * B], p[i * B:(i + 1) * B], n[i * B:(i + 1) * B])
             acts = act.view(1, -1).expand(W, -1).contiguous()
-            send = eng.cs_forward(acts)
+            eng.cs_gathered_ids(acts, _Done())            # second stream, as the trainer does behind the id exchange: row bitmap + source bits
+            eng.cs_forward_hops()
+            if not eng._long_wanted_only():
+                eng.cs_forward_long()                     # every split row, ahead of the waits (graphs with few split rows)
+            send = eng.cs_forward_rows(acts)
             eng.cs_head(send)                         # own slices in place of the peers'
             s2, wg = eng.cs_backward_local(scale)
             eng.cs_backward_hops(s2, acts)
