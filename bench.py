@@ -668,6 +668,8 @@ def eval_pass(model, cfg, torch):
     tie_default = evalr.tie_order
     evalr.tie_order = "id"
     secs = timed(3)
+    evalr._evaluations = 0                 # (the evaluator cross-checks its scorer in the first evaluation of a run and every 16th after it:
+    checked_secs = timed(1)                #  the pass that carries the check, timed on its own)
     # the reference's tie order (the default of the evaluator and of main.py): rows whose K + 1 best scores are (nearly) equal are
     # re-ranked on the host by the reference's own partial_sort_copy -- how many rows that is at this shape, and what it costs
     evalr.tie_order, evalr.tie_rows_replayed = "reference", 0
@@ -696,8 +698,12 @@ def eval_pass(model, cfg, torch):
                          "frac": 6 * flops / best / 1e12 / MFMA_BF16_PEAK_TF, "bf16_flops": 6 * flops,
                          "fp32_equivalent": {"flops": flops, "achieved": flops / best / 1e12, "peak": MFMA_F32_PEAK_TF,
                                              "frac": flops / best / 1e12 / MFMA_F32_PEAK_TF}},
-            "scorer_cross_check": {"what": "every evaluation re-scores its first users with the fp32-MFMA scorer and compares the K returned "
-                                           "scores with the default bf16x3 scorer's (> 1e-6 = mismatch; included in the pass times)",
+            "scorer_cross_check": {"what": "the first evaluation of a run and every %d-th after it re-score their first %d users with the fp32-MFMA "
+                                           "scorer and compare the K returned scores with the default bf16x3 scorer's (> 1e-6 = mismatch, read behind "
+                                           "the pass's launches; a mismatch switches the process to the fp32 scorer and the pass is scored again); "
+                                           "`seconds` is a pass without the check, `seconds_with_check` one that carries it"
+                                           % (evalr.scorer_check_every, evalr.scorer_check_users),
+                                   "seconds_with_check": checked_secs[0],
                                    "users_checked": evalr.scorer_checked_rows, "scorer_mismatch_rows": evalr.scorer_mismatch_rows},
             "tie_order": {"id (device rule: lowest item id among equal scores; what `seconds` above is)": {"seconds": best},
                           "reference (default: tied rows replayed through the reference's partial_sort_copy)":

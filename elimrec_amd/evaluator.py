@@ -73,21 +73,34 @@ class UniEvaluator(object):
         # users with the fp32-MFMA scorer and compares the K returned scores -- a difference beyond the two forms' round-off is
         # counted, logged, and the rest of the evaluation runs on the fp32 scorer (ELIMREC_SCORER_CHECK=0: no check)
         self.scorer_check_users = int(_os.environ.get("ELIMREC_SCORER_CHECK", 1024))
+        # ... in the first evaluation of a run and in every 16th after it (ELIMREC_SCORER_CHECK_EVERY): the check re-scores 1024 users
+        # with the slower scorer, 0.8 ms of a 13 ms pass at the Tiktok shape
+        self.scorer_check_every = max(1, int(_os.environ.get("ELIMREC_SCORER_CHECK_EVERY", 16)))
+        self._evaluations = 0
         self.scorer_checked_rows = self.scorer_mismatch_rows = 0
 
-    def _cross_check_scorer(self, model, users):
-        """Top-K of `users` by the default (bf16 x 3) scorer and by the fp32-MFMA scorer: rows whose returned scores differ by more
-        than 1e-6 (the forms agree to 2.4e-7). Returns the number of such rows; on any, the process keeps the fp32 scorer."""
+    def _cross_check_scorer(self, model, users, cache_key=None):
+        """Top-K of the first `scorer_check_users` users by the default (bf16 x 3) scorer and by the fp32-MFMA scorer, compared ON THE
+        DEVICE: the number of rows whose returned scores differ by more than 1e-6 (the forms agree to 2.4e-7) stays a device scalar,
+        which _cross_check_verdict reads once the pass's own launches are enqueued -- the check costs its two scorer calls, not a host
+        round trip in front of the pass. Returns (count tensor, users checked) or None when there is nothing to check."""
         from . import _lib
         lib = _lib.load()
         if (not users or self.scorer_check_users <= 0 or int(lib.elimrec_score_get_math()) == 0 or int(lib.elimrec_score_get_bf16x3()) == 0
                 or model.latent_dim not in (32, 64) or getattr(model, "_eval_shard", None) is not None
                 or self.max_top > min(128, model.num_items)):
-            return 0
-        users = list(users[:self.scorer_check_users])
+            return None
         device = model._require_gpu()
-        train_ptr, train_items = self._batch_csr(users, self.user_pos_train, device, unique=False)
-        users_t = torch.as_tensor(np.asarray(users, dtype=np.int64)).to(device)
+        key = (str(device), "check", cache_key, self.scorer_check_users) if cache_key is not None else None
+        hit = self._dev_cache.get(key) if key is not None else None
+        if hit is None:
+            users = list(users[:self.scorer_check_users])
+            train_ptr, train_items = self._batch_csr(users, self.user_pos_train, device, unique=False)
+            users_t = torch.as_tensor(np.asarray(users, dtype=np.int64)).to(device)
+            hit = (users_t, train_ptr, train_items)
+            if key is not None:
+                self._dev_cache[key] = hit
+        users_t, train_ptr, train_items = hit
         _, val_a = model.predict_device(users_t, top_k=self.max_top, train_ptr=train_ptr, train_items=train_items)
         lib.elimrec_score_set_bf16x3(0)
         try:
@@ -95,14 +108,23 @@ class UniEvaluator(object):
         finally:
             lib.elimrec_score_set_bf16x3(1)
         diff = (val_a - val_b).abs()
-        bad = int((torch.where(torch.isfinite(val_a) & torch.isfinite(val_b), diff, (val_a != val_b).float()) > 1e-6).any(1).sum())
-        self.scorer_checked_rows += len(users)
+        bad = (torch.where(torch.isfinite(val_a) & torch.isfinite(val_b), diff, (val_a != val_b).float()) > 1e-6).any(1).sum()
+        return bad, int(users_t.numel())
+
+    def _cross_check_verdict(self, pending):
+        """Reads the cross-check's count (a host synchronisation: call it behind the pass's launches). On any differing row the
+        process keeps the fp32 scorer from here on; returns the number of such rows."""
+        if pending is None:
+            return 0
+        from . import _lib
+        bad, n = int(pending[0]), pending[1]
+        self.scorer_checked_rows += n
         self.scorer_mismatch_rows += bad
         if bad:
             from .logger import Logger
             Logger.info("[evaluator] %d of %d cross-checked users got different top-%d scores from the bf16x3 scorer and the fp32-MFMA "
-                        "scorer (> 1e-6): the fp32 scorer is used from here on" % (bad, len(users), self.max_top))
-            lib.elimrec_score_set_bf16x3(0)
+                        "scorer (> 1e-6): the fp32 scorer is used from here on, this pass is scored again" % (bad, n, self.max_top))
+            _lib.load().elimrec_score_set_bf16x3(0)
         return bad
 
     def metrics_info(self):
@@ -161,11 +183,19 @@ class UniEvaluator(object):
         at = lo
         mine = test_users[lo:hi]
         block = self._users_per_launch(model)
-        self._cross_check_scorer(model, mine)
-        for k, batch_users in enumerate(DataIterator(mine, batch_size=block, shuffle=False, drop_last=False)):
-            key = (k, lo, hi, block) if cached else None
-            self.evaluate_batch(model, batch_users, cache_key=key, out=all_dev[at:at + len(batch_users)])
-            at += len(batch_users)
+        check = self._evaluations % self.scorer_check_every == 0
+        self._evaluations += 1
+        pending = self._cross_check_scorer(model, mine, cache_key=(lo, hi) if cached else None) if check else None
+        for attempt in (0, 1):
+            at = lo
+            for k, batch_users in enumerate(DataIterator(mine, batch_size=block, shuffle=False, drop_last=False)):
+                key = (k, lo, hi, block) if cached else None
+                self.evaluate_batch(model, batch_users, cache_key=key, out=all_dev[at:at + len(batch_users)])
+                at += len(batch_users)
+            # the scorer's cross-check of this pass's first users, read behind the pass's launches; a mismatch switches the process to
+            # the fp32 scorer and the pass is scored once more with it
+            if attempt == 1 or not self._cross_check_verdict(pending):
+                break
         if sharded and reduce:
             dist.all_reduce(all_dev, op=dist.ReduceOp.SUM)
         return all_dev
@@ -211,21 +241,21 @@ class UniEvaluator(object):
         tied = torch.nonzero(((hi == lo) | ((hi - lo) <= tol)).any(1)).flatten()
         self.tie_rows_replayed += int(tied.numel())
         if tied.numel():
-            ptr = train_ptr.cpu().numpy()
+            # the tied rows' slices of the block's training lists, cut on the device (two small read-backs: the rows' bounds)
+            lo_t, hi_t = train_ptr[tied], train_ptr[tied + 1]
+            lens = (hi_t - lo_t).cpu().numpy()
+            starts = lo_t.cpu().numpy()
             sub_ptr = np.zeros(tied.numel() + 1, np.int64)
-            rows = tied.cpu().numpy()
-            np.cumsum(ptr[rows + 1] - ptr[rows], out=sub_ptr[1:])
-            items_h = train_items.cpu().numpy()
-            sub_items = np.concatenate([items_h[ptr[r]:ptr[r + 1]] for r in rows] + [np.zeros(0, np.int32)]).astype(np.int32)
+            np.cumsum(lens, out=sub_ptr[1:])
             dev = users_t.device
             step = max(1, (1 << 28) // max(1, model.num_items))          # <= 1 GiB of score rows at a time
             for a in range(0, tied.numel(), step):
                 part = tied[a:a + step]
                 sc = torch.empty(part.numel(), model.num_items, dtype=torch.float32, device=dev)
                 p0 = sub_ptr[a:a + part.numel() + 1] - sub_ptr[a]
-                it = sub_items[sub_ptr[a]:sub_ptr[a + part.numel()]]
-                model.predict_device(users_t[part], scores=sc, train_ptr=torch.from_numpy(p0).to(dev),
-                                     train_items=torch.from_numpy(it if len(it) else np.zeros(1, np.int32)).to(dev))
+                pieces = [train_items[int(starts[a + j]):int(starts[a + j]) + int(lens[a + j])] for j in range(part.numel())]
+                it = torch.cat(pieces) if int(p0[-1]) else torch.zeros(1, dtype=torch.int32, device=dev)
+                model.predict_device(users_t[part], scores=sc, train_ptr=torch.from_numpy(p0).to(dev), train_items=it.contiguous())
                 host = np.ascontiguousarray(sc.cpu().numpy())
                 out = np.empty((part.numel(), K), np.int32)
                 _lib.check(lib.elimrec_topk_reference_order(host.ctypes.data_as(ctypes.c_void_p), host.shape[0], host.shape[1], host.shape[1], K,

@@ -1455,9 +1455,10 @@ def test_reference_tie_order_is_reproduced_on_request(fixture_name):
 
 @pytest.mark.gpu
 def test_evaluator_cross_checks_the_default_scorer_against_the_fp32_scorer(monkeypatch):
-    """Every evaluation re-scores its first users with the fp32-MFMA scorer: on healthy hardware no row differs; a scorer that
-    returns a wrong score (injected here: the first launch's best score overwritten, the signature of round 3's fault) is counted,
-    and the process falls back to the fp32 scorer."""
+    """The first evaluation of a run (and every 16th after it; here: every one) re-scores its first users with the fp32-MFMA scorer:
+    on healthy hardware no row differs; a scorer that returns a wrong score (injected here: the first launch's best score
+    overwritten, the signature of round 3's fault) is counted, the process falls back to the fp32 scorer and the pass is scored
+    again -- its results are the fp32 scorer's."""
     from elimrec_amd import _lib
     lib = _lib.load()
     g = load_golden("kwai")                      # recdim 64: the bf16 x 3 scorer's shape
@@ -1465,11 +1466,13 @@ def test_evaluator_cross_checks_the_default_scorer_against_the_fp32_scorer(monke
     _load_cache(model, g)
     model.fusion_mode, model.predict_type = "rubi", "TIE"
     evalr = model.test_evaluator.evaluator
+    assert evalr.scorer_check_every == 16
+    evalr.scorer_check_every = 1
     math0, b0 = int(lib.elimrec_score_get_math()), int(lib.elimrec_score_get_bf16x3())
     try:
         lib.elimrec_score_set_math(1)
         lib.elimrec_score_set_bf16x3(1)
-        model.test()
+        clean, _ = model.test()
         assert evalr.scorer_checked_rows > 0 and evalr.scorer_mismatch_rows == 0
         real = model.predict_device
         state = {"n": 0}
@@ -1481,8 +1484,9 @@ def test_evaluator_cross_checks_the_default_scorer_against_the_fp32_scorer(monke
                 val[0, 0] = 1.0
             return idx, val
         monkeypatch.setattr(model, "predict_device", faulty)
-        model.test()
+        again, _ = model.test()
         assert evalr.scorer_mismatch_rows == 1 and int(lib.elimrec_score_get_bf16x3()) == 0
+        assert np.abs(np.asarray(again) - np.asarray(clean)).max() < 1e-6       # the re-scored pass: the fault is not in the results
     finally:
         lib.elimrec_score_set_math(math0)
         lib.elimrec_score_set_bf16x3(b0)

@@ -17,3 +17,5 @@ for order in ("id", "reference"):
     for k in range(int(sys.argv[1]) if len(sys.argv) > 1 else 8):
         torch.cuda.synchronize(); t0 = time.perf_counter(); res, buf = model.evaluate(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     print("tie_order=%s: best %.5f s, median %.5f s  (%s)" % (order, min(ts), sorted(ts)[len(ts) // 2], buf.replace("\t", " ")[:60]))
+from elimrec_amd import _lib
+print("scorer cross-check: rows checked %d, mismatch rows %d, bf16x3 scorer on: %d" % (ev.scorer_checked_rows, ev.scorer_mismatch_rows, int(_lib.load().elimrec_score_get_bf16x3())))
