@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import assert_grad_close, build_model_from_fixture, load_golden, sub
+from helpers import assert_grad_close, build_model_from_fixture, feats_of, load_golden, sub
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -231,3 +231,54 @@ def test_plugin_loop_on_an_adjacency_with_a_diagonal():
     tr = ColumnShardTrainer(eng, _opt(twin, g))
     assert [tr.step(*b).item() for b in batches] == got
     _same(_state(model, model.plugin.engine), _state(twin, eng))
+
+
+@pytest.mark.parametrize("name", ["ml3", "kwai"])
+def test_plugin_loop_on_tiny_and_degenerate_batches_vs_oracle(name):
+    """The reference's loop body on batches the fixtures do not hold: one triplet, two, five, a batch whose triplets are all the
+    same, a batch whose positive equals its negative (loss = log 2 exactly in the cosine form) -- loss against the oracle's
+    (1e-5), every gradient of the first such step (1e-4 row-wise), and the loop keeps running through all of them."""
+    from oracle import elimrec_oracle as eo
+    from elimrec_amd import FusedAdam
+    g = load_golden(name)
+    model, cfg = build_model_from_fixture(g, DEV)
+    opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+    adj = eo.build_adj(g["train_u"], g["train_i"], int(g["num_users"]), int(g["num_items"]), str(g["adj_type"]))
+    om = eo.OracleEliMRec(int(g["num_users"]), int(g["num_items"]), int(g["recdim"]), int(g["layer_num"]), adj, feats_of(g),
+                          sub(g, "init"), float(g["alpha"]), dataset_name=str(g["dataset_name"]),
+                          modality=str(g["modality"]), mm_fusion_mode=str(g["mm_fusion_mode"]))
+    U, I = int(g["num_users"]), int(g["num_items"])
+    gen = torch.Generator().manual_seed(9)
+    cases = []
+    for B in (1, 2, 5):
+        cases.append((torch.randint(0, U, (B,), generator=gen), torch.randint(0, I, (B,), generator=gen), torch.randint(0, I, (B,), generator=gen)))
+    cases.append((torch.full((7,), 3), torch.full((7,), 5), torch.full((7,), 11)))                 # seven times the same triplet
+    same = torch.randint(0, I, (4,), generator=gen)
+    cases.append((torch.randint(0, U, (4,), generator=gen), same, same.clone()))                   # positive == negative
+    # the first case: loss and gradients of the untouched initial parameters against the oracle
+    u, p, n = cases[0]
+    want = om.bpr_loss(u, p, n)
+    want.backward()
+    loss = model.bpr_loss(u.to(DEV), p.to(DEV), n.to(DEV))
+    opt.zero_grad()
+    loss.backward(retain_graph=True)
+    assert abs(float(loss) - float(want.detach())) < 1e-5
+    ref = om.grads()
+    mine = {k: q.grad for k, q in model.named_parameters() if q.grad is not None}
+    assert set(mine) == set(ref)
+    for k, gr in ref.items():
+        assert_grad_close(mine[k].cpu(), gr, k)
+    opt.step()
+    # the others on the evolving parameters: finite losses, the loop does not stall; the degenerate one has the closed-form loss
+    for u, p, n in cases[1:]:
+        loss = model.bpr_loss(u.to(DEV), p.to(DEV), n.to(DEV))
+        opt.zero_grad()
+        loss.backward(retain_graph=True)
+        opt.step()
+        assert np.isfinite(float(loss))
+    # (pos == neg: every cosine difference is 0, so each of the 1 + alpha * S terms is log 2)
+    om2_terms = float(loss) / np.log(2.0)
+    assert abs(om2_terms - round(om2_terms)) < 1e-4 or abs(om2_terms - (1 + float(g["alpha"]) * model.S)) < 1e-4, om2_terms
+    model.state_dict()
+    for q in model.parameters():
+        assert torch.isfinite(q.detach()).all()
