@@ -1667,3 +1667,46 @@ def test_native_program_periodic_self_check_and_hyper_parameter_changes(monkeypa
         assert res[mode][0] == res["native"][0], mode
         for k, v in res["native"][1].items():
             assert torch.equal(res[mode][1][k], v), (mode, k)
+
+
+def test_large_batch_step_paths_vs_oracle_and_each_other(monkeypatch):
+    """B = 4096 (12 288 slots: beyond the one-workgroup planner): the device-wide bitmap planner, the adjoint's source bits behind the
+    forward's join, and -- for batches announced with prestage() -- the planner of step t + 1 under step t's backward on the
+    alternating buffer sets. The first step's loss against the oracle (1e-5); eight steps -- losses, parameters, Adam moments --
+    bitwise equal with and without prestage and with the radix-sort planner (ELIMREC_PLAN_SORTED=1)."""
+    from oracle import elimrec_oracle as eo
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, EliMRec, FusedAdam, SyntheticDataset, set_seed
+    cfg = make_config(["--data.input.dataset=synthetic", "--alpha=0.5", "--loss=bpr_loss", "--recdim=64", "--verbose=0"])
+    U, I, B = 2000, 6000, 4096
+    ds = SyntheticDataset(U, I, 60000, feat_dims=(16, 8, 12), seed=2)
+    gen = torch.Generator().manual_seed(1)
+    batches = [(torch.randint(0, U, (B,), generator=gen).to(DEV), torch.randint(0, I, (B,), generator=gen).to(DEV),
+                torch.randint(0, I, (B,), generator=gen).to(DEV)) for _ in range(8)]
+    got = {}
+    for form in ("prestaged", "plain", "sorted"):
+        monkeypatch.setenv("ELIMREC_PLAN_SORTED", "1" if form == "sorted" else "0")
+        set_seed(5)
+        model = EliMRec(cfg, ds)
+        init = {k: v.detach().clone().numpy() for k, v in model.state_dict().items()}
+        model = model.to(DEV)
+        opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+        eng = ColumnShardEngine(model)
+        tr = ColumnShardTrainer(eng, opt)
+        if form == "prestaged":
+            tr.prestage(batches)
+        losses = [float(tr.step(*b)) for b in batches]
+        eng.sync_to_model()
+        st = eng.optimizer_state()
+        got[form] = (losses, {k: v.clone() for k, v in model.state_dict().items()}, st["exp_avg"].clone(), st["exp_avg_sq"].clone())
+        if form == "prestaged":
+            tu, ti = ds.get_train_interactions()
+            adj = eo.build_adj(tu, ti, U, I, cfg["adj_type"])
+            feats = {m: eo.OracleEliMRec.normalize_features(getattr(ds, m + "_feat")) for m in ("v", "a", "t")}
+            om = eo.OracleEliMRec(U, I, 64, cfg["layer_num"], adj, feats, init, cfg["alpha"], dataset_name="synthetic")
+            ol = om.bpr_loss(*(t.cpu() for t in batches[0]))
+            assert abs(losses[0] - float(ol.detach())) < 1e-5
+    a = got["prestaged"]
+    for other in ("plain", "sorted"):
+        b = got[other]
+        assert a[0] == b[0], other
+        assert all(torch.equal(a[1][k], b[1][k]) for k in a[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]), other
