@@ -474,7 +474,13 @@ def main():
             except Exception as e:   # noqa: BLE001
                 out[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         if world == 1 and not args.no_eval:
-            extra("eval", lambda: eval_pass(model, cfg, torch))
+            def eval_line():
+                try:
+                    early = early_state_tie_orders(args, device, cfg, batches, torch)
+                except Exception as e:   # noqa: BLE001
+                    early = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+                return eval_pass(model, cfg, torch, early=early)
+            extra("eval", eval_line)
         if world == 1 and not args.no_reference_work:
             extra("reference_equivalent_work", lambda: reference_work_line(args, device, cfg, batches, torch))
         if world == 1 and not args.no_b_sweep:
@@ -646,7 +652,48 @@ def hop_forms_note():
         return ""
 
 
-def eval_pass(model, cfg, torch):
+def tied_rows(model, evalr, torch):
+    """Users of the validation pass whose K + 1 best masked scores contain two equal values (counted on the device)."""
+    users = list(evalr.user_pos_test.keys())
+    dev = model._require_gpu()
+    n = 0
+    for a in range(0, len(users), 8192):
+        part = users[a:a + 8192]
+        ptr, items = evalr._batch_csr(part, evalr.user_pos_train, dev, unique=False)
+        _, val = model.predict_device(torch.as_tensor(part, device=dev), top_k=evalr.max_top + 1, train_ptr=ptr, train_items=items)
+        n += int((val[:, :-1] == val[:, 1:]).any(1).sum())
+    return n
+
+
+def early_state_tie_orders(args, device, cfg, batches, torch):
+    """The evaluator's two tie orders on a model that has taken TWO training steps from its initial parameters: the TIE scores
+    of the whole catalogue then crowd around 0.5 and most users' best scores collide."""
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
+    _, _, model = build(args, device)
+    model = model.to(device)
+    opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+    tr = ColumnShardTrainer(ColumnShardEngine(model), opt)
+    for i in range(2):
+        tr.step(*batches[i])
+    model.predict_type = "TIE"
+    evalr = model.valid_evaluator.evaluator
+    out = {}
+    for order in ("id", "reference"):
+        evalr.tie_order = order
+        secs = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            model.evaluate()
+            torch.cuda.synchronize()
+            secs.append(time.perf_counter() - t1)
+        out[order + "_seconds"] = min(secs[1:])
+    out["reference_over_id"] = out["reference_seconds"] / out["id_seconds"]
+    out["rows_with_a_tie_in_top_K_plus_1"] = tied_rows(model, evalr, torch)
+    return out
+
+
+def eval_pass(model, cfg, torch, early=None):
     """Secondary metric of SURVEY 8(d): full-catalogue TIE top-K validation pass on the device evaluator (after the timed
     region; the first pass also materialises the cached tables). flops = 2*d per (user, item) for the row means of pass 1
     + 2*d*(1+S) for the (1+S) dot products of pass 2."""
@@ -670,11 +717,12 @@ def eval_pass(model, cfg, torch):
     secs = timed(3)
     evalr._evaluations = 0                 # (the evaluator cross-checks its scorer in the first evaluation of a run and every 16th after it:
     checked_secs = timed(1)                #  the pass that carries the check, timed on its own)
-    # the reference's tie order (the default of the evaluator and of main.py): rows whose K + 1 best scores are (nearly) equal are
-    # re-ranked on the host by the reference's own partial_sort_copy -- how many rows that is at this shape, and what it costs
-    evalr.tie_order, evalr.tie_rows_replayed = "reference", 0
-    ref_secs = timed(2)
-    replayed = evalr.tie_rows_replayed // 2
+    # the reference's tie order (the default of the evaluator and of main.py): evaluate.h:26-33's partial_sort_copy replayed on the
+    # device inside the scoring call, every row -- timed beside the device's own rule, with the number of rows whose K + 1 best
+    # scores hold an exact tie (the rows on which the two rules can differ), at this state and at an early one
+    evalr.tie_order = "reference"
+    ref_secs = timed(3)[1:]
+    tied_now = tied_rows(model, evalr, torch)
     evalr.tie_order = tie_default
     lib.elimrec_score_set_math(0)          # EXACT: IEEE division + libm expf (the default's factors are within ~2 ulp of these)
     exact = timed(2)
@@ -705,9 +753,14 @@ def eval_pass(model, cfg, torch):
                                            % (evalr.scorer_check_every, evalr.scorer_check_users),
                                    "seconds_with_check": checked_secs[0],
                                    "users_checked": evalr.scorer_checked_rows, "scorer_mismatch_rows": evalr.scorer_mismatch_rows},
-            "tie_order": {"id (device rule: lowest item id among equal scores; what `seconds` above is)": {"seconds": best},
-                          "reference (default: tied rows replayed through the reference's partial_sort_copy)":
-                              {"seconds": min(ref_secs), "users_per_s": n_eval / min(ref_secs), "tie_rows_replayed": replayed}},
+            "tie_order": {"what": "seconds per validation pass by the order among equal scores: id = (score desc, item id asc), what `seconds` "
+                                  "above is; reference = the default, std::partial_sort_copy's heap order (evaluate.h:26-33) replayed on the "
+                                  "device by ref_order_kernel inside the scoring call, every row, nothing copied to the host; "
+                                  "rows_with_a_tie_in_top_K_plus_1 = rows on which the two orders can differ",
+                          "after_the_timed_steps": {"id_seconds": best, "reference_seconds": min(ref_secs),
+                                                    "reference_over_id": min(ref_secs) / best,
+                                                    "rows_with_a_tie_in_top_K_plus_1": tied_now},
+                          "after_2_training_steps": early if early is not None else "skipped"},
             "exact_math": {"seconds": min(exact), "users_per_s": n_eval / min(exact),
                            "frac_of_mfma_peak": flops / min(exact) / 1e12 / MFMA_F32_PEAK_TF}}
 

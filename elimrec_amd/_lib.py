@@ -174,6 +174,9 @@ SIGNATURES = {
     "elimrec_slab_hop": (c_i32, [c_sell, c_i32, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f32, c_ptr, c_size, c_i32,
                                  c_ptr]),
     "elimrec_topk_reference_order": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_i32, c_ptr]),
+    "elimrec_topk_reference_order_device": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_i32, c_ptr, c_ptr, c_ptr]),
+    "elimrec_score_topk_ordered": (c_i32, [c_ptr, c_i64, c_i64, c_i64, c_ptr, c_i32, c_i32, c_i32, c_u32, c_i32, c_i32,
+                                           c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_ptr, c_ptr, c_size, c_i32, c_ptr]),
     "elimrec_plan_workspace": (c_size, [c_i64, c_i64, c_i64]),
     "elimrec_plan_tile_count": (c_i64, [c_i64, c_i64, c_i64, c_i64, c_i32]),
     "elimrec_plan_rows": (c_i32, [c_ptr, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i64, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),

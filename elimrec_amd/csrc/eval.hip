@@ -1360,6 +1360,160 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
     }
 }
 
+// The REFERENCE's order among equal scores, on the device (tie_order 1). evaluate.h:26-33 ranks a user's masked score row with
+//     std::partial_sort_copy(index.begin(), index.end(), out, out + K, [&](int x1, int x2) { return ratings[x1] > ratings[x2]; })
+// whose result among equal scores is the heap order of the C++ library's algorithm, not an order of the ids. The algorithm
+// (libstdc++ bits/stl_algo.h __partial_sort_copy, bits/stl_heap.h __make_heap / __adjust_heap / __push_heap / __sort_heap --
+// restated below operation for operation, every comparison the reference's comparator on the two scores):
+//   1. the first K ids go into the result; make_heap (the heap's top is the WORST kept score);
+//   2. every later id x in ascending order: if score[x] > score[top], __adjust_heap(result, 0, K, x);
+//   3. sort_heap.
+// Only step 2 touches the catalogue, and an id changes the heap only if its score beats the top, which never decreases: ONE WAVE
+// per user row tests 64 items (or the maxima of 64 sixteen-item tiles) per step with a ballot against the current top and runs
+// the heap operations of the few set lanes in lane (= id) order -- the sequence of __adjust_heap calls, hence every position in
+// the heap, is the serial algorithm's. The heap lives in LDS, executed redundantly by all 64 lanes (same addresses, same values:
+// broadcast reads, no divergence). A catalogue scored chunk by chunk carries the heap from launch to launch in out_idx / out_val
+// (heap order) and publishes the top's score as the next chunk's store threshold -- it IS the running K-th best score.
+struct RefHeap {
+    float *v; int *id;
+    __device__ __forceinline__ void adjust(int hole, int len, float val, int vid) {      // std::__adjust_heap
+        const int top_index = hole;
+        int second = hole;
+        while (second < (len - 1) / 2) {
+            second = 2 * (second + 1);
+            if (v[second] > v[second - 1]) second--;                                     // comp(first + second, first + (second - 1))
+            v[hole] = v[second]; id[hole] = id[second];
+            hole = second;
+        }
+        if ((len & 1) == 0 && second == (len - 2) / 2) {
+            second = 2 * (second + 1);
+            v[hole] = v[second - 1]; id[hole] = id[second - 1];
+            hole = second - 1;
+        }
+        int parent = (hole - 1) / 2;                                                     // std::__push_heap
+        while (hole > top_index && v[parent] > val) {                                    // comp(first + parent, value)
+            v[hole] = v[parent]; id[hole] = id[parent];
+            hole = parent;
+            parent = (hole - 1) / 2;
+        }
+        v[hole] = val; id[hole] = vid;
+    }
+    __device__ __forceinline__ void make(int len) {                                      // std::__make_heap
+        if (len < 2) return;
+        int parent = (len - 2) / 2;
+        while (true) {
+            const float val = v[parent];
+            const int vid = id[parent];
+            adjust(parent, len, val, vid);
+            if (parent == 0) return;
+            parent--;
+        }
+    }
+    __device__ __forceinline__ void sort(int len) {                                      // std::__sort_heap (__pop_heap per step)
+        while (len > 1) {
+            --len;
+            const float val = v[len];
+            const int vid = id[len];
+            v[len] = v[0]; id[len] = id[0];
+            adjust(0, len, val, vid);
+        }
+    }
+};
+__device__ __forceinline__ void wave_lds_sync() {         // LDS written by other lanes of this wave is read next
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ float lane_value(float v, int lane) {      // v of a wave-uniform lane
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), __builtin_amdgcn_readfirstlane(lane)));
+}
+
+constexpr int REF_KMAX = 1024;
+// scores: row b's items [item0, item0 + n) at scores[b * lds + (item - item0)]; mask_bits (nullable): bit (item) of row b set =
+// masked (score -inf, cpp/uni_evaluator.py:149-154); TILES: tile_max[b * tmax_ld + t] = the maximum BEFORE masking of the range's
+// t-th 16-item tile -- only tiles whose maximum beats the heap's top are read (the chunked scorer stores exactly the tiles whose
+// maximum reaches the threshold this kernel published after the previous chunk, which the top never falls below).
+// first: the range starts the catalogue (fill + make_heap; n >= K); last: sort_heap, out_* = the final lists; otherwise out_* keep
+// the heap and thr[b] (nullable) = its top's score.
+template <bool TILES>
+__global__ __launch_bounds__(256) void ref_order_kernel(const float *__restrict__ scores, int64_t lds, int64_t n,
+                                                        const float *__restrict__ tile_max, int64_t tmax_ld, int B, int K,
+                                                        const uint32_t *__restrict__ mask_bits, int64_t bits_ld, int64_t item0,
+                                                        int32_t *out_idx, float *out_val, int64_t ldo, float *thr, int first, int last) {
+    extern __shared__ float ref_lds[];                   // [4 waves][K] scores, [4 waves][K] ids
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wave;
+    if (b >= B) return;                                  // (no workgroup barrier below)
+    RefHeap h;
+    h.v = ref_lds + wave * K;
+    h.id = reinterpret_cast<int *>(ref_lds + 4 * K) + wave * K;
+    const float *row = scores + (int64_t)b * lds;
+    const uint32_t *bits = mask_bits ? mask_bits + (int64_t)b * bits_ld : nullptr;
+    int32_t *oi = out_idx + (int64_t)b * ldo;
+    float *ov = out_val ? out_val + (int64_t)b * ldo : nullptr;
+    auto score_at = [&](int64_t i) -> float {            // i relative to item0
+        const int64_t g = item0 + i;
+        if (bits && ((bits[g >> 5] >> (g & 31)) & 1u)) return -INFINITY;
+        return row[i];
+    };
+    int64_t start = 0;
+    if (first) {
+        for (int j = lane; j < K; j += 64) { h.v[j] = score_at(j); h.id[j] = (int)(item0 + j); }
+        wave_lds_sync();
+        h.make(K);
+        start = K;
+    } else {
+        for (int j = lane; j < K; j += 64) { h.v[j] = ov[j]; h.id[j] = oi[j]; }
+        wave_lds_sync();
+    }
+    float top = h.v[0];
+    if (TILES) {
+        const float *tmx = tile_max + (int64_t)b * tmax_ld;
+        const int64_t n_tiles = (n + TI - 1) / TI;
+        for (int64_t tb = (start / TI) & ~(int64_t)63; tb < n_tiles; tb += 64) {
+            const int64_t t = tb + lane;
+            const float tm = (t < n_tiles && t >= start / TI) ? tmx[t] : -INFINITY;
+            unsigned long long m = __builtin_amdgcn_ballot_w64(tm > top);
+            while (m) {
+                const int j = __builtin_ctzll(m);
+                m &= m - 1;
+                if (!(lane_value(tm, j) > top)) continue;                 // the top has risen past this tile since the ballot
+                const int64_t i = (tb + j) * TI + (lane & 15);
+                const float v = (i < n && i >= start) ? score_at(i) : -INFINITY;
+                unsigned long long m2 = __builtin_amdgcn_ballot_w64(v > top) & 0xFFFFull;
+                while (m2) {
+                    const int jj = __builtin_ctzll(m2);
+                    m2 &= m2 - 1;
+                    const float vj = lane_value(v, jj);
+                    if (vj > top) {                                       // comp(first, result_first) at the serial algorithm's turn
+                        h.adjust(0, K, vj, (int)(item0 + (tb + j) * TI + jj));
+                        top = h.v[0];
+                    }
+                }
+            }
+        }
+    } else {
+        for (int64_t base = start; base < n; base += 64) {
+            const int64_t i = base + lane;
+            const float v = i < n ? score_at(i) : -INFINITY;
+            unsigned long long m = __builtin_amdgcn_ballot_w64(v > top);
+            while (m) {
+                const int j = __builtin_ctzll(m);
+                m &= m - 1;
+                const float vj = lane_value(v, j);
+                if (vj > top) {
+                    h.adjust(0, K, vj, (int)(item0 + base + j));
+                    top = h.v[0];
+                }
+            }
+        }
+    }
+    if (last) h.sort(K);
+    else if (thr && lane == 0) thr[b] = top;
+    wave_lds_sync();
+    for (int j = lane; j < K; j += 64) { oi[j] = h.id[j]; if (ov) ov[j] = h.v[j]; }
+}
+
 struct MetricIds { int id[8]; };
 
 // metric.h:17-106. One wave per user, a lane per rank: the hit flags of the K ranks are found in parallel (ballots), the
@@ -1486,7 +1640,8 @@ static ScoreLayout score_layout(int B, int64_t U, int64_t I, int S, int K, bool 
     L.cand_val = take(topk_only ? b * (size_t)(K > 0 ? K : 1) * sizeof(float) : 0);      // the running list's scores when the caller keeps none
     L.cand_idx = take(topk_only ? b * sizeof(float) : 0);                                // the running K-th best score per user
     L.planes = off;
-    if (topk_only && (d == 32 || d == 64)) take((size_t)cols * 3 * (size_t)(1 + S) * (size_t)d * 2 + (size_t)cols * (size_t)(S > 0 ? S : 1) * 4);
+    const int64_t prow = I > SCORE_CHUNK ? SCORE_CHUNK : I;            // one chunk's item rows
+    if (d == 32 || d == 64) take((size_t)prow * 3 * (size_t)(1 + S) * (size_t)d * 2 + (size_t)prow * (size_t)(S > 0 ? S : 1) * 4);
     L.total = off;
     return L;
 }
@@ -1520,6 +1675,9 @@ static bool score_t16_path(int d, int S) {
 static bool score_chunked_form(int d, int S, int K, int64_t I, bool want_scores, bool want_topk) {
     return score_t16_path(d, S) && score_uses_chunks() && !want_scores && want_topk && K <= RM_KMAX && I > SCORE_CHUNK;
 }
+static bool score_matrix_chunks(int d, int S, int64_t I, bool want_scores) {
+    return score_t16_path(d, S) && score_uses_chunks() && want_scores && I > SCORE_CHUNK;
+}
 
 // Bytes elimrec_score_topk needs for THIS call shape: recdim d, K, and whether the caller passes a score matrix
 // (want_scores) -- the chunked layout exactly when the call will take the chunked form, the full [B x I] layout otherwise
@@ -1551,8 +1709,11 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
                            const float *d_sqnorm, const int64_t *d_train_ptr, const int32_t *d_train_items,
                            float *d_scores, int64_t lds, int K, int32_t *d_topk_idx, float *d_topk_val,
                            void *d_workspace, size_t workspace_bytes, void *stream, int phase, float *d_row_sum,
-                           int64_t I_total, int64_t id_offset) {
+                           int64_t I_total, int64_t id_offset, int tie_order) {
     ELIMREC_REQUIRE(d_Y && d_users && d_workspace, "score_topk: null pointer");
+    ELIMREC_REQUIRE(tie_order == 0 || tie_order == 1, "score_topk: tie_order 0 (score desc, id asc) or 1 (the reference's partial_sort_copy)");
+    ELIMREC_REQUIRE(tie_order == 0 || (phase == 0 && K <= REF_KMAX),
+                    "score_topk: the reference's tie order needs the whole catalogue in one call (no item shard) and K <= %d", REF_KMAX);
     ELIMREC_REQUIRE(phase == 0 || (d_row_sum && I_total >= I), "score_topk: sharded phases need d_row_sum and I_total >= I");
     if (phase == 1 && predict_type != 2) return 0;             // only TIE has a catalogue-wide mean
     ELIMREC_REQUIRE(d > 0 && d % 4 == 0 && ldy % 4 == 0, "score_topk: recdim/ldy must be multiples of 4");
@@ -1569,6 +1730,9 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
     // only top-K wanted: no [B x I] score block -- the catalogue goes through the scorer in chunks (a workspace sized by
     // elimrec_score_workspace_for is enough; a larger one is accepted)
     const bool chunked = score_chunked_form(d, S, K, I, d_scores != nullptr, d_topk_idx != nullptr);
+    // the score MATRIX of a catalogue beyond one chunk goes through the same launches, chunk by chunk, every tile stored: the rows
+    // predict() returns are then the bits the chunked top-K ranks (one score form per call shape, whatever the caller asks for)
+    const bool matrix_chunks = score_matrix_chunks(d, S, I, d_scores != nullptr);
     ScoreLayout L = score_layout(B, U, I, S, K, chunked);
     if (phase == 1) {        // row sums only: no score block is touched -- the chunked layout (no [B x I] block) will do as well
         const ScoreLayout Lc = score_layout(B, U, I, S, K, true);
@@ -1582,7 +1746,7 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
     // chunk's pieces behind the chunked layout: a workspace sized by elimrec_score_workspace_for has it)
     const int use_b3 = score_bf16x3();
     const ScoreLayout Lp = score_layout(B, U, I, S, K, chunked, d);
-    const bool bf16x3 = chunked && use_b3 && score_math() == 1 && (d == 32 || d == 64) && phase != 1 && workspace_bytes >= Lp.total;
+    const bool bf16x3 = (chunked || matrix_chunks) && use_b3 && score_math() == 1 && (d == 32 || d == 64) && phase != 1 && workspace_bytes >= Lp.total;
     hipStream_t s = (hipStream_t)stream;
     const int tiles = n_item_tiles(I);
     char *ws = (char *)d_workspace;
@@ -1739,9 +1903,10 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
             ELIMREC_LAUNCH_CHECK("score_t16b_pass2");
             return 0;
         };
-        if (chunked) {
-            // only top-K is wanted: the catalogue goes through the scorer SCORE_CHUNK items at a time, a [B x SCORE_CHUNK]
-            // block instead of [B x I]; every chunk leaves its K best (id, score) pairs per user, merged at the end
+        if (chunked || matrix_chunks) {
+            // the catalogue goes through the scorer SCORE_CHUNK items at a time. chunked (only top-K wanted): a [B x SCORE_CHUNK]
+            // block instead of [B x I], a RUNNING top-K per user; matrix_chunks (the caller's [B x I] matrix): the same launches
+            // with every tile stored at its place in the matrix -- the same bits
             const int nch = (int)((I + SCORE_CHUNK - 1) / SCORE_CHUNK);
             if (own_pass1 && bf16x3 && phase == 0) {
                 // pass 1 (row means of sigmoid(u.i)) on the bf16 matrix cores too: chunk by chunk (the fused block's pieces only),
@@ -1768,21 +1933,28 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
                 hipLaunchKernelGGL(row_mean_kernel, dim3(B), dim3(256), 0, s, partial, n_part, B, mean_div, mean_dst);
                 ELIMREC_LAUNCH_CHECK("row_mean");
             }
-            // pass 2 + selection, chunk by chunk, with a RUNNING top-K per user (topk_tiles_kernel): every chunk's selection leaves
-            // the best K so far and their K-th score; the next chunk's scorer stores a tile's scores of a user only where the tile's
-            // maximum reaches that score -- about one tile in seven after the 2 048-item pilot chunk, one in a hundred after the
-            // first full chunk -- so the [B x 16 384] block is hardly written at all (it was 537 MB per launch at 8 192 users). The
-            // lists after the last chunk are the result: no merge launch.
+            // pass 2 + selection, chunk by chunk, with a RUNNING top-K per user: every chunk's selection leaves the best K so far and
+            // their K-th score; the next chunk's scorer stores a tile's scores of a user only where the tile's maximum reaches that
+            // score -- about one tile in seven after the 2 048-item pilot chunk, one in a hundred after the first full chunk -- so
+            // the [B x 16 384] block is hardly written at all (it was 537 MB per launch at 8 192 users). The lists after the last
+            // chunk are the result: no merge launch. tie_order 0: topk_tiles_kernel, lists by (score desc, id asc); tie_order 1:
+            // ref_order_kernel, the reference's heap carried from chunk to chunk (its top IS the K-th best score so far).
             float *thrbuf = (float *)cand_idx;                           // [B]
             float *run_val = d_topk_val ? d_topk_val : cand_val;         // [B x K] (the caller's list is the running list)
             int64_t at = 0;
             for (int c = 0; at < I; ++c) {
                 ScoreArgs ac = a;
                 ac.item0 = at;
-                const int64_t len = (c == 0 && I > SCORE_PILOT) ? SCORE_PILOT : SCORE_CHUNK;
+                const int64_t len = (chunked && c == 0 && I > SCORE_PILOT) ? SCORE_PILOT : SCORE_CHUNK;
                 ac.item_end = ac.item0 + len < I ? ac.item0 + len : I;
                 at = ac.item_end;
-                ac.thr = c == 0 ? nullptr : thrbuf;
+                if (chunked) ac.thr = c == 0 ? nullptr : thrbuf;
+                else {                                                   // this chunk's columns of the caller's matrix
+                    ac.scores = d_scores + ac.item0;
+                    ac.lds = lds;
+                    ac.thr = nullptr;
+                    if (a.tile_max) ac.tile_max = a.tile_max + ac.item0 / TI;
+                }
                 const int64_t cnt = ac.item_end - ac.item0;
                 const int tc = (int)((cnt + TI - 1) / TI);
                 // ~512 workgroups per launch in all: a workgroup walks several tiles with its users' operands resident
@@ -1796,7 +1968,7 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
                     const int cols = (1 + S) * d;
                     uint4 *planes = (uint4 *)(ws + Lp.planes);
                     // (the chunk's inverse item norms behind its planes; predict type normal has no heads to normalise)
-                    float *inrm = (float *)(ws + Lp.planes + (size_t)(chunked && I > SCORE_CHUNK ? SCORE_CHUNK : I) * 3 * (size_t)cols * 2);
+                    float *inrm = (float *)(ws + Lp.planes + (size_t)(I > SCORE_CHUNK ? SCORE_CHUNK : I) * 3 * (size_t)cols * 2);
                     hipLaunchKernelGGL(split3_items_kernel, dim3((unsigned)((cnt * (cols / 8) + 255) / 256)), dim3(256), 0, s, d_Y, ldy, U,
                                        ac.item0, cnt, cols, planes, predict_type != 0 ? a.sqn : (const float *)nullptr, 1 + S,
                                        predict_type != 0 ? inrm : (float *)nullptr);
@@ -1808,19 +1980,29 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
                     rc = pass2(ac, tc, dim3((unsigned)((tc + per - 1) / per), ug));
                 }
                 if (rc) return rc;
-                hipLaunchKernelGGL(topk_tiles_kernel, dim3(B), dim3(256), 0, s, ac.scores, ac.lds, cnt, (const float *)wtmax, ac.tmax_ld,
-                                   tc, K, d_train_ptr, d_train_ptr ? (const uint32_t *)wbits : (const uint32_t *)nullptr, bits_ld,
-                                   d_topk_idx, run_val, fallback, ac.item0, (int64_t)K, (int64_t)0, thrbuf, c == 0 ? 1 : 0);
-                ELIMREC_LAUNCH_CHECK("topk_tiles(chunk)");
+                if (!chunked) continue;
+                if (tie_order == 1) {
+                    hipLaunchKernelGGL(ref_order_kernel<true>, dim3((unsigned)((B + 3) / 4)), dim3(256), (size_t)K * 32, s,
+                                       (const float *)ac.scores, ac.lds, cnt, (const float *)wtmax, ac.tmax_ld, B, K,
+                                       d_train_ptr ? (const uint32_t *)wbits : (const uint32_t *)nullptr, bits_ld, ac.item0, d_topk_idx,
+                                       run_val, (int64_t)K, thrbuf, c == 0 ? 1 : 0, at >= I ? 1 : 0);
+                    ELIMREC_LAUNCH_CHECK("ref_order(chunk)");
+                } else {
+                    hipLaunchKernelGGL(topk_tiles_kernel, dim3(B), dim3(256), 0, s, ac.scores, ac.lds, cnt, (const float *)wtmax, ac.tmax_ld,
+                                       tc, K, d_train_ptr, d_train_ptr ? (const uint32_t *)wbits : (const uint32_t *)nullptr, bits_ld,
+                                       d_topk_idx, run_val, fallback, ac.item0, (int64_t)K, (int64_t)0, thrbuf, c == 0 ? 1 : 0);
+                    ELIMREC_LAUNCH_CHECK("topk_tiles(chunk)");
+                }
             }
-            if (id_offset) {
-                hipLaunchKernelGGL(add_id_offset_kernel, dim3((unsigned)(((int64_t)B * K + 255) / 256)), dim3(256), 0, s, d_topk_idx,
-                                   (int64_t)B * K, (int32_t)id_offset);
-                ELIMREC_LAUNCH_CHECK("add_id_offset");
+            if (chunked) {
+                if (id_offset) {
+                    hipLaunchKernelGGL(add_id_offset_kernel, dim3((unsigned)(((int64_t)B * K + 255) / 256)), dim3(256), 0, s, d_topk_idx,
+                                       (int64_t)B * K, (int32_t)id_offset);
+                    ELIMREC_LAUNCH_CHECK("add_id_offset");
+                }
+                return 0;
             }
-            return 0;
-        }
-        { int rc = pass2(a, t16, grid); if (rc) return rc; }
+        } else { int rc = pass2(a, t16, grid); if (rc) return rc; }
 #undef ELIMREC_T16
 #undef ELIMREC_T16_P2
 #undef ELIMREC_T16_LAUNCH
@@ -1890,7 +2072,24 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
         hipLaunchKernelGGL(mask_train_kernel, dim3(B), dim3(128), 0, s, a.scores, a.lds, d_train_ptr, d_train_items, B);
         ELIMREC_LAUNCH_CHECK("mask_train");
     }
-    if (d_topk_idx) {
+    if (d_topk_idx && tie_order == 1) {
+        // the reference's heap over the whole row: guided by the tile maxima where the scorer left them (the private matrix is
+        // then unmasked: the bitmap), item by item otherwise (the matrix is masked)
+        if (tiles_ready)
+            hipLaunchKernelGGL(ref_order_kernel<true>, dim3((unsigned)((B + 3) / 4)), dim3(256), (size_t)K * 32, s, (const float *)a.scores,
+                               a.lds, I, (const float *)wtmax, a.tmax_ld, B, K, d_train_ptr ? (const uint32_t *)wbits : (const uint32_t *)nullptr,
+                               bits_ld, (int64_t)0, d_topk_idx, d_topk_val, (int64_t)K, (float *)nullptr, 1, 1);
+        else
+            hipLaunchKernelGGL(ref_order_kernel<false>, dim3((unsigned)((B + 3) / 4)), dim3(256), (size_t)K * 32, s, (const float *)a.scores,
+                               a.lds, I, (const float *)nullptr, (int64_t)0, B, K, (const uint32_t *)nullptr, (int64_t)0, (int64_t)0,
+                               d_topk_idx, d_topk_val, (int64_t)K, (float *)nullptr, 1, 1);
+        ELIMREC_LAUNCH_CHECK("ref_order");
+        if (id_offset) {
+            hipLaunchKernelGGL(add_id_offset_kernel, dim3((unsigned)(((int64_t)B * K + 255) / 256)), dim3(256), 0, s, d_topk_idx,
+                               (int64_t)B * K, (int32_t)id_offset);
+            ELIMREC_LAUNCH_CHECK("add_id_offset");
+        }
+    } else if (d_topk_idx) {
         int G = 32;
         while (G < 2 * K && G < 1024) G *= 2;
         if (tiles_ready) {
@@ -1925,7 +2124,33 @@ extern "C" int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int6
                                   void *d_workspace, size_t workspace_bytes, void *stream) {
     return score_topk_impl(d_Y, ldy, U, I, d_users, B, d, S, head_mask, fusion_mode, predict_type, d_sqnorm, d_train_ptr,
                            d_train_items, d_scores, lds, K, d_topk_idx, d_topk_val, d_workspace, workspace_bytes, stream, 0,
-                           nullptr, I, 0);
+                           nullptr, I, 0, 0);
+}
+
+// ... with the order among equal scores chosen by the caller: tie_order 0 = (score descending, item id ascending), 1 = the
+// reference's (evaluate.h:26-33: std::partial_sort_copy's heap order), replayed on the device by ref_order_kernel
+extern "C" int elimrec_score_topk_ordered(const float *d_Y, int64_t ldy, int64_t U, int64_t I, const int64_t *d_users, int B,
+                                          int d, int S, uint32_t head_mask, int fusion_mode, int predict_type,
+                                          const float *d_sqnorm, const int64_t *d_train_ptr, const int32_t *d_train_items,
+                                          float *d_scores, int64_t lds, int K, int32_t *d_topk_idx, float *d_topk_val,
+                                          void *d_workspace, size_t workspace_bytes, int tie_order, void *stream) {
+    return score_topk_impl(d_Y, ldy, U, I, d_users, B, d, S, head_mask, fusion_mode, predict_type, d_sqnorm, d_train_ptr,
+                           d_train_items, d_scores, lds, K, d_topk_idx, d_topk_val, d_workspace, workspace_bytes, stream, 0,
+                           nullptr, I, 0, tie_order);
+}
+
+// The reference's ranking of rows of (masked) scores that are already on the device: d_scores [n_rows x ld] -> d_topk_idx /
+// d_topk_val (nullable) [n_rows x K], bit for bit std::partial_sort_copy's lists (one wave per row, ref_order_kernel).
+extern "C" int elimrec_topk_reference_order_device(const float *d_scores, int64_t n_rows, int64_t I, int64_t ld, int K,
+                                                   int32_t *d_topk_idx, float *d_topk_val, void *stream) {
+    ELIMREC_REQUIRE(d_scores && d_topk_idx && I > 0 && K > 0 && K <= I && K <= REF_KMAX && ld >= I && I < INT32_MAX && n_rows < INT32_MAX,
+                    "topk_reference_order_device: bad arguments (0 < K <= min(I, %d), ld >= I)", REF_KMAX);
+    if (n_rows <= 0) return 0;
+    hipLaunchKernelGGL(ref_order_kernel<false>, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), (size_t)K * 32, (hipStream_t)stream, d_scores,
+                       ld, I, (const float *)nullptr, (int64_t)0, (int)n_rows, K, (const uint32_t *)nullptr, (int64_t)0, (int64_t)0,
+                       d_topk_idx, d_topk_val, (int64_t)K, (float *)nullptr, 1, 1);
+    ELIMREC_LAUNCH_CHECK("ref_order");
+    return 0;
 }
 
 extern "C" int elimrec_score_topk_shard(const float *d_Y, int64_t ldy, int64_t U, int64_t I, const int64_t *d_users, int B,
@@ -1938,7 +2163,7 @@ extern "C" int elimrec_score_topk_shard(const float *d_Y, int64_t ldy, int64_t U
     ELIMREC_REQUIRE(id_offset >= 0 && id_offset + I <= I_total && I_total < (int64_t)INT32_MAX, "score_topk_shard: bad item range");
     return score_topk_impl(d_Y, ldy, U, I, d_users, B, d, S, head_mask, fusion_mode, predict_type, d_sqnorm, d_train_ptr,
                            d_train_items, d_scores, lds, K, d_topk_idx, d_topk_val, d_workspace, workspace_bytes, stream, phase,
-                           d_row_sum, I_total, id_offset);
+                           d_row_sum, I_total, id_offset, 0);
 }
 
 // Merge per-shard (or per-chunk) candidate lists: d_cand_val / d_cand_idx [B x n_cand] (idx < 0 = no candidate) -> the K

@@ -11,7 +11,8 @@
 //   linear_fwd(A, W, bias?) -> A W^T + bias                linear_bwd_w(A, B) -> (A^T B, column sums of A)
 //   bpr_head_fwd(Y, U, I, users, pos, neg, d, block_weights) -> (loss_rows, grad_rows, keys)
 //   adam_step_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step) -> p
-//   score_topk(Y, U, I, users, d, S, head_mask, fusion_mode, predict_type, train_ptr?, train_items?, K) -> (idx, val)
+//   score_topk(Y, U, I, users, d, S, head_mask, fusion_mode, predict_type, train_ptr?, train_items?, K, tie_order=0) -> (idx, val)
+//       (tie_order 1: the reference's partial_sort_copy order among equal scores, evaluate.h:26-33, replayed on the device)
 //   rank_metrics(topk_idx, truth_ptr, truth_items, metric_ids) -> f32[B x n_metrics x K]
 //   sample_triplets(user_ids, ptr, items, num_items, n, seed, epoch) -> (users, pos, neg)
 #include <ATen/ATen.h>
@@ -128,12 +129,13 @@ at::Tensor adam_step_(at::Tensor p, const at::Tensor &g, at::Tensor m, at::Tenso
 std::tuple<at::Tensor, at::Tensor> score_topk(const at::Tensor &Y, int64_t U, int64_t I, const at::Tensor &users, int64_t d, int64_t S,
                                               int64_t head_mask, int64_t fusion_mode, int64_t predict_type,
                                               const c10::optional<at::Tensor> &train_ptr,
-                                              const c10::optional<at::Tensor> &train_items, int64_t K) {
+                                              const c10::optional<at::Tensor> &train_items, int64_t K, int64_t tie_order) {
     const at::Tensor y = rowmajor(Y, "Y");
     need(users, "users", at::kLong, 1);
     const at::Tensor u = users.contiguous();
     const int64_t B = u.numel();
     TORCH_CHECK(K >= 1, "elimrec::score_topk: K >= 1");
+    TORCH_CHECK(tie_order == 0 || tie_order == 1, "elimrec::score_topk: tie_order 0 (score desc, id asc) or 1 (the reference's heap order)");
     at::Tensor tp, ti;
     if (train_ptr.has_value() && train_ptr->defined()) {
         TORCH_CHECK(train_items.has_value() && train_items->defined(), "elimrec::score_topk: train_ptr needs train_items");
@@ -143,10 +145,10 @@ std::tuple<at::Tensor, at::Tensor> score_topk(const at::Tensor &Y, int64_t U, in
     at::Tensor idx = at::empty({B, K}, y.options().dtype(at::kInt)), val = at::empty({B, K}, y.options());
     const size_t need_ws = elimrec_score_workspace2((int)B, U, I, (int)S, (int)K);
     at::Tensor ws = at::empty({(int64_t)(need_ws ? need_ws : 1)}, y.options().dtype(at::kByte));
-    check(elimrec_score_topk(y.data_ptr<float>(), y.stride(0), U, I, u.data_ptr<int64_t>(), (int)B, (int)d, (int)S, (uint32_t)head_mask,
-                             (int)fusion_mode, (int)predict_type, nullptr, tp.defined() ? tp.data_ptr<int64_t>() : nullptr,
-                             ti.defined() ? ti.data_ptr<int32_t>() : nullptr, nullptr, 0, (int)K, idx.data_ptr<int32_t>(),
-                             val.data_ptr<float>(), ws.data_ptr(), (size_t)ws.numel(), cur_stream()),
+    check(elimrec_score_topk_ordered(y.data_ptr<float>(), y.stride(0), U, I, u.data_ptr<int64_t>(), (int)B, (int)d, (int)S, (uint32_t)head_mask,
+                                     (int)fusion_mode, (int)predict_type, nullptr, tp.defined() ? tp.data_ptr<int64_t>() : nullptr,
+                                     ti.defined() ? ti.data_ptr<int32_t>() : nullptr, nullptr, 0, (int)K, idx.data_ptr<int32_t>(),
+                                     val.data_ptr<float>(), ws.data_ptr(), (size_t)ws.numel(), (int)tie_order, cur_stream()),
           "score_topk");
     return {idx, val};
 }
@@ -336,7 +338,7 @@ TORCH_LIBRARY(elimrec, m) {
     m.def("linear_bwd_w(Tensor A, Tensor B) -> (Tensor, Tensor)");
     m.def("bpr_head_fwd(Tensor Y, int U, int I, Tensor users, Tensor pos, Tensor neg, int d, float[] block_weights) -> (Tensor, Tensor, Tensor)");
     m.def("adam_step_(Tensor(a!) p, Tensor g, Tensor(b!) m, Tensor(c!) v, float lr, float beta1, float beta2, float eps, float weight_decay, int step) -> Tensor(a!)");
-    m.def("score_topk(Tensor Y, int U, int I, Tensor users, int d, int S, int head_mask, int fusion_mode, int predict_type, Tensor? train_ptr, Tensor? train_items, int K) -> (Tensor, Tensor)");
+    m.def("score_topk(Tensor Y, int U, int I, Tensor users, int d, int S, int head_mask, int fusion_mode, int predict_type, Tensor? train_ptr, Tensor? train_items, int K, int tie_order=0) -> (Tensor, Tensor)");
     m.def("rank_metrics(Tensor topk_idx, Tensor truth_ptr, Tensor truth_items, int[] metric_ids) -> Tensor");
     m.def("sample_triplets(Tensor user_ids, Tensor ptr, Tensor items, int num_items, int n, int seed, int epoch) -> (Tensor, Tensor, Tensor)");
     m.def("bpr_head_bwd(Tensor grad_rows, Tensor keys, Tensor grad_out, int n_rows) -> Tensor");

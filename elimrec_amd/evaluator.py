@@ -7,11 +7,11 @@ top-K and the metric curves all run on the GPU (csrc/eval.hip) and only the per-
 ([users x metrics*K] floats) come back to the host for the final mean -- the reference instead
 copies a [128 x I] score matrix to the host per batch and ranks it on 8 CPU threads.
 
-Tie rule: the device ranks by (score descending, item id ascending); the reference's
-std::partial_sort_copy breaks ties in heap order (SURVEY quirk 6). The two agree whenever a row
-has no tied scores at or across the K boundary; the rows that have are re-ranked by the reference's
-own algorithm (tie_order = "reference", the default; "id" keeps the device's rule and never leaves
-the device).
+Tie rule: the reference's std::partial_sort_copy breaks ties in the C++ library's heap order
+(SURVEY quirk 6). tie_order = "reference" (the default) gives exactly those lists: the library
+algorithm is replayed on the device, one wave per user, inside the scoring call (csrc/eval.hip
+ref_order_kernel) -- same cost as tie_order = "id", the device's own rule (score descending, item
+id ascending). The two agree on every row without tied scores at or across the K boundary.
 """
 import numpy as np
 import torch
@@ -60,9 +60,8 @@ class UniEvaluator(object):
         self.top_show = np.arange(top_k) + 1 if isinstance(top_k, int) else np.sort(top_k)
         self._dev_cache = {}
         self._default_users = None
-        # ties among equal scores: "reference" (default) = the reference's lists, rows with a tie at or across K re-ranked on the
-        # host by its own algorithm (evaluate.h:26-33); "id" = the device's rule (score descending, item id ascending), nothing
-        # leaves the device (--tie_order / ELIMREC_TIE_ORDER)
+        # ties among equal scores: "reference" (default) = the reference's lists (evaluate.h:26-33's partial_sort_copy replayed on
+        # the device, every row); "id" = the device's own rule (score descending, item id ascending) (--tie_order / ELIMREC_TIE_ORDER)
         import os as _os
         self.tie_order = _os.environ.get("ELIMREC_TIE_ORDER", "reference")
         if self.tie_order not in ("id", "reference"):
@@ -217,51 +216,37 @@ class UniEvaluator(object):
             block //= 2
         return block
 
-    # the chunked top-K scorer's default math (six bf16 piece products per fp32 product, v_exp / v_rcp) returns scores within
-    # 2.4e-7 of the score-matrix form the replayed rows are ranked on: two scores further apart than twice
-    # that have the same order in both forms
-    NEAR_TIE = 4.8e-7
-
     def _topk_in_reference_order(self, model, users_t, train_ptr, train_items):
-        """tie_order = "reference": the device's top-(K + 1); a row whose K + 1 best scores are clearly apart has ONE ranking
-        under any tie rule and in either score form -- the device's list is the reference's. The other rows (equal or
-        near-equal scores inside the list or straddling K: rare on trained tables) get their masked score ROWS from the device
-        -- one score form for the whole row, the one predict() returns -- and are ranked on the host by the reference's own
-        algorithm, std::partial_sort_copy (evaluate.h:26-33, elimrec_topk_reference_order): selection and order of those rows
-        are the reference's code on that row. With EXACT evaluation math both score forms are the same bits and only exact
-        ties are replayed."""
-        import ctypes
-        from . import _lib
+        """tie_order = "reference": the lists evaluate.h:26-33 makes of these users' masked score rows -- std::partial_sort_copy's
+        heap order among equal scores -- computed ON THE DEVICE inside the scoring call (csrc/eval.hip ref_order_kernel: one wave
+        per user replays the library algorithm operation for operation on the scores the scorer has just produced, the heap carried
+        from catalogue chunk to chunk). Every row, tied or not; no score row is materialised or copied, nothing synchronises with
+        the host, and the pass costs what the "id" order costs whatever the state of training.
+        Item-sharded tables (several ranks, shard_eval.py): a rank sees only its items, and the algorithm is sequential over the
+        catalogue -- the merged (score, id) lists are the reference's on every row without a tie at or across K; the rows that
+        have one get their whole score rows (all-gathered, as predict() returns them) ranked by the same device kernel."""
         K = self.max_top
-        lib = _lib.load()
-        tol = 0.0 if int(lib.elimrec_score_get_math()) == 0 else self.NEAR_TIE
+        if getattr(model, "_eval_shard", None) is None:
+            return model.predict_device(users_t, top_k=K, train_ptr=train_ptr, train_items=train_items, tie_order="reference")
+        if K + 1 > min(256, model.num_items):
+            raise ValueError("tie_order=reference over item-sharded tables needs the merged top-(K + 1) list: K + 1 = %d exceeds "
+                             "min(256, num_items = %d); evaluate with --tie_order=id" % (K + 1, model.num_items))
         idx1, val1 = model.predict_device(users_t, top_k=K + 1, train_ptr=train_ptr, train_items=train_items)
         idx, val = idx1[:, :K].contiguous(), val1[:, :K].contiguous()
-        hi, lo = val1[:, :-1], val1[:, 1:]
-        tied = torch.nonzero(((hi == lo) | ((hi - lo) <= tol)).any(1)).flatten()
+        tied = torch.nonzero((val1[:, :-1] == val1[:, 1:]).any(1)).flatten()       # (every rank holds the same merged lists)
         self.tie_rows_replayed += int(tied.numel())
         if tied.numel():
-            # the tied rows' slices of the block's training lists, cut on the device (two small read-backs: the rows' bounds)
             lo_t, hi_t = train_ptr[tied], train_ptr[tied + 1]
-            lens = (hi_t - lo_t).cpu().numpy()
-            starts = lo_t.cpu().numpy()
-            sub_ptr = np.zeros(tied.numel() + 1, np.int64)
-            np.cumsum(lens, out=sub_ptr[1:])
-            dev = users_t.device
-            step = max(1, (1 << 28) // max(1, model.num_items))          # <= 1 GiB of score rows at a time
-            for a in range(0, tied.numel(), step):
-                part = tied[a:a + step]
-                sc = torch.empty(part.numel(), model.num_items, dtype=torch.float32, device=dev)
-                p0 = sub_ptr[a:a + part.numel() + 1] - sub_ptr[a]
-                pieces = [train_items[int(starts[a + j]):int(starts[a + j]) + int(lens[a + j])] for j in range(part.numel())]
-                it = torch.cat(pieces) if int(p0[-1]) else torch.zeros(1, dtype=torch.int32, device=dev)
-                model.predict_device(users_t[part], scores=sc, train_ptr=torch.from_numpy(p0).to(dev), train_items=it.contiguous())
-                host = np.ascontiguousarray(sc.cpu().numpy())
-                out = np.empty((part.numel(), K), np.int32)
-                _lib.check(lib.elimrec_topk_reference_order(host.ctypes.data_as(ctypes.c_void_p), host.shape[0], host.shape[1], host.shape[1], K,
-                                                            out.ctypes.data_as(ctypes.c_void_p)), "topk_reference_order")
-                idx[part] = torch.from_numpy(out).to(dev)
-                val[part] = torch.gather(sc, 1, idx[part].long())
+            sub_ptr = torch.zeros(tied.numel() + 1, dtype=torch.int64, device=users_t.device)
+            torch.cumsum(hi_t - lo_t, 0, out=sub_ptr[1:])
+            take = torch.repeat_interleave(lo_t - sub_ptr[:-1], hi_t - lo_t) + torch.arange(int(sub_ptr[-1]), device=users_t.device)
+            it = train_items[take] if take.numel() else torch.zeros(1, dtype=torch.int32, device=users_t.device)
+            sc = torch.empty(tied.numel(), model.num_items, dtype=torch.float32, device=users_t.device)
+            model.predict_device(users_t[tied], scores=sc, train_ptr=sub_ptr, train_items=it.contiguous())
+            ti = torch.empty(tied.numel(), K, dtype=torch.int32, device=users_t.device)
+            tv = torch.empty(tied.numel(), K, dtype=torch.float32, device=users_t.device)
+            ops.topk_reference_order(sc, K, ti, tv)
+            idx[tied], val[tied] = ti, tv
         return idx, val
 
     def evaluate_batch(self, model, batch_users, return_topk=False, cache_key=None, out=None):
@@ -280,10 +265,6 @@ class UniEvaluator(object):
                 self._dev_cache[key] = hit
         users_t, train_ptr, train_items, truth_ptr, truth_items = hit
         if self.tie_order == "reference":
-            if self.max_top + 1 > min(256, model.num_items):
-                raise ValueError("tie_order=reference needs the device's top-(K + 1) list: K + 1 = %d exceeds min(256, num_items = %d); "
-                                 "evaluate with --tie_order=id (the device's rule: lowest item id first among equal scores)"
-                                 % (self.max_top + 1, model.num_items))
             idx, val = self._topk_in_reference_order(model, users_t, train_ptr, train_items)
         else:
             idx, val = model.predict_device(users_t, top_k=self.max_top, train_ptr=train_ptr, train_items=train_items)

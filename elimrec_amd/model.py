@@ -1125,9 +1125,10 @@ class EliMRec(BasicModel):
         return sum(1 << h for h, m in enumerate(self._mods) if m in modality)
 
     @torch.no_grad()
-    def predict_device(self, user_ids, scores=None, top_k=0, train_ptr=None, train_items=None):
+    def predict_device(self, user_ids, scores=None, top_k=0, train_ptr=None, train_items=None, tie_order="id"):
         """Device-side predict (+ optional train-item masking and top-K). Uses the tables cached
-        by the LAST training forward, like the reference (:98-99)."""
+        by the LAST training forward, like the reference (:98-99). tie_order: the lists' order among equal
+        scores -- "id" (lowest item id first) or "reference" (evaluate.h:26-33's partial_sort_copy, replayed on the device)."""
         dev = self._require_gpu()
         self._plugin.realise_forward()
         if self._ws is None or self._cache is None:
@@ -1140,6 +1141,8 @@ class EliMRec(BasicModel):
             if scores is not None:
                 scores.copy_(sh.scores(users, train_ptr, train_items))
             if top_k:
+                if tie_order != "id":
+                    raise ValueError("item-sharded tables rank by (score, id); the evaluator re-ranks tied rows in the reference's order")
                 return sh.topk(users, top_k, train_ptr, train_items)
             return None, None
         # top-K only (the evaluator): no [B x I] score block in the workspace, the catalogue is scored in chunks
@@ -1160,7 +1163,8 @@ class EliMRec(BasicModel):
             self._ws["sqn_version"] = self._table_version
         ops.score_topk(self._ws["Y"], self.num_users, I, users, self.latent_dim, self.S, self._head_mask(),
                        self.fusion_mode, self.predict_type, self._ws["score_ws"], scores=scores, K=top_k,
-                       topk_idx=idx, topk_val=val, train_ptr=train_ptr, train_items=train_items, sqnorm=self._ws["sqn"])
+                       topk_idx=idx, topk_val=val, train_ptr=train_ptr, train_items=train_items, sqnorm=self._ws["sqn"],
+                       tie_order=tie_order)
         return idx, val
 
     def predict(self, user_ids, candidate_items=None):

@@ -587,11 +587,12 @@ def adam_step_raw(p_ptr, g_ptr, m_ptr, v_ptr, n, lr, beta1, beta2, eps, weight_d
 
 
 def score_workspace(B, U, I, S, K, topk_only=False, d=None):
-    """Bytes of score_topk's workspace. topk_only: the call will ask for top-K lists only (no score matrix); with the
+    """Bytes of score_topk's workspace. topk_only: the call will ask for top-K lists only (no score matrix). With the
     recdim `d` given the library itself decides whether that call takes the chunked form (no [B x I] block) and returns
-    the layout it will use -- the full one for a recdim / K / scorer switch outside the chunked form's range."""
-    if topk_only and d is not None:
-        return int(_lib.load().elimrec_score_workspace_for(B, U, I, S, K, int(d), 0))
+    the layout it will use -- the full one for a recdim / K / scorer switch outside the chunked form's range -- with room
+    for one chunk's bf16 piece planes (the default scorer of recdim 32 / 64, for lists and for score matrices alike)."""
+    if d is not None:
+        return int(_lib.load().elimrec_score_workspace_for(B, U, I, S, K, int(d), 0 if topk_only else 1))
     if topk_only:
         return int(_lib.load().elimrec_score_workspace_topk(B, U, I, S, K))
     return int(_lib.load().elimrec_score_workspace2(B, U, I, S, K))
@@ -608,20 +609,34 @@ FUSION_MODES = {"rubi": 0, "hm": 1, "sum": 2}
 PREDICT_TYPES = {"TE": 1, "TIE": 2}   # anything else -> 0 ("normal", models/EliMRec.py:113)
 
 
+TIE_ORDERS = {"id": 0, "reference": 1}   # among equal scores: lowest item id first / the reference's heap order (evaluate.h:26-33)
+
+
 def score_topk(Y, U, I, users, d, S, head_mask, fusion_mode, predict_type, workspace, scores=None, K=0,
-               topk_idx=None, topk_val=None, train_ptr=None, train_items=None, sqnorm=None):
+               topk_idx=None, topk_val=None, train_ptr=None, train_items=None, sqnorm=None, tie_order="id"):
     y, ldy = _rowmajor(Y, "Y")
     B = users.numel()
     sp, lds = (None, 0)
     if scores is not None:
         sp, lds = _rowmajor(scores, "scores")
-    _lib.check(_lib.load().elimrec_score_topk(y, ldy, U, I, _dev(users, "users", torch.int64), B, d, S, int(head_mask),
-                                              FUSION_MODES[fusion_mode], PREDICT_TYPES.get(predict_type, 0),
-                                              _dev(sqnorm, "sqnorm"), _dev(train_ptr, "train_ptr", torch.int64),
-                                              _dev(train_items, "train_items", torch.int32), sp, lds, int(K),
-                                              _dev(topk_idx, "topk_idx", torch.int32), _dev(topk_val, "topk_val"),
-                                              _dev(workspace, "workspace", torch.uint8), workspace.numel(), _stream()),
+    _lib.check(_lib.load().elimrec_score_topk_ordered(y, ldy, U, I, _dev(users, "users", torch.int64), B, d, S, int(head_mask),
+                                                      FUSION_MODES[fusion_mode], PREDICT_TYPES.get(predict_type, 0),
+                                                      _dev(sqnorm, "sqnorm"), _dev(train_ptr, "train_ptr", torch.int64),
+                                                      _dev(train_items, "train_items", torch.int32), sp, lds, int(K),
+                                                      _dev(topk_idx, "topk_idx", torch.int32), _dev(topk_val, "topk_val"),
+                                                      _dev(workspace, "workspace", torch.uint8), workspace.numel(),
+                                                      TIE_ORDERS[tie_order], _stream()),
                "score_topk")
+
+
+def topk_reference_order(scores, K, out_idx, out_val=None):
+    """Rows of masked scores on the device -> the reference's top-K lists (std::partial_sort_copy's order, evaluate.h:26-33)."""
+    sp, lds = _rowmajor(scores, "scores")
+    B, I = scores.shape
+    assert out_idx.is_contiguous() and out_idx.shape == (B, K) and (out_val is None or (out_val.is_contiguous() and out_val.shape == (B, K)))
+    _lib.check(_lib.load().elimrec_topk_reference_order_device(sp, B, I, lds, int(K), _dev(out_idx, "out_idx", torch.int32),
+                                                               _dev(out_val, "out_val"), _stream()), "topk_reference_order_device")
+    return out_idx, out_val
 
 
 def score_topk_shard(Y, U, I, users, d, S, head_mask, fusion_mode, predict_type, workspace, phase, row_sum, I_total, id_offset,

@@ -465,10 +465,25 @@ int elimrec_score_topk(const float *d_Y, int64_t ldy, int64_t U, int64_t I, cons
                        float *d_scores, int64_t lds, int K, int32_t *d_topk_idx, float *d_topk_val,
                        void *d_workspace, size_t workspace_bytes, void *stream);
 
-/* The reference's order among EQUAL scores (evaluate.h:26-33: std::partial_sort_copy of the item ids by score, whose order of
- * ties is the C++ library's heap order, not an order of the ids), for callers that want its lists bit for bit on rows that tie at
- * or across K: a HOST function over host rows of masked scores [n_rows x ld] -> h_topk [n_rows x K], running that algorithm of
- * the C++ library this package is built with. The device ranking stays (score descending, id ascending). */
+/* The reference's order among EQUAL scores. /root/reference/evaluator/backend/cpp/include/evaluate.h:26-33 ranks a user's masked
+ * score row with std::partial_sort_copy over the item ids under comp(x1, x2) = ratings[x1] > ratings[x2]; among equal scores its
+ * lists are the heap order of the C++ library's algorithm (first K ids -> make_heap; every later id that beats the heap's top ->
+ * __adjust_heap; sort_heap), not an order of the ids. Three entry points give those lists bit for bit:
+ *  - elimrec_score_topk_ordered: elimrec_score_topk with tie_order 1 -- ON THE DEVICE, inside the scoring call: one wave per user
+ *    row replays the algorithm operation for operation (csrc/eval.hip ref_order_kernel), scanning 64 items (or the maxima of 64
+ *    sixteen-item tiles) per step against the heap's top; a catalogue scored chunk by chunk carries the heap between the chunks.
+ *    No score row leaves the device, no host synchronisation; K <= 1024. tie_order 0 = elimrec_score_topk.
+ *  - elimrec_topk_reference_order_device: the same kernel over rows of masked scores already on the device, [n_rows x ld] ->
+ *    d_topk_idx / d_topk_val (nullable) [n_rows x K].
+ *  - elimrec_topk_reference_order: a HOST function over host rows running std::partial_sort_copy of the C++ library this package
+ *    is built with (what the device kernel is tested against, beside the reference's own compiled evaluate.h). */
+int elimrec_score_topk_ordered(const float *d_Y, int64_t ldy, int64_t U, int64_t I, const int64_t *d_users,
+                               int B, int d, int S, uint32_t head_mask, int fusion_mode, int predict_type,
+                               const float *d_sqnorm, const int64_t *d_train_ptr, const int32_t *d_train_items,
+                               float *d_scores, int64_t lds, int K, int32_t *d_topk_idx, float *d_topk_val,
+                               void *d_workspace, size_t workspace_bytes, int tie_order, void *stream);
+int elimrec_topk_reference_order_device(const float *d_scores, int64_t n_rows, int64_t I, int64_t ld, int K,
+                                        int32_t *d_topk_idx, float *d_topk_val, void *stream);
 int elimrec_topk_reference_order(const float *h_scores, int64_t n_rows, int64_t I, int64_t ld, int K, int32_t *h_topk);
 
 /* Precision/Recall/MAP/NDCG/MRR prefix curves @1..K from ranked lists (metric.h:17-106).

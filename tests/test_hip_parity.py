@@ -1383,18 +1383,15 @@ def test_device_evaluator_against_the_references_own_compiled_code(fixture_name)
 
 
 @pytest.mark.gpu
-def test_reference_tie_order_is_reproduced_on_request(fixture_name):
-    """--tie_order=reference. The fixture's cached tables with groups of DUPLICATED item rows (equal rows score equally under every
-    user, so ties sit inside the top-K and across its boundary for most users): with the device's own rule the lists differ from
-    those of the reference's compiled evaluate.h on rows with ties; on request every row -- tied or not -- carries the reference's
-    list and metric row bit for bit (rows without a tie have one ranking under any rule; the others are re-ranked on the host by
-    std::partial_sort_copy, the reference's algorithm). EXACT evaluation math, so that the score matrix the reference's code ranks
-    and the evaluator's chunk-wise scores are the same bits."""
-    from elimrec_amd import _lib
+def test_reference_tie_order_is_reproduced_on_request(fixture_name, eval_math):
+    """--tie_order=reference (the default). The fixture's cached tables with groups of DUPLICATED item rows (equal rows score
+    equally under every user, so ties sit inside the top-K and across its boundary for most users): with the device's own rule the
+    lists differ from those of the reference's compiled evaluate.h on rows with ties; in reference order EVERY row -- tied or not --
+    carries the reference's list, scores and metric row bit for bit, computed on the device inside the scoring call
+    (ref_order_kernel), in both evaluation math modes: the lists are what the reference's code makes of the rows predict() returns."""
     from oracle import eval_oracle as ev
     if ev.ref_lib() is None:
         pytest.skip("oracle/_ref/libref_eval.so was not built (needs /root/reference at build time)")
-    lib = _lib.load()
     g = load_golden(fixture_name)
     model, _ = build_model_from_fixture(g, DEV)
     _load_cache(model, g)
@@ -1410,47 +1407,170 @@ def test_reference_tie_order_is_reproduced_on_request(fixture_name):
     K = int(g["evalbatch/top_k"])
     mids = g["evalbatch/metric_ids"]
     evalr = model.test_evaluator.evaluator
-    math0 = int(lib.elimrec_score_get_math())
+    dev_scores = torch.empty(len(users), model.num_items, device=DEV)
+    train_ptr, train_items = evalr._batch_csr(users, evalr.user_pos_train, DEV, unique=False)
+    model.predict_device(users, scores=dev_scores, train_ptr=train_ptr, train_items=train_items)
+    sc = np.ascontiguousarray(dev_scores.cpu().numpy())
+    test = csr_dict(g, "test")
+    tp, ti = ev.truth_to_csr([sorted(set(test[int(u)])) for u in users])
+    ref_rows, ref_topk = ev.evaluate_matrix(sc.copy(), tp, ti, mids, K, use_ref=True)
+    ref_rows = np.asarray(ref_rows, np.float32).reshape(len(users), -1)
+    _, port_topk = ev.evaluate_matrix(sc.copy(), tp, ti, mids, K)             # (the C restatement agrees with the reference's code)
+    assert np.array_equal(port_topk, ref_topk)
     try:
-        lib.elimrec_score_set_math(0)
-        dev_scores = torch.empty(len(users), model.num_items, device=DEV)
-        train_ptr, train_items = evalr._batch_csr(users, evalr.user_pos_train, DEV, unique=False)
-        model.predict_device(users, scores=dev_scores, train_ptr=train_ptr, train_items=train_items)
-        sc = np.ascontiguousarray(dev_scores.cpu().numpy())
-        test = csr_dict(g, "test")
-        tp, ti = ev.truth_to_csr([sorted(set(test[int(u)])) for u in users])
-        ref_rows, ref_topk = ev.evaluate_matrix(sc.copy(), tp, ti, mids, K, use_ref=True)
-        ref_rows = np.asarray(ref_rows, np.float32).reshape(len(users), -1)
         evalr.tie_order = "id"
         rows_id, idx_id, _ = evalr.evaluate_batch(model, users, return_topk=True)
-        evalr.tie_order, evalr.tie_rows_replayed = "reference", 0
+        evalr.tie_order = "reference"
         rows_ref, idx_ref, val_ref = evalr.evaluate_batch(model, users, return_topk=True)
     finally:
-        lib.elimrec_score_set_math(math0)
         evalr.tie_order = "reference"
     tied = ~_tie_free(sc, K)
-    assert tied.sum() >= 3 and evalr.tie_rows_replayed == int(tied.sum())             # (EXACT math: exact ties only)
+    assert tied.sum() >= 3
     assert not np.array_equal(idx_id.cpu().numpy(), ref_topk)                     # the device's rule IS another order on these rows
     assert np.array_equal(idx_id.cpu().numpy()[~tied], ref_topk[~tied])
-    assert np.array_equal(idx_ref.cpu().numpy(), ref_topk)                        # ... and on request the reference's, everywhere
+    assert np.array_equal(idx_ref.cpu().numpy(), ref_topk)                        # ... and by default the reference's, everywhere
     assert np.array_equal(rows_ref.cpu().numpy(), ref_rows)
     assert np.array_equal(val_ref.cpu().numpy(), np.take_along_axis(sc, ref_topk.astype(np.int64), 1))
-    # the DEFAULT evaluation math: the chunked top-K scorer and the score-matrix form differ by <= 2.4e-7, so a tie in one need not
-    # be a tie in the other -- rows whose K + 1 best scores are closer than twice that are replayed on the score rows predict()
-    # returns, and every row carries what the reference's code makes of THOSE rows
-    lib.elimrec_score_set_math(1)
-    try:
-        model.predict_device(users, scores=dev_scores, train_ptr=train_ptr, train_items=train_items)
-        sc_fast = np.ascontiguousarray(dev_scores.cpu().numpy())
-        _, fast_topk = ev.evaluate_matrix(sc_fast.copy(), tp, ti, mids, K, use_ref=True)
-        evalr.tie_rows_replayed = 0
-        _, idx_fast, val_fast = evalr.evaluate_batch(model, users, return_topk=True)
-    finally:
-        lib.elimrec_score_set_math(math0)
-    assert evalr.tie_rows_replayed >= int(tied.sum())
-    assert np.array_equal(idx_fast.cpu().numpy(), fast_topk)
-    replayed = ~_tie_free(sc_fast, K)
-    assert np.array_equal(val_fast.cpu().numpy()[replayed], np.take_along_axis(sc_fast, fast_topk.astype(np.int64), 1)[replayed])
+    # the same lists from the kernel over the materialised rows (elimrec_topk_reference_order_device)
+    from elimrec_amd import ops
+    oi = torch.empty(len(users), K, dtype=torch.int32, device=DEV)
+    ov = torch.empty(len(users), K, device=DEV)
+    ops.topk_reference_order(dev_scores, K, oi, ov)
+    assert np.array_equal(oi.cpu().numpy(), ref_topk) and np.array_equal(ov.cpu().numpy(), val_ref.cpu().numpy())
+
+
+def _reference_lists(sc, K):
+    """The oracle's lists of rows of scores: the C restatement of evaluate.h:26-33 and, where it was built, the reference's own
+    compiled header (both must agree)."""
+    from oracle import eval_oracle as ev
+    tp, ti = ev.truth_to_csr([[0]] * sc.shape[0])
+    _, port = ev.evaluate_matrix(sc.copy(), tp, ti, [1], K)
+    if ev.ref_lib() is not None:
+        _, ref = ev.evaluate_matrix(sc.copy(), tp, ti, [1], K, use_ref=True)
+        assert np.array_equal(port, ref)
+    return port
+
+
+@pytest.mark.gpu
+def test_reference_order_kernel_known_answers_and_edge_rows():
+    """ref_order_kernel (the reference's std::partial_sort_copy replayed by one wave per row) against the oracle, bit for bit on the
+    ids AND on the order among equal scores: SURVEY section 4's known answer, a row of all-equal scores, ascending rows (every item
+    enters the heap) and descending rows (none does), -inf (masked) scores inside the first K, K = 1 / K = I / even and odd K up
+    to 1024, rows shorter than a 64-item step."""
+    from elimrec_amd import ops
+    rng = np.random.default_rng(11)
+
+    def check(sc, K):
+        sc = np.ascontiguousarray(sc, np.float32)
+        want = _reference_lists(sc, K)
+        oi = torch.empty(sc.shape[0], K, dtype=torch.int32, device=DEV)
+        ov = torch.empty(sc.shape[0], K, device=DEV)
+        ops.topk_reference_order(_t(sc), K, oi, ov)
+        assert np.array_equal(oi.cpu().numpy(), want), (sc.shape, K)
+        assert np.array_equal(ov.cpu().numpy(), np.take_along_axis(sc, want.astype(np.int64), 1))
+
+    kat = np.array([[.5, .5, .5, .1, .9, .5]], np.float32)
+    for K in (1, 2, 3, 4, 5, 6):
+        check(kat, K)
+    check(np.full((3, 1000), 0.25, np.float32), 10)                       # all equal: the order is the heap's alone
+    check(np.full((2, 70), 0.25, np.float32), 70)
+    for I in (5, 63, 64, 65, 200, 4097):
+        base = rng.integers(0, 7, size=(6, I)).astype(np.float32) / 8     # eight distinct values: ties everywhere
+        for K in sorted({1, 2, min(7, I), min(10, I), min(64, I), min(65, I), I if I <= 200 else 1024}):
+            check(base, K)
+    asc = np.tile(np.arange(3000, dtype=np.float32), (2, 1))
+    check(asc, 10); check(asc[:, ::-1].copy(), 10); check(np.floor(asc / 7), 33)
+    masked = rng.integers(0, 5, size=(8, 500)).astype(np.float32)
+    masked[:, :12][rng.random((8, 12)) < 0.6] = -np.inf                   # masked items among the first K ids
+    masked[rng.random(masked.shape) < 0.3] = -np.inf
+    check(masked, 10); check(masked, 11)
+    few = np.full((2, 300), -np.inf, np.float32)                          # fewer than K unmasked items: -inf ids in heap order
+    few[:, [5, 17, 200]] = [0.5, 0.7, 0.5]
+    check(few, 10)
+    # a padded matrix (ld > I): rows cut out of a wider block
+    wide = _t(rng.integers(0, 9, size=(5, 640)).astype(np.float32))
+    oi = torch.empty(5, 10, dtype=torch.int32, device=DEV)
+    ops.topk_reference_order(wide[:, :600], 10, oi)
+    assert np.array_equal(oi.cpu().numpy(), _reference_lists(wide[:, :600].cpu().numpy(), 10))
+
+
+@pytest.mark.gpu
+def test_reference_order_at_the_tiktok_catalogue_with_early_training_scores():
+    """SURVEY section 7's probe: early in training the TIE scores of 76 085 items span [0.4985, 0.5027] and take only ~17 k distinct
+    fp32 values -- nearly every row ties inside its top-K. (a) the kernel over such rows, materialised; (b) the whole evaluator path
+    at that catalogue size: test_reference_order_inside_the_scoring_call."""
+    from elimrec_amd import ops
+    rng = np.random.default_rng(3)
+    I, K = 76085, 10
+    levels = np.sort(rng.choice(np.arange(int(0.4985 * 2 ** 25), int(0.5027 * 2 ** 25)), size=17000, replace=False)).astype(np.float32) / 2 ** 25
+    bell = np.clip(8500 + rng.standard_normal((32, I)) * 2100, 0, 16999).astype(np.int64)          # sparse upper tail: some ties in the top-K
+    crowd = 16999 - np.minimum((np.abs(rng.standard_normal((32, I))) * 4000).astype(np.int64), 16999)   # the mode at the top: all tied
+    sc = np.ascontiguousarray(levels[np.concatenate([bell, crowd])], np.float32)
+    assert 36 <= (~_tie_free(sc, K)).sum()
+    want = _reference_lists(sc, K)
+    oi = torch.empty(64, K, dtype=torch.int32, device=DEV)
+    ops.topk_reference_order(_t(sc), K, oi)
+    assert np.array_equal(oi.cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,I", [(64, 76085), (32, 40000), (128, 33000), (64, 9000)])
+def test_reference_order_inside_the_scoring_call(d, I, eval_math):
+    """elimrec_score_topk_ordered with tie_order = reference at catalogue sizes beyond one scorer chunk (the heap carried from chunk
+    to chunk, tiles below the running threshold never stored, train items masked by bitmap) and below (one launch, tile-guided):
+    the lists equal the oracle's ranking of the score matrix the SAME call shape returns -- one score form for lists and matrix,
+    in both math modes (recdim 32 / 64 default math: six bf16 piece products, chunk by chunk for the matrix too) -- on tables
+    with massive ties (nine distinct item rows), on early-training tables (scores crowded around 0.5: SURVEY section 7) and on
+    continuous ones; K = 10 and 50; lists and matrix from one call as well."""
+    from elimrec_amd import ops
+    U, S = 150, 3
+    Cy = (1 + S) * d
+    g = torch.Generator().manual_seed(6)
+    Yr = torch.randn(U + I, Cy, generator=g) * 0.3
+    Yt = Yr.clone()
+    Yt[U:] = Yt[U:U + 9].repeat((I + 8) // 9, 1)[:I]
+    Ye = torch.round(torch.randn(U + I, Cy, generator=g) * 4) / 256           # tiny, coarsely quantised rows: colliding scores
+    users = torch.arange(0, 140)
+    B = len(users)
+    rng = np.random.default_rng(1)
+    lists = [rng.choice(I, size=int(rng.integers(0, 60)), replace=False).tolist() for _ in range(B)]
+    lists[2] = list(range(0, 30))                                # the first K ids masked: -inf entries in the initial heap
+    lists[4] = [i for i in range(I) if i % 1000 != 7]            # fewer unmasked items than K = 50... (I / 1000 of them)
+    ptr = torch.zeros(B + 1, dtype=torch.int64)
+    ptr[1:] = torch.tensor(np.cumsum([len(x) for x in lists]))
+    items = torch.tensor([i for x in lists for i in x], dtype=torch.int32)
+    ud, pd, itd = users.to(DEV), ptr.to(DEV), items.to(DEV)
+    n_tied = 0
+    for Y in (Yt, Ye, Yr):
+        Yd = Y.to(DEV)
+        ref = torch.empty(B, I, device=DEV)
+        ws = torch.empty(ops.score_workspace(B, U, I, S, 1, d=d), dtype=torch.uint8, device=DEV)
+        ops.score_topk(Yd, U, I, ud, d, S, 0b111, "rubi", "TIE", ws, scores=ref, train_ptr=pd, train_items=itd)
+        sc = ref.cpu().numpy()
+        for K in (10, 50):
+            want = _reference_lists(sc, K)
+            n_tied += int((~_tie_free(sc, K)).sum())
+            ws = torch.empty(ops.score_workspace(B, U, I, S, K, topk_only=True, d=d), dtype=torch.uint8, device=DEV)
+            if I > 16384:                                # no [B x I] score block: a [B x 16384] one
+                assert ws.numel() <= ops.score_workspace(B, U, I, S, K, d=d) - B * (I - 16384) * 4
+            idx = torch.empty(B, K, dtype=torch.int32, device=DEV)
+            val = torch.empty(B, K, device=DEV)
+            ops.score_topk(Yd, U, I, ud, d, S, 0b111, "rubi", "TIE", ws, K=K, topk_idx=idx, topk_val=val, train_ptr=pd,
+                           train_items=itd, tie_order="reference")
+            assert np.array_equal(idx.cpu().numpy(), want), (K, (idx.cpu().numpy() != want).any(1).nonzero())
+            assert np.array_equal(val.cpu().numpy(), np.take_along_axis(sc, want.astype(np.int64), 1))
+            # the device's own rule on the same call shape: the stable sort of the same matrix (rows with K unmasked items)
+            ops.score_topk(Yd, U, I, ud, d, S, 0b111, "rubi", "TIE", ws, K=K, topk_idx=idx, topk_val=val, train_ptr=pd, train_items=itd)
+            order = np.argsort(-sc, axis=1, kind="stable")[:, :K]
+            full = np.isfinite(np.take_along_axis(sc, order, 1)).all(1)
+            assert np.array_equal(idx.cpu().numpy()[full], order[full])
+            # lists and matrix from ONE call
+            ws = torch.empty(ops.score_workspace(B, U, I, S, K, d=d), dtype=torch.uint8, device=DEV)
+            both = torch.empty(B, I, device=DEV)
+            ops.score_topk(Yd, U, I, ud, d, S, 0b111, "rubi", "TIE", ws, scores=both, K=K, topk_idx=idx, topk_val=val, train_ptr=pd,
+                           train_items=itd, tie_order="reference")
+            assert torch.equal(both, ref) and np.array_equal(idx.cpu().numpy(), want)
+    assert n_tied >= 2 * B                                       # (the tie rule was exercised on most rows of two of the tables)
 
 
 @pytest.mark.gpu
