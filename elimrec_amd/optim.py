@@ -26,8 +26,8 @@ class FusedAdam(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=True):
         ctl = self._ctl
-        if ctl is not None and set_to_none and not ctl.grads_set and not ctl.grads_deferred():
-            return              # no .grad was ever assigned (the deferred step keeps its gradients inside the engine)
+        if ctl is not None and set_to_none and not ctl.grads_set and not ctl.grads_deferred() and not ctl.any_raw_grad():
+            return              # no .grad is set (the deferred step keeps its gradients inside the engine)
         super().zero_grad(set_to_none=set_to_none)
         if ctl is not None and set_to_none:
             ctl.grads_set = False

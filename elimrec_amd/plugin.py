@@ -256,6 +256,17 @@ class StepController(object):
         if p is not None and p["bwd"] and not p["grads"]:
             p["bwd"] = False
 
+    def any_raw_grad(self):
+        """Is any parameter's .grad set? (autograd's AccumulateGrad writes .grad without passing the Python setter that
+        maintains grads_set: a regulariser on a parameter outside bpr_loss)"""
+        ps = self.__dict__.get("_params")
+        if ps is None:
+            ps = self._params = list(self.model.parameters())
+        for q in ps:
+            if (_GRAD.__get__(q) if isinstance(q, torch.Tensor) else None) is not None:
+                return True
+        return False
+
     def grads_deferred(self):
         p = self.pending
         return p is not None and p["bwd"] and not p["grads"]
@@ -273,6 +284,14 @@ class StepController(object):
         m, eng, tr = self.model, self.engine, self.trainer
         if scale is not None and tr.world > 1:
             scale = scale / tr.world
+        # gradients of an EARLIER backward() that are still in .grad and live in the flat buffer this pass is about to write
+        # (they were handed out as views of it): moved out first, so that this pass's gradients are ADDED to them below
+        gv0 = (m._ws or {}).get("grad_views") or {}
+        for name, prm in m.named_parameters():
+            have = prm._raw_grad() if isinstance(prm, LazyGradParameter) else prm.grad
+            view = gv0.get(name)
+            if have is not None and view is not None and have.data_ptr() == view.data_ptr():
+                _GRAD.__set__(prm, have.clone())
         tr.backward_only(p["ctx"], grads_only=True, scale=scale)
         p["bwd"] = p["grads"] = True
         ws = m._ws
@@ -321,6 +340,10 @@ class StepController(object):
         if self.trainer.opt is not opt:
             self.trainer.set_optimizer(opt)
         eng, tr = self.engine, self.trainer
+        if not p["grads"] and (self.grads_set or self.any_raw_grad()):
+            # gradients of an earlier backward() are still in .grad (bpr_loss(b1).backward(); bpr_loss(b2).backward(); step()):
+            # torch's update consumes their SUM -- this batch's gradients are added to them, the update reads .grad
+            self.materialise_grads()
         if p["grads"]:
             # the gradients were materialised (and may have been edited): the update reads them where they are
             self._update_from_grads(opt)

@@ -395,7 +395,7 @@ class ColumnShardTrainer(object):
         g = self.opt.param_groups[0]
         # everything a step's launches take by VALUE besides the per-step patches: a program is frozen on them
         key = (B, tuple(eng.model._block_weights()), g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"],
-               eng.prestaged_ok(users, pos, neg))          # (... and the planner's place in the second stream's order)
+               eng.prestaged_ok(users, pos, neg) and eng.ahead_safe())   # (... and the planner's place in the second stream's order)
         progs = st["programs"].get(key)
         if progs is not None and progs[eng.cur] is not None:
             if st["check_every"] and (st["native_steps"] + st["checks"] + 1) % st["check_every"] == 0:
@@ -473,6 +473,7 @@ class ColumnShardTrainer(object):
                                                               # last batch switches the size too)
         loss = eng._next_loss_slot()
         eng.native_prologue()
+        eng._last_plan_cur = eng.cur                          # (the program's planner writes this buffer set: ahead_safe)
         values = dict(users=users.data_ptr(), pos=pos.data_ptr(), neg=neg.data_ptr(), loss=loss.data_ptr(), step=eng.step_count + 1)
         if self.multi and self.lookup:
             sizes = self._lookup_sizes(users, None)
@@ -1016,8 +1017,12 @@ class ColumnShardEngine(object):
             # second stream behind the main one before the planner writes into it
             program.sync(aux, torch.cuda.current_stream())
             self._ws_new_seen = getattr(m, "_ws_new", 0)
-        # the planner ahead of the previous step's end (prestage): one rank, the triplets announced as complete
-        ahead = (aux is not None and self._forked and not fresh and not self.multi and self.prestaged_ok(users, pos, neg))
+        # the planner ahead of the previous step's end (prestage): one rank, the triplets announced as complete -- and the pass
+        # before this one planned into the OTHER set of batch buffers (ahead_safe: a forward_only / gradients-only pass does not
+        # flip the sets, and its head and adjoint kernels may still be reading the one this planner is about to write)
+        ahead = (aux is not None and self._forked and not fresh and not self.multi and self.prestaged_ok(users, pos, neg)
+                 and self.ahead_safe())
+        self._last_plan_cur = self.cur
 
         # the per-line source bits are needed by the first ADJOINT hop only. Issued on the second stream right behind the planner,
         # before the weight packing and the feature blocks: one join per step (the second stream's forward work is then 72 us
@@ -1128,6 +1133,12 @@ class ColumnShardEngine(object):
             return
         program.sync(aux, torch.cuda.current_stream())       # once: whatever produced them is done before any of their planners runs
         self._prestaged = {id(u): (u, p, n) for u, p, n in batches}
+
+    def ahead_safe(self):
+        """May this pass's planner write its batch buffers before the previous pass has drained? Only if that pass planned into
+        the other buffer set, i.e. the sets have flipped since (cs_update / native_epilogue flip them; forward_only and
+        backward_only(grads_only=True) -- a loss read without a step, gradients for a foreign optimizer -- do not)."""
+        return getattr(self, "_last_plan_cur", None) != self.cur
 
     def prestaged_ok(self, users, pos, neg):
         e = getattr(self, "_prestaged", {}).get(id(users))

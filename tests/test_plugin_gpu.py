@@ -192,6 +192,74 @@ def test_plugin_stale_backward_raises_and_second_loss_settles_the_first():
     assert np.isfinite(second.item())
 
 
+def test_plugin_two_backwards_before_one_step_accumulate_like_torch():
+    """bpr_loss(b1).backward(); bpr_loss(b2).backward(); opt.step(): torch semantics -- .grad holds g1 + g2 and the update
+    consumes the sum (the fused step used to run on b2 alone and drop g1). Checked against a twin model that
+    materialises both gradients separately and steps torch's own Adam on their sum; a regulariser's gradient written by
+    autograd's AccumulateGrad (never through the Python .grad setter) is zeroed by zero_grad() and not carried over."""
+    g = load_golden("ml3")
+    b = _batches(g, 2)
+    # the twin: each batch's gradients alone (read through .grad), summed by hand
+    twin, _ = build_model_from_fixture(g, DEV)
+    topt = _opt(twin, g, torch.optim.Adam)
+    parts = []
+    for u, p, neg in b:
+        topt.zero_grad()
+        loss = twin.bpr_loss(u, p, neg)
+        loss.backward()
+        parts.append({k: prm.grad.detach().clone() for k, prm in twin.named_parameters() if prm.grad is not None})
+    topt.zero_grad()
+    for k, prm in twin.named_parameters():
+        if k in parts[0]:
+            prm.grad = parts[0][k] + parts[1][k]
+    topt.step()
+    want = {k: v.detach().cpu() for k, v in twin.state_dict().items()}
+    model, _ = build_model_from_fixture(g, DEV)
+    opt = _opt(model, g)
+    opt.zero_grad()
+    model.bpr_loss(*b[0]).backward()
+    model.bpr_loss(*b[1]).backward()                     # settles the first: g1 lands in .grad
+    opt.step()
+    got = model.state_dict()
+    for k in want:
+        assert (got[k].cpu() - want[k]).abs().max().item() < 3e-7, k
+    # AccumulateGrad behind the setter's back
+    opt.zero_grad()
+    assert not model.plugin.grads_set and not model.plugin.any_raw_grad()
+    reg = (model.embedding_user_after_GCN.weight ** 2).sum()
+    reg.backward()
+    assert not model.plugin.grads_set and model.plugin.any_raw_grad()
+    opt.zero_grad()
+    assert not model.plugin.any_raw_grad()
+
+
+def test_loss_read_without_a_step_then_prestaged_steps_stay_bitwise():
+    """A pass that does not flip the batch-buffer sets (a loss read and nothing else: forward_only) followed by steps on
+    PRESTAGED batches: the next planner must not run ahead into the set the unfinished pass still reads. Every loss
+    and the final state equal a run without the extra read, bit for bit, over many alternations."""
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer
+    g = load_golden("kwai")
+    n = 24
+    bs = _batches(g, n)
+
+    def run(with_reads):
+        model, _ = build_model_from_fixture(g, DEV)
+        eng = ColumnShardEngine(model)
+        tr = ColumnShardTrainer(eng, _opt(model, g))
+        tr.prestage(bs)
+        losses = []
+        for k, b in enumerate(bs):
+            if with_reads and k % 2 == 1:
+                ctx = tr.forward_only(*bs[(k + 3) % n])              # another batch's forward: planned, never stepped
+                assert ctx is not None and not eng.ahead_safe()
+            losses.append(tr.step(*b))
+        return [float(x) for x in torch.stack(losses).cpu()], _state(model, eng)
+    base_l, base = run(False)
+    read_l, read = run(True)
+    assert read_l == base_l
+    _same(read, base)
+
+
 @pytest.mark.parametrize("extra", [["--lean_tables=1"], ["--feature_dtype=bf16"]])
 def test_plugin_loop_under_lean_tables_and_16bit_features(extra):
     g = load_golden("ml3")
