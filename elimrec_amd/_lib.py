@@ -135,6 +135,12 @@ SIGNATURES = {
     "elimrec_bpr_head_rows": (c_i32, [c_ptr, c_i64, c_ptr, c_i32, c_i32, c_i32, ctypes.POINTER(c_f32), c_ptr, c_ptr, c_ptr]),
     "elimrec_bpr_head_rows_sum": (c_i32, [c_ptr, c_i64, c_ptr, c_i32, c_i32, c_i32, ctypes.POINTER(c_f32), c_ptr, c_ptr, c_ptr, c_ptr,
                                           c_ptr]),
+    "elimrec_bpr_head_rows_sum_pub": (c_i32, [c_ptr, c_i64, c_ptr, c_i32, c_i32, c_i32, ctypes.POINTER(c_f32), c_ptr, c_ptr, c_ptr, c_ptr,
+                                              c_ptr, c_ptr]),
+    "elimrec_loss_pub_create": (c_i32, [c_i32, ctypes.POINTER(c_ptr)]),
+    "elimrec_loss_pub_destroy": (c_i32, [c_ptr]),
+    "elimrec_loss_pub_issued": (c_u32, [c_ptr]),
+    "elimrec_loss_pub_wait": (c_i32, [c_ptr, c_u32, ctypes.c_double, ctypes.POINTER(c_f32)]),
     "elimrec_sum": (c_i32, [c_ptr, c_i64, c_ptr, c_ptr]),
     "elimrec_segment_reduce_workspace": (c_size, [c_i64]),
     "elimrec_segment_plan_workspace": (c_size, [c_i64]),

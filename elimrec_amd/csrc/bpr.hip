@@ -2,6 +2,8 @@
 // IndexBackward, and the row-sparse input gradient of the head Linears.
 // (models/EliMRec.py:129-142,277-297 forward; main.py:99-100 autograd.)
 #include "common.h"
+#include <chrono>
+#include <cstring>
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
@@ -131,7 +133,8 @@ __global__ __launch_bounds__(256) void bpr_head_kernel(const float *__restrict__
 __global__ __launch_bounds__(256) void bpr_head_sum_kernel(const float *__restrict__ Y, int64_t ldy, int B, int d, int n_blocks,
                                                            BlockWeights bw, float inv_b, float *__restrict__ loss_rows,
                                                            float *__restrict__ grad_rows, const int32_t *__restrict__ slot_rows,
-                                                           int LB, float *__restrict__ loss_out, int32_t *__restrict__ ticket) {
+                                                           int LB, float *__restrict__ loss_out, int32_t *__restrict__ ticket,
+                                                           unsigned long long *pub_slots, int n_pub, uint32_t *__restrict__ pub_counter) {
     __shared__ float s[1024];
     __shared__ int is_last;
     bpr_head_body<true>(Y, ldy, 0, nullptr, nullptr, nullptr, B, d, n_blocks, bw, inv_b, loss_rows, grad_rows, nullptr, slot_rows, LB);
@@ -158,6 +161,15 @@ __global__ __launch_bounds__(256) void bpr_head_sum_kernel(const float *__restri
     if (threadIdx.x == 0) {
         loss_out[0] = s[0];
         __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (pub_slots) {
+            // the loss to the host, 120 us into the step instead of behind its last launch: (sequence number, value) as ONE 8-byte
+            // system-scope store into coherent host memory. The sequence number counts the publishing launches of this stream
+            // (one thread per launch touches the counter; launches of a stream are ordered) -- the host counts the same way.
+            const uint32_t q = pub_counter[0] + 1u;
+            pub_counter[0] = q;
+            __hip_atomic_store(pub_slots + (q % (uint32_t)n_pub), ((unsigned long long)q << 32) | (unsigned long long)__float_as_uint(s[0]),
+                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
@@ -1309,9 +1321,81 @@ extern "C" int elimrec_bpr_head_rows_sum(const float *d_Y, int64_t ldy, const in
     BlockWeights bw;
     for (int k = 0; k < kMaxBlocks; ++k) bw.w[k] = k < n_blocks ? block_weights[k] : 0.f;
     hipLaunchKernelGGL(bpr_head_sum_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_Y, ldy, B, d, n_blocks, bw,
-                       1.0f / (float)B, d_loss_rows, d_grad_rows, d_slot_rows, bpr_group_lanes(d), d_loss, d_ticket);
+                       1.0f / (float)B, d_loss_rows, d_grad_rows, d_slot_rows, bpr_group_lanes(d), d_loss, d_ticket,
+                       (unsigned long long *)nullptr, 0, (uint32_t *)nullptr);
     ELIMREC_LAUNCH_CHECK("bpr_head_rows_sum");
     return 0;
+}
+
+// ... and the loss PUBLISHED to the host from that launch (main.py:102 of the reference reads `loss.cpu().item()` after every
+// step: a read of the device tensor waits for the whole step -- adjoint hops, Adam -- and the host cannot enqueue step t + 1
+// under step t). pub: elimrec_loss_pub_create's block; the host waits on the slot with elimrec_loss_pub_wait, not on the stream.
+struct LossPub { unsigned long long *h_slots; unsigned long long *d_slots; uint32_t *d_counter; int n; uint32_t issued; };
+
+extern "C" int elimrec_bpr_head_rows_sum_pub(const float *d_Y, int64_t ldy, const int32_t *d_slot_rows, int B, int d,
+                                             int n_blocks, const float *block_weights, float *d_loss_rows, float *d_grad_rows,
+                                             float *d_loss, int32_t *d_ticket, void *pub, void *stream) {
+    ELIMREC_REQUIRE(d_Y && d_slot_rows && d_loss_rows && block_weights && d_loss && d_ticket && pub, "bpr_head_rows_sum_pub: null pointer");
+    ELIMREC_REQUIRE(d > 0 && d % 4 == 0, "bpr_head_rows_sum_pub: recdim must be a positive multiple of 4");
+    ELIMREC_REQUIRE(n_blocks >= 1 && n_blocks <= kMaxBlocks, "bpr_head_rows_sum_pub: 1..%d head blocks supported", kMaxBlocks);
+    ELIMREC_REQUIRE(ldy % 4 == 0 && ldy >= (int64_t)n_blocks * d && B > 0, "bpr_head_rows_sum_pub: bad ldy / empty batch");
+    LossPub *lp = (LossPub *)pub;
+    BlockWeights bw;
+    for (int k = 0; k < kMaxBlocks; ++k) bw.w[k] = k < n_blocks ? block_weights[k] : 0.f;
+    hipLaunchKernelGGL(bpr_head_sum_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, d_Y, ldy, B, d, n_blocks, bw,
+                       1.0f / (float)B, d_loss_rows, d_grad_rows, d_slot_rows, bpr_group_lanes(d), d_loss, d_ticket,
+                       lp->d_slots, lp->n, lp->d_counter);
+    ELIMREC_LAUNCH_CHECK("bpr_head_rows_sum_pub");
+    lp->issued += 1;                       // (the sequence number the launch just enqueued will publish)
+    return 0;
+}
+
+extern "C" int elimrec_loss_pub_create(int n_slots, void **out_pub) {
+    ELIMREC_REQUIRE(out_pub && n_slots >= 2, "loss_pub_create: n_slots >= 2");
+    LossPub *lp = new LossPub();
+    lp->n = n_slots; lp->issued = 0;
+    int rc = check_hip(hipHostMalloc((void **)&lp->h_slots, (size_t)n_slots * 8, hipHostMallocMapped | hipHostMallocCoherent), "hipHostMalloc(loss pub)");
+    if (rc) { delete lp; return rc; }
+    memset(lp->h_slots, 0, (size_t)n_slots * 8);
+    rc = check_hip(hipHostGetDevicePointer((void **)&lp->d_slots, lp->h_slots, 0), "hipHostGetDevicePointer(loss pub)");
+    if (!rc) rc = check_hip(hipMalloc((void **)&lp->d_counter, 256), "hipMalloc(loss pub counter)");
+    if (!rc) rc = check_hip(hipMemset(lp->d_counter, 0, 256), "hipMemset(loss pub counter)");
+    if (rc) { (void)hipHostFree(lp->h_slots); delete lp; return rc; }
+    *out_pub = lp;
+    return 0;
+}
+
+extern "C" int elimrec_loss_pub_destroy(void *pub) {
+    if (!pub) return 0;
+    LossPub *lp = (LossPub *)pub;
+    (void)hipFree(lp->d_counter);
+    (void)hipHostFree(lp->h_slots);
+    delete lp;
+    return 0;
+}
+
+// the sequence number of the most recently ENQUEUED publishing launch (what a caller notes right after issuing a step)
+extern "C" uint32_t elimrec_loss_pub_issued(void *pub) { return pub ? ((LossPub *)pub)->issued : 0u; }
+
+// Waits (spinning on the coherent host slot, no stream synchronisation) until launch `seq` has published; *value = its loss.
+// Returns 0; ELIMREC_E_UNSUPPORTED when the slot already holds a LATER launch's value (the ring wrapped: read the device tensor
+// instead); ELIMREC_E_WORKSPACE on time-out.
+extern "C" int elimrec_loss_pub_wait(void *pub, uint32_t seq, double timeout_s, float *value) {
+    ELIMREC_REQUIRE(pub && value && seq > 0, "loss_pub_wait: bad arguments");
+    LossPub *lp = (LossPub *)pub;
+    const volatile unsigned long long *slot = lp->h_slots + (seq % (uint32_t)lp->n);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint64_t spin = 0;; ++spin) {
+        const unsigned long long w = __atomic_load_n(slot, __ATOMIC_ACQUIRE);
+        const uint32_t got = (uint32_t)(w >> 32);
+        if (got == seq) { const uint32_t b = (uint32_t)w; memcpy(value, &b, 4); return 0; }
+        if ((int32_t)(got - seq) > 0) { set_error("loss_pub_wait: slot of launch %u already holds launch %u", seq, got); return ELIMREC_E_UNSUPPORTED; }
+        if ((spin & 1023) == 1023 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+            set_error("loss_pub_wait: launch %u did not publish within %.1f s", seq, timeout_s);
+            return ELIMREC_E_WORKSPACE;
+        }
+        __builtin_ia32_pause();
+    }
 }
 
 extern "C" int elimrec_sum(const float *d_x, int64_t n, float *d_out, void *stream) {

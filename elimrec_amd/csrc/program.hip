@@ -52,7 +52,7 @@ static const FnEntry kFns[] = {
     ELIMREC_FN(elimrec_batch_plan), ELIMREC_FN(elimrec_slab_hop), ELIMREC_FN(elimrec_slab_sweep_hop), ELIMREC_FN(elimrec_slab_sweep_hop_adam), ELIMREC_FN(elimrec_slab_source_bits), ELIMREC_FN(elimrec_slab_hop_bwd_w),
     ELIMREC_FN(elimrec_slab_hop_adam), ELIMREC_FN(elimrec_slab_rows), ELIMREC_FN(elimrec_slab_merge_rows),
     ELIMREC_FN(elimrec_head_fwd_fused), ELIMREC_FN(elimrec_bpr_head_rows),
-    ELIMREC_FN(elimrec_bpr_head_rows_sum), ELIMREC_FN(elimrec_sum), ELIMREC_FN(elimrec_segment_apply_head_bwd),
+    ELIMREC_FN(elimrec_bpr_head_rows_sum), ELIMREC_FN(elimrec_bpr_head_rows_sum_pub), ELIMREC_FN(elimrec_sum), ELIMREC_FN(elimrec_segment_apply_head_bwd),
     ELIMREC_FN(elimrec_segment_apply_head_bwd_packed), ELIMREC_FN(elimrec_segment_apply_head_bwd_sources),
     ELIMREC_FN(elimrec_segment_apply_head_bwd_split), ELIMREC_FN(elimrec_linear_fwd_batched), ELIMREC_FN(elimrec_linear_bwd_w_batched),
     ELIMREC_FN(elimrec_linear_bwd_w_batched_merge), ELIMREC_FN(elimrec_linear_bwd_w_reduce), ELIMREC_FN(elimrec_adam_multi),

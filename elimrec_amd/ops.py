@@ -449,6 +449,49 @@ def bpr_head_rows_sum(Y, slot_rows, d, block_weights, loss_rows, grad_rows, loss
                "bpr_head_rows_sum")
 
 
+def bpr_head_rows_sum_pub(Y, slot_rows, d, block_weights, loss_rows, grad_rows, loss_out, ticket, pub):
+    """bpr_head_rows_sum whose summing workgroup also publishes the loss to the host (pub: LossPublisher.handle)."""
+    y, ldy = _rowmajor(Y, "Y")
+    nb = len(block_weights)
+    w = (ctypes.c_float * nb)(*[float(x) for x in block_weights])
+    B = slot_rows.numel() // 3
+    _lib.check(_lib.load().elimrec_bpr_head_rows_sum_pub(y, ldy, _dev(slot_rows, "slot_rows", torch.int32), B, d, nb, w,
+                                                         _dev(loss_rows, "loss_rows"), _dev(grad_rows, "grad_rows"),
+                                                         _dev(loss_out, "loss_out"), _dev(ticket, "ticket", torch.int32), pub, _stream()),
+               "bpr_head_rows_sum_pub")
+
+
+class LossPublisher(object):
+    """elimrec_loss_pub_*: a ring of coherent host words the loss-summing launch of a step writes (sequence number, value) into,
+    so that the caller's `loss.item()` (main.py:102 of the reference) waits for THAT launch and not for the whole step."""
+
+    def __init__(self, n_slots=64):
+        h = ctypes.c_void_p()
+        _lib.check(_lib.load().elimrec_loss_pub_create(int(n_slots), ctypes.byref(h)), "loss_pub_create")
+        self.handle = h
+        self._val = ctypes.c_float()
+
+    def issued(self):
+        return int(_lib.load().elimrec_loss_pub_issued(self.handle))
+
+    def wait(self, seq, timeout_s=60.0):
+        """The loss launch `seq` published, or None when the ring has wrapped past it."""
+        rc = _lib.load().elimrec_loss_pub_wait(self.handle, int(seq), float(timeout_s), ctypes.byref(self._val))
+        if rc == 0:
+            return float(self._val.value)
+        if rc == 10002:            # ELIMREC_E_UNSUPPORTED: overwritten by a later step
+            return None
+        _lib.check(rc, "loss_pub_wait")
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.load().elimrec_loss_pub_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
 def fixed_order_sum(x, out):
     _lib.check(_lib.load().elimrec_sum(_dev(x, "x"), x.numel(), _dev(out, "out"), _stream()), "sum")
     return out

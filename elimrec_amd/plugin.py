@@ -49,6 +49,12 @@ class LazyGradParameter(nn.Parameter):
     def grad(self):
         ctl = self.__dict__.get("_elimrec_ctl")
         if ctl is not None and ctl.grads_deferred():
+            tr = getattr(ctl, "trainer", None)
+            if tr is not None and tr.world > 1:
+                # materialising is a collective (all-gather of the column slices, all-to-all + all-reduce of the backward half): a
+                # read on ONE rank -- gradient-norm logging on rank 0 -- would hang the job. The same guard as sync_params.
+                raise RuntimeError("reading .grad between backward() and the optimizer step materialises the gradients, which is a "
+                                   "collective over %d ranks: call model.plugin.materialise_grads() on ALL ranks first" % tr.world)
             ctl.materialise_grads()
         return _GRAD.__get__(self)
 
@@ -100,14 +106,30 @@ class EmbeddingParameter(LazyGradParameter):
             return func(*args, **(kwargs or {}))
 
 
+_HOST_READS = frozenset(("item", "cpu", "tolist", "__float__"))      # the loss taken to the host (main.py:102: loss.cpu().item())
+
+
 class PendingLoss(torch.Tensor):
     """The 0-dim loss `bpr_loss` returns: a view of a slot the step will fill. `backward()` without arguments is taken as a
-    request (no autograd engine); every other use makes the value real first."""
+    request (no autograd engine); every other use makes the value real first. A caller that takes every step's loss to the
+    host (`loss.cpu().item()`, main.py:102) is noticed: from the next step on the loss-summing launch publishes the value
+    into coherent host memory and the read waits for that launch alone -- not for the adjoint hops and Adam behind it."""
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
         reads = _reads_values(func) or func is torch.Tensor.backward
+        name = getattr(func, "__name__", "")
+        if name in _HOST_READS and len(args) == 1 and not kwargs and isinstance(args[0], PendingLoss):
+            me = args[0]
+            ctl = me.__dict__.get("_elimrec_ctl")
+            if ctl is not None:
+                ctl.host_read_gen = me.__dict__.get("_elimrec_gen")
+                seq = me.__dict__.get("_elimrec_pub")
+                if seq is not None:
+                    val = ctl.engine.loss_publisher().wait(seq)
+                    if val is not None:
+                        return torch.tensor(val, dtype=torch.float32) if name == "cpu" else val
         for me in _instances(args, PendingLoss, kwargs):
             ctl = me.__dict__.get("_elimrec_ctl")
             if ctl is None:
@@ -153,6 +175,8 @@ class StepController(object):
         self.grads_set = False           # some .grad may be non-None (zero_grad has work to do)
         self._seen = None                # version counters of the embedding parameters when the master copy was last loaded
         self.fast_steps = self.slow_steps = 0
+        self.host_read_gen = None        # generation of the last loss the caller took to the host (PendingLoss)
+        self.published_steps = 0
 
     # ------------------------------------------------------------------ wiring
     def adopt(self, params):
@@ -212,6 +236,7 @@ class StepController(object):
         users, pos, neg = m._index_tensors(users, pos, neg)
         if not (users.numel() == pos.numel() == neg.numel()):
             raise ValueError("bpr_loss: users, pos_items, neg_items must have the same length")
+        publish = self.host_read_gen is not None and self.host_read_gen == self.gen     # the loss before this one went to the host
         self.gen += 1
         if torch.is_grad_enabled():
             out = _DeferredBprFn.apply(self, m.embedding_user_after_GCN.weight)
@@ -222,7 +247,8 @@ class StepController(object):
         handle.__dict__["_elimrec_ctl"] = self
         self.pending = dict(gen=self.gen, users=users, pos=pos, neg=neg, slot=slot,
                             versions=(users._version, pos._version, neg._version),
-                            ctx=None, bwd=False, grads=False, grad_ok=bool(out.requires_grad))
+                            ctx=None, bwd=False, grads=False, grad_ok=bool(out.requires_grad), publish=publish,
+                            hdict=handle.__dict__)
         handle.__dict__["_elimrec_gen"] = self.gen
         return handle
 
@@ -353,7 +379,10 @@ class StepController(object):
             self.slow_steps += 1
         else:
             self._check_batch(p)
-            tr.step(p["users"], p["pos"], p["neg"], loss=p["slot"])
+            tr.step(p["users"], p["pos"], p["neg"], loss=p["slot"], publish=p["publish"])
+            if eng.last_pub_seq is not None:
+                p["hdict"]["_elimrec_pub"] = eng.last_pub_seq
+                self.published_steps += 1
             self.fast_steps += 1
         self.pending = None
         return True

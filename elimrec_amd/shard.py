@@ -341,10 +341,15 @@ class ColumnShardTrainer(object):
         t.copy_(host)
         return self._Done()
 
-    def step(self, users, pos, neg, loss=None):
+    def step(self, users, pos, neg, loss=None, publish=False):
         """One training step on this rank's triplets; returns the local loss (0-dim tensor). loss: the device tensor the
         step's loss goes to (default: the next slot of the engine's loss ring) -- plugin.py hands the slot out when the
-        caller asks for the loss and runs the step when the caller's optimizer steps."""
+        caller asks for the loss and runs the step when the caller's optimizer steps. publish: the launch that sums the loss
+        also stores it into coherent host memory (engine.loss_publisher(), sequence number engine.last_pub_seq): a caller that
+        reads every step's loss on the host (main.py:102 of the reference) waits for that launch, not for the step's end."""
+        eng = self.engine
+        eng.publish_loss = bool(publish) and not self.multi and eng._fused_head_ok()
+        eng.last_pub_seq = None
         if loss is not None:
             self.engine._loss_given = loss
         try:
@@ -353,6 +358,9 @@ class ColumnShardTrainer(object):
                     return self._step(users, pos, neg)
             return self._step(users, pos, neg)
         finally:
+            if eng.publish_loss:
+                eng.last_pub_seq = eng.loss_publisher().issued()
+                eng.publish_loss = False
             if loss is not None:
                 self.engine._loss_given = None
 
@@ -395,7 +403,8 @@ class ColumnShardTrainer(object):
         g = self.opt.param_groups[0]
         # everything a step's launches take by VALUE besides the per-step patches: a program is frozen on them
         key = (B, tuple(eng.model._block_weights()), g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"],
-               eng.prestaged_ok(users, pos, neg) and eng.ahead_safe())   # (... and the planner's place in the second stream's order)
+               eng.prestaged_ok(users, pos, neg) and eng.ahead_safe(),   # (... and the planner's place in the second stream's order)
+               bool(getattr(eng, "publish_loss", False)))                # (... and which launch sums the loss)
         progs = st["programs"].get(key)
         if progs is not None and progs[eng.cur] is not None:
             if st["check_every"] and (st["native_steps"] + st["checks"] + 1) % st["check_every"] == 0:
@@ -1299,6 +1308,13 @@ class ColumnShardEngine(object):
         ops.fixed_order_sum(ws["loss_rows"], loss)
         return loss
 
+    def loss_publisher(self):
+        """The host-visible loss ring of this engine (ops.LossPublisher), created on first use."""
+        pub = self.__dict__.get("_loss_pub")
+        if pub is None:
+            pub = self._loss_pub = ops.LossPublisher(64)
+        return pub
+
     def _next_loss_slot(self):
         """The next slot of the loss ring (a caller holding the tensors of earlier steps -- main.py stacks an epoch's losses
         before it copies them to the host -- does not see them change for LOSS_RING steps)."""
@@ -1349,7 +1365,13 @@ class ColumnShardEngine(object):
         # tensors of earlier steps -- main.py stacks an epoch's losses before it copies them to the host -- does not see them
         # change (LOSS_RING steps back; `loss_ring_len` lets a caller that keeps more clone them).
         loss = self._next_loss_slot()
-        if getattr(self, "_step_in_flight", False) and self._loss_sum_late():
+        if getattr(self, "_step_in_flight", False) and getattr(self, "publish_loss", False):
+            # the caller reads every step's loss on the host: summed HERE (the workgroup that finishes last) and stored into
+            # coherent host memory by that workgroup -- the host's read returns 120 us into the step and step t + 1 is enqueued
+            # under step t's adjoint hops
+            ops.bpr_head_rows_sum_pub(YAct, ws["slot_seg"][:3 * B], d, bw, ws["loss_rows"], ws["grad_rows"], loss, self._loss_ticket,
+                                      self.loss_publisher().handle)
+        elif getattr(self, "_step_in_flight", False) and self._loss_sum_late():
             # a whole step: only the host reads the loss, so its fixed-order sum rides in the LAST launch of the step
             # (an extra workgroup of the Adam hop) instead of ending this one behind a ticket and an acquire
             ops.bpr_head_rows(YAct, ws["slot_seg"][:3 * B], d, bw, ws["loss_rows"], ws["grad_rows"])

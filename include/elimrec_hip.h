@@ -303,6 +303,22 @@ int elimrec_bpr_head_rows_sum(const float *d_Y, int64_t ldy, const int32_t *d_sl
                               int n_blocks, const float *block_weights, float *d_loss_rows, float *d_grad_rows,
                               float *d_loss, int32_t *d_ticket, void *stream);
 
+/* ... and the batch loss PUBLISHED to the host from that launch. /root/reference/main.py:102 reads `loss.cpu().item()` after
+ * every step; a read of the device tensor waits for the whole step (adjoint hops, Adam), so the host could not enqueue step t + 1
+ * under step t. Here the launch that sums the loss (about 120 us into a 280 us step) also stores (sequence number, value) as one
+ * 8-byte system-scope word into coherent host memory, and the caller's `.item()` waits on that word -- not on the stream.
+ * pub: elimrec_loss_pub_create(n_slots) (a ring of n_slots host words + a device-side launch counter). Every
+ * elimrec_bpr_head_rows_sum_pub enqueue publishes under the next sequence number (elimrec_loss_pub_issued right after the enqueue);
+ * elimrec_loss_pub_wait(pub, seq, timeout_s, &value) spins until launch `seq` has published: 0 = value is its loss (the bits of
+ * *d_loss); ELIMREC_E_UNSUPPORTED = the ring has wrapped past it (read the device tensor); ELIMREC_E_WORKSPACE = timed out. */
+int elimrec_loss_pub_create(int n_slots, void **out_pub);
+int elimrec_loss_pub_destroy(void *pub);
+uint32_t elimrec_loss_pub_issued(void *pub);
+int elimrec_loss_pub_wait(void *pub, uint32_t seq, double timeout_s, float *value);
+int elimrec_bpr_head_rows_sum_pub(const float *d_Y, int64_t ldy, const int32_t *d_slot_rows, int B, int d,
+                                  int n_blocks, const float *block_weights, float *d_loss_rows, float *d_grad_rows,
+                                  float *d_loss, int32_t *d_ticket, void *pub, void *stream);
+
 /* out[0] = sum_i x[i] in a fixed order (single workgroup, deterministic). */
 int elimrec_sum(const float *d_x, int64_t n, float *d_out, void *stream);
 

@@ -96,7 +96,13 @@ class Net(object):
         if self.loss_name != "bpr_loss":
             if self.world > 1:
                 raise ValueError("--loss=%s runs through the generic autograd path, which is single-GPU" % self.loss_name)
-        elif getattr(rec, "_lazy", False) and rec.latent_dim % (4 * self.world) == 0:
+        elif getattr(rec, "_lazy", False) and rec.latent_dim % (4 * self.world) != 0:
+            # (the replicated-table trainer below no longer carries the folded forms a lazy model needs: fail here, by name, instead
+            # of at the first step)
+            ok = [w for w in range(1, 9) if rec.latent_dim % (4 * w) == 0]
+            raise ValueError("recdim %d does not split into 4-float column groups over %d ranks: the column-shard engine needs "
+                             "recdim %% (4 x world) == 0 -- launch on %s GPUs (or pad recdim)" % (rec.latent_dim, self.world, ok))
+        elif getattr(rec, "_lazy", False):
             # the column-shard engine with this job's world / rank. It attaches itself to the model (elimrec_amd/plugin.py): the
             # epoch loop below is the reference's own four lines (main.py:98-101) and runs on it
             self.engine = ColumnShardEngine(rec)

@@ -75,6 +75,59 @@ def test_plugin_loop_equals_trainer_step_bitwise(name):
     _same(_state(model, ctl.engine), want)
 
 
+@pytest.mark.parametrize("name", ["ml3", "kwai"])
+def test_plugin_loop_with_line_102_reads_the_published_loss(name):
+    """main.py:98-102 verbatim -- `loss.cpu().item()` after EVERY step. From the second step on the launch that sums the loss
+    publishes it into coherent host memory and the read waits for that launch alone: every step still goes down the one-enqueue
+    path, and every loss, parameter and Adam moment has the bits of ColumnShardTrainer.step (the published word is the loss
+    tensor's value; the step's arithmetic does not change with the launch that sums the loss rows)."""
+    g = load_golden(name)
+    n = 21
+    want_losses, want, _ = _trainer_run(g, n)
+    model, _ = build_model_from_fixture(g, DEV)
+    opt = _opt(model, g)
+    got, held = [], []
+    for k, (u, p, neg) in enumerate(_batches(g, n)):
+        loss = model.bpr_loss(u, p, neg)
+        opt.zero_grad()
+        loss.backward(retain_graph=True)
+        opt.step()
+        got.append(loss.cpu().item() if k % 2 == 0 else loss.item())          # main.py:102, both spellings
+        held.append(loss)
+    ctl = model.plugin
+    assert got == want_losses
+    assert ctl.fast_steps == n and ctl.slow_steps == 0
+    fused = ctl.engine._fused_head_ok()                                       # (the fused head's BPR launch is the one that publishes)
+    assert ctl.published_steps == (n - 1 if fused else 0)                     # every step after the first noticed read
+    assert [float(x) for x in torch.stack([h.detach() for h in held[-8:]]).cpu()] == want_losses[-8:]    # the device tensors too
+    _same(_state(model, ctl.engine), want)
+    # a caller that stops reading: back to the late sum, same bits
+    for u, p, neg in _batches(g, 3):
+        loss = model.bpr_loss(u, p, neg)
+        opt.zero_grad()
+        loss.backward(retain_graph=True)
+        opt.step()
+    assert ctl.published_steps == (n if fused else 0)                         # (the step after the last read still published)
+    if not fused:
+        return
+    # a value asked for after the host ring (64 launches) has wrapped past it comes from the device tensor: the same bits
+    from elimrec_amd import ops
+    model2, _ = build_model_from_fixture(g, DEV)
+    opt2 = _opt(model2, g)
+    held2 = []
+    for k, (u, p, neg) in enumerate(_batches(g, n)):
+        loss = model2.bpr_loss(u, p, neg)
+        if k == 1:
+            model2.plugin.engine._loss_pub = ops.LossPublisher(2)             # a two-word ring
+        opt2.zero_grad()
+        loss.backward(retain_graph=True)
+        opt2.step()
+        assert loss.item() == want_losses[k]
+        held2.append(loss)
+    assert model2.plugin.engine.loss_publisher().wait(held2[3].__dict__["_elimrec_pub"]) is None      # wrapped
+    assert [h.item() for h in held2] == want_losses
+
+
 def test_plugin_loop_with_per_step_loss_item_and_reads_in_between():
     """The reference's line 102 (`loss.cpu().item()` every step) and every other look at an intermediate result -- the loss
     before backward, .grad after it, the cached tables, predict() -- leave the bits alone: the halves run launch by launch."""
