@@ -795,8 +795,8 @@ def reduced_precision_line(args, device, cfg, batches, first_losses, torch, step
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     B = batches[0][0].numel()
-    return {"what": "--feature_dtype=bf16: S_m / c stored in bf16 (c as hi + lo), rows widened at the lookup, fp32 arithmetic; same "
-                    "initial parameters and batches as the fp32 headline",
+    return {"what": "--feature_dtype=bf16: S_m / c stored in bf16 (c as hi + lo) and read by the fused head where they lie, widened in "
+                    "registers (elimrec_head_fwd_fused_src16), fp32 arithmetic; same initial parameters and batches as the fp32 headline",
             "ms_per_step": 1e3 * dt, "triplets_per_s": B / dt, "steps": steps,
             "loss_delta_vs_f32": {"steps_compared": n_cmp, "max_abs": float((a - b).abs().max()), "mean_abs": float((a - b).abs().mean()),
                                   "f32_loss_first_last": [float(b[0]), float(b[-1])], "bf16_loss_first_last": [float(a[0]), float(a[-1])]},

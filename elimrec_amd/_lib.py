@@ -77,6 +77,12 @@ class HeadRows(ctypes.Structure):
                 ("d_narrow_out", ctypes.c_void_p), ("ld_narrow_out", ctypes.c_int64)]
 
 
+class HeadSrc16(ctypes.Structure):
+    """struct elimrec_head_src16."""
+    _fields_ = [("d_table", ctypes.c_void_p), ("row_elems", ctypes.c_int64), ("dtype", ctypes.c_int32),
+                ("d_S_out", ctypes.c_void_p), ("ld_S_out", ctypes.c_int64), ("d_c_out", ctypes.c_void_p)]
+
+
 class ProgramOp(ctypes.Structure):
     """struct elimrec_op."""
     _fields_ = [("kind", ctypes.c_int32), ("fn", ctypes.c_int32), ("args", ctypes.c_uint64 * PROGRAM_MAX_ARGS)]
@@ -218,6 +224,10 @@ SIGNATURES = {
                                             ctypes.POINTER(c_i64), ctypes.POINTER(c_i32), ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr),
                                             c_ptr, c_ptr, c_ptr, c_ptr, ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr), c_ptr, c_size,
                                             c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr]),
+    "elimrec_head_fwd_fused_src16": (c_i32, [ctypes.POINTER(HeadSrc16), c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i32,
+                                             ctypes.POINTER(c_i32), ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr), c_ptr, c_ptr, c_ptr, c_ptr,
+                                             ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr), c_ptr, c_size, c_ptr, c_i64, c_ptr, c_i64,
+                                             c_i32, c_i32, c_ptr]),
     "elimrec_score_set_math": (None, [c_i32]),
     "elimrec_score_get_math": (c_i32, []),
     "elimrec_score_set_bf16x3": (None, [c_i32]),

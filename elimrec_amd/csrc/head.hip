@@ -11,6 +11,7 @@
 // Specialised for recdim = 64 (two 32-column MFMA tiles) and feature widths that fit LDS; other shapes keep the
 // batched-GEMM path.
 #include "common.h"
+#include <hip/hip_fp16.h>
 #include "rows_args.h"
 #include <cstdlib>
 
@@ -58,7 +59,29 @@ struct HeadFwdArgs {
     int stage;                                      // head_fwd16_kernel: 0 = whole head; 1 = the feature blocks only, WITHOUT the
                                                     // shared part (needs nothing of the graph: can run beside the forward hops);
                                                     // 2 = the rest (shared part added to what stage 1 left in OutAct, fusion, heads)
+    // 16-bit constants read where they lie (elimrec_head_fwd_fused_src16): rows [S_1 | .. | S_n | c_hi c_lo] of fp16 (1) / bf16 (2)
+    // elements, widened in registers -- no separate widening pass over the batch's rows in front of the head. s_out / c_out
+    // (nullable): the widened rows in active-row order, for the weight-gradient launches of the backward half.
+    int sdtype; const uint16_t *tab16; int64_t row_elems; int s_off[HMAXM]; int c_off;
+    float *s_out; int64_t ld_sout; float *c_out;
 };
+
+__device__ __forceinline__ float widen16(uint32_t h, int sdtype) {        // one fp16 / bf16 element (low 16 bits of h) -> fp32, exact
+    if (sdtype == 2) return __uint_as_float(h << 16);
+    const unsigned short hs = (unsigned short)h;
+    return __half2float(*reinterpret_cast<const __half *>(&hs));
+}
+// four consecutive elements of feature table m of `node`, as fp32
+__device__ __forceinline__ float4 head_s4(const HeadFwdArgs &a, int m, int64_t node, int c4) {
+    if (a.sdtype == 0) return *reinterpret_cast<const float4 *>(a.S[m] + node * a.ldS[m] + 4 * c4);
+    const uint2 w = *reinterpret_cast<const uint2 *>(a.tab16 + node * a.row_elems + a.s_off[m] + 4 * c4);
+    return make_float4(widen16(w.x & 0xFFFFu, a.sdtype), widen16(w.x >> 16, a.sdtype), widen16(w.y & 0xFFFFu, a.sdtype), widen16(w.y >> 16, a.sdtype));
+}
+__device__ __forceinline__ float head_c(const HeadFwdArgs &a, int64_t node) {      // c = hi + lo in 16-bit storage
+    if (a.sdtype == 0) return a.c[node];
+    const uint32_t w = *reinterpret_cast<const uint32_t *>(a.tab16 + node * a.row_elems + a.c_off);
+    return widen16(w & 0xFFFFu, a.sdtype) + widen16(w >> 16, a.sdtype);
+}
 
 // acc += A[32 x (2*nsteps)] . B for MFMA steps [s0, s0 + nsteps): A from LDS (row stride folded into ap together with this
 // lane's row / k-parity), B = packed weights (bp = start of the column tile + lane). 16 B operands in flight.
@@ -301,7 +324,9 @@ __device__ __forceinline__ void head_fwd16_body(const HeadFwdArgs &a, const Rows
     if (tid < H16) {
         const int node = tid < nrows ? a.act[r0 + tid] : 0;
         s_act[tid] = node;
-        s_c[tid] = tid < nrows ? a.c[node] : 0.f;
+        const float cv = (tid < nrows && a.stage != 2) ? head_c(a, node) : 0.f;       // (stage 2 multiplies nothing by c)
+        s_c[tid] = cv;
+        if (a.c_out && tid < nrows && a.stage != 2) a.c_out[r0 + tid] = cv;
     }
     // out0 -> block 0 of the Out tile, narrow -> AN (compact rows: no index needed)
     if (a.stage != 1)
@@ -344,7 +369,10 @@ __device__ __forceinline__ void head_fwd16_body(const HeadFwdArgs &a, const Rows
         for (int e = tid; e < H16 * D4; e += 256) {
             const int r = e / D4, c4 = e % D4;
             float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < nrows) x = *reinterpret_cast<const float4 *>(a.S[m] + (int64_t)s_act[r] * a.ldS[m] + 4 * c4);
+            if (r < nrows) {
+                x = head_s4(a, m, (int64_t)s_act[r], c4);
+                if (a.s_out) *reinterpret_cast<float4 *>(a.s_out + (int64_t)(r0 + r) * a.ld_sout + a.s_off[m] + 4 * c4) = x;
+            }
             *reinterpret_cast<float4 *>(Am + r * lda + 4 * c4) = x;
         }
     }
@@ -423,15 +451,18 @@ extern "C" size_t elimrec_head_pack_bwd_offset(int n_mod, const int *D) {
     return (size_t)head_pack_layout(n_mod, D).fwd_total;
 }
 
-static int head_fwd_fused_impl(const elimrec_head_rows *rows, const int32_t *d_act, const int32_t *d_seg_info, int64_t R, const float *d_out0,
+static int head_fwd_fused_impl(const elimrec_head_src16 *src, const elimrec_head_rows *rows, const int32_t *d_act, const int32_t *d_seg_info, int64_t R, const float *d_out0,
                                       int64_t ld_out0, const float *d_narrow, int64_t ld_nar, const float *d_c, int n_mod,
                                       const float *const *d_S, const int64_t *ldS, const int *D, const float *const *d_Wm,
                                       const float *const *d_bm, const float *d_Wf_user, const float *d_bf_user,
                                       const float *d_Wf_item, const float *d_bf_item, const float *const *d_Ws,
                                       const float *const *d_bs, float *d_pack, size_t pack_floats, float *d_OutAct,
                                       int64_t ld_out, float *d_YAct, int64_t ld_y, int recdim, int phase, void *stream) {
-    ELIMREC_REQUIRE(d_act && d_seg_info && d_out0 && d_narrow && d_c && d_S && d_Wm && d_Wf_user && d_Wf_item && d_Ws && d_pack &&
+    ELIMREC_REQUIRE(d_act && d_seg_info && d_out0 && d_narrow && (src || (d_c && d_S)) && d_Wm && d_Wf_user && d_Wf_item && d_Ws && d_pack &&
                         d_OutAct && d_YAct, "head_fwd_fused: null pointer");
+    ELIMREC_REQUIRE(!src || (src->d_table && (src->dtype == 1 || src->dtype == 2) && src->row_elems % 8 == 0 &&
+                             (!src->d_S_out || src->ld_S_out % 4 == 0)),
+                    "head_fwd_fused_src16: a table of fp16 (1) / bf16 (2) rows, 16-byte aligned rows");
     if (recdim != HD || n_mod < 1 || n_mod > HMAXM) { set_error("head_fwd_fused: recdim must be %d and 1..%d feature tables", HD, HMAXM); return ELIMREC_E_UNSUPPORTED; }
     const int C = (1 + n_mod) * HD;
     ELIMREC_REQUIRE(ld_out0 % 4 == 0 && ld_nar % 4 == 0 && ld_out >= C && ld_y >= C, "head_fwd_fused: bad leading dimensions");
@@ -459,8 +490,10 @@ static int head_fwd_fused_impl(const elimrec_head_rows *rows, const int32_t *d_a
     const int rows_t = form16 ? H16 : HROWS;
     if (form16) lds_f = H16 * (HD + 4);              // narrow tile first
     for (int m = 0; m < n_mod; ++m) {
-        ELIMREC_REQUIRE(d_S[m] && d_Wm[m] && d_Ws[m] && D[m] > 0 && D[m] % 4 == 0 && ldS[m] % 4 == 0, "head_fwd_fused: bad feature table %d", m);
-        a.S[m] = d_S[m]; a.ldS[m] = ldS[m]; a.D[m] = D[m]; a.bias_m[m] = d_bm ? d_bm[m] : nullptr;
+        ELIMREC_REQUIRE((src || (d_S[m] && ldS[m] % 4 == 0)) && d_Wm[m] && d_Ws[m] && D[m] > 0 && D[m] % 4 == 0, "head_fwd_fused: bad feature table %d", m);
+        if (!src) { a.S[m] = d_S[m]; a.ldS[m] = ldS[m]; }
+        a.s_off[m] = m == 0 ? 0 : a.s_off[m - 1] + D[m - 1];
+        a.D[m] = D[m]; a.bias_m[m] = d_bm ? d_bm[m] : nullptr;
         a.a_off[m] = lds_f;
         lds_f += rows_t * (D[m] + (form16 ? 4 : 1));
         a.off_Wm[m] = add_job(d_Wm[m], D[m]);
@@ -492,6 +525,13 @@ static int head_fwd_fused_impl(const elimrec_head_rows *rows, const int32_t *d_a
     const size_t lds_bytes = (size_t)lds_f * sizeof(float);
     if (lds_bytes > 158 * 1024) { set_error("head_fwd_fused: feature widths need %zu B of LDS", lds_bytes); return ELIMREC_E_UNSUPPORTED; }
     a.act = d_act; a.seg_info = d_seg_info; a.out0 = d_out0; a.ld_out0 = ld_out0; a.narrow = d_narrow; a.ld_nar = ld_nar; a.c = d_c;
+    if (src) {
+        if (!form16) { set_error("head_fwd_fused_src16: needs the 16-row form"); return ELIMREC_E_UNSUPPORTED; }
+        a.sdtype = src->dtype; a.tab16 = (const uint16_t *)src->d_table; a.row_elems = src->row_elems;
+        a.c_off = a.s_off[n_mod - 1] + D[n_mod - 1];
+        ELIMREC_REQUIRE(a.c_off + 2 <= src->row_elems && a.c_off % 2 == 0, "head_fwd_fused_src16: rows shorter than sum(D) + 2 elements");
+        a.s_out = src->d_S_out; a.ld_sout = src->ld_S_out; a.c_out = src->d_c_out;
+    }
     a.n_mod = n_mod; a.pk = d_pack; a.bias_f[0] = d_bf_user; a.bias_f[1] = d_bf_item;
     a.OutAct = d_OutAct; a.ld_out = ld_out; a.YAct = d_YAct; a.ld_y = ld_y;
     hipStream_t s = (hipStream_t)stream;
@@ -552,8 +592,22 @@ extern "C" int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg
                                       const float *d_Wf_item, const float *d_bf_item, const float *const *d_Ws,
                                       const float *const *d_bs, float *d_pack, size_t pack_floats, float *d_OutAct,
                                       int64_t ld_out, float *d_YAct, int64_t ld_y, int recdim, int phase, void *stream) {
-    return head_fwd_fused_impl(nullptr, d_act, d_seg_info, R, d_out0, ld_out0, d_narrow, ld_nar, d_c, n_mod, d_S, ldS, D, d_Wm, d_bm,
+    return head_fwd_fused_impl(nullptr, nullptr, d_act, d_seg_info, R, d_out0, ld_out0, d_narrow, ld_nar, d_c, n_mod, d_S, ldS, D, d_Wm, d_bm,
                                d_Wf_user, d_bf_user, d_Wf_item, d_bf_item, d_Ws, d_bs, d_pack, pack_floats, d_OutAct, ld_out, d_YAct,
+                               ld_y, recdim, phase, stream);
+}
+
+// ... with the feature constants read from their 16-bit storage (lookup.hip's packed rows, one rank holding every row): see
+// HeadFwdArgs::sdtype. Same phases; the same bits as elimrec_lookup_unpack(direct) followed by elimrec_head_fwd_fused on its rows.
+extern "C" int elimrec_head_fwd_fused_src16(const elimrec_head_src16 *src, const int32_t *d_act, const int32_t *d_seg_info, int64_t R,
+                                            const float *d_out0, int64_t ld_out0, const float *d_narrow, int64_t ld_nar, int n_mod,
+                                            const int *D, const float *const *d_Wm, const float *const *d_bm, const float *d_Wf_user,
+                                            const float *d_bf_user, const float *d_Wf_item, const float *d_bf_item,
+                                            const float *const *d_Ws, const float *const *d_bs, float *d_pack, size_t pack_floats,
+                                            float *d_OutAct, int64_t ld_out, float *d_YAct, int64_t ld_y, int recdim, int phase, void *stream) {
+    ELIMREC_REQUIRE(src, "head_fwd_fused_src16: null source");
+    return head_fwd_fused_impl(src, nullptr, d_act, d_seg_info, R, d_out0, ld_out0, d_narrow, ld_nar, nullptr, n_mod, nullptr, nullptr, D, d_Wm,
+                               d_bm, d_Wf_user, d_bf_user, d_Wf_item, d_bf_item, d_Ws, d_bs, d_pack, pack_floats, d_OutAct, ld_out, d_YAct,
                                ld_y, recdim, phase, stream);
 }
 
@@ -565,7 +619,7 @@ extern "C" int elimrec_head_fwd_fused_rows(const elimrec_head_rows *rows, const 
                                            float *d_OutAct, int64_t ld_out, float *d_YAct, int64_t ld_y, int recdim, void *stream) {
     ELIMREC_REQUIRE(rows && d_OutAct, "head_fwd_fused_rows: null pointer");
     // (out0 / narrow of the plain entry are the buffers this launch fills itself: block 0 of OutAct and rows->d_narrow_out)
-    return head_fwd_fused_impl(rows, d_act, d_seg_info, R, d_OutAct, ld_out, rows->d_narrow_out, rows->ld_narrow_out, d_c, n_mod, d_S, ldS, D,
+    return head_fwd_fused_impl(nullptr, rows, d_act, d_seg_info, R, d_OutAct, ld_out, rows->d_narrow_out, rows->ld_narrow_out, d_c, n_mod, d_S, ldS, D,
                                d_Wm, d_bm, d_Wf_user, d_bf_user, d_Wf_item, d_bf_item, d_Ws, d_bs, d_pack, pack_floats, d_OutAct, ld_out,
                                d_YAct, ld_y, recdim, 4, stream);
 }

@@ -790,6 +790,30 @@ def head_fwd_fused(act, seg_info, out0, narrow, c, S, Wm, bm, Wf_user, bf_user, 
     return True
 
 
+def head_fwd_fused_src16(fshard, S_out, c_out, act, seg_info, out0, narrow, Wm, bm, Wf_user, bf_user, Wf_item, bf_item, Ws, bs, pack,
+                         OutAct, YAct, d, phase=0):
+    """elimrec_head_fwd_fused_src16: head_fwd_fused with the feature constants read from `fshard`'s 16-bit rows (lookup.FeatureShard
+    holding EVERY row: one rank); S_out [R x sum_d] / c_out [R] (or None) receive the widened rows of the active nodes."""
+    n = len(fshard.dims)
+    R = act.numel()
+    src = _lib.HeadSrc16()
+    src.d_table, src.row_elems, src.dtype = fshard.table.data_ptr(), fshard.row_elems, fshard.code
+    if S_out is not None:
+        assert S_out.stride(1) == 1 and S_out.shape[0] >= R and S_out.shape[1] == fshard.sum_d and c_out.numel() >= R
+        src.d_S_out, src.ld_S_out, src.d_c_out = _dev(S_out, "S_out"), S_out.stride(0), _dev(c_out, "c_out")
+    ptr = lambda ts: (ctypes.c_void_p * max(n, 1))(*[_dev(t, "table") for t in ts])
+    D = (ctypes.c_int * max(n, 1))(*fshard.dims)
+    rc = _lib.load().elimrec_head_fwd_fused_src16(
+        ctypes.byref(src), _dev(act, "act", torch.int32), _dev(seg_info, "seg_info", torch.int32), R, _dev(out0, "out0"), out0.stride(0),
+        _dev(narrow, "narrow"), narrow.stride(0), n, D, ptr(Wm), ptr(bm), _dev(Wf_user, "Wf_user"), _dev(bf_user, "bf_user"),
+        _dev(Wf_item, "Wf_item"), _dev(bf_item, "bf_item"), ptr(Ws), ptr(bs), _dev(pack, "pack"), pack.numel(), _dev(OutAct, "OutAct"),
+        OutAct.stride(0), _dev(YAct, "YAct"), YAct.stride(0), int(d), int(phase), _stream())
+    if rc == 10002:           # ELIMREC_E_UNSUPPORTED
+        return False
+    _lib.check(rc, "head_fwd_fused_src16")
+    return True
+
+
 def peer_cols_to_rows(recv, out0, out1):
     """recv [W x R x 2*dl] (per peer: layer mean | shared part of my rows in its columns) -> out0 / out1 [R x W*dl] row views."""
     W, R, two_dl = recv.shape

@@ -799,6 +799,13 @@ class ColumnShardEngine(object):
                     ws["fold"] = None                # the full tables are gone: every consumer goes through the shards
             self.lookup_row_bytes = self.fshard.row_bytes
             self._lookup_bufs = {}
+        # ONE rank holding every row of 16-bit constants: the fused head reads them where they lie and widens in registers
+        # (elimrec_head_fwd_fused_src16) -- no widening pass over the batch's rows in front of the head, and the step keeps the
+        # shape of the fp32 one (feature blocks beside the forward hops, rows evaluated by the head's launch); the head's feature
+        # launch leaves the widened rows behind for the backward half's weight gradients
+        self._direct16 = bool(self.lookup and self.fshard is not None and self.fshard.code != 0 and not self.multi
+                              and self.fshard.owners.world == 1 and not self.wide and self._head16
+                              and os.environ.get("ELIMREC_DIRECT16", "1") != "0")
         # data set "tiktok": word_embedding keeps receiving the gradient the reference's retained graph gives it (default), or stays
         # frozen (--word_embedding=frozen)
         self.word_train = False
@@ -1080,7 +1087,7 @@ class ColumnShardEngine(object):
                 m._region("cs_plan", (m._ws_gen, users.data_ptr(), pos.data_ptr(), neg.data_ptr(), R), plan)
             if self._fused_head_ok():
                 m._region("cs_pack", (m._ws_gen, R), pack)
-                self._head_split = self._head16 and not self.lookup and self._split_head
+                self._head_split = self._head16 and (not self.lookup or self._direct16) and self._split_head
                 if self._head_split:
                     m._region("cs_head_features", (m._ws_gen, R), features)
                 self._rows_in_head = (self._head_split and self._rows_in_head_on and not self.multi and not self.wide
@@ -1240,7 +1247,8 @@ class ColumnShardEngine(object):
             else:
                 slab.rows(self.plan, self.ns, self.w, L, U, [t.data for t in tabs] + [None], self.long_tab, acts, counts, R, W,
                           out0, narrow, by_node)
-            if self.lookup and not (self.multi and self.lookup_exchange):     # this rank holds every row: no exchange, widen in place
+            if self.lookup and not (self.multi and self.lookup_exchange) and not (self._direct16 and self._fused_head_ok()):
+                # this rank holds every row: no exchange, widen in place (16-bit rows under the fused head: read by the head itself)
                 self.fshard.unpack(ws["active_rows"][:R], None, self.s_rows, self.c_rows, direct=True)
         if late_wait:
             m._region("cs_fwd_long%d" % self.cur, (m._ws_gen,), long_rows)
@@ -1396,7 +1404,11 @@ class ColumnShardEngine(object):
         tabs = self._tabs
         rows = dict(plan=self.plan, ns=self.ns, w=self.w, L=m.n_layers, U=m.num_users, layers=[t.data for t in tabs] + [None],
                     long_tab=self.long_tab, narrow=self.nar_act)
-        ok = ops.head_fwd_fused_rows(rows, ws["active_rows"][:R], ws["seg_info"], fold["c"], [fold[k] for k in m._mods],
+        if self._direct16:       # (phase 4 reads neither S nor c: the compact buffers stand in for the table arguments)
+            c_tab, s_tabs = self.c_rows, [m._fold_rows["S"][k] for k in m._mods]
+        else:
+            c_tab, s_tabs = fold["c"], [fold[k] for k in m._mods]
+        ok = ops.head_fwd_fused_rows(rows, ws["active_rows"][:R], ws["seg_info"], c_tab, s_tabs,
                                      [W[k + "_dense.weight"] for k in m._mods], [W[k + "_dense.bias"] for k in m._mods], wu,
                                      W["embedding_user_after_GCN.bias"], wi, W["embedding_item_after_GCN.bias"],
                                      [W["s_dense_%s.weight" % k] for k in m._mods], [W["s_dense_%s.bias" % k] for k in m._mods],
@@ -1411,6 +1423,21 @@ class ColumnShardEngine(object):
         wu, wi = m._fusion_weights(W)
         out0 = self._out0_src if self._out0_src is not None else OutAct[:, :d]
         nar = self._nar_src if self._nar_src is not None else self.nar_act
+        if self._direct16:
+            # 16-bit constants where they lie; the launches that read them (every phase but 4) leave the widened rows of the
+            # active nodes in s_rows / c_rows (the backward half's weight gradients read those)
+            if phase == 1:
+                rows_src = (None, None)
+            else:
+                rows_src = (self.s_rows, self.c_rows) if phase != 4 else (None, None)
+            ok = ops.head_fwd_fused_src16(self.fshard, rows_src[0], rows_src[1], ws["active_rows"][:R], ws["seg_info"], out0, nar,
+                                          [W[k + "_dense.weight"] for k in m._mods], [W[k + "_dense.bias"] for k in m._mods], wu,
+                                          W["embedding_user_after_GCN.bias"], wi, W["embedding_item_after_GCN.bias"],
+                                          [W["s_dense_%s.weight" % k] for k in m._mods], [W["s_dense_%s.bias" % k] for k in m._mods],
+                                          self._pack, OutAct, YAct, d, phase=phase)
+            if not ok:
+                raise RuntimeError("fused head forward (16-bit constants) refused a shape _fused_head_ok accepted")
+            return
         if self.lookup:      # compact rows of the constants (looked up / widened for this batch): row r, not row act[r]
             rows, c_tab, s_tabs = self.iota[:R], self.c_rows, [m._fold_rows["S"][k] for k in m._mods]
         else:

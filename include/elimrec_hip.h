@@ -761,6 +761,28 @@ int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg_info, int6
                            const float *const *d_bs, float *d_pack, size_t pack_floats, float *d_OutAct,
                            int64_t ld_out, float *d_YAct, int64_t ld_y, int recdim, int phase, void *stream);
 
+/* elimrec_head_fwd_fused with the feature constants read from 16-bit storage where they lie (BASELINE.json configs[1] "bf16";
+ * models/EliMRec.py:233-236's v/a/t_dense inputs in their folded form): src->d_table holds one packed row per node,
+ * [S_1 | .. | S_n | c_hi c_lo] of fp16 (dtype 1) or bf16 (dtype 2) elements, row_elems elements per row (a multiple of 8) -- the
+ * layout elimrec_lookup_pack / _unpack use, this rank holding every row. Rows are widened in registers (exactly; c = hi + lo);
+ * arithmetic and results are those of elimrec_lookup_unpack(direct) + elimrec_head_fwd_fused on its fp32 rows, without that pass.
+ * d_S_out [R x ld_S_out] / d_c_out [R] (nullable): the widened rows of the launch's active rows, written by the phases that
+ * read them (0, 2, 3) for the backward half's weight-gradient launches. */
+typedef struct elimrec_head_src16 {
+    const void *d_table;
+    int64_t row_elems;
+    int32_t dtype;
+    float *d_S_out;
+    int64_t ld_S_out;
+    float *d_c_out;
+} elimrec_head_src16;
+int elimrec_head_fwd_fused_src16(const elimrec_head_src16 *src, const int32_t *d_act, const int32_t *d_seg_info, int64_t R,
+                                 const float *d_out0, int64_t ld_out0, const float *d_narrow, int64_t ld_nar, int n_mod,
+                                 const int *D, const float *const *d_Wm, const float *const *d_bm, const float *d_Wf_user,
+                                 const float *d_bf_user, const float *d_Wf_item, const float *d_bf_item,
+                                 const float *const *d_Ws, const float *const *d_bs, float *d_pack, size_t pack_floats,
+                                 float *d_OutAct, int64_t ld_out, float *d_YAct, int64_t ld_y, int recdim, int phase, void *stream);
+
 /* Phase 4 of elimrec_head_fwd_fused with the layer means of the active rows EVALUATED by the same launch instead of read back
  * from elimrec_slab_rows (one rank owning every table column, recdim 64 = ns * w): the arguments of that call in a host
  * struct -- plan, slab geometry, layer tables X^0 .. X^L (layers[L] NULL: hop L inline through the plain CSR, split rows

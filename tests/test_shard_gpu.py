@@ -1295,6 +1295,36 @@ def test_16bit_feature_storage_equals_fp32_engine_on_rounded_constants(dtype, na
     assert np.abs(np.array(res["stored"][0]) - np.array(res["plain"][0])).max() < 2e-3
 
 
+@pytest.mark.parametrize("dtype", ["f16", "bf16"])
+def test_16bit_constants_read_by_the_head_equal_the_widening_pass_bitwise(dtype, monkeypatch):
+    """One rank, 16-bit constants: by default the fused head reads the packed 16-bit rows where they lie and widens in registers
+    (elimrec_head_fwd_fused_src16; the step keeps the fp32 step's shape: feature blocks beside the hops, rows evaluated in the
+    head's launch); ELIMREC_DIRECT16=0 keeps the earlier form -- a widening pass over the batch's rows (elimrec_lookup_unpack)
+    in front of a head that reads its fp32 output. The same arithmetic on the same values: 14 steps (the one-call program takes
+    over midway), every loss, the embedding tables, every other parameter and both Adam moments bit for bit."""
+    from elimrec_amd import ColumnShardEngine, ColumnShardTrainer, FusedAdam
+    g = load_golden("kwai")
+    bs = [tuple(_t(g["step%d/%s" % (1 + k % 2, key)]) for key in ("users", "pos", "neg")) for k in range(14)]
+    res = {}
+    for direct in ("1", "0"):
+        monkeypatch.setenv("ELIMREC_DIRECT16", direct)
+        model, _ = build_model_from_fixture(g, DEV)
+        opt = FusedAdam(model.parameters(), lr=float(g["lr"]), weight_decay=float(g["weight_decay"]))
+        eng = ColumnShardEngine(model, feature_dtype=dtype)
+        tr = ColumnShardTrainer(eng, opt)
+        losses = [tr.step(*b) for b in bs]
+        assert eng._direct16 == (direct == "1") and eng._fused_head_ok()
+        st = eng.optimizer_state()
+        res[direct] = ([float(x) for x in torch.stack(losses).cpu()], eng.master[eng.cur].dense().clone(),
+                       {k: v.detach().clone() for k, v in model.state_dict().items() if not k.startswith("embedding_")},
+                       st["exp_avg"].clone(), st["exp_avg_sq"].clone(), tr._native_state()["native_steps"])
+    assert res["1"][0] == res["0"][0]
+    assert torch.equal(res["1"][1], res["0"][1]) and torch.equal(res["1"][3], res["0"][3]) and torch.equal(res["1"][4], res["0"][4])
+    for k, v in res["0"][2].items():
+        assert torch.equal(res["1"][2][k], v), k
+    assert res["1"][5] > 0                                           # the direct form runs as a one-call program too
+
+
 @pytest.mark.parametrize("name", ["ml3", "kwai", "gcmc"])
 def test_hop_kernel_fold_of_the_constants_equals_the_model_fold(name, monkeypatch):
     """The distributed fold's arithmetic (ColumnShardEngine._horner_mean: t <- X0 + A t with the slab hop kernels, widths
