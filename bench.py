@@ -433,6 +433,12 @@ def main():
                                     "chip_random_row_gather_GBps": {"table in Infinity Cache (38 MB, 1152-B rows)": 8600,
                                                                     "151 MB table": 7650, "rows shared through L2": 17800},
                                     "frac_of_random_gather_rate": int(eng.plan.nnz) * eng.dl * 4 / (hop_us * 1e-6) / 1e9 / 8600.0},
+                         # ... the two ceilings side by side: `frac` prices the launch's ALGORITHMIC bytes against the HBM peak; the
+                         # launch's real work is gathering nnz row pieces of a table that lives in the Infinity Cache, whose ceiling is
+                         # the chip's random-row gather rate -- the headroom of this kernel is 1 - gather_frac, not 1 - frac
+                         "gather_ceiling_TBps": 8.6,
+                         "gather_achieved_TBps": int(eng.plan.nnz) * eng.dl * 4 / (hop_us * 1e-6) / 1e12,
+                         "gather_frac": int(eng.plan.nnz) * eng.dl * 4 / (hop_us * 1e-6) / 1e9 / 8600.0,
                          "algorithmic_bytes_per_launch": sb["hop_minimal"],
                          "algorithmic_bytes_formula": "read X + write X' + index stream once: 2*N*dl*4 + plan.index_bytes() (8 B per index entry + the tile / item records)",
                          "bytes_with_index_per_group": sb["hop"],
@@ -493,6 +499,25 @@ def main():
         if not args.no_cpu_baseline and world == 1:     # the host baseline is timed on rank 0 at N=1 only
             cpu_batches = [tuple(x.cpu() for x in b) for b in batches[:5]]
             extra("cpu_baseline", lambda: cpu_baseline(ds, {k: v.cpu().numpy() for k, v in init_state.items()}, cfg, cpu_batches))
+        # the secondary lines' headline figures once more INSIDE `config` (records that keep only the contract's keys keep these)
+        def pick(key, *path):
+            v = out.get(key)
+            for q in path:
+                v = v.get(q) if isinstance(v, dict) else None
+            return v
+        out["config"]["also_measured"] = {
+            "reference_equivalent_work_ms_per_step": pick("reference_equivalent_work", "ms_per_step"),
+            "reference_equivalent_work_triplets_per_s": pick("reference_equivalent_work", "value"),
+            "reference_equivalent_work_frac_of_hbm_peak": pick("reference_equivalent_work", "frac_of_hbm_peak"),
+            "plugin_api_loop_ms_per_step": pick("plugin_api_loop", "ms_per_step"),
+            "plugin_api_loop_with_line_102_item_ms_per_step": pick("plugin_api_loop", "with_line_102_loss_item_every_step", "ms_per_step"),
+            "reduced_precision_bf16_ms_per_step": pick("reduced_precision", "ms_per_step"),
+            "eval_seconds_id_order": pick("eval", "tie_order", "after_the_timed_steps", "id_seconds"),
+            "eval_seconds_reference_order": pick("eval", "tie_order", "after_the_timed_steps", "reference_seconds"),
+            "eval_seconds_reference_order_after_2_steps": pick("eval", "tie_order", "after_2_training_steps", "reference_seconds"),
+            "eval_seconds_id_order_after_2_steps": pick("eval", "tie_order", "after_2_training_steps", "id_seconds"),
+            "batch_sweep_ms_per_step": {str(x["batch"]): x["ms_per_step"] for x in (pick("batch_sweep", "sizes") or []) if isinstance(x, dict)},
+        }
         try:        # C-side stdio first (RCCL prints its version banner there), so that the JSON line is the LAST line on stdout
             import ctypes
             ctypes.CDLL(None).fflush(None)
