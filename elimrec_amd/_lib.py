@@ -228,6 +228,8 @@ SIGNATURES = {
                                              ctypes.POINTER(c_i32), ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr), c_ptr, c_ptr, c_ptr, c_ptr,
                                              ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr), c_ptr, c_size, c_ptr, c_i64, c_ptr, c_i64,
                                              c_i32, c_i32, c_ptr]),
+    "elimrec_score_range_violations": (c_i32, [ctypes.POINTER(c_i64), c_i32, c_ptr]),
+    "elimrec_score_range_check": (c_i32, [c_ptr, c_ptr, c_i32, c_i32, c_i32, c_i32, c_ptr, c_ptr]),
     "elimrec_score_set_math": (None, [c_i32]),
     "elimrec_score_get_math": (c_i32, []),
     "elimrec_score_set_bf16x3": (None, [c_i32]),

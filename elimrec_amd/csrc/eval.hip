@@ -203,6 +203,14 @@ struct ScoreArgs {
                                      // indexed relative to item0 (a chunk of the catalogue when only top-K is wanted)
     const uint4 *planes;             // score_t16b_kernel: the chunk's item rows as three bf16 planes, [item - item0][3][COLS]
     const float *inrm;               // score_t16b_kernel pass 2: 1 / max(|row's head block|, eps) of the chunk's items, [item - item0][S]
+    // range invariant: every score of a valid (user, item) pair lies in [lo, hi] -- the image of the last sigmoid over the bounded
+    // argument of this (predict type, fusion mode): sigma([0, 1]) for normal / rubi TE, sigma([-1, 1]) for rubi TIE, [0, 1] otherwise;
+    // a TIE row mean lies in (0, 1). Checked where it costs nothing: on every RETURNED score (range_check_kernel over the K-lists:
+    // a wrongly high score -- round 3's fault, 1.0 on sixteen lanes of one launch in 49 000 -- necessarily enters its user's list)
+    // and on every row mean; per score in the scorers' epilogues it cost 6 % of a validation pass (one compare per tile maximum:
+    // 1.5 %). Violations add 1 to *range_flag (elimrec_score_range_violations).
+    float lo, hi;
+    int *range_flag;
 };
 
 __device__ __forceinline__ float fuse(int mode, float x, const float *z, int S, uint32_t mask) {
@@ -1045,6 +1053,22 @@ __global__ void mean_from_sum_kernel(const float *__restrict__ row_sum, int B, i
     if (b < B) row_mean[b] = row_sum[b] / (float)I_total;
 }
 
+// The range invariant on what a call RETURNS: every listed score (ids >= 0, not -inf: a masked filler of the reference's order)
+// inside [lo, hi], every TIE row mean inside (0, 1). One count per offending user row / mean into *flag.
+__global__ __launch_bounds__(256) void range_check_kernel(const float *__restrict__ vals, const int32_t *__restrict__ idx, int B, int K,
+                                                          float lo, float hi, const float *__restrict__ mean, int *__restrict__ flag) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    bool bad = false;
+    if (vals)
+        for (int k = 0; k < K; ++k) {
+            const float v = vals[(int64_t)b * K + k];
+            if (idx[(int64_t)b * K + k] >= 0 && v != -INFINITY) bad = bad || !(v >= lo && v <= hi);
+        }
+    if (mean) bad = bad || !(mean[b] > 0.f && mean[b] < 1.f);
+    if (bad) atomicAdd(flag, 1);
+}
+
 // ... and this shard's item ids become catalogue ids
 __global__ void add_id_offset_kernel(int32_t *__restrict__ idx, int64_t n, int32_t off) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1615,6 +1639,38 @@ extern "C" int elimrec_score_get_bf16x3(void) { return score_bf16x3(); }
 extern "C" void elimrec_score_set_math(int mode) { g_score_math = mode ? 1 : 0; }
 extern "C" int elimrec_score_get_math(void) { return score_math(); }
 
+// ONE device word per process counting the waves that saw a score outside their launch's range invariant (ScoreArgs::lo / hi)
+static int *g_range_flag = nullptr;
+static int *score_range_flag() {
+    if (!g_range_flag) {
+        if (hipMalloc((void **)&g_range_flag, 256) != hipSuccess) { g_range_flag = nullptr; return nullptr; }
+        (void)hipMemset(g_range_flag, 0, 256);
+    }
+    return g_range_flag;
+}
+// *h_count = waves that saw an out-of-range score since the last reset, read BEHIND everything enqueued on `stream` (it
+// synchronises with it); reset != 0: the word is cleared behind the read.
+extern "C" int elimrec_score_range_violations(int64_t *h_count, int reset, void *stream) {
+    ELIMREC_REQUIRE(h_count, "score_range_violations: null pointer");
+    *h_count = 0;
+    if (!g_range_flag) return 0;                     // no scorer launch yet
+    int v = 0;
+    hipStream_t s = (hipStream_t)stream;
+    int rc = check_hip(hipMemcpyAsync(&v, g_range_flag, sizeof(int), hipMemcpyDeviceToHost, s), "score_range_violations: copy");
+    if (rc) return rc;
+    if (reset) { rc = check_hip(hipMemsetAsync(g_range_flag, 0, sizeof(int), s), "score_range_violations: reset"); if (rc) return rc; }
+    rc = check_hip(hipStreamSynchronize(s), "score_range_violations: synchronize");
+    *h_count = v;
+    return rc;
+}
+
+static void score_range_bounds(int predict_type, int fusion_mode, float *lo, float *hi) {      // sigma(1) = 0.7310586, sigma(-1) = 0.2689414
+    const float slack = 1e-6f;
+    *lo = 0.f; *hi = 1.f;
+    if (predict_type == 0 || (fusion_mode == 0 && predict_type == 1)) { *lo = 0.5f - slack; *hi = 0.7310586f + slack; }
+    else if (fusion_mode == 0 && predict_type == 2) { *lo = 0.2689414f - slack; *hi = 0.7310586f + slack; }
+}
+
 static inline int n_item_tiles(int64_t I) { return (int)((I + TI - 1) / TI); }   // 16-item tiles (the finest of the forms)
 
 constexpr int64_t SCORE_PILOT = 2048;     // ... the first chunk of a chunked pass: its top-K gives every later launch a store threshold
@@ -1761,6 +1817,8 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
     a.fusion_mode = fusion_mode; a.predict_type = predict_type; a.row_mean = mean; a.partial = partial;
     a.scores = d_scores ? d_scores : wscores; a.lds = d_scores ? lds : (chunked ? SCORE_CHUNK : I);
     a.item0 = 0; a.item_end = I; a.planes = nullptr; a.inrm = nullptr; a.thr = nullptr;
+    score_range_bounds(predict_type, fusion_mode, &a.lo, &a.hi);      // the range invariant of the (predict type, fusion mode)
+    a.range_flag = score_range_flag();
     float *wsqn = (float *)(ws + L.sqn);
     if (!d_sqnorm && predict_type != 0) {            // not supplied: compute the whole table for this call
         const int64_t N = U + I;
@@ -1995,6 +2053,12 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
                 }
             }
             if (chunked) {
+                if (a.range_flag) {
+                    hipLaunchKernelGGL(range_check_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, (const float *)run_val,
+                                       (const int32_t *)d_topk_idx, B, K, a.lo, a.hi, predict_type == 2 ? (const float *)mean : (const float *)nullptr,
+                                       a.range_flag);
+                    ELIMREC_LAUNCH_CHECK("range_check");
+                }
                 if (id_offset) {
                     hipLaunchKernelGGL(add_id_offset_kernel, dim3((unsigned)(((int64_t)B * K + 255) / 256)), dim3(256), 0, s, d_topk_idx,
                                        (int64_t)B * K, (int32_t)id_offset);
@@ -2114,6 +2178,29 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
             ELIMREC_LAUNCH_CHECK("add_id_offset");
         }
     }
+    if (a.range_flag && t16_path && ((d_topk_idx && d_topk_val) || predict_type == 2)) {
+        const bool lists = d_topk_idx && d_topk_val;
+        hipLaunchKernelGGL(range_check_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, lists ? (const float *)d_topk_val : (const float *)nullptr,
+                           (const int32_t *)d_topk_idx, B, K, a.lo, a.hi, predict_type == 2 ? (const float *)mean : (const float *)nullptr, a.range_flag);
+        ELIMREC_LAUNCH_CHECK("range_check");
+    }
+    return 0;
+}
+
+// The check every scoring call ends with, over lists the caller holds (d_topk_val / d_topk_idx [B x K]; d_row_mean [B] nullable):
+// offending user rows are added to the counter elimrec_score_range_violations reads.
+extern "C" int elimrec_score_range_check(const float *d_topk_val, const int32_t *d_topk_idx, int B, int K, int predict_type, int fusion_mode,
+                                         const float *d_row_mean, void *stream) {
+    ELIMREC_REQUIRE((d_topk_val && d_topk_idx && K > 0) || d_row_mean, "score_range_check: nothing to check");
+    ELIMREC_REQUIRE(fusion_mode >= 0 && fusion_mode <= 2 && predict_type >= 0 && predict_type <= 2, "score_range_check: bad fusion_mode/predict_type");
+    if (B <= 0) return 0;
+    int *flag = score_range_flag();
+    ELIMREC_REQUIRE(flag, "score_range_check: no device counter");
+    float lo, hi;
+    score_range_bounds(predict_type, fusion_mode, &lo, &hi);
+    hipLaunchKernelGGL(range_check_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_topk_val, d_topk_idx, B, K, lo, hi,
+                       d_row_mean, flag);
+    ELIMREC_LAUNCH_CHECK("range_check");
     return 0;
 }
 

@@ -77,6 +77,7 @@ class UniEvaluator(object):
         self.scorer_check_every = max(1, int(_os.environ.get("ELIMREC_SCORER_CHECK_EVERY", 16)))
         self._evaluations = 0
         self.scorer_checked_rows = self.scorer_mismatch_rows = 0
+        self.range_violations = 0          # scorer waves that saw a score outside their launch's range invariant, over all passes
 
     def _cross_check_scorer(self, model, users, cache_key=None):
         """Top-K of the first `scorer_check_users` users by the default (bf16 x 3) scorer and by the fp32-MFMA scorer, compared ON THE
@@ -109,6 +110,31 @@ class UniEvaluator(object):
         diff = (val_a - val_b).abs()
         bad = (torch.where(torch.isfinite(val_a) & torch.isfinite(val_b), diff, (val_a != val_b).float()) > 1e-6).any(1).sum()
         return bad, int(users_t.numel())
+
+    def _range_verdict(self, model, first, act=True):
+        """Reads (and clears) the scorers' range-invariant counter behind the pass's launches. Violations under the default
+        (bf16 x 3) scorer switch the process to the fp32 scorer and the pass is scored again; under the fp32 scorer they are an
+        error: the cached tables themselves must hold non-finite values. act = False (several ranks: a rank must not leave the
+        collectives of the pass on its own): counted and logged only."""
+        from . import _lib
+        n = ops.score_range_violations(reset=True)
+        self.range_violations += n
+        if not n:
+            return 0
+        if not act:
+            from .logger import Logger
+            Logger.info("[evaluator] %d scorer waves of this rank saw a score outside the range of predict type %s / fusion %s"
+                        % (n, model.predict_type, model.fusion_mode))
+            return 0
+        lib = _lib.load()
+        from .logger import Logger
+        if first and int(lib.elimrec_score_get_bf16x3()) and int(lib.elimrec_score_get_math()) == 1 and model.latent_dim in (32, 64):
+            Logger.info("[evaluator] %d scorer waves saw a score outside the range of predict type %s / fusion %s: the fp32 scorer is "
+                        "used from here on, this pass is scored again" % (n, model.predict_type, model.fusion_mode))
+            lib.elimrec_score_set_bf16x3(0)
+            return n
+        raise FloatingPointError("the evaluator's scores left the range of predict type %s / fusion %s in %d scorer waves (fp32 scorer): "
+                                 "the cached tables hold non-finite or corrupted values" % (model.predict_type, model.fusion_mode, n))
 
     def _cross_check_verdict(self, pending):
         """Reads the cross-check's count (a host synchronisation: call it behind the pass's launches). On any differing row the
@@ -192,8 +218,10 @@ class UniEvaluator(object):
                 self.evaluate_batch(model, batch_users, cache_key=key, out=all_dev[at:at + len(batch_users)])
                 at += len(batch_users)
             # the scorer's cross-check of this pass's first users, read behind the pass's launches; a mismatch switches the process to
-            # the fp32 scorer and the pass is scored once more with it
-            if attempt == 1 or not self._cross_check_verdict(pending):
+            # the fp32 scorer and the pass is scored once more with it. Likewise the range invariant EVERY scorer launch of the pass
+            # checked in its epilogue (every score is a sigmoid of a bounded argument: csrc/eval.hip ScoreArgs::lo / hi)
+            out_of_range = self._range_verdict(model, first=attempt == 0, act=not sharded and getattr(model, "_eval_shard", None) is None)
+            if attempt == 1 or not (self._cross_check_verdict(pending) or out_of_range):
                 break
         if sharded and reduce:
             dist.all_reduce(all_dev, op=dist.ReduceOp.SUM)

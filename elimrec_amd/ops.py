@@ -682,6 +682,23 @@ def topk_reference_order(scores, K, out_idx, out_val=None):
     return out_idx, out_val
 
 
+def score_range_violations(reset=True):
+    """Waves of the scorer launches since the last reset that saw a score outside their launch's range invariant (a host
+    synchronisation with the current stream)."""
+    n = ctypes.c_int64(0)
+    _lib.check(_lib.load().elimrec_score_range_violations(ctypes.byref(n), 1 if reset else 0, _stream()), "score_range_violations")
+    return int(n.value)
+
+
+def score_range_check(topk_val, topk_idx, predict_type, fusion_mode, row_mean=None):
+    """The range check every scoring call ends with, over lists the caller holds (counted into score_range_violations)."""
+    B, K = topk_val.shape
+    assert topk_val.is_contiguous() and topk_idx.is_contiguous() and topk_idx.shape == (B, K)
+    _lib.check(_lib.load().elimrec_score_range_check(_dev(topk_val, "topk_val"), _dev(topk_idx, "topk_idx", torch.int32), B, K,
+                                                     PREDICT_TYPES.get(predict_type, 0), FUSION_MODES[fusion_mode],
+                                                     _dev(row_mean, "row_mean"), _stream()), "score_range_check")
+
+
 def score_topk_shard(Y, U, I, users, d, S, head_mask, fusion_mode, predict_type, workspace, phase, row_sum, I_total, id_offset,
                      scores=None, K=0, topk_idx=None, topk_val=None, train_ptr=None, train_items=None, sqnorm=None):
     """elimrec_score_topk_shard: Y = [all user rows ; this shard's I item rows]. phase 1 -> row_sum [B] (TIE), phase 2 ->

@@ -470,6 +470,19 @@ int elimrec_score_get_math(void);
 void elimrec_score_set_bf16x3(int on);
 int elimrec_score_get_bf16x3(void);
 
+/* Range invariant of the scorer (recdim 32 / 64 / 128 forms): every score of a valid (user, item) pair is the last sigmoid of a
+ * bounded argument -- sigma([0, 1]) for predict type normal and rubi TE, sigma([-1, 1]) for rubi TIE (models/EliMRec.py:96-113,
+ * 171-188), [0, 1] for the logarithmic fusions -- and a TIE row mean lies in (0, 1). Every elimrec_score_topk* call checks, in a
+ * last small launch, every score it RETURNS in a K-list (a wrongly high score necessarily enters its user's list) and every row
+ * mean it used; an offending user row adds 1 to a device counter. *h_count = the counter, read behind everything enqueued on
+ * `stream` (synchronises with it); reset != 0 clears it behind the read. The evaluator reads it after every pass. (The same
+ * comparison inside the scorers' epilogues cost 1.5 - 6 % of a validation pass and is not taken.) */
+int elimrec_score_range_violations(int64_t *h_count, int reset, void *stream);
+/* ... the same check over lists the caller holds: d_topk_val / d_topk_idx [B x K] (ids < 0 and -inf scores are fillers, not
+ * checked), d_row_mean [B] (nullable). */
+int elimrec_score_range_check(const float *d_topk_val, const int32_t *d_topk_idx, int B, int K, int predict_type, int fusion_mode,
+                              const float *d_row_mean, void *stream);
+
 /* d_sqnorm (nullable): [N x (1+S)] squared norms of every head block of every row of Y, from
  * elimrec_row_sqnorms; pass it when several user blocks are scored against the same tables (an
  * evaluation pass), otherwise it is recomputed inside every call. */

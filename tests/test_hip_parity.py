@@ -1,5 +1,6 @@
 """Parity of the HIP path (through the C ABI) against the golden vectors captured from the
 reference and against the CPU oracle on seeded inputs. Needs a real MI355X: `-m gpu`."""
+import collections
 import os
 import numpy as np
 import pytest
@@ -611,6 +612,23 @@ def test_sampler_contract_on_device():
     # negatives uniform over the catalogue
     cn = np.bincount(n, minlength=ds.num_items)
     assert cn.min() > 0 and cn.max() < 4 * len(n) / ds.num_items
+    # positives uniform, with replacement, over the drawn user's training items (data/sampler.py:113-115): Pearson chi-square over
+    # all (user, training item) cells of 24 further epochs (about 20 draws expected per cell), 5 sigma
+    uu, pp = [u], [p]
+    for _ in range(24):
+        eu, ep, _ = smp.sample_epoch()
+        uu.append(eu.cpu().numpy()); pp.append(ep.cpu().numpy())
+    uu, pp = np.concatenate(uu), np.concatenate(pp)
+    drawn = np.bincount(uu, minlength=ds.num_users)
+    cell = collections.Counter(zip(uu.tolist(), pp.tolist()))
+    chi2, dof = 0.0, 0
+    for a, items in sets.items():
+        if drawn[a] == 0 or len(items) < 2:
+            continue
+        e = drawn[a] / len(items)
+        chi2 += sum((cell.get((a, it), 0) - e) ** 2 / e for it in items)
+        dof += len(items) - 1
+    assert dof > 1000 and abs(chi2 - dof) < 5 * np.sqrt(2 * dof), (chi2, dof)
     # a new epoch draws a new stream; the same (seed, epoch) replays
     u2, _, _ = smp.sample_epoch()
     assert not np.array_equal(u2.cpu().numpy(), u)
@@ -1571,6 +1589,67 @@ def test_reference_order_inside_the_scoring_call(d, I, eval_math):
                            train_items=itd, tie_order="reference")
             assert torch.equal(both, ref) and np.array_equal(idx.cpu().numpy(), want)
     assert n_tied >= 2 * B                                       # (the tie rule was exercised on most rows of two of the tables)
+    assert ops.score_range_violations(reset=True) == 0           # ... and no launch saw a score outside rubi TIE's [0.2689, 0.7311]
+
+
+@pytest.mark.gpu
+def test_every_scoring_call_checks_the_scores_it_returns_against_the_range_of_its_predict_type(monkeypatch):
+    """The permanent guard behind round 3's fault (one launch in 49 000 returned 1.0 on sixteen lanes): every scoring call ends with
+    a check of the scores it returns in its K-lists -- a wrongly HIGH score necessarily enters its user's list -- against the interval
+    its (predict type, fusion mode) can produce (rubi TIE: sigma([-1, 1]) = [0.2689, 0.7311]) and of its TIE row means against
+    (0, 1); offending user rows are counted on the device and the evaluator reads the count after every pass. Clean tables: zero,
+    in every mode. The check itself over crafted lists; the evaluator's reaction (fp32 scorer + the pass again, then an error)."""
+    from elimrec_amd import _lib, ops
+    lib = _lib.load()
+    g = load_golden("kwai")
+    model, _ = build_model_from_fixture(g, DEV)
+    _load_cache(model, g)
+    users = g["evalbatch/users"].tolist()
+    ops.score_range_violations(reset=True)
+    for mode in ("rubi", "hm", "sum"):
+        for ptype in ("normal", "TE", "TIE"):
+            model.fusion_mode, model.predict_type = mode, ptype
+            sc = model.predict(users).numpy()
+            model.test()
+            assert ops.score_range_violations(reset=True) == 0, (mode, ptype)
+            if mode == "rubi":
+                lo, hi = (0.2689414, 0.7310586) if ptype == "TIE" else (0.5, 0.7310586)
+                assert sc.min() >= lo - 1e-6 and sc.max() <= hi + 1e-6, (ptype, sc.min(), sc.max())
+    # the check over crafted lists: round 3's signature, a NaN, a score below the range, a bad row mean; fillers are not scores
+    val = torch.full((6, 4), 0.6, device=DEV)
+    idx = torch.arange(24, dtype=torch.int32, device=DEV).view(6, 4).contiguous()
+    val[1, 0] = 1.0
+    val[2, 3] = float("nan")
+    val[3, 2] = 0.2
+    val[4, 1], idx[4, 1] = -float("inf"), 7              # the reference order's masked filler
+    val[5, 3], idx[5, 3] = -float("inf"), -1             # the id order's "no candidate"
+    ops.score_range_check(val, idx, "TIE", "rubi")
+    assert ops.score_range_violations(reset=True) == 3
+    ops.score_range_check(val, idx, "TIE", "hm")         # [0, 1]: only the NaN
+    assert ops.score_range_violations(reset=True) == 1
+    ops.score_range_check(val, idx, "TE", "rubi")        # [0.5, 0.7311]: 1.0, NaN, 0.2
+    assert ops.score_range_violations(reset=True) == 3
+    mean = torch.tensor([0.5, 0.5, 0.5, 0.5, 0.0, float("nan")], device=DEV)
+    ops.score_range_check(torch.full((6, 4), 0.6, device=DEV), idx.clamp(min=0), "TIE", "rubi", row_mean=mean)
+    assert ops.score_range_violations(reset=True) == 2
+    # the evaluator: a count behind a pass under the default scorer -> fp32 scorer, the pass again; a count again -> an error
+    model.fusion_mode, model.predict_type = "rubi", "TIE"
+    evalr = model.test_evaluator.evaluator
+    b0 = int(lib.elimrec_score_get_bf16x3())
+    calls = []
+    real = ops.score_range_violations
+    try:
+        lib.elimrec_score_set_bf16x3(1)
+        monkeypatch.setattr(ops, "score_range_violations", lambda reset=True: (calls.append(1), real(reset), 2 if len(calls) == 1 else 0)[2])
+        want, _ = model.test()
+        assert len(calls) == 2 and int(lib.elimrec_score_get_bf16x3()) == 0 and evalr.range_violations == 2
+        monkeypatch.setattr(ops, "score_range_violations", lambda reset=True: (real(reset), 5)[1])
+        with pytest.raises(FloatingPointError, match="left the range"):
+            model.test()
+    finally:
+        monkeypatch.setattr(ops, "score_range_violations", real)
+        lib.elimrec_score_set_bf16x3(b0)
+        ops.score_range_violations(reset=True)
 
 
 @pytest.mark.gpu
