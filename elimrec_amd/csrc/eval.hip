@@ -794,6 +794,13 @@ __global__ __launch_bounds__(256) void split3_items_kernel(const float *__restri
 // together and the CU's two workgroups drift apart -- 0.0169 s per validation pass against 0.0157 s: the item tile is then
 // staged twice per CU.)
 constexpr int TWB = 8, NTB = 64 * TWB;
+// tiles per barrier window of score_t16b_kernel (ring of 2 * window item-tile buffers in LDS): as many as 150 KB hold, at most 4
+constexpr int t16b_row4(int pass, int nb, int d) { return 3 * ((pass == 1 ? 1 : nb) * d) / 8 + 1; }
+constexpr int t16b_win(int pass, int nb, int d) {
+    int w = 4;
+    while (w > 1 && (size_t)2 * w * 16 * t16b_row4(pass, nb, d) * 16 > (size_t)150 * 1024) --w;
+    return w;
+}
 template <int PASS, int NB, int PT, int FM, int D>
 __global__ __launch_bounds__(NTB, 2) void score_t16b_kernel(ScoreArgs a, int n_tiles) {
     constexpr bool FAST = true;
@@ -801,8 +808,15 @@ __global__ __launch_bounds__(NTB, 2) void score_t16b_kernel(ScoreArgs a, int n_t
     constexpr int ROW4 = 3 * COLS / 8 + 1;            // LDS row of an item in uint4 units: three planes + 16 B of padding
     constexpr int KB = D / 32;                         // 32-deep MFMA steps per head block
     extern __shared__ float smem[];
-    uint4 *it0 = reinterpret_cast<uint4 *>(smem), *it1 = it0 + TI * ROW4;
-    float *unorm = reinterpret_cast<float *>(it1 + TI * ROW4);     // [128][NB-1]
+    // 2 * WIN item-tile buffers in a ring, tiles staged WIN ahead, ONE barrier per WIN tiles: inside a window the waves read
+    // buffers k .. k + WIN - 1 and write k + WIN .. k + 2 WIN - 1 (mod 2 WIN) -- the ones the window before read, which every wave
+    // has left behind at the barrier in between -- so the eight waves drift up to WIN - 1 tiles apart and one SIMD's two waves
+    // overlap their MFMA and epilogue phases instead of meeting at a barrier after every 16 items (WIN = 3 at recdim 64 with
+    // three heads: 149 KB of LDS; one workgroup per CU either way -- the kernel's 218 registers allow two waves per SIMD)
+    constexpr int WIN = t16b_win(PASS, NB, D), RING = 2 * WIN;
+    static_assert(ROW4 == t16b_row4(PASS, NB, D), "LDS row size");
+    uint4 *itb = reinterpret_cast<uint4 *>(smem);
+    float *unorm = reinterpret_cast<float *>(itb + RING * TI * ROW4);     // [128][NB-1]
     float *umean = unorm + TWB * TU * (NB > 1 ? NB - 1 : 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
@@ -875,16 +889,20 @@ __global__ __launch_bounds__(NTB, 2) void score_t16b_kernel(ScoreArgs a, int n_t
     // 64-B store (below) instead of sixteen 4-B ones, each of which cost a 32-B write at the memory side
     const int per = (n_tiles + (int)gridDim.x - 1) / (int)gridDim.x;
     const int t_begin = (int)blockIdx.x * per, t_end = t_begin + per < n_tiles ? t_begin + per : n_tiles;
-    if (t_begin < t_end) { load_tile(t_begin); load_sqn(t_begin, sq_cur); store_tile(it0); }
+    if (t_begin < t_end) load_sqn(t_begin, sq_cur);
+#pragma unroll
+    for (int w = 0; w < WIN; ++w)
+        if (t_begin + w < t_end) { load_tile(t_begin + w); store_tile(itb + w * (TI * ROW4)); }
     __syncthreads();
-    int cur = 0;
     float mxb[4] = {0.f, 0.f, 0.f, 0.f};              // PASS 2: lane li holds the maximum of tile (base + li) of its four users
-    for (int tile = t_begin; tile < t_end; ++tile, cur ^= 1) {
-        const int next = tile + 1;
-        if (next < t_end) { load_tile(next); load_sqn(next, sq_nxt); }
+    int ring = 0, in_win = 0;                         // this tile's buffer; its place in the barrier window
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int next = tile + 1, ahead = tile + WIN;
+        if (ahead < t_end) load_tile(ahead);
+        if (next < t_end) load_sqn(next, sq_nxt);
         const int64_t i0 = a.item0 + (int64_t)tile * TI;
         v4f_s acc[NH];
-        const uint4 *brow = (cur ? it1 : it0) + li * ROW4 + kq;          // this lane's item row, its k-block of 8
+        const uint4 *brow = itb + ring * (TI * ROW4) + li * ROW4 + kq;   // this lane's item row, its k-block of 8
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             acc[h] = (v4f_s){0.f, 0.f, 0.f, 0.f};
@@ -986,10 +1004,11 @@ __global__ __launch_bounds__(NTB, 2) void score_t16b_kernel(ScoreArgs a, int n_t
                 }
             }
         }
-        if (next < t_end) store_tile(cur ? it0 : it1);
+        if (ahead < t_end) store_tile(itb + (ring + WIN >= RING ? ring + WIN - RING : ring + WIN) * (TI * ROW4));
 #pragma unroll
         for (int q = 0; q < NQ; ++q) sq_cur[q] = sq_nxt[q];
-        __syncthreads();
+        ring = ring + 1 == RING ? 0 : ring + 1;
+        if (++in_win == WIN) { in_win = 0; __syncthreads(); }      // (workgroup-uniform) the end of a window
     }
     if (PASS == 1) {                                  // one partial per (workgroup, user): row_mean_kernel adds them in order
 #pragma unroll
@@ -1919,7 +1938,7 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
         };
         auto b3_lds = [d](int pass, int nb) {
             const int nh = pass == 1 ? 1 : nb;
-            return ((size_t)2 * TI * (3 * nh * d / 8 + 1) * 16 + ((size_t)TWB * TU * (nb > 1 ? nb - 1 : 1) + TWB * TU) * sizeof(float));
+            return ((size_t)2 * t16b_win(pass, nb, d) * TI * (3 * nh * d / 8 + 1) * 16 + ((size_t)TWB * TU * (nb > 1 ? nb - 1 : 1) + TWB * TU) * sizeof(float));
         };
 #define ELIMREC_T16B_LAUNCH1(NB, GRID, DD)                                                                   \
     hipLaunchKernelGGL((score_t16b_kernel<1, NB, -1, -1, DD>), GRID, dim3(NTB), b3_lds(1, NB), s, a, t16)
