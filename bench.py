@@ -255,9 +255,18 @@ def main():
     ap.add_argument("--feature-dtype", choices=["f32", "f16", "bf16"], default="f32", help="storage of the folded constants")
     ap.add_argument("--no-b-sweep", action="store_true", help="skip the batch-size sweep line")
     ap.add_argument("--no-reduced-precision", action="store_true", help="skip the bf16-feature-storage line (configs[1]'s label)")
+    ap.add_argument("--no-projection", action="store_true", help="skip the multi-GPU projection block (emulated ranks on this GPU)")
+    ap.add_argument("--projection-only", action="store_true", help=argparse.SUPPRESS)   # the child process of projection_in_child()
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)      # a rank started by supervise()
     args = ap.parse_args()
 
+    if args.projection_only:
+        import torch
+        device = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        cfg, ds, _ = build(args, device)
+        print(json.dumps(multi_gpu_projection(args, device, cfg, ds, WORKLOAD["batch_size"], torch)), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # bare `python bench.py --gpus N`: start the N ranks ourselves, as CHILD processes of a parent that has not touched
         # the GPU (nothing above imports torch), and leave with their exit code -- the same launch line the driver uses
@@ -491,6 +500,8 @@ def main():
             extra("reference_equivalent_work", lambda: reference_work_line(args, device, cfg, batches, torch))
         if world == 1 and not args.no_b_sweep:
             extra("batch_sweep", lambda: batch_sweep(trainer, sampler, pools, B, torch))
+        if world == 1 and not args.no_projection:
+            extra("multi_gpu_projection", projection_in_child)
         if world == 1 and not args.no_reduced_precision and args.feature_dtype == "f32":
             extra("reduced_precision", lambda: reduced_precision_line(args, device, cfg, batches, first_losses, torch))
         mu = pmc_field("mfma_utilisation")
@@ -517,6 +528,9 @@ def main():
             "eval_seconds_reference_order_after_2_steps": pick("eval", "tie_order", "after_2_training_steps", "reference_seconds"),
             "eval_seconds_id_order_after_2_steps": pick("eval", "tie_order", "after_2_training_steps", "id_seconds"),
             "batch_sweep_ms_per_step": {str(x["batch"]): x["ms_per_step"] for x in (pick("batch_sweep", "sizes") or []) if isinstance(x, dict)},
+            "multi_gpu_PROJECTION_not_measured": {w: {"per_rank_kernel_ms": v.get("per_rank_kernel_ms"), "projected_ms_per_step": v.get("projected_ms_per_step"),
+                                                      "projected_triplets_per_s": v.get("projected_triplets_per_s")}
+                                                  for w, v in (pick("multi_gpu_projection", "worlds") or {}).items()},
         }
         try:        # C-side stdio first (RCCL prints its version banner there), so that the JSON line is the LAST line on stdout
             import ctypes
@@ -682,6 +696,111 @@ def hop_forms_note():
                 % (us("sweep"), us("tile"), os.path.basename(paths[-1])))
     except Exception:
         return ""
+
+
+XGMI_LINK_GBS = 153.0          # one direct xGMI link, one direction (MI355X_MICROARCH.md: 7 links x ~153 GB/s per GPU)
+COLLECTIVE_LATENCY_US = 10.0    # launch + first-byte latency charged per collective on the critical path (assumed, not measured here)
+
+
+def multi_gpu_projection(args, device, cfg, ds, B, torch, worlds=(2, 4, 8), steps=20):
+    """A PROJECTION, not a measurement: what one rank of a W-GPU job computes per step, measured on THIS one GPU (rank 0's engine
+    runs every kernel of its step at the real per-rank sizes with its own send buffers fed back as the peers' -- tools/c4_rank_time.py's
+    method), plus the step's collectives priced on the direct xGMI links (every pair of GPUs of a node has its own link: the W - 1
+    chunks of an all_to_all / all_gather travel at once, each at one link's rate). Nothing here has run on more than one GPU."""
+    from elimrec_amd import ColumnShardEngine, FusedAdam, PairwiseSamplerV2
+
+    class _Done:
+        def wait(self):
+            pass
+    sampler = PairwiseSamplerV2(ds, batch_size=B, device=device, seed=cfg["seed"])
+    u, p, n = sampler.sample_epoch()
+    out = {"what": "PROJECTION from one-GPU measurements -- per-rank kernel time of an emulated rank of a W-rank column-sharded job "
+                   "(B = %d triplets per rank) + the step's critical-path collectives on direct xGMI links at %.0f GB/s per link and "
+                   "direction, %.0f us charged per collective; the id all_gather, the constants' lookup all_to_all and the weight-gradient "
+                   "all_reduce run under the hops (DESIGN.md section 6) and are listed but not added" % (B, XGMI_LINK_GBS, COLLECTIVE_LATENCY_US),
+           "worlds": {}}
+    R, d = 3 * B, WORKLOAD["recdim"]
+    sum_d = sum(WORKLOAD["feat_dims"])
+    for W in worlds:
+        if d % (4 * W):
+            continue
+        _, _, model = build(args, device)
+        model = model.to(device)
+        opt = FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"])
+        eng = ColumnShardEngine(model)
+        eng.cs_setup(W, 0, opt)
+        eng.multi_aux = True
+        scale = torch.full((1,), 1.0 / W, device=device)
+
+        def step(i):
+            act = eng.cs_plan(u[i * B:(i + 1) * B], p[i * B:(i + 1) * B], n[i * B:(i + 1) * B])
+            ps = eng.plan_stream()
+            if ps is not None:                            # the planner ran on the second stream: the copy below reads its list
+                torch.cuda.current_stream().wait_stream(ps)
+            acts = act.view(1, -1).expand(W, -1).contiguous()
+            eng.cs_gathered_ids(acts, _Done())
+            eng.cs_forward_hops()
+            if not eng._long_wanted_only():
+                eng.cs_forward_long()
+            send = eng.cs_forward_rows(acts)
+            eng.cs_head(send)
+            s2, _ = eng.cs_backward_local(scale)
+            eng.cs_backward_hops(s2, acts)
+            eng.cs_update()
+        for i in range(4):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(4, 4 + steps):
+            step(i)
+        torch.cuda.synchronize()
+        kernel_ms = 1e3 * (time.perf_counter() - t0) / steps
+        dl = d // W
+        chunk = lambda total_sent: total_sent / (W - 1)                       # bytes per peer: they travel on W - 1 links at once
+        coll = {"all_gather_ids": 4 * R * (W - 1), "all_to_all_rows_fwd": R * 2 * dl * 4 * (W - 1), "all_to_all_sources_bwd": R * 2 * dl * 4 * (W - 1),
+                "all_to_all_v_constants_lookup_upper_bound": int(R * (sum_d + 4) * 4 * (W - 1) / W), "all_reduce_weight_grads": 4 * 70000}
+        t_us = {k: chunk(v) / (XGMI_LINK_GBS * 1e3) + COLLECTIVE_LATENCY_US for k, v in coll.items()}
+        critical_us = t_us["all_to_all_rows_fwd"] + t_us["all_to_all_sources_bwd"]
+        step_ms = kernel_ms + critical_us / 1e3
+        out["worlds"][str(W)] = {
+            "columns_per_rank": dl, "per_rank_kernel_ms": kernel_ms, "bytes_sent_per_rank_step": coll,
+            "modelled_us_per_collective": {k: round(v, 1) for k, v in t_us.items()},
+            "critical_path_collectives_us": round(critical_us, 1), "projected_ms_per_step": step_ms,
+            "projected_triplets_per_s": B * W / (step_ms * 1e-3)}
+        del model, opt, eng
+        torch.cuda.empty_cache()
+    # the alternative north_star names for the graph table too: ROW shards (each rank computes 1/W of a hop's output rows from
+    # the whole input table), an all_gather of the table per hop on the direct links -- priced, not built
+    N = ds.num_users + ds.num_items
+    L = WORKLOAD["layer_num"]
+    table = N * d * 4
+    alt = {}
+    for W in worlds:
+        per_link = table / W                                                  # every peer sends me its 1/W of the rows on its own link
+        hop_gather_us = per_link / (XGMI_LINK_GBS * 1e3) + COLLECTIVE_LATENCY_US
+        alt[str(W)] = {"all_gather_bytes_received_per_hop": int(table * (W - 1) / W), "modelled_us_per_hop_all_gather": round(hop_gather_us, 1),
+                       "hops_per_step": 2 * L, "all_gather_us_per_step": round(2 * L * hop_gather_us, 1)}
+    out["row_sharded_graph_table_alternative"] = {
+        "what": "not built: per hop every rank needs the whole [N x d] input (%.1f MB): an all_gather on the direct links -- NOT the ring "
+                "time earlier rounds quoted (7x more); per-rank hop work would shrink with W (full 256-B rows, 1/W of them), which the "
+                "column shards' does not below 32 columns per rank" % (table / 1e6),
+        "worlds": alt}
+    return out
+
+
+def projection_in_child(limit_s=240):
+    """multi_gpu_projection in a process of its own (`bench.py --projection-only`): it builds three more engines with emulated
+    peers on this GPU, and nothing it does -- a fault included -- may cost the headline line. Returns the block, or the reason."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--projection-only"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=limit_s, cwd=ROOT)
+    except subprocess.TimeoutExpired:
+        return {"error": "the projection's process did not finish within %d s" % limit_s}
+    lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "the projection's process ended with code %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-300:])}
+    return json.loads(lines[-1])
 
 
 def tied_rows(model, evalr, torch):

@@ -896,7 +896,7 @@ __global__ __launch_bounds__(512) void head_bwd_input_mfma_kernel(const float *_
     }
 }
 
-// The same kernel on 16-row tiles (ELIMREC_HEAD_BWD_ROWS=16; not the default, see the launch site): twice the workgroups
+// The same kernel on 16-row tiles (taken when the caller hands over the packed operands, see the launch site): twice the workgroups
 // at half the threads, a quarter of the LDS, v_mfma_f32_16x16x4_f32, four 16-column output tiles per wave.
 typedef float v4f_ __attribute__((ext_vector_type(4)));
 constexpr int HM16 = 16;
@@ -1723,11 +1723,9 @@ static int segment_apply_head_bwd_impl(const float *d_rows, int64_t n, int ld, c
     }
     // 16-row tiles: with the weights read unpacked from L2 the smaller MFMA doubles the operand loads (32.4 us against
     // 28.5 for the 32-row kernel at the Tiktok shape) -- used when the caller hands over the packed operands
-    // (recdim 64), or with ELIMREC_HEAD_BWD_ROWS=16
-    static int rows16 = -1;
-    if (rows16 < 0) { const char *e = getenv("ELIMREC_HEAD_BWD_ROWS"); rows16 = e ? atoi(e) : 0; }
-    const bool packed = d_pack_bwd && d == 64 && rows16 != 32;
-    if ((packed || rows16 == 16) && C % 16 == 0 && (1 + S) * d % 4 == 0) {
+    // (recdim 64)
+    const bool packed = d_pack_bwd && d == 64;
+    if (packed && C % 16 == 0 && (1 + S) * d % 4 == 0) {
         const size_t lds16 = (size_t)HM16 * ((1 + S) * d + 4) * sizeof(float);
         HeadPackPtrs pk = {};
         if (packed) {
@@ -1746,7 +1744,7 @@ static int segment_apply_head_bwd_impl(const float *d_rows, int64_t n, int ld, c
         ELIMREC_LAUNCH_CHECK("segment_apply_head_bwd16");
         return 0;
     }
-    ELIMREC_REQUIRE(!src, "segment_apply_head_bwd_sources: the 16-row kernel is switched off (ELIMREC_HEAD_BWD_ROWS)");
+    ELIMREC_REQUIRE(!src, "segment_apply_head_bwd_sources: needs the packed operands of the 16-row head (recdim 64)");
     hipLaunchKernelGGL(head_bwd_input_mfma_kernel, dim3((unsigned)((n + HM_ROWS - 1) / HM_ROWS)), dim3(512), lds_m,
                        (hipStream_t)stream, (const float *)d_reduced, (int64_t)ld, d_active_rows, d_seg_info, n, U, d, C, S, hp,
                        d_W_user, d_W_item, 1.0f, (float *)nullptr, (int64_t)0, 0, d_compact, seg);

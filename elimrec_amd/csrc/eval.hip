@@ -6,10 +6,6 @@
 
 namespace elimrec {
 
-constexpr int SI = 64;    // items per workgroup tile (one per lane)
-constexpr int SU = 32;    // users per workgroup tile (8 per wave)
-constexpr int SK = 128;   // columns staged per step
-constexpr int SLD = SK + 1;
 constexpr int kMaxS = 4;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
@@ -257,93 +253,6 @@ __device__ __forceinline__ void fuse2(int mode, float x, float m, const float *z
     }
 }
 
-// PASS 1: partial row sums of ui = sigmoid(<Yf[u], Yf[item]>) over this item tile.
-// PASS 2: final scores.
-template <int PASS>
-__global__ __launch_bounds__(256) void score_kernel(ScoreArgs a) {
-    __shared__ float it[SI * SLD];
-    __shared__ float us[SU * SLD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t i0 = (int64_t)blockIdx.x * SI;
-    const int b0 = blockIdx.y * SU;
-    const int nblk = (PASS == 1) ? 1 : 1 + a.S;
-    float dot[1 + kMaxS][8];
-    float isq[1 + kMaxS];
-    float usq[1 + kMaxS][8];
-    for (int h = 0; h < 1 + kMaxS; ++h) { isq[h] = 0.f; for (int u = 0; u < 8; ++u) { dot[h][u] = 0.f; usq[h][u] = 0.f; } }
-
-#pragma unroll
-    for (int h = 0; h < 1 + kMaxS; ++h) {
-        if (h >= nblk) break;
-        for (int k0 = 0; k0 < a.d; k0 += SK) {
-            const int kc = (a.d - k0) < SK ? (a.d - k0) : SK;
-            __syncthreads();
-            // stage item rows: SI x kc, 4 floats per thread-step
-            for (int e = tid * 4; e < SI * kc; e += 1024) {
-                const int r = e / kc, c = e - r * kc;
-                const int64_t item = i0 + r;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (item < a.I) v = *reinterpret_cast<const float4 *>(a.Y + (a.U + item) * a.ldy + h * a.d + k0 + c);
-                float *dst = it + r * SLD + c;
-                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-            }
-            for (int e = tid * 4; e < SU * kc; e += 1024) {
-                const int r = e / kc, c = e - r * kc;
-                const int b = b0 + r;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (b < a.B) v = *reinterpret_cast<const float4 *>(a.Y + a.users[b] * a.ldy + h * a.d + k0 + c);
-                float *dst = us + r * SLD + c;
-                dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-            }
-            __syncthreads();
-            const float *ip = it + lane * SLD;
-            const float *up = us + (wave * 8) * SLD;
-            for (int k = 0; k < kc; ++k) {
-                const float x = ip[k];
-                isq[h] = fmaf(x, x, isq[h]);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const float y = up[u * SLD + k];
-                    dot[h][u] = fmaf(x, y, dot[h][u]);
-                    usq[h][u] = fmaf(y, y, usq[h][u]);
-                }
-            }
-        }
-    }
-    const int64_t item = i0 + lane;
-    const bool item_ok = item < a.I;
-    if (PASS == 1) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            float v = item_ok ? sigmoidf_(dot[0][u]) : 0.f;
-            v = wave_sum(v);
-            const int b = b0 + wave * 8 + u;
-            if (lane == 0 && b < a.B) a.partial[(int64_t)blockIdx.x * a.B + b] = v;
-        }
-        return;
-    }
-    const float eps = 1e-12f;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int b = b0 + wave * 8 + u;
-        if (b >= a.B || !item_ok) continue;
-        const float ui = sigmoidf_(dot[0][u]);
-        float out;
-        if (a.predict_type == 0) {
-            out = sigmoidf_(ui);                                    // EliMRec.py:113
-        } else {
-            float z[kMaxS];
-#pragma unroll
-            for (int h = 0; h < kMaxS; ++h)
-                z[h] = (h < a.S) ? dot[1 + h][u] / (fmaxf(sqrtf(usq[1 + h][u]), eps) * fmaxf(sqrtf(isq[1 + h]), eps)) : 0.f;
-            const float te = fuse(a.fusion_mode, ui, z, a.S, a.head_mask);
-            if (a.predict_type == 1) out = sigmoidf_(te);           // :103-105
-            else out = sigmoidf_(te - fuse(a.fusion_mode, a.row_mean[b], z, a.S, a.head_mask));   // :106-111
-        }
-        a.scores[(int64_t)b * a.lds + item] = out;
-    }
-}
-
 // MFMA form of the same scorer (used when d % 4 == 0 and the head count fits): a workgroup owns 32 items
 // x up to 128 users (the whole evaluation block, so every item row leaves HBM exactly once per block);
 // wave w owns users [32w, 32w+32). Per head block the user and item rows are staged 64 columns at a time
@@ -431,131 +340,7 @@ __global__ __launch_bounds__(256) void score_mfma_kernel(ScoreArgs a) {
     }
 }
 
-// The same scorer with the USERS resident: the kernel above re-stages the 128 user rows (128 KB) for every 32-item
-// tile, 2 378 times per block at the Tiktok shape, and that staging -- not the MFMAs -- is where its time goes
-// (12 % of the fp32 MFMA rate). Here a workgroup keeps its 128 users for the whole launch: every wave holds the MFMA
-// A operands of its 32 users in registers (NB * D / 2 floats per lane), the workgroup walks item tiles
-// blockIdx.x, + gridDim.x, ... and only the 32 item rows of a tile go through LDS. Same k order per output and the
-// same partial-sum layout as score_mfma_kernel, so the scores are bit-identical.
-// PT / FM: predict type and fusion mode as compile-time constants (PASS 2; -1 = read them from the arguments) -- one
-// epilogue instead of seven in the instruction stream and in the register budget.
-template <int PASS, int NB, int D, int PT, int FM>
-__global__ __launch_bounds__(256, 2) void score_resident_kernel(ScoreArgs a, int n_tiles) {
-    const int ptype = PT >= 0 ? PT : a.predict_type, fmode = FM >= 0 ? FM : a.fusion_mode;
-    constexpr int NH = (PASS == 1) ? 1 : NB;          // head blocks this pass needs
-    constexpr int COLS = NH * D, LD = COLS + 1;
-    constexpr int PFN = MI * COLS / 1024;             // float4 per thread per item tile
-    extern __shared__ float smem[];
-    float *it0 = smem, *it1 = smem + MI * LD;         // two item-tile buffers
-    float *unorm = it1 + MI * LD;                     // [MU][NB-1]  max(|user block 1+h|, eps)
-    float *umean = unorm + MU * (NB > 1 ? NB - 1 : 1);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 31, lk = lane >> 5;
-    const int b0 = blockIdx.y * MU;
-    const float eps = 1e-12f;
-    // A operands: user (wave*32 + li), element k = 2*ks + lk of head block h
-    float ua[NH][D / 2];
-    {
-        const int ub = b0 + wave * 32 + li;
-        const float *urow = ub < a.B ? a.Y + a.users[ub] * a.ldy + lk : nullptr;
-#pragma unroll
-        for (int h = 0; h < NH; ++h)
-#pragma unroll
-            for (int ks = 0; ks < D / 2; ++ks) ua[h][ks] = urow ? urow[h * D + 2 * ks] : 0.f;
-    }
-    if (PASS == 2 && tid < MU) {
-        const int b = b0 + tid;
-        const int64_t un = b < a.B ? a.users[b] : -1;
-        for (int h = 0; h + 1 < NB; ++h)
-            unorm[tid * (NB - 1) + h] = (un >= 0 && ptype != 0) ? fmaxf(sqrtf(a.sqn[un * NB + 1 + h]), eps) : 1.f;
-        umean[tid] = (b < a.B && ptype == 2) ? a.row_mean[b] : 0.f;
-    }
-    // item tiles are double-buffered: the next tile's rows are in flight (registers) during this tile's MFMAs and
-    // epilogue and go to the other LDS buffer afterwards -- one barrier per tile
-    float4 pf[PFN];
-    auto load_tile = [&](int tile) {
-#pragma unroll
-        for (int q = 0; q < PFN; ++q) {
-            const int e = (tid + 256 * q) * 4;
-            const int r = e / COLS, c = e - r * COLS;
-            const int64_t item = (int64_t)tile * MI + r;
-            pf[q] = item < a.I ? *reinterpret_cast<const float4 *>(a.Y + (a.U + item) * a.ldy + c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    };
-    auto store_tile = [&](float *buf) {
-#pragma unroll
-        for (int q = 0; q < PFN; ++q) {
-            const int e = (tid + 256 * q) * 4;
-            const int r = e / COLS, c = e - r * COLS;
-            float *dst = buf + r * LD + c;
-            dst[0] = pf[q].x; dst[1] = pf[q].y; dst[2] = pf[q].z; dst[3] = pf[q].w;
-        }
-    };
-    if ((int)blockIdx.x < n_tiles) { load_tile(blockIdx.x); store_tile(it0); }
-    __syncthreads();
-    int cur = 0;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x, cur ^= 1) {
-        const int64_t i0 = (int64_t)tile * MI;
-        const int next = tile + gridDim.x;
-        if (next < n_tiles) load_tile(next);
-        v16f_s acc[NH];
-        const float *bp = (cur ? it1 : it0) + li * LD + lk;
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            acc[h] = (v16f_s){0};
-#pragma unroll
-            for (int ks = 0; ks < D / 2; ++ks)
-                acc[h] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[h][ks], bp[h * D + 2 * ks], acc[h], 0, 0, 0);
-        }
-        const int64_t item = i0 + li;
-        const bool item_ok = item < a.I;
-        if (PASS == 1) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int b = b0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                float v = (item_ok && b < a.B) ? sigmoidf_(acc[0][r]) : 0.f;
-#pragma unroll
-                for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);      // over the 32 items of the tile
-                if (li == 0 && b < a.B) a.partial[(int64_t)tile * a.B + b] = v;
-            }
-        } else {
-            float inorm[NB > 1 ? NB - 1 : 1];
-#pragma unroll
-            for (int h = 0; h + 1 < NB; ++h)
-                inorm[h] = (item_ok && ptype != 0) ? fmaxf(sqrtf(a.sqn[(a.U + item) * NB + 1 + h]), eps) : 1.f;
-            // all 16 outputs of the lane are computed unconditionally (independent chains the scheduler can
-            // interleave; rows / items past the end hold zeros) and only the store is predicated
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int urow = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const float ui = sigmoidf_(acc[0][r]);
-                float out;
-                if (ptype == 0) {
-                    out = sigmoidf_(ui);
-                } else {
-                    float z[kMaxS];
-#pragma unroll
-                    for (int h = 0; h < kMaxS; ++h)
-                        z[h] = (h + 1 < NB) ? acc[(h + 1 < NH) ? h + 1 : 0][r] / (unorm[urow * (NB - 1) + (h + 1 < NB ? h : 0)] * inorm[h + 1 < NB ? h : 0]) : 0.f;
-                    if (ptype == 1) out = sigmoidf_(fuse(fmode, ui, z, NB - 1, a.head_mask));
-                    else {
-                        float te, nde;
-                        fuse2(fmode, ui, umean[urow], z, NB - 1, a.head_mask, te, nde);
-                        out = sigmoidf_(te - nde);
-                    }
-                }
-                if (item_ok && b0 + urow < a.B) a.scores[(int64_t)(b0 + urow) * a.lds + item] = out;
-                // four independent chains at a time are enough to hide the VALU latencies; all 16 interleaved cost
-                // 370 registers and the second wave per SIMD
-                if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        if (next < n_tiles) store_tile(cur ? it0 : it1);
-        __syncthreads();
-    }
-}
-
-// The scorer the evaluator runs (recdim 64, 1-3 single-modal heads): the resident form above needs 128 registers for a
+// The scorer the evaluator runs (recdim 64, 1-3 single-modal heads): a users-resident 32 x 32 form (removed in round 6) needed 128 registers for a
 // wave's 32 users' A operands, 64 accumulators and a 16-output epilogue -- 370 registers, ONE wave per SIMD, nothing to
 // hide the epilogue's transcendental chains or the item loads behind (15 % of the fp32 MFMA rate, 18 % MFMA-busy,
 // 30 % VALU-busy by the PMC counters). Here a wave owns 16 users (v_mfma_f32_16x16x4_f32: 64 A registers for four
@@ -1648,11 +1433,8 @@ static int score_math() {
     }
     return g_score_math;
 }
-static int g_score_b3 = -1;
-static int score_bf16x3() {
-    if (g_score_b3 < 0) { const char *e = getenv("ELIMREC_SCORE_BF16X3"); g_score_b3 = (e && e[0] == '0') ? 0 : 1; }
-    return g_score_b3;
-}
+static int g_score_b3 = 1;
+static int score_bf16x3() { return g_score_b3; }
 extern "C" void elimrec_score_set_bf16x3(int on) { g_score_b3 = on ? 1 : 0; }
 extern "C" int elimrec_score_get_bf16x3(void) { return score_bf16x3(); }
 extern "C" void elimrec_score_set_math(int mode) { g_score_math = mode ? 1 : 0; }
@@ -1737,13 +1519,12 @@ extern "C" size_t elimrec_score_workspace_topk(int B, int64_t U, int64_t I, int 
 // elimrec_score_topk: the 16-user-per-wave scorer (recdim 32 / 64 / 128, 1..3 heads, MFMA + T16 forms enabled), K <= 256
 // (the tile-guided selection with its running list) and more than one chunk -- any catalogue size.
 constexpr size_t TOPK_MERGE_LDS_MAX = 160 * 1024;
-static bool score_env_flag(const char *name, char off, int *cache) {
-    if (*cache < 0) { const char *e = getenv(name); *cache = (e && e[0] == off) ? 0 : 1; }
-    return *cache != 0;
-}
-static bool score_uses_mfma() { static int c = -1; return score_env_flag("ELIMREC_SCORE_VALU", '1', &c); }
-static bool score_uses_t16() { static int c = -1; return score_env_flag("ELIMREC_SCORE_T16", '0', &c); }
-static bool score_uses_chunks() { static int c = -1; return score_env_flag("ELIMREC_SCORE_CHUNKED", '0', &c); }
+// (the plain-VALU scorer, the one-user-tile-per-workgroup MFMA scorer without tile maxima and the unchunked top-K were run-time
+// switches until round 6 -- ELIMREC_SCORE_VALU / _T16 / _CHUNKED / _RESIDENT; each lost to the form below at every shape measured,
+// docs/REJECTED.md -- and are now fixed: the forms are chosen by recdim and call shape alone)
+static bool score_uses_mfma() { return true; }
+static bool score_uses_t16() { return true; }
+static bool score_uses_chunks() { return true; }
 static bool score_t16_path(int d, int S) {
     return score_uses_mfma() && score_uses_t16() && (d == 32 || d == 64 || d == 128) && S >= 1 && S <= 3;
 }
@@ -1771,10 +1552,6 @@ extern "C" int elimrec_row_sqnorms(const float *d_Y, int64_t ldy, int64_t n_rows
     return 0;
 }
 
-static size_t resident_lds(int pass, int nb, int d) {
-    const int cols = (pass == 1 ? 1 : nb) * d;
-    return ((size_t)2 * MI * (cols + 1) + (size_t)MU * (nb > 1 ? nb - 1 : 1) + MU) * sizeof(float);
-}
 
 // phase 0: the whole call. Item-sharded evaluation (this rank holds items [id_offset, id_offset + I) of I_total):
 // phase 1 = pass 1 only, d_row_sum[b] = sum over MY items of sigmoid(u.i) (TIE; a no-op otherwise); the caller adds the
@@ -1798,9 +1575,6 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
     ELIMREC_REQUIRE(d_scores || d_topk_idx || phase == 1, "score_topk: nothing to output");
     ELIMREC_REQUIRE(!d_topk_idx || (K > 0 && K <= I), "score_topk: need 0 < K <= I");
     if (B <= 0) return 0;
-    static int use_resident = -1;
-    if (use_resident < 0) { const char *e = getenv("ELIMREC_SCORE_RESIDENT"); use_resident = (e && e[0] == '0') ? 0 : 1; }
-    const bool use_mfma = score_uses_mfma();
     const bool t16_path = score_t16_path(d, S);
     // only top-K wanted: no [B x I] score block -- the catalogue goes through the scorer in chunks (a workspace sized by
     // elimrec_score_workspace_for is enough; a larger one is accepted)
@@ -2090,43 +1864,7 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
 #undef ELIMREC_T16_P2
 #undef ELIMREC_T16_LAUNCH
 #undef ELIMREC_T16_LAUNCH_D
-    } else if (use_mfma && use_resident && d == 64 && S >= 1 && S <= 3) {
-        // users resident in registers, a persistent grid over the item tiles (two workgroups per CU)
-        dim3 grid((unsigned)(tiles < 512 ? tiles : 512), (B + MU - 1) / MU);
-#define ELIMREC_SCORE_RESIDENT2(NB, PT, FM)                                                                  \
-    do {                                                                                                   \
-        static bool attr = false;                                                                          \
-        if (!attr) {                                                                                       \
-            (void)hipFuncSetAttribute((const void *)score_resident_kernel<2, NB, 64, PT, FM>,              \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)resident_lds(2, NB, 64)); \
-            attr = true;                                                                                   \
-        }                                                                                                  \
-        hipLaunchKernelGGL((score_resident_kernel<2, NB, 64, PT, FM>), grid, dim3(256), resident_lds(2, NB, 64), s, a, tiles); \
-    } while (0)
-#define ELIMREC_SCORE_RESIDENT(NB)                                                                          \
-    do {                                                                                                   \
-        if (own_pass1) {                                                                                   \
-            hipLaunchKernelGGL((score_resident_kernel<1, NB, 64, -1, -1>), grid, dim3(256), resident_lds(1, NB, 64), s, a, tiles); \
-            ELIMREC_LAUNCH_CHECK("score_resident_pass1");                                                  \
-            hipLaunchKernelGGL(row_mean_kernel, dim3(B), dim3(256), 0, s, partial, tiles, B, mean_div, mean_dst); \
-            ELIMREC_LAUNCH_CHECK("row_mean");                                                              \
-        }                                                                                                  \
-        if (phase == 1) return 0;                                                                          \
-        if (predict_type == 0) ELIMREC_SCORE_RESIDENT2(NB, 0, 0);                                          \
-        else if (predict_type == 1 && fusion_mode == 0) ELIMREC_SCORE_RESIDENT2(NB, 1, 0);                 \
-        else if (predict_type == 1 && fusion_mode == 1) ELIMREC_SCORE_RESIDENT2(NB, 1, 1);                 \
-        else if (predict_type == 1) ELIMREC_SCORE_RESIDENT2(NB, 1, 2);                                     \
-        else if (fusion_mode == 0) ELIMREC_SCORE_RESIDENT2(NB, 2, 0);                                      \
-        else if (fusion_mode == 1) ELIMREC_SCORE_RESIDENT2(NB, 2, 1);                                      \
-        else ELIMREC_SCORE_RESIDENT2(NB, 2, 2);                                                            \
-        ELIMREC_LAUNCH_CHECK("score_resident_pass2");                                                      \
-    } while (0)
-        if (S == 1) ELIMREC_SCORE_RESIDENT(2);
-        else if (S == 2) ELIMREC_SCORE_RESIDENT(3);
-        else ELIMREC_SCORE_RESIDENT(4);
-#undef ELIMREC_SCORE_RESIDENT2
-#undef ELIMREC_SCORE_RESIDENT
-    } else if (use_mfma) {
+    } else {
         dim3 grid(tiles, (B + MU - 1) / MU);
         if (own_pass1) {
             hipLaunchKernelGGL(score_mfma_kernel<1>, grid, dim3(256), 0, s, a);
@@ -2137,18 +1875,6 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
         if (phase == 1) return 0;
         hipLaunchKernelGGL(score_mfma_kernel<2>, grid, dim3(256), 0, s, a);
         ELIMREC_LAUNCH_CHECK("score_mfma_pass2");
-    } else {
-        const int vtiles = (int)((I + SI - 1) / SI);
-        dim3 grid(vtiles, (B + SU - 1) / SU);
-        if (own_pass1) {
-            hipLaunchKernelGGL(score_kernel<1>, grid, dim3(256), 0, s, a);
-            ELIMREC_LAUNCH_CHECK("score_pass1");
-            hipLaunchKernelGGL(row_mean_kernel, dim3(B), dim3(256), 0, s, partial, vtiles, B, mean_div, mean_dst);
-            ELIMREC_LAUNCH_CHECK("row_mean");
-        }
-        if (phase == 1) return 0;
-        hipLaunchKernelGGL(score_kernel<2>, grid, dim3(256), 0, s, a);
-        ELIMREC_LAUNCH_CHECK("score_pass2");
     }
     if (d_train_ptr && (d_scores || !tiles_ready)) {       // the caller's score matrix is masked; a private one only if a sweep reads it
         ELIMREC_REQUIRE(d_train_items, "score_topk: train_items missing");

@@ -17,29 +17,11 @@
 
 namespace elimrec {
 
-typedef float v16h __attribute__((ext_vector_type(16)));
 constexpr int HD = 64;            // recdim
-constexpr int HROWS = 32;         // rows per tile
 constexpr int HMAXM = 3;
 
 struct PackJob { const float *W; int64_t ld; int K; int64_t dst; int N; int64_t sn, sk; };   // 16-row form: element (n, k) = W[n*sn + k*sk], N columns
 struct PackJobs { PackJob j[16]; int n; int first_block[17]; };
-
-// fragment-major copy of a [64 x K] weight matrix: element (n, k) at ((n / 32) * (K / 2) + k / 2) * 64 + (k & 1) * 32 + n % 32,
-// i.e. the B operand of MFMA step s of column tile nt is the 64 consecutive floats at ((nt * K/2) + s) * 64
-__global__ __launch_bounds__(256) void pack_head_weights_kernel(PackJobs jobs, float *__restrict__ pk) {
-    int q = 0;
-    while (q + 1 < jobs.n && (int)blockIdx.x >= jobs.first_block[q + 1]) ++q;
-    const PackJob &jb = jobs.j[q];
-    const int64_t total = (int64_t)HD * jb.K;
-    const int nb = jobs.first_block[q + 1] - jobs.first_block[q];
-    for (int64_t e = (int64_t)((int)blockIdx.x - jobs.first_block[q]) * 256 + threadIdx.x; e < total; e += (int64_t)nb * 256) {
-        const int lane = (int)(e & 63);
-        const int64_t blk = e >> 6;                 // nt * (K/2) + s
-        const int nt = (int)(blk / (jb.K / 2)), s = (int)(blk - (int64_t)nt * (jb.K / 2));
-        pk[jb.dst + e] = jb.W[(int64_t)(nt * 32 + (lane & 31)) * jb.ld + 2 * s + (lane >> 5)];
-    }
-}
 
 struct HeadFwdArgs {
     const int32_t *act, *seg_info;
@@ -83,176 +65,11 @@ __device__ __forceinline__ float head_c(const HeadFwdArgs &a, int64_t node) {   
     return widen16(w & 0xFFFFu, a.sdtype) + widen16(w >> 16, a.sdtype);
 }
 
-// acc += A[32 x (2*nsteps)] . B for MFMA steps [s0, s0 + nsteps): A from LDS (row stride folded into ap together with this
-// lane's row / k-parity), B = packed weights (bp = start of the column tile + lane). 16 B operands in flight.
-__device__ __forceinline__ v16h head_mfma_run(v16h acc, const float *ap, const float *__restrict__ bp, int s0, int nsteps) {
-    constexpr int PF = 16;
-    s0 = __builtin_amdgcn_readfirstlane(s0);           // wave-uniform: plain scalar loop control, no exec masking
-    nsteps = __builtin_amdgcn_readfirstlane(nsteps);
-    const float *a0 = ap + 2 * s0;
-    const float *b0 = bp + (int64_t)s0 * 64;
-    float bq[PF];
-    if (nsteps >= PF) {
-#pragma unroll
-        for (int u = 0; u < PF; ++u) bq[u] = b0[u * 64];
-    }
-    int s = 0;
-    for (; s + PF <= nsteps; s += PF) {
-        float bc[PF], av[PF];
-#pragma unroll
-        for (int u = 0; u < PF; ++u) bc[u] = bq[u];
-        if (s + 2 * PF <= nsteps) {                    // the next block's B operands, in flight under this block's MFMAs
-#pragma unroll
-            for (int u = 0; u < PF; ++u) bq[u] = b0[(int64_t)(s + PF + u) * 64];
-        }
-#pragma unroll
-        for (int u = 0; u < PF; ++u) av[u] = a0[2 * (s + u)];
-#pragma unroll
-        for (int u = 0; u < PF; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bc[u], acc, 0, 0, 0);
-    }
-    for (; s < nsteps; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[2 * s], b0[(int64_t)s * 64], acc, 0, 0, 0);
-    return acc;
-}
-
-__global__ __launch_bounds__(256) void head_fwd_fused_kernel(HeadFwdArgs a) {
-    extern __shared__ float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nt = wave & 1, kh = wave >> 1;
-    const int n_act = a.seg_info[0], n_lo = a.seg_info[1];
-    const int tu = (n_lo + HROWS - 1) / HROWS;
-    const int ti = (n_act - n_lo + HROWS - 1) / HROWS;
-    const int t = blockIdx.x;
-    if (t >= tu + ti) return;
-    const bool user = t < tu;
-    const int r0 = user ? t * HROWS : n_lo + (t - tu) * HROWS;
-    const int r1 = min(r0 + HROWS, user ? n_lo : n_act);
-    const int nrows = r1 - r0;
-    const int side = user ? 0 : 1;
-    constexpr int LDA = HD + 1;
-    float *A0 = lds;                                   // out0 rows   [32][65]
-    float *AN = lds + HROWS * LDA;                     // narrow rows [32][65]
-    float *OutT = lds + a.out_off;                     // Out tile    [32][C + 1]
-    float *Part = lds + a.part_off;                    // K-half partial sums [<= 4][32][64]
-    __shared__ float s_c[HROWS];
-    const int C = (1 + a.n_mod) * HD, LDO = C + 1;
-    if (tid < HROWS) s_c[tid] = tid < nrows ? a.c[a.act[r0 + tid]] : 0.f;
-    // ---- load the row tiles: out0, narrow (compact rows) and the folded feature rows S_m[node] (gathered)
-    for (int e = tid; e < HROWS * (HD / 4); e += 256) {
-        const int r = e / (HD / 4), c4 = e % (HD / 4);
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f), y = x;
-        if (r < nrows) {
-            x = *reinterpret_cast<const float4 *>(a.out0 + (int64_t)(r0 + r) * a.ld_out0 + 4 * c4);
-            y = *reinterpret_cast<const float4 *>(a.narrow + (int64_t)(r0 + r) * a.ld_nar + 4 * c4);
-        }
-        float *p = A0 + r * LDA + 4 * c4, *q = AN + r * LDA + 4 * c4;
-        p[0] = x.x; p[1] = x.y; p[2] = x.z; p[3] = x.w;
-        q[0] = y.x; q[1] = y.y; q[2] = y.z; q[3] = y.w;
-        float *o = OutT + r * LDO + 4 * c4;            // block 0 of the Out tile
-        o[0] = x.x; o[1] = x.y; o[2] = x.z; o[3] = x.w;
-    }
-    for (int m = 0; m < a.n_mod; ++m) {
-        const int D4 = a.D[m] / 4, lda = a.D[m] + 1;
-        float *Am = lds + a.a_off[m];
-        for (int e = tid; e < HROWS * D4; e += 256) {
-            const int r = e / D4, c4 = e % D4;
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < nrows) x = *reinterpret_cast<const float4 *>(a.S[m] + (int64_t)a.act[r0 + r] * a.ldS[m] + 4 * c4);
-            float *p = Am + r * lda + 4 * c4;
-            p[0] = x.x; p[1] = x.y; p[2] = x.z; p[3] = x.w;
-        }
-    }
-    __syncthreads();
-    const int ai = lane & 31, ak = lane >> 5;
-    // ---- stage 1: feature blocks, K = D_m split in halves over the wave pairs
-    v16h accm[HMAXM];
-#pragma unroll
-    for (int m = 0; m < HMAXM; ++m) {
-        accm[m] = (v16h){0};
-        if (m < a.n_mod) {
-            const int K = a.D[m], steps = K / 2, hs = (steps + 1) / 2;
-            const int s0 = kh * hs, ns = min(hs, steps - s0);
-            const float *ap = lds + a.a_off[m] + ai * (K + 1) + ak;
-            const float *bp = a.pk + a.off_Wm[m] + (int64_t)nt * steps * 64 + lane;
-            if (ns > 0) accm[m] = head_mfma_run(accm[m], ap, bp, s0, ns);
-        }
-    }
-    if (kh == 1) {
-#pragma unroll
-        for (int m = 0; m < HMAXM; ++m)
-            if (m < a.n_mod)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * ak;
-                    Part[(m * HROWS + row) * HD + nt * 32 + ai] = accm[m][r];
-                }
-    }
-    __syncthreads();
-    if (kh == 0) {
-#pragma unroll
-        for (int m = 0; m < HMAXM; ++m)
-            if (m < a.n_mod) {
-                const int col = nt * 32 + ai;
-                const float bm = a.bias_m[m] ? a.bias_m[m][col] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * ak;
-                    const float v = (accm[m][r] + Part[(m * HROWS + row) * HD + col]) + s_c[row] * bm + AN[row * LDA + col];
-                    OutT[row * LDO + (m + 1) * HD + col] = v;
-                    if (row < nrows) a.OutAct[(int64_t)(r0 + row) * a.ld_out + (m + 1) * HD + col] = v;
-                }
-            }
-    }
-    __syncthreads();
-    // ---- stage 2: fused Linear over the whole Out tile (K = C) and the single-modal heads (K = 64)
-    v16h accy[1 + HMAXM];
-    {
-        const int steps = C / 2, hs = steps / 2;
-        const float *ap = OutT + ai * LDO + ak;
-        const float *bp = a.pk + a.off_Wf[side] + (int64_t)nt * steps * 64 + lane;
-        accy[0] = head_mfma_run((v16h){0}, ap, bp, kh * hs, hs);
-    }
-#pragma unroll
-    for (int m = 0; m < HMAXM; ++m) {
-        accy[1 + m] = (v16h){0};
-        if (m < a.n_mod) {
-            const int steps = HD / 2, hs = steps / 2;
-            const float *ap = OutT + ai * LDO + (m + 1) * HD + ak;
-            const float *bp = a.pk + a.off_Ws[m] + (int64_t)nt * steps * 64 + lane;
-            accy[1 + m] = head_mfma_run(accy[1 + m], ap, bp, kh * hs, hs);
-        }
-    }
-    if (kh == 1) {
-#pragma unroll
-        for (int b = 0; b < 1 + HMAXM; ++b)
-            if (b <= a.n_mod)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * ak;
-                    Part[(b * HROWS + row) * HD + nt * 32 + ai] = accy[b][r];
-                }
-    }
-    __syncthreads();
-    if (kh == 0) {
-        const int col = nt * 32 + ai;
-#pragma unroll
-        for (int b = 0; b < 1 + HMAXM; ++b)
-            if (b <= a.n_mod) {
-                const float *bias = b == 0 ? a.bias_f[side] : a.bias_s[b - 1];
-                const float bb = bias ? bias[col] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * ak;
-                    if (row < nrows) a.YAct[(int64_t)(r0 + row) * a.ld_y + b * HD + col] = (accy[b][r] + Part[(b * HROWS + row) * HD + col]) + bb;
-                }
-            }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------------------
-// The same head on 16-row tiles (default): twice the workgroups, a third of the LDS (three workgroups per CU instead of
-// one), v_mfma_f32_16x16x4_f32, and wave w owns output columns [16w, 16w + 16) of EVERY block over the whole K -- no
-// K-split, no partial-sum exchange, two barriers fewer, every wave takes part in both epilogues. The 32-row form above
-// is a chain of exposed latencies at one wave per SIMD (launch + LDS skeleton 12 us, MFMAs 9, gathers + stores 10).
+// The head on 16-row tiles: v_mfma_f32_16x16x4_f32, wave w owns output columns [16w, 16w + 16) of EVERY block over the whole
+// K -- no K-split, no partial-sum exchange, every wave takes part in both epilogues, three workgroups per CU. (A 32-row form --
+// v_mfma_f32_32x32x2_f32, K split over wave pairs, one workgroup per CU -- was the first fused head and a run-time switch until
+// round 6: a chain of exposed latencies at one wave per SIMD, launch + LDS skeleton 12 us, MFMAs 9, gathers + stores 10; removed.)
 // Packed weights: element (n, k) of a [64 x K] matrix at ((n / 16) * (K / 4) + k / 4) * 64 + (k & 3) * 16 + n % 16,
 // i.e. the B operand of MFMA step s of column tile ct is the 64 consecutive floats at ((ct * K/4) + s) * 64.
 typedef float v4h __attribute__((ext_vector_type(4)));
@@ -472,7 +289,7 @@ static int head_fwd_fused_impl(const elimrec_head_src16 *src, const elimrec_head
     HeadFwdArgs a = {};
     PackJobs pj = {};
     int64_t off = 0;
-    int lds_f = 2 * HROWS * (HD + 1);
+    int lds_f = H16 * (HD + 4);                      // narrow tile first
     int blocks = 0;
     auto add_job_g = [&](const float *W, int N, int K, int64_t sn, int64_t sk) {
         PackJob &j = pj.j[pj.n];
@@ -485,38 +302,34 @@ static int head_fwd_fused_impl(const elimrec_head_src16 *src, const elimrec_head
         return at;
     };
     auto add_job = [&](const float *W, int K) { return add_job_g(W, HD, K, K, 1); };
-    static int form16 = -1;
-    if (form16 < 0) { const char *e = getenv("ELIMREC_HEAD_ROWS"); form16 = (e && atoi(e) == 32) ? 0 : 1; }
-    const int rows_t = form16 ? H16 : HROWS;
-    if (form16) lds_f = H16 * (HD + 4);              // narrow tile first
+    constexpr int rows_t = H16;
     for (int m = 0; m < n_mod; ++m) {
         ELIMREC_REQUIRE((src || (d_S[m] && ldS[m] % 4 == 0)) && d_Wm[m] && d_Ws[m] && D[m] > 0 && D[m] % 4 == 0, "head_fwd_fused: bad feature table %d", m);
         if (!src) { a.S[m] = d_S[m]; a.ldS[m] = ldS[m]; }
         a.s_off[m] = m == 0 ? 0 : a.s_off[m - 1] + D[m - 1];
         a.D[m] = D[m]; a.bias_m[m] = d_bm ? d_bm[m] : nullptr;
         a.a_off[m] = lds_f;
-        lds_f += rows_t * (D[m] + (form16 ? 4 : 1));
+        lds_f += rows_t * (D[m] + 4);
         a.off_Wm[m] = add_job(d_Wm[m], D[m]);
     }
     a.off_Wf[0] = add_job(d_Wf_user, C);
     a.off_Wf[1] = add_job(d_Wf_item, C);
     for (int m = 0; m < n_mod; ++m) { a.off_Ws[m] = add_job(d_Ws[m], HD); a.bias_s[m] = d_bs ? d_bs[m] : nullptr; }
-    if (form16) {        // the head backward's operands B[k][c] = W[k][c] (common.h: head_pack_layout)
-        add_job_g(d_Wf_user, C, HD, 1, C);
-        add_job_g(d_Wf_item, C, HD, 1, C);
-        for (int m = 0; m < n_mod; ++m) add_job_g(d_Ws[m], HD, HD, 1, HD);
-        ELIMREC_REQUIRE(off == head_pack_layout(n_mod, D).total, "head_fwd_fused: pack layout mismatch");
-    }
+    // the head backward's operands B[k][c] = W[k][c] (common.h: head_pack_layout)
+    add_job_g(d_Wf_user, C, HD, 1, C);
+    add_job_g(d_Wf_item, C, HD, 1, C);
+    for (int m = 0; m < n_mod; ++m) add_job_g(d_Ws[m], HD, HD, 1, HD);
+    ELIMREC_REQUIRE(off == head_pack_layout(n_mod, D).total, "head_fwd_fused: pack layout mismatch");
     pj.first_block[pj.n] = blocks;
-    a.out_off = lds_f; lds_f += rows_t * (C + (form16 ? 4 : 1));
-    a.part_off = lds_f; if (!form16) lds_f += (1 + n_mod) * HROWS * HD;
-    if (form16 && phase == 4) {
+    a.out_off = lds_f; lds_f += rows_t * (C + 4);
+    a.part_off = lds_f;
+    if (phase == 4) {
         // the second launch of the two-launch head stages no feature rows: narrow tile + Out tile only (21 KB instead of 51 KB at
         // three 128-d tables: as many workgroups per CU as the registers allow -- a launch of thousands of tiles (large batches) is
         // paced by how many tiles a CU holds; at B = 2048 every tile is resident either way)
         a.out_off = H16 * (HD + 4);
         lds_f = a.out_off + rows_t * (C + 4);
-    } else if (form16 && phase == 3) {
+    } else if (phase == 3) {
         // ... and the first launch stages nothing else: the feature tiles from offset 0
         int at = 0;
         for (int m = 0; m < n_mod; ++m) { a.a_off[m] = at; at += rows_t * (D[m] + 4); }
@@ -526,7 +339,6 @@ static int head_fwd_fused_impl(const elimrec_head_src16 *src, const elimrec_head
     if (lds_bytes > 158 * 1024) { set_error("head_fwd_fused: feature widths need %zu B of LDS", lds_bytes); return ELIMREC_E_UNSUPPORTED; }
     a.act = d_act; a.seg_info = d_seg_info; a.out0 = d_out0; a.ld_out0 = ld_out0; a.narrow = d_narrow; a.ld_nar = ld_nar; a.c = d_c;
     if (src) {
-        if (!form16) { set_error("head_fwd_fused_src16: needs the 16-row form"); return ELIMREC_E_UNSUPPORTED; }
         a.sdtype = src->dtype; a.tab16 = (const uint16_t *)src->d_table; a.row_elems = src->row_elems;
         a.c_off = a.s_off[n_mod - 1] + D[n_mod - 1];
         ELIMREC_REQUIRE(a.c_off + 2 <= src->row_elems && a.c_off % 2 == 0, "head_fwd_fused_src16: rows shorter than sum(D) + 2 elements");
@@ -535,53 +347,38 @@ static int head_fwd_fused_impl(const elimrec_head_src16 *src, const elimrec_head
     a.n_mod = n_mod; a.pk = d_pack; a.bias_f[0] = d_bf_user; a.bias_f[1] = d_bf_item;
     a.OutAct = d_OutAct; a.ld_out = ld_out; a.YAct = d_YAct; a.ld_y = ld_y;
     hipStream_t s = (hipStream_t)stream;
-    if (phase >= 3 && !form16) { set_error("head_fwd_fused: phases 3 / 4 need the 16-row form"); return ELIMREC_E_UNSUPPORTED; }
     a.stage = phase == 3 ? 1 : (phase == 4 ? 2 : 0);
     if (phase < 2) {
-        if (form16) hipLaunchKernelGGL(pack_head_weights16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pj, d_pack);
-        else hipLaunchKernelGGL(pack_head_weights_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pj, d_pack);
+        hipLaunchKernelGGL(pack_head_weights16_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pj, d_pack);
         ELIMREC_LAUNCH_CHECK("pack_head_weights");
     }
     if (phase == 1) return 0;
-    if (form16) {
-        static size_t lds_set16 = 0;
-        if (lds_bytes > 64 * 1024 && lds_bytes > lds_set16) {
-            hipError_t e = hipFuncSetAttribute((const void *)head_fwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            if (e != hipSuccess) return check_hip(e, "head_fwd_fused: LDS size");
-            lds_set16 = lds_bytes;
+    static size_t lds_set16 = 0;
+    if (lds_bytes > 64 * 1024 && lds_bytes > lds_set16) {
+        hipError_t e = hipFuncSetAttribute((const void *)head_fwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return check_hip(e, "head_fwd_fused: LDS size");
+        lds_set16 = lds_bytes;
+    }
+    const unsigned tiles = (unsigned)((R + H16 - 1) / H16 + 2);     // user tiles + item tiles <= R/16 + 2
+    if (rows) {
+        RowsArgs ra = {};
+        int rc = rows_args_fill("head_fwd_fused_rows", rows->A, rows->ns, rows->w, rows->L, rows->U, rows->layers, rows->d_long, ra);
+        if (rc) return rc;
+        ELIMREC_REQUIRE(ra.nc4 == HD / 4 && rows->d_narrow_out && rows->ld_narrow_out % 4 == 0 && phase == 4,
+                        "head_fwd_fused_rows: %d table columns per row, a narrow buffer, phase 4", HD);
+        ra.narrow = rows->d_narrow_out; ra.ld_narrow = rows->ld_narrow_out;
+        static size_t lds_set16r = 0;
+        if (lds_bytes > 64 * 1024 && lds_bytes > lds_set16r) {
+            hipError_t e = hipFuncSetAttribute((const void *)head_rows_fwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return check_hip(e, "head_fwd_fused_rows: LDS size");
+            lds_set16r = lds_bytes;
         }
-        const unsigned tiles = (unsigned)((R + H16 - 1) / H16 + 2);     // user tiles + item tiles <= R/16 + 2
-        if (rows) {
-            RowsArgs ra = {};
-            int rc = rows_args_fill("head_fwd_fused_rows", rows->A, rows->ns, rows->w, rows->L, rows->U, rows->layers, rows->d_long, ra);
-            if (rc) return rc;
-            ELIMREC_REQUIRE(ra.nc4 == HD / 4 && rows->d_narrow_out && rows->ld_narrow_out % 4 == 0 && phase == 4,
-                            "head_fwd_fused_rows: %d table columns per row, a narrow buffer, phase 4", HD);
-            ra.narrow = rows->d_narrow_out; ra.ld_narrow = rows->ld_narrow_out;
-            static size_t lds_set16r = 0;
-            if (lds_bytes > 64 * 1024 && lds_bytes > lds_set16r) {
-                hipError_t e = hipFuncSetAttribute((const void *)head_rows_fwd16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-                if (e != hipSuccess) return check_hip(e, "head_fwd_fused_rows: LDS size");
-                lds_set16r = lds_bytes;
-            }
-            hipLaunchKernelGGL(head_rows_fwd16_kernel, dim3(tiles), dim3(256), lds_bytes, s, a, ra);
-            ELIMREC_LAUNCH_CHECK("head_rows_fwd16");
-            return 0;
-        }
-        hipLaunchKernelGGL(head_fwd16_kernel, dim3(tiles), dim3(256), lds_bytes, s, a);
-        ELIMREC_LAUNCH_CHECK("head_fwd16");
+        hipLaunchKernelGGL(head_rows_fwd16_kernel, dim3(tiles), dim3(256), lds_bytes, s, a, ra);
+        ELIMREC_LAUNCH_CHECK("head_rows_fwd16");
         return 0;
     }
-    if (rows) { set_error("head_fwd_fused_rows: needs the 16-row form"); return ELIMREC_E_UNSUPPORTED; }
-    static size_t lds_set = 0;
-    if (lds_bytes > 64 * 1024 && lds_bytes > lds_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)head_fwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return check_hip(e, "head_fwd_fused: LDS size");
-        lds_set = lds_bytes;
-    }
-    const unsigned tiles = (unsigned)((R + HROWS - 1) / HROWS + 1);      // user tiles + item tiles <= R/32 + 2
-    hipLaunchKernelGGL(head_fwd_fused_kernel, dim3(tiles + 1), dim3(256), lds_bytes, s, a);
-    ELIMREC_LAUNCH_CHECK("head_fwd_fused");
+    hipLaunchKernelGGL(head_fwd16_kernel, dim3(tiles), dim3(256), lds_bytes, s, a);
+    ELIMREC_LAUNCH_CHECK("head_fwd16");
     return 0;
 }
 

@@ -736,24 +736,12 @@ static SideStream &side_stream() {
 }
 static inline size_t narrow_partials_offset(const elimrec_csr *m, int C) { return (size_t)m->split.n_seg * C; }
 
-static int g_ticket_fixup = -1;
-extern "C" int elimrec_ticket_fixup(void) {
-    if (g_ticket_fixup < 0) {
-        const char *e = getenv("ELIMREC_TICKET_FIXUP");
-        g_ticket_fixup = (e && e[0] == '0') ? 0 : 1;
-    }
-    return g_ticket_fixup;
-}
+static int g_ticket_fixup = 1;
+extern "C" int elimrec_ticket_fixup(void) { return g_ticket_fixup; }
 extern "C" void elimrec_set_ticket_fixup(int on) { g_ticket_fixup = on ? 1 : 0; }
 
-static int g_concurrency = -1;
-extern "C" int elimrec_concurrency(void) {
-    if (g_concurrency < 0) {
-        const char *e = getenv("ELIMREC_CONCURRENCY");
-        g_concurrency = (e && e[0] == '1') ? 1 : 0;     // measured: +0.6 % at the Tiktok shape, so off by default
-    }
-    return g_concurrency;
-}
+static int g_concurrency = 0;                            // measured: +0.6 % at the Tiktok shape, so off by default
+extern "C" int elimrec_concurrency(void) { return g_concurrency; }
 extern "C" void elimrec_set_concurrency(int on) { g_concurrency = on ? 1 : 0; }
 
 static int bwd_narrow_chain(const elimrec_csr *PT, const elimrec_csr *QT, int L, int C, int d4, const float *H_u,

@@ -54,27 +54,24 @@ class UniEvaluator(object):
         # share every item tile through L2 and amortises the launches and the users' operand loads of every catalogue chunk
         # (128: 0.048 s, 1024: 0.036 s, 2048: 0.0335 s per validation pass at the Tiktok shape with EXACT math; with the default
         # math 2048: 0.0271, 4096: 0.0258, 8192: 0.0253, 32768: 0.0250 -- 8192 users x 16384 items is a 537 MB score block)
-        import os
-        self.block_users = max(int(batch_size), int(os.environ.get("ELIMREC_EVAL_BLOCK", 8192)))
+        self.block_users = max(int(batch_size), 8192)
+        self.workspace_gib = 8.0                # the scorer's workspace budget: users per launch are halved until it fits
         self.max_top = top_k if isinstance(top_k, int) else max(top_k)
         self.top_show = np.arange(top_k) + 1 if isinstance(top_k, int) else np.sort(top_k)
         self._dev_cache = {}
         self._default_users = None
         # ties among equal scores: "reference" (default) = the reference's lists (evaluate.h:26-33's partial_sort_copy replayed on
-        # the device, every row); "id" = the device's own rule (score descending, item id ascending) (--tie_order / ELIMREC_TIE_ORDER)
-        import os as _os
-        self.tie_order = _os.environ.get("ELIMREC_TIE_ORDER", "reference")
-        if self.tie_order not in ("id", "reference"):
-            raise ValueError("ELIMREC_TIE_ORDER must be id or reference")
+        # the device, every row); "id" = the device's own rule (score descending, item id ascending) (--tie_order)
+        self.tie_order = "reference"
         self.tie_rows_replayed = 0
         # the default scorer (dot products as six bf16 piece products, csrc/eval.hip score_t16b_kernel) returned a wrong score once
         # in round 3 on one device and never again in 49 000 replays: every evaluation re-scores its first
         # users with the fp32-MFMA scorer and compares the K returned scores -- a difference beyond the two forms' round-off is
-        # counted, logged, and the rest of the evaluation runs on the fp32 scorer (ELIMREC_SCORER_CHECK=0: no check)
-        self.scorer_check_users = int(_os.environ.get("ELIMREC_SCORER_CHECK", 1024))
-        # ... in the first evaluation of a run and in every 16th after it (ELIMREC_SCORER_CHECK_EVERY): the check re-scores 1024 users
-        # with the slower scorer, 0.8 ms of a 13 ms pass at the Tiktok shape
-        self.scorer_check_every = max(1, int(_os.environ.get("ELIMREC_SCORER_CHECK_EVERY", 16)))
+        # counted, logged, and the rest of the evaluation runs on the fp32 scorer (scorer_check_users = 0: no check)
+        self.scorer_check_users = 1024
+        # ... in the first evaluation of a run and in every 16th after it: the check re-scores 1024 users with the slower scorer,
+        # 0.8 ms of a 13 ms pass at the Tiktok shape
+        self.scorer_check_every = 16
         self._evaluations = 0
         self.scorer_checked_rows = self.scorer_mismatch_rows = 0
         self.range_violations = 0          # scorer waves that saw a score outside their launch's range invariant, over all passes
@@ -229,16 +226,15 @@ class UniEvaluator(object):
 
     def _users_per_launch(self, model):
         """block_users, halved until the scorer's workspace for this catalogue (or this rank's item shard) fits the budget
-        (ELIMREC_EVAL_WS_GB, default 8): a recdim outside the chunked scorer's set needs a [users x items] score block, which
+        (workspace_gib, default 8): a recdim outside the chunked scorer's set needs a [users x items] score block, which
         at 12.5 M items per rank is 50 MB per user."""
-        import os
         block = self.block_users
         sh = getattr(model, "_eval_shard", None)
         # (item shards differ by one item between ranks when I % W != 0, and the sharded scorer's collectives run once per user
         # block: the block size must come out the same on every rank, so it is sized from the LARGEST shard)
         bounds = getattr(sh, "bounds", None)
         n_items = (max(b - a for a, b in zip(bounds[:-1], bounds[1:])) if bounds else sh.i1 - sh.i0) if sh is not None else model.num_items
-        budget = float(os.environ.get("ELIMREC_EVAL_WS_GB", 8)) * 2 ** 30
+        budget = float(self.workspace_gib) * 2 ** 30
         while block > 16 and ops.score_workspace(block, model.num_users, n_items, model.S, self.max_top, topk_only=True,
                                                  d=model.latent_dim) > budget:
             block //= 2

@@ -1147,7 +1147,7 @@ class EliMRec(BasicModel):
             return None, None
         # top-K only (the evaluator): no [B x I] score block in the workspace, the catalogue is scored in chunks
         import os
-        chunked = scores is None and top_k > 0 and os.environ.get("ELIMREC_SCORE_CHUNKED", "1") != "0"
+        chunked = scores is None and top_k > 0
         need = ops.score_workspace(B, self.num_users, I, self.S, max(top_k, 1), topk_only=chunked, d=self.latent_dim)
         if self._ws.get("score_ws") is None or self._ws["score_ws"].numel() < need:
             self._ws["score_ws"] = torch.empty(need, dtype=torch.uint8, device=dev)

@@ -181,8 +181,7 @@ def assemble_x0(user_emb, item_emb, X0, M):
     return X0
 
 
-import os as _os
-LONG_ROW_THRESHOLD = int(_os.environ.get("ELIMREC_LONG_ROW", "64"))   # rows with more non-zeros are split across waves (csrc/spmm.hip)
+LONG_ROW_THRESHOLD = 64   # rows with more non-zeros are split across waves (csrc/spmm.hip)
 
 
 class Csr:

@@ -668,6 +668,7 @@ class ColumnShardEngine(object):
         self.world = None
 
     loss_ring_len = LOSS_RING      # the loss tensor a step returns is overwritten that many steps later
+    materialize_rows = 1 << 18     # rows per owner and all_to_all when the cached tables are materialised row-sharded
     mask = property(lambda self: self._masks[self.cur])
 
     # ------------------------------------------------------------------ set-up
@@ -758,7 +759,7 @@ class ColumnShardEngine(object):
         self._adam_in_hop = False
         self._out0_src = self._nar_src = None
         self._pairs = {}
-        self._head16 = os.environ.get("ELIMREC_HEAD_ROWS", "16") != "32"
+        self._head16 = True                     # (the fused head's 16-row form; the 32-row form was removed in round 6)
         self._split_head = os.environ.get("ELIMREC_HEAD_SPLIT", "1") != "0"     # feature blocks of the head beside the forward hops
         self._head_split = False
         # ... and the layer means of the active rows evaluated by the head's main-stream launch itself (no rows launch): one rank
@@ -919,8 +920,7 @@ class ColumnShardEngine(object):
             self._pack_bwd_off = 0
             if self._fused:
                 self._pack = torch.empty(ops.head_pack_floats(dims), dtype=torch.float32, device=m._device())
-                if os.environ.get("ELIMREC_HEAD_ROWS", "16") != "32" and os.environ.get("ELIMREC_HEAD_BWD_ROWS", "16") != "32":
-                    self._pack_bwd_off = ops.head_pack_bwd_offset(dims)
+                self._pack_bwd_off = ops.head_pack_bwd_offset(dims)
         return self._fused
 
     def _aux_stream(self):
@@ -979,7 +979,7 @@ class ColumnShardEngine(object):
         merge rides in the weight-gradient launch)."""
         import os
         return (not self.multi and not self.wide and self._fused_head_ok() and bool(self._pack_bwd_off) and self.model.latent_dim == 64
-                and os.environ.get("ELIMREC_HEAD_SOURCES", "1") != "0" and os.environ.get("ELIMREC_HEAD_BWD_ROWS", "16") != "32")
+                and os.environ.get("ELIMREC_HEAD_SOURCES", "1") != "0")
 
     @_once
     def _loss_sum_late(self):
@@ -991,7 +991,7 @@ class ColumnShardEngine(object):
     def _split_in_head(self):
         import os
         return (not self.wide and self._fused_head_ok() and bool(self._pack_bwd_off) and self.model.latent_dim == 64
-                and os.environ.get("ELIMREC_HEAD_SOURCES", "1") != "0" and os.environ.get("ELIMREC_HEAD_BWD_ROWS", "16") != "32")
+                and os.environ.get("ELIMREC_HEAD_SOURCES", "1") != "0")
 
     @_once
     def _fuse_merge(self):
@@ -1893,7 +1893,7 @@ class ColumnShardEngine(object):
         """Row-sharded constants: the cached tables are built ROW-sharded too -- every rank computes Out / Y for the nodes it
         owns (its users, its items) from its own rows of S_m / c, and evaluation runs item-sharded (shard_eval.py).
         rows_of(node ids, out0, narrow): (layer mean | shared part) of listed rows in MY columns. In chunks of
-        ELIMREC_MATERIALIZE_ROWS of every owner's rows (the transient stays a few GiB whatever N is): one all_to_all hands
+        `materialize_rows` (2^18) of every owner's rows (the transient stays a few GiB whatever N is): one all_to_all hands
         every owner its chunk's rows of every rank's columns (the column shards' transpose), the projections run on the
         chunk, and one all_gather at the end replicates the users' Y rows (every rank scores all users against its items)."""
         import os
@@ -1912,7 +1912,7 @@ class ColumnShardEngine(object):
         Yu_loc, Yi = torch.empty(nu, Cy, dtype=torch.float32, device=dev), Yshard[U:]
         Wt = ws["snap_views"]                                       # the weights the last forward used (predict() is stale)
         wu, wi = m._fusion_weights(Wt)
-        step = max(1024, int(os.environ.get("ELIMREC_MATERIALIZE_ROWS", 1 << 18)))
+        step = self.materialize_rows
         for r0 in range(0, max(rows), step):
             span = [(min(r0, n), min(r0 + step, n)) for n in rows]          # this chunk of every owner's local rows
             cnt = [b - a for a, b in span]

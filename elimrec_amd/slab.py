@@ -16,7 +16,7 @@ from .ops import _dev, _stream
 
 # rows with more non-zeros are cut into segments of this length: the longest work item bounds a hop's critical path
 # (32: 21 us per hop on an 8-column shard at the Tiktok shape; 64: 29 us; 16: 40 us -- too many partial rows)
-LONG_ROW_THRESHOLD = int(os.environ.get("ELIMREC_SLAB_LONG_ROW", "32"))
+LONG_ROW_THRESHOLD = 32
 
 
 def choose_slabs(dl, n_rows=None):
@@ -76,8 +76,8 @@ class SellPlan(object):
         T = int(threshold)
         # a wave per row up to 64 neighbours per lane group at 8 groups (measured: 0.319 against 0.322 ms per step with 32),
         # 32 with more, narrower groups (column shards; not re-measured)
-        T1 = int(os.environ.get("ELIMREC_SLAB_T1", (64 if ipw <= 8 else 32) * ipw)) if tiered else T
-        T2 = int(os.environ.get("ELIMREC_SLAB_T2", 256 * ipw)) if tiered else T
+        T1 = (64 if ipw <= 8 else 32) * ipw if tiered else T
+        T2 = 256 * ipw if tiered else T
         long_rows = np.nonzero(deg > T)[0]
         short_rows = np.nonzero(deg <= T)[0]
         if rows_from:                # a plan of rows [rows_from, n) only: the rows below belong to another launch (SweepPlan)
@@ -88,7 +88,7 @@ class SellPlan(object):
         w1 = w1[np.argsort(-deg[w1], kind="stable")]
         w4 = w4[np.argsort(-deg[w4], kind="stable")]
         # segments of the split rows (tiered: of the rows above T2 only): slot numbers run row by row, segment by segment
-        TS = int(os.environ.get("ELIMREC_SLAB_SEGT", T)) if tiered else T      # segment length of the rows above T2
+        TS = T                                                                 # segment length of the rows above T2
         nseg = np.where(deg[long_rows] > T2, (deg[long_rows] + TS - 1) // TS, 0) if tiered else (deg[long_rows] + T - 1) // T
         seg_ptr = np.concatenate([[0], np.cumsum(nseg)]).astype(np.int64)
         n_seg = int(seg_ptr[-1])
@@ -156,9 +156,9 @@ class SellPlan(object):
         dev = rowptr.device
         n_rows = int(rowptr.numel()) - 1
         T = int(threshold)
-        T1 = int(os.environ.get("ELIMREC_SLAB_T1", (64 if ipw <= 8 else 32) * ipw))
-        T2 = int(os.environ.get("ELIMREC_SLAB_T2", 256 * ipw))
-        TS = int(os.environ.get("ELIMREC_SLAB_SEGT", T))
+        T1 = (64 if ipw <= 8 else 32) * ipw
+        T2 = 256 * ipw
+        TS = T
         G = int(ipw)
         split = -1 if side_split is None else int(side_split)
         i32 = lambda n: torch.empty(max(int(n), 1), dtype=torch.int32, device=dev)
@@ -334,7 +334,7 @@ class SweepPlan(object):
     item rows). Row blocks and entry streams depend on the table geometry (LDS rows per workgroup, XCD roles per slab) and are
     made per (ns, w)."""
 
-    BPX = int(os.environ.get("ELIMREC_SWEEP_BPX", "32"))            # workgroups per XCD role (32 CUs per XCD)
+    BPX = 32                                                          # workgroups per XCD role (32 CUs per XCD)
 
     def __init__(self, plan, m, n_sweep, device, threshold, ipw):
         m = m.tocsr()

@@ -214,11 +214,11 @@ int elimrec_propagate_bipartite(const elimrec_csr *P, const elimrec_csr *Q, int6
                                 void *d_workspace, size_t workspace_bytes, void *stream);
 
 /* The C-column and d-column chains of the bipartite propagation are independent for most of a call;
- * optionally (elimrec_set_concurrency(1) or ELIMREC_CONCURRENCY=1; default off -- the step is bandwidth
+ * optionally (elimrec_set_concurrency(1); default off -- the step is bandwidth
  * bound, measured gain 0.6 %) the d-column chain runs on an internal side stream forked from / joined to
  * `stream` with events (capturable). The row-split scratch d_partials must hold [n_seg x 2C] floats. */
 int elimrec_ticket_fixup(void);               /* 1 (default): in-launch combine when d_tickets is given */
-void elimrec_set_ticket_fixup(int on);        /* also ELIMREC_TICKET_FIXUP=0 */
+void elimrec_set_ticket_fixup(int on);
 int elimrec_concurrency(void);
 void elimrec_set_concurrency(int on);
 
@@ -465,7 +465,7 @@ int elimrec_score_get_math(void);
 /* FAST math, chunked top-K (no score matrix), recdim 32 / 64: both scorer passes run on the bf16 matrix cores from EXACT
  * three-piece splits of the fp32 operands (x = x1 + x2 + x3, bf16 each; the six piece products above 2^-24 relative,
  * accumulated in fp32): the same scores to fp32 round-off (within 2.4e-7 of the EXACT mode, tests) at 2.7x less matrix-core
- * time. On by default (env ELIMREC_SCORE_BF16X3=0 or this switch turn it off); needs the workspace of
+ * time. On by default (this switch turns it off); needs the workspace of
  * elimrec_score_workspace_for (room for one chunk's pieces), otherwise the fp32 MFMA form runs. */
 void elimrec_score_set_bf16x3(int on);
 int elimrec_score_get_bf16x3(void);

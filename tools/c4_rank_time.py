@@ -42,6 +42,9 @@ for W in [int(x) for x in sys.argv[1:]] or [1, 8]:
 
         def step(i):
             act = eng.cs_plan(u[i * B:(i + 1) * B], p[i * B:(i + 1) * B], n[i * B:(i + 1) * B])
+            ps = eng.plan_stream()
+            if ps is not None:                            # the planner ran on the second stream: the copy below reads its list
+                torch.cuda.current_stream().wait_stream(ps)
             acts = act.view(1, -1).expand(W, -1).contiguous()
             eng.cs_gathered_ids(acts, _Done())            # second stream, as the trainer does behind the id exchange: row bitmap + source bits
             eng.cs_forward_hops()

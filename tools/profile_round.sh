@@ -3,9 +3,9 @@
 # Kernel stats and PMC counters in SEPARATE rocprofv3 runs (no --pmc together with trace domains).
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${ROUND:-r05}; rm -rf $O; mkdir -p $O
-B="python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-reference-work --no-b-sweep --no-reduced-precision"
+B="python3 $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-reference-work --no-b-sweep --no-projection --no-reduced-precision"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o b -- $B > $O/bench_stats.log 2>&1 < /dev/null
-P="python3 $R/bench.py --steps 9 --warmup 1 --no-cpu-baseline --no-reference-work --no-eval --no-b-sweep --no-reduced-precision"
+P="python3 $R/bench.py --steps 9 --warmup 1 --no-cpu-baseline --no-reference-work --no-eval --no-b-sweep --no-projection --no-reduced-precision"
 timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -o p -- $P > /dev/null 2>&1 < /dev/null
 timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -o p -- $P > /dev/null 2>&1 < /dev/null
 timeout 400 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/mfma -o p -- $P > /dev/null 2>&1 < /dev/null

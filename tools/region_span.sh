@@ -2,7 +2,7 @@
 # On the GPU box: the 20-step timed region of bench.py under --kernel-trace: GPU span of the region against the wall clock the line reports.
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/region; rm -rf $O; mkdir -p $O
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O -o r -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-reference-work --no-b-sweep --no-reduced-precision --no-eval > $O/run.log 2>/dev/null < /dev/null
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O -o r -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-reference-work --no-b-sweep --no-projection --no-reduced-precision --no-eval > $O/run.log 2>/dev/null < /dev/null
 f=$(find $O -name "*kernel_trace.csv" | head -1)
 python3 - "$f" "$O/run.log" <<'PY'
 import csv, json, sys
