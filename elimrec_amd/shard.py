@@ -759,7 +759,6 @@ class ColumnShardEngine(object):
         self._adam_in_hop = False
         self._out0_src = self._nar_src = None
         self._pairs = {}
-        self._head16 = True                     # (the fused head's 16-row form; the 32-row form was removed in round 6)
         self._split_head = os.environ.get("ELIMREC_HEAD_SPLIT", "1") != "0"     # feature blocks of the head beside the forward hops
         self._head_split = False
         # ... and the layer means of the active rows evaluated by the head's main-stream launch itself (no rows launch): one rank
@@ -805,7 +804,7 @@ class ColumnShardEngine(object):
         # shape of the fp32 one (feature blocks beside the forward hops, rows evaluated by the head's launch); the head's feature
         # launch leaves the widened rows behind for the backward half's weight gradients
         self._direct16 = bool(self.lookup and self.fshard is not None and self.fshard.code != 0 and not self.multi
-                              and self.fshard.owners.world == 1 and not self.wide and self._head16
+                              and self.fshard.owners.world == 1 and not self.wide
                               and os.environ.get("ELIMREC_DIRECT16", "1") != "0")
         # data set "tiktok": word_embedding keeps receiving the gradient the reference's retained graph gives it (default), or stays
         # frozen (--word_embedding=frozen)
@@ -1087,7 +1086,7 @@ class ColumnShardEngine(object):
                 m._region("cs_plan", (m._ws_gen, users.data_ptr(), pos.data_ptr(), neg.data_ptr(), R), plan)
             if self._fused_head_ok():
                 m._region("cs_pack", (m._ws_gen, R), pack)
-                self._head_split = self._head16 and (not self.lookup or self._direct16) and self._split_head
+                self._head_split = (not self.lookup or self._direct16) and self._split_head
                 if self._head_split:
                     m._region("cs_head_features", (m._ws_gen, R), features)
                 self._rows_in_head = (self._head_split and self._rows_in_head_on and not self.multi and not self.wide
@@ -1288,23 +1287,20 @@ class ColumnShardEngine(object):
         if recv is not None:                                      # [W, R, (out0 | narrow)] -> my rows, all columns
             W = recv.shape[0]
             r = recv.view(W, R, 2, self.dl)
-            if fused and self._head16:
+            if fused:
                 # one pass: [R, (out0 | narrow), d]; the fused head reads both halves with a 2d row stride and writes
                 # block 0 of OutAct itself
                 pair = self._pair(R, d)
                 ops.peer_cols_to_rows(recv.view(W, R, 2 * self.dl), pair[:, 0, :], pair[:, 1, :])
                 self._out0_src, self._nar_src = pair[:, 0, :], pair[:, 1, :]
-            elif fused or self.lookup:
+            elif self.lookup:
                 ops.peer_cols_to_rows(recv.view(W, R, 2 * self.dl), ws["OutAct"][:R, :d], self.nar_act[:R])
                 self._out0_src = self._nar_src = None
             else:
                 ws["OutAct"][:R, :d].unflatten(1, (W, self.dl)).copy_(r[:, :, 0].permute(1, 0, 2))
-                if fused or self.lookup:
-                    self.nar_act.unflatten(1, (W, self.dl)).copy_(r[:, :, 1].permute(1, 0, 2))
-                else:
-                    act = ws["active_rows"][:R].long()
-                    idx = torch.where(act >= 0, act, torch.full_like(act, self.narrow_x.shape[0] - 1))
-                    self.narrow_x.index_copy_(0, idx, r[:, :, 1].permute(1, 0, 2).reshape(R, d))
+                act = ws["active_rows"][:R].long()
+                idx = torch.where(act >= 0, act, torch.full_like(act, self.narrow_x.shape[0] - 1))
+                self.narrow_x.index_copy_(0, idx, r[:, :, 1].permute(1, 0, 2).reshape(R, d))
                 self._out0_src = self._nar_src = None
         else:
             self._out0_src = self._nar_src = None
