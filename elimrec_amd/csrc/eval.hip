@@ -1298,9 +1298,20 @@ __global__ __launch_bounds__(256) void ref_order_kernel(const float *__restrict_
     if (TILES) {
         const float *tmx = tile_max + (int64_t)b * tmax_ld;
         const int64_t n_tiles = (n + TI - 1) / TI;
-        for (int64_t tb = (start / TI) & ~(int64_t)63; tb < n_tiles; tb += 64) {
-            const int64_t t = tb + lane;
-            const float tm = (t < n_tiles && t >= start / TI) ? tmx[t] : -INFINITY;
+        // (the maxima of 8 x 64 tiles are fetched at once: the loads of a chunk's 1024 tiles are two round trips, not sixteen
+        // dependent ones -- the kernel is a chain of latencies, one wave per user)
+        constexpr int PF = 8;
+        for (int64_t tb0 = (start / TI) & ~(int64_t)63; tb0 < n_tiles; tb0 += 64 * PF) {
+            float tmv[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int64_t t = tb0 + 64 * u + lane;
+                tmv[u] = (t < n_tiles && t >= start / TI) ? tmx[t] : -INFINITY;
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+            const int64_t tb = tb0 + 64 * u;
+            const float tm = tmv[u];
             unsigned long long m = __builtin_amdgcn_ballot_w64(tm > top);
             while (m) {
                 const int j = __builtin_ctzll(m);
@@ -1319,19 +1330,30 @@ __global__ __launch_bounds__(256) void ref_order_kernel(const float *__restrict_
                     }
                 }
             }
+            }
         }
     } else {
-        for (int64_t base = start; base < n; base += 64) {
-            const int64_t i = base + lane;
-            const float v = i < n ? score_at(i) : -INFINITY;
-            unsigned long long m = __builtin_amdgcn_ballot_w64(v > top);
-            while (m) {
-                const int j = __builtin_ctzll(m);
-                m &= m - 1;
-                const float vj = lane_value(v, j);
-                if (vj > top) {
-                    h.adjust(0, K, vj, (int)(item0 + base + j));
-                    top = h.v[0];
+        constexpr int PF = 8;                              // 8 x 64 scores in flight per round trip
+        for (int64_t base0 = start; base0 < n; base0 += 64 * PF) {
+            float vv[PF];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int64_t i = base0 + 64 * u + lane;
+                vv[u] = i < n ? score_at(i) : -INFINITY;
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int64_t base = base0 + 64 * u;
+                const float v = vv[u];
+                unsigned long long m = __builtin_amdgcn_ballot_w64(v > top);
+                while (m) {
+                    const int j = __builtin_ctzll(m);
+                    m &= m - 1;
+                    const float vj = lane_value(v, j);
+                    if (vj > top) {
+                        h.adjust(0, K, vj, (int)(item0 + base + j));
+                        top = h.v[0];
+                    }
                 }
             }
         }
