@@ -1553,8 +1553,8 @@ static bool score_t16_path(int d, int S) {
 static bool score_chunked_form(int d, int S, int K, int64_t I, bool want_scores, bool want_topk) {
     return score_t16_path(d, S) && score_uses_chunks() && !want_scores && want_topk && K <= RM_KMAX && I > SCORE_CHUNK;
 }
-static bool score_matrix_chunks(int d, int S, int64_t I, bool want_scores) {
-    return score_t16_path(d, S) && score_uses_chunks() && want_scores && I > SCORE_CHUNK;
+static bool score_matrix_chunks(int d, int S, int64_t I) {
+    return score_t16_path(d, S) && score_uses_chunks() && I > SCORE_CHUNK;
 }
 
 // Bytes elimrec_score_topk needs for THIS call shape: recdim d, K, and whether the caller passes a score matrix
@@ -1603,7 +1603,7 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
     const bool chunked = score_chunked_form(d, S, K, I, d_scores != nullptr, d_topk_idx != nullptr);
     // the score MATRIX of a catalogue beyond one chunk goes through the same launches, chunk by chunk, every tile stored: the rows
     // predict() returns are then the bits the chunked top-K ranks (one score form per call shape, whatever the caller asks for)
-    const bool matrix_chunks = score_matrix_chunks(d, S, I, d_scores != nullptr);
+    const bool matrix_chunks = !chunked && score_matrix_chunks(d, S, I);      // (a [B x I] block, the caller's or -- K > 256 -- a private one)
     ScoreLayout L = score_layout(B, U, I, S, K, chunked);
     if (phase == 1) {        // row sums only: no score block is touched -- the chunked layout (no [B x I] block) will do as well
         const ScoreLayout Lc = score_layout(B, U, I, S, K, true);
@@ -1822,9 +1822,9 @@ static int score_topk_impl(const float *d_Y, int64_t ldy, int64_t U, int64_t I, 
                 ac.item_end = ac.item0 + len < I ? ac.item0 + len : I;
                 at = ac.item_end;
                 if (chunked) ac.thr = c == 0 ? nullptr : thrbuf;
-                else {                                                   // this chunk's columns of the caller's matrix
-                    ac.scores = d_scores + ac.item0;
-                    ac.lds = lds;
+                else {                                                   // this chunk's columns of the [B x I] block
+                    ac.scores = a.scores + ac.item0;
+                    ac.lds = a.lds;
                     ac.thr = nullptr;
                     if (a.tile_max) ac.tile_max = a.tile_max + ac.item0 / TI;
                 }

@@ -1197,7 +1197,9 @@ def test_topk_only_workspace_fits_any_recdim_and_k(d, K):
                    train_items=masked.to(DEV))
     order = np.argsort(-sc, axis=1, kind="stable")[:, :K]
     from elimrec_amd import _lib
-    b3 = d in (32, 64) and K <= 256 and _lib.load().elimrec_score_get_math() == 1 and _lib.load().elimrec_score_get_bf16x3() == 1
+    # (recdim 32 / 64 with a workspace sized for the recdim: every call shape -- K beyond 256 too, since round 6 -- goes through the
+    #  chunk launches on the bf16 matrix cores; `sc` above came from a workspace without room for the pieces: the fp32 form)
+    b3 = d in (32, 64) and _lib.load().elimrec_score_get_math() == 1 and _lib.load().elimrec_score_get_bf16x3() == 1
     if not b3:
         assert np.array_equal(idx.cpu().numpy(), order)
         assert np.array_equal(val.cpu().numpy(), np.take_along_axis(sc, order, 1))
@@ -1206,6 +1208,14 @@ def test_topk_only_workspace_fits_any_recdim_and_k(d, K):
         assert np.abs(got_v - np.take_along_axis(sc, got_i, 1)).max() < 2.4e-7
         for r in np.nonzero((got_i != order).any(1))[0]:
             assert np.abs(sc[r][got_i[r]] - sc[r][order[r]]).max() < 4.8e-7, r
+    # the reference's order on the same call shapes (K = 300: the whole-catalogue form with the item-by-item scan; recdim 48 / 256:
+    # the generic scorer's masked matrix): the oracle's ranking of the matrix the SAME workspace shape returns
+    ws_m = torch.empty(ops.score_workspace(B, U, I, S, K, d=d), dtype=torch.uint8, device=DEV)
+    ops.score_topk(Y, U, I, users, d, S, 0b111, "rubi", "TIE", ws_m, scores=ref, train_ptr=ptr.to(DEV), train_items=masked.to(DEV))
+    want = _reference_lists(ref.cpu().numpy(), K)
+    ops.score_topk(Y, U, I, users, d, S, 0b111, "rubi", "TIE", ws, K=K, topk_idx=idx, topk_val=val, train_ptr=ptr.to(DEV),
+                   train_items=masked.to(DEV), tie_order="reference")
+    assert np.array_equal(idx.cpu().numpy(), want)
 
 
 @pytest.mark.gpu

@@ -1295,8 +1295,9 @@ def test_16bit_feature_storage_equals_fp32_engine_on_rounded_constants(dtype, na
     assert np.abs(np.array(res["stored"][0]) - np.array(res["plain"][0])).max() < 2e-3
 
 
+@pytest.mark.parametrize("form", ["split+rows", "split", "one-launch"])
 @pytest.mark.parametrize("dtype", ["f16", "bf16"])
-def test_16bit_constants_read_by_the_head_equal_the_widening_pass_bitwise(dtype, monkeypatch):
+def test_16bit_constants_read_by_the_head_equal_the_widening_pass_bitwise(dtype, form, monkeypatch):
     """One rank, 16-bit constants: by default the fused head reads the packed 16-bit rows where they lie and widens in registers
     (elimrec_head_fwd_fused_src16; the step keeps the fp32 step's shape: feature blocks beside the hops, rows evaluated in the
     head's launch); ELIMREC_DIRECT16=0 keeps the earlier form -- a widening pass over the batch's rows (elimrec_lookup_unpack)
@@ -1306,6 +1307,12 @@ def test_16bit_constants_read_by_the_head_equal_the_widening_pass_bitwise(dtype,
     g = load_golden("kwai")
     bs = [tuple(_t(g["step%d/%s" % (1 + k % 2, key)]) for key in ("users", "pos", "neg")) for k in range(14)]
     res = {}
+    # the head's three launch forms under the direct reads: feature blocks on the second stream + rows in the head's launch
+    # (default), feature blocks on the second stream + a rows launch, everything in one head launch
+    if form != "split+rows":
+        monkeypatch.setenv("ELIMREC_ROWS_IN_HEAD", "0")
+    if form == "one-launch":
+        monkeypatch.setenv("ELIMREC_HEAD_SPLIT", "0")
     for direct in ("1", "0"):
         monkeypatch.setenv("ELIMREC_DIRECT16", direct)
         model, _ = build_model_from_fixture(g, DEV)
