@@ -154,11 +154,13 @@ class Net(object):
         self.opt.zero_grad()
         loss.backward(retain_graph=True)
         self.opt.step()
-        return loss.detach()
+        return loss
 
     def train_epoch(self, batches):
-        """One pass over the sampler; the mean loss of the epoch over all ranks (one device->host copy for all batches
-        instead of the reference's per-batch loss.cpu().item())."""
+        """One pass over the sampler; the mean loss of the epoch. One rank: the reference's line 102 verbatim --
+        `loss.cpu().item()` after every batch (the engine publishes each step's loss to the host from the launch that sums it,
+        elimrec_amd/plugin.py: the read does not wait for the step). Several ranks: the losses stay on the device and are
+        all-reduced once per epoch."""
         self.recommender.train()
         tracker = Meter(name="MultiLoss(bpr)")
         tracker.reset()
@@ -173,13 +175,17 @@ class Net(object):
             shard_trainer.prestage(batches)           # ... complete before the first step: every step's planner may run ahead
             if getattr(shard_trainer, "lookup", False) and getattr(shard_trainer, "multi", False):
                 shard_trainer.plan_lookup(batches)    # row-sharded constants: this epoch's lookup split sizes, planned ahead
-        on_device = torch.stack([keep(step(users, pos, neg)) for users, pos, neg in batches])
-        if self.world > 1:
+        if self.world == 1:
+            for users, pos, neg in batches:
+                loss = step(users, pos, neg)
+                tracker.update(val=loss.cpu().item())                               # main.py:102
+        else:
             import torch.distributed as dist
+            on_device = torch.stack([keep(step(users, pos, neg).detach()) for users, pos, neg in batches])
             dist.all_reduce(on_device, op=dist.ReduceOp.SUM)
             on_device /= self.world
-        for value in on_device.cpu().tolist():
-            tracker.update(val=value)
+            for value in on_device.cpu().tolist():
+                tracker.update(val=value)
         if self.world > 1:       # every rank sees a bad index of any rank: all raise together, none is left in a collective
             import torch.distributed as dist
             dist.all_reduce(self.recommender._index_err(), op=dist.ReduceOp.MAX)
