@@ -780,10 +780,19 @@ def multi_gpu_projection(args, device, cfg, ds, B, torch, worlds=(2, 4, 8), step
         hop_gather_us = per_link / (XGMI_LINK_GBS * 1e3) + COLLECTIVE_LATENCY_US
         alt[str(W)] = {"all_gather_bytes_received_per_hop": int(table * (W - 1) / W), "modelled_us_per_hop_all_gather": round(hop_gather_us, 1),
                        "hops_per_step": 2 * L, "all_gather_us_per_step": round(2 * L * hop_gather_us, 1)}
+    # one hop of one rank under either partition, measured on one MI355X with tools/row_range_hop.py on the round-6 build (constants of
+    # that run, not of this one): rank 0's rows r, r + W, ... at full width against all rows at d / W columns
+    measured = {"2": (21.4, 23.5), "4": (18.4, 24.0), "8": (15.5, 24.4)}
+    for W in worlds:
+        m = measured.get(str(W))
+        if m is not None:
+            alt[str(W)]["hop_us_per_rank_row_partition_measured_r06"] = m[0]
+            alt[str(W)]["hop_us_per_rank_column_partition_measured_r06"] = m[1]
+            alt[str(W)]["row_partition_hop_plus_all_gather_us"] = round(m[0] + alt[str(W)]["modelled_us_per_hop_all_gather"], 1)
     out["row_sharded_graph_table_alternative"] = {
         "what": "not built: per hop every rank needs the whole [N x d] input (%.1f MB): an all_gather on the direct links -- NOT the ring "
-                "time earlier rounds quoted (7x more); per-rank hop work would shrink with W (full 256-B rows, 1/W of them), which the "
-                "column shards' does not below 32 columns per rank" % (table / 1e6),
+                "time earlier rounds quoted (7x more). A rank's hop over 1/W of the rows at full width was measured beside the column "
+                "shards' hop (DESIGN.md section 6): the smaller hop does not pay for its exchange at 153 GB/s per link" % (table / 1e6),
         "worlds": alt}
     return out
 
