@@ -39,11 +39,9 @@ template <typename R, typename... A> constexpr int arg_count(R (*)(A...)) { retu
 // fence (cache write-back + invalidate for the host and other devices) when one is recorded -- the kernels' own agent-scope
 // release / acquire is what the streams need of each other. A program that lists the library's RCCL calls keeps the default
 // events: peers write into this device's buffers over xGMI, and a stream that consumes them behind an event must see them at
-// system scope. ELIMREC_EVENT_FENCE=1 keeps the default events everywhere.
+// system scope (elimrec_program_create_scoped states it).
 static unsigned event_flags(bool has_collectives) {
-    static int fence = -1;
-    if (fence < 0) { const char *e = getenv("ELIMREC_EVENT_FENCE"); fence = (e && e[0] == '1') ? 1 : 0; }
-    return (fence || has_collectives) ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
+    return has_collectives ? hipEventDisableTiming : (hipEventDisableTiming | hipEventDisableSystemFence);
 }
 
 struct FnEntry { const char *name; int (*thunk)(const uint64_t *); int n_args; };

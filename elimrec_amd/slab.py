@@ -17,6 +17,8 @@ from .ops import _dev, _stream
 # rows with more non-zeros are cut into segments of this length: the longest work item bounds a hop's critical path
 # (32: 21 us per hop on an 8-column shard at the Tiktok shape; 64: 29 us; 16: 40 us -- too many partial rows)
 LONG_ROW_THRESHOLD = 32
+SLAB_W_CAP = 32      # widest slab (floats): a 128-B row piece per gather (tools/hop_only.py overrides it for geometry sweeps)
+SLAB_GROUPS = 0      # 0: as many slab groups as divide the slab count and the 8 XCDs
 
 
 def choose_slabs(dl, n_rows=None):
@@ -27,7 +29,7 @@ def choose_slabs(dl, n_rows=None):
     footprint wins; 128-B pieces halve every XCD's footprint at no cost per line."""
     if dl % 4 != 0:
         raise ValueError("column count must be a multiple of 4 (got %d)" % dl)
-    cap = int(os.environ.get("ELIMREC_SLAB_W", "0")) or 32
+    cap = SLAB_W_CAP
     w = 4
     while w * 2 <= cap and dl % (w * 2) == 0:
         w *= 2
@@ -36,7 +38,7 @@ def choose_slabs(dl, n_rows=None):
 
 def choose_groups(ns):
     """Slab groups of a hop launch: as many as divide both the slab count and the 8 XCDs."""
-    gs = int(os.environ.get("ELIMREC_SLAB_GS", "0"))
+    gs = SLAB_GROUPS
     if gs > 0 and ns % gs == 0:
         return gs
     for gs in (8, 4, 2, 1):

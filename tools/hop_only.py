@@ -1,9 +1,11 @@
 """N full hops of a slab-major table at the Tiktok shape (SHAPE=c4: Tiktok x16 items), for rocprofv3 (--pmc / --kernel-trace). Dev tool.
-usage: hop_only.py [d] [hops]   env: ELIMREC_SLAB_W / ELIMREC_SLAB_GS choose the geometry"""
+usage: hop_only.py [d] [hops]   env: SLAB_W / SLAB_GS choose the geometry (slab.SLAB_W_CAP / slab.SLAB_GROUPS)"""
 import os, sys, torch
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from elimrec_amd import SyntheticDataset, slab
 from elimrec_amd.model import create_adj_mat
+slab.SLAB_W_CAP = int(os.environ.get("SLAB_W", os.environ.get("ELIMREC_SLAB_W", "0"))) or 32
+slab.SLAB_GROUPS = int(os.environ.get("SLAB_GS", os.environ.get("ELIMREC_SLAB_GS", "0")))
 dev = "cuda:0"
 d = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 hops = int(sys.argv[2]) if len(sys.argv) > 2 else 12
