@@ -259,18 +259,22 @@ class UniEvaluator(object):
         idx, val = idx1[:, :K].contiguous(), val1[:, :K].contiguous()
         tied = torch.nonzero((val1[:, :-1] == val1[:, 1:]).any(1)).flatten()       # (every rank holds the same merged lists)
         self.tie_rows_replayed += int(tied.numel())
-        if tied.numel():
-            lo_t, hi_t = train_ptr[tied], train_ptr[tied + 1]
-            sub_ptr = torch.zeros(tied.numel() + 1, dtype=torch.int64, device=users_t.device)
+        # <= 1 GiB of score rows at a time (a row of configs[4]'s catalogue is 400 MB); every rank holds the same merged lists, hence
+        # the same `tied` and the same number of (collective) score-row calls
+        step = max(1, (1 << 28) // max(1, model.num_items))
+        for a in range(0, int(tied.numel()), step):
+            part = tied[a:a + step]
+            lo_t, hi_t = train_ptr[part], train_ptr[part + 1]
+            sub_ptr = torch.zeros(part.numel() + 1, dtype=torch.int64, device=users_t.device)
             torch.cumsum(hi_t - lo_t, 0, out=sub_ptr[1:])
             take = torch.repeat_interleave(lo_t - sub_ptr[:-1], hi_t - lo_t) + torch.arange(int(sub_ptr[-1]), device=users_t.device)
             it = train_items[take] if take.numel() else torch.zeros(1, dtype=torch.int32, device=users_t.device)
-            sc = torch.empty(tied.numel(), model.num_items, dtype=torch.float32, device=users_t.device)
-            model.predict_device(users_t[tied], scores=sc, train_ptr=sub_ptr, train_items=it.contiguous())
-            ti = torch.empty(tied.numel(), K, dtype=torch.int32, device=users_t.device)
-            tv = torch.empty(tied.numel(), K, dtype=torch.float32, device=users_t.device)
+            sc = torch.empty(part.numel(), model.num_items, dtype=torch.float32, device=users_t.device)
+            model.predict_device(users_t[part], scores=sc, train_ptr=sub_ptr, train_items=it.contiguous())
+            ti = torch.empty(part.numel(), K, dtype=torch.int32, device=users_t.device)
+            tv = torch.empty(part.numel(), K, dtype=torch.float32, device=users_t.device)
             ops.topk_reference_order(sc, K, ti, tv)
-            idx[tied], val[tied] = ti, tv
+            idx[part], val[part] = ti, tv
         return idx, val
 
     def evaluate_batch(self, model, batch_users, return_topk=False, cache_key=None, out=None):

@@ -1073,6 +1073,29 @@ def _two_proc_worker(rank, world, port, out_dir, feature_shard="replicated", nam
     eng.sync_to_model()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), losses=np.array(losses), eval_result=res, predict=pred,
              **{k: v.detach().cpu().numpy() for k, v in model.state_dict().items()})
+    if feature_shard == "row":
+        # the reference's tie order over ITEM-SHARDED tables: every item of my shard gets a twin (equal rows score equally under
+        # every user), so every user's merged K + 1 best hold exact ties; those rows' all-gathered score rows are ranked by the
+        # device replay of evaluate.h:26-33 -- the lists must be the oracle's ranking of the rows predict() returns
+        from elimrec_amd import ops
+        from oracle import eval_oracle as evo
+        sh, Y, U_ = model._eval_shard, model._eval_shard_Y, model.num_users
+        nloc = Y.shape[0] - U_
+        Y[U_ + 1:U_ + nloc:2] = Y[U_:U_ + nloc - 1:2].clone()
+        ops.row_sqnorms(Y, model.latent_dim, 1 + model.S, sh.backend.sqn)
+        evalr = model.test_evaluator.evaluator
+        evalr._dev_cache.clear()
+        ev_users = g["evalbatch/users"].tolist()
+        K = evalr.max_top
+        assert evalr.tie_order == "reference"
+        _, idx, _ = evalr.evaluate_batch(model, ev_users, return_topk=True)
+        assert evalr.tie_rows_replayed >= len(ev_users) // 2
+        tp_, ti_ = evalr._batch_csr(ev_users, evalr.user_pos_train, DEV, unique=False)
+        sc = torch.empty(len(ev_users), model.num_items, device=DEV)
+        model.predict_device(ev_users, scores=sc, train_ptr=tp_, train_items=ti_)
+        tp0, ti0 = evo.truth_to_csr([[0]] * len(ev_users))
+        _, want = evo.evaluate_matrix(sc.cpu().numpy(), tp0, ti0, [1], K)
+        assert np.array_equal(idx.cpu().numpy(), want)
     dist.destroy_process_group()
 
 
