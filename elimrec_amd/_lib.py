@@ -220,6 +220,10 @@ SIGNATURES = {
                                        ctypes.POINTER(c_i64), ctypes.POINTER(c_i32), ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr),
                                        c_ptr, c_ptr, c_ptr, c_ptr, ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr), c_ptr, c_size,
                                        c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32, c_ptr]),
+    "elimrec_head_fwd_fused_peers": (c_i32, [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_i64, c_ptr, c_i32, ctypes.POINTER(c_ptr),
+                                             ctypes.POINTER(c_i64), ctypes.POINTER(c_i32), ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr),
+                                             c_ptr, c_ptr, c_ptr, c_ptr, ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr), c_ptr, c_size,
+                                             c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32, c_ptr]),
     "elimrec_head_fwd_fused_rows": (c_i32, [ctypes.POINTER(HeadRows), c_ptr, c_ptr, c_i64, c_ptr, c_i32, ctypes.POINTER(c_ptr),
                                             ctypes.POINTER(c_i64), ctypes.POINTER(c_i32), ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr),
                                             c_ptr, c_ptr, c_ptr, c_ptr, ctypes.POINTER(c_ptr), ctypes.POINTER(c_ptr), c_ptr, c_size,

@@ -46,6 +46,9 @@ struct HeadFwdArgs {
     // (nullable): the widened rows in active-row order, for the weight-gradient launches of the backward half.
     int sdtype; const uint16_t *tab16; int64_t row_elems; int s_off[HMAXM]; int c_off;
     float *s_out; int64_t ld_sout; float *c_out;
+    // out0 / narrow as the forward exchange delivers them (elimrec_head_fwd_fused_peers): peer q's piece of row r, columns
+    // [q*dl, (q+1)*dl), at out0 + q * peer_stride + r * ld_out0 -- the received [W][R][out0 dl | narrow dl] buffer read in place
+    int peer_dl; int64_t peer_stride;
 };
 
 __device__ __forceinline__ float widen16(uint32_t h, int sdtype) {        // one fp16 / bf16 element (low 16 bits of h) -> fp32, exact
@@ -156,8 +159,10 @@ __device__ __forceinline__ void head_fwd16_body(const HeadFwdArgs &a, const Rows
                 *reinterpret_cast<float4 *>(ra->narrow + (int64_t)(r0 + r) * ra->ld_narrow + 4 * c4) = y;      // (kept, as the rows launch does)
             }
         } else if (r < nrows) {
-            x = *reinterpret_cast<const float4 *>(a.out0 + (int64_t)(r0 + r) * a.ld_out0 + 4 * c4);
-            y = *reinterpret_cast<const float4 *>(a.narrow + (int64_t)(r0 + r) * a.ld_nar + 4 * c4);
+            int64_t col = 4 * c4;
+            if (a.peer_dl) { const int q = (4 * c4) / a.peer_dl; col = q * a.peer_stride + (4 * c4 - q * a.peer_dl); }
+            x = *reinterpret_cast<const float4 *>(a.out0 + (int64_t)(r0 + r) * a.ld_out0 + col);
+            y = *reinterpret_cast<const float4 *>(a.narrow + (int64_t)(r0 + r) * a.ld_nar + col);
         }
         *reinterpret_cast<float4 *>(OutT + r * LDO + 4 * c4) = x;
         *reinterpret_cast<float4 *>(AN + r * LDN + 4 * c4) = y;
@@ -268,7 +273,7 @@ extern "C" size_t elimrec_head_pack_bwd_offset(int n_mod, const int *D) {
     return (size_t)head_pack_layout(n_mod, D).fwd_total;
 }
 
-static int head_fwd_fused_impl(const elimrec_head_src16 *src, const elimrec_head_rows *rows, const int32_t *d_act, const int32_t *d_seg_info, int64_t R, const float *d_out0,
+static int head_fwd_fused_impl(int peer_world, int64_t peer_dl, const elimrec_head_src16 *src, const elimrec_head_rows *rows, const int32_t *d_act, const int32_t *d_seg_info, int64_t R, const float *d_out0,
                                       int64_t ld_out0, const float *d_narrow, int64_t ld_nar, const float *d_c, int n_mod,
                                       const float *const *d_S, const int64_t *ldS, const int *D, const float *const *d_Wm,
                                       const float *const *d_bm, const float *d_Wf_user, const float *d_bf_user,
@@ -338,6 +343,11 @@ static int head_fwd_fused_impl(const elimrec_head_src16 *src, const elimrec_head
     const size_t lds_bytes = (size_t)lds_f * sizeof(float);
     if (lds_bytes > 158 * 1024) { set_error("head_fwd_fused: feature widths need %zu B of LDS", lds_bytes); return ELIMREC_E_UNSUPPORTED; }
     a.act = d_act; a.seg_info = d_seg_info; a.out0 = d_out0; a.ld_out0 = ld_out0; a.narrow = d_narrow; a.ld_nar = ld_nar; a.c = d_c;
+    if (peer_world > 0) {
+        ELIMREC_REQUIRE(!rows && peer_dl > 0 && peer_dl % 4 == 0 && peer_world * peer_dl == HD && ld_out0 == 2 * peer_dl && ld_nar == ld_out0,
+                        "head_fwd_fused_peers: %d peers x %lld columns (a multiple of 4) must make the %d columns of a row", peer_world, (long long)peer_dl, HD);
+        a.peer_dl = (int)peer_dl; a.peer_stride = R * 2 * peer_dl;
+    }
     if (src) {
         a.sdtype = src->dtype; a.tab16 = (const uint16_t *)src->d_table; a.row_elems = src->row_elems;
         a.c_off = a.s_off[n_mod - 1] + D[n_mod - 1];
@@ -389,9 +399,23 @@ extern "C" int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg
                                       const float *d_Wf_item, const float *d_bf_item, const float *const *d_Ws,
                                       const float *const *d_bs, float *d_pack, size_t pack_floats, float *d_OutAct,
                                       int64_t ld_out, float *d_YAct, int64_t ld_y, int recdim, int phase, void *stream) {
-    return head_fwd_fused_impl(nullptr, nullptr, d_act, d_seg_info, R, d_out0, ld_out0, d_narrow, ld_nar, d_c, n_mod, d_S, ldS, D, d_Wm, d_bm,
+    return head_fwd_fused_impl(0, 0, nullptr, nullptr, d_act, d_seg_info, R, d_out0, ld_out0, d_narrow, ld_nar, d_c, n_mod, d_S, ldS, D, d_Wm, d_bm,
                                d_Wf_user, d_bf_user, d_Wf_item, d_bf_item, d_Ws, d_bs, d_pack, pack_floats, d_OutAct, ld_out, d_YAct,
                                ld_y, recdim, phase, stream);
+}
+
+// ... with out0 / narrow read where the forward exchange of the column shards left them: d_recv = [world][R][out0 dl | narrow dl],
+// peer q's columns of MY rows (ops.peer_cols_to_rows + elimrec_head_fwd_fused without the pass in between; same bits).
+extern "C" int elimrec_head_fwd_fused_peers(const int32_t *d_act, const int32_t *d_seg_info, int64_t R, const float *d_recv, int world,
+                                            int64_t dl, const float *d_c, int n_mod, const float *const *d_S, const int64_t *ldS,
+                                            const int *D, const float *const *d_Wm, const float *const *d_bm, const float *d_Wf_user,
+                                            const float *d_bf_user, const float *d_Wf_item, const float *d_bf_item,
+                                            const float *const *d_Ws, const float *const *d_bs, float *d_pack, size_t pack_floats,
+                                            float *d_OutAct, int64_t ld_out, float *d_YAct, int64_t ld_y, int recdim, int phase, void *stream) {
+    ELIMREC_REQUIRE(d_recv && world > 0 && dl > 0 && (phase == 0 || phase == 2 || phase == 4), "head_fwd_fused_peers: a received buffer, phase 0, 2 or 4");
+    return head_fwd_fused_impl(world, dl, nullptr, nullptr, d_act, d_seg_info, R, d_recv, 2 * dl, d_recv + dl, 2 * dl, d_c, n_mod, d_S, ldS, D,
+                               d_Wm, d_bm, d_Wf_user, d_bf_user, d_Wf_item, d_bf_item, d_Ws, d_bs, d_pack, pack_floats, d_OutAct, ld_out,
+                               d_YAct, ld_y, recdim, phase, stream);
 }
 
 // ... with the feature constants read from their 16-bit storage (lookup.hip's packed rows, one rank holding every row): see
@@ -403,7 +427,7 @@ extern "C" int elimrec_head_fwd_fused_src16(const elimrec_head_src16 *src, const
                                             const float *const *d_Ws, const float *const *d_bs, float *d_pack, size_t pack_floats,
                                             float *d_OutAct, int64_t ld_out, float *d_YAct, int64_t ld_y, int recdim, int phase, void *stream) {
     ELIMREC_REQUIRE(src, "head_fwd_fused_src16: null source");
-    return head_fwd_fused_impl(src, nullptr, d_act, d_seg_info, R, d_out0, ld_out0, d_narrow, ld_nar, nullptr, n_mod, nullptr, nullptr, D, d_Wm,
+    return head_fwd_fused_impl(0, 0, src, nullptr, d_act, d_seg_info, R, d_out0, ld_out0, d_narrow, ld_nar, nullptr, n_mod, nullptr, nullptr, D, d_Wm,
                                d_bm, d_Wf_user, d_bf_user, d_Wf_item, d_bf_item, d_Ws, d_bs, d_pack, pack_floats, d_OutAct, ld_out, d_YAct,
                                ld_y, recdim, phase, stream);
 }
@@ -416,7 +440,7 @@ extern "C" int elimrec_head_fwd_fused_rows(const elimrec_head_rows *rows, const 
                                            float *d_OutAct, int64_t ld_out, float *d_YAct, int64_t ld_y, int recdim, void *stream) {
     ELIMREC_REQUIRE(rows && d_OutAct, "head_fwd_fused_rows: null pointer");
     // (out0 / narrow of the plain entry are the buffers this launch fills itself: block 0 of OutAct and rows->d_narrow_out)
-    return head_fwd_fused_impl(nullptr, rows, d_act, d_seg_info, R, d_OutAct, ld_out, rows->d_narrow_out, rows->ld_narrow_out, d_c, n_mod, d_S, ldS, D,
+    return head_fwd_fused_impl(0, 0, nullptr, rows, d_act, d_seg_info, R, d_OutAct, ld_out, rows->d_narrow_out, rows->ld_narrow_out, d_c, n_mod, d_S, ldS, D,
                                d_Wm, d_bm, d_Wf_user, d_bf_user, d_Wf_item, d_bf_item, d_Ws, d_bs, d_pack, pack_floats, d_OutAct, ld_out,
                                d_YAct, ld_y, recdim, 4, stream);
 }

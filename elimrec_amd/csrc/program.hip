@@ -59,6 +59,7 @@ static const FnEntry kFns[] = {
     ELIMREC_FN(elimrec_peer_cols_to_rows), ELIMREC_FN(elimrec_rows_bitmap), ELIMREC_FN(elimrec_comm_all_gather), ELIMREC_FN(elimrec_comm_all_reduce_f32),
     ELIMREC_FN(elimrec_comm_all_to_all), ELIMREC_FN(elimrec_comm_all_to_all_v), ELIMREC_FN(elimrec_wide_from_master),
     ELIMREC_FN(elimrec_wide_rows), ELIMREC_FN(elimrec_wide_grad), ELIMREC_FN(elimrec_head_fwd_fused_rows), ELIMREC_FN(elimrec_head_fwd_fused_src16),
+    ELIMREC_FN(elimrec_head_fwd_fused_peers),
 };
 constexpr int kNumFns = (int)(sizeof(kFns) / sizeof(kFns[0]));
 

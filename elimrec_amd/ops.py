@@ -783,11 +783,13 @@ def head_fwd_fused_rows(rows, act, seg_info, c, S, Wm, bm, Wf_user, bf_user, Wf_
     return True
 
 
-def head_fwd_fused(act, seg_info, out0, narrow, c, S, Wm, bm, Wf_user, bf_user, Wf_item, bf_item, Ws, bs, pack, OutAct, YAct, d, phase=0):
+def head_fwd_fused(act, seg_info, out0, narrow, c, S, Wm, bm, Wf_user, bf_user, Wf_item, bf_item, Ws, bs, pack, OutAct, YAct, d, phase=0,
+                   peers=None):
     """elimrec_head_fwd_fused: S / Wm / bm / Ws / bs are lists over the feature tables. phase 0: pack the weights and
     run the head; 1: pack only; 2: head only (pack holds the packed weights); 3 / 4: the head in two launches (the feature
     blocks without the shared part -- no out0 / narrow needed --, then the rest). Returns False when the shape is outside the
-    fused kernel's range (the caller keeps the batched GEMMs)."""
+    fused kernel's range (the caller keeps the batched GEMMs). peers: the forward exchange's received buffer [W, R, 2 * dl]
+    (out0 | narrow pieces of every peer) read in place of out0 / narrow (elimrec_head_fwd_fused_peers)."""
     n = len(S)
     R = act.numel()
     ptr = lambda ts: (ctypes.c_void_p * max(n, 1))(*[_dev(t, "table") for t in ts])
@@ -795,6 +797,17 @@ def head_fwd_fused(act, seg_info, out0, narrow, c, S, Wm, bm, Wf_user, bf_user, 
     D = (ctypes.c_int * max(n, 1))(*[t.shape[1] for t in S])
     for w in list(Wm) + list(Ws) + [Wf_user, Wf_item]:
         assert w.is_contiguous()
+    if peers is not None:
+        assert peers.dim() == 3 and peers.is_contiguous() and peers.shape[1] == R and peers.shape[2] % 2 == 0
+        rc = _lib.load().elimrec_head_fwd_fused_peers(
+            _dev(act, "act", torch.int32), _dev(seg_info, "seg_info", torch.int32), R, _dev(peers, "peers"), peers.shape[0],
+            peers.shape[2] // 2, _dev(c, "c"), n, ptr(S), ldS, D, ptr(Wm), ptr(bm), _dev(Wf_user, "Wf_user"),
+            _dev(bf_user, "bf_user"), _dev(Wf_item, "Wf_item"), _dev(bf_item, "bf_item"), ptr(Ws), ptr(bs), _dev(pack, "pack"),
+            pack.numel(), _dev(OutAct, "OutAct"), OutAct.stride(0), _dev(YAct, "YAct"), YAct.stride(0), int(d), int(phase), _stream())
+        if rc == 10002:
+            return False
+        _lib.check(rc, "head_fwd_fused_peers")
+        return True
     rc = _lib.load().elimrec_head_fwd_fused(
         _dev(act, "act", torch.int32), _dev(seg_info, "seg_info", torch.int32), R, _dev(out0, "out0"), out0.stride(0),
         _dev(narrow, "narrow"), narrow.stride(0), _dev(c, "c"), n, ptr(S), ldS, D, ptr(Wm), ptr(bm), _dev(Wf_user, "Wf_user"),

@@ -548,6 +548,9 @@ class ColumnShardTrainer(object):
             eng.cs_forward_long()                                  # the split rows of hop L need neither ids nor plan: ahead of the waits
         if h_ids is not None:
             h_ids.wait()
+            if (self._hip_engine and isinstance(h_ids, self._OnStream) and h_ids.recorded is not None
+                    and h_ids.stream is eng.plan_stream()):
+                eng.plan_joined()                                  # the id exchange followed the plan on ITS stream: one wait covers both
         send = ph["cs_forward_rows"](acts)                         # [W, R, 2*dl]: layer means of the peers' rows, my columns
         if self.multi:
             if self.lookup and not lookup_early:
@@ -590,7 +593,11 @@ class ColumnShardTrainer(object):
                     h_w = self._all_reduce_async(wgrads)
             else:
                 recv2 = send2
-            if late:
+            if late and W == 1:
+                # a group of one rank (the multi-rank step measured on one GPU): the sums are global as they are -- no all-reduce,
+                # and the projection weights' optimizer spans ride in the last hop's launch as the one-rank step's do
+                ph["cs_backward_hops"](recv2, acts, None, True)
+            elif late:
                 # the weight gradients are FINISHED by the adjoint's first two hop launches (behind their tiles); they are reduced
                 # under the last hop, and the projection weights' optimizer spans follow in a launch of their own (cs_update)
                 ph["cs_backward_hops"](recv2, acts, None, lambda: self._all_reduce_async(wgrads))
@@ -757,7 +764,7 @@ class ColumnShardEngine(object):
         self._aux = None
         self._aux_pending = False
         self._adam_in_hop = False
-        self._out0_src = self._nar_src = None
+        self._out0_src = self._nar_src = self._peer_src = None
         self._pairs = {}
         self._split_head = os.environ.get("ELIMREC_HEAD_SPLIT", "1") != "0"     # feature blocks of the head beside the forward hops
         self._head_split = False
@@ -1095,11 +1102,20 @@ class ColumnShardEngine(object):
         # several ranks: the second stream goes on to the adjoint's source bits once the ids are gathered (cs_gathered_ids); what
         # the forward joins is the plan and the packed weights, recorded here
         self._plan_rec = program.record(aux) if self.multi else None
+        self._plan_waited = False
         return act
 
     def plan_stream(self):
         """The stream cs_plan's launches went to when it is not the caller's (the second stream), else None."""
         return self._aux_stream()
+
+    def plan_joined(self):
+        """The caller's stream has waited for something enqueued on the second stream BEHIND this step's plan and packed weights
+        (the id exchange's event): cs_forward_rows need not wait for the plan's own event again (each wait on another queue's
+        event costs the main queue ~5 us of command-processor latency, satisfied or not)."""
+        if getattr(self, "_plan_rec", None) is not None:
+            self._plan_rec = None
+            self._plan_waited = True
 
     def wgrads_deferred(self):
         """Several ranks: the weight gradients ride behind the adjoint hops' tiles (both phases) and are all-reduced late."""
@@ -1194,7 +1210,9 @@ class ColumnShardEngine(object):
 
         def join_plan():
             rec = getattr(self, "_plan_rec", None)
-            if rec is not None:                                  # (several ranks: the plan's event, not the stream's tail)
+            if getattr(self, "_plan_waited", False):             # plan_joined(): already behind it
+                self._plan_waited = False
+            elif rec is not None:                                  # (several ranks: the plan's event, not the stream's tail)
                 program.wait(torch.cuda.current_stream(), rec)
                 self._plan_rec = None
             else:
@@ -1287,7 +1305,12 @@ class ColumnShardEngine(object):
         if recv is not None:                                      # [W, R, (out0 | narrow)] -> my rows, all columns
             W = recv.shape[0]
             r = recv.view(W, R, 2, self.dl)
-            if fused:
+            self._peer_src = None
+            if fused and not self._direct16 and self.dl % 4 == 0:
+                # the fused head reads the peers' pieces where the exchange left them and writes block 0 of OutAct itself
+                self._peer_src = recv.view(W, R, 2 * self.dl)
+                self._out0_src = self._nar_src = None
+            elif fused:
                 # one pass: [R, (out0 | narrow), d]; the fused head reads both halves with a 2d row stride and writes
                 # block 0 of OutAct itself
                 pair = self._pair(R, d)
@@ -1303,7 +1326,7 @@ class ColumnShardEngine(object):
                 self.narrow_x.index_copy_(0, idx, r[:, :, 1].permute(1, 0, 2).reshape(R, d))
                 self._out0_src = self._nar_src = None
         else:
-            self._out0_src = self._nar_src = None
+            self._out0_src = self._nar_src = self._peer_src = None
         m._slab_fwd = True
         if fused:
             return self._head_forward_fused(ws, R, B)
@@ -1363,7 +1386,8 @@ class ColumnShardEngine(object):
             else:
                 self._head_fused_call(ws, R, phase=4 if split else (2 if packed else 0))
         m._region("cs_head_fused%d" % (self.cur if with_rows else 2), (m._ws_gen, R, B, packed, split, with_rows, self.nar_act.data_ptr(),
-                                    0 if self._out0_src is None else self._out0_src.data_ptr()), head)
+                                    0 if self._out0_src is None else self._out0_src.data_ptr(),
+                                    0 if self._peer_src is None else self._peer_src.data_ptr()), head)
         # the cosine-BPR rows and the batch loss in one launch (the workgroup that finishes last adds the loss rows in
         # elimrec_sum's order). Issued directly: the loss goes to the next slot of a ring, so that a caller holding the
         # tensors of earlier steps -- main.py stacks an epoch's losses before it copies them to the host -- does not see them
@@ -1442,7 +1466,8 @@ class ColumnShardEngine(object):
                                 s_tabs, [W[k + "_dense.weight"] for k in m._mods],
                                 [W[k + "_dense.bias"] for k in m._mods], wu, W["embedding_user_after_GCN.bias"], wi,
                                 W["embedding_item_after_GCN.bias"], [W["s_dense_%s.weight" % k] for k in m._mods],
-                                [W["s_dense_%s.bias" % k] for k in m._mods], self._pack, OutAct, YAct, d, phase=phase)
+                                [W["s_dense_%s.bias" % k] for k in m._mods], self._pack, OutAct, YAct, d, phase=phase,
+                                peers=self._peer_src if phase in (0, 2, 4) else None)
         if not ok:
             raise RuntimeError("fused head forward refused a shape _fused_head_ok accepted")
 
@@ -1489,12 +1514,20 @@ class ColumnShardEngine(object):
                   lambda: ops.source_rows_split(ws["dOutR"][:R], ws["seg_info"][0:1], d, m.M, W, send))
         return send, wg
 
+    def join_source_bits(self):
+        """The caller's stream behind the second stream's source bits of the adjoint's first hop (several ranks: cs_gathered_ids;
+        large batches: cs_forward_rows), once per step."""
+        if getattr(self, "_bits_join", False):
+            program.sync(torch.cuda.current_stream(), self._aux)
+            self._bits_join = False
+
     @torch.no_grad()
     def cs_backward_hops(self, recv2, acts, grads_ready=None, reduce_wgrads=None):
         """grads_ready (several ranks): the handle of the weight gradients' all-reduce. Waited for before the LAST hop, whose
         launch then carries the projection weights' optimizer spans as one rank's does; without it they run in cs_update.
         reduce_wgrads (several ranks, deferred weight gradients): called once the hops that finish the weight gradients are
-        enqueued; returns the all-reduce's handle (kept in self.wgrads_handle), which then runs under the last hop."""
+        enqueued; returns the all-reduce's handle (kept in self.wgrads_handle), which then runs under the last hop. True: a
+        group of one rank -- nothing to reduce, the spans ride in the last hop."""
         m = self.model
         U, I, L = m.num_users, m.num_items, m.n_layers
         W, R = acts.shape
@@ -1505,9 +1538,7 @@ class ColumnShardEngine(object):
 
         single = not self.multi
         merged = single and getattr(self, "_merged", False)
-        if getattr(self, "_bits_join", False):                      # the source bits from the second stream (several ranks: cs_gathered_ids)
-            program.sync(torch.cuda.current_stream(), self._aux)
-            self._bits_join = False
+        self.join_source_bits()
         reduce = getattr(self, "_reduce", None) if (single or reduce_wgrads is not None) else None
         self._reduce = None
         self.wgrads_handle = None
@@ -1526,7 +1557,7 @@ class ColumnShardEngine(object):
                 slab.wide_grad(t, U, inv, self.grad)
             self._timed(lambda: m._region("cs_bwd_hops", (m._ws_gen, recv2.data_ptr(), acts.data_ptr(), R, W, self._bits_ready), wide_hops), L)
             self._adam_in_hop = self._tail_in_hop = False
-            if reduce_wgrads is not None:
+            if reduce_wgrads is not None and reduce_wgrads is not True:
                 self.wgrads_handle = reduce_wgrads()
             return
 
@@ -1558,7 +1589,9 @@ class ColumnShardEngine(object):
             g = self.opt.param_groups[0]
             nxt = 1 - self.cur
             in_hop = single or grads_ready is not None
-            if reduce_wgrads is not None:                     # finished by the hops above: reduce them under this last hop
+            if reduce_wgrads is True:                         # (a group of one rank: nothing to reduce)
+                in_hop = True
+            elif reduce_wgrads is not None:                   # finished by the hops above: reduce them under this last hop
                 self.wgrads_handle = reduce_wgrads()
                 in_hop = False
             if grads_ready is not None:

@@ -774,6 +774,18 @@ int elimrec_head_fwd_fused(const int32_t *d_act, const int32_t *d_seg_info, int6
                            const float *const *d_bs, float *d_pack, size_t pack_floats, float *d_OutAct,
                            int64_t ld_out, float *d_YAct, int64_t ld_y, int recdim, int phase, void *stream);
 
+/* elimrec_head_fwd_fused with d_out0 / d_narrow read where the column shards' forward exchange left them (SURVEY section 8(e):
+ * each rank evaluates models/EliMRec.py:255-261's layer means on its recdim / world columns and sends every peer the rows that
+ * peer's triplets name). d_recv = [world][R][out0: dl | narrow: dl] fp32, piece q = rank q's columns [q*dl, (q+1)*dl) of MY R
+ * active rows, world * dl = recdim = 64, dl a multiple of 4. Phases 0, 2, 4. The bits of elimrec_peer_cols_to_rows followed by
+ * elimrec_head_fwd_fused on its rows, without that pass over the rows. */
+int elimrec_head_fwd_fused_peers(const int32_t *d_act, const int32_t *d_seg_info, int64_t R, const float *d_recv, int world,
+                                 int64_t dl, const float *d_c, int n_mod, const float *const *d_S, const int64_t *ldS,
+                                 const int *D, const float *const *d_Wm, const float *const *d_bm, const float *d_Wf_user,
+                                 const float *d_bf_user, const float *d_Wf_item, const float *d_bf_item,
+                                 const float *const *d_Ws, const float *const *d_bs, float *d_pack, size_t pack_floats,
+                                 float *d_OutAct, int64_t ld_out, float *d_YAct, int64_t ld_y, int recdim, int phase, void *stream);
+
 /* elimrec_head_fwd_fused with the feature constants read from 16-bit storage where they lie (BASELINE.json configs[1] "bf16";
  * models/EliMRec.py:233-236's v/a/t_dense inputs in their folded form): src->d_table holds one packed row per node,
  * [S_1 | .. | S_n | c_hi c_lo] of fp16 (dtype 1) or bf16 (dtype 2) elements, row_elems elements per row (a multiple of 8) -- the

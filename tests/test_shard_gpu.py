@@ -1563,6 +1563,66 @@ def test_peer_cols_to_rows_and_rows_bitmap_vs_torch(W, R, dl):
     assert torch.equal(mask2[:(N + 31) // 32], mask[:(N + 31) // 32])
 
 
+@pytest.mark.parametrize("W", [1, 2, 4, 8])
+def test_fused_head_reads_the_peers_pieces_in_place(W):
+    """elimrec_head_fwd_fused_peers: the fused head on the forward exchange's received buffer [W x R x (out0 dl | narrow dl)]
+    leaves the bits of elimrec_peer_cols_to_rows followed by elimrec_head_fwd_fused on its two row views -- OutAct (block 0
+    included, which the launch writes itself) and YAct, phases 0 and 2; a buffer whose pieces are not 4-float multiples or
+    do not make 64 columns is refused."""
+    from elimrec_amd import ColumnShardEngine, EliMRec, FusedAdam, SyntheticDataset, _lib, ops, set_seed
+    cfg = make_config(["--data.input.dataset=synthetic", "--alpha=0.5", "--loss=bpr_loss", "--recdim=64", "--verbose=0"])
+    ds = SyntheticDataset(700, 1900, 9000, feat_dims=(128, 24, 64), seed=1)
+    set_seed(7)
+    model = EliMRec(cfg, ds).to(DEV)
+    eng = ColumnShardEngine(model)
+    eng.cs_setup(1, 0, FusedAdam(model.parameters(), lr=cfg["lr"], weight_decay=cfg["weight_decay"]))
+    assert eng._fused_head_ok()
+    gen = torch.Generator().manual_seed(3)
+    B = 300
+    u = torch.randint(0, 700, (B,), generator=gen).to(DEV)
+    p = torch.randint(0, 1900, (B,), generator=gen).to(DEV)
+    n = torch.randint(0, 1900, (B,), generator=gen).to(DEV)
+    eng._rows_in_head_on = False                    # the rows launch leaves out0 / narrow of the active rows for this test to cut up
+    acts = eng.cs_plan(u, p, n).view(1, -1)
+    eng.cs_forward(acts)
+    torch.cuda.synchronize()
+    ws = model._ws
+    R, d, dl = model._plan_n, 64, 64 // W
+    out0, nar = ws["OutAct"][:R, :d].clone(), eng.nar_act[:R].clone()
+    recv = torch.empty(W, R, 2 * dl, device=DEV)
+    for q in range(W):
+        recv[q, :, :dl] = out0[:, q * dl:(q + 1) * dl]
+        recv[q, :, dl:] = nar[:, q * dl:(q + 1) * dl]
+    got = {}
+    for form in ("rows", "peers"):
+        for phase in (0, 2):
+            ws["OutAct"][:R].fill_(-3.0)
+            ws["YAct"][:R].fill_(-3.0)
+            if form == "rows":
+                pair = torch.zeros(R, 2, d, device=DEV)
+                ops.peer_cols_to_rows(recv, pair[:, 0, :], pair[:, 1, :])
+                eng._out0_src, eng._nar_src, eng._peer_src = pair[:, 0, :], pair[:, 1, :], None
+            else:
+                eng._out0_src, eng._nar_src, eng._peer_src = None, None, recv
+            eng._head_fused_call(ws, R, phase)
+            torch.cuda.synchronize()
+            got[form, phase] = (ws["OutAct"][:R].clone(), ws["YAct"][:R].clone())
+    na = int(ws["seg_info"][0])
+    for phase in (0, 2):
+        for a, b in zip(got["rows", phase], got["peers", phase]):
+            assert torch.equal(a[:na], b[:na])
+        assert torch.equal(got["peers", phase][0][:na, :d], out0[:na])
+    eng._out0_src = eng._nar_src = eng._peer_src = None
+    if W == 1:
+        bad = torch.zeros(3, R, 2 * 20, device=DEV)          # 3 x 20 columns are not a row of 64
+        with pytest.raises(RuntimeError, match="must make the 64 columns"):
+            eng._peer_src = bad
+            try:
+                eng._head_fused_call(ws, R, 2)
+            finally:
+                eng._peer_src = None
+
+
 # ----------------------------------------------------------------------------- adjacencies with a diagonal: the wide form
 def test_wide_form_trains_the_norm_adjacency_fixture_on_the_column_shard_engine():
     """The fifth fixture (`ablate`: adj_type = norm, D^-1 (A + I); mean fusion; modality ablation 'va') on ColumnShardTrainer
